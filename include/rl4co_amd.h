@@ -1,0 +1,218 @@
+/*
+ * rl4co_amd.h — C-ABI of the MI355X-native autoregressive rollout engine.
+ *
+ * This is the drop-in boundary for ONE hot path of ai4co/rl4co: the batched
+ * TSP/CVRP environment step + AttentionModel decode loop + tour-length reward.
+ * Every entry point below names the reference function(s) it replaces
+ * (paths relative to the reference checkout, `rl4co/...:line`).
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers into caller-owned buffers (the Python
+ *     boundary hands in torch tensors' data_ptr()); the library allocates
+ *     nothing persistent and keeps no threads;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - every function returns an int status (RL4CO_OK = 0) and never throws;
+ *   - the reference raises Python `assert`s from inside the loop (one host
+ *     sync each). Here those conditions are recorded as sticky bits
+ *     OR-ed into the caller's `int32_t* err` word, which the host checks ONCE
+ *     per rollout and converts back into the reference's assertion messages;
+ *   - masks are uint8 with 1 = feasible (torch.bool storage), indices int64,
+ *     payload float32 unless a dtype tag says otherwise.
+ */
+#ifndef RL4CO_AMD_H
+#define RL4CO_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------ */
+#define RL4CO_OK 0
+#define RL4CO_ERR_ARG 1     /* bad argument (null pointer, size out of range)  */
+#define RL4CO_ERR_HIP 2     /* HIP runtime error, see rl4co_last_error()       */
+#define RL4CO_ERR_UNSUPPORTED 3
+
+/* ---- sticky error bits written to `err` (device int32) ------------------ */
+#define RL4CO_EBIT_NAN_LOGIT 1   /* nn/attention.py:295-296 "Logits contain NaNs"        */
+#define RL4CO_EBIT_INFEASIBLE 2  /* utils/decoding.py:393,409 "infeasible action selected" */
+#define RL4CO_EBIT_INVALID_TOUR 4 /* tsp/env.py:161, cvrp/env.py:157-163 "Invalid tour"   */
+#define RL4CO_EBIT_CAPACITY 8    /* cvrp/env.py:175-177 "Used more than capacity"         */
+#define RL4CO_EBIT_MAX_STEPS 16  /* constructive/base.py:236-238 max_steps exceeded       */
+#define RL4CO_EBIT_NEG_INF_LOGP 32 /* utils/decoding.py:56 "Logprobs should not be -inf"  */
+
+/* ---- enums --------------------------------------------------------------- */
+#define RL4CO_ENV_TSP 0
+#define RL4CO_ENV_CVRP 1
+
+#define RL4CO_DECODE_GREEDY 0   /* utils/decoding.py:387-397 */
+#define RL4CO_DECODE_SAMPLE 1   /* utils/decoding.py:399-413 */
+#define RL4CO_DECODE_EVALUATE 2 /* utils/decoding.py:448-461 */
+
+#define RL4CO_DT_F32 0
+#define RL4CO_DT_BF16 1
+
+#define RL4CO_EMBED_DIM 128 /* the engine is specialised for the AM default d=128, H=8 */
+#define RL4CO_NUM_HEADS 8
+
+/* Library identification. */
+const char* rl4co_version(void);
+/* Last HIP error string seen by the calling thread ("" if none). */
+const char* rl4co_last_error(void);
+
+/* --------------------------------------------------------------------------
+ * a1  gather_by_index(src, idx, dim=1)            rl4co/utils/ops.py:54-66
+ * out[b,k,:] = src[b, idx[b,k], :]   src [B,N,D] f32, idx [B,K] i64, out [B,K,D]
+ * -------------------------------------------------------------------------- */
+int rl4co_gather_by_index_f32(const float* src, const int64_t* idx, int B, int N, int D,
+                              int K, float* out, int32_t* err, void* stream);
+
+/* --------------------------------------------------------------------------
+ * a2/a3  get_tour_length / TSPEnv._get_reward / CVRPEnv._get_reward
+ *        rl4co/utils/ops.py:77-90, envs/routing/tsp/env.py:150-156,
+ *        envs/routing/cvrp/env.py:138-147
+ * out[b] = (negate ? -1 : 1) * sum_t || p[t+1 mod n] - p[t] ||_2  over the closed
+ * tour p = (prepend_depot ? locs[b,0] : -) ++ locs[b, actions[b,:]]  (n = T + prepend).
+ * Bit-exact restatement of ATen's CPU arithmetic: per segment
+ * sqrt(fma(dy,dy,fl(dx*dx))), row sum in the 8-lane x 4-ILP cascade order of
+ * aten/src/ATen/native/cpu/SumKernel.cpp.
+ * locs [B_locs,N,2] f32 with trajectory b reading instance b % B_locs
+ * (multistart: s-major batchify, ops.py:10-28); actions [B,T] i64.
+ * -------------------------------------------------------------------------- */
+int rl4co_tour_length_f32(const float* locs, const int64_t* actions, int B, int B_locs, int N,
+                          int T, int prepend_depot, int negate, float* out, void* stream);
+
+/* --------------------------------------------------------------------------
+ * a4  check_solution_validity   tsp/env.py:158-164, cvrp/env.py:149-177
+ * TSP : every row of actions [B,T==N] is a permutation of 0..N-1.
+ * CVRP: customers 1..N-1 appear exactly once, everything else is 0, and the
+ *       running load (reset at the depot, clamped at 0) never exceeds
+ *       vehicle_capacity + 1e-5.  demand [B_inst,N-1], capacity [B_inst].
+ * Violations set RL4CO_EBIT_INVALID_TOUR / RL4CO_EBIT_CAPACITY in *err.
+ * -------------------------------------------------------------------------- */
+int rl4co_tsp_check_solution(const int64_t* actions, int B, int N, int T, int32_t* err,
+                             void* stream);
+int rl4co_cvrp_check_solution(const int64_t* actions, const float* demand,
+                              const float* vehicle_capacity, int B, int B_inst, int N, int T,
+                              int32_t* err, void* stream);
+
+/* --------------------------------------------------------------------------
+ * a6  TSPEnv._step              envs/routing/tsp/env.py:60-86
+ * first = (i==0) ? action : first ; cur = action ; mask[action] = 0 ; i += 1 ;
+ * done = !any(mask).   action/first/cur/i int64 [B], mask/done uint8.
+ * (a5 TSPEnv._reset is pure allocation and lives in the host mirror.)
+ * -------------------------------------------------------------------------- */
+int rl4co_tsp_step(const int64_t* action, uint8_t* action_mask, int64_t* first_node,
+                   int64_t* current_node, int64_t* step_i, uint8_t* done, int B, int N,
+                   int32_t* err, void* stream);
+
+/* --------------------------------------------------------------------------
+ * a8+a9  CVRPEnv._step + get_action_mask   envs/routing/cvrp/env.py:66-96,126-136
+ * used = (used + demand[clamp(a-1,0,n-1)]) * (a != 0); visited[a] = 1; cur = a;
+ * done = (sum visited == N); mask_loc = visited[1:] | (demand + used > cap + 1e-5);
+ * mask[0] = !((cur==0) & any(!mask_loc)); mask[1:] = !mask_loc.
+ * demand [B_inst,N-1] (trajectory b reads row b % B_inst), used/cap f32 [B].
+ * Passing action == NULL only recomputes the mask (a9 / a7's reset mask).
+ * -------------------------------------------------------------------------- */
+int rl4co_cvrp_step(const int64_t* action, const float* demand, float* used_capacity,
+                    const float* vehicle_capacity, uint8_t* visited, int64_t* current_node,
+                    uint8_t* action_mask, uint8_t* done, int B, int B_inst, int N,
+                    int32_t* err, void* stream);
+
+/* --------------------------------------------------------------------------
+ * a13-a21  AttentionModel decode: one step, or the whole autoregressive loop.
+ *
+ * Replaces, per step: TSPContext/VRPContext (env_embeddings/context.py:105-149),
+ * AttentionModelDecoder._compute_q/_compute_kvl/forward (zoo/am/decoder.py:128-193),
+ * PointerAttention.forward (nn/attention.py:274-320), process_logits
+ * (utils/decoding.py:138-188), Greedy/Sampling/Evaluate (decoding.py:344-461),
+ * TSPEnv._step / CVRPEnv._step (+ get_action_mask); and, with max_steps > 1, the
+ * `while not td["done"].all()` loop of ConstructivePolicy.forward
+ * (models/common/constructive/base.py:226-238).
+ *
+ * The cache is the *folded* form of PrecomputedCache (zoo/am/decoder.py:21-40,
+ * 201-228) — algebraically identical, built once per rollout by dense GEMMs:
+ *   glimpse_key = h Wk^T, glimpse_val = h Wv^T                     [B_inst,N,128]
+ *   logit_key   = h (W_out^T Wl)^T   (project_out folded into the logit key)
+ *   ctx_first   = h W_ctx[:, :128]^T, ctx_cur = h W_ctx[:,128:256]^T (TSP)
+ *   ctx_cur     = h W_ctx[:, :128]^T, w_cap = W_ctx[:,128]           (CVRP)
+ *   q_bias      = project_fixed_context(mean_j h_j) or NULL (POMO)  [B_inst,128]
+ *   q_step0     = W_ctx W_placeholder (TSP, step i==0)               [128]
+ * so that one decode step is a pure stream over the three [N,128] planes.
+ * Trajectory r (0..B-1) uses instance r % B_inst (s-major multistart layout).
+ * -------------------------------------------------------------------------- */
+typedef struct rl4co_am_decode_args {
+  /* problem */
+  int32_t env;         /* RL4CO_ENV_*                                            */
+  int32_t B;           /* trajectories = instances x starts                      */
+  int32_t B_inst;      /* instances owning cache rows                            */
+  int32_t N;           /* nodes incl. depot                                      */
+  /* decode configuration */
+  int32_t mode;        /* RL4CO_DECODE_*                                         */
+  int32_t max_steps;   /* 1 = single step; >= horizon = full rollout             */
+  int32_t mask_inner;  /* PointerAttention(mask_inner=True) default 1            */
+  int32_t mask_logits; /* process_logits(mask_logits=True) default 1             */
+  float tanh_clipping; /* 10.0 default (am/policy.py:74); 0 disables             */
+  float temperature;   /* 1.0 default                                            */
+  /* folded cache */
+  int32_t cache_dtype; /* RL4CO_DT_F32 | RL4CO_DT_BF16 for the three planes      */
+  int32_t _pad0;
+  const void* glimpse_key;
+  const void* glimpse_val;
+  const void* logit_key;
+  int64_t kvl_row_stride;   /* elements between node rows   (128 planar, 384 interleaved) */
+  int64_t kvl_batch_stride; /* elements between instances                                  */
+  const float* ctx_first;   /* [B_inst,N,128] TSP only                                     */
+  const float* ctx_cur;     /* [B_inst,N,128]                                              */
+  const float* q_bias;      /* [B_inst,128] or NULL                                        */
+  const float* q_step0;     /* [128] TSP only                                              */
+  const float* w_cap;       /* [128] CVRP only                                             */
+  /* environment state, read at entry and written back at exit */
+  uint8_t* action_mask;     /* [B,N] 1 = feasible                                          */
+  int64_t* first_node;      /* [B] TSP                                                     */
+  int64_t* current_node;    /* [B]                                                         */
+  int64_t* step_i;          /* [B] TSP                                                     */
+  uint8_t* done;            /* [B]                                                         */
+  const float* demand;      /* [B_inst,N-1] CVRP                                           */
+  float* used_capacity;     /* [B] CVRP                                                    */
+  const float* vehicle_capacity; /* [B] CVRP                                               */
+  uint8_t* visited;         /* [B,N] CVRP                                                  */
+  /* decoding inputs */
+  const float* exp_noise;   /* [max_steps,B,N] Exp(1) draws (parity mode) or NULL          */
+  uint64_t philox_seed;     /* in-kernel Exp(1) noise when exp_noise == NULL               */
+  uint64_t philox_offset;
+  const int64_t* forced_actions; /* [B,out_stride] for RL4CO_DECODE_EVALUATE               */
+  /* outputs */
+  int32_t t0;               /* column of the first step in actions/logps                   */
+  int32_t out_stride;       /* row stride (Tmax) of actions/logps/forced_actions           */
+  int64_t* actions;         /* [B,out_stride]                                              */
+  float* logps;             /* [B,out_stride] log p(a_t)                                   */
+  float* all_logps;         /* [B,out_stride,N] or NULL (store_all_logp / entropy)         */
+  float* entropy;           /* [B] accumulated -sum p log p, or NULL                       */
+  int32_t* n_steps;         /* [B] steps actually taken by each trajectory, or NULL        */
+  int32_t* err;             /* sticky error bits                                           */
+} rl4co_am_decode_args;
+
+int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream);
+
+/* Bytes of LDS one trajectory needs for N nodes (for occupancy planning / tests). */
+int rl4co_am_decode_lds_bytes(int N, int env);
+
+/* --------------------------------------------------------------------------
+ * a19  select_start_nodes        rl4co/utils/ops.py:128-161
+ * out[s*B + b] = s % num_loc (+1 for depot environments), s-major.
+ * -------------------------------------------------------------------------- */
+int rl4co_select_start_nodes(int64_t* out, int B, int num_starts, int num_loc, int has_depot,
+                             void* stream);
+
+/* --------------------------------------------------------------------------
+ * Micro-benchmark helper: HBM read stream (float4 grid-stride sum), used by
+ * bench.py to report the achievable-copy ceiling next to the 8 TB/s spec.
+ * -------------------------------------------------------------------------- */
+int rl4co_hbm_read_probe(const void* src, int64_t bytes, float* sink, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RL4CO_AMD_H */

@@ -1,0 +1,942 @@
+"""ORACLE (test infrastructure, not product): CPU restatement of the ai4co/rl4co rollout hot path.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+this module. Nothing under ``rl4co_amd/`` does.
+
+The reference's hot path is 100 % stock ATen ops; the third-party packages it needs and that are
+absent here (tensordict, torchrl, lightning, hydra) are containers and loop glue, not arithmetic
+(SURVEY.md §8c). This file restates the path op-for-op — same ATen calls, same order — with the
+state held in a plain ``dict`` instead of a TensorDict. Each function cites the reference
+file:line it follows (paths relative to the reference checkout).
+
+Pinning: ``oracle/gen_golden.py`` imports the reference's own source files verbatim (through the
+test-only stand-ins in ``oracle/shims``) and checks this restatement against them bit-for-bit;
+the vectors it emits are committed under ``tests/golden``. See DESIGN.md §3.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Callable
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from einops import rearrange
+from torch import Tensor
+
+# ----------------------------------------------------------------------------------------------
+# rl4co/utils/ops.py
+# ----------------------------------------------------------------------------------------------
+
+
+def _batchify_single(x: Tensor, repeats: int) -> Tensor:
+    """ops.py:10-13"""
+    s = x.shape
+    return x.expand(repeats, *s).contiguous().view(s[0] * repeats, *s[1:])
+
+
+def batchify(x, shape):
+    """ops.py:16-30 (dict = TensorDict stand-in: applied per entry)"""
+    if isinstance(x, dict):
+        return {k: batchify(v, shape) for k, v in x.items()}
+    shape = [shape] if isinstance(shape, int) else shape
+    for s in reversed(shape):
+        x = _batchify_single(x, s) if s > 0 else x
+    return x
+
+
+def _unbatchify_single(x: Tensor, repeats: int) -> Tensor:
+    """ops.py:33-36"""
+    s = x.shape
+    return x.view(repeats, s[0] // repeats, *s[1:]).permute(1, 0, *range(2, len(s) + 1))
+
+
+def unbatchify(x, shape):
+    """ops.py:39-51"""
+    if isinstance(x, dict):
+        return {k: unbatchify(v, shape) for k, v in x.items()}
+    shape = [shape] if isinstance(shape, int) else shape
+    for s in reversed(shape):
+        x = _unbatchify_single(x, s) if s > 0 else x
+    return x
+
+
+def gather_by_index(src: Tensor, idx: Tensor, dim: int = 1, squeeze: bool = True) -> Tensor:
+    """ops.py:54-66"""
+    expanded_shape = list(src.shape)
+    expanded_shape[dim] = -1
+    idx = idx.view(idx.shape + (1,) * (src.dim() - idx.dim())).expand(expanded_shape)
+    squeeze = idx.size(dim) == 1 and squeeze
+    return src.gather(dim, idx).squeeze(dim) if squeeze else src.gather(dim, idx)
+
+
+def unbatchify_and_gather(x, idx: Tensor, n: int):
+    """ops.py:69-74"""
+    if isinstance(x, dict):
+        return {k: unbatchify_and_gather(v, idx, n) for k, v in x.items()}
+    x = unbatchify(x, n)
+    return gather_by_index(x, idx, dim=idx.dim())
+
+
+def get_distance(x: Tensor, y: Tensor) -> Tensor:
+    """ops.py:77-79"""
+    return (x - y).norm(p=2, dim=-1)
+
+
+def get_tour_length(ordered_locs: Tensor) -> Tensor:
+    """ops.py:82-90"""
+    ordered_locs_next = torch.roll(ordered_locs, -1, dims=-2)
+    return get_distance(ordered_locs_next, ordered_locs).sum(-1)
+
+
+def calculate_entropy(logprobs: Tensor) -> Tensor:
+    """ops.py:103-111"""
+    logprobs = torch.nan_to_num(logprobs, nan=0.0)
+    entropy = -(logprobs.exp() * logprobs).sum(dim=-1)
+    entropy = entropy.sum(dim=1)
+    assert entropy.isfinite().all(), "Entropy is not finite"
+    return entropy
+
+
+def get_num_starts(td: dict, env_name: str | None = None) -> int:
+    """ops.py:115-125"""
+    num_starts = td["action_mask"].shape[-1]
+    if env_name == "pdp":
+        num_starts = (num_starts - 1) // 2
+    elif env_name in ["cvrp", "cvrptw", "sdvrp", "mtsp", "op", "pctsp", "spctsp"]:
+        num_starts = num_starts - 1
+    return num_starts
+
+
+def select_start_nodes(td: dict, env, num_starts: int) -> Tensor:
+    """ops.py:128-161 (tsp / depot branches)"""
+    num_loc = env.num_loc
+    batch = td["action_mask"].shape[0]
+    device = td["action_mask"].device
+    if env.name in ["tsp", "atsp", "flp", "mcp"]:
+        return torch.arange(num_starts, device=device).repeat_interleave(batch) % num_loc
+    return torch.arange(num_starts, device=device).repeat_interleave(batch) % num_loc + 1
+
+
+# ----------------------------------------------------------------------------------------------
+# environments: rl4co/envs/routing/{tsp,cvrp}/{env,generator}.py, rl4co/envs/common/base.py
+# ----------------------------------------------------------------------------------------------
+
+CAPACITIES = {  # cvrp/generator.py:15-30
+    10: 20.0, 15: 25.0, 20: 30.0, 30: 33.0, 40: 37.0, 50: 40.0, 60: 43.0, 75: 45.0,
+    100: 50.0, 125: 55.0, 150: 60.0, 200: 70.0, 500: 100.0, 1000: 150.0,
+}
+
+
+class TSPEnv:
+    """envs/routing/tsp/env.py:22-164 with envs/common/base.py:121-190."""
+
+    name = "tsp"
+
+    def __init__(self, num_loc: int = 20, check_solution: bool = True):
+        self.num_loc = num_loc
+        self.check_solution = check_solution
+
+    def generate(self, batch_size: int) -> dict:
+        """tsp/generator.py:49-58: Uniform(0,1).sample((B,N,2))"""
+        u = torch.distributions.Uniform(low=0.0, high=1.0)
+        return {"locs": u.sample((batch_size, self.num_loc, 2))}
+
+    def reset(self, td: dict | None = None, batch_size: int | None = None) -> dict:
+        """base.py:135-143 -> tsp/env.py:88-113; torchrl's EnvBase.reset adds done/terminated."""
+        if td is None:
+            td = self.generate(batch_size)
+        init_locs = td["locs"]
+        b = init_locs.shape[0]
+        device = init_locs.device
+        num_loc = init_locs.shape[-2]
+        current_node = torch.zeros((b,), dtype=torch.int64, device=device)
+        return {
+            "locs": init_locs,
+            "first_node": current_node,
+            "current_node": current_node,
+            "i": torch.zeros((b, 1), dtype=torch.int64, device=device),
+            "action_mask": torch.ones((b, num_loc), dtype=torch.bool, device=device),
+            "reward": torch.zeros((b, 1), dtype=torch.float32),
+            "done": torch.zeros((b, 1), dtype=torch.bool, device=device),
+        }
+
+    def step(self, td: dict) -> dict:
+        """tsp/env.py:60-86"""
+        current_node = td["action"]
+        first_node = current_node if td["i"].all() == 0 else td["first_node"]
+        available = td["action_mask"].scatter(
+            -1, current_node.unsqueeze(-1).expand_as(td["action_mask"]), 0
+        )
+        done = torch.sum(available, dim=-1) == 0
+        reward = torch.zeros_like(done)
+        td.update(
+            {
+                "first_node": first_node,
+                "current_node": current_node,
+                "i": td["i"] + 1,
+                "action_mask": available,
+                "reward": reward,
+                "done": done,
+            }
+        )
+        return td
+
+    def get_reward(self, td: dict, actions: Tensor, check_solution: bool | None = None) -> Tensor:
+        """base.py:180-190 -> tsp/env.py:150-156"""
+        check_solution = self.check_solution if check_solution is None else check_solution
+        if check_solution:
+            self.check_solution_validity(td, actions)
+        locs_ordered = gather_by_index(td["locs"], actions)
+        return -get_tour_length(locs_ordered)
+
+    @staticmethod
+    def check_solution_validity(td: dict, actions: Tensor) -> None:
+        """tsp/env.py:158-164"""
+        assert (
+            torch.arange(actions.size(1), out=actions.data.new()).view(1, -1).expand_as(actions)
+            == actions.data.sort(1)[0]
+        ).all(), "Invalid tour"
+
+    def get_num_starts(self, td):
+        return get_num_starts(td, self.name)
+
+    def select_start_nodes(self, td, num_starts):
+        return select_start_nodes(td, self, num_starts)
+
+
+class CVRPEnv:
+    """envs/routing/cvrp/env.py:22-177"""
+
+    name = "cvrp"
+
+    def __init__(self, num_loc: int = 20, check_solution: bool = True, capacity: float | None = None):
+        self.num_loc = num_loc
+        self.check_solution = check_solution
+        self.vehicle_capacity = 1.0
+        if capacity is None:  # cvrp/generator.py:99-110
+            capacity = CAPACITIES.get(num_loc, None)
+        if capacity is None:
+            closest = min(CAPACITIES.keys(), key=lambda x: abs(x - num_loc))
+            capacity = CAPACITIES[closest]
+        self.capacity = capacity
+
+    def generate(self, batch_size: int) -> dict:
+        """cvrp/generator.py:114-140 (depot sampled with the locations; demand U{1..9}/capacity)"""
+        loc_sampler = torch.distributions.Uniform(low=0.0, high=1.0)
+        demand_sampler = torch.distributions.Uniform(low=0, high=9)  # min_demand-1, max_demand-1
+        locs = loc_sampler.sample((batch_size, self.num_loc + 1, 2))
+        depot = locs[..., 0, :]
+        locs = locs[..., 1:, :]
+        demand = demand_sampler.sample((batch_size, self.num_loc))
+        demand = (demand.int() + 1).float()
+        capacity = torch.full((batch_size, 1), self.capacity)
+        return {"locs": locs, "depot": depot, "demand": demand / self.capacity, "capacity": capacity}
+
+    def reset(self, td: dict | None = None, batch_size: int | None = None) -> dict:
+        """cvrp/env.py:98-124"""
+        if td is None:
+            td = self.generate(batch_size)
+        b = td["locs"].shape[0]
+        device = td["locs"].device
+        td_reset = {
+            "locs": torch.cat((td["depot"][:, None, :], td["locs"]), -2),
+            "demand": td["demand"],
+            "current_node": torch.zeros(b, 1, dtype=torch.long, device=device),
+            "used_capacity": torch.zeros((b, 1), device=device),
+            "vehicle_capacity": torch.full((b, 1), self.vehicle_capacity, device=device),
+            "visited": torch.zeros((b, td["locs"].shape[-2] + 1), dtype=torch.uint8, device=device),
+            "done": torch.zeros((b, 1), dtype=torch.bool, device=device),
+        }
+        td_reset["action_mask"] = self.get_action_mask(td_reset)
+        return td_reset
+
+    def step(self, td: dict) -> dict:
+        """cvrp/env.py:66-96"""
+        current_node = td["action"][:, None]
+        n_loc = td["demand"].size(-1)
+        selected_demand = gather_by_index(
+            td["demand"], torch.clamp(current_node - 1, 0, n_loc - 1), squeeze=False
+        )
+        used_capacity = (td["used_capacity"] + selected_demand) * (current_node != 0).float()
+        visited = td["visited"].scatter(-1, current_node, 1)
+        done = visited.sum(-1) == visited.size(-1)
+        reward = torch.zeros_like(done)
+        td.update(
+            {
+                "current_node": current_node,
+                "used_capacity": used_capacity,
+                "visited": visited,
+                "reward": reward,
+                "done": done,
+            }
+        )
+        td["action_mask"] = self.get_action_mask(td)
+        return td
+
+    @staticmethod
+    def get_action_mask(td: dict) -> Tensor:
+        """cvrp/env.py:126-136"""
+        exceeds_cap = td["demand"] + td["used_capacity"] > td["vehicle_capacity"] + 1e-5
+        mask_loc = td["visited"][..., 1:].to(exceeds_cap.dtype) | exceeds_cap
+        mask_depot = (td["current_node"] == 0) & ((mask_loc == 0).int().sum(-1) > 0)[:, None]
+        return ~torch.cat((mask_depot, mask_loc), -1)
+
+    def get_reward(self, td: dict, actions: Tensor, check_solution: bool | None = None) -> Tensor:
+        """base.py:180-190 -> cvrp/env.py:138-147"""
+        check_solution = self.check_solution if check_solution is None else check_solution
+        if check_solution:
+            self.check_solution_validity(td, actions)
+        locs_ordered = torch.cat(
+            [td["locs"][..., 0:1, :], gather_by_index(td["locs"], actions)], dim=1
+        )
+        return -get_tour_length(locs_ordered)
+
+    @staticmethod
+    def check_solution_validity(td: dict, actions: Tensor) -> None:
+        """cvrp/env.py:149-177"""
+        batch_size, graph_size = td["demand"].size()
+        sorted_pi = actions.data.sort(1)[0]
+        assert (
+            torch.arange(1, graph_size + 1, out=sorted_pi.data.new())
+            .view(1, -1)
+            .expand(batch_size, graph_size)
+            == sorted_pi[:, -graph_size:]
+        ).all() and (sorted_pi[:, :-graph_size] == 0).all(), "Invalid tour"
+        demand_with_depot = torch.cat((-td["vehicle_capacity"], td["demand"]), 1)
+        d = demand_with_depot.gather(1, actions)
+        used_cap = torch.zeros_like(td["demand"][:, 0])
+        for i in range(actions.size(1)):
+            used_cap += d[:, i]
+            used_cap[used_cap < 0] = 0
+            assert (used_cap <= td["vehicle_capacity"][:, 0] + 1e-5).all(), "Used more than capacity"
+
+    def get_num_starts(self, td):
+        return get_num_starts(td, self.name)
+
+    def select_start_nodes(self, td, num_starts):
+        return select_start_nodes(td, self, num_starts)
+
+
+def get_env(name: str, num_loc: int, **kw):
+    return {"tsp": TSPEnv, "cvrp": CVRPEnv}[name](num_loc=num_loc, **kw)
+
+
+# ----------------------------------------------------------------------------------------------
+# rl4co/models/nn/attention.py
+# ----------------------------------------------------------------------------------------------
+
+
+def scaled_dot_product_attention_simple(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False):
+    """attention.py:19-50"""
+    scores = torch.matmul(q, k.transpose(-2, -1)) / (k.size(-1) ** 0.5)
+    if attn_mask is not None:
+        if attn_mask.dtype == torch.bool:
+            scores.masked_fill_(~attn_mask, float("-inf"))
+        else:
+            scores += attn_mask
+    attn_weights = F.softmax(scores, dim=-1)
+    return torch.matmul(attn_weights, v)
+
+
+def _resolve_sdpa(sdpa_fn) -> Callable:
+    """attention.py:259-272"""
+    if sdpa_fn is None or sdpa_fn == "default":
+        return F.scaled_dot_product_attention
+    if sdpa_fn == "simple":
+        return scaled_dot_product_attention_simple
+    if callable(sdpa_fn):
+        return sdpa_fn
+    raise ValueError(f"Unknown sdpa_fn: {sdpa_fn}")
+
+
+class MultiHeadAttention(nn.Module):
+    """attention.py:64-134"""
+
+    def __init__(self, embed_dim: int, num_heads: int, bias: bool = True, sdpa_fn=None):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.sdpa_fn = _resolve_sdpa(sdpa_fn)
+        self.Wqkv = nn.Linear(embed_dim, 3 * embed_dim, bias=bias)
+        self.out_proj = nn.Linear(embed_dim, embed_dim, bias=bias)
+
+    def forward(self, x, attn_mask=None):
+        q, k, v = rearrange(
+            self.Wqkv(x), "b s (three h d) -> three b h s d", three=3, h=self.num_heads
+        ).unbind(dim=0)
+        out = self.sdpa_fn(q, k, v, attn_mask=attn_mask, dropout_p=0.0)
+        return self.out_proj(rearrange(out, "b h s d -> b s (h d)"))
+
+
+class PointerAttention(nn.Module):
+    """attention.py:218-320"""
+
+    def __init__(self, embed_dim, num_heads, mask_inner=True, out_bias=False, check_nan=True,
+                 sdpa_fn="default"):
+        super().__init__()
+        self.num_heads = num_heads
+        self.mask_inner = mask_inner
+        self.project_out = nn.Linear(embed_dim, embed_dim, bias=out_bias)
+        self.check_nan = check_nan
+        self.sdpa_fn = _resolve_sdpa(sdpa_fn)
+
+    def forward(self, query, key, value, logit_key, attn_mask=None):
+        heads = self._inner_mha(query, key, value, attn_mask)
+        glimpse = self.project_out(heads)
+        logits = (torch.bmm(glimpse, logit_key.squeeze(-2).transpose(-2, -1))).squeeze(
+            -2
+        ) / math.sqrt(glimpse.size(-1))
+        if self.check_nan:
+            assert not torch.isnan(logits).any(), "Logits contain NaNs"
+        return logits
+
+    def _inner_mha(self, query, key, value, attn_mask):
+        q = self._make_heads(query)
+        k = self._make_heads(key)
+        v = self._make_heads(value)
+        if self.mask_inner:
+            attn_mask = (
+                attn_mask.unsqueeze(1) if attn_mask.ndim == 3 else attn_mask.unsqueeze(1).unsqueeze(2)
+            )
+        else:
+            attn_mask = None
+        heads = self.sdpa_fn(q, k, v, attn_mask=attn_mask)
+        return rearrange(heads, "... h n g -> ... n (h g)", h=self.num_heads)
+
+    def _make_heads(self, v):
+        return rearrange(v, "... g (h s) -> ... h g s", h=self.num_heads)
+
+
+# ----------------------------------------------------------------------------------------------
+# rl4co/models/nn/{ops,mlp}.py, nn/graph/attnnet.py, nn/env_embeddings/*, zoo/am/*
+# ----------------------------------------------------------------------------------------------
+
+
+class SkipConnection(nn.Module):
+    """nn/ops.py:9-15"""
+
+    def __init__(self, module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, x):
+        return x + self.module(x)
+
+
+class Normalization(nn.Module):
+    """nn/ops.py:30-54"""
+
+    def __init__(self, embed_dim, normalization="batch"):
+        super().__init__()
+        if normalization != "layer":
+            cls = {"batch": nn.BatchNorm1d, "instance": nn.InstanceNorm1d}.get(normalization, None)
+            self.normalizer = cls(embed_dim, affine=True)
+        else:
+            self.normalizer = "layer"
+
+    def forward(self, x):
+        if isinstance(self.normalizer, nn.BatchNorm1d):
+            return self.normalizer(x.view(-1, x.size(-1))).view(*x.size())
+        elif isinstance(self.normalizer, nn.InstanceNorm1d):
+            return self.normalizer(x.permute(0, 2, 1)).permute(0, 2, 1)
+        elif self.normalizer == "layer":
+            return (x - x.mean((1, 2)).view(-1, 1, 1)) / torch.sqrt(
+                x.var((1, 2)).view(-1, 1, 1) + 1e-05
+            )
+        return x
+
+
+class MLP(nn.Module):
+    """nn/mlp.py:8-61 (hidden ReLU, identity output, no norms/dropout in the AM encoder)"""
+
+    def __init__(self, input_dim, output_dim, num_neurons):
+        super().__init__()
+        input_dims = [input_dim] + num_neurons
+        output_dims = num_neurons + [output_dim]
+        self.lins = nn.ModuleList()
+        for in_dim, out_dim in zip(input_dims, output_dims):
+            self.lins.append(nn.Linear(in_dim, out_dim))
+
+    def forward(self, xs):
+        for lin in self.lins[:-1]:
+            xs = F.relu(lin(xs))
+        return self.lins[-1](xs)
+
+
+class MultiHeadAttentionLayer(nn.Sequential):
+    """nn/graph/attnnet.py:16-54 — NB the FFN is constructed before the MHA (RNG order)."""
+
+    def __init__(self, embed_dim, num_heads=8, feedforward_hidden=512, normalization="batch",
+                 sdpa_fn=None):
+        num_neurons = [feedforward_hidden] if feedforward_hidden > 0 else []
+        ffn = MLP(embed_dim, embed_dim, num_neurons)
+        super().__init__(
+            SkipConnection(MultiHeadAttention(embed_dim, num_heads, bias=True, sdpa_fn=sdpa_fn)),
+            Normalization(embed_dim, normalization),
+            SkipConnection(ffn),
+            Normalization(embed_dim, normalization),
+        )
+
+
+class GraphAttentionNetwork(nn.Module):
+    """nn/graph/attnnet.py:57-106"""
+
+    def __init__(self, num_heads, embed_dim, num_layers, normalization="batch",
+                 feedforward_hidden=512, sdpa_fn=None):
+        super().__init__()
+        self.layers = nn.Sequential(
+            *(
+                MultiHeadAttentionLayer(embed_dim, num_heads, feedforward_hidden, normalization, sdpa_fn)
+                for _ in range(num_layers)
+            )
+        )
+
+    def forward(self, x):
+        return self.layers(x)
+
+
+class TSPInitEmbedding(nn.Module):
+    """env_embeddings/init.py:55-68"""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.init_embed = nn.Linear(2, embed_dim, True)
+
+    def forward(self, td):
+        return self.init_embed(td["locs"])
+
+
+class VRPInitEmbedding(nn.Module):
+    """env_embeddings/init.py:115-136"""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.init_embed = nn.Linear(3, embed_dim, True)
+        self.init_embed_depot = nn.Linear(2, embed_dim, True)
+
+    def forward(self, td):
+        depot, cities = td["locs"][:, :1, :], td["locs"][:, 1:, :]
+        depot_embedding = self.init_embed_depot(depot)
+        node_embeddings = self.init_embed(torch.cat((cities, td["demand"][..., None]), -1))
+        return torch.cat((depot_embedding, node_embeddings), -2)
+
+
+class TSPContext(nn.Module):
+    """env_embeddings/context.py:50-60,105-134"""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.project_context = nn.Linear(2 * embed_dim, embed_dim, bias=False)
+        self.W_placeholder = nn.Parameter(torch.Tensor(2 * self.embed_dim).uniform_(-1, 1))
+
+    def forward(self, embeddings, td):
+        batch_size = embeddings.size(0)
+        node_dim = (-1,) if td["first_node"].dim() == 1 else (td["first_node"].size(-1), -1)
+        if td["i"][(0,) * td["i"].dim()].item() < 1:
+            if td["first_node"].dim() < 2:  # len(td.batch_size) < 2
+                context_embedding = self.W_placeholder[None, :].expand(
+                    batch_size, self.W_placeholder.size(-1)
+                )
+            else:
+                context_embedding = self.W_placeholder[None, None, :].expand(
+                    batch_size, td["first_node"].size(1), self.W_placeholder.size(-1)
+                )
+        else:
+            context_embedding = gather_by_index(
+                embeddings,
+                torch.stack([td["first_node"], td["current_node"]], -1).view(batch_size, -1),
+            ).view(batch_size, *node_dim)
+        return self.project_context(context_embedding)
+
+
+class VRPContext(nn.Module):
+    """env_embeddings/context.py:50-74,137-149"""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.project_context = nn.Linear(embed_dim + 1, embed_dim, bias=False)
+
+    def forward(self, embeddings, td):
+        cur_node_embedding = gather_by_index(embeddings, td["current_node"])
+        state_embedding = td["vehicle_capacity"] - td["used_capacity"]
+        context_embedding = torch.cat([cur_node_embedding, state_embedding], -1)
+        return self.project_context(context_embedding)
+
+
+class StaticEmbedding(nn.Module):
+    """env_embeddings/dynamic.py:47-57"""
+
+    def forward(self, td):
+        return 0, 0, 0
+
+
+@dataclass
+class PrecomputedCache:
+    """zoo/am/decoder.py:21-40"""
+
+    node_embeddings: Tensor
+    graph_context: Tensor | float
+    glimpse_key: Tensor
+    glimpse_val: Tensor
+    logit_key: Tensor
+
+
+class AttentionModelEncoder(nn.Module):
+    """zoo/am/encoder.py:12-87"""
+
+    def __init__(self, embed_dim=128, env_name="tsp", num_heads=8, num_layers=3,
+                 normalization="batch", feedforward_hidden=512, sdpa_fn=None):
+        super().__init__()
+        self.env_name = env_name
+        self.init_embedding = {"tsp": TSPInitEmbedding, "cvrp": VRPInitEmbedding}[env_name](embed_dim)
+        self.net = GraphAttentionNetwork(
+            num_heads, embed_dim, num_layers, normalization, feedforward_hidden, sdpa_fn=sdpa_fn
+        )
+
+    def forward(self, td):
+        init_h = self.init_embedding(td)
+        h = self.net(init_h)
+        return h, init_h
+
+
+class AttentionModelDecoder(nn.Module):
+    """zoo/am/decoder.py:43-228"""
+
+    def __init__(self, embed_dim=128, num_heads=8, env_name="tsp", mask_inner=True,
+                 out_bias_pointer_attn=False, linear_bias=False, use_graph_context=True,
+                 check_nan=True, sdpa_fn=None):
+        super().__init__()
+        self.env_name = env_name
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.context_embedding = {"tsp": TSPContext, "cvrp": VRPContext}[env_name](embed_dim)
+        self.dynamic_embedding = StaticEmbedding()
+        self.is_dynamic_embedding = False
+        self.pointer = PointerAttention(
+            embed_dim, num_heads, mask_inner=mask_inner, out_bias=out_bias_pointer_attn,
+            check_nan=check_nan, sdpa_fn=sdpa_fn,
+        )
+        self.project_node_embeddings = nn.Linear(embed_dim, 3 * embed_dim, bias=linear_bias)
+        self.project_fixed_context = nn.Linear(embed_dim, embed_dim, bias=linear_bias)
+        self.use_graph_context = use_graph_context
+
+    def _compute_q(self, cached: PrecomputedCache, td: dict):
+        """decoder.py:128-140 (td.dim() == 2  <=>  state tensors carry a starts dimension)"""
+        graph_context_cache = cached.graph_context
+        if td["action_mask"].dim() == 3 and isinstance(graph_context_cache, Tensor):
+            graph_context_cache = graph_context_cache.unsqueeze(1)
+        step_context = self.context_embedding(cached.node_embeddings, td)
+        glimpse_q = step_context + graph_context_cache
+        glimpse_q = glimpse_q.unsqueeze(1) if glimpse_q.ndim == 2 else glimpse_q
+        return glimpse_q
+
+    def _compute_kvl(self, cached: PrecomputedCache, td: dict):
+        """decoder.py:142-154"""
+        glimpse_k_dyn, glimpse_v_dyn, logit_k_dyn = self.dynamic_embedding(td)
+        glimpse_k = cached.glimpse_key + glimpse_k_dyn
+        glimpse_v = cached.glimpse_val + glimpse_v_dyn
+        logit_k = cached.logit_key + logit_k_dyn
+        return glimpse_k, glimpse_v, logit_k
+
+    def forward(self, td: dict, cached: PrecomputedCache, num_starts: int = 0):
+        """decoder.py:156-193"""
+        if num_starts > 1:
+            td = unbatchify(td, num_starts)
+        glimpse_q = self._compute_q(cached, td)
+        glimpse_k, glimpse_v, logit_k = self._compute_kvl(cached, td)
+        mask = td["action_mask"]
+        logits = self.pointer(glimpse_q, glimpse_k, glimpse_v, logit_k, mask)
+        if num_starts > 1:
+            logits = rearrange(logits, "b s l -> (s b) l", s=num_starts)
+            mask = rearrange(mask, "b s l -> (s b) l", s=num_starts)
+        return logits, mask
+
+    def pre_decoder_hook(self, td, env, embeddings, num_starts: int = 0):
+        return td, env, self._precompute_cache(embeddings, num_starts=num_starts)
+
+    def _precompute_cache(self, embeddings: Tensor, num_starts: int = 0) -> PrecomputedCache:
+        """decoder.py:201-228"""
+        glimpse_key_fixed, glimpse_val_fixed, logit_key_fixed = self.project_node_embeddings(
+            embeddings
+        ).chunk(3, dim=-1)
+        if self.use_graph_context:
+            graph_context = self.project_fixed_context(embeddings.mean(1))
+        else:
+            graph_context = 0
+        return PrecomputedCache(
+            node_embeddings=embeddings,
+            graph_context=graph_context,
+            glimpse_key=glimpse_key_fixed,
+            glimpse_val=glimpse_val_fixed,
+            logit_key=logit_key_fixed,
+        )
+
+
+# ----------------------------------------------------------------------------------------------
+# rl4co/utils/decoding.py
+# ----------------------------------------------------------------------------------------------
+
+
+def get_log_likelihood(logprobs, actions=None, mask=None, return_sum: bool = True):
+    """decoding.py:38-62"""
+    if actions is not None and logprobs.dim() == 3:
+        logprobs = logprobs.gather(-1, actions.unsqueeze(-1)).squeeze(-1)
+    if mask is not None:
+        logprobs[~mask] = 0
+    assert (logprobs > -1000).data.all(), "Logprobs should not be -inf, check sampling procedure!"
+    return logprobs.sum(1) if return_sum else logprobs
+
+
+def process_logits(logits, mask=None, temperature=1.0, tanh_clipping=0, mask_logits=True):
+    """decoding.py:138-188 (top-k / top-p are out of scope)"""
+    if tanh_clipping > 0:
+        logits = torch.tanh(logits) * tanh_clipping
+    if mask_logits:
+        assert mask is not None, "mask must be provided if mask_logits is True"
+        logits[~mask] = float("-inf")
+    logits = logits / temperature
+    return F.log_softmax(logits, dim=-1)
+
+
+class DecodingStrategy:
+    """decoding.py:191-423 (greedy / sampling / evaluate, optional multistart)."""
+
+    name = "base"
+
+    def __init__(self, temperature=1.0, mask_logits=True, tanh_clipping=0, num_starts=None,
+                 multistart=False, select_best=False, store_all_logp=False, num_samples=None,
+                 multisample=False, noise_recorder: list | None = None, **kwargs):
+        self.temperature = temperature
+        self.mask_logits = mask_logits
+        self.tanh_clipping = tanh_clipping
+        assert not (multistart and multisample)
+        if num_samples is not None:
+            multisample = True if num_samples > 1 else False
+        if num_starts is not None:
+            multistart = True if num_starts > 1 else False
+        self.multistart = multistart
+        self.multisample = multisample
+        self.num_starts = num_starts if multistart else num_samples
+        self.select_best = select_best
+        self.store_all_logp = store_all_logp
+        self.actions = []
+        self.logprobs = []
+        self.noise_recorder = noise_recorder
+
+    def pre_decoder_hook(self, td: dict, env, action=None):
+        """decoding.py:282-330"""
+        if self.multistart or self.multisample:
+            if self.num_starts is None:
+                self.num_starts = env.get_num_starts(td)
+        else:
+            self.num_starts = 0
+        if self.num_starts >= 1:
+            if self.multistart:
+                if action is None:
+                    action = env.select_start_nodes(td, num_starts=self.num_starts)
+                td = batchify(td, self.num_starts)
+                td["action"] = action
+                td = env.step(td)
+                if self.store_all_logp:
+                    logprobs = torch.zeros_like(td["action_mask"])
+                else:
+                    logprobs = torch.zeros_like(action, device=action.device)
+                self.logprobs.append(logprobs)
+                self.actions.append(action)
+            else:
+                td = batchify(td, self.num_starts)
+        return td, env, self.num_starts
+
+    def post_decoder_hook(self, td: dict, env):
+        """decoding.py:332-342"""
+        assert len(self.logprobs) > 0
+        logprobs = torch.stack(self.logprobs, 1)
+        actions = torch.stack(self.actions, 1)
+        if self.num_starts > 0 and self.select_best:
+            logprobs, actions, td, env = self._select_best(logprobs, actions, td, env)
+        return logprobs, actions, td, env
+
+    def step(self, logits, mask, td: dict, action=None):
+        """decoding.py:344-385"""
+        if not self.mask_logits:
+            mask = None
+        logprobs = process_logits(
+            logits, mask, temperature=self.temperature, tanh_clipping=self.tanh_clipping,
+            mask_logits=self.mask_logits,
+        )
+        logprobs, selected_action, td = self._step(logprobs, mask, td, action=action)
+        if not self.store_all_logp:
+            logprobs = gather_by_index(logprobs, selected_action, dim=1)
+        td["action"] = selected_action
+        self.actions.append(selected_action)
+        self.logprobs.append(logprobs)
+        return td
+
+    @staticmethod
+    def greedy(logprobs, mask=None):
+        """decoding.py:387-397"""
+        selected = logprobs.argmax(dim=-1)
+        if mask is not None:
+            assert not (~mask).gather(1, selected.unsqueeze(-1)).data.any(), "infeasible action selected"
+        return selected
+
+    def sampling(self, logprobs, mask=None):
+        """decoding.py:399-413. torch.multinomial(p, 1) == argmax(p / q), q = empty_like(p).
+        exponential_(1) on the same generator [SURVEY.md §8c probe]; when a recorder is attached
+        the draw is made explicitly so the HIP kernel can consume the very same noise."""
+        probs = logprobs.exp()
+        if self.noise_recorder is not None:
+            q = torch.empty_like(probs).exponential_(1)
+            self.noise_recorder.append(q.clone())
+            selected = torch.div(probs, q).argmax(dim=-1)
+        else:
+            selected = torch.multinomial(probs, 1).squeeze(1)
+        if mask is not None:
+            assert not (~mask).gather(1, selected.unsqueeze(-1)).data.any(), "infeasible action selected"
+        return selected
+
+    def _select_best(self, logprobs, actions, td: dict, env):
+        """decoding.py:415-423"""
+        rewards = env.get_reward(td, actions)
+        _, max_idxs = unbatchify(rewards, self.num_starts).max(dim=-1)
+        actions = unbatchify_and_gather(actions, max_idxs, self.num_starts)
+        logprobs = unbatchify_and_gather(logprobs, max_idxs, self.num_starts)
+        td = unbatchify_and_gather(td, max_idxs, self.num_starts)
+        return logprobs, actions, td, env
+
+
+class Greedy(DecodingStrategy):
+    name = "greedy"
+
+    def _step(self, logprobs, mask, td, **kw):
+        return logprobs, self.greedy(logprobs, mask), td
+
+
+class Sampling(DecodingStrategy):
+    name = "sampling"
+
+    def _step(self, logprobs, mask, td, **kw):
+        return logprobs, self.sampling(logprobs, mask), td
+
+
+class Evaluate(DecodingStrategy):
+    name = "evaluate"
+
+    def _step(self, logprobs, mask, td, action=None, **kw):
+        return logprobs, action, td
+
+
+def get_decoding_strategy(decoding_strategy: str, **config) -> DecodingStrategy:
+    """decoding.py:17-35"""
+    registry = {
+        "greedy": Greedy, "sampling": Sampling, "multistart_greedy": Greedy,
+        "multistart_sampling": Sampling, "evaluate": Evaluate,
+    }
+    if "multistart" in decoding_strategy:
+        config["multistart"] = True
+    return registry.get(decoding_strategy, Sampling)(**config)
+
+
+# ----------------------------------------------------------------------------------------------
+# rl4co/models/zoo/am/policy.py + rl4co/models/common/constructive/base.py
+# ----------------------------------------------------------------------------------------------
+
+
+class AttentionModelPolicy(nn.Module):
+    """zoo/am/policy.py:10-122 (constructor defaults) + constructive/base.py:154-263 (forward).
+
+    Modules are created in the reference's order, so ``torch.manual_seed(s)`` followed by
+    construction yields the reference's weights and ``state_dict()`` keys."""
+
+    def __init__(self, env_name="tsp", embed_dim=128, num_encoder_layers=3, num_heads=8,
+                 normalization="batch", feedforward_hidden=512, use_graph_context=True,
+                 linear_bias_decoder=False, sdpa_fn=None, sdpa_fn_encoder=None, sdpa_fn_decoder=None,
+                 mask_inner=True, out_bias_pointer_attn=False, check_nan=True, temperature=1.0,
+                 tanh_clipping=10.0, mask_logits=True, train_decode_type="sampling",
+                 val_decode_type="greedy", test_decode_type="greedy"):
+        super().__init__()
+        self.env_name = env_name
+        self.encoder = AttentionModelEncoder(
+            embed_dim=embed_dim, env_name=env_name, num_heads=num_heads,
+            num_layers=num_encoder_layers, normalization=normalization,
+            feedforward_hidden=feedforward_hidden,
+            sdpa_fn=sdpa_fn if sdpa_fn_encoder is None else sdpa_fn_encoder,
+        )
+        self.decoder = AttentionModelDecoder(
+            embed_dim=embed_dim, num_heads=num_heads, env_name=env_name, mask_inner=mask_inner,
+            out_bias_pointer_attn=out_bias_pointer_attn, linear_bias=linear_bias_decoder,
+            use_graph_context=use_graph_context, check_nan=check_nan,
+            sdpa_fn=sdpa_fn if sdpa_fn_decoder is None else sdpa_fn_decoder,
+        )
+        self.temperature = temperature
+        self.tanh_clipping = tanh_clipping
+        self.mask_logits = mask_logits
+        self.train_decode_type = train_decode_type
+        self.val_decode_type = val_decode_type
+        self.test_decode_type = test_decode_type
+
+    def forward(self, td: dict, env, phase: str = "train", calc_reward: bool = True,
+                return_actions: bool = True, return_entropy: bool = False,
+                return_hidden: bool = False, return_init_embeds: bool = False,
+                return_sum_log_likelihood: bool = True, actions=None, max_steps=1_000_000,
+                **decoding_kwargs) -> dict:
+        """constructive/base.py:154-263"""
+        hidden, init_embeds = self.encoder(td)
+        decode_type = decoding_kwargs.pop("decode_type", None)
+        if actions is not None:
+            decode_type = "evaluate"
+        elif decode_type is None:
+            decode_type = getattr(self, f"{phase}_decode_type")
+        decode_strategy = get_decoding_strategy(
+            decode_type,
+            temperature=decoding_kwargs.pop("temperature", self.temperature),
+            tanh_clipping=decoding_kwargs.pop("tanh_clipping", self.tanh_clipping),
+            mask_logits=decoding_kwargs.pop("mask_logits", self.mask_logits),
+            store_all_logp=decoding_kwargs.pop("store_all_logp", return_entropy),
+            **decoding_kwargs,
+        )
+        td, env, num_starts = decode_strategy.pre_decoder_hook(td, env)
+        td, env, hidden = self.decoder.pre_decoder_hook(td, env, hidden, num_starts)
+        step = 0
+        while not td["done"].all():
+            logits, mask = self.decoder(td, hidden, num_starts)
+            td = decode_strategy.step(
+                logits, mask, td, action=actions[..., step] if actions is not None else None
+            )
+            td = env.step(td)
+            step += 1
+            if step > max_steps:
+                break
+        logprobs, actions, td, env = decode_strategy.post_decoder_hook(td, env)
+        if calc_reward:
+            td["reward"] = env.get_reward(td, actions)
+        outdict = {
+            "reward": td["reward"],
+            "log_likelihood": get_log_likelihood(
+                logprobs, actions, td.get("mask", None), return_sum_log_likelihood
+            ),
+        }
+        if return_actions:
+            outdict["actions"] = actions
+        if return_entropy:
+            outdict["entropy"] = calculate_entropy(logprobs)
+        if return_hidden:
+            outdict["hidden"] = hidden
+        if return_init_embeds:
+            outdict["init_embeds"] = init_embeds
+        return outdict
+
+
+def pomo_policy(env_name="tsp", **kw) -> AttentionModelPolicy:
+    """zoo/pomo/model.py:52-67: 6 layers, instance norm, no graph context, multistart decode types."""
+    cfg = dict(
+        env_name=env_name, num_encoder_layers=6, normalization="instance", use_graph_context=False,
+        train_decode_type="multistart_sampling", val_decode_type="multistart_greedy",
+        test_decode_type="multistart_greedy",
+    )
+    cfg.update(kw)
+    return AttentionModelPolicy(**cfg)

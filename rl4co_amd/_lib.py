@@ -1,0 +1,111 @@
+"""ctypes binding of the C-ABI declared in ``include/rl4co_amd.h``.
+
+The library is the product: there is NO CPU fallback. Importing this module is cheap;
+the first call to :func:`lib` loads ``librl4co_amd.so`` and raises if it is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from functools import lru_cache
+
+from . import build as _build
+
+RL4CO_OK = 0
+ENV_TSP, ENV_CVRP = 0, 1
+DECODE_GREEDY, DECODE_SAMPLE, DECODE_EVALUATE = 0, 1, 2
+DT_F32, DT_BF16 = 0, 1
+
+EBIT_NAN_LOGIT = 1
+EBIT_INFEASIBLE = 2
+EBIT_INVALID_TOUR = 4
+EBIT_CAPACITY = 8
+EBIT_MAX_STEPS = 16
+EBIT_NEG_INF_LOGP = 32
+
+# Reference assertion messages (file:line in the reference checkout) per sticky bit.
+ERROR_MESSAGES = {
+    EBIT_NAN_LOGIT: "Logits contain NaNs",  # nn/attention.py:296
+    EBIT_INFEASIBLE: "infeasible action selected",  # utils/decoding.py:393,409
+    EBIT_INVALID_TOUR: "Invalid tour",  # tsp/env.py:164, cvrp/env.py:163
+    EBIT_CAPACITY: "Used more than capacity",  # cvrp/env.py:176
+    EBIT_MAX_STEPS: "Exceeded maximum number of steps during decoding",  # constructive/base.py:237
+    EBIT_NEG_INF_LOGP: "Logprobs should not be -inf, check sampling procedure!",  # decoding.py:56
+}
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class AmDecodeArgs(C.Structure):
+    """Mirror of ``struct rl4co_am_decode_args`` (field order and types must match the header)."""
+
+    _fields_ = [
+        ("env", _i32), ("B", _i32), ("B_inst", _i32), ("N", _i32),
+        ("mode", _i32), ("max_steps", _i32), ("mask_inner", _i32), ("mask_logits", _i32),
+        ("tanh_clipping", _f32), ("temperature", _f32),
+        ("cache_dtype", _i32), ("_pad0", _i32),
+        ("glimpse_key", _vp), ("glimpse_val", _vp), ("logit_key", _vp),
+        ("kvl_row_stride", _i64), ("kvl_batch_stride", _i64),
+        ("ctx_first", _vp), ("ctx_cur", _vp), ("q_bias", _vp), ("q_step0", _vp), ("w_cap", _vp),
+        ("action_mask", _vp), ("first_node", _vp), ("current_node", _vp), ("step_i", _vp),
+        ("done", _vp),
+        ("demand", _vp), ("used_capacity", _vp), ("vehicle_capacity", _vp), ("visited", _vp),
+        ("exp_noise", _vp), ("philox_seed", C.c_uint64), ("philox_offset", C.c_uint64),
+        ("forced_actions", _vp),
+        ("t0", _i32), ("out_stride", _i32),
+        ("actions", _vp), ("logps", _vp), ("all_logps", _vp), ("entropy", _vp),
+        ("n_steps", _vp), ("err", _vp),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/rl4co_amd.h declares.
+SYMBOLS = {
+    "rl4co_version": (C.c_char_p, []),
+    "rl4co_last_error": (C.c_char_p, []),
+    "rl4co_gather_by_index_f32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "rl4co_tour_length_f32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_tsp_check_solution": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_cvrp_check_solution": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_tsp_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_cvrp_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_am_decode": (C.c_int, [C.POINTER(AmDecodeArgs), _vp]),
+    "rl4co_am_decode_lds_bytes": (C.c_int, [C.c_int, C.c_int]),
+    "rl4co_select_start_nodes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "rl4co_hbm_read_probe": (C.c_int, [_vp, _i64, _vp, _vp]),
+}
+
+
+class Rl4coLibraryError(RuntimeError):
+    pass
+
+
+@lru_cache(maxsize=None)
+def lib() -> C.CDLL:
+    """Load ``librl4co_amd.so`` (building it in-tree first if it is stale or absent)."""
+    path = _build.build_library()
+    try:
+        handle = C.CDLL(str(path))
+    except OSError as exc:  # pragma: no cover - depends on the environment
+        raise Rl4coLibraryError(
+            f"cannot load {path}: {exc}. The HIP extension is required; there is no CPU fallback."
+        ) from exc
+    for name, (restype, argtypes) in SYMBOLS.items():
+        fn = getattr(handle, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+    return handle
+
+
+def check(status: int, what: str) -> None:
+    if status != RL4CO_OK:
+        msg = lib().rl4co_last_error().decode("utf-8", "replace")
+        raise Rl4coLibraryError(f"{what} failed with status {status}: {msg}")
+
+
+def raise_for_error_bits(bits: int) -> None:
+    """Re-raise the reference's assertion for the lowest sticky error bit set."""
+    if bits == 0:
+        return
+    for bit, msg in ERROR_MESSAGES.items():
+        if bits & bit:
+            raise AssertionError(msg)
+    raise AssertionError(f"rollout kernel reported error bits {bits:#x}")

@@ -1,0 +1,396 @@
+// am_decode.hip — fused AttentionModel decode step / persistent rollout for gfx950.
+//
+// One wavefront (= one 64-thread workgroup) owns one trajectory for the whole
+// autoregressive loop. Per step it streams the trajectory's three folded cache
+// planes (glimpse key, glimpse value, logit key; [N,128] each) from HBM with
+// 16-byte coalesced loads, keeps the feasibility mask / per-head scores / logits
+// in LDS, reduces with wave butterflies, selects the action (greedy, sampled or
+// forced), updates the TSP / CVRP state in registers+LDS and goes on to the next
+// step — no host round trip, no inter-workgroup traffic (instances are
+// independent), no weights (they were folded into the cache once per rollout).
+//
+// Reference semantics restated (file:line in the reference checkout):
+//   context / query      env_embeddings/context.py:105-149, zoo/am/decoder.py:128-140
+//   pointer attention    nn/attention.py:274-320 (8 heads x 16, mask_inner, /sqrt(128))
+//   logits -> logprobs   utils/decoding.py:138-188 (tanh clip, mask, temperature, log_softmax)
+//   selection            utils/decoding.py:387-413,448-461
+//   env transition       envs/routing/tsp/env.py:60-86, envs/routing/cvrp/env.py:66-96,126-136
+//   loop                 models/common/constructive/base.py:226-238
+//
+// Arithmetic order (mirrored lane-for-lane by oracle/am_decode_ref.c):
+//   EPL = elements per lane per 16-byte load (4 fp32 / 8 bf16); a cache row is
+//   covered by LPR = 128/EPL lanes, a wave load covers RPL = 64/LPR rows, a head
+//   by LPH = 16/EPL lanes.
+//   score(j,h)  = fma-chain over the lane's EPL dims (ascending), then butterfly
+//                 add over xor 1..LPH/2 ; q is pre-scaled by 1/4 (exact)
+//   softmax     = m: max ; p = exp(s-m) ; l, o[d] accumulate per lane over its
+//                 rows in ascending j, then butterfly add over xor LPR..32 ;
+//                 heads[d] = o[d] / l
+//   logit(j)    = fma-chain over EPL dims, butterfly add xor 1..LPR/2, / sqrt(128)
+//   log_softmax = lane-strided (j = lane + 64k) max / sum of exp, butterfly xor
+//                 1..32 ; lp = (z - zmax) - log(sum)
+//   argmax      = lane-strided strict '>' scan, butterfly with (value, lowest index)
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+#include "rl4co_math.h"
+
+namespace {
+
+constexpr int kD = RL4CO_EMBED_DIM;
+constexpr int kH = RL4CO_NUM_HEADS;
+constexpr int kDH = kD / kH;
+constexpr float kNegInf = -__builtin_huge_valf();
+
+struct CacheF32 {
+  using elem = float;
+  static constexpr int EPL = 4;
+  __device__ static inline void load(const elem* p, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+};
+
+struct CacheBF16 {
+  using elem = uint16_t;
+  static constexpr int EPL = 8;
+  __device__ static inline void load(const elem* p, float (&v)[8]) {
+    const uint4 t = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
+    v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+  }
+};
+
+__device__ inline int lds_pad(int N) { return (N + 63) & ~63; }
+
+template <class C, int ENV>
+__global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_args a) {
+  constexpr int EPL = C::EPL;
+  constexpr int LPR = kD / EPL;   // lanes per cache row
+  constexpr int RPL = 64 / LPR;   // rows per wave-wide load
+  constexpr int LPH = kDH / EPL;  // lanes per head
+  using elem = typename C::elem;
+
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const int r = blockIdx.x;  // trajectory
+  const int N = a.N;
+  const int Np = lds_pad(N);
+  float* sc = reinterpret_cast<float*>(smem);  // [Np*kH] per-head scores, (j*kH + h)
+  float* lg = sc + Np * kH;                    // [Np] clipped logits, then log-probs
+  uint8_t* mk = reinterpret_cast<uint8_t*>(lg + Np);  // [Np] 1 = feasible
+  uint8_t* vis = mk + Np;                             // [Np] CVRP visited flags
+
+  const int cb = r % a.B_inst;  // instance whose cache this trajectory reads
+  const int rg = lane / LPR;    // row group inside a wave-wide load
+  const int li = lane % LPR;    // lane position inside the row
+  const int hd = li / LPH;      // head this lane contributes to
+  const int e0 = li * EPL;      // first embedding dim held by this lane
+
+  const elem* Kg = static_cast<const elem*>(a.glimpse_key) + (int64_t)cb * a.kvl_batch_stride + e0;
+  const elem* Vg = static_cast<const elem*>(a.glimpse_val) + (int64_t)cb * a.kvl_batch_stride + e0;
+  const elem* Kl = static_cast<const elem*>(a.logit_key) + (int64_t)cb * a.kvl_batch_stride + e0;
+  const int64_t rs = a.kvl_row_stride;
+  const float* ctxc = a.ctx_cur + (int64_t)cb * N * kD + e0;
+  const float* ctxf = (ENV == RL4CO_ENV_TSP) ? a.ctx_first + (int64_t)cb * N * kD + e0 : nullptr;
+
+  // ---- load the trajectory state ---------------------------------------------------
+  uint8_t* gmask = a.action_mask + (int64_t)r * N;
+  for (int j = lane; j < Np; j += 64) mk[j] = (j < N) ? gmask[j] : (uint8_t)0;
+  if (ENV == RL4CO_ENV_CVRP) {
+    const uint8_t* gv = a.visited + (int64_t)r * N;
+    for (int j = lane; j < Np; j += 64) vis[j] = (j < N) ? gv[j] : (uint8_t)1;
+  }
+  int cur = (int)a.current_node[r];
+  int first = (ENV == RL4CO_ENV_TSP) ? (int)a.first_node[r] : 0;
+  long long step_i = (ENV == RL4CO_ENV_TSP) ? a.step_i[r] : 0;
+  float used = (ENV == RL4CO_ENV_CVRP) ? a.used_capacity[r] : 0.0f;
+  const float cap = (ENV == RL4CO_ENV_CVRP) ? a.vehicle_capacity[r] : 0.0f;
+  const float* dem = (ENV == RL4CO_ENV_CVRP) ? a.demand + (int64_t)cb * (N - 1) : nullptr;
+  bool done = a.done[r] != 0;
+  __syncthreads();
+
+  float qb[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) qb[e] = a.q_bias ? a.q_bias[(int64_t)cb * kD + e0 + e] : 0.0f;
+
+  const float sqrt_d = 11.3137084989847604f;  // fl32(sqrt(128)), attention.py:293
+  const bool single = a.max_steps == 1;
+  uint32_t errbits = 0;
+  float ent_acc = 0.0f;
+  int t = 0;
+
+  for (; t < a.max_steps && (!done || single); ++t) {
+    // ---- query: folded context projection + graph context (decoder.py:128-140) ------
+    float q[EPL];
+    if (ENV == RL4CO_ENV_TSP) {
+      if (step_i < 1) {  // context.py:120 placeholder context
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) q[e] = a.q_step0[e0 + e] + qb[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e)
+          q[e] = (ctxf[(int64_t)first * kD + e] + ctxc[(int64_t)cur * kD + e]) + qb[e];
+      }
+    } else {
+      const float rem = cap - used;  // context.py:147-149
+#pragma unroll
+      for (int e = 0; e < EPL; ++e)
+        q[e] = fmaf(a.w_cap[e0 + e], rem, ctxc[(int64_t)cur * kD + e]) + qb[e];
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) q[e] = q[e] * 0.25f;  // 1/sqrt(16), exact
+
+    // ---- pass 1: per-head scores over the glimpse keys -------------------------------
+    float m = kNegInf;
+    for (int j0 = 0; j0 < N; j0 += RPL) {
+      const int j = j0 + rg;
+      const bool valid = j < N;
+      float k[EPL];
+      if (valid) {
+        C::load(Kg + (int64_t)j * rs, k);
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) k[e] = 0.0f;
+      }
+      float acc = 0.0f;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) acc = fmaf(q[e], k[e], acc);
+#pragma unroll
+      for (int s = 1; s < LPH; s <<= 1) acc = acc + rl4co::shfl_xor_f(acc, s);
+      const bool feas = valid && (!a.mask_inner || mk[j] != 0);
+      const float sv = feas ? acc : kNegInf;
+      if (valid && (li % LPH) == 0) sc[j * kH + hd] = sv;
+      m = fmaxf(m, sv);
+    }
+#pragma unroll
+    for (int s = LPR; s < 64; s <<= 1) m = fmaxf(m, rl4co::shfl_xor_f(m, s));
+    __syncthreads();
+
+    // ---- pass 2: softmax weights and weighted value sum ------------------------------
+    float l = 0.0f;
+    float o[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) o[e] = 0.0f;
+    for (int j0 = 0; j0 < N; j0 += RPL) {
+      const int j = j0 + rg;
+      const bool valid = j < N;
+      float v[EPL];
+      float p = 0.0f;
+      if (valid) {
+        C::load(Vg + (int64_t)j * rs, v);
+        p = rl4co_expf(sc[j * kH + hd] - m);
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) v[e] = 0.0f;
+      }
+      l = l + p;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) o[e] = fmaf(p, v[e], o[e]);
+    }
+#pragma unroll
+    for (int s = LPR; s < 64; s <<= 1) {
+      l = l + rl4co::shfl_xor_f(l, s);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) o[e] = o[e] + rl4co::shfl_xor_f(o[e], s);
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) o[e] = o[e] / l;
+
+    // ---- pass 3: pointer logits against the (project_out-folded) logit key -----------
+    bool nan_seen = false;
+    for (int j0 = 0; j0 < N; j0 += RPL) {
+      const int j = j0 + rg;
+      const bool valid = j < N;
+      float k[EPL];
+      if (valid) {
+        C::load(Kl + (int64_t)j * rs, k);
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) k[e] = 0.0f;
+      }
+      float acc = 0.0f;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) acc = fmaf(o[e], k[e], acc);
+#pragma unroll
+      for (int s = 1; s < LPR; s <<= 1) acc = acc + rl4co::shfl_xor_f(acc, s);
+      float z = acc / sqrt_d;
+      if (valid && z != z) nan_seen = true;  // attention.py:295-296
+      if (a.tanh_clipping > 0.0f) z = rl4co_tanhf(z) * a.tanh_clipping;
+      if (a.mask_logits && !(valid && mk[j] != 0)) z = kNegInf;
+      z = z / a.temperature;
+      if (valid && li == 0) lg[j] = z;
+    }
+    if (__any(nan_seen)) errbits |= RL4CO_EBIT_NAN_LOGIT;
+    __syncthreads();
+
+    // ---- log_softmax over the N logits (decoding.py:188) -----------------------------
+    float zmax = kNegInf;
+    for (int j = lane; j < N; j += 64) zmax = fmaxf(zmax, lg[j]);
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) zmax = fmaxf(zmax, rl4co::shfl_xor_f(zmax, s));
+    float zsum = 0.0f;
+    for (int j = lane; j < N; j += 64) zsum = zsum + rl4co_expf(lg[j] - zmax);
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) zsum = zsum + rl4co::shfl_xor_f(zsum, s);
+    const float lse = rl4co_logf(zsum);
+
+    // ---- selection ---------------------------------------------------------------------
+    float best = kNegInf;
+    int bi = 0x7fffffff;
+    float ent = 0.0f;
+    const int64_t tcol = (int64_t)a.t0 + t;
+    for (int j = lane; j < N; j += 64) {
+      const float lp = (lg[j] - zmax) - lse;
+      lg[j] = lp;
+      float key = lp;
+      if (a.mode == RL4CO_DECODE_SAMPLE) {
+        const float nz = a.exp_noise
+                             ? a.exp_noise[((int64_t)t * a.B + r) * N + j]
+                             : rl4co_exp1_noise(a.philox_seed, a.philox_offset + (uint64_t)tcol,
+                                                (uint32_t)r, (uint32_t)j);
+        key = rl4co_expf(lp) / nz;  // multinomial(p,1) == argmax(p / Exp(1))
+      }
+      if (bi == 0x7fffffff || key > best) {  // strict '>' keeps the lowest index on ties
+        best = key;
+        bi = j;
+      }
+      if (a.entropy && lp > kNegInf) ent = fmaf(rl4co_expf(lp), lp, ent);
+      if (a.all_logps) a.all_logps[((int64_t)r * a.out_stride + tcol) * N + j] = lp;
+    }
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+      const float ov = rl4co::shfl_xor_f(best, s);
+      const int oi = rl4co::shfl_xor_i(bi, s);
+      if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) {
+        best = ov;
+        bi = oi;
+      }
+    }
+    if (a.entropy) {
+#pragma unroll
+      for (int s = 1; s < 64; s <<= 1) ent = ent + rl4co::shfl_xor_f(ent, s);
+      ent_acc = ent_acc - ent;
+    }
+    if (a.mode == RL4CO_DECODE_EVALUATE) bi = (int)a.forced_actions[(int64_t)r * a.out_stride + tcol];
+    if (bi < 0 || bi >= N) {  // forced action out of range
+      errbits |= RL4CO_EBIT_INFEASIBLE;
+      bi = 0;
+    }
+    __syncthreads();
+    const float logp = lg[bi];
+    if (mk[bi] == 0) errbits |= RL4CO_EBIT_INFEASIBLE;  // decoding.py:393,409
+    if (!(logp > -1000.0f)) errbits |= RL4CO_EBIT_NEG_INF_LOGP;  // decoding.py:56
+    if (lane == 0) {
+      a.actions[(int64_t)r * a.out_stride + tcol] = bi;
+      a.logps[(int64_t)r * a.out_stride + tcol] = logp;
+    }
+    __syncthreads();
+
+    // ---- environment transition -------------------------------------------------------
+    if (ENV == RL4CO_ENV_TSP) {
+      if (step_i == 0) first = bi;  // tsp/env.py:63
+      cur = bi;
+      if (lane == 0) mk[bi] = 0;
+      step_i += 1;
+      __syncthreads();
+      bool any_left = false;
+      for (int j = lane; j < N; j += 64) any_left |= mk[j] != 0;
+      done = !__any(any_left);  // tsp/env.py:71
+    } else {
+      const int di = min(max(bi - 1, 0), N - 2);               // cvrp/env.py:71-73
+      used = (used + dem[di]) * (bi != 0 ? 1.0f : 0.0f);       // cvrp/env.py:76
+      cur = bi;
+      if (lane == 0) vis[bi] = 1;
+      __syncthreads();
+      const float thr = cap + 1e-5f;  // cvrp/env.py:128
+      bool any_feasible = false, all_visited = true;
+      for (int j = lane; j < N; j += 64) {
+        all_visited &= vis[j] != 0;
+        if (j >= 1) {
+          const bool masked = (vis[j] != 0) || (dem[j - 1] + used > thr);
+          mk[j] = masked ? 0 : 1;
+          any_feasible |= !masked;
+        }
+      }
+      any_feasible = __any(any_feasible);
+      done = __all(all_visited);  // cvrp/env.py:83
+      if (lane == 0) mk[0] = ((cur == 0) && any_feasible) ? 0 : 1;  // cvrp/env.py:134-135
+      __syncthreads();
+    }
+  }
+  if (!single && !done && t >= a.max_steps) errbits |= RL4CO_EBIT_MAX_STEPS;
+
+  // ---- write the state back ------------------------------------------------------------
+  for (int j = lane; j < N; j += 64) gmask[j] = mk[j];
+  if (ENV == RL4CO_ENV_CVRP) {
+    uint8_t* gv = a.visited + (int64_t)r * N;
+    for (int j = lane; j < N; j += 64) gv[j] = vis[j];
+  }
+  if (lane == 0) {
+    a.current_node[r] = cur;
+    a.done[r] = done ? 1 : 0;
+    if (ENV == RL4CO_ENV_TSP) {
+      a.first_node[r] = first;
+      a.step_i[r] = step_i;
+    } else {
+      a.used_capacity[r] = used;
+    }
+    if (a.n_steps) a.n_steps[r] = t;
+    if (a.entropy) a.entropy[r] += ent_acc;
+    if (errbits) atomicOr(a.err, (int)errbits);
+  }
+}
+
+template <class C, int ENV>
+int launch(const rl4co_am_decode_args& a, hipStream_t stream) {
+  const int lds = rl4co_am_decode_lds_bytes(a.N, ENV);
+  if (lds > 64 * 1024) {
+    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_decode_kernel<C, ENV>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  }
+  hipLaunchKernelGGL((am_decode_kernel<C, ENV>), dim3(a.B), dim3(64), lds, stream, a);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
+}  // namespace
+
+extern "C" int rl4co_am_decode_lds_bytes(int N, int env) {
+  (void)env;
+  const int Np = (N + 63) & ~63;
+  return Np * kH * 4 + Np * 4 + Np + Np;
+}
+
+extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
+  RL4CO_REQUIRE(args != nullptr);
+  const rl4co_am_decode_args& a = *args;
+  RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP);
+  RL4CO_REQUIRE(a.B > 0 && a.B_inst > 0 && a.B % a.B_inst == 0);
+  RL4CO_REQUIRE(a.N >= 2 && a.N <= 4096);
+  RL4CO_REQUIRE(a.max_steps >= 1);
+  RL4CO_REQUIRE(a.mode >= RL4CO_DECODE_GREEDY && a.mode <= RL4CO_DECODE_EVALUATE);
+  RL4CO_REQUIRE(a.cache_dtype == RL4CO_DT_F32 || a.cache_dtype == RL4CO_DT_BF16);
+  RL4CO_REQUIRE(a.glimpse_key && a.glimpse_val && a.logit_key && a.ctx_cur);
+  RL4CO_REQUIRE(a.kvl_row_stride >= kD && a.kvl_row_stride % 8 == 0);
+  RL4CO_REQUIRE(a.kvl_batch_stride >= (int64_t)a.N * kD && a.kvl_batch_stride % 8 == 0);
+  RL4CO_REQUIRE(a.action_mask && a.current_node && a.done && a.actions && a.logps && a.err);
+  RL4CO_REQUIRE(a.out_stride >= 1 && a.t0 >= 0 && (int64_t)a.t0 + a.max_steps <= a.out_stride);
+  RL4CO_REQUIRE(a.temperature > 0.0f);
+  RL4CO_REQUIRE(a.mode != RL4CO_DECODE_EVALUATE || a.forced_actions != nullptr);
+  if (a.env == RL4CO_ENV_TSP) {
+    RL4CO_REQUIRE(a.ctx_first && a.q_step0 && a.first_node && a.step_i);
+  } else {
+    RL4CO_REQUIRE(a.w_cap && a.demand && a.used_capacity && a.vehicle_capacity && a.visited);
+  }
+  RL4CO_REQUIRE(rl4co_am_decode_lds_bytes(a.N, a.env) <= 160 * 1024);
+  hipStream_t s = rl4co::as_stream(stream);
+  if (a.cache_dtype == RL4CO_DT_F32) {
+    return a.env == RL4CO_ENV_TSP ? launch<CacheF32, RL4CO_ENV_TSP>(a, s)
+                                  : launch<CacheF32, RL4CO_ENV_CVRP>(a, s);
+  }
+  return a.env == RL4CO_ENV_TSP ? launch<CacheBF16, RL4CO_ENV_TSP>(a, s)
+                                : launch<CacheBF16, RL4CO_ENV_CVRP>(a, s);
+}
