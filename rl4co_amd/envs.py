@@ -1,0 +1,256 @@
+"""Host-side mirror of the reference environment surface for TSP and CVRP.
+
+Same names, arguments and error behaviour as ``RL4COEnvBase`` (envs/common/base.py:19-333),
+``TSPEnv`` (envs/routing/tsp/env.py:22-192) and ``CVRPEnv`` (envs/routing/cvrp/env.py:22-256)
+for the methods on the rollout path — ``reset``, ``step``, ``get_reward``,
+``check_solution_validity``, ``get_action_mask``, ``get_num_starts``, ``select_start_nodes`` —
+with the arithmetic done by the HIP kernels behind ``include/rl4co_amd.h``.
+
+Differences a caller can observe, both deliberate:
+  * state tensors are updated IN PLACE by the kernels (the reference re-allocates them every
+    step and swaps them into the TensorDict);
+  * validity asserts are evaluated on the device and raised once, by ``get_reward``, with the
+    reference's messages, instead of synchronising the host every step.
+Out of scope (not on the rollout path): dataset files, rendering, local search, torchrl specs.
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from . import kernels as K
+from .tensordict import TensorDict
+
+CAPACITIES = {  # cvrp/generator.py:15-30 (Kool et al. 2019 and follow-ups)
+    10: 20.0, 15: 25.0, 20: 30.0, 30: 33.0, 40: 37.0, 50: 40.0, 60: 43.0, 75: 45.0,
+    100: 50.0, 125: 55.0, 150: 60.0, 200: 70.0, 500: 100.0, 1000: 150.0,
+}
+
+
+class Generator:
+    """envs/common/utils.py:19-31"""
+
+    def __call__(self, batch_size) -> TensorDict:
+        batch_size = [batch_size] if isinstance(batch_size, int) else list(batch_size)
+        return self._generate(batch_size)
+
+    def _generate(self, batch_size) -> TensorDict:
+        raise NotImplementedError
+
+
+class TSPGenerator(Generator):
+    """tsp/generator.py:14-58 (uniform locations; other samplers are out of scope).
+
+    ``device`` chooses where the instances are drawn: "cpu" reproduces the reference stream of
+    the global torch generator exactly; a CUDA device draws directly into HBM (row N2 of §8f)."""
+
+    def __init__(self, num_loc: int = 20, min_loc: float = 0.0, max_loc: float = 1.0, device="cpu"):
+        self.num_loc = num_loc
+        self.min_loc = min_loc
+        self.max_loc = max_loc
+        self.device = device
+
+    def _uniform(self, shape, low, high):
+        if str(self.device) == "cpu":
+            return torch.distributions.Uniform(low=low, high=high).sample(shape)
+        return torch.rand(shape, device=self.device) * (high - low) + low
+
+    def _generate(self, batch_size) -> TensorDict:
+        locs = self._uniform((*batch_size, self.num_loc, 2), self.min_loc, self.max_loc)
+        return TensorDict({"locs": locs}, batch_size=batch_size)
+
+
+class CVRPGenerator(TSPGenerator):
+    """cvrp/generator.py:33-140"""
+
+    def __init__(self, num_loc: int = 20, min_loc: float = 0.0, max_loc: float = 1.0,
+                 min_demand: int = 1, max_demand: int = 10, vehicle_capacity: float = 1.0,
+                 capacity: float | None = None, device="cpu"):
+        super().__init__(num_loc, min_loc, max_loc, device)
+        self.min_demand = min_demand
+        self.max_demand = max_demand
+        self.vehicle_capacity = vehicle_capacity
+        if capacity is None:
+            capacity = CAPACITIES.get(num_loc, None)
+        if capacity is None:
+            closest = min(CAPACITIES.keys(), key=lambda x: abs(x - num_loc))
+            capacity = CAPACITIES[closest]
+        self.capacity = capacity
+
+    def _generate(self, batch_size) -> TensorDict:
+        locs = self._uniform((*batch_size, self.num_loc + 1, 2), self.min_loc, self.max_loc)
+        depot = locs[..., 0, :]
+        locs = locs[..., 1:, :]
+        demand = self._uniform((*batch_size, self.num_loc), self.min_demand - 1, self.max_demand - 1)
+        demand = (demand.int() + 1).float()
+        capacity = torch.full((*batch_size, 1), self.capacity, device=demand.device)
+        return TensorDict(
+            {"locs": locs, "depot": depot, "demand": demand / self.capacity, "capacity": capacity},
+            batch_size=batch_size,
+        )
+
+
+class RL4COEnvBase:
+    """envs/common/base.py:19-333, rollout-path methods only."""
+
+    name = "base"
+    has_depot = False
+
+    def __init__(self, *, generator: Generator | None = None, generator_params: dict | None = None,
+                 check_solution: bool = True, device="cuda", seed: int | None = None, **unused):
+        self.check_solution = check_solution
+        self.device = torch.device(device)
+        self.generator = generator if generator is not None else self._default_generator(**(generator_params or {}))
+        if seed is not None:
+            torch.manual_seed(seed)
+
+    # -- RL4COEnvBase.reset (base.py:135-143) ---------------------------------------------------
+    def reset(self, td: TensorDict | None = None, batch_size=None) -> TensorDict:
+        if batch_size is None:
+            batch_size = [] if td is None else td.batch_size
+        if td is None or len(td) == 0:
+            td = self.generator(batch_size=batch_size)
+        batch_size = [batch_size] if isinstance(batch_size, int) else list(batch_size)
+        td = td.to(self.device)
+        return self._reset(td, batch_size=batch_size)
+
+    # -- RL4COEnvBase.step (base.py:121-133) ----------------------------------------------------
+    def step(self, td: TensorDict) -> dict:
+        return {"next": self._step(td)}
+
+    # -- RL4COEnvBase.get_reward (base.py:180-190) ------------------------------------------------
+    def get_reward(self, td: TensorDict, actions: Tensor, check_solution: bool | None = None) -> Tensor:
+        check_solution = self.check_solution if check_solution is None else check_solution
+        if check_solution:
+            self.check_solution_validity(td, actions)
+        return self._get_reward(td, actions)
+
+    def get_num_starts(self, td) -> int:
+        """ops.py:115-125"""
+        num_starts = td["action_mask"].shape[-1]
+        return num_starts - 1 if self.has_depot else num_starts
+
+    def select_start_nodes(self, td, num_starts: int) -> Tensor:
+        """ops.py:128-161"""
+        num_loc = getattr(self.generator, "num_loc", 0xFFFFFFFF)
+        batch = td["action_mask"].shape[0]
+        return K.select_start_nodes(batch, num_starts, num_loc, self.has_depot, td["action_mask"].device)
+
+    def to(self, device):
+        if device is not None:
+            self.device = torch.device(device)
+        return self
+
+    # subclasses
+    def _default_generator(self, **kw) -> Generator:
+        raise NotImplementedError
+
+    def _reset(self, td, batch_size):
+        raise NotImplementedError
+
+    def _step(self, td):
+        raise NotImplementedError
+
+    def _get_reward(self, td, actions):
+        raise NotImplementedError
+
+    def check_solution_validity(self, td, actions) -> None:
+        raise NotImplementedError
+
+
+class TSPEnv(RL4COEnvBase):
+    name = "tsp"
+    has_depot = False
+
+    def _default_generator(self, **kw):
+        return TSPGenerator(**kw)
+
+    def _reset(self, td: TensorDict, batch_size) -> TensorDict:
+        """tsp/env.py:88-113 (+ torchrl's done flag)"""
+        init_locs = td["locs"].contiguous()
+        device = init_locs.device
+        b = init_locs.shape[0]
+        num_loc = init_locs.shape[-2]
+        return TensorDict(
+            {
+                "locs": init_locs,
+                "first_node": torch.zeros((b,), dtype=torch.int64, device=device),
+                "current_node": torch.zeros((b,), dtype=torch.int64, device=device),
+                "i": torch.zeros((b, 1), dtype=torch.int64, device=device),
+                "action_mask": torch.ones((b, num_loc), dtype=torch.bool, device=device),
+                "reward": torch.zeros((b, 1), dtype=torch.float32, device=device),
+                "done": torch.zeros((b,), dtype=torch.bool, device=device),
+            },
+            batch_size=[b],
+        )
+
+    def _step(self, td: TensorDict) -> TensorDict:
+        """tsp/env.py:60-86 via rl4co_tsp_step (in place)."""
+        K.tsp_step(td["action"].contiguous(), td["action_mask"], td["first_node"], td["current_node"],
+                   td["i"], td["done"])
+        return td
+
+    def _get_reward(self, td: TensorDict, actions: Tensor) -> Tensor:
+        """tsp/env.py:150-156"""
+        return K.tour_length(td["locs"], actions.contiguous(), prepend_depot=False, negate=True)
+
+    def check_solution_validity(self, td: TensorDict, actions: Tensor) -> None:
+        """tsp/env.py:158-164"""
+        err = K.new_error_word(actions.device)
+        K.tsp_check_solution(actions.contiguous(), td["locs"].shape[-2], err)
+        K.raise_if_error(err)
+
+
+class CVRPEnv(RL4COEnvBase):
+    name = "cvrp"
+    has_depot = True
+
+    def _default_generator(self, **kw):
+        return CVRPGenerator(**kw)
+
+    def _reset(self, td: TensorDict, batch_size) -> TensorDict:
+        """cvrp/env.py:98-124"""
+        device = td["locs"].device
+        b = td["locs"].shape[0]
+        n = td["locs"].shape[-2] + 1
+        td_reset = TensorDict(
+            {
+                "locs": torch.cat((td["depot"][:, None, :], td["locs"]), -2).contiguous(),
+                "demand": td["demand"].contiguous(),
+                "current_node": torch.zeros(b, 1, dtype=torch.long, device=device),
+                "used_capacity": torch.zeros((b, 1), device=device),
+                "vehicle_capacity": torch.full((b, 1), self.generator.vehicle_capacity, device=device),
+                "visited": torch.zeros((b, n), dtype=torch.uint8, device=device),
+                "action_mask": torch.zeros((b, n), dtype=torch.bool, device=device),
+                "done": torch.zeros((b,), dtype=torch.bool, device=device),
+            },
+            batch_size=[b],
+        )
+        self.get_action_mask(td_reset)
+        return td_reset
+
+    def _step(self, td: TensorDict) -> TensorDict:
+        """cvrp/env.py:66-96 via rl4co_cvrp_step (in place, mask included)."""
+        K.cvrp_step(td["action"].contiguous(), td["demand"], td["used_capacity"], td["vehicle_capacity"],
+                    td["visited"], td["current_node"], td["action_mask"], td["done"])
+        return td
+
+    def get_action_mask(self, td: TensorDict) -> Tensor:
+        """cvrp/env.py:126-136 (recomputed in place into td['action_mask'])."""
+        K.cvrp_step(None, td["demand"], td["used_capacity"], td["vehicle_capacity"], td["visited"],
+                    td["current_node"], td["action_mask"], None)
+        return td["action_mask"]
+
+    def _get_reward(self, td: TensorDict, actions: Tensor) -> Tensor:
+        """cvrp/env.py:138-147"""
+        return K.tour_length(td["locs"], actions.contiguous(), prepend_depot=True, negate=True)
+
+    def check_solution_validity(self, td: TensorDict, actions: Tensor) -> None:
+        """cvrp/env.py:149-177"""
+        err = K.new_error_word(actions.device)
+        K.cvrp_check_solution(actions.contiguous(), td["demand"], td["vehicle_capacity"].reshape(-1).contiguous(), err)
+        K.raise_if_error(err)
+
+
+def get_env(name: str, **kw) -> RL4COEnvBase:
+    return {"tsp": TSPEnv, "cvrp": CVRPEnv}[name](**kw)

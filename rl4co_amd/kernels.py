@@ -1,0 +1,236 @@
+"""Thin torch-tensor front end over the C-ABI (``include/rl4co_amd.h``).
+
+torch is plumbing here: it owns device memory and the HIP stream; every function below hands
+raw device pointers + sizes to ``librl4co_amd.so`` on ``torch.cuda.current_stream()``.
+There is no CPU path: a non-CUDA tensor is an error.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from .cache import FoldedCache
+
+MODE_IDS = {"greedy": _lib.DECODE_GREEDY, "sampling": _lib.DECODE_SAMPLE, "evaluate": _lib.DECODE_EVALUATE}
+ENV_IDS = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP}
+
+
+def _ptr(t: Tensor | None) -> int | None:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: Tensor, dtype: torch.dtype | None = None, name: str = "tensor") -> Tensor:
+    if not t.is_cuda:
+        raise _lib.Rl4coLibraryError(
+            f"{name} lives on {t.device}; the rl4co_amd kernels only run on the MI355X (no CPU fallback)"
+        )
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+def _u8(t: Tensor, name: str) -> Tensor:
+    """bool tensors share the uint8 storage the kernels read/write."""
+    _dev(t, None, name)
+    if t.dtype == torch.bool:
+        return t.view(torch.uint8)
+    if t.dtype != torch.uint8:
+        raise TypeError(f"{name} must be bool or uint8, got {t.dtype}")
+    return t
+
+
+def new_error_word(device) -> Tensor:
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def raise_if_error(err: Tensor) -> None:
+    """ONE host sync per rollout instead of the reference's 4-5 per decode step."""
+    _lib.raise_for_error_bits(int(err.item()))
+
+
+# ------------------------------------------------------------------------------------------------
+
+
+def gather_by_index(src: Tensor, idx: Tensor, err: Tensor | None = None) -> Tensor:
+    """ops.py:54-66 for src [B,N,D] fp32, idx [B,K] int64 -> [B,K,D]."""
+    _dev(src, torch.float32, "src"), _dev(idx, torch.int64, "idx")
+    b, n, d = src.shape
+    k = idx.shape[1]
+    out = torch.empty((b, k, d), dtype=torch.float32, device=src.device)
+    st = _lib.lib().rl4co_gather_by_index_f32(_ptr(src), _ptr(idx), b, n, d, k, _ptr(out), _ptr(err), _stream())
+    _lib.check(st, "rl4co_gather_by_index_f32")
+    return out
+
+
+def tour_length(locs: Tensor, actions: Tensor, prepend_depot: bool = False, negate: bool = False) -> Tensor:
+    """ops.py:82-90 over gather(locs, actions) (+ depot for CVRP, cvrp/env.py:138-147).
+
+    locs [B_locs,N,2] fp32 with B % B_locs == 0 (s-major multistart), actions [B,T] int64."""
+    _dev(locs, torch.float32, "locs"), _dev(actions, torch.int64, "actions")
+    b, t = actions.shape
+    b_locs, n, two = locs.shape
+    assert two == 2
+    out = torch.empty((b,), dtype=torch.float32, device=locs.device)
+    st = _lib.lib().rl4co_tour_length_f32(
+        _ptr(locs), _ptr(actions), b, b_locs, n, t, int(prepend_depot), int(negate), _ptr(out), _stream()
+    )
+    _lib.check(st, "rl4co_tour_length_f32")
+    return out
+
+
+def tsp_check_solution(actions: Tensor, num_nodes: int, err: Tensor) -> None:
+    _dev(actions, torch.int64, "actions")
+    b, t = actions.shape
+    st = _lib.lib().rl4co_tsp_check_solution(_ptr(actions), b, num_nodes, t, _ptr(err), _stream())
+    _lib.check(st, "rl4co_tsp_check_solution")
+
+
+def cvrp_check_solution(actions: Tensor, demand: Tensor, vehicle_capacity: Tensor, err: Tensor) -> None:
+    _dev(actions, torch.int64, "actions"), _dev(demand, torch.float32, "demand")
+    _dev(vehicle_capacity, torch.float32, "vehicle_capacity")
+    b, t = actions.shape
+    b_inst, n1 = demand.shape
+    st = _lib.lib().rl4co_cvrp_check_solution(
+        _ptr(actions), _ptr(demand), _ptr(vehicle_capacity), b, b_inst, n1 + 1, t, _ptr(err), _stream()
+    )
+    _lib.check(st, "rl4co_cvrp_check_solution")
+
+
+def tsp_step(action: Tensor, action_mask: Tensor, first_node: Tensor, current_node: Tensor,
+             step_i: Tensor, done: Tensor, err: Tensor | None = None) -> None:
+    """In-place TSPEnv._step (tsp/env.py:60-86)."""
+    _dev(action, torch.int64, "action")
+    mask = _u8(action_mask, "action_mask")
+    b, n = mask.shape
+    st = _lib.lib().rl4co_tsp_step(
+        _ptr(action), _ptr(mask), _ptr(_dev(first_node, torch.int64, "first_node")),
+        _ptr(_dev(current_node, torch.int64, "current_node")), _ptr(_dev(step_i, torch.int64, "i")),
+        _ptr(_u8(done, "done")), b, n, _ptr(err), _stream(),
+    )
+    _lib.check(st, "rl4co_tsp_step")
+
+
+def cvrp_step(action: Tensor | None, demand: Tensor, used_capacity: Tensor, vehicle_capacity: Tensor,
+              visited: Tensor, current_node: Tensor, action_mask: Tensor, done: Tensor | None,
+              err: Tensor | None = None) -> None:
+    """In-place CVRPEnv._step + get_action_mask (cvrp/env.py:66-96,126-136); action=None -> mask only."""
+    mask = _u8(action_mask, "action_mask")
+    b, n = mask.shape
+    b_inst = demand.shape[0]
+    st = _lib.lib().rl4co_cvrp_step(
+        _ptr(None if action is None else _dev(action, torch.int64, "action")),
+        _ptr(_dev(demand, torch.float32, "demand")), _ptr(_dev(used_capacity, torch.float32, "used_capacity")),
+        _ptr(_dev(vehicle_capacity, torch.float32, "vehicle_capacity")), _ptr(_u8(visited, "visited")),
+        _ptr(_dev(current_node, torch.int64, "current_node")), _ptr(mask),
+        _ptr(None if done is None else _u8(done, "done")), b, b_inst, n, _ptr(err), _stream(),
+    )
+    _lib.check(st, "rl4co_cvrp_step")
+
+
+def select_start_nodes(batch: int, num_starts: int, num_loc: int, has_depot: bool, device) -> Tensor:
+    """ops.py:128-161: s-major ``arange(S).repeat_interleave(B) % num_loc (+1)``."""
+    out = torch.empty((batch * num_starts,), dtype=torch.int64, device=device)
+    if not out.is_cuda:
+        raise _lib.Rl4coLibraryError("select_start_nodes needs a CUDA device")
+    st = _lib.lib().rl4co_select_start_nodes(_ptr(out), batch, num_starts, num_loc, int(has_depot), _stream())
+    _lib.check(st, "rl4co_select_start_nodes")
+    return out
+
+
+def am_decode(
+    cache: FoldedCache,
+    state: dict,
+    *,
+    mode: str,
+    max_steps: int,
+    actions: Tensor,
+    logps: Tensor,
+    err: Tensor,
+    t0: int = 0,
+    tanh_clipping: float = 10.0,
+    temperature: float = 1.0,
+    mask_inner: bool = True,
+    mask_logits: bool = True,
+    exp_noise: Tensor | None = None,
+    philox_seed: int = 0,
+    philox_offset: int = 0,
+    forced_actions: Tensor | None = None,
+    all_logps: Tensor | None = None,
+    entropy: Tensor | None = None,
+    n_steps: Tensor | None = None,
+) -> None:
+    """Run ``max_steps`` fused decode steps (1 = a single step, >= horizon = whole rollout).
+
+    ``state`` holds the environment tensors (updated in place): action_mask [B,N] bool,
+    current_node, done; TSP: first_node, i; CVRP: demand, used_capacity, vehicle_capacity, visited.
+    """
+    env_name = cache.env_name
+    a = _lib.AmDecodeArgs()
+    mask = _u8(state["action_mask"], "action_mask")
+    b, n = mask.shape
+    assert n == cache.num_nodes, (n, cache.num_nodes)
+    a.env = ENV_IDS[env_name]
+    a.B, a.B_inst, a.N = b, cache.num_instances, n
+    a.mode = MODE_IDS[mode]
+    a.max_steps = int(max_steps)
+    a.mask_inner, a.mask_logits = int(mask_inner), int(mask_logits)
+    a.tanh_clipping, a.temperature = float(tanh_clipping), float(temperature)
+    kvl = _dev(cache.kvl, None, "cache.kvl")
+    if kvl.dtype == torch.float32:
+        a.cache_dtype = _lib.DT_F32
+    elif kvl.dtype == torch.bfloat16:
+        a.cache_dtype = _lib.DT_BF16
+    else:
+        raise TypeError(f"cache dtype must be float32 or bfloat16, got {kvl.dtype}")
+    a.glimpse_key, a.glimpse_val, a.logit_key = (cache.plane(i).data_ptr() for i in range(3))
+    a.kvl_row_stride, a.kvl_batch_stride = cache.row_stride, cache.batch_stride
+    a.ctx_cur = _ptr(_dev(cache.ctx_cur, torch.float32, "ctx_cur"))
+    a.q_bias = _ptr(None if cache.q_bias is None else _dev(cache.q_bias, torch.float32, "q_bias"))
+    a.action_mask = _ptr(mask)
+    a.current_node = _ptr(_dev(state["current_node"], torch.int64, "current_node"))
+    a.done = _ptr(_u8(state["done"], "done"))
+    if env_name == "tsp":
+        a.ctx_first = _ptr(_dev(cache.ctx_first, torch.float32, "ctx_first"))
+        a.q_step0 = _ptr(_dev(cache.q_step0, torch.float32, "q_step0"))
+        a.first_node = _ptr(_dev(state["first_node"], torch.int64, "first_node"))
+        a.step_i = _ptr(_dev(state["i"], torch.int64, "i"))
+    else:
+        a.w_cap = _ptr(_dev(cache.w_cap, torch.float32, "w_cap"))
+        a.demand = _ptr(_dev(state["demand"], torch.float32, "demand"))
+        assert state["demand"].shape[0] in (cache.num_instances,), "demand rows must match cache instances"
+        a.used_capacity = _ptr(_dev(state["used_capacity"], torch.float32, "used_capacity"))
+        a.vehicle_capacity = _ptr(_dev(state["vehicle_capacity"], torch.float32, "vehicle_capacity"))
+        a.visited = _ptr(_u8(state["visited"], "visited"))
+    if exp_noise is not None:
+        _dev(exp_noise, torch.float32, "exp_noise")
+        assert exp_noise.numel() >= max_steps * b * n, "exp_noise must hold [max_steps,B,N] draws"
+        a.exp_noise = _ptr(exp_noise)
+    a.philox_seed, a.philox_offset = int(philox_seed), int(philox_offset)
+    if forced_actions is not None:
+        _dev(forced_actions, torch.int64, "forced_actions")
+        assert forced_actions.shape == actions.shape
+        a.forced_actions = _ptr(forced_actions)
+    _dev(actions, torch.int64, "actions"), _dev(logps, torch.float32, "logps")
+    assert actions.shape == logps.shape and actions.shape[0] == b
+    a.t0, a.out_stride = int(t0), actions.shape[1]
+    a.actions, a.logps = _ptr(actions), _ptr(logps)
+    a.all_logps = _ptr(None if all_logps is None else _dev(all_logps, torch.float32, "all_logps"))
+    a.entropy = _ptr(None if entropy is None else _dev(entropy, torch.float32, "entropy"))
+    a.n_steps = _ptr(None if n_steps is None else _dev(n_steps, torch.int32, "n_steps"))
+    a.err = _ptr(_dev(err, torch.int32, "err"))
+    st = _lib.lib().rl4co_am_decode(C.byref(a), _stream())
+    _lib.check(st, "rl4co_am_decode")
+
+
+def hbm_read_probe(buf: Tensor, sink: Tensor) -> None:
+    st = _lib.lib().rl4co_hbm_read_probe(_ptr(buf), buf.numel() * buf.element_size(), _ptr(sink), _stream())
+    _lib.check(st, "rl4co_hbm_read_probe")

@@ -1,0 +1,554 @@
+"""Host-side mirror of ``AttentionModelPolicy`` whose rollout runs in the fused HIP kernel.
+
+Drop-in at the reference's ``policy`` seam: same constructor arguments as
+``zoo/am/policy.py:50-122``, same ``forward`` signature and output dict as
+``models/common/constructive/base.py:154-263``, and the SAME module tree — hence identical
+``state_dict()`` keys, so reference checkpoints load unchanged.
+
+What runs where
+  * encoder (``zoo/am/encoder.py``, ``nn/graph/attnnet.py``): dense GEMM/attention work, run
+    through torch on the GPU (hipBLASLt / MIOpen); the only MFMA-shaped part of the path.
+  * cache folding (``rl4co_amd/cache.py``): one GEMM per rollout.
+  * the whole ``while not done`` loop (base.py:226-238) — context, pointer attention, logits
+    processing, selection, env transition: ONE launch of ``rl4co_am_decode`` (no grad).
+  * reward: ``env.get_reward`` -> ``rl4co_tour_length_f32``.
+  * training: REINFORCE differentiates ``log_likelihood`` (reinforce.py:101). The rollout is
+    sampled without grad by the kernel; ``log_likelihood`` is then re-evaluated teacher-forced
+    over all T steps at once with autograd (the reference's own ``decode_type="evaluate"``
+    semantics, decoding.py:448-461, as PPO already does, rl/ppo/ppo.py:128-170).
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from . import kernels as K
+from .cache import FoldedCache, build_folded_cache
+from .envs import RL4COEnvBase, get_env
+from .tensordict import TensorDict
+
+# ------------------------------------------------------------------------------------------------
+# module tree (names = reference attribute names, so state_dict keys coincide)
+# ------------------------------------------------------------------------------------------------
+
+
+class _Skip(nn.Module):
+    """nn/ops.py:9-15 SkipConnection: parameters live under ``.module``."""
+
+    def __init__(self, module: nn.Module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, x):
+        return x + self.module(x)
+
+
+class _Norm(nn.Module):
+    """nn/ops.py:30-54 Normalization: parameters live under ``.normalizer``."""
+
+    def __init__(self, embed_dim: int, normalization: str):
+        super().__init__()
+        self.kind = normalization
+        if normalization == "batch":
+            self.normalizer = nn.BatchNorm1d(embed_dim, affine=True)
+        elif normalization == "instance":
+            self.normalizer = nn.InstanceNorm1d(embed_dim, affine=True)
+        elif normalization == "layer":
+            self.normalizer = "layer"
+        else:
+            raise ValueError(f"unknown normalization {normalization!r}")
+
+    def forward(self, x: Tensor) -> Tensor:
+        if self.kind == "batch":
+            b, n, d = x.shape
+            return self.normalizer(x.reshape(b * n, d)).view(b, n, d)
+        if self.kind == "instance":
+            return self.normalizer(x.transpose(1, 2)).transpose(1, 2)
+        mean = x.mean((1, 2), keepdim=True)
+        var = x.var((1, 2), keepdim=True)
+        return (x - mean) / torch.sqrt(var + 1e-5)
+
+
+class _SelfAttention(nn.Module):
+    """nn/attention.py:64-134 MultiHeadAttention (``Wqkv`` + ``out_proj``)."""
+
+    def __init__(self, embed_dim: int, num_heads: int):
+        super().__init__()
+        self.num_heads = num_heads
+        self.Wqkv = nn.Linear(embed_dim, 3 * embed_dim, bias=True)
+        self.out_proj = nn.Linear(embed_dim, embed_dim, bias=True)
+
+    def forward(self, x: Tensor) -> Tensor:
+        b, n, d = x.shape
+        qkv = self.Wqkv(x).view(b, n, 3, self.num_heads, d // self.num_heads)
+        q, k, v = qkv.permute(2, 0, 3, 1, 4).unbind(0)
+        out = F.scaled_dot_product_attention(q, k, v)
+        return self.out_proj(out.transpose(1, 2).reshape(b, n, d))
+
+
+class _FeedForward(nn.Module):
+    """nn/mlp.py MLP(128 -> 512 -> 128, ReLU): parameters live under ``.lins``."""
+
+    def __init__(self, embed_dim: int, hidden: int):
+        super().__init__()
+        dims = [embed_dim] + ([hidden] if hidden > 0 else []) + [embed_dim]
+        self.lins = nn.ModuleList(nn.Linear(i, o) for i, o in zip(dims[:-1], dims[1:]))
+
+    def forward(self, x: Tensor) -> Tensor:
+        for lin in self.lins[:-1]:
+            x = F.relu(lin(x))
+        return self.lins[-1](x)
+
+
+class _EncoderLayer(nn.Sequential):
+    """nn/graph/attnnet.py:16-54. The FFN is created before the attention block, as in the
+    reference, so a seeded construction consumes the RNG in the same order."""
+
+    def __init__(self, embed_dim, num_heads, feedforward_hidden, normalization):
+        ffn = _FeedForward(embed_dim, feedforward_hidden)
+        attn = _SelfAttention(embed_dim, num_heads)
+        super().__init__(_Skip(attn), _Norm(embed_dim, normalization), _Skip(ffn), _Norm(embed_dim, normalization))
+
+
+class _GraphAttentionNetwork(nn.Module):
+    """nn/graph/attnnet.py:57-106"""
+
+    def __init__(self, num_heads, embed_dim, num_layers, normalization, feedforward_hidden):
+        super().__init__()
+        self.layers = nn.Sequential(
+            *(_EncoderLayer(embed_dim, num_heads, feedforward_hidden, normalization) for _ in range(num_layers))
+        )
+
+    def forward(self, x):
+        return self.layers(x)
+
+
+class _TSPInit(nn.Module):
+    """env_embeddings/init.py:55-68"""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.init_embed = nn.Linear(2, embed_dim, True)
+
+    def forward(self, td):
+        return self.init_embed(td["locs"])
+
+
+class _VRPInit(nn.Module):
+    """env_embeddings/init.py:115-136"""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.init_embed = nn.Linear(3, embed_dim, True)
+        self.init_embed_depot = nn.Linear(2, embed_dim, True)
+
+    def forward(self, td):
+        locs = td["locs"]
+        feats = torch.cat((locs[:, 1:, :], td["demand"][..., None]), -1)
+        return torch.cat((self.init_embed_depot(locs[:, :1, :]), self.init_embed(feats)), -2)
+
+
+class AttentionModelEncoder(nn.Module):
+    """zoo/am/encoder.py:12-87"""
+
+    def __init__(self, embed_dim=128, env_name="tsp", num_heads=8, num_layers=3, normalization="batch",
+                 feedforward_hidden=512):
+        super().__init__()
+        self.env_name = env_name
+        self.init_embedding = {"tsp": _TSPInit, "cvrp": _VRPInit}[env_name](embed_dim)
+        self.net = _GraphAttentionNetwork(num_heads, embed_dim, num_layers, normalization, feedforward_hidden)
+
+    def forward(self, td):
+        init_h = self.init_embedding(td)
+        return self.net(init_h), init_h
+
+
+class _TSPContext(nn.Module):
+    """env_embeddings/context.py:105-134 — parameters only; the arithmetic is in the kernel."""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.project_context = nn.Linear(2 * embed_dim, embed_dim, bias=False)
+        self.W_placeholder = nn.Parameter(torch.Tensor(2 * embed_dim).uniform_(-1, 1))
+
+
+class _VRPContext(nn.Module):
+    """env_embeddings/context.py:137-149"""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.project_context = nn.Linear(embed_dim + 1, embed_dim, bias=False)
+
+
+class _Pointer(nn.Module):
+    """nn/attention.py:218-320 PointerAttention: holds ``project_out``."""
+
+    def __init__(self, embed_dim, out_bias=False):
+        super().__init__()
+        self.project_out = nn.Linear(embed_dim, embed_dim, bias=out_bias)
+
+
+class AttentionModelDecoder(nn.Module):
+    """zoo/am/decoder.py:43-228 parameter holder + cache builder for the fused kernel."""
+
+    def __init__(self, embed_dim=128, num_heads=8, env_name="tsp", mask_inner=True,
+                 use_graph_context=True, check_nan=True):
+        super().__init__()
+        self.env_name = env_name
+        self.embed_dim = embed_dim
+        self.num_heads = num_heads
+        self.mask_inner = mask_inner
+        self.check_nan = check_nan
+        self.context_embedding = {"tsp": _TSPContext, "cvrp": _VRPContext}[env_name](embed_dim)
+        self.dynamic_embedding = nn.Module()  # StaticEmbedding (dynamic.py:47-57): no parameters
+        self.pointer = _Pointer(embed_dim)
+        self.project_node_embeddings = nn.Linear(embed_dim, 3 * embed_dim, bias=False)
+        self.project_fixed_context = nn.Linear(embed_dim, embed_dim, bias=False)
+        self.use_graph_context = use_graph_context
+
+    def precompute_cache(self, h: Tensor, cache_dtype: torch.dtype) -> FoldedCache:
+        """zoo/am/decoder.py:201-228, folded (rl4co_amd/cache.py)."""
+        return build_folded_cache(
+            self.env_name, h,
+            w_node=self.project_node_embeddings.weight,
+            w_out=self.pointer.project_out.weight,
+            w_ctx=self.context_embedding.project_context.weight,
+            w_fixed=self.project_fixed_context.weight if self.use_graph_context else None,
+            w_placeholder=getattr(self.context_embedding, "W_placeholder", None),
+            cache_dtype=cache_dtype,
+        )
+
+
+# ------------------------------------------------------------------------------------------------
+# decode-type parsing (utils/decoding.py:17-35, 191-330)
+# ------------------------------------------------------------------------------------------------
+
+_KNOWN_DECODE_TYPES = ("greedy", "sampling", "multistart_greedy", "multistart_sampling", "evaluate")
+
+
+def _parse_decode_type(decode_type: str):
+    if decode_type not in _KNOWN_DECODE_TYPES:
+        if decode_type == "beam_search":
+            raise NotImplementedError("beam_search is outside the accelerated hot path (SURVEY.md §2 row 2)")
+        decode_type = "sampling"  # decoding.py:27-35 falls back to Sampling
+    multistart = "multistart" in decode_type
+    mode = "greedy" if "greedy" in decode_type else ("evaluate" if decode_type == "evaluate" else "sampling")
+    return mode, multistart
+
+
+class AttentionModelPolicy(nn.Module):
+    """Attention Model policy (Kool et al. 2019) with the autoregressive loop on the MI355X.
+
+    Args follow ``zoo/am/policy.py:50-85``. Extra, engine-specific arguments:
+        cache_dtype: dtype of the three streamed cache planes (``torch.bfloat16`` halves the
+            bytes per decode step; ``torch.float32`` is the parity configuration).
+        encoder_autocast: optional autocast dtype for the encoder GEMMs.
+    """
+
+    def __init__(self, env_name: str = "tsp", embed_dim: int = 128, num_encoder_layers: int = 3,
+                 num_heads: int = 8, normalization: str = "batch", feedforward_hidden: int = 512,
+                 use_graph_context: bool = True, mask_inner: bool = True, check_nan: bool = True,
+                 temperature: float = 1.0, tanh_clipping: float = 10.0, mask_logits: bool = True,
+                 train_decode_type: str = "sampling", val_decode_type: str = "greedy",
+                 test_decode_type: str = "greedy", cache_dtype: torch.dtype = torch.float32,
+                 encoder_autocast: torch.dtype | None = None, **unused_kwargs):
+        super().__init__()
+        if isinstance(env_name, RL4COEnvBase):
+            env_name = env_name.name
+        if embed_dim != 128 or num_heads != 8:
+            raise ValueError("the fused decode kernel is specialised for embed_dim=128, num_heads=8")
+        self.env_name = env_name
+        self.encoder = AttentionModelEncoder(embed_dim, env_name, num_heads, num_encoder_layers,
+                                             normalization, feedforward_hidden)
+        self.decoder = AttentionModelDecoder(embed_dim, num_heads, env_name, mask_inner,
+                                             use_graph_context, check_nan)
+        self.temperature = temperature
+        self.tanh_clipping = tanh_clipping
+        self.mask_logits = mask_logits
+        self.train_decode_type = train_decode_type
+        self.val_decode_type = val_decode_type
+        self.test_decode_type = test_decode_type
+        self.cache_dtype = cache_dtype
+        self.encoder_autocast = encoder_autocast
+        self._philox_calls = 0
+
+    # -- helpers --------------------------------------------------------------------------------
+    def _encode(self, td):
+        if self.encoder_autocast is not None:
+            with torch.autocast("cuda", dtype=self.encoder_autocast):
+                h, init_h = self.encoder(td)
+            return h.float(), init_h.float()
+        return self.encoder(td)
+
+    @staticmethod
+    def _max_horizon(env_name: str, n: int) -> int:
+        # TSP: exactly N steps. CVRP: every customer + at most one depot visit per customer + 1.
+        return n if env_name == "tsp" else 2 * n
+
+    def _initial_state(self, td, num_starts: int):
+        """State tensors the kernel updates in place; with multistart the rows are expanded
+        s-major (batchify, ops.py:10-30) while instance-level data (cache, demand) stays [B,...]."""
+        s = max(num_starts, 1)
+
+        def rep(x: Tensor) -> Tensor:
+            x = x.reshape(x.shape[0], -1) if x.dim() > 1 else x
+            out = x.unsqueeze(0).expand(s, *x.shape).reshape(s * x.shape[0], *x.shape[1:]).contiguous()
+            return out
+
+        st = {
+            "action_mask": rep(td["action_mask"]),
+            "current_node": rep(td["current_node"].reshape(-1)),
+            "done": rep(td["done"].reshape(-1)),
+        }
+        if self.env_name == "tsp":
+            st["first_node"] = rep(td["first_node"].reshape(-1))
+            st["i"] = rep(td["i"].reshape(-1))
+        else:
+            st["demand"] = td["demand"].contiguous()
+            st["used_capacity"] = rep(td["used_capacity"].reshape(-1))
+            st["vehicle_capacity"] = rep(td["vehicle_capacity"].reshape(-1))
+            st["visited"] = rep(td["visited"])
+        if s == 1:
+            st = {k: (v.clone() if k != "demand" else v) for k, v in st.items()}
+        return st
+
+    # -- forward (constructive/base.py:154-263) ---------------------------------------------------
+    def forward(self, td: TensorDict, env: str | RL4COEnvBase | None = None, phase: str = "train",
+                calc_reward: bool = True, return_actions: bool = True, return_entropy: bool = False,
+                return_hidden: bool = False, return_init_embeds: bool = False,
+                return_sum_log_likelihood: bool = True, actions: Tensor | None = None,
+                max_steps: int = 1_000_000, **decoding_kwargs) -> dict:
+        hidden, init_embeds = self._encode(td)
+        if isinstance(env, str) or env is None:
+            env = get_env(self.env_name if env is None else env)
+
+        decode_type = decoding_kwargs.pop("decode_type", None)
+        if actions is not None:
+            decode_type = "evaluate"
+        elif decode_type is None:
+            decode_type = getattr(self, f"{phase}_decode_type")
+        mode, multistart = _parse_decode_type(decode_type)
+        temperature = decoding_kwargs.pop("temperature", self.temperature)
+        tanh_clipping = decoding_kwargs.pop("tanh_clipping", self.tanh_clipping)
+        mask_logits = decoding_kwargs.pop("mask_logits", self.mask_logits)
+        store_all_logp = decoding_kwargs.pop("store_all_logp", return_entropy)
+        select_best = decoding_kwargs.pop("select_best", False)
+        num_starts = decoding_kwargs.pop("num_starts", None)
+        num_samples = decoding_kwargs.pop("num_samples", None)
+        exp_noise = decoding_kwargs.pop("exp_noise", None)  # parity hook: injected Exp(1) draws
+        seed = decoding_kwargs.pop("seed", None)
+        multisample = bool(decoding_kwargs.pop("multisample", False))
+        if num_samples is not None:
+            multisample = num_samples > 1
+        if num_starts is not None:
+            multistart = num_starts > 1
+        assert not (multistart and multisample), "Using both multistart and multisample is not supported"
+        if multistart or multisample:
+            n_rep = num_starts if multistart else num_samples
+            if n_rep is None:
+                n_rep = env.get_num_starts(td)
+        else:
+            n_rep = 0
+
+        device = hidden.device
+        b_inst, n = td["action_mask"].shape[0], td["action_mask"].shape[-1]
+        b = b_inst * max(n_rep, 1)
+        with torch.no_grad():
+            cache = self.decoder.precompute_cache(hidden.detach(), self.cache_dtype)
+        state = self._initial_state(td, n_rep)
+        horizon = min(self._max_horizon(self.env_name, n), max_steps)
+        err = K.new_error_word(device)
+
+        t0 = 0
+        if mode == "evaluate":
+            forced = actions.contiguous()
+            tmax = forced.shape[1]
+            out_actions = torch.zeros_like(forced)
+        else:
+            forced = None
+            tmax = horizon
+            out_actions = torch.zeros((b, tmax), dtype=torch.int64, device=device)
+        logps = torch.zeros((b, tmax), dtype=torch.float32, device=device)
+        n_steps = torch.zeros((b,), dtype=torch.int32, device=device)
+        all_logps = torch.zeros((b, tmax, n), dtype=torch.float32, device=device) if store_all_logp else None
+
+        if multistart and n_rep >= 1 and mode != "evaluate":
+            # pre_decoder_hook (decoding.py:306-326): first action fixed per start, log-prob 0
+            first = env.select_start_nodes(td, num_starts=n_rep)
+            out_actions[:, 0] = first
+            self._env_step_state(state, first, err)
+            t0 = 1
+
+        if mode == "sampling" and exp_noise is None:
+            self._philox_calls += 1
+            philox_seed = int(seed) if seed is not None else int(torch.randint(0, 2**62, (1,)).item())
+        else:
+            philox_seed = 0
+        K.am_decode(
+            cache, state, mode=mode, max_steps=tmax - t0, t0=t0, actions=out_actions, logps=logps, err=err,
+            tanh_clipping=tanh_clipping, temperature=temperature, mask_inner=self.decoder.mask_inner,
+            mask_logits=mask_logits, exp_noise=exp_noise, philox_seed=philox_seed,
+            forced_actions=forced, all_logps=all_logps, n_steps=n_steps,
+        )
+        # ONE host sync for the whole rollout: horizon + sticky error bits
+        t_used = t0 + int(n_steps.max().item())
+        K.raise_if_error(err)
+        out_actions = out_actions[:, :t_used].contiguous()
+        logps = logps[:, :t_used]
+        if all_logps is not None:
+            all_logps = all_logps[:, :t_used]
+
+        # td mirrors the reference's final state (batchified rows when multistart)
+        td_out = self._final_td(td, state, n_rep)
+        td_out.set("action", out_actions[:, -1])
+
+        if n_rep > 0 and select_best:
+            rewards = env.get_reward(td_out, out_actions)
+            best = rewards.view(n_rep, b_inst).transpose(0, 1).max(dim=-1)[1]  # unbatchify + max
+            rows = best * b_inst + torch.arange(b_inst, device=device)
+            out_actions, logps = out_actions[rows], logps[rows]
+            if all_logps is not None:
+                all_logps = all_logps[rows]
+            td_out = td_out[rows] if hasattr(td_out, "__getitem__") else td_out
+            reward = rewards[rows] if calc_reward else None
+        else:
+            reward = env.get_reward(td_out, out_actions) if calc_reward else td_out.get("reward", None)
+        if calc_reward:
+            td_out.set("reward", reward)
+
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            step_logps = self.evaluate_log_probs(td, hidden, out_actions, n_rep, tanh_clipping, temperature,
+                                                 mask_logits, skip_first=(t0 == 1))
+        else:
+            step_logps = logps
+        if not bool((step_logps.detach() > -1000).all()):
+            raise AssertionError("Logprobs should not be -inf, check sampling procedure!")
+        outdict = {
+            "reward": reward,
+            "log_likelihood": step_logps.sum(1) if return_sum_log_likelihood else step_logps,
+        }
+        if return_actions:
+            outdict["actions"] = out_actions
+        if return_entropy:
+            lp = torch.nan_to_num(all_logps, nan=0.0)
+            entropy = -(lp.exp() * lp).sum(dim=-1).sum(dim=1)
+            assert entropy.isfinite().all(), "Entropy is not finite"
+            outdict["entropy"] = entropy
+        if return_hidden:
+            outdict["hidden"] = hidden
+        if return_init_embeds:
+            outdict["init_embeds"] = init_embeds
+        return outdict
+
+    # -- pieces -------------------------------------------------------------------------------------
+    def _env_step_state(self, state: dict, action: Tensor, err: Tensor) -> None:
+        if self.env_name == "tsp":
+            K.tsp_step(action, state["action_mask"], state["first_node"], state["current_node"],
+                       state["i"], state["done"], err)
+        else:
+            K.cvrp_step(action, state["demand"], state["used_capacity"], state["vehicle_capacity"],
+                        state["visited"], state["current_node"], state["action_mask"], state["done"], err)
+
+    def _final_td(self, td, state: dict, n_rep: int) -> TensorDict:
+        s = max(n_rep, 1)
+        b_inst = td["action_mask"].shape[0]
+
+        def rep(x: Tensor) -> Tensor:
+            if s == 1:
+                return x
+            return x.unsqueeze(0).expand(s, *x.shape).reshape(s * x.shape[0], *x.shape[1:])
+
+        out = {"locs": rep(td["locs"]), "action_mask": state["action_mask"], "done": state["done"]}
+        if self.env_name == "tsp":
+            out.update(first_node=state["first_node"], current_node=state["current_node"],
+                       i=state["i"].view(-1, 1))
+        else:
+            out.update(demand=rep(td["demand"]), current_node=state["current_node"].view(-1, 1),
+                       used_capacity=state["used_capacity"].view(-1, 1),
+                       vehicle_capacity=state["vehicle_capacity"].view(-1, 1), visited=state["visited"])
+        return TensorDict(out, batch_size=[s * b_inst])
+
+    # -- teacher-forced, differentiable re-evaluation (row N1 of SURVEY.md §8f) -------------------
+    def evaluate_log_probs(self, td, hidden: Tensor, actions: Tensor, n_rep: int, tanh_clipping: float,
+                           temperature: float, mask_logits: bool, skip_first: bool = False) -> Tensor:
+        """log p(a_t | s_t) for all t at once, with autograd through encoder and decoder weights.
+
+        With the actions known every step's query is known up front, so the T sequential
+        single-query attentions of the reference loop become ONE masked [T x N] attention per
+        instance (dense, MFMA-friendly). Masks/contexts are replayed with the env-step kernels."""
+        dec = self.decoder
+        s = max(n_rep, 1)
+        b_inst, n, d = hidden.shape
+        b, t_len = actions.shape
+        masks, ctx_nodes, extras = self._replay(td, actions, n_rep)
+        h = hidden if s == 1 else hidden.unsqueeze(0).expand(s, b_inst, n, d).reshape(b, n, d)
+        w_ctx = dec.context_embedding.project_context.weight
+        if self.env_name == "tsp":
+            first, prev = ctx_nodes  # [B,T] each (t = 0 is the placeholder)
+            idx = torch.stack([first, prev], -1).view(b, t_len * 2)
+            ctx = h.gather(1, idx[..., None].expand(b, t_len * 2, d)).view(b, t_len, 2 * d)
+            placeholder = dec.context_embedding.W_placeholder.expand(b, 1, 2 * d)
+            use_ph = extras  # [B,T] bool: step used the placeholder context
+            ctx = torch.where(use_ph[..., None], placeholder, ctx)
+        else:
+            (prev,) = ctx_nodes
+            cur = h.gather(1, prev[..., None].expand(b, t_len, d))
+            ctx = torch.cat([cur, extras[..., None]], -1)  # remaining capacity
+        q = F.linear(ctx, w_ctx)
+        if dec.use_graph_context:
+            g = dec.project_fixed_context(hidden.mean(1))
+            g = g if s == 1 else g.unsqueeze(0).expand(s, b_inst, d).reshape(b, d)
+            q = q + g[:, None, :]
+        kvl = dec.project_node_embeddings(hidden)
+        kvl = kvl if s == 1 else kvl.unsqueeze(0).expand(s, b_inst, n, 3 * d).reshape(b, n, 3 * d)
+        k_g, v_g, k_l = kvl.chunk(3, dim=-1)
+        nh = dec.num_heads
+        qh = q.view(b, t_len, nh, d // nh).transpose(1, 2)
+        kh = k_g.reshape(b, n, nh, d // nh).transpose(1, 2)
+        vh = v_g.reshape(b, n, nh, d // nh).transpose(1, 2)
+        attn_mask = masks[:, None, :, :] if dec.mask_inner else None
+        heads = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=attn_mask)
+        glimpse = dec.pointer.project_out(heads.transpose(1, 2).reshape(b, t_len, d))
+        logits = torch.bmm(glimpse, k_l.transpose(1, 2)) / math.sqrt(d)
+        if tanh_clipping > 0:
+            logits = torch.tanh(logits) * tanh_clipping
+        if mask_logits:
+            logits = logits.masked_fill(~masks, float("-inf"))
+        logp = F.log_softmax(logits / temperature, dim=-1)
+        step_logps = logp.gather(-1, actions[..., None]).squeeze(-1)
+        if skip_first:  # multistart: the first action is imposed, its log-prob is 0 (decoding.py:318-323)
+            step_logps = torch.cat([torch.zeros_like(step_logps[:, :1]), step_logps[:, 1:]], 1)
+        return step_logps
+
+    @torch.no_grad()
+    def _replay(self, td, actions: Tensor, n_rep: int):
+        """Replay the trajectory through the env-step kernels to recover, per step, the mask the
+        decoder saw and the context indices (cheap: T tiny launches, no host sync)."""
+        state = self._initial_state(td, n_rep)
+        b, t_len = actions.shape
+        n = state["action_mask"].shape[1]
+        device = actions.device
+        masks = torch.empty((b, t_len, n), dtype=torch.bool, device=device)
+        prev = torch.empty((b, t_len), dtype=torch.int64, device=device)
+        err = K.new_error_word(device)
+        if self.env_name == "tsp":
+            first = torch.empty((b, t_len), dtype=torch.int64, device=device)
+            use_ph = torch.empty((b, t_len), dtype=torch.bool, device=device)
+        else:
+            rem = torch.empty((b, t_len), dtype=torch.float32, device=device)
+        for t in range(t_len):
+            masks[:, t] = state["action_mask"]
+            prev[:, t] = state["current_node"]
+            if self.env_name == "tsp":
+                first[:, t] = state["first_node"]
+                use_ph[:, t] = state["i"] < 1
+            else:
+                rem[:, t] = state["vehicle_capacity"] - state["used_capacity"]
+            self._env_step_state(state, actions[:, t].contiguous(), err)
+        if self.env_name == "tsp":
+            return masks, (first, prev), use_ph
+        return masks, (prev,), rem

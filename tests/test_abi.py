@@ -1,0 +1,69 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads, and exports every
+symbol ``include/rl4co_amd.h`` declares (no compute is launched without a GPU)."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+HEADER = (ROOT / "include" / "rl4co_amd.h").read_text()
+
+
+def declared_functions():
+    names = re.findall(r"^\s*(?:const\s+char\s*\*|int)\s+(rl4co_\w+)\s*\(", HEADER, flags=re.M)
+    return sorted(set(names))
+
+
+def test_header_declares_expected_entry_points():
+    names = declared_functions()
+    for must in ["rl4co_am_decode", "rl4co_tour_length_f32", "rl4co_tsp_step", "rl4co_cvrp_step",
+                 "rl4co_tsp_check_solution", "rl4co_cvrp_check_solution", "rl4co_gather_by_index_f32"]:
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from rl4co_amd import _lib
+
+    handle = _lib.lib()
+    names = declared_functions()
+    assert sorted(_lib.SYMBOLS) == names, "ctypes table and header disagree"
+    for name in names:
+        assert getattr(handle, name) is not None
+    assert b"gfx950" in handle.rl4co_version()
+
+
+def test_struct_layout_matches_header():
+    """Field order of the ctypes mirror == field order in the C struct."""
+    from rl4co_amd import _lib
+
+    body = re.search(r"typedef struct rl4co_am_decode_args \{(.*?)\} rl4co_am_decode_args;", HEADER, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    c_fields = re.findall(r"(\w+)\s*;", body)
+    py_fields = [f[0] for f in _lib.AmDecodeArgs._fields_]
+    assert c_fields == py_fields
+    assert ctypes.sizeof(_lib.AmDecodeArgs) % 8 == 0
+
+
+def test_argument_validation_without_gpu():
+    """Bad arguments are rejected on the host before any launch (status + message, no exception)."""
+    from rl4co_amd import _lib
+
+    handle = _lib.lib()
+    args = _lib.AmDecodeArgs()
+    st = handle.rl4co_am_decode(ctypes.byref(args), None)
+    assert st == 1  # RL4CO_ERR_ARG
+    assert b"requirement failed" in handle.rl4co_last_error()
+    assert handle.rl4co_am_decode_lds_bytes(100, 0) == 128 * 8 * 4 + 128 * 4 + 256
+    with pytest.raises(_lib.Rl4coLibraryError):
+        _lib.check(st, "rl4co_am_decode")
+
+
+def test_error_bits_map_to_reference_messages():
+    from rl4co_amd import _lib
+
+    with pytest.raises(AssertionError, match="Logits contain NaNs"):
+        _lib.raise_for_error_bits(_lib.EBIT_NAN_LOGIT | _lib.EBIT_INFEASIBLE)
+    with pytest.raises(AssertionError, match="Used more than capacity"):
+        _lib.raise_for_error_bits(_lib.EBIT_CAPACITY)
+    _lib.raise_for_error_bits(0)

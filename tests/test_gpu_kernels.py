@@ -1,0 +1,181 @@
+"""GPU parity: reward / env-step / solution-check kernels vs the oracle (bit-exact).
+
+These are integer/byte/index kernels plus the tour-length reduction whose fp32 arithmetic is
+restated to be BITWISE equal to ATen's CPU result, so every comparison is exact equality.
+"""
+import pytest
+import torch
+
+from oracle import reference_torch as R
+from tests.helpers import clone_td, device_state, make_instances
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    from rl4co_amd import kernels
+
+    return kernels
+
+
+def _random_tours(b, n, gen):
+    return torch.stack([torch.randperm(n, generator=gen) for _ in range(b)])
+
+
+@pytest.mark.parametrize("n", [5, 8, 20, 21, 100, 101, 201, 500, 501, 1001, 2500])
+def test_tsp_reward_bit_exact(K, n):
+    gen = torch.Generator().manual_seed(n)
+    b = 64
+    locs = torch.rand(b, n, 2, generator=gen)
+    actions = _random_tours(b, n, gen)
+    env = R.TSPEnv(n)
+    want = env.get_reward({"locs": locs}, actions)
+    got = K.tour_length(locs.cuda(), actions.cuda(), prepend_depot=False, negate=True).cpu()
+    assert torch.equal(got, want), (got - want).abs().max()
+
+
+@pytest.mark.parametrize("n_loc,t_extra", [(20, 7), (100, 15), (500, 31), (1000, 40)])
+def test_cvrp_reward_bit_exact(K, n_loc, t_extra):
+    """CVRP tours: T = customers + depot returns; the depot is prepended (cvrp/env.py:138-147)."""
+    gen = torch.Generator().manual_seed(n_loc)
+    b = 32
+    n = n_loc + 1
+    locs = torch.rand(b, n, 2, generator=gen)
+    rows = []
+    for _ in range(b):
+        seq = (torch.randperm(n_loc, generator=gen) + 1).tolist()
+        for _ in range(t_extra):  # sprinkle depot returns
+            pos = int(torch.randint(0, len(seq) + 1, (1,), generator=gen))
+            seq.insert(pos, 0)
+        rows.append(torch.tensor(seq))
+    actions = torch.stack(rows)
+    env = R.CVRPEnv(n_loc, check_solution=False)
+    want = env.get_reward({"locs": locs}, actions)
+    got = K.tour_length(locs.cuda(), actions.cuda(), prepend_depot=True, negate=True).cpu()
+    assert torch.equal(got, want)
+
+
+def test_reward_multistart_layout(K):
+    """s-major batchify: trajectory r reads instance r % B (ops.py:10-28)."""
+    gen = torch.Generator().manual_seed(3)
+    b, s, n = 16, 5, 50
+    locs = torch.rand(b, n, 2, generator=gen)
+    actions = _random_tours(b * s, n, gen)
+    want = -R.get_tour_length(R.gather_by_index(R.batchify(locs, s), actions))
+    got = K.tour_length(locs.cuda(), actions.cuda(), negate=True).cpu()
+    assert torch.equal(got, want)
+
+
+def test_gather_by_index(K):
+    gen = torch.Generator().manual_seed(4)
+    src = torch.rand(9, 33, 128, generator=gen)
+    idx = torch.randint(0, 33, (9, 2), generator=gen)
+    want = R.gather_by_index(src, idx)
+    got = K.gather_by_index(src.cuda(), idx.cuda()).cpu()
+    assert torch.equal(got, want)
+
+
+def test_tsp_step_matches_oracle(K):
+    env, data = make_instances("tsp", 20, 37)
+    td = env.reset(clone_td(data))
+    st = device_state("tsp", td, "cuda")
+    gen = torch.Generator().manual_seed(5)
+    err = K.new_error_word("cuda")
+    for _ in range(20):
+        action = torch.multinomial(td["action_mask"].float(), 1, generator=gen).squeeze(-1)
+        td["action"] = action
+        td = env.step(td)
+        K.tsp_step(action.cuda(), st["action_mask"], st["first_node"], st["current_node"], st["i"], st["done"], err)
+        assert torch.equal(st["action_mask"].cpu(), td["action_mask"])
+        assert torch.equal(st["first_node"].cpu(), td["first_node"])
+        assert torch.equal(st["current_node"].cpu(), td["current_node"])
+        assert torch.equal(st["i"].cpu(), td["i"].reshape(-1))
+        assert torch.equal(st["done"].cpu(), td["done"].reshape(-1))
+    assert td["done"].all() and int(err.item()) == 0
+
+
+@pytest.mark.parametrize("n_loc", [20, 100])
+def test_cvrp_step_and_mask_match_oracle(K, n_loc):
+    env, data = make_instances("cvrp", n_loc, 29)
+    td = env.reset(clone_td(data))
+    st = device_state("cvrp", td, "cuda")
+    # a7: the reset mask is get_action_mask on the fresh state
+    st["action_mask"].zero_()
+    K.cvrp_step(None, st["demand"], st["used_capacity"], st["vehicle_capacity"], st["visited"],
+                st["current_node"], st["action_mask"], None)
+    assert torch.equal(st["action_mask"].cpu(), td["action_mask"])
+    gen = torch.Generator().manual_seed(6)
+    err = K.new_error_word("cuda")
+    steps = 0
+    while not td["done"].all():
+        action = torch.multinomial(td["action_mask"].float(), 1, generator=gen).squeeze(-1)
+        td["action"] = action
+        td = env.step(td)
+        K.cvrp_step(action.cuda(), st["demand"], st["used_capacity"], st["vehicle_capacity"], st["visited"],
+                    st["current_node"], st["action_mask"], st["done"], err)
+        assert torch.equal(st["action_mask"].cpu(), td["action_mask"])
+        assert torch.equal(st["used_capacity"].cpu(), td["used_capacity"].reshape(-1))
+        assert torch.equal(st["visited"].cpu(), td["visited"])
+        assert torch.equal(st["current_node"].cpu(), td["current_node"].reshape(-1))
+        assert torch.equal(st["done"].cpu(), td["done"].reshape(-1))
+        steps += 1
+        assert steps < 4 * n_loc
+    assert int(err.item()) == 0
+
+
+def test_check_solution_flags(K):
+    from rl4co_amd import _lib
+
+    gen = torch.Generator().manual_seed(7)
+    good = _random_tours(8, 30, gen).cuda()
+    err = K.new_error_word("cuda")
+    K.tsp_check_solution(good, 30, err)
+    assert int(err.item()) == 0
+    bad = good.clone()
+    bad[3, 5] = bad[3, 6]
+    K.tsp_check_solution(bad, 30, err)
+    assert int(err.item()) == _lib.EBIT_INVALID_TOUR
+    with pytest.raises(AssertionError, match="Invalid tour"):
+        K.raise_if_error(err)
+
+    # CVRP: a valid greedy-feasible tour, a duplicated customer, and a capacity violation
+    n_loc = 10
+    demand = torch.full((2, n_loc), 0.3)
+    cap = torch.ones(2)
+    ok = torch.tensor([[1, 2, 3, 0, 4, 5, 6, 0, 7, 8, 9, 0, 10, 0]] * 2)
+    env = R.CVRPEnv(n_loc)
+    env.check_solution_validity({"demand": demand, "vehicle_capacity": cap[:, None]}, ok)
+    err = K.new_error_word("cuda")
+    K.cvrp_check_solution(ok.cuda(), demand.cuda(), cap.cuda(), err)
+    assert int(err.item()) == 0
+    over = torch.tensor([[1, 2, 3, 4, 0, 5, 6, 0, 7, 8, 9, 0, 10, 0]] * 2)  # 4 x 0.3 > 1
+    K.cvrp_check_solution(over.cuda(), demand.cuda(), cap.cuda(), err)
+    assert int(err.item()) == _lib.EBIT_CAPACITY
+    err.zero_()
+    dup = ok.clone()
+    dup[1, 0] = 2
+    K.cvrp_check_solution(dup.cuda(), demand.cuda(), cap.cuda(), err)
+    assert int(err.item()) & _lib.EBIT_INVALID_TOUR
+
+
+def test_select_start_nodes(K):
+    class E:
+        name = "tsp"
+        num_loc = 20
+
+    td = {"action_mask": torch.ones(6, 20, dtype=torch.bool)}
+    want = R.select_start_nodes(td, E, 7)
+    got = K.select_start_nodes(6, 7, 20, False, "cuda").cpu()
+    assert torch.equal(got, want)
+    E.name = "cvrp"
+    want = R.select_start_nodes({"action_mask": torch.ones(6, 21, dtype=torch.bool)}, E, 20)
+    got = K.select_start_nodes(6, 20, 20, True, "cuda").cpu()
+    assert torch.equal(got, want)
+
+
+def test_cpu_tensor_fails_loudly(K):
+    from rl4co_amd._lib import Rl4coLibraryError
+
+    with pytest.raises(Rl4coLibraryError, match="no CPU fallback"):
+        K.tour_length(torch.rand(2, 5, 2), torch.zeros(2, 5, dtype=torch.int64))
