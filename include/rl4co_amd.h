@@ -199,6 +199,11 @@ int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream);
 /* Bytes of LDS one trajectory needs for N nodes (for occupancy planning / tests). */
 int rl4co_am_decode_lds_bytes(int N, int env);
 
+/* Number of row groups G the kernel splits a trajectory's cache rows into for the given
+ * cache dtype (row j -> group j % G). G fixes the fp32 summation tree of the glimpse
+ * (am_decode.hip header), so the specified-order oracle asks for it instead of guessing. */
+int rl4co_am_decode_row_groups(int cache_dtype);
+
 /* --------------------------------------------------------------------------
  * a19  select_start_nodes        rl4co/utils/ops.py:128-161
  * out[s*B + b] = s % num_loc (+1 for depot environments), s-major.

@@ -1,0 +1,157 @@
+"""ORACLE (test infrastructure): ctypes front end of ``oracle/rollout_ref.c``.
+
+Builds ``oracle/_build/librollout_ref.so`` with gcc on first use. Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s cpu_baseline leg may import this module.
+All tensors are CPU torch tensors; the argument block is the product's own
+``rl4co_am_decode_args`` (same struct, host pointers).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import hashlib
+import subprocess
+from functools import lru_cache
+from pathlib import Path
+
+import torch
+from torch import Tensor
+
+HERE = Path(__file__).resolve().parent
+ROOT = HERE.parent
+SRC = HERE / "rollout_ref.c"
+DEPS = [SRC, ROOT / "include" / "rl4co_amd.h", ROOT / "rl4co_amd" / "csrc" / "rl4co_math.h"]
+OUT = HERE / "_build" / "librollout_ref.so"
+STAMP = HERE / "_build" / "librollout_ref.so.hash"
+CFLAGS = ["-O2", "-std=c11", "-ffp-contract=off", "-mfma", "-fPIC", "-shared"]
+
+
+def _hash() -> str:
+    h = hashlib.sha256()
+    for p in DEPS:
+        h.update(p.read_bytes())
+    h.update(" ".join(CFLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False) -> Path:
+    if not force and OUT.exists() and STAMP.exists() and STAMP.read_text().strip() == _hash():
+        return OUT
+    OUT.parent.mkdir(parents=True, exist_ok=True)
+    cmd = ["gcc", *CFLAGS, "-o", str(OUT), str(SRC), "-lm"]
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f"gcc failed:\n{proc.stderr}")
+    STAMP.write_text(_hash() + "\n")
+    return OUT
+
+
+@lru_cache(maxsize=None)
+def lib() -> C.CDLL:
+    from rl4co_amd._lib import AmDecodeArgs  # the struct definition is shared with the product header
+
+    h = C.CDLL(str(build()))
+    vp, i = C.c_void_p, C.c_int
+    h.oracle_tour_length_f32.argtypes = [vp, vp, i, i, i, i, i, i, vp]
+    h.oracle_tsp_step.argtypes = [vp] * 6 + [i, i]
+    h.oracle_cvrp_step.argtypes = [vp] * 8 + [i, i, i]
+    h.oracle_am_decode.argtypes = [C.POINTER(AmDecodeArgs), i]
+    for name in ("oracle_expf", "oracle_logf", "oracle_tanhf"):
+        fn = getattr(h, name)
+        fn.argtypes = [C.c_float]
+        fn.restype = C.c_float
+    h.oracle_exp1_noise.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
+    h.oracle_exp1_noise.restype = C.c_float
+    return h
+
+
+def _cpu(t: Tensor, dtype=None) -> Tensor:
+    assert t.device.type == "cpu" and t.is_contiguous(), "oracle tensors must be contiguous CPU tensors"
+    if dtype is not None:
+        assert t.dtype == dtype, (t.dtype, dtype)
+    return t
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def tour_length(locs: Tensor, actions: Tensor, prepend_depot=False, negate=False) -> Tensor:
+    _cpu(locs, torch.float32), _cpu(actions, torch.int64)
+    b, t = actions.shape
+    b_locs, n, _ = locs.shape
+    out = torch.empty(b, dtype=torch.float32)
+    st = lib().oracle_tour_length_f32(_p(locs), _p(actions), b, b_locs, n, t, int(prepend_depot), int(negate), _p(out))
+    assert st == 0
+    return out
+
+
+def tsp_step(action, mask, first, cur, step_i, done) -> None:
+    b, n = mask.shape
+    st = lib().oracle_tsp_step(_p(_cpu(action, torch.int64)), _p(_u8(mask)), _p(first), _p(cur), _p(step_i),
+                               _p(_u8(done)), b, n)
+    assert st == 0
+
+
+def cvrp_step(action, demand, used, cap, visited, cur, mask, done) -> None:
+    b, n = mask.shape
+    st = lib().oracle_cvrp_step(_p(action), _p(_cpu(demand, torch.float32)), _p(used), _p(cap), _p(_u8(visited)),
+                                _p(cur), _p(_u8(mask)), _p(None if done is None else _u8(done)), b, demand.shape[0], n)
+    assert st == 0
+
+
+def _u8(t: Tensor) -> Tensor:
+    _cpu(t)
+    return t.view(torch.uint8) if t.dtype == torch.bool else t
+
+
+def am_decode(cache, state: dict, *, mode: str, max_steps: int, actions: Tensor, logps: Tensor, err: Tensor,
+              row_groups: int, t0: int = 0, tanh_clipping: float = 10.0, temperature: float = 1.0,
+              mask_inner: bool = True, mask_logits: bool = True, exp_noise: Tensor | None = None,
+              philox_seed: int = 0, philox_offset: int = 0, forced_actions: Tensor | None = None,
+              all_logps: Tensor | None = None, entropy: Tensor | None = None, n_steps: Tensor | None = None) -> None:
+    """Mirror of ``rl4co_amd.kernels.am_decode`` for CPU tensors, run by the C oracle.
+
+    ``cache`` is a ``rl4co_amd.cache.FoldedCache`` whose tensors live on the CPU (bf16 planes are
+    read as raw uint16)."""
+    from rl4co_amd import _lib
+
+    a = _lib.AmDecodeArgs()
+    mask = _u8(state["action_mask"])
+    b, n = mask.shape
+    a.env = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP}[cache.env_name]
+    a.B, a.B_inst, a.N = b, cache.num_instances, n
+    a.mode = {"greedy": 0, "sampling": 1, "evaluate": 2}[mode]
+    a.max_steps = int(max_steps)
+    a.mask_inner, a.mask_logits = int(mask_inner), int(mask_logits)
+    a.tanh_clipping, a.temperature = float(tanh_clipping), float(temperature)
+    kvl = _cpu(cache.kvl)
+    a.cache_dtype = _lib.DT_BF16 if kvl.dtype == torch.bfloat16 else _lib.DT_F32
+    a.glimpse_key, a.glimpse_val, a.logit_key = (cache.plane(i).data_ptr() for i in range(3))
+    a.kvl_row_stride, a.kvl_batch_stride = cache.row_stride, cache.batch_stride
+    a.ctx_cur = _p(_cpu(cache.ctx_cur, torch.float32))
+    a.q_bias = _p(None if cache.q_bias is None else _cpu(cache.q_bias, torch.float32))
+    a.action_mask = _p(mask)
+    a.current_node = _p(_cpu(state["current_node"], torch.int64))
+    a.done = _p(_u8(state["done"]))
+    if cache.env_name == "tsp":
+        a.ctx_first = _p(_cpu(cache.ctx_first, torch.float32))
+        a.q_step0 = _p(_cpu(cache.q_step0, torch.float32))
+        a.first_node = _p(_cpu(state["first_node"], torch.int64))
+        a.step_i = _p(_cpu(state["i"], torch.int64))
+    else:
+        a.w_cap = _p(_cpu(cache.w_cap, torch.float32))
+        a.demand = _p(_cpu(state["demand"], torch.float32))
+        a.used_capacity = _p(_cpu(state["used_capacity"], torch.float32))
+        a.vehicle_capacity = _p(_cpu(state["vehicle_capacity"], torch.float32))
+        a.visited = _p(_u8(state["visited"]))
+    a.exp_noise = _p(None if exp_noise is None else _cpu(exp_noise, torch.float32))
+    a.philox_seed, a.philox_offset = int(philox_seed), int(philox_offset)
+    a.forced_actions = _p(None if forced_actions is None else _cpu(forced_actions, torch.int64))
+    a.t0, a.out_stride = int(t0), actions.shape[1]
+    a.actions, a.logps = _p(_cpu(actions, torch.int64)), _p(_cpu(logps, torch.float32))
+    a.all_logps = _p(None if all_logps is None else _cpu(all_logps, torch.float32))
+    a.entropy = _p(None if entropy is None else _cpu(entropy, torch.float32))
+    a.n_steps = _p(None if n_steps is None else _cpu(n_steps, torch.int32))
+    a.err = _p(_cpu(err, torch.int32))
+    st = lib().oracle_am_decode(C.byref(a), int(row_groups))
+    assert st == 0, "oracle_am_decode rejected its arguments"

@@ -1,0 +1,406 @@
+/*
+ * rollout_ref.c — ORACLE (test infrastructure, NOT product): plain-C CPU restatement of the
+ * hot path with a SPECIFIED fp32 operation order.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may build, load or call
+ * this file. Nothing under rl4co_amd/ links or loads it.
+ *
+ * Two jobs:
+ *  1. get_tour_length / get_reward (rl4co/utils/ops.py:77-90, envs/routing/tsp/env.py:150-156,
+ *     envs/routing/cvrp/env.py:138-147) restated to be BIT-IDENTICAL to the reference's ATen CPU
+ *     arithmetic: per segment sqrt(fma(dy,dy,fl(dx*dx))) (ATen vector_norm on a size-2 dim), row
+ *     sum in the 8-lane x 4-ILP cascade order of ATen's vectorized_inner_sum/multi_row_sum
+ *     (SURVEY.md §8a-a2). tests/test_oracle_cpu.py pins this against torch itself.
+ *  2. the AttentionModel decode loop (models/common/constructive/base.py:226-238 and callees —
+ *     env_embeddings/context.py:105-149, zoo/am/decoder.py:128-193, nn/attention.py:274-320,
+ *     utils/decoding.py:138-188,344-461, tsp/env.py:60-86, cvrp/env.py:66-96,126-136) in the
+ *     specified operation order documented at the top of rl4co_amd/csrc/am_decode.hip. No fixed
+ *     order can be bitwise equal to ATen's opaque SDPA/GEMM kernels, so the
+ *     chain of evidence is: reference source == torch restatement (bit-exact, oracle/gen_golden.py)
+ *     ~= this file (same actions except fp32 near-ties, log-likelihood <= 1e-5; tests/
+ *     test_oracle_cpu.py) == HIP kernel (bit-exact, tests/test_gpu_*.py).
+ *
+ * The deterministic exp/log/tanh/Philox come from the product header rl4co_math.h (header-only,
+ * plain C): oracle and kernel must round identically, so they share the definition.
+ * Build: gcc -O2 -ffp-contract=off -mfma -shared -fPIC (oracle/Makefile).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/rl4co_amd.h"
+#include "../rl4co_amd/csrc/rl4co_math.h"
+
+#define D RL4CO_EMBED_DIM
+#define H RL4CO_NUM_HEADS
+#define DH (D / H)
+
+/* ------------------------------------------------------------------------------------------ */
+/* tour length                                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+typedef struct {
+  const float* locs;      /* [N,2] */
+  const int64_t* actions; /* [T] */
+  int prepend, n;
+} tour_view;
+
+static inline void tv_point(const tour_view* tv, int t, float* x, float* y) {
+  int node;
+  if (tv->prepend) node = (t == 0) ? 0 : (int)tv->actions[t - 1];
+  else node = (int)tv->actions[t];
+  *x = tv->locs[2 * node];
+  *y = tv->locs[2 * node + 1];
+}
+
+static inline float tv_seg(const tour_view* tv, int t) {
+  float x0, y0, x1, y1;
+  tv_point(tv, t, &x0, &y0);
+  tv_point(tv, t + 1 == tv->n ? 0 : t + 1, &x1, &y1); /* torch.roll(-1) */
+  const float dx = x1 - x0, dy = y1 - y0;
+  return sqrtf(fmaf(dy, dy, dx * dx));
+}
+
+/* ATen multi_row_sum<float, 4> for ONE of the 8 vector lanes (element 8*v + lane of the row). */
+static float lane_row_sum(const tour_view* tv, int lane8, int nvec) {
+  enum { ILP = 4, LEVELS = 4 };
+  const int size = nvec / ILP;
+  int ceil_log2 = 0;
+  while ((1LL << ceil_log2) < size) ++ceil_log2;
+  int level_power = ceil_log2 / LEVELS;
+  if (level_power < 4) level_power = 4;
+  const int level_step = 1 << level_power;
+  const int level_mask = level_step - 1;
+  float acc[LEVELS][ILP];
+  memset(acc, 0, sizeof(acc));
+  int i = 0;
+  for (; i + level_step <= size;) {
+    for (int j = 0; j < level_step; ++j, ++i)
+      for (int k = 0; k < ILP; ++k) acc[0][k] = acc[0][k] + tv_seg(tv, 8 * (i * ILP + k) + lane8);
+    for (int j = 1; j < LEVELS; ++j) {
+      for (int k = 0; k < ILP; ++k) {
+        acc[j][k] = acc[j][k] + acc[j - 1][k];
+        acc[j - 1][k] = 0.0f;
+      }
+      const int mask = level_mask << (j * level_power);
+      if ((i & mask) != 0) break;
+    }
+  }
+  for (; i < size; ++i)
+    for (int k = 0; k < ILP; ++k) acc[0][k] = acc[0][k] + tv_seg(tv, 8 * (i * ILP + k) + lane8);
+  for (int j = 1; j < LEVELS; ++j)
+    for (int k = 0; k < ILP; ++k) acc[0][k] = acc[0][k] + acc[j][k];
+  for (int v = size * ILP; v < nvec; ++v) acc[0][0] = acc[0][0] + tv_seg(tv, 8 * v + lane8);
+  for (int k = 1; k < ILP; ++k) acc[0][0] = acc[0][0] + acc[0][k];
+  return acc[0][0];
+}
+
+int oracle_tour_length_f32(const float* locs, const int64_t* actions, int B, int B_locs, int N, int T,
+                           int prepend_depot, int negate, float* out) {
+  for (int b = 0; b < B; ++b) {
+    tour_view tv = {locs + (int64_t)(b % B_locs) * N * 2, actions + (int64_t)b * T, prepend_depot ? 1 : 0,
+                    T + (prepend_depot ? 1 : 0)};
+    const int n = tv.n, nvec = n / 8;
+    float fin = 0.0f;
+    if (n < 8) {
+      /* ATen takes scalar_inner_sum below one vector: row_sum<float> with 4 ILP partials,
+       * leftovers into partial 0, then partials folded in order */
+      float p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      const int g = n / 4;
+      for (int i = 0; i < g; ++i)
+        for (int k = 0; k < 4; ++k) p[k] = p[k] + tv_seg(&tv, 4 * i + k);
+      for (int k = 4 * g; k < n; ++k) p[0] = p[0] + tv_seg(&tv, k);
+      for (int k = 1; k < 4; ++k) p[0] = p[0] + p[k];
+      out[b] = negate ? -p[0] : p[0];
+      continue;
+    }
+    for (int k = nvec * 8; k < n; ++k) fin = fin + tv_seg(&tv, k); /* scalar tail first */
+    for (int l = 0; l < 8; ++l) fin = fin + lane_row_sum(&tv, l, nvec);
+    out[b] = negate ? -fin : fin;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* environment transitions (bit/byte work + one fp32 add, mul, compare)                         */
+/* ------------------------------------------------------------------------------------------ */
+
+int oracle_tsp_step(const int64_t* action, uint8_t* mask, int64_t* first, int64_t* cur, int64_t* step_i,
+                    uint8_t* done, int B, int N) {
+  for (int b = 0; b < B; ++b) {
+    const int64_t a = action[b];
+    if (a < 0 || a >= N) return 1;
+    if (step_i[b] == 0) first[b] = a; /* tsp/env.py:63 */
+    cur[b] = a;
+    mask[(int64_t)b * N + a] = 0;
+    step_i[b] += 1;
+    int any = 0;
+    for (int j = 0; j < N; ++j) any |= mask[(int64_t)b * N + j];
+    done[b] = any ? 0 : 1;
+  }
+  return 0;
+}
+
+static void cvrp_mask_row(const float* dem, float used, float cap, const uint8_t* vis, int64_t cur, uint8_t* mk,
+                          int N) {
+  const float thr = cap + 1e-5f; /* cvrp/env.py:128 */
+  int any_feasible = 0;
+  for (int j = 1; j < N; ++j) {
+    const int masked = (vis[j] != 0) || (dem[j - 1] + used > thr);
+    mk[j] = masked ? 0 : 1;
+    any_feasible |= !masked;
+  }
+  mk[0] = ((cur == 0) && any_feasible) ? 0 : 1; /* cvrp/env.py:134-135 */
+}
+
+int oracle_cvrp_step(const int64_t* action, const float* demand, float* used, const float* cap, uint8_t* visited,
+                     int64_t* cur, uint8_t* mask, uint8_t* done, int B, int B_inst, int N) {
+  for (int b = 0; b < B; ++b) {
+    const float* dem = demand + (int64_t)(b % B_inst) * (N - 1);
+    uint8_t* vis = visited + (int64_t)b * N;
+    if (action) {
+      const int64_t a = action[b];
+      if (a < 0 || a >= N) return 1;
+      int64_t di = a - 1;
+      if (di < 0) di = 0;
+      if (di > N - 2) di = N - 2;
+      used[b] = (used[b] + dem[di]) * (a != 0 ? 1.0f : 0.0f); /* cvrp/env.py:76 */
+      cur[b] = a;
+      vis[a] = 1;
+      int all = 1;
+      for (int j = 0; j < N; ++j) all &= vis[j] != 0;
+      done[b] = all ? 1 : 0;
+    }
+    cvrp_mask_row(dem, used[b], cap[b], vis, cur[b], mask + (int64_t)b * N, N);
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* AttentionModel decode loop in the specified operation order                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+/* pairwise butterfly sum == the value every lane holds after xor-shuffle adds over n lanes */
+static float tree_sum(const float* x, int n) {
+  if (n == 1) return x[0];
+  return tree_sum(x, n / 2) + tree_sum(x + n / 2, n / 2);
+}
+
+static inline float cache_at(const void* base, int dtype, int64_t idx) {
+  if (dtype == RL4CO_DT_BF16) return rl4co_bits_to_float((uint32_t)((const uint16_t*)base)[idx] << 16);
+  return ((const float*)base)[idx];
+}
+
+/* Same argument block as rl4co_am_decode, with HOST pointers. `row_groups` = the G reported by
+ * rl4co_am_decode_row_groups(cache_dtype). Returns 0, or 1 on a bad argument. */
+int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
+  const int N = a->N, G = row_groups;
+  const int EPL = a->cache_dtype == RL4CO_DT_BF16 ? 8 : 4;
+  const int LPR = D / EPL, LPH = DH / EPL;
+  if (G < 1 || G > 64 || (G & (G - 1))) return 1;
+  float* sc = (float*)malloc(sizeof(float) * (size_t)N * H);
+  float* lg = (float*)malloc(sizeof(float) * (size_t)N);
+  uint8_t* mk = (uint8_t*)malloc((size_t)N);
+  uint8_t* vis = (uint8_t*)malloc((size_t)N);
+  float* og = (float*)malloc(sizeof(float) * (size_t)G * D);
+  float* lgp = (float*)malloc(sizeof(float) * (size_t)G * H);
+  const float sqrt_d = 11.3137084989847604f;
+  const float neg_inf = -INFINITY;
+  const int single = a->max_steps == 1;
+  uint32_t errbits_all = 0;
+
+  for (int r = 0; r < a->B; ++r) {
+    const int cb = r % a->B_inst;
+    const int64_t cbase = (int64_t)cb * a->kvl_batch_stride;
+    const float* ctxc = a->ctx_cur + (int64_t)cb * N * D;
+    const float* ctxf = a->env == RL4CO_ENV_TSP ? a->ctx_first + (int64_t)cb * N * D : NULL;
+    uint8_t* gmask = a->action_mask + (int64_t)r * N;
+    memcpy(mk, gmask, (size_t)N);
+    if (a->env == RL4CO_ENV_CVRP) memcpy(vis, a->visited + (int64_t)r * N, (size_t)N);
+    int cur = (int)a->current_node[r];
+    int first = a->env == RL4CO_ENV_TSP ? (int)a->first_node[r] : 0;
+    long long step_i = a->env == RL4CO_ENV_TSP ? a->step_i[r] : 0;
+    float used = a->env == RL4CO_ENV_CVRP ? a->used_capacity[r] : 0.0f;
+    const float cap = a->env == RL4CO_ENV_CVRP ? a->vehicle_capacity[r] : 0.0f;
+    const float* dem = a->env == RL4CO_ENV_CVRP ? a->demand + (int64_t)cb * (N - 1) : NULL;
+    int done = a->done[r] != 0;
+    uint32_t errbits = 0;
+    float ent_acc = 0.0f;
+    int t = 0;
+
+    for (; t < a->max_steps && (!done || single); ++t) {
+      /* query */
+      float q[D];
+      for (int d = 0; d < D; ++d) {
+        const float qb = a->q_bias ? a->q_bias[(int64_t)cb * D + d] : 0.0f;
+        float v;
+        if (a->env == RL4CO_ENV_TSP) {
+          if (step_i < 1) v = a->q_step0[d] + qb;
+          else v = (ctxf[(int64_t)first * D + d] + ctxc[(int64_t)cur * D + d]) + qb;
+        } else {
+          const float rem = cap - used;
+          v = fmaf(a->w_cap[d], rem, ctxc[(int64_t)cur * D + d]) + qb;
+        }
+        q[d] = v * 0.25f;
+      }
+      /* pass 1: scores */
+      float m[H];
+      for (int h = 0; h < H; ++h) m[h] = neg_inf;
+      for (int j = 0; j < N; ++j) {
+        const int feas = !a->mask_inner || mk[j] != 0;
+        for (int h = 0; h < H; ++h) {
+          float part[4];
+          for (int c = 0; c < LPH; ++c) {
+            float acc = 0.0f;
+            for (int e = 0; e < EPL; ++e) {
+              const int d = h * DH + c * EPL + e;
+              acc = fmaf(q[d], cache_at(a->glimpse_key, a->cache_dtype, cbase + (int64_t)j * a->kvl_row_stride + d),
+                         acc);
+            }
+            part[c] = acc;
+          }
+          const float s = feas ? tree_sum(part, LPH) : neg_inf;
+          sc[j * H + h] = s;
+          m[h] = fmaxf(m[h], s);
+        }
+      }
+      /* pass 2: softmax-weighted values, per row group then tree */
+      for (int i = 0; i < G * D; ++i) og[i] = 0.0f;
+      for (int i = 0; i < G * H; ++i) lgp[i] = 0.0f;
+      for (int j = 0; j < N; ++j) {
+        const int g = j % G;
+        for (int h = 0; h < H; ++h) {
+          const float p = rl4co_expf(sc[j * H + h] - m[h]);
+          lgp[g * H + h] = lgp[g * H + h] + p;
+          for (int e = 0; e < DH; ++e) {
+            const int d = h * DH + e;
+            og[g * D + d] =
+                fmaf(p, cache_at(a->glimpse_val, a->cache_dtype, cbase + (int64_t)j * a->kvl_row_stride + d),
+                     og[g * D + d]);
+          }
+        }
+      }
+      float o[D];
+      for (int h = 0; h < H; ++h) {
+        float tmp[64];
+        for (int g = 0; g < G; ++g) tmp[g] = lgp[g * H + h];
+        const float l = tree_sum(tmp, G);
+        for (int e = 0; e < DH; ++e) {
+          const int d = h * DH + e;
+          for (int g = 0; g < G; ++g) tmp[g] = og[g * D + d];
+          o[d] = tree_sum(tmp, G) / l;
+        }
+      }
+      /* pass 3: logits */
+      int nan_seen = 0;
+      float zmax = neg_inf;
+      for (int j = 0; j < N; ++j) {
+        float part[32];
+        for (int c = 0; c < LPR; ++c) {
+          float acc = 0.0f;
+          for (int e = 0; e < EPL; ++e) {
+            const int d = c * EPL + e;
+            acc = fmaf(o[d], cache_at(a->logit_key, a->cache_dtype, cbase + (int64_t)j * a->kvl_row_stride + d), acc);
+          }
+          part[c] = acc;
+        }
+        float z = tree_sum(part, LPR) / sqrt_d;
+        if (z != z) nan_seen = 1;
+        if (a->tanh_clipping > 0.0f) z = rl4co_tanhf(z) * a->tanh_clipping;
+        if (a->mask_logits && mk[j] == 0) z = neg_inf;
+        z = z / a->temperature;
+        lg[j] = z;
+        zmax = fmaxf(zmax, z);
+      }
+      if (nan_seen) errbits |= RL4CO_EBIT_NAN_LOGIT;
+      /* log_softmax: 64 lane-strided partial sums, then tree */
+      float part64[64];
+      for (int k = 0; k < 64; ++k) {
+        float s = 0.0f;
+        for (int j = k; j < N; j += 64) s = s + rl4co_expf(lg[j] - zmax);
+        part64[k] = s;
+      }
+      const float lse = rl4co_logf(tree_sum(part64, 64));
+      /* selection */
+      const int64_t tcol = (int64_t)a->t0 + t;
+      float best = neg_inf;
+      int bi = -1;
+      for (int k = 0; k < 64; ++k) part64[k] = 0.0f;
+      for (int j = 0; j < N; ++j) {
+        const float lp = (lg[j] - zmax) - lse;
+        lg[j] = lp;
+        float key = lp;
+        if (a->mode == RL4CO_DECODE_SAMPLE) {
+          const float nz = a->exp_noise ? a->exp_noise[((int64_t)t * a->B + r) * N + j]
+                                        : rl4co_exp1_noise(a->philox_seed, a->philox_offset + (uint64_t)tcol,
+                                                           (uint32_t)r, (uint32_t)j);
+          key = rl4co_expf(lp) / nz;
+        }
+        if (bi < 0 || key > best) { /* ascending j + strict '>' == lowest index among maxima */
+          best = key;
+          bi = j;
+        }
+        if (a->entropy && lp > neg_inf) part64[j % 64] = fmaf(rl4co_expf(lp), lp, part64[j % 64]);
+        if (a->all_logps) a->all_logps[((int64_t)r * a->out_stride + tcol) * N + j] = lp;
+      }
+      if (a->entropy) ent_acc = ent_acc - tree_sum(part64, 64);
+      if (a->mode == RL4CO_DECODE_EVALUATE) bi = (int)a->forced_actions[(int64_t)r * a->out_stride + tcol];
+      if (bi < 0 || bi >= N) {
+        errbits |= RL4CO_EBIT_INFEASIBLE;
+        bi = 0;
+      }
+      const float logp = lg[bi];
+      if (mk[bi] == 0) errbits |= RL4CO_EBIT_INFEASIBLE;
+      if (!(logp > -1000.0f)) errbits |= RL4CO_EBIT_NEG_INF_LOGP;
+      a->actions[(int64_t)r * a->out_stride + tcol] = bi;
+      a->logps[(int64_t)r * a->out_stride + tcol] = logp;
+      /* environment transition */
+      if (a->env == RL4CO_ENV_TSP) {
+        if (step_i == 0) first = bi;
+        cur = bi;
+        mk[bi] = 0;
+        step_i += 1;
+        int any = 0;
+        for (int j = 0; j < N; ++j) any |= mk[j];
+        done = !any;
+      } else {
+        int di = bi - 1;
+        if (di < 0) di = 0;
+        if (di > N - 2) di = N - 2;
+        used = (used + dem[di]) * (bi != 0 ? 1.0f : 0.0f);
+        cur = bi;
+        vis[bi] = 1;
+        int all = 1;
+        for (int j = 0; j < N; ++j) all &= vis[j] != 0;
+        done = all;
+        cvrp_mask_row(dem, used, cap, vis, cur, mk, N);
+      }
+    }
+    if (!single && !done && t >= a->max_steps) errbits |= RL4CO_EBIT_MAX_STEPS;
+    memcpy(gmask, mk, (size_t)N);
+    if (a->env == RL4CO_ENV_CVRP) memcpy(a->visited + (int64_t)r * N, vis, (size_t)N);
+    a->current_node[r] = cur;
+    a->done[r] = done ? 1 : 0;
+    if (a->env == RL4CO_ENV_TSP) {
+      a->first_node[r] = first;
+      a->step_i[r] = step_i;
+    } else {
+      a->used_capacity[r] = used;
+    }
+    if (a->n_steps) a->n_steps[r] = t;
+    if (a->entropy) a->entropy[r] += ent_acc;
+    errbits_all |= errbits;
+  }
+  if (a->err) *a->err |= (int32_t)errbits_all;
+  free(sc); free(lg); free(mk); free(vis); free(og); free(lgp);
+  return 0;
+}
+
+/* deterministic math exposed for tests/test_math.py */
+float oracle_expf(float x) { return rl4co_expf(x); }
+float oracle_logf(float x) { return rl4co_logf(x); }
+float oracle_tanhf(float x) { return rl4co_tanhf(x); }
+float oracle_exp1_noise(uint64_t seed, uint64_t step, uint32_t traj, uint32_t node) {
+  return rl4co_exp1_noise(seed, step, traj, node);
+}

@@ -3,11 +3,12 @@
 // One wavefront (= one 64-thread workgroup) owns one trajectory for the whole
 // autoregressive loop. Per step it streams the trajectory's three folded cache
 // planes (glimpse key, glimpse value, logit key; [N,128] each) from HBM with
-// 16-byte coalesced loads, keeps the feasibility mask / per-head scores / logits
-// in LDS, reduces with wave butterflies, selects the action (greedy, sampled or
-// forced), updates the TSP / CVRP state in registers+LDS and goes on to the next
-// step — no host round trip, no inter-workgroup traffic (instances are
-// independent), no weights (they were folded into the cache once per rollout).
+// 16-byte coalesced loads (kUnroll wave-wide loads in flight per pass), keeps the
+// feasibility mask / per-head scores / logits in LDS, reduces with wave
+// butterflies, selects the action (greedy, sampled or forced), updates the TSP /
+// CVRP state in registers+LDS and goes on to the next step — no host round trip,
+// no inter-workgroup traffic (instances are independent), no weights (they were
+// folded into the cache once per rollout, rl4co_amd/cache.py).
 //
 // Reference semantics restated (file:line in the reference checkout):
 //   context / query      env_embeddings/context.py:105-149, zoo/am/decoder.py:128-140
@@ -17,19 +18,23 @@
 //   env transition       envs/routing/tsp/env.py:60-86, envs/routing/cvrp/env.py:66-96,126-136
 //   loop                 models/common/constructive/base.py:226-238
 //
-// Arithmetic order (mirrored lane-for-lane by oracle/am_decode_ref.c):
+// Arithmetic order — the parity contract, mirrored value-for-value by
+// oracle/rollout_ref.c (every op is an IEEE fp32 add/mul/fma/div, -ffp-contract=off):
 //   EPL = elements per lane per 16-byte load (4 fp32 / 8 bf16); a cache row is
-//   covered by LPR = 128/EPL lanes, a wave load covers RPL = 64/LPR rows, a head
-//   by LPH = 16/EPL lanes.
-//   score(j,h)  = fma-chain over the lane's EPL dims (ascending), then butterfly
-//                 add over xor 1..LPH/2 ; q is pre-scaled by 1/4 (exact)
-//   softmax     = m: max ; p = exp(s-m) ; l, o[d] accumulate per lane over its
-//                 rows in ascending j, then butterfly add over xor LPR..32 ;
-//                 heads[d] = o[d] / l
-//   logit(j)    = fma-chain over EPL dims, butterfly add xor 1..LPR/2, / sqrt(128)
-//   log_softmax = lane-strided (j = lane + 64k) max / sum of exp, butterfly xor
-//                 1..32 ; lp = (z - zmax) - log(sum)
-//   argmax      = lane-strided strict '>' scan, butterfly with (value, lowest index)
+//   covered by LPR = 128/EPL lanes, a wave-wide load covers G = 64/LPR rows ("row
+//   groups": row j belongs to group j % G), a head by LPH = 16/EPL lanes.
+//   tree(x_0..x_{n-1}) = pairwise butterfly sum: tree(lo half) + tree(hi half).
+//   q[d]        = ((ctx_first[first][d] + ctx_cur[cur][d]) + q_bias[d]) * 0.25   (TSP, i > 0)
+//   score(j,h)  = tree over the head's LPH chunks of [fma chain over the chunk's EPL dims,
+//                 ascending, from 0]
+//   softmax     = m = max_j score ; p_j = exp(score_j - m) ; per row group g:
+//                 l_g = sum_j p_j, o_g[d] = fma(p_j, v_j[d], o_g[d]) over its rows in
+//                 ascending j ; l = tree_g(l_g), o[d] = tree_g(o_g[d]) ; heads[d] = o[d] / l
+//   logit(j)    = tree over the row's LPR chunks of [fma chain over EPL dims] ; / fl(sqrt(128))
+//   log_softmax = zmax = max ; s_k = sum over j = k, k+64, ... of exp(z_j - zmax) (k < 64) ;
+//                 lse = log(tree_k(s_k)) ; lp_j = (z_j - zmax) - lse
+//   argmax      = maximum key, lowest index on ties (greedy: key = lp ; sampling:
+//                 key = exp(lp) / noise)
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -40,22 +45,27 @@ namespace {
 constexpr int kD = RL4CO_EMBED_DIM;
 constexpr int kH = RL4CO_NUM_HEADS;
 constexpr int kDH = kD / kH;
+constexpr int kUnroll = 4;  // wave-wide 1 KiB loads kept in flight per pass
 constexpr float kNegInf = -__builtin_huge_valf();
 
 struct CacheF32 {
   using elem = float;
+  using raw = float4;
   static constexpr int EPL = 4;
-  __device__ static inline void load(const elem* p, float (&v)[4]) {
-    const float4 t = *reinterpret_cast<const float4*>(p);
+  __device__ static inline raw zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+  __device__ static inline raw ld(const elem* p) { return *reinterpret_cast<const float4*>(p); }
+  __device__ static inline void cvt(const raw& t, float (&v)[4]) {
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
   }
 };
 
 struct CacheBF16 {
   using elem = uint16_t;
+  using raw = uint4;
   static constexpr int EPL = 8;
-  __device__ static inline void load(const elem* p, float (&v)[8]) {
-    const uint4 t = *reinterpret_cast<const uint4*>(p);
+  __device__ static inline raw zero() { return make_uint4(0u, 0u, 0u, 0u); }
+  __device__ static inline raw ld(const elem* p) { return *reinterpret_cast<const uint4*>(p); }
+  __device__ static inline void cvt(const raw& t, float (&v)[8]) {
     v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
     v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
     v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
@@ -63,15 +73,16 @@ struct CacheBF16 {
   }
 };
 
-__device__ inline int lds_pad(int N) { return (N + 63) & ~63; }
+__host__ __device__ inline int lds_pad(int N) { return (N + 63) & ~63; }
 
 template <class C, int ENV>
 __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_args a) {
   constexpr int EPL = C::EPL;
   constexpr int LPR = kD / EPL;   // lanes per cache row
-  constexpr int RPL = 64 / LPR;   // rows per wave-wide load
+  constexpr int RPL = 64 / LPR;   // rows per wave-wide load (= row groups G)
   constexpr int LPH = kDH / EPL;  // lanes per head
   using elem = typename C::elem;
+  using raw_t = typename C::raw;
 
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
@@ -79,7 +90,7 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
   const int N = a.N;
   const int Np = lds_pad(N);
   float* sc = reinterpret_cast<float*>(smem);  // [Np*kH] per-head scores, (j*kH + h)
-  float* lg = sc + Np * kH;                    // [Np] clipped logits, then log-probs
+  float* lg = sc + Np * kH;                    // [Np] raw logits -> clipped logits -> log-probs
   uint8_t* mk = reinterpret_cast<uint8_t*>(lg + Np);  // [Np] 1 = feasible
   uint8_t* vis = mk + Np;                             // [Np] CVRP visited flags
 
@@ -145,25 +156,29 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
 
     // ---- pass 1: per-head scores over the glimpse keys -------------------------------
     float m = kNegInf;
-    for (int j0 = 0; j0 < N; j0 += RPL) {
-      const int j = j0 + rg;
-      const bool valid = j < N;
-      float k[EPL];
-      if (valid) {
-        C::load(Kg + (int64_t)j * rs, k);
-      } else {
+    for (int j0 = 0; j0 < N; j0 += RPL * kUnroll) {
+      raw_t rw[kUnroll];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) k[e] = 0.0f;
+      for (int u = 0; u < kUnroll; ++u) {
+        const int j = j0 + u * RPL + rg;
+        rw[u] = (j < N) ? C::ld(Kg + (int64_t)j * rs) : C::zero();
       }
-      float acc = 0.0f;
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) acc = fmaf(q[e], k[e], acc);
+      for (int u = 0; u < kUnroll; ++u) {
+        const int j = j0 + u * RPL + rg;
+        const bool valid = j < N;
+        float k[EPL];
+        C::cvt(rw[u], k);
+        float acc = 0.0f;
 #pragma unroll
-      for (int s = 1; s < LPH; s <<= 1) acc = acc + rl4co::shfl_xor_f(acc, s);
-      const bool feas = valid && (!a.mask_inner || mk[j] != 0);
-      const float sv = feas ? acc : kNegInf;
-      if (valid && (li % LPH) == 0) sc[j * kH + hd] = sv;
-      m = fmaxf(m, sv);
+        for (int e = 0; e < EPL; ++e) acc = fmaf(q[e], k[e], acc);
+#pragma unroll
+        for (int s = 1; s < LPH; s <<= 1) acc = acc + rl4co::shfl_xor_f(acc, s);
+        const bool feas = valid && (!a.mask_inner || mk[valid ? j : 0] != 0);
+        const float sv = feas ? acc : kNegInf;
+        if (valid && (li % LPH) == 0) sc[j * kH + hd] = sv;
+        m = fmaxf(m, sv);
+      }
     }
 #pragma unroll
     for (int s = LPR; s < 64; s <<= 1) m = fmaxf(m, rl4co::shfl_xor_f(m, s));
@@ -174,21 +189,24 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
     float o[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) o[e] = 0.0f;
-    for (int j0 = 0; j0 < N; j0 += RPL) {
-      const int j = j0 + rg;
-      const bool valid = j < N;
-      float v[EPL];
-      float p = 0.0f;
-      if (valid) {
-        C::load(Vg + (int64_t)j * rs, v);
-        p = rl4co_expf(sc[j * kH + hd] - m);
-      } else {
+    for (int j0 = 0; j0 < N; j0 += RPL * kUnroll) {
+      raw_t rw[kUnroll];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) v[e] = 0.0f;
+      for (int u = 0; u < kUnroll; ++u) {
+        const int j = j0 + u * RPL + rg;
+        rw[u] = (j < N) ? C::ld(Vg + (int64_t)j * rs) : C::zero();
       }
-      l = l + p;
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) o[e] = fmaf(p, v[e], o[e]);
+      for (int u = 0; u < kUnroll; ++u) {
+        const int j = j0 + u * RPL + rg;
+        const bool valid = j < N;
+        float v[EPL];
+        C::cvt(rw[u], v);
+        const float p = valid ? rl4co_expf(sc[j * kH + hd] - m) : 0.0f;
+        l = l + p;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[e] = fmaf(p, v[e], o[e]);
+      }
     }
 #pragma unroll
     for (int s = LPR; s < 64; s <<= 1) {
@@ -200,35 +218,43 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
     for (int e = 0; e < EPL; ++e) o[e] = o[e] / l;
 
     // ---- pass 3: pointer logits against the (project_out-folded) logit key -----------
-    bool nan_seen = false;
-    for (int j0 = 0; j0 < N; j0 += RPL) {
-      const int j = j0 + rg;
-      const bool valid = j < N;
-      float k[EPL];
-      if (valid) {
-        C::load(Kl + (int64_t)j * rs, k);
-      } else {
+    for (int j0 = 0; j0 < N; j0 += RPL * kUnroll) {
+      raw_t rw[kUnroll];
 #pragma unroll
-        for (int e = 0; e < EPL; ++e) k[e] = 0.0f;
+      for (int u = 0; u < kUnroll; ++u) {
+        const int j = j0 + u * RPL + rg;
+        rw[u] = (j < N) ? C::ld(Kl + (int64_t)j * rs) : C::zero();
       }
-      float acc = 0.0f;
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) acc = fmaf(o[e], k[e], acc);
+      for (int u = 0; u < kUnroll; ++u) {
+        const int j = j0 + u * RPL + rg;
+        float k[EPL];
+        C::cvt(rw[u], k);
+        float acc = 0.0f;
 #pragma unroll
-      for (int s = 1; s < LPR; s <<= 1) acc = acc + rl4co::shfl_xor_f(acc, s);
-      float z = acc / sqrt_d;
-      if (valid && z != z) nan_seen = true;  // attention.py:295-296
-      if (a.tanh_clipping > 0.0f) z = rl4co_tanhf(z) * a.tanh_clipping;
-      if (a.mask_logits && !(valid && mk[j] != 0)) z = kNegInf;
-      z = z / a.temperature;
-      if (valid && li == 0) lg[j] = z;
+        for (int e = 0; e < EPL; ++e) acc = fmaf(o[e], k[e], acc);
+#pragma unroll
+        for (int s = 1; s < LPR; s <<= 1) acc = acc + rl4co::shfl_xor_f(acc, s);
+        if (j < N && li == 0) lg[j] = acc;
+      }
     }
-    if (__any(nan_seen)) errbits |= RL4CO_EBIT_NAN_LOGIT;
     __syncthreads();
 
-    // ---- log_softmax over the N logits (decoding.py:188) -----------------------------
+    // ---- logits -> clipped / masked / tempered (decoding.py:169-185), lane-strided ----
+    bool nan_seen = false;
     float zmax = kNegInf;
-    for (int j = lane; j < N; j += 64) zmax = fmaxf(zmax, lg[j]);
+    for (int j = lane; j < N; j += 64) {
+      float z = lg[j] / sqrt_d;
+      if (z != z) nan_seen = true;  // attention.py:295-296
+      if (a.tanh_clipping > 0.0f) z = rl4co_tanhf(z) * a.tanh_clipping;
+      if (a.mask_logits && mk[j] == 0) z = kNegInf;
+      z = z / a.temperature;
+      lg[j] = z;
+      zmax = fmaxf(zmax, z);
+    }
+    if (__any(nan_seen)) errbits |= RL4CO_EBIT_NAN_LOGIT;
+
+    // ---- log_softmax over the N logits (decoding.py:188) -----------------------------
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) zmax = fmaxf(zmax, rl4co::shfl_xor_f(zmax, s));
     float zsum = 0.0f;
@@ -360,8 +386,12 @@ int launch(const rl4co_am_decode_args& a, hipStream_t stream) {
 
 extern "C" int rl4co_am_decode_lds_bytes(int N, int env) {
   (void)env;
-  const int Np = (N + 63) & ~63;
+  const int Np = lds_pad(N);
   return Np * kH * 4 + Np * 4 + Np + Np;
+}
+
+extern "C" int rl4co_am_decode_row_groups(int cache_dtype) {
+  return cache_dtype == RL4CO_DT_BF16 ? 64 / (kD / CacheBF16::EPL) : 64 / (kD / CacheF32::EPL);
 }
 
 extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {

@@ -93,6 +93,20 @@ __global__ void __launch_bounds__(256) tour_length_kernel(const float* __restric
   tv.actions = actions + (int64_t)(active ? b : 0) * T;
   const int n = tv.n;
   const int nvec = n / 8;
+  if (n < 8) {
+    // below one 8-wide vector ATen takes scalar_inner_sum: row_sum<float> with 4 ILP
+    // partials, leftovers into partial 0, partials folded in order
+    if (active && lane8 == 0) {
+      float p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+      const int g = n / 4;
+      for (int i = 0; i < g; ++i)
+        for (int k = 0; k < 4; ++k) p[k] = p[k] + tv.seg(4 * i + k);
+      for (int k = 4 * g; k < n; ++k) p[0] = p[0] + tv.seg(k);
+      for (int k = 1; k < 4; ++k) p[0] = p[0] + p[k];
+      out[b] = negate ? -p[0] : p[0];
+    }
+    return;
+  }
   float part = 0.0f;
   if (active) part = lane_row_sum(tv, lane8, nvec);
   // vectorized_inner_sum epilogue: scalar tail first, then the 8 lane partials in order.

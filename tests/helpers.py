@@ -1,12 +1,32 @@
-"""Shared builders for the parity tests: seeded instances, oracle policies, device state."""
+"""Shared builders for the parity tests: golden fixtures, seeded instances, oracle policies, state."""
 from __future__ import annotations
 
+import hashlib
+import json
+from pathlib import Path
+
+import numpy as np
 import torch
 
 from oracle import reference_torch as R
 
+ROOT = Path(__file__).resolve().parents[1]
+GOLDEN_DIR = ROOT / "tests" / "golden"
 WEIGHT_SEED = 0
 DATA_SEED = 1234
+SAMPLE_SEED = 4321
+
+
+def manifest() -> dict:
+    return {c["name"]: c for c in json.loads((GOLDEN_DIR / "MANIFEST.json").read_text())["cases"]}
+
+
+def state_hash(sd: dict) -> str:
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(sd[k].detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
 
 
 def make_policy(env_name: str, pomo: bool = False, seed: int = WEIGHT_SEED, **kw):
@@ -20,6 +40,39 @@ def make_instances(env_name: str, num_loc: int, batch: int, seed: int = DATA_SEE
     torch.manual_seed(seed)
     data = env.generate(batch)
     return env, data
+
+
+class GoldenCase:
+    """One fixture of tests/golden: the REAL reference's outputs (oracle/gen_golden.py) plus the
+    seeded policy/inputs rebuilt through the restatement and verified against the stored hashes."""
+
+    def __init__(self, name: str):
+        self.meta = manifest()[name]
+        z = np.load(GOLDEN_DIR / f"{name}.npz")
+        self.actions = torch.from_numpy(z["actions"].astype(np.int64))
+        self.reward = torch.from_numpy(z["reward"])
+        self.log_likelihood = torch.from_numpy(z["log_likelihood"])
+        m = self.meta
+        self.env_name, self.num_loc, self.batch = m["env"], m["num_loc"], m["batch"]
+        self.env = R.get_env(self.env_name, self.num_loc)
+        torch.manual_seed(m["data_seed"])
+        self.data = self.env.generate(self.batch)
+        stored = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
+        for k, v in stored.items():
+            assert torch.equal(v, self.data[k]), f"seeded {k} differs from the stored fixture input"
+        assert state_hash(self.data) == m["inputs_sha256"], "seeded inputs differ from the golden run"
+        torch.manual_seed(m["weight_seed"])
+        self.policy = R.AttentionModelPolicy(env_name=self.env_name, **m["policy_kwargs"]).eval()
+        assert state_hash(self.policy.state_dict()) == m["weights_sha256"], "seeded weights differ from the golden run"
+
+    def reset(self) -> dict:
+        return self.env.reset(clone_td(self.data))
+
+    @property
+    def num_starts(self) -> int:
+        if "multistart" not in self.meta["decode_type"]:
+            return 0
+        return self.meta["forward_kwargs"].get("num_starts", self.num_loc)
 
 
 def clone_td(td: dict) -> dict:
@@ -37,19 +90,40 @@ def decoder_weights(pol) -> dict:
     )
 
 
-def device_state(env_name: str, td: dict, device) -> dict:
-    """Copy an oracle reset state onto the GPU in the layout the kernels update in place."""
+def fold_cache(pol, env_name: str, h: torch.Tensor, dtype=torch.float32, device="cpu"):
+    from rl4co_amd.cache import build_folded_cache
+
+    w = {k: (v.detach().to(device) if v is not None else None) for k, v in decoder_weights(pol).items()}
+    return build_folded_cache(env_name, h.to(device), cache_dtype=dtype, **w)
+
+
+def rollout_state(env_name: str, td: dict, device="cpu", num_starts: int = 0) -> dict:
+    """Copy an oracle reset state into the flat layout the kernels / C oracle update in place
+    (s-major batchify of the trajectory rows when ``num_starts`` > 0; instance data stays [B,...])."""
+    s = max(num_starts, 1)
+
+    def rep(x):
+        x = x.to(device)
+        return x.unsqueeze(0).expand(s, *x.shape).reshape(s * x.shape[0], *x.shape[1:]).contiguous().clone()
+
     st = {
-        "action_mask": td["action_mask"].to(device).contiguous(),
-        "current_node": td["current_node"].reshape(-1).to(device).contiguous(),
-        "done": td["done"].reshape(-1).to(device).contiguous(),
+        "action_mask": rep(td["action_mask"]),
+        "current_node": rep(td["current_node"].reshape(-1)),
+        "done": rep(td["done"].reshape(-1)),
     }
     if env_name == "tsp":
-        st["first_node"] = td["first_node"].to(device).clone().contiguous()
-        st["i"] = td["i"].reshape(-1).to(device).contiguous()
+        st["first_node"] = rep(td["first_node"].reshape(-1))
+        st["i"] = rep(td["i"].reshape(-1))
     else:
         st["demand"] = td["demand"].to(device).contiguous()
-        st["used_capacity"] = td["used_capacity"].reshape(-1).to(device).contiguous()
-        st["vehicle_capacity"] = td["vehicle_capacity"].reshape(-1).to(device).contiguous()
-        st["visited"] = td["visited"].to(device).contiguous()
+        st["used_capacity"] = rep(td["used_capacity"].reshape(-1))
+        st["vehicle_capacity"] = rep(td["vehicle_capacity"].reshape(-1))
+        st["visited"] = rep(td["visited"])
     return st
+
+
+device_state = rollout_state  # name used by the GPU tests
+
+
+def max_horizon(env_name: str, n: int) -> int:
+    return n if env_name == "tsp" else 2 * n

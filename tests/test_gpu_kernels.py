@@ -23,7 +23,7 @@ def _random_tours(b, n, gen):
     return torch.stack([torch.randperm(n, generator=gen) for _ in range(b)])
 
 
-@pytest.mark.parametrize("n", [5, 8, 20, 21, 100, 101, 201, 500, 501, 1001, 2500])
+@pytest.mark.parametrize("n", [2, 3, 5, 6, 7, 8, 9, 20, 21, 100, 101, 201, 500, 501, 513, 1001, 2500])
 def test_tsp_reward_bit_exact(K, n):
     gen = torch.Generator().manual_seed(n)
     b = 64
