@@ -1,0 +1,231 @@
+#!/usr/bin/env python
+"""bench.py — the rollout hot path on N MI355X GPUs of one node (driver contract).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic instances already resident in
+HBM: ``env.reset`` -> AttentionModel policy greedy rollout (encoder, cache fold, ONE persistent
+launch of the fused decode kernel for all T decode steps, tour-length reward, validity check).
+Workload at every N: BASELINE.json configs[1] — TSPEnv num_loc=100, batch 4096 per GPU, AM
+(3 layers, d=128, 8 heads), bf16 cache planes with fp32 arithmetic, greedy. Instances shard
+across ranks with no data-path collective (weak scaling; SURVEY.md §8e: inference = replicas).
+
+Rank 0 prints ONE JSON line. ``value`` = whole-job instance·decode-steps per second
+(B·T·N_gpus·K / wall), wall = max over ranks of the barrier-bracketed timed region.
+``roofline``: the decode kernel's algorithmic bytes per launch (SURVEY.md §8d per instance-step
+figure x B x T) / its mean launch duration, measured here with HIP events on the launch stream.
+``cpu_baseline``: the reference path (torch restatement, pinned bit-exact to the reference's own
+source by oracle/gen_golden.py) timed on this box's host cores on a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_instance_step(env_name: str, n: int, elem: int) -> int:
+    """3·N·d·e (K_g,V_g,K_l) + N (mask read) + N (mask write) + context rows
+    (TSP: 2·d·e, CVRP: d·e + 8) + d·4 (graph context) + 16 (action, logp, scalars)."""
+    d = 128
+    ctx = 2 * d * elem if env_name == "tsp" else d * elem + 8
+    return 3 * n * d * elem + 2 * n + ctx + d * 4 + 16
+
+
+def cpu_baseline(env_name: str, num_loc: int, sample_batch: int, repeats: int) -> dict:
+    """Reference path on the host cores: oracle restatement (stock ATen ops, fp32, same ops in
+    the same order as the reference), greedy rollout, span = reset -> policy -> reward."""
+    from oracle import reference_torch as R
+
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    env = R.get_env(env_name, num_loc, check_solution=True)
+    torch.manual_seed(0)
+    pol = R.AttentionModelPolicy(env_name).eval()
+    torch.manual_seed(1234)
+    data = env.generate(sample_batch)
+    times, steps = [], 0
+    with torch.inference_mode():
+        for i in range(repeats + 1):
+            t0 = time.perf_counter()
+            td = env.reset({k: v.clone() for k, v in data.items()})
+            out = pol(td, env, phase="test", decode_type="greedy")
+            dt = time.perf_counter() - t0
+            steps = out["actions"].shape[1]
+            if i > 0:  # first pass is the warm-up
+                times.append(dt)
+    best = min(times)
+    return {
+        "value": sample_batch * steps / best,
+        "unit": "instance·step/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{env_name.upper()}-{num_loc} batch {sample_batch} greedy full rollout (encoder+decode+reward), "
+                  f"fp32 torch CPU, best of {repeats} after 1 warm-up, {best:.3f} s each",
+        "mean_reward": float(out["reward"].mean()),
+    }
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--env", default="tsp", choices=["tsp", "cvrp"])
+    ap.add_argument("--num-loc", type=int, default=100)
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--cache-dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--decode", default="greedy", choices=["greedy", "sampling"])
+    ap.add_argument("--no-check-solution", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=512)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the rollout engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # "nccl" == RCCL on ROCm
+
+    from rl4co_amd import kernels as K
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    cache_dtype = torch.bfloat16 if args.cache_dtype == "bf16" else torch.float32
+    torch.manual_seed(0)  # random-init weights of the reference architecture, identical on every rank
+    policy = AttentionModelPolicy(env_name=args.env, cache_dtype=cache_dtype).to(device).eval()
+    env = get_env(args.env, generator_params=dict(num_loc=args.num_loc, device=device), device=device,
+                  check_solution=not args.no_check_solution)
+    torch.manual_seed(1234 + rank)  # each rank owns its shard of the synthetic instances
+    data = env.generator(batch_size=[args.batch])
+    torch.cuda.synchronize()
+
+    def step():
+        td = env.reset(data)
+        return policy(td, env, phase="test", decode_type=args.decode)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.inference_mode():
+        for _ in range(args.warmup):
+            out = step()
+        policy.decode_events = []
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        wall = time.perf_counter() - t0
+    decode_ms = [a.elapsed_time(b) for a, b in policy.decode_events]
+    policy.decode_events = None
+    t_steps = out["actions"].shape[1]
+    n_nodes = args.num_loc + (1 if args.env == "cvrp" else 0)
+
+    if world > 1:
+        tw = torch.tensor([wall], dtype=torch.float64, device=device)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+        ts = torch.tensor([t_steps], dtype=torch.int64, device=device)
+        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+        total_instance_steps = args.batch * int(ts.item()) * args.steps
+    else:
+        total_instance_steps = args.batch * t_steps * args.steps
+
+    if rank == 0:
+        elem = 2 if args.cache_dtype == "bf16" else 4
+        per_unit = algorithmic_bytes_per_instance_step(args.env, n_nodes, elem)
+        bytes_per_launch = per_unit * args.batch * t_steps
+        mean_decode_ms = sum(decode_ms) / len(decode_ms)
+        achieved = bytes_per_launch / (mean_decode_ms * 1e-3) / 1e9
+        # achievable-stream ceiling on this box (float4 grid-stride read of 2 GiB)
+        probe = torch.empty(2 << 30, dtype=torch.uint8, device=device)
+        sink = torch.zeros(1, device=device)
+        K.hbm_read_probe(probe, sink)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            K.hbm_read_probe(probe, sink)
+        e1.record()
+        torch.cuda.synchronize()
+        probe_gbs = 5 * probe.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del probe
+        value = total_instance_steps / wall
+        line = {
+            "metric": "decode_steps_per_sec",
+            "value": value,
+            "unit": "instance·step/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if args.cache_dtype == "f32" else "f32 arithmetic on bf16 cache planes",
+            "data": "synthetic",
+            "config": {
+                "workload": f"BASELINE configs[1]: {args.env.upper()}Env num_loc={args.num_loc} batch={args.batch}/GPU "
+                            f"AttentionModel(3L,d128,h8) {args.decode} rollout, {args.cache_dtype} cache",
+                "env": args.env, "num_loc": args.num_loc, "batch_per_gpu": args.batch, "decode_steps": t_steps,
+                "decode_type": args.decode, "cache_dtype": args.cache_dtype,
+                "check_solution": not args.no_check_solution, "parallelism": f"replicas x{world} (instances sharded)",
+            },
+            "node_steps_per_sec": value * n_nodes,
+            "instances_per_sec": args.batch * world * args.steps / wall,
+            "mean_reward": float(out["reward"].mean()),
+            "roofline": {
+                "kernel": "am_decode_kernel (fused persistent rollout, all T decode steps in one launch)",
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_instance_step": per_unit,
+                "instance_steps_per_launch": args.batch * t_steps,
+                "bytes_per_launch": bytes_per_launch,
+                "launch_ms_mean": mean_decode_ms,
+                "launch_ms_min": min(decode_ms),
+                "us_per_decode_step": mean_decode_ms * 1e3 / t_steps,
+                "launches_timed": len(decode_ms),
+                "hbm_read_probe_GBs": probe_gbs,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.env, args.num_loc, args.cpu_sample_batch, repeats=3)
+            line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -275,6 +275,7 @@ class AttentionModelPolicy(nn.Module):
         self.cache_dtype = cache_dtype
         self.encoder_autocast = encoder_autocast
         self._philox_calls = 0
+        self.decode_events: list | None = None  # set to [] by bench.py to time the decode launches
 
     # -- helpers --------------------------------------------------------------------------------
     def _encode(self, td):
@@ -363,37 +364,46 @@ class AttentionModelPolicy(nn.Module):
         horizon = min(self._max_horizon(self.env_name, n), max_steps)
         err = K.new_error_word(device)
 
-        t0 = 0
+        # pre_decoder_hook (decoding.py:306-326): with multistart the first action is imposed per
+        # start (log-prob 0) and consumes NO column of a caller-provided `actions` tensor — the
+        # evaluate strategy replays `actions[..., step]` from the first DECODED step
+        # (constructive/base.py:219-232).
+        t0 = 1 if (multistart and n_rep >= 1) else 0
         if mode == "evaluate":
-            forced = actions.contiguous()
-            tmax = forced.shape[1]
-            out_actions = torch.zeros_like(forced)
+            given = actions.contiguous()
+            tmax = t0 + given.shape[1]
+            forced = torch.zeros((b, tmax), dtype=torch.int64, device=device)
+            forced[:, t0:] = given
         else:
             forced = None
             tmax = horizon
-            out_actions = torch.zeros((b, tmax), dtype=torch.int64, device=device)
+        out_actions = torch.zeros((b, tmax), dtype=torch.int64, device=device)
         logps = torch.zeros((b, tmax), dtype=torch.float32, device=device)
         n_steps = torch.zeros((b,), dtype=torch.int32, device=device)
         all_logps = torch.zeros((b, tmax, n), dtype=torch.float32, device=device) if store_all_logp else None
 
-        if multistart and n_rep >= 1 and mode != "evaluate":
-            # pre_decoder_hook (decoding.py:306-326): first action fixed per start, log-prob 0
+        if t0 == 1:
             first = env.select_start_nodes(td, num_starts=n_rep)
             out_actions[:, 0] = first
             self._env_step_state(state, first, err)
-            t0 = 1
 
         if mode == "sampling" and exp_noise is None:
             self._philox_calls += 1
             philox_seed = int(seed) if seed is not None else int(torch.randint(0, 2**62, (1,)).item())
         else:
             philox_seed = 0
+        if self.decode_events is not None:  # bench.py: HIP events around the decode kernel launch
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
         K.am_decode(
             cache, state, mode=mode, max_steps=tmax - t0, t0=t0, actions=out_actions, logps=logps, err=err,
             tanh_clipping=tanh_clipping, temperature=temperature, mask_inner=self.decoder.mask_inner,
             mask_logits=mask_logits, exp_noise=exp_noise, philox_seed=philox_seed,
             forced_actions=forced, all_logps=all_logps, n_steps=n_steps,
         )
+        if self.decode_events is not None:
+            ev1.record()
+            self.decode_events.append((ev0, ev1))
         # ONE host sync for the whole rollout: horizon + sticky error bits
         t_used = t0 + int(n_steps.max().item())
         K.raise_if_error(err)

@@ -1,0 +1,69 @@
+"""TEST INFRASTRUCTURE: run the host-side mirror (rl4co_amd.policy / rl4co_amd.envs) without a GPU.
+
+The product has no CPU path (rl4co_amd.kernels refuses non-CUDA tensors). To cover the HOST logic
+(decode-type parsing, multistart layout, horizon handling, select_best, teacher-forced
+log-likelihood, output dict) in the CPU suite, this fixture swaps the kernel front end for the
+C oracle — the test plays the device. Never used outside tests/.
+"""
+from __future__ import annotations
+
+import pytest
+import torch
+
+from oracle import c_oracle
+
+
+def _tour_length(locs, actions, prepend_depot=False, negate=False):
+    return c_oracle.tour_length(locs.contiguous(), actions.contiguous(), prepend_depot, negate)
+
+
+def _tsp_step(action, action_mask, first_node, current_node, step_i, done, err=None):
+    c_oracle.tsp_step(action.contiguous(), action_mask, first_node, current_node, step_i, done)
+
+
+def _cvrp_step(action, demand, used_capacity, vehicle_capacity, visited, current_node, action_mask, done, err=None):
+    c_oracle.cvrp_step(None if action is None else action.contiguous(), demand, used_capacity, vehicle_capacity,
+                       visited, current_node, action_mask, done)
+
+
+def _select_start_nodes(batch, num_starts, num_loc, has_depot, device):
+    return torch.arange(num_starts).repeat_interleave(batch) % num_loc + (1 if has_depot else 0)
+
+
+def _tsp_check(actions, num_nodes, err):
+    n = actions.shape[1]
+    ok = n == num_nodes and bool((actions.sort(1).values == torch.arange(n)).all())
+    if not ok:
+        err |= 4
+
+
+def _cvrp_check(actions, demand, vehicle_capacity, err):
+    from oracle import reference_torch as R
+
+    s = actions.shape[0] // demand.shape[0]
+    td = {"demand": R.batchify(demand, s) if s > 1 else demand,
+          "vehicle_capacity": (R.batchify(vehicle_capacity, s) if s > 1 else vehicle_capacity).reshape(-1, 1)}
+    try:
+        R.CVRPEnv.check_solution_validity(td, actions)
+    except AssertionError as e:  # map the message back to the sticky bit
+        err |= 8 if "capacity" in str(e) else 4
+
+
+def _am_decode(cache, state, **kw):
+    dt = 1 if cache.kvl.dtype == torch.bfloat16 else 0
+    c_oracle.am_decode(cache, state, row_groups=4 if dt else 2, **kw)
+
+
+@pytest.fixture
+def cpu_device(monkeypatch):
+    """Patch rl4co_amd.kernels so that policy/env host code runs on CPU tensors via the C oracle."""
+    from rl4co_amd import kernels as K
+
+    monkeypatch.setattr(K, "tour_length", _tour_length)
+    monkeypatch.setattr(K, "tsp_step", _tsp_step)
+    monkeypatch.setattr(K, "cvrp_step", _cvrp_step)
+    monkeypatch.setattr(K, "select_start_nodes", _select_start_nodes)
+    monkeypatch.setattr(K, "tsp_check_solution", _tsp_check)
+    monkeypatch.setattr(K, "cvrp_check_solution", _cvrp_check)
+    monkeypatch.setattr(K, "am_decode", _am_decode)
+    return "cpu"

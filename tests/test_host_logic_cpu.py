@@ -1,0 +1,157 @@
+"""CPU coverage of the host-side mirror of the reference interface (no GPU).
+
+The arithmetic kernels are replaced by the C oracle through tests/fake_device.py, so these tests
+exercise exactly the Python the product runs on the GPU box: env reset/step/get_reward surfaces,
+policy.forward orchestration for every decode type, state_dict compatibility with the reference,
+the teacher-forced differentiable log-likelihood.
+"""
+import pytest
+import torch
+
+from oracle import reference_torch as R
+from tests.fake_device import cpu_device  # noqa: F401  (fixture)
+from tests.helpers import GoldenCase, clone_td, manifest
+
+SMALL = sorted(c for c, m in manifest().items() if m["batch"] <= 128)
+
+
+def _product_policy(g: GoldenCase, **kw):
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    pk = dict(g.meta["policy_kwargs"])
+    pk.pop("sdpa_fn_decoder", None)
+    pol = AttentionModelPolicy(env_name=g.env_name, **pk, **kw).eval()
+    missing = pol.load_state_dict(g.policy.state_dict(), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return pol
+
+
+def _product_env(g: GoldenCase):
+    from rl4co_amd.envs import get_env
+
+    return get_env(g.env_name, generator_params=dict(num_loc=g.num_loc), device="cpu")
+
+
+def _product_td(g: GoldenCase):
+    from rl4co_amd.tensordict import TensorDict
+
+    return TensorDict({k: v.clone() for k, v in g.data.items()}, batch_size=[g.batch])
+
+
+def test_state_dict_keys_equal_reference():
+    """Checkpoints of the reference's AttentionModelPolicy load unchanged (same keys and shapes)."""
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    for env_name in ("tsp", "cvrp"):
+        ref = R.AttentionModelPolicy(env_name)
+        ours = AttentionModelPolicy(env_name)
+        assert list(ref.state_dict().keys()) == list(ours.state_dict().keys())
+        for k, v in ref.state_dict().items():
+            assert ours.state_dict()[k].shape == v.shape, k
+    ref = R.pomo_policy("tsp")
+    ours = AttentionModelPolicy("tsp", num_encoder_layers=6, normalization="instance", use_graph_context=False)
+    assert list(ref.state_dict().keys()) == list(ours.state_dict().keys())
+
+
+def test_seeded_construction_matches_reference_weights():
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    torch.manual_seed(0)
+    ref = R.AttentionModelPolicy("cvrp")
+    torch.manual_seed(0)
+    ours = AttentionModelPolicy("cvrp")
+    for k, v in ref.state_dict().items():
+        assert torch.equal(ours.state_dict()[k], v), k
+
+
+@pytest.mark.parametrize("name", SMALL)
+def test_policy_forward_matches_reference_golden(cpu_device, name):
+    g = GoldenCase(name)
+    pol, env = _product_policy(g), _product_env(g)
+    td = env.reset(_product_td(g))
+    kw = dict(g.meta["forward_kwargs"])
+    if "sampling" in g.meta["decode_type"]:
+        s = g.num_starts
+        b = g.batch * max(s, 1)
+        n = g.num_loc + (g.env_name == "cvrp")
+        torch.manual_seed(g.meta["sample_seed"])
+        kw["exp_noise"] = torch.stack([torch.empty(b, n).exponential_(1) for _ in range(2 * n)], 0).contiguous()
+    with torch.inference_mode():
+        out = pol(td, env, phase="test", decode_type=g.meta["decode_type"], **kw)
+    assert out["actions"].shape == g.actions.shape
+    same = (out["actions"] == g.actions).all(1)
+    assert int((~same).sum()) <= max(1, len(same) // 50)
+    assert torch.equal(out["reward"][same], g.reward[same])
+    torch.testing.assert_close(out["log_likelihood"][same], g.log_likelihood[same], rtol=1e-5, atol=5e-5)
+
+
+def test_env_surface_step_by_step(cpu_device):
+    """reset / step / get_reward / get_action_mask driven like the reference's rollout() helper."""
+    for name in ("tsp50_b64_greedy", "cvrp20_b128_greedy"):
+        g = GoldenCase(name)
+        env = _product_env(g)
+        td = env.reset(_product_td(g))
+        ref_td = g.reset()
+        assert torch.equal(td["action_mask"], ref_td["action_mask"])
+        assert torch.equal(td["locs"], ref_td["locs"])
+        t = g.actions.shape[1]
+        for i in range(t):
+            td.set("action", g.actions[:, i].contiguous())
+            td = env.step(td)["next"]
+        assert bool(td["done"].all())
+        assert torch.equal(env.get_reward(td, g.actions), g.reward)
+        bad = g.actions.clone()
+        bad[0, 0] = bad[0, 1] if g.env_name == "tsp" else bad[0, (bad[0] > 0).nonzero()[1]]
+        if g.env_name == "cvrp":
+            bad[0, (g.actions[0] > 0).nonzero()[0]] = g.actions[0, (g.actions[0] > 0).nonzero()[1]]
+        with pytest.raises(AssertionError, match="Invalid tour"):
+            env.get_reward(td, bad)
+
+
+def test_select_best_and_num_starts(cpu_device):
+    g = GoldenCase("pomo_tsp20_b16_msgreedy")
+    pol, env = _product_policy(g), _product_env(g)
+    with torch.inference_mode():
+        out = pol(env.reset(_product_td(g)), env, phase="test", decode_type="multistart_greedy", select_best=True)
+        ref = g.policy(g.reset(), g.env, phase="test", decode_type="multistart_greedy", select_best=True)
+    assert out["reward"].shape == (g.batch,)
+    assert torch.equal(out["reward"], ref["reward"])
+    assert torch.equal(out["actions"], ref["actions"])
+
+
+@pytest.mark.parametrize("name", ["tsp20_b64_greedy_simple", "cvrp20_b128_greedy", "pomo_tsp20_b16_msgreedy"])
+def test_training_log_likelihood_has_reference_gradients(cpu_device, name):
+    """phase='train': sampled by the kernel, log-likelihood re-evaluated teacher-forced with
+    autograd; value and parameter gradients must match the reference's decode_type='evaluate'
+    path on the same actions (reinforce.py:99-102 differentiates exactly this)."""
+    g = GoldenCase(name)
+    pol, env = _product_policy(g), _product_env(g)
+    pol.train()
+    ref_pol = g.policy
+    ref_pol.train()
+    s = g.num_starts
+    decode = "multistart_sampling" if s else "sampling"
+    out = pol(env.reset(_product_td(g)), env, phase="train", decode_type=decode, seed=11,
+              **g.meta["forward_kwargs"])
+    assert out["log_likelihood"].requires_grad
+    # reference quirk: with multistart the forced `actions` start AFTER the imposed start node
+    # (pre_decoder_hook consumes no column, constructive/base.py:219-232)
+    forced = out["actions"][:, 1:] if s else out["actions"]
+    ref = ref_pol(g.reset(), g.env, phase="train", actions=forced, **(dict(num_starts=s) if s else {}))
+    assert torch.equal(ref["actions"], out["actions"])
+    # and the product's own evaluate path follows the same convention
+    with torch.no_grad():
+        ev = pol(env.reset(_product_td(g)), env, phase="train", actions=forced, **(dict(num_starts=s) if s else {}))
+    assert torch.equal(ev["actions"], out["actions"])
+    torch.testing.assert_close(ev["log_likelihood"], ref["log_likelihood"].detach(), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(out["reward"], ref["reward"], rtol=0, atol=0)
+    torch.testing.assert_close(out["log_likelihood"], ref["log_likelihood"], rtol=1e-4, atol=1e-4)
+    adv = torch.linspace(-1, 1, out["log_likelihood"].shape[0])
+    (adv * out["log_likelihood"]).mean().backward()
+    (adv * ref["log_likelihood"]).mean().backward()
+    ours = dict(pol.named_parameters())
+    for k, p in ref_pol.named_parameters():
+        if p.grad is None:
+            assert ours[k].grad is None or float(ours[k].grad.abs().max()) == 0.0, k
+            continue
+        torch.testing.assert_close(ours[k].grad, p.grad, rtol=2e-3, atol=2e-5, msg=lambda m: f"{k}: {m}")
