@@ -37,6 +37,11 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def log(msg: str) -> None:
+    """Progress goes to stderr; stdout carries exactly one JSON line."""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def algorithmic_bytes_per_instance_step(env_name: str, n: int, elem: int) -> int:
     """3·N·d·e (K_g,V_g,K_l) + N (mask read) + N (mask write) + context rows
     (TSP: 2·d·e, CVRP: d·e + 8) + d·4 (graph context) + 16 (action, logp, scalars)."""
@@ -50,7 +55,9 @@ def cpu_baseline(env_name: str, num_loc: int, sample_batch: int, repeats: int) -
     the same order as the reference), greedy rollout, span = reset -> policy -> reward."""
     from oracle import reference_torch as R
 
-    threads = os.cpu_count() or 1
+    # host cores this process may actually run on (cgroup/affinity aware: os.cpu_count() can
+    # report the whole machine inside a CPU-limited container and oversubscribe OpenMP)
+    threads = max(1, min(len(os.sched_getaffinity(0)), torch.get_num_threads()))
     torch.set_num_threads(threads)
     env = R.get_env(env_name, num_loc, check_solution=True)
     torch.manual_seed(0)
@@ -59,6 +66,16 @@ def cpu_baseline(env_name: str, num_loc: int, sample_batch: int, repeats: int) -
     data = env.generate(sample_batch)
     times, steps = [], 0
     with torch.inference_mode():
+        # size the sample so that the whole leg stays within ~30 s of CPU work on any host
+        probe_b = min(32, sample_batch)
+        t0 = time.perf_counter()
+        pol(env.reset({k: v[:probe_b].clone() for k, v in data.items()}), env, phase="test", decode_type="greedy")
+        per_inst = (time.perf_counter() - t0) / probe_b
+        budget_b = int(30.0 / (repeats + 1) / max(per_inst, 1e-6))
+        if budget_b < sample_batch:
+            sample_batch = max(probe_b, budget_b)
+            data = {k: v[:sample_batch] for k, v in data.items()}
+        log(f"cpu_baseline: {threads} threads, sample batch {sample_batch} (probe {per_inst * 1e3:.2f} ms/instance)")
         for i in range(repeats + 1):
             t0 = time.perf_counter()
             td = env.reset({k: v.clone() for k, v in data.items()})
@@ -132,9 +149,12 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    log(f"rank {rank}/{world}: instances resident, warming up")
     with torch.inference_mode():
         for _ in range(args.warmup):
             out = step()
+        torch.cuda.synchronize()
+        log("timing")
         policy.decode_events = []
         barrier()
         t0 = time.perf_counter()
@@ -142,6 +162,7 @@ def main() -> None:
             out = step()
         barrier()
         wall = time.perf_counter() - t0
+    log(f"timed region done: {wall:.3f} s for {args.steps} steps")
     decode_ms = [a.elapsed_time(b) for a, b in policy.decode_events]
     policy.decode_events = None
     t_steps = out["actions"].shape[1]

@@ -81,7 +81,16 @@ class Rl4coLibraryError(RuntimeError):
 
 @lru_cache(maxsize=None)
 def lib() -> C.CDLL:
-    """Load ``librl4co_amd.so`` (building it in-tree first if it is stale or absent)."""
+    """Load ``librl4co_amd.so`` (building it in-tree first if it is stale or absent).
+
+    torch is imported FIRST on purpose: the PyTorch-ROCm wheel bundles its own HIP runtime
+    (``torch/lib/libamdhip64.so``, soname ``libamdhip64.so.7``). Our library needs the same soname,
+    so once torch's copy is resident the dynamic loader binds us to it and kernels, streams and
+    device pointers all live in ONE runtime. Loaded the other way round the process ends up with
+    two HIP runtimes (ours from /opt/rocm, torch's bundled one) and torch's stream handles are
+    meaningless to ours ("no ROCm-capable device is detected")."""
+    import torch  # noqa: F401  (see above)
+
     path = _build.build_library()
     try:
         handle = C.CDLL(str(path))
