@@ -32,7 +32,7 @@ EMBED_DIM = 128
 @dataclass
 class FoldedCache:
     env_name: str
-    kvl: Tensor  # [B, 3, N, 128] fp32 or bf16: planes (glimpse_key, glimpse_val, logit_key)
+    kvl: Tensor  # [3, B, N, 128] fp32 or bf16, plane-major: (glimpse_key, glimpse_val, logit_key)
     ctx_first: Tensor | None  # [B, N, 128] fp32 (TSP)
     ctx_cur: Tensor  # [B, N, 128] fp32
     q_bias: Tensor | None  # [B, 128] fp32
@@ -41,14 +41,14 @@ class FoldedCache:
 
     @property
     def num_instances(self) -> int:
-        return self.kvl.shape[0]
+        return self.kvl.shape[1]
 
     @property
     def num_nodes(self) -> int:
         return self.kvl.shape[2]
 
     def plane(self, i: int) -> Tensor:
-        return self.kvl[:, i]
+        return self.kvl[i]
 
     @property
     def row_stride(self) -> int:
@@ -56,21 +56,19 @@ class FoldedCache:
 
     @property
     def batch_stride(self) -> int:
-        return self.kvl.stride(0)
+        return self.kvl.stride(1)
 
 
-def fold_weights(env_name: str, w_node: Tensor, w_out: Tensor, w_ctx: Tensor) -> Tensor:
-    """Stack the per-node projection matrices: ``[Wk; Wv; W_out^T Wl; W_ctx blocks]`` -> [R,128]."""
+def fold_weights(env_name: str, w_node: Tensor, w_out: Tensor, w_ctx: Tensor) -> list[Tensor]:
+    """Per-node projection matrices ``[Wk, Wv, W_out^T Wl, W_ctx blocks...]``, each [128,128]."""
     d = EMBED_DIM
     wk, wv, wl = w_node[:d], w_node[d : 2 * d], w_node[2 * d :]
     wl_folded = w_out.t() @ wl  # logits = heads^T W_out^T (Wl h_j)
     if env_name == "tsp":
-        blocks = [wk, wv, wl_folded, w_ctx[:, :d], w_ctx[:, d : 2 * d]]
-    elif env_name == "cvrp":
-        blocks = [wk, wv, wl_folded, w_ctx[:, :d]]
-    else:
-        raise ValueError(f"fused decode supports tsp/cvrp, got {env_name!r}")
-    return torch.cat(blocks, 0)
+        return [wk, wv, wl_folded, w_ctx[:, :d], w_ctx[:, d : 2 * d]]
+    if env_name == "cvrp":
+        return [wk, wv, wl_folded, w_ctx[:, :d]]
+    raise ValueError(f"fused decode supports tsp/cvrp, got {env_name!r}")
 
 
 def build_folded_cache(
@@ -82,27 +80,37 @@ def build_folded_cache(
     w_fixed: Tensor | None,
     w_placeholder: Tensor | None,
     cache_dtype: torch.dtype = torch.float32,
+    gemm_dtype: torch.dtype = torch.float32,
 ) -> FoldedCache:
-    """One GEMM ``[B*N,128] x [128,R]`` + a GEMV for the graph context; runs in fp32."""
+    """One ``[B*N,128] x [128,128]`` GEMM per plane, written straight into its plane of the
+    plane-major cache (no permute/cast copies), plus a GEMV for the graph context.
+
+    ``gemm_dtype`` is the input type of the three streamed-plane GEMMs (fp32 = the parity
+    configuration; bf16 = MFMA rate, the reference's own mixed-precision regime,
+    utils/trainer.py:57). The two gathered context tables are always folded in fp32."""
     assert h.dim() == 3 and h.shape[-1] == EMBED_DIM
     d = EMBED_DIM
-    h = h.float()
-    w_all = fold_weights(env_name, w_node.float(), w_out.float(), w_ctx.float())
-    proj = torch.matmul(h, w_all.t())  # [B, N, R]
-    b, n, _ = proj.shape
-    # planar [B,3,N,128]: each decode pass streams one contiguous N*128 plane per instance
-    kvl = proj[..., : 3 * d].reshape(b, n, 3, d).permute(0, 2, 1, 3).to(cache_dtype).contiguous()
+    b, n, _ = h.shape
+    w_blocks = fold_weights(env_name, w_node.float(), w_out.float(), w_ctx.float())
+    kvl = torch.empty((3, b, n, d), dtype=cache_dtype, device=h.device)
+    h_g = h.reshape(b * n, d).to(gemm_dtype)
+    for i in range(3):
+        w_t = w_blocks[i].to(gemm_dtype).t()
+        if gemm_dtype == cache_dtype:
+            torch.matmul(h_g, w_t, out=kvl[i].view(b * n, d))
+        else:
+            kvl[i].view(b * n, d).copy_(torch.matmul(h_g, w_t))
+    h32 = h.reshape(b * n, d).float()
+    ctx = [torch.matmul(h32, w.t()).view(b, n, d) for w in w_blocks[3:]]
     q_bias = None
     if w_fixed is not None:
-        q_bias = torch.matmul(h.mean(1), w_fixed.float().t()).contiguous()
+        q_bias = torch.matmul(h.float().mean(1), w_fixed.float().t()).contiguous()
     if env_name == "tsp":
-        ctx_first = proj[..., 3 * d : 4 * d].contiguous()
-        ctx_cur = proj[..., 4 * d : 5 * d].contiguous()
+        ctx_first, ctx_cur = ctx
         q_step0 = torch.mv(w_ctx.float(), w_placeholder.float()).contiguous()
         w_cap = None
     else:
-        ctx_first = None
-        ctx_cur = proj[..., 3 * d : 4 * d].contiguous()
+        ctx_first, ctx_cur = None, ctx[0]
         q_step0 = None
         w_cap = w_ctx.float()[:, d].contiguous()
     return FoldedCache(env_name, kvl, ctx_first, ctx_cur, q_bias, q_step0, w_cap)

@@ -1,0 +1,151 @@
+"""One process per GPU: instance sharding and the single exchange step of the path.
+
+The rollout shards embarrassingly by instance — no collective on the data path.
+The reference's only communication is Lightning DDP's gradient bucket all-reduce
+(``rl4co/utils/trainer.py:83-86``: ``DDPStrategy(find_unused_parameters=True,
+gradient_as_bucket_view=True)``; AM-3L 710 144 params = 2.84 MB fp32, POMO-6L ≈ 5.2 MB — one
+bucket) plus scalar metric reductions (``rl/common/base.py:220-227`` ``sync_dist=True``).
+
+MI355X mapping: ONE all-reduce(sum) of one flat fp32 buffer per optimizer step over RCCL/xGMI
+(backend "nccl" on ROCm), then divide by the world size — DDP's mean-of-per-rank-mean-loss
+semantics. At a few MB the ring is latency-bound (7 xGMI links x ~153 GB/s per GPU), so a single
+message beats per-parameter launches; the flat buffer is a persistent view the parameters' grads
+alias (``gradient_as_bucket_view``), so there is no pack/unpack copy.
+Backend-agnostic (gloo on CPU for the tests, nccl/RCCL on the GPUs).
+"""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+
+
+def init_process_group(backend: str | None = None, device: torch.device | None = None) -> tuple[int, int]:
+    """Initialise from the torchrun environment (RANK / WORLD_SIZE / MASTER_*). Returns (rank, world)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    return rank, world
+
+
+def world_info() -> tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_bounds(total: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous block [lo, hi) of ``total`` instances owned by ``rank`` (sizes differ by <= 1)."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_instances(td, rank: int | None = None, world: int | None = None):
+    """Slice a batch (TensorDict / dict of tensors / tensor) to this rank's contiguous shard."""
+    r, w = world_info()
+    rank = r if rank is None else rank
+    world = w if world is None else world
+    if isinstance(td, Tensor):
+        lo, hi = shard_bounds(td.shape[0], rank, world)
+        return td[lo:hi]
+    if isinstance(td, dict) and not hasattr(td, "batch_size"):
+        return {k: shard_instances(v, rank, world) for k, v in td.items()}
+    lo, hi = shard_bounds(td.batch_size[0], rank, world)
+    return td[lo:hi]
+
+
+class FlatGradBucket:
+    """All trainable gradients of a module as views into ONE flat fp32 buffer.
+
+    ``allreduce_mean()`` = one collective per optimizer step (the reference's DDP bucket). Parameters
+    that received no gradient this step contribute zeros (DDP ``find_unused_parameters=True``)."""
+
+    def __init__(self, module: nn.Module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError("module has no trainable parameters")
+        device, dtype = self.params[0].device, torch.float32
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(self.numel, dtype=dtype, device=device)
+        off = 0
+        for p in self.params:
+            if p.dtype != dtype:
+                raise TypeError("FlatGradBucket expects fp32 master parameters")
+            view = self.flat[off : off + p.numel()].view_as(p)
+            if p.grad is not None:
+                view.copy_(p.grad)
+            p.grad = view  # autograd accumulates in place into the bucket from now on
+            off += p.numel()
+
+    @property
+    def nbytes(self) -> int:
+        return self.numel * 4
+
+    def zero_(self) -> None:
+        self.flat.zero_()
+
+    def _rebind(self) -> None:
+        """``optimizer.zero_grad(set_to_none=True)`` drops the views; re-attach them."""
+        off = 0
+        for p in self.params:
+            view = self.flat[off : off + p.numel()].view_as(p)
+            if p.grad is None:
+                view.zero_()
+                p.grad = view
+            elif p.grad.data_ptr() != view.data_ptr():
+                view.copy_(p.grad)
+                p.grad = view
+            off += p.numel()
+
+    def allreduce_mean(self, async_op: bool = False):
+        """sum over ranks / world size, in place. Returns the work handle when ``async_op``."""
+        self._rebind()
+        _, world = world_info()
+        if world == 1:
+            return None
+        work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True)
+        if async_op:
+            return _ScaledWork(work, self.flat, world)
+        work.wait()
+        self.flat.div_(world)
+        return None
+
+
+class _ScaledWork:
+    def __init__(self, work, flat: Tensor, world: int):
+        self.work, self.flat, self.world = work, flat, world
+
+    def wait(self) -> None:
+        self.work.wait()
+        self.flat.div_(self.world)
+
+
+def allreduce_scalars(values: dict[str, float | Tensor], device=None, op: str = "mean") -> dict[str, float]:
+    """Logged metrics (``sync_dist=True``): ONE small all-reduce for all keys of a step."""
+    _, world = world_info()
+    keys = sorted(values)
+    buf = torch.tensor([float(values[k]) for k in keys], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(buf, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+        if op == "mean":
+            buf /= world
+    return {k: float(v) for k, v in zip(keys, buf.tolist())}
+
+
+def broadcast_decision(flag: bool, src: int = 0, device=None) -> bool:
+    """RolloutBaseline's per-rank t-test decision (reinforce/baselines.py:200-218) must agree on
+    every rank: rank ``src`` decides, everyone follows."""
+    _, world = world_info()
+    if world == 1:
+        return bool(flag)
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=device)
+    dist.broadcast(t, src=src)
+    return bool(int(t.item()))

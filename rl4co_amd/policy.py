@@ -210,7 +210,8 @@ class AttentionModelDecoder(nn.Module):
         self.project_fixed_context = nn.Linear(embed_dim, embed_dim, bias=False)
         self.use_graph_context = use_graph_context
 
-    def precompute_cache(self, h: Tensor, cache_dtype: torch.dtype) -> FoldedCache:
+    def precompute_cache(self, h: Tensor, cache_dtype: torch.dtype,
+                         gemm_dtype: torch.dtype = torch.float32) -> FoldedCache:
         """zoo/am/decoder.py:201-228, folded (rl4co_amd/cache.py)."""
         return build_folded_cache(
             self.env_name, h,
@@ -220,6 +221,7 @@ class AttentionModelDecoder(nn.Module):
             w_fixed=self.project_fixed_context.weight if self.use_graph_context else None,
             w_placeholder=getattr(self.context_embedding, "W_placeholder", None),
             cache_dtype=cache_dtype,
+            gemm_dtype=gemm_dtype,
         )
 
 
@@ -281,8 +283,7 @@ class AttentionModelPolicy(nn.Module):
     def _encode(self, td):
         if self.encoder_autocast is not None:
             with torch.autocast("cuda", dtype=self.encoder_autocast):
-                h, init_h = self.encoder(td)
-            return h.float(), init_h.float()
+                return self.encoder(td)
         return self.encoder(td)
 
     @staticmethod
@@ -359,7 +360,8 @@ class AttentionModelPolicy(nn.Module):
         b_inst, n = td["action_mask"].shape[0], td["action_mask"].shape[-1]
         b = b_inst * max(n_rep, 1)
         with torch.no_grad():
-            cache = self.decoder.precompute_cache(hidden.detach(), self.cache_dtype)
+            cache = self.decoder.precompute_cache(hidden.detach(), self.cache_dtype,
+                                                  self.encoder_autocast or torch.float32)
         state = self._initial_state(td, n_rep)
         horizon = min(self._max_horizon(self.env_name, n), max_steps)
         err = K.new_error_word(device)
@@ -492,6 +494,7 @@ class AttentionModelPolicy(nn.Module):
         instance (dense, MFMA-friendly). Masks/contexts are replayed with the env-step kernels."""
         dec = self.decoder
         s = max(n_rep, 1)
+        hidden = hidden.float()  # encoder_autocast may hand over bf16 activations
         b_inst, n, d = hidden.shape
         b, t_len = actions.shape
         masks, ctx_nodes, extras = self._replay(td, actions, n_rep)

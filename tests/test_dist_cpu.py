@@ -1,0 +1,105 @@
+"""N > 1 path on CPU: world_size-2 gloo processes (no GPU): instance sharding has no data-path
+collective, the gradient exchange is ONE flat all-reduce with DDP (mean) semantics."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from rl4co_amd import dist as D
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 1))
+
+
+def _worker(rank: int, world: int, port: int, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    r, w = D.init_process_group("gloo")
+    assert (r, w) == (rank, world) == D.world_info()
+    # --- sharding: contiguous blocks, union = everything, no communication involved ----------
+    torch.manual_seed(123)
+    data = {"locs": torch.rand(11, 5, 2), "demand": torch.rand(11, 4)}
+    mine = D.shard_instances(data)
+    lo, hi = D.shard_bounds(11, rank, world)
+    assert torch.equal(mine["locs"], data["locs"][lo:hi]) and mine["demand"].shape[0] == hi - lo
+    # --- flat gradient bucket: one all-reduce == mean of per-rank gradients ---------------------
+    model = _model()
+    model[3].weight.requires_grad_(True)
+    bucket = D.FlatGradBucket(model)
+    x = data["locs"].reshape(11, 10)[:, :8][lo:hi]
+    loss = model(x).mean()
+    loss.backward()
+    local = [p.grad.clone() for p in bucket.params]
+    bucket.allreduce_mean()
+    gathered = [torch.zeros_like(bucket.flat) for _ in range(world)]
+    flat_local = torch.cat([g.reshape(-1) for g in local])
+    dist.all_gather(gathered, flat_local)
+    want = torch.stack(gathered).sum(0) / world
+    assert torch.allclose(bucket.flat, want, atol=0, rtol=0)
+    for p in bucket.params:  # grads are views of the bucket: an optimizer sees the reduced values
+        assert p.grad.data_ptr() >= bucket.flat.data_ptr()
+    # zero_grad(set_to_none=True) then a second step still lands in the bucket
+    opt = torch.optim.SGD(model.parameters(), lr=0.1)
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    model(x).sum().backward()
+    h = bucket.allreduce_mean(async_op=True)
+    h.wait()
+    assert torch.isfinite(bucket.flat).all() and float(bucket.flat.abs().sum()) > 0
+    # parameters stay identical across ranks after identical reduced updates
+    flat_params = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    both = [torch.zeros_like(flat_params) for _ in range(world)]
+    dist.all_gather(both, flat_params)
+    assert torch.equal(both[0], both[1])
+    # --- scalar metrics and the baseline decision ---------------------------------------------
+    m = D.allreduce_scalars({"reward": float(rank + 1), "loss": 2.0 * rank})
+    assert m == {"loss": 1.0, "reward": 1.5}
+    assert D.allreduce_scalars({"t": float(rank)}, op="max") == {"t": 1.0}
+    assert D.broadcast_decision(rank == 0) is True
+    out_q.put((rank, bucket.nbytes, float(bucket.flat.sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0, "gloo worker failed"
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert res[0][1] == res[1][1] and res[0][2] == pytest.approx(res[1][2], rel=0, abs=0)
+
+
+def test_shard_bounds_cover_everything():
+    for total in (1, 7, 4096, 32768):
+        for world in (1, 2, 3, 8):
+            spans = [D.shard_bounds(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_single_process_is_a_noop():
+    model = _model()
+    bucket = D.FlatGradBucket(model)
+    model(torch.ones(3, 8)).sum().backward()
+    before = bucket.flat.clone()
+    assert bucket.allreduce_mean() is None and torch.equal(bucket.flat, before)
+    assert bucket.nbytes == 4 * sum(p.numel() for p in model.parameters())
