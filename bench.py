@@ -195,7 +195,10 @@ def main() -> None:
     if rank == 0:
         elem = 2 if args.cache_dtype == "bf16" else 4
         per_unit = algorithmic_bytes_per_instance_step(args.env, n_nodes, elem)
-        bytes_per_launch = per_unit * args.batch * t_steps
+        # units one launch streams: trajectories stop reading the cache once done (CVRP), so the
+        # kernel's own step count is used, not B x T_max (identical for TSP)
+        units_per_launch = policy.last_instance_steps
+        bytes_per_launch = per_unit * units_per_launch
         mean_decode_ms = sum(decode_ms) / len(decode_ms)
         achieved = bytes_per_launch / (mean_decode_ms * 1e-3) / 1e9
         # achievable-stream ceiling on this box (float4 grid-stride read of 2 GiB)
@@ -244,7 +247,7 @@ def main() -> None:
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
                 "algorithmic_bytes_per_instance_step": per_unit,
-                "instance_steps_per_launch": args.batch * t_steps,
+                "instance_steps_per_launch": units_per_launch,
                 "bytes_per_launch": bytes_per_launch,
                 "launch_ms_mean": mean_decode_ms,
                 "launch_ms_min": min(decode_ms),

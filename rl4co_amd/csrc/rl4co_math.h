@@ -137,12 +137,15 @@ RL4CO_HD void rl4co_philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1) {
   }
 }
 
-/* Exp(1) draw for (step, trajectory, node): -log(u), u uniform in (0,1). */
+/* Exp(1) draw for (step, trajectory, node): -log(u), u uniform on the open interval (0,1).
+ * 23 random bits: (k + 0.5) * 2^-23 is exact in fp32 for k < 2^23 (a 24-bit significand), so
+ * u <= 1 - 2^-24 < 1 and the draw is strictly positive — with 24 bits (k + 0.5) rounds up to 2^24
+ * for the top k, u becomes 1.0, the noise 0 and a masked node's key 0/0 = NaN. */
 RL4CO_HD float rl4co_exp1_noise(uint64_t seed, uint64_t step, uint32_t traj, uint32_t node) {
   uint32_t c[4] = {(uint32_t)step, traj, node >> 2, (uint32_t)(step >> 32) ^ 0x52344c43u};
   rl4co_philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
   uint32_t w = c[node & 3];
-  float u = ((float)(w >> 8) + 0.5f) * 5.9604644775390625e-8f; /* (k+0.5)/2^24 in (0,1) */
+  float u = ((float)(w >> 9) + 0.5f) * 1.1920928955078125e-7f; /* (k+0.5)/2^23 in (0,1) */
   return -rl4co_logf(u);
 }
 

@@ -277,6 +277,7 @@ class AttentionModelPolicy(nn.Module):
         self.cache_dtype = cache_dtype
         self.encoder_autocast = encoder_autocast
         self._philox_calls = 0
+        self.last_instance_steps = 0
         self.decode_events: list | None = None  # set to [] by bench.py to time the decode launches
 
     # -- helpers --------------------------------------------------------------------------------
@@ -407,7 +408,9 @@ class AttentionModelPolicy(nn.Module):
             ev1.record()
             self.decode_events.append((ev0, ev1))
         # ONE host sync for the whole rollout: horizon + sticky error bits
-        t_used = t0 + int(n_steps.max().item())
+        horizon_used, streamed = torch.stack((n_steps.max(), n_steps.sum())).tolist()
+        t_used = t0 + int(horizon_used)
+        self.last_instance_steps = int(streamed)  # instance-steps the decode launch really streamed
         K.raise_if_error(err)
         out_actions = out_actions[:, :t_used].contiguous()
         logps = logps[:, :t_used]

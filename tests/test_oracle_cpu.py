@@ -207,3 +207,19 @@ def test_c_oracle_row_group_invariance_of_actions():
     a8, l8, _ = c_rollout(g, "greedy", row_groups=8)
     assert (a2 == a8).all(1).float().mean() > 0.98
     torch.testing.assert_close(l2.sum(1), l8.sum(1), rtol=1e-5, atol=1e-5)
+
+
+def test_philox_noise_is_strictly_positive_and_exponential():
+    """In-kernel Exp(1) noise: never 0 / inf / NaN (a zero draw on a masked node made the
+    sampling key 0/0), mean and variance of Exp(1)."""
+    import ctypes
+
+    h = c_oracle.lib()
+    vals = np.array([h.oracle_exp1_noise(ctypes.c_uint64(7), ctypes.c_uint64(s), t, n)
+                     for s in range(8) for t in range(64) for n in range(100)], dtype=np.float64)
+    assert np.isfinite(vals).all() and (vals > 0).all()
+    assert abs(vals.mean() - 1.0) < 0.02 and abs(vals.var() - 1.0) < 0.06
+    # the extreme uniform words map strictly inside (0, 1) in fp32
+    for k in (0, 2**23 - 1):
+        u = np.float32(np.float32(k) + np.float32(0.5)) * np.float32(2.0 ** -23)
+        assert 0.0 < float(u) < 1.0
