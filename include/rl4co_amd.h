@@ -205,6 +205,64 @@ int rl4co_am_decode_lds_bytes(int N, int env);
 int rl4co_am_decode_row_groups(int cache_dtype);
 
 /* --------------------------------------------------------------------------
+ * a11-a13  fused encoder + decoder-cache fold on the matrix cores (inference rollouts).
+ *
+ * Replaces, per instance and in one launch: TSPInitEmbedding / VRPInitEmbedding
+ * (models/nn/env_embeddings/init.py:55-68,115-136), GraphAttentionNetwork with L x
+ * [x + MHA(x) -> Norm -> x + MLP(x) -> Norm] (models/nn/graph/attnnet.py:16-106,
+ * nn/attention.py:110-134, nn/ops.py:30-54, nn/mlp.py:52-61; 8 heads, d = 128, FFN 512) and
+ * AttentionModelDecoder._precompute_cache (zoo/am/decoder.py:201-228) in the folded form of
+ * rl4co_am_decode_args. bf16 MFMA inputs, fp32 accumulation, bf16 residual stream (the
+ * reference's mixed-precision regime, utils/trainer.py:57). Normalisation: norm = 0 is
+ * batch norm in EVAL mode, passed as a per-channel (scale, shift) pair folded from the
+ * running statistics; norm = 1 is instance norm (POMO), scale/shift = gamma/beta.
+ * Train-mode batch statistics couple instances and stay on the torch path (which also
+ * provides autograd). N <= rl4co_am_encoder_max_nodes().
+ *
+ * Weight matrices are nn.Linear weights [out,in] re-packed once per weight update into MFMA
+ * fragment order: [out/32 tiles][in/16 ksteps][64 lanes][8] bf16 with lane = 32*hi + row,
+ * element s = W[32*tile + row][16*kstep + 8*hi + s]   (rl4co_amd/encoder.py: pack_weight).
+ * -------------------------------------------------------------------------- */
+typedef struct rl4co_am_encoder_args {
+  int32_t env;         /* RL4CO_ENV_*                                              */
+  int32_t B;           /* instances                                                */
+  int32_t N;           /* nodes incl. depot                                        */
+  int32_t num_layers;  /* 3 (AM) / 6 (POMO)                                        */
+  int32_t norm;        /* 0 = per-channel affine (batch norm, eval), 1 = instance  */
+  int32_t cache_dtype; /* dtype of the three kvl planes written                    */
+  const float* locs;   /* [B,N,2] (CVRP: depot first, cvrp/env.py:108)             */
+  const float* demand; /* [B,N-1] CVRP                                             */
+  const float* w_init; /* [128,2] TSP / [128,3] CVRP customers                     */
+  const float* b_init; /* [128]                                                    */
+  const float* w_depot; /* [128,2] CVRP                                            */
+  const float* b_depot; /* [128]                                                   */
+  const void* wqkv_packed; /* [L] x packed [384,128]                               */
+  const float* bqkv;       /* [L,384]                                              */
+  const void* wo_packed;   /* [L] x packed [128,128]                               */
+  const float* bo;         /* [L,128]                                              */
+  const float* n1_scale;   /* [L,128]                                              */
+  const float* n1_shift;   /* [L,128]                                              */
+  const void* w1_packed;   /* [L] x packed [512,128]                               */
+  const float* b1;         /* [L,512]                                              */
+  const void* w2_packed;   /* [L] x packed [128,512]                               */
+  const float* b2;         /* [L,128]                                              */
+  const float* n2_scale;   /* [L,128]                                              */
+  const float* n2_shift;   /* [L,128]                                              */
+  const void* wfold_packed; /* 5 (TSP) / 4 (CVRP) x packed [128,128]: Wk, Wv, W_out^T Wl, W_ctx blocks */
+  const float* w_fixed;     /* [128,128] project_fixed_context or NULL              */
+  void* kvl;                /* planes 0..2 of the folded cache                      */
+  int64_t kvl_plane_stride; /* elements between planes                              */
+  int64_t kvl_batch_stride; /* elements between instances                           */
+  float* ctx_first;         /* [B,N,128] TSP                                        */
+  float* ctx_cur;           /* [B,N,128]                                            */
+  float* q_bias;            /* [B,128] or NULL                                      */
+  float* hidden;            /* [B,N,128] final node embeddings, or NULL             */
+} rl4co_am_encoder_args;
+
+int rl4co_am_encoder(const rl4co_am_encoder_args* args, void* stream);
+int rl4co_am_encoder_max_nodes(void);
+
+/* --------------------------------------------------------------------------
  * a19  select_start_nodes        rl4co/utils/ops.py:128-161
  * out[s*B + b] = s % num_loc (+1 for depot environments), s-major.
  * -------------------------------------------------------------------------- */

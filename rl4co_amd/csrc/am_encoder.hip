@@ -1,0 +1,461 @@
+// am_encoder.hip — fused AttentionModel encoder + decoder-cache fold on the gfx950 matrix cores.
+//
+// Replaces, for inference rollouts (eval-mode normalisation), per instance and in ONE launch:
+//   TSPInitEmbedding / VRPInitEmbedding     models/nn/env_embeddings/init.py:55-68,115-136
+//   GraphAttentionNetwork (L layers of      models/nn/graph/attnnet.py:16-106
+//     x + MHA(x) -> Norm -> x + MLP(x) -> Norm)   nn/attention.py:110-134, nn/ops.py:30-54, nn/mlp.py:52-61
+//   AttentionModelDecoder._precompute_cache models/zoo/am/decoder.py:201-228 (folded form, cache.py)
+// The reference runs ~45 ATen kernels that round-trip [B*N,128..512] activations through HBM
+// (profiles/r01_run2: 5.2 ms at TSP-100 x 4096 in bf16). Here one 256-thread workgroup owns one
+// instance: the residual stream lives in LDS (bf16, like torch autocast), every GEMM runs on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation, weights stream from L2 in pre-packed fragment
+// order, and the only HBM traffic is the coordinates in and the folded cache planes out.
+//
+// Work split (4 waves, N <= 128 tokens = TT tiles of 32):
+//   * "transposed" GEMMs  Out^T[dim][token] = W[dim][k] . In^T[k][token]: A = weight fragment
+//     (one 16-B global load per lane, reused over the TT token tiles), B = activation rows read
+//     from LDS ([token][k], ds_read_b128). Wave w owns output-dim tile w (32 dims) of every GEMM,
+//     so each weight fragment is fetched by exactly one wave of the workgroup.
+//   * attention is wave-private: wave w computes Q, K (transposed form) and V (plain form) for
+//     head pair (2w, 2w+1) of all tokens and keeps them in registers as MFMA fragments:
+//       S^T[key][query] = K . Q^T     (A = K regs, B = Q regs; K-dim 16 = one head, no waste)
+//       softmax over keys = in-lane over the accumulator registers + one cross-half exchange
+//       O^T[dim][query]  = V^T . P^T  (A = V regs, B = P regs)
+//     All four operands are accumulator-layout registers (lane = row/col index, registers = k),
+//     so no LDS transpose is needed; the k-slot permutation of the layout is the same on both
+//     operands of each product and therefore cancels.
+//   * exchanges through LDS only where a GEMM needs all 128 input dims produced by other waves:
+//     attention output -> out-proj, norm1 output -> FFN1, FFN hidden chunks -> FFN2.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kD = RL4CO_EMBED_DIM;
+constexpr int kFF = 512;
+constexpr int kRS = kD + 8;  // LDS row stride (bf16 elements): 272 B rows spread the banks
+constexpr int kThreads = 256;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ inline f32x16 mfma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// accumulator layout of the 32x32 MFMA: register r of lane (l31, hi) is row rowmap(r, hi), col l31
+__device__ inline int rowmap(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__device__ inline f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.0f;
+  return z;
+}
+
+// registers 8u..8u+7 of an accumulator as one bf16 MFMA operand fragment
+__device__ inline bf16x8 frag_from_acc(const f32x16& c, int u) {
+  bf16x8 f;
+#pragma unroll
+  for (int s = 0; s < 8; ++s) f[s] = (__bf16)c[8 * u + s];
+  return f;
+}
+
+// packed weight fragment: [tile][kstep][64 lanes][8] bf16
+__device__ inline bf16x8 load_w(const __bf16* packed, int ksteps, int tile, int ks, int lane) {
+  return *reinterpret_cast<const bf16x8*>(packed + (((int64_t)tile * ksteps + ks) * 64 + lane) * 8);
+}
+
+// activation fragment from LDS rows [token][k]: lane reads 8 contiguous k of its token row
+__device__ inline bf16x8 load_x(const __bf16* xs, int tt, int ks, int l31, int hi) {
+  return *reinterpret_cast<const bf16x8*>(xs + (32 * tt + l31) * kRS + 16 * ks + 8 * hi);
+}
+
+// Out^T tile (32 dims x 32*TT tokens) += W[tile] . X^T over ksteps [k0, k0 + nk)
+template <int TT>
+__device__ inline void gemm_t(f32x16 (&acc)[TT], const __bf16* packed, int ksteps_total, int tile, int k0,
+                              int nk, int kx0, const __bf16* xs, int lane) {
+  const int l31 = lane & 31, hi = lane >> 5;
+  bf16x8 wn = load_w(packed, ksteps_total, tile, k0, lane);
+  for (int ks = 0; ks < nk; ++ks) {
+    const bf16x8 wf = wn;
+    if (ks + 1 < nk) wn = load_w(packed, ksteps_total, tile, k0 + ks + 1, lane);
+    bf16x8 xf[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) xf[tt] = load_x(xs, tt, kx0 + ks, l31, hi);
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) acc[tt] = mfma(wf, xf[tt], acc[tt]);
+  }
+}
+
+// write an Out^T accumulator tile to LDS rows [token][dim]: 4 consecutive dims per 8-byte store
+template <int TT>
+__device__ inline void store_t(__bf16* ys, const f32x16 (&acc)[TT], int dim0, int lane) {
+  const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      bf16x4 v;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) v[s] = (__bf16)acc[tt][4 * c + s];
+      *reinterpret_cast<bf16x4*>(ys + (32 * tt + l31) * kRS + dim0 + 8 * c + 4 * hi) = v;
+    }
+  }
+}
+
+struct LayerPtrs {
+  const __bf16 *wqkv, *wo, *w1, *w2;
+  const float *bqkv, *bo, *b1, *b2, *n1a, *n1b, *n2a, *n2b;
+};
+
+// residual + bias + normalisation epilogue for the wave's 32-dim tile; result back into xs (bf16)
+template <int TT>
+__device__ inline void residual_norm(__bf16* xs, f32x16 (&y)[TT], int dim0, const float* bias, const float* na,
+                                     const float* nb, int norm, int N, int lane) {
+  const int l31 = lane & 31, hi = lane >> 5;
+  float bb[16], ga[16], be[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int d = dim0 + rowmap(r, hi);
+    bb[r] = bias[d];
+    ga[r] = na[d];
+    be[r] = nb[d];
+  }
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bf16x4 x = *reinterpret_cast<const bf16x4*>(xs + (32 * tt + l31) * kRS + dim0 + 8 * c + 4 * hi);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) y[tt][4 * c + s] = (float)x[s] + (y[tt][4 * c + s] + bb[4 * c + s]);
+    }
+  }
+  if (norm == 1) {
+    // instance norm (nn/ops.py:46-47, POMO): per (instance, channel) statistics over the N tokens
+    const float inv_n = 1.0f / (float)N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float s = 0.0f;
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) s += (32 * tt + l31 < N) ? y[tt][r] : 0.0f;
+#pragma unroll
+      for (int m = 1; m < 32; m <<= 1) s += __shfl_xor(s, m, 64);
+      const float mean = s * inv_n;
+      float v = 0.0f;
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        const float d = y[tt][r] - mean;
+        v += (32 * tt + l31 < N) ? d * d : 0.0f;
+      }
+#pragma unroll
+      for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+      const float rstd = rsqrtf(v * inv_n + 1e-5f);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) y[tt][r] = (y[tt][r] - mean) * rstd * ga[r] + be[r];
+    }
+  } else {
+    // batch norm in eval mode = per-channel affine folded on the host (scale, shift)
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) y[tt][r] = fmaf(y[tt][r], ga[r], be[r]);
+  }
+  store_t<TT>(xs, y, dim0, lane);
+}
+
+template <int TT>
+__global__ void __launch_bounds__(kThreads) am_encoder_kernel(const rl4co_am_encoder_args a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __bf16* xs = reinterpret_cast<__bf16*>(smem);  // residual stream [128][kRS]
+  __bf16* ys = xs + 128 * kRS;                   // attention output / FFN hidden chunk (even)
+  __bf16* zs = ys + 128 * kRS;                   // FFN hidden chunk (odd)
+  float* meanv = reinterpret_cast<float*>(zs + 128 * kRS);  // [128]
+
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.x;
+  const int N = a.N;
+
+  // ---- init embedding (K = 2 or 3: plain VALU), padding rows zeroed ---------------------------
+  {
+    const float* loc = a.locs + (int64_t)b * N * 2;
+    for (int idx = tid; idx < 32 * TT * kD; idx += kThreads) {
+      const int tok = idx >> 7, d = idx & 127;
+      float v = 0.0f;
+      if (tok < N) {
+        const float x = loc[2 * tok], y = loc[2 * tok + 1];
+        if (a.env == RL4CO_ENV_CVRP && tok == 0) {
+          v = fmaf(a.w_depot[2 * d + 1], y, fmaf(a.w_depot[2 * d], x, a.b_depot[d]));
+        } else if (a.env == RL4CO_ENV_CVRP) {
+          const float dm = a.demand[(int64_t)b * (N - 1) + tok - 1];
+          v = fmaf(a.w_init[3 * d + 2], dm, fmaf(a.w_init[3 * d + 1], y, fmaf(a.w_init[3 * d], x, a.b_init[d])));
+        } else {
+          v = fmaf(a.w_init[2 * d + 1], y, fmaf(a.w_init[2 * d], x, a.b_init[d]));
+        }
+      }
+      xs[tok * kRS + d] = (__bf16)v;
+    }
+  }
+  __syncthreads();
+
+  const __bf16* wqkv_all = static_cast<const __bf16*>(a.wqkv_packed);
+  const __bf16* wo_all = static_cast<const __bf16*>(a.wo_packed);
+  const __bf16* w1_all = static_cast<const __bf16*>(a.w1_packed);
+  const __bf16* w2_all = static_cast<const __bf16*>(a.w2_packed);
+
+  for (int layer = 0; layer < a.num_layers; ++layer) {
+    LayerPtrs L;
+    L.wqkv = wqkv_all + (int64_t)layer * 3 * kD * kD;
+    L.wo = wo_all + (int64_t)layer * kD * kD;
+    L.w1 = w1_all + (int64_t)layer * kFF * kD;
+    L.w2 = w2_all + (int64_t)layer * kD * kFF;
+    L.bqkv = a.bqkv + layer * 3 * kD;
+    L.bo = a.bo + layer * kD;
+    L.b1 = a.b1 + layer * kFF;
+    L.b2 = a.b2 + layer * kD;
+    L.n1a = a.n1_scale + layer * kD;
+    L.n1b = a.n1_shift + layer * kD;
+    L.n2a = a.n2_scale + layer * kD;
+    L.n2b = a.n2_shift + layer * kD;
+
+    // ---- Q, K (transposed form) and V (plain form) of head pair w, kept as fragments ---------
+    bf16x8 qf[TT][2], kf[TT][2], vf[TT][2];
+    {
+      f32x16 acc[TT];
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[tt] = zero16();
+      gemm_t<TT>(acc, L.wqkv, 8, w, 0, 8, 0, xs, lane);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tt][r] += L.bqkv[32 * w + rowmap(r, hi)];
+        qf[tt][0] = frag_from_acc(acc[tt], 0);
+        qf[tt][1] = frag_from_acc(acc[tt], 1);
+      }
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[tt] = zero16();
+      gemm_t<TT>(acc, L.wqkv, 8, 4 + w, 0, 8, 0, xs, lane);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tt][r] += L.bqkv[kD + 32 * w + rowmap(r, hi)];
+        kf[tt][0] = frag_from_acc(acc[tt], 0);
+        kf[tt][1] = frag_from_acc(acc[tt], 1);
+      }
+      // V = X . Wv^T: A = token rows from LDS, B = weight fragment -> C[row = token][col = dim]
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) acc[tt] = zero16();
+      {
+        bf16x8 wn = load_w(L.wqkv, 8, 8 + w, 0, lane);
+        for (int ks = 0; ks < 8; ++ks) {
+          const bf16x8 wf = wn;
+          if (ks + 1 < 8) wn = load_w(L.wqkv, 8, 8 + w, ks + 1, lane);
+          bf16x8 xf[TT];
+#pragma unroll
+          for (int tt = 0; tt < TT; ++tt) xf[tt] = load_x(xs, tt, ks, l31, hi);
+#pragma unroll
+          for (int tt = 0; tt < TT; ++tt) acc[tt] = mfma(xf[tt], wf, acc[tt]);
+        }
+      }
+      const float bv = L.bqkv[2 * kD + 32 * w + l31];
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[tt][r] += bv;
+        vf[tt][0] = frag_from_acc(acc[tt], 0);
+        vf[tt][1] = frag_from_acc(acc[tt], 1);
+      }
+    }
+
+    // ---- attention for heads 2w, 2w+1 over all queries, wave-private ---------------------------
+    {
+      f32x16 o[TT];
+#pragma unroll
+      for (int qt = 0; qt < TT; ++qt) o[qt] = zero16();
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+        for (int qt = 0; qt < TT; ++qt) {
+          f32x16 s[TT];
+          float m = -__builtin_huge_valf();
+#pragma unroll
+          for (int kt = 0; kt < TT; ++kt) {
+            s[kt] = mfma(kf[kt][hh], qf[qt][hh], zero16());
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int key = 32 * kt + rowmap(r, hi);
+              const float sv = (key < N) ? s[kt][r] * 0.25f : -__builtin_huge_valf();  // 1/sqrt(16)
+              s[kt][r] = sv;
+              m = fmaxf(m, sv);
+            }
+          }
+          m = fmaxf(m, __shfl_xor(m, 32, 64));
+          float l = 0.0f;
+#pragma unroll
+          for (int kt = 0; kt < TT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float p = __expf(s[kt][r] - m);
+              s[kt][r] = p;
+              l += p;
+            }
+          }
+          l += __shfl_xor(l, 32, 64);
+          f32x16 acc = zero16();
+#pragma unroll
+          for (int kt = 0; kt < TT; ++kt) {
+            acc = mfma(vf[kt][0], frag_from_acc(s[kt], 0), acc);
+            acc = mfma(vf[kt][1], frag_from_acc(s[kt], 1), acc);
+          }
+          const float inv = 1.0f / l;
+#pragma unroll
+          for (int r = 0; r < 8; ++r) o[qt][8 * hh + r] = acc[8 * hh + r] * inv;
+        }
+      }
+      store_t<TT>(ys, o, 32 * w, lane);  // attention output rows [token][dims of head pair w]
+    }
+    __syncthreads();
+
+    // ---- out-proj + residual + norm1 ---------------------------------------------------------------
+    {
+      f32x16 y[TT];
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) y[tt] = zero16();
+      gemm_t<TT>(y, L.wo, 8, w, 0, 8, 0, ys, lane);
+      residual_norm<TT>(xs, y, 32 * w, L.bo, L.n1a, L.n1b, a.norm, N, lane);
+    }
+    __syncthreads();
+
+    // ---- FFN: hidden in 4 chunks of 128, FFN2 accumulates across chunks -----------------------------
+    {
+      f32x16 y2[TT];
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) y2[tt] = zero16();
+      for (int c = 0; c < 4; ++c) {
+        __bf16* hb = (c & 1) ? zs : ys;
+        f32x16 h1[TT];
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) h1[tt] = zero16();
+        gemm_t<TT>(h1, L.w1, 8, 4 * c + w, 0, 8, 0, xs, lane);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) h1[tt][r] = fmaxf(h1[tt][r] + L.b1[32 * (4 * c + w) + rowmap(r, hi)], 0.0f);
+        store_t<TT>(hb, h1, 32 * w, lane);
+        __syncthreads();
+        gemm_t<TT>(y2, L.w2, 32, w, 8 * c, 8, 0, hb, lane);
+      }
+      residual_norm<TT>(xs, y2, 32 * w, L.b2, L.n2a, L.n2b, a.norm, N, lane);
+    }
+    __syncthreads();
+  }
+
+  // ---- optional: final node embeddings h (fp32) ---------------------------------------------------
+  if (a.hidden) {
+    float* hout = a.hidden + (int64_t)b * N * kD;
+    for (int idx = tid; idx < N * kD; idx += kThreads) hout[idx] = (float)xs[(idx >> 7) * kRS + (idx & 127)];
+  }
+
+  // ---- fold: cache planes straight out of the accumulators ------------------------------------------
+  const __bf16* wf_all = static_cast<const __bf16*>(a.wfold_packed);
+  const int nblocks = (a.env == RL4CO_ENV_TSP) ? 5 : 4;
+  for (int blk = 0; blk < nblocks; ++blk) {
+    f32x16 acc[TT];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) acc[tt] = zero16();
+    gemm_t<TT>(acc, wf_all + (int64_t)blk * kD * kD, 8, w, 0, 8, 0, xs, lane);
+    if (blk < 3 && a.cache_dtype == RL4CO_DT_BF16) {
+      __bf16* out = static_cast<__bf16*>(a.kvl) + (int64_t)blk * a.kvl_plane_stride + (int64_t)b * a.kvl_batch_stride;
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        const int tok = 32 * tt + l31;
+        if (tok < N) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            bf16x4 v;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) v[s] = (__bf16)acc[tt][4 * c + s];
+            *reinterpret_cast<bf16x4*>(out + (int64_t)tok * kD + 32 * w + 8 * c + 4 * hi) = v;
+          }
+        }
+      }
+    } else {
+      float* out;
+      if (blk < 3) {
+        out = static_cast<float*>(a.kvl) + (int64_t)blk * a.kvl_plane_stride + (int64_t)b * a.kvl_batch_stride;
+      } else if (a.env == RL4CO_ENV_TSP) {
+        out = (blk == 3 ? a.ctx_first : a.ctx_cur) + (int64_t)b * N * kD;
+      } else {
+        out = a.ctx_cur + (int64_t)b * N * kD;
+      }
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        const int tok = 32 * tt + l31;
+        if (tok < N) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float4 v = make_float4(acc[tt][4 * c], acc[tt][4 * c + 1], acc[tt][4 * c + 2], acc[tt][4 * c + 3]);
+            *reinterpret_cast<float4*>(out + (int64_t)tok * kD + 32 * w + 8 * c + 4 * hi) = v;
+          }
+        }
+      }
+    }
+  }
+
+  // ---- graph context: project_fixed_context(mean_j h_j)  (decoder.py:216-219) -----------------------
+  if (a.q_bias) {
+    if (tid < kD) {
+      float s = 0.0f;
+      for (int tok = 0; tok < N; ++tok) s += (float)xs[tok * kRS + tid];
+      meanv[tid] = s / (float)N;
+    }
+    __syncthreads();
+    if (tid < kD) {
+      const float* wr = a.w_fixed + tid * kD;
+      float acc = 0.0f;
+      for (int k = 0; k < kD; ++k) acc = fmaf(wr[k], meanv[k], acc);
+      a.q_bias[(int64_t)b * kD + tid] = acc;
+    }
+  }
+}
+
+template <int TT>
+int launch_encoder(const rl4co_am_encoder_args& a, hipStream_t stream) {
+  const int lds = 3 * 128 * kRS * 2 + kD * 4;
+  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_encoder_kernel<TT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL((am_encoder_kernel<TT>), dim3(a.B), dim3(kThreads), lds, stream, a);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
+}  // namespace
+
+extern "C" int rl4co_am_encoder_max_nodes(void) { return 128; }
+
+extern "C" int rl4co_am_encoder(const rl4co_am_encoder_args* args, void* stream) {
+  RL4CO_REQUIRE(args != nullptr);
+  const rl4co_am_encoder_args& a = *args;
+  RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP);
+  RL4CO_REQUIRE(a.B > 0 && a.N >= 2 && a.N <= 128);
+  RL4CO_REQUIRE(a.num_layers >= 1 && (a.norm == 0 || a.norm == 1));
+  RL4CO_REQUIRE(a.cache_dtype == RL4CO_DT_F32 || a.cache_dtype == RL4CO_DT_BF16);
+  RL4CO_REQUIRE(a.locs && a.w_init && a.b_init);
+  RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || (a.demand && a.w_depot && a.b_depot));
+  RL4CO_REQUIRE(a.wqkv_packed && a.wo_packed && a.w1_packed && a.w2_packed && a.wfold_packed);
+  RL4CO_REQUIRE(a.bqkv && a.bo && a.b1 && a.b2 && a.n1_scale && a.n1_shift && a.n2_scale && a.n2_shift);
+  RL4CO_REQUIRE(a.kvl && a.ctx_cur && (a.env == RL4CO_ENV_CVRP || a.ctx_first));
+  RL4CO_REQUIRE(a.q_bias == nullptr || a.w_fixed != nullptr);
+  RL4CO_REQUIRE(a.kvl_batch_stride >= (int64_t)a.N * kD && a.kvl_plane_stride >= a.kvl_batch_stride);
+  hipStream_t s = rl4co::as_stream(stream);
+  const int tt = (a.N + 31) / 32;
+  switch (tt) {
+    case 1: return launch_encoder<1>(a, s);
+    case 2: return launch_encoder<2>(a, s);
+    case 3: return launch_encoder<3>(a, s);
+    default: return launch_encoder<4>(a, s);
+  }
+}

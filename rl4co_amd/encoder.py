@@ -1,0 +1,158 @@
+"""Host side of the fused MFMA encoder + cache-fold kernel (``csrc/am_encoder.hip``).
+
+Packs the policy's own parameters (same module tree / state_dict as the reference) into the
+fragment order the kernel streams, folds eval-mode batch norm into a per-channel affine, and
+launches ``rl4co_am_encoder`` — one workgroup per instance, activations never leave the CU.
+Used for inference rollouts in the bf16 regime; training (autograd, train-mode batch statistics)
+stays on the torch path (``policy.AttentionModelEncoder.forward``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from .cache import EMBED_DIM, FoldedCache, fold_weights
+
+_vp, _i32, _i64 = C.c_void_p, C.c_int32, C.c_int64
+
+
+class AmEncoderArgs(C.Structure):
+    """Mirror of ``struct rl4co_am_encoder_args`` (field order and types must match the header)."""
+
+    _fields_ = [
+        ("env", _i32), ("B", _i32), ("N", _i32), ("num_layers", _i32), ("norm", _i32), ("cache_dtype", _i32),
+        ("locs", _vp), ("demand", _vp), ("w_init", _vp), ("b_init", _vp), ("w_depot", _vp), ("b_depot", _vp),
+        ("wqkv_packed", _vp), ("bqkv", _vp), ("wo_packed", _vp), ("bo", _vp), ("n1_scale", _vp), ("n1_shift", _vp),
+        ("w1_packed", _vp), ("b1", _vp), ("w2_packed", _vp), ("b2", _vp), ("n2_scale", _vp), ("n2_shift", _vp),
+        ("wfold_packed", _vp), ("w_fixed", _vp),
+        ("kvl", _vp), ("kvl_plane_stride", _i64), ("kvl_batch_stride", _i64),
+        ("ctx_first", _vp), ("ctx_cur", _vp), ("q_bias", _vp), ("hidden", _vp),
+    ]
+
+
+def pack_weight(w: Tensor) -> Tensor:
+    """nn.Linear weight [out,in] -> bf16 [out/32, in/16, 64, 8] in MFMA fragment order:
+    lane = 32*hi + row, element s = W[32*tile + row][16*kstep + 8*hi + s]."""
+    out_f, in_f = w.shape
+    assert out_f % 32 == 0 and in_f % 16 == 0, (out_f, in_f)
+    t = w.detach().to(torch.bfloat16).view(out_f // 32, 32, in_f // 16, 2, 8)  # [tile,row,ks,hi,s]
+    return t.permute(0, 2, 3, 1, 4).contiguous().view(out_f // 32, in_f // 16, 64, 8)
+
+
+def _norm_affine(norm_module) -> tuple[Tensor, Tensor, int]:
+    """(scale, shift, kind): eval-mode batch norm folded to an affine; instance norm -> gamma/beta."""
+    n = norm_module.normalizer
+    if norm_module.kind == "batch":
+        scale = n.weight.detach().float() * torch.rsqrt(n.running_var.float() + n.eps)
+        shift = n.bias.detach().float() - n.running_mean.float() * scale
+        return scale, shift, 0
+    if norm_module.kind == "instance":
+        return n.weight.detach().float(), n.bias.detach().float(), 1
+    raise NotImplementedError("fused encoder supports batch (eval) and instance normalisation")
+
+
+class PackedEncoder:
+    """Device-resident packed parameters of one policy, rebuilt when any parameter changes."""
+
+    def __init__(self, policy):
+        self.policy = policy
+        self.version = None
+        self.t: dict[str, Tensor] = {}
+
+    def _current_version(self):
+        pol = self.policy
+        tensors = list(pol.parameters()) + list(pol.buffers())
+        return (tuple(p._version for p in tensors), tensors[0].device, pol.training)
+
+    def refresh(self) -> dict[str, Tensor]:
+        ver = self._current_version()
+        if ver == self.version:
+            return self.t
+        pol = self.policy
+        enc, dec = pol.encoder, pol.decoder
+        layers = list(enc.net.layers)
+        f32 = lambda x: x.detach().float().contiguous()  # noqa: E731
+        t: dict[str, Tensor] = {}
+        ie = enc.init_embedding
+        t["w_init"], t["b_init"] = f32(ie.init_embed.weight), f32(ie.init_embed.bias)
+        if pol.env_name == "cvrp":
+            t["w_depot"], t["b_depot"] = f32(ie.init_embed_depot.weight), f32(ie.init_embed_depot.bias)
+        t["wqkv"] = torch.stack([pack_weight(l[0].module.Wqkv.weight) for l in layers]).contiguous()
+        t["bqkv"] = torch.stack([f32(l[0].module.Wqkv.bias) for l in layers]).contiguous()
+        t["wo"] = torch.stack([pack_weight(l[0].module.out_proj.weight) for l in layers]).contiguous()
+        t["bo"] = torch.stack([f32(l[0].module.out_proj.bias) for l in layers]).contiguous()
+        t["w1"] = torch.stack([pack_weight(l[2].module.lins[0].weight) for l in layers]).contiguous()
+        t["b1"] = torch.stack([f32(l[2].module.lins[0].bias) for l in layers]).contiguous()
+        t["w2"] = torch.stack([pack_weight(l[2].module.lins[1].weight) for l in layers]).contiguous()
+        t["b2"] = torch.stack([f32(l[2].module.lins[1].bias) for l in layers]).contiguous()
+        kinds = set()
+        for name, idx in (("n1", 1), ("n2", 3)):
+            sc, sh = [], []
+            for l in layers:
+                a, b, k = _norm_affine(l[idx])
+                sc.append(a), sh.append(b), kinds.add(k)
+            t[f"{name}_scale"], t[f"{name}_shift"] = torch.stack(sc).contiguous(), torch.stack(sh).contiguous()
+        assert len(kinds) == 1
+        self.norm_kind = kinds.pop()
+        w_ctx = dec.context_embedding.project_context.weight.detach().float()
+        blocks = fold_weights(pol.env_name, dec.project_node_embeddings.weight.detach().float(),
+                              dec.pointer.project_out.weight.detach().float(), w_ctx)
+        t["wfold"] = torch.stack([pack_weight(b) for b in blocks]).contiguous()
+        t["w_fixed"] = f32(dec.project_fixed_context.weight) if dec.use_graph_context else None
+        if pol.env_name == "tsp":
+            t["q_step0"] = torch.mv(w_ctx, dec.context_embedding.W_placeholder.detach().float()).contiguous()
+            t["w_cap"] = None
+        else:
+            t["q_step0"] = None
+            t["w_cap"] = w_ctx[:, EMBED_DIM].contiguous()
+        self.num_layers = len(layers)
+        self.t, self.version = t, ver
+        return t
+
+    def supported(self, td) -> bool:
+        pol = self.policy
+        n = td["action_mask"].shape[-1]
+        if n > _lib.lib().rl4co_am_encoder_max_nodes():
+            return False
+        kind = pol.encoder.net.layers[0][1].kind
+        if kind == "batch" and pol.training:  # batch statistics couple instances: torch path
+            return False
+        return kind in ("batch", "instance") and td["locs"].is_cuda
+
+    def encode(self, td, cache_dtype: torch.dtype, want_hidden: bool = False) -> tuple[FoldedCache, Tensor | None]:
+        t = self.refresh()
+        pol = self.policy
+        locs = td["locs"]
+        if locs.dtype != torch.float32 or not locs.is_contiguous():
+            locs = locs.float().contiguous()
+        b, n, _ = locs.shape
+        dev = locs.device
+        d = EMBED_DIM
+        kvl = torch.empty((3, b, n, d), dtype=cache_dtype, device=dev)
+        ctx_cur = torch.empty((b, n, d), dtype=torch.float32, device=dev)
+        ctx_first = torch.empty((b, n, d), dtype=torch.float32, device=dev) if pol.env_name == "tsp" else None
+        q_bias = torch.empty((b, d), dtype=torch.float32, device=dev) if t["w_fixed"] is not None else None
+        hidden = torch.empty((b, n, d), dtype=torch.float32, device=dev) if want_hidden else None
+        a = AmEncoderArgs()
+        a.env = _lib.ENV_TSP if pol.env_name == "tsp" else _lib.ENV_CVRP
+        a.B, a.N, a.num_layers, a.norm = b, n, self.num_layers, self.norm_kind
+        a.cache_dtype = _lib.DT_BF16 if cache_dtype == torch.bfloat16 else _lib.DT_F32
+        a.locs = locs.data_ptr()
+        ptr = lambda x: None if x is None else x.data_ptr()  # noqa: E731
+        if pol.env_name == "cvrp":
+            demand = td["demand"].float().contiguous()
+            a.demand, a.w_depot, a.b_depot = demand.data_ptr(), ptr(t["w_depot"]), ptr(t["b_depot"])
+        a.w_init, a.b_init = ptr(t["w_init"]), ptr(t["b_init"])
+        a.wqkv_packed, a.bqkv, a.wo_packed, a.bo = ptr(t["wqkv"]), ptr(t["bqkv"]), ptr(t["wo"]), ptr(t["bo"])
+        a.n1_scale, a.n1_shift, a.n2_scale, a.n2_shift = (ptr(t[k]) for k in ("n1_scale", "n1_shift", "n2_scale", "n2_shift"))
+        a.w1_packed, a.b1, a.w2_packed, a.b2 = ptr(t["w1"]), ptr(t["b1"]), ptr(t["w2"]), ptr(t["b2"])
+        a.wfold_packed, a.w_fixed = ptr(t["wfold"]), ptr(t["w_fixed"])
+        a.kvl, a.kvl_plane_stride, a.kvl_batch_stride = kvl.data_ptr(), kvl.stride(0), kvl.stride(1)
+        a.ctx_first, a.ctx_cur, a.q_bias, a.hidden = ptr(ctx_first), ptr(ctx_cur), ptr(q_bias), ptr(hidden)
+        st = _lib.lib().rl4co_am_encoder(C.byref(a), torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "rl4co_am_encoder")
+        cache = FoldedCache(pol.env_name, kvl, ctx_first, ctx_cur, q_bias, t["q_step0"], t["w_cap"])
+        return cache, hidden

@@ -257,7 +257,7 @@ class AttentionModelPolicy(nn.Module):
                  temperature: float = 1.0, tanh_clipping: float = 10.0, mask_logits: bool = True,
                  train_decode_type: str = "sampling", val_decode_type: str = "greedy",
                  test_decode_type: str = "greedy", cache_dtype: torch.dtype = torch.float32,
-                 encoder_autocast: torch.dtype | None = None, **unused_kwargs):
+                 encoder_autocast: torch.dtype | None = None, fused_encoder: bool = True, **unused_kwargs):
         super().__init__()
         if isinstance(env_name, RL4COEnvBase):
             env_name = env_name.name
@@ -276,11 +276,22 @@ class AttentionModelPolicy(nn.Module):
         self.test_decode_type = test_decode_type
         self.cache_dtype = cache_dtype
         self.encoder_autocast = encoder_autocast
+        # inference rollouts in the bf16 regime run encoder + cache fold in ONE hand-written MFMA
+        # kernel (csrc/am_encoder.hip); fp32 parity runs and training stay on the torch encoder
+        self.fused_encoder = fused_encoder
+        self._packed = None
         self._philox_calls = 0
         self.last_instance_steps = 0
         self.decode_events: list | None = None  # set to [] by bench.py to time the decode launches
 
     # -- helpers --------------------------------------------------------------------------------
+    def _packed_encoder(self):
+        if self._packed is None:
+            from .encoder import PackedEncoder
+
+            self._packed = PackedEncoder(self)
+        return self._packed
+
     def _encode(self, td):
         if self.encoder_autocast is not None:
             with torch.autocast("cuda", dtype=self.encoder_autocast):
@@ -325,7 +336,15 @@ class AttentionModelPolicy(nn.Module):
                 return_hidden: bool = False, return_init_embeds: bool = False,
                 return_sum_log_likelihood: bool = True, actions: Tensor | None = None,
                 max_steps: int = 1_000_000, **decoding_kwargs) -> dict:
-        hidden, init_embeds = self._encode(td)
+        grad_path = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        use_fused = (self.fused_encoder and self.encoder_autocast == torch.bfloat16 and not grad_path
+                     and not return_init_embeds and self._packed_encoder().supported(td))
+        if use_fused:
+            cache, hidden = self._packed_encoder().encode(td, self.cache_dtype, want_hidden=return_hidden)
+            init_embeds = None
+        else:
+            cache = None
+            hidden, init_embeds = self._encode(td)
         if isinstance(env, str) or env is None:
             env = get_env(self.env_name if env is None else env)
 
@@ -357,12 +376,13 @@ class AttentionModelPolicy(nn.Module):
         else:
             n_rep = 0
 
-        device = hidden.device
+        device = td["action_mask"].device
         b_inst, n = td["action_mask"].shape[0], td["action_mask"].shape[-1]
         b = b_inst * max(n_rep, 1)
-        with torch.no_grad():
-            cache = self.decoder.precompute_cache(hidden.detach(), self.cache_dtype,
-                                                  self.encoder_autocast or torch.float32)
+        if cache is None:
+            with torch.no_grad():
+                cache = self.decoder.precompute_cache(hidden.detach(), self.cache_dtype,
+                                                      self.encoder_autocast or torch.float32)
         state = self._initial_state(td, n_rep)
         horizon = min(self._max_horizon(self.env_name, n), max_steps)
         err = K.new_error_word(device)
@@ -435,7 +455,7 @@ class AttentionModelPolicy(nn.Module):
         if calc_reward:
             td_out.set("reward", reward)
 
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if grad_path:
             step_logps = self.evaluate_log_probs(td, hidden, out_actions, n_rep, tanh_clipping, temperature,
                                                  mask_logits, skip_first=(t0 == 1))
         else:

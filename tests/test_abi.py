@@ -33,16 +33,36 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in handle.rl4co_version()
 
 
-def test_struct_layout_matches_header():
-    """Field order of the ctypes mirror == field order in the C struct."""
-    from rl4co_amd import _lib
-
-    body = re.search(r"typedef struct rl4co_am_decode_args \{(.*?)\} rl4co_am_decode_args;", HEADER, re.S).group(1)
+def _c_fields(struct_name):
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct_name, struct_name), HEADER, re.S).group(1)
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    c_fields = re.findall(r"(\w+)\s*;", body)
-    py_fields = [f[0] for f in _lib.AmDecodeArgs._fields_]
-    assert c_fields == py_fields
+    return re.findall(r"(\w+)\s*;", body)
+
+
+def test_struct_layout_matches_header():
+    """Field order of the ctypes mirrors == field order in the C structs."""
+    from rl4co_amd import _lib
+    from rl4co_amd.encoder import AmEncoderArgs
+
+    assert _c_fields("rl4co_am_decode_args") == [f[0] for f in _lib.AmDecodeArgs._fields_]
     assert ctypes.sizeof(_lib.AmDecodeArgs) % 8 == 0
+    assert _c_fields("rl4co_am_encoder_args") == [f[0] for f in AmEncoderArgs._fields_]
+    assert ctypes.sizeof(AmEncoderArgs) == 6 * 4 + 27 * 8
+
+
+def test_weight_packing_is_the_documented_fragment_order():
+    """pack_weight: [out/32][in/16][lane = 32*hi + row][s] = W[32*tile + row][16*kstep + 8*hi + s]."""
+    import torch
+
+    from rl4co_amd.encoder import pack_weight
+
+    w = torch.arange(64 * 48, dtype=torch.float32).view(64, 48) / 8.0  # exactly representable in bf16? use small ints
+    w = (torch.arange(64 * 48) % 251).float().view(64, 48)
+    p = pack_weight(w).float()
+    assert p.shape == (2, 3, 64, 8)
+    for tile, ks, lane, s in [(0, 0, 0, 0), (1, 2, 63, 7), (0, 1, 37, 3), (1, 0, 31, 5), (1, 1, 32, 0)]:
+        row, hi = lane & 31, lane >> 5
+        assert p[tile, ks, lane, s] == w[32 * tile + row, 16 * ks + 8 * hi + s]
 
 
 def test_argument_validation_without_gpu():

@@ -1,0 +1,139 @@
+"""GPU: fused MFMA encoder + cache fold (csrc/am_encoder.hip) vs the torch encoder.
+
+Floating-point kernel => tolerance test, tolerance stated here: the kernel computes with bf16 MFMA
+inputs / fp32 accumulation / a bf16 residual stream, i.e. the same precision regime as the
+reference under its default mixed-precision autocast (utils/trainer.py:57). Against the fp32 torch
+encoder + fp32 fold of the SAME weights every output (three cache planes, context tables, graph
+context, final embeddings) must be within 3e-2 relative Frobenius error, and no worse than 2.5x
+the error torch's own bf16 autocast path makes on the same inputs.
+"""
+import pytest
+import torch
+
+from tests.helpers import GoldenCase
+
+pytestmark = pytest.mark.gpu
+
+REL_TOL = 3e-2
+
+
+def _rel(a, b):
+    a, b = a.float(), b.float()
+    return float((a - b).norm() / b.norm())
+
+
+def _policy(g, **kw):
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    pk = dict(g.meta["policy_kwargs"])
+    pk.pop("sdpa_fn_decoder", None)
+    pol = AttentionModelPolicy(env_name=g.env_name, **pk, **kw).eval()
+    pol.load_state_dict(g.policy.state_dict(), strict=True)
+    return pol.cuda()
+
+
+def _td(g):
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.tensordict import TensorDict
+
+    env = get_env(g.env_name, generator_params=dict(num_loc=g.num_loc), device="cuda")
+    return env, env.reset(TensorDict({k: v.clone() for k, v in g.data.items()}, batch_size=[g.batch]))
+
+
+def _perturb_norm_stats(pol):
+    """Untrained batch norm has running stats (0, 1): make the folded affine non-trivial."""
+    gen = torch.Generator().manual_seed(5)
+    for m in pol.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen).cuda() * 0.1)
+            m.running_var.copy_((torch.rand(m.running_var.shape, generator=gen).cuda() + 0.5))
+            m.weight.data.copy_(torch.rand(m.weight.shape, generator=gen).cuda() + 0.5)
+            m.bias.data.copy_(torch.randn(m.bias.shape, generator=gen).cuda() * 0.1)
+
+
+@pytest.mark.parametrize("name", ["tsp20_b64_greedy_simple", "tsp50_b64_greedy", "tsp100_b64_greedy",
+                                  "cvrp20_b128_greedy", "cvrp100_b64_greedy", "pomo_tsp50_b8_mssampling",
+                                  "pomo_cvrp20_b16_msgreedy"])
+@pytest.mark.parametrize("cache_dtype", [torch.bfloat16, torch.float32], ids=["bf16", "f32"])
+def test_fused_encoder_matches_torch(name, cache_dtype):
+    g = GoldenCase(name)
+    pol = _policy(g, encoder_autocast=torch.bfloat16, cache_dtype=cache_dtype)
+    _perturb_norm_stats(pol)
+    env, td = _td(g)
+    packed = pol._packed_encoder()
+    assert packed.supported(td)
+    with torch.inference_mode():
+        cache, hidden = packed.encode(td, cache_dtype, want_hidden=True)
+        torch.cuda.synchronize()
+        h32, _ = pol.encoder(td)  # fp32 torch encoder, same weights
+        ref = pol.decoder.precompute_cache(h32, torch.float32, torch.float32)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            h16, _ = pol.encoder(td)
+        auto = pol.decoder.precompute_cache(h16, cache_dtype, torch.bfloat16)
+    checks = {"hidden": (hidden, h32, h16.float())}
+    for i, nm in enumerate(("glimpse_key", "glimpse_val", "logit_key")):
+        checks[nm] = (cache.kvl[i], ref.kvl[i], auto.kvl[i])
+    checks["ctx_cur"] = (cache.ctx_cur, ref.ctx_cur, auto.ctx_cur)
+    if g.env_name == "tsp":
+        checks["ctx_first"] = (cache.ctx_first, ref.ctx_first, auto.ctx_first)
+    if ref.q_bias is not None:
+        checks["q_bias"] = (cache.q_bias, ref.q_bias, auto.q_bias)
+    else:
+        assert cache.q_bias is None
+    for nm, (got, want, autoc) in checks.items():
+        assert torch.isfinite(got.float()).all(), nm
+        e_fused, e_auto = _rel(got, want), _rel(autoc, want)
+        assert e_fused <= REL_TOL, f"{nm}: fused rel err {e_fused:.4f}"
+        assert e_fused <= 2.5 * e_auto + 2e-3, f"{nm}: fused {e_fused:.4f} vs torch-autocast {e_auto:.4f}"
+    if g.env_name == "tsp":
+        assert torch.equal(cache.q_step0, ref.q_step0)
+    else:
+        assert torch.equal(cache.w_cap, ref.w_cap)
+
+
+def test_fused_encoder_rollout_quality_full_size():
+    """TSP-100 x 4096 greedy with the fused encoder: valid tours, mean tour length within 0.5 % of
+    the fp32 reference's (bf16 regime), and the policy actually took the fused path."""
+    g = GoldenCase("c2_tsp100_b4096_greedy")
+    pol = _policy(g, encoder_autocast=torch.bfloat16, cache_dtype=torch.bfloat16)
+    env, td = _td(g)
+    calls = []
+    orig = pol._packed_encoder().encode
+    pol._packed_encoder().encode = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    with torch.inference_mode():
+        out = pol(td, env, phase="test")
+    assert calls, "fused encoder was not used"
+    reward = out["reward"].cpu()
+    assert abs(float(reward.mean() - g.reward.mean())) <= 5e-3 * abs(float(g.reward.mean()))
+    pol2 = _policy(g, encoder_autocast=torch.bfloat16, cache_dtype=torch.bfloat16, fused_encoder=False)
+    with torch.inference_mode():
+        out2 = pol2(td, env, phase="test")
+    assert abs(float(out2["reward"].mean() - out["reward"].mean())) <= 2e-3 * abs(float(g.reward.mean()))
+
+
+def test_fused_encoder_not_used_for_training_or_fp32():
+    g = GoldenCase("tsp20_b64_greedy_simple")
+    env, td = _td(g)
+    for kw, phase in ((dict(encoder_autocast=None), "test"), (dict(encoder_autocast=torch.bfloat16), "train")):
+        pol = _policy(g, **kw)
+        if phase == "train":
+            pol.train()
+        pol._packed_encoder().encode = lambda *a, **k: (_ for _ in ()).throw(AssertionError("fused path taken"))
+        if phase == "train":
+            out = pol(td, env, phase="train", seed=1)
+            assert out["log_likelihood"].requires_grad
+        else:
+            with torch.inference_mode():
+                pol(td, env, phase="test")
+
+
+def test_packed_weights_refresh_after_update():
+    g = GoldenCase("tsp20_b64_greedy_simple")
+    pol = _policy(g, encoder_autocast=torch.bfloat16)
+    env, td = _td(g)
+    with torch.inference_mode():
+        c1, _ = pol._packed_encoder().encode(td, torch.float32)
+        with torch.no_grad():
+            pol.encoder.net.layers[0][0].module.Wqkv.weight.mul_(1.5)
+        c2, _ = pol._packed_encoder().encode(td, torch.float32)
+    assert not torch.equal(c1.kvl, c2.kvl)
