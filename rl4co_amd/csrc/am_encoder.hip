@@ -36,6 +36,7 @@ constexpr int kD = RL4CO_EMBED_DIM;
 constexpr int kFF = 512;
 constexpr int kRS = kD + 8;  // LDS row stride (bf16 elements): 272 B rows spread the banks
 constexpr int kThreads = 256;
+constexpr float kQScale = 0.25f * 1.44269504088896341f;  // head_dim^-1/2 * log2(e)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -73,20 +74,34 @@ __device__ inline bf16x8 load_x(const __bf16* xs, int tt, int ks, int l31, int h
   return *reinterpret_cast<const bf16x8*>(xs + (32 * tt + l31) * kRS + 16 * ks + 8 * hi);
 }
 
-// Out^T tile (32 dims x 32*TT tokens) += W[tile] . X^T over ksteps [k0, k0 + nk)
-template <int TT>
+// Out^T tile (32 dims x 32*TT tokens) += W[tile] . X^T over 8 ksteps starting at weight kstep k0.
+// All 8 weight fragments are requested up front (8 x 1 KiB per wave in flight from L2) and the
+// LDS activation fragments are double-buffered one kstep ahead, so the MFMA pipe is not stalled
+// by a load at every kstep (one wave per SIMD: there is no other wave to hide the latency).
+template <int TT, bool W_IS_A = true>
 __device__ inline void gemm_t(f32x16 (&acc)[TT], const __bf16* packed, int ksteps_total, int tile, int k0,
-                              int nk, int kx0, const __bf16* xs, int lane) {
+                              const __bf16* xs, int lane) {
   const int l31 = lane & 31, hi = lane >> 5;
-  bf16x8 wn = load_w(packed, ksteps_total, tile, k0, lane);
-  for (int ks = 0; ks < nk; ++ks) {
-    const bf16x8 wf = wn;
-    if (ks + 1 < nk) wn = load_w(packed, ksteps_total, tile, k0 + ks + 1, lane);
-    bf16x8 xf[TT];
+  bf16x8 wf[8];
 #pragma unroll
-    for (int tt = 0; tt < TT; ++tt) xf[tt] = load_x(xs, tt, kx0 + ks, l31, hi);
+  for (int ks = 0; ks < 8; ++ks) wf[ks] = load_w(packed, ksteps_total, tile, k0 + ks, lane);
+  bf16x8 xa[TT], xb[TT];
 #pragma unroll
-    for (int tt = 0; tt < TT; ++tt) acc[tt] = mfma(wf, xf[tt], acc[tt]);
+  for (int tt = 0; tt < TT; ++tt) xa[tt] = load_x(xs, tt, 0, l31, hi);
+#pragma unroll
+  for (int ks = 0; ks < 8; ks += 2) {
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) xb[tt] = load_x(xs, tt, ks + 1, l31, hi);
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+      acc[tt] = W_IS_A ? mfma(wf[ks], xa[tt], acc[tt]) : mfma(xa[tt], wf[ks], acc[tt]);
+    if (ks + 2 < 8) {
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) xa[tt] = load_x(xs, tt, ks + 2, l31, hi);
+    }
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+      acc[tt] = W_IS_A ? mfma(wf[ks + 1], xb[tt], acc[tt]) : mfma(xb[tt], wf[ks + 1], acc[tt]);
   }
 }
 
@@ -227,17 +242,18 @@ __global__ void __launch_bounds__(kThreads) am_encoder_kernel(const rl4co_am_enc
       f32x16 acc[TT];
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) acc[tt] = zero16();
-      gemm_t<TT>(acc, L.wqkv, 8, w, 0, 8, 0, xs, lane);
+      gemm_t<TT>(acc, L.wqkv, 8, w, 0, xs, lane);
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tt][r] += L.bqkv[32 * w + rowmap(r, hi)];
+        // 1/sqrt(16) and log2(e) folded into Q: softmax below is exp2(s - max)
+        for (int r = 0; r < 16; ++r) acc[tt][r] = (acc[tt][r] + L.bqkv[32 * w + rowmap(r, hi)]) * kQScale;
         qf[tt][0] = frag_from_acc(acc[tt], 0);
         qf[tt][1] = frag_from_acc(acc[tt], 1);
       }
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) acc[tt] = zero16();
-      gemm_t<TT>(acc, L.wqkv, 8, 4 + w, 0, 8, 0, xs, lane);
+      gemm_t<TT>(acc, L.wqkv, 8, 4 + w, 0, xs, lane);
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
 #pragma unroll
@@ -248,18 +264,7 @@ __global__ void __launch_bounds__(kThreads) am_encoder_kernel(const rl4co_am_enc
       // V = X . Wv^T: A = token rows from LDS, B = weight fragment -> C[row = token][col = dim]
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) acc[tt] = zero16();
-      {
-        bf16x8 wn = load_w(L.wqkv, 8, 8 + w, 0, lane);
-        for (int ks = 0; ks < 8; ++ks) {
-          const bf16x8 wf = wn;
-          if (ks + 1 < 8) wn = load_w(L.wqkv, 8, 8 + w, ks + 1, lane);
-          bf16x8 xf[TT];
-#pragma unroll
-          for (int tt = 0; tt < TT; ++tt) xf[tt] = load_x(xs, tt, ks, l31, hi);
-#pragma unroll
-          for (int tt = 0; tt < TT; ++tt) acc[tt] = mfma(xf[tt], wf, acc[tt]);
-        }
-      }
+      gemm_t<TT, false>(acc, L.wqkv, 8, 8 + w, 0, xs, lane);
       const float bv = L.bqkv[2 * kD + 32 * w + l31];
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
@@ -284,13 +289,13 @@ __global__ void __launch_bounds__(kThreads) am_encoder_kernel(const rl4co_am_enc
 #pragma unroll
           for (int kt = 0; kt < TT; ++kt) {
             s[kt] = mfma(kf[kt][hh], qf[qt][hh], zero16());
+            if (kt == TT - 1) {  // TT = ceil(N/32): only the last key tile can hold padding keys
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int key = 32 * kt + rowmap(r, hi);
-              const float sv = (key < N) ? s[kt][r] * 0.25f : -__builtin_huge_valf();  // 1/sqrt(16)
-              s[kt][r] = sv;
-              m = fmaxf(m, sv);
+              for (int r = 0; r < 16; ++r)
+                s[kt][r] = (32 * kt + rowmap(r, hi) < N) ? s[kt][r] : -__builtin_huge_valf();
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, s[kt][r]);
           }
           m = fmaxf(m, __shfl_xor(m, 32, 64));
           float l = 0.0f;
@@ -298,7 +303,7 @@ __global__ void __launch_bounds__(kThreads) am_encoder_kernel(const rl4co_am_enc
           for (int kt = 0; kt < TT; ++kt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-              const float p = __expf(s[kt][r] - m);
+              const float p = __builtin_amdgcn_exp2f(s[kt][r] - m);
               s[kt][r] = p;
               l += p;
             }
@@ -324,7 +329,7 @@ __global__ void __launch_bounds__(kThreads) am_encoder_kernel(const rl4co_am_enc
       f32x16 y[TT];
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) y[tt] = zero16();
-      gemm_t<TT>(y, L.wo, 8, w, 0, 8, 0, ys, lane);
+      gemm_t<TT>(y, L.wo, 8, w, 0, ys, lane);
       residual_norm<TT>(xs, y, 32 * w, L.bo, L.n1a, L.n1b, a.norm, N, lane);
     }
     __syncthreads();
@@ -339,14 +344,14 @@ __global__ void __launch_bounds__(kThreads) am_encoder_kernel(const rl4co_am_enc
         f32x16 h1[TT];
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) h1[tt] = zero16();
-        gemm_t<TT>(h1, L.w1, 8, 4 * c + w, 0, 8, 0, xs, lane);
+        gemm_t<TT>(h1, L.w1, 8, 4 * c + w, 0, xs, lane);
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) h1[tt][r] = fmaxf(h1[tt][r] + L.b1[32 * (4 * c + w) + rowmap(r, hi)], 0.0f);
         store_t<TT>(hb, h1, 32 * w, lane);
         __syncthreads();
-        gemm_t<TT>(y2, L.w2, 32, w, 8 * c, 8, 0, hb, lane);
+        gemm_t<TT>(y2, L.w2, 32, w, 8 * c, hb, lane);
       }
       residual_norm<TT>(xs, y2, 32 * w, L.b2, L.n2a, L.n2b, a.norm, N, lane);
     }
@@ -366,7 +371,7 @@ __global__ void __launch_bounds__(kThreads) am_encoder_kernel(const rl4co_am_enc
     f32x16 acc[TT];
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) acc[tt] = zero16();
-    gemm_t<TT>(acc, wf_all + (int64_t)blk * kD * kD, 8, w, 0, 8, 0, xs, lane);
+    gemm_t<TT>(acc, wf_all + (int64_t)blk * kD * kD, 8, w, 0, xs, lane);
     if (blk < 3 && a.cache_dtype == RL4CO_DT_BF16) {
       __bf16* out = static_cast<__bf16*>(a.kvl) + (int64_t)blk * a.kvl_plane_stride + (int64_t)b * a.kvl_batch_stride;
 #pragma unroll
