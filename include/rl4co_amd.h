@@ -53,6 +53,11 @@ extern "C" {
 #define RL4CO_DT_F32 0
 #define RL4CO_DT_BF16 1
 
+/* kernel variants of rl4co_am_decode (same results up to the documented summation tree) */
+#define RL4CO_VARIANT_AUTO 0
+#define RL4CO_VARIANT_STREAM 1 /* planes streamed from HBM every step, 1 wave per trajectory     */
+#define RL4CO_VARIANT_LDS 2    /* bf16 planes loaded into LDS once per rollout, 4 waves / trajectory */
+
 #define RL4CO_EMBED_DIM 128 /* the engine is specialised for the AM default d=128, H=8 */
 #define RL4CO_NUM_HEADS 8
 
@@ -157,7 +162,7 @@ typedef struct rl4co_am_decode_args {
   float temperature;   /* 1.0 default                                            */
   /* folded cache */
   int32_t cache_dtype; /* RL4CO_DT_F32 | RL4CO_DT_BF16 for the three planes      */
-  int32_t _pad0;
+  int32_t variant;     /* RL4CO_VARIANT_*: 0 = let the library choose              */
   const void* glimpse_key;
   const void* glimpse_val;
   const void* logit_key;
@@ -199,10 +204,12 @@ int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream);
 /* Bytes of LDS one trajectory needs for N nodes (for occupancy planning / tests). */
 int rl4co_am_decode_lds_bytes(int N, int env);
 
-/* Number of row groups G the kernel splits a trajectory's cache rows into for the given
- * cache dtype (row j -> group j % G). G fixes the fp32 summation tree of the glimpse
- * (am_decode.hip header), so the specified-order oracle asks for it instead of guessing. */
-int rl4co_am_decode_row_groups(int cache_dtype);
+/* Number of row groups G the kernel that will serve `args` splits a trajectory's cache rows
+ * into (row j -> group j % G). G fixes the fp32 summation tree of the glimpse (am_decode.hip
+ * header), so the specified-order oracle asks for it instead of guessing. -1 on bad args. */
+int rl4co_am_decode_row_groups(const rl4co_am_decode_args* args);
+/* The variant (RL4CO_VARIANT_STREAM / _LDS) rl4co_am_decode will run for `args`. */
+int rl4co_am_decode_variant(const rl4co_am_decode_args* args);
 
 /* --------------------------------------------------------------------------
  * a11-a13  fused encoder + decoder-cache fold on the matrix cores (inference rollouts).

@@ -14,6 +14,7 @@ RL4CO_OK = 0
 ENV_TSP, ENV_CVRP = 0, 1
 DECODE_GREEDY, DECODE_SAMPLE, DECODE_EVALUATE = 0, 1, 2
 DT_F32, DT_BF16 = 0, 1
+VARIANT_AUTO, VARIANT_STREAM, VARIANT_LDS = 0, 1, 2
 
 EBIT_NAN_LOGIT = 1
 EBIT_INFEASIBLE = 2
@@ -42,7 +43,7 @@ class AmDecodeArgs(C.Structure):
         ("env", _i32), ("B", _i32), ("B_inst", _i32), ("N", _i32),
         ("mode", _i32), ("max_steps", _i32), ("mask_inner", _i32), ("mask_logits", _i32),
         ("tanh_clipping", _f32), ("temperature", _f32),
-        ("cache_dtype", _i32), ("_pad0", _i32),
+        ("cache_dtype", _i32), ("variant", _i32),
         ("glimpse_key", _vp), ("glimpse_val", _vp), ("logit_key", _vp),
         ("kvl_row_stride", _i64), ("kvl_batch_stride", _i64),
         ("ctx_first", _vp), ("ctx_cur", _vp), ("q_bias", _vp), ("q_step0", _vp), ("w_cap", _vp),
@@ -71,7 +72,8 @@ SYMBOLS = {
     "rl4co_am_encoder": (C.c_int, [_vp, _vp]),
     "rl4co_am_encoder_max_nodes": (C.c_int, []),
     "rl4co_am_decode_lds_bytes": (C.c_int, [C.c_int, C.c_int]),
-    "rl4co_am_decode_row_groups": (C.c_int, [C.c_int]),
+    "rl4co_am_decode_row_groups": (C.c_int, [C.POINTER(AmDecodeArgs)]),
+    "rl4co_am_decode_variant": (C.c_int, [C.POINTER(AmDecodeArgs)]),
     "rl4co_select_start_nodes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "rl4co_hbm_read_probe": (C.c_int, [_vp, _i64, _vp, _vp]),
 }
@@ -105,6 +107,17 @@ def lib() -> C.CDLL:
         fn.restype = restype
         fn.argtypes = argtypes
     return handle
+
+
+def decode_row_groups(num_nodes: int, cache_dtype_id: int, max_steps: int, variant: int = VARIANT_AUTO) -> int:
+    """Row groups G (the glimpse summation tree) of the kernel variant that serves this shape —
+    a pure host query, usable without a GPU; the specified-order oracle mirrors it."""
+    a = AmDecodeArgs()
+    a.N, a.cache_dtype, a.max_steps, a.variant = int(num_nodes), int(cache_dtype_id), int(max_steps), int(variant)
+    g = lib().rl4co_am_decode_row_groups(C.byref(a))
+    if g <= 0:
+        raise Rl4coLibraryError(f"no decode kernel variant {variant} for N={num_nodes}, dtype id {cache_dtype_id}")
+    return g
 
 
 def check(status: int, what: str) -> None:

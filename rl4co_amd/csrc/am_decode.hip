@@ -370,6 +370,354 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
   }
 }
 
+// ================================================================================================
+// LDS-resident variant (bf16 planes, N small enough that one trajectory's three planes fit in
+// half a CU's LDS): the planes are read from HBM ONCE per rollout instead of once per decode
+// step and every step streams them from LDS. 4 waves per trajectory, 2 trajectories per CU.
+//
+// Same arithmetic contract as the streaming kernel with G = 16 row groups (row j -> wave
+// (j % 16) / 4, row group j % 4): per-group partial sums in ascending j, then the pairwise tree
+// — butterfly inside the wave, ((w0 + w1) + (w2 + w3)) across waves through LDS.
+// ================================================================================================
+constexpr int kLdsWaves = 4;
+constexpr int kLdsGroups = 16;
+
+__host__ __device__ inline int lds_variant_sc_rows(int N) { return N < 80 ? 80 : N; }
+__host__ __device__ inline int lds_variant_bytes(int N) {
+  const int nw = (N + 3) & ~3;
+  return 3 * N * kD * 2 + lds_variant_sc_rows(N) * kH * 4 + nw * 4 + kLdsWaves * kH * 4 + 32 + 2 * nw;
+}
+
+__device__ inline void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+template <int ENV>
+__global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const rl4co_am_decode_args a) {
+  using C = CacheBF16;
+  constexpr int EPL = 8, LPR = 16, LPH = 2;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, lane = tid & 63;
+  const int r = blockIdx.x;
+  const int N = a.N;
+  const int nw = (N + 3) & ~3;
+  uint16_t* planes = reinterpret_cast<uint16_t*>(smem);             // [3][N][128] bf16
+  float* sc = reinterpret_cast<float*>(planes + 3 * N * kD);        // [max(N,80)][8] scores; later o/l partials
+  float* lg = sc + lds_variant_sc_rows(N) * kH;                     // [nw] logits -> log-probs
+  float* mpart = lg + nw;                                           // [4][8] per-wave head maxima
+  int* shi = reinterpret_cast<int*>(mpart + kLdsWaves * kH);        // [8] broadcast: action, done
+  uint8_t* mk = reinterpret_cast<uint8_t*>(shi + 8);                // [nw] 1 = feasible
+  uint8_t* vis = mk + nw;                                           // [nw] CVRP visited
+
+  const int cb = r % a.B_inst;
+  const int rg = lane / LPR, li = lane % LPR, hd = li / LPH, e0 = li * EPL;
+  const uint16_t* Kg = planes + e0;
+  const uint16_t* Vg = planes + N * kD + e0;
+  const uint16_t* Kl = planes + 2 * N * kD + e0;
+  const float* ctxc = a.ctx_cur + (int64_t)cb * N * kD + e0;
+  const float* ctxf = (ENV == RL4CO_ENV_TSP) ? a.ctx_first + (int64_t)cb * N * kD + e0 : nullptr;
+  // o/l partial slots inside this wave's own (dead after pass 2) score rows
+  auto opart = [&](int wv, int d) -> float* { return sc + ((16 * (d >> 5) + 4 * wv) * kH) + (d & 31); };
+  auto lpart = [&](int wv, int h) -> float* { return sc + ((16 * 4 + 4 * wv) * kH) + h; };
+
+  // ---- planes HBM -> LDS, once per rollout (16-byte coalesced) --------------------------------
+  {
+    const uint16_t* src[3] = {static_cast<const uint16_t*>(a.glimpse_key), static_cast<const uint16_t*>(a.glimpse_val),
+                              static_cast<const uint16_t*>(a.logit_key)};
+    const int chunks = N * (kD / 8);  // 16-byte chunks per plane
+    for (int p = 0; p < 3; ++p) {
+      const uint16_t* g = src[p] + (int64_t)cb * a.kvl_batch_stride;
+      for (int c = tid; c < chunks; c += 64 * kLdsWaves) {
+        const int row = c >> 4, col = (c & 15) * 8;
+        *reinterpret_cast<uint4*>(planes + (p * N + row) * kD + col) =
+            *reinterpret_cast<const uint4*>(g + (int64_t)row * a.kvl_row_stride + col);
+      }
+    }
+  }
+  uint8_t* gmask = a.action_mask + (int64_t)r * N;
+  for (int j = tid; j < nw; j += 64 * kLdsWaves) mk[j] = (j < N) ? gmask[j] : (uint8_t)0;
+  if (ENV == RL4CO_ENV_CVRP) {
+    const uint8_t* gv = a.visited + (int64_t)r * N;
+    for (int j = tid; j < nw; j += 64 * kLdsWaves) vis[j] = (j < N) ? gv[j] : (uint8_t)1;
+  }
+  int cur = (int)a.current_node[r];
+  int first = (ENV == RL4CO_ENV_TSP) ? (int)a.first_node[r] : 0;
+  long long step_i = (ENV == RL4CO_ENV_TSP) ? a.step_i[r] : 0;
+  float used = (ENV == RL4CO_ENV_CVRP) ? a.used_capacity[r] : 0.0f;
+  const float cap = (ENV == RL4CO_ENV_CVRP) ? a.vehicle_capacity[r] : 0.0f;
+  const float* dem = (ENV == RL4CO_ENV_CVRP) ? a.demand + (int64_t)cb * (N - 1) : nullptr;
+  bool done = a.done[r] != 0;
+  __syncthreads();
+
+  float qb[EPL];
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) qb[e] = a.q_bias ? a.q_bias[(int64_t)cb * kD + e0 + e] : 0.0f;
+
+  const float sqrt_d = 11.3137084989847604f;
+  const bool single = a.max_steps == 1;
+  uint32_t errbits = 0;
+  float ent_acc = 0.0f;
+  int t = 0;
+  const int iters = (N + kLdsGroups - 1) / kLdsGroups;
+
+  for (; t < a.max_steps && (!done || single); ++t) {
+    // ---- query ---------------------------------------------------------------------------------
+    float q[EPL];
+    if (ENV == RL4CO_ENV_TSP) {
+      if (step_i < 1) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) q[e] = a.q_step0[e0 + e] + qb[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e)
+          q[e] = (ctxf[(int64_t)first * kD + e] + ctxc[(int64_t)cur * kD + e]) + qb[e];
+      }
+    } else {
+      const float rem = cap - used;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e)
+        q[e] = fmaf(a.w_cap[e0 + e], rem, ctxc[(int64_t)cur * kD + e]) + qb[e];
+    }
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) q[e] = q[e] * 0.25f;
+
+    // ---- pass 1: scores of this wave's rows ------------------------------------------------------
+    float m = kNegInf;
+#pragma unroll 4
+    for (int i = 0; i < iters; ++i) {
+      const int j = kLdsGroups * i + 4 * w + rg;
+      const bool valid = j < N;
+      float k[EPL];
+      C::cvt(valid ? *reinterpret_cast<const uint4*>(Kg + j * kD) : C::zero(), k);
+      float acc = 0.0f;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) acc = fmaf(q[e], k[e], acc);
+      acc = acc + rl4co::shfl_xor_f(acc, 1);
+      const bool feas = valid && (!a.mask_inner || mk[valid ? j : 0] != 0);
+      const float sv = feas ? acc : kNegInf;
+      if (valid && (li & 1) == 0) sc[j * kH + hd] = sv;
+      m = fmaxf(m, sv);
+    }
+    m = fmaxf(m, rl4co::shfl_xor_f(m, 16));
+    m = fmaxf(m, rl4co::shfl_xor_f(m, 32));
+    if (rg == 0 && (li & 1) == 0) mpart[w * kH + hd] = m;
+    __syncthreads();  // B1: all head maxima visible
+    m = fmaxf(fmaxf(mpart[hd], mpart[kH + hd]), fmaxf(mpart[2 * kH + hd], mpart[3 * kH + hd]));
+
+    // ---- pass 2: softmax weights and weighted values ---------------------------------------------
+    float l = 0.0f;
+    float o[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) o[e] = 0.0f;
+#pragma unroll 4
+    for (int i = 0; i < iters; ++i) {
+      const int j = kLdsGroups * i + 4 * w + rg;
+      const bool valid = j < N;
+      float v[EPL];
+      C::cvt(valid ? *reinterpret_cast<const uint4*>(Vg + j * kD) : C::zero(), v);
+      const float p = valid ? rl4co_expf(sc[j * kH + hd] - m) : 0.0f;
+      l = l + p;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) o[e] = fmaf(p, v[e], o[e]);
+    }
+#pragma unroll
+    for (int s = LPR; s < 64; s <<= 1) {
+      l = l + rl4co::shfl_xor_f(l, s);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) o[e] = o[e] + rl4co::shfl_xor_f(o[e], s);
+    }
+    if (rg == 0) {
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) *opart(w, e0 + e) = o[e];
+      if ((li & 1) == 0) *lpart(w, hd) = l;
+    }
+    __syncthreads();  // B2: partials of the four waves visible
+    l = (*lpart(0, hd) + *lpart(1, hd)) + (*lpart(2, hd) + *lpart(3, hd));
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) {
+      const int d = e0 + e;
+      o[e] = ((*opart(0, d) + *opart(1, d)) + (*opart(2, d) + *opart(3, d))) / l;
+    }
+
+    // ---- pass 3: logits of this wave's rows ---------------------------------------------------------
+#pragma unroll 4
+    for (int i = 0; i < iters; ++i) {
+      const int j = kLdsGroups * i + 4 * w + rg;
+      const bool valid = j < N;
+      float k[EPL];
+      C::cvt(valid ? *reinterpret_cast<const uint4*>(Kl + j * kD) : C::zero(), k);
+      float acc = 0.0f;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) acc = fmaf(o[e], k[e], acc);
+#pragma unroll
+      for (int s = 1; s < LPR; s <<= 1) acc = acc + rl4co::shfl_xor_f(acc, s);
+      if (valid && li == 0) lg[j] = acc;
+    }
+    __syncthreads();  // B3: all logits visible to wave 0
+
+    // ---- wave 0: log-softmax, selection, environment transition (same code as streaming) ----------
+    if (w == 0) {
+      bool nan_seen = false;
+      float zmax = kNegInf;
+      for (int j = lane; j < N; j += 64) {
+        float z = lg[j] / sqrt_d;
+        if (z != z) nan_seen = true;
+        if (a.tanh_clipping > 0.0f) z = rl4co_tanhf(z) * a.tanh_clipping;
+        if (a.mask_logits && mk[j] == 0) z = kNegInf;
+        z = z / a.temperature;
+        lg[j] = z;
+        zmax = fmaxf(zmax, z);
+      }
+      if (__any(nan_seen)) errbits |= RL4CO_EBIT_NAN_LOGIT;
+#pragma unroll
+      for (int s = 1; s < 64; s <<= 1) zmax = fmaxf(zmax, rl4co::shfl_xor_f(zmax, s));
+      float zsum = 0.0f;
+      for (int j = lane; j < N; j += 64) zsum = zsum + rl4co_expf(lg[j] - zmax);
+#pragma unroll
+      for (int s = 1; s < 64; s <<= 1) zsum = zsum + rl4co::shfl_xor_f(zsum, s);
+      const float lse = rl4co_logf(zsum);
+      float best = kNegInf;
+      int bi = 0x7fffffff;
+      float ent = 0.0f;
+      const int64_t tcol = (int64_t)a.t0 + t;
+      for (int j = lane; j < N; j += 64) {
+        const float lp = (lg[j] - zmax) - lse;
+        lg[j] = lp;
+        float key = lp;
+        if (a.mode == RL4CO_DECODE_SAMPLE) {
+          const float nz = a.exp_noise
+                               ? a.exp_noise[((int64_t)t * a.B + r) * N + j]
+                               : rl4co_exp1_noise(a.philox_seed, a.philox_offset + (uint64_t)tcol,
+                                                  (uint32_t)r, (uint32_t)j);
+          key = rl4co_expf(lp) / nz;
+        }
+        if (bi == 0x7fffffff || key > best) {
+          best = key;
+          bi = j;
+        }
+        if (a.entropy && lp > kNegInf) ent = fmaf(rl4co_expf(lp), lp, ent);
+        if (a.all_logps) a.all_logps[((int64_t)r * a.out_stride + tcol) * N + j] = lp;
+      }
+#pragma unroll
+      for (int s = 1; s < 64; s <<= 1) {
+        const float ov = rl4co::shfl_xor_f(best, s);
+        const int oi = rl4co::shfl_xor_i(bi, s);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) {
+          best = ov;
+          bi = oi;
+        }
+      }
+      if (a.entropy) {
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) ent = ent + rl4co::shfl_xor_f(ent, s);
+        ent_acc = ent_acc - ent;
+      }
+      if (a.mode == RL4CO_DECODE_EVALUATE) bi = (int)a.forced_actions[(int64_t)r * a.out_stride + tcol];
+      if (bi < 0 || bi >= N) {
+        errbits |= RL4CO_EBIT_INFEASIBLE;
+        bi = 0;
+      }
+      wave_lds_sync();
+      const float logp = lg[bi];
+      if (mk[bi] == 0) errbits |= RL4CO_EBIT_INFEASIBLE;
+      if (!(logp > -1000.0f)) errbits |= RL4CO_EBIT_NEG_INF_LOGP;
+      if (lane == 0) {
+        a.actions[(int64_t)r * a.out_stride + tcol] = bi;
+        a.logps[(int64_t)r * a.out_stride + tcol] = logp;
+      }
+      wave_lds_sync();
+      bool new_done;
+      if (ENV == RL4CO_ENV_TSP) {
+        if (lane == 0) mk[bi] = 0;
+        wave_lds_sync();
+        bool any_left = false;
+        for (int j = lane; j < N; j += 64) any_left |= mk[j] != 0;
+        new_done = !__any(any_left);
+      } else {
+        const int di = min(max(bi - 1, 0), N - 2);
+        const float used_next = (used + dem[di]) * (bi != 0 ? 1.0f : 0.0f);
+        if (lane == 0) vis[bi] = 1;
+        wave_lds_sync();
+        const float thr = cap + 1e-5f;
+        bool any_feasible = false, all_visited = true;
+        for (int j = lane; j < N; j += 64) {
+          all_visited &= vis[j] != 0;
+          if (j >= 1) {
+            const bool masked = (vis[j] != 0) || (dem[j - 1] + used_next > thr);
+            mk[j] = masked ? 0 : 1;
+            any_feasible |= !masked;
+          }
+        }
+        any_feasible = __any(any_feasible);
+        new_done = __all(all_visited);
+        if (lane == 0) mk[0] = ((bi == 0) && any_feasible) ? 0 : 1;
+      }
+      if (lane == 0) {
+        shi[0] = bi;
+        shi[1] = new_done ? 1 : 0;
+      }
+    }
+    __syncthreads();  // B4: action, done flag and the updated mask visible to every wave
+    {
+      const int bi = shi[0];
+      done = shi[1] != 0;
+      if (ENV == RL4CO_ENV_TSP) {
+        if (step_i == 0) first = bi;
+        cur = bi;
+        step_i += 1;
+      } else {
+        const int di = min(max(bi - 1, 0), N - 2);
+        used = (used + dem[di]) * (bi != 0 ? 1.0f : 0.0f);
+        cur = bi;
+      }
+    }
+  }
+  if (w == 0) {
+    if (!single && !done && t >= a.max_steps) errbits |= RL4CO_EBIT_MAX_STEPS;
+    for (int j = lane; j < N; j += 64) gmask[j] = mk[j];
+    if (ENV == RL4CO_ENV_CVRP) {
+      uint8_t* gv = a.visited + (int64_t)r * N;
+      for (int j = lane; j < N; j += 64) gv[j] = vis[j];
+    }
+    if (lane == 0) {
+      a.current_node[r] = cur;
+      a.done[r] = done ? 1 : 0;
+      if (ENV == RL4CO_ENV_TSP) {
+        a.first_node[r] = first;
+        a.step_i[r] = step_i;
+      } else {
+        a.used_capacity[r] = used;
+      }
+      if (a.n_steps) a.n_steps[r] = t;
+      if (a.entropy) a.entropy[r] += ent_acc;
+      if (errbits) atomicOr(a.err, (int)errbits);
+    }
+  }
+}
+
+template <int ENV>
+int launch_lds(const rl4co_am_decode_args& a, hipStream_t stream) {
+  const int lds = lds_variant_bytes(a.N);
+  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_decode_lds_kernel<ENV>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL((am_decode_lds_kernel<ENV>), dim3(a.B), dim3(64 * kLdsWaves), lds, stream, a);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
+// Which kernel serves these arguments: the LDS-resident one needs bf16 planes, a trajectory's
+// planes + scratch within half a CU's LDS (2 workgroups per CU) and enough steps to amortise
+// the one-off load.
+inline int resolve_variant(const rl4co_am_decode_args& a) {
+  const bool fits = a.cache_dtype == RL4CO_DT_BF16 && lds_variant_bytes(a.N) <= 80 * 1024;
+  if (a.variant == RL4CO_VARIANT_STREAM) return RL4CO_VARIANT_STREAM;
+  if (a.variant == RL4CO_VARIANT_LDS) return fits ? RL4CO_VARIANT_LDS : -1;
+  return (fits && a.max_steps >= 4) ? RL4CO_VARIANT_LDS : RL4CO_VARIANT_STREAM;
+}
+
 template <class C, int ENV>
 int launch(const rl4co_am_decode_args& a, hipStream_t stream) {
   const int lds = rl4co_am_decode_lds_bytes(a.N, ENV);
@@ -390,8 +738,16 @@ extern "C" int rl4co_am_decode_lds_bytes(int N, int env) {
   return Np * kH * 4 + Np * 4 + Np + Np;
 }
 
-extern "C" int rl4co_am_decode_row_groups(int cache_dtype) {
-  return cache_dtype == RL4CO_DT_BF16 ? 64 / (kD / CacheBF16::EPL) : 64 / (kD / CacheF32::EPL);
+extern "C" int rl4co_am_decode_row_groups(const rl4co_am_decode_args* args) {
+  if (args == nullptr) return -1;
+  const int v = resolve_variant(*args);
+  if (v < 0) return -1;
+  if (v == RL4CO_VARIANT_LDS) return kLdsGroups;
+  return args->cache_dtype == RL4CO_DT_BF16 ? 64 / (kD / CacheBF16::EPL) : 64 / (kD / CacheF32::EPL);
+}
+
+extern "C" int rl4co_am_decode_variant(const rl4co_am_decode_args* args) {
+  return args == nullptr ? -1 : resolve_variant(*args);
 }
 
 extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
@@ -416,7 +772,13 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
     RL4CO_REQUIRE(a.w_cap && a.demand && a.used_capacity && a.vehicle_capacity && a.visited);
   }
   RL4CO_REQUIRE(rl4co_am_decode_lds_bytes(a.N, a.env) <= 160 * 1024);
+  RL4CO_REQUIRE(a.variant >= RL4CO_VARIANT_AUTO && a.variant <= RL4CO_VARIANT_LDS);
+  const int variant = resolve_variant(a);
+  RL4CO_REQUIRE(variant >= 0);  // RL4CO_VARIANT_LDS requested but the planes do not fit / are not bf16
   hipStream_t s = rl4co::as_stream(stream);
+  if (variant == RL4CO_VARIANT_LDS) {
+    return a.env == RL4CO_ENV_TSP ? launch_lds<RL4CO_ENV_TSP>(a, s) : launch_lds<RL4CO_ENV_CVRP>(a, s);
+  }
   if (a.cache_dtype == RL4CO_DT_F32) {
     return a.env == RL4CO_ENV_TSP ? launch<CacheF32, RL4CO_ENV_TSP>(a, s)
                                   : launch<CacheF32, RL4CO_ENV_CVRP>(a, s);

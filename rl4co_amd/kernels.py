@@ -16,6 +16,12 @@ from .cache import FoldedCache
 
 MODE_IDS = {"greedy": _lib.DECODE_GREEDY, "sampling": _lib.DECODE_SAMPLE, "evaluate": _lib.DECODE_EVALUATE}
 ENV_IDS = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP}
+VARIANT_IDS = {"auto": _lib.VARIANT_AUTO, "stream": _lib.VARIANT_STREAM, "lds": _lib.VARIANT_LDS}
+
+
+def decode_row_groups(num_nodes: int, cache_dtype: torch.dtype, max_steps: int, variant: str = "auto") -> int:
+    dt = _lib.DT_BF16 if cache_dtype == torch.bfloat16 else _lib.DT_F32
+    return _lib.decode_row_groups(num_nodes, dt, max_steps, VARIANT_IDS[variant])
 
 
 def _ptr(t: Tensor | None) -> int | None:
@@ -167,6 +173,7 @@ def am_decode(
     all_logps: Tensor | None = None,
     entropy: Tensor | None = None,
     n_steps: Tensor | None = None,
+    variant: str = "auto",
 ) -> None:
     """Run ``max_steps`` fused decode steps (1 = a single step, >= horizon = whole rollout).
 
@@ -182,6 +189,7 @@ def am_decode(
     a.B, a.B_inst, a.N = b, cache.num_instances, n
     a.mode = MODE_IDS[mode]
     a.max_steps = int(max_steps)
+    a.variant = VARIANT_IDS[variant]
     a.mask_inner, a.mask_logits = int(mask_inner), int(mask_logits)
     a.tanh_clipping, a.temperature = float(tanh_clipping), float(temperature)
     kvl = _dev(cache.kvl, None, "cache.kvl")

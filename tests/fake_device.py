@@ -50,8 +50,12 @@ def _cvrp_check(actions, demand, vehicle_capacity, err):
 
 
 def _am_decode(cache, state, **kw):
-    dt = 1 if cache.kvl.dtype == torch.bfloat16 else 0
-    c_oracle.am_decode(cache, state, row_groups=4 if dt else 2, **kw)
+    from rl4co_amd import _lib
+
+    variant = {"auto": 0, "stream": 1, "lds": 2}[kw.pop("variant", "auto")]
+    dt = _lib.DT_BF16 if cache.kvl.dtype == torch.bfloat16 else _lib.DT_F32
+    groups = _lib.decode_row_groups(cache.num_nodes, dt, kw["max_steps"], variant)  # host-only query
+    c_oracle.am_decode(cache, state, row_groups=groups, **kw)
 
 
 @pytest.fixture

@@ -37,7 +37,7 @@ def _encode(g: GoldenCase):
     return td0, h
 
 
-def _run(K, backend, g, td0, h, mode, dtype=torch.float32, max_steps=None, **kw):
+def _run(K, backend, g, td0, h, mode, dtype=torch.float32, max_steps=None, variant="auto", **kw):
     """One rollout on ``backend`` in {"hip", "c"}; returns (actions, logps, state, n_steps, t)."""
     dev = "cuda" if backend == "hip" else "cpu"
     cache = fold_cache(g.policy, g.env_name, h, dtype, device="cuda")
@@ -68,12 +68,10 @@ def _run(K, backend, g, td0, h, mode, dtype=torch.float32, max_steps=None, **kw)
     steps = (tmax - t0) if max_steps is None else max_steps
     if backend == "hip":
         K.am_decode(cache, st, mode=mode, max_steps=steps, t0=t0, actions=actions, logps=logps, err=err,
-                    n_steps=n_steps, **kw)
+                    n_steps=n_steps, variant=variant, **kw)
         torch.cuda.synchronize()
     else:
-        from rl4co_amd import _lib
-
-        groups = _lib.lib().rl4co_am_decode_row_groups(_lib.DT_BF16 if dtype == torch.bfloat16 else _lib.DT_F32)
+        groups = K.decode_row_groups(n, dtype, steps, variant)
         c_oracle.am_decode(cache, st, mode=mode, max_steps=steps, t0=t0, actions=actions, logps=logps, err=err,
                            n_steps=n_steps, row_groups=groups, **kw)
     t = t0 + int(n_steps.max())
@@ -96,25 +94,30 @@ def _assert_bit_exact(hip, ref):
 # bit-exact vs the specified-order oracle
 # ---------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+CONFIGS = [(torch.float32, "stream"), (torch.bfloat16, "stream"), (torch.bfloat16, "lds")]
+CONFIG_IDS = ["f32-stream", "bf16-stream", "bf16-lds"]
+
+
+@pytest.mark.parametrize("dtype,variant", CONFIGS, ids=CONFIG_IDS)
 @pytest.mark.parametrize("name", [c for c in SMALL if "greedy" in manifest()[c]["decode_type"]])
-def test_greedy_bit_exact_vs_c_oracle(K, name, dtype):
+def test_greedy_bit_exact_vs_c_oracle(K, name, dtype, variant):
     g = GoldenCase(name)
     td0, h = _encode(g)
-    _assert_bit_exact(_run(K, "hip", g, td0, h, "greedy", dtype), _run(K, "c", g, td0, h, "greedy", dtype))
+    _assert_bit_exact(_run(K, "hip", g, td0, h, "greedy", dtype, variant=variant),
+                      _run(K, "c", g, td0, h, "greedy", dtype, variant=variant))
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("dtype,variant", CONFIGS, ids=CONFIG_IDS)
 @pytest.mark.parametrize("name", ["tsp100_b64_sampling", "cvrp100_b64_sampling", "pomo_tsp50_b8_mssampling"])
-def test_sampling_injected_noise_bit_exact_vs_c_oracle(K, name, dtype):
+def test_sampling_injected_noise_bit_exact_vs_c_oracle(K, name, dtype, variant):
     g = GoldenCase(name)
     td0, h = _encode(g)
     b = g.batch * max(g.num_starts, 1)
     n = g.num_loc + (g.env_name == "cvrp")
     torch.manual_seed(g.meta["sample_seed"])
     noise = torch.stack([torch.empty(b, n).exponential_(1) for _ in range(max_horizon(g.env_name, n))], 0).contiguous()
-    _assert_bit_exact(_run(K, "hip", g, td0, h, "sampling", dtype, exp_noise=noise),
-                      _run(K, "c", g, td0, h, "sampling", dtype, exp_noise=noise))
+    _assert_bit_exact(_run(K, "hip", g, td0, h, "sampling", dtype, variant=variant, exp_noise=noise),
+                      _run(K, "c", g, td0, h, "sampling", dtype, variant=variant, exp_noise=noise))
 
 
 @pytest.mark.parametrize("name", ["tsp50_b64_greedy", "cvrp20_b128_greedy"])
@@ -125,6 +128,8 @@ def test_sampling_philox_bit_exact_vs_c_oracle(K, name):
     hip = _run(K, "hip", g, td0, h, "sampling", philox_seed=0x1234ABCD5678, philox_offset=7)
     ref = _run(K, "c", g, td0, h, "sampling", philox_seed=0x1234ABCD5678, philox_offset=7)
     _assert_bit_exact(hip, ref)
+    kw = dict(dtype=torch.bfloat16, variant="lds", philox_seed=5, philox_offset=0)
+    _assert_bit_exact(_run(K, "hip", g, td0, h, "sampling", **kw), _run(K, "c", g, td0, h, "sampling", **kw))
     other = _run(K, "hip", g, td0, h, "sampling", philox_seed=99, philox_offset=7)
     assert not torch.equal(other[0], hip[0])
     # sampled tours are valid
@@ -148,6 +153,18 @@ def test_evaluate_mode_bit_exact_and_entropy(K, name):
         ent = torch.zeros(b, device=dev)
         r = _run(K, backend, g, td0, h, "evaluate", forced_actions=forced, all_logps=all_lp, entropy=ent)
         outs.append((r, all_lp.cpu(), ent.cpu()))
+    # the LDS-resident variant on bf16 planes, same options
+    lds = []
+    for backend in ("hip", "c"):
+        dev = "cuda" if backend == "hip" else "cpu"
+        all_lp = torch.zeros(b, tmax, n, device=dev)
+        ent = torch.zeros(b, device=dev)
+        r = _run(K, backend, g, td0, h, "evaluate", torch.bfloat16, variant="lds", forced_actions=forced,
+                 all_logps=all_lp, entropy=ent)
+        lds.append((r, all_lp.cpu(), ent.cpu()))
+    _assert_bit_exact(lds[0][0], lds[1][0])
+    assert torch.equal(lds[0][1].view(torch.int32), lds[1][1].view(torch.int32))
+    assert torch.equal(lds[0][2].view(torch.int32), lds[1][2].view(torch.int32))
     _assert_bit_exact(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1].view(torch.int32), outs[1][1].view(torch.int32))
     assert torch.equal(outs[0][2].view(torch.int32), outs[1][2].view(torch.int32))
@@ -246,12 +263,13 @@ def test_full_size_tsp100_b4096_vs_reference_golden(K):
     assert abs(float(reward.mean() - g.reward.mean())) <= 1e-4 * abs(float(g.reward.mean()))
 
 
-def test_full_size_tsp100_b4096_bf16_properties(K):
+@pytest.mark.parametrize("variant", ["stream", "lds"])
+def test_full_size_tsp100_b4096_bf16_properties(K, variant):
     """The throughput configuration (bf16 cache planes): trajectories legitimately differ from the
     fp32 reference; validity, bit-exact reward arithmetic and tour quality must hold."""
     g = GoldenCase("c2_tsp100_b4096_greedy")
     td0, h = _encode(g)
-    a, l, st, n_steps, t, err = _run(K, "hip", g, td0, h, "greedy", torch.bfloat16)
+    a, l, st, n_steps, t, err = _run(K, "hip", g, td0, h, "greedy", torch.bfloat16, variant=variant)
     assert err == 0 and t == 100
     assert torch.equal(a.sort(1).values, torch.arange(100).expand_as(a))
     reward = K.tour_length(td0["locs"].cuda(), a.cuda(), negate=True).cpu()
@@ -290,3 +308,17 @@ def test_error_bits_surface_reference_assertions(K):
         _lib.raise_for_error_bits(err)
     c = _run(K, "c", g, td0, h, "evaluate", forced_actions=forced)
     assert c[5] == err
+
+
+def test_variant_selection_and_limits(K):
+    """auto = LDS-resident when the bf16 planes of one trajectory fit half a CU's LDS and the
+    rollout is long enough; an explicit 'lds' request that cannot be served is an argument error."""
+    from rl4co_amd import _lib
+
+    assert K.decode_row_groups(100, torch.bfloat16, 100) == 16
+    assert K.decode_row_groups(101, torch.bfloat16, 202) == 16
+    assert K.decode_row_groups(100, torch.bfloat16, 1) == 4      # single-step calls stream
+    assert K.decode_row_groups(100, torch.float32, 100) == 2
+    assert K.decode_row_groups(501, torch.bfloat16, 1002) == 4   # does not fit: stream
+    with pytest.raises(_lib.Rl4coLibraryError):
+        K.decode_row_groups(501, torch.bfloat16, 1002, "lds")
