@@ -172,16 +172,14 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
         float acc = 0.0f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc = fmaf(q[e], k[e], acc);
-#pragma unroll
-        for (int s = 1; s < LPH; s <<= 1) acc = acc + rl4co::shfl_xor_f(acc, s);
+        acc = rl4co::bfly_sum<1, LPH>(acc);
         const bool feas = valid && (!a.mask_inner || mk[valid ? j : 0] != 0);
         const float sv = feas ? acc : kNegInf;
         if (valid && (li % LPH) == 0) sc[j * kH + hd] = sv;
         m = fmaxf(m, sv);
       }
     }
-#pragma unroll
-    for (int s = LPR; s < 64; s <<= 1) m = fmaxf(m, rl4co::shfl_xor_f(m, s));
+    m = rl4co::bfly_max<LPR, 64>(m);
     __syncthreads();
 
     // ---- pass 2: softmax weights and weighted value sum ------------------------------
@@ -208,14 +206,9 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
         for (int e = 0; e < EPL; ++e) o[e] = fmaf(p, v[e], o[e]);
       }
     }
+    l = rl4co::bfly_sum<LPR, 64>(l);
 #pragma unroll
-    for (int s = LPR; s < 64; s <<= 1) {
-      l = l + rl4co::shfl_xor_f(l, s);
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) o[e] = o[e] + rl4co::shfl_xor_f(o[e], s);
-    }
-#pragma unroll
-    for (int e = 0; e < EPL; ++e) o[e] = o[e] / l;
+    for (int e = 0; e < EPL; ++e) o[e] = rl4co::bfly_sum<LPR, 64>(o[e]) / l;
 
     // ---- pass 3: pointer logits against the (project_out-folded) logit key -----------
     for (int j0 = 0; j0 < N; j0 += RPL * kUnroll) {
@@ -233,8 +226,7 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
         float acc = 0.0f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc = fmaf(o[e], k[e], acc);
-#pragma unroll
-        for (int s = 1; s < LPR; s <<= 1) acc = acc + rl4co::shfl_xor_f(acc, s);
+        acc = rl4co::bfly_sum<1, LPR>(acc);
         if (j < N && li == 0) lg[j] = acc;
       }
     }
@@ -255,12 +247,10 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
     if (__any(nan_seen)) errbits |= RL4CO_EBIT_NAN_LOGIT;
 
     // ---- log_softmax over the N logits (decoding.py:188) -----------------------------
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) zmax = fmaxf(zmax, rl4co::shfl_xor_f(zmax, s));
+    zmax = rl4co::bfly_max<1, 64>(zmax);
     float zsum = 0.0f;
     for (int j = lane; j < N; j += 64) zsum = zsum + rl4co_expf(lg[j] - zmax);
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) zsum = zsum + rl4co::shfl_xor_f(zsum, s);
+    zsum = rl4co::bfly_sum<1, 64>(zsum);
     const float lse = rl4co_logf(zsum);
 
     // ---- selection ---------------------------------------------------------------------
@@ -286,20 +276,8 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
       if (a.entropy && lp > kNegInf) ent = fmaf(rl4co_expf(lp), lp, ent);
       if (a.all_logps) a.all_logps[((int64_t)r * a.out_stride + tcol) * N + j] = lp;
     }
-#pragma unroll
-    for (int s = 1; s < 64; s <<= 1) {
-      const float ov = rl4co::shfl_xor_f(best, s);
-      const int oi = rl4co::shfl_xor_i(bi, s);
-      if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) {
-        best = ov;
-        bi = oi;
-      }
-    }
-    if (a.entropy) {
-#pragma unroll
-      for (int s = 1; s < 64; s <<= 1) ent = ent + rl4co::shfl_xor_f(ent, s);
-      ent_acc = ent_acc - ent;
-    }
+    rl4co::bfly_argmax(best, bi);
+    if (a.entropy) ent_acc = ent_acc - rl4co::bfly_sum<1, 64>(ent);
     if (a.mode == RL4CO_DECODE_EVALUATE) bi = (int)a.forced_actions[(int64_t)r * a.out_stride + tcol];
     if (bi < 0 || bi >= N) {  // forced action out of range
       errbits |= RL4CO_EBIT_INFEASIBLE;
@@ -394,7 +372,7 @@ __device__ inline void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <int ENV>
+template <int ENV, int ITERS>
 __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const rl4co_am_decode_args a) {
   using C = CacheBF16;
   constexpr int EPL = 8, LPR = 16, LPH = 2;
@@ -461,8 +439,6 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
   uint32_t errbits = 0;
   float ent_acc = 0.0f;
   int t = 0;
-  const int iters = (N + kLdsGroups - 1) / kLdsGroups;
-
   for (; t < a.max_steps && (!done || single); ++t) {
     // ---- query ---------------------------------------------------------------------------------
     float q[EPL];
@@ -486,8 +462,8 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
 
     // ---- pass 1: scores of this wave's rows ------------------------------------------------------
     float m = kNegInf;
-#pragma unroll 4
-    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
       const int j = kLdsGroups * i + 4 * w + rg;
       const bool valid = j < N;
       float k[EPL];
@@ -495,14 +471,13 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
       float acc = 0.0f;
 #pragma unroll
       for (int e = 0; e < EPL; ++e) acc = fmaf(q[e], k[e], acc);
-      acc = acc + rl4co::shfl_xor_f(acc, 1);
+      acc = rl4co::bfly_sum<1, LPH>(acc);
       const bool feas = valid && (!a.mask_inner || mk[valid ? j : 0] != 0);
       const float sv = feas ? acc : kNegInf;
       if (valid && (li & 1) == 0) sc[j * kH + hd] = sv;
       m = fmaxf(m, sv);
     }
-    m = fmaxf(m, rl4co::shfl_xor_f(m, 16));
-    m = fmaxf(m, rl4co::shfl_xor_f(m, 32));
+    m = rl4co::bfly_max<LPR, 64>(m);
     if (rg == 0 && (li & 1) == 0) mpart[w * kH + hd] = m;
     __syncthreads();  // B1: all head maxima visible
     m = fmaxf(fmaxf(mpart[hd], mpart[kH + hd]), fmaxf(mpart[2 * kH + hd], mpart[3 * kH + hd]));
@@ -512,8 +487,8 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
     float o[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) o[e] = 0.0f;
-#pragma unroll 4
-    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
       const int j = kLdsGroups * i + 4 * w + rg;
       const bool valid = j < N;
       float v[EPL];
@@ -523,12 +498,9 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
 #pragma unroll
       for (int e = 0; e < EPL; ++e) o[e] = fmaf(p, v[e], o[e]);
     }
+    l = rl4co::bfly_sum<LPR, 64>(l);
 #pragma unroll
-    for (int s = LPR; s < 64; s <<= 1) {
-      l = l + rl4co::shfl_xor_f(l, s);
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) o[e] = o[e] + rl4co::shfl_xor_f(o[e], s);
-    }
+    for (int e = 0; e < EPL; ++e) o[e] = rl4co::bfly_sum<LPR, 64>(o[e]);
     if (rg == 0) {
 #pragma unroll
       for (int e = 0; e < EPL; ++e) *opart(w, e0 + e) = o[e];
@@ -543,8 +515,8 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
     }
 
     // ---- pass 3: logits of this wave's rows ---------------------------------------------------------
-#pragma unroll 4
-    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int i = 0; i < ITERS; ++i) {
       const int j = kLdsGroups * i + 4 * w + rg;
       const bool valid = j < N;
       float k[EPL];
@@ -552,8 +524,7 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
       float acc = 0.0f;
 #pragma unroll
       for (int e = 0; e < EPL; ++e) acc = fmaf(o[e], k[e], acc);
-#pragma unroll
-      for (int s = 1; s < LPR; s <<= 1) acc = acc + rl4co::shfl_xor_f(acc, s);
+      acc = rl4co::bfly_sum<1, LPR>(acc);
       if (valid && li == 0) lg[j] = acc;
     }
     __syncthreads();  // B3: all logits visible to wave 0
@@ -572,12 +543,10 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
         zmax = fmaxf(zmax, z);
       }
       if (__any(nan_seen)) errbits |= RL4CO_EBIT_NAN_LOGIT;
-#pragma unroll
-      for (int s = 1; s < 64; s <<= 1) zmax = fmaxf(zmax, rl4co::shfl_xor_f(zmax, s));
+      zmax = rl4co::bfly_max<1, 64>(zmax);
       float zsum = 0.0f;
       for (int j = lane; j < N; j += 64) zsum = zsum + rl4co_expf(lg[j] - zmax);
-#pragma unroll
-      for (int s = 1; s < 64; s <<= 1) zsum = zsum + rl4co::shfl_xor_f(zsum, s);
+      zsum = rl4co::bfly_sum<1, 64>(zsum);
       const float lse = rl4co_logf(zsum);
       float best = kNegInf;
       int bi = 0x7fffffff;
@@ -601,20 +570,8 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
         if (a.entropy && lp > kNegInf) ent = fmaf(rl4co_expf(lp), lp, ent);
         if (a.all_logps) a.all_logps[((int64_t)r * a.out_stride + tcol) * N + j] = lp;
       }
-#pragma unroll
-      for (int s = 1; s < 64; s <<= 1) {
-        const float ov = rl4co::shfl_xor_f(best, s);
-        const int oi = rl4co::shfl_xor_i(bi, s);
-        if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) {
-          best = ov;
-          bi = oi;
-        }
-      }
-      if (a.entropy) {
-#pragma unroll
-        for (int s = 1; s < 64; s <<= 1) ent = ent + rl4co::shfl_xor_f(ent, s);
-        ent_acc = ent_acc - ent;
-      }
+      rl4co::bfly_argmax(best, bi);
+      if (a.entropy) ent_acc = ent_acc - rl4co::bfly_sum<1, 64>(ent);
       if (a.mode == RL4CO_DECODE_EVALUATE) bi = (int)a.forced_actions[(int64_t)r * a.out_stride + tcol];
       if (bi < 0 || bi >= N) {
         errbits |= RL4CO_EBIT_INFEASIBLE;
@@ -698,14 +655,28 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
   }
 }
 
-template <int ENV>
-int launch_lds(const rl4co_am_decode_args& a, hipStream_t stream) {
+template <int ENV, int ITERS>
+int launch_lds_iters(const rl4co_am_decode_args& a, hipStream_t stream) {
   const int lds = lds_variant_bytes(a.N);
-  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_decode_lds_kernel<ENV>),
+  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_decode_lds_kernel<ENV, ITERS>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL((am_decode_lds_kernel<ENV>), dim3(a.B), dim3(64 * kLdsWaves), lds, stream, a);
+  hipLaunchKernelGGL((am_decode_lds_kernel<ENV, ITERS>), dim3(a.B), dim3(64 * kLdsWaves), lds, stream, a);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
+}
+
+template <int ENV>
+int launch_lds(const rl4co_am_decode_args& a, hipStream_t stream) {
+  switch ((a.N + kLdsGroups - 1) / kLdsGroups) {  // rows per wave per pass, fully unrolled
+    case 1: return launch_lds_iters<ENV, 1>(a, stream);
+    case 2: return launch_lds_iters<ENV, 2>(a, stream);
+    case 3: return launch_lds_iters<ENV, 3>(a, stream);
+    case 4: return launch_lds_iters<ENV, 4>(a, stream);
+    case 5: return launch_lds_iters<ENV, 5>(a, stream);
+    case 6: return launch_lds_iters<ENV, 6>(a, stream);
+    case 7: return launch_lds_iters<ENV, 7>(a, stream);
+    default: return rl4co::record_arg_error("LDS-resident decode variant supports N <= 112");
+  }
 }
 
 // Which kernel serves these arguments: the LDS-resident one needs bf16 planes, a trajectory's

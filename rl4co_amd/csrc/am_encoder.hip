@@ -156,8 +156,7 @@ __device__ inline void residual_norm(__bf16* xs, f32x16 (&y)[TT], int dim0, cons
       float s = 0.0f;
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) s += (32 * tt + l31 < N) ? y[tt][r] : 0.0f;
-#pragma unroll
-      for (int m = 1; m < 32; m <<= 1) s += __shfl_xor(s, m, 64);
+      s = rl4co::bfly_sum<1, 32>(s);
       const float mean = s * inv_n;
       float v = 0.0f;
 #pragma unroll
@@ -165,8 +164,7 @@ __device__ inline void residual_norm(__bf16* xs, f32x16 (&y)[TT], int dim0, cons
         const float d = y[tt][r] - mean;
         v += (32 * tt + l31 < N) ? d * d : 0.0f;
       }
-#pragma unroll
-      for (int m = 1; m < 32; m <<= 1) v += __shfl_xor(v, m, 64);
+      v = rl4co::bfly_sum<1, 32>(v);
       const float rstd = rsqrtf(v * inv_n + 1e-5f);
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) y[tt][r] = (y[tt][r] - mean) * rstd * ga[r] + be[r];
@@ -297,7 +295,7 @@ __global__ void __launch_bounds__(kThreads) am_encoder_kernel(const rl4co_am_enc
 #pragma unroll
             for (int r = 0; r < 16; ++r) m = fmaxf(m, s[kt][r]);
           }
-          m = fmaxf(m, __shfl_xor(m, 32, 64));
+          m = fmaxf(m, rl4co::bfly_f<32>(m));
           float l = 0.0f;
 #pragma unroll
           for (int kt = 0; kt < TT; ++kt) {
@@ -308,7 +306,7 @@ __global__ void __launch_bounds__(kThreads) am_encoder_kernel(const rl4co_am_enc
               l += p;
             }
           }
-          l += __shfl_xor(l, 32, 64);
+          l += rl4co::bfly_f<32>(l);
           f32x16 acc = zero16();
 #pragma unroll
           for (int kt = 0; kt < TT; ++kt) {

@@ -26,11 +26,80 @@ int record_arg_error(const char* what);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-// Wave-wide (64-lane) butterfly helpers. On gfx950 a workgroup of 64 threads is
-// exactly one wavefront, so these are the only cross-lane primitives the decode
-// kernel needs.
-__device__ inline float shfl_xor_f(float v, int m) { return __shfl_xor(v, m, 64); }
-__device__ inline int shfl_xor_i(int v, int m) { return __shfl_xor(v, m, 64); }
+// Wave-wide (64-lane) butterfly partner fetch WITHOUT the LDS crossbar: ds_bpermute (what
+// __shfl_xor compiles to) costs an LDS round trip (~100+ cycles) per step and the decode kernels
+// run dependent chains of them; DPP modifiers and the gfx950 permlane swaps are plain VALU ops.
+//   S = 1, 2  : quad_perm
+//   S = 4, 8  : row_half_mirror / row_mirror — equal to the xor-4 / xor-8 partner ONLY when the
+//               value is already uniform inside each 4- / 8-lane group, which holds at that
+//               point of an ascending butterfly (the way every caller uses them)
+//   S = 16, 32: v_permlane16_swap / v_permlane32_swap (swap odd rows / the upper half of one
+//               copy with even rows / the lower half of the other)
+// The value returned is bit-identical to __shfl_xor(v, S, 64) under those conditions.
+template <int CTRL>
+__device__ inline int dpp_mov_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+
+template <int S>
+__device__ inline int bfly_i(int v) {
+  static_assert(S == 1 || S == 2 || S == 4 || S == 8 || S == 16 || S == 32, "butterfly step");
+  if constexpr (S == 1) {
+    return dpp_mov_i<0xB1>(v);  // quad_perm:[1,0,3,2]
+  } else if constexpr (S == 2) {
+    return dpp_mov_i<0x4E>(v);  // quad_perm:[2,3,0,1]
+  } else if constexpr (S == 4) {
+    return dpp_mov_i<0x141>(v);  // row_half_mirror
+  } else if constexpr (S == 8) {
+    return dpp_mov_i<0x140>(v);  // row_mirror
+  } else if constexpr (S == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    return (threadIdx.x & 16) ? (int)r[0] : (int)r[1];
+  } else {
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (threadIdx.x & 32) ? (int)r[0] : (int)r[1];
+  }
+}
+
+template <int S>
+__device__ inline float bfly_f(float v) {
+  return __builtin_bit_cast(float, bfly_i<S>(__builtin_bit_cast(int, v)));
+}
+
+// v + partner over the butterfly steps LO, 2*LO, ..., < HI (ascending), i.e. the pairwise tree
+template <int LO, int HI>
+__device__ inline float bfly_sum(float v) {
+  if constexpr (LO < HI) {
+    v = v + bfly_f<LO>(v);
+    return bfly_sum<LO * 2, HI>(v);
+  } else {
+    return v;
+  }
+}
+
+template <int LO, int HI>
+__device__ inline float bfly_max(float v) {
+  if constexpr (LO < HI) {
+    v = fmaxf(v, bfly_f<LO>(v));
+    return bfly_max<LO * 2, HI>(v);
+  } else {
+    return v;
+  }
+}
+
+// (maximum key, lowest index on ties) over the whole wave; idx == 0x7fffffff marks "empty"
+template <int S = 1>
+__device__ inline void bfly_argmax(float& best, int& bi) {
+  if constexpr (S < 64) {
+    const float ov = bfly_f<S>(best);
+    const int oi = bfly_i<S>(bi);
+    if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > best || (ov == best && oi < bi))) {
+      best = ov;
+      bi = oi;
+    }
+    bfly_argmax<S * 2>(best, bi);
+  }
+}
 
 }  // namespace rl4co
 
