@@ -54,6 +54,12 @@ CASES = [
          decode="multistart_sampling", fw_kw=dict(num_starts=8)),
     dict(name="pomo_cvrp20_b16_msgreedy", env="cvrp", num_loc=20, batch=16, policy="pomo",
          decode="multistart_greedy"),
+    # BASELINE.json configs[3] / [4] shapes at a CPU-affordable batch: POMO 8-start sampling on
+    # TSP-100, and CVRP-500 sampling (N = 501: the n >= 512 cascade of the tour-length sum)
+    dict(name="c4_pomo_tsp100_b32_s8_sampling", env="tsp", num_loc=100, batch=32, policy="pomo",
+         decode="multistart_sampling", fw_kw=dict(num_starts=8)),
+    dict(name="c5_cvrp500_b16_sampling", env="cvrp", num_loc=500, batch=16, policy="am", decode="sampling",
+         store_inputs=False),
     # BASELINE.json configs[1] / [2] at full size (inputs are re-created from the seed; only the
     # reference's actions (uint8) / rewards are stored)
     dict(name="c2_tsp100_b4096_greedy", env="tsp", num_loc=100, batch=4096, policy="am", decode="greedy",
@@ -136,9 +142,8 @@ def run_case(ref, case: dict) -> dict:
         assert torch.equal(noise, redraw)
 
     actions = out_ref["actions"]
-    assert int(actions.max()) < 256
     fixture = {
-        "actions": actions.numpy().astype(np.uint8),
+        "actions": actions.numpy().astype(np.uint8 if int(actions.max()) < 256 else np.uint16),
         "reward": out_ref["reward"].numpy(),
         "log_likelihood": out_ref["log_likelihood"].numpy(),
     }

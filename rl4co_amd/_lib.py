@@ -14,7 +14,7 @@ RL4CO_OK = 0
 ENV_TSP, ENV_CVRP = 0, 1
 DECODE_GREEDY, DECODE_SAMPLE, DECODE_EVALUATE = 0, 1, 2
 DT_F32, DT_BF16 = 0, 1
-VARIANT_AUTO, VARIANT_STREAM, VARIANT_LDS = 0, 1, 2
+VARIANT_AUTO, VARIANT_STREAM, VARIANT_LDS, VARIANT_WIDE = 0, 1, 2, 3
 
 EBIT_NAN_LOGIT = 1
 EBIT_INFEASIBLE = 2
@@ -109,11 +109,13 @@ def lib() -> C.CDLL:
     return handle
 
 
-def decode_row_groups(num_nodes: int, cache_dtype_id: int, max_steps: int, variant: int = VARIANT_AUTO) -> int:
+def decode_row_groups(num_nodes: int, cache_dtype_id: int, max_steps: int, variant: int = VARIANT_AUTO,
+                      num_trajectories: int = 1 << 20) -> int:
     """Row groups G (the glimpse summation tree) of the kernel variant that serves this shape —
     a pure host query, usable without a GPU; the specified-order oracle mirrors it."""
     a = AmDecodeArgs()
     a.N, a.cache_dtype, a.max_steps, a.variant = int(num_nodes), int(cache_dtype_id), int(max_steps), int(variant)
+    a.B = int(num_trajectories)
     g = lib().rl4co_am_decode_row_groups(C.byref(a))
     if g <= 0:
         raise Rl4coLibraryError(f"no decode kernel variant {variant} for N={num_nodes}, dtype id {cache_dtype_id}")

@@ -361,10 +361,11 @@ constexpr int kLdsWaves = 4;
 constexpr int kLdsGroups = 16;
 
 __host__ __device__ inline int lds_variant_sc_rows(int N) { return N < 80 ? 80 : N; }
-__host__ __device__ inline int lds_variant_bytes(int N) {
+__host__ __device__ inline int wide_scratch_bytes(int N) {
   const int nw = (N + 3) & ~3;
-  return 3 * N * kD * 2 + lds_variant_sc_rows(N) * kH * 4 + nw * 4 + kLdsWaves * kH * 4 + 32 + 2 * nw;
+  return lds_variant_sc_rows(N) * kH * 4 + nw * 4 + kLdsWaves * kH * 4 + 32 + 2 * nw;
 }
+__host__ __device__ inline int lds_variant_bytes(int N) { return 3 * N * kD * 2 + wide_scratch_bytes(N); }
 
 __device__ inline void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -372,9 +373,15 @@ __device__ inline void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-template <int ENV, int ITERS>
+// RESIDENT = true : planes copied into LDS once per rollout (ITERS = rows per wave per pass, unrolled)
+// RESIDENT = false: "wide" streaming — the same 4-wave structure reading the planes from HBM/L2
+//                   every step; for rollouts with too few trajectories to fill the chip with one
+//                   wave each and planes too large for LDS (CVRP-500 x 1024: 4096 waves instead
+//                   of 1024). ITERS = 0: runtime row count, 4 loads in flight per wave and pass.
+template <int ENV, int ITERS, bool RESIDENT>
 __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const rl4co_am_decode_args a) {
   using C = CacheBF16;
+  constexpr int U = ITERS > 0 ? ITERS : 4;  // rows per wave handled per unrolled block
   constexpr int EPL = 8, LPR = 16, LPH = 2;
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -382,8 +389,8 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
   const int r = blockIdx.x;
   const int N = a.N;
   const int nw = (N + 3) & ~3;
-  uint16_t* planes = reinterpret_cast<uint16_t*>(smem);             // [3][N][128] bf16
-  float* sc = reinterpret_cast<float*>(planes + 3 * N * kD);        // [max(N,80)][8] scores; later o/l partials
+  uint16_t* planes = reinterpret_cast<uint16_t*>(smem);             // [3][N][128] bf16 (RESIDENT only)
+  float* sc = reinterpret_cast<float*>(planes + (RESIDENT ? 3 * N * kD : 0));  // [max(N,80)][8] scores; later o/l partials
   float* lg = sc + lds_variant_sc_rows(N) * kH;                     // [nw] logits -> log-probs
   float* mpart = lg + nw;                                           // [4][8] per-wave head maxima
   int* shi = reinterpret_cast<int*>(mpart + kLdsWaves * kH);        // [8] broadcast: action, done
@@ -392,9 +399,20 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
 
   const int cb = r % a.B_inst;
   const int rg = lane / LPR, li = lane % LPR, hd = li / LPH, e0 = li * EPL;
-  const uint16_t* Kg = planes + e0;
-  const uint16_t* Vg = planes + N * kD + e0;
-  const uint16_t* Kl = planes + 2 * N * kD + e0;
+  const uint16_t *Kg, *Vg, *Kl;
+  int64_t rs;
+  if constexpr (RESIDENT) {
+    Kg = planes + e0;
+    Vg = planes + N * kD + e0;
+    Kl = planes + 2 * N * kD + e0;
+    rs = kD;
+  } else {
+    Kg = static_cast<const uint16_t*>(a.glimpse_key) + (int64_t)cb * a.kvl_batch_stride + e0;
+    Vg = static_cast<const uint16_t*>(a.glimpse_val) + (int64_t)cb * a.kvl_batch_stride + e0;
+    Kl = static_cast<const uint16_t*>(a.logit_key) + (int64_t)cb * a.kvl_batch_stride + e0;
+    rs = a.kvl_row_stride;
+  }
+  const int iters = ITERS > 0 ? ITERS : (N + kLdsGroups - 1) / kLdsGroups;
   const float* ctxc = a.ctx_cur + (int64_t)cb * N * kD + e0;
   const float* ctxf = (ENV == RL4CO_ENV_TSP) ? a.ctx_first + (int64_t)cb * N * kD + e0 : nullptr;
   // o/l partial slots inside this wave's own (dead after pass 2) score rows
@@ -402,7 +420,7 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
   auto lpart = [&](int wv, int h) -> float* { return sc + ((16 * 4 + 4 * wv) * kH) + h; };
 
   // ---- planes HBM -> LDS, once per rollout (16-byte coalesced) --------------------------------
-  {
+  if constexpr (RESIDENT) {
     const uint16_t* src[3] = {static_cast<const uint16_t*>(a.glimpse_key), static_cast<const uint16_t*>(a.glimpse_val),
                               static_cast<const uint16_t*>(a.logit_key)};
     const int chunks = N * (kD / 8);  // 16-byte chunks per plane
@@ -462,20 +480,28 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
 
     // ---- pass 1: scores of this wave's rows ------------------------------------------------------
     float m = kNegInf;
+    for (int i0 = 0; i0 < iters; i0 += U) {
+      uint4 rw[U];
 #pragma unroll
-    for (int i = 0; i < ITERS; ++i) {
-      const int j = kLdsGroups * i + 4 * w + rg;
-      const bool valid = j < N;
-      float k[EPL];
-      C::cvt(valid ? *reinterpret_cast<const uint4*>(Kg + j * kD) : C::zero(), k);
-      float acc = 0.0f;
+      for (int u = 0; u < U; ++u) {
+        const int j = kLdsGroups * (i0 + u) + 4 * w + rg;
+        rw[u] = (j < N) ? *reinterpret_cast<const uint4*>(Kg + (int64_t)j * rs) : C::zero();
+      }
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) acc = fmaf(q[e], k[e], acc);
-      acc = rl4co::bfly_sum<1, LPH>(acc);
-      const bool feas = valid && (!a.mask_inner || mk[valid ? j : 0] != 0);
-      const float sv = feas ? acc : kNegInf;
-      if (valid && (li & 1) == 0) sc[j * kH + hd] = sv;
-      m = fmaxf(m, sv);
+      for (int u = 0; u < U; ++u) {
+        const int j = kLdsGroups * (i0 + u) + 4 * w + rg;
+        const bool valid = j < N;
+        float k[EPL];
+        C::cvt(rw[u], k);
+        float acc = 0.0f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc = fmaf(q[e], k[e], acc);
+        acc = rl4co::bfly_sum<1, LPH>(acc);
+        const bool feas = valid && (!a.mask_inner || mk[valid ? j : 0] != 0);
+        const float sv = feas ? acc : kNegInf;
+        if (valid && (li & 1) == 0) sc[j * kH + hd] = sv;
+        m = fmaxf(m, sv);
+      }
     }
     m = rl4co::bfly_max<LPR, 64>(m);
     if (rg == 0 && (li & 1) == 0) mpart[w * kH + hd] = m;
@@ -487,16 +513,24 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
     float o[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) o[e] = 0.0f;
+    for (int i0 = 0; i0 < iters; i0 += U) {
+      uint4 rw[U];
 #pragma unroll
-    for (int i = 0; i < ITERS; ++i) {
-      const int j = kLdsGroups * i + 4 * w + rg;
-      const bool valid = j < N;
-      float v[EPL];
-      C::cvt(valid ? *reinterpret_cast<const uint4*>(Vg + j * kD) : C::zero(), v);
-      const float p = valid ? rl4co_expf(sc[j * kH + hd] - m) : 0.0f;
-      l = l + p;
+      for (int u = 0; u < U; ++u) {
+        const int j = kLdsGroups * (i0 + u) + 4 * w + rg;
+        rw[u] = (j < N) ? *reinterpret_cast<const uint4*>(Vg + (int64_t)j * rs) : C::zero();
+      }
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) o[e] = fmaf(p, v[e], o[e]);
+      for (int u = 0; u < U; ++u) {
+        const int j = kLdsGroups * (i0 + u) + 4 * w + rg;
+        const bool valid = j < N;
+        float v[EPL];
+        C::cvt(rw[u], v);
+        const float p = valid ? rl4co_expf(sc[j * kH + hd] - m) : 0.0f;
+        l = l + p;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) o[e] = fmaf(p, v[e], o[e]);
+      }
     }
     l = rl4co::bfly_sum<LPR, 64>(l);
 #pragma unroll
@@ -515,17 +549,24 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
     }
 
     // ---- pass 3: logits of this wave's rows ---------------------------------------------------------
+    for (int i0 = 0; i0 < iters; i0 += U) {
+      uint4 rw[U];
 #pragma unroll
-    for (int i = 0; i < ITERS; ++i) {
-      const int j = kLdsGroups * i + 4 * w + rg;
-      const bool valid = j < N;
-      float k[EPL];
-      C::cvt(valid ? *reinterpret_cast<const uint4*>(Kl + j * kD) : C::zero(), k);
-      float acc = 0.0f;
+      for (int u = 0; u < U; ++u) {
+        const int j = kLdsGroups * (i0 + u) + 4 * w + rg;
+        rw[u] = (j < N) ? *reinterpret_cast<const uint4*>(Kl + (int64_t)j * rs) : C::zero();
+      }
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) acc = fmaf(o[e], k[e], acc);
-      acc = rl4co::bfly_sum<1, LPR>(acc);
-      if (valid && li == 0) lg[j] = acc;
+      for (int u = 0; u < U; ++u) {
+        const int j = kLdsGroups * (i0 + u) + 4 * w + rg;
+        float k[EPL];
+        C::cvt(rw[u], k);
+        float acc = 0.0f;
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) acc = fmaf(o[e], k[e], acc);
+        acc = rl4co::bfly_sum<1, LPR>(acc);
+        if (j < N && li == 0) lg[j] = acc;
+      }
     }
     __syncthreads();  // B3: all logits visible to wave 0
 
@@ -655,12 +696,14 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
   }
 }
 
-template <int ENV, int ITERS>
-int launch_lds_iters(const rl4co_am_decode_args& a, hipStream_t stream) {
-  const int lds = lds_variant_bytes(a.N);
-  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_decode_lds_kernel<ENV, ITERS>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL((am_decode_lds_kernel<ENV, ITERS>), dim3(a.B), dim3(64 * kLdsWaves), lds, stream, a);
+template <int ENV, int ITERS, bool RESIDENT>
+int launch_wide(const rl4co_am_decode_args& a, hipStream_t stream) {
+  const int lds = RESIDENT ? lds_variant_bytes(a.N) : wide_scratch_bytes(a.N);
+  if (lds > 64 * 1024) {
+    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_decode_lds_kernel<ENV, ITERS, RESIDENT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  }
+  hipLaunchKernelGGL((am_decode_lds_kernel<ENV, ITERS, RESIDENT>), dim3(a.B), dim3(64 * kLdsWaves), lds, stream, a);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }
@@ -668,25 +711,37 @@ int launch_lds_iters(const rl4co_am_decode_args& a, hipStream_t stream) {
 template <int ENV>
 int launch_lds(const rl4co_am_decode_args& a, hipStream_t stream) {
   switch ((a.N + kLdsGroups - 1) / kLdsGroups) {  // rows per wave per pass, fully unrolled
-    case 1: return launch_lds_iters<ENV, 1>(a, stream);
-    case 2: return launch_lds_iters<ENV, 2>(a, stream);
-    case 3: return launch_lds_iters<ENV, 3>(a, stream);
-    case 4: return launch_lds_iters<ENV, 4>(a, stream);
-    case 5: return launch_lds_iters<ENV, 5>(a, stream);
-    case 6: return launch_lds_iters<ENV, 6>(a, stream);
-    case 7: return launch_lds_iters<ENV, 7>(a, stream);
+    case 1: return launch_wide<ENV, 1, true>(a, stream);
+    case 2: return launch_wide<ENV, 2, true>(a, stream);
+    case 3: return launch_wide<ENV, 3, true>(a, stream);
+    case 4: return launch_wide<ENV, 4, true>(a, stream);
+    case 5: return launch_wide<ENV, 5, true>(a, stream);
+    case 6: return launch_wide<ENV, 6, true>(a, stream);
+    case 7: return launch_wide<ENV, 7, true>(a, stream);
     default: return rl4co::record_arg_error("LDS-resident decode variant supports N <= 112");
   }
 }
 
-// Which kernel serves these arguments: the LDS-resident one needs bf16 planes, a trajectory's
-// planes + scratch within half a CU's LDS (2 workgroups per CU) and enough steps to amortise
-// the one-off load.
+// Which kernel serves these arguments. Measured on MI355X (TSP-100, bf16): with thousands of
+// trajectories the streaming kernel keeps 16 independent waves per CU in flight and runs at ~0.9
+// of the HBM peak (4.4 ms per 4096 x 100 steps), while the LDS-resident kernel can only host two
+// trajectories per CU and becomes latency-bound (6.1 ms). The resident kernel wins when there
+// are too few trajectories to fill the chip with one wave each: it puts 4 waves on every
+// trajectory and takes HBM out of the per-step critical path (measured: 0.70 vs 1.54 ms at B = 256,
+// 1.54 vs 1.84 ms at B = 1024, 3.06 vs 2.12 ms at B = 2048). Auto picks it for B <= 1024.
 inline int resolve_variant(const rl4co_am_decode_args& a) {
-  const bool fits = a.cache_dtype == RL4CO_DT_BF16 && lds_variant_bytes(a.N) <= 80 * 1024;
+  const bool bf16 = a.cache_dtype == RL4CO_DT_BF16;
+  const bool fits = bf16 && lds_variant_bytes(a.N) <= 80 * 1024 && (a.N + kLdsGroups - 1) / kLdsGroups <= 7;
+  const bool wide_ok = bf16 && wide_scratch_bytes(a.N) <= 64 * 1024;
   if (a.variant == RL4CO_VARIANT_STREAM) return RL4CO_VARIANT_STREAM;
   if (a.variant == RL4CO_VARIANT_LDS) return fits ? RL4CO_VARIANT_LDS : -1;
-  return (fits && a.max_steps >= 4) ? RL4CO_VARIANT_LDS : RL4CO_VARIANT_STREAM;
+  if (a.variant == RL4CO_VARIANT_WIDE) return wide_ok ? RL4CO_VARIANT_WIDE : -1;
+  if (a.max_steps < 4) return RL4CO_VARIANT_STREAM;
+  if (fits && a.B <= 1024) return RL4CO_VARIANT_LDS;
+  // one wave per trajectory needs >= ~16 waves per CU to hide its latency chain: with fewer
+  // trajectories than that, four waves per trajectory keep the memory pipes busier
+  if (wide_ok && a.B <= 2048) return RL4CO_VARIANT_WIDE;
+  return RL4CO_VARIANT_STREAM;
 }
 
 template <class C, int ENV>
@@ -713,7 +768,7 @@ extern "C" int rl4co_am_decode_row_groups(const rl4co_am_decode_args* args) {
   if (args == nullptr) return -1;
   const int v = resolve_variant(*args);
   if (v < 0) return -1;
-  if (v == RL4CO_VARIANT_LDS) return kLdsGroups;
+  if (v == RL4CO_VARIANT_LDS || v == RL4CO_VARIANT_WIDE) return kLdsGroups;
   return args->cache_dtype == RL4CO_DT_BF16 ? 64 / (kD / CacheBF16::EPL) : 64 / (kD / CacheF32::EPL);
 }
 
@@ -743,12 +798,16 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
     RL4CO_REQUIRE(a.w_cap && a.demand && a.used_capacity && a.vehicle_capacity && a.visited);
   }
   RL4CO_REQUIRE(rl4co_am_decode_lds_bytes(a.N, a.env) <= 160 * 1024);
-  RL4CO_REQUIRE(a.variant >= RL4CO_VARIANT_AUTO && a.variant <= RL4CO_VARIANT_LDS);
+  RL4CO_REQUIRE(a.variant >= RL4CO_VARIANT_AUTO && a.variant <= RL4CO_VARIANT_WIDE);
   const int variant = resolve_variant(a);
   RL4CO_REQUIRE(variant >= 0);  // RL4CO_VARIANT_LDS requested but the planes do not fit / are not bf16
   hipStream_t s = rl4co::as_stream(stream);
   if (variant == RL4CO_VARIANT_LDS) {
     return a.env == RL4CO_ENV_TSP ? launch_lds<RL4CO_ENV_TSP>(a, s) : launch_lds<RL4CO_ENV_CVRP>(a, s);
+  }
+  if (variant == RL4CO_VARIANT_WIDE) {
+    return a.env == RL4CO_ENV_TSP ? launch_wide<RL4CO_ENV_TSP, 0, false>(a, s)
+                                  : launch_wide<RL4CO_ENV_CVRP, 0, false>(a, s);
   }
   if (a.cache_dtype == RL4CO_DT_F32) {
     return a.env == RL4CO_ENV_TSP ? launch<CacheF32, RL4CO_ENV_TSP>(a, s)

@@ -16,12 +16,13 @@ from .cache import FoldedCache
 
 MODE_IDS = {"greedy": _lib.DECODE_GREEDY, "sampling": _lib.DECODE_SAMPLE, "evaluate": _lib.DECODE_EVALUATE}
 ENV_IDS = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP}
-VARIANT_IDS = {"auto": _lib.VARIANT_AUTO, "stream": _lib.VARIANT_STREAM, "lds": _lib.VARIANT_LDS}
+VARIANT_IDS = {"auto": _lib.VARIANT_AUTO, "stream": _lib.VARIANT_STREAM, "lds": _lib.VARIANT_LDS, "wide": _lib.VARIANT_WIDE}
 
 
-def decode_row_groups(num_nodes: int, cache_dtype: torch.dtype, max_steps: int, variant: str = "auto") -> int:
+def decode_row_groups(num_nodes: int, cache_dtype: torch.dtype, max_steps: int, variant: str = "auto",
+                      num_trajectories: int = 1 << 20) -> int:
     dt = _lib.DT_BF16 if cache_dtype == torch.bfloat16 else _lib.DT_F32
-    return _lib.decode_row_groups(num_nodes, dt, max_steps, VARIANT_IDS[variant])
+    return _lib.decode_row_groups(num_nodes, dt, max_steps, VARIANT_IDS[variant], num_trajectories)
 
 
 def _ptr(t: Tensor | None) -> int | None:

@@ -52,9 +52,10 @@ def _cvrp_check(actions, demand, vehicle_capacity, err):
 def _am_decode(cache, state, **kw):
     from rl4co_amd import _lib
 
-    variant = {"auto": 0, "stream": 1, "lds": 2}[kw.pop("variant", "auto")]
+    variant = {"auto": 0, "stream": 1, "lds": 2, "wide": 3}[kw.pop("variant", "auto")]
     dt = _lib.DT_BF16 if cache.kvl.dtype == torch.bfloat16 else _lib.DT_F32
-    groups = _lib.decode_row_groups(cache.num_nodes, dt, kw["max_steps"], variant)  # host-only query
+    groups = _lib.decode_row_groups(cache.num_nodes, dt, kw["max_steps"], variant,
+                                    state["action_mask"].shape[0])  # host-only query
     c_oracle.am_decode(cache, state, row_groups=groups, **kw)
 
 

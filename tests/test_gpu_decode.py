@@ -71,7 +71,7 @@ def _run(K, backend, g, td0, h, mode, dtype=torch.float32, max_steps=None, varia
                     n_steps=n_steps, variant=variant, **kw)
         torch.cuda.synchronize()
     else:
-        groups = K.decode_row_groups(n, dtype, steps, variant)
+        groups = K.decode_row_groups(n, dtype, steps, variant, b)
         c_oracle.am_decode(cache, st, mode=mode, max_steps=steps, t0=t0, actions=actions, logps=logps, err=err,
                            n_steps=n_steps, row_groups=groups, **kw)
     t = t0 + int(n_steps.max())
@@ -94,23 +94,34 @@ def _assert_bit_exact(hip, ref):
 # bit-exact vs the specified-order oracle
 # ---------------------------------------------------------------------------------------------
 
-CONFIGS = [(torch.float32, "stream"), (torch.bfloat16, "stream"), (torch.bfloat16, "lds")]
-CONFIG_IDS = ["f32-stream", "bf16-stream", "bf16-lds"]
+CONFIGS = [(torch.float32, "stream"), (torch.bfloat16, "stream"), (torch.bfloat16, "lds"), (torch.bfloat16, "wide")]
+CONFIG_IDS = ["f32-stream", "bf16-stream", "bf16-lds", "bf16-wide"]
+
+
+def _skip_if_unservable(g, dtype, variant):
+    n = g.num_loc + (g.env_name == "cvrp")
+    try:
+        __import__("rl4co_amd.kernels").kernels.decode_row_groups(n, dtype, 2 * n, variant, 64)
+    except Exception:
+        pytest.skip(f"variant {variant} cannot serve N={n}")
 
 
 @pytest.mark.parametrize("dtype,variant", CONFIGS, ids=CONFIG_IDS)
 @pytest.mark.parametrize("name", [c for c in SMALL if "greedy" in manifest()[c]["decode_type"]])
 def test_greedy_bit_exact_vs_c_oracle(K, name, dtype, variant):
     g = GoldenCase(name)
+    _skip_if_unservable(g, dtype, variant)
     td0, h = _encode(g)
     _assert_bit_exact(_run(K, "hip", g, td0, h, "greedy", dtype, variant=variant),
                       _run(K, "c", g, td0, h, "greedy", dtype, variant=variant))
 
 
 @pytest.mark.parametrize("dtype,variant", CONFIGS, ids=CONFIG_IDS)
-@pytest.mark.parametrize("name", ["tsp100_b64_sampling", "cvrp100_b64_sampling", "pomo_tsp50_b8_mssampling"])
+@pytest.mark.parametrize("name", ["tsp100_b64_sampling", "cvrp100_b64_sampling", "pomo_tsp50_b8_mssampling",
+                                  "c4_pomo_tsp100_b32_s8_sampling", "c5_cvrp500_b16_sampling"])
 def test_sampling_injected_noise_bit_exact_vs_c_oracle(K, name, dtype, variant):
     g = GoldenCase(name)
+    _skip_if_unservable(g, dtype, variant)
     td0, h = _encode(g)
     b = g.batch * max(g.num_starts, 1)
     n = g.num_loc + (g.env_name == "cvrp")
@@ -230,7 +241,8 @@ def test_greedy_vs_reference_golden(K, name):
             assert (a[r, t0 + int(n_steps[r]):t] == 0).all() and (l[r, t0 + int(n_steps[r]):t] == 0).all()
 
 
-@pytest.mark.parametrize("name", ["tsp100_b64_sampling", "cvrp100_b64_sampling", "pomo_tsp50_b8_mssampling"])
+@pytest.mark.parametrize("name", ["tsp100_b64_sampling", "cvrp100_b64_sampling", "pomo_tsp50_b8_mssampling",
+                                  "c4_pomo_tsp100_b32_s8_sampling", "c5_cvrp500_b16_sampling"])
 def test_sampling_vs_reference_golden(K, name):
     """Fixed-seed sampling: the reference's multinomial stream, re-drawn from its seed, drives the
     kernel; rewards within 1e-5 relative (bit-identical wherever the trajectory is)."""
@@ -315,10 +327,12 @@ def test_variant_selection_and_limits(K):
     rollout is long enough; an explicit 'lds' request that cannot be served is an argument error."""
     from rl4co_amd import _lib
 
-    assert K.decode_row_groups(100, torch.bfloat16, 100) == 16
-    assert K.decode_row_groups(101, torch.bfloat16, 202) == 16
-    assert K.decode_row_groups(100, torch.bfloat16, 1) == 4      # single-step calls stream
-    assert K.decode_row_groups(100, torch.float32, 100) == 2
-    assert K.decode_row_groups(501, torch.bfloat16, 1002) == 4   # does not fit: stream
+    assert K.decode_row_groups(100, torch.bfloat16, 100, "auto", 256) == 16   # few trajectories: resident
+    assert K.decode_row_groups(101, torch.bfloat16, 202, "auto", 1024) == 16
+    assert K.decode_row_groups(100, torch.bfloat16, 100, "auto", 4096) == 4   # chip-filling batch: stream
+    assert K.decode_row_groups(100, torch.bfloat16, 100, "lds", 4096) == 16
+    assert K.decode_row_groups(100, torch.bfloat16, 1, "auto", 64) == 4       # single-step calls stream
+    assert K.decode_row_groups(100, torch.float32, 100, "auto", 64) == 2
+    assert K.decode_row_groups(501, torch.bfloat16, 1002, "auto", 64) == 4    # does not fit: stream
     with pytest.raises(_lib.Rl4coLibraryError):
         K.decode_row_groups(501, torch.bfloat16, 1002, "lds")
