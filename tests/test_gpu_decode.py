@@ -333,6 +333,7 @@ def test_variant_selection_and_limits(K):
     assert K.decode_row_groups(100, torch.bfloat16, 100, "lds", 4096) == 16
     assert K.decode_row_groups(100, torch.bfloat16, 1, "auto", 64) == 4       # single-step calls stream
     assert K.decode_row_groups(100, torch.float32, 100, "auto", 64) == 2
-    assert K.decode_row_groups(501, torch.bfloat16, 1002, "auto", 64) == 4    # does not fit: stream
+    assert K.decode_row_groups(501, torch.bfloat16, 1002, "auto", 64) == 16   # planes too big: wide streaming
+    assert K.decode_row_groups(501, torch.bfloat16, 1002, "auto", 4096) == 4  # chip-filling: one wave each
     with pytest.raises(_lib.Rl4coLibraryError):
         K.decode_row_groups(501, torch.bfloat16, 1002, "lds")
