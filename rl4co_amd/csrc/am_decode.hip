@@ -75,6 +75,18 @@ struct CacheBF16 {
 
 __host__ __device__ inline int lds_pad(int N) { return (N + 63) & ~63; }
 
+// blockIdx -> trajectory. Trajectories are stored s-major (row r = s * B_inst + instance, the
+// reference's batchify layout) and the S trajectories of an instance stream the SAME cache planes.
+// Workgroup b is dispatched to XCD b % 8 (observed placement, used for speed only), and each XCD
+// has its own L2 — so consecutive workgroups of one XCD are given the S starts of one instance:
+// they run concurrently on that XCD and all but the first touch of a plane row hit its L2.
+__device__ inline int trajectory_of_block(int b, int B, int B_inst) {
+  const int S = B / B_inst;
+  if (S == 1 || (B_inst & 7) != 0) return b;
+  const int xcd = b & 7, k = b >> 3;
+  return (k % S) * B_inst + (k / S) * 8 + xcd;
+}
+
 template <class C, int ENV>
 __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_args a) {
   constexpr int EPL = C::EPL;
@@ -86,7 +98,7 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
 
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
-  const int r = blockIdx.x;  // trajectory
+  const int r = trajectory_of_block(blockIdx.x, a.B, a.B_inst);
   const int N = a.N;
   const int Np = lds_pad(N);
   float* sc = reinterpret_cast<float*>(smem);  // [Np*kH] per-head scores, (j*kH + h)
@@ -386,7 +398,7 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x;
   const int w = tid >> 6, lane = tid & 63;
-  const int r = blockIdx.x;
+  const int r = trajectory_of_block(blockIdx.x, a.B, a.B_inst);
   const int N = a.N;
   const int nw = (N + 3) & ~3;
   uint16_t* planes = reinterpret_cast<uint16_t*>(smem);             // [3][N][128] bf16 (RESIDENT only)

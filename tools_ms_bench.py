@@ -1,0 +1,36 @@
+"""Multistart (POMO) decode microbench: B_inst instances x S starts, TSP-100, bf16 planes."""
+import sys, torch
+sys.path.insert(0, "/root/repo")
+from rl4co_amd.policy import AttentionModelPolicy
+from rl4co_amd.envs import get_env
+from rl4co_amd import kernels as K
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+variants = sys.argv[3:] or ["stream"]
+torch.manual_seed(0)
+pol = AttentionModelPolicy("tsp", cache_dtype=torch.bfloat16, encoder_autocast=torch.bfloat16,
+                           num_encoder_layers=6, normalization="instance", use_graph_context=False).cuda().eval()
+env = get_env("tsp", generator_params=dict(num_loc=100, device="cuda"), device="cuda")
+td = env.reset(batch_size=[B])
+with torch.inference_mode():
+    cache, _ = pol._packed_encoder().encode(td, torch.bfloat16)
+    for variant in variants:
+        times = []
+        for it in range(4):
+            st = pol._initial_state(td, S)
+            actions = torch.zeros(B * S, 100, dtype=torch.int64, device="cuda")
+            logps = torch.zeros(B * S, 100, device="cuda")
+            err = K.new_error_word("cuda")
+            first = env.select_start_nodes(td, S)
+            actions[:, 0] = first
+            pol._env_step_state(st, first, err)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            K.am_decode(cache, st, mode="sampling", max_steps=99, t0=1, actions=actions, logps=logps, err=err,
+                        philox_seed=7, variant=variant)
+            e1.record(); torch.cuda.synchronize()
+            K.raise_if_error(err)
+            times.append(e0.elapsed_time(e1))
+        ms = min(times[1:])
+        print(f"B={B} S={S} {variant}: {ms:.3f} ms ({B*S*99/ms/1e3:.1f} M trajectory-steps/s, "
+              f"{B*S*99*78040/ms/1e6:.0f} GB/s algorithmic per-trajectory bytes)")
