@@ -285,11 +285,11 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
       for (int h = 0; h < H; ++h) {
         float tmp[64];
         for (int g = 0; g < G; ++g) tmp[g] = lgp[g * H + h];
-        const float l = tree_sum(tmp, G);
+        const float rl = 1.0f / tree_sum(tmp, G); /* one division per head; heads = o * (1/l) */
         for (int e = 0; e < DH; ++e) {
           const int d = h * DH + e;
           for (int g = 0; g < G; ++g) tmp[g] = og[g * D + d];
-          o[d] = tree_sum(tmp, G) / l;
+          o[d] = tree_sum(tmp, G) * rl;
         }
       }
       /* pass 3: logits */

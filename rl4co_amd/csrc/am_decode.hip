@@ -29,7 +29,7 @@
 //                 ascending, from 0]
 //   softmax     = m = max_j score ; p_j = exp(score_j - m) ; per row group g:
 //                 l_g = sum_j p_j, o_g[d] = fma(p_j, v_j[d], o_g[d]) over its rows in
-//                 ascending j ; l = tree_g(l_g), o[d] = tree_g(o_g[d]) ; heads[d] = o[d] / l
+//                 ascending j ; l = tree_g(l_g), o[d] = tree_g(o_g[d]) ; heads[d] = o[d] * (1 / l)
 //   logit(j)    = tree over the row's LPR chunks of [fma chain over EPL dims] ; / fl(sqrt(128))
 //   log_softmax = zmax = max ; s_k = sum over j = k, k+64, ... of exp(z_j - zmax) (k < 64) ;
 //                 lse = log(tree_k(s_k)) ; lp_j = (z_j - zmax) - lse
@@ -105,6 +105,7 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
   float* lg = sc + Np * kH;                    // [Np] raw logits -> clipped logits -> log-probs
   uint8_t* mk = reinterpret_cast<uint8_t*>(lg + Np);  // [Np] 1 = feasible
   uint8_t* vis = mk + Np;                             // [Np] CVRP visited flags
+  float* mh = reinterpret_cast<float*>(vis + Np);     // [8] per-head score maxima
 
   const int cb = r % a.B_inst;  // instance whose cache this trajectory reads
   const int rg = lane / LPR;    // row group inside a wave-wide load
@@ -192,6 +193,15 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
       }
     }
     m = rl4co::bfly_max<LPR, 64>(m);
+    if (rg == 0 && (li % LPH) == 0) mh[hd] = m;
+    __syncthreads();
+    // softmax numerators once per (node, head) — lane-strided over the N*8 scores, so each
+    // exp is evaluated exactly once instead of once per lane of the head (index % 8 = head is
+    // fixed per lane because 64 % 8 == 0)
+    {
+      const float mm = mh[lane & (kH - 1)];
+      for (int idx = lane; idx < N * kH; idx += 64) sc[idx] = rl4co_expf(sc[idx] - mm);
+    }
     __syncthreads();
 
     // ---- pass 2: softmax weights and weighted value sum ------------------------------
@@ -212,15 +222,15 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
         const bool valid = j < N;
         float v[EPL];
         C::cvt(rw[u], v);
-        const float p = valid ? rl4co_expf(sc[j * kH + hd] - m) : 0.0f;
+        const float p = valid ? sc[j * kH + hd] : 0.0f;
         l = l + p;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) o[e] = fmaf(p, v[e], o[e]);
       }
     }
-    l = rl4co::bfly_sum<LPR, 64>(l);
+    l = 1.0f / rl4co::bfly_sum<LPR, 64>(l);  // one IEEE division per step; heads = o * (1/l)
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) o[e] = rl4co::bfly_sum<LPR, 64>(o[e]) / l;
+    for (int e = 0; e < EPL; ++e) o[e] = rl4co::bfly_sum<LPR, 64>(o[e]) * l;
 
     // ---- pass 3: pointer logits against the (project_out-folded) logit key -----------
     for (int j0 = 0; j0 < N; j0 += RPL * kUnroll) {
@@ -252,7 +262,7 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
       if (z != z) nan_seen = true;  // attention.py:295-296
       if (a.tanh_clipping > 0.0f) z = rl4co_tanhf(z) * a.tanh_clipping;
       if (a.mask_logits && mk[j] == 0) z = kNegInf;
-      z = z / a.temperature;
+      if (a.temperature != 1.0f) z = z / a.temperature;  // x / 1.0f == x exactly
       lg[j] = z;
       zmax = fmaxf(zmax, z);
     }
@@ -518,7 +528,20 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
     m = rl4co::bfly_max<LPR, 64>(m);
     if (rg == 0 && (li & 1) == 0) mpart[w * kH + hd] = m;
     __syncthreads();  // B1: all head maxima visible
-    m = fmaxf(fmaxf(mpart[hd], mpart[kH + hd]), fmaxf(mpart[2 * kH + hd], mpart[3 * kH + hd]));
+    // softmax numerators of this wave's rows, each evaluated once (lane-strided over the wave's
+    // 4-row chunks: 32 consecutive floats per chunk, head = index % 8 fixed per lane)
+    {
+      const int hh = lane & (kH - 1);
+      const float mm = fmaxf(fmaxf(mpart[hh], mpart[kH + hh]), fmaxf(mpart[2 * kH + hh], mpart[3 * kH + hh]));
+      for (int tix = lane; tix < 32 * iters; tix += 64) {
+        const int row0 = kLdsGroups * (tix >> 5) + 4 * w;  // first row of the chunk
+        if (row0 + ((tix & 31) >> 3) < N) {
+          float* p = sc + row0 * kH + (tix & 31);
+          *p = rl4co_expf(*p - mm);
+        }
+      }
+    }
+    wave_lds_sync();  // the numerators are consumed by this same wave only
 
     // ---- pass 2: softmax weights and weighted values ---------------------------------------------
     float l = 0.0f;
@@ -538,7 +561,7 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
         const bool valid = j < N;
         float v[EPL];
         C::cvt(rw[u], v);
-        const float p = valid ? rl4co_expf(sc[j * kH + hd] - m) : 0.0f;
+        const float p = valid ? sc[j * kH + hd] : 0.0f;
         l = l + p;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) o[e] = fmaf(p, v[e], o[e]);
@@ -553,11 +576,11 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
       if ((li & 1) == 0) *lpart(w, hd) = l;
     }
     __syncthreads();  // B2: partials of the four waves visible
-    l = (*lpart(0, hd) + *lpart(1, hd)) + (*lpart(2, hd) + *lpart(3, hd));
+    l = 1.0f / ((*lpart(0, hd) + *lpart(1, hd)) + (*lpart(2, hd) + *lpart(3, hd)));
 #pragma unroll
     for (int e = 0; e < EPL; ++e) {
       const int d = e0 + e;
-      o[e] = ((*opart(0, d) + *opart(1, d)) + (*opart(2, d) + *opart(3, d))) / l;
+      o[e] = ((*opart(0, d) + *opart(1, d)) + (*opart(2, d) + *opart(3, d))) * l;
     }
 
     // ---- pass 3: logits of this wave's rows ---------------------------------------------------------
@@ -591,7 +614,7 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
         if (z != z) nan_seen = true;
         if (a.tanh_clipping > 0.0f) z = rl4co_tanhf(z) * a.tanh_clipping;
         if (a.mask_logits && mk[j] == 0) z = kNegInf;
-        z = z / a.temperature;
+        if (a.temperature != 1.0f) z = z / a.temperature;
         lg[j] = z;
         zmax = fmaxf(zmax, z);
       }
@@ -773,7 +796,7 @@ int launch(const rl4co_am_decode_args& a, hipStream_t stream) {
 extern "C" int rl4co_am_decode_lds_bytes(int N, int env) {
   (void)env;
   const int Np = lds_pad(N);
-  return Np * kH * 4 + Np * 4 + Np + Np;
+  return Np * kH * 4 + Np * 4 + Np + Np + kH * 4;
 }
 
 extern "C" int rl4co_am_decode_row_groups(const rl4co_am_decode_args* args) {
