@@ -215,6 +215,16 @@ def main() -> None:
         probe_gbs = 5 * probe.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del probe
         value = total_instance_steps / wall
+        workload = (f"BASELINE configs[1]: {args.env.upper()}Env num_loc={args.num_loc} batch={args.batch}/GPU "
+                    f"AttentionModel(3L,d128,h8) {args.decode} rollout, {args.encoder_dtype} encoder GEMMs, {args.cache_dtype} cache")
+        # HBM bytes per decode launch from the separate rocprofv3 --pmc passes (tools/profile_round.sh
+        # + tools/profile_parse.py write profiles/pmc_traffic.json); null when this workload was not profiled
+        traffic = None
+        try:
+            table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            traffic = table.get(workload, {}).get("traffic_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
         line = {
             "metric": "decode_steps_per_sec",
             "value": value,
@@ -229,8 +239,7 @@ def main() -> None:
             "dtype": "f32" if args.cache_dtype == "f32" else "f32 arithmetic on bf16 cache planes",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[1]: {args.env.upper()}Env num_loc={args.num_loc} batch={args.batch}/GPU "
-                            f"AttentionModel(3L,d128,h8) {args.decode} rollout, {args.encoder_dtype} encoder GEMMs, {args.cache_dtype} cache",
+                "workload": workload,
                 "env": args.env, "num_loc": args.num_loc, "batch_per_gpu": args.batch, "decode_steps": t_steps,
                 "decode_type": args.decode, "cache_dtype": args.cache_dtype, "encoder_dtype": args.encoder_dtype,
                 "check_solution": not args.no_check_solution, "parallelism": f"replicas x{world} (instances sharded)",
@@ -245,7 +254,7 @@ def main() -> None:
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
                 "algorithmic_bytes_per_instance_step": per_unit,
                 "instance_steps_per_launch": units_per_launch,
                 "bytes_per_launch": bytes_per_launch,

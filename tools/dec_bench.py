@@ -1,6 +1,6 @@
 """Micro-benchmark of the decode kernel alone (TSP-100 x 4096, bf16 planes), both variants."""
 import sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from rl4co_amd.policy import AttentionModelPolicy
 from rl4co_amd.envs import get_env
 from rl4co_amd import kernels as K

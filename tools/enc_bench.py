@@ -1,6 +1,6 @@
 """Micro-benchmark of the fused encoder kernel alone (TSP-100 x 4096), HIP events."""
 import sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from rl4co_amd.policy import AttentionModelPolicy
 from rl4co_amd.envs import get_env
 torch.manual_seed(0)

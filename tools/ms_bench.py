@@ -1,6 +1,6 @@
 """Multistart (POMO) decode microbench: B_inst instances x S starts, TSP-100, bf16 planes."""
 import sys, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from rl4co_amd.policy import AttentionModelPolicy
 from rl4co_amd.envs import get_env
 from rl4co_amd import kernels as K
