@@ -26,6 +26,8 @@
 //     operands of each product and therefore cancels.
 //   * exchanges through LDS only where a GEMM needs all 128 input dims produced by other waves:
 //     attention output -> out-proj, norm1 output -> FFN1, FFN hidden chunks -> FFN2.
+//   * 70 KB of LDS and <= 256 registers per wave: two instances per CU, so one's softmax / norm /
+//     conversion VALU phases overlap the other's MFMA phases.
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -179,13 +181,14 @@ __device__ inline void residual_norm(__bf16* xs, f32x16 (&y)[TT], int dim0, cons
   store_t<TT>(xs, y, dim0, lane);
 }
 
+// Two workgroups per CU (70 KB LDS, <= 256 registers): while one instance sits in a VALU-heavy
+// phase (softmax, norms, conversions) the other one's waves keep the matrix pipe busy.
 template <int TT>
-__global__ void __launch_bounds__(kThreads) am_encoder_kernel(const rl4co_am_encoder_args a) {
+__global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_encoder_args a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __bf16* xs = reinterpret_cast<__bf16*>(smem);  // residual stream [128][kRS]
-  __bf16* ys = xs + 128 * kRS;                   // attention output / FFN hidden chunk (even)
-  __bf16* zs = ys + 128 * kRS;                   // FFN hidden chunk (odd)
-  float* meanv = reinterpret_cast<float*>(zs + 128 * kRS);  // [128]
+  __bf16* ys = xs + 128 * kRS;                   // Q^T (wave-private columns) -> attention output -> FFN hidden chunk
+  float* meanv = reinterpret_cast<float*>(ys + 128 * kRS);  // [128]
 
   const int tid = threadIdx.x;
   const int w = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -235,7 +238,7 @@ __global__ void __launch_bounds__(kThreads) am_encoder_kernel(const rl4co_am_enc
     L.n2b = a.n2_shift + layer * kD;
 
     // ---- Q, K (transposed form) and V (plain form) of head pair w, kept as fragments ---------
-    bf16x8 qf[TT][2], kf[TT][2], vf[TT][2];
+    bf16x8 kf[TT][2], vf[TT][2];
     {
       f32x16 acc[TT];
 #pragma unroll
@@ -246,9 +249,10 @@ __global__ void __launch_bounds__(kThreads) am_encoder_kernel(const rl4co_am_enc
 #pragma unroll
         // 1/sqrt(16) and log2(e) folded into Q: softmax below is exp2(s - max)
         for (int r = 0; r < 16; ++r) acc[tt][r] = (acc[tt][r] + L.bqkv[32 * w + rowmap(r, hi)]) * kQScale;
-        qf[tt][0] = frag_from_acc(acc[tt], 0);
-        qf[tt][1] = frag_from_acc(acc[tt], 1);
       }
+      // Q^T parked in this wave's own 32 columns of ys (each lane re-reads only its own token
+      // row, and later overwrites it with the attention output of that same row)
+      store_t<TT>(ys, acc, 32 * w, lane);
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) acc[tt] = zero16();
       gemm_t<TT>(acc, L.wqkv, 8, 4 + w, 0, xs, lane);
@@ -274,51 +278,65 @@ __global__ void __launch_bounds__(kThreads) am_encoder_kernel(const rl4co_am_enc
     }
 
     // ---- attention for heads 2w, 2w+1 over all queries, wave-private ---------------------------
-    {
-      f32x16 o[TT];
 #pragma unroll
-      for (int qt = 0; qt < TT; ++qt) o[qt] = zero16();
+    for (int qt = 0; qt < TT; ++qt) {
+      __bf16* qrow = ys + (32 * qt + l31) * kRS + 32 * w;
+      f32x16 o = zero16();
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
+        bf16x8 qf;
+        {
+          const bf16x4 lo = *reinterpret_cast<const bf16x4*>(qrow + 16 * hh + 4 * hi);
+          const bf16x4 up = *reinterpret_cast<const bf16x4*>(qrow + 16 * hh + 8 + 4 * hi);
 #pragma unroll
-        for (int qt = 0; qt < TT; ++qt) {
-          f32x16 s[TT];
-          float m = -__builtin_huge_valf();
-#pragma unroll
-          for (int kt = 0; kt < TT; ++kt) {
-            s[kt] = mfma(kf[kt][hh], qf[qt][hh], zero16());
-            if (kt == TT - 1) {  // TT = ceil(N/32): only the last key tile can hold padding keys
-#pragma unroll
-              for (int r = 0; r < 16; ++r)
-                s[kt][r] = (32 * kt + rowmap(r, hi) < N) ? s[kt][r] : -__builtin_huge_valf();
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) m = fmaxf(m, s[kt][r]);
+          for (int i = 0; i < 4; ++i) {
+            qf[i] = lo[i];
+            qf[4 + i] = up[i];
           }
-          m = fmaxf(m, rl4co::bfly_f<32>(m));
-          float l = 0.0f;
-#pragma unroll
-          for (int kt = 0; kt < TT; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float p = __builtin_amdgcn_exp2f(s[kt][r] - m);
-              s[kt][r] = p;
-              l += p;
-            }
-          }
-          l += rl4co::bfly_f<32>(l);
-          f32x16 acc = zero16();
-#pragma unroll
-          for (int kt = 0; kt < TT; ++kt) {
-            acc = mfma(vf[kt][0], frag_from_acc(s[kt], 0), acc);
-            acc = mfma(vf[kt][1], frag_from_acc(s[kt], 1), acc);
-          }
-          const float inv = 1.0f / l;
-#pragma unroll
-          for (int r = 0; r < 8; ++r) o[qt][8 * hh + r] = acc[8 * hh + r] * inv;
         }
+        f32x16 s[TT];
+        float m = -__builtin_huge_valf();
+#pragma unroll
+        for (int kt = 0; kt < TT; ++kt) {
+          s[kt] = mfma(kf[kt][hh], qf, zero16());
+          if (kt == TT - 1) {  // TT = ceil(N/32): only the last key tile can hold padding keys
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              s[kt][r] = (32 * kt + rowmap(r, hi) < N) ? s[kt][r] : -__builtin_huge_valf();
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) m = fmaxf(m, s[kt][r]);
+        }
+        m = fmaxf(m, rl4co::bfly_f<32>(m));
+        float l = 0.0f;
+#pragma unroll
+        for (int kt = 0; kt < TT; ++kt) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(s[kt][r] - m);
+            s[kt][r] = p;
+            l += p;
+          }
+        }
+        l += rl4co::bfly_f<32>(l);
+        f32x16 acc = zero16();
+#pragma unroll
+        for (int kt = 0; kt < TT; ++kt) {
+          acc = mfma(vf[kt][0], frag_from_acc(s[kt], 0), acc);
+          acc = mfma(vf[kt][1], frag_from_acc(s[kt], 1), acc);
+        }
+        const float inv = 1.0f / l;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) o[8 * hh + r] = acc[8 * hh + r] * inv;
       }
-      store_t<TT>(ys, o, 32 * w, lane);  // attention output rows [token][dims of head pair w]
+      // attention output row [token][dims of head pair w] over the Q^T this lane just consumed
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        bf16x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (__bf16)o[4 * c + i];
+        *reinterpret_cast<bf16x4*>(qrow + 8 * c + 4 * hi) = v;
+      }
     }
     __syncthreads();
 
@@ -338,7 +356,6 @@ __global__ void __launch_bounds__(kThreads) am_encoder_kernel(const rl4co_am_enc
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) y2[tt] = zero16();
       for (int c = 0; c < 4; ++c) {
-        __bf16* hb = (c & 1) ? zs : ys;
         f32x16 h1[TT];
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) h1[tt] = zero16();
@@ -347,9 +364,10 @@ __global__ void __launch_bounds__(kThreads) am_encoder_kernel(const rl4co_am_enc
         for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) h1[tt][r] = fmaxf(h1[tt][r] + L.b1[32 * (4 * c + w) + rowmap(r, hi)], 0.0f);
-        store_t<TT>(hb, h1, 32 * w, lane);
+        if (c > 0) __syncthreads();  // every wave is done reading the previous chunk
+        store_t<TT>(ys, h1, 32 * w, lane);
         __syncthreads();
-        gemm_t<TT>(y2, L.w2, 32, w, 8 * c, hb, lane);
+        gemm_t<TT>(y2, L.w2, 32, w, 8 * c, ys, lane);
       }
       residual_norm<TT>(xs, y2, 32 * w, L.b2, L.n2a, L.n2b, a.norm, N, lane);
     }
@@ -427,7 +445,7 @@ __global__ void __launch_bounds__(kThreads) am_encoder_kernel(const rl4co_am_enc
 
 template <int TT>
 int launch_encoder(const rl4co_am_encoder_args& a, hipStream_t stream) {
-  const int lds = 3 * 128 * kRS * 2 + kD * 4;
+  const int lds = 2 * 128 * kRS * 2 + kD * 4;
   RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_encoder_kernel<TT>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipLaunchKernelGGL((am_encoder_kernel<TT>), dim3(a.B), dim3(kThreads), lds, stream, a);
