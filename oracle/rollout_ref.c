@@ -14,7 +14,8 @@
  *  2. the AttentionModel decode loop (models/common/constructive/base.py:226-238 and callees —
  *     env_embeddings/context.py:105-149, zoo/am/decoder.py:128-193, nn/attention.py:274-320,
  *     utils/decoding.py:138-188,344-461, tsp/env.py:60-86, cvrp/env.py:66-96,126-136) in the
- *     specified operation order documented at the top of rl4co_amd/csrc/am_decode.hip. No fixed
+ *     specified operation order documented at the top of rl4co_amd/csrc/am_decode.hip (including
+ *     the per-step list of nodes actually read: masked nodes contribute an exact 0). No fixed
  *     order can be bitwise equal to ATen's opaque SDPA/GEMM kernels, so the
  *     chain of evidence is: reference source == torch restatement (bit-exact, oracle/gen_golden.py)
  *     ~= this file (same actions except fp32 near-ties, log-likelihood <= 1e-5; tests/
@@ -205,6 +206,7 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
   uint8_t* vis = (uint8_t*)malloc((size_t)N);
   float* og = (float*)malloc(sizeof(float) * (size_t)G * D);
   float* lgp = (float*)malloc(sizeof(float) * (size_t)G * H);
+  int* fl = (int*)malloc(sizeof(int) * (size_t)N);
   const float sqrt_d = 11.3137084989847604f;
   const float neg_inf = -INFINITY;
   const int single = a->max_steps == 1;
@@ -244,34 +246,40 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
         }
         q[d] = v * 0.25f;
       }
-      /* pass 1: scores */
+      /* the nodes this step reads: feasible ones ascending (or all, if a mask flag is off) */
+      int F = 0;
+      for (int j = 0; j < N; ++j)
+        if (!(a->mask_inner && a->mask_logits) || mk[j]) fl[F++] = j;
+      /* pass 1: scores, indexed by list position c */
       float m[H];
       for (int h = 0; h < H; ++h) m[h] = neg_inf;
-      for (int j = 0; j < N; ++j) {
+      for (int c = 0; c < F; ++c) {
+        const int j = fl[c];
         const int feas = !a->mask_inner || mk[j] != 0;
         for (int h = 0; h < H; ++h) {
           float part[4];
-          for (int c = 0; c < LPH; ++c) {
+          for (int cc = 0; cc < LPH; ++cc) {
             float acc = 0.0f;
             for (int e = 0; e < EPL; ++e) {
-              const int d = h * DH + c * EPL + e;
+              const int d = h * DH + cc * EPL + e;
               acc = fmaf(q[d], cache_at(a->glimpse_key, a->cache_dtype, cbase + (int64_t)j * a->kvl_row_stride + d),
                          acc);
             }
-            part[c] = acc;
+            part[cc] = acc;
           }
           const float s = feas ? tree_sum(part, LPH) : neg_inf;
-          sc[j * H + h] = s;
+          sc[c * H + h] = s;
           m[h] = fmaxf(m[h], s);
         }
       }
-      /* pass 2: softmax-weighted values, per row group then tree */
+      /* pass 2: softmax-weighted values, per row group (c % G) then tree */
       for (int i = 0; i < G * D; ++i) og[i] = 0.0f;
       for (int i = 0; i < G * H; ++i) lgp[i] = 0.0f;
-      for (int j = 0; j < N; ++j) {
-        const int g = j % G;
+      for (int c = 0; c < F; ++c) {
+        const int j = fl[c];
+        const int g = c % G;
         for (int h = 0; h < H; ++h) {
-          const float p = rl4co_expf(sc[j * H + h] - m[h]);
+          const float p = rl4co_expf(sc[c * H + h] - m[h]);
           lgp[g * H + h] = lgp[g * H + h] + p;
           for (int e = 0; e < DH; ++e) {
             const int d = h * DH + e;
@@ -292,44 +300,49 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
           o[d] = tree_sum(tmp, G) * rl;
         }
       }
-      /* pass 3: logits */
+      /* pass 3: logits of the listed nodes */
       int nan_seen = 0;
       float zmax = neg_inf;
-      for (int j = 0; j < N; ++j) {
+      for (int c = 0; c < F; ++c) {
+        const int j = fl[c];
         float part[32];
-        for (int c = 0; c < LPR; ++c) {
+        for (int cc = 0; cc < LPR; ++cc) {
           float acc = 0.0f;
           for (int e = 0; e < EPL; ++e) {
-            const int d = c * EPL + e;
+            const int d = cc * EPL + e;
             acc = fmaf(o[d], cache_at(a->logit_key, a->cache_dtype, cbase + (int64_t)j * a->kvl_row_stride + d), acc);
           }
-          part[c] = acc;
+          part[cc] = acc;
         }
         float z = tree_sum(part, LPR) / sqrt_d;
         if (z != z) nan_seen = 1;
         if (a->tanh_clipping > 0.0f) z = rl4co_tanhf(z) * a->tanh_clipping;
         if (a->mask_logits && mk[j] == 0) z = neg_inf;
-        z = z / a->temperature;
-        lg[j] = z;
+        if (a->temperature != 1.0f) z = z / a->temperature;
+        lg[c] = z;
         zmax = fmaxf(zmax, z);
       }
       if (nan_seen) errbits |= RL4CO_EBIT_NAN_LOGIT;
-      /* log_softmax: 64 lane-strided partial sums, then tree */
+      /* log_softmax: 64 position-strided partial sums, then tree */
       float part64[64];
       for (int k = 0; k < 64; ++k) {
         float s = 0.0f;
-        for (int j = k; j < N; j += 64) s = s + rl4co_expf(lg[j] - zmax);
+        for (int c = k; c < F; c += 64) s = s + rl4co_expf(lg[c] - zmax);
         part64[k] = s;
       }
       const float lse = rl4co_logf(tree_sum(part64, 64));
       /* selection */
       const int64_t tcol = (int64_t)a->t0 + t;
       float best = neg_inf;
-      int bi = -1;
+      int bc = -1;
       for (int k = 0; k < 64; ++k) part64[k] = 0.0f;
-      for (int j = 0; j < N; ++j) {
-        const float lp = (lg[j] - zmax) - lse;
-        lg[j] = lp;
+      float* alp = a->all_logps ? a->all_logps + ((int64_t)r * a->out_stride + tcol) * N : NULL;
+      if (alp)
+        for (int j = 0; j < N; ++j) alp[j] = neg_inf;
+      for (int c = 0; c < F; ++c) {
+        const int j = fl[c];
+        const float lp = (lg[c] - zmax) - lse;
+        lg[c] = lp;
         float key = lp;
         if (a->mode == RL4CO_DECODE_SAMPLE) {
           const float nz = a->exp_noise ? a->exp_noise[((int64_t)t * a->B + r) * N + j]
@@ -337,20 +350,29 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
                                                            (uint32_t)r, (uint32_t)j);
           key = rl4co_expf(lp) / nz;
         }
-        if (bi < 0 || key > best) { /* ascending j + strict '>' == lowest index among maxima */
+        if (bc < 0 || key > best) { /* ascending c + strict '>' == lowest index among maxima */
           best = key;
-          bi = j;
+          bc = c;
         }
-        if (a->entropy && lp > neg_inf) part64[j % 64] = fmaf(rl4co_expf(lp), lp, part64[j % 64]);
-        if (a->all_logps) a->all_logps[((int64_t)r * a->out_stride + tcol) * N + j] = lp;
+        if (a->entropy && lp > neg_inf) part64[c % 64] = fmaf(rl4co_expf(lp), lp, part64[c % 64]);
+        if (alp) alp[j] = lp;
       }
       if (a->entropy) ent_acc = ent_acc - tree_sum(part64, 64);
-      if (a->mode == RL4CO_DECODE_EVALUATE) bi = (int)a->forced_actions[(int64_t)r * a->out_stride + tcol];
-      if (bi < 0 || bi >= N) {
-        errbits |= RL4CO_EBIT_INFEASIBLE;
-        bi = 0;
+      int bi;
+      float logp;
+      if (a->mode == RL4CO_DECODE_EVALUATE) {
+        bi = (int)a->forced_actions[(int64_t)r * a->out_stride + tcol];
+        if (bi < 0 || bi >= N) {
+          errbits |= RL4CO_EBIT_INFEASIBLE;
+          bi = 0;
+        }
+        logp = neg_inf; /* a node outside the list is masked out */
+        for (int c = 0; c < F; ++c)
+          if (fl[c] == bi) logp = lg[c];
+      } else {
+        bi = bc >= 0 ? fl[bc] : 0;
+        logp = bc >= 0 ? lg[bc] : neg_inf;
       }
-      const float logp = lg[bi];
       if (mk[bi] == 0) errbits |= RL4CO_EBIT_INFEASIBLE;
       if (!(logp > -1000.0f)) errbits |= RL4CO_EBIT_NEG_INF_LOGP;
       a->actions[(int64_t)r * a->out_stride + tcol] = bi;
@@ -393,7 +415,7 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
     errbits_all |= errbits;
   }
   if (a->err) *a->err |= (int32_t)errbits_all;
-  free(sc); free(lg); free(mk); free(vis); free(og); free(lgp);
+  free(sc); free(lg); free(mk); free(vis); free(og); free(lgp); free(fl);
   return 0;
 }
 

@@ -1,14 +1,11 @@
 // am_decode.hip — fused AttentionModel decode step / persistent rollout for gfx950.
 //
-// One wavefront (= one 64-thread workgroup) owns one trajectory for the whole
-// autoregressive loop. Per step it streams the trajectory's three folded cache
-// planes (glimpse key, glimpse value, logit key; [N,128] each) from HBM with
-// 16-byte coalesced loads (kUnroll wave-wide loads in flight per pass), keeps the
-// feasibility mask / per-head scores / logits in LDS, reduces with wave
-// butterflies, selects the action (greedy, sampled or forced), updates the TSP /
-// CVRP state in registers+LDS and goes on to the next step — no host round trip,
-// no inter-workgroup traffic (instances are independent), no weights (they were
-// folded into the cache once per rollout, rl4co_amd/cache.py).
+// One launch runs the whole autoregressive loop of every trajectory: per step it streams the
+// trajectory's three folded cache planes (glimpse key, glimpse value, logit key; [N,128] each),
+// keeps the feasibility mask / per-head scores / logits in LDS, reduces with DPP / permlane
+// butterflies, selects the action (greedy, sampled or forced), updates the TSP / CVRP state and
+// goes on to the next step — no host round trip, no inter-workgroup traffic (instances are
+// independent), no weights (they were folded into the cache once per rollout, rl4co_amd/cache.py).
 //
 // Reference semantics restated (file:line in the reference checkout):
 //   context / query      env_embeddings/context.py:105-149, zoo/am/decoder.py:128-140
@@ -18,23 +15,33 @@
 //   env transition       envs/routing/tsp/env.py:60-86, envs/routing/cvrp/env.py:66-96,126-136
 //   loop                 models/common/constructive/base.py:226-238
 //
+// Masked nodes are never read. The reference computes scores, values and logits for all N nodes
+// and then overwrites the infeasible ones with -inf (attention.py:306-312, decoding.py:174-178):
+// their softmax weight is exactly 0 and their log-prob exactly -inf. With mask_inner and
+// mask_logits both on (the defaults) a step therefore only needs the cache rows of the F
+// currently feasible nodes: each step compacts them (ascending node index) into a list and the
+// three passes walk that list — on a TSP rollout F = N - t, i.e. half the bytes and half the
+// arithmetic of the reference's formulation, with bit-identical semantics (a skipped term is an
+// exact +0). If either flag is off the list simply holds all N nodes.
+//
 // Arithmetic order — the parity contract, mirrored value-for-value by
 // oracle/rollout_ref.c (every op is an IEEE fp32 add/mul/fma/div, -ffp-contract=off):
-//   EPL = elements per lane per 16-byte load (4 fp32 / 8 bf16); a cache row is
-//   covered by LPR = 128/EPL lanes, a wave-wide load covers G = 64/LPR rows ("row
-//   groups": row j belongs to group j % G), a head by LPH = 16/EPL lanes.
+//   list        = feasible nodes ascending (or all nodes), c = position in the list, F = length
+//   EPL = elements per lane per 16-byte load (4 fp32 / 8 bf16); a cache row is covered by
+//   LPR = 128/EPL lanes, a head by LPH = 16/EPL lanes; list entry c belongs to row group c % G
+//   (G = rows handled concurrently: 64/LPR per wave x waves per trajectory).
 //   tree(x_0..x_{n-1}) = pairwise butterfly sum: tree(lo half) + tree(hi half).
 //   q[d]        = ((ctx_first[first][d] + ctx_cur[cur][d]) + q_bias[d]) * 0.25   (TSP, i > 0)
-//   score(j,h)  = tree over the head's LPH chunks of [fma chain over the chunk's EPL dims,
+//   score(c,h)  = tree over the head's LPH chunks of [fma chain over the chunk's EPL dims,
 //                 ascending, from 0]
-//   softmax     = m = max_j score ; p_j = exp(score_j - m) ; per row group g:
-//                 l_g = sum_j p_j, o_g[d] = fma(p_j, v_j[d], o_g[d]) over its rows in
-//                 ascending j ; l = tree_g(l_g), o[d] = tree_g(o_g[d]) ; heads[d] = o[d] * (1 / l)
-//   logit(j)    = tree over the row's LPR chunks of [fma chain over EPL dims] ; / fl(sqrt(128))
-//   log_softmax = zmax = max ; s_k = sum over j = k, k+64, ... of exp(z_j - zmax) (k < 64) ;
-//                 lse = log(tree_k(s_k)) ; lp_j = (z_j - zmax) - lse
+//   softmax     = m = max_c score ; p_c = exp(score_c - m) ; per row group g:
+//                 l_g = sum p_c, o_g[d] = fma(p_c, v_c[d], o_g[d]) over its entries in ascending c ;
+//                 heads[d] = tree_g(o_g[d]) * (1 / tree_g(l_g))
+//   logit(c)    = tree over the row's LPR chunks of [fma chain over EPL dims] ; / fl(sqrt(128))
+//   log_softmax = zmax = max ; s_k = sum over c = k, k+64, ... of exp(z_c - zmax) (k < 64) ;
+//                 lse = log(tree_k(s_k)) ; lp_c = (z_c - zmax) - lse
 //   argmax      = maximum key, lowest index on ties (greedy: key = lp ; sampling:
-//                 key = exp(lp) / noise)
+//                 key = exp(lp) / noise[node])
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -47,6 +54,7 @@ constexpr int kH = RL4CO_NUM_HEADS;
 constexpr int kDH = kD / kH;
 constexpr int kUnroll = 4;  // wave-wide 1 KiB loads kept in flight per pass
 constexpr float kNegInf = -__builtin_huge_valf();
+constexpr float kSqrtD = 11.3137084989847604f;  // fl32(sqrt(128)), attention.py:293
 
 struct CacheF32 {
   using elem = float;
@@ -87,6 +95,161 @@ __device__ inline int trajectory_of_block(int b, int B, int B_inst) {
   return (k % S) * B_inst + (k / S) * 8 + xcd;
 }
 
+// LDS ordering inside ONE wave (cross-lane hand-off through LDS, no other wave involved)
+__device__ inline void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+struct TrajState {
+  int cur, first;
+  long long step_i;
+  float used;
+  bool done;
+  uint32_t errbits;
+  float ent_acc;
+};
+
+// One wave: compact the nodes this step has to read (ascending) into fl[0..F).
+__device__ inline int build_list(const rl4co_am_decode_args& a, const uint8_t* mk, uint16_t* fl, int N, int lane) {
+  int F = 0;
+  if (a.mask_inner && a.mask_logits) {
+    for (int j0 = 0; j0 < N; j0 += 64) {
+      const int j = j0 + lane;
+      const bool f = j < N && mk[j] != 0;
+      const unsigned long long bal = __ballot(f);
+      if (f) fl[F + __popcll(bal & ((1ull << lane) - 1ull))] = (uint16_t)j;
+      F += __popcll(bal);
+    }
+  } else {
+    for (int j = lane; j < N; j += 64) fl[j] = (uint16_t)j;
+    F = N;
+  }
+  wave_lds_sync();
+  return F;
+}
+
+// One wave: raw logits lg[0..F) (list order) -> log-probs, selection, outputs, environment
+// transition on the LDS-resident mask. Returns the action; st is updated (incl. done).
+template <int ENV>
+__device__ inline int finalize_and_step(const rl4co_am_decode_args& a, TrajState& st, float* lg, const uint16_t* fl,
+                                        int F, uint8_t* mk, uint8_t* vis, const float* dem, float cap, int r, int t,
+                                        int N, int lane) {
+  bool nan_seen = false;
+  float zmax = kNegInf;
+  for (int c = lane; c < F; c += 64) {
+    float z = lg[c] / kSqrtD;
+    if (z != z) nan_seen = true;  // attention.py:295-296
+    if (a.tanh_clipping > 0.0f) z = rl4co_tanhf(z) * a.tanh_clipping;
+    if (a.mask_logits && mk[fl[c]] == 0) z = kNegInf;
+    if (a.temperature != 1.0f) z = z / a.temperature;  // x / 1.0f == x exactly
+    lg[c] = z;
+    zmax = fmaxf(zmax, z);
+  }
+  if (__any(nan_seen)) st.errbits |= RL4CO_EBIT_NAN_LOGIT;
+  zmax = rl4co::bfly_max<1, 64>(zmax);
+  float zsum = 0.0f;
+  for (int c = lane; c < F; c += 64) zsum = zsum + rl4co_expf(lg[c] - zmax);
+  zsum = rl4co::bfly_sum<1, 64>(zsum);
+  const float lse = rl4co_logf(zsum);
+
+  float best = kNegInf;
+  int bc = 0x7fffffff;  // best list position
+  float ent = 0.0f;
+  const int64_t tcol = (int64_t)a.t0 + t;
+  float* alp = a.all_logps ? a.all_logps + ((int64_t)r * a.out_stride + tcol) * N : nullptr;
+  if (alp && F < N) {  // nodes outside the list have log-prob -inf
+    for (int j = lane; j < N; j += 64)
+      if (mk[j] == 0) alp[j] = kNegInf;
+  }
+  for (int c = lane; c < F; c += 64) {
+    const int j = fl[c];
+    const float lp = (lg[c] - zmax) - lse;
+    lg[c] = lp;
+    float key = lp;
+    if (a.mode == RL4CO_DECODE_SAMPLE) {
+      const float nz = a.exp_noise
+                           ? a.exp_noise[((int64_t)t * a.B + r) * N + j]
+                           : rl4co_exp1_noise(a.philox_seed, a.philox_offset + (uint64_t)tcol, (uint32_t)r,
+                                              (uint32_t)j);
+      key = rl4co_expf(lp) / nz;  // multinomial(p,1) == argmax(p / Exp(1))
+    }
+    if (bc == 0x7fffffff || key > best) {  // strict '>' keeps the lowest index on ties
+      best = key;
+      bc = c;
+    }
+    if (a.entropy && lp > kNegInf) ent = fmaf(rl4co_expf(lp), lp, ent);
+    if (alp) alp[j] = lp;
+  }
+  rl4co::bfly_argmax(best, bc);
+  if (a.entropy) st.ent_acc = st.ent_acc - rl4co::bfly_sum<1, 64>(ent);
+  wave_lds_sync();
+  int bi;
+  float logp;
+  if (a.mode == RL4CO_DECODE_EVALUATE) {
+    bi = (int)a.forced_actions[(int64_t)r * a.out_stride + tcol];
+    if (bi < 0 || bi >= N) {  // forced action out of range
+      st.errbits |= RL4CO_EBIT_INFEASIBLE;
+      bi = 0;
+    }
+    // position of the forced node in the list (absent = masked out = log-prob -inf)
+    int pos = 0x7fffffff;
+    for (int c = lane; c < F; c += 64)
+      if (fl[c] == bi) pos = c;
+    pos = -rl4co::bfly_i_max(-pos);
+    logp = pos < F ? lg[pos] : kNegInf;
+  } else {
+    bi = (bc < F) ? (int)fl[bc] : 0;
+    logp = (bc < F) ? lg[bc] : kNegInf;
+  }
+  if (mk[bi] == 0) st.errbits |= RL4CO_EBIT_INFEASIBLE;            // decoding.py:393,409
+  if (!(logp > -1000.0f)) st.errbits |= RL4CO_EBIT_NEG_INF_LOGP;   // decoding.py:56
+  if (lane == 0) {
+    a.actions[(int64_t)r * a.out_stride + tcol] = bi;
+    a.logps[(int64_t)r * a.out_stride + tcol] = logp;
+  }
+  wave_lds_sync();
+
+  // ---- environment transition -------------------------------------------------------
+  if (ENV == RL4CO_ENV_TSP) {
+    if (st.step_i == 0) st.first = bi;  // tsp/env.py:63
+    st.cur = bi;
+    if (lane == 0) mk[bi] = 0;
+    st.step_i += 1;
+    wave_lds_sync();
+    bool any_left = false;
+    for (int j = lane; j < N; j += 64) any_left |= mk[j] != 0;
+    st.done = !__any(any_left);  // tsp/env.py:71
+  } else {
+    const int di = min(max(bi - 1, 0), N - 2);                       // cvrp/env.py:71-73
+    st.used = (st.used + dem[di]) * (bi != 0 ? 1.0f : 0.0f);         // cvrp/env.py:76
+    st.cur = bi;
+    if (lane == 0) vis[bi] = 1;
+    wave_lds_sync();
+    const float thr = cap + 1e-5f;  // cvrp/env.py:128
+    bool any_feasible = false, all_visited = true;
+    for (int j = lane; j < N; j += 64) {
+      all_visited &= vis[j] != 0;
+      if (j >= 1) {
+        const bool masked = (vis[j] != 0) || (dem[j - 1] + st.used > thr);
+        mk[j] = masked ? 0 : 1;
+        any_feasible |= !masked;
+      }
+    }
+    any_feasible = __any(any_feasible);
+    st.done = __all(all_visited);  // cvrp/env.py:83
+    if (lane == 0) mk[0] = ((st.cur == 0) && any_feasible) ? 0 : 1;  // cvrp/env.py:134-135
+  }
+  wave_lds_sync();
+  return bi;
+}
+
+// ================================================================================================
+// Streaming kernel: ONE wavefront (= one 64-thread workgroup) per trajectory; with thousands of
+// trajectories 16 independent waves per CU hide each other's latency chains and the kernel runs
+// at the HBM / Infinity-Cache rate. kUnroll wave-wide 1 KiB loads in flight per pass.
+// ================================================================================================
 template <class C, int ENV>
 __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_args a) {
   constexpr int EPL = C::EPL;
@@ -101,11 +264,12 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
   const int r = trajectory_of_block(blockIdx.x, a.B, a.B_inst);
   const int N = a.N;
   const int Np = lds_pad(N);
-  float* sc = reinterpret_cast<float*>(smem);  // [Np*kH] per-head scores, (j*kH + h)
-  float* lg = sc + Np * kH;                    // [Np] raw logits -> clipped logits -> log-probs
-  uint8_t* mk = reinterpret_cast<uint8_t*>(lg + Np);  // [Np] 1 = feasible
-  uint8_t* vis = mk + Np;                             // [Np] CVRP visited flags
-  float* mh = reinterpret_cast<float*>(vis + Np);     // [8] per-head score maxima
+  float* sc = reinterpret_cast<float*>(smem);  // [Np*kH] per-head scores -> softmax numerators, (c*kH + h)
+  float* lg = sc + Np * kH;                    // [Np] raw logits -> clipped logits -> log-probs (list order)
+  float* mh = lg + Np;                         // [8] per-head score maxima
+  uint16_t* fl = reinterpret_cast<uint16_t*>(mh + kH);  // [Np] nodes this step reads, ascending
+  uint8_t* mk = reinterpret_cast<uint8_t*>(fl + Np);    // [Np] 1 = feasible
+  uint8_t* vis = mk + Np;                               // [Np] CVRP visited flags
 
   const int cb = r % a.B_inst;  // instance whose cache this trajectory reads
   const int rg = lane / LPR;    // row group inside a wave-wide load
@@ -127,102 +291,106 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
     const uint8_t* gv = a.visited + (int64_t)r * N;
     for (int j = lane; j < Np; j += 64) vis[j] = (j < N) ? gv[j] : (uint8_t)1;
   }
-  int cur = (int)a.current_node[r];
-  int first = (ENV == RL4CO_ENV_TSP) ? (int)a.first_node[r] : 0;
-  long long step_i = (ENV == RL4CO_ENV_TSP) ? a.step_i[r] : 0;
-  float used = (ENV == RL4CO_ENV_CVRP) ? a.used_capacity[r] : 0.0f;
+  TrajState st;
+  st.cur = (int)a.current_node[r];
+  st.first = (ENV == RL4CO_ENV_TSP) ? (int)a.first_node[r] : 0;
+  st.step_i = (ENV == RL4CO_ENV_TSP) ? a.step_i[r] : 0;
+  st.used = (ENV == RL4CO_ENV_CVRP) ? a.used_capacity[r] : 0.0f;
+  st.done = a.done[r] != 0;
+  st.errbits = 0;
+  st.ent_acc = 0.0f;
   const float cap = (ENV == RL4CO_ENV_CVRP) ? a.vehicle_capacity[r] : 0.0f;
   const float* dem = (ENV == RL4CO_ENV_CVRP) ? a.demand + (int64_t)cb * (N - 1) : nullptr;
-  bool done = a.done[r] != 0;
-  __syncthreads();
+  wave_lds_sync();
 
   float qb[EPL];
 #pragma unroll
   for (int e = 0; e < EPL; ++e) qb[e] = a.q_bias ? a.q_bias[(int64_t)cb * kD + e0 + e] : 0.0f;
 
-  const float sqrt_d = 11.3137084989847604f;  // fl32(sqrt(128)), attention.py:293
   const bool single = a.max_steps == 1;
-  uint32_t errbits = 0;
-  float ent_acc = 0.0f;
   int t = 0;
 
-  for (; t < a.max_steps && (!done || single); ++t) {
+  for (; t < a.max_steps && (!st.done || single); ++t) {
+    const int F = build_list(a, mk, fl, N, lane);
+
     // ---- query: folded context projection + graph context (decoder.py:128-140) ------
     float q[EPL];
     if (ENV == RL4CO_ENV_TSP) {
-      if (step_i < 1) {  // context.py:120 placeholder context
+      if (st.step_i < 1) {  // context.py:120 placeholder context
 #pragma unroll
         for (int e = 0; e < EPL; ++e) q[e] = a.q_step0[e0 + e] + qb[e];
       } else {
 #pragma unroll
         for (int e = 0; e < EPL; ++e)
-          q[e] = (ctxf[(int64_t)first * kD + e] + ctxc[(int64_t)cur * kD + e]) + qb[e];
+          q[e] = (ctxf[(int64_t)st.first * kD + e] + ctxc[(int64_t)st.cur * kD + e]) + qb[e];
       }
     } else {
-      const float rem = cap - used;  // context.py:147-149
+      const float rem = cap - st.used;  // context.py:147-149
 #pragma unroll
       for (int e = 0; e < EPL; ++e)
-        q[e] = fmaf(a.w_cap[e0 + e], rem, ctxc[(int64_t)cur * kD + e]) + qb[e];
+        q[e] = fmaf(a.w_cap[e0 + e], rem, ctxc[(int64_t)st.cur * kD + e]) + qb[e];
     }
 #pragma unroll
     for (int e = 0; e < EPL; ++e) q[e] = q[e] * 0.25f;  // 1/sqrt(16), exact
 
-    // ---- pass 1: per-head scores over the glimpse keys -------------------------------
+    // ---- pass 1: per-head scores over the glimpse keys of the listed nodes -------------
     float m = kNegInf;
-    for (int j0 = 0; j0 < N; j0 += RPL * kUnroll) {
+    for (int c0 = 0; c0 < F; c0 += RPL * kUnroll) {
       raw_t rw[kUnroll];
+      int jj[kUnroll];
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
-        const int j = j0 + u * RPL + rg;
-        rw[u] = (j < N) ? C::ld(Kg + (int64_t)j * rs) : C::zero();
+        const int c = c0 + u * RPL + rg;
+        jj[u] = (c < F) ? (int)fl[c] : -1;
+        rw[u] = (jj[u] >= 0) ? C::ld(Kg + (int64_t)jj[u] * rs) : C::zero();
       }
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
-        const int j = j0 + u * RPL + rg;
-        const bool valid = j < N;
+        const int c = c0 + u * RPL + rg;
+        const bool valid = jj[u] >= 0;
         float k[EPL];
         C::cvt(rw[u], k);
         float acc = 0.0f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc = fmaf(q[e], k[e], acc);
         acc = rl4co::bfly_sum<1, LPH>(acc);
-        const bool feas = valid && (!a.mask_inner || mk[valid ? j : 0] != 0);
+        const bool feas = valid && (!a.mask_inner || mk[valid ? jj[u] : 0] != 0);
         const float sv = feas ? acc : kNegInf;
-        if (valid && (li % LPH) == 0) sc[j * kH + hd] = sv;
+        if (valid && (li % LPH) == 0) sc[c * kH + hd] = sv;
         m = fmaxf(m, sv);
       }
     }
     m = rl4co::bfly_max<LPR, 64>(m);
     if (rg == 0 && (li % LPH) == 0) mh[hd] = m;
-    __syncthreads();
-    // softmax numerators once per (node, head) — lane-strided over the N*8 scores, so each
-    // exp is evaluated exactly once instead of once per lane of the head (index % 8 = head is
-    // fixed per lane because 64 % 8 == 0)
+    wave_lds_sync();
+    // softmax numerators once per (list entry, head) — lane-strided over the F*8 scores, so
+    // each exp is evaluated exactly once (index % 8 = head is fixed per lane: 64 % 8 == 0)
     {
       const float mm = mh[lane & (kH - 1)];
-      for (int idx = lane; idx < N * kH; idx += 64) sc[idx] = rl4co_expf(sc[idx] - mm);
+      for (int idx = lane; idx < F * kH; idx += 64) sc[idx] = rl4co_expf(sc[idx] - mm);
     }
-    __syncthreads();
+    wave_lds_sync();
 
-    // ---- pass 2: softmax weights and weighted value sum ------------------------------
+    // ---- pass 2: softmax-weighted value sum ------------------------------------------------
     float l = 0.0f;
     float o[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; ++e) o[e] = 0.0f;
-    for (int j0 = 0; j0 < N; j0 += RPL * kUnroll) {
+    for (int c0 = 0; c0 < F; c0 += RPL * kUnroll) {
       raw_t rw[kUnroll];
+      bool ok[kUnroll];
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
-        const int j = j0 + u * RPL + rg;
-        rw[u] = (j < N) ? C::ld(Vg + (int64_t)j * rs) : C::zero();
+        const int c = c0 + u * RPL + rg;
+        ok[u] = c < F;
+        rw[u] = ok[u] ? C::ld(Vg + (int64_t)fl[c] * rs) : C::zero();
       }
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
-        const int j = j0 + u * RPL + rg;
-        const bool valid = j < N;
+        const int c = c0 + u * RPL + rg;
         float v[EPL];
         C::cvt(rw[u], v);
-        const float p = valid ? sc[j * kH + hd] : 0.0f;
+        const float p = ok[u] ? sc[c * kH + hd] : 0.0f;
         l = l + p;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) o[e] = fmaf(p, v[e], o[e]);
@@ -233,121 +401,30 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
     for (int e = 0; e < EPL; ++e) o[e] = rl4co::bfly_sum<LPR, 64>(o[e]) * l;
 
     // ---- pass 3: pointer logits against the (project_out-folded) logit key -----------
-    for (int j0 = 0; j0 < N; j0 += RPL * kUnroll) {
+    for (int c0 = 0; c0 < F; c0 += RPL * kUnroll) {
       raw_t rw[kUnroll];
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
-        const int j = j0 + u * RPL + rg;
-        rw[u] = (j < N) ? C::ld(Kl + (int64_t)j * rs) : C::zero();
+        const int c = c0 + u * RPL + rg;
+        rw[u] = (c < F) ? C::ld(Kl + (int64_t)fl[c] * rs) : C::zero();
       }
 #pragma unroll
       for (int u = 0; u < kUnroll; ++u) {
-        const int j = j0 + u * RPL + rg;
+        const int c = c0 + u * RPL + rg;
         float k[EPL];
         C::cvt(rw[u], k);
         float acc = 0.0f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc = fmaf(o[e], k[e], acc);
         acc = rl4co::bfly_sum<1, LPR>(acc);
-        if (j < N && li == 0) lg[j] = acc;
+        if (c < F && li == 0) lg[c] = acc;
       }
     }
-    __syncthreads();
+    wave_lds_sync();
 
-    // ---- logits -> clipped / masked / tempered (decoding.py:169-185), lane-strided ----
-    bool nan_seen = false;
-    float zmax = kNegInf;
-    for (int j = lane; j < N; j += 64) {
-      float z = lg[j] / sqrt_d;
-      if (z != z) nan_seen = true;  // attention.py:295-296
-      if (a.tanh_clipping > 0.0f) z = rl4co_tanhf(z) * a.tanh_clipping;
-      if (a.mask_logits && mk[j] == 0) z = kNegInf;
-      if (a.temperature != 1.0f) z = z / a.temperature;  // x / 1.0f == x exactly
-      lg[j] = z;
-      zmax = fmaxf(zmax, z);
-    }
-    if (__any(nan_seen)) errbits |= RL4CO_EBIT_NAN_LOGIT;
-
-    // ---- log_softmax over the N logits (decoding.py:188) -----------------------------
-    zmax = rl4co::bfly_max<1, 64>(zmax);
-    float zsum = 0.0f;
-    for (int j = lane; j < N; j += 64) zsum = zsum + rl4co_expf(lg[j] - zmax);
-    zsum = rl4co::bfly_sum<1, 64>(zsum);
-    const float lse = rl4co_logf(zsum);
-
-    // ---- selection ---------------------------------------------------------------------
-    float best = kNegInf;
-    int bi = 0x7fffffff;
-    float ent = 0.0f;
-    const int64_t tcol = (int64_t)a.t0 + t;
-    for (int j = lane; j < N; j += 64) {
-      const float lp = (lg[j] - zmax) - lse;
-      lg[j] = lp;
-      float key = lp;
-      if (a.mode == RL4CO_DECODE_SAMPLE) {
-        const float nz = a.exp_noise
-                             ? a.exp_noise[((int64_t)t * a.B + r) * N + j]
-                             : rl4co_exp1_noise(a.philox_seed, a.philox_offset + (uint64_t)tcol,
-                                                (uint32_t)r, (uint32_t)j);
-        key = rl4co_expf(lp) / nz;  // multinomial(p,1) == argmax(p / Exp(1))
-      }
-      if (bi == 0x7fffffff || key > best) {  // strict '>' keeps the lowest index on ties
-        best = key;
-        bi = j;
-      }
-      if (a.entropy && lp > kNegInf) ent = fmaf(rl4co_expf(lp), lp, ent);
-      if (a.all_logps) a.all_logps[((int64_t)r * a.out_stride + tcol) * N + j] = lp;
-    }
-    rl4co::bfly_argmax(best, bi);
-    if (a.entropy) ent_acc = ent_acc - rl4co::bfly_sum<1, 64>(ent);
-    if (a.mode == RL4CO_DECODE_EVALUATE) bi = (int)a.forced_actions[(int64_t)r * a.out_stride + tcol];
-    if (bi < 0 || bi >= N) {  // forced action out of range
-      errbits |= RL4CO_EBIT_INFEASIBLE;
-      bi = 0;
-    }
-    __syncthreads();
-    const float logp = lg[bi];
-    if (mk[bi] == 0) errbits |= RL4CO_EBIT_INFEASIBLE;  // decoding.py:393,409
-    if (!(logp > -1000.0f)) errbits |= RL4CO_EBIT_NEG_INF_LOGP;  // decoding.py:56
-    if (lane == 0) {
-      a.actions[(int64_t)r * a.out_stride + tcol] = bi;
-      a.logps[(int64_t)r * a.out_stride + tcol] = logp;
-    }
-    __syncthreads();
-
-    // ---- environment transition -------------------------------------------------------
-    if (ENV == RL4CO_ENV_TSP) {
-      if (step_i == 0) first = bi;  // tsp/env.py:63
-      cur = bi;
-      if (lane == 0) mk[bi] = 0;
-      step_i += 1;
-      __syncthreads();
-      bool any_left = false;
-      for (int j = lane; j < N; j += 64) any_left |= mk[j] != 0;
-      done = !__any(any_left);  // tsp/env.py:71
-    } else {
-      const int di = min(max(bi - 1, 0), N - 2);               // cvrp/env.py:71-73
-      used = (used + dem[di]) * (bi != 0 ? 1.0f : 0.0f);       // cvrp/env.py:76
-      cur = bi;
-      if (lane == 0) vis[bi] = 1;
-      __syncthreads();
-      const float thr = cap + 1e-5f;  // cvrp/env.py:128
-      bool any_feasible = false, all_visited = true;
-      for (int j = lane; j < N; j += 64) {
-        all_visited &= vis[j] != 0;
-        if (j >= 1) {
-          const bool masked = (vis[j] != 0) || (dem[j - 1] + used > thr);
-          mk[j] = masked ? 0 : 1;
-          any_feasible |= !masked;
-        }
-      }
-      any_feasible = __any(any_feasible);
-      done = __all(all_visited);  // cvrp/env.py:83
-      if (lane == 0) mk[0] = ((cur == 0) && any_feasible) ? 0 : 1;  // cvrp/env.py:134-135
-      __syncthreads();
-    }
+    finalize_and_step<ENV>(a, st, lg, fl, F, mk, vis, dem, cap, r, t, N, lane);
   }
-  if (!single && !done && t >= a.max_steps) errbits |= RL4CO_EBIT_MAX_STEPS;
+  if (!single && !st.done && t >= a.max_steps) st.errbits |= RL4CO_EBIT_MAX_STEPS;
 
   // ---- write the state back ------------------------------------------------------------
   for (int j = lane; j < N; j += 64) gmask[j] = mk[j];
@@ -356,28 +433,33 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
     for (int j = lane; j < N; j += 64) gv[j] = vis[j];
   }
   if (lane == 0) {
-    a.current_node[r] = cur;
-    a.done[r] = done ? 1 : 0;
+    a.current_node[r] = st.cur;
+    a.done[r] = st.done ? 1 : 0;
     if (ENV == RL4CO_ENV_TSP) {
-      a.first_node[r] = first;
-      a.step_i[r] = step_i;
+      a.first_node[r] = st.first;
+      a.step_i[r] = st.step_i;
     } else {
-      a.used_capacity[r] = used;
+      a.used_capacity[r] = st.used;
     }
     if (a.n_steps) a.n_steps[r] = t;
-    if (a.entropy) a.entropy[r] += ent_acc;
-    if (errbits) atomicOr(a.err, (int)errbits);
+    if (a.entropy) a.entropy[r] += st.ent_acc;
+    if (st.errbits) atomicOr(a.err, (int)st.errbits);
   }
 }
 
 // ================================================================================================
-// LDS-resident variant (bf16 planes, N small enough that one trajectory's three planes fit in
-// half a CU's LDS): the planes are read from HBM ONCE per rollout instead of once per decode
-// step and every step streams them from LDS. 4 waves per trajectory, 2 trajectories per CU.
-//
-// Same arithmetic contract as the streaming kernel with G = 16 row groups (row j -> wave
-// (j % 16) / 4, row group j % 4): per-group partial sums in ascending j, then the pairwise tree
-// — butterfly inside the wave, ((w0 + w1) + (w2 + w3)) across waves through LDS.
+// Four waves per trajectory (bf16 planes), G = 16 row groups: list entry c -> wave (c % 16) / 4,
+// row group c % 4; per-group partial sums in ascending c, then the pairwise tree — butterfly
+// inside the wave, ((w0 + w1) + (w2 + w3)) across waves through LDS.
+//   RESIDENT = true : "LDS-resident" — the three planes are copied into LDS ONCE per rollout and
+//                     every step reads them from there (needs them to fit half a CU's LDS).
+//                     Wins when there are too few trajectories to fill the chip with one wave
+//                     each: 0.65 vs 1.34 ms at 256 trajectories, 1.5 vs 1.8 ms at 1024 (TSP-100);
+//                     with thousands of trajectories only two fit per CU and the latency chain
+//                     of a step is exposed (5.8 vs 4.4 ms at 4096), so auto picks it for B <= 1024.
+//   RESIDENT = false: "wide" streaming — same structure reading the planes from HBM/L2 every
+//                     step; for few trajectories whose planes do not fit LDS (CVRP-500 x 1024:
+//                     4096 waves instead of 1024, 120 -> 61 us per step).
 // ================================================================================================
 constexpr int kLdsWaves = 4;
 constexpr int kLdsGroups = 16;
@@ -385,26 +467,15 @@ constexpr int kLdsGroups = 16;
 __host__ __device__ inline int lds_variant_sc_rows(int N) { return N < 80 ? 80 : N; }
 __host__ __device__ inline int wide_scratch_bytes(int N) {
   const int nw = (N + 3) & ~3;
-  return lds_variant_sc_rows(N) * kH * 4 + nw * 4 + kLdsWaves * kH * 4 + 32 + 2 * nw;
+  return lds_variant_sc_rows(N) * kH * 4 + nw * 4 + kLdsWaves * kH * 4 + 32 + 2 * nw + 2 * nw;
 }
 __host__ __device__ inline int lds_variant_bytes(int N) { return 3 * N * kD * 2 + wide_scratch_bytes(N); }
 
-__device__ inline void wave_lds_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// RESIDENT = true : planes copied into LDS once per rollout (ITERS = rows per wave per pass, unrolled)
-// RESIDENT = false: "wide" streaming — the same 4-wave structure reading the planes from HBM/L2
-//                   every step; for rollouts with too few trajectories to fill the chip with one
-//                   wave each and planes too large for LDS (CVRP-500 x 1024: 4096 waves instead
-//                   of 1024). ITERS = 0: runtime row count, 4 loads in flight per wave and pass.
-template <int ENV, int ITERS, bool RESIDENT>
-__global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const rl4co_am_decode_args a) {
+template <int ENV, bool RESIDENT>
+__global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_wide_kernel(const rl4co_am_decode_args a) {
   using C = CacheBF16;
-  constexpr int U = ITERS > 0 ? ITERS : 4;  // rows per wave handled per unrolled block
   constexpr int EPL = 8, LPR = 16, LPH = 2;
+  constexpr int U = 4;  // list entries per wave handled per unrolled block
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x;
   const int w = tid >> 6, lane = tid & 63;
@@ -412,11 +483,12 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
   const int N = a.N;
   const int nw = (N + 3) & ~3;
   uint16_t* planes = reinterpret_cast<uint16_t*>(smem);             // [3][N][128] bf16 (RESIDENT only)
-  float* sc = reinterpret_cast<float*>(planes + (RESIDENT ? 3 * N * kD : 0));  // [max(N,80)][8] scores; later o/l partials
-  float* lg = sc + lds_variant_sc_rows(N) * kH;                     // [nw] logits -> log-probs
+  float* sc = reinterpret_cast<float*>(planes + (RESIDENT ? 3 * N * kD : 0));  // [max(N,80)][8]; later o/l partials
+  float* lg = sc + lds_variant_sc_rows(N) * kH;                     // [nw] logits -> log-probs (list order)
   float* mpart = lg + nw;                                           // [4][8] per-wave head maxima
-  int* shi = reinterpret_cast<int*>(mpart + kLdsWaves * kH);        // [8] broadcast: action, done
-  uint8_t* mk = reinterpret_cast<uint8_t*>(shi + 8);                // [nw] 1 = feasible
+  int* shi = reinterpret_cast<int*>(mpart + kLdsWaves * kH);        // [8] broadcast: action, done, F
+  uint16_t* fl = reinterpret_cast<uint16_t*>(shi + 8);              // [nw] nodes this step reads
+  uint8_t* mk = reinterpret_cast<uint8_t*>(fl + nw);                // [nw] 1 = feasible
   uint8_t* vis = mk + nw;                                           // [nw] CVRP visited
 
   const int cb = r % a.B_inst;
@@ -434,10 +506,9 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
     Kl = static_cast<const uint16_t*>(a.logit_key) + (int64_t)cb * a.kvl_batch_stride + e0;
     rs = a.kvl_row_stride;
   }
-  const int iters = ITERS > 0 ? ITERS : (N + kLdsGroups - 1) / kLdsGroups;
   const float* ctxc = a.ctx_cur + (int64_t)cb * N * kD + e0;
   const float* ctxf = (ENV == RL4CO_ENV_TSP) ? a.ctx_first + (int64_t)cb * N * kD + e0 : nullptr;
-  // o/l partial slots inside this wave's own (dead after pass 2) score rows
+  // o/l partial slots inside this wave's own (dead after pass 2) score chunks
   auto opart = [&](int wv, int d) -> float* { return sc + ((16 * (d >> 5) + 4 * wv) * kH) + (d & 31); };
   auto lpart = [&](int wv, int h) -> float* { return sc + ((16 * 4 + 4 * wv) * kH) + h; };
 
@@ -461,82 +532,92 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
     const uint8_t* gv = a.visited + (int64_t)r * N;
     for (int j = tid; j < nw; j += 64 * kLdsWaves) vis[j] = (j < N) ? gv[j] : (uint8_t)1;
   }
-  int cur = (int)a.current_node[r];
-  int first = (ENV == RL4CO_ENV_TSP) ? (int)a.first_node[r] : 0;
-  long long step_i = (ENV == RL4CO_ENV_TSP) ? a.step_i[r] : 0;
-  float used = (ENV == RL4CO_ENV_CVRP) ? a.used_capacity[r] : 0.0f;
+  TrajState st;
+  st.cur = (int)a.current_node[r];
+  st.first = (ENV == RL4CO_ENV_TSP) ? (int)a.first_node[r] : 0;
+  st.step_i = (ENV == RL4CO_ENV_TSP) ? a.step_i[r] : 0;
+  st.used = (ENV == RL4CO_ENV_CVRP) ? a.used_capacity[r] : 0.0f;
+  st.done = a.done[r] != 0;
+  st.errbits = 0;
+  st.ent_acc = 0.0f;
   const float cap = (ENV == RL4CO_ENV_CVRP) ? a.vehicle_capacity[r] : 0.0f;
   const float* dem = (ENV == RL4CO_ENV_CVRP) ? a.demand + (int64_t)cb * (N - 1) : nullptr;
-  bool done = a.done[r] != 0;
+  __syncthreads();
+  if (w == 0) {
+    const int F0 = build_list(a, mk, fl, N, lane);
+    if (lane == 0) shi[2] = F0;
+  }
   __syncthreads();
 
   float qb[EPL];
 #pragma unroll
   for (int e = 0; e < EPL; ++e) qb[e] = a.q_bias ? a.q_bias[(int64_t)cb * kD + e0 + e] : 0.0f;
 
-  const float sqrt_d = 11.3137084989847604f;
   const bool single = a.max_steps == 1;
-  uint32_t errbits = 0;
-  float ent_acc = 0.0f;
   int t = 0;
-  for (; t < a.max_steps && (!done || single); ++t) {
+
+  for (; t < a.max_steps && (!st.done || single); ++t) {
+    const int F = shi[2];
+    const int iters = (F + kLdsGroups - 1) / kLdsGroups;
     // ---- query ---------------------------------------------------------------------------------
     float q[EPL];
     if (ENV == RL4CO_ENV_TSP) {
-      if (step_i < 1) {
+      if (st.step_i < 1) {
 #pragma unroll
         for (int e = 0; e < EPL; ++e) q[e] = a.q_step0[e0 + e] + qb[e];
       } else {
 #pragma unroll
         for (int e = 0; e < EPL; ++e)
-          q[e] = (ctxf[(int64_t)first * kD + e] + ctxc[(int64_t)cur * kD + e]) + qb[e];
+          q[e] = (ctxf[(int64_t)st.first * kD + e] + ctxc[(int64_t)st.cur * kD + e]) + qb[e];
       }
     } else {
-      const float rem = cap - used;
+      const float rem = cap - st.used;
 #pragma unroll
       for (int e = 0; e < EPL; ++e)
-        q[e] = fmaf(a.w_cap[e0 + e], rem, ctxc[(int64_t)cur * kD + e]) + qb[e];
+        q[e] = fmaf(a.w_cap[e0 + e], rem, ctxc[(int64_t)st.cur * kD + e]) + qb[e];
     }
 #pragma unroll
     for (int e = 0; e < EPL; ++e) q[e] = q[e] * 0.25f;
 
-    // ---- pass 1: scores of this wave's rows ------------------------------------------------------
+    // ---- pass 1: scores of this wave's list entries ----------------------------------------------
     float m = kNegInf;
     for (int i0 = 0; i0 < iters; i0 += U) {
       uint4 rw[U];
+      int jj[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int j = kLdsGroups * (i0 + u) + 4 * w + rg;
-        rw[u] = (j < N) ? *reinterpret_cast<const uint4*>(Kg + (int64_t)j * rs) : C::zero();
+        const int c = kLdsGroups * (i0 + u) + 4 * w + rg;
+        jj[u] = (c < F) ? (int)fl[c] : -1;
+        rw[u] = (jj[u] >= 0) ? *reinterpret_cast<const uint4*>(Kg + (int64_t)jj[u] * rs) : C::zero();
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int j = kLdsGroups * (i0 + u) + 4 * w + rg;
-        const bool valid = j < N;
+        const int c = kLdsGroups * (i0 + u) + 4 * w + rg;
+        const bool valid = jj[u] >= 0;
         float k[EPL];
         C::cvt(rw[u], k);
         float acc = 0.0f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc = fmaf(q[e], k[e], acc);
         acc = rl4co::bfly_sum<1, LPH>(acc);
-        const bool feas = valid && (!a.mask_inner || mk[valid ? j : 0] != 0);
+        const bool feas = valid && (!a.mask_inner || mk[valid ? jj[u] : 0] != 0);
         const float sv = feas ? acc : kNegInf;
-        if (valid && (li & 1) == 0) sc[j * kH + hd] = sv;
+        if (valid && (li & 1) == 0) sc[c * kH + hd] = sv;
         m = fmaxf(m, sv);
       }
     }
     m = rl4co::bfly_max<LPR, 64>(m);
     if (rg == 0 && (li & 1) == 0) mpart[w * kH + hd] = m;
     __syncthreads();  // B1: all head maxima visible
-    // softmax numerators of this wave's rows, each evaluated once (lane-strided over the wave's
-    // 4-row chunks: 32 consecutive floats per chunk, head = index % 8 fixed per lane)
+    // softmax numerators of this wave's entries, each evaluated once (lane-strided over the
+    // wave's 4-entry chunks: 32 consecutive floats per chunk, head = index % 8 fixed per lane)
     {
       const int hh = lane & (kH - 1);
       const float mm = fmaxf(fmaxf(mpart[hh], mpart[kH + hh]), fmaxf(mpart[2 * kH + hh], mpart[3 * kH + hh]));
       for (int tix = lane; tix < 32 * iters; tix += 64) {
-        const int row0 = kLdsGroups * (tix >> 5) + 4 * w;  // first row of the chunk
-        if (row0 + ((tix & 31) >> 3) < N) {
-          float* p = sc + row0 * kH + (tix & 31);
+        const int c0 = kLdsGroups * (tix >> 5) + 4 * w;  // first entry of the chunk
+        if (c0 + ((tix & 31) >> 3) < F) {
+          float* p = sc + c0 * kH + (tix & 31);
           *p = rl4co_expf(*p - mm);
         }
       }
@@ -550,18 +631,19 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
     for (int e = 0; e < EPL; ++e) o[e] = 0.0f;
     for (int i0 = 0; i0 < iters; i0 += U) {
       uint4 rw[U];
+      bool ok[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int j = kLdsGroups * (i0 + u) + 4 * w + rg;
-        rw[u] = (j < N) ? *reinterpret_cast<const uint4*>(Vg + (int64_t)j * rs) : C::zero();
+        const int c = kLdsGroups * (i0 + u) + 4 * w + rg;
+        ok[u] = c < F;
+        rw[u] = ok[u] ? *reinterpret_cast<const uint4*>(Vg + (int64_t)fl[c] * rs) : C::zero();
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int j = kLdsGroups * (i0 + u) + 4 * w + rg;
-        const bool valid = j < N;
+        const int c = kLdsGroups * (i0 + u) + 4 * w + rg;
         float v[EPL];
         C::cvt(rw[u], v);
-        const float p = valid ? sc[j * kH + hd] : 0.0f;
+        const float p = ok[u] ? sc[c * kH + hd] : 0.0f;
         l = l + p;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) o[e] = fmaf(p, v[e], o[e]);
@@ -583,190 +665,92 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_lds_kernel(const 
       o[e] = ((*opart(0, d) + *opart(1, d)) + (*opart(2, d) + *opart(3, d))) * l;
     }
 
-    // ---- pass 3: logits of this wave's rows ---------------------------------------------------------
+    // ---- pass 3: logits of this wave's list entries ---------------------------------------------------
     for (int i0 = 0; i0 < iters; i0 += U) {
       uint4 rw[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int j = kLdsGroups * (i0 + u) + 4 * w + rg;
-        rw[u] = (j < N) ? *reinterpret_cast<const uint4*>(Kl + (int64_t)j * rs) : C::zero();
+        const int c = kLdsGroups * (i0 + u) + 4 * w + rg;
+        rw[u] = (c < F) ? *reinterpret_cast<const uint4*>(Kl + (int64_t)fl[c] * rs) : C::zero();
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        const int j = kLdsGroups * (i0 + u) + 4 * w + rg;
+        const int c = kLdsGroups * (i0 + u) + 4 * w + rg;
         float k[EPL];
         C::cvt(rw[u], k);
         float acc = 0.0f;
 #pragma unroll
         for (int e = 0; e < EPL; ++e) acc = fmaf(o[e], k[e], acc);
         acc = rl4co::bfly_sum<1, LPR>(acc);
-        if (j < N && li == 0) lg[j] = acc;
+        if (c < F && li == 0) lg[c] = acc;
       }
     }
     __syncthreads();  // B3: all logits visible to wave 0
 
-    // ---- wave 0: log-softmax, selection, environment transition (same code as streaming) ----------
+    // ---- wave 0: log-softmax, selection, environment transition, next step's list ------------------
     if (w == 0) {
-      bool nan_seen = false;
-      float zmax = kNegInf;
-      for (int j = lane; j < N; j += 64) {
-        float z = lg[j] / sqrt_d;
-        if (z != z) nan_seen = true;
-        if (a.tanh_clipping > 0.0f) z = rl4co_tanhf(z) * a.tanh_clipping;
-        if (a.mask_logits && mk[j] == 0) z = kNegInf;
-        if (a.temperature != 1.0f) z = z / a.temperature;
-        lg[j] = z;
-        zmax = fmaxf(zmax, z);
-      }
-      if (__any(nan_seen)) errbits |= RL4CO_EBIT_NAN_LOGIT;
-      zmax = rl4co::bfly_max<1, 64>(zmax);
-      float zsum = 0.0f;
-      for (int j = lane; j < N; j += 64) zsum = zsum + rl4co_expf(lg[j] - zmax);
-      zsum = rl4co::bfly_sum<1, 64>(zsum);
-      const float lse = rl4co_logf(zsum);
-      float best = kNegInf;
-      int bi = 0x7fffffff;
-      float ent = 0.0f;
-      const int64_t tcol = (int64_t)a.t0 + t;
-      for (int j = lane; j < N; j += 64) {
-        const float lp = (lg[j] - zmax) - lse;
-        lg[j] = lp;
-        float key = lp;
-        if (a.mode == RL4CO_DECODE_SAMPLE) {
-          const float nz = a.exp_noise
-                               ? a.exp_noise[((int64_t)t * a.B + r) * N + j]
-                               : rl4co_exp1_noise(a.philox_seed, a.philox_offset + (uint64_t)tcol,
-                                                  (uint32_t)r, (uint32_t)j);
-          key = rl4co_expf(lp) / nz;
-        }
-        if (bi == 0x7fffffff || key > best) {
-          best = key;
-          bi = j;
-        }
-        if (a.entropy && lp > kNegInf) ent = fmaf(rl4co_expf(lp), lp, ent);
-        if (a.all_logps) a.all_logps[((int64_t)r * a.out_stride + tcol) * N + j] = lp;
-      }
-      rl4co::bfly_argmax(best, bi);
-      if (a.entropy) ent_acc = ent_acc - rl4co::bfly_sum<1, 64>(ent);
-      if (a.mode == RL4CO_DECODE_EVALUATE) bi = (int)a.forced_actions[(int64_t)r * a.out_stride + tcol];
-      if (bi < 0 || bi >= N) {
-        errbits |= RL4CO_EBIT_INFEASIBLE;
-        bi = 0;
-      }
-      wave_lds_sync();
-      const float logp = lg[bi];
-      if (mk[bi] == 0) errbits |= RL4CO_EBIT_INFEASIBLE;
-      if (!(logp > -1000.0f)) errbits |= RL4CO_EBIT_NEG_INF_LOGP;
-      if (lane == 0) {
-        a.actions[(int64_t)r * a.out_stride + tcol] = bi;
-        a.logps[(int64_t)r * a.out_stride + tcol] = logp;
-      }
-      wave_lds_sync();
-      bool new_done;
-      if (ENV == RL4CO_ENV_TSP) {
-        if (lane == 0) mk[bi] = 0;
-        wave_lds_sync();
-        bool any_left = false;
-        for (int j = lane; j < N; j += 64) any_left |= mk[j] != 0;
-        new_done = !__any(any_left);
-      } else {
-        const int di = min(max(bi - 1, 0), N - 2);
-        const float used_next = (used + dem[di]) * (bi != 0 ? 1.0f : 0.0f);
-        if (lane == 0) vis[bi] = 1;
-        wave_lds_sync();
-        const float thr = cap + 1e-5f;
-        bool any_feasible = false, all_visited = true;
-        for (int j = lane; j < N; j += 64) {
-          all_visited &= vis[j] != 0;
-          if (j >= 1) {
-            const bool masked = (vis[j] != 0) || (dem[j - 1] + used_next > thr);
-            mk[j] = masked ? 0 : 1;
-            any_feasible |= !masked;
-          }
-        }
-        any_feasible = __any(any_feasible);
-        new_done = __all(all_visited);
-        if (lane == 0) mk[0] = ((bi == 0) && any_feasible) ? 0 : 1;
-      }
+      const int bi = finalize_and_step<ENV>(a, st, lg, fl, F, mk, vis, dem, cap, r, t, N, lane);
+      const int Fn = build_list(a, mk, fl, N, lane);
       if (lane == 0) {
         shi[0] = bi;
-        shi[1] = new_done ? 1 : 0;
+        shi[1] = st.done ? 1 : 0;
+        shi[2] = Fn;
       }
     }
-    __syncthreads();  // B4: action, done flag and the updated mask visible to every wave
-    {
+    __syncthreads();  // B4: action, done flag, mask and list visible to every wave
+    if (w != 0) {
       const int bi = shi[0];
-      done = shi[1] != 0;
+      st.done = shi[1] != 0;
       if (ENV == RL4CO_ENV_TSP) {
-        if (step_i == 0) first = bi;
-        cur = bi;
-        step_i += 1;
+        if (st.step_i == 0) st.first = bi;
+        st.cur = bi;
+        st.step_i += 1;
       } else {
         const int di = min(max(bi - 1, 0), N - 2);
-        used = (used + dem[di]) * (bi != 0 ? 1.0f : 0.0f);
-        cur = bi;
+        st.used = (st.used + dem[di]) * (bi != 0 ? 1.0f : 0.0f);
+        st.cur = bi;
       }
     }
   }
   if (w == 0) {
-    if (!single && !done && t >= a.max_steps) errbits |= RL4CO_EBIT_MAX_STEPS;
+    if (!single && !st.done && t >= a.max_steps) st.errbits |= RL4CO_EBIT_MAX_STEPS;
     for (int j = lane; j < N; j += 64) gmask[j] = mk[j];
     if (ENV == RL4CO_ENV_CVRP) {
       uint8_t* gv = a.visited + (int64_t)r * N;
       for (int j = lane; j < N; j += 64) gv[j] = vis[j];
     }
     if (lane == 0) {
-      a.current_node[r] = cur;
-      a.done[r] = done ? 1 : 0;
+      a.current_node[r] = st.cur;
+      a.done[r] = st.done ? 1 : 0;
       if (ENV == RL4CO_ENV_TSP) {
-        a.first_node[r] = first;
-        a.step_i[r] = step_i;
+        a.first_node[r] = st.first;
+        a.step_i[r] = st.step_i;
       } else {
-        a.used_capacity[r] = used;
+        a.used_capacity[r] = st.used;
       }
       if (a.n_steps) a.n_steps[r] = t;
-      if (a.entropy) a.entropy[r] += ent_acc;
-      if (errbits) atomicOr(a.err, (int)errbits);
+      if (a.entropy) a.entropy[r] += st.ent_acc;
+      if (st.errbits) atomicOr(a.err, (int)st.errbits);
     }
   }
 }
 
-template <int ENV, int ITERS, bool RESIDENT>
+template <int ENV, bool RESIDENT>
 int launch_wide(const rl4co_am_decode_args& a, hipStream_t stream) {
   const int lds = RESIDENT ? lds_variant_bytes(a.N) : wide_scratch_bytes(a.N);
   if (lds > 64 * 1024) {
-    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_decode_lds_kernel<ENV, ITERS, RESIDENT>),
+    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_decode_wide_kernel<ENV, RESIDENT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
-  hipLaunchKernelGGL((am_decode_lds_kernel<ENV, ITERS, RESIDENT>), dim3(a.B), dim3(64 * kLdsWaves), lds, stream, a);
+  hipLaunchKernelGGL((am_decode_wide_kernel<ENV, RESIDENT>), dim3(a.B), dim3(64 * kLdsWaves), lds, stream, a);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }
 
-template <int ENV>
-int launch_lds(const rl4co_am_decode_args& a, hipStream_t stream) {
-  switch ((a.N + kLdsGroups - 1) / kLdsGroups) {  // rows per wave per pass, fully unrolled
-    case 1: return launch_wide<ENV, 1, true>(a, stream);
-    case 2: return launch_wide<ENV, 2, true>(a, stream);
-    case 3: return launch_wide<ENV, 3, true>(a, stream);
-    case 4: return launch_wide<ENV, 4, true>(a, stream);
-    case 5: return launch_wide<ENV, 5, true>(a, stream);
-    case 6: return launch_wide<ENV, 6, true>(a, stream);
-    case 7: return launch_wide<ENV, 7, true>(a, stream);
-    default: return rl4co::record_arg_error("LDS-resident decode variant supports N <= 112");
-  }
-}
-
-// Which kernel serves these arguments. Measured on MI355X (TSP-100, bf16): with thousands of
-// trajectories the streaming kernel keeps 16 independent waves per CU in flight and runs at ~0.9
-// of the HBM peak (4.4 ms per 4096 x 100 steps), while the LDS-resident kernel can only host two
-// trajectories per CU and becomes latency-bound (6.1 ms). The resident kernel wins when there
-// are too few trajectories to fill the chip with one wave each: it puts 4 waves on every
-// trajectory and takes HBM out of the per-step critical path (measured: 0.70 vs 1.54 ms at B = 256,
-// 1.54 vs 1.84 ms at B = 1024, 3.06 vs 2.12 ms at B = 2048). Auto picks it for B <= 1024.
+// Which kernel serves these arguments (rules from measurements on MI355X, see the kernel headers).
 inline int resolve_variant(const rl4co_am_decode_args& a) {
   const bool bf16 = a.cache_dtype == RL4CO_DT_BF16;
-  const bool fits = bf16 && lds_variant_bytes(a.N) <= 80 * 1024 && (a.N + kLdsGroups - 1) / kLdsGroups <= 7;
+  const bool fits = bf16 && lds_variant_bytes(a.N) <= 80 * 1024;
   const bool wide_ok = bf16 && wide_scratch_bytes(a.N) <= 64 * 1024;
   if (a.variant == RL4CO_VARIANT_STREAM) return RL4CO_VARIANT_STREAM;
   if (a.variant == RL4CO_VARIANT_LDS) return fits ? RL4CO_VARIANT_LDS : -1;
@@ -796,7 +780,7 @@ int launch(const rl4co_am_decode_args& a, hipStream_t stream) {
 extern "C" int rl4co_am_decode_lds_bytes(int N, int env) {
   (void)env;
   const int Np = lds_pad(N);
-  return Np * kH * 4 + Np * 4 + Np + Np + kH * 4;
+  return Np * kH * 4 + Np * 4 + kH * 4 + Np * 2 + Np + Np;
 }
 
 extern "C" int rl4co_am_decode_row_groups(const rl4co_am_decode_args* args) {
@@ -835,14 +819,14 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
   RL4CO_REQUIRE(rl4co_am_decode_lds_bytes(a.N, a.env) <= 160 * 1024);
   RL4CO_REQUIRE(a.variant >= RL4CO_VARIANT_AUTO && a.variant <= RL4CO_VARIANT_WIDE);
   const int variant = resolve_variant(a);
-  RL4CO_REQUIRE(variant >= 0);  // RL4CO_VARIANT_LDS requested but the planes do not fit / are not bf16
+  RL4CO_REQUIRE(variant >= 0);  // explicit variant requested that cannot serve these planes
   hipStream_t s = rl4co::as_stream(stream);
   if (variant == RL4CO_VARIANT_LDS) {
-    return a.env == RL4CO_ENV_TSP ? launch_lds<RL4CO_ENV_TSP>(a, s) : launch_lds<RL4CO_ENV_CVRP>(a, s);
+    return a.env == RL4CO_ENV_TSP ? launch_wide<RL4CO_ENV_TSP, true>(a, s) : launch_wide<RL4CO_ENV_CVRP, true>(a, s);
   }
   if (variant == RL4CO_VARIANT_WIDE) {
-    return a.env == RL4CO_ENV_TSP ? launch_wide<RL4CO_ENV_TSP, 0, false>(a, s)
-                                  : launch_wide<RL4CO_ENV_CVRP, 0, false>(a, s);
+    return a.env == RL4CO_ENV_TSP ? launch_wide<RL4CO_ENV_TSP, false>(a, s)
+                                  : launch_wide<RL4CO_ENV_CVRP, false>(a, s);
   }
   if (a.cache_dtype == RL4CO_DT_F32) {
     return a.env == RL4CO_ENV_TSP ? launch<CacheF32, RL4CO_ENV_TSP>(a, s)

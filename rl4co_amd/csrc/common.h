@@ -87,6 +87,17 @@ __device__ inline float bfly_max(float v) {
   }
 }
 
+// integer maximum over the whole wave
+template <int S = 1>
+__device__ inline int bfly_i_max(int v) {
+  if constexpr (S < 64) {
+    const int o = bfly_i<S>(v);
+    return bfly_i_max<S * 2>(o > v ? o : v);
+  } else {
+    return v;
+  }
+}
+
 // (maximum key, lowest index on ties) over the whole wave; idx == 0x7fffffff marks "empty"
 template <int S = 1>
 __device__ inline void bfly_argmax(float& best, int& bi) {

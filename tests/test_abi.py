@@ -74,7 +74,7 @@ def test_argument_validation_without_gpu():
     st = handle.rl4co_am_decode(ctypes.byref(args), None)
     assert st == 1  # RL4CO_ERR_ARG
     assert b"requirement failed" in handle.rl4co_last_error()
-    assert handle.rl4co_am_decode_lds_bytes(100, 0) == 128 * 8 * 4 + 128 * 4 + 256 + 32
+    assert handle.rl4co_am_decode_lds_bytes(100, 0) == 128 * 8 * 4 + 128 * 4 + 32 + 128 * 2 + 256
     with pytest.raises(_lib.Rl4coLibraryError):
         _lib.check(st, "rl4co_am_decode")
 
