@@ -263,6 +263,10 @@ def main() -> None:
                 "us_per_decode_step": mean_decode_ms * 1e3 / t_steps,
                 "launches_timed": len(decode_ms),
                 "hbm_read_probe_GBs": probe_gbs,
+                # the kernel skips the cache rows of masked nodes (exact zeros in the reference's
+                # formulation), so the algorithmic figure can exceed what HBM really moves; the
+                # PMC traffic over the same launch time is the true HBM utilisation
+                "hbm_utilisation_from_traffic": (traffic / (mean_decode_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
