@@ -57,7 +57,7 @@ def build_library(force: bool = False, verbose: bool = False) -> Path:
     if not force and is_fresh():
         return LIB_PATH
     LIB_DIR.mkdir(parents=True, exist_ok=True)
-    tmp = LIB_DIR / "librl4co_amd.so.tmp"
+    tmp = LIB_DIR / f"librl4co_amd.so.tmp.{os.getpid()}"  # several ranks may build at once: atomic replace
     cmd = [_hipcc(), *FLAGS, f"-I{INCLUDE}", "-o", str(tmp)] + [str(CSRC / s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))

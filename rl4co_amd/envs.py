@@ -194,11 +194,14 @@ class TSPEnv(RL4COEnvBase):
         """tsp/env.py:150-156"""
         return K.tour_length(td["locs"], actions.contiguous(), prepend_depot=False, negate=True)
 
-    def check_solution_validity(self, td: TensorDict, actions: Tensor) -> None:
-        """tsp/env.py:158-164"""
-        err = K.new_error_word(actions.device)
+    def check_solution_validity(self, td: TensorDict, actions: Tensor, err: Tensor | None = None) -> None:
+        """tsp/env.py:158-164. With ``err`` the violation bits are OR-ed into the caller's error
+        word and the host check is left to the caller (one sync per rollout)."""
+        own = err is None
+        err = K.new_error_word(actions.device) if own else err
         K.tsp_check_solution(actions.contiguous(), td["locs"].shape[-2], err)
-        K.raise_if_error(err)
+        if own:
+            K.raise_if_error(err)
 
 
 class CVRPEnv(RL4COEnvBase):
@@ -245,11 +248,13 @@ class CVRPEnv(RL4COEnvBase):
         """cvrp/env.py:138-147"""
         return K.tour_length(td["locs"], actions.contiguous(), prepend_depot=True, negate=True)
 
-    def check_solution_validity(self, td: TensorDict, actions: Tensor) -> None:
-        """cvrp/env.py:149-177"""
-        err = K.new_error_word(actions.device)
+    def check_solution_validity(self, td: TensorDict, actions: Tensor, err: Tensor | None = None) -> None:
+        """cvrp/env.py:149-177 (trailing depot padding is neutral). ``err``: see TSPEnv."""
+        own = err is None
+        err = K.new_error_word(actions.device) if own else err
         K.cvrp_check_solution(actions.contiguous(), td["demand"], td["vehicle_capacity"].reshape(-1).contiguous(), err)
-        K.raise_if_error(err)
+        if own:
+            K.raise_if_error(err)
 
 
 def get_env(name: str, **kw) -> RL4COEnvBase:

@@ -427,11 +427,18 @@ class AttentionModelPolicy(nn.Module):
         if self.decode_events is not None:
             ev1.record()
             self.decode_events.append((ev0, ev1))
-        # ONE host sync for the whole rollout: horizon + sticky error bits
-        horizon_used, streamed = torch.stack((n_steps.max(), n_steps.sum())).tolist()
+        # validity check on the padded action buffer (trailing depot zeros are neutral), into the
+        # same error word — then ONE host sync for the whole rollout: horizon + every sticky bit
+        checked = bool(calc_reward and env.check_solution and not (n_rep > 0 and select_best))
+        if checked:
+            env.check_solution_validity(td, out_actions, err=err)
+        horizon_used, streamed, err_bits = torch.stack(
+            (n_steps.max().to(torch.int64), n_steps.sum(dtype=torch.int64), err[0].to(torch.int64))).tolist()
         t_used = t0 + int(horizon_used)
         self.last_instance_steps = int(streamed)  # instance-steps the decode launch really streamed
-        K.raise_if_error(err)
+        from . import _lib as _l
+
+        _l.raise_for_error_bits(int(err_bits))
         out_actions = out_actions[:, :t_used].contiguous()
         logps = logps[:, :t_used]
         if all_logps is not None:
@@ -451,7 +458,8 @@ class AttentionModelPolicy(nn.Module):
             td_out = td_out[rows] if hasattr(td_out, "__getitem__") else td_out
             reward = rewards[rows] if calc_reward else None
         else:
-            reward = env.get_reward(td_out, out_actions) if calc_reward else td_out.get("reward", None)
+            reward = (env.get_reward(td_out, out_actions, check_solution=False if checked else None)
+                      if calc_reward else td_out.get("reward", None))
         if calc_reward:
             td_out.set("reward", reward)
 
@@ -460,7 +468,9 @@ class AttentionModelPolicy(nn.Module):
                                                  mask_logits, skip_first=(t0 == 1))
         else:
             step_logps = logps
-        if not bool((step_logps.detach() > -1000).all()):
+        # decoding.py:56: on the kernel path this is the RL4CO_EBIT_NEG_INF_LOGP sticky bit (already
+        # raised above); only the autograd re-evaluation needs its own check
+        if grad_path and not bool((step_logps.detach() > -1000).all()):
             raise AssertionError("Logprobs should not be -inf, check sampling procedure!")
         outdict = {
             "reward": reward,
