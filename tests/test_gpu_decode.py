@@ -186,6 +186,15 @@ def test_evaluate_mode_bit_exact_and_entropy(K, name):
     torch.testing.assert_close(outs[0][2], want_ent, rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("dtype,variant", CONFIGS, ids=CONFIG_IDS)
+def test_mask_inner_off_bit_exact_vs_c_oracle(K, dtype, variant):
+    """mask_inner=False disables the feasible-row compaction (every node stays in the glimpse)."""
+    g = GoldenCase("cvrp20_b128_greedy")
+    td0, h = _encode(g)
+    _assert_bit_exact(_run(K, "hip", g, td0, h, "greedy", dtype, variant=variant, mask_inner=False),
+                      _run(K, "c", g, td0, h, "greedy", dtype, variant=variant, mask_inner=False))
+
+
 def test_single_step_calls_equal_persistent_rollout(K):
     """max_steps=1 called T times (the step-by-step surface) == one persistent launch, bitwise."""
     g = GoldenCase("cvrp20_b128_greedy")

@@ -223,3 +223,26 @@ def test_philox_noise_is_strictly_positive_and_exponential():
     for k in (0, 2**23 - 1):
         u = np.float32(np.float32(k) + np.float32(0.5)) * np.float32(2.0 ** -23)
         assert 0.0 < float(u) < 1.0
+
+
+def test_c_oracle_mask_inner_off_matches_restatement():
+    """PointerAttention(mask_inner=False): the glimpse attends to every node, so the step list
+    holds all N nodes (no compaction) — still the restatement's trajectories / log-likelihoods."""
+    g = GoldenCase("tsp20_b64_greedy_simple")
+    torch.manual_seed(g.meta["weight_seed"])
+    pol = R.AttentionModelPolicy(env_name="tsp", mask_inner=False).eval()
+    td0 = g.reset()
+    with torch.inference_mode():
+        want = pol(g.reset(), g.env, phase="test", decode_type="greedy")
+        h, _ = pol.encoder(td0)
+    cache = fold_cache(pol, "tsp", h)
+    st = rollout_state("tsp", td0)
+    actions = torch.zeros(g.batch, 20, dtype=torch.int64)
+    logps = torch.zeros(g.batch, 20)
+    err = torch.zeros(1, dtype=torch.int32)
+    c_oracle.am_decode(cache, st, mode="greedy", max_steps=20, actions=actions, logps=logps, err=err,
+                       row_groups=2, mask_inner=False)
+    assert int(err.item()) == 0
+    same = (actions == want["actions"]).all(1)
+    assert int((~same).sum()) <= 1
+    torch.testing.assert_close(logps.sum(1)[same], want["log_likelihood"][same], rtol=1e-5, atol=2e-5)
