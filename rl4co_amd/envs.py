@@ -192,7 +192,7 @@ class TSPEnv(RL4COEnvBase):
 
     def _get_reward(self, td: TensorDict, actions: Tensor) -> Tensor:
         """tsp/env.py:150-156"""
-        return K.tour_length(td["locs"], actions.contiguous(), prepend_depot=False, negate=True)
+        return K.tour_length(td["locs"].contiguous(), actions.contiguous(), prepend_depot=False, negate=True)
 
     def check_solution_validity(self, td: TensorDict, actions: Tensor, err: Tensor | None = None) -> None:
         """tsp/env.py:158-164. With ``err`` the violation bits are OR-ed into the caller's error
@@ -246,7 +246,7 @@ class CVRPEnv(RL4COEnvBase):
 
     def _get_reward(self, td: TensorDict, actions: Tensor) -> Tensor:
         """cvrp/env.py:138-147"""
-        return K.tour_length(td["locs"], actions.contiguous(), prepend_depot=True, negate=True)
+        return K.tour_length(td["locs"].contiguous(), actions.contiguous(), prepend_depot=True, negate=True)
 
     def check_solution_validity(self, td: TensorDict, actions: Tensor, err: Tensor | None = None) -> None:
         """cvrp/env.py:149-177 (trailing depot padding is neutral). ``err``: see TSPEnv."""
