@@ -271,6 +271,59 @@ int rl4co_am_encoder(const rl4co_am_encoder_args* args, void* stream);
 int rl4co_am_encoder_max_nodes(void);
 
 /* --------------------------------------------------------------------------
+ * N1  teacher-forced log-likelihood, backward pass.
+ *
+ * Replaces the autograd graph the reference builds through its T-step decode loop
+ * (rl/reinforce/reinforce.py:99-102 differentiates out["log_likelihood"];
+ * models/common/constructive/base.py:226-263; decode_type="evaluate",
+ * utils/decoding.py:448-461): given the actions of B trajectories and the upstream
+ * gradient g[B,T] of their per-step log-probs, recompute every step from the reset state and
+ * return dL/d(folded cache) for L = sum g * log p. Outputs are fp32; d_ctx_first, d_q_step0
+ * and d_w_cap are accumulated atomically and must be zero-initialised by the caller, the
+ * others are written. One workgroup per instance, its B / B_inst trajectories (s-major rows)
+ * replayed in turn. N <= rl4co_am_teacher_max_nodes().
+ * -------------------------------------------------------------------------- */
+typedef struct rl4co_am_teacher_args {
+  int32_t env;
+  int32_t B;            /* trajectories                                             */
+  int32_t B_inst;       /* instances                                                */
+  int32_t N;
+  int32_t T;            /* columns of actions / grad_logp / logp_out                */
+  int32_t t0;           /* 1: column 0 is the imposed multistart node (log-prob 0)  */
+  int32_t mask_inner;
+  int32_t mask_logits;
+  float tanh_clipping;
+  float temperature;
+  int32_t cache_dtype;  /* dtype of the three planes                                */
+  int32_t _pad0;
+  const void* glimpse_key;
+  const void* glimpse_val;
+  const void* logit_key;
+  int64_t kvl_row_stride;
+  int64_t kvl_batch_stride;
+  const float* ctx_first;
+  const float* ctx_cur;
+  const float* q_bias;
+  const float* q_step0;
+  const float* w_cap;
+  const int64_t* actions;        /* [B,T]                                           */
+  const float* demand;           /* [B_inst,N-1] CVRP                               */
+  const float* vehicle_capacity; /* [B_inst] CVRP                                   */
+  const float* grad_logp;        /* [B,T]                                           */
+  float* d_kvl;                  /* [3,B_inst,N,128]                                */
+  float* d_ctx_first;            /* [B_inst,N,128] TSP, zero-initialised            */
+  float* d_ctx_cur;              /* [B_inst,N,128]                                  */
+  float* d_q_bias;               /* [B_inst,128] or NULL                            */
+  float* d_q_step0;              /* [128] TSP, zero-initialised                     */
+  float* d_w_cap;                /* [128] CVRP, zero-initialised                    */
+  float* logp_out;               /* [B,T] forward values, or NULL                   */
+  int32_t* err;
+} rl4co_am_teacher_args;
+
+int rl4co_am_teacher_backward(const rl4co_am_teacher_args* args, void* stream);
+int rl4co_am_teacher_max_nodes(void);
+
+/* --------------------------------------------------------------------------
  * a19  select_start_nodes        rl4co/utils/ops.py:128-161
  * out[s*B + b] = s % num_loc (+1 for depot environments), s-major.
  * -------------------------------------------------------------------------- */

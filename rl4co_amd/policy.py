@@ -257,7 +257,8 @@ class AttentionModelPolicy(nn.Module):
                  temperature: float = 1.0, tanh_clipping: float = 10.0, mask_logits: bool = True,
                  train_decode_type: str = "sampling", val_decode_type: str = "greedy",
                  test_decode_type: str = "greedy", cache_dtype: torch.dtype = torch.float32,
-                 encoder_autocast: torch.dtype | None = None, fused_encoder: bool = True, **unused_kwargs):
+                 encoder_autocast: torch.dtype | None = None, fused_encoder: bool = True,
+                 fused_backward: bool = True, **unused_kwargs):
         super().__init__()
         if isinstance(env_name, RL4COEnvBase):
             env_name = env_name.name
@@ -279,6 +280,9 @@ class AttentionModelPolicy(nn.Module):
         # inference rollouts in the bf16 regime run encoder + cache fold in ONE hand-written MFMA
         # kernel (csrc/am_encoder.hip); fp32 parity runs and training stay on the torch encoder
         self.fused_encoder = fused_encoder
+        # training: gradient of the log-likelihood w.r.t. the folded cache from the HIP backward
+        # kernel (csrc/am_teacher.hip) instead of a dense [B,T,N] torch re-evaluation
+        self.fused_backward = fused_backward
         self._packed = None
         self._philox_calls = 0
         self.last_instance_steps = 0
@@ -379,6 +383,13 @@ class AttentionModelPolicy(nn.Module):
         device = td["action_mask"].device
         b_inst, n = td["action_mask"].shape[0], td["action_mask"].shape[-1]
         b = b_inst * max(n_rep, 1)
+        cache_g = None
+        if cache is None and grad_path and self.fused_backward and hidden.is_cuda:
+            from . import teacher
+
+            if n <= teacher.max_nodes() and not return_entropy:
+                cache_g = teacher.build_cache_autograd(self.env_name, hidden, self.decoder)
+                cache = teacher.detached_cache(self.env_name, cache_g, self.cache_dtype)
         if cache is None:
             with torch.no_grad():
                 cache = self.decoder.precompute_cache(hidden.detach(), self.cache_dtype,
@@ -463,7 +474,15 @@ class AttentionModelPolicy(nn.Module):
         if calc_reward:
             td_out.set("reward", reward)
 
-        if grad_path:
+        if grad_path and cache_g is not None and not (n_rep > 0 and select_best):
+            from . import teacher
+
+            meta = dict(t0=t0, mask_inner=self.decoder.mask_inner, mask_logits=mask_logits,
+                        tanh_clipping=tanh_clipping, temperature=temperature)
+            if self.env_name == "cvrp":
+                meta.update(demand=td["demand"], vehicle_capacity=td["vehicle_capacity"])
+            step_logps = teacher.teacher_forced_logps(self.env_name, cache_g, cache, out_actions, logps, meta)
+        elif grad_path:
             step_logps = self.evaluate_log_probs(td, hidden, out_actions, n_rep, tanh_clipping, temperature,
                                                  mask_logits, skip_first=(t0 == 1))
         else:

@@ -1,0 +1,128 @@
+"""Differentiable teacher-forced log-likelihood on the HIP backward kernel (``csrc/am_teacher.hip``).
+
+Training (REINFORCE / POMO, ``rl/reinforce/reinforce.py:99-102``) differentiates the
+log-likelihood of the sampled trajectories. The rollout kernel already produced the forward values
+(per-step log-probs); this module supplies their gradient w.r.t. the folded decoder cache through
+one launch of ``rl4co_am_teacher_backward`` and lets torch autograd carry it on through the fold
+GEMMs and the encoder. Falls back to ``policy.evaluate_log_probs`` (pure torch) for graphs larger
+than the kernel supports.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import Tensor
+
+from . import _lib
+from .cache import EMBED_DIM, FoldedCache, fold_weights
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+
+class AmTeacherArgs(C.Structure):
+    """Mirror of ``struct rl4co_am_teacher_args`` (field order and types must match the header)."""
+
+    _fields_ = [
+        ("env", _i32), ("B", _i32), ("B_inst", _i32), ("N", _i32), ("T", _i32), ("t0", _i32),
+        ("mask_inner", _i32), ("mask_logits", _i32), ("tanh_clipping", _f32), ("temperature", _f32),
+        ("cache_dtype", _i32), ("_pad0", _i32),
+        ("glimpse_key", _vp), ("glimpse_val", _vp), ("logit_key", _vp),
+        ("kvl_row_stride", _i64), ("kvl_batch_stride", _i64),
+        ("ctx_first", _vp), ("ctx_cur", _vp), ("q_bias", _vp), ("q_step0", _vp), ("w_cap", _vp),
+        ("actions", _vp), ("demand", _vp), ("vehicle_capacity", _vp), ("grad_logp", _vp),
+        ("d_kvl", _vp), ("d_ctx_first", _vp), ("d_ctx_cur", _vp), ("d_q_bias", _vp), ("d_q_step0", _vp),
+        ("d_w_cap", _vp), ("logp_out", _vp), ("err", _vp),
+    ]
+
+
+def max_nodes() -> int:
+    return _lib.lib().rl4co_am_teacher_max_nodes()
+
+
+def build_cache_autograd(env_name: str, h: Tensor, decoder) -> dict[str, Tensor]:
+    """The folded cache as differentiable fp32 tensors (same algebra as cache.build_folded_cache)."""
+    d = EMBED_DIM
+    h = h.float()
+    w_ctx = decoder.context_embedding.project_context.weight.float()
+    blocks = fold_weights(env_name, decoder.project_node_embeddings.weight.float(),
+                          decoder.pointer.project_out.weight.float(), w_ctx)
+    planes = [torch.matmul(h, w.t()) for w in blocks]
+    out = {"kvl": torch.stack(planes[:3], 0), "ctx_cur": planes[-1] if env_name == "cvrp" else planes[4]}
+    if env_name == "tsp":
+        out["ctx_first"] = planes[3]
+        out["q_step0"] = torch.mv(w_ctx, decoder.context_embedding.W_placeholder.float())
+    else:
+        out["w_cap"] = w_ctx[:, d]
+    out["q_bias"] = (torch.matmul(h.mean(1), decoder.project_fixed_context.weight.float().t())
+                     if decoder.use_graph_context else None)
+    return out
+
+
+def detached_cache(env_name: str, g: dict[str, Tensor], cache_dtype: torch.dtype) -> FoldedCache:
+    """Rollout view of the autograd cache: detached, planes in the streaming dtype."""
+    det = lambda x: None if x is None else x.detach().contiguous()  # noqa: E731
+    return FoldedCache(env_name, g["kvl"].detach().to(cache_dtype).contiguous(), det(g.get("ctx_first")),
+                       det(g["ctx_cur"]), det(g.get("q_bias")), det(g.get("q_step0")), det(g.get("w_cap")))
+
+
+class TeacherForcedLogLik(torch.autograd.Function):
+    """log p(a_t | s_t) [B,T]: forward = the rollout kernel's values, backward = HIP kernel."""
+
+    @staticmethod
+    def forward(ctx, kvl, ctx_first, ctx_cur, q_bias, q_extra, logps, cache: FoldedCache, actions: Tensor, meta: dict):
+        ctx.cache, ctx.actions, ctx.meta = cache, actions, meta
+        ctx.has = (ctx_first is not None, q_bias is not None)
+        return logps.detach().clone()
+
+    @staticmethod
+    def backward(ctx, grad_logp):
+        cache, actions, meta = ctx.cache, ctx.actions, ctx.meta
+        b, t = actions.shape
+        b_inst, n = cache.num_instances, cache.num_nodes
+        dev = actions.device
+        tsp = cache.env_name == "tsp"
+        f32 = dict(dtype=torch.float32, device=dev)
+        d_kvl = torch.empty((3, b_inst, n, EMBED_DIM), **f32)
+        d_ctx_cur = torch.empty((b_inst, n, EMBED_DIM), **f32)
+        d_ctx_first = torch.zeros((b_inst, n, EMBED_DIM), **f32) if tsp else None
+        d_q_bias = torch.empty((b_inst, EMBED_DIM), **f32) if cache.q_bias is not None else None
+        d_extra = torch.zeros((EMBED_DIM,), **f32)
+        err = torch.zeros(1, dtype=torch.int32, device=dev)
+        a = AmTeacherArgs()
+        a.env = _lib.ENV_TSP if tsp else _lib.ENV_CVRP
+        a.B, a.B_inst, a.N, a.T, a.t0 = b, b_inst, n, t, int(meta["t0"])
+        a.mask_inner, a.mask_logits = int(meta["mask_inner"]), int(meta["mask_logits"])
+        a.tanh_clipping, a.temperature = float(meta["tanh_clipping"]), float(meta["temperature"])
+        a.cache_dtype = _lib.DT_BF16 if cache.kvl.dtype == torch.bfloat16 else _lib.DT_F32
+        a.glimpse_key, a.glimpse_val, a.logit_key = (cache.plane(i).data_ptr() for i in range(3))
+        a.kvl_row_stride, a.kvl_batch_stride = cache.row_stride, cache.batch_stride
+        ptr = lambda x: None if x is None else x.data_ptr()  # noqa: E731
+        a.ctx_first, a.ctx_cur, a.q_bias = ptr(cache.ctx_first), ptr(cache.ctx_cur), ptr(cache.q_bias)
+        a.q_step0, a.w_cap = ptr(cache.q_step0), ptr(cache.w_cap)
+        acts = actions.contiguous()
+        g = grad_logp.contiguous().float()
+        a.actions, a.grad_logp = acts.data_ptr(), g.data_ptr()
+        if not tsp:
+            demand = meta["demand"].contiguous()
+            vcap = meta["vehicle_capacity"].reshape(-1).contiguous()
+            a.demand, a.vehicle_capacity = demand.data_ptr(), vcap.data_ptr()
+        a.d_kvl, a.d_ctx_cur, a.d_ctx_first, a.d_q_bias = ptr(d_kvl), ptr(d_ctx_cur), ptr(d_ctx_first), ptr(d_q_bias)
+        if tsp:
+            a.d_q_step0 = d_extra.data_ptr()
+        else:
+            a.d_w_cap = d_extra.data_ptr()
+        a.err = err.data_ptr()
+        st = _lib.lib().rl4co_am_teacher_backward(C.byref(a), torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "rl4co_am_teacher_backward")
+        has_first, has_bias = ctx.has
+        return (d_kvl, d_ctx_first if has_first else None, d_ctx_cur, d_q_bias if has_bias else None, d_extra,
+                None, None, None, None)
+
+
+def teacher_forced_logps(env_name: str, g: dict[str, Tensor], cache: FoldedCache, actions: Tensor, logps: Tensor,
+                         meta: dict) -> Tensor:
+    """Differentiable per-step log-probs of ``actions`` (values = ``logps`` from the rollout)."""
+    extra = g["q_step0"] if env_name == "tsp" else g["w_cap"]
+    return TeacherForcedLogLik.apply(g["kvl"], g.get("ctx_first"), g["ctx_cur"], g.get("q_bias"), extra, logps,
+                                     cache, actions, meta)

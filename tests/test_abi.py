@@ -48,6 +48,9 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.AmDecodeArgs) % 8 == 0
     assert _c_fields("rl4co_am_encoder_args") == [f[0] for f in AmEncoderArgs._fields_]
     assert ctypes.sizeof(AmEncoderArgs) == 6 * 4 + 27 * 8
+    from rl4co_amd.teacher import AmTeacherArgs
+
+    assert _c_fields("rl4co_am_teacher_args") == [f[0] for f in AmTeacherArgs._fields_]
 
 
 def test_weight_packing_is_the_documented_fragment_order():
