@@ -66,16 +66,23 @@ def test_backward_kernel_matches_torch_autograd(name, starts):
     ll_f, gr_f = results[True]
     ll_t, gr_t = results[False]
     torch.testing.assert_close(ll_f, ll_t, rtol=1e-4, atol=1e-3)
-    checked = 0
+    # gradients that are analytically ~0 (e.g. a bias in front of a train-mode batch norm) are pure
+    # rounding noise on both paths: measure every error against the largest gradient norm too
+    scale = max(float(gt.norm()) for gt in gr_t.values() if gt is not None)
+    checked, worst = 0, (0.0, "")
     for k, gt in gr_t.items():
         gf = gr_f[k]
-        if gt is None or float(gt.norm()) == 0.0:
-            assert gf is None or float(gf.norm()) <= 1e-6, k
+        if gt is None:
+            assert gf is None or float(gf.norm()) <= 1e-6 * scale, k
             continue
-        rel = float((gf - gt).norm() / gt.norm())
-        assert rel <= 2e-3, f"{k}: relative gradient error {rel:.2e}"
+        assert gf is not None, k
+        err = float((gf - gt).norm())
+        bound = 2e-3 * float(gt.norm()) + 2e-5 * scale
+        worst = max(worst, (err / bound, k))
+        assert err <= bound, f"{k}: |dg| {err:.3e} vs bound {bound:.3e} (|g| {float(gt.norm()):.3e}, scale {scale:.3e})"
         checked += 1
     assert checked >= 20
+    print(f"worst gradient error / bound = {worst[0]:.3f} at {worst[1]}")
 
 
 def test_training_step_uses_rollout_logps_and_learns():
