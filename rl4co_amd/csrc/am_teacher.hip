@@ -10,11 +10,11 @@
 // (three planes, context tables, graph context, placeholder query / capacity column). torch
 // autograd carries it on through the fold GEMMs and the encoder.
 //
-// One 256-thread workgroup per INSTANCE; its S trajectories (multistart) are replayed one after
-// the other. Every lane owns a fixed set of cache elements — rows j = 16 i + 4 w + rg (i < ROWS),
+// One 256- or 512-thread workgroup per INSTANCE; its S trajectories (multistart) are replayed one after
+// the other. Every lane owns a fixed set of cache elements — rows j = 4 NW i + 4 w + rg (i < ROWS),
 // dims 8 li .. 8 li + 7 — of all three planes: they are loaded into registers ONCE per instance
 // and their gradients are accumulated in registers over all S x T steps (no atomics, no plane
-// traffic inside the loop; N <= 16 * ROWS <= 112). Per step the four waves meet only three times:
+// traffic inside the loop; N <= 4 NW ROWS <= 112). Per step the waves meet only three times:
 // each exchange ships wave-local partial sums built so that the missing global scalar (softmax
 // max / log-sum-exp / sum a*da) can be applied AFTER the exchange (online-softmax style), and the
 // next step's feasibility mask is prepared by an otherwise idle wave into a second buffer.
@@ -30,7 +30,6 @@ constexpr int kD = RL4CO_EMBED_DIM;
 constexpr int kH = RL4CO_NUM_HEADS;
 constexpr float kNegInf = -__builtin_huge_valf();
 constexpr float kSqrtD = 11.3137084989847604f;
-constexpr int kW = 4;  // waves per workgroup
 
 __device__ inline float load_plane(const void* base, int dtype, int64_t idx) {
   if (dtype == RL4CO_DT_BF16) return __uint_as_float((uint32_t)static_cast<const uint16_t*>(base)[idx] << 16);
@@ -41,8 +40,11 @@ __device__ inline float load_plane(const void* base, int dtype, int64_t idx) {
 __device__ inline float rg_sum(float v) { return rl4co::bfly_sum<16, 64>(v); }
 __device__ inline float rg_max(float v) { return rl4co::bfly_max<16, 64>(v); }
 
-template <int ENV, int ROWS>
-__global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teacher_args a) {
+// NW waves per workgroup; row j is owned by wave (j / 4) % NW, row group j % 4, slot j / (4 NW)
+template <int ENV, int ROWS, int NW>
+__global__ void __launch_bounds__(64 * NW) am_teacher_kernel(const rl4co_am_teacher_args a) {
+  constexpr int kW = NW;
+  constexpr int kRowStep = 4 * NW;
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x;
   const int w = tid >> 6, lane = tid & 63;
@@ -70,7 +72,7 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
   const int64_t pbase = (int64_t)inst * a.kvl_batch_stride;
 #pragma unroll
   for (int i = 0; i < ROWS; ++i) {
-    const int j = 16 * i + 4 * w + rg;
+    const int j = kRowStep * i + 4 * w + rg;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int64_t idx = pbase + (int64_t)j * a.kvl_row_stride + e0 + e;
@@ -120,11 +122,35 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
     for (int e = 0; e < 8; ++e) dqf[e] = 0.0f;
     __syncthreads();
 
+    // Everything a step reads from global memory is known one step ahead (teacher forcing): the
+    // action, its upstream gradient and the context row of the node just visited are requested
+    // during the previous step, so no load latency sits on the step's critical path.
+    long long at_next = act[0];
+    float g_next = gl[0];
+    float crow[8], frow[8], wcap[8];  // ctx_cur[cur], ctx_first[first] (TSP), w_cap (CVRP)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      crow[e] = (ENV == RL4CO_ENV_CVRP) ? ctxc[e] : 0.0f;  // CVRP starts at the depot (node 0)
+      frow[e] = 0.0f;
+      wcap[e] = (ENV == RL4CO_ENV_CVRP) ? a.w_cap[e0 + e] : 0.0f;
+    }
     for (int t = 0; t < T && !done; ++t) {
-      int at = (int)act[t];
+      int at = (int)at_next;
+      const float g = g_next;
+      if (t + 1 < T) {
+        at_next = act[t + 1];
+        g_next = gl[t + 1];
+      }
       if (at < 0 || at >= N) {
         errbits |= RL4CO_EBIT_INFEASIBLE;
         at = 0;
+      }
+      float crow_next[8];  // context row of the NEXT step (its current node is this step's action)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) crow_next[e] = ctxc[(int64_t)at * kD + e];
+      if (ENV == RL4CO_ENV_TSP && step_i == 0) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) frow[e] = ctxf[(int64_t)at * kD + e];  // first node, fixed from now on
       }
       // masks are double-buffered: this step reads mkb[t & 1]; wave 3 prepares the mask and the
       // done flag of step t + 1 into the other buffer while the step is being computed (the
@@ -179,7 +205,6 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
       }
       const bool decoded = t >= a.t0;  // multistart: column 0 is imposed, log-prob 0 (decoding.py:306-326)
       if (decoded) {
-        const float g = gl[t];
         // ---- query -----------------------------------------------------------------------------
         float q[8];
         if (ENV == RL4CO_ENV_TSP) {
@@ -188,12 +213,11 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
             for (int e = 0; e < 8; ++e) q[e] = a.q_step0[e0 + e] + qb[e];
           } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-              q[e] = (ctxf[(int64_t)first_t * kD + e] + ctxc[(int64_t)cur_t * kD + e]) + qb[e];
+            for (int e = 0; e < 8; ++e) q[e] = (frow[e] + crow[e]) + qb[e];
           }
         } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) q[e] = fmaf(a.w_cap[e0 + e], rem, ctxc[(int64_t)cur_t * kD + e]) + qb[e];
+          for (int e = 0; e < 8; ++e) q[e] = fmaf(wcap[e], rem, crow[e]) + qb[e];
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) q[e] *= 0.25f;
@@ -204,7 +228,7 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
         float mw = kNegInf;
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
-          const int j = 16 * i + 4 * w + rg;
+          const int j = kRowStep * i + 4 * w + rg;
           float acc = 0.0f;
 #pragma unroll
           for (int e = 0; e < 8; ++e) acc = fmaf(q[e], kg[i][e], acc);
@@ -239,7 +263,9 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
           }
         }
         __syncthreads();  // exchange 1: (max, sum, weighted values) of the four waves
-        float m = fmaxf(fmaxf(mpart[hd], mpart[kH + hd]), fmaxf(mpart[2 * kH + hd], mpart[3 * kH + hd]));
+        float m = kNegInf;
+#pragma unroll
+        for (int ww = 0; ww < kW; ++ww) m = fmaxf(m, mpart[ww * kH + hd]);
         float scl[kW];
         l = 0.0f;
 #pragma unroll
@@ -264,7 +290,7 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
         float zm = kNegInf;
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
-          const int j = 16 * i + 4 * w + rg;
+          const int j = kRowStep * i + 4 * w + rg;
           float acc = 0.0f;
 #pragma unroll
           for (int e = 0; e < 8; ++e) acc = fmaf(heads[e], kl[i][e], acc);
@@ -299,7 +325,7 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
         float ez[ROWS];
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
-          const int j = 16 * i + 4 * w + rg;
+          const int j = kRowStep * i + 4 * w + rg;
           ez[i] = __expf(z[i] - zm_safe);  // 0 for masked rows
           se += ez[i];
           const float c1 = ez[i] * dzdu[i];
@@ -328,7 +354,9 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
           lsep[w * 2 + 1] = se;
         }
         __syncthreads();  // exchange 2: log-sum-exp pieces and the d-heads partial sums
-        const float zmax = fmaxf(fmaxf(lsep[0], lsep[2]), fmaxf(lsep[4], lsep[6]));
+        float zmax = kNegInf;
+#pragma unroll
+        for (int ww = 0; ww < kW; ++ww) zmax = fmaxf(zmax, lsep[ww * 2]);
         float zs[kW];
         float tot = 0.0f;
 #pragma unroll
@@ -354,7 +382,7 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
         const float my_soft = zs[w] * inv_tot;  // exp(z - zm_w) -> softmax probability for this wave's rows
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
-          const int j = 16 * i + 4 * w + rg;
+          const int j = kRowStep * i + 4 * w + rg;
           const float prob = ez[i] * my_soft;
           const float dz = g * ((j == at ? 1.0f : 0.0f) - prob);
           const float ddr = (z[i] > kNegInf) ? dz * dzdu[i] / kSqrtD : 0.0f;
@@ -410,13 +438,19 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
           if ((li & 1) == 0) adap[w * kH + hd] = ada;
         }
         __syncthreads();  // exchange 3: attention-backward sums
-        ada = (adap[hd] + adap[kH + hd]) + (adap[2 * kH + hd] + adap[3 * kH + hd]);
+        ada = 0.0f;
+#pragma unroll
+        for (int ww = 0; ww < kW; ++ww) ada += adap[ww * kH + hd];
         float dqs[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int d = e0 + e;
-          const float X = (dhpart[d] + dhpart[kD + d]) + (dhpart[2 * kD + d] + dhpart[3 * kD + d]);
-          const float Y = (opart[d] + opart[kD + d]) + (opart[2 * kD + d] + opart[3 * kD + d]);
+          float X = 0.0f, Y = 0.0f;
+#pragma unroll
+          for (int ww = 0; ww < kW; ++ww) {
+            X += dhpart[ww * kD + d];
+            Y += opart[ww * kD + d];
+          }
           dqs[e] = X - ada * Y;  // d L / d q_scaled
         }
 #pragma unroll
@@ -446,6 +480,8 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
           }
         }
       }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) crow[e] = crow_next[e];
       __syncthreads();  // end of step: next mask / done flag visible, exchange buffers free
       done = shi[(t + 1) & 1] != 0;
     }
@@ -463,7 +499,7 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
   const int64_t plane = (int64_t)a.B_inst * N * kD;
 #pragma unroll
   for (int i = 0; i < ROWS; ++i) {
-    const int j = 16 * i + 4 * w + rg;
+    const int j = kRowStep * i + 4 * w + rg;
     if (j < N) {
       float* r0 = dk + (int64_t)j * kD + e0;
       *reinterpret_cast<float4*>(r0) = make_float4(dkg[i][0], dkg[i][1], dkg[i][2], dkg[i][3]);
@@ -487,25 +523,27 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
   if (errbits && lane == 0) atomicOr(a.err, (int)errbits);
 }
 
-template <int ENV, int ROWS>
+template <int ENV, int ROWS, int NW>
 int launch_teacher(const rl4co_am_teacher_args& a, hipStream_t stream) {
   const int nw = (a.N + 3) & ~3;
-  const int lds = (3 * kW * kH + kW * 2 + 8 + 8) * 4 + 3 * kW * kD * 4 + a.N * kD * 4 + 3 * nw;
+  const int lds = (3 * NW * kH + NW * 2 + 8 + 8) * 4 + 3 * NW * kD * 4 + a.N * kD * 4 + 3 * nw;
   if (lds > 64 * 1024) {
-    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_teacher_kernel<ENV, ROWS>),
+    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_teacher_kernel<ENV, ROWS, NW>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
-  hipLaunchKernelGGL((am_teacher_kernel<ENV, ROWS>), dim3(a.B_inst), dim3(64 * kW), lds, stream, a);
+  hipLaunchKernelGGL((am_teacher_kernel<ENV, ROWS, NW>), dim3(a.B_inst), dim3(64 * NW), lds, stream, a);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }
 
+// Measured on MI355X: eight waves per workgroup (2 per SIMD, 256-register cap) spill the step's
+// working set to scratch and run 5x slower than four waves with the full 512-register budget, so
+// the row ownership stays at 4 waves: 2 / 4 / 7 rows per lane for N <= 32 / 64 / 112.
 template <int ENV>
 int dispatch_rows(const rl4co_am_teacher_args& a, hipStream_t s) {
-  const int rows = (a.N + 15) / 16;
-  if (rows <= 2) return launch_teacher<ENV, 2>(a, s);
-  if (rows <= 4) return launch_teacher<ENV, 4>(a, s);
-  return launch_teacher<ENV, 7>(a, s);
+  if (a.N <= 32) return launch_teacher<ENV, 2, 4>(a, s);
+  if (a.N <= 64) return launch_teacher<ENV, 4, 4>(a, s);
+  return launch_teacher<ENV, 7, 4>(a, s);
 }
 
 }  // namespace

@@ -1,0 +1,33 @@
+"""Micro-benchmark of the teacher-forced backward kernel alone (TSP-N, B instances x S starts)."""
+import sys, os, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rl4co_amd.policy import AttentionModelPolicy
+from rl4co_amd.envs import get_env
+from rl4co_amd import teacher
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+N = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+torch.manual_seed(0)
+pol = AttentionModelPolicy("tsp", num_encoder_layers=6, normalization="instance", use_graph_context=False,
+                           cache_dtype=torch.bfloat16).cuda().eval()
+env = get_env("tsp", generator_params=dict(num_loc=N, device="cuda"), device="cuda", check_solution=False)
+td = env.reset(batch_size=[B])
+with torch.no_grad():
+    out = pol(td, env, phase="train", decode_type="multistart_sampling" if S > 1 else "sampling", num_starts=S, seed=1)
+    h, _ = pol.encoder(td)
+    g = teacher.build_cache_autograd("tsp", h, pol.decoder)
+    cache = teacher.detached_cache("tsp", g, torch.bfloat16)
+for k in ("kvl", "ctx_first", "ctx_cur", "q_step0"):
+    g[k] = g[k].detach().requires_grad_(True)
+meta = dict(t0=1 if S > 1 else 0, mask_inner=True, mask_logits=True, tanh_clipping=10.0, temperature=1.0)
+logps = torch.zeros(out["actions"].shape, device="cuda")
+lp = teacher.teacher_forced_logps("tsp", g, cache, out["actions"], logps, meta)
+grad = torch.ones_like(lp)
+for it in range(3):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    torch.autograd.grad(lp, [g["kvl"]], grad, retain_graph=True)
+    e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1)
+steps = B * S * (N - (1 if S > 1 else 0))
+print(f"teacher backward B={B} S={S} N={N}: {ms:.2f} ms  ({steps/ms/1e3:.1f} M trajectory-steps/s)")
