@@ -10,14 +10,12 @@
 // (three planes, context tables, graph context, placeholder query / capacity column). torch
 // autograd carries it on through the fold GEMMs and the encoder.
 //
-// One 256- or 512-thread workgroup per INSTANCE; its S trajectories (multistart) are replayed one after
-// the other. Every lane owns a fixed set of cache elements — rows j = 4 NW i + 4 w + rg (i < ROWS),
+// One 256-thread workgroup per INSTANCE; its S trajectories (multistart) are replayed one after
+// the other. Every lane owns a fixed set of cache elements — rows j = 16 i + 4 w + rg (i < ROWS),
 // dims 8 li .. 8 li + 7 — of all three planes: they are loaded into registers ONCE per instance
 // and their gradients are accumulated in registers over all S x T steps (no atomics, no plane
-// traffic inside the loop; N <= 4 NW ROWS <= 112). Per step the waves meet only three times:
-// each exchange ships wave-local partial sums built so that the missing global scalar (softmax
-// max / log-sum-exp / sum a*da) can be applied AFTER the exchange (online-softmax style), and the
-// next step's feasibility mask is prepared by an otherwise idle wave into a second buffer.
+// traffic inside the loop; N <= 16 * ROWS <= 112). Per step the four waves exchange only the
+// 128-wide reductions (glimpse, d heads, d query) and a few scalars through LDS.
 // fp32 arithmetic throughout; this is a floating-point kernel tested against torch autograd
 // (tests/test_gpu_teacher.py, tolerance stated there), not part of the bit-exact decode contract.
 #include <hip/hip_runtime.h>
@@ -30,6 +28,7 @@ constexpr int kD = RL4CO_EMBED_DIM;
 constexpr int kH = RL4CO_NUM_HEADS;
 constexpr float kNegInf = -__builtin_huge_valf();
 constexpr float kSqrtD = 11.3137084989847604f;
+constexpr int kW = 4;  // waves per workgroup
 
 __device__ inline float load_plane(const void* base, int dtype, int64_t idx) {
   if (dtype == RL4CO_DT_BF16) return __uint_as_float((uint32_t)static_cast<const uint16_t*>(base)[idx] << 16);
@@ -40,11 +39,8 @@ __device__ inline float load_plane(const void* base, int dtype, int64_t idx) {
 __device__ inline float rg_sum(float v) { return rl4co::bfly_sum<16, 64>(v); }
 __device__ inline float rg_max(float v) { return rl4co::bfly_max<16, 64>(v); }
 
-// NW waves per workgroup; row j is owned by wave (j / 4) % NW, row group j % 4, slot j / (4 NW)
-template <int ENV, int ROWS, int NW>
-__global__ void __launch_bounds__(64 * NW) am_teacher_kernel(const rl4co_am_teacher_args a) {
-  constexpr int kW = NW;
-  constexpr int kRowStep = 4 * NW;
+template <int ENV, int ROWS>
+__global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teacher_args a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x;
   const int w = tid >> 6, lane = tid & 63;
@@ -63,8 +59,8 @@ __global__ void __launch_bounds__(64 * NW) am_teacher_kernel(const rl4co_am_teac
   float* dhpart = opart + kW * kD;                  // [4][128]
   float* dqpart = dhpart + kW * kD;                 // [4][128]
   float* dctx = dqpart + kW * kD;                   // [N][128] d ctx_cur of this instance
-  uint8_t* mk = reinterpret_cast<uint8_t*>(dctx + N * kD);  // [2][nw] double-buffered feasibility mask
-  uint8_t* vis = mk + 2 * nw;                               // [nw]
+  uint8_t* mk = reinterpret_cast<uint8_t*>(dctx + N * kD);  // [nw]
+  uint8_t* vis = mk + nw;                                   // [nw]
 
   // ---- this lane's slice of the three planes, resident in registers -------------------------
   float kg[ROWS][8], vv[ROWS][8], kl[ROWS][8];
@@ -72,7 +68,7 @@ __global__ void __launch_bounds__(64 * NW) am_teacher_kernel(const rl4co_am_teac
   const int64_t pbase = (int64_t)inst * a.kvl_batch_stride;
 #pragma unroll
   for (int i = 0; i < ROWS; ++i) {
-    const int j = kRowStep * i + 4 * w + rg;
+    const int j = 16 * i + 4 * w + rg;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int64_t idx = pbase + (int64_t)j * a.kvl_row_stride + e0 + e;
@@ -112,7 +108,6 @@ __global__ void __launch_bounds__(64 * NW) am_teacher_kernel(const rl4co_am_teac
       mk[j] = (j < N) ? ((ENV == RL4CO_ENV_CVRP && j == 0) ? 0 : 1) : 0;  // fresh CVRP: depot masked
       vis[j] = (j < N) ? 0 : 1;
     }
-    if (tid == 0) shi[0] = 0;
     int cur = 0, first = 0;
     long long step_i = 0;
     float used = 0.0f;
@@ -122,131 +117,60 @@ __global__ void __launch_bounds__(64 * NW) am_teacher_kernel(const rl4co_am_teac
     for (int e = 0; e < 8; ++e) dqf[e] = 0.0f;
     __syncthreads();
 
-    // Everything a step reads from global memory is known one step ahead (teacher forcing): the
-    // action, its upstream gradient and the context row of the node just visited are requested
-    // during the previous step, so no load latency sits on the step's critical path.
-    long long at_next = act[0];
-    float g_next = gl[0];
-    float crow[8], frow[8], wcap[8];  // ctx_cur[cur], ctx_first[first] (TSP), w_cap (CVRP)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      crow[e] = (ENV == RL4CO_ENV_CVRP) ? ctxc[e] : 0.0f;  // CVRP starts at the depot (node 0)
-      frow[e] = 0.0f;
-      wcap[e] = (ENV == RL4CO_ENV_CVRP) ? a.w_cap[e0 + e] : 0.0f;
-    }
     for (int t = 0; t < T && !done; ++t) {
-      int at = (int)at_next;
-      const float g = g_next;
-      if (t + 1 < T) {
-        at_next = act[t + 1];
-        g_next = gl[t + 1];
-      }
+      int at = (int)act[t];
       if (at < 0 || at >= N) {
         errbits |= RL4CO_EBIT_INFEASIBLE;
         at = 0;
       }
-      float crow_next[8];  // context row of the NEXT step (its current node is this step's action)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) crow_next[e] = ctxc[(int64_t)at * kD + e];
-      if (ENV == RL4CO_ENV_TSP && step_i == 0) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) frow[e] = ctxf[(int64_t)at * kD + e];  // first node, fixed from now on
-      }
-      // masks are double-buffered: this step reads mkb[t & 1]; wave 3 prepares the mask and the
-      // done flag of step t + 1 into the other buffer while the step is being computed (the
-      // transition only needs the given action), so no barrier is spent on the environment.
-      const uint8_t* mkc = mk + (t & 1) * nw;
-      uint8_t* mkn = mk + ((t + 1) & 1) * nw;
-      const float rem = cap - used;   // context of THIS step (before the transition)
-      const int cur_t = cur, first_t = first;
-      const long long step_t = step_i;
-      if (mkc[at] == 0 && t >= a.t0) errbits |= RL4CO_EBIT_INFEASIBLE;
-      // ---- environment transition with the given action (scalars on every wave) --------------
-      if (ENV == RL4CO_ENV_TSP) {
-        if (step_i == 0) first = at;
-        cur = at;
-        step_i += 1;
-        if (w == kW - 1) {
-          bool any_left = false;
-          for (int j = lane; j < nw; j += 64) {
-            const uint8_t v = (j == at) ? (uint8_t)0 : mkc[j];
-            mkn[j] = v;
-            any_left |= v != 0;
-          }
-          any_left = __any(any_left);
-          if (lane == 0) shi[(t + 1) & 1] = any_left ? 0 : 1;
-        }
-      } else {
-        const int di = min(max(at - 1, 0), N - 2);
-        used = (used + dem[di]) * (at != 0 ? 1.0f : 0.0f);
-        cur = at;
-        if (w == kW - 1) {
-          const float thr = cap + 1e-5f;
-          bool any_feasible = false, all_visited = true;
-          for (int j = lane; j < nw; j += 64) {
-            const bool v = j < N && (vis[j] != 0 || j == at);
-            if (j < N && j == at) vis[j] = 1;
-            all_visited &= (j >= N) || v;
-            if (j >= 1 && j < N) {
-              const bool masked = v || (dem[j - 1] + used > thr);
-              mkn[j] = masked ? 0 : 1;
-              any_feasible |= !masked;
-            } else if (j >= N) {
-              mkn[j] = 0;
-            }
-          }
-          any_feasible = __any(any_feasible);
-          all_visited = __all(all_visited);
-          if (lane == 0) {
-            mkn[0] = ((at == 0) && any_feasible) ? 0 : 1;
-            shi[(t + 1) & 1] = all_visited ? 1 : 0;
-          }
-        }
-      }
       const bool decoded = t >= a.t0;  // multistart: column 0 is imposed, log-prob 0 (decoding.py:306-326)
       if (decoded) {
+        const float g = gl[t];
         // ---- query -----------------------------------------------------------------------------
         float q[8];
+        const float rem = cap - used;
         if (ENV == RL4CO_ENV_TSP) {
-          if (step_t < 1) {
+          if (step_i < 1) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) q[e] = a.q_step0[e0 + e] + qb[e];
           } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) q[e] = (frow[e] + crow[e]) + qb[e];
+            for (int e = 0; e < 8; ++e) q[e] = (ctxf[(int64_t)first * kD + e] + ctxc[(int64_t)cur * kD + e]) + qb[e];
           }
         } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) q[e] = fmaf(wcap[e], rem, crow[e]) + qb[e];
+          for (int e = 0; e < 8; ++e) q[e] = fmaf(a.w_cap[e0 + e], rem, ctxc[(int64_t)cur * kD + e]) + qb[e];
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) q[e] *= 0.25f;
 
-        // ---- forward: scores, wave-local softmax, ONE exchange (online-softmax merge) -----------
+        // ---- forward: scores, softmax, glimpse --------------------------------------------------
         float sv[ROWS];
         bool feas[ROWS];
-        float mw = kNegInf;
+        float m = kNegInf;
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
-          const int j = kRowStep * i + 4 * w + rg;
+          const int j = 16 * i + 4 * w + rg;
           float acc = 0.0f;
 #pragma unroll
           for (int e = 0; e < 8; ++e) acc = fmaf(q[e], kg[i][e], acc);
           acc += rl4co::bfly_f<1>(acc);
-          feas[i] = j < N && mkc[j < N ? j : 0] != 0;
+          feas[i] = j < N && mk[j < N ? j : 0] != 0;
           const bool in_glimpse = j < N && (!a.mask_inner || feas[i]);
           sv[i] = in_glimpse ? acc : kNegInf;
-          mw = fmaxf(mw, sv[i]);
+          m = fmaxf(m, sv[i]);
         }
-        mw = rg_max(mw);
-        const float mw_safe = (mw > kNegInf) ? mw : 0.0f;  // a wave whose rows are all masked
+        m = rg_max(m);
+        if (rg == 0 && (li & 1) == 0) mpart[w * kH + hd] = m;
+        __syncthreads();  // B1
+        m = fmaxf(fmaxf(mpart[hd], mpart[kH + hd]), fmaxf(mpart[2 * kH + hd], mpart[3 * kH + hd]));
         float l = 0.0f, o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = 0.0f;
         float p[ROWS];
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
-          p[i] = __expf(sv[i] - mw_safe);
+          p[i] = __expf(sv[i] - m);
           l += p[i];
 #pragma unroll
           for (int e = 0; e < 8; ++e) o[e] = fmaf(p[i], vv[i][e], o[e]);
@@ -257,40 +181,23 @@ __global__ void __launch_bounds__(64 * NW) am_teacher_kernel(const rl4co_am_teac
         if (rg == 0) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) opart[w * kD + e0 + e] = o[e];
-          if ((li & 1) == 0) {
-            lpart[w * kH + hd] = l;
-            mpart[w * kH + hd] = mw;
-          }
+          if ((li & 1) == 0) lpart[w * kH + hd] = l;
         }
-        __syncthreads();  // exchange 1: (max, sum, weighted values) of the four waves
-        float m = kNegInf;
-#pragma unroll
-        for (int ww = 0; ww < kW; ++ww) m = fmaxf(m, mpart[ww * kH + hd]);
-        float scl[kW];
-        l = 0.0f;
-#pragma unroll
-        for (int ww = 0; ww < kW; ++ww) {
-          const float mm = mpart[ww * kH + hd];
-          scl[ww] = (mm > kNegInf) ? __expf(mm - m) : 0.0f;
-          l = fmaf(lpart[ww * kH + hd], scl[ww], l);
-        }
+        __syncthreads();  // B2
+        l = (lpart[hd] + lpart[kH + hd]) + (lpart[2 * kH + hd] + lpart[3 * kH + hd]);
         const float inv_l = 1.0f / l;
         float heads[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int d = e0 + e;
-          float acc = 0.0f;
-#pragma unroll
-          for (int ww = 0; ww < kW; ++ww) acc = fmaf(opart[ww * kD + d], scl[ww], acc);
-          heads[e] = acc * inv_l;
+          heads[e] = ((opart[d] + opart[kD + d]) + (opart[2 * kD + d] + opart[3 * kD + d])) * inv_l;
         }
-        const float my_scale = scl[w] * inv_l;  // p -> attention probability for this wave's rows
-        // ---- forward: logits, clip; backward terms that do not need lse yet -------------------------
+        // ---- forward: logits, clip, log-softmax -----------------------------------------------------
         float z[ROWS], dzdu[ROWS];
         float zm = kNegInf;
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
-          const int j = kRowStep * i + 4 * w + rg;
+          const int j = 16 * i + 4 * w + rg;
           float acc = 0.0f;
 #pragma unroll
           for (int e = 0; e < 8; ++e) acc = fmaf(heads[e], kl[i][e], acc);
@@ -313,99 +220,65 @@ __global__ void __launch_bounds__(64 * NW) am_teacher_kernel(const rl4co_am_teac
           zm = fmaxf(zm, z[i]);
         }
         zm = rg_max(zm);
-        const float zm_safe = (zm > kNegInf) ? zm : 0.0f;
-        // d heads = g/sqrt(d) * [ dzdu_a * kl_a  -  sum_i softmax_i * dzdu_i * kl_i ]; the softmax
-        // needs lse, but exp(z_i - zm_w) does not: ship the wave-local sums with (zm_w, se_w)
-        float se = 0.0f, wsum[8], hot[8];
+        float se = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          wsum[e] = 0.0f;
-          hot[e] = 0.0f;
-        }
-        float ez[ROWS];
-#pragma unroll
-        for (int i = 0; i < ROWS; ++i) {
-          const int j = kRowStep * i + 4 * w + rg;
-          ez[i] = __expf(z[i] - zm_safe);  // 0 for masked rows
-          se += ez[i];
-          const float c1 = ez[i] * dzdu[i];
-          const float c2 = (j == at && z[i] > kNegInf) ? dzdu[i] : 0.0f;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            wsum[e] = fmaf(c1, kl[i][e], wsum[e]);
-            hot[e] = fmaf(c2, kl[i][e], hot[e]);
-          }
-        }
+        for (int i = 0; i < ROWS; ++i) se += __expf(z[i] - zm);  // exp(-inf - zm) = 0; zm = -inf only if no row
         se = rg_sum(se);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          wsum[e] = rg_sum(wsum[e]);
-          hot[e] = rg_sum(hot[e]);
-        }
-        if (rg == 0) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            dhpart[w * kD + e0 + e] = wsum[e];
-            dqpart[w * kD + e0 + e] = hot[e];  // dqpart doubles as the one-hot term buffer here
-          }
-        }
         if (lane == 0) {
           lsep[w * 2] = zm;
-          lsep[w * 2 + 1] = se;
+          lsep[w * 2 + 1] = (zm > kNegInf) ? se : 0.0f;
         }
-        __syncthreads();  // exchange 2: log-sum-exp pieces and the d-heads partial sums
-        float zmax = kNegInf;
-#pragma unroll
-        for (int ww = 0; ww < kW; ++ww) zmax = fmaxf(zmax, lsep[ww * 2]);
-        float zs[kW];
+        __syncthreads();  // B3
+        const float zmax = fmaxf(fmaxf(lsep[0], lsep[2]), fmaxf(lsep[4], lsep[6]));
         float tot = 0.0f;
 #pragma unroll
-        for (int ww = 0; ww < kW; ++ww) {
-          zs[ww] = (lsep[ww * 2] > kNegInf) ? __expf(lsep[ww * 2] - zmax) : 0.0f;
-          tot = fmaf(lsep[ww * 2 + 1], zs[ww], tot);
-        }
+        for (int ww = 0; ww < kW; ++ww)
+          tot += (lsep[ww * 2] > kNegInf) ? lsep[ww * 2 + 1] * __expf(lsep[ww * 2] - zmax) : 0.0f;
         const float lse = zmax + __logf(tot);
-        const float inv_tot = 1.0f / tot;
-        float dh[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int d = e0 + e;
-          float soft = 0.0f, oh = 0.0f;
-#pragma unroll
-          for (int ww = 0; ww < kW; ++ww) {
-            soft = fmaf(dhpart[ww * kD + d], zs[ww], soft);
-            oh += dqpart[ww * kD + d];
-          }
-          dh[e] = (g / kSqrtD) * (oh - soft * inv_tot);
-        }
-        // per-row d(heads . kl_row) now that lse is known; logit-key gradient; log p(a_t)
-        const float my_soft = zs[w] * inv_tot;  // exp(z - zm_w) -> softmax probability for this wave's rows
+        // log p(a_t): written by the lane that owns row a_t
+        float dd_row[ROWS];  // d L / d (heads . kl_row), i.e. through clip and 1/sqrt(d)
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
-          const int j = kRowStep * i + 4 * w + rg;
-          const float prob = ez[i] * my_soft;
+          const int j = 16 * i + 4 * w + rg;
+          const float prob = __expf(z[i] - lse);  // 0 for masked rows
           const float dz = g * ((j == at ? 1.0f : 0.0f) - prob);
-          const float ddr = (z[i] > kNegInf) ? dz * dzdu[i] / kSqrtD : 0.0f;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) dkl[i][e] = fmaf(ddr, heads[e], dkl[i][e]);
+          dd_row[i] = (z[i] > kNegInf) ? dz * dzdu[i] / kSqrtD : 0.0f;
           if (j == at && li == 0) {
             const float lp = z[i] - lse;
             if (a.logp_out) a.logp_out[(int64_t)r * T + t] = lp;
             if (!(lp > -1000.0f)) errbits |= RL4CO_EBIT_NEG_INF_LOGP;
           }
         }
-        // ---- backward: glimpse attention. ds_i = a_i (da_i - ada); d q = sum ds_i kg_i =
-        //      sum a_i da_i kg_i - ada * sum a_i kg_i  -> both sums and ada in ONE exchange --------
-        float ada = 0.0f, xs[8], ys[8];
+        // ---- backward: logits -> heads, logit keys ------------------------------------------------
+        float dh[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          xs[e] = 0.0f;
-          ys[e] = 0.0f;
-        }
-        float av[ROWS], da[ROWS];
+        for (int e = 0; e < 8; ++e) dh[e] = 0.0f;
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
-          av[i] = p[i] * my_scale;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            dh[e] = fmaf(dd_row[i], kl[i][e], dh[e]);
+            dkl[i][e] = fmaf(dd_row[i], heads[e], dkl[i][e]);
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dh[e] = rg_sum(dh[e]);
+        if (rg == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dhpart[w * kD + e0 + e] = dh[e];
+        }
+        __syncthreads();  // B4
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int d = e0 + e;
+          dh[e] = (dhpart[d] + dhpart[kD + d]) + (dhpart[2 * kD + d] + dhpart[3 * kD + d]);
+        }
+        // ---- backward: glimpse attention (softmax over nodes, per head) ---------------------------
+        float av[ROWS], da[ROWS];
+        float ada = 0.0f;
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) {
+          av[i] = p[i] * inv_l;
           float acc = 0.0f;
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -414,76 +287,94 @@ __global__ void __launch_bounds__(64 * NW) am_teacher_kernel(const rl4co_am_teac
           }
           acc += rl4co::bfly_f<1>(acc);  // the head's 16 dims live on a lane pair
           da[i] = acc;
-          const float ad = av[i] * acc;
-          ada += ad;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            xs[e] = fmaf(ad, kg[i][e], xs[e]);
-            ys[e] = fmaf(av[i], kg[i][e], ys[e]);
-          }
+          ada = fmaf(av[i], acc, ada);
         }
         ada = rg_sum(ada);
+        if (rg == 0 && (li & 1) == 0) adap[w * kH + hd] = ada;
+        __syncthreads();  // B5
+        ada = (adap[hd] + adap[kH + hd]) + (adap[2 * kH + hd] + adap[3 * kH + hd]);
+        float dq[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          xs[e] = rg_sum(xs[e]);
-          ys[e] = rg_sum(ys[e]);
-        }
-        __syncthreads();  // exchange-2 buffers (dhpart, dqpart) fully consumed before they are reused
-        if (rg == 0) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            dhpart[w * kD + e0 + e] = xs[e];
-            opart[w * kD + e0 + e] = ys[e];
-          }
-          if ((li & 1) == 0) adap[w * kH + hd] = ada;
-        }
-        __syncthreads();  // exchange 3: attention-backward sums
-        ada = 0.0f;
-#pragma unroll
-        for (int ww = 0; ww < kW; ++ww) ada += adap[ww * kH + hd];
-        float dqs[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int d = e0 + e;
-          float X = 0.0f, Y = 0.0f;
-#pragma unroll
-          for (int ww = 0; ww < kW; ++ww) {
-            X += dhpart[ww * kD + d];
-            Y += opart[ww * kD + d];
-          }
-          dqs[e] = X - ada * Y;  // d L / d q_scaled
-        }
+        for (int e = 0; e < 8; ++e) dq[e] = 0.0f;
 #pragma unroll
         for (int i = 0; i < ROWS; ++i) {
           const float ds = av[i] * (da[i] - ada);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) dkg[i][e] = fmaf(ds, q[e], dkg[i][e]);
+          for (int e = 0; e < 8; ++e) {
+            dq[e] = fmaf(ds, kg[i][e], dq[e]);
+            dkg[i][e] = fmaf(ds, q[e], dkg[i][e]);
+          }
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dq[e] = rg_sum(dq[e]);
+        if (rg == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dqpart[w * kD + e0 + e] = dq[e];
+        }
+        __syncthreads();  // B6
         // ---- backward: query -> context rows, graph context, placeholder / capacity column ------------
         if (w == 0 && rg == 0) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int d = e0 + e;
-            const float dqr = 0.25f * dqs[e];
+            const float dqr = 0.25f * ((dqpart[d] + dqpart[kD + d]) + (dqpart[2 * kD + d] + dqpart[3 * kD + d]));
             dqb[e] += dqr;
             if (ENV == RL4CO_ENV_TSP) {
-              if (step_t < 1) {
+              if (step_i < 1) {
                 dqs0[e] += dqr;
               } else {
                 dqf[e] += dqr;
-                dctx[cur_t * kD + d] += dqr;
+                dctx[cur * kD + d] += dqr;
               }
             } else {
               dwc[e] = fmaf(dqr, rem, dwc[e]);
-              dctx[cur_t * kD + d] += dqr;
+              dctx[cur * kD + d] += dqr;
             }
           }
         }
+        if (mk[at] == 0) errbits |= RL4CO_EBIT_INFEASIBLE;
       }
-#pragma unroll
-      for (int e = 0; e < 8; ++e) crow[e] = crow_next[e];
-      __syncthreads();  // end of step: next mask / done flag visible, exchange buffers free
-      done = shi[(t + 1) & 1] != 0;
+      // ---- environment transition with the given action (all waves keep the scalars) -------------
+      __syncthreads();
+      if (ENV == RL4CO_ENV_TSP) {
+        if (step_i == 0) first = at;
+        cur = at;
+        step_i += 1;
+        if (tid == 0) mk[at] = 0;
+        __syncthreads();
+        if (w == 0) {
+          bool any_left = false;
+          for (int j = lane; j < N; j += 64) any_left |= mk[j] != 0;
+          any_left = __any(any_left);
+          if (lane == 0) shi[0] = any_left ? 0 : 1;
+        }
+      } else {
+        const int di = min(max(at - 1, 0), N - 2);
+        used = (used + dem[di]) * (at != 0 ? 1.0f : 0.0f);
+        cur = at;
+        if (tid == 0) vis[at] = 1;
+        __syncthreads();
+        if (w == 0) {
+          const float thr = cap + 1e-5f;
+          bool any_feasible = false, all_visited = true;
+          for (int j = lane; j < N; j += 64) {
+            all_visited &= vis[j] != 0;
+            if (j >= 1) {
+              const bool masked = (vis[j] != 0) || (dem[j - 1] + used > thr);
+              mk[j] = masked ? 0 : 1;
+              any_feasible |= !masked;
+            }
+          }
+          any_feasible = __any(any_feasible);
+          all_visited = __all(all_visited);
+          if (lane == 0) {
+            mk[0] = ((cur == 0) && any_feasible) ? 0 : 1;
+            shi[0] = all_visited ? 1 : 0;
+          }
+        }
+      }
+      __syncthreads();  // B7: mask, done flag
+      done = shi[0] != 0;
     }
     // d ctx_first: one row per trajectory (tsp: every step after the first reads h[first])
     if (ENV == RL4CO_ENV_TSP && w == 0 && rg == 0) {
@@ -499,7 +390,7 @@ __global__ void __launch_bounds__(64 * NW) am_teacher_kernel(const rl4co_am_teac
   const int64_t plane = (int64_t)a.B_inst * N * kD;
 #pragma unroll
   for (int i = 0; i < ROWS; ++i) {
-    const int j = kRowStep * i + 4 * w + rg;
+    const int j = 16 * i + 4 * w + rg;
     if (j < N) {
       float* r0 = dk + (int64_t)j * kD + e0;
       *reinterpret_cast<float4*>(r0) = make_float4(dkg[i][0], dkg[i][1], dkg[i][2], dkg[i][3]);
@@ -523,27 +414,25 @@ __global__ void __launch_bounds__(64 * NW) am_teacher_kernel(const rl4co_am_teac
   if (errbits && lane == 0) atomicOr(a.err, (int)errbits);
 }
 
-template <int ENV, int ROWS, int NW>
+template <int ENV, int ROWS>
 int launch_teacher(const rl4co_am_teacher_args& a, hipStream_t stream) {
   const int nw = (a.N + 3) & ~3;
-  const int lds = (3 * NW * kH + NW * 2 + 8 + 8) * 4 + 3 * NW * kD * 4 + a.N * kD * 4 + 3 * nw;
+  const int lds = (3 * kW * kH + kW * 2 + 8 + 8) * 4 + 3 * kW * kD * 4 + a.N * kD * 4 + 2 * nw;
   if (lds > 64 * 1024) {
-    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_teacher_kernel<ENV, ROWS, NW>),
+    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_teacher_kernel<ENV, ROWS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
-  hipLaunchKernelGGL((am_teacher_kernel<ENV, ROWS, NW>), dim3(a.B_inst), dim3(64 * NW), lds, stream, a);
+  hipLaunchKernelGGL((am_teacher_kernel<ENV, ROWS>), dim3(a.B_inst), dim3(64 * kW), lds, stream, a);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }
 
-// Measured on MI355X: eight waves per workgroup (2 per SIMD, 256-register cap) spill the step's
-// working set to scratch and run 5x slower than four waves with the full 512-register budget, so
-// the row ownership stays at 4 waves: 2 / 4 / 7 rows per lane for N <= 32 / 64 / 112.
 template <int ENV>
 int dispatch_rows(const rl4co_am_teacher_args& a, hipStream_t s) {
-  if (a.N <= 32) return launch_teacher<ENV, 2, 4>(a, s);
-  if (a.N <= 64) return launch_teacher<ENV, 4, 4>(a, s);
-  return launch_teacher<ENV, 7, 4>(a, s);
+  const int rows = (a.N + 15) / 16;
+  if (rows <= 2) return launch_teacher<ENV, 2>(a, s);
+  if (rows <= 4) return launch_teacher<ENV, 4>(a, s);
+  return launch_teacher<ENV, 7>(a, s);
 }
 
 }  // namespace
