@@ -67,6 +67,15 @@ class _Norm(nn.Module):
             b, n, d = x.shape
             return self.normalizer(x.reshape(b * n, d)).view(b, n, d)
         if self.kind == "instance":
+            if self.training and x.is_cuda and torch.is_grad_enabled():
+                # same arithmetic as InstanceNorm1d (biased variance over the nodes, eps inside the
+                # sqrt) written out: MIOpen's batch-norm backward that F.instance_norm dispatches to
+                # costs 24 ms per POMO training step at 4096 x 100 nodes, these fused-by-autograd
+                # elementwise ops about 2 ms
+                n = self.normalizer
+                mean = x.mean(dim=1, keepdim=True)
+                var = x.var(dim=1, unbiased=False, keepdim=True)
+                return (x - mean) * torch.rsqrt(var + n.eps) * n.weight + n.bias
             return self.normalizer(x.transpose(1, 2)).transpose(1, 2)
         mean = x.mean((1, 2), keepdim=True)
         var = x.var((1, 2), keepdim=True)

@@ -101,3 +101,25 @@ def test_training_step_uses_rollout_logps_and_learns():
         opt.step()
         costs.append(float(-out["reward"].mean()))
     assert sum(costs[-5:]) / 5 < sum(costs[:5]) / 5 - 0.2, costs
+
+
+def test_manual_instance_norm_matches_module():
+    """The written-out training-time instance norm equals nn.InstanceNorm1d in value and gradient."""
+    from rl4co_amd.policy import _Norm
+
+    torch.manual_seed(0)
+    norm = _Norm(128, "instance").cuda()
+    with torch.no_grad():
+        norm.normalizer.weight.uniform_(0.5, 1.5)
+        norm.normalizer.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(16, 50, 128, device="cuda", requires_grad=True)
+    norm.train()
+    y = norm(x)
+    gy = torch.randn_like(y)
+    gx, gw = torch.autograd.grad(y, [x, norm.normalizer.weight], gy)
+    norm.eval()
+    y2 = norm(x)
+    gx2, gw2 = torch.autograd.grad(y2, [x, norm.normalizer.weight], gy)
+    torch.testing.assert_close(y, y2, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(gx, gx2, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(gw, gw2, rtol=1e-4, atol=1e-4)
