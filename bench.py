@@ -135,9 +135,10 @@ def main() -> None:
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
 
+    from rl4co_amd import dist as D
+
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # "nccl" == RCCL on ROCm
+        D.init_process_group("nccl", device=device)  # "nccl" == RCCL on ROCm; rendezvous on 127.0.0.1
 
     from rl4co_amd import kernels as K
     from rl4co_amd.envs import get_env
@@ -159,8 +160,7 @@ def main() -> None:
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        D.barrier()
         torch.cuda.synchronize()
 
     log(f"rank {rank}/{world}: instances resident, warming up")
@@ -182,15 +182,9 @@ def main() -> None:
     t_steps = out["actions"].shape[1]
     n_nodes = args.num_loc + (1 if args.env == "cvrp" else 0)
 
-    if world > 1:
-        tw = torch.tensor([wall], dtype=torch.float64, device=device)
-        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
-        wall = float(tw.item())
-        ts = torch.tensor([t_steps], dtype=torch.int64, device=device)
-        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
-        total_instance_steps = args.batch * int(ts.item()) * args.steps
-    else:
-        total_instance_steps = args.batch * t_steps * args.steps
+    # whole-job numbers: wall = max over ranks, work = sum over ranks (each rank owns its shard)
+    wall = D.reduce_scalar(wall, "max", device)
+    total_instance_steps = int(D.reduce_scalar(args.batch * t_steps * args.steps, "sum", device))
 
     if rank == 0:
         elem = 2 if args.cache_dtype == "bf16" else 4

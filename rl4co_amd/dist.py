@@ -140,6 +140,23 @@ def allreduce_scalars(values: dict[str, float | Tensor], device=None, op: str = 
     return {k: float(v) for k, v in zip(keys, buf.tolist())}
 
 
+def barrier() -> None:
+    """Process-group barrier (no-op for a single process)."""
+    if world_info()[1] > 1:
+        dist.barrier()
+
+
+def reduce_scalar(value: float, op: str = "max", device=None) -> float:
+    """max / sum of one python scalar over the ranks — the timing aggregation of bench.py
+    (wall time = max over ranks, work = sum over ranks)."""
+    _, world = world_info()
+    if world == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+    return float(t.item())
+
+
 def broadcast_decision(flag: bool, src: int = 0, device=None) -> bool:
     """RolloutBaseline's per-rank t-test decision (reinforce/baselines.py:200-218) must agree on
     every rank: rank ``src`` decides, everyone follows."""

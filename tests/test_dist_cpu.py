@@ -67,6 +67,10 @@ def _worker(rank: int, world: int, port: int, out_q):
     assert m == {"loss": 1.0, "reward": 1.5}
     assert D.allreduce_scalars({"t": float(rank)}, op="max") == {"t": 1.0}
     assert D.broadcast_decision(rank == 0) is True
+    # bench.py's aggregation: wall = max over ranks, work = sum over ranks
+    assert D.reduce_scalar(1.0 + rank, "max") == 2.0
+    assert D.reduce_scalar(4096 * 100 * 5, "sum") == 2 * 4096 * 100 * 5
+    D.barrier()
     out_q.put((rank, bucket.nbytes, float(bucket.flat.sum())))
     dist.barrier()
     dist.destroy_process_group()
@@ -103,3 +107,5 @@ def test_single_process_is_a_noop():
     before = bucket.flat.clone()
     assert bucket.allreduce_mean() is None and torch.equal(bucket.flat, before)
     assert bucket.nbytes == 4 * sum(p.numel() for p in model.parameters())
+    assert D.reduce_scalar(3.5, "max") == 3.5 and D.reduce_scalar(7, "sum") == 7.0
+    D.barrier()
