@@ -230,7 +230,10 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.cache_dtype == "f32" else "f32 arithmetic on bf16 cache planes",
+            "dtype": "bf16" if (args.cache_dtype == "bf16" and args.encoder_dtype == "bf16") else
+                     ("f32" if (args.cache_dtype == "f32" and args.encoder_dtype == "f32") else "mixed"),
+            "dtype_detail": f"encoder GEMMs/attention: {args.encoder_dtype} MFMA inputs, fp32 accumulate; cache planes: "
+                            f"{args.cache_dtype}; decode arithmetic (scores, softmax, logits, log-probs, reward): fp32",
             "data": "synthetic",
             "config": {
                 "workload": workload,
