@@ -170,6 +170,7 @@ def main() -> None:
         torch.cuda.synchronize()
         log("timing")
         policy.decode_events = []
+        policy.encode_events = []
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -178,7 +179,8 @@ def main() -> None:
         wall = time.perf_counter() - t0
     log(f"timed region done: {wall:.3f} s for {args.steps} steps")
     decode_ms = [a.elapsed_time(b) for a, b in policy.decode_events]
-    policy.decode_events = None
+    encode_ms = [a.elapsed_time(b) for a, b in policy.encode_events]
+    policy.decode_events = policy.encode_events = None
     t_steps = out["actions"].shape[1]
     n_nodes = args.num_loc + (1 if args.env == "cvrp" else 0)
 
@@ -266,6 +268,18 @@ def main() -> None:
                 "hbm_utilisation_from_traffic": (traffic / (mean_decode_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             },
         }
+        if encode_ms:  # second kernel of the step: fused encoder + cache fold on the matrix cores
+            n_, d_, ff_, layers_ = n_nodes, 128, 512, 3
+            flop_inst = layers_ * (2 * n_ * d_ * 3 * d_ + 4 * n_ * n_ * d_ + 2 * n_ * d_ * d_ + 4 * n_ * d_ * ff_) \
+                + (5 if args.env == "tsp" else 4) * 2 * n_ * d_ * d_
+            enc_ms = sum(encode_ms) / len(encode_ms)
+            tf = flop_inst * args.batch / (enc_ms * 1e-3) / 1e12
+            line["encoder_roofline"] = {
+                "kernel": "am_encoder_kernel (init embedding + 3 x [MHA, norm, FFN, norm] + cache fold, one workgroup per instance)",
+                "bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0,
+                "flop_per_instance": flop_inst, "launch_ms_mean": enc_ms,
+                "note": "algorithmic FLOPs at N nodes (the kernel pads to 128 tokens); bf16 dense MFMA peak",
+            }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.env, args.num_loc, args.cpu_sample_batch, repeats=3)
             line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]

@@ -295,6 +295,7 @@ class AttentionModelPolicy(nn.Module):
         self._packed = None
         self._philox_calls = 0
         self.last_instance_steps = 0
+        self.encode_events: list | None = None
         self.decode_events: list | None = None  # set to [] by bench.py to time the decode launches
 
     # -- helpers --------------------------------------------------------------------------------
@@ -353,7 +354,13 @@ class AttentionModelPolicy(nn.Module):
         use_fused = (self.fused_encoder and self.encoder_autocast == torch.bfloat16 and not grad_path
                      and not return_init_embeds and self._packed_encoder().supported(td))
         if use_fused:
+            if self.encode_events is not None:  # bench.py: HIP events around the encoder launch
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
             cache, hidden = self._packed_encoder().encode(td, self.cache_dtype, want_hidden=return_hidden)
+            if self.encode_events is not None:
+                ev1.record()
+                self.encode_events.append((ev0, ev1))
             init_embeds = None
         else:
             cache = None
