@@ -58,6 +58,8 @@ extern "C" {
 #define RL4CO_VARIANT_STREAM 1 /* planes streamed from HBM every step, 1 wave per trajectory     */
 #define RL4CO_VARIANT_LDS 2    /* bf16 planes loaded into LDS once per rollout, 4 waves / trajectory */
 #define RL4CO_VARIANT_WIDE 3   /* bf16 planes streamed every step, 4 waves / trajectory (few trajectories, large N) */
+#define RL4CO_VARIANT_MS 4     /* multistart on the matrix cores: one workgroup per instance, planes in LDS, up to
+                                  32 trajectories per MFMA column tile; bf16 query/glimpse (tolerance-tested) */
 
 #define RL4CO_EMBED_DIM 128 /* the engine is specialised for the AM default d=128, H=8 */
 #define RL4CO_NUM_HEADS 8
@@ -208,7 +210,7 @@ int rl4co_am_decode_lds_bytes(int N, int env);
 /* Number of row groups G the kernel that will serve `args` splits a trajectory's cache rows
  * into (row j -> group j % G). G fixes the fp32 summation tree of the glimpse (am_decode.hip
  * header), so the specified-order oracle asks for it instead of guessing. -1 on bad args. */
-int rl4co_am_decode_row_groups(const rl4co_am_decode_args* args);
+int rl4co_am_decode_row_groups(const rl4co_am_decode_args* args); /* 0: variant without such a contract (MS) */
 /* The variant (RL4CO_VARIANT_STREAM / _LDS) rl4co_am_decode will run for `args`. */
 int rl4co_am_decode_variant(const rl4co_am_decode_args* args);
 

@@ -14,7 +14,7 @@ RL4CO_OK = 0
 ENV_TSP, ENV_CVRP = 0, 1
 DECODE_GREEDY, DECODE_SAMPLE, DECODE_EVALUATE = 0, 1, 2
 DT_F32, DT_BF16 = 0, 1
-VARIANT_AUTO, VARIANT_STREAM, VARIANT_LDS, VARIANT_WIDE = 0, 1, 2, 3
+VARIANT_AUTO, VARIANT_STREAM, VARIANT_LDS, VARIANT_WIDE, VARIANT_MS = 0, 1, 2, 3, 4
 
 EBIT_NAN_LOGIT = 1
 EBIT_INFEASIBLE = 2
@@ -112,14 +112,15 @@ def lib() -> C.CDLL:
 
 
 def decode_row_groups(num_nodes: int, cache_dtype_id: int, max_steps: int, variant: int = VARIANT_AUTO,
-                      num_trajectories: int = 1 << 20) -> int:
+                      num_trajectories: int = 1 << 20, num_instances: int | None = None) -> int:
     """Row groups G (the glimpse summation tree) of the kernel variant that serves this shape —
     a pure host query, usable without a GPU; the specified-order oracle mirrors it."""
     a = AmDecodeArgs()
     a.N, a.cache_dtype, a.max_steps, a.variant = int(num_nodes), int(cache_dtype_id), int(max_steps), int(variant)
     a.B = int(num_trajectories)
+    a.B_inst = int(num_trajectories if num_instances is None else num_instances)
     g = lib().rl4co_am_decode_row_groups(C.byref(a))
-    if g <= 0:
+    if g < 0:
         raise Rl4coLibraryError(f"no decode kernel variant {variant} for N={num_nodes}, dtype id {cache_dtype_id}")
     return g
 

@@ -750,12 +750,16 @@ int launch_wide(const rl4co_am_decode_args& a, hipStream_t stream) {
 // Which kernel serves these arguments (rules from measurements on MI355X, see the kernel headers).
 inline int resolve_variant(const rl4co_am_decode_args& a) {
   const bool bf16 = a.cache_dtype == RL4CO_DT_BF16;
+  // multistart on the matrix cores (am_decode_ms.hip): bf16 planes, N <= 128, plain outputs
+  const bool ms_ok = bf16 && a.N <= 128 && a.B_inst > 0 && a.all_logps == nullptr && a.entropy == nullptr;
+  if (a.variant == RL4CO_VARIANT_MS) return ms_ok ? RL4CO_VARIANT_MS : -1;
   const bool fits = bf16 && lds_variant_bytes(a.N) <= 80 * 1024;
   const bool wide_ok = bf16 && wide_scratch_bytes(a.N) <= 64 * 1024;
   if (a.variant == RL4CO_VARIANT_STREAM) return RL4CO_VARIANT_STREAM;
   if (a.variant == RL4CO_VARIANT_LDS) return fits ? RL4CO_VARIANT_LDS : -1;
   if (a.variant == RL4CO_VARIANT_WIDE) return wide_ok ? RL4CO_VARIANT_WIDE : -1;
   if (a.max_steps < 4) return RL4CO_VARIANT_STREAM;
+  if (ms_ok && a.B >= 4 * a.B_inst) return RL4CO_VARIANT_MS;  // >= 4 starts share one instance's planes
   if (fits && a.B <= 1024) return RL4CO_VARIANT_LDS;
   // one wave per trajectory needs >= ~16 waves per CU to hide its latency chain: with fewer
   // trajectories than that, four waves per trajectory keep the memory pipes busier
@@ -787,6 +791,7 @@ extern "C" int rl4co_am_decode_row_groups(const rl4co_am_decode_args* args) {
   if (args == nullptr) return -1;
   const int v = resolve_variant(*args);
   if (v < 0) return -1;
+  if (v == RL4CO_VARIANT_MS) return 0;  // bf16 MFMA variant: tolerance-tested, no specified-order oracle
   if (v == RL4CO_VARIANT_LDS || v == RL4CO_VARIANT_WIDE) return kLdsGroups;
   return args->cache_dtype == RL4CO_DT_BF16 ? 64 / (kD / CacheBF16::EPL) : 64 / (kD / CacheF32::EPL);
 }
@@ -817,10 +822,11 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
     RL4CO_REQUIRE(a.w_cap && a.demand && a.used_capacity && a.vehicle_capacity && a.visited);
   }
   RL4CO_REQUIRE(rl4co_am_decode_lds_bytes(a.N, a.env) <= 160 * 1024);
-  RL4CO_REQUIRE(a.variant >= RL4CO_VARIANT_AUTO && a.variant <= RL4CO_VARIANT_WIDE);
+  RL4CO_REQUIRE(a.variant >= RL4CO_VARIANT_AUTO && a.variant <= RL4CO_VARIANT_MS);
   const int variant = resolve_variant(a);
   RL4CO_REQUIRE(variant >= 0);  // explicit variant requested that cannot serve these planes
   hipStream_t s = rl4co::as_stream(stream);
+  if (variant == RL4CO_VARIANT_MS) return rl4co::launch_decode_ms(a, s);
   if (variant == RL4CO_VARIANT_LDS) {
     return a.env == RL4CO_ENV_TSP ? launch_wide<RL4CO_ENV_TSP, true>(a, s) : launch_wide<RL4CO_ENV_CVRP, true>(a, s);
   }

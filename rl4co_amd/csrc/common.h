@@ -26,6 +26,9 @@ int record_arg_error(const char* what);
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// am_decode_ms.hip: multistart decode on the matrix cores (dispatched from rl4co_am_decode)
+int launch_decode_ms(const rl4co_am_decode_args& a, hipStream_t stream);
+
 // Wave-wide (64-lane) butterfly partner fetch WITHOUT the LDS crossbar: ds_bpermute (what
 // __shfl_xor compiles to) costs an LDS round trip (~100+ cycles) per step and the decode kernels
 // run dependent chains of them; DPP modifiers and the gfx950 permlane swaps are plain VALU ops.

@@ -16,13 +16,15 @@ from .cache import FoldedCache
 
 MODE_IDS = {"greedy": _lib.DECODE_GREEDY, "sampling": _lib.DECODE_SAMPLE, "evaluate": _lib.DECODE_EVALUATE}
 ENV_IDS = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP}
-VARIANT_IDS = {"auto": _lib.VARIANT_AUTO, "stream": _lib.VARIANT_STREAM, "lds": _lib.VARIANT_LDS, "wide": _lib.VARIANT_WIDE}
+VARIANT_IDS = {"auto": _lib.VARIANT_AUTO, "stream": _lib.VARIANT_STREAM, "lds": _lib.VARIANT_LDS, "wide": _lib.VARIANT_WIDE, "ms": _lib.VARIANT_MS}
 
 
 def decode_row_groups(num_nodes: int, cache_dtype: torch.dtype, max_steps: int, variant: str = "auto",
-                      num_trajectories: int = 1 << 20) -> int:
+                      num_trajectories: int = 1 << 20, num_instances: int | None = None) -> int:
+    """Row groups of the specified-order contract of the variant that would run (0 = the multistart
+    MFMA variant, which has none)."""
     dt = _lib.DT_BF16 if cache_dtype == torch.bfloat16 else _lib.DT_F32
-    return _lib.decode_row_groups(num_nodes, dt, max_steps, VARIANT_IDS[variant], num_trajectories)
+    return _lib.decode_row_groups(num_nodes, dt, max_steps, VARIANT_IDS[variant], num_trajectories, num_instances)
 
 
 def _ptr(t: Tensor | None) -> int | None:

@@ -52,10 +52,12 @@ def _cvrp_check(actions, demand, vehicle_capacity, err):
 def _am_decode(cache, state, **kw):
     from rl4co_amd import _lib
 
-    variant = {"auto": 0, "stream": 1, "lds": 2, "wide": 3}[kw.pop("variant", "auto")]
+    variant = {"auto": 0, "stream": 1, "lds": 2, "wide": 3, "ms": 4}[kw.pop("variant", "auto")]
     dt = _lib.DT_BF16 if cache.kvl.dtype == torch.bfloat16 else _lib.DT_F32
-    groups = _lib.decode_row_groups(cache.num_nodes, dt, kw["max_steps"], variant,
-                                    state["action_mask"].shape[0])  # host-only query
+    b = state["action_mask"].shape[0]
+    groups = _lib.decode_row_groups(cache.num_nodes, dt, kw["max_steps"], variant, b, cache.num_instances)  # host-only
+    if groups == 0:  # the MFMA multistart variant has no specified-order oracle: mirror the streaming one
+        groups = _lib.decode_row_groups(cache.num_nodes, dt, kw["max_steps"], 1, b, cache.num_instances)
     c_oracle.am_decode(cache, state, row_groups=groups, **kw)
 
 

@@ -1,0 +1,135 @@
+"""GPU: multistart decode on the matrix cores (csrc/am_decode_ms.hip) vs the streaming kernel.
+
+Floating-point variant => tolerance test (tolerances stated here). The MS kernel rounds the query
+and the glimpse to bf16 for the MFMAs, so it cannot be bit-identical to the fp32 specified order;
+it must (a) produce valid tours, (b) assign each chosen action a log-prob that the streaming kernel,
+EVALUATING the same trajectory on the same bf16 planes, reproduces within 0.05 per step and 2 %
+over the whole trajectory, (c) be greedy under that reference scoring up to the same noise
+(chosen log-prob >= max log-prob - 0.1), (d) reach the same tour quality (mean within 1 %).
+"""
+import pytest
+import torch
+
+from oracle import reference_torch as R
+from tests.helpers import GoldenCase, fold_cache, max_horizon, rollout_state
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def K():
+    from rl4co_amd import kernels
+
+    return kernels
+
+
+def _rollout(K, g, td0, cache, starts, variant, mode="greedy", forced=None, want_all=False, **kw):
+    st = rollout_state(g.env_name, td0, device="cuda", num_starts=starts)
+    b, n = st["action_mask"].shape
+    tmax = max_horizon(g.env_name, n)
+    actions = torch.zeros(b, tmax, dtype=torch.int64, device="cuda")
+    logps = torch.zeros(b, tmax, device="cuda")
+    n_steps = torch.zeros(b, dtype=torch.int32, device="cuda")
+    err = K.new_error_word("cuda")
+    t0 = 0
+    if starts > 0:
+        first = g.env.select_start_nodes(td0, starts).cuda()
+        actions[:, 0] = first
+        if g.env_name == "tsp":
+            K.tsp_step(first, st["action_mask"], st["first_node"], st["current_node"], st["i"], st["done"])
+        else:
+            K.cvrp_step(first, st["demand"], st["used_capacity"], st["vehicle_capacity"], st["visited"],
+                        st["current_node"], st["action_mask"], st["done"])
+        t0 = 1
+    all_lp = torch.zeros(b, tmax, n, device="cuda") if want_all else None
+    if forced is not None:
+        f = torch.zeros(b, tmax, dtype=torch.int64, device="cuda")
+        f[:, : forced.shape[1]] = forced
+        forced = f
+    K.am_decode(cache, st, mode=mode, max_steps=tmax - t0, t0=t0, actions=actions, logps=logps, err=err,
+                n_steps=n_steps, variant=variant, forced_actions=forced, all_logps=all_lp, **kw)
+    torch.cuda.synchronize()
+    t = t0 + int(n_steps.max())
+    return actions[:, :t], logps[:, :t], st, int(err.item()), all_lp
+
+
+CASES = [("pomo_tsp20_b16_msgreedy", 20), ("pomo_tsp50_b8_mssampling", 8), ("pomo_tsp50_b8_mssampling", 40),
+         ("pomo_cvrp20_b16_msgreedy", 20), ("c4_pomo_tsp100_b32_s8_sampling", 8), ("tsp100_b64_greedy", 5),
+         ("cvrp100_b64_greedy", 6)]
+
+
+@pytest.mark.parametrize("name,starts", CASES)
+def test_ms_greedy_consistent_with_streaming_kernel(K, name, starts):
+    g = GoldenCase(name)
+    td0 = g.reset()
+    with torch.inference_mode():
+        h, _ = g.policy.encoder(td0)
+    cache = fold_cache(g.policy, g.env_name, h, torch.bfloat16, device="cuda")
+    a_ms, l_ms, st_ms, err, _ = _rollout(K, g, td0, cache, starts, "ms")
+    assert err == 0 and bool(st_ms["done"].all())
+    # validity
+    rows = R.batchify({k: v for k, v in td0.items() if torch.is_tensor(v)}, starts)
+    g.env.check_solution_validity(rows, a_ms.cpu())
+    # the streaming kernel evaluates the same trajectories on the same planes
+    a_ev, l_ev, st_ev, err2, all_lp = _rollout(K, g, td0, cache, starts, "stream", mode="evaluate",
+                                               forced=a_ms[:, 1:].contiguous() if starts else a_ms, want_all=True)
+    assert err2 == 0 and torch.equal(a_ev, a_ms)
+    t = a_ms.shape[1]
+    assert float((l_ms - l_ev).abs().max()) <= 0.05, float((l_ms - l_ev).abs().max())
+    ll_ms, ll_ev = l_ms.sum(1), l_ev.sum(1)
+    assert float(((ll_ms - ll_ev).abs() / ll_ev.abs().clamp_min(1.0)).max()) <= 2e-2
+    # greedy under the reference scoring, up to the bf16 noise
+    best = all_lp[:, :t].max(-1).values
+    decided = slice(1, t) if starts else slice(0, t)
+    assert float((best[:, decided] - l_ev[:, decided]).max()) <= 0.1
+    # same tour quality as the streaming kernel's own greedy rollout
+    a_st, _, _, err3, _ = _rollout(K, g, td0, cache, starts, "stream")
+    locs = td0["locs"].cuda()
+    r_ms = K.tour_length(locs, a_ms.contiguous(), prepend_depot=(g.env_name == "cvrp"), negate=True)
+    r_st = K.tour_length(locs, a_st.contiguous(), prepend_depot=(g.env_name == "cvrp"), negate=True)
+    assert abs(float(r_ms.mean() - r_st.mean())) <= 1e-2 * abs(float(r_st.mean()))
+    same = (a_ms.shape == a_st.shape) and float((a_ms == a_st).all(1).float().mean())
+    print(f"{name} S={starts}: {same:.1%} trajectories identical to the streaming kernel, "
+          f"max |dlogp| {float((l_ms - l_ev).abs().max()):.4f}")
+
+
+@pytest.mark.parametrize("name,starts", [("pomo_tsp50_b8_mssampling", 8), ("pomo_cvrp20_b16_msgreedy", 6)])
+def test_ms_sampling_valid_and_consistent(K, name, starts):
+    g = GoldenCase(name)
+    td0 = g.reset()
+    with torch.inference_mode():
+        h, _ = g.policy.encoder(td0)
+    cache = fold_cache(g.policy, g.env_name, h, torch.bfloat16, device="cuda")
+    a1, l1, st1, err, _ = _rollout(K, g, td0, cache, starts, "ms", mode="sampling", philox_seed=11)
+    a2, _, _, _, _ = _rollout(K, g, td0, cache, starts, "ms", mode="sampling", philox_seed=11)
+    a3, _, _, _, _ = _rollout(K, g, td0, cache, starts, "ms", mode="sampling", philox_seed=12)
+    assert err == 0 and torch.equal(a1, a2) and not torch.equal(a1, a3)
+    rows = R.batchify({k: v for k, v in td0.items() if torch.is_tensor(v)}, starts)
+    g.env.check_solution_validity(rows, a1.cpu())
+    _, l_ev, _, err2, _ = _rollout(K, g, td0, cache, starts, "stream", mode="evaluate", forced=a1[:, 1:].contiguous())
+    assert err2 == 0 and float((l1 - l_ev).abs().max()) <= 0.05
+    # sampled trajectories are not the greedy ones and their likelihood is lower on average
+    ag, lg, _, _, _ = _rollout(K, g, td0, cache, starts, "ms")
+    assert float(l1.sum(1).mean()) < float(lg.sum(1).mean())
+
+
+def test_ms_is_auto_selected_for_multistart_and_policy_runs(K):
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    assert K.decode_row_groups(100, torch.bfloat16, 99, "auto", 4096 * 8, 4096) == 0      # MS
+    assert K.decode_row_groups(100, torch.bfloat16, 100, "auto", 4096, 4096) == 4          # single start: stream
+    assert K.decode_row_groups(100, torch.float32, 99, "auto", 4096 * 8, 4096) == 2        # fp32 planes: stream
+    torch.manual_seed(0)
+    kw = dict(num_encoder_layers=6, normalization="instance", use_graph_context=False, cache_dtype=torch.bfloat16,
+              encoder_autocast=torch.bfloat16)
+    pol = AttentionModelPolicy("tsp", **kw).cuda().eval()
+    env = get_env("tsp", generator_params=dict(num_loc=50, device="cuda"), device="cuda")
+    td = env.reset(batch_size=[64])
+    with torch.inference_mode():
+        out = pol(td, env, phase="test", decode_type="multistart_greedy", num_starts=50)  # check_solution on
+    assert out["actions"].shape == (64 * 50, 50)
+    best = out["reward"].view(50, 64).max(0).values
+    with torch.inference_mode():
+        single = pol(td, env, phase="test", decode_type="greedy")
+    assert float(best.mean()) >= float(single["reward"].mean()) - 1e-3
