@@ -72,7 +72,7 @@ def test_ms_greedy_consistent_with_streaming_kernel(K, name, starts):
     g.env.check_solution_validity(rows, a_ms.cpu())
     # the streaming kernel evaluates the same trajectories on the same planes
     a_ev, l_ev, st_ev, err2, all_lp = _rollout(K, g, td0, cache, starts, "stream", mode="evaluate",
-                                               forced=a_ms[:, 1:].contiguous() if starts else a_ms, want_all=True)
+                                               forced=a_ms, want_all=True)  # same column layout as `actions`
     assert err2 == 0 and torch.equal(a_ev, a_ms)
     t = a_ms.shape[1]
     assert float((l_ms - l_ev).abs().max()) <= 0.05, float((l_ms - l_ev).abs().max())
@@ -106,7 +106,7 @@ def test_ms_sampling_valid_and_consistent(K, name, starts):
     assert err == 0 and torch.equal(a1, a2) and not torch.equal(a1, a3)
     rows = R.batchify({k: v for k, v in td0.items() if torch.is_tensor(v)}, starts)
     g.env.check_solution_validity(rows, a1.cpu())
-    _, l_ev, _, err2, _ = _rollout(K, g, td0, cache, starts, "stream", mode="evaluate", forced=a1[:, 1:].contiguous())
+    _, l_ev, _, err2, _ = _rollout(K, g, td0, cache, starts, "stream", mode="evaluate", forced=a1)
     assert err2 == 0 and float((l1 - l_ev).abs().max()) <= 0.05
     # sampled trajectories are not the greedy ones and their likelihood is lower on average
     ag, lg, _, _, _ = _rollout(K, g, td0, cache, starts, "ms")
