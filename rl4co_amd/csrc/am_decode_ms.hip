@@ -61,6 +61,25 @@ __device__ inline bf16x8 lds_frag(const __bf16* base, int row, int col) {
 }
 __device__ inline float bf16_bits_to_float(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
 
+// 128-bit node sets as four words that are only ever indexed with compile-time constants: a
+// runtime index would send the array to scratch memory (a global-memory round trip per access)
+struct Bits128 {
+  uint32_t w[4];
+  __device__ inline uint32_t word(int k) const {  // k runtime, wave-uniform or not
+    return k == 0 ? w[0] : (k == 1 ? w[1] : (k == 2 ? w[2] : w[3]));
+  }
+  __device__ inline bool test(int j) const { return (word(j >> 5) >> (j & 31)) & 1u; }
+  __device__ inline void set(int j, bool on) {
+    const uint32_t bit = 1u << (j & 31);
+    const int k = j >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t m = (i == k) ? bit : 0u;
+      w[i] = on ? (w[i] | m) : (w[i] & ~m);
+    }
+  }
+};
+
 struct Xchg {  // per (wave, trajectory) pieces of the log-softmax / selection over nodes
   float zmax, se, best_key, best_z;
   int best_idx;
@@ -129,14 +148,18 @@ __global__ void __launch_bounds__(kThreads) am_decode_ms_kernel(const rl4co_am_d
     const int sl = s0 + l31;
     const bool lane_ok = sl < S;
     const int r = (lane_ok ? sl : s0) * a.B_inst + inst;
-    uint32_t mw[4] = {0, 0, 0, 0}, vw[4] = {0, 0, 0, 0};
-    {
-      const uint8_t* gm = a.action_mask + (int64_t)r * N;
-      for (int j = 0; j < N; ++j) mw[j >> 5] |= (lane_ok && gm[j]) ? (1u << (j & 31)) : 0u;
-      if (ENV == RL4CO_ENV_CVRP) {
-        const uint8_t* gv = a.visited + (int64_t)r * N;
-        for (int j = 0; j < N; ++j) vw[j >> 5] |= (lane_ok && gv[j]) ? (1u << (j & 31)) : 0u;
+    Bits128 mw, vw;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      uint32_t m = 0, v = 0;
+      const uint8_t* gm = a.action_mask + (int64_t)r * N + 32 * kt;
+      const uint8_t* gv = (ENV == RL4CO_ENV_CVRP) ? a.visited + (int64_t)r * N + 32 * kt : nullptr;
+      for (int b = 0; b < 32 && 32 * kt + b < N; ++b) {
+        m |= (lane_ok && gm[b]) ? (1u << b) : 0u;
+        if (ENV == RL4CO_ENV_CVRP) v |= (lane_ok && gv[b]) ? (1u << b) : 0u;
       }
+      mw.w[kt] = m;
+      vw.w[kt] = v;
     }
     int cur = (int)a.current_node[r];
     int first = (ENV == RL4CO_ENV_TSP) ? (int)a.first_node[r] : 0;
@@ -199,7 +222,7 @@ __global__ void __launch_bounds__(kThreads) am_decode_ms_kernel(const rl4co_am_d
 #pragma unroll
           for (int kt = 0; kt < 4; ++kt) {
             sc[kt] = mfma(lds_frag(kgs, 32 * kt + l31, 16 * h + 8 * hi), qf, zero16());
-            const uint32_t mbits = (a.mask_inner ? mw[kt] : nv[kt]) >> (4 * hi);
+            const uint32_t mbits = (a.mask_inner ? mw.w[kt] : nv[kt]) >> (4 * hi);
 #pragma unroll
             for (int rr = 0; rr < 16; ++rr) {
               const bool f = (mbits >> ((rr & 3) + 8 * (rr >> 2))) & 1u;
@@ -248,7 +271,7 @@ __global__ void __launch_bounds__(kThreads) am_decode_ms_kernel(const rl4co_am_d
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks)
           u = mfma(lds_frag(kls, 32 * w + l31, 16 * ks + 8 * hi), lds_frag(hs, l31, 16 * ks + 8 * hi), u);
-        const uint32_t lbits = (a.mask_logits ? mw[w] : nv[w]) >> (4 * hi);
+        const uint32_t lbits = (a.mask_logits ? mw.word(w) : (w == 0 ? nv[0] : (w == 1 ? nv[1] : (w == 2 ? nv[2] : nv[3])))) >> (4 * hi);
         const int forced = (a.mode == RL4CO_DECODE_EVALUATE && lane_ok)
                                ? (int)a.forced_actions[(int64_t)r * a.out_stride + tcol] : -1;
         float z[16];
@@ -364,7 +387,7 @@ __global__ void __launch_bounds__(kThreads) am_decode_ms_kernel(const rl4co_am_d
           }
         }
         if (!done) {
-          if (!((mw[act >> 5] >> (act & 31)) & 1u)) errbits |= RL4CO_EBIT_INFEASIBLE;
+          if (!mw.test(act)) errbits |= RL4CO_EBIT_INFEASIBLE;
           if (!(logp > -1000.0f)) errbits |= RL4CO_EBIT_NEG_INF_LOGP;
           if (w == 0 && hi == 0) {
             a.actions[(int64_t)r * a.out_stride + tcol] = act;
@@ -376,20 +399,20 @@ __global__ void __launch_bounds__(kThreads) am_decode_ms_kernel(const rl4co_am_d
             if (step_i == 0) first = act;
             cur = act;
             step_i += 1;
-            mw[act >> 5] &= ~(1u << (act & 31));
-            done = (mw[0] | mw[1] | mw[2] | mw[3]) == 0u;
+            mw.set(act, false);
+            done = (mw.w[0] | mw.w[1] | mw.w[2] | mw.w[3]) == 0u;
           } else {
             const int di = min(max(act - 1, 0), N - 2);
             used = (used + dems[di + 1]) * (act != 0 ? 1.0f : 0.0f);
             cur = act;
-            vw[act >> 5] |= 1u << (act & 31);
+            vw.set(act, true);
             bool all_visited = true, any_feasible = false;
+#pragma unroll
             for (int kt = 0; kt < 4; ++kt) {
               uint32_t mbits = 0;
-              for (int b = 0; b < 32; ++b) {
+              for (int b = 0; b < 32 && 32 * kt + b < N; ++b) {
                 const int j = 32 * kt + b;
-                if (j >= N) break;
-                const bool v = (vw[kt] >> b) & 1u;
+                const bool v = (vw.w[kt] >> b) & 1u;
                 all_visited &= v;
                 if (j >= 1) {
                   const bool masked = v || (dems[j] + used > thr);
@@ -397,9 +420,9 @@ __global__ void __launch_bounds__(kThreads) am_decode_ms_kernel(const rl4co_am_d
                   any_feasible |= !masked;
                 }
               }
-              mw[kt] = mbits;
+              mw.w[kt] = mbits;
             }
-            if (!((cur == 0) && any_feasible)) mw[0] |= 1u;
+            if (!((cur == 0) && any_feasible)) mw.w[0] |= 1u;
             done = all_visited;
           }
         }
@@ -413,10 +436,10 @@ __global__ void __launch_bounds__(kThreads) am_decode_ms_kernel(const rl4co_am_d
     // ---- write back the column tile's final state -------------------------------------------------------
     if (w == 0 && hi == 0 && lane_ok) {
       uint8_t* gm = a.action_mask + (int64_t)r * N;
-      for (int j = 0; j < N; ++j) gm[j] = (mw[j >> 5] >> (j & 31)) & 1u;
+      for (int j = 0; j < N; ++j) gm[j] = mw.test(j) ? 1 : 0;
       if (ENV == RL4CO_ENV_CVRP) {
         uint8_t* gv = a.visited + (int64_t)r * N;
-        for (int j = 0; j < N; ++j) gv[j] = (vw[j >> 5] >> (j & 31)) & 1u;
+        for (int j = 0; j < N; ++j) gv[j] = vw.test(j) ? 1 : 0;
         a.used_capacity[r] = used;
       } else {
         a.first_node[r] = first;
