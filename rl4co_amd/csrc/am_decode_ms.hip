@@ -136,6 +136,8 @@ __global__ void __launch_bounds__(kThreads) am_decode_ms_kernel(const rl4co_am_d
   const float* ctxc = a.ctx_cur + (int64_t)inst * N * kD;
   const float* ctxf = (ENV == RL4CO_ENV_TSP) ? a.ctx_first + (int64_t)inst * N * kD : nullptr;
   const bool single = a.max_steps == 1;
+  const float inv_temp = 1.0f / a.temperature;
+  const float clip_over_temp = a.tanh_clipping * inv_temp;
   uint32_t errbits = 0;
   uint32_t nv[4];  // nodes that exist (j < N), per 32-node word
 #pragma unroll
@@ -249,7 +251,7 @@ __global__ void __launch_bounds__(kThreads) am_decode_ms_kernel(const rl4co_am_d
             acc = mfma(lds_frag(vts, 32 * w + l31, 32 * kt + 8 * hi), frag_from_acc(sc[kt], 0), acc);
             acc = mfma(lds_frag(vts, 32 * w + l31, 32 * kt + 16 + 8 * hi), frag_from_acc(sc[kt], 1), acc);
           }
-          const float inv = (l > 0.0f) ? 1.0f / l : 0.0f;
+          const float inv = (l > 0.0f) ? __builtin_amdgcn_rcpf(l) : 0.0f;
 #pragma unroll
           for (int rr = 0; rr < 8; ++rr) o[8 * hh + rr] = acc[8 * hh + rr] * inv;
         }
@@ -278,14 +280,16 @@ __global__ void __launch_bounds__(kThreads) am_decode_ms_kernel(const rl4co_am_d
         float zmax = kNegInf;
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
-          const float uu = u[rr] / kSqrtD;
+          // this variant is tolerance-tested, not bit-exact: hardware reciprocals instead of IEEE division
+          const float uu = u[rr] * (1.0f / kSqrtD);
           if (uu != uu && lane_ok && !done) errbits |= RL4CO_EBIT_NAN_LOGIT;
           float zz = uu;
           if (a.tanh_clipping > 0.0f) {
             const float ex = __expf(-2.0f * fabsf(uu));
-            zz = copysignf((1.0f - ex) / (1.0f + ex), uu) * a.tanh_clipping;
+            zz = copysignf((1.0f - ex) * __builtin_amdgcn_rcpf(1.0f + ex), uu) * clip_over_temp;
+          } else {
+            zz = zz * inv_temp;
           }
-          if (a.temperature != 1.0f) zz = zz / a.temperature;
           const bool f = (lbits >> ((rr & 3) + 8 * (rr >> 2))) & 1u;
           z[rr] = f ? zz : kNegInf;
           zmax = fmaxf(zmax, z[rr]);
