@@ -285,6 +285,9 @@ int rl4co_am_encoder_max_nodes(void);
  * others are written. One workgroup per instance, its B / B_inst trajectories (s-major rows)
  * replayed in turn. N <= rl4co_am_teacher_max_nodes().
  * -------------------------------------------------------------------------- */
+#define RL4CO_TEACHER_AUTO 0   /* MMA when the planes are bf16 and T fits its step tables, else REPLAY */
+#define RL4CO_TEACHER_REPLAY 1 /* am_teacher.hip: fp32 step-by-step replay, planes in registers        */
+#define RL4CO_TEACHER_MMA 2    /* am_teacher_mma.hip: 16-step blocks on v_mfma_f32_16x16x16_bf16       */
 typedef struct rl4co_am_teacher_args {
   int32_t env;
   int32_t B;            /* trajectories                                             */
@@ -297,7 +300,7 @@ typedef struct rl4co_am_teacher_args {
   float tanh_clipping;
   float temperature;
   int32_t cache_dtype;  /* dtype of the three planes                                */
-  int32_t _pad0;
+  int32_t variant;      /* RL4CO_TEACHER_AUTO / _REPLAY / _MMA                      */
   const void* glimpse_key;
   const void* glimpse_val;
   const void* logit_key;
@@ -324,6 +327,8 @@ typedef struct rl4co_am_teacher_args {
 
 int rl4co_am_teacher_backward(const rl4co_am_teacher_args* args, void* stream);
 int rl4co_am_teacher_max_nodes(void);
+/* The variant rl4co_am_teacher_backward would run for these arguments (1 or 2), -1 if invalid. */
+int rl4co_am_teacher_variant(const rl4co_am_teacher_args* args);
 
 /* --------------------------------------------------------------------------
  * a19  select_start_nodes        rl4co/utils/ops.py:128-161

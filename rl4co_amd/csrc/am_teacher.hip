@@ -439,13 +439,12 @@ int dispatch_rows(const rl4co_am_teacher_args& a, hipStream_t s) {
 
 extern "C" int rl4co_am_teacher_max_nodes(void) { return 112; }
 
-extern "C" int rl4co_am_teacher_backward(const rl4co_am_teacher_args* args, void* stream) {
-  RL4CO_REQUIRE(args != nullptr);
-  const rl4co_am_teacher_args& a = *args;
+static int validate_teacher(const rl4co_am_teacher_args& a) {
   RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP);
   RL4CO_REQUIRE(a.B > 0 && a.B_inst > 0 && a.B % a.B_inst == 0);
   RL4CO_REQUIRE(a.N >= 2 && a.N <= 112 && a.T >= 1 && a.t0 >= 0 && a.t0 <= 1);
   RL4CO_REQUIRE(a.cache_dtype == RL4CO_DT_F32 || a.cache_dtype == RL4CO_DT_BF16);
+  RL4CO_REQUIRE(a.variant >= RL4CO_TEACHER_AUTO && a.variant <= RL4CO_TEACHER_MMA);
   RL4CO_REQUIRE(a.glimpse_key && a.glimpse_val && a.logit_key && a.ctx_cur && a.actions && a.grad_logp);
   RL4CO_REQUIRE(a.kvl_row_stride >= kD && a.kvl_batch_stride >= (int64_t)a.N * kD);
   RL4CO_REQUIRE(a.temperature > 0.0f);
@@ -456,6 +455,31 @@ extern "C" int rl4co_am_teacher_backward(const rl4co_am_teacher_args* args, void
     RL4CO_REQUIRE(a.w_cap && a.demand && a.vehicle_capacity && a.d_w_cap);
   }
   RL4CO_REQUIRE(a.q_bias == nullptr || a.d_q_bias != nullptr);
+  return RL4CO_OK;
+}
+
+// MMA needs bf16 planes (16-byte aligned rows) and its step tables to hold every action column
+static int resolve_teacher_variant(const rl4co_am_teacher_args& a) {
+  const bool mma_ok = a.cache_dtype == RL4CO_DT_BF16 && a.N <= rl4co::teacher_mma_max_nodes() &&
+                      a.T <= rl4co::teacher_mma_max_steps() && a.kvl_row_stride % 8 == 0 && a.kvl_batch_stride % 8 == 0;
+  if (a.variant == RL4CO_TEACHER_MMA) return mma_ok ? RL4CO_TEACHER_MMA : -1;
+  if (a.variant == RL4CO_TEACHER_REPLAY) return RL4CO_TEACHER_REPLAY;
+  return mma_ok ? RL4CO_TEACHER_MMA : RL4CO_TEACHER_REPLAY;
+}
+
+extern "C" int rl4co_am_teacher_variant(const rl4co_am_teacher_args* args) {
+  if (args == nullptr || validate_teacher(*args) != RL4CO_OK) return -1;
+  return resolve_teacher_variant(*args);
+}
+
+extern "C" int rl4co_am_teacher_backward(const rl4co_am_teacher_args* args, void* stream) {
+  RL4CO_REQUIRE(args != nullptr);
+  const rl4co_am_teacher_args& a = *args;
+  const int st = validate_teacher(a);
+  if (st != RL4CO_OK) return st;
+  const int variant = resolve_teacher_variant(a);
+  RL4CO_REQUIRE(variant > 0);  // RL4CO_TEACHER_MMA requested for planes / sizes it does not support
   hipStream_t s = rl4co::as_stream(stream);
+  if (variant == RL4CO_TEACHER_MMA) return rl4co::launch_teacher_mma(a, s);
   return a.env == RL4CO_ENV_TSP ? dispatch_rows<RL4CO_ENV_TSP>(a, s) : dispatch_rows<RL4CO_ENV_CVRP>(a, s);
 }

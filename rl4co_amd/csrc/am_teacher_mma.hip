@@ -1,0 +1,587 @@
+// am_teacher_mma.hip — teacher-forced backward on the matrix cores.
+//
+// With the actions known, every decode step of a trajectory is known up front
+// (decode_type="evaluate", utils/decoding.py:448-461; the two-phase pattern of rl/ppo/ppo.py:128-170):
+// the T queries, the T feasibility masks and the T upstream gradients can be laid side by side and
+// the per-step GEMVs of am_teacher.hip become small GEMMs with the STEP as the MFMA column:
+//
+//   scores^T[j,t] = Kg_h[j,:] . Q_h^T[:,t]      glimpse O_h^T[d,t] = sum_j V_h^T[d,j] P^T[j,t]
+//   logits^T[j,t] = Kl[j,:] . O^T[:,t]          dO^T[d,t] = sum_j Kl^T[d,j] dU^T[j,t]
+//   dA^T[j,t]     = V_h[j,:] . dO_h^T[:,t]      dQ_h^T[d,t] = sum_j Kg_h^T[d,j] dS^T[j,t]
+//   dKl^T[d,j] += sum_t O^T[d,t] dU[t,j]        dV_h^T[d,j] += sum_t dO_h^T[d,t] A[t,j]
+//   dKg_h^T[d,j] += sum_t Q_h^T[d,t] dS[t,j]
+//
+// One 512-thread workgroup per INSTANCE (8 waves = 8 heads, two waves per SIMD so the VALU of one
+// overlaps the MFMAs of the other); its S multistart trajectories are replayed one after the other
+// in blocks of 16 steps, all products on v_mfma_f32_16x16x16_bf16. In that instruction's
+// accumulator layout a lane owns ONE step (column lane & 15) and four consecutive rows, which is
+// also its B-operand layout: softmax / log-softmax over nodes are in-lane reductions plus two
+// cross-row-group exchanges, and accumulators chain into the next product without a shuffle.
+// The three bf16 planes sit in LDS once, in their natural [node][dim] layout; the products that
+// contract over nodes or over steps read them (and the 16-step staging blocks) through the
+// gfx950 transpose read ds_read_b64_tr_b16, so no transposed copy exists. The gradients of the
+// three planes accumulate in registers over all S x T steps of the instance (84 registers per
+// lane) and are written once — no atomics on the planes; only the context-row scatter
+// (d ctx_cur[cur_t]) uses fp32 L2 atomics, from the one workgroup that owns the instance.
+//
+// Numerics: bf16 MFMA operands (planes, queries, softmax numerators, glimpses, dU, dS), fp32
+// accumulation and fp32 softmax / tanh / log-softmax — the mixed-precision regime the reference
+// trains in (utils/trainer.py:57 precision="16-mixed"). Tested against am_teacher.hip (fp32 replay)
+// and torch autograd by tolerance (tests/test_gpu_teacher.py).
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kD = RL4CO_EMBED_DIM;
+constexpr int kRS = kD + 8;  // LDS row stride (bf16 elements): conflict-free 8-byte row reads
+constexpr int kWaves = 8;
+constexpr int kThreads = 64 * kWaves;
+constexpr int kMaxTiles = 7;  // node tiles of 16: N <= 112
+constexpr int kMaxT = 256;    // action columns the step tables hold
+constexpr float kNegInf = -__builtin_huge_valf();
+constexpr float kSqrtD = 11.3137084989847604f;
+constexpr float kLog2e = 1.44269504088896341f;
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// C[m = 4 g + r][n = lane & 15] += sum_k A[m = lane & 15][k = 4 g + s] * B[k = 4 g + s][n = lane & 15]
+__device__ inline f32x4 mfma16(const bf16x4& a, const bf16x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+__device__ inline f32x4 zero4() { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+__device__ inline bf16x4 lds_b64(const __bf16* p) { return *reinterpret_cast<const bf16x4*>(p); }
+// ds_read_b64_tr_b16: the 16 lanes of a row group address a [4 rows][16 columns] block (lane i:
+// row i / 4, columns 4 (i % 4) ..) and lane c receives column c of it — four consecutive ROWS
+__device__ inline bf16x4 lds_tr(const __bf16* p) {
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+  return __builtin_bit_cast(bf16x4, v);
+}
+__device__ inline bf16x4 to_bf16(const f32x4& v) {
+  bf16x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+  return o;
+}
+// LDS hand-off inside ONE wave
+__device__ inline void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// across the four row groups of a wave (lanes differing in bits 4, 5)
+__device__ inline float rg_sum(float v) { return rl4co::bfly_sum<16, 64>(v); }
+__device__ inline float rg_max(float v) { return rl4co::bfly_max<16, 64>(v); }
+// across the sixteen steps of a row group (lane bits 0..3)
+__device__ inline float step_sum(float v) { return rl4co::bfly_sum<1, 16>(v); }
+
+struct Layout {  // byte offsets into dynamic LDS
+  int kgs, vs, kls, ob, dub, qb, dob, pb, sact, srem, sg, smask, spos, sval, xz, xa, sinfo, total;
+};
+__host__ __device__ inline Layout make_layout(int nt) {
+  Layout L;
+  const int plane = nt * 16 * kRS * 2, blk = 16 * kRS * 2;
+  int o = 0;
+  L.kgs = o; o += plane;
+  L.vs = o; o += plane;
+  L.kls = o; o += plane;
+  L.ob = o; o += blk;
+  L.dub = o; o += blk;
+  L.qb = o; o += blk;
+  L.dob = o; o += blk;
+  L.pb = o; o += kWaves * blk;
+  L.sact = o; o += kMaxT * 4;
+  L.srem = o; o += kMaxT * 4;
+  L.sg = o; o += kMaxT * 4;
+  L.smask = o; o += kMaxT * 16;
+  L.spos = o; o += 128 * 4;
+  L.xz = o; o += kWaves * 16 * 2 * 4;
+  L.xa = o; o += 16 * 4;
+  L.sinfo = o; o += 16;
+  L.sval = o; o += kMaxT;
+  L.total = (o + 15) & ~15;
+  return L;
+}
+
+template <int ENV, int NT>
+__global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co_am_teacher_args a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int w = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
+  const int h = w;  // attention stages: wave = head; logits stage: wave = node tile
+  const int inst = blockIdx.x;
+  const int N = a.N, T = a.T, S = a.B / a.B_inst;
+  const Layout L = make_layout(NT);  // NT node tiles of 16 (template): rows N .. 16 NT - 1 are zero
+  __bf16* kgs = reinterpret_cast<__bf16*>(smem + L.kgs);
+  __bf16* vs = reinterpret_cast<__bf16*>(smem + L.vs);
+  __bf16* kls = reinterpret_cast<__bf16*>(smem + L.kls);
+  __bf16* ob = reinterpret_cast<__bf16*>(smem + L.ob);    // [16 steps][kRS] glimpses of the block
+  __bf16* dub = reinterpret_cast<__bf16*>(smem + L.dub);  // [16 steps][kRS] d logits (pre-clip, raw)
+  __bf16* qb = reinterpret_cast<__bf16*>(smem + L.qb);    // [16 steps][kRS] queries (x 0.25 log2 e)
+  __bf16* dob = reinterpret_cast<__bf16*>(smem + L.dob);  // [16 steps][kRS] d glimpse / softmax denominator
+  __bf16* pbw = reinterpret_cast<__bf16*>(smem + L.pb) + w * 16 * kRS;  // this wave's [16 steps][kRS] P, then dS
+  int* sact = reinterpret_cast<int*>(smem + L.sact);
+  float* srem = reinterpret_cast<float*>(smem + L.srem);
+  float* sg = reinterpret_cast<float*>(smem + L.sg);
+  uint32_t* smask = reinterpret_cast<uint32_t*>(smem + L.smask);
+  int* spos = reinterpret_cast<int*>(smem + L.spos);
+  uint8_t* sval = smem + L.sval;
+  float* xz = reinterpret_cast<float*>(smem + L.xz);
+  float* xa = reinterpret_cast<float*>(smem + L.xa);
+  int* sinfo = reinterpret_cast<int*>(smem + L.sinfo);
+
+  // per-lane element offsets: natural operand (row = lane & 15, 4 consecutive columns at 4 g) and
+  // transpose read (row 4 g + (lane & 15) / 4, columns 4 (lane & 3))
+  const int nao = tl * kRS + 4 * g;
+  const int tro = (4 * g + (tl >> 2)) * kRS + 4 * (tl & 3);
+  const int dcol = 16 * h + 4 * g;  // the four dims of head h this lane owns in accumulator layout
+
+  // ---- planes HBM -> LDS once per instance (rows >= N zero: they are contracted over) ------------
+  {
+    const uint16_t* gk = static_cast<const uint16_t*>(a.glimpse_key) + (int64_t)inst * a.kvl_batch_stride;
+    const uint16_t* gv = static_cast<const uint16_t*>(a.glimpse_val) + (int64_t)inst * a.kvl_batch_stride;
+    const uint16_t* gl = static_cast<const uint16_t*>(a.logit_key) + (int64_t)inst * a.kvl_batch_stride;
+    for (int c = tid; c < NT * 16 * 16; c += kThreads) {
+      const int row = c >> 4, col = (c & 15) * 8;
+      uint4 k4 = make_uint4(0, 0, 0, 0), v4 = k4, l4 = k4;
+      if (row < N) {
+        k4 = *reinterpret_cast<const uint4*>(gk + (int64_t)row * a.kvl_row_stride + col);
+        v4 = *reinterpret_cast<const uint4*>(gv + (int64_t)row * a.kvl_row_stride + col);
+        l4 = *reinterpret_cast<const uint4*>(gl + (int64_t)row * a.kvl_row_stride + col);
+      }
+      *reinterpret_cast<uint4*>(kgs + row * kRS + col) = k4;
+      *reinterpret_cast<uint4*>(vs + row * kRS + col) = v4;
+      *reinterpret_cast<uint4*>(kls + row * kRS + col) = l4;
+    }
+  }
+  float* dcc = a.d_ctx_cur + (int64_t)inst * N * kD;
+  for (int i = tid; i < N * kD / 4; i += kThreads) reinterpret_cast<float4*>(dcc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  __threadfence();  // the zeros reach L2 before this workgroup's atomics on the same rows
+
+  uint32_t nv[4];  // nodes that exist, per 32-node word
+#pragma unroll
+  for (int k = 0; k < 4; ++k) nv[k] = (N >= 32 * (k + 1)) ? 0xffffffffu : (N > 32 * k ? ((1u << (N - 32 * k)) - 1u) : 0u);
+
+  const float* ctxc = a.ctx_cur + (int64_t)inst * N * kD + dcol;
+  const float* ctxf = (ENV == RL4CO_ENV_TSP) ? a.ctx_first + (int64_t)inst * N * kD + dcol : nullptr;
+  const float* dem = (ENV == RL4CO_ENV_CVRP) ? a.demand + (int64_t)inst * (N - 1) : nullptr;
+  const float cap = (ENV == RL4CO_ENV_CVRP) ? a.vehicle_capacity[inst] : 0.0f;
+  const float thr = cap + 1e-5f;
+  float qb4[4], qx4[4];  // graph context; placeholder query (TSP) or capacity column (CVRP)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    qb4[e] = a.q_bias ? a.q_bias[(int64_t)inst * kD + dcol + e] : 0.0f;
+    qx4[e] = (ENV == RL4CO_ENV_TSP) ? a.q_step0[dcol + e] : a.w_cap[dcol + e];
+  }
+  const float inv_temp = 1.0f / a.temperature;
+  const float clip_over_temp = a.tanh_clipping * inv_temp;
+
+  f32x4 dkg[NT], dvg[NT], dkl[NT];  // [d = 4 g + r of head h][node 16 jt + (lane & 15)]
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+    dkg[jt] = zero4();
+    dvg[jt] = zero4();
+    dkl[jt] = zero4();
+  }
+  float dqb[4] = {0.f, 0.f, 0.f, 0.f}, dqx[4] = {0.f, 0.f, 0.f, 0.f};
+  uint32_t errbits = 0;
+
+  for (int s = 0; s < S; ++s) {
+    const int r = s * a.B_inst + inst;
+    const int64_t* act = a.actions + (int64_t)r * T;
+    const float* gl = a.grad_logp + (int64_t)r * T;
+    __syncthreads();  // the previous trajectory's tables are no longer read
+
+    // ---- step tables of this trajectory (the environment replayed in closed form) -------------------
+    // sact[t]: action; spos[j]: first column that visits node j (tsp/env.py:60-86, cvrp/env.py:66-96)
+    for (int t = tid; t < kMaxT; t += kThreads) {
+      int at = 0;
+      if (t < T) {
+        at = (int)act[t];
+        if (at < 0 || at >= N) {
+          errbits |= RL4CO_EBIT_INFEASIBLE;
+          at = 0;
+        }
+      }
+      sact[t] = at;
+    }
+    for (int j = tid; j < 128; j += kThreads) spos[j] = 0x7fffffff;
+    __syncthreads();
+    for (int t = tid; t < T; t += kThreads) atomicMin(&spos[sact[t]], t);
+    __syncthreads();
+    if (tid == 0) {
+      int t_end = T;
+      if (ENV == RL4CO_ENV_CVRP) {  // done once every node (depot included) has been visited (cvrp/env.py:80-83)
+        int last = 0;
+        for (int j = 0; j < N; ++j) last = max(last, spos[j]);
+        if (last != 0x7fffffff) t_end = min(T, last + 1);
+      }
+      sinfo[0] = t_end;
+    }
+    if (ENV == RL4CO_ENV_CVRP) {
+      // used capacity BEFORE column t: the loads since the last depot visit, summed in visiting
+      // order from zero — the same fp32 sequence as used = (used + demand) * (action != 0)
+      for (int t = tid; t < kMaxT; t += kThreads) {
+        int u = min(t, T) - 1;
+        while (u >= 0 && sact[u] != 0) --u;
+        float used = 0.0f;
+        for (int v = u + 1; v < min(t, T); ++v) used = used + dem[min(max(sact[v] - 1, 0), N - 2)];
+        srem[t] = used;
+      }
+    }
+    __syncthreads();
+    const int t_end = sinfo[0];
+    // feasibility words: thread (t, k) builds word k of column t
+    for (int idx = tid; idx < kMaxT * 4; idx += kThreads) {
+      const int t = idx >> 2, k = idx & 3;
+      const bool live = t < t_end;
+      uint32_t word = 0;
+      if (ENV == RL4CO_ENV_TSP) {
+        for (int b = 0; b < 32; ++b) {
+          const int j = 32 * k + b;
+          if (j < N && spos[j] >= t) word |= 1u << b;
+        }
+      } else {
+        const float used = srem[t];
+        for (int b = 0; b < 32; ++b) {
+          const int j = 32 * k + b;
+          if (j >= 1 && j < N && spos[j] >= t && !(dem[j - 1] + used > thr)) word |= 1u << b;
+        }
+        // depot: infeasible only while standing on it with a customer still feasible (cvrp/env.py:126-136)
+        uint32_t any = word;
+        any |= rl4co::bfly_i<1>((int)any);
+        any |= rl4co::bfly_i<2>((int)any);
+        const int cur = (t == 0) ? 0 : sact[t - 1];
+        if (k == 0 && !((cur == 0) && any != 0u)) word |= 1u;
+      }
+      smask[idx] = live ? word : (k == 0 ? 1u : 0u);  // dead columns: a finite dummy (node 0 only), gradient 0
+    }
+    for (int t = tid; t < kMaxT; t += kThreads) {
+      const bool valid = t >= a.t0 && t < t_end;
+      sval[t] = valid ? 1 : 0;
+      sg[t] = valid ? gl[t] : 0.0f;
+    }
+    __syncthreads();
+    if (ENV == RL4CO_ENV_CVRP) {  // srem: used -> remaining capacity (context.py:147-149), own entries only
+      for (int t = tid; t < kMaxT; t += kThreads) srem[t] = cap - srem[t];
+      __syncthreads();
+    }
+
+    const int first = sact[0];
+    float f4[4] = {0.f, 0.f, 0.f, 0.f}, dqf[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ENV == RL4CO_ENV_TSP) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) f4[e] = ctxf[(int64_t)first * kD + e];
+    }
+    const int ntb = (t_end + 15) >> 4;
+
+    for (int tb = 0; tb < ntb; ++tb) {
+      const int t = 16 * tb + tl;  // this lane's column (same in the four row groups)
+      const int cur = (t == 0) ? 0 : sact[t - 1];
+      const int at = sact[t];
+      const float gt = sg[t];
+      const bool valid = sval[t] != 0;
+      const uint4 mw4 = *reinterpret_cast<const uint4*>(smask + 4 * t);
+      const uint32_t mw[4] = {mw4.x, mw4.y, mw4.z, mw4.w};
+      const float rem = (ENV == RL4CO_ENV_CVRP) ? srem[t] : 0.0f;
+
+      // ---- 0. query of head h for the block's 16 steps (context.py:105-149, decoder.py:135-136) --
+      bf16x4 qf;
+      {
+        const float4 c4 = *reinterpret_cast<const float4*>(ctxc + (int64_t)cur * kD);
+        const float c[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float q;
+          if (ENV == RL4CO_ENV_TSP) q = (t == 0) ? qx4[e] + qb4[e] : (f4[e] + c[e]) + qb4[e];
+          else q = fmaf(qx4[e], rem, c[e]) + qb4[e];
+          qf[e] = (__bf16)(q * (0.25f * kLog2e));
+        }
+        *reinterpret_cast<bf16x4*>(qb + tl * kRS + dcol) = qf;
+      }
+
+      // ---- 1. scores^T and softmax numerators over nodes (attention.py:300-314) -----------------------
+      bf16x4 pf[NT];
+      float inv_l;
+      {
+        f32x4 sc[NT];
+        float m = kNegInf;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+          {
+            sc[jt] = mfma16(lds_b64(kgs + 16 * jt * kRS + 16 * h + nao), qf, zero4());
+            const uint32_t bits = (a.mask_inner ? mw[jt >> 1] : nv[jt >> 1]) >> (16 * (jt & 1) + 4 * g);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              sc[jt][rr] = ((bits >> rr) & 1u) ? sc[jt][rr] : kNegInf;
+              m = fmaxf(m, sc[jt][rr]);
+            }
+          }
+        }
+        m = rg_max(m);
+        float l = 0.0f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+          {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              const float p = __builtin_amdgcn_exp2f(sc[jt][rr] - m);
+              l += p;
+              pf[jt][rr] = (__bf16)p;
+            }
+            *reinterpret_cast<bf16x4*>(pbw + tl * kRS + 16 * jt + 4 * g) = pf[jt];
+          }
+        }
+        l = rg_sum(l);
+        inv_l = __builtin_amdgcn_rcpf(l);
+      }
+
+      // ---- 2. glimpse O_h^T = V_h^T P^T --------------------------------------------------------------
+      {
+        f32x4 o = zero4();
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+          o = mfma16(lds_tr(vs + 16 * jt * kRS + 16 * h + tro), pf[jt], o);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) o[rr] *= inv_l;
+        *reinterpret_cast<bf16x4*>(ob + tl * kRS + dcol) = to_bf16(o);
+      }
+      __syncthreads();  // B1: all heads' glimpses
+
+      // ---- 3. logits of node tile w, clip, log-softmax pieces (attention.py:291-293, decoding.py:169-188)
+      float z[4], dzdu[4];
+      {
+        float zmax = kNegInf;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          z[rr] = kNegInf;
+          dzdu[rr] = 0.0f;
+        }
+        if (w < NT) {
+          f32x4 u = zero4();
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks)
+            u = mfma16(lds_b64(kls + 16 * w * kRS + 16 * ks + nao), lds_b64(ob + 16 * ks + nao), u);
+          // w is a runtime value: select, never index (an indexed register array goes to scratch)
+          const uint32_t wsel = a.mask_logits ? (w < 2 ? mw4.x : (w < 4 ? mw4.y : (w < 6 ? mw4.z : mw4.w)))
+                                              : (w < 2 ? nv[0] : (w < 4 ? nv[1] : (w < 6 ? nv[2] : nv[3])));
+          const uint32_t bits = wsel >> (16 * (w & 1) + 4 * g);
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const float uu = u[rr] * (1.0f / kSqrtD);
+            if (uu != uu && valid) errbits |= RL4CO_EBIT_NAN_LOGIT;
+            float zz, dd;
+            if (a.tanh_clipping > 0.0f) {
+              const float ex = __expf(-2.0f * fabsf(uu));
+              const float th = copysignf((1.0f - ex) * __builtin_amdgcn_rcpf(1.0f + ex), uu);
+              zz = th * clip_over_temp;
+              dd = clip_over_temp * (1.0f - th * th);
+            } else {
+              zz = uu * inv_temp;
+              dd = inv_temp;
+            }
+            const bool f = (bits >> rr) & 1u;
+            z[rr] = f ? zz : kNegInf;
+            dzdu[rr] = dd;
+            zmax = fmaxf(zmax, z[rr]);
+            if (16 * w + 4 * g + rr == at) xa[tl] = z[rr];
+          }
+        }
+        zmax = rg_max(zmax);
+        const float zs = (zmax > kNegInf) ? zmax : 0.0f;
+        float se = 0.0f;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) se += __expf(z[rr] - zs);
+        se = rg_sum(se);
+        if (g == 0) {
+          xz[(w * 16 + tl) * 2] = zmax;
+          xz[(w * 16 + tl) * 2 + 1] = (zmax > kNegInf) ? se : 0.0f;
+        }
+      }
+      __syncthreads();  // B2: log-sum-exp pieces of all node tiles
+      {
+        float zm = kNegInf;
+#pragma unroll
+        for (int ww = 0; ww < kWaves; ++ww) zm = fmaxf(zm, xz[(ww * 16 + tl) * 2]);
+        float tot = 0.0f;
+#pragma unroll
+        for (int ww = 0; ww < kWaves; ++ww) {
+          const float zw = xz[(ww * 16 + tl) * 2];
+          tot += (zw > kNegInf) ? xz[(ww * 16 + tl) * 2 + 1] * __expf(zw - zm) : 0.0f;
+        }
+        const float lse = zm + __logf(tot);
+        if (w == 0 && g == 0 && valid) {  // log p(a_t) (decoding.py:381) and the reference's assertions
+          const float lp = xa[tl] - lse;
+          const int ak = at >> 5;  // static indexing only: a runtime index would spill the words to scratch
+          const uint32_t aw = ak == 0 ? mw4.x : (ak == 1 ? mw4.y : (ak == 2 ? mw4.z : mw4.w));
+          const bool feasible = (aw >> (at & 31)) & 1u;
+          if (!feasible) errbits |= RL4CO_EBIT_INFEASIBLE;
+          if (!(lp > -1000.0f)) errbits |= RL4CO_EBIT_NEG_INF_LOGP;
+          if (a.logp_out) a.logp_out[(int64_t)r * T + t] = lp;
+        }
+        if (w < NT) {
+          f32x4 du;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const float prob = __expf(z[rr] - lse);  // 0 for masked nodes
+            const float dz = gt * (((16 * w + 4 * g + rr) == at ? 1.0f : 0.0f) - prob);
+            du[rr] = (z[rr] > kNegInf) ? dz * dzdu[rr] * (1.0f / kSqrtD) : 0.0f;
+          }
+          *reinterpret_cast<bf16x4*>(dub + tl * kRS + 16 * w + 4 * g) = to_bf16(du);
+        }
+      }
+      __syncthreads();  // B3: d logits of all node tiles
+
+      // ---- 4. d glimpse of head h, d logit keys ----------------------------------------------------------
+      bf16x4 dof;
+      {
+        f32x4 dO = zero4();
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+          dO = mfma16(lds_tr(kls + 16 * jt * kRS + 16 * h + tro), lds_b64(dub + 16 * jt + nao), dO);
+        const bf16x4 ot = lds_tr(ob + 16 * h + tro);  // O_h^T[d][steps 4 g ..]
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt)
+          dkl[jt] = mfma16(ot, lds_tr(dub + 16 * jt + tro), dkl[jt]);
+        dof = to_bf16(dO);
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) dO[rr] *= inv_l;
+        *reinterpret_cast<bf16x4*>(dob + tl * kRS + dcol) = to_bf16(dO);
+      }
+
+      // ---- 5. softmax backward of head h; d values, d keys, d query ------------------------------------
+      // dA^T is produced twice (7 cheap MFMAs) instead of being held in 28 registers: pass 1 reduces
+      // sum_j a_j dA_j, pass 2 turns each tile into dS, stages it and feeds d query at once
+      f32x4 dq = zero4();
+      {
+        float ada = 0.0f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+          {
+            const f32x4 da = mfma16(lds_b64(vs + 16 * jt * kRS + 16 * h + nao), dof, zero4());
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) ada = fmaf((float)pf[jt][rr], da[rr], ada);
+          }
+        }
+        ada = rg_sum(ada) * inv_l;
+        wave_lds_sync();  // this wave's P block, dO and Q columns are in LDS
+        {
+          const bf16x4 dt = lds_tr(dob + 16 * h + tro);  // (dO_h / l)^T[d][steps]
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt)
+            dvg[jt] = mfma16(dt, lds_tr(pbw + 16 * jt + tro), dvg[jt]);
+        }
+        wave_lds_sync();  // the transpose reads of P are done: the block is reused for dS
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+          {
+            const f32x4 da = mfma16(lds_b64(vs + 16 * jt * kRS + 16 * h + nao), dof, zero4());
+            bf16x4 dsf;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) dsf[rr] = (__bf16)((float)pf[jt][rr] * (da[rr] - ada) * inv_l);
+            *reinterpret_cast<bf16x4*>(pbw + tl * kRS + 16 * jt + 4 * g) = dsf;
+            dq = mfma16(lds_tr(kgs + 16 * jt * kRS + 16 * h + tro), dsf, dq);
+          }
+        }
+        wave_lds_sync();
+        {
+          const bf16x4 qt = lds_tr(qb + 16 * h + tro);  // Q_h^T[d][steps]
+#pragma unroll
+          for (int jt = 0; jt < NT; ++jt)
+            dkg[jt] = mfma16(qt, lds_tr(pbw + 16 * jt + tro), dkg[jt]);
+        }
+      }
+
+      // ---- 6. d query -> context rows, graph context, placeholder / capacity column ---------------------
+      if (valid) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dqr = 0.25f * dq[e];
+          dqb[e] += dqr;
+          if (ENV == RL4CO_ENV_TSP) {
+            if (t == 0) {
+              dqx[e] += dqr;
+            } else {
+              dqf[e] += dqr;
+              unsafeAtomicAdd(dcc + (int64_t)cur * kD + dcol + e, dqr);
+            }
+          } else {
+            dqx[e] = fmaf(dqr, rem, dqx[e]);
+            unsafeAtomicAdd(dcc + (int64_t)cur * kD + dcol + e, dqr);
+          }
+        }
+      }
+      __syncthreads();  // B4: the glimpse / d-logit blocks are rewritten by the next step block
+    }
+
+    // d ctx_first: one row per trajectory (every step after the first reads h[first])
+    if (ENV == RL4CO_ENV_TSP) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = step_sum(dqf[e]);
+        if (tl == 0) unsafeAtomicAdd(a.d_ctx_first + ((int64_t)inst * N + first) * kD + dcol + e, v);
+      }
+    }
+  }
+
+  // ---- the instance's plane gradients: dims 16 h + 4 g .. + 3 of node 16 jt + (lane & 15) -----------
+  {
+    float* dk = a.d_kvl + (int64_t)inst * N * kD;
+    const int64_t plane = (int64_t)a.B_inst * N * kD;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      const int j = 16 * jt + tl;
+      if (j < N) {
+        float* p0 = dk + (int64_t)j * kD + dcol;
+        const float c = 1.0f / kLog2e;  // the staged queries carried log2(e)
+        *reinterpret_cast<float4*>(p0) = make_float4(dkg[jt][0] * c, dkg[jt][1] * c, dkg[jt][2] * c, dkg[jt][3] * c);
+        *reinterpret_cast<float4*>(p0 + plane) = make_float4(dvg[jt][0], dvg[jt][1], dvg[jt][2], dvg[jt][3]);
+        *reinterpret_cast<float4*>(p0 + 2 * plane) = make_float4(dkl[jt][0], dkl[jt][1], dkl[jt][2], dkl[jt][3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float vb = step_sum(dqb[e]), vx = step_sum(dqx[e]);
+    if (tl == 0) {
+      if (a.d_q_bias) a.d_q_bias[(int64_t)inst * kD + dcol + e] = vb;
+      unsafeAtomicAdd((ENV == RL4CO_ENV_TSP ? a.d_q_step0 : a.d_w_cap) + dcol + e, vx);
+    }
+  }
+  if (errbits) atomicOr(a.err, (int)errbits);
+}
+
+}  // namespace
+
+namespace rl4co {
+
+int teacher_mma_max_nodes() { return 16 * kMaxTiles; }
+int teacher_mma_max_steps() { return kMaxT; }
+
+template <int ENV, int NT>
+static int launch_tiles(const rl4co_am_teacher_args& a, hipStream_t stream) {
+  const Layout L = make_layout(NT);
+  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_teacher_mma_kernel<ENV, NT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+  hipLaunchKernelGGL((am_teacher_mma_kernel<ENV, NT>), dim3(a.B_inst), dim3(kThreads), L.total, stream, a);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
+template <int ENV>
+static int dispatch_tiles(const rl4co_am_teacher_args& a, hipStream_t stream) {
+  const int nt = (a.N + 15) >> 4;
+  if (nt <= 2) return launch_tiles<ENV, 2>(a, stream);
+  if (nt <= 4) return launch_tiles<ENV, 4>(a, stream);
+  return launch_tiles<ENV, kMaxTiles>(a, stream);
+}
+
+int launch_teacher_mma(const rl4co_am_teacher_args& a, hipStream_t stream) {
+  return a.env == RL4CO_ENV_TSP ? dispatch_tiles<RL4CO_ENV_TSP>(a, stream) : dispatch_tiles<RL4CO_ENV_CVRP>(a, stream);
+}
+
+}  // namespace rl4co

@@ -29,6 +29,11 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 // am_decode_ms.hip: multistart decode on the matrix cores (dispatched from rl4co_am_decode)
 int launch_decode_ms(const rl4co_am_decode_args& a, hipStream_t stream);
 
+// am_teacher_mma.hip: teacher-forced backward on the matrix cores (dispatched from rl4co_am_teacher_backward)
+int launch_teacher_mma(const rl4co_am_teacher_args& a, hipStream_t stream);
+int teacher_mma_max_nodes();
+int teacher_mma_max_steps();
+
 // Wave-wide (64-lane) butterfly partner fetch WITHOUT the LDS crossbar: ds_bpermute (what
 // __shfl_xor compiles to) costs an LDS round trip (~100+ cycles) per step and the decode kernels
 // run dependent chains of them; DPP modifiers and the gfx950 permlane swaps are plain VALU ops.

@@ -267,7 +267,7 @@ class AttentionModelPolicy(nn.Module):
                  train_decode_type: str = "sampling", val_decode_type: str = "greedy",
                  test_decode_type: str = "greedy", cache_dtype: torch.dtype = torch.float32,
                  encoder_autocast: torch.dtype | None = None, fused_encoder: bool = True,
-                 fused_backward: bool = True, **unused_kwargs):
+                 fused_backward: bool = True, teacher_variant: str = "auto", **unused_kwargs):
         super().__init__()
         if isinstance(env_name, RL4COEnvBase):
             env_name = env_name.name
@@ -292,6 +292,7 @@ class AttentionModelPolicy(nn.Module):
         # training: gradient of the log-likelihood w.r.t. the folded cache from the HIP backward
         # kernel (csrc/am_teacher.hip) instead of a dense [B,T,N] torch re-evaluation
         self.fused_backward = fused_backward
+        self.teacher_variant = teacher_variant  # "auto" | "replay" | "mma" (teacher.run_backward)
         self._packed = None
         self._philox_calls = 0
         self.last_instance_steps = 0
@@ -494,7 +495,7 @@ class AttentionModelPolicy(nn.Module):
             from . import teacher
 
             meta = dict(t0=t0, mask_inner=self.decoder.mask_inner, mask_logits=mask_logits,
-                        tanh_clipping=tanh_clipping, temperature=temperature)
+                        tanh_clipping=tanh_clipping, temperature=temperature, teacher_variant=self.teacher_variant)
             if self.env_name == "cvrp":
                 meta.update(demand=td["demand"], vehicle_capacity=td["vehicle_capacity"])
             step_logps = teacher.teacher_forced_logps(self.env_name, cache_g, cache, out_actions, logps, meta)

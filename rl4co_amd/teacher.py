@@ -26,7 +26,7 @@ class AmTeacherArgs(C.Structure):
     _fields_ = [
         ("env", _i32), ("B", _i32), ("B_inst", _i32), ("N", _i32), ("T", _i32), ("t0", _i32),
         ("mask_inner", _i32), ("mask_logits", _i32), ("tanh_clipping", _f32), ("temperature", _f32),
-        ("cache_dtype", _i32), ("_pad0", _i32),
+        ("cache_dtype", _i32), ("variant", _i32),
         ("glimpse_key", _vp), ("glimpse_val", _vp), ("logit_key", _vp),
         ("kvl_row_stride", _i64), ("kvl_batch_stride", _i64),
         ("ctx_first", _vp), ("ctx_cur", _vp), ("q_bias", _vp), ("q_step0", _vp), ("w_cap", _vp),
@@ -36,8 +36,64 @@ class AmTeacherArgs(C.Structure):
     ]
 
 
+VARIANT_IDS = {"auto": 0, "replay": 1, "mma": 2}
+
+
 def max_nodes() -> int:
     return _lib.lib().rl4co_am_teacher_max_nodes()
+
+
+def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: dict, variant: str = "auto",
+                 want_logp: bool = False) -> dict:
+    """One launch of ``rl4co_am_teacher_backward``: dL/d(folded cache) for L = sum grad_logp * log p.
+
+    ``variant``: "replay" (``csrc/am_teacher.hip``, fp32 step-by-step), "mma"
+    (``csrc/am_teacher_mma.hip``, 16-step blocks on the matrix cores, bf16 planes) or "auto".
+    Returns the gradient tensors, the variant that ran and (``want_logp``) the recomputed log-probs.
+    """
+    b, t = actions.shape
+    b_inst, n = cache.num_instances, cache.num_nodes
+    dev = actions.device
+    tsp = cache.env_name == "tsp"
+    f32 = dict(dtype=torch.float32, device=dev)
+    d_kvl = torch.empty((3, b_inst, n, EMBED_DIM), **f32)
+    d_ctx_cur = torch.empty((b_inst, n, EMBED_DIM), **f32)
+    d_ctx_first = torch.zeros((b_inst, n, EMBED_DIM), **f32) if tsp else None
+    d_q_bias = torch.empty((b_inst, EMBED_DIM), **f32) if cache.q_bias is not None else None
+    d_extra = torch.zeros((EMBED_DIM,), **f32)
+    logp = torch.zeros((b, t), **f32) if want_logp else None
+    err = torch.zeros(1, dtype=torch.int32, device=dev)
+    a = AmTeacherArgs()
+    a.env = _lib.ENV_TSP if tsp else _lib.ENV_CVRP
+    a.B, a.B_inst, a.N, a.T, a.t0 = b, b_inst, n, t, int(meta["t0"])
+    a.mask_inner, a.mask_logits = int(meta["mask_inner"]), int(meta["mask_logits"])
+    a.tanh_clipping, a.temperature = float(meta["tanh_clipping"]), float(meta["temperature"])
+    a.cache_dtype = _lib.DT_BF16 if cache.kvl.dtype == torch.bfloat16 else _lib.DT_F32
+    a.variant = VARIANT_IDS[variant]
+    a.glimpse_key, a.glimpse_val, a.logit_key = (cache.plane(i).data_ptr() for i in range(3))
+    a.kvl_row_stride, a.kvl_batch_stride = cache.row_stride, cache.batch_stride
+    ptr = lambda x: None if x is None else x.data_ptr()  # noqa: E731
+    a.ctx_first, a.ctx_cur, a.q_bias = ptr(cache.ctx_first), ptr(cache.ctx_cur), ptr(cache.q_bias)
+    a.q_step0, a.w_cap = ptr(cache.q_step0), ptr(cache.w_cap)
+    acts = actions.contiguous()
+    g = grad_logp.contiguous().float()
+    a.actions, a.grad_logp = acts.data_ptr(), g.data_ptr()
+    if not tsp:
+        demand = meta["demand"].contiguous()
+        vcap = meta["vehicle_capacity"].reshape(-1).contiguous()
+        a.demand, a.vehicle_capacity = demand.data_ptr(), vcap.data_ptr()
+    a.d_kvl, a.d_ctx_cur, a.d_ctx_first, a.d_q_bias = ptr(d_kvl), ptr(d_ctx_cur), ptr(d_ctx_first), ptr(d_q_bias)
+    if tsp:
+        a.d_q_step0 = d_extra.data_ptr()
+    else:
+        a.d_w_cap = d_extra.data_ptr()
+    a.logp_out = ptr(logp)
+    a.err = err.data_ptr()
+    ran = _lib.lib().rl4co_am_teacher_variant(C.byref(a))
+    st = _lib.lib().rl4co_am_teacher_backward(C.byref(a), torch.cuda.current_stream().cuda_stream)
+    _lib.check(st, "rl4co_am_teacher_backward")
+    return {"d_kvl": d_kvl, "d_ctx_first": d_ctx_first, "d_ctx_cur": d_ctx_cur, "d_q_bias": d_q_bias,
+            "d_extra": d_extra, "logp": logp, "err": err, "variant": {1: "replay", 2: "mma"}.get(ran, "invalid")}
 
 
 def build_cache_autograd(env_name: str, h: Tensor, decoder) -> dict[str, Tensor]:
@@ -77,47 +133,10 @@ class TeacherForcedLogLik(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_logp):
-        cache, actions, meta = ctx.cache, ctx.actions, ctx.meta
-        b, t = actions.shape
-        b_inst, n = cache.num_instances, cache.num_nodes
-        dev = actions.device
-        tsp = cache.env_name == "tsp"
-        f32 = dict(dtype=torch.float32, device=dev)
-        d_kvl = torch.empty((3, b_inst, n, EMBED_DIM), **f32)
-        d_ctx_cur = torch.empty((b_inst, n, EMBED_DIM), **f32)
-        d_ctx_first = torch.zeros((b_inst, n, EMBED_DIM), **f32) if tsp else None
-        d_q_bias = torch.empty((b_inst, EMBED_DIM), **f32) if cache.q_bias is not None else None
-        d_extra = torch.zeros((EMBED_DIM,), **f32)
-        err = torch.zeros(1, dtype=torch.int32, device=dev)
-        a = AmTeacherArgs()
-        a.env = _lib.ENV_TSP if tsp else _lib.ENV_CVRP
-        a.B, a.B_inst, a.N, a.T, a.t0 = b, b_inst, n, t, int(meta["t0"])
-        a.mask_inner, a.mask_logits = int(meta["mask_inner"]), int(meta["mask_logits"])
-        a.tanh_clipping, a.temperature = float(meta["tanh_clipping"]), float(meta["temperature"])
-        a.cache_dtype = _lib.DT_BF16 if cache.kvl.dtype == torch.bfloat16 else _lib.DT_F32
-        a.glimpse_key, a.glimpse_val, a.logit_key = (cache.plane(i).data_ptr() for i in range(3))
-        a.kvl_row_stride, a.kvl_batch_stride = cache.row_stride, cache.batch_stride
-        ptr = lambda x: None if x is None else x.data_ptr()  # noqa: E731
-        a.ctx_first, a.ctx_cur, a.q_bias = ptr(cache.ctx_first), ptr(cache.ctx_cur), ptr(cache.q_bias)
-        a.q_step0, a.w_cap = ptr(cache.q_step0), ptr(cache.w_cap)
-        acts = actions.contiguous()
-        g = grad_logp.contiguous().float()
-        a.actions, a.grad_logp = acts.data_ptr(), g.data_ptr()
-        if not tsp:
-            demand = meta["demand"].contiguous()
-            vcap = meta["vehicle_capacity"].reshape(-1).contiguous()
-            a.demand, a.vehicle_capacity = demand.data_ptr(), vcap.data_ptr()
-        a.d_kvl, a.d_ctx_cur, a.d_ctx_first, a.d_q_bias = ptr(d_kvl), ptr(d_ctx_cur), ptr(d_ctx_first), ptr(d_q_bias)
-        if tsp:
-            a.d_q_step0 = d_extra.data_ptr()
-        else:
-            a.d_w_cap = d_extra.data_ptr()
-        a.err = err.data_ptr()
-        st = _lib.lib().rl4co_am_teacher_backward(C.byref(a), torch.cuda.current_stream().cuda_stream)
-        _lib.check(st, "rl4co_am_teacher_backward")
+        out = run_backward(ctx.cache, ctx.actions, grad_logp, ctx.meta, variant=ctx.meta.get("teacher_variant", "auto"))
         has_first, has_bias = ctx.has
-        return (d_kvl, d_ctx_first if has_first else None, d_ctx_cur, d_q_bias if has_bias else None, d_extra,
-                None, None, None, None)
+        return (out["d_kvl"], out["d_ctx_first"] if has_first else None, out["d_ctx_cur"],
+                out["d_q_bias"] if has_bias else None, out["d_extra"], None, None, None, None)
 
 
 def teacher_forced_logps(env_name: str, g: dict[str, Tensor], cache: FoldedCache, actions: Tensor, logps: Tensor,

@@ -1,0 +1,124 @@
+"""GPU: teacher-forced backward on the matrix cores (csrc/am_teacher_mma.hip) vs the fp32 replay
+kernel (csrc/am_teacher.hip, itself tested against torch autograd in test_gpu_teacher.py).
+
+Both kernels get the SAME bf16 planes, trajectories and upstream gradients. The MMA variant rounds
+its MFMA operands (queries, softmax numerators, glimpses, d logits, d scores) to bf16 and
+accumulates in fp32, so this is a tolerance test: every gradient tensor within 3e-2 relative
+Frobenius error of the replay kernel's (measured 3e-3 .. 6e-3); recomputed per-step log-probs
+within 0.08 absolute at the worst step (measured 8e-3 TSP, 4e-2 CVRP where the capacity column
+widens the query's range) and 1e-2 on average.
+"""
+import pytest
+import torch
+
+from tests.helpers import GoldenCase
+from tests.test_gpu_teacher import _policy, _td
+
+pytestmark = pytest.mark.gpu
+
+GRAD_RTOL = 3e-2
+LOGP_ATOL = 8e-2
+LOGP_MEAN = 1e-2
+
+
+def _capture(name, starts, cache_dtype=torch.bfloat16, seed=5):
+    """Sampled trajectories + the folded cache the policy would hand to the backward kernel."""
+    from rl4co_amd import teacher
+
+    g = GoldenCase(name)
+    env, td = _td(g)
+    pol = _policy(g, cache_dtype=cache_dtype)
+    kw = dict(num_starts=starts) if starts else {}
+    got = {}
+    orig = teacher.teacher_forced_logps
+
+    def spy(env_name, cache_g, cache, actions, logps, meta):
+        got.update(cache=cache, actions=actions.clone(), logps=logps.detach().clone(), meta=dict(meta))
+        return orig(env_name, cache_g, cache, actions, logps, meta)
+
+    teacher.teacher_forced_logps = spy
+    try:
+        pol(env.reset(td), env, phase="train", decode_type="multistart_sampling" if starts else "sampling", seed=seed, **kw)
+    finally:
+        teacher.teacher_forced_logps = orig
+    assert got, "the policy did not take the kernel backward path"
+    return got
+
+
+def _compare(got, grad_scale=1.0):
+    from rl4co_amd import teacher
+
+    torch.manual_seed(3)
+    grad = torch.randn(got["actions"].shape, device="cuda") * grad_scale
+    ref = teacher.run_backward(got["cache"], got["actions"], grad, got["meta"], variant="replay", want_logp=True)
+    out = teacher.run_backward(got["cache"], got["actions"], grad, got["meta"], variant="mma", want_logp=True)
+    assert ref["variant"] == "replay" and out["variant"] == "mma"
+    assert int(ref["err"]) == 0 and int(out["err"]) == 0
+    worst = {}
+    for k in ("d_kvl", "d_ctx_first", "d_ctx_cur", "d_q_bias", "d_extra"):
+        if ref[k] is None:
+            assert out[k] is None
+            continue
+        if k == "d_kvl":
+            for i, nm in enumerate(("glimpse_key", "glimpse_val", "logit_key")):
+                e = float((out[k][i] - ref[k][i]).norm()) / max(float(ref[k][i].norm()), 1e-30)
+                worst[f"d_{nm}"] = e
+        else:
+            worst[k] = float((out[k] - ref[k]).norm()) / max(float(ref[k].norm()), 1e-30)
+    # decoded columns only: both kernels leave imposed / finished columns untouched (zero here)
+    dlogp = float((out["logp"] - ref["logp"]).abs().max())
+    print({k: f"{v:.2e}" for k, v in worst.items()}, f"max |dlogp| {dlogp:.2e}")
+    for k, e in worst.items():
+        assert e <= GRAD_RTOL, f"{k}: relative error {e:.3e}"
+    assert dlogp <= LOGP_ATOL
+    assert float((out["logp"] - ref["logp"]).abs().mean()) <= LOGP_MEAN
+    # the recomputed log-probs also agree with the rollout kernel's own values
+    dec = ref["logp"] != 0
+    assert float((out["logp"] - got["logps"])[dec].abs().max()) <= LOGP_ATOL
+    return worst
+
+
+@pytest.mark.parametrize("name,starts", [("tsp20_b64_greedy_simple", 0), ("tsp50_b64_greedy", 0),
+                                         ("cvrp20_b128_greedy", 0), ("tsp100_b64_greedy", 0),
+                                         ("cvrp100_b64_greedy", 0), ("pomo_tsp20_b16_msgreedy", 5),
+                                         ("pomo_cvrp20_b16_msgreedy", 4), ("c4_pomo_tsp100_b32_s8_sampling", 8)])
+def test_mma_matches_replay(name, starts):
+    _compare(_capture(name, starts))
+
+
+def test_auto_picks_mma_for_bf16_and_replay_for_f32():
+    from rl4co_amd import teacher
+
+    got = _capture("tsp20_b64_greedy_simple", 0)
+    grad = torch.ones(got["actions"].shape, device="cuda")
+    assert teacher.run_backward(got["cache"], got["actions"], grad, got["meta"])["variant"] == "mma"
+    got32 = _capture("tsp20_b64_greedy_simple", 0, cache_dtype=torch.float32)
+    assert teacher.run_backward(got32["cache"], got32["actions"], grad, got32["meta"])["variant"] == "replay"
+    with pytest.raises(RuntimeError):
+        teacher.run_backward(got32["cache"], got32["actions"], grad, got32["meta"], variant="mma")
+
+
+def test_mma_flags_infeasible_actions():
+    from rl4co_amd import _lib, teacher
+
+    got = _capture("tsp20_b64_greedy_simple", 0)
+    acts = got["actions"].clone()
+    acts[3, 5] = acts[3, 2]  # node visited twice
+    grad = torch.ones(acts.shape, device="cuda")
+    out = teacher.run_backward(got["cache"], acts, grad, got["meta"], variant="mma")
+    assert int(out["err"]) & _lib.EBIT_INFEASIBLE
+
+
+def test_mma_gradient_is_linear_in_upstream_gradient():
+    """d(cache) is linear in grad_logp: scaling the upstream gradient scales every output (bf16 operands
+    carry an 8-bit exponent, so tiny REINFORCE advantages do not underflow)."""
+    from rl4co_amd import teacher
+
+    got = _capture("tsp50_b64_greedy", 0)
+    torch.manual_seed(1)
+    grad = torch.randn(got["actions"].shape, device="cuda")
+    a = teacher.run_backward(got["cache"], got["actions"], grad, got["meta"], variant="mma")
+    b = teacher.run_backward(got["cache"], got["actions"], grad * 2.0 ** -20, got["meta"], variant="mma")
+    for k in ("d_kvl", "d_ctx_first", "d_ctx_cur", "d_q_bias", "d_extra"):
+        if a[k] is not None:
+            torch.testing.assert_close(b[k] * 2.0 ** 20, a[k], rtol=1e-5, atol=1e-6 * float(a[k].abs().max()))

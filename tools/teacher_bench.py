@@ -21,13 +21,13 @@ for k in ("kvl", "ctx_first", "ctx_cur", "q_step0"):
     g[k] = g[k].detach().requires_grad_(True)
 meta = dict(t0=1 if S > 1 else 0, mask_inner=True, mask_logits=True, tanh_clipping=10.0, temperature=1.0)
 logps = torch.zeros(out["actions"].shape, device="cuda")
-lp = teacher.teacher_forced_logps("tsp", g, cache, out["actions"], logps, meta)
-grad = torch.ones_like(lp)
-for it in range(3):
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    torch.autograd.grad(lp, [g["kvl"]], grad, retain_graph=True)
-    e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1)
+grad = torch.ones(out["actions"].shape, device="cuda")
 steps = B * S * (N - (1 if S > 1 else 0))
-print(f"teacher backward B={B} S={S} N={N}: {ms:.2f} ms  ({steps/ms/1e3:.1f} M trajectory-steps/s)")
+for variant in ("replay", "mma"):
+    for it in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        teacher.run_backward(cache, out["actions"], grad, meta, variant=variant)
+        e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    print(f"teacher backward [{variant}] B={B} S={S} N={N}: {ms:.2f} ms  ({steps/ms/1e3:.1f} M trajectory-steps/s)")
