@@ -761,7 +761,7 @@ inline int resolve_variant(const rl4co_am_decode_args& a) {
   if (a.max_steps < 4) return RL4CO_VARIANT_STREAM;
   // measured (TSP-100): 474 M trajectory-steps/s at 32 starts vs 275 M for the streaming kernel, but
   // only 128 M at 8 starts (a column tile holds 32 trajectories): worth it from 16 starts up
-  if (ms_ok && a.B >= 16 * a.B_inst) return RL4CO_VARIANT_MS;
+  if (ms_ok && a.B >= 8 * a.B_inst) return RL4CO_VARIANT_MS;  // measured: 8 starts 464 M vs 276 M trajectory-steps/s
   if (fits && a.B <= 1024) return RL4CO_VARIANT_LDS;
   // one wave per trajectory needs >= ~16 waves per CU to hide its latency chain: with fewer
   // trajectories than that, four waves per trajectory keep the memory pipes busier

@@ -2,25 +2,30 @@
 //
 // With multistart decoding (utils/decoding.py:282-330, zoo/pomo/model.py:88-143) the S
 // trajectories of one instance read the SAME decoder cache and differ only in their query and
-// mask: a decode step for all of them is three small GEMMs — scores = K_g . Q^T, glimpse =
-// V^T . P^T, logits = K_l' . heads^T — with the trajectories as the N dimension. The streaming
+// mask: a decode step for all of them is three small GEMMs — scores^T = K_g . Q^T, glimpse^T =
+// V^T . P^T, logits^T = K_l' . heads^T — with the TRAJECTORY as the MFMA column. The streaming
 // kernel (am_decode.hip) runs one wave per trajectory and is VALU-bound there (275 M
-// trajectory-steps/s at TSP-100 x 4096 x 8); here one workgroup owns one instance, keeps its three
-// bf16 planes resident in LDS for the whole rollout and advances up to 32 trajectories per
-// v_mfma_f32_32x32x16_bf16 column tile.
+// trajectory-steps/s at TSP-100 x 4096 x 8); here one 512-thread workgroup owns one instance,
+// keeps its three bf16 planes (and the fp32 context table when it fits) resident in LDS for the
+// whole rollout and advances 16 trajectories per v_mfma_f32_16x16x16_bf16 column tile.
 //
-// Layout (same accumulator-layout trick as am_encoder.hip): every product is computed "transposed"
-// so that the MFMA column index — lane & 31 — is the TRAJECTORY: the softmax over keys, the
-// log-softmax and the argmax over nodes are then in-lane reductions over accumulator registers
-// plus one cross-half exchange, and each lane carries its trajectory's state (feasibility bit
-// mask, current / first node, load) in registers. Wave w owns heads (2w, 2w+1) for the glimpse and
-// key tile w for the logits; the waves meet three times per step (query rows, glimpse rows,
-// log-sum-exp / argmax pieces).
+// Layout (the one am_teacher_mma.hip uses): in the 16x16x16 accumulator a lane owns ONE
+// trajectory (column lane & 15) and four consecutive rows 4 g .. 4 g + 3, which is also the
+// B-operand layout, so scores chain into the glimpse product without a shuffle; the softmax over
+// keys, the log-softmax and the arg-max over nodes are in-lane reductions plus two cross-row-group
+// exchanges, and every lane carries its trajectory's state (feasibility bit mask, current / first
+// node, load) in registers. Wave h owns head h for the glimpse and node tile h for the logits;
+// the planes stay in their natural [node][dim] layout and the glimpse product reads V through the
+// gfx950 transpose read ds_read_b64_tr_b16. A decode step is a LATENCY chain (dependent MFMAs,
+// cross-lane reductions, two workgroup barriers), not an issue-bound stream, so each wave advances
+// TWO column tiles (32 trajectories) through the same instruction stream — two independent chains
+// the scheduler interleaves, every plane fragment read once for both — and two waves share a SIMD.
 //
-// Numerics: bf16 MFMA inputs (planes, query, glimpse), fp32 accumulation and fp32 softmax / tanh /
-// log-softmax — the reference's mixed-precision regime. This variant is NOT part of the bit-exact
-// contract of am_decode.hip (a bf16 query cannot reproduce the fp32 specified order); it is tested
-// by tolerance against the streaming kernel on the same planes (tests/test_gpu_decode_ms.py).
+// Numerics: bf16 MFMA inputs (planes, query, softmax numerators, glimpse), fp32 accumulation and
+// fp32 softmax / tanh / log-softmax — the reference's mixed-precision regime. This variant is NOT
+// part of the bit-exact contract of am_decode.hip (a bf16 query cannot reproduce the fp32
+// specified order); it is tested by tolerance against the streaming kernel on the same planes
+// (tests/test_gpu_decode_ms.py).
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -29,87 +34,530 @@
 namespace {
 
 constexpr int kD = RL4CO_EMBED_DIM;
-constexpr int kH = RL4CO_NUM_HEADS;
 constexpr int kRS = kD + 8;  // LDS row stride in bf16 elements
-constexpr int kThreads = 256;
+constexpr int kWaves = 8;
+constexpr int kThreads = 64 * kWaves;
+constexpr int kLdsBudget = 160 * 1024;
 constexpr float kNegInf = -__builtin_huge_valf();
 constexpr float kSqrtD = 11.3137084989847604f;
 constexpr float kLog2e = 1.44269504088896341f;
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-__device__ inline f32x16 mfma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+// C[m = 4 g + r][n = lane & 15] += sum_k A[m = lane & 15][k = 4 g + s] * B[k = 4 g + s][n = lane & 15]
+__device__ inline f32x4 mfma16(const bf16x4& a, const bf16x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
-__device__ inline int rowmap(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
-__device__ inline f32x16 zero16() {
-  f32x16 z;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) z[i] = 0.0f;
-  return z;
+__device__ inline f32x4 zero4() { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+__device__ inline bf16x4 lds_b64(const __bf16* p) { return *reinterpret_cast<const bf16x4*>(p); }
+// the 16 lanes of a row group address a [4 rows][16 columns] block (lane i: row i / 4, columns
+// 4 (i % 4) ..); lane c receives column c of it, i.e. four consecutive ROWS
+__device__ inline bf16x4 lds_tr(const __bf16* p) {
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+  return __builtin_bit_cast(bf16x4, v);
 }
-__device__ inline bf16x8 frag_from_acc(const f32x16& c, int u) {
-  bf16x8 f;
-#pragma unroll
-  for (int s = 0; s < 8; ++s) f[s] = (__bf16)c[8 * u + s];
-  return f;
-}
-__device__ inline bf16x8 lds_frag(const __bf16* base, int row, int col) {
-  return *reinterpret_cast<const bf16x8*>(base + row * kRS + col);
-}
-__device__ inline float bf16_bits_to_float(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ inline float rg_sum(float v) { return rl4co::bfly_sum<16, 64>(v); }
+__device__ inline float rg_max(float v) { return rl4co::bfly_max<16, 64>(v); }
 
-// 128-bit node sets as four words that are only ever indexed with compile-time constants: a
-// runtime index would send the array to scratch memory (a global-memory round trip per access)
+// 128-bit node sets as four NAMED words: an array member invites the optimiser to turn a chain
+// of selects into one dynamically indexed load, which sends the whole trajectory state to scratch
+// memory (a global-memory round trip per access)
 struct Bits128 {
-  uint32_t w[4];
-  __device__ inline uint32_t word(int k) const {  // k runtime, wave-uniform or not
-    return k == 0 ? w[0] : (k == 1 ? w[1] : (k == 2 ? w[2] : w[3]));
+  uint32_t w0, w1, w2, w3;
+  __device__ inline uint32_t word(int k) const { return k == 0 ? w0 : (k == 1 ? w1 : (k == 2 ? w2 : w3)); }
+  __device__ inline void put(int k, uint32_t v) {
+    w0 = k == 0 ? v : w0;
+    w1 = k == 1 ? v : w1;
+    w2 = k == 2 ? v : w2;
+    w3 = k == 3 ? v : w3;
   }
+  __device__ inline uint32_t any() const { return w0 | w1 | w2 | w3; }
   __device__ inline bool test(int j) const { return (word(j >> 5) >> (j & 31)) & 1u; }
   __device__ inline void set(int j, bool on) {
     const uint32_t bit = 1u << (j & 31);
     const int k = j >> 5;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const uint32_t m = (i == k) ? bit : 0u;
-      w[i] = on ? (w[i] | m) : (w[i] & ~m);
-    }
+    const uint32_t m0 = k == 0 ? bit : 0u, m1 = k == 1 ? bit : 0u, m2 = k == 2 ? bit : 0u, m3 = k == 3 ? bit : 0u;
+    w0 = on ? (w0 | m0) : (w0 & ~m0);
+    w1 = on ? (w1 | m1) : (w1 & ~m1);
+    w2 = on ? (w2 | m2) : (w2 & ~m2);
+    w3 = on ? (w3 | m3) : (w3 & ~m3);
   }
 };
 
-struct Xchg {  // per (wave, trajectory) pieces of the log-softmax / selection over nodes
+struct __align__(16) Xchg {  // per (node tile, trajectory) pieces of the log-softmax / selection over nodes
   float zmax, se, best_key, best_z;
   int best_idx;
   float forced_z;
+  int pad0, pad1;
 };
 
-template <int ENV>
-__global__ void __launch_bounds__(kThreads) am_decode_ms_kernel(const rl4co_am_decode_args a) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  __bf16* kgs = reinterpret_cast<__bf16*>(smem);  // [128 keys][kRS]   glimpse keys, natural
-  __bf16* vts = kgs + 128 * kRS;                  // [128 dims][kRS]   glimpse values TRANSPOSED, keys in
-                                                  //                   accumulator order inside each 16-group
-  __bf16* kls = vts + 128 * kRS;                  // [128 keys][kRS]   logit keys, natural
-  __bf16* qs = kls + 128 * kRS;                   // [32 traj][kRS]    queries of this step
-  __bf16* hs = qs + 32 * kRS;                     // [32 traj][kRS]    glimpses of this step
-  Xchg* xs = reinterpret_cast<Xchg*>(hs + 32 * kRS);  // [4 waves][32 traj]
-  float* dems = reinterpret_cast<float*>(xs + 4 * 32);  // [128] CVRP demands (index j-1 at j), 0 elsewhere
+struct Layout {  // byte offsets into dynamic LDS
+  int kgs, vs, kls, hs, xs, dems, ctx, total;
+  bool ctx_in_lds;
+};
+__host__ __device__ inline Layout make_layout(int nt, int n) {
+  Layout L;
+  const int plane = nt * 16 * kRS * 2;
+  int o = 0;
+  L.kgs = o; o += plane;
+  L.vs = o; o += plane;
+  L.kls = o; o += plane;
+  L.hs = o; o += 2 * 16 * kRS * 2;                      // two column tiles
+  L.xs = o; o += 2 * kWaves * 16 * (int)sizeof(Xchg);
+  L.dems = o; o += 128 * 4;
+  L.ctx = o;
+  L.ctx_in_lds = o + n * kD * 4 <= kLdsBudget;  // fp32 context rows next to the planes when they fit
+  if (L.ctx_in_lds) o += n * kD * 4;
+  L.total = (o + 15) & ~15;
+  return L;
+}
 
+struct Traj {  // one trajectory's state, replicated in the four row groups and the eight waves
+  Bits128 mw, vw;
+  int cur, first, r;
+  long long step_i;
+  float used;
+  bool done, ok;
+  int nsteps;
+  float f4[4];  // context row of the first node (TSP), fetched when it becomes known
+  // outputs are parked in registers and written every 32 steps: a global store per step would put
+  // its L2 round trip in front of the next barrier 100 times per rollout. Copy 4 w + g of the
+  // trajectory parks the step with t % 32 == 4 w + g.
+  int park_act;
+  float park_logp;
+  int64_t park_col;
+};
+
+struct Sel {  // log-softmax / selection pieces over a set of nodes
+  float zmax, se, key, z, fz;
+  int idx;
+};
+// merge two disjoint node sets; symmetric in its arguments so every replica gets identical bits
+__device__ inline Sel merge(const Sel& p, const Sel& q) {
+  Sel o;
+  o.zmax = fmaxf(p.zmax, q.zmax);
+  const float zs = (o.zmax > kNegInf) ? o.zmax : 0.0f;
+  o.se = p.se * __expf(p.zmax - zs) + q.se * __expf(q.zmax - zs);  // exp(-inf) = 0 for an empty set
+  const bool take_q = (q.idx != 0x7fffffff) & ((p.idx == 0x7fffffff) | (q.key > p.key) | ((q.key == p.key) & (q.idx < p.idx)));
+  o.key = take_q ? q.key : p.key;
+  o.z = take_q ? q.z : p.z;
+  o.idx = take_q ? q.idx : p.idx;
+  o.fz = fmaxf(p.fz, q.fz);
+  return o;
+}
+template <int STEP>
+__device__ inline Sel partner(const Sel& p) {
+  Sel o;
+  o.zmax = rl4co::bfly_f<STEP>(p.zmax);
+  o.se = rl4co::bfly_f<STEP>(p.se);
+  o.key = rl4co::bfly_f<STEP>(p.key);
+  o.z = rl4co::bfly_f<STEP>(p.z);
+  o.fz = rl4co::bfly_f<STEP>(p.fz);
+  o.idx = rl4co::bfly_i<STEP>(p.idx);
+  return o;
+}
+
+struct Shared {
+  const __bf16 *kgs, *vs, *kls;
+  __bf16* hs;   // [CT][16 trajectories][kRS] glimpses of this step
+  Xchg* xs;     // [CT][8 node tiles][16 trajectories]
+  const float *dems, *ctxs;
+  bool ctx_in_lds;
+};
+
+// MODE: 0 greedy, 1 sampling, 2 evaluate (RL4CO_DECODE_*). CT column tiles of 16 trajectories advance together.
+template <int ENV, int NT, int MODE, int CT>
+__device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, const Shared& sh, int inst, int s0,
+                                             uint32_t& errbits) {
   const int tid = threadIdx.x;
-  const int w = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int w = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
+  const int h = w;
+  const int N = a.N, S = a.B / a.B_inst;
+  const int nao = tl * kRS + 4 * g;                         // natural operand: row lane & 15, columns 4 g ..
+  const int tro = (4 * g + (tl >> 2)) * kRS + 4 * (tl & 3);  // transpose read
+  const int dcol = 16 * h + 4 * g;                          // the four dims of head h this lane owns
+  const float cap = (ENV == RL4CO_ENV_CVRP) ? a.vehicle_capacity[inst] : 0.0f;
+  const float thr = cap + 1e-5f;
+  const float* ctxc = a.ctx_cur + (int64_t)inst * N * kD + dcol;
+  const float* ctxf = (ENV == RL4CO_ENV_TSP) ? a.ctx_first + (int64_t)inst * N * kD + dcol : nullptr;
+  float qb4[4], qx4[4];  // graph context; placeholder query (TSP) or capacity column (CVRP)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    qb4[e] = a.q_bias ? a.q_bias[(int64_t)inst * kD + dcol + e] : 0.0f;
+    qx4[e] = (ENV == RL4CO_ENV_TSP) ? a.q_step0[dcol + e] : a.w_cap[dcol + e];
+  }
+  const bool single = a.max_steps == 1;
+  const float inv_temp = 1.0f / a.temperature;
+  const float clip_over_temp = a.tanh_clipping * inv_temp;
+  const bool clip = a.tanh_clipping > 0.0f;
+  Bits128 nv;  // nodes that exist (j < N), per 32-node word
+#pragma unroll
+  for (int k = 0; k < 4; ++k) nv.put(k, (N >= 32 * (k + 1)) ? 0xffffffffu : (N > 32 * k ? ((1u << (N - 32 * k)) - 1u) : 0u));
+  const uint32_t inner_sel = a.mask_inner ? 0xffffffffu : 0u, logit_sel = a.mask_logits ? 0xffffffffu : 0u;
+
+  Traj tj[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    Traj& x = tj[c];
+    const int sl = s0 + 16 * c + tl;
+    x.ok = sl < S;
+    x.r = (x.ok ? sl : s0) * a.B_inst + inst;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      uint32_t m = 0, v = 0;
+      const uint8_t* gm = a.action_mask + (int64_t)x.r * N + 32 * k;
+      const uint8_t* gv = (ENV == RL4CO_ENV_CVRP) ? a.visited + (int64_t)x.r * N + 32 * k : nullptr;
+      for (int b = 0; b < 32 && 32 * k + b < N; ++b) {
+        m |= (x.ok && gm[b]) ? (1u << b) : 0u;
+        if (ENV == RL4CO_ENV_CVRP) v |= (x.ok && gv[b]) ? (1u << b) : 0u;
+      }
+      x.mw.put(k, m);
+      x.vw.put(k, v);
+    }
+    x.cur = (int)a.current_node[x.r];
+    x.first = (ENV == RL4CO_ENV_TSP) ? (int)a.first_node[x.r] : 0;
+    x.step_i = (ENV == RL4CO_ENV_TSP) ? a.step_i[x.r] : 0;
+    x.used = (ENV == RL4CO_ENV_CVRP) ? a.used_capacity[x.r] : 0.0f;
+    x.done = !x.ok || a.done[x.r] != 0;
+    x.nsteps = 0;
+    x.park_act = 0;
+    x.park_logp = 0.0f;
+    x.park_col = -1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x.f4[e] = (ENV == RL4CO_ENV_TSP && x.step_i > 0) ? ctxf[(int64_t)x.first * kD + e] : 0.0f;
+  }
+  int forced[CT];  // evaluate: the given action of the coming step, fetched one step ahead
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+    forced[c] = (MODE == RL4CO_DECODE_EVALUATE && tj[c].ok) ? (int)a.forced_actions[(int64_t)tj[c].r * a.out_stride + a.t0] : -1;
+  __syncthreads();
+
+  int t = 0;
+  for (; t < a.max_steps; ++t) {
+    bool all_done = true;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) all_done &= tj[c].done;
+    if (!single && __all(all_done)) break;  // identical on every wave
+    const int64_t tcol = (int64_t)a.t0 + t;
+
+    // ---- 1. query of head h (folded context + graph context), x 1/sqrt(16) x log2(e) -----------------
+    bf16x4 qf[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      const Traj& x = tj[c];
+      const float4 c4 = sh.ctx_in_lds ? *reinterpret_cast<const float4*>(sh.ctxs + x.cur * kD + dcol)
+                                      : *reinterpret_cast<const float4*>(ctxc + (int64_t)x.cur * kD);
+      const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float q;
+        if (ENV == RL4CO_ENV_TSP) q = (x.step_i < 1) ? qx4[e] + qb4[e] : (x.f4[e] + cc[e]) + qb4[e];
+        else q = fmaf(qx4[e], cap - x.used, cc[e]) + qb4[e];
+        qf[c][e] = (__bf16)(q * (0.25f * kLog2e));
+      }
+    }
+    // ---- 2. glimpse of head h ---------------------------------------------------------------------------
+    {
+      f32x4 sc[CT][NT];
+      float m[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) m[c] = kNegInf;
+#pragma clang loop unroll(full)
+      for (int jt = 0; jt < NT; ++jt) {
+        const bf16x4 kf = lds_b64(sh.kgs + 16 * jt * kRS + 16 * h + nao);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          sc[c][jt] = mfma16(kf, qf[c], zero4());
+          const uint32_t word = (tj[c].mw.word(jt >> 1) & inner_sel) | (nv.word(jt >> 1) & ~inner_sel);
+          const uint32_t bits = word >> (16 * (jt & 1) + 4 * g);
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            sc[c][jt][rr] = ((bits >> rr) & 1u) ? sc[c][jt][rr] : kNegInf;
+            m[c] = fmaxf(m[c], sc[c][jt][rr]);
+          }
+        }
+      }
+      float l[CT];
+      f32x4 o0[CT], o1[CT];  // two accumulators per tile: half the dependent-MFMA chain
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        m[c] = rg_max(m[c]);
+        m[c] = (m[c] > kNegInf) ? m[c] : 0.0f;
+        l[c] = 0.0f;
+        o0[c] = zero4();
+        o1[c] = zero4();
+      }
+#pragma clang loop unroll(full)
+      for (int jt = 0; jt < NT; ++jt) {
+        const bf16x4 vf = lds_tr(sh.vs + 16 * jt * kRS + 16 * h + tro);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          bf16x4 pf;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const float p = __builtin_amdgcn_exp2f(sc[c][jt][rr] - m[c]);
+            l[c] += p;
+            pf[rr] = (__bf16)p;
+          }
+          if (jt & 1) o1[c] = mfma16(vf, pf, o1[c]);
+          else o0[c] = mfma16(vf, pf, o0[c]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const float ls = rg_sum(l[c]);
+        const float inv = (ls > 0.0f) ? __builtin_amdgcn_rcpf(ls) : 0.0f;
+        bf16x4 of;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) of[rr] = (__bf16)((o0[c][rr] + o1[c][rr]) * inv);
+        *reinterpret_cast<bf16x4*>(sh.hs + (16 * c + tl) * kRS + dcol) = of;
+      }
+    }
+    __syncthreads();  // B1
+
+    // ---- 3. logits of node tile w, local log-softmax / selection pieces ------------------------------------
+    if (w < NT) {
+      f32x4 u0[CT], u1[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        u0[c] = zero4();
+        u1[c] = zero4();
+      }
+#pragma clang loop unroll(full)
+      for (int ks = 0; ks < 8; ++ks) {
+        const bf16x4 lf = lds_b64(sh.kls + 16 * w * kRS + 16 * ks + nao);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          const bf16x4 hf = lds_b64(sh.hs + 16 * c * kRS + 16 * ks + nao);
+          if (ks & 1) u1[c] = mfma16(lf, hf, u1[c]);
+          else u0[c] = mfma16(lf, hf, u0[c]);
+        }
+      }
+      const int node0 = 16 * w + 4 * g;  // this lane's four consecutive nodes
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const Traj& x = tj[c];
+        const uint32_t mword = x.mw.word(w >> 1), nword = nv.word(w >> 1);
+        const uint32_t lbits = ((mword & logit_sel) | (nword & ~logit_sel)) >> (16 * (w & 1) + 4 * g);
+        // log(Exp(1) noise) of this lane's four nodes; they share one Philox block (rl4co_math.h)
+        float lnz[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (MODE == RL4CO_DECODE_SAMPLE) {
+          if (a.exp_noise) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              lnz[i] = (node0 + i < N && x.ok) ? __logf(a.exp_noise[((int64_t)t * a.B + x.r) * N + node0 + i]) : 0.0f;
+          } else {
+            float uu4[4];
+            rl4co_uniform4(a.philox_seed, a.philox_offset + (uint64_t)tcol, (uint32_t)x.r, (uint32_t)(node0 >> 2), uu4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lnz[i] = __logf(-__logf(uu4[i]));
+          }
+        }
+        Sel p;
+        float z[4];
+        p.zmax = kNegInf;
+        bool nan_seen = false;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          // this variant is tolerance-tested, not bit-exact: hardware reciprocals instead of IEEE division
+          const float uu = (u0[c][rr] + u1[c][rr]) * (1.0f / kSqrtD);
+          nan_seen |= uu != uu;
+          const float ex = __expf(-2.0f * fabsf(uu));
+          const float th = copysignf((1.0f - ex) * __builtin_amdgcn_rcpf(1.0f + ex), uu) * clip_over_temp;
+          const float zz = clip ? th : uu * inv_temp;
+          z[rr] = ((lbits >> rr) & 1u) ? zz : kNegInf;
+          p.zmax = fmaxf(p.zmax, z[rr]);
+        }
+        if (nan_seen & x.ok & !x.done) errbits |= RL4CO_EBIT_NAN_LOGIT;
+        const float zs = (p.zmax > kNegInf) ? p.zmax : 0.0f;
+        p.se = 0.0f;
+        p.key = kNegInf;
+        p.z = kNegInf;
+        p.fz = kNegInf;
+        p.idx = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int node = node0 + i;
+          const float zz = z[i];
+          p.se += __expf(zz - zs);
+          // multinomial(p,1) == argmax(p / Exp(1)) == argmax(z - log(noise)); greedy: noise = 1
+          const float key = (MODE == RL4CO_DECODE_SAMPLE) ? zz - lnz[i] : zz;
+          const bool take = (zz > kNegInf) & ((key > p.key) | (p.idx == 0x7fffffff));  // ascending nodes: ties keep the lower
+          p.key = take ? key : p.key;
+          p.z = take ? zz : p.z;
+          p.idx = take ? node : p.idx;
+          if (MODE == RL4CO_DECODE_EVALUATE) p.fz = (node == forced[c]) ? zz : p.fz;
+        }
+        // the four row groups hold different nodes of the same trajectory
+        p = merge(p, partner<16>(p));
+        p = merge(p, partner<32>(p));
+        if (g == 0) {
+          Xchg e;
+          e.zmax = p.zmax;
+          e.se = p.se;
+          e.best_key = p.key;
+          e.best_z = p.z;
+          e.best_idx = p.idx;
+          e.forced_z = p.fz;
+          e.pad0 = 0;
+          e.pad1 = 0;
+          sh.xs[(c * kWaves + w) * 16 + tl] = e;
+        }
+      }
+    }
+    __syncthreads();  // B2
+
+    // ---- 4. every lane: finish the selection of its trajectory, transition ------------------------------
+    // row group g folds node tiles g and g + 4, then the row groups meet in two butterfly steps
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      Traj& x = tj[c];
+      Sel p;
+      {
+        const Xchg e = sh.xs[(c * kWaves + g) * 16 + tl];  // g < 4 <= NT... (NT >= 2: tiles 0, 1 exist; others guarded)
+        const bool has = g < NT;
+        p.zmax = has ? e.zmax : kNegInf;
+        p.se = has ? e.se : 0.0f;
+        p.key = has ? e.best_key : kNegInf;
+        p.z = has ? e.best_z : kNegInf;
+        p.idx = has ? e.best_idx : 0x7fffffff;
+        p.fz = has ? e.forced_z : kNegInf;
+      }
+      if (NT > 4) {
+        const Xchg e = sh.xs[(c * kWaves + g + 4) * 16 + tl];
+        const bool has = g + 4 < NT;
+        Sel q;
+        q.zmax = has ? e.zmax : kNegInf;
+        q.se = has ? e.se : 0.0f;
+        q.key = has ? e.best_key : kNegInf;
+        q.z = has ? e.best_z : kNegInf;
+        q.idx = has ? e.best_idx : 0x7fffffff;
+        q.fz = has ? e.forced_z : kNegInf;
+        p = merge(p, q);
+      }
+      p = merge(p, partner<16>(p));
+      p = merge(p, partner<32>(p));
+      const float lse = p.zmax + __logf(p.se);
+      int act;
+      float logp;
+      if (MODE == RL4CO_DECODE_EVALUATE) {
+        logp = p.fz - lse;
+        act = x.ok ? forced[c] : 0;
+        if (act < 0 || act >= N) {
+          if (x.ok && !x.done) errbits |= RL4CO_EBIT_INFEASIBLE;
+          act = 0;
+        }
+      } else {
+        act = (p.idx == 0x7fffffff) ? 0 : p.idx;
+        logp = p.z - lse;
+      }
+      if (!x.done) {
+        if (!x.mw.test(act)) errbits |= RL4CO_EBIT_INFEASIBLE;
+        if (!(logp > -1000.0f)) errbits |= RL4CO_EBIT_NEG_INF_LOGP;
+        if ((t & 31) == 4 * w + g) {
+          x.park_act = act;
+          x.park_logp = logp;
+          x.park_col = tcol;
+        }
+        x.nsteps = t + 1;
+        // environment transition on the lane-resident state
+        if (ENV == RL4CO_ENV_TSP) {
+          if (x.step_i == 0) {
+            x.first = act;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x.f4[e] = ctxf[(int64_t)x.first * kD + e];
+          }
+          x.cur = act;
+          x.step_i += 1;
+          x.mw.set(act, false);
+          x.done = x.mw.any() == 0u;
+        } else {
+          const int di = min(max(act - 1, 0), N - 2);
+          x.used = (x.used + sh.dems[di + 1]) * (act != 0 ? 1.0f : 0.0f);
+          x.cur = act;
+          x.vw.set(act, true);
+          bool all_visited = true, any_feasible = false;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            uint32_t mbits = 0;
+            for (int b = 0; b < 32 && 32 * k + b < N; ++b) {
+              const int j = 32 * k + b;
+              const bool v = (x.vw.word(k) >> b) & 1u;
+              all_visited &= v;
+              if (j >= 1) {
+                const bool masked = v || (sh.dems[j] + x.used > thr);
+                mbits |= masked ? 0u : (1u << b);
+                any_feasible |= !masked;
+              }
+            }
+            x.mw.put(k, mbits);
+          }
+          if (!((x.cur == 0) && any_feasible)) x.mw.w0 |= 1u;
+          x.done = all_visited;
+        }
+      }
+      if (MODE == RL4CO_DECODE_EVALUATE && x.ok && t + 1 < a.max_steps)
+        forced[c] = (int)a.forced_actions[(int64_t)x.r * a.out_stride + tcol + 1];
+      if (((t & 31) == 31 || single) && x.park_col >= 0 && x.ok) {
+        a.actions[(int64_t)x.r * a.out_stride + x.park_col] = x.park_act;
+        a.logps[(int64_t)x.r * a.out_stride + x.park_col] = x.park_logp;
+        x.park_col = -1;
+      }
+    }
+    if (single) break;
+  }
+
+  // ---- parked outputs, final state of the column tiles ------------------------------------------------------
+#pragma unroll
+  for (int c = 0; c < CT; ++c) {
+    Traj& x = tj[c];
+    if (x.park_col >= 0 && x.ok) {
+      a.actions[(int64_t)x.r * a.out_stride + x.park_col] = x.park_act;
+      a.logps[(int64_t)x.r * a.out_stride + x.park_col] = x.park_logp;
+    }
+    if (w == 0 && g == 0 && x.ok) {
+      uint8_t* gm = a.action_mask + (int64_t)x.r * N;
+      for (int j = 0; j < N; ++j) gm[j] = x.mw.test(j) ? 1 : 0;
+      if (ENV == RL4CO_ENV_CVRP) {
+        uint8_t* gv = a.visited + (int64_t)x.r * N;
+        for (int j = 0; j < N; ++j) gv[j] = x.vw.test(j) ? 1 : 0;
+        a.used_capacity[x.r] = x.used;
+      } else {
+        a.first_node[x.r] = x.first;
+        a.step_i[x.r] = x.step_i;
+      }
+      a.current_node[x.r] = x.cur;
+      a.done[x.r] = x.done ? 1 : 0;
+      if (a.n_steps) a.n_steps[x.r] = x.nsteps;
+      if (!single && !x.done) errbits |= RL4CO_EBIT_MAX_STEPS;
+    }
+  }
+  __syncthreads();
+}
+
+template <int ENV, int NT, int MODE>
+__global__ void __launch_bounds__(kThreads, 2) am_decode_ms_kernel(const rl4co_am_decode_args a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int tid = threadIdx.x;
   const int inst = blockIdx.x;
   const int N = a.N;
   const int S = a.B / a.B_inst;
+  const Layout L = make_layout(NT, N);
+  __bf16* kgs = reinterpret_cast<__bf16*>(smem + L.kgs);  // [16 NT nodes][kRS] glimpse keys
+  __bf16* vs = reinterpret_cast<__bf16*>(smem + L.vs);    // glimpse values
+  __bf16* kls = reinterpret_cast<__bf16*>(smem + L.kls);  // logit keys
+  float* dems = reinterpret_cast<float*>(smem + L.dems);  // [128] CVRP demands (index j-1 at j), 0 elsewhere
+  float* ctxs = reinterpret_cast<float*>(smem + L.ctx);   // [N][128] fp32 context rows (if they fit)
 
-  // ---- planes HBM -> LDS, once per instance -----------------------------------------------------
+  // ---- planes (and context rows) HBM -> LDS, once per instance ----------------------------------------
   {
     const uint16_t* gk = static_cast<const uint16_t*>(a.glimpse_key) + (int64_t)inst * a.kvl_batch_stride;
     const uint16_t* gv = static_cast<const uint16_t*>(a.glimpse_val) + (int64_t)inst * a.kvl_batch_stride;
     const uint16_t* gl = static_cast<const uint16_t*>(a.logit_key) + (int64_t)inst * a.kvl_batch_stride;
-    for (int c = tid; c < 128 * 16; c += kThreads) {  // 16-byte chunks: row = c / 16, col = (c % 16) * 8
+    for (int c = tid; c < NT * 16 * 16; c += kThreads) {  // 16-byte chunks: row = c / 16, col = (c % 16) * 8
       const int row = c >> 4, col = (c & 15) * 8;
       uint4 k4 = make_uint4(0, 0, 0, 0), l4 = k4, v4 = k4;
       if (row < N) {
@@ -119,366 +567,64 @@ __global__ void __launch_bounds__(kThreads) am_decode_ms_kernel(const rl4co_am_d
       }
       *reinterpret_cast<uint4*>(kgs + row * kRS + col) = k4;
       *reinterpret_cast<uint4*>(kls + row * kRS + col) = l4;
-      // V^T with the key index stored at the position the accumulator layout expects:
-      // position 16 g + 8 h + s  <-  key 16 g + (s & 3) + 8 (s >> 2) + 4 h
-      const int g = row >> 4, kk = row & 15;  // kk = (s & 3) + 8 (s >> 2) + 4 h
-      const int h = (kk >> 2) & 1, s = (kk & 3) + 4 * (kk >> 3);
-      const int pos = 16 * g + 8 * h + s;
-      const uint16_t* v16 = reinterpret_cast<const uint16_t*>(&v4);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) reinterpret_cast<uint16_t*>(vts)[(col + e) * kRS + pos] = v16[e];
+      *reinterpret_cast<uint4*>(vs + row * kRS + col) = v4;
     }
     for (int j = tid; j < 128; j += kThreads)
       dems[j] = (ENV == RL4CO_ENV_CVRP && j >= 1 && j < N) ? a.demand[(int64_t)inst * (N - 1) + j - 1] : 0.0f;
+    if (L.ctx_in_lds) {
+      const float4* src = reinterpret_cast<const float4*>(a.ctx_cur + (int64_t)inst * N * kD);
+      for (int i = tid; i < N * kD / 4; i += kThreads) reinterpret_cast<float4*>(ctxs)[i] = src[i];
+    }
   }
-  const float cap = (ENV == RL4CO_ENV_CVRP) ? a.vehicle_capacity[inst] : 0.0f;
-  const float thr = cap + 1e-5f;
-  const float* ctxc = a.ctx_cur + (int64_t)inst * N * kD;
-  const float* ctxf = (ENV == RL4CO_ENV_TSP) ? a.ctx_first + (int64_t)inst * N * kD : nullptr;
-  const bool single = a.max_steps == 1;
-  const float inv_temp = 1.0f / a.temperature;
-  const float clip_over_temp = a.tanh_clipping * inv_temp;
+  Shared sh;
+  sh.kgs = kgs;
+  sh.vs = vs;
+  sh.kls = kls;
+  sh.hs = reinterpret_cast<__bf16*>(smem + L.hs);
+  sh.xs = reinterpret_cast<Xchg*>(smem + L.xs);
+  sh.dems = dems;
+  sh.ctxs = ctxs;
+  sh.ctx_in_lds = L.ctx_in_lds;
   uint32_t errbits = 0;
-  uint32_t nv[4];  // nodes that exist (j < N), per 32-node word
-#pragma unroll
-  for (int kt = 0; kt < 4; ++kt)
-    nv[kt] = (N >= 32 * (kt + 1)) ? 0xffffffffu : (N > 32 * kt ? ((1u << (N - 32 * kt)) - 1u) : 0u);
+  int s0 = 0;
+  for (; s0 + 16 < S; s0 += 32) rollout_tiles<ENV, NT, MODE, 2>(a, sh, inst, s0, errbits);  // pairs of column tiles
+  if (s0 < S) rollout_tiles<ENV, NT, MODE, 1>(a, sh, inst, s0, errbits);                    // a last single tile
+  if (errbits) atomicOr(a.err, (int)errbits);
+}
 
-  for (int s0 = 0; s0 < S; s0 += 32) {  // column tiles of 32 trajectories
-    // ---- per-lane trajectory state (lane l31 <-> trajectory s0 + l31; replicated in both halves
-    //      and in all four waves) and the same for the query-building threads (trajectory tid / 8)
-    const int sl = s0 + l31;
-    const bool lane_ok = sl < S;
-    const int r = (lane_ok ? sl : s0) * a.B_inst + inst;
-    Bits128 mw, vw;
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-      uint32_t m = 0, v = 0;
-      const uint8_t* gm = a.action_mask + (int64_t)r * N + 32 * kt;
-      const uint8_t* gv = (ENV == RL4CO_ENV_CVRP) ? a.visited + (int64_t)r * N + 32 * kt : nullptr;
-      for (int b = 0; b < 32 && 32 * kt + b < N; ++b) {
-        m |= (lane_ok && gm[b]) ? (1u << b) : 0u;
-        if (ENV == RL4CO_ENV_CVRP) v |= (lane_ok && gv[b]) ? (1u << b) : 0u;
-      }
-      mw.w[kt] = m;
-      vw.w[kt] = v;
-    }
-    int cur = (int)a.current_node[r];
-    int first = (ENV == RL4CO_ENV_TSP) ? (int)a.first_node[r] : 0;
-    long long step_i = (ENV == RL4CO_ENV_TSP) ? a.step_i[r] : 0;
-    float used = (ENV == RL4CO_ENV_CVRP) ? a.used_capacity[r] : 0.0f;
-    bool done = !lane_ok || a.done[r] != 0;
-    float ent_acc = 0.0f;
-    int nsteps = 0;
-    // query builder: thread tid builds 16 dims of trajectory tid / 8, whose state lives on lane
-    // tid / 8 of this (and every) wave
-    const int qt = tid >> 3, qd0 = (tid & 7) * 16;
-    __syncthreads();
+template <int ENV, int NT, int MODE>
+int launch_mode(const rl4co_am_decode_args& a, hipStream_t stream) {
+  const Layout L = make_layout(NT, a.N);
+  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_decode_ms_kernel<ENV, NT, MODE>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+  hipLaunchKernelGGL((am_decode_ms_kernel<ENV, NT, MODE>), dim3(a.B_inst), dim3(kThreads), L.total, stream, a);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
 
-    int t = 0;
-    for (; t < a.max_steps; ++t) {
-      if (!single && __all(done)) break;  // identical on every wave
-      // ---- 1. query rows (folded context + graph context), pre-scaled by 1/sqrt(16) * log2(e) ------
-      {
-        const int q_cur = __shfl(cur, qt, 64), q_first = __shfl(first, qt, 64);
-        const int q_step = __shfl((int)(step_i > 0 ? 1 : 0), qt, 64);
-        const float q_used = __shfl(used, qt, 64);
-        float qv[16];
-        const float* qb = a.q_bias ? a.q_bias + (int64_t)inst * kD + qd0 : nullptr;
-        if (ENV == RL4CO_ENV_TSP) {
-          if (q_step < 1) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) qv[e] = a.q_step0[qd0 + e] + (qb ? qb[e] : 0.0f);
-          } else {
-            const float* f = ctxf + (int64_t)q_first * kD + qd0;
-            const float* c = ctxc + (int64_t)q_cur * kD + qd0;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) qv[e] = (f[e] + c[e]) + (qb ? qb[e] : 0.0f);
-          }
-        } else {
-          const float rem = cap - q_used;
-          const float* c = ctxc + (int64_t)q_cur * kD + qd0;
-#pragma unroll
-          for (int e = 0; e < 16; ++e) qv[e] = fmaf(a.w_cap[qd0 + e], rem, c[e]) + (qb ? qb[e] : 0.0f);
-        }
-        bf16x8 lo, up;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          lo[e] = (__bf16)(qv[e] * (0.25f * kLog2e));
-          up[e] = (__bf16)(qv[8 + e] * (0.25f * kLog2e));
-        }
-        *reinterpret_cast<bf16x8*>(qs + qt * kRS + qd0) = lo;
-        *reinterpret_cast<bf16x8*>(qs + qt * kRS + qd0 + 8) = up;
-      }
-      __syncthreads();  // B1
+template <int ENV, int NT>
+int launch_tiles(const rl4co_am_decode_args& a, hipStream_t stream) {
+  if (a.mode == RL4CO_DECODE_GREEDY) return launch_mode<ENV, NT, RL4CO_DECODE_GREEDY>(a, stream);
+  if (a.mode == RL4CO_DECODE_SAMPLE) return launch_mode<ENV, NT, RL4CO_DECODE_SAMPLE>(a, stream);
+  return launch_mode<ENV, NT, RL4CO_DECODE_EVALUATE>(a, stream);
+}
 
-      // ---- 2. glimpse of head pair w for all trajectories -----------------------------------------------
-      {
-        f32x16 o = zero16();
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const int h = 2 * w + hh;
-          const bf16x8 qf = lds_frag(qs, l31, 16 * h + 8 * hi);
-          f32x16 sc[4];
-          float m = kNegInf;
-#pragma unroll
-          for (int kt = 0; kt < 4; ++kt) {
-            sc[kt] = mfma(lds_frag(kgs, 32 * kt + l31, 16 * h + 8 * hi), qf, zero16());
-            const uint32_t mbits = (a.mask_inner ? mw.w[kt] : nv[kt]) >> (4 * hi);
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-              const bool f = (mbits >> ((rr & 3) + 8 * (rr >> 2))) & 1u;
-              sc[kt][rr] = f ? sc[kt][rr] : kNegInf;
-              m = fmaxf(m, sc[kt][rr]);
-            }
-          }
-          m = fmaxf(m, rl4co::bfly_f<32>(m));
-          const float ms = (m > kNegInf) ? m : 0.0f;
-          float l = 0.0f;
-#pragma unroll
-          for (int kt = 0; kt < 4; ++kt) {
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr) {
-              const float p = __builtin_amdgcn_exp2f(sc[kt][rr] - ms);
-              sc[kt][rr] = p;
-              l += p;
-            }
-          }
-          l += rl4co::bfly_f<32>(l);
-          f32x16 acc = zero16();
-#pragma unroll
-          for (int kt = 0; kt < 4; ++kt) {
-            acc = mfma(lds_frag(vts, 32 * w + l31, 32 * kt + 8 * hi), frag_from_acc(sc[kt], 0), acc);
-            acc = mfma(lds_frag(vts, 32 * w + l31, 32 * kt + 16 + 8 * hi), frag_from_acc(sc[kt], 1), acc);
-          }
-          const float inv = (l > 0.0f) ? __builtin_amdgcn_rcpf(l) : 0.0f;
-#pragma unroll
-          for (int rr = 0; rr < 8; ++rr) o[8 * hh + rr] = acc[8 * hh + rr] * inv;
-        }
-        __bf16* hrow = hs + l31 * kRS + 32 * w;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          bf16x4 v;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = (__bf16)o[4 * c + i];
-          *reinterpret_cast<bf16x4*>(hrow + 8 * c + 4 * hi) = v;
-        }
-      }
-      __syncthreads();  // B2
-
-      // ---- 3. logits of key tile w for all trajectories, local log-softmax / selection pieces -----
-      const int64_t tcol = (int64_t)a.t0 + t;
-      {
-        f32x16 u = zero16();
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-          u = mfma(lds_frag(kls, 32 * w + l31, 16 * ks + 8 * hi), lds_frag(hs, l31, 16 * ks + 8 * hi), u);
-        const uint32_t lbits = (a.mask_logits ? mw.word(w) : (w == 0 ? nv[0] : (w == 1 ? nv[1] : (w == 2 ? nv[2] : nv[3])))) >> (4 * hi);
-        const int forced = (a.mode == RL4CO_DECODE_EVALUATE && lane_ok)
-                               ? (int)a.forced_actions[(int64_t)r * a.out_stride + tcol] : -1;
-        float z[16];
-        float zmax = kNegInf;
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-          // this variant is tolerance-tested, not bit-exact: hardware reciprocals instead of IEEE division
-          const float uu = u[rr] * (1.0f / kSqrtD);
-          if (uu != uu && lane_ok && !done) errbits |= RL4CO_EBIT_NAN_LOGIT;
-          float zz = uu;
-          if (a.tanh_clipping > 0.0f) {
-            const float ex = __expf(-2.0f * fabsf(uu));
-            zz = copysignf((1.0f - ex) * __builtin_amdgcn_rcpf(1.0f + ex), uu) * clip_over_temp;
-          } else {
-            zz = zz * inv_temp;
-          }
-          const bool f = (lbits >> ((rr & 3) + 8 * (rr >> 2))) & 1u;
-          z[rr] = f ? zz : kNegInf;
-          zmax = fmaxf(zmax, z[rr]);
-        }
-        zmax = fmaxf(zmax, rl4co::bfly_f<32>(zmax));
-        const float zs = (zmax > kNegInf) ? zmax : 0.0f;
-        float se = 0.0f, best = kNegInf, best_z = kNegInf, fz = kNegInf;
-        int bi = 0x7fffffff;
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {  // 4 consecutive nodes 32 w + 8 g4 + 4 hi + (0..3)
-          const int node0 = 32 * w + 8 * g4 + 4 * hi;
-          float nz[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-          if (a.mode == RL4CO_DECODE_SAMPLE) {
-            if (a.exp_noise) {
-#pragma unroll
-              for (int i = 0; i < 4; ++i)
-                nz[i] = (node0 + i < N && lane_ok) ? a.exp_noise[((int64_t)t * a.B + r) * N + node0 + i] : 1.0f;
-            } else {
-#pragma unroll
-              for (int i = 0; i < 4; ++i)
-                nz[i] = rl4co_exp1_noise(a.philox_seed, a.philox_offset + (uint64_t)tcol, (uint32_t)r, (uint32_t)(node0 + i));
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int rr = 4 * g4 + i, node = node0 + i;
-            const float zz = z[rr];
-            se += __expf(zz - zs);
-            // multinomial(p,1) == argmax(p / Exp(1)) == argmax(z - log(noise)); greedy: noise = 1
-            const float key = (a.mode == RL4CO_DECODE_SAMPLE) ? zz - __logf(nz[i]) : zz;
-            if (zz > kNegInf && (key > best || (key == best && node < bi))) {
-              best = key;
-              best_z = zz;
-              bi = node;
-            }
-            if (node == forced) fz = zz;
-          }
-        }
-        se += rl4co::bfly_f<32>(se);
-        {  // combine the two halves (they hold different nodes of the same trajectory)
-          const float ob = rl4co::bfly_f<32>(best), oz = rl4co::bfly_f<32>(best_z);
-          const int oi = rl4co::bfly_i<32>(bi);
-          if (oi != 0x7fffffff && (bi == 0x7fffffff || ob > best || (ob == best && oi < bi))) {
-            best = ob;
-            best_z = oz;
-            bi = oi;
-          }
-          fz = fmaxf(fz, rl4co::bfly_f<32>(fz));
-        }
-        if (hi == 0) {
-          Xchg x;
-          x.zmax = zmax;
-          x.se = (zmax > kNegInf) ? se : 0.0f;
-          x.best_key = best;
-          x.best_z = best_z;
-          x.best_idx = bi;
-          x.forced_z = fz;
-          xs[w * 32 + l31] = x;
-        }
-      }
-      __syncthreads();  // B3
-
-      // ---- 4. every wave / every query thread: finish the selection of its trajectory, transition -----
-      auto select = [&](int traj, int& action, float& logp) {
-        float zmax = kNegInf;
-#pragma unroll
-        for (int ww = 0; ww < 4; ++ww) zmax = fmaxf(zmax, xs[ww * 32 + traj].zmax);
-        float tot = 0.0f, best = kNegInf, bz = kNegInf, fz = kNegInf;
-        int bi = 0x7fffffff;
-#pragma unroll
-        for (int ww = 0; ww < 4; ++ww) {
-          const Xchg x = xs[ww * 32 + traj];
-          tot += (x.zmax > kNegInf) ? x.se * __expf(x.zmax - zmax) : 0.0f;
-          if (x.best_idx != 0x7fffffff && (bi == 0x7fffffff || x.best_key > best || (x.best_key == best && x.best_idx < bi))) {
-            best = x.best_key;
-            bz = x.best_z;
-            bi = x.best_idx;
-          }
-          fz = fmaxf(fz, x.forced_z);
-        }
-        const float lse = zmax + __logf(tot);
-        if (a.mode == RL4CO_DECODE_EVALUATE) {
-          action = -2;  // caller substitutes the forced action
-          logp = fz - lse;
-        } else {
-          action = (bi == 0x7fffffff) ? 0 : bi;
-          logp = bz - lse;
-        }
-      };
-      {
-        int act;
-        float logp;
-        select(l31, act, logp);
-        if (a.mode == RL4CO_DECODE_EVALUATE) {
-          act = lane_ok ? (int)a.forced_actions[(int64_t)r * a.out_stride + tcol] : 0;
-          if (act < 0 || act >= N) {
-            if (lane_ok && !done) errbits |= RL4CO_EBIT_INFEASIBLE;
-            act = 0;
-          }
-        }
-        if (!done) {
-          if (!mw.test(act)) errbits |= RL4CO_EBIT_INFEASIBLE;
-          if (!(logp > -1000.0f)) errbits |= RL4CO_EBIT_NEG_INF_LOGP;
-          if (w == 0 && hi == 0) {
-            a.actions[(int64_t)r * a.out_stride + tcol] = act;
-            a.logps[(int64_t)r * a.out_stride + tcol] = logp;
-          }
-          nsteps = t + 1;
-          // environment transition on the lane-resident state
-          if (ENV == RL4CO_ENV_TSP) {
-            if (step_i == 0) first = act;
-            cur = act;
-            step_i += 1;
-            mw.set(act, false);
-            done = (mw.w[0] | mw.w[1] | mw.w[2] | mw.w[3]) == 0u;
-          } else {
-            const int di = min(max(act - 1, 0), N - 2);
-            used = (used + dems[di + 1]) * (act != 0 ? 1.0f : 0.0f);
-            cur = act;
-            vw.set(act, true);
-            bool all_visited = true, any_feasible = false;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-              uint32_t mbits = 0;
-              for (int b = 0; b < 32 && 32 * kt + b < N; ++b) {
-                const int j = 32 * kt + b;
-                const bool v = (vw.w[kt] >> b) & 1u;
-                all_visited &= v;
-                if (j >= 1) {
-                  const bool masked = v || (dems[j] + used > thr);
-                  mbits |= masked ? 0u : (1u << b);
-                  any_feasible |= !masked;
-                }
-              }
-              mw.w[kt] = mbits;
-            }
-            if (!((cur == 0) && any_feasible)) mw.w[0] |= 1u;
-            done = all_visited;
-          }
-        }
-      }
-      if (single) {
-        ++t;
-        break;
-      }
-    }
-
-    // ---- write back the column tile's final state -------------------------------------------------------
-    if (w == 0 && hi == 0 && lane_ok) {
-      uint8_t* gm = a.action_mask + (int64_t)r * N;
-      for (int j = 0; j < N; ++j) gm[j] = mw.test(j) ? 1 : 0;
-      if (ENV == RL4CO_ENV_CVRP) {
-        uint8_t* gv = a.visited + (int64_t)r * N;
-        for (int j = 0; j < N; ++j) gv[j] = vw.test(j) ? 1 : 0;
-        a.used_capacity[r] = used;
-      } else {
-        a.first_node[r] = first;
-        a.step_i[r] = step_i;
-      }
-      a.current_node[r] = cur;
-      a.done[r] = done ? 1 : 0;
-      if (a.n_steps) a.n_steps[r] = nsteps;
-      if (a.entropy) a.entropy[r] += ent_acc;
-      if (!single && !done) errbits |= RL4CO_EBIT_MAX_STEPS;
-    }
-    __syncthreads();
-  }
-  if (errbits && (lane & 31) == 0) atomicOr(a.err, (int)errbits);
+template <int ENV>
+int dispatch_tiles(const rl4co_am_decode_args& a, hipStream_t stream) {
+  const int nt = (a.N + 15) >> 4;
+  if (nt <= 2) return launch_tiles<ENV, 2>(a, stream);
+  if (nt <= 4) return launch_tiles<ENV, 4>(a, stream);
+  if (nt <= 7) return launch_tiles<ENV, 7>(a, stream);
+  return launch_tiles<ENV, 8>(a, stream);
 }
 
 }  // namespace
 
-extern "C" int rl4co_am_decode_ms_lds_bytes(void) {
-  return (3 * 128 + 2 * 32) * kRS * 2 + 4 * 32 * (int)sizeof(Xchg) + 128 * 4;
-}
+// dynamic LDS of the multistart variant at the largest graph (N = 128)
+extern "C" int rl4co_am_decode_ms_lds_bytes(void) { return make_layout(8, 128).total; }
 
 namespace rl4co {
 int launch_decode_ms(const rl4co_am_decode_args& a, hipStream_t stream) {
-  const int lds = rl4co_am_decode_ms_lds_bytes();
-  if (a.env == RL4CO_ENV_TSP) {
-    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_decode_ms_kernel<RL4CO_ENV_TSP>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL((am_decode_ms_kernel<RL4CO_ENV_TSP>), dim3(a.B_inst), dim3(kThreads), lds, stream, a);
-  } else {
-    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_decode_ms_kernel<RL4CO_ENV_CVRP>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    hipLaunchKernelGGL((am_decode_ms_kernel<RL4CO_ENV_CVRP>), dim3(a.B_inst), dim3(kThreads), lds, stream, a);
-  }
-  RL4CO_HIP_TRY(hipGetLastError());
-  return RL4CO_OK;
+  return a.env == RL4CO_ENV_TSP ? dispatch_tiles<RL4CO_ENV_TSP>(a, stream) : dispatch_tiles<RL4CO_ENV_CVRP>(a, stream);
 }
 }  // namespace rl4co

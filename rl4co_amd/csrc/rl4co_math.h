@@ -1,6 +1,6 @@
 /*
  * rl4co_math.h — deterministic fp32 exp / log / tanh shared by the HIP kernels
- * and by the specified-order C oracle (oracle/am_decode_ref.c).
+ * and by the specified-order C oracle (oracle/rollout_ref.c).
  *
  * Why not the vendor libm: glibc's expf/tanhf and ROCm's ocml versions differ in
  * the last ulp, and greedy decoding breaks ties at the tanh-saturation plateau
@@ -147,6 +147,14 @@ RL4CO_HD float rl4co_exp1_noise(uint64_t seed, uint64_t step, uint32_t traj, uin
   uint32_t w = c[node & 3];
   float u = ((float)(w >> 9) + 0.5f) * 1.1920928955078125e-7f; /* (k+0.5)/2^23 in (0,1) */
   return -rl4co_logf(u);
+}
+
+/* The four uniforms of nodes 4 g .. 4 g + 3 (one Philox block): u[i] is the value whose -log
+ * rl4co_exp1_noise(seed, step, traj, 4 g + i) returns. */
+RL4CO_HD void rl4co_uniform4(uint64_t seed, uint64_t step, uint32_t traj, uint32_t node_group, float u[4]) {
+  uint32_t c[4] = {(uint32_t)step, traj, node_group, (uint32_t)(step >> 32) ^ 0x52344c43u};
+  rl4co_philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+  for (int i = 0; i < 4; ++i) u[i] = ((float)(c[i] >> 9) + 0.5f) * 1.1920928955078125e-7f;
 }
 
 #endif /* RL4CO_MATH_H */

@@ -117,8 +117,9 @@ def test_ms_is_auto_selected_for_multistart_and_policy_runs(K):
     from rl4co_amd.envs import get_env
     from rl4co_amd.policy import AttentionModelPolicy
 
-    assert K.decode_row_groups(100, torch.bfloat16, 99, "auto", 4096 * 32, 4096) == 0     # MS from 16 starts up
-    assert K.decode_row_groups(100, torch.bfloat16, 99, "auto", 4096 * 8, 4096) == 4      # 8 starts: streaming
+    assert K.decode_row_groups(100, torch.bfloat16, 99, "auto", 4096 * 32, 4096) == 0     # MS from 8 starts up
+    assert K.decode_row_groups(100, torch.bfloat16, 99, "auto", 4096 * 8, 4096) == 0
+    assert K.decode_row_groups(100, torch.bfloat16, 99, "auto", 4096 * 4, 4096) == 4      # 4 starts: streaming
     assert K.decode_row_groups(100, torch.bfloat16, 100, "auto", 4096, 4096) == 4          # single start: stream
     assert K.decode_row_groups(100, torch.float32, 99, "auto", 4096 * 8, 4096) == 2        # fp32 planes: stream
     torch.manual_seed(0)

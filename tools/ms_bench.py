@@ -7,6 +7,7 @@ from rl4co_amd import kernels as K
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 S = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 variants = sys.argv[3:] or ["stream"]
+MODE = __import__("os").environ.get("MODE", "sampling")
 torch.manual_seed(0)
 pol = AttentionModelPolicy("tsp", cache_dtype=torch.bfloat16, encoder_autocast=torch.bfloat16,
                            num_encoder_layers=6, normalization="instance", use_graph_context=False).cuda().eval()
@@ -18,19 +19,23 @@ with torch.inference_mode():
         times = []
         for it in range(4):
             st = pol._initial_state(td, S)
-            actions = torch.zeros(B * S, 100, dtype=torch.int64, device="cuda")
-            logps = torch.zeros(B * S, 100, device="cuda")
+            actions = torch.zeros(B * S, 128, dtype=torch.int64, device="cuda")
+            logps = torch.zeros(B * S, 128, device="cuda")
             err = K.new_error_word("cuda")
             first = env.select_start_nodes(td, S)
             actions[:, 0] = first
             pol._env_step_state(st, first, err)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            K.am_decode(cache, st, mode="sampling", max_steps=99, t0=1, actions=actions, logps=logps, err=err,
+            K.am_decode(cache, st, mode=MODE, max_steps=99, t0=1, actions=actions, logps=logps, err=err,
                         philox_seed=7, variant=variant)
             e1.record(); torch.cuda.synchronize()
             K.raise_if_error(err)
             times.append(e0.elapsed_time(e1))
         ms = min(times[1:])
-        print(f"B={B} S={S} {variant}: {ms:.3f} ms ({B*S*99/ms/1e3:.1f} M trajectory-steps/s, "
+        print(f"B={B} S={S} {MODE} {variant}: {ms:.3f} ms ({B*S*99/ms/1e3:.1f} M trajectory-steps/s, "
               f"{B*S*99*78040/ms/1e6:.0f} GB/s algorithmic per-trajectory bytes)")
+
+        if __import__("os").environ.get("PROF"):
+            for w in range(8):
+                print("wave", w, [int(x) for x in logps[w, 110:116].tolist()], "cycles: stage12, B1 wait, stage3, B2 wait, stage4, loop head")
