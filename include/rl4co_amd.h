@@ -332,6 +332,22 @@ int rl4co_am_teacher_max_nodes(void);
 int rl4co_am_teacher_variant(const rl4co_am_teacher_args* args);
 
 /* --------------------------------------------------------------------------
+ * a12 (training)  SkipConnection + Normalization("instance")
+ *   rl4co/models/nn/ops.py:9-15,30-54 ; nn/graph/attnnet.py:16-54 ; zoo/pomo/model.py:59-63
+ * forward : y = x + s ; out = (y - mean_n y) * rsqrt(var_n y + eps) * gamma + beta, statistics per
+ *           instance and channel over the N nodes (biased variance). bf16 activations [B,N,128],
+ *           fp32 arithmetic; y, mean[B,128], rstd[B,128] are kept for the backward pass.
+ * backward: dy (the gradient of BOTH skip inputs) from dout; dgamma / dbeta accumulated
+ *           atomically (zero-initialised by the caller). N <= rl4co_skip_inorm_max_nodes().
+ * -------------------------------------------------------------------------- */
+int rl4co_skip_inorm_fwd_bf16(const void* x, const void* s, const float* gamma, const float* beta, float eps,
+                              int B, int N, void* y, void* out, float* mean, float* rstd, void* stream);
+int rl4co_skip_inorm_bwd_bf16(const void* dout, const void* y, const float* gamma, const float* mean,
+                              const float* rstd, int B, int N, void* dy, float* dgamma, float* dbeta,
+                              void* stream);
+int rl4co_skip_inorm_max_nodes(void);
+
+/* --------------------------------------------------------------------------
  * a19  select_start_nodes        rl4co/utils/ops.py:128-161
  * out[s*B + b] = s % num_loc (+1 for depot environments), s-major.
  * -------------------------------------------------------------------------- */

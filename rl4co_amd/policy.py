@@ -122,6 +122,23 @@ class _EncoderLayer(nn.Sequential):
         attn = _SelfAttention(embed_dim, num_heads)
         super().__init__(_Skip(attn), _Norm(embed_dim, normalization), _Skip(ffn), _Norm(embed_dim, normalization))
 
+    def forward(self, x):
+        # training under bf16 autocast with instance norm (the POMO recipe): skip + norm as one HIP
+        # kernel forward and one backward (csrc/am_train_ops.hip) instead of autograd's elementwise chain
+        if (self.training and torch.is_grad_enabled() and x.is_cuda and self[1].kind == "instance"
+                and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16):
+            from . import train_ops
+
+            x = x.to(torch.bfloat16)
+            for skip, norm in ((self[0], self[1]), (self[2], self[3])):
+                s = skip.module(x)
+                if train_ops.usable(x, s):
+                    x = train_ops.skip_instance_norm(x, s, norm.normalizer.weight, norm.normalizer.bias, norm.normalizer.eps)
+                else:
+                    x = norm(x + s)
+            return x
+        return super().forward(x)
+
 
 class _GraphAttentionNetwork(nn.Module):
     """nn/graph/attnnet.py:57-106"""

@@ -123,3 +123,36 @@ def test_manual_instance_norm_matches_module():
     torch.testing.assert_close(y, y2, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(gx, gx2, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(gw, gw2, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("n", [20, 50, 100, 101, 128])
+def test_fused_skip_instance_norm_matches_torch(n):
+    """csrc/am_train_ops.hip: Normalization("instance")(x + s) forward and backward on bf16 activations
+    vs the same arithmetic in torch fp32 on the bf16-rounded inputs. Tolerances: output 1.5e-2 + 1.6e-2 |ref|
+    (bf16 rounding of the output and of the skip sum), input gradient 3e-2 relative
+    Frobenius, affine gradients 1e-2 relative."""
+    from rl4co_amd import train_ops
+
+    torch.manual_seed(n)
+    b, d = 64, 128
+    x = torch.randn(b, n, d, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    s = (0.5 * torch.randn(b, n, d, device="cuda")).to(torch.bfloat16).requires_grad_(True)
+    w = torch.empty(d, device="cuda").uniform_(0.5, 1.5).requires_grad_(True)
+    bb = torch.empty(d, device="cuda").uniform_(-0.5, 0.5).requires_grad_(True)
+    go = torch.randn(b, n, d, device="cuda").to(torch.bfloat16)
+    assert train_ops.usable(x, s)
+    out = train_ops.skip_instance_norm(x, s, w, bb, 1e-5)
+    gx, gs, gw, gb = torch.autograd.grad(out, [x, s, w, bb], go)
+    assert torch.equal(gx, gs)
+    x32, s32 = x.detach().float().requires_grad_(True), s.detach().float().requires_grad_(True)
+    w32, b32 = w.detach().clone().requires_grad_(True), bb.detach().clone().requires_grad_(True)
+    y = x32 + s32
+    mean = y.mean(1, keepdim=True)
+    var = y.var(1, unbiased=False, keepdim=True)
+    ref = (y - mean) * torch.rsqrt(var + 1e-5) * w32 + b32
+    rx, rs_, rw, rb = torch.autograd.grad(ref, [x32, s32, w32, b32], go.float())
+    # bf16 output (2^-8 relative) of a normalised value computed from the bf16-rounded skip sum
+    torch.testing.assert_close(out.detach().float(), ref.detach(), rtol=1.6e-2, atol=1.5e-2)
+    rel = lambda a, r: float((a.float() - r).norm() / r.norm())  # noqa: E731
+    assert rel(gx, rx) <= 3e-2, rel(gx, rx)
+    assert rel(gw, rw) <= 1e-2 and rel(gb, rb) <= 1e-2, (rel(gw, rw), rel(gb, rb))
