@@ -348,6 +348,22 @@ int rl4co_skip_inorm_bwd_bf16(const void* dout, const void* y, const float* gamm
 int rl4co_skip_inorm_max_nodes(void);
 
 /* --------------------------------------------------------------------------
+ * a12 (training)  nn.Linear over the token rows: Wqkv, out_proj, MLP
+ *   rl4co/models/nn/attention.py:64-134 ; nn/mlp.py:52-61
+ * out[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]); bf16 A, W, out, fp32 bias and accumulate.
+ * epilogue: relu != 0 -> max(.,0); mask != NULL -> (mask[m,n] > 0 ? . : 0) (ReLU backward, bf16 mask).
+ * With W = weight^T (contiguous) it is the input gradient dX = dY . weight.
+ * N and K multiples of 128; bias and mask may be NULL.
+ * -------------------------------------------------------------------------- */
+int rl4co_linear_bf16(const void* a, const void* w, const float* bias, const void* mask, int64_t M, int N, int K,
+                      int relu, void* out, void* stream);
+/* Weight gradient of the same layers: partial[c][N,K] = dY[rows of chunk c]^T . X[rows of chunk c]
+ * (bf16 dY [M,N], X [M,K]; fp32 partial [chunks,N,K], every element written); dW = sum over c.
+ * The rows are split into `chunks` equal ranges (a multiple of 32 rows each). */
+int rl4co_wgrad_bf16(const void* dy, const void* x, int64_t M, int N, int K, int chunks, float* partial,
+                     void* stream);
+
+/* --------------------------------------------------------------------------
  * a19  select_start_nodes        rl4co/utils/ops.py:128-161
  * out[s*B + b] = s % num_loc (+1 for depot environments), s-major.
  * -------------------------------------------------------------------------- */

@@ -179,3 +179,215 @@ extern "C" int rl4co_skip_inorm_bwd_bf16(const void* dout, const void* y, const 
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Token-parallel linear layers of the training encoder on the matrix cores.
+//
+//   out[M,N] = epilogue( A[M,K] . W[N,K]^T + bias[N] )        bf16 in / out, fp32 accumulate
+//
+// is nn.Linear (Wqkv, out_proj, the MLP: nn/attention.py:64-134, nn/mlp.py:52-61) over the
+// M = B x nodes token rows, and — called with the transposed weight — its input gradient
+// dX = dY . W. The shapes are tall and skinny (M ~ 4e5, K and N in {128, 384, 512}): the work is
+// HBM-bound (read A once, write out once), which the library GEMM misses by 10x at these shapes
+// (1.0 ms for [409600,128] x [128,512], 0.5 TB/s). One workgroup owns a stripe of 128 token rows:
+// in every shape used either K = 128 (the A chunk is loaded once and reused for all column tiles)
+// or N = 128 (a single column tile), so A is never re-read. Products are computed transposed —
+// v_mfma_f32_32x32x16_bf16 with the FEATURE as the accumulator row — so a lane holds four
+// consecutive features of one token and the epilogue packs 8-byte LDS writes; the tile leaves
+// through LDS as coalesced 16-byte rows. Epilogue: + bias, then optionally ReLU, or the ReLU
+// backward mask (mask[m,n] > 0 ? v : 0) when the call computes d hidden = d out . W2.
+namespace {
+
+constexpr int kTM = 128, kTN = 128, kTK = 128;  // tile: token rows x features x contraction chunk
+constexpr int kLS = kTK + 8;                    // LDS row stride (bf16)
+constexpr int kGemmThreads = 256;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4g __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__global__ void __launch_bounds__(kGemmThreads, 2) linear_bf16_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+                                                                      const float* __restrict__ bias, const uint16_t* __restrict__ mask,
+                                                                      int M, int N, int K, int relu, uint16_t* __restrict__ out) {
+  extern __shared__ __align__(16) unsigned char smem_g[];
+  __bf16* as = reinterpret_cast<__bf16*>(smem_g);  // [128 tokens][kLS]
+  __bf16* ws = as + kTM * kLS;                       // [128 features][kLS]; reused as the output tile
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.x * kTM;
+  const int nkc = K / kTK, nnt = N / kTN;
+
+  for (int nt = 0; nt < nnt; ++nt) {
+    f32x16 acc[4];  // [feature tile ct][feature 32 ct + rowmap(r, hi)], token 32 w + l31
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
+    for (int kc = 0; kc < nkc; ++kc) {
+      __syncthreads();  // previous chunk / output tile fully consumed
+      if (nkc > 1 || nt == 0) {
+        for (int c = tid; c < kTM * 16; c += kGemmThreads) {
+          const int row = c >> 4, col = (c & 15) * 8;
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (m0 + row < M) v = *reinterpret_cast<const uint4*>(A + (m0 + row) * K + kc * kTK + col);
+          *reinterpret_cast<uint4*>(as + row * kLS + col) = v;
+        }
+      }
+      for (int c = tid; c < kTN * 16; c += kGemmThreads) {
+        const int row = c >> 4, col = (c & 15) * 8;
+        *reinterpret_cast<uint4*>(ws + row * kLS + col) =
+            *reinterpret_cast<const uint4*>(W + (int64_t)(nt * kTN + row) * K + kc * kTK + col);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < kTK / 16; ++ks) {
+        const bf16x8 tok = *reinterpret_cast<const bf16x8*>(as + (32 * w + l31) * kLS + 16 * ks + 8 * hi);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          const bf16x8 feat = *reinterpret_cast<const bf16x8*>(ws + (32 * ct + l31) * kLS + 16 * ks + 8 * hi);
+          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(feat, tok, acc[ct], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();  // every wave is done reading ws: it becomes the [token][feature] output tile
+    const int64_t row = m0 + 32 * w + l31;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f0 = 32 * ct + 8 * q + 4 * hi;  // four consecutive features
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          v[i] = acc[ct][4 * q + i] + (bias ? bias[nt * kTN + f0 + i] : 0.0f);
+          if (relu) v[i] = fmaxf(v[i], 0.0f);
+        }
+        if (mask && row < M) {
+          const uint2 mk = *reinterpret_cast<const uint2*>(mask + row * N + nt * kTN + f0);
+          // bf16 > 0  <=>  sign bit clear and magnitude non-zero
+          v[0] = ((mk.x & 0x8000u) == 0 && (mk.x & 0x7fffu) != 0) ? v[0] : 0.0f;
+          v[1] = ((mk.x >> 31) == 0 && (mk.x & 0x7fff0000u) != 0) ? v[1] : 0.0f;
+          v[2] = ((mk.y & 0x8000u) == 0 && (mk.y & 0x7fffu) != 0) ? v[2] : 0.0f;
+          v[3] = ((mk.y >> 31) == 0 && (mk.y & 0x7fff0000u) != 0) ? v[3] : 0.0f;
+        }
+        bf16x4g o;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+        *reinterpret_cast<bf16x4g*>(ws + (32 * w + l31) * kLS + f0) = o;
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < kTM * 16; c += kGemmThreads) {
+      const int r = c >> 4, col = (c & 15) * 8;
+      if (m0 + r < M)
+        *reinterpret_cast<uint4*>(out + (m0 + r) * N + nt * kTN + col) = *reinterpret_cast<const uint4*>(ws + r * kLS + col);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int rl4co_linear_bf16(const void* a, const void* w, const float* bias, const void* mask, int64_t M, int N, int K,
+                                 int relu, void* out, void* stream) {
+  RL4CO_REQUIRE(a && w && out);
+  RL4CO_REQUIRE(M > 0 && M < (int64_t)1 << 31 && N > 0 && K > 0 && N % kTN == 0 && K % kTK == 0);
+  RL4CO_REQUIRE(!(relu && mask));
+  const int lds = (kTM + kTN) * kLS * 2;
+  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  const int blocks = (int)((M + kTM - 1) / kTM);
+  hipLaunchKernelGGL(linear_bf16_kernel, dim3(blocks), dim3(kGemmThreads), lds, rl4co::as_stream(stream),
+                     static_cast<const uint16_t*>(a), static_cast<const uint16_t*>(w), bias,
+                     static_cast<const uint16_t*>(mask), (int)M, N, K, relu, static_cast<uint16_t*>(out));
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradients of those linear layers: dW[N,K] = dY[M,N]^T . X[M,K], the contraction running
+// over the M ~ 4e5 token rows. The library GEMM takes 0.7 - 1.0 ms per call here (24 calls per
+// REINFORCE step); the work is two streaming reads. Split over the token rows: workgroup
+// (tile, chunk) accumulates one 128 x 128 tile of dW over its chunk of rows on
+// v_mfma_f32_16x16x16_bf16 — both operands want the TOKEN on the contraction slots, so the
+// [token][column] LDS tiles are read through ds_read_b64_tr_b16 — and writes an fp32 partial;
+// the chunks are summed afterwards (deterministic, no atomics).
+namespace {
+
+constexpr int kWT = 32;        // token rows per LDS step
+constexpr int kWLS = 128 + 8;  // LDS row stride (bf16)
+
+typedef __bf16 bf16x4w __attribute__((ext_vector_type(4)));
+typedef short s16x4w __attribute__((ext_vector_type(4)));
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4w lds_s16x4w;
+
+__device__ inline bf16x4w lds_tr_w(const __bf16* p) {
+  const s16x4w v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4w*)p);
+  return __builtin_bit_cast(bf16x4w, v);
+}
+
+__global__ void __launch_bounds__(256) wgrad_bf16_kernel(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X, int M, int N,
+                                                         int K, int rows_per_chunk, float* __restrict__ partial) {
+  __shared__ __align__(16) __bf16 dyt[kWT * kWLS];  // [32 tokens][128 output features of this tile]
+  __shared__ __align__(16) __bf16 xt[kWT * kWLS];   // [32 tokens][128 input features of this tile]
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
+  const int kt_n = K / 128;
+  const int tile = blockIdx.x, nt = tile / kt_n, kt = tile % kt_n, chunk = blockIdx.y;
+  const int64_t m_begin = (int64_t)chunk * rows_per_chunk;
+  const int64_t m_end = min((int64_t)M, m_begin + rows_per_chunk);
+  const int tro = (4 * g + (tl >> 2)) * kWLS + 4 * (tl & 3);
+  f32x4w acc[2][8];  // [feature block 32 w + 16 nb][input block 16 kb]
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) acc[nb][kb] = f32x4w{0.0f, 0.0f, 0.0f, 0.0f};
+  const int lrow = tid >> 3, lcol = (tid & 7) * 16;  // this thread stages 32 bytes of each tile row
+  for (int64_t m0 = m_begin; m0 < m_end; m0 += kWT) {
+    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
+    if (m0 + lrow < m_end) {
+      const uint16_t* pa = dY + (m0 + lrow) * N + nt * 128 + lcol;
+      const uint16_t* pb = X + (m0 + lrow) * K + kt * 128 + lcol;
+      a0 = *reinterpret_cast<const uint4*>(pa);
+      a1 = *reinterpret_cast<const uint4*>(pa + 8);
+      b0 = *reinterpret_cast<const uint4*>(pb);
+      b1 = *reinterpret_cast<const uint4*>(pb + 8);
+    }
+    __syncthreads();  // the previous step's fragments are consumed
+    *reinterpret_cast<uint4*>(dyt + lrow * kWLS + lcol) = a0;
+    *reinterpret_cast<uint4*>(dyt + lrow * kWLS + lcol + 8) = a1;
+    *reinterpret_cast<uint4*>(xt + lrow * kWLS + lcol) = b0;
+    *reinterpret_cast<uint4*>(xt + lrow * kWLS + lcol + 8) = b1;
+    __syncthreads();
+#pragma unroll
+    for (int ts = 0; ts < kWT / 16; ++ts) {
+      bf16x4w af[2];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) af[nb] = lds_tr_w(dyt + 16 * ts * kWLS + 32 * w + 16 * nb + tro);
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) {
+        const bf16x4w bf = lds_tr_w(xt + 16 * ts * kWLS + 16 * kb + tro);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) acc[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af[nb], bf, acc[nb][kb], 0, 0, 0);
+      }
+    }
+  }
+  float* out = partial + (int64_t)chunk * N * K;
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[(int64_t)(nt * 128 + 32 * w + 16 * nb + 4 * g + r) * K + kt * 128 + 16 * kb + tl] = acc[nb][kb][r];
+}
+
+}  // namespace
+
+extern "C" int rl4co_wgrad_bf16(const void* dy, const void* x, int64_t M, int N, int K, int chunks, float* partial, void* stream) {
+  RL4CO_REQUIRE(dy && x && partial);
+  RL4CO_REQUIRE(M > 0 && M < (int64_t)1 << 31 && N > 0 && K > 0 && N % 128 == 0 && K % 128 == 0 && chunks > 0 && chunks <= 65535);
+  const int rows = (int)(((M + chunks - 1) / chunks + kWT - 1) / kWT * kWT);
+  hipLaunchKernelGGL(wgrad_bf16_kernel, dim3((N / 128) * (K / 128), chunks), dim3(256), 0, rl4co::as_stream(stream),
+                     static_cast<const uint16_t*>(dy), static_cast<const uint16_t*>(x), (int)M, N, K, rows, partial);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}

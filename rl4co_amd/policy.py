@@ -91,12 +91,19 @@ class _SelfAttention(nn.Module):
         self.Wqkv = nn.Linear(embed_dim, 3 * embed_dim, bias=True)
         self.out_proj = nn.Linear(embed_dim, embed_dim, bias=True)
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, fused: bool = False) -> Tensor:
         b, n, d = x.shape
-        qkv = self.Wqkv(x).view(b, n, 3, self.num_heads, d // self.num_heads)
+        if fused:  # training under bf16 autocast: the two projections on csrc/am_train_ops.hip
+            from . import train_ops
+
+            qkv = train_ops.linear(x, self.Wqkv.weight, self.Wqkv.bias).view(b, n, 3, self.num_heads, d // self.num_heads)
+        else:
+            qkv = self.Wqkv(x).view(b, n, 3, self.num_heads, d // self.num_heads)
         q, k, v = qkv.permute(2, 0, 3, 1, 4).unbind(0)
-        out = F.scaled_dot_product_attention(q, k, v)
-        return self.out_proj(out.transpose(1, 2).reshape(b, n, d))
+        out = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(b, n, d)
+        if fused:
+            return train_ops.linear(out, self.out_proj.weight, self.out_proj.bias)
+        return self.out_proj(out)
 
 
 class _FeedForward(nn.Module):
@@ -107,7 +114,11 @@ class _FeedForward(nn.Module):
         dims = [embed_dim] + ([hidden] if hidden > 0 else []) + [embed_dim]
         self.lins = nn.ModuleList(nn.Linear(i, o) for i, o in zip(dims[:-1], dims[1:]))
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, fused: bool = False) -> Tensor:
+        if fused and len(self.lins) == 2:
+            from . import train_ops
+
+            return train_ops.mlp(x, self.lins[0].weight, self.lins[0].bias, self.lins[1].weight, self.lins[1].bias)
         for lin in self.lins[:-1]:
             x = F.relu(lin(x))
         return self.lins[-1](x)
@@ -121,6 +132,7 @@ class _EncoderLayer(nn.Sequential):
         ffn = _FeedForward(embed_dim, feedforward_hidden)
         attn = _SelfAttention(embed_dim, num_heads)
         super().__init__(_Skip(attn), _Norm(embed_dim, normalization), _Skip(ffn), _Norm(embed_dim, normalization))
+        self.fused_linear = True  # training: projections / MLP on the HIP GEMM (False: library GEMMs)
 
     def forward(self, x):
         # training under bf16 autocast with instance norm (the POMO recipe): skip + norm as one HIP
@@ -130,8 +142,11 @@ class _EncoderLayer(nn.Sequential):
             from . import train_ops
 
             x = x.to(torch.bfloat16)
+            attn, ffn = self[0].module, self[2].module
+            gemm_ok = (self.fused_linear and train_ops.linear_usable(x, attn.Wqkv.weight, attn.out_proj.weight,
+                                                                      *(lin.weight for lin in ffn.lins)))
             for skip, norm in ((self[0], self[1]), (self[2], self[3])):
-                s = skip.module(x)
+                s = skip.module(x, fused=gemm_ok)
                 if train_ops.usable(x, s):
                     x = train_ops.skip_instance_norm(x, s, norm.normalizer.weight, norm.normalizer.bias, norm.normalizer.eps)
                 else:

@@ -63,3 +63,93 @@ def usable(x: Tensor, s: Tensor) -> bool:
 
 def skip_instance_norm(x: Tensor, s: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5) -> Tensor:
     return _SkipInstanceNorm.apply(x, s, weight, bias, eps)
+
+
+# ---------------------------------------------------------------------------------------------------
+# nn.Linear over the token rows on the tall-skinny MFMA kernel (csrc/am_train_ops.hip)
+# ---------------------------------------------------------------------------------------------------
+def _gemm(a2d: Tensor, w: Tensor, bias: Tensor | None = None, mask: Tensor | None = None, relu: bool = False) -> Tensor:
+    """out[M,N] = epilogue(a2d[M,K] @ w[N,K]^T + bias); bf16 a2d / w / out, fp32 bias."""
+    m, k = a2d.shape
+    n = w.shape[0]
+    out = torch.empty((m, n), dtype=torch.bfloat16, device=a2d.device)
+    st = _lib.lib().rl4co_linear_bf16(a2d.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
+                                      None if mask is None else mask.data_ptr(), m, n, k, int(relu), out.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream)
+    _lib.check(st, "rl4co_linear_bf16")
+    return out
+
+
+def _wgrad(d2: Tensor, x2: Tensor) -> Tensor:
+    """dW[N,K] = d2[M,N]^T @ x2[M,K] (fp32 result): split over the rows, partials summed by torch."""
+    m, n = d2.shape
+    k = x2.shape[1]
+    tiles = (n // 128) * (k // 128)
+    chunks = max(1, min(1024 // tiles, (m + 255) // 256))
+    partial = torch.empty((chunks, n, k), dtype=torch.float32, device=d2.device)
+    st = _lib.lib().rl4co_wgrad_bf16(d2.data_ptr(), x2.data_ptr(), m, n, k, chunks, partial.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream)
+    _lib.check(st, "rl4co_wgrad_bf16")
+    return partial.sum(0)
+
+
+def linear_usable(x: Tensor, *weights: Tensor) -> bool:
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 128 == 0
+            and all(w.shape[0] % 128 == 0 and w.shape[1] % 128 == 0 for w in weights))
+
+
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b (Wqkv, out_proj). Backward: dX on the same kernel with W^T; dW / db by torch."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Tensor):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        w16 = weight.detach().to(torch.bfloat16).contiguous()
+        out = _gemm(x2, w16, bias.detach().float().contiguous())
+        ctx.save_for_backward(x2, w16)
+        ctx.pdt = weight.dtype
+        return out.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        x2, w16 = ctx.saved_tensors
+        d = dout.reshape(-1, dout.shape[-1]).to(torch.bfloat16).contiguous()
+        dx = _gemm(d, w16.t().contiguous())
+        dw = _wgrad(d, x2).to(ctx.pdt)
+        db = d.sum(0, dtype=torch.float32).to(ctx.pdt)
+        return dx.view(*dout.shape[:-1], x2.shape[-1]), dw, db
+
+
+class _MLP(torch.autograd.Function):
+    """y = relu(x W1^T + b1) W2^T + b2 (nn/mlp.py:52-61); the ReLU and its backward mask ride in the
+    GEMM epilogues, the hidden activation is written once and read twice."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor):
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        w1_16, w2_16 = w1.detach().to(torch.bfloat16).contiguous(), w2.detach().to(torch.bfloat16).contiguous()
+        h = _gemm(x2, w1_16, b1.detach().float().contiguous(), relu=True)
+        y = _gemm(h, w2_16, b2.detach().float().contiguous())
+        ctx.save_for_backward(x2, h, w1_16, w2_16)
+        ctx.pdt = w1.dtype
+        return y.view(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        x2, h, w1_16, w2_16 = ctx.saved_tensors
+        d = dy.reshape(-1, dy.shape[-1]).to(torch.bfloat16).contiguous()
+        dh = _gemm(d, w2_16.t().contiguous(), mask=h)  # (d W2) * [h > 0]
+        dw2 = _wgrad(d, h).to(ctx.pdt)
+        db2 = d.sum(0, dtype=torch.float32).to(ctx.pdt)
+        dx = _gemm(dh, w1_16.t().contiguous())
+        dw1 = _wgrad(dh, x2).to(ctx.pdt)
+        db1 = dh.sum(0, dtype=torch.float32).to(ctx.pdt)
+        return dx.view(*dy.shape[:-1], x2.shape[-1]), dw1, db1, dw2, db2
+
+
+def linear(x: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
+    return _Linear.apply(x, weight, bias)
+
+
+def mlp(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor) -> Tensor:
+    return _MLP.apply(x, w1, b1, w2, b2)

@@ -156,3 +156,72 @@ def test_fused_skip_instance_norm_matches_torch(n):
     rel = lambda a, r: float((a.float() - r).norm() / r.norm())  # noqa: E731
     assert rel(gx, rx) <= 3e-2, rel(gx, rx)
     assert rel(gw, rw) <= 1e-2 and rel(gb, rb) <= 1e-2, (rel(gw, rw), rel(gb, rb))
+
+
+@pytest.mark.parametrize("m,k,n", [(4096 * 100, 128, 384), (1000, 128, 128), (12345, 128, 512), (12800, 512, 128), (300, 384, 128)])
+def test_linear_bf16_kernel_matches_torch(m, k, n):
+    """csrc/am_train_ops.hip rl4co_linear_bf16 vs torch (fp32 matmul of the bf16-rounded operands):
+    bf16 output => 2^-8 relative rounding of the result; bound 1e-2 relative + 1e-2 absolute."""
+    from rl4co_amd import train_ops
+
+    torch.manual_seed(k + n)
+    a = torch.randn(m, k, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(n, k, device="cuda") / k ** 0.5).to(torch.bfloat16)
+    b = torch.randn(n, device="cuda")
+    ref = a.float() @ w.float().t() + b
+    torch.testing.assert_close(train_ops._gemm(a, w, b).float(), ref, rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(train_ops._gemm(a, w, b, relu=True).float(), ref.clamp_min(0), rtol=1e-2, atol=1e-2)
+    mask = torch.randn(m, n, device="cuda").to(torch.bfloat16)
+    mask[0, :4] = torch.tensor([0.0, -0.0, 1e-30, -1e-30], device="cuda").to(torch.bfloat16)
+    torch.testing.assert_close(train_ops._gemm(a, w, None, mask=mask).float(), (a.float() @ w.float().t()) * (mask > 0),
+                               rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("m,n,k", [(4096 * 100, 384, 128), (1000, 128, 128), (12345, 512, 128), (12800, 128, 512)])
+def test_wgrad_bf16_kernel_matches_torch(m, n, k):
+    """rl4co_wgrad_bf16 (split over the rows, fp32 partials) vs fp32 matmul of the same bf16 operands:
+    fp32 accumulation of exact bf16 products => 1e-3 relative Frobenius error (summation order only)."""
+    from rl4co_amd import train_ops
+
+    torch.manual_seed(n + k)
+    d = torch.randn(m, n, device="cuda").to(torch.bfloat16)
+    x = torch.randn(m, k, device="cuda").to(torch.bfloat16)
+    got = train_ops._wgrad(d, x)
+    ref = d.float().t() @ x.float()
+    assert got.shape == ref.shape and got.dtype == torch.float32
+    assert float((got - ref).norm() / ref.norm()) <= 1e-3
+
+
+def test_fused_linear_and_mlp_gradients_match_torch():
+    """autograd Functions over the kernel vs torch.nn.functional on the same bf16 inputs, fp32 weights and
+    fp32 arithmetic in the reference. The kernel path rounds weights, hidden activation and d hidden
+    to bf16 (the autocast regime): every gradient within 4e-2 relative Frobenius error (measured <= 2.7e-2)."""
+    import torch.nn.functional as F
+
+    from rl4co_amd import train_ops
+
+    torch.manual_seed(0)
+    x = torch.randn(64, 100, 128, device="cuda").to(torch.bfloat16)
+    w1 = (torch.randn(512, 128, device="cuda") / 128 ** 0.5).requires_grad_(True)
+    b1 = torch.randn(512, device="cuda").requires_grad_(True)
+    w2 = (torch.randn(128, 512, device="cuda") / 512 ** 0.5).requires_grad_(True)
+    b2 = torch.randn(128, device="cuda").requires_grad_(True)
+    go = torch.randn(64, 100, 128, device="cuda").to(torch.bfloat16)
+    xk = x.clone().requires_grad_(True)
+    gk = torch.autograd.grad(train_ops.mlp(xk, w1, b1, w2, b2), [xk, w1, b1, w2, b2], go)
+    xr = x.float().requires_grad_(True)
+    ref = F.linear(F.relu(F.linear(xr, w1, b1)), w2, b2)
+    gr = torch.autograd.grad(ref, [xr, w1, b1, w2, b2], go.float())
+    for a, r, nm in zip(gk, gr, ("dx", "dw1", "db1", "dw2", "db2")):
+        rel = float((a.float() - r).norm() / r.norm())
+        assert rel <= 4e-2, (nm, rel)
+    wq = (torch.randn(384, 128, device="cuda") / 128 ** 0.5).requires_grad_(True)
+    bq = torch.randn(384, device="cuda").requires_grad_(True)
+    gq = torch.randn(64, 100, 384, device="cuda").to(torch.bfloat16)
+    xk = x.clone().requires_grad_(True)
+    gk = torch.autograd.grad(train_ops.linear(xk, wq, bq), [xk, wq, bq], gq)
+    xr = x.float().requires_grad_(True)
+    gr = torch.autograd.grad(F.linear(xr, wq, bq), [xr, wq, bq], gq.float())
+    for a, r, nm in zip(gk, gr, ("dx", "dw", "db")):
+        rel = float((a.float() - r).norm() / r.norm())
+        assert rel <= 2e-2, (nm, rel)
