@@ -359,9 +359,10 @@ int rl4co_linear_bf16(const void* a, const void* w, const float* bias, const voi
                       int relu, void* out, void* stream);
 /* Weight gradient of the same layers: partial[c][N,K] = dY[rows of chunk c]^T . X[rows of chunk c]
  * (bf16 dY [M,N], X [M,K]; fp32 partial [chunks,N,K], every element written); dW = sum over c.
+ * partial_bias [chunks,N] (or NULL) receives the column sums of dY per chunk: db = sum over c.
  * The rows are split into `chunks` equal ranges (a multiple of 32 rows each). */
 int rl4co_wgrad_bf16(const void* dy, const void* x, int64_t M, int N, int K, int chunks, float* partial,
-                     void* stream);
+                     float* partial_bias, void* stream);
 
 /* --------------------------------------------------------------------------
  * a19  select_start_nodes        rl4co/utils/ops.py:128-161

@@ -326,7 +326,8 @@ __device__ inline bf16x4w lds_tr_w(const __bf16* p) {
 }
 
 __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X, int M, int N,
-                                                         int K, int rows_per_chunk, float* __restrict__ partial) {
+                                                         int K, int rows_per_chunk, float* __restrict__ partial,
+                                                         float* __restrict__ partial_bias) {
   __shared__ __align__(16) __bf16 dyt[kWT * kWLS];  // [32 tokens][128 output features of this tile]
   __shared__ __align__(16) __bf16 xt[kWT * kWLS];   // [32 tokens][128 input features of this tile]
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
@@ -340,6 +341,11 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const uint16_t* __restr
   for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) acc[nb][kb] = f32x4w{0.0f, 0.0f, 0.0f, 0.0f};
+  // bias gradient = column sums of dY: one more MFMA per feature block against a ones operand
+  // (tiles with kt == 0 only); every accumulator column then holds the same sum
+  const bool with_bias = partial_bias != nullptr && kt == 0;
+  f32x4w accb[2] = {f32x4w{0.0f, 0.0f, 0.0f, 0.0f}, f32x4w{0.0f, 0.0f, 0.0f, 0.0f}};
+  const bf16x4w ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
   const int lrow = tid >> 3, lcol = (tid & 7) * 16;  // this thread stages 32 bytes of each tile row
   for (int64_t m0 = m_begin; m0 < m_end; m0 += kWT) {
     uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
@@ -362,6 +368,10 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const uint16_t* __restr
       bf16x4w af[2];
 #pragma unroll
       for (int nb = 0; nb < 2; ++nb) af[nb] = lds_tr_w(dyt + 16 * ts * kWLS + 32 * w + 16 * nb + tro);
+      if (with_bias) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) accb[nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af[nb], ones, accb[nb], 0, 0, 0);
+      }
 #pragma unroll
       for (int kb = 0; kb < 8; ++kb) {
         const bf16x4w bf = lds_tr_w(xt + 16 * ts * kWLS + 16 * kb + tro);
@@ -378,16 +388,23 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const uint16_t* __restr
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         out[(int64_t)(nt * 128 + 32 * w + 16 * nb + 4 * g + r) * K + kt * 128 + 16 * kb + tl] = acc[nb][kb][r];
+  if (with_bias && tl == 0) {
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) partial_bias[(int64_t)chunk * N + nt * 128 + 32 * w + 16 * nb + 4 * g + r] = accb[nb][r];
+  }
 }
 
 }  // namespace
 
-extern "C" int rl4co_wgrad_bf16(const void* dy, const void* x, int64_t M, int N, int K, int chunks, float* partial, void* stream) {
+extern "C" int rl4co_wgrad_bf16(const void* dy, const void* x, int64_t M, int N, int K, int chunks, float* partial,
+                                float* partial_bias, void* stream) {
   RL4CO_REQUIRE(dy && x && partial);
   RL4CO_REQUIRE(M > 0 && M < (int64_t)1 << 31 && N > 0 && K > 0 && N % 128 == 0 && K % 128 == 0 && chunks > 0 && chunks <= 65535);
   const int rows = (int)(((M + chunks - 1) / chunks + kWT - 1) / kWT * kWT);
   hipLaunchKernelGGL(wgrad_bf16_kernel, dim3((N / 128) * (K / 128), chunks), dim3(256), 0, rl4co::as_stream(stream),
-                     static_cast<const uint16_t*>(dy), static_cast<const uint16_t*>(x), (int)M, N, K, rows, partial);
+                     static_cast<const uint16_t*>(dy), static_cast<const uint16_t*>(x), (int)M, N, K, rows, partial, partial_bias);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }

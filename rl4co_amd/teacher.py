@@ -99,11 +99,20 @@ def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: d
 def build_cache_autograd(env_name: str, h: Tensor, decoder) -> dict[str, Tensor]:
     """The folded cache as differentiable fp32 tensors (same algebra as cache.build_folded_cache)."""
     d = EMBED_DIM
-    h = h.float()
     w_ctx = decoder.context_embedding.project_context.weight.float()
     blocks = fold_weights(env_name, decoder.project_node_embeddings.weight.float(),
                           decoder.pointer.project_out.weight.float(), w_ctx)
-    planes = [torch.matmul(h, w.t()) for w in blocks]
+    if h.is_cuda and h.dtype == torch.bfloat16:
+        # bf16 encoder output (autocast training): the fold GEMMs and their backward run on the
+        # tall-skinny MFMA kernels (csrc/am_train_ops.hip) instead of five fp32 library GEMMs
+        from . import train_ops
+
+        planes = [train_ops.linear(h, w, None) for w in blocks]  # bf16: the rollout streams bf16 planes anyway
+        planes = planes[:3] + [p.float() for p in planes[3:]]     # the context tables are read as fp32
+    else:
+        h = h.float()
+        planes = [torch.matmul(h, w.t()) for w in blocks]
+    h = h.float()
     out = {"kvl": torch.stack(planes[:3], 0), "ctx_cur": planes[-1] if env_name == "cvrp" else planes[4]}
     if env_name == "tsp":
         out["ctx_first"] = planes[3]

@@ -80,17 +80,20 @@ def _gemm(a2d: Tensor, w: Tensor, bias: Tensor | None = None, mask: Tensor | Non
     return out
 
 
-def _wgrad(d2: Tensor, x2: Tensor) -> Tensor:
-    """dW[N,K] = d2[M,N]^T @ x2[M,K] (fp32 result): split over the rows, partials summed by torch."""
+def _wgrad(d2: Tensor, x2: Tensor, with_bias: bool = False):
+    """dW[N,K] = d2[M,N]^T @ x2[M,K] and (``with_bias``) db[N] = column sums of d2, both fp32: split over
+    the rows on the kernel, partials summed by torch."""
     m, n = d2.shape
     k = x2.shape[1]
     tiles = (n // 128) * (k // 128)
     chunks = max(1, min(1024 // tiles, (m + 255) // 256))
     partial = torch.empty((chunks, n, k), dtype=torch.float32, device=d2.device)
+    pbias = torch.empty((chunks, n), dtype=torch.float32, device=d2.device) if with_bias else None
     st = _lib.lib().rl4co_wgrad_bf16(d2.data_ptr(), x2.data_ptr(), m, n, k, chunks, partial.data_ptr(),
-                                     torch.cuda.current_stream().cuda_stream)
+                                     None if pbias is None else pbias.data_ptr(), torch.cuda.current_stream().cuda_stream)
     _lib.check(st, "rl4co_wgrad_bf16")
-    return partial.sum(0)
+    dw = partial.sum(0)
+    return (dw, pbias.sum(0)) if with_bias else dw
 
 
 def linear_usable(x: Tensor, *weights: Tensor) -> bool:
@@ -102,12 +105,12 @@ class _Linear(torch.autograd.Function):
     """y = x W^T + b (Wqkv, out_proj). Backward: dX on the same kernel with W^T; dW / db by torch."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, weight: Tensor, bias: Tensor):
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Tensor | None):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
         w16 = weight.detach().to(torch.bfloat16).contiguous()
-        out = _gemm(x2, w16, bias.detach().float().contiguous())
+        out = _gemm(x2, w16, None if bias is None else bias.detach().float().contiguous())
         ctx.save_for_backward(x2, w16)
-        ctx.pdt = weight.dtype
+        ctx.pdt, ctx.has_bias = weight.dtype, bias is not None
         return out.view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
@@ -115,9 +118,10 @@ class _Linear(torch.autograd.Function):
         x2, w16 = ctx.saved_tensors
         d = dout.reshape(-1, dout.shape[-1]).to(torch.bfloat16).contiguous()
         dx = _gemm(d, w16.t().contiguous())
-        dw = _wgrad(d, x2).to(ctx.pdt)
-        db = d.sum(0, dtype=torch.float32).to(ctx.pdt)
-        return dx.view(*dout.shape[:-1], x2.shape[-1]), dw, db
+        if ctx.has_bias:
+            dw, db = _wgrad(d, x2, with_bias=True)
+            return dx.view(*dout.shape[:-1], x2.shape[-1]), dw.to(ctx.pdt), db.to(ctx.pdt)
+        return dx.view(*dout.shape[:-1], x2.shape[-1]), _wgrad(d, x2).to(ctx.pdt), None
 
 
 class _MLP(torch.autograd.Function):
@@ -139,15 +143,13 @@ class _MLP(torch.autograd.Function):
         x2, h, w1_16, w2_16 = ctx.saved_tensors
         d = dy.reshape(-1, dy.shape[-1]).to(torch.bfloat16).contiguous()
         dh = _gemm(d, w2_16.t().contiguous(), mask=h)  # (d W2) * [h > 0]
-        dw2 = _wgrad(d, h).to(ctx.pdt)
-        db2 = d.sum(0, dtype=torch.float32).to(ctx.pdt)
+        dw2, db2 = _wgrad(d, h, with_bias=True)
         dx = _gemm(dh, w1_16.t().contiguous())
-        dw1 = _wgrad(dh, x2).to(ctx.pdt)
-        db1 = dh.sum(0, dtype=torch.float32).to(ctx.pdt)
-        return dx.view(*dy.shape[:-1], x2.shape[-1]), dw1, db1, dw2, db2
+        dw1, db1 = _wgrad(dh, x2, with_bias=True)
+        return (dx.view(*dy.shape[:-1], x2.shape[-1]), dw1.to(ctx.pdt), db1.to(ctx.pdt), dw2.to(ctx.pdt), db2.to(ctx.pdt))
 
 
-def linear(x: Tensor, weight: Tensor, bias: Tensor) -> Tensor:
+def linear(x: Tensor, weight: Tensor, bias: Tensor | None) -> Tensor:
     return _Linear.apply(x, weight, bias)
 
 
