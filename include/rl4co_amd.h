@@ -365,6 +365,18 @@ int rl4co_wgrad_bf16(const void* dy, const void* x, int64_t M, int N, int K, int
                      float* partial_bias, void* stream);
 
 /* --------------------------------------------------------------------------
+ * a12 (training)  encoder self-attention on the packed projection output
+ *   rl4co/models/nn/attention.py:110-134 (rearrange to heads + scaled_dot_product_attention)
+ * qkv [B,N,384] bf16 = per node (q | k | v), each 8 heads x 16 dims. forward: out [B,N,128] bf16
+ * (heads concatenated) and lse [B,8,N] fp32 (log2-domain log-sum-exp of the scaled scores);
+ * backward: dqkv [B,N,384] bf16 from dout [B,N,128]. N <= rl4co_attn_max_nodes().
+ * -------------------------------------------------------------------------- */
+int rl4co_attn_fwd_bf16(const void* qkv, int B, int N, void* out, float* lse, void* stream);
+int rl4co_attn_bwd_bf16(const void* qkv, const void* dout, const float* lse, int B, int N, void* dqkv,
+                        void* stream);
+int rl4co_attn_max_nodes(void);
+
+/* --------------------------------------------------------------------------
  * a19  select_start_nodes        rl4co/utils/ops.py:128-161
  * out[s*B + b] = s % num_loc (+1 for depot environments), s-major.
  * -------------------------------------------------------------------------- */

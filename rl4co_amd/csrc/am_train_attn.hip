@@ -1,0 +1,250 @@
+// am_train_attn.hip — encoder self-attention for training, forward and backward, straight on the
+// packed projection output (nn/attention.py:64-134 MultiHeadAttention).
+//
+// The reference computes qkv = Wqkv(x), rearranges it to [3, B, heads, N, 16] and calls
+// scaled_dot_product_attention. At N ~ 100 nodes and 16 dims per head the library flash kernels
+// are launch- and layout-bound (forward 0.44 ms, backward 1.25 ms per layer at 4096 x 100, plus
+// the cat that re-packs dq / dk / dv into d qkv). Here one 512-thread workgroup owns one instance:
+// its [N, 384] qkv rows sit in LDS once, wave h owns head h, and everything runs on
+// v_mfma_f32_16x16x16_bf16 in the layout am_teacher_mma.hip uses — the QUERY is the accumulator
+// column, so the softmax over keys is in-lane plus two row-group exchanges and probabilities chain
+// into the value product without a shuffle; products that contract over keys or over queries read
+// the same LDS rows through ds_read_b64_tr_b16.
+//
+//   forward   S^T = K_h Q_h^T / 4 ; P = softmax_keys ; O_h^T = V_h^T P^T      -> out [B,N,128], L = log-sum-exp [B,8,N]
+//   backward  P = exp(S - L) ; dP^T = V_h dO_h^T ; D = sum_keys P dP ; dS = P (dP - D)
+//             dQ_h^T = K_h^T dS^T / 4 ; dK_h^T += Q_h^T dS / 4 ; dV_h^T += dO_h^T P   -> d qkv [B,N,384]
+//
+// bf16 operands, fp32 accumulation and softmax; tolerance-tested against torch SDPA.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kD = RL4CO_EMBED_DIM;
+constexpr int kQS = 3 * kD + 8;  // LDS row stride of the qkv tile (bf16)
+constexpr int kOS = kD + 8;      // LDS row stride of 128-wide tiles
+constexpr int kWaves = 8;
+constexpr int kThreads = 64 * kWaves;
+constexpr float kNegInf = -__builtin_huge_valf();
+constexpr float kScale = 0.25f * 1.44269504088896341f;  // 1/sqrt(16) in the exp2 domain
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ inline f32x4 mfma16(const bf16x4& a, const bf16x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+__device__ inline f32x4 zero4() { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+__device__ inline bf16x4 lds_b64(const __bf16* p) { return *reinterpret_cast<const bf16x4*>(p); }
+__device__ inline bf16x4 lds_tr(const __bf16* p) {
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+  return __builtin_bit_cast(bf16x4, v);
+}
+__device__ inline bf16x4 to_bf16(const f32x4& v) {
+  bf16x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+  return o;
+}
+__device__ inline void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ inline float rg_sum(float v) { return rl4co::bfly_sum<16, 64>(v); }
+__device__ inline float rg_max(float v) { return rl4co::bfly_max<16, 64>(v); }
+
+// rows [0, 16 NT) x `cols` bf16 columns of an instance -> LDS (rows >= N zero)
+template <int NT>
+__device__ inline void stage_rows(const uint16_t* __restrict__ src, int N, int cols, __bf16* dst, int stride, int tid) {
+  const int cpr = cols / 8;  // 16-byte chunks per row
+  for (int c = tid; c < NT * 16 * cpr; c += kThreads) {
+    const int row = c / cpr, col = (c % cpr) * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < N) v = *reinterpret_cast<const uint4*>(src + (int64_t)row * cols + col);
+    *reinterpret_cast<uint4*>(dst + row * stride + col) = v;
+  }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(kThreads, 2) attn_fwd_kernel(const uint16_t* __restrict__ qkv, int N, uint16_t* __restrict__ out,
+                                                               float* __restrict__ lse) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __bf16* qs = reinterpret_cast<__bf16*>(smem);  // [16 NT][kQS]: q | k | v of every node
+  const int tid = threadIdx.x, h = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
+  const int64_t inst = blockIdx.x;
+  stage_rows<NT>(qkv + inst * N * 3 * kD, N, 3 * kD, qs, kQS, tid);
+  __syncthreads();
+  const int nao = tl * kQS + 4 * g;
+  const int tro = (4 * g + (tl >> 2)) * kQS + 4 * (tl & 3);
+  for (int tb = 0; tb < NT; ++tb) {
+    const int t = 16 * tb + tl;
+    const bf16x4 qf = lds_b64(qs + 16 * tb * kQS + 16 * h + nao);
+    f32x4 sc[NT];
+    float m = kNegInf;
+#pragma clang loop unroll(full)
+    for (int jt = 0; jt < NT; ++jt) {
+      sc[jt] = mfma16(lds_b64(qs + 16 * jt * kQS + kD + 16 * h + nao), qf, zero4());
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        sc[jt][rr] = (16 * jt + 4 * g + rr < N) ? sc[jt][rr] * kScale : kNegInf;
+        m = fmaxf(m, sc[jt][rr]);
+      }
+    }
+    m = rg_max(m);
+    float l = 0.0f;
+    f32x4 o0 = zero4(), o1 = zero4();
+#pragma clang loop unroll(full)
+    for (int jt = 0; jt < NT; ++jt) {
+      bf16x4 pf;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const float p = __builtin_amdgcn_exp2f(sc[jt][rr] - m);
+        l += p;
+        pf[rr] = (__bf16)p;
+      }
+      const bf16x4 vf = lds_tr(qs + 16 * jt * kQS + 2 * kD + 16 * h + tro);
+      if (jt & 1) o1 = mfma16(vf, pf, o1);
+      else o0 = mfma16(vf, pf, o0);
+    }
+    l = rg_sum(l);
+    const float inv = __builtin_amdgcn_rcpf(l);
+    if (t < N) {
+      f32x4 o;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) o[rr] = (o0[rr] + o1[rr]) * inv;
+      *reinterpret_cast<bf16x4*>(out + (inst * N + t) * kD + 16 * h + 4 * g) = to_bf16(o);
+      if (g == 0) lse[(inst * kWaves + h) * N + t] = m + __builtin_amdgcn_logf(l);  // log2 domain
+    }
+  }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(kThreads, 2) attn_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+                                                               const float* __restrict__ lse, int N, uint16_t* __restrict__ dqkv) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __bf16* qs = reinterpret_cast<__bf16*>(smem);                   // [16 NT][kQS]
+  __bf16* dos = qs + NT * 16 * kQS;                                // [16 NT][kOS] d out
+  const int tid = threadIdx.x, h = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
+  __bf16* pbw = dos + NT * 16 * kOS + h * 16 * kOS;                // this wave's [16 queries][kOS] P, then dS
+  const int64_t inst = blockIdx.x;
+  stage_rows<NT>(qkv + inst * N * 3 * kD, N, 3 * kD, qs, kQS, tid);
+  stage_rows<NT>(dout + inst * N * kD, N, kD, dos, kOS, tid);
+  __syncthreads();
+  const int nao = tl * kQS + 4 * g, nao_o = tl * kOS + 4 * g;
+  const int tro = (4 * g + (tl >> 2)) * kQS + 4 * (tl & 3), tro_o = (4 * g + (tl >> 2)) * kOS + 4 * (tl & 3);
+  f32x4 dk[NT], dv[NT];  // [d = 4 g + r of head h][key 16 jt + (lane & 15)]
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+    dk[jt] = zero4();
+    dv[jt] = zero4();
+  }
+  for (int tb = 0; tb < NT; ++tb) {
+    const int t = 16 * tb + tl;
+    const bool tv = t < N;
+    const bf16x4 qf = lds_b64(qs + 16 * tb * kQS + 16 * h + nao);
+    const bf16x4 dof = lds_b64(dos + 16 * tb * kOS + 16 * h + nao_o);
+    const float L = tv ? lse[(inst * kWaves + h) * N + t] : 0.0f;
+    bf16x4 pf[NT];
+    f32x4 dp[NT];
+    float dsum = 0.0f;
+#pragma clang loop unroll(full)
+    for (int jt = 0; jt < NT; ++jt) {
+      const f32x4 s = mfma16(lds_b64(qs + 16 * jt * kQS + kD + 16 * h + nao), qf, zero4());
+      dp[jt] = mfma16(lds_b64(qs + 16 * jt * kQS + 2 * kD + 16 * h + nao), dof, zero4());
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const bool ok = tv && (16 * jt + 4 * g + rr < N);
+        const float p = ok ? __builtin_amdgcn_exp2f(s[rr] * kScale - L) : 0.0f;
+        pf[jt][rr] = (__bf16)p;
+        dsum = fmaf((float)pf[jt][rr], dp[jt][rr], dsum);
+      }
+      *reinterpret_cast<bf16x4*>(pbw + tl * kOS + 16 * jt + 4 * g) = pf[jt];
+    }
+    dsum = rg_sum(dsum);
+    wave_lds_sync();
+    {
+      const bf16x4 dt = lds_tr(dos + 16 * tb * kOS + 16 * h + tro_o);  // dO_h^T[d][queries]
+#pragma clang loop unroll(full)
+      for (int jt = 0; jt < NT; ++jt) dv[jt] = mfma16(dt, lds_tr(pbw + 16 * jt + tro_o), dv[jt]);
+    }
+    wave_lds_sync();  // the transpose reads of P are done: the block is reused for dS
+    f32x4 dq = zero4();
+#pragma clang loop unroll(full)
+    for (int jt = 0; jt < NT; ++jt) {
+      bf16x4 dsf;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) dsf[rr] = (__bf16)((float)pf[jt][rr] * (dp[jt][rr] - dsum));
+      *reinterpret_cast<bf16x4*>(pbw + tl * kOS + 16 * jt + 4 * g) = dsf;
+      dq = mfma16(lds_tr(qs + 16 * jt * kQS + kD + 16 * h + tro), dsf, dq);
+    }
+    wave_lds_sync();
+    {
+      const bf16x4 qt = lds_tr(qs + 16 * tb * kQS + 16 * h + tro);  // Q_h^T[d][queries]
+#pragma clang loop unroll(full)
+      for (int jt = 0; jt < NT; ++jt) dk[jt] = mfma16(qt, lds_tr(pbw + 16 * jt + tro_o), dk[jt]);
+    }
+    if (tv) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) dq[rr] *= 0.25f;
+      *reinterpret_cast<bf16x4*>(dqkv + (inst * N + t) * 3 * kD + 16 * h + 4 * g) = to_bf16(dq);
+    }
+    wave_lds_sync();  // the next query block rewrites this wave's staging block
+  }
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+    const int j = 16 * jt + tl;
+    if (j < N) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) dk[jt][rr] *= 0.25f;
+      uint16_t* row = dqkv + (inst * N + j) * 3 * kD + 16 * h + 4 * g;
+      *reinterpret_cast<bf16x4*>(row + kD) = to_bf16(dk[jt]);
+      *reinterpret_cast<bf16x4*>(row + 2 * kD) = to_bf16(dv[jt]);
+    }
+  }
+}
+
+template <int NT>
+int launch_fwd(const void* qkv, int B, int N, void* out, float* lse, hipStream_t s) {
+  const int lds = NT * 16 * kQS * 2;
+  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL(attn_fwd_kernel<NT>, dim3(B), dim3(kThreads), lds, s, static_cast<const uint16_t*>(qkv), N,
+                     static_cast<uint16_t*>(out), lse);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+template <int NT>
+int launch_bwd(const void* qkv, const void* dout, const float* lse, int B, int N, void* dqkv, hipStream_t s) {
+  const int lds = (NT * 16 * kQS + NT * 16 * kOS + kWaves * 16 * kOS) * 2;
+  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL(attn_bwd_kernel<NT>, dim3(B), dim3(kThreads), lds, s, static_cast<const uint16_t*>(qkv),
+                     static_cast<const uint16_t*>(dout), lse, N, static_cast<uint16_t*>(dqkv));
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
+}  // namespace
+
+extern "C" int rl4co_attn_max_nodes(void) { return 112; }
+
+extern "C" int rl4co_attn_fwd_bf16(const void* qkv, int B, int N, void* out, float* lse, void* stream) {
+  RL4CO_REQUIRE(qkv && out && lse && B > 0 && N >= 1 && N <= 112);
+  hipStream_t s = rl4co::as_stream(stream);
+  const int nt = (N + 15) >> 4;
+  if (nt <= 2) return launch_fwd<2>(qkv, B, N, out, lse, s);
+  if (nt <= 4) return launch_fwd<4>(qkv, B, N, out, lse, s);
+  return launch_fwd<7>(qkv, B, N, out, lse, s);
+}
+
+extern "C" int rl4co_attn_bwd_bf16(const void* qkv, const void* dout, const float* lse, int B, int N, void* dqkv, void* stream) {
+  RL4CO_REQUIRE(qkv && dout && lse && dqkv && B > 0 && N >= 1 && N <= 112);
+  hipStream_t s = rl4co::as_stream(stream);
+  const int nt = (N + 15) >> 4;
+  if (nt <= 2) return launch_bwd<2>(qkv, dout, lse, B, N, dqkv, s);
+  if (nt <= 4) return launch_bwd<4>(qkv, dout, lse, B, N, dqkv, s);
+  return launch_bwd<7>(qkv, dout, lse, B, N, dqkv, s);
+}

@@ -96,7 +96,10 @@ class _SelfAttention(nn.Module):
         if fused:  # training under bf16 autocast: the two projections on csrc/am_train_ops.hip
             from . import train_ops
 
-            qkv = train_ops.linear(x, self.Wqkv.weight, self.Wqkv.bias).view(b, n, 3, self.num_heads, d // self.num_heads)
+            qkv = train_ops.linear(x, self.Wqkv.weight, self.Wqkv.bias)
+            if self.num_heads == 8 and train_ops.attention_usable(qkv):
+                return train_ops.linear(train_ops.attention(qkv), self.out_proj.weight, self.out_proj.bias)
+            qkv = qkv.view(b, n, 3, self.num_heads, d // self.num_heads)
         else:
             qkv = self.Wqkv(x).view(b, n, 3, self.num_heads, d // self.num_heads)
         q, k, v = qkv.permute(2, 0, 3, 1, 4).unbind(0)

@@ -155,3 +155,41 @@ def linear(x: Tensor, weight: Tensor, bias: Tensor | None) -> Tensor:
 
 def mlp(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor) -> Tensor:
     return _MLP.apply(x, w1, b1, w2, b2)
+
+
+# ---------------------------------------------------------------------------------------------------
+# encoder self-attention on the packed qkv rows (csrc/am_train_attn.hip)
+# ---------------------------------------------------------------------------------------------------
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv: Tensor):
+        b, n, _ = qkv.shape
+        q = qkv.contiguous()
+        out = torch.empty((b, n, EMBED_DIM), dtype=torch.bfloat16, device=qkv.device)
+        lse = torch.empty((b, 8, n), dtype=torch.float32, device=qkv.device)
+        st = _lib.lib().rl4co_attn_fwd_bf16(q.data_ptr(), b, n, out.data_ptr(), lse.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "rl4co_attn_fwd_bf16")
+        ctx.save_for_backward(q, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        q, lse = ctx.saved_tensors
+        b, n, _ = q.shape
+        d = dout.to(torch.bfloat16).contiguous()
+        dqkv = torch.empty_like(q)
+        st = _lib.lib().rl4co_attn_bwd_bf16(q.data_ptr(), d.data_ptr(), lse.data_ptr(), b, n, dqkv.data_ptr(),
+                                            torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "rl4co_attn_bwd_bf16")
+        return dqkv
+
+
+def attention_usable(qkv: Tensor) -> bool:
+    return (qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.dim() == 3 and qkv.shape[-1] == 3 * EMBED_DIM
+            and qkv.shape[1] <= _lib.lib().rl4co_attn_max_nodes())
+
+
+def attention(qkv: Tensor) -> Tensor:
+    """softmax(q k^T / 4) v per head on qkv [B,N,384] (q | k | v, 8 heads x 16) -> [B,N,128]."""
+    return _Attention.apply(qkv)

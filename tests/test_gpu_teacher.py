@@ -225,3 +225,29 @@ def test_fused_linear_and_mlp_gradients_match_torch():
     for a, r, nm in zip(gk, gr, ("dx", "dw", "db")):
         rel = float((a.float() - r).norm() / r.norm())
         assert rel <= 2e-2, (nm, rel)
+
+
+@pytest.mark.parametrize("n", [20, 50, 100, 101, 112])
+def test_fused_attention_matches_torch_sdpa(n):
+    """csrc/am_train_attn.hip forward / backward vs torch SDPA in fp32 on the same bf16 qkv: output within
+    1.5e-2 absolute (bf16 output, bf16 softmax numerators), d qkv within 3e-2 relative Frobenius error."""
+    import torch.nn.functional as F
+
+    from rl4co_amd import train_ops
+
+    torch.manual_seed(n)
+    b = 32
+    qkv = torch.randn(b, n, 384, device="cuda").to(torch.bfloat16)
+    go = torch.randn(b, n, 128, device="cuda").to(torch.bfloat16)
+    assert train_ops.attention_usable(qkv)
+    qk = qkv.clone().requires_grad_(True)
+    out = train_ops.attention(qk)
+    (gk,) = torch.autograd.grad(out, [qk], go)
+    qr = qkv.float().requires_grad_(True)
+    q, k, v = qr.view(b, n, 3, 8, 16).permute(2, 0, 3, 1, 4).unbind(0)
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(b, n, 128)
+    (gr,) = torch.autograd.grad(ref, [qr], go.float())
+    torch.testing.assert_close(out.detach().float(), ref.detach(), rtol=1.6e-2, atol=1.5e-2)
+    for name, sl in (("dq", slice(0, 128)), ("dk", slice(128, 256)), ("dv", slice(256, 384))):
+        rel = float((gk[..., sl].float() - gr[..., sl]).norm() / gr[..., sl].norm())
+        assert rel <= 3e-2, (name, rel)
