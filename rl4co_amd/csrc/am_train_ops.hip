@@ -211,77 +211,103 @@ __global__ void __launch_bounds__(kGemmThreads, 2) linear_bf16_kernel(const uint
                                                                       int M, int N, int K, int relu, uint16_t* __restrict__ out) {
   extern __shared__ __align__(16) unsigned char smem_g[];
   __bf16* as = reinterpret_cast<__bf16*>(smem_g);  // [128 tokens][kLS]
-  __bf16* ws = as + kTM * kLS;                       // [128 features][kLS]; reused as the output tile
+  __bf16* ws = as + kTM * kLS;                       // [128 features][kLS]
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int64_t m0 = (int64_t)blockIdx.x * kTM;
-  const int nkc = K / kTK, nnt = N / kTN;
-
-  for (int nt = 0; nt < nnt; ++nt) {
-    f32x16 acc[4];  // [feature tile ct][feature 32 ct + rowmap(r, hi)], token 32 w + l31
+  const int nkc = K / kTK, nnt = N / kTN, steps = nnt * nkc;
+  // a step = (feature tile nt, contraction chunk kc). The operands of step i + 1 are fetched into
+  // registers while the MFMAs of step i run; the token chunk is re-fetched only when it changes.
+  const int srow = tid >> 4, scol = (tid & 15) * 8;  // this thread stages rows srow + 16 j, 16 bytes at scol
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // a plain vector: an array of HIP's uint4 struct goes to scratch
+  u32x4 pa[8], pw[8];
+#define RL4CO_FETCH(STEP, WITH_A)                                                                              \
+  {                                                                                                            \
+    const int nt_ = (STEP) / nkc, kc_ = (STEP) % nkc;                                                          \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                            \
+      const int64_t row_ = min(m0 + srow + 16 * j, (int64_t)M - 1); /* rows past M: computed, never stored */   \
+      if (WITH_A) pa[j] = *reinterpret_cast<const u32x4*>(A + row_ * K + kc_ * kTK + scol);                    \
+      pw[j] = *reinterpret_cast<const u32x4*>(W + (int64_t)(nt_ * kTN + srow + 16 * j) * K + kc_ * kTK + scol); \
+    }                                                                                                          \
+  }
+#define RL4CO_COMMIT(WITH_A)                                                                        \
+  {                                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                 \
+      if (WITH_A) *reinterpret_cast<u32x4*>(as + (srow + 16 * j) * kLS + scol) = pa[j];             \
+      *reinterpret_cast<u32x4*>(ws + (srow + 16 * j) * kLS + scol) = pw[j];                         \
+    }                                                                                               \
+  }
+  RL4CO_FETCH(0, true)
+  RL4CO_COMMIT(true)
+  __syncthreads();
+  f32x16 acc[4];  // [feature tile ct][feature 32 ct + rowmap(r, hi)], token 32 w + l31
+  for (int step = 0; step < steps; ++step) {
+    const int nt = step / nkc, kc = step % nkc;
+    const bool more = step + 1 < steps, next_a = nkc > 1;  // K = 128: the token chunk never changes
+    if (more) RL4CO_FETCH(step + 1, next_a)
+    if (kc == 0) {
 #pragma unroll
-    for (int ct = 0; ct < 4; ++ct)
+      for (int ct = 0; ct < 4; ++ct)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
-    for (int kc = 0; kc < nkc; ++kc) {
-      __syncthreads();  // previous chunk / output tile fully consumed
-      if (nkc > 1 || nt == 0) {
-        for (int c = tid; c < kTM * 16; c += kGemmThreads) {
-          const int row = c >> 4, col = (c & 15) * 8;
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if (m0 + row < M) v = *reinterpret_cast<const uint4*>(A + (m0 + row) * K + kc * kTK + col);
-          *reinterpret_cast<uint4*>(as + row * kLS + col) = v;
-        }
+        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
+    }
+#pragma unroll
+    for (int ks = 0; ks < kTK / 16; ++ks) {
+      const bf16x8 tok = *reinterpret_cast<const bf16x8*>(as + (32 * w + l31) * kLS + 16 * ks + 8 * hi);
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        const bf16x8 feat = *reinterpret_cast<const bf16x8*>(ws + (32 * ct + l31) * kLS + 16 * ks + 8 * hi);
+        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(feat, tok, acc[ct], 0, 0, 0);
       }
-      for (int c = tid; c < kTN * 16; c += kGemmThreads) {
-        const int row = c >> 4, col = (c & 15) * 8;
-        *reinterpret_cast<uint4*>(ws + row * kLS + col) =
-            *reinterpret_cast<const uint4*>(W + (int64_t)(nt * kTN + row) * K + kc * kTK + col);
-      }
-      __syncthreads();
-#pragma unroll
-      for (int ks = 0; ks < kTK / 16; ++ks) {
-        const bf16x8 tok = *reinterpret_cast<const bf16x8*>(as + (32 * w + l31) * kLS + 16 * ks + 8 * hi);
+    }
+    if (kc == nkc - 1) {
+      // epilogue straight from the accumulators: a lane holds four consecutive features of its
+      // token (8-byte stores; the 256-byte row segments of a tile merge in L2)
+      const int64_t row = m0 + 32 * w + l31;
+      if (row < M) {
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
-          const bf16x8 feat = *reinterpret_cast<const bf16x8*>(ws + (32 * ct + l31) * kLS + 16 * ks + 8 * hi);
-          acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(feat, tok, acc[ct], 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int f0 = nt * kTN + 32 * ct + 8 * q + 4 * hi;
+            float v[4];
+            if (bias) {
+              const float4 b4 = *reinterpret_cast<const float4*>(bias + f0);
+              v[0] = acc[ct][4 * q] + b4.x;
+              v[1] = acc[ct][4 * q + 1] + b4.y;
+              v[2] = acc[ct][4 * q + 2] + b4.z;
+              v[3] = acc[ct][4 * q + 3] + b4.w;
+            } else {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) v[i] = acc[ct][4 * q + i];
+            }
+            if (relu) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
+            }
+            if (mask) {
+              const uint2 mk = *reinterpret_cast<const uint2*>(mask + row * N + f0);
+              // bf16 > 0  <=>  sign bit clear and magnitude non-zero
+              v[0] = ((mk.x & 0x8000u) == 0 && (mk.x & 0x7fffu) != 0) ? v[0] : 0.0f;
+              v[1] = ((mk.x >> 31) == 0 && (mk.x & 0x7fff0000u) != 0) ? v[1] : 0.0f;
+              v[2] = ((mk.y & 0x8000u) == 0 && (mk.y & 0x7fffu) != 0) ? v[2] : 0.0f;
+              v[3] = ((mk.y >> 31) == 0 && (mk.y & 0x7fff0000u) != 0) ? v[3] : 0.0f;
+            }
+            bf16x4g o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+            *reinterpret_cast<bf16x4g*>(out + row * N + f0) = o;
+          }
         }
       }
     }
-    __syncthreads();  // every wave is done reading ws: it becomes the [token][feature] output tile
-    const int64_t row = m0 + 32 * w + l31;
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int f0 = 32 * ct + 8 * q + 4 * hi;  // four consecutive features
-        float v[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          v[i] = acc[ct][4 * q + i] + (bias ? bias[nt * kTN + f0 + i] : 0.0f);
-          if (relu) v[i] = fmaxf(v[i], 0.0f);
-        }
-        if (mask && row < M) {
-          const uint2 mk = *reinterpret_cast<const uint2*>(mask + row * N + nt * kTN + f0);
-          // bf16 > 0  <=>  sign bit clear and magnitude non-zero
-          v[0] = ((mk.x & 0x8000u) == 0 && (mk.x & 0x7fffu) != 0) ? v[0] : 0.0f;
-          v[1] = ((mk.x >> 31) == 0 && (mk.x & 0x7fff0000u) != 0) ? v[1] : 0.0f;
-          v[2] = ((mk.y & 0x8000u) == 0 && (mk.y & 0x7fffu) != 0) ? v[2] : 0.0f;
-          v[3] = ((mk.y >> 31) == 0 && (mk.y & 0x7fff0000u) != 0) ? v[3] : 0.0f;
-        }
-        bf16x4g o;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
-        *reinterpret_cast<bf16x4g*>(ws + (32 * w + l31) * kLS + f0) = o;
-      }
-    }
-    __syncthreads();
-    for (int c = tid; c < kTM * 16; c += kGemmThreads) {
-      const int r = c >> 4, col = (c & 15) * 8;
-      if (m0 + r < M)
-        *reinterpret_cast<uint4*>(out + (m0 + r) * N + nt * kTN + col) = *reinterpret_cast<const uint4*>(ws + r * kLS + col);
+    if (more) {
+      __syncthreads();  // every wave is done with this step's LDS operands
+      RL4CO_COMMIT(next_a)
+      __syncthreads();
     }
   }
+#undef RL4CO_FETCH
+#undef RL4CO_COMMIT
 }
 
 }  // namespace
