@@ -316,7 +316,7 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
         *reinterpret_cast<bf16x4*>(sh.hs + (16 * c + tl) * kRS + dcol) = of;
       }
     }
-    __syncthreads();  // B1
+    rl4co::lds_barrier();  // B1 (LDS only: parked stores stay in flight)
 
     // ---- 3. logits of node tile w, local log-softmax / selection pieces ------------------------------------
     if (w < NT) {
@@ -408,7 +408,7 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
         }
       }
     }
-    __syncthreads();  // B2
+    rl4co::lds_barrier();  // B2
 
     // ---- 4. every lane: finish the selection of its trajectory, transition ------------------------------
     // row group g folds node tiles g and g + 4, then the row groups meet in two butterfly steps

@@ -278,6 +278,9 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
       for (int e = 0; e < 4; ++e) f4[e] = ctxf[(int64_t)first * kD + e];
     }
     const int ntb = (t_end + 15) >> 4;
+    // context row of this lane's step, fetched one step block ahead (an L2 round trip otherwise
+    // opens every block's dependency chain)
+    float4 c4n = *reinterpret_cast<const float4*>(ctxc + (int64_t)(tl == 0 ? 0 : sact[tl - 1]) * kD);
 
     for (int tb = 0; tb < ntb; ++tb) {
       const int t = 16 * tb + tl;  // this lane's column (same in the four row groups)
@@ -292,8 +295,9 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
       // ---- 0. query of head h for the block's 16 steps (context.py:105-149, decoder.py:135-136) --
       bf16x4 qf;
       {
-        const float4 c4 = *reinterpret_cast<const float4*>(ctxc + (int64_t)cur * kD);
+        const float4 c4 = c4n;
         const float c[4] = {c4.x, c4.y, c4.z, c4.w};
+        c4n = *reinterpret_cast<const float4*>(ctxc + (int64_t)sact[min(t + 15, kMaxT - 1)] * kD);  // cur of step t + 16
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float q;
@@ -350,7 +354,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
         for (int rr = 0; rr < 4; ++rr) o[rr] *= inv_l;
         *reinterpret_cast<bf16x4*>(ob + tl * kRS + dcol) = to_bf16(o);
       }
-      __syncthreads();  // B1: all heads' glimpses
+      rl4co::lds_barrier();  // B1: all heads' glimpses
 
       // ---- 3. logits of node tile w, clip, log-softmax pieces (attention.py:291-293, decoding.py:169-188)
       float z[4], dzdu[4];
@@ -402,7 +406,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
           xz[(w * 16 + tl) * 2 + 1] = (zmax > kNegInf) ? se : 0.0f;
         }
       }
-      __syncthreads();  // B2: log-sum-exp pieces of all node tiles
+      rl4co::lds_barrier();  // B2: log-sum-exp pieces of all node tiles
       {
         float zm = kNegInf;
 #pragma unroll
@@ -434,7 +438,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
           *reinterpret_cast<bf16x4*>(dub + tl * kRS + 16 * w + 4 * g) = to_bf16(du);
         }
       }
-      __syncthreads();  // B3: d logits of all node tiles
+      rl4co::lds_barrier();  // B3: d logits of all node tiles
 
       // ---- 4. d glimpse of head h, d logit keys ----------------------------------------------------------
       bf16x4 dof;
@@ -515,7 +519,8 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
           }
         }
       }
-      __syncthreads();  // B4: the glimpse / d-logit blocks are rewritten by the next step block
+      rl4co::lds_barrier();  // B4: the glimpse / d-logit blocks are rewritten by the next step block (LDS only:
+                             // the context-row atomics stay in flight)
     }
 
     // d ctx_first: one row per trajectory (every step after the first reads h[first])

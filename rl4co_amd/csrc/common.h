@@ -34,6 +34,14 @@ int launch_teacher_mma(const rl4co_am_teacher_args& a, hipStream_t stream);
 int teacher_mma_max_nodes();
 int teacher_mma_max_steps();
 
+// Workgroup barrier for LDS hand-offs only. __syncthreads() waits for EVERY outstanding memory
+// operation (s_waitcnt vmcnt(0) lgkmcnt(0)) before s_barrier, which puts the L2 round trip of any
+// in-flight global store / atomic / prefetch in front of each barrier; kernels that meet several
+// times per step on LDS data only need their LDS traffic drained.
+__device__ inline void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Wave-wide (64-lane) butterfly partner fetch WITHOUT the LDS crossbar: ds_bpermute (what
 // __shfl_xor compiles to) costs an LDS round trip (~100+ cycles) per step and the decode kernels
 // run dependent chains of them; DPP modifiers and the gfx950 permlane swaps are plain VALU ops.

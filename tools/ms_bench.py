@@ -19,8 +19,8 @@ with torch.inference_mode():
         times = []
         for it in range(4):
             st = pol._initial_state(td, S)
-            actions = torch.zeros(B * S, 128, dtype=torch.int64, device="cuda")
-            logps = torch.zeros(B * S, 128, device="cuda")
+            actions = torch.zeros(B * S, 100, dtype=torch.int64, device="cuda")
+            logps = torch.zeros(B * S, 100, device="cuda")
             err = K.new_error_word("cuda")
             first = env.select_start_nodes(td, S)
             actions[:, 0] = first
@@ -36,6 +36,3 @@ with torch.inference_mode():
         print(f"B={B} S={S} {MODE} {variant}: {ms:.3f} ms ({B*S*99/ms/1e3:.1f} M trajectory-steps/s, "
               f"{B*S*99*78040/ms/1e6:.0f} GB/s algorithmic per-trajectory bytes)")
 
-        if __import__("os").environ.get("PROF"):
-            for w in range(8):
-                print("wave", w, [int(x) for x in logps[w, 110:116].tolist()], "cycles: stage12, B1 wait, stage3, B2 wait, stage4, loop head")

@@ -31,3 +31,4 @@ for variant in ("replay", "mma"):
         e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1)
     print(f"teacher backward [{variant}] B={B} S={S} N={N}: {ms:.2f} ms  ({steps/ms/1e3:.1f} M trajectory-steps/s)")
+
