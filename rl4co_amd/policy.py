@@ -135,13 +135,14 @@ class _EncoderLayer(nn.Sequential):
         ffn = _FeedForward(embed_dim, feedforward_hidden)
         attn = _SelfAttention(embed_dim, num_heads)
         super().__init__(_Skip(attn), _Norm(embed_dim, normalization), _Skip(ffn), _Norm(embed_dim, normalization))
-        self.fused_linear = True  # training: projections / MLP on the HIP GEMM (False: library GEMMs)
+        self.fused_linear = True  # training: projections / MLP / attention on the HIP kernels (False: library)
+        self.fused_train = True   # training under bf16 autocast: skip + norm (and the above) on HIP kernels
 
     def forward(self, x):
         # training under bf16 autocast with instance norm (the POMO recipe): skip + norm as one HIP
         # kernel forward and one backward (csrc/am_train_ops.hip) instead of autograd's elementwise chain
-        if (self.training and torch.is_grad_enabled() and x.is_cuda and self[1].kind == "instance"
-                and torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16):
+        if (self.fused_train and self.training and torch.is_grad_enabled() and x.is_cuda and self[1].kind == "instance"
+                and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16):
             from . import train_ops
 
             x = x.to(torch.bfloat16)
