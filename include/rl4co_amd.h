@@ -348,6 +348,22 @@ int rl4co_skip_inorm_bwd_bf16(const void* dout, const void* y, const float* gamm
 int rl4co_skip_inorm_max_nodes(void);
 
 /* --------------------------------------------------------------------------
+ * a12 (training)  SkipConnection + Normalization("batch") — the AttentionModel default
+ *   rl4co/models/nn/ops.py:9-15,30-54 ; zoo/am/policy.py:50-122
+ * BatchNorm1d over the M = B x nodes rows of bf16 [M,128] activations, batch statistics:
+ *   stats : y = x + s (s may be NULL: y is not written, statistics of x);
+ *           sums[0][c] += sum_m y, sums[1][c] += sum_m y^2      (fp32 [2,128], zero-initialised)
+ *   apply : out = (y - mean) * rstd * gamma + beta               (mean / rstd from the host)
+ *   bwd   : sums[0][c] += sum dout, sums[1][c] += sum dout * xh  (zero-initialised), then
+ *           dy = rstd gamma (dout - sums[0]/M - xh sums[1]/M); sums[1] = dgamma, sums[0] = dbeta.
+ * -------------------------------------------------------------------------- */
+int rl4co_skip_bnorm_stats_bf16(const void* x, const void* s, int64_t M, void* y, float* sums, void* stream);
+int rl4co_bnorm_apply_bf16(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                           int64_t M, void* out, void* stream);
+int rl4co_bnorm_bwd_bf16(const void* dout, const void* y, const float* mean, const float* rstd, const float* gamma,
+                         int64_t M, float* sums, void* dy, void* stream);
+
+/* --------------------------------------------------------------------------
  * a12 (training)  nn.Linear over the token rows: Wqkv, out_proj, MLP
  *   rl4co/models/nn/attention.py:64-134 ; nn/mlp.py:52-61
  * out[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]); bf16 A, W, out, fp32 bias and accumulate.

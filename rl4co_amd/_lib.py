@@ -75,6 +75,9 @@ SYMBOLS = {
     "rl4co_skip_inorm_fwd_bf16": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "rl4co_skip_inorm_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "rl4co_skip_inorm_max_nodes": (C.c_int, []),
+    "rl4co_skip_bnorm_stats_bf16": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp]),
+    "rl4co_bnorm_apply_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp]),
+    "rl4co_bnorm_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
     "rl4co_linear_bf16": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_attn_fwd_bf16": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "rl4co_attn_bwd_bf16": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),

@@ -434,3 +434,162 @@ extern "C" int rl4co_wgrad_bf16(const void* dy, const void* x, int64_t M, int N,
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// SkipConnection + Normalization("batch") in training (the AttentionModel default,
+// nn/ops.py:30-54, zoo/am/policy.py:50-122): BatchNorm1d over the M = B x nodes token rows, i.e.
+// statistics ACROSS instances — two passes over HBM instead of one:
+//   stats    per-channel sum and sum of squared deviations of y = x + s (bf16-rounded, written)
+//            by a shifted two-term formula: partial sums per workgroup -> fp32 atomics [2][128]
+//   apply    out = (y - mean) rstd gamma + beta
+//   backward reduce: sum dout, sum dout * xh  -> [2][128] ; apply: dy = rstd gamma (dout - m1 - xh m2)
+// Running statistics are updated by the host wrapper exactly as nn.BatchNorm1d does.
+namespace {
+
+constexpr int kBnRows = 64;  // token rows per workgroup pass
+
+// y = x + s (optional), per-channel partial sums of y and y^2 in fp32 -> atomics. The variance is
+// formed as E[y^2] - mean^2 in fp32 from fp32 sums of bf16 values: with |mean| <~ sigma (post-skip
+// activations of a normalised residual stream) the cancellation costs < 1e-6 relative.
+__global__ void __launch_bounds__(256) bn_stats_kernel(const uint32_t* __restrict__ x, const uint32_t* __restrict__ s, int64_t M,
+                                                       uint32_t* __restrict__ y, float* __restrict__ sums) {
+  __shared__ float red[256 * 4];
+  const int tid = threadIdx.x, cp = tid & 63, q = tid >> 6;
+  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+  for (int64_t r0 = (int64_t)blockIdx.x * kBnRows; r0 < M; r0 += (int64_t)gridDim.x * kBnRows) {
+#pragma unroll 4
+    for (int i = 0; i < kBnRows / 4; ++i) {
+      const int64_t r = r0 + q + 4 * i;
+      if (r < M) {
+        const uint32_t xv = x[r * 64 + cp];
+        uint32_t ys = xv;
+        if (s) {
+          const uint32_t sv = s[r * 64 + cp];
+          ys = pack_bf16(bf16_lo(xv) + bf16_lo(sv), bf16_hi(xv) + bf16_hi(sv));
+          y[r * 64 + cp] = ys;
+        }
+        const float v0 = bf16_lo(ys), v1 = bf16_hi(ys);
+        a0 += v0;
+        a1 += v1;
+        b0 = fmaf(v0, v0, b0);
+        b1 = fmaf(v1, v1, b1);
+      }
+    }
+  }
+  red[tid * 4] = a0;
+  red[tid * 4 + 1] = a1;
+  red[tid * 4 + 2] = b0;
+  red[tid * 4 + 3] = b1;
+  __syncthreads();
+  if (q == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v = (red[cp * 4 + e] + red[(64 + cp) * 4 + e]) + (red[(128 + cp) * 4 + e] + red[(192 + cp) * 4 + e]);
+      // sums[0][c] = sum y, sums[1][c] = sum y^2, channels 2 cp + (e & 1)
+      unsafeAtomicAdd(sums + (e >> 1) * kD + 2 * cp + (e & 1), v);
+    }
+  }
+}
+
+// out = (y - mean) * rstd * gamma + beta
+__global__ void __launch_bounds__(256) bn_apply_kernel(const uint32_t* __restrict__ y, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int64_t M, uint32_t* __restrict__ out) {
+  const int tid = threadIdx.x, cp = tid & 63, q = tid >> 6;
+  const float m0 = mean[2 * cp], m1 = mean[2 * cp + 1];
+  const float k0 = rstd[2 * cp] * gamma[2 * cp], k1 = rstd[2 * cp + 1] * gamma[2 * cp + 1];
+  const float b0 = beta[2 * cp], b1 = beta[2 * cp + 1];
+  for (int64_t r = (int64_t)blockIdx.x * 4 + q; r < M; r += (int64_t)gridDim.x * 4) {
+    const uint32_t v = y[r * 64 + cp];
+    out[r * 64 + cp] = pack_bf16(fmaf(bf16_lo(v) - m0, k0, b0), fmaf(bf16_hi(v) - m1, k1, b1));
+  }
+}
+
+// sums[0][c] += sum dout ; sums[1][c] += sum dout * xh
+__global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const uint32_t* __restrict__ dout, const uint32_t* __restrict__ y,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd, int64_t M,
+                                                            float* __restrict__ sums) {
+  __shared__ float red[256 * 4];
+  const int tid = threadIdx.x, cp = tid & 63, q = tid >> 6;
+  const float m0 = mean[2 * cp], m1 = mean[2 * cp + 1], r0s = rstd[2 * cp], r1s = rstd[2 * cp + 1];
+  float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+  for (int64_t r0 = (int64_t)blockIdx.x * kBnRows; r0 < M; r0 += (int64_t)gridDim.x * kBnRows) {
+#pragma unroll 4
+    for (int i = 0; i < kBnRows / 4; ++i) {
+      const int64_t r = r0 + q + 4 * i;
+      if (r < M) {
+        const uint32_t d = dout[r * 64 + cp], v = y[r * 64 + cp];
+        const float d0 = bf16_lo(d), d1 = bf16_hi(d);
+        a0 += d0;
+        a1 += d1;
+        b0 = fmaf(d0, (bf16_lo(v) - m0) * r0s, b0);
+        b1 = fmaf(d1, (bf16_hi(v) - m1) * r1s, b1);
+      }
+    }
+  }
+  red[tid * 4] = a0;
+  red[tid * 4 + 1] = a1;
+  red[tid * 4 + 2] = b0;
+  red[tid * 4 + 3] = b1;
+  __syncthreads();
+  if (q == 0) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float v = (red[cp * 4 + e] + red[(64 + cp) * 4 + e]) + (red[(128 + cp) * 4 + e] + red[(192 + cp) * 4 + e]);
+      unsafeAtomicAdd(sums + (e >> 1) * kD + 2 * cp + (e & 1), v);
+    }
+  }
+}
+
+// dy = rstd * gamma * (dout - sums[0] / M - xh * sums[1] / M)
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const uint32_t* __restrict__ dout, const uint32_t* __restrict__ y,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ sums, int64_t M,
+                                                           uint32_t* __restrict__ dy) {
+  const int tid = threadIdx.x, cp = tid & 63, q = tid >> 6;
+  const float inv_m = 1.0f / (float)M;
+  const float m0 = mean[2 * cp], m1 = mean[2 * cp + 1], r0s = rstd[2 * cp], r1s = rstd[2 * cp + 1];
+  const float k0 = r0s * gamma[2 * cp], k1 = r1s * gamma[2 * cp + 1];
+  const float sd0 = sums[2 * cp] * inv_m, sd1 = sums[2 * cp + 1] * inv_m;
+  const float sx0 = sums[kD + 2 * cp] * inv_m, sx1 = sums[kD + 2 * cp + 1] * inv_m;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + q; r < M; r += (int64_t)gridDim.x * 4) {
+    const uint32_t d = dout[r * 64 + cp], v = y[r * 64 + cp];
+    const float x0 = (bf16_lo(v) - m0) * r0s, x1 = (bf16_hi(v) - m1) * r1s;
+    dy[r * 64 + cp] = pack_bf16(k0 * (bf16_lo(d) - sd0 - x0 * sx0), k1 * (bf16_hi(d) - sd1 - x1 * sx1));
+  }
+}
+
+}  // namespace
+
+extern "C" int rl4co_skip_bnorm_stats_bf16(const void* x, const void* s, int64_t M, void* y, float* sums, void* stream) {
+  RL4CO_REQUIRE(x && sums && M > 0 && (s == nullptr || y != nullptr));
+  const int blocks = (int)min((int64_t)2048, (M + kBnRows - 1) / kBnRows);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(256), 0, rl4co::as_stream(stream), static_cast<const uint32_t*>(x),
+                     static_cast<const uint32_t*>(s), M, static_cast<uint32_t*>(y), sums);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
+extern "C" int rl4co_bnorm_apply_bf16(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                                      int64_t M, void* out, void* stream) {
+  RL4CO_REQUIRE(y && mean && rstd && gamma && beta && out && M > 0);
+  const int blocks = (int)min((int64_t)8192, (M + 3) / 4);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, rl4co::as_stream(stream), static_cast<const uint32_t*>(y), mean,
+                     rstd, gamma, beta, M, static_cast<uint32_t*>(out));
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
+extern "C" int rl4co_bnorm_bwd_bf16(const void* dout, const void* y, const float* mean, const float* rstd, const float* gamma,
+                                    int64_t M, float* sums, void* dy, void* stream) {
+  RL4CO_REQUIRE(dout && y && mean && rstd && gamma && sums && dy && M > 0);
+  hipStream_t st = rl4co::as_stream(stream);
+  const int rb = (int)min((int64_t)2048, (M + kBnRows - 1) / kBnRows);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(rb), dim3(256), 0, st, static_cast<const uint32_t*>(dout),
+                     static_cast<const uint32_t*>(y), mean, rstd, M, sums);
+  const int ab = (int)min((int64_t)8192, (M + 3) / 4);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ab), dim3(256), 0, st, static_cast<const uint32_t*>(dout),
+                     static_cast<const uint32_t*>(y), mean, rstd, gamma, sums, M, static_cast<uint32_t*>(dy));
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}

@@ -139,9 +139,10 @@ class _EncoderLayer(nn.Sequential):
         self.fused_train = True   # training under bf16 autocast: skip + norm (and the above) on HIP kernels
 
     def forward(self, x):
-        # training under bf16 autocast with instance norm (the POMO recipe): skip + norm as one HIP
-        # kernel forward and one backward (csrc/am_train_ops.hip) instead of autograd's elementwise chain
-        if (self.fused_train and self.training and torch.is_grad_enabled() and x.is_cuda and self[1].kind == "instance"
+        # training under bf16 autocast: projections, MLP, attention and skip + norm (instance: one kernel
+        # each way; batch: statistics + apply) on csrc/am_train_ops.hip / am_train_attn.hip instead of
+        # library GEMMs and autograd's elementwise chains
+        if (self.fused_train and self.training and torch.is_grad_enabled() and x.is_cuda and self[1].kind in ("instance", "batch")
                 and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16):
             from . import train_ops
 
@@ -151,7 +152,9 @@ class _EncoderLayer(nn.Sequential):
                                                                       *(lin.weight for lin in ffn.lins)))
             for skip, norm in ((self[0], self[1]), (self[2], self[3])):
                 s = skip.module(x, fused=gemm_ok)
-                if train_ops.usable(x, s):
+                if norm.kind == "batch" and train_ops.batch_usable(x, s):
+                    x = train_ops.skip_batch_norm(x, s, norm.normalizer)
+                elif norm.kind == "instance" and train_ops.usable(x, s):
                     x = train_ops.skip_instance_norm(x, s, norm.normalizer.weight, norm.normalizer.bias, norm.normalizer.eps)
                 else:
                     x = norm(x + s)

@@ -55,10 +55,65 @@ class _SkipInstanceNorm(torch.autograd.Function):
         return dy, dy, dgamma.to(ctx.param_dtype), dbeta.to(ctx.param_dtype), None
 
 
+class _SkipBatchNorm(torch.autograd.Function):
+    """Normalization("batch")(x + s) in training: BatchNorm1d over all B x N rows with batch statistics."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, s: Tensor, weight: Tensor, bias: Tensor, eps: float):
+        xc, sc = x.contiguous(), s.contiguous()
+        m = xc.numel() // EMBED_DIM
+        w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
+        y, out = torch.empty_like(xc), torch.empty_like(xc)
+        sums = torch.zeros((2, EMBED_DIM), dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().rl4co_skip_bnorm_stats_bf16(xc.data_ptr(), sc.data_ptr(), m, y.data_ptr(), sums.data_ptr(), stream),
+                   "rl4co_skip_bnorm_stats_bf16")
+        mean = sums[0] / m
+        var = (sums[1] / m - mean * mean).clamp_min_(0.0)  # biased, as F.batch_norm normalises with
+        rstd = torch.rsqrt(var + eps)
+        _lib.check(_lib.lib().rl4co_bnorm_apply_bf16(y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w32.data_ptr(), b32.data_ptr(),
+                                                     m, out.data_ptr(), stream), "rl4co_bnorm_apply_bf16")
+        ctx.save_for_backward(y, w32, mean, rstd)
+        ctx.pdt = weight.dtype
+        ctx.mark_non_differentiable(mean, var)
+        return out, mean, var
+
+    @staticmethod
+    def backward(ctx, dout: Tensor, _dmean, _dvar):
+        y, w32, mean, rstd = ctx.saved_tensors
+        m = y.numel() // EMBED_DIM
+        d = dout.to(torch.bfloat16).contiguous()
+        dy = torch.empty_like(y)
+        sums = torch.zeros((2, EMBED_DIM), dtype=torch.float32, device=y.device)
+        _lib.check(_lib.lib().rl4co_bnorm_bwd_bf16(d.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w32.data_ptr(), m,
+                                                   sums.data_ptr(), dy.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                   "rl4co_bnorm_bwd_bf16")
+        return dy, dy, sums[1].to(ctx.pdt), sums[0].to(ctx.pdt), None
+
+
+def skip_batch_norm(x: Tensor, s: Tensor, bn: torch.nn.BatchNorm1d) -> Tensor:
+    """``bn((x + s).view(-1, 128)).view_as(x)`` in training mode, running statistics updated like
+    nn.BatchNorm1d (momentum, unbiased running variance, num_batches_tracked)."""
+    out, mean, var = _SkipBatchNorm.apply(x, s, bn.weight, bn.bias, bn.eps)
+    if bn.track_running_stats and bn.running_mean is not None:
+        with torch.no_grad():
+            m = x.numel() // EMBED_DIM
+            bn.num_batches_tracked += 1
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
+            bn.running_var.mul_(1 - mom).add_((var * (m / max(m - 1, 1))).to(bn.running_var.dtype), alpha=mom)
+    return out
+
+
 def usable(x: Tensor, s: Tensor) -> bool:
     """bf16 [B,N,128] activations on the GPU with N inside the kernel's register budget."""
     return (x.is_cuda and x.dtype == torch.bfloat16 and s.dtype == torch.bfloat16 and x.dim() == 3
             and x.shape == s.shape and x.shape[-1] == EMBED_DIM and x.shape[1] <= max_nodes())
+
+
+def batch_usable(x: Tensor, s: Tensor) -> bool:
+    return (x.is_cuda and x.dtype == torch.bfloat16 and s.dtype == torch.bfloat16 and x.shape == s.shape
+            and x.shape[-1] == EMBED_DIM)
 
 
 def skip_instance_norm(x: Tensor, s: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5) -> Tensor:

@@ -253,11 +253,11 @@ def test_fused_attention_matches_torch_sdpa(n):
         assert rel <= 3e-2, (name, rel)
 
 
-def _pomo_policy(seed=0, fused=True):
+def _pomo_policy(seed=0, fused=True, normalization="instance", graph_context=False, env_name="tsp"):
     from rl4co_amd.policy import AttentionModelPolicy, _EncoderLayer
 
     torch.manual_seed(seed)
-    pol = AttentionModelPolicy("tsp", num_encoder_layers=3, normalization="instance", use_graph_context=False,
+    pol = AttentionModelPolicy(env_name, num_encoder_layers=3, normalization=normalization, use_graph_context=graph_context,
                                cache_dtype=torch.bfloat16, encoder_autocast=torch.bfloat16,
                                train_decode_type="multistart_sampling").cuda().train()
     for m in pol.modules():
@@ -266,24 +266,27 @@ def _pomo_policy(seed=0, fused=True):
     return pol
 
 
-def test_bf16_training_step_on_kernels_matches_torch_path():
+@pytest.mark.parametrize("normalization,graph_context,env_name", [("instance", False, "tsp"), ("batch", True, "tsp"),
+                                                                   ("batch", True, "cvrp")])
+def test_bf16_training_step_on_kernels_matches_torch_path(normalization, graph_context, env_name):
     """The whole bf16-autocast POMO training step on the HIP kernels (encoder linears, attention, skip + norm,
     fold GEMMs, multistart rollout, MMA teacher backward) vs the same step with the torch encoder: the
     same trajectories are evaluated (actions given), so the parameter gradients must agree up to bf16
     rounding: cosine similarity >= 0.98 per tensor that carries signal, >= 0.995 over all parameters."""
     from rl4co_amd.envs import get_env
 
-    env = get_env("tsp", generator_params=dict(num_loc=50, device="cuda"), device="cuda", check_solution=False)
+    env = get_env(env_name, generator_params=dict(num_loc=50, device="cuda"), device="cuda", check_solution=False)
     torch.manual_seed(1)
     data = env.generator(batch_size=[64])
-    ref_pol = _pomo_policy(fused=False)
+    kw = dict(normalization=normalization, graph_context=graph_context, env_name=env_name)
+    ref_pol = _pomo_policy(fused=False, **kw)
     with torch.no_grad():
         out0 = ref_pol(env.reset(data), env, phase="train", num_starts=8, seed=3)
     acts = out0["actions"][:, 1:].contiguous()
     adv = torch.linspace(-1.0, 1.0, out0["actions"].shape[0], device="cuda")
     grads = {}
     for fused in (True, False):
-        pol = _pomo_policy(fused=fused)
+        pol = _pomo_policy(fused=fused, **kw)
         out = pol(env.reset(data), env, phase="train", num_starts=8, actions=acts)
         (adv * out["log_likelihood"]).mean().backward()
         grads[fused] = {k: p.grad.detach().float().flatten() for k, p in pol.named_parameters() if p.grad is not None}
@@ -322,3 +325,35 @@ def test_bf16_training_on_kernels_learns():
         opt.step()
         costs.append(float(-r.mean()))
     assert sum(costs[-5:]) / 5 < sum(costs[:5]) / 5 - 0.2, costs
+
+
+def test_fused_skip_batch_norm_matches_torch():
+    """Training-mode BatchNorm1d(x + s) over all B x N rows on csrc/am_train_ops.hip vs nn.BatchNorm1d in fp32
+    on the bf16-rounded skip sum: output 1.5e-2 + 1.6e-2 |ref|, input gradient 3e-2 relative, affine
+    gradients 1e-2, running statistics 1e-3."""
+    from rl4co_amd import train_ops
+
+    torch.manual_seed(0)
+    b, n, d = 64, 100, 128
+    x = (torch.randn(b, n, d, device="cuda") + 0.3).to(torch.bfloat16).requires_grad_(True)
+    s = (0.5 * torch.randn(b, n, d, device="cuda")).to(torch.bfloat16).requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(d).cuda().train()
+    ref_bn = torch.nn.BatchNorm1d(d).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+        ref_bn.load_state_dict(bn.state_dict())
+    go = torch.randn(b, n, d, device="cuda").to(torch.bfloat16)
+    out = train_ops.skip_batch_norm(x, s, bn)
+    gx, gs, gw, gb = torch.autograd.grad(out, [x, s, bn.weight, bn.bias], go)
+    assert torch.equal(gx, gs)
+    y = (x.detach() + s.detach()).float().requires_grad_(True)  # bf16 + bf16 -> bf16 sum, as the kernel rounds it
+    ref = ref_bn(y.view(-1, d)).view(b, n, d)
+    ry, rw, rb = torch.autograd.grad(ref, [y, ref_bn.weight, ref_bn.bias], go.float())
+    torch.testing.assert_close(out.detach().float(), ref.detach(), rtol=1.6e-2, atol=1.5e-2)
+    rel = lambda a, r: float((a.float() - r).norm() / r.norm())  # noqa: E731
+    assert rel(gx, ry) <= 3e-2, rel(gx, ry)
+    assert rel(gw, rw) <= 1e-2 and rel(gb, rb) <= 1e-2, (rel(gw, rw), rel(gb, rb))
+    torch.testing.assert_close(bn.running_mean, ref_bn.running_mean, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(bn.running_var, ref_bn.running_var, rtol=1e-3, atol=1e-4)
+    assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked) == 1
