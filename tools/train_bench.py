@@ -27,6 +27,9 @@ ap.add_argument("--starts", type=int, default=8)
 ap.add_argument("--num-loc", type=int, default=100)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--warmup", type=int, default=2)
+ap.add_argument("--model", default="pomo", choices=["pomo", "am"], help="pomo: 6L instance norm, shared baseline over starts; am: 3L batch norm + graph context, batch-mean baseline")
+ap.add_argument("--env", default="tsp", choices=["tsp", "cvrp"])
+ap.add_argument("--no-fused-encoder", action="store_true", help="torch encoder (library GEMMs, SDPA, autograd norm) for comparison")
 args = ap.parse_args()
 
 local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -35,10 +38,19 @@ device = torch.device("cuda", local_rank)
 rank, world = D.init_process_group(device=device)
 
 torch.manual_seed(0)
-policy = AttentionModelPolicy("tsp", num_encoder_layers=6, normalization="instance", use_graph_context=False,
-                              cache_dtype=torch.bfloat16, encoder_autocast=torch.bfloat16,
-                              train_decode_type="multistart_sampling").to(device).train()
-env = get_env("tsp", generator_params=dict(num_loc=args.num_loc, device=device), device=device, check_solution=False)
+if args.model == "pomo":
+    policy = AttentionModelPolicy(args.env, num_encoder_layers=6, normalization="instance", use_graph_context=False,
+                                  cache_dtype=torch.bfloat16, encoder_autocast=torch.bfloat16,
+                                  train_decode_type="multistart_sampling").to(device).train()
+else:
+    policy = AttentionModelPolicy(args.env, cache_dtype=torch.bfloat16, encoder_autocast=torch.bfloat16,
+                                  train_decode_type="multistart_sampling" if args.starts > 1 else "sampling").to(device).train()
+if args.no_fused_encoder:
+    from rl4co_amd.policy import _EncoderLayer
+    for m in policy.modules():
+        if isinstance(m, _EncoderLayer):
+            m.fused_train = False
+env = get_env(args.env, generator_params=dict(num_loc=args.num_loc, device=device), device=device, check_solution=False)
 opt = torch.optim.Adam(policy.parameters(), lr=1e-4)
 bucket = D.FlatGradBucket(policy)
 torch.manual_seed(1234 + rank)
@@ -48,10 +60,11 @@ S, B = args.starts, args.batch
 
 def step(i):
     td = env.reset(data)
-    out = policy(td, env, phase="train", num_starts=S, seed=1000 * i + rank)
+    out = policy(td, env, phase="train", seed=1000 * i + rank, **(dict(num_starts=S) if S > 1 else {}))
     reward = out["reward"].view(S, B).t()           # unbatchify -> [B, S]
     ll = out["log_likelihood"].view(S, B).t()
-    adv = reward - reward.mean(dim=1, keepdim=True)  # SharedBaseline
+    # SharedBaseline over the starts (POMO); a single start falls back to the batch mean
+    adv = reward - (reward.mean(dim=1, keepdim=True) if S > 1 else reward.mean())
     loss = -(adv.detach() * ll).mean()
     loss.backward()
     bucket.allreduce_mean()
@@ -75,7 +88,8 @@ if world > 1:
 wall = time.perf_counter() - t0
 if rank == 0:
     traj = B * S * world * args.steps
-    print(json.dumps({"workload": f"POMO REINFORCE train step, TSP-{args.num_loc}, {B} instances x {S} starts per GPU",
+    print(json.dumps({"workload": f"{args.model.upper()} REINFORCE train step, {args.env.upper()}-{args.num_loc}, {B} instances x {S} starts per GPU"
+                                  + (" (torch encoder)" if args.no_fused_encoder else ""),
                       "n_gpus": world, "ms_per_step": wall / args.steps * 1e3,
                       "trajectories_per_sec": traj / wall, "instance_steps_per_sec": traj * t / wall,
                       "grad_bucket_bytes": bucket.nbytes, "mean_reward": r,
