@@ -332,6 +332,12 @@ int rl4co_am_teacher_max_nodes(void);
 int rl4co_am_teacher_variant(const rl4co_am_teacher_args* args);
 
 /* --------------------------------------------------------------------------
+ * a11 (training)  init embedding  env_embeddings/init.py:55-68,115-136
+ * out[m,:] = W[128,F] . feats[m,:F] + b  (F <= 4: x, y (, demand)); fp32 in, bf16 out [M,128].
+ * -------------------------------------------------------------------------- */
+int rl4co_init_embed_bf16(const float* feats, const float* w, const float* b, int64_t M, int F, void* out, void* stream);
+
+/* --------------------------------------------------------------------------
  * a12 (training)  SkipConnection + Normalization("instance")
  *   rl4co/models/nn/ops.py:9-15,30-54 ; nn/graph/attnnet.py:16-54 ; zoo/pomo/model.py:59-63
  * forward : y = x + s ; out = (y - mean_n y) * rsqrt(var_n y + eps) * gamma + beta, statistics per

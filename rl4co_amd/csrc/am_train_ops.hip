@@ -593,3 +593,42 @@ extern "C" int rl4co_bnorm_bwd_bf16(const void* dout, const void* y, const float
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// a11 init embedding in training: out[m,:] = W[128,F] . feats[m,:F] + b, F = 2 (x, y) or 3 (x, y,
+// demand) (env_embeddings/init.py:55-68,115-136). A K = 2 "GEMM" costs the library 0.97 ms at
+// 409 600 rows; it is 128 fused multiply-adds per row.
+namespace {
+__global__ void __launch_bounds__(256) init_embed_kernel(const float* __restrict__ feats, const float* __restrict__ W,
+                                                         const float* __restrict__ b, int64_t M, int F, uint32_t* __restrict__ out) {
+  const int tid = threadIdx.x, cp = tid & 63, q = tid >> 6;
+  float w0[4], w1[4];
+#pragma unroll
+  for (int f = 0; f < 4; ++f) {
+    w0[f] = f < F ? W[(2 * cp) * F + f] : 0.0f;
+    w1[f] = f < F ? W[(2 * cp + 1) * F + f] : 0.0f;
+  }
+  const float b0 = b[2 * cp], b1 = b[2 * cp + 1];
+  for (int64_t r = (int64_t)blockIdx.x * 4 + q; r < M; r += (int64_t)gridDim.x * 4) {
+    float a0 = b0, a1 = b1;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      if (f < F) {
+        const float x = feats[r * F + f];
+        a0 = fmaf(w0[f], x, a0);
+        a1 = fmaf(w1[f], x, a1);
+      }
+    }
+    out[r * 64 + cp] = pack_bf16(a0, a1);
+  }
+}
+}  // namespace
+
+extern "C" int rl4co_init_embed_bf16(const float* feats, const float* w, const float* b, int64_t M, int F, void* out, void* stream) {
+  RL4CO_REQUIRE(feats && w && b && out && M > 0 && F >= 1 && F <= 4);
+  const int blocks = (int)min((int64_t)8192, (M + 3) / 4);
+  hipLaunchKernelGGL(init_embed_kernel, dim3(blocks), dim3(256), 0, rl4co::as_stream(stream), feats, w, b, M, F,
+                     static_cast<uint32_t*>(out));
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}

@@ -175,6 +175,12 @@ class _GraphAttentionNetwork(nn.Module):
         return self.layers(x)
 
 
+def _train_kernels_active(x: Tensor) -> bool:
+    """bf16-autocast training on the GPU: the regime csrc/am_train_ops.hip serves."""
+    return (x.is_cuda and torch.is_grad_enabled() and torch.is_autocast_enabled()
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+
+
 class _TSPInit(nn.Module):
     """env_embeddings/init.py:55-68"""
 
@@ -183,7 +189,12 @@ class _TSPInit(nn.Module):
         self.init_embed = nn.Linear(2, embed_dim, True)
 
     def forward(self, td):
-        return self.init_embed(td["locs"])
+        locs = td["locs"]
+        if _train_kernels_active(locs):
+            from . import train_ops
+
+            return train_ops.init_embed(locs, self.init_embed)
+        return self.init_embed(locs)
 
 
 class _VRPInit(nn.Module):
@@ -197,6 +208,11 @@ class _VRPInit(nn.Module):
     def forward(self, td):
         locs = td["locs"]
         feats = torch.cat((locs[:, 1:, :], td["demand"][..., None]), -1)
+        if _train_kernels_active(locs):
+            from . import train_ops
+
+            return torch.cat((train_ops.init_embed(locs[:, :1, :], self.init_embed_depot),
+                              train_ops.init_embed(feats, self.init_embed)), -2)
         return torch.cat((self.init_embed_depot(locs[:, :1, :]), self.init_embed(feats)), -2)
 
 

@@ -248,3 +248,32 @@ def attention_usable(qkv: Tensor) -> bool:
 def attention(qkv: Tensor) -> Tensor:
     """softmax(q k^T / 4) v per head on qkv [B,N,384] (q | k | v, 8 heads x 16) -> [B,N,128]."""
     return _Attention.apply(qkv)
+
+
+# ---------------------------------------------------------------------------------------------------
+# init embedding (K = 2 / 3 "GEMM") in training
+# ---------------------------------------------------------------------------------------------------
+class _InitEmbed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats: Tensor, weight: Tensor, bias: Tensor):
+        f2 = feats.reshape(-1, feats.shape[-1]).float().contiguous()
+        out = torch.empty((f2.shape[0], EMBED_DIM), dtype=torch.bfloat16, device=feats.device)
+        st = _lib.lib().rl4co_init_embed_bf16(f2.data_ptr(), weight.detach().float().contiguous().data_ptr(),
+                                              bias.detach().float().contiguous().data_ptr(), f2.shape[0], f2.shape[1],
+                                              out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "rl4co_init_embed_bf16")
+        ctx.save_for_backward(f2)
+        ctx.pdt = weight.dtype
+        return out.view(*feats.shape[:-1], EMBED_DIM)
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        (f2,) = ctx.saved_tensors
+        d = dout.reshape(-1, EMBED_DIM)
+        dw = torch.matmul(d.t().float(), f2) if d.dtype != torch.float32 else torch.matmul(d.t(), f2)
+        return None, dw.to(ctx.pdt), d.sum(0, dtype=torch.float32).to(ctx.pdt)
+
+
+def init_embed(feats: Tensor, lin: torch.nn.Linear) -> Tensor:
+    """``lin(feats)`` for the 2- / 3-feature init embeddings, bf16 output (training under autocast)."""
+    return _InitEmbed.apply(feats, lin.weight, lin.bias)
