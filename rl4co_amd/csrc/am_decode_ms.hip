@@ -546,6 +546,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_decode_ms_kernel(const rl4co_a
   const int N = a.N;
   const int S = a.B / a.B_inst;
   const Layout L = make_layout(NT, N);
+  if ((tid >> 6) >= 4) __builtin_amdgcn_s_setprio(1);  // even out the younger half of the workgroup (issue arbitration)
   __bf16* kgs = reinterpret_cast<__bf16*>(smem + L.kgs);  // [16 NT nodes][kRS] glimpse keys
   __bf16* vs = reinterpret_cast<__bf16*>(smem + L.vs);    // glimpse values
   __bf16* kls = reinterpret_cast<__bf16*>(smem + L.kls);  // logit keys

@@ -115,6 +115,9 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
   const int h = w;  // attention stages: wave = head; logits stage: wave = node tile
   const int inst = blockIdx.x;
   const int N = a.N, T = a.T, S = a.B / a.B_inst;
+  // the second-dispatched half of an 8-wave workgroup loses the issue arbitration on every segment
+  // (older wave first); a static priority for it evens the halves out between the barriers
+  if (w >= 4) __builtin_amdgcn_s_setprio(1);
   const Layout L = make_layout(NT);  // NT node tiles of 16 (template): rows N .. 16 NT - 1 are zero
   __bf16* kgs = reinterpret_cast<__bf16*>(smem + L.kgs);
   __bf16* vs = reinterpret_cast<__bf16*>(smem + L.vs);
