@@ -76,17 +76,23 @@ __device__ inline bf16x8 load_x(const __bf16* xs, int tt, int ks, int l31, int h
   return *reinterpret_cast<const bf16x8*>(xs + (32 * tt + l31) * kRS + 16 * ks + 8 * hi);
 }
 
-// Out^T tile (32 dims x 32*TT tokens) += W[tile] . X^T over 8 ksteps starting at weight kstep k0.
-// All 8 weight fragments are requested up front (8 x 1 KiB per wave in flight from L2) and the
-// LDS activation fragments are double-buffered one kstep ahead, so the MFMA pipe is not stalled
-// by a load at every kstep (one wave per SIMD: there is no other wave to hide the latency).
-template <int TT, bool W_IS_A = true>
-__device__ inline void gemm_t(f32x16 (&acc)[TT], const __bf16* packed, int ksteps_total, int tile, int k0,
-                              const __bf16* xs, int lane) {
-  const int l31 = lane & 31, hi = lane >> 5;
-  bf16x8 wf[8];
+// The 8 weight fragments of one GEMM call (8 x 1 KiB per wave, streamed from L2).
+__device__ inline void load_wfrags(bf16x8 (&wf)[8], const __bf16* packed, int ksteps_total, int tile, int k0, int lane) {
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) wf[ks] = load_w(packed, ksteps_total, tile, k0 + ks, lane);
+}
+
+// Out^T tile (32 dims x 32*TT tokens) += W . X^T over 8 ksteps with the weight fragments `wf`
+// already requested by the caller. An L2 round trip is 2-4 K cycles and a call is only 32 MFMAs
+// (1 K cycles), so fetching the fragments at the top of the call that uses them leaves the matrix
+// pipe idle most of the time: instead every call hands over — as soon as fragment ks has fed its
+// last MFMA, the same registers receive fragment ks of the NEXT GEMM (nxt_*; nullptr: none), whose
+// latency then hides under the rest of this call and whatever epilogue separates the two. The LDS
+// activation fragments are double-buffered one kstep ahead.
+template <int TT, bool W_IS_A = true>
+__device__ inline void gemm_t(f32x16 (&acc)[TT], bf16x8 (&wf)[8], const __bf16* xs, int lane, const __bf16* nxt_packed,
+                              int nxt_ksteps_total, int nxt_tile, int nxt_k0) {
+  const int l31 = lane & 31, hi = lane >> 5;
   bf16x8 xa[TT], xb[TT];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) xa[tt] = load_x(xs, tt, 0, l31, hi);
@@ -97,6 +103,7 @@ __device__ inline void gemm_t(f32x16 (&acc)[TT], const __bf16* packed, int kstep
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt)
       acc[tt] = W_IS_A ? mfma(wf[ks], xa[tt], acc[tt]) : mfma(xa[tt], wf[ks], acc[tt]);
+    if (nxt_packed) wf[ks] = load_w(nxt_packed, nxt_ksteps_total, nxt_tile, nxt_k0 + ks, lane);
     if (ks + 2 < 8) {
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) xa[tt] = load_x(xs, tt, ks + 2, l31, hi);
@@ -104,6 +111,7 @@ __device__ inline void gemm_t(f32x16 (&acc)[TT], const __bf16* packed, int kstep
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt)
       acc[tt] = W_IS_A ? mfma(wf[ks + 1], xb[tt], acc[tt]) : mfma(xb[tt], wf[ks + 1], acc[tt]);
+    if (nxt_packed) wf[ks + 1] = load_w(nxt_packed, nxt_ksteps_total, nxt_tile, nxt_k0 + ks + 1, lane);
   }
 }
 
@@ -196,21 +204,28 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
   const int N = a.N;
 
   // ---- init embedding (K = 2 or 3: plain VALU), padding rows zeroed ---------------------------
+  // The instance's coordinates (and demands) are staged in LDS first: read per token from global
+  // memory they are a chain of dependent L2 round trips (28 K cycles per instance, measured).
+  // thread = channel d (tid & 127) x token parity; its weights are read once.
   {
+    float* lsh = reinterpret_cast<float*>(ys);  // [2 N] coordinates, then [N] demands (ys is free here)
     const float* loc = a.locs + (int64_t)b * N * 2;
-    for (int idx = tid; idx < 32 * TT * kD; idx += kThreads) {
-      const int tok = idx >> 7, d = idx & 127;
+    const bool cvrp = a.env == RL4CO_ENV_CVRP;
+    for (int i = tid; i < 2 * N; i += kThreads) lsh[i] = loc[i];
+    if (cvrp)
+      for (int i = tid; i < N - 1; i += kThreads) lsh[2 * N + 1 + i] = a.demand[(int64_t)b * (N - 1) + i];
+    const int d = tid & 127;
+    const float wx = cvrp ? a.w_init[3 * d] : a.w_init[2 * d], wy = cvrp ? a.w_init[3 * d + 1] : a.w_init[2 * d + 1];
+    const float wd = cvrp ? a.w_init[3 * d + 2] : 0.0f, bi = a.b_init[d];
+    const float dx = cvrp ? a.w_depot[2 * d] : 0.0f, dy = cvrp ? a.w_depot[2 * d + 1] : 0.0f, db = cvrp ? a.b_depot[d] : 0.0f;
+    __syncthreads();
+    for (int tok = tid >> 7; tok < 32 * TT; tok += kThreads / 128) {
       float v = 0.0f;
       if (tok < N) {
-        const float x = loc[2 * tok], y = loc[2 * tok + 1];
-        if (a.env == RL4CO_ENV_CVRP && tok == 0) {
-          v = fmaf(a.w_depot[2 * d + 1], y, fmaf(a.w_depot[2 * d], x, a.b_depot[d]));
-        } else if (a.env == RL4CO_ENV_CVRP) {
-          const float dm = a.demand[(int64_t)b * (N - 1) + tok - 1];
-          v = fmaf(a.w_init[3 * d + 2], dm, fmaf(a.w_init[3 * d + 1], y, fmaf(a.w_init[3 * d], x, a.b_init[d])));
-        } else {
-          v = fmaf(a.w_init[2 * d + 1], y, fmaf(a.w_init[2 * d], x, a.b_init[d]));
-        }
+        const float x = lsh[2 * tok], y = lsh[2 * tok + 1];
+        if (cvrp && tok == 0) v = fmaf(dy, y, fmaf(dx, x, db));
+        else if (cvrp) v = fmaf(wd, lsh[2 * N + tok], fmaf(wy, y, fmaf(wx, x, bi)));
+        else v = fmaf(wy, y, fmaf(wx, x, bi));
       }
       xs[tok * kRS + d] = (__bf16)v;
     }
@@ -222,6 +237,9 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
   const __bf16* w1_all = static_cast<const __bf16*>(a.w1_packed);
   const __bf16* w2_all = static_cast<const __bf16*>(a.w2_packed);
 
+  const __bf16* wf_all = static_cast<const __bf16*>(a.wfold_packed);
+  bf16x8 wf[8];  // weight fragments of the NEXT GEMM, always one call ahead (gemm_t)
+  load_wfrags(wf, wqkv_all, 8, w, 0, lane);
   for (int layer = 0; layer < a.num_layers; ++layer) {
     LayerPtrs L;
     L.wqkv = wqkv_all + (int64_t)layer * 3 * kD * kD;
@@ -243,7 +261,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       f32x16 acc[TT];
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) acc[tt] = zero16();
-      gemm_t<TT>(acc, L.wqkv, 8, w, 0, xs, lane);
+      gemm_t<TT>(acc, wf, xs, lane, L.wqkv, 8, 4 + w, 0);
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
 #pragma unroll
@@ -255,7 +273,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       store_t<TT>(ys, acc, 32 * w, lane);
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) acc[tt] = zero16();
-      gemm_t<TT>(acc, L.wqkv, 8, 4 + w, 0, xs, lane);
+      gemm_t<TT>(acc, wf, xs, lane, L.wqkv, 8, 8 + w, 0);
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
 #pragma unroll
@@ -266,7 +284,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       // V = X . Wv^T: A = token rows from LDS, B = weight fragment -> C[row = token][col = dim]
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) acc[tt] = zero16();
-      gemm_t<TT, false>(acc, L.wqkv, 8, 8 + w, 0, xs, lane);
+      gemm_t<TT, false>(acc, wf, xs, lane, nullptr, 0, 0, 0);  // nothing in flight across the attention (register peak)
       const float bv = L.bqkv[2 * kD + 32 * w + l31];
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
@@ -338,6 +356,8 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         *reinterpret_cast<bf16x4*>(qrow + 8 * c + 4 * hi) = v;
       }
     }
+    __builtin_amdgcn_sched_barrier(0);     // keep these loads out of the attention loop (its register peak)
+    load_wfrags(wf, L.wo, 8, w, 0, lane);  // out-proj weights: in flight across the barrier
     __syncthreads();
 
     // ---- out-proj + residual + norm1 ---------------------------------------------------------------
@@ -345,7 +365,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       f32x16 y[TT];
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) y[tt] = zero16();
-      gemm_t<TT>(y, L.wo, 8, w, 0, ys, lane);
+      gemm_t<TT>(y, wf, ys, lane, L.w1, 8, w, 0);  // next: FFN1 chunk 0
       residual_norm<TT>(xs, y, 32 * w, L.bo, L.n1a, L.n1b, a.norm, N, lane);
     }
     __syncthreads();
@@ -359,7 +379,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         f32x16 h1[TT];
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) h1[tt] = zero16();
-        gemm_t<TT>(h1, L.w1, 8, 4 * c + w, 0, xs, lane);
+        gemm_t<TT>(h1, wf, xs, lane, L.w2, 32, w, 8 * c);  // next: FFN2 of this chunk
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
@@ -367,7 +387,10 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         if (c > 0) __syncthreads();  // every wave is done reading the previous chunk
         store_t<TT>(ys, h1, 32 * w, lane);
         __syncthreads();
-        gemm_t<TT>(y2, L.w2, 32, w, 8 * c, ys, lane);
+        // next: FFN1 of the next chunk, then the next layer's Q projection, finally the first fold block
+        const bool last_layer = layer + 1 == a.num_layers;
+        const __bf16* nxt = c < 3 ? L.w1 : (last_layer ? wf_all : wqkv_all + (int64_t)(layer + 1) * 3 * kD * kD);
+        gemm_t<TT>(y2, wf, ys, lane, nxt, 8, c < 3 ? 4 * (c + 1) + w : w, 0);
       }
       residual_norm<TT>(xs, y2, 32 * w, L.b2, L.n2a, L.n2b, a.norm, N, lane);
     }
@@ -381,13 +404,12 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
   }
 
   // ---- fold: cache planes straight out of the accumulators ------------------------------------------
-  const __bf16* wf_all = static_cast<const __bf16*>(a.wfold_packed);
   const int nblocks = (a.env == RL4CO_ENV_TSP) ? 5 : 4;
   for (int blk = 0; blk < nblocks; ++blk) {
     f32x16 acc[TT];
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) acc[tt] = zero16();
-    gemm_t<TT>(acc, wf_all + (int64_t)blk * kD * kD, 8, w, 0, xs, lane);
+    gemm_t<TT>(acc, wf, xs, lane, blk + 1 < nblocks ? wf_all + (int64_t)(blk + 1) * kD * kD : nullptr, 8, w, 0);
     if (blk < 3 && a.cache_dtype == RL4CO_DT_BF16) {
       __bf16* out = static_cast<__bf16*>(a.kvl) + (int64_t)blk * a.kvl_plane_stride + (int64_t)b * a.kvl_batch_stride;
 #pragma unroll

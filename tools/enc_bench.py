@@ -18,3 +18,5 @@ with torch.inference_mode():
 ms = e0.elapsed_time(e1) / 10
 flops = 4096 * (3 * (128*128*384*2 + 2*8*128*128*16*2*1.5 + 128*128*128*2 + 2*128*128*512*2) + 5*128*128*128*2)
 print(f"encoder {ms:.3f} ms  {flops/ms/1e9:.1f} TFLOP/s (padded-128 MFMA flops incl. 50% PV waste)")
+
+
