@@ -362,6 +362,42 @@ class AttentionModelPolicy(nn.Module):
             self._packed = PackedEncoder(self)
         return self._packed
 
+    def _encode_tokens_bf16(self, td):
+        """Inference encoder for graphs beyond the fused kernel's 128 nodes (C5: CVRP-500): the same
+        layer algebra on the token-parallel kernels of the training path — init embedding, the four
+        projections per layer with bias / ReLU epilogues (csrc/am_train_ops.hip), eval-mode batch norm
+        as one affine pass — and torch's SDPA for the N x N attention. bf16 activations."""
+        from . import train_ops as T
+
+        enc = self.encoder
+        init = enc.init_embedding
+        if self.env_name == "cvrp":
+            locs = td["locs"]
+            feats = torch.cat((locs[:, 1:, :], td["demand"][..., None]), -1)
+            x = torch.cat((T.init_embed(locs[:, :1, :], init.init_embed_depot), T.init_embed(feats, init.init_embed)), -2)
+        else:
+            x = T.init_embed(td["locs"], init.init_embed)
+        init_h = x
+        b, n, d = x.shape
+        bf = torch.bfloat16
+        for layer in enc.net.layers:
+            attn, norm1, ffn, norm2 = layer[0].module, layer[1].normalizer, layer[2].module, layer[3].normalizer
+            x2 = x.reshape(b * n, d)
+            qkv = T._gemm(x2, attn.Wqkv.weight.to(bf).contiguous(), attn.Wqkv.bias.float().contiguous())
+            q, k, v = qkv.view(b, n, 3, attn.num_heads, d // attn.num_heads).permute(2, 0, 3, 1, 4).unbind(0)
+            o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(b * n, d)
+            s_ = T._gemm(o, attn.out_proj.weight.to(bf).contiguous(), attn.out_proj.bias.float().contiguous())
+            x2 = T.batch_norm_eval(x2 + s_, norm1)
+            h = T._gemm(x2, ffn.lins[0].weight.to(bf).contiguous(), ffn.lins[0].bias.float().contiguous(), relu=True)
+            s_ = T._gemm(h, ffn.lins[1].weight.to(bf).contiguous(), ffn.lins[1].bias.float().contiguous())
+            x = T.batch_norm_eval(x2 + s_, norm2).view(b, n, d)
+        return x, init_h
+
+    def _token_encoder_usable(self, td) -> bool:
+        layer0 = self.encoder.net.layers[0]
+        return (td["locs"].is_cuda and self.encoder_autocast == torch.bfloat16 and layer0[1].kind == "batch"
+                and not self.training and len(layer0[2].module.lins) == 2 and layer0[2].module.lins[0].out_features % 128 == 0)
+
     def _encode(self, td):
         if self.encoder_autocast is not None:
             with torch.autocast("cuda", dtype=self.encoder_autocast):
@@ -420,7 +456,10 @@ class AttentionModelPolicy(nn.Module):
             init_embeds = None
         else:
             cache = None
-            hidden, init_embeds = self._encode(td)
+            if not grad_path and self.fused_encoder and self._token_encoder_usable(td):
+                hidden, init_embeds = self._encode_tokens_bf16(td)  # N > 128: token-parallel kernels + SDPA
+            else:
+                hidden, init_embeds = self._encode(td)
         if isinstance(env, str) or env is None:
             env = get_env(self.env_name if env is None else env)
 

@@ -105,6 +105,20 @@ def skip_batch_norm(x: Tensor, s: Tensor, bn: torch.nn.BatchNorm1d) -> Tensor:
     return out
 
 
+def batch_norm_eval(y: Tensor, bn: torch.nn.BatchNorm1d) -> Tensor:
+    """Eval-mode BatchNorm1d on bf16 rows [M,128]: one affine pass with the running statistics."""
+    yc = y.contiguous()
+    m = yc.numel() // EMBED_DIM
+    out = torch.empty_like(yc)
+    mean = bn.running_mean.float().contiguous()
+    rstd = torch.rsqrt(bn.running_var.float() + bn.eps).contiguous()
+    st = _lib.lib().rl4co_bnorm_apply_bf16(yc.data_ptr(), mean.data_ptr(), rstd.data_ptr(), bn.weight.detach().float().contiguous().data_ptr(),
+                                           bn.bias.detach().float().contiguous().data_ptr(), m, out.data_ptr(),
+                                           torch.cuda.current_stream().cuda_stream)
+    _lib.check(st, "rl4co_bnorm_apply_bf16")
+    return out
+
+
 def usable(x: Tensor, s: Tensor) -> bool:
     """bf16 [B,N,128] activations on the GPU with N inside the kernel's register budget."""
     return (x.is_cuda and x.dtype == torch.bfloat16 and s.dtype == torch.bfloat16 and x.dim() == 3

@@ -137,3 +137,30 @@ def test_packed_weights_refresh_after_update():
             pol.encoder.net.layers[0][0].module.Wqkv.weight.mul_(1.5)
         c2, _ = pol._packed_encoder().encode(td, torch.float32)
     assert not torch.equal(c1.kvl, c2.kvl)
+
+
+def test_token_parallel_encoder_for_large_graphs_matches_torch():
+    """N > 128 (the fused per-instance kernel's limit): the inference encoder runs on the token-parallel
+    kernels (csrc/am_train_ops.hip) + SDPA. Same bound as the fused encoder test: within 3e-2 relative
+    Frobenius error of the fp32 torch encoder."""
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    torch.manual_seed(0)
+    pol = AttentionModelPolicy("cvrp", cache_dtype=torch.bfloat16, encoder_autocast=torch.bfloat16).cuda().eval()
+    with torch.no_grad():  # non-trivial running statistics
+        for m in pol.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.uniform_(-0.2, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+    env = get_env("cvrp", generator_params=dict(num_loc=200, device="cuda"), device="cuda")
+    td = env.reset(batch_size=[16])
+    assert pol._token_encoder_usable(td) and not pol._packed_encoder().supported(td)
+    with torch.inference_mode():
+        h, h0 = pol._encode_tokens_bf16(td)
+        ref, ref0 = pol.encoder(td)  # fp32
+        rel = float((h.float() - ref).norm() / ref.norm())
+        assert rel <= 3e-2, rel
+        assert float((h0.float() - ref0).norm() / ref0.norm()) <= 1e-2
+        out = pol(td, env, phase="test", decode_type="greedy")  # end to end through the WIDE decode variant
+    assert out["reward"].shape == (16,) and bool(torch.isfinite(out["reward"]).all())
