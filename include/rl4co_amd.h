@@ -41,10 +41,13 @@ extern "C" {
 #define RL4CO_EBIT_CAPACITY 8    /* cvrp/env.py:175-177 "Used more than capacity"         */
 #define RL4CO_EBIT_MAX_STEPS 16  /* constructive/base.py:236-238 max_steps exceeded       */
 #define RL4CO_EBIT_NEG_INF_LOGP 32 /* utils/decoding.py:56 "Logprobs should not be -inf"  */
+#define RL4CO_EBIT_DUPLICATES 64  /* op/env.py:178-181 "Duplicates"                        */
+#define RL4CO_EBIT_MAX_LENGTH 128 /* op/env.py:192-194 "Max length exceeded"               */
 
 /* ---- enums --------------------------------------------------------------- */
 #define RL4CO_ENV_TSP 0
 #define RL4CO_ENV_CVRP 1
+#define RL4CO_ENV_OP 2 /* orienteering problem: streaming decode variant only */
 
 #define RL4CO_DECODE_GREEDY 0   /* utils/decoding.py:387-397 */
 #define RL4CO_DECODE_SAMPLE 1   /* utils/decoding.py:399-413 */
@@ -130,6 +133,26 @@ int rl4co_cvrp_step(const int64_t* action, const float* demand, float* used_capa
                     int32_t* err, void* stream);
 
 /* --------------------------------------------------------------------------
+ * N4  OPEnv (orienteering)      envs/routing/op/env.py:67-194
+ * reset: max_length_table[b,j] = (max_length[b] - |loc_0 - loc_j|) - 1e-6  (op/env.py:118-122)
+ * step : tour += |loc_a - loc_cur| ; visited[a] = 1 ; done = (a == 0) & (i > 0) ; i += 1 ; cur = a ;
+ *        mask[j] = !(visited[j] | visited[0] | tour + |loc_j - loc_cur| > max_length_table[j]) ; mask[0] = 1
+ *        (action == NULL: mask only). Distances are sqrt(fma(dy,dy,dx*dx)) like the tour length.
+ * reward: out[b] = sum_t prize[b % B_values, actions[b,t]] in ATen's inner-dim sum order (op/env.py:156-166)
+ * check : no customer twice (RL4CO_EBIT_DUPLICATES), closed tour length <= max_length + 1e-5 measured
+ *         at every node as the reference does (RL4CO_EBIT_MAX_LENGTH)   (op/env.py:168-194)
+ * locs [B_inst,N,2], max_length_table / prize [B_inst,N] (trajectory b reads row b % B_inst).
+ * -------------------------------------------------------------------------- */
+int rl4co_op_max_length(const float* locs, const float* max_length, int B, int N, float* table, void* stream);
+int rl4co_op_step(const int64_t* action, const float* locs, const float* max_length_table, float* tour_length,
+                  uint8_t* visited, int64_t* current_node, int64_t* step_i, uint8_t* action_mask, uint8_t* done,
+                  int B, int B_inst, int N, int32_t* err, void* stream);
+int rl4co_gather_sum_f32(const float* values, const int64_t* actions, int B, int B_values, int N, int T, float* out,
+                         void* stream);
+int rl4co_op_check_solution(const int64_t* actions, const float* locs, const float* max_length_table, int B, int B_inst,
+                            int N, int T, int32_t* err, void* stream);
+
+/* --------------------------------------------------------------------------
  * a13-a21  AttentionModel decode: one step, or the whole autoregressive loop.
  *
  * Replaces, per step: TSPContext/VRPContext (env_embeddings/context.py:105-149),
@@ -186,7 +209,11 @@ typedef struct rl4co_am_decode_args {
   const float* demand;      /* [B_inst,N-1] CVRP                                           */
   float* used_capacity;     /* [B] CVRP                                                    */
   const float* vehicle_capacity; /* [B] CVRP                                               */
-  uint8_t* visited;         /* [B,N] CVRP                                                  */
+  uint8_t* visited;         /* [B,N] CVRP, OP                                              */
+  /* OP (orienteering, envs/routing/op/env.py): used_capacity carries the tour length so far, step_i
+   * the step counter; the depot row of max_length plays the vehicle capacity in the context scalar */
+  const float* locs;        /* [B_inst,N,2] OP                                             */
+  const float* max_length;  /* [B_inst,N] OP: longest tour with which node j may be entered */
   /* decoding inputs */
   const float* exp_noise;   /* [max_steps,B,N] Exp(1) draws (parity mode) or NULL          */
   uint64_t philox_seed;     /* in-kernel Exp(1) noise when exp_noise == NULL               */

@@ -54,6 +54,9 @@ def lib() -> C.CDLL:
     h.oracle_tour_length_f32.argtypes = [vp, vp, i, i, i, i, i, i, vp]
     h.oracle_tsp_step.argtypes = [vp] * 6 + [i, i]
     h.oracle_cvrp_step.argtypes = [vp] * 8 + [i, i, i]
+    h.oracle_op_step.argtypes = [vp] * 9 + [i, i, i]
+    h.oracle_op_max_length.argtypes = [vp, vp, i, i, vp]
+    h.oracle_gather_sum_f32.argtypes = [vp, vp, i, i, i, i, vp]
     h.oracle_am_decode.argtypes = [C.POINTER(AmDecodeArgs), i]
     for name in ("oracle_expf", "oracle_logf", "oracle_tanhf"):
         fn = getattr(h, name)
@@ -99,6 +102,33 @@ def cvrp_step(action, demand, used, cap, visited, cur, mask, done) -> None:
     assert st == 0
 
 
+def op_max_length(locs: Tensor, max_length: Tensor) -> Tensor:
+    b, n, _ = locs.shape
+    out = torch.empty((b, n), dtype=torch.float32)
+    st = lib().oracle_op_max_length(_p(_cpu(locs, torch.float32)), _p(_cpu(max_length.reshape(-1).contiguous(), torch.float32)),
+                                    b, n, _p(out))
+    assert st == 0
+    return out
+
+
+def op_step(action, locs, max_length, tour_length, visited, cur, step_i, mask, done) -> None:
+    b, n = mask.shape
+    st = lib().oracle_op_step(_p(None if action is None else _cpu(action, torch.int64)), _p(_cpu(locs, torch.float32)),
+                              _p(_cpu(max_length, torch.float32)), _p(_cpu(tour_length, torch.float32)), _p(_u8(visited)),
+                              _p(_cpu(cur, torch.int64)), _p(_cpu(step_i, torch.int64)), _p(_u8(mask)), _p(_u8(done)),
+                              b, locs.shape[0], n)
+    assert st == 0, "oracle_op_step: action out of range"
+
+
+def gather_sum(values: Tensor, actions: Tensor) -> Tensor:
+    b, t = actions.shape
+    out = torch.empty((b,), dtype=torch.float32)
+    st = lib().oracle_gather_sum_f32(_p(_cpu(values, torch.float32)), _p(_cpu(actions, torch.int64)), b, values.shape[0],
+                                     values.shape[1], t, _p(out))
+    assert st == 0
+    return out
+
+
 def _u8(t: Tensor) -> Tensor:
     _cpu(t)
     return t.view(torch.uint8) if t.dtype == torch.bool else t
@@ -118,7 +148,7 @@ def am_decode(cache, state: dict, *, mode: str, max_steps: int, actions: Tensor,
     a = _lib.AmDecodeArgs()
     mask = _u8(state["action_mask"])
     b, n = mask.shape
-    a.env = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP}[cache.env_name]
+    a.env = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP, "op": _lib.ENV_OP}[cache.env_name]
     a.B, a.B_inst, a.N = b, cache.num_instances, n
     a.mode = {"greedy": 0, "sampling": 1, "evaluate": 2}[mode]
     a.max_steps = int(max_steps)
@@ -138,6 +168,13 @@ def am_decode(cache, state: dict, *, mode: str, max_steps: int, actions: Tensor,
         a.q_step0 = _p(_cpu(cache.q_step0, torch.float32))
         a.first_node = _p(_cpu(state["first_node"], torch.int64))
         a.step_i = _p(_cpu(state["i"], torch.int64))
+    elif cache.env_name == "op":
+        a.w_cap = _p(_cpu(cache.w_cap, torch.float32))
+        a.locs = _p(_cpu(state["locs"], torch.float32))
+        a.max_length = _p(_cpu(state["max_length"], torch.float32))
+        a.used_capacity = _p(_cpu(state["tour_length"], torch.float32))
+        a.step_i = _p(_cpu(state["i"], torch.int64))
+        a.visited = _p(_u8(state["visited"]))
     else:
         a.w_cap = _p(_cpu(cache.w_cap, torch.float32))
         a.demand = _p(_cpu(state["demand"], torch.float32))

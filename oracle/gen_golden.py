@@ -54,6 +54,10 @@ CASES = [
          decode="multistart_sampling", fw_kw=dict(num_starts=8)),
     dict(name="pomo_cvrp20_b16_msgreedy", env="cvrp", num_loc=20, batch=16, policy="pomo",
          decode="multistart_greedy"),
+    # the orienteering problem shares the decode kernel (current-node + scalar context)
+    dict(name="op20_b128_greedy", env="op", num_loc=20, batch=128, policy="am", decode="greedy"),
+    dict(name="op50_b64_sampling", env="op", num_loc=50, batch=64, policy="am", decode="sampling"),
+    dict(name="op100_b64_greedy", env="op", num_loc=100, batch=64, policy="am", decode="greedy"),
     # BASELINE.json configs[3] / [4] shapes at a CPU-affordable batch: POMO 8-start sampling on
     # TSP-100, and CVRP-500 sampling (N = 501: the n >= 512 cascade of the tour-length sum)
     dict(name="c4_pomo_tsp100_b32_s8_sampling", env="tsp", num_loc=100, batch=32, policy="pomo",
@@ -91,8 +95,11 @@ def run_case(ref, case: dict) -> dict:
     fw_kw = dict(case.get("fw_kw", {}))
 
     # ---- the real reference -----------------------------------------------------------------
-    env_cls = ref.TSPEnv if env_name == "tsp" else ref.CVRPEnv
-    ref_env = env_cls(generator_params=dict(num_loc=n), seed=0)
+    env_cls = {"tsp": ref.TSPEnv, "cvrp": ref.CVRPEnv, "op": ref.OPEnv}[env_name]
+    gen_kw = dict(num_loc=n)
+    if env_name == "op":  # the default prize sampler Uniform(1.0, 1.0) does not pass torch's argument validation;
+        gen_kw["prize_distribution"] = "dist"  # "dist" takes no sampler and is what prize_type="dist" (the default) uses
+    ref_env = env_cls(generator_params=gen_kw, seed=0)
     torch.manual_seed(WEIGHT_SEED)
     ref_pol = ref.AttentionModelPolicy(env_name=env_name, **pol_kw).eval()
     torch.manual_seed(DATA_SEED)

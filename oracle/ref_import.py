@@ -37,6 +37,7 @@ _SHELL_PACKAGES = [
     "rl4co.envs.routing",
     "rl4co.envs.routing.tsp",
     "rl4co.envs.routing.cvrp",
+    "rl4co.envs.routing.op",
     "rl4co.models",
     "rl4co.models.nn",
     "rl4co.models.nn.graph",
@@ -52,6 +53,7 @@ _LAZY = {
         "RL4COEnvBase": "rl4co.envs.common.base",
         "TSPEnv": "rl4co.envs.routing.tsp.env",
         "CVRPEnv": "rl4co.envs.routing.cvrp.env",
+        "OPEnv": "rl4co.envs.routing.op.env",
     },
     "rl4co.models.zoo.am": {"AttentionModelPolicy": "rl4co.models.zoo.am.policy"},
 }
@@ -72,9 +74,9 @@ class _Shell(types.ModuleType):
 
 
 def _get_env(env_name: str, *args, **kwargs):
-    """rl4co/envs/__init__.py:65-84 restricted to the two environments on the path."""
+    """rl4co/envs/__init__.py:65-84 restricted to the environments on the path."""
     envs = sys.modules["rl4co.envs"]
-    registry = {"tsp": "TSPEnv", "cvrp": "CVRPEnv"}
+    registry = {"tsp": "TSPEnv", "cvrp": "CVRPEnv", "op": "OPEnv"}
     if env_name not in registry:
         raise ValueError(f"Unknown environment {env_name}. Available (oracle shell): {list(registry)}")
     return getattr(envs, registry[env_name])(*args, **kwargs)
@@ -110,7 +112,7 @@ def install() -> None:
         if "." in pkg:
             parent, _, child = pkg.rpartition(".")
             setattr(sys.modules[parent], child, mod)
-    for env in ("tsp", "cvrp"):  # matplotlib renderers: not on the path, not installed
+    for env in ("tsp", "cvrp", "op"):  # matplotlib renderers: not on the path, not installed
         stub = types.ModuleType(f"rl4co.envs.routing.{env}.render")
         stub.render = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError("render is out of scope"))
         stub.render_improvement = stub.render
@@ -126,6 +128,7 @@ def load():
     ns.decoding = importlib.import_module("rl4co.utils.decoding")
     ns.TSPEnv = importlib.import_module("rl4co.envs.routing.tsp.env").TSPEnv
     ns.CVRPEnv = importlib.import_module("rl4co.envs.routing.cvrp.env").CVRPEnv
+    ns.OPEnv = importlib.import_module("rl4co.envs.routing.op.env").OPEnv
     ns.TSPGenerator = importlib.import_module("rl4co.envs.routing.tsp.generator").TSPGenerator
     ns.CVRPGenerator = importlib.import_module("rl4co.envs.routing.cvrp.generator").CVRPGenerator
     ns.AttentionModelPolicy = importlib.import_module("rl4co.models.zoo.am.policy").AttentionModelPolicy

@@ -319,8 +319,130 @@ class CVRPEnv:
         return select_start_nodes(td, self, num_starts)
 
 
+OP_MAX_LENGTHS = {20: 2.0, 50: 3.0, 100: 4.0}  # op/generator.py:13
+
+
+class OPEnv:
+    """envs/routing/op/env.py:16-182 (orienteering: collect prizes, be back at the depot within max_length)"""
+
+    name = "op"
+
+    def __init__(self, num_loc: int = 20, check_solution: bool = True, max_length: float | None = None,
+                 prize_type: str = "dist"):
+        self.num_loc = num_loc
+        self.check_solution = check_solution
+        self.prize_type = prize_type
+        if max_length is None:  # op/generator.py:90-101
+            max_length = OP_MAX_LENGTHS.get(num_loc, None)
+        if max_length is None:
+            closest = min(OP_MAX_LENGTHS.keys(), key=lambda x: abs(x - num_loc))
+            max_length = OP_MAX_LENGTHS[closest]
+        self.max_length = max_length
+
+    def generate(self, batch_size: int) -> dict:
+        """op/generator.py:103-142 (depot sampled with the locations)"""
+        loc_sampler = torch.distributions.Uniform(low=0.0, high=1.0)
+        locs = loc_sampler.sample((batch_size, self.num_loc + 1, 2))
+        locs_with_depot = locs
+        if self.prize_type == "const":
+            prize = torch.ones(batch_size, self.num_loc)
+        elif self.prize_type == "unif":
+            prize = (1 + torch.randint(0, 100, (batch_size, self.num_loc)).float()) / 100
+        else:  # "dist": the distance to the depot, quantised to 1..100 hundredths
+            prize = (locs_with_depot[..., 0:1, :] - locs_with_depot[..., 1:, :]).norm(p=2, dim=-1)
+            prize = (1 + (prize / prize.max(dim=-1, keepdim=True)[0] * 99).int()).float() / 100
+        return {"locs": locs_with_depot[..., 1:, :], "depot": locs_with_depot[..., 0, :], "prize": prize,
+                "max_length": torch.full((batch_size,), self.max_length)}
+
+    def reset(self, td: dict | None = None, batch_size: int | None = None) -> dict:
+        """op/env.py:100-135"""
+        if td is None:
+            td = self.generate(batch_size)
+        b = td["locs"].shape[0]
+        device = td["locs"].device
+        locs_with_depot = torch.cat((td["depot"][:, None, :], td["locs"]), -2)
+        td_reset = {
+            "locs": locs_with_depot,
+            "prize": torch.nn.functional.pad(td["prize"], (1, 0), mode="constant", value=0),
+            "tour_length": torch.zeros(b, device=device),
+            # the longest tour with which a node may still be ENTERED: the way back to the depot and a
+            # 1e-6 margin are taken off once, here
+            "max_length": td["max_length"][..., None]
+            - (td["depot"][..., None, :] - locs_with_depot).norm(p=2, dim=-1)
+            - 1e-6,
+            "current_node": torch.zeros(b, 1, dtype=torch.long, device=device),
+            "visited": torch.zeros((b, locs_with_depot.shape[-2]), dtype=torch.bool, device=device),
+            "current_total_prize": torch.zeros(b, dtype=torch.float, device=device),
+            "i": torch.zeros((b,), dtype=torch.int64, device=device),
+            "done": torch.zeros((b,), dtype=torch.bool, device=device),
+        }
+        td_reset["action_mask"] = self.get_action_mask(td_reset)
+        return td_reset
+
+    def step(self, td: dict) -> dict:
+        """op/env.py:67-98"""
+        current_node = td["action"][:, None]
+        previus_loc = gather_by_index(td["locs"], td["current_node"])
+        current_loc = gather_by_index(td["locs"], current_node)
+        tour_length = td["tour_length"] + (current_loc - previus_loc).norm(p=2, dim=-1)
+        current_total_prize = td["current_total_prize"] + gather_by_index(td["prize"], current_node, dim=-1)
+        visited = td["visited"].scatter(-1, current_node, 1)
+        done = (current_node.squeeze(-1) == 0) & (td["i"] > 0)
+        td.update(
+            {
+                "tour_length": tour_length,
+                "current_node": current_node,
+                "visited": visited,
+                "current_total_prize": current_total_prize,
+                "i": td["i"] + 1,
+                "reward": torch.zeros_like(done),
+                "done": done,
+            }
+        )
+        td["action_mask"] = self.get_action_mask(td)
+        return td
+
+    @staticmethod
+    def get_action_mask(td: dict) -> Tensor:
+        """op/env.py:137-154"""
+        current_loc = gather_by_index(td["locs"], td["current_node"])[..., None, :]
+        exceeds_length = td["tour_length"][..., None] + (td["locs"] - current_loc).norm(p=2, dim=-1) > td["max_length"]
+        mask = td["visited"] | td["visited"][..., 0:1] | exceeds_length
+        action_mask = ~mask
+        action_mask[..., 0] = 1  # the depot can always be visited
+        return action_mask
+
+    def get_reward(self, td: dict, actions: Tensor, check_solution: bool | None = None) -> Tensor:
+        """base.py:180-190 -> op/env.py:156-166"""
+        check_solution = self.check_solution if check_solution is None else check_solution
+        if check_solution:
+            self.check_solution_validity(td, actions)
+        if actions.size(-1) == 1:
+            assert (actions == 0).all(), "If all length 1 tours, they should be zero"
+            return torch.zeros(actions.size(0), dtype=torch.float, device=actions.device)
+        return td["prize"].gather(1, actions).sum(-1)
+
+    @staticmethod
+    def check_solution_validity(td: dict, actions: Tensor, add_distance_to_depot: bool = True) -> None:
+        """op/env.py:168-194"""
+        sorted_actions = actions.data.sort(1)[0]
+        assert ((sorted_actions[:, 1:] == 0) | (sorted_actions[:, 1:] > sorted_actions[:, :-1])).all(), "Duplicates"
+        locs_ordered = gather_by_index(td["locs"], actions)
+        length = get_tour_length(locs_ordered)
+        max_length = td["max_length"]
+        if add_distance_to_depot:
+            max_length = max_length + (td["locs"][..., 0:1, :] - td["locs"]).norm(p=2, dim=-1) + 1e-6
+        assert (length[..., None] <= max_length + 1e-5).all(), "Max length exceeded"
+
+    def get_num_starts(self, td):
+        return get_num_starts(td, self.name)
+
+    def select_start_nodes(self, td, num_starts):
+        return select_start_nodes(td, self, num_starts)
+
+
 def get_env(name: str, num_loc: int, **kw):
-    return {"tsp": TSPEnv, "cvrp": CVRPEnv}[name](num_loc=num_loc, **kw)
+    return {"tsp": TSPEnv, "cvrp": CVRPEnv, "op": OPEnv}[name](num_loc=num_loc, **kw)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -523,6 +645,21 @@ class VRPInitEmbedding(nn.Module):
         return torch.cat((depot_embedding, node_embeddings), -2)
 
 
+class OPInitEmbedding(nn.Module):
+    """env_embeddings/init.py:254-280"""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.init_embed = nn.Linear(3, embed_dim, True)
+        self.init_embed_depot = nn.Linear(2, embed_dim, True)
+
+    def forward(self, td):
+        depot, cities = td["locs"][:, :1, :], td["locs"][:, 1:, :]
+        depot_embedding = self.init_embed_depot(depot)
+        node_embeddings = self.init_embed(torch.cat((cities, td["prize"][..., 1:, None]), -1))
+        return torch.cat((depot_embedding, node_embeddings), -2)
+
+
 class TSPContext(nn.Module):
     """env_embeddings/context.py:50-60,105-134"""
 
@@ -567,6 +704,21 @@ class VRPContext(nn.Module):
         return self.project_context(context_embedding)
 
 
+class OPContext(nn.Module):
+    """env_embeddings/context.py:50-74,201-213: current node embedding + remaining length"""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.project_context = nn.Linear(embed_dim + 1, embed_dim, bias=False)
+
+    def forward(self, embeddings, td):
+        cur_node_embedding = gather_by_index(embeddings, td["current_node"])
+        state_embedding = (td["max_length"][..., 0] - td["tour_length"])[..., None]
+        context_embedding = torch.cat([cur_node_embedding, state_embedding], -1)
+        return self.project_context(context_embedding)
+
+
 class StaticEmbedding(nn.Module):
     """env_embeddings/dynamic.py:47-57"""
 
@@ -592,7 +744,7 @@ class AttentionModelEncoder(nn.Module):
                  normalization="batch", feedforward_hidden=512, sdpa_fn=None):
         super().__init__()
         self.env_name = env_name
-        self.init_embedding = {"tsp": TSPInitEmbedding, "cvrp": VRPInitEmbedding}[env_name](embed_dim)
+        self.init_embedding = {"tsp": TSPInitEmbedding, "cvrp": VRPInitEmbedding, "op": OPInitEmbedding}[env_name](embed_dim)
         self.net = GraphAttentionNetwork(
             num_heads, embed_dim, num_layers, normalization, feedforward_hidden, sdpa_fn=sdpa_fn
         )
@@ -613,7 +765,7 @@ class AttentionModelDecoder(nn.Module):
         self.env_name = env_name
         self.embed_dim = embed_dim
         self.num_heads = num_heads
-        self.context_embedding = {"tsp": TSPContext, "cvrp": VRPContext}[env_name](embed_dim)
+        self.context_embedding = {"tsp": TSPContext, "cvrp": VRPContext, "op": OPContext}[env_name](embed_dim)
         self.dynamic_embedding = StaticEmbedding()
         self.is_dynamic_embedding = False
         self.pointer = PointerAttention(

@@ -45,6 +45,7 @@ typedef struct {
   const float* locs;      /* [N,2] */
   const int64_t* actions; /* [T] */
   int prepend, n;
+  const float* values;    /* non-NULL: element t is values[actions[t]] (OP reward: gathered prizes) */
 } tour_view;
 
 static inline void tv_point(const tour_view* tv, int t, float* x, float* y) {
@@ -56,6 +57,7 @@ static inline void tv_point(const tour_view* tv, int t, float* x, float* y) {
 }
 
 static inline float tv_seg(const tour_view* tv, int t) {
+  if (tv->values) return tv->values[tv->actions[t]];
   float x0, y0, x1, y1;
   tv_point(tv, t, &x0, &y0);
   tv_point(tv, t + 1 == tv->n ? 0 : t + 1, &x1, &y1); /* torch.roll(-1) */
@@ -97,11 +99,17 @@ static float lane_row_sum(const tour_view* tv, int lane8, int nvec) {
   return acc[0][0];
 }
 
-int oracle_tour_length_f32(const float* locs, const int64_t* actions, int B, int B_locs, int N, int T,
-                           int prepend_depot, int negate, float* out) {
+static int row_sums(const float* locs, const float* gather_values, const int64_t* actions, int B, int B_locs, int N, int T,
+                    int prepend_depot, int negate, float* out) {
   for (int b = 0; b < B; ++b) {
     tour_view tv = {locs + (int64_t)(b % B_locs) * N * 2, actions + (int64_t)b * T, prepend_depot ? 1 : 0,
-                    T + (prepend_depot ? 1 : 0)};
+                    T + (prepend_depot ? 1 : 0), NULL};
+    if (gather_values) { /* out[b] = sum_t values[b % B_locs][actions[b][t]]  (op/env.py:156-166) */
+      tv.locs = NULL;
+      tv.values = gather_values + (int64_t)(b % B_locs) * N;
+      tv.prepend = 0;
+      tv.n = T;
+    }
     const int n = tv.n, nvec = n / 8;
     float fin = 0.0f;
     if (n < 8) {
@@ -121,6 +129,16 @@ int oracle_tour_length_f32(const float* locs, const int64_t* actions, int B, int
     out[b] = negate ? -fin : fin;
   }
   return 0;
+}
+
+int oracle_tour_length_f32(const float* locs, const int64_t* actions, int B, int B_locs, int N, int T,
+                           int prepend_depot, int negate, float* out) {
+  return row_sums(locs, NULL, actions, B, B_locs, N, T, prepend_depot, negate, out);
+}
+
+/* OPEnv._get_reward (op/env.py:156-166): prize.gather(1, actions).sum(-1), ATen's inner-dim sum order */
+int oracle_gather_sum_f32(const float* values, const int64_t* actions, int B, int B_values, int N, int T, float* out) {
+  return row_sums(NULL, values, actions, B, B_values, N, T, 0, 0, out);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -178,6 +196,49 @@ int oracle_cvrp_step(const int64_t* action, const float* demand, float* used, co
   return 0;
 }
 
+/* ---- orienteering problem (envs/routing/op/env.py) ------------------------------------------- */
+static inline float op_dist(const float* locs, int i, int j) { /* (locs[j] - locs[i]).norm(p=2, dim=-1) */
+  const float dx = locs[2 * j] - locs[2 * i], dy = locs[2 * j + 1] - locs[2 * i + 1];
+  return sqrtf(fmaf(dy, dy, dx * dx));
+}
+
+/* op/env.py:118-122: max_length[b][j] = (max_length[b] - |depot - loc_j|) - 1e-6 */
+int oracle_op_max_length(const float* locs, const float* max_length, int B, int N, float* out) {
+  for (int b = 0; b < B; ++b)
+    for (int j = 0; j < N; ++j) out[(int64_t)b * N + j] = (max_length[b] - op_dist(locs + (int64_t)b * N * 2, j, 0)) - 1e-6f;
+  return 0;
+}
+
+/* op/env.py:137-154 */
+static void op_mask_row(const float* locs, const float* maxlen, float tour, const uint8_t* vis, int cur, uint8_t* mk, int N) {
+  for (int j = 0; j < N; ++j) {
+    const int exceeds = tour + op_dist(locs, cur, j) > maxlen[j];
+    mk[j] = (vis[j] || vis[0] || exceeds) ? 0 : 1;
+  }
+  mk[0] = 1; /* the depot can always be visited */
+}
+
+/* op/env.py:67-98 (action == NULL: mask only, as at reset) */
+int oracle_op_step(const int64_t* action, const float* locs, const float* maxlen, float* tour_length, uint8_t* visited,
+                   int64_t* cur, int64_t* step_i, uint8_t* mask, uint8_t* done, int B, int B_inst, int N) {
+  for (int b = 0; b < B; ++b) {
+    const float* lc = locs + (int64_t)(b % B_inst) * N * 2;
+    const float* ml = maxlen + (int64_t)(b % B_inst) * N;
+    uint8_t* vis = visited + (int64_t)b * N;
+    if (action) {
+      const int64_t a = action[b];
+      if (a < 0 || a >= N) return 1;
+      tour_length[b] = tour_length[b] + op_dist(lc, (int)cur[b], (int)a);
+      vis[a] = 1;
+      done[b] = (a == 0 && step_i[b] > 0) ? 1 : 0;
+      step_i[b] += 1;
+      cur[b] = a;
+    }
+    op_mask_row(lc, ml, tour_length[b], vis, (int)cur[b], mask + (int64_t)b * N, N);
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* AttentionModel decode loop in the specified operation order                                  */
 /* ------------------------------------------------------------------------------------------ */
@@ -219,12 +280,16 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
     const float* ctxf = a->env == RL4CO_ENV_TSP ? a->ctx_first + (int64_t)cb * N * D : NULL;
     uint8_t* gmask = a->action_mask + (int64_t)r * N;
     memcpy(mk, gmask, (size_t)N);
-    if (a->env == RL4CO_ENV_CVRP) memcpy(vis, a->visited + (int64_t)r * N, (size_t)N);
+    if (a->env != RL4CO_ENV_TSP) memcpy(vis, a->visited + (int64_t)r * N, (size_t)N);
     int cur = (int)a->current_node[r];
     int first = a->env == RL4CO_ENV_TSP ? (int)a->first_node[r] : 0;
-    long long step_i = a->env == RL4CO_ENV_TSP ? a->step_i[r] : 0;
-    float used = a->env == RL4CO_ENV_CVRP ? a->used_capacity[r] : 0.0f;
-    const float cap = a->env == RL4CO_ENV_CVRP ? a->vehicle_capacity[r] : 0.0f;
+    long long step_i = a->env != RL4CO_ENV_CVRP ? a->step_i[r] : 0;
+    /* OP: `used` is the tour length so far and `cap` the longest tour that may still reach the depot
+     * directly, max_length[.., 0]; the context scalar is cap - used in both environments */
+    float used = a->env != RL4CO_ENV_TSP ? a->used_capacity[r] : 0.0f;
+    const float* oplocs = a->env == RL4CO_ENV_OP ? a->locs + (int64_t)cb * N * 2 : NULL;
+    const float* opmax = a->env == RL4CO_ENV_OP ? a->max_length + (int64_t)cb * N : NULL;
+    const float cap = a->env == RL4CO_ENV_CVRP ? a->vehicle_capacity[r] : (a->env == RL4CO_ENV_OP ? opmax[0] : 0.0f);
     const float* dem = a->env == RL4CO_ENV_CVRP ? a->demand + (int64_t)cb * (N - 1) : NULL;
     int done = a->done[r] != 0;
     uint32_t errbits = 0;
@@ -386,6 +451,13 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
         int any = 0;
         for (int j = 0; j < N; ++j) any |= mk[j];
         done = !any;
+      } else if (a->env == RL4CO_ENV_OP) {
+        used = used + op_dist(oplocs, cur, bi); /* op/env.py:71-73 */
+        vis[bi] = 1;
+        done = (bi == 0) && (step_i > 0);       /* op/env.py:84 */
+        step_i += 1;
+        cur = bi;
+        op_mask_row(oplocs, opmax, used, vis, cur, mk, N);
       } else {
         int di = bi - 1;
         if (di < 0) di = 0;
@@ -401,15 +473,12 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
     }
     if (!single && !done && t >= a->max_steps) errbits |= RL4CO_EBIT_MAX_STEPS;
     memcpy(gmask, mk, (size_t)N);
-    if (a->env == RL4CO_ENV_CVRP) memcpy(a->visited + (int64_t)r * N, vis, (size_t)N);
+    if (a->env != RL4CO_ENV_TSP) memcpy(a->visited + (int64_t)r * N, vis, (size_t)N);
     a->current_node[r] = cur;
     a->done[r] = done ? 1 : 0;
-    if (a->env == RL4CO_ENV_TSP) {
-      a->first_node[r] = first;
-      a->step_i[r] = step_i;
-    } else {
-      a->used_capacity[r] = used;
-    }
+    if (a->env == RL4CO_ENV_TSP) a->first_node[r] = first;
+    if (a->env != RL4CO_ENV_CVRP) a->step_i[r] = step_i;
+    if (a->env != RL4CO_ENV_TSP) a->used_capacity[r] = used;
     if (a->n_steps) a->n_steps[r] = t;
     if (a->entropy) a->entropy[r] += ent_acc;
     errbits_all |= errbits;

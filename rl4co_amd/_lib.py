@@ -11,7 +11,7 @@ from functools import lru_cache
 from . import build as _build
 
 RL4CO_OK = 0
-ENV_TSP, ENV_CVRP = 0, 1
+ENV_TSP, ENV_CVRP, ENV_OP = 0, 1, 2
 DECODE_GREEDY, DECODE_SAMPLE, DECODE_EVALUATE = 0, 1, 2
 DT_F32, DT_BF16 = 0, 1
 VARIANT_AUTO, VARIANT_STREAM, VARIANT_LDS, VARIANT_WIDE, VARIANT_MS = 0, 1, 2, 3, 4
@@ -22,6 +22,8 @@ EBIT_INVALID_TOUR = 4
 EBIT_CAPACITY = 8
 EBIT_MAX_STEPS = 16
 EBIT_NEG_INF_LOGP = 32
+EBIT_DUPLICATES = 64
+EBIT_MAX_LENGTH = 128
 
 # Reference assertion messages (file:line in the reference checkout) per sticky bit.
 ERROR_MESSAGES = {
@@ -31,6 +33,8 @@ ERROR_MESSAGES = {
     EBIT_CAPACITY: "Used more than capacity",  # cvrp/env.py:176
     EBIT_MAX_STEPS: "Exceeded maximum number of steps during decoding",  # constructive/base.py:237
     EBIT_NEG_INF_LOGP: "Logprobs should not be -inf, check sampling procedure!",  # decoding.py:56
+    EBIT_DUPLICATES: "Duplicates",  # op/env.py:181
+    EBIT_MAX_LENGTH: "Max length exceeded",  # op/env.py:192-194
 }
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -50,6 +54,7 @@ class AmDecodeArgs(C.Structure):
         ("action_mask", _vp), ("first_node", _vp), ("current_node", _vp), ("step_i", _vp),
         ("done", _vp),
         ("demand", _vp), ("used_capacity", _vp), ("vehicle_capacity", _vp), ("visited", _vp),
+        ("locs", _vp), ("max_length", _vp),
         ("exp_noise", _vp), ("philox_seed", C.c_uint64), ("philox_offset", C.c_uint64),
         ("forced_actions", _vp),
         ("t0", _i32), ("out_stride", _i32),
@@ -68,6 +73,10 @@ SYMBOLS = {
     "rl4co_cvrp_check_solution": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_tsp_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_cvrp_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_op_max_length": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_op_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_gather_sum_f32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_op_check_solution": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_am_decode": (C.c_int, [C.POINTER(AmDecodeArgs), _vp]),
     "rl4co_am_teacher_backward": (C.c_int, [_vp, _vp]),
     "rl4co_am_teacher_max_nodes": (C.c_int, []),

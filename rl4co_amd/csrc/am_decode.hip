@@ -135,7 +135,7 @@ __device__ inline int build_list(const rl4co_am_decode_args& a, const uint8_t* m
 template <int ENV>
 __device__ inline int finalize_and_step(const rl4co_am_decode_args& a, TrajState& st, float* lg, const uint16_t* fl,
                                         int F, uint8_t* mk, uint8_t* vis, const float* dem, float cap, int r, int t,
-                                        int N, int lane) {
+                                        int N, int lane, const float* oplocs = nullptr, const float* opmax = nullptr) {
   bool nan_seen = false;
   float zmax = kNegInf;
   for (int c = lane; c < F; c += 64) {
@@ -221,6 +221,26 @@ __device__ inline int finalize_and_step(const rl4co_am_decode_args& a, TrajState
     bool any_left = false;
     for (int j = lane; j < N; j += 64) any_left |= mk[j] != 0;
     st.done = !__any(any_left);  // tsp/env.py:71
+  } else if (ENV == RL4CO_ENV_OP) {
+    // orienteering (op/env.py:67-98,137-154); st.used is the tour length, distances as in the
+    // tour-length kernel: sqrt(fma(dy, dy, dx * dx))
+    const float cx = oplocs[2 * st.cur], cy = oplocs[2 * st.cur + 1];
+    const float bx = oplocs[2 * bi], by = oplocs[2 * bi + 1];
+    {
+      const float dx = bx - cx, dy = by - cy;
+      st.used = st.used + sqrtf(fmaf(dy, dy, dx * dx));
+    }
+    if (lane == 0) vis[bi] = 1;
+    st.done = (bi == 0) && (st.step_i > 0);
+    st.step_i += 1;
+    st.cur = bi;
+    wave_lds_sync();
+    const bool depot_visited = vis[0] != 0;
+    for (int j = lane; j < N; j += 64) {
+      const float dx = oplocs[2 * j] - bx, dy = oplocs[2 * j + 1] - by;
+      const bool exceeds = st.used + sqrtf(fmaf(dy, dy, dx * dx)) > opmax[j];
+      mk[j] = (j == 0 || !(vis[j] != 0 || depot_visited || exceeds)) ? 1 : 0;
+    }
   } else {
     const int di = min(max(bi - 1, 0), N - 2);                       // cvrp/env.py:71-73
     st.used = (st.used + dem[di]) * (bi != 0 ? 1.0f : 0.0f);         // cvrp/env.py:76
@@ -287,19 +307,23 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
   // ---- load the trajectory state ---------------------------------------------------
   uint8_t* gmask = a.action_mask + (int64_t)r * N;
   for (int j = lane; j < Np; j += 64) mk[j] = (j < N) ? gmask[j] : (uint8_t)0;
-  if (ENV == RL4CO_ENV_CVRP) {
+  if (ENV != RL4CO_ENV_TSP) {
     const uint8_t* gv = a.visited + (int64_t)r * N;
     for (int j = lane; j < Np; j += 64) vis[j] = (j < N) ? gv[j] : (uint8_t)1;
   }
   TrajState st;
   st.cur = (int)a.current_node[r];
   st.first = (ENV == RL4CO_ENV_TSP) ? (int)a.first_node[r] : 0;
-  st.step_i = (ENV == RL4CO_ENV_TSP) ? a.step_i[r] : 0;
-  st.used = (ENV == RL4CO_ENV_CVRP) ? a.used_capacity[r] : 0.0f;
+  st.step_i = (ENV != RL4CO_ENV_CVRP) ? a.step_i[r] : 0;
+  st.used = (ENV != RL4CO_ENV_TSP) ? a.used_capacity[r] : 0.0f;  // OP: tour length so far
   st.done = a.done[r] != 0;
   st.errbits = 0;
   st.ent_acc = 0.0f;
-  const float cap = (ENV == RL4CO_ENV_CVRP) ? a.vehicle_capacity[r] : 0.0f;
+  const float* oplocs = (ENV == RL4CO_ENV_OP) ? a.locs + (int64_t)cb * N * 2 : nullptr;
+  const float* opmax = (ENV == RL4CO_ENV_OP) ? a.max_length + (int64_t)cb * N : nullptr;
+  // the context scalar is cap - used in both depot environments (context.py:147-149, 211-213):
+  // OP: longest tour that may still end at the depot (its row of the table) minus the tour so far
+  const float cap = (ENV == RL4CO_ENV_CVRP) ? a.vehicle_capacity[r] : ((ENV == RL4CO_ENV_OP) ? opmax[0] : 0.0f);
   const float* dem = (ENV == RL4CO_ENV_CVRP) ? a.demand + (int64_t)cb * (N - 1) : nullptr;
   wave_lds_sync();
 
@@ -422,25 +446,22 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
     }
     wave_lds_sync();
 
-    finalize_and_step<ENV>(a, st, lg, fl, F, mk, vis, dem, cap, r, t, N, lane);
+    finalize_and_step<ENV>(a, st, lg, fl, F, mk, vis, dem, cap, r, t, N, lane, oplocs, opmax);
   }
   if (!single && !st.done && t >= a.max_steps) st.errbits |= RL4CO_EBIT_MAX_STEPS;
 
   // ---- write the state back ------------------------------------------------------------
   for (int j = lane; j < N; j += 64) gmask[j] = mk[j];
-  if (ENV == RL4CO_ENV_CVRP) {
+  if (ENV != RL4CO_ENV_TSP) {
     uint8_t* gv = a.visited + (int64_t)r * N;
     for (int j = lane; j < N; j += 64) gv[j] = vis[j];
   }
   if (lane == 0) {
     a.current_node[r] = st.cur;
     a.done[r] = st.done ? 1 : 0;
-    if (ENV == RL4CO_ENV_TSP) {
-      a.first_node[r] = st.first;
-      a.step_i[r] = st.step_i;
-    } else {
-      a.used_capacity[r] = st.used;
-    }
+    if (ENV == RL4CO_ENV_TSP) a.first_node[r] = st.first;
+    if (ENV != RL4CO_ENV_CVRP) a.step_i[r] = st.step_i;
+    if (ENV != RL4CO_ENV_TSP) a.used_capacity[r] = st.used;
     if (a.n_steps) a.n_steps[r] = t;
     if (a.entropy) a.entropy[r] += st.ent_acc;
     if (st.errbits) atomicOr(a.err, (int)st.errbits);
@@ -749,6 +770,8 @@ int launch_wide(const rl4co_am_decode_args& a, hipStream_t stream) {
 
 // Which kernel serves these arguments (rules from measurements on MI355X, see the kernel headers).
 inline int resolve_variant(const rl4co_am_decode_args& a) {
+  // the orienteering transition (distance-based mask) exists in the streaming kernel only
+  if (a.env == RL4CO_ENV_OP) return (a.variant == RL4CO_VARIANT_AUTO || a.variant == RL4CO_VARIANT_STREAM) ? RL4CO_VARIANT_STREAM : -1;
   const bool bf16 = a.cache_dtype == RL4CO_DT_BF16;
   // multistart on the matrix cores (am_decode_ms.hip): bf16 planes, N <= 128, plain outputs
   const bool ms_ok = bf16 && a.N <= 128 && a.B_inst > 0 && a.all_logps == nullptr && a.entropy == nullptr;
@@ -759,8 +782,6 @@ inline int resolve_variant(const rl4co_am_decode_args& a) {
   if (a.variant == RL4CO_VARIANT_LDS) return fits ? RL4CO_VARIANT_LDS : -1;
   if (a.variant == RL4CO_VARIANT_WIDE) return wide_ok ? RL4CO_VARIANT_WIDE : -1;
   if (a.max_steps < 4) return RL4CO_VARIANT_STREAM;
-  // measured (TSP-100): 474 M trajectory-steps/s at 32 starts vs 275 M for the streaming kernel, but
-  // only 128 M at 8 starts (a column tile holds 32 trajectories): worth it from 16 starts up
   if (ms_ok && a.B >= 8 * a.B_inst) return RL4CO_VARIANT_MS;  // measured: 8 starts 464 M vs 276 M trajectory-steps/s
   if (fits && a.B <= 1024) return RL4CO_VARIANT_LDS;
   // one wave per trajectory needs >= ~16 waves per CU to hide its latency chain: with fewer
@@ -805,7 +826,7 @@ extern "C" int rl4co_am_decode_variant(const rl4co_am_decode_args* args) {
 extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
   RL4CO_REQUIRE(args != nullptr);
   const rl4co_am_decode_args& a = *args;
-  RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP);
+  RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP || a.env == RL4CO_ENV_OP);
   RL4CO_REQUIRE(a.B > 0 && a.B_inst > 0 && a.B % a.B_inst == 0);
   RL4CO_REQUIRE(a.N >= 2 && a.N <= 4096);
   RL4CO_REQUIRE(a.max_steps >= 1);
@@ -820,8 +841,10 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
   RL4CO_REQUIRE(a.mode != RL4CO_DECODE_EVALUATE || a.forced_actions != nullptr);
   if (a.env == RL4CO_ENV_TSP) {
     RL4CO_REQUIRE(a.ctx_first && a.q_step0 && a.first_node && a.step_i);
-  } else {
+  } else if (a.env == RL4CO_ENV_CVRP) {
     RL4CO_REQUIRE(a.w_cap && a.demand && a.used_capacity && a.vehicle_capacity && a.visited);
+  } else {
+    RL4CO_REQUIRE(a.w_cap && a.locs && a.max_length && a.used_capacity && a.step_i && a.visited);
   }
   RL4CO_REQUIRE(rl4co_am_decode_lds_bytes(a.N, a.env) <= 160 * 1024);
   RL4CO_REQUIRE(a.variant >= RL4CO_VARIANT_AUTO && a.variant <= RL4CO_VARIANT_MS);
@@ -836,6 +859,8 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
     return a.env == RL4CO_ENV_TSP ? launch_wide<RL4CO_ENV_TSP, false>(a, s)
                                   : launch_wide<RL4CO_ENV_CVRP, false>(a, s);
   }
+  if (a.env == RL4CO_ENV_OP)
+    return a.cache_dtype == RL4CO_DT_F32 ? launch<CacheF32, RL4CO_ENV_OP>(a, s) : launch<CacheBF16, RL4CO_ENV_OP>(a, s);
   if (a.cache_dtype == RL4CO_DT_F32) {
     return a.env == RL4CO_ENV_TSP ? launch<CacheF32, RL4CO_ENV_TSP>(a, s)
                                   : launch<CacheF32, RL4CO_ENV_CVRP>(a, s);

@@ -129,3 +129,126 @@ extern "C" int rl4co_cvrp_step(const int64_t* action, const float* demand, float
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Orienteering problem (envs/routing/op/env.py). Distances are (a - b).norm(p=2, dim=-1) on a size-2
+// dim, i.e. sqrt(fma(dy, dy, dx * dx)) — the arithmetic of the tour-length kernel.
+namespace {
+
+__device__ inline float op_dist(const float* locs, int i, int j) {
+  const float dx = locs[2 * j] - locs[2 * i], dy = locs[2 * j + 1] - locs[2 * i + 1];
+  return sqrtf(fmaf(dy, dy, dx * dx));
+}
+
+__global__ void op_max_length_kernel(const float* __restrict__ locs, const float* __restrict__ max_length, int B, int N,
+                                     float* __restrict__ table) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * N) return;
+  const int b = (int)(idx / N), j = (int)(idx % N);
+  table[idx] = (max_length[b] - op_dist(locs + (int64_t)b * N * 2, j, 0)) - 1e-6f;  // op/env.py:118-122
+}
+
+__global__ void __launch_bounds__(64) op_step_kernel(const int64_t* __restrict__ action, const float* __restrict__ locs,
+                                                     const float* __restrict__ maxlen, float* __restrict__ tour_length,
+                                                     uint8_t* __restrict__ visited, int64_t* __restrict__ cur,
+                                                     int64_t* __restrict__ step_i, uint8_t* __restrict__ mask,
+                                                     uint8_t* __restrict__ done, int B, int B_inst, int N, int32_t* err) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* lc = locs + (int64_t)(b % B_inst) * N * 2;
+  const float* ml = maxlen + (int64_t)(b % B_inst) * N;
+  uint8_t* vis = visited + (int64_t)b * N;
+  uint8_t* row = mask + (int64_t)b * N;
+  float tour = tour_length[b];
+  int c = (int)cur[b];
+  bool bad = false;
+  if (action != nullptr) {
+    int64_t a = action[b];
+    if (a < 0 || a >= N) {
+      bad = true;
+      a = 0;
+    }
+    tour = tour + op_dist(lc, c, (int)a);  // op/env.py:71-73
+    if (lane == 0) {
+      const int64_t i = step_i[b];
+      vis[a] = 1;                                // op/env.py:81
+      done[b] = (a == 0 && i > 0) ? 1 : 0;       // op/env.py:84
+      step_i[b] = i + 1;
+      cur[b] = a;
+      tour_length[b] = tour;
+    }
+    c = (int)a;
+  }
+  __syncthreads();  // vis[a] visible to the wave
+  const bool depot_visited = vis[0] != 0;
+  for (int j = lane; j < N; j += 64) {
+    const bool exceeds = tour + op_dist(lc, c, j) > ml[j];  // op/env.py:142-146
+    row[j] = (j == 0 || !(vis[j] != 0 || depot_visited || exceeds)) ? 1 : 0;
+  }
+  if (bad && lane == 0 && err) atomicOr(err, RL4CO_EBIT_INFEASIBLE);
+}
+
+// op/env.py:168-194 on the padded action buffer (trailing depot zeros are neutral): duplicates among
+// the customers; closed tour length (ATen order is irrelevant for an inequality with a 1e-5 margin
+// unless the tour sits within rounding of the limit: the kernel sums in visiting order) against
+// max_length_table[j] + |loc_0 - loc_j| + 1e-6 + 1e-5 for every node j, as the reference's broadcast does.
+__global__ void __launch_bounds__(64) op_check_kernel(const int64_t* __restrict__ actions, const float* __restrict__ locs,
+                                                      const float* __restrict__ maxlen, int B_inst, int N, int T,
+                                                      int32_t* __restrict__ err) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int64_t* act = actions + (int64_t)b * T;
+  const float* lc = locs + (int64_t)(b % B_inst) * N * 2;
+  const float* ml = maxlen + (int64_t)(b % B_inst) * N;
+  __shared__ int seen[1024];
+  bool bad = false;
+  for (int j = lane; j < N; j += 64) seen[j] = 0;
+  __syncthreads();
+  for (int t = lane; t < T; t += 64) {
+    const int64_t a = act[t];
+    if (a < 0 || a >= N) bad = true;
+    else if (a != 0 && atomicAdd(&seen[a], 1) != 0) bad = true;
+  }
+  float length = 0.0f;
+  if (lane == 0) {
+    for (int t = 0; t < T; ++t) {
+      const int p0 = (int)act[t], p1 = (int)act[t + 1 == T ? 0 : t + 1];
+      if (p0 >= 0 && p0 < N && p1 >= 0 && p1 < N) length += op_dist(lc, p0, p1);
+    }
+  }
+  length = __shfl(length, 0, 64);
+  bool over = false;
+  for (int j = lane; j < N; j += 64) over |= !(length <= ((ml[j] + op_dist(lc, j, 0)) + 1e-6f) + 1e-5f);
+  if (__any(bad) && lane == 0) atomicOr(err, RL4CO_EBIT_DUPLICATES);
+  if (__any(over) && lane == 0) atomicOr(err, RL4CO_EBIT_MAX_LENGTH);
+}
+
+}  // namespace
+
+extern "C" int rl4co_op_max_length(const float* locs, const float* max_length, int B, int N, float* table, void* stream) {
+  RL4CO_REQUIRE(locs && max_length && table && B > 0 && N >= 2);
+  const int64_t total = (int64_t)B * N;
+  hipLaunchKernelGGL(op_max_length_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, rl4co::as_stream(stream), locs,
+                     max_length, B, N, table);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
+extern "C" int rl4co_op_step(const int64_t* action, const float* locs, const float* max_length_table, float* tour_length,
+                             uint8_t* visited, int64_t* current_node, int64_t* step_i, uint8_t* action_mask, uint8_t* done,
+                             int B, int B_inst, int N, int32_t* err, void* stream) {
+  RL4CO_REQUIRE(locs && max_length_table && tour_length && visited && current_node && step_i && action_mask && done);
+  RL4CO_REQUIRE(B > 0 && B_inst > 0 && B % B_inst == 0 && N >= 2);
+  hipLaunchKernelGGL(op_step_kernel, dim3(B), dim3(64), 0, rl4co::as_stream(stream), action, locs, max_length_table, tour_length,
+                     visited, current_node, step_i, action_mask, done, B, B_inst, N, err);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
+extern "C" int rl4co_op_check_solution(const int64_t* actions, const float* locs, const float* max_length_table, int B,
+                                       int B_inst, int N, int T, int32_t* err, void* stream) {
+  RL4CO_REQUIRE(actions && locs && max_length_table && err && B > 0 && B_inst > 0 && N >= 2 && N <= 1024 && T >= 1);
+  hipLaunchKernelGGL(op_check_kernel, dim3(B), dim3(64), 0, rl4co::as_stream(stream), actions, locs, max_length_table, B_inst, N,
+                     T, err);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+

@@ -21,6 +21,7 @@ struct TourView {
   const int64_t* actions;  // [T]
   int prepend;             // 1: point 0 is the depot locs[0]
   int n;                   // number of tour points = T + prepend
+  const float* values;     // non-null: element t is values[actions[t]] (OP reward: gathered prizes)
   __device__ inline float2 point(int t) const {
     int node;
     if (prepend) node = (t == 0) ? 0 : (int)actions[t - 1];
@@ -28,6 +29,7 @@ struct TourView {
     return *reinterpret_cast<const float2*>(locs + 2 * (int64_t)node);
   }
   __device__ inline float seg(int t) const {
+    if (values) return values[actions[t]];
     const float2 p0 = point(t);
     const float2 p1 = point(t + 1 == n ? 0 : t + 1);  // torch.roll(-1)
     const float dx = p1.x - p0.x;
@@ -81,7 +83,8 @@ __global__ void __launch_bounds__(256) tour_length_kernel(const float* __restric
                                                           const int64_t* __restrict__ actions,
                                                           int B, int B_locs, int N, int T,
                                                           int prepend, int negate,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out,
+                                                          const float* __restrict__ gather_values) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = gid >> 3;
   const int lane8 = gid & 7;
@@ -89,8 +92,10 @@ __global__ void __launch_bounds__(256) tour_length_kernel(const float* __restric
   TourView tv;
   tv.prepend = prepend;
   tv.n = T + prepend;
-  tv.locs = locs + (int64_t)(active ? b % B_locs : 0) * N * 2;
+  tv.locs = locs ? locs + (int64_t)(active ? b % B_locs : 0) * N * 2 : nullptr;
   tv.actions = actions + (int64_t)(active ? b : 0) * T;
+  // OPEnv._get_reward (op/env.py:156-166): the same inner-dim sum over prize.gather(1, actions)
+  tv.values = gather_values ? gather_values + (int64_t)(active ? b % B_locs : 0) * N : nullptr;
   const int n = tv.n;
   const int nvec = n / 8;
   if (n < 8) {
@@ -240,7 +245,21 @@ extern "C" int rl4co_tour_length_f32(const float* locs, const int64_t* actions, 
   const int64_t total = (int64_t)B * 8;
   const int blocks = (int)((total + threads - 1) / threads);
   hipLaunchKernelGGL(tour_length_kernel, dim3(blocks), dim3(threads), 0, rl4co::as_stream(stream),
-                     locs, actions, B, B_locs, N, T, prepend_depot ? 1 : 0, negate ? 1 : 0, out);
+                     locs, actions, B, B_locs, N, T, prepend_depot ? 1 : 0, negate ? 1 : 0, out,
+                     static_cast<const float*>(nullptr));
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
+extern "C" int rl4co_gather_sum_f32(const float* values, const int64_t* actions, int B, int B_values, int N, int T, float* out,
+                                    void* stream) {
+  RL4CO_REQUIRE(values && actions && out);
+  RL4CO_REQUIRE(B > 0 && B_values > 0 && B % B_values == 0 && N > 0 && T > 0);
+  const int threads = 256;
+  const int64_t total = (int64_t)B * 8;
+  const int blocks = (int)((total + threads - 1) / threads);
+  hipLaunchKernelGGL(tour_length_kernel, dim3(blocks), dim3(threads), 0, rl4co::as_stream(stream),
+                     static_cast<const float*>(nullptr), actions, B, B_values, N, T, 0, 0, out, values);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }

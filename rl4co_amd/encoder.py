@@ -78,7 +78,7 @@ class PackedEncoder:
         t: dict[str, Tensor] = {}
         ie = enc.init_embedding
         t["w_init"], t["b_init"] = f32(ie.init_embed.weight), f32(ie.init_embed.bias)
-        if pol.env_name == "cvrp":
+        if pol.env_name in ("cvrp", "op"):
             t["w_depot"], t["b_depot"] = f32(ie.init_embed_depot.weight), f32(ie.init_embed_depot.bias)
         t["wqkv"] = torch.stack([pack_weight(l[0].module.Wqkv.weight) for l in layers]).contiguous()
         t["bqkv"] = torch.stack([f32(l[0].module.Wqkv.bias) for l in layers]).contiguous()
@@ -142,8 +142,10 @@ class PackedEncoder:
         a.cache_dtype = _lib.DT_BF16 if cache_dtype == torch.bfloat16 else _lib.DT_F32
         a.locs = locs.data_ptr()
         ptr = lambda x: None if x is None else x.data_ptr()  # noqa: E731
-        if pol.env_name == "cvrp":
-            demand = td["demand"].float().contiguous()
+        if pol.env_name in ("cvrp", "op"):
+            # OP embeds the customers' prize where CVRP embeds their demand (init.py:115-136, 254-280)
+            third = td["demand"] if pol.env_name == "cvrp" else td["prize"][..., 1:]
+            demand = third.float().contiguous()
             a.demand, a.w_depot, a.b_depot = demand.data_ptr(), ptr(t["w_depot"]), ptr(t["b_depot"])
         a.w_init, a.b_init = ptr(t["w_init"]), ptr(t["b_init"])
         a.wqkv_packed, a.bqkv, a.wo_packed, a.bo = ptr(t["wqkv"]), ptr(t["bqkv"]), ptr(t["wo"]), ptr(t["bo"])

@@ -16,6 +16,7 @@ Out of scope (not on the rollout path): dataset files, rendering, local search, 
 from __future__ import annotations
 
 import torch
+import torch.nn.functional as F
 from torch import Tensor
 
 from . import kernels as K
@@ -88,6 +89,39 @@ class CVRPGenerator(TSPGenerator):
             {"locs": locs, "depot": depot, "demand": demand / self.capacity, "capacity": capacity},
             batch_size=batch_size,
         )
+
+
+OP_MAX_LENGTHS = {20: 2.0, 50: 3.0, 100: 4.0}  # op/generator.py:13
+
+
+class OPGenerator(TSPGenerator):
+    """op/generator.py:16-142 (uniform locations, depot sampled with them; prize_type const | unif | dist)"""
+
+    def __init__(self, num_loc: int = 20, min_loc: float = 0.0, max_loc: float = 1.0, prize_type: str = "dist",
+                 max_length: float | None = None, device="cpu", **unused):
+        super().__init__(num_loc, min_loc, max_loc, device)
+        assert prize_type in ("dist", "unif", "const"), f"Invalid prize_type: {prize_type}"
+        self.prize_type = prize_type
+        if max_length is None:
+            max_length = OP_MAX_LENGTHS.get(num_loc, None)
+        if max_length is None:
+            closest = min(OP_MAX_LENGTHS.keys(), key=lambda x: abs(x - num_loc))
+            max_length = OP_MAX_LENGTHS[closest]
+        self.max_length = max_length
+
+    def _generate(self, batch_size) -> TensorDict:
+        locs_with_depot = self._uniform((*batch_size, self.num_loc + 1, 2), self.min_loc, self.max_loc)
+        dev = locs_with_depot.device
+        if self.prize_type == "const":
+            prize = torch.ones(*batch_size, self.num_loc, device=dev)
+        elif self.prize_type == "unif":
+            prize = (1 + torch.randint(0, 100, (*batch_size, self.num_loc), device=dev).float()) / 100
+        else:  # the distance to the depot, quantised to 1..100 hundredths (op/generator.py:119-121)
+            prize = (locs_with_depot[..., 0:1, :] - locs_with_depot[..., 1:, :]).norm(p=2, dim=-1)
+            prize = (1 + (prize / prize.max(dim=-1, keepdim=True)[0] * 99).int()).float() / 100
+        max_length = torch.full((*batch_size,), self.max_length, device=dev)
+        return TensorDict({"locs": locs_with_depot[..., 1:, :], "depot": locs_with_depot[..., 0, :], "prize": prize,
+                           "max_length": max_length}, batch_size=batch_size)
 
 
 class RL4COEnvBase:
@@ -257,5 +291,69 @@ class CVRPEnv(RL4COEnvBase):
             K.raise_if_error(err)
 
 
+class OPEnv(RL4COEnvBase):
+    """Orienteering problem (envs/routing/op/env.py:16-194): collect prizes and be back at the depot
+    within ``max_length``. State and arithmetic live in ``rl4co_op_*`` (csrc/env_step.hip)."""
+
+    name = "op"
+    has_depot = True
+
+    def _default_generator(self, **kw):
+        return OPGenerator(**kw)
+
+    def _reset(self, td: TensorDict, batch_size) -> TensorDict:
+        """op/env.py:100-135; ``max_length`` becomes the per-node entry limit table"""
+        device = td["locs"].device
+        b = td["locs"].shape[0]
+        n = td["locs"].shape[-2] + 1
+        locs = torch.cat((td["depot"][:, None, :], td["locs"]), -2).contiguous()
+        td_reset = TensorDict(
+            {
+                "locs": locs,
+                "prize": F.pad(td["prize"], (1, 0), mode="constant", value=0).contiguous(),  # 0 for the depot
+                "tour_length": torch.zeros(b, device=device),
+                "max_length": K.op_max_length(locs, td["max_length"]),
+                "current_node": torch.zeros(b, 1, dtype=torch.long, device=device),
+                "visited": torch.zeros((b, n), dtype=torch.uint8, device=device),
+                "current_total_prize": torch.zeros(b, dtype=torch.float, device=device),
+                "i": torch.zeros((b,), dtype=torch.int64, device=device),
+                "action_mask": torch.zeros((b, n), dtype=torch.bool, device=device),
+                "done": torch.zeros((b,), dtype=torch.bool, device=device),
+            },
+            batch_size=[b],
+        )
+        self.get_action_mask(td_reset)
+        return td_reset
+
+    def _step(self, td: TensorDict) -> TensorDict:
+        """op/env.py:67-98 via rl4co_op_step (in place, mask included)"""
+        action = td["action"].contiguous()
+        td["current_total_prize"] += td["prize"].gather(1, action[:, None]).squeeze(1)
+        K.op_step(action, td["locs"], td["max_length"], td["tour_length"], td["visited"], td["current_node"], td["i"],
+                  td["action_mask"], td["done"])
+        return td
+
+    def get_action_mask(self, td: TensorDict) -> Tensor:
+        """op/env.py:137-154 (recomputed in place into td['action_mask'])"""
+        K.op_step(None, td["locs"], td["max_length"], td["tour_length"], td["visited"], td["current_node"], td["i"],
+                  td["action_mask"], td["done"])
+        return td["action_mask"]
+
+    def _get_reward(self, td: TensorDict, actions: Tensor) -> Tensor:
+        """op/env.py:156-166"""
+        if actions.size(-1) == 1:
+            assert bool((actions == 0).all()), "If all length 1 tours, they should be zero"
+            return torch.zeros(actions.size(0), dtype=torch.float, device=actions.device)
+        return K.gather_sum(td["prize"], actions.contiguous())
+
+    def check_solution_validity(self, td: TensorDict, actions: Tensor, err: Tensor | None = None) -> None:
+        """op/env.py:168-194. ``err``: see TSPEnv."""
+        own = err is None
+        err = K.new_error_word(actions.device) if own else err
+        K.op_check_solution(actions.contiguous(), td["locs"], td["max_length"], err)
+        if own:
+            K.raise_if_error(err)
+
+
 def get_env(name: str, **kw) -> RL4COEnvBase:
-    return {"tsp": TSPEnv, "cvrp": CVRPEnv}[name](**kw)
+    return {"tsp": TSPEnv, "cvrp": CVRPEnv, "op": OPEnv}[name](**kw)

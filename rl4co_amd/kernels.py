@@ -15,7 +15,7 @@ from . import _lib
 from .cache import FoldedCache
 
 MODE_IDS = {"greedy": _lib.DECODE_GREEDY, "sampling": _lib.DECODE_SAMPLE, "evaluate": _lib.DECODE_EVALUATE}
-ENV_IDS = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP}
+ENV_IDS = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP, "op": _lib.ENV_OP}
 VARIANT_IDS = {"auto": _lib.VARIANT_AUTO, "stream": _lib.VARIANT_STREAM, "lds": _lib.VARIANT_LDS, "wide": _lib.VARIANT_WIDE, "ms": _lib.VARIANT_MS}
 
 
@@ -214,6 +214,16 @@ def am_decode(
         a.q_step0 = _ptr(_dev(cache.q_step0, torch.float32, "q_step0"))
         a.first_node = _ptr(_dev(state["first_node"], torch.int64, "first_node"))
         a.step_i = _ptr(_dev(state["i"], torch.int64, "i"))
+    elif env_name == "op":
+        # orienteering: the tour length rides in the used_capacity slot, the per-node entry limits
+        # (max_length table) and the coordinates are instance data like CVRP's demand
+        a.w_cap = _ptr(_dev(cache.w_cap, torch.float32, "w_cap"))
+        assert state["locs"].shape[0] == cache.num_instances and state["max_length"].shape[0] == cache.num_instances
+        a.locs = _ptr(_dev(state["locs"], torch.float32, "locs"))
+        a.max_length = _ptr(_dev(state["max_length"], torch.float32, "max_length"))
+        a.used_capacity = _ptr(_dev(state["tour_length"], torch.float32, "tour_length"))
+        a.step_i = _ptr(_dev(state["i"], torch.int64, "i"))
+        a.visited = _ptr(_u8(state["visited"], "visited"))
     else:
         a.w_cap = _ptr(_dev(cache.w_cap, torch.float32, "w_cap"))
         a.demand = _ptr(_dev(state["demand"], torch.float32, "demand"))
@@ -240,6 +250,50 @@ def am_decode(
     a.err = _ptr(_dev(err, torch.int32, "err"))
     st = _lib.lib().rl4co_am_decode(C.byref(a), _stream())
     _lib.check(st, "rl4co_am_decode")
+
+
+def op_max_length(locs: Tensor, max_length: Tensor) -> Tensor:
+    """op/env.py:118-122: table[b,j] = (max_length[b] - |loc_0 - loc_j|) - 1e-6 (locs include the depot)."""
+    b, n, _ = locs.shape
+    locs = _dev(locs, torch.float32, "locs")
+    ml = _dev(max_length.reshape(-1).contiguous(), torch.float32, "max_length")
+    out = torch.empty((b, n), dtype=torch.float32, device=locs.device)
+    st = _lib.lib().rl4co_op_max_length(_ptr(locs), _ptr(ml), b, n, _ptr(out), _stream())
+    _lib.check(st, "rl4co_op_max_length")
+    return out
+
+
+def op_step(action: Tensor | None, locs: Tensor, max_length: Tensor, tour_length: Tensor, visited: Tensor,
+            current_node: Tensor, step_i: Tensor, action_mask: Tensor, done: Tensor, err: Tensor | None = None) -> None:
+    """In-place OPEnv._step + get_action_mask (op/env.py:67-98,137-154); action=None -> mask only."""
+    b, n = action_mask.shape
+    st = _lib.lib().rl4co_op_step(
+        _ptr(None if action is None else _dev(action, torch.int64, "action")), _ptr(_dev(locs, torch.float32, "locs")),
+        _ptr(_dev(max_length, torch.float32, "max_length")), _ptr(_dev(tour_length, torch.float32, "tour_length")),
+        _ptr(_u8(visited, "visited")), _ptr(_dev(current_node, torch.int64, "current_node")),
+        _ptr(_dev(step_i, torch.int64, "i")), _ptr(_u8(action_mask, "action_mask")), _ptr(_u8(done, "done")),
+        b, locs.shape[0], n, _ptr(err), _stream())
+    _lib.check(st, "rl4co_op_step")
+
+
+def gather_sum(values: Tensor, actions: Tensor) -> Tensor:
+    """out[b] = sum_t values[b % B_values, actions[b, t]] in ATen's inner-dim sum order (op/env.py:156-166)."""
+    b, t = actions.shape
+    values = _dev(values, torch.float32, "values")
+    out = torch.empty((b,), dtype=torch.float32, device=actions.device)
+    st = _lib.lib().rl4co_gather_sum_f32(_ptr(values), _ptr(_dev(actions, torch.int64, "actions")), b, values.shape[0],
+                                         values.shape[1], t, _ptr(out), _stream())
+    _lib.check(st, "rl4co_gather_sum_f32")
+    return out
+
+
+def op_check_solution(actions: Tensor, locs: Tensor, max_length: Tensor, err: Tensor) -> None:
+    """op/env.py:168-194 into the sticky error word (RL4CO_EBIT_DUPLICATES / RL4CO_EBIT_MAX_LENGTH)."""
+    b, t = actions.shape
+    st = _lib.lib().rl4co_op_check_solution(_ptr(_dev(actions, torch.int64, "actions")), _ptr(_dev(locs, torch.float32, "locs")),
+                                            _ptr(_dev(max_length, torch.float32, "max_length")), b, locs.shape[0],
+                                            locs.shape[1], t, _ptr(_dev(err, torch.int32, "err")), _stream())
+    _lib.check(st, "rl4co_op_check_solution")
 
 
 def hbm_read_probe(buf: Tensor, sink: Tensor) -> None:

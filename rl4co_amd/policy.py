@@ -216,6 +216,20 @@ class _VRPInit(nn.Module):
         return torch.cat((self.init_embed_depot(locs[:, :1, :]), self.init_embed(feats)), -2)
 
 
+class _OPInit(_VRPInit):
+    """env_embeddings/init.py:254-280: as the VRP embedding with the customers' PRIZE as third feature"""
+
+    def forward(self, td):
+        locs = td["locs"]
+        feats = torch.cat((locs[:, 1:, :], td["prize"][..., 1:, None]), -1)
+        if _train_kernels_active(locs):
+            from . import train_ops
+
+            return torch.cat((train_ops.init_embed(locs[:, :1, :], self.init_embed_depot),
+                              train_ops.init_embed(feats, self.init_embed)), -2)
+        return torch.cat((self.init_embed_depot(locs[:, :1, :]), self.init_embed(feats)), -2)
+
+
 class AttentionModelEncoder(nn.Module):
     """zoo/am/encoder.py:12-87"""
 
@@ -223,7 +237,7 @@ class AttentionModelEncoder(nn.Module):
                  feedforward_hidden=512):
         super().__init__()
         self.env_name = env_name
-        self.init_embedding = {"tsp": _TSPInit, "cvrp": _VRPInit}[env_name](embed_dim)
+        self.init_embedding = {"tsp": _TSPInit, "cvrp": _VRPInit, "op": _OPInit}[env_name](embed_dim)
         self.net = _GraphAttentionNetwork(num_heads, embed_dim, num_layers, normalization, feedforward_hidden)
 
     def forward(self, td):
@@ -267,7 +281,7 @@ class AttentionModelDecoder(nn.Module):
         self.num_heads = num_heads
         self.mask_inner = mask_inner
         self.check_nan = check_nan
-        self.context_embedding = {"tsp": _TSPContext, "cvrp": _VRPContext}[env_name](embed_dim)
+        self.context_embedding = {"tsp": _TSPContext, "cvrp": _VRPContext, "op": _VRPContext}[env_name](embed_dim)
         self.dynamic_embedding = nn.Module()  # StaticEmbedding (dynamic.py:47-57): no parameters
         self.pointer = _Pointer(embed_dim)
         self.project_node_embeddings = nn.Linear(embed_dim, 3 * embed_dim, bias=False)
@@ -371,9 +385,10 @@ class AttentionModelPolicy(nn.Module):
 
         enc = self.encoder
         init = enc.init_embedding
-        if self.env_name == "cvrp":
+        if self.env_name in ("cvrp", "op"):
             locs = td["locs"]
-            feats = torch.cat((locs[:, 1:, :], td["demand"][..., None]), -1)
+            third = td["demand"] if self.env_name == "cvrp" else td["prize"][..., 1:]
+            feats = torch.cat((locs[:, 1:, :], third[..., None]), -1)
             x = torch.cat((T.init_embed(locs[:, :1, :], init.init_embed_depot), T.init_embed(feats, init.init_embed)), -2)
         else:
             x = T.init_embed(td["locs"], init.init_embed)
@@ -407,7 +422,8 @@ class AttentionModelPolicy(nn.Module):
     @staticmethod
     def _max_horizon(env_name: str, n: int) -> int:
         # TSP: exactly N steps. CVRP: every customer + at most one depot visit per customer + 1.
-        return n if env_name == "tsp" else 2 * n
+        # OP: every customer once, the closing depot visit, and a depot pick at step 0 costs one more.
+        return n if env_name == "tsp" else (n + 2 if env_name == "op" else 2 * n)
 
     def _initial_state(self, td, num_starts: int):
         """State tensors the kernel updates in place; with multistart the rows are expanded
@@ -427,13 +443,19 @@ class AttentionModelPolicy(nn.Module):
         if self.env_name == "tsp":
             st["first_node"] = rep(td["first_node"].reshape(-1))
             st["i"] = rep(td["i"].reshape(-1))
+        elif self.env_name == "op":
+            st["locs"] = td["locs"].contiguous()              # instance data, like CVRP's demand
+            st["max_length"] = td["max_length"].contiguous()  # [B_inst, N] entry limits
+            st["tour_length"] = rep(td["tour_length"].reshape(-1))
+            st["i"] = rep(td["i"].reshape(-1))
+            st["visited"] = rep(td["visited"])
         else:
             st["demand"] = td["demand"].contiguous()
             st["used_capacity"] = rep(td["used_capacity"].reshape(-1))
             st["vehicle_capacity"] = rep(td["vehicle_capacity"].reshape(-1))
             st["visited"] = rep(td["visited"])
         if s == 1:
-            st = {k: (v.clone() if k != "demand" else v) for k, v in st.items()}
+            st = {k: (v.clone() if k not in ("demand", "locs", "max_length") else v) for k, v in st.items()}
         return st
 
     # -- forward (constructive/base.py:154-263) ---------------------------------------------------
@@ -495,7 +517,7 @@ class AttentionModelPolicy(nn.Module):
         b_inst, n = td["action_mask"].shape[0], td["action_mask"].shape[-1]
         b = b_inst * max(n_rep, 1)
         cache_g = None
-        if cache is None and grad_path and self.fused_backward and hidden.is_cuda:
+        if cache is None and grad_path and self.fused_backward and hidden.is_cuda and self.env_name in ("tsp", "cvrp"):
             from . import teacher
 
             if n <= teacher.max_nodes() and not return_entropy:
@@ -624,6 +646,9 @@ class AttentionModelPolicy(nn.Module):
         if self.env_name == "tsp":
             K.tsp_step(action, state["action_mask"], state["first_node"], state["current_node"],
                        state["i"], state["done"], err)
+        elif self.env_name == "op":
+            K.op_step(action, state["locs"], state["max_length"], state["tour_length"], state["visited"],
+                      state["current_node"], state["i"], state["action_mask"], state["done"], err)
         else:
             K.cvrp_step(action, state["demand"], state["used_capacity"], state["vehicle_capacity"],
                         state["visited"], state["current_node"], state["action_mask"], state["done"], err)
@@ -641,6 +666,9 @@ class AttentionModelPolicy(nn.Module):
         if self.env_name == "tsp":
             out.update(first_node=state["first_node"], current_node=state["current_node"],
                        i=state["i"].view(-1, 1))
+        elif self.env_name == "op":
+            out.update(prize=rep(td["prize"]), max_length=rep(td["max_length"]), current_node=state["current_node"].view(-1, 1),
+                       tour_length=state["tour_length"], visited=state["visited"], i=state["i"])
         else:
             out.update(demand=rep(td["demand"]), current_node=state["current_node"].view(-1, 1),
                        used_capacity=state["used_capacity"].view(-1, 1),
@@ -722,6 +750,9 @@ class AttentionModelPolicy(nn.Module):
             if self.env_name == "tsp":
                 first[:, t] = state["first_node"]
                 use_ph[:, t] = state["i"] < 1
+            elif self.env_name == "op":
+                ml0 = state["max_length"][:, 0]
+                rem[:, t] = (ml0 if ml0.shape[0] == b else ml0.repeat(b // ml0.shape[0])) - state["tour_length"]
             else:
                 rem[:, t] = state["vehicle_capacity"] - state["used_capacity"]
             self._env_step_state(state, actions[:, t].contiguous(), err)

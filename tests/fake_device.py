@@ -26,6 +26,22 @@ def _cvrp_step(action, demand, used_capacity, vehicle_capacity, visited, current
                        visited, current_node, action_mask, done)
 
 
+def _op_step(action, locs, max_length, tour_length, visited, current_node, step_i, action_mask, done, err=None):
+    c_oracle.op_step(None if action is None else action.contiguous(), locs, max_length, tour_length, visited, current_node,
+                     step_i, action_mask, done)
+
+
+def _op_check(actions, locs, max_length, err):
+    from oracle import reference_torch as R
+
+    s = actions.shape[0] // locs.shape[0]
+    td = {"locs": R.batchify(locs, s) if s > 1 else locs, "max_length": R.batchify(max_length, s) if s > 1 else max_length}
+    try:
+        R.OPEnv.check_solution_validity(td, actions)
+    except AssertionError as e:
+        err |= 64 if "Duplicates" in str(e) else 128
+
+
 def _select_start_nodes(batch, num_starts, num_loc, has_depot, device):
     return torch.arange(num_starts).repeat_interleave(batch) % num_loc + (1 if has_depot else 0)
 
@@ -72,5 +88,9 @@ def cpu_device(monkeypatch):
     monkeypatch.setattr(K, "select_start_nodes", _select_start_nodes)
     monkeypatch.setattr(K, "tsp_check_solution", _tsp_check)
     monkeypatch.setattr(K, "cvrp_check_solution", _cvrp_check)
+    monkeypatch.setattr(K, "op_step", _op_step)
+    monkeypatch.setattr(K, "op_max_length", c_oracle.op_max_length)
+    monkeypatch.setattr(K, "gather_sum", lambda values, actions: c_oracle.gather_sum(values.contiguous(), actions.contiguous()))
+    monkeypatch.setattr(K, "op_check_solution", _op_check)
     monkeypatch.setattr(K, "am_decode", _am_decode)
     return "cpu"

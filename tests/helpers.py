@@ -114,6 +114,12 @@ def rollout_state(env_name: str, td: dict, device="cpu", num_starts: int = 0) ->
     if env_name == "tsp":
         st["first_node"] = rep(td["first_node"].reshape(-1))
         st["i"] = rep(td["i"].reshape(-1))
+    elif env_name == "op":
+        st["locs"] = td["locs"].to(device).contiguous()
+        st["max_length"] = td["max_length"].to(device).contiguous()
+        st["tour_length"] = rep(td["tour_length"].reshape(-1))
+        st["i"] = rep(td["i"].reshape(-1))
+        st["visited"] = rep(td["visited"].to(torch.uint8))
     else:
         st["demand"] = td["demand"].to(device).contiguous()
         st["used_capacity"] = rep(td["used_capacity"].reshape(-1))
@@ -126,4 +132,20 @@ device_state = rollout_state  # name used by the GPU tests
 
 
 def max_horizon(env_name: str, n: int) -> int:
-    return n if env_name == "tsp" else 2 * n
+    return n if env_name == "tsp" else (n + 2 if env_name == "op" else 2 * n)
+
+
+def oracle_reward(env_name: str, td0: dict, actions: torch.Tensor) -> torch.Tensor:
+    """The environment's reward of `actions` through the C oracle (tour length, or gathered prizes for OP)."""
+    from oracle import c_oracle
+
+    if env_name == "op":
+        return c_oracle.gather_sum(td0["prize"].contiguous(), actions.contiguous())
+    return c_oracle.tour_length(td0["locs"], actions, prepend_depot=(env_name == "cvrp"), negate=True)
+
+
+def kernel_reward(K, env_name: str, td0: dict, actions: torch.Tensor) -> torch.Tensor:
+    """Same through the HIP kernels (inputs are moved to the GPU)."""
+    if env_name == "op":
+        return K.gather_sum(td0["prize"].cuda().contiguous(), actions.cuda().contiguous())
+    return K.tour_length(td0["locs"].cuda(), actions.cuda().contiguous(), prepend_depot=(env_name == "cvrp"), negate=True)

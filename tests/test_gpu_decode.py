@@ -16,7 +16,7 @@ import torch
 
 from oracle import c_oracle
 from oracle import reference_torch as R
-from tests.helpers import GoldenCase, fold_cache, manifest, max_horizon, rollout_state
+from tests.helpers import kernel_reward, GoldenCase, fold_cache, manifest, max_horizon, rollout_state
 
 pytestmark = pytest.mark.gpu
 
@@ -226,7 +226,7 @@ def _vs_golden(K, g, actions, logps, t, td0, max_flips):
     same = (actions == g.actions).all(1)
     flips = int((~same).sum())
     assert flips <= max_flips, f"{flips} of {len(same)} trajectories differ from the reference"
-    reward = K.tour_length(td0["locs"].cuda(), actions.cuda(), prepend_depot=(g.env_name == "cvrp"), negate=True).cpu()
+    reward = kernel_reward(K, g.env_name, td0, actions).cpu()
     # the kernel's tour length of its own actions == ATen's arithmetic on the same actions, bit for bit
     rows = R.batchify({k: v for k, v in td0.items() if torch.is_tensor(v)}, g.num_starts) if g.num_starts else td0
     env = R.get_env(g.env_name, g.num_loc, check_solution=True)

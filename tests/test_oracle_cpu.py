@@ -10,7 +10,7 @@ import torch
 
 from oracle import c_oracle
 from oracle import reference_torch as R
-from tests.helpers import (GoldenCase, clone_td, fold_cache, make_instances, manifest, max_horizon,
+from tests.helpers import (GoldenCase, oracle_reward, clone_td, fold_cache, make_instances, manifest, max_horizon,
                            rollout_state)
 
 ALL_CASES = sorted(manifest())
@@ -158,7 +158,7 @@ def test_c_oracle_greedy_matches_reference(name):
     same = (actions == g.actions).all(1)
     flips = int((~same).sum())
     assert flips <= max(1, g.actions.shape[0] // 100), f"{flips} of {len(same)} trajectories differ"
-    reward = c_oracle.tour_length(td0["locs"], actions, prepend_depot=(g.env_name == "cvrp"), negate=True)
+    reward = oracle_reward(g.env_name, td0, actions)
     assert torch.equal(reward[same], g.reward[same])
     torch.testing.assert_close(logps.sum(1)[same], g.log_likelihood[same], rtol=1e-5, atol=2e-5)
     # a flipped trajectory is still a valid tour of near-identical quality
@@ -184,7 +184,7 @@ def test_c_oracle_sampling_matches_reference(name):
     t = g.actions.shape[1]
     same = (actions[:, :t] == g.actions).all(1) if actions.shape[1] == t else torch.zeros(b, dtype=torch.bool)
     assert int((~same).sum()) <= max(1, b // 50)
-    reward = c_oracle.tour_length(td0["locs"], actions, prepend_depot=(g.env_name == "cvrp"), negate=True)
+    reward = oracle_reward(g.env_name, td0, actions)
     assert torch.equal(reward[same], g.reward[same])
     torch.testing.assert_close(reward.mean(), g.reward.mean(), rtol=1e-5, atol=0) if bool(same.all()) else None
     torch.testing.assert_close(logps[:, :t].sum(1)[same], g.log_likelihood[same], rtol=1e-5, atol=5e-5)
