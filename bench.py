@@ -111,7 +111,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--env", default="tsp", choices=["tsp", "cvrp"])
+    ap.add_argument("--env", default="tsp", choices=["tsp", "cvrp", "op"])
     ap.add_argument("--num-loc", type=int, default=100)
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--cache-dtype", default="bf16", choices=["bf16", "f32"])
@@ -182,7 +182,7 @@ def main() -> None:
     encode_ms = [a.elapsed_time(b) for a, b in policy.encode_events]
     policy.decode_events = policy.encode_events = None
     t_steps = out["actions"].shape[1]
-    n_nodes = args.num_loc + (1 if args.env == "cvrp" else 0)
+    n_nodes = args.num_loc + (0 if args.env == "tsp" else 1)
 
     # whole-job numbers: wall = max over ranks, work = sum over ranks (each rank owns its shard)
     wall = D.reduce_scalar(wall, "max", device)

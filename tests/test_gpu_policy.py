@@ -97,3 +97,32 @@ def test_cpu_policy_call_fails_loudly():
     with pytest.raises(Rl4coLibraryError, match="no CPU fallback"):
         with torch.inference_mode():
             pol(env.reset(td), env, phase="test")
+
+
+def test_op_policy_trains_and_validates_on_gpu():
+    """Orienteering end to end on the device: rollouts are valid (check_solution on), the REINFORCE
+    gradient (torch teacher-forced re-evaluation: the backward kernels serve TSP / CVRP only) is
+    finite and a few steps raise the collected prize."""
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    torch.manual_seed(0)
+    env = get_env("op", generator_params=dict(num_loc=20, device="cuda"), device="cuda", check_solution=True)
+    pol = AttentionModelPolicy("op").cuda().train()
+    data = env.generator(batch_size=[256])
+    opt = torch.optim.Adam(pol.parameters(), lr=1e-3)
+    prizes = []
+    for i in range(25):
+        out = pol(env.reset(data), env, phase="train", seed=i)
+        r = out["reward"]
+        loss = -((r - r.mean()).detach() * out["log_likelihood"]).mean()
+        opt.zero_grad()
+        loss.backward()
+        assert all(torch.isfinite(p.grad).all() for p in pol.parameters() if p.grad is not None)
+        opt.step()
+        prizes.append(float(r.mean()))
+    assert sum(prizes[-5:]) / 5 > sum(prizes[:5]) / 5 + 0.05, prizes
+    pol.eval()
+    with torch.inference_mode():
+        out = pol(env.reset(data), env, phase="test", decode_type="greedy")
+    assert float(out["reward"].mean()) > 0
