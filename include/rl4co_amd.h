@@ -227,6 +227,9 @@ typedef struct rl4co_am_decode_args {
   float* all_logps;         /* [B,out_stride,N] or NULL (store_all_logp / entropy)         */
   float* entropy;           /* [B] accumulated -sum p log p, or NULL                       */
   int32_t* n_steps;         /* [B] steps actually taken by each trajectory, or NULL        */
+  int32_t* steps_summary;   /* [2] or NULL: [0] = max, [1] += sum over trajectories of the  */
+                            /* steps taken (zero-initialised): what the host needs of        */
+                            /* n_steps, without a reduction launch                           */
   int32_t* err;             /* sticky error bits                                           */
 } rl4co_am_decode_args;
 

@@ -138,7 +138,8 @@ def am_decode(cache, state: dict, *, mode: str, max_steps: int, actions: Tensor,
               row_groups: int, t0: int = 0, tanh_clipping: float = 10.0, temperature: float = 1.0,
               mask_inner: bool = True, mask_logits: bool = True, exp_noise: Tensor | None = None,
               philox_seed: int = 0, philox_offset: int = 0, forced_actions: Tensor | None = None,
-              all_logps: Tensor | None = None, entropy: Tensor | None = None, n_steps: Tensor | None = None) -> None:
+              all_logps: Tensor | None = None, entropy: Tensor | None = None, n_steps: Tensor | None = None,
+              steps_summary: Tensor | None = None) -> None:
     """Mirror of ``rl4co_amd.kernels.am_decode`` for CPU tensors, run by the C oracle.
 
     ``cache`` is a ``rl4co_amd.cache.FoldedCache`` whose tensors live on the CPU (bf16 planes are
@@ -189,6 +190,7 @@ def am_decode(cache, state: dict, *, mode: str, max_steps: int, actions: Tensor,
     a.all_logps = _p(None if all_logps is None else _cpu(all_logps, torch.float32))
     a.entropy = _p(None if entropy is None else _cpu(entropy, torch.float32))
     a.n_steps = _p(None if n_steps is None else _cpu(n_steps, torch.int32))
+    a.steps_summary = _p(None if steps_summary is None else _cpu(steps_summary, torch.int32))
     a.err = _p(_cpu(err, torch.int32))
     st = lib().oracle_am_decode(C.byref(a), int(row_groups))
     assert st == 0, "oracle_am_decode rejected its arguments"

@@ -480,6 +480,10 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
     if (a->env != RL4CO_ENV_CVRP) a->step_i[r] = step_i;
     if (a->env != RL4CO_ENV_TSP) a->used_capacity[r] = used;
     if (a->n_steps) a->n_steps[r] = t;
+    if (a->steps_summary) {
+      if (t > a->steps_summary[0]) a->steps_summary[0] = t;
+      a->steps_summary[1] += t;
+    }
     if (a->entropy) a->entropy[r] += ent_acc;
     errbits_all |= errbits;
   }

@@ -59,7 +59,7 @@ class AmDecodeArgs(C.Structure):
         ("forced_actions", _vp),
         ("t0", _i32), ("out_stride", _i32),
         ("actions", _vp), ("logps", _vp), ("all_logps", _vp), ("entropy", _vp),
-        ("n_steps", _vp), ("err", _vp),
+        ("n_steps", _vp), ("steps_summary", _vp), ("err", _vp),
     ]
 
 

@@ -463,6 +463,10 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
     if (ENV != RL4CO_ENV_CVRP) a.step_i[r] = st.step_i;
     if (ENV != RL4CO_ENV_TSP) a.used_capacity[r] = st.used;
     if (a.n_steps) a.n_steps[r] = t;
+    if (a.steps_summary) {
+      atomicMax(a.steps_summary, t);
+      atomicAdd(a.steps_summary + 1, t);
+    }
     if (a.entropy) a.entropy[r] += st.ent_acc;
     if (st.errbits) atomicOr(a.err, (int)st.errbits);
   }
@@ -750,6 +754,10 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_wide_kernel(const
         a.used_capacity[r] = st.used;
       }
       if (a.n_steps) a.n_steps[r] = t;
+      if (a.steps_summary) {
+        atomicMax(a.steps_summary, t);
+        atomicAdd(a.steps_summary + 1, t);
+      }
       if (a.entropy) a.entropy[r] += st.ent_acc;
       if (st.errbits) atomicOr(a.err, (int)st.errbits);
     }

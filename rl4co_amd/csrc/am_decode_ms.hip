@@ -532,6 +532,10 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
       a.current_node[x.r] = x.cur;
       a.done[x.r] = x.done ? 1 : 0;
       if (a.n_steps) a.n_steps[x.r] = x.nsteps;
+      if (a.steps_summary) {
+        atomicMax(a.steps_summary, x.nsteps);
+        atomicAdd(a.steps_summary + 1, x.nsteps);
+      }
       if (!single && !x.done) errbits |= RL4CO_EBIT_MAX_STEPS;
     }
   }

@@ -176,6 +176,7 @@ def am_decode(
     all_logps: Tensor | None = None,
     entropy: Tensor | None = None,
     n_steps: Tensor | None = None,
+    steps_summary: Tensor | None = None,
     variant: str = "auto",
 ) -> None:
     """Run ``max_steps`` fused decode steps (1 = a single step, >= horizon = whole rollout).
@@ -247,6 +248,7 @@ def am_decode(
     a.all_logps = _ptr(None if all_logps is None else _dev(all_logps, torch.float32, "all_logps"))
     a.entropy = _ptr(None if entropy is None else _dev(entropy, torch.float32, "entropy"))
     a.n_steps = _ptr(None if n_steps is None else _dev(n_steps, torch.int32, "n_steps"))
+    a.steps_summary = _ptr(None if steps_summary is None else _dev(steps_summary, torch.int32, "steps_summary"))
     a.err = _ptr(_dev(err, torch.int32, "err"))
     st = _lib.lib().rl4co_am_decode(C.byref(a), _stream())
     _lib.check(st, "rl4co_am_decode")

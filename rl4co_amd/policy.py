@@ -529,7 +529,9 @@ class AttentionModelPolicy(nn.Module):
                                                       self.encoder_autocast or torch.float32)
         state = self._initial_state(td, n_rep)
         horizon = min(self._max_horizon(self.env_name, n), max_steps)
-        err = K.new_error_word(device)
+        # status word read back ONCE per rollout: [sticky error bits, longest trajectory, streamed instance-steps]
+        status = torch.zeros(3, dtype=torch.int32, device=device)
+        err = status[:1]
 
         # pre_decoder_hook (decoding.py:306-326): with multistart the first action is imposed per
         # start (log-prob 0) and consumes NO column of a caller-provided `actions` tensor — the
@@ -546,7 +548,6 @@ class AttentionModelPolicy(nn.Module):
             tmax = horizon
         out_actions = torch.zeros((b, tmax), dtype=torch.int64, device=device)
         logps = torch.zeros((b, tmax), dtype=torch.float32, device=device)
-        n_steps = torch.zeros((b,), dtype=torch.int32, device=device)
         all_logps = torch.zeros((b, tmax, n), dtype=torch.float32, device=device) if store_all_logp else None
 
         if t0 == 1:
@@ -566,7 +567,7 @@ class AttentionModelPolicy(nn.Module):
             cache, state, mode=mode, max_steps=tmax - t0, t0=t0, actions=out_actions, logps=logps, err=err,
             tanh_clipping=tanh_clipping, temperature=temperature, mask_inner=self.decoder.mask_inner,
             mask_logits=mask_logits, exp_noise=exp_noise, philox_seed=philox_seed,
-            forced_actions=forced, all_logps=all_logps, n_steps=n_steps,
+            forced_actions=forced, all_logps=all_logps, steps_summary=status[1:3],
         )
         if self.decode_events is not None:
             ev1.record()
@@ -576,8 +577,7 @@ class AttentionModelPolicy(nn.Module):
         checked = bool(calc_reward and env.check_solution and not (n_rep > 0 and select_best))
         if checked:
             env.check_solution_validity(td, out_actions, err=err)
-        horizon_used, streamed, err_bits = torch.stack(
-            (n_steps.max().to(torch.int64), n_steps.sum(dtype=torch.int64), err[0].to(torch.int64))).tolist()
+        err_bits, horizon_used, streamed = status.tolist()  # one 12-byte read-back, no reduction launches
         t_used = t0 + int(horizon_used)
         self.last_instance_steps = int(streamed)  # instance-steps the decode launch really streamed
         from . import _lib as _l
