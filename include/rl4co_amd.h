@@ -345,6 +345,8 @@ typedef struct rl4co_am_teacher_args {
   const int64_t* actions;        /* [B,T]                                           */
   const float* demand;           /* [B_inst,N-1] CVRP                               */
   const float* vehicle_capacity; /* [B_inst] CVRP                                   */
+  const float* locs;             /* [B_inst,N,2] OP (MMA variant only)              */
+  const float* max_length;       /* [B_inst,N] OP entry-limit table                 */
   const float* grad_logp;        /* [B,T]                                           */
   float* d_kvl;                  /* [3,B_inst,N,128]                                */
   float* d_ctx_first;            /* [B_inst,N,128] TSP, zero-initialised            */

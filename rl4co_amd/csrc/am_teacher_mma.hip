@@ -172,7 +172,11 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
   const float* ctxc = a.ctx_cur + (int64_t)inst * N * kD + dcol;
   const float* ctxf = (ENV == RL4CO_ENV_TSP) ? a.ctx_first + (int64_t)inst * N * kD + dcol : nullptr;
   const float* dem = (ENV == RL4CO_ENV_CVRP) ? a.demand + (int64_t)inst * (N - 1) : nullptr;
-  const float cap = (ENV == RL4CO_ENV_CVRP) ? a.vehicle_capacity[inst] : 0.0f;
+  const float* oplocs = (ENV == RL4CO_ENV_OP) ? a.locs + (int64_t)inst * N * 2 : nullptr;
+  const float* opmax = (ENV == RL4CO_ENV_OP) ? a.max_length + (int64_t)inst * N : nullptr;
+  // context scalar = cap - used in both depot environments (OP: longest tour that may still end at
+  // the depot minus the tour so far, env_embeddings/context.py:147-149, 211-213)
+  const float cap = (ENV == RL4CO_ENV_CVRP) ? a.vehicle_capacity[inst] : ((ENV == RL4CO_ENV_OP) ? opmax[0] : 0.0f);
   const float thr = cap + 1e-5f;
   float qb4[4], qx4[4];  // graph context; placeholder query (TSP) or capacity column (CVRP)
 #pragma unroll
@@ -223,6 +227,13 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
         for (int j = 0; j < N; ++j) last = max(last, spos[j]);
         if (last != 0x7fffffff) t_end = min(T, last + 1);
       }
+      if (ENV == RL4CO_ENV_OP) {  // done at the first return to the depot after step 0 (op/env.py:84)
+        for (int t = 1; t < T; ++t)
+          if (sact[t] == 0) {
+            t_end = t + 1;
+            break;
+          }
+      }
       sinfo[0] = t_end;
     }
     if (ENV == RL4CO_ENV_CVRP) {
@@ -233,6 +244,20 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
         while (u >= 0 && sact[u] != 0) --u;
         float used = 0.0f;
         for (int v = u + 1; v < min(t, T); ++v) used = used + dem[min(max(sact[v] - 1, 0), N - 2)];
+        srem[t] = used;
+      }
+    }
+    if (ENV == RL4CO_ENV_OP) {
+      // tour length BEFORE column t, accumulated in visiting order like tour += |loc_a - loc_cur|
+      for (int t = tid; t < kMaxT; t += kThreads) {
+        float used = 0.0f;
+        int prev = 0;
+        for (int v = 0; v < min(t, T); ++v) {
+          const int nx = sact[v];
+          const float dx = oplocs[2 * nx] - oplocs[2 * prev], dy = oplocs[2 * nx + 1] - oplocs[2 * prev + 1];
+          used = used + sqrtf(fmaf(dy, dy, dx * dx));
+          prev = nx;
+        }
         srem[t] = used;
       }
     }
@@ -247,6 +272,20 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
         for (int b = 0; b < 32; ++b) {
           const int j = 32 * k + b;
           if (j < N && spos[j] >= t) word |= 1u << b;
+        }
+      } else if (ENV == RL4CO_ENV_OP) {
+        // op/env.py:137-154: unvisited, depot not yet closed, and the node can still be entered
+        const float used = srem[t];
+        const int cur = (t == 0) ? 0 : sact[t - 1];
+        const float cx = oplocs[2 * cur], cy = oplocs[2 * cur + 1];
+        const bool depot_visited = spos[0] < t;
+        for (int b = 0; b < 32; ++b) {
+          const int j = 32 * k + b;
+          if (j < N) {
+            const float dx = oplocs[2 * j] - cx, dy = oplocs[2 * j + 1] - cy;
+            const bool exceeds = used + sqrtf(fmaf(dy, dy, dx * dx)) > opmax[j];
+            if (j == 0 || !(spos[j] < t || depot_visited || exceeds)) word |= 1u << b;
+          }
         }
       } else {
         const float used = srem[t];
@@ -269,7 +308,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
       sg[t] = valid ? gl[t] : 0.0f;
     }
     __syncthreads();
-    if (ENV == RL4CO_ENV_CVRP) {  // srem: used -> remaining capacity (context.py:147-149), own entries only
+    if (ENV != RL4CO_ENV_TSP) {  // srem: used -> remaining capacity / length (context.py:147-149, 211-213), own entries only
       for (int t = tid; t < kMaxT; t += kThreads) srem[t] = cap - srem[t];
       __syncthreads();
     }
@@ -293,7 +332,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
       const bool valid = sval[t] != 0;
       const uint4 mw4 = *reinterpret_cast<const uint4*>(smask + 4 * t);
       const uint32_t mw[4] = {mw4.x, mw4.y, mw4.z, mw4.w};
-      const float rem = (ENV == RL4CO_ENV_CVRP) ? srem[t] : 0.0f;
+      const float rem = (ENV != RL4CO_ENV_TSP) ? srem[t] : 0.0f;
 
       // ---- 0. query of head h for the block's 16 steps (context.py:105-149, decoder.py:135-136) --
       bf16x4 qf;
@@ -589,6 +628,7 @@ static int dispatch_tiles(const rl4co_am_teacher_args& a, hipStream_t stream) {
 }
 
 int launch_teacher_mma(const rl4co_am_teacher_args& a, hipStream_t stream) {
+  if (a.env == RL4CO_ENV_OP) return dispatch_tiles<RL4CO_ENV_OP>(a, stream);
   return a.env == RL4CO_ENV_TSP ? dispatch_tiles<RL4CO_ENV_TSP>(a, stream) : dispatch_tiles<RL4CO_ENV_CVRP>(a, stream);
 }
 

@@ -517,10 +517,10 @@ class AttentionModelPolicy(nn.Module):
         b_inst, n = td["action_mask"].shape[0], td["action_mask"].shape[-1]
         b = b_inst * max(n_rep, 1)
         cache_g = None
-        if cache is None and grad_path and self.fused_backward and hidden.is_cuda and self.env_name in ("tsp", "cvrp"):
+        if cache is None and grad_path and self.fused_backward and hidden.is_cuda:
             from . import teacher
 
-            if n <= teacher.max_nodes() and not return_entropy:
+            if teacher.supports(self.env_name, self.cache_dtype, n) and not return_entropy:
                 cache_g = teacher.build_cache_autograd(self.env_name, hidden, self.decoder)
                 cache = teacher.detached_cache(self.env_name, cache_g, self.cache_dtype)
         if cache is None:
@@ -614,6 +614,8 @@ class AttentionModelPolicy(nn.Module):
                         tanh_clipping=tanh_clipping, temperature=temperature, teacher_variant=self.teacher_variant)
             if self.env_name == "cvrp":
                 meta.update(demand=td["demand"], vehicle_capacity=td["vehicle_capacity"])
+            elif self.env_name == "op":
+                meta.update(locs=td["locs"], max_length=td["max_length"])
             step_logps = teacher.teacher_forced_logps(self.env_name, cache_g, cache, out_actions, logps, meta)
         elif grad_path:
             step_logps = self.evaluate_log_probs(td, hidden, out_actions, n_rep, tanh_clipping, temperature,

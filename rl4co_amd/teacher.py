@@ -30,7 +30,7 @@ class AmTeacherArgs(C.Structure):
         ("glimpse_key", _vp), ("glimpse_val", _vp), ("logit_key", _vp),
         ("kvl_row_stride", _i64), ("kvl_batch_stride", _i64),
         ("ctx_first", _vp), ("ctx_cur", _vp), ("q_bias", _vp), ("q_step0", _vp), ("w_cap", _vp),
-        ("actions", _vp), ("demand", _vp), ("vehicle_capacity", _vp), ("grad_logp", _vp),
+        ("actions", _vp), ("demand", _vp), ("vehicle_capacity", _vp), ("locs", _vp), ("max_length", _vp), ("grad_logp", _vp),
         ("d_kvl", _vp), ("d_ctx_first", _vp), ("d_ctx_cur", _vp), ("d_q_bias", _vp), ("d_q_step0", _vp),
         ("d_w_cap", _vp), ("logp_out", _vp), ("err", _vp),
     ]
@@ -41,6 +41,13 @@ VARIANT_IDS = {"auto": 0, "replay": 1, "mma": 2}
 
 def max_nodes() -> int:
     return _lib.lib().rl4co_am_teacher_max_nodes()
+
+
+def supports(env_name: str, cache_dtype: torch.dtype, num_nodes: int) -> bool:
+    """TSP / CVRP: both variants; orienteering: the MMA variant only (bf16 planes)."""
+    if num_nodes > max_nodes():
+        return False
+    return env_name in ("tsp", "cvrp") or (env_name == "op" and cache_dtype == torch.bfloat16)
 
 
 def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: dict, variant: str = "auto",
@@ -64,7 +71,7 @@ def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: d
     logp = torch.zeros((b, t), **f32) if want_logp else None
     err = torch.zeros(1, dtype=torch.int32, device=dev)
     a = AmTeacherArgs()
-    a.env = _lib.ENV_TSP if tsp else _lib.ENV_CVRP
+    a.env = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP, "op": _lib.ENV_OP}[cache.env_name]
     a.B, a.B_inst, a.N, a.T, a.t0 = b, b_inst, n, t, int(meta["t0"])
     a.mask_inner, a.mask_logits = int(meta["mask_inner"]), int(meta["mask_logits"])
     a.tanh_clipping, a.temperature = float(meta["tanh_clipping"]), float(meta["temperature"])
@@ -78,10 +85,13 @@ def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: d
     acts = actions.contiguous()
     g = grad_logp.contiguous().float()
     a.actions, a.grad_logp = acts.data_ptr(), g.data_ptr()
-    if not tsp:
+    if cache.env_name == "cvrp":
         demand = meta["demand"].contiguous()
         vcap = meta["vehicle_capacity"].reshape(-1).contiguous()
         a.demand, a.vehicle_capacity = demand.data_ptr(), vcap.data_ptr()
+    elif cache.env_name == "op":
+        locs, maxlen = meta["locs"].float().contiguous(), meta["max_length"].float().contiguous()
+        a.locs, a.max_length = locs.data_ptr(), maxlen.data_ptr()
     a.d_kvl, a.d_ctx_cur, a.d_ctx_first, a.d_q_bias = ptr(d_kvl), ptr(d_ctx_cur), ptr(d_ctx_first), ptr(d_q_bias)
     if tsp:
         a.d_q_step0 = d_extra.data_ptr()
@@ -113,7 +123,7 @@ def build_cache_autograd(env_name: str, h: Tensor, decoder) -> dict[str, Tensor]
         h = h.float()
         planes = [torch.matmul(h, w.t()) for w in blocks]
     h = h.float()
-    out = {"kvl": torch.stack(planes[:3], 0), "ctx_cur": planes[-1] if env_name == "cvrp" else planes[4]}
+    out = {"kvl": torch.stack(planes[:3], 0), "ctx_cur": planes[4] if env_name == "tsp" else planes[-1]}
     if env_name == "tsp":
         out["ctx_first"] = planes[3]
         out["q_step0"] = torch.mv(w_ctx, decoder.context_embedding.W_placeholder.float())
