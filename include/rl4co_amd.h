@@ -43,11 +43,13 @@ extern "C" {
 #define RL4CO_EBIT_NEG_INF_LOGP 32 /* utils/decoding.py:56 "Logprobs should not be -inf"  */
 #define RL4CO_EBIT_DUPLICATES 64  /* op/env.py:178-181 "Duplicates"                        */
 #define RL4CO_EBIT_MAX_LENGTH 128 /* op/env.py:192-194 "Max length exceeded"               */
+#define RL4CO_EBIT_PRIZE 256      /* pctsp/env.py:192-201 "Total prize does not satisfy min total prize" */
 
 /* ---- enums --------------------------------------------------------------- */
 #define RL4CO_ENV_TSP 0
 #define RL4CO_ENV_CVRP 1
 #define RL4CO_ENV_OP 2 /* orienteering problem: streaming decode variant only */
+#define RL4CO_ENV_PCTSP 3 /* prize-collecting TSP (same row): streaming decode variant only */
 
 #define RL4CO_DECODE_GREEDY 0   /* utils/decoding.py:387-397 */
 #define RL4CO_DECODE_SAMPLE 1   /* utils/decoding.py:399-413 */
@@ -153,6 +155,23 @@ int rl4co_op_check_solution(const int64_t* actions, const float* locs, const flo
                             int N, int T, int32_t* err, void* stream);
 
 /* --------------------------------------------------------------------------
+ * N4  PCTSPEnv (prize-collecting TSP)   envs/routing/pctsp/env.py:62-201
+ * step : prize += real_prize[a] ; visited[a] = 1 ; done = (i > 0) & (a == 0) ; i += 1 ; cur = a ;
+ *        mask[j>=1] = !(visited[j] | visited[0]) ; mask[0] = !((prize < 1.0) & (some customer unvisited))
+ *        (action == NULL: mask only). real_prize [B_inst,N] with 0 for the depot.
+ * reward (host composition, fp32): gather_sum(penalty, actions) - (tour_length(depot ++ tour) +
+ *        gather_sum(penalty, 1..N-1)) — three ATen-order sums, pctsp/env.py:150-173.
+ * check : no customer twice (RL4CO_EBIT_DUPLICATES); collected prize >= 1 - 1e-5 or every customer
+ *         visited (RL4CO_EBIT_PRIZE)   pctsp/env.py:175-201. Trailing depot zeros are neutral.
+ * -------------------------------------------------------------------------- */
+int rl4co_pctsp_step(const int64_t* action, const float* real_prize, float* cur_total_prize, uint8_t* visited,
+                     int64_t* current_node, int64_t* step_i, uint8_t* action_mask, uint8_t* done, int B, int B_inst,
+                     int N, int32_t* err, void* stream);
+/* prize_sum [B] = rl4co_gather_sum_f32(real_prize, actions) (the reference's summation order) */
+int rl4co_pctsp_check_solution(const int64_t* actions, const float* prize_sum, int B, int N, int T, int32_t* err,
+                               void* stream);
+
+/* --------------------------------------------------------------------------
  * a13-a21  AttentionModel decode: one step, or the whole autoregressive loop.
  *
  * Replaces, per step: TSPContext/VRPContext (env_embeddings/context.py:105-149),
@@ -214,6 +233,8 @@ typedef struct rl4co_am_decode_args {
    * the step counter; the depot row of max_length plays the vehicle capacity in the context scalar */
   const float* locs;        /* [B_inst,N,2] OP                                             */
   const float* max_length;  /* [B_inst,N] OP: longest tour with which node j may be entered */
+  /* PCTSP (envs/routing/pctsp/env.py): demand = real prize WITH the depot column [B_inst,N],
+   * used_capacity = prize collected so far, vehicle_capacity = prize_required [B], step_i, visited */
   /* decoding inputs */
   const float* exp_noise;   /* [max_steps,B,N] Exp(1) draws (parity mode) or NULL          */
   uint64_t philox_seed;     /* in-kernel Exp(1) noise when exp_noise == NULL               */
@@ -272,8 +293,9 @@ typedef struct rl4co_am_encoder_args {
   int32_t norm;        /* 0 = per-channel affine (batch norm, eval), 1 = instance  */
   int32_t cache_dtype; /* dtype of the three kvl planes written                    */
   const float* locs;   /* [B,N,2] (CVRP: depot first, cvrp/env.py:108)             */
-  const float* demand; /* [B,N-1] CVRP                                             */
-  const float* w_init; /* [128,2] TSP / [128,3] CVRP customers                     */
+  const float* demand; /* [B,N-1] CVRP demand / OP prize / PCTSP expected prize     */
+  const float* feature4; /* [B,N-1] PCTSP penalty (w_init is then [128,4]) or NULL  */
+  const float* w_init; /* [128,2] TSP / [128,3] CVRP customers / [128,4] PCTSP      */
   const float* b_init; /* [128]                                                    */
   const float* w_depot; /* [128,2] CVRP                                            */
   const float* b_depot; /* [128]                                                   */

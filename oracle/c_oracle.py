@@ -55,6 +55,7 @@ def lib() -> C.CDLL:
     h.oracle_tsp_step.argtypes = [vp] * 6 + [i, i]
     h.oracle_cvrp_step.argtypes = [vp] * 8 + [i, i, i]
     h.oracle_op_step.argtypes = [vp] * 9 + [i, i, i]
+    h.oracle_pctsp_step.argtypes = [vp] * 8 + [i, i, i]
     h.oracle_op_max_length.argtypes = [vp, vp, i, i, vp]
     h.oracle_gather_sum_f32.argtypes = [vp, vp, i, i, i, i, vp]
     h.oracle_am_decode.argtypes = [C.POINTER(AmDecodeArgs), i]
@@ -120,6 +121,14 @@ def op_step(action, locs, max_length, tour_length, visited, cur, step_i, mask, d
     assert st == 0, "oracle_op_step: action out of range"
 
 
+def pctsp_step(action, real_prize, cur_total_prize, visited, cur, step_i, mask, done) -> None:
+    b, n = mask.shape
+    st = lib().oracle_pctsp_step(_p(None if action is None else _cpu(action, torch.int64)), _p(_cpu(real_prize, torch.float32)),
+                                 _p(_cpu(cur_total_prize, torch.float32)), _p(_u8(visited)), _p(_cpu(cur, torch.int64)),
+                                 _p(_cpu(step_i, torch.int64)), _p(_u8(mask)), _p(_u8(done)), b, real_prize.shape[0], n)
+    assert st == 0, "oracle_pctsp_step: action out of range"
+
+
 def gather_sum(values: Tensor, actions: Tensor) -> Tensor:
     b, t = actions.shape
     out = torch.empty((b,), dtype=torch.float32)
@@ -149,7 +158,7 @@ def am_decode(cache, state: dict, *, mode: str, max_steps: int, actions: Tensor,
     a = _lib.AmDecodeArgs()
     mask = _u8(state["action_mask"])
     b, n = mask.shape
-    a.env = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP, "op": _lib.ENV_OP}[cache.env_name]
+    a.env = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP, "op": _lib.ENV_OP, "pctsp": _lib.ENV_PCTSP}[cache.env_name]
     a.B, a.B_inst, a.N = b, cache.num_instances, n
     a.mode = {"greedy": 0, "sampling": 1, "evaluate": 2}[mode]
     a.max_steps = int(max_steps)
@@ -169,6 +178,13 @@ def am_decode(cache, state: dict, *, mode: str, max_steps: int, actions: Tensor,
         a.q_step0 = _p(_cpu(cache.q_step0, torch.float32))
         a.first_node = _p(_cpu(state["first_node"], torch.int64))
         a.step_i = _p(_cpu(state["i"], torch.int64))
+    elif cache.env_name == "pctsp":
+        a.w_cap = _p(_cpu(cache.w_cap, torch.float32))
+        a.demand = _p(_cpu(state["real_prize"], torch.float32))
+        a.used_capacity = _p(_cpu(state["cur_total_prize"], torch.float32))
+        a.vehicle_capacity = _p(_cpu(state["prize_required"], torch.float32))
+        a.step_i = _p(_cpu(state["i"], torch.int64))
+        a.visited = _p(_u8(state["visited"]))
     elif cache.env_name == "op":
         a.w_cap = _p(_cpu(cache.w_cap, torch.float32))
         a.locs = _p(_cpu(state["locs"], torch.float32))

@@ -441,8 +441,120 @@ class OPEnv:
         return select_start_nodes(td, self, num_starts)
 
 
+class PCTSPEnv:
+    """envs/routing/pctsp/env.py:17-219 (prize-collecting TSP, deterministic prizes)"""
+
+    name = "pctsp"
+
+    def __init__(self, num_loc: int = 20, check_solution: bool = True, penalty_factor: float = 3.0,
+                 prize_required: float = 1.0):
+        self.num_loc = num_loc
+        self.check_solution = check_solution
+        self.prize_required = prize_required
+        max_penalty = OP_MAX_LENGTHS.get(num_loc, None)  # pctsp/generator.py:13,74-87 (same table)
+        if max_penalty is None:
+            closest = min(OP_MAX_LENGTHS.keys(), key=lambda x: abs(x - num_loc))
+            max_penalty = OP_MAX_LENGTHS[closest]
+        self.max_penalty = max_penalty * penalty_factor / num_loc
+
+    def generate(self, batch_size: int) -> dict:
+        """pctsp/generator.py:91-122: locations (+ depot), penalties, deterministic prizes, stochastic prizes"""
+        locs = torch.distributions.Uniform(low=0.0, high=1.0).sample((batch_size, self.num_loc + 1, 2))
+        depot, locs = locs[..., 0, :], locs[..., 1:, :]
+        penalty = torch.distributions.Uniform(low=0.0, high=self.max_penalty).sample((batch_size, self.num_loc))
+        det = torch.distributions.Uniform(low=0.0, high=4.0 / self.num_loc).sample((batch_size, self.num_loc))
+        sto = torch.distributions.Uniform(low=0.0, high=2.0).sample((batch_size, self.num_loc)) * det
+        return {"locs": locs, "depot": depot, "penalty": penalty, "deterministic_prize": det, "stochastic_prize": sto}
+
+    def reset(self, td: dict | None = None, batch_size: int | None = None) -> dict:
+        """pctsp/env.py:93-139"""
+        if td is None:
+            td = self.generate(batch_size)
+        b = td["locs"].shape[0]
+        device = td["locs"].device
+        real_prize = td["deterministic_prize"]
+        penalty = td["penalty"]
+        td_reset = {
+            "locs": torch.cat([td["depot"][..., None, :], td["locs"]], dim=-2),
+            "current_node": torch.zeros((b,), dtype=torch.int64, device=device),
+            "expected_prize": td["deterministic_prize"],
+            "real_prize": torch.cat([torch.zeros_like(real_prize[..., :1]), real_prize], dim=-1),
+            "penalty": torch.nn.functional.pad(penalty, (1, 0), mode="constant", value=0),
+            "cur_total_prize": torch.zeros(b, device=device),
+            "cur_total_penalty": penalty.sum(-1),
+            "visited": torch.zeros((b, self.num_loc + 1), dtype=torch.bool, device=device),
+            "prize_required": torch.full((b,), self.prize_required, device=device),
+            "i": torch.zeros((b,), dtype=torch.int64, device=device),
+            "done": torch.zeros((b,), dtype=torch.bool, device=device),
+        }
+        td_reset["action_mask"] = self.get_action_mask(td_reset)
+        return td_reset
+
+    def step(self, td: dict) -> dict:
+        """pctsp/env.py:62-91"""
+        current_node = td["action"]
+        cur_total_prize = td["cur_total_prize"] + gather_by_index(td["real_prize"], current_node)
+        cur_total_penalty = td["cur_total_penalty"] + gather_by_index(td["penalty"], current_node)
+        visited = td["visited"].scatter(-1, current_node[..., None], 1)
+        done = (td["i"] > 0) & (current_node == 0)
+        td.update(
+            {
+                "current_node": current_node,
+                "cur_total_prize": cur_total_prize,
+                "cur_total_penalty": cur_total_penalty,
+                "visited": visited,
+                "i": td["i"] + 1,
+                "reward": torch.zeros_like(done),
+                "done": done,
+            }
+        )
+        td["action_mask"] = self.get_action_mask(td)
+        return td
+
+    @staticmethod
+    def get_action_mask(td: dict) -> Tensor:
+        """pctsp/env.py:141-148: the depot opens once a total prize of 1 is collected (or nothing is left)"""
+        mask = td["visited"] | td["visited"][..., 0:1]
+        mask[..., 0] = (td["cur_total_prize"] < 1.0) & (
+            td["visited"][..., 1:].int().sum(-1) < td["visited"][..., 1:].size(-1)
+        )
+        return ~(mask > 0)
+
+    def get_reward(self, td: dict, actions: Tensor, check_solution: bool | None = None) -> Tensor:
+        """base.py:180-190 -> pctsp/env.py:150-173: saved penalties - (tour length + all penalties)"""
+        check_solution = self.check_solution if check_solution is None else check_solution
+        if check_solution:
+            self.check_solution_validity(td, actions)
+        if actions.size(-1) == 1:
+            assert (actions == 0).all(), "If all length 1 tours, they should be zero"
+            return torch.zeros(actions.size(0), dtype=torch.float, device=actions.device)
+        locs_ordered = torch.cat([td["locs"][..., 0:1, :], gather_by_index(td["locs"], actions)], dim=1)
+        length = get_tour_length(locs_ordered)
+        saved_penalty = td["penalty"].gather(1, actions)
+        return saved_penalty.sum(-1) - (length + td["penalty"][..., 1:].sum(-1))
+
+    @staticmethod
+    def check_solution_validity(td: dict, actions: Tensor) -> None:
+        """pctsp/env.py:175-201"""
+        sorted_actions = actions.data.sort(1)[0]
+        assert ((sorted_actions[..., 1:] == 0) | (sorted_actions[..., 1:] > sorted_actions[..., :-1])).all(), "Duplicates"
+        prize = td["real_prize"][..., 1:]
+        prize_with_depot = torch.cat((torch.zeros_like(prize[:, :1]), prize), 1)
+        p = prize_with_depot.gather(1, actions)
+        assert (
+            (p.sum(-1) >= 1 - 1e-5)
+            | (sorted_actions.size(-1) - (sorted_actions == 0).int().sum(-1) == (td["locs"].size(-2) - 1))
+        ).all(), "Total prize does not satisfy min total prize"
+
+    def get_num_starts(self, td):
+        return get_num_starts(td, self.name)
+
+    def select_start_nodes(self, td, num_starts):
+        return select_start_nodes(td, self, num_starts)
+
+
 def get_env(name: str, num_loc: int, **kw):
-    return {"tsp": TSPEnv, "cvrp": CVRPEnv, "op": OPEnv}[name](num_loc=num_loc, **kw)
+    return {"tsp": TSPEnv, "cvrp": CVRPEnv, "op": OPEnv, "pctsp": PCTSPEnv}[name](num_loc=num_loc, **kw)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -660,6 +772,23 @@ class OPInitEmbedding(nn.Module):
         return torch.cat((depot_embedding, node_embeddings), -2)
 
 
+class PCTSPInitEmbedding(nn.Module):
+    """env_embeddings/init.py:221-251: x, y, expected prize, penalty"""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.init_embed = nn.Linear(4, embed_dim, True)
+        self.init_embed_depot = nn.Linear(2, embed_dim, True)
+
+    def forward(self, td):
+        depot, cities = td["locs"][:, :1, :], td["locs"][:, 1:, :]
+        depot_embedding = self.init_embed_depot(depot)
+        node_embeddings = self.init_embed(
+            torch.cat((cities, td["expected_prize"][..., None], td["penalty"][..., 1:, None]), -1)
+        )
+        return torch.cat((depot_embedding, node_embeddings), -2)
+
+
 class TSPContext(nn.Module):
     """env_embeddings/context.py:50-60,105-134"""
 
@@ -719,6 +848,21 @@ class OPContext(nn.Module):
         return self.project_context(context_embedding)
 
 
+class PCTSPContext(nn.Module):
+    """env_embeddings/context.py:50-74,184-198: current node embedding + prize still to collect (clamped at 0)"""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.project_context = nn.Linear(embed_dim + 1, embed_dim, bias=False)
+
+    def forward(self, embeddings, td):
+        cur_node_embedding = gather_by_index(embeddings, td["current_node"])
+        state_embedding = torch.clamp(td["prize_required"] - td["cur_total_prize"], min=0)[..., None]
+        context_embedding = torch.cat([cur_node_embedding, state_embedding], -1)
+        return self.project_context(context_embedding)
+
+
 class StaticEmbedding(nn.Module):
     """env_embeddings/dynamic.py:47-57"""
 
@@ -744,7 +888,7 @@ class AttentionModelEncoder(nn.Module):
                  normalization="batch", feedforward_hidden=512, sdpa_fn=None):
         super().__init__()
         self.env_name = env_name
-        self.init_embedding = {"tsp": TSPInitEmbedding, "cvrp": VRPInitEmbedding, "op": OPInitEmbedding}[env_name](embed_dim)
+        self.init_embedding = {"tsp": TSPInitEmbedding, "cvrp": VRPInitEmbedding, "op": OPInitEmbedding, "pctsp": PCTSPInitEmbedding}[env_name](embed_dim)
         self.net = GraphAttentionNetwork(
             num_heads, embed_dim, num_layers, normalization, feedforward_hidden, sdpa_fn=sdpa_fn
         )
@@ -765,7 +909,7 @@ class AttentionModelDecoder(nn.Module):
         self.env_name = env_name
         self.embed_dim = embed_dim
         self.num_heads = num_heads
-        self.context_embedding = {"tsp": TSPContext, "cvrp": VRPContext, "op": OPContext}[env_name](embed_dim)
+        self.context_embedding = {"tsp": TSPContext, "cvrp": VRPContext, "op": OPContext, "pctsp": PCTSPContext}[env_name](embed_dim)
         self.dynamic_embedding = StaticEmbedding()
         self.is_dynamic_embedding = False
         self.pointer = PointerAttention(

@@ -239,6 +239,35 @@ int oracle_op_step(const int64_t* action, const float* locs, const float* maxlen
   return 0;
 }
 
+/* ---- prize-collecting TSP (envs/routing/pctsp/env.py) ------------------------------------------ */
+static void pctsp_mask_row(float prize, const uint8_t* vis, uint8_t* mk, int N) { /* pctsp/env.py:141-148 */
+  int unvisited = 0;
+  for (int j = 1; j < N; ++j) {
+    mk[j] = (vis[j] || vis[0]) ? 0 : 1;
+    unvisited |= !vis[j];
+  }
+  mk[0] = ((prize < 1.0f) && unvisited) ? 0 : 1;
+}
+
+int oracle_pctsp_step(const int64_t* action, const float* real_prize, float* prize, uint8_t* visited, int64_t* cur,
+                      int64_t* step_i, uint8_t* mask, uint8_t* done, int B, int B_inst, int N) {
+  for (int b = 0; b < B; ++b) {
+    const float* rp = real_prize + (int64_t)(b % B_inst) * N;
+    uint8_t* vis = visited + (int64_t)b * N;
+    if (action) {
+      const int64_t a = action[b];
+      if (a < 0 || a >= N) return 1;
+      prize[b] = prize[b] + rp[a];
+      vis[a] = 1;
+      done[b] = (step_i[b] > 0 && a == 0) ? 1 : 0;
+      step_i[b] += 1;
+      cur[b] = a;
+    }
+    pctsp_mask_row(prize[b], vis, mask + (int64_t)b * N, N);
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* AttentionModel decode loop in the specified operation order                                  */
 /* ------------------------------------------------------------------------------------------ */
@@ -289,7 +318,9 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
     float used = a->env != RL4CO_ENV_TSP ? a->used_capacity[r] : 0.0f;
     const float* oplocs = a->env == RL4CO_ENV_OP ? a->locs + (int64_t)cb * N * 2 : NULL;
     const float* opmax = a->env == RL4CO_ENV_OP ? a->max_length + (int64_t)cb * N : NULL;
-    const float cap = a->env == RL4CO_ENV_CVRP ? a->vehicle_capacity[r] : (a->env == RL4CO_ENV_OP ? opmax[0] : 0.0f);
+    const float cap = (a->env == RL4CO_ENV_CVRP || a->env == RL4CO_ENV_PCTSP) ? a->vehicle_capacity[r]
+                      : (a->env == RL4CO_ENV_OP ? opmax[0] : 0.0f); /* PCTSP: prize_required */
+    const float* rprize = a->env == RL4CO_ENV_PCTSP ? a->demand + (int64_t)cb * N : NULL;
     const float* dem = a->env == RL4CO_ENV_CVRP ? a->demand + (int64_t)cb * (N - 1) : NULL;
     int done = a->done[r] != 0;
     uint32_t errbits = 0;
@@ -306,7 +337,8 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
           if (step_i < 1) v = a->q_step0[d] + qb;
           else v = (ctxf[(int64_t)first * D + d] + ctxc[(int64_t)cur * D + d]) + qb;
         } else {
-          const float rem = cap - used;
+          float rem = cap - used;
+          if (a->env == RL4CO_ENV_PCTSP && !(rem > 0.0f)) rem = 0.0f; /* clamp(min=0), context.py:195 */
           v = fmaf(a->w_cap[d], rem, ctxc[(int64_t)cur * D + d]) + qb;
         }
         q[d] = v * 0.25f;
@@ -451,6 +483,13 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
         int any = 0;
         for (int j = 0; j < N; ++j) any |= mk[j];
         done = !any;
+      } else if (a->env == RL4CO_ENV_PCTSP) {
+        used = used + rprize[bi];               /* pctsp/env.py:66 */
+        vis[bi] = 1;
+        done = (step_i > 0) && (bi == 0);       /* pctsp/env.py:73 */
+        step_i += 1;
+        cur = bi;
+        pctsp_mask_row(used, vis, mk, N);
       } else if (a->env == RL4CO_ENV_OP) {
         used = used + op_dist(oplocs, cur, bi); /* op/env.py:71-73 */
         vis[bi] = 1;

@@ -11,7 +11,7 @@ from functools import lru_cache
 from . import build as _build
 
 RL4CO_OK = 0
-ENV_TSP, ENV_CVRP, ENV_OP = 0, 1, 2
+ENV_TSP, ENV_CVRP, ENV_OP, ENV_PCTSP = 0, 1, 2, 3
 DECODE_GREEDY, DECODE_SAMPLE, DECODE_EVALUATE = 0, 1, 2
 DT_F32, DT_BF16 = 0, 1
 VARIANT_AUTO, VARIANT_STREAM, VARIANT_LDS, VARIANT_WIDE, VARIANT_MS = 0, 1, 2, 3, 4
@@ -24,6 +24,7 @@ EBIT_MAX_STEPS = 16
 EBIT_NEG_INF_LOGP = 32
 EBIT_DUPLICATES = 64
 EBIT_MAX_LENGTH = 128
+EBIT_PRIZE = 256
 
 # Reference assertion messages (file:line in the reference checkout) per sticky bit.
 ERROR_MESSAGES = {
@@ -35,6 +36,7 @@ ERROR_MESSAGES = {
     EBIT_NEG_INF_LOGP: "Logprobs should not be -inf, check sampling procedure!",  # decoding.py:56
     EBIT_DUPLICATES: "Duplicates",  # op/env.py:181
     EBIT_MAX_LENGTH: "Max length exceeded",  # op/env.py:192-194
+    EBIT_PRIZE: "Total prize does not satisfy min total prize",  # pctsp/env.py:192-201
 }
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -77,6 +79,8 @@ SYMBOLS = {
     "rl4co_op_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_gather_sum_f32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_op_check_solution": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_pctsp_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_pctsp_check_solution": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_am_decode": (C.c_int, [C.POINTER(AmDecodeArgs), _vp]),
     "rl4co_am_teacher_backward": (C.c_int, [_vp, _vp]),
     "rl4co_am_teacher_max_nodes": (C.c_int, []),

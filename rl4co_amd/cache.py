@@ -66,7 +66,7 @@ def fold_weights(env_name: str, w_node: Tensor, w_out: Tensor, w_ctx: Tensor) ->
     wl_folded = w_out.t() @ wl  # logits = heads^T W_out^T (Wl h_j)
     if env_name == "tsp":
         return [wk, wv, wl_folded, w_ctx[:, :d], w_ctx[:, d : 2 * d]]
-    if env_name in ("cvrp", "op"):  # current-node embedding + one scalar (capacity / remaining length)
+    if env_name in ("cvrp", "op", "pctsp"):  # current-node embedding + one scalar (capacity / remaining length)
         return [wk, wv, wl_folded, w_ctx[:, :d]]
     raise ValueError(f"fused decode supports tsp/cvrp/op, got {env_name!r}")
 

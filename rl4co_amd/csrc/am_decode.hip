@@ -221,6 +221,25 @@ __device__ inline int finalize_and_step(const rl4co_am_decode_args& a, TrajState
     bool any_left = false;
     for (int j = lane; j < N; j += 64) any_left |= mk[j] != 0;
     st.done = !__any(any_left);  // tsp/env.py:71
+  } else if (ENV == RL4CO_ENV_PCTSP) {
+    // prize-collecting TSP (pctsp/env.py:62-91,141-148); st.used is the prize collected so far,
+    // dem the real prize per node (depot column 0)
+    st.used = st.used + dem[bi];
+    if (lane == 0) vis[bi] = 1;
+    st.done = (bi == 0) && (st.step_i > 0);
+    st.step_i += 1;
+    st.cur = bi;
+    wave_lds_sync();
+    const bool depot_visited = vis[0] != 0;
+    bool unvisited = false;
+    for (int j = lane; j < N; j += 64) {
+      if (j >= 1) {
+        mk[j] = (vis[j] != 0 || depot_visited) ? 0 : 1;
+        unvisited |= vis[j] == 0;
+      }
+    }
+    unvisited = __any(unvisited);
+    if (lane == 0) mk[0] = ((st.used < 1.0f) && unvisited) ? 0 : 1;
   } else if (ENV == RL4CO_ENV_OP) {
     // orienteering (op/env.py:67-98,137-154); st.used is the tour length, distances as in the
     // tour-length kernel: sqrt(fma(dy, dy, dx * dx))
@@ -323,8 +342,12 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
   const float* opmax = (ENV == RL4CO_ENV_OP) ? a.max_length + (int64_t)cb * N : nullptr;
   // the context scalar is cap - used in both depot environments (context.py:147-149, 211-213):
   // OP: longest tour that may still end at the depot (its row of the table) minus the tour so far
-  const float cap = (ENV == RL4CO_ENV_CVRP) ? a.vehicle_capacity[r] : ((ENV == RL4CO_ENV_OP) ? opmax[0] : 0.0f);
-  const float* dem = (ENV == RL4CO_ENV_CVRP) ? a.demand + (int64_t)cb * (N - 1) : nullptr;
+  // PCTSP: prize still to collect, clamped at 0 (context.py:184-198)
+  const float cap = (ENV == RL4CO_ENV_CVRP || ENV == RL4CO_ENV_PCTSP) ? a.vehicle_capacity[r]
+                                                                      : ((ENV == RL4CO_ENV_OP) ? opmax[0] : 0.0f);
+  const float* dem = (ENV == RL4CO_ENV_CVRP)    ? a.demand + (int64_t)cb * (N - 1)
+                     : (ENV == RL4CO_ENV_PCTSP) ? a.demand + (int64_t)cb * N
+                                                : nullptr;
   wave_lds_sync();
 
   float qb[EPL];
@@ -349,7 +372,8 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
           q[e] = (ctxf[(int64_t)st.first * kD + e] + ctxc[(int64_t)st.cur * kD + e]) + qb[e];
       }
     } else {
-      const float rem = cap - st.used;  // context.py:147-149
+      float rem = cap - st.used;  // context.py:147-149
+      if (ENV == RL4CO_ENV_PCTSP && !(rem > 0.0f)) rem = 0.0f;
 #pragma unroll
       for (int e = 0; e < EPL; ++e)
         q[e] = fmaf(a.w_cap[e0 + e], rem, ctxc[(int64_t)st.cur * kD + e]) + qb[e];
@@ -779,7 +803,7 @@ int launch_wide(const rl4co_am_decode_args& a, hipStream_t stream) {
 // Which kernel serves these arguments (rules from measurements on MI355X, see the kernel headers).
 inline int resolve_variant(const rl4co_am_decode_args& a) {
   // the orienteering transition (distance-based mask) exists in the streaming kernel only
-  if (a.env == RL4CO_ENV_OP) return (a.variant == RL4CO_VARIANT_AUTO || a.variant == RL4CO_VARIANT_STREAM) ? RL4CO_VARIANT_STREAM : -1;
+  if (a.env == RL4CO_ENV_OP || a.env == RL4CO_ENV_PCTSP) return (a.variant == RL4CO_VARIANT_AUTO || a.variant == RL4CO_VARIANT_STREAM) ? RL4CO_VARIANT_STREAM : -1;
   const bool bf16 = a.cache_dtype == RL4CO_DT_BF16;
   // multistart on the matrix cores (am_decode_ms.hip): bf16 planes, N <= 128, plain outputs
   const bool ms_ok = bf16 && a.N <= 128 && a.B_inst > 0 && a.all_logps == nullptr && a.entropy == nullptr;
@@ -834,7 +858,8 @@ extern "C" int rl4co_am_decode_variant(const rl4co_am_decode_args* args) {
 extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
   RL4CO_REQUIRE(args != nullptr);
   const rl4co_am_decode_args& a = *args;
-  RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP || a.env == RL4CO_ENV_OP);
+  RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP || a.env == RL4CO_ENV_OP ||
+                a.env == RL4CO_ENV_PCTSP);
   RL4CO_REQUIRE(a.B > 0 && a.B_inst > 0 && a.B % a.B_inst == 0);
   RL4CO_REQUIRE(a.N >= 2 && a.N <= 4096);
   RL4CO_REQUIRE(a.max_steps >= 1);
@@ -851,6 +876,8 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
     RL4CO_REQUIRE(a.ctx_first && a.q_step0 && a.first_node && a.step_i);
   } else if (a.env == RL4CO_ENV_CVRP) {
     RL4CO_REQUIRE(a.w_cap && a.demand && a.used_capacity && a.vehicle_capacity && a.visited);
+  } else if (a.env == RL4CO_ENV_PCTSP) {
+    RL4CO_REQUIRE(a.w_cap && a.demand && a.used_capacity && a.vehicle_capacity && a.step_i && a.visited);
   } else {
     RL4CO_REQUIRE(a.w_cap && a.locs && a.max_length && a.used_capacity && a.step_i && a.visited);
   }
@@ -867,6 +894,9 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
     return a.env == RL4CO_ENV_TSP ? launch_wide<RL4CO_ENV_TSP, false>(a, s)
                                   : launch_wide<RL4CO_ENV_CVRP, false>(a, s);
   }
+  if (a.env == RL4CO_ENV_PCTSP)
+    return a.cache_dtype == RL4CO_DT_F32 ? launch<CacheF32, RL4CO_ENV_PCTSP>(a, s)
+                                         : launch<CacheBF16, RL4CO_ENV_PCTSP>(a, s);
   if (a.env == RL4CO_ENV_OP)
     return a.cache_dtype == RL4CO_DT_F32 ? launch<CacheF32, RL4CO_ENV_OP>(a, s) : launch<CacheBF16, RL4CO_ENV_OP>(a, s);
   if (a.cache_dtype == RL4CO_DT_F32) {

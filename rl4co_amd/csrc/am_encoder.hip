@@ -212,11 +212,16 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
     const float* loc = a.locs + (int64_t)b * N * 2;
     const bool cvrp = a.env == RL4CO_ENV_CVRP;
     for (int i = tid; i < 2 * N; i += kThreads) lsh[i] = loc[i];
+    const bool four = cvrp && a.feature4 != nullptr;  // PCTSP: (x, y, expected prize, penalty), init.py:283-312
     if (cvrp)
       for (int i = tid; i < N - 1; i += kThreads) lsh[2 * N + 1 + i] = a.demand[(int64_t)b * (N - 1) + i];
+    if (four)
+      for (int i = tid; i < N - 1; i += kThreads) lsh[3 * N + 1 + i] = a.feature4[(int64_t)b * (N - 1) + i];
     const int d = tid & 127;
-    const float wx = cvrp ? a.w_init[3 * d] : a.w_init[2 * d], wy = cvrp ? a.w_init[3 * d + 1] : a.w_init[2 * d + 1];
-    const float wd = cvrp ? a.w_init[3 * d + 2] : 0.0f, bi = a.b_init[d];
+    const int ws = four ? 4 : (cvrp ? 3 : 2);  // row stride of w_init
+    const float wx = a.w_init[ws * d], wy = a.w_init[ws * d + 1];
+    const float wd = cvrp ? a.w_init[ws * d + 2] : 0.0f, bi = a.b_init[d];
+    const float wp = four ? a.w_init[ws * d + 3] : 0.0f;
     const float dx = cvrp ? a.w_depot[2 * d] : 0.0f, dy = cvrp ? a.w_depot[2 * d + 1] : 0.0f, db = cvrp ? a.b_depot[d] : 0.0f;
     __syncthreads();
     for (int tok = tid >> 7; tok < 32 * TT; tok += kThreads / 128) {
@@ -224,6 +229,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       if (tok < N) {
         const float x = lsh[2 * tok], y = lsh[2 * tok + 1];
         if (cvrp && tok == 0) v = fmaf(dy, y, fmaf(dx, x, db));
+        else if (four) v = fmaf(wp, lsh[3 * N + tok], fmaf(wd, lsh[2 * N + tok], fmaf(wy, y, fmaf(wx, x, bi))));
         else if (cvrp) v = fmaf(wd, lsh[2 * N + tok], fmaf(wy, y, fmaf(wx, x, bi)));
         else v = fmaf(wy, y, fmaf(wx, x, bi));
       }

@@ -171,12 +171,16 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
 
   const float* ctxc = a.ctx_cur + (int64_t)inst * N * kD + dcol;
   const float* ctxf = (ENV == RL4CO_ENV_TSP) ? a.ctx_first + (int64_t)inst * N * kD + dcol : nullptr;
-  const float* dem = (ENV == RL4CO_ENV_CVRP) ? a.demand + (int64_t)inst * (N - 1) : nullptr;
+  const float* dem = (ENV == RL4CO_ENV_CVRP)    ? a.demand + (int64_t)inst * (N - 1)
+                     : (ENV == RL4CO_ENV_PCTSP) ? a.demand + (int64_t)inst * N  // real prize, depot column 0
+                                                : nullptr;
   const float* oplocs = (ENV == RL4CO_ENV_OP) ? a.locs + (int64_t)inst * N * 2 : nullptr;
   const float* opmax = (ENV == RL4CO_ENV_OP) ? a.max_length + (int64_t)inst * N : nullptr;
   // context scalar = cap - used in both depot environments (OP: longest tour that may still end at
   // the depot minus the tour so far, env_embeddings/context.py:147-149, 211-213)
-  const float cap = (ENV == RL4CO_ENV_CVRP) ? a.vehicle_capacity[inst] : ((ENV == RL4CO_ENV_OP) ? opmax[0] : 0.0f);
+  // PCTSP: prize_required - prize collected, clamped at 0 (context.py:184-198)
+  const float cap = (ENV == RL4CO_ENV_CVRP || ENV == RL4CO_ENV_PCTSP) ? a.vehicle_capacity[inst]
+                                                                      : ((ENV == RL4CO_ENV_OP) ? opmax[0] : 0.0f);
   const float thr = cap + 1e-5f;
   float qb4[4], qx4[4];  // graph context; placeholder query (TSP) or capacity column (CVRP)
 #pragma unroll
@@ -227,7 +231,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
         for (int j = 0; j < N; ++j) last = max(last, spos[j]);
         if (last != 0x7fffffff) t_end = min(T, last + 1);
       }
-      if (ENV == RL4CO_ENV_OP) {  // done at the first return to the depot after step 0 (op/env.py:84)
+      if (ENV == RL4CO_ENV_OP || ENV == RL4CO_ENV_PCTSP) {  // done at the first return to the depot after step 0 (op/env.py:84, pctsp/env.py:73)
         for (int t = 1; t < T; ++t)
           if (sact[t] == 0) {
             t_end = t + 1;
@@ -261,6 +265,14 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
         srem[t] = used;
       }
     }
+    if (ENV == RL4CO_ENV_PCTSP) {
+      // prize collected BEFORE column t, accumulated in visiting order like prize += real_prize[a]
+      for (int t = tid; t < kMaxT; t += kThreads) {
+        float used = 0.0f;
+        for (int v = 0; v < min(t, T); ++v) used = used + dem[sact[v]];
+        srem[t] = used;
+      }
+    }
     __syncthreads();
     const int t_end = sinfo[0];
     // feasibility words: thread (t, k) builds word k of column t
@@ -287,6 +299,19 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
             if (j == 0 || !(spos[j] < t || depot_visited || exceeds)) word |= 1u << b;
           }
         }
+      } else if (ENV == RL4CO_ENV_PCTSP) {
+        // pctsp/env.py:141-148: customers while unvisited and the depot not yet closed; the depot opens
+        // once a total prize of 1 is collected or no customer is left
+        const bool depot_visited = spos[0] < t;
+        uint32_t left = 0;
+        for (int b = 0; b < 32; ++b) {
+          const int j = 32 * k + b;
+          if (j >= 1 && j < N && spos[j] >= t) left |= 1u << b;
+        }
+        word = depot_visited ? 0u : left;
+        left |= rl4co::bfly_i<1>((int)left);
+        left |= rl4co::bfly_i<2>((int)left);
+        if (k == 0 && !((srem[t] < 1.0f) && left != 0u)) word |= 1u;
       } else {
         const float used = srem[t];
         for (int b = 0; b < 32; ++b) {
@@ -309,7 +334,11 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
     }
     __syncthreads();
     if (ENV != RL4CO_ENV_TSP) {  // srem: used -> remaining capacity / length (context.py:147-149, 211-213), own entries only
-      for (int t = tid; t < kMaxT; t += kThreads) srem[t] = cap - srem[t];
+      for (int t = tid; t < kMaxT; t += kThreads) {
+        float rem = cap - srem[t];
+        if (ENV == RL4CO_ENV_PCTSP && !(rem > 0.0f)) rem = 0.0f;
+        srem[t] = rem;
+      }
       __syncthreads();
     }
 
@@ -629,6 +658,7 @@ static int dispatch_tiles(const rl4co_am_teacher_args& a, hipStream_t stream) {
 
 int launch_teacher_mma(const rl4co_am_teacher_args& a, hipStream_t stream) {
   if (a.env == RL4CO_ENV_OP) return dispatch_tiles<RL4CO_ENV_OP>(a, stream);
+  if (a.env == RL4CO_ENV_PCTSP) return dispatch_tiles<RL4CO_ENV_PCTSP>(a, stream);
   return a.env == RL4CO_ENV_TSP ? dispatch_tiles<RL4CO_ENV_TSP>(a, stream) : dispatch_tiles<RL4CO_ENV_CVRP>(a, stream);
 }
 

@@ -114,6 +114,16 @@ __device__ inline int bfly_i_max(int v) {
   }
 }
 
+// integer sum over the whole wave
+template <int S = 1>
+__device__ inline int bfly_i_sum(int v) {
+  if constexpr (S < 64) {
+    return bfly_i_sum<S * 2>(v + bfly_i<S>(v));
+  } else {
+    return v;
+  }
+}
+
 // (maximum key, lowest index on ties) over the whole wave; idx == 0x7fffffff marks "empty"
 template <int S = 1>
 __device__ inline void bfly_argmax(float& best, int& bi) {

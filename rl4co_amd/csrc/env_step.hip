@@ -221,7 +221,95 @@ __global__ void __launch_bounds__(64) op_check_kernel(const int64_t* __restrict_
   if (__any(over) && lane == 0) atomicOr(err, RL4CO_EBIT_MAX_LENGTH);
 }
 
+// ---- prize-collecting TSP (envs/routing/pctsp/env.py:62-91,141-148) ---------------------------
+__global__ void __launch_bounds__(64) pctsp_step_kernel(const int64_t* __restrict__ action,
+                                                        const float* __restrict__ real_prize,
+                                                        float* __restrict__ total_prize, uint8_t* __restrict__ visited,
+                                                        int64_t* __restrict__ cur, int64_t* __restrict__ step_i,
+                                                        uint8_t* __restrict__ mask, uint8_t* __restrict__ done, int B_inst,
+                                                        int N, int32_t* err) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* rp = real_prize + (int64_t)(b % B_inst) * N;
+  uint8_t* vis = visited + (int64_t)b * N;
+  uint8_t* row = mask + (int64_t)b * N;
+  float prize = total_prize[b];
+  bool bad = false;
+  if (action != nullptr) {
+    int64_t a = action[b];
+    if (a < 0 || a >= N) {
+      bad = true;
+      a = 0;
+    }
+    prize = prize + rp[a];  // pctsp/env.py:66
+    if (lane == 0) {
+      const int64_t i = step_i[b];
+      vis[a] = 1;                           // pctsp/env.py:70
+      done[b] = (i > 0 && a == 0) ? 1 : 0;  // pctsp/env.py:73
+      step_i[b] = i + 1;
+      cur[b] = a;
+      total_prize[b] = prize;
+    }
+  }
+  __syncthreads();
+  const bool depot_visited = vis[0] != 0;
+  bool unvisited = false;
+  for (int j = lane; j < N; j += 64) {
+    if (j >= 1) {
+      row[j] = (vis[j] != 0 || depot_visited) ? 0 : 1;
+      unvisited |= vis[j] == 0;
+    }
+  }
+  unvisited = __any(unvisited);
+  if (lane == 0) row[0] = ((prize < 1.0f) && unvisited) ? 0 : 1;  // pctsp/env.py:144-147
+  if (bad && lane == 0 && err) atomicOr(err, RL4CO_EBIT_INFEASIBLE);
+}
+
+// pctsp/env.py:175-201 on the padded action buffer: duplicates among the customers; total prize
+// (summed by rl4co_gather_sum_f32 in the reference's order) >= 1 - 1e-5 unless every customer is on the tour
+__global__ void __launch_bounds__(64) pctsp_check_kernel(const int64_t* __restrict__ actions,
+                                                         const float* __restrict__ prize_sum, int N, int T,
+                                                         int32_t* __restrict__ err) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int64_t* act = actions + (int64_t)b * T;
+  __shared__ int seen[1024];
+  bool bad = false;
+  for (int j = lane; j < N; j += 64) seen[j] = 0;
+  __syncthreads();
+  int customers = 0;
+  for (int t = lane; t < T; t += 64) {
+    const int64_t a = act[t];
+    if (a < 0 || a >= N) bad = true;
+    else if (a != 0) {
+      customers += 1;
+      if (atomicAdd(&seen[a], 1) != 0) bad = true;
+    }
+  }
+  customers = rl4co::bfly_i_sum(customers);
+  const bool short_prize = !(prize_sum[b] >= 1.0f - 1e-5f) && customers != N - 1;
+  if (__any(bad) && lane == 0) atomicOr(err, RL4CO_EBIT_DUPLICATES);
+  if (short_prize && lane == 0) atomicOr(err, RL4CO_EBIT_PRIZE);
+}
+
 }  // namespace
+
+extern "C" int rl4co_pctsp_step(const int64_t* action, const float* real_prize, float* cur_total_prize, uint8_t* visited,
+                                int64_t* current_node, int64_t* step_i, uint8_t* action_mask, uint8_t* done, int B,
+                                int B_inst, int N, int32_t* err, void* stream) {
+  RL4CO_REQUIRE(real_prize && cur_total_prize && visited && current_node && step_i && action_mask && done);
+  RL4CO_REQUIRE(B > 0 && B_inst > 0 && B % B_inst == 0 && N >= 2);
+  hipLaunchKernelGGL(pctsp_step_kernel, dim3(B), dim3(64), 0, rl4co::as_stream(stream), action, real_prize, cur_total_prize,
+                     visited, current_node, step_i, action_mask, done, B_inst, N, err);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
+extern "C" int rl4co_pctsp_check_solution(const int64_t* actions, const float* prize_sum, int B, int N, int T, int32_t* err,
+                                          void* stream) {
+  RL4CO_REQUIRE(actions && prize_sum && err && B > 0 && N >= 2 && N <= 1024 && T >= 1);
+  hipLaunchKernelGGL(pctsp_check_kernel, dim3(B), dim3(64), 0, rl4co::as_stream(stream), actions, prize_sum, N, T, err);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
 
 extern "C" int rl4co_op_max_length(const float* locs, const float* max_length, int B, int N, float* table, void* stream) {
   RL4CO_REQUIRE(locs && max_length && table && B > 0 && N >= 2);

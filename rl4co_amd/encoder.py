@@ -24,7 +24,7 @@ class AmEncoderArgs(C.Structure):
 
     _fields_ = [
         ("env", _i32), ("B", _i32), ("N", _i32), ("num_layers", _i32), ("norm", _i32), ("cache_dtype", _i32),
-        ("locs", _vp), ("demand", _vp), ("w_init", _vp), ("b_init", _vp), ("w_depot", _vp), ("b_depot", _vp),
+        ("locs", _vp), ("demand", _vp), ("feature4", _vp), ("w_init", _vp), ("b_init", _vp), ("w_depot", _vp), ("b_depot", _vp),
         ("wqkv_packed", _vp), ("bqkv", _vp), ("wo_packed", _vp), ("bo", _vp), ("n1_scale", _vp), ("n1_shift", _vp),
         ("w1_packed", _vp), ("b1", _vp), ("w2_packed", _vp), ("b2", _vp), ("n2_scale", _vp), ("n2_shift", _vp),
         ("wfold_packed", _vp), ("w_fixed", _vp),
@@ -65,7 +65,9 @@ class PackedEncoder:
     def _current_version(self):
         pol = self.policy
         tensors = list(pol.parameters()) + list(pol.buffers())
-        return (tuple(p._version for p in tensors), tensors[0].device, pol.training)
+        # inference tensors (a model built or loaded under torch.inference_mode) carry no version counter:
+        # their storage address stands in, so in-place updates of such weights need an explicit refresh
+        return (tuple(-p.data_ptr() if p.is_inference() else p._version for p in tensors), tensors[0].device, pol.training)
 
     def refresh(self) -> dict[str, Tensor]:
         ver = self._current_version()
@@ -78,7 +80,7 @@ class PackedEncoder:
         t: dict[str, Tensor] = {}
         ie = enc.init_embedding
         t["w_init"], t["b_init"] = f32(ie.init_embed.weight), f32(ie.init_embed.bias)
-        if pol.env_name in ("cvrp", "op"):
+        if pol.env_name in ("cvrp", "op", "pctsp"):
             t["w_depot"], t["b_depot"] = f32(ie.init_embed_depot.weight), f32(ie.init_embed_depot.bias)
         t["wqkv"] = torch.stack([pack_weight(l[0].module.Wqkv.weight) for l in layers]).contiguous()
         t["bqkv"] = torch.stack([f32(l[0].module.Wqkv.bias) for l in layers]).contiguous()
@@ -142,11 +144,16 @@ class PackedEncoder:
         a.cache_dtype = _lib.DT_BF16 if cache_dtype == torch.bfloat16 else _lib.DT_F32
         a.locs = locs.data_ptr()
         ptr = lambda x: None if x is None else x.data_ptr()  # noqa: E731
-        if pol.env_name in ("cvrp", "op"):
-            # OP embeds the customers' prize where CVRP embeds their demand (init.py:115-136, 254-280)
-            third = td["demand"] if pol.env_name == "cvrp" else td["prize"][..., 1:]
+        if pol.env_name in ("cvrp", "op", "pctsp"):
+            # OP embeds the customers' prize where CVRP embeds their demand (init.py:115-136, 254-280);
+            # PCTSP the expected prize and, as a fourth feature, the penalty (init.py:283-312)
+            third = {"cvrp": "demand", "op": "prize", "pctsp": "expected_prize"}[pol.env_name]
+            third = td[third][..., 1:] if pol.env_name == "op" else td[third]
             demand = third.float().contiguous()
             a.demand, a.w_depot, a.b_depot = demand.data_ptr(), ptr(t["w_depot"]), ptr(t["b_depot"])
+            if pol.env_name == "pctsp":
+                penalty = td["penalty"][..., 1:].float().contiguous()
+                a.feature4 = penalty.data_ptr()
         a.w_init, a.b_init = ptr(t["w_init"]), ptr(t["b_init"])
         a.wqkv_packed, a.bqkv, a.wo_packed, a.bo = ptr(t["wqkv"]), ptr(t["bqkv"]), ptr(t["wo"]), ptr(t["bo"])
         a.n1_scale, a.n1_shift, a.n2_scale, a.n2_shift = (ptr(t[k]) for k in ("n1_scale", "n1_shift", "n2_scale", "n2_shift"))

@@ -124,6 +124,30 @@ class OPGenerator(TSPGenerator):
                            "max_length": max_length}, batch_size=batch_size)
 
 
+class PCTSPGenerator(TSPGenerator):
+    """pctsp/generator.py:37-128: uniform locations (depot sampled with them), penalties U(0, max_penalty),
+    deterministic prizes U(0, 4/n) and stochastic prizes U(0, 2) x deterministic"""
+
+    def __init__(self, num_loc: int = 20, min_loc: float = 0.0, max_loc: float = 1.0, penalty_factor: float = 3.0,
+                 prize_required: float = 1.0, max_penalty: float | None = None, device="cpu", **unused):
+        super().__init__(num_loc, min_loc, max_loc, device)
+        self.prize_required = prize_required
+        if max_penalty is None:
+            max_penalty = OP_MAX_LENGTHS.get(num_loc, None)  # the same table as OP (pctsp/generator.py:13)
+        if max_penalty is None:
+            closest = min(OP_MAX_LENGTHS.keys(), key=lambda x: abs(x - num_loc))
+            max_penalty = OP_MAX_LENGTHS[closest]
+        self.max_penalty = max_penalty * penalty_factor / num_loc  # Kool et al. (2019) scaling
+
+    def _generate(self, batch_size) -> TensorDict:
+        locs_with_depot = self._uniform((*batch_size, self.num_loc + 1, 2), self.min_loc, self.max_loc)
+        penalty = self._uniform((*batch_size, self.num_loc), 0.0, self.max_penalty)
+        det = self._uniform((*batch_size, self.num_loc), 0.0, 4.0 / self.num_loc)
+        sto = self._uniform((*batch_size, self.num_loc), 0.0, 2.0) * det
+        return TensorDict({"locs": locs_with_depot[..., 1:, :], "depot": locs_with_depot[..., 0, :], "penalty": penalty,
+                           "deterministic_prize": det, "stochastic_prize": sto}, batch_size=batch_size)
+
+
 class RL4COEnvBase:
     """envs/common/base.py:19-333, rollout-path methods only."""
 
@@ -355,5 +379,80 @@ class OPEnv(RL4COEnvBase):
             K.raise_if_error(err)
 
 
+class PCTSPEnv(RL4COEnvBase):
+    """Prize-collecting TSP (envs/routing/pctsp/env.py:17-219, deterministic prizes): the tour may
+    return to the depot once a total prize of 1 is collected; the cost is the tour length plus the
+    penalties of the customers left out. State and arithmetic live in ``rl4co_pctsp_*``."""
+
+    name = "pctsp"
+    has_depot = True
+    _stochastic = False
+
+    def _default_generator(self, **kw):
+        return PCTSPGenerator(**kw)
+
+    def _reset(self, td: TensorDict, batch_size) -> TensorDict:
+        """pctsp/env.py:93-139"""
+        device = td["locs"].device
+        b = td["locs"].shape[0]
+        n = td["locs"].shape[-2] + 1
+        expected_prize = td["deterministic_prize"]
+        real_prize = td["stochastic_prize"] if self._stochastic else td["deterministic_prize"]
+        penalty = td["penalty"]
+        td_reset = TensorDict(
+            {
+                "locs": torch.cat((td["depot"][:, None, :], td["locs"]), -2).contiguous(),
+                "current_node": torch.zeros(b, dtype=torch.long, device=device),
+                "expected_prize": expected_prize.contiguous(),
+                "real_prize": F.pad(real_prize, (1, 0), mode="constant", value=0).contiguous(),  # 0 for the depot
+                "penalty": F.pad(penalty, (1, 0), mode="constant", value=0).contiguous(),
+                "cur_total_prize": torch.zeros(b, device=device),
+                "cur_total_penalty": penalty.sum(-1),  # sum all penalties (minus the visited ones)
+                "visited": torch.zeros((b, n), dtype=torch.uint8, device=device),
+                "prize_required": torch.full((b,), float(self.generator.prize_required), device=device),
+                "i": torch.zeros((b,), dtype=torch.int64, device=device),
+                "action_mask": torch.zeros((b, n), dtype=torch.bool, device=device),
+                "done": torch.zeros((b,), dtype=torch.bool, device=device),
+            },
+            batch_size=[b],
+        )
+        self.get_action_mask(td_reset)
+        return td_reset
+
+    def _step(self, td: TensorDict) -> TensorDict:
+        """pctsp/env.py:62-91 via rl4co_pctsp_step (in place, mask included)"""
+        action = td["action"].contiguous()
+        td["cur_total_penalty"] += td["penalty"].gather(1, action[:, None]).squeeze(1)  # pctsp/env.py:67-69
+        K.pctsp_step(action, td["real_prize"], td["cur_total_prize"], td["visited"], td["current_node"], td["i"],
+                     td["action_mask"], td["done"])
+        return td
+
+    def get_action_mask(self, td: TensorDict) -> Tensor:
+        """pctsp/env.py:141-148 (recomputed in place into td['action_mask'])"""
+        K.pctsp_step(None, td["real_prize"], td["cur_total_prize"], td["visited"], td["current_node"], td["i"],
+                     td["action_mask"], td["done"])
+        return td["action_mask"]
+
+    def _get_reward(self, td: TensorDict, actions: Tensor) -> Tensor:
+        """pctsp/env.py:150-173: saved penalties - (tour length from the depot + all penalties)"""
+        if actions.size(-1) == 1:
+            assert bool((actions == 0).all()), "If all length 1 tours, they should be zero"
+            return torch.zeros(actions.size(0), dtype=torch.float, device=actions.device)
+        actions = actions.contiguous()
+        length = K.tour_length(td["locs"].contiguous(), actions, prepend_depot=True, negate=False)
+        saved = K.gather_sum(td["penalty"], actions)
+        n = td["penalty"].shape[-1]
+        every = torch.arange(1, n, device=actions.device).expand(actions.shape[0], n - 1).contiguous()
+        return saved - (length + K.gather_sum(td["penalty"], every))  # the three sums in the reference's order
+
+    def check_solution_validity(self, td: TensorDict, actions: Tensor, err: Tensor | None = None) -> None:
+        """pctsp/env.py:175-201. ``err``: see TSPEnv."""
+        own = err is None
+        err = K.new_error_word(actions.device) if own else err
+        K.pctsp_check_solution(actions.contiguous(), td["real_prize"], err)
+        if own:
+            K.raise_if_error(err)
+
+
 def get_env(name: str, **kw) -> RL4COEnvBase:
-    return {"tsp": TSPEnv, "cvrp": CVRPEnv, "op": OPEnv}[name](**kw)
+    return {"tsp": TSPEnv, "cvrp": CVRPEnv, "op": OPEnv, "pctsp": PCTSPEnv}[name](**kw)

@@ -15,7 +15,7 @@ from . import _lib
 from .cache import FoldedCache
 
 MODE_IDS = {"greedy": _lib.DECODE_GREEDY, "sampling": _lib.DECODE_SAMPLE, "evaluate": _lib.DECODE_EVALUATE}
-ENV_IDS = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP, "op": _lib.ENV_OP}
+ENV_IDS = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP, "op": _lib.ENV_OP, "pctsp": _lib.ENV_PCTSP}
 VARIANT_IDS = {"auto": _lib.VARIANT_AUTO, "stream": _lib.VARIANT_STREAM, "lds": _lib.VARIANT_LDS, "wide": _lib.VARIANT_WIDE, "ms": _lib.VARIANT_MS}
 
 
@@ -225,6 +225,16 @@ def am_decode(
         a.used_capacity = _ptr(_dev(state["tour_length"], torch.float32, "tour_length"))
         a.step_i = _ptr(_dev(state["i"], torch.int64, "i"))
         a.visited = _ptr(_u8(state["visited"], "visited"))
+    elif env_name == "pctsp":
+        # prize-collecting TSP: the real prize per node (depot column 0) rides in the demand slot, the
+        # prize collected so far in used_capacity, prize_required in vehicle_capacity
+        a.w_cap = _ptr(_dev(cache.w_cap, torch.float32, "w_cap"))
+        assert state["real_prize"].shape == (cache.num_instances, n)
+        a.demand = _ptr(_dev(state["real_prize"], torch.float32, "real_prize"))
+        a.used_capacity = _ptr(_dev(state["cur_total_prize"], torch.float32, "cur_total_prize"))
+        a.vehicle_capacity = _ptr(_dev(state["prize_required"], torch.float32, "prize_required"))
+        a.step_i = _ptr(_dev(state["i"], torch.int64, "i"))
+        a.visited = _ptr(_u8(state["visited"], "visited"))
     else:
         a.w_cap = _ptr(_dev(cache.w_cap, torch.float32, "w_cap"))
         a.demand = _ptr(_dev(state["demand"], torch.float32, "demand"))
@@ -276,6 +286,29 @@ def op_step(action: Tensor | None, locs: Tensor, max_length: Tensor, tour_length
         _ptr(_dev(step_i, torch.int64, "i")), _ptr(_u8(action_mask, "action_mask")), _ptr(_u8(done, "done")),
         b, locs.shape[0], n, _ptr(err), _stream())
     _lib.check(st, "rl4co_op_step")
+
+
+def pctsp_step(action: Tensor | None, real_prize: Tensor, cur_total_prize: Tensor, visited: Tensor, current_node: Tensor,
+               step_i: Tensor, action_mask: Tensor, done: Tensor, err: Tensor | None = None) -> None:
+    """In-place PCTSPEnv._step + get_action_mask (pctsp/env.py:62-91,141-148); action=None -> mask only.
+    ``real_prize`` [B_inst, N] carries 0 in the depot column."""
+    b, n = action_mask.shape
+    st = _lib.lib().rl4co_pctsp_step(
+        _ptr(None if action is None else _dev(action, torch.int64, "action")),
+        _ptr(_dev(real_prize, torch.float32, "real_prize")), _ptr(_dev(cur_total_prize, torch.float32, "cur_total_prize")),
+        _ptr(_u8(visited, "visited")), _ptr(_dev(current_node, torch.int64, "current_node")),
+        _ptr(_dev(step_i, torch.int64, "i")), _ptr(_u8(action_mask, "action_mask")), _ptr(_u8(done, "done")),
+        b, real_prize.shape[0], n, _ptr(err), _stream())
+    _lib.check(st, "rl4co_pctsp_step")
+
+
+def pctsp_check_solution(actions: Tensor, real_prize: Tensor, err: Tensor) -> None:
+    """pctsp/env.py:175-201 into the sticky error word (RL4CO_EBIT_DUPLICATES / RL4CO_EBIT_PRIZE)."""
+    b, t = actions.shape
+    prize_sum = gather_sum(real_prize, actions)
+    st = _lib.lib().rl4co_pctsp_check_solution(_ptr(_dev(actions, torch.int64, "actions")), _ptr(prize_sum), b,
+                                               real_prize.shape[1], t, _ptr(_dev(err, torch.int32, "err")), _stream())
+    _lib.check(st, "rl4co_pctsp_check_solution")
 
 
 def gather_sum(values: Tensor, actions: Tensor) -> Tensor:

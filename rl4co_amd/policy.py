@@ -230,6 +230,25 @@ class _OPInit(_VRPInit):
         return torch.cat((self.init_embed_depot(locs[:, :1, :]), self.init_embed(feats)), -2)
 
 
+class _PCTSPInit(nn.Module):
+    """env_embeddings/init.py:283-312: customers (x, y, expected prize, penalty), depot (x, y)"""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.init_embed = nn.Linear(4, embed_dim, True)
+        self.init_embed_depot = nn.Linear(2, embed_dim, True)
+
+    def forward(self, td):
+        locs = td["locs"]
+        feats = torch.cat((locs[:, 1:, :], td["expected_prize"][..., None], td["penalty"][..., 1:, None]), -1)
+        if _train_kernels_active(locs):
+            from . import train_ops
+
+            return torch.cat((train_ops.init_embed(locs[:, :1, :], self.init_embed_depot),
+                              train_ops.init_embed(feats, self.init_embed)), -2)
+        return torch.cat((self.init_embed_depot(locs[:, :1, :]), self.init_embed(feats)), -2)
+
+
 class AttentionModelEncoder(nn.Module):
     """zoo/am/encoder.py:12-87"""
 
@@ -237,7 +256,7 @@ class AttentionModelEncoder(nn.Module):
                  feedforward_hidden=512):
         super().__init__()
         self.env_name = env_name
-        self.init_embedding = {"tsp": _TSPInit, "cvrp": _VRPInit, "op": _OPInit}[env_name](embed_dim)
+        self.init_embedding = {"tsp": _TSPInit, "cvrp": _VRPInit, "op": _OPInit, "pctsp": _PCTSPInit}[env_name](embed_dim)
         self.net = _GraphAttentionNetwork(num_heads, embed_dim, num_layers, normalization, feedforward_hidden)
 
     def forward(self, td):
@@ -281,7 +300,7 @@ class AttentionModelDecoder(nn.Module):
         self.num_heads = num_heads
         self.mask_inner = mask_inner
         self.check_nan = check_nan
-        self.context_embedding = {"tsp": _TSPContext, "cvrp": _VRPContext, "op": _VRPContext}[env_name](embed_dim)
+        self.context_embedding = {"tsp": _TSPContext, "cvrp": _VRPContext, "op": _VRPContext, "pctsp": _VRPContext}[env_name](embed_dim)
         self.dynamic_embedding = nn.Module()  # StaticEmbedding (dynamic.py:47-57): no parameters
         self.pointer = _Pointer(embed_dim)
         self.project_node_embeddings = nn.Linear(embed_dim, 3 * embed_dim, bias=False)
@@ -385,10 +404,13 @@ class AttentionModelPolicy(nn.Module):
 
         enc = self.encoder
         init = enc.init_embedding
-        if self.env_name in ("cvrp", "op"):
+        if self.env_name in ("cvrp", "op", "pctsp"):
             locs = td["locs"]
-            third = td["demand"] if self.env_name == "cvrp" else td["prize"][..., 1:]
+            third = {"cvrp": "demand", "op": "prize", "pctsp": "expected_prize"}[self.env_name]
+            third = td[third][..., 1:] if self.env_name == "op" else td[third]
             feats = torch.cat((locs[:, 1:, :], third[..., None]), -1)
+            if self.env_name == "pctsp":
+                feats = torch.cat((feats, td["penalty"][..., 1:, None]), -1)
             x = torch.cat((T.init_embed(locs[:, :1, :], init.init_embed_depot), T.init_embed(feats, init.init_embed)), -2)
         else:
             x = T.init_embed(td["locs"], init.init_embed)
@@ -423,7 +445,8 @@ class AttentionModelPolicy(nn.Module):
     def _max_horizon(env_name: str, n: int) -> int:
         # TSP: exactly N steps. CVRP: every customer + at most one depot visit per customer + 1.
         # OP: every customer once, the closing depot visit, and a depot pick at step 0 costs one more.
-        return n if env_name == "tsp" else (n + 2 if env_name == "op" else 2 * n)
+        # PCTSP: every customer once and the closing depot visit (the depot is masked at step 0).
+        return n if env_name in ("tsp", "pctsp") else (n + 2 if env_name == "op" else 2 * n)
 
     def _initial_state(self, td, num_starts: int):
         """State tensors the kernel updates in place; with multistart the rows are expanded
@@ -443,6 +466,12 @@ class AttentionModelPolicy(nn.Module):
         if self.env_name == "tsp":
             st["first_node"] = rep(td["first_node"].reshape(-1))
             st["i"] = rep(td["i"].reshape(-1))
+        elif self.env_name == "pctsp":
+            st["real_prize"] = td["real_prize"].contiguous()  # instance data [B_inst, N], depot column 0
+            st["cur_total_prize"] = rep(td["cur_total_prize"].reshape(-1))
+            st["prize_required"] = rep(td["prize_required"].reshape(-1))
+            st["i"] = rep(td["i"].reshape(-1))
+            st["visited"] = rep(td["visited"])
         elif self.env_name == "op":
             st["locs"] = td["locs"].contiguous()              # instance data, like CVRP's demand
             st["max_length"] = td["max_length"].contiguous()  # [B_inst, N] entry limits
@@ -455,7 +484,7 @@ class AttentionModelPolicy(nn.Module):
             st["vehicle_capacity"] = rep(td["vehicle_capacity"].reshape(-1))
             st["visited"] = rep(td["visited"])
         if s == 1:
-            st = {k: (v.clone() if k not in ("demand", "locs", "max_length") else v) for k, v in st.items()}
+            st = {k: (v.clone() if k not in ("demand", "locs", "max_length", "real_prize") else v) for k, v in st.items()}
         return st
 
     # -- forward (constructive/base.py:154-263) ---------------------------------------------------
@@ -616,6 +645,8 @@ class AttentionModelPolicy(nn.Module):
                 meta.update(demand=td["demand"], vehicle_capacity=td["vehicle_capacity"])
             elif self.env_name == "op":
                 meta.update(locs=td["locs"], max_length=td["max_length"])
+            elif self.env_name == "pctsp":
+                meta.update(real_prize=td["real_prize"], prize_required=td["prize_required"])
             step_logps = teacher.teacher_forced_logps(self.env_name, cache_g, cache, out_actions, logps, meta)
         elif grad_path:
             step_logps = self.evaluate_log_probs(td, hidden, out_actions, n_rep, tanh_clipping, temperature,
@@ -651,6 +682,9 @@ class AttentionModelPolicy(nn.Module):
         elif self.env_name == "op":
             K.op_step(action, state["locs"], state["max_length"], state["tour_length"], state["visited"],
                       state["current_node"], state["i"], state["action_mask"], state["done"], err)
+        elif self.env_name == "pctsp":
+            K.pctsp_step(action, state["real_prize"], state["cur_total_prize"], state["visited"], state["current_node"],
+                         state["i"], state["action_mask"], state["done"], err)
         else:
             K.cvrp_step(action, state["demand"], state["used_capacity"], state["vehicle_capacity"],
                         state["visited"], state["current_node"], state["action_mask"], state["done"], err)
@@ -671,6 +705,10 @@ class AttentionModelPolicy(nn.Module):
         elif self.env_name == "op":
             out.update(prize=rep(td["prize"]), max_length=rep(td["max_length"]), current_node=state["current_node"].view(-1, 1),
                        tour_length=state["tour_length"], visited=state["visited"], i=state["i"])
+        elif self.env_name == "pctsp":
+            out.update(real_prize=rep(td["real_prize"]), expected_prize=rep(td["expected_prize"]), penalty=rep(td["penalty"]),
+                       prize_required=state["prize_required"], cur_total_prize=state["cur_total_prize"],
+                       current_node=state["current_node"], visited=state["visited"], i=state["i"])
         else:
             out.update(demand=rep(td["demand"]), current_node=state["current_node"].view(-1, 1),
                        used_capacity=state["used_capacity"].view(-1, 1),
@@ -755,6 +793,8 @@ class AttentionModelPolicy(nn.Module):
             elif self.env_name == "op":
                 ml0 = state["max_length"][:, 0]
                 rem[:, t] = (ml0 if ml0.shape[0] == b else ml0.repeat(b // ml0.shape[0])) - state["tour_length"]
+            elif self.env_name == "pctsp":
+                rem[:, t] = torch.clamp(state["prize_required"] - state["cur_total_prize"], min=0)
             else:
                 rem[:, t] = state["vehicle_capacity"] - state["used_capacity"]
             self._env_step_state(state, actions[:, t].contiguous(), err)

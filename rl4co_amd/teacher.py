@@ -44,10 +44,10 @@ def max_nodes() -> int:
 
 
 def supports(env_name: str, cache_dtype: torch.dtype, num_nodes: int) -> bool:
-    """TSP / CVRP: both variants; orienteering: the MMA variant only (bf16 planes)."""
+    """TSP / CVRP: both variants; orienteering and prize-collecting TSP: the MMA variant only (bf16 planes)."""
     if num_nodes > max_nodes():
         return False
-    return env_name in ("tsp", "cvrp") or (env_name == "op" and cache_dtype == torch.bfloat16)
+    return env_name in ("tsp", "cvrp") or (env_name in ("op", "pctsp") and cache_dtype == torch.bfloat16)
 
 
 def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: dict, variant: str = "auto",
@@ -71,7 +71,7 @@ def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: d
     logp = torch.zeros((b, t), **f32) if want_logp else None
     err = torch.zeros(1, dtype=torch.int32, device=dev)
     a = AmTeacherArgs()
-    a.env = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP, "op": _lib.ENV_OP}[cache.env_name]
+    a.env = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP, "op": _lib.ENV_OP, "pctsp": _lib.ENV_PCTSP}[cache.env_name]
     a.B, a.B_inst, a.N, a.T, a.t0 = b, b_inst, n, t, int(meta["t0"])
     a.mask_inner, a.mask_logits = int(meta["mask_inner"]), int(meta["mask_logits"])
     a.tanh_clipping, a.temperature = float(meta["tanh_clipping"]), float(meta["temperature"])
@@ -88,6 +88,10 @@ def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: d
     if cache.env_name == "cvrp":
         demand = meta["demand"].contiguous()
         vcap = meta["vehicle_capacity"].reshape(-1).contiguous()
+        a.demand, a.vehicle_capacity = demand.data_ptr(), vcap.data_ptr()
+    elif cache.env_name == "pctsp":
+        demand = meta["real_prize"].float().contiguous()  # [B_inst, N], depot column 0
+        vcap = meta["prize_required"].float().reshape(-1).contiguous()
         a.demand, a.vehicle_capacity = demand.data_ptr(), vcap.data_ptr()
     elif cache.env_name == "op":
         locs, maxlen = meta["locs"].float().contiguous(), meta["max_length"].float().contiguous()

@@ -42,6 +42,22 @@ def _op_check(actions, locs, max_length, err):
         err |= 64 if "Duplicates" in str(e) else 128
 
 
+def _pctsp_step(action, real_prize, cur_total_prize, visited, current_node, step_i, action_mask, done, err=None):
+    c_oracle.pctsp_step(None if action is None else action.contiguous(), real_prize, cur_total_prize, visited, current_node,
+                        step_i, action_mask, done)
+
+
+def _pctsp_check(actions, real_prize, err):
+    from oracle import reference_torch as R
+
+    s = actions.shape[0] // real_prize.shape[0]
+    rp = R.batchify(real_prize, s) if s > 1 else real_prize
+    try:
+        R.PCTSPEnv.check_solution_validity({"real_prize": rp, "locs": rp[..., None]}, actions)
+    except AssertionError as e:
+        err |= 64 if "Duplicates" in str(e) else 256
+
+
 def _select_start_nodes(batch, num_starts, num_loc, has_depot, device):
     return torch.arange(num_starts).repeat_interleave(batch) % num_loc + (1 if has_depot else 0)
 
@@ -92,5 +108,7 @@ def cpu_device(monkeypatch):
     monkeypatch.setattr(K, "op_max_length", c_oracle.op_max_length)
     monkeypatch.setattr(K, "gather_sum", lambda values, actions: c_oracle.gather_sum(values.contiguous(), actions.contiguous()))
     monkeypatch.setattr(K, "op_check_solution", _op_check)
+    monkeypatch.setattr(K, "pctsp_step", _pctsp_step)
+    monkeypatch.setattr(K, "pctsp_check_solution", _pctsp_check)
     monkeypatch.setattr(K, "am_decode", _am_decode)
     return "cpu"

@@ -114,6 +114,12 @@ def rollout_state(env_name: str, td: dict, device="cpu", num_starts: int = 0) ->
     if env_name == "tsp":
         st["first_node"] = rep(td["first_node"].reshape(-1))
         st["i"] = rep(td["i"].reshape(-1))
+    elif env_name == "pctsp":
+        st["real_prize"] = td["real_prize"].to(device).contiguous()
+        st["cur_total_prize"] = rep(td["cur_total_prize"].reshape(-1))
+        st["prize_required"] = rep(td["prize_required"].reshape(-1))
+        st["i"] = rep(td["i"].reshape(-1))
+        st["visited"] = rep(td["visited"].to(torch.uint8))
     elif env_name == "op":
         st["locs"] = td["locs"].to(device).contiguous()
         st["max_length"] = td["max_length"].to(device).contiguous()
@@ -132,7 +138,7 @@ device_state = rollout_state  # name used by the GPU tests
 
 
 def max_horizon(env_name: str, n: int) -> int:
-    return n if env_name == "tsp" else (n + 2 if env_name == "op" else 2 * n)
+    return n if env_name in ("tsp", "pctsp") else (n + 2 if env_name == "op" else 2 * n)
 
 
 def oracle_reward(env_name: str, td0: dict, actions: torch.Tensor) -> torch.Tensor:
@@ -141,6 +147,12 @@ def oracle_reward(env_name: str, td0: dict, actions: torch.Tensor) -> torch.Tens
 
     if env_name == "op":
         return c_oracle.gather_sum(td0["prize"].contiguous(), actions.contiguous())
+    if env_name == "pctsp":  # pctsp/env.py:150-173: three sums in the reference's order
+        pen = td0["penalty"].contiguous()
+        n = pen.shape[-1]
+        every = torch.arange(1, n).expand(actions.shape[0], n - 1).contiguous()
+        length = c_oracle.tour_length(td0["locs"], actions.contiguous(), prepend_depot=True, negate=False)
+        return c_oracle.gather_sum(pen, actions.contiguous()) - (length + c_oracle.gather_sum(pen, every))
     return c_oracle.tour_length(td0["locs"], actions, prepend_depot=(env_name == "cvrp"), negate=True)
 
 
@@ -148,4 +160,10 @@ def kernel_reward(K, env_name: str, td0: dict, actions: torch.Tensor) -> torch.T
     """Same through the HIP kernels (inputs are moved to the GPU)."""
     if env_name == "op":
         return K.gather_sum(td0["prize"].cuda().contiguous(), actions.cuda().contiguous())
+    if env_name == "pctsp":
+        pen, acts = td0["penalty"].cuda().contiguous(), actions.cuda().contiguous()
+        n = pen.shape[-1]
+        every = torch.arange(1, n, device="cuda").expand(acts.shape[0], n - 1).contiguous()
+        length = K.tour_length(td0["locs"].cuda(), acts, prepend_depot=True, negate=False)
+        return K.gather_sum(pen, acts) - (length + K.gather_sum(pen, every))
     return K.tour_length(td0["locs"].cuda(), actions.cuda().contiguous(), prepend_depot=(env_name == "cvrp"), negate=True)

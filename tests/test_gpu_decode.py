@@ -100,8 +100,8 @@ CONFIG_IDS = ["f32-stream", "bf16-stream", "bf16-lds", "bf16-wide"]
 
 def _skip_if_unservable(g, dtype, variant):
     n = g.num_loc + (g.env_name != "tsp")
-    if g.env_name == "op" and variant != "stream":
-        pytest.skip("the orienteering transition exists in the streaming kernel only")
+    if g.env_name in ("op", "pctsp") and variant != "stream":
+        pytest.skip("the orienteering / prize-collecting transitions exist in the streaming kernel only")
     try:
         __import__("rl4co_amd.kernels").kernels.decode_row_groups(n, dtype, 2 * n, variant, 64)
     except Exception:
@@ -120,13 +120,14 @@ def test_greedy_bit_exact_vs_c_oracle(K, name, dtype, variant):
 
 @pytest.mark.parametrize("dtype,variant", CONFIGS, ids=CONFIG_IDS)
 @pytest.mark.parametrize("name", ["tsp100_b64_sampling", "cvrp100_b64_sampling", "pomo_tsp50_b8_mssampling",
+                                  "op50_b64_sampling", "pctsp50_b64_sampling",
                                   "c4_pomo_tsp100_b32_s8_sampling", "c5_cvrp500_b16_sampling"])
 def test_sampling_injected_noise_bit_exact_vs_c_oracle(K, name, dtype, variant):
     g = GoldenCase(name)
     _skip_if_unservable(g, dtype, variant)
     td0, h = _encode(g)
     b = g.batch * max(g.num_starts, 1)
-    n = g.num_loc + (g.env_name == "cvrp")
+    n = g.num_loc + (g.env_name != "tsp")
     torch.manual_seed(g.meta["sample_seed"])
     noise = torch.stack([torch.empty(b, n).exponential_(1) for _ in range(max_horizon(g.env_name, n))], 0).contiguous()
     _assert_bit_exact(_run(K, "hip", g, td0, h, "sampling", dtype, variant=variant, exp_noise=noise),
@@ -155,7 +156,7 @@ def test_evaluate_mode_bit_exact_and_entropy(K, name):
     g = GoldenCase(name)
     td0, h = _encode(g)
     b, t = g.actions.shape
-    n = g.num_loc + (g.env_name == "cvrp")
+    n = g.num_loc + (g.env_name != "tsp")
     tmax = max_horizon(g.env_name, n)
     forced = torch.zeros(b, tmax, dtype=torch.int64)
     forced[:, :t] = g.actions
@@ -253,6 +254,7 @@ def test_greedy_vs_reference_golden(K, name):
 
 
 @pytest.mark.parametrize("name", ["tsp100_b64_sampling", "cvrp100_b64_sampling", "pomo_tsp50_b8_mssampling",
+                                  "op50_b64_sampling", "pctsp50_b64_sampling",
                                   "c4_pomo_tsp100_b32_s8_sampling", "c5_cvrp500_b16_sampling"])
 def test_sampling_vs_reference_golden(K, name):
     """Fixed-seed sampling: the reference's multinomial stream, re-drawn from its seed, drives the
@@ -260,7 +262,7 @@ def test_sampling_vs_reference_golden(K, name):
     g = GoldenCase(name)
     td0, h = _encode(g)
     b = g.batch * max(g.num_starts, 1)
-    n = g.num_loc + (g.env_name == "cvrp")
+    n = g.num_loc + (g.env_name != "tsp")
     torch.manual_seed(g.meta["sample_seed"])
     noise = torch.stack([torch.empty(b, n).exponential_(1) for _ in range(max_horizon(g.env_name, n))], 0).contiguous()
     a, l, st, n_steps, t, err = _run(K, "hip", g, td0, h, "sampling", exp_noise=noise)

@@ -79,6 +79,37 @@ def test_tour_length_multistart_row_mapping():
 # env transitions: C oracle == torch restatement under a random feasible policy
 # ---------------------------------------------------------------------------------------------
 
+@pytest.mark.parametrize("env_name,num_loc", [("op", 20), ("op", 100), ("pctsp", 20), ("pctsp", 100)])
+def test_depot_env_steps_match_restatement(env_name, num_loc):
+    """Orienteering / prize-collecting TSP transitions and masks: C oracle == restatement, bit for bit,
+    under a random feasible policy; then the reward composition of tests/helpers.oracle_reward."""
+    env, data = make_instances(env_name, num_loc, 64)
+    td0 = env.reset(clone_td(data))
+    td = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in td0.items()}
+    st = rollout_state(env_name, td)
+    g = torch.Generator().manual_seed(3)
+    acts = []
+    while not bool(td["done"].all()):
+        action = torch.multinomial(td["action_mask"].float(), 1, generator=g).squeeze(1)
+        td["action"] = action
+        td = env.step(td)
+        acts.append(action)
+        if env_name == "op":
+            c_oracle.op_step(action, st["locs"], st["max_length"], st["tour_length"], st["visited"], st["current_node"],
+                             st["i"], st["action_mask"], st["done"])
+            assert torch.equal(st["tour_length"], td["tour_length"])
+        else:
+            c_oracle.pctsp_step(action, st["real_prize"], st["cur_total_prize"], st["visited"], st["current_node"],
+                                st["i"], st["action_mask"], st["done"])
+            assert torch.equal(st["cur_total_prize"], td["cur_total_prize"])
+        assert torch.equal(st["visited"].bool(), td["visited"].bool())
+        assert torch.equal(st["action_mask"], td["action_mask"])
+        assert torch.equal(st["done"], td["done"].reshape(-1))
+        assert torch.equal(st["i"], td["i"].reshape(-1))
+    actions = torch.stack(acts, 1)
+    assert torch.equal(oracle_reward(env_name, td0, actions), env.get_reward(td0, actions))
+
+
 @pytest.mark.parametrize("env_name,num_loc", [("tsp", 20), ("cvrp", 20), ("cvrp", 50)])
 def test_env_steps_match_restatement(env_name, num_loc):
     env, data = make_instances(env_name, num_loc, 64)
@@ -175,7 +206,7 @@ def test_c_oracle_sampling_matches_reference(name):
     g = GoldenCase(name)
     s = g.num_starts
     b = g.batch * max(s, 1)
-    n = g.num_loc + (1 if g.env_name == "cvrp" else 0)
+    n = g.num_loc + (0 if g.env_name == "tsp" else 1)
     steps = g.actions.shape[1] - (1 if s > 0 else 0)
     torch.manual_seed(g.meta["sample_seed"])
     noise = torch.stack([torch.empty(b, n).exponential_(1) for _ in range(max_horizon(g.env_name, n))], 0)
