@@ -44,12 +44,16 @@ extern "C" {
 #define RL4CO_EBIT_DUPLICATES 64  /* op/env.py:178-181 "Duplicates"                        */
 #define RL4CO_EBIT_MAX_LENGTH 128 /* op/env.py:192-194 "Max length exceeded"               */
 #define RL4CO_EBIT_PRIZE 256      /* pctsp/env.py:192-201 "Total prize does not satisfy min total prize" */
+#define RL4CO_EBIT_NOT_ALL_NODES 512   /* pdp/env.py:208-213 "Not visiting all nodes"                  */
+#define RL4CO_EBIT_DEPOT_MIDDLE 1024   /* pdp/env.py:216-218 "Going back to depot in the middle ..."   */
+#define RL4CO_EBIT_NO_PICKUP 2048      /* pdp/env.py:220-223 "Deliverying without pick-up"             */
 
 /* ---- enums --------------------------------------------------------------- */
 #define RL4CO_ENV_TSP 0
 #define RL4CO_ENV_CVRP 1
 #define RL4CO_ENV_OP 2 /* orienteering problem: streaming decode variant only */
 #define RL4CO_ENV_PCTSP 3 /* prize-collecting TSP (same row): streaming decode variant only */
+#define RL4CO_ENV_PDP 4 /* pickup and delivery (same row): streaming decode variant only */
 
 #define RL4CO_DECODE_GREEDY 0   /* utils/decoding.py:387-397 */
 #define RL4CO_DECODE_SAMPLE 1   /* utils/decoding.py:399-413 */
@@ -172,6 +176,21 @@ int rl4co_pctsp_check_solution(const int64_t* actions, const float* prize_sum, i
                                void* stream);
 
 /* --------------------------------------------------------------------------
+ * N4  PDPEnv (pickup and delivery)   envs/routing/pdp/env.py:64-99,204-223
+ * Nodes: 0 = depot, 1..n/2 pickups, n/2+1..n their deliveries (n = N - 1 even).
+ * step : available[a] = 0 ; to_deliver[(a + n/2) % (n + 1)] = 1 ; mask = available & to_deliver ;
+ *        done = no node available ; i += 1 ; cur = a   (action == NULL: mask only).
+ * check (actions [B,T]; a depot visit is prepended unless force_start_at_depot): every node exactly once
+ *        (RL4CO_EBIT_NOT_ALL_NODES), no depot visit strictly inside the tour (RL4CO_EBIT_DEPOT_MIDDLE),
+ *        every pickup before its delivery (RL4CO_EBIT_NO_PICKUP).
+ * reward: rl4co_tour_length_f32(prepend_depot = 1, negate = 1)   pdp/env.py:191-202
+ * -------------------------------------------------------------------------- */
+int rl4co_pdp_step(const int64_t* action, uint8_t* available, uint8_t* to_deliver, int64_t* current_node, int64_t* step_i,
+                   uint8_t* action_mask, uint8_t* done, int B, int N, int32_t* err, void* stream);
+int rl4co_pdp_check_solution(const int64_t* actions, int B, int N, int T, int force_start_at_depot, int32_t* err,
+                             void* stream);
+
+/* --------------------------------------------------------------------------
  * a13-a21  AttentionModel decode: one step, or the whole autoregressive loop.
  *
  * Replaces, per step: TSPContext/VRPContext (env_embeddings/context.py:105-149),
@@ -235,6 +254,9 @@ typedef struct rl4co_am_decode_args {
   const float* max_length;  /* [B_inst,N] OP: longest tour with which node j may be entered */
   /* PCTSP (envs/routing/pctsp/env.py): demand = real prize WITH the depot column [B_inst,N],
    * used_capacity = prize collected so far, vehicle_capacity = prize_required [B], step_i, visited */
+  /* PDP (envs/routing/pdp/env.py): visited carries the `available` flags (1 = not yet visited), to_deliver
+   * the precedence flags; step_i; the context is the current node's row alone (no scalar, w_cap NULL) */
+  uint8_t* to_deliver;      /* [B,N] PDP                                                   */
   /* decoding inputs */
   const float* exp_noise;   /* [max_steps,B,N] Exp(1) draws (parity mode) or NULL          */
   uint64_t philox_seed;     /* in-kernel Exp(1) noise when exp_noise == NULL               */
@@ -286,7 +308,7 @@ int rl4co_am_decode_variant(const rl4co_am_decode_args* args);
  * element s = W[32*tile + row][16*kstep + 8*hi + s]   (rl4co_amd/encoder.py: pack_weight).
  * -------------------------------------------------------------------------- */
 typedef struct rl4co_am_encoder_args {
-  int32_t env;         /* RL4CO_ENV_*                                              */
+  int32_t env;         /* RL4CO_ENV_TSP | RL4CO_ENV_CVRP (every depot env with a 3- or 4-feature customer embedding) | RL4CO_ENV_PDP */
   int32_t B;           /* instances                                                */
   int32_t N;           /* nodes incl. depot                                        */
   int32_t num_layers;  /* 3 (AM) / 6 (POMO)                                        */
@@ -297,8 +319,10 @@ typedef struct rl4co_am_encoder_args {
   const float* feature4; /* [B,N-1] PCTSP penalty (w_init is then [128,4]) or NULL  */
   const float* w_init; /* [128,2] TSP / [128,3] CVRP customers / [128,4] PCTSP      */
   const float* b_init; /* [128]                                                    */
-  const float* w_depot; /* [128,2] CVRP                                            */
+  const float* w_depot; /* [128,2] depot environments                              */
   const float* b_depot; /* [128]                                                   */
+  const float* w_extra; /* [128,2] RL4CO_ENV_PDP: the delivery embedding; w_init is then the pickup embedding */
+  const float* b_extra; /* [128]     [128,4] over (x, y, x', y' of the paired delivery), init.py:335-360      */
   const void* wqkv_packed; /* [L] x packed [384,128]                               */
   const float* bqkv;       /* [L,384]                                              */
   const void* wo_packed;   /* [L] x packed [128,128]                               */

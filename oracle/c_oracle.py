@@ -56,6 +56,7 @@ def lib() -> C.CDLL:
     h.oracle_cvrp_step.argtypes = [vp] * 8 + [i, i, i]
     h.oracle_op_step.argtypes = [vp] * 9 + [i, i, i]
     h.oracle_pctsp_step.argtypes = [vp] * 8 + [i, i, i]
+    h.oracle_pdp_step.argtypes = [vp] * 7 + [i, i]
     h.oracle_op_max_length.argtypes = [vp, vp, i, i, vp]
     h.oracle_gather_sum_f32.argtypes = [vp, vp, i, i, i, i, vp]
     h.oracle_am_decode.argtypes = [C.POINTER(AmDecodeArgs), i]
@@ -121,6 +122,14 @@ def op_step(action, locs, max_length, tour_length, visited, cur, step_i, mask, d
     assert st == 0, "oracle_op_step: action out of range"
 
 
+def pdp_step(action, available, to_deliver, cur, step_i, mask, done) -> None:
+    b, n = mask.shape
+    st = lib().oracle_pdp_step(_p(None if action is None else _cpu(action, torch.int64)), _p(_u8(available)),
+                               _p(_u8(to_deliver)), _p(_cpu(cur, torch.int64)), _p(_cpu(step_i, torch.int64)),
+                               _p(_u8(mask)), _p(_u8(done)), b, n)
+    assert st == 0, "oracle_pdp_step: action out of range"
+
+
 def pctsp_step(action, real_prize, cur_total_prize, visited, cur, step_i, mask, done) -> None:
     b, n = mask.shape
     st = lib().oracle_pctsp_step(_p(None if action is None else _cpu(action, torch.int64)), _p(_cpu(real_prize, torch.float32)),
@@ -158,7 +167,7 @@ def am_decode(cache, state: dict, *, mode: str, max_steps: int, actions: Tensor,
     a = _lib.AmDecodeArgs()
     mask = _u8(state["action_mask"])
     b, n = mask.shape
-    a.env = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP, "op": _lib.ENV_OP, "pctsp": _lib.ENV_PCTSP}[cache.env_name]
+    a.env = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP, "op": _lib.ENV_OP, "pctsp": _lib.ENV_PCTSP, "pdp": _lib.ENV_PDP}[cache.env_name]
     a.B, a.B_inst, a.N = b, cache.num_instances, n
     a.mode = {"greedy": 0, "sampling": 1, "evaluate": 2}[mode]
     a.max_steps = int(max_steps)
@@ -177,6 +186,10 @@ def am_decode(cache, state: dict, *, mode: str, max_steps: int, actions: Tensor,
         a.ctx_first = _p(_cpu(cache.ctx_first, torch.float32))
         a.q_step0 = _p(_cpu(cache.q_step0, torch.float32))
         a.first_node = _p(_cpu(state["first_node"], torch.int64))
+        a.step_i = _p(_cpu(state["i"], torch.int64))
+    elif cache.env_name == "pdp":
+        a.visited = _p(_u8(state["available"]))
+        a.to_deliver = _p(_u8(state["to_deliver"]))
         a.step_i = _p(_cpu(state["i"], torch.int64))
     elif cache.env_name == "pctsp":
         a.w_cap = _p(_cpu(cache.w_cap, torch.float32))

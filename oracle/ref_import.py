@@ -39,6 +39,7 @@ _SHELL_PACKAGES = [
     "rl4co.envs.routing.cvrp",
     "rl4co.envs.routing.op",
     "rl4co.envs.routing.pctsp",
+    "rl4co.envs.routing.pdp",
     "rl4co.models",
     "rl4co.models.nn",
     "rl4co.models.nn.graph",
@@ -56,6 +57,7 @@ _LAZY = {
         "CVRPEnv": "rl4co.envs.routing.cvrp.env",
         "OPEnv": "rl4co.envs.routing.op.env",
         "PCTSPEnv": "rl4co.envs.routing.pctsp.env",
+        "PDPEnv": "rl4co.envs.routing.pdp.env",
     },
     "rl4co.models.zoo.am": {"AttentionModelPolicy": "rl4co.models.zoo.am.policy"},
 }
@@ -78,7 +80,7 @@ class _Shell(types.ModuleType):
 def _get_env(env_name: str, *args, **kwargs):
     """rl4co/envs/__init__.py:65-84 restricted to the environments on the path."""
     envs = sys.modules["rl4co.envs"]
-    registry = {"tsp": "TSPEnv", "cvrp": "CVRPEnv", "op": "OPEnv", "pctsp": "PCTSPEnv"}
+    registry = {"tsp": "TSPEnv", "cvrp": "CVRPEnv", "op": "OPEnv", "pctsp": "PCTSPEnv", "pdp": "PDPEnv"}
     if env_name not in registry:
         raise ValueError(f"Unknown environment {env_name}. Available (oracle shell): {list(registry)}")
     return getattr(envs, registry[env_name])(*args, **kwargs)
@@ -114,7 +116,7 @@ def install() -> None:
         if "." in pkg:
             parent, _, child = pkg.rpartition(".")
             setattr(sys.modules[parent], child, mod)
-    for env in ("tsp", "cvrp", "op", "pctsp"):  # matplotlib renderers: not on the path, not installed
+    for env in ("tsp", "cvrp", "op", "pctsp", "pdp"):  # matplotlib renderers: not on the path, not installed
         stub = types.ModuleType(f"rl4co.envs.routing.{env}.render")
         stub.render = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError("render is out of scope"))
         stub.render_improvement = stub.render
@@ -132,6 +134,7 @@ def load():
     ns.CVRPEnv = importlib.import_module("rl4co.envs.routing.cvrp.env").CVRPEnv
     ns.OPEnv = importlib.import_module("rl4co.envs.routing.op.env").OPEnv
     ns.PCTSPEnv = importlib.import_module("rl4co.envs.routing.pctsp.env").PCTSPEnv
+    ns.PDPEnv = importlib.import_module("rl4co.envs.routing.pdp.env").PDPEnv
     ns.TSPGenerator = importlib.import_module("rl4co.envs.routing.tsp.generator").TSPGenerator
     ns.CVRPGenerator = importlib.import_module("rl4co.envs.routing.cvrp.generator").CVRPGenerator
     ns.AttentionModelPolicy = importlib.import_module("rl4co.models.zoo.am.policy").AttentionModelPolicy

@@ -116,6 +116,8 @@ def select_start_nodes(td: dict, env, num_starts: int) -> Tensor:
     device = td["action_mask"].device
     if env.name in ["tsp", "atsp", "flp", "mcp"]:
         return torch.arange(num_starts, device=device).repeat_interleave(batch) % num_loc
+    if env.name == "pdp":  # pdp/env.py:216-225: only the pickups can start a tour
+        return torch.arange(num_starts, device=device).repeat_interleave(batch) % (num_loc // 2) + 1
     return torch.arange(num_starts, device=device).repeat_interleave(batch) % num_loc + 1
 
 
@@ -553,8 +555,102 @@ class PCTSPEnv:
         return select_start_nodes(td, self, num_starts)
 
 
+class PDPEnv:
+    """envs/routing/pdp/env.py:17-225 (pickup and delivery: node j in 1..n/2 is picked up before j + n/2 is delivered)"""
+
+    name = "pdp"
+
+    def __init__(self, num_loc: int = 20, check_solution: bool = True, force_start_at_depot: bool = False):
+        self.num_loc = num_loc + (num_loc % 2)  # pdp/generator.py:48-51: the number of locations must be even
+        self.check_solution = check_solution
+        self.force_start_at_depot = force_start_at_depot
+
+    def generate(self, batch_size: int) -> dict:
+        """pdp/generator.py:71-88 (depot sampled with the locations)"""
+        locs = torch.distributions.Uniform(low=0.0, high=1.0).sample((batch_size, self.num_loc + 1, 2))
+        return {"locs": locs[..., 1:, :], "depot": locs[..., 0, :]}
+
+    def reset(self, td: dict | None = None, batch_size: int | None = None) -> dict:
+        """pdp/env.py:101-150"""
+        if td is None:
+            td = self.generate(batch_size)
+        b = td["locs"].shape[0]
+        device = td["locs"].device
+        n = self.num_loc
+        locs = torch.cat((td["depot"][:, None, :], td["locs"]), -2)
+        to_deliver = torch.cat([torch.ones(b, n // 2 + 1, dtype=torch.bool, device=device),
+                                torch.zeros(b, n // 2, dtype=torch.bool, device=device)], dim=-1)
+        available = torch.ones((b, n + 1), dtype=torch.bool, device=device)
+        action_mask = torch.ones_like(available)
+        if self.force_start_at_depot:
+            action_mask[..., 1:] = False
+        else:
+            action_mask = action_mask & to_deliver
+            available[..., 0] = False
+            action_mask[..., 0] = False
+        return {
+            "locs": locs,
+            "current_node": torch.zeros((b, 1), dtype=torch.int64, device=device),
+            "to_deliver": to_deliver,
+            "available": available,
+            "i": torch.zeros((b, 1), dtype=torch.int64, device=device),
+            "action_mask": action_mask,
+            "done": torch.zeros((b,), dtype=torch.bool, device=device),
+        }
+
+    @staticmethod
+    def step(td: dict) -> dict:
+        """pdp/env.py:64-99"""
+        current_node = td["action"].unsqueeze(-1)
+        num_loc = td["locs"].shape[-2] - 1
+        new_to_deliver = (current_node + num_loc // 2) % (num_loc + 1)
+        available = td["available"].scatter(-1, current_node.expand_as(td["action_mask"]), 0)
+        to_deliver = td["to_deliver"].scatter(-1, new_to_deliver.expand_as(td["to_deliver"]), 1)
+        action_mask = available & to_deliver
+        done = torch.count_nonzero(available, dim=-1) == 0
+        td.update(
+            {
+                "current_node": current_node,
+                "available": available,
+                "to_deliver": to_deliver,
+                "i": td["i"] + 1,
+                "action_mask": action_mask,
+                "reward": torch.zeros_like(done),
+                "done": done,
+            }
+        )
+        return td
+
+    def get_reward(self, td: dict, actions: Tensor, check_solution: bool | None = None) -> Tensor:
+        """base.py:180-190 -> pdp/env.py:191-202"""
+        check_solution = self.check_solution if check_solution is None else check_solution
+        if check_solution:
+            self.check_solution_validity(td, actions)
+        locs_ordered = torch.cat([td["locs"][..., 0:1, :], gather_by_index(td["locs"], actions)], dim=1)
+        return -get_tour_length(locs_ordered)
+
+    def check_solution_validity(self, td: dict, actions: Tensor) -> None:
+        """pdp/env.py:204-223"""
+        if not self.force_start_at_depot:
+            actions = torch.cat((torch.zeros_like(actions[:, 0:1]), actions), dim=-1)
+        assert (
+            torch.arange(actions.size(1), device=actions.device).view(1, -1).expand_as(actions) == actions.sort(1)[0]
+        ).all(), "Not visiting all nodes"
+        assert (actions[:, 1:-1] != 0).all(), "Going back to depot in the middle of the tour (not allowed)"
+        visited_time = torch.argsort(actions, 1)
+        assert (
+            visited_time[:, 1 : actions.size(1) // 2 + 1] < visited_time[:, actions.size(1) // 2 + 1 :]
+        ).all(), "Deliverying without pick-up"
+
+    def get_num_starts(self, td):
+        return (td["locs"].shape[-2] - 1) // 2
+
+    def select_start_nodes(self, td, num_starts):
+        return select_start_nodes(td, self, num_starts)
+
+
 def get_env(name: str, num_loc: int, **kw):
-    return {"tsp": TSPEnv, "cvrp": CVRPEnv, "op": OPEnv, "pctsp": PCTSPEnv}[name](num_loc=num_loc, **kw)
+    return {"tsp": TSPEnv, "cvrp": CVRPEnv, "op": OPEnv, "pctsp": PCTSPEnv, "pdp": PDPEnv}[name](num_loc=num_loc, **kw)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -789,6 +885,37 @@ class PCTSPInitEmbedding(nn.Module):
         return torch.cat((depot_embedding, node_embeddings), -2)
 
 
+class PDPInitEmbedding(nn.Module):
+    """env_embeddings/init.py:335-360: depot (x, y); pickup (x, y, x', y' of its delivery); delivery (x, y)"""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.init_embed_depot = nn.Linear(2, embed_dim, True)
+        self.init_embed_pick = nn.Linear(4, embed_dim, True)
+        self.init_embed_delivery = nn.Linear(2, embed_dim, True)
+
+    def forward(self, td):
+        depot, locs = td["locs"][..., 0:1, :], td["locs"][..., 1:, :]
+        num_locs = locs.size(-2)
+        pick_feats = torch.cat([locs[:, : num_locs // 2, :], locs[:, num_locs // 2 :, :]], -1)
+        delivery_feats = locs[:, num_locs // 2 :, :]
+        return torch.cat([self.init_embed_depot(depot), self.init_embed_pick(pick_feats),
+                          self.init_embed_delivery(delivery_feats)], -2)
+
+
+class PDPContext(nn.Module):
+    """env_embeddings/context.py:50-65,232-243: the current node embedding alone"""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.project_context = nn.Linear(embed_dim, embed_dim, bias=False)
+
+    def forward(self, embeddings, td):
+        cur_node_embedding = gather_by_index(embeddings, td["current_node"]).squeeze()
+        return self.project_context(cur_node_embedding)
+
+
 class TSPContext(nn.Module):
     """env_embeddings/context.py:50-60,105-134"""
 
@@ -888,7 +1015,8 @@ class AttentionModelEncoder(nn.Module):
                  normalization="batch", feedforward_hidden=512, sdpa_fn=None):
         super().__init__()
         self.env_name = env_name
-        self.init_embedding = {"tsp": TSPInitEmbedding, "cvrp": VRPInitEmbedding, "op": OPInitEmbedding, "pctsp": PCTSPInitEmbedding}[env_name](embed_dim)
+        self.init_embedding = {"tsp": TSPInitEmbedding, "cvrp": VRPInitEmbedding, "op": OPInitEmbedding, "pctsp": PCTSPInitEmbedding,
+                               "pdp": PDPInitEmbedding}[env_name](embed_dim)
         self.net = GraphAttentionNetwork(
             num_heads, embed_dim, num_layers, normalization, feedforward_hidden, sdpa_fn=sdpa_fn
         )
@@ -909,7 +1037,8 @@ class AttentionModelDecoder(nn.Module):
         self.env_name = env_name
         self.embed_dim = embed_dim
         self.num_heads = num_heads
-        self.context_embedding = {"tsp": TSPContext, "cvrp": VRPContext, "op": OPContext, "pctsp": PCTSPContext}[env_name](embed_dim)
+        self.context_embedding = {"tsp": TSPContext, "cvrp": VRPContext, "op": OPContext, "pctsp": PCTSPContext,
+                                  "pdp": PDPContext}[env_name](embed_dim)
         self.dynamic_embedding = StaticEmbedding()
         self.is_dynamic_embedding = False
         self.pointer = PointerAttention(

@@ -268,6 +268,36 @@ int oracle_pctsp_step(const int64_t* action, const float* real_prize, float* pri
   return 0;
 }
 
+/* ---- pickup and delivery (envs/routing/pdp/env.py:64-99) ---------------------------------------- */
+static void pdp_transition(int a, uint8_t* avail, uint8_t* tod, uint8_t* mk, int N) {
+  const int n = N - 1;
+  avail[a] = 0;
+  tod[(a + n / 2) % (n + 1)] = 1;
+  for (int j = 0; j < N; ++j) mk[j] = (avail[j] && tod[j]) ? 1 : 0;
+}
+
+int oracle_pdp_step(const int64_t* action, uint8_t* available, uint8_t* to_deliver, int64_t* cur, int64_t* step_i,
+                    uint8_t* mask, uint8_t* done, int B, int N) {
+  for (int b = 0; b < B; ++b) {
+    uint8_t* av = available + (int64_t)b * N;
+    uint8_t* td = to_deliver + (int64_t)b * N;
+    uint8_t* mk = mask + (int64_t)b * N;
+    if (action) {
+      const int64_t a = action[b];
+      if (a < 0 || a >= N) return 1;
+      pdp_transition((int)a, av, td, mk, N);
+      int left = 0;
+      for (int j = 0; j < N; ++j) left |= av[j];
+      done[b] = left ? 0 : 1;
+      step_i[b] += 1;
+      cur[b] = a;
+    } else {
+      for (int j = 0; j < N; ++j) mk[j] = (av[j] && td[j]) ? 1 : 0;
+    }
+  }
+  return 0;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* AttentionModel decode loop in the specified operation order                                  */
 /* ------------------------------------------------------------------------------------------ */
@@ -294,6 +324,7 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
   float* lg = (float*)malloc(sizeof(float) * (size_t)N);
   uint8_t* mk = (uint8_t*)malloc((size_t)N);
   uint8_t* vis = (uint8_t*)malloc((size_t)N);
+  uint8_t* tod = (uint8_t*)malloc((size_t)N); /* PDP: to_deliver (vis holds `available`) */
   float* og = (float*)malloc(sizeof(float) * (size_t)G * D);
   float* lgp = (float*)malloc(sizeof(float) * (size_t)G * H);
   int* fl = (int*)malloc(sizeof(int) * (size_t)N);
@@ -310,12 +341,14 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
     uint8_t* gmask = a->action_mask + (int64_t)r * N;
     memcpy(mk, gmask, (size_t)N);
     if (a->env != RL4CO_ENV_TSP) memcpy(vis, a->visited + (int64_t)r * N, (size_t)N);
+    if (a->env == RL4CO_ENV_PDP) memcpy(tod, a->to_deliver + (int64_t)r * N, (size_t)N);
+    const int scalar_ctx = a->env == RL4CO_ENV_CVRP || a->env == RL4CO_ENV_OP || a->env == RL4CO_ENV_PCTSP;
     int cur = (int)a->current_node[r];
     int first = a->env == RL4CO_ENV_TSP ? (int)a->first_node[r] : 0;
     long long step_i = a->env != RL4CO_ENV_CVRP ? a->step_i[r] : 0;
     /* OP: `used` is the tour length so far and `cap` the longest tour that may still reach the depot
      * directly, max_length[.., 0]; the context scalar is cap - used in both environments */
-    float used = a->env != RL4CO_ENV_TSP ? a->used_capacity[r] : 0.0f;
+    float used = scalar_ctx ? a->used_capacity[r] : 0.0f;
     const float* oplocs = a->env == RL4CO_ENV_OP ? a->locs + (int64_t)cb * N * 2 : NULL;
     const float* opmax = a->env == RL4CO_ENV_OP ? a->max_length + (int64_t)cb * N : NULL;
     const float cap = (a->env == RL4CO_ENV_CVRP || a->env == RL4CO_ENV_PCTSP) ? a->vehicle_capacity[r]
@@ -336,6 +369,8 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
         if (a->env == RL4CO_ENV_TSP) {
           if (step_i < 1) v = a->q_step0[d] + qb;
           else v = (ctxf[(int64_t)first * D + d] + ctxc[(int64_t)cur * D + d]) + qb;
+        } else if (a->env == RL4CO_ENV_PDP) {
+          v = ctxc[(int64_t)cur * D + d] + qb; /* context.py:232-243: the current node alone */
         } else {
           float rem = cap - used;
           if (a->env == RL4CO_ENV_PCTSP && !(rem > 0.0f)) rem = 0.0f; /* clamp(min=0), context.py:195 */
@@ -483,6 +518,13 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
         int any = 0;
         for (int j = 0; j < N; ++j) any |= mk[j];
         done = !any;
+      } else if (a->env == RL4CO_ENV_PDP) {
+        pdp_transition(bi, vis, tod, mk, N);    /* pdp/env.py:64-80 */
+        int left = 0;
+        for (int j = 0; j < N; ++j) left |= vis[j];
+        done = !left;                           /* pdp/env.py:83 */
+        step_i += 1;
+        cur = bi;
       } else if (a->env == RL4CO_ENV_PCTSP) {
         used = used + rprize[bi];               /* pctsp/env.py:66 */
         vis[bi] = 1;
@@ -513,11 +555,12 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
     if (!single && !done && t >= a->max_steps) errbits |= RL4CO_EBIT_MAX_STEPS;
     memcpy(gmask, mk, (size_t)N);
     if (a->env != RL4CO_ENV_TSP) memcpy(a->visited + (int64_t)r * N, vis, (size_t)N);
+    if (a->env == RL4CO_ENV_PDP) memcpy(a->to_deliver + (int64_t)r * N, tod, (size_t)N);
     a->current_node[r] = cur;
     a->done[r] = done ? 1 : 0;
     if (a->env == RL4CO_ENV_TSP) a->first_node[r] = first;
     if (a->env != RL4CO_ENV_CVRP) a->step_i[r] = step_i;
-    if (a->env != RL4CO_ENV_TSP) a->used_capacity[r] = used;
+    if (scalar_ctx) a->used_capacity[r] = used;
     if (a->n_steps) a->n_steps[r] = t;
     if (a->steps_summary) {
       if (t > a->steps_summary[0]) a->steps_summary[0] = t;
@@ -527,7 +570,7 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
     errbits_all |= errbits;
   }
   if (a->err) *a->err |= (int32_t)errbits_all;
-  free(sc); free(lg); free(mk); free(vis); free(og); free(lgp); free(fl);
+  free(sc); free(lg); free(mk); free(vis); free(tod); free(og); free(lgp); free(fl);
   return 0;
 }
 

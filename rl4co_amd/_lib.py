@@ -11,7 +11,7 @@ from functools import lru_cache
 from . import build as _build
 
 RL4CO_OK = 0
-ENV_TSP, ENV_CVRP, ENV_OP, ENV_PCTSP = 0, 1, 2, 3
+ENV_TSP, ENV_CVRP, ENV_OP, ENV_PCTSP, ENV_PDP = 0, 1, 2, 3, 4
 DECODE_GREEDY, DECODE_SAMPLE, DECODE_EVALUATE = 0, 1, 2
 DT_F32, DT_BF16 = 0, 1
 VARIANT_AUTO, VARIANT_STREAM, VARIANT_LDS, VARIANT_WIDE, VARIANT_MS = 0, 1, 2, 3, 4
@@ -25,6 +25,9 @@ EBIT_NEG_INF_LOGP = 32
 EBIT_DUPLICATES = 64
 EBIT_MAX_LENGTH = 128
 EBIT_PRIZE = 256
+EBIT_NOT_ALL_NODES = 512
+EBIT_DEPOT_MIDDLE = 1024
+EBIT_NO_PICKUP = 2048
 
 # Reference assertion messages (file:line in the reference checkout) per sticky bit.
 ERROR_MESSAGES = {
@@ -37,6 +40,9 @@ ERROR_MESSAGES = {
     EBIT_DUPLICATES: "Duplicates",  # op/env.py:181
     EBIT_MAX_LENGTH: "Max length exceeded",  # op/env.py:192-194
     EBIT_PRIZE: "Total prize does not satisfy min total prize",  # pctsp/env.py:192-201
+    EBIT_NOT_ALL_NODES: "Not visiting all nodes",  # pdp/env.py:208-213
+    EBIT_DEPOT_MIDDLE: "Going back to depot in the middle of the tour (not allowed)",  # pdp/env.py:216-218
+    EBIT_NO_PICKUP: "Deliverying without pick-up",  # pdp/env.py:220-223
 }
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -56,7 +62,7 @@ class AmDecodeArgs(C.Structure):
         ("action_mask", _vp), ("first_node", _vp), ("current_node", _vp), ("step_i", _vp),
         ("done", _vp),
         ("demand", _vp), ("used_capacity", _vp), ("vehicle_capacity", _vp), ("visited", _vp),
-        ("locs", _vp), ("max_length", _vp),
+        ("locs", _vp), ("max_length", _vp), ("to_deliver", _vp),
         ("exp_noise", _vp), ("philox_seed", C.c_uint64), ("philox_offset", C.c_uint64),
         ("forced_actions", _vp),
         ("t0", _i32), ("out_stride", _i32),
@@ -81,6 +87,8 @@ SYMBOLS = {
     "rl4co_op_check_solution": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_pctsp_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_pctsp_check_solution": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_pdp_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_pdp_check_solution": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_am_decode": (C.c_int, [C.POINTER(AmDecodeArgs), _vp]),
     "rl4co_am_teacher_backward": (C.c_int, [_vp, _vp]),
     "rl4co_am_teacher_max_nodes": (C.c_int, []),

@@ -221,6 +221,23 @@ __device__ inline int finalize_and_step(const rl4co_am_decode_args& a, TrajState
     bool any_left = false;
     for (int j = lane; j < N; j += 64) any_left |= mk[j] != 0;
     st.done = !__any(any_left);  // tsp/env.py:71
+  } else if (ENV == RL4CO_ENV_PDP) {
+    // pickup and delivery (pdp/env.py:64-99); vis[j]: bit 0 = available, bit 1 = to_deliver
+    const int n = N - 1;
+    if (lane == 0) {
+      vis[bi] &= (uint8_t)~1u;
+      vis[(bi + n / 2) % (n + 1)] |= 2;
+    }
+    st.step_i += 1;
+    st.cur = bi;
+    wave_lds_sync();
+    bool left = false;
+    for (int j = lane; j < N; j += 64) {
+      const uint8_t v = vis[j];
+      mk[j] = (v == 3) ? 1 : 0;
+      left |= (v & 1) != 0;
+    }
+    st.done = !__any(left);  // pdp/env.py:83
   } else if (ENV == RL4CO_ENV_PCTSP) {
     // prize-collecting TSP (pctsp/env.py:62-91,141-148); st.used is the prize collected so far,
     // dem the real prize per node (depot column 0)
@@ -326,7 +343,12 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
   // ---- load the trajectory state ---------------------------------------------------
   uint8_t* gmask = a.action_mask + (int64_t)r * N;
   for (int j = lane; j < Np; j += 64) mk[j] = (j < N) ? gmask[j] : (uint8_t)0;
-  if (ENV != RL4CO_ENV_TSP) {
+  constexpr bool kScalarCtx = ENV == RL4CO_ENV_CVRP || ENV == RL4CO_ENV_OP || ENV == RL4CO_ENV_PCTSP;
+  if (ENV == RL4CO_ENV_PDP) {  // bit 0 = available, bit 1 = to_deliver
+    const uint8_t* gv = a.visited + (int64_t)r * N;
+    const uint8_t* gt = a.to_deliver + (int64_t)r * N;
+    for (int j = lane; j < Np; j += 64) vis[j] = (j < N) ? (uint8_t)((gv[j] != 0 ? 1 : 0) | (gt[j] != 0 ? 2 : 0)) : (uint8_t)0;
+  } else if (ENV != RL4CO_ENV_TSP) {
     const uint8_t* gv = a.visited + (int64_t)r * N;
     for (int j = lane; j < Np; j += 64) vis[j] = (j < N) ? gv[j] : (uint8_t)1;
   }
@@ -334,7 +356,7 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
   st.cur = (int)a.current_node[r];
   st.first = (ENV == RL4CO_ENV_TSP) ? (int)a.first_node[r] : 0;
   st.step_i = (ENV != RL4CO_ENV_CVRP) ? a.step_i[r] : 0;
-  st.used = (ENV != RL4CO_ENV_TSP) ? a.used_capacity[r] : 0.0f;  // OP: tour length so far
+  st.used = kScalarCtx ? a.used_capacity[r] : 0.0f;  // OP: tour length so far
   st.done = a.done[r] != 0;
   st.errbits = 0;
   st.ent_acc = 0.0f;
@@ -371,6 +393,9 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
         for (int e = 0; e < EPL; ++e)
           q[e] = (ctxf[(int64_t)st.first * kD + e] + ctxc[(int64_t)st.cur * kD + e]) + qb[e];
       }
+    } else if (ENV == RL4CO_ENV_PDP) {  // context.py:232-243: the current node alone
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) q[e] = ctxc[(int64_t)st.cur * kD + e] + qb[e];
     } else {
       float rem = cap - st.used;  // context.py:147-149
       if (ENV == RL4CO_ENV_PCTSP && !(rem > 0.0f)) rem = 0.0f;
@@ -476,7 +501,14 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
 
   // ---- write the state back ------------------------------------------------------------
   for (int j = lane; j < N; j += 64) gmask[j] = mk[j];
-  if (ENV != RL4CO_ENV_TSP) {
+  if (ENV == RL4CO_ENV_PDP) {
+    uint8_t* gv = a.visited + (int64_t)r * N;
+    uint8_t* gt = a.to_deliver + (int64_t)r * N;
+    for (int j = lane; j < N; j += 64) {
+      gv[j] = vis[j] & 1;
+      gt[j] = (vis[j] >> 1) & 1;
+    }
+  } else if (ENV != RL4CO_ENV_TSP) {
     uint8_t* gv = a.visited + (int64_t)r * N;
     for (int j = lane; j < N; j += 64) gv[j] = vis[j];
   }
@@ -485,7 +517,7 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
     a.done[r] = st.done ? 1 : 0;
     if (ENV == RL4CO_ENV_TSP) a.first_node[r] = st.first;
     if (ENV != RL4CO_ENV_CVRP) a.step_i[r] = st.step_i;
-    if (ENV != RL4CO_ENV_TSP) a.used_capacity[r] = st.used;
+    if (kScalarCtx) a.used_capacity[r] = st.used;
     if (a.n_steps) a.n_steps[r] = t;
     if (a.steps_summary) {
       atomicMax(a.steps_summary, t);
@@ -803,7 +835,7 @@ int launch_wide(const rl4co_am_decode_args& a, hipStream_t stream) {
 // Which kernel serves these arguments (rules from measurements on MI355X, see the kernel headers).
 inline int resolve_variant(const rl4co_am_decode_args& a) {
   // the orienteering transition (distance-based mask) exists in the streaming kernel only
-  if (a.env == RL4CO_ENV_OP || a.env == RL4CO_ENV_PCTSP) return (a.variant == RL4CO_VARIANT_AUTO || a.variant == RL4CO_VARIANT_STREAM) ? RL4CO_VARIANT_STREAM : -1;
+  if (a.env == RL4CO_ENV_OP || a.env == RL4CO_ENV_PCTSP || a.env == RL4CO_ENV_PDP) return (a.variant == RL4CO_VARIANT_AUTO || a.variant == RL4CO_VARIANT_STREAM) ? RL4CO_VARIANT_STREAM : -1;
   const bool bf16 = a.cache_dtype == RL4CO_DT_BF16;
   // multistart on the matrix cores (am_decode_ms.hip): bf16 planes, N <= 128, plain outputs
   const bool ms_ok = bf16 && a.N <= 128 && a.B_inst > 0 && a.all_logps == nullptr && a.entropy == nullptr;
@@ -859,7 +891,7 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
   RL4CO_REQUIRE(args != nullptr);
   const rl4co_am_decode_args& a = *args;
   RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP || a.env == RL4CO_ENV_OP ||
-                a.env == RL4CO_ENV_PCTSP);
+                a.env == RL4CO_ENV_PCTSP || a.env == RL4CO_ENV_PDP);
   RL4CO_REQUIRE(a.B > 0 && a.B_inst > 0 && a.B % a.B_inst == 0);
   RL4CO_REQUIRE(a.N >= 2 && a.N <= 4096);
   RL4CO_REQUIRE(a.max_steps >= 1);
@@ -876,6 +908,8 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
     RL4CO_REQUIRE(a.ctx_first && a.q_step0 && a.first_node && a.step_i);
   } else if (a.env == RL4CO_ENV_CVRP) {
     RL4CO_REQUIRE(a.w_cap && a.demand && a.used_capacity && a.vehicle_capacity && a.visited);
+  } else if (a.env == RL4CO_ENV_PDP) {
+    RL4CO_REQUIRE(a.visited && a.to_deliver && a.step_i && (a.N - 1) % 2 == 0);
   } else if (a.env == RL4CO_ENV_PCTSP) {
     RL4CO_REQUIRE(a.w_cap && a.demand && a.used_capacity && a.vehicle_capacity && a.step_i && a.visited);
   } else {
@@ -894,6 +928,8 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
     return a.env == RL4CO_ENV_TSP ? launch_wide<RL4CO_ENV_TSP, false>(a, s)
                                   : launch_wide<RL4CO_ENV_CVRP, false>(a, s);
   }
+  if (a.env == RL4CO_ENV_PDP)
+    return a.cache_dtype == RL4CO_DT_F32 ? launch<CacheF32, RL4CO_ENV_PDP>(a, s) : launch<CacheBF16, RL4CO_ENV_PDP>(a, s);
   if (a.env == RL4CO_ENV_PCTSP)
     return a.cache_dtype == RL4CO_DT_F32 ? launch<CacheF32, RL4CO_ENV_PCTSP>(a, s)
                                          : launch<CacheBF16, RL4CO_ENV_PCTSP>(a, s);

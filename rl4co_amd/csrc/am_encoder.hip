@@ -210,7 +210,10 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
   {
     float* lsh = reinterpret_cast<float*>(ys);  // [2 N] coordinates, then [N] demands (ys is free here)
     const float* loc = a.locs + (int64_t)b * N * 2;
+    const bool pdp = a.env == RL4CO_ENV_PDP;  // depot | pickups (x, y, x', y' of the delivery) | deliveries, init.py:335-360
     const bool cvrp = a.env == RL4CO_ENV_CVRP;
+    const bool depot = cvrp || pdp;
+    const int half = (N - 1) / 2;
     for (int i = tid; i < 2 * N; i += kThreads) lsh[i] = loc[i];
     const bool four = cvrp && a.feature4 != nullptr;  // PCTSP: (x, y, expected prize, penalty), init.py:283-312
     if (cvrp)
@@ -218,17 +221,21 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
     if (four)
       for (int i = tid; i < N - 1; i += kThreads) lsh[3 * N + 1 + i] = a.feature4[(int64_t)b * (N - 1) + i];
     const int d = tid & 127;
-    const int ws = four ? 4 : (cvrp ? 3 : 2);  // row stride of w_init
+    const int ws = (four || pdp) ? 4 : (cvrp ? 3 : 2);  // row stride of w_init
     const float wx = a.w_init[ws * d], wy = a.w_init[ws * d + 1];
-    const float wd = cvrp ? a.w_init[ws * d + 2] : 0.0f, bi = a.b_init[d];
-    const float wp = four ? a.w_init[ws * d + 3] : 0.0f;
-    const float dx = cvrp ? a.w_depot[2 * d] : 0.0f, dy = cvrp ? a.w_depot[2 * d + 1] : 0.0f, db = cvrp ? a.b_depot[d] : 0.0f;
+    const float wd = depot ? a.w_init[ws * d + 2] : 0.0f, bi = a.b_init[d];
+    const float wp = (four || pdp) ? a.w_init[ws * d + 3] : 0.0f;
+    const float dx = depot ? a.w_depot[2 * d] : 0.0f, dy = depot ? a.w_depot[2 * d + 1] : 0.0f, db = depot ? a.b_depot[d] : 0.0f;
+    const float ex = pdp ? a.w_extra[2 * d] : 0.0f, ey = pdp ? a.w_extra[2 * d + 1] : 0.0f, eb = pdp ? a.b_extra[d] : 0.0f;
     __syncthreads();
     for (int tok = tid >> 7; tok < 32 * TT; tok += kThreads / 128) {
       float v = 0.0f;
       if (tok < N) {
         const float x = lsh[2 * tok], y = lsh[2 * tok + 1];
-        if (cvrp && tok == 0) v = fmaf(dy, y, fmaf(dx, x, db));
+        if (depot && tok == 0) v = fmaf(dy, y, fmaf(dx, x, db));
+        else if (pdp && tok <= half)
+          v = fmaf(wp, lsh[2 * (tok + half) + 1], fmaf(wd, lsh[2 * (tok + half)], fmaf(wy, y, fmaf(wx, x, bi))));
+        else if (pdp) v = fmaf(ey, y, fmaf(ex, x, eb));
         else if (four) v = fmaf(wp, lsh[3 * N + tok], fmaf(wd, lsh[2 * N + tok], fmaf(wy, y, fmaf(wx, x, bi))));
         else if (cvrp) v = fmaf(wd, lsh[2 * N + tok], fmaf(wy, y, fmaf(wx, x, bi)));
         else v = fmaf(wy, y, fmaf(wx, x, bi));
@@ -488,15 +495,16 @@ extern "C" int rl4co_am_encoder_max_nodes(void) { return 128; }
 extern "C" int rl4co_am_encoder(const rl4co_am_encoder_args* args, void* stream) {
   RL4CO_REQUIRE(args != nullptr);
   const rl4co_am_encoder_args& a = *args;
-  RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP);
+  RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP || a.env == RL4CO_ENV_PDP);
   RL4CO_REQUIRE(a.B > 0 && a.N >= 2 && a.N <= 128);
   RL4CO_REQUIRE(a.num_layers >= 1 && (a.norm == 0 || a.norm == 1));
   RL4CO_REQUIRE(a.cache_dtype == RL4CO_DT_F32 || a.cache_dtype == RL4CO_DT_BF16);
   RL4CO_REQUIRE(a.locs && a.w_init && a.b_init);
-  RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || (a.demand && a.w_depot && a.b_depot));
+  RL4CO_REQUIRE(a.env != RL4CO_ENV_CVRP || (a.demand && a.w_depot && a.b_depot));
+  RL4CO_REQUIRE(a.env != RL4CO_ENV_PDP || (a.w_depot && a.b_depot && a.w_extra && a.b_extra && (a.N - 1) % 2 == 0));
   RL4CO_REQUIRE(a.wqkv_packed && a.wo_packed && a.w1_packed && a.w2_packed && a.wfold_packed);
   RL4CO_REQUIRE(a.bqkv && a.bo && a.b1 && a.b2 && a.n1_scale && a.n1_shift && a.n2_scale && a.n2_shift);
-  RL4CO_REQUIRE(a.kvl && a.ctx_cur && (a.env == RL4CO_ENV_CVRP || a.ctx_first));
+  RL4CO_REQUIRE(a.kvl && a.ctx_cur && (a.env != RL4CO_ENV_TSP || a.ctx_first));
   RL4CO_REQUIRE(a.q_bias == nullptr || a.w_fixed != nullptr);
   RL4CO_REQUIRE(a.kvl_batch_stride >= (int64_t)a.N * kD && a.kvl_plane_stride >= a.kvl_batch_stride);
   hipStream_t s = rl4co::as_stream(stream);

@@ -186,7 +186,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     qb4[e] = a.q_bias ? a.q_bias[(int64_t)inst * kD + dcol + e] : 0.0f;
-    qx4[e] = (ENV == RL4CO_ENV_TSP) ? a.q_step0[dcol + e] : a.w_cap[dcol + e];
+    qx4[e] = (ENV == RL4CO_ENV_TSP) ? a.q_step0[dcol + e] : ((ENV == RL4CO_ENV_PDP) ? 0.0f : a.w_cap[dcol + e]);
   }
   const float inv_temp = 1.0f / a.temperature;
   const float clip_over_temp = a.tanh_clipping * inv_temp;
@@ -265,6 +265,9 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
         srem[t] = used;
       }
     }
+    if (ENV == RL4CO_ENV_PDP) {  // no context scalar (context.py:232-243)
+      for (int t = tid; t < kMaxT; t += kThreads) srem[t] = 0.0f;
+    }
     if (ENV == RL4CO_ENV_PCTSP) {
       // prize collected BEFORE column t, accumulated in visiting order like prize += real_prize[a]
       for (int t = tid; t < kMaxT; t += kThreads) {
@@ -299,6 +302,15 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
             if (j == 0 || !(spos[j] < t || depot_visited || exceeds)) word |= 1u << b;
           }
         }
+      } else if (ENV == RL4CO_ENV_PDP) {
+        // pdp/env.py:64-99: unvisited, a delivery only once its pickup is on the tour; the depot only as the
+        // forced first step of force_start_at_depot (recognised by the trajectory starting at node 0)
+        const int half = (N - 1) / 2;
+        for (int b = 0; b < 32; ++b) {
+          const int j = 32 * k + b;
+          if (j >= 1 && j < N && spos[j] >= t && (j <= half || spos[j - half] < t)) word |= 1u << b;
+        }
+        if (t == 0 && sact[0] == 0) word = (k == 0) ? 1u : 0u;
       } else if (ENV == RL4CO_ENV_PCTSP) {
         // pctsp/env.py:141-148: customers while unvisited and the depot not yet closed; the depot opens
         // once a total prize of 1 is collected or no customer is left
@@ -625,7 +637,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
     const float vb = step_sum(dqb[e]), vx = step_sum(dqx[e]);
     if (tl == 0) {
       if (a.d_q_bias) a.d_q_bias[(int64_t)inst * kD + dcol + e] = vb;
-      unsafeAtomicAdd((ENV == RL4CO_ENV_TSP ? a.d_q_step0 : a.d_w_cap) + dcol + e, vx);
+      if (ENV != RL4CO_ENV_PDP) unsafeAtomicAdd((ENV == RL4CO_ENV_TSP ? a.d_q_step0 : a.d_w_cap) + dcol + e, vx);
     }
   }
   if (errbits) atomicOr(a.err, (int)errbits);
@@ -659,6 +671,7 @@ static int dispatch_tiles(const rl4co_am_teacher_args& a, hipStream_t stream) {
 int launch_teacher_mma(const rl4co_am_teacher_args& a, hipStream_t stream) {
   if (a.env == RL4CO_ENV_OP) return dispatch_tiles<RL4CO_ENV_OP>(a, stream);
   if (a.env == RL4CO_ENV_PCTSP) return dispatch_tiles<RL4CO_ENV_PCTSP>(a, stream);
+  if (a.env == RL4CO_ENV_PDP) return dispatch_tiles<RL4CO_ENV_PDP>(a, stream);
   return a.env == RL4CO_ENV_TSP ? dispatch_tiles<RL4CO_ENV_TSP>(a, stream) : dispatch_tiles<RL4CO_ENV_CVRP>(a, stream);
 }
 

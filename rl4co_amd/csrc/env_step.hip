@@ -290,7 +290,99 @@ __global__ void __launch_bounds__(64) pctsp_check_kernel(const int64_t* __restri
   if (short_prize && lane == 0) atomicOr(err, RL4CO_EBIT_PRIZE);
 }
 
+// ---- pickup and delivery (envs/routing/pdp/env.py:64-99) --------------------------------------
+__global__ void __launch_bounds__(64) pdp_step_kernel(const int64_t* __restrict__ action, uint8_t* __restrict__ available,
+                                                      uint8_t* __restrict__ to_deliver, int64_t* __restrict__ cur,
+                                                      int64_t* __restrict__ step_i, uint8_t* __restrict__ mask,
+                                                      uint8_t* __restrict__ done, int N, int32_t* err) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  uint8_t* av = available + (int64_t)b * N;
+  uint8_t* td = to_deliver + (int64_t)b * N;
+  uint8_t* row = mask + (int64_t)b * N;
+  bool bad = false;
+  if (action != nullptr) {
+    int64_t a = action[b];
+    if (a < 0 || a >= N) {
+      bad = true;
+      a = 0;
+    }
+    if (lane == 0) {
+      const int n = N - 1;
+      av[a] = 0;                            // pdp/env.py:73
+      td[((int)a + n / 2) % (n + 1)] = 1;   // pdp/env.py:70,75
+      step_i[b] += 1;
+      cur[b] = a;
+    }
+  }
+  __syncthreads();
+  bool left = false;
+  for (int j = lane; j < N; j += 64) {
+    const bool a_ = av[j] != 0;
+    row[j] = (a_ && td[j] != 0) ? 1 : 0;    // pdp/env.py:79
+    left |= a_;
+  }
+  left = __any(left);
+  if (action != nullptr && lane == 0) done[b] = left ? 0 : 1;  // pdp/env.py:83
+  if (bad && lane == 0 && err) atomicOr(err, RL4CO_EBIT_INFEASIBLE);
+}
+
+// pdp/env.py:204-223. The tour checked is 0 ++ actions unless force_start_at_depot (then actions itself).
+__global__ void __launch_bounds__(64) pdp_check_kernel(const int64_t* __restrict__ actions, int N, int T, int force,
+                                                       int32_t* __restrict__ err) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int64_t* act = actions + (int64_t)b * T;
+  __shared__ int when[1024];  // position of node j in the checked tour, -1 = absent
+  const int off = force ? 0 : 1;
+  const int L = T + off;
+  for (int j = lane; j < N; j += 64) when[j] = -1;
+  __syncthreads();
+  bool dup = L != N, mid = false;
+  if (!force && lane == 0) when[0] = 0;
+  __syncthreads();
+  for (int t = lane; t < T; t += 64) {
+    const int64_t a = act[t];
+    if (a < 0 || a >= N) dup = true;
+    else {
+      if (atomicExch(&when[a], t + off) != -1) dup = true;
+      const int p = t + off;  // position in the checked tour
+      if (a == 0 && p >= 1 && p <= L - 2) mid = true;
+    }
+  }
+  __syncthreads();
+  bool order = false;
+  const int half = (N - 1) / 2;
+  for (int j = 1 + lane; j <= half; j += 64) {
+    if (when[j] < 0 || when[j + half] < 0) dup = true;
+    else if (!(when[j] < when[j + half])) order = true;
+  }
+  if (lane == 0 && when[0] < 0) dup = true;
+  dup = __any(dup);
+  if (dup && lane == 0) atomicOr(err, RL4CO_EBIT_NOT_ALL_NODES);
+  // the reference asserts in sequence: later conditions are only reached when the earlier ones hold
+  if (!dup && __any(mid) && lane == 0) atomicOr(err, RL4CO_EBIT_DEPOT_MIDDLE);
+  if (!dup && __any(order) && lane == 0) atomicOr(err, RL4CO_EBIT_NO_PICKUP);
+}
+
 }  // namespace
+
+extern "C" int rl4co_pdp_step(const int64_t* action, uint8_t* available, uint8_t* to_deliver, int64_t* current_node,
+                              int64_t* step_i, uint8_t* action_mask, uint8_t* done, int B, int N, int32_t* err, void* stream) {
+  RL4CO_REQUIRE(available && to_deliver && current_node && step_i && action_mask && done);
+  RL4CO_REQUIRE(B > 0 && N >= 3 && (N - 1) % 2 == 0);
+  hipLaunchKernelGGL(pdp_step_kernel, dim3(B), dim3(64), 0, rl4co::as_stream(stream), action, available, to_deliver,
+                     current_node, step_i, action_mask, done, N, err);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
+extern "C" int rl4co_pdp_check_solution(const int64_t* actions, int B, int N, int T, int force_start_at_depot, int32_t* err,
+                                        void* stream) {
+  RL4CO_REQUIRE(actions && err && B > 0 && N >= 3 && N <= 1024 && (N - 1) % 2 == 0 && T >= 1);
+  hipLaunchKernelGGL(pdp_check_kernel, dim3(B), dim3(64), 0, rl4co::as_stream(stream), actions, N, T,
+                     force_start_at_depot ? 1 : 0, err);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
 
 extern "C" int rl4co_pctsp_step(const int64_t* action, const float* real_prize, float* cur_total_prize, uint8_t* visited,
                                 int64_t* current_node, int64_t* step_i, uint8_t* action_mask, uint8_t* done, int B,

@@ -24,7 +24,7 @@ class AmEncoderArgs(C.Structure):
 
     _fields_ = [
         ("env", _i32), ("B", _i32), ("N", _i32), ("num_layers", _i32), ("norm", _i32), ("cache_dtype", _i32),
-        ("locs", _vp), ("demand", _vp), ("feature4", _vp), ("w_init", _vp), ("b_init", _vp), ("w_depot", _vp), ("b_depot", _vp),
+        ("locs", _vp), ("demand", _vp), ("feature4", _vp), ("w_init", _vp), ("b_init", _vp), ("w_depot", _vp), ("b_depot", _vp), ("w_extra", _vp), ("b_extra", _vp),
         ("wqkv_packed", _vp), ("bqkv", _vp), ("wo_packed", _vp), ("bo", _vp), ("n1_scale", _vp), ("n1_shift", _vp),
         ("w1_packed", _vp), ("b1", _vp), ("w2_packed", _vp), ("b2", _vp), ("n2_scale", _vp), ("n2_shift", _vp),
         ("wfold_packed", _vp), ("w_fixed", _vp),
@@ -79,8 +79,12 @@ class PackedEncoder:
         f32 = lambda x: x.detach().float().contiguous()  # noqa: E731
         t: dict[str, Tensor] = {}
         ie = enc.init_embedding
-        t["w_init"], t["b_init"] = f32(ie.init_embed.weight), f32(ie.init_embed.bias)
-        if pol.env_name in ("cvrp", "op", "pctsp"):
+        if pol.env_name == "pdp":
+            t["w_init"], t["b_init"] = f32(ie.init_embed_pick.weight), f32(ie.init_embed_pick.bias)
+            t["w_extra"], t["b_extra"] = f32(ie.init_embed_delivery.weight), f32(ie.init_embed_delivery.bias)
+        else:
+            t["w_init"], t["b_init"] = f32(ie.init_embed.weight), f32(ie.init_embed.bias)
+        if pol.env_name != "tsp":
             t["w_depot"], t["b_depot"] = f32(ie.init_embed_depot.weight), f32(ie.init_embed_depot.bias)
         t["wqkv"] = torch.stack([pack_weight(l[0].module.Wqkv.weight) for l in layers]).contiguous()
         t["bqkv"] = torch.stack([f32(l[0].module.Wqkv.bias) for l in layers]).contiguous()
@@ -109,7 +113,7 @@ class PackedEncoder:
             t["w_cap"] = None
         else:
             t["q_step0"] = None
-            t["w_cap"] = w_ctx[:, EMBED_DIM].contiguous()
+            t["w_cap"] = w_ctx[:, EMBED_DIM].contiguous() if w_ctx.shape[1] > EMBED_DIM else None  # PDP: no scalar
         self.num_layers = len(layers)
         self.t, self.version = t, ver
         return t
@@ -139,7 +143,7 @@ class PackedEncoder:
         q_bias = torch.empty((b, d), dtype=torch.float32, device=dev) if t["w_fixed"] is not None else None
         hidden = torch.empty((b, n, d), dtype=torch.float32, device=dev) if want_hidden else None
         a = AmEncoderArgs()
-        a.env = _lib.ENV_TSP if pol.env_name == "tsp" else _lib.ENV_CVRP
+        a.env = {"tsp": _lib.ENV_TSP, "pdp": _lib.ENV_PDP}.get(pol.env_name, _lib.ENV_CVRP)
         a.B, a.N, a.num_layers, a.norm = b, n, self.num_layers, self.norm_kind
         a.cache_dtype = _lib.DT_BF16 if cache_dtype == torch.bfloat16 else _lib.DT_F32
         a.locs = locs.data_ptr()
@@ -154,6 +158,9 @@ class PackedEncoder:
             if pol.env_name == "pctsp":
                 penalty = td["penalty"][..., 1:].float().contiguous()
                 a.feature4 = penalty.data_ptr()
+        if pol.env_name == "pdp":
+            a.w_depot, a.b_depot = ptr(t["w_depot"]), ptr(t["b_depot"])
+            a.w_extra, a.b_extra = ptr(t["w_extra"]), ptr(t["b_extra"])
         a.w_init, a.b_init = ptr(t["w_init"]), ptr(t["b_init"])
         a.wqkv_packed, a.bqkv, a.wo_packed, a.bo = ptr(t["wqkv"]), ptr(t["bqkv"]), ptr(t["wo"]), ptr(t["bo"])
         a.n1_scale, a.n1_shift, a.n2_scale, a.n2_shift = (ptr(t[k]) for k in ("n1_scale", "n1_shift", "n2_scale", "n2_shift"))

@@ -148,6 +148,18 @@ class PCTSPGenerator(TSPGenerator):
                            "deterministic_prize": det, "stochastic_prize": sto}, batch_size=batch_size)
 
 
+class PDPGenerator(TSPGenerator):
+    """pdp/generator.py:30-88: uniform locations, depot sampled with them; an even number of locations
+    (the first half are pickups, node j + n/2 is the delivery of pickup j)"""
+
+    def __init__(self, num_loc: int = 20, min_loc: float = 0.0, max_loc: float = 1.0, device="cpu", **unused):
+        super().__init__(num_loc + (num_loc % 2), min_loc, max_loc, device)  # pdp/generator.py:48-51
+
+    def _generate(self, batch_size) -> TensorDict:
+        locs = self._uniform((*batch_size, self.num_loc + 1, 2), self.min_loc, self.max_loc)
+        return TensorDict({"locs": locs[..., 1:, :], "depot": locs[..., 0, :]}, batch_size=batch_size)
+
+
 class RL4COEnvBase:
     """envs/common/base.py:19-333, rollout-path methods only."""
 
@@ -454,5 +466,81 @@ class PCTSPEnv(RL4COEnvBase):
             K.raise_if_error(err)
 
 
+class PDPEnv(RL4COEnvBase):
+    """Pickup and delivery problem (envs/routing/pdp/env.py:17-225): every pickup before its delivery, one
+    vehicle of unlimited capacity, tour closed through the depot. State in ``rl4co_pdp_*`` (csrc/env_step.hip)."""
+
+    name = "pdp"
+    has_depot = True
+
+    def __init__(self, *, force_start_at_depot: bool = False, **kw):
+        super().__init__(**kw)
+        self.force_start_at_depot = force_start_at_depot
+
+    def _default_generator(self, **kw):
+        return PDPGenerator(**kw)
+
+    def _reset(self, td: TensorDict, batch_size) -> TensorDict:
+        """pdp/env.py:101-150"""
+        device = td["locs"].device
+        b = td["locs"].shape[0]
+        n = td["locs"].shape[-2]
+        assert n % 2 == 0, "PDP needs an even number of locations (pickup / delivery pairs)"
+        to_deliver = torch.zeros((b, n + 1), dtype=torch.bool, device=device)
+        to_deliver[:, : n // 2 + 1] = True  # the depot and the pickups; deliveries open with their pickup
+        available = torch.ones((b, n + 1), dtype=torch.bool, device=device)
+        action_mask = torch.ones((b, n + 1), dtype=torch.bool, device=device)
+        if self.force_start_at_depot:
+            action_mask[:, 1:] = False
+        else:
+            action_mask = action_mask & to_deliver
+            available[:, 0] = False  # the depot is added by get_reward
+            action_mask[:, 0] = False
+        return TensorDict(
+            {
+                "locs": torch.cat((td["depot"][:, None, :], td["locs"]), -2).contiguous(),
+                "current_node": torch.zeros(b, 1, dtype=torch.long, device=device),
+                "to_deliver": to_deliver,
+                "available": available,
+                "i": torch.zeros((b, 1), dtype=torch.int64, device=device),
+                "action_mask": action_mask,
+                "done": torch.zeros((b,), dtype=torch.bool, device=device),
+            },
+            batch_size=[b],
+        )
+
+    def _step(self, td: TensorDict) -> TensorDict:
+        """pdp/env.py:64-99 via rl4co_pdp_step (in place)"""
+        K.pdp_step(td["action"].contiguous(), td["available"], td["to_deliver"], td["current_node"], td["i"],
+                   td["action_mask"], td["done"])
+        return td
+
+    def get_action_mask(self, td: TensorDict) -> Tensor:
+        """pdp/env.py:79 (recomputed in place into td['action_mask'])"""
+        K.pdp_step(None, td["available"], td["to_deliver"], td["current_node"], td["i"], td["action_mask"], td["done"])
+        return td["action_mask"]
+
+    def _get_reward(self, td: TensorDict, actions: Tensor) -> Tensor:
+        """pdp/env.py:191-202"""
+        return K.tour_length(td["locs"].contiguous(), actions.contiguous(), prepend_depot=True, negate=True)
+
+    def check_solution_validity(self, td: TensorDict, actions: Tensor, err: Tensor | None = None) -> None:
+        """pdp/env.py:204-223. ``err``: see TSPEnv."""
+        own = err is None
+        err = K.new_error_word(actions.device) if own else err
+        K.pdp_check_solution(actions.contiguous(), td["locs"].shape[-2], self.force_start_at_depot, err)
+        if own:
+            K.raise_if_error(err)
+
+    def get_num_starts(self, td) -> int:
+        """pdp/env.py:225-227: only the pickups can start a tour"""
+        return (td["locs"].shape[-2] - 1) // 2
+
+    def select_start_nodes(self, td, num_starts: int) -> Tensor:
+        """pdp/env.py:229-238"""
+        half = (td["locs"].shape[-2] - 1) // 2
+        return K.select_start_nodes(td["action_mask"].shape[0], num_starts, half, True, td["action_mask"].device)
+
+
 def get_env(name: str, **kw) -> RL4COEnvBase:
-    return {"tsp": TSPEnv, "cvrp": CVRPEnv, "op": OPEnv, "pctsp": PCTSPEnv}[name](**kw)
+    return {"tsp": TSPEnv, "cvrp": CVRPEnv, "op": OPEnv, "pctsp": PCTSPEnv, "pdp": PDPEnv}[name](**kw)

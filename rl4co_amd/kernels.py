@@ -15,7 +15,7 @@ from . import _lib
 from .cache import FoldedCache
 
 MODE_IDS = {"greedy": _lib.DECODE_GREEDY, "sampling": _lib.DECODE_SAMPLE, "evaluate": _lib.DECODE_EVALUATE}
-ENV_IDS = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP, "op": _lib.ENV_OP, "pctsp": _lib.ENV_PCTSP}
+ENV_IDS = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP, "op": _lib.ENV_OP, "pctsp": _lib.ENV_PCTSP, "pdp": _lib.ENV_PDP}
 VARIANT_IDS = {"auto": _lib.VARIANT_AUTO, "stream": _lib.VARIANT_STREAM, "lds": _lib.VARIANT_LDS, "wide": _lib.VARIANT_WIDE, "ms": _lib.VARIANT_MS}
 
 
@@ -225,6 +225,11 @@ def am_decode(
         a.used_capacity = _ptr(_dev(state["tour_length"], torch.float32, "tour_length"))
         a.step_i = _ptr(_dev(state["i"], torch.int64, "i"))
         a.visited = _ptr(_u8(state["visited"], "visited"))
+    elif env_name == "pdp":
+        # pickup and delivery: `available` rides in the visited slot; no context scalar
+        a.visited = _ptr(_u8(state["available"], "available"))
+        a.to_deliver = _ptr(_u8(state["to_deliver"], "to_deliver"))
+        a.step_i = _ptr(_dev(state["i"], torch.int64, "i"))
     elif env_name == "pctsp":
         # prize-collecting TSP: the real prize per node (depot column 0) rides in the demand slot, the
         # prize collected so far in used_capacity, prize_required in vehicle_capacity
@@ -286,6 +291,26 @@ def op_step(action: Tensor | None, locs: Tensor, max_length: Tensor, tour_length
         _ptr(_dev(step_i, torch.int64, "i")), _ptr(_u8(action_mask, "action_mask")), _ptr(_u8(done, "done")),
         b, locs.shape[0], n, _ptr(err), _stream())
     _lib.check(st, "rl4co_op_step")
+
+
+def pdp_step(action: Tensor | None, available: Tensor, to_deliver: Tensor, current_node: Tensor, step_i: Tensor,
+             action_mask: Tensor, done: Tensor, err: Tensor | None = None) -> None:
+    """In-place PDPEnv._step (pdp/env.py:64-99); action=None -> mask = available & to_deliver only."""
+    b, n = action_mask.shape
+    st = _lib.lib().rl4co_pdp_step(
+        _ptr(None if action is None else _dev(action, torch.int64, "action")), _ptr(_u8(available, "available")),
+        _ptr(_u8(to_deliver, "to_deliver")), _ptr(_dev(current_node, torch.int64, "current_node")),
+        _ptr(_dev(step_i, torch.int64, "i")), _ptr(_u8(action_mask, "action_mask")), _ptr(_u8(done, "done")),
+        b, n, _ptr(err), _stream())
+    _lib.check(st, "rl4co_pdp_step")
+
+
+def pdp_check_solution(actions: Tensor, num_nodes: int, force_start_at_depot: bool, err: Tensor) -> None:
+    """pdp/env.py:204-223 into the sticky error word (NOT_ALL_NODES / DEPOT_MIDDLE / NO_PICKUP)."""
+    b, t = actions.shape
+    st = _lib.lib().rl4co_pdp_check_solution(_ptr(_dev(actions, torch.int64, "actions")), b, num_nodes, t,
+                                             int(force_start_at_depot), _ptr(_dev(err, torch.int32, "err")), _stream())
+    _lib.check(st, "rl4co_pdp_check_solution")
 
 
 def pctsp_step(action: Tensor | None, real_prize: Tensor, cur_total_prize: Tensor, visited: Tensor, current_node: Tensor,

@@ -249,6 +249,38 @@ class _PCTSPInit(nn.Module):
         return torch.cat((self.init_embed_depot(locs[:, :1, :]), self.init_embed(feats)), -2)
 
 
+class _PDPInit(nn.Module):
+    """env_embeddings/init.py:335-360: depot (x, y) | pickups (x, y, x', y' of the delivery) | deliveries (x, y)"""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.init_embed_depot = nn.Linear(2, embed_dim, True)
+        self.init_embed_pick = nn.Linear(4, embed_dim, True)
+        self.init_embed_delivery = nn.Linear(2, embed_dim, True)
+
+    def features(self, td):
+        locs = td["locs"]
+        half = (locs.shape[-2] - 1) // 2
+        pick = torch.cat((locs[:, 1 : half + 1, :], locs[:, half + 1 :, :]), -1)
+        return ((locs[:, :1, :], self.init_embed_depot), (pick, self.init_embed_pick),
+                (locs[:, half + 1 :, :], self.init_embed_delivery))
+
+    def forward(self, td):
+        if _train_kernels_active(td["locs"]):
+            from . import train_ops
+
+            return torch.cat([train_ops.init_embed(f.contiguous(), lin) for f, lin in self.features(td)], -2)
+        return torch.cat([lin(f) for f, lin in self.features(td)], -2)
+
+
+class _NodeContext(nn.Module):
+    """env_embeddings/context.py:232-243 (PDP): the current node embedding alone"""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.project_context = nn.Linear(embed_dim, embed_dim, bias=False)
+
+
 class AttentionModelEncoder(nn.Module):
     """zoo/am/encoder.py:12-87"""
 
@@ -256,7 +288,8 @@ class AttentionModelEncoder(nn.Module):
                  feedforward_hidden=512):
         super().__init__()
         self.env_name = env_name
-        self.init_embedding = {"tsp": _TSPInit, "cvrp": _VRPInit, "op": _OPInit, "pctsp": _PCTSPInit}[env_name](embed_dim)
+        self.init_embedding = {"tsp": _TSPInit, "cvrp": _VRPInit, "op": _OPInit, "pctsp": _PCTSPInit,
+                               "pdp": _PDPInit}[env_name](embed_dim)
         self.net = _GraphAttentionNetwork(num_heads, embed_dim, num_layers, normalization, feedforward_hidden)
 
     def forward(self, td):
@@ -300,7 +333,8 @@ class AttentionModelDecoder(nn.Module):
         self.num_heads = num_heads
         self.mask_inner = mask_inner
         self.check_nan = check_nan
-        self.context_embedding = {"tsp": _TSPContext, "cvrp": _VRPContext, "op": _VRPContext, "pctsp": _VRPContext}[env_name](embed_dim)
+        self.context_embedding = {"tsp": _TSPContext, "cvrp": _VRPContext, "op": _VRPContext, "pctsp": _VRPContext,
+                                  "pdp": _NodeContext}[env_name](embed_dim)
         self.dynamic_embedding = nn.Module()  # StaticEmbedding (dynamic.py:47-57): no parameters
         self.pointer = _Pointer(embed_dim)
         self.project_node_embeddings = nn.Linear(embed_dim, 3 * embed_dim, bias=False)
@@ -404,7 +438,9 @@ class AttentionModelPolicy(nn.Module):
 
         enc = self.encoder
         init = enc.init_embedding
-        if self.env_name in ("cvrp", "op", "pctsp"):
+        if self.env_name == "pdp":
+            x = torch.cat([T.init_embed(f.contiguous(), lin) for f, lin in init.features(td)], -2)
+        elif self.env_name in ("cvrp", "op", "pctsp"):
             locs = td["locs"]
             third = {"cvrp": "demand", "op": "prize", "pctsp": "expected_prize"}[self.env_name]
             third = td[third][..., 1:] if self.env_name == "op" else td[third]
@@ -446,7 +482,8 @@ class AttentionModelPolicy(nn.Module):
         # TSP: exactly N steps. CVRP: every customer + at most one depot visit per customer + 1.
         # OP: every customer once, the closing depot visit, and a depot pick at step 0 costs one more.
         # PCTSP: every customer once and the closing depot visit (the depot is masked at step 0).
-        return n if env_name in ("tsp", "pctsp") else (n + 2 if env_name == "op" else 2 * n)
+        # PDP: every node once (the depot too under force_start_at_depot).
+        return n if env_name in ("tsp", "pctsp", "pdp") else (n + 2 if env_name == "op" else 2 * n)
 
     def _initial_state(self, td, num_starts: int):
         """State tensors the kernel updates in place; with multistart the rows are expanded
@@ -465,6 +502,10 @@ class AttentionModelPolicy(nn.Module):
         }
         if self.env_name == "tsp":
             st["first_node"] = rep(td["first_node"].reshape(-1))
+            st["i"] = rep(td["i"].reshape(-1))
+        elif self.env_name == "pdp":
+            st["available"] = rep(td["available"])
+            st["to_deliver"] = rep(td["to_deliver"])
             st["i"] = rep(td["i"].reshape(-1))
         elif self.env_name == "pctsp":
             st["real_prize"] = td["real_prize"].contiguous()  # instance data [B_inst, N], depot column 0
@@ -558,6 +599,9 @@ class AttentionModelPolicy(nn.Module):
                                                       self.encoder_autocast or torch.float32)
         state = self._initial_state(td, n_rep)
         horizon = min(self._max_horizon(self.env_name, n), max_steps)
+        if self.env_name == "pdp" and not getattr(env, "force_start_at_depot", False):
+            horizon = min(horizon, n - 1)  # the depot is never visited: exactly one step per location (no padding
+            #                                column: a trailing 0 would read as a depot visit in check_solution_validity)
         # status word read back ONCE per rollout: [sticky error bits, longest trajectory, streamed instance-steps]
         status = torch.zeros(3, dtype=torch.int32, device=device)
         err = status[:1]
@@ -682,6 +726,9 @@ class AttentionModelPolicy(nn.Module):
         elif self.env_name == "op":
             K.op_step(action, state["locs"], state["max_length"], state["tour_length"], state["visited"],
                       state["current_node"], state["i"], state["action_mask"], state["done"], err)
+        elif self.env_name == "pdp":
+            K.pdp_step(action, state["available"], state["to_deliver"], state["current_node"], state["i"],
+                       state["action_mask"], state["done"], err)
         elif self.env_name == "pctsp":
             K.pctsp_step(action, state["real_prize"], state["cur_total_prize"], state["visited"], state["current_node"],
                          state["i"], state["action_mask"], state["done"], err)
@@ -705,6 +752,9 @@ class AttentionModelPolicy(nn.Module):
         elif self.env_name == "op":
             out.update(prize=rep(td["prize"]), max_length=rep(td["max_length"]), current_node=state["current_node"].view(-1, 1),
                        tour_length=state["tour_length"], visited=state["visited"], i=state["i"])
+        elif self.env_name == "pdp":
+            out.update(available=state["available"], to_deliver=state["to_deliver"],
+                       current_node=state["current_node"].view(-1, 1), i=state["i"].view(-1, 1))
         elif self.env_name == "pctsp":
             out.update(real_prize=rep(td["real_prize"]), expected_prize=rep(td["expected_prize"]), penalty=rep(td["penalty"]),
                        prize_required=state["prize_required"], cur_total_prize=state["cur_total_prize"],
@@ -741,7 +791,7 @@ class AttentionModelPolicy(nn.Module):
         else:
             (prev,) = ctx_nodes
             cur = h.gather(1, prev[..., None].expand(b, t_len, d))
-            ctx = torch.cat([cur, extras[..., None]], -1)  # remaining capacity
+            ctx = cur if self.env_name == "pdp" else torch.cat([cur, extras[..., None]], -1)  # + remaining capacity
         q = F.linear(ctx, w_ctx)
         if dec.use_graph_context:
             g = dec.project_fixed_context(hidden.mean(1))
@@ -795,6 +845,8 @@ class AttentionModelPolicy(nn.Module):
                 rem[:, t] = (ml0 if ml0.shape[0] == b else ml0.repeat(b // ml0.shape[0])) - state["tour_length"]
             elif self.env_name == "pctsp":
                 rem[:, t] = torch.clamp(state["prize_required"] - state["cur_total_prize"], min=0)
+            elif self.env_name == "pdp":
+                pass  # no context scalar
             else:
                 rem[:, t] = state["vehicle_capacity"] - state["used_capacity"]
             self._env_step_state(state, actions[:, t].contiguous(), err)

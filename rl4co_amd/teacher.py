@@ -47,7 +47,7 @@ def supports(env_name: str, cache_dtype: torch.dtype, num_nodes: int) -> bool:
     """TSP / CVRP: both variants; orienteering and prize-collecting TSP: the MMA variant only (bf16 planes)."""
     if num_nodes > max_nodes():
         return False
-    return env_name in ("tsp", "cvrp") or (env_name in ("op", "pctsp") and cache_dtype == torch.bfloat16)
+    return env_name in ("tsp", "cvrp") or (env_name in ("op", "pctsp", "pdp") and cache_dtype == torch.bfloat16)
 
 
 def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: dict, variant: str = "auto",
@@ -71,7 +71,7 @@ def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: d
     logp = torch.zeros((b, t), **f32) if want_logp else None
     err = torch.zeros(1, dtype=torch.int32, device=dev)
     a = AmTeacherArgs()
-    a.env = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP, "op": _lib.ENV_OP, "pctsp": _lib.ENV_PCTSP}[cache.env_name]
+    a.env = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP, "op": _lib.ENV_OP, "pctsp": _lib.ENV_PCTSP, "pdp": _lib.ENV_PDP}[cache.env_name]
     a.B, a.B_inst, a.N, a.T, a.t0 = b, b_inst, n, t, int(meta["t0"])
     a.mask_inner, a.mask_logits = int(meta["mask_inner"]), int(meta["mask_logits"])
     a.tanh_clipping, a.temperature = float(meta["tanh_clipping"]), float(meta["temperature"])
@@ -131,7 +131,7 @@ def build_cache_autograd(env_name: str, h: Tensor, decoder) -> dict[str, Tensor]
     if env_name == "tsp":
         out["ctx_first"] = planes[3]
         out["q_step0"] = torch.mv(w_ctx, decoder.context_embedding.W_placeholder.float())
-    else:
+    elif w_ctx.shape[1] > d:  # PDP has no context scalar
         out["w_cap"] = w_ctx[:, d]
     out["q_bias"] = (torch.matmul(h.mean(1), decoder.project_fixed_context.weight.float().t())
                      if decoder.use_graph_context else None)
@@ -151,20 +151,20 @@ class TeacherForcedLogLik(torch.autograd.Function):
     @staticmethod
     def forward(ctx, kvl, ctx_first, ctx_cur, q_bias, q_extra, logps, cache: FoldedCache, actions: Tensor, meta: dict):
         ctx.cache, ctx.actions, ctx.meta = cache, actions, meta
-        ctx.has = (ctx_first is not None, q_bias is not None)
+        ctx.has = (ctx_first is not None, q_bias is not None, q_extra is not None)
         return logps.detach().clone()
 
     @staticmethod
     def backward(ctx, grad_logp):
         out = run_backward(ctx.cache, ctx.actions, grad_logp, ctx.meta, variant=ctx.meta.get("teacher_variant", "auto"))
-        has_first, has_bias = ctx.has
+        has_first, has_bias, has_extra = ctx.has
         return (out["d_kvl"], out["d_ctx_first"] if has_first else None, out["d_ctx_cur"],
-                out["d_q_bias"] if has_bias else None, out["d_extra"], None, None, None, None)
+                out["d_q_bias"] if has_bias else None, out["d_extra"] if has_extra else None, None, None, None, None)
 
 
 def teacher_forced_logps(env_name: str, g: dict[str, Tensor], cache: FoldedCache, actions: Tensor, logps: Tensor,
                          meta: dict) -> Tensor:
     """Differentiable per-step log-probs of ``actions`` (values = ``logps`` from the rollout)."""
-    extra = g["q_step0"] if env_name == "tsp" else g["w_cap"]
+    extra = g["q_step0"] if env_name == "tsp" else g.get("w_cap")  # None for PDP (no context scalar)
     return TeacherForcedLogLik.apply(g["kvl"], g.get("ctx_first"), g["ctx_cur"], g.get("q_bias"), extra, logps,
                                      cache, actions, meta)

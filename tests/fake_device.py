@@ -58,6 +58,21 @@ def _pctsp_check(actions, real_prize, err):
         err |= 64 if "Duplicates" in str(e) else 256
 
 
+def _pdp_step(action, available, to_deliver, current_node, step_i, action_mask, done, err=None):
+    c_oracle.pdp_step(None if action is None else action.contiguous(), available, to_deliver, current_node, step_i,
+                      action_mask, done)
+
+
+def _pdp_check(actions, num_nodes, force_start_at_depot, err):
+    from oracle import reference_torch as R
+
+    env = R.PDPEnv(num_loc=num_nodes - 1, force_start_at_depot=force_start_at_depot)
+    try:
+        env.check_solution_validity({}, actions)
+    except AssertionError as e:
+        err |= 512 if "Not visiting" in str(e) else (1024 if "depot" in str(e) else 2048)
+
+
 def _select_start_nodes(batch, num_starts, num_loc, has_depot, device):
     return torch.arange(num_starts).repeat_interleave(batch) % num_loc + (1 if has_depot else 0)
 
@@ -108,6 +123,8 @@ def cpu_device(monkeypatch):
     monkeypatch.setattr(K, "op_max_length", c_oracle.op_max_length)
     monkeypatch.setattr(K, "gather_sum", lambda values, actions: c_oracle.gather_sum(values.contiguous(), actions.contiguous()))
     monkeypatch.setattr(K, "op_check_solution", _op_check)
+    monkeypatch.setattr(K, "pdp_step", _pdp_step)
+    monkeypatch.setattr(K, "pdp_check_solution", _pdp_check)
     monkeypatch.setattr(K, "pctsp_step", _pctsp_step)
     monkeypatch.setattr(K, "pctsp_check_solution", _pctsp_check)
     monkeypatch.setattr(K, "am_decode", _am_decode)

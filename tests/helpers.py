@@ -72,7 +72,8 @@ class GoldenCase:
     def num_starts(self) -> int:
         if "multistart" not in self.meta["decode_type"]:
             return 0
-        return self.meta["forward_kwargs"].get("num_starts", self.num_loc)
+        default = self.num_loc // 2 if self.env_name == "pdp" else self.num_loc  # pdp/env.py:225-227: pickups only
+        return self.meta["forward_kwargs"].get("num_starts", default)
 
 
 def clone_td(td: dict) -> dict:
@@ -114,6 +115,10 @@ def rollout_state(env_name: str, td: dict, device="cpu", num_starts: int = 0) ->
     if env_name == "tsp":
         st["first_node"] = rep(td["first_node"].reshape(-1))
         st["i"] = rep(td["i"].reshape(-1))
+    elif env_name == "pdp":
+        st["available"] = rep(td["available"].to(torch.uint8))
+        st["to_deliver"] = rep(td["to_deliver"].to(torch.uint8))
+        st["i"] = rep(td["i"].reshape(-1))
     elif env_name == "pctsp":
         st["real_prize"] = td["real_prize"].to(device).contiguous()
         st["cur_total_prize"] = rep(td["cur_total_prize"].reshape(-1))
@@ -137,8 +142,27 @@ def rollout_state(env_name: str, td: dict, device="cpu", num_starts: int = 0) ->
 device_state = rollout_state  # name used by the GPU tests
 
 
+def apply_step(mod, env_name: str, action: torch.Tensor, st: dict) -> None:
+    """One environment transition on the flat state through `mod` (rl4co_amd.kernels or oracle.c_oracle)."""
+    if env_name == "tsp":
+        mod.tsp_step(action, st["action_mask"], st["first_node"], st["current_node"], st["i"], st["done"])
+    elif env_name == "cvrp":
+        mod.cvrp_step(action, st["demand"], st["used_capacity"], st["vehicle_capacity"], st["visited"],
+                      st["current_node"], st["action_mask"], st["done"])
+    elif env_name == "op":
+        mod.op_step(action, st["locs"], st["max_length"], st["tour_length"], st["visited"], st["current_node"], st["i"],
+                    st["action_mask"], st["done"])
+    elif env_name == "pctsp":
+        mod.pctsp_step(action, st["real_prize"], st["cur_total_prize"], st["visited"], st["current_node"], st["i"],
+                       st["action_mask"], st["done"])
+    elif env_name == "pdp":
+        mod.pdp_step(action, st["available"], st["to_deliver"], st["current_node"], st["i"], st["action_mask"], st["done"])
+    else:
+        raise ValueError(env_name)
+
+
 def max_horizon(env_name: str, n: int) -> int:
-    return n if env_name in ("tsp", "pctsp") else (n + 2 if env_name == "op" else 2 * n)
+    return n if env_name in ("tsp", "pctsp", "pdp") else (n + 2 if env_name == "op" else 2 * n)
 
 
 def oracle_reward(env_name: str, td0: dict, actions: torch.Tensor) -> torch.Tensor:
@@ -153,7 +177,7 @@ def oracle_reward(env_name: str, td0: dict, actions: torch.Tensor) -> torch.Tens
         every = torch.arange(1, n).expand(actions.shape[0], n - 1).contiguous()
         length = c_oracle.tour_length(td0["locs"], actions.contiguous(), prepend_depot=True, negate=False)
         return c_oracle.gather_sum(pen, actions.contiguous()) - (length + c_oracle.gather_sum(pen, every))
-    return c_oracle.tour_length(td0["locs"], actions, prepend_depot=(env_name == "cvrp"), negate=True)
+    return c_oracle.tour_length(td0["locs"], actions, prepend_depot=(env_name in ("cvrp", "pdp")), negate=True)
 
 
 def kernel_reward(K, env_name: str, td0: dict, actions: torch.Tensor) -> torch.Tensor:
@@ -166,4 +190,5 @@ def kernel_reward(K, env_name: str, td0: dict, actions: torch.Tensor) -> torch.T
         every = torch.arange(1, n, device="cuda").expand(acts.shape[0], n - 1).contiguous()
         length = K.tour_length(td0["locs"].cuda(), acts, prepend_depot=True, negate=False)
         return K.gather_sum(pen, acts) - (length + K.gather_sum(pen, every))
-    return K.tour_length(td0["locs"].cuda(), actions.cuda().contiguous(), prepend_depot=(env_name == "cvrp"), negate=True)
+    return K.tour_length(td0["locs"].cuda(), actions.cuda().contiguous(), prepend_depot=(env_name in ("cvrp", "pdp")),
+                         negate=True)

@@ -16,7 +16,7 @@ import torch
 
 from oracle import c_oracle
 from oracle import reference_torch as R
-from tests.helpers import kernel_reward, GoldenCase, fold_cache, manifest, max_horizon, rollout_state
+from tests.helpers import apply_step, kernel_reward, GoldenCase, fold_cache, manifest, max_horizon, rollout_state
 
 pytestmark = pytest.mark.gpu
 
@@ -58,11 +58,7 @@ def _run(K, backend, g, td0, h, mode, dtype=torch.float32, max_steps=None, varia
         first = g.env.select_start_nodes(td0, s).to(dev)
         actions[:, 0] = first
         step = (K if backend == "hip" else c_oracle)
-        if g.env_name == "tsp":
-            step.tsp_step(first, st["action_mask"], st["first_node"], st["current_node"], st["i"], st["done"])
-        else:
-            step.cvrp_step(first, st["demand"], st["used_capacity"], st["vehicle_capacity"], st["visited"],
-                           st["current_node"], st["action_mask"], st["done"])
+        apply_step(step, g.env_name, first, st)
         t0 = 1
     kw = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in kw.items()}
     steps = (tmax - t0) if max_steps is None else max_steps
@@ -100,8 +96,8 @@ CONFIG_IDS = ["f32-stream", "bf16-stream", "bf16-lds", "bf16-wide"]
 
 def _skip_if_unservable(g, dtype, variant):
     n = g.num_loc + (g.env_name != "tsp")
-    if g.env_name in ("op", "pctsp") and variant != "stream":
-        pytest.skip("the orienteering / prize-collecting transitions exist in the streaming kernel only")
+    if g.env_name in ("op", "pctsp", "pdp") and variant != "stream":
+        pytest.skip("the orienteering / prize-collecting / pickup-delivery transitions exist in the streaming kernel only")
     try:
         __import__("rl4co_amd.kernels").kernels.decode_row_groups(n, dtype, 2 * n, variant, 64)
     except Exception:
@@ -120,7 +116,7 @@ def test_greedy_bit_exact_vs_c_oracle(K, name, dtype, variant):
 
 @pytest.mark.parametrize("dtype,variant", CONFIGS, ids=CONFIG_IDS)
 @pytest.mark.parametrize("name", ["tsp100_b64_sampling", "cvrp100_b64_sampling", "pomo_tsp50_b8_mssampling",
-                                  "op50_b64_sampling", "pctsp50_b64_sampling",
+                                  "op50_b64_sampling", "pctsp50_b64_sampling", "pdp50_b64_sampling",
                                   "c4_pomo_tsp100_b32_s8_sampling", "c5_cvrp500_b16_sampling"])
 def test_sampling_injected_noise_bit_exact_vs_c_oracle(K, name, dtype, variant):
     g = GoldenCase(name)
@@ -254,7 +250,7 @@ def test_greedy_vs_reference_golden(K, name):
 
 
 @pytest.mark.parametrize("name", ["tsp100_b64_sampling", "cvrp100_b64_sampling", "pomo_tsp50_b8_mssampling",
-                                  "op50_b64_sampling", "pctsp50_b64_sampling",
+                                  "op50_b64_sampling", "pctsp50_b64_sampling", "pdp50_b64_sampling",
                                   "c4_pomo_tsp100_b32_s8_sampling", "c5_cvrp500_b16_sampling"])
 def test_sampling_vs_reference_golden(K, name):
     """Fixed-seed sampling: the reference's multinomial stream, re-drawn from its seed, drives the

@@ -10,7 +10,7 @@ import torch
 
 from oracle import c_oracle
 from oracle import reference_torch as R
-from tests.helpers import (GoldenCase, oracle_reward, clone_td, fold_cache, make_instances, manifest, max_horizon,
+from tests.helpers import (GoldenCase, apply_step, oracle_reward, clone_td, fold_cache, make_instances, manifest, max_horizon,
                            rollout_state)
 
 ALL_CASES = sorted(manifest())
@@ -79,7 +79,8 @@ def test_tour_length_multistart_row_mapping():
 # env transitions: C oracle == torch restatement under a random feasible policy
 # ---------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("env_name,num_loc", [("op", 20), ("op", 100), ("pctsp", 20), ("pctsp", 100)])
+@pytest.mark.parametrize("env_name,num_loc", [("op", 20), ("op", 100), ("pctsp", 20), ("pctsp", 100), ("pdp", 20),
+                                              ("pdp", 100)])
 def test_depot_env_steps_match_restatement(env_name, num_loc):
     """Orienteering / prize-collecting TSP transitions and masks: C oracle == restatement, bit for bit,
     under a random feasible policy; then the reward composition of tests/helpers.oracle_reward."""
@@ -98,11 +99,16 @@ def test_depot_env_steps_match_restatement(env_name, num_loc):
             c_oracle.op_step(action, st["locs"], st["max_length"], st["tour_length"], st["visited"], st["current_node"],
                              st["i"], st["action_mask"], st["done"])
             assert torch.equal(st["tour_length"], td["tour_length"])
+        elif env_name == "pdp":
+            apply_step(c_oracle, "pdp", action, st)
+            assert torch.equal(st["available"].bool(), td["available"])
+            assert torch.equal(st["to_deliver"].bool(), td["to_deliver"])
         else:
             c_oracle.pctsp_step(action, st["real_prize"], st["cur_total_prize"], st["visited"], st["current_node"],
                                 st["i"], st["action_mask"], st["done"])
             assert torch.equal(st["cur_total_prize"], td["cur_total_prize"])
-        assert torch.equal(st["visited"].bool(), td["visited"].bool())
+        if env_name != "pdp":
+            assert torch.equal(st["visited"].bool(), td["visited"].bool())
         assert torch.equal(st["action_mask"], td["action_mask"])
         assert torch.equal(st["done"], td["done"].reshape(-1))
         assert torch.equal(st["i"], td["i"].reshape(-1))
@@ -160,11 +166,7 @@ def c_rollout(g: GoldenCase, mode: str, cache_dtype=torch.float32, row_groups=No
     if s > 0:
         first = g.env.select_start_nodes(td0, s)
         actions[:, 0] = first
-        if g.env_name == "tsp":
-            c_oracle.tsp_step(first, st["action_mask"], st["first_node"], st["current_node"], st["i"], st["done"])
-        else:
-            c_oracle.cvrp_step(first, st["demand"], st["used_capacity"], st["vehicle_capacity"], st["visited"],
-                               st["current_node"], st["action_mask"], st["done"])
+        apply_step(c_oracle, g.env_name, first, st)
         t0 = 1
     if row_groups is None:
         row_groups = 4 if cache_dtype == torch.bfloat16 else 2
