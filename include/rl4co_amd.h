@@ -47,6 +47,11 @@ extern "C" {
 #define RL4CO_EBIT_NOT_ALL_NODES 512   /* pdp/env.py:208-213 "Not visiting all nodes"                  */
 #define RL4CO_EBIT_DEPOT_MIDDLE 1024   /* pdp/env.py:216-218 "Going back to depot in the middle ..."   */
 #define RL4CO_EBIT_NO_PICKUP 2048      /* pdp/env.py:220-223 "Deliverying without pick-up"             */
+#define RL4CO_EBIT_TW_NEGATIVE 4096    /* cvrptw/env.py:153 "Time windows must be non-negative."       */
+#define RL4CO_EBIT_TW_RETURN 8192      /* cvrptw/env.py:154-157 "vehicle cannot perform service and get back to depot in time." */
+#define RL4CO_EBIT_TW_DURATION 16384   /* cvrptw/env.py:158 "Service durations must be non-negative."  */
+#define RL4CO_EBIT_TW_EMPTY 32768      /* cvrptw/env.py:159-161 "there are unfeasible time windows"    */
+#define RL4CO_EBIT_TW_DEADLINE 65536   /* cvrptw/env.py:176-179 "vehicle cannot start service before deadline" */
 
 /* ---- enums --------------------------------------------------------------- */
 #define RL4CO_ENV_TSP 0
@@ -54,6 +59,7 @@ extern "C" {
 #define RL4CO_ENV_OP 2 /* orienteering problem: streaming decode variant only */
 #define RL4CO_ENV_PCTSP 3 /* prize-collecting TSP (same row): streaming decode variant only */
 #define RL4CO_ENV_PDP 4 /* pickup and delivery (same row): streaming decode variant only */
+#define RL4CO_ENV_CVRPTW 5 /* CVRP with time windows (same row): streaming decode variant only */
 
 #define RL4CO_DECODE_GREEDY 0   /* utils/decoding.py:387-397 */
 #define RL4CO_DECODE_SAMPLE 1   /* utils/decoding.py:399-413 */
@@ -191,6 +197,23 @@ int rl4co_pdp_check_solution(const int64_t* actions, int B, int N, int T, int fo
                              void* stream);
 
 /* --------------------------------------------------------------------------
+ * N4  CVRPTWEnv (CVRP + time windows)   envs/routing/cvrptw/env.py:83-190
+ * step : d = |loc_a - loc_cur| ; time = (a != 0) * (max(time + d, tw_start[a]) + duration[a]) ; then the CVRP
+ *        transition (a8) ; mask = cvrp_mask & (time + |loc_j - loc_a| <= tw_end[j])   (action == NULL: mask only).
+ *        Distances are sqrt(fma(dy, dy, dx * dx)) like the tour-length kernel.
+ * check: the instance-data assertions (RL4CO_EBIT_TW_NEGATIVE / _RETURN / _DURATION / _EMPTY; `max_time` is
+ *        tw_end of instance 0's depot, as in the reference) and the deadline replay
+ *        t = max(trunc(t + d), tw_start) <= tw_end ; t += duration ; t = 0 at the depot (RL4CO_EBIT_TW_DEADLINE).
+ *        The CVRP part of the check is rl4co_cvrp_check_solution. Trailing depot zeros are neutral.
+ * -------------------------------------------------------------------------- */
+int rl4co_cvrptw_step(const int64_t* action, const float* demand, const float* locs, const float* time_windows,
+                      const float* durations, float* used_capacity, const float* vehicle_capacity, float* current_time,
+                      uint8_t* visited, int64_t* current_node, uint8_t* action_mask, uint8_t* done, int B, int B_inst, int N,
+                      int32_t* err, void* stream);
+int rl4co_cvrptw_check_solution(const int64_t* actions, const float* locs, const float* time_windows,
+                                const float* durations, int B, int B_inst, int N, int T, int32_t* err, void* stream);
+
+/* --------------------------------------------------------------------------
  * a13-a21  AttentionModel decode: one step, or the whole autoregressive loop.
  *
  * Replaces, per step: TSPContext/VRPContext (env_embeddings/context.py:105-149),
@@ -257,6 +280,12 @@ typedef struct rl4co_am_decode_args {
   /* PDP (envs/routing/pdp/env.py): visited carries the `available` flags (1 = not yet visited), to_deliver
    * the precedence flags; step_i; the context is the current node's row alone (no scalar, w_cap NULL) */
   uint8_t* to_deliver;      /* [B,N] PDP                                                   */
+  /* CVRPTW (envs/routing/cvrptw/env.py): the CVRP fields plus locs, time_windows, durations, current_time; the
+   * context carries two scalars, q = w_time * time + (w_cap * (cap - used) + ctx_cur[cur]) (context.py:152-166) */
+  const float* time_windows; /* [B_inst,N,2] (start, end), fp32                             */
+  const float* durations;    /* [B_inst,N] service times                                    */
+  float* current_time;       /* [B]                                                         */
+  const float* w_time;       /* [128] = W_ctx[:, 129]                                       */
   /* decoding inputs */
   const float* exp_noise;   /* [max_steps,B,N] Exp(1) draws (parity mode) or NULL          */
   uint64_t philox_seed;     /* in-kernel Exp(1) noise when exp_noise == NULL               */
@@ -316,8 +345,10 @@ typedef struct rl4co_am_encoder_args {
   int32_t cache_dtype; /* dtype of the three kvl planes written                    */
   const float* locs;   /* [B,N,2] (CVRP: depot first, cvrp/env.py:108)             */
   const float* demand; /* [B,N-1] CVRP demand / OP prize / PCTSP expected prize     */
-  const float* feature4; /* [B,N-1] PCTSP penalty (w_init is then [128,4]) or NULL  */
-  const float* w_init; /* [128,2] TSP / [128,3] CVRP customers / [128,4] PCTSP      */
+  const float* feature4; /* [B,N-1] PCTSP penalty / CVRPTW tw start (w_init is then [128,4] / [128,6]) or NULL */
+  const float* feature5; /* [B,N-1] CVRPTW tw end, or NULL                          */
+  const float* feature6; /* [B,N-1] CVRPTW service time, or NULL (feature4..6 are set together) */
+  const float* w_init; /* [128,2] TSP / [128,3] CVRP customers / [128,4] PCTSP / [128,6] CVRPTW */
   const float* b_init; /* [128]                                                    */
   const float* w_depot; /* [128,2] depot environments                              */
   const float* b_depot; /* [128]                                                   */
@@ -411,7 +442,7 @@ int rl4co_am_teacher_variant(const rl4co_am_teacher_args* args);
 
 /* --------------------------------------------------------------------------
  * a11 (training)  init embedding  env_embeddings/init.py:55-68,115-136
- * out[m,:] = W[128,F] . feats[m,:F] + b  (F <= 4: x, y (, demand)); fp32 in, bf16 out [M,128].
+ * out[m,:] = W[128,F] . feats[m,:F] + b  (F <= 6: x, y (, demand, ...)); fp32 in, bf16 out [M,128].
  * -------------------------------------------------------------------------- */
 int rl4co_init_embed_bf16(const float* feats, const float* w, const float* b, int64_t M, int F, void* out, void* stream);
 

@@ -57,6 +57,7 @@ def lib() -> C.CDLL:
     h.oracle_op_step.argtypes = [vp] * 9 + [i, i, i]
     h.oracle_pctsp_step.argtypes = [vp] * 8 + [i, i, i]
     h.oracle_pdp_step.argtypes = [vp] * 7 + [i, i]
+    h.oracle_cvrptw_step.argtypes = [vp] * 12 + [i, i, i]
     h.oracle_op_max_length.argtypes = [vp, vp, i, i, vp]
     h.oracle_gather_sum_f32.argtypes = [vp, vp, i, i, i, i, vp]
     h.oracle_am_decode.argtypes = [C.POINTER(AmDecodeArgs), i]
@@ -122,6 +123,16 @@ def op_step(action, locs, max_length, tour_length, visited, cur, step_i, mask, d
     assert st == 0, "oracle_op_step: action out of range"
 
 
+def cvrptw_step(action, demand, locs, time_windows, durations, used, cap, current_time, visited, cur, mask, done) -> None:
+    b, n = mask.shape
+    st = lib().oracle_cvrptw_step(_p(None if action is None else _cpu(action, torch.int64)), _p(_cpu(demand, torch.float32)),
+                                  _p(_cpu(locs, torch.float32)), _p(_cpu(time_windows, torch.float32)),
+                                  _p(_cpu(durations, torch.float32)), _p(_cpu(used, torch.float32)), _p(_cpu(cap, torch.float32)),
+                                  _p(_cpu(current_time, torch.float32)), _p(_u8(visited)), _p(_cpu(cur, torch.int64)),
+                                  _p(_u8(mask)), _p(None if done is None else _u8(done)), b, demand.shape[0], n)
+    assert st == 0, "oracle_cvrptw_step: action out of range"
+
+
 def pdp_step(action, available, to_deliver, cur, step_i, mask, done) -> None:
     b, n = mask.shape
     st = lib().oracle_pdp_step(_p(None if action is None else _cpu(action, torch.int64)), _p(_u8(available)),
@@ -167,7 +178,7 @@ def am_decode(cache, state: dict, *, mode: str, max_steps: int, actions: Tensor,
     a = _lib.AmDecodeArgs()
     mask = _u8(state["action_mask"])
     b, n = mask.shape
-    a.env = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP, "op": _lib.ENV_OP, "pctsp": _lib.ENV_PCTSP, "pdp": _lib.ENV_PDP}[cache.env_name]
+    a.env = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP, "op": _lib.ENV_OP, "pctsp": _lib.ENV_PCTSP, "pdp": _lib.ENV_PDP, "cvrptw": _lib.ENV_CVRPTW}[cache.env_name]
     a.B, a.B_inst, a.N = b, cache.num_instances, n
     a.mode = {"greedy": 0, "sampling": 1, "evaluate": 2}[mode]
     a.max_steps = int(max_steps)
@@ -206,6 +217,12 @@ def am_decode(cache, state: dict, *, mode: str, max_steps: int, actions: Tensor,
         a.step_i = _p(_cpu(state["i"], torch.int64))
         a.visited = _p(_u8(state["visited"]))
     else:
+        if cache.env_name == "cvrptw":
+            a.w_time = _p(_cpu(cache.w_time, torch.float32))
+            a.locs = _p(_cpu(state["locs"], torch.float32))
+            a.time_windows = _p(_cpu(state["time_windows"], torch.float32))
+            a.durations = _p(_cpu(state["durations"], torch.float32))
+            a.current_time = _p(_cpu(state["current_time"], torch.float32))
         a.w_cap = _p(_cpu(cache.w_cap, torch.float32))
         a.demand = _p(_cpu(state["demand"], torch.float32))
         a.used_capacity = _p(_cpu(state["used_capacity"], torch.float32))

@@ -65,6 +65,10 @@ CASES = [
     dict(name="pdp20_b128_greedy", env="pdp", num_loc=20, batch=128, policy="am", decode="greedy"),
     dict(name="pdp50_b64_sampling", env="pdp", num_loc=50, batch=64, policy="am", decode="sampling"),
     dict(name="pdp100_b64_greedy", env="pdp", num_loc=100, batch=64, policy="am", decode="greedy"),
+    # CVRP with time windows (same row): distance/time masks, two context scalars, six init features
+    dict(name="cvrptw20_b128_greedy", env="cvrptw", num_loc=20, batch=128, policy="am", decode="greedy"),
+    dict(name="cvrptw50_b64_sampling", env="cvrptw", num_loc=50, batch=64, policy="am", decode="sampling"),
+    dict(name="cvrptw100_b64_greedy", env="cvrptw", num_loc=100, batch=64, policy="am", decode="greedy"),
     dict(name="pomo_pdp20_b16_msgreedy", env="pdp", num_loc=20, batch=16, policy="pomo", decode="multistart_greedy"),
     # BASELINE.json configs[3] / [4] shapes at a CPU-affordable batch: POMO 8-start sampling on
     # TSP-100, and CVRP-500 sampling (N = 501: the n >= 512 cascade of the tour-length sum)
@@ -103,7 +107,7 @@ def run_case(ref, case: dict) -> dict:
     fw_kw = dict(case.get("fw_kw", {}))
 
     # ---- the real reference -----------------------------------------------------------------
-    env_cls = {"tsp": ref.TSPEnv, "cvrp": ref.CVRPEnv, "op": ref.OPEnv, "pctsp": ref.PCTSPEnv, "pdp": ref.PDPEnv}[env_name]
+    env_cls = {"tsp": ref.TSPEnv, "cvrp": ref.CVRPEnv, "op": ref.OPEnv, "pctsp": ref.PCTSPEnv, "pdp": ref.PDPEnv, "cvrptw": ref.CVRPTWEnv}[env_name]
     gen_kw = dict(num_loc=n)
     if env_name == "op":  # the default prize sampler Uniform(1.0, 1.0) does not pass torch's argument validation;
         gen_kw["prize_distribution"] = "dist"  # "dist" takes no sampler and is what prize_type="dist" (the default) uses

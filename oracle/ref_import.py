@@ -40,6 +40,7 @@ _SHELL_PACKAGES = [
     "rl4co.envs.routing.op",
     "rl4co.envs.routing.pctsp",
     "rl4co.envs.routing.pdp",
+    "rl4co.envs.routing.cvrptw",
     "rl4co.models",
     "rl4co.models.nn",
     "rl4co.models.nn.graph",
@@ -58,6 +59,7 @@ _LAZY = {
         "OPEnv": "rl4co.envs.routing.op.env",
         "PCTSPEnv": "rl4co.envs.routing.pctsp.env",
         "PDPEnv": "rl4co.envs.routing.pdp.env",
+        "CVRPTWEnv": "rl4co.envs.routing.cvrptw.env",
     },
     "rl4co.models.zoo.am": {"AttentionModelPolicy": "rl4co.models.zoo.am.policy"},
 }
@@ -80,7 +82,7 @@ class _Shell(types.ModuleType):
 def _get_env(env_name: str, *args, **kwargs):
     """rl4co/envs/__init__.py:65-84 restricted to the environments on the path."""
     envs = sys.modules["rl4co.envs"]
-    registry = {"tsp": "TSPEnv", "cvrp": "CVRPEnv", "op": "OPEnv", "pctsp": "PCTSPEnv", "pdp": "PDPEnv"}
+    registry = {"tsp": "TSPEnv", "cvrp": "CVRPEnv", "op": "OPEnv", "pctsp": "PCTSPEnv", "pdp": "PDPEnv", "cvrptw": "CVRPTWEnv"}
     if env_name not in registry:
         raise ValueError(f"Unknown environment {env_name}. Available (oracle shell): {list(registry)}")
     return getattr(envs, registry[env_name])(*args, **kwargs)
@@ -116,7 +118,7 @@ def install() -> None:
         if "." in pkg:
             parent, _, child = pkg.rpartition(".")
             setattr(sys.modules[parent], child, mod)
-    for env in ("tsp", "cvrp", "op", "pctsp", "pdp"):  # matplotlib renderers: not on the path, not installed
+    for env in ("tsp", "cvrp", "op", "pctsp", "pdp", "cvrptw"):  # matplotlib renderers: not on the path, not installed
         stub = types.ModuleType(f"rl4co.envs.routing.{env}.render")
         stub.render = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError("render is out of scope"))
         stub.render_improvement = stub.render
@@ -135,6 +137,7 @@ def load():
     ns.OPEnv = importlib.import_module("rl4co.envs.routing.op.env").OPEnv
     ns.PCTSPEnv = importlib.import_module("rl4co.envs.routing.pctsp.env").PCTSPEnv
     ns.PDPEnv = importlib.import_module("rl4co.envs.routing.pdp.env").PDPEnv
+    ns.CVRPTWEnv = importlib.import_module("rl4co.envs.routing.cvrptw.env").CVRPTWEnv
     ns.TSPGenerator = importlib.import_module("rl4co.envs.routing.tsp.generator").TSPGenerator
     ns.CVRPGenerator = importlib.import_module("rl4co.envs.routing.cvrp.generator").CVRPGenerator
     ns.AttentionModelPolicy = importlib.import_module("rl4co.models.zoo.am.policy").AttentionModelPolicy

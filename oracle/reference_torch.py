@@ -321,6 +321,138 @@ class CVRPEnv:
         return select_start_nodes(td, self, num_starts)
 
 
+class CVRPTWEnv(CVRPEnv):
+    """envs/routing/cvrptw/env.py:16-199 with cvrptw/generator.py:13-158 (CVRP + time windows; unscaled by default:
+    coordinates in [0, 150], integer-valued time windows in [0, 480], service durations 0)"""
+
+    name = "cvrptw"
+
+    def __init__(self, num_loc: int = 20, check_solution: bool = True, capacity: float | None = None,
+                 max_loc: float = 150.0, max_time: float = 480, scale: bool = False):
+        super().__init__(num_loc, check_solution, capacity)
+        self.max_loc, self.max_time, self.scale = max_loc, max_time, scale
+
+    def generate(self, batch_size: int) -> dict:
+        """cvrp/generator.py:114-140 with a depot sampler (cvrptw/generator.py:49), then cvrptw/generator.py:77-158"""
+        loc_sampler = torch.distributions.Uniform(low=0.0, high=self.max_loc)
+        depot = loc_sampler.sample((batch_size, 2))
+        locs = loc_sampler.sample((batch_size, self.num_loc, 2))
+        demand = torch.distributions.Uniform(low=0, high=9).sample((batch_size, self.num_loc))
+        demand = (demand.int() + 1).float()
+        td = {"locs": locs, "depot": depot, "demand": demand / self.capacity,
+              "capacity": torch.full((batch_size, 1), self.capacity)}
+        durations = torch.zeros(batch_size, self.num_loc + 1, dtype=torch.float32)
+        dist = get_distance(td["depot"], td["locs"].transpose(0, 1)).transpose(0, 1)
+        dist = torch.cat((torch.zeros(batch_size, 1), dist), dim=1)
+        upper_bound = self.max_time - dist - durations
+        ts_1 = torch.rand(batch_size, self.num_loc + 1)
+        ts_2 = torch.rand(batch_size, self.num_loc + 1)
+        min_ts = (dist + (upper_bound - dist) * ts_1).int()
+        max_ts = (dist + (upper_bound - dist) * ts_2).int()
+        min_times = torch.min(min_ts, max_ts)
+        max_times = torch.max(min_ts, max_ts)
+        min_times[..., :, 0] = 0.0
+        max_times[..., :, 0] = self.max_time
+        mask = min_times == max_times
+        if torch.any(mask):
+            min_tmp = min_times.clone()
+            min_tmp[mask] = torch.max(dist[mask].int(), min_tmp[mask] - 1)
+            min_times = min_tmp
+            mask = min_times == max_times
+            if torch.any(mask):
+                max_tmp = max_times.clone()
+                max_tmp[mask] = torch.min(
+                    torch.floor(upper_bound[mask]).int(),
+                    torch.max(torch.ceil(min_tmp[mask] + durations[mask]).int(), max_tmp[mask] + 1),
+                )
+                max_times = max_tmp
+        if self.scale:
+            durations = durations / self.max_time
+            min_times = min_times / self.max_time
+            max_times = max_times / self.max_time
+            td["depot"] = td["depot"] / self.max_time
+            td["locs"] = td["locs"] / self.max_time
+        time_windows = torch.stack((min_times, max_times), dim=-1)
+        assert torch.all(min_times < max_times)
+        durations[:, 0] = 0.0
+        td.update({"durations": durations, "time_windows": time_windows})
+        return td
+
+    def reset(self, td: dict | None = None, batch_size: int | None = None) -> dict:
+        """cvrptw/env.py:115-139"""
+        if td is None:
+            td = self.generate(batch_size)
+        b = td["locs"].shape[0]
+        device = td["locs"].device
+        td_reset = {
+            "locs": torch.cat((td["depot"][..., None, :], td["locs"]), -2),
+            "demand": td["demand"],
+            "current_node": torch.zeros(b, 1, dtype=torch.long, device=device),
+            "current_time": torch.zeros(b, 1, dtype=torch.float32, device=device),
+            "used_capacity": torch.zeros((b, 1), device=device),
+            "vehicle_capacity": torch.full((b, 1), self.vehicle_capacity, device=device),
+            "visited": torch.zeros((b, td["locs"].shape[-2] + 1), dtype=torch.uint8, device=device),
+            "durations": td["durations"],
+            "time_windows": td["time_windows"],
+            "done": torch.zeros((b, 1), dtype=torch.bool, device=device),
+        }
+        td_reset["action_mask"] = self.get_action_mask(td_reset)
+        return td_reset
+
+    @staticmethod
+    def get_action_mask(td: dict) -> Tensor:
+        """cvrptw/env.py:83-95"""
+        not_masked = CVRPEnv.get_action_mask(td)
+        current_loc = gather_by_index(td["locs"], td["current_node"])
+        dist = get_distance(current_loc[..., None, :], td["locs"])
+        td.update({"current_loc": current_loc, "distances": dist})
+        can_reach_in_time = td["current_time"] + dist <= td["time_windows"][..., 1]
+        return not_masked & can_reach_in_time
+
+    def step(self, td: dict) -> dict:
+        """cvrptw/env.py:97-113"""
+        batch_size = td["locs"].shape[0]
+        distance = gather_by_index(td["distances"], td["action"]).reshape([batch_size, 1])
+        duration = gather_by_index(td["durations"], td["action"]).reshape([batch_size, 1])
+        start_times = gather_by_index(td["time_windows"], td["action"])[..., 0].reshape([batch_size, 1])
+        td["current_time"] = (td["action"][:, None] != 0) * (
+            torch.max(td["current_time"] + distance, start_times) + duration
+        )
+        return super().step(td)
+
+    @staticmethod
+    def check_solution_validity(td: dict, actions: Tensor) -> None:
+        """cvrptw/env.py:146-190"""
+        CVRPEnv.check_solution_validity(td, actions)
+        batch_size = td["locs"].shape[0]
+        distances = get_distance(td["locs"][..., 0, :], td["locs"].transpose(0, 1)).transpose(0, 1)
+        assert torch.all(distances >= 0.0), "Distances must be non-negative."
+        assert torch.all(td["time_windows"] >= 0.0), "Time windows must be non-negative."
+        assert torch.all(
+            td["time_windows"][..., :, 0] + distances + td["durations"] <= td["time_windows"][..., 0, 1][0]
+        ), "vehicle cannot perform service and get back to depot in time."
+        assert torch.all(td["durations"] >= 0.0), "Service durations must be non-negative."
+        assert torch.all(td["time_windows"][..., 0] < td["time_windows"][..., 1]), "there are unfeasible time windows"
+        curr_time = torch.zeros(batch_size, 1, dtype=torch.float32, device=actions.device)
+        curr_node = torch.zeros_like(curr_time, dtype=torch.int64)
+        for ii in range(actions.size(1)):
+            next_node = actions[:, ii]
+            dist = get_distance(
+                gather_by_index(td["locs"], curr_node).reshape([batch_size, 2]),
+                gather_by_index(td["locs"], next_node).reshape([batch_size, 2]),
+            ).reshape([batch_size, 1])
+            curr_time = torch.max(
+                (curr_time + dist).int(),
+                gather_by_index(td["time_windows"], next_node)[..., 0].reshape([batch_size, 1]),
+            )
+            assert torch.all(
+                curr_time <= gather_by_index(td["time_windows"], next_node)[..., 1].reshape([batch_size, 1])
+            ), "vehicle cannot start service before deadline"
+            curr_time = curr_time + gather_by_index(td["durations"], next_node).reshape([batch_size, 1])
+            curr_node = next_node
+            curr_time[curr_node == 0] = 0.0
+
+
 OP_MAX_LENGTHS = {20: 2.0, 50: 3.0, 100: 4.0}  # op/generator.py:13
 
 
@@ -650,7 +782,8 @@ class PDPEnv:
 
 
 def get_env(name: str, num_loc: int, **kw):
-    return {"tsp": TSPEnv, "cvrp": CVRPEnv, "op": OPEnv, "pctsp": PCTSPEnv, "pdp": PDPEnv}[name](num_loc=num_loc, **kw)
+    return {"tsp": TSPEnv, "cvrp": CVRPEnv, "op": OPEnv, "pctsp": PCTSPEnv, "pdp": PDPEnv,
+            "cvrptw": CVRPTWEnv}[name](num_loc=num_loc, **kw)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -853,6 +986,25 @@ class VRPInitEmbedding(nn.Module):
         return torch.cat((depot_embedding, node_embeddings), -2)
 
 
+class VRPTWInitEmbedding(nn.Module):
+    """env_embeddings/init.py:139-153: customers (x, y, demand, tw start, tw end, service time)"""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.init_embed = nn.Linear(6, embed_dim, True)
+        self.init_embed_depot = nn.Linear(2, embed_dim, True)
+
+    def forward(self, td):
+        depot, cities = td["locs"][:, :1, :], td["locs"][:, 1:, :]
+        durations = td["durations"][..., 1:]
+        time_windows = td["time_windows"][..., 1:, :]
+        depot_embedding = self.init_embed_depot(depot)
+        node_embeddings = self.init_embed(
+            torch.cat((cities, td["demand"][..., None], time_windows, durations[..., None]), -1)
+        )
+        return torch.cat((depot_embedding, node_embeddings), -2)
+
+
 class OPInitEmbedding(nn.Module):
     """env_embeddings/init.py:254-280"""
 
@@ -960,6 +1112,22 @@ class VRPContext(nn.Module):
         return self.project_context(context_embedding)
 
 
+class VRPTWContext(nn.Module):
+    """env_embeddings/context.py:50-74,137-166: current node embedding, remaining capacity, current time"""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.project_context = nn.Linear(embed_dim + 2, embed_dim, bias=False)
+
+    def forward(self, embeddings, td):
+        cur_node_embedding = gather_by_index(embeddings, td["current_node"])
+        capacity = td["vehicle_capacity"] - td["used_capacity"]
+        state_embedding = torch.cat([capacity, td["current_time"]], -1)
+        context_embedding = torch.cat([cur_node_embedding, state_embedding], -1)
+        return self.project_context(context_embedding)
+
+
 class OPContext(nn.Module):
     """env_embeddings/context.py:50-74,201-213: current node embedding + remaining length"""
 
@@ -1016,7 +1184,7 @@ class AttentionModelEncoder(nn.Module):
         super().__init__()
         self.env_name = env_name
         self.init_embedding = {"tsp": TSPInitEmbedding, "cvrp": VRPInitEmbedding, "op": OPInitEmbedding, "pctsp": PCTSPInitEmbedding,
-                               "pdp": PDPInitEmbedding}[env_name](embed_dim)
+                               "pdp": PDPInitEmbedding, "cvrptw": VRPTWInitEmbedding}[env_name](embed_dim)
         self.net = GraphAttentionNetwork(
             num_heads, embed_dim, num_layers, normalization, feedforward_hidden, sdpa_fn=sdpa_fn
         )
@@ -1038,7 +1206,7 @@ class AttentionModelDecoder(nn.Module):
         self.embed_dim = embed_dim
         self.num_heads = num_heads
         self.context_embedding = {"tsp": TSPContext, "cvrp": VRPContext, "op": OPContext, "pctsp": PCTSPContext,
-                                  "pdp": PDPContext}[env_name](embed_dim)
+                                  "pdp": PDPContext, "cvrptw": VRPTWContext}[env_name](embed_dim)
         self.dynamic_embedding = StaticEmbedding()
         self.is_dynamic_embedding = False
         self.pointer = PointerAttention(

@@ -239,6 +239,49 @@ int oracle_op_step(const int64_t* action, const float* locs, const float* maxlen
   return 0;
 }
 
+/* ---- CVRP with time windows (envs/routing/cvrptw/env.py:83-113) -------------------------------- */
+static float cvrptw_time(const float* locs, const float* tw, const float* dur, float time, int cur, int a) {
+  const float d = op_dist(locs, cur, a); /* td["distances"][a]: measured from the node the vehicle stands on */
+  const float served = fmaxf(time + d, tw[2 * a]) + dur[a];
+  return (a != 0 ? 1.0f : 0.0f) * served; /* cvrptw/env.py:108-110 */
+}
+
+static void cvrptw_mask_row(const float* dem, float used, float cap, const uint8_t* vis, int cur, const float* locs,
+                            const float* tw, float time, uint8_t* mk, int N) {
+  cvrp_mask_row(dem, used, cap, vis, cur, mk, N);
+  for (int j = 0; j < N; ++j) /* cvrptw/env.py:91-95 */
+    if (!(time + op_dist(locs, cur, j) <= tw[2 * j + 1])) mk[j] = 0;
+}
+
+int oracle_cvrptw_step(const int64_t* action, const float* demand, const float* locs, const float* time_windows,
+                       const float* durations, float* used, const float* cap, float* time, uint8_t* visited, int64_t* cur,
+                       uint8_t* mask, uint8_t* done, int B, int B_inst, int N) {
+  for (int b = 0; b < B; ++b) {
+    const int ib = b % B_inst;
+    const float* dem = demand + (int64_t)ib * (N - 1);
+    const float* lc = locs + (int64_t)ib * N * 2;
+    const float* tw = time_windows + (int64_t)ib * N * 2;
+    const float* du = durations + (int64_t)ib * N;
+    uint8_t* vis = visited + (int64_t)b * N;
+    if (action) {
+      const int64_t a = action[b];
+      if (a < 0 || a >= N) return 1;
+      time[b] = cvrptw_time(lc, tw, du, time[b], (int)cur[b], (int)a);
+      int64_t di = a - 1;
+      if (di < 0) di = 0;
+      if (di > N - 2) di = N - 2;
+      used[b] = (used[b] + dem[di]) * (a != 0 ? 1.0f : 0.0f);
+      cur[b] = a;
+      vis[a] = 1;
+      int all = 1;
+      for (int j = 0; j < N; ++j) all &= vis[j] != 0;
+      done[b] = all ? 1 : 0;
+    }
+    cvrptw_mask_row(dem, used[b], cap[b], vis, (int)cur[b], lc, tw, time[b], mask + (int64_t)b * N, N);
+  }
+  return 0;
+}
+
 /* ---- prize-collecting TSP (envs/routing/pctsp/env.py) ------------------------------------------ */
 static void pctsp_mask_row(float prize, const uint8_t* vis, uint8_t* mk, int N) { /* pctsp/env.py:141-148 */
   int unvisited = 0;
@@ -342,19 +385,25 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
     memcpy(mk, gmask, (size_t)N);
     if (a->env != RL4CO_ENV_TSP) memcpy(vis, a->visited + (int64_t)r * N, (size_t)N);
     if (a->env == RL4CO_ENV_PDP) memcpy(tod, a->to_deliver + (int64_t)r * N, (size_t)N);
-    const int scalar_ctx = a->env == RL4CO_ENV_CVRP || a->env == RL4CO_ENV_OP || a->env == RL4CO_ENV_PCTSP;
+    const int scalar_ctx = a->env == RL4CO_ENV_CVRP || a->env == RL4CO_ENV_OP || a->env == RL4CO_ENV_PCTSP ||
+                           a->env == RL4CO_ENV_CVRPTW;
+    const int tw_env = a->env == RL4CO_ENV_CVRPTW;
+    const float* twlocs = tw_env ? a->locs + (int64_t)cb * N * 2 : NULL;
+    const float* tw = tw_env ? a->time_windows + (int64_t)cb * N * 2 : NULL;
+    const float* dur = tw_env ? a->durations + (int64_t)cb * N : NULL;
+    float now = tw_env ? a->current_time[r] : 0.0f;
     int cur = (int)a->current_node[r];
     int first = a->env == RL4CO_ENV_TSP ? (int)a->first_node[r] : 0;
-    long long step_i = a->env != RL4CO_ENV_CVRP ? a->step_i[r] : 0;
+    long long step_i = (a->env != RL4CO_ENV_CVRP && a->env != RL4CO_ENV_CVRPTW) ? a->step_i[r] : 0;
     /* OP: `used` is the tour length so far and `cap` the longest tour that may still reach the depot
      * directly, max_length[.., 0]; the context scalar is cap - used in both environments */
     float used = scalar_ctx ? a->used_capacity[r] : 0.0f;
     const float* oplocs = a->env == RL4CO_ENV_OP ? a->locs + (int64_t)cb * N * 2 : NULL;
     const float* opmax = a->env == RL4CO_ENV_OP ? a->max_length + (int64_t)cb * N : NULL;
-    const float cap = (a->env == RL4CO_ENV_CVRP || a->env == RL4CO_ENV_PCTSP) ? a->vehicle_capacity[r]
+    const float cap = (a->env == RL4CO_ENV_CVRP || a->env == RL4CO_ENV_PCTSP || a->env == RL4CO_ENV_CVRPTW) ? a->vehicle_capacity[r]
                       : (a->env == RL4CO_ENV_OP ? opmax[0] : 0.0f); /* PCTSP: prize_required */
     const float* rprize = a->env == RL4CO_ENV_PCTSP ? a->demand + (int64_t)cb * N : NULL;
-    const float* dem = a->env == RL4CO_ENV_CVRP ? a->demand + (int64_t)cb * (N - 1) : NULL;
+    const float* dem = (a->env == RL4CO_ENV_CVRP || a->env == RL4CO_ENV_CVRPTW) ? a->demand + (int64_t)cb * (N - 1) : NULL;
     int done = a->done[r] != 0;
     uint32_t errbits = 0;
     float ent_acc = 0.0f;
@@ -374,7 +423,9 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
         } else {
           float rem = cap - used;
           if (a->env == RL4CO_ENV_PCTSP && !(rem > 0.0f)) rem = 0.0f; /* clamp(min=0), context.py:195 */
-          v = fmaf(a->w_cap[d], rem, ctxc[(int64_t)cur * D + d]) + qb;
+          v = fmaf(a->w_cap[d], rem, ctxc[(int64_t)cur * D + d]);
+          if (tw_env) v = fmaf(a->w_time[d], now, v); /* context.py:152-166: second scalar, the current time */
+          v = v + qb;
         }
         q[d] = v * 0.25f;
       }
@@ -518,6 +569,18 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
         int any = 0;
         for (int j = 0; j < N; ++j) any |= mk[j];
         done = !any;
+      } else if (a->env == RL4CO_ENV_CVRPTW) {
+        now = cvrptw_time(twlocs, tw, dur, now, cur, bi);
+        int di = bi - 1;
+        if (di < 0) di = 0;
+        if (di > N - 2) di = N - 2;
+        used = (used + dem[di]) * (bi != 0 ? 1.0f : 0.0f);
+        cur = bi;
+        vis[bi] = 1;
+        int all = 1;
+        for (int j = 0; j < N; ++j) all &= vis[j] != 0;
+        done = all;
+        cvrptw_mask_row(dem, used, cap, vis, cur, twlocs, tw, now, mk, N);
       } else if (a->env == RL4CO_ENV_PDP) {
         pdp_transition(bi, vis, tod, mk, N);    /* pdp/env.py:64-80 */
         int left = 0;
@@ -559,7 +622,8 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
     a->current_node[r] = cur;
     a->done[r] = done ? 1 : 0;
     if (a->env == RL4CO_ENV_TSP) a->first_node[r] = first;
-    if (a->env != RL4CO_ENV_CVRP) a->step_i[r] = step_i;
+    if (a->env != RL4CO_ENV_CVRP && !tw_env) a->step_i[r] = step_i;
+    if (tw_env) a->current_time[r] = now;
     if (scalar_ctx) a->used_capacity[r] = used;
     if (a->n_steps) a->n_steps[r] = t;
     if (a->steps_summary) {

@@ -11,7 +11,7 @@ from functools import lru_cache
 from . import build as _build
 
 RL4CO_OK = 0
-ENV_TSP, ENV_CVRP, ENV_OP, ENV_PCTSP, ENV_PDP = 0, 1, 2, 3, 4
+ENV_TSP, ENV_CVRP, ENV_OP, ENV_PCTSP, ENV_PDP, ENV_CVRPTW = 0, 1, 2, 3, 4, 5
 DECODE_GREEDY, DECODE_SAMPLE, DECODE_EVALUATE = 0, 1, 2
 DT_F32, DT_BF16 = 0, 1
 VARIANT_AUTO, VARIANT_STREAM, VARIANT_LDS, VARIANT_WIDE, VARIANT_MS = 0, 1, 2, 3, 4
@@ -28,6 +28,7 @@ EBIT_PRIZE = 256
 EBIT_NOT_ALL_NODES = 512
 EBIT_DEPOT_MIDDLE = 1024
 EBIT_NO_PICKUP = 2048
+EBIT_TW_NEGATIVE, EBIT_TW_RETURN, EBIT_TW_DURATION, EBIT_TW_EMPTY, EBIT_TW_DEADLINE = 4096, 8192, 16384, 32768, 65536
 
 # Reference assertion messages (file:line in the reference checkout) per sticky bit.
 ERROR_MESSAGES = {
@@ -43,6 +44,11 @@ ERROR_MESSAGES = {
     EBIT_NOT_ALL_NODES: "Not visiting all nodes",  # pdp/env.py:208-213
     EBIT_DEPOT_MIDDLE: "Going back to depot in the middle of the tour (not allowed)",  # pdp/env.py:216-218
     EBIT_NO_PICKUP: "Deliverying without pick-up",  # pdp/env.py:220-223
+    EBIT_TW_NEGATIVE: "Time windows must be non-negative.",  # cvrptw/env.py:153
+    EBIT_TW_RETURN: "vehicle cannot perform service and get back to depot in time.",  # cvrptw/env.py:154-157
+    EBIT_TW_DURATION: "Service durations must be non-negative.",  # cvrptw/env.py:158
+    EBIT_TW_EMPTY: "there are unfeasible time windows",  # cvrptw/env.py:159-161
+    EBIT_TW_DEADLINE: "vehicle cannot start service before deadline",  # cvrptw/env.py:176-179
 }
 
 _vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
@@ -63,6 +69,7 @@ class AmDecodeArgs(C.Structure):
         ("done", _vp),
         ("demand", _vp), ("used_capacity", _vp), ("vehicle_capacity", _vp), ("visited", _vp),
         ("locs", _vp), ("max_length", _vp), ("to_deliver", _vp),
+        ("time_windows", _vp), ("durations", _vp), ("current_time", _vp), ("w_time", _vp),
         ("exp_noise", _vp), ("philox_seed", C.c_uint64), ("philox_offset", C.c_uint64),
         ("forced_actions", _vp),
         ("t0", _i32), ("out_stride", _i32),
@@ -87,6 +94,8 @@ SYMBOLS = {
     "rl4co_op_check_solution": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_pctsp_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_pctsp_check_solution": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_cvrptw_step": (C.c_int, [_vp] * 12 + [C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_cvrptw_check_solution": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_pdp_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_pdp_check_solution": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_am_decode": (C.c_int, [C.POINTER(AmDecodeArgs), _vp]),

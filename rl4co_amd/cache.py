@@ -38,6 +38,7 @@ class FoldedCache:
     q_bias: Tensor | None  # [B, 128] fp32
     q_step0: Tensor | None  # [128] fp32 (TSP)
     w_cap: Tensor | None  # [128] fp32 (CVRP)
+    w_time: Tensor | None = None  # [128] fp32 (CVRPTW: W_ctx[:, 129], the current-time column)
 
     @property
     def num_instances(self) -> int:
@@ -66,7 +67,7 @@ def fold_weights(env_name: str, w_node: Tensor, w_out: Tensor, w_ctx: Tensor) ->
     wl_folded = w_out.t() @ wl  # logits = heads^T W_out^T (Wl h_j)
     if env_name == "tsp":
         return [wk, wv, wl_folded, w_ctx[:, :d], w_ctx[:, d : 2 * d]]
-    if env_name in ("cvrp", "op", "pctsp", "pdp"):  # current-node embedding (+ one scalar: capacity / remaining length / prize)
+    if env_name in ("cvrp", "op", "pctsp", "pdp", "cvrptw"):  # current-node embedding (+ one scalar: capacity / remaining length / prize)
         return [wk, wv, wl_folded, w_ctx[:, :d]]
     raise ValueError(f"fused decode supports tsp/cvrp/op, got {env_name!r}")
 
@@ -113,4 +114,5 @@ def build_folded_cache(
         ctx_first, ctx_cur = None, ctx[0]
         q_step0 = None
         w_cap = w_ctx.float()[:, d].contiguous() if w_ctx.shape[1] > d else None  # PDP: no context scalar
-    return FoldedCache(env_name, kvl, ctx_first, ctx_cur, q_bias, q_step0, w_cap)
+    w_time = w_ctx.float()[:, d + 1].contiguous() if w_ctx.shape[1] > d + 1 else None  # CVRPTW: current time
+    return FoldedCache(env_name, kvl, ctx_first, ctx_cur, q_bias, q_step0, w_cap, w_time)

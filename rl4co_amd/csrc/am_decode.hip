@@ -106,6 +106,7 @@ struct TrajState {
   int cur, first;
   long long step_i;
   float used;
+  float time;  // CVRPTW: current time
   bool done;
   uint32_t errbits;
   float ent_acc;
@@ -135,7 +136,8 @@ __device__ inline int build_list(const rl4co_am_decode_args& a, const uint8_t* m
 template <int ENV>
 __device__ inline int finalize_and_step(const rl4co_am_decode_args& a, TrajState& st, float* lg, const uint16_t* fl,
                                         int F, uint8_t* mk, uint8_t* vis, const float* dem, float cap, int r, int t,
-                                        int N, int lane, const float* oplocs = nullptr, const float* opmax = nullptr) {
+                                        int N, int lane, const float* oplocs = nullptr, const float* opmax = nullptr,
+                                        const float* twdur = nullptr) {
   bool nan_seen = false;
   float zmax = kNegInf;
   for (int c = lane; c < F; c += 64) {
@@ -278,6 +280,13 @@ __device__ inline int finalize_and_step(const rl4co_am_decode_args& a, TrajState
       mk[j] = (j == 0 || !(vis[j] != 0 || depot_visited || exceeds)) ? 1 : 0;
     }
   } else {
+    if (ENV == RL4CO_ENV_CVRPTW) {
+      // cvrptw/env.py:97-113 (oplocs = coordinates, opmax = (start, end) windows, twdur = service times): the
+      // clock advances by the distance from the node the vehicle stands on, waits for the window, serves
+      const float dx = oplocs[2 * bi] - oplocs[2 * st.cur], dy = oplocs[2 * bi + 1] - oplocs[2 * st.cur + 1];
+      const float served = fmaxf(st.time + sqrtf(fmaf(dy, dy, dx * dx)), opmax[2 * bi]) + twdur[bi];
+      st.time = (bi != 0 ? 1.0f : 0.0f) * served;
+    }
     const int di = min(max(bi - 1, 0), N - 2);                       // cvrp/env.py:71-73
     st.used = (st.used + dem[di]) * (bi != 0 ? 1.0f : 0.0f);         // cvrp/env.py:76
     st.cur = bi;
@@ -296,6 +305,14 @@ __device__ inline int finalize_and_step(const rl4co_am_decode_args& a, TrajState
     any_feasible = __any(any_feasible);
     st.done = __all(all_visited);  // cvrp/env.py:83
     if (lane == 0) mk[0] = ((st.cur == 0) && any_feasible) ? 0 : 1;  // cvrp/env.py:134-135
+    if (ENV == RL4CO_ENV_CVRPTW) {  // cvrptw/env.py:91-95: only nodes whose window is still open on arrival
+      wave_lds_sync();
+      const float bx = oplocs[2 * bi], by = oplocs[2 * bi + 1];
+      for (int j = lane; j < N; j += 64) {
+        const float dx = oplocs[2 * j] - bx, dy = oplocs[2 * j + 1] - by;
+        if (!(st.time + sqrtf(fmaf(dy, dy, dx * dx)) <= opmax[2 * j + 1])) mk[j] = 0;
+      }
+    }
   }
   wave_lds_sync();
   return bi;
@@ -343,7 +360,8 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
   // ---- load the trajectory state ---------------------------------------------------
   uint8_t* gmask = a.action_mask + (int64_t)r * N;
   for (int j = lane; j < Np; j += 64) mk[j] = (j < N) ? gmask[j] : (uint8_t)0;
-  constexpr bool kScalarCtx = ENV == RL4CO_ENV_CVRP || ENV == RL4CO_ENV_OP || ENV == RL4CO_ENV_PCTSP;
+  constexpr bool kScalarCtx = ENV == RL4CO_ENV_CVRP || ENV == RL4CO_ENV_OP || ENV == RL4CO_ENV_PCTSP || ENV == RL4CO_ENV_CVRPTW;
+  constexpr bool kCvrpLike = ENV == RL4CO_ENV_CVRP || ENV == RL4CO_ENV_CVRPTW;
   if (ENV == RL4CO_ENV_PDP) {  // bit 0 = available, bit 1 = to_deliver
     const uint8_t* gv = a.visited + (int64_t)r * N;
     const uint8_t* gt = a.to_deliver + (int64_t)r * N;
@@ -355,19 +373,23 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
   TrajState st;
   st.cur = (int)a.current_node[r];
   st.first = (ENV == RL4CO_ENV_TSP) ? (int)a.first_node[r] : 0;
-  st.step_i = (ENV != RL4CO_ENV_CVRP) ? a.step_i[r] : 0;
+  st.step_i = !kCvrpLike ? a.step_i[r] : 0;
+  st.time = (ENV == RL4CO_ENV_CVRPTW) ? a.current_time[r] : 0.0f;
   st.used = kScalarCtx ? a.used_capacity[r] : 0.0f;  // OP: tour length so far
   st.done = a.done[r] != 0;
   st.errbits = 0;
   st.ent_acc = 0.0f;
-  const float* oplocs = (ENV == RL4CO_ENV_OP) ? a.locs + (int64_t)cb * N * 2 : nullptr;
-  const float* opmax = (ENV == RL4CO_ENV_OP) ? a.max_length + (int64_t)cb * N : nullptr;
+  const float* oplocs = (ENV == RL4CO_ENV_OP || ENV == RL4CO_ENV_CVRPTW) ? a.locs + (int64_t)cb * N * 2 : nullptr;
+  const float* opmax = (ENV == RL4CO_ENV_OP)       ? a.max_length + (int64_t)cb * N
+                       : (ENV == RL4CO_ENV_CVRPTW) ? a.time_windows + (int64_t)cb * N * 2  // (start, end) per node
+                                                   : nullptr;
+  const float* twdur = (ENV == RL4CO_ENV_CVRPTW) ? a.durations + (int64_t)cb * N : nullptr;
   // the context scalar is cap - used in both depot environments (context.py:147-149, 211-213):
   // OP: longest tour that may still end at the depot (its row of the table) minus the tour so far
   // PCTSP: prize still to collect, clamped at 0 (context.py:184-198)
-  const float cap = (ENV == RL4CO_ENV_CVRP || ENV == RL4CO_ENV_PCTSP) ? a.vehicle_capacity[r]
+  const float cap = (kCvrpLike || ENV == RL4CO_ENV_PCTSP) ? a.vehicle_capacity[r]
                                                                       : ((ENV == RL4CO_ENV_OP) ? opmax[0] : 0.0f);
-  const float* dem = (ENV == RL4CO_ENV_CVRP)    ? a.demand + (int64_t)cb * (N - 1)
+  const float* dem = kCvrpLike                  ? a.demand + (int64_t)cb * (N - 1)
                      : (ENV == RL4CO_ENV_PCTSP) ? a.demand + (int64_t)cb * N
                                                 : nullptr;
   wave_lds_sync();
@@ -400,8 +422,11 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
       float rem = cap - st.used;  // context.py:147-149
       if (ENV == RL4CO_ENV_PCTSP && !(rem > 0.0f)) rem = 0.0f;
 #pragma unroll
-      for (int e = 0; e < EPL; ++e)
-        q[e] = fmaf(a.w_cap[e0 + e], rem, ctxc[(int64_t)st.cur * kD + e]) + qb[e];
+      for (int e = 0; e < EPL; ++e) {
+        float v = fmaf(a.w_cap[e0 + e], rem, ctxc[(int64_t)st.cur * kD + e]);
+        if (ENV == RL4CO_ENV_CVRPTW) v = fmaf(a.w_time[e0 + e], st.time, v);  // context.py:152-166
+        q[e] = v + qb[e];
+      }
     }
 #pragma unroll
     for (int e = 0; e < EPL; ++e) q[e] = q[e] * 0.25f;  // 1/sqrt(16), exact
@@ -495,7 +520,7 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
     }
     wave_lds_sync();
 
-    finalize_and_step<ENV>(a, st, lg, fl, F, mk, vis, dem, cap, r, t, N, lane, oplocs, opmax);
+    finalize_and_step<ENV>(a, st, lg, fl, F, mk, vis, dem, cap, r, t, N, lane, oplocs, opmax, twdur);
   }
   if (!single && !st.done && t >= a.max_steps) st.errbits |= RL4CO_EBIT_MAX_STEPS;
 
@@ -516,7 +541,8 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
     a.current_node[r] = st.cur;
     a.done[r] = st.done ? 1 : 0;
     if (ENV == RL4CO_ENV_TSP) a.first_node[r] = st.first;
-    if (ENV != RL4CO_ENV_CVRP) a.step_i[r] = st.step_i;
+    if (!kCvrpLike) a.step_i[r] = st.step_i;
+    if (ENV == RL4CO_ENV_CVRPTW) a.current_time[r] = st.time;
     if (kScalarCtx) a.used_capacity[r] = st.used;
     if (a.n_steps) a.n_steps[r] = t;
     if (a.steps_summary) {
@@ -835,7 +861,7 @@ int launch_wide(const rl4co_am_decode_args& a, hipStream_t stream) {
 // Which kernel serves these arguments (rules from measurements on MI355X, see the kernel headers).
 inline int resolve_variant(const rl4co_am_decode_args& a) {
   // the orienteering transition (distance-based mask) exists in the streaming kernel only
-  if (a.env == RL4CO_ENV_OP || a.env == RL4CO_ENV_PCTSP || a.env == RL4CO_ENV_PDP) return (a.variant == RL4CO_VARIANT_AUTO || a.variant == RL4CO_VARIANT_STREAM) ? RL4CO_VARIANT_STREAM : -1;
+  if (a.env == RL4CO_ENV_OP || a.env == RL4CO_ENV_PCTSP || a.env == RL4CO_ENV_PDP || a.env == RL4CO_ENV_CVRPTW) return (a.variant == RL4CO_VARIANT_AUTO || a.variant == RL4CO_VARIANT_STREAM) ? RL4CO_VARIANT_STREAM : -1;
   const bool bf16 = a.cache_dtype == RL4CO_DT_BF16;
   // multistart on the matrix cores (am_decode_ms.hip): bf16 planes, N <= 128, plain outputs
   const bool ms_ok = bf16 && a.N <= 128 && a.B_inst > 0 && a.all_logps == nullptr && a.entropy == nullptr;
@@ -891,7 +917,7 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
   RL4CO_REQUIRE(args != nullptr);
   const rl4co_am_decode_args& a = *args;
   RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP || a.env == RL4CO_ENV_OP ||
-                a.env == RL4CO_ENV_PCTSP || a.env == RL4CO_ENV_PDP);
+                a.env == RL4CO_ENV_PCTSP || a.env == RL4CO_ENV_PDP || a.env == RL4CO_ENV_CVRPTW);
   RL4CO_REQUIRE(a.B > 0 && a.B_inst > 0 && a.B % a.B_inst == 0);
   RL4CO_REQUIRE(a.N >= 2 && a.N <= 4096);
   RL4CO_REQUIRE(a.max_steps >= 1);
@@ -908,6 +934,9 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
     RL4CO_REQUIRE(a.ctx_first && a.q_step0 && a.first_node && a.step_i);
   } else if (a.env == RL4CO_ENV_CVRP) {
     RL4CO_REQUIRE(a.w_cap && a.demand && a.used_capacity && a.vehicle_capacity && a.visited);
+  } else if (a.env == RL4CO_ENV_CVRPTW) {
+    RL4CO_REQUIRE(a.w_cap && a.w_time && a.demand && a.used_capacity && a.vehicle_capacity && a.visited);
+    RL4CO_REQUIRE(a.locs && a.time_windows && a.durations && a.current_time);
   } else if (a.env == RL4CO_ENV_PDP) {
     RL4CO_REQUIRE(a.visited && a.to_deliver && a.step_i && (a.N - 1) % 2 == 0);
   } else if (a.env == RL4CO_ENV_PCTSP) {
@@ -928,6 +957,9 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
     return a.env == RL4CO_ENV_TSP ? launch_wide<RL4CO_ENV_TSP, false>(a, s)
                                   : launch_wide<RL4CO_ENV_CVRP, false>(a, s);
   }
+  if (a.env == RL4CO_ENV_CVRPTW)
+    return a.cache_dtype == RL4CO_DT_F32 ? launch<CacheF32, RL4CO_ENV_CVRPTW>(a, s)
+                                         : launch<CacheBF16, RL4CO_ENV_CVRPTW>(a, s);
   if (a.env == RL4CO_ENV_PDP)
     return a.cache_dtype == RL4CO_DT_F32 ? launch<CacheF32, RL4CO_ENV_PDP>(a, s) : launch<CacheBF16, RL4CO_ENV_PDP>(a, s);
   if (a.env == RL4CO_ENV_PCTSP)

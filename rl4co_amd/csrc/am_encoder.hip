@@ -218,10 +218,17 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
     const bool four = cvrp && a.feature4 != nullptr;  // PCTSP: (x, y, expected prize, penalty), init.py:283-312
     if (cvrp)
       for (int i = tid; i < N - 1; i += kThreads) lsh[2 * N + 1 + i] = a.demand[(int64_t)b * (N - 1) + i];
+    const bool six = four && a.feature5 != nullptr && a.feature6 != nullptr;  // CVRPTW: + tw start, tw end, service time
     if (four)
       for (int i = tid; i < N - 1; i += kThreads) lsh[3 * N + 1 + i] = a.feature4[(int64_t)b * (N - 1) + i];
+    if (six)
+      for (int i = tid; i < N - 1; i += kThreads) {
+        lsh[4 * N + 1 + i] = a.feature5[(int64_t)b * (N - 1) + i];
+        lsh[5 * N + 1 + i] = a.feature6[(int64_t)b * (N - 1) + i];
+      }
     const int d = tid & 127;
-    const int ws = (four || pdp) ? 4 : (cvrp ? 3 : 2);  // row stride of w_init
+    const int ws = six ? 6 : ((four || pdp) ? 4 : (cvrp ? 3 : 2));  // row stride of w_init
+    const float w5 = six ? a.w_init[ws * d + 4] : 0.0f, w6 = six ? a.w_init[ws * d + 5] : 0.0f;
     const float wx = a.w_init[ws * d], wy = a.w_init[ws * d + 1];
     const float wd = depot ? a.w_init[ws * d + 2] : 0.0f, bi = a.b_init[d];
     const float wp = (four || pdp) ? a.w_init[ws * d + 3] : 0.0f;
@@ -236,6 +243,9 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         else if (pdp && tok <= half)
           v = fmaf(wp, lsh[2 * (tok + half) + 1], fmaf(wd, lsh[2 * (tok + half)], fmaf(wy, y, fmaf(wx, x, bi))));
         else if (pdp) v = fmaf(ey, y, fmaf(ex, x, eb));
+        else if (six)
+          v = fmaf(w6, lsh[5 * N + tok],
+                   fmaf(w5, lsh[4 * N + tok], fmaf(wp, lsh[3 * N + tok], fmaf(wd, lsh[2 * N + tok], fmaf(wy, y, fmaf(wx, x, bi))))));
         else if (four) v = fmaf(wp, lsh[3 * N + tok], fmaf(wd, lsh[2 * N + tok], fmaf(wy, y, fmaf(wx, x, bi))));
         else if (cvrp) v = fmaf(wd, lsh[2 * N + tok], fmaf(wy, y, fmaf(wx, x, bi)));
         else v = fmaf(wy, y, fmaf(wx, x, bi));

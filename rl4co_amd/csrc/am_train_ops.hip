@@ -602,9 +602,9 @@ namespace {
 __global__ void __launch_bounds__(256) init_embed_kernel(const float* __restrict__ feats, const float* __restrict__ W,
                                                          const float* __restrict__ b, int64_t M, int F, uint32_t* __restrict__ out) {
   const int tid = threadIdx.x, cp = tid & 63, q = tid >> 6;
-  float w0[4], w1[4];
+  float w0[6], w1[6];
 #pragma unroll
-  for (int f = 0; f < 4; ++f) {
+  for (int f = 0; f < 6; ++f) {
     w0[f] = f < F ? W[(2 * cp) * F + f] : 0.0f;
     w1[f] = f < F ? W[(2 * cp + 1) * F + f] : 0.0f;
   }
@@ -612,7 +612,7 @@ __global__ void __launch_bounds__(256) init_embed_kernel(const float* __restrict
   for (int64_t r = (int64_t)blockIdx.x * 4 + q; r < M; r += (int64_t)gridDim.x * 4) {
     float a0 = b0, a1 = b1;
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
+    for (int f = 0; f < 6; ++f) {
       if (f < F) {
         const float x = feats[r * F + f];
         a0 = fmaf(w0[f], x, a0);
@@ -625,7 +625,7 @@ __global__ void __launch_bounds__(256) init_embed_kernel(const float* __restrict
 }  // namespace
 
 extern "C" int rl4co_init_embed_bf16(const float* feats, const float* w, const float* b, int64_t M, int F, void* out, void* stream) {
-  RL4CO_REQUIRE(feats && w && b && out && M > 0 && F >= 1 && F <= 4);
+  RL4CO_REQUIRE(feats && w && b && out && M > 0 && F >= 1 && F <= 6);
   const int blocks = (int)min((int64_t)8192, (M + 3) / 4);
   hipLaunchKernelGGL(init_embed_kernel, dim3(blocks), dim3(256), 0, rl4co::as_stream(stream), feats, w, b, M, F,
                      static_cast<uint32_t*>(out));

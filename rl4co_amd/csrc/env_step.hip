@@ -221,6 +221,109 @@ __global__ void __launch_bounds__(64) op_check_kernel(const int64_t* __restrict_
   if (__any(over) && lane == 0) atomicOr(err, RL4CO_EBIT_MAX_LENGTH);
 }
 
+// ---- CVRP with time windows (envs/routing/cvrptw/env.py:83-113) -----------------------------------
+__global__ void __launch_bounds__(64) cvrptw_step_kernel(const int64_t* __restrict__ action, const float* __restrict__ demand,
+                                                         const float* __restrict__ locs, const float* __restrict__ tw,
+                                                         const float* __restrict__ dur, float* __restrict__ used_capacity,
+                                                         const float* __restrict__ vehicle_capacity,
+                                                         float* __restrict__ current_time, uint8_t* __restrict__ visited,
+                                                         int64_t* __restrict__ cur, uint8_t* __restrict__ mask,
+                                                         uint8_t* __restrict__ done, int B_inst, int N, int32_t* err) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int ib = b % B_inst;
+  const float* dem = demand + (int64_t)ib * (N - 1);
+  const float* lc = locs + (int64_t)ib * N * 2;
+  const float* w = tw + (int64_t)ib * N * 2;
+  const float* du = dur + (int64_t)ib * N;
+  uint8_t* vis = visited + (int64_t)b * N;
+  uint8_t* row = mask + (int64_t)b * N;
+  float used = used_capacity[b], now = current_time[b];
+  int c = (int)cur[b];
+  bool bad = false;
+  if (action != nullptr) {
+    int64_t a = action[b];
+    if (a < 0 || a >= N) {
+      bad = true;
+      a = 0;
+    }
+    now = (a != 0 ? 1.0f : 0.0f) * (fmaxf(now + op_dist(lc, c, (int)a), w[2 * a]) + du[a]);  // cvrptw/env.py:108-110
+    int64_t di = a - 1;
+    if (di < 0) di = 0;
+    if (di > N - 2) di = N - 2;
+    used = (used + dem[di]) * (a != 0 ? 1.0f : 0.0f);
+    c = (int)a;
+  }
+  const float thr = vehicle_capacity[b] + 1e-5f;
+  bool any_feasible = false, all_visited = true;
+  for (int j = lane; j < N; j += 64) {
+    uint8_t v = vis[j];
+    if (action != nullptr && j == c) {
+      v = 1;
+      vis[j] = 1;
+    }
+    all_visited &= v != 0;
+    if (j >= 1) {
+      const bool masked = (v != 0) || (dem[j - 1] + used > thr);
+      any_feasible |= !masked;  // the depot rule looks at capacity and visits only (CVRPEnv.get_action_mask)
+      row[j] = (!masked && (now + op_dist(lc, c, j) <= w[2 * j + 1])) ? 1 : 0;  // cvrptw/env.py:91-95
+    }
+  }
+  any_feasible = __any(any_feasible);
+  all_visited = __all(all_visited);
+  if (lane == 0) {
+    row[0] = (!((c == 0) && any_feasible) && (now + op_dist(lc, c, 0) <= w[1])) ? 1 : 0;
+    if (action != nullptr) {
+      used_capacity[b] = used;
+      current_time[b] = now;
+      cur[b] = c;
+      done[b] = all_visited ? 1 : 0;
+    }
+    if (bad && err) atomicOr(err, RL4CO_EBIT_INFEASIBLE);
+  }
+}
+
+// cvrptw/env.py:146-190 without its CVRP part (rl4co_cvrp_check_solution): instance-data assertions and the
+// deadline replay along the tour (trailing depot zeros are neutral: t stays 0 at the depot)
+__global__ void __launch_bounds__(64) cvrptw_check_kernel(const int64_t* __restrict__ actions, const float* __restrict__ locs,
+                                                          const float* __restrict__ tw, const float* __restrict__ dur,
+                                                          int B_inst, int N, int T, int32_t* __restrict__ err) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int ib = b % B_inst;
+  const float* lc = locs + (int64_t)ib * N * 2;
+  const float* w = tw + (int64_t)ib * N * 2;
+  const float* du = dur + (int64_t)ib * N;
+  const float max_time = tw[1];  // time_windows[..., 0, 1][0]: the depot's closing time of the FIRST instance
+  bool neg = false, ret = false, dneg = false, empty = false;
+  for (int j = lane; j < N; j += 64) {
+    neg |= !(w[2 * j] >= 0.0f) || !(w[2 * j + 1] >= 0.0f);
+    ret |= !((w[2 * j] + op_dist(lc, j, 0)) + du[j] <= max_time);
+    dneg |= !(du[j] >= 0.0f);
+    empty |= !(w[2 * j] < w[2 * j + 1]);
+  }
+  int bits = 0;
+  if (__any(neg)) bits |= RL4CO_EBIT_TW_NEGATIVE;
+  if (__any(ret)) bits |= RL4CO_EBIT_TW_RETURN;
+  if (__any(dneg)) bits |= RL4CO_EBIT_TW_DURATION;
+  if (__any(empty)) bits |= RL4CO_EBIT_TW_EMPTY;
+  if (lane == 0) {
+    const int64_t* act = actions + (int64_t)b * T;
+    float t = 0.0f;
+    int c = 0;
+    bool late = false;
+    for (int i = 0; i < T; ++i) {
+      int64_t nx = act[i];
+      if (nx < 0 || nx >= N) nx = 0;  // out of range is the CVRP check's finding
+      t = fmaxf(truncf(t + op_dist(lc, c, (int)nx)), w[2 * nx]);  // max((t + d).int(), tw_start)
+      late |= !(t <= w[2 * nx + 1]);
+      t = t + du[nx];
+      c = (int)nx;
+      if (c == 0) t = 0.0f;
+    }
+    if (late) bits |= RL4CO_EBIT_TW_DEADLINE;
+    if (bits) atomicOr(err, bits);
+  }
+}
+
 // ---- prize-collecting TSP (envs/routing/pctsp/env.py:62-91,141-148) ---------------------------
 __global__ void __launch_bounds__(64) pctsp_step_kernel(const int64_t* __restrict__ action,
                                                         const float* __restrict__ real_prize,
@@ -364,6 +467,31 @@ __global__ void __launch_bounds__(64) pdp_check_kernel(const int64_t* __restrict
 }
 
 }  // namespace
+
+extern "C" int rl4co_cvrptw_step(const int64_t* action, const float* demand, const float* locs, const float* time_windows,
+                                 const float* durations, float* used_capacity, const float* vehicle_capacity,
+                                 float* current_time, uint8_t* visited, int64_t* current_node, uint8_t* action_mask,
+                                 uint8_t* done, int B, int B_inst, int N, int32_t* err, void* stream) {
+  RL4CO_REQUIRE(demand && locs && time_windows && durations && used_capacity && vehicle_capacity && current_time);
+  RL4CO_REQUIRE(visited && current_node && action_mask && (action == nullptr || done != nullptr));
+  RL4CO_REQUIRE(B > 0 && B_inst > 0 && B % B_inst == 0 && N > 1);
+  hipLaunchKernelGGL(cvrptw_step_kernel, dim3(B), dim3(64), 0, rl4co::as_stream(stream), action, demand, locs, time_windows,
+                     durations, used_capacity, vehicle_capacity, current_time, visited, current_node, action_mask, done,
+                     B_inst, N, err);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
+extern "C" int rl4co_cvrptw_check_solution(const int64_t* actions, const float* locs, const float* time_windows,
+                                           const float* durations, int B, int B_inst, int N, int T, int32_t* err,
+                                           void* stream) {
+  RL4CO_REQUIRE(actions && locs && time_windows && durations && err);
+  RL4CO_REQUIRE(B > 0 && B_inst > 0 && B % B_inst == 0 && N > 1 && T >= 1);
+  hipLaunchKernelGGL(cvrptw_check_kernel, dim3(B), dim3(64), 0, rl4co::as_stream(stream), actions, locs, time_windows,
+                     durations, B_inst, N, T, err);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
 
 extern "C" int rl4co_pdp_step(const int64_t* action, uint8_t* available, uint8_t* to_deliver, int64_t* current_node,
                               int64_t* step_i, uint8_t* action_mask, uint8_t* done, int B, int N, int32_t* err, void* stream) {

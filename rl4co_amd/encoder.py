@@ -24,7 +24,7 @@ class AmEncoderArgs(C.Structure):
 
     _fields_ = [
         ("env", _i32), ("B", _i32), ("N", _i32), ("num_layers", _i32), ("norm", _i32), ("cache_dtype", _i32),
-        ("locs", _vp), ("demand", _vp), ("feature4", _vp), ("w_init", _vp), ("b_init", _vp), ("w_depot", _vp), ("b_depot", _vp), ("w_extra", _vp), ("b_extra", _vp),
+        ("locs", _vp), ("demand", _vp), ("feature4", _vp), ("feature5", _vp), ("feature6", _vp), ("w_init", _vp), ("b_init", _vp), ("w_depot", _vp), ("b_depot", _vp), ("w_extra", _vp), ("b_extra", _vp),
         ("wqkv_packed", _vp), ("bqkv", _vp), ("wo_packed", _vp), ("bo", _vp), ("n1_scale", _vp), ("n1_shift", _vp),
         ("w1_packed", _vp), ("b1", _vp), ("w2_packed", _vp), ("b2", _vp), ("n2_scale", _vp), ("n2_shift", _vp),
         ("wfold_packed", _vp), ("w_fixed", _vp),
@@ -114,6 +114,7 @@ class PackedEncoder:
         else:
             t["q_step0"] = None
             t["w_cap"] = w_ctx[:, EMBED_DIM].contiguous() if w_ctx.shape[1] > EMBED_DIM else None  # PDP: no scalar
+        t["w_time"] = w_ctx[:, EMBED_DIM + 1].contiguous() if w_ctx.shape[1] > EMBED_DIM + 1 else None  # CVRPTW
         self.num_layers = len(layers)
         self.t, self.version = t, ver
         return t
@@ -148,16 +149,21 @@ class PackedEncoder:
         a.cache_dtype = _lib.DT_BF16 if cache_dtype == torch.bfloat16 else _lib.DT_F32
         a.locs = locs.data_ptr()
         ptr = lambda x: None if x is None else x.data_ptr()  # noqa: E731
-        if pol.env_name in ("cvrp", "op", "pctsp"):
+        if pol.env_name in ("cvrp", "op", "pctsp", "cvrptw"):
             # OP embeds the customers' prize where CVRP embeds their demand (init.py:115-136, 254-280);
             # PCTSP the expected prize and, as a fourth feature, the penalty (init.py:283-312)
-            third = {"cvrp": "demand", "op": "prize", "pctsp": "expected_prize"}[pol.env_name]
+            third = {"cvrp": "demand", "op": "prize", "pctsp": "expected_prize", "cvrptw": "demand"}[pol.env_name]
             third = td[third][..., 1:] if pol.env_name == "op" else td[third]
             demand = third.float().contiguous()
             a.demand, a.w_depot, a.b_depot = demand.data_ptr(), ptr(t["w_depot"]), ptr(t["b_depot"])
             if pol.env_name == "pctsp":
                 penalty = td["penalty"][..., 1:].float().contiguous()
                 a.feature4 = penalty.data_ptr()
+            if pol.env_name == "cvrptw":  # init.py:139-153: + tw start, tw end, service time
+                tw0 = td["time_windows"][..., 1:, 0].float().contiguous()
+                tw1 = td["time_windows"][..., 1:, 1].float().contiguous()
+                dur = td["durations"][..., 1:].float().contiguous()
+                a.feature4, a.feature5, a.feature6 = tw0.data_ptr(), tw1.data_ptr(), dur.data_ptr()
         if pol.env_name == "pdp":
             a.w_depot, a.b_depot = ptr(t["w_depot"]), ptr(t["b_depot"])
             a.w_extra, a.b_extra = ptr(t["w_extra"]), ptr(t["b_extra"])
@@ -170,5 +176,5 @@ class PackedEncoder:
         a.ctx_first, a.ctx_cur, a.q_bias, a.hidden = ptr(ctx_first), ptr(ctx_cur), ptr(q_bias), ptr(hidden)
         st = _lib.lib().rl4co_am_encoder(C.byref(a), torch.cuda.current_stream().cuda_stream)
         _lib.check(st, "rl4co_am_encoder")
-        cache = FoldedCache(pol.env_name, kvl, ctx_first, ctx_cur, q_bias, t["q_step0"], t["w_cap"])
+        cache = FoldedCache(pol.env_name, kvl, ctx_first, ctx_cur, q_bias, t["q_step0"], t["w_cap"], t["w_time"])
         return cache, hidden

@@ -91,6 +91,55 @@ class CVRPGenerator(TSPGenerator):
         )
 
 
+class CVRPTWGenerator(CVRPGenerator):
+    """cvrptw/generator.py:13-158: CVRP data (depot sampled on its own) plus integer-valued time windows inside
+    [distance from the depot, max_time - distance back] and zero service times; unscaled unless ``scale``"""
+
+    def __init__(self, num_loc: int = 20, min_loc: float = 0.0, max_loc: float = 150.0, min_demand: int = 1,
+                 max_demand: int = 10, vehicle_capacity: float = 1.0, capacity: float | None = None,
+                 max_time: float = 480, scale: bool = False, device="cpu", **unused):
+        super().__init__(num_loc, min_loc, max_loc, min_demand, max_demand, vehicle_capacity, capacity, device)
+        self.min_time, self.max_time, self.scale = 0.0, max_time, scale
+
+    def _generate(self, batch_size) -> TensorDict:
+        depot = self._uniform((*batch_size, 2), self.min_loc, self.max_loc)
+        locs = self._uniform((*batch_size, self.num_loc, 2), self.min_loc, self.max_loc)
+        demand = self._uniform((*batch_size, self.num_loc), self.min_demand - 1, self.max_demand - 1)
+        demand = (demand.int() + 1).float()
+        dev = locs.device
+        capacity = torch.full((*batch_size, 1), self.capacity, device=dev)
+        durations = torch.zeros(*batch_size, self.num_loc + 1, dtype=torch.float32, device=dev)
+        dist = (depot[..., None, :] - locs).norm(p=2, dim=-1)
+        dist = torch.cat((torch.zeros(*batch_size, 1, device=dev), dist), dim=-1)
+        upper_bound = self.max_time - dist - durations
+        if str(self.device) == "cpu":
+            ts_1, ts_2 = torch.rand(*batch_size, self.num_loc + 1), torch.rand(*batch_size, self.num_loc + 1)
+        else:
+            ts_1 = torch.rand(*batch_size, self.num_loc + 1, device=dev)
+            ts_2 = torch.rand(*batch_size, self.num_loc + 1, device=dev)
+        min_ts = (dist + (upper_bound - dist) * ts_1).int()
+        max_ts = (dist + (upper_bound - dist) * ts_2).int()
+        min_times, max_times = torch.min(min_ts, max_ts), torch.max(min_ts, max_ts)
+        min_times[..., 0] = 0
+        max_times[..., 0] = int(self.max_time)
+        mask = min_times == max_times  # cvrptw/generator.py:113-133: windows must not be empty
+        if bool(mask.any()):
+            min_times = torch.where(mask, torch.max(dist.int(), min_times - 1), min_times)
+            mask = min_times == max_times
+            if bool(mask.any()):
+                widened = torch.min(torch.floor(upper_bound).int(),
+                                    torch.max(torch.ceil(min_times + durations).int(), max_times + 1))
+                max_times = torch.where(mask, widened, max_times)
+        if self.scale:
+            durations, min_times, max_times = durations / self.max_time, min_times / self.max_time, max_times / self.max_time
+            depot, locs = depot / self.max_time, locs / self.max_time
+        time_windows = torch.stack((min_times, max_times), dim=-1)
+        assert bool((min_times < max_times).all()), \
+            "Please make sure the relation between max_loc and max_time allows for feasible solutions."
+        return TensorDict({"locs": locs, "depot": depot, "demand": demand / self.capacity, "capacity": capacity,
+                           "durations": durations, "time_windows": time_windows}, batch_size=batch_size)
+
+
 OP_MAX_LENGTHS = {20: 2.0, 50: 3.0, 100: 4.0}  # op/generator.py:13
 
 
@@ -327,6 +376,59 @@ class CVRPEnv(RL4COEnvBase):
             K.raise_if_error(err)
 
 
+class CVRPTWEnv(CVRPEnv):
+    """CVRP with time windows (envs/routing/cvrptw/env.py:16-199): a customer can only be entered while its window
+    is open on arrival; the vehicle waits for the window to open, serves, and the clock restarts at the depot.
+    ``time_windows`` keeps the generator's dtype (integers unless scaled); the kernels read fp32 copies
+    (exact: the values are below 2**24)."""
+
+    name = "cvrptw"
+
+    def _default_generator(self, **kw):
+        return CVRPTWGenerator(**kw)
+
+    @staticmethod
+    def _tw(td):
+        return td["time_windows"].float().contiguous(), td["durations"].float().contiguous()
+
+    def _reset(self, td: TensorDict, batch_size) -> TensorDict:
+        """cvrptw/env.py:115-139"""
+        td_reset = super()._reset(td, batch_size)
+        b = td["locs"].shape[0]
+        td_reset.set("current_time", torch.zeros(b, 1, dtype=torch.float32, device=td["locs"].device))
+        td_reset.set("durations", td["durations"])
+        td_reset.set("time_windows", td["time_windows"])
+        self.get_action_mask(td_reset)
+        return td_reset
+
+    def _step(self, td: TensorDict) -> TensorDict:
+        """cvrptw/env.py:97-113 then cvrp/env.py:66-96, one kernel (rl4co_cvrptw_step), in place"""
+        tw, dur = self._tw(td)
+        K.cvrptw_step(td["action"].contiguous(), td["demand"], td["locs"], tw, dur, td["used_capacity"],
+                      td["vehicle_capacity"], td["current_time"], td["visited"], td["current_node"], td["action_mask"],
+                      td["done"])
+        return td
+
+    def get_action_mask(self, td: TensorDict) -> Tensor:
+        """cvrptw/env.py:83-95 (recomputed in place into td['action_mask'])"""
+        if "time_windows" not in td.keys():  # CVRPEnv._reset asks for the mask before the windows are attached
+            return super().get_action_mask(td)
+        tw, dur = self._tw(td)
+        K.cvrptw_step(None, td["demand"], td["locs"], tw, dur, td["used_capacity"], td["vehicle_capacity"],
+                      td["current_time"], td["visited"], td["current_node"], td["action_mask"], None)
+        return td["action_mask"]
+
+    def check_solution_validity(self, td: TensorDict, actions: Tensor, err: Tensor | None = None) -> None:
+        """cvrptw/env.py:146-190: the CVRP check, then the window data assertions and the deadline replay"""
+        own = err is None
+        err = K.new_error_word(actions.device) if own else err
+        super().check_solution_validity(td, actions, err=err)
+        tw, dur = self._tw(td)
+        K.cvrptw_check_solution(actions.contiguous(), td["locs"].contiguous(), tw, dur, err)
+        if own:
+            K.raise_if_error(err)
+
+
 class OPEnv(RL4COEnvBase):
     """Orienteering problem (envs/routing/op/env.py:16-194): collect prizes and be back at the depot
     within ``max_length``. State and arithmetic live in ``rl4co_op_*`` (csrc/env_step.hip)."""
@@ -543,4 +645,4 @@ class PDPEnv(RL4COEnvBase):
 
 
 def get_env(name: str, **kw) -> RL4COEnvBase:
-    return {"tsp": TSPEnv, "cvrp": CVRPEnv, "op": OPEnv, "pctsp": PCTSPEnv, "pdp": PDPEnv}[name](**kw)
+    return {"tsp": TSPEnv, "cvrp": CVRPEnv, "op": OPEnv, "pctsp": PCTSPEnv, "pdp": PDPEnv, "cvrptw": CVRPTWEnv}[name](**kw)

@@ -15,7 +15,7 @@ from . import _lib
 from .cache import FoldedCache
 
 MODE_IDS = {"greedy": _lib.DECODE_GREEDY, "sampling": _lib.DECODE_SAMPLE, "evaluate": _lib.DECODE_EVALUATE}
-ENV_IDS = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP, "op": _lib.ENV_OP, "pctsp": _lib.ENV_PCTSP, "pdp": _lib.ENV_PDP}
+ENV_IDS = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP, "op": _lib.ENV_OP, "pctsp": _lib.ENV_PCTSP, "pdp": _lib.ENV_PDP, "cvrptw": _lib.ENV_CVRPTW}
 VARIANT_IDS = {"auto": _lib.VARIANT_AUTO, "stream": _lib.VARIANT_STREAM, "lds": _lib.VARIANT_LDS, "wide": _lib.VARIANT_WIDE, "ms": _lib.VARIANT_MS}
 
 
@@ -241,6 +241,13 @@ def am_decode(
         a.step_i = _ptr(_dev(state["i"], torch.int64, "i"))
         a.visited = _ptr(_u8(state["visited"], "visited"))
     else:
+        if env_name == "cvrptw":  # CVRP + clock: coordinates, (start, end) windows, service times as fp32 instance data
+            a.w_time = _ptr(_dev(cache.w_time, torch.float32, "w_time"))
+            a.locs = _ptr(_dev(state["locs"], torch.float32, "locs"))
+            a.time_windows = _ptr(_dev(state["time_windows"], torch.float32, "time_windows"))
+            a.durations = _ptr(_dev(state["durations"], torch.float32, "durations"))
+            a.current_time = _ptr(_dev(state["current_time"], torch.float32, "current_time"))
+            assert state["time_windows"].shape == (cache.num_instances, n, 2)
         a.w_cap = _ptr(_dev(cache.w_cap, torch.float32, "w_cap"))
         a.demand = _ptr(_dev(state["demand"], torch.float32, "demand"))
         assert state["demand"].shape[0] in (cache.num_instances,), "demand rows must match cache instances"
@@ -291,6 +298,33 @@ def op_step(action: Tensor | None, locs: Tensor, max_length: Tensor, tour_length
         _ptr(_dev(step_i, torch.int64, "i")), _ptr(_u8(action_mask, "action_mask")), _ptr(_u8(done, "done")),
         b, locs.shape[0], n, _ptr(err), _stream())
     _lib.check(st, "rl4co_op_step")
+
+
+def cvrptw_step(action: Tensor | None, demand: Tensor, locs: Tensor, time_windows: Tensor, durations: Tensor,
+                used_capacity: Tensor, vehicle_capacity: Tensor, current_time: Tensor, visited: Tensor, current_node: Tensor,
+                action_mask: Tensor, done: Tensor | None, err: Tensor | None = None) -> None:
+    """In-place CVRPTWEnv._step + get_action_mask (cvrptw/env.py:83-113); action=None -> mask only.
+    ``time_windows`` [B_inst,N,2] and ``durations`` [B_inst,N] are fp32 (the reference's integer windows cast)."""
+    b, n = action_mask.shape
+    st = _lib.lib().rl4co_cvrptw_step(
+        _ptr(None if action is None else _dev(action, torch.int64, "action")), _ptr(_dev(demand, torch.float32, "demand")),
+        _ptr(_dev(locs, torch.float32, "locs")), _ptr(_dev(time_windows, torch.float32, "time_windows")),
+        _ptr(_dev(durations, torch.float32, "durations")), _ptr(_dev(used_capacity, torch.float32, "used_capacity")),
+        _ptr(_dev(vehicle_capacity, torch.float32, "vehicle_capacity")), _ptr(_dev(current_time, torch.float32, "current_time")),
+        _ptr(_u8(visited, "visited")), _ptr(_dev(current_node, torch.int64, "current_node")),
+        _ptr(_u8(action_mask, "action_mask")), _ptr(None if done is None else _u8(done, "done")),
+        b, demand.shape[0], n, _ptr(err), _stream())
+    _lib.check(st, "rl4co_cvrptw_step")
+
+
+def cvrptw_check_solution(actions: Tensor, locs: Tensor, time_windows: Tensor, durations: Tensor, err: Tensor) -> None:
+    """cvrptw/env.py:151-190 (the part on top of the CVRP check) into the sticky error word."""
+    b, t = actions.shape
+    st = _lib.lib().rl4co_cvrptw_check_solution(
+        _ptr(_dev(actions, torch.int64, "actions")), _ptr(_dev(locs, torch.float32, "locs")),
+        _ptr(_dev(time_windows, torch.float32, "time_windows")), _ptr(_dev(durations, torch.float32, "durations")),
+        b, locs.shape[0], locs.shape[1], t, _ptr(_dev(err, torch.int32, "err")), _stream())
+    _lib.check(st, "rl4co_cvrptw_check_solution")
 
 
 def pdp_step(action: Tensor | None, available: Tensor, to_deliver: Tensor, current_node: Tensor, step_i: Tensor,

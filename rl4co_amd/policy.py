@@ -249,6 +249,34 @@ class _PCTSPInit(nn.Module):
         return torch.cat((self.init_embed_depot(locs[:, :1, :]), self.init_embed(feats)), -2)
 
 
+class _VRPTWInit(nn.Module):
+    """env_embeddings/init.py:139-153: customers (x, y, demand, tw start, tw end, service time), depot (x, y)"""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.init_embed = nn.Linear(6, embed_dim, True)
+        self.init_embed_depot = nn.Linear(2, embed_dim, True)
+
+    def forward(self, td):
+        locs = td["locs"]
+        feats = torch.cat((locs[:, 1:, :], td["demand"][..., None], td["time_windows"][..., 1:, :].to(locs.dtype),
+                           td["durations"][..., 1:, None].to(locs.dtype)), -1)
+        if _train_kernels_active(locs):
+            from . import train_ops
+
+            return torch.cat((train_ops.init_embed(locs[:, :1, :], self.init_embed_depot),
+                              train_ops.init_embed(feats, self.init_embed)), -2)
+        return torch.cat((self.init_embed_depot(locs[:, :1, :]), self.init_embed(feats)), -2)
+
+
+class _VRPTWContext(nn.Module):
+    """env_embeddings/context.py:152-166: current node embedding, remaining capacity, current time"""
+
+    def __init__(self, embed_dim):
+        super().__init__()
+        self.project_context = nn.Linear(embed_dim + 2, embed_dim, bias=False)
+
+
 class _PDPInit(nn.Module):
     """env_embeddings/init.py:335-360: depot (x, y) | pickups (x, y, x', y' of the delivery) | deliveries (x, y)"""
 
@@ -289,7 +317,7 @@ class AttentionModelEncoder(nn.Module):
         super().__init__()
         self.env_name = env_name
         self.init_embedding = {"tsp": _TSPInit, "cvrp": _VRPInit, "op": _OPInit, "pctsp": _PCTSPInit,
-                               "pdp": _PDPInit}[env_name](embed_dim)
+                               "pdp": _PDPInit, "cvrptw": _VRPTWInit}[env_name](embed_dim)
         self.net = _GraphAttentionNetwork(num_heads, embed_dim, num_layers, normalization, feedforward_hidden)
 
     def forward(self, td):
@@ -334,7 +362,7 @@ class AttentionModelDecoder(nn.Module):
         self.mask_inner = mask_inner
         self.check_nan = check_nan
         self.context_embedding = {"tsp": _TSPContext, "cvrp": _VRPContext, "op": _VRPContext, "pctsp": _VRPContext,
-                                  "pdp": _NodeContext}[env_name](embed_dim)
+                                  "pdp": _NodeContext, "cvrptw": _VRPTWContext}[env_name](embed_dim)
         self.dynamic_embedding = nn.Module()  # StaticEmbedding (dynamic.py:47-57): no parameters
         self.pointer = _Pointer(embed_dim)
         self.project_node_embeddings = nn.Linear(embed_dim, 3 * embed_dim, bias=False)
@@ -440,6 +468,11 @@ class AttentionModelPolicy(nn.Module):
         init = enc.init_embedding
         if self.env_name == "pdp":
             x = torch.cat([T.init_embed(f.contiguous(), lin) for f, lin in init.features(td)], -2)
+        elif self.env_name == "cvrptw":
+            locs = td["locs"]
+            feats = torch.cat((locs[:, 1:, :], td["demand"][..., None], td["time_windows"][..., 1:, :].float(),
+                               td["durations"][..., 1:, None].float()), -1)
+            x = torch.cat((T.init_embed(locs[:, :1, :], init.init_embed_depot), T.init_embed(feats, init.init_embed)), -2)
         elif self.env_name in ("cvrp", "op", "pctsp"):
             locs = td["locs"]
             third = {"cvrp": "demand", "op": "prize", "pctsp": "expected_prize"}[self.env_name]
@@ -524,8 +557,13 @@ class AttentionModelPolicy(nn.Module):
             st["used_capacity"] = rep(td["used_capacity"].reshape(-1))
             st["vehicle_capacity"] = rep(td["vehicle_capacity"].reshape(-1))
             st["visited"] = rep(td["visited"])
+            if self.env_name == "cvrptw":  # instance data as fp32 (the reference keeps integer-valued windows)
+                st["locs"] = td["locs"].contiguous()
+                st["time_windows"] = td["time_windows"].float().contiguous()
+                st["durations"] = td["durations"].float().contiguous()
+                st["current_time"] = rep(td["current_time"].reshape(-1))
         if s == 1:
-            st = {k: (v.clone() if k not in ("demand", "locs", "max_length", "real_prize") else v) for k, v in st.items()}
+            st = {k: (v.clone() if k not in ("demand", "locs", "max_length", "real_prize", "time_windows", "durations") else v) for k, v in st.items()}
         return st
 
     # -- forward (constructive/base.py:154-263) ---------------------------------------------------
@@ -726,6 +764,10 @@ class AttentionModelPolicy(nn.Module):
         elif self.env_name == "op":
             K.op_step(action, state["locs"], state["max_length"], state["tour_length"], state["visited"],
                       state["current_node"], state["i"], state["action_mask"], state["done"], err)
+        elif self.env_name == "cvrptw":
+            K.cvrptw_step(action, state["demand"], state["locs"], state["time_windows"], state["durations"],
+                          state["used_capacity"], state["vehicle_capacity"], state["current_time"], state["visited"],
+                          state["current_node"], state["action_mask"], state["done"], err)
         elif self.env_name == "pdp":
             K.pdp_step(action, state["available"], state["to_deliver"], state["current_node"], state["i"],
                        state["action_mask"], state["done"], err)
@@ -763,6 +805,9 @@ class AttentionModelPolicy(nn.Module):
             out.update(demand=rep(td["demand"]), current_node=state["current_node"].view(-1, 1),
                        used_capacity=state["used_capacity"].view(-1, 1),
                        vehicle_capacity=state["vehicle_capacity"].view(-1, 1), visited=state["visited"])
+            if self.env_name == "cvrptw":
+                out.update(time_windows=rep(td["time_windows"]), durations=rep(td["durations"]),
+                           current_time=state["current_time"].view(-1, 1))
         return TensorDict(out, batch_size=[s * b_inst])
 
     # -- teacher-forced, differentiable re-evaluation (row N1 of SURVEY.md §8f) -------------------
@@ -791,7 +836,12 @@ class AttentionModelPolicy(nn.Module):
         else:
             (prev,) = ctx_nodes
             cur = h.gather(1, prev[..., None].expand(b, t_len, d))
-            ctx = cur if self.env_name == "pdp" else torch.cat([cur, extras[..., None]], -1)  # + remaining capacity
+            if self.env_name == "pdp":
+                ctx = cur
+            elif self.env_name == "cvrptw":
+                ctx = torch.cat([cur, extras], -1)  # + remaining capacity, current time
+            else:
+                ctx = torch.cat([cur, extras[..., None]], -1)  # + remaining capacity
         q = F.linear(ctx, w_ctx)
         if dec.use_graph_context:
             g = dec.project_fixed_context(hidden.mean(1))
@@ -834,6 +884,7 @@ class AttentionModelPolicy(nn.Module):
             use_ph = torch.empty((b, t_len), dtype=torch.bool, device=device)
         else:
             rem = torch.empty((b, t_len), dtype=torch.float32, device=device)
+            now = torch.empty((b, t_len), dtype=torch.float32, device=device) if self.env_name == "cvrptw" else None
         for t in range(t_len):
             masks[:, t] = state["action_mask"]
             prev[:, t] = state["current_node"]
@@ -849,7 +900,9 @@ class AttentionModelPolicy(nn.Module):
                 pass  # no context scalar
             else:
                 rem[:, t] = state["vehicle_capacity"] - state["used_capacity"]
+                if now is not None:
+                    now[:, t] = state["current_time"]
             self._env_step_state(state, actions[:, t].contiguous(), err)
         if self.env_name == "tsp":
             return masks, (first, prev), use_ph
-        return masks, (prev,), rem
+        return masks, (prev,), (rem if self.env_name != "cvrptw" else torch.stack((rem, now), -1))

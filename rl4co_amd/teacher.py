@@ -44,7 +44,8 @@ def max_nodes() -> int:
 
 
 def supports(env_name: str, cache_dtype: torch.dtype, num_nodes: int) -> bool:
-    """TSP / CVRP: both variants; orienteering and prize-collecting TSP: the MMA variant only (bf16 planes)."""
+    """TSP / CVRP: both variants; orienteering, prize-collecting TSP, pickup-delivery: the MMA variant only (bf16
+    planes); CVRP with time windows: not served (the policy falls back to the dense torch re-evaluation)."""
     if num_nodes > max_nodes():
         return False
     return env_name in ("tsp", "cvrp") or (env_name in ("op", "pctsp", "pdp") and cache_dtype == torch.bfloat16)

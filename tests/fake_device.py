@@ -58,6 +58,30 @@ def _pctsp_check(actions, real_prize, err):
         err |= 64 if "Duplicates" in str(e) else 256
 
 
+def _cvrptw_step(action, demand, locs, time_windows, durations, used_capacity, vehicle_capacity, current_time, visited,
+                 current_node, action_mask, done, err=None):
+    c_oracle.cvrptw_step(None if action is None else action.contiguous(), demand, locs, time_windows, durations,
+                         used_capacity, vehicle_capacity, current_time, visited, current_node, action_mask, done)
+
+
+def _cvrptw_check(actions, locs, time_windows, durations, err):
+    from oracle import reference_torch as R
+
+    s = actions.shape[0] // locs.shape[0]
+    rep = (lambda x: R.batchify(x, s)) if s > 1 else (lambda x: x)
+    td = {"locs": rep(locs), "time_windows": rep(time_windows), "durations": rep(durations)}
+    orig = R.CVRPEnv.__dict__["check_solution_validity"]  # the staticmethod object itself
+    R.CVRPEnv.check_solution_validity = staticmethod(lambda td, actions: None)  # the CVRP part has its own stand-in
+    try:
+        R.CVRPTWEnv.check_solution_validity(td, actions)
+    except AssertionError as e:
+        msg = str(e)
+        err |= (4096 if "Time windows" in msg else 8192 if "get back" in msg else 16384 if "durations" in msg
+                else 32768 if "unfeasible" in msg else 65536)
+    finally:
+        R.CVRPEnv.check_solution_validity = orig
+
+
 def _pdp_step(action, available, to_deliver, current_node, step_i, action_mask, done, err=None):
     c_oracle.pdp_step(None if action is None else action.contiguous(), available, to_deliver, current_node, step_i,
                       action_mask, done)
@@ -123,6 +147,8 @@ def cpu_device(monkeypatch):
     monkeypatch.setattr(K, "op_max_length", c_oracle.op_max_length)
     monkeypatch.setattr(K, "gather_sum", lambda values, actions: c_oracle.gather_sum(values.contiguous(), actions.contiguous()))
     monkeypatch.setattr(K, "op_check_solution", _op_check)
+    monkeypatch.setattr(K, "cvrptw_step", _cvrptw_step)
+    monkeypatch.setattr(K, "cvrptw_check_solution", _cvrptw_check)
     monkeypatch.setattr(K, "pdp_step", _pdp_step)
     monkeypatch.setattr(K, "pdp_check_solution", _pdp_check)
     monkeypatch.setattr(K, "pctsp_step", _pctsp_step)

@@ -136,6 +136,11 @@ def rollout_state(env_name: str, td: dict, device="cpu", num_starts: int = 0) ->
         st["used_capacity"] = rep(td["used_capacity"].reshape(-1))
         st["vehicle_capacity"] = rep(td["vehicle_capacity"].reshape(-1))
         st["visited"] = rep(td["visited"])
+        if env_name == "cvrptw":
+            st["locs"] = td["locs"].to(device).contiguous()
+            st["time_windows"] = td["time_windows"].to(device).float().contiguous()
+            st["durations"] = td["durations"].to(device).float().contiguous()
+            st["current_time"] = rep(td["current_time"].reshape(-1))
     return st
 
 
@@ -155,6 +160,10 @@ def apply_step(mod, env_name: str, action: torch.Tensor, st: dict) -> None:
     elif env_name == "pctsp":
         mod.pctsp_step(action, st["real_prize"], st["cur_total_prize"], st["visited"], st["current_node"], st["i"],
                        st["action_mask"], st["done"])
+    elif env_name == "cvrptw":
+        mod.cvrptw_step(action, st["demand"], st["locs"], st["time_windows"], st["durations"], st["used_capacity"],
+                        st["vehicle_capacity"], st["current_time"], st["visited"], st["current_node"], st["action_mask"],
+                        st["done"])
     elif env_name == "pdp":
         mod.pdp_step(action, st["available"], st["to_deliver"], st["current_node"], st["i"], st["action_mask"], st["done"])
     else:
@@ -177,7 +186,7 @@ def oracle_reward(env_name: str, td0: dict, actions: torch.Tensor) -> torch.Tens
         every = torch.arange(1, n).expand(actions.shape[0], n - 1).contiguous()
         length = c_oracle.tour_length(td0["locs"], actions.contiguous(), prepend_depot=True, negate=False)
         return c_oracle.gather_sum(pen, actions.contiguous()) - (length + c_oracle.gather_sum(pen, every))
-    return c_oracle.tour_length(td0["locs"], actions, prepend_depot=(env_name in ("cvrp", "pdp")), negate=True)
+    return c_oracle.tour_length(td0["locs"], actions, prepend_depot=(env_name in ("cvrp", "pdp", "cvrptw")), negate=True)
 
 
 def kernel_reward(K, env_name: str, td0: dict, actions: torch.Tensor) -> torch.Tensor:
@@ -190,5 +199,25 @@ def kernel_reward(K, env_name: str, td0: dict, actions: torch.Tensor) -> torch.T
         every = torch.arange(1, n, device="cuda").expand(acts.shape[0], n - 1).contiguous()
         length = K.tour_length(td0["locs"].cuda(), acts, prepend_depot=True, negate=False)
         return K.gather_sum(pen, acts) - (length + K.gather_sum(pen, every))
-    return K.tour_length(td0["locs"].cuda(), actions.cuda().contiguous(), prepend_depot=(env_name in ("cvrp", "pdp")),
+    return K.tour_length(td0["locs"].cuda(), actions.cuda().contiguous(), prepend_depot=(env_name in ("cvrp", "pdp", "cvrptw")),
                          negate=True)
+
+
+def ll_rtol(env_name: str, gpu: bool = False) -> float:
+    """Relative tolerance of a rollout's summed log-likelihood against the reference (fp32 both sides, different
+    operation order: folded cache, specified-order reductions). 1e-5 for the normalised environments. CVRPTW feeds
+    unnormalised coordinates / times (up to 150 / 480) through the same fp32 arithmetic: queries and scores are
+    hundreds of times larger, so is their rounding noise (CPU fold, measured 2e-5 on one trajectory of cvrptw100:
+    bound 5e-5; cache folded by the GPU's GEMMs, whose summation order differs from oneDNN's, measured 7e-4 on one
+    trajectory of cvrptw20: bound 2e-3). Rewards of identical trajectories stay bit-identical everywhere."""
+    if env_name == "cvrptw":
+        return 2e-3 if gpu else 5e-5
+    return 1e-5
+
+
+def flip_budget(env_name: str, rows: int, gpu: bool = False) -> int:
+    """Trajectories that may leave the reference's at an fp32 near-tie: 1 % (2 % against the GPU-side encoder);
+    5 % for CVRPTW on the GPU (see ll_rtol: measured 2 of 64)."""
+    if env_name == "cvrptw" and gpu:
+        return max(1, rows // 20)
+    return max(1, rows // (50 if gpu else 100))

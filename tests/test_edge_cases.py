@@ -97,7 +97,7 @@ def test_shapes_bit_exact_gpu(env_name, num_loc, batch, dtype, variant):
     pol, env, td0, h = _setup(env_name, num_loc, batch)
     cache = fold_cache(pol, env_name, h, dtype, device="cuda")
     cache_cpu = type(cache)(cache.env_name, *(None if x is None else x.cpu().contiguous() for x in (
-        cache.kvl, cache.ctx_first, cache.ctx_cur, cache.q_bias, cache.q_step0, cache.w_cap)))
+        cache.kvl, cache.ctx_first, cache.ctx_cur, cache.q_bias, cache.q_step0, cache.w_cap, cache.w_time)))
     n = td0["action_mask"].shape[1]
     tmax = max_horizon(env_name, n)
     groups = K.decode_row_groups(n, dtype, tmax, variant, batch)

@@ -10,6 +10,7 @@ import torch
 
 from oracle import reference_torch as R
 from tests.fake_device import cpu_device  # noqa: F401  (fixture)
+from tests.helpers import ll_rtol  # noqa: E402
 from tests.helpers import GoldenCase, clone_td, manifest
 
 SMALL = sorted(c for c, m in manifest().items() if m["batch"] <= 128)
@@ -82,7 +83,7 @@ def test_policy_forward_matches_reference_golden(cpu_device, name):
     same = (out["actions"] == g.actions).all(1)
     assert int((~same).sum()) <= max(1, len(same) // 50)
     assert torch.equal(out["reward"][same], g.reward[same])
-    torch.testing.assert_close(out["log_likelihood"][same], g.log_likelihood[same], rtol=1e-5, atol=5e-5)
+    torch.testing.assert_close(out["log_likelihood"][same], g.log_likelihood[same], rtol=ll_rtol(g.env_name), atol=5e-5)
 
 
 def test_env_surface_step_by_step(cpu_device):
