@@ -424,6 +424,9 @@ typedef struct rl4co_am_teacher_args {
   const float* vehicle_capacity; /* [B_inst] CVRP                                   */
   const float* locs;             /* [B_inst,N,2] OP (MMA variant only)              */
   const float* max_length;       /* [B_inst,N] OP entry-limit table                 */
+  const float* time_windows;     /* [B_inst,N,2] CVRPTW (start, end), fp32 (MMA variant only; locs too) */
+  const float* durations;        /* [B_inst,N] CVRPTW service times                 */
+  const float* w_time;           /* [128] CVRPTW: W_ctx[:, 129]                     */
   const float* grad_logp;        /* [B,T]                                           */
   float* d_kvl;                  /* [3,B_inst,N,128]                                */
   float* d_ctx_first;            /* [B_inst,N,128] TSP, zero-initialised            */
@@ -431,6 +434,7 @@ typedef struct rl4co_am_teacher_args {
   float* d_q_bias;               /* [B_inst,128] or NULL                            */
   float* d_q_step0;              /* [128] TSP, zero-initialised                     */
   float* d_w_cap;                /* [128] CVRP, zero-initialised                    */
+  float* d_w_time;               /* [128] CVRPTW, zero-initialised                  */
   float* logp_out;               /* [B,T] forward values, or NULL                   */
   int32_t* err;
 } rl4co_am_teacher_args;

@@ -441,7 +441,7 @@ extern "C" int rl4co_am_teacher_max_nodes(void) { return 112; }
 
 static int validate_teacher(const rl4co_am_teacher_args& a) {
   RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP || a.env == RL4CO_ENV_OP ||
-                a.env == RL4CO_ENV_PCTSP || a.env == RL4CO_ENV_PDP);
+                a.env == RL4CO_ENV_PCTSP || a.env == RL4CO_ENV_PDP || a.env == RL4CO_ENV_CVRPTW);
   RL4CO_REQUIRE(a.B > 0 && a.B_inst > 0 && a.B % a.B_inst == 0);
   RL4CO_REQUIRE(a.N >= 2 && a.N <= 112 && a.T >= 1 && a.t0 >= 0 && a.t0 <= 1);
   RL4CO_REQUIRE(a.cache_dtype == RL4CO_DT_F32 || a.cache_dtype == RL4CO_DT_BF16);
@@ -454,6 +454,9 @@ static int validate_teacher(const rl4co_am_teacher_args& a) {
     RL4CO_REQUIRE(a.ctx_first && a.q_step0 && a.d_ctx_first && a.d_q_step0);
   } else if (a.env == RL4CO_ENV_CVRP || a.env == RL4CO_ENV_PCTSP) {  // PCTSP: real prize [B_inst,N], prize_required
     RL4CO_REQUIRE(a.w_cap && a.demand && a.vehicle_capacity && a.d_w_cap);
+  } else if (a.env == RL4CO_ENV_CVRPTW) {
+    RL4CO_REQUIRE(a.w_cap && a.demand && a.vehicle_capacity && a.d_w_cap);
+    RL4CO_REQUIRE(a.locs && a.time_windows && a.durations && a.w_time && a.d_w_time);
   } else if (a.env == RL4CO_ENV_OP) {
     RL4CO_REQUIRE(a.w_cap && a.locs && a.max_length && a.d_w_cap);
   } else {
@@ -467,7 +470,7 @@ static int validate_teacher(const rl4co_am_teacher_args& a) {
 static int resolve_teacher_variant(const rl4co_am_teacher_args& a) {
   const bool mma_ok = a.cache_dtype == RL4CO_DT_BF16 && a.N <= rl4co::teacher_mma_max_nodes() &&
                       a.T <= rl4co::teacher_mma_max_steps() && a.kvl_row_stride % 8 == 0 && a.kvl_batch_stride % 8 == 0;
-  if (a.env == RL4CO_ENV_OP || a.env == RL4CO_ENV_PCTSP || a.env == RL4CO_ENV_PDP)  // closed-form replay exists in the MMA variant only
+  if (a.env == RL4CO_ENV_OP || a.env == RL4CO_ENV_PCTSP || a.env == RL4CO_ENV_PDP || a.env == RL4CO_ENV_CVRPTW)  // closed-form replay exists in the MMA variant only
     return (mma_ok && a.variant != RL4CO_TEACHER_REPLAY) ? RL4CO_TEACHER_MMA : -1;
   if (a.variant == RL4CO_TEACHER_MMA) return mma_ok ? RL4CO_TEACHER_MMA : -1;
   if (a.variant == RL4CO_TEACHER_REPLAY) return RL4CO_TEACHER_REPLAY;

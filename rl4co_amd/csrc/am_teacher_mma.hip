@@ -80,7 +80,7 @@ __device__ inline float rg_max(float v) { return rl4co::bfly_max<16, 64>(v); }
 __device__ inline float step_sum(float v) { return rl4co::bfly_sum<1, 16>(v); }
 
 struct Layout {  // byte offsets into dynamic LDS
-  int kgs, vs, kls, ob, dub, qb, dob, pb, sact, srem, sg, smask, spos, sval, xz, xa, sinfo, total;
+  int kgs, vs, kls, ob, dub, qb, dob, pb, sact, srem, stime, sg, smask, spos, sval, xz, xa, sinfo, total;
 };
 __host__ __device__ inline Layout make_layout(int nt) {
   Layout L;
@@ -96,6 +96,7 @@ __host__ __device__ inline Layout make_layout(int nt) {
   L.pb = o; o += kWaves * blk;
   L.sact = o; o += kMaxT * 4;
   L.srem = o; o += kMaxT * 4;
+  L.stime = o; o += kMaxT * 4;
   L.sg = o; o += kMaxT * 4;
   L.smask = o; o += kMaxT * 16;
   L.spos = o; o += 128 * 4;
@@ -129,6 +130,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
   __bf16* pbw = reinterpret_cast<__bf16*>(smem + L.pb) + w * 16 * kRS;  // this wave's [16 steps][kRS] P, then dS
   int* sact = reinterpret_cast<int*>(smem + L.sact);
   float* srem = reinterpret_cast<float*>(smem + L.srem);
+  float* stime = reinterpret_cast<float*>(smem + L.stime);  // CVRPTW: the clock before each column
   float* sg = reinterpret_cast<float*>(smem + L.sg);
   uint32_t* smask = reinterpret_cast<uint32_t*>(smem + L.smask);
   int* spos = reinterpret_cast<int*>(smem + L.spos);
@@ -171,7 +173,12 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
 
   const float* ctxc = a.ctx_cur + (int64_t)inst * N * kD + dcol;
   const float* ctxf = (ENV == RL4CO_ENV_TSP) ? a.ctx_first + (int64_t)inst * N * kD + dcol : nullptr;
-  const float* dem = (ENV == RL4CO_ENV_CVRP)    ? a.demand + (int64_t)inst * (N - 1)
+  constexpr bool kCvrpLike = ENV == RL4CO_ENV_CVRP || ENV == RL4CO_ENV_CVRPTW;
+  constexpr bool kClock = ENV == RL4CO_ENV_CVRPTW;
+  const float* twl = kClock ? a.locs + (int64_t)inst * N * 2 : nullptr;          // coordinates
+  const float* tww = kClock ? a.time_windows + (int64_t)inst * N * 2 : nullptr;  // (start, end) per node
+  const float* twd = kClock ? a.durations + (int64_t)inst * N : nullptr;         // service times
+  const float* dem = kCvrpLike                  ? a.demand + (int64_t)inst * (N - 1)
                      : (ENV == RL4CO_ENV_PCTSP) ? a.demand + (int64_t)inst * N  // real prize, depot column 0
                                                 : nullptr;
   const float* oplocs = (ENV == RL4CO_ENV_OP) ? a.locs + (int64_t)inst * N * 2 : nullptr;
@@ -179,14 +186,15 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
   // context scalar = cap - used in both depot environments (OP: longest tour that may still end at
   // the depot minus the tour so far, env_embeddings/context.py:147-149, 211-213)
   // PCTSP: prize_required - prize collected, clamped at 0 (context.py:184-198)
-  const float cap = (ENV == RL4CO_ENV_CVRP || ENV == RL4CO_ENV_PCTSP) ? a.vehicle_capacity[inst]
+  const float cap = (kCvrpLike || ENV == RL4CO_ENV_PCTSP) ? a.vehicle_capacity[inst]
                                                                       : ((ENV == RL4CO_ENV_OP) ? opmax[0] : 0.0f);
   const float thr = cap + 1e-5f;
-  float qb4[4], qx4[4];  // graph context; placeholder query (TSP) or capacity column (CVRP)
+  float qb4[4], qx4[4], qt4[4];  // graph context; placeholder query (TSP) or capacity column (CVRP); time column (CVRPTW)
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     qb4[e] = a.q_bias ? a.q_bias[(int64_t)inst * kD + dcol + e] : 0.0f;
     qx4[e] = (ENV == RL4CO_ENV_TSP) ? a.q_step0[dcol + e] : ((ENV == RL4CO_ENV_PDP) ? 0.0f : a.w_cap[dcol + e]);
+    qt4[e] = kClock ? a.w_time[dcol + e] : 0.0f;
   }
   const float inv_temp = 1.0f / a.temperature;
   const float clip_over_temp = a.tanh_clipping * inv_temp;
@@ -198,7 +206,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
     dvg[jt] = zero4();
     dkl[jt] = zero4();
   }
-  float dqb[4] = {0.f, 0.f, 0.f, 0.f}, dqx[4] = {0.f, 0.f, 0.f, 0.f};
+  float dqb[4] = {0.f, 0.f, 0.f, 0.f}, dqx[4] = {0.f, 0.f, 0.f, 0.f}, dqt[4] = {0.f, 0.f, 0.f, 0.f};
   uint32_t errbits = 0;
 
   for (int s = 0; s < S; ++s) {
@@ -226,7 +234,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
     __syncthreads();
     if (tid == 0) {
       int t_end = T;
-      if (ENV == RL4CO_ENV_CVRP) {  // done once every node (depot included) has been visited (cvrp/env.py:80-83)
+      if (kCvrpLike) {  // done once every node (depot included) has been visited (cvrp/env.py:80-83)
         int last = 0;
         for (int j = 0; j < N; ++j) last = max(last, spos[j]);
         if (last != 0x7fffffff) t_end = min(T, last + 1);
@@ -240,7 +248,22 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
       }
       sinfo[0] = t_end;
     }
-    if (ENV == RL4CO_ENV_CVRP) {
+    if (kClock) {
+      // the clock BEFORE column t, replayed in visiting order: advance by the distance, wait for the window, serve;
+      // back at the depot it restarts (cvrptw/env.py:97-113, same fp32 sequence as the decode kernel)
+      for (int t = tid; t < kMaxT; t += kThreads) {
+        float now = 0.0f;
+        int prev = 0;
+        for (int v = 0; v < min(t, T); ++v) {
+          const int nx = sact[v];
+          const float dx = twl[2 * nx] - twl[2 * prev], dy = twl[2 * nx + 1] - twl[2 * prev + 1];
+          now = (nx != 0 ? 1.0f : 0.0f) * (fmaxf(now + sqrtf(fmaf(dy, dy, dx * dx)), tww[2 * nx]) + twd[nx]);
+          prev = nx;
+        }
+        stime[t] = now;
+      }
+    }
+    if (kCvrpLike) {
       // used capacity BEFORE column t: the loads since the last depot visit, summed in visiting
       // order from zero — the same fp32 sequence as used = (used + demand) * (action != 0)
       for (int t = tid; t < kMaxT; t += kThreads) {
@@ -336,6 +359,16 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
         any |= rl4co::bfly_i<2>((int)any);
         const int cur = (t == 0) ? 0 : sact[t - 1];
         if (k == 0 && !((cur == 0) && any != 0u)) word |= 1u;
+        if (kClock) {  // cvrptw/env.py:91-95: only nodes whose window is still open on arrival (the depot too)
+          const float now = stime[t], cx = twl[2 * cur], cy = twl[2 * cur + 1];
+          for (int b = 0; b < 32; ++b) {
+            const int j = 32 * k + b;
+            if ((word >> b) & 1u) {
+              const float dx = twl[2 * j] - cx, dy = twl[2 * j + 1] - cy;
+              if (!(now + sqrtf(fmaf(dy, dy, dx * dx)) <= tww[2 * j + 1])) word &= ~(1u << b);
+            }
+          }
+        }
       }
       smask[idx] = live ? word : (k == 0 ? 1u : 0u);  // dead columns: a finite dummy (node 0 only), gradient 0
     }
@@ -374,6 +407,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
       const uint4 mw4 = *reinterpret_cast<const uint4*>(smask + 4 * t);
       const uint32_t mw[4] = {mw4.x, mw4.y, mw4.z, mw4.w};
       const float rem = (ENV != RL4CO_ENV_TSP) ? srem[t] : 0.0f;
+      const float now = kClock ? stime[t] : 0.0f;
 
       // ---- 0. query of head h for the block's 16 steps (context.py:105-149, decoder.py:135-136) --
       bf16x4 qf;
@@ -385,6 +419,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
         for (int e = 0; e < 4; ++e) {
           float q;
           if (ENV == RL4CO_ENV_TSP) q = (t == 0) ? qx4[e] + qb4[e] : (f4[e] + c[e]) + qb4[e];
+          else if (kClock) q = fmaf(qt4[e], now, fmaf(qx4[e], rem, c[e])) + qb4[e];  // context.py:152-166
           else q = fmaf(qx4[e], rem, c[e]) + qb4[e];
           qf[e] = (__bf16)(q * (0.25f * kLog2e));
         }
@@ -598,6 +633,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
             }
           } else {
             dqx[e] = fmaf(dqr, rem, dqx[e]);
+            if (kClock) dqt[e] = fmaf(dqr, now, dqt[e]);
             unsafeAtomicAdd(dcc + (int64_t)cur * kD + dcol + e, dqr);
           }
         }
@@ -639,6 +675,10 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
       if (a.d_q_bias) a.d_q_bias[(int64_t)inst * kD + dcol + e] = vb;
       if (ENV != RL4CO_ENV_PDP) unsafeAtomicAdd((ENV == RL4CO_ENV_TSP ? a.d_q_step0 : a.d_w_cap) + dcol + e, vx);
     }
+    if (kClock) {
+      const float vt = step_sum(dqt[e]);
+      if (tl == 0) unsafeAtomicAdd(a.d_w_time + dcol + e, vt);
+    }
   }
   if (errbits) atomicOr(a.err, (int)errbits);
 }
@@ -672,6 +712,7 @@ int launch_teacher_mma(const rl4co_am_teacher_args& a, hipStream_t stream) {
   if (a.env == RL4CO_ENV_OP) return dispatch_tiles<RL4CO_ENV_OP>(a, stream);
   if (a.env == RL4CO_ENV_PCTSP) return dispatch_tiles<RL4CO_ENV_PCTSP>(a, stream);
   if (a.env == RL4CO_ENV_PDP) return dispatch_tiles<RL4CO_ENV_PDP>(a, stream);
+  if (a.env == RL4CO_ENV_CVRPTW) return dispatch_tiles<RL4CO_ENV_CVRPTW>(a, stream);
   return a.env == RL4CO_ENV_TSP ? dispatch_tiles<RL4CO_ENV_TSP>(a, stream) : dispatch_tiles<RL4CO_ENV_CVRP>(a, stream);
 }
 

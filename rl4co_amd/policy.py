@@ -723,8 +723,10 @@ class AttentionModelPolicy(nn.Module):
 
             meta = dict(t0=t0, mask_inner=self.decoder.mask_inner, mask_logits=mask_logits,
                         tanh_clipping=tanh_clipping, temperature=temperature, teacher_variant=self.teacher_variant)
-            if self.env_name == "cvrp":
+            if self.env_name in ("cvrp", "cvrptw"):
                 meta.update(demand=td["demand"], vehicle_capacity=td["vehicle_capacity"])
+                if self.env_name == "cvrptw":
+                    meta.update(locs=td["locs"], time_windows=td["time_windows"], durations=td["durations"])
             elif self.env_name == "op":
                 meta.update(locs=td["locs"], max_length=td["max_length"])
             elif self.env_name == "pctsp":

@@ -30,9 +30,10 @@ class AmTeacherArgs(C.Structure):
         ("glimpse_key", _vp), ("glimpse_val", _vp), ("logit_key", _vp),
         ("kvl_row_stride", _i64), ("kvl_batch_stride", _i64),
         ("ctx_first", _vp), ("ctx_cur", _vp), ("q_bias", _vp), ("q_step0", _vp), ("w_cap", _vp),
-        ("actions", _vp), ("demand", _vp), ("vehicle_capacity", _vp), ("locs", _vp), ("max_length", _vp), ("grad_logp", _vp),
+        ("actions", _vp), ("demand", _vp), ("vehicle_capacity", _vp), ("locs", _vp), ("max_length", _vp),
+        ("time_windows", _vp), ("durations", _vp), ("w_time", _vp), ("grad_logp", _vp),
         ("d_kvl", _vp), ("d_ctx_first", _vp), ("d_ctx_cur", _vp), ("d_q_bias", _vp), ("d_q_step0", _vp),
-        ("d_w_cap", _vp), ("logp_out", _vp), ("err", _vp),
+        ("d_w_cap", _vp), ("d_w_time", _vp), ("logp_out", _vp), ("err", _vp),
     ]
 
 
@@ -44,11 +45,11 @@ def max_nodes() -> int:
 
 
 def supports(env_name: str, cache_dtype: torch.dtype, num_nodes: int) -> bool:
-    """TSP / CVRP: both variants; orienteering, prize-collecting TSP, pickup-delivery: the MMA variant only (bf16
-    planes); CVRP with time windows: not served (the policy falls back to the dense torch re-evaluation)."""
+    """TSP / CVRP: both variants; orienteering, prize-collecting TSP, pickup-delivery, CVRP with time windows: the
+    MMA variant only (bf16 planes)."""
     if num_nodes > max_nodes():
         return False
-    return env_name in ("tsp", "cvrp") or (env_name in ("op", "pctsp", "pdp") and cache_dtype == torch.bfloat16)
+    return env_name in ("tsp", "cvrp") or (env_name in ("op", "pctsp", "pdp", "cvrptw") and cache_dtype == torch.bfloat16)
 
 
 def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: dict, variant: str = "auto",
@@ -69,10 +70,11 @@ def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: d
     d_ctx_first = torch.zeros((b_inst, n, EMBED_DIM), **f32) if tsp else None
     d_q_bias = torch.empty((b_inst, EMBED_DIM), **f32) if cache.q_bias is not None else None
     d_extra = torch.zeros((EMBED_DIM,), **f32)
+    d_time = torch.zeros((EMBED_DIM,), **f32) if cache.w_time is not None else None
     logp = torch.zeros((b, t), **f32) if want_logp else None
     err = torch.zeros(1, dtype=torch.int32, device=dev)
     a = AmTeacherArgs()
-    a.env = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP, "op": _lib.ENV_OP, "pctsp": _lib.ENV_PCTSP, "pdp": _lib.ENV_PDP}[cache.env_name]
+    a.env = {"tsp": _lib.ENV_TSP, "cvrp": _lib.ENV_CVRP, "op": _lib.ENV_OP, "pctsp": _lib.ENV_PCTSP, "pdp": _lib.ENV_PDP, "cvrptw": _lib.ENV_CVRPTW}[cache.env_name]
     a.B, a.B_inst, a.N, a.T, a.t0 = b, b_inst, n, t, int(meta["t0"])
     a.mask_inner, a.mask_logits = int(meta["mask_inner"]), int(meta["mask_logits"])
     a.tanh_clipping, a.temperature = float(meta["tanh_clipping"]), float(meta["temperature"])
@@ -86,10 +88,15 @@ def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: d
     acts = actions.contiguous()
     g = grad_logp.contiguous().float()
     a.actions, a.grad_logp = acts.data_ptr(), g.data_ptr()
-    if cache.env_name == "cvrp":
+    if cache.env_name in ("cvrp", "cvrptw"):
         demand = meta["demand"].contiguous()
         vcap = meta["vehicle_capacity"].reshape(-1).contiguous()
         a.demand, a.vehicle_capacity = demand.data_ptr(), vcap.data_ptr()
+        if cache.env_name == "cvrptw":
+            locs, tw = meta["locs"].float().contiguous(), meta["time_windows"].float().contiguous()
+            dur = meta["durations"].float().contiguous()
+            a.locs, a.time_windows, a.durations = locs.data_ptr(), tw.data_ptr(), dur.data_ptr()
+            a.w_time, a.d_w_time = ptr(cache.w_time), d_time.data_ptr()
     elif cache.env_name == "pctsp":
         demand = meta["real_prize"].float().contiguous()  # [B_inst, N], depot column 0
         vcap = meta["prize_required"].float().reshape(-1).contiguous()
@@ -108,7 +115,7 @@ def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: d
     st = _lib.lib().rl4co_am_teacher_backward(C.byref(a), torch.cuda.current_stream().cuda_stream)
     _lib.check(st, "rl4co_am_teacher_backward")
     return {"d_kvl": d_kvl, "d_ctx_first": d_ctx_first, "d_ctx_cur": d_ctx_cur, "d_q_bias": d_q_bias,
-            "d_extra": d_extra, "logp": logp, "err": err, "variant": {1: "replay", 2: "mma"}.get(ran, "invalid")}
+            "d_extra": d_extra, "d_time": d_time, "logp": logp, "err": err, "variant": {1: "replay", 2: "mma"}.get(ran, "invalid")}
 
 
 def build_cache_autograd(env_name: str, h: Tensor, decoder) -> dict[str, Tensor]:
@@ -134,6 +141,8 @@ def build_cache_autograd(env_name: str, h: Tensor, decoder) -> dict[str, Tensor]
         out["q_step0"] = torch.mv(w_ctx, decoder.context_embedding.W_placeholder.float())
     elif w_ctx.shape[1] > d:  # PDP has no context scalar
         out["w_cap"] = w_ctx[:, d]
+        if w_ctx.shape[1] > d + 1:  # CVRPTW: the current-time column
+            out["w_time"] = w_ctx[:, d + 1]
     out["q_bias"] = (torch.matmul(h.mean(1), decoder.project_fixed_context.weight.float().t())
                      if decoder.use_graph_context else None)
     return out
@@ -143,29 +152,32 @@ def detached_cache(env_name: str, g: dict[str, Tensor], cache_dtype: torch.dtype
     """Rollout view of the autograd cache: detached, planes in the streaming dtype."""
     det = lambda x: None if x is None else x.detach().contiguous()  # noqa: E731
     return FoldedCache(env_name, g["kvl"].detach().to(cache_dtype).contiguous(), det(g.get("ctx_first")),
-                       det(g["ctx_cur"]), det(g.get("q_bias")), det(g.get("q_step0")), det(g.get("w_cap")))
+                       det(g["ctx_cur"]), det(g.get("q_bias")), det(g.get("q_step0")), det(g.get("w_cap")),
+                       det(g.get("w_time")))
 
 
 class TeacherForcedLogLik(torch.autograd.Function):
     """log p(a_t | s_t) [B,T]: forward = the rollout kernel's values, backward = HIP kernel."""
 
     @staticmethod
-    def forward(ctx, kvl, ctx_first, ctx_cur, q_bias, q_extra, logps, cache: FoldedCache, actions: Tensor, meta: dict):
+    def forward(ctx, kvl, ctx_first, ctx_cur, q_bias, q_extra, q_time, logps, cache: FoldedCache, actions: Tensor,
+                meta: dict):
         ctx.cache, ctx.actions, ctx.meta = cache, actions, meta
-        ctx.has = (ctx_first is not None, q_bias is not None, q_extra is not None)
+        ctx.has = (ctx_first is not None, q_bias is not None, q_extra is not None, q_time is not None)
         return logps.detach().clone()
 
     @staticmethod
     def backward(ctx, grad_logp):
         out = run_backward(ctx.cache, ctx.actions, grad_logp, ctx.meta, variant=ctx.meta.get("teacher_variant", "auto"))
-        has_first, has_bias, has_extra = ctx.has
+        has_first, has_bias, has_extra, has_time = ctx.has
         return (out["d_kvl"], out["d_ctx_first"] if has_first else None, out["d_ctx_cur"],
-                out["d_q_bias"] if has_bias else None, out["d_extra"] if has_extra else None, None, None, None, None)
+                out["d_q_bias"] if has_bias else None, out["d_extra"] if has_extra else None,
+                out["d_time"] if has_time else None, None, None, None, None)
 
 
 def teacher_forced_logps(env_name: str, g: dict[str, Tensor], cache: FoldedCache, actions: Tensor, logps: Tensor,
                          meta: dict) -> Tensor:
     """Differentiable per-step log-probs of ``actions`` (values = ``logps`` from the rollout)."""
     extra = g["q_step0"] if env_name == "tsp" else g.get("w_cap")  # None for PDP (no context scalar)
-    return TeacherForcedLogLik.apply(g["kvl"], g.get("ctx_first"), g["ctx_cur"], g.get("q_bias"), extra, logps,
-                                     cache, actions, meta)
+    return TeacherForcedLogLik.apply(g["kvl"], g.get("ctx_first"), g["ctx_cur"], g.get("q_bias"), extra, g.get("w_time"),
+                                     logps, cache, actions, meta)

@@ -214,7 +214,7 @@ def test_pdp_policy_trains_and_validates_on_gpu():
 
 def test_cvrptw_policy_trains_and_validates_on_gpu():
     """CVRP with time windows end to end on the device: rollouts are valid (check_solution on: CVRP + deadlines),
-    training runs on the dense torch re-evaluation (the backward kernels do not carry the clock), gradients are
+    training runs through the MMA backward kernel (clock and deadline masks replayed in closed form), gradients are
     finite and a few steps shorten the tours; the fused bf16 encoder (six init features) agrees with the torch
     encoder on tour quality."""
     from rl4co_amd.envs import get_env

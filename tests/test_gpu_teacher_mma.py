@@ -156,7 +156,7 @@ def test_mma_at_the_node_limit_and_long_horizons(env_name, num_loc, starts):
 
 
 @pytest.mark.parametrize("env_name,num_loc", [("op", 20), ("op", 100), ("pctsp", 20), ("pctsp", 100), ("pdp", 20),
-                                              ("pdp", 100)])
+                                              ("pdp", 100), ("cvrptw", 20), ("cvrptw", 50)])
 def test_mma_orienteering_matches_torch_autograd(env_name, num_loc):
     """Orienteering and prize-collecting TSP have no replay kernel: the MMA backward (closed-form replay of tour
     length / collected prize and of their masks) is checked against torch autograd through the dense re-evaluation on the same trajectories.
