@@ -111,7 +111,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--env", default="tsp", choices=["tsp", "cvrp", "op", "pctsp", "pdp"])
+    ap.add_argument("--env", default="tsp", choices=["tsp", "cvrp", "op", "pctsp", "pdp", "cvrptw"])
     ap.add_argument("--num-loc", type=int, default=100)
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--cache-dtype", default="bf16", choices=["bf16", "f32"])

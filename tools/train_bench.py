@@ -28,7 +28,7 @@ ap.add_argument("--num-loc", type=int, default=100)
 ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--model", default="pomo", choices=["pomo", "am"], help="pomo: 6L instance norm, shared baseline over starts; am: 3L batch norm + graph context, batch-mean baseline")
-ap.add_argument("--env", default="tsp", choices=["tsp", "cvrp", "op", "pctsp", "pdp"])
+ap.add_argument("--env", default="tsp", choices=["tsp", "cvrp", "op", "pctsp", "pdp", "cvrptw"])
 ap.add_argument("--no-fused-encoder", action="store_true", help="torch encoder (library GEMMs, SDPA, autograd norm) for comparison")
 args = ap.parse_args()
 
