@@ -131,6 +131,9 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the rollout engine has no CPU path")
+    # RL4CO_BENCH_SHARED_GPU=1 (testing the multi-rank path on a one-GPU box): ranks share the visible devices
+    if os.environ.get("RL4CO_BENCH_SHARED_GPU") == "1":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -138,7 +141,9 @@ def main() -> None:
     from rl4co_amd import dist as D
 
     if world > 1:
-        D.init_process_group("nccl", device=device)  # "nccl" == RCCL on ROCm; rendezvous on 127.0.0.1
+        # "nccl" == RCCL on ROCm; rendezvous on 127.0.0.1. RCCL refuses two ranks on one device, so the shared-GPU
+        # test mode above rides on gloo (RL4CO_DIST_BACKEND) — the data path has no collective either way
+        D.init_process_group(os.environ.get("RL4CO_DIST_BACKEND", "nccl"), device=device)
 
     from rl4co_amd import kernels as K
     from rl4co_amd.envs import get_env
