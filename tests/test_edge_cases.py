@@ -5,7 +5,8 @@ import torch
 
 from oracle import c_oracle
 from oracle import reference_torch as R
-from tests.helpers import clone_td, fold_cache, make_instances, make_policy, max_horizon, rollout_state
+from tests.helpers import (clone_td, fold_cache, kernel_reward, make_instances, make_policy, max_horizon, oracle_reward,
+                           rollout_state)
 
 
 def _setup(env_name, num_loc, batch, seed=7):
@@ -34,7 +35,9 @@ def _c_rollout(pol, env_name, td0, h, dtype=torch.float32, variant_groups=None, 
 
 
 @pytest.mark.parametrize("env_name,num_loc,batch", [("tsp", 2, 5), ("tsp", 3, 4), ("tsp", 7, 9), ("cvrp", 1, 6),
-                                                    ("cvrp", 2, 6), ("cvrp", 9, 1), ("tsp", 20, 1)])
+                                                    ("cvrp", 2, 6), ("cvrp", 9, 1), ("tsp", 20, 1), ("op", 1, 5),
+                                                    ("op", 3, 7), ("pctsp", 1, 5), ("pctsp", 4, 3), ("pdp", 2, 6),
+                                                    ("pdp", 4, 1), ("cvrptw", 1, 5), ("cvrptw", 3, 4)])
 def test_tiny_graphs_cpu(env_name, num_loc, batch):
     """N = 2, 3 nodes, a single customer, a batch of one: the C oracle reproduces the
     restatement's greedy rollout (valid tours, same rewards on identical trajectories)."""
@@ -46,7 +49,7 @@ def test_tiny_graphs_cpu(env_name, num_loc, batch):
     assert actions.shape == want["actions"].shape
     same = (actions == want["actions"]).all(1)
     assert bool(same.all()) or int((~same).sum()) <= 1
-    reward = c_oracle.tour_length(td0["locs"], actions, prepend_depot=(env_name == "cvrp"), negate=True)
+    reward = oracle_reward(env_name, td0, actions)
     assert torch.equal(reward[same], want["reward"][same])
     env.check_solution_validity(td0, actions)
 
@@ -90,6 +93,11 @@ def test_multistart_more_starts_than_nodes_wraps():
     ("tsp", 64, 9, torch.bfloat16, "stream"), ("tsp", 65, 9, torch.bfloat16, "wide"),
     ("cvrp", 200, 12, torch.bfloat16, "wide"), ("tsp", 1000, 3, torch.bfloat16, "stream"),
     ("tsp", 1000, 3, torch.float32, "stream"), ("cvrp", 127, 5, torch.bfloat16, "stream"),
+    ("op", 1, 5, torch.float32, "stream"), ("op", 63, 9, torch.bfloat16, "stream"), ("op", 300, 4, torch.bfloat16, "stream"),
+    ("pctsp", 1, 5, torch.float32, "stream"), ("pctsp", 64, 9, torch.bfloat16, "stream"),
+    ("pctsp", 300, 4, torch.float32, "stream"), ("pdp", 2, 6, torch.float32, "stream"), ("pdp", 64, 9, torch.bfloat16, "stream"),
+    ("pdp", 300, 3, torch.bfloat16, "stream"), ("cvrptw", 1, 5, torch.float32, "stream"),
+    ("cvrptw", 65, 9, torch.bfloat16, "stream"), ("cvrptw", 200, 3, torch.float32, "stream"),
 ])
 def test_shapes_bit_exact_gpu(env_name, num_loc, batch, dtype, variant):
     from rl4co_amd import kernels as K
@@ -117,8 +125,7 @@ def test_shapes_bit_exact_gpu(env_name, num_loc, batch, dtype, variant):
     assert torch.equal(logps[:, :t].cpu().view(torch.int32), l_c.contiguous().view(torch.int32))
     for k in st_c:
         assert torch.equal(st[k].cpu(), st_c[k]), k
-    reward = K.tour_length(td0["locs"].cuda(), actions[:, :t].contiguous(), prepend_depot=(env_name == "cvrp"),
-                           negate=True).cpu()
+    reward = kernel_reward(K, env_name, td0, actions[:, :t].contiguous()).cpu()
     assert torch.equal(reward, env.get_reward(td0, a_c))
 
 
