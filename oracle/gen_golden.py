@@ -61,6 +61,9 @@ CASES = [
     dict(name="pctsp20_b128_greedy", env="pctsp", num_loc=20, batch=128, policy="am", decode="greedy"),
     dict(name="pctsp50_b64_sampling", env="pctsp", num_loc=50, batch=64, policy="am", decode="sampling"),
     dict(name="pctsp100_b64_greedy", env="pctsp", num_loc=100, batch=64, policy="am", decode="greedy"),
+    # stochastic PCTSP: the init embedding sees the EXPECTED prize, the transition collects the REAL one
+    dict(name="spctsp20_b128_greedy", env="spctsp", num_loc=20, batch=128, policy="am", decode="greedy"),
+    dict(name="spctsp50_b64_sampling", env="spctsp", num_loc=50, batch=64, policy="am", decode="sampling"),
     # pickup and delivery (same row): precedence masks; POMO multistart from the pickups
     dict(name="pdp20_b128_greedy", env="pdp", num_loc=20, batch=128, policy="am", decode="greedy"),
     dict(name="pdp50_b64_sampling", env="pdp", num_loc=50, batch=64, policy="am", decode="sampling"),
@@ -107,7 +110,7 @@ def run_case(ref, case: dict) -> dict:
     fw_kw = dict(case.get("fw_kw", {}))
 
     # ---- the real reference -----------------------------------------------------------------
-    env_cls = {"tsp": ref.TSPEnv, "cvrp": ref.CVRPEnv, "op": ref.OPEnv, "pctsp": ref.PCTSPEnv, "pdp": ref.PDPEnv, "cvrptw": ref.CVRPTWEnv}[env_name]
+    env_cls = {"tsp": ref.TSPEnv, "cvrp": ref.CVRPEnv, "op": ref.OPEnv, "pctsp": ref.PCTSPEnv, "pdp": ref.PDPEnv, "cvrptw": ref.CVRPTWEnv, "spctsp": ref.SPCTSPEnv}[env_name]
     gen_kw = dict(num_loc=n)
     if env_name == "op":  # the default prize sampler Uniform(1.0, 1.0) does not pass torch's argument validation;
         gen_kw["prize_distribution"] = "dist"  # "dist" takes no sampler and is what prize_type="dist" (the default) uses

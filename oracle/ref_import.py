@@ -41,6 +41,7 @@ _SHELL_PACKAGES = [
     "rl4co.envs.routing.pctsp",
     "rl4co.envs.routing.pdp",
     "rl4co.envs.routing.cvrptw",
+    "rl4co.envs.routing.spctsp",
     "rl4co.models",
     "rl4co.models.nn",
     "rl4co.models.nn.graph",
@@ -60,6 +61,7 @@ _LAZY = {
         "PCTSPEnv": "rl4co.envs.routing.pctsp.env",
         "PDPEnv": "rl4co.envs.routing.pdp.env",
         "CVRPTWEnv": "rl4co.envs.routing.cvrptw.env",
+        "SPCTSPEnv": "rl4co.envs.routing.spctsp.env",
     },
     "rl4co.models.zoo.am": {"AttentionModelPolicy": "rl4co.models.zoo.am.policy"},
 }
@@ -82,7 +84,7 @@ class _Shell(types.ModuleType):
 def _get_env(env_name: str, *args, **kwargs):
     """rl4co/envs/__init__.py:65-84 restricted to the environments on the path."""
     envs = sys.modules["rl4co.envs"]
-    registry = {"tsp": "TSPEnv", "cvrp": "CVRPEnv", "op": "OPEnv", "pctsp": "PCTSPEnv", "pdp": "PDPEnv", "cvrptw": "CVRPTWEnv"}
+    registry = {"tsp": "TSPEnv", "cvrp": "CVRPEnv", "op": "OPEnv", "pctsp": "PCTSPEnv", "pdp": "PDPEnv", "cvrptw": "CVRPTWEnv", "spctsp": "SPCTSPEnv"}
     if env_name not in registry:
         raise ValueError(f"Unknown environment {env_name}. Available (oracle shell): {list(registry)}")
     return getattr(envs, registry[env_name])(*args, **kwargs)
@@ -138,6 +140,7 @@ def load():
     ns.PCTSPEnv = importlib.import_module("rl4co.envs.routing.pctsp.env").PCTSPEnv
     ns.PDPEnv = importlib.import_module("rl4co.envs.routing.pdp.env").PDPEnv
     ns.CVRPTWEnv = importlib.import_module("rl4co.envs.routing.cvrptw.env").CVRPTWEnv
+    ns.SPCTSPEnv = importlib.import_module("rl4co.envs.routing.spctsp.env").SPCTSPEnv
     ns.TSPGenerator = importlib.import_module("rl4co.envs.routing.tsp.generator").TSPGenerator
     ns.CVRPGenerator = importlib.import_module("rl4co.envs.routing.cvrp.generator").CVRPGenerator
     ns.AttentionModelPolicy = importlib.import_module("rl4co.models.zoo.am.policy").AttentionModelPolicy

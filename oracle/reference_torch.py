@@ -581,7 +581,10 @@ class PCTSPEnv:
     name = "pctsp"
 
     def __init__(self, num_loc: int = 20, check_solution: bool = True, penalty_factor: float = 3.0,
-                 prize_required: float = 1.0):
+                 prize_required: float = 1.0, stochastic: bool = False):
+        self.stochastic = stochastic  # spctsp/env.py:8-21: the real prize differs from the expected one
+        if stochastic:
+            self.name = "spctsp"
         self.num_loc = num_loc
         self.check_solution = check_solution
         self.prize_required = prize_required
@@ -606,7 +609,7 @@ class PCTSPEnv:
             td = self.generate(batch_size)
         b = td["locs"].shape[0]
         device = td["locs"].device
-        real_prize = td["deterministic_prize"]
+        real_prize = td["stochastic_prize"] if self.stochastic else td["deterministic_prize"]  # pctsp/env.py:98
         penalty = td["penalty"]
         td_reset = {
             "locs": torch.cat([td["depot"][..., None, :], td["locs"]], dim=-2),
@@ -782,6 +785,8 @@ class PDPEnv:
 
 
 def get_env(name: str, num_loc: int, **kw):
+    if name == "spctsp":
+        return PCTSPEnv(num_loc=num_loc, stochastic=True, **kw)
     return {"tsp": TSPEnv, "cvrp": CVRPEnv, "op": OPEnv, "pctsp": PCTSPEnv, "pdp": PDPEnv,
             "cvrptw": CVRPTWEnv}[name](num_loc=num_loc, **kw)
 
@@ -1184,7 +1189,8 @@ class AttentionModelEncoder(nn.Module):
         super().__init__()
         self.env_name = env_name
         self.init_embedding = {"tsp": TSPInitEmbedding, "cvrp": VRPInitEmbedding, "op": OPInitEmbedding, "pctsp": PCTSPInitEmbedding,
-                               "pdp": PDPInitEmbedding, "cvrptw": VRPTWInitEmbedding}[env_name](embed_dim)
+                               "pdp": PDPInitEmbedding, "cvrptw": VRPTWInitEmbedding,
+                               "spctsp": PCTSPInitEmbedding}[env_name](embed_dim)
         self.net = GraphAttentionNetwork(
             num_heads, embed_dim, num_layers, normalization, feedforward_hidden, sdpa_fn=sdpa_fn
         )
@@ -1206,7 +1212,8 @@ class AttentionModelDecoder(nn.Module):
         self.embed_dim = embed_dim
         self.num_heads = num_heads
         self.context_embedding = {"tsp": TSPContext, "cvrp": VRPContext, "op": OPContext, "pctsp": PCTSPContext,
-                                  "pdp": PDPContext, "cvrptw": VRPTWContext}[env_name](embed_dim)
+                                  "pdp": PDPContext, "cvrptw": VRPTWContext,
+                                  "spctsp": PCTSPContext}[env_name](embed_dim)
         self.dynamic_embedding = StaticEmbedding()
         self.is_dynamic_embedding = False
         self.pointer = PointerAttention(

@@ -28,6 +28,14 @@ from torch import Tensor
 
 EMBED_DIM = 128
 
+# environments that share another one's kernels (same state, masks, embeddings): stochastic PCTSP only
+# differs in which generated prize its reset() calls "real" (spctsp/env.py:8-21)
+KERNEL_ENV = {"spctsp": "pctsp"}
+
+
+def canonical_env(env_name: str) -> str:
+    return KERNEL_ENV.get(env_name, env_name)
+
 
 @dataclass
 class FoldedCache:

@@ -568,6 +568,14 @@ class PCTSPEnv(RL4COEnvBase):
             K.raise_if_error(err)
 
 
+class SPCTSPEnv(PCTSPEnv):
+    """Stochastic PCTSP (envs/routing/spctsp/env.py:8-21): the prize collected at a node is the generator's
+    ``stochastic_prize``; the policy still embeds the expected one. Same kernels as PCTSP."""
+
+    name = "spctsp"
+    _stochastic = True
+
+
 class PDPEnv(RL4COEnvBase):
     """Pickup and delivery problem (envs/routing/pdp/env.py:17-225): every pickup before its delivery, one
     vehicle of unlimited capacity, tour closed through the depot. State in ``rl4co_pdp_*`` (csrc/env_step.hip)."""
@@ -645,4 +653,5 @@ class PDPEnv(RL4COEnvBase):
 
 
 def get_env(name: str, **kw) -> RL4COEnvBase:
-    return {"tsp": TSPEnv, "cvrp": CVRPEnv, "op": OPEnv, "pctsp": PCTSPEnv, "pdp": PDPEnv, "cvrptw": CVRPTWEnv}[name](**kw)
+    return {"tsp": TSPEnv, "cvrp": CVRPEnv, "op": OPEnv, "pctsp": PCTSPEnv, "pdp": PDPEnv, "cvrptw": CVRPTWEnv,
+            "spctsp": SPCTSPEnv}[name](**kw)

@@ -27,7 +27,7 @@ import torch.nn.functional as F
 from torch import Tensor
 
 from . import kernels as K
-from .cache import FoldedCache, build_folded_cache
+from .cache import FoldedCache, build_folded_cache, canonical_env
 from .envs import RL4COEnvBase, get_env
 from .tensordict import TensorDict
 
@@ -315,7 +315,7 @@ class AttentionModelEncoder(nn.Module):
     def __init__(self, embed_dim=128, env_name="tsp", num_heads=8, num_layers=3, normalization="batch",
                  feedforward_hidden=512):
         super().__init__()
-        self.env_name = env_name
+        self.env_name = env_name = canonical_env(env_name)
         self.init_embedding = {"tsp": _TSPInit, "cvrp": _VRPInit, "op": _OPInit, "pctsp": _PCTSPInit,
                                "pdp": _PDPInit, "cvrptw": _VRPTWInit}[env_name](embed_dim)
         self.net = _GraphAttentionNetwork(num_heads, embed_dim, num_layers, normalization, feedforward_hidden)
@@ -356,7 +356,7 @@ class AttentionModelDecoder(nn.Module):
     def __init__(self, embed_dim=128, num_heads=8, env_name="tsp", mask_inner=True,
                  use_graph_context=True, check_nan=True):
         super().__init__()
-        self.env_name = env_name
+        self.env_name = env_name = canonical_env(env_name)
         self.embed_dim = embed_dim
         self.num_heads = num_heads
         self.mask_inner = mask_inner
@@ -423,7 +423,7 @@ class AttentionModelPolicy(nn.Module):
             env_name = env_name.name
         if embed_dim != 128 or num_heads != 8:
             raise ValueError("the fused decode kernel is specialised for embed_dim=128, num_heads=8")
-        self.env_name = env_name
+        self.env_name = env_name = canonical_env(env_name)
         self.encoder = AttentionModelEncoder(embed_dim, env_name, num_heads, num_encoder_layers,
                                              normalization, feedforward_hidden)
         self.decoder = AttentionModelDecoder(embed_dim, num_heads, env_name, mask_inner,

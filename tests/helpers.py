@@ -53,8 +53,12 @@ class GoldenCase:
         self.reward = torch.from_numpy(z["reward"])
         self.log_likelihood = torch.from_numpy(z["log_likelihood"])
         m = self.meta
-        self.env_name, self.num_loc, self.batch = m["env"], m["num_loc"], m["batch"]
-        self.env = R.get_env(self.env_name, self.num_loc)
+        from rl4co_amd.cache import canonical_env
+
+        # env_label: the reference's environment name; env_name: the environment whose kernels serve it
+        self.env_label, self.num_loc, self.batch = m["env"], m["num_loc"], m["batch"]
+        self.env_name = canonical_env(self.env_label)
+        self.env = R.get_env(self.env_label, self.num_loc)
         torch.manual_seed(m["data_seed"])
         self.data = self.env.generate(self.batch)
         stored = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("in_")}
@@ -62,7 +66,7 @@ class GoldenCase:
             assert torch.equal(v, self.data[k]), f"seeded {k} differs from the stored fixture input"
         assert state_hash(self.data) == m["inputs_sha256"], "seeded inputs differ from the golden run"
         torch.manual_seed(m["weight_seed"])
-        self.policy = R.AttentionModelPolicy(env_name=self.env_name, **m["policy_kwargs"]).eval()
+        self.policy = R.AttentionModelPolicy(env_name=self.env_label, **m["policy_kwargs"]).eval()
         assert state_hash(self.policy.state_dict()) == m["weights_sha256"], "seeded weights differ from the golden run"
 
     def reset(self) -> dict:

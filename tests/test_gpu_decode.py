@@ -229,7 +229,7 @@ def _vs_golden(K, g, actions, logps, t, td0, max_flips):
     reward = kernel_reward(K, g.env_name, td0, actions).cpu()
     # the kernel's tour length of its own actions == ATen's arithmetic on the same actions, bit for bit
     rows = R.batchify({k: v for k, v in td0.items() if torch.is_tensor(v)}, g.num_starts) if g.num_starts else td0
-    env = R.get_env(g.env_name, g.num_loc, check_solution=True)
+    env = R.get_env(g.env_label, g.num_loc, check_solution=True)
     assert torch.equal(reward, env.get_reward(rows, actions))
     # identical trajectories => bit-identical rewards vs the reference run
     assert torch.equal(reward[same], g.reward[same])

@@ -24,10 +24,10 @@ def _product(g: GoldenCase, **kw):
 
     pk = dict(g.meta["policy_kwargs"])
     pk.pop("sdpa_fn_decoder", None)
-    pol = AttentionModelPolicy(env_name=g.env_name, **pk, **kw).eval()
+    pol = AttentionModelPolicy(env_name=g.env_label, **pk, **kw).eval()
     pol.load_state_dict(g.policy.state_dict(), strict=True)
     pol = pol.cuda()
-    env = get_env(g.env_name, generator_params=dict(num_loc=g.num_loc), device="cuda")
+    env = get_env(g.env_label, generator_params=dict(num_loc=g.num_loc), device="cuda")
     td = TensorDict({k: v.clone() for k, v in g.data.items()}, batch_size=[g.batch])
     return pol, env, td
 
@@ -244,3 +244,24 @@ def test_cvrptw_policy_trains_and_validates_on_gpu():
         out = pol(env.reset(data), env, phase="test", decode_type="greedy")
         out_bf = fused(env.reset(data), env, phase="test", decode_type="greedy")
     assert abs(float(out_bf["reward"].mean() - out["reward"].mean())) <= 3e-2 * abs(float(out["reward"].mean()))
+
+
+def test_spctsp_env_collects_the_stochastic_prize_on_gpu():
+    """Stochastic PCTSP shares PCTSP's kernels: the init embedding sees the expected prize, the transition and the
+    validity check the generator's stochastic one (spctsp/env.py:8-21, pctsp/env.py:96-98)."""
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    torch.manual_seed(0)
+    env = get_env("spctsp", generator_params=dict(num_loc=20, device="cuda"), device="cuda", check_solution=True)
+    data = env.generator(batch_size=[128])
+    td = env.reset(data)
+    assert torch.equal(td["real_prize"][:, 1:], data["stochastic_prize"]) and torch.equal(td["expected_prize"], data["deterministic_prize"])
+    pol = AttentionModelPolicy("spctsp").cuda().eval()
+    assert pol.env_name == "pctsp"
+    with torch.inference_mode():
+        out = pol(td, env, phase="test", decode_type="greedy")
+    acts = out["actions"]
+    prize = td["real_prize"].gather(1, acts).sum(1)
+    customers = (acts != 0).sum(1)
+    assert bool(((prize >= 1 - 1e-5) | (customers == 20)).all())
