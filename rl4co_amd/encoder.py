@@ -61,15 +61,27 @@ class PackedEncoder:
         self.policy = policy
         self.version = None
         self.t: dict[str, Tensor] = {}
+        self._tensors: list[Tensor] | None = None
 
     def _current_version(self):
+        """Cheap change detector on the path of every rollout (it sits between the previous rollout's
+        sync and this one's first launch): the module tree is walked once, afterwards only the version
+        counters and storage addresses of the same Parameter / buffer objects are read. Modules keep
+        their Parameter objects across ``.to()`` / ``load_state_dict`` / optimizer steps (the storage
+        address or the version counter moves instead); ``refresh(force=True)`` re-walks the tree after
+        structural surgery (a parameter object replaced by assignment)."""
         pol = self.policy
-        tensors = list(pol.parameters()) + list(pol.buffers())
+        tensors = self._tensors
+        if tensors is None:
+            tensors = self._tensors = list(pol.parameters()) + list(pol.buffers())
         # inference tensors (a model built or loaded under torch.inference_mode) carry no version counter:
-        # their storage address stands in, so in-place updates of such weights need an explicit refresh
-        return (tuple(-p.data_ptr() if p.is_inference() else p._version for p in tensors), tensors[0].device, pol.training)
+        # for them only the storage address is available, so in-place updates of such weights need refresh(force=True)
+        return (tuple(0 if p.is_inference() else p._version for p in tensors), tuple(p.data_ptr() for p in tensors),
+                pol.training)
 
-    def refresh(self) -> dict[str, Tensor]:
+    def refresh(self, force: bool = False) -> dict[str, Tensor]:
+        if force:
+            self._tensors, self.version = None, None
         ver = self._current_version()
         if ver == self.version:
             return self.t
