@@ -209,6 +209,20 @@ class PDPGenerator(TSPGenerator):
         return TensorDict({"locs": locs[..., 1:, :], "depot": locs[..., 0, :]}, batch_size=batch_size)
 
 
+def _zero_state(device, **fields) -> dict:
+    """Zero-initialised state tensors as views of ONE allocation (one fill launch instead of one per field: reset
+    sits between two rollouts with the GPU idle). fields: name=(shape, dtype); every view starts 16-byte aligned."""
+    offs, total = {}, 0
+    for name, (shape, dtype) in fields.items():
+        nbytes = int(torch.tensor([], dtype=dtype).element_size())
+        for d in shape:
+            nbytes *= int(d)
+        offs[name] = (total, nbytes)
+        total += (nbytes + 15) // 16 * 16
+    buf = torch.zeros(max(total, 16), dtype=torch.uint8, device=device)
+    return {name: buf[o : o + nb].view(fields[name][1]).view(fields[name][0]) for name, (o, nb) in offs.items()}
+
+
 class RL4COEnvBase:
     """envs/common/base.py:19-333, rollout-path methods only."""
 
@@ -290,15 +304,17 @@ class TSPEnv(RL4COEnvBase):
         device = init_locs.device
         b = init_locs.shape[0]
         num_loc = init_locs.shape[-2]
+        z = _zero_state(device, first_node=((b,), torch.int64), current_node=((b,), torch.int64), i=((b, 1), torch.int64),
+                        reward=((b, 1), torch.float32), done=((b,), torch.bool))
         return TensorDict(
             {
                 "locs": init_locs,
-                "first_node": torch.zeros((b,), dtype=torch.int64, device=device),
-                "current_node": torch.zeros((b,), dtype=torch.int64, device=device),
-                "i": torch.zeros((b, 1), dtype=torch.int64, device=device),
+                "first_node": z["first_node"],
+                "current_node": z["current_node"],
+                "i": z["i"],
                 "action_mask": torch.ones((b, num_loc), dtype=torch.bool, device=device),
-                "reward": torch.zeros((b, 1), dtype=torch.float32, device=device),
-                "done": torch.zeros((b,), dtype=torch.bool, device=device),
+                "reward": z["reward"],
+                "done": z["done"],
             },
             batch_size=[b],
         )

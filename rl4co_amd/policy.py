@@ -688,6 +688,14 @@ class AttentionModelPolicy(nn.Module):
         checked = bool(calc_reward and env.check_solution and not (n_rep > 0 and select_best))
         if checked:
             env.check_solution_validity(td, out_actions, err=err)
+        # TSP / PDP take exactly `tmax` steps, so the action buffer is the tour: the reward goes out before
+        # the read-back instead of after it (with a ragged horizon the buffer's trailing zeros would change
+        # the association of the reference-ordered sums, so every other environment waits for the horizon)
+        td_early = reward_early = None
+        if self.env_name in ("tsp", "pdp") and calc_reward and not (n_rep > 0 and select_best):
+            td_early = self._final_td(td, state, n_rep)
+            td_early.set("action", out_actions[:, -1])
+            reward_early = env.get_reward(td_early, out_actions, check_solution=False if checked else None)
         err_bits, horizon_used, streamed = status.tolist()  # one 12-byte read-back, no reduction launches
         t_used = t0 + int(horizon_used)
         self.last_instance_steps = int(streamed)  # instance-steps the decode launch really streamed
@@ -700,7 +708,9 @@ class AttentionModelPolicy(nn.Module):
             all_logps = all_logps[:, :t_used]
 
         # td mirrors the reference's final state (batchified rows when multistart)
-        td_out = self._final_td(td, state, n_rep)
+        if reward_early is not None and t_used != tmax:  # cut short by max_steps: the early reward saw padding
+            td_early = reward_early = None
+        td_out = td_early if td_early is not None else self._final_td(td, state, n_rep)
         td_out.set("action", out_actions[:, -1])
 
         if n_rep > 0 and select_best:
@@ -712,6 +722,8 @@ class AttentionModelPolicy(nn.Module):
                 all_logps = all_logps[rows]
             td_out = td_out[rows] if hasattr(td_out, "__getitem__") else td_out
             reward = rewards[rows] if calc_reward else None
+        elif reward_early is not None:
+            reward = reward_early
         else:
             reward = (env.get_reward(td_out, out_actions, check_solution=False if checked else None)
                       if calc_reward else td_out.get("reward", None))
