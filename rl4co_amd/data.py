@@ -1,7 +1,9 @@
 """The callers / data formats either side of the rollout.
 
 * npz instance files with the reference's ``{locs, depot, demand, capacity}`` schema
-  (``rl4co/data/utils.py:11-30``), loaded straight to the GPU.
+  (``rl4co/data/utils.py:11-30``), loaded straight to the GPU; the file generators of
+  ``rl4co/data/generate_data.py`` (same numpy draws under the same seed -> the same val / test files) and a
+  batch-indexed dataset (``rl4co/data/dataset.py``) that keeps the instances on the device.
 * dihedral-8 state augmentation (``rl4co/data/transforms.py:16-46,105-151``) and the POMO
   evaluation epilogue — best over starts, then best over augmentations
   (``rl4co/models/zoo/pomo/model.py:88-143``): pure gathers/maxima around the same fused rollout.
@@ -35,6 +37,164 @@ def load_npz_to_tensordict(filename: str, device=None) -> TensorDict:
 def save_tensordict_to_npz(td, filename: str, compress: bool = False) -> None:
     x_dict = {k: v.detach().cpu().numpy() for k, v in td.items()}
     (np.savez_compressed if compress else np.savez)(filename, **x_dict)
+
+
+# ---- instance files (data/generate_data.py:24-311) -------------------------------------------------
+# The reference's dataset files are plain numpy draws under np.random.seed(seed): the same calls in the
+# same order reproduce its val / test files byte for byte (tests/test_data_cpu.py checks that against
+# the reference source). Problems on the path: tsp, vrp (= CVRP), pdp, op, pctsp.
+
+CAPACITIES = {10: 20.0, 15: 25.0, 20: 30.0, 30: 33.0, 40: 37.0, 50: 40.0, 60: 43.0, 75: 45.0, 100: 50.0, 125: 55.0,
+              150: 60.0, 200: 70.0, 500: 100.0, 1000: 150.0}  # generate_data.py:44-58
+MAX_LENGTHS = {20: 2.0, 50: 3.0, 100: 4.0}  # generate_data.py:103,128
+DISTRIBUTIONS_PER_PROBLEM = {"tsp": [None], "vrp": [None], "pctsp": [None], "op": ["const", "unif", "dist"], "pdp": [None]}
+
+
+def generate_tsp_data(dataset_size: int, tsp_size: int) -> dict:
+    return {"locs": np.random.uniform(size=(dataset_size, tsp_size, 2)).astype(np.float32)}
+
+
+def generate_vrp_data(dataset_size: int, vrp_size: int, capacities: dict | None = None) -> dict:
+    caps = dict(CAPACITIES)
+    if capacities is not None:
+        caps.update({k: v for k, v in capacities.items() if k in caps})
+    return {
+        "depot": np.random.uniform(size=(dataset_size, 2)).astype(np.float32),
+        "locs": np.random.uniform(size=(dataset_size, vrp_size, 2)).astype(np.float32),
+        "demand": np.random.randint(1, 10, size=(dataset_size, vrp_size)).astype(np.float32),  # 1 ... 9, NOT normalised
+        "capacity": np.full(dataset_size, caps[vrp_size]).astype(np.float32),
+    }
+
+
+def generate_pdp_data(dataset_size: int, pdp_size: int) -> dict:
+    depot = np.random.uniform(size=(dataset_size, 2))
+    loc = np.random.uniform(size=(dataset_size, pdp_size, 2))
+    return {"locs": loc.astype(np.float32), "depot": depot.astype(np.float32)}
+
+
+def generate_op_data(dataset_size: int, op_size: int, prize_type: str = "const", max_lengths: dict | None = None) -> dict:
+    depot = np.random.uniform(size=(dataset_size, 2))
+    loc = np.random.uniform(size=(dataset_size, op_size, 2))
+    if prize_type == "const":
+        prize = np.ones((dataset_size, op_size))
+    elif prize_type == "unif":
+        prize = (1 + np.random.randint(0, 100, size=(dataset_size, op_size))) / 100.0
+    else:
+        assert prize_type == "dist"
+        prize_ = np.linalg.norm(depot[:, None, :] - loc, axis=-1)
+        prize = (1 + (prize_ / prize_.max(axis=-1, keepdims=True) * 99).astype(int)) / 100.0
+    max_lengths = MAX_LENGTHS if max_lengths is None else max_lengths
+    return {"depot": depot.astype(np.float32), "locs": loc.astype(np.float32), "prize": prize.astype(np.float32),
+            "max_length": np.full(dataset_size, max_lengths[op_size]).astype(np.float32)}
+
+
+def generate_pctsp_data(dataset_size: int, pctsp_size: int, penalty_factor: float = 3, max_lengths: dict | None = None) -> dict:
+    depot = np.random.uniform(size=(dataset_size, 2))
+    loc = np.random.uniform(size=(dataset_size, pctsp_size, 2))
+    max_lengths = MAX_LENGTHS if max_lengths is None else max_lengths
+    penalty_max = max_lengths[pctsp_size] * (penalty_factor) / float(pctsp_size)
+    penalty = np.random.uniform(size=(dataset_size, pctsp_size)) * penalty_max
+    deterministic_prize = np.random.uniform(size=(dataset_size, pctsp_size)) * 4 / float(pctsp_size)
+    stochastic_prize = np.random.uniform(size=(dataset_size, pctsp_size)) * deterministic_prize * 2
+    return {"locs": loc.astype(np.float32), "depot": depot.astype(np.float32), "penalty": penalty.astype(np.float32),
+            "deterministic_prize": deterministic_prize.astype(np.float32),
+            "stochastic_prize": stochastic_prize.astype(np.float32)}
+
+
+_GENERATORS = {"tsp": generate_tsp_data, "vrp": generate_vrp_data, "pdp": generate_pdp_data, "op": generate_op_data,
+               "pctsp": generate_pctsp_data}
+
+
+def generate_env_data(env_type: str, *args, **kwargs) -> dict:
+    """generate_data.py:24-34 (``None`` arguments are dropped, as there)"""
+    if env_type not in _GENERATORS:
+        raise NotImplementedError(f"Environment type {env_type} not implemented")
+    return _GENERATORS[env_type](*[a for a in args if a is not None], **kwargs)
+
+
+def generate_dataset(filename=None, data_dir: str = "data", name: str | None = None, problem="all",
+                     data_distribution: str = "all", dataset_size: int = 10000, graph_sizes=(20, 50, 100),
+                     overwrite: bool = False, seed: int = 1234, distributions_per_problem: dict | None = None) -> list[str]:
+    """generate_data.py:214-311: one npz per (problem, distribution, graph size), named
+    ``<data_dir>/<problem>/<problem>[_<dist>]<size>_<name>_seed<seed>.npz``. Returns the files written."""
+    if isinstance(problem, list) and len(problem) == 1:
+        problem = problem[0]
+    graph_sizes = [graph_sizes] if isinstance(graph_sizes, int) else list(graph_sizes)
+    dpp = DISTRIBUTIONS_PER_PROBLEM if distributions_per_problem is None else distributions_per_problem
+    problems = dpp if problem == "all" else {problem: (dpp[problem] if data_distribution == "all" else [data_distribution])}
+    filenames = [filename] if isinstance(filename, str) else filename
+    written, it = [], 0
+    for prob, distributions in problems.items():
+        for distribution in distributions or [None]:
+            for graph_size in graph_sizes:
+                if filename is None:
+                    datadir = os.path.join(data_dir, prob)
+                    os.makedirs(datadir, exist_ok=True)
+                    fname = os.path.join(datadir, "{}{}{}_{}_seed{}.npz".format(
+                        prob, (f"_{distribution}" if distribution is not None else ""), graph_size, name, seed))
+                else:
+                    if it >= len(filenames):
+                        raise ValueError("Number of filenames does not match number of problems")
+                    fname = check_extension(filenames[it], extension=".npz")
+                    if os.path.dirname(fname):
+                        os.makedirs(os.path.dirname(fname), exist_ok=True)
+                    it += 1
+                if not overwrite and os.path.isfile(fname):
+                    continue
+                np.random.seed(seed)
+                dataset = generate_env_data(prob, dataset_size, graph_size, distribution)
+                np.savez(fname, **dataset)
+                written.append(fname)
+    return written
+
+
+def generate_default_datasets(data_dir: str) -> list[str]:
+    """generate_data.py:314-317: the val (seed 4321) and test (seed 1234) files of every problem on the path"""
+    return (generate_dataset(data_dir=data_dir, name="val", problem="all", seed=4321)
+            + generate_dataset(data_dir=data_dir, name="test", problem="all", seed=1234))
+
+
+# ---- datasets (data/dataset.py:14-130) -------------------------------------------------------------
+
+class TensorDictDataset:
+    """A TensorDict of instances served batch by batch (``__getitems__``): the tensors stay where they are (on the
+    GPU after ``load_npz_to_tensordict(..., device=)``) and a batch is ONE gather per key — what the reference's
+    ``FastTdDataset`` / ``TensorDictDatasetFastGeneration`` do, without the per-item dict disassembly of its default
+    ``TensorDictDataset`` (data/dataset.py:41-71) that dominates an epoch once the rollout is fast."""
+
+    def __init__(self, td):
+        self.data = td
+        self.data_len = td.batch_size[0]
+
+    def __len__(self) -> int:
+        return self.data_len
+
+    def __getitems__(self, index):
+        idx = torch.as_tensor(index, device=next(iter(self.data.values())).device)
+        return TensorDict({k: v[idx] for k, v in self.data.items()}, batch_size=[idx.numel()])
+
+    def __getitem__(self, i: int):
+        return {k: v[i] for k, v in self.data.items()}
+
+    def add_key(self, key: str, value: Tensor):
+        """dataset.py:63-64,118-120: e.g. the rollout baseline's rewards ("extra") next to every instance"""
+        assert len(value) == self.data_len, "Data and extra must be same length"
+        self.data.set(key, value)
+        return self
+
+    @staticmethod
+    def collate_fn(batch):
+        """Batches come out of ``__getitems__`` assembled; a list of per-item dicts is stacked (dataset.py:66-73)."""
+        if isinstance(batch, (list, tuple)):
+            return TensorDict({k: torch.stack([b[k] for b in batch]) for k in batch[0].keys()}, batch_size=[len(batch)])
+        return batch
+
+    def batches(self, batch_size: int, shuffle: bool = False, generator: torch.Generator | None = None):
+        """One epoch of device-resident batches (the DataLoader of rl/common/base.py:264-273 without worker processes)."""
+        dev = next(iter(self.data.values())).device
+        order = torch.randperm(self.data_len, generator=generator).to(dev) if shuffle else torch.arange(self.data_len, device=dev)
+        for lo in range(0, self.data_len, batch_size):
+            yield self.__getitems__(order[lo : lo + batch_size])
 
 
 # ---- augmentation (data/transforms.py) -------------------------------------------------------------

@@ -1,4 +1,5 @@
-"""Host-side mirror of the reference environment surface for TSP and CVRP.
+"""Host-side mirror of the reference environment surface for TSP, CVRP and the routing environments that share
+their decode kernel (OP, PCTSP / SPCTSP, PDP, CVRPTW).
 
 Same names, arguments and error behaviour as ``RL4COEnvBase`` (envs/common/base.py:19-333),
 ``TSPEnv`` (envs/routing/tsp/env.py:22-192) and ``CVRPEnv`` (envs/routing/cvrp/env.py:22-256)
@@ -11,9 +12,12 @@ Differences a caller can observe, both deliberate:
     step and swaps them into the TensorDict);
   * validity asserts are evaluated on the device and raised once, by ``get_reward``, with the
     reference's messages, instead of synchronising the host every step.
-Out of scope (not on the rollout path): dataset files, rendering, local search, torchrl specs.
+``dataset`` / ``load_data`` (base.py:234-286) serve npz instance files straight to the device (rl4co_amd/data.py).
+Out of scope (not on the rollout path): rendering, local search, torchrl specs.
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.nn.functional as F
@@ -233,6 +237,10 @@ class RL4COEnvBase:
                  check_solution: bool = True, device="cuda", seed: int | None = None, **unused):
         self.check_solution = check_solution
         self.device = torch.device(device)
+        self.data_dir = unused.get("data_dir", "data/")  # base.py:57-75: per-phase instance files (npz), optional
+        for phase in ("train", "val", "test"):
+            f = unused.get(f"{phase}_file", None)
+            setattr(self, f"{phase}_file", None if f is None else os.path.join(self.data_dir, f))
         self.generator = generator if generator is not None else self._default_generator(**(generator_params or {}))
         if seed is not None:
             torch.manual_seed(seed)
@@ -257,6 +265,30 @@ class RL4COEnvBase:
         if check_solution:
             self.check_solution_validity(td, actions)
         return self._get_reward(td, actions)
+
+    # -- RL4COEnvBase.dataset / load_data (base.py:234-286) ----------------------------------------
+    def dataset(self, batch_size=(), phase: str = "train", filename: str | None = None):
+        """Instances of one phase as a dataset: loaded from ``<phase>_file`` / ``filename`` (npz, straight to this
+        env's device) or generated on the device. A missing file falls back to generation, as in the reference."""
+        from .data import TensorDictDataset
+
+        f = getattr(self, f"{phase}_file", None) if filename is None else filename
+        batch_size = [batch_size] if isinstance(batch_size, int) else list(batch_size)
+        td = None
+        if f is not None:
+            try:
+                td = self.load_data(f, batch_size, device=self.device)
+            except FileNotFoundError:
+                td = None
+        if td is None:
+            td = self.generator(batch_size=batch_size)
+        return TensorDictDataset(td)
+
+    @staticmethod
+    def load_data(fpath, batch_size=(), device=None):
+        from .data import load_npz_to_tensordict
+
+        return load_npz_to_tensordict(fpath, device=device)
 
     def get_num_starts(self, td) -> int:
         """ops.py:115-125"""
@@ -378,6 +410,15 @@ class CVRPEnv(RL4COEnvBase):
         K.cvrp_step(None, td["demand"], td["used_capacity"], td["vehicle_capacity"], td["visited"],
                     td["current_node"], td["action_mask"], None)
         return td["action_mask"]
+
+    @staticmethod
+    def load_data(fpath, batch_size=(), device=None):
+        """cvrp/env.py:179-186: the instance files hold integer demands 1..9 and the capacity; normalise to [0, 1]"""
+        from .data import load_npz_to_tensordict
+
+        td = load_npz_to_tensordict(fpath, device=device)
+        td.set("demand", td["demand"] / td["capacity"][:, None])
+        return td
 
     def _get_reward(self, td: TensorDict, actions: Tensor) -> Tensor:
         """cvrp/env.py:138-147"""

@@ -97,3 +97,80 @@ def test_pomo_evaluate_epilogue(cpu_device):
     torch.testing.assert_close(-lengths, out["max_aug_reward"], rtol=1e-5, atol=1e-5)
     # augmentation can only help: best over 8 symmetries >= the identity block's best start
     assert bool((out["max_aug_reward"] >= out["max_reward"][:, 0] - 1e-6).all())
+
+
+# ---------------------------------------------------------------------------------------------
+# instance files and datasets (row N2): generate_data.py / dataset.py / RL4COEnvBase.dataset
+# ---------------------------------------------------------------------------------------------
+
+@needs_reference
+@pytest.mark.parametrize("problem,size,dist", [("tsp", 20, None), ("vrp", 50, None), ("pdp", 20, None), ("op", 20, "const"),
+                                               ("op", 50, "unif"), ("op", 100, "dist"), ("pctsp", 50, None)])
+def test_generated_instance_files_equal_reference_generator(problem, size, dist):
+    """The same numpy draws under the same seed: every array of the file equals the reference generator's, bit for bit."""
+    import importlib
+
+    from rl4co_amd import data as D
+
+    ref_import.install()
+    ref_gen = importlib.import_module("rl4co.data.generate_data")
+    np.random.seed(4321)
+    want = ref_gen.generate_env_data(problem, 64, size, dist)
+    np.random.seed(4321)
+    got = D.generate_env_data(problem, 64, size, dist)
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert got[k].dtype == want[k].dtype and np.array_equal(got[k], want[k]), k
+
+
+@needs_reference
+def test_generate_dataset_files_equal_reference(tmp_path):
+    import importlib
+
+    from rl4co_amd import data as D
+
+    ref_import.install()
+    ref_gen = importlib.import_module("rl4co.data.generate_data")
+    kw = dict(name="val", problem="op", dataset_size=32, graph_sizes=[20, 50], seed=4321)
+    ours = D.generate_dataset(data_dir=str(tmp_path / "ours"), **kw)
+    ref_gen.generate_dataset(data_dir=str(tmp_path / "ref"), **kw)
+    assert len(ours) == 6  # three prize distributions x two sizes
+    for f in ours:
+        rel = f[len(str(tmp_path / "ours")) + 1:]
+        a, b = np.load(f), np.load(str(tmp_path / "ref" / rel))
+        assert sorted(a.files) == sorted(b.files)
+        for k in a.files:
+            assert np.array_equal(a[k], b[k]), (rel, k)
+    assert D.generate_dataset(data_dir=str(tmp_path / "ours"), **kw) == []  # existing files are kept unless overwrite=True
+    with pytest.raises(NotImplementedError):
+        D.generate_env_data("mdpp", 4, 10)
+
+
+def test_dataset_serves_batches_and_env_dataset_loads_files(cpu_device, tmp_path):
+    from rl4co_amd import data as D
+    from rl4co_amd.envs import get_env
+
+    files = D.generate_dataset(data_dir=str(tmp_path), name="test", problem="vrp", dataset_size=40, graph_sizes=20, seed=1234)
+    assert files == [str(tmp_path / "vrp" / "vrp20_test_seed1234.npz")]
+    env = get_env("cvrp", generator_params=dict(num_loc=20), device="cpu", data_dir=str(tmp_path),
+                  test_file="vrp/vrp20_test_seed1234.npz")
+    ds = env.dataset(phase="test")
+    assert len(ds) == 40 and sorted(ds.data.keys()) == ["capacity", "demand", "depot", "locs"]
+    raw = np.load(files[0])
+    assert np.array_equal(ds.data["demand"].numpy(), raw["demand"] / raw["capacity"][:, None])  # cvrp/env.py:179-186
+    td0 = env.reset(ds.__getitems__(list(range(8))))  # a loaded batch resets like a generated one
+    assert td0["action_mask"].shape == (8, 21) and bool(td0["action_mask"][:, 1:].all())
+    batches = list(ds.batches(16))
+    assert [b.batch_size[0] for b in batches] == [16, 16, 8]
+    assert torch.equal(torch.cat([b["locs"] for b in batches]), ds.data["locs"])
+    g = torch.Generator().manual_seed(0)
+    shuffled = torch.cat([b["demand"] for b in ds.batches(16, shuffle=True, generator=g)])
+    assert not torch.equal(shuffled, ds.data["demand"]) and torch.equal(shuffled.sort(0).values, ds.data["demand"].sort(0).values)
+    ds.add_key("extra", torch.arange(40.0))
+    b0 = ds.__getitems__([3, 5])
+    assert b0["extra"].tolist() == [3.0, 5.0] and torch.equal(b0["locs"], ds.data["locs"][[3, 5]])
+    stacked = ds.collate_fn([ds[i] for i in (3, 5)])
+    assert torch.equal(stacked["locs"], b0["locs"])
+    # no file configured / file missing: generated on the fly (base.py:240-262)
+    assert len(env.dataset(batch_size=[12], phase="val")) == 12
+    assert len(env.dataset(batch_size=[7], phase="val", filename=str(tmp_path / "missing.npz"))) == 7
