@@ -197,6 +197,27 @@ class TensorDictDataset:
             yield self.__getitems__(order[lo : lo + batch_size])
 
 
+def greedy_rollout_rewards(policy, env, dataset: TensorDictDataset, batch_size: int = 64) -> Tensor:
+    """``RolloutBaseline.rollout`` (rl/reinforce/baselines.py:218-237): the policy's greedy reward of every instance
+    of the dataset, batch by batch through the fused rollout; instances and rewards stay on the device."""
+    was_training = policy.training
+    policy.eval()
+    try:
+        with torch.inference_mode():
+            rewards = [policy(env.reset(batch), env, phase="test", decode_type="greedy")["reward"]
+                       for batch in dataset.batches(batch_size)]
+    finally:
+        policy.train(was_training)
+    return torch.cat(rewards, 0)
+
+
+def wrap_dataset_with_baseline(policy, env, dataset: TensorDictDataset, batch_size: int = 64) -> TensorDictDataset:
+    """``RolloutBaseline.wrap_dataset`` (baselines.py:239-248): the baseline policy's greedy reward rides with
+    every instance as ``extra`` — evaluated once per epoch over the whole dataset (1.28 M instances by default,
+    SURVEY.md §8f N2), which is why it runs through the same rollout kernels with the data kept on the GPU."""
+    return dataset.add_key("extra", greedy_rollout_rewards(policy, env, dataset, batch_size).detach())
+
+
 # ---- augmentation (data/transforms.py) -------------------------------------------------------------
 
 def dihedral_8_augmentation(xy: Tensor) -> Tensor:

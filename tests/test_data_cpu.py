@@ -174,3 +174,24 @@ def test_dataset_serves_batches_and_env_dataset_loads_files(cpu_device, tmp_path
     # no file configured / file missing: generated on the fly (base.py:240-262)
     assert len(env.dataset(batch_size=[12], phase="val")) == 12
     assert len(env.dataset(batch_size=[7], phase="val", filename=str(tmp_path / "missing.npz"))) == 7
+
+
+def test_rollout_baseline_wraps_dataset_with_greedy_rewards(cpu_device):
+    """RolloutBaseline.rollout / wrap_dataset (baselines.py:218-248): batch-wise greedy rewards == one big greedy
+    rollout, attached to the dataset as "extra" and served with every batch."""
+    from rl4co_amd import data as D
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.policy import AttentionModelPolicy
+    from rl4co_amd.tensordict import TensorDict
+
+    g = GoldenCase("tsp20_b64_greedy_simple")
+    pol = AttentionModelPolicy(env_name="tsp", **{k: v for k, v in g.meta["policy_kwargs"].items() if k != "sdpa_fn_decoder"})
+    pol.load_state_dict(g.policy.state_dict())
+    pol.train()
+    env = get_env("tsp", generator_params=dict(num_loc=20), device="cpu")
+    ds = D.TensorDictDataset(TensorDict({k: v.clone() for k, v in g.data.items()}, batch_size=[g.batch]))
+    ds = D.wrap_dataset_with_baseline(pol, env, ds, batch_size=24)
+    assert pol.training  # the mode is restored
+    assert torch.equal(ds.data["extra"], g.reward)  # greedy rewards of the golden run, in dataset order
+    batch = next(ds.batches(16))
+    assert torch.equal(batch["extra"], g.reward[:16])
