@@ -449,6 +449,11 @@ int rl4co_am_teacher_variant(const rl4co_am_teacher_args* args);
  * out[m,:] = W[128,F] . feats[m,:F] + b  (F <= 6: x, y (, demand, ...)); fp32 in, bf16 out [M,128].
  * -------------------------------------------------------------------------- */
 int rl4co_init_embed_bf16(const float* feats, const float* w, const float* b, int64_t M, int F, void* out, void* stream);
+/* backward of the above w.r.t. W and b: partial[g, c, 0..F-1] = sum over the rows of block g of dout[m,c] * feats[m,f],
+ * partial[g, c, F] = sum of dout[m,c]; dout bf16 [M,128], partial fp32 [blocks,128,F+1] (summed over g by the caller in a
+ * fixed order: deterministic). Returns the number of blocks the launch uses through *blocks_out when partial == NULL. */
+int rl4co_init_embed_wgrad_bf16(const void* dout, const float* feats, int64_t M, int F, float* partial, int* blocks_out,
+                                void* stream);
 
 /* --------------------------------------------------------------------------
  * a12 (training)  SkipConnection + Normalization("instance")

@@ -624,6 +624,61 @@ __global__ void __launch_bounds__(256) init_embed_kernel(const float* __restrict
 }
 }  // namespace
 
+namespace {
+constexpr int kInitWgradBlocks = 1024;
+// Thread = channel pair (tid & 63) x row lane (tid >> 6): a wave reads one 256-byte row of dout per iteration,
+// the row's F features are a broadcast load. Per-block partial sums, reduced by the caller in a fixed order.
+__global__ void __launch_bounds__(256) init_embed_wgrad_kernel(const uint32_t* __restrict__ dout, const float* __restrict__ feats,
+                                                               int64_t M, int F, float* __restrict__ partial) {
+  const int tid = threadIdx.x, cp = tid & 63, q = tid >> 6;
+  __shared__ float red[4][128][7];
+  float a0[7], a1[7];
+#pragma unroll
+  for (int f = 0; f < 7; ++f) a0[f] = a1[f] = 0.0f;
+  const int64_t per = (M + gridDim.x - 1) / gridDim.x;
+  const int64_t lo = (int64_t)blockIdx.x * per, hi = min(M, lo + per);
+  for (int64_t r = lo + q; r < hi; r += 4) {
+    const uint32_t pk = dout[r * 64 + cp];
+    const float d0 = __uint_as_float(pk << 16), d1 = __uint_as_float(pk & 0xffff0000u);
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+      if (f < F) {
+        const float x = feats[r * F + f];
+        a0[f] = fmaf(d0, x, a0[f]);
+        a1[f] = fmaf(d1, x, a1[f]);
+      }
+    }
+    a0[6] += d0;
+    a1[6] += d1;
+  }
+#pragma unroll
+  for (int f = 0; f < 7; ++f) {
+    red[q][2 * cp][f] = a0[f];
+    red[q][2 * cp + 1][f] = a1[f];
+  }
+  __syncthreads();
+  float* out = partial + (int64_t)blockIdx.x * 128 * (F + 1);
+  for (int i = tid; i < 128 * (F + 1); i += 256) {
+    const int c = i / (F + 1), f = i % (F + 1);
+    const int src = f < F ? f : 6;
+    out[i] = ((red[0][c][src] + red[1][c][src]) + red[2][c][src]) + red[3][c][src];
+  }
+}
+}  // namespace
+
+extern "C" int rl4co_init_embed_wgrad_bf16(const void* dout, const float* feats, int64_t M, int F, float* partial,
+                                           int* blocks_out, void* stream) {
+  RL4CO_REQUIRE(M > 0 && F >= 1 && F <= 6);
+  const int blocks = (int)min((int64_t)kInitWgradBlocks, (M + 63) / 64);
+  if (blocks_out) *blocks_out = blocks;
+  if (partial == nullptr) return RL4CO_OK;  // size query
+  RL4CO_REQUIRE(dout && feats);
+  hipLaunchKernelGGL(init_embed_wgrad_kernel, dim3(blocks), dim3(256), 0, rl4co::as_stream(stream),
+                     static_cast<const uint32_t*>(dout), feats, M, F, partial);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
 extern "C" int rl4co_init_embed_bf16(const float* feats, const float* w, const float* b, int64_t M, int F, void* out, void* stream) {
   RL4CO_REQUIRE(feats && w && b && out && M > 0 && F >= 1 && F <= 6);
   const int blocks = (int)min((int64_t)8192, (M + 3) / 4);

@@ -284,8 +284,23 @@ class _InitEmbed(torch.autograd.Function):
     def backward(ctx, dout: Tensor):
         (f2,) = ctx.saved_tensors
         d = dout.reshape(-1, EMBED_DIM)
-        dw = torch.matmul(d.t().float(), f2) if d.dtype != torch.float32 else torch.matmul(d.t(), f2)
-        return None, dw.to(ctx.pdt), d.sum(0, dtype=torch.float32).to(ctx.pdt)
+        if d.dtype != torch.bfloat16:  # not under autocast: the library path
+            return None, torch.matmul(d.t().float(), f2).to(ctx.pdt), d.sum(0, dtype=torch.float32).to(ctx.pdt)
+        # a [128, M] x [M, F] product with F <= 6 is a reduction, not a GEMM (the library needs 1 ms and an fp32 copy of
+        # dout for it at M = 409 600): per-block partial sums of dW and db in one pass over dout, summed in a fixed order
+        d = d.contiguous()
+        m, f = f2.shape
+        import ctypes as C
+
+        nblk = C.c_int(0)
+        lib = _lib.lib()
+        _lib.check(lib.rl4co_init_embed_wgrad_bf16(None, None, m, f, None, C.byref(nblk), None), "rl4co_init_embed_wgrad_bf16")
+        partial = torch.empty((nblk.value, EMBED_DIM, f + 1), dtype=torch.float32, device=d.device)
+        st = lib.rl4co_init_embed_wgrad_bf16(d.data_ptr(), f2.data_ptr(), m, f, partial.data_ptr(), None,
+                                             torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "rl4co_init_embed_wgrad_bf16")
+        g = partial.sum(0)
+        return None, g[:, :f].to(ctx.pdt), g[:, f].to(ctx.pdt)
 
 
 def init_embed(feats: Tensor, lin: torch.nn.Linear) -> Tensor:

@@ -357,3 +357,28 @@ def test_fused_skip_batch_norm_matches_torch():
     torch.testing.assert_close(bn.running_mean, ref_bn.running_mean, rtol=1e-3, atol=1e-4)
     torch.testing.assert_close(bn.running_var, ref_bn.running_var, rtol=1e-3, atol=1e-4)
     assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("m,f", [(1, 2), (63, 3), (4096 * 100, 2), (4096 * 100 + 7, 4), (70000, 6)])
+def test_init_embed_forward_and_weight_gradients_match_torch(m, f):
+    """Init embedding under autocast (rl4co_init_embed_bf16 / rl4co_init_embed_wgrad_bf16) vs torch fp32 on the same
+    bf16-rounded upstream gradient: output within bf16 rounding, dW / db within 1e-3 relative (fp32 sums over up to
+    409 600 rows in a different order), and bit-reproducible from run to run (fixed-order partial sums)."""
+    from rl4co_amd import train_ops
+
+    torch.manual_seed(m + f)
+    lin = torch.nn.Linear(f, 128).cuda()
+    feats = (torch.rand(m, f, device="cuda") * (400.0 if f == 6 else 1.0)).requires_grad_(False)
+    dout = torch.randn(m, 128, device="cuda").to(torch.bfloat16)
+    out = train_ops.init_embed(feats, lin)
+    ref = torch.nn.functional.linear(feats, lin.weight, lin.bias)
+    torch.testing.assert_close(out.detach().float(), ref.detach(), rtol=8e-3, atol=8e-3 * float(ref.detach().abs().max()))
+    out.backward(dout)
+    gw, gb = lin.weight.grad.clone(), lin.bias.grad.clone()
+    want_w = dout.float().t() @ feats
+    want_b = dout.float().sum(0)
+    assert float((gw - want_w).norm()) <= 1e-3 * float(want_w.norm()) + 1e-4
+    assert float((gb - want_b).norm()) <= 1e-3 * float(want_b.norm()) + 1e-4
+    lin.zero_grad()
+    train_ops.init_embed(feats, lin).backward(dout)
+    assert torch.equal(lin.weight.grad, gw) and torch.equal(lin.bias.grad, gb)
