@@ -500,9 +500,11 @@ int rl4co_linear_bf16(const void* a, const void* w, const float* bias, const voi
 /* Weight gradient of the same layers: partial[c][N,K] = dY[rows of chunk c]^T . X[rows of chunk c]
  * (bf16 dY [M,N], X [M,K]; fp32 partial [chunks,N,K], every element written); dW = sum over c.
  * partial_bias [chunks,N] (or NULL) receives the column sums of dY per chunk: db = sum over c.
- * The rows are split into `chunks` equal ranges (a multiple of 32 rows each). */
+ * The rows are split into `chunks` equal ranges (a multiple of 32 rows each).
+ * chunk_stride: elements between consecutive chunks of BOTH partial arrays; 0 = packed (N*K and N). With
+ * partial_bias = partial + N*K and chunk_stride = N*K + N one reduction over the chunk axis yields dW and db. */
 int rl4co_wgrad_bf16(const void* dy, const void* x, int64_t M, int N, int K, int chunks, float* partial,
-                     float* partial_bias, void* stream);
+                     float* partial_bias, int64_t chunk_stride, void* stream);
 
 /* --------------------------------------------------------------------------
  * a12 (training)  encoder self-attention on the packed projection output

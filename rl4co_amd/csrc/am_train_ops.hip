@@ -353,7 +353,7 @@ __device__ inline bf16x4w lds_tr_w(const __bf16* p) {
 
 __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X, int M, int N,
                                                          int K, int rows_per_chunk, float* __restrict__ partial,
-                                                         float* __restrict__ partial_bias) {
+                                                         float* __restrict__ partial_bias, int64_t pstride, int64_t bstride) {
   __shared__ __align__(16) __bf16 dyt[kWT * kWLS];  // [32 tokens][128 output features of this tile]
   __shared__ __align__(16) __bf16 xt[kWT * kWLS];   // [32 tokens][128 input features of this tile]
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const uint16_t* __restr
       }
     }
   }
-  float* out = partial + (int64_t)chunk * N * K;
+  float* out = partial + (int64_t)chunk * pstride;
 #pragma unroll
   for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -418,19 +418,22 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const uint16_t* __restr
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) partial_bias[(int64_t)chunk * N + nt * 128 + 32 * w + 16 * nb + 4 * g + r] = accb[nb][r];
+      for (int r = 0; r < 4; ++r) partial_bias[(int64_t)chunk * bstride + nt * 128 + 32 * w + 16 * nb + 4 * g + r] = accb[nb][r];
   }
 }
 
 }  // namespace
 
 extern "C" int rl4co_wgrad_bf16(const void* dy, const void* x, int64_t M, int N, int K, int chunks, float* partial,
-                                float* partial_bias, void* stream) {
+                                float* partial_bias, int64_t chunk_stride, void* stream) {
+  RL4CO_REQUIRE(chunk_stride == 0 || chunk_stride >= (int64_t)N * K);
+  const int64_t pstride = chunk_stride ? chunk_stride : (int64_t)N * K, bstride = chunk_stride ? chunk_stride : (int64_t)N;
   RL4CO_REQUIRE(dy && x && partial);
   RL4CO_REQUIRE(M > 0 && M < (int64_t)1 << 31 && N > 0 && K > 0 && N % 128 == 0 && K % 128 == 0 && chunks > 0 && chunks <= 65535);
   const int rows = (int)(((M + chunks - 1) / chunks + kWT - 1) / kWT * kWT);
   hipLaunchKernelGGL(wgrad_bf16_kernel, dim3((N / 128) * (K / 128), chunks), dim3(256), 0, rl4co::as_stream(stream),
-                     static_cast<const uint16_t*>(dy), static_cast<const uint16_t*>(x), (int)M, N, K, rows, partial, partial_bias);
+                     static_cast<const uint16_t*>(dy), static_cast<const uint16_t*>(x), (int)M, N, K, rows, partial, partial_bias,
+                     pstride, bstride);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }

@@ -156,13 +156,16 @@ def _wgrad(d2: Tensor, x2: Tensor, with_bias: bool = False):
     k = x2.shape[1]
     tiles = (n // 128) * (k // 128)
     chunks = max(1, min(1024 // tiles, (m + 255) // 256))
-    partial = torch.empty((chunks, n, k), dtype=torch.float32, device=d2.device)
-    pbias = torch.empty((chunks, n), dtype=torch.float32, device=d2.device) if with_bias else None
+    # one buffer per chunk: [N*K weight partials | N bias partials] -> ONE reduction over the chunk axis for both
+    width = n * k + (n if with_bias else 0)
+    partial = torch.empty((chunks, width), dtype=torch.float32, device=d2.device)
     st = _lib.lib().rl4co_wgrad_bf16(d2.data_ptr(), x2.data_ptr(), m, n, k, chunks, partial.data_ptr(),
-                                     None if pbias is None else pbias.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                                     partial.data_ptr() + 4 * n * k if with_bias else None, width,
+                                     torch.cuda.current_stream().cuda_stream)
     _lib.check(st, "rl4co_wgrad_bf16")
-    dw = partial.sum(0)
-    return (dw, pbias.sum(0)) if with_bias else dw
+    g = partial.sum(0)
+    dw = g[: n * k].view(n, k)
+    return (dw, g[n * k :]) if with_bias else dw
 
 
 def linear_usable(x: Tensor, *weights: Tensor) -> bool:
