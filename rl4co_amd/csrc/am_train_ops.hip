@@ -260,50 +260,65 @@ __global__ void __launch_bounds__(kGemmThreads, 2) linear_bf16_kernel(const uint
       }
     }
     if (kc == nkc - 1) {
-      // epilogue straight from the accumulators: a lane holds four consecutive features of its
-      // token (8-byte stores; the 256-byte row segments of a tile merge in L2)
-      const int64_t row = m0 + 32 * w + l31;
-      if (row < M) {
+      // epilogue: + bias, ReLU in the accumulators; the tile then leaves through LDS so that the global stores
+      // are 16 bytes per lane over contiguous 256-byte row segments (stored straight from the accumulators a lane
+      // owns 8 bytes in each of 32 different rows: the write path, not HBM, bounded the wide-N shapes at 2.4 TB/s).
+      // The weight tile `ws` is dead once every wave has issued its products; each wave stages and drains only
+      // its own 32 token rows, so the staging itself needs no workgroup barrier.
+      rl4co::lds_barrier();
+      __bf16* os = ws;  // [128 tokens][kLS]
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
+      for (int ct = 0; ct < 4; ++ct) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int f0 = nt * kTN + 32 * ct + 8 * q + 4 * hi;
-            float v[4];
-            if (bias) {
-              const float4 b4 = *reinterpret_cast<const float4*>(bias + f0);
-              v[0] = acc[ct][4 * q] + b4.x;
-              v[1] = acc[ct][4 * q + 1] + b4.y;
-              v[2] = acc[ct][4 * q + 2] + b4.z;
-              v[3] = acc[ct][4 * q + 3] + b4.w;
-            } else {
+        for (int q = 0; q < 4; ++q) {
+          const int fl = 32 * ct + 8 * q + 4 * hi;  // feature inside the tile
+          float v[4];
+          if (bias) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bias + nt * kTN + fl);
+            v[0] = acc[ct][4 * q] + b4.x;
+            v[1] = acc[ct][4 * q + 1] + b4.y;
+            v[2] = acc[ct][4 * q + 2] + b4.z;
+            v[3] = acc[ct][4 * q + 3] + b4.w;
+          } else {
 #pragma unroll
-              for (int i = 0; i < 4; ++i) v[i] = acc[ct][4 * q + i];
-            }
-            if (relu) {
-#pragma unroll
-              for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
-            }
-            if (mask) {
-              const uint2 mk = *reinterpret_cast<const uint2*>(mask + row * N + f0);
-              // bf16 > 0  <=>  sign bit clear and magnitude non-zero
-              v[0] = ((mk.x & 0x8000u) == 0 && (mk.x & 0x7fffu) != 0) ? v[0] : 0.0f;
-              v[1] = ((mk.x >> 31) == 0 && (mk.x & 0x7fff0000u) != 0) ? v[1] : 0.0f;
-              v[2] = ((mk.y & 0x8000u) == 0 && (mk.y & 0x7fffu) != 0) ? v[2] : 0.0f;
-              v[3] = ((mk.y >> 31) == 0 && (mk.y & 0x7fff0000u) != 0) ? v[3] : 0.0f;
-            }
-            bf16x4g o;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
-            *reinterpret_cast<bf16x4g*>(out + row * N + f0) = o;
+            for (int i = 0; i < 4; ++i) v[i] = acc[ct][4 * q + i];
           }
+          if (relu) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
+          }
+          bf16x4g o;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+          *reinterpret_cast<bf16x4g*>(os + (32 * w + l31) * kLS + fl) = o;
+        }
+      }
+      rl4co::lds_barrier_wave();
+      const int orow = lane >> 4, ocol = (lane & 15) * 8;  // four rows per pass, 16 bytes per lane
+#pragma unroll
+      for (int p8 = 0; p8 < 8; ++p8) {
+        const int tr = 32 * w + 4 * p8 + orow;
+        const int64_t row = m0 + tr;
+        u32x4 val = *reinterpret_cast<const u32x4*>(os + tr * kLS + ocol);
+        if (row < M) {
+          if (mask) {  // ReLU backward: keep where the forward activation was positive (bf16 > 0)
+            const u32x4 mk = *reinterpret_cast<const u32x4*>(mask + row * N + nt * kTN + ocol);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const uint32_t m_ = mk[i];
+              const uint32_t keep_lo = ((m_ & 0x8000u) == 0 && (m_ & 0x7fffu) != 0) ? 0x0000ffffu : 0u;
+              const uint32_t keep_hi = ((m_ >> 31) == 0 && (m_ & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
+              val[i] &= (keep_lo | keep_hi);
+            }
+          }
+          *reinterpret_cast<u32x4*>(out + row * N + nt * kTN + ocol) = val;
         }
       }
     }
     if (more) {
-      __syncthreads();  // every wave is done with this step's LDS operands
+      rl4co::lds_barrier();  // every wave is done with this step's LDS operands (and with the staged output tile)
       RL4CO_COMMIT(next_a)
-      __syncthreads();
+      rl4co::lds_barrier();
     }
   }
 #undef RL4CO_FETCH

@@ -38,6 +38,14 @@ int teacher_mma_max_steps();
 // operation (s_waitcnt vmcnt(0) lgkmcnt(0)) before s_barrier, which puts the L2 round trip of any
 // in-flight global store / atomic / prefetch in front of each barrier; kernels that meet several
 // times per step on LDS data only need their LDS traffic drained.
+// LDS hand-over inside ONE wavefront (lanes exchange rows only their own wave wrote): DS operations of a wave
+// execute in order, so a compiler/memory fence without an s_barrier is enough.
+__device__ inline void lds_barrier_wave() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
 __device__ inline void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }

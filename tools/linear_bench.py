@@ -1,0 +1,29 @@
+"""Micro-benchmark of rl4co_linear_bf16 / rl4co_wgrad_bf16 on the training shapes (M = 4096 x 100 token rows)."""
+import sys, torch
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from rl4co_amd import train_ops as T
+
+M = 409600
+def bench(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3  # us
+
+for k, n, relu in ((128, 384, False), (128, 128, False), (128, 512, True), (512, 128, False), (384, 128, False)):
+    a = torch.randn(M, k, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(n, k, device="cuda") * 0.05).to(torch.bfloat16)
+    b = torch.zeros(n, device="cuda")
+    us = bench(lambda: T._gemm(a, w, b, relu=relu))
+    gb = (M * k + M * n) * 2 / 1e9
+    lib = bench(lambda: torch.nn.functional.linear(a, w))
+    print(f"linear  K={k:4d} N={n:4d}: {us:7.1f} us  {gb / us * 1e6 / 1e3:6.2f} TB/s  ({gb*1e3:5.0f} MB)   hipBLASLt {lib:7.1f} us")
+for n, k in ((384, 128), (128, 128), (512, 128), (128, 512)):
+    d = torch.randn(M, n, device="cuda").to(torch.bfloat16)
+    x = torch.randn(M, k, device="cuda").to(torch.bfloat16)
+    us = bench(lambda: T._wgrad(d, x, with_bias=True))
+    gb = (M * k + M * n) * 2 / 1e9
+    print(f"wgrad   N={n:4d} K={k:4d}: {us:7.1f} us  {gb / us * 1e6 / 1e3:6.2f} TB/s")
