@@ -433,21 +433,17 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) acc[tt] = zero16();
     gemm_t<TT>(acc, wf, xs, lane, blk + 1 < nblocks ? wf_all + (int64_t)(blk + 1) * kD * kD : nullptr, 8, w, 0);
+    // The tile leaves through LDS (`ys` is free after the last layer): stored straight from the accumulators a lane
+    // owns 8 / 16 bytes in each of 32 token rows; staged, a plane of an instance is ONE contiguous run of 16-byte lanes.
     if (blk < 3 && a.cache_dtype == RL4CO_DT_BF16) {
       __bf16* out = static_cast<__bf16*>(a.kvl) + (int64_t)blk * a.kvl_plane_stride + (int64_t)b * a.kvl_batch_stride;
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt) {
-        const int tok = 32 * tt + l31;
-        if (tok < N) {
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            bf16x4 v;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) v[s] = (__bf16)acc[tt][4 * c + s];
-            *reinterpret_cast<bf16x4*>(out + (int64_t)tok * kD + 32 * w + 8 * c + 4 * hi) = v;
-          }
-        }
+      store_t<TT>(ys, acc, 32 * w, lane);
+      __syncthreads();
+      for (int i = tid; i < N * 16; i += kThreads) {
+        const int row = i >> 4, c16 = i & 15;
+        *reinterpret_cast<uint4*>(out + (int64_t)row * kD + 8 * c16) = *reinterpret_cast<const uint4*>(ys + row * kRS + 8 * c16);
       }
+      __syncthreads();
     } else {
       float* out;
       if (blk < 3) {
@@ -457,16 +453,29 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       } else {
         out = a.ctx_cur + (int64_t)b * N * kD;
       }
+      constexpr int kFS = kD + 4;  // fp32 staging row stride: 64 token rows fit the 34 KB of ys
+      float* fs = reinterpret_cast<float*>(ys);
 #pragma unroll
-      for (int tt = 0; tt < TT; ++tt) {
-        const int tok = 32 * tt + l31;
-        if (tok < N) {
+      for (int p = 0; p < (TT + 1) / 2; ++p) {
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float4 v = make_float4(acc[tt][4 * c], acc[tt][4 * c + 1], acc[tt][4 * c + 2], acc[tt][4 * c + 3]);
-            *reinterpret_cast<float4*>(out + (int64_t)tok * kD + 32 * w + 8 * c + 4 * hi) = v;
+        for (int t2 = 0; t2 < 2; ++t2) {
+          const int tt = 2 * p + t2;
+          if (tt < TT) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const float4 v = make_float4(acc[tt][4 * c], acc[tt][4 * c + 1], acc[tt][4 * c + 2], acc[tt][4 * c + 3]);
+              *reinterpret_cast<float4*>(fs + (32 * t2 + l31) * kFS + 32 * w + 8 * c + 4 * hi) = v;
+            }
           }
         }
+        __syncthreads();
+        const int rows = min(64, N - 64 * p);
+        for (int i = tid; i < rows * 32; i += kThreads) {
+          const int row = i >> 5, c4 = i & 31;
+          *reinterpret_cast<float4*>(out + (int64_t)(64 * p + row) * kD + 4 * c4) =
+              *reinterpret_cast<const float4*>(fs + row * kFS + 4 * c4);
+        }
+        __syncthreads();
       }
     }
   }
