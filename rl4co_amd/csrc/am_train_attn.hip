@@ -117,9 +117,17 @@ __global__ void __launch_bounds__(kThreads, 2) attn_fwd_kernel(const uint16_t* _
       f32x4 o;
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) o[rr] = (o0[rr] + o1[rr]) * inv;
-      *reinterpret_cast<bf16x4*>(out + (inst * N + t) * kD + 16 * h + 4 * g) = to_bf16(o);
+      // parked over this wave's own (consumed) Q columns of the block; the tile leaves coalesced below
+      *reinterpret_cast<bf16x4*>(qs + t * kQS + 16 * h + 4 * g) = to_bf16(o);
       if (g == 0) lse[(inst * kWaves + h) * N + t] = m + __builtin_amdgcn_logf(l);  // log2 domain
     }
+  }
+  // 8-byte stores from the accumulators put 32 bytes per wave into each of 16 rows; staged, the instance's
+  // [N, 128] output is one contiguous run of 16-byte lanes
+  __syncthreads();
+  for (int c = tid; c < N * 16; c += kThreads) {
+    const int row = c >> 4, col = (c & 15) * 8;
+    *reinterpret_cast<uint4*>(out + (inst * N + row) * kD + col) = *reinterpret_cast<const uint4*>(qs + row * kQS + col);
   }
 }
 
@@ -191,7 +199,7 @@ __global__ void __launch_bounds__(kThreads, 2) attn_bwd_kernel(const uint16_t* _
     if (tv) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) dq[rr] *= 0.25f;
-      *reinterpret_cast<bf16x4*>(dqkv + (inst * N + t) * 3 * kD + 16 * h + 4 * g) = to_bf16(dq);
+      *reinterpret_cast<bf16x4*>(qs + t * kQS + 16 * h + 4 * g) = to_bf16(dq);  // over this wave's consumed Q columns
     }
     wave_lds_sync();  // the next query block rewrites this wave's staging block
   }
@@ -201,10 +209,16 @@ __global__ void __launch_bounds__(kThreads, 2) attn_bwd_kernel(const uint16_t* _
     if (j < N) {
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) dk[jt][rr] *= 0.25f;
-      uint16_t* row = dqkv + (inst * N + j) * 3 * kD + 16 * h + 4 * g;
+      // this wave's K / V columns are dead (only head h reads them): d k, d v take their place
+      __bf16* row = qs + j * kQS + 16 * h + 4 * g;
       *reinterpret_cast<bf16x4*>(row + kD) = to_bf16(dk[jt]);
       *reinterpret_cast<bf16x4*>(row + 2 * kD) = to_bf16(dv[jt]);
     }
+  }
+  __syncthreads();  // [N][d q | d k | d v] complete in LDS: one contiguous run of 16-byte lanes per instance
+  for (int c = tid; c < N * 48; c += kThreads) {
+    const int row = c / 48, col = (c % 48) * 8;
+    *reinterpret_cast<uint4*>(dqkv + (inst * N + row) * 3 * kD + col) = *reinterpret_cast<const uint4*>(qs + row * kQS + col);
   }
 }
 
