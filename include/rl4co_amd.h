@@ -461,8 +461,8 @@ int rl4co_init_embed_wgrad_bf16(const void* dout, const float* feats, int64_t M,
  * forward : y = x + s ; out = (y - mean_n y) * rsqrt(var_n y + eps) * gamma + beta, statistics per
  *           instance and channel over the N nodes (biased variance). bf16 activations [B,N,128],
  *           fp32 arithmetic; y, mean[B,128], rstd[B,128] are kept for the backward pass.
- * backward: dy (the gradient of BOTH skip inputs) from dout; dgamma / dbeta accumulated
- *           atomically (zero-initialised by the caller). N <= rl4co_skip_inorm_max_nodes().
+ * backward: dy (the gradient of BOTH skip inputs) from dout; dgamma / dbeta [B,128]: the per-instance
+ *           contributions (every element written; the caller sums over B). N <= rl4co_skip_inorm_max_nodes().
  * -------------------------------------------------------------------------- */
 int rl4co_skip_inorm_fwd_bf16(const void* x, const void* s, const float* gamma, const float* beta, float eps,
                               int B, int N, void* y, void* out, float* mean, float* rstd, void* stream);

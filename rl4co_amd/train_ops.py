@@ -46,13 +46,14 @@ class _SkipInstanceNorm(torch.autograd.Function):
         if dc.dtype != torch.bfloat16:
             dc = dc.to(torch.bfloat16)
         dy = torch.empty_like(y)
-        dgamma = torch.zeros(d, dtype=torch.float32, device=y.device)
-        dbeta = torch.zeros(d, dtype=torch.float32, device=y.device)
+        part = torch.empty((2, b, d), dtype=torch.float32, device=y.device)  # per-instance d gamma | d beta
+        dgamma, dbeta = part[0], part[1]
         st = _lib.lib().rl4co_skip_inorm_bwd_bf16(dc.data_ptr(), y.data_ptr(), w32.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                                   b, n, dy.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
                                                   torch.cuda.current_stream().cuda_stream)
         _lib.check(st, "rl4co_skip_inorm_bwd_bf16")
-        return dy, dy, dgamma.to(ctx.param_dtype), dbeta.to(ctx.param_dtype), None
+        g = part.sum(1)  # one reduction over the instances for both, fixed order
+        return dy, dy, g[0].to(ctx.param_dtype), g[1].to(ctx.param_dtype), None
 
 
 class _SkipBatchNorm(torch.autograd.Function):
