@@ -27,3 +27,16 @@ for n, k in ((384, 128), (128, 128), (512, 128), (128, 512)):
     us = bench(lambda: T._wgrad(d, x, with_bias=True))
     gb = (M * k + M * n) * 2 / 1e9
     print(f"wgrad   N={n:4d} K={k:4d}: {us:7.1f} us  {gb / us * 1e6 / 1e3:6.2f} TB/s")
+
+# skip connection + instance norm (POMO), forward and backward, 4096 instances x 100 nodes
+x = torch.randn(4096, 100, 128, device="cuda").to(torch.bfloat16).requires_grad_(True)
+s_ = torch.randn(4096, 100, 128, device="cuda").to(torch.bfloat16).requires_grad_(True)
+gamma = torch.ones(128, device="cuda", requires_grad=True)
+beta = torch.zeros(128, device="cuda", requires_grad=True)
+us_f = bench(lambda: T.skip_instance_norm(x, s_, gamma, beta))
+out = T.skip_instance_norm(x, s_, gamma, beta)
+dout = torch.randn_like(out)
+us_fb = bench(lambda: torch.autograd.grad(T.skip_instance_norm(x, s_, gamma, beta), (x, s_, gamma, beta), dout))
+mb = 4096 * 100 * 128 * 2 / 1e6
+print(f"skip_inorm fwd: {us_f:7.1f} us ({4 * mb:.0f} MB -> {4 * mb / us_f:.2f} TB/s)   fwd+bwd: {us_fb:7.1f} us "
+      f"(bwd alone ~{us_fb - us_f:.1f} us, {3 * mb:.0f} MB -> {3 * mb / (us_fb - us_f):.2f} TB/s)")
