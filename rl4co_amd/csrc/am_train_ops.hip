@@ -58,13 +58,22 @@ __global__ void __launch_bounds__(kThreads) skip_inorm_fwd_kernel(const uint32_t
   const int64_t base = (int64_t)blockIdx.x * N * (kD / 2);
   float v[kMaxRows][2];
   float sum[2] = {0.0f, 0.0f};
+  // every row's loads are issued before the first use (rows past N re-read row N - 1 and are ignored): guarded
+  // per row the compiler emitted one load -> wait -> use round trip after another, 28 serial HBM latencies
+  uint32_t ra[kMaxRows], rb[kMaxRows];
+#pragma unroll
+  for (int i = 0; i < kMaxRows; ++i) {
+    const int n = min(q + 4 * i, N - 1);
+    ra[i] = x[base + (int64_t)n * (kD / 2) + cp];
+    rb[i] = s[base + (int64_t)n * (kD / 2) + cp];
+  }
 #pragma unroll
   for (int i = 0; i < kMaxRows; ++i) {
     const int n = q + 4 * i;
     v[i][0] = 0.0f;
     v[i][1] = 0.0f;
     if (n < N) {
-      const uint32_t a = x[base + (int64_t)n * (kD / 2) + cp], b = s[base + (int64_t)n * (kD / 2) + cp];
+      const uint32_t a = ra[i], b = rb[i];
       // the skip sum is rounded to bf16 like the reference's x + module(x) under autocast, and it is
       // the value the backward pass re-reads
       const uint32_t ys = pack_bf16(bf16_lo(a) + bf16_lo(b), bf16_hi(a) + bf16_hi(b));
@@ -117,12 +126,19 @@ __global__ void __launch_bounds__(kThreads) skip_inorm_bwd_kernel(const uint32_t
   const float g[2] = {gamma[2 * cp], gamma[2 * cp + 1]};
   float xh[kMaxRows][2], dd[kMaxRows][2];
   float s_d[2] = {0.0f, 0.0f}, s_dx[2] = {0.0f, 0.0f};
+  uint32_t ra[kMaxRows], rb[kMaxRows];  // all loads first (see the forward kernel)
+#pragma unroll
+  for (int i = 0; i < kMaxRows; ++i) {
+    const int n = min(q + 4 * i, N - 1);
+    ra[i] = dout[base + (int64_t)n * (kD / 2) + cp];
+    rb[i] = y[base + (int64_t)n * (kD / 2) + cp];
+  }
 #pragma unroll
   for (int i = 0; i < kMaxRows; ++i) {
     const int n = q + 4 * i;
     xh[i][0] = xh[i][1] = dd[i][0] = dd[i][1] = 0.0f;
     if (n < N) {
-      const uint32_t a = dout[base + (int64_t)n * (kD / 2) + cp], b = y[base + (int64_t)n * (kD / 2) + cp];
+      const uint32_t a = ra[i], b = rb[i];
       dd[i][0] = bf16_lo(a);
       dd[i][1] = bf16_hi(a);
       xh[i][0] = (bf16_lo(b) - mu[0]) * rs[0];
