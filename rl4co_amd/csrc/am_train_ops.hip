@@ -491,22 +491,31 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(const uint32_t* __restric
   const int tid = threadIdx.x, cp = tid & 63, q = tid >> 6;
   float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
   for (int64_t r0 = (int64_t)blockIdx.x * kBnRows; r0 < M; r0 += (int64_t)gridDim.x * kBnRows) {
-#pragma unroll 4
-    for (int i = 0; i < kBnRows / 4; ++i) {
-      const int64_t r = r0 + q + 4 * i;
-      if (r < M) {
-        const uint32_t xv = x[r * 64 + cp];
-        uint32_t ys = xv;
-        if (s) {
-          const uint32_t sv = s[r * 64 + cp];
-          ys = pack_bf16(bf16_lo(xv) + bf16_lo(sv), bf16_hi(xv) + bf16_hi(sv));
-          y[r * 64 + cp] = ys;
+    // eight rows per thread in flight: loads first (rows past M re-read row M - 1 and are ignored) — a guard per
+    // row makes the compiler wait for each load before issuing the next
+    for (int i0 = 0; i0 < kBnRows / 4; i0 += 8) {
+      uint32_t xv[8], sv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t r = min(r0 + q + 4 * (i0 + j), M - 1);
+        xv[j] = x[r * 64 + cp];
+        sv[j] = s ? s[r * 64 + cp] : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t r = r0 + q + 4 * (i0 + j);
+        if (r < M) {
+          uint32_t ys = xv[j];
+          if (s) {
+            ys = pack_bf16(bf16_lo(xv[j]) + bf16_lo(sv[j]), bf16_hi(xv[j]) + bf16_hi(sv[j]));
+            y[r * 64 + cp] = ys;
+          }
+          const float v0 = bf16_lo(ys), v1 = bf16_hi(ys);
+          a0 += v0;
+          a1 += v1;
+          b0 = fmaf(v0, v0, b0);
+          b1 = fmaf(v1, v1, b1);
         }
-        const float v0 = bf16_lo(ys), v1 = bf16_hi(ys);
-        a0 += v0;
-        a1 += v1;
-        b0 = fmaf(v0, v0, b0);
-        b1 = fmaf(v1, v1, b1);
       }
     }
   }
@@ -533,9 +542,15 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const uint32_t* __restric
   const float m0 = mean[2 * cp], m1 = mean[2 * cp + 1];
   const float k0 = rstd[2 * cp] * gamma[2 * cp], k1 = rstd[2 * cp + 1] * gamma[2 * cp + 1];
   const float b0 = beta[2 * cp], b1 = beta[2 * cp + 1];
-  for (int64_t r = (int64_t)blockIdx.x * 4 + q; r < M; r += (int64_t)gridDim.x * 4) {
-    const uint32_t v = y[r * 64 + cp];
-    out[r * 64 + cp] = pack_bf16(fmaf(bf16_lo(v) - m0, k0, b0), fmaf(bf16_hi(v) - m1, k1, b1));
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + q; r < M; r += 4 * stride) {  // four rows in flight per thread
+    uint32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = y[min(r + j * stride, M - 1) * 64 + cp];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (r + j * stride < M)
+        out[(r + j * stride) * 64 + cp] = pack_bf16(fmaf(bf16_lo(v[j]) - m0, k0, b0), fmaf(bf16_hi(v[j]) - m1, k1, b1));
   }
 }
 
@@ -548,16 +563,23 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const uint32_t* __re
   const float m0 = mean[2 * cp], m1 = mean[2 * cp + 1], r0s = rstd[2 * cp], r1s = rstd[2 * cp + 1];
   float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
   for (int64_t r0 = (int64_t)blockIdx.x * kBnRows; r0 < M; r0 += (int64_t)gridDim.x * kBnRows) {
-#pragma unroll 4
-    for (int i = 0; i < kBnRows / 4; ++i) {
-      const int64_t r = r0 + q + 4 * i;
-      if (r < M) {
-        const uint32_t d = dout[r * 64 + cp], v = y[r * 64 + cp];
-        const float d0 = bf16_lo(d), d1 = bf16_hi(d);
-        a0 += d0;
-        a1 += d1;
-        b0 = fmaf(d0, (bf16_lo(v) - m0) * r0s, b0);
-        b1 = fmaf(d1, (bf16_hi(v) - m1) * r1s, b1);
+    for (int i0 = 0; i0 < kBnRows / 4; i0 += 8) {  // loads first, as in bn_stats_kernel
+      uint32_t dv[8], yv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t r = min(r0 + q + 4 * (i0 + j), M - 1);
+        dv[j] = dout[r * 64 + cp];
+        yv[j] = y[r * 64 + cp];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (r0 + q + 4 * (i0 + j) < M) {
+          const float d0 = bf16_lo(dv[j]), d1 = bf16_hi(dv[j]);
+          a0 += d0;
+          a1 += d1;
+          b0 = fmaf(d0, (bf16_lo(yv[j]) - m0) * r0s, b0);
+          b1 = fmaf(d1, (bf16_hi(yv[j]) - m1) * r1s, b1);
+        }
       }
     }
   }
@@ -586,10 +608,23 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const uint32_t* __res
   const float k0 = r0s * gamma[2 * cp], k1 = r1s * gamma[2 * cp + 1];
   const float sd0 = sums[2 * cp] * inv_m, sd1 = sums[2 * cp + 1] * inv_m;
   const float sx0 = sums[kD + 2 * cp] * inv_m, sx1 = sums[kD + 2 * cp + 1] * inv_m;
-  for (int64_t r = (int64_t)blockIdx.x * 4 + q; r < M; r += (int64_t)gridDim.x * 4) {
-    const uint32_t d = dout[r * 64 + cp], v = y[r * 64 + cp];
-    const float x0 = (bf16_lo(v) - m0) * r0s, x1 = (bf16_hi(v) - m1) * r1s;
-    dy[r * 64 + cp] = pack_bf16(k0 * (bf16_lo(d) - sd0 - x0 * sx0), k1 * (bf16_hi(d) - sd1 - x1 * sx1));
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + q; r < M; r += 4 * stride) {  // four rows in flight per thread
+    uint32_t dv[4], yv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t rr = min(r + j * stride, M - 1);
+      dv[j] = dout[rr * 64 + cp];
+      yv[j] = y[rr * 64 + cp];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (r + j * stride < M) {
+        const float x0 = (bf16_lo(yv[j]) - m0) * r0s, x1 = (bf16_hi(yv[j]) - m1) * r1s;
+        dy[(r + j * stride) * 64 + cp] =
+            pack_bf16(k0 * (bf16_lo(dv[j]) - sd0 - x0 * sx0), k1 * (bf16_hi(dv[j]) - sd1 - x1 * sx1));
+      }
+    }
   }
 }
 
