@@ -62,11 +62,24 @@ __device__ inline float rg_max(float v) { return rl4co::bfly_max<16, 64>(v); }
 template <int NT>
 __device__ inline void stage_rows(const uint16_t* __restrict__ src, int N, int cols, __bf16* dst, int stride, int tid) {
   const int cpr = cols / 8;  // 16-byte chunks per row
-  for (int c = tid; c < NT * 16 * cpr; c += kThreads) {
-    const int row = c / cpr, col = (c % cpr) * 8;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < N) v = *reinterpret_cast<const uint4*>(src + (int64_t)row * cols + col);
-    *reinterpret_cast<uint4*>(dst + row * stride + col) = v;
+  const int total = NT * 16 * cpr;
+  // eight chunks per thread in flight: load -> LDS store one chunk at a time is one exposed HBM round trip per chunk
+  for (int c0 = tid; c0 < total; c0 += 8 * kThreads) {
+    uint4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j * kThreads;
+      const int row = min(c / cpr, N - 1), col = (c % cpr) * 8;  // clamped: rows >= N are zeroed below
+      v[j] = *reinterpret_cast<const uint4*>(src + (int64_t)row * cols + col);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j * kThreads;
+      if (c < total) {
+        const int row = c / cpr, col = (c % cpr) * 8;
+        *reinterpret_cast<uint4*>(dst + row * stride + col) = row < N ? v[j] : make_uint4(0, 0, 0, 0);
+      }
+    }
   }
 }
 

@@ -40,3 +40,11 @@ us_fb = bench(lambda: torch.autograd.grad(T.skip_instance_norm(x, s_, gamma, bet
 mb = 4096 * 100 * 128 * 2 / 1e6
 print(f"skip_inorm fwd: {us_f:7.1f} us ({4 * mb:.0f} MB -> {4 * mb / us_f:.2f} TB/s)   fwd+bwd: {us_fb:7.1f} us "
       f"(bwd alone ~{us_fb - us_f:.1f} us, {3 * mb:.0f} MB -> {3 * mb / (us_fb - us_f):.2f} TB/s)")
+
+# training attention (8 heads, per instance), forward and backward
+qkv = torch.randn(4096, 100, 384, device="cuda").to(torch.bfloat16).requires_grad_(True)
+us_f = bench(lambda: T.attention(qkv))
+o = T.attention(qkv)
+do = torch.randn_like(o)
+us_fb = bench(lambda: torch.autograd.grad(T.attention(qkv), (qkv,), do))
+print(f"attention fwd: {us_f:7.1f} us   fwd+bwd: {us_fb:7.1f} us (bwd alone ~{us_fb - us_f:.1f} us)")
