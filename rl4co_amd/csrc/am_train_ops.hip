@@ -311,6 +311,14 @@ __global__ void __launch_bounds__(kGemmThreads, 2) linear_bf16_kernel(const uint
       }
       rl4co::lds_barrier_wave();
       const int orow = lane >> 4, ocol = (lane & 15) * 8;  // four rows per pass, 16 bytes per lane
+      u32x4 mks[8];  // the ReLU-backward mask rows of this wave, all requested before the first is used
+      if (mask) {
+#pragma unroll
+        for (int p8 = 0; p8 < 8; ++p8) {
+          const int64_t row = min(m0 + 32 * w + 4 * p8 + orow, (int64_t)M - 1);
+          mks[p8] = *reinterpret_cast<const u32x4*>(mask + row * N + nt * kTN + ocol);
+        }
+      }
 #pragma unroll
       for (int p8 = 0; p8 < 8; ++p8) {
         const int tr = 32 * w + 4 * p8 + orow;
@@ -318,7 +326,7 @@ __global__ void __launch_bounds__(kGemmThreads, 2) linear_bf16_kernel(const uint
         u32x4 val = *reinterpret_cast<const u32x4*>(os + tr * kLS + ocol);
         if (row < M) {
           if (mask) {  // ReLU backward: keep where the forward activation was positive (bf16 > 0)
-            const u32x4 mk = *reinterpret_cast<const u32x4*>(mask + row * N + nt * kTN + ocol);
+            const u32x4 mk = mks[p8];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               const uint32_t m_ = mk[i];
