@@ -377,7 +377,8 @@ extern "C" int rl4co_linear_bf16(const void* a, const void* w, const float* bias
 // the chunks are summed afterwards (deterministic, no atomics).
 namespace {
 
-constexpr int kWT = 32;        // token rows per LDS step
+constexpr int kWT = 64;        // token rows per LDS step: the step is one exposed HBM round trip, so the products per
+                               // step must outlast it (at 32 rows two resident workgroups kept the matrix pipe ~40 % busy)
 constexpr int kWLS = 128 + 8;  // LDS row stride (bf16)
 
 typedef __bf16 bf16x4w __attribute__((ext_vector_type(4)));
@@ -412,21 +413,30 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const uint16_t* __restr
   f32x4w accb[2] = {f32x4w{0.0f, 0.0f, 0.0f, 0.0f}, f32x4w{0.0f, 0.0f, 0.0f, 0.0f}};
   const bf16x4w ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
   const int lrow = tid >> 3, lcol = (tid & 7) * 16;  // this thread stages 32 bytes of each tile row
+  typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
   for (int64_t m0 = m_begin; m0 < m_end; m0 += kWT) {
-    uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
-    if (m0 + lrow < m_end) {
-      const uint16_t* pa = dY + (m0 + lrow) * N + nt * 128 + lcol;
-      const uint16_t* pb = X + (m0 + lrow) * K + kt * 128 + lcol;
-      a0 = *reinterpret_cast<const uint4*>(pa);
-      a1 = *reinterpret_cast<const uint4*>(pa + 8);
-      b0 = *reinterpret_cast<const uint4*>(pb);
-      b1 = *reinterpret_cast<const uint4*>(pb + 8);
+    u32x4w a0[kWT / 32], a1[kWT / 32], b0[kWT / 32], b1[kWT / 32];  // a thread stages row lrow of every 32-row group
+#pragma unroll
+    for (int rg = 0; rg < kWT / 32; ++rg) {
+      const int64_t row = min(m0 + 32 * rg + lrow, m_end - 1);  // rows past the chunk: re-read, zeroed below
+      const uint16_t* pa = dY + row * N + nt * 128 + lcol;
+      const uint16_t* pb = X + row * K + kt * 128 + lcol;
+      a0[rg] = *reinterpret_cast<const u32x4w*>(pa);
+      a1[rg] = *reinterpret_cast<const u32x4w*>(pa + 8);
+      b0[rg] = *reinterpret_cast<const u32x4w*>(pb);
+      b1[rg] = *reinterpret_cast<const u32x4w*>(pb + 8);
     }
     __syncthreads();  // the previous step's fragments are consumed
-    *reinterpret_cast<uint4*>(dyt + lrow * kWLS + lcol) = a0;
-    *reinterpret_cast<uint4*>(dyt + lrow * kWLS + lcol + 8) = a1;
-    *reinterpret_cast<uint4*>(xt + lrow * kWLS + lcol) = b0;
-    *reinterpret_cast<uint4*>(xt + lrow * kWLS + lcol + 8) = b1;
+#pragma unroll
+    for (int rg = 0; rg < kWT / 32; ++rg) {
+      const bool live = m0 + 32 * rg + lrow < m_end;
+      const u32x4w z = {0u, 0u, 0u, 0u};
+      const int r = 32 * rg + lrow;
+      *reinterpret_cast<u32x4w*>(dyt + r * kWLS + lcol) = live ? a0[rg] : z;
+      *reinterpret_cast<u32x4w*>(dyt + r * kWLS + lcol + 8) = live ? a1[rg] : z;
+      *reinterpret_cast<u32x4w*>(xt + r * kWLS + lcol) = live ? b0[rg] : z;
+      *reinterpret_cast<u32x4w*>(xt + r * kWLS + lcol + 8) = live ? b1[rg] : z;
+    }
     __syncthreads();
 #pragma unroll
     for (int ts = 0; ts < kWT / 16; ++ts) {
