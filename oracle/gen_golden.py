@@ -72,6 +72,10 @@ CASES = [
     dict(name="cvrptw20_b128_greedy", env="cvrptw", num_loc=20, batch=128, policy="am", decode="greedy"),
     dict(name="cvrptw50_b64_sampling", env="cvrptw", num_loc=50, batch=64, policy="am", decode="sampling"),
     dict(name="cvrptw100_b64_greedy", env="cvrptw", num_loc=100, batch=64, policy="am", decode="greedy"),
+    # POMO multistart on the other depot environments (start node s % num_loc + 1, batchified state)
+    dict(name="pomo_op20_b16_msgreedy", env="op", num_loc=20, batch=16, policy="pomo", decode="multistart_greedy"),
+    dict(name="pomo_pctsp20_b16_msgreedy", env="pctsp", num_loc=20, batch=16, policy="pomo", decode="multistart_greedy"),
+    dict(name="pomo_cvrptw20_b16_mssampling", env="cvrptw", num_loc=20, batch=16, policy="pomo", decode="multistart_sampling"),
     dict(name="pomo_pdp20_b16_msgreedy", env="pdp", num_loc=20, batch=16, policy="pomo", decode="multistart_greedy"),
     # BASELINE.json configs[3] / [4] shapes at a CPU-affordable batch: POMO 8-start sampling on
     # TSP-100, and CVRP-500 sampling (N = 501: the n >= 512 cascade of the tour-length sum)

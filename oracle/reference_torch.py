@@ -118,7 +118,13 @@ def select_start_nodes(td: dict, env, num_starts: int) -> Tensor:
         return torch.arange(num_starts, device=device).repeat_interleave(batch) % num_loc
     if env.name == "pdp":  # pdp/env.py:216-225: only the pickups can start a tour
         return torch.arange(num_starts, device=device).repeat_interleave(batch) % (num_loc // 2) + 1
-    return torch.arange(num_starts, device=device).repeat_interleave(batch) % num_loc + 1
+    selected = torch.arange(num_starts, device=device).repeat_interleave(batch) % num_loc + 1
+    if env.name == "op" and bool((td["action_mask"][..., 1:].float().sum(-1) < num_starts).any()):
+        # ops.py:150-160: some customers cannot be entered at all (too far for max_length): the start nodes are
+        # resampled from the feasible ones, with replacement, "b n -> (n b)"
+        selected = torch.multinomial(td["action_mask"][..., 1:].float(), num_starts, replacement=True) + 1
+        selected = selected.t().reshape(-1)
+    return selected
 
 
 # ----------------------------------------------------------------------------------------------

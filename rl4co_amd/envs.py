@@ -534,6 +534,15 @@ class OPEnv(RL4COEnvBase):
                   td["action_mask"], td["done"])
         return td["action_mask"]
 
+    def select_start_nodes(self, td, num_starts: int) -> Tensor:
+        """ops.py:128-161, orienteering branch: when an instance has fewer feasible customers than starts (nodes too far
+        to be entered within max_length), the start nodes are resampled from the feasible ones with replacement
+        (torch.multinomial on the mask, s-major "b n -> (n b)") instead of the s % num_loc + 1 rule."""
+        feasible = td["action_mask"][..., 1:].float()
+        if bool((feasible.sum(-1) < num_starts).any()):
+            return (torch.multinomial(feasible, num_starts, replacement=True) + 1).t().reshape(-1)
+        return super().select_start_nodes(td, num_starts)
+
     def _get_reward(self, td: TensorDict, actions: Tensor) -> Tensor:
         """op/env.py:156-166"""
         if actions.size(-1) == 1:

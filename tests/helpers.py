@@ -72,6 +72,12 @@ class GoldenCase:
     def reset(self) -> dict:
         return self.env.reset(clone_td(self.data))
 
+    def start_nodes(self, td0: dict, num_starts: int) -> torch.Tensor:
+        """The multistart nodes of the golden run. For OP the reference may RESAMPLE them (ops.py:150-160,
+        torch.multinomial on the global generator, the first draw after the run's manual_seed(sample_seed))."""
+        torch.manual_seed(self.meta["sample_seed"])
+        return self.env.select_start_nodes(td0, num_starts)
+
     @property
     def num_starts(self) -> int:
         if "multistart" not in self.meta["decode_type"]:

@@ -56,7 +56,7 @@ def _run(K, backend, g, td0, h, mode, dtype=torch.float32, max_steps=None, varia
     err = torch.zeros(1, dtype=torch.int32, device=dev)
     t0 = 0
     if s > 0:
-        first = g.env.select_start_nodes(td0, s).to(dev)
+        first = g.start_nodes(td0, s).to(dev)
         actions[:, 0] = first
         step = (K if backend == "hip" else c_oracle)
         apply_step(step, g.env_name, first, st)

@@ -170,7 +170,7 @@ def c_rollout(g: GoldenCase, mode: str, cache_dtype=torch.float32, row_groups=No
     err = torch.zeros(1, dtype=torch.int32)
     t0 = 0
     if s > 0:
-        first = g.env.select_start_nodes(td0, s)
+        first = g.start_nodes(td0, s)
         actions[:, 0] = first
         apply_step(c_oracle, g.env_name, first, st)
         t0 = 1
