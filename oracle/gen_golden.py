@@ -77,6 +77,17 @@ CASES = [
     dict(name="pomo_pctsp20_b16_msgreedy", env="pctsp", num_loc=20, batch=16, policy="pomo", decode="multistart_greedy"),
     dict(name="pomo_cvrptw20_b16_mssampling", env="cvrptw", num_loc=20, batch=16, policy="pomo", decode="multistart_sampling"),
     dict(name="pomo_pdp20_b16_msgreedy", env="pdp", num_loc=20, batch=16, policy="pomo", decode="multistart_greedy"),
+    # non-default decoding arguments of ConstructivePolicy.forward (constructive/base.py:154-263, decoding.py:282-461):
+    # best-of-starts selection, temperature / clipping, multisample. Policy-level fixtures: the decode-level tests
+    # (kernel vs C oracle) drive the kernels directly and cover these arguments through their own parameters.
+    dict(name="kw_tsp50_b32_ms_selectbest", env="tsp", num_loc=50, batch=32, policy="pomo", decode="multistart_greedy",
+         fw_kw=dict(select_best=True), policy_only=True),
+    dict(name="kw_tsp50_b32_sampling_temp", env="tsp", num_loc=50, batch=32, policy="am", decode="sampling",
+         fw_kw=dict(temperature=0.7, tanh_clipping=8.0), policy_only=True),
+    dict(name="kw_cvrp20_b32_multisample", env="cvrp", num_loc=20, batch=32, policy="am", decode="sampling",
+         fw_kw=dict(num_samples=4), policy_only=True),
+    dict(name="kw_cvrp20_b32_multisample_best", env="cvrp", num_loc=20, batch=32, policy="am", decode="sampling",
+         fw_kw=dict(num_samples=4, select_best=True), policy_only=True),
     # BASELINE.json configs[3] / [4] shapes at a CPU-affordable batch: POMO 8-start sampling on
     # TSP-100, and CVRP-500 sampling (N = 501: the n >= 512 cascade of the tour-length sum)
     dict(name="c4_pomo_tsp100_b32_s8_sampling", env="tsp", num_loc=100, batch=32, policy="pomo",
@@ -184,7 +195,7 @@ def run_case(ref, case: dict) -> dict:
         "inputs_sha256": state_hash({k: v for k, v in data.items()}),
         "steps": int(actions.shape[1]), "mean_reward": float(out_ref["reward"].mean()),
         "reference_cpu_seconds": round(wall, 3), "torch": torch.__version__,
-        "threads": torch.get_num_threads(),
+        "threads": torch.get_num_threads(), "policy_only": bool(case.get("policy_only", False)),
     }
     return fixture, meta
 

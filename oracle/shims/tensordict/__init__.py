@@ -3,7 +3,8 @@
 Implements exactly the surface the reference's rollout path touches:
 construction with ``batch_size``, mapping access, ``get/set/update/keys/items/values``, ``clone``,
 ``to``, ``device``, ``shape/batch_size/dim/size``, ``is_empty``, ``exclude/select`` and the
-``expand/contiguous/view/permute`` methods ``batchify``/``unbatchify`` call (utils/ops.py:10-51).
+``expand/contiguous/view/permute`` methods ``batchify``/``unbatchify`` call (utils/ops.py:10-51), plus
+``gather/squeeze`` over the batch dimensions for ``unbatchify_and_gather`` (utils/ops.py:69-74).
 """
 from __future__ import annotations
 
@@ -170,6 +171,24 @@ class TensorDict(TensorDictBase):
         nb = len(self._batch_size)
         new_bs = torch.Size([self._batch_size[d] for d in dims])
         return self._map(lambda v: v.permute(*dims, *range(nb, v.dim())), new_bs)
+
+    def gather(self, dim, index):
+        """Every entry gathered along batch dimension ``dim`` (the index is broadcast over the entry's feature
+        dimensions) — what ``unbatchify_and_gather`` (utils/ops.py:69-74) asks of the best-of-starts selection."""
+        nb = len(self._batch_size)
+
+        def g(v):
+            idx = index.view(*index.shape, *([1] * (v.dim() - nb))).expand(*index.shape, *v.shape[nb:])
+            return v.gather(dim, idx)
+
+        return self._map(g, index.shape)
+
+    def squeeze(self, dim):
+        bs = list(self._batch_size)
+        if bs[dim] != 1:
+            return self
+        bs.pop(dim)
+        return self._map(lambda v: v.squeeze(dim), torch.Size(bs))
 
     def __repr__(self):
         fields = ", ".join(f"{k}: {tuple(v.shape) if torch.is_tensor(v) else type(v).__name__}" for k, v in self._data.items())

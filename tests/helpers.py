@@ -72,6 +72,12 @@ class GoldenCase:
     def reset(self) -> dict:
         return self.env.reset(clone_td(self.data))
 
+    @property
+    def rollout_rows(self) -> int:
+        """Trajectories the decode loop advances: instances x starts (multistart) or x samples (multisample)."""
+        reps = self.num_starts or int(self.meta["forward_kwargs"].get("num_samples", 0) or 0)
+        return self.batch * max(reps, 1)
+
     def start_nodes(self, td0: dict, num_starts: int) -> torch.Tensor:
         """The multistart nodes of the golden run. For OP the reference may RESAMPLE them (ops.py:150-160,
         torch.multinomial on the global generator, the first draw after the run's manual_seed(sample_seed))."""
@@ -84,6 +90,12 @@ class GoldenCase:
             return 0
         default = self.num_loc // 2 if self.env_name == "pdp" else self.num_loc  # pdp/env.py:225-227: pickups only
         return self.meta["forward_kwargs"].get("num_starts", default)
+
+
+def decode_level(name: str) -> bool:
+    """Fixtures the decode-level tests (kernel / C oracle driven directly) can replay: the policy-only ones exercise
+    arguments of ConstructivePolicy.forward (select_best, multisample, temperature ...) through the policy surface."""
+    return not manifest()[name].get("policy_only", False)
 
 
 def clone_td(td: dict) -> dict:

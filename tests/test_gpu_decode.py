@@ -21,7 +21,7 @@ from tests.helpers import apply_step, kernel_reward, GoldenCase, fold_cache, man
 
 pytestmark = pytest.mark.gpu
 
-SMALL = sorted(c for c, m in manifest().items() if m["batch"] <= 256)
+SMALL = sorted(c for c, m in manifest().items() if m["batch"] <= 256 and not m.get("policy_only", False))
 
 
 @pytest.fixture(scope="module")

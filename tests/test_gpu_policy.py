@@ -38,7 +38,7 @@ def test_policy_forward_vs_reference_golden(name):
     pol, env, td = _product(g)
     kw = dict(g.meta["forward_kwargs"])
     if "sampling" in g.meta["decode_type"]:
-        b = g.batch * max(g.num_starts, 1)
+        b = g.rollout_rows
         n = g.num_loc + (g.env_name != "tsp")
         torch.manual_seed(g.meta["sample_seed"])
         kw["exp_noise"] = torch.stack([torch.empty(b, n).exponential_(1) for _ in range(2 * n)], 0).contiguous().cuda()

@@ -72,8 +72,7 @@ def test_policy_forward_matches_reference_golden(cpu_device, name):
     td = env.reset(_product_td(g))
     kw = dict(g.meta["forward_kwargs"])
     if "sampling" in g.meta["decode_type"]:
-        s = g.num_starts
-        b = g.batch * max(s, 1)
+        b = g.rollout_rows
         n = g.num_loc + (g.env_name != "tsp")
         torch.manual_seed(g.meta["sample_seed"])
         kw["exp_noise"] = torch.stack([torch.empty(b, n).exponential_(1) for _ in range(2 * n)], 0).contiguous()

@@ -11,7 +11,7 @@ import torch
 from oracle import c_oracle
 from oracle import reference_torch as R
 from tests.helpers import ll_rtol  # noqa: E402
-from tests.helpers import (GoldenCase, apply_step, oracle_reward, clone_td, fold_cache, make_instances, manifest, max_horizon,
+from tests.helpers import (GoldenCase, apply_step, decode_level, oracle_reward, clone_td, fold_cache, make_instances, manifest, max_horizon,
                            rollout_state)
 
 ALL_CASES = sorted(manifest())
@@ -184,7 +184,7 @@ def c_rollout(g: GoldenCase, mode: str, cache_dtype=torch.float32, row_groups=No
     return actions[:, :t].contiguous(), logps[:, :t], td0
 
 
-GREEDY_SMALL = [c for c in SMALL_CASES if "greedy" in manifest()[c]["decode_type"]]
+GREEDY_SMALL = [c for c in SMALL_CASES if "greedy" in manifest()[c]["decode_type"] and decode_level(c)]
 
 
 @pytest.mark.parametrize("name", GREEDY_SMALL)
@@ -206,7 +206,7 @@ def test_c_oracle_greedy_matches_reference(name):
     assert abs(float(reward.mean() - g.reward.mean())) < 5e-3 * abs(float(g.reward.mean()))
 
 
-@pytest.mark.parametrize("name", [c for c in SMALL_CASES if "sampling" in manifest()[c]["decode_type"]])
+@pytest.mark.parametrize("name", [c for c in SMALL_CASES if "sampling" in manifest()[c]["decode_type"] and decode_level(c)])
 def test_c_oracle_sampling_matches_reference(name):
     """Sampling parity with a fixed seed: the reference's multinomial stream is one [B,N]
     exponential_ draw per step (checked in gen_golden); fed the same draws the oracle reproduces
