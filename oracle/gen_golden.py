@@ -86,6 +86,10 @@ CASES = [
          fw_kw=dict(temperature=0.7, tanh_clipping=8.0), policy_only=True),
     dict(name="kw_cvrp20_b32_multisample", env="cvrp", num_loc=20, batch=32, policy="am", decode="sampling",
          fw_kw=dict(num_samples=4), policy_only=True),
+    dict(name="kw_tsp20_b32_sampling_entropy", env="tsp", num_loc=20, batch=32, policy="am", decode="sampling",
+         fw_kw=dict(return_entropy=True), policy_only=True),
+    dict(name="kw_cvrp20_b32_greedy_entropy", env="cvrp", num_loc=20, batch=32, policy="am", decode="greedy",
+         fw_kw=dict(return_entropy=True), policy_only=True),
     dict(name="kw_cvrp20_b32_multisample_best", env="cvrp", num_loc=20, batch=32, policy="am", decode="sampling",
          fw_kw=dict(num_samples=4, select_best=True), policy_only=True),
     # BASELINE.json configs[3] / [4] shapes at a CPU-affordable batch: POMO 8-start sampling on
@@ -159,7 +163,7 @@ def run_case(ref, case: dict) -> dict:
     torch.manual_seed(SAMPLE_SEED)
     with torch.inference_mode():
         out = pol(td1, env, phase="test", decode_type=case["decode"], **fw_kw)
-    for k in ("actions", "reward", "log_likelihood"):
+    for k in ("actions", "reward", "log_likelihood") + (("entropy",) if "entropy" in out_ref else ()):
         assert out[k].shape == out_ref[k].shape, (case["name"], k, out[k].shape, out_ref[k].shape)
         assert torch.equal(out[k], out_ref[k]), f"{case['name']}: restatement {k} differs from the reference"
 
@@ -184,6 +188,8 @@ def run_case(ref, case: dict) -> dict:
         "reward": out_ref["reward"].numpy(),
         "log_likelihood": out_ref["log_likelihood"].numpy(),
     }
+    if "entropy" in out_ref:
+        fixture["entropy"] = out_ref["entropy"].numpy()
     if case.get("store_inputs", True):
         for k, v in data.items():
             fixture[f"in_{k}"] = v.numpy()

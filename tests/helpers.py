@@ -52,6 +52,7 @@ class GoldenCase:
         self.actions = torch.from_numpy(z["actions"].astype(np.int64))
         self.reward = torch.from_numpy(z["reward"])
         self.log_likelihood = torch.from_numpy(z["log_likelihood"])
+        self.entropy = torch.from_numpy(z["entropy"]) if "entropy" in z.files else None
         m = self.meta
         from rl4co_amd.cache import canonical_env
 

@@ -67,6 +67,8 @@ def test_policy_forward_vs_reference_golden(name):
     torch.testing.assert_close(out["log_likelihood"].cpu()[same], g.log_likelihood[same],
                                rtol=2e-2 if tw else max(1e-4, ll_rtol(g.env_name, gpu=True)), atol=1e-4)
     assert abs(float(reward.mean() - g.reward.mean())) <= (5e-3 if tw else 1e-3) * abs(float(g.reward.mean()))
+    if g.entropy is not None:
+        torch.testing.assert_close(out["entropy"].cpu()[same], g.entropy[same], rtol=2e-3, atol=2e-3)
 
 
 def test_bf16_cache_policy_quality_and_validity():

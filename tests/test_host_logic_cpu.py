@@ -84,6 +84,8 @@ def test_policy_forward_matches_reference_golden(cpu_device, name):
     assert int((~same).sum()) <= max(1, len(same) // 50)
     assert torch.equal(out["reward"][same], g.reward[same])
     torch.testing.assert_close(out["log_likelihood"][same], g.log_likelihood[same], rtol=ll_rtol(g.env_name), atol=5e-5)
+    if g.entropy is not None:  # calculate_entropy (utils/ops.py:103-111) over the stored per-step distributions
+        torch.testing.assert_close(out["entropy"][same], g.entropy[same], rtol=1e-4, atol=1e-4)
 
 
 def test_env_surface_step_by_step(cpu_device):
