@@ -285,3 +285,52 @@ def test_c_oracle_mask_inner_off_matches_restatement():
     same = (actions == want["actions"]).all(1)
     assert int((~same).sum()) <= 1
     torch.testing.assert_close(logps.sum(1)[same], want["log_likelihood"][same], rtol=1e-5, atol=2e-5)
+
+
+def _random_shapes():
+    import random
+
+    rnd = random.Random(20240924)
+    out = []
+    for env_name in ("tsp", "cvrp", "op", "pctsp", "pdp", "cvrptw"):
+        for _ in range(5):
+            n = rnd.randint(2, 40) if env_name == "tsp" else rnd.randint(1, 40)
+            if env_name == "pdp":
+                n = max(2, n + (n % 2))
+            out.append((env_name, n, rnd.randint(1, 9), rnd.randint(0, 10**6)))
+    return out
+
+
+@pytest.mark.parametrize("env_name,num_loc,batch,seed", _random_shapes())
+def test_random_shapes_env_walks_match_restatement(env_name, num_loc, batch, seed):
+    """Thirty random (environment, size, batch) shapes — odd sizes, a single customer, a batch of one: a random
+    feasible walk to the end through the C oracle's transition == the restatement's, state and mask bit for bit,
+    and the reward composition of the walk == the restatement's get_reward (validity check included)."""
+    env, data = make_instances(env_name, num_loc, batch, seed=seed)
+    td0 = env.reset(clone_td(data))
+    td = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in td0.items()}
+    st = rollout_state(env_name, td)
+    g = torch.Generator().manual_seed(seed)
+    acts = []
+    for _ in range(4 * (num_loc + 2)):
+        if bool(td["done"].all()):
+            break
+        probs = td["action_mask"].float()
+        probs[td["done"].reshape(-1)] = 0.0
+        probs[td["done"].reshape(-1), 0] = 1.0  # finished rows wait at node 0 (the kernels' padding convention)
+        action = torch.multinomial(probs, 1, generator=g).squeeze(1)
+        if env_name in ("tsp", "pdp", "op", "pctsp"):  # these finish in lock-step or ignore further steps: stop rows exactly
+            action = torch.where(td["done"].reshape(-1), td["current_node"].reshape(-1), action)
+        td["action"] = action
+        live = ~td["done"].reshape(-1).clone()
+        if not bool(live.all()) and env_name in ("op", "pctsp"):
+            break  # ragged finish: the remaining rows are covered by the lock-step shapes
+        td = env.step(td)
+        apply_step(c_oracle, env_name, action, st)
+        acts.append(action)
+        assert torch.equal(st["action_mask"], td["action_mask"])
+        assert torch.equal(st["done"], td["done"].reshape(-1))
+        assert torch.equal(st["current_node"], td["current_node"].reshape(-1))
+    if bool(td["done"].all()) and acts:
+        actions = torch.stack(acts, 1)
+        assert torch.equal(oracle_reward(env_name, td0, actions), env.get_reward(td0, actions))
