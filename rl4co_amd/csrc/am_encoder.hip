@@ -488,11 +488,17 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       meanv[tid] = s / (float)N;
     }
     __syncthreads();
-    if (tid < kD) {
-      const float* wr = a.w_fixed + tid * kD;
-      float acc = 0.0f;
-      for (int k = 0; k < kD; ++k) acc = fmaf(wr[k], meanv[k], acc);
-      a.q_bias[(int64_t)b * kD + tid] = acc;
+    // wave w: output rows 32 w .. 32 w + 31; a row of W is ONE coalesced 512-byte load (two consecutive inputs per
+    // lane) and a butterfly sum (a thread per row read its 128 inputs at a 512-byte lane stride: 64 cache lines per
+    // load instruction)
+    const float2 mv = *reinterpret_cast<const float2*>(meanv + 2 * lane);
+    float2 wv[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) wv[r] = *reinterpret_cast<const float2*>(a.w_fixed + (int64_t)(32 * w + r) * kD + 2 * lane);
+#pragma unroll
+    for (int r = 0; r < 32; ++r) {
+      const float acc = rl4co::bfly_sum<1, 64>(fmaf(wv[r].y, mv.y, wv[r].x * mv.x));
+      if (lane == r) a.q_bias[(int64_t)b * kD + 32 * w + r] = acc;
     }
   }
 }
