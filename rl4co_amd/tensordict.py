@@ -5,7 +5,7 @@ container on this path; when it is installed we use it unchange
 minimal stand-in provides the handful of methods the boundary touches: mapping access,
 ``set/get/update``, ``batch_size``/``shape``/``device``, ``clone``, ``to`` and the
 ``expand/contiguous/view/permute`` quartet that ``batchify``/``unbatchify`` rely on
-(utils/ops.py:10-51).
+(utils/ops.py:10-51), and ``gather/squeeze`` over the batch dimensions (``unbatchify_and_gather``).
 """
 from __future__ import annotations
 
@@ -95,6 +95,24 @@ except Exception:  # noqa: BLE001
             return self._map(
                 lambda v: v.permute(*dims, *range(nb, v.dim())), new_bs
             )
+
+        def gather(self, dim, index):
+            """Every entry gathered along batch dimension ``dim`` (``unbatchify_and_gather``, utils/ops.py:69-74:
+            the best-of-starts selection of the reference's decode loop applies it to the state it got back)."""
+            nb = len(self.batch_size)
+
+            def g(v):
+                idx = index.view(*index.shape, *([1] * (v.dim() - nb))).expand(*index.shape, *v.shape[nb:])
+                return v.gather(dim, idx)
+
+            return self._map(g, index.shape)
+
+        def squeeze(self, dim):
+            bs = list(self.batch_size)
+            if bs[dim] != 1:
+                return self
+            bs.pop(dim)
+            return self._map(lambda v: v.squeeze(dim), torch.Size(bs))
 
         def __getitem__(self, key):
             if isinstance(key, str):
