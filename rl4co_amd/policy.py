@@ -685,14 +685,17 @@ class AttentionModelPolicy(nn.Module):
             self.decode_events.append((ev0, ev1))
         # validity check on the padded action buffer (trailing depot zeros are neutral), into the
         # same error word — then ONE host sync for the whole rollout: horizon + every sticky bit
-        checked = bool(calc_reward and env.check_solution and not (n_rep > 0 and select_best))
+        # (an environment that is not one of this package's — e.g. the reference's own torch environment passed as
+        # `env` — has no device-side check: its get_reward validates the unpadded actions itself, after the read-back)
+        native_env = isinstance(env, RL4COEnvBase)
+        checked = bool(native_env and calc_reward and env.check_solution and not (n_rep > 0 and select_best))
         if checked:
             env.check_solution_validity(td, out_actions, err=err)
         # TSP / PDP take exactly `tmax` steps, so the action buffer is the tour: the reward goes out before
         # the read-back instead of after it (with a ragged horizon the buffer's trailing zeros would change
         # the association of the reference-ordered sums, so every other environment waits for the horizon)
         td_early = reward_early = None
-        if self.env_name in ("tsp", "pdp") and calc_reward and not (n_rep > 0 and select_best):
+        if native_env and self.env_name in ("tsp", "pdp") and calc_reward and not (n_rep > 0 and select_best):
             td_early = self._final_td(td, state, n_rep)
             td_early.set("action", out_actions[:, -1])
             reward_early = env.get_reward(td_early, out_actions, check_solution=False if checked else None)

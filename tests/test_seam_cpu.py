@@ -34,3 +34,39 @@ def test_reference_policy_drives_product_env(cpu_device, name):
     assert torch.equal(out["log_likelihood"], g.log_likelihood)
     if g.entropy is not None:
         assert torch.equal(out["entropy"], g.entropy)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_product_policy_runs_on_reference_env(cpu_device, name):
+    """The `policy` seam the other way round: the product policy handed the REFERENCE's own environment object
+    (state tensors from its reset, reward and validity check by its get_reward, start nodes by its
+    select_start_nodes) — same outputs as the all-reference run up to fp32 near-tie flips."""
+    from rl4co_amd.policy import AttentionModelPolicy
+    from tests.helpers import ll_rtol
+
+    ref = ref_import.load()
+    g = GoldenCase(name)
+    pk = dict(g.meta["policy_kwargs"])
+    pk.pop("sdpa_fn_decoder", None)
+    pol = AttentionModelPolicy(env_name=g.env_label, **pk).eval()
+    pol.load_state_dict(g.policy.state_dict())
+    env_cls = {"tsp": ref.TSPEnv, "cvrp": ref.CVRPEnv, "op": ref.OPEnv, "pctsp": ref.PCTSPEnv, "spctsp": ref.SPCTSPEnv,
+               "pdp": ref.PDPEnv, "cvrptw": ref.CVRPTWEnv}[g.env_label]
+    gen_kw = dict(num_loc=g.num_loc)
+    if g.env_label == "op":
+        gen_kw["prize_distribution"] = "dist"  # as in oracle/gen_golden.py
+    env = env_cls(generator_params=gen_kw)
+    td = ref.TensorDict({k: v.clone() for k, v in g.data.items()}, batch_size=[g.batch])
+    kw = dict(g.meta["forward_kwargs"])
+    if "sampling" in g.meta["decode_type"]:
+        n = g.num_loc + (g.env_name != "tsp")
+        torch.manual_seed(g.meta["sample_seed"])
+        kw["exp_noise"] = torch.stack([torch.empty(g.rollout_rows, n).exponential_(1) for _ in range(2 * n)], 0).contiguous()
+    torch.manual_seed(g.meta["sample_seed"])
+    with torch.inference_mode():
+        out = pol(env.reset(td), env, phase="test", decode_type=g.meta["decode_type"], **kw)
+    assert out["actions"].shape == g.actions.shape
+    same = (out["actions"] == g.actions).all(1)
+    assert int((~same).sum()) <= max(1, len(same) // 50)
+    assert torch.equal(out["reward"][same], g.reward[same])
+    torch.testing.assert_close(out["log_likelihood"][same], g.log_likelihood[same], rtol=ll_rtol(g.env_name), atol=5e-5)
