@@ -48,6 +48,10 @@ _SHELL_PACKAGES = [
     "rl4co.models.common",
     "rl4co.models.zoo",
     "rl4co.models.zoo.am",
+    "rl4co.models.rl",
+    "rl4co.models.rl.common",
+    "rl4co.models.rl.reinforce",
+    "rl4co.tasks",
 ]
 
 # names the reference imports from a package's __init__ -> module that really defines them
