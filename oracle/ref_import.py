@@ -19,6 +19,7 @@ skip when ``/root/reference`` is absent (e.g. on the GPU box).
 from __future__ import annotations
 
 import importlib
+import importlib.util
 import os
 import sys
 import types
@@ -52,6 +53,7 @@ _SHELL_PACKAGES = [
     "rl4co.models.rl.common",
     "rl4co.models.rl.reinforce",
     "rl4co.tasks",
+    "rl4co.models.zoo.pomo",
 ]
 
 # names the reference imports from a package's __init__ -> module that really defines them
@@ -108,7 +110,7 @@ def install() -> None:
         return
     if not available():
         raise RuntimeError(f"reference checkout not found under {REFERENCE_ROOT}")
-    for name in ("tensordict", "torchrl", "lightning"):
+    for name in ("tensordict", "torchrl", "lightning", "omegaconf"):
         try:  # never shadow a real installation
             spec = importlib.util.find_spec(name)
         except (ImportError, ValueError):
