@@ -232,3 +232,70 @@ def test_reference_pomo_and_reinforce_modules_step_unchanged(cpu_device):
     with torch.inference_mode():
         am.shared_step(b2, 0, "test")
     torch.testing.assert_close(torch.as_tensor(am.logged[-1][0]["test/reward"]).float(), g2.reward.mean(), rtol=1e-6, atol=0)
+
+
+def test_reference_training_epoch_glue_runs_unchanged(cpu_device):
+    """`RL4COLitModule.setup` / dataloaders / optimizer (rl/common/base.py:117-330, verbatim) over the product
+    objects: datasets from `env.dataset(size, phase)`, torch DataLoaders over the device-resident dataset (batched
+    `__getitems__` + `collate_fn`), REINFORCE's rollout baseline attached to the training set by `wrap_dataset`, the
+    optimizer built by `configure_optimizers`, and a few optimisation steps through `shared_step`."""
+    import importlib
+
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    ref_import.load()
+    reinforce = importlib.import_module("rl4co.models.rl.reinforce.reinforce")
+    pomo = importlib.import_module("rl4co.models.zoo.pomo.model")
+    torch.manual_seed(0)
+    env = get_env("cvrp", generator_params=dict(num_loc=10), device="cpu")
+
+    am = reinforce.REINFORCE(env, AttentionModelPolicy("cvrp"), baseline="rollout", batch_size=8, train_data_size=24,
+                             val_data_size=16, test_data_size=8, optimizer_kwargs={"lr": 1e-3})
+    am.setup("fit")
+    assert len(am.train_dataset) == 24  # epoch 0 of baseline="rollout" is its warm-up: exponential baseline, no wrapping
+    opt = am.configure_optimizers()
+
+    def train_epoch():
+        seen = 0
+        for i, batch in enumerate(am.train_dataloader()):
+            assert batch.batch_size[0] == 8
+            out = am.shared_step(batch, i, "train")
+            opt.zero_grad()
+            out["loss"].backward()
+            opt.step()
+            seen += 1
+        return seen
+
+    assert train_epoch() == 3
+    am.eval()
+    with torch.inference_mode():
+        for i, batch in enumerate(am.val_dataloader()):
+            am.shared_step(batch, i, "val")
+    assert "val/reward" in am.logged[-1][0]
+    # end of epoch 0 (reinforce.py:125-135, base.py:263-272): the warm-up ends, the greedy rollout baseline takes over
+    # and the next epoch's training set carries its rewards as "extra"
+    am.train()
+    am.baseline.epoch_callback(am.policy, env=env, batch_size=8, device="cpu", epoch=0, dataset_size=16)
+    assert am.baseline.alpha == 1
+    am.train_dataset = am.wrap_dataset(env.dataset(24, "train"))
+    assert "extra" in am.train_dataset.data.keys() and am.train_dataset.data["extra"].shape == (24,)
+    first = next(iter(am.train_dataloader()))
+    assert first["extra"].shape == (8,)
+    assert train_epoch() == 3
+
+    pm = pomo.POMO(env, policy=AttentionModelPolicy("cvrp", num_encoder_layers=3, normalization="instance",
+                                                     use_graph_context=False),
+                   batch_size=4, train_data_size=8, val_data_size=4, test_data_size=4, num_augment=8)
+    pm.setup("fit")
+    opt = pm.configure_optimizers()
+    for i, batch in enumerate(pm.train_dataloader()):
+        out = pm.shared_step(batch, i, "train")
+        opt.zero_grad()
+        out["loss"].backward()
+        opt.step()
+    pm.eval()
+    with torch.inference_mode():
+        for i, batch in enumerate(pm.test_dataloader()):
+            pm.shared_step(batch, i, "test")
+    assert "test/reward" in pm.logged[-1][0]
