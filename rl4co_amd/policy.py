@@ -609,11 +609,23 @@ class AttentionModelPolicy(nn.Module):
         exp_noise = decoding_kwargs.pop("exp_noise", None)  # parity hook: injected Exp(1) draws
         seed = decoding_kwargs.pop("seed", None)
         multisample = bool(decoding_kwargs.pop("multisample", False))
+        select_start_nodes_fn = decoding_kwargs.pop("select_start_nodes_fn", None)
+        # sampling modifiers outside the path (top-k / top-p / a second temperature): their neutral values pass
+        if decoding_kwargs.pop("top_k", 0) or decoding_kwargs.pop("top_p", 0.0):
+            raise NotImplementedError("top-k / top-p sampling is not part of the fused decode kernel")
+        decoding_kwargs.pop("top_p", None)
+        if decoding_kwargs.pop("softmax_temp", None) is not None:
+            raise NotImplementedError("softmax_temp is not supported; use temperature")
+        # decoding.py:238-255, in the reference's order: the flags are checked as PASSED, then overridden by the counts
+        # (SamplingEval passes decode_type="sampling", multisample=True, num_starts=n: it ends up multistart AND
+        # multisample, i.e. n sampled rollouts per instance whose first node comes from `select_start_nodes_fn`)
+        assert not (multistart and multisample), "Using both multistart and multisample is not supported"
+        if num_samples and num_starts:
+            assert not (num_samples > 1 and num_starts > 1), f"num_samples={num_samples} and num_starts={num_starts} are both > 1"
         if num_samples is not None:
             multisample = num_samples > 1
         if num_starts is not None:
             multistart = num_starts > 1
-        assert not (multistart and multisample), "Using both multistart and multisample is not supported"
         if multistart or multisample:
             n_rep = num_starts if multistart else num_samples
             if n_rep is None:
@@ -662,7 +674,10 @@ class AttentionModelPolicy(nn.Module):
         all_logps = torch.zeros((b, tmax, n), dtype=torch.float32, device=device) if store_all_logp else None
 
         if t0 == 1:
-            first = env.select_start_nodes(td, num_starts=n_rep)
+            if select_start_nodes_fn is not None:  # decoding.py:308-311: (td, env, num_starts) -> [num_starts * B] nodes, s-major
+                first = select_start_nodes_fn(td, env, n_rep).to(device=device, dtype=torch.int64).contiguous()
+            else:
+                first = env.select_start_nodes(td, num_starts=n_rep)
             out_actions[:, 0] = first
             self._env_step_state(state, first, err)
 
