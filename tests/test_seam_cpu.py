@@ -365,3 +365,20 @@ def test_ppo_style_reevaluation_matches_reference_policy(cpu_device, name):
     torch.testing.assert_close(got["log_likelihood"], want["log_likelihood"], rtol=1e-3, atol=2e-4)
     torch.testing.assert_close(got["entropy"], want["entropy"], rtol=1e-4, atol=1e-4)
     assert torch.equal(got["reward"], want["reward"])
+
+
+@pytest.mark.parametrize("env_name,num_loc", [("tsp", 20), ("cvrp", 20), ("op", 20), ("pctsp", 20), ("spctsp", 20), ("pdp", 20),
+                                              ("cvrptw", 20)])
+def test_reference_rollout_helper_with_random_policy(cpu_device, env_name, num_loc):
+    """`rollout(env, td, policy)` + `random_policy` (utils/decoding.py:78-112, verbatim): the step-by-step driver the
+    reference's own environment tests use — reset, `env.step(td)["next"]` until `td["done"].all()`, `env.get_reward` with
+    the validity check — over every product environment."""
+    from rl4co_amd.envs import get_env
+
+    ref = ref_import.load()
+    env = get_env(env_name, generator_params=dict(num_loc=num_loc), device="cpu")
+    torch.manual_seed(5)
+    td = env.reset(batch_size=[16])
+    reward, td_out, actions = ref.decoding.rollout(env, td, ref.decoding.random_policy)
+    assert reward.shape == (16,) and bool(torch.isfinite(reward).all()) and actions.shape[0] == 16
+    assert bool(td_out["done"].all())
