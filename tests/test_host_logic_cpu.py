@@ -122,7 +122,9 @@ def test_select_best_and_num_starts(cpu_device):
     assert torch.equal(out["actions"], ref["actions"])
 
 
-@pytest.mark.parametrize("name", ["tsp20_b64_greedy_simple", "cvrp20_b128_greedy", "pomo_tsp20_b16_msgreedy"])
+@pytest.mark.parametrize("name", ["tsp20_b64_greedy_simple", "cvrp20_b128_greedy", "pomo_tsp20_b16_msgreedy",
+                                  "op20_b128_greedy", "pctsp20_b128_greedy", "spctsp20_b128_greedy", "pdp20_b128_greedy",
+                                  "cvrptw20_b128_greedy", "pomo_pdp20_b16_msgreedy", "pomo_cvrptw20_b16_mssampling"])
 def test_training_log_likelihood_has_reference_gradients(cpu_device, name):
     """phase='train': sampled by the kernel, log-likelihood re-evaluated teacher-forced with
     autograd; value and parameter gradients must match the reference's decode_type='evaluate'
@@ -156,5 +158,9 @@ def test_training_log_likelihood_has_reference_gradients(cpu_device, name):
     for k, p in ref_pol.named_parameters():
         if p.grad is None:
             assert ours[k].grad is None or float(ours[k].grad.abs().max()) == 0.0, k
+            continue
+        if g.env_name == "cvrptw":  # unnormalised inputs (to 480): gradients span orders of magnitude inside one tensor
+            err, nrm = float((ours[k].grad - p.grad).norm()), float(p.grad.norm())
+            assert err <= 1e-3 * nrm + 1e-6, (k, err, nrm)
             continue
         torch.testing.assert_close(ours[k].grad, p.grad, rtol=2e-3, atol=2e-5, msg=lambda m: f"{k}: {m}")
