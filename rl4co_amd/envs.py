@@ -253,7 +253,10 @@ class RL4COEnvBase:
             td = self.generator(batch_size=batch_size)
         batch_size = [batch_size] if isinstance(batch_size, int) else list(batch_size)
         td = td.to(self.device)
-        return self._reset(td, batch_size=batch_size)
+        out = self._reset(td, batch_size=batch_size)
+        if "terminated" not in out.keys():  # torchrl's EnvBase.reset adds `done` and `terminated`
+            out.set("terminated", torch.zeros_like(out["done"]))
+        return out
 
     # -- RL4COEnvBase.step (base.py:121-133) ----------------------------------------------------
     def step(self, td: TensorDict) -> dict:
@@ -464,6 +467,7 @@ class CVRPTWEnv(CVRPEnv):
         K.cvrptw_step(td["action"].contiguous(), td["demand"], td["locs"], tw, dur, td["used_capacity"],
                       td["vehicle_capacity"], td["current_time"], td["visited"], td["current_node"], td["action_mask"],
                       td["done"])
+        self._attach_distances(td)
         return td
 
     def get_action_mask(self, td: TensorDict) -> Tensor:
@@ -473,7 +477,17 @@ class CVRPTWEnv(CVRPEnv):
         tw, dur = self._tw(td)
         K.cvrptw_step(None, td["demand"], td["locs"], tw, dur, td["used_capacity"], td["vehicle_capacity"],
                       td["current_time"], td["visited"], td["current_node"], td["action_mask"], None)
+        self._attach_distances(td)
         return td["action_mask"]
+
+    @staticmethod
+    def _attach_distances(td: TensorDict) -> None:
+        """cvrptw/env.py:88-90: the reference leaves `current_loc` and `distances` (from the current node to every node)
+        in the state as side products of its mask; the kernels recompute them, these copies are for readers of the td"""
+        cur = td["current_node"].reshape(-1, 1, 1).expand(-1, 1, 2)
+        current_loc = td["locs"].gather(1, cur).squeeze(1)
+        td.set("current_loc", current_loc)
+        td.set("distances", (current_loc[:, None, :] - td["locs"]).norm(p=2, dim=-1))
 
     def check_solution_validity(self, td: TensorDict, actions: Tensor, err: Tensor | None = None) -> None:
         """cvrptw/env.py:146-190: the CVRP check, then the window data assertions and the deadline replay"""
@@ -509,7 +523,7 @@ class OPEnv(RL4COEnvBase):
                 "tour_length": torch.zeros(b, device=device),
                 "max_length": K.op_max_length(locs, td["max_length"]),
                 "current_node": torch.zeros(b, 1, dtype=torch.long, device=device),
-                "visited": torch.zeros((b, n), dtype=torch.uint8, device=device),
+                "visited": torch.zeros((b, n), dtype=torch.bool, device=device),  # bool as in the reference; the kernels see its uint8 storage
                 "current_total_prize": torch.zeros(b, dtype=torch.float, device=device),
                 "i": torch.zeros((b,), dtype=torch.int64, device=device),
                 "action_mask": torch.zeros((b, n), dtype=torch.bool, device=device),
@@ -588,7 +602,7 @@ class PCTSPEnv(RL4COEnvBase):
                 "penalty": F.pad(penalty, (1, 0), mode="constant", value=0).contiguous(),
                 "cur_total_prize": torch.zeros(b, device=device),
                 "cur_total_penalty": penalty.sum(-1),  # sum all penalties (minus the visited ones)
-                "visited": torch.zeros((b, n), dtype=torch.uint8, device=device),
+                "visited": torch.zeros((b, n), dtype=torch.bool, device=device),  # bool as in the reference; the kernels see its uint8 storage
                 "prize_required": torch.full((b,), float(self.generator.prize_required), device=device),
                 "i": torch.zeros((b,), dtype=torch.int64, device=device),
                 "action_mask": torch.zeros((b, n), dtype=torch.bool, device=device),

@@ -382,3 +382,59 @@ def test_reference_rollout_helper_with_random_policy(cpu_device, env_name, num_l
     reward, td_out, actions = ref.decoding.rollout(env, td, ref.decoding.random_policy)
     assert reward.shape == (16,) and bool(torch.isfinite(reward).all()) and actions.shape[0] == 16
     assert bool(td_out["done"].all())
+
+
+@pytest.mark.parametrize("env_name,num_loc", [("tsp", 20), ("tsp", 50), ("cvrp", 20), ("cvrp", 100), ("op", 20), ("op", 100),
+                                              ("pctsp", 50), ("spctsp", 20), ("pdp", 20), ("pdp", 50), ("cvrptw", 20),
+                                              ("cvrptw", 100)])
+def test_product_generators_follow_the_reference_stream(env_name, num_loc):
+    """Row a10: on the CPU the product generators consume the global torch generator exactly as the reference's do —
+    same seed, same instances, key by key, dtype included (CVRPTW's integer-valued windows stay int32)."""
+    from rl4co_amd.envs import get_env
+
+    ref = ref_import.load()
+    env_cls = {"tsp": ref.TSPEnv, "cvrp": ref.CVRPEnv, "op": ref.OPEnv, "pctsp": ref.PCTSPEnv, "spctsp": ref.SPCTSPEnv,
+               "pdp": ref.PDPEnv, "cvrptw": ref.CVRPTWEnv}[env_name]
+    gen_kw = dict(num_loc=num_loc)
+    if env_name == "op":
+        gen_kw["prize_distribution"] = "dist"
+    renv = env_cls(generator_params=gen_kw)
+    env = get_env(env_name, generator_params=dict(num_loc=num_loc), device="cpu")
+    for seed in (0, 7):
+        torch.manual_seed(seed)
+        want = renv.generator(batch_size=[33])
+        torch.manual_seed(seed)
+        got = env.generator(batch_size=[33])
+        assert sorted(got.keys()) == sorted(want.keys()), (sorted(got.keys()), sorted(want.keys()))
+        for k in want.keys():
+            assert got[k].dtype == want[k].dtype and torch.equal(got[k], want[k]), (k, got[k].dtype, want[k].dtype)
+
+
+@pytest.mark.parametrize("env_name", ["tsp", "cvrp", "op", "pctsp", "spctsp", "pdp", "cvrptw"])
+def test_reset_state_has_the_reference_keys_and_dtypes(cpu_device, env_name):
+    """What a reader of the state TensorDict sees after `reset`: every key the reference's reset leaves (torchrl's
+    `terminated` and CVRPTW's `current_loc` / `distances` side products included), same dtypes and values; the only
+    deliberate differences are the shape of `done` / `terminated` ([B] instead of torchrl's [B, 1]) and CVRP's
+    pre-existing uint8 `visited`, which the reference shares."""
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.tensordict import TensorDict
+
+    ref = ref_import.load()
+    env_cls = {"tsp": ref.TSPEnv, "cvrp": ref.CVRPEnv, "op": ref.OPEnv, "pctsp": ref.PCTSPEnv, "spctsp": ref.SPCTSPEnv,
+               "pdp": ref.PDPEnv, "cvrptw": ref.CVRPTWEnv}[env_name]
+    kw = dict(num_loc=20)
+    if env_name == "op":
+        kw["prize_distribution"] = "dist"
+    renv = env_cls(generator_params=kw)
+    env = get_env(env_name, generator_params=dict(num_loc=20), device="cpu")
+    torch.manual_seed(0)
+    data = renv.generator(batch_size=[5])
+    want = renv.reset(data.clone())
+    got = env.reset(TensorDict({k: v.clone() for k, v in data.items()}, batch_size=[5]))
+    assert set(want.keys()) <= set(got.keys()), sorted(set(want.keys()) - set(got.keys()))
+    for k in want.keys():
+        a, b = want[k], got[k]
+        if k in ("done", "terminated"):
+            assert b.dtype == a.dtype and torch.equal(a.reshape(-1), b.reshape(-1))
+            continue
+        assert a.dtype == b.dtype and a.shape == b.shape and torch.equal(a, b), (k, a.dtype, b.dtype, a.shape, b.shape)
