@@ -531,6 +531,14 @@ int rl4co_select_start_nodes(int64_t* out, int B, int num_starts, int num_loc, i
  * -------------------------------------------------------------------------- */
 int rl4co_hbm_read_probe(const void* src, int64_t bytes, float* sink, void* stream);
 
+/* --------------------------------------------------------------------------
+ * Deterministic-math probe: y[i] = f(x[i]) on the device, f = 0 exp / 1 log / 2 tanh of
+ * csrc/rl4co_math.h (the fp32 polynomials behind torch.tanh / log_softmax / exp in
+ * utils/decoding.py:169-188). tests/test_math.py checks device == host bit for bit and
+ * both against float64 libm.
+ * -------------------------------------------------------------------------- */
+int rl4co_math_probe_f32(int fn, const float* x, int64_t n, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

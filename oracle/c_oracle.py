@@ -65,6 +65,7 @@ def lib() -> C.CDLL:
         fn = getattr(h, name)
         fn.argtypes = [C.c_float]
         fn.restype = C.c_float
+    h.oracle_math_array.argtypes = [i, vp, C.c_int64, vp]
     h.oracle_exp1_noise.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
     h.oracle_exp1_noise.restype = C.c_float
     return h
@@ -240,3 +241,11 @@ def am_decode(cache, state: dict, *, mode: str, max_steps: int, actions: Tensor,
     a.err = _p(_cpu(err, torch.int32))
     st = lib().oracle_am_decode(C.byref(a), int(row_groups))
     assert st == 0, "oracle_am_decode rejected its arguments"
+
+
+def math_array(fn: str, x: Tensor) -> Tensor:
+    """exp / log / tanh of the shared deterministic header over a whole tensor (tests/test_math.py)."""
+    _cpu(x, torch.float32)
+    y = torch.empty_like(x)
+    assert lib().oracle_math_array({"exp": 0, "log": 1, "tanh": 2}[fn], _p(x), x.numel(), _p(y)) == 0
+    return y

@@ -645,3 +645,9 @@ float oracle_tanhf(float x) { return rl4co_tanhf(x); }
 float oracle_exp1_noise(uint64_t seed, uint64_t step, uint32_t traj, uint32_t node) {
   return rl4co_exp1_noise(seed, step, traj, node);
 }
+
+/* array form (fn: 0 exp, 1 log, 2 tanh) so tests/test_math.py can sweep millions of arguments */
+int oracle_math_array(int fn, const float* x, int64_t n, float* y) {
+  for (int64_t i = 0; i < n; ++i) y[i] = fn == 0 ? rl4co_expf(x[i]) : (fn == 1 ? rl4co_logf(x[i]) : rl4co_tanhf(x[i]));
+  return 0;
+}

@@ -122,6 +122,7 @@ SYMBOLS = {
     "rl4co_am_decode_variant": (C.c_int, [C.POINTER(AmDecodeArgs)]),
     "rl4co_select_start_nodes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "rl4co_hbm_read_probe": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "rl4co_math_probe_f32": (C.c_int, [C.c_int, _vp, _i64, _vp, _vp]),
 }
 
 

@@ -8,8 +8,10 @@
  * index — so host oracle and device kernel must round identically. Every
  * operation below is an explicit IEEE fp32 mul/add/fma/div in a fixed order;
  * both sides are compiled with -ffp-contract=off so nothing is re-fused.
- * Accuracy (tests/test_math.py): <= 2 ulp vs the correctly rounded result on the
- * ranges the decode path uses (Cephes single-precision polynomials).
+ * Accuracy (tests/test_math.py, against float64 libm over the ranges the decode path
+ * uses): exp <= 1.0 ulp, log <= 0.82 ulp, tanh <= 1.3 ulp measured (asserted at 1.25 /
+ * 1.0 / 1.75); Cephes single-precision polynomials. The same test pins the device
+ * evaluation to the host's bit for bit and the tanh == 1.0 knee to torch's.
  */
 #ifndef RL4CO_MATH_H
 #define RL4CO_MATH_H

@@ -393,3 +393,12 @@ def op_check_solution(actions: Tensor, locs: Tensor, max_length: Tensor, err: Te
 def hbm_read_probe(buf: Tensor, sink: Tensor) -> None:
     st = _lib.lib().rl4co_hbm_read_probe(_ptr(buf), buf.numel() * buf.element_size(), _ptr(sink), _stream())
     _lib.check(st, "rl4co_hbm_read_probe")
+
+
+def math_probe(fn: str, x: Tensor) -> Tensor:
+    """exp / log / tanh of csrc/rl4co_math.h evaluated on the device (tests/test_math.py)."""
+    x = _dev(x.contiguous(), torch.float32, "x")
+    y = torch.empty_like(x)
+    st = _lib.lib().rl4co_math_probe_f32({"exp": 0, "log": 1, "tanh": 2}[fn], _ptr(x), x.numel(), _ptr(y), _stream())
+    _lib.check(st, "rl4co_math_probe_f32")
+    return y
