@@ -249,7 +249,9 @@ class RL4COEnvBase:
     def reset(self, td: TensorDict | None = None, batch_size=None) -> TensorDict:
         if batch_size is None:
             batch_size = [] if td is None else td.batch_size
-        if td is None or len(td) == 0:
+        # base.py:135-143 tests `td.is_empty()` (no KEYS), not len(): with the real tensordict package len() is the
+        # leading batch size, which is 0 / undefined for a populated TensorDict with batch_size=[]
+        if td is None or (td.is_empty() if hasattr(td, "is_empty") else len(td) == 0):
             td = self.generator(batch_size=batch_size)
         batch_size = [batch_size] if isinstance(batch_size, int) else list(batch_size)
         td = td.to(self.device)

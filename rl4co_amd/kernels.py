@@ -57,6 +57,14 @@ def _u8(t: Tensor, name: str) -> Tensor:
     return t
 
 
+def _check_rows(b: int, **tensors) -> None:
+    """Every per-trajectory tensor of a step call must hold exactly ``b`` rows (the mask's): a shorter ``action``
+    (e.g. an instance-level action against batchified multistart state) would be read out of bounds on the device."""
+    for name, t in tensors.items():
+        if t is not None and t.shape[0] != b:
+            raise ValueError(f"{name} has {t.shape[0]} rows, action_mask has {b}")
+
+
 def new_error_word(device) -> Tensor:
     return torch.zeros(1, dtype=torch.int32, device=device)
 
@@ -120,6 +128,7 @@ def tsp_step(action: Tensor, action_mask: Tensor, first_node: Tensor, current_no
     _dev(action, torch.int64, "action")
     mask = _u8(action_mask, "action_mask")
     b, n = mask.shape
+    _check_rows(b, action=action, first_node=first_node, current_node=current_node, i=step_i, done=done)
     st = _lib.lib().rl4co_tsp_step(
         _ptr(action), _ptr(mask), _ptr(_dev(first_node, torch.int64, "first_node")),
         _ptr(_dev(current_node, torch.int64, "current_node")), _ptr(_dev(step_i, torch.int64, "i")),
@@ -135,6 +144,8 @@ def cvrp_step(action: Tensor | None, demand: Tensor, used_capacity: Tensor, vehi
     mask = _u8(action_mask, "action_mask")
     b, n = mask.shape
     b_inst = demand.shape[0]
+    _check_rows(b, action=action, used_capacity=used_capacity, vehicle_capacity=vehicle_capacity, visited=visited,
+                current_node=current_node, done=done)
     st = _lib.lib().rl4co_cvrp_step(
         _ptr(None if action is None else _dev(action, torch.int64, "action")),
         _ptr(_dev(demand, torch.float32, "demand")), _ptr(_dev(used_capacity, torch.float32, "used_capacity")),
@@ -291,6 +302,7 @@ def op_step(action: Tensor | None, locs: Tensor, max_length: Tensor, tour_length
             current_node: Tensor, step_i: Tensor, action_mask: Tensor, done: Tensor, err: Tensor | None = None) -> None:
     """In-place OPEnv._step + get_action_mask (op/env.py:67-98,137-154); action=None -> mask only."""
     b, n = action_mask.shape
+    _check_rows(b, action=action, tour_length=tour_length, visited=visited, current_node=current_node, i=step_i, done=done)
     st = _lib.lib().rl4co_op_step(
         _ptr(None if action is None else _dev(action, torch.int64, "action")), _ptr(_dev(locs, torch.float32, "locs")),
         _ptr(_dev(max_length, torch.float32, "max_length")), _ptr(_dev(tour_length, torch.float32, "tour_length")),
@@ -306,6 +318,8 @@ def cvrptw_step(action: Tensor | None, demand: Tensor, locs: Tensor, time_window
     """In-place CVRPTWEnv._step + get_action_mask (cvrptw/env.py:83-113); action=None -> mask only.
     ``time_windows`` [B_inst,N,2] and ``durations`` [B_inst,N] are fp32 (the reference's integer windows cast)."""
     b, n = action_mask.shape
+    _check_rows(b, action=action, used_capacity=used_capacity, vehicle_capacity=vehicle_capacity, current_time=current_time,
+                visited=visited, current_node=current_node, done=done)
     st = _lib.lib().rl4co_cvrptw_step(
         _ptr(None if action is None else _dev(action, torch.int64, "action")), _ptr(_dev(demand, torch.float32, "demand")),
         _ptr(_dev(locs, torch.float32, "locs")), _ptr(_dev(time_windows, torch.float32, "time_windows")),
@@ -331,6 +345,7 @@ def pdp_step(action: Tensor | None, available: Tensor, to_deliver: Tensor, curre
              action_mask: Tensor, done: Tensor, err: Tensor | None = None) -> None:
     """In-place PDPEnv._step (pdp/env.py:64-99); action=None -> mask = available & to_deliver only."""
     b, n = action_mask.shape
+    _check_rows(b, action=action, available=available, to_deliver=to_deliver, current_node=current_node, i=step_i, done=done)
     st = _lib.lib().rl4co_pdp_step(
         _ptr(None if action is None else _dev(action, torch.int64, "action")), _ptr(_u8(available, "available")),
         _ptr(_u8(to_deliver, "to_deliver")), _ptr(_dev(current_node, torch.int64, "current_node")),
@@ -352,6 +367,8 @@ def pctsp_step(action: Tensor | None, real_prize: Tensor, cur_total_prize: Tenso
     """In-place PCTSPEnv._step + get_action_mask (pctsp/env.py:62-91,141-148); action=None -> mask only.
     ``real_prize`` [B_inst, N] carries 0 in the depot column."""
     b, n = action_mask.shape
+    _check_rows(b, action=action, cur_total_prize=cur_total_prize, visited=visited, current_node=current_node, i=step_i,
+                done=done)
     st = _lib.lib().rl4co_pctsp_step(
         _ptr(None if action is None else _dev(action, torch.int64, "action")),
         _ptr(_dev(real_prize, torch.float32, "real_prize")), _ptr(_dev(cur_total_prize, torch.float32, "cur_total_prize")),

@@ -444,6 +444,7 @@ class AttentionModelPolicy(nn.Module):
         self.fused_backward = fused_backward
         self.teacher_variant = teacher_variant  # "auto" | "replay" | "mma" (teacher.run_backward)
         self._packed = None
+        self._bwd_err = None  # device int32 word the teacher backward ORs its sticky bits into (read with the next status)
         self._philox_calls = 0
         self.last_instance_steps = 0
         self.encode_events: list | None = None
@@ -499,9 +500,20 @@ class AttentionModelPolicy(nn.Module):
             x = T.batch_norm_eval(x2 + s_, norm2).view(b, n, d)
         return x, init_h
 
+    def _bf16_regime(self) -> bool:
+        """The encoder's GEMM inputs are bf16: asked for by the constructor (``encoder_autocast=torch.bfloat16``) or by
+        an ambient ``torch.autocast("cuda", dtype=torch.bfloat16)`` — what Lightning's ``precision="bf16-mixed"`` wraps
+        around training steps AND the validation / ``RolloutBaseline`` rollouts (utils/trainer.py:57 picks the
+        precision; the reference's default "16-mixed" is fp16 autocast: no hand-written kernel claims that regime,
+        the torch encoder runs under it exactly as the reference's does)."""
+        if self.encoder_autocast == torch.bfloat16:
+            return True
+        return (self.encoder_autocast is None and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+
     def _token_encoder_usable(self, td) -> bool:
         layer0 = self.encoder.net.layers[0]
-        return (td["locs"].is_cuda and self.encoder_autocast == torch.bfloat16 and layer0[1].kind == "batch"
+        return (td["locs"].is_cuda and self._bf16_regime() and layer0[1].kind == "batch"
                 and not self.training and len(layer0[2].module.lins) == 2 and layer0[2].module.lins[0].out_features % 128 == 0)
 
     def _encode(self, td):
@@ -573,7 +585,7 @@ class AttentionModelPolicy(nn.Module):
                 return_sum_log_likelihood: bool = True, actions: Tensor | None = None,
                 max_steps: int = 1_000_000, **decoding_kwargs) -> dict:
         grad_path = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        use_fused = (self.fused_encoder and self.encoder_autocast == torch.bfloat16 and not grad_path
+        use_fused = (self.fused_encoder and self._bf16_regime() and not grad_path
                      and not return_init_embeds and self._packed_encoder().supported(td))
         if use_fused:
             if self.encode_events is not None:  # bench.py: HIP events around the encoder launch
@@ -714,6 +726,9 @@ class AttentionModelPolicy(nn.Module):
             td_early = self._final_td(td, state, n_rep)
             td_early.set("action", out_actions[:, -1])
             reward_early = env.get_reward(td_early, out_actions, check_solution=False if checked else None)
+        if self._bwd_err is not None:  # sticky bits of the previous step's backward kernel ride on this read-back
+            status[:1].bitwise_or_(self._bwd_err)
+            self._bwd_err = None
         err_bits, horizon_used, streamed = status.tolist()  # one 12-byte read-back, no reduction launches
         t_used = t0 + int(horizon_used)
         self.last_instance_steps = int(streamed)  # instance-steps the decode launch really streamed
@@ -731,27 +746,15 @@ class AttentionModelPolicy(nn.Module):
         td_out = td_early if td_early is not None else self._final_td(td, state, n_rep)
         td_out.set("action", out_actions[:, -1])
 
-        if n_rep > 0 and select_best:
-            rewards = env.get_reward(td_out, out_actions)
-            best = rewards.view(n_rep, b_inst).transpose(0, 1).max(dim=-1)[1]  # unbatchify + max
-            rows = best * b_inst + torch.arange(b_inst, device=device)
-            out_actions, logps = out_actions[rows], logps[rows]
-            if all_logps is not None:
-                all_logps = all_logps[rows]
-            td_out = td_out[rows] if hasattr(td_out, "__getitem__") else td_out
-            reward = rewards[rows] if calc_reward else None
-        elif reward_early is not None:
-            reward = reward_early
-        else:
-            reward = (env.get_reward(td_out, out_actions, check_solution=False if checked else None)
-                      if calc_reward else td_out.get("reward", None))
-        if calc_reward:
-            td_out.set("reward", reward)
-
-        if grad_path and cache_g is not None and not (n_rep > 0 and select_best):
+        # differentiable re-evaluation of the ROLLED-OUT rows (all s * b_inst of them: the replay needs the imposed
+        # start nodes and the batchified state) — before any best-of selection narrows the rows
+        full_logp = None  # [B, T, N] differentiable log-softmax, only when a differentiable entropy is asked for
+        if grad_path and cache_g is not None:
             from . import teacher
 
-            meta = dict(t0=t0, mask_inner=self.decoder.mask_inner, mask_logits=mask_logits,
+            if self._bwd_err is None:
+                self._bwd_err = torch.zeros(1, dtype=torch.int32, device=device)
+            meta = dict(t0=t0, mask_inner=self.decoder.mask_inner, mask_logits=mask_logits, err_sink=self._bwd_err,
                         tanh_clipping=tanh_clipping, temperature=temperature, teacher_variant=self.teacher_variant)
             if self.env_name in ("cvrp", "cvrptw"):
                 meta.update(demand=td["demand"], vehicle_capacity=td["vehicle_capacity"])
@@ -764,9 +767,30 @@ class AttentionModelPolicy(nn.Module):
             step_logps = teacher.teacher_forced_logps(self.env_name, cache_g, cache, out_actions, logps, meta)
         elif grad_path:
             step_logps = self.evaluate_log_probs(td, hidden, out_actions, n_rep, tanh_clipping, temperature,
-                                                 mask_logits, skip_first=(t0 == 1))
+                                                 mask_logits, skip_first=(t0 == 1), return_full=return_entropy)
+            if return_entropy:
+                step_logps, full_logp = step_logps
         else:
             step_logps = logps
+
+        if n_rep > 0 and select_best:
+            rewards = env.get_reward(td_out, out_actions)
+            best = rewards.view(n_rep, b_inst).transpose(0, 1).max(dim=-1)[1]  # unbatchify + max
+            rows = best * b_inst + torch.arange(b_inst, device=device)
+            out_actions, logps, step_logps = out_actions[rows], logps[rows], step_logps[rows]
+            if all_logps is not None:
+                all_logps = all_logps[rows]
+            if full_logp is not None:
+                full_logp = full_logp[rows]
+            td_out = td_out[rows] if hasattr(td_out, "__getitem__") else td_out
+            reward = rewards[rows] if calc_reward else None
+        elif reward_early is not None:
+            reward = reward_early
+        else:
+            reward = (env.get_reward(td_out, out_actions, check_solution=False if checked else None)
+                      if calc_reward else td_out.get("reward", None))
+        if calc_reward:
+            td_out.set("reward", reward)
         # decoding.py:56: on the kernel path this is the RL4CO_EBIT_NEG_INF_LOGP sticky bit (already
         # raised above); only the autograd re-evaluation needs its own check
         if grad_path and not bool((step_logps.detach() > -1000).all()):
@@ -778,7 +802,13 @@ class AttentionModelPolicy(nn.Module):
         if return_actions:
             outdict["actions"] = out_actions
         if return_entropy:
-            lp = torch.nan_to_num(all_logps, nan=0.0)
+            # ops.py:103-111 on the [B, T, N] log-probs. Under autograd the reference's entropy carries history (PPO's
+            # entropy bonus differentiates it): then it is built from the differentiable log-softmax of the
+            # re-evaluation, not from the kernel's (history-free) all_logps; the imposed multistart step has p = 1
+            lp_src = all_logps
+            if full_logp is not None:
+                lp_src = full_logp if t0 == 0 else torch.cat([all_logps[:, :1], full_logp[:, 1:]], 1)
+            lp = torch.nan_to_num(lp_src, nan=0.0)
             entropy = -(lp.exp() * lp).sum(dim=-1).sum(dim=1)
             assert entropy.isfinite().all(), "Entropy is not finite"
             outdict["entropy"] = entropy
@@ -787,6 +817,15 @@ class AttentionModelPolicy(nn.Module):
         if return_init_embeds:
             outdict["init_embeds"] = init_embeds
         return outdict
+
+    def check_backward_errors(self) -> None:
+        """Raise the reference's assertion for any sticky bit the LAST teacher-forced backward kernel set (a sync).
+        Rollouts do this on their own: the word rides on the next rollout's status read-back."""
+        if self._bwd_err is not None:
+            bits, self._bwd_err = int(self._bwd_err.item()), None
+            from . import _lib as _l
+
+            _l.raise_for_error_bits(bits)
 
     # -- pieces -------------------------------------------------------------------------------------
     def _env_step_state(self, state: dict, action: Tensor, err: Tensor) -> None:
@@ -844,7 +883,7 @@ class AttentionModelPolicy(nn.Module):
 
     # -- teacher-forced, differentiable re-evaluation (row N1 of SURVEY.md §8f) -------------------
     def evaluate_log_probs(self, td, hidden: Tensor, actions: Tensor, n_rep: int, tanh_clipping: float,
-                           temperature: float, mask_logits: bool, skip_first: bool = False) -> Tensor:
+                           temperature: float, mask_logits: bool, skip_first: bool = False, return_full: bool = False):
         """log p(a_t | s_t) for all t at once, with autograd through encoder and decoder weights.
 
         With the actions known every step's query is known up front, so the T sequential
@@ -898,7 +937,7 @@ class AttentionModelPolicy(nn.Module):
         step_logps = logp.gather(-1, actions[..., None]).squeeze(-1)
         if skip_first:  # multistart: the first action is imposed, its log-prob is 0 (decoding.py:318-323)
             step_logps = torch.cat([torch.zeros_like(step_logps[:, :1]), step_logps[:, 1:]], 1)
-        return step_logps
+        return (step_logps, logp) if return_full else step_logps
 
     @torch.no_grad()
     def _replay(self, td, actions: Tensor, n_rep: int):

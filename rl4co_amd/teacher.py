@@ -169,6 +169,14 @@ class TeacherForcedLogLik(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_logp):
         out = run_backward(ctx.cache, ctx.actions, grad_logp, ctx.meta, variant=ctx.meta.get("teacher_variant", "auto"))
+        # the kernel's sticky error word (infeasible / out-of-range replayed action, NaN): OR-ed into the caller's
+        # deferred word, which the policy reads together with the NEXT rollout's status (no sync inside backward);
+        # without a sink the word is checked here
+        sink = ctx.meta.get("err_sink")
+        if sink is not None:
+            sink.bitwise_or_(out["err"])
+        else:
+            _lib.raise_for_error_bits(int(out["err"].item()))
         has_first, has_bias, has_extra, has_time = ctx.has
         return (out["d_kvl"], out["d_ctx_first"] if has_first else None, out["d_ctx_cur"],
                 out["d_q_bias"] if has_bias else None, out["d_extra"] if has_extra else None,

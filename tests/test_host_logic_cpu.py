@@ -164,3 +164,68 @@ def test_training_log_likelihood_has_reference_gradients(cpu_device, name):
             assert err <= 1e-3 * nrm + 1e-6, (k, err, nrm)
             continue
         torch.testing.assert_close(ours[k].grad, p.grad, rtol=2e-3, atol=2e-5, msg=lambda m: f"{k}: {m}")
+
+
+@pytest.mark.parametrize("decode,kw", [("multistart_greedy", {}), ("sampling", dict(num_samples=4))])
+def test_select_best_with_grad_enabled(cpu_device, decode, kw):
+    """Best-of selection OUTSIDE no_grad with trainable parameters (policy.py:766): the differentiable
+    re-evaluation replays all s x B rows (imposed start nodes, batchified state) and THEN narrows to the selected
+    rows — values as the reference's (decoding.py:332-342,415-423), with autograd history into the parameters."""
+    g = GoldenCase("pomo_tsp20_b16_msgreedy" if "multistart" in decode else "cvrp20_b128_greedy")
+    pol, env = _product_policy(g), _product_env(g)
+    n = g.num_loc + (g.env_name != "tsp")
+    extra = {}
+    if decode == "sampling":
+        torch.manual_seed(5)
+        extra["exp_noise"] = torch.stack([torch.empty(g.batch * 4, n).exponential_(1) for _ in range(2 * n)], 0).contiguous()
+    out = pol(env.reset(_product_td(g)), env, phase="test", decode_type=decode, select_best=True, **kw, **extra)
+    assert out["reward"].shape == (g.batch,) and out["actions"].shape[0] == g.batch
+    assert out["log_likelihood"].shape == (g.batch,) and out["log_likelihood"].requires_grad
+    with torch.inference_mode():
+        want = pol(env.reset(_product_td(g)), env, phase="test", decode_type=decode, select_best=True, **kw, **extra)
+    assert torch.equal(out["actions"], want["actions"]) and torch.equal(out["reward"], want["reward"])
+    torch.testing.assert_close(out["log_likelihood"].detach(), want["log_likelihood"], rtol=1e-4, atol=1e-4)
+    out["log_likelihood"].sum().backward()
+    assert any(p.grad is not None and float(p.grad.abs().max()) > 0 for p in pol.parameters())
+
+
+def test_entropy_is_differentiable_under_grad(cpu_device):
+    """return_entropy with autograd on (PPO's entropy bonus, rl/ppo/ppo.py): the reference's entropy carries history;
+    ours is built from the differentiable re-evaluation and equals the kernel's value."""
+    g = GoldenCase("cvrp20_b128_greedy")
+    pol, env = _product_policy(g), _product_env(g)
+    out = pol(env.reset(_product_td(g)), env, phase="test", decode_type="greedy", return_entropy=True)
+    assert out["entropy"].requires_grad
+    with torch.inference_mode():
+        want = pol(env.reset(_product_td(g)), env, phase="test", decode_type="greedy", return_entropy=True)
+    torch.testing.assert_close(out["entropy"].detach(), want["entropy"], rtol=1e-4, atol=1e-4)
+    ref = g.policy(g.reset(), g.env, phase="test", decode_type="greedy", return_entropy=True)
+    torch.testing.assert_close(out["entropy"].detach(), ref["entropy"].detach(), rtol=1e-4, atol=1e-4)
+    out["entropy"].sum().backward()
+    ref["entropy"].sum().backward()
+    ours = dict(pol.named_parameters())
+    for k, p in g.policy.named_parameters():
+        if p.grad is not None and float(p.grad.abs().max()) > 0:
+            torch.testing.assert_close(ours[k].grad, p.grad, rtol=5e-3, atol=5e-5, msg=lambda m: f"{k}: {m}")
+
+
+def test_step_wrappers_reject_mismatched_rows():
+    """kernels.*_step: an action tensor with fewer rows than the mask would be read out of bounds on the device
+    (ADVICE r1): refused on the host, before the non-CUDA check even matters."""
+    from rl4co_amd import kernels as K
+
+    with pytest.raises(ValueError, match="rows"):
+        K._check_rows(8, action=torch.zeros(4, dtype=torch.int64), done=torch.zeros(8, dtype=torch.bool))
+    K._check_rows(8, action=None, done=torch.zeros(8, dtype=torch.bool))
+
+
+def test_reset_regenerates_only_an_empty_tensordict(cpu_device):
+    """base.py:135-143 tests td.is_empty(), not len(td)."""
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.tensordict import TensorDict
+
+    env = get_env("tsp", generator_params=dict(num_loc=10), device="cpu")
+    td = env.reset(TensorDict({}, batch_size=[4]))
+    assert td["locs"].shape == (4, 10, 2)
+    full = TensorDict({"locs": torch.rand(3, 10, 2)}, batch_size=[3])
+    assert torch.equal(env.reset(full)["locs"], full["locs"])
