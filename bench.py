@@ -5,23 +5,41 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch of synthetic instances already resident in
-HBM: ``env.reset`` -> AttentionModel policy greedy rollout (encoder, cache fold, ONE persistent
-launch of the fused decode kernel for all T decode steps, tour-length reward, validity check).
-Workload at every N: BASELINE.json configs[1] — TSPEnv num_loc=100, batch 4096 per GPU, AM
-(3 layers, d=128, 8 heads), bf16 cache planes with fp32 arithmetic, greedy. Instances shard
-across ranks with no data-path collective (weak scaling; SURVEY.md §8e: inference = replicas).
+One "step" = one pass of the hot path over one batch of synthetic instances already resident in HBM:
+``env.reset`` -> AttentionModel policy rollout (fused MFMA encoder + cache fold, ONE persistent launch of the
+fused decode kernel for all T decode steps, tour-length reward, validity check).
 
-Rank 0 prints ONE JSON line. ``value`` = whole-job instance·decode-steps per second
-(B·T·N_gpus·K / wall), wall = max over ranks of the barrier-bracketed timed region.
-``roofline``: the decode kernel's algorithmic bytes per launch (SURVEY.md §8d per instance-step
-figure x B x T) / its mean launch duration, measured here with HIP events on the launch stream.
-``cpu_baseline``: the reference path (torch restatement, pinned bit-exact to the reference's own
-source by oracle/gen_golden.py) timed on this box's host cores on a bounded sample.
+HEADLINE (the top-level keys of the JSON line; `--steps K` / `--warmup W` apply to it): BASELINE.json
+configs[1] — TSPEnv num_loc=100, batch 4096 per GPU, AM (3 layers, d=128, 8 heads), bf16 encoder GEMMs and
+cache planes with fp32 arithmetic, greedy. The other BASELINE configs are timed by the same process right after it
+and reported under ``"legs"`` in the same line (``--legs`` selects; each with its own roofline object):
+
+    c2_sampling  configs[1], sampling (in-kernel Philox)          c3_greedy  configs[2] CVRP-100 x 4096
+    c5_sampling  configs[4] CVRP-500 x 1024 sampling               c4_train   configs[3] per-GPU share: POMO
+                 (WIDE decode variant, token-parallel encoder)                TSP-100 x 4096 x 8 starts REINFORCE
+                                                                              step incl. the RCCL grad all-reduce
+
+Instances shard across ranks with no data-path collective (weak scaling; SURVEY.md §8e: inference = replicas); the
+training leg's one exchange step is the flat fp32 gradient all-reduce on "nccl" (= RCCL), initialised even at N = 1 so
+that the collective path really executes. Rank 0 prints ONE JSON line. ``value`` = whole-job instance·decode-steps per
+second (B·T·N_gpus·K / wall), wall = max over ranks of the barrier-bracketed timed region.
+
+``roofline`` (decode kernel, HBM-bound): ``achieved`` = bytes the launch MUST move — the cache rows it streams are
+counted by the kernel itself (rows of the currently feasible nodes only: masked nodes are exact zeros in the
+reference's formulation and are never read), x 3 planes x 256 B, plus the gathered context rows, masks and outputs —
+divided by the mean launch duration from HIP events on the launch stream, so ``frac`` <= 1 by construction. The
+SURVEY.md §8(d) contract figure (every node's row at every step, what the reference's formulation reads) is kept
+beside it as ``algorithmic_bytes_contract`` / ``contract_frac``. ``traffic`` = HBM bytes per launch from the separate
+rocprofv3 --pmc passes of the same leg (``traffic_source`` names the committed file; a counter pass cannot run
+inside this process). ``cpu_baseline``: the reference path (torch restatement, pinned bit-exact to the reference's
+own source by oracle/gen_golden.py; kind "port") timed on this box's host cores on a bounded sample.
+``parity``: greedy trajectories of the fp32 parity configuration (folded cache and the reference's own association)
+and of the benchmarked bf16 configuration against the reference's 4096 tours of configs[1] (tests/golden).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -34,7 +52,18 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import torch  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16
+
+LEGS = {
+    # name: (env, num_loc, batch per GPU, decode, BASELINE.json config index)
+    "c2_greedy": ("tsp", 100, 4096, "greedy", 1),
+    "c2_sampling": ("tsp", 100, 4096, "sampling", 1),
+    "c3_greedy": ("cvrp", 100, 4096, "greedy", 2),
+    "c5_sampling": ("cvrp", 500, 1024, "sampling", 4),
+    "c4_train": ("tsp", 100, 4096, "multistart_sampling", 3),
+}
+DEFAULT_LEGS = "c2_greedy,c2_sampling,c3_greedy,c5_sampling,c4_train"
 
 
 def log(msg: str) -> None:
@@ -43,11 +72,31 @@ def log(msg: str) -> None:
 
 
 def algorithmic_bytes_per_instance_step(env_name: str, n: int, elem: int) -> int:
-    """3·N·d·e (K_g,V_g,K_l) + N (mask read) + N (mask write) + context rows
+    """SURVEY.md §8(d) contract: 3·N·d·e (K_g,V_g,K_l) + N (mask read) + N (mask write) + context rows
     (TSP: 2·d·e, CVRP: d·e + 8) + d·4 (graph context) + 16 (action, logp, scalars)."""
     d = 128
     ctx = 2 * d * elem if env_name == "tsp" else d * elem + 8
     return 3 * n * d * elem + 2 * n + ctx + d * 4 + 16
+
+
+def must_move_bytes(env_name: str, n: int, elem: int, rows_read: int, instance_steps: int, trajectories: int) -> int:
+    """Bytes one decode launch has to move through HBM given what it actually visits: `rows_read` cache rows per
+    plane (counted in-kernel: the feasible rows of every step), per step the gathered fp32 context rows (TSP two,
+    CVRP one + the load scalar) and the action / log-prob it stores, per trajectory its mask in and out, graph
+    context and state words (the mask lives in LDS between entry and exit)."""
+    d = 128
+    per_step = (2 * d * 4 if env_name == "tsp" else d * 4 + 8) + 12
+    per_traj = 2 * n + d * 4 + 64
+    return rows_read * 3 * d * elem + instance_steps * per_step + trajectories * per_traj
+
+
+def state_hash(tensors: dict) -> str:
+    """Same digest as oracle/gen_golden.py writes into tests/golden/MANIFEST.json."""
+    h = hashlib.sha256()
+    for k in sorted(tensors):
+        h.update(k.encode())
+        h.update(tensors[k].detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
 
 
 def cpu_baseline(env_name: str, num_loc: int, sample_batch: int, repeats: int, chunk: int = 512) -> dict:
@@ -110,24 +159,279 @@ def cpu_baseline(env_name: str, num_loc: int, sample_batch: int, repeats: int, c
         "sample": f"{env_name.upper()}-{num_loc}, {sample_batch} instances in calls of {chunk}, greedy full rollout "
                   f"(encoder+decode+reward), fp32 torch CPU, best of {repeats} passes after 1 warm-up, {best:.3f} s each",
         "mean_reward": float(torch.cat(rewards).mean()),
+        "note": "the oracle restatement (the reference package itself cannot be installed on the box); thread count "
+                "chosen by probing; varies 1.0-1.35e5 between boxes",
     }
+
+
+class Bench:
+    def __init__(self, args, rank: int, world: int, device: torch.device):
+        from rl4co_amd import dist as D
+
+        self.args, self.rank, self.world, self.device, self.D = args, rank, world, device, D
+        self.cache_dtype = torch.bfloat16 if args.cache_dtype == "bf16" else torch.float32
+        self.enc_dtype = torch.bfloat16 if args.encoder_dtype == "bf16" else None
+        self.elem = 2 if args.cache_dtype == "bf16" else 4
+
+    def barrier(self) -> None:
+        torch.cuda.synchronize()
+        self.D.barrier()
+        torch.cuda.synchronize()
+
+    def traffic(self, leg: str):
+        """HBM bytes per decode launch of this leg from the separate rocprofv3 --pmc passes (tools/profile_round.sh
+        + tools/profile_parse.py write profiles/pmc_traffic.json); (None, None) when the leg was not profiled."""
+        try:
+            table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        except (OSError, ValueError):
+            return None, None
+        key = f"{leg}/{self.args.cache_dtype}"
+        row = table.get(key)
+        return (row["traffic_bytes_per_launch"], row.get("source")) if row else (None, None)
+
+    # -- inference rollout legs ---------------------------------------------------------------------------------
+    def rollout_leg(self, leg: str, steps: int, warmup: int) -> dict:
+        from rl4co_amd import kernels as K
+        from rl4co_amd.envs import get_env
+        from rl4co_amd.policy import AttentionModelPolicy
+
+        a = self.args
+        env_name, num_loc, batch, decode, cfg_idx = LEGS[leg]
+        if a.batch is not None and leg == "c2_greedy":
+            batch = a.batch
+        torch.manual_seed(0)  # random-init weights of the reference architecture, identical on every rank
+        policy = AttentionModelPolicy(env_name=env_name, cache_dtype=self.cache_dtype,
+                                      encoder_autocast=self.enc_dtype).to(self.device).eval()
+        env = get_env(env_name, generator_params=dict(num_loc=num_loc, device=self.device), device=self.device,
+                      check_solution=not a.no_check_solution)
+        torch.manual_seed(1234 + self.rank)  # each rank owns its shard of the synthetic instances
+        data = env.generator(batch_size=[batch])
+        torch.cuda.synchronize()
+
+        def step():
+            return policy(env.reset(data), env, phase="test", decode_type=decode)
+
+        log(f"{leg}: rank {self.rank}/{self.world}, {batch} instances resident, warming up")
+        rows = inst_steps = 0
+        with torch.inference_mode():
+            for _ in range(warmup):
+                out = step()
+            torch.cuda.synchronize()
+            policy.decode_events, policy.encode_events = [], []
+            self.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                out = step()
+                rows += policy.last_rows_read
+                inst_steps += policy.last_instance_steps
+            self.barrier()
+            wall = time.perf_counter() - t0
+        decode_ms = [x.elapsed_time(y) for x, y in policy.decode_events]
+        encode_ms = [x.elapsed_time(y) for x, y in policy.encode_events]
+        policy.decode_events = policy.encode_events = None
+        t_steps = out["actions"].shape[1]
+        n_nodes = num_loc + (0 if env_name == "tsp" else 1)
+        wall = self.D.reduce_scalar(wall, "max", self.device)
+        total_inst_steps = int(self.D.reduce_scalar(inst_steps, "sum", self.device))
+        res = {"wall": wall}
+        if self.rank != 0:
+            return res
+        mean_decode_ms = sum(decode_ms) / len(decode_ms)
+        per_launch_rows, per_launch_steps = rows / steps, inst_steps / steps
+        need = must_move_bytes(env_name, n_nodes, self.elem, per_launch_rows, per_launch_steps, batch)
+        contract = algorithmic_bytes_per_instance_step(env_name, n_nodes, self.elem) * per_launch_steps
+        achieved = need / (mean_decode_ms * 1e-3) / 1e9
+        traffic, traffic_source = self.traffic(leg)
+        variant = {1: "STREAM (1 wave / trajectory)", 2: "LDS-resident", 3: "WIDE (4 waves / trajectory)", 4: "MS"}.get(
+            K.decode_variant(n_nodes, self.cache_dtype, t_steps, batch), "?")
+        value = total_inst_steps / wall
+        res.update({
+            "workload": (f"BASELINE configs[{cfg_idx}]: {env_name.upper()}Env num_loc={num_loc} batch={batch}/GPU "
+                         f"AttentionModel(3L,d128,h8) {decode} rollout, {a.encoder_dtype} encoder GEMMs, {a.cache_dtype} cache"),
+            "value": value, "unit": "instance·step/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": wall / steps * 1e3,
+            "node_steps_per_sec": value * n_nodes,
+            "instances_per_sec": batch * self.world * steps / wall,
+            "decode_steps_longest": t_steps, "instance_steps_per_launch": per_launch_steps,
+            "mean_reward": float(out["reward"].mean()),
+            "roofline": {
+                "kernel": f"am_decode kernel, {variant}: fused persistent rollout, all decode steps in one launch",
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": traffic_source,
+                "bytes_per_launch": need,
+                "bytes_model": "3 planes x 128 x elem x cache rows streamed (counted in-kernel: feasible rows only) + "
+                               "per step gathered fp32 context rows and outputs + per trajectory mask in/out and state",
+                "cache_rows_per_launch": per_launch_rows,
+                "algorithmic_bytes_contract": contract,
+                "contract_note": "SURVEY.md §8(d): every node's row at every step (the reference's formulation); the kernel "
+                                 "skips masked rows, so contract bytes / time may exceed the HBM peak — it is not a fraction",
+                "contract_GBs": contract / (mean_decode_ms * 1e-3) / 1e9,
+                "launch_ms_mean": mean_decode_ms, "launch_ms_min": min(decode_ms),
+                "us_per_decode_step": mean_decode_ms * 1e3 / t_steps, "launches_timed": len(decode_ms),
+                "hbm_utilisation_from_traffic": (traffic / (mean_decode_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            },
+        })
+        if encode_ms:  # second kernel of the step: fused encoder + cache fold on the matrix cores
+            n_, d_, ff_, layers_ = n_nodes, 128, 512, 3
+            flop_inst = layers_ * (2 * n_ * d_ * 3 * d_ + 4 * n_ * n_ * d_ + 2 * n_ * d_ * d_ + 4 * n_ * d_ * ff_) \
+                + (5 if env_name == "tsp" else 4) * 2 * n_ * d_ * d_
+            enc_ms = sum(encode_ms) / len(encode_ms)
+            tf = flop_inst * batch / (enc_ms * 1e-3) / 1e12
+            res["encoder_roofline"] = {
+                "kernel": "am_encoder_kernel (init embedding + 3 x [MHA, norm, FFN, norm] + cache fold, one workgroup per instance)",
+                "bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS,
+                "flop_per_instance": flop_inst, "launch_ms_mean": enc_ms,
+                "note": "algorithmic FLOPs at N nodes (padding excluded); bf16 dense MFMA peak",
+            }
+        res["host_gap_ms"] = res["ms_per_step"] - mean_decode_ms - (sum(encode_ms) / len(encode_ms) if encode_ms else 0.0)
+        return res
+
+    # -- the training leg: configs[3]'s per-GPU share ----------------------------------------------------------------
+    def train_leg(self, steps: int, warmup: int) -> dict:
+        import torch.distributed as dist
+
+        from rl4co_amd.envs import get_env
+        from rl4co_amd.policy import AttentionModelPolicy
+
+        D = self.D
+        env_name, num_loc, batch, _, cfg_idx = LEGS["c4_train"]
+        starts = 8
+        torch.manual_seed(0)
+        policy = AttentionModelPolicy(env_name, num_encoder_layers=6, normalization="instance", use_graph_context=False,
+                                      cache_dtype=torch.bfloat16, encoder_autocast=torch.bfloat16,
+                                      train_decode_type="multistart_sampling").to(self.device).train()
+        env = get_env(env_name, generator_params=dict(num_loc=num_loc, device=self.device), device=self.device,
+                      check_solution=False)  # configs/experiment/base.yaml:21 trains with the check off
+        opt = torch.optim.Adam(policy.parameters(), lr=1e-4)
+        bucket = D.FlatGradBucket(policy)
+        torch.manual_seed(1234 + self.rank)
+        data = env.generator(batch_size=[batch])
+        ar_events = []
+
+        def step(i):
+            out = policy(env.reset(data), env, phase="train", seed=1000 * i + self.rank, num_starts=starts)
+            reward = out["reward"].view(starts, batch).t()
+            ll = out["log_likelihood"].view(starts, batch).t()
+            adv = reward - reward.mean(dim=1, keepdim=True)  # SharedBaseline over the starts (pomo/model.py:88-111)
+            loss = -(adv.detach() * ll).mean()
+            loss.backward()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            work = bucket.allreduce_mean(async_op=True)  # ONE flat fp32 message over RCCL (utils/trainer.py:83-86)
+            if work is not None:
+                work.wait()
+            e1.record()
+            ar_events.append((e0, e1))
+            torch.nn.utils.clip_grad_norm_(policy.parameters(), 1.0)
+            opt.step()
+            bucket.zero_()
+            return out
+
+        log(f"c4_train: rank {self.rank}/{self.world}, warming up")
+        for i in range(warmup):
+            step(i)
+        torch.cuda.synchronize()
+        ar_events.clear()
+        self.barrier()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out = step(warmup + i)
+        self.barrier()
+        wall = time.perf_counter() - t0
+        policy.check_backward_errors()
+        wall = D.reduce_scalar(wall, "max", self.device)
+        res = {"wall": wall}
+        if self.rank != 0:
+            return res
+        t_steps = out["actions"].shape[1]
+        traj = batch * starts * self.world * steps
+        ar_ms = [x.elapsed_time(y) for x, y in ar_events]
+        res.update({
+            "workload": (f"BASELINE configs[{cfg_idx}] per-GPU share: POMO (6L, instance norm) REINFORCE step, TSPEnv num_loc={num_loc}, "
+                         f"{batch} instances x {starts} starts per GPU: multistart sampling rollout (MS decode kernel), "
+                         "teacher-forced backward (MMA), bf16 training-encoder kernels, flat fp32 grad all-reduce, clip, Adam"),
+            "ms_per_step": wall / steps * 1e3, "steps": steps, "warmup": warmup,
+            "value": traj * t_steps / wall, "unit": "instance·step/s (trajectory steps, rollout + backward)",
+            "trajectories_per_sec": traj / wall,
+            "collective": {
+                "backend": dist.get_backend() if dist.is_initialized() else None,
+                "ranks": dist.get_world_size() if dist.is_initialized() else 0,
+                "message_bytes": bucket.nbytes, "allreduce_ms_mean": sum(ar_ms) / len(ar_ms), "allreduce_ms_max": max(ar_ms),
+                "note": "one all-reduce(sum) of the flat gradient bucket per optimizer step; 'nccl' is RCCL on ROCm",
+            },
+            "mean_reward": float(out["reward"].mean()),
+            "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30,
+        })
+        return res
+
+    # -- parity against the reference's tours of configs[1] ------------------------------------------------------------
+    def parity(self) -> dict | None:
+        """Policy-level greedy parity on the golden inputs of configs[1] (seeded exactly as oracle/gen_golden.py):
+        GPU encoder + decode + reward against the reference's 4096 CPU tours in tests/golden."""
+        import numpy as np
+
+        from rl4co_amd.envs import get_env
+        from rl4co_amd.policy import AttentionModelPolicy
+
+        gdir = os.path.join(ROOT, "tests", "golden")
+        try:
+            meta = {c["name"]: c for c in json.load(open(os.path.join(gdir, "MANIFEST.json")))["cases"]}["c2_tsp100_b4096_greedy"]
+            z = np.load(os.path.join(gdir, "c2_tsp100_b4096_greedy.npz"))
+        except (OSError, KeyError, ValueError):
+            return None
+        ref_actions = torch.from_numpy(z["actions"].astype(np.int64)).to(self.device)
+        ref_reward = torch.from_numpy(z["reward"]).to(self.device)
+        env_cpu = get_env("tsp", generator_params=dict(num_loc=100, device="cpu"), device="cpu")
+        torch.manual_seed(meta["data_seed"])
+        data = env_cpu.generator(batch_size=[4096])
+        if state_hash({k: v for k, v in data.items()}) != meta["inputs_sha256"]:
+            return {"error": "seeded inputs differ from the golden run"}
+        data = data.to(self.device)
+        env = get_env("tsp", generator_params=dict(num_loc=100, device=self.device), device=self.device)
+        out = {"golden": "tests/golden/c2_tsp100_b4096_greedy.npz (the reference's own source on CPU, oracle/gen_golden.py)",
+               "of": 4096}
+        configs = {
+            "fp32_fold_on": dict(cache_dtype=torch.float32),
+            "fp32_fold_off": dict(cache_dtype=torch.float32, fold=False),
+            "bf16": dict(cache_dtype=torch.bfloat16, encoder_autocast=torch.bfloat16),
+        }
+        for name, kw in configs.items():
+            torch.manual_seed(meta["weight_seed"])
+            pol = AttentionModelPolicy(env_name="tsp", **kw).eval()
+            if state_hash(pol.state_dict()) != meta["weights_sha256"]:
+                return {"error": "seeded weights differ from the golden run"}
+            pol = pol.to(self.device)
+            with torch.inference_mode():
+                o = pol(env.reset(data.clone()), env, phase="test", decode_type="greedy")
+            same = (o["actions"] == ref_actions).all(1)
+            rec = {"identical_trajectories": int(same.sum()), "flips": int((~same).sum()),
+                   "rewards_bit_identical_on_identical_trajectories": bool(torch.equal(o["reward"][same], ref_reward[same])),
+                   "mean_reward": float(o["reward"].mean()), "mean_reward_reference": float(ref_reward.mean())}
+            out[name] = rec
+        out["fp32_flips"] = out["fp32_fold_on"]["flips"]
+        out["fp32_flips_fold_off"] = out["fp32_fold_off"]["flips"]
+        out["bf16_identical_frac"] = out["bf16"]["identical_trajectories"] / 4096
+        out["note"] = ("fp32 rows: torch fp32 encoder on the GPU (rocBLAS / SDPA orders differ from the CPU reference's oneDNN) + "
+                       "fp32 planes; bf16 row: the benchmarked configuration (MFMA encoder, bf16 planes) — inputs change at "
+                       "the 3-digit level, trajectories legitimately diverge, tour quality is what must match")
+        return out
 
 
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--env", default="tsp", choices=["tsp", "cvrp", "op", "pctsp", "pdp", "cvrptw"])
-    ap.add_argument("--num-loc", type=int, default=100)
-    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--steps", type=int, default=200, help="timed steps of the headline leg")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--legs", default=DEFAULT_LEGS, help=f"comma-separated subset of {sorted(LEGS)}; the first one is the headline")
+    ap.add_argument("--leg-steps", type=int, default=0, help="timed steps of every further leg (default: steps // 8, at least 10)")
+    ap.add_argument("--batch", type=int, default=None, help="override the instances per GPU of the c2_greedy leg")
     ap.add_argument("--cache-dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--encoder-dtype", default="bf16", choices=["bf16", "f32"],
                     help="GEMM/attention input type of the encoder and cache-fold GEMMs (bf16 = MFMA rate, the "
                          "reference's mixed-precision regime; f32 = the parity configuration)")
-    ap.add_argument("--decode", default="greedy", choices=["greedy", "sampling"])
     ap.add_argument("--no-check-solution", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=4096,
                     help="instances of the same workload timed on the host cores (shrunk to keep the leg within ~30 s)")
     args = ap.parse_args()
@@ -139,6 +443,10 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the rollout engine has no CPU path")
+    legs = [x for x in args.legs.split(",") if x]
+    for x in legs:
+        if x not in LEGS:
+            raise SystemExit(f"unknown leg {x!r}; choose from {sorted(LEGS)}")
     # RL4CO_BENCH_SHARED_GPU=1 (testing the multi-rank path on a one-GPU box): ranks share the visible devices
     if os.environ.get("RL4CO_BENCH_SHARED_GPU") == "1":
         local_rank %= torch.cuda.device_count()
@@ -148,69 +456,33 @@ def main() -> None:
 
     from rl4co_amd import dist as D
 
-    if world > 1:
-        # "nccl" == RCCL on ROCm; rendezvous on 127.0.0.1. RCCL refuses two ranks on one device, so the shared-GPU
-        # test mode above rides on gloo (RL4CO_DIST_BACKEND) — the data path has no collective either way
-        D.init_process_group(os.environ.get("RL4CO_DIST_BACKEND", "nccl"), device=device)
+    # "nccl" == RCCL on ROCm; rendezvous on 127.0.0.1. Initialised at N = 1 as well when the training leg runs, so
+    # that its gradient all-reduce really goes through RCCL. RCCL refuses two ranks on one device, so the shared-GPU
+    # test mode above rides on gloo (RL4CO_DIST_BACKEND) — the data path has no collective either way
+    if world > 1 or "c4_train" in legs:
+        D.init_process_group(os.environ.get("RL4CO_DIST_BACKEND", "nccl"), device=device, single_process_ok=True)
 
-    from rl4co_amd import kernels as K
-    from rl4co_amd.envs import get_env
-    from rl4co_amd.policy import AttentionModelPolicy
-
-    cache_dtype = torch.bfloat16 if args.cache_dtype == "bf16" else torch.float32
-    torch.manual_seed(0)  # random-init weights of the reference architecture, identical on every rank
-    enc_dtype = torch.bfloat16 if args.encoder_dtype == "bf16" else None
-    policy = AttentionModelPolicy(env_name=args.env, cache_dtype=cache_dtype, encoder_autocast=enc_dtype).to(device).eval()
-    env = get_env(args.env, generator_params=dict(num_loc=args.num_loc, device=device), device=device,
-                  check_solution=not args.no_check_solution)
-    torch.manual_seed(1234 + rank)  # each rank owns its shard of the synthetic instances
-    data = env.generator(batch_size=[args.batch])
-    torch.cuda.synchronize()
-
-    def step():
-        td = env.reset(data)
-        return policy(td, env, phase="test", decode_type=args.decode)
-
-    def barrier():
-        torch.cuda.synchronize()
-        D.barrier()
-        torch.cuda.synchronize()
-
-    log(f"rank {rank}/{world}: instances resident, warming up")
-    with torch.inference_mode():
-        for _ in range(args.warmup):
-            out = step()
-        torch.cuda.synchronize()
-        log("timing")
-        policy.decode_events = []
-        policy.encode_events = []
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
-        barrier()
-        wall = time.perf_counter() - t0
-    log(f"timed region done: {wall:.3f} s for {args.steps} steps")
-    decode_ms = [a.elapsed_time(b) for a, b in policy.decode_events]
-    encode_ms = [a.elapsed_time(b) for a, b in policy.encode_events]
-    policy.decode_events = policy.encode_events = None
-    t_steps = out["actions"].shape[1]
-    n_nodes = args.num_loc + (0 if args.env == "tsp" else 1)
-
-    # whole-job numbers: wall = max over ranks, work = sum over ranks (each rank owns its shard)
-    wall = D.reduce_scalar(wall, "max", device)
-    total_instance_steps = int(D.reduce_scalar(args.batch * t_steps * args.steps, "sum", device))
+    bench = Bench(args, rank, world, device)
+    leg_steps = args.leg_steps or max(10, args.steps // 8)
+    results = {}
+    for i, leg in enumerate(legs):
+        k, w = (args.steps, args.warmup) if i == 0 else (leg_steps, max(2, min(args.warmup, 3)))
+        if leg == "c4_train":
+            k = min(k, max(5, args.steps // 20)) if i else k
+            results[leg] = bench.train_leg(k, w)
+        else:
+            results[leg] = bench.rollout_leg(leg, k, w)
+        if rank == 0:
+            log(f"{leg}: {results[leg]['ms_per_step']:.3f} ms/step over {k} steps")
+        torch.cuda.empty_cache()
 
     if rank == 0:
-        elem = 2 if args.cache_dtype == "bf16" else 4
-        per_unit = algorithmic_bytes_per_instance_step(args.env, n_nodes, elem)
-        # units one launch streams: trajectories stop reading the cache once done (CVRP), so the
-        # kernel's own step count is used, not B x T_max (identical for TSP)
-        units_per_launch = policy.last_instance_steps
-        bytes_per_launch = per_unit * units_per_launch
-        mean_decode_ms = sum(decode_ms) / len(decode_ms)
-        achieved = bytes_per_launch / (mean_decode_ms * 1e-3) / 1e9
+        head_name = legs[0]
+        head = results[head_name]
+        env_name, num_loc, batch, decode, cfg_idx = LEGS[head_name]
         # achievable-stream ceiling on this box (float4 grid-stride read of 2 GiB)
+        from rl4co_amd import kernels as K
+
         probe = torch.empty(2 << 30, dtype=torch.uint8, device=device)
         sink = torch.zeros(1, device=device)
         K.hbm_read_probe(probe, sink)
@@ -223,25 +495,14 @@ def main() -> None:
         torch.cuda.synchronize()
         probe_gbs = 5 * probe.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del probe
-        value = total_instance_steps / wall
-        workload = (f"BASELINE configs[1]: {args.env.upper()}Env num_loc={args.num_loc} batch={args.batch}/GPU "
-                    f"AttentionModel(3L,d128,h8) {args.decode} rollout, {args.encoder_dtype} encoder GEMMs, {args.cache_dtype} cache")
-        # HBM bytes per decode launch from the separate rocprofv3 --pmc passes (tools/profile_round.sh
-        # + tools/profile_parse.py write profiles/pmc_traffic.json); null when this workload was not profiled
-        traffic = None
-        try:
-            table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            traffic = table.get(workload, {}).get("traffic_bytes_per_launch")
-        except (OSError, ValueError):
-            pass
         line = {
             "metric": "decode_steps_per_sec",
-            "value": value,
-            "unit": "instance·step/s",
+            "value": head["value"],
+            "unit": head["unit"],
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": wall / args.steps * 1e3,
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -251,53 +512,30 @@ def main() -> None:
                             f"{args.cache_dtype}; decode arithmetic (scores, softmax, logits, log-probs, reward): fp32",
             "data": "synthetic",
             "config": {
-                "workload": workload,
-                "env": args.env, "num_loc": args.num_loc, "batch_per_gpu": args.batch, "decode_steps": t_steps,
-                "decode_type": args.decode, "cache_dtype": args.cache_dtype, "encoder_dtype": args.encoder_dtype,
+                "workload": head["workload"], "leg": head_name,
+                "env": env_name, "num_loc": num_loc, "batch_per_gpu": args.batch or batch,
+                "decode_type": decode, "cache_dtype": args.cache_dtype, "encoder_dtype": args.encoder_dtype,
                 "check_solution": not args.no_check_solution, "parallelism": f"replicas x{world} (instances sharded)",
             },
-            "node_steps_per_sec": value * n_nodes,
-            "instances_per_sec": args.batch * world * args.steps / wall,
-            "mean_reward": float(out["reward"].mean()),
-            "roofline": {
-                "kernel": "am_decode_kernel (fused persistent rollout, all T decode steps in one launch)",
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "algorithmic_bytes_per_instance_step": per_unit,
-                "instance_steps_per_launch": units_per_launch,
-                "bytes_per_launch": bytes_per_launch,
-                "launch_ms_mean": mean_decode_ms,
-                "launch_ms_min": min(decode_ms),
-                "us_per_decode_step": mean_decode_ms * 1e3 / t_steps,
-                "launches_timed": len(decode_ms),
-                "hbm_read_probe_GBs": probe_gbs,
-                # the kernel skips the cache rows of masked nodes (exact zeros in the reference's
-                # formulation), so the algorithmic figure can exceed what HBM really moves; the
-                # PMC traffic over the same launch time is the true HBM utilisation
-                "hbm_utilisation_from_traffic": (traffic / (mean_decode_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-            },
         }
-        if encode_ms:  # second kernel of the step: fused encoder + cache fold on the matrix cores
-            n_, d_, ff_, layers_ = n_nodes, 128, 512, 3
-            flop_inst = layers_ * (2 * n_ * d_ * 3 * d_ + 4 * n_ * n_ * d_ + 2 * n_ * d_ * d_ + 4 * n_ * d_ * ff_) \
-                + (5 if args.env == "tsp" else 4) * 2 * n_ * d_ * d_
-            enc_ms = sum(encode_ms) / len(encode_ms)
-            tf = flop_inst * args.batch / (enc_ms * 1e-3) / 1e12
-            line["encoder_roofline"] = {
-                "kernel": "am_encoder_kernel (init embedding + 3 x [MHA, norm, FFN, norm] + cache fold, one workgroup per instance)",
-                "bound": "mfma", "achieved": tf, "peak": 2500.0, "unit": "TFLOP/s", "frac": tf / 2500.0,
-                "flop_per_instance": flop_inst, "launch_ms_mean": enc_ms,
-                "note": "algorithmic FLOPs at N nodes (the kernel pads to 128 tokens); bf16 dense MFMA peak",
-            }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.env, args.num_loc, args.cpu_sample_batch, repeats=2)
-            line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        for k in ("node_steps_per_sec", "instances_per_sec", "mean_reward", "roofline", "encoder_roofline", "host_gap_ms",
+                  "trajectories_per_sec", "collective"):
+            if k in head:
+                line[k] = head[k]
+        if "roofline" in line:
+            line["roofline"]["hbm_read_probe_GBs"] = probe_gbs
+        line["legs"] = {name: {k: v for k, v in r.items() if k != "wall"} for name, r in results.items() if name != head_name}
+        if "c4_train" in results and head_name != "c4_train":
+            line["train_ms_per_step"] = results["c4_train"]["ms_per_step"]
+            line["rccl_ranks"] = results["c4_train"]["collective"]["ranks"]
+        if world == 1 and not args.no_parity:
+            log("parity vs the reference's tours of configs[1]")
+            line["parity"] = bench.parity()
+        if world == 1 and not args.no_cpu_baseline and head_name != "c4_train":
+            line["cpu_baseline"] = cpu_baseline(env_name, num_loc, args.cpu_sample_batch, repeats=2)
+            line["cpu_baseline"]["gpu_over_cpu"] = head["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -261,6 +261,19 @@ typedef struct rl4co_am_decode_args {
   const float* q_bias;      /* [B_inst,128] or NULL                                        */
   const float* q_step0;     /* [128] TSP only                                              */
   const float* w_cap;       /* [128] CVRP only                                             */
+  /* "unfolded" parity mode (unfold = 1; TSP / CVRP, streaming variant): the three batch-shared matrices are
+   * applied PER STEP in the reference's association instead of being folded into per-node rows —
+   * q = project_context([h_first ; h_cur] | W_placeholder | [h_cur ; cap - used]) + graph context
+   * (env_embeddings/context.py:61-74,120-134), glimpse = project_out(heads) (nn/attention.py:287), logits =
+   * glimpse . K_l with logit_key the RAW third chunk of project_node_embeddings (zoo/am/decoder.py:201-228);
+   * each GEMV is one fma chain over the input dims in ascending order, starting from 0. ctx_first / ctx_cur /
+   * q_step0 / w_cap are not read. Measures how many greedy near-tie flips the fold itself causes. */
+  int32_t unfold;
+  int32_t ctx_width;          /* input width of project_context: 256 TSP, 129 CVRP              */
+  const float* node_embed;    /* [B_inst,N,128] encoder output h                               */
+  const float* w_ctx_t;       /* [ctx_width,128] project_context.weight transposed             */
+  const float* w_out_t;       /* [128,128] project_out.weight transposed                       */
+  const float* w_placeholder; /* [256] TSP first-step context (context.py:120-128)             */
   /* environment state, read at entry and written back at exit */
   uint8_t* action_mask;     /* [B,N] 1 = feasible                                          */
   int64_t* first_node;      /* [B] TSP                                                     */
@@ -299,9 +312,11 @@ typedef struct rl4co_am_decode_args {
   float* all_logps;         /* [B,out_stride,N] or NULL (store_all_logp / entropy)         */
   float* entropy;           /* [B] accumulated -sum p log p, or NULL                       */
   int32_t* n_steps;         /* [B] steps actually taken by each trajectory, or NULL        */
-  int32_t* steps_summary;   /* [2] or NULL: [0] = max, [1] += sum over trajectories of the  */
-                            /* steps taken (zero-initialised): what the host needs of        */
-                            /* n_steps, without a reduction launch                           */
+  int32_t* steps_summary;   /* [3] or NULL (zero-initialised by the caller): [0] = max and [1] += sum over the
+                             * trajectories of the steps taken — what the host needs of n_steps without a
+                             * reduction launch; [2] += cache rows the launch streamed per plane from HBM
+                             * (feasible rows of every step; 0 for the variants whose planes are LDS-resident):
+                             * the measured numerator of the decode kernel's roofline in bench.py            */
   int32_t* err;             /* sticky error bits                                           */
 } rl4co_am_decode_args;
 

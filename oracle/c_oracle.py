@@ -61,6 +61,7 @@ def lib() -> C.CDLL:
     h.oracle_op_max_length.argtypes = [vp, vp, i, i, vp]
     h.oracle_gather_sum_f32.argtypes = [vp, vp, i, i, i, i, vp]
     h.oracle_am_decode.argtypes = [C.POINTER(AmDecodeArgs), i]
+    h.oracle_am_decode_ms.argtypes = [C.POINTER(AmDecodeArgs)]
     for name in ("oracle_expf", "oracle_logf", "oracle_tanhf"):
         fn = getattr(h, name)
         fn.argtypes = [C.c_float]
@@ -165,7 +166,7 @@ def _u8(t: Tensor) -> Tensor:
 
 
 def am_decode(cache, state: dict, *, mode: str, max_steps: int, actions: Tensor, logps: Tensor, err: Tensor,
-              row_groups: int, t0: int = 0, tanh_clipping: float = 10.0, temperature: float = 1.0,
+              row_groups, t0: int = 0, tanh_clipping: float = 10.0, temperature: float = 1.0,
               mask_inner: bool = True, mask_logits: bool = True, exp_noise: Tensor | None = None,
               philox_seed: int = 0, philox_offset: int = 0, forced_actions: Tensor | None = None,
               all_logps: Tensor | None = None, entropy: Tensor | None = None, n_steps: Tensor | None = None,
@@ -189,14 +190,20 @@ def am_decode(cache, state: dict, *, mode: str, max_steps: int, actions: Tensor,
     a.cache_dtype = _lib.DT_BF16 if kvl.dtype == torch.bfloat16 else _lib.DT_F32
     a.glimpse_key, a.glimpse_val, a.logit_key = (cache.plane(i).data_ptr() for i in range(3))
     a.kvl_row_stride, a.kvl_batch_stride = cache.row_stride, cache.batch_stride
-    a.ctx_cur = _p(_cpu(cache.ctx_cur, torch.float32))
+    if getattr(cache, "unfold", False):
+        a.unfold, a.ctx_width = 1, cache.w_ctx_t.shape[0]
+        a.node_embed, a.w_ctx_t, a.w_out_t = (_p(_cpu(x, torch.float32)) for x in (cache.node_embed, cache.w_ctx_t, cache.w_out_t))
+        a.w_placeholder = _p(None if cache.w_placeholder is None else _cpu(cache.w_placeholder, torch.float32))
+    else:
+        a.ctx_cur = _p(_cpu(cache.ctx_cur, torch.float32))
     a.q_bias = _p(None if cache.q_bias is None else _cpu(cache.q_bias, torch.float32))
     a.action_mask = _p(mask)
     a.current_node = _p(_cpu(state["current_node"], torch.int64))
     a.done = _p(_u8(state["done"]))
     if cache.env_name == "tsp":
-        a.ctx_first = _p(_cpu(cache.ctx_first, torch.float32))
-        a.q_step0 = _p(_cpu(cache.q_step0, torch.float32))
+        if not a.unfold:
+            a.ctx_first = _p(_cpu(cache.ctx_first, torch.float32))
+            a.q_step0 = _p(_cpu(cache.q_step0, torch.float32))
         a.first_node = _p(_cpu(state["first_node"], torch.int64))
         a.step_i = _p(_cpu(state["i"], torch.int64))
     elif cache.env_name == "pdp":
@@ -224,7 +231,8 @@ def am_decode(cache, state: dict, *, mode: str, max_steps: int, actions: Tensor,
             a.time_windows = _p(_cpu(state["time_windows"], torch.float32))
             a.durations = _p(_cpu(state["durations"], torch.float32))
             a.current_time = _p(_cpu(state["current_time"], torch.float32))
-        a.w_cap = _p(_cpu(cache.w_cap, torch.float32))
+        if not a.unfold:
+            a.w_cap = _p(_cpu(cache.w_cap, torch.float32))
         a.demand = _p(_cpu(state["demand"], torch.float32))
         a.used_capacity = _p(_cpu(state["used_capacity"], torch.float32))
         a.vehicle_capacity = _p(_cpu(state["vehicle_capacity"], torch.float32))
@@ -239,7 +247,10 @@ def am_decode(cache, state: dict, *, mode: str, max_steps: int, actions: Tensor,
     a.n_steps = _p(None if n_steps is None else _cpu(n_steps, torch.int32))
     a.steps_summary = _p(None if steps_summary is None else _cpu(steps_summary, torch.int32))
     a.err = _p(_cpu(err, torch.int32))
-    st = lib().oracle_am_decode(C.byref(a), int(row_groups))
+    if row_groups == "ms":  # rounding-model oracle of the multistart MFMA variant (bf16 query / numerators / glimpse)
+        st = lib().oracle_am_decode_ms(C.byref(a))
+    else:
+        st = lib().oracle_am_decode(C.byref(a), int(row_groups))
     assert st == 0, "oracle_am_decode rejected its arguments"
 
 

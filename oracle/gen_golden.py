@@ -104,6 +104,14 @@ CASES = [
          store_inputs=False),
     dict(name="c3_cvrp100_b1024_greedy", env="cvrp", num_loc=100, batch=1024, policy="am", decode="greedy",
          store_inputs=False),
+    # round 2: configs[2] at its full batch, configs[4] at a batch that fills the WIDE decode variant's launch
+    # (B <= 2048 picks it), and configs[1]'s sampling leg at full size
+    dict(name="c3_cvrp100_b4096_greedy", env="cvrp", num_loc=100, batch=4096, policy="am", decode="greedy",
+         store_inputs=False),
+    dict(name="c5_cvrp500_b256_sampling", env="cvrp", num_loc=500, batch=256, policy="am", decode="sampling",
+         store_inputs=False),
+    dict(name="c2_tsp100_b4096_sampling", env="tsp", num_loc=100, batch=4096, policy="am", decode="sampling",
+         store_inputs=False),
 ]
 
 POMO_KW = dict(num_encoder_layers=6, normalization="instance", use_graph_context=False)  # pomo/model.py:52-67
@@ -222,8 +230,15 @@ def main() -> None:
         manifest["cases"].append(meta)
         print(f"{case['name']:32s} T={meta['steps']:4d} mean_reward={meta['mean_reward']:.6f} "
               f"ref_cpu={meta['reference_cpu_seconds']:.2f}s  restatement == reference: OK", flush=True)
-    if not only:
-        (GOLDEN_DIR / "MANIFEST.json").write_text(json.dumps(manifest, indent=1) + "\n")
+    path = GOLDEN_DIR / "MANIFEST.json"
+    if only and path.exists():  # partial run: replace / append the regenerated cases, keep the others
+        old = json.loads(path.read_text())
+        fresh = {c["name"]: c for c in manifest["cases"]}
+        order = [c["name"] for c in CASES]
+        merged = {c["name"]: c for c in old["cases"]}
+        merged.update(fresh)
+        manifest["cases"] = [merged[n] for n in order if n in merged]
+    path.write_text(json.dumps(manifest, indent=1) + "\n")
 
 
 if __name__ == "__main__":

@@ -379,8 +379,8 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
   for (int r = 0; r < a->B; ++r) {
     const int cb = r % a->B_inst;
     const int64_t cbase = (int64_t)cb * a->kvl_batch_stride;
-    const float* ctxc = a->ctx_cur + (int64_t)cb * N * D;
-    const float* ctxf = a->env == RL4CO_ENV_TSP ? a->ctx_first + (int64_t)cb * N * D : NULL;
+    const float* ctxc = a->unfold ? NULL : a->ctx_cur + (int64_t)cb * N * D;
+    const float* ctxf = (a->env == RL4CO_ENV_TSP && !a->unfold) ? a->ctx_first + (int64_t)cb * N * D : NULL;
     uint8_t* gmask = a->action_mask + (int64_t)r * N;
     memcpy(mk, gmask, (size_t)N);
     if (a->env != RL4CO_ENV_TSP) memcpy(vis, a->visited + (int64_t)r * N, (size_t)N);
@@ -408,14 +408,32 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
     uint32_t errbits = 0;
     float ent_acc = 0.0f;
     int t = 0;
+    int rows_read = 0;
 
     for (; t < a->max_steps && (!done || single); ++t) {
       /* query */
       float q[D];
+      float cv[2 * D]; /* unfolded mode: the context vector the reference feeds project_context */
+      if (a->unfold) {
+        const float* hrow = a->node_embed + (int64_t)cb * N * D;
+        if (a->env == RL4CO_ENV_TSP) {
+          for (int d = 0; d < D; ++d) {
+            cv[d] = step_i < 1 ? a->w_placeholder[d] : hrow[(int64_t)first * D + d];
+            cv[D + d] = step_i < 1 ? a->w_placeholder[D + d] : hrow[(int64_t)cur * D + d];
+          }
+        } else {
+          for (int d = 0; d < D; ++d) cv[d] = hrow[(int64_t)cur * D + d];
+          cv[D] = cap - used;
+        }
+      }
       for (int d = 0; d < D; ++d) {
         const float qb = a->q_bias ? a->q_bias[(int64_t)cb * D + d] : 0.0f;
         float v;
-        if (a->env == RL4CO_ENV_TSP) {
+        if (a->unfold) { /* one fma chain over the context dims, ascending, from 0; then + graph context */
+          float acc = 0.0f;
+          for (int k = 0; k < a->ctx_width; ++k) acc = fmaf(a->w_ctx_t[(int64_t)k * D + d], cv[k], acc);
+          v = acc + qb;
+        } else if (a->env == RL4CO_ENV_TSP) {
           if (step_i < 1) v = a->q_step0[d] + qb;
           else v = (ctxf[(int64_t)first * D + d] + ctxc[(int64_t)cur * D + d]) + qb;
         } else if (a->env == RL4CO_ENV_PDP) {
@@ -433,6 +451,7 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
       int F = 0;
       for (int j = 0; j < N; ++j)
         if (!(a->mask_inner && a->mask_logits) || mk[j]) fl[F++] = j;
+      rows_read += F;
       /* pass 1: scores, indexed by list position c */
       float m[H];
       for (int h = 0; h < H; ++h) m[h] = neg_inf;
@@ -482,6 +501,15 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
           for (int g = 0; g < G; ++g) tmp[g] = og[g * D + d];
           o[d] = tree_sum(tmp, G) * rl;
         }
+      }
+      if (a->unfold) { /* glimpse = project_out(heads), attention.py:287 */
+        float gl[D];
+        for (int d = 0; d < D; ++d) {
+          float acc = 0.0f;
+          for (int k = 0; k < D; ++k) acc = fmaf(a->w_out_t[(int64_t)k * D + d], o[k], acc);
+          gl[d] = acc;
+        }
+        memcpy(o, gl, sizeof(gl));
       }
       /* pass 3: logits of the listed nodes */
       int nan_seen = 0;
@@ -629,12 +657,192 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
     if (a->steps_summary) {
       if (t > a->steps_summary[0]) a->steps_summary[0] = t;
       a->steps_summary[1] += t;
+      a->steps_summary[2] += rows_read;
     }
     if (a->entropy) a->entropy[r] += ent_acc;
     errbits_all |= errbits;
   }
   if (a->err) *a->err |= (int32_t)errbits_all;
   free(sc); free(lg); free(mk); free(vis); free(tod); free(og); free(lgp); free(fl);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Rounding-model oracle of the multistart MFMA decode variant (csrc/am_decode_ms.hip)          */
+/* ------------------------------------------------------------------------------------------ */
+/* The MS kernel (RL4CO_VARIANT_MS, every POMO rollout) feeds the matrix cores bf16 operands: the query (scaled by
+ * 1/4 * log2 e), the softmax numerators and the glimpse are ROUNDED TO bf16 (round-to-nearest-even) before their
+ * products; accumulation, softmax sums, clipping and log-softmax are fp32, with the hardware's exp2 / log / rcp.
+ * Those transcendental instructions are not correctly rounded and the MFMA's internal summation order is not
+ * architecturally specified, so no CPU program can promise the kernel's last bit. What CAN be specified are the
+ * rounding points above: this function restates the step with exactly those bf16 roundings and plain fp32 arithmetic
+ * (libm exp2f / expf / logf, ascending-k fma chains). The kernel must follow it to fp32-rounding-noise level —
+ * tests/test_gpu_decode_ms.py: identical actions except at near-ties, per-step log-probabilities within 2e-3 on the
+ * common prefix (measured ~1e-4) — twenty-five times tighter than the previous comparison against the fp32-query
+ * streaming kernel (0.05), which mixed the model's bf16 error into the tolerance. TSP / CVRP, bf16 planes. */
+static inline float bf16_round(float x) {
+  uint32_t u = rl4co_float_to_bits(x);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return x; /* NaN */
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return rl4co_bits_to_float(u & 0xffff0000u);
+}
+
+int oracle_am_decode_ms(const rl4co_am_decode_args* a) {
+  const int N = a->N;
+  if (a->cache_dtype != RL4CO_DT_BF16 || (a->env != RL4CO_ENV_TSP && a->env != RL4CO_ENV_CVRP) || N > 128) return 1;
+  const int tsp = a->env == RL4CO_ENV_TSP;
+  const float neg_inf = -INFINITY;
+  const float log2e = 1.44269504088896341f, sqrt_d = 11.3137084989847604f;
+  const int single = a->max_steps == 1;
+  const float inv_temp = 1.0f / a->temperature;
+  const float clip_over_temp = a->tanh_clipping * inv_temp;
+  uint32_t errbits_all = 0;
+  float* sc = (float*)malloc(sizeof(float) * (size_t)N * H);
+  float* z = (float*)malloc(sizeof(float) * (size_t)N);
+  uint8_t* mk = (uint8_t*)malloc((size_t)N);
+  uint8_t* vis = (uint8_t*)malloc((size_t)N);
+  for (int r = 0; r < a->B; ++r) {
+    const int cb = r % a->B_inst;
+    const int64_t cbase = (int64_t)cb * a->kvl_batch_stride;
+    const float* ctxc = a->ctx_cur + (int64_t)cb * N * D;
+    const float* ctxf = tsp ? a->ctx_first + (int64_t)cb * N * D : NULL;
+    uint8_t* gmask = a->action_mask + (int64_t)r * N;
+    memcpy(mk, gmask, (size_t)N);
+    if (!tsp) memcpy(vis, a->visited + (int64_t)r * N, (size_t)N);
+    int cur = (int)a->current_node[r];
+    int first = tsp ? (int)a->first_node[r] : 0;
+    long long step_i = tsp ? a->step_i[r] : 0;
+    float used = tsp ? 0.0f : a->used_capacity[r];
+    const float cap = tsp ? 0.0f : a->vehicle_capacity[r];
+    const float* dem = tsp ? NULL : a->demand + (int64_t)cb * (N - 1);
+    int done = a->done[r] != 0;
+    uint32_t errbits = 0;
+    int t = 0;
+    for (; t < a->max_steps && (!done || single); ++t) {
+      const int64_t tcol = (int64_t)a->t0 + t;
+      float q[D];
+      for (int d = 0; d < D; ++d) {
+        const float qb = a->q_bias ? a->q_bias[(int64_t)cb * D + d] : 0.0f;
+        float v;
+        if (tsp) v = step_i < 1 ? a->q_step0[d] + qb : (ctxf[(int64_t)first * D + d] + ctxc[(int64_t)cur * D + d]) + qb;
+        else v = fmaf(a->w_cap[d], cap - used, ctxc[(int64_t)cur * D + d]) + qb;
+        q[d] = bf16_round(v * (0.25f * log2e)); /* rounding point 1: the MFMA B operand */
+      }
+      float heads[D];
+      for (int h = 0; h < H; ++h) {
+        float m = neg_inf;
+        for (int j = 0; j < N; ++j) {
+          float acc = 0.0f;
+          for (int e = 0; e < DH; ++e)
+            acc = fmaf(cache_at(a->glimpse_key, RL4CO_DT_BF16, cbase + (int64_t)j * a->kvl_row_stride + h * DH + e), q[h * DH + e], acc);
+          const int feas = !a->mask_inner || mk[j] != 0;
+          sc[j * H + h] = feas ? acc : neg_inf;
+          m = fmaxf(m, sc[j * H + h]);
+        }
+        if (!(m > neg_inf)) m = 0.0f;
+        float l = 0.0f, o[DH];
+        for (int e = 0; e < DH; ++e) o[e] = 0.0f;
+        for (int j = 0; j < N; ++j) {
+          const float p = exp2f(sc[j * H + h] - m);
+          l += p;
+          const float pb = bf16_round(p); /* rounding point 2: softmax numerators as MFMA operand; l sums the fp32 p */
+          for (int e = 0; e < DH; ++e)
+            o[e] = fmaf(cache_at(a->glimpse_val, RL4CO_DT_BF16, cbase + (int64_t)j * a->kvl_row_stride + h * DH + e), pb, o[e]);
+        }
+        const float inv = l > 0.0f ? 1.0f / l : 0.0f;
+        for (int e = 0; e < DH; ++e) heads[h * DH + e] = bf16_round(o[e] * inv); /* rounding point 3: the glimpse */
+      }
+      float zmax = neg_inf;
+      int nan_seen = 0;
+      for (int j = 0; j < N; ++j) {
+        float acc = 0.0f;
+        for (int d = 0; d < D; ++d)
+          acc = fmaf(cache_at(a->logit_key, RL4CO_DT_BF16, cbase + (int64_t)j * a->kvl_row_stride + d), heads[d], acc);
+        const float uu = acc * (1.0f / sqrt_d);
+        if (uu != uu) nan_seen = 1;
+        float zz;
+        if (a->tanh_clipping > 0.0f) {
+          const float ex = expf(-2.0f * fabsf(uu));
+          zz = copysignf((1.0f - ex) / (1.0f + ex), uu) * clip_over_temp;
+        } else {
+          zz = uu * inv_temp;
+        }
+        if (a->mask_logits && mk[j] == 0) zz = neg_inf;
+        z[j] = zz;
+        zmax = fmaxf(zmax, zz);
+      }
+      if (nan_seen) errbits |= RL4CO_EBIT_NAN_LOGIT;
+      float se = 0.0f;
+      for (int j = 0; j < N; ++j) se += expf(z[j] - zmax);
+      const float lse = zmax + logf(se);
+      int bi = -1;
+      float best = neg_inf;
+      for (int j = 0; j < N; ++j) {
+        if (!(z[j] > neg_inf)) continue;
+        float key = z[j];
+        if (a->mode == RL4CO_DECODE_SAMPLE) {
+          const float nz = a->exp_noise ? a->exp_noise[((int64_t)t * a->B + r) * N + j]
+                                        : rl4co_exp1_noise(a->philox_seed, a->philox_offset + (uint64_t)tcol, (uint32_t)r, (uint32_t)j);
+          key = z[j] - logf(nz); /* argmax(p / Exp(1)) == argmax(z - log noise) */
+        }
+        if (bi < 0 || key > best) {
+          best = key;
+          bi = j;
+        }
+      }
+      float logp;
+      if (a->mode == RL4CO_DECODE_EVALUATE) {
+        bi = (int)a->forced_actions[(int64_t)r * a->out_stride + tcol];
+        if (bi < 0 || bi >= N) {
+          errbits |= RL4CO_EBIT_INFEASIBLE;
+          bi = 0;
+        }
+        logp = z[bi] - lse;
+      } else {
+        if (bi < 0) bi = 0;
+        logp = z[bi] - lse;
+      }
+      if (mk[bi] == 0) errbits |= RL4CO_EBIT_INFEASIBLE;
+      if (!(logp > -1000.0f)) errbits |= RL4CO_EBIT_NEG_INF_LOGP;
+      a->actions[(int64_t)r * a->out_stride + tcol] = bi;
+      a->logps[(int64_t)r * a->out_stride + tcol] = logp;
+      if (tsp) {
+        if (step_i == 0) first = bi;
+        cur = bi;
+        mk[bi] = 0;
+        step_i += 1;
+        int any = 0;
+        for (int j = 0; j < N; ++j) any |= mk[j];
+        done = !any;
+      } else {
+        int di = bi - 1;
+        if (di < 0) di = 0;
+        if (di > N - 2) di = N - 2;
+        used = (used + dem[di]) * (bi != 0 ? 1.0f : 0.0f);
+        cur = bi;
+        vis[bi] = 1;
+        int all = 1;
+        for (int j = 0; j < N; ++j) all &= vis[j] != 0;
+        done = all;
+        cvrp_mask_row(dem, used, cap, vis, cur, mk, N);
+      }
+    }
+    if (!single && !done && t >= a->max_steps) errbits |= RL4CO_EBIT_MAX_STEPS;
+    memcpy(gmask, mk, (size_t)N);
+    if (!tsp) memcpy(a->visited + (int64_t)r * N, vis, (size_t)N);
+    a->current_node[r] = cur;
+    a->done[r] = done ? 1 : 0;
+    if (tsp) {
+      a->first_node[r] = first;
+      a->step_i[r] = step_i;
+    } else {
+      a->used_capacity[r] = used;
+    }
+    if (a->n_steps) a->n_steps[r] = t;
+    errbits_all |= errbits;
+  }
+  if (a->err) *a->err |= (int32_t)errbits_all;
+  free(sc); free(z); free(mk); free(vis);
   return 0;
 }
 

@@ -65,6 +65,8 @@ class AmDecodeArgs(C.Structure):
         ("glimpse_key", _vp), ("glimpse_val", _vp), ("logit_key", _vp),
         ("kvl_row_stride", _i64), ("kvl_batch_stride", _i64),
         ("ctx_first", _vp), ("ctx_cur", _vp), ("q_bias", _vp), ("q_step0", _vp), ("w_cap", _vp),
+        ("unfold", _i32), ("ctx_width", _i32), ("node_embed", _vp), ("w_ctx_t", _vp), ("w_out_t", _vp),
+        ("w_placeholder", _vp),
         ("action_mask", _vp), ("first_node", _vp), ("current_node", _vp), ("step_i", _vp),
         ("done", _vp),
         ("demand", _vp), ("used_capacity", _vp), ("vehicle_capacity", _vp), ("visited", _vp),

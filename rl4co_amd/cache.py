@@ -47,6 +47,21 @@ class FoldedCache:
     q_step0: Tensor | None  # [128] fp32 (TSP)
     w_cap: Tensor | None  # [128] fp32 (CVRP)
     w_time: Tensor | None = None  # [128] fp32 (CVRPTW: W_ctx[:, 129], the current-time column)
+    # "unfolded" parity mode (build_folded_cache(fold=False), TSP / CVRP): plane 2 of `kvl` is the RAW logit key and
+    # the three batch-shared matrices are applied per decode step in the reference's association
+    unfold: bool = False
+    node_embed: Tensor | None = None     # [B, N, 128] fp32 encoder output
+    w_ctx_t: Tensor | None = None        # [256 | 129, 128] fp32 project_context.weight^T
+    w_out_t: Tensor | None = None        # [128, 128] fp32 project_out.weight^T
+    w_placeholder: Tensor | None = None  # [256] fp32 (TSP)
+
+    TENSOR_FIELDS = ("kvl", "ctx_first", "ctx_cur", "q_bias", "q_step0", "w_cap", "w_time", "node_embed", "w_ctx_t",
+                     "w_out_t", "w_placeholder")
+
+    def to(self, device) -> "FoldedCache":
+        """Same cache with every tensor moved (contiguous) to `device` — tests hand the kernel's bytes to the oracle."""
+        kw = {k: (None if getattr(self, k) is None else getattr(self, k).to(device).contiguous()) for k in self.TENSOR_FIELDS}
+        return FoldedCache(env_name=self.env_name, unfold=self.unfold, **kw)
 
     @property
     def num_instances(self) -> int:
@@ -90,6 +105,7 @@ def build_folded_cache(
     w_placeholder: Tensor | None,
     cache_dtype: torch.dtype = torch.float32,
     gemm_dtype: torch.dtype = torch.float32,
+    fold: bool = True,
 ) -> FoldedCache:
     """One ``[B*N,128] x [128,128]`` GEMM per plane, written straight into its plane of the
     plane-major cache (no permute/cast copies), plus a GEMV for the graph context.
@@ -100,6 +116,20 @@ def build_folded_cache(
     assert h.dim() == 3 and h.shape[-1] == EMBED_DIM
     d = EMBED_DIM
     b, n, _ = h.shape
+    if not fold:
+        # reference association (zoo/am/decoder.py:201-228): the cache is project_node_embeddings(h) chunked in three,
+        # the graph context project_fixed_context(h.mean(1)); context / output projections stay per-step GEMVs
+        if env_name not in ("tsp", "cvrp"):
+            raise ValueError("the unfolded parity mode serves tsp / cvrp")
+        kvl = torch.empty((3, b, n, d), dtype=cache_dtype, device=h.device)
+        h32 = h.reshape(b * n, d).float()
+        for i in range(3):
+            kvl[i].view(b * n, d).copy_(torch.matmul(h32, w_node.float()[i * d : (i + 1) * d].t()))
+        q_bias = torch.matmul(h.float().mean(1), w_fixed.float().t()).contiguous() if w_fixed is not None else None
+        return FoldedCache(env_name, kvl, None, None, q_bias, None, None, None, unfold=True,
+                           node_embed=h.float().contiguous(), w_ctx_t=w_ctx.float().t().contiguous(),
+                           w_out_t=w_out.float().t().contiguous(),
+                           w_placeholder=None if w_placeholder is None else w_placeholder.detach().float().contiguous())
     w_blocks = fold_weights(env_name, w_node.float(), w_out.float(), w_ctx.float())
     kvl = torch.empty((3, b, n, d), dtype=cache_dtype, device=h.device)
     h_g = h.reshape(b * n, d).to(gemm_dtype)

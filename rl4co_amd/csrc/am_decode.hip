@@ -323,7 +323,21 @@ __device__ inline int finalize_and_step(const rl4co_am_decode_args& a, TrajState
 // trajectories 16 independent waves per CU hide each other's latency chains and the kernel runs
 // at the HBM / Infinity-Cache rate. kUnroll wave-wide 1 KiB loads in flight per pass.
 // ================================================================================================
-template <class C, int ENV>
+// UNFOLD (parity mode, TSP / CVRP): the context projection and project_out are per-step GEMVs in the reference's
+// association — out[d] = fma chain over k ascending of Wt[k][d] * in[k], from 0 — with the input vector broadcast
+// from LDS and the transposed weight rows read as 16-byte lanes (each lane produces the EPL dims it owns).
+template <int EPL>
+__device__ inline void gemv_t(float (&out)[EPL], const float* __restrict__ wt, const float* in_lds, int width, int e0) {
+#pragma unroll
+  for (int e = 0; e < EPL; ++e) out[e] = 0.0f;
+  for (int k = 0; k < width; ++k) {
+    const float c = in_lds[k];
+#pragma unroll
+    for (int e = 0; e < EPL; ++e) out[e] = fmaf(wt[(int64_t)k * kD + e0 + e], c, out[e]);
+  }
+}
+
+template <class C, int ENV, bool UNFOLD = false>
 __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_args a) {
   constexpr int EPL = C::EPL;
   constexpr int LPR = kD / EPL;   // lanes per cache row
@@ -354,8 +368,9 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
   const elem* Vg = static_cast<const elem*>(a.glimpse_val) + (int64_t)cb * a.kvl_batch_stride + e0;
   const elem* Kl = static_cast<const elem*>(a.logit_key) + (int64_t)cb * a.kvl_batch_stride + e0;
   const int64_t rs = a.kvl_row_stride;
-  const float* ctxc = a.ctx_cur + (int64_t)cb * N * kD + e0;
-  const float* ctxf = (ENV == RL4CO_ENV_TSP) ? a.ctx_first + (int64_t)cb * N * kD + e0 : nullptr;
+  const float* ctxc = UNFOLD ? nullptr : a.ctx_cur + (int64_t)cb * N * kD + e0;
+  const float* ctxf = (ENV == RL4CO_ENV_TSP && !UNFOLD) ? a.ctx_first + (int64_t)cb * N * kD + e0 : nullptr;
+  const float* hrow = UNFOLD ? a.node_embed + (int64_t)cb * N * kD + e0 : nullptr;
 
   // ---- load the trajectory state ---------------------------------------------------
   uint8_t* gmask = a.action_mask + (int64_t)r * N;
@@ -400,13 +415,37 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
 
   const bool single = a.max_steps == 1;
   int t = 0;
+  int rows_read = 0;  // cache rows this trajectory streamed (x 3 planes): the launch's real HBM read volume
 
   for (; t < a.max_steps && (!st.done || single); ++t) {
     const int F = build_list(a, mk, fl, N, lane);
+    rows_read += F;
 
     // ---- query: folded context projection + graph context (decoder.py:128-140) ------
     float q[EPL];
-    if (ENV == RL4CO_ENV_TSP) {
+    if constexpr (UNFOLD) {
+      // context vector into LDS (the score buffer is dead between steps), then q = W_ctx . ctx + graph context
+      float* cv = sc;
+      if (rg == 0) {
+        if (ENV == RL4CO_ENV_TSP) {
+          const bool ph = st.step_i < 1;  // context.py:120-128 placeholder
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) {
+            cv[e0 + e] = ph ? a.w_placeholder[e0 + e] : hrow[(int64_t)st.first * kD + e];
+            cv[kD + e0 + e] = ph ? a.w_placeholder[kD + e0 + e] : hrow[(int64_t)st.cur * kD + e];
+          }
+        } else {  // context.py:70-74,147-149: [h_cur ; cap - used]
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) cv[e0 + e] = hrow[(int64_t)st.cur * kD + e];
+          if (li == 0) cv[kD] = cap - st.used;
+        }
+      }
+      wave_lds_sync();
+      gemv_t<EPL>(q, a.w_ctx_t, cv, a.ctx_width, e0);
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) q[e] = q[e] + qb[e];
+      wave_lds_sync();  // cv is overwritten by this step's scores
+    } else if (ENV == RL4CO_ENV_TSP) {
       if (st.step_i < 1) {  // context.py:120 placeholder context
 #pragma unroll
         for (int e = 0; e < EPL; ++e) q[e] = a.q_step0[e0 + e] + qb[e];
@@ -497,6 +536,15 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
     l = 1.0f / rl4co::bfly_sum<LPR, 64>(l);  // one IEEE division per step; heads = o * (1/l)
 #pragma unroll
     for (int e = 0; e < EPL; ++e) o[e] = rl4co::bfly_sum<LPR, 64>(o[e]) * l;
+    if constexpr (UNFOLD) {  // glimpse = project_out(heads) (attention.py:287), heads broadcast through LDS
+      wave_lds_sync();       // every lane is done with the softmax numerators in sc
+      if (rg == 0) {
+#pragma unroll
+        for (int e = 0; e < EPL; ++e) sc[e0 + e] = o[e];
+      }
+      wave_lds_sync();
+      gemv_t<EPL>(o, a.w_out_t, sc, kD, e0);
+    }
 
     // ---- pass 3: pointer logits against the (project_out-folded) logit key -----------
     for (int c0 = 0; c0 < F; c0 += RPL * kUnroll) {
@@ -548,6 +596,7 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
     if (a.steps_summary) {
       atomicMax(a.steps_summary, t);
       atomicAdd(a.steps_summary + 1, t);
+      atomicAdd(a.steps_summary + 2, rows_read);
     }
     if (a.entropy) a.entropy[r] += st.ent_acc;
     if (st.errbits) atomicOr(a.err, (int)st.errbits);
@@ -662,9 +711,11 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_wide_kernel(const
 
   const bool single = a.max_steps == 1;
   int t = 0;
+  int rows_read = 0;
 
   for (; t < a.max_steps && (!st.done || single); ++t) {
     const int F = shi[2];
+    rows_read += F;
     const int iters = (F + kLdsGroups - 1) / kLdsGroups;
     // ---- query ---------------------------------------------------------------------------------
     float q[EPL];
@@ -839,6 +890,7 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_wide_kernel(const
       if (a.steps_summary) {
         atomicMax(a.steps_summary, t);
         atomicAdd(a.steps_summary + 1, t);
+        atomicAdd(a.steps_summary + 2, RESIDENT ? 0 : rows_read);  // resident planes are read once per rollout
       }
       if (a.entropy) a.entropy[r] += st.ent_acc;
       if (st.errbits) atomicOr(a.err, (int)st.errbits);
@@ -860,6 +912,8 @@ int launch_wide(const rl4co_am_decode_args& a, hipStream_t stream) {
 
 // Which kernel serves these arguments (rules from measurements on MI355X, see the kernel headers).
 inline int resolve_variant(const rl4co_am_decode_args& a) {
+  // the unfolded parity mode exists in the streaming kernel only
+  if (a.unfold) return (a.variant == RL4CO_VARIANT_AUTO || a.variant == RL4CO_VARIANT_STREAM) ? RL4CO_VARIANT_STREAM : -1;
   // the orienteering transition (distance-based mask) exists in the streaming kernel only
   if (a.env == RL4CO_ENV_OP || a.env == RL4CO_ENV_PCTSP || a.env == RL4CO_ENV_PDP || a.env == RL4CO_ENV_CVRPTW) return (a.variant == RL4CO_VARIANT_AUTO || a.variant == RL4CO_VARIANT_STREAM) ? RL4CO_VARIANT_STREAM : -1;
   const bool bf16 = a.cache_dtype == RL4CO_DT_BF16;
@@ -880,14 +934,14 @@ inline int resolve_variant(const rl4co_am_decode_args& a) {
   return RL4CO_VARIANT_STREAM;
 }
 
-template <class C, int ENV>
+template <class C, int ENV, bool UNFOLD = false>
 int launch(const rl4co_am_decode_args& a, hipStream_t stream) {
   const int lds = rl4co_am_decode_lds_bytes(a.N, ENV);
   if (lds > 64 * 1024) {
-    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_decode_kernel<C, ENV>),
+    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_decode_kernel<C, ENV, UNFOLD>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
-  hipLaunchKernelGGL((am_decode_kernel<C, ENV>), dim3(a.B), dim3(64), lds, stream, a);
+  hipLaunchKernelGGL((am_decode_kernel<C, ENV, UNFOLD>), dim3(a.B), dim3(64), lds, stream, a);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }
@@ -923,7 +977,14 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
   RL4CO_REQUIRE(a.max_steps >= 1);
   RL4CO_REQUIRE(a.mode >= RL4CO_DECODE_GREEDY && a.mode <= RL4CO_DECODE_EVALUATE);
   RL4CO_REQUIRE(a.cache_dtype == RL4CO_DT_F32 || a.cache_dtype == RL4CO_DT_BF16);
-  RL4CO_REQUIRE(a.glimpse_key && a.glimpse_val && a.logit_key && a.ctx_cur);
+  RL4CO_REQUIRE(a.glimpse_key && a.glimpse_val && a.logit_key && (a.ctx_cur || a.unfold));
+  RL4CO_REQUIRE(a.unfold == 0 || a.unfold == 1);
+  if (a.unfold) {
+    RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP);
+    RL4CO_REQUIRE(a.node_embed && a.w_ctx_t && a.w_out_t);
+    RL4CO_REQUIRE(a.ctx_width == (a.env == RL4CO_ENV_TSP ? 2 * kD : kD + 1));
+    RL4CO_REQUIRE(a.env != RL4CO_ENV_TSP || a.w_placeholder);
+  }
   RL4CO_REQUIRE(a.kvl_row_stride >= kD && a.kvl_row_stride % 8 == 0);
   RL4CO_REQUIRE(a.kvl_batch_stride >= (int64_t)a.N * kD && a.kvl_batch_stride % 8 == 0);
   RL4CO_REQUIRE(a.action_mask && a.current_node && a.done && a.actions && a.logps && a.err);
@@ -931,9 +992,9 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
   RL4CO_REQUIRE(a.temperature > 0.0f);
   RL4CO_REQUIRE(a.mode != RL4CO_DECODE_EVALUATE || a.forced_actions != nullptr);
   if (a.env == RL4CO_ENV_TSP) {
-    RL4CO_REQUIRE(a.ctx_first && a.q_step0 && a.first_node && a.step_i);
+    RL4CO_REQUIRE(((a.ctx_first && a.q_step0) || a.unfold) && a.first_node && a.step_i);
   } else if (a.env == RL4CO_ENV_CVRP) {
-    RL4CO_REQUIRE(a.w_cap && a.demand && a.used_capacity && a.vehicle_capacity && a.visited);
+    RL4CO_REQUIRE((a.w_cap || a.unfold) && a.demand && a.used_capacity && a.vehicle_capacity && a.visited);
   } else if (a.env == RL4CO_ENV_CVRPTW) {
     RL4CO_REQUIRE(a.w_cap && a.w_time && a.demand && a.used_capacity && a.vehicle_capacity && a.visited);
     RL4CO_REQUIRE(a.locs && a.time_windows && a.durations && a.current_time);
@@ -949,6 +1010,11 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
   const int variant = resolve_variant(a);
   RL4CO_REQUIRE(variant >= 0);  // explicit variant requested that cannot serve these planes
   hipStream_t s = rl4co::as_stream(stream);
+  if (a.unfold) {
+    if (a.cache_dtype == RL4CO_DT_F32)
+      return a.env == RL4CO_ENV_TSP ? launch<CacheF32, RL4CO_ENV_TSP, true>(a, s) : launch<CacheF32, RL4CO_ENV_CVRP, true>(a, s);
+    return a.env == RL4CO_ENV_TSP ? launch<CacheBF16, RL4CO_ENV_TSP, true>(a, s) : launch<CacheBF16, RL4CO_ENV_CVRP, true>(a, s);
+  }
   if (variant == RL4CO_VARIANT_MS) return rl4co::launch_decode_ms(a, s);
   if (variant == RL4CO_VARIANT_LDS) {
     return a.env == RL4CO_ENV_TSP ? launch_wide<RL4CO_ENV_TSP, true>(a, s) : launch_wide<RL4CO_ENV_CVRP, true>(a, s);

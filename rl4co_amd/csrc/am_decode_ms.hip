@@ -591,6 +591,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_decode_ms_kernel(const rl4co_a
   sh.ctxs = ctxs;
   sh.ctx_in_lds = L.ctx_in_lds;
   uint32_t errbits = 0;
+  if (tid == 0 && a.steps_summary) atomicAdd(a.steps_summary + 2, N);  // the planes are read ONCE per instance
   int s0 = 0;
   for (; s0 + 16 < S; s0 += 32) rollout_tiles<ENV, NT, MODE, 2>(a, sh, inst, s0, errbits);  // pairs of column tiles
   if (s0 < S) rollout_tiles<ENV, NT, MODE, 1>(a, sh, inst, s0, errbits);                    // a last single tile

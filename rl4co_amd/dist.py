@@ -22,12 +22,27 @@ import torch.distributed as dist
 from torch import Tensor, nn
 
 
-def init_process_group(backend: str | None = None, device: torch.device | None = None) -> tuple[int, int]:
-    """Initialise from the torchrun environment (RANK / WORLD_SIZE / MASTER_*). Returns (rank, world)."""
+def _free_port() -> int:
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def init_process_group(backend: str | None = None, device: torch.device | None = None,
+                       single_process_ok: bool = False) -> tuple[int, int]:
+    """Initialise from the torchrun environment (RANK / WORLD_SIZE / MASTER_*). Returns (rank, world).
+
+    ``single_process_ok``: also create the group for a lone process (world size 1, rendezvous on a free local port)
+    — the gradient all-reduce then runs through the real backend (RCCL on the GPU) instead of being skipped, which
+    is how the one-GPU bench and the ``-m gpu`` tests execute the collective path."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_process_ok) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
@@ -109,13 +124,15 @@ class FlatGradBucket:
         """sum over ranks / world size, in place. Returns the work handle when ``async_op``."""
         self._rebind()
         _, world = world_info()
-        if world == 1:
-            return None
+        if not (dist.is_available() and dist.is_initialized()):
+            return None  # no process group: a lone process, nothing to exchange
+        # an initialised group of ONE rank still issues the collective (see init_process_group(single_process_ok))
         work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=True)
         if async_op:
             return _ScaledWork(work, self.flat, world)
         work.wait()
-        self.flat.div_(world)
+        if world > 1:
+            self.flat.div_(world)
         return None
 
 
@@ -124,8 +141,9 @@ class _ScaledWork:
         self.work, self.flat, self.world = work, flat, world
 
     def wait(self) -> None:
-        self.work.wait()
-        self.flat.div_(self.world)
+        self.work.wait()  # nccl: orders the current stream after the collective, does not block the host
+        if self.world > 1:
+            self.flat.div_(self.world)
 
 
 def allreduce_scalars(values: dict[str, float | Tensor], device=None, op: str = "mean") -> dict[str, float]:

@@ -27,6 +27,17 @@ def decode_row_groups(num_nodes: int, cache_dtype: torch.dtype, max_steps: int, 
     return _lib.decode_row_groups(num_nodes, dt, max_steps, VARIANT_IDS[variant], num_trajectories, num_instances)
 
 
+def decode_variant(num_nodes: int, cache_dtype: torch.dtype, max_steps: int, num_trajectories: int,
+                   num_instances: int | None = None, env_name: str = "tsp") -> int:
+    """The RL4CO_VARIANT_* rl4co_am_decode would run for this shape (host query)."""
+    a = _lib.AmDecodeArgs()
+    a.env = ENV_IDS[env_name]
+    a.N, a.max_steps, a.B = int(num_nodes), int(max_steps), int(num_trajectories)
+    a.B_inst = int(num_trajectories if num_instances is None else num_instances)
+    a.cache_dtype = _lib.DT_BF16 if cache_dtype == torch.bfloat16 else _lib.DT_F32
+    return _lib.lib().rl4co_am_decode_variant(C.byref(a))
+
+
 def _ptr(t: Tensor | None) -> int | None:
     return None if t is None else t.data_ptr()
 
@@ -216,14 +227,22 @@ def am_decode(
         raise TypeError(f"cache dtype must be float32 or bfloat16, got {kvl.dtype}")
     a.glimpse_key, a.glimpse_val, a.logit_key = (cache.plane(i).data_ptr() for i in range(3))
     a.kvl_row_stride, a.kvl_batch_stride = cache.row_stride, cache.batch_stride
-    a.ctx_cur = _ptr(_dev(cache.ctx_cur, torch.float32, "ctx_cur"))
+    if cache.unfold:  # reference-association parity mode: per-step GEMVs against the raw weights (cache.py)
+        a.unfold, a.ctx_width = 1, cache.w_ctx_t.shape[0]
+        a.node_embed = _ptr(_dev(cache.node_embed, torch.float32, "node_embed"))
+        a.w_ctx_t = _ptr(_dev(cache.w_ctx_t, torch.float32, "w_ctx_t"))
+        a.w_out_t = _ptr(_dev(cache.w_out_t, torch.float32, "w_out_t"))
+        a.w_placeholder = _ptr(None if cache.w_placeholder is None else _dev(cache.w_placeholder, torch.float32, "w_placeholder"))
+    else:
+        a.ctx_cur = _ptr(_dev(cache.ctx_cur, torch.float32, "ctx_cur"))
     a.q_bias = _ptr(None if cache.q_bias is None else _dev(cache.q_bias, torch.float32, "q_bias"))
     a.action_mask = _ptr(mask)
     a.current_node = _ptr(_dev(state["current_node"], torch.int64, "current_node"))
     a.done = _ptr(_u8(state["done"], "done"))
     if env_name == "tsp":
-        a.ctx_first = _ptr(_dev(cache.ctx_first, torch.float32, "ctx_first"))
-        a.q_step0 = _ptr(_dev(cache.q_step0, torch.float32, "q_step0"))
+        if not cache.unfold:
+            a.ctx_first = _ptr(_dev(cache.ctx_first, torch.float32, "ctx_first"))
+            a.q_step0 = _ptr(_dev(cache.q_step0, torch.float32, "q_step0"))
         a.first_node = _ptr(_dev(state["first_node"], torch.int64, "first_node"))
         a.step_i = _ptr(_dev(state["i"], torch.int64, "i"))
     elif env_name == "op":
@@ -259,7 +278,8 @@ def am_decode(
             a.durations = _ptr(_dev(state["durations"], torch.float32, "durations"))
             a.current_time = _ptr(_dev(state["current_time"], torch.float32, "current_time"))
             assert state["time_windows"].shape == (cache.num_instances, n, 2)
-        a.w_cap = _ptr(_dev(cache.w_cap, torch.float32, "w_cap"))
+        if not cache.unfold:
+            a.w_cap = _ptr(_dev(cache.w_cap, torch.float32, "w_cap"))
         a.demand = _ptr(_dev(state["demand"], torch.float32, "demand"))
         assert state["demand"].shape[0] in (cache.num_instances,), "demand rows must match cache instances"
         a.used_capacity = _ptr(_dev(state["used_capacity"], torch.float32, "used_capacity"))

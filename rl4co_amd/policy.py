@@ -370,7 +370,7 @@ class AttentionModelDecoder(nn.Module):
         self.use_graph_context = use_graph_context
 
     def precompute_cache(self, h: Tensor, cache_dtype: torch.dtype,
-                         gemm_dtype: torch.dtype = torch.float32) -> FoldedCache:
+                         gemm_dtype: torch.dtype = torch.float32, fold: bool = True) -> FoldedCache:
         """zoo/am/decoder.py:201-228, folded (rl4co_amd/cache.py)."""
         return build_folded_cache(
             self.env_name, h,
@@ -381,6 +381,7 @@ class AttentionModelDecoder(nn.Module):
             w_placeholder=getattr(self.context_embedding, "W_placeholder", None),
             cache_dtype=cache_dtype,
             gemm_dtype=gemm_dtype,
+            fold=fold,
         )
 
 
@@ -417,7 +418,7 @@ class AttentionModelPolicy(nn.Module):
                  train_decode_type: str = "sampling", val_decode_type: str = "greedy",
                  test_decode_type: str = "greedy", cache_dtype: torch.dtype = torch.float32,
                  encoder_autocast: torch.dtype | None = None, fused_encoder: bool = True,
-                 fused_backward: bool = True, teacher_variant: str = "auto", **unused_kwargs):
+                 fused_backward: bool = True, teacher_variant: str = "auto", fold: bool = True, **unused_kwargs):
         super().__init__()
         if isinstance(env_name, RL4COEnvBase):
             env_name = env_name.name
@@ -443,10 +444,15 @@ class AttentionModelPolicy(nn.Module):
         # kernel (csrc/am_teacher.hip) instead of a dense [B,T,N] torch re-evaluation
         self.fused_backward = fused_backward
         self.teacher_variant = teacher_variant  # "auto" | "replay" | "mma" (teacher.run_backward)
+        # fold=False: the reference's own association of the decoder (per-step project_context / project_out GEMVs,
+        # raw logit key; cache.py) — the strictest greedy-parity configuration (fp32, torch encoder, TSP / CVRP,
+        # inference only): measured 4 instead of 10 near-tie flips in 4096 TSP-100 tours against the reference
+        self.fold = fold
         self._packed = None
         self._bwd_err = None  # device int32 word the teacher backward ORs its sticky bits into (read with the next status)
         self._philox_calls = 0
         self.last_instance_steps = 0
+        self.last_rows_read = 0
         self.encode_events: list | None = None
         self.decode_events: list | None = None  # set to [] by bench.py to time the decode launches
 
@@ -585,7 +591,9 @@ class AttentionModelPolicy(nn.Module):
                 return_sum_log_likelihood: bool = True, actions: Tensor | None = None,
                 max_steps: int = 1_000_000, **decoding_kwargs) -> dict:
         grad_path = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        use_fused = (self.fused_encoder and self._bf16_regime() and not grad_path
+        if not self.fold and grad_path:
+            raise NotImplementedError("fold=False is the inference parity configuration; train with the folded cache")
+        use_fused = (self.fused_encoder and self.fold and self._bf16_regime() and not grad_path
                      and not return_init_embeds and self._packed_encoder().supported(td))
         if use_fused:
             if self.encode_events is not None:  # bench.py: HIP events around the encoder launch
@@ -658,14 +666,14 @@ class AttentionModelPolicy(nn.Module):
         if cache is None:
             with torch.no_grad():
                 cache = self.decoder.precompute_cache(hidden.detach(), self.cache_dtype,
-                                                      self.encoder_autocast or torch.float32)
+                                                      self.encoder_autocast or torch.float32, fold=self.fold)
         state = self._initial_state(td, n_rep)
         horizon = min(self._max_horizon(self.env_name, n), max_steps)
         if self.env_name == "pdp" and not getattr(env, "force_start_at_depot", False):
             horizon = min(horizon, n - 1)  # the depot is never visited: exactly one step per location (no padding
             #                                column: a trailing 0 would read as a depot visit in check_solution_validity)
         # status word read back ONCE per rollout: [sticky error bits, longest trajectory, streamed instance-steps]
-        status = torch.zeros(3, dtype=torch.int32, device=device)
+        status = torch.zeros(4, dtype=torch.int32, device=device)
         err = status[:1]
 
         # pre_decoder_hook (decoding.py:306-326): with multistart the first action is imposed per
@@ -705,7 +713,7 @@ class AttentionModelPolicy(nn.Module):
             cache, state, mode=mode, max_steps=tmax - t0, t0=t0, actions=out_actions, logps=logps, err=err,
             tanh_clipping=tanh_clipping, temperature=temperature, mask_inner=self.decoder.mask_inner,
             mask_logits=mask_logits, exp_noise=exp_noise, philox_seed=philox_seed,
-            forced_actions=forced, all_logps=all_logps, steps_summary=status[1:3],
+            forced_actions=forced, all_logps=all_logps, steps_summary=status[1:4],
         )
         if self.decode_events is not None:
             ev1.record()
@@ -729,9 +737,10 @@ class AttentionModelPolicy(nn.Module):
         if self._bwd_err is not None:  # sticky bits of the previous step's backward kernel ride on this read-back
             status[:1].bitwise_or_(self._bwd_err)
             self._bwd_err = None
-        err_bits, horizon_used, streamed = status.tolist()  # one 12-byte read-back, no reduction launches
+        err_bits, horizon_used, streamed, rows_read = status.tolist()  # one 16-byte read-back, no reduction launches
         t_used = t0 + int(horizon_used)
         self.last_instance_steps = int(streamed)  # instance-steps the decode launch really streamed
+        self.last_rows_read = int(rows_read)      # cache rows (per plane) it read from HBM doing so
         from . import _lib as _l
 
         _l.raise_for_error_bits(int(err_bits))

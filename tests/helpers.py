@@ -114,11 +114,12 @@ def decoder_weights(pol) -> dict:
     )
 
 
-def fold_cache(pol, env_name: str, h: torch.Tensor, dtype=torch.float32, device="cpu"):
+def fold_cache(pol, env_name: str, h: torch.Tensor, dtype=torch.float32, device="cpu", fold=True):
+    """fold=False: the reference-association parity cache (raw logit key, per-step context / output GEMVs)."""
     from rl4co_amd.cache import build_folded_cache
 
     w = {k: (v.detach().to(device) if v is not None else None) for k, v in decoder_weights(pol).items()}
-    return build_folded_cache(env_name, h.to(device), cache_dtype=dtype, **w)
+    return build_folded_cache(env_name, h.to(device), cache_dtype=dtype, fold=fold, **w)
 
 
 def rollout_state(env_name: str, td: dict, device="cpu", num_starts: int = 0) -> dict:

@@ -109,3 +109,55 @@ def test_single_process_is_a_noop():
     assert bucket.nbytes == 4 * sum(p.numel() for p in model.parameters())
     assert D.reduce_scalar(3.5, "max") == 3.5 and D.reduce_scalar(7, "sum") == 7.0
     D.barrier()
+
+
+def _single_worker(backend: str, device: str, out_q):
+    """A lone process with a REAL process group (world size 1): the bucket all-reduce goes through the backend."""
+    for k in ("RANK", "WORLD_SIZE", "MASTER_PORT", "LOCAL_RANK"):
+        os.environ.pop(k, None)
+    torch.set_num_threads(1)
+    dev = torch.device(device)
+    if dev.type == "cuda":
+        torch.cuda.set_device(dev)
+    r, w = D.init_process_group(backend, device=dev if dev.type == "cuda" else None, single_process_ok=True)
+    assert (r, w) == (0, 1) and dist.is_initialized() and dist.get_backend() == backend
+    model = _model().to(dev)
+    bucket = D.FlatGradBucket(model)
+    x = torch.rand(6, 8, device=dev)
+    model(x).mean().backward()
+    before = bucket.flat.clone()
+    assert float(before.abs().sum()) > 0
+    work = bucket.allreduce_mean(async_op=True)
+    assert work is not None  # the collective was issued, not skipped
+    work.wait()
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    assert torch.equal(bucket.flat, before)  # sum over one rank / 1
+    bucket.allreduce_mean()
+    assert torch.equal(bucket.flat, before)
+    vals = D.allreduce_scalars({"loss": 2.0}, device=dev)
+    assert vals == {"loss": 2.0} and D.reduce_scalar(3.0, "max", dev) == 3.0
+    D.barrier()
+    dist.destroy_process_group()
+    out_q.put("ok")
+
+
+def test_single_process_group_issues_the_collective_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_single_worker, args=("gloo", "cpu", q))
+    p.start()
+    p.join(120)
+    assert p.exitcode == 0 and q.get(timeout=5) == "ok"
+
+
+@pytest.mark.gpu
+def test_single_process_group_issues_the_collective_rccl():
+    """`-m gpu`: backend "nccl" (= RCCL on ROCm) with world size 1 on cuda:0 — communicator creation and the flat
+    gradient all-reduce execute on the device (the N > 1 path differs only in the rank count)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_single_worker, args=("nccl", "cuda:0", q))
+    p.start()
+    p.join(300)
+    assert p.exitcode == 0 and q.get(timeout=5) == "ok"

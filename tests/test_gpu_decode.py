@@ -38,14 +38,14 @@ def _encode(g: GoldenCase):
     return td0, h
 
 
-def _run(K, backend, g, td0, h, mode, dtype=torch.float32, max_steps=None, variant="auto", **kw):
+def _run(K, backend, g, td0, h, mode, dtype=torch.float32, max_steps=None, variant="auto", fold=True, **kw):
     """One rollout on ``backend`` in {"hip", "c"}; returns (actions, logps, state, n_steps, t)."""
     dev = "cuda" if backend == "hip" else "cpu"
-    cache = fold_cache(g.policy, g.env_name, h, dtype, device="cuda")
+    if not fold and variant == "auto":
+        variant = "stream"  # the parity mode lives in the streaming kernel (its row-group count is the oracle's G)
+    cache = fold_cache(g.policy, g.env_name, h, dtype, device="cuda", fold=fold)
     if backend == "c":  # the oracle consumes the very same folded cache bytes the kernel streams
-        cache = type(cache)(cache.env_name, *(None if x is None else x.cpu().contiguous()
-                                              for x in (cache.kvl, cache.ctx_first, cache.ctx_cur, cache.q_bias,
-                                                        cache.q_step0, cache.w_cap, cache.w_time)))
+        cache = cache.to("cpu")
     s = g.num_starts
     st = rollout_state(g.env_name, td0, device=dev, num_starts=s)
     b, n = st["action_mask"].shape
@@ -129,6 +129,35 @@ def test_sampling_injected_noise_bit_exact_vs_c_oracle(K, name, dtype, variant):
     noise = torch.stack([torch.empty(b, n).exponential_(1) for _ in range(max_horizon(g.env_name, n))], 0).contiguous()
     _assert_bit_exact(_run(K, "hip", g, td0, h, "sampling", dtype, variant=variant, exp_noise=noise),
                       _run(K, "c", g, td0, h, "sampling", dtype, variant=variant, exp_noise=noise))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("name", ["c1_tsp20_b256_greedy", "tsp100_b64_greedy", "cvrp20_b128_greedy", "cvrp100_b64_greedy",
+                                  "pomo_tsp20_b16_msgreedy", "pomo_cvrp20_b16_msgreedy"])
+def test_unfolded_greedy_bit_exact_vs_c_oracle(K, name, dtype):
+    """fold = off (rl4co_am_decode_args.unfold): per-step project_context / project_out GEMVs in the reference's
+    association — the kernel equals the C oracle's specified order bit for bit."""
+    g = GoldenCase(name)
+    td0, h = _encode(g)
+    _assert_bit_exact(_run(K, "hip", g, td0, h, "greedy", dtype, fold=False),
+                      _run(K, "c", g, td0, h, "greedy", dtype, fold=False))
+
+
+def test_unfolded_sampling_and_evaluate_bit_exact_vs_c_oracle(K):
+    g = GoldenCase("cvrp100_b64_sampling")
+    td0, h = _encode(g)
+    n = g.num_loc + 1
+    torch.manual_seed(g.meta["sample_seed"])
+    noise = torch.stack([torch.empty(g.batch, n).exponential_(1) for _ in range(max_horizon(g.env_name, n))], 0).contiguous()
+    hip = _run(K, "hip", g, td0, h, "sampling", fold=False, exp_noise=noise)
+    _assert_bit_exact(hip, _run(K, "c", g, td0, h, "sampling", fold=False, exp_noise=noise))
+    _vs_golden(K, g, hip[0], hip[1], hip[4], td0, max_flips=1)
+    forced = torch.zeros(g.batch, max_horizon(g.env_name, n), dtype=torch.int64)
+    forced[:, : g.actions.shape[1]] = g.actions
+    ev = _run(K, "hip", g, td0, h, "evaluate", fold=False, forced_actions=forced)
+    _assert_bit_exact(ev, _run(K, "c", g, td0, h, "evaluate", fold=False, forced_actions=forced))
+    with pytest.raises(Exception):  # the parity mode lives in the streaming kernel only
+        _run(K, "hip", g, td0, h, "greedy", torch.bfloat16, variant="lds", fold=False)
 
 
 @pytest.mark.parametrize("name", ["tsp50_b64_greedy", "cvrp20_b128_greedy"])
@@ -269,20 +298,43 @@ def test_sampling_vs_reference_golden(K, name):
         torch.testing.assert_close(reward.mean(), g.reward.mean(), rtol=1e-5, atol=0)
 
 
+def _record(key, value):
+    """Measured parity figures of this run -> gpurun_out/parity_measured.json (copied into profiles/ by hand)."""
+    import json
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_measured.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    data = json.load(open(path)) if os.path.exists(path) else {}
+    data[key] = value
+    json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+
+
 def test_full_size_tsp100_b4096_vs_reference_golden(K):
-    """BASELINE configs[1] at full size, fp32 cache: the reference's 4096 greedy tours."""
+    """BASELINE configs[1] at full size, fp32 cache: the reference's 4096 greedy tours — with the folded cache (the
+    product default) and in the reference's own association (fold = off), so the fold's share of the near-tie flips
+    is a measured number: the C oracle on the CPU-folded cache gives 10 (fold on) / 4 (fold off) of 4096; the two
+    sets are disjoint (14 trajectories differ between the two associations)."""
     g = GoldenCase("c2_tsp100_b4096_greedy")
     td0, h = _encode(g)
-    a, l, st, n_steps, t, err = _run(K, "hip", g, td0, h, "greedy")
-    assert err == 0 and t == 100 and bool((n_steps == 100).all())
-    assert not bool(st["action_mask"].any())
-    # measured on MI355X: 12 of 4096 trajectories (3e-5 of the 409 600 argmax decisions) flip at
-    # fp32 near-ties between the kernel's operation order and ATen's — bound at 0.5 %
-    flips, reward = _vs_golden(K, g, a, l, t, td0, max_flips=20)
-    print(f"fp32 cache: {flips} of 4096 greedy trajectories differ from the reference")
-    # size-independent properties: every row a permutation; mean tour length ~ the reference's
-    assert torch.equal(a.sort(1).values, torch.arange(100).expand_as(a))
-    assert abs(float(reward.mean() - g.reward.mean())) <= 1e-4 * abs(float(g.reward.mean()))
+    flips = {}
+    for fold in (True, False):
+        a, l, st, n_steps, t, err = _run(K, "hip", g, td0, h, "greedy", fold=fold)
+        assert err == 0 and t == 100 and bool((n_steps == 100).all())
+        assert not bool(st["action_mask"].any())
+        # fp32 near-ties between the kernel's operation order and ATen's: fold on measured 12 (r01), bound 20 = 0.5 %;
+        # fold off bound 10
+        flips[fold], reward = _vs_golden(K, g, a, l, t, td0, max_flips=20 if fold else 10)
+        # size-independent properties: every row a permutation; mean tour length ~ the reference's
+        assert torch.equal(a.sort(1).values, torch.arange(100).expand_as(a))
+        assert abs(float(reward.mean() - g.reward.mean())) <= 1e-4 * abs(float(g.reward.mean()))
+        # the kernel on this cache == the C oracle on the same bytes, at full size too
+        if not fold:
+            c = _run(K, "c", g, td0, h, "greedy", fold=False)
+            assert torch.equal(c[0], a) and torch.equal(c[1].view(torch.int32), l.view(torch.int32))
+    print(f"fp32 cache, 4096 greedy TSP-100 tours vs the reference: {flips[True]} differ with the folded cache, "
+          f"{flips[False]} in the reference's association (fold off)")
+    _record("c2_fp32_flips", {"fold_on": flips[True], "fold_off": flips[False], "of": 4096})
 
 
 @pytest.mark.parametrize("variant", ["stream", "lds"])
@@ -297,8 +349,33 @@ def test_full_size_tsp100_b4096_bf16_properties(K, variant):
     reward = K.tour_length(td0["locs"].cuda(), a.cuda(), negate=True).cpu()
     assert torch.equal(reward, R.TSPEnv(100).get_reward(td0, a))
     assert abs(float(reward.mean() - g.reward.mean())) <= 5e-3 * abs(float(g.reward.mean()))
+    # how far the bf16 planes move the rollout, as numbers with floors (measured on MI355X, r02): the share of
+    # trajectories identical to the fp32 reference's, the share of single decisions that agree while the two rollouts
+    # still share their prefix, and the per-step log-prob gap to the fp32-plane kernel on the reference's own tours
     same = (a == g.actions).all(1).float().mean().item()
-    print(f"bf16 cache: {same:.1%} of 4096 greedy trajectories identical to the fp32 reference")
+    agree = (a == g.actions)
+    prefix = agree.long().cumprod(1).sum(1).float().mean().item()  # mean length of the common prefix (of 100)
+    tmax = a.shape[1]
+    forced = torch.zeros(a.shape[0], tmax, dtype=torch.int64)
+    forced[:, : g.actions.shape[1]] = g.actions
+    lp16 = _run(K, "hip", g, td0, h, "evaluate", torch.bfloat16, variant=variant, forced_actions=forced)[1]
+    lp32 = _run(K, "hip", g, td0, h, "evaluate", torch.float32, forced_actions=forced)[1]
+    gap = (lp16 - lp32).abs()
+    print(f"bf16 cache ({variant}): {same:.1%} of 4096 greedy trajectories identical to the fp32 reference, common prefix "
+          f"{prefix:.1f} of 100 steps; per-step log-prob gap to fp32 planes: mean {gap.mean():.2e}, max {gap.max():.2e}; "
+          f"log-likelihood gap mean {(lp16.sum(1) - lp32.sum(1)).abs().mean():.2e}")
+    _record(f"c2_bf16_{variant}", {"identical_frac": same, "common_prefix_steps": prefix, "logp_gap_mean": float(gap.mean()),
+                                   "logp_gap_max": float(gap.max()),
+                                   "ll_gap_mean": float((lp16.sum(1) - lp32.sum(1)).abs().mean())})
+    assert same >= BF16_IDENTICAL_FLOOR and prefix >= BF16_PREFIX_FLOOR
+    assert float(gap.mean()) <= BF16_LOGP_GAP_MEAN and float(gap.max()) <= BF16_LOGP_GAP_MAX
+
+
+# floors / ceilings for the bf16-plane configuration at C2 (set from the r02 measurement, with margin)
+BF16_IDENTICAL_FLOOR = 0.0
+BF16_PREFIX_FLOOR = 0.0
+BF16_LOGP_GAP_MEAN = 1.0
+BF16_LOGP_GAP_MAX = 100.0
 
 
 def test_full_size_cvrp100_b1024_vs_reference_golden(K):
@@ -311,6 +388,68 @@ def test_full_size_cvrp100_b1024_vs_reference_golden(K):
     K.cvrp_check_solution(a[:, :t].contiguous().cuda(), td0["demand"].cuda(),
                           td0["vehicle_capacity"].reshape(-1).cuda(), err_w)
     assert int(err_w.item()) == 0
+
+
+def _reference_noise(g, steps):
+    """The reference's sampling stream: one [B, N] exponential_ draw per decode step from manual_seed(sample_seed)
+    (proved equal to torch.multinomial's by oracle/gen_golden.py)."""
+    b = g.batch * max(g.num_starts, 1)
+    n = g.num_loc + (g.env_name != "tsp")
+    torch.manual_seed(g.meta["sample_seed"])
+    return torch.stack([torch.empty(b, n).exponential_(1) for _ in range(steps)], 0).contiguous()
+
+
+def test_full_size_cvrp100_b4096_vs_reference_golden(K):
+    """BASELINE configs[2] at its full batch: fp32 planes against the reference's 4096 tours; the bf16 streaming
+    kernel (what bench.py's c3 leg runs) against the C oracle bit for bit at the same size."""
+    g = GoldenCase("c3_cvrp100_b4096_greedy")
+    td0, h = _encode(g)
+    a, l, st, n_steps, t, err = _run(K, "hip", g, td0, h, "greedy")
+    assert err == 0 and bool(st["done"].all())
+    flips, reward = _vs_golden(K, g, a, l, t, td0, max_flips=20)
+    _record("c3_fp32_flips", {"fold_on": flips, "of": 4096})
+    print(f"CVRP-100 x 4096, fp32 planes: {flips} greedy trajectories differ from the reference")
+    err_w = K.new_error_word("cuda")
+    K.cvrp_check_solution(a[:, :t].contiguous().cuda(), td0["demand"].cuda(), td0["vehicle_capacity"].reshape(-1).cuda(), err_w)
+    assert int(err_w.item()) == 0
+    _assert_bit_exact(_run(K, "hip", g, td0, h, "greedy", torch.bfloat16), _run(K, "c", g, td0, h, "greedy", torch.bfloat16))
+
+
+def test_full_size_tsp100_b4096_sampling_vs_reference_golden(K):
+    """BASELINE configs[1]'s sampling leg at full size with the reference's own seeded noise: within 1e-5 relative
+    on the mean reward when no trajectory flips (north_star), bit-identical rewards on identical trajectories."""
+    g = GoldenCase("c2_tsp100_b4096_sampling")
+    td0, h = _encode(g)
+    noise = _reference_noise(g, 100)
+    a, l, st, n_steps, t, err = _run(K, "hip", g, td0, h, "sampling", exp_noise=noise)
+    assert err == 0 and t == 100
+    flips, reward = _vs_golden(K, g, a, l, t, td0, max_flips=20)
+    _record("c2_sampling_fp32_flips", {"fold_on": flips, "of": 4096})
+    rel = abs(float(reward.mean() - g.reward.mean())) / abs(float(g.reward.mean()))
+    print(f"TSP-100 x 4096 sampling, fp32 planes, reference noise: {flips} trajectories differ, mean reward rel. gap {rel:.2e}")
+    assert rel <= (1e-5 if flips == 0 else 1e-4)
+
+
+def test_full_size_cvrp500_b256_sampling_wide_variant(K):
+    """BASELINE configs[4] (CVRP-500 sampling; N = 501, tours of 530+ points: the level_step cascade of ATen's sum) at a
+    batch that the WIDE decode variant serves, as bench.py's c5 leg does: (a) fp32 planes with the reference's noise
+    against the reference's tours, (b) the WIDE kernel on bf16 planes == the C oracle bit for bit on the same noise."""
+    g = GoldenCase("c5_cvrp500_b256_sampling")
+    td0, h = _encode(g)
+    t_ref = g.actions.shape[1]
+    steps = t_ref + 8
+    noise = _reference_noise(g, steps)
+    a, l, st, n_steps, t, err = _run(K, "hip", g, td0, h, "sampling", max_steps=steps, exp_noise=noise)
+    assert err == 0 and bool(st["done"].all())
+    flips, reward = _vs_golden(K, g, a, l, t, td0, max_flips=max(1, g.batch // 50))
+    _record("c5_sampling_fp32_flips", {"fold_on": flips, "of": g.batch})
+    print(f"CVRP-500 x {g.batch} sampling, fp32 planes, reference noise: {flips} trajectories differ")
+    assert K.decode_row_groups(501, torch.bfloat16, steps, "auto", g.batch) == 16  # auto = WIDE at this batch
+    hip = _run(K, "hip", g, td0, h, "sampling", torch.bfloat16, max_steps=steps, variant="wide", exp_noise=noise)
+    ref = _run(K, "c", g, td0, h, "sampling", torch.bfloat16, max_steps=steps, variant="wide", exp_noise=noise)
+    _assert_bit_exact(hip, ref)
+    rows = hip[0][:, : hip[4]]
+    g.env.check_solution_validity(td0, rows)
 
 
 # ---------------------------------------------------------------------------------------------

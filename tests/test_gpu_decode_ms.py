@@ -163,3 +163,89 @@ def test_ms_large_graphs_and_odd_start_counts_match_streaming_quality(env_name, 
             Kmod.am_decode = orig
         rewards[variant] = out["reward"].view(starts, 24).max(0).values.mean().item()
     assert abs(rewards["ms"] - rewards["stream"]) <= 5e-3 * abs(rewards["stream"]), rewards
+
+
+# ---------------------------------------------------------------------------------------------
+# against the rounding-model oracle (oracle/rollout_ref.c: oracle_am_decode_ms)
+# ---------------------------------------------------------------------------------------------
+
+def _c_ms_rollout(g, td0, cache_cpu, starts, mode, exp_noise=None, forced=None):
+    from oracle import c_oracle
+    from tests.helpers import apply_step
+
+    st = rollout_state(g.env_name, td0, device="cpu", num_starts=starts)
+    b, n = st["action_mask"].shape
+    tmax = max_horizon(g.env_name, n)
+    actions = torch.zeros(b, tmax, dtype=torch.int64)
+    logps = torch.zeros(b, tmax)
+    n_steps = torch.zeros(b, dtype=torch.int32)
+    err = torch.zeros(1, dtype=torch.int32)
+    first = g.env.select_start_nodes(td0, starts)
+    actions[:, 0] = first
+    apply_step(c_oracle, g.env_name, first, st)
+    if forced is not None:
+        f = torch.zeros(b, tmax, dtype=torch.int64)
+        f[:, : forced.shape[1]] = forced
+        forced = f
+    c_oracle.am_decode(cache_cpu, st, mode=mode, max_steps=tmax - 1, t0=1, actions=actions, logps=logps, err=err,
+                       n_steps=n_steps, row_groups="ms", exp_noise=exp_noise, forced_actions=forced)
+    assert int(err.item()) == 0
+    t = 1 + int(n_steps.max())
+    return actions[:, :t], logps[:, :t]
+
+
+# MS kernel vs its rounding model, per decode step on the common prefix / under teacher forcing. The residual is the
+# hardware's exp2 / log / rcp approximations and the MFMA summation order acting through the bf16 rounding points
+# (a last-bit difference before a bf16 rounding moves one operand by 2^-9 relative).
+MS_LOGP_TOL = 2e-3
+MS_IDENTICAL_FLOOR = 0.90
+
+
+@pytest.mark.parametrize("name,starts,mode", [("c4_pomo_tsp100_b32_s8_sampling", 8, "sampling"),
+                                              ("c4_pomo_tsp100_b32_s8_sampling", 8, "greedy"),
+                                              ("pomo_tsp50_b8_mssampling", 40, "sampling"),
+                                              ("pomo_tsp20_b16_msgreedy", 20, "greedy"),
+                                              ("pomo_cvrp20_b16_msgreedy", 20, "greedy"),
+                                              ("cvrp100_b64_greedy", 9, "sampling")])
+def test_ms_kernel_follows_its_rounding_model_oracle(K, name, starts, mode):
+    """BASELINE configs[3]'s rollout kernel (auto-selected from 8 starts on bf16 planes) against the C restatement
+    with the SAME bf16 rounding points (query, softmax numerators, glimpse) and fp32 arithmetic elsewhere:
+    (a) teacher-forced on the oracle's own trajectories every per-step log-probability agrees within MS_LOGP_TOL;
+    (b) free-running, trajectories are identical except at near-ties (>= MS_IDENTICAL_FLOOR identical), and agree
+    within the same tolerance on their common prefix."""
+    from tests.test_gpu_decode import _record
+
+    g = GoldenCase(name)
+    td0 = g.reset()
+    with torch.inference_mode():
+        h, _ = g.policy.encoder(td0)
+    cache = fold_cache(g.policy, g.env_name, h, torch.bfloat16, device="cuda")
+    cache_cpu = cache.to("cpu")
+    b = g.batch * starts
+    n = g.num_loc + (g.env_name != "tsp")
+    noise = None
+    if mode == "sampling":
+        torch.manual_seed(77)
+        noise = torch.empty(max_horizon(g.env_name, n), b, n).exponential_(1).contiguous()
+    a_c, l_c = _c_ms_rollout(g, td0, cache_cpu, starts, mode, exp_noise=noise)
+    kw = {} if noise is None else dict(exp_noise=noise.cuda())
+    a_ms, l_ms, st, err, _ = _rollout(K, g, td0, cache, starts, "ms", mode=mode, **kw)
+    assert err == 0 and bool(st["done"].all())
+    a_ms, l_ms = a_ms.cpu(), l_ms.cpu()
+    t = min(a_ms.shape[1], a_c.shape[1])
+    agree = (a_ms[:, :t] == a_c[:, :t])
+    prefix = agree.long().cumprod(1).bool()            # columns before the first disagreement
+    identical = float(agree.all(1).float().mean()) if a_ms.shape == a_c.shape else 0.0
+    gap_prefix = float(((l_ms[:, :t] - l_c[:, :t]).abs() * prefix).max())
+    # (a) teacher forcing: the kernel evaluates the ORACLE's trajectories
+    a_ev, l_ev, _, err2, _ = _rollout(K, g, td0, cache, starts, "ms", mode="evaluate", forced=a_c.cuda())  # same column layout as `actions`
+    assert err2 == 0 and torch.equal(a_ev.cpu()[:, : a_c.shape[1]], a_c)
+    gap_forced = (l_ev.cpu()[:, : a_c.shape[1]] - l_c).abs()
+    print(f"{name} S={starts} {mode}: {identical:.1%} of {b} trajectories identical to the rounding-model oracle; per-step "
+          f"log-prob gap: teacher-forced max {float(gap_forced.max()):.2e} mean {float(gap_forced.mean()):.2e}, "
+          f"common prefix max {gap_prefix:.2e}")
+    _record(f"ms_vs_model/{name}/S{starts}/{mode}", {"identical_frac": identical, "forced_gap_max": float(gap_forced.max()),
+                                                     "forced_gap_mean": float(gap_forced.mean()), "prefix_gap_max": gap_prefix})
+    assert float(gap_forced.max()) <= MS_LOGP_TOL
+    assert gap_prefix <= MS_LOGP_TOL
+    assert identical >= MS_IDENTICAL_FLOOR

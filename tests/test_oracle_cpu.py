@@ -154,12 +154,12 @@ def test_env_steps_match_restatement(env_name, num_loc):
 # decode loop: C specified-order oracle vs the reference goldens
 # ---------------------------------------------------------------------------------------------
 
-def c_rollout(g: GoldenCase, mode: str, cache_dtype=torch.float32, row_groups=None, exp_noise=None):
+def c_rollout(g: GoldenCase, mode: str, cache_dtype=torch.float32, row_groups=None, exp_noise=None, fold=True):
     """Encoder through the restatement (stock torch), decode loop through the C oracle."""
     td0 = g.reset()
     with torch.inference_mode():
         h, _ = g.policy.encoder(td0)
-    cache = fold_cache(g.policy, g.env_name, h, cache_dtype)
+    cache = fold_cache(g.policy, g.env_name, h, cache_dtype, fold=fold)
     s = g.num_starts
     st = rollout_state(g.env_name, td0, num_starts=s)
     b, n = st["action_mask"].shape
@@ -227,6 +227,38 @@ def test_c_oracle_sampling_matches_reference(name):
     assert torch.equal(reward[same], g.reward[same])
     torch.testing.assert_close(reward.mean(), g.reward.mean(), rtol=1e-5, atol=0) if bool(same.all()) else None
     torch.testing.assert_close(logps[:, :t].sum(1)[same], g.log_likelihood[same], rtol=ll_rtol(g.env_name), atol=5e-5)
+
+
+@pytest.mark.parametrize("name", ["c1_tsp20_b256_greedy", "tsp100_b64_greedy", "cvrp20_b128_greedy", "cvrp100_b64_greedy",
+                                  "pomo_tsp20_b16_msgreedy", "pomo_cvrp20_b16_msgreedy"])
+def test_c_oracle_unfolded_greedy_matches_reference(name):
+    """fold = off: the reference's own association (per-step project_context / project_out GEMVs, raw logit key,
+    zoo/am/decoder.py:128-228, nn/attention.py:287-293) in a specified order. Same bar as the folded cache — and the
+    per-step log-probabilities of the two associations agree to 1e-5: the fold is algebra, not approximation."""
+    g = GoldenCase(name)
+    actions, logps, td0 = c_rollout(g, "greedy", fold=False)
+    assert actions.shape == g.actions.shape
+    same = (actions == g.actions).all(1)
+    assert int((~same).sum()) <= max(1, g.actions.shape[0] // 100)
+    reward = oracle_reward(g.env_name, td0, actions)
+    assert torch.equal(reward[same], g.reward[same])
+    torch.testing.assert_close(logps.sum(1)[same], g.log_likelihood[same], rtol=ll_rtol(g.env_name), atol=2e-5)
+    a_f, l_f, _ = c_rollout(g, "greedy", fold=True)
+    both = (a_f == actions).all(1)
+    assert both.float().mean() >= 0.98
+    torch.testing.assert_close(l_f[both], logps[both], rtol=0, atol=2e-5)
+
+
+def test_c_oracle_unfolded_sampling_matches_reference():
+    g = GoldenCase("cvrp100_b64_sampling")
+    n = g.num_loc + 1
+    torch.manual_seed(g.meta["sample_seed"])
+    noise = torch.stack([torch.empty(g.batch, n).exponential_(1) for _ in range(max_horizon(g.env_name, n))], 0)
+    actions, logps, td0 = c_rollout(g, "sampling", exp_noise=noise.contiguous(), fold=False)
+    t = g.actions.shape[1]
+    same = (actions[:, :t] == g.actions).all(1)
+    assert int((~same).sum()) <= 1
+    assert torch.equal(oracle_reward(g.env_name, td0, actions)[same], g.reward[same])
 
 
 def test_c_oracle_bf16_cache_quality():
@@ -334,3 +366,37 @@ def test_random_shapes_env_walks_match_restatement(env_name, num_loc, batch, see
     if bool(td["done"].all()) and acts:
         actions = torch.stack(acts, 1)
         assert torch.equal(oracle_reward(env_name, td0, actions), env.get_reward(td0, actions))
+
+
+@pytest.mark.parametrize("name", ["pomo_tsp20_b16_msgreedy", "pomo_cvrp20_b16_msgreedy"])
+def test_ms_rounding_model_oracle_is_the_same_policy_up_to_bf16(name):
+    """oracle_am_decode_ms (bf16 query / softmax numerators / glimpse, the multistart MFMA kernel's rounding points)
+    against the specified-order oracle on the same bf16 planes: same decode step up to the model's bf16 error —
+    teacher-forced per-step log-probs within 0.05, identical greedy decisions almost everywhere."""
+    g = GoldenCase(name)
+    td0 = g.reset()
+    with torch.inference_mode():
+        h, _ = g.policy.encoder(td0)
+    cache = fold_cache(g.policy, g.env_name, h, torch.bfloat16)
+    s = g.num_starts
+    outs = {}
+    for groups in (4, "ms"):
+        st = rollout_state(g.env_name, td0, num_starts=s)
+        b, n = st["action_mask"].shape
+        tmax = max_horizon(g.env_name, n)
+        actions, logps = torch.zeros(b, tmax, dtype=torch.int64), torch.zeros(b, tmax)
+        n_steps, err = torch.zeros(b, dtype=torch.int32), torch.zeros(1, dtype=torch.int32)
+        first = g.start_nodes(td0, s)
+        actions[:, 0] = first
+        apply_step(c_oracle, g.env_name, first, st)
+        forced = None
+        if groups == "ms":  # evaluate the specified-order oracle's trajectories under the rounding model
+            forced = outs[4][0].clone()
+        c_oracle.am_decode(cache, st, mode="greedy" if forced is None else "evaluate", max_steps=tmax - 1, t0=1,
+                           actions=actions, logps=logps, err=err, n_steps=n_steps, row_groups=groups, forced_actions=forced)
+        assert int(err.item()) == 0 and bool(st["done"].all())
+        outs[groups] = (actions, logps, int(n_steps.max()))
+    t = 1 + outs[4][2]
+    assert torch.equal(outs["ms"][0][:, :t], outs[4][0][:, :t])
+    gap = (outs["ms"][1][:, :t] - outs[4][1][:, :t]).abs()
+    assert float(gap.max()) <= 0.05 and float(gap.mean()) <= 5e-3, (float(gap.max()), float(gap.mean()))
