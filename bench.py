@@ -418,6 +418,11 @@ class Bench:
 
 
 def main() -> None:
+    # stdout carries exactly ONE line (the JSON): RCCL prints a version banner to the process's stdout at communicator
+    # creation, so file descriptor 1 is pointed at stderr for the run and the line goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200, help="timed steps of the headline leg")
@@ -534,7 +539,7 @@ def main() -> None:
         if world == 1 and not args.no_cpu_baseline and head_name != "c4_train":
             line["cpu_baseline"] = cpu_baseline(env_name, num_loc, args.cpu_sample_batch, repeats=2)
             line["cpu_baseline"]["gpu_over_cpu"] = head["value"] / line["cpu_baseline"]["value"]
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -534,6 +534,15 @@ int rl4co_attn_bwd_bf16(const void* qkv, const void* dout, const float* lse, int
 int rl4co_attn_max_nodes(void);
 
 /* --------------------------------------------------------------------------
+ * a12 (inference, large graphs)  MultiHeadAttention.forward   rl4co/models/nn/attention.py:110-134
+ * out[b, i, 16 h ..] = softmax_j(q_h[i] . k_h[j] / 4) v_h[j] on the packed projection output qkv [B,N,384]
+ * (q | k | v, 8 heads x 16), bf16 -> out [B,N,128] bf16, any N: keys / values stream through LDS in blocks of
+ * 64 nodes with a running (max, sum, output) per query — the N x N score matrix is never materialised
+ * (csrc/am_attn_flash.hip). Serves the encoder beyond rl4co_am_encoder_max_nodes() (BASELINE configs[4]).
+ * -------------------------------------------------------------------------- */
+int rl4co_attn_flash_bf16(const void* qkv, int B, int N, void* out, void* stream);
+
+/* --------------------------------------------------------------------------
  * a19  select_start_nodes        rl4co/utils/ops.py:128-161
  * out[s*B + b] = s % num_loc (+1 for depot environments), s-major.
  * -------------------------------------------------------------------------- */

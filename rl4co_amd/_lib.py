@@ -116,6 +116,7 @@ SYMBOLS = {
     "rl4co_attn_fwd_bf16": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "rl4co_attn_bwd_bf16": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_attn_max_nodes": (C.c_int, []),
+    "rl4co_attn_flash_bf16": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_wgrad_bf16": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp]),
     "rl4co_am_encoder": (C.c_int, [_vp, _vp]),
     "rl4co_am_encoder_max_nodes": (C.c_int, []),

@@ -1,0 +1,189 @@
+// am_attn_flash.hip — encoder self-attention for graphs too large for one workgroup's LDS (N > 128: BASELINE
+// configs[4], CVRP-500), inference. Replaces the head rearrangement + scaled_dot_product_attention of
+// nn/attention.py:110-134 (MultiHeadAttention.forward) on the packed projection output qkv [B, N, 384]
+// (q | k | v, 8 heads x 16), bf16 -> out [B, N, 128] bf16.
+//
+// The N x N score matrix never exists: keys / values stream through LDS in blocks of 64 nodes and every query
+// keeps a running (max, sum, output) triple — the online softmax of flash attention — in registers:
+//   * one 512-thread workgroup = (instance, block of kQT * 16 queries); wave h owns head h, like am_train_attn.hip;
+//   * v_mfma_f32_16x16x16_bf16 with the QUERY as accumulator column (lane & 15) and four consecutive KEYS (rows
+//     4 g ..) per lane: S^T = K_h Q_h^T chains into O_h^T += V_h^T P^T without a shuffle (P in the accumulator
+//     layout is the B operand; V^T through ds_read_b64_tr_b16), the 16 head dims are exactly one MFMA k-step;
+//   * a query tile's state is 8 registers (Q fragment 2, max 1, partial sum 1, O^T 4), so a wave carries kQT = 8
+//     tiles and each key block's K / V fragments (read from LDS once per block) serve all of them;
+//   * the block maximum needs the four row groups of a query to agree (two permlane swaps); the softmax
+//     denominator does not — every lane sums its own keys against the shared running maximum and the four
+//     partial sums meet once, after the last block;
+//   * the next key block's rows are fetched into registers while the current one is consumed (one LDS buffer,
+//     two barriers per block); finished tiles leave through the same LDS buffer as contiguous 16-byte lanes.
+// bf16 operands, fp32 accumulation / softmax in the exp2 domain; tolerance-tested against fp32 torch attention.
+#include <hip/hip_runtime.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kD = RL4CO_EMBED_DIM;
+constexpr int kWaves = 8;
+constexpr int kThreads = 64 * kWaves;
+constexpr int kKB = 64;              // keys per LDS block
+constexpr int kQT = 8;               // query tiles (of 16) per workgroup pass
+constexpr int kKS = 2 * kD + 8;      // LDS row stride of a k | v row (bf16 elements)
+constexpr int kOS = kD + 8;          // LDS row stride of the output staging rows
+constexpr float kNegInf = -__builtin_huge_valf();
+constexpr float kScale = 0.25f * 1.44269504088896341f;  // 1/sqrt(16) in the exp2 domain
+
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+__device__ inline f32x4 mfma16(const bf16x4& a, const bf16x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+__device__ inline f32x4 zero4() { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
+__device__ inline bf16x4 lds_b64(const __bf16* p) { return *reinterpret_cast<const bf16x4*>(p); }
+__device__ inline bf16x4 lds_tr(const __bf16* p) {
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+  return __builtin_bit_cast(bf16x4, v);
+}
+
+// blockIdx -> (instance, query block). Workgroup b lands on XCD b % 8 (observed placement): the query blocks of ONE
+// instance re-read the same k | v rows, so they are given consecutive slots of one XCD and share its L2.
+__device__ inline void block_map(int b, int B, int QB, int& inst, int& qb) {
+  if ((B & 7) != 0) {
+    inst = b / QB;
+    qb = b % QB;
+    return;
+  }
+  const int xcd = b & 7, k = b >> 3;
+  qb = k % QB;
+  inst = (k / QB) * 8 + xcd;
+}
+
+__global__ void __launch_bounds__(kThreads, 2) attn_flash_kernel(const uint16_t* __restrict__ qkv, int B, int N, int QB,
+                                                                 uint16_t* __restrict__ out) {
+  constexpr int kLds = kKB * kKS > kQT * 16 * kOS ? kKB * kKS : kQT * 16 * kOS;
+  __shared__ __align__(16) __bf16 kv[kLds];  // one key block: [64][k 128 | v 128]; later the output staging rows
+  const int tid = threadIdx.x, h = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
+  int inst, qb;
+  block_map(blockIdx.x, B, QB, inst, qb);
+  const uint16_t* base = qkv + (int64_t)inst * N * 3 * kD;
+  const int q0 = qb * kQT * 16;  // first query of this workgroup
+  const int nblocks = (N + kKB - 1) / kKB;
+
+  // ---- this wave's query fragments: B operand, lane = query column, four consecutive dims of head h ---------
+  bf16x4 qf[kQT];
+  float m[kQT], l[kQT];
+  f32x4 o[kQT];
+#pragma unroll
+  for (int t = 0; t < kQT; ++t) {
+    const int q = min(q0 + 16 * t + tl, N - 1);  // clamped: rows >= N are computed and dropped
+    qf[t] = *reinterpret_cast<const bf16x4*>(base + (int64_t)q * 3 * kD + 16 * h + 4 * g);
+    m[t] = kNegInf;
+    l[t] = 0.0f;
+    o[t] = zero4();
+  }
+
+  // ---- key blocks: rows prefetched into registers one block ahead --------------------------------------------
+  // a block is 64 rows x 512 bytes (k | v) = 2048 16-byte chunks, four per thread
+  uint4 pre[4];
+  auto fetch = [&](int kb) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = tid + j * kThreads;
+      const int row = min(kb * kKB + (c >> 5), N - 1), col = (c & 31) * 8;
+      pre[j] = *reinterpret_cast<const uint4*>(base + (int64_t)row * 3 * kD + kD + col);
+    }
+  };
+  auto commit = [&](int kb) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = tid + j * kThreads;
+      const int r = c >> 5, col = (c & 31) * 8;
+      const bool ok = kb * kKB + r < N;  // rows past the graph are zero (their scores are masked as well)
+      *reinterpret_cast<uint4*>(kv + r * kKS + col) = ok ? pre[j] : make_uint4(0, 0, 0, 0);
+    }
+  };
+  const int nao = tl * kKS + 4 * g;                          // natural operand read: row lane & 15, columns 4 g ..
+  const int tro = (4 * g + (tl >> 2)) * kKS + 4 * (tl & 3);  // transpose read
+  fetch(0);
+  for (int kb = 0; kb < nblocks; ++kb) {
+    if (kb > 0) __syncthreads();  // every wave is done reading the previous block
+    commit(kb);
+    __syncthreads();
+    if (kb + 1 < nblocks) fetch(kb + 1);
+    bf16x4 kf[4], vf[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      kf[j] = lds_b64(kv + 16 * j * kKS + 16 * h + nao);
+      vf[j] = lds_tr(kv + 16 * j * kKS + kD + 16 * h + tro);
+    }
+    const bool tail = (kb + 1) * kKB > N;
+#pragma unroll
+    for (int t = 0; t < kQT; ++t) {
+      f32x4 s[4];
+      float bm = kNegInf;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s[j] = mfma16(kf[j], qf[t], zero4());
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          float v = s[j][rr] * kScale;
+          if (tail) v = (kb * kKB + 16 * j + 4 * g + rr < N) ? v : kNegInf;
+          s[j][rr] = v;
+          bm = fmaxf(bm, v);
+        }
+      }
+      bm = rl4co::bfly_max<16, 64>(bm);  // the four row groups of a query agree on the block maximum
+      const float mn = fmaxf(m[t], bm);   // finite: every block holds at least one real key
+      const float alpha = __builtin_amdgcn_exp2f(m[t] - mn);  // exp2(-inf) = 0 on the first block
+      m[t] = mn;
+      float ls = 0.0f;
+      f32x4 acc = {o[t][0] * alpha, o[t][1] * alpha, o[t][2] * alpha, o[t][3] * alpha};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        bf16x4 pf;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const float p = __builtin_amdgcn_exp2f(s[j][rr] - mn);
+          ls += p;
+          pf[rr] = (__bf16)p;
+        }
+        acc = mfma16(vf[j], pf, acc);
+      }
+      o[t] = acc;
+      l[t] = fmaf(l[t], alpha, ls);  // this lane's keys only; the row groups meet after the last block
+    }
+  }
+  __syncthreads();  // the key block is dead: its buffer stages the output rows [kQT * 16][128]
+
+  // ---- normalise, stage, leave as contiguous 16-byte lanes ------------------------------------------------------
+#pragma unroll
+  for (int t = 0; t < kQT; ++t) {
+    const float inv = __builtin_amdgcn_rcpf(rl4co::bfly_sum<16, 64>(l[t]));
+    bf16x4 ov;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) ov[rr] = (__bf16)(o[t][rr] * inv);
+    *reinterpret_cast<bf16x4*>(kv + (16 * t + tl) * kOS + 16 * h + 4 * g) = ov;
+  }
+  __syncthreads();
+  const int rows = min(kQT * 16, N - q0);
+  uint16_t* dst = out + ((int64_t)inst * N + q0) * kD;
+  for (int c = tid; c < rows * 16; c += kThreads) {
+    const int row = c >> 4, col = (c & 15) * 8;
+    *reinterpret_cast<uint4*>(dst + (int64_t)row * kD + col) = *reinterpret_cast<const uint4*>(kv + row * kOS + col);
+  }
+}
+
+}  // namespace
+
+extern "C" int rl4co_attn_flash_bf16(const void* qkv, int B, int N, void* out, void* stream) {
+  RL4CO_REQUIRE(qkv && out && B > 0 && N >= 1 && N <= 65536);
+  const int QB = (N + kQT * 16 - 1) / (kQT * 16);
+  RL4CO_REQUIRE((int64_t)B * QB < (1ll << 31));
+  hipLaunchKernelGGL(attn_flash_kernel, dim3(B * QB), dim3(kThreads), 0, rl4co::as_stream(stream),
+                     static_cast<const uint16_t*>(qkv), B, N, QB, static_cast<uint16_t*>(out));
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}

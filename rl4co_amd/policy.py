@@ -449,6 +449,7 @@ class AttentionModelPolicy(nn.Module):
         # inference only): measured 4 instead of 10 near-tie flips in 4096 TSP-100 tours against the reference
         self.fold = fold
         self._packed = None
+        self._ambient_autocast = None  # set for the duration of a forward() entered under torch.autocast
         self._bwd_err = None  # device int32 word the teacher backward ORs its sticky bits into (read with the next status)
         self._philox_calls = 0
         self.last_instance_steps = 0
@@ -468,7 +469,9 @@ class AttentionModelPolicy(nn.Module):
         """Inference encoder for graphs beyond the fused kernel's 128 nodes (C5: CVRP-500): the same
         layer algebra on the token-parallel kernels of the training path — init embedding, the four
         projections per layer with bias / ReLU epilogues (csrc/am_train_ops.hip), eval-mode batch norm
-        as one affine pass — and torch's SDPA for the N x N attention. bf16 activations."""
+        as one affine pass — and the flash-style attention kernel (csrc/am_attn_flash.hip: keys / values
+        streamed through LDS with an online softmax) for the N x N attention. bf16 activations; no ATen
+        kernel on the path."""
         from . import train_ops as T
 
         enc = self.encoder
@@ -497,8 +500,7 @@ class AttentionModelPolicy(nn.Module):
             attn, norm1, ffn, norm2 = layer[0].module, layer[1].normalizer, layer[2].module, layer[3].normalizer
             x2 = x.reshape(b * n, d)
             qkv = T._gemm(x2, attn.Wqkv.weight.to(bf).contiguous(), attn.Wqkv.bias.float().contiguous())
-            q, k, v = qkv.view(b, n, 3, attn.num_heads, d // attn.num_heads).permute(2, 0, 3, 1, 4).unbind(0)
-            o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(b * n, d)
+            o = T.attention_flash(qkv.view(b, n, 3 * d)).view(b * n, d)  # keys / values streamed through LDS, any N
             s_ = T._gemm(o, attn.out_proj.weight.to(bf).contiguous(), attn.out_proj.bias.float().contiguous())
             x2 = T.batch_norm_eval(x2 + s_, norm1)
             h = T._gemm(x2, ffn.lins[0].weight.to(bf).contiguous(), ffn.lins[0].bias.float().contiguous(), relu=True)
@@ -512,10 +514,11 @@ class AttentionModelPolicy(nn.Module):
         around training steps AND the validation / ``RolloutBaseline`` rollouts (utils/trainer.py:57 picks the
         precision; the reference's default "16-mixed" is fp16 autocast: no hand-written kernel claims that regime,
         the torch encoder runs under it exactly as the reference's does)."""
-        if self.encoder_autocast == torch.bfloat16:
-            return True
-        return (self.encoder_autocast is None and torch.is_autocast_enabled()
-                and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+        return self._encoder_regime() == torch.bfloat16
+
+    def _encoder_regime(self):
+        """Autocast dtype of the encoder: the constructor's choice, else the ambient one (None = fp32)."""
+        return self.encoder_autocast if self.encoder_autocast is not None else self._ambient_autocast
 
     def _token_encoder_usable(self, td) -> bool:
         layer0 = self.encoder.net.layers[0]
@@ -523,8 +526,9 @@ class AttentionModelPolicy(nn.Module):
                 and not self.training and len(layer0[2].module.lins) == 2 and layer0[2].module.lins[0].out_features % 128 == 0)
 
     def _encode(self, td):
-        if self.encoder_autocast is not None:
-            with torch.autocast("cuda", dtype=self.encoder_autocast):
+        regime = self._encoder_regime()
+        if regime is not None and td["locs"].is_cuda:
+            with torch.autocast("cuda", dtype=regime):
                 return self.encoder(td)
         return self.encoder(td)
 
@@ -585,11 +589,25 @@ class AttentionModelPolicy(nn.Module):
         return st
 
     # -- forward (constructive/base.py:154-263) ---------------------------------------------------
-    def forward(self, td: TensorDict, env: str | RL4COEnvBase | None = None, phase: str = "train",
-                calc_reward: bool = True, return_actions: bool = True, return_entropy: bool = False,
-                return_hidden: bool = False, return_init_embeds: bool = False,
-                return_sum_log_likelihood: bool = True, actions: Tensor | None = None,
-                max_steps: int = 1_000_000, **decoding_kwargs) -> dict:
+    def forward(self, td: TensorDict, *args, **kwargs) -> dict:
+        """Ambient autocast (Lightning's mixed-precision plugin wraps every step in it) selects the ENCODER's regime
+        only: cache fold, context tables, reward and log-likelihood arithmetic are fp32 by contract, so everything
+        but the encoder runs with autocast switched off and the encoder re-enters it explicitly (``_encode``)."""
+        on_cuda = td["locs"].is_cuda if "locs" in td.keys() else torch.cuda.is_available()
+        if on_cuda and torch.is_autocast_enabled():
+            self._ambient_autocast = torch.get_autocast_dtype("cuda")
+            try:
+                with torch.autocast("cuda", enabled=False):
+                    return self._forward(td, *args, **kwargs)
+            finally:
+                self._ambient_autocast = None
+        return self._forward(td, *args, **kwargs)
+
+    def _forward(self, td: TensorDict, env: str | RL4COEnvBase | None = None, phase: str = "train",
+                 calc_reward: bool = True, return_actions: bool = True, return_entropy: bool = False,
+                 return_hidden: bool = False, return_init_embeds: bool = False,
+                 return_sum_log_likelihood: bool = True, actions: Tensor | None = None,
+                 max_steps: int = 1_000_000, **decoding_kwargs) -> dict:
         grad_path = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if not self.fold and grad_path:
             raise NotImplementedError("fold=False is the inference parity configuration; train with the folded cache")
@@ -607,7 +625,13 @@ class AttentionModelPolicy(nn.Module):
         else:
             cache = None
             if not grad_path and self.fused_encoder and self._token_encoder_usable(td):
-                hidden, init_embeds = self._encode_tokens_bf16(td)  # N > 128: token-parallel kernels + SDPA
+                if self.encode_events is not None:
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record()
+                hidden, init_embeds = self._encode_tokens_bf16(td)  # N > 128: token-parallel kernels + flash attention
+                if self.encode_events is not None:
+                    ev1.record()
+                    self.encode_events.append((ev0, ev1))
             else:
                 hidden, init_embeds = self._encode(td)
         if isinstance(env, str) or env is None:
@@ -665,8 +689,10 @@ class AttentionModelPolicy(nn.Module):
                 cache = teacher.detached_cache(self.env_name, cache_g, self.cache_dtype)
         if cache is None:
             with torch.no_grad():
+                regime = self._encoder_regime()  # fp16 (the reference's default "16-mixed"): the fold stays fp32
                 cache = self.decoder.precompute_cache(hidden.detach(), self.cache_dtype,
-                                                      self.encoder_autocast or torch.float32, fold=self.fold)
+                                                      torch.bfloat16 if regime == torch.bfloat16 else torch.float32,
+                                                      fold=self.fold)
         state = self._initial_state(td, n_rep)
         horizon = min(self._max_horizon(self.env_name, n), max_steps)
         if self.env_name == "pdp" and not getattr(env, "force_start_at_depot", False):

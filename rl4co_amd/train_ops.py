@@ -268,6 +268,18 @@ def attention(qkv: Tensor) -> Tensor:
     return _Attention.apply(qkv)
 
 
+def attention_flash(qkv: Tensor) -> Tensor:
+    """Inference attention for any N (csrc/am_attn_flash.hip): softmax(q k^T / 4) v per head on the packed
+    qkv [B,N,384] bf16 -> [B,N,128] bf16; keys / values stream through LDS, no N x N matrix, no autograd."""
+    assert qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.dim() == 3 and qkv.shape[-1] == 3 * EMBED_DIM
+    qkv = qkv.contiguous()
+    b, n, _ = qkv.shape
+    out = torch.empty((b, n, EMBED_DIM), dtype=torch.bfloat16, device=qkv.device)
+    st = _lib.lib().rl4co_attn_flash_bf16(qkv.data_ptr(), b, n, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.check(st, "rl4co_attn_flash_bf16")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------
 # init embedding (K = 2 / 3 "GEMM") in training
 # ---------------------------------------------------------------------------------------------------

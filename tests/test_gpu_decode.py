@@ -313,8 +313,11 @@ def _record(key, value):
 def test_full_size_tsp100_b4096_vs_reference_golden(K):
     """BASELINE configs[1] at full size, fp32 cache: the reference's 4096 greedy tours — with the folded cache (the
     product default) and in the reference's own association (fold = off), so the fold's share of the near-tie flips
-    is a measured number: the C oracle on the CPU-folded cache gives 10 (fold on) / 4 (fold off) of 4096; the two
-    sets are disjoint (14 trajectories differ between the two associations)."""
+    is a measured number. Measured (r02): planes built by the CPU's GEMMs, C oracle: 10 (fold on) / 4 (fold off) of
+    4096, disjoint sets; planes built by the GPU's GEMMs (this test): 12 / 15; whole policy on the GPU (bench.py's
+    parity block): 9 / 12. The flip count sits at the noise floor of fp32 re-association (~3e-5 of the 409 600 argmax
+    decisions) whichever association is used: what moves it is the summation order of whoever builds the planes
+    (oneDNN vs rocBLAS), not the fold."""
     g = GoldenCase("c2_tsp100_b4096_greedy")
     td0, h = _encode(g)
     flips = {}
@@ -322,9 +325,8 @@ def test_full_size_tsp100_b4096_vs_reference_golden(K):
         a, l, st, n_steps, t, err = _run(K, "hip", g, td0, h, "greedy", fold=fold)
         assert err == 0 and t == 100 and bool((n_steps == 100).all())
         assert not bool(st["action_mask"].any())
-        # fp32 near-ties between the kernel's operation order and ATen's: fold on measured 12 (r01), bound 20 = 0.5 %;
-        # fold off bound 10
-        flips[fold], reward = _vs_golden(K, g, a, l, t, td0, max_flips=20 if fold else 10)
+        # fp32 near-ties between the kernel's operation order and ATen's: measured 12 (fold on) / 15 (fold off), bound 0.5 %
+        flips[fold], reward = _vs_golden(K, g, a, l, t, td0, max_flips=20)
         # size-independent properties: every row a permutation; mean tour length ~ the reference's
         assert torch.equal(a.sort(1).values, torch.arange(100).expand_as(a))
         assert abs(float(reward.mean() - g.reward.mean())) <= 1e-4 * abs(float(g.reward.mean()))
@@ -361,21 +363,40 @@ def test_full_size_tsp100_b4096_bf16_properties(K, variant):
     lp16 = _run(K, "hip", g, td0, h, "evaluate", torch.bfloat16, variant=variant, forced_actions=forced)[1]
     lp32 = _run(K, "hip", g, td0, h, "evaluate", torch.float32, forced_actions=forced)[1]
     gap = (lp16 - lp32).abs()
+    # where a bf16 rollout first leaves the reference's tour it does so at a NEAR-TIE of the fp32 policy: the fp32-plane
+    # kernel, teacher-forced along the common prefix, rates the bf16 choice within a few 1e-2 of its own best node
+    all32 = torch.zeros(a.shape[0], tmax, a.shape[1], device="cuda")
+    _run(K, "hip", g, td0, h, "evaluate", torch.float32, forced_actions=forced, all_logps=all32)
+    first = agree.long().cumprod(1).sum(1).clamp(max=a.shape[1] - 1)          # first divergent step of every trajectory
+    rows = torch.arange(a.shape[0])
+    lp_at = all32.cpu()[rows, first]                                          # fp32 log-probs at that state [B, N]
+    regret = lp_at.max(-1).values - lp_at[rows, a[rows, first]]
+    regret = regret[~agree.all(1)]
     print(f"bf16 cache ({variant}): {same:.1%} of 4096 greedy trajectories identical to the fp32 reference, common prefix "
           f"{prefix:.1f} of 100 steps; per-step log-prob gap to fp32 planes: mean {gap.mean():.2e}, max {gap.max():.2e}; "
-          f"log-likelihood gap mean {(lp16.sum(1) - lp32.sum(1)).abs().mean():.2e}")
+          f"log-likelihood gap mean {(lp16.sum(1) - lp32.sum(1)).abs().mean():.2e}; fp32 log-prob regret of the first "
+          f"divergent choice: mean {float(regret.mean()):.2e}, max {float(regret.max()):.2e}")
     _record(f"c2_bf16_{variant}", {"identical_frac": same, "common_prefix_steps": prefix, "logp_gap_mean": float(gap.mean()),
                                    "logp_gap_max": float(gap.max()),
-                                   "ll_gap_mean": float((lp16.sum(1) - lp32.sum(1)).abs().mean())})
-    assert same >= BF16_IDENTICAL_FLOOR and prefix >= BF16_PREFIX_FLOOR
+                                   "ll_gap_mean": float((lp16.sum(1) - lp32.sum(1)).abs().mean()),
+                                   "first_divergence_regret_mean": float(regret.mean()),
+                                   "first_divergence_regret_max": float(regret.max())})
+    assert prefix >= BF16_PREFIX_FLOOR
     assert float(gap.mean()) <= BF16_LOGP_GAP_MEAN and float(gap.max()) <= BF16_LOGP_GAP_MAX
+    assert float(regret.mean()) <= BF16_REGRET_MEAN and float(regret.max()) <= BF16_REGRET_MAX
 
 
-# floors / ceilings for the bf16-plane configuration at C2 (set from the r02 measurement, with margin)
-BF16_IDENTICAL_FLOOR = 0.0
-BF16_PREFIX_FLOOR = 0.0
-BF16_LOGP_GAP_MEAN = 1.0
-BF16_LOGP_GAP_MAX = 100.0
+# The bf16-plane configuration at C2 against the fp32 reference, measured on MI355X (r02, gpurun_out/parity_measured.json
+# -> profiles/r02_parity_measured.json): with RANDOM-INIT weights the policy is close to uniform (every step is a
+# near-tie at the 1e-2 level), so 3-digit planes move the greedy arg-max early: 0 of 4096 tours stay identical, the
+# common prefix is 9.2 of 100 steps; the per-step log-prob gap to fp32 planes on the SAME tours is 1.0e-3 mean /
+# 6.9e-3 max (log-likelihood 1.1e-2). Ceilings below = those measurements with margin; "identical tours" is therefore
+# not a property this configuration can promise — equal tour quality is (asserted above: mean within 0.5 %).
+BF16_PREFIX_FLOOR = 5.0
+BF16_LOGP_GAP_MEAN = 3e-3
+BF16_LOGP_GAP_MAX = 2e-2
+BF16_REGRET_MEAN = 2e-2
+BF16_REGRET_MAX = 1e-1
 
 
 def test_full_size_cvrp100_b1024_vs_reference_golden(K):
@@ -406,7 +427,7 @@ def test_full_size_cvrp100_b4096_vs_reference_golden(K):
     td0, h = _encode(g)
     a, l, st, n_steps, t, err = _run(K, "hip", g, td0, h, "greedy")
     assert err == 0 and bool(st["done"].all())
-    flips, reward = _vs_golden(K, g, a, l, t, td0, max_flips=20)
+    flips, reward = _vs_golden(K, g, a, l, t, td0, max_flips=32)  # measured 20 (r02)
     _record("c3_fp32_flips", {"fold_on": flips, "of": 4096})
     print(f"CVRP-100 x 4096, fp32 planes: {flips} greedy trajectories differ from the reference")
     err_w = K.new_error_word("cuda")

@@ -1,16 +1,21 @@
-"""GPU: fused MFMA encoder + cache fold (csrc/am_encoder.hip) vs the torch encoder.
+"""GPU: fused MFMA encoder + cache fold (csrc/am_encoder.hip) vs the ORACLE's encoder.
 
 Floating-point kernel => tolerance test, tolerance stated here: the kernel computes with bf16 MFMA
 inputs / fp32 accumulation / a bf16 residual stream, i.e. the same precision regime as the
-reference under its default mixed-precision autocast (utils/trainer.py:57). Against the fp32 torch
-encoder + fp32 fold of the SAME weights every output (three cache planes, context tables, graph
-context, final embeddings) must be within 3e-2 relative Frobenius error, and no worse than 2.5x
-the error torch's own bf16 autocast path makes on the same inputs.
+reference under mixed-precision autocast (utils/trainer.py:57). The reference values come from the
+oracle restatement (oracle/reference_torch.py, pinned bit for bit to the reference's source) run in
+fp32 on the CPU with the same weights, and the expected cache rows from its embeddings and weights
+in float64 — not from the product's own torch modules. Every output (three cache planes, context
+tables, graph context, final embeddings) must be within 3e-2 relative Frobenius error, and no worse
+than 2.5x the error torch's own bf16 autocast path makes on the same inputs. A second test makes the
+normalisation epsilon matter (tiny running variances), where a wrong epsilon shows at the 10 % level.
 """
+import copy
+
 import pytest
 import torch
 
-from tests.helpers import GoldenCase
+from tests.helpers import GoldenCase, decoder_weights
 
 pytestmark = pytest.mark.gpu
 
@@ -51,6 +56,35 @@ def _perturb_norm_stats(pol):
             m.bias.data.copy_(torch.randn(m.bias.shape, generator=gen).cuda() * 0.1)
 
 
+def _oracle_reference(g, pol, eps=None):
+    """The oracle's fp32 CPU encoder with the (perturbed) weights of `pol`, and the cache rows it implies (float64)."""
+    ref_pol = copy.deepcopy(g.policy)
+    ref_pol.load_state_dict({k: v.detach().cpu() for k, v in pol.state_dict().items()}, strict=True)
+    ref_pol.eval()
+    if eps is not None:
+        n_bn = 0
+        for m in ref_pol.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.eps, n_bn = eps, n_bn + 1
+        assert n_bn > 0
+    with torch.inference_mode():
+        h, _ = ref_pol.encoder(g.reset())
+    h64 = h.double()
+    w = {k: (None if v is None else v.double()) for k, v in decoder_weights(ref_pol).items()}
+    d = 128
+    wk, wv, wl = w["w_node"][:d], w["w_node"][d : 2 * d], w["w_node"][2 * d :]
+    out = {"hidden": h, "glimpse_key": h64 @ wk.t(), "glimpse_val": h64 @ wv.t(),
+           "logit_key": h64 @ (w["w_out"].t() @ wl).t()}
+    if g.env_name == "tsp":
+        out["ctx_first"] = h64 @ w["w_ctx"][:, :d].t()
+        out["ctx_cur"] = h64 @ w["w_ctx"][:, d : 2 * d].t()
+    else:
+        out["ctx_cur"] = h64 @ w["w_ctx"][:, :d].t()
+    if w["w_fixed"] is not None:
+        out["q_bias"] = h64.mean(1) @ w["w_fixed"].t()
+    return {k: v.float().cuda() for k, v in out.items()}
+
+
 @pytest.mark.parametrize("name", ["tsp20_b64_greedy_simple", "tsp50_b64_greedy", "tsp100_b64_greedy",
                                   "cvrp20_b128_greedy", "cvrp100_b64_greedy", "pomo_tsp50_b8_mssampling",
                                   "pomo_cvrp20_b16_msgreedy"])
@@ -65,19 +99,19 @@ def test_fused_encoder_matches_torch(name, cache_dtype):
     with torch.inference_mode():
         cache, hidden = packed.encode(td, cache_dtype, want_hidden=True)
         torch.cuda.synchronize()
-        h32, _ = pol.encoder(td)  # fp32 torch encoder, same weights
-        ref = pol.decoder.precompute_cache(h32, torch.float32, torch.float32)
+        ref = pol.decoder.precompute_cache(pol.encoder(td)[0], torch.float32, torch.float32)  # for the exact vectors below
         with torch.autocast("cuda", dtype=torch.bfloat16):
             h16, _ = pol.encoder(td)
         auto = pol.decoder.precompute_cache(h16, cache_dtype, torch.bfloat16)
-    checks = {"hidden": (hidden, h32, h16.float())}
+    want = _oracle_reference(g, pol)  # the oracle's CPU fp32 encoder, float64 fold
+    checks = {"hidden": (hidden, want["hidden"], h16.float())}
     for i, nm in enumerate(("glimpse_key", "glimpse_val", "logit_key")):
-        checks[nm] = (cache.kvl[i], ref.kvl[i], auto.kvl[i])
-    checks["ctx_cur"] = (cache.ctx_cur, ref.ctx_cur, auto.ctx_cur)
+        checks[nm] = (cache.kvl[i], want[nm], auto.kvl[i])
+    checks["ctx_cur"] = (cache.ctx_cur, want["ctx_cur"], auto.ctx_cur)
     if g.env_name == "tsp":
-        checks["ctx_first"] = (cache.ctx_first, ref.ctx_first, auto.ctx_first)
-    if ref.q_bias is not None:
-        checks["q_bias"] = (cache.q_bias, ref.q_bias, auto.q_bias)
+        checks["ctx_first"] = (cache.ctx_first, want["ctx_first"], auto.ctx_first)
+    if "q_bias" in want:
+        checks["q_bias"] = (cache.q_bias, want["q_bias"], auto.q_bias)
     else:
         assert cache.q_bias is None
     for nm, (got, want, autoc) in checks.items():
@@ -89,6 +123,31 @@ def test_fused_encoder_matches_torch(name, cache_dtype):
         assert torch.equal(cache.q_step0, ref.q_step0)
     else:
         assert torch.equal(cache.w_cap, ref.w_cap)
+
+
+@pytest.mark.parametrize("name", ["tsp50_b64_greedy", "cvrp20_b128_greedy"])
+def test_fused_encoder_normalisation_epsilon_matters(name):
+    """Eval-mode batch norm with running variances of 2e-5 .. 2e-4: the 1e-5 epsilon of nn.BatchNorm1d (nn/ops.py:30-54)
+    changes the scale by 2 - 20 %. The kernel (host-folded affine) must still match the oracle's encoder at the
+    usual bound; the same comparison against an epsilon of 1e-3 is off by far more than the bound — i.e. this test
+    would catch a wrong epsilon, which the unit-variance tests above cannot."""
+    g = GoldenCase(name)
+    pol = _policy(g, encoder_autocast=torch.bfloat16, cache_dtype=torch.float32)
+    gen = torch.Generator().manual_seed(9)
+    for m in pol.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_var.copy_((torch.rand(m.running_var.shape, generator=gen) * 1.8e-4 + 2e-5).cuda())
+            m.running_mean.copy_((torch.randn(m.running_mean.shape, generator=gen) * 0.05).cuda())
+            # keep activations O(1): the affine undoes most of the 1/sqrt(var) blow-up
+            m.weight.data.copy_((torch.rand(m.weight.shape, generator=gen) * 0.01 + 0.005).cuda())
+    env, td = _td(g)
+    with torch.inference_mode():
+        cache, hidden = pol._packed_encoder().encode(td, torch.float32, want_hidden=True)
+    want = _oracle_reference(g, pol)
+    assert _rel(hidden, want["hidden"]) <= REL_TOL
+    assert _rel(cache.kvl[0], want["glimpse_key"]) <= REL_TOL
+    wrong = _oracle_reference(g, pol, eps=1e-3)  # the same weights under a wrong epsilon are a different function
+    assert _rel(wrong["hidden"], want["hidden"]) > 3 * REL_TOL
 
 
 def test_fused_encoder_rollout_quality_full_size():
@@ -141,8 +200,8 @@ def test_packed_weights_refresh_after_update():
 
 def test_token_parallel_encoder_for_large_graphs_matches_torch():
     """N > 128 (the fused per-instance kernel's limit): the inference encoder runs on the token-parallel
-    kernels (csrc/am_train_ops.hip) + SDPA. Same bound as the fused encoder test: within 3e-2 relative
-    Frobenius error of the fp32 torch encoder."""
+    kernels (csrc/am_train_ops.hip) + the flash-style attention kernel (csrc/am_attn_flash.hip). Same bound as the
+    fused encoder test: within 3e-2 relative Frobenius error of the fp32 torch encoder."""
     from rl4co_amd.envs import get_env
     from rl4co_amd.policy import AttentionModelPolicy
 
@@ -164,3 +223,31 @@ def test_token_parallel_encoder_for_large_graphs_matches_torch():
         assert float((h0.float() - ref0).norm() / ref0.norm()) <= 1e-2
         out = pol(td, env, phase="test", decode_type="greedy")  # end to end through the WIDE decode variant
     assert out["reward"].shape == (16,) and bool(torch.isfinite(out["reward"]).all())
+
+
+@pytest.mark.parametrize("b,n", [(1, 1), (3, 17), (8, 64), (5, 129), (16, 200), (8, 501), (13, 777), (2, 1500)])
+def test_attention_flash_matches_fp32_attention(b, n):
+    """csrc/am_attn_flash.hip (any N, keys / values streamed through LDS, online softmax) against fp32 attention of
+    the SAME bf16 q | k | v (nn/attention.py:110-134 semantics: 8 heads x 16, scale 1/4). Tolerance: bf16 output
+    rounding (2^-9 relative) plus bf16 softmax numerators: 1.5e-2 absolute on O(1) outputs, relative Frobenius 1e-2
+    (the same bound the training attention kernel is held to)."""
+    import torch.nn.functional as F
+
+    from rl4co_amd import train_ops as T
+
+    gen = torch.Generator().manual_seed(100 * b + n)
+    qkv = (torch.randn(b, n, 384, generator=gen) * 1.5).to(torch.bfloat16).cuda()
+    out = T.attention_flash(qkv)
+    torch.cuda.synchronize()
+    q, k, v = qkv.float().view(b, n, 3, 8, 16).permute(2, 0, 3, 1, 4).unbind(0)
+    ref = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(b, n, 128)
+    assert out.shape == (b, n, 128) and torch.isfinite(out.float()).all()
+    assert float((out.float() - ref).abs().max()) <= 1.5e-2 * max(1.0, float(ref.abs().max()))
+    assert _rel(out, ref) <= 1e-2
+    # sharp softmax (large scores): the running maximum / rescaling path
+    qkv2 = qkv.clone()
+    qkv2[..., :256] *= 4.0
+    out2 = T.attention_flash(qkv2)
+    q, k, v = qkv2.float().view(b, n, 3, 8, 16).permute(2, 0, 3, 1, 4).unbind(0)
+    ref2 = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(b, n, 128)
+    assert torch.isfinite(out2.float()).all() and _rel(out2, ref2) <= 1.5e-2
