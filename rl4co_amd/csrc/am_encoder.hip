@@ -38,7 +38,6 @@ constexpr int kD = RL4CO_EMBED_DIM;
 constexpr int kFF = 512;
 constexpr int kRS = kD + 8;  // LDS row stride (bf16 elements): 272 B rows spread the banks
 constexpr int kThreads = 256;
-constexpr float kQScale = 0.25f * 1.44269504088896341f;  // head_dim^-1/2 * log2(e)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -50,6 +49,14 @@ __device__ inline f32x16 mfma(const bf16x8& a, const bf16x8& b, const f32x16& c)
 
 // accumulator layout of the 32x32 MFMA: register r of lane (l31, hi) is row rowmap(r, hi), col l31
 __device__ inline int rowmap(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+// bias of the wave's 32-dim output tile in accumulator layout (transposed form: register r <-> dim rowmap(r, hi))
+__device__ inline f32x16 bias_tile(const float* bias, int dim0, int hi) {
+  f32x16 t;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) t[r] = bias[dim0 + rowmap(r, hi)];
+  return t;
+}
 
 __device__ inline f32x16 zero16() {
   f32x16 z;
@@ -89,9 +96,11 @@ __device__ inline void load_wfrags(bf16x8 (&wf)[8], const __bf16* packed, int ks
 // last MFMA, the same registers receive fragment ks of the NEXT GEMM (nxt_*; nullptr: none), whose
 // latency then hides under the rest of this call and whatever epilogue separates the two. The LDS
 // activation fragments are double-buffered one kstep ahead.
-template <int TT, bool W_IS_A = true>
+// INIT: the first k-step takes `cinit` as its C operand (an MFMA's C need not be its D) — the bias tile of the GEMM,
+// shared by the TT token tiles, enters the accumulators for free instead of through 16 TT adds in the epilogue.
+template <int TT, bool W_IS_A = true, bool INIT = true>
 __device__ inline void gemm_t(f32x16 (&acc)[TT], bf16x8 (&wf)[8], const __bf16* xs, int lane, const __bf16* nxt_packed,
-                              int nxt_ksteps_total, int nxt_tile, int nxt_k0) {
+                              int nxt_ksteps_total, int nxt_tile, int nxt_k0, const f32x16& cinit) {
   const int l31 = lane & 31, hi = lane >> 5;
   bf16x8 xa[TT], xb[TT];
 #pragma unroll
@@ -101,8 +110,10 @@ __device__ inline void gemm_t(f32x16 (&acc)[TT], bf16x8 (&wf)[8], const __bf16* 
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) xb[tt] = load_x(xs, tt, ks + 1, l31, hi);
 #pragma unroll
-    for (int tt = 0; tt < TT; ++tt)
-      acc[tt] = W_IS_A ? mfma(wf[ks], xa[tt], acc[tt]) : mfma(xa[tt], wf[ks], acc[tt]);
+    for (int tt = 0; tt < TT; ++tt) {
+      const f32x16& c = (INIT && ks == 0) ? cinit : acc[tt];
+      acc[tt] = W_IS_A ? mfma(wf[ks], xa[tt], c) : mfma(xa[tt], wf[ks], c);
+    }
     if (nxt_packed) wf[ks] = load_w(nxt_packed, nxt_ksteps_total, nxt_tile, nxt_k0 + ks, lane);
     if (ks + 2 < 8) {
 #pragma unroll
@@ -133,19 +144,18 @@ __device__ inline void store_t(__bf16* ys, const f32x16 (&acc)[TT], int dim0, in
 
 struct LayerPtrs {
   const __bf16 *wqkv, *wo, *w1, *w2;
-  const float *bqkv, *bo, *b1, *b2, *n1a, *n1b, *n2a, *n2b;
+  const float *bqkv, *b1, *n1a, *n1b, *n2a, *n2b;
 };
 
 // residual + bias + normalisation epilogue for the wave's 32-dim tile; result back into xs (bf16)
 template <int TT>
-__device__ inline void residual_norm(__bf16* xs, f32x16 (&y)[TT], int dim0, const float* bias, const float* na,
+__device__ inline void residual_norm(__bf16* xs, f32x16 (&y)[TT], int dim0, const float* na,
                                      const float* nb, int norm, int N, int lane) {
   const int l31 = lane & 31, hi = lane >> 5;
-  float bb[16], ga[16], be[16];
+  float ga[16], be[16];  // (the GEMM's bias is folded into `nb` on the host, or cancels: instance norm)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int d = dim0 + rowmap(r, hi);
-    bb[r] = bias[d];
     ga[r] = na[d];
     be[r] = nb[d];
   }
@@ -155,7 +165,7 @@ __device__ inline void residual_norm(__bf16* xs, f32x16 (&y)[TT], int dim0, cons
     for (int c = 0; c < 4; ++c) {
       const bf16x4 x = *reinterpret_cast<const bf16x4*>(xs + (32 * tt + l31) * kRS + dim0 + 8 * c + 4 * hi);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) y[tt][4 * c + s] = (float)x[s] + (y[tt][4 * c + s] + bb[4 * c + s]);
+      for (int s = 0; s < 4; ++s) y[tt][4 * c + s] = (float)x[s] + y[tt][4 * c + s];
     }
   }
   if (norm == 1) {
@@ -191,7 +201,30 @@ __device__ inline void residual_norm(__bf16* xs, f32x16 (&y)[TT], int dim0, cons
 
 // Two workgroups per CU (70 KB LDS, <= 256 registers): while one instance sits in a VALU-heavy
 // phase (softmax, norms, conversions) the other one's waves keep the matrix pipe busy.
-template <int TT>
+// |score| bound below which exp2 needs no max subtraction: scores in [-48, 48] (log2 domain) keep every softmax
+// numerator in [2^-48, 2^48] and a row sum below 2^55 — far inside fp32 / bf16 range, same relative precision
+constexpr float kFastBound = 48.0f;
+
+// squared norms of the two heads' 16-dim slices of one token column, from a transposed-form accumulator tile
+// (register r of lane (l31, hi) is dim rowmap(r, hi) of token l31: a head = 8 registers here + 8 in the other half)
+__device__ inline void head_sqnorms(const f32x16& c, float& h0, float& h1) {
+  float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    s0 = fmaf(c[r], c[r], s0);
+    s1 = fmaf(c[8 + r], c[8 + r], s1);
+  }
+  h0 = s0 + rl4co::bfly_f<32>(s0);
+  h1 = s1 + rl4co::bfly_f<32>(s1);
+}
+__device__ inline float wave_max32(float v) {  // maximum over the 32 token columns (both halves hold the same value)
+  return rl4co::bfly_max<1, 32>(v);
+}
+
+// VR4: valid 4-register groups of the LAST key tile (keys 32 (TT-1) ..): ceil((N - 32 (TT-1)) / 8). Registers beyond
+// them are padding keys in every lane — their exps, conversions and (from 8 registers up) the second value product
+// are dropped at compile time (TSP-100: four valid keys in the fourth tile, 12 of 16 registers gone).
+template <int TT, int VR4>
 __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_encoder_args a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __bf16* xs = reinterpret_cast<__bf16*>(smem);  // residual stream [128][kRS]
@@ -270,55 +303,74 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
     L.w1 = w1_all + (int64_t)layer * kFF * kD;
     L.w2 = w2_all + (int64_t)layer * kD * kFF;
     L.bqkv = a.bqkv + layer * 3 * kD;
-    L.bo = a.bo + layer * kD;
     L.b1 = a.b1 + layer * kFF;
-    L.b2 = a.b2 + layer * kD;
     L.n1a = a.n1_scale + layer * kD;
     L.n1b = a.n1_shift + layer * kD;
     L.n2a = a.n2_scale + layer * kD;
     L.n2b = a.n2_shift + layer * kD;
 
     // ---- Q, K (transposed form) and V (plain form) of head pair w, kept as fragments ---------
-    bf16x8 kf[TT][2], vf[TT][2];
+    // vfh[hh]: V^T fragments for head hh of the pair — the lanes holding the OTHER head's dims carry ones instead, so
+    // the value product's idle output rows deliver the softmax denominator (sum of the bf16 numerators) for free
+    bf16x8 kf[TT][2], vfh[2][TT][2];
+    float qn2[2] = {0.0f, 0.0f}, kn2[2] = {0.0f, 0.0f};  // max over tokens of |q|^2, |k|^2 per head of the pair
     {
       f32x16 acc[TT];
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt) acc[tt] = zero16();
-      gemm_t<TT>(acc, wf, xs, lane, L.wqkv, 8, 4 + w, 0);
+      // 1/sqrt(16) and log2(e) are folded into the packed Wq and its bias on the host (encoder.py): the softmax below
+      // is exp2(s - max) and the projection needs no epilogue arithmetic at all
+      gemm_t<TT>(acc, wf, xs, lane, L.wqkv, 8, 4 + w, 0, bias_tile(L.bqkv, 32 * w, hi));
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
-#pragma unroll
-        // 1/sqrt(16) and log2(e) folded into Q: softmax below is exp2(s - max)
-        for (int r = 0; r < 16; ++r) acc[tt][r] = (acc[tt][r] + L.bqkv[32 * w + rowmap(r, hi)]) * kQScale;
+        float h0, h1;
+        head_sqnorms(acc[tt], h0, h1);
+        qn2[0] = fmaxf(qn2[0], h0);
+        qn2[1] = fmaxf(qn2[1], h1);
       }
       // Q^T parked in this wave's own 32 columns of ys (each lane re-reads only its own token
       // row, and later overwrites it with the attention output of that same row)
       store_t<TT>(ys, acc, 32 * w, lane);
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt) acc[tt] = zero16();
-      gemm_t<TT>(acc, wf, xs, lane, L.wqkv, 8, 8 + w, 0);
+      gemm_t<TT>(acc, wf, xs, lane, L.wqkv, 8, 8 + w, 0, bias_tile(L.bqkv + kD, 32 * w, hi));
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tt][r] += L.bqkv[kD + 32 * w + rowmap(r, hi)];
         kf[tt][0] = frag_from_acc(acc[tt], 0);
         kf[tt][1] = frag_from_acc(acc[tt], 1);
+        float h0, h1;
+        head_sqnorms(acc[tt], h0, h1);
+        kn2[0] = fmaxf(kn2[0], h0);
+        kn2[1] = fmaxf(kn2[1], h1);
       }
       // V = X . Wv^T: A = token rows from LDS, B = weight fragment -> C[row = token][col = dim]
+      {
+        const float bv = L.bqkv[2 * kD + 32 * w + l31];  // plain form: the bias belongs to the lane's dim column
+        f32x16 bt;
 #pragma unroll
-      for (int tt = 0; tt < TT; ++tt) acc[tt] = zero16();
-      gemm_t<TT, false>(acc, wf, xs, lane, nullptr, 0, 0, 0);  // nothing in flight across the attention (register peak)
-      const float bv = L.bqkv[2 * kD + 32 * w + l31];
+        for (int r = 0; r < 16; ++r) bt[r] = bv;
+        gemm_t<TT, false>(acc, wf, xs, lane, nullptr, 0, 0, 0, bt);  // nothing in flight across the attention (register peak)
+      }
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[tt][r] += bv;
-        vf[tt][0] = frag_from_acc(acc[tt], 0);
-        vf[tt][1] = frag_from_acc(acc[tt], 1);
+        for (int u = 0; u < 2; ++u) {
+          const bf16x8 v = frag_from_acc(acc[tt], u);
+          bf16x8 ones;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+          vfh[0][tt][u] = (l31 < 16) ? v : ones;   // lane = dim column: dims 0..15 are head 2w, 16..31 head 2w + 1
+          vfh[1][tt][u] = (l31 < 16) ? ones : v;
+        }
       }
+    }
+    // |score| <= max_i |q_i| max_j |k_j| per head (Cauchy-Schwarz; fp32 norms, the products see their bf16 roundings:
+    // the bound keeps a wide margin): below kFastBound the softmax needs no running maximum
+    bool fast_head[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const float b2 = wave_max32(qn2[hh]) * wave_max32(kn2[hh]);
+      fast_head[hh] = __builtin_amdgcn_readfirstlane((b2 <= kFastBound * kFastBound) ? 1 : 0) != 0;
     }
 
     // ---- attention for heads 2w, 2w+1 over all queries, wave-private ---------------------------
+    constexpr int kLastRegs = 4 * VR4;  // registers of the last key tile that can hold real keys
 #pragma unroll
     for (int qt = 0; qt < TT; ++qt) {
       __bf16* qrow = ys + (32 * qt + l31) * kRS + 32 * w;
@@ -335,40 +387,64 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
             qf[4 + i] = up[i];
           }
         }
-        f32x16 s[TT];
-        float m = -__builtin_huge_valf();
+        f32x16 acc0, acc1;  // two accumulators: half the dependent-MFMA chain; each starts from a literal-zero C operand
+        if (TT == 1) acc1 = zero16();
+        if (fast_head[hh]) {
+          // bounded scores: p = exp2(s) tile by tile — no maximum, no subtraction, no score tile kept alive
 #pragma unroll
-        for (int kt = 0; kt < TT; ++kt) {
-          s[kt] = mfma(kf[kt][hh], qf, zero16());
-          if (kt == TT - 1) {  // TT = ceil(N/32): only the last key tile can hold padding keys
+          for (int kt = 0; kt < TT; ++kt) {
+            const f32x16 sk = mfma(kf[kt][hh], qf, zero16());
+            const int nreg = (kt == TT - 1) ? kLastRegs : 16;
+            f32x16 p;
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              s[kt][r] = (32 * kt + rowmap(r, hi) < N) ? s[kt][r] : -__builtin_huge_valf();
+            for (int r = 0; r < 16; ++r) {
+              float v = 0.0f;
+              if (r < nreg) {
+                v = __builtin_amdgcn_exp2f(sk[r]);
+                if (kt == TT - 1) v = (32 * kt + rowmap(r, hi) < N) ? v : 0.0f;  // padding keys inside the valid registers
+              }
+              p[r] = v;
+            }
+            if (kt & 1) {
+              acc1 = mfma(vfh[hh][kt][0], frag_from_acc(p, 0), kt == 1 ? zero16() : acc1);
+              if (nreg > 8) acc1 = mfma(vfh[hh][kt][1], frag_from_acc(p, 1), acc1);
+            } else {
+              acc0 = mfma(vfh[hh][kt][0], frag_from_acc(p, 0), kt == 0 ? zero16() : acc0);
+              if (nreg > 8) acc0 = mfma(vfh[hh][kt][1], frag_from_acc(p, 1), acc0);
+            }
           }
+        } else {
+          f32x16 s[TT];
+          float m = -__builtin_huge_valf();
 #pragma unroll
-          for (int r = 0; r < 16; ++r) m = fmaxf(m, s[kt][r]);
-        }
-        m = fmaxf(m, rl4co::bfly_f<32>(m));
-        float l = 0.0f;
+          for (int kt = 0; kt < TT; ++kt) {
+            s[kt] = mfma(kf[kt][hh], qf, zero16());
+            if (kt == TT - 1) {  // TT = ceil(N/32): only the last key tile can hold padding keys
 #pragma unroll
-        for (int kt = 0; kt < TT; ++kt) {
+              for (int r = 0; r < 16; ++r)
+                s[kt][r] = (r < kLastRegs && 32 * kt + rowmap(r, hi) < N) ? s[kt][r] : -__builtin_huge_valf();
+            }
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float p = __builtin_amdgcn_exp2f(s[kt][r] - m);
-            s[kt][r] = p;
-            l += p;
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, s[kt][r]);
+          }
+          m = fmaxf(m, rl4co::bfly_f<32>(m));
+#pragma unroll
+          for (int kt = 0; kt < TT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - m);
+            if (kt & 1) {
+              acc1 = mfma(vfh[hh][kt][0], frag_from_acc(s[kt], 0), kt == 1 ? zero16() : acc1);
+              acc1 = mfma(vfh[hh][kt][1], frag_from_acc(s[kt], 1), acc1);
+            } else {
+              acc0 = mfma(vfh[hh][kt][0], frag_from_acc(s[kt], 0), kt == 0 ? zero16() : acc0);
+              acc0 = mfma(vfh[hh][kt][1], frag_from_acc(s[kt], 1), acc0);
+            }
           }
         }
-        l += rl4co::bfly_f<32>(l);
-        f32x16 acc = zero16();
+        // rows of the other head's dims carried ones: every one of them is the row sum of this query's numerators
+        const float inv = 1.0f / (acc0[8 * (1 - hh)] + acc1[8 * (1 - hh)]);
 #pragma unroll
-        for (int kt = 0; kt < TT; ++kt) {
-          acc = mfma(vf[kt][0], frag_from_acc(s[kt], 0), acc);
-          acc = mfma(vf[kt][1], frag_from_acc(s[kt], 1), acc);
-        }
-        const float inv = 1.0f / l;
-#pragma unroll
-        for (int r = 0; r < 8; ++r) o[8 * hh + r] = acc[8 * hh + r] * inv;
+        for (int r = 0; r < 8; ++r) o[8 * hh + r] = (acc0[8 * hh + r] + acc1[8 * hh + r]) * inv;
       }
       // attention output row [token][dims of head pair w] over the Q^T this lane just consumed
 #pragma unroll
@@ -386,10 +462,10 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
     // ---- out-proj + residual + norm1 ---------------------------------------------------------------
     {
       f32x16 y[TT];
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt) y[tt] = zero16();
-      gemm_t<TT>(y, wf, ys, lane, L.w1, 8, w, 0);  // next: FFN1 chunk 0
-      residual_norm<TT>(xs, y, 32 * w, L.bo, L.n1a, L.n1b, a.norm, N, lane);
+      // (out_proj's bias rides in the norm's shift — batch norm — or cancels in the per-channel mean — instance norm:
+      // folded on the host, encoder.py)
+      gemm_t<TT>(y, wf, ys, lane, L.w1, 8, w, 0, zero16());  // next: FFN1 chunk 0
+      residual_norm<TT>(xs, y, 32 * w, L.n1a, L.n1b, a.norm, N, lane);
     }
     __syncthreads();
 
@@ -397,25 +473,23 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
     {
       f32x16 y2[TT];
 #pragma unroll
-      for (int tt = 0; tt < TT; ++tt) y2[tt] = zero16();
+      for (int tt = 0; tt < TT; ++tt) y2[tt] = zero16();  // the chunk loop accumulates; the MLP's output bias: see out_proj
       for (int c = 0; c < 4; ++c) {
         f32x16 h1[TT];
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt) h1[tt] = zero16();
-        gemm_t<TT>(h1, wf, xs, lane, L.w2, 32, w, 8 * c);  // next: FFN2 of this chunk
+        gemm_t<TT>(h1, wf, xs, lane, L.w2, 32, w, 8 * c, bias_tile(L.b1, 32 * (4 * c + w), hi));  // next: FFN2 of this chunk
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) h1[tt][r] = fmaxf(h1[tt][r] + L.b1[32 * (4 * c + w) + rowmap(r, hi)], 0.0f);
+          for (int r = 0; r < 16; ++r) h1[tt][r] = fmaxf(h1[tt][r], 0.0f);
         if (c > 0) __syncthreads();  // every wave is done reading the previous chunk
         store_t<TT>(ys, h1, 32 * w, lane);
         __syncthreads();
         // next: FFN1 of the next chunk, then the next layer's Q projection, finally the first fold block
         const bool last_layer = layer + 1 == a.num_layers;
         const __bf16* nxt = c < 3 ? L.w1 : (last_layer ? wf_all : wqkv_all + (int64_t)(layer + 1) * 3 * kD * kD);
-        gemm_t<TT>(y2, wf, ys, lane, nxt, 8, c < 3 ? 4 * (c + 1) + w : w, 0);
+        gemm_t<TT, true, false>(y2, wf, ys, lane, nxt, 8, c < 3 ? 4 * (c + 1) + w : w, 0, y2[0]);
       }
-      residual_norm<TT>(xs, y2, 32 * w, L.b2, L.n2a, L.n2b, a.norm, N, lane);
+      residual_norm<TT>(xs, y2, 32 * w, L.n2a, L.n2b, a.norm, N, lane);
     }
     __syncthreads();
   }
@@ -430,9 +504,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
   const int nblocks = (a.env == RL4CO_ENV_TSP) ? 5 : 4;
   for (int blk = 0; blk < nblocks; ++blk) {
     f32x16 acc[TT];
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt) acc[tt] = zero16();
-    gemm_t<TT>(acc, wf, xs, lane, blk + 1 < nblocks ? wf_all + (int64_t)(blk + 1) * kD * kD : nullptr, 8, w, 0);
+    gemm_t<TT>(acc, wf, xs, lane, blk + 1 < nblocks ? wf_all + (int64_t)(blk + 1) * kD * kD : nullptr, 8, w, 0, zero16());
     // The tile leaves through LDS (`ys` is free after the last layer): stored straight from the accumulators a lane
     // owns 8 / 16 bytes in each of 32 token rows; staged, a plane of an instance is ONE contiguous run of 16-byte lanes.
     if (blk < 3 && a.cache_dtype == RL4CO_DT_BF16) {
@@ -503,14 +575,25 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
   }
 }
 
-template <int TT>
+template <int TT, int VR4>
 int launch_encoder(const rl4co_am_encoder_args& a, hipStream_t stream) {
   const int lds = 2 * 128 * kRS * 2 + kD * 4;
-  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_encoder_kernel<TT>),
+  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_encoder_kernel<TT, VR4>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL((am_encoder_kernel<TT>), dim3(a.B), dim3(kThreads), lds, stream, a);
+  hipLaunchKernelGGL((am_encoder_kernel<TT, VR4>), dim3(a.B), dim3(kThreads), lds, stream, a);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
+}
+
+template <int TT>
+int launch_encoder_tiles(const rl4co_am_encoder_args& a, hipStream_t stream) {
+  const int vr4 = (a.N - 32 * (TT - 1) + 7) / 8;  // valid 4-register groups of the last key tile
+  switch (vr4) {
+    case 1: return launch_encoder<TT, 1>(a, stream);
+    case 2: return launch_encoder<TT, 2>(a, stream);
+    case 3: return launch_encoder<TT, 3>(a, stream);
+    default: return launch_encoder<TT, 4>(a, stream);
+  }
 }
 
 }  // namespace
@@ -535,9 +618,9 @@ extern "C" int rl4co_am_encoder(const rl4co_am_encoder_args* args, void* stream)
   hipStream_t s = rl4co::as_stream(stream);
   const int tt = (a.N + 31) / 32;
   switch (tt) {
-    case 1: return launch_encoder<1>(a, s);
-    case 2: return launch_encoder<2>(a, s);
-    case 3: return launch_encoder<3>(a, s);
-    default: return launch_encoder<4>(a, s);
+    case 1: return launch_encoder_tiles<1>(a, s);
+    case 2: return launch_encoder_tiles<2>(a, s);
+    case 3: return launch_encoder_tiles<3>(a, s);
+    default: return launch_encoder_tiles<4>(a, s);
   }
 }

@@ -98,8 +98,11 @@ class PackedEncoder:
             t["w_init"], t["b_init"] = f32(ie.init_embed.weight), f32(ie.init_embed.bias)
         if pol.env_name != "tsp":
             t["w_depot"], t["b_depot"] = f32(ie.init_embed_depot.weight), f32(ie.init_embed_depot.bias)
-        t["wqkv"] = torch.stack([pack_weight(l[0].module.Wqkv.weight) for l in layers]).contiguous()
-        t["bqkv"] = torch.stack([f32(l[0].module.Wqkv.bias) for l in layers]).contiguous()
+        # the query rows of Wqkv (and their bias) carry head_dim^-1/2 * log2(e): the kernel's softmax is exp2(q . k)
+        qscale = torch.ones(3 * EMBED_DIM, 1, device=layers[0][0].module.Wqkv.weight.device)
+        qscale[:EMBED_DIM] = 0.25 * 1.4426950408889634
+        t["wqkv"] = torch.stack([pack_weight(l[0].module.Wqkv.weight.detach().float() * qscale) for l in layers]).contiguous()
+        t["bqkv"] = torch.stack([f32(l[0].module.Wqkv.bias.detach().float() * qscale[:, 0]) for l in layers]).contiguous()
         t["wo"] = torch.stack([pack_weight(l[0].module.out_proj.weight) for l in layers]).contiguous()
         t["bo"] = torch.stack([f32(l[0].module.out_proj.bias) for l in layers]).contiguous()
         t["w1"] = torch.stack([pack_weight(l[2].module.lins[0].weight) for l in layers]).contiguous()
@@ -107,10 +110,16 @@ class PackedEncoder:
         t["w2"] = torch.stack([pack_weight(l[2].module.lins[1].weight) for l in layers]).contiguous()
         t["b2"] = torch.stack([f32(l[2].module.lins[1].bias) for l in layers]).contiguous()
         kinds = set()
-        for name, idx in (("n1", 1), ("n2", 3)):
+        # the bias of the GEMM in front of a norm (out_proj before norm1, the MLP's second linear before norm2) is a
+        # per-channel constant added to every token: under eval-mode batch norm it moves the affine's shift by
+        # bias * scale; under instance norm it cancels in the per-channel mean over the nodes. The kernel adds neither
+        # (rl4co_am_encoder_args.bo / b2 are still passed for reference and ignored).
+        for name, idx, bias_of in (("n1", 1, lambda l: l[0].module.out_proj.bias), ("n2", 3, lambda l: l[2].module.lins[1].bias)):
             sc, sh = [], []
             for l in layers:
                 a, b, k = _norm_affine(l[idx])
+                if k == 0:
+                    b = b + bias_of(l).detach().float() * a
                 sc.append(a), sh.append(b), kinds.add(k)
             t[f"{name}_scale"], t[f"{name}_shift"] = torch.stack(sc).contiguous(), torch.stack(sh).contiguous()
         assert len(kinds) == 1

@@ -251,3 +251,38 @@ def test_attention_flash_matches_fp32_attention(b, n):
     q, k, v = qkv2.float().view(b, n, 3, 8, 16).permute(2, 0, 3, 1, 4).unbind(0)
     ref2 = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(b, n, 128)
     assert torch.isfinite(out2.float()).all() and _rel(out2, ref2) <= 1.5e-2
+
+
+@pytest.mark.parametrize("env_name,num_loc", [("tsp", 9), ("tsp", 44), ("tsp", 72), ("cvrp", 109), ("tsp", 120), ("tsp", 128),
+                                              ("cvrp", 40), ("tsp", 97)])
+@pytest.mark.parametrize("sharp", [False, True], ids=["bounded-scores", "exact-max-path"])
+def test_fused_encoder_tile_shapes_and_softmax_paths(env_name, num_loc, sharp):
+    """Every (token tiles, valid registers of the last key tile) instantiation of the fused encoder, and both softmax
+    paths of its attention: with bounded scores (|q||k| <= 48 in the log2 domain, the usual case) the numerators are
+    exp2(s) with no running maximum and the denominator comes out of the value product's idle rows; `sharp` scales
+    Wqkv until the bound fails, which must select the exact max-subtracting path. Same tolerance either way,
+    against the fp32 torch encoder of the same weights."""
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    torch.manual_seed(num_loc)
+    pol = AttentionModelPolicy(env_name, cache_dtype=torch.float32, encoder_autocast=torch.bfloat16).cuda().eval()
+    _perturb_norm_stats(pol)
+    if sharp:
+        with torch.no_grad():
+            for layer in pol.encoder.net.layers:
+                layer[0].module.Wqkv.weight[:256] *= 12.0  # q and k rows: scores x 144
+    env = get_env(env_name, generator_params=dict(num_loc=num_loc, device="cuda"), device="cuda")
+    td = env.reset(batch_size=[24])
+    with torch.inference_mode():
+        cache, hidden = pol._packed_encoder().encode(td, torch.float32, want_hidden=True)
+        h32, _ = pol.encoder(td)
+        ref = pol.decoder.precompute_cache(h32, torch.float32, torch.float32)
+        if sharp:  # the premise: scores beyond the fast path's bound do occur
+            qkv = pol.encoder.net.layers[0][0].module.Wqkv(pol.encoder.init_embedding(td))
+            q, k = qkv[..., :128].view(24, -1, 8, 16), qkv[..., 128:256].view(24, -1, 8, 16)
+            assert float((q.norm(dim=-1).amax(1) * k.norm(dim=-1).amax(1)).max()) * 0.25 * 1.4427 > 48.0
+    assert torch.isfinite(hidden).all()
+    tol = 5e-2 if sharp else REL_TOL  # one-hot attention amplifies bf16 score rounding into different winners
+    assert _rel(hidden, h32) <= tol, _rel(hidden, h32)
+    assert _rel(cache.kvl[2], ref.kvl[2]) <= tol
