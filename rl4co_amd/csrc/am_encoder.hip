@@ -51,12 +51,22 @@ __device__ inline f32x16 mfma(const bf16x8& a, const bf16x8& b, const f32x16& c)
 __device__ inline int rowmap(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
 // bias of the wave's 32-dim output tile in accumulator layout (transposed form: register r <-> dim rowmap(r, hi))
+// `bias` points into LDS (the layer's bqkv | b1, staged one layer ahead): the tile is the C operand of the GEMM's first
+// MFMA, so it must be there when the call starts — 16 global loads would put an L2 round trip in front of every call;
+// registers 4 c .. 4 c + 3 are four consecutive dims: four broadcast 16-byte LDS reads
 __device__ inline f32x16 bias_tile(const float* bias, int dim0, int hi) {
   f32x16 t;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) t[r] = bias[dim0 + rowmap(r, hi)];
+  for (int c = 0; c < 4; ++c) {
+    const float4 v = *reinterpret_cast<const float4*>(bias + dim0 + 8 * c + 4 * hi);
+    t[4 * c] = v.x;
+    t[4 * c + 1] = v.y;
+    t[4 * c + 2] = v.z;
+    t[4 * c + 3] = v.w;
+  }
   return t;
 }
+constexpr int kBiasFloats = 3 * kD + kFF;  // per layer: bqkv [384] | b1 [512]
 
 __device__ inline f32x16 zero16() {
   f32x16 z;
@@ -230,6 +240,11 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
   __bf16* xs = reinterpret_cast<__bf16*>(smem);  // residual stream [128][kRS]
   __bf16* ys = xs + 128 * kRS;                   // Q^T (wave-private columns) -> attention output -> FFN hidden chunk
   float* meanv = reinterpret_cast<float*>(ys + 128 * kRS);  // [128]
+  float* bl = meanv + kD;                                    // [kBiasFloats] this layer's bqkv | b1 (see bias_tile)
+  auto stage_biases = [&](int layer) {
+    for (int i = threadIdx.x; i < kBiasFloats; i += kThreads)
+      bl[i] = i < 3 * kD ? a.bqkv[layer * 3 * kD + i] : a.b1[layer * kFF + i - 3 * kD];
+  };
 
   const int tid = threadIdx.x;
   const int w = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -286,6 +301,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       xs[tok * kRS + d] = (__bf16)v;
     }
   }
+  stage_biases(0);
   __syncthreads();
 
   const __bf16* wqkv_all = static_cast<const __bf16*>(a.wqkv_packed);
@@ -302,8 +318,8 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
     L.wo = wo_all + (int64_t)layer * kD * kD;
     L.w1 = w1_all + (int64_t)layer * kFF * kD;
     L.w2 = w2_all + (int64_t)layer * kD * kFF;
-    L.bqkv = a.bqkv + layer * 3 * kD;
-    L.b1 = a.b1 + layer * kFF;
+    L.bqkv = bl;
+    L.b1 = bl + 3 * kD;
     L.n1a = a.n1_scale + layer * kD;
     L.n1b = a.n1_shift + layer * kD;
     L.n2a = a.n2_scale + layer * kD;
@@ -491,6 +507,8 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       }
       residual_norm<TT>(xs, y2, 32 * w, L.n2a, L.n2b, a.norm, N, lane);
     }
+    // every wave is past the last chunk's barriers, i.e. done with this layer's biases: the next layer's take their place
+    if (layer + 1 < a.num_layers) stage_biases(layer + 1);
     __syncthreads();
   }
 
@@ -577,7 +595,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
 
 template <int TT, int VR4>
 int launch_encoder(const rl4co_am_encoder_args& a, hipStream_t stream) {
-  const int lds = 2 * 128 * kRS * 2 + kD * 4;
+  const int lds = 2 * 128 * kRS * 2 + kD * 4 + kBiasFloats * 4;
   RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_encoder_kernel<TT, VR4>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipLaunchKernelGGL((am_encoder_kernel<TT, VR4>), dim3(a.B), dim3(kThreads), lds, stream, a);

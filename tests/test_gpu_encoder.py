@@ -167,7 +167,11 @@ def test_fused_encoder_rollout_quality_full_size():
     pol2 = _policy(g, encoder_autocast=torch.bfloat16, cache_dtype=torch.bfloat16, fused_encoder=False)
     with torch.inference_mode():
         out2 = pol2(td, env, phase="test")
-    assert abs(float(out2["reward"].mean() - out["reward"].mean())) <= 2e-3 * abs(float(g.reward.mean()))
+    # two bf16 evaluations of a random-init (near-uniform) policy are two chaotic greedy rollouts: over five fresh
+    # instance sets of 4096 the fused kernel's mean tour length sat 0.004 - 0.082 BELOW torch's bf16 autocast path and
+    # 0.03 - 0.10 above fp32 (tools/enc_quality.py, r02; its embeddings are closer to fp32 than autocast's: 4.75e-3 vs
+    # 5.26e-3 relative); on the golden set the gap is +0.080 the other way. Bound: 0.4 % between the two bf16 paths
+    assert abs(float(out2["reward"].mean() - out["reward"].mean())) <= 4e-3 * abs(float(g.reward.mean()))
 
 
 def test_fused_encoder_not_used_for_training_or_fp32():
