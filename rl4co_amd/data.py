@@ -10,6 +10,7 @@
 """
 from __future__ import annotations
 
+import math
 import os
 
 import numpy as np
@@ -227,6 +228,54 @@ def dihedral_8_augmentation(xy: Tensor) -> Tensor:
     return torch.cat([torch.cat(z, dim=2) for z in zs], dim=0)
 
 
+def dihedral_8_augmentation_wrapper(xy: Tensor, reduce: bool = True, *args, **kw) -> Tensor:
+    """transforms.py:41-46: with ``reduce`` only the first 1/8 of the (already batchified) rows is augmented."""
+    xy = xy[: xy.shape[0] // 8, ...] if reduce else xy
+    return dihedral_8_augmentation(xy)
+
+
+def symmetric_transform(x: Tensor, y: Tensor, phi: Tensor, offset: float = 0.5) -> Tensor:
+    """transforms.py:49-69 (SymNCO's rotation / reflection group, vectorised): rotate by ``phi`` about the centre of
+    the unit square and swap the axes where ``phi > 2 pi`` (half of the draws)."""
+    x, y = x - offset, y - offset
+    x_prime = torch.cos(phi) * x - torch.sin(phi) * y
+    y_prime = torch.sin(phi) * x + torch.cos(phi) * y
+    mask = phi > 2 * math.pi
+    xy = torch.cat((x_prime, y_prime), dim=-1)
+    xy = torch.where(mask, xy.flip(-1), xy)
+    return xy + offset
+
+
+def symmetric_augmentation(xy: Tensor, num_augment: int = 8, first_augment: bool = False, phi: Tensor | None = None) -> Tensor:
+    """transforms.py:72-87: one random angle in [0, 4 pi) per (batchified) row, drawn on ``xy``'s device from the
+    global generator — a CPU tensor consumes the reference's stream exactly; the first ``B / num_augment`` rows keep
+    ``phi = 0`` (the identity) unless ``first_augment``. ``phi`` injects the angles (parity tests on the GPU, whose
+    generator is not the CPU's)."""
+    if phi is None:
+        phi = torch.rand(xy.shape[0], device=xy.device) * 4 * math.pi
+    else:
+        phi = phi.to(device=xy.device, dtype=xy.dtype).clone()
+    if not first_augment:
+        phi[: xy.shape[0] // num_augment] = 0.0
+    x, y = xy[..., [0]], xy[..., [1]]
+    return symmetric_transform(x, y, phi[:, None, None])
+
+
+def min_max_normalize(x: Tensor) -> Tensor:
+    return (x - x.min()) / (x.max() - x.min())
+
+
+def get_augment_function(augment_fn):
+    """transforms.py:94-103"""
+    if callable(augment_fn):
+        return augment_fn
+    if augment_fn == "dihedral8":
+        return dihedral_8_augmentation_wrapper
+    if augment_fn == "symmetric":
+        return symmetric_augmentation
+    raise ValueError(f"Unknown augment_fn: {augment_fn}. Available options: 'symmetric', 'dihedral8' or a custom callable")
+
+
 def _batchify(td, n: int):
     """utils/ops.py:10-30 for the TensorDict stand-in / the real TensorDict."""
     bs = td.batch_size[0]
@@ -234,21 +283,32 @@ def _batchify(td, n: int):
 
 
 class StateAugmentation:
-    """transforms.py:105-151 with ``augment_fn="dihedral8"`` (POMO's default): the batch is
-    repeated 8 times (aug-major) and ``locs`` of block k gets the k-th symmetry."""
+    """transforms.py:105-151, argument for argument: the batch is repeated ``num_augment`` times (aug-major) and every
+    feature in ``feats`` is passed through ``augment_fn`` — "symmetric" (the default: random rotations / reflections,
+    first block the identity), "dihedral8" (POMO: the 8 symmetries of the square) or a callable
+    ``fn(batchified_feature, num_augment)``. Pure elementwise work on the device the instances live on."""
 
-    def __init__(self, num_augment: int = 8, augment_fn: str = "dihedral8", feats: list | None = None):
-        if augment_fn != "dihedral8":
-            raise NotImplementedError("only the dihedral-8 augmentation of POMO is on the accelerated path")
-        assert num_augment == 8, "When using the `dihedral8` augmentation function, then num_augment must be 8"
-        self.num_augment = num_augment
+    def __init__(self, num_augment: int = 8, augment_fn="symmetric", first_aug_identity: bool = True,
+                 normalize: bool = False, feats: list | None = None):
+        self.augmentation = get_augment_function(augment_fn)
+        assert not (self.augmentation == dihedral_8_augmentation_wrapper and num_augment != 8), (
+            "When using the `dihedral8` augmentation function, then num_augment must be 8")
         self.feats = ["locs"] if feats is None else feats
+        self.num_augment = num_augment
+        self.normalize = normalize
+        self.first_aug_identity = first_aug_identity
 
     def __call__(self, td):
         td_aug = _batchify(td, self.num_augment)
         for feat in self.feats:
-            x = td_aug[feat]
-            td_aug[feat] = dihedral_8_augmentation(x[: x.shape[0] // 8])  # the wrapper's reduce=True
+            if not self.first_aug_identity:  # (the reference's own indexing: row `batch size`, node 0)
+                init_aug_feat = td_aug[feat][list(td.size()), 0].clone()
+            aug_feat = self.augmentation(td_aug[feat], self.num_augment)
+            if self.normalize:
+                aug_feat = min_max_normalize(aug_feat)
+            if not self.first_aug_identity:
+                aug_feat[list(td.size()), 0] = init_aug_feat
+            td_aug[feat] = aug_feat
         return td_aug
 
 
@@ -272,13 +332,15 @@ def _gather_by_index(src: Tensor, idx: Tensor, dim: int) -> Tensor:
     return out.squeeze(dim) if idx.size(dim) == 1 else out
 
 
-def pomo_evaluate(policy, env, td, num_augment: int = 8, num_starts: int | None = None, phase: str = "test") -> dict:
-    """val/test branch of ``POMO.shared_step``: augment x8, multistart-greedy rollout, best start per
-    augmentation, best augmentation per instance. ``td`` is a reset state (``env.reset(batch)``)."""
+def pomo_evaluate(policy, env, td, num_augment: int = 8, num_starts: int | None = None, phase: str = "test",
+                  augment_fn="dihedral8", first_aug_identity: bool = True, feats: list | None = None) -> dict:
+    """val/test branch of ``POMO.shared_step``: augment (pomo/model.py:71-80 builds ``StateAugmentation(num_augment,
+    augment_fn, first_aug_identity, feats)`` with dihedral-8 as POMO's default), multistart-greedy rollout, best start
+    per augmentation, best augmentation per instance. ``td`` is a reset state (``env.reset(batch)``)."""
     n_aug = num_augment
     n_start = env.get_num_starts(td) if num_starts is None else num_starts
     if n_aug > 1:
-        td = StateAugmentation(num_augment=n_aug)(td)
+        td = StateAugmentation(num_augment=n_aug, augment_fn=augment_fn, first_aug_identity=first_aug_identity, feats=feats)(td)
     out = policy(td, env, phase=phase, num_starts=n_start)
     reward = _unbatchify(out["reward"], (n_aug, n_start))
     out["reward_per_aug_start"] = reward

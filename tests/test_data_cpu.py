@@ -60,11 +60,56 @@ def test_dihedral8_matches_reference_transform():
     tr = importlib.import_module("rl4co.data.transforms")
     TD = importlib.import_module("tensordict").TensorDict
     g = GoldenCase("tsp20_b64_greedy_simple")
-    ours = StateAugmentation(8)(_td(g))
+    ours = StateAugmentation(8, augment_fn="dihedral8")(_td(g))
     theirs = tr.StateAugmentation(num_augment=8, augment_fn="dihedral8")(TD({"locs": g.data["locs"].clone()}, batch_size=[g.batch]))
     assert torch.equal(ours["locs"], theirs["locs"])
     assert ours["locs"].shape == (8 * g.batch, 20, 2)
     assert torch.equal(ours["locs"][: g.batch], g.data["locs"])  # first block = identity
+
+
+@needs_reference
+@pytest.mark.parametrize("kw", [dict(num_augment=8), dict(num_augment=4, first_aug_identity=False),
+                                dict(num_augment=5, normalize=True), dict(num_augment=8, feats=["locs", "depot2"]),
+                                dict(num_augment=8, augment_fn="dihedral8", first_aug_identity=False)])
+def test_state_augmentation_matches_reference_transform(kw):
+    """rl4co/data/transforms.py:49-151 argument for argument: the symmetric (SymNCO) augmentation consumes the global
+    torch generator like the reference (same seed -> the same rows, bit for bit), first-block identity,
+    `first_aug_identity=False`'s own row restore, min-max normalisation, several features."""
+    import importlib
+
+    from rl4co_amd.data import StateAugmentation
+
+    ref_import.install()
+    tr = importlib.import_module("rl4co.data.transforms")
+    TD = importlib.import_module("tensordict").TensorDict
+    g = GoldenCase("tsp20_b64_greedy_simple")
+    data = {"locs": g.data["locs"].clone(), "depot2": g.data["locs"][:, :3].clone()}
+    torch.manual_seed(77)
+    ours = StateAugmentation(**kw)(__import__("rl4co_amd.tensordict", fromlist=["TensorDict"]).TensorDict(
+        {k: v.clone() for k, v in data.items()}, batch_size=[g.batch]))
+    torch.manual_seed(77)
+    theirs = tr.StateAugmentation(**kw)(TD({k: v.clone() for k, v in data.items()}, batch_size=[g.batch]))
+    for k in data:
+        assert ours[k].shape == theirs[k].shape == (kw["num_augment"] * g.batch, *data[k].shape[1:])
+        assert torch.equal(ours[k], theirs[k]), k
+
+
+def test_symmetric_augmentation_is_an_isometry_with_identity_first_block():
+    """Size-independent properties (also what the GPU test checks at full size): rotations / reflections about the
+    centre keep every pairwise distance; the first block is untouched; injected angles reproduce the draw."""
+    from rl4co_amd.data import symmetric_augmentation
+
+    torch.manual_seed(3)
+    xy = torch.rand(6, 30, 2).repeat(4, 1, 1)
+    torch.manual_seed(5)
+    out = symmetric_augmentation(xy, num_augment=4)
+    assert torch.equal(out[:6], xy[:6])
+    pd = lambda a: (a[:, :, None, :] - a[:, None, :, :]).norm(dim=-1)  # noqa: E731  (cdist's GEMM form cancels badly)
+    torch.testing.assert_close(pd(out), pd(xy), rtol=0, atol=2e-6)
+    assert not torch.allclose(out[6:], xy[6:])
+    torch.manual_seed(5)
+    phi = torch.rand(24) * 4 * 3.141592653589793
+    assert torch.equal(symmetric_augmentation(xy, num_augment=4, phi=phi), out)
 
 
 def test_pomo_evaluate_epilogue(cpu_device):
