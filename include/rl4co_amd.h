@@ -106,6 +106,13 @@ int rl4co_gather_by_index_f32(const float* src, const int64_t* idx, int B, int N
  * -------------------------------------------------------------------------- */
 int rl4co_tour_length_f32(const float* locs, const int64_t* actions, int B, int B_locs, int N,
                           int T, int prepend_depot, int negate, float* out, void* stream);
+/* Same arithmetic with the horizon read ON THE DEVICE: actions is a [B,row_stride] buffer whose first
+ * T = t_add + *steps_dev columns (clamped to row_stride) are the tour — steps_dev is word [0] of the decode launch's
+ * steps_summary. Lets the reward of a data-dependent horizon (CVRP) go out before the rollout's single read-back and
+ * inside a captured HIP graph; the row-sum association follows the real T exactly as above. */
+int rl4co_tour_length_dyn_f32(const float* locs, const int64_t* actions, int B, int B_locs, int N, int row_stride,
+                              const int32_t* steps_dev, int t_add, int prepend_depot, int negate, float* out,
+                              void* stream);
 
 /* --------------------------------------------------------------------------
  * a4  check_solution_validity   tsp/env.py:158-164, cvrp/env.py:149-177
@@ -303,6 +310,8 @@ typedef struct rl4co_am_decode_args {
   const float* exp_noise;   /* [max_steps,B,N] Exp(1) draws (parity mode) or NULL          */
   uint64_t philox_seed;     /* in-kernel Exp(1) noise when exp_noise == NULL               */
   uint64_t philox_offset;
+  const uint64_t* philox_seed_dev; /* optional device word XOR-ed into philox_seed at kernel entry: a captured HIP
+                                    * graph bakes the argument block, the word lets every replay draw fresh noise */
   const int64_t* forced_actions; /* [B,out_stride] for RL4CO_DECODE_EVALUATE               */
   /* outputs */
   int32_t t0;               /* column of the first step in actions/logps                   */

@@ -557,7 +557,7 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
         float key = lp;
         if (a->mode == RL4CO_DECODE_SAMPLE) {
           const float nz = a->exp_noise ? a->exp_noise[((int64_t)t * a->B + r) * N + j]
-                                        : rl4co_exp1_noise(a->philox_seed, a->philox_offset + (uint64_t)tcol,
+                                        : rl4co_exp1_noise(a->philox_seed ^ (a->philox_seed_dev ? *a->philox_seed_dev : 0ull), a->philox_offset + (uint64_t)tcol,
                                                            (uint32_t)r, (uint32_t)j);
           key = rl4co_expf(lp) / nz;
         }
@@ -782,7 +782,7 @@ int oracle_am_decode_ms(const rl4co_am_decode_args* a) {
         float key = z[j];
         if (a->mode == RL4CO_DECODE_SAMPLE) {
           const float nz = a->exp_noise ? a->exp_noise[((int64_t)t * a->B + r) * N + j]
-                                        : rl4co_exp1_noise(a->philox_seed, a->philox_offset + (uint64_t)tcol, (uint32_t)r, (uint32_t)j);
+                                        : rl4co_exp1_noise(a->philox_seed ^ (a->philox_seed_dev ? *a->philox_seed_dev : 0ull), a->philox_offset + (uint64_t)tcol, (uint32_t)r, (uint32_t)j);
           key = z[j] - logf(nz); /* argmax(p / Exp(1)) == argmax(z - log noise) */
         }
         if (bi < 0 || key > best) {

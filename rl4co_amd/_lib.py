@@ -72,7 +72,7 @@ class AmDecodeArgs(C.Structure):
         ("demand", _vp), ("used_capacity", _vp), ("vehicle_capacity", _vp), ("visited", _vp),
         ("locs", _vp), ("max_length", _vp), ("to_deliver", _vp),
         ("time_windows", _vp), ("durations", _vp), ("current_time", _vp), ("w_time", _vp),
-        ("exp_noise", _vp), ("philox_seed", C.c_uint64), ("philox_offset", C.c_uint64),
+        ("exp_noise", _vp), ("philox_seed", C.c_uint64), ("philox_offset", C.c_uint64), ("philox_seed_dev", _vp),
         ("forced_actions", _vp),
         ("t0", _i32), ("out_stride", _i32),
         ("actions", _vp), ("logps", _vp), ("all_logps", _vp), ("entropy", _vp),
@@ -86,6 +86,7 @@ SYMBOLS = {
     "rl4co_last_error": (C.c_char_p, []),
     "rl4co_gather_by_index_f32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "rl4co_tour_length_f32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_tour_length_dyn_f32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_tsp_check_solution": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_cvrp_check_solution": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_tsp_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),

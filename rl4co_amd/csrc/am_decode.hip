@@ -173,7 +173,8 @@ __device__ inline int finalize_and_step(const rl4co_am_decode_args& a, TrajState
     if (a.mode == RL4CO_DECODE_SAMPLE) {
       const float nz = a.exp_noise
                            ? a.exp_noise[((int64_t)t * a.B + r) * N + j]
-                           : rl4co_exp1_noise(a.philox_seed, a.philox_offset + (uint64_t)tcol, (uint32_t)r,
+                           : rl4co_exp1_noise(a.philox_seed ^ (a.philox_seed_dev ? *a.philox_seed_dev : 0ull),
+                                              a.philox_offset + (uint64_t)tcol, (uint32_t)r,
                                               (uint32_t)j);
       key = rl4co_expf(lp) / nz;  // multinomial(p,1) == argmax(p / Exp(1))
     }

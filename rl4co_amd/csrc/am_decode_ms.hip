@@ -351,7 +351,8 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
               lnz[i] = (node0 + i < N && x.ok) ? __logf(a.exp_noise[((int64_t)t * a.B + x.r) * N + node0 + i]) : 0.0f;
           } else {
             float uu4[4];
-            rl4co_uniform4(a.philox_seed, a.philox_offset + (uint64_t)tcol, (uint32_t)x.r, (uint32_t)(node0 >> 2), uu4);
+            rl4co_uniform4(a.philox_seed ^ (a.philox_seed_dev ? *a.philox_seed_dev : 0ull), a.philox_offset + (uint64_t)tcol,
+                           (uint32_t)x.r, (uint32_t)(node0 >> 2), uu4);
 #pragma unroll
             for (int i = 0; i < 4; ++i) lnz[i] = __logf(-__logf(uu4[i]));
           }

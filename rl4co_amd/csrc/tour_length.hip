@@ -84,16 +84,22 @@ __global__ void __launch_bounds__(256) tour_length_kernel(const float* __restric
                                                           int B, int B_locs, int N, int T,
                                                           int prepend, int negate,
                                                           float* __restrict__ out,
-                                                          const float* __restrict__ gather_values) {
+                                                          const float* __restrict__ gather_values,
+                                                          int row_stride, const int32_t* __restrict__ t_dev, int t_add) {
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = gid >> 3;
   const int lane8 = gid & 7;
   const bool active = b < B;
+  // device-side horizon (rl4co_tour_length_dyn_f32): the tour length of a rollout whose step count the HOST does not
+  // know yet — T = t_add + *t_dev, what the decode launch left in its steps summary — so the reward can be issued
+  // before the one read-back of the rollout (and inside a captured HIP graph). The association of the row sum depends
+  // on T, so it has to be the real one: summing the padded buffer is not the reference's arithmetic.
+  if (t_dev) T = min(row_stride, t_add + *t_dev);
   TourView tv;
   tv.prepend = prepend;
   tv.n = T + prepend;
   tv.locs = locs ? locs + (int64_t)(active ? b % B_locs : 0) * N * 2 : nullptr;
-  tv.actions = actions + (int64_t)(active ? b : 0) * T;
+  tv.actions = actions + (int64_t)(active ? b : 0) * row_stride;
   // OPEnv._get_reward (op/env.py:156-166): the same inner-dim sum over prize.gather(1, actions)
   tv.values = gather_values ? gather_values + (int64_t)(active ? b % B_locs : 0) * N : nullptr;
   const int n = tv.n;
@@ -246,7 +252,22 @@ extern "C" int rl4co_tour_length_f32(const float* locs, const int64_t* actions, 
   const int blocks = (int)((total + threads - 1) / threads);
   hipLaunchKernelGGL(tour_length_kernel, dim3(blocks), dim3(threads), 0, rl4co::as_stream(stream),
                      locs, actions, B, B_locs, N, T, prepend_depot ? 1 : 0, negate ? 1 : 0, out,
-                     static_cast<const float*>(nullptr));
+                     static_cast<const float*>(nullptr), T, static_cast<const int32_t*>(nullptr), 0);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
+extern "C" int rl4co_tour_length_dyn_f32(const float* locs, const int64_t* actions, int B, int B_locs, int N, int row_stride,
+                                         const int32_t* steps_dev, int t_add, int prepend_depot, int negate, float* out,
+                                         void* stream) {
+  RL4CO_REQUIRE(locs && actions && out && steps_dev);
+  RL4CO_REQUIRE(B > 0 && B_locs > 0 && B % B_locs == 0 && N > 0 && row_stride > 0 && t_add >= 0);
+  const int threads = 256;
+  const int64_t total = (int64_t)B * 8;
+  const int blocks = (int)((total + threads - 1) / threads);
+  hipLaunchKernelGGL(tour_length_kernel, dim3(blocks), dim3(threads), 0, rl4co::as_stream(stream), locs, actions, B, B_locs, N,
+                     row_stride, prepend_depot ? 1 : 0, negate ? 1 : 0, out, static_cast<const float*>(nullptr), row_stride,
+                     steps_dev, t_add);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }
@@ -259,7 +280,8 @@ extern "C" int rl4co_gather_sum_f32(const float* values, const int64_t* actions,
   const int64_t total = (int64_t)B * 8;
   const int blocks = (int)((total + threads - 1) / threads);
   hipLaunchKernelGGL(tour_length_kernel, dim3(blocks), dim3(threads), 0, rl4co::as_stream(stream),
-                     static_cast<const float*>(nullptr), actions, B, B_values, N, T, 0, 0, out, values);
+                     static_cast<const float*>(nullptr), actions, B, B_values, N, T, 0, 0, out, values, T,
+                     static_cast<const int32_t*>(nullptr), 0);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }

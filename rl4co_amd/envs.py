@@ -265,11 +265,13 @@ class RL4COEnvBase:
         return {"next": self._step(td)}
 
     # -- RL4COEnvBase.get_reward (base.py:180-190) ------------------------------------------------
-    def get_reward(self, td: TensorDict, actions: Tensor, check_solution: bool | None = None) -> Tensor:
+    def get_reward(self, td: TensorDict, actions: Tensor, check_solution: bool | None = None, horizon=None) -> Tensor:
+        """``horizon = (steps_dev, t_add)`` (tour-length environments): ``actions`` is a padded buffer whose real
+        length the device knows (kernels.tour_length) — the policy's way to issue the reward before its read-back."""
         check_solution = self.check_solution if check_solution is None else check_solution
         if check_solution:
             self.check_solution_validity(td, actions)
-        return self._get_reward(td, actions)
+        return self._get_reward(td, actions) if horizon is None else self._get_reward(td, actions, horizon=horizon)
 
     # -- RL4COEnvBase.dataset / load_data (base.py:234-286) ----------------------------------------
     def dataset(self, batch_size=(), phase: str = "train", filename: str | None = None):
@@ -362,9 +364,9 @@ class TSPEnv(RL4COEnvBase):
                    td["i"], td["done"])
         return td
 
-    def _get_reward(self, td: TensorDict, actions: Tensor) -> Tensor:
+    def _get_reward(self, td: TensorDict, actions: Tensor, horizon=None) -> Tensor:
         """tsp/env.py:150-156"""
-        return K.tour_length(td["locs"].contiguous(), actions.contiguous(), prepend_depot=False, negate=True)
+        return K.tour_length(td["locs"].contiguous(), actions.contiguous(), prepend_depot=False, negate=True, horizon=horizon)
 
     def check_solution_validity(self, td: TensorDict, actions: Tensor, err: Tensor | None = None) -> None:
         """tsp/env.py:158-164. With ``err`` the violation bits are OR-ed into the caller's error
@@ -425,9 +427,9 @@ class CVRPEnv(RL4COEnvBase):
         td.set("demand", td["demand"] / td["capacity"][:, None])
         return td
 
-    def _get_reward(self, td: TensorDict, actions: Tensor) -> Tensor:
+    def _get_reward(self, td: TensorDict, actions: Tensor, horizon=None) -> Tensor:
         """cvrp/env.py:138-147"""
-        return K.tour_length(td["locs"].contiguous(), actions.contiguous(), prepend_depot=True, negate=True)
+        return K.tour_length(td["locs"].contiguous(), actions.contiguous(), prepend_depot=True, negate=True, horizon=horizon)
 
     def check_solution_validity(self, td: TensorDict, actions: Tensor, err: Tensor | None = None) -> None:
         """cvrp/env.py:149-177 (trailing depot padding is neutral). ``err``: see TSPEnv."""
@@ -712,9 +714,9 @@ class PDPEnv(RL4COEnvBase):
         K.pdp_step(None, td["available"], td["to_deliver"], td["current_node"], td["i"], td["action_mask"], td["done"])
         return td["action_mask"]
 
-    def _get_reward(self, td: TensorDict, actions: Tensor) -> Tensor:
+    def _get_reward(self, td: TensorDict, actions: Tensor, horizon=None) -> Tensor:
         """pdp/env.py:191-202"""
-        return K.tour_length(td["locs"].contiguous(), actions.contiguous(), prepend_depot=True, negate=True)
+        return K.tour_length(td["locs"].contiguous(), actions.contiguous(), prepend_depot=True, negate=True, horizon=horizon)
 
     def check_solution_validity(self, td: TensorDict, actions: Tensor, err: Tensor | None = None) -> None:
         """pdp/env.py:204-223. ``err``: see TSPEnv."""

@@ -1,0 +1,87 @@
+"""The whole rollout as ONE captured HIP graph (`GraphedRollout`) — removes the host from between the kernels.
+
+An inference rollout is a fixed sequence of launches whose arguments do not depend on the data: reset-state fills, the
+fused encoder, state clones, the persistent decode launch, the validity check, the reward (its horizon is read on the
+device, ``kernels.tour_length(horizon=)``) — and then ONE read-back. Issued from Python that sequence costs ~150 us of
+GPU idle time per TSP-100 x 4096 rollout (17 dispatches; measured with tools/gap_summary.py: 5 % of the step). Captured
+once with ``torch.cuda.graph`` (= hipStreamBeginCapture on the stream every ``rl4co_*`` entry point launches on) and
+replayed with one ``hipGraphLaunch``, the dispatches run back to back; the host only copies the new instances into the
+graph's static input buffer, replays, and reads the 16-byte status word.
+
+    rollout = GraphedRollout(policy, env, example_batch, decode_type="greedy")
+    out = rollout(batch)          # same dict as policy(env.reset(batch), env, phase="test", decode_type=...)
+
+Semantics (those of every CUDA/HIP-graph wrapper): the returned tensors are views of buffers the graph owns and are
+overwritten by the next call — clone what must outlive it; shapes, decode arguments and the policy's weights VALUES may
+change between calls only in ways a fixed launch sequence tolerates (new weight values: the packed encoder buffers are
+refreshed in place before the replay; a different batch shape: a new capture). Sampling draws fresh noise on every
+replay through a device-resident seed word (``rl4co_am_decode_args.philox_seed_dev``). Inference only (no autograd).
+"""
+from __future__ import annotations
+
+import torch
+
+from .tensordict import TensorDict
+
+
+class GraphedRollout:
+    def __init__(self, policy, env, example, decode_type: str = "greedy", warmup: int = 2, **forward_kwargs):
+        if not example["locs"].is_cuda:
+            raise RuntimeError("GraphedRollout needs CUDA tensors (HIP graph capture)")
+        self.policy, self.env = policy, env
+        self.decode_type = decode_type
+        self.kw = dict(forward_kwargs)
+        self.batch = example.batch_size[0]
+        dev = example["locs"].device
+        # static input buffers: the graph reads the instances from here
+        self.static_in = TensorDict({k: v.clone() for k, v in example.items() if torch.is_tensor(v)}, batch_size=[self.batch])
+        self.seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._calls = 0
+        packed = getattr(policy, "_packed_encoder", None)
+        if packed is not None:
+            policy._packed_encoder().refresh()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.inference_mode():
+            for _ in range(max(1, warmup)):  # library init, hipFuncSetAttribute, allocator warm-up outside the capture
+                self._enqueue()()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self._packed_version = self._weights_version()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.inference_mode(), torch.cuda.graph(self.graph):
+            self._finish = self._enqueue()
+
+    def _enqueue(self):
+        td = self.env.reset(self.static_in)
+        return self.policy(td, self.env, phase="test", decode_type=self.decode_type, philox_seed_dev=self.seed_dev,
+                           _defer_finish=True, **self.kw)
+
+    def _weights_version(self):
+        pe = self.policy._packed_encoder()
+        return pe._current_version()
+
+    def __call__(self, batch) -> dict:
+        if batch.batch_size[0] != self.batch:
+            raise ValueError(f"captured for {self.batch} instances, got {batch.batch_size[0]}")
+        with torch.inference_mode():
+            for k, v in self.static_in.items():
+                src = batch[k]
+                if src.data_ptr() != v.data_ptr():
+                    v.copy_(src)
+            # new weight values: re-pack INTO the buffers the captured launches point at
+            ver = self._weights_version()
+            if ver != self._packed_version:
+                pe = self.policy._packed_encoder()
+                old = dict(pe.t)
+                pe.refresh()
+                for k, t_new in pe.t.items():
+                    t_old = old.get(k)
+                    if torch.is_tensor(t_old) and torch.is_tensor(t_new) and t_old.data_ptr() != t_new.data_ptr():
+                        t_old.copy_(t_new)
+                        pe.t[k] = t_old
+                self._packed_version = ver
+            self._calls += 1
+            self.seed_dev.fill_(self._calls * 0x9E3779B97F4A7C15 % (1 << 62))
+            self.graph.replay()
+            return self._finish()

@@ -99,15 +99,24 @@ def gather_by_index(src: Tensor, idx: Tensor, err: Tensor | None = None) -> Tens
     return out
 
 
-def tour_length(locs: Tensor, actions: Tensor, prepend_depot: bool = False, negate: bool = False) -> Tensor:
+def tour_length(locs: Tensor, actions: Tensor, prepend_depot: bool = False, negate: bool = False,
+                horizon: tuple[Tensor, int] | None = None) -> Tensor:
     """ops.py:82-90 over gather(locs, actions) (+ depot for CVRP, cvrp/env.py:138-147).
 
-    locs [B_locs,N,2] fp32 with B % B_locs == 0 (s-major multistart), actions [B,T] int64."""
+    locs [B_locs,N,2] fp32 with B % B_locs == 0 (s-major multistart), actions [B,T] int64.
+    ``horizon = (steps_dev, t_add)``: the tour is the first ``t_add + steps_dev[0]`` columns of the (padded) buffer,
+    the count read on the device (rl4co_tour_length_dyn_f32) — no host value needed."""
     _dev(locs, torch.float32, "locs"), _dev(actions, torch.int64, "actions")
     b, t = actions.shape
     b_locs, n, two = locs.shape
     assert two == 2
     out = torch.empty((b,), dtype=torch.float32, device=locs.device)
+    if horizon is not None:
+        steps_dev, t_add = horizon
+        st = _lib.lib().rl4co_tour_length_dyn_f32(_ptr(locs), _ptr(actions), b, b_locs, n, t, _ptr(_dev(steps_dev, torch.int32, "steps")),
+                                                  int(t_add), int(prepend_depot), int(negate), _ptr(out), _stream())
+        _lib.check(st, "rl4co_tour_length_dyn_f32")
+        return out
     st = _lib.lib().rl4co_tour_length_f32(
         _ptr(locs), _ptr(actions), b, b_locs, n, t, int(prepend_depot), int(negate), _ptr(out), _stream()
     )
@@ -194,6 +203,7 @@ def am_decode(
     exp_noise: Tensor | None = None,
     philox_seed: int = 0,
     philox_offset: int = 0,
+    philox_seed_dev: Tensor | None = None,
     forced_actions: Tensor | None = None,
     all_logps: Tensor | None = None,
     entropy: Tensor | None = None,
@@ -290,6 +300,8 @@ def am_decode(
         assert exp_noise.numel() >= max_steps * b * n, "exp_noise must hold [max_steps,B,N] draws"
         a.exp_noise = _ptr(exp_noise)
     a.philox_seed, a.philox_offset = int(philox_seed), int(philox_offset)
+    if philox_seed_dev is not None:
+        a.philox_seed_dev = _ptr(_dev(philox_seed_dev, torch.int64, "philox_seed_dev"))
     if forced_actions is not None:
         _dev(forced_actions, torch.int64, "forced_actions")
         assert forced_actions.shape == actions.shape

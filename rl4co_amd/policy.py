@@ -732,13 +732,14 @@ class AttentionModelPolicy(nn.Module):
             philox_seed = int(seed) if seed is not None else int(torch.randint(0, 2**62, (1,)).item())
         else:
             philox_seed = 0
+        seed_dev = decoding_kwargs.pop("philox_seed_dev", None)  # graph.GraphedRollout: fresh noise per replay
         if self.decode_events is not None:  # bench.py: HIP events around the decode kernel launch
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             ev0.record()
         K.am_decode(
             cache, state, mode=mode, max_steps=tmax - t0, t0=t0, actions=out_actions, logps=logps, err=err,
             tanh_clipping=tanh_clipping, temperature=temperature, mask_inner=self.decoder.mask_inner,
-            mask_logits=mask_logits, exp_noise=exp_noise, philox_seed=philox_seed,
+            mask_logits=mask_logits, exp_noise=exp_noise, philox_seed=philox_seed, philox_seed_dev=seed_dev,
             forced_actions=forced, all_logps=all_logps, steps_summary=status[1:4],
         )
         if self.decode_events is not None:
@@ -752,106 +753,115 @@ class AttentionModelPolicy(nn.Module):
         checked = bool(native_env and calc_reward and env.check_solution and not (n_rep > 0 and select_best))
         if checked:
             env.check_solution_validity(td, out_actions, err=err)
-        # TSP / PDP take exactly `tmax` steps, so the action buffer is the tour: the reward goes out before
-        # the read-back instead of after it (with a ragged horizon the buffer's trailing zeros would change
-        # the association of the reference-ordered sums, so every other environment waits for the horizon)
+        # tour-length environments: the reward goes out BEFORE the read-back. The buffer is padded to the longest
+        # possible rollout and trailing zeros would change the association of the reference-ordered sums, so the kernel
+        # takes the real horizon from the device (the decode launch's own step count, kernels.tour_length(horizon=))
         td_early = reward_early = None
-        if native_env and self.env_name in ("tsp", "pdp") and calc_reward and not (n_rep > 0 and select_best):
+        if (native_env and self.env_name in ("tsp", "pdp", "cvrp", "cvrptw") and calc_reward and mode != "evaluate"
+                and (checked or not env.check_solution) and not (n_rep > 0 and select_best)):
             td_early = self._final_td(td, state, n_rep)
-            td_early.set("action", out_actions[:, -1])
-            reward_early = env.get_reward(td_early, out_actions, check_solution=False if checked else None)
+            reward_early = env.get_reward(td_early, out_actions, check_solution=False, horizon=(status[1:2], t0))
         if self._bwd_err is not None:  # sticky bits of the previous step's backward kernel ride on this read-back
             status[:1].bitwise_or_(self._bwd_err)
             self._bwd_err = None
-        err_bits, horizon_used, streamed, rows_read = status.tolist()  # one 16-byte read-back, no reduction launches
-        t_used = t0 + int(horizon_used)
-        self.last_instance_steps = int(streamed)  # instance-steps the decode launch really streamed
-        self.last_rows_read = int(rows_read)      # cache rows (per plane) it read from HBM doing so
-        from . import _lib as _l
+        # everything above only ENQUEUES device work; `finish` performs the rollout's one host read-back and assembles the
+        # reference's output dict. graph.GraphedRollout captures the part above in a HIP graph and calls `finish` after
+        # every replay (it only reads the buffers the launches wrote).
+        defer = bool(decoding_kwargs.pop("_defer_finish", False))
+        launched = (out_actions, logps, all_logps, td_early, reward_early)
 
-        _l.raise_for_error_bits(int(err_bits))
-        out_actions = out_actions[:, :t_used].contiguous()
-        logps = logps[:, :t_used]
-        if all_logps is not None:
-            all_logps = all_logps[:, :t_used]
+        def finish():
+            nonlocal out_actions, logps, all_logps, td_early, reward_early
+            out_actions, logps, all_logps, td_early, reward_early = launched  # re-runnable: a graph replay refills the same buffers
+            err_bits, horizon_used, streamed, rows_read = status.tolist()  # one 16-byte read-back, no reduction launches
+            t_used = t0 + int(horizon_used)
+            self.last_instance_steps = int(streamed)  # instance-steps the decode launch really streamed
+            self.last_rows_read = int(rows_read)      # cache rows (per plane) it read from HBM doing so
+            from . import _lib as _l
 
-        # td mirrors the reference's final state (batchified rows when multistart)
-        if reward_early is not None and t_used != tmax:  # cut short by max_steps: the early reward saw padding
-            td_early = reward_early = None
-        td_out = td_early if td_early is not None else self._final_td(td, state, n_rep)
-        td_out.set("action", out_actions[:, -1])
-
-        # differentiable re-evaluation of the ROLLED-OUT rows (all s * b_inst of them: the replay needs the imposed
-        # start nodes and the batchified state) — before any best-of selection narrows the rows
-        full_logp = None  # [B, T, N] differentiable log-softmax, only when a differentiable entropy is asked for
-        if grad_path and cache_g is not None:
-            from . import teacher
-
-            if self._bwd_err is None:
-                self._bwd_err = torch.zeros(1, dtype=torch.int32, device=device)
-            meta = dict(t0=t0, mask_inner=self.decoder.mask_inner, mask_logits=mask_logits, err_sink=self._bwd_err,
-                        tanh_clipping=tanh_clipping, temperature=temperature, teacher_variant=self.teacher_variant)
-            if self.env_name in ("cvrp", "cvrptw"):
-                meta.update(demand=td["demand"], vehicle_capacity=td["vehicle_capacity"])
-                if self.env_name == "cvrptw":
-                    meta.update(locs=td["locs"], time_windows=td["time_windows"], durations=td["durations"])
-            elif self.env_name == "op":
-                meta.update(locs=td["locs"], max_length=td["max_length"])
-            elif self.env_name == "pctsp":
-                meta.update(real_prize=td["real_prize"], prize_required=td["prize_required"])
-            step_logps = teacher.teacher_forced_logps(self.env_name, cache_g, cache, out_actions, logps, meta)
-        elif grad_path:
-            step_logps = self.evaluate_log_probs(td, hidden, out_actions, n_rep, tanh_clipping, temperature,
-                                                 mask_logits, skip_first=(t0 == 1), return_full=return_entropy)
-            if return_entropy:
-                step_logps, full_logp = step_logps
-        else:
-            step_logps = logps
-
-        if n_rep > 0 and select_best:
-            rewards = env.get_reward(td_out, out_actions)
-            best = rewards.view(n_rep, b_inst).transpose(0, 1).max(dim=-1)[1]  # unbatchify + max
-            rows = best * b_inst + torch.arange(b_inst, device=device)
-            out_actions, logps, step_logps = out_actions[rows], logps[rows], step_logps[rows]
+            _l.raise_for_error_bits(int(err_bits))
+            out_actions = out_actions[:, :t_used].contiguous()
+            logps = logps[:, :t_used]
             if all_logps is not None:
-                all_logps = all_logps[rows]
-            if full_logp is not None:
-                full_logp = full_logp[rows]
-            td_out = td_out[rows] if hasattr(td_out, "__getitem__") else td_out
-            reward = rewards[rows] if calc_reward else None
-        elif reward_early is not None:
-            reward = reward_early
-        else:
-            reward = (env.get_reward(td_out, out_actions, check_solution=False if checked else None)
-                      if calc_reward else td_out.get("reward", None))
-        if calc_reward:
-            td_out.set("reward", reward)
-        # decoding.py:56: on the kernel path this is the RL4CO_EBIT_NEG_INF_LOGP sticky bit (already
-        # raised above); only the autograd re-evaluation needs its own check
-        if grad_path and not bool((step_logps.detach() > -1000).all()):
-            raise AssertionError("Logprobs should not be -inf, check sampling procedure!")
-        outdict = {
-            "reward": reward,
-            "log_likelihood": step_logps.sum(1) if return_sum_log_likelihood else step_logps,
-        }
-        if return_actions:
-            outdict["actions"] = out_actions
-        if return_entropy:
-            # ops.py:103-111 on the [B, T, N] log-probs. Under autograd the reference's entropy carries history (PPO's
-            # entropy bonus differentiates it): then it is built from the differentiable log-softmax of the
-            # re-evaluation, not from the kernel's (history-free) all_logps; the imposed multistart step has p = 1
-            lp_src = all_logps
-            if full_logp is not None:
-                lp_src = full_logp if t0 == 0 else torch.cat([all_logps[:, :1], full_logp[:, 1:]], 1)
-            lp = torch.nan_to_num(lp_src, nan=0.0)
-            entropy = -(lp.exp() * lp).sum(dim=-1).sum(dim=1)
-            assert entropy.isfinite().all(), "Entropy is not finite"
-            outdict["entropy"] = entropy
-        if return_hidden:
-            outdict["hidden"] = hidden
-        if return_init_embeds:
-            outdict["init_embeds"] = init_embeds
-        return outdict
+                all_logps = all_logps[:, :t_used]
+
+            # td mirrors the reference's final state (batchified rows when multistart)
+            td_out = td_early if td_early is not None else self._final_td(td, state, n_rep)
+            td_out.set("action", out_actions[:, -1])
+
+            # differentiable re-evaluation of the ROLLED-OUT rows (all s * b_inst of them: the replay needs the imposed
+            # start nodes and the batchified state) — before any best-of selection narrows the rows
+            full_logp = None  # [B, T, N] differentiable log-softmax, only when a differentiable entropy is asked for
+            if grad_path and cache_g is not None:
+                from . import teacher
+
+                if self._bwd_err is None:
+                    self._bwd_err = torch.zeros(1, dtype=torch.int32, device=device)
+                meta = dict(t0=t0, mask_inner=self.decoder.mask_inner, mask_logits=mask_logits, err_sink=self._bwd_err,
+                            tanh_clipping=tanh_clipping, temperature=temperature, teacher_variant=self.teacher_variant)
+                if self.env_name in ("cvrp", "cvrptw"):
+                    meta.update(demand=td["demand"], vehicle_capacity=td["vehicle_capacity"])
+                    if self.env_name == "cvrptw":
+                        meta.update(locs=td["locs"], time_windows=td["time_windows"], durations=td["durations"])
+                elif self.env_name == "op":
+                    meta.update(locs=td["locs"], max_length=td["max_length"])
+                elif self.env_name == "pctsp":
+                    meta.update(real_prize=td["real_prize"], prize_required=td["prize_required"])
+                step_logps = teacher.teacher_forced_logps(self.env_name, cache_g, cache, out_actions, logps, meta)
+            elif grad_path:
+                step_logps = self.evaluate_log_probs(td, hidden, out_actions, n_rep, tanh_clipping, temperature,
+                                                     mask_logits, skip_first=(t0 == 1), return_full=return_entropy)
+                if return_entropy:
+                    step_logps, full_logp = step_logps
+            else:
+                step_logps = logps
+
+            if n_rep > 0 and select_best:
+                rewards = env.get_reward(td_out, out_actions)
+                best = rewards.view(n_rep, b_inst).transpose(0, 1).max(dim=-1)[1]  # unbatchify + max
+                rows = best * b_inst + torch.arange(b_inst, device=device)
+                out_actions, logps, step_logps = out_actions[rows], logps[rows], step_logps[rows]
+                if all_logps is not None:
+                    all_logps = all_logps[rows]
+                if full_logp is not None:
+                    full_logp = full_logp[rows]
+                td_out = td_out[rows] if hasattr(td_out, "__getitem__") else td_out
+                reward = rewards[rows] if calc_reward else None
+            elif reward_early is not None:
+                reward = reward_early
+            else:
+                reward = (env.get_reward(td_out, out_actions, check_solution=False if checked else None)
+                          if calc_reward else td_out.get("reward", None))
+            if calc_reward:
+                td_out.set("reward", reward)
+            # decoding.py:56: on the kernel path this is the RL4CO_EBIT_NEG_INF_LOGP sticky bit (already
+            # raised above); only the autograd re-evaluation needs its own check
+            if grad_path and not bool((step_logps.detach() > -1000).all()):
+                raise AssertionError("Logprobs should not be -inf, check sampling procedure!")
+            outdict = {
+                "reward": reward,
+                "log_likelihood": step_logps.sum(1) if return_sum_log_likelihood else step_logps,
+            }
+            if return_actions:
+                outdict["actions"] = out_actions
+            if return_entropy:
+                # ops.py:103-111 on the [B, T, N] log-probs. Under autograd the reference's entropy carries history (PPO's
+                # entropy bonus differentiates it): then it is built from the differentiable log-softmax of the
+                # re-evaluation, not from the kernel's (history-free) all_logps; the imposed multistart step has p = 1
+                lp_src = all_logps
+                if full_logp is not None:
+                    lp_src = full_logp if t0 == 0 else torch.cat([all_logps[:, :1], full_logp[:, 1:]], 1)
+                lp = torch.nan_to_num(lp_src, nan=0.0)
+                entropy = -(lp.exp() * lp).sum(dim=-1).sum(dim=1)
+                assert entropy.isfinite().all(), "Entropy is not finite"
+                outdict["entropy"] = entropy
+            if return_hidden:
+                outdict["hidden"] = hidden
+            if return_init_embeds:
+                outdict["init_embeds"] = init_embeds
+            return outdict
+
+        return finish if defer else finish()
 
     def check_backward_errors(self) -> None:
         """Raise the reference's assertion for any sticky bit the LAST teacher-forced backward kernel set (a sync).

@@ -13,7 +13,10 @@ import torch
 from oracle import c_oracle
 
 
-def _tour_length(locs, actions, prepend_depot=False, negate=False):
+def _tour_length(locs, actions, prepend_depot=False, negate=False, horizon=None):
+    if horizon is not None:  # device-side horizon: on this stand-in "device" the count is simply readable
+        steps, t_add = horizon
+        actions = actions[:, : min(actions.shape[1], int(t_add) + int(steps[0]))]
     return c_oracle.tour_length(locs.contiguous(), actions.contiguous(), prepend_depot, negate)
 
 
@@ -124,6 +127,7 @@ def _am_decode(cache, state, **kw):
     from rl4co_amd import _lib
 
     variant = {"auto": 0, "stream": 1, "lds": 2, "wide": 3, "ms": 4}[kw.pop("variant", "auto")]
+    kw.pop("philox_seed_dev", None)
     dt = _lib.DT_BF16 if cache.kvl.dtype == torch.bfloat16 else _lib.DT_F32
     b = state["action_mask"].shape[0]
     groups = _lib.decode_row_groups(cache.num_nodes, dt, kw["max_steps"], variant, b, cache.num_instances)  # host-only
