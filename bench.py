@@ -213,11 +213,40 @@ class Bench:
 
         log(f"{leg}: rank {self.rank}/{self.world}, {batch} instances resident, warming up")
         rows = inst_steps = 0
+        use_graph = a.launch == "graph"
         with torch.inference_mode():
             for _ in range(warmup):
                 out = step()
             torch.cuda.synchronize()
-            policy.decode_events, policy.encode_events = [], []
+            eager_ms = None
+            if use_graph:
+                # kernel durations for the roofline: an eager pass with HIP events around the two big launches (events
+                # cannot bracket nodes of a captured graph); the timed region below replays the SAME launches as one graph
+                ev_steps = max(10, steps // 8)
+                policy.decode_events, policy.encode_events = [], []
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(ev_steps):
+                    step()
+                torch.cuda.synchronize()
+                eager_ms = (time.perf_counter() - t0) / ev_steps * 1e3
+                decode_ms = [x.elapsed_time(y) for x, y in policy.decode_events]
+                encode_ms = [x.elapsed_time(y) for x, y in policy.encode_events]
+                policy.decode_events = policy.encode_events = None
+                from rl4co_amd.graph import GraphedRollout
+
+                try:
+                    graphed = GraphedRollout(policy, env, data, decode_type=decode)
+                    step = lambda: graphed(data)  # noqa: E731
+                    for _ in range(2):
+                        out = step()
+                except Exception as exc:  # a launch sequence that cannot be captured stays on the eager path, said so
+                    log(f"{leg}: HIP graph capture failed ({type(exc).__name__}: {exc}); timing the eager path")
+                    use_graph = False
+                    torch.cuda.synchronize()
+                    policy.decode_events, policy.encode_events = [], []
+            else:
+                policy.decode_events, policy.encode_events = [], []
             self.barrier()
             t0 = time.perf_counter()
             for _ in range(steps):
@@ -226,9 +255,10 @@ class Bench:
                 inst_steps += policy.last_instance_steps
             self.barrier()
             wall = time.perf_counter() - t0
-        decode_ms = [x.elapsed_time(y) for x, y in policy.decode_events]
-        encode_ms = [x.elapsed_time(y) for x, y in policy.encode_events]
-        policy.decode_events = policy.encode_events = None
+        if not use_graph:
+            decode_ms = [x.elapsed_time(y) for x, y in policy.decode_events]
+            encode_ms = [x.elapsed_time(y) for x, y in policy.encode_events]
+            policy.decode_events = policy.encode_events = None
         t_steps = out["actions"].shape[1]
         n_nodes = num_loc + (0 if env_name == "tsp" else 1)
         wall = self.D.reduce_scalar(wall, "max", self.device)
@@ -250,6 +280,9 @@ class Bench:
                          f"AttentionModel(3L,d128,h8) {decode} rollout, {a.encoder_dtype} encoder GEMMs, {a.cache_dtype} cache"),
             "value": value, "unit": "instance·step/s", "steps": steps, "warmup": warmup,
             "ms_per_step": wall / steps * 1e3,
+            "launch": ("hip_graph: reset + encoder + decode + check + reward captured once, one hipGraphLaunch and one "
+                       "16-byte read-back per step (rl4co_amd/graph.py)") if use_graph else "eager: one host launch per kernel",
+            "eager_ms_per_step": eager_ms,
             "node_steps_per_sec": value * n_nodes,
             "instances_per_sec": batch * self.world * steps / wall,
             "decode_steps_longest": t_steps, "instance_steps_per_launch": per_launch_steps,
@@ -434,6 +467,8 @@ def main() -> None:
     ap.add_argument("--encoder-dtype", default="bf16", choices=["bf16", "f32"],
                     help="GEMM/attention input type of the encoder and cache-fold GEMMs (bf16 = MFMA rate, the "
                          "reference's mixed-precision regime; f32 = the parity configuration)")
+    ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
+                    help="inference legs: replay the rollout as one captured HIP graph (default) or launch kernel by kernel")
     ap.add_argument("--no-check-solution", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -523,7 +558,8 @@ def main() -> None:
                 "check_solution": not args.no_check_solution, "parallelism": f"replicas x{world} (instances sharded)",
             },
         }
-        for k in ("node_steps_per_sec", "instances_per_sec", "mean_reward", "roofline", "encoder_roofline", "host_gap_ms",
+        for k in ("node_steps_per_sec", "instances_per_sec", "mean_reward", "roofline", "encoder_roofline", "host_gap_ms", "launch",
+                  "eager_ms_per_step",
                   "trajectories_per_sec", "collective"):
             if k in head:
                 line[k] = head[k]

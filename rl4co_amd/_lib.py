@@ -6,6 +6,7 @@ the first call to :func:`lib` loads ``librl4co_amd.so`` and raises if it is miss
 from __future__ import annotations
 
 import ctypes as C
+import os
 from functools import lru_cache
 
 from . import build as _build
@@ -146,7 +147,8 @@ def lib() -> C.CDLL:
     meaningless to ours ("no ROCm-capable device is detected")."""
     import torch  # noqa: F401  (see above)
 
-    path = _build.build_library()
+    # RL4CO_AMD_LIB: load a specific build instead (tools/enc_probe.sh times instrumented variants of one kernel)
+    path = os.environ.get("RL4CO_AMD_LIB") or _build.build_library()
     try:
         handle = C.CDLL(str(path))
     except OSError as exc:  # pragma: no cover - depends on the environment

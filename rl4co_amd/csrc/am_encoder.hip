@@ -112,27 +112,29 @@ template <int TT, bool W_IS_A = true, bool INIT = true>
 __device__ inline void gemm_t(f32x16 (&acc)[TT], bf16x8 (&wf)[8], const __bf16* xs, int lane, const __bf16* nxt_packed,
                               int nxt_ksteps_total, int nxt_tile, int nxt_k0, const f32x16& cinit) {
   const int l31 = lane & 31, hi = lane >> 5;
-  bf16x8 xa[TT], xb[TT];
+  // Every MFMA takes one 1 KiB activation fragment from LDS. With the fragments of k-step ks + 1 requested while k-step
+  // ks computes (TT MFMAs = 128 cycles at TT = 4), the eight waves of a CU keep the LDS queue deep enough that the
+  // data is NOT back in time: replacing these reads by loop-invariant ones cut the kernel from 1.12 to 0.63 ms
+  // (tools/enc_probe.sh, r02) — the kernel was waiting on LDS latency, not on issue slots or the matrix pipe. The
+  // fragments are therefore requested TWO k-steps ahead (three rotating register sets).
+  bf16x8 x[3][TT];
 #pragma unroll
-  for (int tt = 0; tt < TT; ++tt) xa[tt] = load_x(xs, tt, 0, l31, hi);
+  for (int tt = 0; tt < TT; ++tt) {
+    x[0][tt] = load_x(xs, tt, 0, l31, hi);
+    x[1][tt] = load_x(xs, tt, 1, l31, hi);
+  }
 #pragma unroll
-  for (int ks = 0; ks < 8; ks += 2) {
+  for (int ks = 0; ks < 8; ++ks) {
+    if (ks + 2 < 8) {
 #pragma unroll
-    for (int tt = 0; tt < TT; ++tt) xb[tt] = load_x(xs, tt, ks + 1, l31, hi);
+      for (int tt = 0; tt < TT; ++tt) x[(ks + 2) % 3][tt] = load_x(xs, tt, ks + 2, l31, hi);
+    }
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
       const f32x16& c = (INIT && ks == 0) ? cinit : acc[tt];
-      acc[tt] = W_IS_A ? mfma(wf[ks], xa[tt], c) : mfma(xa[tt], wf[ks], c);
+      acc[tt] = W_IS_A ? mfma(wf[ks], x[ks % 3][tt], c) : mfma(x[ks % 3][tt], wf[ks], c);
     }
     if (nxt_packed) wf[ks] = load_w(nxt_packed, nxt_ksteps_total, nxt_tile, nxt_k0 + ks, lane);
-    if (ks + 2 < 8) {
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt) xa[tt] = load_x(xs, tt, ks + 2, l31, hi);
-    }
-#pragma unroll
-    for (int tt = 0; tt < TT; ++tt)
-      acc[tt] = W_IS_A ? mfma(wf[ks + 1], xb[tt], acc[tt]) : mfma(xb[tt], wf[ks + 1], acc[tt]);
-    if (nxt_packed) wf[ks + 1] = load_w(nxt_packed, nxt_ksteps_total, nxt_tile, nxt_k0 + ks + 1, lane);
   }
 }
 
