@@ -56,10 +56,10 @@ extern "C" {
 /* ---- enums --------------------------------------------------------------- */
 #define RL4CO_ENV_TSP 0
 #define RL4CO_ENV_CVRP 1
-#define RL4CO_ENV_OP 2 /* orienteering problem: streaming decode variant only */
-#define RL4CO_ENV_PCTSP 3 /* prize-collecting TSP (same row): streaming decode variant only */
-#define RL4CO_ENV_PDP 4 /* pickup and delivery (same row): streaming decode variant only */
-#define RL4CO_ENV_CVRPTW 5 /* CVRP with time windows (same row): streaming decode variant only */
+#define RL4CO_ENV_OP 2 /* orienteering problem: STREAM / LDS / WIDE decode variants */
+#define RL4CO_ENV_PCTSP 3 /* prize-collecting TSP (same row): STREAM / LDS / WIDE decode variants */
+#define RL4CO_ENV_PDP 4 /* pickup and delivery (same row): STREAM / LDS / WIDE decode variants */
+#define RL4CO_ENV_CVRPTW 5 /* CVRP with time windows (same row): STREAM / LDS / WIDE decode variants */
 
 #define RL4CO_DECODE_GREEDY 0   /* utils/decoding.py:387-397 */
 #define RL4CO_DECODE_SAMPLE 1   /* utils/decoding.py:399-413 */

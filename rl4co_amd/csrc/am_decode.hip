@@ -683,22 +683,39 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_wide_kernel(const
       }
     }
   }
+  // ---- trajectory state: the same six environments as the streaming kernel (wave 0 owns the transition, the other
+  // waves receive the scalars it changes through LDS after every step) ----------------------------------------------
+  constexpr bool kScalarCtx = ENV == RL4CO_ENV_CVRP || ENV == RL4CO_ENV_OP || ENV == RL4CO_ENV_PCTSP || ENV == RL4CO_ENV_CVRPTW;
+  constexpr bool kCvrpLike = ENV == RL4CO_ENV_CVRP || ENV == RL4CO_ENV_CVRPTW;
   uint8_t* gmask = a.action_mask + (int64_t)r * N;
   for (int j = tid; j < nw; j += 64 * kLdsWaves) mk[j] = (j < N) ? gmask[j] : (uint8_t)0;
-  if (ENV == RL4CO_ENV_CVRP) {
+  if (ENV == RL4CO_ENV_PDP) {  // bit 0 = available, bit 1 = to_deliver
+    const uint8_t* gv = a.visited + (int64_t)r * N;
+    const uint8_t* gt = a.to_deliver + (int64_t)r * N;
+    for (int j = tid; j < nw; j += 64 * kLdsWaves)
+      vis[j] = (j < N) ? (uint8_t)((gv[j] != 0 ? 1 : 0) | (gt[j] != 0 ? 2 : 0)) : (uint8_t)0;
+  } else if (ENV != RL4CO_ENV_TSP) {
     const uint8_t* gv = a.visited + (int64_t)r * N;
     for (int j = tid; j < nw; j += 64 * kLdsWaves) vis[j] = (j < N) ? gv[j] : (uint8_t)1;
   }
   TrajState st;
   st.cur = (int)a.current_node[r];
   st.first = (ENV == RL4CO_ENV_TSP) ? (int)a.first_node[r] : 0;
-  st.step_i = (ENV == RL4CO_ENV_TSP) ? a.step_i[r] : 0;
-  st.used = (ENV == RL4CO_ENV_CVRP) ? a.used_capacity[r] : 0.0f;
+  st.step_i = !kCvrpLike ? a.step_i[r] : 0;
+  st.time = (ENV == RL4CO_ENV_CVRPTW) ? a.current_time[r] : 0.0f;
+  st.used = kScalarCtx ? a.used_capacity[r] : 0.0f;  // OP: tour length so far; PCTSP: prize collected
   st.done = a.done[r] != 0;
   st.errbits = 0;
   st.ent_acc = 0.0f;
-  const float cap = (ENV == RL4CO_ENV_CVRP) ? a.vehicle_capacity[r] : 0.0f;
-  const float* dem = (ENV == RL4CO_ENV_CVRP) ? a.demand + (int64_t)cb * (N - 1) : nullptr;
+  const float* oplocs = (ENV == RL4CO_ENV_OP || ENV == RL4CO_ENV_CVRPTW) ? a.locs + (int64_t)cb * N * 2 : nullptr;
+  const float* opmax = (ENV == RL4CO_ENV_OP)       ? a.max_length + (int64_t)cb * N
+                       : (ENV == RL4CO_ENV_CVRPTW) ? a.time_windows + (int64_t)cb * N * 2
+                                                   : nullptr;
+  const float* twdur = (ENV == RL4CO_ENV_CVRPTW) ? a.durations + (int64_t)cb * N : nullptr;
+  const float cap = (kCvrpLike || ENV == RL4CO_ENV_PCTSP) ? a.vehicle_capacity[r] : ((ENV == RL4CO_ENV_OP) ? opmax[0] : 0.0f);
+  const float* dem = kCvrpLike                  ? a.demand + (int64_t)cb * (N - 1)
+                     : (ENV == RL4CO_ENV_PCTSP) ? a.demand + (int64_t)cb * N
+                                                : nullptr;
   __syncthreads();
   if (w == 0) {
     const int F0 = build_list(a, mk, fl, N, lane);
@@ -729,11 +746,18 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_wide_kernel(const
         for (int e = 0; e < EPL; ++e)
           q[e] = (ctxf[(int64_t)st.first * kD + e] + ctxc[(int64_t)st.cur * kD + e]) + qb[e];
       }
-    } else {
-      const float rem = cap - st.used;
+    } else if (ENV == RL4CO_ENV_PDP) {  // context.py:232-243: the current node alone
 #pragma unroll
-      for (int e = 0; e < EPL; ++e)
-        q[e] = fmaf(a.w_cap[e0 + e], rem, ctxc[(int64_t)st.cur * kD + e]) + qb[e];
+      for (int e = 0; e < EPL; ++e) q[e] = ctxc[(int64_t)st.cur * kD + e] + qb[e];
+    } else {
+      float rem = cap - st.used;  // context.py:147-149
+      if (ENV == RL4CO_ENV_PCTSP && !(rem > 0.0f)) rem = 0.0f;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) {
+        float v = fmaf(a.w_cap[e0 + e], rem, ctxc[(int64_t)st.cur * kD + e]);
+        if (ENV == RL4CO_ENV_CVRPTW) v = fmaf(a.w_time[e0 + e], st.time, v);  // context.py:152-166
+        q[e] = v + qb[e];
+      }
     }
 #pragma unroll
     for (int e = 0; e < EPL; ++e) q[e] = q[e] * 0.25f;
@@ -848,45 +872,49 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_wide_kernel(const
 
     // ---- wave 0: log-softmax, selection, environment transition, next step's list ------------------
     if (w == 0) {
-      const int bi = finalize_and_step<ENV>(a, st, lg, fl, F, mk, vis, dem, cap, r, t, N, lane);
+      finalize_and_step<ENV>(a, st, lg, fl, F, mk, vis, dem, cap, r, t, N, lane, oplocs, opmax, twdur);
       const int Fn = build_list(a, mk, fl, N, lane);
-      if (lane == 0) {
-        shi[0] = bi;
+      if (lane == 0) {  // the scalars the next query is built from, for the other three waves
+        shi[0] = st.cur;
         shi[1] = st.done ? 1 : 0;
         shi[2] = Fn;
+        shi[3] = st.first;
+        shi[4] = (int)st.step_i;
+        shi[5] = __float_as_int(st.used);
+        shi[6] = __float_as_int(st.time);
       }
     }
-    __syncthreads();  // B4: action, done flag, mask and list visible to every wave
+    __syncthreads();  // B4: state scalars, mask and list visible to every wave
     if (w != 0) {
-      const int bi = shi[0];
+      st.cur = shi[0];
       st.done = shi[1] != 0;
-      if (ENV == RL4CO_ENV_TSP) {
-        if (st.step_i == 0) st.first = bi;
-        st.cur = bi;
-        st.step_i += 1;
-      } else {
-        const int di = min(max(bi - 1, 0), N - 2);
-        st.used = (st.used + dem[di]) * (bi != 0 ? 1.0f : 0.0f);
-        st.cur = bi;
-      }
+      st.first = shi[3];
+      st.step_i = shi[4];
+      st.used = __int_as_float(shi[5]);
+      st.time = __int_as_float(shi[6]);
     }
   }
   if (w == 0) {
     if (!single && !st.done && t >= a.max_steps) st.errbits |= RL4CO_EBIT_MAX_STEPS;
     for (int j = lane; j < N; j += 64) gmask[j] = mk[j];
-    if (ENV == RL4CO_ENV_CVRP) {
+    if (ENV == RL4CO_ENV_PDP) {
+      uint8_t* gv = a.visited + (int64_t)r * N;
+      uint8_t* gt = a.to_deliver + (int64_t)r * N;
+      for (int j = lane; j < N; j += 64) {
+        gv[j] = vis[j] & 1;
+        gt[j] = (vis[j] >> 1) & 1;
+      }
+    } else if (ENV != RL4CO_ENV_TSP) {
       uint8_t* gv = a.visited + (int64_t)r * N;
       for (int j = lane; j < N; j += 64) gv[j] = vis[j];
     }
     if (lane == 0) {
       a.current_node[r] = st.cur;
       a.done[r] = st.done ? 1 : 0;
-      if (ENV == RL4CO_ENV_TSP) {
-        a.first_node[r] = st.first;
-        a.step_i[r] = st.step_i;
-      } else {
-        a.used_capacity[r] = st.used;
-      }
+      if (ENV == RL4CO_ENV_TSP) a.first_node[r] = st.first;
+      if (!kCvrpLike) a.step_i[r] = st.step_i;
+      if (ENV == RL4CO_ENV_CVRPTW) a.current_time[r] = st.time;
+      if (kScalarCtx) a.used_capacity[r] = st.used;
       if (a.n_steps) a.n_steps[r] = t;
       if (a.steps_summary) {
         atomicMax(a.steps_summary, t);
@@ -915,11 +943,10 @@ int launch_wide(const rl4co_am_decode_args& a, hipStream_t stream) {
 inline int resolve_variant(const rl4co_am_decode_args& a) {
   // the unfolded parity mode exists in the streaming kernel only
   if (a.unfold) return (a.variant == RL4CO_VARIANT_AUTO || a.variant == RL4CO_VARIANT_STREAM) ? RL4CO_VARIANT_STREAM : -1;
-  // the orienteering transition (distance-based mask) exists in the streaming kernel only
-  if (a.env == RL4CO_ENV_OP || a.env == RL4CO_ENV_PCTSP || a.env == RL4CO_ENV_PDP || a.env == RL4CO_ENV_CVRPTW) return (a.variant == RL4CO_VARIANT_AUTO || a.variant == RL4CO_VARIANT_STREAM) ? RL4CO_VARIANT_STREAM : -1;
   const bool bf16 = a.cache_dtype == RL4CO_DT_BF16;
-  // multistart on the matrix cores (am_decode_ms.hip): bf16 planes, N <= 128, plain outputs
-  const bool ms_ok = bf16 && a.N <= 128 && a.B_inst > 0 && a.all_logps == nullptr && a.entropy == nullptr;
+  // multistart on the matrix cores (am_decode_ms.hip): TSP / CVRP, bf16 planes, N <= 128, plain outputs
+  const bool ms_ok = bf16 && a.N <= 128 && a.B_inst > 0 && a.all_logps == nullptr && a.entropy == nullptr &&
+                     (a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP);
   if (a.variant == RL4CO_VARIANT_MS) return ms_ok ? RL4CO_VARIANT_MS : -1;
   const bool fits = bf16 && lds_variant_bytes(a.N) <= 80 * 1024;
   const bool wide_ok = bf16 && wide_scratch_bytes(a.N) <= 64 * 1024;
@@ -1017,12 +1044,16 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
     return a.env == RL4CO_ENV_TSP ? launch<CacheBF16, RL4CO_ENV_TSP, true>(a, s) : launch<CacheBF16, RL4CO_ENV_CVRP, true>(a, s);
   }
   if (variant == RL4CO_VARIANT_MS) return rl4co::launch_decode_ms(a, s);
-  if (variant == RL4CO_VARIANT_LDS) {
-    return a.env == RL4CO_ENV_TSP ? launch_wide<RL4CO_ENV_TSP, true>(a, s) : launch_wide<RL4CO_ENV_CVRP, true>(a, s);
-  }
-  if (variant == RL4CO_VARIANT_WIDE) {
-    return a.env == RL4CO_ENV_TSP ? launch_wide<RL4CO_ENV_TSP, false>(a, s)
-                                  : launch_wide<RL4CO_ENV_CVRP, false>(a, s);
+  if (variant == RL4CO_VARIANT_LDS || variant == RL4CO_VARIANT_WIDE) {
+    const bool res = variant == RL4CO_VARIANT_LDS;
+    switch (a.env) {
+      case RL4CO_ENV_TSP: return res ? launch_wide<RL4CO_ENV_TSP, true>(a, s) : launch_wide<RL4CO_ENV_TSP, false>(a, s);
+      case RL4CO_ENV_CVRP: return res ? launch_wide<RL4CO_ENV_CVRP, true>(a, s) : launch_wide<RL4CO_ENV_CVRP, false>(a, s);
+      case RL4CO_ENV_OP: return res ? launch_wide<RL4CO_ENV_OP, true>(a, s) : launch_wide<RL4CO_ENV_OP, false>(a, s);
+      case RL4CO_ENV_PCTSP: return res ? launch_wide<RL4CO_ENV_PCTSP, true>(a, s) : launch_wide<RL4CO_ENV_PCTSP, false>(a, s);
+      case RL4CO_ENV_PDP: return res ? launch_wide<RL4CO_ENV_PDP, true>(a, s) : launch_wide<RL4CO_ENV_PDP, false>(a, s);
+      default: return res ? launch_wide<RL4CO_ENV_CVRPTW, true>(a, s) : launch_wide<RL4CO_ENV_CVRPTW, false>(a, s);
+    }
   }
   if (a.env == RL4CO_ENV_CVRPTW)
     return a.cache_dtype == RL4CO_DT_F32 ? launch<CacheF32, RL4CO_ENV_CVRPTW>(a, s)

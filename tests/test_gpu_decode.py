@@ -97,8 +97,6 @@ CONFIG_IDS = ["f32-stream", "bf16-stream", "bf16-lds", "bf16-wide"]
 
 def _skip_if_unservable(g, dtype, variant):
     n = g.num_loc + (g.env_name != "tsp")
-    if g.env_name in ("op", "pctsp", "pdp", "cvrptw") and variant != "stream":
-        pytest.skip("the orienteering / prize-collecting / pickup-delivery transitions exist in the streaming kernel only")
     try:
         __import__("rl4co_amd.kernels").kernels.decode_row_groups(n, dtype, 2 * n, variant, 64)
     except Exception:
