@@ -559,6 +559,19 @@ int rl4co_select_start_nodes(int64_t* out, int B, int num_starts, int num_loc, i
                              void* stream);
 
 /* --------------------------------------------------------------------------
+ * N2 / a10  instance generation on the device
+ *        rl4co/envs/common/utils.py:34-62 (get_sampler -> Uniform), tsp/generator.py:49-58,
+ *        cvrp/generator.py:114-140
+ * out[i] = low + (high - low) * u_i, u_i = k_i / 2^24 from Philox4x32-10 keyed by `seed` (counter = element block,
+ * stream_id) — U(low, high) like the reference's sampler, drawn straight into HBM in one launch (the reference draws on
+ * the host and uploads). mode 1 = CVRP demands: (trunc(v) + 1) / capacity, i.e. `(U(min-1, max-1).int() + 1) / cap`.
+ * A different generator than torch's: the CPU stream of the reference is reproduced by the host mirror
+ * (envs.*Generator(device="cpu")), not by this kernel; this one is pinned to oracle_uniform_f32 bit for bit.
+ * -------------------------------------------------------------------------- */
+int rl4co_uniform_f32(float* out, int64_t n, float low, float high, uint64_t seed, uint32_t stream_id, int mode,
+                      float capacity, void* stream);
+
+/* --------------------------------------------------------------------------
  * Micro-benchmark helper: HBM read stream (float4 grid-stride sum), used by
  * bench.py to report the achievable-copy ceiling next to the 8 TB/s spec.
  * -------------------------------------------------------------------------- */

@@ -67,6 +67,7 @@ def lib() -> C.CDLL:
         fn.argtypes = [C.c_float]
         fn.restype = C.c_float
     h.oracle_math_array.argtypes = [i, vp, C.c_int64, vp]
+    h.oracle_uniform_f32.argtypes = [vp, C.c_int64, C.c_float, C.c_float, C.c_uint64, C.c_uint32, i, C.c_float]
     h.oracle_exp1_noise.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
     h.oracle_exp1_noise.restype = C.c_float
     return h
@@ -260,3 +261,11 @@ def math_array(fn: str, x: Tensor) -> Tensor:
     y = torch.empty_like(x)
     assert lib().oracle_math_array({"exp": 0, "log": 1, "tanh": 2}[fn], _p(x), x.numel(), _p(y)) == 0
     return y
+
+
+def uniform(shape, low: float, high: float, seed: int, stream_id: int, demand_capacity: float | None = None) -> Tensor:
+    """Host restatement of kernels.uniform (rl4co_uniform_f32): the same Philox words."""
+    out = torch.empty(tuple(shape), dtype=torch.float32)
+    assert lib().oracle_uniform_f32(_p(out), out.numel(), float(low), float(high), int(seed) & ((1 << 64) - 1), int(stream_id),
+                                    0 if demand_capacity is None else 1, float(demand_capacity or 1.0)) == 0
+    return out

@@ -859,3 +859,18 @@ int oracle_math_array(int fn, const float* x, int64_t n, float* y) {
   for (int64_t i = 0; i < n; ++i) y[i] = fn == 0 ? rl4co_expf(x[i]) : (fn == 1 ? rl4co_logf(x[i]) : rl4co_tanhf(x[i]));
   return 0;
 }
+
+/* host restatement of rl4co_uniform_f32 (csrc/api.hip): same Philox block -> same words, same arithmetic */
+int oracle_uniform_f32(float* out, int64_t n, float low, float high, uint64_t seed, uint32_t stream_id, int mode, float capacity) {
+  for (int64_t b = 0; 4 * b < n; ++b) {
+    uint32_t c[4] = {(uint32_t)b, (uint32_t)((uint64_t)b >> 32), stream_id, 0x52344347u};
+    rl4co_philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    for (int i = 0; i < 4 && 4 * b + i < n; ++i) {
+      const float u = (float)(c[i] >> 8) * 5.9604644775390625e-8f;
+      float x = fmaf(high - low, u, low);
+      if (mode == 1) x = (truncf(x) + 1.0f) / capacity;
+      out[4 * b + i] = x;
+    }
+  }
+  return 0;
+}

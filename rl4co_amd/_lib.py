@@ -128,6 +128,7 @@ SYMBOLS = {
     "rl4co_select_start_nodes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
     "rl4co_hbm_read_probe": (C.c_int, [_vp, _i64, _vp, _vp]),
     "rl4co_math_probe_f32": (C.c_int, [C.c_int, _vp, _i64, _vp, _vp]),
+    "rl4co_uniform_f32": (C.c_int, [_vp, _i64, C.c_float, C.c_float, C.c_uint64, C.c_uint32, C.c_int, C.c_float, _vp]),
 }
 
 

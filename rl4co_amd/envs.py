@@ -55,10 +55,16 @@ class TSPGenerator(Generator):
         self.max_loc = max_loc
         self.device = device
 
-    def _uniform(self, shape, low, high):
+    def _uniform(self, shape, low, high, demand_capacity=None):
+        """U(low, high). "cpu": the reference's own sampler on the global torch generator (its exact stream). A CUDA
+        device: ONE launch of rl4co_uniform_f32 straight into HBM, keyed by a seed drawn from the (CPU) torch generator —
+        `torch.manual_seed` still makes the instances reproducible, nothing is synchronised or uploaded.
+        ``demand_capacity``: CVRP's integer demands over the capacity in the same launch."""
         if str(self.device) == "cpu":
-            return torch.distributions.Uniform(low=low, high=high).sample(shape)
-        return torch.rand(shape, device=self.device) * (high - low) + low
+            v = torch.distributions.Uniform(low=low, high=high).sample(shape)
+            return v if demand_capacity is None else (v.int() + 1).float() / demand_capacity
+        seed = int(torch.randint(0, 2**62, (1,)).item())
+        return K.uniform(shape, low, high, seed, 0, self.device, demand_capacity=demand_capacity)
 
     def _generate(self, batch_size) -> TensorDict:
         locs = self._uniform((*batch_size, self.num_loc, 2), self.min_loc, self.max_loc)
@@ -86,11 +92,11 @@ class CVRPGenerator(TSPGenerator):
         locs = self._uniform((*batch_size, self.num_loc + 1, 2), self.min_loc, self.max_loc)
         depot = locs[..., 0, :]
         locs = locs[..., 1:, :]
-        demand = self._uniform((*batch_size, self.num_loc), self.min_demand - 1, self.max_demand - 1)
-        demand = (demand.int() + 1).float()
+        demand = self._uniform((*batch_size, self.num_loc), self.min_demand - 1, self.max_demand - 1,
+                               demand_capacity=self.capacity)  # (U.int() + 1).float() / capacity, cvrp/generator.py:127-136
         capacity = torch.full((*batch_size, 1), self.capacity, device=demand.device)
         return TensorDict(
-            {"locs": locs, "depot": depot, "demand": demand / self.capacity, "capacity": capacity},
+            {"locs": locs, "depot": depot, "demand": demand, "capacity": capacity},
             batch_size=batch_size,
         )
 

@@ -451,3 +451,14 @@ def math_probe(fn: str, x: Tensor) -> Tensor:
     st = _lib.lib().rl4co_math_probe_f32({"exp": 0, "log": 1, "tanh": 2}[fn], _ptr(x), x.numel(), _ptr(y), _stream())
     _lib.check(st, "rl4co_math_probe_f32")
     return y
+
+
+def uniform(shape, low: float, high: float, seed: int, stream_id: int, device, demand_capacity: float | None = None) -> Tensor:
+    """U(low, high) drawn on the device in one launch (rl4co_uniform_f32, Philox4x32-10 keyed by ``seed`` /
+    ``stream_id``); ``demand_capacity``: CVRP's integer-demand map ``(trunc(v) + 1) / capacity`` on top."""
+    out = torch.empty(tuple(shape), dtype=torch.float32, device=device)
+    _dev(out, torch.float32, "out")
+    st = _lib.lib().rl4co_uniform_f32(_ptr(out), out.numel(), float(low), float(high), int(seed) & ((1 << 64) - 1), int(stream_id),
+                                      0 if demand_capacity is None else 1, float(demand_capacity or 1.0), _stream())
+    _lib.check(st, "rl4co_uniform_f32")
+    return out

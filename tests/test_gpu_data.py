@@ -126,3 +126,36 @@ def test_instance_file_to_device_dataset_and_greedy_baseline(tmp_path):
     assert torch.equal(wrapped.data["extra"], rewards)
     first = next(iter(wrapped.batches(8)))
     assert first["extra"].shape == (8,) and first["extra"].is_cuda
+
+
+def test_instance_generator_kernel_equals_host_restatement_and_is_uniform():
+    """rl4co_uniform_f32 (instances drawn straight into HBM): bit-identical to its host restatement
+    (oracle_uniform_f32: same Philox4x32-10 words), statistically U(low, high) like the reference's sampler
+    (envs/common/utils.py:34-62), reproducible under torch.manual_seed, and CVRP's demands are the integers 1 .. 9 over
+    the capacity (cvrp/generator.py:127-136)."""
+    from oracle import c_oracle
+    from rl4co_amd import kernels as K
+    from rl4co_amd.envs import get_env
+
+    for shape, low, high, seed, sid in [((4096, 100, 2), 0.0, 1.0, 1234567, 0), ((7, 3), -2.0, 5.0, 99, 3), ((1,), 0.0, 1.0, 1, 0),
+                                        ((513, 101), 0.0, 9.0, 2**61 + 17, 1)]:
+        dev = K.uniform(shape, low, high, seed, sid, "cuda")
+        assert torch.equal(dev.cpu(), c_oracle.uniform(shape, low, high, seed, sid))
+        assert float(dev.min()) >= low and float(dev.max()) < high
+    dem = K.uniform((2048, 100), 0.0, 9.0, 5, 0, "cuda", demand_capacity=50.0)
+    assert torch.equal(dem.cpu(), c_oracle.uniform((2048, 100), 0.0, 9.0, 5, 0, demand_capacity=50.0))
+    vals = (dem * 50.0).round()
+    assert set(vals.unique().tolist()) == {float(i) for i in range(1, 10)} and torch.equal(vals / 50.0, dem)
+    x = K.uniform((1 << 22,), 0.0, 1.0, 42, 0, "cuda")
+    assert abs(float(x.mean()) - 0.5) < 1e-3 and abs(float(x.var()) - 1.0 / 12.0) < 1e-3
+    hist = torch.histc(x, bins=64, min=0.0, max=1.0)
+    assert float((hist - hist.mean()).abs().max()) < 6.0 * float(hist.mean()) ** 0.5  # every bin within 6 sigma
+    env = get_env("cvrp", generator_params=dict(num_loc=100, device="cuda"), device="cuda")
+    torch.manual_seed(7)
+    a = env.generator(batch_size=[64])
+    torch.manual_seed(7)
+    b = env.generator(batch_size=[64])
+    c = env.generator(batch_size=[64])
+    assert torch.equal(a["locs"], b["locs"]) and torch.equal(a["demand"], b["demand"]) and not torch.equal(a["locs"], c["locs"])
+    assert a["locs"].shape == (64, 100, 2) and a["depot"].shape == (64, 2) and a["locs"].is_cuda
+    assert float(a["demand"].min()) >= 1 / 50 - 1e-7 and float(a["demand"].max()) <= 9 / 50 + 1e-7
