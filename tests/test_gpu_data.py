@@ -144,8 +144,8 @@ def test_instance_generator_kernel_equals_host_restatement_and_is_uniform():
         assert float(dev.min()) >= low and float(dev.max()) < high
     dem = K.uniform((2048, 100), 0.0, 9.0, 5, 0, "cuda", demand_capacity=50.0)
     assert torch.equal(dem.cpu(), c_oracle.uniform((2048, 100), 0.0, 9.0, 5, 0, demand_capacity=50.0))
-    vals = (dem * 50.0).round()
-    assert set(vals.unique().tolist()) == {float(i) for i in range(1, 10)} and torch.equal(vals / 50.0, dem)
+    vals = (dem.cpu() * 50.0).round()  # (on the host: ATen's GPU division by a scalar multiplies by the reciprocal)
+    assert set(vals.unique().tolist()) == {float(i) for i in range(1, 10)} and torch.equal(vals / 50.0, dem.cpu())
     x = K.uniform((1 << 22,), 0.0, 1.0, 42, 0, "cuda")
     assert abs(float(x.mean()) - 0.5) < 1e-3 and abs(float(x.var()) - 1.0 / 12.0) < 1e-3
     hist = torch.histc(x, bins=64, min=0.0, max=1.0)
