@@ -508,6 +508,10 @@ int rl4co_skip_inorm_max_nodes(void);
 int rl4co_skip_bnorm_stats_bf16(const void* x, const void* s, int64_t M, void* y, float* sums, void* stream);
 int rl4co_bnorm_apply_bf16(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
                            int64_t M, void* out, void* stream);
+/* out = bn_eval(x + skip) in one pass (SkipConnection + Normalization("batch") in eval mode, nn/ops.py:9-54): the
+ * token-parallel inference encoder for graphs beyond rl4co_am_encoder_max_nodes(); x, skip, out bf16 [M,128]. */
+int rl4co_skip_bnorm_eval_bf16(const void* x, const void* skip, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, int64_t M, void* out, void* stream);
 int rl4co_bnorm_bwd_bf16(const void* dout, const void* y, const float* mean, const float* rstd, const float* gamma,
                          int64_t M, float* sums, void* dy, void* stream);
 

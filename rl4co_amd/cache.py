@@ -133,7 +133,13 @@ def build_folded_cache(
     w_blocks = fold_weights(env_name, w_node.float(), w_out.float(), w_ctx.float())
     kvl = torch.empty((3, b, n, d), dtype=cache_dtype, device=h.device)
     h_g = h.reshape(b * n, d).to(gemm_dtype)
+    own_gemm = h.is_cuda and gemm_dtype == cache_dtype == torch.bfloat16 and not torch.is_grad_enabled()
     for i in range(3):
+        if own_gemm:  # bf16 planes of an inference rollout: the tall-skinny GEMM kernel (csrc/am_train_ops.hip), straight into the plane
+            from . import train_ops
+
+            train_ops._gemm(h_g.contiguous(), w_blocks[i].to(torch.bfloat16).contiguous(), out=kvl[i].view(b * n, d))
+            continue
         w_t = w_blocks[i].to(gemm_dtype).t()
         if gemm_dtype == cache_dtype:
             torch.matmul(h_g, w_t, out=kvl[i].view(b * n, d))

@@ -572,6 +572,33 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(const uint32_t* __restric
   }
 }
 
+// out = ((x + s) - mean) * rstd * gamma + beta: the skip connection and eval-mode batch norm of an encoder layer in one
+// pass over the token rows (inference on graphs beyond the fused encoder's 128 nodes); the sum stays in fp32
+__global__ void __launch_bounds__(256) skip_bn_eval_kernel(const uint32_t* __restrict__ x, const uint32_t* __restrict__ sk,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, int64_t M,
+                                                           uint32_t* __restrict__ out) {
+  const int tid = threadIdx.x, cp = tid & 63, q = tid >> 6;
+  const float m0 = mean[2 * cp], m1 = mean[2 * cp + 1];
+  const float k0 = rstd[2 * cp] * gamma[2 * cp], k1 = rstd[2 * cp + 1] * gamma[2 * cp + 1];
+  const float b0 = beta[2 * cp], b1 = beta[2 * cp + 1];
+  const int64_t stride = (int64_t)gridDim.x * 4;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + q; r < M; r += 4 * stride) {  // four rows in flight per thread
+    uint32_t v[4], u[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t row = min(r + j * stride, M - 1);
+      v[j] = x[row * 64 + cp];
+      u[j] = sk[row * 64 + cp];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (r + j * stride < M)
+        out[(r + j * stride) * 64 + cp] = pack_bf16(fmaf((bf16_lo(v[j]) + bf16_lo(u[j])) - m0, k0, b0),
+                                                    fmaf((bf16_hi(v[j]) + bf16_hi(u[j])) - m1, k1, b1));
+  }
+}
+
 // sums[0][c] += sum dout ; sums[1][c] += sum dout * xh
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const uint32_t* __restrict__ dout, const uint32_t* __restrict__ y,
                                                             const float* __restrict__ mean, const float* __restrict__ rstd, int64_t M,
@@ -663,6 +690,16 @@ extern "C" int rl4co_bnorm_apply_bf16(const void* y, const float* mean, const fl
   const int blocks = (int)min((int64_t)8192, (M + 3) / 4);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(blocks), dim3(256), 0, rl4co::as_stream(stream), static_cast<const uint32_t*>(y), mean,
                      rstd, gamma, beta, M, static_cast<uint32_t*>(out));
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
+extern "C" int rl4co_skip_bnorm_eval_bf16(const void* x, const void* skip, const float* mean, const float* rstd, const float* gamma,
+                                          const float* beta, int64_t M, void* out, void* stream) {
+  RL4CO_REQUIRE(x && skip && mean && rstd && gamma && beta && out && M > 0);
+  const int blocks = (int)min((int64_t)8192, (M + 3) / 4);
+  hipLaunchKernelGGL(skip_bn_eval_kernel, dim3(blocks), dim3(256), 0, rl4co::as_stream(stream), static_cast<const uint32_t*>(x),
+                     static_cast<const uint32_t*>(skip), mean, rstd, gamma, beta, M, static_cast<uint32_t*>(out));
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }

@@ -502,10 +502,10 @@ class AttentionModelPolicy(nn.Module):
             qkv = T._gemm(x2, attn.Wqkv.weight.to(bf).contiguous(), attn.Wqkv.bias.float().contiguous())
             o = T.attention_flash(qkv.view(b, n, 3 * d)).view(b * n, d)  # keys / values streamed through LDS, any N
             s_ = T._gemm(o, attn.out_proj.weight.to(bf).contiguous(), attn.out_proj.bias.float().contiguous())
-            x2 = T.batch_norm_eval(x2 + s_, norm1)
+            x2 = T.skip_batch_norm_eval(x2, s_, norm1)
             h = T._gemm(x2, ffn.lins[0].weight.to(bf).contiguous(), ffn.lins[0].bias.float().contiguous(), relu=True)
             s_ = T._gemm(h, ffn.lins[1].weight.to(bf).contiguous(), ffn.lins[1].bias.float().contiguous())
-            x = T.batch_norm_eval(x2 + s_, norm2).view(b, n, d)
+            x = T.skip_batch_norm_eval(x2, s_, norm2).view(b, n, d)
         return x, init_h
 
     def _bf16_regime(self) -> bool:

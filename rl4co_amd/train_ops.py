@@ -120,6 +120,21 @@ def batch_norm_eval(y: Tensor, bn: torch.nn.BatchNorm1d) -> Tensor:
     return out
 
 
+def skip_batch_norm_eval(x: Tensor, s: Tensor, bn: torch.nn.BatchNorm1d) -> Tensor:
+    """Eval-mode ``bn(x + s)`` on bf16 rows [M,128] in one pass (the sum stays in fp32)."""
+    xc, sc = x.contiguous(), s.contiguous()
+    m = xc.numel() // EMBED_DIM
+    out = torch.empty_like(xc)
+    mean = bn.running_mean.float().contiguous()
+    rstd = torch.rsqrt(bn.running_var.float() + bn.eps).contiguous()
+    st = _lib.lib().rl4co_skip_bnorm_eval_bf16(xc.data_ptr(), sc.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                               bn.weight.detach().float().contiguous().data_ptr(),
+                                               bn.bias.detach().float().contiguous().data_ptr(), m, out.data_ptr(),
+                                               torch.cuda.current_stream().cuda_stream)
+    _lib.check(st, "rl4co_skip_bnorm_eval_bf16")
+    return out
+
+
 def usable(x: Tensor, s: Tensor) -> bool:
     """bf16 [B,N,128] activations on the GPU with N inside the kernel's register budget."""
     return (x.is_cuda and x.dtype == torch.bfloat16 and s.dtype == torch.bfloat16 and x.dim() == 3
@@ -138,11 +153,15 @@ def skip_instance_norm(x: Tensor, s: Tensor, weight: Tensor, bias: Tensor, eps: 
 # ---------------------------------------------------------------------------------------------------
 # nn.Linear over the token rows on the tall-skinny MFMA kernel (csrc/am_train_ops.hip)
 # ---------------------------------------------------------------------------------------------------
-def _gemm(a2d: Tensor, w: Tensor, bias: Tensor | None = None, mask: Tensor | None = None, relu: bool = False) -> Tensor:
+def _gemm(a2d: Tensor, w: Tensor, bias: Tensor | None = None, mask: Tensor | None = None, relu: bool = False,
+          out: Tensor | None = None) -> Tensor:
     """out[M,N] = epilogue(a2d[M,K] @ w[N,K]^T + bias); bf16 a2d / w / out, fp32 bias."""
     m, k = a2d.shape
     n = w.shape[0]
-    out = torch.empty((m, n), dtype=torch.bfloat16, device=a2d.device)
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.bfloat16, device=a2d.device)
+    else:
+        assert out.shape == (m, n) and out.dtype == torch.bfloat16 and out.is_contiguous()
     st = _lib.lib().rl4co_linear_bf16(a2d.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
                                       None if mask is None else mask.data_ptr(), m, n, k, int(relu), out.data_ptr(),
                                       torch.cuda.current_stream().cuda_stream)

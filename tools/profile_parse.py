@@ -1,8 +1,8 @@
-"""Turn the rocprofv3 output of tools/profile_round.sh (gpurun_out/<tag>/...) into the small,
-committed summaries under profiles/: kernel stats table, PMC HBM traffic, and
-profiles/pmc_traffic.json (read by bench.py for the `roofline.traffic` field).
+"""Turn the rocprofv3 output of tools/profile_legs.sh (gpurun_out/<tag>/<leg>/...) into the small, committed summaries
+under profiles/: per-leg kernel stats, PMC HBM counters, and profiles/pmc_traffic.json (read by bench.py for the
+`roofline.traffic` field of the same leg).
 
-    python tools/profile_parse.py gpurun_out/final r01_final
+    python tools/profile_parse.py gpurun_out/r02 r02
 """
 import collections
 import csv
@@ -14,44 +14,56 @@ from pathlib import Path
 src, tag = Path(sys.argv[1]), sys.argv[2]
 out = Path(__file__).resolve().parents[1] / "profiles"
 out.mkdir(exist_ok=True)
+pt = out / "pmc_traffic.json"
+table = json.loads(pt.read_text()) if pt.exists() else {}
+table = {k: v for k, v in table.items() if "/" in k and " " not in k}  # drop round-1 keys (whole workload strings)
 
-stats = glob.glob(str(src / "trace" / "*" / "*_kernel_stats.csv"))
-if stats:
-    rows = list(csv.DictReader(open(stats[0])))
-    lines = [f"# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline   ({tag}, MI355X)",
-             f"{'kernel':100s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}"]
-    for r in rows[:25]:
-        lines.append(f"{r['Name'][:100]:100s} {r['Calls']:>6s} {float(r['TotalDurationNs'])/1e6:10.3f} "
-                     f"{float(r['AverageNs'])/1e3:10.2f} {float(r['MinNs'])/1e3:10.2f} {float(r['MaxNs'])/1e3:10.2f} "
-                     f"{float(r['Percentage']):6.2f}")
-    (out / f"{tag}_kernel_stats.txt").write_text("\n".join(lines) + "\n")
-    print("\n".join(lines[:8]))
-
-res = {}
-for sub, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-    for f in glob.glob(str(src / sub / "*" / "*_counter_collection.csv")):
-        agg = collections.defaultdict(list)
-        for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == name:
-                agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-        for k, v in agg.items():
-            if any(s in k for s in ("am_decode", "am_encoder", "hbm_read_probe", "tour_length")):
-                res.setdefault(k[:90], {})[name] = {"dispatches": len(v), "mean_KB": sum(v) / len(v)}
-if res:
-    (out / f"{tag}_pmc_hbm.json").write_text(json.dumps(res, indent=1) + "\n")
-    dec = next((v for k, v in res.items() if "am_decode" in k), None)
-    probe = next((v for k, v in res.items() if "hbm_read_probe" in k), None)
-    if dec and "FETCH_SIZE" in dec:
-        # gfx950: FETCH_SIZE reports 1/2 of a wide coalesced stream (MI355X_MICROARCH.md §HBM); the
-        # factor is re-derived here from the probe kernel of the same run (2 GiB read per dispatch)
-        corr = 2.0
-        if probe and "FETCH_SIZE" in probe:
-            corr = (2 << 30) / (probe["FETCH_SIZE"]["mean_KB"] * 1024.0)
-        traffic = dec["FETCH_SIZE"]["mean_KB"] * 1024.0 * corr + dec.get("WRITE_SIZE", {}).get("mean_KB", 0.0) * 1024.0
-        bench_line = json.loads((src / "bench_trace.json").read_text()) if (src / "bench_trace.json").exists() else {}
-        key = bench_line.get("config", {}).get("workload", "unknown")
-        pt = out / "pmc_traffic.json"
-        table = json.loads(pt.read_text()) if pt.exists() else {}
-        table[key] = {"traffic_bytes_per_launch": traffic, "fetch_correction": corr, "source": f"profiles/{tag}_pmc_hbm.json"}
-        pt.write_text(json.dumps(table, indent=1) + "\n")
-        print("traffic", key, traffic / 1e9, "GB per launch, correction", corr)
+for legdir in sorted(p for p in src.iterdir() if p.is_dir()):
+    leg = legdir.name
+    line = {}
+    try:
+        line = json.loads((legdir / "bench_trace.json").read_text().strip().splitlines()[-1])
+    except (OSError, ValueError, IndexError):
+        pass
+    stats = glob.glob(str(legdir / "trace" / "*" / "*_kernel_stats.csv"))
+    if stats:
+        rows = list(csv.DictReader(open(stats[0])))
+        head = (f"# rocprofv3 --kernel-trace --stats -- python bench.py --legs {leg} --steps 10 --warmup 2 --no-cpu-baseline "
+                f"--no-parity --launch eager   ({tag}, MI355X)")
+        if line:
+            roof = line.get("roofline", {})
+            head += (f"\n# same run's JSON line: ms_per_step {line.get('ms_per_step', 0):.3f}; HIP-event mean of the decode launch "
+                     f"{roof.get('launch_ms_mean', float('nan')):.3f} ms, roofline.frac {roof.get('frac', float('nan')):.3f}")
+        lines = [head, f"{'kernel':100s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}"]
+        for r in rows[:30]:
+            lines.append(f"{r['Name'][:100]:100s} {r['Calls']:>6s} {float(r['TotalDurationNs'])/1e6:10.3f} "
+                         f"{float(r['AverageNs'])/1e3:10.2f} {float(r['MinNs'])/1e3:10.2f} {float(r['MaxNs'])/1e3:10.2f} "
+                         f"{float(r['Percentage']):6.2f}")
+        (out / f"{tag}_{leg}_kernel_stats.txt").write_text("\n".join(lines) + "\n")
+        print("\n".join(lines[:7]))
+    res = {}
+    for sub, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
+        for f in glob.glob(str(legdir / sub / "*" / "*_counter_collection.csv")):
+            agg = collections.defaultdict(list)
+            for r in csv.DictReader(open(f)):
+                if r["Counter_Name"] == name:
+                    agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+            for k, v in agg.items():
+                if any(s in k for s in ("am_decode", "am_encoder", "hbm_read_probe", "tour_length", "attn_flash", "linear_bf16")):
+                    res.setdefault(k[:90], {})[name] = {"dispatches": len(v), "mean_KB": sum(v) / len(v)}
+    if res:
+        (out / f"{tag}_{leg}_pmc_hbm.json").write_text(json.dumps(res, indent=1) + "\n")
+        dec = next((v for k, v in res.items() if "am_decode" in k), None)
+        probe = next((v for k, v in res.items() if "hbm_read_probe" in k), None)
+        if dec and "FETCH_SIZE" in dec:
+            # gfx950: FETCH_SIZE reports 1/2 of a wide coalesced stream (MI355X_MICROARCH.md §HBM); the factor is
+            # re-derived here from the probe kernel of the same run (2 GiB read per dispatch) when it ran
+            corr = 2.0
+            if probe and "FETCH_SIZE" in probe:
+                corr = (2 << 30) / (probe["FETCH_SIZE"]["mean_KB"] * 1024.0)
+            traffic = dec["FETCH_SIZE"]["mean_KB"] * 1024.0 * corr + dec.get("WRITE_SIZE", {}).get("mean_KB", 0.0) * 1024.0
+            dtype = line.get("config", {}).get("cache_dtype", "bf16")
+            table[f"{leg}/{dtype}"] = {"traffic_bytes_per_launch": traffic, "fetch_correction": corr,
+                                       "source": f"profiles/{tag}_{leg}_pmc_hbm.json"}
+            print("traffic", leg, traffic / 1e9, "GB per launch, correction", corr)
+pt.write_text(json.dumps(table, indent=1) + "\n")
