@@ -195,9 +195,9 @@ def test_mma_orienteering_matches_torch_autograd(env_name, num_loc):
     # sampled untrained trajectories of PCTSP-100 run ~100 steps at log p ~ -4 each: the bf16-plane noise of the
     # sum grows with T, hence the relative term (measured 0.18 on a log-likelihood of -428)
     # CVRPTW feeds unnormalised coordinates / times (to 150 / 480) through the same planes: the clipped logits saturate
-    # and the bf16 noise of single trajectories is larger (measured 2.0e-3 relative on one of 96 instances drawn by the
-    # device generator, r02; tests/helpers.ll_rtol documents the same effect for the fp32 planes)
-    torch.testing.assert_close(res[True][0], res[False][0], rtol=4e-3 if env_name == "cvrptw" else 1e-3, atol=0.15)
+    # and the bf16 noise of single trajectories is larger (measured 2.0e-3 / 5.4e-3 relative on single instances of the 20- / 50-node draws of the
+    # device generator, r02; 8e-3 seen through the GPU encoder in r01; tests/helpers.ll_rtol documents the same effect for the fp32 planes)
+    torch.testing.assert_close(res[True][0], res[False][0], rtol=1e-2 if env_name == "cvrptw" else 1e-3, atol=0.15)
     scale = max(float(g.norm()) for g in res[False][1].values())
     for k, gt in res[False][1].items():
         gk = res[True][1][k]
