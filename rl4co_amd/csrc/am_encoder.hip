@@ -253,6 +253,17 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
   const int b = blockIdx.x;
   const int N = a.N;
 
+  const __bf16* wqkv_all = static_cast<const __bf16*>(a.wqkv_packed);
+  const __bf16* wo_all = static_cast<const __bf16*>(a.wo_packed);
+  const __bf16* w1_all = static_cast<const __bf16*>(a.w1_packed);
+  const __bf16* w2_all = static_cast<const __bf16*>(a.w2_packed);
+  const __bf16* wf_all = static_cast<const __bf16*>(a.wfold_packed);
+  // weight fragments of the NEXT GEMM, always one call ahead (gemm_t). The first set is requested before anything else:
+  // the fixed cost of an instance (init embedding, first fragments, fold, stores) is 0.38 of the kernel's 1.1 ms
+  // (`tools/enc_layers.py`: 0.62 / 0.85 / 1.11 / 1.78 ms at 1 / 2 / 3 / 6 layers), most of it exposed round trips
+  bf16x8 wf[8];
+  load_wfrags(wf, wqkv_all, 8, w, 0, lane);
+
   // ---- init embedding (K = 2 or 3: plain VALU), padding rows zeroed ---------------------------
   // The instance's coordinates (and demands) are staged in LDS first: read per token from global
   // memory they are a chain of dependent L2 round trips (28 K cycles per instance, measured).
@@ -276,44 +287,66 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         lsh[4 * N + 1 + i] = a.feature5[(int64_t)b * (N - 1) + i];
         lsh[5 * N + 1 + i] = a.feature6[(int64_t)b * (N - 1) + i];
       }
-    const int d = tid & 127;
+    // thread = four consecutive channels (tid & 31) x one of eight token groups: every token row of the residual stream
+    // receives an 8-byte LDS store per thread (a thread per channel stored 2 bytes per token: 64 dependent
+    // ds_write_b16 per thread, part of the 44 K cycles this phase took of an instance's 285 K)
+    const int d0 = 4 * (tid & 31);
     const int ws = six ? 6 : ((four || pdp) ? 4 : (cvrp ? 3 : 2));  // row stride of w_init
-    const float w5 = six ? a.w_init[ws * d + 4] : 0.0f, w6 = six ? a.w_init[ws * d + 5] : 0.0f;
-    const float wx = a.w_init[ws * d], wy = a.w_init[ws * d + 1];
-    const float wd = depot ? a.w_init[ws * d + 2] : 0.0f, bi = a.b_init[d];
-    const float wp = (four || pdp) ? a.w_init[ws * d + 3] : 0.0f;
-    const float dx = depot ? a.w_depot[2 * d] : 0.0f, dy = depot ? a.w_depot[2 * d + 1] : 0.0f, db = depot ? a.b_depot[d] : 0.0f;
-    const float ex = pdp ? a.w_extra[2 * d] : 0.0f, ey = pdp ? a.w_extra[2 * d + 1] : 0.0f, eb = pdp ? a.b_extra[d] : 0.0f;
+    float wq[4][6], bq[4], dq[4][2], dbq[4], eq[4][2], ebq[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int f = 0; f < 6; ++f) wq[c][f] = f < ws ? a.w_init[ws * (d0 + c) + f] : 0.0f;
+      bq[c] = a.b_init[d0 + c];
+      dq[c][0] = depot ? a.w_depot[2 * (d0 + c)] : 0.0f;
+      dq[c][1] = depot ? a.w_depot[2 * (d0 + c) + 1] : 0.0f;
+      dbq[c] = depot ? a.b_depot[d0 + c] : 0.0f;
+      eq[c][0] = pdp ? a.w_extra[2 * (d0 + c)] : 0.0f;
+      eq[c][1] = pdp ? a.w_extra[2 * (d0 + c) + 1] : 0.0f;
+      ebq[c] = pdp ? a.b_extra[d0 + c] : 0.0f;
+    }
+    stage_biases(0);
     __syncthreads();
-    for (int tok = tid >> 7; tok < 32 * TT; tok += kThreads / 128) {
-      float v = 0.0f;
+    for (int tok = tid >> 5; tok < 32 * TT; tok += kThreads / 32) {
+      float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
       if (tok < N) {
         const float x = lsh[2 * tok], y = lsh[2 * tok + 1];
-        if (depot && tok == 0) v = fmaf(dy, y, fmaf(dx, x, db));
-        else if (pdp && tok <= half)
-          v = fmaf(wp, lsh[2 * (tok + half) + 1], fmaf(wd, lsh[2 * (tok + half)], fmaf(wy, y, fmaf(wx, x, bi))));
-        else if (pdp) v = fmaf(ey, y, fmaf(ex, x, eb));
-        else if (six)
-          v = fmaf(w6, lsh[5 * N + tok],
-                   fmaf(w5, lsh[4 * N + tok], fmaf(wp, lsh[3 * N + tok], fmaf(wd, lsh[2 * N + tok], fmaf(wy, y, fmaf(wx, x, bi))))));
-        else if (four) v = fmaf(wp, lsh[3 * N + tok], fmaf(wd, lsh[2 * N + tok], fmaf(wy, y, fmaf(wx, x, bi))));
-        else if (cvrp) v = fmaf(wd, lsh[2 * N + tok], fmaf(wy, y, fmaf(wx, x, bi)));
-        else v = fmaf(wy, y, fmaf(wx, x, bi));
+        // feature vector of this token in the order its embedding's weight rows take them (unused slots: weight 0)
+        float f2 = 0.0f, f3 = 0.0f, f4 = 0.0f, f5 = 0.0f;
+        if (pdp && tok <= half) {
+          f2 = lsh[2 * (tok + half)];
+          f3 = lsh[2 * (tok + half) + 1];
+        } else if (cvrp) {
+          f2 = lsh[2 * N + tok];
+          if (four) f3 = lsh[3 * N + tok];
+          if (six) {
+            f4 = lsh[4 * N + tok];
+            f5 = lsh[5 * N + tok];
+          }
+        }
+        const bool is_depot = depot && tok == 0, is_delivery = pdp && tok > half;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float r;
+          if (is_depot) r = fmaf(dq[c][1], y, fmaf(dq[c][0], x, dbq[c]));
+          else if (is_delivery) r = fmaf(eq[c][1], y, fmaf(eq[c][0], x, ebq[c]));
+          else {
+            r = fmaf(wq[c][1], y, fmaf(wq[c][0], x, bq[c]));  // same fma order as the per-feature chains before
+            if (ws > 2) r = fmaf(wq[c][2], f2, r);
+            if (ws > 3) r = fmaf(wq[c][3], f3, r);
+            if (ws > 4) r = fmaf(wq[c][5], f5, fmaf(wq[c][4], f4, r));
+          }
+          v[c] = r;
+        }
       }
-      xs[tok * kRS + d] = (__bf16)v;
+      bf16x4 pk;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) pk[c] = (__bf16)v[c];
+      *reinterpret_cast<bf16x4*>(xs + tok * kRS + d0) = pk;
     }
   }
-  stage_biases(0);
   __syncthreads();
 
-  const __bf16* wqkv_all = static_cast<const __bf16*>(a.wqkv_packed);
-  const __bf16* wo_all = static_cast<const __bf16*>(a.wo_packed);
-  const __bf16* w1_all = static_cast<const __bf16*>(a.w1_packed);
-  const __bf16* w2_all = static_cast<const __bf16*>(a.w2_packed);
-
-  const __bf16* wf_all = static_cast<const __bf16*>(a.wfold_packed);
-  bf16x8 wf[8];  // weight fragments of the NEXT GEMM, always one call ahead (gemm_t)
-  load_wfrags(wf, wqkv_all, 8, w, 0, lane);
   for (int layer = 0; layer < a.num_layers; ++layer) {
     LayerPtrs L;
     L.wqkv = wqkv_all + (int64_t)layer * 3 * kD * kD;
