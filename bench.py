@@ -179,7 +179,7 @@ class Bench:
         torch.cuda.synchronize()
 
     def traffic(self, leg: str):
-        """HBM bytes per decode launch of this leg from the separate rocprofv3 --pmc passes (tools/profile_round.sh
+        """HBM bytes per decode launch of this leg from the separate rocprofv3 --pmc passes (tools/profile_legs.sh
         + tools/profile_parse.py write profiles/pmc_traffic.json); (None, None) when the leg was not profiled."""
         try:
             table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
