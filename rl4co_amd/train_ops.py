@@ -169,13 +169,20 @@ def _gemm(a2d: Tensor, w: Tensor, bias: Tensor | None = None, mask: Tensor | Non
     return out
 
 
+# row chunks x output tiles per weight-gradient launch: every chunk writes an fp32 partial that one reduction sums.
+# 512 workgroups (two per CU): measured on the four training shapes at 409 600 rows, kernel + reduction
+# (tools/wgrad_chunks_bench.py): 2048 -> 684 us, 1024 -> 592, 512 -> 484, 256 -> 631 — beyond two per CU the partials
+# (67 MB written and re-read at 1024) cost more than the extra parallelism buys
+_WGRAD_MAX_WORKGROUPS = int(__import__("os").environ.get("RL4CO_WGRAD_WORKGROUPS", "512"))
+
+
 def _wgrad(d2: Tensor, x2: Tensor, with_bias: bool = False):
     """dW[N,K] = d2[M,N]^T @ x2[M,K] and (``with_bias``) db[N] = column sums of d2, both fp32: split over
     the rows on the kernel, partials summed by torch."""
     m, n = d2.shape
     k = x2.shape[1]
     tiles = (n // 128) * (k // 128)
-    chunks = max(1, min(1024 // tiles, (m + 255) // 256))
+    chunks = max(1, min(_WGRAD_MAX_WORKGROUPS // tiles, (m + 255) // 256))
     # one buffer per chunk: [N*K weight partials | N bias partials] -> ONE reduction over the chunk axis for both
     width = n * k + (n if with_bias else 0)
     partial = torch.empty((chunks, width), dtype=torch.float32, device=d2.device)
