@@ -347,6 +347,7 @@ class Bench:
             ll = out["log_likelihood"].view(starts, batch).t()
             adv = reward - reward.mean(dim=1, keepdim=True)  # SharedBaseline over the starts (pomo/model.py:88-111)
             loss = -(adv.detach() * ll).mean()
+            bucket.release()  # fresh gradients, gathered into the flat bucket by one multi-tensor copy below
             loss.backward()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -357,7 +358,6 @@ class Bench:
             ar_events.append((e0, e1))
             torch.nn.utils.clip_grad_norm_(policy.parameters(), 1.0)
             opt.step()
-            bucket.zero_()
             return out
 
         log(f"c4_train: rank {self.rank}/{self.world}, warming up")

@@ -110,15 +110,28 @@ class FlatGradBucket:
     def _rebind(self) -> None:
         """``optimizer.zero_grad(set_to_none=True)`` drops the views; re-attach them."""
         off = 0
+        dst, src, empty = [], [], []
         for p in self.params:
             view = self.flat[off : off + p.numel()].view_as(p)
             if p.grad is None:
-                view.zero_()
+                empty.append(view)
                 p.grad = view
             elif p.grad.data_ptr() != view.data_ptr():
-                view.copy_(p.grad)
+                dst.append(view)
+                src.append(p.grad)
                 p.grad = view
             off += p.numel()
+        if empty:
+            torch._foreach_zero_(empty)
+        if dst:
+            torch._foreach_copy_(dst, src)  # one multi-tensor launch for all detached gradients
+
+    def release(self) -> None:
+        """Detach the gradient views before a backward pass (``p.grad = None``): autograd then hands every parameter its
+        freshly computed gradient instead of ADDING it into the (zeroed) view — 80 five-microsecond add kernels per POMO
+        step — and ``allreduce_mean`` gathers them with one multi-tensor copy. Equivalent to ``zero_()`` + accumulate."""
+        for p in self.params:
+            p.grad = None
 
     def allreduce_mean(self, async_op: bool = False):
         """sum over ranks / world size, in place. Returns the work handle when ``async_op``."""

@@ -161,3 +161,28 @@ def test_single_process_group_issues_the_collective_rccl():
     p.start()
     p.join(300)
     assert p.exitcode == 0 and q.get(timeout=5) == "ok"
+
+
+def test_bucket_release_gathers_fresh_gradients_like_accumulation():
+    """FlatGradBucket.release(): gradients computed into fresh tensors and gathered by one multi-tensor copy equal the
+    accumulate-into-zeroed-views path bit for bit; a parameter that received no gradient contributes zeros."""
+    torch.manual_seed(0)
+    x = torch.rand(5, 8)
+    res = []
+    for release in (False, True):
+        model = _model()
+        model[3].weight.requires_grad_(True)
+        extra = torch.nn.Linear(4, 4)  # never used: no gradient
+        params = torch.nn.ModuleList([model, extra])
+        bucket = D.FlatGradBucket(params)
+        for step in range(2):
+            if release:
+                bucket.release()
+            else:
+                bucket.zero_()
+            model(x * (step + 1)).sum().backward()
+            bucket.allreduce_mean()
+        assert all(p.grad.data_ptr() >= bucket.flat.data_ptr() for p in bucket.params)
+        res.append(bucket.flat.clone())
+    assert torch.equal(res[0], res[1]) and float(res[0].abs().sum()) > 0
+    assert float(res[1][-20:].abs().sum()) == 0.0  # the unused layer's slice

@@ -66,11 +66,11 @@ def step(i):
     # SharedBaseline over the starts (POMO); a single start falls back to the batch mean
     adv = reward - (reward.mean(dim=1, keepdim=True) if S > 1 else reward.mean())
     loss = -(adv.detach() * ll).mean()
+    bucket.release()
     loss.backward()
     bucket.allreduce_mean()
     torch.nn.utils.clip_grad_norm_(policy.parameters(), 1.0)
     opt.step()
-    bucket.zero_()
     return float(reward.mean()), out["actions"].shape[1]
 
 
