@@ -29,6 +29,7 @@ ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--model", default="pomo", choices=["pomo", "am"], help="pomo: 6L instance norm, shared baseline over starts; am: 3L batch norm + graph context, batch-mean baseline")
 ap.add_argument("--env", default="tsp", choices=["tsp", "cvrp", "op", "pctsp", "pdp", "cvrptw"])
+ap.add_argument("--no-release", action="store_true", help="accumulate into the zeroed bucket views instead of gathering fresh gradients")
 ap.add_argument("--no-fused-encoder", action="store_true", help="torch encoder (library GEMMs, SDPA, autograd norm) for comparison")
 args = ap.parse_args()
 
@@ -66,7 +67,10 @@ def step(i):
     # SharedBaseline over the starts (POMO); a single start falls back to the batch mean
     adv = reward - (reward.mean(dim=1, keepdim=True) if S > 1 else reward.mean())
     loss = -(adv.detach() * ll).mean()
-    bucket.release()
+    if args.no_release:
+        bucket.zero_()
+    else:
+        bucket.release()
     loss.backward()
     bucket.allreduce_mean()
     torch.nn.utils.clip_grad_norm_(policy.parameters(), 1.0)
