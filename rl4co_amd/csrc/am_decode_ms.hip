@@ -5,9 +5,10 @@
 // mask: a decode step for all of them is three small GEMMs — scores^T = K_g . Q^T, glimpse^T =
 // V^T . P^T, logits^T = K_l' . heads^T — with the TRAJECTORY as the MFMA column. The streaming
 // kernel (am_decode.hip) runs one wave per trajectory and is VALU-bound there (275 M
-// trajectory-steps/s at TSP-100 x 4096 x 8); here one 512-thread workgroup owns one instance,
-// keeps its three bf16 planes (and the fp32 context table when it fits) resident in LDS for the
-// whole rollout and advances 16 trajectories per v_mfma_f32_16x16x16_bf16 column tile.
+// trajectory-steps/s at TSP-100 x 4096 x 8); here one 512-thread workgroup owns one COLUMN TILE of an
+// instance — 16 of its starts, one per v_mfma_f32_16x16x16_bf16 accumulator column — keeps the instance's
+// glimpse keys / values in LDS and its wave's logit-key tile in registers for the whole rollout, and two
+// such workgroups share a CU (make_layout).
 //
 // Layout (the one am_teacher_mma.hip uses): in the 16x16x16 accumulator a lane owns ONE
 // trajectory (column lane & 15) and four consecutive rows 4 g .. 4 g + 3, which is also the
@@ -17,14 +18,14 @@
 // node, load) in registers. Wave h owns head h for the glimpse and node tile h for the logits;
 // the planes stay in their natural [node][dim] layout and the glimpse product reads V through the
 // gfx950 transpose read ds_read_b64_tr_b16. A decode step is a LATENCY chain (dependent MFMAs,
-// cross-lane reductions, two workgroup barriers), not an issue-bound stream, so each wave advances
-// TWO column tiles (32 trajectories) through the same instruction stream — two independent chains
-// the scheduler interleaves, every plane fragment read once for both — and two waves share a SIMD.
+// cross-lane reductions, two workgroup barriers), not an issue-bound stream: the second workgroup on
+// the CU (four waves per SIMD) is what fills the gaps.
 //
 // Numerics: bf16 MFMA inputs (planes, query, softmax numerators, glimpse), fp32 accumulation and
-// fp32 softmax / tanh / log-softmax — the reference's mixed-precision regime. This variant is NOT
-// part of the bit-exact contract of am_decode.hip (a bf16 query cannot reproduce the fp32
-// specified order); it is tested by tolerance against the streaming kernel on the same planes
+// fp32 softmax / tanh / log-softmax with the hardware's exp2 / log / rcp — the reference's
+// mixed-precision regime. Not part of the bit-exact contract of am_decode.hip (a bf16 query cannot
+// reproduce the fp32 specified order); pinned instead to the rounding-model oracle oracle_am_decode_ms
+// (same bf16 rounding points, fp32 elsewhere): identical trajectories, per-step log-probs within 5e-3
 // (tests/test_gpu_decode_ms.py).
 #include <hip/hip_runtime.h>
 
@@ -95,22 +96,26 @@ struct __align__(16) Xchg {  // per (node tile, trajectory) pieces of the log-so
 };
 
 struct Layout {  // byte offsets into dynamic LDS
-  int kgs, vs, kls, hs, xs, dems, ctx, total;
-  bool ctx_in_lds;
+  int kgs, vs, hs, xs, dems, total;
 };
+// One workgroup = (instance, column tile of 16 starts). A decode step of 16 trajectories is a latency chain (~8 K cycles of
+// dependent MFMAs, transcendentals and two barriers) that leaves every pipe idle most of the time, so the layout is sized
+// for TWO workgroups per CU: glimpse keys / values in LDS (61 KB at N = 100), wave w's logit-key tile (16 nodes x 128
+// dims, the same at every step) in 16 registers for the whole rollout, the fp32 context rows read from L2 (two rows per
+// trajectory-step), one column tile of staging — 70 KB and 128 registers. Measured against the first layout (one
+// workgroup per instance advancing two column tiles, all three planes and the context table in LDS, 142 KB, one workgroup
+// per CU), TSP-100 x 4096 sampling: 8 starts 7.1 -> 4.9 ms, 32 starts 13.8 -> 9.8, 100 starts 48.1 -> 34.1 (1.19 G
+// trajectory-steps/s); the tiles of an instance re-read its planes from the XCD's L2.
 __host__ __device__ inline Layout make_layout(int nt, int n) {
+  (void)n;
   Layout L;
   const int plane = nt * 16 * kRS * 2;
   int o = 0;
   L.kgs = o; o += plane;
   L.vs = o; o += plane;
-  L.kls = o; o += plane;
-  L.hs = o; o += 2 * 16 * kRS * 2;                      // two column tiles
-  L.xs = o; o += 2 * kWaves * 16 * (int)sizeof(Xchg);
+  L.hs = o; o += 16 * kRS * 2;                          // one column tile of glimpses
+  L.xs = o; o += kWaves * 16 * (int)sizeof(Xchg);
   L.dems = o; o += 128 * 4;
-  L.ctx = o;
-  L.ctx_in_lds = o + n * kD * 4 <= kLdsBudget;  // fp32 context rows next to the planes when they fit
-  if (L.ctx_in_lds) o += n * kD * 4;
   L.total = (o + 15) & ~15;
   return L;
 }
@@ -161,11 +166,12 @@ __device__ inline Sel partner(const Sel& p) {
 }
 
 struct Shared {
-  const __bf16 *kgs, *vs, *kls;
+  const uint16_t* kl_g;  // this instance's logit-key plane in global memory (row stride kl_rs)
+  int64_t kl_rs;
+  const __bf16 *kgs, *vs;
   __bf16* hs;   // [CT][16 trajectories][kRS] glimpses of this step
   Xchg* xs;     // [CT][8 node tiles][16 trajectories]
-  const float *dems, *ctxs;
-  bool ctx_in_lds;
+  const float* dems;
 };
 
 // MODE: 0 greedy, 1 sampling, 2 evaluate (RL4CO_DECODE_*). CT column tiles of 16 trajectories advance together.
@@ -229,6 +235,14 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
 #pragma unroll
     for (int e = 0; e < 4; ++e) x.f4[e] = (ENV == RL4CO_ENV_TSP && x.step_i > 0) ? ctxf[(int64_t)x.first * kD + e] : 0.0f;
   }
+  // the logit-key tile of this wave (nodes 16 w .., all 128 dims) is the same at every step — 16 registers for the
+  // whole rollout instead of a third LDS plane (rows past the graph: any finite value, their logits are masked)
+  bf16x4 lfr[8];
+  if (w < NT) {
+    const uint16_t* row = sh.kl_g + (int64_t)min(16 * w + tl, N - 1) * sh.kl_rs + 4 * g;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) lfr[ks] = *reinterpret_cast<const bf16x4*>(row + 16 * ks);
+  }
   int forced[CT];  // evaluate: the given action of the coming step, fetched one step ahead
 #pragma unroll
   for (int c = 0; c < CT; ++c)
@@ -248,8 +262,7 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       const Traj& x = tj[c];
-      const float4 c4 = sh.ctx_in_lds ? *reinterpret_cast<const float4*>(sh.ctxs + x.cur * kD + dcol)
-                                      : *reinterpret_cast<const float4*>(ctxc + (int64_t)x.cur * kD);
+      const float4 c4 = *reinterpret_cast<const float4*>(ctxc + (int64_t)x.cur * kD);  // L2-resident context row
       const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -328,7 +341,7 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
       }
 #pragma clang loop unroll(full)
       for (int ks = 0; ks < 8; ++ks) {
-        const bf16x4 lf = lds_b64(sh.kls + 16 * w * kRS + 16 * ks + nao);
+        const bf16x4 lf = lfr[ks];
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
           const bf16x4 hf = lds_b64(sh.hs + 16 * c * kRS + 16 * ks + nao);
@@ -544,58 +557,57 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
 }
 
 template <int ENV, int NT, int MODE>
-__global__ void __launch_bounds__(kThreads, 2) am_decode_ms_kernel(const rl4co_am_decode_args a) {
+__global__ void __launch_bounds__(kThreads, 4) am_decode_ms_kernel(const rl4co_am_decode_args a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x;
-  const int inst = blockIdx.x;
   const int N = a.N;
   const int S = a.B / a.B_inst;
+  // one workgroup per (instance, column tile of 16 starts). Workgroup b lands on XCD b % 8 (observed placement, speed
+  // only): the tiles of one instance take consecutive slots of one XCD and share its L2 copy of the planes.
+  const int ntiles = (S + 15) >> 4, b = blockIdx.x;
+  int inst, tile0;
+  if ((a.B_inst & 7) == 0) {
+    const int xcd = b & 7, k = b >> 3;
+    inst = (k / ntiles) * 8 + xcd;
+    tile0 = k % ntiles;
+  } else {
+    inst = b / ntiles;
+    tile0 = b % ntiles;
+  }
   const Layout L = make_layout(NT, N);
   if ((tid >> 6) >= 4) __builtin_amdgcn_s_setprio(1);  // even out the younger half of the workgroup (issue arbitration)
   __bf16* kgs = reinterpret_cast<__bf16*>(smem + L.kgs);  // [16 NT nodes][kRS] glimpse keys
   __bf16* vs = reinterpret_cast<__bf16*>(smem + L.vs);    // glimpse values
-  __bf16* kls = reinterpret_cast<__bf16*>(smem + L.kls);  // logit keys
   float* dems = reinterpret_cast<float*>(smem + L.dems);  // [128] CVRP demands (index j-1 at j), 0 elsewhere
-  float* ctxs = reinterpret_cast<float*>(smem + L.ctx);   // [N][128] fp32 context rows (if they fit)
 
-  // ---- planes (and context rows) HBM -> LDS, once per instance ----------------------------------------
+  // ---- glimpse planes HBM / L2 -> LDS, once per workgroup ---------------------------------------------------
   {
     const uint16_t* gk = static_cast<const uint16_t*>(a.glimpse_key) + (int64_t)inst * a.kvl_batch_stride;
     const uint16_t* gv = static_cast<const uint16_t*>(a.glimpse_val) + (int64_t)inst * a.kvl_batch_stride;
-    const uint16_t* gl = static_cast<const uint16_t*>(a.logit_key) + (int64_t)inst * a.kvl_batch_stride;
     for (int c = tid; c < NT * 16 * 16; c += kThreads) {  // 16-byte chunks: row = c / 16, col = (c % 16) * 8
       const int row = c >> 4, col = (c & 15) * 8;
-      uint4 k4 = make_uint4(0, 0, 0, 0), l4 = k4, v4 = k4;
+      uint4 k4 = make_uint4(0, 0, 0, 0), v4 = k4;
       if (row < N) {
         k4 = *reinterpret_cast<const uint4*>(gk + (int64_t)row * a.kvl_row_stride + col);
-        l4 = *reinterpret_cast<const uint4*>(gl + (int64_t)row * a.kvl_row_stride + col);
         v4 = *reinterpret_cast<const uint4*>(gv + (int64_t)row * a.kvl_row_stride + col);
       }
       *reinterpret_cast<uint4*>(kgs + row * kRS + col) = k4;
-      *reinterpret_cast<uint4*>(kls + row * kRS + col) = l4;
       *reinterpret_cast<uint4*>(vs + row * kRS + col) = v4;
     }
     for (int j = tid; j < 128; j += kThreads)
       dems[j] = (ENV == RL4CO_ENV_CVRP && j >= 1 && j < N) ? a.demand[(int64_t)inst * (N - 1) + j - 1] : 0.0f;
-    if (L.ctx_in_lds) {
-      const float4* src = reinterpret_cast<const float4*>(a.ctx_cur + (int64_t)inst * N * kD);
-      for (int i = tid; i < N * kD / 4; i += kThreads) reinterpret_cast<float4*>(ctxs)[i] = src[i];
-    }
   }
   Shared sh;
   sh.kgs = kgs;
   sh.vs = vs;
-  sh.kls = kls;
+  sh.kl_g = static_cast<const uint16_t*>(a.logit_key) + (int64_t)inst * a.kvl_batch_stride;
+  sh.kl_rs = a.kvl_row_stride;
   sh.hs = reinterpret_cast<__bf16*>(smem + L.hs);
   sh.xs = reinterpret_cast<Xchg*>(smem + L.xs);
   sh.dems = dems;
-  sh.ctxs = ctxs;
-  sh.ctx_in_lds = L.ctx_in_lds;
   uint32_t errbits = 0;
-  if (tid == 0 && a.steps_summary) atomicAdd(a.steps_summary + 2, N);  // the planes are read ONCE per instance
-  int s0 = 0;
-  for (; s0 + 16 < S; s0 += 32) rollout_tiles<ENV, NT, MODE, 2>(a, sh, inst, s0, errbits);  // pairs of column tiles
-  if (s0 < S) rollout_tiles<ENV, NT, MODE, 1>(a, sh, inst, s0, errbits);                    // a last single tile
+  if (tid == 0 && a.steps_summary) atomicAdd(a.steps_summary + 2, N);  // the planes are read ONCE per workgroup
+  rollout_tiles<ENV, NT, MODE, 1>(a, sh, inst, 16 * tile0, errbits);  // this workgroup's column tile
   if (errbits) atomicOr(a.err, (int)errbits);
 }
 
@@ -604,7 +616,8 @@ int launch_mode(const rl4co_am_decode_args& a, hipStream_t stream) {
   const Layout L = make_layout(NT, a.N);
   RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_decode_ms_kernel<ENV, NT, MODE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
-  hipLaunchKernelGGL((am_decode_ms_kernel<ENV, NT, MODE>), dim3(a.B_inst), dim3(kThreads), L.total, stream, a);
+  const int ntiles = (a.B / a.B_inst + 15) / 16;  // one workgroup per (instance, column tile of 16 starts)
+  hipLaunchKernelGGL((am_decode_ms_kernel<ENV, NT, MODE>), dim3(a.B_inst * ntiles), dim3(kThreads), L.total, stream, a);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }
