@@ -39,6 +39,7 @@ and of the benchmarked bf16 configuration against the reference's 4096 tours of 
 from __future__ import annotations
 
 import argparse
+import gc
 import hashlib
 import json
 import os
@@ -247,6 +248,8 @@ class Bench:
                     policy.decode_events, policy.encode_events = [], []
             else:
                 policy.decode_events, policy.encode_events = [], []
+            gc.collect()
+            gc.freeze()  # (see train_leg: a full collection over torch's module graph is a 60 ms host stall)
             self.barrier()
             t0 = time.perf_counter()
             for _ in range(steps):
@@ -365,6 +368,12 @@ class Bench:
             step(i)
         torch.cuda.synchronize()
         ar_events.clear()
+        # the interpreter's long-lived objects (torch's module graph: ~1e6 of them) leave the cyclic collector's view:
+        # one full collection walking them is a 60 ms host stall (tools/train_steps.py), and the rollout's 16-byte
+        # status read-back keeps the host at most one step ahead of the GPU, so the stall lands on the step time.
+        # The collector stays on for what the loop itself allocates
+        gc.collect()
+        gc.freeze()
         self.barrier()
         t0 = time.perf_counter()
         for i in range(steps):

@@ -14,7 +14,7 @@
 // the other. Every lane owns a fixed set of cache elements — rows j = 16 i + 4 w + rg (i < ROWS),
 // dims 8 li .. 8 li + 7 — of all three planes: they are loaded into registers ONCE per instance
 // and their gradients are accumulated in registers over all S x T steps (no atomics, no plane
-// traffic inside the loop; N <= 16 * ROWS <= 112). Per step the four waves exchange only the
+// traffic inside the loop; N <= 16 * ROWS <= 128). Per step the four waves exchange only the
 // 128-wide reductions (glimpse, d heads, d query) and a few scalars through LDS.
 // fp32 arithmetic throughout; this is a floating-point kernel tested against torch autograd
 // (tests/test_gpu_teacher.py, tolerance stated there), not part of the bit-exact decode contract.
@@ -432,18 +432,19 @@ int dispatch_rows(const rl4co_am_teacher_args& a, hipStream_t s) {
   const int rows = (a.N + 15) / 16;
   if (rows <= 2) return launch_teacher<ENV, 2>(a, s);
   if (rows <= 4) return launch_teacher<ENV, 4>(a, s);
-  return launch_teacher<ENV, 7>(a, s);
+  if (rows <= 7) return launch_teacher<ENV, 7>(a, s);
+  return launch_teacher<ENV, 8>(a, s);
 }
 
 }  // namespace
 
-extern "C" int rl4co_am_teacher_max_nodes(void) { return 112; }
+extern "C" int rl4co_am_teacher_max_nodes(void) { return 128; }
 
 static int validate_teacher(const rl4co_am_teacher_args& a) {
   RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP || a.env == RL4CO_ENV_OP ||
                 a.env == RL4CO_ENV_PCTSP || a.env == RL4CO_ENV_PDP || a.env == RL4CO_ENV_CVRPTW);
   RL4CO_REQUIRE(a.B > 0 && a.B_inst > 0 && a.B % a.B_inst == 0);
-  RL4CO_REQUIRE(a.N >= 2 && a.N <= 112 && a.T >= 1 && a.t0 >= 0 && a.t0 <= 1);
+  RL4CO_REQUIRE(a.N >= 2 && a.N <= 128 && a.T >= 1 && a.t0 >= 0 && a.t0 <= 1);
   RL4CO_REQUIRE(a.cache_dtype == RL4CO_DT_F32 || a.cache_dtype == RL4CO_DT_BF16);
   RL4CO_REQUIRE(a.variant >= RL4CO_TEACHER_AUTO && a.variant <= RL4CO_TEACHER_MMA);
   RL4CO_REQUIRE(a.glimpse_key && a.glimpse_val && a.logit_key && a.ctx_cur && a.actions && a.grad_logp);

@@ -38,7 +38,7 @@ constexpr int kD = RL4CO_EMBED_DIM;
 constexpr int kRS = kD + 8;  // LDS row stride (bf16 elements): conflict-free 8-byte row reads
 constexpr int kWaves = 8;
 constexpr int kThreads = 64 * kWaves;
-constexpr int kMaxTiles = 7;  // node tiles of 16: N <= 112
+constexpr int kMaxTiles = 8;  // node tiles of 16: N <= 128
 constexpr int kMaxT = 256;    // action columns the step tables hold
 constexpr float kNegInf = -__builtin_huge_valf();
 constexpr float kSqrtD = 11.3137084989847604f;
@@ -80,7 +80,7 @@ __device__ inline float rg_max(float v) { return rl4co::bfly_max<16, 64>(v); }
 __device__ inline float step_sum(float v) { return rl4co::bfly_sum<1, 16>(v); }
 
 struct Layout {  // byte offsets into dynamic LDS
-  int kgs, vs, kls, ob, dub, qb, dob, pb, sact, srem, stime, sg, smask, spos, sval, xz, xa, sinfo, total;
+  int kgs, vs, kls, ob, dub, qb, pb, sact, srem, stime, sg, smask, spos, sval, xz, xa, sinfo, total;
 };
 __host__ __device__ inline Layout make_layout(int nt) {
   Layout L;
@@ -92,7 +92,6 @@ __host__ __device__ inline Layout make_layout(int nt) {
   L.ob = o; o += blk;
   L.dub = o; o += blk;
   L.qb = o; o += blk;
-  L.dob = o; o += blk;
   L.pb = o; o += kWaves * blk;
   L.sact = o; o += kMaxT * 4;
   L.srem = o; o += kMaxT * 4;
@@ -126,7 +125,10 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
   __bf16* ob = reinterpret_cast<__bf16*>(smem + L.ob);    // [16 steps][kRS] glimpses of the block
   __bf16* dub = reinterpret_cast<__bf16*>(smem + L.dub);  // [16 steps][kRS] d logits (pre-clip, raw)
   __bf16* qb = reinterpret_cast<__bf16*>(smem + L.qb);    // [16 steps][kRS] queries (x 0.25 log2 e)
-  __bf16* dob = reinterpret_cast<__bf16*>(smem + L.dob);  // [16 steps][kRS] d glimpse / softmax denominator
+  // d glimpse / softmax denominator of the block takes the glimpses' place: after B3 a wave reads only its own head's
+  // columns of `ob` (the O_h^T operand of d Kl) and writes the same columns of `dob` afterwards — eight wave-private
+  // column strips, ordered by program order within the wave. 4 KB that let eight node tiles (N <= 128) fit in 160 KB
+  __bf16* dob = ob;
   __bf16* pbw = reinterpret_cast<__bf16*>(smem + L.pb) + w * 16 * kRS;  // this wave's [16 steps][kRS] P, then dS
   int* sact = reinterpret_cast<int*>(smem + L.sact);
   float* srem = reinterpret_cast<float*>(smem + L.srem);
@@ -705,6 +707,7 @@ static int dispatch_tiles(const rl4co_am_teacher_args& a, hipStream_t stream) {
   const int nt = (a.N + 15) >> 4;
   if (nt <= 2) return launch_tiles<ENV, 2>(a, stream);
   if (nt <= 4) return launch_tiles<ENV, 4>(a, stream);
+  if (nt <= 7) return launch_tiles<ENV, 7>(a, stream);
   return launch_tiles<ENV, kMaxTiles>(a, stream);
 }
 

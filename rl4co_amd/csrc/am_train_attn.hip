@@ -24,7 +24,7 @@ namespace {
 
 constexpr int kD = RL4CO_EMBED_DIM;
 constexpr int kQS = 3 * kD + 8;  // LDS row stride of the qkv tile (bf16)
-constexpr int kOS = kD + 8;      // LDS row stride of 128-wide tiles
+constexpr int kPS = kD + 24;     // LDS row stride of a wave's staging block: 128 key columns (P, then dS) + 16 d-out columns
 constexpr int kWaves = 8;
 constexpr int kThreads = 64 * kWaves;
 constexpr float kNegInf = -__builtin_huge_valf();
@@ -149,15 +149,24 @@ __global__ void __launch_bounds__(kThreads, 2) attn_bwd_kernel(const uint16_t* _
                                                                const float* __restrict__ lse, int N, uint16_t* __restrict__ dqkv) {
   extern __shared__ __align__(16) unsigned char smem[];
   __bf16* qs = reinterpret_cast<__bf16*>(smem);                   // [16 NT][kQS]
-  __bf16* dos = qs + NT * 16 * kQS;                                // [16 NT][kOS] d out
   const int tid = threadIdx.x, h = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
-  __bf16* pbw = dos + NT * 16 * kOS + h * 16 * kOS;                // this wave's [16 queries][kOS] P, then dS
+  __bf16* pbw = qs + NT * 16 * kQS + h * 16 * kPS;                 // this wave's [16 queries][kPS]: P, then dS | dO_h
   const int64_t inst = blockIdx.x;
   stage_rows<NT>(qkv + inst * N * 3 * kD, N, 3 * kD, qs, kQS, tid);
-  stage_rows<NT>(dout + inst * N * kD, N, kD, dos, kOS, tid);
+  // d out never sits in LDS as a whole: a wave only ever touches the 16 columns of its head of the CURRENT query
+  // block, and in the accumulator layout that is 8 bytes per lane — exactly the B operand, straight from global
+  // memory one block ahead; the transposed A operand of d V goes through 512 bytes of the wave's staging block
+  const uint16_t* dorow = dout + inst * N * kD + 16 * h + 4 * g;
+  auto load_do = [&](int tb) {
+    const int t = 16 * tb + tl;
+    uint2 v = make_uint2(0u, 0u);
+    if (t < N) v = *reinterpret_cast<const uint2*>(dorow + (int64_t)t * kD);
+    return __builtin_bit_cast(bf16x4, v);
+  };
+  bf16x4 dof_next = load_do(0);
   __syncthreads();
-  const int nao = tl * kQS + 4 * g, nao_o = tl * kOS + 4 * g;
-  const int tro = (4 * g + (tl >> 2)) * kQS + 4 * (tl & 3), tro_o = (4 * g + (tl >> 2)) * kOS + 4 * (tl & 3);
+  const int nao = tl * kQS + 4 * g;
+  const int tro = (4 * g + (tl >> 2)) * kQS + 4 * (tl & 3), tro_p = (4 * g + (tl >> 2)) * kPS + 4 * (tl & 3);
   f32x4 dk[NT], dv[NT];  // [d = 4 g + r of head h][key 16 jt + (lane & 15)]
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) {
@@ -168,7 +177,9 @@ __global__ void __launch_bounds__(kThreads, 2) attn_bwd_kernel(const uint16_t* _
     const int t = 16 * tb + tl;
     const bool tv = t < N;
     const bf16x4 qf = lds_b64(qs + 16 * tb * kQS + 16 * h + nao);
-    const bf16x4 dof = lds_b64(dos + 16 * tb * kOS + 16 * h + nao_o);
+    const bf16x4 dof = dof_next;
+    if (tb + 1 < NT) dof_next = load_do(tb + 1);
+    *reinterpret_cast<bf16x4*>(pbw + tl * kPS + kD + 4 * g) = dof;
     const float L = tv ? lse[(inst * kWaves + h) * N + t] : 0.0f;
     bf16x4 pf[NT];
     f32x4 dp[NT];
@@ -184,14 +195,14 @@ __global__ void __launch_bounds__(kThreads, 2) attn_bwd_kernel(const uint16_t* _
         pf[jt][rr] = (__bf16)p;
         dsum = fmaf((float)pf[jt][rr], dp[jt][rr], dsum);
       }
-      *reinterpret_cast<bf16x4*>(pbw + tl * kOS + 16 * jt + 4 * g) = pf[jt];
+      *reinterpret_cast<bf16x4*>(pbw + tl * kPS + 16 * jt + 4 * g) = pf[jt];
     }
     dsum = rg_sum(dsum);
     wave_lds_sync();
     {
-      const bf16x4 dt = lds_tr(dos + 16 * tb * kOS + 16 * h + tro_o);  // dO_h^T[d][queries]
+      const bf16x4 dt = lds_tr(pbw + kD + tro_p);  // dO_h^T[d][queries]
 #pragma clang loop unroll(full)
-      for (int jt = 0; jt < NT; ++jt) dv[jt] = mfma16(dt, lds_tr(pbw + 16 * jt + tro_o), dv[jt]);
+      for (int jt = 0; jt < NT; ++jt) dv[jt] = mfma16(dt, lds_tr(pbw + 16 * jt + tro_p), dv[jt]);
     }
     wave_lds_sync();  // the transpose reads of P are done: the block is reused for dS
     f32x4 dq = zero4();
@@ -200,14 +211,14 @@ __global__ void __launch_bounds__(kThreads, 2) attn_bwd_kernel(const uint16_t* _
       bf16x4 dsf;
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) dsf[rr] = (__bf16)((float)pf[jt][rr] * (dp[jt][rr] - dsum));
-      *reinterpret_cast<bf16x4*>(pbw + tl * kOS + 16 * jt + 4 * g) = dsf;
+      *reinterpret_cast<bf16x4*>(pbw + tl * kPS + 16 * jt + 4 * g) = dsf;
       dq = mfma16(lds_tr(qs + 16 * jt * kQS + kD + 16 * h + tro), dsf, dq);
     }
     wave_lds_sync();
     {
       const bf16x4 qt = lds_tr(qs + 16 * tb * kQS + 16 * h + tro);  // Q_h^T[d][queries]
 #pragma clang loop unroll(full)
-      for (int jt = 0; jt < NT; ++jt) dk[jt] = mfma16(qt, lds_tr(pbw + 16 * jt + tro_o), dk[jt]);
+      for (int jt = 0; jt < NT; ++jt) dk[jt] = mfma16(qt, lds_tr(pbw + 16 * jt + tro_p), dk[jt]);
     }
     if (tv) {
 #pragma unroll
@@ -246,7 +257,7 @@ int launch_fwd(const void* qkv, int B, int N, void* out, float* lse, hipStream_t
 }
 template <int NT>
 int launch_bwd(const void* qkv, const void* dout, const float* lse, int B, int N, void* dqkv, hipStream_t s) {
-  const int lds = (NT * 16 * kQS + NT * 16 * kOS + kWaves * 16 * kOS) * 2;
+  const int lds = (NT * 16 * kQS + kWaves * 16 * kPS) * 2;
   RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipLaunchKernelGGL(attn_bwd_kernel<NT>, dim3(B), dim3(kThreads), lds, s, static_cast<const uint16_t*>(qkv),
                      static_cast<const uint16_t*>(dout), lse, N, static_cast<uint16_t*>(dqkv));
@@ -256,22 +267,24 @@ int launch_bwd(const void* qkv, const void* dout, const float* lse, int B, int N
 
 }  // namespace
 
-extern "C" int rl4co_attn_max_nodes(void) { return 112; }
+extern "C" int rl4co_attn_max_nodes(void) { return 128; }
 
 extern "C" int rl4co_attn_fwd_bf16(const void* qkv, int B, int N, void* out, float* lse, void* stream) {
-  RL4CO_REQUIRE(qkv && out && lse && B > 0 && N >= 1 && N <= 112);
+  RL4CO_REQUIRE(qkv && out && lse && B > 0 && N >= 1 && N <= 128);
   hipStream_t s = rl4co::as_stream(stream);
   const int nt = (N + 15) >> 4;
   if (nt <= 2) return launch_fwd<2>(qkv, B, N, out, lse, s);
   if (nt <= 4) return launch_fwd<4>(qkv, B, N, out, lse, s);
-  return launch_fwd<7>(qkv, B, N, out, lse, s);
+  if (nt <= 7) return launch_fwd<7>(qkv, B, N, out, lse, s);
+  return launch_fwd<8>(qkv, B, N, out, lse, s);
 }
 
 extern "C" int rl4co_attn_bwd_bf16(const void* qkv, const void* dout, const float* lse, int B, int N, void* dqkv, void* stream) {
-  RL4CO_REQUIRE(qkv && dout && lse && dqkv && B > 0 && N >= 1 && N <= 112);
+  RL4CO_REQUIRE(qkv && dout && lse && dqkv && B > 0 && N >= 1 && N <= 128);
   hipStream_t s = rl4co::as_stream(stream);
   const int nt = (N + 15) >> 4;
   if (nt <= 2) return launch_bwd<2>(qkv, dout, lse, B, N, dqkv, s);
   if (nt <= 4) return launch_bwd<4>(qkv, dout, lse, B, N, dqkv, s);
-  return launch_bwd<7>(qkv, dout, lse, B, N, dqkv, s);
+  if (nt <= 7) return launch_bwd<7>(qkv, dout, lse, B, N, dqkv, s);
+  return launch_bwd<8>(qkv, dout, lse, B, N, dqkv, s);
 }

@@ -227,7 +227,7 @@ def test_fused_linear_and_mlp_gradients_match_torch():
         assert rel <= 2e-2, (nm, rel)
 
 
-@pytest.mark.parametrize("n", [20, 50, 100, 101, 112])
+@pytest.mark.parametrize("n", [20, 50, 100, 101, 112, 113, 128])
 def test_fused_attention_matches_torch_sdpa(n):
     """csrc/am_train_attn.hip forward / backward vs torch SDPA in fp32 on the same bf16 qkv: output within
     1.5e-2 absolute (bf16 output, bf16 softmax numerators), d qkv within 3e-2 relative Frobenius error."""
@@ -266,18 +266,24 @@ def _pomo_policy(seed=0, fused=True, normalization="instance", graph_context=Fal
     return pol
 
 
-@pytest.mark.parametrize("normalization,graph_context,env_name", [("instance", False, "tsp"), ("batch", True, "tsp"),
-                                                                   ("batch", True, "cvrp")])
-def test_bf16_training_step_on_kernels_matches_torch_path(normalization, graph_context, env_name):
+@pytest.mark.parametrize("normalization,graph_context,env_name,num_loc", [("instance", False, "tsp", 50), ("batch", True, "tsp", 50),
+                                                                           ("batch", True, "cvrp", 50), ("instance", False, "tsp", 128),
+                                                                           ("instance", False, "cvrp", 119)])
+def test_bf16_training_step_on_kernels_matches_torch_path(normalization, graph_context, env_name, num_loc):
     """The whole bf16-autocast POMO training step on the HIP kernels (encoder linears, attention, skip + norm,
     fold GEMMs, multistart rollout, MMA teacher backward) vs the same step with the torch encoder: the
     same trajectories are evaluated (actions given), so the parameter gradients must agree up to bf16
     rounding: cosine similarity >= 0.98 per tensor that carries signal, >= 0.995 over all parameters."""
     from rl4co_amd.envs import get_env
 
-    env = get_env(env_name, generator_params=dict(num_loc=50, device="cuda"), device="cuda", check_solution=False)
+    from rl4co_amd import teacher, train_ops
+
+    env = get_env(env_name, generator_params=dict(num_loc=num_loc, device="cuda"), device="cuda", check_solution=False)
     torch.manual_seed(1)
-    data = env.generator(batch_size=[64])
+    data = env.generator(batch_size=[64 if num_loc <= 50 else 16])
+    n_nodes = num_loc + (env_name != "tsp")
+    # every training kernel serves graphs up to 128 nodes (eight node tiles): no cliff between 113 and 128
+    assert n_nodes <= teacher.max_nodes() == train_ops.max_nodes() == 128
     kw = dict(normalization=normalization, graph_context=graph_context, env_name=env_name)
     ref_pol = _pomo_policy(fused=False, **kw)
     with torch.no_grad():

@@ -124,9 +124,10 @@ def test_mma_gradient_is_linear_in_upstream_gradient():
             torch.testing.assert_close(b[k] * 2.0 ** 20, a[k], rtol=1e-5, atol=1e-6 * float(a[k].abs().max()))
 
 
-@pytest.mark.parametrize("env_name,num_loc,starts", [("tsp", 112, 3), ("cvrp", 111, 0), ("cvrp", 100, 5)])
+@pytest.mark.parametrize("env_name,num_loc,starts", [("tsp", 112, 3), ("cvrp", 111, 0), ("cvrp", 100, 5), ("tsp", 113, 2),
+                                                     ("tsp", 128, 3), ("cvrp", 127, 0)])
 def test_mma_at_the_node_limit_and_long_horizons(env_name, num_loc, starts):
-    """N = 112 (the last node tile full), CVRP horizons beyond 128 columns (more than eight 16-step blocks),
+    """N = 112 (seven node tiles full), N = 113 .. 128 (the eight-tile instantiation), CVRP horizons beyond 128 columns (more than eight 16-step blocks),
     odd multistart counts — on freshly drawn instances instead of the golden ones."""
     from rl4co_amd import teacher
     from rl4co_amd.envs import get_env
@@ -156,7 +157,8 @@ def test_mma_at_the_node_limit_and_long_horizons(env_name, num_loc, starts):
 
 
 @pytest.mark.parametrize("env_name,num_loc", [("op", 20), ("op", 100), ("pctsp", 20), ("pctsp", 100), ("pdp", 20),
-                                              ("pdp", 100), ("cvrptw", 20), ("cvrptw", 50)])
+                                              ("pdp", 100), ("cvrptw", 20), ("cvrptw", 50), ("op", 127), ("pdp", 126),
+                                              ("tsp", 128), ("cvrp", 120)])
 def test_mma_orienteering_matches_torch_autograd(env_name, num_loc):
     """Orienteering and prize-collecting TSP have no replay kernel: the MMA backward (closed-form replay of tour
     length / collected prize and of their masks) is checked against torch autograd through the dense re-evaluation on the same trajectories.
