@@ -461,6 +461,14 @@ typedef struct rl4co_am_teacher_args {
   float* d_w_time;               /* [128] CVRPTW, zero-initialised                  */
   float* logp_out;               /* [B,T] forward values, or NULL                   */
   int32_t* err;
+  /* MMA variant: the three plane gradients as bf16 rows with the caller's strides instead of fp32 d_kvl (which may
+   * then be NULL) — element [p][b][n][c] at d_planes_bf16 + p * plane_stride + b * batch_stride + n * row_stride + c.
+   * Lets the caller place them next to each other as the columns of ONE [B_inst * N, 5 * 128] gradient matrix, the
+   * operand of the fold GEMMs' backward (rl4co_linear_bf16 / rl4co_wgrad_bf16), without an fp32 round trip. */
+  void* d_planes_bf16;
+  int64_t d_planes_row_stride;
+  int64_t d_planes_batch_stride;
+  int64_t d_planes_plane_stride;
 } rl4co_am_teacher_args;
 
 int rl4co_am_teacher_backward(const rl4co_am_teacher_args* args, void* stream);
@@ -519,12 +527,14 @@ int rl4co_bnorm_bwd_bf16(const void* dout, const void* y, const float* mean, con
  * a12 (training)  nn.Linear over the token rows: Wqkv, out_proj, MLP
  *   rl4co/models/nn/attention.py:64-134 ; nn/mlp.py:52-61
  * out[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]); bf16 A, W, out, fp32 bias and accumulate.
- * epilogue: relu != 0 -> max(.,0); mask != NULL -> (mask[m,n] > 0 ? . : 0) (ReLU backward, bf16 mask).
+ * epilogue: relu != 0 -> max(.,0); mask != NULL -> (mask[m,n] > 0 ? . : 0) (ReLU backward, bf16 mask);
+ * residual != NULL -> . + residual[m,n] (bf16 [M,N]: the skip connection's gradient joins the branch's input
+ * gradient here, nn/ops.py:9-15 backward, instead of in one more pass over both). mask and residual exclude each other.
  * With W = weight^T (contiguous) it is the input gradient dX = dY . weight.
- * N and K multiples of 128; bias and mask may be NULL.
+ * N and K multiples of 128; bias, mask and residual may be NULL.
  * -------------------------------------------------------------------------- */
-int rl4co_linear_bf16(const void* a, const void* w, const float* bias, const void* mask, int64_t M, int N, int K,
-                      int relu, void* out, void* stream);
+int rl4co_linear_bf16(const void* a, const void* w, const float* bias, const void* mask, const void* residual, int64_t M,
+                      int N, int K, int relu, void* out, void* stream);
 /* Weight gradient of the same layers: partial[c][N,K] = dY[rows of chunk c]^T . X[rows of chunk c]
  * (bf16 dY [M,N], X [M,K]; fp32 partial [chunks,N,K], every element written); dW = sum over c.
  * partial_bias [chunks,N] (or NULL) receives the column sums of dY per chunk: db = sum over c.

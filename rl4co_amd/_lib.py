@@ -115,7 +115,7 @@ SYMBOLS = {
     "rl4co_bnorm_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
     "rl4co_init_embed_bf16": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp]),
     "rl4co_init_embed_wgrad_bf16": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp]),
-    "rl4co_linear_bf16": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_linear_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_attn_fwd_bf16": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "rl4co_attn_bwd_bf16": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_attn_max_nodes": (C.c_int, []),

@@ -450,7 +450,10 @@ static int validate_teacher(const rl4co_am_teacher_args& a) {
   RL4CO_REQUIRE(a.glimpse_key && a.glimpse_val && a.logit_key && a.ctx_cur && a.actions && a.grad_logp);
   RL4CO_REQUIRE(a.kvl_row_stride >= kD && a.kvl_batch_stride >= (int64_t)a.N * kD);
   RL4CO_REQUIRE(a.temperature > 0.0f);
-  RL4CO_REQUIRE(a.d_kvl && a.d_ctx_cur && a.err);
+  RL4CO_REQUIRE((a.d_kvl || a.d_planes_bf16) && a.d_ctx_cur && a.err);
+  if (a.d_planes_bf16)  // 8-byte stores of four bf16 dims
+    RL4CO_REQUIRE(a.d_planes_row_stride >= kD && a.d_planes_row_stride % 4 == 0 && a.d_planes_batch_stride % 4 == 0 &&
+                  a.d_planes_plane_stride % 4 == 0 && (reinterpret_cast<uintptr_t>(a.d_planes_bf16) & 7) == 0);
   if (a.env == RL4CO_ENV_TSP) {
     RL4CO_REQUIRE(a.ctx_first && a.q_step0 && a.d_ctx_first && a.d_q_step0);
   } else if (a.env == RL4CO_ENV_CVRP || a.env == RL4CO_ENV_PCTSP) {  // PCTSP: real prize [B_inst,N], prize_required
@@ -472,6 +475,8 @@ static int resolve_teacher_variant(const rl4co_am_teacher_args& a) {
   const bool mma_ok = a.cache_dtype == RL4CO_DT_BF16 && a.N <= rl4co::teacher_mma_max_nodes() &&
                       a.T <= rl4co::teacher_mma_max_steps() && a.kvl_row_stride % 8 == 0 && a.kvl_batch_stride % 8 == 0;
   if (a.env == RL4CO_ENV_OP || a.env == RL4CO_ENV_PCTSP || a.env == RL4CO_ENV_PDP || a.env == RL4CO_ENV_CVRPTW)  // closed-form replay exists in the MMA variant only
+    return (mma_ok && a.variant != RL4CO_TEACHER_REPLAY) ? RL4CO_TEACHER_MMA : -1;
+  if (a.d_planes_bf16 || !a.d_kvl)  // bf16 plane gradients come out of the MMA variant only
     return (mma_ok && a.variant != RL4CO_TEACHER_REPLAY) ? RL4CO_TEACHER_MMA : -1;
   if (a.variant == RL4CO_TEACHER_MMA) return mma_ok ? RL4CO_TEACHER_MMA : -1;
   if (a.variant == RL4CO_TEACHER_REPLAY) return RL4CO_TEACHER_REPLAY;

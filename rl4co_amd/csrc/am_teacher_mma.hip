@@ -655,7 +655,21 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
   }
 
   // ---- the instance's plane gradients: dims 16 h + 4 g .. + 3 of node 16 jt + (lane & 15) -----------
-  {
+  const float c = 1.0f / kLog2e;  // the staged queries carried log2(e)
+  if (a.d_planes_bf16) {  // bf16 rows in the caller's layout (columns of the fold GEMMs' gradient operand)
+    __bf16* dk = static_cast<__bf16*>(a.d_planes_bf16) + (int64_t)inst * a.d_planes_batch_stride + dcol;
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) {
+      const int j = 16 * jt + tl;
+      if (j < N) {
+        __bf16* p0 = dk + (int64_t)j * a.d_planes_row_stride;
+        const f32x4 kg = {dkg[jt][0] * c, dkg[jt][1] * c, dkg[jt][2] * c, dkg[jt][3] * c};
+        *reinterpret_cast<bf16x4*>(p0) = to_bf16(kg);
+        *reinterpret_cast<bf16x4*>(p0 + a.d_planes_plane_stride) = to_bf16(dvg[jt]);
+        *reinterpret_cast<bf16x4*>(p0 + 2 * a.d_planes_plane_stride) = to_bf16(dkl[jt]);
+      }
+    }
+  } else {
     float* dk = a.d_kvl + (int64_t)inst * N * kD;
     const int64_t plane = (int64_t)a.B_inst * N * kD;
 #pragma unroll
@@ -663,7 +677,6 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
       const int j = 16 * jt + tl;
       if (j < N) {
         float* p0 = dk + (int64_t)j * kD + dcol;
-        const float c = 1.0f / kLog2e;  // the staged queries carried log2(e)
         *reinterpret_cast<float4*>(p0) = make_float4(dkg[jt][0] * c, dkg[jt][1] * c, dkg[jt][2] * c, dkg[jt][3] * c);
         *reinterpret_cast<float4*>(p0 + plane) = make_float4(dvg[jt][0], dvg[jt][1], dvg[jt][2], dvg[jt][3]);
         *reinterpret_cast<float4*>(p0 + 2 * plane) = make_float4(dkl[jt][0], dkl[jt][1], dkl[jt][2], dkl[jt][3]);

@@ -163,7 +163,13 @@ __global__ void __launch_bounds__(kThreads, 2) attn_bwd_kernel(const uint16_t* _
     if (t < N) v = *reinterpret_cast<const uint2*>(dorow + (int64_t)t * kD);
     return __builtin_bit_cast(bf16x4, v);
   };
+  const float* lrow = lse + (inst * kWaves + h) * N;
+  auto load_lse = [&](int tb) {
+    const int t = 16 * tb + tl;
+    return t < N ? lrow[t] : 0.0f;
+  };
   bf16x4 dof_next = load_do(0);
+  float L_next = load_lse(0);
   __syncthreads();
   const int nao = tl * kQS + 4 * g;
   const int tro = (4 * g + (tl >> 2)) * kQS + 4 * (tl & 3), tro_p = (4 * g + (tl >> 2)) * kPS + 4 * (tl & 3);
@@ -178,9 +184,12 @@ __global__ void __launch_bounds__(kThreads, 2) attn_bwd_kernel(const uint16_t* _
     const bool tv = t < N;
     const bf16x4 qf = lds_b64(qs + 16 * tb * kQS + 16 * h + nao);
     const bf16x4 dof = dof_next;
-    if (tb + 1 < NT) dof_next = load_do(tb + 1);
+    const float L = L_next;
+    if (tb + 1 < NT) {  // both of the next block's global operands: nothing in this iteration waits for memory
+      dof_next = load_do(tb + 1);
+      L_next = load_lse(tb + 1);
+    }
     *reinterpret_cast<bf16x4*>(pbw + tl * kPS + kD + 4 * g) = dof;
-    const float L = tv ? lse[(inst * kWaves + h) * N + t] : 0.0f;
     bf16x4 pf[NT];
     f32x4 dp[NT];
     float dsum = 0.0f;

@@ -224,7 +224,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __global__ void __launch_bounds__(kGemmThreads, 2) linear_bf16_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
                                                                       const float* __restrict__ bias, const uint16_t* __restrict__ mask,
-                                                                      int M, int N, int K, int relu, uint16_t* __restrict__ out) {
+                                                                      const uint16_t* __restrict__ residual, int M, int N, int K, int relu,
+                                                                      uint16_t* __restrict__ out) {
   extern __shared__ __align__(16) unsigned char smem_g[];
   __bf16* as = reinterpret_cast<__bf16*>(smem_g);  // [128 tokens][kLS]
   __bf16* ws = as + kTM * kLS;                       // [128 features][kLS]
@@ -311,12 +312,15 @@ __global__ void __launch_bounds__(kGemmThreads, 2) linear_bf16_kernel(const uint
       }
       rl4co::lds_barrier_wave();
       const int orow = lane >> 4, ocol = (lane & 15) * 8;  // four rows per pass, 16 bytes per lane
-      u32x4 mks[8];  // the ReLU-backward mask rows of this wave, all requested before the first is used
-      if (mask) {
+      // the ReLU-backward mask rows OR the residual rows of this wave (never both: validated by the entry point), all
+      // requested before the first is used
+      const uint16_t* aux = mask ? mask : residual;
+      u32x4 mks[8];
+      if (aux) {
 #pragma unroll
         for (int p8 = 0; p8 < 8; ++p8) {
           const int64_t row = min(m0 + 32 * w + 4 * p8 + orow, (int64_t)M - 1);
-          mks[p8] = *reinterpret_cast<const u32x4*>(mask + row * N + nt * kTN + ocol);
+          mks[p8] = *reinterpret_cast<const u32x4*>(aux + row * N + nt * kTN + ocol);
         }
       }
 #pragma unroll
@@ -333,6 +337,16 @@ __global__ void __launch_bounds__(kGemmThreads, 2) linear_bf16_kernel(const uint
               const uint32_t keep_lo = ((m_ & 0x8000u) == 0 && (m_ & 0x7fffu) != 0) ? 0x0000ffffu : 0u;
               const uint32_t keep_hi = ((m_ >> 31) == 0 && (m_ & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
               val[i] &= (keep_lo | keep_hi);
+            }
+          } else if (residual) {  // + the skip connection's gradient: the sum autograd would form in one more pass
+            const u32x4 rs = mks[p8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float lo = __uint_as_float(val[i] << 16) + __uint_as_float(rs[i] << 16);
+              const float hi = __uint_as_float(val[i] & 0xffff0000u) + __uint_as_float(rs[i] & 0xffff0000u);
+              typedef __bf16 bf16x2g __attribute__((ext_vector_type(2)));
+              const bf16x2g pk = {(__bf16)lo, (__bf16)hi};
+              val[i] = __builtin_bit_cast(uint32_t, pk);
             }
           }
           *reinterpret_cast<u32x4*>(out + row * N + nt * kTN + ocol) = val;
@@ -351,18 +365,19 @@ __global__ void __launch_bounds__(kGemmThreads, 2) linear_bf16_kernel(const uint
 
 }  // namespace
 
-extern "C" int rl4co_linear_bf16(const void* a, const void* w, const float* bias, const void* mask, int64_t M, int N, int K,
-                                 int relu, void* out, void* stream) {
+extern "C" int rl4co_linear_bf16(const void* a, const void* w, const float* bias, const void* mask, const void* residual,
+                                 int64_t M, int N, int K, int relu, void* out, void* stream) {
   RL4CO_REQUIRE(a && w && out);
   RL4CO_REQUIRE(M > 0 && M < (int64_t)1 << 31 && N > 0 && K > 0 && N % kTN == 0 && K % kTK == 0);
-  RL4CO_REQUIRE(!(relu && mask));
+  RL4CO_REQUIRE(!(relu && mask) && !(mask && residual));
   const int lds = (kTM + kTN) * kLS * 2;
   RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   const int blocks = (int)((M + kTM - 1) / kTM);
   hipLaunchKernelGGL(linear_bf16_kernel, dim3(blocks), dim3(kGemmThreads), lds, rl4co::as_stream(stream),
                      static_cast<const uint16_t*>(a), static_cast<const uint16_t*>(w), bias,
-                     static_cast<const uint16_t*>(mask), (int)M, N, K, relu, static_cast<uint16_t*>(out));
+                     static_cast<const uint16_t*>(mask), static_cast<const uint16_t*>(residual), (int)M, N, K, relu,
+                     static_cast<uint16_t*>(out));
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }

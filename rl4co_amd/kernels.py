@@ -228,7 +228,11 @@ def am_decode(
     a.variant = VARIANT_IDS[variant]
     a.mask_inner, a.mask_logits = int(mask_inner), int(mask_logits)
     a.tanh_clipping, a.temperature = float(tanh_clipping), float(temperature)
-    kvl = _dev(cache.kvl, None, "cache.kvl")
+    kvl = cache.kvl  # [3, B, N, 128]: plane pointers + (instance, node) strides — any view with unit channel stride
+    if not kvl.is_cuda:
+        raise _lib.Rl4coLibraryError(f"cache.kvl lives on {kvl.device}; the rl4co_amd kernels only run on the MI355X (no CPU fallback)")
+    if not (kvl.dim() == 4 and kvl.stride(3) == 1):
+        raise ValueError("cache.kvl must be [3, B, N, 128] with unit stride along the channels")
     if kvl.dtype == torch.float32:
         a.cache_dtype = _lib.DT_F32
     elif kvl.dtype == torch.bfloat16:

@@ -150,6 +150,13 @@ class _EncoderLayer(nn.Sequential):
             attn, ffn = self[0].module, self[2].module
             gemm_ok = (self.fused_linear and train_ops.linear_usable(x, attn.Wqkv.weight, attn.out_proj.weight,
                                                                       *(lin.weight for lin in ffn.lins)))
+            # the usual case: each residual sub-block is one autograd node (the skip's gradient joins in a GEMM epilogue)
+            if (gemm_ok and attn.num_heads == 8 and len(ffn.lins) == 2 and self[1].kind == self[3].kind
+                    and all(lin.bias is not None for lin in (attn.Wqkv, attn.out_proj, *ffn.lins))
+                    and train_ops.block_usable(x, self[1].kind, attn.Wqkv.weight, attn.out_proj.weight,
+                                               *(lin.weight for lin in ffn.lins))):
+                x = train_ops.attention_block(x, attn, self[1])
+                return train_ops.mlp_block(x, ffn, self[3])
             for skip, norm in ((self[0], self[1]), (self[2], self[3])):
                 s = skip.module(x, fused=gemm_ok)
                 if norm.kind == "batch" and train_ops.batch_usable(x, s):
@@ -685,7 +692,10 @@ class AttentionModelPolicy(nn.Module):
             from . import teacher
 
             if teacher.supports(self.env_name, self.cache_dtype, n) and not return_entropy:
-                cache_g = teacher.build_cache_autograd(self.env_name, hidden, self.decoder)
+                # bf16 encoder output + bf16 planes + the MMA backward: ONE fold GEMM each way, the planes side by side
+                fused_planes = (hidden.dtype == torch.bfloat16 and self.cache_dtype == torch.bfloat16
+                                and self.teacher_variant != "replay")
+                cache_g = teacher.build_cache_autograd(self.env_name, hidden, self.decoder, fused_planes=fused_planes)
                 cache = teacher.detached_cache(self.env_name, cache_g, self.cache_dtype)
         if cache is None:
             with torch.no_grad():

@@ -34,6 +34,8 @@ class AmTeacherArgs(C.Structure):
         ("time_windows", _vp), ("durations", _vp), ("w_time", _vp), ("grad_logp", _vp),
         ("d_kvl", _vp), ("d_ctx_first", _vp), ("d_ctx_cur", _vp), ("d_q_bias", _vp), ("d_q_step0", _vp),
         ("d_w_cap", _vp), ("d_w_time", _vp), ("logp_out", _vp), ("err", _vp),
+        ("d_planes_bf16", _vp), ("d_planes_row_stride", C.c_int64), ("d_planes_batch_stride", C.c_int64),
+        ("d_planes_plane_stride", C.c_int64),
     ]
 
 
@@ -53,19 +55,21 @@ def supports(env_name: str, cache_dtype: torch.dtype, num_nodes: int) -> bool:
 
 
 def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: dict, variant: str = "auto",
-                 want_logp: bool = False) -> dict:
+                 want_logp: bool = False, d_planes: Tensor | None = None) -> dict:
     """One launch of ``rl4co_am_teacher_backward``: dL/d(folded cache) for L = sum grad_logp * log p.
 
     ``variant``: "replay" (``csrc/am_teacher.hip``, fp32 step-by-step), "mma"
     (``csrc/am_teacher_mma.hip``, 16-step blocks on the matrix cores, bf16 planes) or "auto".
     Returns the gradient tensors, the variant that ran and (``want_logp``) the recomputed log-probs.
+    ``d_planes``: a bf16 [3, B_inst, N, 128] view (any plane / instance / node strides, unit channel stride) that
+    receives the three plane gradients instead of a fresh fp32 ``d_kvl`` (MMA variant only).
     """
     b, t = actions.shape
     b_inst, n = cache.num_instances, cache.num_nodes
     dev = actions.device
     tsp = cache.env_name == "tsp"
     f32 = dict(dtype=torch.float32, device=dev)
-    d_kvl = torch.empty((3, b_inst, n, EMBED_DIM), **f32)
+    d_kvl = torch.empty((3, b_inst, n, EMBED_DIM), **f32) if d_planes is None else None
     d_ctx_cur = torch.empty((b_inst, n, EMBED_DIM), **f32)
     d_ctx_first = torch.zeros((b_inst, n, EMBED_DIM), **f32) if tsp else None
     d_q_bias = torch.empty((b_inst, EMBED_DIM), **f32) if cache.q_bias is not None else None
@@ -105,6 +109,10 @@ def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: d
         locs, maxlen = meta["locs"].float().contiguous(), meta["max_length"].float().contiguous()
         a.locs, a.max_length = locs.data_ptr(), maxlen.data_ptr()
     a.d_kvl, a.d_ctx_cur, a.d_ctx_first, a.d_q_bias = ptr(d_kvl), ptr(d_ctx_cur), ptr(d_ctx_first), ptr(d_q_bias)
+    if d_planes is not None:
+        assert d_planes.dtype == torch.bfloat16 and d_planes.shape == (3, b_inst, n, EMBED_DIM) and d_planes.stride(3) == 1
+        a.d_planes_bf16 = d_planes.data_ptr()
+        a.d_planes_plane_stride, a.d_planes_batch_stride, a.d_planes_row_stride = d_planes.stride()[:3]
     if tsp:
         a.d_q_step0 = d_extra.data_ptr()
     else:
@@ -114,36 +122,56 @@ def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: d
     ran = _lib.lib().rl4co_am_teacher_variant(C.byref(a))
     st = _lib.lib().rl4co_am_teacher_backward(C.byref(a), torch.cuda.current_stream().cuda_stream)
     _lib.check(st, "rl4co_am_teacher_backward")
-    return {"d_kvl": d_kvl, "d_ctx_first": d_ctx_first, "d_ctx_cur": d_ctx_cur, "d_q_bias": d_q_bias,
+    return {"d_kvl": d_kvl if d_planes is None else d_planes, "d_ctx_first": d_ctx_first, "d_ctx_cur": d_ctx_cur, "d_q_bias": d_q_bias,
             "d_extra": d_extra, "d_time": d_time, "logp": logp, "err": err, "variant": {1: "replay", 2: "mma"}.get(ran, "invalid")}
 
 
-def build_cache_autograd(env_name: str, h: Tensor, decoder) -> dict[str, Tensor]:
-    """The folded cache as differentiable fp32 tensors (same algebra as cache.build_folded_cache)."""
+def build_cache_autograd(env_name: str, h: Tensor, decoder, fused_planes: bool = False) -> dict[str, Tensor]:
+    """The folded cache as differentiable tensors (same algebra as cache.build_folded_cache).
+
+    ``fused_planes`` (bf16 encoder output on the GPU, bf16 planes, MMA backward): the five (TSP) / four per-node
+    projections are ONE [B*N,128] x [128, 5*128] GEMM on the tall-skinny MFMA kernel whose output rows hold the planes
+    side by side — the rollout streams them through strided views — and the backward of all of them is ONE input-
+    gradient GEMM and ONE weight-gradient launch on the bf16 gradient matrix the teacher kernel writes in place
+    (``TeacherForcedFoldLogLik``): no per-plane autograd nodes, no stack, no fp32 plane gradients, no gradient adds."""
     d = EMBED_DIM
     w_ctx = decoder.context_embedding.project_context.weight.float()
     blocks = fold_weights(env_name, decoder.project_node_embeddings.weight.float(),
                           decoder.pointer.project_out.weight.float(), w_ctx)
-    if h.is_cuda and h.dtype == torch.bfloat16:
-        # bf16 encoder output (autocast training): the fold GEMMs and their backward run on the
-        # tall-skinny MFMA kernels (csrc/am_train_ops.hip) instead of five fp32 library GEMMs
+    out: dict = {}
+    if fused_planes and h.is_cuda and h.dtype == torch.bfloat16:
         from . import train_ops
 
-        planes = [train_ops.linear(h, w, None) for w in blocks]  # bf16: the rollout streams bf16 planes anyway
-        planes = planes[:3] + [p.float() for p in planes[3:]]     # the context tables are read as fp32
+        b, n, _ = h.shape
+        w_all = torch.cat(blocks, 0)  # [nblk * 128, 128] fp32, differentiable through the fold
+        h2 = h.detach().reshape(b * n, d).contiguous()
+        w16 = w_all.detach().to(torch.bfloat16).contiguous()
+        planes = train_ops._gemm(h2, w16).view(b, n, len(blocks), d)  # row (b, n): [Kg | V | Kl' | ctx ...]
+        out.update(fused=True, h=h, h2=h2, w_all=w_all, w16=w16, planes=planes)
+        out["kvl"] = planes.permute(2, 0, 1, 3)[:3]                       # [3, B, N, 128] strided view, bf16
+        out["ctx_cur"] = planes[:, :, 4 if env_name == "tsp" else 3].float()  # the context tables are read as fp32
+        if env_name == "tsp":
+            out["ctx_first"] = planes[:, :, 3].float()
     else:
-        h = h.float()
-        planes = [torch.matmul(h, w.t()) for w in blocks]
-    h = h.float()
-    out = {"kvl": torch.stack(planes[:3], 0), "ctx_cur": planes[4] if env_name == "tsp" else planes[-1]}
+        if h.is_cuda and h.dtype == torch.bfloat16:
+            # bf16 encoder output (autocast training): the fold GEMMs and their backward run on the
+            # tall-skinny MFMA kernels (csrc/am_train_ops.hip) instead of five fp32 library GEMMs
+            from . import train_ops
+
+            planes = [train_ops.linear(h, w, None) for w in blocks]  # bf16: the rollout streams bf16 planes anyway
+            planes = planes[:3] + [p.float() for p in planes[3:]]     # the context tables are read as fp32
+        else:
+            planes = [torch.matmul(h.float(), w.t()) for w in blocks]
+        out.update(kvl=torch.stack(planes[:3], 0), ctx_cur=planes[4] if env_name == "tsp" else planes[-1])
+        if env_name == "tsp":
+            out["ctx_first"] = planes[3]
     if env_name == "tsp":
-        out["ctx_first"] = planes[3]
         out["q_step0"] = torch.mv(w_ctx, decoder.context_embedding.W_placeholder.float())
     elif w_ctx.shape[1] > d:  # PDP has no context scalar
         out["w_cap"] = w_ctx[:, d]
         if w_ctx.shape[1] > d + 1:  # CVRPTW: the current-time column
             out["w_time"] = w_ctx[:, d + 1]
-    out["q_bias"] = (torch.matmul(h.mean(1), decoder.project_fixed_context.weight.float().t())
+    out["q_bias"] = (torch.matmul(h.float().mean(1), decoder.project_fixed_context.weight.float().t())
                      if decoder.use_graph_context else None)
     return out
 
@@ -151,9 +179,13 @@ def build_cache_autograd(env_name: str, h: Tensor, decoder) -> dict[str, Tensor]
 def detached_cache(env_name: str, g: dict[str, Tensor], cache_dtype: torch.dtype) -> FoldedCache:
     """Rollout view of the autograd cache: detached, planes in the streaming dtype."""
     det = lambda x: None if x is None else x.detach().contiguous()  # noqa: E731
-    return FoldedCache(env_name, g["kvl"].detach().to(cache_dtype).contiguous(), det(g.get("ctx_first")),
-                       det(g["ctx_cur"]), det(g.get("q_bias")), det(g.get("q_step0")), det(g.get("w_cap")),
-                       det(g.get("w_time")))
+    if g.get("fused"):
+        assert cache_dtype == torch.bfloat16
+        kvl = g["kvl"]  # strided view of the fused GEMM's output rows: the kernels take plane pointers and strides
+    else:
+        kvl = g["kvl"].detach().to(cache_dtype).contiguous()
+    return FoldedCache(env_name, kvl, det(g.get("ctx_first")), det(g["ctx_cur"]), det(g.get("q_bias")), det(g.get("q_step0")),
+                       det(g.get("w_cap")), det(g.get("w_time")))
 
 
 class TeacherForcedLogLik(torch.autograd.Function):
@@ -183,9 +215,49 @@ class TeacherForcedLogLik(torch.autograd.Function):
                 out["d_time"] if has_time else None, None, None, None, None)
 
 
+class TeacherForcedFoldLogLik(torch.autograd.Function):
+    """The same node with the cache fold inside it (``build_cache_autograd(fused_planes=True)``): backward = teacher
+    kernel (plane gradients written as bf16 columns of one [B*N, nblk*128] matrix, context-table gradients converted
+    into its remaining columns) -> ONE input-gradient GEMM (d h) and ONE weight-gradient launch (d W_all)."""
+
+    @staticmethod
+    def forward(ctx, h, w_all, q_bias, q_extra, q_time, logps, cache: FoldedCache, actions: Tensor, meta: dict, g: dict):
+        ctx.cache, ctx.actions, ctx.meta = cache, actions, meta
+        ctx.h2, ctx.w16, ctx.h_shape, ctx.nblk = g["h2"], g["w16"], h.shape, w_all.shape[0] // EMBED_DIM
+        ctx.has = (q_bias is not None, q_extra is not None, q_time is not None)
+        ctx.dtypes = (h.dtype, w_all.dtype)
+        return logps.detach().clone()
+
+    @staticmethod
+    def backward(ctx, grad_logp):
+        from . import train_ops
+
+        b, n, d = ctx.h_shape
+        dp = torch.empty((b, n, ctx.nblk, d), dtype=torch.bfloat16, device=grad_logp.device)
+        out = run_backward(ctx.cache, ctx.actions, grad_logp, ctx.meta, variant="mma", d_planes=dp.permute(2, 0, 1, 3)[:3])
+        sink = ctx.meta.get("err_sink")
+        if sink is not None:
+            sink.bitwise_or_(out["err"])
+        else:
+            _lib.raise_for_error_bits(int(out["err"].item()))
+        tsp = ctx.cache.env_name == "tsp"
+        if tsp:
+            dp[:, :, 3].copy_(out["d_ctx_first"])
+        dp[:, :, 4 if tsp else 3].copy_(out["d_ctx_cur"])
+        dp2 = dp.view(b * n, ctx.nblk * d)
+        dh = train_ops._gemm(dp2, ctx.w16.t().contiguous()).view(b, n, d)
+        dw = train_ops._wgrad(dp2, ctx.h2)
+        has_bias, has_extra, has_time = ctx.has
+        return (dh.to(ctx.dtypes[0]), dw.to(ctx.dtypes[1]), out["d_q_bias"] if has_bias else None,
+                out["d_extra"] if has_extra else None, out["d_time"] if has_time else None, None, None, None, None, None)
+
+
 def teacher_forced_logps(env_name: str, g: dict[str, Tensor], cache: FoldedCache, actions: Tensor, logps: Tensor,
                          meta: dict) -> Tensor:
     """Differentiable per-step log-probs of ``actions`` (values = ``logps`` from the rollout)."""
     extra = g["q_step0"] if env_name == "tsp" else g.get("w_cap")  # None for PDP (no context scalar)
+    if g.get("fused"):
+        return TeacherForcedFoldLogLik.apply(g["h"], g["w_all"], g.get("q_bias"), extra, g.get("w_time"), logps, cache,
+                                             actions, meta, g)
     return TeacherForcedLogLik.apply(g["kvl"], g.get("ctx_first"), g["ctx_cur"], g.get("q_bias"), extra, g.get("w_time"),
                                      logps, cache, actions, meta)

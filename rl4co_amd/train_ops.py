@@ -20,40 +20,77 @@ def max_nodes() -> int:
     return _lib.lib().rl4co_skip_inorm_max_nodes()
 
 
+def _inorm_forward(xc: Tensor, sc: Tensor, w32: Tensor, b32: Tensor, eps: float):
+    """(out, y = x + s, mean, rstd) of Normalization("instance")(x + s); bf16 [B,N,128] in / out, fp32 statistics."""
+    b, n, d = xc.shape
+    y = torch.empty_like(xc)
+    out = torch.empty_like(xc)
+    mean = torch.empty((b, d), dtype=torch.float32, device=xc.device)
+    rstd = torch.empty((b, d), dtype=torch.float32, device=xc.device)
+    st = _lib.lib().rl4co_skip_inorm_fwd_bf16(xc.data_ptr(), sc.data_ptr(), w32.data_ptr(), b32.data_ptr(), float(eps),
+                                              b, n, y.data_ptr(), out.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream)
+    _lib.check(st, "rl4co_skip_inorm_fwd_bf16")
+    return out, y, mean, rstd
+
+
+def _inorm_backward(dout: Tensor, y: Tensor, w32: Tensor, mean: Tensor, rstd: Tensor):
+    """(d (x + s) bf16, d gamma fp32, d beta fp32)."""
+    b, n, d = y.shape
+    dc = dout.contiguous()
+    if dc.dtype != torch.bfloat16:
+        dc = dc.to(torch.bfloat16)
+    dy = torch.empty_like(y)
+    part = torch.empty((2, b, d), dtype=torch.float32, device=y.device)  # per-instance d gamma | d beta
+    st = _lib.lib().rl4co_skip_inorm_bwd_bf16(dc.data_ptr(), y.data_ptr(), w32.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                              b, n, dy.data_ptr(), part[0].data_ptr(), part[1].data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream)
+    _lib.check(st, "rl4co_skip_inorm_bwd_bf16")
+    g = part.sum(1)  # one reduction over the instances for both, fixed order
+    return dy, g[0], g[1]
+
+
 class _SkipInstanceNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, s: Tensor, weight: Tensor, bias: Tensor, eps: float):
-        b, n, d = x.shape
-        xc, sc = x.contiguous(), s.contiguous()
         w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
-        y = torch.empty_like(xc)
-        out = torch.empty_like(xc)
-        mean = torch.empty((b, d), dtype=torch.float32, device=x.device)
-        rstd = torch.empty((b, d), dtype=torch.float32, device=x.device)
-        st = _lib.lib().rl4co_skip_inorm_fwd_bf16(xc.data_ptr(), sc.data_ptr(), w32.data_ptr(), b32.data_ptr(), float(eps),
-                                                  b, n, y.data_ptr(), out.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                                  torch.cuda.current_stream().cuda_stream)
-        _lib.check(st, "rl4co_skip_inorm_fwd_bf16")
+        out, y, mean, rstd = _inorm_forward(x.contiguous(), s.contiguous(), w32, b32, eps)
         ctx.save_for_backward(y, w32, mean, rstd)
         ctx.param_dtype = weight.dtype
         return out
 
     @staticmethod
     def backward(ctx, dout: Tensor):
-        y, w32, mean, rstd = ctx.saved_tensors
-        b, n, d = y.shape
-        dc = dout.contiguous()
-        if dc.dtype != torch.bfloat16:
-            dc = dc.to(torch.bfloat16)
-        dy = torch.empty_like(y)
-        part = torch.empty((2, b, d), dtype=torch.float32, device=y.device)  # per-instance d gamma | d beta
-        dgamma, dbeta = part[0], part[1]
-        st = _lib.lib().rl4co_skip_inorm_bwd_bf16(dc.data_ptr(), y.data_ptr(), w32.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                                                  b, n, dy.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(),
-                                                  torch.cuda.current_stream().cuda_stream)
-        _lib.check(st, "rl4co_skip_inorm_bwd_bf16")
-        g = part.sum(1)  # one reduction over the instances for both, fixed order
-        return dy, dy, g[0].to(ctx.param_dtype), g[1].to(ctx.param_dtype), None
+        dy, dgamma, dbeta = _inorm_backward(dout, *ctx.saved_tensors)
+        return dy, dy, dgamma.to(ctx.param_dtype), dbeta.to(ctx.param_dtype), None
+
+
+def _bnorm_forward(xc: Tensor, sc: Tensor, w32: Tensor, b32: Tensor, eps: float):
+    """(out, y = x + s, mean, rstd, var) of BatchNorm1d(x + s) over all B x N rows with batch statistics."""
+    m = xc.numel() // EMBED_DIM
+    y, out = torch.empty_like(xc), torch.empty_like(xc)
+    sums = torch.zeros((2, EMBED_DIM), dtype=torch.float32, device=xc.device)
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(_lib.lib().rl4co_skip_bnorm_stats_bf16(xc.data_ptr(), sc.data_ptr(), m, y.data_ptr(), sums.data_ptr(), stream),
+               "rl4co_skip_bnorm_stats_bf16")
+    mean = sums[0] / m
+    var = (sums[1] / m - mean * mean).clamp_min_(0.0)  # biased, as F.batch_norm normalises with
+    rstd = torch.rsqrt(var + eps)
+    _lib.check(_lib.lib().rl4co_bnorm_apply_bf16(y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w32.data_ptr(), b32.data_ptr(),
+                                                 m, out.data_ptr(), stream), "rl4co_bnorm_apply_bf16")
+    return out, y, mean, rstd, var
+
+
+def _bnorm_backward(dout: Tensor, y: Tensor, w32: Tensor, mean: Tensor, rstd: Tensor):
+    """(d (x + s) bf16, d gamma fp32, d beta fp32)."""
+    m = y.numel() // EMBED_DIM
+    d = dout.to(torch.bfloat16).contiguous()
+    dy = torch.empty_like(y)
+    sums = torch.zeros((2, EMBED_DIM), dtype=torch.float32, device=y.device)
+    _lib.check(_lib.lib().rl4co_bnorm_bwd_bf16(d.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w32.data_ptr(), m,
+                                               sums.data_ptr(), dy.data_ptr(), torch.cuda.current_stream().cuda_stream),
+               "rl4co_bnorm_bwd_bf16")
+    return dy, sums[1], sums[0]
 
 
 class _SkipBatchNorm(torch.autograd.Function):
@@ -61,19 +98,8 @@ class _SkipBatchNorm(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x: Tensor, s: Tensor, weight: Tensor, bias: Tensor, eps: float):
-        xc, sc = x.contiguous(), s.contiguous()
-        m = xc.numel() // EMBED_DIM
         w32, b32 = weight.detach().float().contiguous(), bias.detach().float().contiguous()
-        y, out = torch.empty_like(xc), torch.empty_like(xc)
-        sums = torch.zeros((2, EMBED_DIM), dtype=torch.float32, device=x.device)
-        stream = torch.cuda.current_stream().cuda_stream
-        _lib.check(_lib.lib().rl4co_skip_bnorm_stats_bf16(xc.data_ptr(), sc.data_ptr(), m, y.data_ptr(), sums.data_ptr(), stream),
-                   "rl4co_skip_bnorm_stats_bf16")
-        mean = sums[0] / m
-        var = (sums[1] / m - mean * mean).clamp_min_(0.0)  # biased, as F.batch_norm normalises with
-        rstd = torch.rsqrt(var + eps)
-        _lib.check(_lib.lib().rl4co_bnorm_apply_bf16(y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w32.data_ptr(), b32.data_ptr(),
-                                                     m, out.data_ptr(), stream), "rl4co_bnorm_apply_bf16")
+        out, y, mean, rstd, var = _bnorm_forward(x.contiguous(), s.contiguous(), w32, b32, eps)
         ctx.save_for_backward(y, w32, mean, rstd)
         ctx.pdt = weight.dtype
         ctx.mark_non_differentiable(mean, var)
@@ -81,28 +107,25 @@ class _SkipBatchNorm(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout: Tensor, _dmean, _dvar):
-        y, w32, mean, rstd = ctx.saved_tensors
-        m = y.numel() // EMBED_DIM
-        d = dout.to(torch.bfloat16).contiguous()
-        dy = torch.empty_like(y)
-        sums = torch.zeros((2, EMBED_DIM), dtype=torch.float32, device=y.device)
-        _lib.check(_lib.lib().rl4co_bnorm_bwd_bf16(d.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w32.data_ptr(), m,
-                                                   sums.data_ptr(), dy.data_ptr(), torch.cuda.current_stream().cuda_stream),
-                   "rl4co_bnorm_bwd_bf16")
-        return dy, dy, sums[1].to(ctx.pdt), sums[0].to(ctx.pdt), None
+        dy, dgamma, dbeta = _bnorm_backward(dout, *ctx.saved_tensors)
+        return dy, dy, dgamma.to(ctx.pdt), dbeta.to(ctx.pdt), None
+
+
+def _update_running_stats(bn: torch.nn.BatchNorm1d, mean: Tensor, var: Tensor, m: int) -> None:
+    """nn.BatchNorm1d's bookkeeping in training mode (momentum, unbiased running variance, num_batches_tracked)."""
+    if bn.track_running_stats and bn.running_mean is not None:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
+            bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
+            bn.running_var.mul_(1 - mom).add_((var * (m / max(m - 1, 1))).to(bn.running_var.dtype), alpha=mom)
 
 
 def skip_batch_norm(x: Tensor, s: Tensor, bn: torch.nn.BatchNorm1d) -> Tensor:
     """``bn((x + s).view(-1, 128)).view_as(x)`` in training mode, running statistics updated like
     nn.BatchNorm1d (momentum, unbiased running variance, num_batches_tracked)."""
     out, mean, var = _SkipBatchNorm.apply(x, s, bn.weight, bn.bias, bn.eps)
-    if bn.track_running_stats and bn.running_mean is not None:
-        with torch.no_grad():
-            m = x.numel() // EMBED_DIM
-            bn.num_batches_tracked += 1
-            mom = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-            bn.running_mean.mul_(1 - mom).add_(mean.to(bn.running_mean.dtype), alpha=mom)
-            bn.running_var.mul_(1 - mom).add_((var * (m / max(m - 1, 1))).to(bn.running_var.dtype), alpha=mom)
+    _update_running_stats(bn, mean, var, x.numel() // EMBED_DIM)
     return out
 
 
@@ -154,16 +177,19 @@ def skip_instance_norm(x: Tensor, s: Tensor, weight: Tensor, bias: Tensor, eps: 
 # nn.Linear over the token rows on the tall-skinny MFMA kernel (csrc/am_train_ops.hip)
 # ---------------------------------------------------------------------------------------------------
 def _gemm(a2d: Tensor, w: Tensor, bias: Tensor | None = None, mask: Tensor | None = None, relu: bool = False,
-          out: Tensor | None = None) -> Tensor:
-    """out[M,N] = epilogue(a2d[M,K] @ w[N,K]^T + bias); bf16 a2d / w / out, fp32 bias."""
+          out: Tensor | None = None, residual: Tensor | None = None) -> Tensor:
+    """out[M,N] = epilogue(a2d[M,K] @ w[N,K]^T + bias) (+ residual[M,N]); bf16 a2d / w / out / residual, fp32 bias."""
     m, k = a2d.shape
     n = w.shape[0]
     if out is None:
         out = torch.empty((m, n), dtype=torch.bfloat16, device=a2d.device)
     else:
         assert out.shape == (m, n) and out.dtype == torch.bfloat16 and out.is_contiguous()
+    if residual is not None:
+        assert residual.shape == (m, n) and residual.dtype == torch.bfloat16 and residual.is_contiguous()
     st = _lib.lib().rl4co_linear_bf16(a2d.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
-                                      None if mask is None else mask.data_ptr(), m, n, k, int(relu), out.data_ptr(),
+                                      None if mask is None else mask.data_ptr(),
+                                      None if residual is None else residual.data_ptr(), m, n, k, int(relu), out.data_ptr(),
                                       torch.cuda.current_stream().cuda_stream)
     _lib.check(st, "rl4co_linear_bf16")
     return out
@@ -304,6 +330,141 @@ def attention_flash(qkv: Tensor) -> Tensor:
     st = _lib.lib().rl4co_attn_flash_bf16(qkv.data_ptr(), b, n, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
     _lib.check(st, "rl4co_attn_flash_bf16")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# a whole residual sub-block of the encoder layer as ONE autograd node (nn/graph/attnnet.py:16-54):
+#   Normalization(x + MHA(x))   and   Normalization(x + MLP(x))
+# Same kernels as the pieces above; what the single node buys is the backward of the skip connection: the gradient
+# of x is (gradient through the branch) + (gradient of the sum), and the second term rides in the epilogue of the
+# branch's last input-gradient GEMM (``residual``) instead of being added by autograd in one more pass over both
+# (12 passes of 315 MB per POMO step at 4096 x 100 nodes).
+# ---------------------------------------------------------------------------------------------------
+def _norm_forward(kind: str, xc: Tensor, sc: Tensor, w32: Tensor, b32: Tensor, eps: float):
+    if kind == "instance":
+        out, y, mean, rstd = _inorm_forward(xc, sc, w32, b32, eps)
+        return out, y, mean, rstd, None
+    return _bnorm_forward(xc, sc, w32, b32, eps)
+
+
+def _norm_backward(kind: str, dout: Tensor, y: Tensor, w32: Tensor, mean: Tensor, rstd: Tensor):
+    return (_inorm_backward if kind == "instance" else _bnorm_backward)(dout, y, w32, mean, rstd)
+
+
+def _bf16(w: Tensor) -> Tensor:
+    return w.detach().to(torch.bfloat16).contiguous()
+
+
+def _f32(w: Tensor) -> Tensor:
+    return w.detach().float().contiguous()
+
+
+class _AttentionBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wqkv, bqkv, wo, bo, gamma, beta, eps, kind):
+        b, n, d = x.shape
+        xc = x.contiguous()
+        x2 = xc.view(-1, d)
+        wqkv16, wo16, g32 = _bf16(wqkv), _bf16(wo), _f32(gamma)
+        qkv = _gemm(x2, wqkv16, _f32(bqkv)).view(b, n, 3 * d)
+        att = torch.empty((b, n, d), dtype=torch.bfloat16, device=x.device)
+        lse = torch.empty((b, 8, n), dtype=torch.float32, device=x.device)
+        stream = torch.cuda.current_stream().cuda_stream
+        _lib.check(_lib.lib().rl4co_attn_fwd_bf16(qkv.data_ptr(), b, n, att.data_ptr(), lse.data_ptr(), stream), "rl4co_attn_fwd_bf16")
+        s = _gemm(att.view(-1, d), wo16, _f32(bo)).view(b, n, d)
+        out, y, mean, rstd, var = _norm_forward(kind, xc, s, g32, _f32(beta), eps)
+        ctx.save_for_backward(x2, wqkv16, wo16, qkv, lse, att, y, g32, mean, rstd)
+        ctx.kind, ctx.pdt = kind, wqkv.dtype
+        if kind == "batch":
+            ctx.mark_non_differentiable(mean, var)
+            return out, mean, var
+        return out
+
+    @staticmethod
+    def backward(ctx, dout, *_unused):
+        x2, wqkv16, wo16, qkv, lse, att, y, g32, mean, rstd = ctx.saved_tensors
+        b, n, d = y.shape
+        dy, dgamma, dbeta = _norm_backward(ctx.kind, dout, y, g32, mean, rstd)  # d (x + s): the branch AND the skip
+        d2 = dy.view(-1, d)
+        datt = _gemm(d2, wo16.t().contiguous())
+        dwo, dbo = _wgrad(d2, att.view(-1, d), with_bias=True)
+        dqkv = torch.empty_like(qkv)
+        _lib.check(_lib.lib().rl4co_attn_bwd_bf16(qkv.data_ptr(), datt.data_ptr(), lse.data_ptr(), b, n, dqkv.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream), "rl4co_attn_bwd_bf16")
+        dq2 = dqkv.view(-1, 3 * d)
+        dx = _gemm(dq2, wqkv16.t().contiguous(), residual=d2)
+        dwqkv, dbqkv = _wgrad(dq2, x2, with_bias=True)
+        t = ctx.pdt
+        return (dx.view(b, n, d), dwqkv.to(t), dbqkv.to(t), dwo.to(t), dbo.to(t), dgamma.to(t), dbeta.to(t), None, None)
+
+
+class _MLPBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, gamma, beta, eps, kind):
+        b, n, d = x.shape
+        xc = x.contiguous()
+        x2 = xc.view(-1, d)
+        w1_16, w2_16, g32 = _bf16(w1), _bf16(w2), _f32(gamma)
+        h = _gemm(x2, w1_16, _f32(b1), relu=True)
+        s = _gemm(h, w2_16, _f32(b2)).view(b, n, d)
+        out, y, mean, rstd, var = _norm_forward(kind, xc, s, g32, _f32(beta), eps)
+        ctx.save_for_backward(x2, h, w1_16, w2_16, y, g32, mean, rstd)
+        ctx.kind, ctx.pdt = kind, w1.dtype
+        if kind == "batch":
+            ctx.mark_non_differentiable(mean, var)
+            return out, mean, var
+        return out
+
+    @staticmethod
+    def backward(ctx, dout, *_unused):
+        x2, h, w1_16, w2_16, y, g32, mean, rstd = ctx.saved_tensors
+        b, n, d = y.shape
+        dy, dgamma, dbeta = _norm_backward(ctx.kind, dout, y, g32, mean, rstd)
+        d2 = dy.view(-1, d)
+        dh = _gemm(d2, w2_16.t().contiguous(), mask=h)  # (d W2) * [h > 0]
+        dw2, db2 = _wgrad(d2, h, with_bias=True)
+        dx = _gemm(dh, w1_16.t().contiguous(), residual=d2)
+        dw1, db1 = _wgrad(dh, x2, with_bias=True)
+        t = ctx.pdt
+        return (dx.view(b, n, d), dw1.to(t), db1.to(t), dw2.to(t), db2.to(t), dgamma.to(t), dbeta.to(t), None, None)
+
+
+def _block_norm_args(norm_module, kind: str):
+    nz = norm_module.normalizer
+    return nz.weight, nz.bias, nz.eps
+
+
+def block_usable(x: Tensor, kind: str, *weights: Tensor) -> bool:
+    """bf16 [B,N,128] rows whose every kernel (GEMMs, attention, skip + norm) is served: one autograd node per sub-block."""
+    if kind not in ("instance", "batch") or not linear_usable(x, *weights) or x.dim() != 3 or x.shape[-1] != EMBED_DIM:
+        return False
+    if x.shape[1] > _lib.lib().rl4co_attn_max_nodes():
+        return False
+    return kind == "batch" or x.shape[1] <= max_nodes()
+
+
+def attention_block(x: Tensor, attn, norm) -> Tensor:
+    """``norm(x + attn(x))`` (SkipConnection(MultiHeadAttention) + Normalization) as one autograd node."""
+    gamma, beta, eps = _block_norm_args(norm, norm.kind)
+    res = _AttentionBlock.apply(x, attn.Wqkv.weight, attn.Wqkv.bias, attn.out_proj.weight, attn.out_proj.bias, gamma, beta,
+                                eps, norm.kind)
+    if norm.kind == "batch":
+        out, mean, var = res
+        _update_running_stats(norm.normalizer, mean, var, x.numel() // EMBED_DIM)
+        return out
+    return res
+
+
+def mlp_block(x: Tensor, ffn, norm) -> Tensor:
+    """``norm(x + ffn(x))`` (SkipConnection(MLP 128 -> 512 -> 128) + Normalization) as one autograd node."""
+    gamma, beta, eps = _block_norm_args(norm, norm.kind)
+    l1, l2 = ffn.lins
+    res = _MLPBlock.apply(x, l1.weight, l1.bias, l2.weight, l2.bias, gamma, beta, eps, norm.kind)
+    if norm.kind == "batch":
+        out, mean, var = res
+        _update_running_stats(norm.normalizer, mean, var, x.numel() // EMBED_DIM)
+        return out
+    return res
 
 
 # ---------------------------------------------------------------------------------------------------

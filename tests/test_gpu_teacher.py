@@ -175,6 +175,10 @@ def test_linear_bf16_kernel_matches_torch(m, k, n):
     mask[0, :4] = torch.tensor([0.0, -0.0, 1e-30, -1e-30], device="cuda").to(torch.bfloat16)
     torch.testing.assert_close(train_ops._gemm(a, w, None, mask=mask).float(), (a.float() @ w.float().t()) * (mask > 0),
                                rtol=1e-2, atol=1e-2)
+    # residual epilogue (the skip connection's gradient joining an input-gradient GEMM): exactly the bf16 sum torch
+    # forms from the kernel's own bf16 product and the residual
+    res = torch.randn(m, n, device="cuda").to(torch.bfloat16)
+    assert torch.equal(train_ops._gemm(a, w, None, residual=res), train_ops._gemm(a, w, None) + res)
 
 
 @pytest.mark.parametrize("m,n,k", [(4096 * 100, 384, 128), (1000, 128, 128), (12345, 512, 128), (12800, 128, 512)])
@@ -391,3 +395,42 @@ def test_init_embed_forward_and_weight_gradients_match_torch(m, f):
     lin.zero_grad()
     train_ops.init_embed(feats, lin).backward(dout)
     assert torch.equal(lin.weight.grad, gw) and torch.equal(lin.bias.grad, gb)
+
+
+@pytest.mark.parametrize("env_name,graph_context", [("tsp", False), ("cvrp", True)])
+def test_fused_fold_backward_matches_per_plane_autograd(env_name, graph_context):
+    """teacher.build_cache_autograd(fused_planes=True) — one fold GEMM, strided plane views, the teacher kernel writing
+    bf16 plane gradients into the columns of one gradient matrix, one d h GEMM + one d W launch — against the per-plane
+    autograd nodes (five linears, stack, fp32 plane gradients) on the same trajectories: same log-likelihood values
+    (both return the rollout's), parameter gradients equal up to the bf16 rounding of the plane gradients."""
+    from rl4co_amd import teacher
+    from rl4co_amd.envs import get_env
+
+    env = get_env(env_name, generator_params=dict(num_loc=50, device="cuda"), device="cuda", check_solution=False)
+    torch.manual_seed(1)
+    data = env.generator(batch_size=[64])
+    kw = dict(normalization="instance", graph_context=graph_context, env_name=env_name)
+    with torch.no_grad():
+        out0 = _pomo_policy(**kw)(env.reset(data), env, phase="train", num_starts=8, seed=3)
+    acts = out0["actions"][:, 1:].contiguous()
+    adv = torch.linspace(-1.0, 1.0, out0["actions"].shape[0], device="cuda")
+    orig = teacher.build_cache_autograd
+    seen, grads, lls = [], {}, {}
+    for fused in (True, False):
+        teacher.build_cache_autograd = lambda e, h, d, fused_planes=False, _f=fused: (seen.append((fused_planes, _f)),
+                                                                                     orig(e, h, d, fused_planes=fused_planes and _f))[1]
+        try:
+            pol = _pomo_policy(**kw)
+            out = pol(env.reset(data), env, phase="train", num_starts=8, actions=acts)
+            (adv * out["log_likelihood"]).mean().backward()
+        finally:
+            teacher.build_cache_autograd = orig
+        grads[fused] = {k: p.grad.detach().float().flatten() for k, p in pol.named_parameters() if p.grad is not None}
+        lls[fused] = out["log_likelihood"].detach()
+    assert seen and all(asked for asked, _ in seen), "the policy did not ask for the fused fold in the bf16 regime"
+    torch.testing.assert_close(lls[True], lls[False], rtol=1e-4, atol=1e-3)
+    assert grads[True].keys() == grads[False].keys()
+    a = torch.cat([grads[True][k] for k in grads[False]])
+    r = torch.cat([grads[False][k] for k in grads[False]])
+    assert float(a @ r) / float(a.norm() * r.norm()) >= 0.999
+    assert float((a - r).norm() / r.norm()) <= 3e-2
