@@ -157,18 +157,15 @@ __global__ void __launch_bounds__(kThreads, 2) attn_bwd_kernel(const uint16_t* _
   // block, and in the accumulator layout that is 8 bytes per lane — exactly the B operand, straight from global
   // memory one block ahead; the transposed A operand of d V goes through 512 bytes of the wave's staging block
   const uint16_t* dorow = dout + inst * N * kD + 16 * h + 4 * g;
+  // (unconditional loads from clamped rows, masked where they are consumed: a load under a branch makes the compiler
+  // wait for ALL outstanding loads at the join, i.e. for the prefetch it has just issued)
   auto load_do = [&](int tb) {
-    const int t = 16 * tb + tl;
-    uint2 v = make_uint2(0u, 0u);
-    if (t < N) v = *reinterpret_cast<const uint2*>(dorow + (int64_t)t * kD);
-    return __builtin_bit_cast(bf16x4, v);
+    const int t = min(16 * tb + tl, N - 1);
+    return *reinterpret_cast<const uint2*>(dorow + (int64_t)t * kD);
   };
   const float* lrow = lse + (inst * kWaves + h) * N;
-  auto load_lse = [&](int tb) {
-    const int t = 16 * tb + tl;
-    return t < N ? lrow[t] : 0.0f;
-  };
-  bf16x4 dof_next = load_do(0);
+  auto load_lse = [&](int tb) { return lrow[min(16 * tb + tl, N - 1)]; };
+  uint2 do_next = load_do(0);
   float L_next = load_lse(0);
   __syncthreads();
   const int nao = tl * kQS + 4 * g;
@@ -183,12 +180,12 @@ __global__ void __launch_bounds__(kThreads, 2) attn_bwd_kernel(const uint16_t* _
     const int t = 16 * tb + tl;
     const bool tv = t < N;
     const bf16x4 qf = lds_b64(qs + 16 * tb * kQS + 16 * h + nao);
-    const bf16x4 dof = dof_next;
+    const uint2 do_raw = do_next;
     const float L = L_next;
-    if (tb + 1 < NT) {  // both of the next block's global operands: nothing in this iteration waits for memory
-      dof_next = load_do(tb + 1);
-      L_next = load_lse(tb + 1);
-    }
+    const int tbn = min(tb + 1, NT - 1);  // (the last block re-reads itself: no branch around the loads)
+    do_next = load_do(tbn);
+    L_next = load_lse(tbn);
+    const bf16x4 dof = __builtin_bit_cast(bf16x4, tv ? do_raw : make_uint2(0u, 0u));
     *reinterpret_cast<bf16x4*>(pbw + tl * kPS + kD + 4 * g) = dof;
     bf16x4 pf[NT];
     f32x4 dp[NT];

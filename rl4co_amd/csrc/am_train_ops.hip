@@ -217,6 +217,7 @@ namespace {
 constexpr int kTM = 128, kTN = 128, kTK = 128;  // tile: token rows x features x contraction chunk
 constexpr int kLS = kTK + 8;                    // LDS row stride (bf16)
 constexpr int kGemmThreads = 256;
+constexpr int kMaxLinearN = 1024;  // output features (the bias sits in LDS)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4g __attribute__((ext_vector_type(4)));
@@ -229,6 +230,8 @@ __global__ void __launch_bounds__(kGemmThreads, 2) linear_bf16_kernel(const uint
   extern __shared__ __align__(16) unsigned char smem_g[];
   __bf16* as = reinterpret_cast<__bf16*>(smem_g);  // [128 tokens][kLS]
   __bf16* ws = as + kTM * kLS;                       // [128 features][kLS]
+  float* bl = reinterpret_cast<float*>(ws + kTN * kLS);  // [N] bias: read from LDS in the epilogue (sixteen dependent
+                                                         // L2 round trips per feature tile when read from global there)
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int64_t m0 = (int64_t)blockIdx.x * kTM;
   const int nkc = K / kTK, nnt = N / kTN, steps = nnt * nkc;
@@ -254,9 +257,15 @@ __global__ void __launch_bounds__(kGemmThreads, 2) linear_bf16_kernel(const uint
     }                                                                                               \
   }
   RL4CO_FETCH(0, true)
+  if (bias)
+    for (int i = tid; i < N; i += kGemmThreads) bl[i] = bias[i];
   RL4CO_COMMIT(true)
   __syncthreads();
   f32x16 acc[4];  // [feature tile ct][feature 32 ct + rowmap(r, hi)], token 32 w + l31
+  // the ReLU-backward mask rows OR the residual rows of this wave (never both: validated by the entry point)
+  const uint16_t* aux = mask ? mask : residual;
+  const int orow = lane >> 4, ocol = (lane & 15) * 8;  // output pass: four rows per pass, 16 bytes per lane
+  u32x4 mks[8];
   for (int step = 0; step < steps; ++step) {
     const int nt = step / nkc, kc = step % nkc;
     const bool more = step + 1 < steps, next_a = nkc > 1;  // K = 128: the token chunk never changes
@@ -267,6 +276,13 @@ __global__ void __launch_bounds__(kGemmThreads, 2) linear_bf16_kernel(const uint
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ct][r] = 0.0f;
     }
+    if (aux && kc == nkc - 1) {  // the epilogue's mask / residual rows of this wave: in flight during the products
+#pragma unroll
+      for (int p8 = 0; p8 < 8; ++p8) {
+        const int64_t row = min(m0 + 32 * w + 4 * p8 + orow, (int64_t)M - 1);
+        mks[p8] = *reinterpret_cast<const u32x4*>(aux + row * N + nt * kTN + ocol);
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < kTK / 16; ++ks) {
       const bf16x8 tok = *reinterpret_cast<const bf16x8*>(as + (32 * w + l31) * kLS + 16 * ks + 8 * hi);
@@ -274,6 +290,18 @@ __global__ void __launch_bounds__(kGemmThreads, 2) linear_bf16_kernel(const uint
       for (int ct = 0; ct < 4; ++ct) {
         const bf16x8 feat = *reinterpret_cast<const bf16x8*>(ws + (32 * ct + l31) * kLS + 16 * ks + 8 * hi);
         acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(feat, tok, acc[ct], 0, 0, 0);
+      }
+    }
+    {
+      // The prefetched operands are pinned in their registers HERE, before this step's stores are issued: vmcnt is
+      // one in-order counter for loads and stores, so waiting for them where they are committed to LDS (after the
+      // stores) meant waiting for every store of the step to be acknowledged by L2 first — the step's whole write
+      // latency, exposed once per feature tile (wide-N shapes ran at 3 TB/s, the K-deep ones at 4.4)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {  // (unconditional: under `if (more)` the compiler's scoreboard forgets it at the join)
+        asm volatile("" ::"v"(pw[j]));
+        asm volatile("" ::"v"(pa[j]));
+        asm volatile("" ::"v"(mks[j]));
       }
     }
     if (kc == nkc - 1) {
@@ -291,7 +319,7 @@ __global__ void __launch_bounds__(kGemmThreads, 2) linear_bf16_kernel(const uint
           const int fl = 32 * ct + 8 * q + 4 * hi;  // feature inside the tile
           float v[4];
           if (bias) {
-            const float4 b4 = *reinterpret_cast<const float4*>(bias + nt * kTN + fl);
+            const float4 b4 = *reinterpret_cast<const float4*>(bl + nt * kTN + fl);
             v[0] = acc[ct][4 * q] + b4.x;
             v[1] = acc[ct][4 * q + 1] + b4.y;
             v[2] = acc[ct][4 * q + 2] + b4.z;
@@ -311,18 +339,6 @@ __global__ void __launch_bounds__(kGemmThreads, 2) linear_bf16_kernel(const uint
         }
       }
       rl4co::lds_barrier_wave();
-      const int orow = lane >> 4, ocol = (lane & 15) * 8;  // four rows per pass, 16 bytes per lane
-      // the ReLU-backward mask rows OR the residual rows of this wave (never both: validated by the entry point), all
-      // requested before the first is used
-      const uint16_t* aux = mask ? mask : residual;
-      u32x4 mks[8];
-      if (aux) {
-#pragma unroll
-        for (int p8 = 0; p8 < 8; ++p8) {
-          const int64_t row = min(m0 + 32 * w + 4 * p8 + orow, (int64_t)M - 1);
-          mks[p8] = *reinterpret_cast<const u32x4*>(aux + row * N + nt * kTN + ocol);
-        }
-      }
 #pragma unroll
       for (int p8 = 0; p8 < 8; ++p8) {
         const int tr = 32 * w + 4 * p8 + orow;
@@ -370,7 +386,8 @@ extern "C" int rl4co_linear_bf16(const void* a, const void* w, const float* bias
   RL4CO_REQUIRE(a && w && out);
   RL4CO_REQUIRE(M > 0 && M < (int64_t)1 << 31 && N > 0 && K > 0 && N % kTN == 0 && K % kTK == 0);
   RL4CO_REQUIRE(!(relu && mask) && !(mask && residual));
-  const int lds = (kTM + kTN) * kLS * 2;
+  RL4CO_REQUIRE(N <= kMaxLinearN);
+  const int lds = (kTM + kTN) * kLS * 2 + kMaxLinearN * 4;
   RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   const int blocks = (int)((M + kTM - 1) / kTM);
@@ -429,11 +446,13 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const uint16_t* __restr
   const bf16x4w ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
   const int lrow = tid >> 3, lcol = (tid & 7) * 16;  // this thread stages 32 bytes of each tile row
   typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
-  for (int64_t m0 = m_begin; m0 < m_end; m0 += kWT) {
-    u32x4w a0[kWT / 32], a1[kWT / 32], b0[kWT / 32], b1[kWT / 32];  // a thread stages row lrow of every 32-row group
+  // the rows of step i + 1 are requested before the products of step i (registers), so a step no longer opens with
+  // an exposed HBM round trip: with two workgroups per CU that latency set the kernel's pace (3.3 TB/s of reads)
+  u32x4w a0[kWT / 32], a1[kWT / 32], b0[kWT / 32], b1[kWT / 32];  // a thread stages row lrow of every 32-row group
+  auto fetch = [&](int64_t m0) {
 #pragma unroll
     for (int rg = 0; rg < kWT / 32; ++rg) {
-      const int64_t row = min(m0 + 32 * rg + lrow, m_end - 1);  // rows past the chunk: re-read, zeroed below
+      const int64_t row = min(m0 + 32 * rg + lrow, m_end - 1);  // rows past the chunk: re-read, zeroed at the commit
       const uint16_t* pa = dY + row * N + nt * 128 + lcol;
       const uint16_t* pb = X + row * K + kt * 128 + lcol;
       a0[rg] = *reinterpret_cast<const u32x4w*>(pa);
@@ -441,6 +460,9 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const uint16_t* __restr
       b0[rg] = *reinterpret_cast<const u32x4w*>(pb);
       b1[rg] = *reinterpret_cast<const u32x4w*>(pb + 8);
     }
+  };
+  if (m_begin < m_end) fetch(m_begin);
+  for (int64_t m0 = m_begin; m0 < m_end; m0 += kWT) {
     __syncthreads();  // the previous step's fragments are consumed
 #pragma unroll
     for (int rg = 0; rg < kWT / 32; ++rg) {
@@ -453,6 +475,7 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const uint16_t* __restr
       *reinterpret_cast<u32x4w*>(xt + r * kWLS + lcol + 8) = live ? b1[rg] : z;
     }
     __syncthreads();
+    fetch(min(m0 + kWT, m_end - 1));  // (the last step re-reads a row it drops: no branch around the loads)
 #pragma unroll
     for (int ts = 0; ts < kWT / 16; ++ts) {
       bf16x4w af[2];

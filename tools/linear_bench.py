@@ -22,6 +22,15 @@ for k, n, relu in ((128, 384, False), (128, 128, False), (128, 512, True), (512,
     gb = (M * k + M * n) * 2 / 1e9
     lib = bench(lambda: torch.nn.functional.linear(a, w))
     print(f"linear  K={k:4d} N={n:4d}: {us:7.1f} us  {gb / us * 1e6 / 1e3:6.2f} TB/s  ({gb*1e3:5.0f} MB)   hipBLASLt {lib:7.1f} us")
+# backward-side epilogues: ReLU mask (d hidden), residual (skip gradient), the fold GEMM both ways
+for k, n, kind in ((128, 512, "mask"), (512, 128, "residual"), (384, 128, "residual"), (128, 640, "plain"), (640, 128, "plain")):
+    a = torch.randn(M, k, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(n, k, device="cuda") * 0.05).to(torch.bfloat16)
+    aux = torch.randn(M, n, device="cuda").to(torch.bfloat16)
+    kw = {"mask": dict(mask=aux), "residual": dict(residual=aux), "plain": {}}[kind]
+    us = bench(lambda: T._gemm(a, w, None, **kw))
+    gb = (M * k + M * n * (1 if kind == "plain" else 2)) * 2 / 1e9
+    print(f"linear  K={k:4d} N={n:4d} {kind:8s}: {us:7.1f} us  {gb / us * 1e6 / 1e3:6.2f} TB/s  ({gb*1e3:5.0f} MB)")
 for n, k in ((384, 128), (128, 128), (512, 128), (128, 512)):
     d = torch.randn(M, n, device="cuda").to(torch.bfloat16)
     x = torch.randn(M, k, device="cuda").to(torch.bfloat16)
