@@ -258,11 +258,39 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
     const int64_t tcol = (int64_t)a.t0 + t;
 
     // ---- 1. query of head h (folded context + graph context), x 1/sqrt(16) x log2(e) -----------------
+    float4 c4v[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) c4v[c] = *reinterpret_cast<const float4*>(ctxc + (int64_t)tj[c].cur * kD);  // L2-resident context row
+    // this step's noise: log(Exp(1) noise) of the four nodes this lane owns in the logits stage (they share
+    // one Philox block, rl4co_math.h). Depends on (step, row, node) only, so it is drawn HERE — ten dependent
+    // Philox rounds and two logarithms that used to sit between the two barriers, on the step's critical path,
+    // now overlap the context row's L2 round trip (just requested) and the glimpse
+    float lnz_c[CT][4];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) lnz_c[c][i] = 0.0f;
+      if (MODE == RL4CO_DECODE_SAMPLE && w < NT) {
+        const Traj& x = tj[c];
+        const int node0 = 16 * w + 4 * g;
+        if (a.exp_noise) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            lnz_c[c][i] = (node0 + i < N && x.ok) ? __logf(a.exp_noise[((int64_t)t * a.B + x.r) * N + node0 + i]) : 0.0f;
+        } else {
+          float uu4[4];
+          rl4co_uniform4(a.philox_seed ^ (a.philox_seed_dev ? *a.philox_seed_dev : 0ull), a.philox_offset + (uint64_t)tcol,
+                         (uint32_t)x.r, (uint32_t)(node0 >> 2), uu4);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) lnz_c[c][i] = __logf(-__logf(uu4[i]));
+        }
+      }
+    }
     bf16x4 qf[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       const Traj& x = tj[c];
-      const float4 c4 = *reinterpret_cast<const float4*>(ctxc + (int64_t)x.cur * kD);  // L2-resident context row
+      const float4 c4 = c4v[c];
       const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -355,21 +383,7 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
         const Traj& x = tj[c];
         const uint32_t mword = x.mw.word(w >> 1), nword = nv.word(w >> 1);
         const uint32_t lbits = ((mword & logit_sel) | (nword & ~logit_sel)) >> (16 * (w & 1) + 4 * g);
-        // log(Exp(1) noise) of this lane's four nodes; they share one Philox block (rl4co_math.h)
-        float lnz[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (MODE == RL4CO_DECODE_SAMPLE) {
-          if (a.exp_noise) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              lnz[i] = (node0 + i < N && x.ok) ? __logf(a.exp_noise[((int64_t)t * a.B + x.r) * N + node0 + i]) : 0.0f;
-          } else {
-            float uu4[4];
-            rl4co_uniform4(a.philox_seed ^ (a.philox_seed_dev ? *a.philox_seed_dev : 0ull), a.philox_offset + (uint64_t)tcol,
-                           (uint32_t)x.r, (uint32_t)(node0 >> 2), uu4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) lnz[i] = __logf(-__logf(uu4[i]));
-          }
-        }
+        const float* lnz = lnz_c[c];  // drawn at the top of the step
         Sel p;
         float z[4];
         p.zmax = kNegInf;

@@ -24,7 +24,8 @@ namespace {
 
 constexpr int kD = RL4CO_EMBED_DIM;
 constexpr int kQS = 3 * kD + 8;  // LDS row stride of the qkv tile (bf16)
-constexpr int kPS = kD + 24;     // LDS row stride of a wave's staging block: 128 key columns (P, then dS) + 16 d-out columns
+constexpr int kKV = 2 * kD + 8;  // LDS row stride of a k | v row (forward)
+constexpr int kOS = kD + 8;      // LDS row stride of the staged output rows (forward)
 constexpr int kWaves = 8;
 constexpr int kThreads = 64 * kWaves;
 constexpr float kNegInf = -__builtin_huge_valf();
@@ -83,25 +84,60 @@ __device__ inline void stage_rows(const uint16_t* __restrict__ src, int N, int c
   }
 }
 
+// rows [0, 16 NT) x the k | v columns (128 .. 383 of the packed row) of an instance -> LDS (rows >= N zero)
 template <int NT>
-__global__ void __launch_bounds__(kThreads, 2) attn_fwd_kernel(const uint16_t* __restrict__ qkv, int N, uint16_t* __restrict__ out,
+__device__ inline void stage_kv(const uint16_t* __restrict__ src, int N, __bf16* dst, int tid) {
+  constexpr int cpr = 2 * kD / 8;  // 16-byte chunks per row
+  constexpr int total = NT * 16 * cpr;
+  for (int c0 = tid; c0 < total; c0 += 8 * kThreads) {
+    uint4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = min(c0 + j * kThreads, total - 1);
+      const int row = min(c / cpr, N - 1), col = (c % cpr) * 8;
+      v[j] = *reinterpret_cast<const uint4*>(src + (int64_t)row * 3 * kD + kD + col);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j * kThreads;
+      if (c < total) {
+        const int row = c / cpr, col = (c % cpr) * 8;
+        *reinterpret_cast<uint4*>(dst + row * kKV + col) = row < N ? v[j] : make_uint4(0, 0, 0, 0);
+      }
+    }
+  }
+}
+
+// Forward. Only the keys and values sit in LDS ([16 NT][k 128 | v 128]: 59 KB at N <= 112, so TWO workgroups share a
+// CU and one stages its instance while the other computes); a query block's fragment is 8 bytes per lane in exactly
+// the B-operand layout and comes straight from global memory one block ahead; the finished output tiles wait in
+// registers (4 per block) and leave through the dead k | v rows as contiguous 16-byte lanes.
+template <int NT>
+__global__ void __launch_bounds__(kThreads, 4) attn_fwd_kernel(const uint16_t* __restrict__ qkv, int N, uint16_t* __restrict__ out,
                                                                float* __restrict__ lse) {
   extern __shared__ __align__(16) unsigned char smem[];
-  __bf16* qs = reinterpret_cast<__bf16*>(smem);  // [16 NT][kQS]: q | k | v of every node
+  __bf16* kv = reinterpret_cast<__bf16*>(smem);  // [16 NT][kKV]: k | v of every node; afterwards the output rows [16 NT][kOS]
   const int tid = threadIdx.x, h = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
   const int64_t inst = blockIdx.x;
-  stage_rows<NT>(qkv + inst * N * 3 * kD, N, 3 * kD, qs, kQS, tid);
+  const uint16_t* base = qkv + inst * N * 3 * kD;
+  const uint16_t* qrow = base + 16 * h + 4 * g;
+  auto load_q = [&](int tb) { return *reinterpret_cast<const uint2*>(qrow + (int64_t)min(16 * tb + tl, N - 1) * 3 * kD); };
+  uint2 q_next = load_q(0);
+  stage_kv<NT>(base, N, kv, tid);
   __syncthreads();
-  const int nao = tl * kQS + 4 * g;
-  const int tro = (4 * g + (tl >> 2)) * kQS + 4 * (tl & 3);
+  const int nao = tl * kKV + 4 * g;
+  const int tro = (4 * g + (tl >> 2)) * kKV + 4 * (tl & 3);
+  bf16x4 ov[NT];
+#pragma clang loop unroll(full)
   for (int tb = 0; tb < NT; ++tb) {
     const int t = 16 * tb + tl;
-    const bf16x4 qf = lds_b64(qs + 16 * tb * kQS + 16 * h + nao);
+    const bf16x4 qf = __builtin_bit_cast(bf16x4, q_next);
+    q_next = load_q(min(tb + 1, NT - 1));
     f32x4 sc[NT];
     float m = kNegInf;
 #pragma clang loop unroll(full)
     for (int jt = 0; jt < NT; ++jt) {
-      sc[jt] = mfma16(lds_b64(qs + 16 * jt * kQS + kD + 16 * h + nao), qf, zero4());
+      sc[jt] = mfma16(lds_b64(kv + 16 * jt * kKV + 16 * h + nao), qf, zero4());
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         sc[jt][rr] = (16 * jt + 4 * g + rr < N) ? sc[jt][rr] * kScale : kNegInf;
@@ -120,84 +156,118 @@ __global__ void __launch_bounds__(kThreads, 2) attn_fwd_kernel(const uint16_t* _
         l += p;
         pf[rr] = (__bf16)p;
       }
-      const bf16x4 vf = lds_tr(qs + 16 * jt * kQS + 2 * kD + 16 * h + tro);
+      const bf16x4 vf = lds_tr(kv + 16 * jt * kKV + kD + 16 * h + tro);
       if (jt & 1) o1 = mfma16(vf, pf, o1);
       else o0 = mfma16(vf, pf, o0);
     }
     l = rg_sum(l);
     const float inv = __builtin_amdgcn_rcpf(l);
-    if (t < N) {
-      f32x4 o;
+    f32x4 o;
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) o[rr] = (o0[rr] + o1[rr]) * inv;
-      // parked over this wave's own (consumed) Q columns of the block; the tile leaves coalesced below
-      *reinterpret_cast<bf16x4*>(qs + t * kQS + 16 * h + 4 * g) = to_bf16(o);
-      if (g == 0) lse[(inst * kWaves + h) * N + t] = m + __builtin_amdgcn_logf(l);  // log2 domain
-    }
+    for (int rr = 0; rr < 4; ++rr) o[rr] = (o0[rr] + o1[rr]) * inv;
+    ov[tb] = to_bf16(o);
+    if (t < N && g == 0) lse[(inst * kWaves + h) * N + t] = m + __builtin_amdgcn_logf(l);  // log2 domain
   }
-  // 8-byte stores from the accumulators put 32 bytes per wave into each of 16 rows; staged, the instance's
-  // [N, 128] output is one contiguous run of 16-byte lanes
+  // 8-byte stores from the accumulators would put 32 bytes per wave into each of 16 rows; staged over the dead keys,
+  // the instance's [N, 128] output is one contiguous run of 16-byte lanes
+  __syncthreads();
+#pragma unroll
+  for (int tb = 0; tb < NT; ++tb) *reinterpret_cast<bf16x4*>(kv + (16 * tb + tl) * kOS + 16 * h + 4 * g) = ov[tb];
   __syncthreads();
   for (int c = tid; c < N * 16; c += kThreads) {
     const int row = c >> 4, col = (c & 15) * 8;
-    *reinterpret_cast<uint4*>(out + (inst * N + row) * kD + col) = *reinterpret_cast<const uint4*>(qs + row * kQS + col);
+    *reinterpret_cast<uint4*>(out + (inst * N + row) * kD + col) = *reinterpret_cast<const uint4*>(kv + row * kOS + col);
   }
 }
 
+// Backward. One 256-thread workgroup per (instance, half of the heads): wave w owns head 4 hh + w. A head only ever
+// touches its own 16 columns of q, k, v and d out, so the halves share nothing; what the split buys is footprint —
+// k | v of four heads (30 KB) + the four waves' staging blocks (21 KB) let THREE workgroups (12 waves) share a CU
+// where the eight-head workgroup (150 KB) ran alone. Per query block the q / d out fragments (8 bytes per lane, the
+// B-operand layout) and the log-sum-exp come straight from global memory one block ahead; their transposed A-operand
+// forms go through 2 x 512 bytes of the wave's staging block; d q waits in registers; at the end the whole LDS holds
+// [N][d q | d k | d v] of the four heads and leaves as 16-byte lanes over 128-byte row segments.
+constexpr int kBwdWaves = 4;
+constexpr int kBwdThreads = 64 * kBwdWaves;
+constexpr int kKH = kD + 8;       // LDS row stride of k | v of four heads (64 + 64 columns)
+constexpr int kPS = kD + 32 + 8;  // a wave's staging row: 128 key columns (P, then dS) | 16 d-out | 16 q columns
+constexpr int kDS = 3 * 64 + 8;   // output staging row: d q | d k | d v of four heads
+
 template <int NT>
-__global__ void __launch_bounds__(kThreads, 2) attn_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
-                                                               const float* __restrict__ lse, int N, uint16_t* __restrict__ dqkv) {
+__global__ void __launch_bounds__(kBwdThreads, 3) attn_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
+                                                                  const float* __restrict__ lse, int N, uint16_t* __restrict__ dqkv) {
   extern __shared__ __align__(16) unsigned char smem[];
-  __bf16* qs = reinterpret_cast<__bf16*>(smem);                   // [16 NT][kQS]
-  const int tid = threadIdx.x, h = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
-  __bf16* pbw = qs + NT * 16 * kQS + h * 16 * kPS;                 // this wave's [16 queries][kPS]: P, then dS | dO_h
-  const int64_t inst = blockIdx.x;
-  stage_rows<NT>(qkv + inst * N * 3 * kD, N, 3 * kD, qs, kQS, tid);
-  // d out never sits in LDS as a whole: a wave only ever touches the 16 columns of its head of the CURRENT query
-  // block, and in the accumulator layout that is 8 bytes per lane — exactly the B operand, straight from global
-  // memory one block ahead; the transposed A operand of d V goes through 512 bytes of the wave's staging block
-  const uint16_t* dorow = dout + inst * N * kD + 16 * h + 4 * g;
+  __bf16* kv = reinterpret_cast<__bf16*>(smem);  // [16 NT][kKH]: k (4 heads) | v (4 heads)
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
+  const int64_t inst = blockIdx.x >> 1;
+  const int hh = blockIdx.x & 1, h = 4 * hh + w;
+  __bf16* pbw = kv + NT * 16 * kKH + w * 16 * kPS;  // this wave's [16 queries][kPS]
+  const uint16_t* base = qkv + inst * N * 3 * kD;
+  {  // k | v columns of this half: 16 chunks of 16 bytes per row, eight in flight per thread
+    constexpr int total = NT * 16 * 16;
+    for (int c0 = tid; c0 < total; c0 += 8 * kBwdThreads) {
+      uint4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = min(c0 + j * kBwdThreads, total - 1);
+        const int row = min(c >> 4, N - 1), part = (c >> 3) & 1, ch = c & 7;
+        v[j] = *reinterpret_cast<const uint4*>(base + (int64_t)row * 3 * kD + kD * (1 + part) + 64 * hh + 8 * ch);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j * kBwdThreads;
+        if (c < total) {
+          const int row = c >> 4, col = (c & 15) * 8;
+          *reinterpret_cast<uint4*>(kv + row * kKH + col) = row < N ? v[j] : make_uint4(0, 0, 0, 0);
+        }
+      }
+    }
+  }
   // (unconditional loads from clamped rows, masked where they are consumed: a load under a branch makes the compiler
   // wait for ALL outstanding loads at the join, i.e. for the prefetch it has just issued)
-  auto load_do = [&](int tb) {
-    const int t = min(16 * tb + tl, N - 1);
-    return *reinterpret_cast<const uint2*>(dorow + (int64_t)t * kD);
-  };
+  const uint16_t* qrow = base + 16 * h + 4 * g;
+  const uint16_t* dorow = dout + inst * N * kD + 16 * h + 4 * g;
   const float* lrow = lse + (inst * kWaves + h) * N;
-  auto load_lse = [&](int tb) { return lrow[min(16 * tb + tl, N - 1)]; };
-  uint2 do_next = load_do(0);
-  float L_next = load_lse(0);
+  auto row_of = [&](int tb) { return (int64_t)min(16 * tb + tl, N - 1); };
+  uint2 q_next = *reinterpret_cast<const uint2*>(qrow + row_of(0) * 3 * kD);
+  uint2 do_next = *reinterpret_cast<const uint2*>(dorow + row_of(0) * kD);
+  float L_next = lrow[row_of(0)];
   __syncthreads();
-  const int nao = tl * kQS + 4 * g;
-  const int tro = (4 * g + (tl >> 2)) * kQS + 4 * (tl & 3), tro_p = (4 * g + (tl >> 2)) * kPS + 4 * (tl & 3);
+  const int nao = tl * kKH + 4 * g;
+  const int tro = (4 * g + (tl >> 2)) * kKH + 4 * (tl & 3), tro_p = (4 * g + (tl >> 2)) * kPS + 4 * (tl & 3);
   f32x4 dk[NT], dv[NT];  // [d = 4 g + r of head h][key 16 jt + (lane & 15)]
+  bf16x4 dqv[NT];        // d q of the block's queries, kept until the output staging
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) {
     dk[jt] = zero4();
     dv[jt] = zero4();
   }
+#pragma clang loop unroll(full)
   for (int tb = 0; tb < NT; ++tb) {
     const int t = 16 * tb + tl;
     const bool tv = t < N;
-    const bf16x4 qf = lds_b64(qs + 16 * tb * kQS + 16 * h + nao);
-    const uint2 do_raw = do_next;
+    const bf16x4 qf = __builtin_bit_cast(bf16x4, q_next);
+    const bf16x4 dof = __builtin_bit_cast(bf16x4, tv ? do_next : make_uint2(0u, 0u));
     const float L = L_next;
-    const int tbn = min(tb + 1, NT - 1);  // (the last block re-reads itself: no branch around the loads)
-    do_next = load_do(tbn);
-    L_next = load_lse(tbn);
-    const bf16x4 dof = __builtin_bit_cast(bf16x4, tv ? do_raw : make_uint2(0u, 0u));
+    {
+      const int64_t rn = row_of(min(tb + 1, NT - 1));  // (the last block re-reads itself: no branch around the loads)
+      q_next = *reinterpret_cast<const uint2*>(qrow + rn * 3 * kD);
+      do_next = *reinterpret_cast<const uint2*>(dorow + rn * kD);
+      L_next = lrow[rn];
+    }
     *reinterpret_cast<bf16x4*>(pbw + tl * kPS + kD + 4 * g) = dof;
+    *reinterpret_cast<bf16x4*>(pbw + tl * kPS + kD + 16 + 4 * g) = qf;
     bf16x4 pf[NT];
     f32x4 dp[NT];
     float dsum = 0.0f;
 #pragma clang loop unroll(full)
     for (int jt = 0; jt < NT; ++jt) {
-      const f32x4 s = mfma16(lds_b64(qs + 16 * jt * kQS + kD + 16 * h + nao), qf, zero4());
-      dp[jt] = mfma16(lds_b64(qs + 16 * jt * kQS + 2 * kD + 16 * h + nao), dof, zero4());
+      const f32x4 sc = mfma16(lds_b64(kv + 16 * jt * kKH + 16 * w + nao), qf, zero4());
+      dp[jt] = mfma16(lds_b64(kv + 16 * jt * kKH + 64 + 16 * w + nao), dof, zero4());
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const bool ok = tv && (16 * jt + 4 * g + rr < N);
-        const float p = ok ? __builtin_amdgcn_exp2f(s[rr] * kScale - L) : 0.0f;
+        const float p = ok ? __builtin_amdgcn_exp2f(sc[rr] * kScale - L) : 0.0f;
         pf[jt][rr] = (__bf16)p;
         dsum = fmaf((float)pf[jt][rr], dp[jt][rr], dsum);
       }
@@ -218,43 +288,41 @@ __global__ void __launch_bounds__(kThreads, 2) attn_bwd_kernel(const uint16_t* _
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) dsf[rr] = (__bf16)((float)pf[jt][rr] * (dp[jt][rr] - dsum));
       *reinterpret_cast<bf16x4*>(pbw + tl * kPS + 16 * jt + 4 * g) = dsf;
-      dq = mfma16(lds_tr(qs + 16 * jt * kQS + kD + 16 * h + tro), dsf, dq);
+      dq = mfma16(lds_tr(kv + 16 * jt * kKH + 16 * w + tro), dsf, dq);
     }
     wave_lds_sync();
     {
-      const bf16x4 qt = lds_tr(qs + 16 * tb * kQS + 16 * h + tro);  // Q_h^T[d][queries]
+      const bf16x4 qt = lds_tr(pbw + kD + 16 + tro_p);  // Q_h^T[d][queries]
 #pragma clang loop unroll(full)
       for (int jt = 0; jt < NT; ++jt) dk[jt] = mfma16(qt, lds_tr(pbw + 16 * jt + tro_p), dk[jt]);
     }
-    if (tv) {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) dq[rr] *= 0.25f;
-      *reinterpret_cast<bf16x4*>(qs + t * kQS + 16 * h + 4 * g) = to_bf16(dq);  // over this wave's consumed Q columns
-    }
+    for (int rr = 0; rr < 4; ++rr) dq[rr] *= 0.25f;
+    dqv[tb] = to_bf16(dq);
     wave_lds_sync();  // the next query block rewrites this wave's staging block
   }
+  __syncthreads();  // every wave is done with k | v: the whole LDS becomes [16 NT][d q | d k | d v] of the four heads
+  __bf16* os = reinterpret_cast<__bf16*>(smem);
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) {
-    const int j = 16 * jt + tl;
-    if (j < N) {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) dk[jt][rr] *= 0.25f;
-      // this wave's K / V columns are dead (only head h reads them): d k, d v take their place
-      __bf16* row = qs + j * kQS + 16 * h + 4 * g;
-      *reinterpret_cast<bf16x4*>(row + kD) = to_bf16(dk[jt]);
-      *reinterpret_cast<bf16x4*>(row + 2 * kD) = to_bf16(dv[jt]);
-    }
+    for (int rr = 0; rr < 4; ++rr) dk[jt][rr] *= 0.25f;
+    __bf16* row = os + (16 * jt + tl) * kDS + 16 * w + 4 * g;
+    *reinterpret_cast<bf16x4*>(row) = dqv[jt];
+    *reinterpret_cast<bf16x4*>(row + 64) = to_bf16(dk[jt]);
+    *reinterpret_cast<bf16x4*>(row + 128) = to_bf16(dv[jt]);
   }
-  __syncthreads();  // [N][d q | d k | d v] complete in LDS: one contiguous run of 16-byte lanes per instance
-  for (int c = tid; c < N * 48; c += kThreads) {
-    const int row = c / 48, col = (c % 48) * 8;
-    *reinterpret_cast<uint4*>(dqkv + (inst * N + row) * 3 * kD + col) = *reinterpret_cast<const uint4*>(qs + row * kQS + col);
+  __syncthreads();
+  for (int c = tid; c < N * 24; c += kBwdThreads) {  // three 128-byte segments per row
+    const int row = c / 24, seg = (c % 24) >> 3, ch = c & 7;
+    *reinterpret_cast<uint4*>(dqkv + (inst * N + row) * 3 * kD + seg * kD + 64 * hh + 8 * ch) =
+        *reinterpret_cast<const uint4*>(os + row * kDS + 64 * seg + 8 * ch);
   }
 }
 
 template <int NT>
 int launch_fwd(const void* qkv, int B, int N, void* out, float* lse, hipStream_t s) {
-  const int lds = NT * 16 * kQS * 2;
+  const int lds = NT * 16 * kKV * 2;
   RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipLaunchKernelGGL(attn_fwd_kernel<NT>, dim3(B), dim3(kThreads), lds, s, static_cast<const uint16_t*>(qkv), N,
                      static_cast<uint16_t*>(out), lse);
@@ -263,9 +331,10 @@ int launch_fwd(const void* qkv, int B, int N, void* out, float* lse, hipStream_t
 }
 template <int NT>
 int launch_bwd(const void* qkv, const void* dout, const float* lse, int B, int N, void* dqkv, hipStream_t s) {
-  const int lds = (NT * 16 * kQS + kWaves * 16 * kPS) * 2;
+  constexpr int work = (NT * 16 * kKH + kBwdWaves * 16 * kPS) * 2, stage = NT * 16 * kDS * 2;
+  constexpr int lds = work > stage ? work : stage;
   RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL(attn_bwd_kernel<NT>, dim3(B), dim3(kThreads), lds, s, static_cast<const uint16_t*>(qkv),
+  hipLaunchKernelGGL(attn_bwd_kernel<NT>, dim3(2 * B), dim3(kBwdThreads), lds, s, static_cast<const uint16_t*>(qkv),
                      static_cast<const uint16_t*>(dout), lse, N, static_cast<uint16_t*>(dqkv));
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
@@ -286,7 +355,7 @@ extern "C" int rl4co_attn_fwd_bf16(const void* qkv, int B, int N, void* out, flo
 }
 
 extern "C" int rl4co_attn_bwd_bf16(const void* qkv, const void* dout, const float* lse, int B, int N, void* dqkv, void* stream) {
-  RL4CO_REQUIRE(qkv && dout && lse && dqkv && B > 0 && N >= 1 && N <= 128);
+  RL4CO_REQUIRE(qkv && dout && lse && dqkv && B > 0 && B < (1 << 30) && N >= 1 && N <= 128);
   hipStream_t s = rl4co::as_stream(stream);
   const int nt = (N + 15) >> 4;
   if (nt <= 2) return launch_bwd<2>(qkv, dout, lse, B, N, dqkv, s);
