@@ -424,13 +424,26 @@ __device__ inline bf16x4w lds_tr_w(const __bf16* p) {
 }
 
 __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X, int M, int N,
-                                                         int K, int rows_per_chunk, float* __restrict__ partial,
+                                                         int K, int rows_per_chunk, int n_chunks, float* __restrict__ partial,
                                                          float* __restrict__ partial_bias, int64_t pstride, int64_t bstride) {
   __shared__ __align__(16) __bf16 dyt[kWT * kWLS];  // [32 tokens][128 output features of this tile]
   __shared__ __align__(16) __bf16 xt[kWT * kWLS];   // [32 tokens][128 input features of this tile]
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
   const int kt_n = K / 128;
-  const int tile = blockIdx.x, nt = tile / kt_n, kt = tile % kt_n, chunk = blockIdx.y;
+  // workgroup -> (tile, row chunk). The tiles of ONE chunk re-read the same rows of the operand they share (X for
+  // the wide-N layers, dY for the wide-K one): workgroup b lands on XCD b % 8, so with the chunk count a multiple of 8
+  // the tiles of a chunk take consecutive slots of one XCD and meet in its L2 instead of each pulling the rows from HBM
+  const int tiles = gridDim.x / n_chunks;
+  int tile, chunk;
+  if ((n_chunks & 7) == 0) {
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    tile = slot % tiles;
+    chunk = xcd + 8 * (slot / tiles);
+  } else {
+    tile = blockIdx.x % tiles;
+    chunk = blockIdx.x / tiles;
+  }
+  const int nt = tile / kt_n, kt = tile % kt_n;
   const int64_t m_begin = (int64_t)chunk * rows_per_chunk;
   const int64_t m_end = min((int64_t)M, m_begin + rows_per_chunk);
   const int tro = (4 * g + (tl >> 2)) * kWLS + 4 * (tl & 3);
@@ -443,7 +456,8 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const uint16_t* __restr
   // (tiles with kt == 0 only); every accumulator column then holds the same sum
   const bool with_bias = partial_bias != nullptr && kt == 0;
   f32x4w accb[2] = {f32x4w{0.0f, 0.0f, 0.0f, 0.0f}, f32x4w{0.0f, 0.0f, 0.0f, 0.0f}};
-  const bf16x4w ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
+  typedef __bf16 bf16x8o __attribute__((ext_vector_type(8)));
+  const bf16x8o ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
   const int lrow = tid >> 3, lcol = (tid & 7) * 16;  // this thread stages 32 bytes of each tile row
   typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
   // the rows of step i + 1 are requested before the products of step i (registers), so a step no longer opens with
@@ -476,20 +490,28 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const uint16_t* __restr
     }
     __syncthreads();
     fetch(min(m0 + kWT, m_end - 1));  // (the last step re-reads a row it drops: no branch around the loads)
+    // 32 tokens per product: v_mfma_f32_16x16x32_bf16 (gfx950) runs at twice the rate of the 16-deep instruction, and
+    // the contraction runs over tokens, so ANY assignment of tokens to its 32 slots is right as long as both operands
+    // use the same one — two 16-token transpose reads side by side (tokens 16 ts + 4 g .. and 16 (ts + 1) + 4 g ..)
+    typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+    auto pair = [&](const __bf16* p) {
+      const bf16x4w lo = lds_tr_w(p), hi = lds_tr_w(p + 16 * kWLS);
+      return bf16x8w{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    };
 #pragma unroll
-    for (int ts = 0; ts < kWT / 16; ++ts) {
-      bf16x4w af[2];
+    for (int ts = 0; ts < kWT / 16; ts += 2) {
+      bf16x8w af[2];
 #pragma unroll
-      for (int nb = 0; nb < 2; ++nb) af[nb] = lds_tr_w(dyt + 16 * ts * kWLS + 32 * w + 16 * nb + tro);
+      for (int nb = 0; nb < 2; ++nb) af[nb] = pair(dyt + 16 * ts * kWLS + 32 * w + 16 * nb + tro);
       if (with_bias) {
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) accb[nb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af[nb], ones, accb[nb], 0, 0, 0);
+        for (int nb = 0; nb < 2; ++nb) accb[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nb], ones, accb[nb], 0, 0, 0);
       }
 #pragma unroll
       for (int kb = 0; kb < 8; ++kb) {
-        const bf16x4w bf = lds_tr_w(xt + 16 * ts * kWLS + 16 * kb + tro);
+        const bf16x8w bf = pair(xt + 16 * ts * kWLS + 16 * kb + tro);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) acc[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(af[nb], bf, acc[nb][kb], 0, 0, 0);
+        for (int nb = 0; nb < 2; ++nb) acc[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nb], bf, acc[nb][kb], 0, 0, 0);
       }
     }
   }
@@ -518,9 +540,9 @@ extern "C" int rl4co_wgrad_bf16(const void* dy, const void* x, int64_t M, int N,
   RL4CO_REQUIRE(dy && x && partial);
   RL4CO_REQUIRE(M > 0 && M < (int64_t)1 << 31 && N > 0 && K > 0 && N % 128 == 0 && K % 128 == 0 && chunks > 0 && chunks <= 65535);
   const int rows = (int)(((M + chunks - 1) / chunks + kWT - 1) / kWT * kWT);
-  hipLaunchKernelGGL(wgrad_bf16_kernel, dim3((N / 128) * (K / 128), chunks), dim3(256), 0, rl4co::as_stream(stream),
-                     static_cast<const uint16_t*>(dy), static_cast<const uint16_t*>(x), (int)M, N, K, rows, partial, partial_bias,
-                     pstride, bstride);
+  hipLaunchKernelGGL(wgrad_bf16_kernel, dim3((N / 128) * (K / 128) * chunks), dim3(256), 0, rl4co::as_stream(stream),
+                     static_cast<const uint16_t*>(dy), static_cast<const uint16_t*>(x), (int)M, N, K, rows, chunks, partial,
+                     partial_bias, pstride, bstride);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }

@@ -197,7 +197,8 @@ def _gemm(a2d: Tensor, w: Tensor, bias: Tensor | None = None, mask: Tensor | Non
 
 # row chunks x output tiles per weight-gradient launch: every chunk writes an fp32 partial that one reduction sums.
 # 512 workgroups (two per CU): measured on the four training shapes at 409 600 rows, kernel + reduction
-# (tools/wgrad_chunks_bench.py): 2048 -> 684 us, 1024 -> 592, 512 -> 484, 256 -> 631 — beyond two per CU the partials
+# (tools/wgrad_chunks_bench.py; r02 with the 32-deep MFMA, tools/linear_bench.py: 256 -> 479 us, 384 -> 453, 512 -> 417,
+# 768 -> 493, 1024 -> 499; before: 2048 -> 684 us, 1024 -> 592, 512 -> 484, 256 -> 631) — beyond two per CU the partials
 # (67 MB written and re-read at 1024) cost more than the extra parallelism buys
 _WGRAD_MAX_WORKGROUPS = int(__import__("os").environ.get("RL4CO_WGRAD_WORKGROUPS", "512"))
 
@@ -208,7 +209,12 @@ def _wgrad(d2: Tensor, x2: Tensor, with_bias: bool = False):
     m, n = d2.shape
     k = x2.shape[1]
     tiles = (n // 128) * (k // 128)
-    chunks = max(1, min(_WGRAD_MAX_WORKGROUPS // tiles, (m + 255) // 256))
+    # (a single-tile layer, 128 x 128, is best at one workgroup per CU: 60 us against 67 with two — its partials are
+    # as large as the operands)
+    budget = _WGRAD_MAX_WORKGROUPS // 2 if tiles == 1 else _WGRAD_MAX_WORKGROUPS
+    chunks = max(1, min(budget // tiles, (m + 255) // 256))
+    if chunks >= 8:
+        chunks -= chunks % 8  # a multiple of 8: the kernel then keeps the tiles of a chunk on one XCD (shared rows meet in its L2)
     # one buffer per chunk: [N*K weight partials | N bias partials] -> ONE reduction over the chunk axis for both
     width = n * k + (n if with_bias else 0)
     partial = torch.empty((chunks, width), dtype=torch.float32, device=d2.device)
