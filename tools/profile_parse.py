@@ -32,8 +32,10 @@ for legdir in sorted(p for p in src.iterdir() if p.is_dir()):
                 f"--no-parity --launch eager   ({tag}, MI355X)")
         if line:
             roof = line.get("roofline", {})
-            head += (f"\n# same run's JSON line: ms_per_step {line.get('ms_per_step', 0):.3f}; HIP-event mean of the decode launch "
-                     f"{roof.get('launch_ms_mean', float('nan')):.3f} ms, roofline.frac {roof.get('frac', float('nan')):.3f}")
+            head += f"\n# same run's JSON line: ms_per_step {line.get('ms_per_step', 0):.3f}"
+            if roof.get("launch_ms_mean") is not None:
+                head += (f"; HIP-event mean of the decode launch {roof['launch_ms_mean']:.3f} ms, "
+                         f"roofline.frac {roof.get('frac', float('nan')):.3f}")
         lines = [head, f"{'kernel':100s} {'calls':>6s} {'total_ms':>10s} {'avg_us':>10s} {'min_us':>10s} {'max_us':>10s} {'pct':>6s}"]
         for r in rows[:30]:
             lines.append(f"{r['Name'][:100]:100s} {r['Calls']:>6s} {float(r['TotalDurationNs'])/1e6:10.3f} "
