@@ -263,6 +263,13 @@ class Bench:
             encode_ms = [x.elapsed_time(y) for x, y in policy.encode_events]
             policy.decode_events = policy.encode_events = None
         t_steps = out["actions"].shape[1]
+        # the captured graph (its private memory pool, its streams) is released before the next leg: with two ranks
+        # sharing ONE device (the RL4CO_BENCH_SHARED_GPU test mode) a lingering graph made the following training leg
+        # crawl (3 s per step); nothing should outlive its leg anyway
+        step = graphed = None  # noqa: F841
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.empty_cache()
         n_nodes = num_loc + (0 if env_name == "tsp" else 1)
         wall = self.D.reduce_scalar(wall, "max", self.device)
         total_inst_steps = int(self.D.reduce_scalar(inst_steps, "sum", self.device))
@@ -465,6 +472,10 @@ def main() -> None:
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if os.environ.get("RL4CO_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack every N seconds
+        import faulthandler
+
+        faulthandler.dump_traceback_later(float(os.environ["RL4CO_BENCH_WATCHDOG"]), repeat=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000, help="timed steps of the headline leg (3.5 s of GPU time at the default)")
@@ -499,6 +510,10 @@ def main() -> None:
     # RL4CO_BENCH_SHARED_GPU=1 (testing the multi-rank path on a one-GPU box): ranks share the visible devices
     if os.environ.get("RL4CO_BENCH_SHARED_GPU") == "1":
         local_rank %= torch.cuda.device_count()
+        # two processes on ONE device: kernel by kernel only. With captured graphs alive in both processes the later
+        # training leg's collective stalled for seconds (measured r02: 3 s per step, once a hang) — hardware-queue
+        # oversubscription between the processes, not a property of the one-process-per-GPU layout this mode imitates
+        args.launch = "eager"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -514,11 +529,16 @@ def main() -> None:
     bench = Bench(args, rank, world, device)
     leg_steps = args.leg_steps or max(10, args.steps // 8)
     results = {}
-    for i, leg in enumerate(legs):
+    # execution order: the training leg runs FIRST, in a process that has not captured a HIP graph yet (legs[0] stays
+    # the headline of the JSON line). Observed with two ranks sharing one device: a training leg that followed graphed
+    # rollout legs stalled in its gradient all-reduce; the order removes the interaction whatever its cause
+    order = sorted(range(len(legs)), key=lambda j: (legs[j] != "c4_train", j))
+    for i in order:
+        leg = legs[i]
         k, w = (args.steps, args.warmup) if i == 0 else (leg_steps, max(2, min(args.warmup, 3)))
         if leg == "c4_train":
             k = min(k, max(5, args.steps // 20)) if i else k
-            results[leg] = bench.train_leg(k, w)
+            results[leg] = bench.train_leg(k, max(w, args.warmup))  # first leg of the process: clocks, allocator, code objects
         else:
             results[leg] = bench.rollout_leg(leg, k, w)
         if rank == 0:
