@@ -112,6 +112,9 @@ CASES = [
          store_inputs=False),
     dict(name="c2_tsp100_b4096_sampling", env="tsp", num_loc=100, batch=4096, policy="am", decode="sampling",
          store_inputs=False),
+    # configs[3]'s per-GPU share at full size: POMO-6L, 4096 instances x 8 starts, multistart sampling (32 768 tours)
+    dict(name="c4_pomo_tsp100_b4096_s8_sampling", env="tsp", num_loc=100, batch=4096, policy="pomo",
+         decode="multistart_sampling", fw_kw=dict(num_starts=8), store_inputs=False),
 ]
 
 POMO_KW = dict(num_encoder_layers=6, normalization="instance", use_graph_context=False)  # pomo/model.py:52-67

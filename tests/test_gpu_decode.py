@@ -449,6 +449,39 @@ def test_full_size_tsp100_b4096_sampling_vs_reference_golden(K):
     assert rel <= (1e-5 if flips == 0 else 1e-4)
 
 
+def test_full_size_c4_pomo_tsp100_b4096_s8_sampling_vs_reference_golden(K):
+    """BASELINE configs[3]'s per-GPU share at FULL size — POMO-6L (instance norm, no graph context), TSP-100, 4096
+    instances x 8 starts = 32 768 multistart-sampled tours — with the reference's own seeded noise (1.3 GB, re-drawn from
+    its seed): fp32 planes against the reference's tours (s-major rows, imposed start nodes, reward arithmetic), then
+    the configuration the training leg actually runs (bf16 planes, MS kernel on the matrix cores) for validity and tour
+    quality against the reference's at the same size."""
+    g = GoldenCase("c4_pomo_tsp100_b4096_s8_sampling")
+    assert g.batch == 4096 and g.num_starts == 8
+    td0, h = _encode(g)
+    noise = _reference_noise(g, 100)
+    a, l, st, n_steps, t, err = _run(K, "hip", g, td0, h, "sampling", exp_noise=noise)
+    assert err == 0 and t == 100
+    # same near-tie rate as configs[1] (<= 20 of 4096): 32 768 tours
+    flips, reward = _vs_golden(K, g, a, l, t, td0, max_flips=160)
+    _record("c4_sampling_fp32_flips", {"fold_on": flips, "of": int(a.shape[0])})
+    rel = abs(float(reward.mean() - g.reward.mean())) / abs(float(g.reward.mean()))
+    print(f"POMO TSP-100 x 4096 x 8 sampling, fp32 planes, reference noise: {flips} of {a.shape[0]} tours differ, mean reward rel. gap {rel:.2e}")
+    assert rel <= (1e-5 if flips == 0 else 1e-4)
+    assert torch.equal(a[:, :t].sort(1).values, torch.arange(100).expand(a.shape[0], 100))
+    # the benchmarked regime: bf16 planes -> the MS kernel (auto from 8 starts); same noise, tours legitimately diverge
+    assert K.decode_variant(100, torch.bfloat16, 99, a.shape[0], num_instances=4096) == 4  # RL4CO_VARIANT_MS
+    ms = _run(K, "hip", g, td0, h, "sampling", torch.bfloat16, exp_noise=noise)
+    assert ms[5] == 0 and ms[4] == 100
+    am = ms[0][:, :100]
+    assert torch.equal(am.sort(1).values, torch.arange(100).expand(am.shape[0], 100))
+    r_ms = kernel_reward(K, g.env_name, td0, am.contiguous()).cpu()
+    gap = abs(float(r_ms.mean() - g.reward.mean())) / abs(float(g.reward.mean()))
+    same = float((am == g.actions).all(1).float().mean())
+    _record("c4_sampling_bf16_ms", {"identical_frac": same, "mean_reward_rel_gap": gap})
+    print(f"bf16 planes (MS kernel): identical tours {same:.4f}, mean reward rel. gap {gap:.2e}")
+    assert gap <= 5e-3
+
+
 def test_full_size_cvrp500_b256_sampling_wide_variant(K):
     """BASELINE configs[4] (CVRP-500 sampling; N = 501, tours of 530+ points: the level_step cascade of ATen's sum) at a
     batch that the WIDE decode variant serves, as bench.py's c5 leg does: (a) fp32 planes with the reference's noise
