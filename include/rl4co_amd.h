@@ -75,8 +75,9 @@ extern "C" {
 #define RL4CO_VARIANT_WIDE 3   /* bf16 planes streamed every step, 4 waves / trajectory (few trajectories, large N) */
 #define RL4CO_VARIANT_MS 4     /* multistart on the matrix cores: one workgroup per (instance, column tile of 16
                                   starts), glimpse planes in LDS, logit-key tile in registers, two workgroups per
-                                  CU; bf16 query / glimpse (pinned to the rounding-model oracle, 5e-3); TSP / CVRP,
-                                  auto from 8 starts per instance */
+                                  CU; bf16 query / glimpse (pinned to the rounding-model oracle, 5e-3); every
+                                  environment; auto where measured faster: TSP / PDP / PCTSP from 8 starts per
+                                  instance, CVRP from 16 */
 
 #define RL4CO_EMBED_DIM 128 /* the engine is specialised for the AM default d=128, H=8 */
 #define RL4CO_NUM_HEADS 8

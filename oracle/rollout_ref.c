@@ -689,8 +689,13 @@ static inline float bf16_round(float x) {
 
 int oracle_am_decode_ms(const rl4co_am_decode_args* a) {
   const int N = a->N;
-  if (a->cache_dtype != RL4CO_DT_BF16 || (a->env != RL4CO_ENV_TSP && a->env != RL4CO_ENV_CVRP) || N > 128) return 1;
-  const int tsp = a->env == RL4CO_ENV_TSP;
+  if (a->cache_dtype != RL4CO_DT_BF16 || N > 128) return 1;
+  const int env = a->env;
+  const int tsp = env == RL4CO_ENV_TSP;
+  const int cvrp_like = env == RL4CO_ENV_CVRP || env == RL4CO_ENV_CVRPTW;
+  const int tw_env = env == RL4CO_ENV_CVRPTW;
+  const int scalar_ctx = !tsp && env != RL4CO_ENV_PDP;
+  const int has_step_i = !cvrp_like;
   const float neg_inf = -INFINITY;
   const float log2e = 1.44269504088896341f, sqrt_d = 11.3137084989847604f;
   const int single = a->max_steps == 1;
@@ -701,6 +706,7 @@ int oracle_am_decode_ms(const rl4co_am_decode_args* a) {
   float* z = (float*)malloc(sizeof(float) * (size_t)N);
   uint8_t* mk = (uint8_t*)malloc((size_t)N);
   uint8_t* vis = (uint8_t*)malloc((size_t)N);
+  uint8_t* tod = (uint8_t*)malloc((size_t)N);
   for (int r = 0; r < a->B; ++r) {
     const int cb = r % a->B_inst;
     const int64_t cbase = (int64_t)cb * a->kvl_batch_stride;
@@ -709,12 +715,20 @@ int oracle_am_decode_ms(const rl4co_am_decode_args* a) {
     uint8_t* gmask = a->action_mask + (int64_t)r * N;
     memcpy(mk, gmask, (size_t)N);
     if (!tsp) memcpy(vis, a->visited + (int64_t)r * N, (size_t)N);
+    if (env == RL4CO_ENV_PDP) memcpy(tod, a->to_deliver + (int64_t)r * N, (size_t)N);
     int cur = (int)a->current_node[r];
     int first = tsp ? (int)a->first_node[r] : 0;
-    long long step_i = tsp ? a->step_i[r] : 0;
-    float used = tsp ? 0.0f : a->used_capacity[r];
-    const float cap = tsp ? 0.0f : a->vehicle_capacity[r];
-    const float* dem = tsp ? NULL : a->demand + (int64_t)cb * (N - 1);
+    long long step_i = has_step_i ? a->step_i[r] : 0;
+    float used = scalar_ctx ? a->used_capacity[r] : 0.0f;
+    const float* oplocs = env == RL4CO_ENV_OP ? a->locs + (int64_t)cb * N * 2 : NULL;
+    const float* opmax = env == RL4CO_ENV_OP ? a->max_length + (int64_t)cb * N : NULL;
+    const float* twlocs = tw_env ? a->locs + (int64_t)cb * N * 2 : NULL;
+    const float* tw = tw_env ? a->time_windows + (int64_t)cb * N * 2 : NULL;
+    const float* dur = tw_env ? a->durations + (int64_t)cb * N : NULL;
+    float now = tw_env ? a->current_time[r] : 0.0f;
+    const float cap = (cvrp_like || env == RL4CO_ENV_PCTSP) ? a->vehicle_capacity[r] : (env == RL4CO_ENV_OP ? opmax[0] : 0.0f);
+    const float* rprize = env == RL4CO_ENV_PCTSP ? a->demand + (int64_t)cb * N : NULL;
+    const float* dem = cvrp_like ? a->demand + (int64_t)cb * (N - 1) : NULL;
     int done = a->done[r] != 0;
     uint32_t errbits = 0;
     int t = 0;
@@ -724,8 +738,17 @@ int oracle_am_decode_ms(const rl4co_am_decode_args* a) {
       for (int d = 0; d < D; ++d) {
         const float qb = a->q_bias ? a->q_bias[(int64_t)cb * D + d] : 0.0f;
         float v;
-        if (tsp) v = step_i < 1 ? a->q_step0[d] + qb : (ctxf[(int64_t)first * D + d] + ctxc[(int64_t)cur * D + d]) + qb;
-        else v = fmaf(a->w_cap[d], cap - used, ctxc[(int64_t)cur * D + d]) + qb;
+        if (tsp) {
+          v = step_i < 1 ? a->q_step0[d] + qb : (ctxf[(int64_t)first * D + d] + ctxc[(int64_t)cur * D + d]) + qb;
+        } else if (env == RL4CO_ENV_PDP) {
+          v = ctxc[(int64_t)cur * D + d] + qb;
+        } else {
+          float rem = cap - used;
+          if (env == RL4CO_ENV_PCTSP && !(rem > 0.0f)) rem = 0.0f;
+          v = fmaf(a->w_cap[d], rem, ctxc[(int64_t)cur * D + d]);
+          if (tw_env) v = fmaf(a->w_time[d], now, v);
+          v = v + qb;
+        }
         q[d] = bf16_round(v * (0.25f * log2e)); /* rounding point 1: the MFMA B operand */
       }
       float heads[D];
@@ -814,7 +837,29 @@ int oracle_am_decode_ms(const rl4co_am_decode_args* a) {
         int any = 0;
         for (int j = 0; j < N; ++j) any |= mk[j];
         done = !any;
+      } else if (env == RL4CO_ENV_PDP) {
+        pdp_transition(bi, vis, tod, mk, N);
+        int left = 0;
+        for (int j = 0; j < N; ++j) left |= vis[j];
+        done = !left;
+        step_i += 1;
+        cur = bi;
+      } else if (env == RL4CO_ENV_PCTSP) {
+        used = used + rprize[bi];
+        vis[bi] = 1;
+        done = (step_i > 0) && (bi == 0);
+        step_i += 1;
+        cur = bi;
+        pctsp_mask_row(used, vis, mk, N);
+      } else if (env == RL4CO_ENV_OP) {
+        used = used + op_dist(oplocs, cur, bi);
+        vis[bi] = 1;
+        done = (bi == 0) && (step_i > 0);
+        step_i += 1;
+        cur = bi;
+        op_mask_row(oplocs, opmax, used, vis, cur, mk, N);
       } else {
+        if (tw_env) now = cvrptw_time(twlocs, tw, dur, now, cur, bi);
         int di = bi - 1;
         if (di < 0) di = 0;
         if (di > N - 2) di = N - 2;
@@ -824,25 +869,25 @@ int oracle_am_decode_ms(const rl4co_am_decode_args* a) {
         int all = 1;
         for (int j = 0; j < N; ++j) all &= vis[j] != 0;
         done = all;
-        cvrp_mask_row(dem, used, cap, vis, cur, mk, N);
+        if (tw_env) cvrptw_mask_row(dem, used, cap, vis, cur, twlocs, tw, now, mk, N);
+        else cvrp_mask_row(dem, used, cap, vis, cur, mk, N);
       }
     }
     if (!single && !done && t >= a->max_steps) errbits |= RL4CO_EBIT_MAX_STEPS;
     memcpy(gmask, mk, (size_t)N);
     if (!tsp) memcpy(a->visited + (int64_t)r * N, vis, (size_t)N);
+    if (env == RL4CO_ENV_PDP) memcpy(a->to_deliver + (int64_t)r * N, tod, (size_t)N);
     a->current_node[r] = cur;
     a->done[r] = done ? 1 : 0;
-    if (tsp) {
-      a->first_node[r] = first;
-      a->step_i[r] = step_i;
-    } else {
-      a->used_capacity[r] = used;
-    }
+    if (tsp) a->first_node[r] = first;
+    if (has_step_i) a->step_i[r] = step_i;
+    if (scalar_ctx) a->used_capacity[r] = used;
+    if (tw_env) a->current_time[r] = now;
     if (a->n_steps) a->n_steps[r] = t;
     errbits_all |= errbits;
   }
   if (a->err) *a->err |= (int32_t)errbits_all;
-  free(sc); free(z); free(mk); free(vis);
+  free(sc); free(z); free(mk); free(vis); free(tod);
   return 0;
 }
 

@@ -944,9 +944,8 @@ inline int resolve_variant(const rl4co_am_decode_args& a) {
   // the unfolded parity mode exists in the streaming kernel only
   if (a.unfold) return (a.variant == RL4CO_VARIANT_AUTO || a.variant == RL4CO_VARIANT_STREAM) ? RL4CO_VARIANT_STREAM : -1;
   const bool bf16 = a.cache_dtype == RL4CO_DT_BF16;
-  // multistart on the matrix cores (am_decode_ms.hip): TSP / CVRP, bf16 planes, N <= 128, plain outputs
-  const bool ms_ok = bf16 && a.N <= 128 && a.B_inst > 0 && a.all_logps == nullptr && a.entropy == nullptr &&
-                     (a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP);
+  // multistart on the matrix cores (am_decode_ms.hip): bf16 planes, N <= 128, plain outputs; every environment
+  const bool ms_ok = bf16 && a.N <= 128 && a.B_inst > 0 && a.all_logps == nullptr && a.entropy == nullptr;
   if (a.variant == RL4CO_VARIANT_MS) return ms_ok ? RL4CO_VARIANT_MS : -1;
   const bool fits = bf16 && lds_variant_bytes(a.N) <= 80 * 1024;
   const bool wide_ok = bf16 && wide_scratch_bytes(a.N) <= 64 * 1024;
@@ -954,7 +953,14 @@ inline int resolve_variant(const rl4co_am_decode_args& a) {
   if (a.variant == RL4CO_VARIANT_LDS) return fits ? RL4CO_VARIANT_LDS : -1;
   if (a.variant == RL4CO_VARIANT_WIDE) return wide_ok ? RL4CO_VARIANT_WIDE : -1;
   if (a.max_steps < 4) return RL4CO_VARIANT_STREAM;
-  if (ms_ok && a.B >= 8 * a.B_inst) return RL4CO_VARIANT_MS;  // measured: 8 starts 464 M vs 276 M trajectory-steps/s
+  // auto where it was measured faster than one wave per trajectory (N = 100, 4096 instances, sampling, r02; M trajectory-
+  // steps/s MS vs STREAM): TSP 8 starts 667 vs 276; pickup-delivery 8 starts 633 vs 379; prize-collecting TSP 8 starts
+  // 442 vs 178; CVRP 8 starts 254 vs 277 but 16 starts 463 vs 276 (a full 16-column tile). Orienteering (7-step
+  // ragged tours under random weights: 84 vs 162) and CVRP with time windows (111 vs 278: the per-step mask over all
+  // nodes with a square root each, replicated in every lane of the column) stay on STREAM unless MS is asked for
+  const int ms_from = (a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_PDP || a.env == RL4CO_ENV_PCTSP) ? 8
+                      : (a.env == RL4CO_ENV_CVRP ? 16 : 0);
+  if (ms_ok && ms_from > 0 && a.B >= ms_from * a.B_inst) return RL4CO_VARIANT_MS;
   if (fits && a.B <= 1024) return RL4CO_VARIANT_LDS;
   // one wave per trajectory needs >= ~16 waves per CU to hide its latency chain: with fewer
   // trajectories than that, four waves per trajectory keep the memory pipes busier

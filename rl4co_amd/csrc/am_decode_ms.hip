@@ -21,6 +21,12 @@
 // cross-lane reductions, two workgroup barriers), not an issue-bound stream: the second workgroup on
 // the CU (four waves per SIMD) is what fills the gaps.
 //
+// Environments: all six of the decode kernel. The trajectory state a lane carries is closed-form — bit sets (feasible,
+// visited / available, PDP's to-deliver), current node, step counter, and one or two floats (load, tour length,
+// collected prize, clock); the instance's demands / prizes, coordinates, entry limits, time windows and service times
+// sit in 3.5 KB of LDS. Auto-selected where it was measured faster than one wave per trajectory (am_decode.hip,
+// resolve_variant): TSP / PDP / PCTSP from 8 starts, CVRP from 16; OP and CVRP-TW on request.
+//
 // Numerics: bf16 MFMA inputs (planes, query, softmax numerators, glimpse), fp32 accumulation and
 // fp32 softmax / tanh / log-softmax with the hardware's exp2 / log / rcp — the reference's
 // mixed-precision regime. Not part of the bit-exact contract of am_decode.hip (a bf16 query cannot
@@ -96,7 +102,7 @@ struct __align__(16) Xchg {  // per (node tile, trajectory) pieces of the log-so
 };
 
 struct Layout {  // byte offsets into dynamic LDS
-  int kgs, vs, hs, xs, dems, total;
+  int kgs, vs, hs, xs, dems, envf, total;
 };
 // One workgroup = (instance, column tile of 16 starts). A decode step of 16 trajectories is a latency chain (~8 K cycles of
 // dependent MFMAs, transcendentals and two barriers) that leaves every pipe idle most of the time, so the layout is sized
@@ -116,15 +122,16 @@ __host__ __device__ inline Layout make_layout(int nt, int n) {
   L.hs = o; o += 16 * kRS * 2;                          // one column tile of glimpses
   L.xs = o; o += kWaves * 16 * (int)sizeof(Xchg);
   L.dems = o; o += 128 * 4;
+  L.envf = o; o += 128 * 6 * 4;                          // coordinates | OP entry limits / time windows | service times
   L.total = (o + 15) & ~15;
   return L;
 }
 
 struct Traj {  // one trajectory's state, replicated in the four row groups and the eight waves
-  Bits128 mw, vw;
+  Bits128 mw, vw, tw;  // feasible; visited (PDP: available); PDP: to_deliver
   int cur, first, r;
   long long step_i;
-  float used;
+  float used, now;     // load / tour length / collected prize; CVRPTW clock
   bool done, ok;
   int nsteps;
   float f4[4];  // context row of the first node (TSP), fetched when it becomes known
@@ -171,7 +178,8 @@ struct Shared {
   const __bf16 *kgs, *vs;
   __bf16* hs;   // [CT][16 trajectories][kRS] glimpses of this step
   Xchg* xs;     // [CT][8 node tiles][16 trajectories]
-  const float* dems;
+  const float* dems;  // [128] CVRP / CVRPTW demand (index j - 1 at j), PCTSP real prize at j
+  const float* envf;  // [128][2] coordinates | [128] OP entry limits | [128][2] time windows | [128] service times
 };
 
 // MODE: 0 greedy, 1 sampling, 2 evaluate (RL4CO_DECODE_*). CT column tiles of 16 trajectories advance together.
@@ -185,15 +193,28 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
   const int nao = tl * kRS + 4 * g;                         // natural operand: row lane & 15, columns 4 g ..
   const int tro = (4 * g + (tl >> 2)) * kRS + 4 * (tl & 3);  // transpose read
   const int dcol = 16 * h + 4 * g;                          // the four dims of head h this lane owns
-  const float cap = (ENV == RL4CO_ENV_CVRP) ? a.vehicle_capacity[inst] : 0.0f;
+  constexpr bool kCvrpLike = ENV == RL4CO_ENV_CVRP || ENV == RL4CO_ENV_CVRPTW;
+  constexpr bool kClock = ENV == RL4CO_ENV_CVRPTW;
+  constexpr bool kScalar = ENV != RL4CO_ENV_TSP && ENV != RL4CO_ENV_PDP;  // one context scalar: cap - used
+  constexpr bool kVisited = ENV != RL4CO_ENV_TSP;                         // a visited (PDP: available) set beside the mask
+  constexpr bool kStepI = ENV != RL4CO_ENV_CVRP && ENV != RL4CO_ENV_CVRPTW;
+  const float* locs = sh.envf;             // [N][2]
+  const float* opmax = sh.envf + 256;      // [N] OP: longest tour with which node j may be entered
+  const float* twin = sh.envf + 384;       // [N][2] CVRPTW (start, end)
+  const float* dur = sh.envf + 640;        // [N] CVRPTW service times
+  // context scalar = cap - used: vehicle capacity (CVRP / CVRPTW), prize still required (PCTSP, clamped at 0), longest
+  // tour that may still end at the depot minus the tour so far (OP) — env_embeddings/context.py:105-213
+  const float cap = (kCvrpLike || ENV == RL4CO_ENV_PCTSP) ? a.vehicle_capacity[inst]
+                                                                     : (ENV == RL4CO_ENV_OP ? a.max_length[(int64_t)inst * N] : 0.0f);
   const float thr = cap + 1e-5f;
   const float* ctxc = a.ctx_cur + (int64_t)inst * N * kD + dcol;
   const float* ctxf = (ENV == RL4CO_ENV_TSP) ? a.ctx_first + (int64_t)inst * N * kD + dcol : nullptr;
-  float qb4[4], qx4[4];  // graph context; placeholder query (TSP) or capacity column (CVRP)
+  float qb4[4], qx4[4], qt4[4];  // graph context; placeholder query (TSP) or capacity column; CVRPTW: the time column
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     qb4[e] = a.q_bias ? a.q_bias[(int64_t)inst * kD + dcol + e] : 0.0f;
-    qx4[e] = (ENV == RL4CO_ENV_TSP) ? a.q_step0[dcol + e] : a.w_cap[dcol + e];
+    qx4[e] = (ENV == RL4CO_ENV_TSP) ? a.q_step0[dcol + e] : (kScalar ? a.w_cap[dcol + e] : 0.0f);
+    qt4[e] = kClock ? a.w_time[dcol + e] : 0.0f;
   }
   const bool single = a.max_steps == 1;
   const float inv_temp = 1.0f / a.temperature;
@@ -213,20 +234,24 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
     x.r = (x.ok ? sl : s0) * a.B_inst + inst;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      uint32_t m = 0, v = 0;
+      uint32_t m = 0, v = 0, d = 0;
       const uint8_t* gm = a.action_mask + (int64_t)x.r * N + 32 * k;
-      const uint8_t* gv = (ENV == RL4CO_ENV_CVRP) ? a.visited + (int64_t)x.r * N + 32 * k : nullptr;
+      const uint8_t* gv = kVisited ? a.visited + (int64_t)x.r * N + 32 * k : nullptr;
+      const uint8_t* gd = (ENV == RL4CO_ENV_PDP) ? a.to_deliver + (int64_t)x.r * N + 32 * k : nullptr;
       for (int b = 0; b < 32 && 32 * k + b < N; ++b) {
         m |= (x.ok && gm[b]) ? (1u << b) : 0u;
-        if (ENV == RL4CO_ENV_CVRP) v |= (x.ok && gv[b]) ? (1u << b) : 0u;
+        if (kVisited) v |= (x.ok && gv[b]) ? (1u << b) : 0u;
+        if (ENV == RL4CO_ENV_PDP) d |= (x.ok && gd[b]) ? (1u << b) : 0u;
       }
       x.mw.put(k, m);
       x.vw.put(k, v);
+      x.tw.put(k, d);
     }
     x.cur = (int)a.current_node[x.r];
     x.first = (ENV == RL4CO_ENV_TSP) ? (int)a.first_node[x.r] : 0;
-    x.step_i = (ENV == RL4CO_ENV_TSP) ? a.step_i[x.r] : 0;
-    x.used = (ENV == RL4CO_ENV_CVRP) ? a.used_capacity[x.r] : 0.0f;
+    x.step_i = kStepI ? a.step_i[x.r] : 0;
+    x.used = kScalar ? a.used_capacity[x.r] : 0.0f;
+    x.now = kClock ? a.current_time[x.r] : 0.0f;
     x.done = !x.ok || a.done[x.r] != 0;
     x.nsteps = 0;
     x.park_act = 0;
@@ -295,8 +320,17 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float q;
-        if (ENV == RL4CO_ENV_TSP) q = (x.step_i < 1) ? qx4[e] + qb4[e] : (x.f4[e] + cc[e]) + qb4[e];
-        else q = fmaf(qx4[e], cap - x.used, cc[e]) + qb4[e];
+        if (ENV == RL4CO_ENV_TSP) {
+          q = (x.step_i < 1) ? qx4[e] + qb4[e] : (x.f4[e] + cc[e]) + qb4[e];
+        } else if (ENV == RL4CO_ENV_PDP) {
+          q = cc[e] + qb4[e];  // context.py:232-243: the current node alone
+        } else {
+          float rem = cap - x.used;
+          if (ENV == RL4CO_ENV_PCTSP && !(rem > 0.0f)) rem = 0.0f;  // clamp(min=0), context.py:195
+          q = fmaf(qx4[e], rem, cc[e]);
+          if (kClock) q = fmaf(qt4[e], x.now, q);  // context.py:152-166: second scalar, the current time
+          q = q + qb4[e];
+        }
         qf[c][e] = (__bf16)(q * (0.25f * kLog2e));
       }
     }
@@ -502,11 +536,70 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
           x.step_i += 1;
           x.mw.set(act, false);
           x.done = x.mw.any() == 0u;
+        } else if (ENV == RL4CO_ENV_PDP) {
+          // pdp/env.py:64-83: the node leaves `available`, its delivery (the depot's: nothing) becomes deliverable
+          const int n = N - 1;
+          x.vw.set(act, false);
+          x.tw.set((act + n / 2) % (n + 1), true);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) x.mw.put(k, x.vw.word(k) & x.tw.word(k));
+          x.done = x.vw.any() == 0u;
+          x.step_i += 1;
+          x.cur = act;
+        } else if (ENV == RL4CO_ENV_PCTSP) {
+          // pctsp/env.py:62-75, 141-148: customers while unvisited and the depot not yet closed; the depot opens once a
+          // total prize of 1 is collected or no customer is left
+          x.used = x.used + sh.dems[act];
+          x.vw.set(act, true);
+          x.done = (x.step_i > 0) && (act == 0);
+          x.step_i += 1;
+          x.cur = act;
+          const bool closed = x.vw.w0 & 1u;
+          uint32_t left = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const uint32_t c = ~x.vw.word(k) & nv.word(k) & (k == 0 ? ~1u : ~0u);
+            left |= c;
+            x.mw.put(k, closed ? 0u : c);
+          }
+          if (!((x.used < 1.0f) && left != 0u)) x.mw.w0 |= 1u;
+        } else if (ENV == RL4CO_ENV_OP) {
+          // op/env.py:67-98, 137-154: unvisited, depot not yet closed, and the node can still be entered
+          {
+            const float dx = locs[2 * act] - locs[2 * x.cur], dy = locs[2 * act + 1] - locs[2 * x.cur + 1];
+            x.used = x.used + sqrtf(fmaf(dy, dy, dx * dx));
+          }
+          x.vw.set(act, true);
+          x.done = (act == 0) && (x.step_i > 0);
+          x.step_i += 1;
+          x.cur = act;
+          const bool closed = x.vw.w0 & 1u;
+          const float cx = locs[2 * act], cy = locs[2 * act + 1];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            uint32_t mbits = 0;
+            for (int b = 0; b < 32 && 32 * k + b < N; ++b) {
+              const int j = 32 * k + b;
+              const float dx = locs[2 * j] - cx, dy = locs[2 * j + 1] - cy;
+              const bool exceeds = x.used + sqrtf(fmaf(dy, dy, dx * dx)) > opmax[j];
+              const bool v = (x.vw.word(k) >> b) & 1u;
+              mbits |= (v || closed || exceeds) ? 0u : (1u << b);
+            }
+            x.mw.put(k, mbits);
+          }
+          x.mw.w0 |= 1u;  // the depot can always be visited
         } else {
+          const float cx = kClock ? locs[2 * act] : 0.0f, cy = kClock ? locs[2 * act + 1] : 0.0f;
+          if (kClock) {  // cvrptw/env.py:97-113: advance by the distance, wait for the window, serve; the depot restarts the clock
+            const float dx = cx - locs[2 * x.cur], dy = cy - locs[2 * x.cur + 1];
+            x.now = (act != 0 ? 1.0f : 0.0f) * (fmaxf(x.now + sqrtf(fmaf(dy, dy, dx * dx)), twin[2 * act]) + dur[act]);
+          }
           const int di = min(max(act - 1, 0), N - 2);
           x.used = (x.used + sh.dems[di + 1]) * (act != 0 ? 1.0f : 0.0f);
           x.cur = act;
           x.vw.set(act, true);
+          // (every lane of the trajectory's column rebuilds the whole mask: splitting the nodes over the four row groups
+          // and exchanging the words was measured and is no faster — the step is a latency chain, not this loop)
           bool all_visited = true, any_feasible = false;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -524,6 +617,18 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
             x.mw.put(k, mbits);
           }
           if (!((x.cur == 0) && any_feasible)) x.mw.w0 |= 1u;
+          if (kClock) {  // cvrptw/env.py:91-95: only nodes whose window is still open on arrival (the depot too)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              uint32_t keep = 0;
+              for (int b = 0; b < 32 && 32 * k + b < N; ++b) {
+                const int j = 32 * k + b;
+                const float dx = locs[2 * j] - cx, dy = locs[2 * j + 1] - cy;
+                keep |= (x.now + sqrtf(fmaf(dy, dy, dx * dx)) <= twin[2 * j + 1]) ? (1u << b) : 0u;
+              }
+              x.mw.put(k, x.mw.word(k) & keep);
+            }
+          }
           x.done = all_visited;
         }
       }
@@ -549,14 +654,18 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
     if (w == 0 && g == 0 && x.ok) {
       uint8_t* gm = a.action_mask + (int64_t)x.r * N;
       for (int j = 0; j < N; ++j) gm[j] = x.mw.test(j) ? 1 : 0;
-      if (ENV == RL4CO_ENV_CVRP) {
+      if (kVisited) {
         uint8_t* gv = a.visited + (int64_t)x.r * N;
         for (int j = 0; j < N; ++j) gv[j] = x.vw.test(j) ? 1 : 0;
-        a.used_capacity[x.r] = x.used;
-      } else {
-        a.first_node[x.r] = x.first;
-        a.step_i[x.r] = x.step_i;
       }
+      if (ENV == RL4CO_ENV_PDP) {
+        uint8_t* gd = a.to_deliver + (int64_t)x.r * N;
+        for (int j = 0; j < N; ++j) gd[j] = x.tw.test(j) ? 1 : 0;
+      }
+      if (kScalar) a.used_capacity[x.r] = x.used;
+      if (kClock) a.current_time[x.r] = x.now;
+      if (ENV == RL4CO_ENV_TSP) a.first_node[x.r] = x.first;
+      if (kStepI) a.step_i[x.r] = x.step_i;
       a.current_node[x.r] = x.cur;
       a.done[x.r] = x.done ? 1 : 0;
       if (a.n_steps) a.n_steps[x.r] = x.nsteps;
@@ -608,8 +717,25 @@ __global__ void __launch_bounds__(kThreads, 4) am_decode_ms_kernel(const rl4co_a
       *reinterpret_cast<uint4*>(kgs + row * kRS + col) = k4;
       *reinterpret_cast<uint4*>(vs + row * kRS + col) = v4;
     }
-    for (int j = tid; j < 128; j += kThreads)
-      dems[j] = (ENV == RL4CO_ENV_CVRP && j >= 1 && j < N) ? a.demand[(int64_t)inst * (N - 1) + j - 1] : 0.0f;
+    constexpr bool kDem = ENV == RL4CO_ENV_CVRP || ENV == RL4CO_ENV_CVRPTW;
+    for (int j = tid; j < 128; j += kThreads) {
+      float d = 0.0f;
+      if (kDem && j >= 1 && j < N) d = a.demand[(int64_t)inst * (N - 1) + j - 1];
+      if (ENV == RL4CO_ENV_PCTSP && j < N) d = a.demand[(int64_t)inst * N + j];  // real prize, depot column 0
+      dems[j] = d;
+    }
+    if (ENV == RL4CO_ENV_OP || ENV == RL4CO_ENV_CVRPTW) {
+      float* envf = reinterpret_cast<float*>(smem + L.envf);
+      for (int j = tid; j < 128; j += kThreads) {
+        const bool in = j < N;
+        envf[2 * j] = in ? a.locs[((int64_t)inst * N + j) * 2] : 0.0f;
+        envf[2 * j + 1] = in ? a.locs[((int64_t)inst * N + j) * 2 + 1] : 0.0f;
+        envf[256 + j] = (ENV == RL4CO_ENV_OP && in) ? a.max_length[(int64_t)inst * N + j] : 0.0f;
+        envf[384 + 2 * j] = (ENV == RL4CO_ENV_CVRPTW && in) ? a.time_windows[((int64_t)inst * N + j) * 2] : 0.0f;
+        envf[384 + 2 * j + 1] = (ENV == RL4CO_ENV_CVRPTW && in) ? a.time_windows[((int64_t)inst * N + j) * 2 + 1] : 0.0f;
+        envf[640 + j] = (ENV == RL4CO_ENV_CVRPTW && in) ? a.durations[(int64_t)inst * N + j] : 0.0f;
+      }
+    }
   }
   Shared sh;
   sh.kgs = kgs;
@@ -619,6 +745,7 @@ __global__ void __launch_bounds__(kThreads, 4) am_decode_ms_kernel(const rl4co_a
   sh.hs = reinterpret_cast<__bf16*>(smem + L.hs);
   sh.xs = reinterpret_cast<Xchg*>(smem + L.xs);
   sh.dems = dems;
+  sh.envf = reinterpret_cast<const float*>(smem + L.envf);
   uint32_t errbits = 0;
   if (tid == 0 && a.steps_summary) atomicAdd(a.steps_summary + 2, N);  // the planes are read ONCE per workgroup
   rollout_tiles<ENV, NT, MODE, 1>(a, sh, inst, 16 * tile0, errbits);  // this workgroup's column tile
@@ -659,6 +786,14 @@ extern "C" int rl4co_am_decode_ms_lds_bytes(void) { return make_layout(8, 128).t
 
 namespace rl4co {
 int launch_decode_ms(const rl4co_am_decode_args& a, hipStream_t stream) {
-  return a.env == RL4CO_ENV_TSP ? dispatch_tiles<RL4CO_ENV_TSP>(a, stream) : dispatch_tiles<RL4CO_ENV_CVRP>(a, stream);
+  switch (a.env) {
+    case RL4CO_ENV_TSP: return dispatch_tiles<RL4CO_ENV_TSP>(a, stream);
+    case RL4CO_ENV_CVRP: return dispatch_tiles<RL4CO_ENV_CVRP>(a, stream);
+    case RL4CO_ENV_OP: return dispatch_tiles<RL4CO_ENV_OP>(a, stream);
+    case RL4CO_ENV_PCTSP: return dispatch_tiles<RL4CO_ENV_PCTSP>(a, stream);
+    case RL4CO_ENV_PDP: return dispatch_tiles<RL4CO_ENV_PDP>(a, stream);
+    case RL4CO_ENV_CVRPTW: return dispatch_tiles<RL4CO_ENV_CVRPTW>(a, stream);
+    default: return RL4CO_ERR_ARG;
+  }
 }
 }  // namespace rl4co

@@ -1,4 +1,5 @@
-"""GPU: multistart decode on the matrix cores (csrc/am_decode_ms.hip) vs the streaming kernel.
+"""GPU: multistart decode on the matrix cores (csrc/am_decode_ms.hip) vs the streaming kernel and vs its rounding-model
+oracle (every environment of the decode kernel: TSP, CVRP, orienteering, prize-collecting TSP, pickup-delivery, CVRP-TW).
 
 Floating-point variant => tolerance test (tolerances stated here). The MS kernel rounds the query
 and the glimpse to bf16 for the MFMAs, so it cannot be bit-identical to the fp32 specified order;
@@ -33,13 +34,12 @@ def _rollout(K, g, td0, cache, starts, variant, mode="greedy", forced=None, want
     err = K.new_error_word("cuda")
     t0 = 0
     if starts > 0:
+        from tests.helpers import apply_step
+
+        torch.manual_seed(4242)  # (the orienteering problem draws its start nodes: the same draw on every call)
         first = g.env.select_start_nodes(td0, starts).cuda()
         actions[:, 0] = first
-        if g.env_name == "tsp":
-            K.tsp_step(first, st["action_mask"], st["first_node"], st["current_node"], st["i"], st["done"])
-        else:
-            K.cvrp_step(first, st["demand"], st["used_capacity"], st["vehicle_capacity"], st["visited"],
-                        st["current_node"], st["action_mask"], st["done"])
+        apply_step(K, g.env_name, first, st)
         t0 = 1
     all_lp = torch.zeros(b, tmax, n, device="cuda") if want_all else None
     if forced is not None:
@@ -122,6 +122,12 @@ def test_ms_is_auto_selected_for_multistart_and_policy_runs(K):
     assert K.decode_row_groups(100, torch.bfloat16, 99, "auto", 4096 * 4, 4096) == 4      # 4 starts: streaming
     assert K.decode_row_groups(100, torch.bfloat16, 100, "auto", 4096, 4096) == 4          # single start: stream
     assert K.decode_row_groups(100, torch.float32, 99, "auto", 4096 * 8, 4096) == 2        # fp32 planes: stream
+    # per environment, where MS was measured faster than one wave per trajectory (csrc/am_decode.hip resolve_variant)
+    MS = 4
+    for env_name, starts, want_ms in [("tsp", 8, True), ("pdp", 8, True), ("pctsp", 8, True), ("cvrp", 8, False),
+                                      ("cvrp", 16, True), ("op", 32, False), ("cvrptw", 32, False)]:
+        got = K.decode_variant(101, torch.bfloat16, 150, 4096 * starts, num_instances=4096, env_name=env_name)
+        assert (got == MS) == want_ms, (env_name, starts, got)
     torch.manual_seed(0)
     kw = dict(num_encoder_layers=6, normalization="instance", use_graph_context=False, cache_dtype=torch.bfloat16,
               encoder_autocast=torch.bfloat16)
@@ -180,6 +186,7 @@ def _c_ms_rollout(g, td0, cache_cpu, starts, mode, exp_noise=None, forced=None):
     logps = torch.zeros(b, tmax)
     n_steps = torch.zeros(b, dtype=torch.int32)
     err = torch.zeros(1, dtype=torch.int32)
+    torch.manual_seed(4242)
     first = g.env.select_start_nodes(td0, starts)
     actions[:, 0] = first
     apply_step(c_oracle, g.env_name, first, st)
@@ -206,7 +213,12 @@ MS_IDENTICAL_FLOOR = 0.97
                                               ("pomo_tsp50_b8_mssampling", 40, "sampling"),
                                               ("pomo_tsp20_b16_msgreedy", 20, "greedy"),
                                               ("pomo_cvrp20_b16_msgreedy", 20, "greedy"),
-                                              ("cvrp100_b64_greedy", 9, "sampling")])
+                                              ("cvrp100_b64_greedy", 9, "sampling"),
+                                              # r02: every environment of the decode kernel on the matrix cores
+                                              ("pomo_pdp20_b16_msgreedy", 10, "greedy"), ("pdp100_b64_greedy", 16, "sampling"),
+                                              ("pomo_pctsp20_b16_msgreedy", 20, "greedy"), ("pctsp100_b64_greedy", 9, "sampling"),
+                                              ("pomo_op20_b16_msgreedy", 20, "greedy"), ("op100_b64_greedy", 8, "sampling"),
+                                              ("pomo_cvrptw20_b16_mssampling", 20, "sampling"), ("cvrptw100_b64_greedy", 8, "greedy")])
 def test_ms_kernel_follows_its_rounding_model_oracle(K, name, starts, mode):
     """BASELINE configs[3]'s rollout kernel (auto-selected from 8 starts on bf16 planes) against the C restatement
     with the SAME bf16 rounding points (query, softmax numerators, glimpse) and fp32 arithmetic elsewhere:
@@ -232,6 +244,8 @@ def test_ms_kernel_follows_its_rounding_model_oracle(K, name, starts, mode):
     a_ms, l_ms, st, err, _ = _rollout(K, g, td0, cache, starts, "ms", mode=mode, **kw)
     assert err == 0 and bool(st["done"].all())
     a_ms, l_ms = a_ms.cpu(), l_ms.cpu()
+    rows = R.batchify({k: v for k, v in td0.items() if torch.is_tensor(v)}, starts)
+    g.env.check_solution_validity(rows, a_ms)  # the reference's own validity rules on the kernel's tours
     t = min(a_ms.shape[1], a_c.shape[1])
     agree = (a_ms[:, :t] == a_c[:, :t])
     prefix = agree.long().cumprod(1).bool()            # columns before the first disagreement
