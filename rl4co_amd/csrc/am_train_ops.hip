@@ -379,16 +379,14 @@ __global__ void __launch_bounds__(kGemmThreads, 2) linear_bf16_kernel(const uint
 #undef RL4CO_COMMIT
 }
 
-// K = 128 (every wide layer: Wqkv, MLP up, the fold GEMM, d hidden; and out_proj both ways): the token tile's
-// B-operand fragments live in REGISTERS for all feature tiles (32 per lane) instead of a second LDS tile — no token
-// reads in the product loop (a fifth of its LDS traffic), and with one 35 KB tile per workgroup and <= 168 registers
-// three workgroups share a CU (AUX: the mask / residual rows take 32 more registers, two workgroups). The step
-// structure is the generic kernel's.
-template <bool AUX>
-__global__ void __launch_bounds__(kGemmThreads, AUX ? 2 : 3) linear_k128_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
-                                                                               const float* __restrict__ bias, const uint16_t* __restrict__ mask,
-                                                                               const uint16_t* __restrict__ residual, int M, int N, int relu,
-                                                                               uint16_t* __restrict__ out) {
+// K = 128 without mask / residual rows (Wqkv, MLP up, the fold GEMM, out_proj both ways): the token tile's B-operand
+// fragments live in REGISTERS for all feature tiles (32 per lane) instead of a second LDS tile — no token reads in the
+// product loop (a fifth of its LDS traffic), and with one 35 KB tile per workgroup and <= 168 registers THREE workgroups
+// share a CU. The step structure is the generic kernel's. (A variant carrying the mask / residual rows, 32 more
+// registers and two workgroups per CU, measured slower than the generic kernel on d hidden 128 -> 512: 205 vs 187 us.)
+__global__ void __launch_bounds__(kGemmThreads, 3) linear_k128_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+                                                                      const float* __restrict__ bias, int M, int N, int relu,
+                                                                      uint16_t* __restrict__ out) {
   extern __shared__ __align__(16) unsigned char smem_g[];
   __bf16* ws = reinterpret_cast<__bf16*>(smem_g);        // [128][kLS]: the token tile once, then feature tiles / staged output
   float* bl = reinterpret_cast<float*>(ws + kTN * kLS);  // [N] bias
@@ -420,22 +418,13 @@ __global__ void __launch_bounds__(kGemmThreads, AUX ? 2 : 3) linear_k128_kernel(
 #pragma unroll
   for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(ws + (srow + 16 * j) * kLS + scol) = pw[j];
   __syncthreads();
-  const uint16_t* aux = mask ? mask : residual;
   const int orow = lane >> 4, ocol = (lane & 15) * 8;  // output pass: four rows per pass, 16 bytes per lane
-  u32x4 mks[AUX ? 8 : 1];
   for (int nt = 0; nt < nnt; ++nt) {
     const bool more = nt + 1 < nnt;
     {
       const int ntn = min(nt + 1, nnt - 1);  // (the last tile re-reads itself: no branch around the loads)
 #pragma unroll
       for (int j = 0; j < 8; ++j) pw[j] = *reinterpret_cast<const u32x4*>(W + (int64_t)(ntn * kTN + srow + 16 * j) * kTK + scol);
-    }
-    if (AUX) {
-#pragma unroll
-      for (int p8 = 0; p8 < 8; ++p8) {
-        const int64_t row = min(m0 + 32 * w + 4 * p8 + orow, (int64_t)M - 1);
-        mks[AUX ? p8 : 0] = *reinterpret_cast<const u32x4*>(aux + row * N + nt * kTN + ocol);
-      }
     }
     f32x16 acc[4];
 #pragma unroll
@@ -450,12 +439,9 @@ __global__ void __launch_bounds__(kGemmThreads, AUX ? 2 : 3) linear_k128_kernel(
         acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(feat, tok[ks], acc[ct], 0, 0, 0);
       }
     }
-    // prefetched operands pinned in their registers before this tile's stores are issued (see linear_bf16_kernel)
+    // the prefetched tile pinned in its registers before this tile's stores are issued (see linear_bf16_kernel)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      asm volatile("" ::"v"(pw[j]));
-      if (AUX) asm volatile("" ::"v"(mks[AUX ? j : 0]));
-    }
+    for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(pw[j]));
     rl4co::lds_barrier();  // every wave has issued its products: the feature tile is dead, the output is staged over it
     __bf16* os = ws;
 #pragma unroll
@@ -489,28 +475,7 @@ __global__ void __launch_bounds__(kGemmThreads, AUX ? 2 : 3) linear_k128_kernel(
     for (int p8 = 0; p8 < 8; ++p8) {
       const int tr = 32 * w + 4 * p8 + orow;
       const int64_t row = m0 + tr;
-      u32x4 val = *reinterpret_cast<const u32x4*>(os + tr * kLS + ocol);
-      if (AUX) {
-        const u32x4 ax = mks[AUX ? p8 : 0];
-        if (mask) {  // ReLU backward: keep where the forward activation was positive (bf16 > 0)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const uint32_t m_ = ax[i];
-            const uint32_t keep_lo = ((m_ & 0x8000u) == 0 && (m_ & 0x7fffu) != 0) ? 0x0000ffffu : 0u;
-            const uint32_t keep_hi = ((m_ >> 31) == 0 && (m_ & 0x7fff0000u) != 0) ? 0xffff0000u : 0u;
-            val[i] &= (keep_lo | keep_hi);
-          }
-        } else {  // + the skip connection's gradient
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float lo = __uint_as_float(val[i] << 16) + __uint_as_float(ax[i] << 16);
-            const float hi_ = __uint_as_float(val[i] & 0xffff0000u) + __uint_as_float(ax[i] & 0xffff0000u);
-            typedef __bf16 bf16x2g __attribute__((ext_vector_type(2)));
-            const bf16x2g pk = {(__bf16)lo, (__bf16)hi_};
-            val[i] = __builtin_bit_cast(uint32_t, pk);
-          }
-        }
-      }
+      const u32x4 val = *reinterpret_cast<const u32x4*>(os + tr * kLS + ocol);
       if (row < M) *reinterpret_cast<u32x4*>(out + row * N + nt * kTN + ocol) = val;
     }
     if (more) {
@@ -522,13 +487,11 @@ __global__ void __launch_bounds__(kGemmThreads, AUX ? 2 : 3) linear_k128_kernel(
   }
 }
 
-template <bool AUX>
-int launch_k128(const void* a, const void* w, const float* bias, const void* mask, const void* residual, int64_t M, int N, int relu,
-                void* out, void* stream) {
+int launch_k128(const void* a, const void* w, const float* bias, int64_t M, int N, int relu, void* out, void* stream) {
   const int lds = kTN * kLS * 2 + kMaxLinearN * 4;
-  hipLaunchKernelGGL(linear_k128_kernel<AUX>, dim3((int)((M + kTM - 1) / kTM)), dim3(kGemmThreads), lds, rl4co::as_stream(stream),
-                     static_cast<const uint16_t*>(a), static_cast<const uint16_t*>(w), bias, static_cast<const uint16_t*>(mask),
-                     static_cast<const uint16_t*>(residual), (int)M, N, relu, static_cast<uint16_t*>(out));
+  hipLaunchKernelGGL(linear_k128_kernel, dim3((int)((M + kTM - 1) / kTM)), dim3(kGemmThreads), lds, rl4co::as_stream(stream),
+                     static_cast<const uint16_t*>(a), static_cast<const uint16_t*>(w), bias, (int)M, N, relu,
+                     static_cast<uint16_t*>(out));
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }
@@ -541,9 +504,7 @@ extern "C" int rl4co_linear_bf16(const void* a, const void* w, const float* bias
   RL4CO_REQUIRE(M > 0 && M < (int64_t)1 << 31 && N > 0 && K > 0 && N % kTN == 0 && K % kTK == 0);
   RL4CO_REQUIRE(!(relu && mask) && !(mask && residual));
   RL4CO_REQUIRE(N <= kMaxLinearN);
-  // (with mask / residual rows the register-resident variant holds two workgroups per CU like the generic kernel and
-  // measured slower on the one shape that uses it, d hidden 128 -> 512: 205 us against 187)
-  if (K == kTK && !mask && !residual) return launch_k128<false>(a, w, bias, mask, residual, M, N, relu, out, stream);
+  if (K == kTK && !mask && !residual) return launch_k128(a, w, bias, M, N, relu, out, stream);
   const int lds = (kTM + kTN) * kLS * 2 + kMaxLinearN * 4;
   RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(linear_bf16_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));

@@ -435,7 +435,7 @@ class _MLPBlock(torch.autograd.Function):
         return (dx.view(b, n, d), dw1.to(t), db1.to(t), dw2.to(t), db2.to(t), dgamma.to(t), dbeta.to(t), None, None)
 
 
-def _block_norm_args(norm_module, kind: str):
+def _block_norm_args(norm_module):
     nz = norm_module.normalizer
     return nz.weight, nz.bias, nz.eps
 
@@ -451,7 +451,7 @@ def block_usable(x: Tensor, kind: str, *weights: Tensor) -> bool:
 
 def attention_block(x: Tensor, attn, norm) -> Tensor:
     """``norm(x + attn(x))`` (SkipConnection(MultiHeadAttention) + Normalization) as one autograd node."""
-    gamma, beta, eps = _block_norm_args(norm, norm.kind)
+    gamma, beta, eps = _block_norm_args(norm)
     res = _AttentionBlock.apply(x, attn.Wqkv.weight, attn.Wqkv.bias, attn.out_proj.weight, attn.out_proj.bias, gamma, beta,
                                 eps, norm.kind)
     if norm.kind == "batch":
@@ -463,7 +463,7 @@ def attention_block(x: Tensor, attn, norm) -> Tensor:
 
 def mlp_block(x: Tensor, ffn, norm) -> Tensor:
     """``norm(x + ffn(x))`` (SkipConnection(MLP 128 -> 512 -> 128) + Normalization) as one autograd node."""
-    gamma, beta, eps = _block_norm_args(norm, norm.kind)
+    gamma, beta, eps = _block_norm_args(norm)
     l1, l2 = ffn.lins
     res = _MLPBlock.apply(x, l1.weight, l1.bias, l2.weight, l2.bias, gamma, beta, eps, norm.kind)
     if norm.kind == "batch":
