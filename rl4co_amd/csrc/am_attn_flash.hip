@@ -9,8 +9,10 @@
 //   * v_mfma_f32_16x16x16_bf16 with the QUERY as accumulator column (lane & 15) and four consecutive KEYS (rows
 //     4 g ..) per lane: S^T = K_h Q_h^T chains into O_h^T += V_h^T P^T without a shuffle (P in the accumulator
 //     layout is the B operand; V^T through ds_read_b64_tr_b16), the 16 head dims are exactly one MFMA k-step;
-//   * a query tile's state is 8 registers (Q fragment 2, max 1, partial sum 1, O^T 4), so a wave carries kQT = 8
-//     tiles and each key block's K / V fragments (read from LDS once per block) serve all of them;
+//   * a query tile's state is 8 registers (Q fragment 2, max 1, partial sum 1, O^T 4); a wave carries kQT = 4 tiles
+//     and each key block's K / V fragments (read from LDS once per block) serve all of them. Four, not eight: at 128
+//     registers and 34 KB of LDS TWO workgroups share a CU and cover each other's barriers and key-block round trips
+//     (eight tiles: 167 registers, one workgroup per CU, 840 us per layer at 1024 x 501; four: 731 us);
 //   * the block maximum needs the four row groups of a query to agree (two permlane swaps); the softmax
 //     denominator does not — every lane sums its own keys against the shared running maximum and the four
 //     partial sums meet once, after the last block;
@@ -27,7 +29,7 @@ constexpr int kD = RL4CO_EMBED_DIM;
 constexpr int kWaves = 8;
 constexpr int kThreads = 64 * kWaves;
 constexpr int kKB = 64;              // keys per LDS block
-constexpr int kQT = 8;               // query tiles (of 16) per workgroup pass
+constexpr int kQT = 4;               // query tiles (of 16) per workgroup pass
 constexpr int kKS = 2 * kD + 8;      // LDS row stride of a k | v row (bf16 elements)
 constexpr int kOS = kD + 8;          // LDS row stride of the output staging rows
 constexpr float kNegInf = -__builtin_huge_valf();
@@ -61,7 +63,7 @@ __device__ inline void block_map(int b, int B, int QB, int& inst, int& qb) {
   inst = (k / QB) * 8 + xcd;
 }
 
-__global__ void __launch_bounds__(kThreads, 2) attn_flash_kernel(const uint16_t* __restrict__ qkv, int B, int N, int QB,
+__global__ void __launch_bounds__(kThreads, 4) attn_flash_kernel(const uint16_t* __restrict__ qkv, int B, int N, int QB,
                                                                  uint16_t* __restrict__ out) {
   constexpr int kLds = kKB * kKS > kQT * 16 * kOS ? kKB * kKS : kQT * 16 * kOS;
   __shared__ __align__(16) __bf16 kv[kLds];  // one key block: [64][k 128 | v 128]; later the output staging rows
