@@ -417,7 +417,8 @@ int rl4co_am_encoder_max_nodes(void);
  * return dL/d(folded cache) for L = sum g * log p. Outputs are fp32; d_ctx_first, d_q_step0
  * and d_w_cap are accumulated atomically and must be zero-initialised by the caller, the
  * others are written. One workgroup per instance, its B / B_inst trajectories (s-major rows)
- * replayed in turn. N <= rl4co_am_teacher_max_nodes().
+ * replayed in turn. N <= rl4co_am_teacher_max_nodes(). Every RL4CO_ENV_* on both variants (RL4CO_TEACHER_MMA: bf16
+ * planes, 16-step blocks on the matrix cores; RL4CO_TEACHER_REPLAY: fp32 arithmetic, step by step).
  * -------------------------------------------------------------------------- */
 #define RL4CO_TEACHER_AUTO 0   /* MMA when the planes are bf16 and T fits its step tables, else REPLAY */
 #define RL4CO_TEACHER_REPLAY 1 /* am_teacher.hip: fp32 step-by-step replay, planes in registers        */
@@ -448,9 +449,9 @@ typedef struct rl4co_am_teacher_args {
   const int64_t* actions;        /* [B,T]                                           */
   const float* demand;           /* [B_inst,N-1] CVRP                               */
   const float* vehicle_capacity; /* [B_inst] CVRP                                   */
-  const float* locs;             /* [B_inst,N,2] OP (MMA variant only)              */
+  const float* locs;             /* [B_inst,N,2] OP, CVRPTW                         */
   const float* max_length;       /* [B_inst,N] OP entry-limit table                 */
-  const float* time_windows;     /* [B_inst,N,2] CVRPTW (start, end), fp32 (MMA variant only; locs too) */
+  const float* time_windows;     /* [B_inst,N,2] CVRPTW (start, end), fp32          */
   const float* durations;        /* [B_inst,N] CVRPTW service times                 */
   const float* w_time;           /* [128] CVRPTW: W_ctx[:, 129]                     */
   const float* grad_logp;        /* [B,T]                                           */

@@ -10,6 +10,9 @@
 // (three planes, context tables, graph context, placeholder query / capacity column). torch
 // autograd carries it on through the fold GEMMs and the encoder.
 //
+// Environments: all six of the decode kernel (the transition of each is replayed step by step with the given action,
+// exactly as am_decode.hip's finalize_and_step does; pickup-delivery's reset flavour is read off the first action).
+//
 // One 256-thread workgroup per INSTANCE; its S trajectories (multistart) are replayed one after
 // the other. Every lane owns a fixed set of cache elements — rows j = 16 i + 4 w + rg (i < ROWS),
 // dims 8 li .. 8 li + 7 — of all three planes: they are loaded into registers ONCE per instance
@@ -60,7 +63,8 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
   float* dqpart = dhpart + kW * kD;                 // [4][128]
   float* dctx = dqpart + kW * kD;                   // [N][128] d ctx_cur of this instance
   uint8_t* mk = reinterpret_cast<uint8_t*>(dctx + N * kD);  // [nw]
-  uint8_t* vis = mk + nw;                                   // [nw]
+  uint8_t* vis = mk + nw;                                   // [nw] visited (PDP: NOT available)
+  uint8_t* tod = vis + nw;                                  // [nw] PDP: to_deliver
 
   // ---- this lane's slice of the three planes, resident in registers -------------------------
   float kg[ROWS][8], vv[ROWS][8], kl[ROWS][8];
@@ -85,15 +89,30 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
 
   const float* ctxc = a.ctx_cur + (int64_t)inst * N * kD + e0;
   const float* ctxf = (ENV == RL4CO_ENV_TSP) ? a.ctx_first + (int64_t)inst * N * kD + e0 : nullptr;
-  const float* dem = (ENV == RL4CO_ENV_CVRP) ? a.demand + (int64_t)inst * (N - 1) : nullptr;
-  const float cap = (ENV == RL4CO_ENV_CVRP) ? a.vehicle_capacity[inst] : 0.0f;
-  float qb[8], dqb[8], dqs0[8], dwc[8];
+  constexpr bool kCvrpLike = ENV == RL4CO_ENV_CVRP || ENV == RL4CO_ENV_CVRPTW;
+  constexpr bool kClock = ENV == RL4CO_ENV_CVRPTW;
+  constexpr bool kScalar = ENV != RL4CO_ENV_TSP && ENV != RL4CO_ENV_PDP;  // one context scalar, cap - used
+  const float* dem = kCvrpLike ? a.demand + (int64_t)inst * (N - 1)
+                               : (ENV == RL4CO_ENV_PCTSP ? a.demand + (int64_t)inst * N : nullptr);  // PCTSP: real prize [N]
+  const float* locs = (ENV == RL4CO_ENV_OP || kClock) ? a.locs + (int64_t)inst * N * 2 : nullptr;
+  const float* opmax = (ENV == RL4CO_ENV_OP) ? a.max_length + (int64_t)inst * N : nullptr;
+  const float* twin = kClock ? a.time_windows + (int64_t)inst * N * 2 : nullptr;
+  const float* dur = kClock ? a.durations + (int64_t)inst * N : nullptr;
+  // cap - used: vehicle capacity (CVRP / CVRPTW), prize still required (PCTSP, clamped at 0), longest tour that may
+  // still end at the depot minus the tour so far (OP) — env_embeddings/context.py:105-213
+  const float cap = (kCvrpLike || ENV == RL4CO_ENV_PCTSP) ? a.vehicle_capacity[inst] : (ENV == RL4CO_ENV_OP ? opmax[0] : 0.0f);
+  auto dist = [&](int i, int j) {  // (locs[j] - locs[i]).norm(p=2, dim=-1)
+    const float dx = locs[2 * j] - locs[2 * i], dy = locs[2 * j + 1] - locs[2 * i + 1];
+    return sqrtf(fmaf(dy, dy, dx * dx));
+  };
+  float qb[8], dqb[8], dqs0[8], dwc[8], dwt[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     qb[e] = a.q_bias ? a.q_bias[(int64_t)inst * kD + e0 + e] : 0.0f;
     dqb[e] = 0.0f;
     dqs0[e] = 0.0f;
     dwc[e] = 0.0f;
+    dwt[e] = 0.0f;
   }
   const float inv_temp = 1.0f / a.temperature;
   uint32_t errbits = 0;
@@ -104,13 +123,32 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
     const float* gl = a.grad_logp + (int64_t)r * T;
     // ---- reset state (tsp/env.py:88-113, cvrp/env.py:98-136) ---------------------------------
     __syncthreads();
+    // a trajectory that opens with the depot in pickup-delivery was reset with force_start_at_depot (pdp/env.py:118-126):
+    // only the depot is open at column 0; otherwise the depot is never available and the pickups are open
+    const bool pdp_depot_start = ENV == RL4CO_ENV_PDP && act[0] == 0;
     for (int j = tid; j < nw; j += 64 * kW) {
-      mk[j] = (j < N) ? ((ENV == RL4CO_ENV_CVRP && j == 0) ? 0 : 1) : 0;  // fresh CVRP: depot masked
-      vis[j] = (j < N) ? 0 : 1;
+      uint8_t m_ = 0, v_ = 1, d_ = 0;
+      if (j < N) {
+        v_ = 0;
+        if (ENV == RL4CO_ENV_TSP) m_ = 1;
+        else if (kCvrpLike) m_ = (j == 0) ? 0 : 1;  // fresh CVRP: depot masked (every demand fits an empty vehicle)
+        else if (ENV == RL4CO_ENV_OP) m_ = (j == 0) ? 1 : ((0.0f + dist(0, j) > opmax[j]) ? 0 : 1);  // op/env.py:137-154
+        else if (ENV == RL4CO_ENV_PCTSP) m_ = (j == 0) ? 0 : 1;  // pctsp/env.py:141-148: no prize yet, customers left
+        else {                                                   // PDP
+          const int half = (N - 1) / 2;
+          d_ = j <= half ? 1 : 0;
+          v_ = (!pdp_depot_start && j == 0) ? 1 : 0;  // vis = NOT available
+          m_ = pdp_depot_start ? (j == 0 ? 1 : 0) : ((j >= 1 && j <= half) ? 1 : 0);
+        }
+        if (kClock && !(0.0f + dist(0, j) <= twin[2 * j + 1])) m_ = 0;  // cvrptw/env.py:91-95 at the depot, time 0
+      }
+      mk[j] = m_;
+      vis[j] = v_;
+      tod[j] = d_;
     }
     int cur = 0, first = 0;
     long long step_i = 0;
-    float used = 0.0f;
+    float used = 0.0f, now = 0.0f;
     bool done = false;
     float dqf[8];
 #pragma unroll
@@ -128,7 +166,8 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
         const float g = gl[t];
         // ---- query -----------------------------------------------------------------------------
         float q[8];
-        const float rem = cap - used;
+        float rem = cap - used;
+        if (ENV == RL4CO_ENV_PCTSP && !(rem > 0.0f)) rem = 0.0f;  // clamp(min=0), context.py:195
         if (ENV == RL4CO_ENV_TSP) {
           if (step_i < 1) {
 #pragma unroll
@@ -137,9 +176,16 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
 #pragma unroll
             for (int e = 0; e < 8; ++e) q[e] = (ctxf[(int64_t)first * kD + e] + ctxc[(int64_t)cur * kD + e]) + qb[e];
           }
+        } else if (ENV == RL4CO_ENV_PDP) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) q[e] = ctxc[(int64_t)cur * kD + e] + qb[e];  // context.py:232-243
         } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) q[e] = fmaf(a.w_cap[e0 + e], rem, ctxc[(int64_t)cur * kD + e]) + qb[e];
+          for (int e = 0; e < 8; ++e) {
+            float v = fmaf(a.w_cap[e0 + e], rem, ctxc[(int64_t)cur * kD + e]);
+            if (kClock) v = fmaf(a.w_time[e0 + e], now, v);  // context.py:152-166
+            q[e] = v + qb[e];
+          }
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) q[e] *= 0.25f;
@@ -327,7 +373,8 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
                 dctx[cur * kD + d] += dqr;
               }
             } else {
-              dwc[e] = fmaf(dqr, rem, dwc[e]);
+              if (kScalar) dwc[e] = fmaf(dqr, rem, dwc[e]);
+              if (kClock) dwt[e] = fmaf(dqr, now, dwt[e]);
               dctx[cur * kD + d] += dqr;
             }
           }
@@ -348,7 +395,67 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
           any_left = __any(any_left);
           if (lane == 0) shi[0] = any_left ? 0 : 1;
         }
+      } else if (ENV == RL4CO_ENV_PDP) {
+        // pdp/env.py:64-83: the node leaves `available`, its delivery becomes deliverable; done when nothing is available
+        const int n = N - 1;
+        cur = at;
+        step_i += 1;
+        if (tid == 0) {
+          vis[at] = 1;
+          tod[(at + n / 2) % (n + 1)] = 1;
+        }
+        __syncthreads();
+        if (w == 0) {
+          bool left = false;
+          for (int j = lane; j < N; j += 64) {
+            const bool avail = vis[j] == 0;
+            mk[j] = (avail && tod[j] != 0) ? 1 : 0;
+            left |= avail;
+          }
+          left = __any(left);
+          if (lane == 0) shi[0] = left ? 0 : 1;
+        }
+      } else if (ENV == RL4CO_ENV_PCTSP) {
+        // pctsp/env.py:62-75, 141-148
+        used = used + dem[at];
+        const bool fin = (step_i > 0) && (at == 0);
+        step_i += 1;
+        cur = at;
+        if (tid == 0) vis[at] = 1;
+        __syncthreads();
+        if (w == 0) {
+          const bool closed = vis[0] != 0;
+          bool unvisited = false;
+          for (int j = lane; j < N; j += 64) {
+            if (j >= 1) {
+              mk[j] = (vis[j] != 0 || closed) ? 0 : 1;
+              unvisited |= vis[j] == 0;
+            }
+          }
+          unvisited = __any(unvisited);
+          if (lane == 0) {
+            mk[0] = ((used < 1.0f) && unvisited) ? 0 : 1;
+            shi[0] = fin ? 1 : 0;
+          }
+        }
+      } else if (ENV == RL4CO_ENV_OP) {
+        // op/env.py:67-98, 137-154
+        used = used + dist(cur, at);
+        const bool fin = (at == 0) && (step_i > 0);
+        step_i += 1;
+        cur = at;
+        if (tid == 0) vis[at] = 1;
+        __syncthreads();
+        if (w == 0) {
+          const bool closed = vis[0] != 0;
+          for (int j = lane; j < N; j += 64) {
+            const bool exceeds = used + dist(cur, j) > opmax[j];
+            mk[j] = (j == 0) ? 1 : ((vis[j] != 0 || closed || exceeds) ? 0 : 1);
+          }
+          if (lane == 0) shi[0] = fin ? 1 : 0;
+        }
       } else {
+        if (kClock) now = (at != 0 ? 1.0f : 0.0f) * (fmaxf(now + dist(cur, at), twin[2 * at]) + dur[at]);  // cvrptw/env.py:97-113
         const int di = min(max(at - 1, 0), N - 2);
         used = (used + dem[di]) * (at != 0 ? 1.0f : 0.0f);
         cur = at;
@@ -370,6 +477,13 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
           if (lane == 0) {
             mk[0] = ((cur == 0) && any_feasible) ? 0 : 1;
             shi[0] = all_visited ? 1 : 0;
+          }
+          if (kClock) {  // cvrptw/env.py:91-95: only nodes whose window is still open on arrival (the depot too)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            for (int j = lane; j < N; j += 64)
+              if (!(now + dist(cur, j) <= twin[2 * j + 1])) mk[j] = 0;
           }
         }
       }
@@ -408,7 +522,8 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
     for (int e = 0; e < 8; ++e) {
       if (a.d_q_bias) a.d_q_bias[(int64_t)inst * kD + e0 + e] = dqb[e];
       if (ENV == RL4CO_ENV_TSP) atomicAdd(a.d_q_step0 + e0 + e, dqs0[e]);
-      else atomicAdd(a.d_w_cap + e0 + e, dwc[e]);
+      else if (kScalar) atomicAdd(a.d_w_cap + e0 + e, dwc[e]);
+      if (kClock) atomicAdd(a.d_w_time + e0 + e, dwt[e]);
     }
   }
   if (errbits && lane == 0) atomicOr(a.err, (int)errbits);
@@ -417,7 +532,7 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
 template <int ENV, int ROWS>
 int launch_teacher(const rl4co_am_teacher_args& a, hipStream_t stream) {
   const int nw = (a.N + 3) & ~3;
-  const int lds = (3 * kW * kH + kW * 2 + 8 + 8) * 4 + 3 * kW * kD * 4 + a.N * kD * 4 + 2 * nw;
+  const int lds = (3 * kW * kH + kW * 2 + 8 + 8) * 4 + 3 * kW * kD * 4 + a.N * kD * 4 + 3 * nw;
   if (lds > 64 * 1024) {
     RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_teacher_kernel<ENV, ROWS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -474,8 +589,6 @@ static int validate_teacher(const rl4co_am_teacher_args& a) {
 static int resolve_teacher_variant(const rl4co_am_teacher_args& a) {
   const bool mma_ok = a.cache_dtype == RL4CO_DT_BF16 && a.N <= rl4co::teacher_mma_max_nodes() &&
                       a.T <= rl4co::teacher_mma_max_steps() && a.kvl_row_stride % 8 == 0 && a.kvl_batch_stride % 8 == 0;
-  if (a.env == RL4CO_ENV_OP || a.env == RL4CO_ENV_PCTSP || a.env == RL4CO_ENV_PDP || a.env == RL4CO_ENV_CVRPTW)  // closed-form replay exists in the MMA variant only
-    return (mma_ok && a.variant != RL4CO_TEACHER_REPLAY) ? RL4CO_TEACHER_MMA : -1;
   if (a.d_planes_bf16 || !a.d_kvl)  // bf16 plane gradients come out of the MMA variant only
     return (mma_ok && a.variant != RL4CO_TEACHER_REPLAY) ? RL4CO_TEACHER_MMA : -1;
   if (a.variant == RL4CO_TEACHER_MMA) return mma_ok ? RL4CO_TEACHER_MMA : -1;
@@ -497,5 +610,12 @@ extern "C" int rl4co_am_teacher_backward(const rl4co_am_teacher_args* args, void
   RL4CO_REQUIRE(variant > 0);  // RL4CO_TEACHER_MMA requested for planes / sizes it does not support
   hipStream_t s = rl4co::as_stream(stream);
   if (variant == RL4CO_TEACHER_MMA) return rl4co::launch_teacher_mma(a, s);
-  return a.env == RL4CO_ENV_TSP ? dispatch_rows<RL4CO_ENV_TSP>(a, s) : dispatch_rows<RL4CO_ENV_CVRP>(a, s);
+  switch (a.env) {
+    case RL4CO_ENV_TSP: return dispatch_rows<RL4CO_ENV_TSP>(a, s);
+    case RL4CO_ENV_CVRP: return dispatch_rows<RL4CO_ENV_CVRP>(a, s);
+    case RL4CO_ENV_OP: return dispatch_rows<RL4CO_ENV_OP>(a, s);
+    case RL4CO_ENV_PCTSP: return dispatch_rows<RL4CO_ENV_PCTSP>(a, s);
+    case RL4CO_ENV_PDP: return dispatch_rows<RL4CO_ENV_PDP>(a, s);
+    default: return dispatch_rows<RL4CO_ENV_CVRPTW>(a, s);
+  }
 }

@@ -47,11 +47,11 @@ def max_nodes() -> int:
 
 
 def supports(env_name: str, cache_dtype: torch.dtype, num_nodes: int) -> bool:
-    """TSP / CVRP: both variants; orienteering, prize-collecting TSP, pickup-delivery, CVRP with time windows: the
-    MMA variant only (bf16 planes)."""
+    """TSP, CVRP, orienteering, prize-collecting TSP, pickup-delivery, CVRP with time windows — on both variants (the
+    MMA one needs bf16 planes; fp32 planes take the replay kernel)."""
     if num_nodes > max_nodes():
         return False
-    return env_name in ("tsp", "cvrp") or (env_name in ("op", "pctsp", "pdp", "cvrptw") and cache_dtype == torch.bfloat16)
+    return env_name in ("tsp", "cvrp", "op", "pctsp", "pdp", "cvrptw")
 
 
 def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: dict, variant: str = "auto",

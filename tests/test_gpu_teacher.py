@@ -35,7 +35,12 @@ def _td(g):
 @pytest.mark.parametrize("name,starts", [("tsp20_b64_greedy_simple", 0), ("tsp50_b64_greedy", 0),
                                          ("cvrp20_b128_greedy", 0), ("tsp100_b64_greedy", 0),
                                          ("cvrp100_b64_greedy", 0), ("pomo_tsp20_b16_msgreedy", 5),
-                                         ("pomo_cvrp20_b16_msgreedy", 4), ("c4_pomo_tsp100_b32_s8_sampling", 8)])
+                                         ("pomo_cvrp20_b16_msgreedy", 4), ("c4_pomo_tsp100_b32_s8_sampling", 8),
+                                         # r02: the fp32 replay kernel serves every environment of the decode kernel
+                                         ("op20_b128_greedy", 0), ("op100_b64_greedy", 0), ("pctsp20_b128_greedy", 0),
+                                         ("pctsp100_b64_greedy", 0), ("pdp20_b128_greedy", 0), ("pdp100_b64_greedy", 0),
+                                         ("cvrptw20_b128_greedy", 0), ("cvrptw50_b64_sampling", 0),
+                                         ("pomo_pdp20_b16_msgreedy", 5), ("pomo_pctsp20_b16_msgreedy", 4)])
 def test_backward_kernel_matches_torch_autograd(name, starts):
     g = GoldenCase(name)
     env, td = _td(g)

@@ -81,7 +81,10 @@ def _compare(got, grad_scale=1.0):
 @pytest.mark.parametrize("name,starts", [("tsp20_b64_greedy_simple", 0), ("tsp50_b64_greedy", 0),
                                          ("cvrp20_b128_greedy", 0), ("tsp100_b64_greedy", 0),
                                          ("cvrp100_b64_greedy", 0), ("pomo_tsp20_b16_msgreedy", 5),
-                                         ("pomo_cvrp20_b16_msgreedy", 4), ("c4_pomo_tsp100_b32_s8_sampling", 8)])
+                                         ("pomo_cvrp20_b16_msgreedy", 4), ("c4_pomo_tsp100_b32_s8_sampling", 8),
+                                         ("op50_b64_sampling", 0), ("pctsp50_b64_sampling", 0), ("pdp50_b64_sampling", 0),
+                                         ("cvrptw50_b64_sampling", 0), ("pomo_pdp20_b16_msgreedy", 5),
+                                         ("pomo_cvrptw20_b16_mssampling", 6)])
 def test_mma_matches_replay(name, starts):
     _compare(_capture(name, starts))
 
