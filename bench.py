@@ -239,7 +239,7 @@ class Bench:
                 try:
                     graphed = GraphedRollout(policy, env, data, decode_type=decode)
                     step = lambda: graphed(data)  # noqa: E731
-                    for _ in range(2):
+                    for _ in range(max(2, warmup)):  # replays before the clock starts (the first ones run slower)
                         out = step()
                 except Exception as exc:  # a launch sequence that cannot be captured stays on the eager path, said so
                     log(f"{leg}: HIP graph capture failed ({type(exc).__name__}: {exc}); timing the eager path")
