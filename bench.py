@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — the rollout hot path on N MI355X GPUs of one node (driver contract).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (N > 1 without a launcher: re-executes itself under the one below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -496,13 +496,26 @@ def main() -> None:
                     help="instances of the same workload timed on the host cores (shrunk to keep the leg within ~30 s)")
     args = ap.parse_args()
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the rollout engine has no CPU path")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` started directly: become the launcher. One rank per GPU under torch.distributed.run
+        # (what Lightning's DDP strategy does for the reference, utils/trainer.py:73-86), rendezvous on 127.0.0.1; the
+        # ranks inherit this process's stdout, rank 0 writes the one JSON line
+        shared = os.environ.get("RL4CO_BENCH_SHARED_GPU") == "1"
+        if torch.cuda.device_count() < args.gpus and not shared:
+            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} device(s) visible")
+        from rl4co_amd.dist import _free_port
+
+        os.dup2(json_fd, 1)
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                                  "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                                  os.path.abspath(__file__), *sys.argv[1:]])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the rollout engine has no CPU path")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     legs = [x for x in args.legs.split(",") if x]
     for x in legs:
         if x not in LEGS:

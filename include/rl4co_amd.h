@@ -323,11 +323,13 @@ typedef struct rl4co_am_decode_args {
   float* all_logps;         /* [B,out_stride,N] or NULL (store_all_logp / entropy)         */
   float* entropy;           /* [B] accumulated -sum p log p, or NULL                       */
   int32_t* n_steps;         /* [B] steps actually taken by each trajectory, or NULL        */
-  int32_t* steps_summary;   /* [3] or NULL (zero-initialised by the caller): [0] = max and [1] += sum over the
-                             * trajectories of the steps taken — what the host needs of n_steps without a
-                             * reduction launch; [2] += cache rows the launch streamed per plane from HBM
-                             * (feasible rows of every step; 0 for the variants whose planes are LDS-resident):
-                             * the measured numerator of the decode kernel's roofline in bench.py            */
+  int32_t* steps_summary;   /* [4], 8-byte aligned, or NULL (zero-initialised by the caller): [0] = max and [1] += sum
+                             * over the trajectories of the steps taken — what the host needs of n_steps without a
+                             * reduction launch; [2..3] = ONE 64-bit counter (little endian: low word, high word) += cache
+                             * rows the launch streamed per plane from HBM (feasible rows of every step; 0 for the
+                             * variants whose planes are LDS-resident): the measured numerator of the decode kernel's
+                             * roofline in bench.py. 64 bits: 409 600 trajectories x 5050 rows already reach 2.07e9.
+                             * A misaligned pointer is refused (RL4CO_STATUS_INVALID_ARGUMENT)                       */
   int32_t* err;             /* sticky error bits                                           */
 } rl4co_am_decode_args;
 
@@ -574,6 +576,38 @@ int rl4co_attn_flash_bf16(const void* qkv, int B, int N, void* out, void* stream
  * -------------------------------------------------------------------------- */
 int rl4co_select_start_nodes(int64_t* out, int B, int num_starts, int num_loc, int has_depot,
                              void* stream);
+
+/* --------------------------------------------------------------------------
+ * N3  state augmentation                      rl4co/data/transforms.py:16-87, 105-151
+ * Both kernels read the B instances ONCE and write the aug-major layout [A*B, N, 2] (row a*B + b) that the
+ * multistart rollout consumes — what batchify (utils/ops.py:10-30) followed by the transform produces in the reference.
+ *
+ * dihedral8: the 8 symmetries of the unit square in the reference's order (transforms.py:27-37):
+ *   (x,y) (1-x,y) (x,1-y) (1-x,1-y) (y,x) (1-y,x) (y,1-x) (1-y,1-x); xy [B,N,2] f32 -> out [8*B,N,2]. Bit-exact.
+ * symmetric: rotation by phi_r about (offset, offset) and an axis swap where phi_r > 2 pi (transforms.py:49-69), one
+ *   angle per OUTPUT row r. The caller passes cos(phi), sin(phi) [A*B] f32 and the swap flags [A*B] u8 (the angles are
+ *   host-side RNG state: transforms.py:81 draws them from torch's global generator); the kernel does the fp32
+ *   arithmetic in the reference's order, x' = cos*x - sin*y, y' = sin*x + cos*y (no fused multiply-add).
+ * -------------------------------------------------------------------------- */
+int rl4co_augment_dihedral8_f32(const float* xy, int B, int N, float* out, void* stream);
+int rl4co_augment_symmetric_f32(const float* xy, const float* cos_phi, const float* sin_phi, const uint8_t* swap_axes,
+                                int B, int A, int N, float offset, float* out, void* stream);
+
+/* --------------------------------------------------------------------------
+ * N3  POMO evaluation epilogue                rl4co/models/zoo/pomo/model.py:112-140
+ *                                             (unbatchify / gather_by_index: rl4co/utils/ops.py:33-66)
+ * reward [S*A*B] f32 and actions [S*A*B, T] i64 of a multistart rollout over an augmented batch, rows ordered
+ * (s * A + a) * B + b. One launch computes
+ *   max_reward[b,a]      = max_s reward            best_start[b,a] = its first arg-max (torch.max's tie rule)
+ *   max_aug_reward[b]    = max_a max_reward[b,a]   best_aug[b]     = its first arg-max
+ *   best_ms_actions[b,a] = actions of (best_start[b,a], a, b)          [B,A,T]
+ *   best_aug_actions[b]  = actions of (best_start[b,a*], a* = best_aug[b], b)   [B,T]
+ * Any output pointer may be NULL; actions may be NULL when no action output is asked for. A = 1 and / or S = 1 are
+ * the degenerate cases of the same reduction.
+ * -------------------------------------------------------------------------- */
+int rl4co_pomo_best(const float* reward, const int64_t* actions, int A, int S, int B, int T, float* max_reward,
+                    int64_t* best_start, float* max_aug_reward, int64_t* best_aug, int64_t* best_ms_actions,
+                    int64_t* best_aug_actions, void* stream);
 
 /* --------------------------------------------------------------------------
  * N2 / a10  instance generation on the device

@@ -246,6 +246,8 @@ def am_decode(cache, state: dict, *, mode: str, max_steps: int, actions: Tensor,
     a.all_logps = _p(None if all_logps is None else _cpu(all_logps, torch.float32))
     a.entropy = _p(None if entropy is None else _cpu(entropy, torch.float32))
     a.n_steps = _p(None if n_steps is None else _cpu(n_steps, torch.int32))
+    if steps_summary is not None:
+        assert steps_summary.numel() >= 4 and steps_summary.data_ptr() % 8 == 0, "steps_summary: 4 int32 words, 8-byte aligned"
     a.steps_summary = _p(None if steps_summary is None else _cpu(steps_summary, torch.int32))
     a.err = _p(_cpu(err, torch.int32))
     if row_groups == "ms":  # rounding-model oracle of the multistart MFMA variant (bf16 query / numerators / glimpse)
@@ -268,4 +270,46 @@ def uniform(shape, low: float, high: float, seed: int, stream_id: int, demand_ca
     out = torch.empty(tuple(shape), dtype=torch.float32)
     assert lib().oracle_uniform_f32(_p(out), out.numel(), float(low), float(high), int(seed) & ((1 << 64) - 1), int(stream_id),
                                     0 if demand_capacity is None else 1, float(demand_capacity or 1.0)) == 0
+    return out
+
+
+def augment_dihedral8(xy: Tensor) -> Tensor:
+    """Host restatement of kernels.augment_dihedral8."""
+    b, n, _ = xy.shape
+    out = torch.empty((8 * b, n, 2), dtype=torch.float32)
+    h = lib()
+    h.oracle_augment_dihedral8_f32.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    assert h.oracle_augment_dihedral8_f32(_p(_cpu(xy, torch.float32)), b, n, _p(out)) == 0
+    return out
+
+
+def augment_symmetric(xy: Tensor, cos_phi: Tensor, sin_phi: Tensor, swap_axes: Tensor, offset: float = 0.5) -> Tensor:
+    """Host restatement of kernels.augment_symmetric."""
+    b, n, _ = xy.shape
+    rows = cos_phi.numel()
+    out = torch.empty((rows, n, 2), dtype=torch.float32)
+    h = lib()
+    h.oracle_augment_symmetric_f32.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3 + [C.c_float, C.c_void_p]
+    assert h.oracle_augment_symmetric_f32(_p(_cpu(xy, torch.float32)), _p(_cpu(cos_phi, torch.float32)), _p(_cpu(sin_phi, torch.float32)),
+                                          _p(_u8(swap_axes)), b, rows // b, n, float(offset), _p(out)) == 0
+    return out
+
+
+def pomo_best(reward: Tensor, actions: Tensor | None, num_augment: int, num_starts: int) -> dict:
+    """Host restatement of kernels.pomo_best."""
+    a, s = int(num_augment), int(num_starts)
+    reward = _cpu(reward.reshape(-1).contiguous(), torch.float32)
+    b = reward.numel() // (a * s)
+    out = {"max_reward": torch.empty((b, a)), "best_start": torch.empty((b, a), dtype=torch.int64),
+           "max_aug_reward": torch.empty(b), "best_aug": torch.empty(b, dtype=torch.int64)}
+    t = 0
+    if actions is not None:
+        _cpu(actions, torch.int64)
+        t = actions.shape[1]
+        out["best_multistart_actions"] = torch.empty((b, a, t), dtype=torch.int64)
+        out["best_aug_actions"] = torch.empty((b, t), dtype=torch.int64)
+    h = lib()
+    h.oracle_pomo_best.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] * 6
+    assert h.oracle_pomo_best(_p(reward), _p(actions), a, s, b, t, _p(out["max_reward"]), _p(out["best_start"]), _p(out["max_aug_reward"]),
+                              _p(out["best_aug"]), _p(out.get("best_multistart_actions")), _p(out.get("best_aug_actions"))) == 0
     return out

@@ -657,7 +657,7 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
     if (a->steps_summary) {
       if (t > a->steps_summary[0]) a->steps_summary[0] = t;
       a->steps_summary[1] += t;
-      a->steps_summary[2] += rows_read;
+      { uint64_t rows; memcpy(&rows, a->steps_summary + 2, 8); rows += (uint64_t)rows_read; memcpy(a->steps_summary + 2, &rows, 8); }
     }
     if (a->entropy) a->entropy[r] += ent_acc;
     errbits_all |= errbits;
@@ -916,6 +916,68 @@ int oracle_uniform_f32(float* out, int64_t n, float low, float high, uint64_t se
       if (mode == 1) x = (truncf(x) + 1.0f) / capacity;
       out[4 * b + i] = x;
     }
+  }
+  return 0;
+}
+
+/* ---- N3: state augmentation and the POMO evaluation epilogue (host restatement of csrc/augment.hip) --------------
+ * follows rl4co/data/transforms.py:16-69 (dihedral8 order; symmetric_transform's x' = cos x - sin y, y' = sin x + cos y,
+ * swap where phi > 2 pi, + offset) and rl4co/models/zoo/pomo/model.py:112-140 over utils/ops.py:33-66 (unbatchify to
+ * [B, A, S], max over S then over A with torch.max's first-index tie rule, gather_by_index of the action rows).
+ * Compiled with -ffp-contract=off like the kernels: separate multiplies, one subtraction / addition. */
+int oracle_augment_dihedral8_f32(const float* xy, int B, int N, float* out) {
+  const int64_t pairs = (int64_t)B * N;
+  for (int64_t i = 0; i < pairs; ++i) {
+    const float x = xy[2 * i], y = xy[2 * i + 1], mx = 1.0f - x, my = 1.0f - y;
+    const float t[8][2] = {{x, y}, {mx, y}, {x, my}, {mx, my}, {y, x}, {my, x}, {y, mx}, {my, mx}};
+    for (int a = 0; a < 8; ++a) {
+      out[2 * (i + a * pairs)] = t[a][0];
+      out[2 * (i + a * pairs) + 1] = t[a][1];
+    }
+  }
+  return 0;
+}
+
+int oracle_augment_symmetric_f32(const float* xy, const float* cos_phi, const float* sin_phi, const uint8_t* swap_axes, int B,
+                                 int A, int N, float offset, float* out) {
+  for (int64_t r = 0; r < (int64_t)A * B; ++r) {
+    const float c = cos_phi[r], s = sin_phi[r];
+    const float* src = xy + (r % B) * (int64_t)N * 2;
+    float* dst = out + r * (int64_t)N * 2;
+    for (int j = 0; j < N; ++j) {
+      const float x = src[2 * j] - offset, y = src[2 * j + 1] - offset;
+      const float xp = c * x - s * y;
+      const float yp = s * x + c * y;
+      dst[2 * j] = (swap_axes[r] ? yp : xp) + offset;
+      dst[2 * j + 1] = (swap_axes[r] ? xp : yp) + offset;
+    }
+  }
+  return 0;
+}
+
+int oracle_pomo_best(const float* reward, const int64_t* actions, int A, int S, int B, int T, float* max_reward,
+                     int64_t* best_start, float* max_aug_reward, int64_t* best_aug, int64_t* best_ms_actions,
+                     int64_t* best_aug_actions) {
+  for (int b = 0; b < B; ++b) {
+    float bv = 0.0f;
+    int ba = -1, bs_of_ba = 0;
+    for (int a = 0; a < A; ++a) {
+      float best = reward[(int64_t)a * B + b];
+      int bi = 0;
+      for (int s = 1; s < S; ++s) {
+        const float v = reward[((int64_t)s * A + a) * B + b];
+        if (v > best) { best = v; bi = s; }
+      }
+      if (max_reward) max_reward[(int64_t)b * A + a] = best;
+      if (best_start) best_start[(int64_t)b * A + a] = bi;
+      if (actions && best_ms_actions)
+        memcpy(best_ms_actions + ((int64_t)b * A + a) * T, actions + (((int64_t)bi * A + a) * B + b) * T, (size_t)T * 8);
+      if (ba < 0 || best > bv) { bv = best; ba = a; bs_of_ba = bi; }
+    }
+    if (max_aug_reward) max_aug_reward[b] = bv;
+    if (best_aug) best_aug[b] = ba;
+    if (actions && best_aug_actions)
+      memcpy(best_aug_actions + (int64_t)b * T, actions + (((int64_t)bs_of_ba * A + ba) * B + b) * T, (size_t)T * 8);
   }
   return 0;
 }

@@ -127,6 +127,9 @@ SYMBOLS = {
     "rl4co_am_decode_row_groups": (C.c_int, [C.POINTER(AmDecodeArgs)]),
     "rl4co_am_decode_variant": (C.c_int, [C.POINTER(AmDecodeArgs)]),
     "rl4co_select_start_nodes": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "rl4co_augment_dihedral8_f32": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_augment_symmetric_f32": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_float, _vp, _vp]),
+    "rl4co_pomo_best": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rl4co_hbm_read_probe": (C.c_int, [_vp, _i64, _vp, _vp]),
     "rl4co_math_probe_f32": (C.c_int, [C.c_int, _vp, _i64, _vp, _vp]),
     "rl4co_uniform_f32": (C.c_int, [_vp, _i64, C.c_float, C.c_float, C.c_uint64, C.c_uint32, C.c_int, C.c_float, _vp]),

@@ -597,7 +597,7 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
     if (a.steps_summary) {
       atomicMax(a.steps_summary, t);
       atomicAdd(a.steps_summary + 1, t);
-      atomicAdd(a.steps_summary + 2, rows_read);
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.steps_summary + 2), (unsigned long long)rows_read);
     }
     if (a.entropy) a.entropy[r] += st.ent_acc;
     if (st.errbits) atomicOr(a.err, (int)st.errbits);
@@ -919,7 +919,7 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_wide_kernel(const
       if (a.steps_summary) {
         atomicMax(a.steps_summary, t);
         atomicAdd(a.steps_summary + 1, t);
-        atomicAdd(a.steps_summary + 2, RESIDENT ? 0 : rows_read);  // resident planes are read once per rollout
+        atomicAdd(reinterpret_cast<unsigned long long*>(a.steps_summary + 2), (unsigned long long)(RESIDENT ? 0 : rows_read));  // resident planes are read once per rollout
       }
       if (a.entropy) a.entropy[r] += st.ent_acc;
       if (st.errbits) atomicOr(a.err, (int)st.errbits);
@@ -1024,6 +1024,7 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
   RL4CO_REQUIRE(a.action_mask && a.current_node && a.done && a.actions && a.logps && a.err);
   RL4CO_REQUIRE(a.out_stride >= 1 && a.t0 >= 0 && (int64_t)a.t0 + a.max_steps <= a.out_stride);
   RL4CO_REQUIRE(a.temperature > 0.0f);
+  RL4CO_REQUIRE((reinterpret_cast<uintptr_t>(a.steps_summary) & 7) == 0);  // [2..3] is one 64-bit counter
   RL4CO_REQUIRE(a.mode != RL4CO_DECODE_EVALUATE || a.forced_actions != nullptr);
   if (a.env == RL4CO_ENV_TSP) {
     RL4CO_REQUIRE(((a.ctx_first && a.q_step0) || a.unfold) && a.first_node && a.step_i);

@@ -747,7 +747,7 @@ __global__ void __launch_bounds__(kThreads, 4) am_decode_ms_kernel(const rl4co_a
   sh.dems = dems;
   sh.envf = reinterpret_cast<const float*>(smem + L.envf);
   uint32_t errbits = 0;
-  if (tid == 0 && a.steps_summary) atomicAdd(a.steps_summary + 2, N);  // the planes are read ONCE per workgroup
+  if (tid == 0 && a.steps_summary) atomicAdd(reinterpret_cast<unsigned long long*>(a.steps_summary + 2), (unsigned long long)N);  // the planes are read ONCE per workgroup
   rollout_tiles<ENV, NT, MODE, 1>(a, sh, inst, 16 * tile0, errbits);  // this workgroup's column tile
   if (errbits) atomicOr(a.err, (int)errbits);
 }

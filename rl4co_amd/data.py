@@ -113,39 +113,45 @@ def generate_env_data(env_type: str, *args, **kwargs) -> dict:
     return _GENERATORS[env_type](*[a for a in args if a is not None], **kwargs)
 
 
+def _dataset_jobs(problem, data_distribution, graph_sizes, distributions_per_problem):
+    """Every (problem, distribution, graph size) a call of ``generate_dataset`` covers, in the reference's order
+    (generate_data.py:252-268): problems in table order, each with its distributions, each at every size."""
+    table = DISTRIBUTIONS_PER_PROBLEM if distributions_per_problem is None else distributions_per_problem
+    if isinstance(problem, (list, tuple)) and len(problem) == 1:
+        problem = problem[0]
+    if problem == "all":
+        plan = dict(table)
+    else:
+        plan = {problem: table[problem] if data_distribution == "all" else [data_distribution]}
+    sizes = [graph_sizes] if isinstance(graph_sizes, int) else list(graph_sizes)
+    return [(prob, dist, size) for prob, dists in plan.items() for dist in (dists or [None]) for size in sizes]
+
+
 def generate_dataset(filename=None, data_dir: str = "data", name: str | None = None, problem="all",
                      data_distribution: str = "all", dataset_size: int = 10000, graph_sizes=(20, 50, 100),
                      overwrite: bool = False, seed: int = 1234, distributions_per_problem: dict | None = None) -> list[str]:
-    """generate_data.py:214-311: one npz per (problem, distribution, graph size), named
-    ``<data_dir>/<problem>/<problem>[_<dist>]<size>_<name>_seed<seed>.npz``. Returns the files written."""
-    if isinstance(problem, list) and len(problem) == 1:
-        problem = problem[0]
-    graph_sizes = [graph_sizes] if isinstance(graph_sizes, int) else list(graph_sizes)
-    dpp = DISTRIBUTIONS_PER_PROBLEM if distributions_per_problem is None else distributions_per_problem
-    problems = dpp if problem == "all" else {problem: (dpp[problem] if data_distribution == "all" else [data_distribution])}
-    filenames = [filename] if isinstance(filename, str) else filename
-    written, it = [], 0
-    for prob, distributions in problems.items():
-        for distribution in distributions or [None]:
-            for graph_size in graph_sizes:
-                if filename is None:
-                    datadir = os.path.join(data_dir, prob)
-                    os.makedirs(datadir, exist_ok=True)
-                    fname = os.path.join(datadir, "{}{}{}_{}_seed{}.npz".format(
-                        prob, (f"_{distribution}" if distribution is not None else ""), graph_size, name, seed))
-                else:
-                    if it >= len(filenames):
-                        raise ValueError("Number of filenames does not match number of problems")
-                    fname = check_extension(filenames[it], extension=".npz")
-                    if os.path.dirname(fname):
-                        os.makedirs(os.path.dirname(fname), exist_ok=True)
-                    it += 1
-                if not overwrite and os.path.isfile(fname):
-                    continue
-                np.random.seed(seed)
-                dataset = generate_env_data(prob, dataset_size, graph_size, distribution)
-                np.savez(fname, **dataset)
-                written.append(fname)
+    """The instance files of ``rl4co/data/generate_data.py:214-311``: one npz per job, by default at
+    ``<data_dir>/<problem>/<problem>[_<dist>]<size>_<name>_seed<seed>.npz``; explicit ``filename``(s) are consumed one
+    per job. Every file is drawn under a fresh ``np.random.seed(seed)`` so that a file does not depend on which other
+    files the call wrote; existing files are kept unless ``overwrite``. Returns the files written."""
+    jobs = _dataset_jobs(problem, data_distribution, graph_sizes, distributions_per_problem)
+    explicit = None if filename is None else ([filename] if isinstance(filename, str) else list(filename))
+    if explicit is not None and len(explicit) < len(jobs):
+        raise ValueError("Number of filenames does not match number of problems")
+    written = []
+    for k, (prob, dist, size) in enumerate(jobs):
+        if explicit is None:
+            tag = "" if dist is None else f"_{dist}"
+            path = os.path.join(data_dir, prob, f"{prob}{tag}{size}_{name}_seed{seed}.npz")
+        else:
+            path = check_extension(explicit[k], extension=".npz")
+        if os.path.isfile(path) and not overwrite:
+            continue
+        if os.path.dirname(path):
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+        np.random.seed(seed)
+        np.savez(path, **generate_env_data(prob, dataset_size, size, dist))
+        written.append(path)
     return written
 
 
@@ -219,143 +225,146 @@ def wrap_dataset_with_baseline(policy, env, dataset: TensorDictDataset, batch_si
     return dataset.add_key("extra", greedy_rollout_rewards(policy, env, dataset, batch_size).detach())
 
 
-# ---- augmentation (data/transforms.py) -------------------------------------------------------------
+# ---- augmentation (data/transforms.py) -> csrc/augment.hip -------------------------------------------
+# The instances are read ONCE by a kernel that writes the aug-major [A*B, N, 2] layout the multistart rollout consumes
+# (kernels.augment_dihedral8 / augment_symmetric); only the angle draw of the symmetric group stays on the host side of
+# the boundary, because it IS host state: the reference takes it from torch's global generator (transforms.py:81) and a
+# seeded run must consume that stream identically.
+
+_AUGMENT_KINDS = ("symmetric", "dihedral8")
+
 
 def dihedral_8_augmentation(xy: Tensor) -> Tensor:
-    """transforms.py:16-38: the 8 rotations/reflections of the unit square, aug-major [8*B, N, 2]."""
-    x, y = xy.split(1, dim=2)
-    zs = ((x, y), (1 - x, y), (x, 1 - y), (1 - x, 1 - y), (y, x), (1 - y, x), (y, 1 - x), (1 - y, 1 - x))
-    return torch.cat([torch.cat(z, dim=2) for z in zs], dim=0)
+    """[B, N, 2] -> [8B, N, 2]: the 8 symmetries of the unit square, aug-major (transforms.py:16-38), one launch."""
+    from . import kernels as K
+
+    return K.augment_dihedral8(xy.contiguous())
 
 
 def dihedral_8_augmentation_wrapper(xy: Tensor, reduce: bool = True, *args, **kw) -> Tensor:
-    """transforms.py:41-46: with ``reduce`` only the first 1/8 of the (already batchified) rows is augmented."""
-    xy = xy[: xy.shape[0] // 8, ...] if reduce else xy
-    return dihedral_8_augmentation(xy)
+    """transforms.py:41-46: a batchified feature carries 8 copies of the instances; with ``reduce`` the first copy is
+    what gets augmented (so the output has as many rows as the input)."""
+    return dihedral_8_augmentation(xy[: xy.shape[0] // 8] if reduce else xy)
 
 
-def symmetric_transform(x: Tensor, y: Tensor, phi: Tensor, offset: float = 0.5) -> Tensor:
-    """transforms.py:49-69 (SymNCO's rotation / reflection group, vectorised): rotate by ``phi`` about the centre of
-    the unit square and swap the axes where ``phi > 2 pi`` (half of the draws)."""
-    x, y = x - offset, y - offset
-    x_prime = torch.cos(phi) * x - torch.sin(phi) * y
-    y_prime = torch.sin(phi) * x + torch.cos(phi) * y
-    mask = phi > 2 * math.pi
-    xy = torch.cat((x_prime, y_prime), dim=-1)
-    xy = torch.where(mask, xy.flip(-1), xy)
-    return xy + offset
+def _rotation_terms(phi: Tensor):
+    """(cos phi, sin phi, phi > 2 pi) of one angle per output row: what ``rl4co_augment_symmetric_f32`` takes."""
+    phi = phi.float()
+    return torch.cos(phi).contiguous(), torch.sin(phi).contiguous(), (phi > 2 * math.pi).contiguous()
+
+
+def _draw_angles(rows: int, identity_rows: int, device, phi: Tensor | None = None) -> Tensor:
+    """U[0, 4 pi) per output row from the global generator of ``device`` (transforms.py:81: a CPU feature consumes the
+    reference's own stream), or the injected ``phi``; the first ``identity_rows`` rows get angle 0 — the identity."""
+    phi = torch.rand(rows, device=device) * 4 * math.pi if phi is None else phi.to(device=device, dtype=torch.float32).clone()
+    phi[:identity_rows] = 0.0
+    return phi
 
 
 def symmetric_augmentation(xy: Tensor, num_augment: int = 8, first_augment: bool = False, phi: Tensor | None = None) -> Tensor:
-    """transforms.py:72-87: one random angle in [0, 4 pi) per (batchified) row, drawn on ``xy``'s device from the
-    global generator — a CPU tensor consumes the reference's stream exactly; the first ``B / num_augment`` rows keep
-    ``phi = 0`` (the identity) unless ``first_augment``. ``phi`` injects the angles (parity tests on the GPU, whose
-    generator is not the CPU's)."""
-    if phi is None:
-        phi = torch.rand(xy.shape[0], device=xy.device) * 4 * math.pi
-    else:
-        phi = phi.to(device=xy.device, dtype=xy.dtype).clone()
-    if not first_augment:
-        phi[: xy.shape[0] // num_augment] = 0.0
-    x, y = xy[..., [0]], xy[..., [1]]
-    return symmetric_transform(x, y, phi[:, None, None])
+    """transforms.py:72-87 on an (already batchified) feature [R, N, 2]: every row is rotated about the centre of the
+    unit square by its own angle and mirrored (axis swap) where the angle exceeds 2 pi; unless ``first_augment`` the
+    first ``R / num_augment`` rows keep angle 0. ``phi`` injects the angles (parity tests)."""
+    from . import kernels as K
+
+    rows = xy.shape[0]
+    phi = _draw_angles(rows, 0 if first_augment else rows // num_augment, xy.device, phi)
+    return K.augment_symmetric(xy.contiguous(), *_rotation_terms(phi))
 
 
 def min_max_normalize(x: Tensor) -> Tensor:
-    return (x - x.min()) / (x.max() - x.min())
+    lo, hi = torch.aminmax(x)
+    return (x - lo) / (hi - lo)
 
 
 def get_augment_function(augment_fn):
-    """transforms.py:94-103"""
+    """transforms.py:94-103: a callable passes through, the two names map to this module's functions."""
     if callable(augment_fn):
         return augment_fn
-    if augment_fn == "dihedral8":
-        return dihedral_8_augmentation_wrapper
-    if augment_fn == "symmetric":
-        return symmetric_augmentation
-    raise ValueError(f"Unknown augment_fn: {augment_fn}. Available options: 'symmetric', 'dihedral8' or a custom callable")
+    if augment_fn not in _AUGMENT_KINDS:
+        raise ValueError(f"Unknown augment_fn: {augment_fn}. Available options: 'symmetric', 'dihedral8' or a custom callable")
+    return symmetric_augmentation if augment_fn == "symmetric" else dihedral_8_augmentation_wrapper
 
 
-def _batchify(td, n: int):
-    """utils/ops.py:10-30 for the TensorDict stand-in / the real TensorDict."""
-    bs = td.batch_size[0]
-    return td.expand(n, bs).contiguous().view(bs * n)
+def _tile_rows(v: Tensor, times: int) -> Tensor:
+    """[B, ...] -> [times * B, ...], copy-major (the row order of utils/ops.py:10-30's batchify)."""
+    return v.unsqueeze(0).expand(times, *v.shape).reshape(times * v.shape[0], *v.shape[1:])
 
 
 class StateAugmentation:
-    """transforms.py:105-151, argument for argument: the batch is repeated ``num_augment`` times (aug-major) and every
-    feature in ``feats`` is passed through ``augment_fn`` — "symmetric" (the default: random rotations / reflections,
-    first block the identity), "dihedral8" (POMO: the 8 symmetries of the square) or a callable
-    ``fn(batchified_feature, num_augment)``. Pure elementwise work on the device the instances live on."""
+    """The reference's ``StateAugmentation`` (transforms.py:105-151), argument for argument, on the device kernels.
+
+    The output holds ``num_augment`` copies of the batch (copy-major rows); every feature in ``feats`` is replaced by its
+    augmented version: "symmetric" (default; a fresh angle draw per feature, first copy the identity), "dihedral8" (the 8
+    symmetries of the square; ``num_augment`` must be 8) or a callable ``fn(tiled_feature, num_augment)``. The named
+    groups run as one kernel over the UNTILED feature; the other keys are tiled by one strided copy each."""
 
     def __init__(self, num_augment: int = 8, augment_fn="symmetric", first_aug_identity: bool = True,
                  normalize: bool = False, feats: list | None = None):
         self.augmentation = get_augment_function(augment_fn)
-        assert not (self.augmentation == dihedral_8_augmentation_wrapper and num_augment != 8), (
+        self.kind = augment_fn if (not callable(augment_fn)) else None
+        assert not (self.kind == "dihedral8" and num_augment != 8), (
             "When using the `dihedral8` augmentation function, then num_augment must be 8")
         self.feats = ["locs"] if feats is None else feats
         self.num_augment = num_augment
         self.normalize = normalize
         self.first_aug_identity = first_aug_identity
 
+    def _augmented(self, base: Tensor) -> Tensor:
+        from . import kernels as K
+
+        a, b = self.num_augment, base.shape[0]
+        if self.kind == "dihedral8":
+            return K.augment_dihedral8(base.contiguous())
+        if self.kind == "symmetric":
+            return K.augment_symmetric(base.contiguous(), *_rotation_terms(_draw_angles(a * b, b, base.device)))
+        return self.augmentation(_tile_rows(base, a), a)
+
     def __call__(self, td):
-        td_aug = _batchify(td, self.num_augment)
+        a, b = self.num_augment, td.batch_size[0]
+        out = TensorDict({k: _tile_rows(v, a) for k, v in td.items() if k not in self.feats}, batch_size=[a * b])
         for feat in self.feats:
-            if not self.first_aug_identity:  # (the reference's own indexing: row `batch size`, node 0)
-                init_aug_feat = td_aug[feat][list(td.size()), 0].clone()
-            aug_feat = self.augmentation(td_aug[feat], self.num_augment)
+            new = self._augmented(td[feat])
             if self.normalize:
-                aug_feat = min_max_normalize(aug_feat)
+                new = min_max_normalize(new)
             if not self.first_aug_identity:
-                aug_feat[list(td.size()), 0] = init_aug_feat
-            td_aug[feat] = aug_feat
-        return td_aug
+                # the reference saves and restores ONE coordinate pair around the augmentation — row `batch size` (the
+                # first row of the second copy), node 0 — through its `[list(td.size()), 0]` index (transforms.py:139-147)
+                new[b, 0] = td[feat][0, 0]
+            out[feat] = new
+        return out
 
 
-# ---- POMO evaluation epilogue (zoo/pomo/model.py:88-143, phase != "train") ---------------------------
-
-def _unbatchify(x: Tensor, shape) -> Tensor:
-    """utils/ops.py:33-51 for tensors: [prod(shape)*B, ...] -> [B, *shape, ...]."""
-    for s in reversed(shape):
-        if s > 0:
-            sh = x.shape
-            x = x.view(s, sh[0] // s, *sh[1:]).permute(1, 0, *range(2, len(sh) + 1))
-    return x
-
-
-def _gather_by_index(src: Tensor, idx: Tensor, dim: int) -> Tensor:
-    """utils/ops.py:54-66"""
-    shape = list(src.shape)
-    shape[dim] = -1
-    idx = idx.view(idx.shape + (1,) * (src.dim() - idx.dim())).expand(shape)
-    out = src.gather(dim, idx)
-    return out.squeeze(dim) if idx.size(dim) == 1 else out
-
+# ---- POMO evaluation epilogue (zoo/pomo/model.py:88-143, phase != "train") -> csrc/augment.hip ----------------------
 
 def pomo_evaluate(policy, env, td, num_augment: int = 8, num_starts: int | None = None, phase: str = "test",
                   augment_fn="dihedral8", first_aug_identity: bool = True, feats: list | None = None) -> dict:
-    """val/test branch of ``POMO.shared_step``: augment (pomo/model.py:71-80 builds ``StateAugmentation(num_augment,
-    augment_fn, first_aug_identity, feats)`` with dihedral-8 as POMO's default), multistart-greedy rollout, best start
-    per augmentation, best augmentation per instance. ``td`` is a reset state (``env.reset(batch)``)."""
-    n_aug = num_augment
-    n_start = env.get_num_starts(td) if num_starts is None else num_starts
+    """The val / test branch of ``POMO.shared_step``: augment the reset state ``td``, roll every (augmentation, start)
+    out greedily, keep the best start per augmentation and the best augmentation per instance. The two maxima and the
+    two action gathers are ONE launch (``rl4co_pomo_best``) over the rollout's flat outputs, whose rows are ordered
+    start-major over augmentation-major over instances. Keys as the reference's: ``max_reward`` [B, A] and
+    ``best_multistart_actions`` [B, A, T] (several starts), ``max_aug_reward`` [B] and ``best_aug_actions`` [B, T] (several
+    augmentations), ``actions`` regrouped to [B, A, S, T]; plus ``reward_per_aug_start`` [B, A, S]."""
+    from . import kernels as K
+
+    n_aug = int(num_augment)
+    n_start = env.get_num_starts(td) if num_starts is None else int(num_starts)
     if n_aug > 1:
         td = StateAugmentation(num_augment=n_aug, augment_fn=augment_fn, first_aug_identity=first_aug_identity, feats=feats)(td)
     out = policy(td, env, phase=phase, num_starts=n_start)
-    reward = _unbatchify(out["reward"], (n_aug, n_start))
-    out["reward_per_aug_start"] = reward
+    a, s = max(n_aug, 1), max(n_start, 1)
+    flat_actions = out.get("actions", None)
+    best = K.pomo_best(out["reward"].contiguous(), None if flat_actions is None else flat_actions.contiguous(), a, s)
+    b = best["max_aug_reward"].shape[0]
+    out["reward_per_aug_start"] = out["reward"].view(s, a, b).permute(2, 1, 0)
     if n_start > 1:
-        max_reward, max_idxs = reward.max(dim=-1)
-        out["max_reward"] = max_reward
-        if out.get("actions", None) is not None:
-            actions = _unbatchify(out["actions"], (n_aug, n_start))
-            out["best_multistart_actions"] = _gather_by_index(actions, max_idxs, dim=max_idxs.dim())
-            out["actions"] = actions
+        out["max_reward"] = best["max_reward"]
+        if flat_actions is not None:
+            out["best_multistart_actions"] = best["best_multistart_actions"]
+            out["actions"] = flat_actions.view(s, a, b, -1).permute(2, 1, 0, 3)
     if n_aug > 1:
-        reward_ = out["max_reward"] if n_start > 1 else reward
-        max_aug_reward, max_idxs = reward_.max(dim=1)
-        out["max_aug_reward"] = max_aug_reward
-        if out.get("actions", None) is not None:
-            actions_ = out["best_multistart_actions"] if n_start > 1 else out["actions"]
-            out["best_aug_actions"] = _gather_by_index(actions_, max_idxs, dim=1)
+        # (one explicit start leaves a unit axis on the reference's result: its unbatchify keeps the start axis of size 1)
+        out["max_aug_reward"] = best["max_aug_reward"][:, None] if n_start == 1 else best["max_aug_reward"]
+        if flat_actions is not None:
+            out["best_aug_actions"] = best["best_aug_actions"]
     return out

@@ -37,9 +37,6 @@ class GraphedRollout:
         self.static_in = TensorDict({k: v.clone() for k, v in example.items() if torch.is_tensor(v)}, batch_size=[self.batch])
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         self._calls = 0
-        packed = getattr(policy, "_packed_encoder", None)
-        if packed is not None:
-            policy._packed_encoder().refresh()
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.inference_mode():
@@ -47,19 +44,51 @@ class GraphedRollout:
                 self._enqueue()()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize(dev)
-        self._packed_version = self._weights_version()
+        # Did the warm-up rollouts take the fused-encoder path? Only that path reads PACKED copies of the weights (every
+        # other encoder reads the live parameters inside the graph, so new weight values need nothing from us); the packed
+        # encoder is never built, refreshed or version-checked for a policy that does not use it
+        pe = getattr(policy, "_packed", None)
+        self._fused = pe is not None and bool(pe.t) and pe.version == pe._current_version()
+        self._captured: dict = {}
+        self._packed_version = None
+        if self._fused:
+            # the captured launches point at THESE buffers for as long as the graph lives: hold them (a later eager
+            # rollout after a weight update rebinds pe.t to fresh tensors — without this reference the captured ones
+            # would be freed under the graph)
+            self._captured = dict(pe.t)
+            self._packed_version = pe.version
         self.graph = torch.cuda.CUDAGraph()
         with torch.inference_mode(), torch.cuda.graph(self.graph):
             self._finish = self._enqueue()
+        if self._fused:
+            assert all(pe.t[k] is v for k, v in self._captured.items()), "the capture re-packed the encoder weights"
 
     def _enqueue(self):
         td = self.env.reset(self.static_in)
         return self.policy(td, self.env, phase="test", decode_type=self.decode_type, philox_seed_dev=self.seed_dev,
                            _defer_finish=True, **self.kw)
 
-    def _weights_version(self):
-        pe = self.policy._packed_encoder()
-        return pe._current_version()
+    def _sync_packed_weights(self) -> None:
+        """New weight values (or a packed encoder rebound by an eager rollout in between): re-pack, copy INTO the buffers
+        the captured launches point at, and hand those buffers back to the packed encoder. The captured buffers hold the
+        values of version `_packed_version` — nobody else writes them — so an unchanged version needs no copy whatever
+        `pe.t` currently points at."""
+        pe = self.policy._packed
+        ver = pe._current_version()
+        if ver == self._packed_version:
+            return
+        fresh = pe.refresh()
+        for k, held in self._captured.items():
+            new = fresh.get(k)
+            if torch.is_tensor(held):
+                if not torch.is_tensor(new) or new.shape != held.shape or new.dtype != held.dtype:
+                    raise RuntimeError(f"packed encoder entry {k!r} changed layout: capture a new GraphedRollout")
+                if new.data_ptr() != held.data_ptr():
+                    held.copy_(new)
+            elif new is not None:
+                raise RuntimeError(f"packed encoder entry {k!r} appeared after the capture: capture a new GraphedRollout")
+        pe.t = dict(self._captured)
+        self._packed_version = ver
 
     def __call__(self, batch) -> dict:
         if batch.batch_size[0] != self.batch:
@@ -69,18 +98,8 @@ class GraphedRollout:
                 src = batch[k]
                 if src.data_ptr() != v.data_ptr():
                     v.copy_(src)
-            # new weight values: re-pack INTO the buffers the captured launches point at
-            ver = self._weights_version()
-            if ver != self._packed_version:
-                pe = self.policy._packed_encoder()
-                old = dict(pe.t)
-                pe.refresh()
-                for k, t_new in pe.t.items():
-                    t_old = old.get(k)
-                    if torch.is_tensor(t_old) and torch.is_tensor(t_new) and t_old.data_ptr() != t_new.data_ptr():
-                        t_old.copy_(t_new)
-                        pe.t[k] = t_old
-                self._packed_version = ver
+            if self._fused:
+                self._sync_packed_weights()
             self._calls += 1
             self.seed_dev.fill_(self._calls * 0x9E3779B97F4A7C15 % (1 << 62))
             self.graph.replay()

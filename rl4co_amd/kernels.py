@@ -317,7 +317,11 @@ def am_decode(
     a.all_logps = _ptr(None if all_logps is None else _dev(all_logps, torch.float32, "all_logps"))
     a.entropy = _ptr(None if entropy is None else _dev(entropy, torch.float32, "entropy"))
     a.n_steps = _ptr(None if n_steps is None else _dev(n_steps, torch.int32, "n_steps"))
-    a.steps_summary = _ptr(None if steps_summary is None else _dev(steps_summary, torch.int32, "steps_summary"))
+    if steps_summary is not None:  # [max steps, sum steps, rows low, rows high]: the row counter is ONE 64-bit word
+        _dev(steps_summary, torch.int32, "steps_summary")
+        if steps_summary.numel() < 4 or steps_summary.data_ptr() % 8:
+            raise ValueError("steps_summary must be 4 int32 words on an 8-byte boundary (rl4co_am_decode_args.steps_summary)")
+    a.steps_summary = _ptr(steps_summary)
     a.err = _ptr(_dev(err, torch.int32, "err"))
     st = _lib.lib().rl4co_am_decode(C.byref(a), _stream())
     _lib.check(st, "rl4co_am_decode")
@@ -465,4 +469,58 @@ def uniform(shape, low: float, high: float, seed: int, stream_id: int, device, d
     st = _lib.lib().rl4co_uniform_f32(_ptr(out), out.numel(), float(low), float(high), int(seed) & ((1 << 64) - 1), int(stream_id),
                                       0 if demand_capacity is None else 1, float(demand_capacity or 1.0), _stream())
     _lib.check(st, "rl4co_uniform_f32")
+    return out
+
+
+# ---- N3: state augmentation and the POMO evaluation epilogue (csrc/augment.hip) -------------------------------------
+
+def augment_dihedral8(xy: Tensor) -> Tensor:
+    """[B, N, 2] -> [8 * B, N, 2], aug-major: the 8 symmetries of the unit square (data/transforms.py:16-46)."""
+    b, n, two = xy.shape
+    assert two == 2
+    xy = _dev(xy, torch.float32, "xy")
+    out = torch.empty((8 * b, n, 2), dtype=torch.float32, device=xy.device)
+    st = _lib.lib().rl4co_augment_dihedral8_f32(_ptr(xy), b, n, _ptr(out), _stream())
+    _lib.check(st, "rl4co_augment_dihedral8_f32")
+    return out
+
+
+def augment_symmetric(xy: Tensor, cos_phi: Tensor, sin_phi: Tensor, swap_axes: Tensor, offset: float = 0.5) -> Tensor:
+    """[B, N, 2] and one (cos, sin, swap) per OUTPUT row [A * B] -> [A * B, N, 2] (data/transforms.py:49-69)."""
+    b, n, two = xy.shape
+    rows = cos_phi.numel()
+    assert two == 2 and rows % b == 0 and sin_phi.numel() == rows and swap_axes.numel() == rows
+    xy = _dev(xy, torch.float32, "xy")
+    out = torch.empty((rows, n, 2), dtype=torch.float32, device=xy.device)
+    st = _lib.lib().rl4co_augment_symmetric_f32(_ptr(xy), _ptr(_dev(cos_phi, torch.float32, "cos_phi")),
+                                                _ptr(_dev(sin_phi, torch.float32, "sin_phi")), _ptr(_u8(swap_axes, "swap_axes")),
+                                                b, rows // b, n, float(offset), _ptr(out), _stream())
+    _lib.check(st, "rl4co_augment_symmetric_f32")
+    return out
+
+
+def pomo_best(reward: Tensor, actions: Tensor | None, num_augment: int, num_starts: int) -> dict:
+    """Best start per augmentation and best augmentation per instance of a multistart rollout over an augmented batch
+    (rows (s * A + a) * B + b), with the selected action rows, in one launch (zoo/pomo/model.py:112-140)."""
+    a, s = int(num_augment), int(num_starts)
+    rows = reward.numel()
+    assert rows % (a * s) == 0
+    b = rows // (a * s)
+    reward = _dev(reward.reshape(-1), torch.float32, "reward")
+    dev = reward.device
+    out = {"max_reward": torch.empty((b, a), dtype=torch.float32, device=dev),
+           "best_start": torch.empty((b, a), dtype=torch.int64, device=dev),
+           "max_aug_reward": torch.empty(b, dtype=torch.float32, device=dev),
+           "best_aug": torch.empty(b, dtype=torch.int64, device=dev)}
+    t = 0
+    if actions is not None:
+        actions = _dev(actions, torch.int64, "actions")
+        assert actions.shape[0] == rows
+        t = actions.shape[1]
+        out["best_multistart_actions"] = torch.empty((b, a, t), dtype=torch.int64, device=dev)
+        out["best_aug_actions"] = torch.empty((b, t), dtype=torch.int64, device=dev)
+    st = _lib.lib().rl4co_pomo_best(_ptr(reward), _ptr(actions), a, s, b, t, _ptr(out["max_reward"]), _ptr(out["best_start"]),
+                                    _ptr(out["max_aug_reward"]), _ptr(out["best_aug"]), _ptr(out.get("best_multistart_actions")),
+                                    _ptr(out.get("best_aug_actions")), _stream())
+    _lib.check(st, "rl4co_pomo_best")
     return out

@@ -653,7 +653,10 @@ class AttentionModelPolicy(nn.Module):
         temperature = decoding_kwargs.pop("temperature", self.temperature)
         tanh_clipping = decoding_kwargs.pop("tanh_clipping", self.tanh_clipping)
         mask_logits = decoding_kwargs.pop("mask_logits", self.mask_logits)
-        store_all_logp = decoding_kwargs.pop("store_all_logp", return_entropy)
+        # (not a reference argument) hand the [B, T, N] log-softmax of every step back as out["all_logp"]: the parity
+        # tests and bench.py's parity block measure argmax regret / per-step agreement along a forced trajectory with it
+        return_all_logp = bool(decoding_kwargs.pop("return_all_logp", False))
+        store_all_logp = decoding_kwargs.pop("store_all_logp", return_entropy) or return_all_logp
         select_best = decoding_kwargs.pop("select_best", False)
         num_starts = decoding_kwargs.pop("num_starts", None)
         num_samples = decoding_kwargs.pop("num_samples", None)
@@ -708,8 +711,9 @@ class AttentionModelPolicy(nn.Module):
         if self.env_name == "pdp" and not getattr(env, "force_start_at_depot", False):
             horizon = min(horizon, n - 1)  # the depot is never visited: exactly one step per location (no padding
             #                                column: a trailing 0 would read as a depot visit in check_solution_validity)
-        # status word read back ONCE per rollout: [sticky error bits, longest trajectory, streamed instance-steps]
-        status = torch.zeros(4, dtype=torch.int32, device=device)
+        # status words read back ONCE per rollout: [sticky error bits, -, longest trajectory, streamed instance-steps,
+        # cache rows streamed (one 64-bit counter: low word, high word)]
+        status = torch.zeros(6, dtype=torch.int32, device=device)
         err = status[:1]
 
         # pre_decoder_hook (decoding.py:306-326): with multistart the first action is imposed per
@@ -750,7 +754,7 @@ class AttentionModelPolicy(nn.Module):
             cache, state, mode=mode, max_steps=tmax - t0, t0=t0, actions=out_actions, logps=logps, err=err,
             tanh_clipping=tanh_clipping, temperature=temperature, mask_inner=self.decoder.mask_inner,
             mask_logits=mask_logits, exp_noise=exp_noise, philox_seed=philox_seed, philox_seed_dev=seed_dev,
-            forced_actions=forced, all_logps=all_logps, steps_summary=status[1:4],
+            forced_actions=forced, all_logps=all_logps, steps_summary=status[2:6],
         )
         if self.decode_events is not None:
             ev1.record()
@@ -770,7 +774,7 @@ class AttentionModelPolicy(nn.Module):
         if (native_env and self.env_name in ("tsp", "pdp", "cvrp", "cvrptw") and calc_reward and mode != "evaluate"
                 and (checked or not env.check_solution) and not (n_rep > 0 and select_best)):
             td_early = self._final_td(td, state, n_rep)
-            reward_early = env.get_reward(td_early, out_actions, check_solution=False, horizon=(status[1:2], t0))
+            reward_early = env.get_reward(td_early, out_actions, check_solution=False, horizon=(status[2:3], t0))
         if self._bwd_err is not None:  # sticky bits of the previous step's backward kernel ride on this read-back
             status[:1].bitwise_or_(self._bwd_err)
             self._bwd_err = None
@@ -783,7 +787,8 @@ class AttentionModelPolicy(nn.Module):
         def finish():
             nonlocal out_actions, logps, all_logps, td_early, reward_early
             out_actions, logps, all_logps, td_early, reward_early = launched  # re-runnable: a graph replay refills the same buffers
-            err_bits, horizon_used, streamed, rows_read = status.tolist()  # one 16-byte read-back, no reduction launches
+            err_bits, _, horizon_used, streamed, rows_lo, rows_hi = status.tolist()  # one 24-byte read-back, no reduction launches
+            rows_read = (rows_hi << 32) | (rows_lo & 0xFFFFFFFF)
             t_used = t0 + int(horizon_used)
             self.last_instance_steps = int(streamed)  # instance-steps the decode launch really streamed
             self.last_rows_read = int(rows_read)      # cache rows (per plane) it read from HBM doing so
@@ -865,6 +870,8 @@ class AttentionModelPolicy(nn.Module):
                 entropy = -(lp.exp() * lp).sum(dim=-1).sum(dim=1)
                 assert entropy.isfinite().all(), "Entropy is not finite"
                 outdict["entropy"] = entropy
+            if return_all_logp:
+                outdict["all_logp"] = all_logps
             if return_hidden:
                 outdict["hidden"] = hidden
             if return_init_embeds:

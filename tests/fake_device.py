@@ -158,4 +158,7 @@ def cpu_device(monkeypatch):
     monkeypatch.setattr(K, "pctsp_step", _pctsp_step)
     monkeypatch.setattr(K, "pctsp_check_solution", _pctsp_check)
     monkeypatch.setattr(K, "am_decode", _am_decode)
+    monkeypatch.setattr(K, "augment_dihedral8", c_oracle.augment_dihedral8)
+    monkeypatch.setattr(K, "augment_symmetric", c_oracle.augment_symmetric)
+    monkeypatch.setattr(K, "pomo_best", c_oracle.pomo_best)
     return "cpu"

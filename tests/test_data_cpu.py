@@ -51,7 +51,7 @@ def test_npz_matches_reference_loader(tmp_path):
 
 
 @needs_reference
-def test_dihedral8_matches_reference_transform():
+def test_dihedral8_matches_reference_transform(cpu_device):
     import importlib
 
     from rl4co_amd.data import StateAugmentation
@@ -71,7 +71,7 @@ def test_dihedral8_matches_reference_transform():
 @pytest.mark.parametrize("kw", [dict(num_augment=8), dict(num_augment=4, first_aug_identity=False),
                                 dict(num_augment=5, normalize=True), dict(num_augment=8, feats=["locs", "depot2"]),
                                 dict(num_augment=8, augment_fn="dihedral8", first_aug_identity=False)])
-def test_state_augmentation_matches_reference_transform(kw):
+def test_state_augmentation_matches_reference_transform(kw, cpu_device):
     """rl4co/data/transforms.py:49-151 argument for argument: the symmetric (SymNCO) augmentation consumes the global
     torch generator like the reference (same seed -> the same rows, bit for bit), first-block identity,
     `first_aug_identity=False`'s own row restore, min-max normalisation, several features."""
@@ -94,7 +94,7 @@ def test_state_augmentation_matches_reference_transform(kw):
         assert torch.equal(ours[k], theirs[k]), k
 
 
-def test_symmetric_augmentation_is_an_isometry_with_identity_first_block():
+def test_symmetric_augmentation_is_an_isometry_with_identity_first_block(cpu_device):
     """Size-independent properties (also what the GPU test checks at full size): rotations / reflections about the
     centre keep every pairwise distance; the first block is untouched; injected angles reproduce the draw."""
     from rl4co_amd.data import symmetric_augmentation
@@ -134,7 +134,15 @@ def test_pomo_evaluate_epilogue(cpu_device):
     flat_reward = out["reward"]
     want = R.unbatchify(flat_reward, (8, 5))
     assert torch.equal(out["reward_per_aug_start"], want)
+    assert torch.equal(out["max_reward"], want.max(-1).values)
     assert torch.equal(out["max_aug_reward"], want.max(-1).values.max(-1).values)
+    flat_actions = out["actions"].permute(2, 1, 0, 3).reshape(-1, 20)  # back to the rollout's row order
+    acts = R.unbatchify(flat_actions, (8, 5))
+    assert torch.equal(out["actions"], acts)
+    idx = want.max(-1).indices
+    best_ms = R.gather_by_index(acts, idx, dim=idx.dim())
+    assert torch.equal(out["best_multistart_actions"], best_ms)
+    assert torch.equal(out["best_aug_actions"], R.gather_by_index(best_ms, want.max(-1).values.max(1).indices, dim=1))
     # the selected tour really has the selected reward (on the augmentation-0 coordinates all
     # symmetric copies have the same length up to rounding)
     tours = out["best_aug_actions"]
@@ -142,6 +150,48 @@ def test_pomo_evaluate_epilogue(cpu_device):
     torch.testing.assert_close(-lengths, out["max_aug_reward"], rtol=1e-5, atol=1e-5)
     # augmentation can only help: best over 8 symmetries >= the identity block's best start
     assert bool((out["max_aug_reward"] >= out["max_reward"][:, 0] - 1e-6).all())
+
+
+@needs_reference
+@pytest.mark.parametrize("a,s,b,t", [(8, 6, 16, 20), (1, 7, 5, 9), (8, 1, 4, 3), (3, 100, 7, 50), (70, 2, 3, 4)])
+def test_pomo_best_restatement_equals_reference_epilogue(a, s, b, t):
+    """oracle_pomo_best (the host restatement of rl4co_pomo_best, which the GPU tests pin the kernel to) against the
+    reference's own unbatchify / max / gather_by_index (utils/ops.py:33-66 as used by zoo/pomo/model.py:112-140), with
+    many exact ties in the rewards: the first maximum wins on both axes."""
+    import importlib
+
+    from oracle import c_oracle
+
+    ref_import.install()
+    ops = importlib.import_module("rl4co.utils.ops")
+    torch.manual_seed(a * 1000 + s)
+    reward = torch.randint(0, 4, (s * a * b,)).float() * -0.5  # four distinct values: ties everywhere
+    actions = torch.randint(0, 50, (s * a * b, t))
+    got = c_oracle.pomo_best(reward, actions, a, s)
+    r = ops.unbatchify(reward, (a, s))
+    acts = ops.unbatchify(actions, (a, s))
+    r = r.view(b, a, s)
+    acts = acts.view(b, a, s, t)
+    max_reward, idx = r.max(dim=-1)
+    assert torch.equal(got["max_reward"], max_reward) and torch.equal(got["best_start"], idx)
+    best_ms = ops.gather_by_index(acts, idx, dim=idx.dim()).view(b, a, t)
+    assert torch.equal(got["best_multistart_actions"], best_ms)
+    max_aug, idx2 = max_reward.max(dim=1)
+    assert torch.equal(got["max_aug_reward"], max_aug) and torch.equal(got["best_aug"], idx2)
+    assert torch.equal(got["best_aug_actions"], ops.gather_by_index(best_ms, idx2, dim=1).view(b, t))
+    no_actions = c_oracle.pomo_best(reward, None, a, s)
+    assert torch.equal(no_actions["max_aug_reward"], max_aug) and "best_aug_actions" not in no_actions
+
+
+def test_augmentation_refuses_cpu_tensors_without_the_device():
+    """No CPU fallback: outside the fake-device fixture the augmentation kernels reject host tensors loudly."""
+    from rl4co_amd import _lib
+    from rl4co_amd.data import StateAugmentation
+    from rl4co_amd.tensordict import TensorDict
+
+    td = TensorDict({"locs": torch.rand(4, 5, 2)}, batch_size=[4])
+    with pytest.raises(_lib.Rl4coLibraryError, match="no CPU fallback"):
+        StateAugmentation(8, augment_fn="dihedral8")(td)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -24,14 +24,48 @@ def _td(d, b):
 
 
 def test_dihedral8_on_device_is_exact():
-    from rl4co_amd.data import StateAugmentation, dihedral_8_augmentation
+    """rl4co_augment_dihedral8_f32 == its host restatement (which tests/test_data_cpu.py holds against the reference
+    source) bit for bit, at the full C2 batch as well; block a of the output is the a-th symmetry of the square."""
+    from oracle import c_oracle
+    from rl4co_amd import kernels as K
+    from rl4co_amd.data import StateAugmentation
 
     torch.manual_seed(0)
-    locs = torch.rand(64, 100, 2)
-    cpu = dihedral_8_augmentation(locs)
-    dev = StateAugmentation(8, augment_fn="dihedral8")(_td({"locs": locs.cuda()}, 64))["locs"]
-    assert dev.is_cuda and torch.equal(dev.cpu(), cpu)
-    assert torch.equal(dev[:64].cpu(), locs)
+    for b, n in ((64, 100), (4096, 100), (3, 1), (17, 501)):
+        locs = torch.rand(b, n, 2)
+        dev = StateAugmentation(8, augment_fn="dihedral8")(_td({"locs": locs.cuda(), "other": torch.arange(b).cuda()}, b))
+        assert dev["locs"].is_cuda and torch.equal(dev["locs"].cpu(), c_oracle.augment_dihedral8(locs))
+        assert torch.equal(dev["locs"][:b].cpu(), locs)                                  # identity block
+        assert torch.equal(dev["locs"][4 * b: 5 * b].cpu(), locs.flip(-1))               # (y, x)
+        assert torch.equal(dev["locs"][3 * b: 4 * b].cpu(), 1 - locs)                    # (1 - x, 1 - y)
+        assert torch.equal(dev["other"].cpu(), torch.arange(b).repeat(8))                # other keys: tiled copy-major
+        assert torch.equal(K.augment_dihedral8(locs.cuda()), dev["locs"])
+
+
+def test_symmetric_kernel_and_pomo_best_kernel_equal_their_host_restatements():
+    """Same (cos, sin, swap) in -> same bits out (the arithmetic order is part of the contract: no fma); the fused
+    best-of reduction + action gathers against oracle_pomo_best on rewards full of exact ties."""
+    from oracle import c_oracle
+    from rl4co_amd import kernels as K
+
+    torch.manual_seed(1)
+    for b, a, n in ((32, 8, 50), (5, 3, 7), (4096, 8, 100)):
+        xy = torch.rand(b, n, 2)
+        phi = torch.rand(a * b) * 4 * 3.141592653589793
+        c, s_, sw = torch.cos(phi), torch.sin(phi), phi > 2 * 3.141592653589793
+        want = c_oracle.augment_symmetric(xy, c, s_, sw)
+        got = K.augment_symmetric(xy.cuda(), c.cuda(), s_.cuda(), sw.cuda())
+        assert torch.equal(got.cpu(), want)
+    for a, s, b, t in ((8, 6, 16, 20), (1, 7, 5, 9), (8, 1, 4, 3), (8, 100, 512, 100), (70, 2, 3, 4)):
+        reward = torch.randint(0, 4, (s * a * b,)).float() * -0.5
+        actions = torch.randint(0, 100, (s * a * b, t))
+        want = c_oracle.pomo_best(reward, actions, a, s)
+        got = K.pomo_best(reward.cuda(), actions.cuda(), a, s)
+        assert sorted(got) == sorted(want)
+        for k in want:
+            assert torch.equal(got[k].cpu(), want[k]), (k, a, s, b, t)
+        lean = K.pomo_best(reward.cuda(), None, a, s)
+        assert torch.equal(lean["max_aug_reward"].cpu(), want["max_aug_reward"]) and "best_aug_actions" not in lean
 
 
 @pytest.mark.parametrize("tag,kw", [("a8", dict(num_augment=8)),

@@ -74,3 +74,57 @@ def test_device_horizon_reward_equals_host_horizon_reward():
         want = K.tour_length(locs, padded[:, :t].contiguous(), prepend_depot=True, negate=True)
         got = K.tour_length(locs, padded, prepend_depot=True, negate=True, horizon=(steps, 1))
         assert torch.equal(got, want), t
+
+
+def test_graphed_rollout_survives_an_eager_rollout_after_a_weight_update():
+    """graphed call, optimizer step, EAGER rollout (which rebinds the packed encoder to fresh
+    tensors), graphed call again — the replay must read the new weights from the buffers it captured, not freed or
+    stale memory. Also through a train()/eval() toggle, which is part of the packed encoder's version."""
+    from rl4co_amd.graph import GraphedRollout
+
+    pol, env, d1, d2 = _setup("tsp", 50, 256)
+    g = GraphedRollout(pol, env, d1, decode_type="greedy")
+    assert g._fused
+    first = g(d1)["reward"].clone()
+    for round_ in range(3):
+        with torch.no_grad():
+            for p in pol.parameters():
+                p.mul_(1.03)
+        if round_ == 1:
+            pol.train()
+            pol.eval()
+        with torch.inference_mode():
+            eager = {k: v.clone() for k, v in pol(env.reset(d1), env, phase="test", decode_type="greedy").items()
+                     if k in ("actions", "reward")}
+        filler = [torch.empty(1 << 22, device="cuda").normal_() for _ in range(8)]  # recycle whatever was freed
+        out = g(d1)
+        assert torch.equal(out["actions"], eager["actions"]) and torch.equal(out["reward"], eager["reward"]), round_
+        del filler
+    assert not torch.equal(first, out["reward"])
+    # a second eager rollout must keep working on the (captured) buffers the packed encoder now points at
+    with torch.inference_mode():
+        again = pol(env.reset(d2), env, phase="test", decode_type="greedy")["reward"]
+    assert torch.equal(g(d2)["reward"], again)
+
+
+def test_graphed_rollout_leaves_the_packed_encoder_alone_when_the_fused_path_is_not_taken():
+    """fp32 regime (torch encoder inside the graph): no packed encoder is built; weight updates are read live."""
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.graph import GraphedRollout
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    torch.manual_seed(0)
+    pol = AttentionModelPolicy("tsp", normalization="layer").cuda().eval()  # the fused encoder cannot pack a layer norm
+    env = get_env("tsp", generator_params=dict(num_loc=20, device="cuda"), device="cuda")
+    torch.manual_seed(1)
+    data = env.generator(batch_size=[64])
+    g = GraphedRollout(pol, env, data, decode_type="greedy")
+    assert not g._fused and (pol._packed is None or not pol._packed.t)
+    before = g(data)["reward"].clone()
+    with torch.no_grad():
+        for p in pol.encoder.parameters():
+            p.mul_(1.1)
+    with torch.inference_mode():
+        want = pol(env.reset(data), env, phase="test", decode_type="greedy")["reward"]
+    after = g(data)["reward"]
+    assert torch.equal(after, want) and not torch.equal(before, after)
