@@ -33,8 +33,9 @@ beside it as ``algorithmic_bytes_contract`` / ``contract_frac``. ``traffic`` = H
 rocprofv3 --pmc passes of the same leg (``traffic_source`` names the committed file; a counter pass cannot run
 inside this process). ``cpu_baseline``: the reference path (torch restatement, pinned bit-exact to the reference's
 own source by oracle/gen_golden.py; kind "port") timed on this box's host cores on a bounded sample.
-``parity``: greedy trajectories of the fp32 parity configuration (folded cache and the reference's own association)
-and of the benchmarked bf16 configuration against the reference's 4096 tours of configs[1] (tests/golden).
+``parity``: for every inference leg, the fp32 parity configuration and the benchmarked bf16 configuration against the
+reference's own rollouts (fp32 and under bf16 autocast) of TRAINED weights at the leg's full size
+(tests/golden/trained; tools/trained_parity.py): flips proven near-ties, identical tours, per-decision agreement.
 """
 from __future__ import annotations
 
@@ -413,10 +414,64 @@ class Bench:
         })
         return res
 
-    # -- parity against the reference's tours of configs[1] ------------------------------------------------------------
-    def parity(self) -> dict | None:
-        """Policy-level greedy parity on the golden inputs of configs[1] (seeded exactly as oracle/gen_golden.py):
-        GPU encoder + decode + reward against the reference's 4096 CPU tours in tests/golden."""
+    # -- parity against the reference's tours, every inference leg --------------------------------------------------------
+    def parity(self, legs) -> dict | None:
+        """Policy-level parity on TRAINED weights (tests/golden/weights, trained by tools/train_sharp.py) against the
+        reference's own rollouts of the same weights and seeded instances at the full size of each inference leg's
+        BASELINE config (tests/golden/trained, made by oracle/gen_trained_golden.py from the verbatim reference source):
+
+        * ``fp32``: the parity configuration (torch fp32 encoder on the GPU, fp32 planes) vs the reference's fp32 run —
+          flips and the proof that each is a near-tie (``flip_regret_max``: the product's own log-prob gap between its
+          choice and the reference's at the first divergent step);
+        * ``bf16``: the benchmarked configuration (MFMA encoder, bf16 planes) vs the reference's run under
+          ``torch.autocast(bfloat16)`` and vs its fp32 run — identical tours, per-decision agreement, mean-reward gap;
+        * sampling legs: the reference's seeded multinomial stream injected into the kernel.
+        The random-init golden of round 2 (every greedy step a near-tie) is kept as ``random_init`` for continuity."""
+        from tools import trained_parity as TP
+
+        cases = {"c2_greedy": ("t2_tsp100_b4096_greedy", "greedy"), "c2_sampling": ("t2_tsp100_b4096_sampling", "sampling"),
+                 "c3_greedy": ("t3_cvrp100_b4096_greedy", "greedy"), "c5_sampling": ("t5_cvrp500_b1024_sampling", "sampling")}
+        try:
+            TP.manifest()
+        except (OSError, ValueError):
+            return None
+        out = {"weights": "tests/golden/weights/*.safetensors (AM-3L trained by tools/train_sharp.py; loaded into the reference's "
+                          "own policy class by oracle/gen_trained_golden.py)",
+               "goldens": "tests/golden/trained/*.npz (verbatim reference source, CPU, fp32 and bf16 autocast)"}
+        dev = self.device
+        for leg in legs:
+            if leg not in cases:
+                continue
+            name, decode = cases[leg]
+            case = TP.TrainedCase(name)
+            rec = {"case": name, "batch": case.batch}
+            if decode == "greedy":
+                rec["fp32"] = TP.compare(case, "fp32", dev, against="fp32")
+                rec["bf16_vs_reference_bf16_autocast"] = TP.compare(case, "bf16", dev, against="bf16")
+                rec["bf16_vs_reference_fp32"] = TP.compare(case, "bf16", dev, against="fp32")
+                rec["reference_bf16_vs_reference_fp32_identical"] = case.meta.get("reference_bf16_vs_fp32_identical")
+            else:
+                rec["fp32_reference_noise"] = TP.compare(case, "fp32", dev, against="fp32", decode="sampling", regret=False)
+                rec["bf16_reference_noise"] = TP.compare(case, "bf16", dev, against="fp32", decode="sampling", regret=False)
+                if leg == "c5_sampling":  # configs[4] greedy at the benchmarked batch: the bf16 pipeline vs the reference's
+                    g = TP.TrainedCase("t5_cvrp500_b1024_greedy")
+                    rec["greedy_fp32"] = TP.compare(g, "fp32", dev, against="fp32")
+                    rec["greedy_bf16_vs_reference_bf16_autocast"] = TP.compare(g, "bf16", dev, against="bf16")
+            out[leg] = rec
+            torch.cuda.empty_cache()
+        head = out.get("c2_greedy")
+        if head:
+            out["fp32_flips"] = head["fp32"]["flips"]
+            out["fp32_flip_regret_max"] = head["fp32"]["flip_regret_max"]
+            out["bf16_identical_trajectories"] = head["bf16_vs_reference_bf16_autocast"]["identical"]
+            out["bf16_identical_frac"] = head["bf16_vs_reference_bf16_autocast"]["identical_frac"]
+            out["bf16_step_agreement"] = head["bf16_vs_reference_bf16_autocast"]["step_agreement"]
+        out["random_init"] = self.parity_random_init()
+        return out
+
+    def parity_random_init(self) -> dict | None:
+        """Round 2's block: greedy tours of configs[1] on seeded RANDOM-INIT weights (a near-uniform policy: every step a
+        near-tie at the 1e-2 level) against the reference's (tests/golden/c2_tsp100_b4096_greedy.npz)."""
         import numpy as np
 
         from rl4co_amd.envs import get_env
@@ -437,8 +492,7 @@ class Bench:
             return {"error": "seeded inputs differ from the golden run"}
         data = data.to(self.device)
         env = get_env("tsp", generator_params=dict(num_loc=100, device=self.device), device=self.device)
-        out = {"golden": "tests/golden/c2_tsp100_b4096_greedy.npz (the reference's own source on CPU, oracle/gen_golden.py)",
-               "of": 4096}
+        out = {"golden": "tests/golden/c2_tsp100_b4096_greedy.npz", "of": 4096}
         configs = {
             "fp32_fold_on": dict(cache_dtype=torch.float32),
             "fp32_fold_off": dict(cache_dtype=torch.float32, fold=False),
@@ -453,16 +507,8 @@ class Bench:
             with torch.inference_mode():
                 o = pol(env.reset(data.clone()), env, phase="test", decode_type="greedy")
             same = (o["actions"] == ref_actions).all(1)
-            rec = {"identical_trajectories": int(same.sum()), "flips": int((~same).sum()),
-                   "rewards_bit_identical_on_identical_trajectories": bool(torch.equal(o["reward"][same], ref_reward[same])),
-                   "mean_reward": float(o["reward"].mean()), "mean_reward_reference": float(ref_reward.mean())}
-            out[name] = rec
-        out["fp32_flips"] = out["fp32_fold_on"]["flips"]
-        out["fp32_flips_fold_off"] = out["fp32_fold_off"]["flips"]
-        out["bf16_identical_frac"] = out["bf16"]["identical_trajectories"] / 4096
-        out["note"] = ("fp32 rows: torch fp32 encoder on the GPU (rocBLAS / SDPA orders differ from the CPU reference's oneDNN) + "
-                       "fp32 planes; bf16 row: the benchmarked configuration (MFMA encoder, bf16 planes) — inputs change at "
-                       "the 3-digit level, trajectories legitimately diverge, tour quality is what must match")
+            out[name] = {"identical_trajectories": int(same.sum()), "flips": int((~same).sum()),
+                         "mean_reward": float(o["reward"].mean()), "mean_reward_reference": float(ref_reward.mean())}
         return out
 
 
@@ -612,8 +658,8 @@ def main() -> None:
             line["train_ms_per_step"] = results["c4_train"]["ms_per_step"]
             line["rccl_ranks"] = results["c4_train"]["collective"]["ranks"]
         if world == 1 and not args.no_parity:
-            log("parity vs the reference's tours of configs[1]")
-            line["parity"] = bench.parity()
+            log("parity vs the reference's tours (trained weights, every inference leg)")
+            line["parity"] = bench.parity(legs)
         if world == 1 and not args.no_cpu_baseline and head_name != "c4_train":
             line["cpu_baseline"] = cpu_baseline(env_name, num_loc, args.cpu_sample_batch, repeats=2)
             line["cpu_baseline"]["gpu_over_cpu"] = head["value"] / line["cpu_baseline"]["value"]

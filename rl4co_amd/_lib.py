@@ -195,3 +195,18 @@ def raise_for_error_bits(bits: int) -> None:
         if bits & bit:
             raise AssertionError(msg)
     raise AssertionError(f"rollout kernel reported error bits {bits:#x}")
+
+
+_warned: set[str] = set()
+
+
+def warn_fallback(key: str, message: str) -> None:
+    """One ``RuntimeWarning`` per distinct reason when a part of the path leaves the hand-written kernels for the torch
+    implementation (a shape or precision regime no kernel serves). The results stay correct — torch runs the same
+    algebra — but the speed is torch's; silent fallbacks hid that."""
+    if key in _warned:
+        return
+    _warned.add(key)
+    import warnings
+
+    warnings.warn(f"rl4co_amd: {message}", RuntimeWarning, stacklevel=3)

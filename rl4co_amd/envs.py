@@ -279,6 +279,17 @@ class RL4COEnvBase:
             self.check_solution_validity(td, actions)
         return self._get_reward(td, actions) if horizon is None else self._get_reward(td, actions, horizon=horizon)
 
+    def accepts_reward_horizon(self) -> bool:
+        """True when ``_get_reward`` takes the device-side ``horizon`` (this package's tour-length environments). A user
+        subclass that overrides ``_get_reward(self, td, actions)`` with the reference's two-argument signature does not:
+        the policy then computes its reward after the read-back, from the unpadded actions, as the reference does."""
+        import inspect
+
+        try:
+            return "horizon" in inspect.signature(type(self)._get_reward).parameters
+        except (TypeError, ValueError):
+            return False
+
     # -- RL4COEnvBase.dataset / load_data (base.py:234-286) ----------------------------------------
     def dataset(self, batch_size=(), phase: str = "train", filename: str | None = None):
         """Instances of one phase as a dataset: loaded from ``<phase>_file`` / ``filename`` (npz, straight to this

@@ -157,6 +157,12 @@ class _EncoderLayer(nn.Sequential):
                                                *(lin.weight for lin in ffn.lins))):
                 x = train_ops.attention_block(x, attn, self[1])
                 return train_ops.mlp_block(x, ffn, self[3])
+            from . import _lib as _l
+
+            _l.warn_fallback(f"train-block/{tuple(x.shape[1:])}/{self[1].kind}",
+                             f"training encoder layer on {tuple(x.shape)} {self[1].kind}-norm activations is not served by the fused "
+                             "sub-block kernels (graph beyond the attention / norm kernels' node limit, or an unusual layer "
+                             "shape): falling back piecewise to the per-op kernels and torch")
             for skip, norm in ((self[0], self[1]), (self[2], self[3])):
                 s = skip.module(x, fused=gemm_ok)
                 if norm.kind == "batch" and train_ops.batch_usable(x, s):
@@ -166,6 +172,12 @@ class _EncoderLayer(nn.Sequential):
                 else:
                     x = norm(x + s)
             return x
+        if x.is_cuda and self.training and torch.is_grad_enabled() and torch.is_autocast_enabled():
+            from . import _lib as _l
+
+            _l.warn_fallback(f"train-autocast/{torch.get_autocast_dtype('cuda')}",
+                             f"training under torch.autocast({torch.get_autocast_dtype('cuda')}): the training-encoder kernels "
+                             "serve bf16 autocast (and fp16 where built); this regime runs the torch encoder")
         return super().forward(x)
 
 
@@ -640,6 +652,14 @@ class AttentionModelPolicy(nn.Module):
                     ev1.record()
                     self.encode_events.append((ev0, ev1))
             else:
+                if td["locs"].is_cuda and not grad_path and self._encoder_regime() is not None and not return_init_embeds:
+                    from . import _lib as _l
+
+                    n_nodes = td["action_mask"].shape[-1]
+                    _l.warn_fallback(f"infer-encoder/{self._encoder_regime()}/{n_nodes > 128}/{self.fused_encoder}/{self.fold}",
+                                     f"inference encoder for {n_nodes} nodes under autocast({self._encoder_regime()}) runs on torch: "
+                                     "the fused MFMA encoder serves bf16 up to 128 nodes with batch / instance norm and the folded "
+                                     "cache, the token-parallel kernels bf16 with batch norm beyond that")
                 hidden, init_embeds = self._encode(td)
         if isinstance(env, str) or env is None:
             env = get_env(self.env_name if env is None else env)
@@ -772,12 +792,17 @@ class AttentionModelPolicy(nn.Module):
         # takes the real horizon from the device (the decode launch's own step count, kernels.tour_length(horizon=))
         td_early = reward_early = None
         if (native_env and self.env_name in ("tsp", "pdp", "cvrp", "cvrptw") and calc_reward and mode != "evaluate"
-                and (checked or not env.check_solution) and not (n_rep > 0 and select_best)):
+                and (checked or not env.check_solution) and not (n_rep > 0 and select_best)
+                and env.accepts_reward_horizon()):
             td_early = self._final_td(td, state, n_rep)
             reward_early = env.get_reward(td_early, out_actions, check_solution=False, horizon=(status[2:3], t0))
-        if self._bwd_err is not None:  # sticky bits of the previous step's backward kernel ride on this read-back
+        if self._bwd_err is not None and self._bwd_err.device == device:
+            # sticky bits of earlier teacher-forced backward launches ride on this read-back. The sink is ONE persistent
+            # word, consumed IN PLACE in stream order (OR into the status, then zero): a backward that runs only after
+            # further forwards (baseline / validation rollouts between a grad forward and its loss.backward(), PPO
+            # re-evaluations) still writes into the live word and is reported by the next read-back
             status[:1].bitwise_or_(self._bwd_err)
-            self._bwd_err = None
+            self._bwd_err.zero_()
         # everything above only ENQUEUES device work; `finish` performs the rollout's one host read-back and assembles the
         # reference's output dict. graph.GraphedRollout captures the part above in a HIP graph and calls `finish` after
         # every replay (it only reads the buffers the launches wrote).
@@ -810,7 +835,7 @@ class AttentionModelPolicy(nn.Module):
             if grad_path and cache_g is not None:
                 from . import teacher
 
-                if self._bwd_err is None:
+                if self._bwd_err is None or self._bwd_err.device != device:
                     self._bwd_err = torch.zeros(1, dtype=torch.int32, device=device)
                 meta = dict(t0=t0, mask_inner=self.decoder.mask_inner, mask_logits=mask_logits, err_sink=self._bwd_err,
                             tanh_clipping=tanh_clipping, temperature=temperature, teacher_variant=self.teacher_variant)
@@ -824,6 +849,13 @@ class AttentionModelPolicy(nn.Module):
                     meta.update(real_prize=td["real_prize"], prize_required=td["prize_required"])
                 step_logps = teacher.teacher_forced_logps(self.env_name, cache_g, cache, out_actions, logps, meta)
             elif grad_path:
+                if hidden.is_cuda and self.fused_backward and not return_entropy:
+                    from . import _lib as _l
+
+                    _l.warn_fallback(f"teacher/{self.env_name}/{n}",
+                                     f"teacher-forced backward for {self.env_name} with {n} nodes is beyond the kernels' limit "
+                                     f"({__import__('rl4co_amd.teacher', fromlist=['max_nodes']).max_nodes()} nodes): dense torch "
+                                     "re-evaluation with autograd")
                 step_logps = self.evaluate_log_probs(td, hidden, out_actions, n_rep, tanh_clipping, temperature,
                                                      mask_logits, skip_first=(t0 == 1), return_full=return_entropy)
                 if return_entropy:
@@ -884,7 +916,8 @@ class AttentionModelPolicy(nn.Module):
         """Raise the reference's assertion for any sticky bit the LAST teacher-forced backward kernel set (a sync).
         Rollouts do this on their own: the word rides on the next rollout's status read-back."""
         if self._bwd_err is not None:
-            bits, self._bwd_err = int(self._bwd_err.item()), None
+            bits = int(self._bwd_err.item())
+            self._bwd_err.zero_()
             from . import _lib as _l
 
             _l.raise_for_error_bits(bits)

@@ -90,3 +90,54 @@ def test_error_bits_map_to_reference_messages():
     with pytest.raises(AssertionError, match="Used more than capacity"):
         _lib.raise_for_error_bits(_lib.EBIT_CAPACITY)
     _lib.raise_for_error_bits(0)
+
+
+def test_header_compiles_as_c99_and_layouts_match_ctypes(tmp_path):
+    """The boundary is a C header: it must compile with a plain C compiler (``gcc -std=c99 -pedantic -Werror``, no HIP,
+    no C++), and the ctypes mirrors the Python host marshals through must agree with the COMPILER's layout — sizeof and
+    the offset of every field of every argument struct, not just the field order."""
+    import shutil
+    import subprocess
+
+    from rl4co_amd import _lib
+    from rl4co_amd.encoder import AmEncoderArgs
+    from rl4co_amd.teacher import AmTeacherArgs
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no C compiler")
+    structs = {"rl4co_am_decode_args": _lib.AmDecodeArgs, "rl4co_am_encoder_args": AmEncoderArgs,
+               "rl4co_am_teacher_args": AmTeacherArgs}
+    lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "rl4co_amd.h"', "int main(void) {"]
+    for cname, mirror in structs.items():
+        lines.append(f'  printf("{cname} sizeof %zu\\n", sizeof({cname}));')
+        for field, _ in mirror._fields_:
+            lines.append(f'  printf("{cname} {field} %zu\\n", offsetof({cname}, {field}));')
+    # every declared function is a plain C symbol whose address can be taken from C
+    lines.append("  typedef void (*any_fn)(void);")
+    lines.append("  any_fn symbols[] = {" + ", ".join(f"(any_fn){name}" for name in declared_functions()) + "};")
+    lines.append("  if (sizeof(symbols) == 0) return 2;")
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "abi_probe.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "abi_probe"
+    lib_dir = ROOT / "rl4co_amd" / "lib"
+    _lib.lib()  # make sure the library is built
+    cmd = [gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(src), "-o", str(exe),
+           f"-L{lib_dir}", "-lrl4co_amd", f"-Wl,-rpath,{lib_dir}", "-Wl,--unresolved-symbols=ignore-in-shared-libs"]
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stderr
+    # (the probe is compiled and LINKED against the product library; running it would load the HIP runtime, which the
+    # CPU container cannot initialise, so the layout table is printed by a second, library-free build)
+    cmd2 = [gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", f"-I{ROOT / 'include'}", str(src), "-o", str(exe)]
+    src.write_text("\n".join(l for l in lines if "any_fn" not in l and "symbols" not in l) + "\n")
+    proc = subprocess.run(cmd2, capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stderr
+    table = {}
+    for row in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines():
+        cname, field, value = row.split()
+        table[(cname, field)] = int(value)
+    for cname, mirror in structs.items():
+        assert table[(cname, "sizeof")] == ctypes.sizeof(mirror), cname
+        for field, _ in mirror._fields_:
+            assert table[(cname, field)] == getattr(mirror, field).offset, (cname, field)

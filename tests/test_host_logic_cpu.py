@@ -229,3 +229,71 @@ def test_reset_regenerates_only_an_empty_tensordict(cpu_device):
     assert td["locs"].shape == (4, 10, 2)
     full = TensorDict({"locs": torch.rand(3, 10, 2)}, batch_size=[3])
     assert torch.equal(env.reset(full)["locs"], full["locs"])
+
+
+def test_user_env_subclass_with_reference_signature_get_reward(cpu_device):
+    """a subclass that overrides ``_get_reward(self, td, actions)`` with the reference's signature (no
+    ``horizon``) must keep working — the policy then takes the post-read-back reward path."""
+    from rl4co_amd.envs import TSPEnv
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    calls = []
+
+    class MyTSP(TSPEnv):
+        def _get_reward(self, td, actions):  # the reference's signature (tsp/env.py:150)
+            calls.append(tuple(actions.shape))
+            return super()._get_reward(td, actions) * 2.0
+
+    env = MyTSP(generator_params=dict(num_loc=10), device="cpu")
+    assert not env.accepts_reward_horizon() and TSPEnv(generator_params=dict(num_loc=10), device="cpu").accepts_reward_horizon()
+    torch.manual_seed(0)
+    pol = AttentionModelPolicy("tsp").eval()
+    torch.manual_seed(1)
+    td = env.reset(batch_size=[8])
+    with torch.inference_mode():
+        out = pol(td, env, phase="test", decode_type="greedy")
+    base = TSPEnv(generator_params=dict(num_loc=10), device="cpu")
+    assert calls == [(8, 10)]
+    assert torch.equal(out["reward"], base.get_reward(td, out["actions"]) * 2.0)
+
+
+def test_backward_error_sink_survives_forwards_between_forward_and_backward(cpu_device):
+    """the sticky word of the teacher-forced backward is ONE persistent tensor consumed in place; a
+    forward issued between a grad forward and its backward must not orphan it."""
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    pol = AttentionModelPolicy("tsp")
+    pol._bwd_err = torch.zeros(1, dtype=torch.int32)
+    sink = pol._bwd_err
+    env = __import__("rl4co_amd.envs", fromlist=["get_env"]).get_env("tsp", generator_params=dict(num_loc=10), device="cpu")
+    torch.manual_seed(1)
+    td = env.reset(batch_size=[4])
+    with torch.inference_mode():
+        pol.eval()(td, env, phase="test", decode_type="greedy")  # consumes the (zero) word, keeps the tensor
+    assert pol._bwd_err is sink
+    sink.fill_(2)  # a late backward reports an infeasible action
+    with pytest.raises(AssertionError, match="infeasible action selected"), torch.inference_mode():
+        pol(env.reset(batch_size=[4]), env, phase="test", decode_type="greedy")
+    assert pol._bwd_err is sink and int(sink.item()) == 0
+    sink.fill_(1)
+    with pytest.raises(AssertionError, match="Logits contain NaNs"):
+        pol.check_backward_errors()
+    assert int(sink.item()) == 0
+
+
+def test_trained_parity_measurement_on_the_fake_device(cpu_device):
+    """tools/trained_parity.compare (what the `-m gpu` trained-weight tests and bench.py's parity block run) end to end
+    on the stand-in device: the tanh-plateau fixture (logit key x 400: nearly every greedy step an exact tie at +10,
+    lowest index wins) — the C oracle's specified-order arithmetic must reproduce the reference's tours, and any flip
+    must be a proven near-tie."""
+    from tools.trained_parity import TrainedCase, compare
+
+    case = TrainedCase("sharpkl400_tsp100_b512_greedy")
+    case.batch = 64  # a prefix of the seeded batch is not the same draw: regenerate and slice instead
+    full = TrainedCase("sharpkl400_tsp100_b512_greedy")
+    data = full.instances("cpu")
+    case.instances = lambda device: data[:64]
+    case.actions, case.reward = full.actions[:64], full.reward[:64]
+    rec = compare(case, "fp32", "cpu", against="fp32")
+    assert rec["of"] == 64 and rec["flips"] <= 1 and rec["flip_regret_max"] <= 2e-5, rec
+    assert rec["step_agreement"] >= 0.999 and rec["rewards_bit_identical_on_identical"] is True

@@ -159,9 +159,10 @@ def compare(case: TrainedCase, config: str, device, against: str = "fp32", decod
             first = (a[rows] == r[rows]).long().cumprod(1).sum(1).clamp(max=ref_actions.shape[1] - 1)
             at = lp[rows, first]                                            # the product's log-probs at the shared state
             reg = at.max(-1).values - at.gather(-1, ref_actions[rows, first][:, None]).squeeze(-1)
-            rec.update(flip_regret_max=float(reg.max()), flip_regret_mean=float(reg.mean()),
-                       flips_with_regret_above_1e-5=int((reg > 1e-5).sum()),
-                       flips_with_regret_above_1e-4=int((reg > 1e-4).sum()))
+            rec.update({"flip_regret_max": float(reg.max()), "flip_regret_mean": float(reg.mean()),
+                        "flips_with_regret_above_1e-5": int((reg > 1e-5).sum()),
+                        "flips_with_regret_above_1e-4": int((reg > 1e-4).sum())})
         else:
-            rec.update(flip_regret_max=0.0, flip_regret_mean=0.0, flips_with_regret_above_1e-5=0, flips_with_regret_above_1e-4=0)
+            rec.update({"flip_regret_max": 0.0, "flip_regret_mean": 0.0, "flips_with_regret_above_1e-5": 0,
+                        "flips_with_regret_above_1e-4": 0})
     return rec
