@@ -371,11 +371,16 @@ class Bench:
             opt.step()
             return out
 
+        from rl4co_amd import teacher as T
+
         log(f"c4_train: rank {self.rank}/{self.world}, warming up")
         for i in range(warmup):
             step(i)
         torch.cuda.synchronize()
         ar_events.clear()
+        # HIP events around the two dominant launches of the step (the multistart rollout and the teacher-forced backward):
+        # their durations feed the leg's `roofline` objects; rocprofv3's kernel stats of the same command must agree
+        policy.decode_events, T.backward_events = [], []
         # the interpreter's long-lived objects (torch's module graph: ~1e6 of them) leave the cyclic collector's view:
         # one full collection walking them is a 60 ms host stall (tools/train_steps.py), and the rollout's 16-byte
         # status read-back keeps the host at most one step ahead of the GPU, so the stall lands on the step time.
@@ -396,6 +401,34 @@ class Bench:
         t_steps = out["actions"].shape[1]
         traj = batch * starts * self.world * steps
         ar_ms = [x.elapsed_time(y) for x, y in ar_events]
+        roll_ms = [x.elapsed_time(y) for x, y in policy.decode_events]
+        back_ms = [x.elapsed_time(y) for x, y in T.backward_events]
+        policy.decode_events = T.backward_events = None
+        n_nodes, d = num_loc, 128
+        decisions = batch * starts * (t_steps - 1)  # the first (imposed) start node of every trajectory is not decoded
+        # matrix work per decoded trajectory-step (2 x MACs): rollout = scores, glimpse, logits over the N nodes;
+        # backward = the same three products recomputed + their five gradient products (d logit key, d glimpse,
+        # d glimpse value, d glimpse key, d query)
+        flop_roll = 3 * 2 * n_nodes * d
+        flop_back = 8 * 2 * n_nodes * d
+
+        def chain_roofline(kernel, ms, flop_per_decision, pmc_key):
+            mean = sum(ms) / len(ms)
+            tf = flop_per_decision * decisions / (mean * 1e-3) / 1e12
+            pmc = {}
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_c4_train_pmc.json"))).get(pmc_key, {})
+            except (OSError, ValueError):
+                pass
+            return {"kernel": kernel, "bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": tf / MFMA_PEAK_TFLOPS, "traffic": None, "launch_ms_mean": mean, "launch_ms_min": min(ms),
+                    "launches_timed": len(ms), "flop_per_trajectory_step": flop_per_decision, "trajectory_steps_per_launch": decisions,
+                    "trajectory_steps_per_sec": decisions / (mean * 1e-3),
+                    "note": "algorithmic matrix FLOPs at N nodes against the dense bf16 MFMA peak. Both kernels are per-instance "
+                            "LATENCY CHAINS (16-step column blocks: dependent MFMAs, softmax VALU and LDS hand-overs add up "
+                            "instead of overlapping), not throughput kernels: see pipe_utilisation for where the cycles go",
+                    "pipe_utilisation": pmc or None,
+                    "pipe_utilisation_source": "profiles/r03_c4_train_pmc.json (separate rocprofv3 --pmc passes, tools/train_pmc.sh)" if pmc else None}
         res.update({
             "workload": (f"BASELINE configs[{cfg_idx}] per-GPU share: POMO (6L, instance norm) REINFORCE step, TSPEnv num_loc={num_loc}, "
                          f"{batch} instances x {starts} starts per GPU: multistart sampling rollout (MS decode kernel), "
@@ -412,6 +445,12 @@ class Bench:
             "mean_reward": float(out["reward"].mean()),
             "peak_mem_GB": torch.cuda.max_memory_allocated() / 2 ** 30,
         })
+        if back_ms:
+            res["roofline"] = chain_roofline("am_teacher_mma_kernel (teacher-forced backward, MFMA 16-step blocks): the step's dominant kernel",
+                                             back_ms, flop_back, "am_teacher_mma_kernel")
+        if roll_ms:
+            res["rollout_roofline"] = chain_roofline("am_decode_ms_kernel (multistart sampling rollout on MFMA column tiles)",
+                                                     roll_ms, flop_roll, "am_decode_ms_kernel")
         return res
 
     # -- parity against the reference's tours, every inference leg --------------------------------------------------------

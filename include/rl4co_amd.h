@@ -67,6 +67,8 @@ extern "C" {
 
 #define RL4CO_DT_F32 0
 #define RL4CO_DT_BF16 1
+#define RL4CO_DT_F16 2 /* IEEE half planes: the reference's default "16-mixed" regime (utils/trainer.py:57); served by the
+                          fused encoder (inference) and the streaming decode kernel */
 
 /* kernel variants of rl4co_am_decode (same results up to the documented summation tree) */
 #define RL4CO_VARIANT_AUTO 0
@@ -353,15 +355,15 @@ int rl4co_am_decode_variant(const rl4co_am_decode_args* args);
  * [x + MHA(x) -> Norm -> x + MLP(x) -> Norm] (models/nn/graph/attnnet.py:16-106,
  * nn/attention.py:110-134, nn/ops.py:30-54, nn/mlp.py:52-61; 8 heads, d = 128, FFN 512) and
  * AttentionModelDecoder._precompute_cache (zoo/am/decoder.py:201-228) in the folded form of
- * rl4co_am_decode_args. bf16 MFMA inputs, fp32 accumulation, bf16 residual stream (the
- * reference's mixed-precision regime, utils/trainer.py:57). Normalisation: norm = 0 is
+ * rl4co_am_decode_args. 16-bit MFMA inputs (act_dtype: bf16 or fp16), fp32 accumulation, 16-bit
+ * residual stream (the reference's mixed-precision regimes, utils/trainer.py:57). Normalisation: norm = 0 is
  * batch norm in EVAL mode, passed as a per-channel (scale, shift) pair folded from the
  * running statistics; norm = 1 is instance norm (POMO), scale/shift = gamma/beta.
  * Train-mode batch statistics couple instances and stay on the torch path (which also
  * provides autograd). N <= rl4co_am_encoder_max_nodes().
  *
  * Weight matrices are nn.Linear weights [out,in] re-packed once per weight update into MFMA
- * fragment order: [out/32 tiles][in/16 ksteps][64 lanes][8] bf16 with lane = 32*hi + row,
+ * fragment order: [out/32 tiles][in/16 ksteps][64 lanes][8] elements of act_dtype with lane = 32*hi + row,
  * element s = W[32*tile + row][16*kstep + 8*hi + s]   (rl4co_amd/encoder.py: pack_weight).
  * -------------------------------------------------------------------------- */
 typedef struct rl4co_am_encoder_args {
@@ -370,7 +372,12 @@ typedef struct rl4co_am_encoder_args {
   int32_t N;           /* nodes incl. depot                                        */
   int32_t num_layers;  /* 3 (AM) / 6 (POMO)                                        */
   int32_t norm;        /* 0 = per-channel affine (batch norm, eval), 1 = instance  */
-  int32_t cache_dtype; /* dtype of the three kvl planes written                    */
+  int32_t cache_dtype; /* dtype of the three kvl planes written: RL4CO_DT_F32 or act_dtype */
+  int32_t act_dtype;   /* 16-bit element type of the MFMA operands, the packed weights and the LDS residual stream:
+                          RL4CO_DT_BF16 (autocast bfloat16) or RL4CO_DT_F16 (autocast float16, the reference's
+                          default "16-mixed", utils/trainer.py:57: v_mfma_f32_32x32x16_f16, softmax always
+                          max-subtracted — fp16 lacks the range of the bounded-score shortcut) */
+  int32_t reserved0;   /* keeps the pointers 8-byte aligned; must be 0              */
   const float* locs;   /* [B,N,2] (CVRP: depot first, cvrp/env.py:108)             */
   const float* demand; /* [B,N-1] CVRP demand / OP prize / PCTSP expected prize     */
   const float* feature4; /* [B,N-1] PCTSP penalty / CVRPTW tw start (w_init is then [128,4] / [128,6]) or NULL */

@@ -188,7 +188,7 @@ def am_decode(cache, state: dict, *, mode: str, max_steps: int, actions: Tensor,
     a.mask_inner, a.mask_logits = int(mask_inner), int(mask_logits)
     a.tanh_clipping, a.temperature = float(tanh_clipping), float(temperature)
     kvl = _cpu(cache.kvl)
-    a.cache_dtype = _lib.DT_BF16 if kvl.dtype == torch.bfloat16 else _lib.DT_F32
+    a.cache_dtype = _lib.dtype_id(kvl.dtype)
     a.glimpse_key, a.glimpse_val, a.logit_key = (cache.plane(i).data_ptr() for i in range(3))
     a.kvl_row_stride, a.kvl_batch_stride = cache.row_stride, cache.batch_stride
     if getattr(cache, "unfold", False):

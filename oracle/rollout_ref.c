@@ -351,8 +351,23 @@ static float tree_sum(const float* x, int n) {
   return tree_sum(x, n / 2) + tree_sum(x + n / 2, n / 2);
 }
 
+/* IEEE binary16 -> binary32, exact (what v_cvt_f32_f16 does), subnormals and inf / nan included */
+static inline float half_bits_to_float(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  uint32_t exp = (h >> 10) & 0x1fu, man = h & 0x3ffu;
+  if (exp == 0) {
+    if (man == 0) return rl4co_bits_to_float(sign);
+    int e = -1;
+    do { man <<= 1; ++e; } while (!(man & 0x400u));
+    return rl4co_bits_to_float(sign | ((uint32_t)(127 - 15 - e) << 23) | ((man & 0x3ffu) << 13));
+  }
+  if (exp == 31) return rl4co_bits_to_float(sign | 0x7f800000u | (man << 13));
+  return rl4co_bits_to_float(sign | ((exp + 112u) << 23) | (man << 13));
+}
+
 static inline float cache_at(const void* base, int dtype, int64_t idx) {
   if (dtype == RL4CO_DT_BF16) return rl4co_bits_to_float((uint32_t)((const uint16_t*)base)[idx] << 16);
+  if (dtype == RL4CO_DT_F16) return half_bits_to_float(((const uint16_t*)base)[idx]);
   return ((const float*)base)[idx];
 }
 
@@ -360,7 +375,7 @@ static inline float cache_at(const void* base, int dtype, int64_t idx) {
  * rl4co_am_decode_row_groups(cache_dtype). Returns 0, or 1 on a bad argument. */
 int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
   const int N = a->N, G = row_groups;
-  const int EPL = a->cache_dtype == RL4CO_DT_BF16 ? 8 : 4;
+  const int EPL = a->cache_dtype != RL4CO_DT_F32 ? 8 : 4;
   const int LPR = D / EPL, LPH = DH / EPL;
   if (G < 1 || G > 64 || (G & (G - 1))) return 1;
   float* sc = (float*)malloc(sizeof(float) * (size_t)N * H);
@@ -979,5 +994,11 @@ int oracle_pomo_best(const float* reward, const int64_t* actions, int A, int S, 
     if (actions && best_aug_actions)
       memcpy(best_aug_actions + (int64_t)b * T, actions + (((int64_t)bs_of_ba * A + ba) * B + b) * T, (size_t)T * 8);
   }
+  return 0;
+}
+
+/* binary16 -> binary32 over an array (tests pin the conversion to torch's for all 65 536 bit patterns) */
+int oracle_half_to_float_array(const uint16_t* h, int64_t n, float* out) {
+  for (int64_t i = 0; i < n; ++i) out[i] = half_bits_to_float(h[i]);
   return 0;
 }

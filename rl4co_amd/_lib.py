@@ -14,7 +14,7 @@ from . import build as _build
 RL4CO_OK = 0
 ENV_TSP, ENV_CVRP, ENV_OP, ENV_PCTSP, ENV_PDP, ENV_CVRPTW = 0, 1, 2, 3, 4, 5
 DECODE_GREEDY, DECODE_SAMPLE, DECODE_EVALUATE = 0, 1, 2
-DT_F32, DT_BF16 = 0, 1
+DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 VARIANT_AUTO, VARIANT_STREAM, VARIANT_LDS, VARIANT_WIDE, VARIANT_MS = 0, 1, 2, 3, 4
 
 EBIT_NAN_LOGIT = 1
@@ -134,6 +134,16 @@ SYMBOLS = {
     "rl4co_math_probe_f32": (C.c_int, [C.c_int, _vp, _i64, _vp, _vp]),
     "rl4co_uniform_f32": (C.c_int, [_vp, _i64, C.c_float, C.c_float, C.c_uint64, C.c_uint32, C.c_int, C.c_float, _vp]),
 }
+
+
+def dtype_id(dtype) -> int:
+    """torch dtype of the cache planes -> RL4CO_DT_*"""
+    import torch
+
+    try:
+        return {torch.float32: DT_F32, torch.bfloat16: DT_BF16, torch.float16: DT_F16}[dtype]
+    except KeyError:
+        raise TypeError(f"cache dtype must be float32, bfloat16 or float16, got {dtype}") from None
 
 
 class Rl4coLibraryError(RuntimeError):

@@ -81,6 +81,23 @@ struct CacheBF16 {
   }
 };
 
+// IEEE half planes (torch.float16: the reference's default "16-mixed" precision, utils/trainer.py:57): same 16-byte
+// lanes as bf16, converted with v_cvt_f32_f16 — exact, like the bf16 shift
+struct CacheF16 {
+  using elem = uint16_t;
+  using raw = uint4;
+  static constexpr int EPL = 8;
+  typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+  __device__ static inline raw zero() { return make_uint4(0u, 0u, 0u, 0u); }
+  __device__ static inline raw ld(const elem* p) { return *reinterpret_cast<const uint4*>(p); }
+  __device__ static inline void cvt(const raw& t, float (&v)[8]) {
+    const half2_t a = __builtin_bit_cast(half2_t, t.x), b = __builtin_bit_cast(half2_t, t.y);
+    const half2_t c = __builtin_bit_cast(half2_t, t.z), d = __builtin_bit_cast(half2_t, t.w);
+    v[0] = (float)a[0]; v[1] = (float)a[1]; v[2] = (float)b[0]; v[3] = (float)b[1];
+    v[4] = (float)c[0]; v[5] = (float)c[1]; v[6] = (float)d[0]; v[7] = (float)d[1];
+  }
+};
+
 __host__ __device__ inline int lds_pad(int N) { return (N + 63) & ~63; }
 
 // blockIdx -> trajectory. Trajectories are stored s-major (row r = s * B_inst + instance, the
@@ -943,6 +960,9 @@ int launch_wide(const rl4co_am_decode_args& a, hipStream_t stream) {
 inline int resolve_variant(const rl4co_am_decode_args& a) {
   // the unfolded parity mode exists in the streaming kernel only
   if (a.unfold) return (a.variant == RL4CO_VARIANT_AUTO || a.variant == RL4CO_VARIANT_STREAM) ? RL4CO_VARIANT_STREAM : -1;
+  // fp16 planes: the streaming kernel only (the 4-wave and matrix-core variants are bf16 kernels)
+  if (a.cache_dtype == RL4CO_DT_F16)
+    return (a.variant == RL4CO_VARIANT_AUTO || a.variant == RL4CO_VARIANT_STREAM) ? RL4CO_VARIANT_STREAM : -1;
   const bool bf16 = a.cache_dtype == RL4CO_DT_BF16;
   // multistart on the matrix cores (am_decode_ms.hip): bf16 planes, N <= 128, plain outputs; every environment
   const bool ms_ok = bf16 && a.N <= 128 && a.B_inst > 0 && a.all_logps == nullptr && a.entropy == nullptr;
@@ -994,7 +1014,7 @@ extern "C" int rl4co_am_decode_row_groups(const rl4co_am_decode_args* args) {
   if (v < 0) return -1;
   if (v == RL4CO_VARIANT_MS) return 0;  // bf16 MFMA variant: tolerance-tested, no specified-order oracle
   if (v == RL4CO_VARIANT_LDS || v == RL4CO_VARIANT_WIDE) return kLdsGroups;
-  return args->cache_dtype == RL4CO_DT_BF16 ? 64 / (kD / CacheBF16::EPL) : 64 / (kD / CacheF32::EPL);
+  return args->cache_dtype != RL4CO_DT_F32 ? 64 / (kD / CacheBF16::EPL) : 64 / (kD / CacheF32::EPL);
 }
 
 extern "C" int rl4co_am_decode_variant(const rl4co_am_decode_args* args) {
@@ -1010,7 +1030,8 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
   RL4CO_REQUIRE(a.N >= 2 && a.N <= 4096);
   RL4CO_REQUIRE(a.max_steps >= 1);
   RL4CO_REQUIRE(a.mode >= RL4CO_DECODE_GREEDY && a.mode <= RL4CO_DECODE_EVALUATE);
-  RL4CO_REQUIRE(a.cache_dtype == RL4CO_DT_F32 || a.cache_dtype == RL4CO_DT_BF16);
+  RL4CO_REQUIRE(a.cache_dtype == RL4CO_DT_F32 || a.cache_dtype == RL4CO_DT_BF16 || a.cache_dtype == RL4CO_DT_F16);
+  RL4CO_REQUIRE(a.cache_dtype != RL4CO_DT_F16 || !a.unfold);
   RL4CO_REQUIRE(a.glimpse_key && a.glimpse_val && a.logit_key && (a.ctx_cur || a.unfold));
   RL4CO_REQUIRE(a.unfold == 0 || a.unfold == 1);
   if (a.unfold) {
@@ -1049,6 +1070,16 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
     if (a.cache_dtype == RL4CO_DT_F32)
       return a.env == RL4CO_ENV_TSP ? launch<CacheF32, RL4CO_ENV_TSP, true>(a, s) : launch<CacheF32, RL4CO_ENV_CVRP, true>(a, s);
     return a.env == RL4CO_ENV_TSP ? launch<CacheBF16, RL4CO_ENV_TSP, true>(a, s) : launch<CacheBF16, RL4CO_ENV_CVRP, true>(a, s);
+  }
+  if (a.cache_dtype == RL4CO_DT_F16) {
+    switch (a.env) {
+      case RL4CO_ENV_TSP: return launch<CacheF16, RL4CO_ENV_TSP>(a, s);
+      case RL4CO_ENV_CVRP: return launch<CacheF16, RL4CO_ENV_CVRP>(a, s);
+      case RL4CO_ENV_OP: return launch<CacheF16, RL4CO_ENV_OP>(a, s);
+      case RL4CO_ENV_PCTSP: return launch<CacheF16, RL4CO_ENV_PCTSP>(a, s);
+      case RL4CO_ENV_PDP: return launch<CacheF16, RL4CO_ENV_PDP>(a, s);
+      default: return launch<CacheF16, RL4CO_ENV_CVRPTW>(a, s);
+    }
   }
   if (variant == RL4CO_VARIANT_MS) return rl4co::launch_decode_ms(a, s);
   if (variant == RL4CO_VARIANT_LDS || variant == RL4CO_VARIANT_WIDE) {

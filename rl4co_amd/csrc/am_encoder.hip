@@ -39,12 +39,21 @@ constexpr int kFF = 512;
 constexpr int kRS = kD + 8;  // LDS row stride (bf16 elements): 272 B rows spread the banks
 constexpr int kThreads = 256;
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// The kernel is generic in the 16-bit ELEMENT type E of its MFMA operands / LDS residual stream:
+//   __bf16    torch.autocast(bfloat16) ("bf16-mixed")                      v_mfma_f32_32x32x16_bf16
+//   _Float16  torch.autocast(float16), the reference's DEFAULT "16-mixed"  v_mfma_f32_32x32x16_f16
+//             (rl4co/utils/trainer.py:57)
+// Same fragment layouts, same rate, fp32 accumulation either way; (E)float conversions are the hardware's
+// round-to-nearest-even converts. What differs is the RANGE: see kFastBound.
+template <typename E> using vec8 = E __attribute__((ext_vector_type(8)));
+template <typename E> using vec4 = E __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ inline f32x16 mfma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+__device__ inline f32x16 mfma(const vec8<__bf16>& a, const vec8<__bf16>& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ inline f32x16 mfma(const vec8<_Float16>& a, const vec8<_Float16>& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
 // accumulator layout of the 32x32 MFMA: register r of lane (l31, hi) is row rowmap(r, hi), col l31
@@ -76,25 +85,29 @@ __device__ inline f32x16 zero16() {
 }
 
 // registers 8u..8u+7 of an accumulator as one bf16 MFMA operand fragment
-__device__ inline bf16x8 frag_from_acc(const f32x16& c, int u) {
-  bf16x8 f;
+template <typename E>
+__device__ inline vec8<E> frag_from_acc(const f32x16& c, int u) {
+  vec8<E> f;
 #pragma unroll
-  for (int s = 0; s < 8; ++s) f[s] = (__bf16)c[8 * u + s];
+  for (int s = 0; s < 8; ++s) f[s] = (E)c[8 * u + s];
   return f;
 }
 
 // packed weight fragment: [tile][kstep][64 lanes][8] bf16
-__device__ inline bf16x8 load_w(const __bf16* packed, int ksteps, int tile, int ks, int lane) {
-  return *reinterpret_cast<const bf16x8*>(packed + (((int64_t)tile * ksteps + ks) * 64 + lane) * 8);
+template <typename E>
+__device__ inline vec8<E> load_w(const E* packed, int ksteps, int tile, int ks, int lane) {
+  return *reinterpret_cast<const vec8<E>*>(packed + (((int64_t)tile * ksteps + ks) * 64 + lane) * 8);
 }
 
 // activation fragment from LDS rows [token][k]: lane reads 8 contiguous k of its token row
-__device__ inline bf16x8 load_x(const __bf16* xs, int tt, int ks, int l31, int hi) {
-  return *reinterpret_cast<const bf16x8*>(xs + (32 * tt + l31) * kRS + 16 * ks + 8 * hi);
+template <typename E>
+__device__ inline vec8<E> load_x(const E* xs, int tt, int ks, int l31, int hi) {
+  return *reinterpret_cast<const vec8<E>*>(xs + (32 * tt + l31) * kRS + 16 * ks + 8 * hi);
 }
 
 // The 8 weight fragments of one GEMM call (8 x 1 KiB per wave, streamed from L2).
-__device__ inline void load_wfrags(bf16x8 (&wf)[8], const __bf16* packed, int ksteps_total, int tile, int k0, int lane) {
+template <typename E>
+__device__ inline void load_wfrags(vec8<E> (&wf)[8], const E* packed, int ksteps_total, int tile, int k0, int lane) {
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) wf[ks] = load_w(packed, ksteps_total, tile, k0 + ks, lane);
 }
@@ -108,8 +121,8 @@ __device__ inline void load_wfrags(bf16x8 (&wf)[8], const __bf16* packed, int ks
 // activation fragments are double-buffered one kstep ahead.
 // INIT: the first k-step takes `cinit` as its C operand (an MFMA's C need not be its D) — the bias tile of the GEMM,
 // shared by the TT token tiles, enters the accumulators for free instead of through 16 TT adds in the epilogue.
-template <int TT, bool W_IS_A = true, bool INIT = true>
-__device__ inline void gemm_t(f32x16 (&acc)[TT], bf16x8 (&wf)[8], const __bf16* xs, int lane, const __bf16* nxt_packed,
+template <int TT, bool W_IS_A = true, bool INIT = true, typename E>
+__device__ inline void gemm_t(f32x16 (&acc)[TT], vec8<E> (&wf)[8], const E* xs, int lane, const E* nxt_packed,
                               int nxt_ksteps_total, int nxt_tile, int nxt_k0, const f32x16& cinit) {
   const int l31 = lane & 31, hi = lane >> 5;
   // Every MFMA takes one 1 KiB activation fragment from LDS. With the fragments of k-step ks + 1 requested while k-step
@@ -117,7 +130,7 @@ __device__ inline void gemm_t(f32x16 (&acc)[TT], bf16x8 (&wf)[8], const __bf16* 
   // data is NOT back in time: replacing these reads by loop-invariant ones cut the kernel from 1.12 to 0.63 ms
   // (tools/enc_probe.sh, r02) — the kernel was waiting on LDS latency, not on issue slots or the matrix pipe. The
   // fragments are therefore requested TWO k-steps ahead (three rotating register sets).
-  bf16x8 x[3][TT];
+  vec8<E> x[3][TT];
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
     x[0][tt] = load_x(xs, tt, 0, l31, hi);
@@ -139,29 +152,30 @@ __device__ inline void gemm_t(f32x16 (&acc)[TT], bf16x8 (&wf)[8], const __bf16* 
 }
 
 // write an Out^T accumulator tile to LDS rows [token][dim]: 4 consecutive dims per 8-byte store
-template <int TT>
-__device__ inline void store_t(__bf16* ys, const f32x16 (&acc)[TT], int dim0, int lane) {
+template <int TT, typename E>
+__device__ inline void store_t(E* ys, const f32x16 (&acc)[TT], int dim0, int lane) {
   const int l31 = lane & 31, hi = lane >> 5;
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      bf16x4 v;
+      vec4<E> v;
 #pragma unroll
-      for (int s = 0; s < 4; ++s) v[s] = (__bf16)acc[tt][4 * c + s];
-      *reinterpret_cast<bf16x4*>(ys + (32 * tt + l31) * kRS + dim0 + 8 * c + 4 * hi) = v;
+      for (int s = 0; s < 4; ++s) v[s] = (E)acc[tt][4 * c + s];
+      *reinterpret_cast<vec4<E>*>(ys + (32 * tt + l31) * kRS + dim0 + 8 * c + 4 * hi) = v;
     }
   }
 }
 
+template <typename E>
 struct LayerPtrs {
-  const __bf16 *wqkv, *wo, *w1, *w2;
+  const E *wqkv, *wo, *w1, *w2;
   const float *bqkv, *b1, *n1a, *n1b, *n2a, *n2b;
 };
 
 // residual + bias + normalisation epilogue for the wave's 32-dim tile; result back into xs (bf16)
-template <int TT>
-__device__ inline void residual_norm(__bf16* xs, f32x16 (&y)[TT], int dim0, const float* na,
+template <int TT, typename E>
+__device__ inline void residual_norm(E* xs, f32x16 (&y)[TT], int dim0, const float* na,
                                      const float* nb, int norm, int N, int lane) {
   const int l31 = lane & 31, hi = lane >> 5;
   float ga[16], be[16];  // (the GEMM's bias is folded into `nb` on the host, or cancels: instance norm)
@@ -175,7 +189,7 @@ __device__ inline void residual_norm(__bf16* xs, f32x16 (&y)[TT], int dim0, cons
   for (int tt = 0; tt < TT; ++tt) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const bf16x4 x = *reinterpret_cast<const bf16x4*>(xs + (32 * tt + l31) * kRS + dim0 + 8 * c + 4 * hi);
+      const vec4<E> x = *reinterpret_cast<const vec4<E>*>(xs + (32 * tt + l31) * kRS + dim0 + 8 * c + 4 * hi);
 #pragma unroll
       for (int s = 0; s < 4; ++s) y[tt][4 * c + s] = (float)x[s] + y[tt][4 * c + s];
     }
@@ -215,7 +229,11 @@ __device__ inline void residual_norm(__bf16* xs, f32x16 (&y)[TT], int dim0, cons
 // phase (softmax, norms, conversions) the other one's waves keep the matrix pipe busy.
 // |score| bound below which exp2 needs no max subtraction: scores in [-48, 48] (log2 domain) keep every softmax
 // numerator in [2^-48, 2^48] and a row sum below 2^55 — far inside fp32 / bf16 range, same relative precision
+// fp16 has neither range (numerators would have to stay inside [2^-14, 2^16]): it always takes the exact path, whose
+// numerators exp2(s - max) lie in (0, 1] — what underflows there is below 2^-24 of the row's largest term.
 constexpr float kFastBound = 48.0f;
+template <typename E> constexpr bool kWideRange = true;
+template <> constexpr bool kWideRange<_Float16> = false;
 
 // squared norms of the two heads' 16-dim slices of one token column, from a transposed-form accumulator tile
 // (register r of lane (l31, hi) is dim rowmap(r, hi) of token l31: a head = 8 registers here + 8 in the other half)
@@ -236,11 +254,13 @@ __device__ inline float wave_max32(float v) {  // maximum over the 32 token colu
 // VR4: valid 4-register groups of the LAST key tile (keys 32 (TT-1) ..): ceil((N - 32 (TT-1)) / 8). Registers beyond
 // them are padding keys in every lane — their exps, conversions and (from 8 registers up) the second value product
 // are dropped at compile time (TSP-100: four valid keys in the fourth tile, 12 of 16 registers gone).
-template <int TT, int VR4>
+template <typename E, int TT, int VR4>
 __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_encoder_args a) {
+  using bf16x8 = vec8<E>;  // (historic names: the 16-bit operand fragments of whichever element type E is)
+  using bf16x4 = vec4<E>;
   extern __shared__ __align__(16) unsigned char smem[];
-  __bf16* xs = reinterpret_cast<__bf16*>(smem);  // residual stream [128][kRS]
-  __bf16* ys = xs + 128 * kRS;                   // Q^T (wave-private columns) -> attention output -> FFN hidden chunk
+  E* xs = reinterpret_cast<E*>(smem);  // residual stream [128][kRS]
+  E* ys = xs + 128 * kRS;              // Q^T (wave-private columns) -> attention output -> FFN hidden chunk
   float* meanv = reinterpret_cast<float*>(ys + 128 * kRS);  // [128]
   float* bl = meanv + kD;                                    // [kBiasFloats] this layer's bqkv | b1 (see bias_tile)
   auto stage_biases = [&](int layer) {
@@ -253,11 +273,11 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
   const int b = blockIdx.x;
   const int N = a.N;
 
-  const __bf16* wqkv_all = static_cast<const __bf16*>(a.wqkv_packed);
-  const __bf16* wo_all = static_cast<const __bf16*>(a.wo_packed);
-  const __bf16* w1_all = static_cast<const __bf16*>(a.w1_packed);
-  const __bf16* w2_all = static_cast<const __bf16*>(a.w2_packed);
-  const __bf16* wf_all = static_cast<const __bf16*>(a.wfold_packed);
+  const E* wqkv_all = static_cast<const E*>(a.wqkv_packed);
+  const E* wo_all = static_cast<const E*>(a.wo_packed);
+  const E* w1_all = static_cast<const E*>(a.w1_packed);
+  const E* w2_all = static_cast<const E*>(a.w2_packed);
+  const E* wf_all = static_cast<const E*>(a.wfold_packed);
   // weight fragments of the NEXT GEMM, always one call ahead (gemm_t). The first set is requested before anything else:
   // the fixed cost of an instance (init embedding, first fragments, fold, stores) is 0.38 of the kernel's 1.1 ms
   // (`tools/enc_layers.py`: 0.62 / 0.85 / 1.11 / 1.78 ms at 1 / 2 / 3 / 6 layers), most of it exposed round trips
@@ -341,14 +361,14 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       }
       bf16x4 pk;
 #pragma unroll
-      for (int c = 0; c < 4; ++c) pk[c] = (__bf16)v[c];
+      for (int c = 0; c < 4; ++c) pk[c] = (E)v[c];
       *reinterpret_cast<bf16x4*>(xs + tok * kRS + d0) = pk;
     }
   }
   __syncthreads();
 
   for (int layer = 0; layer < a.num_layers; ++layer) {
-    LayerPtrs L;
+    LayerPtrs<E> L;
     L.wqkv = wqkv_all + (int64_t)layer * 3 * kD * kD;
     L.wo = wo_all + (int64_t)layer * kD * kD;
     L.w1 = w1_all + (int64_t)layer * kFF * kD;
@@ -383,8 +403,8 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       gemm_t<TT>(acc, wf, xs, lane, L.wqkv, 8, 8 + w, 0, bias_tile(L.bqkv + kD, 32 * w, hi));
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
-        kf[tt][0] = frag_from_acc(acc[tt], 0);
-        kf[tt][1] = frag_from_acc(acc[tt], 1);
+        kf[tt][0] = frag_from_acc<E>(acc[tt], 0);
+        kf[tt][1] = frag_from_acc<E>(acc[tt], 1);
         float h0, h1;
         head_sqnorms(acc[tt], h0, h1);
         kn2[0] = fmaxf(kn2[0], h0);
@@ -396,16 +416,16 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         f32x16 bt;
 #pragma unroll
         for (int r = 0; r < 16; ++r) bt[r] = bv;
-        gemm_t<TT, false>(acc, wf, xs, lane, nullptr, 0, 0, 0, bt);  // nothing in flight across the attention (register peak)
+        gemm_t<TT, false>(acc, wf, xs, lane, static_cast<const E*>(nullptr), 0, 0, 0, bt);  // nothing in flight across the attention (register peak)
       }
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-          const bf16x8 v = frag_from_acc(acc[tt], u);
+          const bf16x8 v = frag_from_acc<E>(acc[tt], u);
           bf16x8 ones;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) ones[i] = (__bf16)1.0f;
+          for (int i = 0; i < 8; ++i) ones[i] = (E)1.0f;
           vfh[0][tt][u] = (l31 < 16) ? v : ones;   // lane = dim column: dims 0..15 are head 2w, 16..31 head 2w + 1
           vfh[1][tt][u] = (l31 < 16) ? ones : v;
         }
@@ -417,14 +437,14 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       const float b2 = wave_max32(qn2[hh]) * wave_max32(kn2[hh]);
-      fast_head[hh] = __builtin_amdgcn_readfirstlane((b2 <= kFastBound * kFastBound) ? 1 : 0) != 0;
+      fast_head[hh] = kWideRange<E> && __builtin_amdgcn_readfirstlane((b2 <= kFastBound * kFastBound) ? 1 : 0) != 0;
     }
 
     // ---- attention for heads 2w, 2w+1 over all queries, wave-private ---------------------------
     constexpr int kLastRegs = 4 * VR4;  // registers of the last key tile that can hold real keys
 #pragma unroll
     for (int qt = 0; qt < TT; ++qt) {
-      __bf16* qrow = ys + (32 * qt + l31) * kRS + 32 * w;
+      E* qrow = ys + (32 * qt + l31) * kRS + 32 * w;
       f32x16 o = zero16();
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
@@ -457,11 +477,11 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
               p[r] = v;
             }
             if (kt & 1) {
-              acc1 = mfma(vfh[hh][kt][0], frag_from_acc(p, 0), kt == 1 ? zero16() : acc1);
-              if (nreg > 8) acc1 = mfma(vfh[hh][kt][1], frag_from_acc(p, 1), acc1);
+              acc1 = mfma(vfh[hh][kt][0], frag_from_acc<E>(p, 0), kt == 1 ? zero16() : acc1);
+              if (nreg > 8) acc1 = mfma(vfh[hh][kt][1], frag_from_acc<E>(p, 1), acc1);
             } else {
-              acc0 = mfma(vfh[hh][kt][0], frag_from_acc(p, 0), kt == 0 ? zero16() : acc0);
-              if (nreg > 8) acc0 = mfma(vfh[hh][kt][1], frag_from_acc(p, 1), acc0);
+              acc0 = mfma(vfh[hh][kt][0], frag_from_acc<E>(p, 0), kt == 0 ? zero16() : acc0);
+              if (nreg > 8) acc0 = mfma(vfh[hh][kt][1], frag_from_acc<E>(p, 1), acc0);
             }
           }
         } else {
@@ -484,11 +504,11 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kt][r] = __builtin_amdgcn_exp2f(s[kt][r] - m);
             if (kt & 1) {
-              acc1 = mfma(vfh[hh][kt][0], frag_from_acc(s[kt], 0), kt == 1 ? zero16() : acc1);
-              acc1 = mfma(vfh[hh][kt][1], frag_from_acc(s[kt], 1), acc1);
+              acc1 = mfma(vfh[hh][kt][0], frag_from_acc<E>(s[kt], 0), kt == 1 ? zero16() : acc1);
+              acc1 = mfma(vfh[hh][kt][1], frag_from_acc<E>(s[kt], 1), acc1);
             } else {
-              acc0 = mfma(vfh[hh][kt][0], frag_from_acc(s[kt], 0), kt == 0 ? zero16() : acc0);
-              acc0 = mfma(vfh[hh][kt][1], frag_from_acc(s[kt], 1), acc0);
+              acc0 = mfma(vfh[hh][kt][0], frag_from_acc<E>(s[kt], 0), kt == 0 ? zero16() : acc0);
+              acc0 = mfma(vfh[hh][kt][1], frag_from_acc<E>(s[kt], 1), acc0);
             }
           }
         }
@@ -502,7 +522,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       for (int c = 0; c < 4; ++c) {
         bf16x4 v;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = (__bf16)o[4 * c + i];
+        for (int i = 0; i < 4; ++i) v[i] = (E)o[4 * c + i];
         *reinterpret_cast<bf16x4*>(qrow + 8 * c + 4 * hi) = v;
       }
     }
@@ -537,7 +557,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         __syncthreads();
         // next: FFN1 of the next chunk, then the next layer's Q projection, finally the first fold block
         const bool last_layer = layer + 1 == a.num_layers;
-        const __bf16* nxt = c < 3 ? L.w1 : (last_layer ? wf_all : wqkv_all + (int64_t)(layer + 1) * 3 * kD * kD);
+        const E* nxt = c < 3 ? L.w1 : (last_layer ? wf_all : wqkv_all + (int64_t)(layer + 1) * 3 * kD * kD);
         gemm_t<TT, true, false>(y2, wf, ys, lane, nxt, 8, c < 3 ? 4 * (c + 1) + w : w, 0, y2[0]);
       }
       residual_norm<TT>(xs, y2, 32 * w, L.n2a, L.n2b, a.norm, N, lane);
@@ -557,11 +577,12 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
   const int nblocks = (a.env == RL4CO_ENV_TSP) ? 5 : 4;
   for (int blk = 0; blk < nblocks; ++blk) {
     f32x16 acc[TT];
-    gemm_t<TT>(acc, wf, xs, lane, blk + 1 < nblocks ? wf_all + (int64_t)(blk + 1) * kD * kD : nullptr, 8, w, 0, zero16());
+    gemm_t<TT>(acc, wf, xs, lane, blk + 1 < nblocks ? wf_all + (int64_t)(blk + 1) * kD * kD : static_cast<const E*>(nullptr), 8, w, 0,
+               zero16());
     // The tile leaves through LDS (`ys` is free after the last layer): stored straight from the accumulators a lane
     // owns 8 / 16 bytes in each of 32 token rows; staged, a plane of an instance is ONE contiguous run of 16-byte lanes.
-    if (blk < 3 && a.cache_dtype == RL4CO_DT_BF16) {
-      __bf16* out = static_cast<__bf16*>(a.kvl) + (int64_t)blk * a.kvl_plane_stride + (int64_t)b * a.kvl_batch_stride;
+    if (blk < 3 && a.cache_dtype != RL4CO_DT_F32) {  // 16-bit planes carry the element type of the activations
+      E* out = static_cast<E*>(a.kvl) + (int64_t)blk * a.kvl_plane_stride + (int64_t)b * a.kvl_batch_stride;
       store_t<TT>(ys, acc, 32 * w, lane);
       __syncthreads();
       for (int i = tid; i < N * 16; i += kThreads) {
@@ -628,24 +649,34 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
   }
 }
 
-template <int TT, int VR4>
+template <typename E, int TT, int VR4>
 int launch_encoder(const rl4co_am_encoder_args& a, hipStream_t stream) {
   const int lds = 2 * 128 * kRS * 2 + kD * 4 + kBiasFloats * 4;
-  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_encoder_kernel<TT, VR4>),
+  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_encoder_kernel<E, TT, VR4>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL((am_encoder_kernel<TT, VR4>), dim3(a.B), dim3(kThreads), lds, stream, a);
+  hipLaunchKernelGGL((am_encoder_kernel<E, TT, VR4>), dim3(a.B), dim3(kThreads), lds, stream, a);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }
 
-template <int TT>
+template <typename E, int TT>
 int launch_encoder_tiles(const rl4co_am_encoder_args& a, hipStream_t stream) {
   const int vr4 = (a.N - 32 * (TT - 1) + 7) / 8;  // valid 4-register groups of the last key tile
   switch (vr4) {
-    case 1: return launch_encoder<TT, 1>(a, stream);
-    case 2: return launch_encoder<TT, 2>(a, stream);
-    case 3: return launch_encoder<TT, 3>(a, stream);
-    default: return launch_encoder<TT, 4>(a, stream);
+    case 1: return launch_encoder<E, TT, 1>(a, stream);
+    case 2: return launch_encoder<E, TT, 2>(a, stream);
+    case 3: return launch_encoder<E, TT, 3>(a, stream);
+    default: return launch_encoder<E, TT, 4>(a, stream);
+  }
+}
+
+template <typename E>
+int launch_encoder_elem(const rl4co_am_encoder_args& a, hipStream_t s) {
+  switch ((a.N + 31) / 32) {
+    case 1: return launch_encoder_tiles<E, 1>(a, s);
+    case 2: return launch_encoder_tiles<E, 2>(a, s);
+    case 3: return launch_encoder_tiles<E, 3>(a, s);
+    default: return launch_encoder_tiles<E, 4>(a, s);
   }
 }
 
@@ -659,7 +690,9 @@ extern "C" int rl4co_am_encoder(const rl4co_am_encoder_args* args, void* stream)
   RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP || a.env == RL4CO_ENV_PDP);
   RL4CO_REQUIRE(a.B > 0 && a.N >= 2 && a.N <= 128);
   RL4CO_REQUIRE(a.num_layers >= 1 && (a.norm == 0 || a.norm == 1));
-  RL4CO_REQUIRE(a.cache_dtype == RL4CO_DT_F32 || a.cache_dtype == RL4CO_DT_BF16);
+  RL4CO_REQUIRE(a.act_dtype == RL4CO_DT_BF16 || a.act_dtype == RL4CO_DT_F16);
+  // planes: fp32, or the 16-bit type the activations are computed in
+  RL4CO_REQUIRE(a.cache_dtype == RL4CO_DT_F32 || a.cache_dtype == a.act_dtype);
   RL4CO_REQUIRE(a.locs && a.w_init && a.b_init);
   RL4CO_REQUIRE(a.env != RL4CO_ENV_CVRP || (a.demand && a.w_depot && a.b_depot));
   RL4CO_REQUIRE(a.env != RL4CO_ENV_PDP || (a.w_depot && a.b_depot && a.w_extra && a.b_extra && (a.N - 1) % 2 == 0));
@@ -669,11 +702,5 @@ extern "C" int rl4co_am_encoder(const rl4co_am_encoder_args* args, void* stream)
   RL4CO_REQUIRE(a.q_bias == nullptr || a.w_fixed != nullptr);
   RL4CO_REQUIRE(a.kvl_batch_stride >= (int64_t)a.N * kD && a.kvl_plane_stride >= a.kvl_batch_stride);
   hipStream_t s = rl4co::as_stream(stream);
-  const int tt = (a.N + 31) / 32;
-  switch (tt) {
-    case 1: return launch_encoder_tiles<1>(a, s);
-    case 2: return launch_encoder_tiles<2>(a, s);
-    case 3: return launch_encoder_tiles<3>(a, s);
-    default: return launch_encoder_tiles<4>(a, s);
-  }
+  return a.act_dtype == RL4CO_DT_F16 ? launch_encoder_elem<_Float16>(a, s) : launch_encoder_elem<__bf16>(a, s);
 }

@@ -24,6 +24,7 @@ class AmEncoderArgs(C.Structure):
 
     _fields_ = [
         ("env", _i32), ("B", _i32), ("N", _i32), ("num_layers", _i32), ("norm", _i32), ("cache_dtype", _i32),
+        ("act_dtype", _i32), ("reserved0", _i32),
         ("locs", _vp), ("demand", _vp), ("feature4", _vp), ("feature5", _vp), ("feature6", _vp), ("w_init", _vp), ("b_init", _vp), ("w_depot", _vp), ("b_depot", _vp), ("w_extra", _vp), ("b_extra", _vp),
         ("wqkv_packed", _vp), ("bqkv", _vp), ("wo_packed", _vp), ("bo", _vp), ("n1_scale", _vp), ("n1_shift", _vp),
         ("w1_packed", _vp), ("b1", _vp), ("w2_packed", _vp), ("b2", _vp), ("n2_scale", _vp), ("n2_shift", _vp),
@@ -33,12 +34,13 @@ class AmEncoderArgs(C.Structure):
     ]
 
 
-def pack_weight(w: Tensor) -> Tensor:
-    """nn.Linear weight [out,in] -> bf16 [out/32, in/16, 64, 8] in MFMA fragment order:
-    lane = 32*hi + row, element s = W[32*tile + row][16*kstep + 8*hi + s]."""
+def pack_weight(w: Tensor, dtype: torch.dtype = torch.bfloat16) -> Tensor:
+    """nn.Linear weight [out,in] -> 16-bit [out/32, in/16, 64, 8] in MFMA fragment order:
+    lane = 32*hi + row, element s = W[32*tile + row][16*kstep + 8*hi + s]. ``dtype``: the element type of the
+    kernel's MFMA operands (bfloat16, or float16 for the reference's default "16-mixed" regime)."""
     out_f, in_f = w.shape
     assert out_f % 32 == 0 and in_f % 16 == 0, (out_f, in_f)
-    t = w.detach().to(torch.bfloat16).view(out_f // 32, 32, in_f // 16, 2, 8)  # [tile,row,ks,hi,s]
+    t = w.detach().to(dtype).view(out_f // 32, 32, in_f // 16, 2, 8)  # [tile,row,ks,hi,s]
     return t.permute(0, 2, 3, 1, 4).contiguous().view(out_f // 32, in_f // 16, 64, 8)
 
 
@@ -62,6 +64,7 @@ class PackedEncoder:
         self.version = None
         self.t: dict[str, Tensor] = {}
         self._tensors: list[Tensor] | None = None
+        self.act_dtype = torch.bfloat16  # element type the weights are packed in (a regime switch re-packs)
 
     def _current_version(self):
         """Cheap change detector on the path of every rollout (it sits between the previous rollout's
@@ -77,11 +80,15 @@ class PackedEncoder:
         # inference tensors (a model built or loaded under torch.inference_mode) carry no version counter:
         # for them only the storage address is available, so in-place updates of such weights need refresh(force=True)
         return (tuple(0 if p.is_inference() else p._version for p in tensors), tuple(p.data_ptr() for p in tensors),
-                pol.training)
+                pol.training, self.act_dtype)
 
-    def refresh(self, force: bool = False) -> dict[str, Tensor]:
+    def refresh(self, force: bool = False, act_dtype: torch.dtype | None = None) -> dict[str, Tensor]:
         if force:
             self._tensors, self.version = None, None
+        if act_dtype is not None:
+            if act_dtype not in (torch.bfloat16, torch.float16):
+                raise TypeError(f"the fused encoder computes in bfloat16 or float16, not {act_dtype}")
+            self.act_dtype = act_dtype
         ver = self._current_version()
         if ver == self.version:
             return self.t
@@ -89,6 +96,7 @@ class PackedEncoder:
         enc, dec = pol.encoder, pol.decoder
         layers = list(enc.net.layers)
         f32 = lambda x: x.detach().float().contiguous()  # noqa: E731
+        pack_weight = lambda w: globals()["pack_weight"](w, self.act_dtype)  # noqa: E731
         t: dict[str, Tensor] = {}
         ie = enc.init_embedding
         if pol.env_name == "pdp":
@@ -150,8 +158,13 @@ class PackedEncoder:
             return False
         return kind in ("batch", "instance") and td["locs"].is_cuda
 
-    def encode(self, td, cache_dtype: torch.dtype, want_hidden: bool = False) -> tuple[FoldedCache, Tensor | None]:
-        t = self.refresh()
+    def encode(self, td, cache_dtype: torch.dtype, want_hidden: bool = False,
+               act_dtype: torch.dtype | None = None) -> tuple[FoldedCache, Tensor | None]:
+        """``act_dtype``: bfloat16 / float16 = the autocast regime the encoder is asked to compute in; the planes are
+        written as ``cache_dtype`` = float32 or that same 16-bit type."""
+        t = self.refresh(act_dtype=act_dtype)
+        if cache_dtype not in (torch.float32, self.act_dtype):
+            raise TypeError(f"cache planes must be float32 or the encoder's {self.act_dtype}, got {cache_dtype}")
         pol = self.policy
         locs = td["locs"]
         if locs.dtype != torch.float32 or not locs.is_contiguous():
@@ -167,7 +180,7 @@ class PackedEncoder:
         a = AmEncoderArgs()
         a.env = {"tsp": _lib.ENV_TSP, "pdp": _lib.ENV_PDP}.get(pol.env_name, _lib.ENV_CVRP)
         a.B, a.N, a.num_layers, a.norm = b, n, self.num_layers, self.norm_kind
-        a.cache_dtype = _lib.DT_BF16 if cache_dtype == torch.bfloat16 else _lib.DT_F32
+        a.cache_dtype, a.act_dtype = _lib.dtype_id(cache_dtype), _lib.dtype_id(self.act_dtype)
         a.locs = locs.data_ptr()
         ptr = lambda x: None if x is None else x.data_ptr()  # noqa: E731
         if pol.env_name in ("cvrp", "op", "pctsp", "cvrptw"):

@@ -23,7 +23,7 @@ def decode_row_groups(num_nodes: int, cache_dtype: torch.dtype, max_steps: int, 
                       num_trajectories: int = 1 << 20, num_instances: int | None = None) -> int:
     """Row groups of the specified-order contract of the variant that would run (0 = the multistart
     MFMA variant, which has none)."""
-    dt = _lib.DT_BF16 if cache_dtype == torch.bfloat16 else _lib.DT_F32
+    dt = _lib.dtype_id(cache_dtype)
     return _lib.decode_row_groups(num_nodes, dt, max_steps, VARIANT_IDS[variant], num_trajectories, num_instances)
 
 
@@ -34,7 +34,7 @@ def decode_variant(num_nodes: int, cache_dtype: torch.dtype, max_steps: int, num
     a.env = ENV_IDS[env_name]
     a.N, a.max_steps, a.B = int(num_nodes), int(max_steps), int(num_trajectories)
     a.B_inst = int(num_trajectories if num_instances is None else num_instances)
-    a.cache_dtype = _lib.DT_BF16 if cache_dtype == torch.bfloat16 else _lib.DT_F32
+    a.cache_dtype = _lib.dtype_id(cache_dtype)
     return _lib.lib().rl4co_am_decode_variant(C.byref(a))
 
 
@@ -233,12 +233,7 @@ def am_decode(
         raise _lib.Rl4coLibraryError(f"cache.kvl lives on {kvl.device}; the rl4co_amd kernels only run on the MI355X (no CPU fallback)")
     if not (kvl.dim() == 4 and kvl.stride(3) == 1):
         raise ValueError("cache.kvl must be [3, B, N, 128] with unit stride along the channels")
-    if kvl.dtype == torch.float32:
-        a.cache_dtype = _lib.DT_F32
-    elif kvl.dtype == torch.bfloat16:
-        a.cache_dtype = _lib.DT_BF16
-    else:
-        raise TypeError(f"cache dtype must be float32 or bfloat16, got {kvl.dtype}")
+    a.cache_dtype = _lib.dtype_id(kvl.dtype)
     a.glimpse_key, a.glimpse_val, a.logit_key = (cache.plane(i).data_ptr() for i in range(3))
     a.kvl_row_stride, a.kvl_batch_stride = cache.row_stride, cache.batch_stride
     if cache.unfold:  # reference-association parity mode: per-step GEMVs against the raw weights (cache.py)

@@ -630,13 +630,17 @@ class AttentionModelPolicy(nn.Module):
         grad_path = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if not self.fold and grad_path:
             raise NotImplementedError("fold=False is the inference parity configuration; train with the folded cache")
-        use_fused = (self.fused_encoder and self.fold and self._bf16_regime() and not grad_path
+        regime16 = self._encoder_regime() if self._encoder_regime() in (torch.bfloat16, torch.float16) else None
+        # fused MFMA encoder: a 16-bit autocast regime (bf16, or fp16 = the reference's default "16-mixed") whose planes
+        # are fp32 or that same 16-bit type
+        use_fused = (self.fused_encoder and self.fold and regime16 is not None and not grad_path
+                     and self.cache_dtype in (torch.float32, regime16)
                      and not return_init_embeds and self._packed_encoder().supported(td))
         if use_fused:
             if self.encode_events is not None:  # bench.py: HIP events around the encoder launch
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            cache, hidden = self._packed_encoder().encode(td, self.cache_dtype, want_hidden=return_hidden)
+            cache, hidden = self._packed_encoder().encode(td, self.cache_dtype, want_hidden=return_hidden, act_dtype=regime16)
             if self.encode_events is not None:
                 ev1.record()
                 self.encode_events.append((ev0, ev1))

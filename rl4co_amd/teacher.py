@@ -49,9 +49,12 @@ def max_nodes() -> int:
 def supports(env_name: str, cache_dtype: torch.dtype, num_nodes: int) -> bool:
     """TSP, CVRP, orienteering, prize-collecting TSP, pickup-delivery, CVRP with time windows — on both variants (the
     MMA one needs bf16 planes; fp32 planes take the replay kernel)."""
-    if num_nodes > max_nodes():
-        return False
+    if num_nodes > max_nodes() or cache_dtype not in (torch.float32, torch.bfloat16):
+        return False  # (fp16 planes: the backward kernels read fp32 or bf16 planes)
     return env_name in ("tsp", "cvrp", "op", "pctsp", "pdp", "cvrptw")
+
+
+backward_events: list | None = None  # set to [] by bench.py to time the teacher-forced backward launches
 
 
 def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: dict, variant: str = "auto",
@@ -82,7 +85,9 @@ def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: d
     a.B, a.B_inst, a.N, a.T, a.t0 = b, b_inst, n, t, int(meta["t0"])
     a.mask_inner, a.mask_logits = int(meta["mask_inner"]), int(meta["mask_logits"])
     a.tanh_clipping, a.temperature = float(meta["tanh_clipping"]), float(meta["temperature"])
-    a.cache_dtype = _lib.DT_BF16 if cache.kvl.dtype == torch.bfloat16 else _lib.DT_F32
+    if cache.kvl.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"teacher-forced backward reads float32 or bfloat16 planes, got {cache.kvl.dtype}")
+    a.cache_dtype = _lib.dtype_id(cache.kvl.dtype)
     a.variant = VARIANT_IDS[variant]
     a.glimpse_key, a.glimpse_val, a.logit_key = (cache.plane(i).data_ptr() for i in range(3))
     a.kvl_row_stride, a.kvl_batch_stride = cache.row_stride, cache.batch_stride
@@ -120,8 +125,14 @@ def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: d
     a.logp_out = ptr(logp)
     a.err = err.data_ptr()
     ran = _lib.lib().rl4co_am_teacher_variant(C.byref(a))
+    if backward_events is not None:  # bench.py: HIP events around the launch, on the stream it is issued on
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     st = _lib.lib().rl4co_am_teacher_backward(C.byref(a), torch.cuda.current_stream().cuda_stream)
     _lib.check(st, "rl4co_am_teacher_backward")
+    if backward_events is not None:
+        ev1.record()
+        backward_events.append((ev0, ev1))
     return {"d_kvl": d_kvl if d_planes is None else d_planes, "d_ctx_first": d_ctx_first, "d_ctx_cur": d_ctx_cur, "d_q_bias": d_q_bias,
             "d_extra": d_extra, "d_time": d_time, "logp": logp, "err": err, "variant": {1: "replay", 2: "mma"}.get(ran, "invalid")}
 

@@ -128,7 +128,7 @@ def _am_decode(cache, state, **kw):
 
     variant = {"auto": 0, "stream": 1, "lds": 2, "wide": 3, "ms": 4}[kw.pop("variant", "auto")]
     kw.pop("philox_seed_dev", None)
-    dt = _lib.DT_BF16 if cache.kvl.dtype == torch.bfloat16 else _lib.DT_F32
+    dt = _lib.dtype_id(cache.kvl.dtype)
     b = state["action_mask"].shape[0]
     groups = _lib.decode_row_groups(cache.num_nodes, dt, kw["max_steps"], variant, b, cache.num_instances)  # host-only
     if groups == 0:  # the MFMA multistart variant has no specified-order oracle: mirror the streaming one

@@ -47,7 +47,7 @@ def test_struct_layout_matches_header():
     assert _c_fields("rl4co_am_decode_args") == [f[0] for f in _lib.AmDecodeArgs._fields_]
     assert ctypes.sizeof(_lib.AmDecodeArgs) % 8 == 0
     assert _c_fields("rl4co_am_encoder_args") == [f[0] for f in AmEncoderArgs._fields_]
-    assert ctypes.sizeof(AmEncoderArgs) == 6 * 4 + 32 * 8
+    assert ctypes.sizeof(AmEncoderArgs) == 8 * 4 + 32 * 8
     from rl4co_amd.teacher import AmTeacherArgs
 
     assert _c_fields("rl4co_am_teacher_args") == [f[0] for f in AmTeacherArgs._fields_]

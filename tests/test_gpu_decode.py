@@ -91,8 +91,9 @@ def _assert_bit_exact(hip, ref):
 # bit-exact vs the specified-order oracle
 # ---------------------------------------------------------------------------------------------
 
-CONFIGS = [(torch.float32, "stream"), (torch.bfloat16, "stream"), (torch.bfloat16, "lds"), (torch.bfloat16, "wide")]
-CONFIG_IDS = ["f32-stream", "bf16-stream", "bf16-lds", "bf16-wide"]
+CONFIGS = [(torch.float32, "stream"), (torch.bfloat16, "stream"), (torch.bfloat16, "lds"), (torch.bfloat16, "wide"),
+           (torch.float16, "stream")]  # fp16 planes: the reference's default "16-mixed" regime (streaming kernel)
+CONFIG_IDS = ["f32-stream", "bf16-stream", "bf16-lds", "bf16-wide", "f16-stream"]
 
 
 def _skip_if_unservable(g, dtype, variant):

@@ -290,3 +290,87 @@ def test_fused_encoder_tile_shapes_and_softmax_paths(env_name, num_loc, sharp):
     tol = 5e-2 if sharp else REL_TOL  # one-hot attention amplifies bf16 score rounding into different winners
     assert _rel(hidden, h32) <= tol, _rel(hidden, h32)
     assert _rel(cache.kvl[2], ref.kvl[2]) <= tol
+
+
+# ---------------------------------------------------------------------------------------------
+# fp16: the reference's DEFAULT precision ("16-mixed" = torch.autocast(float16), utils/trainer.py:57)
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", ["tsp20_b64_greedy_simple", "tsp100_b64_greedy", "cvrp20_b128_greedy", "cvrp100_b64_greedy",
+                                  "pomo_tsp50_b8_mssampling"])
+@pytest.mark.parametrize("cache_dtype", [torch.float16, torch.float32], ids=["f16", "f32"])
+def test_fused_encoder_fp16_matches_oracle_and_torch_fp16_autocast(name, cache_dtype):
+    """am_encoder_kernel<_Float16, ...> (v_mfma_f32_32x32x16_f16, fp16 residual stream, always max-subtracted softmax)
+    against the ORACLE's fp32 CPU encoder (float64 fold) — tolerance 1e-2 relative Frobenius: fp16 carries 11
+    significant bits against bf16's 8, so the bound is tighter than the bf16 kernel's 3e-2 — and no worse than 2.5x the
+    error torch's own fp16 autocast path makes on the same inputs."""
+    g = GoldenCase(name)
+    pol = _policy(g, encoder_autocast=torch.float16, cache_dtype=cache_dtype)
+    _perturb_norm_stats(pol)
+    env, td = _td(g)
+    packed = pol._packed_encoder()
+    with torch.inference_mode():
+        cache, hidden = packed.encode(td, cache_dtype, want_hidden=True, act_dtype=torch.float16)
+        torch.cuda.synchronize()
+        with torch.autocast("cuda", dtype=torch.float16):
+            h16, _ = pol.encoder(td)
+        auto = pol.decoder.precompute_cache(h16, cache_dtype, torch.float32)
+    assert cache.kvl.dtype == cache_dtype and packed.t["wqkv"].dtype == torch.float16
+    want = _oracle_reference(g, pol)
+    checks = {"hidden": (hidden, want["hidden"], h16.float())}
+    for i, nm in enumerate(("glimpse_key", "glimpse_val", "logit_key")):
+        checks[nm] = (cache.kvl[i], want[nm], auto.kvl[i])
+    checks["ctx_cur"] = (cache.ctx_cur, want["ctx_cur"], auto.ctx_cur)
+    if g.env_name == "tsp":
+        checks["ctx_first"] = (cache.ctx_first, want["ctx_first"], auto.ctx_first)
+    if "q_bias" in want:
+        checks["q_bias"] = (cache.q_bias, want["q_bias"], auto.q_bias)
+    for nm, (got, ref, autoc) in checks.items():
+        assert torch.isfinite(got.float()).all(), nm
+        e_fused, e_auto = _rel(got, ref), _rel(autoc, ref)
+        assert e_fused <= 1e-2, f"{nm}: fused fp16 rel err {e_fused:.4f}"
+        assert e_fused <= 2.5 * e_auto + 1e-3, f"{nm}: fused {e_fused:.5f} vs torch fp16 autocast {e_auto:.5f}"
+    # switching the regime re-packs the weights; the bf16 kernel still serves the same policy afterwards
+    with torch.inference_mode():
+        cache_b, _ = packed.encode(td, torch.float32, act_dtype=torch.bfloat16)
+    assert packed.t["wqkv"].dtype == torch.bfloat16 and _rel(cache_b.kvl[0], want["glimpse_key"]) <= REL_TOL
+    with pytest.raises(TypeError):
+        packed.encode(td, torch.bfloat16, act_dtype=torch.float16)  # planes are fp32 or the activations' 16-bit type
+
+
+@pytest.mark.parametrize("env_name,num_loc", [("tsp", 50), ("cvrp", 50)])
+def test_policy_under_ambient_fp16_autocast_runs_on_the_kernels(env_name, num_loc):
+    """`RL4COTrainer()`'s default precision wraps validation / baseline rollouts in torch.autocast(float16): the policy
+    must take the fused fp16 encoder and the streaming decode kernel on fp16 planes (no torch fallback, no warning) and
+    produce valid tours whose quality matches the fp32 configuration; as a graph as well."""
+    import warnings
+
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.graph import GraphedRollout
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    torch.manual_seed(0)
+    pol32 = AttentionModelPolicy(env_name).cuda().eval()
+    pol16 = AttentionModelPolicy(env_name, cache_dtype=torch.float16).cuda().eval()
+    pol16.load_state_dict(pol32.state_dict())
+    env = get_env(env_name, generator_params=dict(num_loc=num_loc, device="cuda"), device="cuda")
+    torch.manual_seed(1)
+    data = env.generator(batch_size=[512])
+    pol16.encode_events = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)  # a fallback warning would fail the test
+        with torch.inference_mode(), torch.autocast("cuda", dtype=torch.float16):
+            out16 = pol16(env.reset(data), env, phase="test", decode_type="greedy")
+    assert len(pol16.encode_events) == 1, "ambient fp16 autocast did not select the fused encoder"
+    pol16.encode_events = None
+    assert pol16._packed.act_dtype == torch.float16
+    with torch.inference_mode():
+        out32 = pol32(env.reset(data), env, phase="test", decode_type="greedy")
+    gap = abs(float(out16["reward"].mean() - out32["reward"].mean())) / abs(float(out32["reward"].mean()))
+    assert gap <= 5e-3, gap
+    agree = (out16["actions"][:, : out32["actions"].shape[1]] == out32["actions"][:, : out16["actions"].shape[1]]).all(1).float().mean()
+    assert float(agree) >= 0.02  # random-init weights: near-uniform policy, most tours diverge at some near-tie
+    with torch.autocast("cuda", dtype=torch.float16):
+        g = GraphedRollout(pol16, env, data, decode_type="greedy")
+        again = g(data)
+    assert torch.equal(again["actions"], out16["actions"]) and torch.equal(again["reward"], out16["reward"])

@@ -439,3 +439,52 @@ def test_fused_fold_backward_matches_per_plane_autograd(env_name, graph_context)
     r = torch.cat([grads[False][k] for k in grads[False]])
     assert float(a @ r) / float(a.norm() * r.norm()) >= 0.999
     assert float((a - r).norm() / r.norm()) <= 3e-2
+
+
+@pytest.mark.parametrize("name,starts", [("tsp20_b64_greedy_simple", 0), ("cvrp20_b128_greedy", 0), ("tsp100_b64_greedy", 0),
+                                         ("cvrp100_b64_greedy", 0), ("pomo_tsp20_b16_msgreedy", 5), ("op20_b128_greedy", 0),
+                                         ("pctsp20_b128_greedy", 0), ("pdp20_b128_greedy", 0)])
+def test_backward_kernel_matches_oracle_cpu_gradients(name, starts):
+    """ONE hop, on the GPU — the HIP teacher-forced backward (through the product policy) against the
+    ORACLE's own gradients: the restatement (oracle/reference_torch.py, pinned bit for bit to the reference source) run
+    on the CPU with decode_type="evaluate" on the same trajectories, differentiated by torch autograd exactly as
+    REINFORCE does (reinforce.py:99-102). Log-likelihoods 1e-4, every parameter gradient 2e-3 relative."""
+    import copy
+
+    g = GoldenCase(name)
+    env, td = _td(g)
+    kw = dict(num_starts=starts) if starts else {}
+    pol = _policy(g)
+    calls = []
+    from rl4co_amd import teacher
+
+    orig = teacher.run_backward
+    teacher.run_backward = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        out = pol(env.reset(td), env, phase="train", decode_type="multistart_sampling" if starts else "sampling", seed=5, **kw)
+        adv = torch.linspace(-1.0, 1.0, out["actions"].shape[0], device="cuda")
+        (adv * out["log_likelihood"]).mean().backward()
+    finally:
+        teacher.run_backward = orig
+    assert calls, "the HIP backward kernel was not used"
+    pol.check_backward_errors()
+    ref_pol = copy.deepcopy(g.policy).train()
+    acts = out["actions"].cpu()
+    forced = acts[:, 1:].contiguous() if starts else acts
+    ref = ref_pol(g.reset(), g.env, phase="train", actions=forced, **kw)
+    assert torch.equal(ref["actions"], acts)
+    torch.testing.assert_close(out["log_likelihood"].detach().cpu(), ref["log_likelihood"].detach(), rtol=1e-4, atol=1e-4)
+    (adv.cpu() * ref["log_likelihood"]).mean().backward()
+    ours = dict(pol.named_parameters())
+    scale = max(float(p.grad.norm()) for p in ref_pol.parameters() if p.grad is not None)
+    checked = 0
+    for k, p in ref_pol.named_parameters():
+        got = ours[k].grad
+        if p.grad is None:
+            assert got is None or float(got.norm()) <= 1e-6 * scale, k
+            continue
+        err = float((got.cpu() - p.grad).norm())
+        bound = 2e-3 * float(p.grad.norm()) + 2e-5 * scale
+        assert err <= bound, f"{k}: |dg| {err:.3e} vs bound {bound:.3e}"
+        checked += 1
+    assert checked >= 20

@@ -120,3 +120,17 @@ def test_fixed_seed_sampling_on_trained_weights(name):
     assert rec["flips"] <= FP32_FLIP_BUDGET * rec["of"]
     assert rec["rewards_bit_identical_on_identical"] is True
     assert rec["reward_rel_gap"] <= (1e-5 if rec["flips"] == 0 else 1e-4)
+
+
+@pytest.mark.parametrize("name", ["t2_tsp100_b4096_greedy", "t3_cvrp100_b4096_greedy"])
+def test_fp16_configuration_vs_reference_fp32(name):
+    """The reference's DEFAULT precision ("16-mixed" = fp16 autocast, utils/trainer.py:57) on the fp16 kernels (fused
+    encoder on v_mfma_f32_32x32x16_f16, fp16 planes, fp32 decode arithmetic) against the reference's fp32 tours: with 11
+    significant bits against bf16's 8 it must stay at least as close to fp32 as the bf16 configuration does."""
+    case = TrainedCase(name)
+    rec = compare(case, "fp16", "cuda", against="fp32")
+    _record(f"trained/{name}/fp16_vs_ref_fp32", rec)
+    print(name, "fp16 vs reference fp32:", rec)
+    floor_same, floor_agree, gap = BF16[name][1]
+    assert rec["identical_frac"] >= floor_same and rec["step_agreement"] >= floor_agree and rec["reward_rel_gap"] <= gap
+    assert rec["rewards_bit_identical_on_identical"] is True

@@ -109,6 +109,7 @@ CONFIGS = {
     "fp32": dict(cache_dtype=torch.float32),
     "fp32_fold_off": dict(cache_dtype=torch.float32, fold=False),
     "bf16": dict(cache_dtype=torch.bfloat16, encoder_autocast=torch.bfloat16),
+    "fp16": dict(cache_dtype=torch.float16, encoder_autocast=torch.float16),  # the reference's default "16-mixed"
 }
 
 
