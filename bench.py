@@ -7,7 +7,11 @@
 
 One "step" = one pass of the hot path over one batch of synthetic instances already resident in HBM:
 ``env.reset`` -> AttentionModel policy rollout (fused MFMA encoder + cache fold, ONE persistent launch of the
-fused decode kernel for all T decode steps, tour-length reward, validity check).
+fused decode kernel for all T decode steps, tour-length reward, validity check). Inference legs run the K steps as a
+stream of batches with TWO captured rollouts in flight on two HIP streams (``--launch pipeline``, the default: the next
+batch's launches fill the CUs the finishing decode waves of the previous one release; every step is submitted, finished
+and read back inside the timed region); ``graph_ms_per_step`` (one captured graph per step, one stream) and
+``eager_ms_per_step`` are timed in the same process and reported beside it.
 
 HEADLINE (the top-level keys of the JSON line; `--steps K` / `--warmup W` apply to it): BASELINE.json
 configs[1] — TSPEnv num_loc=100, batch 4096 per GPU, AM (3 layers, d=128, 8 heads), bf16 encoder GEMMs and
@@ -215,7 +219,8 @@ class Bench:
 
         log(f"{leg}: rank {self.rank}/{self.world}, {batch} instances resident, warming up")
         rows = inst_steps = 0
-        use_graph = a.launch == "graph"
+        use_graph = a.launch in ("graph", "pipeline")
+        graph_ms = None
         with torch.inference_mode():
             for _ in range(warmup):
                 out = step()
@@ -242,6 +247,30 @@ class Bench:
                     step = lambda: graphed(data)  # noqa: E731
                     for _ in range(max(2, warmup)):  # replays before the clock starts (the first ones run slower)
                         out = step()
+                    if a.launch == "pipeline":
+                        # one stream first (reported as graph_ms_per_step), then two captured rollouts in flight on two
+                        # streams: the next batch's launches fill the CUs this batch's finishing decode waves release
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for _ in range(ev_steps):
+                            step()
+                        torch.cuda.synchronize()
+                        graph_ms = (time.perf_counter() - t0) / ev_steps * 1e3
+                        from rl4co_amd.graph import PipelinedRollout
+
+                        pipe = PipelinedRollout(policy, env, data, decode_type=decode, depth=2)
+                        tickets = []
+
+                        def step():
+                            if len(tickets) == pipe.depth:
+                                o = pipe.collect(tickets.pop(0))
+                            else:
+                                o = None
+                            tickets.append(pipe.submit(data))
+                            return o
+
+                        for _ in range(max(4, warmup)):
+                            step()
                 except Exception as exc:  # a launch sequence that cannot be captured stays on the eager path, said so
                     log(f"{leg}: HIP graph capture failed ({type(exc).__name__}: {exc}); timing the eager path")
                     use_graph = False
@@ -251,12 +280,30 @@ class Bench:
                 policy.decode_events, policy.encode_events = [], []
             gc.collect()
             gc.freeze()  # (see train_leg: a full collection over torch's module graph is a 60 ms host stall)
+            pipelined = use_graph and a.launch == "pipeline"
+            if pipelined:  # drain: the timed region starts and ends with nothing in flight
+                while tickets:
+                    out = pipe.collect(tickets.pop(0))
             self.barrier()
             t0 = time.perf_counter()
-            for _ in range(steps):
-                out = step()
-                rows += policy.last_rows_read
-                inst_steps += policy.last_instance_steps
+            if pipelined:
+                done = 0
+                for _ in range(steps):
+                    o = step()
+                    if o is not None:
+                        out, done = o, done + 1
+                        rows += policy.last_rows_read
+                        inst_steps += policy.last_instance_steps
+                while tickets:  # the K submitted steps are all finished (and read back) inside the timed region
+                    out, done = pipe.collect(tickets.pop(0)), done + 1
+                    rows += policy.last_rows_read
+                    inst_steps += policy.last_instance_steps
+                assert done == steps
+            else:
+                for _ in range(steps):
+                    out = step()
+                    rows += policy.last_rows_read
+                    inst_steps += policy.last_instance_steps
             self.barrier()
             wall = time.perf_counter() - t0
         if not use_graph:
@@ -267,7 +314,7 @@ class Bench:
         # the captured graph (its private memory pool, its streams) is released before the next leg: with two ranks
         # sharing ONE device (the RL4CO_BENCH_SHARED_GPU test mode) a lingering graph made the following training leg
         # crawl (3 s per step); nothing should outlive its leg anyway
-        step = graphed = None  # noqa: F841
+        step = graphed = pipe = None  # noqa: F841
         torch.cuda.synchronize()
         gc.collect()
         torch.cuda.empty_cache()
@@ -291,9 +338,12 @@ class Bench:
                          f"AttentionModel(3L,d128,h8) {decode} rollout, {a.encoder_dtype} encoder GEMMs, {a.cache_dtype} cache"),
             "value": value, "unit": "instance·step/s", "steps": steps, "warmup": warmup,
             "ms_per_step": wall / steps * 1e3,
-            "launch": ("hip_graph: reset + encoder + decode + check + reward captured once, one hipGraphLaunch and one "
-                       "16-byte read-back per step (rl4co_amd/graph.py)") if use_graph else "eager: one host launch per kernel",
-            "eager_ms_per_step": eager_ms,
+            "launch": (("pipeline: two captured rollouts (hip graphs) in flight on two HIP streams over the stream of batches "
+                        "(rl4co_amd/graph.py PipelinedRollout); every one of the K steps is submitted, finished and read back "
+                        "inside the timed region") if (use_graph and a.launch == "pipeline") else
+                       ("hip_graph: reset + encoder + decode + check + reward captured once, one hipGraphLaunch and one "
+                        "24-byte read-back per step (rl4co_amd/graph.py)") if use_graph else "eager: one host launch per kernel"),
+            "eager_ms_per_step": eager_ms, "graph_ms_per_step": graph_ms,
             "node_steps_per_sec": value * n_nodes,
             "instances_per_sec": batch * self.world * steps / wall,
             "decode_steps_longest": t_steps, "instance_steps_per_launch": per_launch_steps,
@@ -572,8 +622,9 @@ def main() -> None:
     ap.add_argument("--encoder-dtype", default="bf16", choices=["bf16", "f32"],
                     help="GEMM/attention input type of the encoder and cache-fold GEMMs (bf16 = MFMA rate, the "
                          "reference's mixed-precision regime; f32 = the parity configuration)")
-    ap.add_argument("--launch", default="graph", choices=["graph", "eager"],
-                    help="inference legs: replay the rollout as one captured HIP graph (default) or launch kernel by kernel")
+    ap.add_argument("--launch", default="pipeline", choices=["pipeline", "graph", "eager"],
+                    help="inference legs: two captured rollouts in flight on two streams (default), one captured HIP graph "
+                         "replayed per step, or kernel-by-kernel launches")
     ap.add_argument("--no-check-solution", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -686,7 +737,7 @@ def main() -> None:
             },
         }
         for k in ("node_steps_per_sec", "instances_per_sec", "mean_reward", "roofline", "encoder_roofline", "host_gap_ms", "launch",
-                  "eager_ms_per_step",
+                  "eager_ms_per_step", "graph_ms_per_step",
                   "trajectories_per_sec", "collective"):
             if k in head:
                 line[k] = head[k]

@@ -128,3 +128,33 @@ def test_graphed_rollout_leaves_the_packed_encoder_alone_when_the_fused_path_is_
         want = pol(env.reset(data), env, phase="test", decode_type="greedy")["reward"]
     after = g(data)["reward"]
     assert torch.equal(after, want) and not torch.equal(before, after)
+
+
+@pytest.mark.parametrize("env_name,num_loc", [("tsp", 50), ("cvrp", 50)])
+def test_pipelined_rollouts_equal_eager_over_a_stream_of_batches(env_name, num_loc):
+    """PipelinedRollout: two captured rollouts in flight on two streams; outputs in submission order, bit-identical to
+    the eager rollout of each batch; explicit tickets; a weight update in the middle of the stream is picked up."""
+    from rl4co_amd.graph import PipelinedRollout
+
+    pol, env, d1, d2 = _setup(env_name, num_loc, 256)
+    torch.manual_seed(3)
+    batches = [d1, d2] + [env.generator(batch_size=[256]) for _ in range(5)]
+    with torch.inference_mode():
+        want = [{k: v.clone() for k, v in pol(env.reset(b), env, phase="test", decode_type="greedy").items() if k in ("actions", "reward")}
+                for b in batches]
+    pipe = PipelinedRollout(pol, env, d1, decode_type="greedy", depth=2)
+    for i, out in enumerate(pipe.map(batches)):
+        assert torch.equal(out["actions"], want[i]["actions"]) and torch.equal(out["reward"], want[i]["reward"]), i
+    t0 = pipe.submit(batches[0])
+    t1 = pipe.submit(batches[1])
+    with pytest.raises(RuntimeError):
+        pipe.submit(batches[2])  # both slots hold uncollected results
+    assert torch.equal(pipe.collect(t0)["reward"], want[0]["reward"])
+    assert torch.equal(pipe.collect(t1)["reward"], want[1]["reward"])
+    with torch.no_grad():
+        for p in pol.parameters():
+            p.mul_(1.02)
+    with torch.inference_mode():
+        new = [pol(env.reset(b), env, phase="test", decode_type="greedy")["reward"].clone() for b in batches[:3]]
+    got = [out["reward"].clone() for out in pipe.map(batches[:3])]
+    assert all(torch.equal(a, b) for a, b in zip(got, new)) and not torch.equal(new[0], want[0]["reward"])
