@@ -177,7 +177,8 @@ class _EncoderLayer(nn.Sequential):
 
             _l.warn_fallback(f"train-autocast/{torch.get_autocast_dtype('cuda')}",
                              f"training under torch.autocast({torch.get_autocast_dtype('cuda')}): the training-encoder kernels "
-                             "serve bf16 autocast (and fp16 where built); this regime runs the torch encoder")
+                             "serve bf16 autocast; this regime trains on the torch encoder, as the reference does "
+                             "(AttentionModelPolicy(train_half_as_bf16=True) runs fp16-autocast training steps on the bf16 kernels)")
         return super().forward(x)
 
 
@@ -437,7 +438,8 @@ class AttentionModelPolicy(nn.Module):
                  train_decode_type: str = "sampling", val_decode_type: str = "greedy",
                  test_decode_type: str = "greedy", cache_dtype: torch.dtype = torch.float32,
                  encoder_autocast: torch.dtype | None = None, fused_encoder: bool = True,
-                 fused_backward: bool = True, teacher_variant: str = "auto", fold: bool = True, **unused_kwargs):
+                 fused_backward: bool = True, teacher_variant: str = "auto", fold: bool = True,
+                 train_half_as_bf16: bool = False, **unused_kwargs):
         super().__init__()
         if isinstance(env_name, RL4COEnvBase):
             env_name = env_name.name
@@ -467,6 +469,12 @@ class AttentionModelPolicy(nn.Module):
         # raw logit key; cache.py) — the strictest greedy-parity configuration (fp32, torch encoder, TSP / CVRP,
         # inference only): measured 4 instead of 10 near-tie flips in 4096 TSP-100 tours against the reference
         self.fold = fold
+        # TRAINING steps under fp16 autocast (Lightning's default "16-mixed"): the training-encoder kernels compute in
+        # bf16 (same 16-bit storage and MFMA rate, 8 instead of 11 significant bits, no overflow under GradScaler's loss
+        # scale). Off by default — the encoder then trains on torch under fp16 autocast exactly as the reference does;
+        # on, the step runs on the bf16 kernels (a precision CHANGE the caller opts into). Inference under fp16 autocast
+        # is served by true fp16 kernels either way (csrc/am_encoder.hip, act_dtype = f16)
+        self.train_half_as_bf16 = train_half_as_bf16
         self._packed = None
         self._ambient_autocast = None  # set for the duration of a forward() entered under torch.autocast
         self._bwd_err = None  # device int32 word the teacher backward ORs its sticky bits into (read with the next status)
@@ -546,6 +554,8 @@ class AttentionModelPolicy(nn.Module):
 
     def _encode(self, td):
         regime = self._encoder_regime()
+        if regime == torch.float16 and self.train_half_as_bf16 and torch.is_grad_enabled():
+            regime = torch.bfloat16  # opt-in: fp16-autocast TRAINING steps on the bf16 training kernels
         if regime is not None and td["locs"].is_cuda:
             with torch.autocast("cuda", dtype=regime):
                 return self.encoder(td)

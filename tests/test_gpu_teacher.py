@@ -488,3 +488,43 @@ def test_backward_kernel_matches_oracle_cpu_gradients(name, starts):
         assert err <= bound, f"{k}: |dg| {err:.3e} vs bound {bound:.3e}"
         checked += 1
     assert checked >= 20
+
+
+def test_fp16_autocast_training_step_default_and_opt_in_bf16_kernels():
+    """Lightning's default precision ("16-mixed": fp16 autocast + GradScaler, utils/trainer.py:57) around a REINFORCE
+    step. Default: the encoder trains on torch under that autocast (one RuntimeWarning names the fallback); rollout and
+    teacher-forced backward run on the kernels either way. `train_half_as_bf16=True`: the step's encoder runs on the
+    bf16 training kernels (no warning), gradients finite under the loss scale, the optimizer step goes through."""
+    import warnings
+
+    from rl4co_amd import _lib
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    env = get_env("tsp", generator_params=dict(num_loc=50, device="cuda"), device="cuda", check_solution=False)
+    torch.manual_seed(1)
+    data = env.generator(batch_size=[128])
+    for opt_in in (False, True):
+        torch.manual_seed(0)
+        pol = AttentionModelPolicy("tsp", num_encoder_layers=3, normalization="instance", use_graph_context=False,
+                                   cache_dtype=torch.bfloat16, train_decode_type="multistart_sampling",
+                                   train_half_as_bf16=opt_in).cuda().train()
+        opt = torch.optim.Adam(pol.parameters(), lr=1e-4)
+        scaler = torch.amp.GradScaler("cuda", init_scale=2.0 ** 12)
+        before = [p.detach().clone() for p in pol.parameters()]
+        _lib._warned.clear()
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            with torch.autocast("cuda", dtype=torch.float16):
+                out = pol(env.reset(data), env, phase="train", num_starts=8, seed=3)
+                reward, ll = out["reward"].view(8, 128).t(), out["log_likelihood"].view(8, 128).t()
+                loss = -((reward - reward.mean(1, keepdim=True)).detach() * ll).mean()
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+        pol.check_backward_errors()
+        fell_back = [w for w in caught if issubclass(w.category, RuntimeWarning) and "rl4co_amd" in str(w.message)]
+        assert bool(fell_back) == (not opt_in), [str(w.message) for w in fell_back]
+        assert out["log_likelihood"].dtype == torch.float32 and torch.isfinite(loss)
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in pol.parameters() if p.requires_grad and p.grad is not None)
+        assert any(not torch.equal(a, b.detach()) for a, b in zip(before, pol.parameters())), "the step changed no parameter"
