@@ -585,6 +585,38 @@ int rl4co_select_start_nodes(int64_t* out, int B, int num_starts, int num_loc, i
                              void* stream);
 
 /* --------------------------------------------------------------------------
+ * The same training-encoder / attention entry points for IEEE half activations (torch.float16): the reference's
+ * DEFAULT precision is Lightning's "16-mixed" = fp16 autocast (rl4co/utils/trainer.py:57). Identical arguments,
+ * layouts and semantics as their _bf16 namesakes above — every `const void*` / `void*` activation, weight or
+ * gradient operand holds binary16 instead of bfloat16, fp32 operands stay fp32; conversions to half round to
+ * nearest even and overflow to infinity (what GradScaler's inf check expects). One source per kernel, compiled
+ * for both element types (csrc/elem16.h).
+ * -------------------------------------------------------------------------- */
+int rl4co_init_embed_f16(const float* feats, const float* w, const float* b, int64_t M, int F, void* out, void* stream);
+int rl4co_init_embed_wgrad_f16(const void* dout, const float* feats, int64_t M, int F, float* partial, int* blocks_out,
+                                void* stream);
+int rl4co_skip_inorm_fwd_f16(const void* x, const void* s, const float* gamma, const float* beta, float eps,
+                              int B, int N, void* y, void* out, float* mean, float* rstd, void* stream);
+int rl4co_skip_inorm_bwd_f16(const void* dout, const void* y, const float* gamma, const float* mean,
+                              const float* rstd, int B, int N, void* dy, float* dgamma, float* dbeta,
+                              void* stream);
+int rl4co_skip_bnorm_stats_f16(const void* x, const void* s, int64_t M, void* y, float* sums, void* stream);
+int rl4co_bnorm_apply_f16(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                           int64_t M, void* out, void* stream);
+int rl4co_skip_bnorm_eval_f16(const void* x, const void* skip, const float* mean, const float* rstd, const float* gamma,
+                               const float* beta, int64_t M, void* out, void* stream);
+int rl4co_bnorm_bwd_f16(const void* dout, const void* y, const float* mean, const float* rstd, const float* gamma,
+                         int64_t M, float* sums, void* dy, void* stream);
+int rl4co_linear_f16(const void* a, const void* w, const float* bias, const void* mask, const void* residual, int64_t M,
+                      int N, int K, int relu, void* out, void* stream);
+int rl4co_wgrad_f16(const void* dy, const void* x, int64_t M, int N, int K, int chunks, float* partial,
+                     float* partial_bias, int64_t chunk_stride, void* stream);
+int rl4co_attn_fwd_f16(const void* qkv, int B, int N, void* out, float* lse, void* stream);
+int rl4co_attn_bwd_f16(const void* qkv, const void* dout, const float* lse, int B, int N, void* dqkv,
+                        void* stream);
+int rl4co_attn_flash_f16(const void* qkv, int B, int N, void* out, void* stream);
+
+/* --------------------------------------------------------------------------
  * N3  state augmentation                      rl4co/data/transforms.py:16-87, 105-151
  * Both kernels read the B instances ONCE and write the aug-major layout [A*B, N, 2] (row a*B + b) that the
  * multistart rollout consumes — what batchify (utils/ops.py:10-30) followed by the transform produces in the reference.

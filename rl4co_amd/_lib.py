@@ -133,6 +133,20 @@ SYMBOLS = {
     "rl4co_hbm_read_probe": (C.c_int, [_vp, _i64, _vp, _vp]),
     "rl4co_math_probe_f32": (C.c_int, [C.c_int, _vp, _i64, _vp, _vp]),
     "rl4co_uniform_f32": (C.c_int, [_vp, _i64, C.c_float, C.c_float, C.c_uint64, C.c_uint32, C.c_int, C.c_float, _vp]),
+    # IEEE-half twins of the training-encoder / attention kernels (csrc/elem16.h)
+    "rl4co_skip_inorm_fwd_f16": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
+    "rl4co_skip_inorm_bwd_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "rl4co_skip_bnorm_stats_f16": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp]),
+    "rl4co_bnorm_apply_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp]),
+    "rl4co_skip_bnorm_eval_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp]),
+    "rl4co_bnorm_bwd_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
+    "rl4co_init_embed_f16": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp]),
+    "rl4co_init_embed_wgrad_f16": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp]),
+    "rl4co_linear_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_attn_fwd_f16": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
+    "rl4co_attn_bwd_f16": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_attn_flash_f16": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_wgrad_f16": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp]),
 }
 
 

@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include "common.h"
+#include "elem16.h"
 
 namespace {
 
@@ -35,17 +36,17 @@ constexpr int kOS = kD + 8;          // LDS row stride of the output staging row
 constexpr float kNegInf = -__builtin_huge_valf();
 constexpr float kScale = 0.25f * 1.44269504088896341f;  // 1/sqrt(16) in the exp2 domain
 
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef elem_t bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 __device__ inline f32x4 mfma16(const bf16x4& a, const bf16x4& b, const f32x4& c) {
-  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+  return rl4co_e16::mfma_16x16x16(a, b, c);
 }
 __device__ inline f32x4 zero4() { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
-__device__ inline bf16x4 lds_b64(const __bf16* p) { return *reinterpret_cast<const bf16x4*>(p); }
-__device__ inline bf16x4 lds_tr(const __bf16* p) {
+__device__ inline bf16x4 lds_b64(const elem_t* p) { return *reinterpret_cast<const bf16x4*>(p); }
+__device__ inline bf16x4 lds_tr(const elem_t* p) {
   const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
   return __builtin_bit_cast(bf16x4, v);
 }
@@ -66,7 +67,7 @@ __device__ inline void block_map(int b, int B, int QB, int& inst, int& qb) {
 __global__ void __launch_bounds__(kThreads, 4) attn_flash_kernel(const uint16_t* __restrict__ qkv, int B, int N, int QB,
                                                                  uint16_t* __restrict__ out) {
   constexpr int kLds = kKB * kKS > kQT * 16 * kOS ? kKB * kKS : kQT * 16 * kOS;
-  __shared__ __align__(16) __bf16 kv[kLds];  // one key block: [64][k 128 | v 128]; later the output staging rows
+  __shared__ __align__(16) elem_t kv[kLds];  // one key block: [64][k 128 | v 128]; later the output staging rows
   const int tid = threadIdx.x, h = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
   int inst, qb;
   block_map(blockIdx.x, B, QB, inst, qb);
@@ -150,7 +151,7 @@ __global__ void __launch_bounds__(kThreads, 4) attn_flash_kernel(const uint16_t*
         for (int rr = 0; rr < 4; ++rr) {
           const float p = __builtin_amdgcn_exp2f(s[j][rr] - mn);
           ls += p;
-          pf[rr] = (__bf16)p;
+          pf[rr] = (elem_t)p;
         }
         acc = mfma16(vf[j], pf, acc);
       }
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(kThreads, 4) attn_flash_kernel(const uint16_t*
     const float inv = __builtin_amdgcn_rcpf(rl4co::bfly_sum<16, 64>(l[t]));
     bf16x4 ov;
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) ov[rr] = (__bf16)(o[t][rr] * inv);
+    for (int rr = 0; rr < 4; ++rr) ov[rr] = (elem_t)(o[t][rr] * inv);
     *reinterpret_cast<bf16x4*>(kv + (16 * t + tl) * kOS + 16 * h + 4 * g) = ov;
   }
   __syncthreads();
@@ -180,7 +181,7 @@ __global__ void __launch_bounds__(kThreads, 4) attn_flash_kernel(const uint16_t*
 
 }  // namespace
 
-extern "C" int rl4co_attn_flash_bf16(const void* qkv, int B, int N, void* out, void* stream) {
+extern "C" int RL4CO_ENTRY(rl4co_attn_flash)(const void* qkv, int B, int N, void* out, void* stream) {
   RL4CO_REQUIRE(qkv && out && B > 0 && N >= 1 && N <= 65536);
   const int QB = (N + kQT * 16 - 1) / (kQT * 16);
   RL4CO_REQUIRE((int64_t)B * QB < (1ll << 31));

@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include "common.h"
+#include "elem16.h"
 
 namespace {
 
@@ -31,24 +32,24 @@ constexpr int kThreads = 64 * kWaves;
 constexpr float kNegInf = -__builtin_huge_valf();
 constexpr float kScale = 0.25f * 1.44269504088896341f;  // 1/sqrt(16) in the exp2 domain
 
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef elem_t bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 __device__ inline f32x4 mfma16(const bf16x4& a, const bf16x4& b, const f32x4& c) {
-  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+  return rl4co_e16::mfma_16x16x16(a, b, c);
 }
 __device__ inline f32x4 zero4() { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
-__device__ inline bf16x4 lds_b64(const __bf16* p) { return *reinterpret_cast<const bf16x4*>(p); }
-__device__ inline bf16x4 lds_tr(const __bf16* p) {
+__device__ inline bf16x4 lds_b64(const elem_t* p) { return *reinterpret_cast<const bf16x4*>(p); }
+__device__ inline bf16x4 lds_tr(const elem_t* p) {
   const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
   return __builtin_bit_cast(bf16x4, v);
 }
 __device__ inline bf16x4 to_bf16(const f32x4& v) {
   bf16x4 o;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+  for (int i = 0; i < 4; ++i) o[i] = (elem_t)v[i];
   return o;
 }
 __device__ inline void wave_lds_sync() {
@@ -61,7 +62,7 @@ __device__ inline float rg_max(float v) { return rl4co::bfly_max<16, 64>(v); }
 
 // rows [0, 16 NT) x `cols` bf16 columns of an instance -> LDS (rows >= N zero)
 template <int NT>
-__device__ inline void stage_rows(const uint16_t* __restrict__ src, int N, int cols, __bf16* dst, int stride, int tid) {
+__device__ inline void stage_rows(const uint16_t* __restrict__ src, int N, int cols, elem_t* dst, int stride, int tid) {
   const int cpr = cols / 8;  // 16-byte chunks per row
   const int total = NT * 16 * cpr;
   // eight chunks per thread in flight: load -> LDS store one chunk at a time is one exposed HBM round trip per chunk
@@ -86,7 +87,7 @@ __device__ inline void stage_rows(const uint16_t* __restrict__ src, int N, int c
 
 // rows [0, 16 NT) x the k | v columns (128 .. 383 of the packed row) of an instance -> LDS (rows >= N zero)
 template <int NT>
-__device__ inline void stage_kv(const uint16_t* __restrict__ src, int N, __bf16* dst, int tid) {
+__device__ inline void stage_kv(const uint16_t* __restrict__ src, int N, elem_t* dst, int tid) {
   constexpr int cpr = 2 * kD / 8;  // 16-byte chunks per row
   constexpr int total = NT * 16 * cpr;
   for (int c0 = tid; c0 < total; c0 += 8 * kThreads) {
@@ -116,7 +117,7 @@ template <int NT>
 __global__ void __launch_bounds__(kThreads, 4) attn_fwd_kernel(const uint16_t* __restrict__ qkv, int N, uint16_t* __restrict__ out,
                                                                float* __restrict__ lse) {
   extern __shared__ __align__(16) unsigned char smem[];
-  __bf16* kv = reinterpret_cast<__bf16*>(smem);  // [16 NT][kKV]: k | v of every node; afterwards the output rows [16 NT][kOS]
+  elem_t* kv = reinterpret_cast<elem_t*>(smem);  // [16 NT][kKV]: k | v of every node; afterwards the output rows [16 NT][kOS]
   const int tid = threadIdx.x, h = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
   const int64_t inst = blockIdx.x;
   const uint16_t* base = qkv + inst * N * 3 * kD;
@@ -154,7 +155,7 @@ __global__ void __launch_bounds__(kThreads, 4) attn_fwd_kernel(const uint16_t* _
       for (int rr = 0; rr < 4; ++rr) {
         const float p = __builtin_amdgcn_exp2f(sc[jt][rr] - m);
         l += p;
-        pf[rr] = (__bf16)p;
+        pf[rr] = (elem_t)p;
       }
       const bf16x4 vf = lds_tr(kv + 16 * jt * kKV + kD + 16 * h + tro);
       if (jt & 1) o1 = mfma16(vf, pf, o1);
@@ -197,11 +198,11 @@ template <int NT>
 __global__ void __launch_bounds__(kBwdThreads, 3) attn_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
                                                                   const float* __restrict__ lse, int N, uint16_t* __restrict__ dqkv) {
   extern __shared__ __align__(16) unsigned char smem[];
-  __bf16* kv = reinterpret_cast<__bf16*>(smem);  // [16 NT][kKH]: k (4 heads) | v (4 heads)
+  elem_t* kv = reinterpret_cast<elem_t*>(smem);  // [16 NT][kKH]: k (4 heads) | v (4 heads)
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
   const int64_t inst = blockIdx.x >> 1;
   const int hh = blockIdx.x & 1, h = 4 * hh + w;
-  __bf16* pbw = kv + NT * 16 * kKH + w * 16 * kPS;  // this wave's [16 queries][kPS]
+  elem_t* pbw = kv + NT * 16 * kKH + w * 16 * kPS;  // this wave's [16 queries][kPS]
   const uint16_t* base = qkv + inst * N * 3 * kD;
   {  // k | v columns of this half: 16 chunks of 16 bytes per row, eight in flight per thread
     constexpr int total = NT * 16 * 16;
@@ -268,7 +269,7 @@ __global__ void __launch_bounds__(kBwdThreads, 3) attn_bwd_kernel(const uint16_t
       for (int rr = 0; rr < 4; ++rr) {
         const bool ok = tv && (16 * jt + 4 * g + rr < N);
         const float p = ok ? __builtin_amdgcn_exp2f(sc[rr] * kScale - L) : 0.0f;
-        pf[jt][rr] = (__bf16)p;
+        pf[jt][rr] = (elem_t)p;
         dsum = fmaf((float)pf[jt][rr], dp[jt][rr], dsum);
       }
       *reinterpret_cast<bf16x4*>(pbw + tl * kPS + 16 * jt + 4 * g) = pf[jt];
@@ -286,7 +287,7 @@ __global__ void __launch_bounds__(kBwdThreads, 3) attn_bwd_kernel(const uint16_t
     for (int jt = 0; jt < NT; ++jt) {
       bf16x4 dsf;
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) dsf[rr] = (__bf16)((float)pf[jt][rr] * (dp[jt][rr] - dsum));
+      for (int rr = 0; rr < 4; ++rr) dsf[rr] = (elem_t)((float)pf[jt][rr] * (dp[jt][rr] - dsum));
       *reinterpret_cast<bf16x4*>(pbw + tl * kPS + 16 * jt + 4 * g) = dsf;
       dq = mfma16(lds_tr(kv + 16 * jt * kKH + 16 * w + tro), dsf, dq);
     }
@@ -302,12 +303,12 @@ __global__ void __launch_bounds__(kBwdThreads, 3) attn_bwd_kernel(const uint16_t
     wave_lds_sync();  // the next query block rewrites this wave's staging block
   }
   __syncthreads();  // every wave is done with k | v: the whole LDS becomes [16 NT][d q | d k | d v] of the four heads
-  __bf16* os = reinterpret_cast<__bf16*>(smem);
+  elem_t* os = reinterpret_cast<elem_t*>(smem);
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) {
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) dk[jt][rr] *= 0.25f;
-    __bf16* row = os + (16 * jt + tl) * kDS + 16 * w + 4 * g;
+    elem_t* row = os + (16 * jt + tl) * kDS + 16 * w + 4 * g;
     *reinterpret_cast<bf16x4*>(row) = dqv[jt];
     *reinterpret_cast<bf16x4*>(row + 64) = to_bf16(dk[jt]);
     *reinterpret_cast<bf16x4*>(row + 128) = to_bf16(dv[jt]);
@@ -342,9 +343,11 @@ int launch_bwd(const void* qkv, const void* dout, const float* lse, int B, int N
 
 }  // namespace
 
+#if !RL4CO_ELEM_F16
 extern "C" int rl4co_attn_max_nodes(void) { return 128; }
+#endif
 
-extern "C" int rl4co_attn_fwd_bf16(const void* qkv, int B, int N, void* out, float* lse, void* stream) {
+extern "C" int RL4CO_ENTRY(rl4co_attn_fwd)(const void* qkv, int B, int N, void* out, float* lse, void* stream) {
   RL4CO_REQUIRE(qkv && out && lse && B > 0 && N >= 1 && N <= 128);
   hipStream_t s = rl4co::as_stream(stream);
   const int nt = (N + 15) >> 4;
@@ -354,7 +357,7 @@ extern "C" int rl4co_attn_fwd_bf16(const void* qkv, int B, int N, void* out, flo
   return launch_fwd<8>(qkv, B, N, out, lse, s);
 }
 
-extern "C" int rl4co_attn_bwd_bf16(const void* qkv, const void* dout, const float* lse, int B, int N, void* dqkv, void* stream) {
+extern "C" int RL4CO_ENTRY(rl4co_attn_bwd)(const void* qkv, const void* dout, const float* lse, int B, int N, void* dqkv, void* stream) {
   RL4CO_REQUIRE(qkv && dout && lse && dqkv && B > 0 && B < (1 << 30) && N >= 1 && N <= 128);
   hipStream_t s = rl4co::as_stream(stream);
   const int nt = (N + 15) >> 4;

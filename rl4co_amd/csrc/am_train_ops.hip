@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include "common.h"
+#include "elem16.h"
 
 namespace {
 
@@ -25,15 +26,11 @@ constexpr int kD = RL4CO_EMBED_DIM;
 constexpr int kThreads = 256;
 constexpr int kMaxRows = 32;  // nodes per thread: N <= 128
 
-__device__ inline float bf16_lo(uint32_t v) { return __uint_as_float(v << 16); }
-__device__ inline float bf16_hi(uint32_t v) { return __uint_as_float(v & 0xffff0000u); }
-__device__ inline uint32_t pack_bf16(float a, float b) {
-  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-  bf16x2 v;
-  v[0] = (__bf16)a;
-  v[1] = (__bf16)b;
-  return __builtin_bit_cast(uint32_t, v);
-}
+// (historic names: the two packed 16-bit elements of a word, in whichever element type this unit is compiled for —
+// elem16.h)
+__device__ inline float bf16_lo(uint32_t v) { return rl4co_e16::lo(v); }
+__device__ inline float bf16_hi(uint32_t v) { return rl4co_e16::hi(v); }
+__device__ inline uint32_t pack_bf16(float a, float b) { return rl4co_e16::pack(a, b); }
 
 // thread = channel pair (tid & 63) x node class (tid >> 6: nodes q, q + 4, ...); sums over the four
 // node classes meet in LDS
@@ -172,9 +169,11 @@ __global__ void __launch_bounds__(kThreads) skip_inorm_bwd_kernel(const uint32_t
 
 }  // namespace
 
+#if !RL4CO_ELEM_F16
 extern "C" int rl4co_skip_inorm_max_nodes(void) { return 4 * kMaxRows; }
+#endif
 
-extern "C" int rl4co_skip_inorm_fwd_bf16(const void* x, const void* s, const float* gamma, const float* beta, float eps, int B,
+extern "C" int RL4CO_ENTRY(rl4co_skip_inorm_fwd)(const void* x, const void* s, const float* gamma, const float* beta, float eps, int B,
                                          int N, void* y, void* out, float* mean, float* rstd, void* stream) {
   RL4CO_REQUIRE(x && s && gamma && beta && y && out && mean && rstd);
   RL4CO_REQUIRE(B > 0 && N >= 1 && N <= 4 * kMaxRows && eps > 0.0f);
@@ -185,7 +184,7 @@ extern "C" int rl4co_skip_inorm_fwd_bf16(const void* x, const void* s, const flo
   return RL4CO_OK;
 }
 
-extern "C" int rl4co_skip_inorm_bwd_bf16(const void* dout, const void* y, const float* gamma, const float* mean,
+extern "C" int RL4CO_ENTRY(rl4co_skip_inorm_bwd)(const void* dout, const void* y, const float* gamma, const float* mean,
                                          const float* rstd, int B, int N, void* dy, float* dgamma, float* dbeta, void* stream) {
   RL4CO_REQUIRE(dout && y && gamma && mean && rstd && dy && dgamma && dbeta);
   RL4CO_REQUIRE(B > 0 && N >= 1 && N <= 4 * kMaxRows);
@@ -219,8 +218,8 @@ constexpr int kLS = kTK + 8;                    // LDS row stride (bf16)
 constexpr int kGemmThreads = 256;
 constexpr int kMaxLinearN = 1024;  // output features (the bias sits in LDS)
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4g __attribute__((ext_vector_type(4)));
+typedef elem_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef elem_t bf16x4g __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __global__ void __launch_bounds__(kGemmThreads, 2) linear_bf16_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
@@ -228,8 +227,8 @@ __global__ void __launch_bounds__(kGemmThreads, 2) linear_bf16_kernel(const uint
                                                                       const uint16_t* __restrict__ residual, int M, int N, int K, int relu,
                                                                       uint16_t* __restrict__ out) {
   extern __shared__ __align__(16) unsigned char smem_g[];
-  __bf16* as = reinterpret_cast<__bf16*>(smem_g);  // [128 tokens][kLS]
-  __bf16* ws = as + kTM * kLS;                       // [128 features][kLS]
+  elem_t* as = reinterpret_cast<elem_t*>(smem_g);  // [128 tokens][kLS]
+  elem_t* ws = as + kTM * kLS;                       // [128 features][kLS]
   float* bl = reinterpret_cast<float*>(ws + kTN * kLS);  // [N] bias: read from LDS in the epilogue (sixteen dependent
                                                          // L2 round trips per feature tile when read from global there)
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -289,7 +288,7 @@ __global__ void __launch_bounds__(kGemmThreads, 2) linear_bf16_kernel(const uint
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
         const bf16x8 feat = *reinterpret_cast<const bf16x8*>(ws + (32 * ct + l31) * kLS + 16 * ks + 8 * hi);
-        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(feat, tok, acc[ct], 0, 0, 0);
+        acc[ct] = rl4co_e16::mfma_32x32x16(feat, tok, acc[ct]);
       }
     }
     {
@@ -311,7 +310,7 @@ __global__ void __launch_bounds__(kGemmThreads, 2) linear_bf16_kernel(const uint
       // The weight tile `ws` is dead once every wave has issued its products; each wave stages and drains only
       // its own 32 token rows, so the staging itself needs no workgroup barrier.
       rl4co::lds_barrier();
-      __bf16* os = ws;  // [128 tokens][kLS]
+      elem_t* os = ws;  // [128 tokens][kLS]
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
 #pragma unroll
@@ -334,7 +333,7 @@ __global__ void __launch_bounds__(kGemmThreads, 2) linear_bf16_kernel(const uint
           }
           bf16x4g o;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+          for (int i = 0; i < 4; ++i) o[i] = (elem_t)v[i];
           *reinterpret_cast<bf16x4g*>(os + (32 * w + l31) * kLS + fl) = o;
         }
       }
@@ -358,11 +357,9 @@ __global__ void __launch_bounds__(kGemmThreads, 2) linear_bf16_kernel(const uint
             const u32x4 rs = mks[p8];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const float lo = __uint_as_float(val[i] << 16) + __uint_as_float(rs[i] << 16);
-              const float hi = __uint_as_float(val[i] & 0xffff0000u) + __uint_as_float(rs[i] & 0xffff0000u);
-              typedef __bf16 bf16x2g __attribute__((ext_vector_type(2)));
-              const bf16x2g pk = {(__bf16)lo, (__bf16)hi};
-              val[i] = __builtin_bit_cast(uint32_t, pk);
+              const float lo = rl4co_e16::lo(val[i]) + rl4co_e16::lo(rs[i]);
+              const float hi = rl4co_e16::hi(val[i]) + rl4co_e16::hi(rs[i]);
+              val[i] = rl4co_e16::pack(lo, hi);
             }
           }
           *reinterpret_cast<u32x4*>(out + row * N + nt * kTN + ocol) = val;
@@ -388,7 +385,7 @@ __global__ void __launch_bounds__(kGemmThreads, 3) linear_k128_kernel(const uint
                                                                       const float* __restrict__ bias, int M, int N, int relu,
                                                                       uint16_t* __restrict__ out) {
   extern __shared__ __align__(16) unsigned char smem_g[];
-  __bf16* ws = reinterpret_cast<__bf16*>(smem_g);        // [128][kLS]: the token tile once, then feature tiles / staged output
+  elem_t* ws = reinterpret_cast<elem_t*>(smem_g);        // [128][kLS]: the token tile once, then feature tiles / staged output
   float* bl = reinterpret_cast<float*>(ws + kTN * kLS);  // [N] bias
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
   const int64_t m0 = (int64_t)blockIdx.x * kTM;
@@ -436,14 +433,14 @@ __global__ void __launch_bounds__(kGemmThreads, 3) linear_k128_kernel(const uint
 #pragma unroll
       for (int ct = 0; ct < 4; ++ct) {
         const bf16x8 feat = *reinterpret_cast<const bf16x8*>(ws + (32 * ct + l31) * kLS + 16 * ks + 8 * hi);
-        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(feat, tok[ks], acc[ct], 0, 0, 0);
+        acc[ct] = rl4co_e16::mfma_32x32x16(feat, tok[ks], acc[ct]);
       }
     }
     // the prefetched tile pinned in its registers before this tile's stores are issued (see linear_bf16_kernel)
 #pragma unroll
     for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(pw[j]));
     rl4co::lds_barrier();  // every wave has issued its products: the feature tile is dead, the output is staged over it
-    __bf16* os = ws;
+    elem_t* os = ws;
 #pragma unroll
     for (int ct = 0; ct < 4; ++ct) {
 #pragma unroll
@@ -466,7 +463,7 @@ __global__ void __launch_bounds__(kGemmThreads, 3) linear_k128_kernel(const uint
         }
         bf16x4g o;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+        for (int i = 0; i < 4; ++i) o[i] = (elem_t)v[i];
         *reinterpret_cast<bf16x4g*>(os + (32 * w + l31) * kLS + fl) = o;
       }
     }
@@ -498,7 +495,7 @@ int launch_k128(const void* a, const void* w, const float* bias, int64_t M, int 
 
 }  // namespace
 
-extern "C" int rl4co_linear_bf16(const void* a, const void* w, const float* bias, const void* mask, const void* residual,
+extern "C" int RL4CO_ENTRY(rl4co_linear)(const void* a, const void* w, const float* bias, const void* mask, const void* residual,
                                  int64_t M, int N, int K, int relu, void* out, void* stream) {
   RL4CO_REQUIRE(a && w && out);
   RL4CO_REQUIRE(M > 0 && M < (int64_t)1 << 31 && N > 0 && K > 0 && N % kTN == 0 && K % kTK == 0);
@@ -531,12 +528,12 @@ constexpr int kWT = 64;        // token rows per LDS step: the step is one expos
                                // step must outlast it (at 32 rows two resident workgroups kept the matrix pipe ~40 % busy)
 constexpr int kWLS = 128 + 8;  // LDS row stride (bf16)
 
-typedef __bf16 bf16x4w __attribute__((ext_vector_type(4)));
+typedef elem_t bf16x4w __attribute__((ext_vector_type(4)));
 typedef short s16x4w __attribute__((ext_vector_type(4)));
 typedef float f32x4w __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4w lds_s16x4w;
 
-__device__ inline bf16x4w lds_tr_w(const __bf16* p) {
+__device__ inline bf16x4w lds_tr_w(const elem_t* p) {
   const s16x4w v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4w*)p);
   return __builtin_bit_cast(bf16x4w, v);
 }
@@ -544,8 +541,8 @@ __device__ inline bf16x4w lds_tr_w(const __bf16* p) {
 __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X, int M, int N,
                                                          int K, int rows_per_chunk, int n_chunks, float* __restrict__ partial,
                                                          float* __restrict__ partial_bias, int64_t pstride, int64_t bstride) {
-  __shared__ __align__(16) __bf16 dyt[kWT * kWLS];  // [32 tokens][128 output features of this tile]
-  __shared__ __align__(16) __bf16 xt[kWT * kWLS];   // [32 tokens][128 input features of this tile]
+  __shared__ __align__(16) elem_t dyt[kWT * kWLS];  // [32 tokens][128 output features of this tile]
+  __shared__ __align__(16) elem_t xt[kWT * kWLS];   // [32 tokens][128 input features of this tile]
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
   const int kt_n = K / 128;
   // workgroup -> (tile, row chunk). The tiles of ONE chunk re-read the same rows of the operand they share (X for
@@ -574,8 +571,8 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const uint16_t* __restr
   // (tiles with kt == 0 only); every accumulator column then holds the same sum
   const bool with_bias = partial_bias != nullptr && kt == 0;
   f32x4w accb[2] = {f32x4w{0.0f, 0.0f, 0.0f, 0.0f}, f32x4w{0.0f, 0.0f, 0.0f, 0.0f}};
-  typedef __bf16 bf16x8o __attribute__((ext_vector_type(8)));
-  const bf16x8o ones = {(__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f, (__bf16)1.0f};
+  typedef elem_t bf16x8o __attribute__((ext_vector_type(8)));
+  const bf16x8o ones = {(elem_t)1.0f, (elem_t)1.0f, (elem_t)1.0f, (elem_t)1.0f, (elem_t)1.0f, (elem_t)1.0f, (elem_t)1.0f, (elem_t)1.0f};
   const int lrow = tid >> 3, lcol = (tid & 7) * 16;  // this thread stages 32 bytes of each tile row
   typedef uint32_t u32x4w __attribute__((ext_vector_type(4)));
   // the rows of step i + 1 are requested before the products of step i (registers), so a step no longer opens with
@@ -611,8 +608,8 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const uint16_t* __restr
     // 32 tokens per product: v_mfma_f32_16x16x32_bf16 (gfx950) runs at twice the rate of the 16-deep instruction, and
     // the contraction runs over tokens, so ANY assignment of tokens to its 32 slots is right as long as both operands
     // use the same one — two 16-token transpose reads side by side (tokens 16 ts + 4 g .. and 16 (ts + 1) + 4 g ..)
-    typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
-    auto pair = [&](const __bf16* p) {
+    typedef elem_t bf16x8w __attribute__((ext_vector_type(8)));
+    auto pair = [&](const elem_t* p) {
       const bf16x4w lo = lds_tr_w(p), hi = lds_tr_w(p + 16 * kWLS);
       return bf16x8w{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     };
@@ -623,13 +620,13 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const uint16_t* __restr
       for (int nb = 0; nb < 2; ++nb) af[nb] = pair(dyt + 16 * ts * kWLS + 32 * w + 16 * nb + tro);
       if (with_bias) {
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) accb[nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nb], ones, accb[nb], 0, 0, 0);
+        for (int nb = 0; nb < 2; ++nb) accb[nb] = rl4co_e16::mfma_16x16x32(af[nb], ones, accb[nb]);
       }
 #pragma unroll
       for (int kb = 0; kb < 8; ++kb) {
         const bf16x8w bf = pair(xt + 16 * ts * kWLS + 16 * kb + tro);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) acc[nb][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[nb], bf, acc[nb][kb], 0, 0, 0);
+        for (int nb = 0; nb < 2; ++nb) acc[nb][kb] = rl4co_e16::mfma_16x16x32(af[nb], bf, acc[nb][kb]);
       }
     }
   }
@@ -651,7 +648,7 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const uint16_t* __restr
 
 }  // namespace
 
-extern "C" int rl4co_wgrad_bf16(const void* dy, const void* x, int64_t M, int N, int K, int chunks, float* partial,
+extern "C" int RL4CO_ENTRY(rl4co_wgrad)(const void* dy, const void* x, int64_t M, int N, int K, int chunks, float* partial,
                                 float* partial_bias, int64_t chunk_stride, void* stream) {
   RL4CO_REQUIRE(chunk_stride == 0 || chunk_stride >= (int64_t)N * K);
   const int64_t pstride = chunk_stride ? chunk_stride : (int64_t)N * K, bstride = chunk_stride ? chunk_stride : (int64_t)N;
@@ -853,7 +850,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const uint32_t* __res
 
 }  // namespace
 
-extern "C" int rl4co_skip_bnorm_stats_bf16(const void* x, const void* s, int64_t M, void* y, float* sums, void* stream) {
+extern "C" int RL4CO_ENTRY(rl4co_skip_bnorm_stats)(const void* x, const void* s, int64_t M, void* y, float* sums, void* stream) {
   RL4CO_REQUIRE(x && sums && M > 0 && (s == nullptr || y != nullptr));
   const int blocks = (int)min((int64_t)2048, (M + kBnRows - 1) / kBnRows);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(blocks), dim3(256), 0, rl4co::as_stream(stream), static_cast<const uint32_t*>(x),
@@ -862,7 +859,7 @@ extern "C" int rl4co_skip_bnorm_stats_bf16(const void* x, const void* s, int64_t
   return RL4CO_OK;
 }
 
-extern "C" int rl4co_bnorm_apply_bf16(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+extern "C" int RL4CO_ENTRY(rl4co_bnorm_apply)(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
                                       int64_t M, void* out, void* stream) {
   RL4CO_REQUIRE(y && mean && rstd && gamma && beta && out && M > 0);
   const int blocks = (int)min((int64_t)8192, (M + 3) / 4);
@@ -872,7 +869,7 @@ extern "C" int rl4co_bnorm_apply_bf16(const void* y, const float* mean, const fl
   return RL4CO_OK;
 }
 
-extern "C" int rl4co_skip_bnorm_eval_bf16(const void* x, const void* skip, const float* mean, const float* rstd, const float* gamma,
+extern "C" int RL4CO_ENTRY(rl4co_skip_bnorm_eval)(const void* x, const void* skip, const float* mean, const float* rstd, const float* gamma,
                                           const float* beta, int64_t M, void* out, void* stream) {
   RL4CO_REQUIRE(x && skip && mean && rstd && gamma && beta && out && M > 0);
   const int blocks = (int)min((int64_t)8192, (M + 3) / 4);
@@ -882,7 +879,7 @@ extern "C" int rl4co_skip_bnorm_eval_bf16(const void* x, const void* skip, const
   return RL4CO_OK;
 }
 
-extern "C" int rl4co_bnorm_bwd_bf16(const void* dout, const void* y, const float* mean, const float* rstd, const float* gamma,
+extern "C" int RL4CO_ENTRY(rl4co_bnorm_bwd)(const void* dout, const void* y, const float* mean, const float* rstd, const float* gamma,
                                     int64_t M, float* sums, void* dy, void* stream) {
   RL4CO_REQUIRE(dout && y && mean && rstd && gamma && sums && dy && M > 0);
   hipStream_t st = rl4co::as_stream(stream);
@@ -941,7 +938,7 @@ __global__ void __launch_bounds__(256) init_embed_wgrad_kernel(const uint32_t* _
   const int64_t lo = (int64_t)blockIdx.x * per, hi = min(M, lo + per);
   for (int64_t r = lo + q; r < hi; r += 4) {
     const uint32_t pk = dout[r * 64 + cp];
-    const float d0 = __uint_as_float(pk << 16), d1 = __uint_as_float(pk & 0xffff0000u);
+    const float d0 = rl4co_e16::lo(pk), d1 = rl4co_e16::hi(pk);
 #pragma unroll
     for (int f = 0; f < 6; ++f) {
       if (f < F) {
@@ -968,7 +965,7 @@ __global__ void __launch_bounds__(256) init_embed_wgrad_kernel(const uint32_t* _
 }
 }  // namespace
 
-extern "C" int rl4co_init_embed_wgrad_bf16(const void* dout, const float* feats, int64_t M, int F, float* partial,
+extern "C" int RL4CO_ENTRY(rl4co_init_embed_wgrad)(const void* dout, const float* feats, int64_t M, int F, float* partial,
                                            int* blocks_out, void* stream) {
   RL4CO_REQUIRE(M > 0 && F >= 1 && F <= 6);
   const int blocks = (int)min((int64_t)kInitWgradBlocks, (M + 63) / 64);
@@ -981,7 +978,7 @@ extern "C" int rl4co_init_embed_wgrad_bf16(const void* dout, const float* feats,
   return RL4CO_OK;
 }
 
-extern "C" int rl4co_init_embed_bf16(const float* feats, const float* w, const float* b, int64_t M, int F, void* out, void* stream) {
+extern "C" int RL4CO_ENTRY(rl4co_init_embed)(const float* feats, const float* w, const float* b, int64_t M, int F, void* out, void* stream) {
   RL4CO_REQUIRE(feats && w && b && out && M > 0 && F >= 1 && F <= 6);
   const int blocks = (int)min((int64_t)8192, (M + 3) / 4);
   hipLaunchKernelGGL(init_embed_kernel, dim3(blocks), dim3(256), 0, rl4co::as_stream(stream), feats, w, b, M, F,

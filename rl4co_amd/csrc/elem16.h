@@ -1,0 +1,82 @@
+// elem16.h — the 16-bit element type of a training / attention translation unit.
+//
+// The training-encoder kernels (am_train_ops.hip, am_train_attn.hip) and the flash attention (am_attn_flash.hip) are
+// written once against `elem_t` and compiled twice: as they stand for bfloat16 (torch.autocast(bfloat16), entry points
+// rl4co_*_bf16) and through the one-line wrappers *_f16.hip, which define RL4CO_ELEM_F16 and include the same source, for
+// IEEE half (torch.autocast(float16) — the reference's default "16-mixed" precision, rl4co/utils/trainer.py:57 — entry
+// points rl4co_*_f16). Storage, LDS layouts, transpose reads and MFMA shapes are identical; what differs is the MFMA
+// opcode and the conversions: bf16 <-> fp32 is a 16-bit shift, half <-> fp32 the hardware's v_cvt (round to nearest
+// even, overflow to infinity — what GradScaler's inf check expects of fp16 gradients).
+#ifndef RL4CO_ELEM16_H
+#define RL4CO_ELEM16_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifndef RL4CO_ELEM_F16
+#define RL4CO_ELEM_F16 0
+#endif
+
+#if RL4CO_ELEM_F16
+typedef _Float16 elem_t;
+#define RL4CO_ENTRY(stem) stem##_f16
+#else
+typedef __bf16 elem_t;
+#define RL4CO_ENTRY(stem) stem##_bf16
+#endif
+
+namespace rl4co_e16 {
+
+typedef elem_t e2 __attribute__((ext_vector_type(2)));
+typedef elem_t e4 __attribute__((ext_vector_type(4)));
+typedef elem_t e8 __attribute__((ext_vector_type(8)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+// two packed elements of a 32-bit word -> fp32 (low half first in memory)
+__device__ inline float lo(uint32_t v) {
+#if RL4CO_ELEM_F16
+  return (float)__builtin_bit_cast(e2, v)[0];
+#else
+  return __uint_as_float(v << 16);
+#endif
+}
+__device__ inline float hi(uint32_t v) {
+#if RL4CO_ELEM_F16
+  return (float)__builtin_bit_cast(e2, v)[1];
+#else
+  return __uint_as_float(v & 0xffff0000u);
+#endif
+}
+__device__ inline uint32_t pack(float a, float b) {
+  e2 v;
+  v[0] = (elem_t)a;
+  v[1] = (elem_t)b;
+  return __builtin_bit_cast(uint32_t, v);
+}
+
+__device__ inline f16v mfma_32x32x16(const e8& a, const e8& b, const f16v& c) {
+#if RL4CO_ELEM_F16
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ inline f4 mfma_16x16x32(const e8& a, const e8& b, const f4& c) {
+#if RL4CO_ELEM_F16
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ inline f4 mfma_16x16x16(const e4& a, const e4& b, const f4& c) {
+#if RL4CO_ELEM_F16
+  return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+#endif
+}
+
+}  // namespace rl4co_e16
+
+#endif

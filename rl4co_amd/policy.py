@@ -143,10 +143,10 @@ class _EncoderLayer(nn.Sequential):
         # each way; batch: statistics + apply) on csrc/am_train_ops.hip / am_train_attn.hip instead of
         # library GEMMs and autograd's elementwise chains
         if (self.fused_train and self.training and torch.is_grad_enabled() and x.is_cuda and self[1].kind in ("instance", "batch")
-                and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+                and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)):
             from . import train_ops
 
-            x = x.to(torch.bfloat16)
+            x = x.to(torch.get_autocast_dtype("cuda"))
             attn, ffn = self[0].module, self[2].module
             gemm_ok = (self.fused_linear and train_ops.linear_usable(x, attn.Wqkv.weight, attn.out_proj.weight,
                                                                       *(lin.weight for lin in ffn.lins)))
@@ -177,8 +177,8 @@ class _EncoderLayer(nn.Sequential):
 
             _l.warn_fallback(f"train-autocast/{torch.get_autocast_dtype('cuda')}",
                              f"training under torch.autocast({torch.get_autocast_dtype('cuda')}): the training-encoder kernels "
-                             "serve bf16 autocast; this regime trains on the torch encoder, as the reference does "
-                             "(AttentionModelPolicy(train_half_as_bf16=True) runs fp16-autocast training steps on the bf16 kernels)")
+                             "serve bfloat16 and float16 autocast; this regime (or a layer-norm / unusual layer shape) trains "
+                             "on the torch encoder")
         return super().forward(x)
 
 
@@ -196,9 +196,10 @@ class _GraphAttentionNetwork(nn.Module):
 
 
 def _train_kernels_active(x: Tensor) -> bool:
-    """bf16-autocast training on the GPU: the regime csrc/am_train_ops.hip serves."""
+    """16-bit autocast training on the GPU (bfloat16, or float16 = the reference's default "16-mixed"): the regimes
+    csrc/am_train_ops.hip is built for (csrc/elem16.h)."""
     return (x.is_cuda and torch.is_grad_enabled() and torch.is_autocast_enabled()
-            and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+            and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16))
 
 
 class _TSPInit(nn.Module):
@@ -503,13 +504,16 @@ class AttentionModelPolicy(nn.Module):
 
         enc = self.encoder
         init = enc.init_embedding
+        bf = self._encoder_regime()  # the 16-bit autocast type this rollout computes in (bfloat16 or float16)
+        assert bf in (torch.bfloat16, torch.float16)
+        embed = lambda f, lin: T.init_embed(f, lin, dtype=bf)  # noqa: E731
         if self.env_name == "pdp":
-            x = torch.cat([T.init_embed(f.contiguous(), lin) for f, lin in init.features(td)], -2)
+            x = torch.cat([embed(f.contiguous(), lin) for f, lin in init.features(td)], -2)
         elif self.env_name == "cvrptw":
             locs = td["locs"]
             feats = torch.cat((locs[:, 1:, :], td["demand"][..., None], td["time_windows"][..., 1:, :].float(),
                                td["durations"][..., 1:, None].float()), -1)
-            x = torch.cat((T.init_embed(locs[:, :1, :], init.init_embed_depot), T.init_embed(feats, init.init_embed)), -2)
+            x = torch.cat((embed(locs[:, :1, :], init.init_embed_depot), embed(feats, init.init_embed)), -2)
         elif self.env_name in ("cvrp", "op", "pctsp"):
             locs = td["locs"]
             third = {"cvrp": "demand", "op": "prize", "pctsp": "expected_prize"}[self.env_name]
@@ -517,12 +521,11 @@ class AttentionModelPolicy(nn.Module):
             feats = torch.cat((locs[:, 1:, :], third[..., None]), -1)
             if self.env_name == "pctsp":
                 feats = torch.cat((feats, td["penalty"][..., 1:, None]), -1)
-            x = torch.cat((T.init_embed(locs[:, :1, :], init.init_embed_depot), T.init_embed(feats, init.init_embed)), -2)
+            x = torch.cat((embed(locs[:, :1, :], init.init_embed_depot), embed(feats, init.init_embed)), -2)
         else:
-            x = T.init_embed(td["locs"], init.init_embed)
+            x = embed(td["locs"], init.init_embed)
         init_h = x
         b, n, d = x.shape
-        bf = torch.bfloat16
         for layer in enc.net.layers:
             attn, norm1, ffn, norm2 = layer[0].module, layer[1].normalizer, layer[2].module, layer[3].normalizer
             x2 = x.reshape(b * n, d)
@@ -549,7 +552,7 @@ class AttentionModelPolicy(nn.Module):
 
     def _token_encoder_usable(self, td) -> bool:
         layer0 = self.encoder.net.layers[0]
-        return (td["locs"].is_cuda and self._bf16_regime() and layer0[1].kind == "batch"
+        return (td["locs"].is_cuda and self._encoder_regime() in (torch.bfloat16, torch.float16) and layer0[1].kind == "batch"
                 and not self.training and len(layer0[2].module.lins) == 2 and layer0[2].module.lins[0].out_features % 128 == 0)
 
     def _encode(self, td):
@@ -730,16 +733,18 @@ class AttentionModelPolicy(nn.Module):
 
             if teacher.supports(self.env_name, self.cache_dtype, n) and not return_entropy:
                 # bf16 encoder output + bf16 planes + the MMA backward: ONE fold GEMM each way, the planes side by side
-                fused_planes = (hidden.dtype == torch.bfloat16 and self.cache_dtype == torch.bfloat16
+                fused_planes = (hidden.dtype in (torch.bfloat16, torch.float16) and self.cache_dtype == torch.bfloat16
                                 and self.teacher_variant != "replay")
-                cache_g = teacher.build_cache_autograd(self.env_name, hidden, self.decoder, fused_planes=fused_planes)
+                # (fp16 activations: the fold runs in bf16 — its outputs, the streamed planes, are bf16 anyway)
+                h_fold = hidden.to(torch.bfloat16) if (fused_planes and hidden.dtype == torch.float16) else hidden
+                cache_g = teacher.build_cache_autograd(self.env_name, h_fold, self.decoder, fused_planes=fused_planes)
                 cache = teacher.detached_cache(self.env_name, cache_g, self.cache_dtype)
         if cache is None:
             with torch.no_grad():
                 regime = self._encoder_regime()  # fp16 (the reference's default "16-mixed"): the fold stays fp32
                 cache = self.decoder.precompute_cache(hidden.detach(), self.cache_dtype,
-                                                      torch.bfloat16 if regime == torch.bfloat16 else torch.float32,
-                                                      fold=self.fold)
+                                                      torch.bfloat16 if (regime == torch.bfloat16 and self.cache_dtype != torch.float16)
+                                                      else torch.float32, fold=self.fold)
         state = self._initial_state(td, n_rep)
         horizon = min(self._max_horizon(self.env_name, n), max_steps)
         if self.env_name == "pdp" and not getattr(env, "force_start_at_depot", False):

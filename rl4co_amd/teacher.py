@@ -164,8 +164,8 @@ def build_cache_autograd(env_name: str, h: Tensor, decoder, fused_planes: bool =
         if env_name == "tsp":
             out["ctx_first"] = planes[:, :, 3].float()
     else:
-        if h.is_cuda and h.dtype == torch.bfloat16:
-            # bf16 encoder output (autocast training): the fold GEMMs and their backward run on the
+        if h.is_cuda and h.dtype in (torch.bfloat16, torch.float16):
+            # 16-bit encoder output (autocast training): the fold GEMMs and their backward run on the
             # tall-skinny MFMA kernels (csrc/am_train_ops.hip) instead of five fp32 library GEMMs
             from . import train_ops
 

@@ -14,6 +14,15 @@ from torch import Tensor
 from . import _lib
 
 EMBED_DIM = 128
+HALF = (torch.bfloat16, torch.float16)  # element types the kernels are built for (csrc/elem16.h)
+
+
+def _k(stem: str, dtype: torch.dtype):
+    """The entry point of ``stem`` for activations of ``dtype``: rl4co_<stem>_bf16 or its IEEE-half twin rl4co_<stem>_f16
+    (the reference's default "16-mixed" precision is fp16 autocast, utils/trainer.py:57)."""
+    if dtype not in HALF:
+        raise TypeError(f"the training kernels take bfloat16 or float16 activations, got {dtype}")
+    return getattr(_lib.lib(), f"{stem}_{'f16' if dtype == torch.float16 else 'bf16'}")
 
 
 def max_nodes() -> int:
@@ -27,10 +36,10 @@ def _inorm_forward(xc: Tensor, sc: Tensor, w32: Tensor, b32: Tensor, eps: float)
     out = torch.empty_like(xc)
     mean = torch.empty((b, d), dtype=torch.float32, device=xc.device)
     rstd = torch.empty((b, d), dtype=torch.float32, device=xc.device)
-    st = _lib.lib().rl4co_skip_inorm_fwd_bf16(xc.data_ptr(), sc.data_ptr(), w32.data_ptr(), b32.data_ptr(), float(eps),
+    st = _k("rl4co_skip_inorm_fwd", xc.dtype)(xc.data_ptr(), sc.data_ptr(), w32.data_ptr(), b32.data_ptr(), float(eps),
                                               b, n, y.data_ptr(), out.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                               torch.cuda.current_stream().cuda_stream)
-    _lib.check(st, "rl4co_skip_inorm_fwd_bf16")
+    _lib.check(st, "rl4co_skip_inorm_fwd")
     return out, y, mean, rstd
 
 
@@ -38,14 +47,14 @@ def _inorm_backward(dout: Tensor, y: Tensor, w32: Tensor, mean: Tensor, rstd: Te
     """(d (x + s) bf16, d gamma fp32, d beta fp32)."""
     b, n, d = y.shape
     dc = dout.contiguous()
-    if dc.dtype != torch.bfloat16:
-        dc = dc.to(torch.bfloat16)
+    if dc.dtype != y.dtype:
+        dc = dc.to(y.dtype)
     dy = torch.empty_like(y)
     part = torch.empty((2, b, d), dtype=torch.float32, device=y.device)  # per-instance d gamma | d beta
-    st = _lib.lib().rl4co_skip_inorm_bwd_bf16(dc.data_ptr(), y.data_ptr(), w32.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+    st = _k("rl4co_skip_inorm_bwd", y.dtype)(dc.data_ptr(), y.data_ptr(), w32.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                               b, n, dy.data_ptr(), part[0].data_ptr(), part[1].data_ptr(),
                                               torch.cuda.current_stream().cuda_stream)
-    _lib.check(st, "rl4co_skip_inorm_bwd_bf16")
+    _lib.check(st, "rl4co_skip_inorm_bwd")
     g = part.sum(1)  # one reduction over the instances for both, fixed order
     return dy, g[0], g[1]
 
@@ -71,25 +80,25 @@ def _bnorm_forward(xc: Tensor, sc: Tensor, w32: Tensor, b32: Tensor, eps: float)
     y, out = torch.empty_like(xc), torch.empty_like(xc)
     sums = torch.zeros((2, EMBED_DIM), dtype=torch.float32, device=xc.device)
     stream = torch.cuda.current_stream().cuda_stream
-    _lib.check(_lib.lib().rl4co_skip_bnorm_stats_bf16(xc.data_ptr(), sc.data_ptr(), m, y.data_ptr(), sums.data_ptr(), stream),
-               "rl4co_skip_bnorm_stats_bf16")
+    _lib.check(_k("rl4co_skip_bnorm_stats", xc.dtype)(xc.data_ptr(), sc.data_ptr(), m, y.data_ptr(), sums.data_ptr(), stream),
+               "rl4co_skip_bnorm_stats")
     mean = sums[0] / m
     var = (sums[1] / m - mean * mean).clamp_min_(0.0)  # biased, as F.batch_norm normalises with
     rstd = torch.rsqrt(var + eps)
-    _lib.check(_lib.lib().rl4co_bnorm_apply_bf16(y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w32.data_ptr(), b32.data_ptr(),
-                                                 m, out.data_ptr(), stream), "rl4co_bnorm_apply_bf16")
+    _lib.check(_k("rl4co_bnorm_apply", y.dtype)(y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w32.data_ptr(), b32.data_ptr(),
+                                                 m, out.data_ptr(), stream), "rl4co_bnorm_apply")
     return out, y, mean, rstd, var
 
 
 def _bnorm_backward(dout: Tensor, y: Tensor, w32: Tensor, mean: Tensor, rstd: Tensor):
     """(d (x + s) bf16, d gamma fp32, d beta fp32)."""
     m = y.numel() // EMBED_DIM
-    d = dout.to(torch.bfloat16).contiguous()
+    d = dout.to(y.dtype).contiguous()
     dy = torch.empty_like(y)
     sums = torch.zeros((2, EMBED_DIM), dtype=torch.float32, device=y.device)
-    _lib.check(_lib.lib().rl4co_bnorm_bwd_bf16(d.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w32.data_ptr(), m,
+    _lib.check(_k("rl4co_bnorm_bwd", y.dtype)(d.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(), w32.data_ptr(), m,
                                                sums.data_ptr(), dy.data_ptr(), torch.cuda.current_stream().cuda_stream),
-               "rl4co_bnorm_bwd_bf16")
+               "rl4co_bnorm_bwd")
     return dy, sums[1], sums[0]
 
 
@@ -136,10 +145,10 @@ def batch_norm_eval(y: Tensor, bn: torch.nn.BatchNorm1d) -> Tensor:
     out = torch.empty_like(yc)
     mean = bn.running_mean.float().contiguous()
     rstd = torch.rsqrt(bn.running_var.float() + bn.eps).contiguous()
-    st = _lib.lib().rl4co_bnorm_apply_bf16(yc.data_ptr(), mean.data_ptr(), rstd.data_ptr(), bn.weight.detach().float().contiguous().data_ptr(),
+    st = _k("rl4co_bnorm_apply", yc.dtype)(yc.data_ptr(), mean.data_ptr(), rstd.data_ptr(), bn.weight.detach().float().contiguous().data_ptr(),
                                            bn.bias.detach().float().contiguous().data_ptr(), m, out.data_ptr(),
                                            torch.cuda.current_stream().cuda_stream)
-    _lib.check(st, "rl4co_bnorm_apply_bf16")
+    _lib.check(st, "rl4co_bnorm_apply")
     return out
 
 
@@ -150,22 +159,22 @@ def skip_batch_norm_eval(x: Tensor, s: Tensor, bn: torch.nn.BatchNorm1d) -> Tens
     out = torch.empty_like(xc)
     mean = bn.running_mean.float().contiguous()
     rstd = torch.rsqrt(bn.running_var.float() + bn.eps).contiguous()
-    st = _lib.lib().rl4co_skip_bnorm_eval_bf16(xc.data_ptr(), sc.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+    st = _k("rl4co_skip_bnorm_eval", xc.dtype)(xc.data_ptr(), sc.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                                bn.weight.detach().float().contiguous().data_ptr(),
                                                bn.bias.detach().float().contiguous().data_ptr(), m, out.data_ptr(),
                                                torch.cuda.current_stream().cuda_stream)
-    _lib.check(st, "rl4co_skip_bnorm_eval_bf16")
+    _lib.check(st, "rl4co_skip_bnorm_eval")
     return out
 
 
 def usable(x: Tensor, s: Tensor) -> bool:
     """bf16 [B,N,128] activations on the GPU with N inside the kernel's register budget."""
-    return (x.is_cuda and x.dtype == torch.bfloat16 and s.dtype == torch.bfloat16 and x.dim() == 3
+    return (x.is_cuda and x.dtype in HALF and s.dtype == x.dtype and x.dim() == 3
             and x.shape == s.shape and x.shape[-1] == EMBED_DIM and x.shape[1] <= max_nodes())
 
 
 def batch_usable(x: Tensor, s: Tensor) -> bool:
-    return (x.is_cuda and x.dtype == torch.bfloat16 and s.dtype == torch.bfloat16 and x.shape == s.shape
+    return (x.is_cuda and x.dtype in HALF and s.dtype == x.dtype and x.shape == s.shape
             and x.shape[-1] == EMBED_DIM)
 
 
@@ -178,20 +187,23 @@ def skip_instance_norm(x: Tensor, s: Tensor, weight: Tensor, bias: Tensor, eps: 
 # ---------------------------------------------------------------------------------------------------
 def _gemm(a2d: Tensor, w: Tensor, bias: Tensor | None = None, mask: Tensor | None = None, relu: bool = False,
           out: Tensor | None = None, residual: Tensor | None = None) -> Tensor:
-    """out[M,N] = epilogue(a2d[M,K] @ w[N,K]^T + bias) (+ residual[M,N]); bf16 a2d / w / out / residual, fp32 bias."""
+    """out[M,N] = epilogue(a2d[M,K] @ w[N,K]^T + bias) (+ residual[M,N]); a2d / w / out / residual (/ mask) in ONE 16-bit
+    type (bfloat16 or float16), fp32 bias."""
     m, k = a2d.shape
     n = w.shape[0]
+    dt = a2d.dtype
+    assert w.dtype == dt and (mask is None or mask.dtype == dt), (dt, w.dtype)
     if out is None:
-        out = torch.empty((m, n), dtype=torch.bfloat16, device=a2d.device)
+        out = torch.empty((m, n), dtype=dt, device=a2d.device)
     else:
-        assert out.shape == (m, n) and out.dtype == torch.bfloat16 and out.is_contiguous()
+        assert out.shape == (m, n) and out.dtype == dt and out.is_contiguous()
     if residual is not None:
-        assert residual.shape == (m, n) and residual.dtype == torch.bfloat16 and residual.is_contiguous()
-    st = _lib.lib().rl4co_linear_bf16(a2d.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
+        assert residual.shape == (m, n) and residual.dtype == dt and residual.is_contiguous()
+    st = _k("rl4co_linear", a2d.dtype)(a2d.data_ptr(), w.data_ptr(), None if bias is None else bias.data_ptr(),
                                       None if mask is None else mask.data_ptr(),
                                       None if residual is None else residual.data_ptr(), m, n, k, int(relu), out.data_ptr(),
                                       torch.cuda.current_stream().cuda_stream)
-    _lib.check(st, "rl4co_linear_bf16")
+    _lib.check(st, "rl4co_linear")
     return out
 
 
@@ -218,17 +230,17 @@ def _wgrad(d2: Tensor, x2: Tensor, with_bias: bool = False):
     # one buffer per chunk: [N*K weight partials | N bias partials] -> ONE reduction over the chunk axis for both
     width = n * k + (n if with_bias else 0)
     partial = torch.empty((chunks, width), dtype=torch.float32, device=d2.device)
-    st = _lib.lib().rl4co_wgrad_bf16(d2.data_ptr(), x2.data_ptr(), m, n, k, chunks, partial.data_ptr(),
+    st = _k("rl4co_wgrad", d2.dtype)(d2.data_ptr(), x2.data_ptr(), m, n, k, chunks, partial.data_ptr(),
                                      partial.data_ptr() + 4 * n * k if with_bias else None, width,
                                      torch.cuda.current_stream().cuda_stream)
-    _lib.check(st, "rl4co_wgrad_bf16")
+    _lib.check(st, "rl4co_wgrad")
     g = partial.sum(0)
     dw = g[: n * k].view(n, k)
     return (dw, g[n * k :]) if with_bias else dw
 
 
 def linear_usable(x: Tensor, *weights: Tensor) -> bool:
-    return (x.is_cuda and x.dtype == torch.bfloat16 and x.shape[-1] % 128 == 0
+    return (x.is_cuda and x.dtype in HALF and x.shape[-1] % 128 == 0
             and all(w.shape[0] % 128 == 0 and w.shape[1] % 128 == 0 for w in weights))
 
 
@@ -238,7 +250,7 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, weight: Tensor, bias: Tensor | None):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
-        w16 = weight.detach().to(torch.bfloat16).contiguous()
+        w16 = weight.detach().to(x2.dtype).contiguous()
         out = _gemm(x2, w16, None if bias is None else bias.detach().float().contiguous())
         ctx.save_for_backward(x2, w16)
         ctx.pdt, ctx.has_bias = weight.dtype, bias is not None
@@ -247,7 +259,7 @@ class _Linear(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout: Tensor):
         x2, w16 = ctx.saved_tensors
-        d = dout.reshape(-1, dout.shape[-1]).to(torch.bfloat16).contiguous()
+        d = dout.reshape(-1, dout.shape[-1]).to(x2.dtype).contiguous()
         dx = _gemm(d, w16.t().contiguous())
         if ctx.has_bias:
             dw, db = _wgrad(d, x2, with_bias=True)
@@ -262,7 +274,7 @@ class _MLP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor):
         x2 = x.reshape(-1, x.shape[-1]).contiguous()
-        w1_16, w2_16 = w1.detach().to(torch.bfloat16).contiguous(), w2.detach().to(torch.bfloat16).contiguous()
+        w1_16, w2_16 = w1.detach().to(x2.dtype).contiguous(), w2.detach().to(x2.dtype).contiguous()
         h = _gemm(x2, w1_16, b1.detach().float().contiguous(), relu=True)
         y = _gemm(h, w2_16, b2.detach().float().contiguous())
         ctx.save_for_backward(x2, h, w1_16, w2_16)
@@ -272,7 +284,7 @@ class _MLP(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy: Tensor):
         x2, h, w1_16, w2_16 = ctx.saved_tensors
-        d = dy.reshape(-1, dy.shape[-1]).to(torch.bfloat16).contiguous()
+        d = dy.reshape(-1, dy.shape[-1]).to(x2.dtype).contiguous()
         dh = _gemm(d, w2_16.t().contiguous(), mask=h)  # (d W2) * [h > 0]
         dw2, db2 = _wgrad(d, h, with_bias=True)
         dx = _gemm(dh, w1_16.t().contiguous())
@@ -296,11 +308,11 @@ class _Attention(torch.autograd.Function):
     def forward(ctx, qkv: Tensor):
         b, n, _ = qkv.shape
         q = qkv.contiguous()
-        out = torch.empty((b, n, EMBED_DIM), dtype=torch.bfloat16, device=qkv.device)
+        out = torch.empty((b, n, EMBED_DIM), dtype=q.dtype, device=qkv.device)
         lse = torch.empty((b, 8, n), dtype=torch.float32, device=qkv.device)
-        st = _lib.lib().rl4co_attn_fwd_bf16(q.data_ptr(), b, n, out.data_ptr(), lse.data_ptr(),
+        st = _k("rl4co_attn_fwd", q.dtype)(q.data_ptr(), b, n, out.data_ptr(), lse.data_ptr(),
                                             torch.cuda.current_stream().cuda_stream)
-        _lib.check(st, "rl4co_attn_fwd_bf16")
+        _lib.check(st, "rl4co_attn_fwd")
         ctx.save_for_backward(q, lse)
         return out
 
@@ -308,16 +320,16 @@ class _Attention(torch.autograd.Function):
     def backward(ctx, dout: Tensor):
         q, lse = ctx.saved_tensors
         b, n, _ = q.shape
-        d = dout.to(torch.bfloat16).contiguous()
+        d = dout.to(q.dtype).contiguous()
         dqkv = torch.empty_like(q)
-        st = _lib.lib().rl4co_attn_bwd_bf16(q.data_ptr(), d.data_ptr(), lse.data_ptr(), b, n, dqkv.data_ptr(),
+        st = _k("rl4co_attn_bwd", q.dtype)(q.data_ptr(), d.data_ptr(), lse.data_ptr(), b, n, dqkv.data_ptr(),
                                             torch.cuda.current_stream().cuda_stream)
-        _lib.check(st, "rl4co_attn_bwd_bf16")
+        _lib.check(st, "rl4co_attn_bwd")
         return dqkv
 
 
 def attention_usable(qkv: Tensor) -> bool:
-    return (qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.dim() == 3 and qkv.shape[-1] == 3 * EMBED_DIM
+    return (qkv.is_cuda and qkv.dtype in HALF and qkv.dim() == 3 and qkv.shape[-1] == 3 * EMBED_DIM
             and qkv.shape[1] <= _lib.lib().rl4co_attn_max_nodes())
 
 
@@ -329,12 +341,12 @@ def attention(qkv: Tensor) -> Tensor:
 def attention_flash(qkv: Tensor) -> Tensor:
     """Inference attention for any N (csrc/am_attn_flash.hip): softmax(q k^T / 4) v per head on the packed
     qkv [B,N,384] bf16 -> [B,N,128] bf16; keys / values stream through LDS, no N x N matrix, no autograd."""
-    assert qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.dim() == 3 and qkv.shape[-1] == 3 * EMBED_DIM
+    assert qkv.is_cuda and qkv.dtype in HALF and qkv.dim() == 3 and qkv.shape[-1] == 3 * EMBED_DIM
     qkv = qkv.contiguous()
     b, n, _ = qkv.shape
-    out = torch.empty((b, n, EMBED_DIM), dtype=torch.bfloat16, device=qkv.device)
-    st = _lib.lib().rl4co_attn_flash_bf16(qkv.data_ptr(), b, n, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    _lib.check(st, "rl4co_attn_flash_bf16")
+    out = torch.empty((b, n, EMBED_DIM), dtype=qkv.dtype, device=qkv.device)
+    st = _k("rl4co_attn_flash", qkv.dtype)(qkv.data_ptr(), b, n, out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.check(st, "rl4co_attn_flash")
     return out
 
 
@@ -357,8 +369,8 @@ def _norm_backward(kind: str, dout: Tensor, y: Tensor, w32: Tensor, mean: Tensor
     return (_inorm_backward if kind == "instance" else _bnorm_backward)(dout, y, w32, mean, rstd)
 
 
-def _bf16(w: Tensor) -> Tensor:
-    return w.detach().to(torch.bfloat16).contiguous()
+def _h16(w: Tensor, dtype: torch.dtype) -> Tensor:
+    return w.detach().to(dtype).contiguous()
 
 
 def _f32(w: Tensor) -> Tensor:
@@ -371,12 +383,12 @@ class _AttentionBlock(torch.autograd.Function):
         b, n, d = x.shape
         xc = x.contiguous()
         x2 = xc.view(-1, d)
-        wqkv16, wo16, g32 = _bf16(wqkv), _bf16(wo), _f32(gamma)
+        wqkv16, wo16, g32 = _h16(wqkv, x.dtype), _h16(wo, x.dtype), _f32(gamma)
         qkv = _gemm(x2, wqkv16, _f32(bqkv)).view(b, n, 3 * d)
-        att = torch.empty((b, n, d), dtype=torch.bfloat16, device=x.device)
+        att = torch.empty((b, n, d), dtype=x.dtype, device=x.device)
         lse = torch.empty((b, 8, n), dtype=torch.float32, device=x.device)
         stream = torch.cuda.current_stream().cuda_stream
-        _lib.check(_lib.lib().rl4co_attn_fwd_bf16(qkv.data_ptr(), b, n, att.data_ptr(), lse.data_ptr(), stream), "rl4co_attn_fwd_bf16")
+        _lib.check(_k("rl4co_attn_fwd", qkv.dtype)(qkv.data_ptr(), b, n, att.data_ptr(), lse.data_ptr(), stream), "rl4co_attn_fwd")
         s = _gemm(att.view(-1, d), wo16, _f32(bo)).view(b, n, d)
         out, y, mean, rstd, var = _norm_forward(kind, xc, s, g32, _f32(beta), eps)
         ctx.save_for_backward(x2, wqkv16, wo16, qkv, lse, att, y, g32, mean, rstd)
@@ -395,8 +407,8 @@ class _AttentionBlock(torch.autograd.Function):
         datt = _gemm(d2, wo16.t().contiguous())
         dwo, dbo = _wgrad(d2, att.view(-1, d), with_bias=True)
         dqkv = torch.empty_like(qkv)
-        _lib.check(_lib.lib().rl4co_attn_bwd_bf16(qkv.data_ptr(), datt.data_ptr(), lse.data_ptr(), b, n, dqkv.data_ptr(),
-                                                  torch.cuda.current_stream().cuda_stream), "rl4co_attn_bwd_bf16")
+        _lib.check(_k("rl4co_attn_bwd", qkv.dtype)(qkv.data_ptr(), datt.data_ptr(), lse.data_ptr(), b, n, dqkv.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream), "rl4co_attn_bwd")
         dq2 = dqkv.view(-1, 3 * d)
         dx = _gemm(dq2, wqkv16.t().contiguous(), residual=d2)
         dwqkv, dbqkv = _wgrad(dq2, x2, with_bias=True)
@@ -410,7 +422,7 @@ class _MLPBlock(torch.autograd.Function):
         b, n, d = x.shape
         xc = x.contiguous()
         x2 = xc.view(-1, d)
-        w1_16, w2_16, g32 = _bf16(w1), _bf16(w2), _f32(gamma)
+        w1_16, w2_16, g32 = _h16(w1, x.dtype), _h16(w2, x.dtype), _f32(gamma)
         h = _gemm(x2, w1_16, _f32(b1), relu=True)
         s = _gemm(h, w2_16, _f32(b2)).view(b, n, d)
         out, y, mean, rstd, var = _norm_forward(kind, xc, s, g32, _f32(beta), eps)
@@ -478,23 +490,23 @@ def mlp_block(x: Tensor, ffn, norm) -> Tensor:
 # ---------------------------------------------------------------------------------------------------
 class _InitEmbed(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats: Tensor, weight: Tensor, bias: Tensor):
+    def forward(ctx, feats: Tensor, weight: Tensor, bias: Tensor, dtype: torch.dtype = torch.bfloat16):
         f2 = feats.reshape(-1, feats.shape[-1]).float().contiguous()
-        out = torch.empty((f2.shape[0], EMBED_DIM), dtype=torch.bfloat16, device=feats.device)
-        st = _lib.lib().rl4co_init_embed_bf16(f2.data_ptr(), weight.detach().float().contiguous().data_ptr(),
+        out = torch.empty((f2.shape[0], EMBED_DIM), dtype=dtype, device=feats.device)
+        st = _k("rl4co_init_embed", dtype)(f2.data_ptr(), weight.detach().float().contiguous().data_ptr(),
                                               bias.detach().float().contiguous().data_ptr(), f2.shape[0], f2.shape[1],
                                               out.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        _lib.check(st, "rl4co_init_embed_bf16")
+        _lib.check(st, "rl4co_init_embed")
         ctx.save_for_backward(f2)
-        ctx.pdt = weight.dtype
+        ctx.pdt, ctx.adt = weight.dtype, dtype
         return out.view(*feats.shape[:-1], EMBED_DIM)
 
     @staticmethod
     def backward(ctx, dout: Tensor):
         (f2,) = ctx.saved_tensors
         d = dout.reshape(-1, EMBED_DIM)
-        if d.dtype != torch.bfloat16:  # not under autocast: the library path
-            return None, torch.matmul(d.t().float(), f2).to(ctx.pdt), d.sum(0, dtype=torch.float32).to(ctx.pdt)
+        if d.dtype != ctx.adt:  # not under autocast: the library path
+            return None, torch.matmul(d.t().float(), f2).to(ctx.pdt), d.sum(0, dtype=torch.float32).to(ctx.pdt), None
         # a [128, M] x [M, F] product with F <= 6 is a reduction, not a GEMM (the library needs 1 ms and an fp32 copy of
         # dout for it at M = 409 600): per-block partial sums of dW and db in one pass over dout, summed in a fixed order
         d = d.contiguous()
@@ -502,16 +514,20 @@ class _InitEmbed(torch.autograd.Function):
         import ctypes as C
 
         nblk = C.c_int(0)
-        lib = _lib.lib()
-        _lib.check(lib.rl4co_init_embed_wgrad_bf16(None, None, m, f, None, C.byref(nblk), None), "rl4co_init_embed_wgrad_bf16")
+        wgrad = _k("rl4co_init_embed_wgrad", ctx.adt)
+        _lib.check(wgrad(None, None, m, f, None, C.byref(nblk), None), "rl4co_init_embed_wgrad")
         partial = torch.empty((nblk.value, EMBED_DIM, f + 1), dtype=torch.float32, device=d.device)
-        st = lib.rl4co_init_embed_wgrad_bf16(d.data_ptr(), f2.data_ptr(), m, f, partial.data_ptr(), None,
+        st = wgrad(d.data_ptr(), f2.data_ptr(), m, f, partial.data_ptr(), None,
                                              torch.cuda.current_stream().cuda_stream)
-        _lib.check(st, "rl4co_init_embed_wgrad_bf16")
+        _lib.check(st, "rl4co_init_embed_wgrad")
         g = partial.sum(0)
-        return None, g[:, :f].to(ctx.pdt), g[:, f].to(ctx.pdt)
+        return None, g[:, :f].to(ctx.pdt), g[:, f].to(ctx.pdt), None
 
 
-def init_embed(feats: Tensor, lin: torch.nn.Linear) -> Tensor:
-    """``lin(feats)`` for the 2- / 3-feature init embeddings, bf16 output (training under autocast)."""
-    return _InitEmbed.apply(feats, lin.weight, lin.bias)
+def init_embed(feats: Tensor, lin: torch.nn.Linear, dtype: torch.dtype | None = None) -> Tensor:
+    """``lin(feats)`` for the 2- ... 6-feature init embeddings with a 16-bit output: ``dtype``, else the ambient CUDA
+    autocast type when that is bfloat16 / float16, else bfloat16."""
+    if dtype is None:
+        amb = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled() else None
+        dtype = amb if amb in HALF else torch.bfloat16
+    return _InitEmbed.apply(feats, lin.weight, lin.bias, dtype)

@@ -202,7 +202,8 @@ def test_packed_weights_refresh_after_update():
     assert not torch.equal(c1.kvl, c2.kvl)
 
 
-def test_token_parallel_encoder_for_large_graphs_matches_torch():
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_token_parallel_encoder_for_large_graphs_matches_torch(dt):
     """N > 128 (the fused per-instance kernel's limit): the inference encoder runs on the token-parallel
     kernels (csrc/am_train_ops.hip) + the flash-style attention kernel (csrc/am_attn_flash.hip). Same bound as the
     fused encoder test: within 3e-2 relative Frobenius error of the fp32 torch encoder."""
@@ -210,7 +211,7 @@ def test_token_parallel_encoder_for_large_graphs_matches_torch():
     from rl4co_amd.policy import AttentionModelPolicy
 
     torch.manual_seed(0)
-    pol = AttentionModelPolicy("cvrp", cache_dtype=torch.bfloat16, encoder_autocast=torch.bfloat16).cuda().eval()
+    pol = AttentionModelPolicy("cvrp", cache_dtype=dt, encoder_autocast=dt).cuda().eval()
     with torch.no_grad():  # non-trivial running statistics
         for m in pol.modules():
             if isinstance(m, torch.nn.BatchNorm1d):
@@ -221,6 +222,7 @@ def test_token_parallel_encoder_for_large_graphs_matches_torch():
     assert pol._token_encoder_usable(td) and not pol._packed_encoder().supported(td)
     with torch.inference_mode():
         h, h0 = pol._encode_tokens_bf16(td)
+        assert h.dtype == dt
         ref, ref0 = pol.encoder(td)  # fp32
         rel = float((h.float() - ref).norm() / ref.norm())
         assert rel <= 3e-2, rel
@@ -229,8 +231,9 @@ def test_token_parallel_encoder_for_large_graphs_matches_torch():
     assert out["reward"].shape == (16,) and bool(torch.isfinite(out["reward"]).all())
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("b,n", [(1, 1), (3, 17), (8, 64), (5, 129), (16, 200), (8, 501), (13, 777), (2, 1500)])
-def test_attention_flash_matches_fp32_attention(b, n):
+def test_attention_flash_matches_fp32_attention(b, n, dt):
     """csrc/am_attn_flash.hip (any N, keys / values streamed through LDS, online softmax) against fp32 attention of
     the SAME bf16 q | k | v (nn/attention.py:110-134 semantics: 8 heads x 16, scale 1/4). Tolerance: bf16 output
     rounding (2^-9 relative) plus bf16 softmax numerators: 1.5e-2 absolute on O(1) outputs, relative Frobenius 1e-2
@@ -240,7 +243,7 @@ def test_attention_flash_matches_fp32_attention(b, n):
     from rl4co_amd import train_ops as T
 
     gen = torch.Generator().manual_seed(100 * b + n)
-    qkv = (torch.randn(b, n, 384, generator=gen) * 1.5).to(torch.bfloat16).cuda()
+    qkv = (torch.randn(b, n, 384, generator=gen) * 1.5).to(dt).cuda()
     out = T.attention_flash(qkv)
     torch.cuda.synchronize()
     q, k, v = qkv.float().view(b, n, 3, 8, 16).permute(2, 0, 3, 1, 4).unbind(0)
