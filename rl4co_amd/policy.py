@@ -675,8 +675,9 @@ class AttentionModelPolicy(nn.Module):
                     n_nodes = td["action_mask"].shape[-1]
                     _l.warn_fallback(f"infer-encoder/{self._encoder_regime()}/{n_nodes > 128}/{self.fused_encoder}/{self.fold}",
                                      f"inference encoder for {n_nodes} nodes under autocast({self._encoder_regime()}) runs on torch: "
-                                     "the fused MFMA encoder serves bf16 up to 128 nodes with batch / instance norm and the folded "
-                                     "cache, the token-parallel kernels bf16 with batch norm beyond that")
+                                     "the fused MFMA encoder serves bf16 / fp16 up to 128 nodes with batch / instance norm, the folded "
+                                     "cache and planes in fp32 or the activations' type; the token-parallel kernels serve batch norm "
+                                     "beyond that")
                 hidden, init_embeds = self._encode(td)
         if isinstance(env, str) or env is None:
             env = get_env(self.env_name if env is None else env)
@@ -871,10 +872,11 @@ class AttentionModelPolicy(nn.Module):
                 if hidden.is_cuda and self.fused_backward and not return_entropy:
                     from . import _lib as _l
 
-                    _l.warn_fallback(f"teacher/{self.env_name}/{n}",
-                                     f"teacher-forced backward for {self.env_name} with {n} nodes is beyond the kernels' limit "
-                                     f"({__import__('rl4co_amd.teacher', fromlist=['max_nodes']).max_nodes()} nodes): dense torch "
-                                     "re-evaluation with autograd")
+                    t_max = __import__("rl4co_amd.teacher", fromlist=["max_nodes"]).max_nodes()
+                    why = (f"{n} nodes are beyond the kernels' limit ({t_max})" if n > t_max else
+                           f"{self.cache_dtype} planes: the backward kernels read float32 or bfloat16 planes")
+                    _l.warn_fallback(f"teacher/{self.env_name}/{n}/{self.cache_dtype}",
+                                     f"teacher-forced backward for {self.env_name}: {why} — dense torch re-evaluation with autograd")
                 step_logps = self.evaluate_log_probs(td, hidden, out_actions, n_rep, tanh_clipping, temperature,
                                                      mask_logits, skip_first=(t0 == 1), return_full=return_entropy)
                 if return_entropy:
