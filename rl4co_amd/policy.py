@@ -427,9 +427,14 @@ class AttentionModelPolicy(nn.Module):
     """Attention Model policy (Kool et al. 2019) with the autoregressive loop on the MI355X.
 
     Args follow ``zoo/am/policy.py:50-85``. Extra, engine-specific arguments:
-        cache_dtype: dtype of the three streamed cache planes (``torch.bfloat16`` halves the
-            bytes per decode step; ``torch.float32`` is the parity configuration).
-        encoder_autocast: optional autocast dtype for the encoder GEMMs.
+        cache_dtype: dtype of the three streamed cache planes (``torch.bfloat16`` / ``torch.float16`` halve the bytes
+            per decode step; ``torch.float32`` is the parity configuration). ``None`` (the default) follows the
+            precision regime the way the reference's own cache does — its K / V / logit key are the output of a Linear
+            and therefore 16-bit under autocast (zoo/am/decoder.py:201-228): float32 without autocast, bfloat16 under
+            bf16 autocast, under fp16 autocast float16 for inference rollouts and bfloat16 for training steps (the
+            multistart rollout and the MMA backward read bf16 planes). So ``RL4COTrainer()`` with its default
+            ``precision="16-mixed"`` over ``AttentionModelPolicy(env_name)`` reaches the fast kernels with no extra argument.
+        encoder_autocast: optional autocast dtype for the encoder GEMMs (otherwise the ambient autocast decides).
     """
 
     def __init__(self, env_name: str = "tsp", embed_dim: int = 128, num_encoder_layers: int = 3,
@@ -437,7 +442,7 @@ class AttentionModelPolicy(nn.Module):
                  use_graph_context: bool = True, mask_inner: bool = True, check_nan: bool = True,
                  temperature: float = 1.0, tanh_clipping: float = 10.0, mask_logits: bool = True,
                  train_decode_type: str = "sampling", val_decode_type: str = "greedy",
-                 test_decode_type: str = "greedy", cache_dtype: torch.dtype = torch.float32,
+                 test_decode_type: str = "greedy", cache_dtype: torch.dtype | None = None,
                  encoder_autocast: torch.dtype | None = None, fused_encoder: bool = True,
                  fused_backward: bool = True, teacher_variant: str = "auto", fold: bool = True,
                  train_half_as_bf16: bool = False, **unused_kwargs):
@@ -546,6 +551,18 @@ class AttentionModelPolicy(nn.Module):
         the torch encoder runs under it exactly as the reference's does)."""
         return self._encoder_regime() == torch.bfloat16
 
+    def _plane_dtype(self, training: bool) -> torch.dtype:
+        """dtype of the streamed planes of this call: the constructor's ``cache_dtype``, else by regime (see the class
+        docstring)."""
+        if self.cache_dtype is not None:
+            return self.cache_dtype
+        regime = self._encoder_regime()
+        if regime == torch.bfloat16:
+            return torch.bfloat16
+        if regime == torch.float16:
+            return torch.bfloat16 if training else torch.float16
+        return torch.float32
+
     def _encoder_regime(self):
         """Autocast dtype of the encoder: the constructor's choice, else the ambient one (None = fp32)."""
         return self.encoder_autocast if self.encoder_autocast is not None else self._ambient_autocast
@@ -643,17 +660,18 @@ class AttentionModelPolicy(nn.Module):
         grad_path = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if not self.fold and grad_path:
             raise NotImplementedError("fold=False is the inference parity configuration; train with the folded cache")
+        cache_dtype = self._plane_dtype(grad_path)
         regime16 = self._encoder_regime() if self._encoder_regime() in (torch.bfloat16, torch.float16) else None
         # fused MFMA encoder: a 16-bit autocast regime (bf16, or fp16 = the reference's default "16-mixed") whose planes
         # are fp32 or that same 16-bit type
         use_fused = (self.fused_encoder and self.fold and regime16 is not None and not grad_path
-                     and self.cache_dtype in (torch.float32, regime16)
+                     and cache_dtype in (torch.float32, regime16)
                      and not return_init_embeds and self._packed_encoder().supported(td))
         if use_fused:
             if self.encode_events is not None:  # bench.py: HIP events around the encoder launch
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            cache, hidden = self._packed_encoder().encode(td, self.cache_dtype, want_hidden=return_hidden, act_dtype=regime16)
+            cache, hidden = self._packed_encoder().encode(td, cache_dtype, want_hidden=return_hidden, act_dtype=regime16)
             if self.encode_events is not None:
                 ev1.record()
                 self.encode_events.append((ev0, ev1))
@@ -732,19 +750,19 @@ class AttentionModelPolicy(nn.Module):
         if cache is None and grad_path and self.fused_backward and hidden.is_cuda:
             from . import teacher
 
-            if teacher.supports(self.env_name, self.cache_dtype, n) and not return_entropy:
+            if teacher.supports(self.env_name, cache_dtype, n) and not return_entropy:
                 # bf16 encoder output + bf16 planes + the MMA backward: ONE fold GEMM each way, the planes side by side
-                fused_planes = (hidden.dtype in (torch.bfloat16, torch.float16) and self.cache_dtype == torch.bfloat16
+                fused_planes = (hidden.dtype in (torch.bfloat16, torch.float16) and cache_dtype == torch.bfloat16
                                 and self.teacher_variant != "replay")
                 # (fp16 activations: the fold runs in bf16 — its outputs, the streamed planes, are bf16 anyway)
                 h_fold = hidden.to(torch.bfloat16) if (fused_planes and hidden.dtype == torch.float16) else hidden
                 cache_g = teacher.build_cache_autograd(self.env_name, h_fold, self.decoder, fused_planes=fused_planes)
-                cache = teacher.detached_cache(self.env_name, cache_g, self.cache_dtype)
+                cache = teacher.detached_cache(self.env_name, cache_g, cache_dtype)
         if cache is None:
             with torch.no_grad():
                 regime = self._encoder_regime()  # fp16 (the reference's default "16-mixed"): the fold stays fp32
-                cache = self.decoder.precompute_cache(hidden.detach(), self.cache_dtype,
-                                                      torch.bfloat16 if (regime == torch.bfloat16 and self.cache_dtype != torch.float16)
+                cache = self.decoder.precompute_cache(hidden.detach(), cache_dtype,
+                                                      torch.bfloat16 if (regime == torch.bfloat16 and cache_dtype != torch.float16)
                                                       else torch.float32, fold=self.fold)
         state = self._initial_state(td, n_rep)
         horizon = min(self._max_horizon(self.env_name, n), max_steps)
@@ -874,8 +892,8 @@ class AttentionModelPolicy(nn.Module):
 
                     t_max = __import__("rl4co_amd.teacher", fromlist=["max_nodes"]).max_nodes()
                     why = (f"{n} nodes are beyond the kernels' limit ({t_max})" if n > t_max else
-                           f"{self.cache_dtype} planes: the backward kernels read float32 or bfloat16 planes")
-                    _l.warn_fallback(f"teacher/{self.env_name}/{n}/{self.cache_dtype}",
+                           f"{cache_dtype} planes: the backward kernels read float32 or bfloat16 planes")
+                    _l.warn_fallback(f"teacher/{self.env_name}/{n}/{cache_dtype}",
                                      f"teacher-forced backward for {self.env_name}: {why} — dense torch re-evaluation with autograd")
                 step_logps = self.evaluate_log_probs(td, hidden, out_actions, n_rep, tanh_clipping, temperature,
                                                      mask_logits, skip_first=(t0 == 1), return_full=return_entropy)

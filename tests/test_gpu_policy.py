@@ -276,3 +276,58 @@ def test_spctsp_env_collects_the_stochastic_prize_on_gpu():
     prize = td["real_prize"].gather(1, acts).sum(1)
     customers = (acts != 0).sum(1)
     assert bool(((prize >= 1 - 1e-5) | (customers == 20)).all())
+
+
+def test_default_policy_under_default_trainer_precision_reaches_the_fast_kernels():
+    """`AttentionModelPolicy(env_name)` with NO engine-specific argument under the precision `RL4COTrainer()` defaults to
+    ("16-mixed" = fp16 autocast, utils/trainer.py:57) and under "bf16-mixed": inference rollouts take the fused MFMA
+    encoder and stream 16-bit planes; a training step folds into bf16 planes, rolls out on the multistart MFMA kernel and
+    differentiates through the MMA teacher backward; without autocast the same object is the fp32 parity configuration."""
+    import warnings
+
+    from rl4co_amd import kernels as K
+    from rl4co_amd import teacher
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    torch.manual_seed(0)
+    pol = AttentionModelPolicy("tsp", normalization="instance", train_decode_type="multistart_sampling").cuda()
+    env = get_env("tsp", generator_params=dict(num_loc=50, device="cuda"), device="cuda", check_solution=False)
+    torch.manual_seed(1)
+    data = env.generator(batch_size=[64])
+    seen = []
+    orig_decode, orig_back = K.am_decode, teacher.run_backward
+    K.am_decode = lambda cache, state, **kw: (seen.append(("decode", cache.kvl.dtype, K.decode_variant(
+        cache.num_nodes, cache.kvl.dtype, kw["max_steps"], state["action_mask"].shape[0], cache.num_instances))),
+        orig_decode(cache, state, **kw))[1]
+    teacher.run_backward = lambda cache, *a, **k: (lambda out: (seen.append(("backward", cache.kvl.dtype, out["variant"])), out)[1])(
+        orig_back(cache, *a, **k))
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("error", RuntimeWarning)
+            # (64 trajectories: bf16 planes run LDS-resident = variant 2; fp16 planes are served by the streaming kernel = 1)
+            for regime, infer_planes, variant in ((torch.float16, torch.float16, 1), (torch.bfloat16, torch.bfloat16, 2)):
+                seen.clear()
+                pol.eval()
+                pol.encode_events = []
+                with torch.inference_mode(), torch.autocast("cuda", dtype=regime):
+                    out = pol(env.reset(data), env, phase="test", decode_type="greedy")
+                assert len(pol.encode_events) == 1 and seen == [("decode", infer_planes, variant)], seen  # fused encoder
+                pol.encode_events = None
+                assert bool(torch.isfinite(out["reward"]).all())
+                seen.clear()
+                pol.train()
+                with torch.autocast("cuda", dtype=regime):
+                    o = pol(env.reset(data), env, phase="train", num_starts=8, seed=1)
+                    loss = -(o["reward"].detach() * o["log_likelihood"]).mean()
+                loss.backward()
+                pol.check_backward_errors()
+                assert seen == [("decode", torch.bfloat16, 4), ("backward", torch.bfloat16, "mma")], seen  # MS rollout, MMA backward
+                pol.zero_grad()
+            seen.clear()
+            pol.eval()
+            with torch.inference_mode():
+                pol(env.reset(data), env, phase="test", decode_type="greedy")
+            assert seen[0][1] == torch.float32
+    finally:
+        K.am_decode, teacher.run_backward = orig_decode, orig_back
