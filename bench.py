@@ -68,8 +68,11 @@ LEGS = {
     "c3_greedy": ("cvrp", 100, 4096, "greedy", 2),
     "c5_sampling": ("cvrp", 500, 1024, "sampling", 4),
     "c4_train": ("tsp", 100, 4096, "multistart_sampling", 3),
+    # configs[1] once more in the reference's DEFAULT precision ("16-mixed" = fp16 autocast, utils/trainer.py:57): fused
+    # encoder on v_mfma_f32_32x32x16_f16, fp16 planes in the streaming decode kernel
+    "c2_greedy_fp16": ("tsp", 100, 4096, "greedy", 1),
 }
-DEFAULT_LEGS = "c2_greedy,c2_sampling,c3_greedy,c5_sampling,c4_train"
+DEFAULT_LEGS = "c2_greedy,c2_sampling,c3_greedy,c5_sampling,c4_train,c2_greedy_fp16"
 
 
 def log(msg: str) -> None:
@@ -205,9 +208,11 @@ class Bench:
         env_name, num_loc, batch, decode, cfg_idx = LEGS[leg]
         if a.batch is not None and leg == "c2_greedy":
             batch = a.batch
+        half = leg.endswith("_fp16")
+        cache_dtype, enc_dtype, elem = ((torch.float16, torch.float16, 2) if half else (self.cache_dtype, self.enc_dtype, self.elem))
         torch.manual_seed(0)  # random-init weights of the reference architecture, identical on every rank
-        policy = AttentionModelPolicy(env_name=env_name, cache_dtype=self.cache_dtype,
-                                      encoder_autocast=self.enc_dtype).to(self.device).eval()
+        policy = AttentionModelPolicy(env_name=env_name, cache_dtype=cache_dtype,
+                                      encoder_autocast=enc_dtype).to(self.device).eval()
         env = get_env(env_name, generator_params=dict(num_loc=num_loc, device=self.device), device=self.device,
                       check_solution=not a.no_check_solution)
         torch.manual_seed(1234 + self.rank)  # each rank owns its shard of the synthetic instances
@@ -326,16 +331,18 @@ class Bench:
             return res
         mean_decode_ms = sum(decode_ms) / len(decode_ms)
         per_launch_rows, per_launch_steps = rows / steps, inst_steps / steps
-        need = must_move_bytes(env_name, n_nodes, self.elem, per_launch_rows, per_launch_steps, batch)
-        contract = algorithmic_bytes_per_instance_step(env_name, n_nodes, self.elem) * per_launch_steps
+        need = must_move_bytes(env_name, n_nodes, elem, per_launch_rows, per_launch_steps, batch)
+        contract = algorithmic_bytes_per_instance_step(env_name, n_nodes, elem) * per_launch_steps
         achieved = need / (mean_decode_ms * 1e-3) / 1e9
         traffic, traffic_source = self.traffic(leg)
         variant = {1: "STREAM (1 wave / trajectory)", 2: "LDS-resident", 3: "WIDE (4 waves / trajectory)", 4: "MS"}.get(
-            K.decode_variant(n_nodes, self.cache_dtype, t_steps, batch), "?")
+            K.decode_variant(n_nodes, cache_dtype, t_steps, batch), "?")
         value = total_inst_steps / wall
         res.update({
             "workload": (f"BASELINE configs[{cfg_idx}]: {env_name.upper()}Env num_loc={num_loc} batch={batch}/GPU "
-                         f"AttentionModel(3L,d128,h8) {decode} rollout, {a.encoder_dtype} encoder GEMMs, {a.cache_dtype} cache"),
+                         f"AttentionModel(3L,d128,h8) {decode} rollout, " +
+                         ("fp16 encoder GEMMs, fp16 cache (the reference's default 16-mixed regime)" if half else
+                          f"{a.encoder_dtype} encoder GEMMs, {a.cache_dtype} cache")),
             "value": value, "unit": "instance·step/s", "steps": steps, "warmup": warmup,
             "ms_per_step": wall / steps * 1e3,
             "launch": (("pipeline: two captured rollouts (hip graphs) in flight on two HIP streams over the stream of batches "
