@@ -68,7 +68,8 @@ extern "C" {
 #define RL4CO_DT_F32 0
 #define RL4CO_DT_BF16 1
 #define RL4CO_DT_F16 2 /* IEEE half planes: the reference's default "16-mixed" regime (utils/trainer.py:57); served by the
-                          fused encoder (inference) and the streaming decode kernel */
+                          fused encoder, the streaming and the multistart (MS) decode kernels and both teacher-forced
+                          backward variants */
 
 /* kernel variants of rl4co_am_decode (same results up to the documented summation tree) */
 #define RL4CO_VARIANT_AUTO 0

@@ -702,9 +702,26 @@ static inline float bf16_round(float x) {
   return rl4co_bits_to_float(u & 0xffff0000u);
 }
 
+/* fp32 -> binary16 -> fp32, round to nearest even, overflow to infinity (v_cvt_f16_f32): the fp16 build of the MS kernel
+ * (csrc/am_decode_ms_f16.hip) rounds at the same three points with this instead of bf16_round */
+static inline float half_round(float x) {
+  const uint32_t u = rl4co_float_to_bits(x), sign = u & 0x80000000u, mag = u & 0x7fffffffu;
+  if (mag > 0x7f800000u) return x;                                  /* NaN */
+  if (mag >= 0x477ff000u) return rl4co_bits_to_float(sign | 0x7f800000u); /* >= 65520: rounds to infinity */
+  if (mag < 0x38800000u) {                                          /* below 2^-14: subnormal half, spacing 2^-24 */
+    const float ax = rl4co_bits_to_float(mag);
+    const float r = (ax + 12582912.0f * 5.9604644775390625e-8f) - 12582912.0f * 5.9604644775390625e-8f; /* 1.5 * 2^23 * 2^-24 */
+    return rl4co_bits_to_float(sign | rl4co_float_to_bits(r));
+  }
+  uint32_t v = mag + 0xfffu + ((mag >> 13) & 1u);                    /* 13 mantissa bits dropped */
+  return rl4co_bits_to_float(sign | (v & 0xffffe000u));
+}
+static inline float round16(float x, int dtype) { return dtype == RL4CO_DT_F16 ? half_round(x) : bf16_round(x); }
+
 int oracle_am_decode_ms(const rl4co_am_decode_args* a) {
   const int N = a->N;
-  if (a->cache_dtype != RL4CO_DT_BF16 || N > 128) return 1;
+  if ((a->cache_dtype != RL4CO_DT_BF16 && a->cache_dtype != RL4CO_DT_F16) || N > 128) return 1;
+  const int dt16 = a->cache_dtype;
   const int env = a->env;
   const int tsp = env == RL4CO_ENV_TSP;
   const int cvrp_like = env == RL4CO_ENV_CVRP || env == RL4CO_ENV_CVRPTW;
@@ -764,7 +781,7 @@ int oracle_am_decode_ms(const rl4co_am_decode_args* a) {
           if (tw_env) v = fmaf(a->w_time[d], now, v);
           v = v + qb;
         }
-        q[d] = bf16_round(v * (0.25f * log2e)); /* rounding point 1: the MFMA B operand */
+        q[d] = round16(v * (0.25f * log2e), dt16); /* rounding point 1: the MFMA B operand */
       }
       float heads[D];
       for (int h = 0; h < H; ++h) {
@@ -772,7 +789,7 @@ int oracle_am_decode_ms(const rl4co_am_decode_args* a) {
         for (int j = 0; j < N; ++j) {
           float acc = 0.0f;
           for (int e = 0; e < DH; ++e)
-            acc = fmaf(cache_at(a->glimpse_key, RL4CO_DT_BF16, cbase + (int64_t)j * a->kvl_row_stride + h * DH + e), q[h * DH + e], acc);
+            acc = fmaf(cache_at(a->glimpse_key, dt16, cbase + (int64_t)j * a->kvl_row_stride + h * DH + e), q[h * DH + e], acc);
           const int feas = !a->mask_inner || mk[j] != 0;
           sc[j * H + h] = feas ? acc : neg_inf;
           m = fmaxf(m, sc[j * H + h]);
@@ -783,19 +800,19 @@ int oracle_am_decode_ms(const rl4co_am_decode_args* a) {
         for (int j = 0; j < N; ++j) {
           const float p = exp2f(sc[j * H + h] - m);
           l += p;
-          const float pb = bf16_round(p); /* rounding point 2: softmax numerators as MFMA operand; l sums the fp32 p */
+          const float pb = round16(p, dt16); /* rounding point 2: softmax numerators as MFMA operand; l sums the fp32 p */
           for (int e = 0; e < DH; ++e)
-            o[e] = fmaf(cache_at(a->glimpse_val, RL4CO_DT_BF16, cbase + (int64_t)j * a->kvl_row_stride + h * DH + e), pb, o[e]);
+            o[e] = fmaf(cache_at(a->glimpse_val, dt16, cbase + (int64_t)j * a->kvl_row_stride + h * DH + e), pb, o[e]);
         }
         const float inv = l > 0.0f ? 1.0f / l : 0.0f;
-        for (int e = 0; e < DH; ++e) heads[h * DH + e] = bf16_round(o[e] * inv); /* rounding point 3: the glimpse */
+        for (int e = 0; e < DH; ++e) heads[h * DH + e] = round16(o[e] * inv, dt16); /* rounding point 3: the glimpse */
       }
       float zmax = neg_inf;
       int nan_seen = 0;
       for (int j = 0; j < N; ++j) {
         float acc = 0.0f;
         for (int d = 0; d < D; ++d)
-          acc = fmaf(cache_at(a->logit_key, RL4CO_DT_BF16, cbase + (int64_t)j * a->kvl_row_stride + d), heads[d], acc);
+          acc = fmaf(cache_at(a->logit_key, dt16, cbase + (int64_t)j * a->kvl_row_stride + d), heads[d], acc);
         const float uu = acc * (1.0f / sqrt_d);
         if (uu != uu) nan_seen = 1;
         float zz;
@@ -1000,5 +1017,11 @@ int oracle_pomo_best(const float* reward, const int64_t* actions, int A, int S, 
 /* binary16 -> binary32 over an array (tests pin the conversion to torch's for all 65 536 bit patterns) */
 int oracle_half_to_float_array(const uint16_t* h, int64_t n, float* out) {
   for (int64_t i = 0; i < n; ++i) out[i] = half_bits_to_float(h[i]);
+  return 0;
+}
+
+/* fp32 -> binary16 rounding over an array (tests pin it to torch's conversion) */
+int oracle_half_round_array(const float* x, int64_t n, float* out) {
+  for (int64_t i = 0; i < n; ++i) out[i] = half_round(x[i]);
   return 0;
 }

@@ -960,12 +960,11 @@ int launch_wide(const rl4co_am_decode_args& a, hipStream_t stream) {
 inline int resolve_variant(const rl4co_am_decode_args& a) {
   // the unfolded parity mode exists in the streaming kernel only
   if (a.unfold) return (a.variant == RL4CO_VARIANT_AUTO || a.variant == RL4CO_VARIANT_STREAM) ? RL4CO_VARIANT_STREAM : -1;
-  // fp16 planes: the streaming kernel only (the 4-wave and matrix-core variants are bf16 kernels)
-  if (a.cache_dtype == RL4CO_DT_F16)
-    return (a.variant == RL4CO_VARIANT_AUTO || a.variant == RL4CO_VARIANT_STREAM) ? RL4CO_VARIANT_STREAM : -1;
+  // fp16 planes: the streaming kernel and the multistart matrix-core kernel (the 4-wave variants are bf16 kernels)
+  const bool f16 = a.cache_dtype == RL4CO_DT_F16;
   const bool bf16 = a.cache_dtype == RL4CO_DT_BF16;
-  // multistart on the matrix cores (am_decode_ms.hip): bf16 planes, N <= 128, plain outputs; every environment
-  const bool ms_ok = bf16 && a.N <= 128 && a.B_inst > 0 && a.all_logps == nullptr && a.entropy == nullptr;
+  // multistart on the matrix cores (am_decode_ms.hip): 16-bit planes, N <= 128, plain outputs; every environment
+  const bool ms_ok = (bf16 || f16) && a.N <= 128 && a.B_inst > 0 && a.all_logps == nullptr && a.entropy == nullptr;
   if (a.variant == RL4CO_VARIANT_MS) return ms_ok ? RL4CO_VARIANT_MS : -1;
   const bool fits = bf16 && lds_variant_bytes(a.N) <= 80 * 1024;
   const bool wide_ok = bf16 && wide_scratch_bytes(a.N) <= 64 * 1024;
@@ -981,6 +980,7 @@ inline int resolve_variant(const rl4co_am_decode_args& a) {
   const int ms_from = (a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_PDP || a.env == RL4CO_ENV_PCTSP) ? 8
                       : (a.env == RL4CO_ENV_CVRP ? 16 : 0);
   if (ms_ok && ms_from > 0 && a.B >= ms_from * a.B_inst) return RL4CO_VARIANT_MS;
+  if (f16) return RL4CO_VARIANT_STREAM;
   if (fits && a.B <= 1024) return RL4CO_VARIANT_LDS;
   // one wave per trajectory needs >= ~16 waves per CU to hide its latency chain: with fewer
   // trajectories than that, four waves per trajectory keep the memory pipes busier
@@ -1071,6 +1071,7 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
       return a.env == RL4CO_ENV_TSP ? launch<CacheF32, RL4CO_ENV_TSP, true>(a, s) : launch<CacheF32, RL4CO_ENV_CVRP, true>(a, s);
     return a.env == RL4CO_ENV_TSP ? launch<CacheBF16, RL4CO_ENV_TSP, true>(a, s) : launch<CacheBF16, RL4CO_ENV_CVRP, true>(a, s);
   }
+  if (variant == RL4CO_VARIANT_MS && a.cache_dtype == RL4CO_DT_F16) return rl4co::launch_decode_ms_f16(a, s);
   if (a.cache_dtype == RL4CO_DT_F16) {
     switch (a.env) {
       case RL4CO_ENV_TSP: return launch<CacheF16, RL4CO_ENV_TSP>(a, s);

@@ -36,6 +36,7 @@
 #include <hip/hip_runtime.h>
 
 #include "common.h"
+#include "elem16.h"
 #include "rl4co_math.h"
 
 namespace {
@@ -49,20 +50,20 @@ constexpr float kNegInf = -__builtin_huge_valf();
 constexpr float kSqrtD = 11.3137084989847604f;
 constexpr float kLog2e = 1.44269504088896341f;
 
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef elem_t bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 // C[m = 4 g + r][n = lane & 15] += sum_k A[m = lane & 15][k = 4 g + s] * B[k = 4 g + s][n = lane & 15]
 __device__ inline f32x4 mfma16(const bf16x4& a, const bf16x4& b, const f32x4& c) {
-  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+  return rl4co_e16::mfma_16x16x16(a, b, c);
 }
 __device__ inline f32x4 zero4() { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
-__device__ inline bf16x4 lds_b64(const __bf16* p) { return *reinterpret_cast<const bf16x4*>(p); }
+__device__ inline bf16x4 lds_b64(const elem_t* p) { return *reinterpret_cast<const bf16x4*>(p); }
 // the 16 lanes of a row group address a [4 rows][16 columns] block (lane i: row i / 4, columns
 // 4 (i % 4) ..); lane c receives column c of it, i.e. four consecutive ROWS
-__device__ inline bf16x4 lds_tr(const __bf16* p) {
+__device__ inline bf16x4 lds_tr(const elem_t* p) {
   const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
   return __builtin_bit_cast(bf16x4, v);
 }
@@ -175,8 +176,8 @@ __device__ inline Sel partner(const Sel& p) {
 struct Shared {
   const uint16_t* kl_g;  // this instance's logit-key plane in global memory (row stride kl_rs)
   int64_t kl_rs;
-  const __bf16 *kgs, *vs;
-  __bf16* hs;   // [CT][16 trajectories][kRS] glimpses of this step
+  const elem_t *kgs, *vs;
+  elem_t* hs;   // [CT][16 trajectories][kRS] glimpses of this step
   Xchg* xs;     // [CT][8 node tiles][16 trajectories]
   const float* dems;  // [128] CVRP / CVRPTW demand (index j - 1 at j), PCTSP real prize at j
   const float* envf;  // [128][2] coordinates | [128] OP entry limits | [128][2] time windows | [128] service times
@@ -331,7 +332,7 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
           if (kClock) q = fmaf(qt4[e], x.now, q);  // context.py:152-166: second scalar, the current time
           q = q + qb4[e];
         }
-        qf[c][e] = (__bf16)(q * (0.25f * kLog2e));
+        qf[c][e] = (elem_t)(q * (0.25f * kLog2e));
       }
     }
     // ---- 2. glimpse of head h ---------------------------------------------------------------------------
@@ -375,7 +376,7 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
           for (int rr = 0; rr < 4; ++rr) {
             const float p = __builtin_amdgcn_exp2f(sc[c][jt][rr] - m[c]);
             l[c] += p;
-            pf[rr] = (__bf16)p;
+            pf[rr] = (elem_t)p;
           }
           if (jt & 1) o1[c] = mfma16(vf, pf, o1[c]);
           else o0[c] = mfma16(vf, pf, o0[c]);
@@ -387,7 +388,7 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
         const float inv = (ls > 0.0f) ? __builtin_amdgcn_rcpf(ls) : 0.0f;
         bf16x4 of;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) of[rr] = (__bf16)((o0[c][rr] + o1[c][rr]) * inv);
+        for (int rr = 0; rr < 4; ++rr) of[rr] = (elem_t)((o0[c][rr] + o1[c][rr]) * inv);
         *reinterpret_cast<bf16x4*>(sh.hs + (16 * c + tl) * kRS + dcol) = of;
       }
     }
@@ -699,8 +700,8 @@ __global__ void __launch_bounds__(kThreads, 4) am_decode_ms_kernel(const rl4co_a
   }
   const Layout L = make_layout(NT, N);
   if ((tid >> 6) >= 4) __builtin_amdgcn_s_setprio(1);  // even out the younger half of the workgroup (issue arbitration)
-  __bf16* kgs = reinterpret_cast<__bf16*>(smem + L.kgs);  // [16 NT nodes][kRS] glimpse keys
-  __bf16* vs = reinterpret_cast<__bf16*>(smem + L.vs);    // glimpse values
+  elem_t* kgs = reinterpret_cast<elem_t*>(smem + L.kgs);  // [16 NT nodes][kRS] glimpse keys
+  elem_t* vs = reinterpret_cast<elem_t*>(smem + L.vs);    // glimpse values
   float* dems = reinterpret_cast<float*>(smem + L.dems);  // [128] CVRP demands (index j-1 at j), 0 elsewhere
 
   // ---- glimpse planes HBM / L2 -> LDS, once per workgroup ---------------------------------------------------
@@ -742,7 +743,7 @@ __global__ void __launch_bounds__(kThreads, 4) am_decode_ms_kernel(const rl4co_a
   sh.vs = vs;
   sh.kl_g = static_cast<const uint16_t*>(a.logit_key) + (int64_t)inst * a.kvl_batch_stride;
   sh.kl_rs = a.kvl_row_stride;
-  sh.hs = reinterpret_cast<__bf16*>(smem + L.hs);
+  sh.hs = reinterpret_cast<elem_t*>(smem + L.hs);
   sh.xs = reinterpret_cast<Xchg*>(smem + L.xs);
   sh.dems = dems;
   sh.envf = reinterpret_cast<const float*>(smem + L.envf);
@@ -782,10 +783,12 @@ int dispatch_tiles(const rl4co_am_decode_args& a, hipStream_t stream) {
 }  // namespace
 
 // dynamic LDS of the multistart variant at the largest graph (N = 128)
+#if !RL4CO_ELEM_F16
 extern "C" int rl4co_am_decode_ms_lds_bytes(void) { return make_layout(8, 128).total; }
+#endif
 
 namespace rl4co {
-int launch_decode_ms(const rl4co_am_decode_args& a, hipStream_t stream) {
+int RL4CO_CXX(launch_decode_ms)(const rl4co_am_decode_args& a, hipStream_t stream) {
   switch (a.env) {
     case RL4CO_ENV_TSP: return dispatch_tiles<RL4CO_ENV_TSP>(a, stream);
     case RL4CO_ENV_CVRP: return dispatch_tiles<RL4CO_ENV_CVRP>(a, stream);

@@ -1,0 +1,5 @@
+// am_decode_ms_f16.hip — the IEEE-half build of am_decode_ms.hip (see elem16.h): the same source compiled with elem_t = _Float16
+// (fp16 planes, queries, softmax numerators and glimpses; launcher rl4co::launch_*_f16), for the reference's default
+// "16-mixed" precision (rl4co/utils/trainer.py:57).
+#define RL4CO_ELEM_F16 1
+#include "am_decode_ms.hip"

@@ -35,6 +35,7 @@ constexpr int kW = 4;  // waves per workgroup
 
 __device__ inline float load_plane(const void* base, int dtype, int64_t idx) {
   if (dtype == RL4CO_DT_BF16) return __uint_as_float((uint32_t)static_cast<const uint16_t*>(base)[idx] << 16);
+  if (dtype == RL4CO_DT_F16) return (float)static_cast<const _Float16*>(base)[idx];
   return static_cast<const float*>(base)[idx];
 }
 
@@ -560,7 +561,7 @@ static int validate_teacher(const rl4co_am_teacher_args& a) {
                 a.env == RL4CO_ENV_PCTSP || a.env == RL4CO_ENV_PDP || a.env == RL4CO_ENV_CVRPTW);
   RL4CO_REQUIRE(a.B > 0 && a.B_inst > 0 && a.B % a.B_inst == 0);
   RL4CO_REQUIRE(a.N >= 2 && a.N <= 128 && a.T >= 1 && a.t0 >= 0 && a.t0 <= 1);
-  RL4CO_REQUIRE(a.cache_dtype == RL4CO_DT_F32 || a.cache_dtype == RL4CO_DT_BF16);
+  RL4CO_REQUIRE(a.cache_dtype == RL4CO_DT_F32 || a.cache_dtype == RL4CO_DT_BF16 || a.cache_dtype == RL4CO_DT_F16);
   RL4CO_REQUIRE(a.variant >= RL4CO_TEACHER_AUTO && a.variant <= RL4CO_TEACHER_MMA);
   RL4CO_REQUIRE(a.glimpse_key && a.glimpse_val && a.logit_key && a.ctx_cur && a.actions && a.grad_logp);
   RL4CO_REQUIRE(a.kvl_row_stride >= kD && a.kvl_batch_stride >= (int64_t)a.N * kD);
@@ -587,7 +588,7 @@ static int validate_teacher(const rl4co_am_teacher_args& a) {
 
 // MMA needs bf16 planes (16-byte aligned rows) and its step tables to hold every action column
 static int resolve_teacher_variant(const rl4co_am_teacher_args& a) {
-  const bool mma_ok = a.cache_dtype == RL4CO_DT_BF16 && a.N <= rl4co::teacher_mma_max_nodes() &&
+  const bool mma_ok = a.cache_dtype != RL4CO_DT_F32 && a.N <= rl4co::teacher_mma_max_nodes() &&
                       a.T <= rl4co::teacher_mma_max_steps() && a.kvl_row_stride % 8 == 0 && a.kvl_batch_stride % 8 == 0;
   if (a.d_planes_bf16 || !a.d_kvl)  // bf16 plane gradients come out of the MMA variant only
     return (mma_ok && a.variant != RL4CO_TEACHER_REPLAY) ? RL4CO_TEACHER_MMA : -1;
@@ -609,7 +610,8 @@ extern "C" int rl4co_am_teacher_backward(const rl4co_am_teacher_args* args, void
   const int variant = resolve_teacher_variant(a);
   RL4CO_REQUIRE(variant > 0);  // RL4CO_TEACHER_MMA requested for planes / sizes it does not support
   hipStream_t s = rl4co::as_stream(stream);
-  if (variant == RL4CO_TEACHER_MMA) return rl4co::launch_teacher_mma(a, s);
+  if (variant == RL4CO_TEACHER_MMA)
+    return a.cache_dtype == RL4CO_DT_F16 ? rl4co::launch_teacher_mma_f16(a, s) : rl4co::launch_teacher_mma(a, s);
   switch (a.env) {
     case RL4CO_ENV_TSP: return dispatch_rows<RL4CO_ENV_TSP>(a, s);
     case RL4CO_ENV_CVRP: return dispatch_rows<RL4CO_ENV_CVRP>(a, s);

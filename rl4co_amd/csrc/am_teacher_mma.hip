@@ -31,6 +31,7 @@
 #include <hip/hip_runtime.h>
 
 #include "common.h"
+#include "elem16.h"
 
 namespace {
 
@@ -44,27 +45,27 @@ constexpr float kNegInf = -__builtin_huge_valf();
 constexpr float kSqrtD = 11.3137084989847604f;
 constexpr float kLog2e = 1.44269504088896341f;
 
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef elem_t bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 // C[m = 4 g + r][n = lane & 15] += sum_k A[m = lane & 15][k = 4 g + s] * B[k = 4 g + s][n = lane & 15]
 __device__ inline f32x4 mfma16(const bf16x4& a, const bf16x4& b, const f32x4& c) {
-  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+  return rl4co_e16::mfma_16x16x16(a, b, c);
 }
 __device__ inline f32x4 zero4() { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
-__device__ inline bf16x4 lds_b64(const __bf16* p) { return *reinterpret_cast<const bf16x4*>(p); }
+__device__ inline bf16x4 lds_b64(const elem_t* p) { return *reinterpret_cast<const bf16x4*>(p); }
 // ds_read_b64_tr_b16: the 16 lanes of a row group address a [4 rows][16 columns] block (lane i:
 // row i / 4, columns 4 (i % 4) ..) and lane c receives column c of it — four consecutive ROWS
-__device__ inline bf16x4 lds_tr(const __bf16* p) {
+__device__ inline bf16x4 lds_tr(const elem_t* p) {
   const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
   return __builtin_bit_cast(bf16x4, v);
 }
 __device__ inline bf16x4 to_bf16(const f32x4& v) {
   bf16x4 o;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+  for (int i = 0; i < 4; ++i) o[i] = (elem_t)v[i];
   return o;
 }
 // LDS hand-off inside ONE wave
@@ -119,17 +120,17 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
   // (older wave first); a static priority for it evens the halves out between the barriers
   if (w >= 4) __builtin_amdgcn_s_setprio(1);
   const Layout L = make_layout(NT);  // NT node tiles of 16 (template): rows N .. 16 NT - 1 are zero
-  __bf16* kgs = reinterpret_cast<__bf16*>(smem + L.kgs);
-  __bf16* vs = reinterpret_cast<__bf16*>(smem + L.vs);
-  __bf16* kls = reinterpret_cast<__bf16*>(smem + L.kls);
-  __bf16* ob = reinterpret_cast<__bf16*>(smem + L.ob);    // [16 steps][kRS] glimpses of the block
-  __bf16* dub = reinterpret_cast<__bf16*>(smem + L.dub);  // [16 steps][kRS] d logits (pre-clip, raw)
-  __bf16* qb = reinterpret_cast<__bf16*>(smem + L.qb);    // [16 steps][kRS] queries (x 0.25 log2 e)
+  elem_t* kgs = reinterpret_cast<elem_t*>(smem + L.kgs);
+  elem_t* vs = reinterpret_cast<elem_t*>(smem + L.vs);
+  elem_t* kls = reinterpret_cast<elem_t*>(smem + L.kls);
+  elem_t* ob = reinterpret_cast<elem_t*>(smem + L.ob);    // [16 steps][kRS] glimpses of the block
+  elem_t* dub = reinterpret_cast<elem_t*>(smem + L.dub);  // [16 steps][kRS] d logits (pre-clip, raw)
+  elem_t* qb = reinterpret_cast<elem_t*>(smem + L.qb);    // [16 steps][kRS] queries (x 0.25 log2 e)
   // d glimpse / softmax denominator of the block takes the glimpses' place: after B3 a wave reads only its own head's
   // columns of `ob` (the O_h^T operand of d Kl) and writes the same columns of `dob` afterwards — eight wave-private
   // column strips, ordered by program order within the wave. 4 KB that let eight node tiles (N <= 128) fit in 160 KB
-  __bf16* dob = ob;
-  __bf16* pbw = reinterpret_cast<__bf16*>(smem + L.pb) + w * 16 * kRS;  // this wave's [16 steps][kRS] P, then dS
+  elem_t* dob = ob;
+  elem_t* pbw = reinterpret_cast<elem_t*>(smem + L.pb) + w * 16 * kRS;  // this wave's [16 steps][kRS] P, then dS
   int* sact = reinterpret_cast<int*>(smem + L.sact);
   float* srem = reinterpret_cast<float*>(smem + L.srem);
   float* stime = reinterpret_cast<float*>(smem + L.stime);  // CVRPTW: the clock before each column
@@ -423,7 +424,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
           if (ENV == RL4CO_ENV_TSP) q = (t == 0) ? qx4[e] + qb4[e] : (f4[e] + c[e]) + qb4[e];
           else if (kClock) q = fmaf(qt4[e], now, fmaf(qx4[e], rem, c[e])) + qb4[e];  // context.py:152-166
           else q = fmaf(qx4[e], rem, c[e]) + qb4[e];
-          qf[e] = (__bf16)(q * (0.25f * kLog2e));
+          qf[e] = (elem_t)(q * (0.25f * kLog2e));
         }
         *reinterpret_cast<bf16x4*>(qb + tl * kRS + dcol) = qf;
       }
@@ -455,7 +456,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
             for (int rr = 0; rr < 4; ++rr) {
               const float p = __builtin_amdgcn_exp2f(sc[jt][rr] - m);
               l += p;
-              pf[jt][rr] = (__bf16)p;
+              pf[jt][rr] = (elem_t)p;
             }
             *reinterpret_cast<bf16x4*>(pbw + tl * kRS + 16 * jt + 4 * g) = pf[jt];
           }
@@ -606,7 +607,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
             const f32x4 da = mfma16(lds_b64(vs + 16 * jt * kRS + 16 * h + nao), dof, zero4());
             bf16x4 dsf;
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) dsf[rr] = (__bf16)((float)pf[jt][rr] * (da[rr] - ada) * inv_l);
+            for (int rr = 0; rr < 4; ++rr) dsf[rr] = (elem_t)((float)pf[jt][rr] * (da[rr] - ada) * inv_l);
             *reinterpret_cast<bf16x4*>(pbw + tl * kRS + 16 * jt + 4 * g) = dsf;
             dq = mfma16(lds_tr(kgs + 16 * jt * kRS + 16 * h + tro), dsf, dq);
           }
@@ -657,12 +658,12 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
   // ---- the instance's plane gradients: dims 16 h + 4 g .. + 3 of node 16 jt + (lane & 15) -----------
   const float c = 1.0f / kLog2e;  // the staged queries carried log2(e)
   if (a.d_planes_bf16) {  // bf16 rows in the caller's layout (columns of the fold GEMMs' gradient operand)
-    __bf16* dk = static_cast<__bf16*>(a.d_planes_bf16) + (int64_t)inst * a.d_planes_batch_stride + dcol;
+    elem_t* dk = static_cast<elem_t*>(a.d_planes_bf16) + (int64_t)inst * a.d_planes_batch_stride + dcol;
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) {
       const int j = 16 * jt + tl;
       if (j < N) {
-        __bf16* p0 = dk + (int64_t)j * a.d_planes_row_stride;
+        elem_t* p0 = dk + (int64_t)j * a.d_planes_row_stride;
         const f32x4 kg = {dkg[jt][0] * c, dkg[jt][1] * c, dkg[jt][2] * c, dkg[jt][3] * c};
         *reinterpret_cast<bf16x4*>(p0) = to_bf16(kg);
         *reinterpret_cast<bf16x4*>(p0 + a.d_planes_plane_stride) = to_bf16(dvg[jt]);
@@ -702,8 +703,10 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
 
 namespace rl4co {
 
+#if !RL4CO_ELEM_F16
 int teacher_mma_max_nodes() { return 16 * kMaxTiles; }
 int teacher_mma_max_steps() { return kMaxT; }
+#endif
 
 template <int ENV, int NT>
 static int launch_tiles(const rl4co_am_teacher_args& a, hipStream_t stream) {
@@ -724,7 +727,7 @@ static int dispatch_tiles(const rl4co_am_teacher_args& a, hipStream_t stream) {
   return launch_tiles<ENV, kMaxTiles>(a, stream);
 }
 
-int launch_teacher_mma(const rl4co_am_teacher_args& a, hipStream_t stream) {
+int RL4CO_CXX(launch_teacher_mma)(const rl4co_am_teacher_args& a, hipStream_t stream) {
   if (a.env == RL4CO_ENV_OP) return dispatch_tiles<RL4CO_ENV_OP>(a, stream);
   if (a.env == RL4CO_ENV_PCTSP) return dispatch_tiles<RL4CO_ENV_PCTSP>(a, stream);
   if (a.env == RL4CO_ENV_PDP) return dispatch_tiles<RL4CO_ENV_PDP>(a, stream);

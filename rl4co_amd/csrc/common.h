@@ -28,9 +28,11 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 
 // am_decode_ms.hip: multistart decode on the matrix cores (dispatched from rl4co_am_decode)
 int launch_decode_ms(const rl4co_am_decode_args& a, hipStream_t stream);
+int launch_decode_ms_f16(const rl4co_am_decode_args& a, hipStream_t stream);  // fp16 planes (csrc/elem16.h)
 
 // am_teacher_mma.hip: teacher-forced backward on the matrix cores (dispatched from rl4co_am_teacher_backward)
 int launch_teacher_mma(const rl4co_am_teacher_args& a, hipStream_t stream);
+int launch_teacher_mma_f16(const rl4co_am_teacher_args& a, hipStream_t stream);  // fp16 planes
 int teacher_mma_max_nodes();
 int teacher_mma_max_steps();
 

@@ -20,9 +20,11 @@
 #if RL4CO_ELEM_F16
 typedef _Float16 elem_t;
 #define RL4CO_ENTRY(stem) stem##_f16
+#define RL4CO_CXX(stem) stem##_f16
 #else
 typedef __bf16 elem_t;
 #define RL4CO_ENTRY(stem) stem##_bf16
+#define RL4CO_CXX(stem) stem
 #endif
 
 namespace rl4co_e16 {

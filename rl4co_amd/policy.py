@@ -431,8 +431,9 @@ class AttentionModelPolicy(nn.Module):
             per decode step; ``torch.float32`` is the parity configuration). ``None`` (the default) follows the
             precision regime the way the reference's own cache does — its K / V / logit key are the output of a Linear
             and therefore 16-bit under autocast (zoo/am/decoder.py:201-228): float32 without autocast, bfloat16 under
-            bf16 autocast, under fp16 autocast float16 for inference rollouts and bfloat16 for training steps (the
-            multistart rollout and the MMA backward read bf16 planes). So ``RL4COTrainer()`` with its default
+            bf16 autocast, under fp16 autocast float16 for inference rollouts and bfloat16 for training steps (wider
+            exponent for the backward's intermediates; ``cache_dtype=torch.float16`` selects the fp16 builds of the
+            multistart rollout and the MMA backward instead). So ``RL4COTrainer()`` with its default
             ``precision="16-mixed"`` over ``AttentionModelPolicy(env_name)`` reaches the fast kernels with no extra argument.
         encoder_autocast: optional autocast dtype for the encoder GEMMs (otherwise the ambient autocast decides).
     """
@@ -560,6 +561,10 @@ class AttentionModelPolicy(nn.Module):
         if regime == torch.bfloat16:
             return torch.bfloat16
         if regime == torch.float16:
+            # training: bf16 planes — the matrix-core rollout and backward then carry their intermediates (softmax
+            # numerators, d logits, d scores) with an 8-bit exponent: no underflow of small REINFORCE advantages and no
+            # overflow under GradScaler's loss scale, at the same speed (fp16 builds of both kernels exist and are taken
+            # when the caller asks for cache_dtype=torch.float16)
             return torch.bfloat16 if training else torch.float16
         return torch.float32
 
@@ -752,10 +757,10 @@ class AttentionModelPolicy(nn.Module):
 
             if teacher.supports(self.env_name, cache_dtype, n) and not return_entropy:
                 # bf16 encoder output + bf16 planes + the MMA backward: ONE fold GEMM each way, the planes side by side
-                fused_planes = (hidden.dtype in (torch.bfloat16, torch.float16) and cache_dtype == torch.bfloat16
-                                and self.teacher_variant != "replay")
-                # (fp16 activations: the fold runs in bf16 — its outputs, the streamed planes, are bf16 anyway)
-                h_fold = hidden.to(torch.bfloat16) if (fused_planes and hidden.dtype == torch.float16) else hidden
+                half = (torch.bfloat16, torch.float16)
+                fused_planes = hidden.dtype in half and cache_dtype in half and self.teacher_variant != "replay"
+                # (activations in one 16-bit type, planes asked for in the other: the fold runs in the planes' type)
+                h_fold = hidden.to(cache_dtype) if (fused_planes and hidden.dtype != cache_dtype) else hidden
                 cache_g = teacher.build_cache_autograd(self.env_name, h_fold, self.decoder, fused_planes=fused_planes)
                 cache = teacher.detached_cache(self.env_name, cache_g, cache_dtype)
         if cache is None:

@@ -49,8 +49,8 @@ def max_nodes() -> int:
 def supports(env_name: str, cache_dtype: torch.dtype, num_nodes: int) -> bool:
     """TSP, CVRP, orienteering, prize-collecting TSP, pickup-delivery, CVRP with time windows — on both variants (the
     MMA one needs bf16 planes; fp32 planes take the replay kernel)."""
-    if num_nodes > max_nodes() or cache_dtype not in (torch.float32, torch.bfloat16):
-        return False  # (fp16 planes: the backward kernels read fp32 or bf16 planes)
+    if num_nodes > max_nodes() or cache_dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        return False
     return env_name in ("tsp", "cvrp", "op", "pctsp", "pdp", "cvrptw")
 
 
@@ -85,8 +85,7 @@ def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: d
     a.B, a.B_inst, a.N, a.T, a.t0 = b, b_inst, n, t, int(meta["t0"])
     a.mask_inner, a.mask_logits = int(meta["mask_inner"]), int(meta["mask_logits"])
     a.tanh_clipping, a.temperature = float(meta["tanh_clipping"]), float(meta["temperature"])
-    if cache.kvl.dtype not in (torch.float32, torch.bfloat16):
-        raise TypeError(f"teacher-forced backward reads float32 or bfloat16 planes, got {cache.kvl.dtype}")
+
     a.cache_dtype = _lib.dtype_id(cache.kvl.dtype)
     a.variant = VARIANT_IDS[variant]
     a.glimpse_key, a.glimpse_val, a.logit_key = (cache.plane(i).data_ptr() for i in range(3))
@@ -115,7 +114,7 @@ def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: d
         a.locs, a.max_length = locs.data_ptr(), maxlen.data_ptr()
     a.d_kvl, a.d_ctx_cur, a.d_ctx_first, a.d_q_bias = ptr(d_kvl), ptr(d_ctx_cur), ptr(d_ctx_first), ptr(d_q_bias)
     if d_planes is not None:
-        assert d_planes.dtype == torch.bfloat16 and d_planes.shape == (3, b_inst, n, EMBED_DIM) and d_planes.stride(3) == 1
+        assert d_planes.dtype == cache.kvl.dtype and d_planes.shape == (3, b_inst, n, EMBED_DIM) and d_planes.stride(3) == 1
         a.d_planes_bf16 = d_planes.data_ptr()
         a.d_planes_plane_stride, a.d_planes_batch_stride, a.d_planes_row_stride = d_planes.stride()[:3]
     if tsp:
@@ -150,13 +149,13 @@ def build_cache_autograd(env_name: str, h: Tensor, decoder, fused_planes: bool =
     blocks = fold_weights(env_name, decoder.project_node_embeddings.weight.float(),
                           decoder.pointer.project_out.weight.float(), w_ctx)
     out: dict = {}
-    if fused_planes and h.is_cuda and h.dtype == torch.bfloat16:
+    if fused_planes and h.is_cuda and h.dtype in (torch.bfloat16, torch.float16):
         from . import train_ops
 
         b, n, _ = h.shape
         w_all = torch.cat(blocks, 0)  # [nblk * 128, 128] fp32, differentiable through the fold
         h2 = h.detach().reshape(b * n, d).contiguous()
-        w16 = w_all.detach().to(torch.bfloat16).contiguous()
+        w16 = w_all.detach().to(h.dtype).contiguous()
         planes = train_ops._gemm(h2, w16).view(b, n, len(blocks), d)  # row (b, n): [Kg | V | Kl' | ctx ...]
         out.update(fused=True, h=h, h2=h2, w_all=w_all, w16=w16, planes=planes)
         out["kvl"] = planes.permute(2, 0, 1, 3)[:3]                       # [3, B, N, 128] strided view, bf16
@@ -191,7 +190,7 @@ def detached_cache(env_name: str, g: dict[str, Tensor], cache_dtype: torch.dtype
     """Rollout view of the autograd cache: detached, planes in the streaming dtype."""
     det = lambda x: None if x is None else x.detach().contiguous()  # noqa: E731
     if g.get("fused"):
-        assert cache_dtype == torch.bfloat16
+        assert cache_dtype == g["kvl"].dtype and cache_dtype in (torch.bfloat16, torch.float16)
         kvl = g["kvl"]  # strided view of the fused GEMM's output rows: the kernels take plane pointers and strides
     else:
         kvl = g["kvl"].detach().to(cache_dtype).contiguous()
@@ -244,7 +243,7 @@ class TeacherForcedFoldLogLik(torch.autograd.Function):
         from . import train_ops
 
         b, n, d = ctx.h_shape
-        dp = torch.empty((b, n, ctx.nblk, d), dtype=torch.bfloat16, device=grad_logp.device)
+        dp = torch.empty((b, n, ctx.nblk, d), dtype=ctx.h2.dtype, device=grad_logp.device)  # 16-bit, the planes' type
         out = run_backward(ctx.cache, ctx.actions, grad_logp, ctx.meta, variant="mma", d_planes=dp.permute(2, 0, 1, 3)[:3])
         sink = ctx.meta.get("err_sink")
         if sink is not None:

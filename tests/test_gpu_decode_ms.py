@@ -220,6 +220,19 @@ MS_IDENTICAL_FLOOR = 0.97
                                               ("pomo_op20_b16_msgreedy", 20, "greedy"), ("op100_b64_greedy", 8, "sampling"),
                                               ("pomo_cvrptw20_b16_mssampling", 20, "sampling"), ("cvrptw100_b64_greedy", 8, "greedy")])
 def test_ms_kernel_follows_its_rounding_model_oracle(K, name, starts, mode):
+    _check_ms_vs_model(K, name, starts, mode, torch.bfloat16)
+
+
+@pytest.mark.parametrize("name,starts,mode", [("c4_pomo_tsp100_b32_s8_sampling", 8, "sampling"), ("pomo_tsp20_b16_msgreedy", 20, "greedy"),
+                                              ("cvrp100_b64_greedy", 9, "sampling"), ("pdp100_b64_greedy", 16, "sampling"),
+                                              ("pomo_cvrptw20_b16_mssampling", 20, "sampling")])
+def test_ms_kernel_fp16_build_follows_its_rounding_model_oracle(K, name, starts, mode):
+    """The IEEE-half build (csrc/am_decode_ms_f16.hip: fp16 planes, query, softmax numerators and glimpse on
+    v_mfma_f32_16x16x16_f16) against the same model oracle with half rounding at the same three points."""
+    _check_ms_vs_model(K, name, starts, mode, torch.float16)
+
+
+def _check_ms_vs_model(K, name, starts, mode, dt):
     """BASELINE configs[3]'s rollout kernel (auto-selected from 8 starts on bf16 planes) against the C restatement
     with the SAME bf16 rounding points (query, softmax numerators, glimpse) and fp32 arithmetic elsewhere:
     (a) teacher-forced on the oracle's own trajectories every per-step log-probability agrees within MS_LOGP_TOL;
@@ -231,7 +244,7 @@ def test_ms_kernel_follows_its_rounding_model_oracle(K, name, starts, mode):
     td0 = g.reset()
     with torch.inference_mode():
         h, _ = g.policy.encoder(td0)
-    cache = fold_cache(g.policy, g.env_name, h, torch.bfloat16, device="cuda")
+    cache = fold_cache(g.policy, g.env_name, h, dt, device="cuda")
     cache_cpu = cache.to("cpu")
     b = g.batch * starts
     n = g.num_loc + (g.env_name != "tsp")
@@ -258,7 +271,7 @@ def test_ms_kernel_follows_its_rounding_model_oracle(K, name, starts, mode):
     print(f"{name} S={starts} {mode}: {identical:.1%} of {b} trajectories identical to the rounding-model oracle; per-step "
           f"log-prob gap: teacher-forced max {float(gap_forced.max()):.2e} mean {float(gap_forced.mean()):.2e}, "
           f"common prefix max {gap_prefix:.2e}")
-    _record(f"ms_vs_model/{name}/S{starts}/{mode}", {"identical_frac": identical, "forced_gap_max": float(gap_forced.max()),
+    _record(f"ms_vs_model/{name}/S{starts}/{mode}" + ("" if dt == torch.bfloat16 else "/f16"), {"identical_frac": identical, "forced_gap_max": float(gap_forced.max()),
                                                      "forced_gap_mean": float(gap_forced.mean()), "prefix_gap_max": gap_prefix})
     assert float(gap_forced.max()) <= MS_LOGP_TOL
     assert gap_prefix <= MS_LOGP_TOL

@@ -89,6 +89,17 @@ def test_mma_matches_replay(name, starts):
     _compare(_capture(name, starts))
 
 
+@pytest.mark.parametrize("name,starts", [("tsp50_b64_greedy", 0), ("cvrp100_b64_greedy", 0), ("pomo_tsp20_b16_msgreedy", 5),
+                                         ("c4_pomo_tsp100_b32_s8_sampling", 8), ("pdp50_b64_sampling", 0), ("cvrptw50_b64_sampling", 0)])
+def test_mma_fp16_build_matches_replay_on_fp16_planes(name, starts):
+    """csrc/am_teacher_mma_f16.hip (fp16 planes and intermediates on v_mfma_f32_16x16x16_f16) against the fp32 replay
+    kernel reading the SAME fp16 planes: same bounds as the bf16 build (11 significant bits instead of 8: the measured
+    errors are smaller)."""
+    got = _capture(name, starts, cache_dtype=torch.float16)
+    assert got["cache"].kvl.dtype == torch.float16
+    _compare(got)
+
+
 def test_auto_picks_mma_for_bf16_and_replay_for_f32():
     from rl4co_amd import teacher
 

@@ -436,3 +436,21 @@ def test_c_oracle_fp16_planes_track_fp32_planes(name):
     assert int(same16.sum()) >= int(sameb.sum()) and float(same16.float().mean()) >= 0.5
     gap = (l16[:, :t] - l32[:, :t])[same16].abs()
     assert float(gap.max()) <= 2e-3
+
+
+def test_half_round_is_torchs_float_to_half_conversion():
+    """oracle half_round (the rounding points of the fp16 MS kernel's model oracle) == torch's fp32 -> fp16 -> fp32:
+    normals, ties to even, subnormals, overflow to infinity, signed zeros."""
+    import ctypes as C
+
+    h = c_oracle.lib()
+    h.oracle_half_round_array.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    torch.manual_seed(0)
+    x = torch.cat([torch.randn(200000) * 10.0 ** torch.randint(-9, 6, (200000,)).float(),
+                   torch.tensor([0.0, -0.0, 65504.0, 65519.9, 65520.0, 70000.0, -65520.0, 6.1e-5, 6.0e-5, 5.96e-8, 2.98e-8, 2.99e-8,
+                                 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11, 1.0 + 2.0 ** -11 + 2.0 ** -20, float("inf"), -float("inf")])])
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    assert h.oracle_half_round_array(x.data_ptr(), x.numel(), out.data_ptr()) == 0
+    want = x.half().float()
+    assert torch.equal(out.view(torch.int32), want.view(torch.int32)), (x[out != want][:5], out[out != want][:5], want[out != want][:5])
