@@ -645,9 +645,8 @@ __host__ __device__ inline int wide_scratch_bytes(int N) {
 }
 __host__ __device__ inline int lds_variant_bytes(int N) { return 3 * N * kD * 2 + wide_scratch_bytes(N); }
 
-template <int ENV, bool RESIDENT>
+template <int ENV, bool RESIDENT, class C = CacheBF16>  // C: CacheBF16 or CacheF16 (same 16-byte lanes, different convert)
 __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_wide_kernel(const rl4co_am_decode_args a) {
-  using C = CacheBF16;
   constexpr int EPL = 8, LPR = 16, LPH = 2;
   constexpr int U = 4;  // list entries per wave handled per unrolled block
   extern __shared__ __align__(16) unsigned char smem[];
@@ -944,27 +943,31 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_wide_kernel(const
   }
 }
 
-template <int ENV, bool RESIDENT>
-int launch_wide(const rl4co_am_decode_args& a, hipStream_t stream) {
+template <int ENV, bool RESIDENT, class C>
+int launch_wide_c(const rl4co_am_decode_args& a, hipStream_t stream) {
   const int lds = RESIDENT ? lds_variant_bytes(a.N) : wide_scratch_bytes(a.N);
   if (lds > 64 * 1024) {
-    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_decode_wide_kernel<ENV, RESIDENT>),
+    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_decode_wide_kernel<ENV, RESIDENT, C>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   }
-  hipLaunchKernelGGL((am_decode_wide_kernel<ENV, RESIDENT>), dim3(a.B), dim3(64 * kLdsWaves), lds, stream, a);
+  hipLaunchKernelGGL((am_decode_wide_kernel<ENV, RESIDENT, C>), dim3(a.B), dim3(64 * kLdsWaves), lds, stream, a);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
+}
+template <int ENV, bool RESIDENT>
+int launch_wide(const rl4co_am_decode_args& a, hipStream_t stream) {
+  return a.cache_dtype == RL4CO_DT_F16 ? launch_wide_c<ENV, RESIDENT, CacheF16>(a, stream)
+                                       : launch_wide_c<ENV, RESIDENT, CacheBF16>(a, stream);
 }
 
 // Which kernel serves these arguments (rules from measurements on MI355X, see the kernel headers).
 inline int resolve_variant(const rl4co_am_decode_args& a) {
   // the unfolded parity mode exists in the streaming kernel only
   if (a.unfold) return (a.variant == RL4CO_VARIANT_AUTO || a.variant == RL4CO_VARIANT_STREAM) ? RL4CO_VARIANT_STREAM : -1;
-  // fp16 planes: the streaming kernel and the multistart matrix-core kernel (the 4-wave variants are bf16 kernels)
-  const bool f16 = a.cache_dtype == RL4CO_DT_F16;
-  const bool bf16 = a.cache_dtype == RL4CO_DT_BF16;
+  const bool f16 = a.cache_dtype == RL4CO_DT_F16;  // fp16 planes: every variant the bf16 planes have
+  const bool bf16 = a.cache_dtype == RL4CO_DT_BF16 || f16;  // (16-bit planes)
   // multistart on the matrix cores (am_decode_ms.hip): 16-bit planes, N <= 128, plain outputs; every environment
-  const bool ms_ok = (bf16 || f16) && a.N <= 128 && a.B_inst > 0 && a.all_logps == nullptr && a.entropy == nullptr;
+  const bool ms_ok = bf16 && a.N <= 128 && a.B_inst > 0 && a.all_logps == nullptr && a.entropy == nullptr;
   if (a.variant == RL4CO_VARIANT_MS) return ms_ok ? RL4CO_VARIANT_MS : -1;
   const bool fits = bf16 && lds_variant_bytes(a.N) <= 80 * 1024;
   const bool wide_ok = bf16 && wide_scratch_bytes(a.N) <= 64 * 1024;
@@ -980,7 +983,6 @@ inline int resolve_variant(const rl4co_am_decode_args& a) {
   const int ms_from = (a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_PDP || a.env == RL4CO_ENV_PCTSP) ? 8
                       : (a.env == RL4CO_ENV_CVRP ? 16 : 0);
   if (ms_ok && ms_from > 0 && a.B >= ms_from * a.B_inst) return RL4CO_VARIANT_MS;
-  if (f16) return RL4CO_VARIANT_STREAM;
   if (fits && a.B <= 1024) return RL4CO_VARIANT_LDS;
   // one wave per trajectory needs >= ~16 waves per CU to hide its latency chain: with fewer
   // trajectories than that, four waves per trajectory keep the memory pipes busier
@@ -1072,16 +1074,6 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
     return a.env == RL4CO_ENV_TSP ? launch<CacheBF16, RL4CO_ENV_TSP, true>(a, s) : launch<CacheBF16, RL4CO_ENV_CVRP, true>(a, s);
   }
   if (variant == RL4CO_VARIANT_MS && a.cache_dtype == RL4CO_DT_F16) return rl4co::launch_decode_ms_f16(a, s);
-  if (a.cache_dtype == RL4CO_DT_F16) {
-    switch (a.env) {
-      case RL4CO_ENV_TSP: return launch<CacheF16, RL4CO_ENV_TSP>(a, s);
-      case RL4CO_ENV_CVRP: return launch<CacheF16, RL4CO_ENV_CVRP>(a, s);
-      case RL4CO_ENV_OP: return launch<CacheF16, RL4CO_ENV_OP>(a, s);
-      case RL4CO_ENV_PCTSP: return launch<CacheF16, RL4CO_ENV_PCTSP>(a, s);
-      case RL4CO_ENV_PDP: return launch<CacheF16, RL4CO_ENV_PDP>(a, s);
-      default: return launch<CacheF16, RL4CO_ENV_CVRPTW>(a, s);
-    }
-  }
   if (variant == RL4CO_VARIANT_MS) return rl4co::launch_decode_ms(a, s);
   if (variant == RL4CO_VARIANT_LDS || variant == RL4CO_VARIANT_WIDE) {
     const bool res = variant == RL4CO_VARIANT_LDS;
@@ -1092,6 +1084,16 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
       case RL4CO_ENV_PCTSP: return res ? launch_wide<RL4CO_ENV_PCTSP, true>(a, s) : launch_wide<RL4CO_ENV_PCTSP, false>(a, s);
       case RL4CO_ENV_PDP: return res ? launch_wide<RL4CO_ENV_PDP, true>(a, s) : launch_wide<RL4CO_ENV_PDP, false>(a, s);
       default: return res ? launch_wide<RL4CO_ENV_CVRPTW, true>(a, s) : launch_wide<RL4CO_ENV_CVRPTW, false>(a, s);
+    }
+  }
+  if (a.cache_dtype == RL4CO_DT_F16) {
+    switch (a.env) {
+      case RL4CO_ENV_TSP: return launch<CacheF16, RL4CO_ENV_TSP>(a, s);
+      case RL4CO_ENV_CVRP: return launch<CacheF16, RL4CO_ENV_CVRP>(a, s);
+      case RL4CO_ENV_OP: return launch<CacheF16, RL4CO_ENV_OP>(a, s);
+      case RL4CO_ENV_PCTSP: return launch<CacheF16, RL4CO_ENV_PCTSP>(a, s);
+      case RL4CO_ENV_PDP: return launch<CacheF16, RL4CO_ENV_PDP>(a, s);
+      default: return launch<CacheF16, RL4CO_ENV_CVRPTW>(a, s);
     }
   }
   if (a.env == RL4CO_ENV_CVRPTW)

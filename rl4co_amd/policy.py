@@ -692,7 +692,8 @@ class AttentionModelPolicy(nn.Module):
                     ev1.record()
                     self.encode_events.append((ev0, ev1))
             else:
-                if td["locs"].is_cuda and not grad_path and self._encoder_regime() is not None and not return_init_embeds:
+                if (td["locs"].is_cuda and not grad_path and self._encoder_regime() is not None and not return_init_embeds
+                        and self.fused_encoder and self.fold):  # (switched off by the caller: not a fallback)
                     from . import _lib as _l
 
                     n_nodes = td["action_mask"].shape[-1]

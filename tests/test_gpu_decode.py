@@ -92,8 +92,8 @@ def _assert_bit_exact(hip, ref):
 # ---------------------------------------------------------------------------------------------
 
 CONFIGS = [(torch.float32, "stream"), (torch.bfloat16, "stream"), (torch.bfloat16, "lds"), (torch.bfloat16, "wide"),
-           (torch.float16, "stream")]  # fp16 planes: the reference's default "16-mixed" regime (streaming kernel)
-CONFIG_IDS = ["f32-stream", "bf16-stream", "bf16-lds", "bf16-wide", "f16-stream"]
+           (torch.float16, "stream"), (torch.float16, "lds"), (torch.float16, "wide")]  # fp16 planes: the reference's default "16-mixed" regime
+CONFIG_IDS = ["f32-stream", "bf16-stream", "bf16-lds", "bf16-wide", "f16-stream", "f16-lds", "f16-wide"]
 
 
 def _skip_if_unservable(g, dtype, variant):

@@ -305,8 +305,8 @@ def test_default_policy_under_default_trainer_precision_reaches_the_fast_kernels
     try:
         with warnings.catch_warnings():
             warnings.simplefilter("error", RuntimeWarning)
-            # (64 trajectories: bf16 planes run LDS-resident = variant 2; fp16 planes are served by the streaming kernel = 1)
-            for regime, infer_planes, variant in ((torch.float16, torch.float16, 1), (torch.bfloat16, torch.bfloat16, 2)):
+            # (64 trajectories: 16-bit planes run LDS-resident = variant 2)
+            for regime, infer_planes, variant in ((torch.float16, torch.float16, 2), (torch.bfloat16, torch.bfloat16, 2)):
                 seen.clear()
                 pol.eval()
                 pol.encode_events = []
