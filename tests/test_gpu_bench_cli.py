@@ -1,0 +1,55 @@
+"""GPU (`-m gpu`): bench.py's command-line contract, end to end in subprocesses (short runs).
+
+* N = 1: ONE JSON line on stdout with the driver's keys, the `roofline` / `cpu_baseline`-style objects present.
+* N = 2 WITHOUT a launcher: `python bench.py --gpus 2` re-executes itself under torch.distributed.run, one rank per
+  process, barriers and max-over-ranks timing, the gradient all-reduce over a two-rank group. On a one-GPU box the two
+  ranks share the device (RL4CO_BENCH_SHARED_GPU=1, gloo: RCCL refuses two ranks per device); with two GPUs visible the
+  same command runs one rank per GPU over RCCL.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env_extra=None, timeout=600):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=timeout,
+                          env=env, cwd=ROOT)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"stdout must carry exactly one line, got {len(lines)}: {proc.stdout[:500]}"
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_contract_keys():
+    line = _run(["--steps", "10", "--warmup", "2", "--legs", "c2_greedy", "--no-cpu-baseline", "--no-parity"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 10 and line["warmup"] == 2 and line["higher_is_better"] is True
+    assert line["scaling"] == "weak" and line["vs_baseline"] is None and line["data"] == "synthetic" and "workload" in line["config"]
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and 0.3 < roof["frac"] <= 1.0 and abs(roof["achieved"] / roof["peak"] - roof["frac"]) < 1e-9
+    assert abs(line["value"] - 4096 * 100 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
+    assert line["encoder_roofline"]["bound"] == "mfma" and line["launch"].startswith("pipeline")
+
+
+def test_two_ranks_self_spawned():
+    two_gpus = torch.cuda.device_count() >= 2
+    extra = {} if two_gpus else {"RL4CO_BENCH_SHARED_GPU": "1", "RL4CO_DIST_BACKEND": "gloo"}
+    line = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--legs", "c2_greedy,c4_train", "--no-cpu-baseline", "--no-parity"],
+                env_extra=extra)
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2
+    train = line["legs"]["c4_train"]
+    assert train["collective"]["backend"] == ("nccl" if two_gpus else "gloo") and train["collective"]["ranks"] == 2
+    assert train["roofline"]["bound"] == "mfma" and train["rollout_roofline"]["launch_ms_mean"] > 0
+    # whole-job throughput: both ranks' instance-steps over the max-over-ranks wall time
+    assert abs(line["value"] - 2 * 4096 * 100 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
