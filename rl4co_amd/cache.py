@@ -149,7 +149,7 @@ def build_folded_cache(
     ctx = [torch.matmul(h32, w.t()).view(b, n, d) for w in w_blocks[3:]]
     q_bias = None
     if w_fixed is not None:
-        q_bias = torch.matmul(h.float().mean(1), w_fixed.float().t()).contiguous()
+        q_bias = torch.matmul(h.mean(1, dtype=torch.float32), w_fixed.float().t()).contiguous()
     if env_name == "tsp":
         ctx_first, ctx_cur = ctx
         q_step0 = torch.mv(w_ctx.float(), w_placeholder.float()).contiguous()

@@ -181,7 +181,7 @@ def build_cache_autograd(env_name: str, h: Tensor, decoder, fused_planes: bool =
         out["w_cap"] = w_ctx[:, d]
         if w_ctx.shape[1] > d + 1:  # CVRPTW: the current-time column
             out["w_time"] = w_ctx[:, d + 1]
-    out["q_bias"] = (torch.matmul(h.float().mean(1), decoder.project_fixed_context.weight.float().t())
+    out["q_bias"] = (torch.matmul(h.mean(1, dtype=torch.float32), decoder.project_fixed_context.weight.float().t())
                      if decoder.use_graph_context else None)
     return out
 
