@@ -113,17 +113,25 @@ struct Layout {  // byte offsets into dynamic LDS
 // workgroup per instance advancing two column tiles, all three planes and the context table in LDS, 142 KB, one workgroup
 // per CU), TSP-100 x 4096 sampling: 8 starts 7.1 -> 4.9 ms, 32 starts 13.8 -> 9.8, 100 starts 48.1 -> 34.1 (1.19 G
 // trajectory-steps/s); the tiles of an instance re-read its planes from the XCD's L2.
-__host__ __device__ inline Layout make_layout(int nt, int n) {
+// PAIR (r03): with at most 8 starts per instance only half of the 16 accumulator columns carry a trajectory — and the step
+// is VALU-bound (r03 counters: 853 VALU instructions per wave and step against 21 MFMAs; four waves per SIMD each issuing
+// VALU for 27 % of their residency), so every per-lane instruction is paid for 16 columns whether 8 or 16 are alive. A
+// workgroup then takes TWO instances: columns 0-7 the starts of the first, columns 8-15 those of the second. Their planes
+// sit side by side in LDS (`copies` = 2), every product is issued twice — once per instance, with the OTHER instance's
+// columns of the B operand zeroed, chained through the accumulator (exact zeros: bit-identical results) — and everything
+// per-lane (softmax, tanh, noise, selection, transition) serves 16 live trajectories for the same instructions. 131 KB of
+// LDS: one workgroup per CU, the matrix pipe (9 % busy before) takes the doubled products without noticing.
+__host__ __device__ inline Layout make_layout(int nt, int n, int copies = 1) {
   (void)n;
   Layout L;
   const int plane = nt * 16 * kRS * 2;
   int o = 0;
-  L.kgs = o; o += plane;
-  L.vs = o; o += plane;
+  L.kgs = o; o += copies * plane;
+  L.vs = o; o += copies * plane;
   L.hs = o; o += 16 * kRS * 2;                          // one column tile of glimpses
   L.xs = o; o += kWaves * 16 * (int)sizeof(Xchg);
-  L.dems = o; o += 128 * 4;
-  L.envf = o; o += 128 * 6 * 4;                          // coordinates | OP entry limits / time windows | service times
+  L.dems = o; o += copies * 128 * 4;
+  L.envf = o; o += copies * 128 * 6 * 4;                 // coordinates | OP entry limits / time windows | service times
   L.total = (o + 15) & ~15;
   return L;
 }
@@ -175,6 +183,8 @@ __device__ inline Sel partner(const Sel& p) {
 
 struct Shared {
   const uint16_t* kl_g;  // this instance's logit-key plane in global memory (row stride kl_rs)
+  const uint16_t* kl_g2; // PAIR: the second instance's
+  int plane2;            // PAIR: elements from the first instance's LDS plane to the second's
   int64_t kl_rs;
   const elem_t *kgs, *vs;
   elem_t* hs;   // [CT][16 trajectories][kRS] glimpses of this step
@@ -184,12 +194,17 @@ struct Shared {
 };
 
 // MODE: 0 greedy, 1 sampling, 2 evaluate (RL4CO_DECODE_*). CT column tiles of 16 trajectories advance together.
-template <int ENV, int NT, int MODE, int CT>
-__device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, const Shared& sh, int inst, int s0,
+template <int ENV, int NT, int MODE, int CT, bool PAIR = false>
+__device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, const Shared& sh, int inst0, int s0,
                                              uint32_t& errbits) {
+  static_assert(!PAIR || CT == 1, "two instances share ONE column tile");
   const int tid = threadIdx.x;
   const int w = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
   const int h = w;
+  // PAIR: this lane's column belongs to instance inst0 (columns 0-7) or inst0 + 1 (columns 8-15)
+  const int half = PAIR ? (tl >> 3) : 0;
+  const bool inst_ok = inst0 + half < a.B_inst;
+  const int inst = inst_ok ? inst0 + half : inst0;
   const int N = a.N, S = a.B / a.B_inst;
   const int nao = tl * kRS + 4 * g;                         // natural operand: row lane & 15, columns 4 g ..
   const int tro = (4 * g + (tl >> 2)) * kRS + 4 * (tl & 3);  // transpose read
@@ -199,10 +214,12 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
   constexpr bool kScalar = ENV != RL4CO_ENV_TSP && ENV != RL4CO_ENV_PDP;  // one context scalar: cap - used
   constexpr bool kVisited = ENV != RL4CO_ENV_TSP;                         // a visited (PDP: available) set beside the mask
   constexpr bool kStepI = ENV != RL4CO_ENV_CVRP && ENV != RL4CO_ENV_CVRPTW;
-  const float* locs = sh.envf;             // [N][2]
-  const float* opmax = sh.envf + 256;      // [N] OP: longest tour with which node j may be entered
-  const float* twin = sh.envf + 384;       // [N][2] CVRPTW (start, end)
-  const float* dur = sh.envf + 640;        // [N] CVRPTW service times
+  const float* envf_l = sh.envf + half * 768;  // this lane's instance data (PAIR: second copy)
+  const float* dems_l = sh.dems + half * 128;
+  const float* locs = envf_l;              // [N][2]
+  const float* opmax = envf_l + 256;       // [N] OP: longest tour with which node j may be entered
+  const float* twin = envf_l + 384;        // [N][2] CVRPTW (start, end)
+  const float* dur = envf_l + 640;         // [N] CVRPTW service times
   // context scalar = cap - used: vehicle capacity (CVRP / CVRPTW), prize still required (PCTSP, clamped at 0), longest
   // tour that may still end at the depot minus the tour so far (OP) — env_embeddings/context.py:105-213
   const float cap = (kCvrpLike || ENV == RL4CO_ENV_PCTSP) ? a.vehicle_capacity[inst]
@@ -230,9 +247,9 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
     Traj& x = tj[c];
-    const int sl = s0 + 16 * c + tl;
-    x.ok = sl < S;
-    x.r = (x.ok ? sl : s0) * a.B_inst + inst;
+    const int sl = PAIR ? (tl & 7) : s0 + 16 * c + tl;
+    x.ok = sl < S && inst_ok;
+    x.r = (x.ok ? sl : (PAIR ? 0 : s0)) * a.B_inst + inst;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       uint32_t m = 0, v = 0, d = 0;
@@ -263,12 +280,21 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
   }
   // the logit-key tile of this wave (nodes 16 w .., all 128 dims) is the same at every step — 16 registers for the
   // whole rollout instead of a third LDS plane (rows past the graph: any finite value, their logits are masked)
-  bf16x4 lfr[8];
+  bf16x4 lfr[8], lfr2[PAIR ? 8 : 1];
   if (w < NT) {
     const uint16_t* row = sh.kl_g + (int64_t)min(16 * w + tl, N - 1) * sh.kl_rs + 4 * g;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) lfr[ks] = *reinterpret_cast<const bf16x4*>(row + 16 * ks);
+    if (PAIR) {
+      const uint16_t* row2 = sh.kl_g2 + (int64_t)min(16 * w + tl, N - 1) * sh.kl_rs + 4 * g;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) lfr2[PAIR ? ks : 0] = *reinterpret_cast<const bf16x4*>(row2 + 16 * ks);
+    }
   }
+  const bf16x4 zero_b = {(elem_t)0.0f, (elem_t)0.0f, (elem_t)0.0f, (elem_t)0.0f};
+  // the B operand of a product with the other instance's columns zeroed (PAIR)
+  auto only0 = [&](const bf16x4& v) { return half == 0 ? v : zero_b; };
+  auto only1 = [&](const bf16x4& v) { return half == 1 ? v : zero_b; };
   int forced[CT];  // evaluate: the given action of the coming step, fetched one step ahead
 #pragma unroll
   for (int c = 0; c < CT; ++c)
@@ -346,7 +372,12 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
         const bf16x4 kf = lds_b64(sh.kgs + 16 * jt * kRS + 16 * h + nao);
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-          sc[c][jt] = mfma16(kf, qf[c], zero4());
+          if (PAIR) {
+            const bf16x4 kf2 = lds_b64(sh.kgs + sh.plane2 + 16 * jt * kRS + 16 * h + nao);
+            sc[c][jt] = mfma16(kf2, only1(qf[c]), mfma16(kf, only0(qf[c]), zero4()));
+          } else {
+            sc[c][jt] = mfma16(kf, qf[c], zero4());
+          }
           const uint32_t word = (tj[c].mw.word(jt >> 1) & inner_sel) | (nv.word(jt >> 1) & ~inner_sel);
           const uint32_t bits = word >> (16 * (jt & 1) + 4 * g);
 #pragma unroll
@@ -378,8 +409,15 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
             l[c] += p;
             pf[rr] = (elem_t)p;
           }
-          if (jt & 1) o1[c] = mfma16(vf, pf, o1[c]);
-          else o0[c] = mfma16(vf, pf, o0[c]);
+          if (PAIR) {
+            const bf16x4 vf2 = lds_tr(sh.vs + sh.plane2 + 16 * jt * kRS + 16 * h + tro);
+            if (jt & 1) o1[c] = mfma16(vf2, only1(pf), mfma16(vf, only0(pf), o1[c]));
+            else o0[c] = mfma16(vf2, only1(pf), mfma16(vf, only0(pf), o0[c]));
+          } else if (jt & 1) {
+            o1[c] = mfma16(vf, pf, o1[c]);
+          } else {
+            o0[c] = mfma16(vf, pf, o0[c]);
+          }
         }
       }
 #pragma unroll
@@ -408,8 +446,15 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
           const bf16x4 hf = lds_b64(sh.hs + 16 * c * kRS + 16 * ks + nao);
-          if (ks & 1) u1[c] = mfma16(lf, hf, u1[c]);
-          else u0[c] = mfma16(lf, hf, u0[c]);
+          if (PAIR) {
+            const bf16x4 lf2 = lfr2[PAIR ? ks : 0];
+            if (ks & 1) u1[c] = mfma16(lf2, only1(hf), mfma16(lf, only0(hf), u1[c]));
+            else u0[c] = mfma16(lf2, only1(hf), mfma16(lf, only0(hf), u0[c]));
+          } else if (ks & 1) {
+            u1[c] = mfma16(lf, hf, u1[c]);
+          } else {
+            u0[c] = mfma16(lf, hf, u0[c]);
+          }
         }
       }
       const int node0 = 16 * w + 4 * g;  // this lane's four consecutive nodes
@@ -550,7 +595,7 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
         } else if (ENV == RL4CO_ENV_PCTSP) {
           // pctsp/env.py:62-75, 141-148: customers while unvisited and the depot not yet closed; the depot opens once a
           // total prize of 1 is collected or no customer is left
-          x.used = x.used + sh.dems[act];
+          x.used = x.used + dems_l[act];
           x.vw.set(act, true);
           x.done = (x.step_i > 0) && (act == 0);
           x.step_i += 1;
@@ -596,7 +641,7 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
             x.now = (act != 0 ? 1.0f : 0.0f) * (fmaxf(x.now + sqrtf(fmaf(dy, dy, dx * dx)), twin[2 * act]) + dur[act]);
           }
           const int di = min(max(act - 1, 0), N - 2);
-          x.used = (x.used + sh.dems[di + 1]) * (act != 0 ? 1.0f : 0.0f);
+          x.used = (x.used + dems_l[di + 1]) * (act != 0 ? 1.0f : 0.0f);
           x.cur = act;
           x.vw.set(act, true);
           // (every lane of the trajectory's column rebuilds the whole mask: splitting the nodes over the four row groups
@@ -610,7 +655,7 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
               const bool v = (x.vw.word(k) >> b) & 1u;
               all_visited &= v;
               if (j >= 1) {
-                const bool masked = v || (sh.dems[j] + x.used > thr);
+                const bool masked = v || (dems_l[j] + x.used > thr);
                 mbits |= masked ? 0u : (1u << b);
                 any_feasible |= !masked;
               }
@@ -680,8 +725,52 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
   __syncthreads();
 }
 
-template <int ENV, int NT, int MODE>
-__global__ void __launch_bounds__(kThreads, 4) am_decode_ms_kernel(const rl4co_am_decode_args a) {
+// plane / instance-data staging of ONE instance into copy `copy` of the workgroup's LDS
+template <int ENV, int NT>
+__device__ __forceinline__ void stage_instance(const rl4co_am_decode_args& a, const Layout& L, unsigned char* smem, int inst, int copy,
+                                               bool present) {
+  const int tid = threadIdx.x;
+  const int N = a.N;
+  elem_t* kgs = reinterpret_cast<elem_t*>(smem + L.kgs) + copy * NT * 16 * kRS;  // [16 NT nodes][kRS] glimpse keys
+  elem_t* vs = reinterpret_cast<elem_t*>(smem + L.vs) + copy * NT * 16 * kRS;    // glimpse values
+  float* dems = reinterpret_cast<float*>(smem + L.dems) + copy * 128;            // [128] CVRP demands (index j-1 at j), 0 elsewhere
+  const uint16_t* gk = static_cast<const uint16_t*>(a.glimpse_key) + (int64_t)inst * a.kvl_batch_stride;
+  const uint16_t* gv = static_cast<const uint16_t*>(a.glimpse_val) + (int64_t)inst * a.kvl_batch_stride;
+  for (int c = tid; c < NT * 16 * 16; c += kThreads) {  // 16-byte chunks: row = c / 16, col = (c % 16) * 8
+    const int row = c >> 4, col = (c & 15) * 8;
+    uint4 k4 = make_uint4(0, 0, 0, 0), v4 = k4;
+    if (row < N && present) {
+      k4 = *reinterpret_cast<const uint4*>(gk + (int64_t)row * a.kvl_row_stride + col);
+      v4 = *reinterpret_cast<const uint4*>(gv + (int64_t)row * a.kvl_row_stride + col);
+    }
+    *reinterpret_cast<uint4*>(kgs + row * kRS + col) = k4;
+    *reinterpret_cast<uint4*>(vs + row * kRS + col) = v4;
+  }
+  constexpr bool kDem = ENV == RL4CO_ENV_CVRP || ENV == RL4CO_ENV_CVRPTW;
+  for (int j = tid; j < 128; j += kThreads) {
+    float d = 0.0f;
+    if (kDem && j >= 1 && j < N && present) d = a.demand[(int64_t)inst * (N - 1) + j - 1];
+    if (ENV == RL4CO_ENV_PCTSP && j < N && present) d = a.demand[(int64_t)inst * N + j];  // real prize, depot column 0
+    dems[j] = d;
+  }
+  if (ENV == RL4CO_ENV_OP || ENV == RL4CO_ENV_CVRPTW) {
+    float* envf = reinterpret_cast<float*>(smem + L.envf) + copy * 768;
+    for (int j = tid; j < 128; j += kThreads) {
+      const bool in = j < N && present;
+      envf[2 * j] = in ? a.locs[((int64_t)inst * N + j) * 2] : 0.0f;
+      envf[2 * j + 1] = in ? a.locs[((int64_t)inst * N + j) * 2 + 1] : 0.0f;
+      envf[256 + j] = (ENV == RL4CO_ENV_OP && in) ? a.max_length[(int64_t)inst * N + j] : 0.0f;
+      envf[384 + 2 * j] = (ENV == RL4CO_ENV_CVRPTW && in) ? a.time_windows[((int64_t)inst * N + j) * 2] : 0.0f;
+      envf[384 + 2 * j + 1] = (ENV == RL4CO_ENV_CVRPTW && in) ? a.time_windows[((int64_t)inst * N + j) * 2 + 1] : 0.0f;
+      envf[640 + j] = (ENV == RL4CO_ENV_CVRPTW && in) ? a.durations[(int64_t)inst * N + j] : 0.0f;
+    }
+  }
+}
+
+// PAIR: at most 8 starts per instance -> one workgroup = two instances in one column tile (see make_layout); two waves per
+// SIMD (256 registers: the second logit-key tile), one workgroup per CU
+template <int ENV, int NT, int MODE, bool PAIR>
+__global__ void __launch_bounds__(kThreads, PAIR ? 2 : 4) am_decode_ms_kernel(const rl4co_am_decode_args a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x;
   const int N = a.N;
@@ -690,7 +779,10 @@ __global__ void __launch_bounds__(kThreads, 4) am_decode_ms_kernel(const rl4co_a
   // only): the tiles of one instance take consecutive slots of one XCD and share its L2 copy of the planes.
   const int ntiles = (S + 15) >> 4, b = blockIdx.x;
   int inst, tile0;
-  if ((a.B_inst & 7) == 0) {
+  if (PAIR) {
+    inst = 2 * b;
+    tile0 = 0;
+  } else if ((a.B_inst & 7) == 0) {
     const int xcd = b & 7, k = b >> 3;
     inst = (k / ntiles) * 8 + xcd;
     tile0 = k % ntiles;
@@ -698,68 +790,46 @@ __global__ void __launch_bounds__(kThreads, 4) am_decode_ms_kernel(const rl4co_a
     inst = b / ntiles;
     tile0 = b % ntiles;
   }
-  const Layout L = make_layout(NT, N);
+  const Layout L = make_layout(NT, N, PAIR ? 2 : 1);
   if ((tid >> 6) >= 4) __builtin_amdgcn_s_setprio(1);  // even out the younger half of the workgroup (issue arbitration)
-  elem_t* kgs = reinterpret_cast<elem_t*>(smem + L.kgs);  // [16 NT nodes][kRS] glimpse keys
-  elem_t* vs = reinterpret_cast<elem_t*>(smem + L.vs);    // glimpse values
-  float* dems = reinterpret_cast<float*>(smem + L.dems);  // [128] CVRP demands (index j-1 at j), 0 elsewhere
-
-  // ---- glimpse planes HBM / L2 -> LDS, once per workgroup ---------------------------------------------------
-  {
-    const uint16_t* gk = static_cast<const uint16_t*>(a.glimpse_key) + (int64_t)inst * a.kvl_batch_stride;
-    const uint16_t* gv = static_cast<const uint16_t*>(a.glimpse_val) + (int64_t)inst * a.kvl_batch_stride;
-    for (int c = tid; c < NT * 16 * 16; c += kThreads) {  // 16-byte chunks: row = c / 16, col = (c % 16) * 8
-      const int row = c >> 4, col = (c & 15) * 8;
-      uint4 k4 = make_uint4(0, 0, 0, 0), v4 = k4;
-      if (row < N) {
-        k4 = *reinterpret_cast<const uint4*>(gk + (int64_t)row * a.kvl_row_stride + col);
-        v4 = *reinterpret_cast<const uint4*>(gv + (int64_t)row * a.kvl_row_stride + col);
-      }
-      *reinterpret_cast<uint4*>(kgs + row * kRS + col) = k4;
-      *reinterpret_cast<uint4*>(vs + row * kRS + col) = v4;
-    }
-    constexpr bool kDem = ENV == RL4CO_ENV_CVRP || ENV == RL4CO_ENV_CVRPTW;
-    for (int j = tid; j < 128; j += kThreads) {
-      float d = 0.0f;
-      if (kDem && j >= 1 && j < N) d = a.demand[(int64_t)inst * (N - 1) + j - 1];
-      if (ENV == RL4CO_ENV_PCTSP && j < N) d = a.demand[(int64_t)inst * N + j];  // real prize, depot column 0
-      dems[j] = d;
-    }
-    if (ENV == RL4CO_ENV_OP || ENV == RL4CO_ENV_CVRPTW) {
-      float* envf = reinterpret_cast<float*>(smem + L.envf);
-      for (int j = tid; j < 128; j += kThreads) {
-        const bool in = j < N;
-        envf[2 * j] = in ? a.locs[((int64_t)inst * N + j) * 2] : 0.0f;
-        envf[2 * j + 1] = in ? a.locs[((int64_t)inst * N + j) * 2 + 1] : 0.0f;
-        envf[256 + j] = (ENV == RL4CO_ENV_OP && in) ? a.max_length[(int64_t)inst * N + j] : 0.0f;
-        envf[384 + 2 * j] = (ENV == RL4CO_ENV_CVRPTW && in) ? a.time_windows[((int64_t)inst * N + j) * 2] : 0.0f;
-        envf[384 + 2 * j + 1] = (ENV == RL4CO_ENV_CVRPTW && in) ? a.time_windows[((int64_t)inst * N + j) * 2 + 1] : 0.0f;
-        envf[640 + j] = (ENV == RL4CO_ENV_CVRPTW && in) ? a.durations[(int64_t)inst * N + j] : 0.0f;
-      }
-    }
-  }
+  // ---- glimpse planes and instance data HBM / L2 -> LDS, once per workgroup ----------------------------------
+  const bool second = PAIR && inst + 1 < a.B_inst;
+  stage_instance<ENV, NT>(a, L, smem, inst, 0, true);
+  if (PAIR) stage_instance<ENV, NT>(a, L, smem, second ? inst + 1 : inst, 1, second);
   Shared sh;
-  sh.kgs = kgs;
-  sh.vs = vs;
+  sh.kgs = reinterpret_cast<elem_t*>(smem + L.kgs);
+  sh.vs = reinterpret_cast<elem_t*>(smem + L.vs);
+  sh.plane2 = NT * 16 * kRS;
   sh.kl_g = static_cast<const uint16_t*>(a.logit_key) + (int64_t)inst * a.kvl_batch_stride;
+  sh.kl_g2 = static_cast<const uint16_t*>(a.logit_key) + (int64_t)(second ? inst + 1 : inst) * a.kvl_batch_stride;
   sh.kl_rs = a.kvl_row_stride;
   sh.hs = reinterpret_cast<elem_t*>(smem + L.hs);
   sh.xs = reinterpret_cast<Xchg*>(smem + L.xs);
-  sh.dems = dems;
+  sh.dems = reinterpret_cast<const float*>(smem + L.dems);
   sh.envf = reinterpret_cast<const float*>(smem + L.envf);
   uint32_t errbits = 0;
-  if (tid == 0 && a.steps_summary) atomicAdd(reinterpret_cast<unsigned long long*>(a.steps_summary + 2), (unsigned long long)N);  // the planes are read ONCE per workgroup
-  rollout_tiles<ENV, NT, MODE, 1>(a, sh, inst, 16 * tile0, errbits);  // this workgroup's column tile
+  if (tid == 0 && a.steps_summary)  // the planes are read ONCE per workgroup
+    atomicAdd(reinterpret_cast<unsigned long long*>(a.steps_summary + 2), (unsigned long long)(N * (second ? 2 : 1)));
+  rollout_tiles<ENV, NT, MODE, 1, PAIR>(a, sh, inst, 16 * tile0, errbits);  // this workgroup's column tile
   if (errbits) atomicOr(a.err, (int)errbits);
 }
 
 template <int ENV, int NT, int MODE>
 int launch_mode(const rl4co_am_decode_args& a, hipStream_t stream) {
+  const int starts = a.B / a.B_inst;
+  if (starts <= 8 && a.B_inst >= 2) {  // two instances per column tile (make_layout)
+    const Layout L = make_layout(NT, a.N, 2);
+    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_decode_ms_kernel<ENV, NT, MODE, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+    hipLaunchKernelGGL((am_decode_ms_kernel<ENV, NT, MODE, true>), dim3((a.B_inst + 1) / 2), dim3(kThreads), L.total, stream, a);
+    RL4CO_HIP_TRY(hipGetLastError());
+    return RL4CO_OK;
+  }
   const Layout L = make_layout(NT, a.N);
-  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_decode_ms_kernel<ENV, NT, MODE>),
+  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_decode_ms_kernel<ENV, NT, MODE, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
-  const int ntiles = (a.B / a.B_inst + 15) / 16;  // one workgroup per (instance, column tile of 16 starts)
-  hipLaunchKernelGGL((am_decode_ms_kernel<ENV, NT, MODE>), dim3(a.B_inst * ntiles), dim3(kThreads), L.total, stream, a);
+  const int ntiles = (starts + 15) / 16;  // one workgroup per (instance, column tile of 16 starts)
+  hipLaunchKernelGGL((am_decode_ms_kernel<ENV, NT, MODE, false>), dim3(a.B_inst * ntiles), dim3(kThreads), L.total, stream, a);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }
@@ -784,7 +854,7 @@ int dispatch_tiles(const rl4co_am_decode_args& a, hipStream_t stream) {
 
 // dynamic LDS of the multistart variant at the largest graph (N = 128)
 #if !RL4CO_ELEM_F16
-extern "C" int rl4co_am_decode_ms_lds_bytes(void) { return make_layout(8, 128).total; }
+extern "C" int rl4co_am_decode_ms_lds_bytes(void) { return make_layout(8, 128, 2).total; }
 #endif
 
 namespace rl4co {

@@ -276,3 +276,51 @@ def _check_ms_vs_model(K, name, starts, mode, dt):
     assert float(gap_forced.max()) <= MS_LOGP_TOL
     assert gap_prefix <= MS_LOGP_TOL
     assert identical >= MS_IDENTICAL_FLOOR
+
+
+@pytest.mark.parametrize("env_name,num_loc,starts", [("tsp", 100, 8), ("cvrp", 50, 5), ("tsp", 20, 8), ("pdp", 20, 8)])
+def test_ms_pair_mode_two_instances_per_column_tile(K, env_name, num_loc, starts):
+    """At most 8 starts per instance: the MS kernel packs TWO instances into one 16-column tile (am_decode_ms.hip,
+    make_layout). Instances are independent, so the rollout of the first 7 instances must not depend on whether an 8th
+    shares the last workgroup (odd instance count: the second half of that tile is dead), nor on the order of the
+    instances (pairs are formed from neighbours): bit-identical actions and log-probs either way."""
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.policy import AttentionModelPolicy
+    from rl4co_amd.tensordict import TensorDict
+
+    torch.manual_seed(0)
+    pol = AttentionModelPolicy(env_name, num_encoder_layers=3, normalization="instance", use_graph_context=False,
+                               cache_dtype=torch.bfloat16, encoder_autocast=torch.bfloat16).cuda().eval()
+    env = get_env(env_name, generator_params=dict(num_loc=num_loc, device="cuda"), device="cuda")
+    torch.manual_seed(1)
+    data = env.generator(batch_size=[8])
+    n_nodes = num_loc + (env_name != "tsp")
+
+    def rollout(idx):
+        td = TensorDict({k: v[idx].contiguous() for k, v in data.items()}, batch_size=[len(idx)])
+        td0 = env.reset(td)
+        with torch.inference_mode():
+            cache, _ = pol._packed_encoder().encode(td0, torch.bfloat16)
+        st = pol._initial_state(td0, starts)
+        b = len(idx) * starts
+        tmax = pol._max_horizon(env_name, n_nodes)
+        actions = torch.zeros(b, tmax, dtype=torch.int64, device="cuda")
+        logps = torch.zeros(b, tmax, device="cuda")
+        err = K.new_error_word("cuda")
+        first = env.select_start_nodes(td0, num_starts=starts)
+        actions[:, 0] = first
+        pol._env_step_state(st, first, err)
+        K.am_decode(cache, st, mode="greedy", max_steps=tmax - 1, t0=1, actions=actions, logps=logps, err=err, variant="ms")
+        torch.cuda.synchronize()
+        assert int(err.item()) == 0
+        return actions.view(starts, len(idx), tmax), logps.view(starts, len(idx), tmax)
+
+    a8, l8 = rollout(list(range(8)))
+    a7, l7 = rollout(list(range(7)))                 # odd count: the last workgroup holds one instance
+    assert torch.equal(a7, a8[:, :7]) and torch.equal(l7.view(torch.int32), l8[:, :7].view(torch.int32))
+    perm = [3, 0, 6, 1, 7, 2, 5, 4]
+    ap, lp = rollout(perm)                           # other neighbours
+    inv = torch.tensor(perm).argsort().tolist()
+    assert torch.equal(ap[:, inv], a8) and torch.equal(lp[:, inv].view(torch.int32), l8.view(torch.int32))
+    a1, l1 = rollout([5])                            # a single instance: the one-instance kernel
+    assert torch.equal(a1[:, 0], a8[:, 5]) and torch.equal(l1[:, 0].view(torch.int32), l8[:, 5].view(torch.int32))
