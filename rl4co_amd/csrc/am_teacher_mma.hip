@@ -80,8 +80,24 @@ __device__ inline float rg_max(float v) { return rl4co::bfly_max<16, 64>(v); }
 // across the sixteen steps of a row group (lane bits 0..3)
 __device__ inline float step_sum(float v) { return rl4co::bfly_sum<1, 16>(v); }
 
+// d ctx_cur[cur] += dq, four dims of one row. The table rows of an instance are touched by ITS workgroup only, a wave
+// (head) owns its 16 columns and a lane its step: the only possible collision is one node being the current node of
+// two steps. In the TSP every node is left exactly once per trajectory, so the sum is a plain read-modify-write whose
+// read went out a stage earlier (`old` already folded into `v`); the depot environments revisit node 0 and keep the
+// fp32 L2 atomics. 2048 scattered lane-atomics per step block held every wave's first stage for ~2 K cycles
+// (tools/teacher_clock_probe.py)
+template <int ENV>
+__device__ inline void scatter_row(float* row, const float (&v)[4]) {
+  if (ENV == RL4CO_ENV_TSP) {
+    *reinterpret_cast<float4*>(row) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(row + e, v[e]);
+  }
+}
+
 struct Layout {  // byte offsets into dynamic LDS
-  int kgs, vs, kls, ob, dub, qb, pb, sact, srem, stime, sg, smask, spos, sval, xz, xa, sinfo, total;
+  int kgs, vs, kls, ob, dub, qb, pb, sact, srem, stime, sg, smask, spos, sval, xz, xa, sinfo, nact, ng, total;
 };
 __host__ __device__ inline Layout make_layout(int nt) {
   Layout L;
@@ -104,6 +120,8 @@ __host__ __device__ inline Layout make_layout(int nt) {
   L.xa = o; o += 16 * 4;
   L.sinfo = o; o += 16;
   L.sval = o; o += kMaxT;
+  L.nact = o; o += kMaxT;      // the NEXT trajectory's actions (bytes; 255 = out of range) and
+  L.ng = o; o += kMaxT * 4;    // upstream gradients, fetched under this trajectory's set-up
   L.total = (o + 15) & ~15;
   return L;
 }
@@ -116,6 +134,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
   const int h = w;  // attention stages: wave = head; logits stage: wave = node tile
   const int inst = blockIdx.x;
   const int N = a.N, T = a.T, S = a.B / a.B_inst;
+  const int tpad = min(kMaxT, (T + 15) & ~15);  // columns the step blocks read
   // the second-dispatched half of an 8-wave workgroup loses the issue arbitration on every segment
   // (older wave first); a static priority for it evens the halves out between the barriers
   if (w >= 4) __builtin_amdgcn_s_setprio(1);
@@ -138,6 +157,8 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
   uint32_t* smask = reinterpret_cast<uint32_t*>(smem + L.smask);
   int* spos = reinterpret_cast<int*>(smem + L.spos);
   uint8_t* sval = smem + L.sval;
+  uint8_t* snact = smem + L.nact;
+  float* sng = reinterpret_cast<float*>(smem + L.ng);
   float* xz = reinterpret_cast<float*>(smem + L.xz);
   float* xa = reinterpret_cast<float*>(smem + L.xa);
   int* sinfo = reinterpret_cast<int*>(smem + L.sinfo);
@@ -212,27 +233,52 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
   float dqb[4] = {0.f, 0.f, 0.f, 0.f}, dqx[4] = {0.f, 0.f, 0.f, 0.f}, dqt[4] = {0.f, 0.f, 0.f, 0.f};
   uint32_t errbits = 0;
 
+  // actions / upstream gradients of a trajectory are fetched one trajectory AHEAD (thread t < kMaxT owns column t), so
+  // the set-up of a trajectory never opens with an HBM round trip
+  static_assert(kThreads >= kMaxT, "one thread per table column");
+  int an = 0;
+  float gn = 0.0f;
+  if (tid < T) {
+    an = (int)a.actions[(int64_t)inst * T + tid];
+    gn = a.grad_logp[(int64_t)inst * T + tid];
+  }
+  if (tid < kMaxT) {
+    snact[tid] = (an < 0 || an >= N) ? 255 : an;
+    sng[tid] = gn;
+  }
+
   for (int s = 0; s < S; ++s) {
     const int r = s * a.B_inst + inst;
-    const int64_t* act = a.actions + (int64_t)r * T;
-    const float* gl = a.grad_logp + (int64_t)r * T;
-    __syncthreads();  // the previous trajectory's tables are no longer read
+    __syncthreads();  // the previous trajectory's tables are no longer read; the fetched columns are complete
 
     // ---- step tables of this trajectory (the environment replayed in closed form) -------------------
     // sact[t]: action; spos[j]: first column that visits node j (tsp/env.py:60-86, cvrp/env.py:66-96)
-    for (int t = tid; t < kMaxT; t += kThreads) {
-      int at = 0;
-      if (t < T) {
-        at = (int)act[t];
-        if (at < 0 || at >= N) {
-          errbits |= RL4CO_EBIT_INFEASIBLE;
-          at = 0;
-        }
+    if (tid < kMaxT) {
+      int at = snact[tid];
+      if (at == 255) {
+        errbits |= RL4CO_EBIT_INFEASIBLE;
+        at = 0;
       }
-      sact[t] = at;
+      sact[tid] = at;
+    }
+    an = 0;
+    gn = 0.0f;
+    if (s + 1 < S && tid < T) {  // in flight under the set-up below, staged after its last barrier
+      an = (int)a.actions[(int64_t)(r + a.B_inst) * T + tid];
+      gn = a.grad_logp[(int64_t)(r + a.B_inst) * T + tid];
     }
     for (int j = tid; j < 128; j += kThreads) spos[j] = 0x7fffffff;
     __syncthreads();
+    // the two context fetches that open the first step block leave now, under the rest of the set-up
+    const int first = sact[0];
+    float f4[4] = {0.f, 0.f, 0.f, 0.f}, dqf[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ENV == RL4CO_ENV_TSP) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) f4[e] = ctxf[(int64_t)first * kD + e];
+    }
+    // context row of this lane's step, fetched one step block ahead (an L2 round trip otherwise
+    // opens every block's dependency chain)
+    float4 c4n = *reinterpret_cast<const float4*>(ctxc + (int64_t)(tl == 0 ? 0 : sact[tl - 1]) * kD);
     for (int t = tid; t < T; t += kThreads) atomicMin(&spos[sact[t]], t);
     __syncthreads();
     if (tid == 0) {
@@ -254,7 +300,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
     if (kClock) {
       // the clock BEFORE column t, replayed in visiting order: advance by the distance, wait for the window, serve;
       // back at the depot it restarts (cvrptw/env.py:97-113, same fp32 sequence as the decode kernel)
-      for (int t = tid; t < kMaxT; t += kThreads) {
+      for (int t = tid; t < tpad; t += kThreads) {
         float now = 0.0f;
         int prev = 0;
         for (int v = 0; v < min(t, T); ++v) {
@@ -269,7 +315,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
     if (kCvrpLike) {
       // used capacity BEFORE column t: the loads since the last depot visit, summed in visiting
       // order from zero — the same fp32 sequence as used = (used + demand) * (action != 0)
-      for (int t = tid; t < kMaxT; t += kThreads) {
+      for (int t = tid; t < tpad; t += kThreads) {
         int u = min(t, T) - 1;
         while (u >= 0 && sact[u] != 0) --u;
         float used = 0.0f;
@@ -279,7 +325,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
     }
     if (ENV == RL4CO_ENV_OP) {
       // tour length BEFORE column t, accumulated in visiting order like tour += |loc_a - loc_cur|
-      for (int t = tid; t < kMaxT; t += kThreads) {
+      for (int t = tid; t < tpad; t += kThreads) {
         float used = 0.0f;
         int prev = 0;
         for (int v = 0; v < min(t, T); ++v) {
@@ -292,11 +338,11 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
       }
     }
     if (ENV == RL4CO_ENV_PDP) {  // no context scalar (context.py:232-243)
-      for (int t = tid; t < kMaxT; t += kThreads) srem[t] = 0.0f;
+      for (int t = tid; t < tpad; t += kThreads) srem[t] = 0.0f;
     }
     if (ENV == RL4CO_ENV_PCTSP) {
       // prize collected BEFORE column t, accumulated in visiting order like prize += real_prize[a]
-      for (int t = tid; t < kMaxT; t += kThreads) {
+      for (int t = tid; t < tpad; t += kThreads) {
         float used = 0.0f;
         for (int v = 0; v < min(t, T); ++v) used = used + dem[sact[v]];
         srem[t] = used;
@@ -304,8 +350,19 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
     }
     __syncthreads();
     const int t_end = sinfo[0];
+    if (ENV == RL4CO_ENV_TSP) {
+      // feasibility words of a column in two ballots: wave w takes columns w, w + 8, ..; lane = node (and node + 64);
+      // node j is feasible at column t until it has been visited, spos[j] >= t
+      const int p0 = (lane < N) ? spos[lane] : -1, p1 = (lane + 64 < N) ? spos[lane + 64] : -1;
+      for (int t = w; t < tpad; t += kWaves) {
+        const unsigned long long b0 = __ballot(p0 >= t), b1 = __ballot(p1 >= t);
+        if (lane == 0)
+          *reinterpret_cast<uint4*>(smask + 4 * t) = (t < t_end) ? make_uint4((uint32_t)b0, (uint32_t)(b0 >> 32), (uint32_t)b1, (uint32_t)(b1 >> 32))
+                                                                 : make_uint4(1u, 0u, 0u, 0u);
+      }
+    }
     // feasibility words: thread (t, k) builds word k of column t
-    for (int idx = tid; idx < kMaxT * 4; idx += kThreads) {
+    for (int idx = tid; ENV != RL4CO_ENV_TSP && idx < tpad * 4; idx += kThreads) {
       const int t = idx >> 2, k = idx & 3;
       const bool live = t < t_end;
       uint32_t word = 0;
@@ -375,14 +432,18 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
       }
       smask[idx] = live ? word : (k == 0 ? 1u : 0u);  // dead columns: a finite dummy (node 0 only), gradient 0
     }
-    for (int t = tid; t < kMaxT; t += kThreads) {
+    for (int t = tid; t < tpad; t += kThreads) {
       const bool valid = t >= a.t0 && t < t_end;
       sval[t] = valid ? 1 : 0;
-      sg[t] = valid ? gl[t] : 0.0f;
+      sg[t] = valid ? sng[t] : 0.0f;
     }
     __syncthreads();
+    if (tid < kMaxT) {
+      snact[tid] = (an < 0 || an >= N) ? 255 : an;
+      sng[tid] = gn;
+    }
     if (ENV != RL4CO_ENV_TSP) {  // srem: used -> remaining capacity / length (context.py:147-149, 211-213), own entries only
-      for (int t = tid; t < kMaxT; t += kThreads) {
+      for (int t = tid; t < tpad; t += kThreads) {
         float rem = cap - srem[t];
         if (ENV == RL4CO_ENV_PCTSP && !(rem > 0.0f)) rem = 0.0f;
         srem[t] = rem;
@@ -390,17 +451,13 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
       __syncthreads();
     }
 
-    const int first = sact[0];
-    float f4[4] = {0.f, 0.f, 0.f, 0.f}, dqf[4] = {0.f, 0.f, 0.f, 0.f};
-    if (ENV == RL4CO_ENV_TSP) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) f4[e] = ctxf[(int64_t)first * kD + e];
-    }
     const int ntb = (t_end + 15) >> 4;
-    // context row of this lane's step, fetched one step block ahead (an L2 round trip otherwise
-    // opens every block's dependency chain)
-    float4 c4n = *reinterpret_cast<const float4*>(ctxc + (int64_t)(tl == 0 ? 0 : sact[tl - 1]) * kD);
-
+    // the rows fetched during the set-up are "used" here, before the loop: otherwise the waitcnt state merged at the loop
+    // header still counts them as in flight and every block's first stage waits for the fetch it has JUST issued
+    asm volatile("" : "+v"(c4n.x), "+v"(c4n.y), "+v"(c4n.z), "+v"(c4n.w));
+    if (ENV == RL4CO_ENV_TSP) asm volatile("" : "+v"(f4[0]), "+v"(f4[1]), "+v"(f4[2]), "+v"(f4[3]));
+    float pend[4] = {0.f, 0.f, 0.f, 0.f};  // this lane's deferred context-row scatter
+    int pend_cur = -1;
     for (int tb = 0; tb < ntb; ++tb) {
       const int t = 16 * tb + tl;  // this lane's column (same in the four row groups)
       const int cur = (t == 0) ? 0 : sact[t - 1];
@@ -418,6 +475,13 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
         const float4 c4 = c4n;
         const float c[4] = {c4.x, c4.y, c4.z, c4.w};
         c4n = *reinterpret_cast<const float4*>(ctxc + (int64_t)sact[min(t + 15, kMaxT - 1)] * kD);  // cur of step t + 16
+        // the PREVIOUS block's context-row scatter leaves here, behind the fetch: vmcnt is one in-order counter on
+        // gfx9, so the wait for the row above also waits for every atomic issued before it — issued at the end of
+        // their own block they stalled each block's first stage for their whole L2 round trip (tools/teacher_clock_probe.py)
+        if (pend_cur >= 0) {
+          scatter_row<ENV>(dcc + (int64_t)pend_cur * kD + dcol, pend);
+          pend_cur = -1;
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float q;
@@ -582,6 +646,10 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
       // dA^T is produced twice (7 cheap MFMAs) instead of being held in 28 registers: pass 1 reduces
       // sum_j a_j dA_j, pass 2 turns each tile into dS, stages it and feeds d query at once
       f32x4 dq = zero4();
+      const bool scatter = valid && (ENV != RL4CO_ENV_TSP || t != 0);
+      float4 row_old = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ENV == RL4CO_ENV_TSP && scatter)  // read of the read-modify-write below: a whole stage ahead of its use
+        row_old = *reinterpret_cast<const float4*>(dcc + (int64_t)cur * kD + dcol);
       {
         float ada = 0.0f;
 #pragma unroll
@@ -623,28 +691,30 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
 
       // ---- 6. d query -> context rows, graph context, placeholder / capacity column ---------------------
       if (valid) {
+        const float old4[4] = {row_old.x, row_old.y, row_old.z, row_old.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float dqr = 0.25f * dq[e];
           dqb[e] += dqr;
           if (ENV == RL4CO_ENV_TSP) {
-            if (t == 0) {
-              dqx[e] += dqr;
-            } else {
-              dqf[e] += dqr;
-              unsafeAtomicAdd(dcc + (int64_t)cur * kD + dcol + e, dqr);
-            }
+            if (t == 0) dqx[e] += dqr;
+            else dqf[e] += dqr;
           } else {
             dqx[e] = fmaf(dqr, rem, dqx[e]);
             if (kClock) dqt[e] = fmaf(dqr, now, dqt[e]);
-            unsafeAtomicAdd(dcc + (int64_t)cur * kD + dcol + e, dqr);
           }
+          pend[e] = old4[e] + dqr;  // d ctx_cur[cur] += dqr: leaves at the top of the next block (or after the last)
         }
+        if (scatter) pend_cur = cur;
       }
       rl4co::lds_barrier();  // B4: the glimpse / d-logit blocks are rewritten by the next step block (LDS only:
                              // the context-row atomics stay in flight)
     }
 
+    if (pend_cur >= 0) {  // the last block's scatter
+      scatter_row<ENV>(dcc + (int64_t)pend_cur * kD + dcol, pend);
+      pend_cur = -1;
+    }
     // d ctx_first: one row per trajectory (every step after the first reads h[first])
     if (ENV == RL4CO_ENV_TSP) {
 #pragma unroll
