@@ -68,6 +68,11 @@ __device__ inline bf16x4 to_bf16(const f32x4& v) {
   for (int i = 0; i < 4; ++i) o[i] = (elem_t)v[i];
   return o;
 }
+// bit `pos` of `bits` set ? x : -inf, in two VALU operations (v_bfe_i32 spreads the bit, v_bfi_b32 selects)
+__device__ inline float keep_or_neg_inf(uint32_t bits, int pos, float x) {
+  const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)bits, pos, 1);
+  return __builtin_bit_cast(float, (m & __builtin_bit_cast(uint32_t, x)) | (~m & 0xff800000u));
+}
 // LDS hand-off inside ONE wave
 __device__ inline void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -506,7 +511,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
             const uint32_t bits = (a.mask_inner ? mw[jt >> 1] : nv[jt >> 1]) >> (16 * (jt & 1) + 4 * g);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-              sc[jt][rr] = ((bits >> rr) & 1u) ? sc[jt][rr] : kNegInf;
+              sc[jt][rr] = keep_or_neg_inf(bits, rr, sc[jt][rr]);
               m = fmaxf(m, sc[jt][rr]);
             }
           }
@@ -530,8 +535,8 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
       }
 
       // ---- 2. glimpse O_h^T = V_h^T P^T --------------------------------------------------------------
+      f32x4 o = zero4();  // kept: the softmax backward's sum_j a_j dA_j is O_h . dO_h
       {
-        f32x4 o = zero4();
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt)
           o = mfma16(lds_tr(vs + 16 * jt * kRS + 16 * h + tro), pf[jt], o);
@@ -542,12 +547,16 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
       rl4co::lds_barrier();  // B1: all heads' glimpses
 
       // ---- 3. logits of node tile w, clip, log-softmax pieces (attention.py:291-293, decoding.py:169-188)
-      float z[4], dzdu[4];
+      // clipped logits live in [-C, C], C = tanh_clipping / temperature: up to C = 60 their exponentials and the sum
+      // over 128 nodes are plain fp32 numbers, so the log-sum-exp needs no running maximum — one exponential per logit,
+      // kept across B2 and scaled by 1 / sum, instead of three and eight more to merge the node tiles' partial sums
+      const bool bounded = a.tanh_clipping > 0.0f && clip_over_temp <= 60.0f;
+      float z[4], dzdu[4];  // z: the logit, or (bounded) its exponential, 0 for a masked node
       {
         float zmax = kNegInf;
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          z[rr] = kNegInf;
+          z[rr] = bounded ? 0.0f : kNegInf;
           dzdu[rr] = 0.0f;
         }
         if (w < NT) {
@@ -574,35 +583,53 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
               dd = inv_temp;
             }
             const bool f = (bits >> rr) & 1u;
-            z[rr] = f ? zz : kNegInf;
             dzdu[rr] = dd;
-            zmax = fmaxf(zmax, z[rr]);
-            if (16 * w + 4 * g + rr == at) xa[tl] = z[rr];
+            if (16 * w + 4 * g + rr == at) xa[tl] = f ? zz : kNegInf;
+            if (bounded) {
+              z[rr] = f ? __expf(zz) : 0.0f;
+            } else {
+              z[rr] = f ? zz : kNegInf;
+              zmax = fmaxf(zmax, z[rr]);
+            }
           }
         }
-        zmax = rg_max(zmax);
-        const float zs = (zmax > kNegInf) ? zmax : 0.0f;
-        float se = 0.0f;
+        if (bounded) {
+          const float se = rg_sum((z[0] + z[1]) + (z[2] + z[3]));
+          if (g == 0) xz[(w * 16 + tl) * 2 + 1] = se;
+        } else {
+          zmax = rg_max(zmax);
+          const float zs = (zmax > kNegInf) ? zmax : 0.0f;
+          float se = 0.0f;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) se += __expf(z[rr] - zs);
-        se = rg_sum(se);
-        if (g == 0) {
-          xz[(w * 16 + tl) * 2] = zmax;
-          xz[(w * 16 + tl) * 2 + 1] = (zmax > kNegInf) ? se : 0.0f;
+          for (int rr = 0; rr < 4; ++rr) se += __expf(z[rr] - zs);
+          se = rg_sum(se);
+          if (g == 0) {
+            xz[(w * 16 + tl) * 2] = zmax;
+            xz[(w * 16 + tl) * 2 + 1] = (zmax > kNegInf) ? se : 0.0f;
+          }
         }
       }
       rl4co::lds_barrier();  // B2: log-sum-exp pieces of all node tiles
       {
-        float zm = kNegInf;
+        float lse, inv_tot = 0.0f;
+        if (bounded) {
+          float tot = 0.0f;
 #pragma unroll
-        for (int ww = 0; ww < kWaves; ++ww) zm = fmaxf(zm, xz[(ww * 16 + tl) * 2]);
-        float tot = 0.0f;
+          for (int ww = 0; ww < kWaves; ++ww) tot += xz[(ww * 16 + tl) * 2 + 1];
+          lse = __logf(tot);
+          inv_tot = __builtin_amdgcn_rcpf(tot);
+        } else {
+          float zm = kNegInf;
 #pragma unroll
-        for (int ww = 0; ww < kWaves; ++ww) {
-          const float zw = xz[(ww * 16 + tl) * 2];
-          tot += (zw > kNegInf) ? xz[(ww * 16 + tl) * 2 + 1] * __expf(zw - zm) : 0.0f;
+          for (int ww = 0; ww < kWaves; ++ww) zm = fmaxf(zm, xz[(ww * 16 + tl) * 2]);
+          float tot = 0.0f;
+#pragma unroll
+          for (int ww = 0; ww < kWaves; ++ww) {
+            const float zw = xz[(ww * 16 + tl) * 2];
+            tot += (zw > kNegInf) ? xz[(ww * 16 + tl) * 2 + 1] * __expf(zw - zm) : 0.0f;
+          }
+          lse = zm + __logf(tot);
         }
-        const float lse = zm + __logf(tot);
         if (w == 0 && g == 0 && valid) {  // log p(a_t) (decoding.py:381) and the reference's assertions
           const float lp = xa[tl] - lse;
           const int ak = at >> 5;  // static indexing only: a runtime index would spill the words to scratch
@@ -616,9 +643,9 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
           f32x4 du;
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
-            const float prob = __expf(z[rr] - lse);  // 0 for masked nodes
+            const float prob = bounded ? z[rr] * inv_tot : __expf(z[rr] - lse);  // 0 for masked nodes
             const float dz = gt * (((16 * w + 4 * g + rr) == at ? 1.0f : 0.0f) - prob);
-            du[rr] = (z[rr] > kNegInf) ? dz * dzdu[rr] * (1.0f / kSqrtD) : 0.0f;
+            du[rr] = (bounded ? z[rr] > 0.0f : z[rr] > kNegInf) ? dz * dzdu[rr] * (1.0f / kSqrtD) : 0.0f;
           }
           *reinterpret_cast<bf16x4*>(dub + tl * kRS + 16 * w + 4 * g) = to_bf16(du);
         }
@@ -643,8 +670,9 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
       }
 
       // ---- 5. softmax backward of head h; d values, d keys, d query ------------------------------------
-      // dA^T is produced twice (7 cheap MFMAs) instead of being held in 28 registers: pass 1 reduces
-      // sum_j a_j dA_j, pass 2 turns each tile into dS, stages it and feeds d query at once
+      // sum_j a_j dA_j = sum_j a_j (V_j . dO) = O . dO: four products per lane and one exchange across the row groups
+      // instead of a first pass over all node tiles; dA^T itself is produced tile by tile, turned into dS, staged and
+      // fed to d query at once
       f32x4 dq = zero4();
       const bool scatter = valid && (ENV != RL4CO_ENV_TSP || t != 0);
       float4 row_old = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -653,14 +681,8 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
       {
         float ada = 0.0f;
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt) {
-          {
-            const f32x4 da = mfma16(lds_b64(vs + 16 * jt * kRS + 16 * h + nao), dof, zero4());
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) ada = fmaf((float)pf[jt][rr], da[rr], ada);
-          }
-        }
-        ada = rg_sum(ada) * inv_l;
+        for (int rr = 0; rr < 4; ++rr) ada = fmaf(o[rr], (float)dof[rr], ada);
+        ada = rg_sum(ada);
         wave_lds_sync();  // this wave's P block, dO and Q columns are in LDS
         {
           const bf16x4 dt = lds_tr(dob + 16 * h + tro);  // (dO_h / l)^T[d][steps]

@@ -52,8 +52,17 @@ extern "C" int rl4co_debug_clocks(unsigned long long* out, int reset) {
 """
 
 
-def variant_source() -> str:
-    lines = open(os.path.join(SRC, "am_teacher_mma.hip")).read().split("\n")
+PRIO = "  if (w >= 4) __builtin_amdgcn_s_setprio(1);\n"
+VARIANTS = {"clk": None, "base": PRIO, "prio_none": "", "prio_flip": "  if (w < 4) __builtin_amdgcn_s_setprio(1);\n",
+            "prio_odd": "  if (w & 1) __builtin_amdgcn_s_setprio(1);\n"}
+
+
+def variant_source(kind="clk") -> str:
+    text = open(os.path.join(SRC, "am_teacher_mma.hip")).read()
+    assert text.count(PRIO) == 1
+    if kind != "clk":
+        return text.replace(PRIO, VARIANTS[kind])
+    lines = text.split("\n")
     out = []
     for ln in lines:
         hits = [(i, pos) for a, i, pos in MARKS if ln.startswith(a)]
@@ -86,12 +95,16 @@ def build():
     from rl4co_amd import build as B
 
     os.makedirs(OUT, exist_ok=True)
-    src = os.path.join(OUT, "teacher_clk.hip")
-    open(src, "w").write(variant_source())
-    extra = [os.path.join(SRC, n) for n in ("am_teacher.hip", "am_teacher_mma_f16.hip", "api.hip")]
-    cmd = [B._hipcc(), *B.FLAGS, f"-I{B.INCLUDE}", f"-I{SRC}", "-o", os.path.join(OUT, "libteacher_clk.so"), src, *extra]
-    subprocess.run(cmd, check=True)
-    print("built")
+    procs = []
+    for kind in (sys.argv[2:] or VARIANTS):
+        src = os.path.join(OUT, f"teacher_{kind}.hip")
+        open(src, "w").write(variant_source(kind))
+        extra = [os.path.join(SRC, n) for n in ("am_teacher.hip", "am_teacher_mma_f16.hip", "api.hip")]
+        cmd = [B._hipcc(), *B.FLAGS, f"-I{B.INCLUDE}", f"-I{SRC}", "-o", os.path.join(OUT, f"libteacher_{kind}.so"), src, *extra]
+        procs.append((kind, subprocess.Popen(cmd)))
+    for kind, pr in procs:
+        assert pr.wait() == 0, kind
+        print("built", kind)
 
 
 def run():
@@ -105,12 +118,13 @@ def run():
     handle = _lib.lib()
     name = "rl4co_am_teacher_backward"
     restype, argtypes = _lib.SYMBOLS[name]
-    lib = C.CDLL(os.path.join(OUT, "libteacher_clk.so"))
-    fn = getattr(lib, name)
-    fn.restype, fn.argtypes = restype, argtypes
-    setattr(handle, name, fn)
-    dbg = lib.rl4co_debug_clocks
-    dbg.restype, dbg.argtypes = C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]
+
+    def swap(kind):
+        lib = C.CDLL(os.path.join(OUT, f"libteacher_{kind}.so"))
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = restype, argtypes
+        setattr(handle, name, fn)
+        return lib
 
     torch.manual_seed(0)
     starts, batch = 8, 4096
@@ -130,6 +144,19 @@ def run():
         (-(adv.detach() * ll).mean()).backward()
         pol.zero_grad(set_to_none=True)
 
+    timings = {}
+    for kind in [k for k in VARIANTS if k != "clk" and os.path.exists(os.path.join(OUT, f"libteacher_{k}.so"))] * 2:
+        swap(kind)
+        for _ in range(2):
+            step()
+        T.backward_events = []
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+        timings.setdefault(kind, []).append(round(sum(a.elapsed_time(b) for a, b in T.backward_events) / 5, 4))
+    lib = swap("clk")
+    dbg = lib.rl4co_debug_clocks
+    dbg.restype, dbg.argtypes = C.c_int, [C.POINTER(C.c_ulonglong), C.c_int]
     for _ in range(2):
         step()
     assert dbg(buf, 1) == 0
@@ -141,7 +168,7 @@ def run():
     ms = [a.elapsed_time(b) for a, b in T.backward_events]
     T.backward_events = None
     tab = [[buf[w * 16 + i] for i in range(16)] for w in range(8)]
-    res = {"launch_ms_with_probes": sum(ms) / len(ms), "launches": n, "segments": SEGMENTS, "cycles_per_wave": {}}
+    res = {"launch_ms_variants": timings, "launch_ms_with_probes": sum(ms) / len(ms), "launches": n, "segments": SEGMENTS, "cycles_per_wave": {}}
     for w in range(8):
         tot = sum(tab[w][:13])
         res["cycles_per_wave"][f"wave{w}"] = {"total_per_launch": tot / n,
