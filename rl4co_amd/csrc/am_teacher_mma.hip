@@ -56,6 +56,7 @@ __device__ inline f32x4 mfma16(const bf16x4& a, const bf16x4& b, const f32x4& c)
 }
 __device__ inline f32x4 zero4() { return f32x4{0.0f, 0.0f, 0.0f, 0.0f}; }
 __device__ inline bf16x4 lds_b64(const elem_t* p) { return *reinterpret_cast<const bf16x4*>(p); }
+__device__ inline rl4co_e16::e8 lds_b128(const elem_t* p) { return *reinterpret_cast<const rl4co_e16::e8*>(p); }
 // ds_read_b64_tr_b16: the 16 lanes of a row group address a [4 rows][16 columns] block (lane i:
 // row i / 4, columns 4 (i % 4) ..) and lane c receives column c of it — four consecutive ROWS
 __device__ inline bf16x4 lds_tr(const elem_t* p) {
@@ -560,10 +561,17 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
           dzdu[rr] = 0.0f;
         }
         if (w < NT) {
-          f32x4 u = zero4();
+          // contraction over the 128 dims on v_mfma_f32_16x16x32: 8 consecutive dims per lane from both row-major
+          // blocks (one 16-byte read each), two accumulators so the dependent chain is two deep instead of eight
+          f32x4 u = zero4(), u1 = zero4();
+          const int nao8 = tl * kRS + 8 * g;
 #pragma unroll
-          for (int ks = 0; ks < 8; ++ks)
-            u = mfma16(lds_b64(kls + 16 * w * kRS + 16 * ks + nao), lds_b64(ob + 16 * ks + nao), u);
+          for (int ks = 0; ks < 4; ks += 2) {
+            u = rl4co_e16::mfma_16x16x32(lds_b128(kls + 16 * w * kRS + 32 * ks + nao8), lds_b128(ob + 32 * ks + nao8), u);
+            u1 = rl4co_e16::mfma_16x16x32(lds_b128(kls + 16 * w * kRS + 32 * (ks + 1) + nao8), lds_b128(ob + 32 * (ks + 1) + nao8), u1);
+          }
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) u[rr] += u1[rr];
           // w is a runtime value: select, never index (an indexed register array goes to scratch)
           const uint32_t wsel = a.mask_logits ? (w < 2 ? mw4.x : (w < 4 ? mw4.y : (w < 6 ? mw4.z : mw4.w)))
                                               : (w < 2 ? nv[0] : (w < 4 ? nv[1] : (w < 6 ? nv[2] : nv[3])));
