@@ -48,6 +48,7 @@ constexpr float kLog2e = 1.44269504088896341f;
 typedef elem_t bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));  // elementwise fp32 chains two at a time (v_pk_add / mul / fma_f32)
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
 // C[m = 4 g + r][n = lane & 15] += sum_k A[m = lane & 15][k = 4 g + s] * B[k = 4 g + s][n = lane & 15]
@@ -63,16 +64,20 @@ __device__ inline bf16x4 lds_tr(const elem_t* p) {
   const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
   return __builtin_bit_cast(bf16x4, v);
 }
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ inline bf16x4 pack4(const f32x2& a, const f32x2& b) {  // two v_cvt_pk: (a0, a1), (b0, b1)
+  return __builtin_bit_cast(bf16x4, u32x2{rl4co_e16::pack(a[0], a[1]), rl4co_e16::pack(b[0], b[1])});
+}
 __device__ inline bf16x4 to_bf16(const f32x4& v) {
   bf16x4 o;
 #pragma unroll
   for (int i = 0; i < 4; ++i) o[i] = (elem_t)v[i];
   return o;
 }
-// bit `pos` of `bits` set ? x : -inf, in two VALU operations (v_bfe_i32 spreads the bit, v_bfi_b32 selects)
+// bit `pos` of `bits` set ? x : -inf, in two VALU operations (v_bfe_i32 spreads the bit, v_bitop3_b32 selects)
 __device__ inline float keep_or_neg_inf(uint32_t bits, int pos, float x) {
   const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)bits, pos, 1);
-  return __builtin_bit_cast(float, (m & __builtin_bit_cast(uint32_t, x)) | (~m & 0xff800000u));
+  return __builtin_bit_cast(float, __builtin_amdgcn_bitop3_b32(m, __builtin_bit_cast(uint32_t, x), 0xff800000u, 0xCA));  // m ? x : -inf
 }
 // LDS hand-off inside ONE wave
 __device__ inline void wave_lds_sync() {
@@ -518,20 +523,20 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
           }
         }
         m = rg_max(m);
-        float l = 0.0f;
+        const f32x2 m2 = {m, m};
+        f32x2 l2 = {0.0f, 0.0f};
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
           {
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-              const float p = __builtin_amdgcn_exp2f(sc[jt][rr] - m);
-              l += p;
-              pf[jt][rr] = (elem_t)p;
-            }
+            const f32x2 d0 = f32x2{sc[jt][0], sc[jt][1]} - m2, d1 = f32x2{sc[jt][2], sc[jt][3]} - m2;
+            const f32x2 p0 = {__builtin_amdgcn_exp2f(d0[0]), __builtin_amdgcn_exp2f(d0[1])};
+            const f32x2 p1 = {__builtin_amdgcn_exp2f(d1[0]), __builtin_amdgcn_exp2f(d1[1])};
+            l2 += p0 + p1;
+            pf[jt] = pack4(p0, p1);
             *reinterpret_cast<bf16x4*>(pbw + tl * kRS + 16 * jt + 4 * g) = pf[jt];
           }
         }
-        l = rg_sum(l);
+        const float l = rg_sum(l2[0] + l2[1]);
         inv_l = __builtin_amdgcn_rcpf(l);
       }
 
@@ -699,13 +704,16 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
             dvg[jt] = mfma16(dt, lds_tr(pbw + 16 * jt + tro), dvg[jt]);
         }
         wave_lds_sync();  // the transpose reads of P are done: the block is reused for dS
+        const f32x2 il2 = {inv_l, inv_l}, nada2 = {-ada * inv_l, -ada * inv_l};
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
           {
             const f32x4 da = mfma16(lds_b64(vs + 16 * jt * kRS + 16 * h + nao), dof, zero4());
-            bf16x4 dsf;
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) dsf[rr] = (elem_t)((float)pf[jt][rr] * (da[rr] - ada) * inv_l);
+            // dS = a (dA - sum a dA), a = p / l: one packed fma and one packed multiply per two nodes
+            const u32x2 pw = __builtin_bit_cast(u32x2, pf[jt]);
+            const f32x2 s0 = __builtin_elementwise_fma(f32x2{da[0], da[1]}, il2, nada2) * f32x2{rl4co_e16::lo(pw[0]), rl4co_e16::hi(pw[0])};
+            const f32x2 s1 = __builtin_elementwise_fma(f32x2{da[2], da[3]}, il2, nada2) * f32x2{rl4co_e16::lo(pw[1]), rl4co_e16::hi(pw[1])};
+            const bf16x4 dsf = pack4(s0, s1);
             *reinterpret_cast<bf16x4*>(pbw + tl * kRS + 16 * jt + 4 * g) = dsf;
             dq = mfma16(lds_tr(kgs + 16 * jt * kRS + 16 * h + tro), dsf, dq);
           }
