@@ -743,7 +743,7 @@ def main() -> None:
                 "check_solution": not args.no_check_solution, "parallelism": f"replicas x{world} (instances sharded)",
             },
         }
-        for k in ("node_steps_per_sec", "instances_per_sec", "mean_reward", "roofline", "encoder_roofline", "host_gap_ms", "launch",
+        for k in ("node_steps_per_sec", "instances_per_sec", "mean_reward", "roofline", "rollout_roofline", "encoder_roofline", "host_gap_ms", "launch",
                   "eager_ms_per_step", "graph_ms_per_step",
                   "trajectories_per_sec", "collective"):
             if k in head:

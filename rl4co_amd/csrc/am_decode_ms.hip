@@ -301,6 +301,9 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
     forced[c] = (MODE == RL4CO_DECODE_EVALUATE && tj[c].ok) ? (int)a.forced_actions[(int64_t)tj[c].r * a.out_stride + a.t0] : -1;
   __syncthreads();
 
+  // the launch's Philox key, read ONCE: fetched inside the step loop it was a vector-memory load whose wait
+  // (vmcnt is one in-order counter) also held the Philox rounds back behind the context row's L2 round trip
+  const unsigned long long seed = a.philox_seed ^ (a.philox_seed_dev ? *a.philox_seed_dev : 0ull);
   int t = 0;
   for (; t < a.max_steps; ++t) {
     bool all_done = true;
@@ -331,7 +334,7 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
             lnz_c[c][i] = (node0 + i < N && x.ok) ? __logf(a.exp_noise[((int64_t)t * a.B + x.r) * N + node0 + i]) : 0.0f;
         } else {
           float uu4[4];
-          rl4co_uniform4(a.philox_seed ^ (a.philox_seed_dev ? *a.philox_seed_dev : 0ull), a.philox_offset + (uint64_t)tcol,
+          rl4co_uniform4(seed, a.philox_offset + (uint64_t)tcol,
                          (uint32_t)x.r, (uint32_t)(node0 >> 2), uu4);
 #pragma unroll
           for (int i = 0; i < 4; ++i) lnz_c[c][i] = __logf(-__logf(uu4[i]));
