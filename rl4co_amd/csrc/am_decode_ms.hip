@@ -385,13 +385,17 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
           const uint32_t bits = word >> (16 * (jt & 1) + 4 * g);
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
-            sc[c][jt][rr] = ((bits >> rr) & 1u) ? sc[c][jt][rr] : kNegInf;
+            sc[c][jt][rr] = rl4co::keep_or_neg_inf(bits, rr, sc[c][jt][rr]);
             m[c] = fmaxf(m[c], sc[c][jt][rr]);
           }
         }
       }
       float l[CT];
       f32x4 o0[CT], o1[CT];  // two accumulators per tile: half the dependent-MFMA chain
+      // paired: the second instance's products get accumulators of their own and a lane keeps its instance's pair at
+      // the end — the same sums, bit for bit, as chaining both through one accumulator with the other instance's
+      // columns of the B operand zeroed, without the four selects per node tile that zeroing cost
+      f32x4 p0[PAIR ? CT : 1], p1[PAIR ? CT : 1];
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         m[c] = rg_max(m[c]);
@@ -399,6 +403,10 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
         l[c] = 0.0f;
         o0[c] = zero4();
         o1[c] = zero4();
+        if (PAIR) {
+          p0[c] = zero4();
+          p1[c] = zero4();
+        }
       }
 #pragma clang loop unroll(full)
       for (int jt = 0; jt < NT; ++jt) {
@@ -414,8 +422,13 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
           }
           if (PAIR) {
             const bf16x4 vf2 = lds_tr(sh.vs + sh.plane2 + 16 * jt * kRS + 16 * h + tro);
-            if (jt & 1) o1[c] = mfma16(vf2, only1(pf), mfma16(vf, only0(pf), o1[c]));
-            else o0[c] = mfma16(vf2, only1(pf), mfma16(vf, only0(pf), o0[c]));
+            if (jt & 1) {
+              o1[c] = mfma16(vf, pf, o1[c]);
+              p1[c] = mfma16(vf2, pf, p1[c]);
+            } else {
+              o0[c] = mfma16(vf, pf, o0[c]);
+              p0[c] = mfma16(vf2, pf, p0[c]);
+            }
           } else if (jt & 1) {
             o1[c] = mfma16(vf, pf, o1[c]);
           } else {
@@ -429,7 +442,11 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
         const float inv = (ls > 0.0f) ? __builtin_amdgcn_rcpf(ls) : 0.0f;
         bf16x4 of;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) of[rr] = (elem_t)((o0[c][rr] + o1[c][rr]) * inv);
+        for (int rr = 0; rr < 4; ++rr) {
+          float acc = o0[c][rr] + o1[c][rr];
+          if (PAIR) acc = half == 0 ? acc : p0[c][rr] + p1[c][rr];
+          of[rr] = (elem_t)(acc * inv);
+        }
         *reinterpret_cast<bf16x4*>(sh.hs + (16 * c + tl) * kRS + dcol) = of;
       }
     }
@@ -437,11 +454,15 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
 
     // ---- 3. logits of node tile w, local log-softmax / selection pieces ------------------------------------
     if (w < NT) {
-      f32x4 u0[CT], u1[CT];
+      f32x4 u0[CT], u1[CT], v0[PAIR ? CT : 1], v1[PAIR ? CT : 1];  // paired: second instance apart, as in the glimpse
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         u0[c] = zero4();
         u1[c] = zero4();
+        if (PAIR) {
+          v0[c] = zero4();
+          v1[c] = zero4();
+        }
       }
 #pragma clang loop unroll(full)
       for (int ks = 0; ks < 8; ++ks) {
@@ -451,8 +472,13 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
           const bf16x4 hf = lds_b64(sh.hs + 16 * c * kRS + 16 * ks + nao);
           if (PAIR) {
             const bf16x4 lf2 = lfr2[PAIR ? ks : 0];
-            if (ks & 1) u1[c] = mfma16(lf2, only1(hf), mfma16(lf, only0(hf), u1[c]));
-            else u0[c] = mfma16(lf2, only1(hf), mfma16(lf, only0(hf), u0[c]));
+            if (ks & 1) {
+              u1[c] = mfma16(lf, hf, u1[c]);
+              v1[c] = mfma16(lf2, hf, v1[c]);
+            } else {
+              u0[c] = mfma16(lf, hf, u0[c]);
+              v0[c] = mfma16(lf2, hf, v0[c]);
+            }
           } else if (ks & 1) {
             u1[c] = mfma16(lf, hf, u1[c]);
           } else {
@@ -474,7 +500,9 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           // this variant is tolerance-tested, not bit-exact: hardware reciprocals instead of IEEE division
-          const float uu = (u0[c][rr] + u1[c][rr]) * (1.0f / kSqrtD);
+          float usum = u0[c][rr] + u1[c][rr];
+          if (PAIR) usum = half == 0 ? usum : v0[c][rr] + v1[c][rr];
+          const float uu = usum * (1.0f / kSqrtD);
           nan_seen |= uu != uu;
           const float ex = __expf(-2.0f * fabsf(uu));
           const float th = copysignf((1.0f - ex) * __builtin_amdgcn_rcpf(1.0f + ex), uu) * clip_over_temp;

@@ -74,11 +74,6 @@ __device__ inline bf16x4 to_bf16(const f32x4& v) {
   for (int i = 0; i < 4; ++i) o[i] = (elem_t)v[i];
   return o;
 }
-// bit `pos` of `bits` set ? x : -inf, in two VALU operations (v_bfe_i32 spreads the bit, v_bitop3_b32 selects)
-__device__ inline float keep_or_neg_inf(uint32_t bits, int pos, float x) {
-  const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)bits, pos, 1);
-  return __builtin_bit_cast(float, __builtin_amdgcn_bitop3_b32(m, __builtin_bit_cast(uint32_t, x), 0xff800000u, 0xCA));  // m ? x : -inf
-}
 // LDS hand-off inside ONE wave
 __device__ inline void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -517,7 +512,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
             const uint32_t bits = (a.mask_inner ? mw[jt >> 1] : nv[jt >> 1]) >> (16 * (jt & 1) + 4 * g);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-              sc[jt][rr] = keep_or_neg_inf(bits, rr, sc[jt][rr]);
+              sc[jt][rr] = rl4co::keep_or_neg_inf(bits, rr, sc[jt][rr]);
               m = fmaxf(m, sc[jt][rr]);
             }
           }

@@ -48,6 +48,13 @@ __device__ inline void lds_barrier_wave() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// bit `pos` of `bits` set ? x : -inf, in two VALU operations (v_bfe_i32 spreads the bit, v_bitop3_b32 selects) where the
+// compiler's own lowering of the conditional takes three (and, compare, cndmask)
+__device__ inline float keep_or_neg_inf(uint32_t bits, int pos, float x) {
+  const uint32_t m = (uint32_t)__builtin_amdgcn_sbfe((int)bits, pos, 1);
+  return __builtin_bit_cast(float, __builtin_amdgcn_bitop3_b32(m, __builtin_bit_cast(uint32_t, x), 0xff800000u, 0xCA));  // m ? x : -inf
+}
+
 __device__ inline void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
