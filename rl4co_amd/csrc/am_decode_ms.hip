@@ -157,6 +157,11 @@ struct Sel {  // log-softmax / selection pieces over a set of nodes
   int idx;
 };
 // merge two disjoint node sets; symmetric in its arguments so every replica gets identical bits
+// natural log on the hardware log2 (v_log_f32, 1 ulp) and one multiply. The library __logf wraps the same instruction in
+// denormal scaling and an extended-precision product — about fifteen issue slots a call, thirteen calls per lane and
+// step here (the Gumbel noise is log(-log u) of four uniforms), none of whose arguments can be denormal: uniforms and
+// exponential noise are >= 2^-33, -log u >= 2^-25, sums of exponentials >= 1
+__device__ inline float ln_fast(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
 __device__ inline Sel merge(const Sel& p, const Sel& q) {
   Sel o;
   o.zmax = fmaxf(p.zmax, q.zmax);
@@ -331,13 +336,13 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
         if (a.exp_noise) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            lnz_c[c][i] = (node0 + i < N && x.ok) ? __logf(a.exp_noise[((int64_t)t * a.B + x.r) * N + node0 + i]) : 0.0f;
+            lnz_c[c][i] = (node0 + i < N && x.ok) ? ln_fast(a.exp_noise[((int64_t)t * a.B + x.r) * N + node0 + i]) : 0.0f;
         } else {
           float uu4[4];
           rl4co_uniform4(seed, a.philox_offset + (uint64_t)tcol,
                          (uint32_t)x.r, (uint32_t)(node0 >> 2), uu4);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) lnz_c[c][i] = __logf(-__logf(uu4[i]));
+          for (int i = 0; i < 4; ++i) lnz_c[c][i] = ln_fast(-ln_fast(uu4[i]));
         }
       }
     }
@@ -579,7 +584,7 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
       }
       p = merge(p, partner<16>(p));
       p = merge(p, partner<32>(p));
-      const float lse = p.zmax + __logf(p.se);
+      const float lse = p.zmax + ln_fast(p.se);
       int act;
       float logp;
       if (MODE == RL4CO_DECODE_EVALUATE) {
