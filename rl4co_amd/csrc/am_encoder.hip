@@ -268,8 +268,8 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       bl[i] = i < 3 * kD ? a.bqkv[layer * 3 * kD + i] : a.b1[layer * kFF + i - 3 * kD];
   };
 
-  const int tid = threadIdx.x;
-  const int w = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  int tid = threadIdx.x;
+  int w = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;  // (not const: see the top of the layer loop)
   const int b = blockIdx.x;
   const int N = a.N;
 
@@ -368,6 +368,13 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
   __syncthreads();
 
   for (int layer = 0; layer < a.num_layers; ++layer) {
+    // The lane indices pass through an opaque copy once per layer, so every per-lane LDS / weight address below is
+    // derived INSIDE the iteration, next to its use. Hoisted out of the loop as invariants they were ~70 registers
+    // live across the whole kernel — the allocator spilled them (296 bytes of scratch per lane, 310 MB of scratch
+    // writes per launch: the "1.5x write amplification" of the PMC pass) and reloaded them inside the GEMM loops
+    asm volatile("" : "+v"(tid), "+v"(w), "+v"(lane));
+    l31 = lane & 31;
+    hi = lane >> 5;
     LayerPtrs<E> L;
     L.wqkv = wqkv_all + (int64_t)layer * 3 * kD * kD;
     L.wo = wo_all + (int64_t)layer * kD * kD;

@@ -20,7 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 SRC = os.path.join(ROOT, "rl4co_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "probes", "bin")
-VARIANTS = ("base", "xhalf", "xquarter")
+VARIANTS = tuple(v for v in ("base", "xhalf", "xquarter") if os.path.exists(os.path.join(OUT, f"libenc_{v}.so")) or len(sys.argv) > 1 and sys.argv[1] == "build")
 
 LOAD = """  vec8<E> x[3][TT];
 #pragma unroll
