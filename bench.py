@@ -555,6 +555,20 @@ class Bench:
                     rec["greedy_bf16_vs_reference_bf16_autocast"] = TP.compare(g, "bf16", dev, against="bf16")
             out[leg] = rec
             torch.cuda.empty_cache()
+        if "c4_train" in legs and "t4_pomo_tsp100_b256_msgreedy" in TP.manifest():
+            # configs[3]'s POLICY (POMO, trained by the product) at its evaluation protocol (zoo/pomo/model.py:99-140):
+            # a greedy rollout from every start node, and the best of 8 dihedral augmentations x 100 starts
+            case = TP.TrainedCase("t4_pomo_tsp100_b256_msgreedy")
+            out["c4_train"] = {
+                "case": case.name, "batch": case.batch, "num_starts": case.num_starts,
+                "fp32": TP.compare(case, "fp32", dev, against="fp32", decode="multistart_greedy", regret=False),
+                "bf16_vs_reference_bf16_autocast": TP.compare(case, "bf16", dev, against="bf16", decode="multistart_greedy", regret=False),
+                "bf16_vs_reference_fp32": TP.compare(case, "bf16", dev, against="fp32", decode="multistart_greedy", regret=False),
+                "reference_bf16_vs_reference_fp32_identical": case.meta.get("reference_bf16_vs_fp32_identical"),
+                "augmented_fp32": TP.compare_augmented(case, "fp32", dev),
+                "augmented_bf16": TP.compare_augmented(case, "bf16", dev),
+            }
+            torch.cuda.empty_cache()
         head = out.get("c2_greedy")
         if head:
             out["fp32_flips"] = head["fp32"]["flips"]

@@ -53,7 +53,12 @@ CASES = [
     # every step is an exact tie and the tour degenerates to index order)
     dict(name="sharpkl100_tsp100_b1024_greedy", env="tsp", num_loc=100, batch=1024, weights=None, kl_scale=100.0, decode="greedy", bf16=False),
     dict(name="sharpkl400_tsp100_b512_greedy", env="tsp", num_loc=100, batch=512, weights=None, kl_scale=400.0, decode="greedy", bf16=False),
+    # BASELINE configs[3]'s policy (POMO: 6 layers, instance norm, no graph context) at its evaluation protocol
+    # (zoo/pomo/model.py:99-140): one greedy rollout from every start node, and the best of 8 dihedral augmentations x starts
+    dict(name="t4_pomo_tsp100_b256_msgreedy", env="tsp", num_loc=100, batch=256, weights="pomo_tsp100_sharp", arch="pomo",
+         decode="multistart_greedy", bf16=True, augment=8),
 ]
+POMO_KW = dict(num_encoder_layers=6, normalization="instance", use_graph_context=False)  # zoo/pomo/model.py:52-67
 
 
 def load_weights(name: str) -> dict:
@@ -75,7 +80,8 @@ def sharpen_logit_key(sd: dict, scale: float) -> dict:
 def build_policies(ref, case):
     env_name = case["env"]
     torch.manual_seed(WEIGHT_SEED)
-    ref_pol = ref.AttentionModelPolicy(env_name=env_name).eval()
+    arch = POMO_KW if case.get("arch") == "pomo" else {}
+    ref_pol = ref.AttentionModelPolicy(env_name=env_name, **arch).eval()
     if case["weights"] is not None:
         sd = load_weights(case["weights"])
     else:
@@ -83,7 +89,7 @@ def build_policies(ref, case):
     missing = ref_pol.load_state_dict(sd, strict=True)  # product-trained checkpoint -> the reference's module tree
     assert not missing.missing_keys and not missing.unexpected_keys
     torch.manual_seed(WEIGHT_SEED)
-    pol = R.AttentionModelPolicy(env_name=env_name).eval()
+    pol = R.AttentionModelPolicy(env_name=env_name, **arch).eval()
     pol.load_state_dict(sd, strict=True)
     return ref_pol.eval(), pol.eval(), sd
 
@@ -124,6 +130,27 @@ def run_case(ref, case):
         # how sharp the policy is: the share of greedy decisions taken with probability > 0.5 / > 0.9 is
         # exp(per-step log-prob); only the summed log-likelihood is returned, so report its mean per step
         meta["mean_logp_per_step"] = float((out32["log_likelihood"] / out32["actions"].shape[1]).mean())
+    if case.get("augment"):
+        # the reference's own augmentation module and best-of epilogue (data/transforms.py:105-151, pomo/model.py:112-140)
+        import importlib
+
+        tr = importlib.import_module("rl4co.data.transforms")
+        n_aug, n_start = case["augment"], ref_env.get_num_starts(ref_env.reset(data.clone()))
+        t0 = time.perf_counter()
+        with torch.inference_mode():
+            td_aug = tr.StateAugmentation(num_augment=n_aug, augment_fn="dihedral8")(ref_env.reset(data.clone()))
+            out_aug = ref_pol(td_aug, ref_env, phase="test", decode_type=case["decode"], num_starts=n_start)
+            rw = ref.ops.unbatchify(out_aug["reward"], (n_aug, n_start))           # [B, aug, starts]
+            max_reward, _ = rw.max(dim=-1)                                          # best start per augmentation
+            max_aug_reward, _ = max_reward.max(dim=1)                               # best augmentation
+            base = ref.ops.unbatchify(out32["reward"], n_start).max(dim=-1).values  # no augmentation: best start
+        meta["reference_cpu_seconds_augment"] = round(time.perf_counter() - t0, 2)
+        fixture["aug_reward"] = out_aug["reward"].numpy()
+        fixture["aug_max_reward"] = max_reward.numpy()
+        fixture["aug_max_aug_reward"] = max_aug_reward.numpy()
+        fixture["max_reward"] = base.numpy()
+        meta.update(num_augment=n_aug, num_starts=int(n_start), mean_max_reward=float(base.mean()),
+                    mean_max_aug_reward=float(max_aug_reward.mean()))
     if case.get("bf16"):
         t0 = time.perf_counter()
         with torch.inference_mode(), torch.autocast("cpu", dtype=torch.bfloat16):
@@ -139,7 +166,7 @@ def run_case(ref, case):
                     reference_bf16_vs_fp32_identical=int(same.sum()),
                     reference_bf16_dtypes={k: str(out16[k].dtype) for k in ("reward", "log_likelihood")})
     meta.update(name=case["name"], env=env_name, num_loc=n, batch=b, decode_type=case["decode"],
-                weights=case["weights"], kl_scale=case.get("kl_scale"), weight_seed=WEIGHT_SEED, data_seed=DATA_SEED,
+                weights=case["weights"], arch=case.get("arch"), kl_scale=case.get("kl_scale"), weight_seed=WEIGHT_SEED, data_seed=DATA_SEED,
                 sample_seed=SAMPLE_SEED, weights_sha256=state_hash(sd), inputs_sha256=state_hash({k: v for k, v in data.items()}),
                 torch=torch.__version__, threads=torch.get_num_threads())
     return fixture, meta

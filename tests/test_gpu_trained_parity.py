@@ -20,7 +20,7 @@ import os
 import pytest
 import torch
 
-from tools.trained_parity import TrainedCase, compare
+from tools.trained_parity import TrainedCase, compare, compare_augmented
 
 pytestmark = pytest.mark.gpu
 
@@ -134,3 +134,56 @@ def test_fp16_configuration_vs_reference_fp32(name):
     floor_same, floor_agree, gap = BF16[name][1]
     assert rec["identical_frac"] >= floor_same and rec["step_agreement"] >= floor_agree and rec["reward_rel_gap"] <= gap
     assert rec["rewards_bit_identical_on_identical"] is True
+
+
+# BASELINE configs[3]'s policy — POMO (6 layers, instance norm, no graph context), trained by the product (tools/train_sharp.py
+# --arch pomo) and loaded into the reference's own class — at its evaluation protocol (zoo/pomo/model.py:99-140): a greedy
+# rollout from each of the 100 start nodes of 256 instances, and the best of 8 dihedral augmentations x 100 starts
+# (204 800 rollouts). Measured on MI355X (r03, profiles/r03_parity_measured.json):
+#   fp32   25 597 / 25 600 tours identical, best-of-starts reward bit-identical on 256 / 256 instances; augmented: 204 780 /
+#          204 800 rollout rewards, 2047 / 2048 per-augmentation maxima and 255 / 256 final maxima bit-identical
+#   bf16   53.4 % of the fp32 reference's tours, 17.0 % of its bf16-autocast run's (the reference's two regimes agree on
+#          18.6 %); augmented best reward within 2.7e-5
+#   fp16   92.1 % of the fp32 reference's tours; augmented best reward within 1.7e-4
+POMO = "t4_pomo_tsp100_b256_msgreedy"
+
+
+def test_pomo_multistart_fp32_reproduces_the_reference_on_trained_weights():
+    case = TrainedCase(POMO)
+    rec = compare(case, "fp32", "cuda", against="fp32", decode="multistart_greedy", regret=False)
+    _record(f"trained/{POMO}/fp32", rec)
+    print("pomo fp32:", rec)
+    assert rec["of"] == case.batch * case.num_starts == 25600
+    assert rec["rewards_bit_identical_on_identical"] is True
+    assert rec["flips"] <= 0.001 * rec["of"]
+    assert rec["best_of_starts_bit_identical"] >= case.batch - 1 and rec["reward_rel_gap"] <= 1e-6
+
+
+def test_pomo_augmented_best_of_fp32_matches_the_reference_epilogue():
+    """rl4co_amd.data.pomo_evaluate (augmentation kernel, multistart rollouts, fused best-of) against the reference's
+    StateAugmentation + POMO.shared_step maxima."""
+    case = TrainedCase(POMO)
+    rec = compare_augmented(case, "fp32", "cuda")
+    _record(f"trained/{POMO}/augmented_fp32", rec)
+    print("pomo augmented fp32:", rec)
+    assert rec["of_rollouts"] == 8 * 100 * 256
+    assert rec["rollout_rewards_identical_frac"] >= 0.999
+    assert rec["max_reward_bit_identical"] >= rec["of_max_reward"] - 4
+    assert rec["max_aug_reward_bit_identical"] >= rec["instances"] - 3 and rec["max_aug_reward_rel_gap"] <= 2e-5
+
+
+@pytest.mark.parametrize("config,floor_fp32,floor_bf16,gap,aug_gap", [("bf16", 0.45, 0.13, 5e-4, 1.5e-4), ("fp16", 0.88, None, 1e-4, 6e-4)])
+def test_pomo_16bit_configurations_on_trained_weights(config, floor_fp32, floor_bf16, gap, aug_gap):
+    case = TrainedCase(POMO)
+    rec = compare(case, config, "cuda", against="fp32", decode="multistart_greedy", regret=False)
+    _record(f"trained/{POMO}/{config}_vs_fp32", rec)
+    assert rec["rewards_bit_identical_on_identical"] is True
+    assert rec["identical_frac"] >= floor_fp32 and rec["reward_rel_gap"] <= gap
+    if floor_bf16 is not None:
+        r16 = compare(case, config, "cuda", against="bf16", decode="multistart_greedy", regret=False)
+        _record(f"trained/{POMO}/{config}_vs_bf16", r16)
+        assert r16["identical_frac"] >= floor_bf16 and r16["reward_rel_gap"] <= 1e-3
+    aug = compare_augmented(case, config, "cuda")
+    _record(f"trained/{POMO}/augmented_{config}", aug)
+    print(f"pomo {config}:", rec, aug)
+    assert aug["max_aug_reward_rel_gap"] <= aug_gap

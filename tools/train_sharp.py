@@ -38,6 +38,9 @@ def main() -> None:
     ap.add_argument("--lr", type=float, default=2e-4)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--out", default="gpurun_out/weights")
+    ap.add_argument("--arch", default="am", choices=("am", "pomo"),
+                    help="am: the AttentionModel default (3 layers, batch norm, graph context); pomo: BASELINE configs[3]'s "
+                         "policy (zoo/pomo/model.py:45-60: 6 layers, instance norm, no graph context)")
     args = ap.parse_args()
 
     from safetensors.torch import save_file
@@ -48,8 +51,9 @@ def main() -> None:
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     torch.manual_seed(args.seed)
+    arch = dict(num_encoder_layers=6, normalization="instance", use_graph_context=False) if args.arch == "pomo" else {}
     policy = AttentionModelPolicy(args.env, cache_dtype=torch.bfloat16, encoder_autocast=torch.bfloat16,
-                                  train_decode_type="multistart_sampling").to(dev).train()
+                                  train_decode_type="multistart_sampling", **arch).to(dev).train()
     env = get_env(args.env, generator_params=dict(num_loc=args.num_loc, device=dev), device=dev, check_solution=False)
     opt = torch.optim.Adam(policy.parameters(), lr=args.lr)
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[int(args.steps * 0.8), int(args.steps * 0.95)], gamma=0.3)
@@ -82,7 +86,7 @@ def main() -> None:
     policy.check_backward_errors()
     policy.eval()
     os.makedirs(args.out, exist_ok=True)
-    name = f"am_{args.env}{args.num_loc}_sharp"
+    name = f"{args.arch}_{args.env}{args.num_loc}_sharp"
     sd = {k: (v.detach().float() if v.is_floating_point() else v.detach()).cpu().contiguous() for k, v in policy.state_dict().items()}
     save_file(sd, os.path.join(args.out, name + ".safetensors"),
               metadata={"trained_by": "tools/train_sharp.py", "args": json.dumps(vars(args)),
