@@ -115,7 +115,15 @@ __global__ void __launch_bounds__(kThreads, 4) attn_flash_kernel(const uint16_t*
     if (kb > 0) __syncthreads();  // every wave is done reading the previous block
     commit(kb);
     __syncthreads();
-    if (kb + 1 < nblocks) fetch(kb + 1);
+    // Both paths DEFINE the four registers: with the plain "if (..) fetch(..)" the merge of fetched / kept values made the
+    // compiler load into temporaries and copy them right behind the loads — an s_waitcnt vmcnt(2) that put the block's
+    // global round trip back on the critical path; an unconditional fetch gets sunk to the top of the next iteration
+    if (kb + 1 < nblocks) {
+      fetch(kb + 1);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pre[j] = make_uint4(0, 0, 0, 0);
+    }
     bf16x4 kf[4], vf[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
