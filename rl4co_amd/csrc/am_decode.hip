@@ -980,8 +980,12 @@ inline int resolve_variant(const rl4co_am_decode_args& a) {
   // 442 vs 178; CVRP 8 starts 254 vs 277 but 16 starts 463 vs 276 (a full 16-column tile). Orienteering (7-step
   // ragged tours under random weights: 84 vs 162) and CVRP with time windows (111 vs 278: the per-step mask over all
   // nodes with a square root each, replicated in every lane of the column) stay on STREAM unless MS is asked for
-  const int ms_from = (a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_PDP || a.env == RL4CO_ENV_PCTSP) ? 8
-                      : (a.env == RL4CO_ENV_CVRP ? 16 : 0);
+  // r03, with two instances per column tile at <= 8 starts (a launch then costs ~3.3 ms for 4096 instances whatever
+  // the start count; tools/ms_bench.py, sampling, 4096 x S): TSP 3 starts 3.26 vs 5.11 ms (2: 3.24 vs 3.59), prize-
+  // collecting TSP 3 starts 3.38 vs 5.09, pickup-delivery 3 starts 3.43 vs 3.64 (2: 3.42 vs 2.58 — STREAM), CVRP 8 starts
+  // 13.6 vs 14.3 (4: 13.3 vs 7.8 — STREAM: every column of a tile runs to the tile's longest tour)
+  const int ms_from = (a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_PDP || a.env == RL4CO_ENV_PCTSP) ? 3
+                      : (a.env == RL4CO_ENV_CVRP ? 8 : 0);
   if (ms_ok && ms_from > 0 && a.B >= ms_from * a.B_inst) return RL4CO_VARIANT_MS;
   if (fits && a.B <= 1024) return RL4CO_VARIANT_LDS;
   // one wave per trajectory needs >= ~16 waves per CU to hide its latency chain: with fewer

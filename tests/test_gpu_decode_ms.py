@@ -117,15 +117,17 @@ def test_ms_is_auto_selected_for_multistart_and_policy_runs(K):
     from rl4co_amd.envs import get_env
     from rl4co_amd.policy import AttentionModelPolicy
 
-    assert K.decode_row_groups(100, torch.bfloat16, 99, "auto", 4096 * 32, 4096) == 0     # MS from 8 starts up
-    assert K.decode_row_groups(100, torch.bfloat16, 99, "auto", 4096 * 8, 4096) == 0
-    assert K.decode_row_groups(100, torch.bfloat16, 99, "auto", 4096 * 4, 4096) == 4      # 4 starts: streaming
+    assert K.decode_row_groups(100, torch.bfloat16, 99, "auto", 4096 * 32, 4096) == 0     # MS from 3 starts up (r03: two
+    assert K.decode_row_groups(100, torch.bfloat16, 99, "auto", 4096 * 8, 4096) == 0      # instances per column tile)
+    assert K.decode_row_groups(100, torch.bfloat16, 99, "auto", 4096 * 3, 4096) == 0
+    assert K.decode_row_groups(100, torch.bfloat16, 99, "auto", 4096 * 2, 4096) == 4      # 2 starts: streaming
     assert K.decode_row_groups(100, torch.bfloat16, 100, "auto", 4096, 4096) == 4          # single start: stream
     assert K.decode_row_groups(100, torch.float32, 99, "auto", 4096 * 8, 4096) == 2        # fp32 planes: stream
     # per environment, where MS was measured faster than one wave per trajectory (csrc/am_decode.hip resolve_variant)
     MS = 4
-    for env_name, starts, want_ms in [("tsp", 8, True), ("pdp", 8, True), ("pctsp", 8, True), ("cvrp", 8, False),
-                                      ("cvrp", 16, True), ("op", 32, False), ("cvrptw", 32, False)]:
+    for env_name, starts, want_ms in [("tsp", 8, True), ("tsp", 3, True), ("pdp", 3, True), ("pdp", 2, False), ("pctsp", 3, True),
+                                      ("cvrp", 4, False), ("cvrp", 8, True), ("cvrp", 16, True), ("op", 32, False),
+                                      ("cvrptw", 32, False)]:
         got = K.decode_variant(101, torch.bfloat16, 150, 4096 * starts, num_instances=4096, env_name=env_name)
         assert (got == MS) == want_ms, (env_name, starts, got)
     torch.manual_seed(0)
