@@ -4,6 +4,7 @@ through the entry point they share — box-to-box variation (±3 %) is larger th
 
     python tools/ab_probe.py build am_decode_ms.hip             # build container: two small libraries in tools/probes/bin/
     gpurun -- python tools/ab_probe.py run train               # MI355X: training-step timing (rollout + backward events)
+    gpurun -- python tools/ab_probe.py run decode              # MI355X: the streaming greedy decode launch alone
 """
 import ctypes as C
 import os
@@ -97,8 +98,57 @@ def run():
     print(entry, res)
 
 
+def run_decode():
+    """greedy decode launch alone (TSP-100 x 4096 and CVRP-100 x 4096, bf16 planes, streaming kernel), head vs tree"""
+    import torch
+
+    from rl4co_amd import _lib
+    from rl4co_amd import kernels as K
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    entry = open(os.path.join(OUT, "ab_entry.txt")).read().strip()
+    assert entry == "rl4co_am_decode"
+    handle = _lib.lib()
+    restype, argtypes = _lib.SYMBOLS[entry]
+    fns = {}
+    for tag in ("head", "tree"):
+        fn = getattr(C.CDLL(os.path.join(OUT, f"libab_{tag}.so")), entry)
+        fn.restype, fn.argtypes = restype, argtypes
+        fns[tag] = fn
+    for env_name, tmax in (("tsp", 100), ("cvrp", 200)):
+        torch.manual_seed(0)
+        pol = AttentionModelPolicy(env_name, cache_dtype=torch.bfloat16, encoder_autocast=torch.bfloat16).cuda().eval()
+        env = get_env(env_name, generator_params=dict(num_loc=100, device="cuda"), device="cuda")
+        td = env.reset(batch_size=[4096])
+        res, acts = {"head": [], "tree": []}, {}
+        with torch.inference_mode():
+            cache, _ = pol._packed_encoder().encode(td, torch.bfloat16)
+            for rnd in range(4):
+                for tag in ("head", "tree"):
+                    setattr(handle, entry, fns[tag])
+                    times = []
+                    for it in range(5):
+                        st = pol._initial_state(td, 0)
+                        actions = torch.zeros(4096, tmax, dtype=torch.int64, device="cuda")
+                        logps = torch.zeros(4096, tmax, device="cuda")
+                        err = K.new_error_word("cuda")
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        K.am_decode(cache, st, mode="greedy", max_steps=tmax, actions=actions, logps=logps, err=err, variant="stream")
+                        e1.record()
+                        torch.cuda.synchronize()
+                        times.append(e0.elapsed_time(e1))
+                    res[tag].append(round(min(times[1:]), 4))
+                    acts[tag] = (actions.clone(), logps.clone())
+        same = torch.equal(acts["head"][0], acts["tree"][0]) and torch.equal(acts["head"][1], acts["tree"][1])
+        print(env_name, res, "outputs bit-identical:", same)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "build":
         build(sys.argv[2])
+    elif len(sys.argv) > 2 and sys.argv[2] == "decode":
+        run_decode()
     else:
         run()
