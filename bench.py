@@ -59,7 +59,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_PEAK_TFLOPS = 2500.0  # dense bf16
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 / fp16
+MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_*_f32: 256 FLOP / cycle / CU x 256 CUs x 2.4 GHz
 
 LEGS = {
     # name: (env, num_loc, batch per GPU, decode, BASELINE.json config index)
@@ -71,8 +72,12 @@ LEGS = {
     # configs[1] once more in the reference's DEFAULT precision ("16-mixed" = fp16 autocast, utils/trainer.py:57): fused
     # encoder on v_mfma_f32_32x32x16_f16, fp16 planes in the streaming decode kernel
     "c2_greedy_fp16": ("tsp", 100, 4096, "greedy", 1),
+    # configs[1] in the BIT-IDENTICAL configuration (north_star: "greedy tour lengths bit-identical to the reference"): fp32
+    # encoder on v_mfma_f32_16x16x4_f32 (csrc/am_encoder_f32.hip), fp32 planes, fp32 decode arithmetic; its `parity_tours` =
+    # reference tours reproduced on the trained weights at the full size (tests/golden/trained)
+    "c2_greedy_fp32": ("tsp", 100, 4096, "greedy", 1),
 }
-DEFAULT_LEGS = "c2_greedy,c2_sampling,c3_greedy,c5_sampling,c4_train,c2_greedy_fp16"
+DEFAULT_LEGS = "c2_greedy,c2_sampling,c3_greedy,c5_sampling,c4_train,c2_greedy_fp16,c2_greedy_fp32"
 
 
 def log(msg: str) -> None:
@@ -173,6 +178,99 @@ def cpu_baseline(env_name: str, num_loc: int, sample_batch: int, repeats: int, c
     }
 
 
+MAX_LINE_BYTES = 4096  # the driver parses the ONE stdout line; r03's 27 KB line came back as `parsed: null`
+
+
+def _r(x, digits=4):
+    """Numbers of the compact line carry a few significant digits (the detail file keeps the full values)."""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}")
+    return x
+
+
+def compact_roofline(r: dict | None) -> dict | None:
+    if not r:
+        return None
+    keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms_mean")
+    out = {"kernel": r["kernel"].split(":")[0].split(" (")[0][:48]}
+    out.update({k: _r(r.get(k)) for k in keep})
+    for k in ("contract_GBs", "hbm_read_probe_GBs"):
+        if r.get(k) is not None:
+            out[k] = _r(r[k])
+    return out
+
+
+def compact_parity(par: dict | None) -> dict | None:
+    """<= 10 keys: identical tours of the fp32 (bit-identical) configuration and of the benchmarked 16-bit one, per leg."""
+    if not par:
+        return None
+    out = {}
+
+    def frac(rec):
+        return f"{rec['identical']}/{rec['of']}"
+
+    for leg, tag in (("c2_greedy", "c2"), ("c3_greedy", "c3")):
+        rec = par.get(leg)
+        if rec:
+            out[f"{tag}_fp32_tours"] = frac(rec["fp32"])
+            out[f"{tag}_bf16_vs_ref_bf16"] = frac(rec["bf16_vs_reference_bf16_autocast"])
+    rec = par.get("c2_greedy")
+    if rec:
+        out["c2_fp32_flip_regret_max"] = _r(rec["fp32"].get("flip_regret_max"))
+        out["c2_bf16_step_agreement"] = _r(rec["bf16_vs_reference_bf16_autocast"]["step_agreement"])
+        out["c2_bf16_reward_rel_gap"] = _r(rec["bf16_vs_reference_bf16_autocast"]["reward_rel_gap"])
+        out["ref_bf16_vs_ref_fp32_tours"] = rec.get("reference_bf16_vs_reference_fp32_identical")
+    rec = par.get("c2_sampling")
+    if rec:
+        out["c2_sampling_fp32_tours"] = frac(rec["fp32_reference_noise"])
+    rec = par.get("c5_sampling")
+    if rec and "greedy_fp32" in rec:
+        out["c5_greedy_fp32_tours"] = frac(rec["greedy_fp32"])
+    return out
+
+
+def compact_line(detail: dict, head_name: str, results: dict, detail_path: str) -> dict:
+    """The ONE stdout line: the driver's contract keys, the dominant kernel's roofline, cpu_baseline, one number per
+    leg and a parity summary — under MAX_LINE_BYTES. Everything else goes to the detail file."""
+    cfg = detail["config"]
+    line = {k: detail[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                   "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {
+        "workload": cfg["workload"][:160], "leg": head_name, "batch_per_gpu": cfg["batch_per_gpu"],
+        "launch": (detail.get("launch") or "").split(":")[0],
+        "input": "one synthetic batch resident in HBM, reused by every step", "parallelism": cfg["parallelism"],
+    }
+    line["roofline"] = compact_roofline(detail.get("roofline"))
+    if detail.get("encoder_roofline"):
+        line["encoder_roofline"] = compact_roofline(detail["encoder_roofline"])
+    for k in ("node_steps_per_sec", "instances_per_sec", "graph_ms_per_step", "eager_ms_per_step", "train_ms_per_step", "rccl_ranks",
+              "n1_ms_per_step", "scaling_efficiency", "allreduce_ms"):
+        if detail.get(k) is not None:
+            line[k] = _r(detail[k])
+    if detail.get("rank_ms_per_step"):
+        line["rank_ms_per_step"] = {k: _r(v) for k, v in detail["rank_ms_per_step"].items()}
+    legs = {}
+    for name, r in results.items():
+        if name == head_name:
+            continue
+        legs[name] = {"ms_per_step": _r(r["ms_per_step"]), "value": _r(r["value"])}
+        if r.get("roofline"):
+            legs[name]["frac"] = _r(r["roofline"]["frac"], 3)
+        if r.get("scaling_efficiency") is not None:
+            legs[name]["scaling_efficiency"] = _r(r["scaling_efficiency"], 3)
+        if r.get("parity_tours"):
+            legs[name]["parity_tours"] = r["parity_tours"]
+    line["legs"] = legs
+    if detail.get("parity"):
+        line["parity"] = compact_parity(detail["parity"])
+    cb = detail.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": cb["sample"][:150], "gpu_over_cpu": _r(cb.get("gpu_over_cpu"))}
+    line["detail_file"] = os.path.relpath(detail_path, ROOT) if os.path.isabs(detail_path) else detail_path
+    return line
+
+
 class Bench:
     def __init__(self, args, rank: int, world: int, device: torch.device):
         from rl4co_amd import dist as D
@@ -209,7 +307,9 @@ class Bench:
         if a.batch is not None and leg == "c2_greedy":
             batch = a.batch
         half = leg.endswith("_fp16")
-        cache_dtype, enc_dtype, elem = ((torch.float16, torch.float16, 2) if half else (self.cache_dtype, self.enc_dtype, self.elem))
+        full = leg.endswith("_fp32")
+        cache_dtype, enc_dtype, elem = ((torch.float16, torch.float16, 2) if half else
+                                        (torch.float32, None, 4) if full else (self.cache_dtype, self.enc_dtype, self.elem))
         torch.manual_seed(0)  # random-init weights of the reference architecture, identical on every rank
         policy = AttentionModelPolicy(env_name=env_name, cache_dtype=cache_dtype,
                                       encoder_autocast=enc_dtype).to(self.device).eval()
@@ -289,28 +389,44 @@ class Bench:
             if pipelined:  # drain: the timed region starts and ends with nothing in flight
                 while tickets:
                     out = pipe.collect(tickets.pop(0))
+            def region(k):
+                """K steps, all submitted, finished and read back; returns (wall, cache rows read, instance-steps, last output)."""
+                nonlocal step
+                rows_ = steps_ = 0
+                o_last = None
+                t0 = time.perf_counter()
+                if pipelined:
+                    done = 0
+                    for _ in range(k):
+                        o = step()
+                        if o is not None:
+                            o_last, done = o, done + 1
+                            rows_ += policy.last_rows_read
+                            steps_ += policy.last_instance_steps
+                    while tickets:  # the K submitted steps are all finished (and read back) inside the timed region
+                        o_last, done = pipe.collect(tickets.pop(0)), done + 1
+                        rows_ += policy.last_rows_read
+                        steps_ += policy.last_instance_steps
+                    assert done == k
+                else:
+                    for _ in range(k):
+                        o_last = step()
+                        rows_ += policy.last_rows_read
+                        steps_ += policy.last_instance_steps
+                torch.cuda.synchronize()
+                return time.perf_counter() - t0, rows_, steps_, o_last
+
+            solo_ms = None
+            if self.world > 1 and a.solo:
+                # the N = 1 reference of THIS invocation: rank 0 runs the same K steps alone while the other ranks wait at
+                # the barrier — weak scaling, so efficiency = that time / the joint time
+                self.barrier()
+                if self.rank == 0:
+                    solo_ms = region(steps)[0] / steps * 1e3
             self.barrier()
-            t0 = time.perf_counter()
-            if pipelined:
-                done = 0
-                for _ in range(steps):
-                    o = step()
-                    if o is not None:
-                        out, done = o, done + 1
-                        rows += policy.last_rows_read
-                        inst_steps += policy.last_instance_steps
-                while tickets:  # the K submitted steps are all finished (and read back) inside the timed region
-                    out, done = pipe.collect(tickets.pop(0)), done + 1
-                    rows += policy.last_rows_read
-                    inst_steps += policy.last_instance_steps
-                assert done == steps
-            else:
-                for _ in range(steps):
-                    out = step()
-                    rows += policy.last_rows_read
-                    inst_steps += policy.last_instance_steps
+            own_wall, rows, inst_steps, out = region(steps)
             self.barrier()
-            wall = time.perf_counter() - t0
+            wall = own_wall
         if not use_graph:
             decode_ms = [x.elapsed_time(y) for x, y in policy.decode_events]
             encode_ms = [x.elapsed_time(y) for x, y in policy.encode_events]
@@ -324,11 +440,17 @@ class Bench:
         gc.collect()
         torch.cuda.empty_cache()
         n_nodes = num_loc + (0 if env_name == "tsp" else 1)
-        wall = self.D.reduce_scalar(wall, "max", self.device)
+        wall = self.D.reduce_scalar(own_wall, "max", self.device)
+        wall_min = -self.D.reduce_scalar(-own_wall, "max", self.device)
         total_inst_steps = int(self.D.reduce_scalar(inst_steps, "sum", self.device))
         res = {"wall": wall}
         if self.rank != 0:
             return res
+        if self.world > 1:
+            res["rank_ms_per_step"] = {"min": wall_min / steps * 1e3, "max": wall / steps * 1e3}
+            if solo_ms is not None:
+                res["n1_ms_per_step"] = solo_ms
+                res["scaling_efficiency"] = solo_ms / (wall / steps * 1e3)
         mean_decode_ms = sum(decode_ms) / len(decode_ms)
         per_launch_rows, per_launch_steps = rows / steps, inst_steps / steps
         need = must_move_bytes(env_name, n_nodes, elem, per_launch_rows, per_launch_steps, batch)
@@ -342,6 +464,7 @@ class Bench:
             "workload": (f"BASELINE configs[{cfg_idx}]: {env_name.upper()}Env num_loc={num_loc} batch={batch}/GPU "
                          f"AttentionModel(3L,d128,h8) {decode} rollout, " +
                          ("fp16 encoder GEMMs, fp16 cache (the reference's default 16-mixed regime)" if half else
+                          "fp32 encoder (fp32 MFMA), fp32 cache: the bit-identical configuration" if full else
                           f"{a.encoder_dtype} encoder GEMMs, {a.cache_dtype} cache")),
             "value": value, "unit": "instance·step/s", "steps": steps, "warmup": warmup,
             "ms_per_step": wall / steps * 1e3,
@@ -378,12 +501,23 @@ class Bench:
                 + (5 if env_name == "tsp" else 4) * 2 * n_ * d_ * d_
             enc_ms = sum(encode_ms) / len(encode_ms)
             tf = flop_inst * batch / (enc_ms * 1e-3) / 1e12
+            peak = MFMA_F32_PEAK_TFLOPS if full else MFMA_PEAK_TFLOPS
             res["encoder_roofline"] = {
-                "kernel": "am_encoder_kernel (init embedding + 3 x [MHA, norm, FFN, norm] + cache fold, one workgroup per instance)",
-                "bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_PEAK_TFLOPS,
+                "kernel": ("am_encoder_f32_kernel" if full else "am_encoder_kernel") +
+                          " (init embedding + 3 x [MHA, norm, FFN, norm] + cache fold, one workgroup per instance)",
+                "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                 "flop_per_instance": flop_inst, "launch_ms_mean": enc_ms,
-                "note": "algorithmic FLOPs at N nodes (padding excluded); bf16 dense MFMA peak",
+                "note": "algorithmic FLOPs at N nodes (padding excluded); " + ("fp32 MFMA peak" if full else "16-bit dense MFMA peak"),
             }
+        if full and self.world == 1 and not a.no_parity:
+            from tools import trained_parity as TP
+
+            try:
+                rec = TP.compare(TP.TrainedCase("t2_tsp100_b4096_greedy"), "fp32", self.device, against="fp32")
+                res["parity_tours"] = f"{rec['identical']}/{rec['of']}"
+                res["parity"] = rec
+            except (OSError, ValueError, KeyError) as exc:
+                log(f"{leg}: no trained golden for the parity count ({exc})")
         res["host_gap_ms"] = res["ms_per_step"] - mean_decode_ms - (sum(encode_ms) / len(encode_ms) if encode_ms else 0.0)
         return res
 
@@ -409,7 +543,7 @@ class Bench:
         data = env.generator(batch_size=[batch])
         ar_events = []
 
-        def step(i):
+        def step(i, collective=True):
             out = policy(env.reset(data), env, phase="train", seed=1000 * i + self.rank, num_starts=starts)
             reward = out["reward"].view(starts, batch).t()
             ll = out["log_likelihood"].view(starts, batch).t()
@@ -419,11 +553,14 @@ class Bench:
             loss.backward()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            work = bucket.allreduce_mean(async_op=True)  # ONE flat fp32 message over RCCL (utils/trainer.py:83-86)
-            if work is not None:
-                work.wait()
-            e1.record()
-            ar_events.append((e0, e1))
+            if collective:
+                work = bucket.allreduce_mean(async_op=True)  # ONE flat fp32 message over RCCL (utils/trainer.py:83-86)
+                if work is not None:
+                    work.wait()
+                e1.record()
+                ar_events.append((e0, e1))
+            else:  # the solo (N = 1) reference region of a multi-rank run: the other ranks are not there to answer
+                bucket._rebind()
             torch.nn.utils.clip_grad_norm_(policy.parameters(), 1.0)
             opt.step()
             return out
@@ -444,17 +581,34 @@ class Bench:
         # The collector stays on for what the loop itself allocates
         gc.collect()
         gc.freeze()
+        solo_ms = None
+        if self.world > 1 and self.args.solo:  # N = 1 reference of this invocation: rank 0 alone, no collective
+            self.barrier()
+            if self.rank == 0:
+                t0 = time.perf_counter()
+                for i in range(steps):
+                    step(warmup + i, collective=False)
+                torch.cuda.synchronize()
+                solo_ms = (time.perf_counter() - t0) / steps * 1e3
+                policy.decode_events, T.backward_events = [], []
         self.barrier()
         t0 = time.perf_counter()
         for i in range(steps):
-            out = step(warmup + i)
+            out = step(warmup + steps + i)
+        torch.cuda.synchronize()
+        own_wall = time.perf_counter() - t0
         self.barrier()
-        wall = time.perf_counter() - t0
         policy.check_backward_errors()
-        wall = D.reduce_scalar(wall, "max", self.device)
+        wall = D.reduce_scalar(own_wall, "max", self.device)
+        wall_min = -D.reduce_scalar(-own_wall, "max", self.device)
         res = {"wall": wall}
         if self.rank != 0:
             return res
+        if self.world > 1:
+            res["rank_ms_per_step"] = {"min": wall_min / steps * 1e3, "max": wall / steps * 1e3}
+            if solo_ms is not None:
+                res["n1_ms_per_step"] = solo_ms
+                res["scaling_efficiency"] = solo_ms / (wall / steps * 1e3)
         t_steps = out["actions"].shape[1]
         traj = batch * starts * self.world * steps
         ar_ms = [x.elapsed_time(y) for x, y in ar_events]
@@ -646,6 +800,10 @@ def main() -> None:
     ap.add_argument("--launch", default="pipeline", choices=["pipeline", "graph", "eager"],
                     help="inference legs: two captured rollouts in flight on two streams (default), one captured HIP graph "
                          "replayed per step, or kernel-by-kernel launches")
+    ap.add_argument("--no-solo", dest="solo", action="store_false",
+                    help="N > 1: skip the N = 1 reference region (rank 0 alone, same K steps) that `scaling_efficiency` is taken from")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="file the full per-leg / parity detail goes to (the stdout line stays under 4 KB)")
     ap.add_argument("--no-check-solution", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -734,7 +892,7 @@ def main() -> None:
         torch.cuda.synchronize()
         probe_gbs = 5 * probe.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del probe
-        line = {
+        detail = {
             "metric": "decode_steps_per_sec",
             "value": head["value"],
             "unit": head["unit"],
@@ -759,22 +917,39 @@ def main() -> None:
         }
         for k in ("node_steps_per_sec", "instances_per_sec", "mean_reward", "roofline", "rollout_roofline", "encoder_roofline", "host_gap_ms", "launch",
                   "eager_ms_per_step", "graph_ms_per_step",
-                  "trajectories_per_sec", "collective"):
+                  "trajectories_per_sec", "collective", "rank_ms_per_step", "n1_ms_per_step", "scaling_efficiency"):
             if k in head:
-                line[k] = head[k]
-        if "roofline" in line:
-            line["roofline"]["hbm_read_probe_GBs"] = probe_gbs
-        line["legs"] = {name: {k: v for k, v in r.items() if k != "wall"} for name, r in results.items() if name != head_name}
+                detail[k] = head[k]
+        if "roofline" in detail:
+            detail["roofline"]["hbm_read_probe_GBs"] = probe_gbs
+        detail["legs"] = {name: {k: v for k, v in r.items() if k != "wall"} for name, r in results.items() if name != head_name}
         if "c4_train" in results and head_name != "c4_train":
-            line["train_ms_per_step"] = results["c4_train"]["ms_per_step"]
-            line["rccl_ranks"] = results["c4_train"]["collective"]["ranks"]
+            detail["train_ms_per_step"] = results["c4_train"]["ms_per_step"]
+            detail["rccl_ranks"] = results["c4_train"]["collective"]["ranks"]
+            detail["allreduce_ms"] = results["c4_train"]["collective"]["allreduce_ms_mean"]
         if world == 1 and not args.no_parity:
             log("parity vs the reference's tours (trained weights, every inference leg)")
-            line["parity"] = bench.parity(legs)
+            detail["parity"] = bench.parity(legs)
         if world == 1 and not args.no_cpu_baseline and head_name != "c4_train":
-            line["cpu_baseline"] = cpu_baseline(env_name, num_loc, args.cpu_sample_batch, repeats=2)
-            line["cpu_baseline"]["gpu_over_cpu"] = head["value"] / line["cpu_baseline"]["value"]
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+            detail["cpu_baseline"] = cpu_baseline(env_name, num_loc, args.cpu_sample_batch, repeats=2)
+            detail["cpu_baseline"]["gpu_over_cpu"] = head["value"] / detail["cpu_baseline"]["value"]
+        line = compact_line(detail, head_name, results, args.detail)
+        try:  # everything the compact line leaves out: per-leg dicts, rooflines with their notes, the whole parity block
+            os.makedirs(os.path.dirname(os.path.abspath(args.detail)), exist_ok=True)
+            with open(args.detail, "w") as f:
+                json.dump(detail, f, indent=1)
+        except OSError as exc:
+            log(f"could not write {args.detail}: {exc}")
+            line.pop("detail_file", None)
+        encoded = json.dumps(line, separators=(",", ":"))
+        for optional in ("parity", "encoder_roofline", "legs"):  # never again a line the driver cannot parse
+            if len(encoded.encode()) <= MAX_LINE_BYTES:
+                break
+            log(f"stdout line is {len(encoded.encode())} bytes: dropping {optional!r} (kept in the detail file)")
+            line.pop(optional, None)
+            encoded = json.dumps(line, separators=(",", ":"))
+        assert len(encoded.encode()) <= MAX_LINE_BYTES, f"stdout line grew to {len(encoded.encode())} bytes"
+        os.write(json_fd, (encoded + "\n").encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

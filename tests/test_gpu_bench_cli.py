@@ -26,7 +26,15 @@ def _run(args, env_extra=None, timeout=600):
     assert proc.returncode == 0, proc.stderr[-2000:]
     lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, f"stdout must carry exactly one line, got {len(lines)}: {proc.stdout[:500]}"
+    # the driver parses this line: r03's had grown to 27 KB (whole parity block + every leg's dict) and came back as
+    # `parsed: null`. Contract since r04: <= 4 KB, everything else in the detail file the line names
+    assert len(lines[0].encode()) <= 4096, len(lines[0].encode())
     return json.loads(lines[0])
+
+
+def _detail(line):
+    with open(os.path.join(ROOT, line["detail_file"])) as f:
+        return json.load(f)
 
 
 def test_single_gpu_line_has_the_contract_keys():
@@ -37,9 +45,25 @@ def test_single_gpu_line_has_the_contract_keys():
     assert line["n_gpus"] == 1 and line["steps"] == 10 and line["warmup"] == 2 and line["higher_is_better"] is True
     assert line["scaling"] == "weak" and line["vs_baseline"] is None and line["data"] == "synthetic" and "workload" in line["config"]
     roof = line["roofline"]
-    assert roof["bound"] == "hbm" and 0.3 < roof["frac"] <= 1.0 and abs(roof["achieved"] / roof["peak"] - roof["frac"]) < 1e-9
+    assert roof["bound"] == "hbm" and 0.3 < roof["frac"] <= 1.0 and abs(roof["achieved"] / roof["peak"] - roof["frac"]) < 1e-3
     assert abs(line["value"] - 4096 * 100 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
-    assert line["encoder_roofline"]["bound"] == "mfma" and line["launch"].startswith("pipeline")
+    assert line["encoder_roofline"]["bound"] == "mfma" and line["config"]["launch"] == "pipeline"
+    for k in ("kernel", "achieved", "peak", "unit", "traffic", "launch_ms_mean"):
+        assert k in roof, k
+    detail = _detail(line)
+    assert detail["value"] == pytest.approx(line["value"], rel=1e-4) and detail["roofline"]["bytes_per_launch"] > 0
+
+
+def test_default_legs_line_stays_small_and_carries_baseline_and_parity():
+    """The driver's own command shape (all legs, parity block, cpu_baseline) must still fit the line."""
+    line = _run(["--steps", "10", "--warmup", "2", "--leg-steps", "4"], timeout=900)
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
+    assert set(line["legs"]) >= {"c2_sampling", "c3_greedy", "c5_sampling", "c4_train", "c2_greedy_fp32"}
+    assert all(v["ms_per_step"] > 0 for v in line["legs"].values())
+    assert line["parity"]["c2_fp32_tours"].endswith("/4096") and len(line["parity"]) <= 10
+    assert line["legs"]["c2_greedy_fp32"]["parity_tours"].endswith("/4096")
+    detail = _detail(line)
+    assert "parity" in detail and "c4_train" in detail["legs"] and detail["legs"]["c4_train"]["roofline"]["bound"] == "mfma"
 
 
 def test_two_ranks_self_spawned():
@@ -48,7 +72,9 @@ def test_two_ranks_self_spawned():
     line = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--legs", "c2_greedy,c4_train", "--no-cpu-baseline", "--no-parity"],
                 env_extra=extra)
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2
-    train = line["legs"]["c4_train"]
+    assert line["rank_ms_per_step"]["min"] <= line["rank_ms_per_step"]["max"] == pytest.approx(line["ms_per_step"], rel=1e-3)
+    assert 0 < line["scaling_efficiency"] and line["n1_ms_per_step"] > 0 and line["allreduce_ms"] > 0
+    train = _detail(line)["legs"]["c4_train"]
     assert train["collective"]["backend"] == ("nccl" if two_gpus else "gloo") and train["collective"]["ranks"] == 2
     assert train["roofline"]["bound"] == "mfma" and train["rollout_roofline"]["launch_ms_mean"] > 0
     # whole-job throughput: both ranks' instance-steps over the max-over-ranks wall time
