@@ -61,6 +61,7 @@ class GraphedRollout:
             # would be freed under the graph)
             self._captured = dict(pe.t)
             self._packed_version = pe.version
+            self._act_dtype = pe.act_dtype  # the 16-bit regime the captured launches compute in
         self.graph = torch.cuda.CUDAGraph()
         with torch.inference_mode(), torch.cuda.graph(self.graph):
             self._finish = self._enqueue()
@@ -78,10 +79,16 @@ class GraphedRollout:
         values of version `_packed_version` — nobody else writes them — so an unchanged version needs no copy whatever
         `pe.t` currently points at."""
         pe = self.policy._packed
+        if pe.act_dtype != self._act_dtype:
+            # an eager rollout under the OTHER 16-bit regime ran in between and re-packed the weights in its element type:
+            # bring the packed encoder back to the regime of the capture (no weight changed: the version below then tells)
+            pe.refresh(act_dtype=self._act_dtype)
         ver = pe._current_version()
         if ver == self._packed_version:
+            if any(pe.t.get(k) is not v for k, v in self._captured.items()):
+                pe.t = dict(self._captured)  # rebound by that eager rollout: the captured buffers hold this version's values
             return
-        fresh = pe.refresh()
+        fresh = pe.refresh(act_dtype=self._act_dtype)
         for k, held in self._captured.items():
             new = fresh.get(k)
             if torch.is_tensor(held):
@@ -94,9 +101,11 @@ class GraphedRollout:
         pe.t = dict(self._captured)
         self._packed_version = ver
 
-    def enqueue(self, batch) -> None:
+    def enqueue(self, batch, call_index: int | None = None) -> None:
         """Copy the instances into the static input buffers and replay the graph on the CURRENT stream — no host sync.
-        ``finish()`` (same stream) performs the rollout's one read-back."""
+        ``finish()`` (same stream) performs the rollout's one read-back. ``call_index``: position of this rollout in the
+        caller's stream of submissions — ``PipelinedRollout`` passes ONE counter over all its slots, so two slots captured
+        with the same ``seed=`` never replay the same noise (default: this rollout's own call count)."""
         if batch.batch_size[0] != self.batch:
             raise ValueError(f"captured for {self.batch} instances, got {batch.batch_size[0]}")
         with torch.inference_mode():
@@ -107,7 +116,8 @@ class GraphedRollout:
             if self._fused:
                 self._sync_packed_weights()
             self._calls += 1
-            self.seed_dev.fill_(self._calls * 0x9E3779B97F4A7C15 % (1 << 62))
+            index = self._calls if call_index is None else int(call_index)
+            self.seed_dev.fill_(index * 0x9E3779B97F4A7C15 % (1 << 62))
             self.graph.replay()
 
     def finish(self) -> dict:
@@ -117,6 +127,19 @@ class GraphedRollout:
     def __call__(self, batch) -> dict:
         self.enqueue(batch)
         return self.finish()
+
+
+def _tensors_of(obj):
+    """Every CUDA tensor reachable from a rollout's output dict (the TensorDict of the final state included)."""
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            yield obj
+    elif isinstance(obj, dict) or hasattr(obj, "items"):
+        for _, v in obj.items():
+            yield from _tensors_of(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors_of(v)
 
 
 class PipelinedRollout:
@@ -150,6 +173,7 @@ class PipelinedRollout:
         self.policy = policy
         self._pending = [False] * self.depth
         self._next = 0
+        self._submitted = 0  # ONE counter over all slots: the device-resident Philox seed word is derived from it
         self._weights = self._weights_version()
 
     def _weights_version(self):
@@ -174,8 +198,9 @@ class PipelinedRollout:
             self._weights = ver
         s = self.streams[k]
         s.wait_stream(torch.cuda.current_stream())  # the batch may have been produced on the caller's stream
+        self._submitted += 1
         with torch.cuda.stream(s):
-            self.slots[k].enqueue(batch)
+            self.slots[k].enqueue(batch, call_index=self._submitted)
         self._pending[k] = True
         self._next = (k + 1) % self.depth
         return k
@@ -183,8 +208,16 @@ class PipelinedRollout:
     def collect(self, ticket: int) -> dict:
         if not self._pending[ticket]:
             raise RuntimeError("nothing pending on this ticket")
-        with torch.cuda.stream(self.streams[ticket]):  # the read-back is ordered after the slot's replay: same stream
+        side = self.streams[ticket]
+        with torch.cuda.stream(side):  # the read-back is ordered after the slot's replay: same stream
             out = self.slots[ticket].finish()
+        # finish() launches further kernels on the slot's stream AFTER its read-back (the trimmed action copy, the summed
+        # log-likelihood, rewards of the environments without a device-side horizon) and allocates their outputs from that
+        # stream's pool: hand both over to the caller's stream
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(side)
+        for v in _tensors_of(out):
+            v.record_stream(cur)  # (buffers owned by the graph's private pool are never freed while it lives: a no-op there)
         self._pending[ticket] = False
         return out
 

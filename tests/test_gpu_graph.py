@@ -158,3 +158,56 @@ def test_pipelined_rollouts_equal_eager_over_a_stream_of_batches(env_name, num_l
         new = [pol(env.reset(b), env, phase="test", decode_type="greedy")["reward"].clone() for b in batches[:3]]
     got = [out["reward"].clone() for out in pipe.map(batches[:3])]
     assert all(torch.equal(a, b) for a, b in zip(got, new)) and not torch.equal(new[0], want[0]["reward"])
+
+
+def test_pipelined_fixed_seed_sampling_never_repeats_noise_across_slots():
+    """with ``seed=`` both slots capture the same Philox key; the per-replay seed word must come from
+    ONE submission counter, or batches 2k and 2k + 1 replay bit-identical noise (best-of-N sampling of one batch would
+    return its samples in duplicated pairs)."""
+    from rl4co_amd.graph import PipelinedRollout
+
+    pol, env, d1, _ = _setup("tsp", 50, 256)
+    pipe = PipelinedRollout(pol, env, d1, decode_type="sampling", depth=2, seed=1234)
+    tours = [out["actions"].clone() for out in pipe.map([d1] * 6)]
+    for i in range(len(tours)):
+        for j in range(i + 1, len(tours)):
+            assert not torch.equal(tours[i], tours[j]), (i, j)
+
+
+@pytest.mark.parametrize("env_name,num_loc", [("cvrp", 50), ("op", 20)])
+def test_pipelined_outputs_are_handed_over_to_the_callers_stream(env_name, num_loc):
+    """finish() launches on the slot's side stream after its read-back (trimmed actions, summed
+    log-likelihood, OP's reward): the caller consumes them on ITS stream right away, with memory churn in between."""
+    from rl4co_amd.graph import PipelinedRollout
+
+    pol, env, d1, d2 = _setup(env_name, num_loc, 512)
+    torch.manual_seed(5)
+    batches = [d1, d2] + [env.generator(batch_size=[512]) for _ in range(6)]
+    with torch.inference_mode():
+        want = [{k: v.clone() for k, v in pol(env.reset(b), env, phase="test", decode_type="greedy").items()
+                 if k in ("actions", "reward", "log_likelihood")} for b in batches]
+    pipe = PipelinedRollout(pol, env, d1, decode_type="greedy", depth=2)
+    sums = []
+    for out in pipe.map(batches):
+        # consumed on the current (default) stream immediately, no synchronize; allocations recycle freed blocks
+        sums.append((out["log_likelihood"].double().sum() + out["reward"].double().sum() + out["actions"].double().sum()).clone())
+        junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(4)]
+        del junk
+    for i, s in enumerate(sums):
+        w = want[i]["log_likelihood"].double().sum() + want[i]["reward"].double().sum() + want[i]["actions"].double().sum()
+        assert torch.equal(s, w), i
+
+
+def test_graphed_rollout_survives_an_eager_rollout_in_the_other_16bit_regime():
+    """an eager fp16 rollout between replays of a bf16 capture re-packs the weights in fp16; the next
+    replay must bring the packed encoder back to bf16 without claiming a layout change."""
+    from rl4co_amd.graph import GraphedRollout
+
+    pol, env, d1, d2 = _setup("tsp", 50, 256)
+    g = GraphedRollout(pol, env, d1, decode_type="greedy")
+    want = g(d1)["reward"].clone()
+    pol.encoder_autocast, pol.cache_dtype = torch.float16, torch.float16
+    with torch.inference_mode():
+        pol(env.reset(d2), env, phase="test", decode_type="greedy")
+    pol.encoder_autocast, pol.cache_dtype = torch.bfloat16, torch.bfloat16
+    assert torch.equal(g(d1)["reward"], want)
