@@ -416,6 +416,21 @@ typedef struct rl4co_am_encoder_args {
 int rl4co_am_encoder(const rl4co_am_encoder_args* args, void* stream);
 int rl4co_am_encoder_max_nodes(void);
 
+/* The same fused encoder + cache fold in EXACT fp32 (csrc/am_encoder_f32.hip, v_mfma_f32_16x16x4_f32: f32 operands,
+ * f32 accumulate, a k-ordered fmaf chain) — the encoder of the bit-identical configuration (no autocast), replacing the
+ * same reference functions as rl4co_am_encoder with arithmetic in ATen's own order where that is knowable: GEMM then
+ * + bias, x + branch, norm as x * alpha + beta, softmax as exp(s - max) / sum. Same argument struct, read this way:
+ *   act_dtype   RL4CO_DT_F32; cache_dtype any of F32 / BF16 / F16 (planes rounded once on the way out)
+ *   w*_packed   fp32, [out/16 tiles][in/16 chunks][64 lanes][4]: lane = 16 g + c, element s = W[16 tile + c][16 chunk + 4 g + s]
+ *               (rl4co_amd/encoder.py: pack_weight_f32); the query rows of Wqkv and bqkv carry 1 / sqrt(16) (exact)
+ *   bo, b2      ADDED by the kernel (the 16-bit kernel has them folded into the norm's shift)
+ *   n*_scale / n*_shift   norm = 0: alpha = weight / sqrt(running_var + eps), beta = bias - running_mean * alpha;
+ *               norm = 1: gamma, beta (alpha / beta built per instance from two-pass statistics)
+ *   wfold_packed  3 + (ctx_first != NULL) + (ctx_cur != NULL) blocks of [128,128] in that order; with both context
+ *               tables NULL the three blocks are the raw rows of project_node_embeddings (the reference's own
+ *               association of the decoder, cache.py fold=False) and `hidden` carries the node embeddings. */
+int rl4co_am_encoder_f32(const rl4co_am_encoder_args* args, void* stream);
+
 /* --------------------------------------------------------------------------
  * N1  teacher-forced log-likelihood, backward pass.
  *

@@ -44,6 +44,29 @@ def pack_weight(w: Tensor, dtype: torch.dtype = torch.bfloat16) -> Tensor:
     return t.permute(0, 2, 3, 1, 4).contiguous().view(out_f // 32, in_f // 16, 64, 8)
 
 
+def pack_weight_f32(w: Tensor) -> Tensor:
+    """nn.Linear weight [out,in] -> fp32 [out/16, in/16, 64, 4] in the fragment order of ``v_mfma_f32_16x16x4_f32``
+    (csrc/am_encoder_f32.hip): lane = 16*g + c, element s = W[16*tile + c][16*chunk + 4*g + s]."""
+    out_f, in_f = w.shape
+    assert out_f % 16 == 0 and in_f % 16 == 0, (out_f, in_f)
+    t = w.detach().float().view(out_f // 16, 16, in_f // 16, 4, 4)  # [tile, c, chunk, g, s]
+    return t.permute(0, 2, 3, 1, 4).contiguous().view(out_f // 16, in_f // 16, 64, 4)
+
+
+def _norm_affine_f32(norm_module) -> tuple[Tensor, Tensor, int]:
+    """(alpha, beta, kind) the way ATen's CPU batch-norm kernel forms them (native/cpu/batch_norm_kernel.cpp):
+    invstd = 1 / sqrt(var + eps), alpha = invstd * weight, beta = bias - mean * alpha — eval-mode batch norm; instance norm
+    hands over (gamma, beta) and the kernel builds the same pair from the instance's own statistics."""
+    n = norm_module.normalizer
+    if norm_module.kind == "batch":
+        invstd = 1.0 / torch.sqrt(n.running_var.float() + n.eps)
+        alpha = invstd * n.weight.detach().float()
+        return alpha, n.bias.detach().float() - n.running_mean.float() * alpha, 0
+    if norm_module.kind == "instance":
+        return n.weight.detach().float(), n.bias.detach().float(), 1
+    raise NotImplementedError("fused encoder supports batch (eval) and instance normalisation")
+
+
 def _norm_affine(norm_module) -> tuple[Tensor, Tensor, int]:
     """(scale, shift, kind): eval-mode batch norm folded to an affine; instance norm -> gamma/beta."""
     n = norm_module.normalizer
@@ -86,8 +109,8 @@ class PackedEncoder:
         if force:
             self._tensors, self.version = None, None
         if act_dtype is not None:
-            if act_dtype not in (torch.bfloat16, torch.float16):
-                raise TypeError(f"the fused encoder computes in bfloat16 or float16, not {act_dtype}")
+            if act_dtype not in (torch.bfloat16, torch.float16, torch.float32):
+                raise TypeError(f"the fused encoder computes in bfloat16, float16 or float32, not {act_dtype}")
             self.act_dtype = act_dtype
         ver = self._current_version()
         if ver == self.version:
@@ -96,7 +119,8 @@ class PackedEncoder:
         enc, dec = pol.encoder, pol.decoder
         layers = list(enc.net.layers)
         f32 = lambda x: x.detach().float().contiguous()  # noqa: E731
-        pack_weight = lambda w: globals()["pack_weight"](w, self.act_dtype)  # noqa: E731
+        exact = self.act_dtype == torch.float32  # csrc/am_encoder_f32.hip: fp32 MFMA, the reference's own arithmetic order
+        pack_weight = (pack_weight_f32 if exact else lambda w: globals()["pack_weight"](w, self.act_dtype))  # noqa: E731
         t: dict[str, Tensor] = {}
         ie = enc.init_embedding
         if pol.env_name == "pdp":
@@ -107,8 +131,9 @@ class PackedEncoder:
         if pol.env_name != "tsp":
             t["w_depot"], t["b_depot"] = f32(ie.init_embed_depot.weight), f32(ie.init_embed_depot.bias)
         # the query rows of Wqkv (and their bias) carry head_dim^-1/2 * log2(e): the kernel's softmax is exp2(q . k)
+        # (fp32 kernel: only the power of two — exact — and exp(s - max) as exp2((s - max) * log2 e) in the kernel)
         qscale = torch.ones(3 * EMBED_DIM, 1, device=layers[0][0].module.Wqkv.weight.device)
-        qscale[:EMBED_DIM] = 0.25 * 1.4426950408889634
+        qscale[:EMBED_DIM] = 0.25 if exact else 0.25 * 1.4426950408889634
         t["wqkv"] = torch.stack([pack_weight(l[0].module.Wqkv.weight.detach().float() * qscale) for l in layers]).contiguous()
         t["bqkv"] = torch.stack([f32(l[0].module.Wqkv.bias.detach().float() * qscale[:, 0]) for l in layers]).contiguous()
         t["wo"] = torch.stack([pack_weight(l[0].module.out_proj.weight) for l in layers]).contiguous()
@@ -125,8 +150,8 @@ class PackedEncoder:
         for name, idx, bias_of in (("n1", 1, lambda l: l[0].module.out_proj.bias), ("n2", 3, lambda l: l[2].module.lins[1].bias)):
             sc, sh = [], []
             for l in layers:
-                a, b, k = _norm_affine(l[idx])
-                if k == 0:
+                a, b, k = (_norm_affine_f32 if exact else _norm_affine)(l[idx])
+                if k == 0 and not exact:  # (the fp32 kernel adds bo / b2 itself, in the reference's order)
                     b = b + bias_of(l).detach().float() * a
                 sc.append(a), sh.append(b), kinds.add(k)
             t[f"{name}_scale"], t[f"{name}_shift"] = torch.stack(sc).contiguous(), torch.stack(sh).contiguous()
@@ -136,6 +161,10 @@ class PackedEncoder:
         blocks = fold_weights(pol.env_name, dec.project_node_embeddings.weight.detach().float(),
                               dec.pointer.project_out.weight.detach().float(), w_ctx)
         t["wfold"] = torch.stack([pack_weight(b) for b in blocks]).contiguous()
+        if exact and pol.env_name in ("tsp", "cvrp"):
+            # fold=False (the reference's own association of the decoder, cache.py): the three raw planes K_g, V_g, K_l
+            w_node = dec.project_node_embeddings.weight.detach().float()
+            t["wnode"] = torch.stack([pack_weight(w_node[i * EMBED_DIM:(i + 1) * EMBED_DIM]) for i in range(3)]).contiguous()
         t["w_fixed"] = f32(dec.project_fixed_context.weight) if dec.use_graph_context else None
         if pol.env_name == "tsp":
             t["q_step0"] = torch.mv(w_ctx, dec.context_embedding.W_placeholder.detach().float()).contiguous()
@@ -159,12 +188,20 @@ class PackedEncoder:
         return kind in ("batch", "instance") and td["locs"].is_cuda
 
     def encode(self, td, cache_dtype: torch.dtype, want_hidden: bool = False,
-               act_dtype: torch.dtype | None = None) -> tuple[FoldedCache, Tensor | None]:
+               act_dtype: torch.dtype | None = None, fold: bool = True) -> tuple[FoldedCache, Tensor | None]:
         """``act_dtype``: bfloat16 / float16 = the autocast regime the encoder is asked to compute in; the planes are
-        written as ``cache_dtype`` = float32 or that same 16-bit type."""
+        written as ``cache_dtype`` = float32 or that same 16-bit type. float32 = the exact-fp32 kernel
+        (``rl4co_am_encoder_f32``; planes in any of the three types). ``fold=False`` (fp32 kernel, tsp / cvrp): the
+        reference's own association of the decoder — raw K_g / V_g / K_l planes and the node embeddings, no context tables."""
         t = self.refresh(act_dtype=act_dtype)
-        if cache_dtype not in (torch.float32, self.act_dtype):
+        exact = self.act_dtype == torch.float32
+        if exact:
+            if cache_dtype not in (torch.float32, torch.bfloat16, torch.float16):
+                raise TypeError(f"cache planes must be float32, bfloat16 or float16, got {cache_dtype}")
+        elif cache_dtype not in (torch.float32, self.act_dtype):
             raise TypeError(f"cache planes must be float32 or the encoder's {self.act_dtype}, got {cache_dtype}")
+        if not fold and not (exact and "wnode" in t):
+            raise NotImplementedError("fold=False is served by the fp32 encoder kernel for tsp / cvrp")
         pol = self.policy
         locs = td["locs"]
         if locs.dtype != torch.float32 or not locs.is_contiguous():
@@ -173,10 +210,10 @@ class PackedEncoder:
         dev = locs.device
         d = EMBED_DIM
         kvl = torch.empty((3, b, n, d), dtype=cache_dtype, device=dev)
-        ctx_cur = torch.empty((b, n, d), dtype=torch.float32, device=dev)
-        ctx_first = torch.empty((b, n, d), dtype=torch.float32, device=dev) if pol.env_name == "tsp" else None
+        ctx_cur = torch.empty((b, n, d), dtype=torch.float32, device=dev) if fold else None
+        ctx_first = torch.empty((b, n, d), dtype=torch.float32, device=dev) if (fold and pol.env_name == "tsp") else None
         q_bias = torch.empty((b, d), dtype=torch.float32, device=dev) if t["w_fixed"] is not None else None
-        hidden = torch.empty((b, n, d), dtype=torch.float32, device=dev) if want_hidden else None
+        hidden = torch.empty((b, n, d), dtype=torch.float32, device=dev) if (want_hidden or not fold) else None
         a = AmEncoderArgs()
         a.env = {"tsp": _lib.ENV_TSP, "pdp": _lib.ENV_PDP}.get(pol.env_name, _lib.ENV_CVRP)
         a.B, a.N, a.num_layers, a.norm = b, n, self.num_layers, self.norm_kind
@@ -205,10 +242,19 @@ class PackedEncoder:
         a.wqkv_packed, a.bqkv, a.wo_packed, a.bo = ptr(t["wqkv"]), ptr(t["bqkv"]), ptr(t["wo"]), ptr(t["bo"])
         a.n1_scale, a.n1_shift, a.n2_scale, a.n2_shift = (ptr(t[k]) for k in ("n1_scale", "n1_shift", "n2_scale", "n2_shift"))
         a.w1_packed, a.b1, a.w2_packed, a.b2 = ptr(t["w1"]), ptr(t["b1"]), ptr(t["w2"]), ptr(t["b2"])
-        a.wfold_packed, a.w_fixed = ptr(t["wfold"]), ptr(t["w_fixed"])
+        a.wfold_packed, a.w_fixed = ptr(t["wfold"] if fold else t["wnode"]), ptr(t["w_fixed"])
         a.kvl, a.kvl_plane_stride, a.kvl_batch_stride = kvl.data_ptr(), kvl.stride(0), kvl.stride(1)
         a.ctx_first, a.ctx_cur, a.q_bias, a.hidden = ptr(ctx_first), ptr(ctx_cur), ptr(q_bias), ptr(hidden)
-        st = _lib.lib().rl4co_am_encoder(C.byref(a), torch.cuda.current_stream().cuda_stream)
-        _lib.check(st, "rl4co_am_encoder")
+        entry = "rl4co_am_encoder_f32" if exact else "rl4co_am_encoder"
+        st = getattr(_lib.lib(), entry)(C.byref(a), torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, entry)
+        if not fold:
+            dec = pol.decoder
+            ph = getattr(dec.context_embedding, "W_placeholder", None)
+            cache = FoldedCache(pol.env_name, kvl, None, None, q_bias, None, None, None, unfold=True, node_embed=hidden,
+                                w_ctx_t=dec.context_embedding.project_context.weight.detach().float().t().contiguous(),
+                                w_out_t=dec.pointer.project_out.weight.detach().float().t().contiguous(),
+                                w_placeholder=None if ph is None else ph.detach().float().contiguous())
+            return cache, hidden
         cache = FoldedCache(pol.env_name, kvl, ctx_first, ctx_cur, q_bias, t["q_step0"], t["w_cap"], t["w_time"])
         return cache, hidden

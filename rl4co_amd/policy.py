@@ -672,11 +672,19 @@ class AttentionModelPolicy(nn.Module):
         use_fused = (self.fused_encoder and self.fold and regime16 is not None and not grad_path
                      and cache_dtype in (torch.float32, regime16)
                      and not return_init_embeds and self._packed_encoder().supported(td))
+        # fp32 regime (no autocast: the bit-identical configuration): the exact-fp32 MFMA encoder (csrc/am_encoder_f32.hip),
+        # planes in any type, also with fold=False (tsp / cvrp: the reference's own association of the decoder)
+        use_fused_f32 = (self.fused_encoder and self._encoder_regime() is None and not grad_path and td["locs"].is_cuda
+                         and (self.fold or self.env_name in ("tsp", "cvrp"))
+                         and not return_init_embeds and self._packed_encoder().supported(td))
+        if use_fused_f32:
+            use_fused, regime16 = True, torch.float32
         if use_fused:
             if self.encode_events is not None:  # bench.py: HIP events around the encoder launch
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
-            cache, hidden = self._packed_encoder().encode(td, cache_dtype, want_hidden=return_hidden, act_dtype=regime16)
+            cache, hidden = self._packed_encoder().encode(td, cache_dtype, want_hidden=return_hidden, act_dtype=regime16,
+                                                          fold=self.fold)
             if self.encode_events is not None:
                 ev1.record()
                 self.encode_events.append((ev0, ev1))
