@@ -66,18 +66,20 @@ template <int TT, bool W_IS_A>
 __device__ inline void gemm16(f32x4 (&acc)[TT], f32x4 (&wf)[8], const float* xs, int lane, const float* nxt, int nxt_chunks,
                               int nxt_tile, int nxt_j0) {
   const float* xrow = xs + (lane & 15) * kRS + 4 * (lane >> 4);
-  f32x4 x[TT];  // ONE set of activation fragments: tile tt's registers take chunk j + 1 right after their last MFMA of chunk j
+  f32x4 x[2][TT];  // activation fragments of chunk j + 1 requested while chunk j computes (4 TT MFMAs = ~900 cycles)
 #pragma unroll
-  for (int tt = 0; tt < TT; ++tt) x[tt] = *reinterpret_cast<const f32x4*>(xrow + 16 * tt * kRS);
+  for (int tt = 0; tt < TT; ++tt) x[0][tt] = *reinterpret_cast<const f32x4*>(xrow + 16 * tt * kRS);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
+    if (j + 1 < 8) {
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) x[(j + 1) & 1][tt] = *reinterpret_cast<const f32x4*>(xrow + 16 * tt * kRS + 16 * (j + 1));
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
-      for (int tt = 0; tt < TT; ++tt) {
-        acc[tt] = W_IS_A ? mfma4(wf[j][s], x[tt][s], acc[tt]) : mfma4(x[tt][s], wf[j][s], acc[tt]);
-        if (s == 3 && j + 1 < 8) x[tt] = *reinterpret_cast<const f32x4*>(xrow + 16 * tt * kRS + 16 * (j + 1));
-      }
+      for (int tt = 0; tt < TT; ++tt)
+        acc[tt] = W_IS_A ? mfma4(wf[j][s], x[j & 1][tt][s], acc[tt]) : mfma4(x[j & 1][tt][s], wf[j][s], acc[tt]);
     }
     if (nxt) wf[j] = load_w(nxt, nxt_chunks, nxt_tile, nxt_j0 + j, lane);
     __builtin_amdgcn_sched_barrier(0);  // chunk by chunk: hoisted, the LDS reads of all eight chunks would be live at once

@@ -135,7 +135,9 @@ def test_fp32_policy_rollout_never_reaches_the_torch_encoder(env_name, num_loc):
     with torch.inference_mode():
         out = pol(td, env, phase="test", decode_type="greedy", return_hidden=True)
     pol.encoder.forward = real
-    assert _rel(out["hidden"], h_torch) <= REL_TOL
+    # (CVRPTW embeds raw time windows up to 480: activations of 1e2 and softmax logits of 1e2 - 1e3, where one ulp of a
+    # score moves a probability by 1e-4 — two fp32 evaluations in different summation orders differ at that level)
+    assert _rel(out["hidden"], h_torch) <= (1e-4 if env_name == "cvrptw" else REL_TOL)
     assert torch.isfinite(out["reward"]).all() and out["actions"].shape[0] == 96
     # the same rollout from the torch encoder's embeddings: a random-init policy is near-uniform (every step a near-tie at
     # the 1e-2 level), so a few tours may legitimately differ — most must not
