@@ -431,6 +431,15 @@ int rl4co_am_encoder_max_nodes(void);
  *               association of the decoder, cache.py fold=False) and `hidden` carries the node embeddings. */
 int rl4co_am_encoder_f32(const rl4co_am_encoder_args* args, void* stream);
 
+/* The exact-fp32 encoder + cache fold for graphs of ANY size (csrc/am_tokens_f32.hip; BASELINE configs[4], CVRP-500): the
+ * same arithmetic as rl4co_am_encoder_f32 (same GEMM routine and summation order) as launches over tiles of 128 nodes —
+ * init embedding, per layer [Q/K/V projection, attention with keys / values streamed and an online softmax, out-proj +
+ * norm + MLP + norm], fold, graph context. Same argument struct and packing as rl4co_am_encoder_f32; norm must be 0
+ * (batch norm, eval). `workspace`: at least rl4co_am_encoder_tokens_f32_workspace(B, N) bytes of device memory, 16-byte
+ * aligned, contents irrelevant on entry (five [B N, 128] fp32 activation buffers and the per-head transposed values). */
+int rl4co_am_encoder_tokens_f32(const rl4co_am_encoder_args* args, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t rl4co_am_encoder_tokens_f32_workspace(int B, int N);
+
 /* --------------------------------------------------------------------------
  * N1  teacher-forced log-likelihood, backward pass.
  *

@@ -30,115 +30,11 @@
 #include <hip/hip_runtime.h>
 
 #include "common.h"
+#include "enc_f32.h"
 
 namespace {
 
-constexpr int kD = RL4CO_EMBED_DIM;
-constexpr int kFF = 512;
-constexpr int kRS = kD + 4;  // LDS row stride (floats): 528-byte rows — the 16 lanes of a ds_read_b128 group (one g) hit 16 distinct bank quads
-constexpr int kThreads = 512;
-constexpr int kBiasFloats = 3 * kD + kFF + kD + kD;  // per layer: bqkv [384] | b1 [512] | bo [128] | b2 [128]
-constexpr float kLog2e = 1.4426950408889634f;
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ inline f32x4 mfma4(float a, float b, const f32x4& c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-__device__ inline f32x4 zero4() {
-  f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
-  return z;
-}
-
-// packed weight fragment: [tile of 16 output dims][16-k chunk][64 lanes][4] fp32 (rl4co_amd/encoder.py: pack_weight_f32)
-__device__ inline f32x4 load_w(const float* packed, int chunks_total, int tile, int j, int lane) {
-  return *reinterpret_cast<const f32x4*>(packed + (((int64_t)tile * chunks_total + j) * 64 + lane) * 4);
-}
-__device__ inline void load_wfrags(f32x4 (&wf)[8], const float* packed, int chunks_total, int tile, int j0, int lane) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) wf[j] = load_w(packed, chunks_total, tile, j0 + j, lane);
-}
-
-// acc[tt] += (W tile) . X^T over K = 128 (8 chunks of 16, four MFMA steps each). W_IS_A: transposed form (rows = dims,
-// columns = tokens); otherwise plain form (rows = tokens, columns = dims). The weight fragments `wf` were requested one
-// call ahead; as soon as chunk j has fed its last MFMA its registers take chunk j of the NEXT GEMM (nxt; nullptr: none),
-// whose L2 round trip hides under the rest of this call. A chunk is 4 TT MFMAs of 32 cycles; the activation fragments
-// follow the same rule tile by tile (next use (TT - 1) MFMAs = ~200 cycles later; the SIMD's other wave covers the rest).
-template <int TT, bool W_IS_A>
-__device__ inline void gemm16(f32x4 (&acc)[TT], f32x4 (&wf)[8], const float* xs, int lane, const float* nxt, int nxt_chunks,
-                              int nxt_tile, int nxt_j0) {
-  const float* xrow = xs + (lane & 15) * kRS + 4 * (lane >> 4);
-  f32x4 x[2][TT];  // activation fragments of chunk j + 1 requested while chunk j computes (4 TT MFMAs = ~900 cycles)
-#pragma unroll
-  for (int tt = 0; tt < TT; ++tt) x[0][tt] = *reinterpret_cast<const f32x4*>(xrow + 16 * tt * kRS);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    if (j + 1 < 8) {
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt) x[(j + 1) & 1][tt] = *reinterpret_cast<const f32x4*>(xrow + 16 * tt * kRS + 16 * (j + 1));
-    }
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt)
-        acc[tt] = W_IS_A ? mfma4(wf[j][s], x[j & 1][tt][s], acc[tt]) : mfma4(x[j & 1][tt][s], wf[j][s], acc[tt]);
-    }
-    if (nxt) wf[j] = load_w(nxt, nxt_chunks, nxt_tile, nxt_j0 + j, lane);
-    __builtin_amdgcn_sched_barrier(0);  // chunk by chunk: hoisted, the LDS reads of all eight chunks would be live at once
-  }
-}
-
-// transposed-form tile -> LDS rows [token][dim]: the lane's four registers are four consecutive dims of its token
-template <int TT>
-__device__ inline void store_t(float* ys, const f32x4 (&acc)[TT], int dim0, int lane) {
-  float* row = ys + (lane & 15) * kRS + dim0 + 4 * (lane >> 4);
-#pragma unroll
-  for (int tt = 0; tt < TT; ++tt) *reinterpret_cast<f32x4*>(row + 16 * tt * kRS) = acc[tt];
-}
-
-// y = Norm(x + (y + bias)) for the wave's 16-dim tile, back into xs. nn/ops.py:9-15 (skip), 30-54 (norm).
-template <int TT>
-__device__ inline void residual_norm(float* xs, f32x4 (&y)[TT], int dim0, const float* bias_lds, const float* na, const float* nb,
-                                     int norm, int N, int lane) {
-  const int c = lane & 15, g = lane >> 4;
-  const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_lds + dim0 + 4 * g);
-  const f32x4 ga = *reinterpret_cast<const f32x4*>(na + dim0 + 4 * g);
-  const f32x4 be = *reinterpret_cast<const f32x4*>(nb + dim0 + 4 * g);
-  float* row = xs + c * kRS + dim0 + 4 * g;
-#pragma unroll
-  for (int tt = 0; tt < TT; ++tt) {
-    const f32x4 x = *reinterpret_cast<const f32x4*>(row + 16 * tt * kRS);
-    y[tt] = x + (y[tt] + bias);
-  }
-  f32x4 alpha, beta;
-  if (norm == 1) {
-    // instance norm: statistics per (instance, channel) over the N nodes, two passes as ATen's CPU kernel takes them
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float s = 0.0f;
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt) s += (16 * tt + c < N) ? y[tt][r] : 0.0f;
-      s = rl4co::bfly_sum<1, 16>(s);
-      const float mean = s / (float)N;
-      float v = 0.0f;
-#pragma unroll
-      for (int tt = 0; tt < TT; ++tt) {
-        const float d = y[tt][r] - mean;
-        v += (16 * tt + c < N) ? d * d : 0.0f;
-      }
-      v = rl4co::bfly_sum<1, 16>(v);
-      const float invstd = 1.0f / sqrtf(v / (float)N + 1e-5f);
-      alpha[r] = invstd * ga[r];
-      beta[r] = be[r] - mean * alpha[r];
-    }
-  } else {
-    alpha = ga;  // batch norm in eval mode: (alpha, beta) from the running statistics, built on the host the same way
-    beta = be;
-  }
-#pragma unroll
-  for (int tt = 0; tt < TT; ++tt) {
-    y[tt] = y[tt] * alpha + beta;  // (-ffp-contract=off: a multiply and an add, as the vectorised CPU kernel)
-    *reinterpret_cast<f32x4*>(row + 16 * tt * kRS) = y[tt];
-  }
-}
+using namespace rl4co_f32;
 
 template <int TT>
 __global__ void __launch_bounds__(kThreads) am_encoder_f32_kernel(const rl4co_am_encoder_args a) {
@@ -173,78 +69,8 @@ __global__ void __launch_bounds__(kThreads) am_encoder_f32_kernel(const rl4co_am
   load_wfrags(wf, wqkv_all, 8, w, 0, lane);
 
   // ---- init embedding (K = 2 .. 6: plain VALU), padding rows zeroed ----------------------------------------------------
-  {
-    float* lsh = ys;  // [2 N] coordinates, then up to four [N] feature rows
-    const float* loc = a.locs + (int64_t)b * N * 2;
-    const bool pdp = a.env == RL4CO_ENV_PDP;  // depot | pickups (x, y, x', y' of the delivery) | deliveries, init.py:335-360
-    const bool cvrp = a.env == RL4CO_ENV_CVRP;
-    const bool depot = cvrp || pdp;
-    const int half = (N - 1) / 2;
-    for (int i = tid; i < 2 * N; i += kThreads) lsh[i] = loc[i];
-    const bool four = cvrp && a.feature4 != nullptr;  // PCTSP: (x, y, expected prize, penalty), init.py:283-312
-    if (cvrp)
-      for (int i = tid; i < N - 1; i += kThreads) lsh[2 * N + 1 + i] = a.demand[(int64_t)b * (N - 1) + i];
-    const bool six = four && a.feature5 != nullptr && a.feature6 != nullptr;  // CVRPTW: + tw start, tw end, service time
-    if (four)
-      for (int i = tid; i < N - 1; i += kThreads) lsh[3 * N + 1 + i] = a.feature4[(int64_t)b * (N - 1) + i];
-    if (six)
-      for (int i = tid; i < N - 1; i += kThreads) {
-        lsh[4 * N + 1 + i] = a.feature5[(int64_t)b * (N - 1) + i];
-        lsh[5 * N + 1 + i] = a.feature6[(int64_t)b * (N - 1) + i];
-      }
-    // thread = four consecutive channels (tid & 31) x one of sixteen token groups
-    const int d0 = 4 * (tid & 31);
-    const int ws = six ? 6 : ((four || pdp) ? 4 : (cvrp ? 3 : 2));  // row stride of w_init
-    float wq[4][6], bq[4], dq[4][2], dbq[4], eq[4][2], ebq[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-#pragma unroll
-      for (int f = 0; f < 6; ++f) wq[k][f] = f < ws ? a.w_init[ws * (d0 + k) + f] : 0.0f;
-      bq[k] = a.b_init[d0 + k];
-      dq[k][0] = depot ? a.w_depot[2 * (d0 + k)] : 0.0f;
-      dq[k][1] = depot ? a.w_depot[2 * (d0 + k) + 1] : 0.0f;
-      dbq[k] = depot ? a.b_depot[d0 + k] : 0.0f;
-      eq[k][0] = pdp ? a.w_extra[2 * (d0 + k)] : 0.0f;
-      eq[k][1] = pdp ? a.w_extra[2 * (d0 + k) + 1] : 0.0f;
-      ebq[k] = pdp ? a.b_extra[d0 + k] : 0.0f;
-    }
-    stage_biases(0);
-    __syncthreads();
-    for (int tok = tid >> 5; tok < kRows; tok += kThreads / 32) {
-      f32x4 v = zero4();
-      if (tok < N) {
-        const float x = lsh[2 * tok], y = lsh[2 * tok + 1];
-        float f2 = 0.0f, f3 = 0.0f, f4 = 0.0f, f5 = 0.0f;
-        if (pdp && tok <= half) {
-          f2 = lsh[2 * (tok + half)];
-          f3 = lsh[2 * (tok + half) + 1];
-        } else if (cvrp) {
-          f2 = lsh[2 * N + tok];
-          if (four) f3 = lsh[3 * N + tok];
-          if (six) {
-            f4 = lsh[4 * N + tok];
-            f5 = lsh[5 * N + tok];
-          }
-        }
-        const bool is_depot = depot && tok == 0, is_delivery = pdp && tok > half;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          float r;  // the Linear as a k-ordered fma chain over its 2 .. 6 inputs, bias last (GEMM then + bias)
-          if (is_depot) r = fmaf(dq[k][1], y, dq[k][0] * x) + dbq[k];
-          else if (is_delivery) r = fmaf(eq[k][1], y, eq[k][0] * x) + ebq[k];
-          else {
-            r = fmaf(wq[k][1], y, wq[k][0] * x);
-            if (ws > 2) r = fmaf(wq[k][2], f2, r);
-            if (ws > 3) r = fmaf(wq[k][3], f3, r);
-            if (ws > 4) r = fmaf(wq[k][5], f5, fmaf(wq[k][4], f4, r));
-            r += bq[k];
-          }
-          v[k] = r;
-        }
-      }
-      *reinterpret_cast<f32x4*>(xs + tok * kRS + d0) = v;
-    }
-  }
+  stage_biases(0);
+  init_embed_rows(a, b, 0, kRows, xs, ys, tid);  // (ys is free here: the features are staged in it)
   __syncthreads();
 
   for (int layer = 0; layer < a.num_layers; ++layer) {
@@ -389,36 +215,16 @@ __global__ void __launch_bounds__(kThreads) am_encoder_f32_kernel(const rl4co_am
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) acc[tt] = zero4();
     gemm16<TT, true>(acc, wf, xs, lane, blk + 1 < nblocks ? wf_all + (int64_t)(blk + 1) * kD * kD : static_cast<const float*>(nullptr), 8, w, 0);
-    store_t<TT>(ys, acc, 16 * w, lane);
-    __syncthreads();
-    if (blk < 3 && a.cache_dtype != RL4CO_DT_F32) {  // 16-bit planes from the fp32 encoder: rounded once, on the way out
-      uint16_t* out = static_cast<uint16_t*>(a.kvl) + (int64_t)blk * a.kvl_plane_stride + (int64_t)b * a.kvl_batch_stride;
-      const bool half = a.cache_dtype == RL4CO_DT_F16;
-      for (int i = tid; i < N * 32; i += kThreads) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(ys + (i >> 5) * kRS + 4 * (i & 31));
-        uint16_t h[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (half) {
-            const _Float16 e = (_Float16)v[k];
-            h[k] = __builtin_bit_cast(uint16_t, e);
-          } else {
-            const __bf16 e = (__bf16)v[k];
-            h[k] = __builtin_bit_cast(uint16_t, e);
-          }
-        }
-        *reinterpret_cast<uint2*>(out + (int64_t)(i >> 5) * kD + 4 * (i & 31)) =
-            make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
-      }
+    void* out;
+    int plane16 = 0;
+    if (blk < 3) {
+      plane16 = a.cache_dtype == RL4CO_DT_F32 ? 0 : a.cache_dtype;  // 16-bit planes from the fp32 encoder: rounded once, on the way out
+      const int64_t off = (int64_t)blk * a.kvl_plane_stride + (int64_t)b * a.kvl_batch_stride;
+      out = plane16 ? static_cast<void*>(static_cast<uint16_t*>(a.kvl) + off) : static_cast<void*>(static_cast<float*>(a.kvl) + off);
     } else {
-      float* out;
-      if (blk < 3) out = static_cast<float*>(a.kvl) + (int64_t)blk * a.kvl_plane_stride + (int64_t)b * a.kvl_batch_stride;
-      else if (blk == 3 && a.ctx_first) out = a.ctx_first + (int64_t)b * N * kD;
-      else out = a.ctx_cur + (int64_t)b * N * kD;
-      for (int i = tid; i < N * 32; i += kThreads)
-        *reinterpret_cast<f32x4*>(out + (int64_t)(i >> 5) * kD + 4 * (i & 31)) = *reinterpret_cast<const f32x4*>(ys + (i >> 5) * kRS + 4 * (i & 31));
+      out = ((blk == 3 && a.ctx_first) ? a.ctx_first : a.ctx_cur) + (int64_t)b * N * kD;
     }
-    __syncthreads();
+    fold_block_out<TT>(acc, ys, w, lane, tid, N, out, plane16);
   }
 
   // ---- graph context: project_fixed_context(mean_j h_j)  (decoder.py:216-219) ---------------------------------------------

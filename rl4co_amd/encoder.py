@@ -177,22 +177,25 @@ class PackedEncoder:
         self.t, self.version = t, ver
         return t
 
-    def supported(self, td) -> bool:
+    def supported(self, td, act_dtype: torch.dtype | None = None) -> bool:
+        """``act_dtype=torch.float32``: the exact-fp32 kernels — the fused one up to 128 nodes, the token-tile launches
+        (csrc/am_tokens_f32.hip) for any graph size under batch norm."""
         pol = self.policy
         n = td["action_mask"].shape[-1]
-        if n > _lib.lib().rl4co_am_encoder_max_nodes():
-            return False
         kind = pol.encoder.net.layers[0][1].kind
         if kind == "batch" and pol.training:  # batch statistics couple instances: torch path
             return False
+        if n > _lib.lib().rl4co_am_encoder_max_nodes():
+            return act_dtype == torch.float32 and kind == "batch" and td["locs"].is_cuda and 6 * n * 4 + 68 * 1024 <= 160 * 1024
         return kind in ("batch", "instance") and td["locs"].is_cuda
 
     def encode(self, td, cache_dtype: torch.dtype, want_hidden: bool = False,
-               act_dtype: torch.dtype | None = None, fold: bool = True) -> tuple[FoldedCache, Tensor | None]:
+               act_dtype: torch.dtype | None = None, fold: bool = True, tokens: bool | None = None) -> tuple[FoldedCache, Tensor | None]:
         """``act_dtype``: bfloat16 / float16 = the autocast regime the encoder is asked to compute in; the planes are
         written as ``cache_dtype`` = float32 or that same 16-bit type. float32 = the exact-fp32 kernel
         (``rl4co_am_encoder_f32``; planes in any of the three types). ``fold=False`` (fp32 kernel, tsp / cvrp): the
-        reference's own association of the decoder — raw K_g / V_g / K_l planes and the node embeddings, no context tables."""
+        reference's own association of the decoder — raw K_g / V_g / K_l planes and the node embeddings, no context tables.
+        ``tokens``: force (True) / forbid (False) the token-tile launches of the fp32 encoder (default: beyond 128 nodes)."""
         t = self.refresh(act_dtype=act_dtype)
         exact = self.act_dtype == torch.float32
         if exact:
@@ -245,8 +248,18 @@ class PackedEncoder:
         a.wfold_packed, a.w_fixed = ptr(t["wfold"] if fold else t["wnode"]), ptr(t["w_fixed"])
         a.kvl, a.kvl_plane_stride, a.kvl_batch_stride = kvl.data_ptr(), kvl.stride(0), kvl.stride(1)
         a.ctx_first, a.ctx_cur, a.q_bias, a.hidden = ptr(ctx_first), ptr(ctx_cur), ptr(q_bias), ptr(hidden)
-        entry = "rl4co_am_encoder_f32" if exact else "rl4co_am_encoder"
-        st = getattr(_lib.lib(), entry)(C.byref(a), torch.cuda.current_stream().cuda_stream)
+        if tokens is None:
+            tokens = n > _lib.lib().rl4co_am_encoder_max_nodes()
+        if tokens and not exact:
+            raise NotImplementedError("the token-tile launches exist for the fp32 encoder (16-bit: policy._encode_tokens_bf16)")
+        if tokens:
+            entry = "rl4co_am_encoder_tokens_f32"
+            need = _lib.lib().rl4co_am_encoder_tokens_f32_workspace(b, n)
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)  # (the caching allocator hands the same block back every rollout)
+            st = _lib.lib().rl4co_am_encoder_tokens_f32(C.byref(a), ws.data_ptr(), need, torch.cuda.current_stream().cuda_stream)
+        else:
+            entry = "rl4co_am_encoder_f32" if exact else "rl4co_am_encoder"
+            st = getattr(_lib.lib(), entry)(C.byref(a), torch.cuda.current_stream().cuda_stream)
         _lib.check(st, entry)
         if not fold:
             dec = pol.decoder

@@ -676,7 +676,7 @@ class AttentionModelPolicy(nn.Module):
         # planes in any type, also with fold=False (tsp / cvrp: the reference's own association of the decoder)
         use_fused_f32 = (self.fused_encoder and self._encoder_regime() is None and not grad_path and td["locs"].is_cuda
                          and (self.fold or self.env_name in ("tsp", "cvrp"))
-                         and not return_init_embeds and self._packed_encoder().supported(td))
+                         and not return_init_embeds and self._packed_encoder().supported(td, torch.float32))
         if use_fused_f32:
             use_fused, regime16 = True, torch.float32
         if use_fused:

@@ -170,3 +170,73 @@ def test_graphed_fp32_rollout_equals_eager_and_follows_weight_updates():
         with torch.no_grad():
             for p in pol.parameters():
                 p.mul_(1.03)
+
+
+def _double_reference(pol, td):
+    """The policy's own torch modules in float64 on the GPU: the exact value both fp32 evaluations are measured against."""
+    import copy
+
+    p64 = copy.deepcopy(pol).double()
+    td64 = td.clone() if hasattr(td, "clone") else td
+    td64 = type(td)({k: (v.double() if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in td.items()}, batch_size=td.batch_size)
+    with torch.inference_mode():
+        h, _ = p64.encoder(td64)
+        cache = p64.decoder.precompute_cache(h, torch.float64, torch.float64)
+    return h, cache
+
+
+@pytest.mark.parametrize("env_name,num_loc,batch", [("tsp", 100, 64), ("cvrp", 100, 64), ("tsp", 150, 48), ("cvrp", 200, 32),
+                                                    ("cvrp", 500, 16), ("pdp", 140, 16), ("tsp", 256, 8)])
+def test_fp32_token_tile_encoder_matches_float64_and_the_fused_kernel(env_name, num_loc, batch):
+    """csrc/am_tokens_f32.hip (any graph size) against the float64 evaluation of the same modules, against torch's fp32 GPU
+    path, and — up to 128 nodes — against the fused kernel (same GEMM routine: only the attention's softmax order differs)."""
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    torch.manual_seed(0)
+    pol = AttentionModelPolicy(env_name).cuda().eval()
+    _perturb_norm_stats(pol)
+    env = get_env(env_name, generator_params=dict(num_loc=num_loc, device="cuda"), device="cuda")
+    torch.manual_seed(3)
+    td = env.reset(env.generator(batch_size=[batch]))
+    pe = pol._packed_encoder()
+    assert pe.supported(td, torch.float32)
+    with torch.inference_mode():
+        cache, hidden = pe.encode(td, torch.float32, want_hidden=True, act_dtype=torch.float32, tokens=True)
+    torch.cuda.synchronize()
+    h64, c64 = _double_reference(pol, td)
+    h32, c32 = _torch_fp32(pol, td)
+    checks = {"hidden": (hidden, h64, h32), "ctx_cur": (cache.ctx_cur, c64.ctx_cur, c32.ctx_cur), "q_bias": (cache.q_bias, c64.q_bias, c32.q_bias)}
+    for i in range(3):
+        checks[f"plane{i}"] = (cache.kvl[i], c64.kvl[i], c32.kvl[i])
+    if env_name == "tsp":
+        checks["ctx_first"] = (cache.ctx_first, c64.ctx_first, c32.ctx_first)
+    for nm, (got, exact, torch32) in checks.items():
+        assert torch.isfinite(got).all(), nm
+        e_k = float((got.double() - exact).norm() / exact.norm())
+        e_t = float((torch32.double() - exact).norm() / exact.norm())
+        assert e_k <= REL_TOL and e_k <= 3 * e_t + 2e-7, f"{nm}: kernel {e_k:.3e}, torch fp32 {e_t:.3e}"
+    if td["action_mask"].shape[-1] <= 128:
+        with torch.inference_mode():
+            fused, hf = pe.encode(td, torch.float32, want_hidden=True, act_dtype=torch.float32, tokens=False)
+        assert _rel(hidden, hf) <= 1e-6 and _rel(cache.kvl, fused.kvl) <= 1e-6
+
+
+def test_fp32_rollout_beyond_128_nodes_never_reaches_the_torch_encoder():
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    torch.manual_seed(0)
+    pol = AttentionModelPolicy("cvrp").cuda().eval()
+    env = get_env("cvrp", generator_params=dict(num_loc=300, device="cuda"), device="cuda", check_solution=True)
+    torch.manual_seed(3)
+    td = env.reset(env.generator(batch_size=[32]))
+    pol.encoder.forward = lambda *a, **k: (_ for _ in ()).throw(AssertionError("torch encoder reached on the fp32 path"))
+    with torch.inference_mode():
+        out = pol(td, env, phase="test", decode_type="greedy")
+        out16 = AttentionModelPolicy("cvrp", cache_dtype=torch.bfloat16).cuda().eval()  # fp32 encoder, bf16 planes
+        out16.load_state_dict(pol.state_dict())
+        out16.encoder.forward = pol.encoder.forward
+        o2 = out16(td, env, phase="test", decode_type="greedy")
+    assert torch.isfinite(out["reward"]).all() and torch.isfinite(o2["reward"]).all()
+    assert abs(float(out["reward"].mean() - o2["reward"].mean())) <= 0.02 * abs(float(out["reward"].mean()))
