@@ -440,6 +440,13 @@ int rl4co_am_encoder_f32(const rl4co_am_encoder_args* args, void* stream);
 int rl4co_am_encoder_tokens_f32(const rl4co_am_encoder_args* args, void* workspace, int64_t workspace_bytes, void* stream);
 int64_t rl4co_am_encoder_tokens_f32_workspace(int B, int N);
 
+/* fp32 side of the cache fold from the final node embeddings of ANY encoder (zoo/am/decoder.py:201-228, cache.py):
+ * out[i][B,N,128] = h . W_i^T for nblocks <= 5 blocks of [128,128] packed as for rl4co_am_encoder_f32 (the context
+ * tables), and q_bias[B,128] = w_fixed . mean_j h[b,j] (w_fixed plain [128,128] fp32; both NULL: skipped). h: [B,N,128]
+ * rows of h_dtype (RL4CO_DT_F32 / _BF16 / _F16, widened on load); fp32 MFMA, fp32 outputs. */
+int rl4co_am_fold_tables_f32(const void* h, int h_dtype, int B, int N, const float* w_packed, int nblocks, float* const* out,
+                             const float* w_fixed, float* q_bias, void* stream);
+
 /* --------------------------------------------------------------------------
  * N1  teacher-forced log-likelihood, backward pass.
  *

@@ -95,6 +95,28 @@ def fold_weights(env_name: str, w_node: Tensor, w_out: Tensor, w_ctx: Tensor) ->
     raise ValueError(f"fused decode supports tsp/cvrp/op, got {env_name!r}")
 
 
+def _fold_tables_f32(h: Tensor, blocks: list[Tensor], w_fixed: Tensor | None):
+    """[h W_i^T for the [128,128] blocks] (fp32 [B,N,128] each) and project_fixed_context(mean_j h_j) on
+    ``rl4co_am_fold_tables_f32`` — no library GEMM, no reduction launch."""
+    import ctypes as C
+
+    from . import _lib
+    from .encoder import pack_weight_f32
+
+    hc = h.contiguous()
+    b, n, d = hc.shape
+    outs = [torch.empty((b, n, d), dtype=torch.float32, device=h.device) for _ in blocks]
+    packed = torch.stack([pack_weight_f32(w) for w in blocks]).contiguous() if blocks else None
+    ptrs = (C.c_void_p * max(1, len(outs)))(*[o.data_ptr() for o in outs])
+    q_bias = torch.empty((b, d), dtype=torch.float32, device=h.device) if w_fixed is not None else None
+    wf = w_fixed.detach().float().contiguous() if w_fixed is not None else None
+    st = _lib.lib().rl4co_am_fold_tables_f32(hc.data_ptr(), _lib.dtype_id(hc.dtype), b, n, None if packed is None else packed.data_ptr(),
+                                             len(outs), ptrs, None if wf is None else wf.data_ptr(),
+                                             None if q_bias is None else q_bias.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.check(st, "rl4co_am_fold_tables_f32")
+    return outs, q_bias
+
+
 def build_folded_cache(
     env_name: str,
     h: Tensor,
@@ -145,11 +167,16 @@ def build_folded_cache(
             torch.matmul(h_g, w_t, out=kvl[i].view(b * n, d))
         else:
             kvl[i].view(b * n, d).copy_(torch.matmul(h_g, w_t))
-    h32 = h.reshape(b * n, d).float()
-    ctx = [torch.matmul(h32, w.t()).view(b, n, d) for w in w_blocks[3:]]
-    q_bias = None
-    if w_fixed is not None:
-        q_bias = torch.matmul(h.mean(1, dtype=torch.float32), w_fixed.float().t()).contiguous()
+    if h.is_cuda and not torch.is_grad_enabled() and h.dtype in (torch.float32, torch.bfloat16, torch.float16):
+        # inference: the fp32 side of the fold (context tables, graph context) on the library's own fp32-MFMA kernel
+        # (csrc/am_tokens_f32.hip: rl4co_am_fold_tables_f32; the 16-bit embeddings of the token path are widened on load)
+        ctx, q_bias = _fold_tables_f32(h, w_blocks[3:], w_fixed)
+    else:
+        h32 = h.reshape(b * n, d).float()
+        ctx = [torch.matmul(h32, w.t()).view(b, n, d) for w in w_blocks[3:]]
+        q_bias = None
+        if w_fixed is not None:
+            q_bias = torch.matmul(h.mean(1, dtype=torch.float32), w_fixed.float().t()).contiguous()
     if env_name == "tsp":
         ctx_first, ctx_cur = ctx
         q_step0 = torch.mv(w_ctx.float(), w_placeholder.float()).contiguous()

@@ -257,7 +257,26 @@ struct FoldOut {
   int nblocks;
 };
 
-__global__ void __launch_bounds__(kThreads) tok_fold_kernel(const float* __restrict__ x, int N, const float* __restrict__ wfold, const FoldOut fo) {
+// 16-bit rows (the embeddings of the 16-bit token path) widened on the way into the fp32 LDS tile
+__device__ inline void load_tile16(float* xs, const uint16_t* src, int half, int b, int n0, int N, int tid) {
+  const uint16_t* base = src + ((int64_t)b * N + n0) * kD;
+  const int valid = min(kTile, N - n0);
+  for (int i = tid; i < kTile * 32; i += kThreads) {
+    const int row = i >> 5, c4 = i & 31;
+    f32x4 v = zero4();
+    if (row < valid) {
+      const uint2 r = *reinterpret_cast<const uint2*>(base + (int64_t)row * kD + 4 * c4);
+      const uint16_t h[4] = {(uint16_t)(r.x & 0xffff), (uint16_t)(r.x >> 16), (uint16_t)(r.y & 0xffff), (uint16_t)(r.y >> 16)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        v[e] = half ? (float)__builtin_bit_cast(_Float16, h[e]) : __builtin_bit_cast(float, (uint32_t)h[e] << 16);
+    }
+    *reinterpret_cast<f32x4*>(xs + row * kRS + 4 * c4) = v;
+  }
+}
+
+// x_dtype: RL4CO_DT_F32, or the 16-bit type of the rows (widened on load)
+__global__ void __launch_bounds__(kThreads) tok_fold_kernel(const void* __restrict__ x, int x_dtype, int N, const float* __restrict__ wfold, const FoldOut fo) {
   extern __shared__ __align__(16) unsigned char smem[];
   float* xs = reinterpret_cast<float*>(smem);
   float* ys = xs + kTile * kRS;
@@ -265,7 +284,8 @@ __global__ void __launch_bounds__(kThreads) tok_fold_kernel(const float* __restr
   const int b = blockIdx.y, n0 = kTile * blockIdx.x;
   f32x4 wf[8];
   load_wfrags(wf, wfold, 8, w, 0, lane);
-  load_tile(xs, x, b, n0, N, tid);
+  if (x_dtype == RL4CO_DT_F32) load_tile(xs, static_cast<const float*>(x), b, n0, N, tid);
+  else load_tile16(xs, static_cast<const uint16_t*>(x), x_dtype == RL4CO_DT_F16, b, n0, N, tid);
   __syncthreads();
   const int valid = min(kTile, N - n0);
 #pragma unroll 1
@@ -282,14 +302,22 @@ __global__ void __launch_bounds__(kThreads) tok_fold_kernel(const float* __restr
 }
 
 // q_bias[b] = W_fixed . mean_j h[b, j]: 512 threads = 128 channels x 4 row classes, then wave w -> output rows 16 w ..
-__global__ void __launch_bounds__(kThreads) graph_context_kernel(const float* __restrict__ h, int N, const float* __restrict__ w_fixed,
+__global__ void __launch_bounds__(kThreads) graph_context_kernel(const void* __restrict__ h, int h_dtype, int N, const float* __restrict__ w_fixed,
                                                                  float* __restrict__ q_bias) {
   __shared__ float part[4][kD];
   __shared__ float meanv[kD];
   const int tid = threadIdx.x, b = blockIdx.x, d = tid & 127, cls = tid >> 7;
-  const float* hb = h + (int64_t)b * N * kD;
   float s = 0.0f;
-  for (int j = cls; j < N; j += 4) s += hb[(int64_t)j * kD + d];
+  if (h_dtype == RL4CO_DT_F32) {
+    const float* hb = static_cast<const float*>(h) + (int64_t)b * N * kD;
+    for (int j = cls; j < N; j += 4) s += hb[(int64_t)j * kD + d];
+  } else {
+    const uint16_t* hb = static_cast<const uint16_t*>(h) + (int64_t)b * N * kD;
+    for (int j = cls; j < N; j += 4) {
+      const uint16_t e = hb[(int64_t)j * kD + d];
+      s += h_dtype == RL4CO_DT_F16 ? (float)__builtin_bit_cast(_Float16, e) : __builtin_bit_cast(float, (uint32_t)e << 16);
+    }
+  }
   part[cls][d] = s;
   __syncthreads();
   if (tid < kD) meanv[tid] = ((part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid])) / (float)N;
@@ -382,10 +410,40 @@ extern "C" int rl4co_am_encoder_tokens_f32(const rl4co_am_encoder_args* args, vo
   int nb = 3;
   if (a.ctx_first) fo.ptr[nb++] = a.ctx_first;
   if (a.ctx_cur) fo.ptr[nb++] = a.ctx_cur;
-  hipLaunchKernelGGL(tok_fold_kernel, grid, block, 2 * kLdsTile, s, xin, N, static_cast<const float*>(a.wfold_packed), fo);
-  if (a.q_bias) hipLaunchKernelGGL(graph_context_kernel, dim3(a.B), block, 0, s, xin, N, a.w_fixed, a.q_bias);
+  hipLaunchKernelGGL(tok_fold_kernel, grid, block, 2 * kLdsTile, s, static_cast<const void*>(xin), (int)RL4CO_DT_F32, N,
+                     static_cast<const float*>(a.wfold_packed), fo);
+  if (a.q_bias) hipLaunchKernelGGL(graph_context_kernel, dim3(a.B), block, 0, s, static_cast<const void*>(xin), (int)RL4CO_DT_F32, N, a.w_fixed, a.q_bias);
   if (a.hidden)
     RL4CO_HIP_TRY(hipMemcpyAsync(a.hidden, xin, (size_t)a.B * N * kD * 4, hipMemcpyDeviceToDevice, s));
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
+// fp32 tables from the final node embeddings of ANY encoder: out_i[B,N,128] = h . W_i^T for up to five packed [128,128]
+// blocks (pack_weight_f32), fp32 accumulate on the fp32 MFMA, and q_bias = W_fixed . mean_j h_j. Replaces the library
+// GEMMs of the cache fold's fp32 side (context tables, graph context: zoo/am/decoder.py:201-228, cache.py) on the 16-bit
+// token path (h in bf16 / fp16, widened on load). h_dtype: dtype of h's rows; out[i] fp32; any of q_bias / w_fixed NULL: skipped.
+extern "C" int rl4co_am_fold_tables_f32(const void* h, int h_dtype, int B, int N, const float* w_packed, int nblocks, float* const* out,
+                                        const float* w_fixed, float* q_bias, void* stream) {
+  RL4CO_REQUIRE(h != nullptr && B > 0 && N >= 1 && B <= 65535);
+  RL4CO_REQUIRE(h_dtype == RL4CO_DT_F32 || h_dtype == RL4CO_DT_BF16 || h_dtype == RL4CO_DT_F16);
+  RL4CO_REQUIRE(nblocks >= 0 && nblocks <= 5 && (nblocks == 0 || (w_packed != nullptr && out != nullptr)));
+  RL4CO_REQUIRE((q_bias == nullptr) == (w_fixed == nullptr) || q_bias == nullptr);
+  hipStream_t s = rl4co::as_stream(stream);
+  const dim3 grid((N + kTile - 1) / kTile, B), block(kThreads);
+  if (nblocks > 0) {
+    FoldOut fo;
+    fo.nblocks = nblocks;
+    for (int blk = 0; blk < 5; ++blk) {
+      fo.ptr[blk] = blk < nblocks ? out[blk] : nullptr;
+      fo.plane16[blk] = 0;
+      fo.batch_stride[blk] = (int64_t)N * kD;
+      RL4CO_REQUIRE(blk >= nblocks || out[blk] != nullptr);
+    }
+    if (int e = set_lds(tok_fold_kernel, 2 * kLdsTile)) return e;
+    hipLaunchKernelGGL(tok_fold_kernel, grid, block, 2 * kLdsTile, s, h, h_dtype, N, w_packed, fo);
+  }
+  if (q_bias && w_fixed) hipLaunchKernelGGL(graph_context_kernel, dim3(B), block, 0, s, h, h_dtype, N, w_fixed, q_bias);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }

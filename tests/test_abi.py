@@ -11,7 +11,7 @@ HEADER = (ROOT / "include" / "rl4co_amd.h").read_text()
 
 
 def declared_functions():
-    names = re.findall(r"^\s*(?:const\s+char\s*\*|int)\s+(rl4co_\w+)\s*\(", HEADER, flags=re.M)
+    names = re.findall(r"^\s*(?:const\s+char\s*\*|int|int64_t)\s+(rl4co_\w+)\s*\(", HEADER, flags=re.M)
     return sorted(set(names))
 
 
