@@ -80,6 +80,15 @@ LEGS = {
 DEFAULT_LEGS = "c2_greedy,c2_sampling,c3_greedy,c5_sampling,c4_train,c2_greedy_fp16,c2_greedy_fp32"
 
 
+def leg_dtypes(leg: str, args) -> tuple[str, str]:
+    """(cache planes, encoder operands) of a leg: the _fp16 / _fp32 legs fix theirs, the others follow the flags."""
+    if leg.endswith("_fp16"):
+        return "f16", "f16"
+    if leg.endswith("_fp32"):
+        return "f32", "f32"
+    return args.cache_dtype, args.encoder_dtype
+
+
 def log(msg: str) -> None:
     """Progress goes to stderr; stdout carries exactly one JSON line."""
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -178,6 +187,7 @@ def cpu_baseline(env_name: str, num_loc: int, sample_batch: int, repeats: int, c
     }
 
 
+TRAIN_PMC_FILE = "r04_c4_train_pmc.json"  # counters of the training kernels as they are in THIS tree (tools/train_pmc.sh)
 MAX_LINE_BYTES = 4096  # the driver parses the ONE stdout line; r03's 27 KB line came back as `parsed: null`
 
 
@@ -236,7 +246,7 @@ def compact_line(detail: dict, head_name: str, results: dict, detail_path: str) 
     line = {k: detail[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                                    "scaling", "vs_baseline", "dtype", "data")}
     line["config"] = {
-        "workload": cfg["workload"][:160], "leg": head_name, "batch_per_gpu": cfg["batch_per_gpu"],
+        "workload": cfg["workload"][:160], "leg": head_name, "batch_per_gpu": cfg["batch_per_gpu"], "cache_dtype": cfg["cache_dtype"],
         "launch": (detail.get("launch") or "").split(":")[0],
         "input": "one synthetic batch resident in HBM, reused by every step", "parallelism": cfg["parallelism"],
     }
@@ -292,7 +302,7 @@ class Bench:
             table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
         except (OSError, ValueError):
             return None, None
-        key = f"{leg}/{self.args.cache_dtype}"
+        key = f"{leg}/{leg_dtypes(leg, self.args)[0]}"
         row = table.get(key)
         return (row["traffic_bytes_per_launch"], row.get("source")) if row else (None, None)
 
@@ -628,7 +638,7 @@ class Bench:
             tf = flop_per_decision * decisions / (mean * 1e-3) / 1e12
             pmc = {}
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_c4_train_pmc.json"))).get(pmc_key, {})
+                pmc = json.load(open(os.path.join(ROOT, "profiles", TRAIN_PMC_FILE))).get(pmc_key, {})
             except (OSError, ValueError):
                 pass
             return {"kernel": kernel, "bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -639,7 +649,7 @@ class Bench:
                             "LATENCY CHAINS (16-step column blocks: dependent MFMAs, softmax VALU and LDS hand-overs add up "
                             "instead of overlapping), not throughput kernels: see pipe_utilisation for where the cycles go",
                     "pipe_utilisation": pmc or None,
-                    "pipe_utilisation_source": "profiles/r03_c4_train_pmc.json (separate rocprofv3 --pmc passes, tools/train_pmc.sh)" if pmc else None}
+                    "pipe_utilisation_source": f"profiles/{TRAIN_PMC_FILE} (separate rocprofv3 --pmc passes, tools/train_pmc.sh)" if pmc else None}
         res.update({
             "workload": (f"BASELINE configs[{cfg_idx}] per-GPU share: POMO (6L, instance norm) REINFORCE step, TSPEnv num_loc={num_loc}, "
                          f"{batch} instances x {starts} starts per GPU: multistart sampling rollout (MS decode kernel), "
@@ -892,6 +902,7 @@ def main() -> None:
         torch.cuda.synchronize()
         probe_gbs = 5 * probe.numel() / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del probe
+        head_cache, head_enc = leg_dtypes(head_name, args)
         detail = {
             "metric": "decode_steps_per_sec",
             "value": head["value"],
@@ -903,15 +914,14 @@ def main() -> None:
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16" if (args.cache_dtype == "bf16" and args.encoder_dtype == "bf16") else
-                     ("f32" if (args.cache_dtype == "f32" and args.encoder_dtype == "f32") else "mixed"),
-            "dtype_detail": f"encoder GEMMs/attention: {args.encoder_dtype} MFMA inputs, fp32 accumulate; cache planes: "
-                            f"{args.cache_dtype}; decode arithmetic (scores, softmax, logits, log-probs, reward): fp32",
+            "dtype": head_cache if head_cache == head_enc else "mixed",
+            "dtype_detail": f"encoder GEMMs/attention: {head_enc} MFMA inputs, fp32 accumulate; cache planes: "
+                            f"{head_cache}; decode arithmetic (scores, softmax, logits, log-probs, reward): fp32",
             "data": "synthetic",
             "config": {
                 "workload": head["workload"], "leg": head_name,
                 "env": env_name, "num_loc": num_loc, "batch_per_gpu": args.batch or batch,
-                "decode_type": decode, "cache_dtype": args.cache_dtype, "encoder_dtype": args.encoder_dtype,
+                "decode_type": decode, "cache_dtype": head_cache, "encoder_dtype": head_enc,
                 "check_solution": not args.no_check_solution, "parallelism": f"replicas x{world} (instances sharded)",
             },
         }
