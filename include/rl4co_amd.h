@@ -416,6 +416,14 @@ typedef struct rl4co_am_encoder_args {
 int rl4co_am_encoder(const rl4co_am_encoder_args* args, void* stream);
 int rl4co_am_encoder_max_nodes(void);
 
+/* The 16-bit encoder + cache fold for graphs of ANY size (csrc/am_encoder.hip: token-tile kernels; BASELINE configs[4],
+ * CVRP-500): the fused kernel's layer algebra, GEMM routine and packed weights over tiles of 128 nodes — init embedding,
+ * per layer [Q / K / V projection (+ per-head score bounds), rl4co_attn_flash_pre_*, ONE kernel for out-proj + norm + MLP +
+ * norm], fold, graph context. Same argument struct and packing as rl4co_am_encoder; norm must be 0 (batch norm, eval).
+ * `workspace`: at least rl4co_am_encoder_tokens16_workspace(B, N) bytes of device memory, 16-byte aligned. */
+int rl4co_am_encoder_tokens16(const rl4co_am_encoder_args* args, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t rl4co_am_encoder_tokens16_workspace(int B, int N);
+
 /* The same fused encoder + cache fold in EXACT fp32 (csrc/am_encoder_f32.hip, v_mfma_f32_16x16x4_f32: f32 operands,
  * f32 accumulate, a k-ordered fmaf chain) — the encoder of the bit-identical configuration (no autocast), replacing the
  * same reference functions as rl4co_am_encoder with arithmetic in ATen's own order where that is knowable: GEMM then
@@ -608,6 +616,10 @@ int rl4co_attn_max_nodes(void);
  * (csrc/am_attn_flash.hip). Serves the encoder beyond rl4co_am_encoder_max_nodes() (BASELINE configs[4]).
  * -------------------------------------------------------------------------- */
 int rl4co_attn_flash_bf16(const void* qkv, int B, int N, void* out, void* stream);
+/* The same with q already in the exp2 domain (1/4 log2 e folded into the packed W_q: rl4co_am_encoder_tokens16) and,
+ * bound != NULL, per (instance, head) the maxima over the nodes of |q_h|^2 and |k_h|^2 ([B,8,2] fp32): heads whose
+ * product stays below 48^2 take the max-free softmax path (bf16 only; every |score| is then below 48 by Cauchy-Schwarz). */
+int rl4co_attn_flash_pre_bf16(const void* qkv, const float* bound, int B, int N, void* out, void* stream);
 
 /* --------------------------------------------------------------------------
  * a19  select_start_nodes        rl4co/utils/ops.py:128-161
@@ -647,6 +659,7 @@ int rl4co_attn_fwd_f16(const void* qkv, int B, int N, void* out, float* lse, voi
 int rl4co_attn_bwd_f16(const void* qkv, const void* dout, const float* lse, int B, int N, void* dqkv,
                         void* stream);
 int rl4co_attn_flash_f16(const void* qkv, int B, int N, void* out, void* stream);
+int rl4co_attn_flash_pre_f16(const void* qkv, const float* bound, int B, int N, void* out, void* stream);
 
 /* --------------------------------------------------------------------------
  * N3  state augmentation                      rl4co/data/transforms.py:16-87, 105-151

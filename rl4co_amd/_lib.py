@@ -120,9 +120,12 @@ SYMBOLS = {
     "rl4co_attn_bwd_bf16": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_attn_max_nodes": (C.c_int, []),
     "rl4co_attn_flash_bf16": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_attn_flash_pre_bf16": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_wgrad_bf16": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp]),
     "rl4co_am_encoder": (C.c_int, [_vp, _vp]),
     "rl4co_am_encoder_max_nodes": (C.c_int, []),
+    "rl4co_am_encoder_tokens16": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
+    "rl4co_am_encoder_tokens16_workspace": (C.c_int64, [C.c_int, C.c_int]),
     "rl4co_am_encoder_f32": (C.c_int, [_vp, _vp]),
     "rl4co_am_encoder_tokens_f32": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "rl4co_am_encoder_tokens_f32_workspace": (C.c_int64, [C.c_int, C.c_int]),
@@ -150,6 +153,7 @@ SYMBOLS = {
     "rl4co_attn_fwd_f16": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
     "rl4co_attn_bwd_f16": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_attn_flash_f16": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_attn_flash_pre_f16": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_wgrad_f16": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp]),
 }
 

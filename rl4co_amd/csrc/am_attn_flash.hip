@@ -64,8 +64,15 @@ __device__ inline void block_map(int b, int B, int QB, int& inst, int& qb) {
   inst = (k / QB) * 8 + xcd;
 }
 
-__global__ void __launch_bounds__(kThreads, 4) attn_flash_kernel(const uint16_t* __restrict__ qkv, int B, int N, int QB,
-                                                                 uint16_t* __restrict__ out) {
+// PRE (the token-tile encoder, am_encoder.hip: tok16_qkv_kernel): q already carries 1/4 log2 e (folded into the packed
+// W_q), so the scores leave the product in the exp2 domain, and `bound` holds per (instance, head) the maxima over the
+// nodes of |q_h|^2 and |k_h|^2: when their product stays below kFastBound^2 every |score| does (Cauchy-Schwarz) and the
+// softmax needs neither a running maximum nor a rescale — numerators in [2^-48, 2^48], one exp2 per score and nothing
+// else (the wide-exponent element type only: fp16 numerators would overflow).
+constexpr float kFastBound = 48.0f;
+template <bool PRE>
+__global__ void __launch_bounds__(kThreads, 4) attn_flash_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__ bound, int B,
+                                                                 int N, int QB, uint16_t* __restrict__ out) {
   constexpr int kLds = kKB * kKS > kQT * 16 * kOS ? kKB * kKS : kQT * 16 * kOS;
   __shared__ __align__(16) elem_t kv[kLds];  // one key block: [64][k 128 | v 128]; later the output staging rows
   const int tid = threadIdx.x, h = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
@@ -108,6 +115,11 @@ __global__ void __launch_bounds__(kThreads, 4) attn_flash_kernel(const uint16_t*
       *reinterpret_cast<uint4*>(kv + r * kKS + col) = ok ? pre[j] : make_uint4(0, 0, 0, 0);
     }
   };
+  bool fast = false;
+  if (PRE && !RL4CO_ELEM_F16 && bound != nullptr) {
+    const float b2 = bound[((int64_t)inst * 8 + h) * 2] * bound[((int64_t)inst * 8 + h) * 2 + 1];
+    fast = __builtin_amdgcn_readfirstlane(b2 <= kFastBound * kFastBound ? 1 : 0) != 0;
+  }
   const int nao = tl * kKS + 4 * g;                          // natural operand read: row lane & 15, columns 4 g ..
   const int tro = (4 * g + (tl >> 2)) * kKS + 4 * (tl & 3);  // transpose read
   fetch(0);
@@ -131,6 +143,30 @@ __global__ void __launch_bounds__(kThreads, 4) attn_flash_kernel(const uint16_t*
       vf[j] = lds_tr(kv + 16 * j * kKS + kD + 16 * h + tro);
     }
     const bool tail = (kb + 1) * kKB > N;
+    if (fast) {
+      // bounded scores: p = exp2(s) tile by tile — no maximum, no subtraction, no rescale of the accumulators
+#pragma unroll
+      for (int t = 0; t < kQT; ++t) {
+        float ls = 0.0f;
+        f32x4 acc = o[t];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const f32x4 sj = mfma16(kf[j], qf[t], zero4());
+          bf16x4 pf;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            float p = __builtin_amdgcn_exp2f(sj[rr]);
+            if (tail) p = (kb * kKB + 16 * j + 4 * g + rr < N) ? p : 0.0f;
+            ls += p;
+            pf[rr] = (elem_t)p;
+          }
+          acc = mfma16(vf[j], pf, acc);
+        }
+        o[t] = acc;
+        l[t] += ls;
+      }
+      continue;
+    }
 #pragma unroll
     for (int t = 0; t < kQT; ++t) {
       f32x4 s[4];
@@ -140,7 +176,7 @@ __global__ void __launch_bounds__(kThreads, 4) attn_flash_kernel(const uint16_t*
         s[j] = mfma16(kf[j], qf[t], zero4());
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
-          float v = s[j][rr] * kScale;
+          float v = PRE ? s[j][rr] : s[j][rr] * kScale;
           if (tail) v = (kb * kKB + 16 * j + 4 * g + rr < N) ? v : kNegInf;
           s[j][rr] = v;
           bm = fmaxf(bm, v);
@@ -193,8 +229,18 @@ extern "C" int RL4CO_ENTRY(rl4co_attn_flash)(const void* qkv, int B, int N, void
   RL4CO_REQUIRE(qkv && out && B > 0 && N >= 1 && N <= 65536);
   const int QB = (N + kQT * 16 - 1) / (kQT * 16);
   RL4CO_REQUIRE((int64_t)B * QB < (1ll << 31));
-  hipLaunchKernelGGL(attn_flash_kernel, dim3(B * QB), dim3(kThreads), 0, rl4co::as_stream(stream),
-                     static_cast<const uint16_t*>(qkv), B, N, QB, static_cast<uint16_t*>(out));
+  hipLaunchKernelGGL(attn_flash_kernel<false>, dim3(B * QB), dim3(kThreads), 0, rl4co::as_stream(stream),
+                     static_cast<const uint16_t*>(qkv), static_cast<const float*>(nullptr), B, N, QB, static_cast<uint16_t*>(out));
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
+extern "C" int RL4CO_ENTRY(rl4co_attn_flash_pre)(const void* qkv, const float* bound, int B, int N, void* out, void* stream) {
+  RL4CO_REQUIRE(qkv && out && B > 0 && N >= 1 && N <= 65536);
+  const int QB = (N + kQT * 16 - 1) / (kQT * 16);
+  RL4CO_REQUIRE((int64_t)B * QB < (1ll << 31));
+  hipLaunchKernelGGL(attn_flash_kernel<true>, dim3(B * QB), dim3(kThreads), 0, rl4co::as_stream(stream),
+                     static_cast<const uint16_t*>(qkv), bound, B, N, QB, static_cast<uint16_t*>(out));
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }

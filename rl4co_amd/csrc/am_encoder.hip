@@ -225,6 +225,89 @@ __device__ inline void residual_norm(E* xs, f32x16 (&y)[TT], int dim0, const flo
   store_t<TT>(xs, y, dim0, lane);
 }
 
+// Init embedding of rows n0 .. n0 + rows_pad - 1 of instance b into xs (rows past N zeroed); contains one __syncthreads().
+// The instance's coordinates (and demands ...) are staged in LDS (`lsh`, 6 N floats at most) first: read per token from
+// global memory they are a chain of dependent L2 round trips (28 K cycles per instance, measured).
+template <typename E>
+__device__ inline void init_embed_rows16(const rl4co_am_encoder_args& a, int b, int n0, int rows_pad, E* xs, float* lsh, int tid) {
+  const int N = a.N;
+  const float* loc = a.locs + (int64_t)b * N * 2;
+  const bool pdp = a.env == RL4CO_ENV_PDP;  // depot | pickups (x, y, x', y' of the delivery) | deliveries, init.py:335-360
+  const bool cvrp = a.env == RL4CO_ENV_CVRP;
+  const bool depot = cvrp || pdp;
+  const int half = (N - 1) / 2;
+  for (int i = tid; i < 2 * N; i += kThreads) lsh[i] = loc[i];
+  const bool four = cvrp && a.feature4 != nullptr;  // PCTSP: (x, y, expected prize, penalty), init.py:283-312
+  if (cvrp)
+    for (int i = tid; i < N - 1; i += kThreads) lsh[2 * N + 1 + i] = a.demand[(int64_t)b * (N - 1) + i];
+  const bool six = four && a.feature5 != nullptr && a.feature6 != nullptr;  // CVRPTW: + tw start, tw end, service time
+  if (four)
+    for (int i = tid; i < N - 1; i += kThreads) lsh[3 * N + 1 + i] = a.feature4[(int64_t)b * (N - 1) + i];
+  if (six)
+    for (int i = tid; i < N - 1; i += kThreads) {
+      lsh[4 * N + 1 + i] = a.feature5[(int64_t)b * (N - 1) + i];
+      lsh[5 * N + 1 + i] = a.feature6[(int64_t)b * (N - 1) + i];
+    }
+  // thread = four consecutive channels (tid & 31) x one of eight token groups: every token row of the residual stream
+  // receives an 8-byte LDS store per thread (a thread per channel stored 2 bytes per token: 64 dependent
+  // ds_write_b16 per thread, part of the 44 K cycles this phase took of an instance's 285 K)
+  const int d0 = 4 * (tid & 31);
+  const int ws = six ? 6 : ((four || pdp) ? 4 : (cvrp ? 3 : 2));  // row stride of w_init
+  float wq[4][6], bq[4], dq[4][2], dbq[4], eq[4][2], ebq[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+#pragma unroll
+    for (int f = 0; f < 6; ++f) wq[c][f] = f < ws ? a.w_init[ws * (d0 + c) + f] : 0.0f;
+    bq[c] = a.b_init[d0 + c];
+    dq[c][0] = depot ? a.w_depot[2 * (d0 + c)] : 0.0f;
+    dq[c][1] = depot ? a.w_depot[2 * (d0 + c) + 1] : 0.0f;
+    dbq[c] = depot ? a.b_depot[d0 + c] : 0.0f;
+    eq[c][0] = pdp ? a.w_extra[2 * (d0 + c)] : 0.0f;
+    eq[c][1] = pdp ? a.w_extra[2 * (d0 + c) + 1] : 0.0f;
+    ebq[c] = pdp ? a.b_extra[d0 + c] : 0.0f;
+  }
+  __syncthreads();
+  for (int row = tid >> 5; row < rows_pad; row += kThreads / 32) {
+    const int tok = n0 + row;
+    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (tok < N) {
+      const float x = lsh[2 * tok], y = lsh[2 * tok + 1];
+      // feature vector of this token in the order its embedding's weight rows take them (unused slots: weight 0)
+      float f2 = 0.0f, f3 = 0.0f, f4 = 0.0f, f5 = 0.0f;
+      if (pdp && tok <= half) {
+        f2 = lsh[2 * (tok + half)];
+        f3 = lsh[2 * (tok + half) + 1];
+      } else if (cvrp) {
+        f2 = lsh[2 * N + tok];
+        if (four) f3 = lsh[3 * N + tok];
+        if (six) {
+          f4 = lsh[4 * N + tok];
+          f5 = lsh[5 * N + tok];
+        }
+      }
+      const bool is_depot = depot && tok == 0, is_delivery = pdp && tok > half;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float r;
+        if (is_depot) r = fmaf(dq[c][1], y, fmaf(dq[c][0], x, dbq[c]));
+        else if (is_delivery) r = fmaf(eq[c][1], y, fmaf(eq[c][0], x, ebq[c]));
+        else {
+          r = fmaf(wq[c][1], y, fmaf(wq[c][0], x, bq[c]));  // same fma order as the per-feature chains before
+          if (ws > 2) r = fmaf(wq[c][2], f2, r);
+          if (ws > 3) r = fmaf(wq[c][3], f3, r);
+          if (ws > 4) r = fmaf(wq[c][5], f5, fmaf(wq[c][4], f4, r));
+        }
+        v[c] = r;
+      }
+    }
+    vec4<E> pk;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) pk[c] = (E)v[c];
+    *reinterpret_cast<vec4<E>*>(xs + row * kRS + d0) = pk;
+  }
+}
+
+
 // Two workgroups per CU (70 KB LDS, <= 256 registers): while one instance sits in a VALU-heavy
 // phase (softmax, norms, conversions) the other one's waves keep the matrix pipe busy.
 // |score| bound below which exp2 needs no max subtraction: scores in [-48, 48] (log2 domain) keep every softmax
@@ -284,87 +367,9 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
   bf16x8 wf[8];
   load_wfrags(wf, wqkv_all, 8, w, 0, lane);
 
-  // ---- init embedding (K = 2 or 3: plain VALU), padding rows zeroed ---------------------------
-  // The instance's coordinates (and demands) are staged in LDS first: read per token from global
-  // memory they are a chain of dependent L2 round trips (28 K cycles per instance, measured).
-  // thread = channel d (tid & 127) x token parity; its weights are read once.
-  {
-    float* lsh = reinterpret_cast<float*>(ys);  // [2 N] coordinates, then [N] demands (ys is free here)
-    const float* loc = a.locs + (int64_t)b * N * 2;
-    const bool pdp = a.env == RL4CO_ENV_PDP;  // depot | pickups (x, y, x', y' of the delivery) | deliveries, init.py:335-360
-    const bool cvrp = a.env == RL4CO_ENV_CVRP;
-    const bool depot = cvrp || pdp;
-    const int half = (N - 1) / 2;
-    for (int i = tid; i < 2 * N; i += kThreads) lsh[i] = loc[i];
-    const bool four = cvrp && a.feature4 != nullptr;  // PCTSP: (x, y, expected prize, penalty), init.py:283-312
-    if (cvrp)
-      for (int i = tid; i < N - 1; i += kThreads) lsh[2 * N + 1 + i] = a.demand[(int64_t)b * (N - 1) + i];
-    const bool six = four && a.feature5 != nullptr && a.feature6 != nullptr;  // CVRPTW: + tw start, tw end, service time
-    if (four)
-      for (int i = tid; i < N - 1; i += kThreads) lsh[3 * N + 1 + i] = a.feature4[(int64_t)b * (N - 1) + i];
-    if (six)
-      for (int i = tid; i < N - 1; i += kThreads) {
-        lsh[4 * N + 1 + i] = a.feature5[(int64_t)b * (N - 1) + i];
-        lsh[5 * N + 1 + i] = a.feature6[(int64_t)b * (N - 1) + i];
-      }
-    // thread = four consecutive channels (tid & 31) x one of eight token groups: every token row of the residual stream
-    // receives an 8-byte LDS store per thread (a thread per channel stored 2 bytes per token: 64 dependent
-    // ds_write_b16 per thread, part of the 44 K cycles this phase took of an instance's 285 K)
-    const int d0 = 4 * (tid & 31);
-    const int ws = six ? 6 : ((four || pdp) ? 4 : (cvrp ? 3 : 2));  // row stride of w_init
-    float wq[4][6], bq[4], dq[4][2], dbq[4], eq[4][2], ebq[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-#pragma unroll
-      for (int f = 0; f < 6; ++f) wq[c][f] = f < ws ? a.w_init[ws * (d0 + c) + f] : 0.0f;
-      bq[c] = a.b_init[d0 + c];
-      dq[c][0] = depot ? a.w_depot[2 * (d0 + c)] : 0.0f;
-      dq[c][1] = depot ? a.w_depot[2 * (d0 + c) + 1] : 0.0f;
-      dbq[c] = depot ? a.b_depot[d0 + c] : 0.0f;
-      eq[c][0] = pdp ? a.w_extra[2 * (d0 + c)] : 0.0f;
-      eq[c][1] = pdp ? a.w_extra[2 * (d0 + c) + 1] : 0.0f;
-      ebq[c] = pdp ? a.b_extra[d0 + c] : 0.0f;
-    }
-    stage_biases(0);
-    __syncthreads();
-    for (int tok = tid >> 5; tok < 32 * TT; tok += kThreads / 32) {
-      float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-      if (tok < N) {
-        const float x = lsh[2 * tok], y = lsh[2 * tok + 1];
-        // feature vector of this token in the order its embedding's weight rows take them (unused slots: weight 0)
-        float f2 = 0.0f, f3 = 0.0f, f4 = 0.0f, f5 = 0.0f;
-        if (pdp && tok <= half) {
-          f2 = lsh[2 * (tok + half)];
-          f3 = lsh[2 * (tok + half) + 1];
-        } else if (cvrp) {
-          f2 = lsh[2 * N + tok];
-          if (four) f3 = lsh[3 * N + tok];
-          if (six) {
-            f4 = lsh[4 * N + tok];
-            f5 = lsh[5 * N + tok];
-          }
-        }
-        const bool is_depot = depot && tok == 0, is_delivery = pdp && tok > half;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          float r;
-          if (is_depot) r = fmaf(dq[c][1], y, fmaf(dq[c][0], x, dbq[c]));
-          else if (is_delivery) r = fmaf(eq[c][1], y, fmaf(eq[c][0], x, ebq[c]));
-          else {
-            r = fmaf(wq[c][1], y, fmaf(wq[c][0], x, bq[c]));  // same fma order as the per-feature chains before
-            if (ws > 2) r = fmaf(wq[c][2], f2, r);
-            if (ws > 3) r = fmaf(wq[c][3], f3, r);
-            if (ws > 4) r = fmaf(wq[c][5], f5, fmaf(wq[c][4], f4, r));
-          }
-          v[c] = r;
-        }
-      }
-      bf16x4 pk;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) pk[c] = (E)v[c];
-      *reinterpret_cast<bf16x4*>(xs + tok * kRS + d0) = pk;
-    }
-  }
+  // ---- init embedding (K = 2 .. 6: plain VALU), padding rows zeroed ---------------------------
+  stage_biases(0);
+  init_embed_rows16<E>(a, b, 0, 32 * TT, xs, reinterpret_cast<float*>(ys), tid);  // (ys is free here: the features are staged in it)
   __syncthreads();
 
   for (int layer = 0; layer < a.num_layers; ++layer) {
@@ -656,6 +661,254 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
   }
 }
 
+// ================================================================================================================
+// Token-tile kernels: the same layer algebra for graphs beyond 128 nodes (BASELINE configs[4], CVRP-500), batch norm in
+// eval mode. A workgroup owns 128 consecutive nodes of one instance (grid = tiles x instances, two workgroups per CU);
+// the GEMM routine, fragment packing, bias / norm folding are the fused kernel's own, so the packed weights serve both.
+// Per layer three launches instead of seven: Q / K / V projection -> attention (am_attn_flash.hip) -> ONE kernel for
+// out-proj + norm + MLP + norm, whose 512-wide hidden goes through LDS in four chunks and never through HBM (the per-op
+// path moved 22 [B N, 128]-sized 16-bit passes per layer, this one 7).
+// ================================================================================================================
+constexpr int kTokT = 4;  // token tiles of 32 per workgroup
+constexpr int kTok = 32 * kTokT;
+
+template <typename E>
+__device__ inline void tok_load(E* xs, const E* src, int b, int n0, int N, int tid) {
+  const E* base = src + ((int64_t)b * N + n0) * kD;
+  const int valid = min(kTok, N - n0);
+  for (int i = tid; i < kTok * 16; i += kThreads) {
+    const int row = i >> 4, c16 = i & 15;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < valid) v = *reinterpret_cast<const uint4*>(base + (int64_t)row * kD + 8 * c16);
+    *reinterpret_cast<uint4*>(xs + row * kRS + 8 * c16) = v;
+  }
+}
+template <typename E>
+__device__ inline void tok_store(const E* xs, E* dst, int64_t row_stride, int valid, int tid) {
+  for (int i = tid; i < valid * 16; i += kThreads)
+    *reinterpret_cast<uint4*>(dst + (int64_t)(i >> 4) * row_stride + 8 * (i & 15)) = *reinterpret_cast<const uint4*>(xs + (i >> 4) * kRS + 8 * (i & 15));
+}
+
+template <typename E>
+__global__ void __launch_bounds__(kThreads, 2) tok16_init_embed_kernel(const rl4co_am_encoder_args a, E* x0) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  E* xs = reinterpret_cast<E*>(smem);
+  float* lsh = reinterpret_cast<float*>(xs + kTok * kRS);
+  const int tid = threadIdx.x, b = blockIdx.y, n0 = kTok * blockIdx.x;
+  init_embed_rows16<E>(a, b, n0, kTok, xs, lsh, tid);
+  __syncthreads();
+  tok_store(xs, x0 + ((int64_t)b * a.N + n0) * kD, kD, min(kTok, a.N - n0), tid);
+}
+
+// x -> packed qkv rows [B N, 384] (q | k | v; q carries 1/4 log2 e from the packed weights: the attention kernel's scores
+// are in the exp2 domain as they leave the product) and, per (instance, head), the maxima over the nodes of |q_h|^2 and
+// |k_h|^2 (fp32 accumulators, before rounding): |score| <= sqrt of their product, the bound the attention kernel's
+// max-free softmax path is taken under.
+template <typename E>
+__global__ void __launch_bounds__(kThreads, 2) tok16_qkv_kernel(const E* __restrict__ x, int N, const E* __restrict__ wqkv,
+                                                                const float* __restrict__ bqkv, E* __restrict__ qkv,
+                                                                uint32_t* __restrict__ bound) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  E* xs = reinterpret_cast<E*>(smem);
+  E* ys = xs + kTok * kRS;
+  float* bl = reinterpret_cast<float*>(ys + kTok * kRS);  // [384]
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.y, n0 = kTok * blockIdx.x, valid = min(kTok, N - n0);
+  vec8<E> wf[8];
+  load_wfrags(wf, wqkv, 8, w, 0, lane);
+  tok_load(xs, x, b, n0, N, tid);
+  for (int i = tid; i < 3 * kD; i += kThreads) bl[i] = bqkv[i];
+  __syncthreads();
+#pragma unroll 1
+  for (int part = 0; part < 3; ++part) {
+    f32x16 acc[kTokT];
+    gemm_t<kTokT>(acc, wf, xs, lane, part < 2 ? wqkv : static_cast<const E*>(nullptr), 8, 4 * (part + 1) + w, 0,
+                  bias_tile(bl + kD * part, 32 * w, hi));
+    if (part < 2) {
+      float m0 = 0.0f, m1 = 0.0f;
+#pragma unroll
+      for (int tt = 0; tt < kTokT; ++tt) {
+        float h0, h1;
+        head_sqnorms(acc[tt], h0, h1);
+        const bool live = 32 * tt + l31 < valid;
+        m0 = fmaxf(m0, live ? h0 : 0.0f);
+        m1 = fmaxf(m1, live ? h1 : 0.0f);
+      }
+      m0 = wave_max32(m0);
+      m1 = wave_max32(m1);
+      if (lane == 0) {  // non-negative floats order like their bit patterns
+        atomicMax(bound + ((int64_t)b * 8 + 2 * w) * 2 + part, __float_as_uint(m0));
+        atomicMax(bound + ((int64_t)b * 8 + 2 * w + 1) * 2 + part, __float_as_uint(m1));
+      }
+    }
+    if (part > 0) __syncthreads();  // the previous part has left the staging rows
+    store_t<kTokT>(ys, acc, 32 * w, lane);
+    __syncthreads();
+    tok_store(ys, qkv + ((int64_t)b * N + n0) * 3 * kD + kD * part, 3 * kD, valid, tid);
+  }
+}
+
+// Norm(x + out_proj(att)) -> Norm(. + MLP(.)) on one token tile: the second half of am_encoder_kernel's layer body
+template <typename E>
+__global__ void __launch_bounds__(kThreads, 2) tok16_mlp_kernel(const E* __restrict__ x, const E* __restrict__ att, int N,
+                                                                const E* __restrict__ wo, const E* __restrict__ w1,
+                                                                const E* __restrict__ w2, const float* __restrict__ b1,
+                                                                const float* __restrict__ n1a, const float* __restrict__ n1b,
+                                                                const float* __restrict__ n2a, const float* __restrict__ n2b,
+                                                                E* __restrict__ xout) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  E* xs = reinterpret_cast<E*>(smem);
+  E* ys = xs + kTok * kRS;
+  float* bl = reinterpret_cast<float*>(ys + kTok * kRS);  // b1 [512]
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, hi = lane >> 5;
+  const int b = blockIdx.y, n0 = kTok * blockIdx.x;
+  vec8<E> wf[8];
+  load_wfrags(wf, wo, 8, w, 0, lane);
+  tok_load(xs, x, b, n0, N, tid);
+  tok_load(ys, att, b, n0, N, tid);
+  for (int i = tid; i < kFF; i += kThreads) bl[i] = b1[i];
+  __syncthreads();
+  {
+    f32x16 y[kTokT];
+    gemm_t<kTokT>(y, wf, ys, lane, w1, 8, w, 0, zero16());  // (out_proj's bias rides in the norm's shift: encoder.py)
+    residual_norm<kTokT>(xs, y, 32 * w, n1a, n1b, 0, N, lane);
+  }
+  __syncthreads();
+  {
+    f32x16 y2[kTokT];
+#pragma unroll
+    for (int tt = 0; tt < kTokT; ++tt) y2[tt] = zero16();
+#pragma unroll 1
+    for (int c = 0; c < 4; ++c) {
+      f32x16 h1[kTokT];
+      gemm_t<kTokT>(h1, wf, xs, lane, w2, 32, w, 8 * c, bias_tile(bl, 32 * (4 * c + w), hi));
+#pragma unroll
+      for (int tt = 0; tt < kTokT; ++tt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h1[tt][r] = fmaxf(h1[tt][r], 0.0f);
+      __syncthreads();  // every wave is done reading ys (the attention output / the previous chunk)
+      store_t<kTokT>(ys, h1, 32 * w, lane);
+      __syncthreads();
+      gemm_t<kTokT, true, false>(y2, wf, ys, lane, c < 3 ? w1 : static_cast<const E*>(nullptr), 8, 4 * (c + 1) + w, 0, y2[0]);
+    }
+    residual_norm<kTokT>(xs, y2, 32 * w, n2a, n2b, 0, N, lane);
+  }
+  __syncthreads();
+  tok_store(xs, xout + ((int64_t)b * N + n0) * kD, kD, min(kTok, N - n0), tid);
+}
+
+// cache planes (16-bit or fp32) and fp32 context tables of one token tile, as the fused kernel's fold writes them
+template <typename E>
+__global__ void __launch_bounds__(kThreads, 2) tok16_fold_kernel(const E* __restrict__ x, const rl4co_am_encoder_args a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  E* xs = reinterpret_cast<E*>(smem);
+  E* ys = xs + kTok * kRS;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int b = blockIdx.y, n0 = kTok * blockIdx.x, N = a.N, valid = min(kTok, N - n0);
+  const E* wf_all = static_cast<const E*>(a.wfold_packed);
+  vec8<E> wf[8];
+  load_wfrags(wf, wf_all, 8, w, 0, lane);
+  tok_load(xs, x, b, n0, N, tid);
+  __syncthreads();
+  const int nblocks = (a.env == RL4CO_ENV_TSP) ? 5 : 4;
+#pragma unroll 1
+  for (int blk = 0; blk < nblocks; ++blk) {
+    f32x16 acc[kTokT];
+    gemm_t<kTokT>(acc, wf, xs, lane, blk + 1 < nblocks ? wf_all + (int64_t)(blk + 1) * kD * kD : static_cast<const E*>(nullptr), 8, w, 0,
+                  zero16());
+    if (blk < 3 && a.cache_dtype != RL4CO_DT_F32) {
+      store_t<kTokT>(ys, acc, 32 * w, lane);
+      __syncthreads();
+      tok_store(ys, static_cast<E*>(a.kvl) + (int64_t)blk * a.kvl_plane_stride + (int64_t)b * a.kvl_batch_stride + (int64_t)n0 * kD, kD, valid, tid);
+      __syncthreads();
+    } else {
+      float* out;
+      if (blk < 3) out = static_cast<float*>(a.kvl) + (int64_t)blk * a.kvl_plane_stride + (int64_t)b * a.kvl_batch_stride;
+      else if (a.env == RL4CO_ENV_TSP) out = (blk == 3 ? a.ctx_first : a.ctx_cur) + (int64_t)b * N * kD;
+      else out = a.ctx_cur + (int64_t)b * N * kD;
+      out += (int64_t)n0 * kD;
+      constexpr int kFS = kD + 4;  // fp32 staging row stride: 64 token rows fit the 34 KB of ys
+      float* fs = reinterpret_cast<float*>(ys);
+#pragma unroll
+      for (int p = 0; p < kTokT / 2; ++p) {
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const f32x16& t = acc[2 * p + t2];
+            *reinterpret_cast<float4*>(fs + (32 * t2 + l31) * kFS + 32 * w + 8 * c + 4 * hi) = make_float4(t[4 * c], t[4 * c + 1], t[4 * c + 2], t[4 * c + 3]);
+          }
+        }
+        __syncthreads();
+        const int rows = min(64, valid - 64 * p);
+        for (int i = tid; i < rows * 32; i += kThreads)
+          *reinterpret_cast<float4*>(out + (int64_t)(64 * p + (i >> 5)) * kD + 4 * (i & 31)) = *reinterpret_cast<const float4*>(fs + (i >> 5) * kFS + 4 * (i & 31));
+        __syncthreads();
+      }
+    }
+  }
+}
+
+template <typename E>
+__global__ void widen_kernel(const E* __restrict__ src, int64_t n8, float* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const vec8<E> v = *reinterpret_cast<const vec8<E>*>(src + 8 * i);
+  float4 lo = make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]), hi4 = make_float4((float)v[4], (float)v[5], (float)v[6], (float)v[7]);
+  *reinterpret_cast<float4*>(dst + 8 * i) = lo;
+  *reinterpret_cast<float4*>(dst + 8 * i + 4) = hi4;
+}
+
+template <typename E>
+int launch_tokens16(const rl4co_am_encoder_args& a, void* workspace, hipStream_t s) {
+  const int N = a.N;
+  const int64_t mx = ((int64_t)a.B * N * kD + 63) / 64 * 64;
+  E* x0 = static_cast<E*>(workspace);
+  E* x1 = x0 + mx;
+  E* att = x0 + 2 * mx;
+  E* qkv = x0 + 3 * mx;  // [B N, 384]
+  uint32_t* bound = reinterpret_cast<uint32_t*>(x0 + 6 * mx);  // [B][8 heads][q, k] fp32 bit patterns
+  const dim3 grid((N + kTok - 1) / kTok, a.B), block(kThreads);
+  const int lds_tile = kTok * kRS * (int)sizeof(E);
+  const int lds_init = lds_tile + 6 * N * 4 + 64, lds_qkv = 2 * lds_tile + 3 * kD * 4, lds_mlp = 2 * lds_tile + kFF * 4;
+  RL4CO_REQUIRE(lds_init <= 80 * 1024);
+  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tok16_init_embed_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_init));
+  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tok16_qkv_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_qkv));
+  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tok16_mlp_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_mlp));
+  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tok16_fold_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * lds_tile));
+  hipLaunchKernelGGL(tok16_init_embed_kernel<E>, grid, block, lds_init, s, a, x0);
+  E *xin = x0, *xout = x1;
+  const E* wqkv = static_cast<const E*>(a.wqkv_packed);
+  const E* wo = static_cast<const E*>(a.wo_packed);
+  const E* w1 = static_cast<const E*>(a.w1_packed);
+  const E* w2 = static_cast<const E*>(a.w2_packed);
+  const bool half = a.act_dtype == RL4CO_DT_F16;
+  for (int layer = 0; layer < a.num_layers; ++layer) {
+    RL4CO_HIP_TRY(hipMemsetAsync(bound, 0, (size_t)a.B * 8 * 2 * 4, s));
+    hipLaunchKernelGGL(tok16_qkv_kernel<E>, grid, block, lds_qkv, s, xin, N, wqkv + (int64_t)layer * 3 * kD * kD, a.bqkv + layer * 3 * kD, qkv, bound);
+    const int st = half ? rl4co_attn_flash_pre_f16(qkv, reinterpret_cast<const float*>(bound), a.B, N, att, s)
+                        : rl4co_attn_flash_pre_bf16(qkv, reinterpret_cast<const float*>(bound), a.B, N, att, s);
+    if (st != RL4CO_OK) return st;
+    hipLaunchKernelGGL(tok16_mlp_kernel<E>, grid, block, lds_mlp, s, xin, att, N, wo + (int64_t)layer * kD * kD, w1 + (int64_t)layer * kFF * kD,
+                       w2 + (int64_t)layer * kD * kFF, a.b1 + layer * kFF, a.n1_scale + layer * kD, a.n1_shift + layer * kD,
+                       a.n2_scale + layer * kD, a.n2_shift + layer * kD, xout);
+    E* t = xin;
+    xin = xout;
+    xout = t;
+  }
+  hipLaunchKernelGGL(tok16_fold_kernel<E>, grid, block, 2 * lds_tile, s, xin, a);
+  if (a.q_bias) {
+    const int st = rl4co_am_fold_tables_f32(xin, a.act_dtype, a.B, N, nullptr, 0, nullptr, a.w_fixed, a.q_bias, s);
+    if (st != RL4CO_OK) return st;
+  }
+  if (a.hidden) {  // fp32 copy of the final embeddings (return_hidden)
+    const int64_t n8 = (int64_t)a.B * N * kD / 8;
+    hipLaunchKernelGGL(widen_kernel<E>, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, s, xin, n8, a.hidden);
+  }
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
 template <typename E, int TT, int VR4>
 int launch_encoder(const rl4co_am_encoder_args& a, hipStream_t stream) {
   const int lds = 2 * 128 * kRS * 2 + kD * 4 + kBiasFloats * 4;
@@ -710,4 +963,32 @@ extern "C" int rl4co_am_encoder(const rl4co_am_encoder_args* args, void* stream)
   RL4CO_REQUIRE(a.kvl_batch_stride >= (int64_t)a.N * kD && a.kvl_plane_stride >= a.kvl_batch_stride);
   hipStream_t s = rl4co::as_stream(stream);
   return a.act_dtype == RL4CO_DT_F16 ? launch_encoder_elem<_Float16>(a, s) : launch_encoder_elem<__bf16>(a, s);
+}
+
+extern "C" int64_t rl4co_am_encoder_tokens16_workspace(int B, int N) {
+  if (B <= 0 || N <= 0) return 0;
+  const int64_t mx = ((int64_t)B * N * kD + 63) / 64 * 64;
+  return 6 * mx * 2 + (int64_t)B * 8 * 2 * 4;
+}
+
+extern "C" int rl4co_am_encoder_tokens16(const rl4co_am_encoder_args* args, void* workspace, int64_t workspace_bytes, void* stream) {
+  RL4CO_REQUIRE(args != nullptr);
+  const rl4co_am_encoder_args& a = *args;
+  RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP || a.env == RL4CO_ENV_PDP);
+  RL4CO_REQUIRE(a.B > 0 && a.N >= 2 && a.B <= 65535);
+  RL4CO_REQUIRE(a.num_layers >= 1 && a.norm == 0);  // instance norm couples the nodes of an instance: fused kernel only
+  RL4CO_REQUIRE(a.act_dtype == RL4CO_DT_BF16 || a.act_dtype == RL4CO_DT_F16);
+  RL4CO_REQUIRE(a.cache_dtype == RL4CO_DT_F32 || a.cache_dtype == a.act_dtype);
+  RL4CO_REQUIRE(a.locs && a.w_init && a.b_init);
+  RL4CO_REQUIRE(a.env != RL4CO_ENV_CVRP || (a.demand && a.w_depot && a.b_depot));
+  RL4CO_REQUIRE(a.env != RL4CO_ENV_PDP || (a.w_depot && a.b_depot && a.w_extra && a.b_extra && (a.N - 1) % 2 == 0));
+  RL4CO_REQUIRE(a.wqkv_packed && a.wo_packed && a.w1_packed && a.w2_packed && a.wfold_packed);
+  RL4CO_REQUIRE(a.bqkv && a.b1 && a.n1_scale && a.n1_shift && a.n2_scale && a.n2_shift);
+  RL4CO_REQUIRE(a.kvl && a.ctx_cur && (a.env != RL4CO_ENV_TSP || a.ctx_first));
+  RL4CO_REQUIRE(a.q_bias == nullptr || a.w_fixed != nullptr);
+  RL4CO_REQUIRE(a.kvl_batch_stride >= (int64_t)a.N * kD && a.kvl_plane_stride >= a.kvl_batch_stride);
+  RL4CO_REQUIRE(workspace != nullptr && workspace_bytes >= rl4co_am_encoder_tokens16_workspace(a.B, a.N));
+  RL4CO_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0);
+  hipStream_t s = rl4co::as_stream(stream);
+  return a.act_dtype == RL4CO_DT_F16 ? launch_tokens16<_Float16>(a, workspace, s) : launch_tokens16<__bf16>(a, workspace, s);
 }

@@ -186,7 +186,9 @@ class PackedEncoder:
         if kind == "batch" and pol.training:  # batch statistics couple instances: torch path
             return False
         if n > _lib.lib().rl4co_am_encoder_max_nodes():
-            return act_dtype == torch.float32 and kind == "batch" and td["locs"].is_cuda and 6 * n * 4 + 68 * 1024 <= 160 * 1024
+            # token-tile launches (fp32: csrc/am_tokens_f32.hip; 16-bit: the token kernels of csrc/am_encoder.hip): batch norm
+            # only — instance statistics couple all nodes of an instance — and the staged features must fit the LDS
+            return kind == "batch" and td["locs"].is_cuda and 6 * n * 4 + 36 * 1024 <= 80 * 1024
         return kind in ("batch", "instance") and td["locs"].is_cuda
 
     def encode(self, td, cache_dtype: torch.dtype, want_hidden: bool = False,
@@ -250,13 +252,11 @@ class PackedEncoder:
         a.ctx_first, a.ctx_cur, a.q_bias, a.hidden = ptr(ctx_first), ptr(ctx_cur), ptr(q_bias), ptr(hidden)
         if tokens is None:
             tokens = n > _lib.lib().rl4co_am_encoder_max_nodes()
-        if tokens and not exact:
-            raise NotImplementedError("the token-tile launches exist for the fp32 encoder (16-bit: policy._encode_tokens_bf16)")
         if tokens:
-            entry = "rl4co_am_encoder_tokens_f32"
-            need = _lib.lib().rl4co_am_encoder_tokens_f32_workspace(b, n)
+            entry = "rl4co_am_encoder_tokens_f32" if exact else "rl4co_am_encoder_tokens16"
+            need = getattr(_lib.lib(), entry + "_workspace")(b, n)
             ws = torch.empty(need, dtype=torch.uint8, device=dev)  # (the caching allocator hands the same block back every rollout)
-            st = _lib.lib().rl4co_am_encoder_tokens_f32(C.byref(a), ws.data_ptr(), need, torch.cuda.current_stream().cuda_stream)
+            st = getattr(_lib.lib(), entry)(C.byref(a), ws.data_ptr(), need, torch.cuda.current_stream().cuda_stream)
         else:
             entry = "rl4co_am_encoder_f32" if exact else "rl4co_am_encoder"
             st = getattr(_lib.lib(), entry)(C.byref(a), torch.cuda.current_stream().cuda_stream)

@@ -373,3 +373,74 @@ def test_policy_under_ambient_fp16_autocast_runs_on_the_kernels(env_name, num_lo
         g = GraphedRollout(pol16, env, data, decode_type="greedy")
         again = g(data)
     assert torch.equal(again["actions"], out16["actions"]) and torch.equal(again["reward"], out16["reward"])
+
+
+@pytest.mark.parametrize("act", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("env_name,num_loc,batch", [("tsp", 100, 64), ("cvrp", 100, 64), ("cvrp", 200, 32), ("tsp", 300, 16), ("pdp", 140, 16),
+                                                    ("cvrp", 500, 16)])
+def test_token_tile_16bit_encoder_matches_float64(env_name, num_loc, batch, act):
+    """The 16-bit token-tile kernels (csrc/am_encoder.hip: tok16_*, any graph size) against the float64 evaluation of the
+    same modules (3e-2 bf16 / 1e-2 fp16 relative Frobenius error, and no worse than 2.5x torch's own autocast path), and up
+    to 128 nodes against the fused kernel (same GEMMs; the attention is the flash kernel instead of the in-register one)."""
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.policy import AttentionModelPolicy
+    from tests.test_gpu_encoder_f32 import _double_reference
+
+    torch.manual_seed(0)
+    pol = AttentionModelPolicy(env_name, encoder_autocast=act, cache_dtype=act).cuda().eval()
+    _perturb_norm_stats(pol)
+    env = get_env(env_name, generator_params=dict(num_loc=num_loc, device="cuda"), device="cuda")
+    torch.manual_seed(3)
+    td = env.reset(env.generator(batch_size=[batch]))
+    pe = pol._packed_encoder()
+    assert pe.supported(td)
+    with torch.inference_mode():
+        cache, hidden = pe.encode(td, act, want_hidden=True, act_dtype=act, tokens=True)
+        with torch.autocast("cuda", dtype=act):
+            h16, _ = pol.encoder(td)
+    torch.cuda.synchronize()
+    h64, c64 = _double_reference(pol, td)
+    tol = REL_TOL if act == torch.bfloat16 else 1e-2
+    checks = {"hidden": (hidden, h64), "ctx_cur": (cache.ctx_cur, c64.ctx_cur), "q_bias": (cache.q_bias, c64.q_bias)}
+    for i in range(3):
+        checks[f"plane{i}"] = (cache.kvl[i], c64.kvl[i])
+    if env_name == "tsp":
+        checks["ctx_first"] = (cache.ctx_first, c64.ctx_first)
+    for nm, (got, exact) in checks.items():
+        assert torch.isfinite(got.float()).all(), nm
+        e = float((got.double() - exact).norm() / exact.norm())
+        assert e <= tol, f"{nm}: {e:.4f}"
+    e_auto = float((h16.double() - h64).norm() / h64.norm())
+    e_k = float((hidden.double() - h64).norm() / h64.norm())
+    assert e_k <= 2.5 * e_auto + 2e-3, (e_k, e_auto)
+    if td["action_mask"].shape[-1] <= 128:
+        with torch.inference_mode():
+            fused, hf = pe.encode(td, act, want_hidden=True, act_dtype=act, tokens=False)
+        assert _rel(hidden, hf) <= tol and _rel(cache.kvl[2], fused.kvl[2]) <= tol
+
+
+def test_token_tile_attention_fast_and_exact_paths_agree():
+    """rl4co_attn_flash_pre: heads under the score bound take the max-free softmax path, the others the exact one — the
+    same policy with its query weights scaled up (bound exceeded everywhere) must give the exact path's answer, and a bound
+    of zeros / NULL must not change the result of the fast path beyond 16-bit rounding."""
+    import ctypes as C
+
+    from rl4co_amd import _lib
+
+    torch.manual_seed(0)
+    b, n = 8, 333
+    qkv = (torch.randn(b, n, 384, device="cuda") * 0.7).to(torch.bfloat16).contiguous()
+    out = {}
+    for name, bound in (("fast", torch.full((b, 8, 2), 1.0, device="cuda")), ("exact", torch.full((b, 8, 2), 1e9, device="cuda")), ("null", None)):
+        o = torch.empty(b, n, 128, dtype=torch.bfloat16, device="cuda")
+        st = _lib.lib().rl4co_attn_flash_pre_bf16(qkv.data_ptr(), None if bound is None else bound.data_ptr(), b, n, o.data_ptr(),
+                                                  torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "rl4co_attn_flash_pre_bf16")
+        out[name] = o.float()
+    q, k, v = (qkv.float()[..., i * 128:(i + 1) * 128].view(b, n, 8, 16).transpose(1, 2) for i in range(3))
+    want = torch.softmax((q @ k.transpose(-1, -2)) * 0.6931471805599453, -1) @ v  # scores are in the exp2 domain
+    want = want.transpose(1, 2).reshape(b, n, 128)
+    for name, o in out.items():
+        assert _rel(o, want) <= 1e-2, name
+    assert torch.equal(out["exact"], out["null"])
+    assert _rel(out["fast"], out["exact"]) <= 5e-3
