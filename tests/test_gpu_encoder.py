@@ -200,9 +200,10 @@ def test_packed_weights_refresh_after_update():
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 def test_token_parallel_encoder_for_large_graphs_matches_torch(dt):
-    """N > 128 (the fused per-instance kernel's limit): the inference encoder runs on the token-parallel
-    kernels (csrc/am_train_ops.hip) + the flash-style attention kernel (csrc/am_attn_flash.hip). Same bound as the
-    fused encoder test: within 3e-2 relative Frobenius error of the fp32 torch encoder."""
+    """N > 128 (the fused per-instance kernel's limit), the per-op path: token-parallel GEMM / norm kernels
+    (csrc/am_train_ops.hip) + the flash-style attention kernel (csrc/am_attn_flash.hip) — since r04 the path taken when the
+    token-tile kernels do not serve the call (fold off, init embeddings asked for); the policy itself takes the token-tile
+    launches. Same bound as the fused encoder test: within 3e-2 relative Frobenius error of the fp32 torch encoder."""
     from rl4co_amd.envs import get_env
     from rl4co_amd.policy import AttentionModelPolicy
 
@@ -215,7 +216,10 @@ def test_token_parallel_encoder_for_large_graphs_matches_torch(dt):
                 m.running_var.uniform_(0.5, 1.5)
     env = get_env("cvrp", generator_params=dict(num_loc=200, device="cuda"), device="cuda")
     td = env.reset(batch_size=[16])
-    assert pol._token_encoder_usable(td) and not pol._packed_encoder().supported(td)
+    assert pol._token_encoder_usable(td) and pol._packed_encoder().supported(td)
+    calls = []
+    orig = pol._packed_encoder().encode
+    pol._packed_encoder().encode = lambda *a, **k: (calls.append(k.get("tokens")), orig(*a, **k))[1]
     with torch.inference_mode():
         h, h0 = pol._encode_tokens_bf16(td)
         assert h.dtype == dt
@@ -224,6 +228,7 @@ def test_token_parallel_encoder_for_large_graphs_matches_torch(dt):
         assert rel <= 3e-2, rel
         assert float((h0.float() - ref0).norm() / ref0.norm()) <= 1e-2
         out = pol(td, env, phase="test", decode_type="greedy")  # end to end through the WIDE decode variant
+    assert calls, "the policy did not take the token-tile launches"
     assert out["reward"].shape == (16,) and bool(torch.isfinite(out["reward"]).all())
 
 
