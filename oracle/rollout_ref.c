@@ -998,13 +998,13 @@ int oracle_pomo_best(const float* reward, const int64_t* actions, int A, int S, 
       int bi = 0;
       for (int s = 1; s < S; ++s) {
         const float v = reward[((int64_t)s * A + a) * B + b];
-        if (v > best) { best = v; bi = s; }
+        if (v > best || (v != v && best == best)) { best = v; bi = s; }  /* torch.max: a NaN is maximal, the first one wins */
       }
       if (max_reward) max_reward[(int64_t)b * A + a] = best;
       if (best_start) best_start[(int64_t)b * A + a] = bi;
       if (actions && best_ms_actions)
         memcpy(best_ms_actions + ((int64_t)b * A + a) * T, actions + (((int64_t)bi * A + a) * B + b) * T, (size_t)T * 8);
-      if (ba < 0 || best > bv) { bv = best; ba = a; bs_of_ba = bi; }
+      if (ba < 0 || best > bv || (best != best && bv == bv)) { bv = best; ba = a; bs_of_ba = bi; }
     }
     if (max_aug_reward) max_aug_reward[b] = bv;
     if (best_aug) best_aug[b] = ba;

@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(64) pomo_best_kernel(const float* __restrict__
     int bi = 0;
     for (int s = 1; s < S; ++s) {
       const float v = reward[((int64_t)s * A + a) * B + b];
-      if (v > best) {
+      if (v > best || (v != v && best == best)) {  // torch.max: a NaN is maximal, the first one wins
         best = v;
         bi = s;
       }
@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(64) pomo_best_kernel(const float* __restrict__
   int ba = 0;
   float bv = val[0];
   for (int a = 1; a < A; ++a) {
-    if (val[a] > bv) {
+    if (val[a] > bv || (val[a] != val[a] && bv == bv)) {
       bv = val[a];
       ba = a;
     }

@@ -231,14 +231,22 @@ def wrap_dataset_with_baseline(policy, env, dataset: TensorDictDataset, batch_si
 # the boundary, because it IS host state: the reference takes it from torch's global generator (transforms.py:81) and a
 # seeded run must consume that stream identically.
 
+# Device contract (differs from the reference, which runs these on any device): the features must live on the GPU — a CPU
+# tensor raises Rl4coLibraryError, like every other entry of the package (no CPU fallback) — in any floating dtype and
+# layout (converted to contiguous fp32, the type the kernels and the reference's generators use).
+
 _AUGMENT_KINDS = ("symmetric", "dihedral8")
+
+
+def _f32c(x: Tensor) -> Tensor:
+    return x if (x.dtype == torch.float32 and x.is_contiguous()) else x.float().contiguous()
 
 
 def dihedral_8_augmentation(xy: Tensor) -> Tensor:
     """[B, N, 2] -> [8B, N, 2]: the 8 symmetries of the unit square, aug-major (transforms.py:16-38), one launch."""
     from . import kernels as K
 
-    return K.augment_dihedral8(xy.contiguous())
+    return K.augment_dihedral8(_f32c(xy))
 
 
 def dihedral_8_augmentation_wrapper(xy: Tensor, reduce: bool = True, *args, **kw) -> Tensor:
@@ -254,8 +262,9 @@ def _rotation_terms(phi: Tensor):
 
 
 def _draw_angles(rows: int, identity_rows: int, device, phi: Tensor | None = None) -> Tensor:
-    """U[0, 4 pi) per output row from the global generator of ``device`` (transforms.py:81: a CPU feature consumes the
-    reference's own stream), or the injected ``phi``; the first ``identity_rows`` rows get angle 0 — the identity."""
+    """U[0, 4 pi) per output row from the global generator of ``device`` (transforms.py:81; on the GPU that is the device
+    generator — a seeded run reproduces itself, not the reference's CPU stream: the parity tests inject the reference's
+    angles through ``phi``), or the injected ``phi``; the first ``identity_rows`` rows get angle 0 — the identity."""
     phi = torch.rand(rows, device=device) * 4 * math.pi if phi is None else phi.to(device=device, dtype=torch.float32).clone()
     phi[:identity_rows] = 0.0
     return phi
@@ -269,7 +278,7 @@ def symmetric_augmentation(xy: Tensor, num_augment: int = 8, first_augment: bool
 
     rows = xy.shape[0]
     phi = _draw_angles(rows, 0 if first_augment else rows // num_augment, xy.device, phi)
-    return K.augment_symmetric(xy.contiguous(), *_rotation_terms(phi))
+    return K.augment_symmetric(_f32c(xy), *_rotation_terms(phi))
 
 
 def min_max_normalize(x: Tensor) -> Tensor:
@@ -315,9 +324,9 @@ class StateAugmentation:
 
         a, b = self.num_augment, base.shape[0]
         if self.kind == "dihedral8":
-            return K.augment_dihedral8(base.contiguous())
+            return K.augment_dihedral8(_f32c(base))
         if self.kind == "symmetric":
-            return K.augment_symmetric(base.contiguous(), *_rotation_terms(_draw_angles(a * b, b, base.device)))
+            return K.augment_symmetric(_f32c(base), *_rotation_terms(_draw_angles(a * b, b, base.device)))
         return self.augmentation(_tile_rows(base, a), a)
 
     def __call__(self, td):

@@ -428,7 +428,8 @@ class AttentionModelPolicy(nn.Module):
 
     Args follow ``zoo/am/policy.py:50-85``. Extra, engine-specific arguments:
         cache_dtype: dtype of the three streamed cache planes (``torch.bfloat16`` / ``torch.float16`` halve the bytes
-            per decode step; ``torch.float32`` is the parity configuration). ``None`` (the default) follows the
+            per decode step; ``torch.float32`` is the parity configuration). ``None`` (the default SINCE r03; it was
+            float32 before: callers that relied on fp32 planes under an ambient autocast must now ask for them) follows the
             precision regime the way the reference's own cache does — its K / V / logit key are the output of a Linear
             and therefore 16-bit under autocast (zoo/am/decoder.py:201-228): float32 without autocast, bfloat16 under
             bf16 autocast, under fp16 autocast float16 for inference rollouts and bfloat16 for training steps (wider
@@ -476,11 +477,11 @@ class AttentionModelPolicy(nn.Module):
         # raw logit key; cache.py) — the strictest greedy-parity configuration (fp32, torch encoder, TSP / CVRP,
         # inference only): measured 4 instead of 10 near-tie flips in 4096 TSP-100 tours against the reference
         self.fold = fold
-        # TRAINING steps under fp16 autocast (Lightning's default "16-mixed"): the training-encoder kernels compute in
-        # bf16 (same 16-bit storage and MFMA rate, 8 instead of 11 significant bits, no overflow under GradScaler's loss
-        # scale). Off by default — the encoder then trains on torch under fp16 autocast exactly as the reference does;
-        # on, the step runs on the bf16 kernels (a precision CHANGE the caller opts into). Inference under fp16 autocast
-        # is served by true fp16 kernels either way (csrc/am_encoder.hip, act_dtype = f16)
+        # TRAINING steps under fp16 autocast (Lightning's default "16-mixed"). Off (default): the step runs on the fp16
+        # builds of the training-encoder kernels (csrc/*_f16.hip: IEEE-half operands, conversions overflow to infinity,
+        # which is what GradScaler's inf check expects) — the reference's own regime. On: the same step on the bf16 builds
+        # (same 16-bit storage and MFMA rate, 8 instead of 11 significant bits, no overflow under the loss scale) — a
+        # precision CHANGE the caller opts into. Inference under fp16 autocast is served by fp16 kernels either way
         self.train_half_as_bf16 = train_half_as_bf16
         self._packed = None
         self._ambient_autocast = None  # set for the duration of a forward() entered under torch.autocast
@@ -906,7 +907,7 @@ class AttentionModelPolicy(nn.Module):
 
                     t_max = __import__("rl4co_amd.teacher", fromlist=["max_nodes"]).max_nodes()
                     why = (f"{n} nodes are beyond the kernels' limit ({t_max})" if n > t_max else
-                           f"{cache_dtype} planes: the backward kernels read float32 or bfloat16 planes")
+                           f"{cache_dtype} planes are not served by the backward kernels (float32, bfloat16 or float16 planes) for this call")
                     _l.warn_fallback(f"teacher/{self.env_name}/{n}/{cache_dtype}",
                                      f"teacher-forced backward for {self.env_name}: {why} — dense torch re-evaluation with autograd")
                 step_logps = self.evaluate_log_probs(td, hidden, out_actions, n_rep, tanh_clipping, temperature,
