@@ -511,13 +511,16 @@ class Bench:
                 + (5 if env_name == "tsp" else 4) * 2 * n_ * d_ * d_
             enc_ms = sum(encode_ms) / len(encode_ms)
             tf = flop_inst * batch / (enc_ms * 1e-3) / 1e12
-            peak = MFMA_F32_PEAK_TFLOPS if full else MFMA_PEAK_TFLOPS
+            exact = full or enc_dtype is None  # (--encoder-dtype f32: the exact-fp32 kernels on any leg)
+            peak = MFMA_F32_PEAK_TFLOPS if exact else MFMA_PEAK_TFLOPS
             res["encoder_roofline"] = {
-                "kernel": ("am_encoder_f32_kernel" if full else "am_encoder_kernel") +
-                          " (init embedding + 3 x [MHA, norm, FFN, norm] + cache fold, one workgroup per instance)",
+                "kernel": (("am_encoder_f32_kernel" if exact else "am_encoder_kernel") +
+                           " (init embedding + 3 x [MHA, norm, FFN, norm] + cache fold, one workgroup per instance)") if n_nodes <= 128 else
+                          ("token-tile encoder, " + ("am_tokens_f32.hip" if exact else "tok16_* + attn_flash") +
+                           " (init embedding, 3 x [QKV, streamed attention, out-proj + norm + MLP + norm], fold: sum of the launches)"),
                 "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                 "flop_per_instance": flop_inst, "launch_ms_mean": enc_ms,
-                "note": "algorithmic FLOPs at N nodes (padding excluded); " + ("fp32 MFMA peak" if full else "16-bit dense MFMA peak"),
+                "note": "algorithmic FLOPs at N nodes (padding excluded); " + ("fp32 MFMA peak" if exact else "16-bit dense MFMA peak"),
             }
         if full and self.world == 1 and not a.no_parity:
             from tools import trained_parity as TP
