@@ -416,6 +416,26 @@ typedef struct rl4co_am_encoder_args {
 int rl4co_am_encoder(const rl4co_am_encoder_args* args, void* stream);
 int rl4co_am_encoder_max_nodes(void);
 
+/* The TRAINING forward of an instance-norm encoder stack (POMO: zoo/pomo/model.py:59-63; nn/graph/attnnet.py:16-106) in ONE
+ * launch — the fused kernel's layer body fed with the init embedding, one workgroup per instance, N <= 128 — writing, per
+ * layer, every tensor the backward kernels (rl4co_linear_* input gradients, rl4co_wgrad_*, rl4co_attn_bwd_*,
+ * rl4co_skip_inorm_bwd_*) read: the per-op forward it replaces took seven launches and 27 [B N,128]-sized passes per
+ * layer. Of `args` only B, N, num_layers, norm (must be 1), act_dtype, the packed weights (W_q UNSCALED: the scores are
+ * scaled in the kernel, the saved q is the q the products used), bqkv, b1 and n*_scale / n*_shift (gamma, beta) are read. */
+typedef struct rl4co_am_train_save {
+  const void* x0; /* [B,N,128] act_dtype: the encoder's input (init embedding)                     */
+  void* out;      /* [L,B,N,128] layer outputs (out[l-1] is layer l's input; out[L-1] the result)   */
+  void* qkv;      /* [L,B,N,384] q | k | v                                                          */
+  void* att;      /* [L,B,N,128] attention output before out_proj                                   */
+  void* y1;       /* [L,B,N,128] x + attention branch (pre-norm; the branch's bias cancels in the norm) */
+  void* x1;       /* [L,B,N,128] norm1 output                                                       */
+  void* h;        /* [L,B,N,512] relu(x1 W1^T + b1)                                                 */
+  void* y2;       /* [L,B,N,128] x1 + MLP branch (pre-norm)                                         */
+  float* lse;     /* [L,B,8,N] log-sum-exp of the scaled scores, log2 domain (rl4co_attn_fwd's)     */
+  float* stats;   /* [L,4,B,128] mean1, rstd1, mean2, rstd2                                         */
+} rl4co_am_train_save;
+int rl4co_am_encoder_train_fwd(const rl4co_am_encoder_args* args, const rl4co_am_train_save* save, void* stream);
+
 /* The 16-bit encoder + cache fold for graphs of ANY size (csrc/am_encoder.hip: token-tile kernels; BASELINE configs[4],
  * CVRP-500): the fused kernel's layer algebra, GEMM routine and packed weights over tiles of 128 nodes — init embedding,
  * per layer [Q / K / V projection (+ per-head score bounds), rl4co_attn_flash_pre_*, ONE kernel for out-proj + norm + MLP +

@@ -124,6 +124,7 @@ SYMBOLS = {
     "rl4co_wgrad_bf16": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp]),
     "rl4co_am_encoder": (C.c_int, [_vp, _vp]),
     "rl4co_am_encoder_max_nodes": (C.c_int, []),
+    "rl4co_am_encoder_train_fwd": (C.c_int, [_vp, _vp, _vp]),
     "rl4co_am_encoder_tokens16": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "rl4co_am_encoder_tokens16_workspace": (C.c_int64, [C.c_int, C.c_int]),
     "rl4co_am_encoder_f32": (C.c_int, [_vp, _vp]),
@@ -156,6 +157,13 @@ SYMBOLS = {
     "rl4co_attn_flash_pre_f16": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_wgrad_f16": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp]),
 }
+
+
+class AmTrainSave(C.Structure):
+    """Mirror of ``struct rl4co_am_train_save`` (field order and types must match the header)."""
+
+    _fields_ = [("x0", _vp), ("out", _vp), ("qkv", _vp), ("att", _vp), ("y1", _vp), ("x1", _vp), ("h", _vp), ("y2", _vp),
+                ("lse", _vp), ("stats", _vp)]
 
 
 def dtype_id(dtype) -> int:

@@ -167,6 +167,26 @@ __device__ inline void store_t(E* ys, const f32x16 (&acc)[TT], int dim0, int lan
   }
 }
 
+// Out^T accumulator tile -> global rows [token][dim] of `row_stride` elements (tokens < N): 8-byte stores, the two halves of
+// a wave side by side (16 bytes per token row and 8-dim group; the rows' other pieces come from the other waves and meet
+// in the XCD's write-back L2)
+template <int TT, typename E>
+__device__ inline void save_t(E* dst, int64_t row_stride, const f32x16 (&acc)[TT], int dim0, int N, int lane) {
+  const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    if (32 * tt + l31 < N) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        vec4<E> v;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) v[s] = (E)acc[tt][4 * c + s];
+        *reinterpret_cast<vec4<E>*>(dst + (int64_t)(32 * tt + l31) * row_stride + dim0 + 8 * c + 4 * hi) = v;
+      }
+    }
+  }
+}
+
 template <typename E>
 struct LayerPtrs {
   const E *wqkv, *wo, *w1, *w2;
@@ -223,6 +243,79 @@ __device__ inline void residual_norm(E* xs, f32x16 (&y)[TT], int dim0, const flo
       for (int r = 0; r < 16; ++r) y[tt][r] = fmaf(y[tt][r], ga[r], be[r]);
   }
   store_t<TT>(xs, y, dim0, lane);
+}
+
+// What the TRAINING forward (am_encoder_kernel<.., TRAIN = true>, rl4co_am_encoder_train_fwd) keeps for the backward
+// kernels of csrc/am_train_ops.hip / am_train_attn.hip, per layer l — the tensors rl4co_amd/train_ops.py's per-op path
+// saves, in the layouts those kernels read (nn/graph/attnnet.py:16-55, instance norm: zoo/pomo/model.py:59-63).
+template <typename E>
+struct TrainSave {
+  const E* x0;   // [B,N,128] the encoder's input (init embedding)
+  E* out;        // [L,B,N,128] layer outputs (out[l - 1] is layer l's input)
+  E* qkv;        // [L,B,N,384] q | k | v, unscaled
+  E* att;        // [L,B,N,128] attention output (before out_proj)
+  E* y1;         // [L,B,N,128] x + attention branch, pre-norm (the branch's constant bias cancels in the instance norm)
+  E* x1;         // [L,B,N,128] norm1 output = the MLP block's input
+  E* h;          // [L,B,N,512] relu(x1 W1^T + b1)
+  E* y2;         // [L,B,N,128] x1 + MLP branch, pre-norm
+  float* lse;    // [L,B,8,N] log-sum-exp of the scaled scores, log2 domain (am_train_attn.hip's convention)
+  float* stats;  // [L,4,B,128] mean1, rstd1, mean2, rstd2
+};
+constexpr float kTrainScale = 0.25f * 1.44269504088896341f;  // 1/sqrt(16) in the exp2 domain, applied to the scores
+
+// Training epilogue: y = x + branch rounded to the element type (the value the backward re-reads), instance statistics of
+// the ROUNDED values (as csrc/am_train_ops.hip: skip_inorm_fwd_kernel), both saved; normalised output back into xs.
+template <int TT, typename E>
+__device__ inline void residual_norm_train(E* xs, f32x16 (&y)[TT], int dim0, const float* na, const float* nb, int N, int lane,
+                                           E* y_out, float* mean_out, float* rstd_out) {
+  const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const vec4<E> x = *reinterpret_cast<const vec4<E>*>(xs + (32 * tt + l31) * kRS + dim0 + 8 * c + 4 * hi);
+      vec4<E> yr;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        yr[s] = (E)((float)x[s] + y[tt][4 * c + s]);
+        y[tt][4 * c + s] = (float)yr[s];
+      }
+      if (32 * tt + l31 < N) *reinterpret_cast<vec4<E>*>(y_out + (int64_t)(32 * tt + l31) * kD + dim0 + 8 * c + 4 * hi) = yr;
+    }
+  }
+  const float inv_n = 1.0f / (float)N;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int d = dim0 + rowmap(r, hi);
+    float s = 0.0f;
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) s += (32 * tt + l31 < N) ? y[tt][r] : 0.0f;
+    s = rl4co::bfly_sum<1, 32>(s);
+    const float mean = s * inv_n;
+    float v = 0.0f;
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const float dd = y[tt][r] - mean;
+      v += (32 * tt + l31 < N) ? dd * dd : 0.0f;
+    }
+    v = rl4co::bfly_sum<1, 32>(v);
+    const float rstd = rsqrtf(v * inv_n + 1e-5f);
+    if (l31 == 0) {
+      mean_out[d] = mean;
+      rstd_out[d] = rstd;
+    }
+    const float ga = na[d], be = nb[d];
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) y[tt][r] = fmaf((y[tt][r] - mean) * rstd, ga, be);
+  }
+  store_t<TT>(xs, y, dim0, lane);
+}
+
+// rows 0 .. rows - 1 of an LDS tile [.][kRS] -> global rows of `row_stride` elements, 16-byte lanes
+template <typename E>
+__device__ inline void rows_out(const E* xs, E* dst, int64_t row_stride, int rows, int tid) {
+  for (int i = tid; i < rows * 16; i += kThreads)
+    *reinterpret_cast<uint4*>(dst + (int64_t)(i >> 4) * row_stride + 8 * (i & 15)) = *reinterpret_cast<const uint4*>(xs + (i >> 4) * kRS + 8 * (i & 15));
 }
 
 // Init embedding of rows n0 .. n0 + rows_pad - 1 of instance b into xs (rows past N zeroed); contains one __syncthreads().
@@ -337,8 +430,10 @@ __device__ inline float wave_max32(float v) {  // maximum over the 32 token colu
 // VR4: valid 4-register groups of the LAST key tile (keys 32 (TT-1) ..): ceil((N - 32 (TT-1)) / 8). Registers beyond
 // them are padding keys in every lane — their exps, conversions and (from 8 registers up) the second value product
 // are dropped at compile time (TSP-100: four valid keys in the fourth tile, 12 of 16 registers gone).
-template <typename E, int TT, int VR4>
-__global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_encoder_args a) {
+// TRAIN: the training forward of an instance-norm encoder (POMO) — the same layer body fed with the init embedding, scores
+// scaled in the kernel (the saved q is the q the products used), every tensor of TrainSave written on the way, no fold.
+template <typename E, int TT, int VR4, bool TRAIN = false>
+__global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_encoder_args a, const TrainSave<E> ts) {
   using bf16x8 = vec8<E>;  // (historic names: the 16-bit operand fragments of whichever element type E is)
   using bf16x4 = vec4<E>;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -369,7 +464,17 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
 
   // ---- init embedding (K = 2 .. 6: plain VALU), padding rows zeroed ---------------------------
   stage_biases(0);
-  init_embed_rows16<E>(a, b, 0, 32 * TT, xs, reinterpret_cast<float*>(ys), tid);  // (ys is free here: the features are staged in it)
+  if constexpr (TRAIN) {
+    const E* src = ts.x0 + (int64_t)b * N * kD;
+    for (int i = tid; i < 32 * TT * 16; i += kThreads) {
+      const int row = i >> 4, c16 = i & 15;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (row < N) v = *reinterpret_cast<const uint4*>(src + (int64_t)row * kD + 8 * c16);
+      *reinterpret_cast<uint4*>(xs + row * kRS + 8 * c16) = v;
+    }
+  } else {
+    init_embed_rows16<E>(a, b, 0, 32 * TT, xs, reinterpret_cast<float*>(ys), tid);  // (ys is free here: the features are staged in it)
+  }
   __syncthreads();
 
   for (int layer = 0; layer < a.num_layers; ++layer) {
@@ -412,7 +517,9 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       // Q^T parked in this wave's own 32 columns of ys (each lane re-reads only its own token
       // row, and later overwrites it with the attention output of that same row)
       store_t<TT>(ys, acc, 32 * w, lane);
+      if constexpr (TRAIN) save_t<TT>(ts.qkv + ((int64_t)layer * a.B + b) * N * 3 * kD, 3 * kD, acc, 32 * w, N, lane);
       gemm_t<TT>(acc, wf, xs, lane, L.wqkv, 8, 8 + w, 0, bias_tile(L.bqkv + kD, 32 * w, hi));
+      if constexpr (TRAIN) save_t<TT>(ts.qkv + ((int64_t)layer * a.B + b) * N * 3 * kD + kD, 3 * kD, acc, 32 * w, N, lane);
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
         kf[tt][0] = frag_from_acc<E>(acc[tt], 0);
@@ -429,6 +536,18 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
 #pragma unroll
         for (int r = 0; r < 16; ++r) bt[r] = bv;
         gemm_t<TT, false>(acc, wf, xs, lane, static_cast<const E*>(nullptr), 0, 0, 0, bt);  // nothing in flight across the attention (register peak)
+      }
+      if constexpr (TRAIN) {
+        // plain form: the lane owns ONE dim column and sixteen token rows per tile — 2-byte stores, 32 consecutive dims
+        // (64 bytes) of a token row per half wave; the workgroup's four waves complete the row in L2
+        E* vdst = ts.qkv + ((int64_t)layer * a.B + b) * N * 3 * kD + 2 * kD + 32 * w + l31;
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int tok = 32 * tt + rowmap(r, hi);
+            if (tok < N) vdst[(int64_t)tok * 3 * kD] = (E)acc[tt][r];
+          }
       }
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
@@ -448,7 +567,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
     bool fast_head[2];
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
-      const float b2 = wave_max32(qn2[hh]) * wave_max32(kn2[hh]);
+      const float b2 = wave_max32(qn2[hh]) * wave_max32(kn2[hh]) * (TRAIN ? kTrainScale * kTrainScale : 1.0f);
       fast_head[hh] = kWideRange<E> && __builtin_amdgcn_readfirstlane((b2 <= kFastBound * kFastBound) ? 1 : 0) != 0;
     }
 
@@ -472,6 +591,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         }
         f32x16 acc0, acc1;  // two accumulators: half the dependent-MFMA chain; each starts from a literal-zero C operand
         if (TT == 1) acc1 = zero16();
+        float m_used = 0.0f;  // (TRAIN: the maximum the numerators were taken against, for the saved log-sum-exp)
         if (fast_head[hh]) {
           // bounded scores: p = exp2(s) tile by tile — no maximum, no subtraction, no score tile kept alive
 #pragma unroll
@@ -483,7 +603,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
             for (int r = 0; r < 16; ++r) {
               float v = 0.0f;
               if (r < nreg) {
-                v = __builtin_amdgcn_exp2f(sk[r]);
+                v = __builtin_amdgcn_exp2f(TRAIN ? sk[r] * kTrainScale : sk[r]);
                 if (kt == TT - 1) v = (32 * kt + rowmap(r, hi) < N) ? v : 0.0f;  // padding keys inside the valid registers
               }
               p[r] = v;
@@ -502,6 +622,10 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
 #pragma unroll
           for (int kt = 0; kt < TT; ++kt) {
             s[kt] = mfma(kf[kt][hh], qf, zero16());
+            if constexpr (TRAIN) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) s[kt][r] *= kTrainScale;
+            }
             if (kt == TT - 1) {  // TT = ceil(N/32): only the last key tile can hold padding keys
 #pragma unroll
               for (int r = 0; r < 16; ++r)
@@ -511,6 +635,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
             for (int r = 0; r < 16; ++r) m = fmaxf(m, s[kt][r]);
           }
           m = fmaxf(m, rl4co::bfly_f<32>(m));
+          m_used = m;
 #pragma unroll
           for (int kt = 0; kt < TT; ++kt) {
 #pragma unroll
@@ -526,6 +651,11 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         }
         // rows of the other head's dims carried ones: every one of them is the row sum of this query's numerators
         const float inv = 1.0f / (acc0[8 * (1 - hh)] + acc1[8 * (1 - hh)]);
+        if constexpr (TRAIN) {
+          if (hi == 0 && 32 * qt + l31 < N)
+            ts.lse[(((int64_t)layer * a.B + b) * 8 + 2 * w + hh) * N + 32 * qt + l31] =
+                m_used + __builtin_amdgcn_logf(acc0[8 * (1 - hh)] + acc1[8 * (1 - hh)]);  // log2 domain
+        }
 #pragma unroll
         for (int r = 0; r < 8; ++r) o[8 * hh + r] = (acc0[8 * hh + r] + acc1[8 * hh + r]) * inv;
       }
@@ -541,6 +671,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
     __builtin_amdgcn_sched_barrier(0);     // keep these loads out of the attention loop (its register peak)
     load_wfrags(wf, L.wo, 8, w, 0, lane);  // out-proj weights: in flight across the barrier
     __syncthreads();
+    if constexpr (TRAIN) rows_out(ys, ts.att + ((int64_t)layer * a.B + b) * N * kD, kD, N, tid);
 
     // ---- out-proj + residual + norm1 ---------------------------------------------------------------
     {
@@ -548,9 +679,15 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       // (out_proj's bias rides in the norm's shift — batch norm — or cancels in the per-channel mean — instance norm:
       // folded on the host, encoder.py)
       gemm_t<TT>(y, wf, ys, lane, L.w1, 8, w, 0, zero16());  // next: FFN1 chunk 0
-      residual_norm<TT>(xs, y, 32 * w, L.n1a, L.n1b, a.norm, N, lane);
+      if constexpr (TRAIN) {
+        float* st = ts.stats + ((int64_t)layer * 4 * a.B + b) * kD;
+        residual_norm_train<TT>(xs, y, 32 * w, L.n1a, L.n1b, N, lane, ts.y1 + ((int64_t)layer * a.B + b) * N * kD, st, st + (int64_t)a.B * kD);
+      } else {
+        residual_norm<TT>(xs, y, 32 * w, L.n1a, L.n1b, a.norm, N, lane);
+      }
     }
     __syncthreads();
+    if constexpr (TRAIN) rows_out(xs, ts.x1 + ((int64_t)layer * a.B + b) * N * kD, kD, N, tid);
 
     // ---- FFN: hidden in 4 chunks of 128, FFN2 accumulates across chunks -----------------------------
     {
@@ -567,17 +704,25 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         if (c > 0) __syncthreads();  // every wave is done reading the previous chunk
         store_t<TT>(ys, h1, 32 * w, lane);
         __syncthreads();
+        if constexpr (TRAIN) rows_out(ys, ts.h + ((int64_t)layer * a.B + b) * N * kFF + kD * c, kFF, N, tid);
         // next: FFN1 of the next chunk, then the next layer's Q projection, finally the first fold block
         const bool last_layer = layer + 1 == a.num_layers;
         const E* nxt = c < 3 ? L.w1 : (last_layer ? wf_all : wqkv_all + (int64_t)(layer + 1) * 3 * kD * kD);
         gemm_t<TT, true, false>(y2, wf, ys, lane, nxt, 8, c < 3 ? 4 * (c + 1) + w : w, 0, y2[0]);
       }
-      residual_norm<TT>(xs, y2, 32 * w, L.n2a, L.n2b, a.norm, N, lane);
+      if constexpr (TRAIN) {
+        float* st = ts.stats + (((int64_t)layer * 4 + 2) * a.B + b) * kD;
+        residual_norm_train<TT>(xs, y2, 32 * w, L.n2a, L.n2b, N, lane, ts.y2 + ((int64_t)layer * a.B + b) * N * kD, st, st + (int64_t)a.B * kD);
+      } else {
+        residual_norm<TT>(xs, y2, 32 * w, L.n2a, L.n2b, a.norm, N, lane);
+      }
     }
     // every wave is past the last chunk's barriers, i.e. done with this layer's biases: the next layer's take their place
     if (layer + 1 < a.num_layers) stage_biases(layer + 1);
     __syncthreads();
+    if constexpr (TRAIN) rows_out(xs, ts.out + ((int64_t)layer * a.B + b) * N * kD, kD, N, tid);
   }
+  if constexpr (TRAIN) return;  // the training forward ends with the last layer's output (the cache fold has its own autograd node)
 
   // ---- optional: final node embeddings h (fp32) ---------------------------------------------------
   if (a.hidden) {
@@ -912,9 +1057,9 @@ int launch_tokens16(const rl4co_am_encoder_args& a, void* workspace, hipStream_t
 template <typename E, int TT, int VR4>
 int launch_encoder(const rl4co_am_encoder_args& a, hipStream_t stream) {
   const int lds = 2 * 128 * kRS * 2 + kD * 4 + kBiasFloats * 4;
-  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_encoder_kernel<E, TT, VR4>),
+  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_encoder_kernel<E, TT, VR4, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL((am_encoder_kernel<E, TT, VR4>), dim3(a.B), dim3(kThreads), lds, stream, a);
+  hipLaunchKernelGGL((am_encoder_kernel<E, TT, VR4>), dim3(a.B), dim3(kThreads), lds, stream, a, TrainSave<E>{});
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }
@@ -940,7 +1085,59 @@ int launch_encoder_elem(const rl4co_am_encoder_args& a, hipStream_t s) {
   }
 }
 
+template <typename E, int TT, int VR4>
+int launch_train(const rl4co_am_encoder_args& a, const TrainSave<E>& ts, hipStream_t stream) {
+  const int lds = 2 * 128 * kRS * 2 + kD * 4 + kBiasFloats * 4;
+  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_encoder_kernel<E, TT, VR4, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL((am_encoder_kernel<E, TT, VR4, true>), dim3(a.B), dim3(kThreads), lds, stream, a, ts);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+template <typename E, int TT>
+int launch_train_tiles(const rl4co_am_encoder_args& a, const TrainSave<E>& ts, hipStream_t stream) {
+  switch ((a.N - 32 * (TT - 1) + 7) / 8) {
+    case 1: return launch_train<E, TT, 1>(a, ts, stream);
+    case 2: return launch_train<E, TT, 2>(a, ts, stream);
+    case 3: return launch_train<E, TT, 3>(a, ts, stream);
+    default: return launch_train<E, TT, 4>(a, ts, stream);
+  }
+}
+template <typename E>
+int launch_train_elem(const rl4co_am_encoder_args& a, const rl4co_am_train_save& sv, hipStream_t s) {
+  TrainSave<E> ts;
+  ts.x0 = static_cast<const E*>(sv.x0);
+  ts.out = static_cast<E*>(sv.out);
+  ts.qkv = static_cast<E*>(sv.qkv);
+  ts.att = static_cast<E*>(sv.att);
+  ts.y1 = static_cast<E*>(sv.y1);
+  ts.x1 = static_cast<E*>(sv.x1);
+  ts.h = static_cast<E*>(sv.h);
+  ts.y2 = static_cast<E*>(sv.y2);
+  ts.lse = sv.lse;
+  ts.stats = sv.stats;
+  switch ((a.N + 31) / 32) {
+    case 1: return launch_train_tiles<E, 1>(a, ts, s);
+    case 2: return launch_train_tiles<E, 2>(a, ts, s);
+    case 3: return launch_train_tiles<E, 3>(a, ts, s);
+    default: return launch_train_tiles<E, 4>(a, ts, s);
+  }
+}
+
 }  // namespace
+
+extern "C" int rl4co_am_encoder_train_fwd(const rl4co_am_encoder_args* args, const rl4co_am_train_save* save, void* stream) {
+  RL4CO_REQUIRE(args != nullptr && save != nullptr);
+  const rl4co_am_encoder_args& a = *args;
+  RL4CO_REQUIRE(a.B > 0 && a.N >= 2 && a.N <= 128);
+  RL4CO_REQUIRE(a.num_layers >= 1 && a.norm == 1);  // instance norm: batch statistics couple the instances
+  RL4CO_REQUIRE(a.act_dtype == RL4CO_DT_BF16 || a.act_dtype == RL4CO_DT_F16);
+  RL4CO_REQUIRE(a.wqkv_packed && a.wo_packed && a.w1_packed && a.w2_packed);
+  RL4CO_REQUIRE(a.bqkv && a.b1 && a.n1_scale && a.n1_shift && a.n2_scale && a.n2_shift);
+  RL4CO_REQUIRE(save->x0 && save->out && save->qkv && save->att && save->y1 && save->x1 && save->h && save->y2 && save->lse && save->stats);
+  hipStream_t s = rl4co::as_stream(stream);
+  return a.act_dtype == RL4CO_DT_F16 ? launch_train_elem<_Float16>(a, *save, s) : launch_train_elem<__bf16>(a, *save, s);
+}
 
 extern "C" int rl4co_am_encoder_max_nodes(void) { return 128; }
 

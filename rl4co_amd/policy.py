@@ -190,8 +190,19 @@ class _GraphAttentionNetwork(nn.Module):
         self.layers = nn.Sequential(
             *(_EncoderLayer(embed_dim, num_heads, feedforward_hidden, normalization) for _ in range(num_layers))
         )
+        self.fused_stack = True  # training, instance norm: one forward launch for the whole stack (False: per sub-block)
 
     def forward(self, x):
+        # training under 16-bit autocast, instance norm (POMO): the whole stack's forward as ONE launch of the fused
+        # per-instance kernel, which keeps what the per-op backward kernels read (train_ops.encoder_stack)
+        if (self.fused_stack and self.training and torch.is_grad_enabled() and x.is_cuda and torch.is_autocast_enabled()
+                and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
+                and all(getattr(l, "fused_train", False) and getattr(l, "fused_linear", False) for l in self.layers)):
+            from . import train_ops
+
+            x16 = x.to(torch.get_autocast_dtype("cuda"))
+            if train_ops.stack_usable(x16, self.layers):
+                return train_ops.encoder_stack(x16, self.layers)
         return self.layers(x)
 
 

@@ -377,6 +377,36 @@ def _f32(w: Tensor) -> Tensor:
     return w.detach().float().contiguous()
 
 
+def _attention_block_bwd(kind, dout, x2, wqkv16, wo16, qkv, lse, att, y, g32, mean, rstd):
+    """Backward of Normalization(x + MHA(x)) from the forward's saved tensors: (dx [B,N,128], dWqkv, dbqkv, dWo, dbo, dgamma,
+    dbeta) — gradients in fp32, dx in the activations' type."""
+    b, n, d = y.shape
+    dy, dgamma, dbeta = _norm_backward(kind, dout, y, g32, mean, rstd)  # d (x + s): the branch AND the skip
+    d2 = dy.view(-1, d)
+    datt = _gemm(d2, wo16.t().contiguous())
+    dwo, dbo = _wgrad(d2, att.reshape(-1, d), with_bias=True)
+    dqkv = torch.empty_like(qkv)
+    _lib.check(_k("rl4co_attn_bwd", qkv.dtype)(qkv.data_ptr(), datt.data_ptr(), lse.data_ptr(), b, n, dqkv.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), "rl4co_attn_bwd")
+    dq2 = dqkv.view(-1, 3 * d)
+    dx = _gemm(dq2, wqkv16.t().contiguous(), residual=d2)
+    dwqkv, dbqkv = _wgrad(dq2, x2.reshape(-1, d), with_bias=True)
+    return dx.view(b, n, d), dwqkv, dbqkv, dwo, dbo, dgamma, dbeta
+
+
+def _mlp_block_bwd(kind, dout, x2, h, w1_16, w2_16, y, g32, mean, rstd):
+    """Backward of Normalization(x + MLP(x)): (dx, dW1, db1, dW2, db2, dgamma, dbeta)."""
+    b, n, d = y.shape
+    dy, dgamma, dbeta = _norm_backward(kind, dout, y, g32, mean, rstd)
+    d2 = dy.view(-1, d)
+    h2 = h.reshape(-1, h.shape[-1])
+    dh = _gemm(d2, w2_16.t().contiguous(), mask=h2)  # (d W2) * [h > 0]
+    dw2, db2 = _wgrad(d2, h2, with_bias=True)
+    dx = _gemm(dh, w1_16.t().contiguous(), residual=d2)
+    dw1, db1 = _wgrad(dh, x2.reshape(-1, d), with_bias=True)
+    return dx.view(b, n, d), dw1, db1, dw2, db2, dgamma, dbeta
+
+
 class _AttentionBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, wqkv, bqkv, wo, bo, gamma, beta, eps, kind):
@@ -400,20 +430,8 @@ class _AttentionBlock(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, *_unused):
-        x2, wqkv16, wo16, qkv, lse, att, y, g32, mean, rstd = ctx.saved_tensors
-        b, n, d = y.shape
-        dy, dgamma, dbeta = _norm_backward(ctx.kind, dout, y, g32, mean, rstd)  # d (x + s): the branch AND the skip
-        d2 = dy.view(-1, d)
-        datt = _gemm(d2, wo16.t().contiguous())
-        dwo, dbo = _wgrad(d2, att.view(-1, d), with_bias=True)
-        dqkv = torch.empty_like(qkv)
-        _lib.check(_k("rl4co_attn_bwd", qkv.dtype)(qkv.data_ptr(), datt.data_ptr(), lse.data_ptr(), b, n, dqkv.data_ptr(),
-                                                  torch.cuda.current_stream().cuda_stream), "rl4co_attn_bwd")
-        dq2 = dqkv.view(-1, 3 * d)
-        dx = _gemm(dq2, wqkv16.t().contiguous(), residual=d2)
-        dwqkv, dbqkv = _wgrad(dq2, x2, with_bias=True)
-        t = ctx.pdt
-        return (dx.view(b, n, d), dwqkv.to(t), dbqkv.to(t), dwo.to(t), dbo.to(t), dgamma.to(t), dbeta.to(t), None, None)
+        dx, *grads = _attention_block_bwd(ctx.kind, dout, *ctx.saved_tensors)
+        return (dx, *(g.to(ctx.pdt) for g in grads), None, None)
 
 
 class _MLPBlock(torch.autograd.Function):
@@ -435,16 +453,106 @@ class _MLPBlock(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout, *_unused):
-        x2, h, w1_16, w2_16, y, g32, mean, rstd = ctx.saved_tensors
-        b, n, d = y.shape
-        dy, dgamma, dbeta = _norm_backward(ctx.kind, dout, y, g32, mean, rstd)
-        d2 = dy.view(-1, d)
-        dh = _gemm(d2, w2_16.t().contiguous(), mask=h)  # (d W2) * [h > 0]
-        dw2, db2 = _wgrad(d2, h, with_bias=True)
-        dx = _gemm(dh, w1_16.t().contiguous(), residual=d2)
-        dw1, db1 = _wgrad(dh, x2, with_bias=True)
+        dx, *grads = _mlp_block_bwd(ctx.kind, dout, *ctx.saved_tensors)
+        return (dx, *(g.to(ctx.pdt) for g in grads), None, None)
+
+
+# ---------------------------------------------------------------------------------------------------
+# the whole encoder stack's FORWARD as one launch (instance norm: POMO, zoo/pomo/model.py:59-63), the per-op backward
+# kernels fed from what it saved (csrc/am_encoder.hip: am_encoder_kernel<.., TRAIN>, rl4co_am_encoder_train_fwd)
+# ---------------------------------------------------------------------------------------------------
+_STACK_PARAMS = 12  # per layer: Wqkv, bqkv, Wo, bo, gamma1, beta1, W1, b1, W2, b2, gamma2, beta2
+
+
+def _pack_stack(w: Tensor) -> Tensor:
+    """[L, out, in] 16-bit -> the fused kernel's fragment order [L, out/32, in/16, 64, 8] (encoder.pack_weight, all layers at once)."""
+    l, out_f, in_f = w.shape
+    return w.view(l, out_f // 32, 32, in_f // 16, 2, 8).permute(0, 1, 3, 4, 2, 5).contiguous()
+
+
+class _FusedEncoderStack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0: Tensor, n_layers: int, eps: float, *params: Tensor):
+        import ctypes as C
+
+        from .encoder import AmEncoderArgs
+
+        assert len(params) == _STACK_PARAMS * n_layers
+        b, n, d = x0.shape
+        dt, dev = x0.dtype, x0.device
+        x0c = x0.contiguous()
+        per = [params[i::_STACK_PARAMS] for i in range(_STACK_PARAMS)]  # per kind: one tensor per layer
+        stack = lambda ts, to: torch.stack([t.detach() for t in ts]).to(to).contiguous()  # noqa: E731
+        wqkv16, wo16, w1_16, w2_16 = stack(per[0], dt), stack(per[2], dt), stack(per[6], dt), stack(per[8], dt)
+        bqkv, b1 = stack(per[1], torch.float32), stack(per[7], torch.float32)
+        g1, be1, g2, be2 = (stack(per[i], torch.float32) for i in (4, 5, 10, 11))
+        packed = [_pack_stack(w) for w in (wqkv16, wo16, w1_16, w2_16)]
+        new = lambda *shape, dtype=dt: torch.empty(shape, dtype=dtype, device=dev)  # noqa: E731
+        out, qkv, att = new(n_layers, b, n, d), new(n_layers, b, n, 3 * d), new(n_layers, b, n, d)
+        y1, x1, h, y2 = new(n_layers, b, n, d), new(n_layers, b, n, d), new(n_layers, b, n, 4 * d), new(n_layers, b, n, d)
+        lse = new(n_layers, b, 8, n, dtype=torch.float32)
+        stats = new(n_layers, 4, b, d, dtype=torch.float32)
+        a = AmEncoderArgs()
+        a.B, a.N, a.num_layers, a.norm = b, n, n_layers, 1
+        a.act_dtype = a.cache_dtype = _lib.dtype_id(dt)
+        a.wqkv_packed, a.wo_packed, a.w1_packed, a.w2_packed = (p.data_ptr() for p in packed)
+        a.bqkv, a.b1 = bqkv.data_ptr(), b1.data_ptr()
+        a.n1_scale, a.n1_shift, a.n2_scale, a.n2_shift = g1.data_ptr(), be1.data_ptr(), g2.data_ptr(), be2.data_ptr()
+        sv = _lib.AmTrainSave()
+        sv.x0, sv.out, sv.qkv, sv.att, sv.y1, sv.x1, sv.h, sv.y2 = (t.data_ptr() for t in (x0c, out, qkv, att, y1, x1, h, y2))
+        sv.lse, sv.stats = lse.data_ptr(), stats.data_ptr()
+        assert abs(float(eps) - 1e-5) < 1e-12, "the fused training forward has InstanceNorm1d's default epsilon compiled in"
+        st = _lib.lib().rl4co_am_encoder_train_fwd(C.byref(a), C.byref(sv), torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "rl4co_am_encoder_train_fwd")
+        ctx.save_for_backward(x0c, out, qkv, att, y1, x1, h, y2, lse, stats, wqkv16, wo16, w1_16, w2_16, g1, g2)
+        ctx.n_layers, ctx.pdt = n_layers, params[0].dtype
+        return out[n_layers - 1]
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        x0c, out, qkv, att, y1, x1, h, y2, lse, stats, wqkv16, wo16, w1_16, w2_16, g1, g2 = ctx.saved_tensors
         t = ctx.pdt
-        return (dx.view(b, n, d), dw1.to(t), db1.to(t), dw2.to(t), db2.to(t), dgamma.to(t), dbeta.to(t), None, None)
+        grads: list = [None] * (_STACK_PARAMS * ctx.n_layers)
+        d = dout
+        for l in reversed(range(ctx.n_layers)):
+            d, dw1, db1, dw2, db2, dg2, dbe2 = _mlp_block_bwd("instance", d, x1[l], h[l], w1_16[l], w2_16[l], y2[l], g2[l],
+                                                              stats[l, 2], stats[l, 3])
+            x_in = x0c if l == 0 else out[l - 1]
+            d, dwqkv, dbqkv, dwo, dbo, dg1, dbe1 = _attention_block_bwd("instance", d, x_in, wqkv16[l], wo16[l], qkv[l], lse[l],
+                                                                        att[l], y1[l], g1[l], stats[l, 0], stats[l, 1])
+            grads[_STACK_PARAMS * l:_STACK_PARAMS * (l + 1)] = [g.to(t) for g in (dwqkv, dbqkv, dwo, dbo, dg1, dbe1, dw1, db1,
+                                                                                dw2, db2, dg2, dbe2)]
+        return (d, None, None, *grads)
+
+
+def stack_usable(x: Tensor, layers) -> bool:
+    """Every layer an (8-head attention, instance norm, 128 -> 512 -> 128 MLP, instance norm) block with biases, 16-bit
+    [B, N <= 128, 128] activations on the GPU: the fused training forward serves the whole stack."""
+    if not (x.is_cuda and x.dtype in HALF and x.dim() == 3 and x.shape[-1] == EMBED_DIM and 2 <= x.shape[1] <= 128):
+        return False
+    if x.shape[1] > min(max_nodes(), _lib.lib().rl4co_attn_max_nodes()):
+        return False
+    for layer in layers:
+        attn, n1, ffn, n2 = layer[0].module, layer[1], layer[2].module, layer[3]
+        if n1.kind != "instance" or n2.kind != "instance" or attn.num_heads != 8 or len(ffn.lins) != 2:
+            return False
+        if tuple(ffn.lins[0].weight.shape) != (4 * EMBED_DIM, EMBED_DIM) or tuple(ffn.lins[1].weight.shape) != (EMBED_DIM, 4 * EMBED_DIM):
+            return False
+        if any(lin.bias is None for lin in (attn.Wqkv, attn.out_proj, *ffn.lins)):
+            return False
+        if any(abs(nm.normalizer.eps - 1e-5) > 1e-12 or nm.normalizer.weight is None for nm in (n1, n2)):
+            return False
+    return True
+
+
+def encoder_stack(x: Tensor, layers) -> Tensor:
+    """``layers(x)`` for a stack of instance-norm encoder layers: ONE forward launch, the per-op backward kernels."""
+    params = []
+    for layer in layers:
+        attn, n1, ffn, n2 = layer[0].module, layer[1].normalizer, layer[2].module, layer[3].normalizer
+        params += [attn.Wqkv.weight, attn.Wqkv.bias, attn.out_proj.weight, attn.out_proj.bias, n1.weight, n1.bias,
+                   ffn.lins[0].weight, ffn.lins[0].bias, ffn.lins[1].weight, ffn.lins[1].bias, n2.weight, n2.bias]
+    return _FusedEncoderStack.apply(x, len(layers), float(layers[0][1].normalizer.eps), *params)
 
 
 def _block_norm_args(norm_module):

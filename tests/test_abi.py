@@ -107,7 +107,7 @@ def test_header_compiles_as_c99_and_layouts_match_ctypes(tmp_path):
     if gcc is None:
         pytest.skip("no C compiler")
     structs = {"rl4co_am_decode_args": _lib.AmDecodeArgs, "rl4co_am_encoder_args": AmEncoderArgs,
-               "rl4co_am_teacher_args": AmTeacherArgs}
+               "rl4co_am_teacher_args": AmTeacherArgs, "rl4co_am_train_save": _lib.AmTrainSave}
     lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "rl4co_amd.h"', "int main(void) {"]
     for cname, mirror in structs.items():
         lines.append(f'  printf("{cname} sizeof %zu\\n", sizeof({cname}));')
