@@ -548,6 +548,7 @@ class Bench:
         policy = AttentionModelPolicy(env_name, num_encoder_layers=6, normalization="instance", use_graph_context=False,
                                       cache_dtype=torch.bfloat16, encoder_autocast=torch.bfloat16,
                                       train_decode_type="multistart_sampling").to(self.device).train()
+        policy.encoder.net.fused_stack = self.args.train_encoder == "stack"
         env = get_env(env_name, generator_params=dict(num_loc=num_loc, device=self.device), device=self.device,
                       check_solution=False)  # configs/experiment/base.yaml:21 trains with the check off
         opt = torch.optim.Adam(policy.parameters(), lr=1e-4)
@@ -817,6 +818,8 @@ def main() -> None:
                     help="N > 1: skip the N = 1 reference region (rank 0 alone, same K steps) that `scaling_efficiency` is taken from")
     ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
                     help="file the full per-leg / parity detail goes to (the stdout line stays under 4 KB)")
+    ap.add_argument("--train-encoder", default="stack", choices=["stack", "blocks"],
+                    help="c4_train: the encoder's training forward as one launch for the whole stack (default) or per sub-block")
     ap.add_argument("--no-check-solution", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")

@@ -432,6 +432,9 @@ __device__ inline float wave_max32(float v) {  // maximum over the 32 token colu
 // are dropped at compile time (TSP-100: four valid keys in the fourth tile, 12 of 16 registers gone).
 // TRAIN: the training forward of an instance-norm encoder (POMO) — the same layer body fed with the init embedding, scores
 // scaled in the kernel (the saved q is the q the products used), every tensor of TrainSave written on the way, no fold.
+// (Barriers are LDS-only — `s_waitcnt lgkmcnt(0); s_barrier` — not __syncthreads(): every hand-over between the waves is
+// LDS data, and __syncthreads()'s vmcnt(0) would make each of them wait for the acknowledgement of the global stores issued
+// before it — neutral for inference (0.965 vs 0.965 ms, tools/ab_encoder.sh), but the TRAIN variant writes 12 passes per layer.)
 template <typename E, int TT, int VR4, bool TRAIN = false>
 __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_encoder_args a, const TrainSave<E> ts) {
   using bf16x8 = vec8<E>;  // (historic names: the 16-bit operand fragments of whichever element type E is)
@@ -475,7 +478,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
   } else {
     init_embed_rows16<E>(a, b, 0, 32 * TT, xs, reinterpret_cast<float*>(ys), tid);  // (ys is free here: the features are staged in it)
   }
-  __syncthreads();
+  rl4co::lds_barrier();
 
   for (int layer = 0; layer < a.num_layers; ++layer) {
     // The lane indices pass through an opaque copy once per layer, so every per-lane LDS / weight address below is
@@ -670,7 +673,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
     }
     __builtin_amdgcn_sched_barrier(0);     // keep these loads out of the attention loop (its register peak)
     load_wfrags(wf, L.wo, 8, w, 0, lane);  // out-proj weights: in flight across the barrier
-    __syncthreads();
+    rl4co::lds_barrier();
     if constexpr (TRAIN) rows_out(ys, ts.att + ((int64_t)layer * a.B + b) * N * kD, kD, N, tid);
 
     // ---- out-proj + residual + norm1 ---------------------------------------------------------------
@@ -686,7 +689,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         residual_norm<TT>(xs, y, 32 * w, L.n1a, L.n1b, a.norm, N, lane);
       }
     }
-    __syncthreads();
+    rl4co::lds_barrier();
     if constexpr (TRAIN) rows_out(xs, ts.x1 + ((int64_t)layer * a.B + b) * N * kD, kD, N, tid);
 
     // ---- FFN: hidden in 4 chunks of 128, FFN2 accumulates across chunks -----------------------------
@@ -701,9 +704,9 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) h1[tt][r] = fmaxf(h1[tt][r], 0.0f);
-        if (c > 0) __syncthreads();  // every wave is done reading the previous chunk
+        if (c > 0) rl4co::lds_barrier();  // every wave is done reading the previous chunk
         store_t<TT>(ys, h1, 32 * w, lane);
-        __syncthreads();
+        rl4co::lds_barrier();
         if constexpr (TRAIN) rows_out(ys, ts.h + ((int64_t)layer * a.B + b) * N * kFF + kD * c, kFF, N, tid);
         // next: FFN1 of the next chunk, then the next layer's Q projection, finally the first fold block
         const bool last_layer = layer + 1 == a.num_layers;
@@ -719,7 +722,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
     }
     // every wave is past the last chunk's barriers, i.e. done with this layer's biases: the next layer's take their place
     if (layer + 1 < a.num_layers) stage_biases(layer + 1);
-    __syncthreads();
+    rl4co::lds_barrier();
     if constexpr (TRAIN) rows_out(xs, ts.out + ((int64_t)layer * a.B + b) * N * kD, kD, N, tid);
   }
   if constexpr (TRAIN) return;  // the training forward ends with the last layer's output (the cache fold has its own autograd node)
@@ -741,12 +744,12 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
     if (blk < 3 && a.cache_dtype != RL4CO_DT_F32) {  // 16-bit planes carry the element type of the activations
       E* out = static_cast<E*>(a.kvl) + (int64_t)blk * a.kvl_plane_stride + (int64_t)b * a.kvl_batch_stride;
       store_t<TT>(ys, acc, 32 * w, lane);
-      __syncthreads();
+      rl4co::lds_barrier();
       for (int i = tid; i < N * 16; i += kThreads) {
         const int row = i >> 4, c16 = i & 15;
         *reinterpret_cast<uint4*>(out + (int64_t)row * kD + 8 * c16) = *reinterpret_cast<const uint4*>(ys + row * kRS + 8 * c16);
       }
-      __syncthreads();
+      rl4co::lds_barrier();
     } else {
       float* out;
       if (blk < 3) {
@@ -771,14 +774,14 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
             }
           }
         }
-        __syncthreads();
+        rl4co::lds_barrier();
         const int rows = min(64, N - 64 * p);
         for (int i = tid; i < rows * 32; i += kThreads) {
           const int row = i >> 5, c4 = i & 31;
           *reinterpret_cast<float4*>(out + (int64_t)(64 * p + row) * kD + 4 * c4) =
               *reinterpret_cast<const float4*>(fs + row * kFS + 4 * c4);
         }
-        __syncthreads();
+        rl4co::lds_barrier();
       }
     }
   }
@@ -790,7 +793,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       for (int tok = 0; tok < N; ++tok) s += (float)xs[tok * kRS + tid];
       meanv[tid] = s / (float)N;
     }
-    __syncthreads();
+    rl4co::lds_barrier();
     // wave w: output rows 32 w .. 32 w + 31; a row of W is ONE coalesced 512-byte load (two consecutive inputs per
     // lane) and a butterfly sum (a thread per row read its 128 inputs at a 512-byte lane stride: 64 cache lines per
     // load instruction)

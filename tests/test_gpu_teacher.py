@@ -287,8 +287,9 @@ def _pomo_policy(seed=0, fused=True, normalization="instance", graph_context=Fal
 def test_bf16_training_step_on_kernels_matches_torch_path(normalization, graph_context, env_name, num_loc, dt):
     """The whole bf16-autocast POMO training step on the HIP kernels (encoder linears, attention, skip + norm,
     fold GEMMs, multistart rollout, MMA teacher backward) vs the same step with the torch encoder: the
-    same trajectories are evaluated (actions given), so the parameter gradients must agree up to bf16
-    rounding: cosine similarity >= 0.98 per tensor that carries signal, >= 0.995 over all parameters."""
+    same trajectories are evaluated (actions given), so the parameter gradients must agree up to 16-bit
+    rounding: cosine similarity >= 0.97 per tensor that carries signal, >= 0.99 / 0.995 over all parameters, and against the
+    fp32 step no further away than torch's own 16-bit step is."""
     from rl4co_amd.envs import get_env
 
     from rl4co_amd import teacher, train_ops
@@ -306,27 +307,37 @@ def test_bf16_training_step_on_kernels_matches_torch_path(normalization, graph_c
     acts = out0["actions"][:, 1:].contiguous()
     adv = torch.linspace(-1.0, 1.0, out0["actions"].shape[0], device="cuda")
     grads = {}
-    for fused in (True, False):
-        pol = _pomo_policy(fused=fused, **kw)
+    for fused in (True, False, "fp32"):
+        pol = _pomo_policy(fused=fused is True, **kw)
+        if fused == "fp32":  # the same step in fp32 end to end (torch encoder, fp32 planes, replay backward): the truth both 16-bit paths approximate
+            pol.encoder_autocast, pol.cache_dtype = None, torch.float32
         out = pol(env.reset(data), env, phase="train", num_starts=8, actions=acts)
         (adv * out["log_likelihood"]).mean().backward()
         grads[fused] = {k: p.grad.detach().float().flatten() for k, p in pol.named_parameters() if p.grad is not None}
-    assert grads[True].keys() == grads[False].keys()
+    assert grads[True].keys() == grads[False].keys() == grads["fp32"].keys()
+
+    def overall(a, b):
+        dots = sum(float(a[k] @ b[k]) for k in a)
+        return dots / (sum(float(v @ v) for v in a.values()) * sum(float(v @ v) for v in b.values())) ** 0.5
+
     scale = max(float(g.norm()) for g in grads[False].values())
-    dots = norms_a = norms_b = 0.0
     for k, gr in grads[False].items():
         gk = grads[True][k]
-        dots += float(gk @ gr)
-        norms_a += float(gk @ gk)
-        norms_b += float(gr @ gr)
         # tensors whose gradient is analytically ~0 (a bias in front of an instance norm) are rounding noise
         # (measured over 24 runs: the last layer's batch-norm bias, at 2.5 % of the largest gradient norm, sits at
         # cos 0.980 .. 0.989 and moves with the accumulation order of the fp32 atomics from run to run; tensors below
         # 5 % of the scale are compared through the all-parameter cosine only)
         if float(gr.norm()) > 5e-2 * scale:
             cos = float(gk @ gr) / (float(gk.norm()) * float(gr.norm()))
-            assert cos >= 0.98, (k, cos)
-    assert dots / (norms_a * norms_b) ** 0.5 >= 0.995
+            assert cos >= 0.97, (k, cos)
+    # Two 16-bit evaluations differ by their rounding points: the per-op kernels round where torch's autocast does, the
+    # fused stack forward (instance norm, r04) rounds LESS (one rounding for x + branch instead of two). Measured (r04,
+    # tools/probes/step_cos.py; all-parameter cosines): kernels vs torch-16 0.9935 - 0.9956, kernels vs the fp32 step
+    # 0.9928 - 0.9983, torch-16 vs the fp32 step 0.9949 - 0.9991. Asserted: close to the 16-bit torch step, and as close to
+    # the fp32 step as the 16-bit torch step is (within 0.007).
+    assert overall(grads[True], grads[False]) >= (0.99 if normalization == "instance" else 0.995)
+    c_kernel, c_torch = overall(grads[True], grads["fp32"]), overall(grads[False], grads["fp32"])
+    assert c_kernel >= 0.985 and c_kernel >= c_torch - 0.007, (c_kernel, c_torch)
 
 
 def test_bf16_training_on_kernels_learns():
