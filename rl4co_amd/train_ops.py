@@ -43,18 +43,21 @@ def _inorm_forward(xc: Tensor, sc: Tensor, w32: Tensor, b32: Tensor, eps: float)
     return out, y, mean, rstd
 
 
-def _inorm_backward(dout: Tensor, y: Tensor, w32: Tensor, mean: Tensor, rstd: Tensor):
-    """(d (x + s) bf16, d gamma fp32, d beta fp32)."""
+def _inorm_backward(dout: Tensor, y: Tensor, w32: Tensor, mean: Tensor, rstd: Tensor, arena=None, key=None):
+    """(d (x + s) bf16, d gamma fp32, d beta fp32); with an ``arena`` the two are a deferred handle (see _GradArena)."""
     b, n, d = y.shape
     dc = dout.contiguous()
     if dc.dtype != y.dtype:
         dc = dc.to(y.dtype)
     dy = torch.empty_like(y)
-    part = torch.empty((2, b, d), dtype=torch.float32, device=y.device)  # per-instance d gamma | d beta
+    part = (torch.empty((2, b, d), dtype=torch.float32, device=y.device) if arena is None
+            else arena.norm_slot(key, b, d, y.device))  # per-instance d gamma | d beta
     st = _k("rl4co_skip_inorm_bwd", y.dtype)(dc.data_ptr(), y.data_ptr(), w32.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                                               b, n, dy.data_ptr(), part[0].data_ptr(), part[1].data_ptr(),
                                               torch.cuda.current_stream().cuda_stream)
     _lib.check(st, "rl4co_skip_inorm_bwd")
+    if arena is not None:
+        return dy, key, None
     g = part.sum(1)  # one reduction over the instances for both, fixed order
     return dy, g[0], g[1]
 
@@ -215,11 +218,7 @@ def _gemm(a2d: Tensor, w: Tensor, bias: Tensor | None = None, mask: Tensor | Non
 _WGRAD_MAX_WORKGROUPS = int(__import__("os").environ.get("RL4CO_WGRAD_WORKGROUPS", "512"))
 
 
-def _wgrad(d2: Tensor, x2: Tensor, with_bias: bool = False):
-    """dW[N,K] = d2[M,N]^T @ x2[M,K] and (``with_bias``) db[N] = column sums of d2, both fp32: split over
-    the rows on the kernel, partials summed by torch."""
-    m, n = d2.shape
-    k = x2.shape[1]
+def _wgrad_chunks(m: int, n: int, k: int) -> int:
     tiles = (n // 128) * (k // 128)
     # (a single-tile layer, 128 x 128, is best at one workgroup per CU: 60 us against 67 with two — its partials are
     # as large as the operands)
@@ -227,16 +226,69 @@ def _wgrad(d2: Tensor, x2: Tensor, with_bias: bool = False):
     chunks = max(1, min(budget // tiles, (m + 255) // 256))
     if chunks >= 8:
         chunks -= chunks % 8  # a multiple of 8: the kernel then keeps the tiles of a chunk on one XCD (shared rows meet in its L2)
+    return chunks
+
+
+def _wgrad(d2: Tensor, x2: Tensor, with_bias: bool = False, arena: "_GradArena | None" = None, key=None):
+    """dW[N,K] = d2[M,N]^T @ x2[M,K] and (``with_bias``) db[N] = column sums of d2, both fp32: split over
+    the rows on the kernel, partials summed by torch. With an ``arena`` the partials go into its slot ``key`` and the
+    result is a deferred handle: the arena sums the partials of ALL its slots of one shape in one launch (``finish``)."""
+    m, n = d2.shape
+    k = x2.shape[1]
+    chunks = _wgrad_chunks(m, n, k)
     # one buffer per chunk: [N*K weight partials | N bias partials] -> ONE reduction over the chunk axis for both
     width = n * k + (n if with_bias else 0)
-    partial = torch.empty((chunks, width), dtype=torch.float32, device=d2.device)
+    partial = (torch.empty((chunks, width), dtype=torch.float32, device=d2.device) if arena is None
+               else arena.slot(key, chunks, width, d2.device))
     st = _k("rl4co_wgrad", d2.dtype)(d2.data_ptr(), x2.data_ptr(), m, n, k, chunks, partial.data_ptr(),
                                      partial.data_ptr() + 4 * n * k if with_bias else None, width,
                                      torch.cuda.current_stream().cuda_stream)
     _lib.check(st, "rl4co_wgrad")
+    if arena is not None:
+        return (key, n, k, with_bias)
     g = partial.sum(0)
     dw = g[: n * k].view(n, k)
     return (dw, g[n * k :]) if with_bias else dw
+
+
+class _GradArena:
+    """Partial sums of one backward pass over a STACK of identical layers: every (kind, layer) gets a slot of the kind's
+    buffer [L, chunks, width]; ``finish`` reduces each kind with ONE launch over its chunk axis instead of one per layer
+    (38 reduction launches per POMO step before, 0.7 ms). Deterministic: fixed chunking, fixed summation order."""
+
+    def __init__(self, n_layers: int):
+        self.n_layers = n_layers
+        self.buf: dict = {}
+        self.sums: dict = {}
+
+    def slot(self, key, chunks: int, width: int, device) -> Tensor:
+        kind, layer = key
+        if kind not in self.buf:
+            self.buf[kind] = torch.empty((self.n_layers, chunks, width), dtype=torch.float32, device=device)
+        buf = self.buf[kind]
+        assert buf.shape[1:] == (chunks, width), (kind, buf.shape, chunks, width)
+        return buf[layer]
+
+    def norm_slot(self, key, b: int, d: int, device) -> Tensor:
+        kind, layer = key
+        if kind not in self.buf:
+            self.buf[kind] = torch.empty((self.n_layers, 2, b, d), dtype=torch.float32, device=device)
+        return self.buf[kind][layer]
+
+    def finish(self) -> None:
+        # weight-gradient kinds [L, chunks, width] -> [L, width]; norm kinds [L, 2, B, 128] -> [L, 2, 128]
+        self.sums = {kind: buf.sum(1 if buf.dim() == 3 else 2) for kind, buf in self.buf.items()}
+
+    def wgrad(self, handle):
+        (kind, layer), n, k, with_bias = handle
+        g = self.sums[kind][layer]
+        dw = g[: n * k].view(n, k)
+        return (dw, g[n * k:]) if with_bias else dw
+
+    def norm(self, key):
+        kind, layer = key
+        g = self.sums[kind][layer]
+        return g[0], g[1]
 
 
 def linear_usable(x: Tensor, *weights: Tensor) -> bool:
@@ -377,34 +429,47 @@ def _f32(w: Tensor) -> Tensor:
     return w.detach().float().contiguous()
 
 
-def _attention_block_bwd(kind, dout, x2, wqkv16, wo16, qkv, lse, att, y, g32, mean, rstd):
-    """Backward of Normalization(x + MHA(x)) from the forward's saved tensors: (dx [B,N,128], dWqkv, dbqkv, dWo, dbo, dgamma,
-    dbeta) — gradients in fp32, dx in the activations' type."""
+def _attention_block_bwd(kind, dout, x2, wqkv16, wo16, qkv, lse, att, y, g32, mean, rstd, arena=None, layer=0, wt=None):
+    """Backward of Normalization(x + MHA(x)) from the forward's saved tensors: (dx [B,N,128], dWqkv + dbqkv, dWo + dbo,
+    dgamma + dbeta) — gradients in fp32, dx in the activations' type. ``arena``: the reductions are deferred (the three
+    results are then handles for _GradArena); ``wt``: (Wqkv^T, Wo^T) already transposed (a stack transposes all layers once)."""
     b, n, d = y.shape
-    dy, dgamma, dbeta = _norm_backward(kind, dout, y, g32, mean, rstd)  # d (x + s): the branch AND the skip
+    if arena is not None:  # (instance norm: the stack's only kind)
+        dy, hnorm, _ = _inorm_backward(dout, y, g32, mean, rstd, arena, ("norm1", layer))
+    else:
+        dy, dgamma, dbeta = _norm_backward(kind, dout, y, g32, mean, rstd)  # d (x + s): the branch AND the skip
+        hnorm = (dgamma, dbeta)
     d2 = dy.view(-1, d)
-    datt = _gemm(d2, wo16.t().contiguous())
-    dwo, dbo = _wgrad(d2, att.reshape(-1, d), with_bias=True)
+    datt = _gemm(d2, wo16.t().contiguous() if wt is None else wt[1])
+    hwo = _wgrad(d2, att.reshape(-1, d), with_bias=True, arena=arena, key=("wo", layer))
     dqkv = torch.empty_like(qkv)
     _lib.check(_k("rl4co_attn_bwd", qkv.dtype)(qkv.data_ptr(), datt.data_ptr(), lse.data_ptr(), b, n, dqkv.data_ptr(),
                                               torch.cuda.current_stream().cuda_stream), "rl4co_attn_bwd")
     dq2 = dqkv.view(-1, 3 * d)
-    dx = _gemm(dq2, wqkv16.t().contiguous(), residual=d2)
-    dwqkv, dbqkv = _wgrad(dq2, x2.reshape(-1, d), with_bias=True)
-    return dx.view(b, n, d), dwqkv, dbqkv, dwo, dbo, dgamma, dbeta
+    dx = _gemm(dq2, wqkv16.t().contiguous() if wt is None else wt[0], residual=d2)
+    hwqkv = _wgrad(dq2, x2.reshape(-1, d), with_bias=True, arena=arena, key=("wqkv", layer))
+    if arena is not None:
+        return dx.view(b, n, d), hwqkv, hwo, hnorm
+    return dx.view(b, n, d), hwqkv[0], hwqkv[1], hwo[0], hwo[1], hnorm[0], hnorm[1]
 
 
-def _mlp_block_bwd(kind, dout, x2, h, w1_16, w2_16, y, g32, mean, rstd):
-    """Backward of Normalization(x + MLP(x)): (dx, dW1, db1, dW2, db2, dgamma, dbeta)."""
+def _mlp_block_bwd(kind, dout, x2, h, w1_16, w2_16, y, g32, mean, rstd, arena=None, layer=0, wt=None):
+    """Backward of Normalization(x + MLP(x)): (dx, dW1 + db1, dW2 + db2, dgamma + dbeta); ``arena`` / ``wt`` (W1^T, W2^T) as above."""
     b, n, d = y.shape
-    dy, dgamma, dbeta = _norm_backward(kind, dout, y, g32, mean, rstd)
+    if arena is not None:
+        dy, hnorm, _ = _inorm_backward(dout, y, g32, mean, rstd, arena, ("norm2", layer))
+    else:
+        dy, dgamma, dbeta = _norm_backward(kind, dout, y, g32, mean, rstd)
+        hnorm = (dgamma, dbeta)
     d2 = dy.view(-1, d)
     h2 = h.reshape(-1, h.shape[-1])
-    dh = _gemm(d2, w2_16.t().contiguous(), mask=h2)  # (d W2) * [h > 0]
-    dw2, db2 = _wgrad(d2, h2, with_bias=True)
-    dx = _gemm(dh, w1_16.t().contiguous(), residual=d2)
-    dw1, db1 = _wgrad(dh, x2.reshape(-1, d), with_bias=True)
-    return dx.view(b, n, d), dw1, db1, dw2, db2, dgamma, dbeta
+    dh = _gemm(d2, w2_16.t().contiguous() if wt is None else wt[1], mask=h2)  # (d W2) * [h > 0]
+    hw2 = _wgrad(d2, h2, with_bias=True, arena=arena, key=("w2", layer))
+    dx = _gemm(dh, w1_16.t().contiguous() if wt is None else wt[0], residual=d2)
+    hw1 = _wgrad(dh, x2.reshape(-1, d), with_bias=True, arena=arena, key=("w1", layer))
+    if arena is not None:
+        return dx.view(b, n, d), hw1, hw2, hnorm
+    return dx.view(b, n, d), hw1[0], hw1[1], hw2[0], hw2[1], hnorm[0], hnorm[1]
 
 
 class _AttentionBlock(torch.autograd.Function):
@@ -512,14 +577,28 @@ class _FusedEncoderStack(torch.autograd.Function):
     def backward(ctx, dout: Tensor):
         x0c, out, qkv, att, y1, x1, h, y2, lse, stats, wqkv16, wo16, w1_16, w2_16, g1, g2 = ctx.saved_tensors
         t = ctx.pdt
-        grads: list = [None] * (_STACK_PARAMS * ctx.n_layers)
+        nl = ctx.n_layers
+        arena = _GradArena(nl)
+        # the four weight stacks transposed once for all layers (the input-gradient GEMMs read W^T rows)
+        wqkv_t, wo_t, w1_t, w2_t = (w.transpose(1, 2).contiguous() for w in (wqkv16, wo16, w1_16, w2_16))
+        handles = []
         d = dout
-        for l in reversed(range(ctx.n_layers)):
-            d, dw1, db1, dw2, db2, dg2, dbe2 = _mlp_block_bwd("instance", d, x1[l], h[l], w1_16[l], w2_16[l], y2[l], g2[l],
-                                                              stats[l, 2], stats[l, 3])
+        for l in reversed(range(nl)):
+            d, hw1, hw2, hn2 = _mlp_block_bwd("instance", d, x1[l], h[l], w1_16[l], w2_16[l], y2[l], g2[l], stats[l, 2], stats[l, 3],
+                                              arena=arena, layer=l, wt=(w1_t[l], w2_t[l]))
             x_in = x0c if l == 0 else out[l - 1]
-            d, dwqkv, dbqkv, dwo, dbo, dg1, dbe1 = _attention_block_bwd("instance", d, x_in, wqkv16[l], wo16[l], qkv[l], lse[l],
-                                                                        att[l], y1[l], g1[l], stats[l, 0], stats[l, 1])
+            d, hwqkv, hwo, hn1 = _attention_block_bwd("instance", d, x_in, wqkv16[l], wo16[l], qkv[l], lse[l], att[l], y1[l], g1[l],
+                                                      stats[l, 0], stats[l, 1], arena=arena, layer=l, wt=(wqkv_t[l], wo_t[l]))
+            handles.append((l, hwqkv, hwo, hn1, hw1, hw2, hn2))
+        arena.finish()  # ONE reduction launch per kind for all layers
+        grads: list = [None] * (_STACK_PARAMS * nl)
+        for l, hwqkv, hwo, hn1, hw1, hw2, hn2 in handles:
+            dwqkv, dbqkv = arena.wgrad(hwqkv)
+            dwo, dbo = arena.wgrad(hwo)
+            dw1, db1 = arena.wgrad(hw1)
+            dw2, db2 = arena.wgrad(hw2)
+            dg1, dbe1 = arena.norm(hn1)
+            dg2, dbe2 = arena.norm(hn2)
             grads[_STACK_PARAMS * l:_STACK_PARAMS * (l + 1)] = [g.to(t) for g in (dwqkv, dbqkv, dwo, dbo, dg1, dbe1, dw1, db1,
                                                                                 dw2, db2, dg2, dbe2)]
         return (d, None, None, *grads)
