@@ -240,3 +240,34 @@ def test_fp32_rollout_beyond_128_nodes_never_reaches_the_torch_encoder():
         o2 = out16(td, env, phase="test", decode_type="greedy")
     assert torch.isfinite(out["reward"]).all() and torch.isfinite(o2["reward"]).all()
     assert abs(float(out["reward"].mean() - o2["reward"].mean())) <= 0.02 * abs(float(out["reward"].mean()))
+
+
+@pytest.mark.parametrize("num_loc,batch", [(129, 3), (128, 2), (255, 1), (256, 5), (17, 4)])
+def test_token_tile_paths_at_tile_boundaries(num_loc, batch):
+    """Graph sizes around the 128-node tile (CVRP: N = num_loc + 1) and tiny batches: the fp32 and the 16-bit token-tile
+    launches against float64 / each other; fp32 planes out of the 16-bit tiles; the raw (fold=False) planes beyond 128 nodes."""
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    torch.manual_seed(num_loc)
+    pol = AttentionModelPolicy("cvrp").cuda().eval()
+    _perturb_norm_stats(pol)
+    env = get_env("cvrp", generator_params=dict(num_loc=num_loc, device="cuda"), device="cuda")
+    td = env.reset(env.generator(batch_size=[batch]))
+    pe = pol._packed_encoder()
+    with torch.inference_mode():
+        c32, h32 = pe.encode(td, torch.float32, want_hidden=True, act_dtype=torch.float32, tokens=True)
+        c16, h16 = pe.encode(td, torch.float32, want_hidden=True, act_dtype=torch.bfloat16, tokens=True)  # fp32 planes, bf16 tiles
+    h64, c64 = _double_reference(pol, td)
+    assert float((h32.double() - h64).norm() / h64.norm()) <= REL_TOL
+    assert float((c32.kvl.double() - c64.kvl).norm() / c64.kvl.norm()) <= REL_TOL
+    assert c16.kvl.dtype == torch.float32 and float((c16.kvl.double() - c64.kvl).norm() / c64.kvl.norm()) <= 3e-2
+    assert float((h16.double() - h64).norm() / h64.norm()) <= 3e-2 and _rel(c16.ctx_cur, c32.ctx_cur) <= 3e-2
+    assert _rel(c16.q_bias, c32.q_bias) <= 3e-2
+    if num_loc + 1 > 128:
+        with torch.inference_mode():
+            raw, hid = pe.encode(td, torch.float32, act_dtype=torch.float32, fold=False, tokens=True)
+        w_node = pol.decoder.project_node_embeddings.weight.detach().double()
+        assert raw.unfold and raw.node_embed is hid and _rel(hid, h32) <= 1e-6
+        for i in range(3):
+            assert float((raw.kvl[i].double() - h64 @ w_node[128 * i:128 * (i + 1)].t()).norm() / (h64 @ w_node[128 * i:128 * (i + 1)].t()).norm()) <= REL_TOL
