@@ -170,19 +170,35 @@ __device__ inline void store_t(E* ys, const f32x16 (&acc)[TT], int dim0, int lan
 // Out^T accumulator tile -> global rows [token][dim] of `row_stride` elements (tokens < N): 8-byte stores, the two halves of
 // a wave side by side (16 bytes per token row and 8-dim group; the rows' other pieces come from the other waves and meet
 // in the XCD's write-back L2)
+// Two 8-byte pieces per lane (dims 8 c + 4 hi .. of groups c = c0, c0 + 1) -> ONE 16-byte piece per lane: the lower half
+// of the wave ends up with all eight dims of group c0, the upper half with those of group c0 + 1 (v_permlane32_swap on the
+// two dwords of each piece: no LDS). Returns the 16 bytes to store at dims 8 (c0 + hi) .. 8 (c0 + hi) + 7.
+template <typename E>
+__device__ inline uint4 pair16(const vec4<E>& p0, const vec4<E>& p1) {
+  const uint2 a = __builtin_bit_cast(uint2, p0), b = __builtin_bit_cast(uint2, p1);
+  const auto x = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);  // [0]: {lower: a.lower, upper: b.lower}; [1]: {a.upper, b.upper}
+  const auto y = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+  return make_uint4(x[0], y[0], x[1], y[1]);
+}
+
+// Out^T accumulator tile -> global rows [token][dim] of `row_stride` elements (tokens < N): 16-byte stores (pair16), a token
+// row's 32 dims of this wave in two of them; the rows' other pieces come from the other waves and meet in the XCD's
+// write-back L2 (8-byte stores straight from the accumulator layout cost twice as much per byte: tools/probes/train_fwd_probe.sh)
 template <int TT, typename E>
 __device__ inline void save_t(E* dst, int64_t row_stride, const f32x16 (&acc)[TT], int dim0, int N, int lane) {
   const int l31 = lane & 31, hi = lane >> 5;
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
+    vec4<E> v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) v[c][s] = (E)acc[tt][4 * c + s];
+    const uint4 lo = pair16<E>(v[0], v[1]), up = pair16<E>(v[2], v[3]);
     if (32 * tt + l31 < N) {
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        vec4<E> v;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) v[s] = (E)acc[tt][4 * c + s];
-        *reinterpret_cast<vec4<E>*>(dst + (int64_t)(32 * tt + l31) * row_stride + dim0 + 8 * c + 4 * hi) = v;
-      }
+      E* row = dst + (int64_t)(32 * tt + l31) * row_stride + dim0 + 8 * hi;
+      *reinterpret_cast<uint4*>(row) = lo;
+      *reinterpret_cast<uint4*>(row + 16) = up;
     }
   }
 }
@@ -271,16 +287,21 @@ __device__ inline void residual_norm_train(E* xs, f32x16 (&y)[TT], int dim0, con
   const int l31 = lane & 31, hi = lane >> 5;
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
+    vec4<E> yr[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const vec4<E> x = *reinterpret_cast<const vec4<E>*>(xs + (32 * tt + l31) * kRS + dim0 + 8 * c + 4 * hi);
-      vec4<E> yr;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        yr[s] = (E)((float)x[s] + y[tt][4 * c + s]);
-        y[tt][4 * c + s] = (float)yr[s];
+        yr[c][s] = (E)((float)x[s] + y[tt][4 * c + s]);
+        y[tt][4 * c + s] = (float)yr[c][s];
       }
-      if (32 * tt + l31 < N) *reinterpret_cast<vec4<E>*>(y_out + (int64_t)(32 * tt + l31) * kD + dim0 + 8 * c + 4 * hi) = yr;
+    }
+    const uint4 lo = pair16<E>(yr[0], yr[1]), up = pair16<E>(yr[2], yr[3]);
+    if (32 * tt + l31 < N) {
+      E* row = y_out + (int64_t)(32 * tt + l31) * kD + dim0 + 8 * hi;
+      *reinterpret_cast<uint4*>(row) = lo;
+      *reinterpret_cast<uint4*>(row + 16) = up;
     }
   }
   const float inv_n = 1.0f / (float)N;
