@@ -1,10 +1,14 @@
-"""Host side of the fused MFMA encoder + cache-fold kernel (``csrc/am_encoder.hip``).
+"""Host side of the inference encoder + cache-fold kernels.
 
-Packs the policy's own parameters (same module tree / state_dict as the reference) into the
-fragment order the kernel streams, folds eval-mode batch norm into a per-channel affine, and
-launches ``rl4co_am_encoder`` — one workgroup per instance, activations never leave the CU.
-Used for inference rollouts in the bf16 regime; training (autograd, train-mode batch statistics)
-stays on the torch path (``policy.AttentionModelEncoder.forward``).
+Packs the policy's own parameters (same module tree / state_dict as the reference) into the fragment order the kernels
+stream, folds eval-mode batch norm into a per-channel affine, and launches, by regime and graph size:
+
+    16-bit (bf16 / fp16 autocast)   rl4co_am_encoder (N <= 128: one workgroup per instance, activations never leave the CU)
+                                    rl4co_am_encoder_tokens16 (any N: tiles of 128 nodes)            csrc/am_encoder.hip
+    fp32 (no autocast)              rl4co_am_encoder_f32 (N <= 128) / rl4co_am_encoder_tokens_f32    csrc/am_encoder_f32.hip,
+                                    on v_mfma_f32_16x16x4_f32 — the bit-identical configuration      csrc/am_tokens_f32.hip
+
+Inference only; training goes through ``train_ops`` (autograd around the HIP kernels) or the torch modules.
 """
 from __future__ import annotations
 

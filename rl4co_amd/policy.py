@@ -6,9 +6,12 @@ Drop-in at the reference's ``policy`` seam: same constructor ar
 ``state_dict()`` keys, so reference checkpoints load unchanged.
 
 What runs where
-  * encoder (``zoo/am/encoder.py``, ``nn/graph/attnnet.py``): dense GEMM/attention work, run
-    through torch on the GPU (hipBLASLt / MIOpen); the only MFMA-shaped part of the path.
-  * cache folding (``rl4co_amd/cache.py``): one GEMM per rollout.
+  * encoder + cache fold (``zoo/am/encoder.py``, ``nn/graph/attnnet.py``, ``zoo/am/decoder.py:201-228``): the MFMA-shaped
+    part of the path, on the library's own kernels in every precision regime for inference rollouts — the fused per-instance
+    kernels up to 128 nodes (``csrc/am_encoder.hip`` 16-bit, ``csrc/am_encoder_f32.hip`` fp32 = the bit-identical
+    configuration), token-tile launches beyond; training: one fused forward launch for an instance-norm stack and per-op
+    backward kernels behind autograd (``train_ops.py``). The torch modules compute only where no kernel serves the call
+    (layer norm, train-mode batch norm beyond the kernels' shapes, ``fused_encoder=False``), announced by one RuntimeWarning.
   * the whole ``while not done`` loop (base.py:226-238) — context, pointer attention, logits
     processing, selection, env transition: ONE launch of ``rl4co_am_decode`` (no grad).
   * reward: ``env.get_reward`` -> ``rl4co_tour_length_f32``.
@@ -477,15 +480,15 @@ class AttentionModelPolicy(nn.Module):
         self.test_decode_type = test_decode_type
         self.cache_dtype = cache_dtype
         self.encoder_autocast = encoder_autocast
-        # inference rollouts in the bf16 regime run encoder + cache fold in ONE hand-written MFMA
-        # kernel (csrc/am_encoder.hip); fp32 parity runs and training stay on the torch encoder
+        # inference rollouts run encoder + cache fold on the hand-written MFMA kernels of their regime (csrc/am_encoder.hip
+        # 16-bit, csrc/am_encoder_f32.hip / am_tokens_f32.hip fp32); False: the torch encoder (a debugging switch)
         self.fused_encoder = fused_encoder
         # training: gradient of the log-likelihood w.r.t. the folded cache from the HIP backward
         # kernel (csrc/am_teacher.hip) instead of a dense [B,T,N] torch re-evaluation
         self.fused_backward = fused_backward
         self.teacher_variant = teacher_variant  # "auto" | "replay" | "mma" (teacher.run_backward)
         # fold=False: the reference's own association of the decoder (per-step project_context / project_out GEMVs,
-        # raw logit key; cache.py) — the strictest greedy-parity configuration (fp32, torch encoder, TSP / CVRP,
+        # raw logit key; cache.py) — the strictest greedy-parity configuration (fp32 encoder kernel, TSP / CVRP,
         # inference only): measured 4 instead of 10 near-tie flips in 4096 TSP-100 tours against the reference
         self.fold = fold
         # TRAINING steps under fp16 autocast (Lightning's default "16-mixed"). Off (default): the step runs on the fp16
@@ -560,8 +563,7 @@ class AttentionModelPolicy(nn.Module):
         """The encoder's GEMM inputs are bf16: asked for by the constructor (``encoder_autocast=torch.bfloat16``) or by
         an ambient ``torch.autocast("cuda", dtype=torch.bfloat16)`` — what Lightning's ``precision="bf16-mixed"`` wraps
         around training steps AND the validation / ``RolloutBaseline`` rollouts (utils/trainer.py:57 picks the
-        precision; the reference's default "16-mixed" is fp16 autocast: no hand-written kernel claims that regime,
-        the torch encoder runs under it exactly as the reference's does)."""
+        precision; the reference's default "16-mixed" is fp16 autocast, served by the fp16 builds of the same kernels)."""
         return self._encoder_regime() == torch.bfloat16
 
     def _plane_dtype(self, training: bool) -> torch.dtype:

@@ -4,7 +4,11 @@
 reference encoder layer (``nn/ops.py:9-15,30-54``, ``nn/graph/attnnet.py:16-54``) as ONE kernel
 forward and ONE backward over bf16 activations, instead of the dozen elementwise / reduction
 launches autograd builds for the written-out norm. Used by ``policy._EncoderLayer`` in training
-when the encoder runs under bf16 autocast on the GPU; anything else keeps the torch path.
+when the encoder runs under bf16 / fp16 autocast on the GPU; anything else keeps the torch path.
+
+Since r04 the FORWARD of a whole instance-norm stack (POMO) is one launch (``encoder_stack`` /
+``_FusedEncoderStack``: ``rl4co_am_encoder_train_fwd`` keeps what the backward kernels read) and its backward sums the
+weight-gradient / norm partials of all layers with one reduction per kind (``_GradArena``).
 """
 from __future__ import annotations
 
