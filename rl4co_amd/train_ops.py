@@ -551,10 +551,24 @@ class _FusedEncoderStack(torch.autograd.Function):
         dt, dev = x0.dtype, x0.device
         x0c = x0.contiguous()
         per = [params[i::_STACK_PARAMS] for i in range(_STACK_PARAMS)]  # per kind: one tensor per layer
-        stack = lambda ts, to: torch.stack([t.detach() for t in ts]).to(to).contiguous()  # noqa: E731
-        wqkv16, wo16, w1_16, w2_16 = stack(per[0], dt), stack(per[2], dt), stack(per[6], dt), stack(per[8], dt)
-        bqkv, b1 = stack(per[1], torch.float32), stack(per[7], torch.float32)
-        g1, be1, g2, be2 = (stack(per[i], torch.float32) for i in (4, 5, 10, 11))
+
+        def stack16(ts):  # [L, out, in] in the activations' type: ONE multi-tensor copy casts and stacks the layers' weights
+            buf = torch.empty((n_layers, *ts[0].shape), dtype=dt, device=dev)
+            torch._foreach_copy_(list(buf.unbind(0)), [t.detach() for t in ts])
+            return buf
+
+        wqkv16, wo16, w1_16, w2_16 = stack16(per[0]), stack16(per[2]), stack16(per[6]), stack16(per[8])
+        # the six small fp32 kinds (biases, gammas, betas) side by side in one buffer, gathered by one multi-tensor copy
+        small = [per[1], per[7], per[4], per[5], per[10], per[11]]
+        widths = [ts[0].numel() for ts in small]
+        flat = torch.empty(n_layers * sum(widths), dtype=torch.float32, device=dev)
+        views, off = [], 0
+        for wdt in widths:  # kind-major: every kind's [L, width] block is contiguous
+            views.append(flat[off:off + n_layers * wdt].view(n_layers, wdt))
+            off += n_layers * wdt
+        torch._foreach_copy_([v[l] for v, ts in zip(views, small) for l in range(n_layers)],
+                             [t.detach() for ts in small for t in ts])
+        bqkv, b1, g1, be1, g2, be2 = views
         packed = [_pack_stack(w) for w in (wqkv16, wo16, w1_16, w2_16)]
         new = lambda *shape, dtype=dt: torch.empty(shape, dtype=dtype, device=dev)  # noqa: E731
         out, qkv, att = new(n_layers, b, n, d), new(n_layers, b, n, 3 * d), new(n_layers, b, n, d)
