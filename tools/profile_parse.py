@@ -25,7 +25,9 @@ for legdir in sorted(p for p in src.iterdir() if p.is_dir()):
         line = json.loads((legdir / "bench_trace.json").read_text().strip().splitlines()[-1])
     except (OSError, ValueError, IndexError):
         pass
-    stats = glob.glob(str(legdir / "trace" / "*" / "*_kernel_stats.csv"))
+    import os
+
+    stats = sorted(glob.glob(str(legdir / "trace" / "*" / "*_kernel_stats.csv")), key=os.path.getmtime, reverse=True)  # newest run first
     if stats:
         rows = list(csv.DictReader(open(stats[0])))
         head = (f"# rocprofv3 --kernel-trace --stats -- python bench.py --legs {leg} --steps 10 --warmup 2 --no-cpu-baseline "
@@ -45,7 +47,7 @@ for legdir in sorted(p for p in src.iterdir() if p.is_dir()):
         print("\n".join(lines[:7]))
     res = {}
     for sub, name in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
-        for f in glob.glob(str(legdir / sub / "*" / "*_counter_collection.csv")):
+        for f in sorted(glob.glob(str(legdir / sub / "*" / "*_counter_collection.csv")), key=os.path.getmtime, reverse=True)[:1]:
             agg = collections.defaultdict(list)
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] == name:
