@@ -48,7 +48,6 @@ constexpr int kThreads = 256;
 template <typename E> using vec8 = E __attribute__((ext_vector_type(8)));
 template <typename E> using vec4 = E __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4_ __attribute__((ext_vector_type(4)));
 
 __device__ inline f32x16 mfma(const vec8<__bf16>& a, const vec8<__bf16>& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -875,9 +874,9 @@ __global__ void __launch_bounds__(kThreads, 2) tok16_init_embed_kernel(const rl4
 // |k_h|^2 (fp32 accumulators, before rounding): |score| <= sqrt of their product, the bound the attention kernel's
 // max-free softmax path is taken under.
 template <typename E>
-__global__ void __launch_bounds__(kThreads, 2) tok16_qkv_kernel(const E* __restrict__ x, int N, int NP, const E* __restrict__ wqkv,
+__global__ void __launch_bounds__(kThreads, 2) tok16_qkv_kernel(const E* __restrict__ x, int N, const E* __restrict__ wqkv,
                                                                 const float* __restrict__ bqkv, E* __restrict__ qkv,
-                                                                E* __restrict__ vt, uint32_t* __restrict__ bound) {
+                                                                uint32_t* __restrict__ bound) {
   extern __shared__ __align__(16) unsigned char smem[];
   E* xs = reinterpret_cast<E*>(smem);
   E* ys = xs + kTok * kRS;
@@ -911,132 +910,10 @@ __global__ void __launch_bounds__(kThreads, 2) tok16_qkv_kernel(const E* __restr
         atomicMax(bound + ((int64_t)b * 8 + 2 * w + 1) * 2 + part, __float_as_uint(m1));
       }
     }
-    if (part == 2) {
-      // V leaves dim-major per head, vt[b][head][dim 16][NP]: tok16_attn_kernel's value operand is then four consecutive keys
-      // of one dim — a plain 8-byte load. The lane owns one token and, per register, one dim: 2-byte stores, 32 consecutive
-      // tokens (64 bytes) per half wave. Keys N .. NP - 1 are written as zeros (they enter P . V with weight 0).
-#pragma unroll
-      for (int tt = 0; tt < kTokT; ++tt) {
-        const int tok = n0 + 32 * tt + l31;
-        if (tok < NP) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int dim = 32 * w + rowmap(r, hi);
-            vt[(((int64_t)b * 8 + (dim >> 4)) * 16 + (dim & 15)) * NP + tok] = tok < N ? (E)acc[tt][r] : (E)0.0f;
-          }
-        }
-      }
-      break;
-    }
     if (part > 0) __syncthreads();  // the previous part has left the staging rows
     store_t<kTokT>(ys, acc, 32 * w, lane);
     __syncthreads();
     tok_store(ys, qkv + ((int64_t)b * N + n0) * 3 * kD + kD * part, 3 * kD, valid, tid);
-  }
-}
-
-constexpr int kAttnQT = 4;  // query tiles of 16 per wave: 64 queries per workgroup (<= 128 registers: two workgroups per CU)
-// softmax(Q K^T) V for head w (wave w) over 64 queries with NO LDS and no barrier: keys (rows of the packed q | k rows) and
-// values (vt, dim-major) stream from L2 straight into the operand layout of v_mfma_f32_16x16x16 — S^T[key][query] = K . Q^T
-// (A = four consecutive dims of a key row, B = the same of a query row), O^T[dim][query] += V^T . P^T (A = four consecutive
-// keys of a dim, B = the exp'd score registers). q is in the exp2 domain (packed W_q); heads under the score bound take the
-// max-free softmax (bf16 only), the others an online softmax with one running maximum per query column.
-__device__ inline f32x4_ mfma16(const vec4<__bf16>& a, const vec4<__bf16>& b, const f32x4_& c) {
-  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
-}
-__device__ inline f32x4_ mfma16(const vec4<_Float16>& a, const vec4<_Float16>& b, const f32x4_& c) {
-  return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
-}
-template <typename E>
-__global__ void __launch_bounds__(512, 4) tok16_attn_kernel(const E* __restrict__ qkv, const E* __restrict__ vt, const float* __restrict__ bound,
-                                                         int N, int NP, E* __restrict__ att) {
-  constexpr int kQT = kAttnQT;
-  const int tid = threadIdx.x, h = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
-  const int b = blockIdx.y, q0 = 16 * kQT * blockIdx.x;
-  bool fast = false;
-  if (kWideRange<E> && bound != nullptr) {
-    const float b2 = bound[((int64_t)b * 8 + h) * 2] * bound[((int64_t)b * 8 + h) * 2 + 1];
-    fast = __builtin_amdgcn_readfirstlane(b2 <= kFastBound * kFastBound ? 1 : 0) != 0;
-  }
-  const E* rows = qkv + (int64_t)b * N * 3 * kD + 16 * h + 4 * g;
-  vec4<E> qf[kQT];
-  f32x4_ o[kQT];
-  float m[kQT], l[kQT];
-#pragma unroll
-  for (int qt = 0; qt < kQT; ++qt) {
-    qf[qt] = *reinterpret_cast<const vec4<E>*>(rows + (int64_t)min(q0 + 16 * qt + tl, N - 1) * 3 * kD);
-    o[qt] = f32x4_{0.0f, 0.0f, 0.0f, 0.0f};
-    m[qt] = -__builtin_huge_valf();
-    l[qt] = 0.0f;
-  }
-  const E* kbase = rows + kD;
-  const E* vbase = vt + (((int64_t)b * 8 + h) * 16 + tl) * NP + 4 * g;
-  const int nkt = NP / 16;
-  vec4<E> kn = *reinterpret_cast<const vec4<E>*>(kbase + (int64_t)min(tl, N - 1) * 3 * kD);
-  vec4<E> vn = *reinterpret_cast<const vec4<E>*>(vbase);
-#pragma unroll 1
-  for (int kt = 0; kt < nkt; ++kt) {
-    const vec4<E> kc = kn, vc = vn;
-    if (kt + 1 < nkt) {
-      kn = *reinterpret_cast<const vec4<E>*>(kbase + (int64_t)min(16 * (kt + 1) + tl, N - 1) * 3 * kD);
-      vn = *reinterpret_cast<const vec4<E>*>(vbase + 16 * (kt + 1));
-    }
-    const bool last = kt + 1 == nkt;
-    f32x4_ s[kQT];
-#pragma unroll
-    for (int qt = 0; qt < kQT; ++qt) s[qt] = mfma16(kc, qf[qt], f32x4_{0.0f, 0.0f, 0.0f, 0.0f});
-    if (fast) {
-#pragma unroll
-      for (int qt = 0; qt < kQT; ++qt) {
-        vec4<E> pf;
-        float ps = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float p = __builtin_amdgcn_exp2f(s[qt][r]);
-          if (last) p = (16 * kt + 4 * g + r < N) ? p : 0.0f;
-          ps += p;
-          pf[r] = (E)p;
-        }
-        l[qt] += ps;
-        o[qt] = mfma16(vc, pf, o[qt]);
-      }
-    } else {
-#pragma unroll
-      for (int qt = 0; qt < kQT; ++qt) {
-        if (last) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s[qt][r] = (16 * kt + 4 * g + r < N) ? s[qt][r] : -__builtin_huge_valf();
-        }
-        float mt = fmaxf(fmaxf(s[qt][0], s[qt][1]), fmaxf(s[qt][2], s[qt][3]));
-        mt = fmaxf(mt, rl4co::bfly_f<16>(mt));
-        mt = fmaxf(mt, rl4co::bfly_f<32>(mt));
-        const float mn = fmaxf(m[qt], mt);  // finite: every key tile holds at least one real key
-        const float alpha = __builtin_amdgcn_exp2f(m[qt] - mn);
-        m[qt] = mn;
-        vec4<E> pf;
-        float ps = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(s[qt][r] - mn);
-          ps += p;
-          pf[r] = (E)p;
-        }
-        l[qt] = fmaf(l[qt], alpha, ps);
-        o[qt] = mfma16(vc, pf, o[qt] * alpha);
-      }
-    }
-  }
-#pragma unroll
-  for (int qt = 0; qt < kQT; ++qt) {
-    float lt = l[qt];
-    lt += rl4co::bfly_f<16>(lt);
-    lt += rl4co::bfly_f<32>(lt);
-    const float inv = 1.0f / lt;
-    const int tok = q0 + 16 * qt + tl;
-    vec4<E> ov;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) ov[r] = (E)(o[qt][r] * inv);
-    if (tok < N) *reinterpret_cast<vec4<E>*>(att + ((int64_t)b * N + tok) * kD + 16 * h + 4 * g) = ov;
   }
 }
 
@@ -1158,11 +1035,8 @@ int launch_tokens16(const rl4co_am_encoder_args& a, void* workspace, hipStream_t
   E* x0 = static_cast<E*>(workspace);
   E* x1 = x0 + mx;
   E* att = x0 + 2 * mx;
-  E* qkv = x0 + 3 * mx;  // [B N, 384] q | k (the v columns stay unwritten: v goes to vt)
-  const int NP = (N + 15) / 16 * 16;
-  const int64_t vx = ((int64_t)a.B * 8 * 16 * NP + 63) / 64 * 64;
-  E* vt = x0 + 6 * mx;   // [B][8][16][NP]
-  uint32_t* bound = reinterpret_cast<uint32_t*>(vt + vx);  // [B][8 heads][q, k] fp32 bit patterns
+  E* qkv = x0 + 3 * mx;  // [B N, 384]
+  uint32_t* bound = reinterpret_cast<uint32_t*>(x0 + 6 * mx);  // [B][8 heads][q, k] fp32 bit patterns
   const dim3 grid((N + kTok - 1) / kTok, a.B), block(kThreads);
   const int lds_tile = kTok * kRS * (int)sizeof(E);
   const int lds_init = lds_tile + 6 * N * 4 + 64, lds_qkv = 2 * lds_tile + 3 * kD * 4, lds_mlp = 2 * lds_tile + kFF * 4;
@@ -1177,12 +1051,13 @@ int launch_tokens16(const rl4co_am_encoder_args& a, void* workspace, hipStream_t
   const E* wo = static_cast<const E*>(a.wo_packed);
   const E* w1 = static_cast<const E*>(a.w1_packed);
   const E* w2 = static_cast<const E*>(a.w2_packed);
+  const bool half = a.act_dtype == RL4CO_DT_F16;
   for (int layer = 0; layer < a.num_layers; ++layer) {
     RL4CO_HIP_TRY(hipMemsetAsync(bound, 0, (size_t)a.B * 8 * 2 * 4, s));
-    hipLaunchKernelGGL(tok16_qkv_kernel<E>, grid, block, lds_qkv, s, xin, N, NP, wqkv + (int64_t)layer * 3 * kD * kD, a.bqkv + layer * 3 * kD, qkv,
-                       vt, bound);
-    hipLaunchKernelGGL(tok16_attn_kernel<E>, dim3((N + 16 * kAttnQT - 1) / (16 * kAttnQT), a.B), dim3(512), 0, s, static_cast<const E*>(qkv), static_cast<const E*>(vt),
-                       reinterpret_cast<const float*>(bound), N, NP, att);
+    hipLaunchKernelGGL(tok16_qkv_kernel<E>, grid, block, lds_qkv, s, xin, N, wqkv + (int64_t)layer * 3 * kD * kD, a.bqkv + layer * 3 * kD, qkv, bound);
+    const int st = half ? rl4co_attn_flash_pre_f16(qkv, reinterpret_cast<const float*>(bound), a.B, N, att, s)
+                        : rl4co_attn_flash_pre_bf16(qkv, reinterpret_cast<const float*>(bound), a.B, N, att, s);
+    if (st != RL4CO_OK) return st;
     hipLaunchKernelGGL(tok16_mlp_kernel<E>, grid, block, lds_mlp, s, xin, att, N, wo + (int64_t)layer * kD * kD, w1 + (int64_t)layer * kFF * kD,
                        w2 + (int64_t)layer * kD * kFF, a.b1 + layer * kFF, a.n1_scale + layer * kD, a.n1_shift + layer * kD,
                        a.n2_scale + layer * kD, a.n2_shift + layer * kD, xout);
@@ -1314,8 +1189,7 @@ extern "C" int rl4co_am_encoder(const rl4co_am_encoder_args* args, void* stream)
 extern "C" int64_t rl4co_am_encoder_tokens16_workspace(int B, int N) {
   if (B <= 0 || N <= 0) return 0;
   const int64_t mx = ((int64_t)B * N * kD + 63) / 64 * 64;
-  const int64_t vx = ((int64_t)B * 8 * 16 * ((N + 15) / 16 * 16) + 63) / 64 * 64;
-  return (6 * mx + vx) * 2 + (int64_t)B * 8 * 2 * 4;
+  return 6 * mx * 2 + (int64_t)B * 8 * 2 * 4;
 }
 
 extern "C" int rl4co_am_encoder_tokens16(const rl4co_am_encoder_args* args, void* workspace, int64_t workspace_bytes, void* stream) {
