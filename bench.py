@@ -16,30 +16,40 @@ and read back inside the timed region); ``graph_ms_per_step`` (one captured grap
 HEADLINE (the top-level keys of the JSON line; `--steps K` / `--warmup W` apply to it): BASELINE.json
 configs[1] — TSPEnv num_loc=100, batch 4096 per GPU, AM (3 layers, d=128, 8 heads), bf16 encoder GEMMs and
 cache planes with fp32 arithmetic, greedy. The other BASELINE configs are timed by the same process right after it
-and reported under ``"legs"`` in the same line (``--legs`` selects; each with its own roofline object):
+(``--legs`` selects):
 
     c2_sampling  configs[1], sampling (in-kernel Philox)          c3_greedy  configs[2] CVRP-100 x 4096
     c5_sampling  configs[4] CVRP-500 x 1024 sampling               c4_train   configs[3] per-GPU share: POMO
-                 (WIDE decode variant, token-parallel encoder)                TSP-100 x 4096 x 8 starts REINFORCE
-                                                                              step incl. the RCCL grad all-reduce
+                 (WIDE decode variant, token-tile encoder)                    TSP-100 x 4096 x 8 starts REINFORCE
+    c2_greedy_fp16  configs[1] in the reference's default precision           step incl. the RCCL grad all-reduce
+    c2_greedy_fp32  configs[1] in the BIT-IDENTICAL configuration (fp32 MFMA encoder, fp32 planes), with the count of
+                    reference tours it reproduces on the trained weights (``parity_tours``)
+
+THE STDOUT LINE IS <= 4 KB (the driver parses it; r03's 27 KB line came back ``parsed: null``): the contract keys, the
+decode kernel's ``roofline`` {kernel, bound, achieved, peak, unit, frac, traffic, launch_ms_mean}, ``encoder_roofline``,
+``cpu_baseline``, three numbers per leg under ``legs``, a <= 10-key ``parity`` summary and ``detail_file`` — the path of the
+JSON file (default gpurun_out/bench_detail.json) that holds everything else: every leg's full dict, the rooflines with their
+byte models, the whole parity block. Optional blocks are dropped rather than exceed the limit.
 
 Instances shard across ranks with no data-path collective (weak scaling; SURVEY.md §8e: inference = replicas); the
 training leg's one exchange step is the flat fp32 gradient all-reduce on "nccl" (= RCCL), initialised even at N = 1 so
 that the collective path really executes. Rank 0 prints ONE JSON line. ``value`` = whole-job instance·decode-steps per
-second (B·T·N_gpus·K / wall), wall = max over ranks of the barrier-bracketed timed region.
+second (B·T·N_gpus·K / wall), wall = max over ranks of the barrier-bracketed timed region. At N > 1 the line adds
+``rank_ms_per_step`` {min, max}, ``n1_ms_per_step`` (rank 0 runs the same K steps alone while the other ranks wait at the
+barrier), ``scaling_efficiency`` = that / the joint time, ``rccl_ranks``, ``allreduce_ms``.
 
 ``roofline`` (decode kernel, HBM-bound): ``achieved`` = bytes the launch MUST move — the cache rows it streams are
 counted by the kernel itself (rows of the currently feasible nodes only: masked nodes are exact zeros in the
 reference's formulation and are never read), x 3 planes x 256 B, plus the gathered context rows, masks and outputs —
 divided by the mean launch duration from HIP events on the launch stream, so ``frac`` <= 1 by construction. The
 SURVEY.md §8(d) contract figure (every node's row at every step, what the reference's formulation reads) is kept
-beside it as ``algorithmic_bytes_contract`` / ``contract_frac``. ``traffic`` = HBM bytes per launch from the separate
-rocprofv3 --pmc passes of the same leg (``traffic_source`` names the committed file; a counter pass cannot run
-inside this process). ``cpu_baseline``: the reference path (torch restatement, pinned bit-exact to the reference's
-own source by oracle/gen_golden.py; kind "port") timed on this box's host cores on a bounded sample.
-``parity``: for every inference leg, the fp32 parity configuration and the benchmarked bf16 configuration against the
-reference's own rollouts (fp32 and under bf16 autocast) of TRAINED weights at the leg's full size
-(tests/golden/trained; tools/trained_parity.py): flips proven near-ties, identical tours, per-decision agreement.
+beside it as ``contract_GBs`` (detail: ``algorithmic_bytes_contract``). ``traffic`` = HBM bytes per launch from the separate
+rocprofv3 --pmc passes of the same leg (profiles/pmc_traffic.json; a counter pass cannot run inside this process).
+``cpu_baseline``: the reference path (torch restatement, pinned bit-exact to the reference's own source by
+oracle/gen_golden.py; kind "port") timed on this box's host cores on a bounded sample.
+``parity`` (detail file; summary in the line): for every inference leg, the fp32 configuration and the benchmarked bf16
+configuration against the reference's own rollouts (fp32 and under bf16 autocast) of TRAINED weights at the leg's full
+size (tests/golden/trained; tools/trained_parity.py): flips proven near-ties, identical tours, per-decision agreement.
 """
 from __future__ import annotations
 
