@@ -383,7 +383,7 @@ class Bench:
                         graph_ms = (time.perf_counter() - t0) / ev_steps * 1e3
                         from rl4co_amd.graph import PipelinedRollout
 
-                        pipe = PipelinedRollout(policy, env, data, decode_type=decode, depth=2)
+                        pipe = PipelinedRollout(policy, env, data, decode_type=decode, depth=a.pipeline_depth)
                         tickets = []
 
                         def step():
@@ -830,6 +830,7 @@ def main() -> None:
                     help="file the full per-leg / parity detail goes to (the stdout line stays under 4 KB)")
     ap.add_argument("--train-encoder", default="stack", choices=["stack", "blocks"],
                     help="c4_train: the encoder's training forward as one launch for the whole stack (default) or per sub-block")
+    ap.add_argument("--pipeline-depth", type=int, default=2, help="captured rollouts in flight (--launch pipeline)")
     ap.add_argument("--no-check-solution", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
