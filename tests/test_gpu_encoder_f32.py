@@ -271,3 +271,27 @@ def test_token_tile_paths_at_tile_boundaries(num_loc, batch):
         assert raw.unfold and raw.node_embed is hid and _rel(hid, h32) <= 1e-6
         for i in range(3):
             assert float((raw.kvl[i].double() - h64 @ w_node[128 * i:128 * (i + 1)].t()).norm() / (h64 @ w_node[128 * i:128 * (i + 1)].t()).norm()) <= REL_TOL
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16, torch.float16], ids=["f32", "bf16", "f16"])
+@pytest.mark.parametrize("b,n,blocks,graph", [(7, 100, 2, True), (3, 501, 1, True), (16, 129, 2, False), (1, 5, 1, True)])
+def test_fold_tables_kernel_matches_float64(b, n, blocks, graph, dt):
+    """rl4co_am_fold_tables_f32 (context tables + graph context from any encoder's embeddings, 16-bit rows widened on
+    load, fp32 MFMA) against the float64 products of the SAME (rounded) embeddings: fp32 round-off only."""
+    from rl4co_amd.cache import _fold_tables_f32
+
+    gen = torch.Generator().manual_seed(b * 1000 + n)
+    h = torch.randn(b, n, 128, generator=gen).to(dt).cuda()
+    ws = [(torch.randn(128, 128, generator=gen) * 0.1).cuda() for _ in range(blocks)]
+    w_fixed = (torch.randn(128, 128, generator=gen) * 0.1).cuda() if graph else None
+    outs, q_bias = _fold_tables_f32(h, ws, w_fixed)
+    torch.cuda.synchronize()
+    h64 = h.double()
+    for o, w in zip(outs, ws):
+        want = h64 @ w.double().t()
+        assert o.dtype == torch.float32 and float((o.double() - want).norm() / want.norm()) <= 2e-6
+    if graph:
+        want = h64.mean(1) @ w_fixed.double().t()
+        assert float((q_bias.double() - want).norm() / want.norm()) <= 3e-6
+    else:
+        assert q_bias is None
