@@ -359,7 +359,11 @@ int rl4co_am_decode_variant(const rl4co_am_decode_args* args);
  * rl4co_am_decode_args. 16-bit MFMA inputs (act_dtype: bf16 or fp16), fp32 accumulation, 16-bit
  * residual stream (the reference's mixed-precision regimes, utils/trainer.py:57). Normalisation: norm = 0 is
  * batch norm in EVAL mode, passed as a per-channel (scale, shift) pair folded from the
- * running statistics; norm = 1 is instance norm (POMO), scale/shift = gamma/beta.
+ * running statistics; norm = 1 is instance norm (POMO), scale/shift = gamma/beta; norm = 2 is the
+ * reference's "layer" normalisation (nn/ops.py:48-51: ONE mean and ONE unbiased variance over all N x 128
+ * values of an instance, eps 1e-5, no affine) — scale is ignored, the 16-bit kernel reads the bias of the
+ * GEMM in front of the norm (bo / b2) from the shift slot and adds it before the statistics (the fp32
+ * kernel adds bo / b2 itself).
  * Train-mode batch statistics couple instances and stay on the torch path (which also
  * provides autograd). N <= rl4co_am_encoder_max_nodes().
  *
@@ -372,7 +376,7 @@ typedef struct rl4co_am_encoder_args {
   int32_t B;           /* instances                                                */
   int32_t N;           /* nodes incl. depot                                        */
   int32_t num_layers;  /* 3 (AM) / 6 (POMO)                                        */
-  int32_t norm;        /* 0 = per-channel affine (batch norm, eval), 1 = instance  */
+  int32_t norm;        /* 0 = per-channel affine (batch norm, eval), 1 = instance, 2 = layer (fused kernels, N <= 128) */
   int32_t cache_dtype; /* dtype of the three kvl planes written: RL4CO_DT_F32 or act_dtype */
   int32_t act_dtype;   /* 16-bit element type of the MFMA operands, the packed weights and the LDS residual stream:
                           RL4CO_DT_BF16 (autocast bfloat16) or RL4CO_DT_F16 (autocast float16, the reference's
@@ -576,6 +580,19 @@ int rl4co_skip_inorm_bwd_bf16(const void* dout, const void* y, const float* gamm
 int rl4co_skip_inorm_max_nodes(void);
 
 /* --------------------------------------------------------------------------
+ * a12 (training)  SkipConnection + Normalization("layer")
+ *   rl4co/models/nn/ops.py:9-15,48-51
+ * forward : y = x + s ; out = (y - mean y) / sqrt(var y + eps) with ONE mean and ONE unbiased variance (divisor M - 1)
+ *           over all M = N x 128 values of the instance, no affine. 16-bit activations [B,N,128], fp32 arithmetic;
+ *           y and stats[B,2] = (mean, 1 / sqrt(var + eps)) are kept for the backward pass.
+ * backward: dy (the gradient of BOTH skip inputs) = r (dout - sum(dout) / M - xh sum(dout xh) / (M - 1)), xh = (y - mean) r.
+ *           N <= rl4co_skip_inorm_max_nodes().
+ * -------------------------------------------------------------------------- */
+int rl4co_skip_lnorm_fwd_bf16(const void* x, const void* s, float eps, int B, int N, void* y, void* out, float* stats,
+                              void* stream);
+int rl4co_skip_lnorm_bwd_bf16(const void* dout, const void* y, const float* stats, int B, int N, void* dy, void* stream);
+
+/* --------------------------------------------------------------------------
  * a12 (training)  SkipConnection + Normalization("batch") — the AttentionModel default
  *   rl4co/models/nn/ops.py:9-15,30-54 ; zoo/am/policy.py:50-122
  * BatchNorm1d over the M = B x nodes rows of bf16 [M,128] activations, batch statistics:
@@ -664,6 +681,9 @@ int rl4co_skip_inorm_fwd_f16(const void* x, const void* s, const float* gamma, c
 int rl4co_skip_inorm_bwd_f16(const void* dout, const void* y, const float* gamma, const float* mean,
                               const float* rstd, int B, int N, void* dy, float* dgamma, float* dbeta,
                               void* stream);
+int rl4co_skip_lnorm_fwd_f16(const void* x, const void* s, float eps, int B, int N, void* y, void* out, float* stats,
+                             void* stream);
+int rl4co_skip_lnorm_bwd_f16(const void* dout, const void* y, const float* stats, int B, int N, void* dy, void* stream);
 int rl4co_skip_bnorm_stats_f16(const void* x, const void* s, int64_t M, void* y, float* sums, void* stream);
 int rl4co_bnorm_apply_f16(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
                            int64_t M, void* out, void* stream);

@@ -108,6 +108,8 @@ SYMBOLS = {
     "rl4co_am_teacher_variant": (C.c_int, [_vp]),
     "rl4co_skip_inorm_fwd_bf16": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "rl4co_skip_inorm_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "rl4co_skip_lnorm_fwd_bf16": (C.c_int, [_vp, _vp, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "rl4co_skip_lnorm_bwd_bf16": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_skip_inorm_max_nodes": (C.c_int, []),
     "rl4co_skip_bnorm_stats_bf16": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp]),
     "rl4co_bnorm_apply_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp]),
@@ -144,6 +146,8 @@ SYMBOLS = {
     # IEEE-half twins of the training-encoder / attention kernels (csrc/elem16.h)
     "rl4co_skip_inorm_fwd_f16": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
     "rl4co_skip_inorm_bwd_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "rl4co_skip_lnorm_fwd_f16": (C.c_int, [_vp, _vp, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
+    "rl4co_skip_lnorm_bwd_f16": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_skip_bnorm_stats_f16": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp]),
     "rl4co_bnorm_apply_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp]),
     "rl4co_skip_bnorm_eval_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp]),

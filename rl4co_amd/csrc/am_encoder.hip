@@ -210,9 +210,12 @@ struct LayerPtrs {
 };
 
 // residual + bias + normalisation epilogue for the wave's 32-dim tile; result back into xs (bf16)
-template <int TT, typename E>
+// LAYER (normalization="layer", nn/ops.py:48-51): ONE mean and ONE unbiased variance over all N x 128 values of the
+// instance and no affine. The GEMM's bias does not cancel there: it arrives in `nb` and is added BEFORE the statistics;
+// the four waves' partial sums meet in `red` (2 x 4 floats of LDS; two workgroup barriers inside).
+template <int TT, bool LAYER = false, typename E>
 __device__ inline void residual_norm(E* xs, f32x16 (&y)[TT], int dim0, const float* na,
-                                     const float* nb, int norm, int N, int lane) {
+                                     const float* nb, int norm, int N, int lane, float* red = nullptr, int w = 0) {
   const int l31 = lane & 31, hi = lane >> 5;
   float ga[16], be[16];  // (the GEMM's bias is folded into `nb` on the host, or cancels: instance norm)
 #pragma unroll
@@ -230,7 +233,43 @@ __device__ inline void residual_norm(E* xs, f32x16 (&y)[TT], int dim0, const flo
       for (int s = 0; s < 4; ++s) y[tt][4 * c + s] = (float)x[s] + y[tt][4 * c + s];
     }
   }
-  if (norm == 1) {
+  if constexpr (LAYER) {
+    float s = 0.0f;
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      float t16 = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        y[tt][r] += be[r];
+        t16 += y[tt][r];
+      }
+      s += (32 * tt + l31 < N) ? t16 : 0.0f;
+    }
+    s = rl4co::bfly_sum<1, 64>(s);
+    if (lane == 0) red[w] = s;
+    rl4co::lds_barrier();
+    const float cnt = (float)(N * kD);
+    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) / cnt;
+    float v = 0.0f;
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      float t16 = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d = y[tt][r] - mean;
+        t16 = fmaf(d, d, t16);
+      }
+      v += (32 * tt + l31 < N) ? t16 : 0.0f;
+    }
+    v = rl4co::bfly_sum<1, 64>(v);
+    if (lane == 0) red[4 + w] = v;
+    rl4co::lds_barrier();
+    const float rstd = rsqrtf(((red[4] + red[5]) + (red[6] + red[7])) / (cnt - 1.0f) + 1e-5f);
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) y[tt][r] = (y[tt][r] - mean) * rstd;
+  } else if (norm == 1) {
     // instance norm (nn/ops.py:46-47, POMO): per (instance, channel) statistics over the N tokens
     const float inv_n = 1.0f / (float)N;
 #pragma unroll
@@ -456,7 +495,7 @@ __device__ inline float wave_max32(float v) {  // maximum over the 32 token colu
 // (Barriers are LDS-only — `s_waitcnt lgkmcnt(0); s_barrier` — not __syncthreads(): every hand-over between the waves is
 // LDS data, and __syncthreads()'s vmcnt(0) would make each of them wait for the acknowledgement of the global stores issued
 // before it — neutral for inference (0.965 vs 0.965 ms, tools/ab_encoder.sh), but the TRAIN variant writes 12 passes per layer.)
-template <typename E, int TT, int VR4, bool TRAIN = false>
+template <typename E, int TT, int VR4, bool TRAIN = false, bool LAYER = false>
 __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_encoder_args a, const TrainSave<E> ts) {
   using bf16x8 = vec8<E>;  // (historic names: the 16-bit operand fragments of whichever element type E is)
   using bf16x4 = vec4<E>;
@@ -707,7 +746,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         float* st = ts.stats + ((int64_t)layer * 4 * a.B + b) * kD;
         residual_norm_train<TT>(xs, y, 32 * w, L.n1a, L.n1b, N, lane, ts.y1 + ((int64_t)layer * a.B + b) * N * kD, st, st + (int64_t)a.B * kD);
       } else {
-        residual_norm<TT>(xs, y, 32 * w, L.n1a, L.n1b, a.norm, N, lane);
+        residual_norm<TT, LAYER>(xs, y, 32 * w, L.n1a, L.n1b, a.norm, N, lane, meanv, w);
       }
     }
     rl4co::lds_barrier();
@@ -738,7 +777,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         float* st = ts.stats + (((int64_t)layer * 4 + 2) * a.B + b) * kD;
         residual_norm_train<TT>(xs, y2, 32 * w, L.n2a, L.n2b, N, lane, ts.y2 + ((int64_t)layer * a.B + b) * N * kD, st, st + (int64_t)a.B * kD);
       } else {
-        residual_norm<TT>(xs, y2, 32 * w, L.n2a, L.n2b, a.norm, N, lane);
+        residual_norm<TT, LAYER>(xs, y2, 32 * w, L.n2a, L.n2b, a.norm, N, lane, meanv, w);
       }
     }
     // every wave is past the last chunk's barriers, i.e. done with this layer's biases: the next layer's take their place
@@ -966,6 +1005,168 @@ __global__ void __launch_bounds__(kThreads, 2) tok16_mlp_kernel(const E* __restr
   tok_store(xs, xout + ((int64_t)b * N + n0) * kD, kD, min(kTok, N - n0), tid);
 }
 
+// ---- token tiles under instance / layer norm (norm = 1 / 2) ---------------------------------------------------------
+// The statistics span all tiles of an instance, so the two sub-blocks of a layer end BEFORE their norm: each half writes
+// its pre-norm sums (rounded to the element type, like autocast's x + module(x)) and, per tile and channel, the mean and
+// the centred sum of squares of the tile's valid tokens; `tok16_norm_apply_kernel` combines the tiles' pairs (Chan's
+// update: deterministic, no atomics, no cancellation) into the instance's statistics and normalises the rows.
+//   nn/ops.py:46-51 (instance: per channel over the nodes, biased variance; layer: one mean / one unbiased variance)
+constexpr int kStatFloats = 2 * kD;  // per (instance, tile): mean [128] | M2 [128]
+
+// x + y (+ the bias in front of a layer norm) for the wave's 32-dim tile, rounded, back into xs; tile statistics -> st
+template <int TT, typename E>
+__device__ inline void residual_stats(E* xs, f32x16 (&y)[TT], int dim0, const float* pre_bias, int valid, int lane, float* st) {
+  const int l31 = lane & 31, hi = lane >> 5;
+  float be[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) be[r] = pre_bias ? pre_bias[dim0 + rowmap(r, hi)] : 0.0f;
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const vec4<E> x = *reinterpret_cast<const vec4<E>*>(xs + (32 * tt + l31) * kRS + dim0 + 8 * c + 4 * hi);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) y[tt][4 * c + s] = (float)(E)(((float)x[s] + y[tt][4 * c + s]) + be[4 * c + s]);
+    }
+  }
+  const float inv = 1.0f / (float)valid;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float s = 0.0f;
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) s += (32 * tt + l31 < valid) ? y[tt][r] : 0.0f;
+    s = rl4co::bfly_sum<1, 32>(s);
+    const float mean = s * inv;
+    float v = 0.0f;
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const float d = y[tt][r] - mean;
+      v += (32 * tt + l31 < valid) ? d * d : 0.0f;
+    }
+    v = rl4co::bfly_sum<1, 32>(v);
+    if (l31 == 0) {
+      st[dim0 + rowmap(r, hi)] = mean;
+      st[kD + dim0 + rowmap(r, hi)] = v;
+    }
+  }
+  store_t<TT>(xs, y, dim0, lane);
+}
+
+// pre-norm x + out_proj(att) of one token tile
+template <typename E>
+__global__ void __launch_bounds__(kThreads, 2) tok16_attn_half_kernel(const E* __restrict__ x, const E* __restrict__ att, int N,
+                                                                      const E* __restrict__ wo, const float* __restrict__ pre_bias,
+                                                                      E* __restrict__ ypre, float* __restrict__ stats) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  E* xs = reinterpret_cast<E*>(smem);
+  E* ys = xs + kTok * kRS;
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.y, n0 = kTok * blockIdx.x, valid = min(kTok, N - n0);
+  vec8<E> wf[8];
+  load_wfrags(wf, wo, 8, w, 0, lane);
+  tok_load(xs, x, b, n0, N, tid);
+  tok_load(ys, att, b, n0, N, tid);
+  __syncthreads();
+  f32x16 y[kTokT];
+  gemm_t<kTokT>(y, wf, ys, lane, static_cast<const E*>(nullptr), 0, 0, 0, zero16());
+  residual_stats<kTokT>(xs, y, 32 * w, pre_bias, valid, lane, stats + ((int64_t)b * gridDim.x + blockIdx.x) * kStatFloats);
+  __syncthreads();
+  tok_store(xs, ypre + ((int64_t)b * N + n0) * kD, kD, valid, tid);
+}
+
+// pre-norm x + MLP(x) of one token tile (x: the normalised output of the attention half)
+template <typename E>
+__global__ void __launch_bounds__(kThreads, 2) tok16_ffn_half_kernel(const E* __restrict__ x, int N, const E* __restrict__ w1,
+                                                                     const E* __restrict__ w2, const float* __restrict__ b1,
+                                                                     const float* __restrict__ pre_bias, E* __restrict__ ypre,
+                                                                     float* __restrict__ stats) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  E* xs = reinterpret_cast<E*>(smem);
+  E* ys = xs + kTok * kRS;
+  float* bl = reinterpret_cast<float*>(ys + kTok * kRS);  // b1 [512]
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, hi = lane >> 5;
+  const int b = blockIdx.y, n0 = kTok * blockIdx.x, valid = min(kTok, N - n0);
+  vec8<E> wf[8];
+  load_wfrags(wf, w1, 8, w, 0, lane);
+  tok_load(xs, x, b, n0, N, tid);
+  for (int i = tid; i < kFF; i += kThreads) bl[i] = b1[i];
+  __syncthreads();
+  f32x16 y2[kTokT];
+#pragma unroll
+  for (int tt = 0; tt < kTokT; ++tt) y2[tt] = zero16();
+#pragma unroll 1
+  for (int c = 0; c < 4; ++c) {
+    f32x16 h1[kTokT];
+    gemm_t<kTokT>(h1, wf, xs, lane, w2, 32, w, 8 * c, bias_tile(bl, 32 * (4 * c + w), hi));
+#pragma unroll
+    for (int tt = 0; tt < kTokT; ++tt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h1[tt][r] = fmaxf(h1[tt][r], 0.0f);
+    if (c > 0) __syncthreads();  // every wave is done reading the previous chunk
+    store_t<kTokT>(ys, h1, 32 * w, lane);
+    __syncthreads();
+    gemm_t<kTokT, true, false>(y2, wf, ys, lane, c < 3 ? w1 : static_cast<const E*>(nullptr), 8, 4 * (c + 1) + w, 0, y2[0]);
+  }
+  residual_stats<kTokT>(xs, y2, 32 * w, pre_bias, valid, lane, stats + ((int64_t)b * gridDim.x + blockIdx.x) * kStatFloats);
+  __syncthreads();
+  tok_store(xs, ypre + ((int64_t)b * N + n0) * kD, kD, valid, tid);
+}
+
+__device__ inline float block_sum4(float v, float* red, int tid) {  // sum over the 256 threads (red: 4 floats of LDS)
+  v = rl4co::bfly_sum<1, 64>(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// rows of one token tile normalised with the statistics of the WHOLE instance (all its tiles' pairs combined)
+template <typename E>
+__global__ void __launch_bounds__(kThreads) tok16_norm_apply_kernel(const E* __restrict__ ypre, const float* __restrict__ stats, int N,
+                                                                    int kind, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, E* __restrict__ xout) {
+  __shared__ float ab[2 * kD];
+  __shared__ float red[4];
+  const int tid = threadIdx.x, b = blockIdx.y, tiles = gridDim.x, n0 = kTok * blockIdx.x, valid = min(kTok, N - n0);
+  const float* st = stats + (int64_t)b * tiles * kStatFloats;
+  float mean = 0.0f, m2 = 0.0f;
+  if (tid < kD) {
+    float tot = 0.0f;
+    for (int t = 0; t < tiles; ++t) tot += (float)min(kTok, N - kTok * t) * st[t * kStatFloats + tid];
+    mean = tot / (float)N;
+    for (int t = 0; t < tiles; ++t) {
+      const float d = st[t * kStatFloats + tid] - mean;
+      m2 += st[t * kStatFloats + kD + tid] + (float)min(kTok, N - kTok * t) * d * d;
+    }
+  }
+  if (kind == 1) {
+    if (tid < kD) {
+      const float alpha = rsqrtf(m2 / (float)N + 1e-5f) * gamma[tid];
+      ab[tid] = alpha;
+      ab[kD + tid] = beta[tid] - mean * alpha;
+    }
+  } else {  // layer: every channel holds N values
+    const float mean_all = block_sum4(tid < kD ? mean : 0.0f, red, tid) / (float)kD;
+    const float d = mean - mean_all;
+    const float m2_all = block_sum4(tid < kD ? m2 + (float)N * d * d : 0.0f, red, tid);
+    const float rstd = rsqrtf(m2_all / ((float)N * (float)kD - 1.0f) + 1e-5f);
+    if (tid < kD) {
+      ab[tid] = rstd;
+      ab[kD + tid] = -mean_all * rstd;
+    }
+  }
+  __syncthreads();
+  const E* src = ypre + ((int64_t)b * N + n0) * kD;
+  E* dst = xout + ((int64_t)b * N + n0) * kD;
+  for (int i = tid; i < valid * 16; i += kThreads) {
+    const int c0 = 8 * (i & 15);
+    vec8<E> v = *reinterpret_cast<const vec8<E>*>(src + (int64_t)(i >> 4) * kD + c0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (E)fmaf((float)v[e], ab[c0 + e], ab[kD + c0 + e]);
+    *reinterpret_cast<vec8<E>*>(dst + (int64_t)(i >> 4) * kD + c0) = v;
+  }
+}
+
 // cache planes (16-bit or fp32) and fp32 context tables of one token tile, as the fused kernel's fold writes them
 template <typename E>
 __global__ void __launch_bounds__(kThreads, 2) tok16_fold_kernel(const E* __restrict__ x, const rl4co_am_encoder_args a) {
@@ -1036,7 +1237,9 @@ int launch_tokens16(const rl4co_am_encoder_args& a, void* workspace, hipStream_t
   E* x1 = x0 + mx;
   E* att = x0 + 2 * mx;
   E* qkv = x0 + 3 * mx;  // [B N, 384]
-  uint32_t* bound = reinterpret_cast<uint32_t*>(x0 + 6 * mx);  // [B][8 heads][q, k] fp32 bit patterns
+  E* ypre = x0 + 6 * mx;                                        // pre-norm sums (instance / layer norm only)
+  uint32_t* bound = reinterpret_cast<uint32_t*>(x0 + 7 * mx);  // [B][8 heads][q, k] fp32 bit patterns
+  float* stats = reinterpret_cast<float*>(bound + (int64_t)a.B * 8 * 2);  // [B][tiles][mean 128 | M2 128]
   const dim3 grid((N + kTok - 1) / kTok, a.B), block(kThreads);
   const int lds_tile = kTok * kRS * (int)sizeof(E);
   const int lds_init = lds_tile + 6 * N * 4 + 64, lds_qkv = 2 * lds_tile + 3 * kD * 4, lds_mlp = 2 * lds_tile + kFF * 4;
@@ -1045,6 +1248,10 @@ int launch_tokens16(const rl4co_am_encoder_args& a, void* workspace, hipStream_t
   RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tok16_qkv_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_qkv));
   RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tok16_mlp_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_mlp));
   RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tok16_fold_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * lds_tile));
+  if (a.norm != 0) {
+    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tok16_attn_half_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * lds_tile));
+    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tok16_ffn_half_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_mlp));
+  }
   hipLaunchKernelGGL(tok16_init_embed_kernel<E>, grid, block, lds_init, s, a, x0);
   E *xin = x0, *xout = x1;
   const E* wqkv = static_cast<const E*>(a.wqkv_packed);
@@ -1058,9 +1265,21 @@ int launch_tokens16(const rl4co_am_encoder_args& a, void* workspace, hipStream_t
     const int st = half ? rl4co_attn_flash_pre_f16(qkv, reinterpret_cast<const float*>(bound), a.B, N, att, s)
                         : rl4co_attn_flash_pre_bf16(qkv, reinterpret_cast<const float*>(bound), a.B, N, att, s);
     if (st != RL4CO_OK) return st;
-    hipLaunchKernelGGL(tok16_mlp_kernel<E>, grid, block, lds_mlp, s, xin, att, N, wo + (int64_t)layer * kD * kD, w1 + (int64_t)layer * kFF * kD,
-                       w2 + (int64_t)layer * kD * kFF, a.b1 + layer * kFF, a.n1_scale + layer * kD, a.n1_shift + layer * kD,
-                       a.n2_scale + layer * kD, a.n2_shift + layer * kD, xout);
+    if (a.norm == 0) {
+      hipLaunchKernelGGL(tok16_mlp_kernel<E>, grid, block, lds_mlp, s, xin, att, N, wo + (int64_t)layer * kD * kD, w1 + (int64_t)layer * kFF * kD,
+                         w2 + (int64_t)layer * kD * kFF, a.b1 + layer * kFF, a.n1_scale + layer * kD, a.n1_shift + layer * kD,
+                         a.n2_scale + layer * kD, a.n2_shift + layer * kD, xout);
+    } else {
+      // instance / layer norm: each half stops before its norm; the apply kernel sees the whole instance's statistics.
+      // (layer norm: the bias of the GEMM in front of the norm arrives in the shift slot, encoder.py)
+      const float* pb1 = a.norm == 2 ? a.n1_shift + layer * kD : nullptr;
+      const float* pb2 = a.norm == 2 ? a.n2_shift + layer * kD : nullptr;
+      hipLaunchKernelGGL(tok16_attn_half_kernel<E>, grid, block, 2 * lds_tile, s, xin, att, N, wo + (int64_t)layer * kD * kD, pb1, ypre, stats);
+      hipLaunchKernelGGL(tok16_norm_apply_kernel<E>, grid, block, 0, s, ypre, stats, N, a.norm, a.n1_scale + layer * kD, a.n1_shift + layer * kD, xout);
+      hipLaunchKernelGGL(tok16_ffn_half_kernel<E>, grid, block, lds_mlp, s, xout, N, w1 + (int64_t)layer * kFF * kD, w2 + (int64_t)layer * kD * kFF,
+                         a.b1 + layer * kFF, pb2, ypre, stats);
+      hipLaunchKernelGGL(tok16_norm_apply_kernel<E>, grid, block, 0, s, ypre, stats, N, a.norm, a.n2_scale + layer * kD, a.n2_shift + layer * kD, xout);
+    }
     E* t = xin;
     xin = xout;
     xout = t;
@@ -1089,7 +1308,20 @@ int launch_encoder(const rl4co_am_encoder_args& a, hipStream_t stream) {
 }
 
 template <typename E, int TT>
+int launch_encoder_layer(const rl4co_am_encoder_args& a, hipStream_t stream) {
+  // whole-instance ("layer") statistics: its own instantiation — the batch / instance kernel's code stays as tuned — with
+  // the generic key-tile masks (VR4 = 4 serves every N of the tile count)
+  const int lds = 2 * 128 * kRS * 2 + kD * 4 + kBiasFloats * 4;
+  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_encoder_kernel<E, TT, 4, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL((am_encoder_kernel<E, TT, 4, false, true>), dim3(a.B), dim3(kThreads), lds, stream, a, TrainSave<E>{});
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
+template <typename E, int TT>
 int launch_encoder_tiles(const rl4co_am_encoder_args& a, hipStream_t stream) {
+  if (a.norm == 2) return launch_encoder_layer<E, TT>(a, stream);
   const int vr4 = (a.N - 32 * (TT - 1) + 7) / 8;  // valid 4-register groups of the last key tile
   switch (vr4) {
     case 1: return launch_encoder<E, TT, 1>(a, stream);
@@ -1170,7 +1402,7 @@ extern "C" int rl4co_am_encoder(const rl4co_am_encoder_args* args, void* stream)
   const rl4co_am_encoder_args& a = *args;
   RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP || a.env == RL4CO_ENV_PDP);
   RL4CO_REQUIRE(a.B > 0 && a.N >= 2 && a.N <= 128);
-  RL4CO_REQUIRE(a.num_layers >= 1 && (a.norm == 0 || a.norm == 1));
+  RL4CO_REQUIRE(a.num_layers >= 1 && a.norm >= 0 && a.norm <= 2);  // batch (eval, folded affine) | instance | layer
   RL4CO_REQUIRE(a.act_dtype == RL4CO_DT_BF16 || a.act_dtype == RL4CO_DT_F16);
   // planes: fp32, or the 16-bit type the activations are computed in
   RL4CO_REQUIRE(a.cache_dtype == RL4CO_DT_F32 || a.cache_dtype == a.act_dtype);
@@ -1189,7 +1421,7 @@ extern "C" int rl4co_am_encoder(const rl4co_am_encoder_args* args, void* stream)
 extern "C" int64_t rl4co_am_encoder_tokens16_workspace(int B, int N) {
   if (B <= 0 || N <= 0) return 0;
   const int64_t mx = ((int64_t)B * N * kD + 63) / 64 * 64;
-  return 6 * mx * 2 + (int64_t)B * 8 * 2 * 4;
+  return 7 * mx * 2 + (int64_t)B * 8 * 2 * 4 + (int64_t)B * ((N + kTok - 1) / kTok) * kStatFloats * 4;
 }
 
 extern "C" int rl4co_am_encoder_tokens16(const rl4co_am_encoder_args* args, void* workspace, int64_t workspace_bytes, void* stream) {
@@ -1197,7 +1429,7 @@ extern "C" int rl4co_am_encoder_tokens16(const rl4co_am_encoder_args* args, void
   const rl4co_am_encoder_args& a = *args;
   RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP || a.env == RL4CO_ENV_PDP);
   RL4CO_REQUIRE(a.B > 0 && a.N >= 2 && a.B <= 65535);
-  RL4CO_REQUIRE(a.num_layers >= 1 && a.norm == 0);  // instance norm couples the nodes of an instance: fused kernel only
+  RL4CO_REQUIRE(a.num_layers >= 1 && a.norm >= 0 && a.norm <= 2);  // instance / layer norm: split sub-blocks + apply kernel
   RL4CO_REQUIRE(a.act_dtype == RL4CO_DT_BF16 || a.act_dtype == RL4CO_DT_F16);
   RL4CO_REQUIRE(a.cache_dtype == RL4CO_DT_F32 || a.cache_dtype == a.act_dtype);
   RL4CO_REQUIRE(a.locs && a.w_init && a.b_init);

@@ -36,7 +36,7 @@ namespace {
 
 using namespace rl4co_f32;
 
-template <int TT>
+template <int TT, bool LAYER = false>
 __global__ void __launch_bounds__(kThreads) am_encoder_f32_kernel(const rl4co_am_encoder_args a) {
   constexpr int kRows = 16 * TT;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(kThreads) am_encoder_f32_kernel(const rl4co_am
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) y[tt] = zero4();
       gemm16<TT, true>(y, wf, ys, lane, Lw1, 8, w, 0);  // next: FFN1 chunk 0
-      residual_norm<TT>(xs, y, 16 * w, bl + 3 * kD + kFF, a.n1_scale + layer * kD, a.n1_shift + layer * kD, a.norm, N, lane);
+      residual_norm<TT, LAYER>(xs, y, 16 * w, bl + 3 * kD + kFF, a.n1_scale + layer * kD, a.n1_shift + layer * kD, a.norm, N, lane, meanv, w);
     }
     __syncthreads();
 
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(kThreads) am_encoder_f32_kernel(const rl4co_am
         const float* nxt = ch < 3 ? Lw1 : (last_layer ? wf_all : wqkv_all + (int64_t)(layer + 1) * 3 * kD * kD);
         gemm16<TT, true>(y2, wf, ys, lane, nxt, 8, ch < 3 ? 8 * (ch + 1) + w : w, 0);
       }
-      residual_norm<TT>(xs, y2, 16 * w, bl + 4 * kD + kFF, a.n2_scale + layer * kD, a.n2_shift + layer * kD, a.norm, N, lane);
+      residual_norm<TT, LAYER>(xs, y2, 16 * w, bl + 4 * kD + kFF, a.n2_scale + layer * kD, a.n2_shift + layer * kD, a.norm, N, lane, meanv, w);
     }
     __syncthreads();  // (also: every wave is done with this layer's biases and with ys)
     if (layer + 1 < a.num_layers) {
@@ -251,9 +251,15 @@ __global__ void __launch_bounds__(kThreads) am_encoder_f32_kernel(const rl4co_am
 template <int TT>
 int launch_f32(const rl4co_am_encoder_args& a, hipStream_t stream) {
   const int lds = (2 * 16 * TT * kRS + kD + kBiasFloats) * 4;
-  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_encoder_f32_kernel<TT>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL((am_encoder_f32_kernel<TT>), dim3(a.B), dim3(kThreads), lds, stream, a);
+  if (a.norm == 2) {  // whole-instance statistics: its own instantiation, so the batch / instance kernel's code is untouched
+    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_encoder_f32_kernel<TT, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((am_encoder_f32_kernel<TT, true>), dim3(a.B), dim3(kThreads), lds, stream, a);
+  } else {
+    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_encoder_f32_kernel<TT, false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipLaunchKernelGGL((am_encoder_f32_kernel<TT, false>), dim3(a.B), dim3(kThreads), lds, stream, a);
+  }
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }
@@ -265,7 +271,7 @@ extern "C" int rl4co_am_encoder_f32(const rl4co_am_encoder_args* args, void* str
   const rl4co_am_encoder_args& a = *args;
   RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP || a.env == RL4CO_ENV_PDP);
   RL4CO_REQUIRE(a.B > 0 && a.N >= 2 && a.N <= 128);
-  RL4CO_REQUIRE(a.num_layers >= 1 && (a.norm == 0 || a.norm == 1));
+  RL4CO_REQUIRE(a.num_layers >= 1 && a.norm >= 0 && a.norm <= 2);  // batch (eval) | instance | layer
   RL4CO_REQUIRE(a.act_dtype == RL4CO_DT_F32);
   RL4CO_REQUIRE(a.cache_dtype == RL4CO_DT_F32 || a.cache_dtype == RL4CO_DT_BF16 || a.cache_dtype == RL4CO_DT_F16);
   RL4CO_REQUIRE(a.locs && a.w_init && a.b_init);

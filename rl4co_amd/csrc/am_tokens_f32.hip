@@ -14,8 +14,9 @@
 //                                                                      nn/graph/attnnet.py:16-55, nn/ops.py:9-54, nn/mlp.py:52-61
 //   tok_fold         cache planes / context tables from the final embeddings                  zoo/am/decoder.py:201-228 (cache.py)
 //   graph_context    project_fixed_context(mean_j h_j)                                        zoo/am/decoder.py:216-219
-// Normalisation: batch norm in eval mode (alpha, beta from the running statistics); instance norm couples all nodes of an
-// instance and is served by the fused kernel only (N <= 128).
+// Normalisation: batch norm in eval mode (alpha, beta from the running statistics) inside tok_mlp; instance / layer norm
+// couple all nodes of an instance: the layer's two halves then stop before their norm (tok_attn_half / tok_ffn_half write
+// the pre-norm sums and per-tile statistics) and tok_norm_apply normalises with the combined statistics.
 #include <hip/hip_runtime.h>
 
 #include "common.h"
@@ -30,13 +31,13 @@ constexpr int kTile = 16 * kTT;
 constexpr int kLdsTile = kTile * kRS * 4;
 
 struct Workspace {  // fp32 buffers carved out of the caller's workspace
-  float *x0, *x1, *q, *k, *vt, *att;
+  float *x0, *x1, *q, *k, *vt, *att, *ypre, *stats;
 };
 __host__ inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 __host__ inline int64_t np_of(int n) { return round_up(n, 16); }
 __host__ inline int64_t workspace_floats(int B, int N) {
   const int64_t mx = round_up((int64_t)B * N * kD, 64);
-  return 5 * mx + round_up((int64_t)B * 8 * 16 * np_of(N), 64);
+  return 6 * mx + round_up((int64_t)B * 8 * 16 * np_of(N), 64) + round_up((int64_t)B * ((N + 127) / 128) * 256, 64);
 }
 __host__ inline Workspace carve(float* base, int B, int N) {
   const int64_t mx = round_up((int64_t)B * N * kD, 64);
@@ -47,6 +48,8 @@ __host__ inline Workspace carve(float* base, int B, int N) {
   w.k = base + 3 * mx;
   w.att = base + 4 * mx;
   w.vt = base + 5 * mx;
+  w.ypre = w.vt + round_up((int64_t)B * 8 * 16 * np_of(N), 64);  // pre-norm sums + tile statistics: instance / layer norm only
+  w.stats = w.ypre + mx;
   return w;
 }
 
@@ -250,6 +253,166 @@ __global__ void __launch_bounds__(kThreads) tok_mlp_kernel(const float* __restri
   store_tile(xs, xout, b, n0, N, tid);
 }
 
+// ---- token tiles under instance / layer norm (norm = 1 / 2): nn/ops.py:46-51 -------------------------------------------
+// The statistics span all tiles of an instance, so each half of a layer ends BEFORE its norm: it writes the pre-norm sums
+// and, per tile and channel, the mean and the centred sum of squares of the tile's valid tokens; tok_norm_apply_kernel
+// combines the tiles' pairs (Chan's update: deterministic, no atomics, no cancellation) and normalises the rows.
+constexpr int kStatFloats = 2 * kD;  // per (instance, tile): mean [128] | M2 [128]
+
+// x + (y + bias) for the wave's 16-dim tile back into xs; tile statistics -> st
+template <int TT>
+__device__ inline void residual_stats(float* xs, f32x4 (&y)[TT], int dim0, const float* bias_lds, int valid, int lane, float* st) {
+  const int c = lane & 15, g = lane >> 4;
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_lds + dim0 + 4 * g);
+  float* row = xs + c * kRS + dim0 + 4 * g;
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(row + 16 * tt * kRS);
+    y[tt] = x + (y[tt] + bias);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float s = 0.0f;
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) s += (16 * tt + c < valid) ? y[tt][r] : 0.0f;
+    s = rl4co::bfly_sum<1, 16>(s);
+    const float mean = s / (float)valid;
+    float v = 0.0f;
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const float d = y[tt][r] - mean;
+      v += (16 * tt + c < valid) ? d * d : 0.0f;
+    }
+    v = rl4co::bfly_sum<1, 16>(v);
+    if (c == 0) {
+      st[dim0 + 4 * g + r] = mean;
+      st[kD + dim0 + 4 * g + r] = v;
+    }
+  }
+#pragma unroll
+  for (int tt = 0; tt < TT; ++tt) *reinterpret_cast<f32x4*>(row + 16 * tt * kRS) = y[tt];
+}
+
+// pre-norm x + out_proj(att) of one token tile
+__global__ void __launch_bounds__(kThreads) tok_attn_half_kernel(const float* __restrict__ x, const float* __restrict__ att, int N,
+                                                                 const float* __restrict__ wo, const float* __restrict__ bo,
+                                                                 float* __restrict__ ypre, float* __restrict__ stats) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* xs = reinterpret_cast<float*>(smem);
+  float* ys = xs + kTile * kRS;
+  float* bl = ys + kTile * kRS;  // bo [128]
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.y, n0 = kTile * blockIdx.x, valid = min(kTile, N - n0);
+  f32x4 wf[8];
+  load_wfrags(wf, wo, 8, w, 0, lane);
+  load_tile(xs, x, b, n0, N, tid);
+  load_tile(ys, att, b, n0, N, tid);
+  for (int i = tid; i < kD; i += kThreads) bl[i] = bo[i];
+  __syncthreads();
+  f32x4 y[kTT];
+#pragma unroll
+  for (int tt = 0; tt < kTT; ++tt) y[tt] = zero4();
+  gemm16<kTT, true>(y, wf, ys, lane, static_cast<const float*>(nullptr), 0, 0, 0);
+  residual_stats<kTT>(xs, y, 16 * w, bl, valid, lane, stats + ((int64_t)b * gridDim.x + blockIdx.x) * kStatFloats);
+  __syncthreads();
+  store_tile(xs, ypre, b, n0, N, tid);
+}
+
+// pre-norm x + MLP(x) of one token tile (x: the normalised output of the attention half)
+__global__ void __launch_bounds__(kThreads) tok_ffn_half_kernel(const float* __restrict__ x, int N, const float* __restrict__ w1,
+                                                                const float* __restrict__ w2, const float* __restrict__ b1,
+                                                                const float* __restrict__ b2, float* __restrict__ ypre,
+                                                                float* __restrict__ stats) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float* xs = reinterpret_cast<float*>(smem);
+  float* ys = xs + kTile * kRS;
+  float* bl = ys + kTile * kRS;  // b1 [512] | b2 [128]
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, g = (tid & 63) >> 4;
+  const int b = blockIdx.y, n0 = kTile * blockIdx.x, valid = min(kTile, N - n0);
+  f32x4 wf[8];
+  load_wfrags(wf, w1, 8, w, 0, lane);
+  load_tile(xs, x, b, n0, N, tid);
+  for (int i = tid; i < kFF + kD; i += kThreads) bl[i] = i < kFF ? b1[i] : b2[i - kFF];
+  __syncthreads();
+  f32x4 y2[kTT];
+#pragma unroll
+  for (int tt = 0; tt < kTT; ++tt) y2[tt] = zero4();
+#pragma unroll 1
+  for (int ch = 0; ch < 4; ++ch) {
+    f32x4 h1[kTT];
+#pragma unroll
+    for (int tt = 0; tt < kTT; ++tt) h1[tt] = zero4();
+    gemm16<kTT, true>(h1, wf, xs, lane, w2, 32, w, 8 * ch);
+    const f32x4 b14 = *reinterpret_cast<const f32x4*>(bl + 128 * ch + 16 * w + 4 * g);
+#pragma unroll
+    for (int tt = 0; tt < kTT; ++tt) {
+      h1[tt] += b14;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h1[tt][r] = fmaxf(h1[tt][r], 0.0f);
+    }
+    if (ch > 0) __syncthreads();  // every wave is done reading the previous chunk
+    store_t<kTT>(ys, h1, 16 * w, lane);
+    __syncthreads();
+    gemm16<kTT, true>(y2, wf, ys, lane, ch < 3 ? w1 : static_cast<const float*>(nullptr), 8, 8 * (ch + 1) + w, 0);
+  }
+  residual_stats<kTT>(xs, y2, 16 * w, bl + kFF, valid, lane, stats + ((int64_t)b * gridDim.x + blockIdx.x) * kStatFloats);
+  __syncthreads();
+  store_tile(xs, ypre, b, n0, N, tid);
+}
+
+__device__ inline float block_sum8(float v, float* red, int tid) {  // sum over the 512 threads (red: 8 floats of LDS)
+  v = rl4co::bfly_sum<1, 64>(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+}
+
+// rows of one token tile normalised with the statistics of the WHOLE instance (all its tiles' pairs combined)
+__global__ void __launch_bounds__(kThreads) tok_norm_apply_kernel(const float* __restrict__ ypre, const float* __restrict__ stats, int N,
+                                                                  int kind, const float* __restrict__ gamma,
+                                                                  const float* __restrict__ beta, float* __restrict__ xout) {
+  __shared__ __align__(16) float ab[2 * kD];
+  __shared__ float red[8];
+  const int tid = threadIdx.x, b = blockIdx.y, tiles = gridDim.x, n0 = kTile * blockIdx.x, valid = min(kTile, N - n0);
+  const float* st = stats + (int64_t)b * tiles * kStatFloats;
+  float mean = 0.0f, m2 = 0.0f;
+  if (tid < kD) {
+    float tot = 0.0f;
+    for (int t = 0; t < tiles; ++t) tot += (float)min(kTile, N - kTile * t) * st[t * kStatFloats + tid];
+    mean = tot / (float)N;
+    for (int t = 0; t < tiles; ++t) {
+      const float d = st[t * kStatFloats + tid] - mean;
+      m2 += st[t * kStatFloats + kD + tid] + (float)min(kTile, N - kTile * t) * (d * d);
+    }
+  }
+  if (kind == 1) {
+    if (tid < kD) {
+      const float alpha = (1.0f / sqrtf(m2 / (float)N + 1e-5f)) * gamma[tid];
+      ab[tid] = alpha;
+      ab[kD + tid] = beta[tid] - mean * alpha;
+    }
+  } else {  // layer: every channel holds N values
+    const float mean_all = block_sum8(tid < kD ? mean : 0.0f, red, tid) / (float)kD;
+    const float d = mean - mean_all;
+    const float m2_all = block_sum8(tid < kD ? m2 + (float)N * (d * d) : 0.0f, red, tid);
+    const float invstd = 1.0f / sqrtf(m2_all / ((float)N * (float)kD - 1.0f) + 1e-5f);
+    if (tid < kD) {
+      ab[tid] = invstd;
+      ab[kD + tid] = -mean_all * invstd;
+    }
+  }
+  __syncthreads();
+  const float* src = ypre + ((int64_t)b * N + n0) * kD;
+  float* dst = xout + ((int64_t)b * N + n0) * kD;
+  for (int i = tid; i < valid * 32; i += kThreads) {
+    const int c0 = 4 * (i & 31);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(src + (int64_t)(i >> 5) * kD + c0);
+    const f32x4 al = *reinterpret_cast<const f32x4*>(ab + c0), be = *reinterpret_cast<const f32x4*>(ab + kD + c0);
+    *reinterpret_cast<f32x4*>(dst + (int64_t)(i >> 5) * kD + c0) = v * al + be;
+  }
+}
+
 struct FoldOut {
   void* ptr[5];
   int plane16[5];
@@ -349,7 +512,7 @@ extern "C" int rl4co_am_encoder_tokens_f32(const rl4co_am_encoder_args* args, vo
   const rl4co_am_encoder_args& a = *args;
   RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP || a.env == RL4CO_ENV_PDP);
   RL4CO_REQUIRE(a.B > 0 && a.N >= 2 && a.B <= 65535);
-  RL4CO_REQUIRE(a.num_layers >= 1 && a.norm == 0);  // instance norm couples the nodes of an instance: fused kernel only
+  RL4CO_REQUIRE(a.num_layers >= 1 && a.norm >= 0 && a.norm <= 2);  // instance / layer norm: split sub-blocks + apply kernel
   RL4CO_REQUIRE(a.act_dtype == RL4CO_DT_F32);
   RL4CO_REQUIRE(a.cache_dtype == RL4CO_DT_F32 || a.cache_dtype == RL4CO_DT_BF16 || a.cache_dtype == RL4CO_DT_F16);
   RL4CO_REQUIRE(a.locs && a.w_init && a.b_init);
@@ -374,6 +537,10 @@ extern "C" int rl4co_am_encoder_tokens_f32(const rl4co_am_encoder_args* args, vo
   if (int e = set_lds(tok_qkv_kernel, kLdsTile)) return e;
   if (int e = set_lds(tok_mlp_kernel, lds_mlp)) return e;
   if (int e = set_lds(tok_fold_kernel, 2 * kLdsTile)) return e;
+  if (a.norm != 0) {
+    if (int e = set_lds(tok_attn_half_kernel, 2 * kLdsTile + kD * 4)) return e;
+    if (int e = set_lds(tok_ffn_half_kernel, 2 * kLdsTile + (kFF + kD) * 4)) return e;
+  }
 
   hipLaunchKernelGGL(tok_init_embed_kernel, grid, block, lds_init, s, a, ws.x0);
   float *xin = ws.x0, *xout = ws.x1;
@@ -385,9 +552,20 @@ extern "C" int rl4co_am_encoder_tokens_f32(const rl4co_am_encoder_args* args, vo
     hipLaunchKernelGGL(tok_qkv_kernel, grid, block, kLdsTile, s, xin, N, NP, wqkv + (int64_t)layer * 3 * kD * kD, a.bqkv + layer * 3 * kD,
                        ws.q, ws.k, ws.vt);
     hipLaunchKernelGGL(tok_attn_kernel, grid, block, 0, s, ws.q, ws.k, ws.vt, N, NP, ws.att);
-    hipLaunchKernelGGL(tok_mlp_kernel, grid, block, lds_mlp, s, xin, ws.att, N, wo + (int64_t)layer * kD * kD, w1 + (int64_t)layer * kFF * kD,
-                       w2 + (int64_t)layer * kD * kFF, a.bo + layer * kD, a.b1 + layer * kFF, a.b2 + layer * kD, a.n1_scale + layer * kD,
-                       a.n1_shift + layer * kD, a.n2_scale + layer * kD, a.n2_shift + layer * kD, xout);
+    if (a.norm == 0) {
+      hipLaunchKernelGGL(tok_mlp_kernel, grid, block, lds_mlp, s, xin, ws.att, N, wo + (int64_t)layer * kD * kD, w1 + (int64_t)layer * kFF * kD,
+                         w2 + (int64_t)layer * kD * kFF, a.bo + layer * kD, a.b1 + layer * kFF, a.b2 + layer * kD, a.n1_scale + layer * kD,
+                         a.n1_shift + layer * kD, a.n2_scale + layer * kD, a.n2_shift + layer * kD, xout);
+    } else {  // instance / layer norm: each half stops before its norm; the apply kernel sees the whole instance's statistics
+      hipLaunchKernelGGL(tok_attn_half_kernel, grid, block, 2 * kLdsTile + kD * 4, s, xin, ws.att, N, wo + (int64_t)layer * kD * kD,
+                         a.bo + layer * kD, ws.ypre, ws.stats);
+      hipLaunchKernelGGL(tok_norm_apply_kernel, grid, block, 0, s, ws.ypre, ws.stats, N, a.norm, a.n1_scale + layer * kD,
+                         a.n1_shift + layer * kD, xout);
+      hipLaunchKernelGGL(tok_ffn_half_kernel, grid, block, 2 * kLdsTile + (kFF + kD) * 4, s, xout, N, w1 + (int64_t)layer * kFF * kD,
+                         w2 + (int64_t)layer * kD * kFF, a.b1 + layer * kFF, a.b2 + layer * kD, ws.ypre, ws.stats);
+      hipLaunchKernelGGL(tok_norm_apply_kernel, grid, block, 0, s, ws.ypre, ws.stats, N, a.norm, a.n2_scale + layer * kD,
+                         a.n2_shift + layer * kD, xout);
+    }
     float* t = xin;
     xin = xout;
     xout = t;

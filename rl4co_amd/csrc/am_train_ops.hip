@@ -167,11 +167,136 @@ __global__ void __launch_bounds__(kThreads) skip_inorm_bwd_kernel(const uint32_t
   }
 }
 
+// ---- normalization="layer" (nn/ops.py:48-51): (y - mean) / sqrt(var + 1e-5) with ONE mean and ONE UNBIASED variance over
+// all M = N x 128 values of the instance, no affine. Same thread layout as the instance-norm kernels above; the
+// statistics are workgroup-wide sums.
+//   backward  xh = (y - mu) r ;  dy = r * (dout - sum(dout) / M - xh * sum(dout * xh) / (M - 1))
+__device__ inline float block_sum(float v, float* red4, int tid) {
+  v = rl4co::bfly_sum<1, 64>(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red4[tid >> 6] = v;
+  __syncthreads();
+  return (red4[0] + red4[1]) + (red4[2] + red4[3]);
+}
+
+__global__ void __launch_bounds__(kThreads) skip_lnorm_fwd_kernel(const uint32_t* __restrict__ x, const uint32_t* __restrict__ s,
+                                                                  float eps, int N, uint32_t* __restrict__ y,
+                                                                  uint32_t* __restrict__ out, float* __restrict__ stats) {
+  __shared__ float red4[4];
+  const int tid = threadIdx.x, cp = tid & 63, q = tid >> 6;
+  const int64_t base = (int64_t)blockIdx.x * N * (kD / 2);
+  float v[kMaxRows][2];
+  uint32_t ra[kMaxRows], rb[kMaxRows];  // all loads first (see skip_inorm_fwd_kernel)
+#pragma unroll
+  for (int i = 0; i < kMaxRows; ++i) {
+    const int n = min(q + 4 * i, N - 1);
+    ra[i] = x[base + (int64_t)n * (kD / 2) + cp];
+    rb[i] = s[base + (int64_t)n * (kD / 2) + cp];
+  }
+  float sum = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kMaxRows; ++i) {
+    const int n = q + 4 * i;
+    v[i][0] = 0.0f;
+    v[i][1] = 0.0f;
+    if (n < N) {
+      const uint32_t a = ra[i], b = rb[i];
+      const uint32_t ys = pack_bf16(bf16_lo(a) + bf16_lo(b), bf16_hi(a) + bf16_hi(b));  // the skip sum, rounded like autocast's
+      y[base + (int64_t)n * (kD / 2) + cp] = ys;
+      v[i][0] = bf16_lo(ys);
+      v[i][1] = bf16_hi(ys);
+      sum += v[i][0] + v[i][1];
+    }
+  }
+  const float cnt = (float)(N * kD);
+  const float mu = block_sum(sum, red4, tid) / cnt;
+  float sq = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kMaxRows; ++i) {
+    if (q + 4 * i < N) {
+      const float d0 = v[i][0] - mu, d1 = v[i][1] - mu;
+      sq = fmaf(d0, d0, sq);
+      sq = fmaf(d1, d1, sq);
+    }
+  }
+  const float rs = rsqrtf(block_sum(sq, red4, tid) / (cnt - 1.0f) + eps);
+#pragma unroll
+  for (int i = 0; i < kMaxRows; ++i) {
+    const int n = q + 4 * i;
+    if (n < N) out[base + (int64_t)n * (kD / 2) + cp] = pack_bf16((v[i][0] - mu) * rs, (v[i][1] - mu) * rs);
+  }
+  if (tid == 0) {
+    stats[2 * (int64_t)blockIdx.x] = mu;
+    stats[2 * (int64_t)blockIdx.x + 1] = rs;
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) skip_lnorm_bwd_kernel(const uint32_t* __restrict__ dout, const uint32_t* __restrict__ y,
+                                                                  const float* __restrict__ stats, int N, uint32_t* __restrict__ dy) {
+  __shared__ float red4[4];
+  const int tid = threadIdx.x, cp = tid & 63, q = tid >> 6;
+  const int64_t base = (int64_t)blockIdx.x * N * (kD / 2);
+  const float mu = stats[2 * (int64_t)blockIdx.x], rs = stats[2 * (int64_t)blockIdx.x + 1];
+  float xh[kMaxRows][2], dd[kMaxRows][2];
+  uint32_t ra[kMaxRows], rb[kMaxRows];
+#pragma unroll
+  for (int i = 0; i < kMaxRows; ++i) {
+    const int n = min(q + 4 * i, N - 1);
+    ra[i] = dout[base + (int64_t)n * (kD / 2) + cp];
+    rb[i] = y[base + (int64_t)n * (kD / 2) + cp];
+  }
+  float s_d = 0.0f, s_dx = 0.0f;
+#pragma unroll
+  for (int i = 0; i < kMaxRows; ++i) {
+    xh[i][0] = xh[i][1] = dd[i][0] = dd[i][1] = 0.0f;
+    if (q + 4 * i < N) {
+      const uint32_t a = ra[i], b = rb[i];
+      dd[i][0] = bf16_lo(a);
+      dd[i][1] = bf16_hi(a);
+      xh[i][0] = (bf16_lo(b) - mu) * rs;
+      xh[i][1] = (bf16_hi(b) - mu) * rs;
+      s_d += dd[i][0] + dd[i][1];
+      s_dx = fmaf(dd[i][0], xh[i][0], s_dx);
+      s_dx = fmaf(dd[i][1], xh[i][1], s_dx);
+    }
+  }
+  const float cnt = (float)(N * kD);
+  const float m_d = block_sum(s_d, red4, tid) / cnt;
+  const float m_dx = block_sum(s_dx, red4, tid) / (cnt - 1.0f);
+#pragma unroll
+  for (int i = 0; i < kMaxRows; ++i) {
+    const int n = q + 4 * i;
+    if (n < N)
+      dy[base + (int64_t)n * (kD / 2) + cp] =
+          pack_bf16(rs * (dd[i][0] - m_d - xh[i][0] * m_dx), rs * (dd[i][1] - m_d - xh[i][1] * m_dx));
+  }
+}
+
 }  // namespace
 
 #if !RL4CO_ELEM_F16
 extern "C" int rl4co_skip_inorm_max_nodes(void) { return 4 * kMaxRows; }
 #endif
+
+extern "C" int RL4CO_ENTRY(rl4co_skip_lnorm_fwd)(const void* x, const void* s, float eps, int B, int N, void* y, void* out,
+                                                 float* stats, void* stream) {
+  RL4CO_REQUIRE(x && s && y && out && stats);
+  RL4CO_REQUIRE(B > 0 && N >= 1 && N <= 4 * kMaxRows && eps > 0.0f);
+  hipLaunchKernelGGL(skip_lnorm_fwd_kernel, dim3(B), dim3(kThreads), 0, rl4co::as_stream(stream), static_cast<const uint32_t*>(x),
+                     static_cast<const uint32_t*>(s), eps, N, static_cast<uint32_t*>(y), static_cast<uint32_t*>(out), stats);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
+extern "C" int RL4CO_ENTRY(rl4co_skip_lnorm_bwd)(const void* dout, const void* y, const float* stats, int B, int N, void* dy,
+                                                 void* stream) {
+  RL4CO_REQUIRE(dout && y && stats && dy);
+  RL4CO_REQUIRE(B > 0 && N >= 1 && N <= 4 * kMaxRows);
+  hipLaunchKernelGGL(skip_lnorm_bwd_kernel, dim3(B), dim3(kThreads), 0, rl4co::as_stream(stream),
+                     static_cast<const uint32_t*>(dout), static_cast<const uint32_t*>(y), stats, N, static_cast<uint32_t*>(dy));
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
 
 extern "C" int RL4CO_ENTRY(rl4co_skip_inorm_fwd)(const void* x, const void* s, const float* gamma, const float* beta, float eps, int B,
                                          int N, void* y, void* out, float* mean, float* rstd, void* stream) {

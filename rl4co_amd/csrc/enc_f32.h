@@ -76,9 +76,11 @@ __device__ inline void store_t(float* ys, const f32x4 (&acc)[TT], int dim0, int 
 }
 
 // y = Norm(x + (y + bias)) for the wave's 16-dim tile, back into xs. nn/ops.py:9-15 (skip), 30-54 (norm).
-template <int TT>
+// LAYER (normalization="layer", nn/ops.py:48-51): ONE mean and ONE unbiased variance over all N x 128 values of the
+// instance, no affine — the waves' partial sums meet in `red` (2 x 8 floats of LDS; two workgroup barriers inside).
+template <int TT, bool LAYER = false>
 __device__ inline void residual_norm(float* xs, f32x4 (&y)[TT], int dim0, const float* bias_lds, const float* na, const float* nb,
-                                     int norm, int N, int lane) {
+                                     int norm, int N, int lane, float* red = nullptr, int w = 0) {
   const int c = lane & 15, g = lane >> 4;
   const f32x4 bias = *reinterpret_cast<const f32x4*>(bias_lds + dim0 + 4 * g);
   const f32x4 ga = *reinterpret_cast<const f32x4*>(na + dim0 + 4 * g);
@@ -90,7 +92,40 @@ __device__ inline void residual_norm(float* xs, f32x4 (&y)[TT], int dim0, const 
     y[tt] = x + (y[tt] + bias);
   }
   f32x4 alpha, beta;
-  if (norm == 1) {
+  if constexpr (LAYER) {
+    float s = 0.0f;
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      const float t4 = (y[tt][0] + y[tt][1]) + (y[tt][2] + y[tt][3]);
+      s += (16 * tt + c < N) ? t4 : 0.0f;
+    }
+    s = rl4co::bfly_sum<1, 64>(s);
+    if (lane == 0) red[w] = s;
+    __syncthreads();
+    const float cnt = (float)(N * kD);
+    const float mean = (((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]))) / cnt;
+    float v = 0.0f;
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {
+      float t4 = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = y[tt][r] - mean;
+        t4 = fmaf(d, d, t4);
+      }
+      v += (16 * tt + c < N) ? t4 : 0.0f;
+    }
+    v = rl4co::bfly_sum<1, 64>(v);
+    if (lane == 0) red[8 + w] = v;
+    __syncthreads();
+    const float var = (((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]))) / (cnt - 1.0f);
+    const float invstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      alpha[r] = invstd;
+      beta[r] = -mean * invstd;
+    }
+  } else if (norm == 1) {
     // instance norm: statistics per (instance, channel) over the N nodes, two passes as ATen's CPU kernel takes them
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

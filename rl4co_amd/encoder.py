@@ -57,30 +57,35 @@ def pack_weight_f32(w: Tensor) -> Tensor:
     return t.permute(0, 2, 3, 1, 4).contiguous().view(out_f // 16, in_f // 16, 64, 4)
 
 
-def _norm_affine_f32(norm_module) -> tuple[Tensor, Tensor, int]:
+def _norm_affine_f32(norm_module, device=None) -> tuple[Tensor, Tensor, int]:
     """(alpha, beta, kind) the way ATen's CPU batch-norm kernel forms them (native/cpu/batch_norm_kernel.cpp):
     invstd = 1 / sqrt(var + eps), alpha = invstd * weight, beta = bias - mean * alpha — eval-mode batch norm; instance norm
     hands over (gamma, beta) and the kernel builds the same pair from the instance's own statistics."""
     n = norm_module.normalizer
+    if norm_module.kind == "layer":  # nn/ops.py:48-51: whole-instance statistics, no affine — the kernel needs no table
+        return torch.ones(EMBED_DIM, device=device), torch.zeros(EMBED_DIM, device=device), 2
     if norm_module.kind == "batch":
         invstd = 1.0 / torch.sqrt(n.running_var.float() + n.eps)
         alpha = invstd * n.weight.detach().float()
         return alpha, n.bias.detach().float() - n.running_mean.float() * alpha, 0
     if norm_module.kind == "instance":
         return n.weight.detach().float(), n.bias.detach().float(), 1
-    raise NotImplementedError("fused encoder supports batch (eval) and instance normalisation")
+    raise NotImplementedError("fused encoder supports batch (eval), instance and layer normalisation")
 
 
-def _norm_affine(norm_module) -> tuple[Tensor, Tensor, int]:
-    """(scale, shift, kind): eval-mode batch norm folded to an affine; instance norm -> gamma/beta."""
+def _norm_affine(norm_module, device=None) -> tuple[Tensor, Tensor, int]:
+    """(scale, shift, kind): eval-mode batch norm folded to an affine; instance norm -> gamma/beta; layer norm (no affine)
+    -> (1, 0): its shift slot carries the bias of the GEMM in front of it (see ``PackedEncoder.refresh``)."""
     n = norm_module.normalizer
+    if norm_module.kind == "layer":
+        return torch.ones(EMBED_DIM, device=device), torch.zeros(EMBED_DIM, device=device), 2
     if norm_module.kind == "batch":
         scale = n.weight.detach().float() * torch.rsqrt(n.running_var.float() + n.eps)
         shift = n.bias.detach().float() - n.running_mean.float() * scale
         return scale, shift, 0
     if norm_module.kind == "instance":
         return n.weight.detach().float(), n.bias.detach().float(), 1
-    raise NotImplementedError("fused encoder supports batch (eval) and instance normalisation")
+    raise NotImplementedError("fused encoder supports batch (eval), instance and layer normalisation")
 
 
 class PackedEncoder:
@@ -150,13 +155,17 @@ class PackedEncoder:
         # the bias of the GEMM in front of a norm (out_proj before norm1, the MLP's second linear before norm2) is a
         # per-channel constant added to every token: under eval-mode batch norm it moves the affine's shift by
         # bias * scale; under instance norm it cancels in the per-channel mean over the nodes. The kernel adds neither
-        # (rl4co_am_encoder_args.bo / b2 are still passed for reference and ignored).
+        # (rl4co_am_encoder_args.bo / b2 are still passed for reference and ignored). Under layer norm (one mean over the
+        # whole instance) it does NOT cancel: the 16-bit kernel takes it from the shift slot and adds it before the statistics.
+        dev = layers[0][0].module.Wqkv.weight.device
         for name, idx, bias_of in (("n1", 1, lambda l: l[0].module.out_proj.bias), ("n2", 3, lambda l: l[2].module.lins[1].bias)):
             sc, sh = [], []
             for l in layers:
-                a, b, k = (_norm_affine_f32 if exact else _norm_affine)(l[idx])
+                a, b, k = (_norm_affine_f32 if exact else _norm_affine)(l[idx], dev)
                 if k == 0 and not exact:  # (the fp32 kernel adds bo / b2 itself, in the reference's order)
                     b = b + bias_of(l).detach().float() * a
+                elif k == 2 and not exact:
+                    b = bias_of(l).detach().float()
                 sc.append(a), sh.append(b), kinds.add(k)
             t[f"{name}_scale"], t[f"{name}_shift"] = torch.stack(sc).contiguous(), torch.stack(sh).contiguous()
         assert len(kinds) == 1
@@ -183,17 +192,18 @@ class PackedEncoder:
 
     def supported(self, td, act_dtype: torch.dtype | None = None) -> bool:
         """``act_dtype=torch.float32``: the exact-fp32 kernels — the fused one up to 128 nodes, the token-tile launches
-        (csrc/am_tokens_f32.hip) for any graph size under batch norm."""
+        (csrc/am_tokens_f32.hip) for any graph size; every normalisation kind of nn/ops.py:30-54 (batch in eval mode)."""
         pol = self.policy
         n = td["action_mask"].shape[-1]
         kind = pol.encoder.net.layers[0][1].kind
         if kind == "batch" and pol.training:  # batch statistics couple instances: torch path
             return False
         if n > _lib.lib().rl4co_am_encoder_max_nodes():
-            # token-tile launches (fp32: csrc/am_tokens_f32.hip; 16-bit: the token kernels of csrc/am_encoder.hip): batch norm
-            # only — instance statistics couple all nodes of an instance — and the staged features must fit the LDS
-            return kind == "batch" and td["locs"].is_cuda and 6 * n * 4 + 36 * 1024 <= 80 * 1024
-        return kind in ("batch", "instance") and td["locs"].is_cuda
+            # token-tile launches (fp32: csrc/am_tokens_f32.hip; 16-bit: the token kernels of csrc/am_encoder.hip). Instance /
+            # layer statistics couple all nodes of an instance: the layer's halves then stop before their norm and an apply
+            # kernel normalises with the tiles' combined statistics. The staged features must fit the LDS
+            return kind in ("batch", "instance", "layer") and td["locs"].is_cuda and 6 * n * 4 + 36 * 1024 <= 80 * 1024
+        return kind in ("batch", "instance", "layer") and td["locs"].is_cuda
 
     def encode(self, td, cache_dtype: torch.dtype, want_hidden: bool = False,
                act_dtype: torch.dtype | None = None, fold: bool = True, tokens: bool | None = None) -> tuple[FoldedCache, Tensor | None]:

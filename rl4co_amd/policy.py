@@ -145,7 +145,7 @@ class _EncoderLayer(nn.Sequential):
         # training under bf16 autocast: projections, MLP, attention and skip + norm (instance: one kernel
         # each way; batch: statistics + apply) on csrc/am_train_ops.hip / am_train_attn.hip instead of
         # library GEMMs and autograd's elementwise chains
-        if (self.fused_train and self.training and torch.is_grad_enabled() and x.is_cuda and self[1].kind in ("instance", "batch")
+        if (self.fused_train and self.training and torch.is_grad_enabled() and x.is_cuda and self[1].kind in ("instance", "batch", "layer")
                 and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)):
             from . import train_ops
 
@@ -172,6 +172,8 @@ class _EncoderLayer(nn.Sequential):
                     x = train_ops.skip_batch_norm(x, s, norm.normalizer)
                 elif norm.kind == "instance" and train_ops.usable(x, s):
                     x = train_ops.skip_instance_norm(x, s, norm.normalizer.weight, norm.normalizer.bias, norm.normalizer.eps)
+                elif norm.kind == "layer" and train_ops.usable(x, s):
+                    x = train_ops.skip_layer_norm(x, s)
                 else:
                     x = norm(x + s)
             return x

@@ -189,6 +189,49 @@ def skip_instance_norm(x: Tensor, s: Tensor, weight: Tensor, bias: Tensor, eps: 
     return _SkipInstanceNorm.apply(x, s, weight, bias, eps)
 
 
+LAYER_NORM_EPS = 1e-5  # nn/ops.py:50: a literal in the reference's formula
+
+
+def _lnorm_forward(xc: Tensor, sc: Tensor, eps: float = LAYER_NORM_EPS):
+    """(out, y = x + s, stats [B,2] = (mean, 1 / sqrt(var + eps))) of the reference's "layer" normalisation: ONE mean and
+    ONE unbiased variance over all N x 128 values of an instance, no affine (nn/ops.py:48-51)."""
+    b, n, _ = xc.shape
+    y, out = torch.empty_like(xc), torch.empty_like(xc)
+    stats = torch.empty((b, 2), dtype=torch.float32, device=xc.device)
+    st = _k("rl4co_skip_lnorm_fwd", xc.dtype)(xc.data_ptr(), sc.data_ptr(), float(eps), b, n, y.data_ptr(), out.data_ptr(),
+                                              stats.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.check(st, "rl4co_skip_lnorm_fwd")
+    return out, y, stats
+
+
+def _lnorm_backward(dout: Tensor, y: Tensor, stats: Tensor) -> Tensor:
+    b, n, _ = y.shape
+    d = dout.to(y.dtype).contiguous()
+    dy = torch.empty_like(y)
+    st = _k("rl4co_skip_lnorm_bwd", y.dtype)(d.data_ptr(), y.data_ptr(), stats.data_ptr(), b, n, dy.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream)
+    _lib.check(st, "rl4co_skip_lnorm_bwd")
+    return dy
+
+
+class _SkipLayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, s: Tensor):
+        out, y, stats = _lnorm_forward(x.contiguous(), s.contiguous())
+        ctx.save_for_backward(y, stats)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        dy = _lnorm_backward(dout, *ctx.saved_tensors)
+        return dy, dy
+
+
+def skip_layer_norm(x: Tensor, s: Tensor) -> Tensor:
+    """``Normalization("layer")(x + s)`` on 16-bit [B, N <= 128, 128] activations, forward and backward on csrc/am_train_ops.hip."""
+    return _SkipLayerNorm.apply(x, s)
+
+
 # ---------------------------------------------------------------------------------------------------
 # nn.Linear over the token rows on the tall-skinny MFMA kernel (csrc/am_train_ops.hip)
 # ---------------------------------------------------------------------------------------------------
@@ -415,6 +458,9 @@ def attention_flash(qkv: Tensor) -> Tensor:
 # (12 passes of 315 MB per POMO step at 4096 x 100 nodes).
 # ---------------------------------------------------------------------------------------------------
 def _norm_forward(kind: str, xc: Tensor, sc: Tensor, w32: Tensor, b32: Tensor, eps: float):
+    if kind == "layer":  # no affine; the statistics travel in the `mean` slot as [B, 2] = (mean, rstd)
+        out, y, stats = _lnorm_forward(xc, sc, eps)
+        return out, y, stats, None, None
     if kind == "instance":
         out, y, mean, rstd = _inorm_forward(xc, sc, w32, b32, eps)
         return out, y, mean, rstd, None
@@ -422,6 +468,8 @@ def _norm_forward(kind: str, xc: Tensor, sc: Tensor, w32: Tensor, b32: Tensor, e
 
 
 def _norm_backward(kind: str, dout: Tensor, y: Tensor, w32: Tensor, mean: Tensor, rstd: Tensor):
+    if kind == "layer":
+        return _lnorm_backward(dout, y, mean), None, None
     return (_inorm_backward if kind == "instance" else _bnorm_backward)(dout, y, w32, mean, rstd)
 
 
@@ -429,8 +477,8 @@ def _h16(w: Tensor, dtype: torch.dtype) -> Tensor:
     return w.detach().to(dtype).contiguous()
 
 
-def _f32(w: Tensor) -> Tensor:
-    return w.detach().float().contiguous()
+def _f32(w: Tensor | None) -> Tensor | None:
+    return None if w is None else w.detach().float().contiguous()
 
 
 def _attention_block_bwd(kind, dout, x2, wqkv16, wo16, qkv, lse, att, y, g32, mean, rstd, arena=None, layer=0, wt=None):
@@ -500,7 +548,7 @@ class _AttentionBlock(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, *_unused):
         dx, *grads = _attention_block_bwd(ctx.kind, dout, *ctx.saved_tensors)
-        return (dx, *(g.to(ctx.pdt) for g in grads), None, None)
+        return (dx, *(None if g is None else g.to(ctx.pdt) for g in grads), None, None)
 
 
 class _MLPBlock(torch.autograd.Function):
@@ -523,7 +571,7 @@ class _MLPBlock(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, *_unused):
         dx, *grads = _mlp_block_bwd(ctx.kind, dout, *ctx.saved_tensors)
-        return (dx, *(g.to(ctx.pdt) for g in grads), None, None)
+        return (dx, *(None if g is None else g.to(ctx.pdt) for g in grads), None, None)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -653,13 +701,15 @@ def encoder_stack(x: Tensor, layers) -> Tensor:
 
 
 def _block_norm_args(norm_module):
+    if norm_module.kind == "layer":  # no parameters (nn/ops.py:48-51)
+        return None, None, LAYER_NORM_EPS
     nz = norm_module.normalizer
     return nz.weight, nz.bias, nz.eps
 
 
 def block_usable(x: Tensor, kind: str, *weights: Tensor) -> bool:
     """bf16 [B,N,128] rows whose every kernel (GEMMs, attention, skip + norm) is served: one autograd node per sub-block."""
-    if kind not in ("instance", "batch") or not linear_usable(x, *weights) or x.dim() != 3 or x.shape[-1] != EMBED_DIM:
+    if kind not in ("instance", "batch", "layer") or not linear_usable(x, *weights) or x.dim() != 3 or x.shape[-1] != EMBED_DIM:
         return False
     if x.shape[1] > _lib.lib().rl4co_attn_max_nodes():
         return False

@@ -265,6 +265,34 @@ def _vs_golden(K, g, actions, logps, t, td0, max_flips):
     return flips, reward
 
 
+def _flip_regret(K, g, td0, h, actions, fold=True, dtype=torch.float32):
+    """How far from a tie each flipped greedy trajectory is: the kernel, teacher-forced along the REFERENCE's tours
+    (mode "evaluate", all log-probabilities kept), at the first step where its own rollout left the reference's —
+    both rollouts share the state there, so ``max_j lp_j - lp[reference's choice]`` is the margin by which the kernel's
+    arithmetic prefers its own pick. A flip is legitimate only as a near-tie: the margin sits at fp32 re-association
+    level (utils/decoding.py:387-397 takes the arg-max of fp32 log-probabilities; no operation order is specified)."""
+    ref = g.actions
+    rows = (actions[:, : ref.shape[1]] != ref).any(1).nonzero().flatten()
+    if rows.numel() == 0:
+        return torch.zeros(0)
+    cache = fold_cache(g.policy, g.env_name, h, dtype, device="cuda", fold=fold)
+    st = rollout_state(g.env_name, td0, device="cuda")
+    b, n = st["action_mask"].shape
+    t = ref.shape[1]
+    forced = ref.cuda().contiguous()
+    out_a = torch.zeros(b, t, dtype=torch.int64, device="cuda")
+    lps = torch.zeros(b, t, device="cuda")
+    all_lp = torch.zeros(b, t, n, device="cuda")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    K.am_decode(cache, st, mode="evaluate", max_steps=t, actions=out_a, logps=lps, err=err, forced_actions=forced,
+                all_logps=all_lp, variant="auto" if fold else "stream")
+    torch.cuda.synchronize()
+    assert int(err.item()) == 0 and torch.equal(out_a.cpu(), ref)
+    first = (actions[rows, : t] == ref[rows]).long().cumprod(1).sum(1).clamp(max=t - 1)
+    at = all_lp.cpu()[rows, first]
+    return at.max(-1).values - at.gather(-1, ref[rows, first][:, None]).squeeze(-1)
+
+
 @pytest.mark.parametrize("name", [c for c in SMALL if "greedy" in manifest()[c]["decode_type"]])
 def test_greedy_vs_reference_golden(K, name):
     g = GoldenCase(name)
@@ -319,13 +347,17 @@ def test_full_size_tsp100_b4096_vs_reference_golden(K):
     (oneDNN vs rocBLAS), not the fold."""
     g = GoldenCase("c2_tsp100_b4096_greedy")
     td0, h = _encode(g)
-    flips = {}
+    flips, worst = {}, {}
     for fold in (True, False):
         a, l, st, n_steps, t, err = _run(K, "hip", g, td0, h, "greedy", fold=fold)
         assert err == 0 and t == 100 and bool((n_steps == 100).all())
         assert not bool(st["action_mask"].any())
         # fp32 near-ties between the kernel's operation order and ATen's: measured 12 (fold on) / 15 (fold off), bound 0.5 %
         flips[fold], reward = _vs_golden(K, g, a, l, t, td0, max_flips=20)
+        # ... and every one of them IS a near-tie: the kernel's own margin over the reference's choice, at the shared state
+        regret = _flip_regret(K, g, td0, h, a, fold=fold)
+        assert regret.numel() == flips[fold] and (regret.numel() == 0 or float(regret.max()) <= 1e-4), regret
+        worst[fold] = float(regret.max()) if regret.numel() else 0.0
         # size-independent properties: every row a permutation; mean tour length ~ the reference's
         assert torch.equal(a.sort(1).values, torch.arange(100).expand_as(a))
         assert abs(float(reward.mean() - g.reward.mean())) <= 1e-4 * abs(float(g.reward.mean()))
@@ -335,7 +367,8 @@ def test_full_size_tsp100_b4096_vs_reference_golden(K):
             assert torch.equal(c[0], a) and torch.equal(c[1].view(torch.int32), l.view(torch.int32))
     print(f"fp32 cache, 4096 greedy TSP-100 tours vs the reference: {flips[True]} differ with the folded cache, "
           f"{flips[False]} in the reference's association (fold off)")
-    _record("c2_fp32_flips", {"fold_on": flips[True], "fold_off": flips[False], "of": 4096})
+    _record("c2_fp32_flips", {"fold_on": flips[True], "fold_off": flips[False], "of": 4096,
+                              "flip_margin_max": {"fold_on": worst[True], "fold_off": worst[False]}})
 
 
 @pytest.mark.parametrize("variant", ["stream", "lds"])
@@ -427,7 +460,9 @@ def test_full_size_cvrp100_b4096_vs_reference_golden(K):
     a, l, st, n_steps, t, err = _run(K, "hip", g, td0, h, "greedy")
     assert err == 0 and bool(st["done"].all())
     flips, reward = _vs_golden(K, g, a, l, t, td0, max_flips=32)  # measured 20 (r02)
-    _record("c3_fp32_flips", {"fold_on": flips, "of": 4096})
+    regret = _flip_regret(K, g, td0, h, a)  # every flip a near-tie of the kernel's own arithmetic at the shared state
+    assert regret.numel() == flips and (flips == 0 or float(regret.max()) <= 1e-4), regret
+    _record("c3_fp32_flips", {"fold_on": flips, "of": 4096, "flip_margin_max": float(regret.max()) if flips else 0.0})
     print(f"CVRP-100 x 4096, fp32 planes: {flips} greedy trajectories differ from the reference")
     err_w = K.new_error_word("cuda")
     K.cvrp_check_solution(a[:, :t].contiguous().cuda(), td0["demand"].cuda(), td0["vehicle_capacity"].reshape(-1).cuda(), err_w)

@@ -108,13 +108,13 @@ def test_graphed_rollout_survives_an_eager_rollout_after_a_weight_update():
 
 
 def test_graphed_rollout_leaves_the_packed_encoder_alone_when_the_fused_path_is_not_taken():
-    """fp32 regime (torch encoder inside the graph): no packed encoder is built; weight updates are read live."""
+    """Torch encoder inside the graph (fused_encoder=False): no packed encoder is built; weight updates are read live."""
     from rl4co_amd.envs import get_env
     from rl4co_amd.graph import GraphedRollout
     from rl4co_amd.policy import AttentionModelPolicy
 
     torch.manual_seed(0)
-    pol = AttentionModelPolicy("tsp", normalization="layer").cuda().eval()  # the fused encoder cannot pack a layer norm
+    pol = AttentionModelPolicy("tsp", normalization="layer", fused_encoder=False).cuda().eval()
     env = get_env("tsp", generator_params=dict(num_loc=20, device="cuda"), device="cuda")
     torch.manual_seed(1)
     data = env.generator(batch_size=[64])

@@ -125,3 +125,43 @@ def test_leg_dtypes_follow_the_leg_name_then_the_flags():
     assert b.leg_dtypes("c2_greedy_fp32", A) == ("f32", "f32")
     A.cache_dtype = "f32"
     assert b.leg_dtypes("c5_sampling", A) == ("f32", "bf16")
+
+
+def test_layer_norm_tables_carry_the_bias_in_front_of_the_norm():
+    """Normalization("layer") (nn/ops.py:48-51) has no parameters and ONE mean per instance, so the bias of the GEMM in front
+    of it does not cancel: the 16-bit kernel reads it from the shift slot (added before the statistics), the fp32 kernel adds
+    bo / b2 itself and gets (1, 0) tables; the kernel selector is 2."""
+    from rl4co_amd.encoder import PackedEncoder
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    torch.manual_seed(0)
+    pol = AttentionModelPolicy("tsp", normalization="layer", num_encoder_layers=2).eval()
+    with torch.no_grad():
+        for layer in pol.encoder.net.layers:
+            layer[0].module.out_proj.bias.normal_()
+            layer[2].module.lins[1].bias.normal_()
+    assert sum(p.numel() for l in pol.encoder.net.layers for p in l[1].parameters()) == 0
+    pe = PackedEncoder(pol)
+    t = pe.refresh(act_dtype=torch.bfloat16)
+    assert pe.norm_kind == 2
+    layers = list(pol.encoder.net.layers)
+    assert torch.equal(t["n1_shift"], torch.stack([l[0].module.out_proj.bias.detach() for l in layers]))
+    assert torch.equal(t["n2_shift"], torch.stack([l[2].module.lins[1].bias.detach() for l in layers]))
+    assert bool((t["n1_scale"] == 1).all()) and bool((t["n2_scale"] == 1).all())
+    t = pe.refresh(act_dtype=torch.float32)
+    assert pe.norm_kind == 2 and not bool(t["n1_shift"].any()) and not bool(t["n2_shift"].any())
+    assert torch.equal(t["bo"], torch.stack([l[0].module.out_proj.bias.detach() for l in layers]))
+    # the module's own forward is the reference's formula
+    x = torch.randn(3, 9, 128)
+    want = (x - x.mean((1, 2)).view(-1, 1, 1)) / torch.sqrt(x.var((1, 2)).view(-1, 1, 1) + 1e-05)
+    assert torch.equal(layers[0][1](x), want)
+
+
+def test_layer_norm_training_blocks_are_offered_to_the_kernels():
+    from rl4co_amd import train_ops
+
+    assert train_ops._block_norm_args(type("N", (), {"kind": "layer"})()) == (None, None, train_ops.LAYER_NORM_EPS)
+    assert train_ops._f32(None) is None
+    x = torch.zeros(2, 5, 128)
+    assert not train_ops.block_usable(x, "layer", torch.zeros(128, 128))  # CPU tensors: never
+    assert not train_ops.block_usable(x, "group", torch.zeros(128, 128))
