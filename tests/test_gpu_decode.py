@@ -356,7 +356,7 @@ def test_full_size_tsp100_b4096_vs_reference_golden(K):
         flips[fold], reward = _vs_golden(K, g, a, l, t, td0, max_flips=20)
         # ... and every one of them IS a near-tie: the kernel's own margin over the reference's choice, at the shared state
         regret = _flip_regret(K, g, td0, h, a, fold=fold)
-        assert regret.numel() == flips[fold] and (regret.numel() == 0 or float(regret.max()) <= 1e-4), regret
+        assert regret.numel() == flips[fold] and (regret.numel() == 0 or float(regret.max()) <= 1e-5), regret  # measured 6.6e-7
         worst[fold] = float(regret.max()) if regret.numel() else 0.0
         # size-independent properties: every row a permutation; mean tour length ~ the reference's
         assert torch.equal(a.sort(1).values, torch.arange(100).expand_as(a))
@@ -461,7 +461,7 @@ def test_full_size_cvrp100_b4096_vs_reference_golden(K):
     assert err == 0 and bool(st["done"].all())
     flips, reward = _vs_golden(K, g, a, l, t, td0, max_flips=32)  # measured 20 (r02)
     regret = _flip_regret(K, g, td0, h, a)  # every flip a near-tie of the kernel's own arithmetic at the shared state
-    assert regret.numel() == flips and (flips == 0 or float(regret.max()) <= 1e-4), regret
+    assert regret.numel() == flips and (flips == 0 or float(regret.max()) <= 1e-5), regret  # measured 4.8e-7
     _record("c3_fp32_flips", {"fold_on": flips, "of": 4096, "flip_margin_max": float(regret.max()) if flips else 0.0})
     print(f"CVRP-100 x 4096, fp32 planes: {flips} greedy trajectories differ from the reference")
     err_w = K.new_error_word("cuda")
