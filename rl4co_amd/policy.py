@@ -11,7 +11,7 @@ What runs where
     kernels up to 128 nodes (``csrc/am_encoder.hip`` 16-bit, ``csrc/am_encoder_f32.hip`` fp32 = the bit-identical
     configuration), token-tile launches beyond; training: one fused forward launch for an instance-norm stack and per-op
     backward kernels behind autograd (``train_ops.py``). The torch modules compute only where no kernel serves the call
-    (layer norm, train-mode batch norm beyond the kernels' shapes, ``fused_encoder=False``), announced by one RuntimeWarning.
+    (training beyond 128 nodes, train-mode batch norm beyond the kernels' shapes, ``fused_encoder=False``), announced by one RuntimeWarning.
   * the whole ``while not done`` loop (base.py:226-238) — context, pointer attention, logits
     processing, selection, env transition: ONE launch of ``rl4co_am_decode`` (no grad).
   * reward: ``env.get_reward`` -> ``rl4co_tour_length_f32``.
@@ -723,9 +723,8 @@ class AttentionModelPolicy(nn.Module):
                     n_nodes = td["action_mask"].shape[-1]
                     _l.warn_fallback(f"infer-encoder/{self._encoder_regime()}/{n_nodes > 128}/{self.fused_encoder}/{self.fold}",
                                      f"inference encoder for {n_nodes} nodes under autocast({self._encoder_regime()}) runs on torch: "
-                                     "the fused MFMA encoder serves bf16 / fp16 up to 128 nodes with batch / instance norm, the folded "
-                                     "cache and planes in fp32 or the activations' type; the token-parallel kernels serve batch norm "
-                                     "beyond that")
+                                     "the fused MFMA encoder (up to 128 nodes) and the token-tile kernels (beyond) serve bf16 / fp16 with the "
+                                     "folded cache and planes in fp32 or the activations' type")
                 hidden, init_embeds = self._encode(td)
         if isinstance(env, str) or env is None:
             env = get_env(self.env_name if env is None else env)
