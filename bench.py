@@ -86,6 +86,8 @@ LEGS = {
     # encoder on v_mfma_f32_16x16x4_f32 (csrc/am_encoder_f32.hip), fp32 planes, fp32 decode arithmetic; its `parity_tours` =
     # reference tours reproduced on the trained weights at the full size (tests/golden/trained)
     "c2_greedy_fp32": ("tsp", 100, 4096, "greedy", 1),
+    # (not in the default run) configs[4] in the reference's default precision: fp16 planes through the WIDE decode variant
+    "c5_sampling_fp16": ("cvrp", 500, 1024, "sampling", 4),
 }
 DEFAULT_LEGS = "c2_greedy,c2_sampling,c3_greedy,c5_sampling,c4_train,c2_greedy_fp16,c2_greedy_fp32"
 

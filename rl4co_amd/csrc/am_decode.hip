@@ -645,8 +645,11 @@ __host__ __device__ inline int wide_scratch_bytes(int N) {
 }
 __host__ __device__ inline int lds_variant_bytes(int N) { return 3 * N * kD * 2 + wide_scratch_bytes(N); }
 
+// Four workgroups per CU (<= 128 registers): CVRP-500 x 1024 is 1024 workgroups = exactly four per CU, ONE round. The half
+// (fp16) builds took 130 - 138 registers under a bound of two — three per CU, so a quarter of the trajectories waited for
+// a second round: 25.3 ms per C5 step against 19.9 with bf16 planes (r04).
 template <int ENV, bool RESIDENT, class C = CacheBF16>  // C: CacheBF16 or CacheF16 (same 16-byte lanes, different convert)
-__global__ void __launch_bounds__(64 * kLdsWaves, 2) am_decode_wide_kernel(const rl4co_am_decode_args a) {
+__global__ void __launch_bounds__(64 * kLdsWaves, 4) am_decode_wide_kernel(const rl4co_am_decode_args a) {
   constexpr int EPL = 8, LPR = 16, LPH = 2;
   constexpr int U = 4;  // list entries per wave handled per unrolled block
   extern __shared__ __align__(16) unsigned char smem[];
