@@ -148,6 +148,11 @@ __device__ inline int build_list(const rl4co_am_decode_args& a, const uint8_t* m
   return F;
 }
 
+template <int ENV>
+__device__ inline int commit_and_step(const rl4co_am_decode_args& a, TrajState& st, float* lg, const uint16_t* fl, int F,
+                                      uint8_t* mk, uint8_t* vis, const float* dem, float cap, int r, int t, int N, int lane,
+                                      const float* oplocs, const float* opmax, const float* twdur, int bc);
+
 // One wave: raw logits lg[0..F) (list order) -> log-probs, selection, outputs, environment
 // transition on the LDS-resident mask. Returns the action; st is updated (incl. done).
 template <int ENV>
@@ -205,6 +210,16 @@ __device__ inline int finalize_and_step(const rl4co_am_decode_args& a, TrajState
   rl4co::bfly_argmax(best, bc);
   if (a.entropy) st.ent_acc = st.ent_acc - rl4co::bfly_sum<1, 64>(ent);
   wave_lds_sync();
+  return commit_and_step<ENV>(a, st, lg, fl, F, mk, vis, dem, cap, r, t, N, lane, oplocs, opmax, twdur, bc);
+}
+
+// One wave: lg[0..F) hold the step's log-probs (list order) and `bc` the selected list position. Evaluate-mode lookup,
+// outputs, environment transition on the LDS-resident mask. Returns the action; st is updated (incl. done).
+template <int ENV>
+__device__ inline int commit_and_step(const rl4co_am_decode_args& a, TrajState& st, float* lg, const uint16_t* fl, int F,
+                                      uint8_t* mk, uint8_t* vis, const float* dem, float cap, int r, int t, int N, int lane,
+                                      const float* oplocs, const float* opmax, const float* twdur, int bc) {
+  const int64_t tcol = (int64_t)a.t0 + t;
   int bi;
   float logp;
   if (a.mode == RL4CO_DECODE_EVALUATE) {
@@ -638,6 +653,93 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
 constexpr int kLdsWaves = 4;
 constexpr int kLdsGroups = 16;
 
+// The first half of finalize_and_step for the four-wave kernels, bit for bit: the ELEMENTWISE work of a step's N logits
+// — clip, the softmax exponentials, log-probs, the sampling keys with their Philox draws: ~200 VALU operations per node —
+// is dealt over all 256 threads instead of leaving three waves idle behind wave 0, while every order-dependent reduction
+// (the lane-strided sum of the exponentials and its butterfly, the entropy) is still taken by wave 0 in finalize_and_step's
+// own order from the staged terms; maxima and the (key, lowest position) arg-max are exact in any order. `xs`: 2 nw + 16
+// floats of scratch (the score block, dead between B3 and the next step). Returns the selected list position (wave 0).
+template <int ENV>
+__device__ inline int wide_scores(const rl4co_am_decode_args& a, TrajState& st, float* lg, const uint16_t* fl, int F,
+                                  const uint8_t* mk, float* xs, int nw, int r, int t, int N, int tid) {
+  constexpr int T = 64 * kLdsWaves;
+  const int w = tid >> 6, lane = tid & 63;
+  float* ex = xs;             // [nw] softmax exponentials, then sampling keys
+  float* xw = xs + 2 * nw;    // [4] wave maxima | [4] NaN flags | [1] log-sum-exp
+  bool nan_seen = false;
+  float zmax = kNegInf;
+  for (int c = tid; c < F; c += T) {
+    float z = lg[c] / kSqrtD;
+    if (z != z) nan_seen = true;  // attention.py:295-296
+    if (a.tanh_clipping > 0.0f) z = rl4co_tanhf(z) * a.tanh_clipping;
+    if (a.mask_logits && mk[fl[c]] == 0) z = kNegInf;
+    if (a.temperature != 1.0f) z = z / a.temperature;  // x / 1.0f == x exactly
+    lg[c] = z;
+    zmax = fmaxf(zmax, z);
+  }
+  zmax = rl4co::bfly_max<1, 64>(zmax);
+  const bool wave_nan = __any(nan_seen);
+  if (lane == 0) {
+    xw[w] = zmax;
+    xw[4 + w] = wave_nan ? 1.0f : 0.0f;
+  }
+  __syncthreads();
+  zmax = fmaxf(fmaxf(xw[0], xw[1]), fmaxf(xw[2], xw[3]));
+  if ((xw[4] + xw[5]) + (xw[6] + xw[7]) != 0.0f) st.errbits |= RL4CO_EBIT_NAN_LOGIT;
+  for (int c = tid; c < F; c += T) ex[c] = rl4co_expf(lg[c] - zmax);
+  __syncthreads();
+  if (w == 0) {
+    float zsum = 0.0f;
+    for (int c = lane; c < F; c += 64) zsum = zsum + ex[c];
+    zsum = rl4co::bfly_sum<1, 64>(zsum);
+    if (lane == 0) xw[8] = rl4co_logf(zsum);
+  }
+  __syncthreads();
+  const float lse = xw[8];
+  const int64_t tcol = (int64_t)a.t0 + t;
+  float* alp = a.all_logps ? a.all_logps + ((int64_t)r * a.out_stride + tcol) * N : nullptr;
+  if (alp && F < N) {  // nodes outside the list have log-prob -inf
+    for (int j = tid; j < N; j += T)
+      if (mk[j] == 0) alp[j] = kNegInf;
+  }
+  for (int c = tid; c < F; c += T) {
+    const int j = fl[c];
+    const float lp = (lg[c] - zmax) - lse;
+    lg[c] = lp;
+    float key = lp;
+    if (a.mode == RL4CO_DECODE_SAMPLE) {
+      const float nz = a.exp_noise
+                           ? a.exp_noise[((int64_t)t * a.B + r) * N + j]
+                           : rl4co_exp1_noise(a.philox_seed ^ (a.philox_seed_dev ? *a.philox_seed_dev : 0ull),
+                                              a.philox_offset + (uint64_t)tcol, (uint32_t)r,
+                                              (uint32_t)j);
+      key = rl4co_expf(lp) / nz;  // multinomial(p,1) == argmax(p / Exp(1))
+    }
+    ex[c] = key;
+    if (alp) alp[j] = lp;
+  }
+  __syncthreads();
+  int bc = 0x7fffffff;
+  if (w == 0) {
+    float best = kNegInf, ent = 0.0f;
+    for (int c = lane; c < F; c += 64) {
+      const float key = ex[c];
+      if (bc == 0x7fffffff || key > best) {  // strict '>' keeps the lowest index on ties
+        best = key;
+        bc = c;
+      }
+      if (a.entropy) {
+        const float lp = lg[c];
+        if (lp > kNegInf) ent = fmaf(rl4co_expf(lp), lp, ent);
+      }
+    }
+    rl4co::bfly_argmax(best, bc);
+    if (a.entropy) st.ent_acc = st.ent_acc - rl4co::bfly_sum<1, 64>(ent);
+    wave_lds_sync();
+  }
+  return bc;
+}
+
 __host__ __device__ inline int lds_variant_sc_rows(int N) { return N < 80 ? 80 : N; }
 __host__ __device__ inline int wide_scratch_bytes(int N) {
   const int nw = (N + 3) & ~3;
@@ -887,11 +989,13 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 4) am_decode_wide_kernel(const
         if (c < F && li == 0) lg[c] = acc;
       }
     }
-    __syncthreads();  // B3: all logits visible to wave 0
+    __syncthreads();  // B3: all logits visible
 
-    // ---- wave 0: log-softmax, selection, environment transition, next step's list ------------------
+    // ---- all waves: clip, exponentials, log-probs, sampling keys; wave 0: the reductions, then the environment
+    // transition and the next step's list -----------------------------------------------------------------
+    const int bc = wide_scores<ENV>(a, st, lg, fl, F, mk, sc, nw, r, t, N, tid);
     if (w == 0) {
-      finalize_and_step<ENV>(a, st, lg, fl, F, mk, vis, dem, cap, r, t, N, lane, oplocs, opmax, twdur);
+      commit_and_step<ENV>(a, st, lg, fl, F, mk, vis, dem, cap, r, t, N, lane, oplocs, opmax, twdur, bc);
       const int Fn = build_list(a, mk, fl, N, lane);
       if (lane == 0) {  // the scalars the next query is built from, for the other three waves
         shi[0] = st.cur;
