@@ -420,6 +420,16 @@ typedef struct rl4co_am_encoder_args {
 int rl4co_am_encoder(const rl4co_am_encoder_args* args, void* stream);
 int rl4co_am_encoder_max_nodes(void);
 
+/* a12 (training): the INPUT gradient of SkipConnection(MLP 128 -> 512 -> 128, ReLU) in one launch
+ *   rl4co/models/nn/mlp.py:52-61 under rl4co/models/nn/ops.py:9-15 (autograd's backward of x + lin2(relu(lin1(x))))
+ *   dh[M,512] = (dy . W2) * [h > 0]  (written once: rl4co_wgrad_* reads it for dW1 / db1)      dx[M,128] = dh . W1 + dy
+ * dy [M,128], h [M,512] (the forward's hidden activations), dh, dx: 16-bit elements of `dtype` (RL4CO_DT_BF16 / _F16), fp32
+ * accumulation on the matrix cores; w2t_packed = W2^T ([512,128]) and w1t_packed = W1^T ([128,512]) in the encoder's
+ * fragment order (rl4co_am_encoder_args: "[out/32 tiles][in/16 ksteps][64 lanes][8]"). The 512-wide gradient goes
+ * through LDS in four chunks: 1.05 GB of traffic per layer at M = 409 600 where two GEMM launches moved 1.58. */
+int rl4co_mlp_input_grad(const void* dy, const void* h, int64_t M, const void* w2t_packed, const void* w1t_packed, int dtype,
+                         void* dh, void* dx, void* stream);
+
 /* The TRAINING forward of an instance-norm encoder stack (POMO: zoo/pomo/model.py:59-63; nn/graph/attnnet.py:16-106) in ONE
  * launch — the fused kernel's layer body fed with the init embedding, one workgroup per instance, N <= 128 — writing, per
  * layer, every tensor the backward kernels (rl4co_linear_* input gradients, rl4co_wgrad_*, rl4co_attn_bwd_*,

@@ -111,6 +111,7 @@ SYMBOLS = {
     "rl4co_skip_lnorm_fwd_bf16": (C.c_int, [_vp, _vp, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
     "rl4co_skip_lnorm_bwd_bf16": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_skip_inorm_max_nodes": (C.c_int, []),
+    "rl4co_mlp_input_grad": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, C.c_int, _vp, _vp, _vp]),
     "rl4co_skip_bnorm_stats_bf16": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp]),
     "rl4co_bnorm_apply_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp]),
     "rl4co_skip_bnorm_eval_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp]),

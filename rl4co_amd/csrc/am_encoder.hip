@@ -1167,6 +1167,76 @@ __global__ void __launch_bounds__(kThreads) tok16_norm_apply_kernel(const E* __r
   }
 }
 
+// ---- training: the input gradient of x + MLP(x) on one tile of 128 token rows (nn/mlp.py:52-61 under nn/ops.py:9-15) ----
+//   dh = (dy . W2) * [h > 0]   [M,512]  (written ONCE: the two weight-gradient launches read it)
+//   dx = dh . W1 + dy          [M,128]
+// The per-op path ran these as two GEMM launches with dh written (420 MB at 4096 x 100 rows) and read back; here the
+// 512-wide gradient goes through LDS in four chunks exactly as the hidden does in tok16_mlp_kernel: per layer 1.05 GB of
+// traffic instead of 1.58. Weights: W2^T ([512,128]) and W1^T ([128,512]) in pack_weight's fragment order.
+template <typename E>
+__device__ inline void rows_load_strided(E* xs, const E* src, int64_t row_stride, int valid, int tid) {
+  for (int i = tid; i < kTok * 16; i += kThreads) {
+    const int row = i >> 4, c16 = i & 15;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < valid) v = *reinterpret_cast<const uint4*>(src + (int64_t)row * row_stride + 8 * c16);
+    *reinterpret_cast<uint4*>(xs + row * kRS + 8 * c16) = v;
+  }
+}
+
+template <typename E>
+__global__ void __launch_bounds__(kThreads, 2) tok16_mlp_bwd_kernel(const E* __restrict__ dy, const E* __restrict__ h, int M,
+                                                                    const E* __restrict__ w2t, const E* __restrict__ w1t,
+                                                                    E* __restrict__ dh, E* __restrict__ dx) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  E* xs = reinterpret_cast<E*>(smem);  // dy tile
+  E* ys = xs + kTok * kRS;             // h chunk (the ReLU mask), then the dh chunk
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  const int r0 = kTok * blockIdx.x, valid = min(kTok, M - r0);
+  vec8<E> wf[8];
+  load_wfrags(wf, w2t, 8, w, 0, lane);
+  rows_load_strided(xs, dy + (int64_t)r0 * kD, kD, valid, tid);
+  f32x16 acc[kTokT];
+#pragma unroll
+  for (int tt = 0; tt < kTokT; ++tt) acc[tt] = zero16();
+#pragma unroll 1
+  for (int c = 0; c < 4; ++c) {
+    if (c > 0) __syncthreads();  // every wave is done reading the previous dh chunk
+    rows_load_strided(ys, h + (int64_t)r0 * kFF + kD * c, kFF, valid, tid);
+    __syncthreads();
+    f32x16 g[kTokT];
+    gemm_t<kTokT>(g, wf, xs, lane, w1t, 32, w, 8 * c, zero16());  // next: dx += dh chunk . W1 (k-steps 8 c ..)
+    // the ReLU mask from this wave's own 32 hidden columns of the staged h chunk; dh goes back over them
+#pragma unroll
+    for (int tt = 0; tt < kTokT; ++tt) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const vec4<E> hv = *reinterpret_cast<const vec4<E>*>(ys + (32 * tt + l31) * kRS + 32 * w + 8 * q + 4 * hi);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[tt][4 * q + e] = ((float)hv[e] > 0.0f) ? g[tt][4 * q + e] : 0.0f;
+      }
+    }
+    store_t<kTokT>(ys, g, 32 * w, lane);
+    __syncthreads();
+    for (int i = tid; i < valid * 16; i += kThreads)
+      *reinterpret_cast<uint4*>(dh + (int64_t)(r0 + (i >> 4)) * kFF + kD * c + 8 * (i & 15)) =
+          *reinterpret_cast<const uint4*>(ys + (i >> 4) * kRS + 8 * (i & 15));
+    gemm_t<kTokT, true, false>(acc, wf, ys, lane, c < 3 ? w2t : static_cast<const E*>(nullptr), 8, 4 * (c + 1) + w, 0, acc[0]);
+  }
+  // + dy (the skip connection's gradient), this wave's 32 columns of the dy tile, then out through the same tile
+#pragma unroll
+  for (int tt = 0; tt < kTokT; ++tt) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const vec4<E> x = *reinterpret_cast<const vec4<E>*>(xs + (32 * tt + l31) * kRS + 32 * w + 8 * q + 4 * hi);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[tt][4 * q + e] += (float)x[e];
+    }
+  }
+  store_t<kTokT>(xs, acc, 32 * w, lane);
+  __syncthreads();
+  tok_store(xs, dx + (int64_t)r0 * kD, kD, valid, tid);
+}
+
 // cache planes (16-bit or fp32) and fp32 context tables of one token tile, as the fused kernel's fold writes them
 template <typename E>
 __global__ void __launch_bounds__(kThreads, 2) tok16_fold_kernel(const E* __restrict__ x, const rl4co_am_encoder_args a) {
@@ -1393,6 +1463,27 @@ extern "C" int rl4co_am_encoder_train_fwd(const rl4co_am_encoder_args* args, con
   RL4CO_REQUIRE(save->x0 && save->out && save->qkv && save->att && save->y1 && save->x1 && save->h && save->y2 && save->lse && save->stats);
   hipStream_t s = rl4co::as_stream(stream);
   return a.act_dtype == RL4CO_DT_F16 ? launch_train_elem<_Float16>(a, *save, s) : launch_train_elem<__bf16>(a, *save, s);
+}
+
+template <typename E>
+int launch_mlp_bwd(const void* dy, const void* h, int64_t M, const void* w2t, const void* w1t, void* dh, void* dx, hipStream_t s) {
+  const int lds = 2 * kTok * kRS * (int)sizeof(E);
+  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tok16_mlp_bwd_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL(tok16_mlp_bwd_kernel<E>, dim3((unsigned)((M + kTok - 1) / kTok)), dim3(kThreads), lds, s, static_cast<const E*>(dy),
+                     static_cast<const E*>(h), (int)M, static_cast<const E*>(w2t), static_cast<const E*>(w1t), static_cast<E*>(dh),
+                     static_cast<E*>(dx));
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
+extern "C" int rl4co_mlp_input_grad(const void* dy, const void* h, int64_t M, const void* w2t_packed, const void* w1t_packed, int dtype,
+                                    void* dh, void* dx, void* stream) {
+  RL4CO_REQUIRE(dy && h && w2t_packed && w1t_packed && dh && dx);
+  RL4CO_REQUIRE(M > 0 && M < (int64_t)1 << 31);
+  RL4CO_REQUIRE(dtype == RL4CO_DT_BF16 || dtype == RL4CO_DT_F16);
+  hipStream_t s = rl4co::as_stream(stream);
+  return dtype == RL4CO_DT_F16 ? launch_mlp_bwd<_Float16>(dy, h, M, w2t_packed, w1t_packed, dh, dx, s)
+                               : launch_mlp_bwd<__bf16>(dy, h, M, w2t_packed, w1t_packed, dh, dx, s);
 }
 
 extern "C" int rl4co_am_encoder_max_nodes(void) { return 128; }

@@ -505,8 +505,22 @@ def _attention_block_bwd(kind, dout, x2, wqkv16, wo16, qkv, lse, att, y, g32, me
     return dx.view(b, n, d), hwqkv[0], hwqkv[1], hwo[0], hwo[1], hnorm[0], hnorm[1]
 
 
-def _mlp_block_bwd(kind, dout, x2, h, w1_16, w2_16, y, g32, mean, rstd, arena=None, layer=0, wt=None):
-    """Backward of Normalization(x + MLP(x)): (dx, dW1 + db1, dW2 + db2, dgamma + dbeta); ``arena`` / ``wt`` (W1^T, W2^T) as above."""
+def mlp_input_grad(d2: Tensor, h2: Tensor, w1t_packed: Tensor, w2t_packed: Tensor) -> tuple[Tensor, Tensor]:
+    """(dh [M,512], dx [M,128]) = ((dy W2) * [h > 0], dh W1 + dy) in ONE launch (``rl4co_mlp_input_grad``): the 512-wide
+    gradient goes through LDS instead of being written by one GEMM launch and read back by the next. ``w1t_packed`` /
+    ``w2t_packed``: W1^T [128,512] / W2^T [512,128] in the encoder's fragment order (``_pack_stack``)."""
+    m = d2.shape[0]
+    dh = torch.empty((m, 4 * EMBED_DIM), dtype=d2.dtype, device=d2.device)
+    dx = torch.empty((m, EMBED_DIM), dtype=d2.dtype, device=d2.device)
+    st = _lib.lib().rl4co_mlp_input_grad(d2.data_ptr(), h2.data_ptr(), m, w2t_packed.data_ptr(), w1t_packed.data_ptr(),
+                                         _lib.dtype_id(d2.dtype), dh.data_ptr(), dx.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    _lib.check(st, "rl4co_mlp_input_grad")
+    return dh, dx
+
+
+def _mlp_block_bwd(kind, dout, x2, h, w1_16, w2_16, y, g32, mean, rstd, arena=None, layer=0, wt=None, wp=None):
+    """Backward of Normalization(x + MLP(x)): (dx, dW1 + db1, dW2 + db2, dgamma + dbeta); ``arena`` / ``wt`` (W1^T, W2^T) as above;
+    ``wp``: (W1^T, W2^T) in fragment order — both input-gradient GEMMs then run as one launch (``mlp_input_grad``)."""
     b, n, d = y.shape
     if arena is not None:
         dy, hnorm, _ = _inorm_backward(dout, y, g32, mean, rstd, arena, ("norm2", layer))
@@ -515,9 +529,13 @@ def _mlp_block_bwd(kind, dout, x2, h, w1_16, w2_16, y, g32, mean, rstd, arena=No
         hnorm = (dgamma, dbeta)
     d2 = dy.view(-1, d)
     h2 = h.reshape(-1, h.shape[-1])
-    dh = _gemm(d2, w2_16.t().contiguous() if wt is None else wt[1], mask=h2)  # (d W2) * [h > 0]
-    hw2 = _wgrad(d2, h2, with_bias=True, arena=arena, key=("w2", layer))
-    dx = _gemm(dh, w1_16.t().contiguous() if wt is None else wt[0], residual=d2)
+    if wp is not None and h2.shape[-1] == 4 * EMBED_DIM and d2.is_contiguous() and h2.is_contiguous():
+        dh, dx = mlp_input_grad(d2, h2, wp[0], wp[1])
+        hw2 = _wgrad(d2, h2, with_bias=True, arena=arena, key=("w2", layer))
+    else:
+        dh = _gemm(d2, w2_16.t().contiguous() if wt is None else wt[1], mask=h2)  # (d W2) * [h > 0]
+        hw2 = _wgrad(d2, h2, with_bias=True, arena=arena, key=("w2", layer))
+        dx = _gemm(dh, w1_16.t().contiguous() if wt is None else wt[0], residual=d2)
     hw1 = _wgrad(dh, x2.reshape(-1, d), with_bias=True, arena=arena, key=("w1", layer))
     if arena is not None:
         return dx.view(b, n, d), hw1, hw2, hnorm
@@ -578,6 +596,7 @@ class _MLPBlock(torch.autograd.Function):
 # the whole encoder stack's FORWARD as one launch (instance norm: POMO, zoo/pomo/model.py:59-63), the per-op backward
 # kernels fed from what it saved (csrc/am_encoder.hip: am_encoder_kernel<.., TRAIN>, rl4co_am_encoder_train_fwd)
 # ---------------------------------------------------------------------------------------------------
+FUSED_MLP_INPUT_GRAD = True  # (False: the two GEMM launches — tools / tests compare the two)
 _STACK_PARAMS = 12  # per layer: Wqkv, bqkv, Wo, bo, gamma1, beta1, W1, b1, W2, b2, gamma2, beta2
 
 
@@ -647,11 +666,14 @@ class _FusedEncoderStack(torch.autograd.Function):
         arena = _GradArena(nl)
         # the four weight stacks transposed once for all layers (the input-gradient GEMMs read W^T rows)
         wqkv_t, wo_t, w1_t, w2_t = (w.transpose(1, 2).contiguous() for w in (wqkv16, wo16, w1_16, w2_16))
+        # ... and the MLP's two in fragment order: its input gradient is one launch per layer (mlp_input_grad)
+        w1t_p, w2t_p = (_pack_stack(w1_t), _pack_stack(w2_t)) if FUSED_MLP_INPUT_GRAD else (None, None)
         handles = []
         d = dout
         for l in reversed(range(nl)):
             d, hw1, hw2, hn2 = _mlp_block_bwd("instance", d, x1[l], h[l], w1_16[l], w2_16[l], y2[l], g2[l], stats[l, 2], stats[l, 3],
-                                              arena=arena, layer=l, wt=(w1_t[l], w2_t[l]))
+                                              arena=arena, layer=l, wt=(w1_t[l], w2_t[l]),
+                                              wp=None if w1t_p is None else (w1t_p[l], w2t_p[l]))
             x_in = x0c if l == 0 else out[l - 1]
             d, hwqkv, hwo, hn1 = _attention_block_bwd("instance", d, x_in, wqkv16[l], wo16[l], qkv[l], lse[l], att[l], y1[l], g1[l],
                                                       stats[l, 0], stats[l, 1], arena=arena, layer=l, wt=(wqkv_t[l], wo_t[l]))

@@ -274,3 +274,74 @@ def test_pomo_policy_evaluated_beyond_its_training_size_runs_on_the_kernels():
         assert torch.isfinite(out["reward"]).all()
         best.append(out["reward"].double().mean())
     assert abs(float(best[0] - best[1])) <= 0.03 * abs(float(best[0]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training: the MLP's input gradient as one launch (csrc/am_encoder.hip: tok16_mlp_bwd_kernel, rl4co_mlp_input_grad)
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("m", [4096 * 100, 128, 129, 1000, 7])
+def test_mlp_input_grad_one_launch_equals_the_two_gemm_launches(m, dt):
+    """dh = (dy W2) * [h > 0], dx = dh W1 + dy: against the two tall-skinny GEMM launches it replaces (same 16-bit operands,
+    fp32 accumulation, one rounding per output: dh must agree to the last bit except where the two kernels' fp32 summation
+    orders round differently — bounded at one 16-bit ulp, < 0.1 % of the entries — and dx to 16-bit rounding) and against
+    fp32 torch on the same operands."""
+    from rl4co_amd import train_ops as T
+
+    torch.manual_seed(m)
+    dy = (torch.randn(m, 128, device="cuda") * 0.5).to(dt)
+    h = torch.relu(torch.randn(m, 512, device="cuda")).to(dt)
+    w1 = (torch.randn(512, 128, device="cuda") * 0.08).to(dt)   # lin1.weight [512,128]
+    w2 = (torch.randn(128, 512, device="cuda") * 0.05).to(dt)   # lin2.weight [128,512]
+    w1_t, w2_t = w1.t().contiguous(), w2.t().contiguous()
+    dh, dx = T.mlp_input_grad(dy, h, T._pack_stack(w1_t[None])[0], T._pack_stack(w2_t[None])[0])
+    dh_ref = T._gemm(dy, w2_t, mask=h)
+    dx_ref = T._gemm(dh_ref, w1_t, residual=dy)
+    torch.cuda.synchronize()
+    eps16 = 2.0 ** -8 if dt == torch.bfloat16 else 2.0 ** -11
+    assert dh.shape == (m, 512) and dx.shape == (m, 128) and dh.dtype == dt
+    assert torch.equal(dh == 0, dh_ref == 0)                                   # the ReLU mask, exactly
+    differ = (dh != dh_ref).float().mean()
+    assert float(differ) <= 1e-3 and _rel(dh, dh_ref) <= 0.25 * eps16, (float(differ), _rel(dh, dh_ref))
+    assert _rel(dx, dx_ref) <= 1.0 * eps16, _rel(dx, dx_ref)
+    dh32 = (dy.float() @ w2.float()) * (h.float() > 0)
+    dx32 = dh32.to(dt).float() @ w1.float() + dy.float()
+    assert _rel(dh, dh32) <= 1.0 * eps16 and _rel(dx, dx32) <= 1.5 * eps16
+
+
+def test_stack_backward_with_and_without_the_fused_mlp_input_grad_agree():
+    """The instance-norm stack's backward (POMO training) with the one-launch MLP input gradient against the same backward on
+    the two GEMM launches. The two differ by 16-bit roundings of dh / dx that propagate down the stack, so: every gradient
+    that carries signal (norm >= 10: the input, the weight matrices, the norms' weights) has cosine >= 0.999 with its twin;
+    the rest — biases in front of an instance norm, whose exact gradient is ZERO (the bias cancels in the per-channel mean),
+    the key bias of the attention — are round-off in both runs: below 1 % of the largest gradient norm."""
+    from rl4co_amd import train_ops as T
+    from rl4co_amd.policy import _GraphAttentionNetwork
+
+    grads = {}
+    for fused in (True, False):
+        torch.manual_seed(0)
+        net = _GraphAttentionNetwork(8, 128, 3, "instance", 512).cuda().train()
+        torch.manual_seed(1)
+        x = torch.randn(64, 100, 128, device="cuda") * 0.7
+        g = torch.randn(64, 100, 128, device="cuda")
+        T.FUSED_MLP_INPUT_GRAD = fused
+        try:
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                xin = x.clone().requires_grad_()
+                out = net(xin)
+            (out.float() * g).sum().backward()
+        finally:
+            T.FUSED_MLP_INPUT_GRAD = True
+        grads[fused] = [xin.grad.clone()] + [p.grad.clone() for p in net.parameters()]
+    assert len(grads[True]) == len(grads[False]) > 30
+    top = max(float(b.norm()) for b in grads[False])
+    checked = 0
+    for a, b in zip(grads[True], grads[False]):
+        if min(float(a.norm()), float(b.norm())) >= 10.0:
+            cos = float(torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0))
+            assert cos >= 0.999, cos
+            checked += 1
+        else:
+            assert max(float(a.norm()), float(b.norm())) <= 0.01 * top
+    assert checked >= 20
