@@ -529,6 +529,10 @@ def _mlp_block_bwd(kind, dout, x2, h, w1_16, w2_16, y, g32, mean, rstd, arena=No
         hnorm = (dgamma, dbeta)
     d2 = dy.view(-1, d)
     h2 = h.reshape(-1, h.shape[-1])
+    if (wp is None and FUSED_MLP_INPUT_GRAD and tuple(w1_16.shape) == (4 * EMBED_DIM, EMBED_DIM)
+            and tuple(w2_16.shape) == (EMBED_DIM, 4 * EMBED_DIM)):
+        # a single sub-block node (batch / layer norm training, the piecewise path): pack this layer's transposes here
+        wp = (_pack_stack(w1_16.t().contiguous()[None])[0], _pack_stack(w2_16.t().contiguous()[None])[0])
     if wp is not None and h2.shape[-1] == 4 * EMBED_DIM and d2.is_contiguous() and h2.is_contiguous():
         dh, dx = mlp_input_grad(d2, h2, wp[0], wp[1])
         hw2 = _wgrad(d2, h2, with_bias=True, arena=arena, key=("w2", layer))
