@@ -1,11 +1,14 @@
-"""GPU: Normalization("layer") of the reference (nn/ops.py:48-51 — ONE mean and ONE unbiased variance over all N x 128 values
-of an instance, eps 1e-5, no affine) on the library's kernels up to 128 nodes:
+"""GPU (r04): every normalisation of nn/ops.py:30-54 on the kernels, and the one-launch MLP input gradient.
 
+Normalization("layer") of the reference (nn/ops.py:48-51 — ONE mean and ONE unbiased variance over all N x 128 values of an
+instance, eps 1e-5, no affine):
 * inference: the fused fp32 encoder (csrc/am_encoder_f32.hip, LAYER instantiation) against the float64 evaluation of the
   same modules, tolerance 3e-6 relative Frobenius error like the other fp32-encoder tests; the fused 16-bit encoder
   (csrc/am_encoder.hip) at its 16-bit tolerances and no worse than 2.5 x torch's own autocast path;
 * training: skip + layer norm forward / backward (csrc/am_train_ops.hip: rl4co_skip_lnorm_*) against torch autograd in
   fp32 on the same 16-bit inputs, and a whole encoder layer (sub-block autograd nodes) against the torch modules.
+Instance / layer norm beyond 128 nodes on the token tiles (split sub-blocks + statistics apply kernel), fp32 and 16-bit.
+rl4co_mlp_input_grad (csrc/am_encoder.hip: tok16_mlp_bwd_kernel) against the two GEMM launches it replaces.
 Floating point => tolerance tests; every tolerance is written at its assertion.
 """
 import pytest
