@@ -30,6 +30,8 @@
 //     conversion VALU phases overlap the other's MFMA phases.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace {
@@ -1173,9 +1175,9 @@ __global__ void __launch_bounds__(kThreads) tok16_norm_apply_kernel(const E* __r
 // The per-op path ran these as two GEMM launches with dh written (420 MB at 4096 x 100 rows) and read back; here the
 // 512-wide gradient goes through LDS in four chunks exactly as the hidden does in tok16_mlp_kernel: per layer 1.05 GB of
 // traffic instead of 1.58. Weights: W2^T ([512,128]) and W1^T ([128,512]) in pack_weight's fragment order.
-template <typename E>
+template <int ROWS, typename E>
 __device__ inline void rows_load_strided(E* xs, const E* src, int64_t row_stride, int valid, int tid) {
-  for (int i = tid; i < kTok * 16; i += kThreads) {
+  for (int i = tid; i < ROWS * 16; i += kThreads) {
     const int row = i >> 4, c16 = i & 15;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (row < valid) v = *reinterpret_cast<const uint4*>(src + (int64_t)row * row_stride + 8 * c16);
@@ -1183,31 +1185,56 @@ __device__ inline void rows_load_strided(E* xs, const E* src, int64_t row_stride
   }
 }
 
-template <typename E>
-__global__ void __launch_bounds__(kThreads, 2) tok16_mlp_bwd_kernel(const E* __restrict__ dy, const E* __restrict__ h, int M,
-                                                                    const E* __restrict__ w2t, const E* __restrict__ w1t,
-                                                                    E* __restrict__ dh, E* __restrict__ dx) {
+// TT token tiles of 32 rows per workgroup. The kernel is a chain of four (stage h chunk -> product -> mask -> store ->
+// product) rounds per tile whose HBM round trips are exposed to the workgroup, so what hides them is the number of
+// workgroups a CU holds: TT = 2 (64 rows: 35 KB of LDS, <= 168 registers) keeps three of them resident where TT = 4 keeps two.
+template <typename E, int TT>
+__global__ void __launch_bounds__(kThreads, TT <= 2 ? 3 : 2) tok16_mlp_bwd_kernel(const E* __restrict__ dy, const E* __restrict__ h, int M,
+                                                                                  const E* __restrict__ w2t, const E* __restrict__ w1t,
+                                                                                  E* __restrict__ dh, E* __restrict__ dx) {
+  constexpr int kRows = 32 * TT;
   extern __shared__ __align__(16) unsigned char smem[];
   E* xs = reinterpret_cast<E*>(smem);  // dy tile
-  E* ys = xs + kTok * kRS;             // h chunk (the ReLU mask), then the dh chunk
+  E* ys = xs + kRows * kRS;            // h chunk (the ReLU mask), then the dh chunk
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-  const int r0 = kTok * blockIdx.x, valid = min(kTok, M - r0);
+  const int r0 = kRows * blockIdx.x, valid = min(kRows, M - r0);
   vec8<E> wf[8];
   load_wfrags(wf, w2t, 8, w, 0, lane);
-  rows_load_strided(xs, dy + (int64_t)r0 * kD, kD, valid, tid);
-  f32x16 acc[kTokT];
+  rows_load_strided<kRows>(xs, dy + (int64_t)r0 * kD, kD, valid, tid);
+  f32x16 acc[TT];
 #pragma unroll
-  for (int tt = 0; tt < kTokT; ++tt) acc[tt] = zero16();
+  for (int tt = 0; tt < TT; ++tt) acc[tt] = zero16();
+  // the h chunk of round c + 1 travels in registers while round c computes (2 TT 16-byte pieces per thread)
+  constexpr int kPieces = kRows * 16 / kThreads;
+  constexpr bool kAhead = TT <= 2;
+  uint4 hq[kAhead ? kPieces : 1];
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int p = 0; p < kPieces; ++p) {
+      const int i = tid + kThreads * p, row = i >> 4, c16 = i & 15;
+      hq[kAhead ? p : 0] = row < valid ? *reinterpret_cast<const uint4*>(h + (int64_t)(r0 + row) * kFF + kD * c + 8 * c16) : make_uint4(0, 0, 0, 0);
+    }
+  };
+  if constexpr (kAhead) fetch(0);
 #pragma unroll 1
   for (int c = 0; c < 4; ++c) {
     if (c > 0) __syncthreads();  // every wave is done reading the previous dh chunk
-    rows_load_strided(ys, h + (int64_t)r0 * kFF + kD * c, kFF, valid, tid);
+    if constexpr (kAhead) {
+#pragma unroll
+      for (int p = 0; p < kPieces; ++p) {
+        const int i = tid + kThreads * p;
+        *reinterpret_cast<uint4*>(ys + (i >> 4) * kRS + 8 * (i & 15)) = hq[p];
+      }
+      if (c < 3) fetch(c + 1);
+    } else {
+      rows_load_strided<kRows>(ys, h + (int64_t)r0 * kFF + kD * c, kFF, valid, tid);
+    }
     __syncthreads();
-    f32x16 g[kTokT];
-    gemm_t<kTokT>(g, wf, xs, lane, w1t, 32, w, 8 * c, zero16());  // next: dx += dh chunk . W1 (k-steps 8 c ..)
+    f32x16 g[TT];
+    gemm_t<TT>(g, wf, xs, lane, w1t, 32, w, 8 * c, zero16());  // next: dx += dh chunk . W1 (k-steps 8 c ..)
     // the ReLU mask from this wave's own 32 hidden columns of the staged h chunk; dh goes back over them
 #pragma unroll
-    for (int tt = 0; tt < kTokT; ++tt) {
+    for (int tt = 0; tt < TT; ++tt) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const vec4<E> hv = *reinterpret_cast<const vec4<E>*>(ys + (32 * tt + l31) * kRS + 32 * w + 8 * q + 4 * hi);
@@ -1215,16 +1242,16 @@ __global__ void __launch_bounds__(kThreads, 2) tok16_mlp_bwd_kernel(const E* __r
         for (int e = 0; e < 4; ++e) g[tt][4 * q + e] = ((float)hv[e] > 0.0f) ? g[tt][4 * q + e] : 0.0f;
       }
     }
-    store_t<kTokT>(ys, g, 32 * w, lane);
+    store_t<TT>(ys, g, 32 * w, lane);
     __syncthreads();
     for (int i = tid; i < valid * 16; i += kThreads)
       *reinterpret_cast<uint4*>(dh + (int64_t)(r0 + (i >> 4)) * kFF + kD * c + 8 * (i & 15)) =
           *reinterpret_cast<const uint4*>(ys + (i >> 4) * kRS + 8 * (i & 15));
-    gemm_t<kTokT, true, false>(acc, wf, ys, lane, c < 3 ? w2t : static_cast<const E*>(nullptr), 8, 4 * (c + 1) + w, 0, acc[0]);
+    gemm_t<TT, true, false>(acc, wf, ys, lane, c < 3 ? w2t : static_cast<const E*>(nullptr), 8, 4 * (c + 1) + w, 0, acc[0]);
   }
   // + dy (the skip connection's gradient), this wave's 32 columns of the dy tile, then out through the same tile
 #pragma unroll
-  for (int tt = 0; tt < kTokT; ++tt) {
+  for (int tt = 0; tt < TT; ++tt) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const vec4<E> x = *reinterpret_cast<const vec4<E>*>(xs + (32 * tt + l31) * kRS + 32 * w + 8 * q + 4 * hi);
@@ -1232,7 +1259,7 @@ __global__ void __launch_bounds__(kThreads, 2) tok16_mlp_bwd_kernel(const E* __r
       for (int e = 0; e < 4; ++e) acc[tt][4 * q + e] += (float)x[e];
     }
   }
-  store_t<kTokT>(xs, acc, 32 * w, lane);
+  store_t<TT>(xs, acc, 32 * w, lane);
   __syncthreads();
   tok_store(xs, dx + (int64_t)r0 * kD, kD, valid, tid);
 }
@@ -1465,11 +1492,12 @@ extern "C" int rl4co_am_encoder_train_fwd(const rl4co_am_encoder_args* args, con
   return a.act_dtype == RL4CO_DT_F16 ? launch_train_elem<_Float16>(a, *save, s) : launch_train_elem<__bf16>(a, *save, s);
 }
 
-template <typename E>
+template <typename E, int TT>
 int launch_mlp_bwd(const void* dy, const void* h, int64_t M, const void* w2t, const void* w1t, void* dh, void* dx, hipStream_t s) {
-  const int lds = 2 * kTok * kRS * (int)sizeof(E);
-  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tok16_mlp_bwd_kernel<E>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  hipLaunchKernelGGL(tok16_mlp_bwd_kernel<E>, dim3((unsigned)((M + kTok - 1) / kTok)), dim3(kThreads), lds, s, static_cast<const E*>(dy),
+  constexpr int rows = 32 * TT;
+  const int lds = 2 * rows * kRS * (int)sizeof(E);
+  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tok16_mlp_bwd_kernel<E, TT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL((tok16_mlp_bwd_kernel<E, TT>), dim3((unsigned)((M + rows - 1) / rows)), dim3(kThreads), lds, s, static_cast<const E*>(dy),
                      static_cast<const E*>(h), (int)M, static_cast<const E*>(w2t), static_cast<const E*>(w1t), static_cast<E*>(dh),
                      static_cast<E*>(dx));
   RL4CO_HIP_TRY(hipGetLastError());
@@ -1482,8 +1510,18 @@ extern "C" int rl4co_mlp_input_grad(const void* dy, const void* h, int64_t M, co
   RL4CO_REQUIRE(M > 0 && M < (int64_t)1 << 31);
   RL4CO_REQUIRE(dtype == RL4CO_DT_BF16 || dtype == RL4CO_DT_F16);
   hipStream_t s = rl4co::as_stream(stream);
-  return dtype == RL4CO_DT_F16 ? launch_mlp_bwd<_Float16>(dy, h, M, w2t_packed, w1t_packed, dh, dx, s)
-                               : launch_mlp_bwd<__bf16>(dy, h, M, w2t_packed, w1t_packed, dh, dx, s);
+  static const int tiles = [] {  // (probe knob: RL4CO_MLP_BWD_TILES = 2 | 4 token tiles of 32 rows per workgroup)
+    const char* e = getenv("RL4CO_MLP_BWD_TILES");
+    return (e && e[0] == '4') ? 4 : ((e && e[0] == '1') ? 1 : 2);
+  }();
+  if (tiles == 4)
+    return dtype == RL4CO_DT_F16 ? launch_mlp_bwd<_Float16, 4>(dy, h, M, w2t_packed, w1t_packed, dh, dx, s)
+                                 : launch_mlp_bwd<__bf16, 4>(dy, h, M, w2t_packed, w1t_packed, dh, dx, s);
+  if (tiles == 1)
+    return dtype == RL4CO_DT_F16 ? launch_mlp_bwd<_Float16, 1>(dy, h, M, w2t_packed, w1t_packed, dh, dx, s)
+                                 : launch_mlp_bwd<__bf16, 1>(dy, h, M, w2t_packed, w1t_packed, dh, dx, s);
+  return dtype == RL4CO_DT_F16 ? launch_mlp_bwd<_Float16, 2>(dy, h, M, w2t_packed, w1t_packed, dh, dx, s)
+                               : launch_mlp_bwd<__bf16, 2>(dy, h, M, w2t_packed, w1t_packed, dh, dx, s);
 }
 
 extern "C" int rl4co_am_encoder_max_nodes(void) { return 128; }
