@@ -134,24 +134,50 @@ def state_hash(tensors: dict) -> str:
     return h.hexdigest()
 
 
-def cpu_baseline(env_name: str, num_loc: int, sample_batch: int, repeats: int, chunk: int = 512) -> dict:
-    """Reference path on the host cores: oracle restatement (stock ATen ops, fp32, same ops in
-    the same order as the reference), greedy rollout, span = reset -> policy -> reward."""
-    from oracle import reference_torch as R
+def _cpu_rollout_passes(pol, env, data, batch: int, chunk: int, passes: int) -> tuple[list[float], int, float]:
+    """1 warm-up + `passes` timed greedy rollouts of `batch` instances (in calls of `chunk`), the span EvalBase.__call__
+    times (rl4co/tasks/eval.py:38-63): env.reset -> policy(td, env, decode_type="greedy") -> reward.
+    Returns (seconds per timed pass, instance·steps per pass, mean reward)."""
+    times, work, rewards = [], 0, []
+    for i in range(passes + 1):
+        t0 = time.perf_counter()
+        rewards, work = [], 0
+        for lo in range(0, batch, chunk):
+            td = env.reset({k: v[lo : lo + chunk].clone() for k, v in data.items()})
+            out = pol(td, env, phase="test", decode_type="greedy")
+            rewards.append(out["reward"])
+            work += out["actions"].shape[0] * out["actions"].shape[1]
+        if i > 0:  # the first pass is the warm-up
+            times.append(time.perf_counter() - t0)
+    return times, work, float(torch.cat(rewards).mean())
 
-    # host cores this process may actually run on (cgroup/affinity aware: os.cpu_count() can
-    # report the whole machine inside a CPU-limited container and oversubscribe OpenMP)
-    avail = max(1, len(os.sched_getaffinity(0)))
+
+def cpu_baseline(env_name: str, num_loc: int, sample_batch: int, repeats: int = 5, chunk: int = 512) -> dict:
+    """The reference path on the host cores, by the protocol of BASELINE.md §3: the oracle restatement (stock ATen ops,
+    fp32, the reference's ops in the reference's order: kind "port"), greedy rollout, span = reset -> policy -> reward
+    under inference_mode, 1 warm-up + `repeats` (>= 5) timed rollouts, MEDIAN and MIN, thread count reported, a 1-thread
+    figure beside it.
+
+    * C1 = BASELINE configs[0] exactly: TSPEnv num_loc=20, batch 256, default AttentionModelPolicy, greedy — with
+      ``check_solution`` on (the reference's default, envs/common/base.py:54) and off (configs/experiment/base.yaml:21).
+    * the headline workload (C2: TSP-100) on a bounded sample of its 4096 instances (whole calls of 4096 take 13 s each
+      on the host: the sample keeps the leg at ~10 - 30 s of CPU work), same seeds and generator as the GPU leg's shape.
+    `value` = the headline workload's MEDIAN rate (instance·step/s), comparable with the GPU line's `value`."""
+    from oracle import reference_torch as R
+    import statistics
+
+    repeats = max(5, repeats)
+    avail = max(1, len(os.sched_getaffinity(0)))  # cgroup / affinity aware (os.cpu_count() reports the whole machine)
     default_threads = max(1, min(avail, torch.get_num_threads()))
-    env = R.get_env(env_name, num_loc, check_solution=True)
     torch.manual_seed(0)
     pol = R.AttentionModelPolicy(env_name).eval()
+    env = R.get_env(env_name, num_loc, check_solution=True)
     torch.manual_seed(1234)
     data = env.generate(sample_batch)
-    times, steps = [], 0
+    t_leg = time.perf_counter()
     with torch.inference_mode():
-        # the reference's many small ATen ops do not scale to 100+ threads: probe a few thread
-        # counts on a small batch and time the baseline at the fastest one (stated in `cores`)
+        # the reference's many small ATen ops do not scale to 100+ threads: probe a few thread counts on a small batch and
+        # time the baseline at the fastest one (stated in `cores`)
         probe_b = min(64, sample_batch)
         per_inst, threads = float("inf"), default_threads
         for cand in sorted({default_threads, *(c for c in (64, 32, 16, 8) if c <= avail)}, reverse=True):
@@ -164,38 +190,49 @@ def cpu_baseline(env_name: str, num_loc: int, sample_batch: int, repeats: int, c
             if best_c < per_inst:
                 per_inst, threads = best_c, cand
         torch.set_num_threads(threads)
-        # size the sample so that the whole leg stays within ~30 s of CPU work on any host
-        budget_b = int(30.0 / (repeats + 1) / max(per_inst, 1e-6))
+        # ---- the headline workload on a bounded sample: ~12 s for the 1 + repeats passes on any host --------------------
+        budget_b = int(12.0 / (repeats + 1) / max(per_inst, 1e-6))
         if budget_b < sample_batch:
-            sample_batch = max(probe_b, budget_b)
+            sample_batch = max(probe_b, budget_b // 64 * 64)
             data = {k: v[:sample_batch] for k, v in data.items()}
-        # the host path is fastest at a few hundred instances per call (13.6 s for one call of 4096 vs 8 x 0.5 s
-        # for the same instances in calls of 512, measured on the GPU box): the sample is rolled out chunk by chunk
         chunk = min(chunk, sample_batch)
-        log(f"cpu_baseline: {threads} threads, sample {sample_batch} instances in calls of {chunk} "
-            f"(probe {per_inst * 1e3:.2f} ms/instance)")
-        for i in range(repeats + 1):
-            t0 = time.perf_counter()
-            rewards, work = [], 0
-            for lo in range(0, sample_batch, chunk):
-                td = env.reset({k: v[lo : lo + chunk].clone() for k, v in data.items()})
-                out = pol(td, env, phase="test", decode_type="greedy")
-                rewards.append(out["reward"])
-                work += out["actions"].shape[0] * out["actions"].shape[1]  # instance·steps of this call
-            dt = time.perf_counter() - t0
-            if i > 0:  # first pass is the warm-up
-                times.append(dt)
-    best = min(times)
+        log(f"cpu_baseline: {threads} threads, sample {sample_batch} instances in calls of {chunk} (probe {per_inst * 1e3:.2f} ms/instance)")
+        times, work, mean_reward = _cpu_rollout_passes(pol, env, data, sample_batch, chunk, repeats)
+        med, best = statistics.median(times), min(times)
+        # ---- C1 = BASELINE configs[0], exactly: TSP-20 x 256, check_solution on / off --------------------------------
+        c1 = {}
+        torch.manual_seed(0)
+        pol1 = R.AttentionModelPolicy("tsp").eval()
+        for check in (True, False):
+            env1 = R.get_env("tsp", 20, check_solution=check)
+            torch.manual_seed(1234)
+            d1 = env1.generate(256)
+            t1, w1, r1 = _cpu_rollout_passes(pol1, env1, d1, 256, 256, repeats)
+            c1["check" if check else "nocheck"] = {"median": w1 / statistics.median(t1), "best": w1 / min(t1),
+                                                   "median_ms": statistics.median(t1) * 1e3, "min_ms": min(t1) * 1e3,
+                                                   "instances_per_sec": 256 / statistics.median(t1), "mean_reward": r1}
+        # ---- one thread (BASELINE.md §3 "also report 1-thread"): C1 as is, the headline workload on 64 instances --------
+        torch.set_num_threads(1)
+        t1, w1, _ = _cpu_rollout_passes(pol1, env1, d1, 256, 256, 2)
+        one = {"c1": w1 / statistics.median(t1)}
+        if time.perf_counter() - t_leg < 40.0:
+            small = {k: v[:64] for k, v in data.items()}
+            t2, w2, _ = _cpu_rollout_passes(pol, env, small, 64, 64, 1)
+            one["headline"] = w2 / min(t2)
+        torch.set_num_threads(default_threads)
     return {
-        "value": work / best,
-        "unit": "instance·step/s",
-        "cores": threads,
-        "kind": "port",
-        "sample": f"{env_name.upper()}-{num_loc}, {sample_batch} instances in calls of {chunk}, greedy full rollout "
-                  f"(encoder+decode+reward), fp32 torch CPU, best of {repeats} passes after 1 warm-up, {best:.3f} s each",
-        "mean_reward": float(torch.cat(rewards).mean()),
-        "note": "the oracle restatement (the reference package itself cannot be installed on the box); thread count "
-                "chosen by probing; varies 1.0-1.35e5 between boxes",
+        "value": work / med, "best": work / best, "unit": "instance·step/s",
+        "median_s": med, "min_s": best, "passes": repeats,
+        "cores": threads, "kind": "port",
+        "c1_value": c1["check"]["median"], "c1_best": c1["check"]["best"], "c1_nocheck_value": c1["nocheck"]["median"],
+        "one_thread": one,
+        "c1": c1,
+        "sample": f"{env_name.upper()}-{num_loc}: {sample_batch} of the leg's instances in calls of {chunk}; C1 = TSP-20 x 256 whole; "
+                  f"greedy rollout reset->policy->reward, fp32 torch CPU, 1 warm-up + {repeats} passes, median (best beside it)",
+        "mean_reward": mean_reward,
+        "wall_s": time.perf_counter() - t_leg,
+        "note": "the oracle restatement (the reference package itself cannot be installed on the box), BASELINE.md §3 protocol; "
+                "thread count chosen by probing; the headline rate moves 0.7 - 1.6e5 between boxes (host CPU model / load)",
     }
 
 
@@ -287,8 +324,11 @@ def compact_line(detail: dict, head_name: str, results: dict, detail_path: str) 
         line["parity"] = compact_parity(detail["parity"])
     cb = detail.get("cpu_baseline")
     if cb:
-        line["cpu_baseline"] = {"value": _r(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
-                                "sample": cb["sample"][:150], "gpu_over_cpu": _r(cb.get("gpu_over_cpu"))}
+        line["cpu_baseline"] = {"value": _r(cb["value"]), "best": _r(cb.get("best")), "c1_value": _r(cb.get("c1_value")),
+                                "c1_best": _r(cb.get("c1_best")), "c1_nocheck_value": _r(cb.get("c1_nocheck_value")),
+                                "one_thread": {k: _r(v) for k, v in (cb.get("one_thread") or {}).items()},
+                                "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "passes": cb.get("passes"),
+                                "sample": cb["sample"][:170], "gpu_over_cpu": _r(cb.get("gpu_over_cpu"))}
     line["detail_file"] = os.path.relpath(detail_path, ROOT) if os.path.isabs(detail_path) else detail_path
     return line
 
@@ -975,7 +1015,7 @@ def main() -> None:
             log("parity vs the reference's tours (trained weights, every inference leg)")
             detail["parity"] = bench.parity(legs)
         if world == 1 and not args.no_cpu_baseline and head_name != "c4_train":
-            detail["cpu_baseline"] = cpu_baseline(env_name, num_loc, args.cpu_sample_batch, repeats=2)
+            detail["cpu_baseline"] = cpu_baseline(env_name, num_loc, args.cpu_sample_batch, repeats=5)
             detail["cpu_baseline"]["gpu_over_cpu"] = head["value"] / detail["cpu_baseline"]["value"]
         line = compact_line(detail, head_name, results, args.detail)
         try:  # everything the compact line leaves out: per-leg dicts, rooflines with their notes, the whole parity block

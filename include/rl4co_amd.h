@@ -376,7 +376,15 @@ typedef struct rl4co_am_encoder_args {
   int32_t B;           /* instances                                                */
   int32_t N;           /* nodes incl. depot                                        */
   int32_t num_layers;  /* 3 (AM) / 6 (POMO)                                        */
-  int32_t norm;        /* 0 = per-channel affine (batch norm, eval), 1 = instance, 2 = layer (fused kernels, N <= 128) */
+  int32_t norm;        /* 0 = per-channel affine (batch norm, eval), 1 = instance, 2 = layer (nn/ops.py:48-51: one mean / one
+                          unbiased variance per instance, no affine) — every entry point serves all three, the token-tile
+                          ones through split half-layer kernels + a norm-apply kernel. What n*_scale / n*_shift hold:
+                            0: scale = weight / sqrt(running_var + eps), shift = bias - running_mean * scale
+                               (16-bit kernels: + the preceding GEMM's bias * scale; fp32 kernels add bo / b2 themselves)
+                            1: gamma, beta (statistics per instance and channel over the nodes)
+                            2: 16-bit kernels: scale unused, shift = the bias of the GEMM in front of the norm (out_proj /
+                               the MLP's second linear: it does not cancel under a whole-instance mean and is added before
+                               the statistics); fp32 kernels: unused (they add bo / b2 themselves) */
   int32_t cache_dtype; /* dtype of the three kvl planes written: RL4CO_DT_F32 or act_dtype */
   int32_t act_dtype;   /* 16-bit element type of the MFMA operands, the packed weights and the LDS residual stream:
                           RL4CO_DT_BF16 (autocast bfloat16) or RL4CO_DT_F16 (autocast float16, the reference's
@@ -453,7 +461,10 @@ int rl4co_am_encoder_train_fwd(const rl4co_am_encoder_args* args, const rl4co_am
 /* The 16-bit encoder + cache fold for graphs of ANY size (csrc/am_encoder.hip: token-tile kernels; BASELINE configs[4],
  * CVRP-500): the fused kernel's layer algebra, GEMM routine and packed weights over tiles of 128 nodes — init embedding,
  * per layer [Q / K / V projection (+ per-head score bounds), rl4co_attn_flash_pre_*, ONE kernel for out-proj + norm + MLP +
- * norm], fold, graph context. Same argument struct and packing as rl4co_am_encoder; norm must be 0 (batch norm, eval).
+ * norm], fold, graph context. Same argument struct and packing as rl4co_am_encoder; norm 0 (batch norm, eval) runs
+ * the three-launch layer, norm 1 / 2 (instance / layer: statistics over ALL tiles of an instance) two half-layer kernels
+ * that stop before their norm, write the pre-norm sums and per-tile (mean, centred sum of squares), and a norm-apply
+ * kernel combining the tiles' pairs (Chan's update) — the workspace then also holds those sums and statistics. B <= 65535.
  * `workspace`: at least rl4co_am_encoder_tokens16_workspace(B, N) bytes of device memory, 16-byte aligned. */
 int rl4co_am_encoder_tokens16(const rl4co_am_encoder_args* args, void* workspace, int64_t workspace_bytes, void* stream);
 int64_t rl4co_am_encoder_tokens16_workspace(int B, int N);
@@ -476,9 +487,11 @@ int rl4co_am_encoder_f32(const rl4co_am_encoder_args* args, void* stream);
 /* The exact-fp32 encoder + cache fold for graphs of ANY size (csrc/am_tokens_f32.hip; BASELINE configs[4], CVRP-500): the
  * same arithmetic as rl4co_am_encoder_f32 (same GEMM routine and summation order) as launches over tiles of 128 nodes —
  * init embedding, per layer [Q/K/V projection, attention with keys / values streamed and an online softmax, out-proj +
- * norm + MLP + norm], fold, graph context. Same argument struct and packing as rl4co_am_encoder_f32; norm must be 0
- * (batch norm, eval). `workspace`: at least rl4co_am_encoder_tokens_f32_workspace(B, N) bytes of device memory, 16-byte
- * aligned, contents irrelevant on entry (five [B N, 128] fp32 activation buffers and the per-head transposed values). */
+ * norm + MLP + norm], fold, graph context. Same argument struct and packing as rl4co_am_encoder_f32; norm 0 .. 2 as for
+ * rl4co_am_encoder_tokens16 (instance / layer norm: half-layer kernels + norm-apply over the tiles' combined statistics).
+ * B <= 65535. `workspace`: at least rl4co_am_encoder_tokens_f32_workspace(B, N) bytes of device memory, 16-byte aligned,
+ * contents irrelevant on entry (the [B N, 128] fp32 activation buffers, the per-head transposed values, the per-tile
+ * statistics). */
 int rl4co_am_encoder_tokens_f32(const rl4co_am_encoder_args* args, void* workspace, int64_t workspace_bytes, void* stream);
 int64_t rl4co_am_encoder_tokens_f32_workspace(int B, int N);
 

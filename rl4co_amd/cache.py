@@ -167,7 +167,7 @@ def build_folded_cache(
             torch.matmul(h_g, w_t, out=kvl[i].view(b * n, d))
         else:
             kvl[i].view(b * n, d).copy_(torch.matmul(h_g, w_t))
-    if h.is_cuda and not torch.is_grad_enabled() and h.dtype in (torch.float32, torch.bfloat16, torch.float16):
+    if h.is_cuda and not torch.is_grad_enabled() and h.dtype in (torch.float32, torch.bfloat16, torch.float16) and b <= 65535:  # (the entry carries the instance in grid.y)
         # inference: the fp32 side of the fold (context tables, graph context) on the library's own fp32-MFMA kernel
         # (csrc/am_tokens_f32.hip: rl4co_am_fold_tables_f32; the 16-bit embeddings of the token path are widened on load)
         ctx, q_bias = _fold_tables_f32(h, w_blocks[3:], w_fixed)

@@ -36,6 +36,9 @@
 
 namespace {
 
+#ifndef RL4CO_ENC_PRIO
+#define RL4CO_ENC_PRIO 0  // probe (tools/enc_variants.sh): 1 = GEMM calls at priority 2, 2 = GEMM calls + attention, 3 = epilogues
+#endif
 constexpr int kD = RL4CO_EMBED_DIM;
 constexpr int kFF = 512;
 constexpr int kRS = kD + 8;  // LDS row stride (bf16 elements): 272 B rows spread the banks
@@ -78,6 +81,7 @@ __device__ inline f32x16 bias_tile(const float* bias, int dim0, int hi) {
   return t;
 }
 constexpr int kBiasFloats = 3 * kD + kFF;  // per layer: bqkv [384] | b1 [512]
+constexpr int kNormFloats = 4 * kD;         // per layer: n1 scale | n1 shift | n2 scale | n2 shift
 
 __device__ inline f32x16 zero16() {
   f32x16 z;
@@ -123,10 +127,19 @@ __device__ inline void load_wfrags(vec8<E> (&wf)[8], const E* packed, int ksteps
 // activation fragments are double-buffered one kstep ahead.
 // INIT: the first k-step takes `cinit` as its C operand (an MFMA's C need not be its D) — the bias tile of the GEMM,
 // shared by the TT token tiles, enters the accumulators for free instead of through 16 TT adds in the epilogue.
-template <int TT, bool W_IS_A = true, bool INIT = true, typename E>
+// NEXT: 1 = the hand-over always happens (`nxt_packed` is a valid fragment stream), 0 = never, -1 = decided at run time from
+// `nxt_packed`. The run-time form puts a branch behind every k-step (eight basic blocks per call, r05 ISA: s_cbranch +
+// s_and per k-step, the scheduler cannot move anything across them); where the last call of a chain has nothing to fetch the
+// callers hand in a dummy stream instead (8 KB per wave from L2, unused).
+template <int TT, bool W_IS_A = true, bool INIT = true, int NEXT = -1, typename E>
 __device__ inline void gemm_t(f32x16 (&acc)[TT], vec8<E> (&wf)[8], const E* xs, int lane, const E* nxt_packed,
                               int nxt_ksteps_total, int nxt_tile, int nxt_k0, const f32x16& cinit) {
   const int l31 = lane & 31, hi = lane >> 5;
+#if RL4CO_ENC_PRIO == 1 || RL4CO_ENC_PRIO == 2
+  __builtin_amdgcn_s_setprio(2);
+#elif RL4CO_ENC_PRIO == 3
+  __builtin_amdgcn_s_setprio(0);
+#endif
   // Every MFMA takes one 1 KiB activation fragment from LDS. With the fragments of k-step ks + 1 requested while k-step
   // ks computes (TT MFMAs = 128 cycles at TT = 4), the eight waves of a CU keep the LDS queue deep enough that the
   // data is NOT back in time: replacing these reads by loop-invariant ones cut the kernel from 1.12 to 0.63 ms
@@ -149,8 +162,16 @@ __device__ inline void gemm_t(f32x16 (&acc)[TT], vec8<E> (&wf)[8], const E* xs, 
       const f32x16& c = (INIT && ks == 0) ? cinit : acc[tt];
       acc[tt] = W_IS_A ? mfma(wf[ks], x[ks % 3][tt], c) : mfma(x[ks % 3][tt], wf[ks], c);
     }
-    if (nxt_packed) wf[ks] = load_w(nxt_packed, nxt_ksteps_total, nxt_tile, nxt_k0 + ks, lane);
+    if (NEXT == 1 || (NEXT < 0 && nxt_packed)) wf[ks] = load_w(nxt_packed, nxt_ksteps_total, nxt_tile, nxt_k0 + ks, lane);
+    // straight-line calls: keep the k-steps in this order (left alone, the scheduler pulls the LDS reads back to just in
+    // front of their MFMA — less register pressure on paper, the read latency exposed on every product)
+    if (NEXT >= 0) __builtin_amdgcn_sched_barrier(0);
   }
+#if RL4CO_ENC_PRIO == 1 || RL4CO_ENC_PRIO == 2
+  __builtin_amdgcn_s_setprio(0);
+#elif RL4CO_ENC_PRIO == 3
+  __builtin_amdgcn_s_setprio(2);
+#endif
 }
 
 // write an Out^T accumulator tile to LDS rows [token][dim]: 4 consecutive dims per 8-byte store
@@ -506,9 +527,19 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
   E* ys = xs + 128 * kRS;              // Q^T (wave-private columns) -> attention output -> FFN hidden chunk
   float* meanv = reinterpret_cast<float*>(ys + 128 * kRS);  // [128]
   float* bl = meanv + kD;                                    // [kBiasFloats] this layer's bqkv | b1 (see bias_tile)
+  // the norms' per-channel constants, staged with the biases one layer ahead: read from global memory in the epilogue
+  // they put an L2 round trip behind each of the layer's two GEMM -> norm hand-overs. Two buffers by layer parity: a fast
+  // wave stages layer l + 1 while a slow one still reads layer l's second norm.
+  float* nl = bl + kBiasFloats;                              // [2][kNormFloats]
   auto stage_biases = [&](int layer) {
     for (int i = threadIdx.x; i < kBiasFloats; i += kThreads)
       bl[i] = i < 3 * kD ? a.bqkv[layer * 3 * kD + i] : a.b1[layer * kFF + i - 3 * kD];
+#ifdef RL4CO_ENC_NORMLDS
+    for (int i = threadIdx.x; i < kNormFloats; i += kThreads) {
+      const float* src = i < 2 * kD ? (i < kD ? a.n1_scale : a.n1_shift) : (i < 3 * kD ? a.n2_scale : a.n2_shift);
+      nl[(layer & 1) * kNormFloats + i] = src[layer * kD + (i & (kD - 1))];
+    }
+#endif
   };
 
   int tid = threadIdx.x;
@@ -538,7 +569,11 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       *reinterpret_cast<uint4*>(xs + row * kRS + 8 * c16) = v;
     }
   } else {
+#ifdef RL4CO_ENC_SKIP_INIT  // timing probe only: a constant residual stream instead of the embedding
+    for (int i = tid; i < 32 * TT * 16; i += kThreads) *reinterpret_cast<uint4*>(xs + (i >> 4) * kRS + 8 * (i & 15)) = make_uint4(0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u);
+#else
     init_embed_rows16<E>(a, b, 0, 32 * TT, xs, reinterpret_cast<float*>(ys), tid);  // (ys is free here: the features are staged in it)
+#endif
   }
   rl4co::lds_barrier();
 
@@ -557,10 +592,17 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
     L.w2 = w2_all + (int64_t)layer * kD * kFF;
     L.bqkv = bl;
     L.b1 = bl + 3 * kD;
+#ifdef RL4CO_ENC_NORMLDS
+    L.n1a = nl + (layer & 1) * kNormFloats;
+    L.n1b = L.n1a + kD;
+    L.n2a = L.n1a + 2 * kD;
+    L.n2b = L.n1a + 3 * kD;
+#else
     L.n1a = a.n1_scale + layer * kD;
     L.n1b = a.n1_shift + layer * kD;
     L.n2a = a.n2_scale + layer * kD;
     L.n2b = a.n2_shift + layer * kD;
+#endif
 
     // ---- Q, K (transposed form) and V (plain form) of head pair w, kept as fragments ---------
     // vfh[hh]: V^T fragments for head hh of the pair — the lanes holding the OTHER head's dims carry ones instead, so
@@ -571,7 +613,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       f32x16 acc[TT];
       // 1/sqrt(16) and log2(e) are folded into the packed Wq and its bias on the host (encoder.py): the softmax below
       // is exp2(s - max) and the projection needs no epilogue arithmetic at all
-      gemm_t<TT>(acc, wf, xs, lane, L.wqkv, 8, 4 + w, 0, bias_tile(L.bqkv, 32 * w, hi));
+      gemm_t<TT, true, true, 1>(acc, wf, xs, lane, L.wqkv, 8, 4 + w, 0, bias_tile(L.bqkv, 32 * w, hi));
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
         float h0, h1;
@@ -583,7 +625,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       // row, and later overwrites it with the attention output of that same row)
       store_t<TT>(ys, acc, 32 * w, lane);
       if constexpr (TRAIN) save_t<TT>(ts.qkv + ((int64_t)layer * a.B + b) * N * 3 * kD, 3 * kD, acc, 32 * w, N, lane);
-      gemm_t<TT>(acc, wf, xs, lane, L.wqkv, 8, 8 + w, 0, bias_tile(L.bqkv + kD, 32 * w, hi));
+      gemm_t<TT, true, true, 1>(acc, wf, xs, lane, L.wqkv, 8, 8 + w, 0, bias_tile(L.bqkv + kD, 32 * w, hi));
       if constexpr (TRAIN) save_t<TT>(ts.qkv + ((int64_t)layer * a.B + b) * N * 3 * kD + kD, 3 * kD, acc, 32 * w, N, lane);
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
@@ -600,7 +642,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         f32x16 bt;
 #pragma unroll
         for (int r = 0; r < 16; ++r) bt[r] = bv;
-        gemm_t<TT, false>(acc, wf, xs, lane, static_cast<const E*>(nullptr), 0, 0, 0, bt);  // nothing in flight across the attention (register peak)
+        gemm_t<TT, false, true, 0>(acc, wf, xs, lane, static_cast<const E*>(nullptr), 0, 0, 0, bt);  // nothing in flight across the attention (register peak)
       }
       if constexpr (TRAIN) {
         // plain form: the lane owns ONE dim column and sixteen token rows per tile — 2-byte stores, 32 consecutive dims
@@ -638,7 +680,14 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
 
     // ---- attention for heads 2w, 2w+1 over all queries, wave-private ---------------------------
     constexpr int kLastRegs = 4 * VR4;  // registers of the last key tile that can hold real keys
+#if RL4CO_ENC_PRIO == 2
+    __builtin_amdgcn_s_setprio(2);
+#endif
+#ifdef RL4CO_ENC_QTLOOP
+#pragma unroll 1
+#else
 #pragma unroll
+#endif
     for (int qt = 0; qt < TT; ++qt) {
       E* qrow = ys + (32 * qt + l31) * kRS + 32 * w;
       f32x16 o = zero16();
@@ -733,6 +782,9 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         *reinterpret_cast<bf16x4*>(qrow + 8 * c + 4 * hi) = v;
       }
     }
+#if RL4CO_ENC_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
     __builtin_amdgcn_sched_barrier(0);     // keep these loads out of the attention loop (its register peak)
     load_wfrags(wf, L.wo, 8, w, 0, lane);  // out-proj weights: in flight across the barrier
     rl4co::lds_barrier();
@@ -743,7 +795,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       f32x16 y[TT];
       // (out_proj's bias rides in the norm's shift — batch norm — or cancels in the per-channel mean — instance norm:
       // folded on the host, encoder.py)
-      gemm_t<TT>(y, wf, ys, lane, L.w1, 8, w, 0, zero16());  // next: FFN1 chunk 0
+      gemm_t<TT, true, true, 1>(y, wf, ys, lane, L.w1, 8, w, 0, zero16());  // next: FFN1 chunk 0
       if constexpr (TRAIN) {
         float* st = ts.stats + ((int64_t)layer * 4 * a.B + b) * kD;
         residual_norm_train<TT>(xs, y, 32 * w, L.n1a, L.n1b, N, lane, ts.y1 + ((int64_t)layer * a.B + b) * N * kD, st, st + (int64_t)a.B * kD);
@@ -761,7 +813,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       for (int tt = 0; tt < TT; ++tt) y2[tt] = zero16();  // the chunk loop accumulates; the MLP's output bias: see out_proj
       for (int c = 0; c < 4; ++c) {
         f32x16 h1[TT];
-        gemm_t<TT>(h1, wf, xs, lane, L.w2, 32, w, 8 * c, bias_tile(L.b1, 32 * (4 * c + w), hi));  // next: FFN2 of this chunk
+        gemm_t<TT, true, true, 1>(h1, wf, xs, lane, L.w2, 32, w, 8 * c, bias_tile(L.b1, 32 * (4 * c + w), hi));  // next: FFN2 of this chunk
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
@@ -772,8 +824,9 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         if constexpr (TRAIN) rows_out(ys, ts.h + ((int64_t)layer * a.B + b) * N * kFF + kD * c, kFF, N, tid);
         // next: FFN1 of the next chunk, then the next layer's Q projection, finally the first fold block
         const bool last_layer = layer + 1 == a.num_layers;
-        const E* nxt = c < 3 ? L.w1 : (last_layer ? wf_all : wqkv_all + (int64_t)(layer + 1) * 3 * kD * kD);
-        gemm_t<TT, true, false>(y2, wf, ys, lane, nxt, 8, c < 3 ? 4 * (c + 1) + w : w, 0, y2[0]);
+        // (the training forward has no fold: its last call fetches W1's first tile again, unused)
+        const E* nxt = c < 3 ? L.w1 : (last_layer ? (TRAIN ? L.w1 : wf_all) : wqkv_all + (int64_t)(layer + 1) * 3 * kD * kD);
+        gemm_t<TT, true, false, 1>(y2, wf, ys, lane, nxt, 8, c < 3 ? 4 * (c + 1) + w : w, 0, y2[0]);
       }
       if constexpr (TRAIN) {
         float* st = ts.stats + (((int64_t)layer * 4 + 2) * a.B + b) * kD;
@@ -796,11 +849,14 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
   }
 
   // ---- fold: cache planes straight out of the accumulators ------------------------------------------
+#ifdef RL4CO_ENC_SKIP_FOLD  // timing probe only
+  const int nblocks = 0;
+#else
   const int nblocks = (a.env == RL4CO_ENV_TSP) ? 5 : 4;
+#endif
   for (int blk = 0; blk < nblocks; ++blk) {
     f32x16 acc[TT];
-    gemm_t<TT>(acc, wf, xs, lane, blk + 1 < nblocks ? wf_all + (int64_t)(blk + 1) * kD * kD : static_cast<const E*>(nullptr), 8, w, 0,
-               zero16());
+    gemm_t<TT, true, true, 1>(acc, wf, xs, lane, wf_all + (int64_t)(blk + 1 < nblocks ? blk + 1 : 0) * kD * kD, 8, w, 0, zero16());  // (last block: dummy)
     // The tile leaves through LDS (`ys` is free after the last layer): stored straight from the accumulators a lane
     // owns 8 / 16 bytes in each of 32 token rows; staged, a plane of an instance is ONE contiguous run of 16-byte lanes.
     if (blk < 3 && a.cache_dtype != RL4CO_DT_F32) {  // 16-bit planes carry the element type of the activations
@@ -849,7 +905,11 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
   }
 
   // ---- graph context: project_fixed_context(mean_j h_j)  (decoder.py:216-219) -----------------------
+#ifdef RL4CO_ENC_SKIP_GCTX
+  if (false) {
+#else
   if (a.q_bias) {
+#endif
     if (tid < kD) {
       float s = 0.0f;
       for (int tok = 0; tok < N; ++tok) s += (float)xs[tok * kRS + tid];
@@ -1394,9 +1454,12 @@ int launch_tokens16(const rl4co_am_encoder_args& a, void* workspace, hipStream_t
   return RL4CO_OK;
 }
 
+constexpr int kEncLds = 2 * 128 * kRS * 2 + kD * 4 + kBiasFloats * 4 + 2 * kNormFloats * 4;  // 77 824 B: two workgroups per CU
+static_assert(2 * kEncLds <= 160 * 1024, "am_encoder_kernel is built for two workgroups per CU");
+
 template <typename E, int TT, int VR4>
 int launch_encoder(const rl4co_am_encoder_args& a, hipStream_t stream) {
-  const int lds = 2 * 128 * kRS * 2 + kD * 4 + kBiasFloats * 4;
+  const int lds = kEncLds;
   RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_encoder_kernel<E, TT, VR4, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipLaunchKernelGGL((am_encoder_kernel<E, TT, VR4>), dim3(a.B), dim3(kThreads), lds, stream, a, TrainSave<E>{});
@@ -1408,7 +1471,7 @@ template <typename E, int TT>
 int launch_encoder_layer(const rl4co_am_encoder_args& a, hipStream_t stream) {
   // whole-instance ("layer") statistics: its own instantiation — the batch / instance kernel's code stays as tuned — with
   // the generic key-tile masks (VR4 = 4 serves every N of the tile count)
-  const int lds = 2 * 128 * kRS * 2 + kD * 4 + kBiasFloats * 4;
+  const int lds = kEncLds;
   RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_encoder_kernel<E, TT, 4, false, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipLaunchKernelGGL((am_encoder_kernel<E, TT, 4, false, true>), dim3(a.B), dim3(kThreads), lds, stream, a, TrainSave<E>{});
@@ -1430,17 +1493,22 @@ int launch_encoder_tiles(const rl4co_am_encoder_args& a, hipStream_t stream) {
 
 template <typename E>
 int launch_encoder_elem(const rl4co_am_encoder_args& a, hipStream_t s) {
+#ifdef RL4CO_ENC_PROBE  // tools/enc_variants.sh: one instantiation (TSP-100, batch norm) so that a probe build takes seconds
+  RL4CO_REQUIRE((a.N + 31) / 32 == 4 && (a.N - 96 + 7) / 8 == 1 && a.norm != 2);
+  return launch_encoder<E, 4, 1>(a, s);
+#else
   switch ((a.N + 31) / 32) {
     case 1: return launch_encoder_tiles<E, 1>(a, s);
     case 2: return launch_encoder_tiles<E, 2>(a, s);
     case 3: return launch_encoder_tiles<E, 3>(a, s);
     default: return launch_encoder_tiles<E, 4>(a, s);
   }
+#endif
 }
 
 template <typename E, int TT, int VR4>
 int launch_train(const rl4co_am_encoder_args& a, const TrainSave<E>& ts, hipStream_t stream) {
-  const int lds = 2 * 128 * kRS * 2 + kD * 4 + kBiasFloats * 4;
+  const int lds = kEncLds;
   RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_encoder_kernel<E, TT, VR4, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipLaunchKernelGGL((am_encoder_kernel<E, TT, VR4, true>), dim3(a.B), dim3(kThreads), lds, stream, a, ts);
@@ -1469,12 +1537,17 @@ int launch_train_elem(const rl4co_am_encoder_args& a, const rl4co_am_train_save&
   ts.y2 = static_cast<E*>(sv.y2);
   ts.lse = sv.lse;
   ts.stats = sv.stats;
+#ifdef RL4CO_ENC_PROBE
+  RL4CO_REQUIRE((a.N + 31) / 32 == 4 && (a.N - 96 + 7) / 8 == 1);
+  return launch_train<E, 4, 1>(a, ts, s);
+#else
   switch ((a.N + 31) / 32) {
     case 1: return launch_train_tiles<E, 1>(a, ts, s);
     case 2: return launch_train_tiles<E, 2>(a, ts, s);
     case 3: return launch_train_tiles<E, 3>(a, ts, s);
     default: return launch_train_tiles<E, 4>(a, ts, s);
   }
+#endif
 }
 
 }  // namespace
@@ -1489,7 +1562,12 @@ extern "C" int rl4co_am_encoder_train_fwd(const rl4co_am_encoder_args* args, con
   RL4CO_REQUIRE(a.bqkv && a.b1 && a.n1_scale && a.n1_shift && a.n2_scale && a.n2_shift);
   RL4CO_REQUIRE(save->x0 && save->out && save->qkv && save->att && save->y1 && save->x1 && save->h && save->y2 && save->lse && save->stats);
   hipStream_t s = rl4co::as_stream(stream);
+#ifdef RL4CO_ENC_PROBE
+  RL4CO_REQUIRE(a.act_dtype == RL4CO_DT_BF16);
+  return launch_train_elem<__bf16>(a, *save, s);
+#else
   return a.act_dtype == RL4CO_DT_F16 ? launch_train_elem<_Float16>(a, *save, s) : launch_train_elem<__bf16>(a, *save, s);
+#endif
 }
 
 template <typename E, int TT>
@@ -1544,7 +1622,12 @@ extern "C" int rl4co_am_encoder(const rl4co_am_encoder_args* args, void* stream)
   RL4CO_REQUIRE(a.q_bias == nullptr || a.w_fixed != nullptr);
   RL4CO_REQUIRE(a.kvl_batch_stride >= (int64_t)a.N * kD && a.kvl_plane_stride >= a.kvl_batch_stride);
   hipStream_t s = rl4co::as_stream(stream);
+#ifdef RL4CO_ENC_PROBE
+  RL4CO_REQUIRE(a.act_dtype == RL4CO_DT_BF16);
+  return launch_encoder_elem<__bf16>(a, s);
+#else
   return a.act_dtype == RL4CO_DT_F16 ? launch_encoder_elem<_Float16>(a, s) : launch_encoder_elem<__bf16>(a, s);
+#endif
 }
 
 extern "C" int64_t rl4co_am_encoder_tokens16_workspace(int B, int N) {

@@ -190,6 +190,25 @@ class PackedEncoder:
         self.t, self.version = t, ver
         return t
 
+    def _stack_shape_ok(self) -> bool:
+        """Every kernel (fused, token-tile, fp32) has the AttentionModel's layer shape compiled in: 8 heads over 128
+        channels, a 128 -> 512 -> 128 MLP with biases (csrc/am_encoder.hip: kD, kFF). The constructor accepts other
+        ``feedforward_hidden`` / ``num_heads`` values (zoo/am/encoder.py:40-57); those stacks are NOT packed — packed with
+        the wrong shape the kernels would index ``layer * 512 * 128`` into a smaller weight block — and the caller's torch
+        or per-op path serves them."""
+        for layer in self.policy.encoder.net.layers:
+            attn, ffn = layer[0].module, layer[2].module
+            lins = getattr(ffn, "lins", None)
+            if lins is None or len(lins) != 2 or getattr(attn, "num_heads", None) != 8:
+                return False
+            if tuple(attn.Wqkv.weight.shape) != (3 * EMBED_DIM, EMBED_DIM) or tuple(attn.out_proj.weight.shape) != (EMBED_DIM, EMBED_DIM):
+                return False
+            if tuple(lins[0].weight.shape) != (4 * EMBED_DIM, EMBED_DIM) or tuple(lins[1].weight.shape) != (EMBED_DIM, 4 * EMBED_DIM):
+                return False
+            if any(lin.bias is None for lin in (attn.Wqkv, attn.out_proj, lins[0], lins[1])):
+                return False
+        return True
+
     def supported(self, td, act_dtype: torch.dtype | None = None) -> bool:
         """``act_dtype=torch.float32``: the exact-fp32 kernels — the fused one up to 128 nodes, the token-tile launches
         (csrc/am_tokens_f32.hip) for any graph size; every normalisation kind of nn/ops.py:30-54 (batch in eval mode)."""
@@ -198,7 +217,11 @@ class PackedEncoder:
         kind = pol.encoder.net.layers[0][1].kind
         if kind == "batch" and pol.training:  # batch statistics couple instances: torch path
             return False
+        if not self._stack_shape_ok():
+            return False
         if n > _lib.lib().rl4co_am_encoder_max_nodes():
+            if td["locs"].shape[0] > 65535:  # the token-tile launches carry the instance in grid.y
+                return False
             # token-tile launches (fp32: csrc/am_tokens_f32.hip; 16-bit: the token kernels of csrc/am_encoder.hip). Instance /
             # layer statistics couple all nodes of an instance: the layer's halves then stop before their norm and an apply
             # kernel normalises with the tiles' combined statistics. The staged features must fit the LDS
