@@ -247,6 +247,13 @@ def _r(x, digits=4):
     return x
 
 
+def _spread(ms: list, steps: int) -> dict:
+    """min / median / max of the per-step time over the repeated K-step regions of one leg."""
+    import statistics
+
+    return {"min": min(ms), "median": statistics.median(ms), "max": max(ms), "n": len(ms), "steps": steps}
+
+
 def compact_roofline(r: dict | None) -> dict | None:
     if not r:
         return None
@@ -303,16 +310,20 @@ def compact_line(detail: dict, head_name: str, results: dict, detail_path: str) 
     if detail.get("encoder_roofline"):
         line["encoder_roofline"] = compact_roofline(detail["encoder_roofline"])
     for k in ("node_steps_per_sec", "instances_per_sec", "graph_ms_per_step", "eager_ms_per_step", "train_ms_per_step", "rccl_ranks",
-              "n1_ms_per_step", "scaling_efficiency", "allreduce_ms"):
+              "collective_ranks", "collective_backend", "n1_ms_per_step", "scaling_efficiency", "allreduce_ms"):
         if detail.get(k) is not None:
             line[k] = _r(detail[k])
     if detail.get("rank_ms_per_step"):
         line["rank_ms_per_step"] = {k: _r(v) for k, v in detail["rank_ms_per_step"].items()}
+    if detail.get("region_ms_per_step"):  # min / median / max over the repeated K-step regions (ms_per_step = the first one)
+        line["region_ms_per_step"] = {k: _r(v) for k, v in detail["region_ms_per_step"].items()}
     legs = {}
     for name, r in results.items():
         if name == head_name:
             continue
         legs[name] = {"ms_per_step": _r(r["ms_per_step"]), "value": _r(r["value"])}
+        if r.get("region_ms_per_step"):
+            legs[name]["ms_min_med"] = [_r(r["region_ms_per_step"]["min"]), _r(r["region_ms_per_step"]["median"])]
         if r.get("roofline"):
             legs[name]["frac"] = _r(r["roofline"]["frac"], 3)
         if r.get("scaling_efficiency") is not None:
@@ -489,6 +500,13 @@ class Bench:
             own_wall, rows, inst_steps, out = region(steps)
             self.barrier()
             wall = own_wall
+            # spread: REGIONS - 1 further barrier-bracketed K-step regions right after the contract's one (same steps, same
+            # data); `value` / `ms_per_step` stay those of the FIRST region, min / median / max over all of them go beside it
+            region_ms = [own_wall / steps * 1e3]
+            for _ in range(a.regions - 1):
+                self.barrier()
+                region_ms.append(region(steps)[0] / steps * 1e3)
+            self.barrier()
         if not use_graph:
             decode_ms = [x.elapsed_time(y) for x, y in policy.decode_events]
             encode_ms = [x.elapsed_time(y) for x, y in policy.encode_events]
@@ -506,8 +524,11 @@ class Bench:
         wall_min = -self.D.reduce_scalar(-own_wall, "max", self.device)
         total_inst_steps = int(self.D.reduce_scalar(inst_steps, "sum", self.device))
         res = {"wall": wall}
+        # per region the slowest rank's time (what the contract's max-over-ranks clock would have shown for that region)
+        region_ms = [self.D.reduce_scalar(x, "max", self.device) for x in region_ms]
         if self.rank != 0:
             return res
+        res["region_ms_per_step"] = _spread(region_ms, steps)
         if self.world > 1:
             res["rank_ms_per_step"] = {"min": wall_min / steps * 1e3, "max": wall / steps * 1e3}
             if solo_ms is not None:
@@ -570,9 +591,14 @@ class Bench:
                            " (init embedding + 3 x [MHA, norm, FFN, norm] + cache fold, one workgroup per instance)") if n_nodes <= 128 else
                           ("token-tile encoder, " + ("am_tokens_f32.hip" if exact else "tok16_* + attn_flash") +
                            " (init embedding, 3 x [QKV, streamed attention, out-proj + norm + MLP + norm], fold: sum of the launches)"),
-                "bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
+                # beyond 128 nodes the 16-bit encoder's time is its attention kernel (d_h = 16: one exponential per 32 matrix
+                # FLOPs), bound by transcendental / VALU issue — priced against the MFMA peak only for continuity
+                "bound": "mfma" if (exact or n_nodes <= 128) else "valu_exp",
+                "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak,
                 "flop_per_instance": flop_inst, "launch_ms_mean": enc_ms,
-                "note": "algorithmic FLOPs at N nodes (padding excluded); " + ("fp32 MFMA peak" if exact else "16-bit dense MFMA peak"),
+                "note": "algorithmic FLOPs at N nodes (padding excluded); " + ("fp32 MFMA peak" if exact else "16-bit dense MFMA peak") +
+                        ("" if (exact or n_nodes <= 128) else "; the attention launches (59 % of the time) are exp-issue bound: "
+                         f"{layers_ * 8 * n_ * n_ * batch / 1e9:.1f} G exponentials per pass at a quarter of the VALU rate"),
             }
         if full and self.world == 1 and not a.no_parity:
             from tools import trained_parity as TP
@@ -650,33 +676,52 @@ class Bench:
         gc.collect()
         gc.freeze()
         solo_ms = None
-        if self.world > 1 and self.args.solo:  # N = 1 reference of this invocation: rank 0 alone, no collective
+        if self.world > 1 and self.args.solo:
+            # N = 1 reference of this invocation: rank 0 alone, the same K steps WITHOUT the collective (nobody is there to
+            # answer: the region leaves out the all-reduce's launch and wait, stated in the detail file). Its optimizer steps
+            # are undone afterwards — weights and Adam state restored — so the replicas enter the joint region identical
             self.barrier()
             if self.rank == 0:
+                import copy
+
+                snap_p = [p.detach().clone() for p in policy.parameters()]
+                snap_o = copy.deepcopy(opt.state_dict())
                 t0 = time.perf_counter()
                 for i in range(steps):
                     step(warmup + i, collective=False)
                 torch.cuda.synchronize()
                 solo_ms = (time.perf_counter() - t0) / steps * 1e3
+                with torch.no_grad():
+                    for p, q in zip(policy.parameters(), snap_p):
+                        p.copy_(q)
+                opt.load_state_dict(snap_o)
+                del snap_p, snap_o
                 policy.decode_events, T.backward_events = [], []
-        self.barrier()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            out = step(warmup + steps + i)
-        torch.cuda.synchronize()
-        own_wall = time.perf_counter() - t0
+        region_ms = []
+        for r in range(self.args.regions):  # the contract's region first; the further ones only feed `region_ms_per_step`
+            self.barrier()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                o = step(warmup + (r + 1) * steps + i)
+            torch.cuda.synchronize()
+            region_ms.append((time.perf_counter() - t0) / steps * 1e3)
+            if r == 0:
+                own_wall, out = time.perf_counter() - t0, o
         self.barrier()
         policy.check_backward_errors()
         wall = D.reduce_scalar(own_wall, "max", self.device)
         wall_min = -D.reduce_scalar(-own_wall, "max", self.device)
+        region_ms = [D.reduce_scalar(x, "max", self.device) for x in region_ms]
         res = {"wall": wall}
         if self.rank != 0:
             return res
+        res["region_ms_per_step"] = _spread(region_ms, steps)
         if self.world > 1:
             res["rank_ms_per_step"] = {"min": wall_min / steps * 1e3, "max": wall / steps * 1e3}
             if solo_ms is not None:
                 res["n1_ms_per_step"] = solo_ms
                 res["scaling_efficiency"] = solo_ms / (wall / steps * 1e3)
+                res["n1_note"] = "solo region: rank 0 alone, no collective launched (its launch + wait are in the joint region only)"
         t_steps = out["actions"].shape[1]
         traj = batch * starts * self.world * steps
         ar_ms = [x.elapsed_time(y) for x, y in ar_events]
@@ -875,6 +920,12 @@ def main() -> None:
     ap.add_argument("--train-encoder", default="stack", choices=["stack", "blocks"],
                     help="c4_train: the encoder's training forward as one launch for the whole stack (default) or per sub-block")
     ap.add_argument("--pipeline-depth", type=int, default=2, help="captured rollouts in flight (--launch pipeline)")
+    ap.add_argument("--regions", type=int, default=5,
+                    help="barrier-bracketed K-step regions per leg: the first is the contract's (value, ms_per_step), min / median / "
+                         "max over all of them are reported as region_ms_per_step")
+    ap.add_argument("--timeout", type=float, default=float(os.environ.get("RL4CO_BENCH_TIMEOUT", "1500")),
+                    help="seconds after which a rank dumps every thread's stack and exits non-zero instead of hanging (a peer that "
+                         "died leaves the others in a barrier; torch.distributed.run then tears the job down)")
     ap.add_argument("--no-check-solution", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
@@ -897,6 +948,10 @@ def main() -> None:
         os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                                   "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                                   os.path.abspath(__file__), *sys.argv[1:]])
+    if args.timeout > 0 and not os.environ.get("RL4CO_BENCH_WATCHDOG"):  # fail loudly, never hang: stacks to stderr, exit code 1
+        import faulthandler
+
+        faulthandler.dump_traceback_later(args.timeout, exit=True)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -925,6 +980,8 @@ def main() -> None:
     if world > 1 or "c4_train" in legs:
         D.init_process_group(os.environ.get("RL4CO_DIST_BACKEND", "nccl"), device=device, single_process_ok=True)
 
+    if os.environ.get("RL4CO_BENCH_KILL_RANK") == str(rank) and world > 1:  # tests/test_gpu_bench_cli.py: a rank that dies
+        os._exit(17)
     bench = Bench(args, rank, world, device)
     # untimed device warm-up before the first leg: ~1 s of plain HBM reads (the read-probe kernel) so that clocks, the power
     # state and the code-object loader have settled when the first timed region starts — between fresh boxes the first two
@@ -1000,7 +1057,7 @@ def main() -> None:
             },
         }
         for k in ("node_steps_per_sec", "instances_per_sec", "mean_reward", "roofline", "rollout_roofline", "encoder_roofline", "host_gap_ms", "launch",
-                  "eager_ms_per_step", "graph_ms_per_step",
+                  "eager_ms_per_step", "graph_ms_per_step", "region_ms_per_step", "n1_note",
                   "trajectories_per_sec", "collective", "rank_ms_per_step", "n1_ms_per_step", "scaling_efficiency"):
             if k in head:
                 detail[k] = head[k]
@@ -1009,7 +1066,10 @@ def main() -> None:
         detail["legs"] = {name: {k: v for k, v in r.items() if k != "wall"} for name, r in results.items() if name != head_name}
         if "c4_train" in results and head_name != "c4_train":
             detail["train_ms_per_step"] = results["c4_train"]["ms_per_step"]
-            detail["rccl_ranks"] = results["c4_train"]["collective"]["ranks"]
+            coll = results["c4_train"]["collective"]
+            detail["collective_backend"] = coll["backend"]
+            # "nccl" IS RCCL on ROCm; any other backend (gloo: the shared-GPU test mode) is reported under its own name
+            detail["rccl_ranks" if coll["backend"] == "nccl" else "collective_ranks"] = coll["ranks"]
             detail["allreduce_ms"] = results["c4_train"]["collective"]["allreduce_ms_mean"]
         if world == 1 and not args.no_parity:
             log("parity vs the reference's tours (trained weights, every inference leg)")

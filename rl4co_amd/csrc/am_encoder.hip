@@ -82,6 +82,8 @@ __device__ inline f32x16 bias_tile(const float* bias, int dim0, int hi) {
 }
 constexpr int kBiasFloats = 3 * kD + kFF;  // per layer: bqkv [384] | b1 [512]
 constexpr int kNormFloats = 4 * kD;         // per layer: n1 scale | n1 shift | n2 scale | n2 shift
+constexpr int kEncLds = 2 * 128 * kRS * 2 + kD * 4 + kBiasFloats * 4 + 2 * kNormFloats * 4;  // 77 824 B per instance: two per CU
+static_assert(2 * kEncLds <= 160 * 1024, "am_encoder_kernel is built for two instances per CU");
 
 __device__ inline f32x16 zero16() {
   f32x16 z;
@@ -518,11 +520,34 @@ __device__ inline float wave_max32(float v) {  // maximum over the 32 token colu
 // (Barriers are LDS-only — `s_waitcnt lgkmcnt(0); s_barrier` — not __syncthreads(): every hand-over between the waves is
 // LDS data, and __syncthreads()'s vmcnt(0) would make each of them wait for the acknowledgement of the global stores issued
 // before it — neutral for inference (0.965 vs 0.965 ms, tools/ab_encoder.sh), but the TRAIN variant writes 12 passes per layer.)
-template <typename E, int TT, int VR4, bool TRAIN = false, bool LAYER = false>
-__global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_encoder_args a, const TrainSave<E> ts) {
+// DUAL (r05, inference): ONE 512-thread workgroup per CU carries TWO instances ("halves": threads 0-255 / 256-511, each
+// with its own LDS set) through the same barrier sequence, half 1 running kDualOffset barrier intervals behind half 0, and
+// loops over its share of the batch. Two independent 256-thread workgroups meet on a SIMD at whatever phase the dispatcher
+// left them in: r05 counters (profiles/r05_encoder_variants.json) show a wave stalled on the matrix pipe 42 % of its life
+// (the partner's MFMAs) while the pipe idles 52 % of the time — both halves in a GEMM, then both in an epilogue. With the
+// barriers shared, the offset pairs one half's VALU-heavy intervals (attention, norms) with the other's GEMM intervals
+// (FFN); kDualSplit adds the barriers that cut the QKV / attention stretch into intervals of the FFN's length.
+#ifndef RL4CO_ENC_DUAL_OFFSET
+#define RL4CO_ENC_DUAL_OFFSET 8
+#endif
+#ifndef RL4CO_ENC_DUAL_SPLIT
+#define RL4CO_ENC_DUAL_SPLIT 1
+#endif
+#ifndef RL4CO_ENC_DUAL_PERSIST
+#define RL4CO_ENC_DUAL_PERSIST 1
+#endif
+constexpr int kDualOffset = RL4CO_ENC_DUAL_OFFSET;
+constexpr bool kDualSplit = RL4CO_ENC_DUAL_SPLIT != 0;
+constexpr bool kDualPersist = RL4CO_ENC_DUAL_PERSIST != 0;  // one workgroup per CU walking the batch (0: one per pair of instances)
+
+template <typename E, int TT, int VR4, bool TRAIN = false, bool LAYER = false, bool DUAL = false>
+__global__ void __launch_bounds__(DUAL ? 2 * kThreads : kThreads, 2) am_encoder_kernel(const rl4co_am_encoder_args a, const TrainSave<E> ts) {
+  static_assert(!DUAL || (!TRAIN && !LAYER), "the dual-instance form serves the inference kernels");
   using bf16x8 = vec8<E>;  // (historic names: the 16-bit operand fragments of whichever element type E is)
   using bf16x4 = vec4<E>;
-  extern __shared__ __align__(16) unsigned char smem[];
+  extern __shared__ __align__(16) unsigned char smem_all[];
+  const int half = DUAL ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;  // wave-uniform: a scalar (LDS bases stay in SGPRs)
+  unsigned char* smem = smem_all + (DUAL ? half * kEncLds : 0);
   E* xs = reinterpret_cast<E*>(smem);  // residual stream [128][kRS]
   E* ys = xs + 128 * kRS;              // Q^T (wave-private columns) -> attention output -> FFN hidden chunk
   float* meanv = reinterpret_cast<float*>(ys + 128 * kRS);  // [128]
@@ -532,20 +557,32 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
   // wave stages layer l + 1 while a slow one still reads layer l's second norm.
   float* nl = bl + kBiasFloats;                              // [2][kNormFloats]
   auto stage_biases = [&](int layer) {
-    for (int i = threadIdx.x; i < kBiasFloats; i += kThreads)
+    for (int i = threadIdx.x & (kThreads - 1); i < kBiasFloats; i += kThreads)
       bl[i] = i < 3 * kD ? a.bqkv[layer * 3 * kD + i] : a.b1[layer * kFF + i - 3 * kD];
 #ifdef RL4CO_ENC_NORMLDS
-    for (int i = threadIdx.x; i < kNormFloats; i += kThreads) {
+    for (int i = threadIdx.x & (kThreads - 1); i < kNormFloats; i += kThreads) {
       const float* src = i < 2 * kD ? (i < kD ? a.n1_scale : a.n1_shift) : (i < 3 * kD ? a.n2_scale : a.n2_shift);
       nl[(layer & 1) * kNormFloats + i] = src[layer * kD + (i & (kD - 1))];
     }
 #endif
   };
 
-  int tid = threadIdx.x;
+  int tid = threadIdx.x & (kThreads - 1);
   int w = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;  // (not const: see the top of the layer loop)
-  const int b = blockIdx.x;
   const int N = a.N;
+  // DUAL: the workgroup walks pairs of instances; a half whose share is exhausted repeats the batch's last instance (the
+  // same values to the same addresses) — both halves must pass the same number of barriers
+  const int iters = (DUAL && kDualPersist) ? (a.B + 2 * (int)gridDim.x - 1) / (2 * (int)gridDim.x) : 1;
+  if (DUAL && half == 1)
+    for (int i = 0; i < kDualOffset; ++i) rl4co::lds_barrier();
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+  const int b = DUAL ? min(2 * ((int)blockIdx.x + it * (int)gridDim.x) + half, a.B - 1) : (int)blockIdx.x;
+  if constexpr (DUAL) {  // (as at the top of the layer loop: no per-lane address survives from one instance to the next)
+    asm volatile("" : "+v"(tid), "+v"(w), "+v"(lane));
+    l31 = lane & 31;
+    hi = lane >> 5;
+  }
 
   const E* wqkv_all = static_cast<const E*>(a.wqkv_packed);
   const E* wo_all = static_cast<const E*>(a.wo_packed);
@@ -625,6 +662,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       // row, and later overwrites it with the attention output of that same row)
       store_t<TT>(ys, acc, 32 * w, lane);
       if constexpr (TRAIN) save_t<TT>(ts.qkv + ((int64_t)layer * a.B + b) * N * 3 * kD, 3 * kD, acc, 32 * w, N, lane);
+      if constexpr (DUAL && kDualSplit) rl4co::lds_barrier();  // interval a1 | a2 (no LDS hazard: pacing against the other half)
       gemm_t<TT, true, true, 1>(acc, wf, xs, lane, L.wqkv, 8, 8 + w, 0, bias_tile(L.bqkv + kD, 32 * w, hi));
       if constexpr (TRAIN) save_t<TT>(ts.qkv + ((int64_t)layer * a.B + b) * N * 3 * kD + kD, 3 * kD, acc, 32 * w, N, lane);
 #pragma unroll
@@ -636,6 +674,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         kn2[0] = fmaxf(kn2[0], h0);
         kn2[1] = fmaxf(kn2[1], h1);
       }
+      if constexpr (DUAL && kDualSplit) rl4co::lds_barrier();  // a2 | a3
       // V = X . Wv^T: A = token rows from LDS, B = weight fragment -> C[row = token][col = dim]
       {
         const float bv = L.bqkv[2 * kD + 32 * w + l31];  // plain form: the bias belongs to the lane's dim column
@@ -669,6 +708,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         }
       }
     }
+    if constexpr (DUAL && kDualSplit) rl4co::lds_barrier();  // a3 | a4 (attention, one interval per query tile)
     // |score| <= max_i |q_i| max_j |k_j| per head (Cauchy-Schwarz; fp32 norms, the products see their bf16 roundings:
     // the bound keeps a wide margin): below kFastBound the softmax needs no running maximum
     bool fast_head[2];
@@ -780,6 +820,9 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = (E)o[4 * c + i];
         *reinterpret_cast<bf16x4*>(qrow + 8 * c + 4 * hi) = v;
+      }
+      if constexpr (DUAL && kDualSplit) {
+        if (qt + 1 < TT) rl4co::lds_barrier();
       }
     }
 #if RL4CO_ENC_PRIO == 2
@@ -929,6 +972,9 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       if (lane == r) a.q_bias[(int64_t)b * kD + 32 * w + r] = acc;
     }
   }
+  }  // instance loop
+  if (DUAL && half == 0)
+    for (int i = 0; i < kDualOffset; ++i) rl4co::lds_barrier();
 }
 
 // ================================================================================================================
@@ -1454,11 +1500,34 @@ int launch_tokens16(const rl4co_am_encoder_args& a, void* workspace, hipStream_t
   return RL4CO_OK;
 }
 
-constexpr int kEncLds = 2 * 128 * kRS * 2 + kD * 4 + kBiasFloats * 4 + 2 * kNormFloats * 4;  // 77 824 B: two workgroups per CU
-static_assert(2 * kEncLds <= 160 * 1024, "am_encoder_kernel is built for two workgroups per CU");
+#ifndef RL4CO_ENC_DUAL
+#define RL4CO_ENC_DUAL 1  // inference (batch / instance norm): the dual-instance workgroups; 0 = one 256-thread workgroup per instance
+#endif
+
+inline int compute_units() {
+  static const int n = [] {
+    int dev = 0, cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
+    return cu;
+  }();
+  return n;
+}
 
 template <typename E, int TT, int VR4>
 int launch_encoder(const rl4co_am_encoder_args& a, hipStream_t stream) {
+#if RL4CO_ENC_DUAL
+  static const bool dual = [] { const char* e = getenv("RL4CO_ENC_DUAL"); return !(e && e[0] == '0'); }();  // (probe knob)
+  if (dual) {
+    const int lds = 2 * kEncLds;
+    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_encoder_kernel<E, TT, VR4, false, false, true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int pairs = (a.B + 1) / 2;
+    hipLaunchKernelGGL((am_encoder_kernel<E, TT, VR4, false, false, true>), dim3(kDualPersist ? min(pairs, compute_units()) : pairs), dim3(2 * kThreads), lds, stream, a,
+                       TrainSave<E>{});
+    RL4CO_HIP_TRY(hipGetLastError());
+    return RL4CO_OK;
+  }
+#endif
   const int lds = kEncLds;
   RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_encoder_kernel<E, TT, VR4, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));

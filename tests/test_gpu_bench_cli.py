@@ -57,7 +57,16 @@ def test_single_gpu_line_has_the_contract_keys():
 def test_default_legs_line_stays_small_and_carries_baseline_and_parity():
     """The driver's own command shape (all legs, parity block, cpu_baseline) must still fit the line."""
     line = _run(["--steps", "10", "--warmup", "2", "--leg-steps", "4"], timeout=900)
-    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0 and line["cpu_baseline"]["cores"] >= 1
+    cb = line["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    # BASELINE.md §3: C1 (TSP-20 x 256, check_solution on / off) and the headline workload, 1 warm-up + >= 5 passes, median
+    # and best, a one-thread figure
+    assert cb["passes"] >= 5 and cb["best"] >= cb["value"] > 0 and cb["c1_best"] >= cb["c1_value"] > 0 and cb["c1_nocheck_value"] > 0
+    assert cb["one_thread"]["c1"] > 0
+    # spread over the repeated K-step regions, headline and legs
+    rs = line["region_ms_per_step"]
+    assert rs["n"] >= 5 and rs["min"] <= rs["median"] <= rs["max"] and rs["min"] <= line["ms_per_step"] <= rs["max"]
+    assert all(len(v["ms_min_med"]) == 2 for v in line["legs"].values())
     assert set(line["legs"]) >= {"c2_sampling", "c3_greedy", "c5_sampling", "c4_train", "c2_greedy_fp32"}
     assert all(v["ms_per_step"] > 0 for v in line["legs"].values())
     assert line["parity"]["c2_fp32_tours"].endswith("/4096") and len(line["parity"]) <= 10
@@ -71,7 +80,9 @@ def test_two_ranks_self_spawned():
     extra = {} if two_gpus else {"RL4CO_BENCH_SHARED_GPU": "1", "RL4CO_DIST_BACKEND": "gloo"}
     line = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--legs", "c2_greedy,c4_train", "--no-cpu-baseline", "--no-parity"],
                 env_extra=extra)
-    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2
+    assert line["n_gpus"] == 2 and line["collective_backend"] == ("nccl" if two_gpus else "gloo")
+    # "rccl_ranks" only when the collective really ran on RCCL; gloo ranks (two processes sharing one GPU) say so
+    assert line["rccl_ranks" if two_gpus else "collective_ranks"] == 2 and ("rccl_ranks" in line) == two_gpus
     assert line["rank_ms_per_step"]["min"] <= line["rank_ms_per_step"]["max"] == pytest.approx(line["ms_per_step"], rel=1e-3)
     assert 0 < line["scaling_efficiency"] and line["n1_ms_per_step"] > 0 and line["allreduce_ms"] > 0
     train = _detail(line)["legs"]["c4_train"]
@@ -79,3 +90,30 @@ def test_two_ranks_self_spawned():
     assert train["roofline"]["bound"] == "mfma" and train["rollout_roofline"]["launch_ms_mean"] > 0
     # whole-job throughput: both ranks' instance-steps over the max-over-ranks wall time
     assert abs(line["value"] - 2 * 4096 * 100 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
+
+
+def test_all_visible_gpus_on_rccl():
+    """Every GPU of the node, one rank each, the driver's own multi-GPU command shape — RCCL for real (the
+    REINFORCE gradient all-reduce, rl4co/utils/trainer.py:83-86). Needs >= 2 GPUs: the one-GPU boxes skip it."""
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("one GPU visible: RCCL with more than one rank needs a multi-GPU node")
+    line = _run(["--gpus", str(n), "--steps", "6", "--warmup", "2", "--legs", "c2_greedy,c4_train", "--no-cpu-baseline", "--no-parity"],
+                timeout=900)
+    assert line["n_gpus"] == n and line["collective_backend"] == "nccl" and line["rccl_ranks"] == n
+    assert 0.5 < line["scaling_efficiency"] <= 1.2 and line["allreduce_ms"] > 0
+    assert line["legs"]["c4_train"]["scaling_efficiency"] > 0.5
+    assert abs(line["value"] - n * 4096 * 100 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
+
+
+def test_a_dead_rank_fails_the_run_instead_of_hanging():
+    """One rank exits before its first barrier: the job must END with a non-zero status well inside the timeout (the
+    launcher tears the survivors down; bench.py's own --timeout is the backstop), not sit in a collective."""
+    two_gpus = torch.cuda.device_count() >= 2
+    env = dict(os.environ, RL4CO_BENCH_KILL_RANK="1")
+    if not two_gpus:
+        env.update(RL4CO_BENCH_SHARED_GPU="1", RL4CO_DIST_BACKEND="gloo")
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--legs", "c2_greedy",
+                           "--no-cpu-baseline", "--no-parity", "--timeout", "120"], capture_output=True, text=True, timeout=400, env=env, cwd=ROOT)
+    assert proc.returncode != 0
+    assert not [ln for ln in proc.stdout.splitlines() if ln.strip().startswith("{")], "no result line from a broken run"

@@ -449,3 +449,22 @@ def test_token_tile_attention_fast_and_exact_paths_agree():
         assert _rel(o, want) <= 1e-2, name
     assert torch.equal(out["exact"], out["null"])
     assert _rel(out["fast"], out["exact"]) <= 5e-3
+
+
+@pytest.mark.parametrize("rows", [1, 2, 3, 5, 63])
+def test_fused_encoder_rows_do_not_depend_on_the_batch(rows):
+    """Instances are independent: the planes of the first `rows` instances encoded alone are bit-identical to the same rows
+    of the full batch — whatever the kernel's grouping of instances (r05: two instances per workgroup, a persistent walk
+    over the batch; an odd count leaves one half of the last workgroup repeating the final instance)."""
+    g = GoldenCase("tsp100_b64_greedy")
+    pol = _policy(g, encoder_autocast=torch.bfloat16, cache_dtype=torch.bfloat16)
+    _perturb_norm_stats(pol)
+    env, td = _td(g)
+    packed = pol._packed_encoder()
+    with torch.inference_mode():
+        full, hid = packed.encode(td, torch.bfloat16, want_hidden=True)
+        part, hid_p = packed.encode(td[:rows], torch.bfloat16, want_hidden=True)
+        torch.cuda.synchronize()
+    assert torch.equal(part.kvl, full.kvl[:, :rows]) and torch.equal(hid_p, hid[:rows])
+    assert torch.equal(part.ctx_cur, full.ctx_cur[:rows]) and torch.equal(part.ctx_first, full.ctx_first[:rows])
+    assert torch.equal(part.q_bias, full.q_bias[:rows])
