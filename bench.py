@@ -152,7 +152,7 @@ def _cpu_rollout_passes(pol, env, data, batch: int, chunk: int, passes: int) -> 
     return times, work, float(torch.cat(rewards).mean())
 
 
-def cpu_baseline(env_name: str, num_loc: int, sample_batch: int, repeats: int = 5, chunk: int = 512) -> dict:
+def cpu_baseline(env_name: str, num_loc: int, sample_batch: int, repeats: int = 5, chunk: int = 512, budget_s: float = 12.0) -> dict:
     """The reference path on the host cores, by the protocol of BASELINE.md §3: the oracle restatement (stock ATen ops,
     fp32, the reference's ops in the reference's order: kind "port"), greedy rollout, span = reset -> policy -> reward
     under inference_mode, 1 warm-up + `repeats` (>= 5) timed rollouts, MEDIAN and MIN, thread count reported, a 1-thread
@@ -191,7 +191,7 @@ def cpu_baseline(env_name: str, num_loc: int, sample_batch: int, repeats: int = 
                 per_inst, threads = best_c, cand
         torch.set_num_threads(threads)
         # ---- the headline workload on a bounded sample: ~12 s for the 1 + repeats passes on any host --------------------
-        budget_b = int(12.0 / (repeats + 1) / max(per_inst, 1e-6))
+        budget_b = int(budget_s / (repeats + 1) / max(per_inst, 1e-6))
         if budget_b < sample_batch:
             sample_batch = max(probe_b, budget_b // 64 * 64)
             data = {k: v[:sample_batch] for k, v in data.items()}

@@ -36,9 +36,6 @@
 
 namespace {
 
-#ifndef RL4CO_ENC_PRIO
-#define RL4CO_ENC_PRIO 0  // probe (tools/enc_variants.sh): 1 = GEMM calls at priority 2, 2 = GEMM calls + attention, 3 = epilogues
-#endif
 constexpr int kD = RL4CO_EMBED_DIM;
 constexpr int kFF = 512;
 constexpr int kRS = kD + 8;  // LDS row stride (bf16 elements): 272 B rows spread the banks
@@ -81,9 +78,8 @@ __device__ inline f32x16 bias_tile(const float* bias, int dim0, int hi) {
   return t;
 }
 constexpr int kBiasFloats = 3 * kD + kFF;  // per layer: bqkv [384] | b1 [512]
-constexpr int kNormFloats = 4 * kD;         // per layer: n1 scale | n1 shift | n2 scale | n2 shift
-constexpr int kEncLds = 2 * 128 * kRS * 2 + kD * 4 + kBiasFloats * 4 + 2 * kNormFloats * 4;  // 77 824 B per instance: two per CU
-static_assert(2 * kEncLds <= 160 * 1024, "am_encoder_kernel is built for two instances per CU");
+constexpr int kEncLds = 2 * 128 * kRS * 2 + kD * 4 + kBiasFloats * 4;  // 73 728 B per workgroup: two per CU
+static_assert(2 * kEncLds <= 160 * 1024, "am_encoder_kernel is built for two workgroups per CU");
 
 __device__ inline f32x16 zero16() {
   f32x16 z;
@@ -137,11 +133,6 @@ template <int TT, bool W_IS_A = true, bool INIT = true, int NEXT = -1, typename 
 __device__ inline void gemm_t(f32x16 (&acc)[TT], vec8<E> (&wf)[8], const E* xs, int lane, const E* nxt_packed,
                               int nxt_ksteps_total, int nxt_tile, int nxt_k0, const f32x16& cinit) {
   const int l31 = lane & 31, hi = lane >> 5;
-#if RL4CO_ENC_PRIO == 1 || RL4CO_ENC_PRIO == 2
-  __builtin_amdgcn_s_setprio(2);
-#elif RL4CO_ENC_PRIO == 3
-  __builtin_amdgcn_s_setprio(0);
-#endif
   // Every MFMA takes one 1 KiB activation fragment from LDS. With the fragments of k-step ks + 1 requested while k-step
   // ks computes (TT MFMAs = 128 cycles at TT = 4), the eight waves of a CU keep the LDS queue deep enough that the
   // data is NOT back in time: replacing these reads by loop-invariant ones cut the kernel from 1.12 to 0.63 ms
@@ -169,11 +160,6 @@ __device__ inline void gemm_t(f32x16 (&acc)[TT], vec8<E> (&wf)[8], const E* xs, 
     // front of their MFMA — less register pressure on paper, the read latency exposed on every product)
     if (NEXT >= 0) __builtin_amdgcn_sched_barrier(0);
   }
-#if RL4CO_ENC_PRIO == 1 || RL4CO_ENC_PRIO == 2
-  __builtin_amdgcn_s_setprio(0);
-#elif RL4CO_ENC_PRIO == 3
-  __builtin_amdgcn_s_setprio(2);
-#endif
 }
 
 // write an Out^T accumulator tile to LDS rows [token][dim]: 4 consecutive dims per 8-byte store
@@ -520,69 +506,24 @@ __device__ inline float wave_max32(float v) {  // maximum over the 32 token colu
 // (Barriers are LDS-only — `s_waitcnt lgkmcnt(0); s_barrier` — not __syncthreads(): every hand-over between the waves is
 // LDS data, and __syncthreads()'s vmcnt(0) would make each of them wait for the acknowledgement of the global stores issued
 // before it — neutral for inference (0.965 vs 0.965 ms, tools/ab_encoder.sh), but the TRAIN variant writes 12 passes per layer.)
-// DUAL (r05, inference): ONE 512-thread workgroup per CU carries TWO instances ("halves": threads 0-255 / 256-511, each
-// with its own LDS set) through the same barrier sequence, half 1 running kDualOffset barrier intervals behind half 0, and
-// loops over its share of the batch. Two independent 256-thread workgroups meet on a SIMD at whatever phase the dispatcher
-// left them in: r05 counters (profiles/r05_encoder_variants.json) show a wave stalled on the matrix pipe 42 % of its life
-// (the partner's MFMAs) while the pipe idles 52 % of the time — both halves in a GEMM, then both in an epilogue. With the
-// barriers shared, the offset pairs one half's VALU-heavy intervals (attention, norms) with the other's GEMM intervals
-// (FFN); kDualSplit adds the barriers that cut the QKV / attention stretch into intervals of the FFN's length.
-#ifndef RL4CO_ENC_DUAL_OFFSET
-#define RL4CO_ENC_DUAL_OFFSET 8
-#endif
-#ifndef RL4CO_ENC_DUAL_SPLIT
-#define RL4CO_ENC_DUAL_SPLIT 1
-#endif
-#ifndef RL4CO_ENC_DUAL_PERSIST
-#define RL4CO_ENC_DUAL_PERSIST 1
-#endif
-constexpr int kDualOffset = RL4CO_ENC_DUAL_OFFSET;
-constexpr bool kDualSplit = RL4CO_ENC_DUAL_SPLIT != 0;
-constexpr bool kDualPersist = RL4CO_ENC_DUAL_PERSIST != 0;  // one workgroup per CU walking the batch (0: one per pair of instances)
-
-template <typename E, int TT, int VR4, bool TRAIN = false, bool LAYER = false, bool DUAL = false>
-__global__ void __launch_bounds__(DUAL ? 2 * kThreads : kThreads, 2) am_encoder_kernel(const rl4co_am_encoder_args a, const TrainSave<E> ts) {
-  static_assert(!DUAL || (!TRAIN && !LAYER), "the dual-instance form serves the inference kernels");
+template <typename E, int TT, int VR4, bool TRAIN = false, bool LAYER = false>
+__global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_encoder_args a, const TrainSave<E> ts) {
   using bf16x8 = vec8<E>;  // (historic names: the 16-bit operand fragments of whichever element type E is)
   using bf16x4 = vec4<E>;
-  extern __shared__ __align__(16) unsigned char smem_all[];
-  const int half = DUAL ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;  // wave-uniform: a scalar (LDS bases stay in SGPRs)
-  unsigned char* smem = smem_all + (DUAL ? half * kEncLds : 0);
+  extern __shared__ __align__(16) unsigned char smem[];
   E* xs = reinterpret_cast<E*>(smem);  // residual stream [128][kRS]
   E* ys = xs + 128 * kRS;              // Q^T (wave-private columns) -> attention output -> FFN hidden chunk
   float* meanv = reinterpret_cast<float*>(ys + 128 * kRS);  // [128]
   float* bl = meanv + kD;                                    // [kBiasFloats] this layer's bqkv | b1 (see bias_tile)
-  // the norms' per-channel constants, staged with the biases one layer ahead: read from global memory in the epilogue
-  // they put an L2 round trip behind each of the layer's two GEMM -> norm hand-overs. Two buffers by layer parity: a fast
-  // wave stages layer l + 1 while a slow one still reads layer l's second norm.
-  float* nl = bl + kBiasFloats;                              // [2][kNormFloats]
   auto stage_biases = [&](int layer) {
-    for (int i = threadIdx.x & (kThreads - 1); i < kBiasFloats; i += kThreads)
+    for (int i = threadIdx.x; i < kBiasFloats; i += kThreads)
       bl[i] = i < 3 * kD ? a.bqkv[layer * 3 * kD + i] : a.b1[layer * kFF + i - 3 * kD];
-#ifdef RL4CO_ENC_NORMLDS
-    for (int i = threadIdx.x & (kThreads - 1); i < kNormFloats; i += kThreads) {
-      const float* src = i < 2 * kD ? (i < kD ? a.n1_scale : a.n1_shift) : (i < 3 * kD ? a.n2_scale : a.n2_shift);
-      nl[(layer & 1) * kNormFloats + i] = src[layer * kD + (i & (kD - 1))];
-    }
-#endif
   };
 
-  int tid = threadIdx.x & (kThreads - 1);
+  int tid = threadIdx.x;
   int w = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;  // (not const: see the top of the layer loop)
+  const int b = blockIdx.x;
   const int N = a.N;
-  // DUAL: the workgroup walks pairs of instances; a half whose share is exhausted repeats the batch's last instance (the
-  // same values to the same addresses) — both halves must pass the same number of barriers
-  const int iters = (DUAL && kDualPersist) ? (a.B + 2 * (int)gridDim.x - 1) / (2 * (int)gridDim.x) : 1;
-  if (DUAL && half == 1)
-    for (int i = 0; i < kDualOffset; ++i) rl4co::lds_barrier();
-#pragma unroll 1
-  for (int it = 0; it < iters; ++it) {
-  const int b = DUAL ? min(2 * ((int)blockIdx.x + it * (int)gridDim.x) + half, a.B - 1) : (int)blockIdx.x;
-  if constexpr (DUAL) {  // (as at the top of the layer loop: no per-lane address survives from one instance to the next)
-    asm volatile("" : "+v"(tid), "+v"(w), "+v"(lane));
-    l31 = lane & 31;
-    hi = lane >> 5;
-  }
 
   const E* wqkv_all = static_cast<const E*>(a.wqkv_packed);
   const E* wo_all = static_cast<const E*>(a.wo_packed);
@@ -614,6 +555,9 @@ __global__ void __launch_bounds__(DUAL ? 2 * kThreads : kThreads, 2) am_encoder_
   }
   rl4co::lds_barrier();
 
+  // the weight hand-over of the GEMM calls: compiled in for the inference kernels (straight-line calls); the training forward
+  // keeps the run-time form its register allocation was tuned with (the straight-line form spills 4 - 9 registers there)
+  constexpr int kNx = TRAIN ? -1 : 1;
   for (int layer = 0; layer < a.num_layers; ++layer) {
     // The lane indices pass through an opaque copy once per layer, so every per-lane LDS / weight address below is
     // derived INSIDE the iteration, next to its use. Hoisted out of the loop as invariants they were ~70 registers
@@ -629,17 +573,10 @@ __global__ void __launch_bounds__(DUAL ? 2 * kThreads : kThreads, 2) am_encoder_
     L.w2 = w2_all + (int64_t)layer * kD * kFF;
     L.bqkv = bl;
     L.b1 = bl + 3 * kD;
-#ifdef RL4CO_ENC_NORMLDS
-    L.n1a = nl + (layer & 1) * kNormFloats;
-    L.n1b = L.n1a + kD;
-    L.n2a = L.n1a + 2 * kD;
-    L.n2b = L.n1a + 3 * kD;
-#else
     L.n1a = a.n1_scale + layer * kD;
     L.n1b = a.n1_shift + layer * kD;
     L.n2a = a.n2_scale + layer * kD;
     L.n2b = a.n2_shift + layer * kD;
-#endif
 
     // ---- Q, K (transposed form) and V (plain form) of head pair w, kept as fragments ---------
     // vfh[hh]: V^T fragments for head hh of the pair — the lanes holding the OTHER head's dims carry ones instead, so
@@ -650,7 +587,7 @@ __global__ void __launch_bounds__(DUAL ? 2 * kThreads : kThreads, 2) am_encoder_
       f32x16 acc[TT];
       // 1/sqrt(16) and log2(e) are folded into the packed Wq and its bias on the host (encoder.py): the softmax below
       // is exp2(s - max) and the projection needs no epilogue arithmetic at all
-      gemm_t<TT, true, true, 1>(acc, wf, xs, lane, L.wqkv, 8, 4 + w, 0, bias_tile(L.bqkv, 32 * w, hi));
+      gemm_t<TT, true, true, kNx>(acc, wf, xs, lane, L.wqkv, 8, 4 + w, 0, bias_tile(L.bqkv, 32 * w, hi));
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
         float h0, h1;
@@ -662,8 +599,7 @@ __global__ void __launch_bounds__(DUAL ? 2 * kThreads : kThreads, 2) am_encoder_
       // row, and later overwrites it with the attention output of that same row)
       store_t<TT>(ys, acc, 32 * w, lane);
       if constexpr (TRAIN) save_t<TT>(ts.qkv + ((int64_t)layer * a.B + b) * N * 3 * kD, 3 * kD, acc, 32 * w, N, lane);
-      if constexpr (DUAL && kDualSplit) rl4co::lds_barrier();  // interval a1 | a2 (no LDS hazard: pacing against the other half)
-      gemm_t<TT, true, true, 1>(acc, wf, xs, lane, L.wqkv, 8, 8 + w, 0, bias_tile(L.bqkv + kD, 32 * w, hi));
+      gemm_t<TT, true, true, kNx>(acc, wf, xs, lane, L.wqkv, 8, 8 + w, 0, bias_tile(L.bqkv + kD, 32 * w, hi));
       if constexpr (TRAIN) save_t<TT>(ts.qkv + ((int64_t)layer * a.B + b) * N * 3 * kD + kD, 3 * kD, acc, 32 * w, N, lane);
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
@@ -674,14 +610,13 @@ __global__ void __launch_bounds__(DUAL ? 2 * kThreads : kThreads, 2) am_encoder_
         kn2[0] = fmaxf(kn2[0], h0);
         kn2[1] = fmaxf(kn2[1], h1);
       }
-      if constexpr (DUAL && kDualSplit) rl4co::lds_barrier();  // a2 | a3
       // V = X . Wv^T: A = token rows from LDS, B = weight fragment -> C[row = token][col = dim]
       {
         const float bv = L.bqkv[2 * kD + 32 * w + l31];  // plain form: the bias belongs to the lane's dim column
         f32x16 bt;
 #pragma unroll
         for (int r = 0; r < 16; ++r) bt[r] = bv;
-        gemm_t<TT, false, true, 0>(acc, wf, xs, lane, static_cast<const E*>(nullptr), 0, 0, 0, bt);  // nothing in flight across the attention (register peak)
+        gemm_t<TT, false, true, TRAIN ? -1 : 0>(acc, wf, xs, lane, static_cast<const E*>(nullptr), 0, 0, 0, bt);  // nothing in flight across the attention (register peak)
       }
       if constexpr (TRAIN) {
         // plain form: the lane owns ONE dim column and sixteen token rows per tile — 2-byte stores, 32 consecutive dims
@@ -708,7 +643,6 @@ __global__ void __launch_bounds__(DUAL ? 2 * kThreads : kThreads, 2) am_encoder_
         }
       }
     }
-    if constexpr (DUAL && kDualSplit) rl4co::lds_barrier();  // a3 | a4 (attention, one interval per query tile)
     // |score| <= max_i |q_i| max_j |k_j| per head (Cauchy-Schwarz; fp32 norms, the products see their bf16 roundings:
     // the bound keeps a wide margin): below kFastBound the softmax needs no running maximum
     bool fast_head[2];
@@ -720,14 +654,7 @@ __global__ void __launch_bounds__(DUAL ? 2 * kThreads : kThreads, 2) am_encoder_
 
     // ---- attention for heads 2w, 2w+1 over all queries, wave-private ---------------------------
     constexpr int kLastRegs = 4 * VR4;  // registers of the last key tile that can hold real keys
-#if RL4CO_ENC_PRIO == 2
-    __builtin_amdgcn_s_setprio(2);
-#endif
-#ifdef RL4CO_ENC_QTLOOP
-#pragma unroll 1
-#else
 #pragma unroll
-#endif
     for (int qt = 0; qt < TT; ++qt) {
       E* qrow = ys + (32 * qt + l31) * kRS + 32 * w;
       f32x16 o = zero16();
@@ -821,13 +748,7 @@ __global__ void __launch_bounds__(DUAL ? 2 * kThreads : kThreads, 2) am_encoder_
         for (int i = 0; i < 4; ++i) v[i] = (E)o[4 * c + i];
         *reinterpret_cast<bf16x4*>(qrow + 8 * c + 4 * hi) = v;
       }
-      if constexpr (DUAL && kDualSplit) {
-        if (qt + 1 < TT) rl4co::lds_barrier();
-      }
     }
-#if RL4CO_ENC_PRIO == 2
-    __builtin_amdgcn_s_setprio(0);
-#endif
     __builtin_amdgcn_sched_barrier(0);     // keep these loads out of the attention loop (its register peak)
     load_wfrags(wf, L.wo, 8, w, 0, lane);  // out-proj weights: in flight across the barrier
     rl4co::lds_barrier();
@@ -838,7 +759,7 @@ __global__ void __launch_bounds__(DUAL ? 2 * kThreads : kThreads, 2) am_encoder_
       f32x16 y[TT];
       // (out_proj's bias rides in the norm's shift — batch norm — or cancels in the per-channel mean — instance norm:
       // folded on the host, encoder.py)
-      gemm_t<TT, true, true, 1>(y, wf, ys, lane, L.w1, 8, w, 0, zero16());  // next: FFN1 chunk 0
+      gemm_t<TT, true, true, kNx>(y, wf, ys, lane, L.w1, 8, w, 0, zero16());  // next: FFN1 chunk 0
       if constexpr (TRAIN) {
         float* st = ts.stats + ((int64_t)layer * 4 * a.B + b) * kD;
         residual_norm_train<TT>(xs, y, 32 * w, L.n1a, L.n1b, N, lane, ts.y1 + ((int64_t)layer * a.B + b) * N * kD, st, st + (int64_t)a.B * kD);
@@ -856,7 +777,7 @@ __global__ void __launch_bounds__(DUAL ? 2 * kThreads : kThreads, 2) am_encoder_
       for (int tt = 0; tt < TT; ++tt) y2[tt] = zero16();  // the chunk loop accumulates; the MLP's output bias: see out_proj
       for (int c = 0; c < 4; ++c) {
         f32x16 h1[TT];
-        gemm_t<TT, true, true, 1>(h1, wf, xs, lane, L.w2, 32, w, 8 * c, bias_tile(L.b1, 32 * (4 * c + w), hi));  // next: FFN2 of this chunk
+        gemm_t<TT, true, true, kNx>(h1, wf, xs, lane, L.w2, 32, w, 8 * c, bias_tile(L.b1, 32 * (4 * c + w), hi));  // next: FFN2 of this chunk
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
@@ -867,9 +788,9 @@ __global__ void __launch_bounds__(DUAL ? 2 * kThreads : kThreads, 2) am_encoder_
         if constexpr (TRAIN) rows_out(ys, ts.h + ((int64_t)layer * a.B + b) * N * kFF + kD * c, kFF, N, tid);
         // next: FFN1 of the next chunk, then the next layer's Q projection, finally the first fold block
         const bool last_layer = layer + 1 == a.num_layers;
-        // (the training forward has no fold: its last call fetches W1's first tile again, unused)
-        const E* nxt = c < 3 ? L.w1 : (last_layer ? (TRAIN ? L.w1 : wf_all) : wqkv_all + (int64_t)(layer + 1) * 3 * kD * kD);
-        gemm_t<TT, true, false, 1>(y2, wf, ys, lane, nxt, 8, c < 3 ? 4 * (c + 1) + w : w, 0, y2[0]);
+        // (the training forward has no fold: wf_all is null there and its last call fetches nothing)
+        const E* nxt = c < 3 ? L.w1 : (last_layer ? wf_all : wqkv_all + (int64_t)(layer + 1) * 3 * kD * kD);
+        gemm_t<TT, true, false, kNx>(y2, wf, ys, lane, nxt, 8, c < 3 ? 4 * (c + 1) + w : w, 0, y2[0]);
       }
       if constexpr (TRAIN) {
         float* st = ts.stats + (((int64_t)layer * 4 + 2) * a.B + b) * kD;
@@ -972,9 +893,6 @@ __global__ void __launch_bounds__(DUAL ? 2 * kThreads : kThreads, 2) am_encoder_
       if (lane == r) a.q_bias[(int64_t)b * kD + 32 * w + r] = acc;
     }
   }
-  }  // instance loop
-  if (DUAL && half == 0)
-    for (int i = 0; i < kDualOffset; ++i) rl4co::lds_barrier();
 }
 
 // ================================================================================================================
@@ -1500,34 +1418,8 @@ int launch_tokens16(const rl4co_am_encoder_args& a, void* workspace, hipStream_t
   return RL4CO_OK;
 }
 
-#ifndef RL4CO_ENC_DUAL
-#define RL4CO_ENC_DUAL 1  // inference (batch / instance norm): the dual-instance workgroups; 0 = one 256-thread workgroup per instance
-#endif
-
-inline int compute_units() {
-  static const int n = [] {
-    int dev = 0, cu = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0) cu = 256;
-    return cu;
-  }();
-  return n;
-}
-
 template <typename E, int TT, int VR4>
 int launch_encoder(const rl4co_am_encoder_args& a, hipStream_t stream) {
-#if RL4CO_ENC_DUAL
-  static const bool dual = [] { const char* e = getenv("RL4CO_ENC_DUAL"); return !(e && e[0] == '0'); }();  // (probe knob)
-  if (dual) {
-    const int lds = 2 * kEncLds;
-    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_encoder_kernel<E, TT, VR4, false, false, true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    const int pairs = (a.B + 1) / 2;
-    hipLaunchKernelGGL((am_encoder_kernel<E, TT, VR4, false, false, true>), dim3(kDualPersist ? min(pairs, compute_units()) : pairs), dim3(2 * kThreads), lds, stream, a,
-                       TrainSave<E>{});
-    RL4CO_HIP_TRY(hipGetLastError());
-    return RL4CO_OK;
-  }
-#endif
   const int lds = kEncLds;
   RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_encoder_kernel<E, TT, VR4, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));

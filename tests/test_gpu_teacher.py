@@ -680,9 +680,16 @@ def test_fused_training_forward_saves_match_the_oracle_cpu_encoder(n, layers, dt
         train_ops._FusedEncoderStack.backward = staticmethod(orig)
     assert captured, "the one-launch training forward did not run"
     ref, _, out64, want = _oracle_stack_f64(net, x0)
+    # the kernel leaves out the bias of the GEMM in front of each instance norm (out_proj's, the MLP's second linear's): a
+    # per-channel constant cancels in the per-channel mean. Its saved pre-norm sums and means are the oracle's minus that bias
+    bo = torch.stack([l[0].module.out_proj.bias.detach().double().cpu() for l in net.layers])
+    b2 = torch.stack([l[2].module.lins[1].bias.detach().double().cpu() for l in net.layers])
+    shift = {"y1": bo, "y2": b2}
     worst = {}
     for k, w in want.items():
         got = captured[k].double().cpu()
+        if k in shift:
+            got = got + shift[k][:, None, None, :]
         for layer in range(layers):
             e = float((got[layer] - w[layer]).norm() / w[layer].norm())
             worst[k] = max(worst.get(k, 0.0), e)
@@ -694,7 +701,7 @@ def test_fused_training_forward_saves_match_the_oracle_cpu_encoder(n, layers, dt
             y = want[key][layer]
             mean, var = y.mean(1), y.var(1, unbiased=False)
             # (the kernel takes the statistics of the ROUNDED sums: a mean moves by a fraction of the channel's spread)
-            assert float((st[layer, j] - mean).norm() / var.sqrt().norm()) <= tol
+            assert float((st[layer, j] + shift[key][layer] - mean).norm() / var.sqrt().norm()) <= tol
             rstd = (var + 1e-5).rsqrt()
             assert float((st[layer, j + 1] - rstd).norm() / rstd.norm()) <= tol
     # log-sum-exp of the scaled scores, log2 domain (am_train_attn.hip's convention): from the oracle's q, k
@@ -710,7 +717,8 @@ def test_c4_shaped_step_gradients_per_tensor_against_the_fp32_step(dt):
     per PARAMETER TENSOR: relative error of its gradient against the same step in fp32 end to end (torch fp32 encoder,
     fp32 planes, fp32 replay backward — itself pinned per tensor to torch autograd at 2e-3 and to the oracle's CPU gradients
     above). A 16-bit evaluation cannot meet an absolute 2e-2 against the fp32 truth — torch's OWN autocast step does not —
-    so the bar is two-sided: every tensor with signal within `CAP` absolutely AND within 1.35x of what torch's autocast step
+    so the bar is two-sided: every tensor with signal within `CAP` absolutely (first run: torch's autocast step itself is up to
+    0.16 / 0.05 away per tensor in bf16 / fp16) AND within 1.35x of what torch's autocast step
     (the reference's regime, utils/trainer.py:57) loses on that same tensor. Replaces the all-parameter cosine as the
     tightest statement about the whole step."""
     from rl4co_amd.envs import get_env
@@ -744,7 +752,7 @@ def test_c4_shaped_step_gradients_per_tensor_against_the_fp32_step(dt):
         grads[mode] = {k: p.grad.detach().double().flatten() for k, p in pol.named_parameters() if p.grad is not None}
     truth = grads["fp32"]
     scale = max(float(g.norm()) for g in truth.values())
-    CAP = 0.16 if dt == torch.bfloat16 else 0.04
+    CAP = 0.25 if dt == torch.bfloat16 else 0.06
     rows = []
     for k, g in truth.items():
         if float(g.norm()) <= 5e-2 * scale:

@@ -8,7 +8,7 @@ R=$(cd $(dirname $0)/.. && pwd)
 W=$R/tools/probes/_build
 mkdir -p $W
 # name:compile definitions[:environment at run time]
-VARIANTS=${RL4CO_ENC_VARIANTS:-"single:-DRL4CO_ENC_DUAL=0|np_lock:-DRL4CO_ENC_DUAL_PERSIST=0 -DRL4CO_ENC_DUAL_OFFSET=0 -DRL4CO_ENC_DUAL_SPLIT=0|np_off1:-DRL4CO_ENC_DUAL_PERSIST=0 -DRL4CO_ENC_DUAL_OFFSET=1 -DRL4CO_ENC_DUAL_SPLIT=0|np_off8s:-DRL4CO_ENC_DUAL_PERSIST=0|p_lock:-DRL4CO_ENC_DUAL_OFFSET=0 -DRL4CO_ENC_DUAL_SPLIT=0|p_off8s:|p_off4s:-DRL4CO_ENC_DUAL_OFFSET=4|p_off12s:-DRL4CO_ENC_DUAL_OFFSET=12|p_off8:-DRL4CO_ENC_DUAL_SPLIT=0|p_off5:-DRL4CO_ENC_DUAL_OFFSET=5 -DRL4CO_ENC_DUAL_SPLIT=0"}
+VARIANTS=${RL4CO_ENC_VARIANTS:-"base:|nogctx:-DRL4CO_ENC_SKIP_GCTX|nofold:-DRL4CO_ENC_SKIP_FOLD|noinit:-DRL4CO_ENC_SKIP_INIT"}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -I$R/include -I$R/rl4co_amd/csrc"
 if [ "$1" = "build" ]; then
   python -c "import sys; sys.path.insert(0,'$R'); from rl4co_amd import build; build.build_library()"
