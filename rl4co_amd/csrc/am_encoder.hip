@@ -78,8 +78,22 @@ __device__ inline f32x16 bias_tile(const float* bias, int dim0, int hi) {
   return t;
 }
 constexpr int kBiasFloats = 3 * kD + kFF;  // per layer: bqkv [384] | b1 [512]
-constexpr int kEncLds = 2 * 128 * kRS * 2 + kD * 4 + kBiasFloats * 4;  // 73 728 B per workgroup: two per CU
+constexpr int kNormFloats = 4 * kD;         // per layer: n1 scale | n1 shift | n2 scale | n2 shift
+// xs | ys | meanv | biases and norm constants of two layers (this one's and the next one's): 81 408 B, two workgroups per CU
+constexpr int kEncLds = 2 * 128 * kRS * 2 + kD * 4 + 2 * kBiasFloats * 4 + 2 * kNormFloats * 4;
 static_assert(2 * kEncLds <= 160 * 1024, "am_encoder_kernel is built for two workgroups per CU");
+
+// max(x, 0) in ONE instruction: fmaxf under the kernels' IEEE mode is v_max_f32 x, x, x (quieting a signalling NaN) followed
+// by v_max_f32 0, x — two VALU operations per hidden unit, 768 per wave and instance in the fused kernel (r05 ISA). The
+// median of (x, 0, +inf) is the same value for every x that is not a NaN; `inf` arrives through an opaque copy (the
+// compiler folds the literal form back into the max pair), and unlike an inline-asm v_max the instruction stays visible to
+// the hazard recogniser (the operands are MFMA results: wait states are software-managed).
+__device__ inline float opaque_inf() {
+  float v = __builtin_huge_valf();
+  asm volatile("" : "+s"(v));
+  return v;
+}
+__device__ inline float relu(float x, float inf) { return __builtin_amdgcn_fmed3f(x, 0.0f, inf); }
 
 __device__ inline f32x16 zero16() {
   f32x16 z;
@@ -197,6 +211,7 @@ __device__ inline uint4 pair16(const vec4<E>& p0, const vec4<E>& p1) {
 // write-back L2 (8-byte stores straight from the accumulator layout cost twice as much per byte: tools/probes/train_fwd_probe.sh)
 template <int TT, typename E>
 __device__ inline void save_t(E* dst, int64_t row_stride, const f32x16 (&acc)[TT], int dim0, int N, int lane) {
+  asm volatile("" : "+v"(lane));  // (row offsets derived per call: kept from the top of the layer they are spilled, and a scratch reload waits with vmcnt(0))
   const int l31 = lane & 31, hi = lane >> 5;
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
@@ -334,6 +349,7 @@ constexpr float kTrainScale = 0.25f * 1.44269504088896341f;  // 1/sqrt(16) in th
 template <int TT, typename E>
 __device__ inline void residual_norm_train(E* xs, f32x16 (&y)[TT], int dim0, const float* na, const float* nb, int N, int lane,
                                            E* y_out, float* mean_out, float* rstd_out) {
+  asm volatile("" : "+v"(lane));  // (as in save_t)
   const int l31 = lane & 31, hi = lane >> 5;
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
@@ -382,11 +398,20 @@ __device__ inline void residual_norm_train(E* xs, f32x16 (&y)[TT], int dim0, con
   store_t<TT>(xs, y, dim0, lane);
 }
 
-// rows 0 .. rows - 1 of an LDS tile [.][kRS] -> global rows of `row_stride` elements, 16-byte lanes
-template <typename E>
+// rows 0 .. rows - 1 (1 <= rows <= 32 TT) of an LDS tile [.][kRS] -> global rows of `row_stride` elements, 16-byte lanes.
+// A FIXED number of UNCONDITIONAL stores per thread (pieces past the last row repeat that row's: the same bytes to the same
+// address): behind a loop with a run-time trip count the compiler cannot tell how many stores are younger than the weight
+// fragment the next GEMM call waits for — loads and stores share vmcnt — and emits s_waitcnt vmcnt(0): every such call then
+// started by draining all of these stores, an HBM write round trip on the workgroup's chain (r05 ISA).
+template <int TT, typename E>
 __device__ inline void rows_out(const E* xs, E* dst, int64_t row_stride, int rows, int tid) {
-  for (int i = tid; i < rows * 16; i += kThreads)
-    *reinterpret_cast<uint4*>(dst + (int64_t)(i >> 4) * row_stride + 8 * (i & 15)) = *reinterpret_cast<const uint4*>(xs + (i >> 4) * kRS + 8 * (i & 15));
+  asm volatile("" : "+v"(tid));  // the 2 TT piece addresses are derived HERE, per call (shared between the calls of a layer they are 16 - 32 more live registers)
+#pragma unroll
+  for (int j = 0; j < 2 * TT; ++j) {
+    const int i = tid + kThreads * j, row = min(i >> 4, rows - 1), c16 = i & 15;
+    *reinterpret_cast<uint4*>(dst + (int64_t)row * row_stride + 8 * c16) = *reinterpret_cast<const uint4*>(xs + row * kRS + 8 * c16);
+    if (j & 1) __builtin_amdgcn_sched_barrier(0);  // two pieces in flight at a time (all of them: 32 registers the training forward does not have)
+  }
 }
 
 // Init embedding of rows n0 .. n0 + rows_pad - 1 of instance b into xs (rows past N zeroed); contains one __syncthreads().
@@ -514,10 +539,32 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
   E* xs = reinterpret_cast<E*>(smem);  // residual stream [128][kRS]
   E* ys = xs + 128 * kRS;              // Q^T (wave-private columns) -> attention output -> FFN hidden chunk
   float* meanv = reinterpret_cast<float*>(ys + 128 * kRS);  // [128]
-  float* bl = meanv + kD;                                    // [kBiasFloats] this layer's bqkv | b1 (see bias_tile)
-  auto stage_biases = [&](int layer) {
-    for (int i = threadIdx.x; i < kBiasFloats; i += kThreads)
-      bl[i] = i < 3 * kD ? a.bqkv[layer * 3 * kD + i] : a.b1[layer * kFF + i - 3 * kD];
+  float* bl2 = meanv + kD;                                   // [2][kBiasFloats] bqkv | b1 by layer parity (see bias_tile)
+  float* nl2 = bl2 + 2 * kBiasFloats;                        // [2][kNormFloats] n1 scale | n1 shift | n2 scale | n2 shift
+  // A layer's constants travel global -> registers -> LDS with ALL loads of the set out before the first store. As one loop
+  // (what `for (i = tid; ..) bl[i] = src[i]` compiles to: global_load_dword; s_waitcnt vmcnt(0); ds_write_b32 per iteration,
+  // r05 ISA) staging the 896 biases was four SERIALISED L2 round trips on every wave at the start of the kernel and at the
+  // end of every layer, and the two norm epilogues fetched their constants from global memory right where they need them —
+  // six exposed round trips per layer on a chain that is latency-bound (profiles/r05_encoder_variants.json); now one, in
+  // front of the end-of-layer barrier. Both sets by layer parity: a fast wave stages layer l + 1 while a slow one still
+  // reads layer l's second norm. (Requested a GEMM or a barrier EARLIER than they are stored the six values cost 19 - 30
+  // spilled registers: the kernel sits at 254 of 256.)
+  // (`t0`: the thread index AS LAUNDERED at the top of the layer — derived from threadIdx.x the four store addresses are loop
+  // invariants, hoisted out of the layer loop, spilled, and reloaded one scratch round trip at a time right here)
+  auto stage_layer = [&](int layer, int t0) {
+    // every source is chosen per WAVE (a scalar select): wave w takes norm array w, waves 0 - 2 the 384 qkv biases, all four
+    // the 512 MLP biases, two consecutive floats per lane. (Chosen per lane the four norm pointers become a vector load of
+    // the pointer from the kernel-argument segment in front of the load of the value: two dependent round trips.)
+    const int ws = __builtin_amdgcn_readfirstlane(t0 >> 6), l2 = 2 * (t0 & 63);
+    const float* nsrc = ws < 2 ? (ws == 0 ? a.n1_scale : a.n1_shift) : (ws == 2 ? a.n2_scale : a.n2_shift);
+    const float2 nv = *reinterpret_cast<const float2*>(nsrc + layer * kD + l2);
+    const float2 b1v = *reinterpret_cast<const float2*>(a.b1 + layer * kFF + 2 * t0);
+    float2 qv = make_float2(0.0f, 0.0f);
+    if (ws < 3) qv = *reinterpret_cast<const float2*>(a.bqkv + layer * 3 * kD + 2 * t0);
+    float* bdst = bl2 + (layer & 1) * kBiasFloats;
+    if (ws < 3) *reinterpret_cast<float2*>(bdst + 2 * t0) = qv;
+    *reinterpret_cast<float2*>(bdst + 3 * kD + 2 * t0) = b1v;
+    *reinterpret_cast<float2*>(nl2 + (layer & 1) * kNormFloats + ws * kD + l2) = nv;
   };
 
   int tid = threadIdx.x;
@@ -537,7 +584,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
   load_wfrags(wf, wqkv_all, 8, w, 0, lane);
 
   // ---- init embedding (K = 2 .. 6: plain VALU), padding rows zeroed ---------------------------
-  stage_biases(0);
+  stage_layer(0, tid);
   if constexpr (TRAIN) {
     const E* src = ts.x0 + (int64_t)b * N * kD;
     for (int i = tid; i < 32 * TT * 16; i += kThreads) {
@@ -555,9 +602,11 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
   }
   rl4co::lds_barrier();
 
-  // the weight hand-over of the GEMM calls: compiled in for the inference kernels (straight-line calls); the training forward
-  // keeps the run-time form its register allocation was tuned with (the straight-line form spills 4 - 9 registers there)
-  constexpr int kNx = TRAIN ? -1 : 1;
+  // the weight hand-over of the GEMM calls is compiled in (straight-line calls): with the run-time form the number of loads
+  // younger than a fragment depends on the path, and every call's first MFMA waits with vmcnt(0) — draining, in the training
+  // forward, all the saves issued before it
+  constexpr int kNx = 1;
+  const float kInf = opaque_inf();
   for (int layer = 0; layer < a.num_layers; ++layer) {
     // The lane indices pass through an opaque copy once per layer, so every per-lane LDS / weight address below is
     // derived INSIDE the iteration, next to its use. Hoisted out of the loop as invariants they were ~70 registers
@@ -571,13 +620,12 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
     L.wo = wo_all + (int64_t)layer * kD * kD;
     L.w1 = w1_all + (int64_t)layer * kFF * kD;
     L.w2 = w2_all + (int64_t)layer * kD * kFF;
-    L.bqkv = bl;
-    L.b1 = bl + 3 * kD;
-    L.n1a = a.n1_scale + layer * kD;
-    L.n1b = a.n1_shift + layer * kD;
-    L.n2a = a.n2_scale + layer * kD;
-    L.n2b = a.n2_shift + layer * kD;
-
+    L.bqkv = bl2 + (layer & 1) * kBiasFloats;
+    L.b1 = L.bqkv + 3 * kD;
+    L.n1a = nl2 + (layer & 1) * kNormFloats;
+    L.n1b = L.n1a + kD;
+    L.n2a = L.n1a + 2 * kD;
+    L.n2b = L.n1a + 3 * kD;
     // ---- Q, K (transposed form) and V (plain form) of head pair w, kept as fragments ---------
     // vfh[hh]: V^T fragments for head hh of the pair — the lanes holding the OTHER head's dims carry ones instead, so
     // the value product's idle output rows deliver the softmax denominator (sum of the bf16 numerators) for free
@@ -616,7 +664,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         f32x16 bt;
 #pragma unroll
         for (int r = 0; r < 16; ++r) bt[r] = bv;
-        gemm_t<TT, false, true, TRAIN ? -1 : 0>(acc, wf, xs, lane, static_cast<const E*>(nullptr), 0, 0, 0, bt);  // nothing in flight across the attention (register peak)
+        gemm_t<TT, false, true, 0>(acc, wf, xs, lane, static_cast<const E*>(nullptr), 0, 0, 0, bt);  // nothing in flight across the attention (register peak)
       }
       if constexpr (TRAIN) {
         // plain form: the lane owns ONE dim column and sixteen token rows per tile — 2-byte stores, 32 consecutive dims
@@ -752,7 +800,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
     __builtin_amdgcn_sched_barrier(0);     // keep these loads out of the attention loop (its register peak)
     load_wfrags(wf, L.wo, 8, w, 0, lane);  // out-proj weights: in flight across the barrier
     rl4co::lds_barrier();
-    if constexpr (TRAIN) rows_out(ys, ts.att + ((int64_t)layer * a.B + b) * N * kD, kD, N, tid);
+    if constexpr (TRAIN) rows_out<TT>(ys, ts.att + ((int64_t)layer * a.B + b) * N * kD, kD, N, tid);
 
     // ---- out-proj + residual + norm1 ---------------------------------------------------------------
     {
@@ -768,7 +816,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       }
     }
     rl4co::lds_barrier();
-    if constexpr (TRAIN) rows_out(xs, ts.x1 + ((int64_t)layer * a.B + b) * N * kD, kD, N, tid);
+    if constexpr (TRAIN) rows_out<TT>(xs, ts.x1 + ((int64_t)layer * a.B + b) * N * kD, kD, N, tid);
 
     // ---- FFN: hidden in 4 chunks of 128, FFN2 accumulates across chunks -----------------------------
     {
@@ -781,15 +829,15 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) h1[tt][r] = fmaxf(h1[tt][r], 0.0f);
+          for (int r = 0; r < 16; ++r) h1[tt][r] = relu(h1[tt][r], kInf);
         if (c > 0) rl4co::lds_barrier();  // every wave is done reading the previous chunk
         store_t<TT>(ys, h1, 32 * w, lane);
         rl4co::lds_barrier();
-        if constexpr (TRAIN) rows_out(ys, ts.h + ((int64_t)layer * a.B + b) * N * kFF + kD * c, kFF, N, tid);
+        if constexpr (TRAIN) rows_out<TT>(ys, ts.h + ((int64_t)layer * a.B + b) * N * kFF + kD * c, kFF, N, tid);
         // next: FFN1 of the next chunk, then the next layer's Q projection, finally the first fold block
         const bool last_layer = layer + 1 == a.num_layers;
-        // (the training forward has no fold: wf_all is null there and its last call fetches nothing)
-        const E* nxt = c < 3 ? L.w1 : (last_layer ? wf_all : wqkv_all + (int64_t)(layer + 1) * 3 * kD * kD);
+        // (the training forward has no fold: its last call fetches W1's first tile again, unused)
+        const E* nxt = c < 3 ? L.w1 : (last_layer ? (TRAIN ? L.w1 : wf_all) : wqkv_all + (int64_t)(layer + 1) * 3 * kD * kD);
         gemm_t<TT, true, false, kNx>(y2, wf, ys, lane, nxt, 8, c < 3 ? 4 * (c + 1) + w : w, 0, y2[0]);
       }
       if constexpr (TRAIN) {
@@ -799,10 +847,10 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         residual_norm<TT, LAYER>(xs, y2, 32 * w, L.n2a, L.n2b, a.norm, N, lane, meanv, w);
       }
     }
-    // every wave is past the last chunk's barriers, i.e. done with this layer's biases: the next layer's take their place
-    if (layer + 1 < a.num_layers) stage_biases(layer + 1);
+    // every wave is past the last chunk's barriers, i.e. done with the previous layer's half of both sets
+    if (layer + 1 < a.num_layers) stage_layer(layer + 1, tid);
     rl4co::lds_barrier();
-    if constexpr (TRAIN) rows_out(xs, ts.out + ((int64_t)layer * a.B + b) * N * kD, kD, N, tid);
+    if constexpr (TRAIN) rows_out<TT>(xs, ts.out + ((int64_t)layer * a.B + b) * N * kD, kD, N, tid);
   }
   if constexpr (TRAIN) return;  // the training forward ends with the last layer's output (the cache fold has its own autograd node)
 
@@ -827,10 +875,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       E* out = static_cast<E*>(a.kvl) + (int64_t)blk * a.kvl_plane_stride + (int64_t)b * a.kvl_batch_stride;
       store_t<TT>(ys, acc, 32 * w, lane);
       rl4co::lds_barrier();
-      for (int i = tid; i < N * 16; i += kThreads) {
-        const int row = i >> 4, c16 = i & 15;
-        *reinterpret_cast<uint4*>(out + (int64_t)row * kD + 8 * c16) = *reinterpret_cast<const uint4*>(ys + row * kRS + 8 * c16);
-      }
+      rows_out<TT>(ys, out, kD, N, tid);  // (a fixed number of stores: the next block's first MFMA waits for its weights only)
       rl4co::lds_barrier();
     } else {
       float* out;
@@ -858,8 +903,9 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         }
         rl4co::lds_barrier();
         const int rows = min(64, N - 64 * p);
-        for (int i = tid; i < rows * 32; i += kThreads) {
-          const int row = i >> 5, c4 = i & 31;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {  // 64 rows x 32 pieces / 256 threads, unconditional (see rows_out)
+          const int i = tid + kThreads * j, row = min(i >> 5, rows - 1), c4 = i & 31;
           *reinterpret_cast<float4*>(out + (int64_t)(64 * p + row) * kD + 4 * c4) =
               *reinterpret_cast<const float4*>(fs + row * kFS + 4 * c4);
         }
@@ -874,19 +920,19 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
 #else
   if (a.q_bias) {
 #endif
+    // wave w: output rows 32 w .. 32 w + 31; a row of W is ONE coalesced 512-byte load (two consecutive inputs per
+    // lane) and a butterfly sum (a thread per row read its 128 inputs at a 512-byte lane stride: 64 cache lines per
+    // load instruction). The rows are requested BEFORE the column means they will meet (registers are free here).
+    float2 wv[32];
+#pragma unroll
+    for (int r = 0; r < 32; ++r) wv[r] = *reinterpret_cast<const float2*>(a.w_fixed + (int64_t)(32 * w + r) * kD + 2 * lane);
     if (tid < kD) {
       float s = 0.0f;
       for (int tok = 0; tok < N; ++tok) s += (float)xs[tok * kRS + tid];
       meanv[tid] = s / (float)N;
     }
     rl4co::lds_barrier();
-    // wave w: output rows 32 w .. 32 w + 31; a row of W is ONE coalesced 512-byte load (two consecutive inputs per
-    // lane) and a butterfly sum (a thread per row read its 128 inputs at a 512-byte lane stride: 64 cache lines per
-    // load instruction)
     const float2 mv = *reinterpret_cast<const float2*>(meanv + 2 * lane);
-    float2 wv[32];
-#pragma unroll
-    for (int r = 0; r < 32; ++r) wv[r] = *reinterpret_cast<const float2*>(a.w_fixed + (int64_t)(32 * w + r) * kD + 2 * lane);
 #pragma unroll
     for (int r = 0; r < 32; ++r) {
       const float acc = rl4co::bfly_sum<1, 64>(fmaf(wv[r].y, mv.y, wv[r].x * mv.x));
@@ -997,6 +1043,7 @@ __global__ void __launch_bounds__(kThreads, 2) tok16_mlp_kernel(const E* __restr
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, hi = lane >> 5;
   const int b = blockIdx.y, n0 = kTok * blockIdx.x;
   vec8<E> wf[8];
+  const float kInf = opaque_inf();
   load_wfrags(wf, wo, 8, w, 0, lane);
   tok_load(xs, x, b, n0, N, tid);
   tok_load(ys, att, b, n0, N, tid);
@@ -1019,7 +1066,7 @@ __global__ void __launch_bounds__(kThreads, 2) tok16_mlp_kernel(const E* __restr
 #pragma unroll
       for (int tt = 0; tt < kTokT; ++tt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) h1[tt][r] = fmaxf(h1[tt][r], 0.0f);
+        for (int r = 0; r < 16; ++r) h1[tt][r] = relu(h1[tt][r], kInf);
       __syncthreads();  // every wave is done reading ys (the attention output / the previous chunk)
       store_t<kTokT>(ys, h1, 32 * w, lane);
       __syncthreads();
@@ -1113,6 +1160,7 @@ __global__ void __launch_bounds__(kThreads, 2) tok16_ffn_half_kernel(const E* __
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, hi = lane >> 5;
   const int b = blockIdx.y, n0 = kTok * blockIdx.x, valid = min(kTok, N - n0);
   vec8<E> wf[8];
+  const float kInf = opaque_inf();
   load_wfrags(wf, w1, 8, w, 0, lane);
   tok_load(xs, x, b, n0, N, tid);
   for (int i = tid; i < kFF; i += kThreads) bl[i] = b1[i];
@@ -1127,7 +1175,7 @@ __global__ void __launch_bounds__(kThreads, 2) tok16_ffn_half_kernel(const E* __
 #pragma unroll
     for (int tt = 0; tt < kTokT; ++tt)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) h1[tt][r] = fmaxf(h1[tt][r], 0.0f);
+      for (int r = 0; r < 16; ++r) h1[tt][r] = relu(h1[tt][r], kInf);
     if (c > 0) __syncthreads();  // every wave is done reading the previous chunk
     store_t<kTokT>(ys, h1, 32 * w, lane);
     __syncthreads();
