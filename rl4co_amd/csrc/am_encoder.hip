@@ -176,18 +176,26 @@ __device__ inline void gemm_t(f32x16 (&acc)[TT], vec8<E> (&wf)[8], const E* xs, 
   }
 }
 
-// write an Out^T accumulator tile to LDS rows [token][dim]: 4 consecutive dims per 8-byte store
+// write an Out^T accumulator tile to LDS rows [token][dim]: 4 consecutive dims per 8-byte store.
+// `nvalid` (fused kernel): token rows >= nvalid — the padding of the last tile, TSP-100: 28 of its 32 rows — are written as
+// ZEROS. No valid row ever reads them (the GEMMs are row-wise, attention masks padding keys, the norm statistics count
+// valid tokens only), but every GEMM drags them through the matrix cores as B operands, and the kernel runs against the
+// package POWER limit (r05, tools/enc_power_probe.py: the same binary on zeroed data is 16 % faster, 2.38 instead of 2.05
+// GHz): a zero operand row toggles nothing. Eight v_cndmask per store of the last tile.
 template <int TT, typename E>
-__device__ inline void store_t(E* ys, const f32x16 (&acc)[TT], int dim0, int lane) {
+__device__ inline void store_t(E* ys, const f32x16 (&acc)[TT], int dim0, int lane, int nvalid = 32 * TT) {
   const int l31 = lane & 31, hi = lane >> 5;
 #pragma unroll
   for (int tt = 0; tt < TT; ++tt) {
+    const bool live = tt + 1 < TT || 32 * tt + l31 < nvalid;  // (TT = ceil(N / 32): only the last tile holds padding)
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       vec4<E> v;
 #pragma unroll
       for (int s = 0; s < 4; ++s) v[s] = (E)acc[tt][4 * c + s];
-      *reinterpret_cast<vec4<E>*>(ys + (32 * tt + l31) * kRS + dim0 + 8 * c + 4 * hi) = v;
+      uint2 u = __builtin_bit_cast(uint2, v);
+      if (tt + 1 == TT) u = live ? u : make_uint2(0u, 0u);
+      *reinterpret_cast<uint2*>(ys + (32 * tt + l31) * kRS + dim0 + 8 * c + 4 * hi) = u;
     }
   }
 }
@@ -323,7 +331,7 @@ __device__ inline void residual_norm(E* xs, f32x16 (&y)[TT], int dim0, const flo
 #pragma unroll
       for (int r = 0; r < 16; ++r) y[tt][r] = fmaf(y[tt][r], ga[r], be[r]);
   }
-  store_t<TT>(xs, y, dim0, lane);
+  store_t<TT>(xs, y, dim0, lane, N);
 }
 
 // What the TRAINING forward (am_encoder_kernel<.., TRAIN = true>, rl4co_am_encoder_train_fwd) keeps for the backward
@@ -395,7 +403,7 @@ __device__ inline void residual_norm_train(E* xs, f32x16 (&y)[TT], int dim0, con
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) y[tt][r] = fmaf((y[tt][r] - mean) * rstd, ga, be);
   }
-  store_t<TT>(xs, y, dim0, lane);
+  store_t<TT>(xs, y, dim0, lane, N);
 }
 
 // rows 0 .. rows - 1 (1 <= rows <= 32 TT) of an LDS tile [.][kRS] -> global rows of `row_stride` elements, 16-byte lanes.
@@ -645,12 +653,16 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       }
       // Q^T parked in this wave's own 32 columns of ys (each lane re-reads only its own token
       // row, and later overwrites it with the attention output of that same row)
-      store_t<TT>(ys, acc, 32 * w, lane);
+      store_t<TT>(ys, acc, 32 * w, lane, N);
       if constexpr (TRAIN) save_t<TT>(ts.qkv + ((int64_t)layer * a.B + b) * N * 3 * kD, 3 * kD, acc, 32 * w, N, lane);
       gemm_t<TT, true, true, kNx>(acc, wf, xs, lane, L.wqkv, 8, 8 + w, 0, bias_tile(L.bqkv + kD, 32 * w, hi));
       if constexpr (TRAIN) save_t<TT>(ts.qkv + ((int64_t)layer * a.B + b) * N * 3 * kD + kD, 3 * kD, acc, 32 * w, N, lane);
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) {
+        if (tt + 1 == TT) {  // padding keys: zero operand rows (see store_t) — their scores are masked either way
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[tt][r] = (32 * tt + l31 < N) ? acc[tt][r] : 0.0f;
+        }
         kf[tt][0] = frag_from_acc<E>(acc[tt], 0);
         kf[tt][1] = frag_from_acc<E>(acc[tt], 1);
         float h0, h1;
@@ -794,7 +806,9 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
         bf16x4 v;
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = (E)o[4 * c + i];
-        *reinterpret_cast<bf16x4*>(qrow + 8 * c + 4 * hi) = v;
+        uint2 u = __builtin_bit_cast(uint2, v);
+        if (qt + 1 == TT) u = (32 * qt + l31 < N) ? u : make_uint2(0u, 0u);  // padding queries: zero rows for the out-proj (see store_t)
+        *reinterpret_cast<uint2*>(qrow + 8 * c + 4 * hi) = u;
       }
     }
     __builtin_amdgcn_sched_barrier(0);     // keep these loads out of the attention loop (its register peak)
@@ -831,7 +845,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
 #pragma unroll
           for (int r = 0; r < 16; ++r) h1[tt][r] = relu(h1[tt][r], kInf);
         if (c > 0) rl4co::lds_barrier();  // every wave is done reading the previous chunk
-        store_t<TT>(ys, h1, 32 * w, lane);
+        store_t<TT>(ys, h1, 32 * w, lane, N);
         rl4co::lds_barrier();
         if constexpr (TRAIN) rows_out<TT>(ys, ts.h + ((int64_t)layer * a.B + b) * N * kFF + kD * c, kFF, N, tid);
         // next: FFN1 of the next chunk, then the next layer's Q projection, finally the first fold block
