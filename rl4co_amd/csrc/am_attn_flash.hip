@@ -21,6 +21,8 @@
 // bf16 operands, fp32 accumulation / softmax in the exp2 domain; tolerance-tested against fp32 torch attention.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "elem16.h"
 
@@ -98,18 +100,26 @@ __global__ void __launch_bounds__(kThreads, 4) attn_flash_kernel(const uint16_t*
   // ---- key blocks: rows prefetched into registers one block ahead --------------------------------------------
   // a block is 64 rows x 512 bytes (k | v) = 2048 16-byte chunks, four per thread
   uint4 pre[4];
+  // (the four row addresses are derived from an OPAQUE copy of the thread index inside every call: as loop-carried 64-bit
+  // pointers they and the two LDS offsets below did not fit the 128 registers of four waves per SIMD — r05 ISA: 11 scratch
+  // accesses in the key-block loop, every reload behind an s_waitcnt vmcnt(0) that also drained the NEXT block's prefetch)
+  const uint16_t* kvbase = base + kD;
   auto fetch = [&](int kb) {
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int c = tid + j * kThreads;
+      const int c = t_ + j * kThreads;
       const int row = min(kb * kKB + (c >> 5), N - 1), col = (c & 31) * 8;
-      pre[j] = *reinterpret_cast<const uint4*>(base + (int64_t)row * 3 * kD + kD + col);
+      pre[j] = *reinterpret_cast<const uint4*>(kvbase + (uint32_t)(row * (3 * kD) + col));
     }
   };
   auto commit = [&](int kb) {
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int c = tid + j * kThreads;
+      const int c = t_ + j * kThreads;
       const int r = c >> 5, col = (c & 31) * 8;
       const bool ok = kb * kKB + r < N;  // rows past the graph are zero (their scores are masked as well)
       *reinterpret_cast<uint4*>(kv + r * kKS + col) = ok ? pre[j] : make_uint4(0, 0, 0, 0);
@@ -123,14 +133,19 @@ __global__ void __launch_bounds__(kThreads, 4) attn_flash_kernel(const uint16_t*
   const int nao = tl * kKS + 4 * g;                          // natural operand read: row lane & 15, columns 4 g ..
   const int tro = (4 * g + (tl >> 2)) * kKS + 4 * (tl & 3);  // transpose read
   fetch(0);
-  for (int kb = 0; kb < nblocks; ++kb) {
+  // Only the LAST key block can hold rows past the graph. `tail` as a run-time condition inside the element loops came out
+  // as two selects per score in EVERY block (index compare + tail select: 68 v_cndmask, 16 compares and 16 index adds per
+  // block and wave, r05 ISA — a third of the block's VALU work): the last block is peeled off the loop instead, the loop
+  // body carries no masks at all.
+  auto key_block = [&](int kb, auto tail_c, auto fast_c) {
+    constexpr bool TAIL = decltype(tail_c)::value, FAST = decltype(fast_c)::value;
     if (kb > 0) __syncthreads();  // every wave is done reading the previous block
     commit(kb);
     __syncthreads();
     // Both paths DEFINE the four registers: with the plain "if (..) fetch(..)" the merge of fetched / kept values made the
     // compiler load into temporaries and copy them right behind the loads — an s_waitcnt vmcnt(2) that put the block's
     // global round trip back on the critical path; an unconditional fetch gets sunk to the top of the next iteration
-    if (kb + 1 < nblocks) {
+    if (!TAIL) {
       fetch(kb + 1);
     } else {
 #pragma unroll
@@ -142,67 +157,73 @@ __global__ void __launch_bounds__(kThreads, 4) attn_flash_kernel(const uint16_t*
       kf[j] = lds_b64(kv + 16 * j * kKS + 16 * h + nao);
       vf[j] = lds_tr(kv + 16 * j * kKS + kD + 16 * h + tro);
     }
-    const bool tail = (kb + 1) * kKB > N;
-    if (fast) {
-      // bounded scores: p = exp2(s) tile by tile — no maximum, no subtraction, no rescale of the accumulators
+      if constexpr (FAST) {
+        // bounded scores: p = exp2(s) tile by tile — no maximum, no subtraction, no rescale of the accumulators
+#pragma unroll
+        for (int t = 0; t < kQT; ++t) {
+          float ls = 0.0f;
+          f32x4 acc = o[t];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const f32x4 sj = mfma16(kf[j], qf[t], zero4());
+            bf16x4 pf;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              float p = __builtin_amdgcn_exp2f(sj[rr]);
+              if (TAIL) p = (kb * kKB + 16 * j + 4 * g + rr < N) ? p : 0.0f;
+              ls += p;
+              pf[rr] = (elem_t)p;
+            }
+            acc = mfma16(vf[j], pf, acc);
+          }
+          o[t] = acc;
+          l[t] += ls;
+        }
+        return;
+      }
 #pragma unroll
       for (int t = 0; t < kQT; ++t) {
-        float ls = 0.0f;
-        f32x4 acc = o[t];
+        f32x4 s[4];
+        float bm = kNegInf;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const f32x4 sj = mfma16(kf[j], qf[t], zero4());
+          s[j] = mfma16(kf[j], qf[t], zero4());
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            float v = PRE ? s[j][rr] : s[j][rr] * kScale;
+            if (TAIL) v = (kb * kKB + 16 * j + 4 * g + rr < N) ? v : kNegInf;
+            s[j][rr] = v;
+            bm = fmaxf(bm, v);
+          }
+        }
+        bm = rl4co::bfly_max<16, 64>(bm);  // the four row groups of a query agree on the block maximum
+        const float mn = fmaxf(m[t], bm);   // finite: every block holds at least one real key
+        const float alpha = __builtin_amdgcn_exp2f(m[t] - mn);  // exp2(-inf) = 0 on the first block
+        m[t] = mn;
+        float ls = 0.0f;
+        f32x4 acc = {o[t][0] * alpha, o[t][1] * alpha, o[t][2] * alpha, o[t][3] * alpha};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
           bf16x4 pf;
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
-            float p = __builtin_amdgcn_exp2f(sj[rr]);
-            if (tail) p = (kb * kKB + 16 * j + 4 * g + rr < N) ? p : 0.0f;
+            const float p = __builtin_amdgcn_exp2f(s[j][rr] - mn);
             ls += p;
             pf[rr] = (elem_t)p;
           }
           acc = mfma16(vf[j], pf, acc);
         }
         o[t] = acc;
-        l[t] += ls;
+        l[t] = fmaf(l[t], alpha, ls);  // this lane's keys only; the row groups meet after the last block
       }
-      continue;
-    }
-#pragma unroll
-    for (int t = 0; t < kQT; ++t) {
-      f32x4 s[4];
-      float bm = kNegInf;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        s[j] = mfma16(kf[j], qf[t], zero4());
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          float v = PRE ? s[j][rr] : s[j][rr] * kScale;
-          if (tail) v = (kb * kKB + 16 * j + 4 * g + rr < N) ? v : kNegInf;
-          s[j][rr] = v;
-          bm = fmaxf(bm, v);
-        }
-      }
-      bm = rl4co::bfly_max<16, 64>(bm);  // the four row groups of a query agree on the block maximum
-      const float mn = fmaxf(m[t], bm);   // finite: every block holds at least one real key
-      const float alpha = __builtin_amdgcn_exp2f(m[t] - mn);  // exp2(-inf) = 0 on the first block
-      m[t] = mn;
-      float ls = 0.0f;
-      f32x4 acc = {o[t][0] * alpha, o[t][1] * alpha, o[t][2] * alpha, o[t][3] * alpha};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        bf16x4 pf;
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          const float p = __builtin_amdgcn_exp2f(s[j][rr] - mn);
-          ls += p;
-          pf[rr] = (elem_t)p;
-        }
-        acc = mfma16(vf[j], pf, acc);
-      }
-      o[t] = acc;
-      l[t] = fmaf(l[t], alpha, ls);  // this lane's keys only; the row groups meet after the last block
-    }
-  }
+  };
+  // (the softmax path is chosen ONCE, outside the loop: with both bodies inside it the loop did not fit its 128 registers)
+  auto key_blocks = [&](auto fast_c) {
+    for (int kb = 0; kb + 1 < nblocks; ++kb) key_block(kb, std::false_type{}, fast_c);
+    key_block(nblocks - 1, std::true_type{}, fast_c);
+  };
+  if (fast) key_blocks(std::true_type{});
+  else key_blocks(std::false_type{});
   __syncthreads();  // the key block is dead: its buffer stages the output rows [kQT * 16][128]
 
   // ---- normalise, stage, leave as contiguous 16-byte lanes ------------------------------------------------------
