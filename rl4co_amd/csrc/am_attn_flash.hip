@@ -166,15 +166,14 @@ __global__ void __launch_bounds__(kThreads, 4) attn_flash_kernel(const uint16_t*
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const f32x4 sj = mfma16(kf[j], qf[t], zero4());
-            bf16x4 pf;
+            float p[4];
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-              float p = __builtin_amdgcn_exp2f(sj[rr]);
-              if (TAIL) p = (kb * kKB + 16 * j + 4 * g + rr < N) ? p : 0.0f;
-              ls += p;
-              pf[rr] = (elem_t)p;
+              p[rr] = __builtin_amdgcn_exp2f(sj[rr]);
+              if (TAIL) p[rr] = (kb * kKB + 16 * j + 4 * g + rr < N) ? p[rr] : 0.0f;
+              ls += p[rr];
             }
-            acc = mfma16(vf[j], pf, acc);
+            acc = mfma16(vf[j], rl4co_e16::cvt4(p[0], p[1], p[2], p[3]), acc);
           }
           o[t] = acc;
           l[t] += ls;
@@ -204,14 +203,13 @@ __global__ void __launch_bounds__(kThreads, 4) attn_flash_kernel(const uint16_t*
         f32x4 acc = {o[t][0] * alpha, o[t][1] * alpha, o[t][2] * alpha, o[t][3] * alpha};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          bf16x4 pf;
+          float p[4];
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
-            const float p = __builtin_amdgcn_exp2f(s[j][rr] - mn);
-            ls += p;
-            pf[rr] = (elem_t)p;
+            p[rr] = __builtin_amdgcn_exp2f(s[j][rr] - mn);
+            ls += p[rr];
           }
-          acc = mfma16(vf[j], pf, acc);
+          acc = mfma16(vf[j], rl4co_e16::cvt4(p[0], p[1], p[2], p[3]), acc);
         }
         o[t] = acc;
         l[t] = fmaf(l[t], alpha, ls);  // this lane's keys only; the row groups meet after the last block
@@ -230,10 +228,8 @@ __global__ void __launch_bounds__(kThreads, 4) attn_flash_kernel(const uint16_t*
 #pragma unroll
   for (int t = 0; t < kQT; ++t) {
     const float inv = __builtin_amdgcn_rcpf(rl4co::bfly_sum<16, 64>(l[t]));
-    bf16x4 ov;
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) ov[rr] = (elem_t)(o[t][rr] * inv);
-    *reinterpret_cast<bf16x4*>(kv + (16 * t + tl) * kOS + 16 * h + 4 * g) = ov;
+    *reinterpret_cast<bf16x4*>(kv + (16 * t + tl) * kOS + 16 * h + 4 * g) =
+        rl4co_e16::cvt4(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv);
   }
   __syncthreads();
   const int rows = min(kQT * 16, N - q0);

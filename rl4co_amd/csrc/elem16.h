@@ -57,6 +57,17 @@ __device__ inline uint32_t pack(float a, float b) {
   return __builtin_bit_cast(uint32_t, v);
 }
 
+// four fp32 -> four packed elements as TWO pair conversions (v_cvt_pk_bf16_f32 a, b / v_cvt_pkrtz..: one instruction per
+// pair). Built element by element — `v[i] = (elem_t)x[i]` with other arithmetic between the conversions — the compiler
+// converts each value alone (v_cvt_pk x, 0) and merges the halves with v_perm_b32: three instructions per pair (r05 ISA:
+// 592 single conversions + 296 v_perm in am_attn_flash alone).
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ inline e4 cvt4(float a, float b, float c, float d) {
+  const e2 lo2 = __builtin_convertvector(f2{a, b}, e2), hi2 = __builtin_convertvector(f2{c, d}, e2);
+  const uint2 u = make_uint2(__builtin_bit_cast(uint32_t, lo2), __builtin_bit_cast(uint32_t, hi2));
+  return __builtin_bit_cast(e4, u);
+}
+
 __device__ inline f16v mfma_32x32x16(const e8& a, const e8& b, const f16v& c) {
 #if RL4CO_ELEM_F16
   return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);

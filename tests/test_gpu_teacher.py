@@ -718,7 +718,7 @@ def test_c4_shaped_step_gradients_per_tensor_against_the_fp32_step(dt):
     fp32 planes, fp32 replay backward — itself pinned per tensor to torch autograd at 2e-3 and to the oracle's CPU gradients
     above). A 16-bit evaluation cannot meet an absolute 2e-2 against the fp32 truth — torch's OWN autocast step does not —
     so the bar is two-sided: every tensor with signal within `CAP` absolutely (first run: torch's autocast step itself is up to
-    0.16 / 0.05 away per tensor in bf16 / fp16) AND within 2x (median over the tensors: 1.25x) of what torch's autocast step
+    0.16 / 0.05 away per tensor in bf16 / fp16) AND within 1.6x (median over the tensors: 1.15x) of what torch's autocast step
     (the reference's regime, utils/trainer.py:57) loses on that same tensor. Replaces the all-parameter cosine as the
     tightest statement about the whole step."""
     from rl4co_amd.envs import get_env
@@ -760,14 +760,14 @@ def test_c4_shaped_step_gradients_per_tensor_against_the_fp32_step(dt):
         e_k = float((grads["kernels"][k] - g).norm() / g.norm())
         e_t = float((grads["torch16"][k] - g).norm() / g.norm())
         rows.append((e_k / max(e_t, 1e-3), e_k, e_t, k))
-    assert len(rows) >= 40
+    assert len(rows) >= 20
     rows.sort(reverse=True)
     print("worst ratio kernels / torch-autocast:", [(round(r, 2), round(a, 4), round(b, 4), k) for r, a, b, k in rows[:6]],
           "max abs:", max(r[1] for r in rows), "median ratio:", rows[len(rows) // 2][0])
     for ratio, e_k, e_t, k in rows:
         assert e_k <= CAP, f"{k}: kernels {e_k:.4f} (torch autocast {e_t:.4f})"
-        # per tensor no more than twice torch-autocast's own loss (first run: the worst is the last norm's bias, 0.062 against
-        # 0.039 — a sum over all B N tokens of a gradient the kernels round to 16 bits once more than autocast does) ...
-        assert e_k <= 2.0 * e_t + 5e-3, f"{k}: kernels {e_k:.4f} vs torch autocast {e_t:.4f}"
-    # ... and over all tensors no worse than it on the whole (median of the per-tensor ratios)
-    assert rows[len(rows) // 2][0] <= 1.25, rows[len(rows) // 2]
+        # per tensor no more than 1.6x torch-autocast's own loss (measured r05: worst 1.21 in bf16 — the last norm's bias —
+        # 1.33 in fp16; the fp32 atomics of the weight-gradient partials move these a little from run to run) ...
+        assert e_k <= 1.6 * e_t + 5e-3, f"{k}: kernels {e_k:.4f} vs torch autocast {e_t:.4f}"
+    # ... and over all tensors no worse than it on the whole (median of the per-tensor ratios; measured 0.81 / 1.01)
+    assert rows[len(rows) // 2][0] <= 1.15, rows[len(rows) // 2]
