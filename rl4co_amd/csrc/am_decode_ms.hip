@@ -352,6 +352,7 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
       const Traj& x = tj[c];
       const float4 c4 = c4v[c];
       const float cc[4] = {c4.x, c4.y, c4.z, c4.w};
+      float q4[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         float q;
@@ -366,8 +367,9 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
           if (kClock) q = fmaf(qt4[e], x.now, q);  // context.py:152-166: second scalar, the current time
           q = q + qb4[e];
         }
-        qf[c][e] = (elem_t)(q * (0.25f * kLog2e));
+        q4[e] = q * (0.25f * kLog2e);
       }
+      qf[c] = rl4co_e16::cvt4(q4[0], q4[1], q4[2], q4[3]);  // (two pair conversions: elem16.h)
     }
     // ---- 2. glimpse of head h ---------------------------------------------------------------------------
     {
@@ -418,13 +420,13 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
         const bf16x4 vf = lds_tr(sh.vs + 16 * jt * kRS + 16 * h + tro);
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
-          bf16x4 pf;
+          float p4[4];
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
-            const float p = __builtin_amdgcn_exp2f(sc[c][jt][rr] - m[c]);
-            l[c] += p;
-            pf[rr] = (elem_t)p;
+            p4[rr] = __builtin_amdgcn_exp2f(sc[c][jt][rr] - m[c]);
+            l[c] += p4[rr];
           }
+          const bf16x4 pf = rl4co_e16::cvt4(p4[0], p4[1], p4[2], p4[3]);
           if (PAIR) {
             const bf16x4 vf2 = lds_tr(sh.vs + sh.plane2 + 16 * jt * kRS + 16 * h + tro);
             if (jt & 1) {
@@ -445,14 +447,14 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
       for (int c = 0; c < CT; ++c) {
         const float ls = rg_sum(l[c]);
         const float inv = (ls > 0.0f) ? __builtin_amdgcn_rcpf(ls) : 0.0f;
-        bf16x4 of;
+        float o4[4];
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) {
           float acc = o0[c][rr] + o1[c][rr];
           if (PAIR) acc = half == 0 ? acc : p0[c][rr] + p1[c][rr];
-          of[rr] = (elem_t)(acc * inv);
+          o4[rr] = acc * inv;
         }
-        *reinterpret_cast<bf16x4*>(sh.hs + (16 * c + tl) * kRS + dcol) = of;
+        *reinterpret_cast<bf16x4*>(sh.hs + (16 * c + tl) * kRS + dcol) = rl4co_e16::cvt4(o4[0], o4[1], o4[2], o4[3]);
       }
     }
     rl4co::lds_barrier();  // B1 (LDS only: parked stores stay in flight)

@@ -68,12 +68,7 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ inline bf16x4 pack4(const f32x2& a, const f32x2& b) {  // two v_cvt_pk: (a0, a1), (b0, b1)
   return __builtin_bit_cast(bf16x4, u32x2{rl4co_e16::pack(a[0], a[1]), rl4co_e16::pack(b[0], b[1])});
 }
-__device__ inline bf16x4 to_bf16(const f32x4& v) {
-  bf16x4 o;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = (elem_t)v[i];
-  return o;
-}
+__device__ inline bf16x4 to_bf16(const f32x4& v) { return rl4co_e16::cvt4(v[0], v[1], v[2], v[3]); }  // two pair conversions (elem16.h)
 // LDS hand-off inside ONE wave
 __device__ inline void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -488,14 +483,16 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
           scatter_row<ENV>(dcc + (int64_t)pend_cur * kD + dcol, pend);
           pend_cur = -1;
         }
+        float q4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float q;
           if (ENV == RL4CO_ENV_TSP) q = (t == 0) ? qx4[e] + qb4[e] : (f4[e] + c[e]) + qb4[e];
           else if (kClock) q = fmaf(qt4[e], now, fmaf(qx4[e], rem, c[e])) + qb4[e];  // context.py:152-166
           else q = fmaf(qx4[e], rem, c[e]) + qb4[e];
-          qf[e] = (elem_t)(q * (0.25f * kLog2e));
+          q4[e] = q * (0.25f * kLog2e);
         }
+        qf = rl4co_e16::cvt4(q4[0], q4[1], q4[2], q4[3]);
         *reinterpret_cast<bf16x4*>(qb + tl * kRS + dcol) = qf;
       }
 

@@ -46,12 +46,7 @@ __device__ inline bf16x4 lds_tr(const elem_t* p) {
   const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
   return __builtin_bit_cast(bf16x4, v);
 }
-__device__ inline bf16x4 to_bf16(const f32x4& v) {
-  bf16x4 o;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) o[i] = (elem_t)v[i];
-  return o;
-}
+__device__ inline bf16x4 to_bf16(const f32x4& v) { return rl4co_e16::cvt4(v[0], v[1], v[2], v[3]); }  // two pair conversions (elem16.h)
 __device__ inline void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
@@ -150,13 +145,13 @@ __global__ void __launch_bounds__(kThreads, 4) attn_fwd_kernel(const uint16_t* _
     f32x4 o0 = zero4(), o1 = zero4();
 #pragma clang loop unroll(full)
     for (int jt = 0; jt < NT; ++jt) {
-      bf16x4 pf;
+      float p4[4];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const float p = __builtin_amdgcn_exp2f(sc[jt][rr] - m);
-        l += p;
-        pf[rr] = (elem_t)p;
+        p4[rr] = __builtin_amdgcn_exp2f(sc[jt][rr] - m);
+        l += p4[rr];
       }
+      const bf16x4 pf = rl4co_e16::cvt4(p4[0], p4[1], p4[2], p4[3]);
       const bf16x4 vf = lds_tr(kv + 16 * jt * kKV + kD + 16 * h + tro);
       if (jt & 1) o1 = mfma16(vf, pf, o1);
       else o0 = mfma16(vf, pf, o0);
@@ -265,13 +260,15 @@ __global__ void __launch_bounds__(kBwdThreads, 3) attn_bwd_kernel(const uint16_t
     for (int jt = 0; jt < NT; ++jt) {
       const f32x4 sc = mfma16(lds_b64(kv + 16 * jt * kKH + 16 * w + nao), qf, zero4());
       dp[jt] = mfma16(lds_b64(kv + 16 * jt * kKH + 64 + 16 * w + nao), dof, zero4());
+      float p4[4];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
         const bool ok = tv && (16 * jt + 4 * g + rr < N);
-        const float p = ok ? __builtin_amdgcn_exp2f(sc[rr] * kScale - L) : 0.0f;
-        pf[jt][rr] = (elem_t)p;
-        dsum = fmaf((float)pf[jt][rr], dp[jt][rr], dsum);
+        p4[rr] = ok ? __builtin_amdgcn_exp2f(sc[rr] * kScale - L) : 0.0f;
       }
+      pf[jt] = rl4co_e16::cvt4(p4[0], p4[1], p4[2], p4[3]);
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) dsum = fmaf((float)pf[jt][rr], dp[jt][rr], dsum);
       *reinterpret_cast<bf16x4*>(pbw + tl * kPS + 16 * jt + 4 * g) = pf[jt];
     }
     dsum = rg_sum(dsum);
@@ -285,9 +282,10 @@ __global__ void __launch_bounds__(kBwdThreads, 3) attn_bwd_kernel(const uint16_t
     f32x4 dq = zero4();
 #pragma clang loop unroll(full)
     for (int jt = 0; jt < NT; ++jt) {
-      bf16x4 dsf;
+      float d4[4];
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) dsf[rr] = (elem_t)((float)pf[jt][rr] * (dp[jt][rr] - dsum));
+      for (int rr = 0; rr < 4; ++rr) d4[rr] = (float)pf[jt][rr] * (dp[jt][rr] - dsum);
+      const bf16x4 dsf = rl4co_e16::cvt4(d4[0], d4[1], d4[2], d4[3]);
       *reinterpret_cast<bf16x4*>(pbw + tl * kPS + 16 * jt + 4 * g) = dsf;
       dq = mfma16(lds_tr(kv + 16 * jt * kKH + 16 * w + tro), dsf, dq);
     }
