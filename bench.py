@@ -1004,7 +1004,9 @@ def main() -> None:
     order = sorted(range(len(legs)), key=lambda j: (legs[j] != "c4_train", j))
     for i in order:
         leg = legs[i]
-        k, w = (args.steps, args.warmup) if i == 0 else (leg_steps, max(2, min(args.warmup, 3)))
+        # (the further legs warm up for at least five steps: their first region otherwise opens on a chip that idled through the
+        # previous leg's teardown — r05: c4 20.8 ms in the first region against 20.1 - 20.3 in the four after it)
+        k, w = (args.steps, args.warmup) if i == 0 else (leg_steps, max(5, args.warmup))
         if leg == "c4_train":
             k = min(k, max(5, args.steps // 20)) if i else k
             results[leg] = bench.train_leg(k, max(w, args.warmup))  # first leg of the process: clocks, allocator, code objects

@@ -65,7 +65,8 @@ def test_default_legs_line_stays_small_and_carries_baseline_and_parity():
     assert cb["one_thread"]["c1"] > 0
     # spread over the repeated K-step regions, headline and legs
     rs = line["region_ms_per_step"]
-    assert rs["n"] >= 5 and rs["min"] <= rs["median"] <= rs["max"] and rs["min"] <= line["ms_per_step"] <= rs["max"]
+    assert rs["n"] >= 5 and rs["min"] <= rs["median"] <= rs["max"]
+    assert rs["min"] * (1 - 1e-3) <= line["ms_per_step"] <= rs["max"] * (1 + 1e-3)  # (the line's numbers carry four digits)
     assert all(len(v["ms_min_med"]) == 2 for v in line["legs"].values())
     assert set(line["legs"]) >= {"c2_sampling", "c3_greedy", "c5_sampling", "c4_train", "c2_greedy_fp32"}
     assert all(v["ms_per_step"] > 0 for v in line["legs"].values())
