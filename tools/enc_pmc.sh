@@ -27,3 +27,4 @@ for f in glob.glob(sys.argv[1]+"/p*/*/*_counter_collection.csv"):
 for k,v in sorted(agg.items()):
     print(f"{k:36s} mean {sum(v['v'])/len(v['v']):16.1f}  n={len(v['v'])}")
 PY
+find $O -name "*counter_collection.csv" -size +2M -delete

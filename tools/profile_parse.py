@@ -53,6 +53,11 @@ for legdir in sorted(p for p in src.iterdir() if p.is_dir()):
                 if r["Counter_Name"] == name:
                     agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
             for k, v in agg.items():
+                if "hbm_read_probe" in k:
+                    # the calibration launches read 2 GiB each; bench.py's untimed warm-up runs the same kernel over 256 MiB
+                    # (thousands of dispatches, pruned to a handful by profile_legs.sh): keep the large ones only
+                    big = [x for x in v if x >= 0.5 * max(v)]
+                    v = big or v
                 if any(s in k for s in ("am_decode", "am_encoder", "hbm_read_probe", "tour_length", "attn_flash", "linear_bf16")):
                     res.setdefault(k[:90], {})[name] = {"dispatches": len(v), "mean_KB": sum(v) / len(v)}
     if res:

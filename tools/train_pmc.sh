@@ -21,4 +21,4 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- 
 find $O -name "*_kernel_trace.csv" -delete
 find $O -name "*.db" -delete
 python3 $R/tools/train_pmc_parse.py $O
-du -sh $O
+find $O -name "*counter_collection.csv" -size +2M -delete; du -sh $O
