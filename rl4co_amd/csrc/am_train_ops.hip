@@ -651,7 +651,14 @@ namespace {
 
 constexpr int kWT = 64;        // token rows per LDS step: the step is one exposed HBM round trip, so the products per
                                // step must outlast it (at 32 rows two resident workgroups kept the matrix pipe ~40 % busy)
-constexpr int kWLS = 128 + 8;  // LDS row stride (bf16)
+#ifndef RL4CO_WLS
+#define RL4CO_WLS 144  // (probe knob: tools/kernel_variant.sh am_train_ops.hip <name> "-DRL4CO_WLS=136")
+#endif
+// LDS row stride (bf16). Both tiles are READ only through ds_read_b64_tr_b16: a 32-lane group takes eight rows x 32 bytes,
+// and with 272-byte rows (68 dwords) consecutive rows overlap in four of their eight banks — SQ_LDS_BANK_CONFLICT /
+// SQ_LDS_IDX_ACTIVE = 0.50 (profiles/r05_c4_train_pmc.json). 288-byte rows (72 dwords = 8 mod 64) put the eight rows on
+// disjoint banks: -3 % on the wide shapes (r05: 123.6 -> 119.0 us at N = 512, K = 128).
+constexpr int kWLS = RL4CO_WLS;
 
 typedef elem_t bf16x4w __attribute__((ext_vector_type(4)));
 typedef short s16x4w __attribute__((ext_vector_type(4)));
