@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from rl4co_amd.policy import AttentionModelPolicy
 from rl4co_amd.envs import get_env
 
-DT = torch.bfloat16
+DT = torch.float32 if (len(sys.argv) > 1 and sys.argv[1] == "f32") else torch.bfloat16  # python tools/enc_power_probe.py [f32]
 env = get_env("tsp", generator_params=dict(num_loc=100, device="cuda"), device="cuda")
 td = env.reset(batch_size=[4096])
 
@@ -38,7 +38,7 @@ def smi():
 
 for name in ("random", "zeros", "tiny", "random"):
     torch.manual_seed(0)
-    pol = AttentionModelPolicy("tsp", cache_dtype=DT, encoder_autocast=DT).cuda().eval()
+    pol = AttentionModelPolicy("tsp", cache_dtype=DT, encoder_autocast=None if DT == torch.float32 else DT).cuda().eval()
     t = td
     if name == "zeros":
         with torch.no_grad():
@@ -53,6 +53,6 @@ for name in ("random", "zeros", "tiny", "random"):
     got = {}
     th = threading.Thread(target=lambda: got.update(smi=(time.sleep(0.25), smi())[1]))
     th.start()
-    ms = bench(pol, t, iters=600)
+    ms = bench(pol, t, iters=600 if DT != torch.float32 else 100)
     th.join()
     print(f"{name:7s} {ms:.3f} ms   [{got.get('smi')}]")
