@@ -979,8 +979,7 @@ __device__ inline void tok_load(E* xs, const E* src, int b, int n0, int N, int t
 }
 template <typename E>
 __device__ inline void tok_store(const E* xs, E* dst, int64_t row_stride, int valid, int tid) {
-  for (int i = tid; i < valid * 16; i += kThreads)
-    *reinterpret_cast<uint4*>(dst + (int64_t)(i >> 4) * row_stride + 8 * (i & 15)) = *reinterpret_cast<const uint4*>(xs + (i >> 4) * kRS + 8 * (i & 15));
+  rows_out<kTokT>(xs, dst, row_stride, valid, tid);  // a FIXED number of unconditional stores (see rows_out: no vmcnt(0) behind it)
 }
 
 template <typename E>
@@ -1016,8 +1015,8 @@ __global__ void __launch_bounds__(kThreads, 2) tok16_qkv_kernel(const E* __restr
 #pragma unroll 1
   for (int part = 0; part < 3; ++part) {
     f32x16 acc[kTokT];
-    gemm_t<kTokT>(acc, wf, xs, lane, part < 2 ? wqkv : static_cast<const E*>(nullptr), 8, 4 * (part + 1) + w, 0,
-                  bias_tile(bl + kD * part, 32 * w, hi));
+    gemm_t<kTokT, true, true, 1>(acc, wf, xs, lane, wqkv, 8, part < 2 ? 4 * (part + 1) + w : w, 0,  // (last part: a dummy fetch)
+                                 bias_tile(bl + kD * part, 32 * w, hi));
     if (part < 2) {
       float m0 = 0.0f, m1 = 0.0f;
 #pragma unroll
@@ -1065,7 +1064,7 @@ __global__ void __launch_bounds__(kThreads, 2) tok16_mlp_kernel(const E* __restr
   __syncthreads();
   {
     f32x16 y[kTokT];
-    gemm_t<kTokT>(y, wf, ys, lane, w1, 8, w, 0, zero16());  // (out_proj's bias rides in the norm's shift: encoder.py)
+    gemm_t<kTokT, true, true, 1>(y, wf, ys, lane, w1, 8, w, 0, zero16());  // (out_proj's bias rides in the norm's shift: encoder.py)
     residual_norm<kTokT>(xs, y, 32 * w, n1a, n1b, 0, N, lane);
   }
   __syncthreads();
@@ -1076,7 +1075,7 @@ __global__ void __launch_bounds__(kThreads, 2) tok16_mlp_kernel(const E* __restr
 #pragma unroll 1
     for (int c = 0; c < 4; ++c) {
       f32x16 h1[kTokT];
-      gemm_t<kTokT>(h1, wf, xs, lane, w2, 32, w, 8 * c, bias_tile(bl, 32 * (4 * c + w), hi));
+      gemm_t<kTokT, true, true, 1>(h1, wf, xs, lane, w2, 32, w, 8 * c, bias_tile(bl, 32 * (4 * c + w), hi));
 #pragma unroll
       for (int tt = 0; tt < kTokT; ++tt)
 #pragma unroll
@@ -1084,7 +1083,7 @@ __global__ void __launch_bounds__(kThreads, 2) tok16_mlp_kernel(const E* __restr
       __syncthreads();  // every wave is done reading ys (the attention output / the previous chunk)
       store_t<kTokT>(ys, h1, 32 * w, lane);
       __syncthreads();
-      gemm_t<kTokT, true, false>(y2, wf, ys, lane, c < 3 ? w1 : static_cast<const E*>(nullptr), 8, 4 * (c + 1) + w, 0, y2[0]);
+      gemm_t<kTokT, true, false, 1>(y2, wf, ys, lane, w1, 8, c < 3 ? 4 * (c + 1) + w : w, 0, y2[0]);  // (last chunk: a dummy fetch)
     }
     residual_norm<kTokT>(xs, y2, 32 * w, n2a, n2b, 0, N, lane);
   }
@@ -1155,7 +1154,7 @@ __global__ void __launch_bounds__(kThreads, 2) tok16_attn_half_kernel(const E* _
   tok_load(ys, att, b, n0, N, tid);
   __syncthreads();
   f32x16 y[kTokT];
-  gemm_t<kTokT>(y, wf, ys, lane, static_cast<const E*>(nullptr), 0, 0, 0, zero16());
+  gemm_t<kTokT, true, true, 0>(y, wf, ys, lane, static_cast<const E*>(nullptr), 0, 0, 0, zero16());
   residual_stats<kTokT>(xs, y, 32 * w, pre_bias, valid, lane, stats + ((int64_t)b * gridDim.x + blockIdx.x) * kStatFloats);
   __syncthreads();
   tok_store(xs, ypre + ((int64_t)b * N + n0) * kD, kD, valid, tid);
@@ -1185,7 +1184,7 @@ __global__ void __launch_bounds__(kThreads, 2) tok16_ffn_half_kernel(const E* __
 #pragma unroll 1
   for (int c = 0; c < 4; ++c) {
     f32x16 h1[kTokT];
-    gemm_t<kTokT>(h1, wf, xs, lane, w2, 32, w, 8 * c, bias_tile(bl, 32 * (4 * c + w), hi));
+    gemm_t<kTokT, true, true, 1>(h1, wf, xs, lane, w2, 32, w, 8 * c, bias_tile(bl, 32 * (4 * c + w), hi));
 #pragma unroll
     for (int tt = 0; tt < kTokT; ++tt)
 #pragma unroll
@@ -1193,7 +1192,7 @@ __global__ void __launch_bounds__(kThreads, 2) tok16_ffn_half_kernel(const E* __
     if (c > 0) __syncthreads();  // every wave is done reading the previous chunk
     store_t<kTokT>(ys, h1, 32 * w, lane);
     __syncthreads();
-    gemm_t<kTokT, true, false>(y2, wf, ys, lane, c < 3 ? w1 : static_cast<const E*>(nullptr), 8, 4 * (c + 1) + w, 0, y2[0]);
+    gemm_t<kTokT, true, false, 1>(y2, wf, ys, lane, w1, 8, c < 3 ? 4 * (c + 1) + w : w, 0, y2[0]);
   }
   residual_stats<kTokT>(xs, y2, 32 * w, pre_bias, valid, lane, stats + ((int64_t)b * gridDim.x + blockIdx.x) * kStatFloats);
   __syncthreads();
@@ -1295,10 +1294,13 @@ __global__ void __launch_bounds__(kThreads, TT <= 2 ? 3 : 2) tok16_mlp_bwd_kerne
   constexpr bool kAhead = TT <= 2;
   uint4 hq[kAhead ? kPieces : 1];
   auto fetch = [&](int c) {
+    int t_ = tid;
+    asm volatile("" : "+v"(t_));  // (row addresses per call: kept across the chunk loop two of them were spilled, and a scratch reload waits with vmcnt(0))
 #pragma unroll
     for (int p = 0; p < kPieces; ++p) {
-      const int i = tid + kThreads * p, row = i >> 4, c16 = i & 15;
-      hq[kAhead ? p : 0] = row < valid ? *reinterpret_cast<const uint4*>(h + (int64_t)(r0 + row) * kFF + kD * c + 8 * c16) : make_uint4(0, 0, 0, 0);
+      const int i = t_ + kThreads * p, row = i >> 4, c16 = i & 15;
+      const uint4 hv = *reinterpret_cast<const uint4*>(h + (int64_t)(r0 + min(row, valid - 1)) * kFF + kD * c + 8 * c16);  // (unconditional: a counted load)
+      hq[kAhead ? p : 0] = row < valid ? hv : make_uint4(0, 0, 0, 0);
     }
   };
   if constexpr (kAhead) fetch(0);
@@ -1317,7 +1319,7 @@ __global__ void __launch_bounds__(kThreads, TT <= 2 ? 3 : 2) tok16_mlp_bwd_kerne
     }
     __syncthreads();
     f32x16 g[TT];
-    gemm_t<TT>(g, wf, xs, lane, w1t, 32, w, 8 * c, zero16());  // next: dx += dh chunk . W1 (k-steps 8 c ..)
+    gemm_t<TT, true, true, 1>(g, wf, xs, lane, w1t, 32, w, 8 * c, zero16());  // next: dx += dh chunk . W1 (k-steps 8 c ..)
     // the ReLU mask from this wave's own 32 hidden columns of the staged h chunk; dh goes back over them
 #pragma unroll
     for (int tt = 0; tt < TT; ++tt) {
@@ -1330,10 +1332,8 @@ __global__ void __launch_bounds__(kThreads, TT <= 2 ? 3 : 2) tok16_mlp_bwd_kerne
     }
     store_t<TT>(ys, g, 32 * w, lane);
     __syncthreads();
-    for (int i = tid; i < valid * 16; i += kThreads)
-      *reinterpret_cast<uint4*>(dh + (int64_t)(r0 + (i >> 4)) * kFF + kD * c + 8 * (i & 15)) =
-          *reinterpret_cast<const uint4*>(ys + (i >> 4) * kRS + 8 * (i & 15));
-    gemm_t<TT, true, false>(acc, wf, ys, lane, c < 3 ? w2t : static_cast<const E*>(nullptr), 8, 4 * (c + 1) + w, 0, acc[0]);
+    rows_out<TT>(ys, dh + (int64_t)r0 * kFF + kD * c, kFF, valid, tid);  // (fixed-trip stores: the product below waits for its weights only)
+    gemm_t<TT, true, false, 1>(acc, wf, ys, lane, w2t, 8, c < 3 ? 4 * (c + 1) + w : w, 0, acc[0]);  // (last chunk: a dummy fetch)
   }
   // + dy (the skip connection's gradient), this wave's 32 columns of the dy tile, then out through the same tile
 #pragma unroll
@@ -1347,7 +1347,7 @@ __global__ void __launch_bounds__(kThreads, TT <= 2 ? 3 : 2) tok16_mlp_bwd_kerne
   }
   store_t<TT>(xs, acc, 32 * w, lane);
   __syncthreads();
-  tok_store(xs, dx + (int64_t)r0 * kD, kD, valid, tid);
+  rows_out<TT>(xs, dx + (int64_t)r0 * kD, kD, valid, tid);
 }
 
 // cache planes (16-bit or fp32) and fp32 context tables of one token tile, as the fused kernel's fold writes them
@@ -1367,8 +1367,7 @@ __global__ void __launch_bounds__(kThreads, 2) tok16_fold_kernel(const E* __rest
 #pragma unroll 1
   for (int blk = 0; blk < nblocks; ++blk) {
     f32x16 acc[kTokT];
-    gemm_t<kTokT>(acc, wf, xs, lane, blk + 1 < nblocks ? wf_all + (int64_t)(blk + 1) * kD * kD : static_cast<const E*>(nullptr), 8, w, 0,
-                  zero16());
+    gemm_t<kTokT, true, true, 1>(acc, wf, xs, lane, wf_all + (int64_t)(blk + 1 < nblocks ? blk + 1 : 0) * kD * kD, 8, w, 0, zero16());
     if (blk < 3 && a.cache_dtype != RL4CO_DT_F32) {
       store_t<kTokT>(ys, acc, 32 * w, lane);
       __syncthreads();
@@ -1394,8 +1393,13 @@ __global__ void __launch_bounds__(kThreads, 2) tok16_fold_kernel(const E* __rest
         }
         __syncthreads();
         const int rows = min(64, valid - 64 * p);
-        for (int i = tid; i < rows * 32; i += kThreads)
-          *reinterpret_cast<float4*>(out + (int64_t)(64 * p + (i >> 5)) * kD + 4 * (i & 31)) = *reinterpret_cast<const float4*>(fs + (i >> 5) * kFS + 4 * (i & 31));
+        if (rows > 0) {  // (uniform; a fixed number of unconditional stores: see rows_out)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int i = tid + kThreads * j, row = min(i >> 5, rows - 1), c4 = i & 31;
+            *reinterpret_cast<float4*>(out + (int64_t)(64 * p + row) * kD + 4 * c4) = *reinterpret_cast<const float4*>(fs + row * kFS + 4 * c4);
+          }
+        }
         __syncthreads();
       }
     }
