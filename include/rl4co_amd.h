@@ -661,11 +661,12 @@ int rl4co_wgrad_bf16(const void* dy, const void* x, int64_t M, int N, int K, int
  *   rl4co/models/nn/attention.py:110-134 (rearrange to heads + scaled_dot_product_attention)
  * qkv [B,N,384] bf16 = per node (q | k | v), each 8 heads x 16 dims. forward: out [B,N,128] bf16
  * (heads concatenated) and lse [B,8,N] fp32 (log2-domain log-sum-exp of the scaled scores);
- * backward: dqkv [B,N,384] bf16 from dout [B,N,128]. N <= rl4co_attn_max_nodes().
+ * backward: dqkv [B,N,384] bf16 from dout [B,N,128] and the forward's own out (the softmax
+ * backward's row term sum_keys P dP is taken as sum_d dout out). N <= rl4co_attn_max_nodes().
  * -------------------------------------------------------------------------- */
 int rl4co_attn_fwd_bf16(const void* qkv, int B, int N, void* out, float* lse, void* stream);
-int rl4co_attn_bwd_bf16(const void* qkv, const void* dout, const float* lse, int B, int N, void* dqkv,
-                        void* stream);
+int rl4co_attn_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse, int B, int N,
+                        void* dqkv, void* stream);
 int rl4co_attn_max_nodes(void);
 
 /* --------------------------------------------------------------------------
@@ -719,8 +720,8 @@ int rl4co_linear_f16(const void* a, const void* w, const float* bias, const void
 int rl4co_wgrad_f16(const void* dy, const void* x, int64_t M, int N, int K, int chunks, float* partial,
                      float* partial_bias, int64_t chunk_stride, void* stream);
 int rl4co_attn_fwd_f16(const void* qkv, int B, int N, void* out, float* lse, void* stream);
-int rl4co_attn_bwd_f16(const void* qkv, const void* dout, const float* lse, int B, int N, void* dqkv,
-                        void* stream);
+int rl4co_attn_bwd_f16(const void* qkv, const void* out, const void* dout, const float* lse, int B, int N,
+                       void* dqkv, void* stream);
 int rl4co_attn_flash_f16(const void* qkv, int B, int N, void* out, void* stream);
 int rl4co_attn_flash_pre_f16(const void* qkv, const float* bound, int B, int N, void* out, void* stream);
 

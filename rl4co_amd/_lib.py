@@ -120,7 +120,7 @@ SYMBOLS = {
     "rl4co_init_embed_wgrad_bf16": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp]),
     "rl4co_linear_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_attn_fwd_bf16": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
-    "rl4co_attn_bwd_bf16": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_attn_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_attn_max_nodes": (C.c_int, []),
     "rl4co_attn_flash_bf16": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_attn_flash_pre_bf16": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
@@ -157,7 +157,7 @@ SYMBOLS = {
     "rl4co_init_embed_wgrad_f16": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp]),
     "rl4co_linear_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_attn_fwd_f16": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
-    "rl4co_attn_bwd_f16": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_attn_bwd_f16": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_attn_flash_f16": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_attn_flash_pre_f16": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_wgrad_f16": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp]),

@@ -190,8 +190,9 @@ constexpr int kPS = kD + 32 + 8;  // a wave's staging row: 128 key columns (P, t
 constexpr int kDS = 3 * 64 + 8;   // output staging row: d q | d k | d v of four heads
 
 template <int NT>
-__global__ void __launch_bounds__(kBwdThreads, 3) attn_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ dout,
-                                                                  const float* __restrict__ lse, int N, uint16_t* __restrict__ dqkv) {
+__global__ void __launch_bounds__(kBwdThreads, 3) attn_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
+                                                                  const uint16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                                  int N, uint16_t* __restrict__ dqkv) {
   extern __shared__ __align__(16) unsigned char smem[];
   elem_t* kv = reinterpret_cast<elem_t*>(smem);  // [16 NT][kKH]: k (4 heads) | v (4 heads)
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
@@ -223,10 +224,12 @@ __global__ void __launch_bounds__(kBwdThreads, 3) attn_bwd_kernel(const uint16_t
   // wait for ALL outstanding loads at the join, i.e. for the prefetch it has just issued)
   const uint16_t* qrow = base + 16 * h + 4 * g;
   const uint16_t* dorow = dout + inst * N * kD + 16 * h + 4 * g;
+  const uint16_t* orow = out + inst * N * kD + 16 * h + 4 * g;
   const float* lrow = lse + (inst * kWaves + h) * N;
   auto row_of = [&](int tb) { return (int64_t)min(16 * tb + tl, N - 1); };
   uint2 q_next = *reinterpret_cast<const uint2*>(qrow + row_of(0) * 3 * kD);
   uint2 do_next = *reinterpret_cast<const uint2*>(dorow + row_of(0) * kD);
+  uint2 o_next = *reinterpret_cast<const uint2*>(orow + row_of(0) * kD);
   float L_next = lrow[row_of(0)];
   __syncthreads();
   const int nao = tl * kKH + 4 * g;
@@ -245,33 +248,51 @@ __global__ void __launch_bounds__(kBwdThreads, 3) attn_bwd_kernel(const uint16_t
     const bf16x4 qf = __builtin_bit_cast(bf16x4, q_next);
     const bf16x4 dof = __builtin_bit_cast(bf16x4, tv ? do_next : make_uint2(0u, 0u));
     const float L = L_next;
+    // D = sum_keys P dP = sum_d dO O of this (query, head): from the forward's saved output — 4 products per lane and
+    // the row-group sum — instead of 4 NT products with P converted back from its 16-bit form (r05). It enters the
+    // dP product as the accumulator's initial value, so that MFMA leaves dP - D and dS is one multiply per element:
+    // the kernel is VALU-issue bound (profiles/r05_c4_train_pmc.json: 10 VALU per MFMA), 51 -> 20 VALU per key tile.
+    float dsum;
+    {
+      const uint2 ou = o_next, du = tv ? do_next : make_uint2(0u, 0u);
+      dsum = rl4co_e16::lo(ou.x) * rl4co_e16::lo(du.x);
+      dsum = fmaf(rl4co_e16::hi(ou.x), rl4co_e16::hi(du.x), dsum);
+      dsum = fmaf(rl4co_e16::lo(ou.y), rl4co_e16::lo(du.y), dsum);
+      dsum = fmaf(rl4co_e16::hi(ou.y), rl4co_e16::hi(du.y), dsum);
+      dsum = -rg_sum(dsum);
+    }
+    const f32x4 negD = {dsum, dsum, dsum, dsum};
     {
       const int64_t rn = row_of(min(tb + 1, NT - 1));  // (the last block re-reads itself: no branch around the loads)
       q_next = *reinterpret_cast<const uint2*>(qrow + rn * 3 * kD);
       do_next = *reinterpret_cast<const uint2*>(dorow + rn * kD);
+      o_next = *reinterpret_cast<const uint2*>(orow + rn * kD);
       L_next = lrow[rn];
     }
     *reinterpret_cast<bf16x4*>(pbw + tl * kPS + kD + 4 * g) = dof;
     *reinterpret_cast<bf16x4*>(pbw + tl * kPS + kD + 16 + 4 * g) = qf;
-    bf16x4 pf[NT];
-    f32x4 dp[NT];
-    float dsum = 0.0f;
+    // No mask on the queries past N: their d out is zero, so dP - D = 0 = dS and d v receives nothing from them, while P
+    // itself stays finite (the clamped row's own scores and log-sum-exp). Keys past N: their k and v rows are zero, so
+    // d q receives nothing from them and their own d k / d v rows are never stored — but their P = exp2(-L) must not
+    // overflow (inf x 0): the exponent is clamped at 0 in the tiles that can hold them (N > 16 (smallest tile count
+    // dispatched to this NT) - 16).
+    constexpr int kMinN = NT == 2 ? 1 : (NT == 4 ? 33 : (NT == 7 ? 65 : 113));
+    bf16x4 pf[NT], dsf[NT];
 #pragma clang loop unroll(full)
     for (int jt = 0; jt < NT; ++jt) {
       const f32x4 sc = mfma16(lds_b64(kv + 16 * jt * kKH + 16 * w + nao), qf, zero4());
-      dp[jt] = mfma16(lds_b64(kv + 16 * jt * kKH + 64 + 16 * w + nao), dof, zero4());
+      const f32x4 dp = mfma16(lds_b64(kv + 16 * jt * kKH + 64 + 16 * w + nao), dof, negD);
       float p4[4];
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) {
-        const bool ok = tv && (16 * jt + 4 * g + rr < N);
-        p4[rr] = ok ? __builtin_amdgcn_exp2f(sc[rr] * kScale - L) : 0.0f;
+        float e = fmaf(sc[rr], kScale, -L);
+        if (16 * (jt + 1) > kMinN) e = fminf(e, 0.0f);
+        p4[rr] = __builtin_amdgcn_exp2f(e);
       }
       pf[jt] = rl4co_e16::cvt4(p4[0], p4[1], p4[2], p4[3]);
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) dsum = fmaf((float)pf[jt][rr], dp[jt][rr], dsum);
+      dsf[jt] = rl4co_e16::cvt4(p4[0] * dp[0], p4[1] * dp[1], p4[2] * dp[2], p4[3] * dp[3]);
       *reinterpret_cast<bf16x4*>(pbw + tl * kPS + 16 * jt + 4 * g) = pf[jt];
     }
-    dsum = rg_sum(dsum);
     wave_lds_sync();
     {
       const bf16x4 dt = lds_tr(pbw + kD + tro_p);  // dO_h^T[d][queries]
@@ -282,12 +303,8 @@ __global__ void __launch_bounds__(kBwdThreads, 3) attn_bwd_kernel(const uint16_t
     f32x4 dq = zero4();
 #pragma clang loop unroll(full)
     for (int jt = 0; jt < NT; ++jt) {
-      float d4[4];
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) d4[rr] = (float)pf[jt][rr] * (dp[jt][rr] - dsum);
-      const bf16x4 dsf = rl4co_e16::cvt4(d4[0], d4[1], d4[2], d4[3]);
-      *reinterpret_cast<bf16x4*>(pbw + tl * kPS + 16 * jt + 4 * g) = dsf;
-      dq = mfma16(lds_tr(kv + 16 * jt * kKH + 16 * w + tro), dsf, dq);
+      *reinterpret_cast<bf16x4*>(pbw + tl * kPS + 16 * jt + 4 * g) = dsf[jt];
+      dq = mfma16(lds_tr(kv + 16 * jt * kKH + 16 * w + tro), dsf[jt], dq);
     }
     wave_lds_sync();
     {
@@ -329,12 +346,12 @@ int launch_fwd(const void* qkv, int B, int N, void* out, float* lse, hipStream_t
   return RL4CO_OK;
 }
 template <int NT>
-int launch_bwd(const void* qkv, const void* dout, const float* lse, int B, int N, void* dqkv, hipStream_t s) {
+int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, int B, int N, void* dqkv, hipStream_t s) {
   constexpr int work = (NT * 16 * kKH + kBwdWaves * 16 * kPS) * 2, stage = NT * 16 * kDS * 2;
   constexpr int lds = work > stage ? work : stage;
   RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipLaunchKernelGGL(attn_bwd_kernel<NT>, dim3(2 * B), dim3(kBwdThreads), lds, s, static_cast<const uint16_t*>(qkv),
-                     static_cast<const uint16_t*>(dout), lse, N, static_cast<uint16_t*>(dqkv));
+                     static_cast<const uint16_t*>(out), static_cast<const uint16_t*>(dout), lse, N, static_cast<uint16_t*>(dqkv));
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }
@@ -355,12 +372,13 @@ extern "C" int RL4CO_ENTRY(rl4co_attn_fwd)(const void* qkv, int B, int N, void* 
   return launch_fwd<8>(qkv, B, N, out, lse, s);
 }
 
-extern "C" int RL4CO_ENTRY(rl4co_attn_bwd)(const void* qkv, const void* dout, const float* lse, int B, int N, void* dqkv, void* stream) {
-  RL4CO_REQUIRE(qkv && dout && lse && dqkv && B > 0 && B < (1 << 30) && N >= 1 && N <= 128);
+extern "C" int RL4CO_ENTRY(rl4co_attn_bwd)(const void* qkv, const void* out, const void* dout, const float* lse, int B, int N, void* dqkv,
+                                           void* stream) {
+  RL4CO_REQUIRE(qkv && out && dout && lse && dqkv && B > 0 && B < (1 << 30) && N >= 1 && N <= 128);
   hipStream_t s = rl4co::as_stream(stream);
   const int nt = (N + 15) >> 4;
-  if (nt <= 2) return launch_bwd<2>(qkv, dout, lse, B, N, dqkv, s);
-  if (nt <= 4) return launch_bwd<4>(qkv, dout, lse, B, N, dqkv, s);
-  if (nt <= 7) return launch_bwd<7>(qkv, dout, lse, B, N, dqkv, s);
-  return launch_bwd<8>(qkv, dout, lse, B, N, dqkv, s);
+  if (nt <= 2) return launch_bwd<2>(qkv, out, dout, lse, B, N, dqkv, s);
+  if (nt <= 4) return launch_bwd<4>(qkv, out, dout, lse, B, N, dqkv, s);
+  if (nt <= 7) return launch_bwd<7>(qkv, out, dout, lse, B, N, dqkv, s);
+  return launch_bwd<8>(qkv, out, dout, lse, B, N, dqkv, s);
 }

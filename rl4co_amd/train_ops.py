@@ -412,16 +412,16 @@ class _Attention(torch.autograd.Function):
         st = _k("rl4co_attn_fwd", q.dtype)(q.data_ptr(), b, n, out.data_ptr(), lse.data_ptr(),
                                             torch.cuda.current_stream().cuda_stream)
         _lib.check(st, "rl4co_attn_fwd")
-        ctx.save_for_backward(q, lse)
+        ctx.save_for_backward(q, lse, out)
         return out
 
     @staticmethod
     def backward(ctx, dout: Tensor):
-        q, lse = ctx.saved_tensors
+        q, lse, out = ctx.saved_tensors
         b, n, _ = q.shape
         d = dout.to(q.dtype).contiguous()
         dqkv = torch.empty_like(q)
-        st = _k("rl4co_attn_bwd", q.dtype)(q.data_ptr(), d.data_ptr(), lse.data_ptr(), b, n, dqkv.data_ptr(),
+        st = _k("rl4co_attn_bwd", q.dtype)(q.data_ptr(), out.data_ptr(), d.data_ptr(), lse.data_ptr(), b, n, dqkv.data_ptr(),
                                             torch.cuda.current_stream().cuda_stream)
         _lib.check(st, "rl4co_attn_bwd")
         return dqkv
@@ -495,7 +495,7 @@ def _attention_block_bwd(kind, dout, x2, wqkv16, wo16, qkv, lse, att, y, g32, me
     datt = _gemm(d2, wo16.t().contiguous() if wt is None else wt[1])
     hwo = _wgrad(d2, att.reshape(-1, d), with_bias=True, arena=arena, key=("wo", layer))
     dqkv = torch.empty_like(qkv)
-    _lib.check(_k("rl4co_attn_bwd", qkv.dtype)(qkv.data_ptr(), datt.data_ptr(), lse.data_ptr(), b, n, dqkv.data_ptr(),
+    _lib.check(_k("rl4co_attn_bwd", qkv.dtype)(qkv.data_ptr(), att.data_ptr(), datt.data_ptr(), lse.data_ptr(), b, n, dqkv.data_ptr(),
                                               torch.cuda.current_stream().cuda_stream), "rl4co_attn_bwd")
     dq2 = dqkv.view(-1, 3 * d)
     dx = _gemm(dq2, wqkv16.t().contiguous() if wt is None else wt[0], residual=d2)

@@ -241,7 +241,7 @@ def test_fused_linear_and_mlp_gradients_match_torch(dt):
 
 
 @pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
-@pytest.mark.parametrize("n", [20, 50, 100, 101, 112, 113, 128])
+@pytest.mark.parametrize("n", [2, 17, 20, 33, 40, 50, 64, 65, 81, 100, 101, 112, 113, 128])
 def test_fused_attention_matches_torch_sdpa(n, dt):
     """csrc/am_train_attn.hip forward / backward vs torch SDPA in fp32 on the same bf16 qkv: output within
     1.5e-2 absolute (bf16 output, bf16 softmax numerators), d qkv within 3e-2 relative Frobenius error."""
@@ -265,6 +265,25 @@ def test_fused_attention_matches_torch_sdpa(n, dt):
     for name, sl in (("dq", slice(0, 128)), ("dk", slice(128, 256)), ("dv", slice(256, 384))):
         rel = float((gk[..., sl].float() - gr[..., sl]).norm() / gr[..., sl].norm())
         assert rel <= 3e-2, (name, rel)
+
+
+@pytest.mark.parametrize("n", [40, 100])
+def test_fused_attention_backward_stays_finite_when_every_score_is_far_below_zero(n):
+    """The backward does not mask the key rows past N (csrc/am_train_attn.hip: their k / v rows are zero, so nothing they
+    produce is stored or reaches d q) — but their probability exp2(0 - lse) must not overflow when an instance's
+    log-sum-exp is far below -128: q = +6 |u|, k = -6 |u'| puts every scaled score near -130 in the log2 domain."""
+    from rl4co_amd import train_ops
+
+    torch.manual_seed(n)
+    b = 8
+    qkv = torch.randn(b, n, 384, device="cuda")
+    qkv[..., :128] = 6.0 * qkv[..., :128].abs()
+    qkv[..., 128:256] = -6.0 * qkv[..., 128:256].abs()
+    qk = qkv.bfloat16().requires_grad_(True)
+    out = train_ops.attention(qk)
+    (gk,) = torch.autograd.grad(out, [qk], torch.randn(b, n, 128, device="cuda").bfloat16())
+    assert torch.isfinite(out.float()).all() and torch.isfinite(gk.float()).all()
+    assert float(gk.float().abs().max()) > 0.0
 
 
 def _pomo_policy(seed=0, fused=True, normalization="instance", graph_context=False, env_name="tsp", dt=torch.bfloat16):
