@@ -178,27 +178,53 @@ __global__ void __launch_bounds__(kThreads, 4) attn_fwd_kernel(const uint16_t* _
 
 // Backward. One 256-thread workgroup per (instance, half of the heads): wave w owns head 4 hh + w. A head only ever
 // touches its own 16 columns of q, k, v and d out, so the halves share nothing; what the split buys is footprint —
-// k | v of four heads (30 KB) + the four waves' staging blocks (21 KB) let THREE workgroups (12 waves) share a CU
-// where the eight-head workgroup (150 KB) ran alone. Per query block the q / d out fragments (8 bytes per lane, the
-// B-operand layout) and the log-sum-exp come straight from global memory one block ahead; their transposed A-operand
-// forms go through 2 x 512 bytes of the wave's staging block; d q waits in registers; at the end the whole LDS holds
-// [N][d q | d k | d v] of the four heads and leaves as 16-byte lanes over 128-byte row segments.
+// k | v of four heads (30 KB) + the four waves' staging blocks (20 KB) let THREE workgroups (12 waves) share a CU
+// where the eight-head workgroup (150 KB) ran alone. Per query block the q / d out fragments (8 bytes per lane) and the
+// row statistics come straight from global memory one block ahead. Orientation (r05): the score tile is computed with the
+// QUERY on the accumulator rows, S[q][key] = Q K^T — then P and dS leave the softmax already in the B-operand layout of
+// BOTH products that contract over queries (d V^T = dO^T P, d K^T = Q^T dS) and only dS goes through LDS, for the one
+// product that contracts over keys (d Q^T = K^T dS^T): a [key][query] block written as 8-byte lanes and read back through
+// ds_read_b64_tr_b16. (Until r05 the key sat on the rows: P AND dS each made the round trip, two more wave syncs per block.)
+// d q waits in registers; at the end the whole LDS holds [N][d q | d k | d v] of the four heads and leaves as 16-byte
+// lanes over 128-byte row segments.
 constexpr int kBwdWaves = 4;
 constexpr int kBwdThreads = 64 * kBwdWaves;
 constexpr int kKH = kD + 8;       // LDS row stride of k | v of four heads (64 + 64 columns)
-constexpr int kPS = kD + 32 + 8;  // a wave's staging row: 128 key columns (P, then dS) | 16 d-out | 16 q columns
+constexpr int kSS = 16;           // a wave's dS block: [16 NT keys][16 queries], dense (the transpose read's 8 rows x 32 bytes tile the 64 banks)
+constexpr int kQD = 32 + 8;       // a wave's [16 queries][16 d-out | 16 q columns] rows
 constexpr int kDS = 3 * 64 + 8;   // output staging row: d q | d k | d v of four heads
+
+#ifndef RL4CO_ATTN_BWD_PROBE
+#define RL4CO_ATTN_BWD_PROBE 0  // timing probes (tools/kernel_variant.sh): 1 = no query blocks (load + store phases only), 2 = no
+#endif                          // exponentials, 3 = per-phase shader-clock sums in g_attn_bwd_clk (rl4co_attn_bwd_probe_read)
+#if RL4CO_ATTN_BWD_PROBE >= 3
+__device__ unsigned long long g_attn_bwd_clk[4];
+#define RL4CO_ABP_MARK(i)                                                               \
+  {                                                                                     \
+    const unsigned long long now_ = __builtin_readcyclecounter();                       \
+    if (threadIdx.x == 0) atomicAdd(&g_attn_bwd_clk[i], now_ - clk_);                    \
+    clk_ = now_;                                                                        \
+  }
+#else
+#define RL4CO_ABP_MARK(i)
+#endif
 
 template <int NT>
 __global__ void __launch_bounds__(kBwdThreads, 3) attn_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
                                                                   const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                   int N, uint16_t* __restrict__ dqkv) {
   extern __shared__ __align__(16) unsigned char smem[];
+#if RL4CO_ATTN_BWD_PROBE >= 3
+  unsigned long long clk_ = __builtin_readcyclecounter();
+#endif
   elem_t* kv = reinterpret_cast<elem_t*>(smem);  // [16 NT][kKH]: k (4 heads) | v (4 heads)
   const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
   const int64_t inst = blockIdx.x >> 1;
   const int hh = blockIdx.x & 1, h = 4 * hh + w;
-  elem_t* pbw = kv + NT * 16 * kKH + w * 16 * kPS;  // this wave's [16 queries][kPS]
+  constexpr int kWaveStage = NT * 16 * kSS + 16 * kQD + 64;  // (elements) dS block | d-out, q rows | 16 x (L, -D) fp32
+  elem_t* dsb = kv + NT * 16 * kKH + w * kWaveStage;
+  elem_t* qd = dsb + NT * 16 * kSS;
+  float2* ld = reinterpret_cast<float2*>(qd + 16 * kQD);
   const uint16_t* base = qkv + inst * N * 3 * kD;
   {  // k | v columns of this half: 16 chunks of 16 bytes per row, eight in flight per thread
     constexpr int total = NT * 16 * 16;
@@ -233,7 +259,8 @@ __global__ void __launch_bounds__(kBwdThreads, 3) attn_bwd_kernel(const uint16_t
   float L_next = lrow[row_of(0)];
   __syncthreads();
   const int nao = tl * kKH + 4 * g;
-  const int tro = (4 * g + (tl >> 2)) * kKH + 4 * (tl & 3), tro_p = (4 * g + (tl >> 2)) * kPS + 4 * (tl & 3);
+  const int tro = (4 * g + (tl >> 2)) * kKH + 4 * (tl & 3), tro_q = (4 * g + (tl >> 2)) * kQD + 4 * (tl & 3),
+            tro_s = (4 * g + (tl >> 2)) * kSS + 4 * (tl & 3);
   f32x4 dk[NT], dv[NT];  // [d = 4 g + r of head h][key 16 jt + (lane & 15)]
   bf16x4 dqv[NT];        // d q of the block's queries, kept until the output staging
 #pragma unroll
@@ -241,8 +268,9 @@ __global__ void __launch_bounds__(kBwdThreads, 3) attn_bwd_kernel(const uint16_t
     dk[jt] = zero4();
     dv[jt] = zero4();
   }
+  RL4CO_ABP_MARK(0)
 #pragma clang loop unroll(full)
-  for (int tb = 0; tb < NT; ++tb) {
+  for (int tb = 0; tb < (RL4CO_ATTN_BWD_PROBE == 1 ? 0 : NT); ++tb) {
     const int t = 16 * tb + tl;
     const bool tv = t < N;
     const bf16x4 qf = __builtin_bit_cast(bf16x4, q_next);
@@ -261,63 +289,85 @@ __global__ void __launch_bounds__(kBwdThreads, 3) attn_bwd_kernel(const uint16_t
       dsum = fmaf(rl4co_e16::hi(ou.y), rl4co_e16::hi(du.y), dsum);
       dsum = -rg_sum(dsum);
     }
-    const f32x4 negD = {dsum, dsum, dsum, dsum};
-    {
+    if (RL4CO_ATTN_BWD_PROBE != 4) {
       const int64_t rn = row_of(min(tb + 1, NT - 1));  // (the last block re-reads itself: no branch around the loads)
       q_next = *reinterpret_cast<const uint2*>(qrow + rn * 3 * kD);
       do_next = *reinterpret_cast<const uint2*>(dorow + rn * kD);
       o_next = *reinterpret_cast<const uint2*>(orow + rn * kD);
       L_next = lrow[rn];
     }
-    *reinterpret_cast<bf16x4*>(pbw + tl * kPS + kD + 4 * g) = dof;
-    *reinterpret_cast<bf16x4*>(pbw + tl * kPS + kD + 16 + 4 * g) = qf;
+    *reinterpret_cast<bf16x4*>(qd + tl * kQD + 4 * g) = dof;
+    *reinterpret_cast<bf16x4*>(qd + tl * kQD + 16 + 4 * g) = qf;
+    if (g == 0) ld[tl] = make_float2(L, dsum);
+    wave_lds_sync();
+    // this lane's accumulator rows are queries 4 g .. 4 g + 3 of the block: their (L, -D)
+    const float4 s01 = *reinterpret_cast<const float4*>(ld + 4 * g), s23 = *reinterpret_cast<const float4*>(ld + 4 * g + 2);
+    const float Lr[4] = {s01.x, s01.z, s23.x, s23.z};
+    const f32x4 negD = {s01.y, s01.w, s23.y, s23.w};
+    const bf16x4 dt = lds_tr(qd + tro_q);       // dO_h^T[d][queries]
+    const bf16x4 qt = lds_tr(qd + 16 + tro_q);  // Q_h^T[d][queries]
     // No mask on the queries past N: their d out is zero, so dP - D = 0 = dS and d v receives nothing from them, while P
     // itself stays finite (the clamped row's own scores and log-sum-exp). Keys past N: their k and v rows are zero, so
     // d q receives nothing from them and their own d k / d v rows are never stored — but their P = exp2(-L) must not
     // overflow (inf x 0): the exponent is clamped at 0 in the tiles that can hold them (N > 16 (smallest tile count
     // dispatched to this NT) - 16).
     constexpr int kMinN = NT == 2 ? 1 : (NT == 4 ? 33 : (NT == 7 ? 65 : 113));
-    bf16x4 pf[NT], dsf[NT];
+    // Key tiles in groups of four, every stage over the whole group before the next one: written tile by tile the
+    // compiler keeps that order — LDS read, wait, score MFMA, 8 idle slots, exponentials, ... — and with three waves per
+    // SIMD nothing covers the latencies (r05: the whole block was one dependent chain of ~ 4.6 K cycles).
+    constexpr int kG = NT == 8 ? 2 : 4;  // (eight tiles: d k, d v and the waiting d q take 80 registers — groups of two fit the 168 of three waves per SIMD)
 #pragma clang loop unroll(full)
-    for (int jt = 0; jt < NT; ++jt) {
-      const f32x4 sc = mfma16(lds_b64(kv + 16 * jt * kKH + 16 * w + nao), qf, zero4());
-      const f32x4 dp = mfma16(lds_b64(kv + 16 * jt * kKH + 64 + 16 * w + nao), dof, negD);
-      float p4[4];
+    for (int j0 = 0; j0 < NT; j0 += kG) {
+      bf16x4 kf[kG], vf[kG], pf[kG], dsf[kG];
+      f32x4 sc[kG], dp[kG];
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        float e = fmaf(sc[rr], kScale, -L);
-        if (16 * (jt + 1) > kMinN) e = fminf(e, 0.0f);
-        p4[rr] = __builtin_amdgcn_exp2f(e);
-      }
-      pf[jt] = rl4co_e16::cvt4(p4[0], p4[1], p4[2], p4[3]);
-      dsf[jt] = rl4co_e16::cvt4(p4[0] * dp[0], p4[1] * dp[1], p4[2] * dp[2], p4[3] * dp[3]);
-      *reinterpret_cast<bf16x4*>(pbw + tl * kPS + 16 * jt + 4 * g) = pf[jt];
+      for (int j = 0; j < kG; ++j)
+        if (j0 + j < NT) {
+          kf[j] = lds_b64(kv + 16 * (j0 + j) * kKH + 16 * w + nao);
+          vf[j] = lds_b64(kv + 16 * (j0 + j) * kKH + 64 + 16 * w + nao);
+        }
+#pragma unroll
+      for (int j = 0; j < kG; ++j)
+        if (j0 + j < NT) sc[j] = mfma16(qf, kf[j], zero4());  // S[query 4 g + r][key tl]
+#pragma unroll
+      for (int j = 0; j < kG; ++j)
+        if (j0 + j < NT) dp[j] = mfma16(dof, vf[j], negD);  // dP - D
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < kG; ++j)
+        if (j0 + j < NT) {
+          float p4[4];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            float e = fmaf(sc[j][rr], kScale, -Lr[rr]);
+            if (16 * (j0 + j + 1) > kMinN) e = fminf(e, 0.0f);
+            p4[rr] = RL4CO_ATTN_BWD_PROBE == 2 ? e : __builtin_amdgcn_exp2f(e);
+          }
+          pf[j] = rl4co_e16::cvt4(p4[0], p4[1], p4[2], p4[3]);
+          dsf[j] = rl4co_e16::cvt4(p4[0] * dp[j][0], p4[1] * dp[j][1], p4[2] * dp[j][2], p4[3] * dp[j][3]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < kG; ++j)
+        if (j0 + j < NT) {
+          dv[j0 + j] = mfma16(dt, pf[j], dv[j0 + j]);
+          dk[j0 + j] = mfma16(qt, dsf[j], dk[j0 + j]);
+          *reinterpret_cast<bf16x4*>(dsb + (16 * (j0 + j) + tl) * kSS + 4 * g) = dsf[j];  // [key][queries 4 g ..]
+        }
     }
     wave_lds_sync();
-    {
-      const bf16x4 dt = lds_tr(pbw + kD + tro_p);  // dO_h^T[d][queries]
-#pragma clang loop unroll(full)
-      for (int jt = 0; jt < NT; ++jt) dv[jt] = mfma16(dt, lds_tr(pbw + 16 * jt + tro_p), dv[jt]);
-    }
-    wave_lds_sync();  // the transpose reads of P are done: the block is reused for dS
     f32x4 dq = zero4();
 #pragma clang loop unroll(full)
-    for (int jt = 0; jt < NT; ++jt) {
-      *reinterpret_cast<bf16x4*>(pbw + tl * kPS + 16 * jt + 4 * g) = dsf[jt];
-      dq = mfma16(lds_tr(kv + 16 * jt * kKH + 16 * w + tro), dsf[jt], dq);
-    }
-    wave_lds_sync();
-    {
-      const bf16x4 qt = lds_tr(pbw + kD + 16 + tro_p);  // Q_h^T[d][queries]
-#pragma clang loop unroll(full)
-      for (int jt = 0; jt < NT; ++jt) dk[jt] = mfma16(qt, lds_tr(pbw + 16 * jt + tro_p), dk[jt]);
-    }
+    for (int jt = 0; jt < NT; ++jt)
+      dq = mfma16(lds_tr(kv + 16 * jt * kKH + 16 * w + tro), lds_tr(dsb + 16 * jt * kSS + tro_s), dq);
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) dq[rr] *= 0.25f;
     dqv[tb] = to_bf16(dq);
     wave_lds_sync();  // the next query block rewrites this wave's staging block
   }
+  RL4CO_ABP_MARK(1)
   __syncthreads();  // every wave is done with k | v: the whole LDS becomes [16 NT][d q | d k | d v] of the four heads
+  RL4CO_ABP_MARK(2)
   elem_t* os = reinterpret_cast<elem_t*>(smem);
 #pragma unroll
   for (int jt = 0; jt < NT; ++jt) {
@@ -334,6 +384,7 @@ __global__ void __launch_bounds__(kBwdThreads, 3) attn_bwd_kernel(const uint16_t
     *reinterpret_cast<uint4*>(dqkv + (inst * N + row) * 3 * kD + seg * kD + 64 * hh + 8 * ch) =
         *reinterpret_cast<const uint4*>(os + row * kDS + 64 * seg + 8 * ch);
   }
+  RL4CO_ABP_MARK(3)
 }
 
 template <int NT>
@@ -347,7 +398,7 @@ int launch_fwd(const void* qkv, int B, int N, void* out, float* lse, hipStream_t
 }
 template <int NT>
 int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, int B, int N, void* dqkv, hipStream_t s) {
-  constexpr int work = (NT * 16 * kKH + kBwdWaves * 16 * kPS) * 2, stage = NT * 16 * kDS * 2;
+  constexpr int work = (NT * 16 * kKH + kBwdWaves * (NT * 16 * kSS + 16 * kQD + 64)) * 2, stage = NT * 16 * kDS * 2;
   constexpr int lds = work > stage ? work : stage;
   RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipLaunchKernelGGL(attn_bwd_kernel<NT>, dim3(2 * B), dim3(kBwdThreads), lds, s, static_cast<const uint16_t*>(qkv),
@@ -360,6 +411,16 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
 
 #if !RL4CO_ELEM_F16
 extern "C" int rl4co_attn_max_nodes(void) { return 128; }
+#if RL4CO_ATTN_BWD_PROBE >= 3
+extern "C" int rl4co_attn_bwd_probe_read(unsigned long long* out, int reset) {
+  RL4CO_HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_bwd_clk), sizeof(g_attn_bwd_clk)));
+  if (reset) {
+    const unsigned long long z[4] = {0, 0, 0, 0};
+    RL4CO_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_attn_bwd_clk), z, sizeof(z)));
+  }
+  return RL4CO_OK;
+}
+#endif
 #endif
 
 extern "C" int RL4CO_ENTRY(rl4co_attn_fwd)(const void* qkv, int B, int N, void* out, float* lse, void* stream) {

@@ -22,7 +22,7 @@ for b, n, scale in ((4096, 100, 1.0), (256, 100, 0.5), (256, 50, 1.0), (256, 128
 
     def bwd():
         if old:
-            return lib.rl4co_attn_bwdold_bf16(vp(qkv.data_ptr()), vp(go.data_ptr()), vp(lse.data_ptr()), b, n, vp(dqkv.data_ptr()), vp(s))
+            return lib.rl4co_attn_bwd_bf16(vp(qkv.data_ptr()), vp(go.data_ptr()), vp(lse.data_ptr()), b, n, vp(dqkv.data_ptr()), vp(s))
         return lib.rl4co_attn_bwd_bf16(vp(qkv.data_ptr()), vp(out.data_ptr()), vp(go.data_ptr()), vp(lse.data_ptr()), b, n, vp(dqkv.data_ptr()), vp(s))
 
     assert bwd() == 0
