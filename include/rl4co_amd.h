@@ -495,6 +495,14 @@ int rl4co_am_encoder_f32(const rl4co_am_encoder_args* args, void* stream);
 int rl4co_am_encoder_tokens_f32(const rl4co_am_encoder_args* args, void* workspace, int64_t workspace_bytes, void* stream);
 int64_t rl4co_am_encoder_tokens_f32_workspace(int B, int N);
 
+/* The init embeddings alone: out[B,N,128] in the activations' type (act_dtype BF16 / F16: ..._init_embeds16; F32:
+ * ..._init_embeds_f32) from the same argument struct — only env, B, N, act_dtype, the feature pointers and the init
+ * embedding's weights are read. Replaces `init_embeds` of AttentionModelPolicy.forward(return_init_embeds=True)
+ * (rl4co/models/zoo/am/encoder.py:84-103 returns them next to the final embeddings; env_embeddings/init.py). It is the
+ * token path's first launch, i.e. the routine the fused kernels run internally. */
+int rl4co_am_encoder_init_embeds16(const rl4co_am_encoder_args* args, void* out, void* stream);
+int rl4co_am_encoder_init_embeds_f32(const rl4co_am_encoder_args* args, float* out, void* stream);
+
 /* fp32 side of the cache fold from the final node embeddings of ANY encoder (zoo/am/decoder.py:201-228, cache.py):
  * out[i][B,N,128] = h . W_i^T for nblocks <= 5 blocks of [128,128] packed as for rl4co_am_encoder_f32 (the context
  * tables), and q_bias[B,128] = w_fixed . mean_j h[b,j] (w_fixed plain [128,128] fp32; both NULL: skipped). h: [B,N,128]

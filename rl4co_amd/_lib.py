@@ -133,6 +133,8 @@ SYMBOLS = {
     "rl4co_am_encoder_f32": (C.c_int, [_vp, _vp]),
     "rl4co_am_encoder_tokens_f32": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "rl4co_am_encoder_tokens_f32_workspace": (C.c_int64, [C.c_int, C.c_int]),
+    "rl4co_am_encoder_init_embeds16": (C.c_int, [_vp, _vp, _vp]),
+    "rl4co_am_encoder_init_embeds_f32": (C.c_int, [_vp, _vp, _vp]),
     "rl4co_am_fold_tables_f32": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, _vp, C.c_int, _vp, _vp, _vp, _vp]),
     "rl4co_am_decode_lds_bytes": (C.c_int, [C.c_int, C.c_int]),
     "rl4co_am_decode_row_groups": (C.c_int, [C.POINTER(AmDecodeArgs)]),

@@ -1684,3 +1684,31 @@ extern "C" int rl4co_am_encoder_tokens16(const rl4co_am_encoder_args* args, void
   hipStream_t s = rl4co::as_stream(stream);
   return a.act_dtype == RL4CO_DT_F16 ? launch_tokens16<_Float16>(a, workspace, s) : launch_tokens16<__bf16>(a, workspace, s);
 }
+
+// The init embeddings alone (reference: `init_embeds` of AttentionModelPolicy.forward(return_init_embeds=True),
+// zoo/am/encoder.py:84-103, env_embeddings/init.py): the token path's first launch, i.e. the same init_embed_rows16 the
+// fused kernel runs — so what is handed back is what the encoder computed from, in the activations' type.
+extern "C" int rl4co_am_encoder_init_embeds16(const rl4co_am_encoder_args* args, void* out, void* stream) {
+  RL4CO_REQUIRE(args != nullptr && out != nullptr);
+  const rl4co_am_encoder_args& a = *args;
+  RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP || a.env == RL4CO_ENV_PDP);
+  RL4CO_REQUIRE(a.B > 0 && a.N >= 2 && a.B <= 65535);
+  RL4CO_REQUIRE(a.act_dtype == RL4CO_DT_BF16 || a.act_dtype == RL4CO_DT_F16);
+  RL4CO_REQUIRE(a.locs && a.w_init && a.b_init);
+  RL4CO_REQUIRE(a.env != RL4CO_ENV_CVRP || (a.demand && a.w_depot && a.b_depot));
+  RL4CO_REQUIRE(a.env != RL4CO_ENV_PDP || (a.w_depot && a.b_depot && a.w_extra && a.b_extra && (a.N - 1) % 2 == 0));
+  hipStream_t s = rl4co::as_stream(stream);
+  const dim3 grid((a.N + kTok - 1) / kTok, a.B), block(kThreads);
+  const bool half = a.act_dtype == RL4CO_DT_F16;
+  const int lds_init = kTok * kRS * 2 + 6 * a.N * 4 + 64;
+  RL4CO_REQUIRE(lds_init <= 80 * 1024);
+  if (half) {
+    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tok16_init_embed_kernel<_Float16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_init));
+    hipLaunchKernelGGL(tok16_init_embed_kernel<_Float16>, grid, block, lds_init, s, a, static_cast<_Float16*>(out));
+  } else {
+    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(tok16_init_embed_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_init));
+    hipLaunchKernelGGL(tok16_init_embed_kernel<__bf16>, grid, block, lds_init, s, a, static_cast<__bf16*>(out));
+  }
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}

@@ -637,3 +637,24 @@ extern "C" int rl4co_am_fold_tables_f32(const void* h, int h_dtype, int B, int N
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }
+
+// The init embeddings alone, fp32 (`init_embeds` of AttentionModelPolicy.forward(return_init_embeds=True) in the
+// bit-identical configuration): the token path's first launch — the same init_embed_rows as the fused fp32 kernel.
+extern "C" int rl4co_am_encoder_init_embeds_f32(const rl4co_am_encoder_args* args, float* out, void* stream) {
+  RL4CO_REQUIRE(args != nullptr && out != nullptr);
+  const rl4co_am_encoder_args& a = *args;
+  RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP || a.env == RL4CO_ENV_PDP);
+  RL4CO_REQUIRE(a.B > 0 && a.N >= 2 && a.B <= 65535);
+  RL4CO_REQUIRE(a.act_dtype == RL4CO_DT_F32);
+  RL4CO_REQUIRE(a.locs && a.w_init && a.b_init);
+  RL4CO_REQUIRE(a.env != RL4CO_ENV_CVRP || (a.demand && a.w_depot && a.b_depot));
+  RL4CO_REQUIRE(a.env != RL4CO_ENV_PDP || (a.w_depot && a.b_depot && a.w_extra && a.b_extra && (a.N - 1) % 2 == 0));
+  hipStream_t s = rl4co::as_stream(stream);
+  const dim3 grid((a.N + kTile - 1) / kTile, a.B), block(kThreads);
+  const int lds_init = kLdsTile + 6 * a.N * 4 + 64;
+  RL4CO_REQUIRE(lds_init <= 160 * 1024);
+  if (int e = set_lds(tok_init_embed_kernel, lds_init)) return e;
+  hipLaunchKernelGGL(tok_init_embed_kernel, grid, block, lds_init, s, a, out);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}

@@ -229,12 +229,15 @@ class PackedEncoder:
         return kind in ("batch", "instance", "layer") and td["locs"].is_cuda
 
     def encode(self, td, cache_dtype: torch.dtype, want_hidden: bool = False,
-               act_dtype: torch.dtype | None = None, fold: bool = True, tokens: bool | None = None) -> tuple[FoldedCache, Tensor | None]:
+               act_dtype: torch.dtype | None = None, fold: bool = True, tokens: bool | None = None,
+               init_embeds_out: Tensor | None = None) -> tuple[FoldedCache, Tensor | None]:
         """``act_dtype``: bfloat16 / float16 = the autocast regime the encoder is asked to compute in; the planes are
         written as ``cache_dtype`` = float32 or that same 16-bit type. float32 = the exact-fp32 kernel
         (``rl4co_am_encoder_f32``; planes in any of the three types). ``fold=False`` (fp32 kernel, tsp / cvrp): the
         reference's own association of the decoder — raw K_g / V_g / K_l planes and the node embeddings, no context tables.
-        ``tokens``: force (True) / forbid (False) the token-tile launches of the fp32 encoder (default: beyond 128 nodes)."""
+        ``tokens``: force (True) / forbid (False) the token-tile launches of the fp32 encoder (default: beyond 128 nodes).
+        ``init_embeds_out`` ([B, N, 128] of ``act_dtype``): also filled with the init embeddings (``return_init_embeds``) by one
+        more launch of the routine the encoder kernels run internally (``rl4co_am_encoder_init_embeds16`` / ``_f32``)."""
         t = self.refresh(act_dtype=act_dtype)
         exact = self.act_dtype == torch.float32
         if exact:
@@ -298,6 +301,12 @@ class PackedEncoder:
             entry = "rl4co_am_encoder_f32" if exact else "rl4co_am_encoder"
             st = getattr(_lib.lib(), entry)(C.byref(a), torch.cuda.current_stream().cuda_stream)
         _lib.check(st, entry)
+        if init_embeds_out is not None:
+            if (init_embeds_out.shape != (b, n, d) or init_embeds_out.dtype != self.act_dtype or not init_embeds_out.is_contiguous()
+                    or init_embeds_out.device != dev):
+                raise ValueError("init_embeds_out must be a contiguous [B, N, 128] tensor of the encoder's activation type")
+            entry = "rl4co_am_encoder_init_embeds_f32" if exact else "rl4co_am_encoder_init_embeds16"
+            _lib.check(getattr(_lib.lib(), entry)(C.byref(a), init_embeds_out.data_ptr(), torch.cuda.current_stream().cuda_stream), entry)
         if not fold:
             dec = pol.decoder
             ph = getattr(dec.context_embedding, "W_placeholder", None)

@@ -687,24 +687,26 @@ class AttentionModelPolicy(nn.Module):
         # are fp32 or that same 16-bit type
         use_fused = (self.fused_encoder and self.fold and regime16 is not None and not grad_path
                      and cache_dtype in (torch.float32, regime16)
-                     and not return_init_embeds and self._packed_encoder().supported(td))
+                     and self._packed_encoder().supported(td))
         # fp32 regime (no autocast: the bit-identical configuration): the exact-fp32 MFMA encoder (csrc/am_encoder_f32.hip),
         # planes in any type, also with fold=False (tsp / cvrp: the reference's own association of the decoder)
         use_fused_f32 = (self.fused_encoder and self._encoder_regime() is None and not grad_path and td["locs"].is_cuda
                          and (self.fold or self.env_name in ("tsp", "cvrp"))
-                         and not return_init_embeds and self._packed_encoder().supported(td, torch.float32))
+                         and self._packed_encoder().supported(td, torch.float32))
         if use_fused_f32:
             use_fused, regime16 = True, torch.float32
         if use_fused:
             if self.encode_events is not None:  # bench.py: HIP events around the encoder launch
                 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 ev0.record()
+            # return_init_embeds (zoo/am/encoder.py:84-103): one more launch of the kernels' own init-embedding routine
+            init_embeds = (torch.empty((*td["locs"].shape[:2], 128), dtype=regime16, device=td["locs"].device)
+                           if return_init_embeds else None)
             cache, hidden = self._packed_encoder().encode(td, cache_dtype, want_hidden=return_hidden, act_dtype=regime16,
-                                                          fold=self.fold)
+                                                          fold=self.fold, init_embeds_out=init_embeds)
             if self.encode_events is not None:
                 ev1.record()
                 self.encode_events.append((ev0, ev1))
-            init_embeds = None
         else:
             cache = None
             if not grad_path and self.fused_encoder and self._token_encoder_usable(td):
@@ -716,7 +718,7 @@ class AttentionModelPolicy(nn.Module):
                     ev1.record()
                     self.encode_events.append((ev0, ev1))
             else:
-                if (td["locs"].is_cuda and not grad_path and self._encoder_regime() is not None and not return_init_embeds
+                if (td["locs"].is_cuda and not grad_path and self._encoder_regime() is not None
                         and self.fused_encoder and self.fold):  # (switched off by the caller: not a fallback)
                     from . import _lib as _l
 

@@ -295,3 +295,35 @@ def test_fold_tables_kernel_matches_float64(b, n, blocks, graph, dt):
         assert float((q_bias.double() - want).norm() / want.norm()) <= 3e-6
     else:
         assert q_bias is None
+
+
+@pytest.mark.parametrize("regime", ["fp32", "bf16", "f16"])
+@pytest.mark.parametrize("env_name,num_loc", [("tsp", 100), ("cvrp", 50), ("op", 20), ("pctsp", 20), ("pdp", 20), ("cvrptw", 20), ("cvrp", 200)])
+def test_return_init_embeds_is_served_by_the_kernels_own_init_embedding(env_name, num_loc, regime):
+    """AttentionModelPolicy.forward(return_init_embeds=True) (zoo/am/encoder.py:84-103) no longer sends inference to the torch
+    encoder: `init_embeds` is one more launch of the init-embedding routine the encoder kernels run
+    (rl4co_am_encoder_init_embeds_f32 / _16), in the activations' type. Against the module's own init embedding in fp32:
+    fp32 to round-off (K <= 6 products in a different order), 16-bit within one rounding of the output."""
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    dt = {"fp32": None, "bf16": torch.bfloat16, "f16": torch.float16}[regime]
+    torch.manual_seed(0)
+    pol = AttentionModelPolicy(env_name, encoder_autocast=dt, **({} if dt is None else {"cache_dtype": dt})).cuda().eval()
+    env = get_env(env_name, generator_params=dict(num_loc=num_loc, device="cuda"), device="cuda")
+    torch.manual_seed(3)
+    td = env.reset(env.generator(batch_size=[48]))
+    with torch.inference_mode():
+        ref = pol.encoder.init_embedding(td).float()
+    real = pol.encoder.forward
+    pol.encoder.forward = lambda *a, **k: (_ for _ in ()).throw(AssertionError("torch encoder reached"))
+    try:
+        with torch.inference_mode():
+            out = pol(td, env, phase="test", decode_type="greedy", return_init_embeds=True, return_hidden=True)
+    finally:
+        pol.encoder.forward = real
+    ie = out["init_embeds"]
+    assert ie.shape == ref.shape and ie.dtype == (torch.float32 if dt is None else dt)
+    tol = {"fp32": 2e-6, "bf16": 2.0 ** -8, "f16": 2.0 ** -11}[regime]
+    assert _rel(ie.float(), ref) <= tol, _rel(ie.float(), ref)
+    assert torch.isfinite(out["reward"]).all()
