@@ -609,7 +609,91 @@ __global__ void __launch_bounds__(kGemmThreads, 3) linear_k128_kernel(const uint
   }
 }
 
+// K = 128 AND N = 128 (out_proj both ways — six input-gradient launches per REINFORCE step): persistent workgroups. One tile
+// per workgroup made every tile pay its own load -> product -> store chain (13 us of a workgroup's life for 0.5 us of
+// products; 54 us per launch against 26 at the HBM rate, r05). Here the WEIGHTS are the resident operand — wave w keeps the
+// A fragments of its 32 output features in registers for the whole launch — and the workgroup walks token tiles: the next
+// tile's rows travel in registers under the products of this one, the tile leaves through the same LDS rows it came in by.
+__global__ void __launch_bounds__(kGemmThreads, 3) linear_k128_n128_kernel(const uint16_t* __restrict__ A, const uint16_t* __restrict__ W,
+                                                                           const float* __restrict__ bias, int M, int relu,
+                                                                           uint16_t* __restrict__ out) {
+  extern __shared__ __align__(16) unsigned char smem_g[];
+  elem_t* xs = reinterpret_cast<elem_t*>(smem_g);  // [128 tokens][kLS]: the token tile, then the staged output tile
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  bf16x8 wf[kTK / 16];
+#pragma unroll
+  for (int ks = 0; ks < kTK / 16; ++ks)
+    wf[ks] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const elem_t*>(W) + (int64_t)(32 * w + l31) * kTK + 16 * ks + 8 * hi);
+  float4 bq[4];  // the bias of the four-feature groups this lane's accumulator rows hold
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    bq[q] = bias ? *reinterpret_cast<const float4*>(bias + 32 * w + 8 * q + 4 * hi) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int ntiles = (M + kTM - 1) / kTM;
+  const int srow = tid >> 4, scol = (tid & 15) * 8;  // this thread moves rows srow + 16 j, 16 bytes at scol
+  u32x4 pa[8];
+  auto fetch = [&](int tile) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t row = min((int64_t)tile * kTM + srow + 16 * j, (int64_t)M - 1);  // rows past M: computed, never stored
+      pa[j] = *reinterpret_cast<const u32x4*>(A + row * kTK + scol);
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(xs + (srow + 16 * j) * kLS + scol) = pa[j];
+    __syncthreads();
+    fetch(min(tile + (int)gridDim.x, ntiles - 1));  // (the last round re-reads a tile it drops: no branch around the loads)
+    f32x16 acc[4];  // [token tile tt][feature 32 w + rowmap(r, hi)], token 32 tt + l31
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tt][r] = 0.0f;
+#pragma unroll
+    for (int ks = 0; ks < kTK / 16; ++ks) {
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const bf16x8 tok = *reinterpret_cast<const bf16x8*>(xs + (32 * tt + l31) * kLS + 16 * ks + 8 * hi);
+        acc[tt] = rl4co_e16::mfma_32x32x16(wf[ks], tok, acc[tt]);
+      }
+    }
+    // the prefetched rows pinned in their registers before this tile's stores are issued (see linear_bf16_kernel)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) asm volatile("" ::"v"(pa[j]));
+    __syncthreads();  // every wave has read the token tile: the output is staged over it
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[4] = {acc[tt][4 * q] + bq[q].x, acc[tt][4 * q + 1] + bq[q].y, acc[tt][4 * q + 2] + bq[q].z, acc[tt][4 * q + 3] + bq[q].w};
+        if (relu) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = fmaxf(v[i], 0.0f);
+        }
+        *reinterpret_cast<bf16x4g*>(xs + (32 * tt + l31) * kLS + 32 * w + 8 * q + 4 * hi) = rl4co_e16::cvt4(v[0], v[1], v[2], v[3]);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t row = (int64_t)tile * kTM + srow + 16 * j;
+      const u32x4 val = *reinterpret_cast<const u32x4*>(xs + (srow + 16 * j) * kLS + scol);
+      if (row < M) *reinterpret_cast<u32x4*>(out + row * kTN + scol) = val;
+    }
+    __syncthreads();  // the staged tile is drained before the next one is committed over it
+  }
+}
+
 int launch_k128(const void* a, const void* w, const float* bias, int64_t M, int N, int relu, void* out, void* stream) {
+  if (N == kTN) {
+    const int ntiles = (int)((M + kTM - 1) / kTM);
+    hipLaunchKernelGGL(linear_k128_n128_kernel, dim3(ntiles < 768 ? ntiles : 768), dim3(kGemmThreads), kTM * kLS * 2, rl4co::as_stream(stream),
+                       static_cast<const uint16_t*>(a), static_cast<const uint16_t*>(w), bias, (int)M, relu, static_cast<uint16_t*>(out));
+    RL4CO_HIP_TRY(hipGetLastError());
+    return RL4CO_OK;
+  }
   const int lds = kTN * kLS * 2 + kMaxLinearN * 4;
   hipLaunchKernelGGL(linear_k128_kernel, dim3((int)((M + kTM - 1) / kTM)), dim3(kGemmThreads), lds, rl4co::as_stream(stream),
                      static_cast<const uint16_t*>(a), static_cast<const uint16_t*>(w), bias, (int)M, N, relu,
