@@ -458,6 +458,11 @@ class Bench:
                 policy.decode_events, policy.encode_events = [], []
             gc.collect()
             gc.freeze()  # (see train_leg: a full collection over torch's module graph is a 60 ms host stall)
+            # ... which the chip idles through: the untimed steps directly in front of the clock are repeated after it (r05: the
+            # first region of every leg was its slowest, 1 - 7 % above the median of the four after it — it opened on
+            # clocks that had ramped down during the collection)
+            for _ in range(warmup):
+                out = step()
             pipelined = use_graph and a.launch == "pipeline"
             if pipelined:  # drain: the timed region starts and ends with nothing in flight
                 while tickets:
@@ -675,6 +680,11 @@ class Bench:
         # The collector stays on for what the loop itself allocates
         gc.collect()
         gc.freeze()
+        for i in range(min(warmup, 3)):  # the chip idled through the collection: the region must not open on ramped-down clocks
+            step(i)
+        torch.cuda.synchronize()
+        ar_events.clear()
+        policy.decode_events, T.backward_events = [], []
         solo_ms = None
         if self.world > 1 and self.args.solo:
             # N = 1 reference of this invocation: rank 0 alone, the same K steps WITHOUT the collective (nobody is there to
