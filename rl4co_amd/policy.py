@@ -685,13 +685,15 @@ class AttentionModelPolicy(nn.Module):
         regime16 = self._encoder_regime() if self._encoder_regime() in (torch.bfloat16, torch.float16) else None
         # fused MFMA encoder: a 16-bit autocast regime (bf16, or fp16 = the reference's default "16-mixed") whose planes
         # are fp32 or that same 16-bit type
+        # (return_init_embeds: one more launch with the instance in grid.y — up to 65535 instances)
+        ie_ok = not return_init_embeds or td["locs"].shape[0] <= 65535
         use_fused = (self.fused_encoder and self.fold and regime16 is not None and not grad_path
-                     and cache_dtype in (torch.float32, regime16)
+                     and cache_dtype in (torch.float32, regime16) and ie_ok
                      and self._packed_encoder().supported(td))
         # fp32 regime (no autocast: the bit-identical configuration): the exact-fp32 MFMA encoder (csrc/am_encoder_f32.hip),
         # planes in any type, also with fold=False (tsp / cvrp: the reference's own association of the decoder)
         use_fused_f32 = (self.fused_encoder and self._encoder_regime() is None and not grad_path and td["locs"].is_cuda
-                         and (self.fold or self.env_name in ("tsp", "cvrp"))
+                         and (self.fold or self.env_name in ("tsp", "cvrp")) and ie_ok
                          and self._packed_encoder().supported(td, torch.float32))
         if use_fused_f32:
             use_fused, regime16 = True, torch.float32
