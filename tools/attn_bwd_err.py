@@ -1,13 +1,11 @@
 """GPU box: error of csrc/am_train_attn.hip's backward against fp32 SDPA autograd on the same 16-bit q | k | v, and its time.
-   RL4CO_AMD_LIB=<lib> python tools/attn_bwd_err.py [old]     ('old': the entry point without the forward's output, <= r04)"""
+   RL4CO_AMD_LIB=<lib> python tools/attn_bwd_err.py"""
 import ctypes as C
 import os
-import sys
 
 import torch
 import torch.nn.functional as F
 
-old = len(sys.argv) > 1 and sys.argv[1] == "old"
 lib = C.CDLL(os.environ.get("RL4CO_AMD_LIB", "rl4co_amd/lib/librl4co_amd.so"))
 vp = C.c_void_p
 for b, n, scale in ((4096, 100, 1.0), (256, 100, 0.5), (256, 50, 1.0), (256, 128, 2.0)):
@@ -21,8 +19,6 @@ for b, n, scale in ((4096, 100, 1.0), (256, 100, 0.5), (256, 50, 1.0), (256, 128
     assert lib.rl4co_attn_fwd_bf16(vp(qkv.data_ptr()), b, n, vp(out.data_ptr()), vp(lse.data_ptr()), vp(s)) == 0
 
     def bwd():
-        if old:
-            return lib.rl4co_attn_bwd_bf16(vp(qkv.data_ptr()), vp(go.data_ptr()), vp(lse.data_ptr()), b, n, vp(dqkv.data_ptr()), vp(s))
         return lib.rl4co_attn_bwd_bf16(vp(qkv.data_ptr()), vp(out.data_ptr()), vp(go.data_ptr()), vp(lse.data_ptr()), b, n, vp(dqkv.data_ptr()), vp(s))
 
     assert bwd() == 0
