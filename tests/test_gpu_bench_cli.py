@@ -93,6 +93,24 @@ def test_two_ranks_self_spawned():
     assert abs(line["value"] - 2 * 4096 * 100 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
 
 
+@pytest.mark.parametrize("n", [4, 8])
+def test_the_drivers_rank_counts_on_one_shared_gpu(n):
+    """The rank arithmetic of the driver's N = 4 and N = 8 runs (instance sharding, max-over-ranks clock, per-rank and per-region
+    spread, the solo reference, the gradient all-reduce) with all ranks time-sharing ONE device over gloo — what a one-GPU box
+    can check of `bench.py --gpus 8`; the times themselves mean nothing here."""
+    if torch.cuda.device_count() >= n:
+        pytest.skip("enough GPUs for the real thing: test_all_visible_gpus_on_rccl")
+    line = _run(["--gpus", str(n), "--steps", "4", "--warmup", "1", "--legs", "c2_greedy,c4_train", "--no-cpu-baseline", "--no-parity"],
+                env_extra={"RL4CO_BENCH_SHARED_GPU": "1", "RL4CO_DIST_BACKEND": "gloo"}, timeout=600)
+    assert line["n_gpus"] == n and line["collective_backend"] == "gloo" and line["collective_ranks"] == n and "rccl_ranks" not in line
+    assert line["config"]["parallelism"].startswith(f"replicas x{n}")
+    assert line["rank_ms_per_step"]["min"] <= line["rank_ms_per_step"]["max"] == pytest.approx(line["ms_per_step"], rel=1e-3)
+    assert line["region_ms_per_step"]["n"] == 5 and line["n1_ms_per_step"] > 0 and 0 < line["scaling_efficiency"] <= 1.2
+    assert abs(line["value"] - n * 4096 * 100 / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-6
+    train = _detail(line)["legs"]["c4_train"]
+    assert train["collective"]["ranks"] == n and train["collective"]["backend"] == "gloo" and line["allreduce_ms"] > 0
+
+
 def test_all_visible_gpus_on_rccl():
     """Every GPU of the node, one rank each, the driver's own multi-GPU command shape — RCCL for real (the
     REINFORCE gradient all-reduce, rl4co/utils/trainer.py:83-86). Needs >= 2 GPUs: the one-GPU boxes skip it."""
