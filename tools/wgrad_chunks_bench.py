@@ -10,7 +10,7 @@ def bench(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for wg in (1024, 512, 256, 2048):
+for wg in [int(x) for x in (sys.argv[1:] or ["1024", "512", "256", "2048"])]:
     T._WGRAD_MAX_WORKGROUPS = wg
     out = []
     for n, k in ((384, 128), (128, 128), (512, 128), (128, 512)):
