@@ -754,7 +754,10 @@ __device__ inline bf16x4w lds_tr_w(const elem_t* p) {
   return __builtin_bit_cast(bf16x4w, v);
 }
 
-__global__ void __launch_bounds__(256) wgrad_bf16_kernel(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X, int M, int N,
+// (launch bounds WITH a minimum of two workgroups per CU, r05: left to 512 registers the compiler put the 72 accumulators in
+// AGPRs with a different destination than source register for every product and moved all of them back through
+// v_accvgpr_read / _write each step — 112 of the loop's 180 VALU instructions, none in the source)
+__global__ void __launch_bounds__(256, 2) wgrad_bf16_kernel(const uint16_t* __restrict__ dY, const uint16_t* __restrict__ X, int M, int N,
                                                          int K, int rows_per_chunk, int n_chunks, float* __restrict__ partial,
                                                          float* __restrict__ partial_bias, int64_t pstride, int64_t bstride) {
   __shared__ __align__(16) elem_t dyt[kWT * kWLS];  // [32 tokens][128 output features of this tile]
