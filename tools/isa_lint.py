@@ -1,7 +1,9 @@
 #!/usr/bin/env python
-"""Per-kernel lint of a gfx950 assembly listing for the four patterns that cost r05 its largest gains:
+"""Per-kernel lint of a gfx950 assembly listing for the patterns that cost r05 its largest gains:
 `s_waitcnt vmcnt(0)` inside loops, scratch (spill) accesses inside loops, single `v_cvt_pk_bf16_f32 x, 0` conversions
-(+ `v_perm_b32` merges), `v_max x, x, x` canonicalisations.
+(+ `v_perm_b32` merges), `v_max x, x, x` canonicalisations, and accumulators shuttled through `v_accvgpr_read / _write / _mov`
+inside loops (MFMAs in the AGPR form with a destination different from their accumulator source: launch bounds without a
+minimum workgroup count — the weight-gradient kernel moved all 72 of its accumulators every step).
 
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Iinclude -Irl4co_amd/csrc -S --cuda-device-only \
           -o /tmp/k.s rl4co_amd/csrc/am_attn_flash.hip
@@ -30,4 +32,5 @@ for f in re.split(r'\n(?=_Z[\w]+:)', t):
     scr=sum(1 for i,l in enumerate(L) if 'scratch_' in l and inl(i))
     single=sum(1 for l in L if re.search(r'v_cvt_pk_bf16_f32 v\d+, v\d+, s\d+',l))
     canon=sum(1 for l in L if re.search(r'v_max_f32_e32 (v\d+), (v\d+), \2\b',l))
-    print(f"{dn:70s} lines {len(L):5d} loop-vmcnt0 {vm0:3d} loop-scratch {scr:3d} single-cvt {single:4d} canon {canon:3d}")
+    agpr=sum(1 for i,l in enumerate(L) if 'v_accvgpr_' in l and inl(i))
+    print(f"{dn:70s} lines {len(L):5d} loop-vmcnt0 {vm0:3d} loop-scratch {scr:3d} single-cvt {single:4d} canon {canon:3d} loop-agpr-moves {agpr:3d}")
