@@ -49,7 +49,7 @@ rocprofv3 --pmc passes of the same leg (profiles/pmc_traffic.json; a counter pas
 oracle/gen_golden.py; kind "port") timed on this box's host cores on a bounded sample.
 ``parity`` (detail file; summary in the line): for every inference leg, the fp32 configuration and the benchmarked bf16
 configuration against the reference's own rollouts (fp32 and under bf16 autocast) of TRAINED weights at the leg's full
-size (tests/golden/trained; tools/trained_parity.py): flips proven near-ties, identical tours, per-decision agreement.
+size (tests/golden/trained; tests/trained_parity.py): flips proven near-ties, identical tours, per-decision agreement.
 """
 from __future__ import annotations
 
@@ -99,6 +99,16 @@ def leg_dtypes(leg: str, args) -> tuple[str, str]:
     if leg.endswith("_fp32"):
         return "f32", "f32"
     return args.cache_dtype, args.encoder_dtype
+
+
+def _trained_parity():
+    """tests/trained_parity.py — the measurement shared with tests/test_gpu_trained_parity.py (fixtures only: no oracle, no reference)."""
+    tdir = os.path.join(ROOT, "tests")
+    if tdir not in sys.path:
+        sys.path.insert(0, tdir)
+    import trained_parity
+
+    return trained_parity
 
 
 def log(msg: str) -> None:
@@ -260,9 +270,13 @@ def compact_roofline(r: dict | None) -> dict | None:
     keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms_mean")
     out = {"kernel": r["kernel"].split(":")[0].split(" (")[0][:48]}
     out.update({k: _r(r.get(k)) for k in keep})
-    for k in ("contract_GBs", "hbm_read_probe_GBs"):
+    # the SURVEY.md §8(d) figure reproducible from the line alone: contract bytes per launch, the rate and the (> 1) "fraction"
+    # they give — the kernel never reads masked rows, so this is NOT a utilisation; `frac` (must-move bytes) is
+    for k in ("contract_GBs", "frac_contract", "contract_bytes", "bytes_per_launch", "hbm_read_probe_GBs", "frac_large_batch"):
         if r.get(k) is not None:
             out[k] = _r(r[k])
+    if r.get("traffic_source"):
+        out["traffic_source"] = str(r["traffic_source"])[:96]
     return out
 
 
@@ -305,6 +319,8 @@ def compact_line(detail: dict, head_name: str, results: dict, detail_path: str) 
         "workload": cfg["workload"][:160], "leg": head_name, "batch_per_gpu": cfg["batch_per_gpu"], "cache_dtype": cfg["cache_dtype"],
         "launch": (detail.get("launch") or "").split(":")[0],
         "input": "one synthetic batch resident in HBM, reused by every step", "parallelism": cfg["parallelism"],
+        # what really runs before the clock starts (the echoed `warmup` is only the first group of it)
+        "untimed_steps": detail.get("untimed_steps"), "untimed_extra": "1 s HBM read loop before the first leg",
     }
     line["roofline"] = compact_roofline(detail.get("roofline"))
     if detail.get("encoder_roofline"):
@@ -313,6 +329,8 @@ def compact_line(detail: dict, head_name: str, results: dict, detail_path: str) 
               "collective_ranks", "collective_backend", "n1_ms_per_step", "scaling_efficiency", "allreduce_ms"):
         if detail.get(k) is not None:
             line[k] = _r(detail[k])
+    if detail.get("placement"):  # the start-up self-check's result: ranks and DISTINCT devices they sit on
+        line["distinct_gpus"] = detail["placement"]["distinct_devices"]
     if detail.get("rank_ms_per_step"):
         line["rank_ms_per_step"] = {k: _r(v) for k, v in detail["rank_ms_per_step"].items()}
     if detail.get("region_ms_per_step"):  # min / median / max over the repeated K-step regions (ms_per_step = the first one)
@@ -399,6 +417,7 @@ class Bench:
         rows = inst_steps = 0
         use_graph = a.launch in ("graph", "pipeline")
         graph_ms = None
+        untimed = warmup  # every step the leg runs BEFORE its timed region (reported: `--warmup` is only the first group)
         with torch.inference_mode():
             for _ in range(warmup):
                 out = step()
@@ -415,6 +434,7 @@ class Bench:
                     step()
                 torch.cuda.synchronize()
                 eager_ms = (time.perf_counter() - t0) / ev_steps * 1e3
+                untimed += ev_steps
                 decode_ms = [x.elapsed_time(y) for x, y in policy.decode_events]
                 encode_ms = [x.elapsed_time(y) for x, y in policy.encode_events]
                 policy.decode_events = policy.encode_events = None
@@ -425,6 +445,7 @@ class Bench:
                     step = lambda: graphed(data)  # noqa: E731
                     for _ in range(max(2, warmup)):  # replays before the clock starts (the first ones run slower)
                         out = step()
+                    untimed += max(2, warmup)
                     if a.launch == "pipeline":
                         # one stream first (reported as graph_ms_per_step), then two captured rollouts in flight on two
                         # streams: the next batch's launches fill the CUs this batch's finishing decode waves release
@@ -434,6 +455,7 @@ class Bench:
                             step()
                         torch.cuda.synchronize()
                         graph_ms = (time.perf_counter() - t0) / ev_steps * 1e3
+                        untimed += ev_steps
                         from rl4co_amd.graph import PipelinedRollout
 
                         pipe = PipelinedRollout(policy, env, data, decode_type=decode, depth=a.pipeline_depth)
@@ -449,6 +471,7 @@ class Bench:
 
                         for _ in range(max(4, warmup)):
                             step()
+                        untimed += max(4, warmup)
                 except Exception as exc:  # a launch sequence that cannot be captured stays on the eager path, said so
                     log(f"{leg}: HIP graph capture failed ({type(exc).__name__}: {exc}); timing the eager path")
                     use_graph = False
@@ -463,6 +486,10 @@ class Bench:
             # clocks that had ramped down during the collection)
             for _ in range(warmup):
                 out = step()
+            untimed += warmup
+            if not use_graph:  #  the eager leg's kernel durations come from the timed regions only, as in train_leg
+                torch.cuda.synchronize()
+                policy.decode_events, policy.encode_events = [], []
             pipelined = use_graph and a.launch == "pipeline"
             if pipelined:  # drain: the timed region starts and ends with nothing in flight
                 while tickets:
@@ -562,6 +589,10 @@ class Bench:
                        ("hip_graph: reset + encoder + decode + check + reward captured once, one hipGraphLaunch and one "
                         "24-byte read-back per step (rl4co_amd/graph.py)") if use_graph else "eager: one host launch per kernel"),
             "eager_ms_per_step": eager_ms, "graph_ms_per_step": graph_ms,
+            "untimed_steps": untimed,
+            "untimed_note": "steps of this leg executed before the timed region: --warmup eager steps, the HIP-event pass for the "
+                            "kernel durations, graph replays, the one-graph timing pass, the pipeline fill, --warmup again after the "
+                            "garbage collection; plus (once per process) 1 s of plain HBM reads before the first leg",
             "node_steps_per_sec": value * n_nodes,
             "instances_per_sec": batch * self.world * steps / wall,
             "decode_steps_longest": t_steps, "instance_steps_per_launch": per_launch_steps,
@@ -578,6 +609,7 @@ class Bench:
                 "contract_note": "SURVEY.md §8(d): every node's row at every step (the reference's formulation); the kernel "
                                  "skips masked rows, so contract bytes / time may exceed the HBM peak — it is not a fraction",
                 "contract_GBs": contract / (mean_decode_ms * 1e-3) / 1e9,
+                "frac_contract": contract / (mean_decode_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "contract_bytes": contract,
                 "launch_ms_mean": mean_decode_ms, "launch_ms_min": min(decode_ms),
                 "us_per_decode_step": mean_decode_ms * 1e3 / t_steps, "launches_timed": len(decode_ms),
                 "hbm_utilisation_from_traffic": (traffic / (mean_decode_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
@@ -606,7 +638,7 @@ class Bench:
                          f"{layers_ * 8 * n_ * n_ * batch / 1e9:.1f} G exponentials per pass at a quarter of the VALU rate"),
             }
         if full and self.world == 1 and not a.no_parity:
-            from tools import trained_parity as TP
+            TP = _trained_parity()
 
             try:
                 rec = TP.compare(TP.TrainedCase("t2_tsp100_b4096_greedy"), "fp32", self.device, against="fp32")
@@ -616,6 +648,27 @@ class Bench:
                 log(f"{leg}: no trained golden for the parity count ({exc})")
         res["host_gap_ms"] = res["ms_per_step"] - mean_decode_ms - (sum(encode_ms) / len(encode_ms) if encode_ms else 0.0)
         return res
+
+    def large_batch_probe(self, leg: str, batch: int = 16384) -> dict | None:
+        """HBM or Infinity Cache? The headline batch's planes (315 MB) shrink below the 256 MiB MALL after ~20
+        decode steps and FETCH_SIZE counts MALL hits, so the decode launch's rate is measured once more IN THIS PROCESS at
+        four times the batch (planes 1.26 GB: the feasible rows stay above 256 MiB for most of the rollout): same kernel,
+        same byte model (rows counted in-kernel), HIP events on the launch stream. A lower rate here is the MALL's share."""
+        a = self.args
+        saved = (a.batch, a.launch, a.regions)
+        a.batch, a.launch, a.regions = batch, "eager", 1
+        try:
+            r = self.rollout_leg(leg, 3, 1)
+        except RuntimeError as exc:  # (out of memory on a smaller part: the probe is optional)
+            log(f"large-batch probe skipped: {exc}")
+            return None
+        finally:
+            a.batch, a.launch, a.regions = saved
+        if self.rank != 0:
+            return None
+        roof = r["roofline"]
+        return {"batch": batch, "GBs": roof["achieved"], "frac": roof["frac"], "launch_ms_mean": roof["launch_ms_mean"],
+                "bytes_per_launch": roof["bytes_per_launch"], "launches_timed": roof["launches_timed"]}
 
     # -- the training leg: configs[3]'s per-GPU share ----------------------------------------------------------------
     def train_leg(self, steps: int, warmup: int) -> dict:
@@ -800,7 +853,7 @@ class Bench:
           ``torch.autocast(bfloat16)`` and vs its fp32 run — identical tours, per-decision agreement, mean-reward gap;
         * sampling legs: the reference's seeded multinomial stream injected into the kernel.
         The random-init golden of round 2 (every greedy step a near-tie) is kept as ``random_init`` for continuity."""
-        from tools import trained_parity as TP
+        TP = _trained_parity()
 
         cases = {"c2_greedy": ("t2_tsp100_b4096_greedy", "greedy"), "c2_sampling": ("t2_tsp100_b4096_sampling", "sampling"),
                  "c3_greedy": ("t3_cvrp100_b4096_greedy", "greedy"), "c5_sampling": ("t5_cvrp500_b1024_sampling", "sampling")}
@@ -939,6 +992,8 @@ def main() -> None:
     ap.add_argument("--no-check-solution", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-large-batch", action="store_true",
+                    help="skip the decode launch at 16 384 instances (roofline.frac_large_batch: the HBM rate with planes 4 x the MALL)")
     ap.add_argument("--cpu-sample-batch", type=int, default=4096,
                     help="instances of the same workload timed on the host cores (shrunk to keep the leg within ~30 s)")
     args = ap.parse_args()
@@ -989,6 +1044,16 @@ def main() -> None:
     # test mode above rides on gloo (RL4CO_DIST_BACKEND) — the data path has no collective either way
     if world > 1 or "c4_train" in legs:
         D.init_process_group(os.environ.get("RL4CO_DIST_BACKEND", "nccl"), device=device, single_process_ok=True)
+
+    # start-up self-check, before anything is timed: exactly N ranks, one GPU each (distinct device identities), the current
+    # device is the assigned one, and the collective backend sums over all N — the first 8-GPU run is the driver's
+    placement = None
+    if dist.is_initialized():
+        placement = D.check_placement(device, args.gpus, allow_shared=os.environ.get("RL4CO_BENCH_SHARED_GPU") == "1")
+        if world > 1 and dist.get_backend() == "nccl" and placement["distinct_devices"] != args.gpus:
+            raise SystemExit(f"rank {rank}: {placement['distinct_devices']} distinct GPUs for --gpus {args.gpus}")
+        if rank == 0:
+            log(f"placement: {placement['world']} rank(s) on {placement['distinct_devices']} device(s), backend {placement['backend']}")
 
     if os.environ.get("RL4CO_BENCH_KILL_RANK") == str(rank) and world > 1:  # tests/test_gpu_bench_cli.py: a rank that dies
         os._exit(17)
@@ -1071,12 +1136,20 @@ def main() -> None:
             },
         }
         for k in ("node_steps_per_sec", "instances_per_sec", "mean_reward", "roofline", "rollout_roofline", "encoder_roofline", "host_gap_ms", "launch",
+                  "untimed_steps", "untimed_note",
                   "eager_ms_per_step", "graph_ms_per_step", "region_ms_per_step", "n1_note",
                   "trajectories_per_sec", "collective", "rank_ms_per_step", "n1_ms_per_step", "scaling_efficiency"):
             if k in head:
                 detail[k] = head[k]
         if "roofline" in detail:
             detail["roofline"]["hbm_read_probe_GBs"] = probe_gbs
+            if head_name == "c2_greedy" and world == 1 and args.batch is None and not args.no_large_batch:
+                big = bench.large_batch_probe(head_name)
+                if big:
+                    detail["roofline"]["large_batch"] = big
+                    detail["roofline"]["frac_large_batch"] = big["frac"]  # 16 384 instances: planes 4 x the Infinity Cache
+        if placement:
+            detail["placement"] = placement
         detail["legs"] = {name: {k: v for k, v in r.items() if k != "wall"} for name, r in results.items() if name != head_name}
         if "c4_train" in results and head_name != "c4_train":
             detail["train_ms_per_step"] = results["c4_train"]["ms_per_step"]

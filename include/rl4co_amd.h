@@ -28,6 +28,14 @@
 extern "C" {
 #endif
 
+/* ---- ABI version ----------------------------------------------------------
+ * Bumped whenever an exported signature or struct layout changes. A binding compares rl4co_abi_version() (what the
+ * loaded library was built with) against the RL4CO_ABI_VERSION of the header it was written for and refuses to run on a
+ * mismatch: a changed argument list under an unchanged symbol name still links (r05: rl4co_attn_bwd_* gained `out` in
+ * second position — a caller built for the old list would pass dout as out and lse as dout).
+ *   6: rl4co_attn_bwd_{bf16,f16} take the forward's `out`; rl4co_abi_version() itself. */
+#define RL4CO_ABI_VERSION 6
+
 /* ---- status codes ------------------------------------------------------ */
 #define RL4CO_OK 0
 #define RL4CO_ERR_ARG 1     /* bad argument (null pointer, size out of range)  */
@@ -87,6 +95,8 @@ extern "C" {
 
 /* Library identification. */
 const char* rl4co_version(void);
+/* RL4CO_ABI_VERSION of the header the loaded library was compiled against (see above). */
+int rl4co_abi_version(void);
 /* Last HIP error string seen by the calling thread ("" if none). */
 const char* rl4co_last_error(void);
 

@@ -12,6 +12,7 @@ from functools import lru_cache
 from . import build as _build
 
 RL4CO_OK = 0
+ABI_VERSION = 6  # RL4CO_ABI_VERSION of include/rl4co_amd.h this binding's argument lists were written for
 ENV_TSP, ENV_CVRP, ENV_OP, ENV_PCTSP, ENV_PDP, ENV_CVRPTW = 0, 1, 2, 3, 4, 5
 DECODE_GREEDY, DECODE_SAMPLE, DECODE_EVALUATE = 0, 1, 2
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
@@ -85,6 +86,7 @@ class AmDecodeArgs(C.Structure):
 SYMBOLS = {
     "rl4co_version": (C.c_char_p, []),
     "rl4co_last_error": (C.c_char_p, []),
+    "rl4co_abi_version": (C.c_int, []),
     "rl4co_gather_by_index_f32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _vp]),
     "rl4co_tour_length_f32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_tour_length_dyn_f32": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, C.c_int, C.c_int, C.c_int, _vp, _vp]),
@@ -211,6 +213,9 @@ def lib() -> C.CDLL:
         fn = getattr(handle, name)  # AttributeError if the symbol is not exported
         fn.restype = restype
         fn.argtypes = argtypes
+    got = handle.rl4co_abi_version()
+    if got != ABI_VERSION:  # a stale build under unchanged symbol names would run with shifted arguments: refuse
+        raise Rl4coLibraryError(f"{path} was built for ABI version {got}, this binding is written for {ABI_VERSION}: rebuild the library")
     return handle
 
 

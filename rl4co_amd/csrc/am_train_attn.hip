@@ -308,9 +308,8 @@ __global__ void __launch_bounds__(kBwdThreads, 3) attn_bwd_kernel(const uint16_t
     const bf16x4 qt = lds_tr(qd + 16 + tro_q);  // Q_h^T[d][queries]
     // No mask on the queries past N: their d out is zero, so dP - D = 0 = dS and d v receives nothing from them, while P
     // itself stays finite (the clamped row's own scores and log-sum-exp). Keys past N: their k and v rows are zero, so
-    // d q receives nothing from them and their own d k / d v rows are never stored — but their P = exp2(-L) must not
-    // overflow (inf x 0): the exponent is clamped at 0 in the tiles that can hold them (N > 16 (smallest tile count
-    // dispatched to this NT) - 16).
+    // d q receives nothing from them and their own d k / d v rows are never stored — their P (and with it dS) is set to
+    // zero by a select in the tiles that can hold them (N > 16 (smallest tile count dispatched to this NT) - 16).
     constexpr int kMinN = NT == 2 ? 1 : (NT == 4 ? 33 : (NT == 7 ? 65 : 113));
     // Key tiles in groups of four, every stage over the whole group before the next one: written tile by tile the
     // compiler keeps that order — LDS read, wait, score MFMA, 8 idle slots, exponentials, ... — and with three waves per
@@ -339,9 +338,13 @@ __global__ void __launch_bounds__(kBwdThreads, 3) attn_bwd_kernel(const uint16_t
           float p4[4];
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
-            float e = fmaf(sc[j][rr], kScale, -Lr[rr]);
-            if (16 * (j0 + j + 1) > kMinN) e = fminf(e, 0.0f);
+            const float e = fmaf(sc[j][rr], kScale, -Lr[rr]);
             p4[rr] = RL4CO_ATTN_BWD_PROBE == 2 ? e : __builtin_amdgcn_exp2f(e);
+            // tiles that can hold keys past N: P = 0 there, hence dS = 0 (one select per element, tail tiles only). Relying on
+            // the zeroed k rows alone left dS_pad = -D P_pad in the staged block: under fp16 loss scaling (large d out, L <= 0
+            // so P_pad = 1) it can overflow where no valid key's dS does, and inf x 0 in the d q product is a NaN for every
+            // query of the head
+            if (16 * (j0 + j + 1) > kMinN) p4[rr] = (16 * (j0 + j) + tl < N) ? p4[rr] : 0.0f;
           }
           pf[j] = rl4co_e16::cvt4(p4[0], p4[1], p4[2], p4[3]);
           dsf[j] = rl4co_e16::cvt4(p4[0] * dp[j][0], p4[1] * dp[j][1], p4[2] * dp[j][2], p4[3] * dp[j][3]);

@@ -28,6 +28,8 @@ int record_arg_error(const char* what) {
 
 extern "C" const char* rl4co_version(void) { return "rl4co_amd 0.1.0 (gfx950)"; }
 
+extern "C" int rl4co_abi_version(void) { return RL4CO_ABI_VERSION; }
+
 extern "C" const char* rl4co_last_error(void) { return g_last_error; }
 
 // Deterministic-math probe: y[i] = f(x[i]) with f the fp32 exp / log / tanh of rl4co_math.h evaluated ON THE

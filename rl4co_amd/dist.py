@@ -50,6 +50,52 @@ def init_process_group(backend: str | None = None, device: torch.device | None =
     return rank, world
 
 
+def device_identity(device: torch.device | None) -> str:
+    """What distinguishes this process's compute device from its peers': the GPU's UUID (falls back to its PCI bus id /
+    its index) — for a CPU process the process id (every process is its own "device")."""
+    if device is None or torch.device(device).type != "cuda":
+        return f"cpu:{os.getpid()}"
+    props = torch.cuda.get_device_properties(device)
+    for attr in ("uuid", "pci_bus_id"):
+        v = getattr(props, attr, None)
+        if v is not None:
+            return f"{attr}:{v}:{getattr(props, 'pci_device_id', '')}"
+    return f"index:{torch.device(device).index}"
+
+
+def check_placement(device: torch.device | None, expect_world: int, allow_shared: bool = False,
+                    identity: str | None = None) -> dict:
+    """Start-up self-check of a one-process-per-GPU job, BEFORE anything is timed (the reference leaves this to Lightning's
+    DDP strategy, utils/trainer.py:73-86): the group has exactly ``expect_world`` ranks, every rank sits on a device of
+    its own (two ranks time-sharing one GPU would report a "scaling" that is nothing of the kind), the process's current
+    device is the one it was handed, and the backend's all-reduce really sums over all ranks. Raises ``RuntimeError``
+    on any rank that sees a violation — every rank sees the same gathered table, so all of them fail together."""
+    rank, world = world_info()
+    if world != expect_world:
+        raise RuntimeError(f"process group has {world} rank(s), the job was launched for {expect_world}")
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    if dev.type == "cuda" and torch.cuda.current_device() != (dev.index or 0):
+        raise RuntimeError(f"rank {rank}: current device {torch.cuda.current_device()} is not the assigned {dev}")
+    mine = (rank, identity or device_identity(dev), dev.index if dev.type == "cuda" else -1)
+    table = [mine]
+    if world > 1:
+        table = [None] * world
+        dist.all_gather_object(table, mine)
+    idents = [t[1] for t in table]
+    if sorted(t[0] for t in table) != list(range(world)):
+        raise RuntimeError(f"ranks are not 0..{world - 1}: {table}")
+    if len(set(idents)) != world and not allow_shared:
+        raise RuntimeError(f"ranks share a device (one process per GPU expected): {table}")
+    backend = dist.get_backend() if (dist.is_available() and dist.is_initialized()) else None
+    if backend is not None:
+        t = torch.full((4,), float(rank + 1), dtype=torch.float32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        want = world * (world + 1) / 2
+        if not bool((t == want).all()):
+            raise RuntimeError(f"rank {rank}: all-reduce over {backend} returned {t.tolist()}, expected {want}")
+    return {"world": world, "backend": backend, "distinct_devices": len(set(idents)), "devices": idents}
+
+
 def world_info() -> tuple[int, int]:
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()

@@ -518,20 +518,11 @@ def mlp_input_grad(d2: Tensor, h2: Tensor, w1t_packed: Tensor, w2t_packed: Tenso
     return dh, dx
 
 
-_PACKED_T: dict = {}
-
-
 def _packed_transposes(w1_16: Tensor, w2_16: Tensor) -> tuple[Tensor, Tensor]:
-    """(W1^T, W2^T) in the fused kernels' fragment order, cached on the 16-bit copies' identity (a handful of entries: the
-    cache is cleared when it grows past the layers of a few stacks)."""
-    key = (w1_16.data_ptr(), w1_16._version, w2_16.data_ptr(), w2_16._version, w1_16.dtype)
-    hit = _PACKED_T.get(key)
-    if hit is None:
-        if len(_PACKED_T) > 64:
-            _PACKED_T.clear()
-        hit = (_pack_stack(w1_16.t().contiguous()[None])[0], _pack_stack(w2_16.t().contiguous()[None])[0], w1_16, w2_16)
-        _PACKED_T[key] = hit  # (the 16-bit copies are kept alive with the entry: their addresses are the key)
-    return hit[0], hit[1]
+    """(W1^T, W2^T) in the fused kernels' fragment order, packed per call (two 128 x 512 transposes and two packing launches).
+    A cache keyed on the 16-bit copies' identity (r04 / r05) never hit: under autocast those copies are fresh tensors every
+    forward, and the cache kept them alive — so their addresses were never reused — pinning ~33 MB of dead weights."""
+    return _pack_stack(w1_16.t().contiguous()[None])[0], _pack_stack(w2_16.t().contiguous()[None])[0]
 
 
 def _mlp_block_bwd(kind, dout, x2, h, w1_16, w2_16, y, g32, mean, rstd, arena=None, layer=0, wt=None, wp=None):
@@ -547,9 +538,7 @@ def _mlp_block_bwd(kind, dout, x2, h, w1_16, w2_16, y, g32, mean, rstd, arena=No
     h2 = h.reshape(-1, h.shape[-1])
     if (wp is None and FUSED_MLP_INPUT_GRAD and tuple(w1_16.shape) == (4 * EMBED_DIM, EMBED_DIM)
             and tuple(w2_16.shape) == (EMBED_DIM, 4 * EMBED_DIM)):
-        # a single sub-block node (batch / layer norm training, the piecewise path): this layer's transposes in fragment
-        # order, packed once per (weight storage, version) — gradient accumulation and repeated backward passes over the
-        # same weights reuse them
+        # a single sub-block node (batch / layer norm training, the piecewise path): this layer's transposes in fragment order
         wp = _packed_transposes(w1_16, w2_16)
     if wp is not None and h2.shape[-1] == 4 * EMBED_DIM and d2.is_contiguous() and h2.is_contiguous():
         dh, dx = mlp_input_grad(d2, h2, wp[0], wp[1])

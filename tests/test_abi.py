@@ -31,6 +31,8 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert getattr(handle, name) is not None
     assert b"gfx950" in handle.rl4co_version()
+    # the binding, the header and the built library agree on the ABI version (a stale .so under unchanged names is refused)
+    assert int(re.search(r"#define RL4CO_ABI_VERSION (\d+)", HEADER).group(1)) == _lib.ABI_VERSION == handle.rl4co_abi_version()
 
 
 def _c_fields(struct_name):

@@ -70,6 +70,14 @@ def _worker(rank: int, world: int, port: int, out_q):
     # bench.py's aggregation: wall = max over ranks, work = sum over ranks
     assert D.reduce_scalar(1.0 + rank, "max") == 2.0
     assert D.reduce_scalar(4096 * 100 * 5, "sum") == 2 * 4096 * 100 * 5
+    # --- bench.py's start-up self-check: N ranks, a device each, a collective that really sums --------------------------
+    info = D.check_placement(None, world)
+    assert info["world"] == world and info["distinct_devices"] == world and info["backend"] == "gloo"
+    with pytest.raises(RuntimeError, match="share a device"):  # both ranks see the same table and fail together
+        D.check_placement(None, world, identity="uuid:the-same-gpu")
+    assert D.check_placement(None, world, identity="uuid:the-same-gpu", allow_shared=True)["distinct_devices"] == 1
+    with pytest.raises(RuntimeError, match="launched for 8"):
+        D.check_placement(None, 8)
     D.barrier()
     out_q.put((rank, bucket.nbytes, float(bucket.flat.sum())))
     dist.barrier()

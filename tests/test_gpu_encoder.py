@@ -454,8 +454,9 @@ def test_token_tile_attention_fast_and_exact_paths_agree():
 @pytest.mark.parametrize("rows", [1, 2, 3, 5, 63])
 def test_fused_encoder_rows_do_not_depend_on_the_batch(rows):
     """Instances are independent: the planes of the first `rows` instances encoded alone are bit-identical to the same rows
-    of the full batch — whatever the kernel's grouping of instances (r05: two instances per workgroup, a persistent walk
-    over the batch; an odd count leaves one half of the last workgroup repeating the final instance)."""
+    of the full batch — whatever the batch they arrive in (the kernel is one workgroup per instance, `launch_encoder`: dim3(B); the r05 probes that
+    carried two instances per workgroup / walked the batch persistently were measured and removed, DESIGN.md §4.2 — this
+    test is what any such regrouping has to keep passing)."""
     g = GoldenCase("tsp100_b64_greedy")
     pol = _policy(g, encoder_autocast=torch.bfloat16, cache_dtype=torch.bfloat16)
     _perturb_norm_stats(pol)

@@ -20,7 +20,7 @@ import os
 import pytest
 import torch
 
-from tools.trained_parity import TrainedCase, compare, compare_augmented
+from trained_parity import TrainedCase, compare, compare_augmented
 
 pytestmark = pytest.mark.gpu
 

@@ -282,11 +282,11 @@ def test_backward_error_sink_survives_forwards_between_forward_and_backward(cpu_
 
 
 def test_trained_parity_measurement_on_the_fake_device(cpu_device):
-    """tools/trained_parity.compare (what the `-m gpu` trained-weight tests and bench.py's parity block run) end to end
+    """tests/trained_parity.compare (what the `-m gpu` trained-weight tests and bench.py's parity block run) end to end
     on the stand-in device: the tanh-plateau fixture (logit key x 400: nearly every greedy step an exact tie at +10,
     lowest index wins) — the C oracle's specified-order arithmetic must reproduce the reference's tours, and any flip
     must be a proven near-tie."""
-    from tools.trained_parity import TrainedCase, compare
+    from trained_parity import TrainedCase, compare
 
     case = TrainedCase("sharpkl400_tsp100_b512_greedy")
     case.batch = 64  # a prefix of the seeded batch is not the same draw: regenerate and slice instead

@@ -3,7 +3,8 @@
 Shared by ``tests/test_gpu_trained_parity.py`` (asserts) and ``bench.py``'s ``parity`` block (reports). Nothing here
 touches ``oracle/`` or ``/root/reference``: the fixtures hold the reference's actions / rewards (made in the build
 container by ``oracle/gen_trained_golden.py``), inputs are re-created from their seed and verified by hash, weights
-come from ``tests/golden/weights/*.safetensors`` (trained by ``tools/train_sharp.py``).
+come from ``tests/golden/weights/*.safetensors`` (trained by ``tools/train_sharp.py``). Lives under ``tests/`` (r06: test
+infrastructure does not belong in the scratch directory ``tools/``); ``bench.py`` puts ``tests/`` on its path to import it.
 
 What is measured for one (case, product configuration):
 
@@ -24,7 +25,7 @@ import os
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # (this file lives in tests/)
 TRAINED_DIR = os.path.join(ROOT, "tests", "golden", "trained")
 WEIGHT_DIR = os.path.join(ROOT, "tests", "golden", "weights")
 

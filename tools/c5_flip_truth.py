@@ -15,7 +15,8 @@ import torch
 import torch.nn.functional as F
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tools.trained_parity import CONFIGS, TrainedCase, _pad  # noqa: E402
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from trained_parity import CONFIGS, TrainedCase, _pad  # noqa: E402
 
 dev = "cuda"
 case = TrainedCase(sys.argv[2] if len(sys.argv) > 2 else "t5_cvrp500_b1024_greedy")

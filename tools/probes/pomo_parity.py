@@ -1,6 +1,6 @@
 import json, sys, torch
-sys.path.insert(0, "/root/repo")
-from tools.trained_parity import TrainedCase, compare, compare_augmented
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+from trained_parity import TrainedCase, compare, compare_augmented
 c = TrainedCase("t4_pomo_tsp100_b256_msgreedy")
 res = {}
 for cfg, ag in (("fp32", "fp32"), ("bf16", "fp32"), ("bf16", "bf16"), ("fp16", "fp32")):
