@@ -33,8 +33,9 @@ extern "C" {
  * loaded library was built with) against the RL4CO_ABI_VERSION of the header it was written for and refuses to run on a
  * mismatch: a changed argument list under an unchanged symbol name still links (r05: rl4co_attn_bwd_* gained `out` in
  * second position — a caller built for the old list would pass dout as out and lse as dout).
- *   6: rl4co_attn_bwd_{bf16,f16} take the forward's `out`; rl4co_abi_version() itself. */
-#define RL4CO_ABI_VERSION 6
+ *   6: rl4co_attn_bwd_{bf16,f16} take the forward's `out`; rl4co_abi_version() itself.
+ *   7: rl4co_am_decode_args / rl4co_am_teacher_args end in the context tables' dtype and strides (ctx_dtype ...). */
+#define RL4CO_ABI_VERSION 7
 
 /* ---- status codes ------------------------------------------------------ */
 #define RL4CO_OK 0
@@ -278,8 +279,8 @@ typedef struct rl4co_am_decode_args {
   const void* logit_key;
   int64_t kvl_row_stride;   /* elements between node rows   (128 planar, 384 interleaved) */
   int64_t kvl_batch_stride; /* elements between instances                                  */
-  const float* ctx_first;   /* [B_inst,N,128] TSP only                                     */
-  const float* ctx_cur;     /* [B_inst,N,128]                                              */
+  const void* ctx_first;    /* [B_inst,N,128] TSP only; element type ctx_dtype (fp32 unless set) */
+  const void* ctx_cur;      /* [B_inst,N,128]                                              */
   const float* q_bias;      /* [B_inst,128] or NULL                                        */
   const float* q_step0;     /* [128] TSP only                                              */
   const float* w_cap;       /* [128] CVRP only                                             */
@@ -344,6 +345,15 @@ typedef struct rl4co_am_decode_args {
                              * roofline in bench.py. 64 bits: 409 600 trajectories x 5050 rows already reach 2.07e9.
                              * A misaligned pointer is refused (RL4CO_STATUS_INVALID_ARGUMENT)                       */
   int32_t* err;             /* sticky error bits                                           */
+  /* (r06) the folded context tables in the element type of the planes: ctx_dtype = RL4CO_DT_BF16 / _F16 (0 = RL4CO_DT_F32,
+   * the default) with their own strides in ELEMENTS (0 = dense: row 128, instance N * 128) — e.g. columns 3 and 4 of the
+   * ONE [B_inst * N, 5 * 128] 16-bit matrix a fused cache-fold GEMM writes (row stride 640): no fp32 copies of the tables.
+   * The rows are widened to fp32 on load; everything downstream is the fp32 arithmetic of the fp32 tables. Multistart
+   * variant (am_decode_ms.hip); the other variants require RL4CO_DT_F32. */
+  int32_t ctx_dtype;
+  int32_t reserved0;
+  int64_t ctx_row_stride;
+  int64_t ctx_batch_stride;
 } rl4co_am_decode_args;
 
 int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream);
@@ -555,8 +565,8 @@ typedef struct rl4co_am_teacher_args {
   const void* logit_key;
   int64_t kvl_row_stride;
   int64_t kvl_batch_stride;
-  const float* ctx_first;
-  const float* ctx_cur;
+  const void* ctx_first;         /* element type ctx_dtype (fp32 unless set), strides below */
+  const void* ctx_cur;
   const float* q_bias;
   const float* q_step0;
   const float* w_cap;
@@ -586,6 +596,15 @@ typedef struct rl4co_am_teacher_args {
   int64_t d_planes_row_stride;
   int64_t d_planes_batch_stride;
   int64_t d_planes_plane_stride;
+  /* (r06, MMA variant) context tables in the planes' element type, as in rl4co_am_decode_args: ctx_dtype (0 = fp32),
+   * strides in elements (0 = dense). d_ctx_in_planes = 1 (needs d_planes_bf16): the context-table gradients leave the
+   * kernel converted to the planes' type as planes 3 (ctx_first, TSP) and 4 (ctx_cur; plane 3 in the depot environments)
+   * of the same strided gradient matrix — d_ctx_first / d_ctx_cur remain the kernel's fp32 accumulation scratch
+   * (d_ctx_first zero-initialised by the caller) and hold nothing the caller needs afterwards. */
+  int32_t ctx_dtype;
+  int32_t d_ctx_in_planes;
+  int64_t ctx_row_stride;
+  int64_t ctx_batch_stride;
 } rl4co_am_teacher_args;
 
 int rl4co_am_teacher_backward(const rl4co_am_teacher_args* args, void* stream);

@@ -394,8 +394,8 @@ int oracle_am_decode(const rl4co_am_decode_args* a, int row_groups) {
   for (int r = 0; r < a->B; ++r) {
     const int cb = r % a->B_inst;
     const int64_t cbase = (int64_t)cb * a->kvl_batch_stride;
-    const float* ctxc = a->unfold ? NULL : a->ctx_cur + (int64_t)cb * N * D;
-    const float* ctxf = (a->env == RL4CO_ENV_TSP && !a->unfold) ? a->ctx_first + (int64_t)cb * N * D : NULL;
+    const float* ctxc = a->unfold ? NULL : (const float*)a->ctx_cur + (int64_t)cb * N * D;
+    const float* ctxf = (a->env == RL4CO_ENV_TSP && !a->unfold) ? (const float*)a->ctx_first + (int64_t)cb * N * D : NULL;
     uint8_t* gmask = a->action_mask + (int64_t)r * N;
     memcpy(mk, gmask, (size_t)N);
     if (a->env != RL4CO_ENV_TSP) memcpy(vis, a->visited + (int64_t)r * N, (size_t)N);
@@ -742,8 +742,8 @@ int oracle_am_decode_ms(const rl4co_am_decode_args* a) {
   for (int r = 0; r < a->B; ++r) {
     const int cb = r % a->B_inst;
     const int64_t cbase = (int64_t)cb * a->kvl_batch_stride;
-    const float* ctxc = a->ctx_cur + (int64_t)cb * N * D;
-    const float* ctxf = tsp ? a->ctx_first + (int64_t)cb * N * D : NULL;
+    const float* ctxc = (const float*)a->ctx_cur + (int64_t)cb * N * D;
+    const float* ctxf = tsp ? (const float*)a->ctx_first + (int64_t)cb * N * D : NULL;
     uint8_t* gmask = a->action_mask + (int64_t)r * N;
     memcpy(mk, gmask, (size_t)N);
     if (!tsp) memcpy(vis, a->visited + (int64_t)r * N, (size_t)N);

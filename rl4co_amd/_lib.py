@@ -12,7 +12,7 @@ from functools import lru_cache
 from . import build as _build
 
 RL4CO_OK = 0
-ABI_VERSION = 6  # RL4CO_ABI_VERSION of include/rl4co_amd.h this binding's argument lists were written for
+ABI_VERSION = 7  # RL4CO_ABI_VERSION of include/rl4co_amd.h this binding's argument lists were written for
 ENV_TSP, ENV_CVRP, ENV_OP, ENV_PCTSP, ENV_PDP, ENV_CVRPTW = 0, 1, 2, 3, 4, 5
 DECODE_GREEDY, DECODE_SAMPLE, DECODE_EVALUATE = 0, 1, 2
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
@@ -79,6 +79,7 @@ class AmDecodeArgs(C.Structure):
         ("t0", _i32), ("out_stride", _i32),
         ("actions", _vp), ("logps", _vp), ("all_logps", _vp), ("entropy", _vp),
         ("n_steps", _vp), ("steps_summary", _vp), ("err", _vp),
+        ("ctx_dtype", _i32), ("reserved0", _i32), ("ctx_row_stride", _i64), ("ctx_batch_stride", _i64),
     ]
 
 

@@ -100,6 +100,36 @@ struct CacheF16 {
 
 __host__ __device__ inline int lds_pad(int N) { return (N + 63) & ~63; }
 
+// The folded context tables of one instance, EPL dims from e0 on, as fp32: dense fp32 [N,128] rows (the default), or — r06,
+// ctx_dtype — rows in the planes' 16-bit element type with the caller's strides (e.g. column blocks of the one 16-bit
+// matrix the fused cache fold writes), widened exactly on load: the arithmetic downstream is that of the fp32 tables, so
+// the specified-order oracle, given the widened values, still equals the kernel bit for bit.
+template <class C>
+struct CtxTables {
+  const char *cur, *first;
+  int64_t rs;  // bytes between node rows
+  bool half;
+  __device__ inline CtxTables(const rl4co_am_decode_args& a, int cb, int N, int e0) {
+    half = a.ctx_dtype != RL4CO_DT_F32;
+    const int64_t esz = half ? 2 : 4;
+    rs = (a.ctx_row_stride ? a.ctx_row_stride : (int64_t)kD) * esz;
+    const int64_t off = ((int64_t)cb * (a.ctx_batch_stride ? a.ctx_batch_stride : (int64_t)N * kD) + e0) * esz;
+    cur = a.ctx_cur ? static_cast<const char*>(a.ctx_cur) + off : nullptr;
+    first = a.ctx_first ? static_cast<const char*>(a.ctx_first) + off : nullptr;
+  }
+  __device__ inline void load(const char* table, int64_t row, float (&v)[C::EPL]) const {
+    const char* p = table + row * rs;
+    if constexpr (sizeof(typename C::elem) == 2) {
+      if (half) {
+        C::cvt(C::ld(reinterpret_cast<const typename C::elem*>(p)), v);
+        return;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < C::EPL; ++e) v[e] = reinterpret_cast<const float*>(p)[e];
+  }
+};
+
 // blockIdx -> trajectory. Trajectories are stored s-major (row r = s * B_inst + instance, the
 // reference's batchify layout) and the S trajectories of an instance stream the SAME cache planes.
 // Workgroup b is dispatched to XCD b % 8 (observed placement, used for speed only), and each XCD
@@ -401,8 +431,7 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
   const elem* Vg = static_cast<const elem*>(a.glimpse_val) + (int64_t)cb * a.kvl_batch_stride + e0;
   const elem* Kl = static_cast<const elem*>(a.logit_key) + (int64_t)cb * a.kvl_batch_stride + e0;
   const int64_t rs = a.kvl_row_stride;
-  const float* ctxc = UNFOLD ? nullptr : a.ctx_cur + (int64_t)cb * N * kD + e0;
-  const float* ctxf = (ENV == RL4CO_ENV_TSP && !UNFOLD) ? a.ctx_first + (int64_t)cb * N * kD + e0 : nullptr;
+  const CtxTables<C> ctx(a, cb, N, e0);  // (UNFOLD: not read)
   const float* hrow = UNFOLD ? a.node_embed + (int64_t)cb * N * kD + e0 : nullptr;
 
   // ---- load the trajectory state ---------------------------------------------------
@@ -483,19 +512,25 @@ __global__ void __launch_bounds__(64) am_decode_kernel(const rl4co_am_decode_arg
 #pragma unroll
         for (int e = 0; e < EPL; ++e) q[e] = a.q_step0[e0 + e] + qb[e];
       } else {
+        float cf[EPL], cc[EPL];
+        ctx.load(ctx.first, st.first, cf);
+        ctx.load(ctx.cur, st.cur, cc);
 #pragma unroll
-        for (int e = 0; e < EPL; ++e)
-          q[e] = (ctxf[(int64_t)st.first * kD + e] + ctxc[(int64_t)st.cur * kD + e]) + qb[e];
+        for (int e = 0; e < EPL; ++e) q[e] = (cf[e] + cc[e]) + qb[e];
       }
     } else if (ENV == RL4CO_ENV_PDP) {  // context.py:232-243: the current node alone
+      float cc[EPL];
+      ctx.load(ctx.cur, st.cur, cc);
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) q[e] = ctxc[(int64_t)st.cur * kD + e] + qb[e];
+      for (int e = 0; e < EPL; ++e) q[e] = cc[e] + qb[e];
     } else {
       float rem = cap - st.used;  // context.py:147-149
       if (ENV == RL4CO_ENV_PCTSP && !(rem > 0.0f)) rem = 0.0f;
+      float cc[EPL];
+      ctx.load(ctx.cur, st.cur, cc);
 #pragma unroll
       for (int e = 0; e < EPL; ++e) {
-        float v = fmaf(a.w_cap[e0 + e], rem, ctxc[(int64_t)st.cur * kD + e]);
+        float v = fmaf(a.w_cap[e0 + e], rem, cc[e]);
         if (ENV == RL4CO_ENV_CVRPTW) v = fmaf(a.w_time[e0 + e], st.time, v);  // context.py:152-166
         q[e] = v + qb[e];
       }
@@ -784,8 +819,7 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 4) am_decode_wide_kernel(const
     Kl = static_cast<const uint16_t*>(a.logit_key) + (int64_t)cb * a.kvl_batch_stride + e0;
     rs = a.kvl_row_stride;
   }
-  const float* ctxc = a.ctx_cur + (int64_t)cb * N * kD + e0;
-  const float* ctxf = (ENV == RL4CO_ENV_TSP) ? a.ctx_first + (int64_t)cb * N * kD + e0 : nullptr;
+  const CtxTables<C> ctx(a, cb, N, e0);
   // o/l partial slots inside this wave's own (dead after pass 2) score chunks
   auto opart = [&](int wv, int d) -> float* { return sc + ((16 * (d >> 5) + 4 * wv) * kH) + (d & 31); };
   auto lpart = [&](int wv, int h) -> float* { return sc + ((16 * 4 + 4 * wv) * kH) + h; };
@@ -863,19 +897,25 @@ __global__ void __launch_bounds__(64 * kLdsWaves, 4) am_decode_wide_kernel(const
 #pragma unroll
         for (int e = 0; e < EPL; ++e) q[e] = a.q_step0[e0 + e] + qb[e];
       } else {
+        float cf[EPL], cc[EPL];
+        ctx.load(ctx.first, st.first, cf);
+        ctx.load(ctx.cur, st.cur, cc);
 #pragma unroll
-        for (int e = 0; e < EPL; ++e)
-          q[e] = (ctxf[(int64_t)st.first * kD + e] + ctxc[(int64_t)st.cur * kD + e]) + qb[e];
+        for (int e = 0; e < EPL; ++e) q[e] = (cf[e] + cc[e]) + qb[e];
       }
     } else if (ENV == RL4CO_ENV_PDP) {  // context.py:232-243: the current node alone
+      float cc[EPL];
+      ctx.load(ctx.cur, st.cur, cc);
 #pragma unroll
-      for (int e = 0; e < EPL; ++e) q[e] = ctxc[(int64_t)st.cur * kD + e] + qb[e];
+      for (int e = 0; e < EPL; ++e) q[e] = cc[e] + qb[e];
     } else {
       float rem = cap - st.used;  // context.py:147-149
       if (ENV == RL4CO_ENV_PCTSP && !(rem > 0.0f)) rem = 0.0f;
+      float cc[EPL];
+      ctx.load(ctx.cur, st.cur, cc);
 #pragma unroll
       for (int e = 0; e < EPL; ++e) {
-        float v = fmaf(a.w_cap[e0 + e], rem, ctxc[(int64_t)st.cur * kD + e]);
+        float v = fmaf(a.w_cap[e0 + e], rem, cc[e]);
         if (ENV == RL4CO_ENV_CVRPTW) v = fmaf(a.w_time[e0 + e], st.time, v);  // context.py:152-166
         q[e] = v + qb[e];
       }
@@ -1147,6 +1187,11 @@ extern "C" int rl4co_am_decode(const rl4co_am_decode_args* args, void* stream) {
   RL4CO_REQUIRE(a.cache_dtype != RL4CO_DT_F16 || !a.unfold);
   RL4CO_REQUIRE(a.glimpse_key && a.glimpse_val && a.logit_key && (a.ctx_cur || a.unfold));
   RL4CO_REQUIRE(a.unfold == 0 || a.unfold == 1);
+  // (r06) context tables in the planes' 16-bit type / with their own strides: 16-byte rows for the 8-dim lanes
+  RL4CO_REQUIRE(a.ctx_dtype == RL4CO_DT_F32 || (a.ctx_dtype == a.cache_dtype && !a.unfold));
+  RL4CO_REQUIRE(a.ctx_row_stride == 0 || (a.ctx_row_stride >= kD && a.ctx_row_stride % 8 == 0));
+  RL4CO_REQUIRE(a.ctx_batch_stride == 0 || (a.ctx_batch_stride >= (int64_t)a.N * kD && a.ctx_batch_stride % 8 == 0));
+  RL4CO_REQUIRE(a.ctx_dtype == RL4CO_DT_F32 || ((reinterpret_cast<uintptr_t>(a.ctx_cur) | reinterpret_cast<uintptr_t>(a.ctx_first)) & 15) == 0);
   if (a.unfold) {
     RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP);
     RL4CO_REQUIRE(a.node_embed && a.w_ctx_t && a.w_out_t);

@@ -162,11 +162,21 @@ struct Sel {  // log-softmax / selection pieces over a set of nodes
 // step here (the Gumbel noise is log(-log u) of four uniforms), none of whose arguments can be denormal: uniforms and
 // exponential noise are >= 2^-33, -log u >= 2^-25, sums of exponentials >= 1
 __device__ inline float ln_fast(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
-__device__ inline Sel merge(const Sel& p, const Sel& q) {
+// BOUNDED (r06): clipped logits live in [-C, C], C = tanh_clipping / temperature; up to C = 60 their exponentials and the
+// sum over <= 128 nodes are plain fp32 numbers, so the log-sum-exp needs no running maximum — the pieces are exp(z) sums
+// and a merge is ONE addition instead of a maximum, two subtractions, two exponentials and a multiply-add (five merges per
+// wave and step: the step is VALU-issue bound, r05 counters: 795 VALU instructions per wave-step against 44 MFMAs). The
+// teacher kernel (am_teacher_mma.hip, `bounded`) has summed its log-softmax that way since r03.
+__device__ inline Sel merge(const Sel& p, const Sel& q, bool bounded) {
   Sel o;
-  o.zmax = fmaxf(p.zmax, q.zmax);
-  const float zs = (o.zmax > kNegInf) ? o.zmax : 0.0f;
-  o.se = p.se * __expf(p.zmax - zs) + q.se * __expf(q.zmax - zs);  // exp(-inf) = 0 for an empty set
+  if (bounded) {
+    o.zmax = 0.0f;
+    o.se = p.se + q.se;
+  } else {
+    o.zmax = fmaxf(p.zmax, q.zmax);
+    const float zs = (o.zmax > kNegInf) ? o.zmax : 0.0f;
+    o.se = p.se * __expf(p.zmax - zs) + q.se * __expf(q.zmax - zs);  // exp(-inf) = 0 for an empty set
+  }
   const bool take_q = (q.idx != 0x7fffffff) & ((p.idx == 0x7fffffff) | (q.key > p.key) | ((q.key == p.key) & (q.idx < p.idx)));
   o.key = take_q ? q.key : p.key;
   o.z = take_q ? q.z : p.z;
@@ -230,8 +240,20 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
   const float cap = (kCvrpLike || ENV == RL4CO_ENV_PCTSP) ? a.vehicle_capacity[inst]
                                                                      : (ENV == RL4CO_ENV_OP ? a.max_length[(int64_t)inst * N] : 0.0f);
   const float thr = cap + 1e-5f;
-  const float* ctxc = a.ctx_cur + (int64_t)inst * N * kD + dcol;
-  const float* ctxf = (ENV == RL4CO_ENV_TSP) ? a.ctx_first + (int64_t)inst * N * kD + dcol : nullptr;
+  // context tables: dense fp32 [B_inst,N,128], or (r06, ctx_dtype) rows in the planes' 16-bit type with the caller's strides
+  const bool ctx16 = a.ctx_dtype != RL4CO_DT_F32;
+  const int64_t ctx_esz = ctx16 ? 2 : 4;
+  const int64_t ctx_rs = (a.ctx_row_stride ? a.ctx_row_stride : (int64_t)kD) * ctx_esz;  // bytes between node rows
+  const int64_t ctx_off = ((int64_t)inst * (a.ctx_batch_stride ? a.ctx_batch_stride : (int64_t)N * kD) + dcol) * ctx_esz;
+  const char* ctxc = static_cast<const char*>(a.ctx_cur) + ctx_off;
+  const char* ctxf = (ENV == RL4CO_ENV_TSP) ? static_cast<const char*>(a.ctx_first) + ctx_off : nullptr;
+  auto first_row = [&](int node, float (&f)[4]) {
+    const float4 v = rl4co_e16::load_ctx4(ctxf + (int64_t)node * ctx_rs, ctx16);
+    f[0] = v.x;
+    f[1] = v.y;
+    f[2] = v.z;
+    f[3] = v.w;
+  };
   float qb4[4], qx4[4], qt4[4];  // graph context; placeholder query (TSP) or capacity column; CVRPTW: the time column
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -243,6 +265,7 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
   const float inv_temp = 1.0f / a.temperature;
   const float clip_over_temp = a.tanh_clipping * inv_temp;
   const bool clip = a.tanh_clipping > 0.0f;
+  const bool bounded = clip && clip_over_temp <= 60.0f;  // (uniform: a scalar branch around the maximum bookkeeping, see merge)
   Bits128 nv;  // nodes that exist (j < N), per 32-node word
 #pragma unroll
   for (int k = 0; k < 4; ++k) nv.put(k, (N >= 32 * (k + 1)) ? 0xffffffffu : (N > 32 * k ? ((1u << (N - 32 * k)) - 1u) : 0u));
@@ -281,7 +304,8 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
     x.park_logp = 0.0f;
     x.park_col = -1;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) x.f4[e] = (ENV == RL4CO_ENV_TSP && x.step_i > 0) ? ctxf[(int64_t)x.first * kD + e] : 0.0f;
+    for (int e = 0; e < 4; ++e) x.f4[e] = 0.0f;
+    if (ENV == RL4CO_ENV_TSP && x.step_i > 0) first_row(x.first, x.f4);
   }
   // the logit-key tile of this wave (nodes 16 w .., all 128 dims) is the same at every step — 16 registers for the
   // whole rollout instead of a third LDS plane (rows past the graph: any finite value, their logits are masked)
@@ -320,7 +344,7 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
     // ---- 1. query of head h (folded context + graph context), x 1/sqrt(16) x log2(e) -----------------
     float4 c4v[CT];
 #pragma unroll
-    for (int c = 0; c < CT; ++c) c4v[c] = *reinterpret_cast<const float4*>(ctxc + (int64_t)tj[c].cur * kD);  // L2-resident context row
+    for (int c = 0; c < CT; ++c) c4v[c] = rl4co_e16::load_ctx4(ctxc + (int64_t)tj[c].cur * ctx_rs, ctx16);  // L2-resident context row
     // this step's noise: log(Exp(1) noise) of the four nodes this lane owns in the logits stage (they share
     // one Philox block, rl4co_math.h). Depends on (step, row, node) only, so it is drawn HERE — ten dependent
     // Philox rounds and two logarithms that used to sit between the two barriers, on the step's critical path,
@@ -515,10 +539,16 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
           const float th = copysignf((1.0f - ex) * __builtin_amdgcn_rcpf(1.0f + ex), uu) * clip_over_temp;
           const float zz = clip ? th : uu * inv_temp;
           z[rr] = ((lbits >> rr) & 1u) ? zz : kNegInf;
-          p.zmax = fmaxf(p.zmax, z[rr]);
         }
         if (nan_seen & x.ok & !x.done) errbits |= RL4CO_EBIT_NAN_LOGIT;
-        const float zs = (p.zmax > kNegInf) ? p.zmax : 0.0f;
+        float zs = 0.0f;
+        if (bounded) {
+          p.zmax = 0.0f;
+        } else {
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) p.zmax = fmaxf(p.zmax, z[rr]);
+          zs = (p.zmax > kNegInf) ? p.zmax : 0.0f;
+        }
         p.se = 0.0f;
         p.key = kNegInf;
         p.z = kNegInf;
@@ -538,8 +568,8 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
           if (MODE == RL4CO_DECODE_EVALUATE) p.fz = (node == forced[c]) ? zz : p.fz;
         }
         // the four row groups hold different nodes of the same trajectory
-        p = merge(p, partner<16>(p));
-        p = merge(p, partner<32>(p));
+        p = merge(p, partner<16>(p), bounded);
+        p = merge(p, partner<32>(p), bounded);
         if (g == 0) {
           Xchg e;
           e.zmax = p.zmax;
@@ -582,11 +612,11 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
         q.z = has ? e.best_z : kNegInf;
         q.idx = has ? e.best_idx : 0x7fffffff;
         q.fz = has ? e.forced_z : kNegInf;
-        p = merge(p, q);
+        p = merge(p, q, bounded);
       }
-      p = merge(p, partner<16>(p));
-      p = merge(p, partner<32>(p));
-      const float lse = p.zmax + ln_fast(p.se);
+      p = merge(p, partner<16>(p), bounded);
+      p = merge(p, partner<32>(p), bounded);
+      const float lse = (bounded ? 0.0f : p.zmax) + ln_fast(p.se);
       int act;
       float logp;
       if (MODE == RL4CO_DECODE_EVALUATE) {
@@ -613,8 +643,7 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
         if (ENV == RL4CO_ENV_TSP) {
           if (x.step_i == 0) {
             x.first = act;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) x.f4[e] = ctxf[(int64_t)x.first * kD + e];
+            first_row(x.first, x.f4);
           }
           x.cur = act;
           x.step_i += 1;

@@ -88,8 +88,8 @@ __global__ void __launch_bounds__(64 * kW) am_teacher_kernel(const rl4co_am_teac
   }
   for (int idx = tid; idx < N * kD; idx += 64 * kW) dctx[idx] = 0.0f;
 
-  const float* ctxc = a.ctx_cur + (int64_t)inst * N * kD + e0;
-  const float* ctxf = (ENV == RL4CO_ENV_TSP) ? a.ctx_first + (int64_t)inst * N * kD + e0 : nullptr;
+  const float* ctxc = static_cast<const float*>(a.ctx_cur) + (int64_t)inst * N * kD + e0;
+  const float* ctxf = (ENV == RL4CO_ENV_TSP) ? static_cast<const float*>(a.ctx_first) + (int64_t)inst * N * kD + e0 : nullptr;
   constexpr bool kCvrpLike = ENV == RL4CO_ENV_CVRP || ENV == RL4CO_ENV_CVRPTW;
   constexpr bool kClock = ENV == RL4CO_ENV_CVRPTW;
   constexpr bool kScalar = ENV != RL4CO_ENV_TSP && ENV != RL4CO_ENV_PDP;  // one context scalar, cap - used
@@ -583,6 +583,11 @@ static int validate_teacher(const rl4co_am_teacher_args& a) {
     RL4CO_REQUIRE((a.N - 1) % 2 == 0);  // PDP: pickups 1..n/2, deliveries n/2+1..n; no instance data
   }
   RL4CO_REQUIRE(a.q_bias == nullptr || a.d_q_bias != nullptr);
+  // (r06) context tables in the planes' 16-bit type with their own strides, gradients into planes 3 / 4: MMA variant only
+  RL4CO_REQUIRE(a.ctx_dtype == RL4CO_DT_F32 || (a.ctx_dtype == a.cache_dtype && a.cache_dtype != RL4CO_DT_F32));
+  RL4CO_REQUIRE(a.ctx_row_stride == 0 || (a.ctx_row_stride >= kD && a.ctx_row_stride % 4 == 0));
+  RL4CO_REQUIRE(a.ctx_batch_stride == 0 || (a.ctx_batch_stride >= (int64_t)a.N * kD && a.ctx_batch_stride % 4 == 0));
+  RL4CO_REQUIRE(a.d_ctx_in_planes == 0 || (a.d_ctx_in_planes == 1 && a.d_planes_bf16 != nullptr));
   return RL4CO_OK;
 }
 
@@ -590,6 +595,8 @@ static int validate_teacher(const rl4co_am_teacher_args& a) {
 static int resolve_teacher_variant(const rl4co_am_teacher_args& a) {
   const bool mma_ok = a.cache_dtype != RL4CO_DT_F32 && a.N <= rl4co::teacher_mma_max_nodes() &&
                       a.T <= rl4co::teacher_mma_max_steps() && a.kvl_row_stride % 8 == 0 && a.kvl_batch_stride % 8 == 0;
+  if (a.ctx_dtype != RL4CO_DT_F32 || a.ctx_row_stride || a.ctx_batch_stride)  // 16-bit / strided context tables: MMA variant only
+    return (mma_ok && a.variant != RL4CO_TEACHER_REPLAY) ? RL4CO_TEACHER_MMA : -1;
   if (a.d_planes_bf16 || !a.d_kvl)  // bf16 plane gradients come out of the MMA variant only
     return (mma_ok && a.variant != RL4CO_TEACHER_REPLAY) ? RL4CO_TEACHER_MMA : -1;
   if (a.variant == RL4CO_TEACHER_MMA) return mma_ok ? RL4CO_TEACHER_MMA : -1;

@@ -90,6 +90,27 @@ __device__ inline f4 mfma_16x16x16(const e4& a, const e4& b, const f4& c) {
 #endif
 }
 
+// four dims of a folded context-table row: fp32 (16 bytes at p), or (r06) the translation unit's 16-bit element type (8
+// bytes at p) widened on load. BRANCH-FREE on purpose: one 16-byte load from the enclosing 16-byte line in either case
+// (fp32 rows: p itself, it is 16-byte aligned), the halves picked by selects. Written as `if (half) load 8 else load 16`
+// the compiler put a branch around each load and an s_waitcnt vmcnt(0) behind the 8-byte one — the row is requested one
+// step block AHEAD of its use, so that wait exposed its whole L2 round trip and drained the context-row scatter issued
+// before it as well (first r06 build: teacher backward 5.2 -> 9.8 ms). Table bases and row strides are multiples of 16 B.
+__device__ inline float4 load_ctx4(const char* p, bool half_rows) {
+  // (pointer arithmetic on p, not an integer round trip: the load must stay a GLOBAL load — a flat one counts on lgkmcnt too
+  // and every LDS wait of the step block would wait for the prefetch)
+  const uint32_t low = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(p)) & 15u;
+  const uint4 raw = *reinterpret_cast<const uint4*>(p - low);
+  const bool upper = (low & 8u) != 0;
+  const uint32_t u0 = upper ? raw.z : raw.x, u1 = upper ? raw.w : raw.y;
+  float4 v;
+  v.x = half_rows ? lo(u0) : __uint_as_float(raw.x);
+  v.y = half_rows ? hi(u0) : __uint_as_float(raw.y);
+  v.z = half_rows ? lo(u1) : __uint_as_float(raw.z);
+  v.w = half_rows ? hi(u1) : __uint_as_float(raw.w);
+  return v;
+}
+
 }  // namespace rl4co_e16
 
 #endif

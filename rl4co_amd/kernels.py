@@ -58,6 +58,23 @@ def _dev(t: Tensor, dtype: torch.dtype | None = None, name: str = "tensor") -> T
     return t
 
 
+def _ctx_table(a, t: Tensor, plane_dtype: torch.dtype, name: str) -> Tensor:
+    """A folded context table for ``rl4co_am_decode_args``: dense fp32 [B,N,128] (every variant), or — multistart variant —
+    rows in the planes' 16-bit type with any (instance, node) strides, e.g. a column block of the fused fold GEMM's output
+    matrix (``teacher.build_cache_autograd(fused_planes=True)``): sets ctx_dtype / ctx_row_stride / ctx_batch_stride."""
+    if not t.is_cuda:
+        raise _lib.Rl4coLibraryError(f"{name} lives on {t.device}; the rl4co_amd kernels only run on the MI355X (no CPU fallback)")
+    if t.dtype == torch.float32:
+        return _dev(t, torch.float32, name)
+    if t.dtype != plane_dtype or t.dim() != 3 or t.stride(2) != 1:
+        raise TypeError(f"{name} must be fp32, or [B,N,128] in the planes' dtype {plane_dtype} with unit channel stride")
+    dt, rs, bs = _lib.dtype_id(t.dtype), t.stride(1), t.stride(0)
+    if a.ctx_dtype not in (0, dt) or (a.ctx_row_stride not in (0, rs)) or (a.ctx_batch_stride not in (0, bs)):
+        raise ValueError("ctx_first and ctx_cur must share dtype and strides")
+    a.ctx_dtype, a.ctx_row_stride, a.ctx_batch_stride = dt, rs, bs
+    return t
+
+
 def _u8(t: Tensor, name: str) -> Tensor:
     """bool tensors share the uint8 storage the kernels read/write."""
     _dev(t, None, name)
@@ -243,14 +260,14 @@ def am_decode(
         a.w_out_t = _ptr(_dev(cache.w_out_t, torch.float32, "w_out_t"))
         a.w_placeholder = _ptr(None if cache.w_placeholder is None else _dev(cache.w_placeholder, torch.float32, "w_placeholder"))
     else:
-        a.ctx_cur = _ptr(_dev(cache.ctx_cur, torch.float32, "ctx_cur"))
+        a.ctx_cur = _ptr(_ctx_table(a, cache.ctx_cur, kvl.dtype, "ctx_cur"))
     a.q_bias = _ptr(None if cache.q_bias is None else _dev(cache.q_bias, torch.float32, "q_bias"))
     a.action_mask = _ptr(mask)
     a.current_node = _ptr(_dev(state["current_node"], torch.int64, "current_node"))
     a.done = _ptr(_u8(state["done"], "done"))
     if env_name == "tsp":
         if not cache.unfold:
-            a.ctx_first = _ptr(_dev(cache.ctx_first, torch.float32, "ctx_first"))
+            a.ctx_first = _ptr(_ctx_table(a, cache.ctx_first, kvl.dtype, "ctx_first"))
             a.q_step0 = _ptr(_dev(cache.q_step0, torch.float32, "q_step0"))
         a.first_node = _ptr(_dev(state["first_node"], torch.int64, "first_node"))
         a.step_i = _ptr(_dev(state["i"], torch.int64, "i"))

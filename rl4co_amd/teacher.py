@@ -36,6 +36,7 @@ class AmTeacherArgs(C.Structure):
         ("d_w_cap", _vp), ("d_w_time", _vp), ("logp_out", _vp), ("err", _vp),
         ("d_planes_bf16", _vp), ("d_planes_row_stride", C.c_int64), ("d_planes_batch_stride", C.c_int64),
         ("d_planes_plane_stride", C.c_int64),
+        ("ctx_dtype", _i32), ("d_ctx_in_planes", _i32), ("ctx_row_stride", _i64), ("ctx_batch_stride", _i64),
     ]
 
 
@@ -92,6 +93,11 @@ def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: d
     a.kvl_row_stride, a.kvl_batch_stride = cache.row_stride, cache.batch_stride
     ptr = lambda x: None if x is None else x.data_ptr()  # noqa: E731
     a.ctx_first, a.ctx_cur, a.q_bias = ptr(cache.ctx_first), ptr(cache.ctx_cur), ptr(cache.q_bias)
+    if cache.ctx_cur.dtype != torch.float32:  # context tables in the planes' 16-bit type (strided views of the fold GEMM's output)
+        cc = cache.ctx_cur
+        assert cc.dtype == cache.kvl.dtype and cc.dim() == 3 and cc.stride(2) == 1
+        assert cache.ctx_first is None or (cache.ctx_first.dtype == cc.dtype and cache.ctx_first.stride() == cc.stride())
+        a.ctx_dtype, a.ctx_row_stride, a.ctx_batch_stride = _lib.dtype_id(cc.dtype), cc.stride(1), cc.stride(0)
     a.q_step0, a.w_cap = ptr(cache.q_step0), ptr(cache.w_cap)
     acts = actions.contiguous()
     g = grad_logp.contiguous().float()
@@ -114,9 +120,14 @@ def run_backward(cache: FoldedCache, actions: Tensor, grad_logp: Tensor, meta: d
         a.locs, a.max_length = locs.data_ptr(), maxlen.data_ptr()
     a.d_kvl, a.d_ctx_cur, a.d_ctx_first, a.d_q_bias = ptr(d_kvl), ptr(d_ctx_cur), ptr(d_ctx_first), ptr(d_q_bias)
     if d_planes is not None:
-        assert d_planes.dtype == cache.kvl.dtype and d_planes.shape == (3, b_inst, n, EMBED_DIM) and d_planes.stride(3) == 1
+        # [3, ...]: the three plane gradients; [5, ...] (TSP) / [4, ...] (depot environments): the context-table gradients as
+        # well, converted by the kernel into planes 3 / 4 (d_ctx_in_planes) — the fp32 tensors below are then its scratch
+        nblk = 5 if tsp else 4
+        assert d_planes.dtype == cache.kvl.dtype and d_planes.shape[1:] == (b_inst, n, EMBED_DIM) and d_planes.stride(3) == 1
+        assert d_planes.shape[0] in (3, nblk)
         a.d_planes_bf16 = d_planes.data_ptr()
         a.d_planes_plane_stride, a.d_planes_batch_stride, a.d_planes_row_stride = d_planes.stride()[:3]
+        a.d_ctx_in_planes = int(d_planes.shape[0] == nblk)
     if tsp:
         a.d_q_step0 = d_extra.data_ptr()
     else:
@@ -159,9 +170,11 @@ def build_cache_autograd(env_name: str, h: Tensor, decoder, fused_planes: bool =
         planes = train_ops._gemm(h2, w16).view(b, n, len(blocks), d)  # row (b, n): [Kg | V | Kl' | ctx ...]
         out.update(fused=True, h=h, h2=h2, w_all=w_all, w16=w16, planes=planes)
         out["kvl"] = planes.permute(2, 0, 1, 3)[:3]                       # [3, B, N, 128] strided view, bf16
-        out["ctx_cur"] = planes[:, :, 4 if env_name == "tsp" else 3].float()  # the context tables are read as fp32
+        # (r06) the context tables stay columns of the same matrix: the multistart rollout and the MMA teacher backward read
+        # 16-bit rows at its row stride and widen them on load (two 68 us fp32 copies per step less)
+        out["ctx_cur"] = planes[:, :, 4 if env_name == "tsp" else 3]
         if env_name == "tsp":
-            out["ctx_first"] = planes[:, :, 3].float()
+            out["ctx_first"] = planes[:, :, 3]
     else:
         if h.is_cuda and h.dtype in (torch.bfloat16, torch.float16):
             # 16-bit encoder output (autocast training): the fold GEMMs and their backward run on the
@@ -189,12 +202,14 @@ def build_cache_autograd(env_name: str, h: Tensor, decoder, fused_planes: bool =
 def detached_cache(env_name: str, g: dict[str, Tensor], cache_dtype: torch.dtype) -> FoldedCache:
     """Rollout view of the autograd cache: detached, planes in the streaming dtype."""
     det = lambda x: None if x is None else x.detach().contiguous()  # noqa: E731
+    view = det
     if g.get("fused"):
         assert cache_dtype == g["kvl"].dtype and cache_dtype in (torch.bfloat16, torch.float16)
         kvl = g["kvl"]  # strided view of the fused GEMM's output rows: the kernels take plane pointers and strides
+        view = lambda x: None if x is None else x.detach()  # noqa: E731  (the context tables: column blocks of the same rows)
     else:
         kvl = g["kvl"].detach().to(cache_dtype).contiguous()
-    return FoldedCache(env_name, kvl, det(g.get("ctx_first")), det(g["ctx_cur"]), det(g.get("q_bias")), det(g.get("q_step0")),
+    return FoldedCache(env_name, kvl, view(g.get("ctx_first")), view(g["ctx_cur"]), det(g.get("q_bias")), det(g.get("q_step0")),
                        det(g.get("w_cap")), det(g.get("w_time")))
 
 
@@ -244,16 +259,14 @@ class TeacherForcedFoldLogLik(torch.autograd.Function):
 
         b, n, d = ctx.h_shape
         dp = torch.empty((b, n, ctx.nblk, d), dtype=ctx.h2.dtype, device=grad_logp.device)  # 16-bit, the planes' type
-        out = run_backward(ctx.cache, ctx.actions, grad_logp, ctx.meta, variant="mma", d_planes=dp.permute(2, 0, 1, 3)[:3])
+        # all nblk column blocks come out of the kernel: the three plane gradients and (r06) the context-table gradients,
+        # converted on the way out (two 53 us conversion copies per step less)
+        out = run_backward(ctx.cache, ctx.actions, grad_logp, ctx.meta, variant="mma", d_planes=dp.permute(2, 0, 1, 3))
         sink = ctx.meta.get("err_sink")
         if sink is not None:
             sink.bitwise_or_(out["err"])
         else:
             _lib.raise_for_error_bits(int(out["err"].item()))
-        tsp = ctx.cache.env_name == "tsp"
-        if tsp:
-            dp[:, :, 3].copy_(out["d_ctx_first"])
-        dp[:, :, 4 if tsp else 3].copy_(out["d_ctx_cur"])
         dp2 = dp.view(b * n, ctx.nblk * d)
         dh = train_ops._gemm(dp2, ctx.w16.t().contiguous()).view(b, n, d)
         dw = train_ops._wgrad(dp2, ctx.h2)

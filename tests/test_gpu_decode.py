@@ -38,12 +38,14 @@ def _encode(g: GoldenCase):
     return td0, h
 
 
-def _run(K, backend, g, td0, h, mode, dtype=torch.float32, max_steps=None, variant="auto", fold=True, **kw):
+def _run(K, backend, g, td0, h, mode, dtype=torch.float32, max_steps=None, variant="auto", fold=True, cache_hook=None, **kw):
     """One rollout on ``backend`` in {"hip", "c"}; returns (actions, logps, state, n_steps, t)."""
     dev = "cuda" if backend == "hip" else "cpu"
     if not fold and variant == "auto":
         variant = "stream"  # the parity mode lives in the streaming kernel (its row-group count is the oracle's G)
     cache = fold_cache(g.policy, g.env_name, h, dtype, device="cuda", fold=fold)
+    if cache_hook is not None:
+        cache = cache_hook(cache)
     if backend == "c":  # the oracle consumes the very same folded cache bytes the kernel streams
         cache = cache.to("cpu")
     s = g.num_starts
@@ -112,6 +114,51 @@ def test_greedy_bit_exact_vs_c_oracle(K, name, dtype, variant):
     td0, h = _encode(g)
     _assert_bit_exact(_run(K, "hip", g, td0, h, "greedy", dtype, variant=variant),
                       _run(K, "c", g, td0, h, "greedy", dtype, variant=variant))
+
+
+def _ctx_rounded(cache, dtype):
+    """The same cache with its context tables rounded to the planes' 16-bit type, held as fp32 (the widened values)."""
+    import dataclasses
+
+    return dataclasses.replace(cache, ctx_cur=cache.ctx_cur.to(dtype).float(),
+                               ctx_first=None if cache.ctx_first is None else cache.ctx_first.to(dtype).float())
+
+
+def _ctx_as_columns(cache, dtype):
+    """... and as 16-bit column blocks of ONE [B, N, 5 * 128] matrix beside the planes (the fused cache fold's layout): strided
+    views, row stride 640 elements."""
+    import dataclasses
+
+    b, n = cache.num_instances, cache.num_nodes
+    big = torch.zeros(b, n, 5, 128, dtype=dtype, device=cache.kvl.device)
+    big[:, :, :3] = cache.kvl.permute(1, 2, 0, 3)
+    big[:, :, 4] = cache.ctx_cur.to(dtype)
+    if cache.ctx_first is not None:
+        big[:, :, 3] = cache.ctx_first.to(dtype)
+    return dataclasses.replace(cache, kvl=big.permute(2, 0, 1, 3)[:3], ctx_cur=big[:, :, 4],
+                               ctx_first=None if cache.ctx_first is None else big[:, :, 3])
+
+
+@pytest.mark.parametrize("dtype,variant", [c for c in CONFIGS if c[0] != torch.float32], ids=[i for i in CONFIG_IDS if not i.startswith("f32")])
+@pytest.mark.parametrize("name,mode", [("tsp50_b64_greedy", "greedy"), ("cvrp100_b64_greedy", "greedy"), ("tsp100_b64_sampling", "sampling"),
+                                       ("pdp50_b64_sampling", "sampling"), ("cvrptw50_b64_sampling", "sampling")])
+def test_16bit_context_tables_equal_their_widened_fp32_form(K, name, mode, dtype, variant):
+    """(r06) ctx_dtype: the folded context tables as 16-bit rows at the planes' stride (columns of the fused fold's output
+    matrix) — widened on load, so the rollout is bit for bit the rollout on fp32 tables that hold the same rounded values
+    (which the C oracle reproduces: the bit-exact gate covers the 16-bit tables through this equality)."""
+    if name not in manifest():
+        pytest.skip(f"no golden {name}")
+    g = GoldenCase(name)
+    _skip_if_unservable(g, dtype, variant)
+    td0, h = _encode(g)
+    kw = {}
+    if mode == "sampling":
+        kw = dict(philox_seed=1234, philox_offset=7)
+    wide = _run(K, "hip", g, td0, h, mode, dtype, variant=variant, cache_hook=lambda c: _ctx_rounded(c, dtype), **kw)
+    cols = _run(K, "hip", g, td0, h, mode, dtype, variant=variant, cache_hook=lambda c: _ctx_as_columns(c, dtype), **kw)
+    _assert_bit_exact(cols, wide)
+    if mode == "greedy":  # and the widened form against the specified-order oracle
+        _assert_bit_exact(wide, _run(K, "c", g, td0, h, mode, dtype, variant=variant, cache_hook=lambda c: _ctx_rounded(c, dtype)))
 
 
 @pytest.mark.parametrize("dtype,variant", CONFIGS, ids=CONFIG_IDS)

@@ -93,6 +93,29 @@ def test_ms_greedy_consistent_with_streaming_kernel(K, name, starts):
           f"max |dlogp| {float((l_ms - l_ev).abs().max()):.4f}")
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("name,starts,mode", [("pomo_tsp50_b8_mssampling", 8, "sampling"), ("c4_pomo_tsp100_b32_s8_sampling", 8, "sampling"),
+                                              ("pomo_cvrp20_b16_msgreedy", 20, "greedy"), ("pomo_tsp20_b16_msgreedy", 20, "greedy")])
+def test_ms_16bit_context_tables_equal_their_widened_fp32_form(K, name, starts, mode, dtype):
+    """(r06) ctx_dtype in the multistart kernel: context rows in the planes' 16-bit type at the row stride of the fused
+    fold's [B, N, 5 * 128] matrix — widened on load, so actions and log-probs are bit for bit those of fp32 tables holding
+    the same rounded values."""
+    from tests.test_gpu_decode import _ctx_as_columns, _ctx_rounded
+
+    g = GoldenCase(name)
+    td0 = g.reset()
+    with torch.inference_mode():
+        h, _ = g.policy.encoder(td0)
+    cache = fold_cache(g.policy, g.env_name, h, dtype, device="cuda")
+    kw = dict(philox_seed=77) if mode == "sampling" else {}
+    a1, l1, st1, e1, _ = _rollout(K, g, td0, _ctx_rounded(cache, dtype), starts, "ms", mode=mode, **kw)
+    a2, l2, st2, e2, _ = _rollout(K, g, td0, _ctx_as_columns(cache, dtype), starts, "ms", mode=mode, **kw)
+    assert e1 == 0 and e2 == 0 and torch.equal(a1, a2)
+    assert torch.equal(l1.view(torch.int32), l2.view(torch.int32))
+    for k in st1:
+        assert torch.equal(st1[k], st2[k]), k
+
+
 @pytest.mark.parametrize("name,starts", [("pomo_tsp50_b8_mssampling", 8), ("pomo_cvrp20_b16_msgreedy", 6)])
 def test_ms_sampling_valid_and_consistent(K, name, starts):
     g = GoldenCase(name)

@@ -289,24 +289,28 @@ def test_fused_attention_backward_stays_finite_when_every_score_is_far_below_zer
 @pytest.mark.parametrize("n", [40, 100, 119])
 def test_fused_attention_backward_f16_large_dout_no_nan_from_the_padding_keys(n):
     """ fp16 with a loss-scaled d out: the key rows past N must carry P = 0 AND dS = 0. Left unmasked their
-    dS = -D P_pad (P_pad = 1 once the log-sum-exp is <= 0) overflows fp16 where no valid key's dS = P (dP - D), P ~ 1 / N,
-    does — and inf x 0 against the zeroed k rows is a NaN in d q for every query of the head."""
+    dS = -D P_pad (P_pad = 1 once the log-sum-exp is <= 0) overflows fp16 where no valid key's dS = P (dP - D), P = 1 / N,
+    does — and inf x 0 against the zeroed k rows is a NaN in d q for every query of the head. The case: every node carries
+    the same key (uniform attention, scores far below zero so the log-sum-exp is negative), values 1 + noise, d out ~ 6000:
+    D = sum_d dO O ~ 16 x 6000 overflows fp16, every true gradient (d v = mean d out, d q, d k ~ noise) is small."""
     from rl4co_amd import train_ops
 
     torch.manual_seed(100 + n)
     b = 8
     qkv = torch.randn(b, n, 384, device="cuda")
     qkv[..., :128] = 3.0 * qkv[..., :128].abs()
-    qkv[..., 128:256] = -3.0 * qkv[..., 128:256].abs()
-    qkv[..., 256:] = 1.0 + 0.1 * qkv[..., 256:]  # O ~ 1 in every dim, so D = sum_d dO O is of d out's own size x 16
+    qkv[..., 128:256] = (-3.0 * qkv[:, :1, 128:256].abs()).expand(b, n, 128)
+    qkv[..., 256:] = 1.0 + 0.01 * qkv[..., 256:]
     qk = qkv.half().requires_grad_(True)
-    go = (20000.0 + 2000.0 * torch.randn(b, n, 128, device="cuda")).half()  # ~ a GradScaler at 2^14 .. 2^15
+    go = (6000.0 + 600.0 * torch.randn(b, n, 128, device="cuda")).half()
     out = train_ops.attention(qk)
     (gk,) = torch.autograd.grad(out, [qk], go)
     assert torch.isfinite(out.float()).all()
     assert not torch.isnan(gk.float()).any(), "NaN in the attention backward (padding keys leaked an overflow into d q)"
-    # d q and d k are differences of near-equal terms here and stay small; d v = P^T dO is of d out's size and must be finite
-    assert torch.isfinite(gk[..., 256:].float()).all() and float(gk[..., 256:].float().abs().max()) > 0.0
+    assert torch.isfinite(gk.float()).all()
+    dv = gk[..., 256:].float()
+    want = go.float().mean(dim=1, keepdim=True).expand_as(dv)  # uniform attention: d v_j = mean over the queries of d out
+    assert float((dv - want).abs().max()) <= 0.02 * 6000.0
 
 
 def _pomo_policy(seed=0, fused=True, normalization="instance", graph_context=False, env_name="tsp", dt=torch.bfloat16):

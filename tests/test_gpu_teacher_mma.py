@@ -100,6 +100,51 @@ def test_mma_fp16_build_matches_replay_on_fp16_planes(name, starts):
     _compare(got)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("name,starts", [("tsp50_b64_greedy", 0), ("c4_pomo_tsp100_b32_s8_sampling", 8), ("pomo_tsp20_b16_msgreedy", 5),
+                                         ("cvrp100_b64_greedy", 0), ("pomo_cvrp20_b16_msgreedy", 4), ("pdp50_b64_sampling", 0)])
+def test_mma_16bit_context_tables_and_gradients_in_the_planes_matrix(name, starts, dtype):
+    """(r06) ctx_dtype + d_ctx_in_planes: the context tables read as 16-bit rows at the stride of the fused fold's
+    [B, N, nblk * 128] matrix, their gradients written (converted) as planes 3 / 4 of the gradient matrix — against the
+    same launch on fp32 tables holding the same rounded values: plane gradients bit-identical (register sums, fixed order),
+    context-table gradients equal up to the 16-bit rounding of the output (their fp32 sums are built by L2 atomics)."""
+    import dataclasses
+
+    from rl4co_amd import teacher
+
+    got = _capture(name, starts, cache_dtype=dtype)
+    cache = got["cache"]
+    tsp = cache.env_name == "tsp"
+    nblk = 5 if tsp else 4
+    b, n = cache.num_instances, cache.num_nodes
+    big = torch.zeros(b, n, nblk, 128, dtype=dtype, device="cuda")
+    big[:, :, :3] = cache.kvl.permute(1, 2, 0, 3)
+    big[:, :, nblk - 1] = cache.ctx_cur.to(dtype)
+    if tsp:
+        big[:, :, 3] = cache.ctx_first.to(dtype)
+    wide = dataclasses.replace(cache, ctx_cur=cache.ctx_cur.to(dtype).float(),
+                               ctx_first=cache.ctx_first.to(dtype).float() if tsp else None)
+    cols = dataclasses.replace(cache, kvl=big.permute(2, 0, 1, 3)[:3], ctx_cur=big[:, :, nblk - 1], ctx_first=big[:, :, 3] if tsp else None)
+    torch.manual_seed(3)
+    grad = torch.randn(got["actions"].shape, device="cuda")
+    dp_a = torch.zeros(b, n, 3, 128, dtype=dtype, device="cuda")
+    dp_b = torch.full((b, n, nblk, 128), float("nan"), dtype=dtype, device="cuda")
+    out_a = teacher.run_backward(wide, got["actions"], grad, got["meta"], variant="mma", want_logp=True, d_planes=dp_a.permute(2, 0, 1, 3))
+    out_b = teacher.run_backward(cols, got["actions"], grad, got["meta"], variant="mma", want_logp=True, d_planes=dp_b.permute(2, 0, 1, 3))
+    assert int(out_a["err"]) == 0 and int(out_b["err"]) == 0
+    assert torch.equal(out_a["logp"], out_b["logp"])
+    assert torch.equal(dp_a.view(torch.int16), dp_b[:, :, :3].contiguous().view(torch.int16))
+    ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    want_cur = out_a["d_ctx_cur"]
+    torch.testing.assert_close(dp_b[:, :, nblk - 1].float(), want_cur, rtol=2 * ulp, atol=1e-6 * float(want_cur.abs().max()) + 1e-30)
+    if tsp:
+        want_first = out_a["d_ctx_first"]
+        torch.testing.assert_close(dp_b[:, :, 3].float(), want_first, rtol=2 * ulp, atol=1e-6 * float(want_first.abs().max()) + 1e-30)
+    for k in ("d_q_bias", "d_extra"):
+        if out_a[k] is not None:
+            torch.testing.assert_close(out_b[k], out_a[k], rtol=1e-5, atol=1e-6 * float(out_a[k].abs().max()))
+
+
 def test_auto_picks_mma_for_bf16_and_replay_for_f32():
     from rl4co_amd import teacher
 

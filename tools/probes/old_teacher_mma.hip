@@ -81,23 +81,28 @@ __device__ inline float rg_max(float v) { return rl4co::bfly_max<16, 64>(v); }
 // across the sixteen steps of a row group (lane bits 0..3)
 __device__ inline float step_sum(float v) { return rl4co::bfly_sum<1, 16>(v); }
 
+// d ctx_cur[cur] += dq, four dims of one row. The table rows of an instance are touched by ITS workgroup only, a wave
+// (head) owns its 16 columns and a lane its step: the only possible collision is one node being the current node of
+// two steps. In the TSP every node is left exactly once per trajectory, so the sum is a plain read-modify-write whose
+// read went out a stage earlier (`old` already folded into `v`); the depot environments revisit node 0 and keep the
+// fp32 L2 atomics. 2048 scattered lane-atomics per step block held every wave's first stage for ~2 K cycles
+// (tools/teacher_clock_probe.py)
+template <int ENV>
+__device__ inline void scatter_row(float* row, const float (&v)[4]) {
+  if (ENV == RL4CO_ENV_TSP) {
+    *reinterpret_cast<float4*>(row) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(row + e, v[e]);
+  }
+}
+
 struct Layout {  // byte offsets into dynamic LDS
-  int kgs, vs, kls, ob, dub, qb, pb, scol, sstep, sg, srem, stime, smask, sraw, spos, xz, xa, sinfo, nact, ng;
-  int mc, npre, total;
+  int kgs, vs, kls, ob, dub, qb, pb, sact, srem, stime, sg, smask, spos, sval, xz, xa, sinfo, nact, ng, total;
 };
-// PACKED COLUMNS (r06). A trajectory used to run in step blocks of its own: at TSP-100 seven blocks, the last one with 4 of
-// its 16 columns alive, and column 0 (the imposed multistart node, gradient 0) always dead — 56 blocks per instance for 792
-// live steps. Every column of a block is independent of the others (own mask, own query, own upstream gradient), so the LIVE
-// columns t0 <= t < t_end of a GROUP of consecutive trajectories are now laid side by side in one column table of `mc`
-// entries and walked in blocks of 16: 50 blocks at TSP-100 x 8 starts, one table set-up per group instead of per trajectory.
-// What a column needs of its trajectory travels with it: action, current node, first node, step index, trajectory slot.
-__host__ __device__ inline Layout make_layout(int nt, int env) {
+__host__ __device__ inline Layout make_layout(int nt) {
   Layout L;
   const int plane = nt * 16 * kRS * 2, blk = 16 * kRS * 2;
-  L.mc = nt <= 7 ? 416 : kMaxT;   // packed columns per group (a multiple of 16; >= kMaxT so that one trajectory always fits)
-  L.npre = nt <= 7 ? 512 : 0;     // raw columns (actions, upstream gradients) fetched one group ahead; 0: read in place
-  const int mcp = L.mc + 16;      // + one block: a block's look-ahead reads (next current / first node) stay inside the tables
-  const bool scalar = env != RL4CO_ENV_TSP && env != RL4CO_ENV_PDP;
   int o = 0;
   L.kgs = o; o += plane;
   L.vs = o; o += plane;
@@ -106,41 +111,23 @@ __host__ __device__ inline Layout make_layout(int nt, int env) {
   L.dub = o; o += blk;
   L.qb = o; o += blk;
   L.pb = o; o += kWaves * blk;
-  // one word per packed column — byte 0 action | byte 1 current node (the previous action of its trajectory; 0 at step 0) |
-  // byte 2 first node of its trajectory (TSP: the row of ctx_first) | byte 3 flags: bit 0 valid, bit 1 step 0, bits 2-6
-  // trajectory slot inside the group, bit 7 "late" (stage 5). ONE ds_read_b32 per block and lane (and one for the look-ahead);
-  // as five byte tables every field cost its own address add, read and mask on a VALU-issue-bound chain
-  L.scol = o; o += mcp * 4;
-  L.sstep = o; o += mcp;   // step index inside its trajectory (read by the one lane that writes logp_out)
-  o = (o + 3) & ~3;
-  L.sg = o; o += mcp * 4;
-  L.srem = o; o += scalar ? mcp * 4 : 0;
-  L.stime = o; o += env == RL4CO_ENV_CVRPTW ? mcp * 4 : 0;
-  o = (o + 15) & ~15;
-  L.smask = o; o += mcp * 16;
-  L.sraw = o; o += kMaxT;       // the trajectory under set-up: its T actions
-  L.spos = o; o += 128 * 4;     // ... and the first column that visits node j
+  L.sact = o; o += kMaxT * 4;
+  L.srem = o; o += kMaxT * 4;
+  L.stime = o; o += kMaxT * 4;
+  L.sg = o; o += kMaxT * 4;
+  L.smask = o; o += kMaxT * 16;
+  L.spos = o; o += 128 * 4;
   L.xz = o; o += kWaves * 16 * 2 * 4;
   L.xa = o; o += 16 * 4;
   L.sinfo = o; o += 16;
-  L.nact = o; o += L.npre;      // the NEXT group's actions (bytes; 255 = out of range) and
-  L.ng = o; o += L.npre * 4;    // upstream gradients, fetched under this group's set-up
+  L.sval = o; o += kMaxT;
+  L.nact = o; o += kMaxT;      // the NEXT trajectory's actions (bytes; 255 = out of range) and
+  L.ng = o; o += kMaxT * 4;    // upstream gradients, fetched under this trajectory's set-up
   L.total = (o + 15) & ~15;
   return L;
 }
 
-// four consecutive fp32 values through L2 (agent scope: the CU's L1 is bypassed). The context-row sums are accumulated by
-// plain read-modify-write AND (blocks that hold two trajectories, the final flush) by L2 atomics: an L1 line filled before
-// an atomic landed would serve a stale row.
-__device__ inline float4 load4_l2(const float* p) {
-  float4 v;
-  v.x = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  v.y = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  v.z = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  v.w = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return v;
-}
-template <int ENV, int NT, bool CTX16>
+template <int ENV, int NT>
 __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co_am_teacher_args a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -148,10 +135,11 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
   const int h = w;  // attention stages: wave = head; logits stage: wave = node tile
   const int inst = blockIdx.x;
   const int N = a.N, T = a.T, S = a.B / a.B_inst;
+  const int tpad = min(kMaxT, (T + 15) & ~15);  // columns the step blocks read
   // the second-dispatched half of an 8-wave workgroup loses the issue arbitration on every segment
   // (older wave first); a static priority for it evens the halves out between the barriers
   if (w >= 4) __builtin_amdgcn_s_setprio(1);
-  const Layout L = make_layout(NT, ENV);  // NT node tiles of 16 (template): rows N .. 16 NT - 1 are zero
+  const Layout L = make_layout(NT);  // NT node tiles of 16 (template): rows N .. 16 NT - 1 are zero
   elem_t* kgs = reinterpret_cast<elem_t*>(smem + L.kgs);
   elem_t* vs = reinterpret_cast<elem_t*>(smem + L.vs);
   elem_t* kls = reinterpret_cast<elem_t*>(smem + L.kls);
@@ -163,14 +151,13 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
   // column strips, ordered by program order within the wave. 4 KB that let eight node tiles (N <= 128) fit in 160 KB
   elem_t* dob = ob;
   elem_t* pbw = reinterpret_cast<elem_t*>(smem + L.pb) + w * 16 * kRS;  // this wave's [16 steps][kRS] P, then dS
-  uint32_t* scol = reinterpret_cast<uint32_t*>(smem + L.scol);
-  uint8_t* sstep = smem + L.sstep;
-  float* sg = reinterpret_cast<float*>(smem + L.sg);
+  int* sact = reinterpret_cast<int*>(smem + L.sact);
   float* srem = reinterpret_cast<float*>(smem + L.srem);
   float* stime = reinterpret_cast<float*>(smem + L.stime);  // CVRPTW: the clock before each column
+  float* sg = reinterpret_cast<float*>(smem + L.sg);
   uint32_t* smask = reinterpret_cast<uint32_t*>(smem + L.smask);
-  uint8_t* sraw = smem + L.sraw;
   int* spos = reinterpret_cast<int*>(smem + L.spos);
+  uint8_t* sval = smem + L.sval;
   uint8_t* snact = smem + L.nact;
   float* sng = reinterpret_cast<float*>(smem + L.ng);
   float* xz = reinterpret_cast<float*>(smem + L.xz);
@@ -209,26 +196,10 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
 #pragma unroll
   for (int k = 0; k < 4; ++k) nv[k] = (N >= 32 * (k + 1)) ? 0xffffffffu : (N > 32 * k ? ((1u << (N - 32 * k)) - 1u) : 0u);
 
-  // context tables: fp32 [B_inst,N,128] or (CTX16: ctx_dtype = the planes' 16-bit type) with the caller's strides. The row
-  // type is a template parameter: chosen at run time each of the two fetches per block paid a dozen selects (elem16.h
-  // load_ctx4, which the multistart rollout keeps: its compile time forbids doubling its instantiations)
-  constexpr uint32_t ctx_esz = CTX16 ? 2 : 4;
-  const uint32_t ctx_rs = (uint32_t)(a.ctx_row_stride ? a.ctx_row_stride : kD) * ctx_esz;  // bytes between node rows (< 2^16)
-  const int64_t ctx_bs = a.ctx_batch_stride ? a.ctx_batch_stride : (int64_t)N * kD;
-  const char* ctxc = static_cast<const char*>(a.ctx_cur) + ((int64_t)inst * ctx_bs + dcol) * ctx_esz;
-  const char* ctxf = (ENV == RL4CO_ENV_TSP) ? static_cast<const char*>(a.ctx_first) + ((int64_t)inst * ctx_bs + dcol) * ctx_esz : nullptr;
-  auto ctx_row = [&](const char* table, uint32_t node) -> float4 {  // four dims of a row (node < 128: a 32-bit offset)
-    const char* p = table + node * ctx_rs;
-    if constexpr (CTX16) {
-      const uint2 u = *reinterpret_cast<const uint2*>(p);
-      return make_float4(rl4co_e16::lo(u.x), rl4co_e16::hi(u.x), rl4co_e16::lo(u.y), rl4co_e16::hi(u.y));
-    } else {
-      return *reinterpret_cast<const float4*>(p);
-    }
-  };
+  const float* ctxc = static_cast<const float*>(a.ctx_cur) + (int64_t)inst * N * kD + dcol;
+  const float* ctxf = (ENV == RL4CO_ENV_TSP) ? static_cast<const float*>(a.ctx_first) + (int64_t)inst * N * kD + dcol : nullptr;
   constexpr bool kCvrpLike = ENV == RL4CO_ENV_CVRP || ENV == RL4CO_ENV_CVRPTW;
   constexpr bool kClock = ENV == RL4CO_ENV_CVRPTW;
-  constexpr bool kScalar = ENV != RL4CO_ENV_TSP && ENV != RL4CO_ENV_PDP;  // one context scalar: cap - used (PDP: none, context.py:232-243)
   const float* twl = kClock ? a.locs + (int64_t)inst * N * 2 : nullptr;          // coordinates
   const float* tww = kClock ? a.time_windows + (int64_t)inst * N * 2 : nullptr;  // (start, end) per node
   const float* twd = kClock ? a.durations + (int64_t)inst * N : nullptr;         // service times
@@ -261,383 +232,262 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
     dkl[jt] = zero4();
   }
   float dqb[4] = {0.f, 0.f, 0.f, 0.f}, dqx[4] = {0.f, 0.f, 0.f, 0.f}, dqt[4] = {0.f, 0.f, 0.f, 0.f};
-  // d ctx_first (TSP): a lane sums the d query of its columns for as long as they belong to trajectories with the same
-  // first node and hands the sum to that row (L2 atomics) when the first node of its column changes, and at the end
-  float dqf[4] = {0.f, 0.f, 0.f, 0.f};
-  int my_first = -1;
-  float* dcf = (ENV == RL4CO_ENV_TSP) ? a.d_ctx_first + (int64_t)inst * N * kD + dcol : nullptr;
   uint32_t errbits = 0;
 
-  // trajectories per group: every live column of the group fits the tables, every raw column the one-group-ahead fetch;
-  // a block never holds more than two trajectories (the TSP context-row scatter relies on it: see stage 5)
-  const int t0c = min(a.t0, T);
-  const int live_max = max(1, T - t0c);
-  int G = max(1, L.mc / live_max);
-  if (L.npre > 0) G = max(1, min(G, L.npre / T));
-  G = min(G, 31);
-  if (live_max < 16) G = 1;
-#ifdef RL4CO_TEACHER_NOPACK  // timing probe: one trajectory per group, as before r06
-  G = 1;
-#endif
-
-  // actions / upstream gradients of a group are fetched one group AHEAD (thread i owns raw column i of the group's
-  // [trajectory][T] block), so a group's set-up never opens with an HBM round trip
+  // actions / upstream gradients of a trajectory are fetched one trajectory AHEAD (thread t < kMaxT owns column t), so
+  // the set-up of a trajectory never opens with an HBM round trip
+  static_assert(kThreads >= kMaxT, "one thread per table column");
   int an = 0;
   float gn = 0.0f;
-  auto fetch_group = [&](int s_first) {
+  if (tid < T) {
+    an = (int)a.actions[(int64_t)inst * T + tid];
+    gn = a.grad_logp[(int64_t)inst * T + tid];
+  }
+  if (tid < kMaxT) {
+    snact[tid] = (an < 0 || an >= N) ? 255 : an;
+    sng[tid] = gn;
+  }
+
+  for (int s = 0; s < S; ++s) {
+    const int r = s * a.B_inst + inst;
+    __syncthreads();  // the previous trajectory's tables are no longer read; the fetched columns are complete
+
+    // ---- step tables of this trajectory (the environment replayed in closed form) -------------------
+    // sact[t]: action; spos[j]: first column that visits node j (tsp/env.py:60-86, cvrp/env.py:66-96)
+    if (tid < kMaxT) {
+      int at = snact[tid];
+      if (at == 255) {
+        errbits |= RL4CO_EBIT_INFEASIBLE;
+        at = 0;
+      }
+      sact[tid] = at;
+    }
     an = 0;
     gn = 0.0f;
-    const int cnt = min(G, S - s_first) * T;
-    if (L.npre > 0 && s_first < S && tid < cnt) {
-      const int k = tid / T, t = tid - k * T;
-      const int64_t idx = (int64_t)((s_first + k) * a.B_inst + inst) * T + t;
-      an = (int)a.actions[idx];
-      gn = a.grad_logp[idx];
+    if (s + 1 < S && tid < T) {  // in flight under the set-up below, staged after its last barrier
+      an = (int)a.actions[(int64_t)(r + a.B_inst) * T + tid];
+      gn = a.grad_logp[(int64_t)(r + a.B_inst) * T + tid];
     }
-  };
-  auto stage_group = [&]() {
-    if (L.npre > 0 && tid < L.npre) {
+    for (int j = tid; j < 128; j += kThreads) spos[j] = 0x7fffffff;
+    __syncthreads();
+    // the two context fetches that open the first step block leave now, under the rest of the set-up
+    const int first = sact[0];
+    float f4[4] = {0.f, 0.f, 0.f, 0.f}, dqf[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ENV == RL4CO_ENV_TSP) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) f4[e] = ctxf[(int64_t)first * kD + e];
+    }
+    // context row of this lane's step, fetched one step block ahead (an L2 round trip otherwise
+    // opens every block's dependency chain)
+    float4 c4n = *reinterpret_cast<const float4*>(ctxc + (int64_t)(tl == 0 ? 0 : sact[tl - 1]) * kD);
+    for (int t = tid; t < T; t += kThreads) atomicMin(&spos[sact[t]], t);
+    __syncthreads();
+    if (tid == 0) {
+      int t_end = T;
+      if (kCvrpLike) {  // done once every node (depot included) has been visited (cvrp/env.py:80-83)
+        int last = 0;
+        for (int j = 0; j < N; ++j) last = max(last, spos[j]);
+        if (last != 0x7fffffff) t_end = min(T, last + 1);
+      }
+      if (ENV == RL4CO_ENV_OP || ENV == RL4CO_ENV_PCTSP) {  // done at the first return to the depot after step 0 (op/env.py:84, pctsp/env.py:73)
+        for (int t = 1; t < T; ++t)
+          if (sact[t] == 0) {
+            t_end = t + 1;
+            break;
+          }
+      }
+      sinfo[0] = t_end;
+    }
+    if (kClock) {
+      // the clock BEFORE column t, replayed in visiting order: advance by the distance, wait for the window, serve;
+      // back at the depot it restarts (cvrptw/env.py:97-113, same fp32 sequence as the decode kernel)
+      for (int t = tid; t < tpad; t += kThreads) {
+        float now = 0.0f;
+        int prev = 0;
+        for (int v = 0; v < min(t, T); ++v) {
+          const int nx = sact[v];
+          const float dx = twl[2 * nx] - twl[2 * prev], dy = twl[2 * nx + 1] - twl[2 * prev + 1];
+          now = (nx != 0 ? 1.0f : 0.0f) * (fmaxf(now + sqrtf(fmaf(dy, dy, dx * dx)), tww[2 * nx]) + twd[nx]);
+          prev = nx;
+        }
+        stime[t] = now;
+      }
+    }
+    if (kCvrpLike) {
+      // used capacity BEFORE column t: the loads since the last depot visit, summed in visiting
+      // order from zero — the same fp32 sequence as used = (used + demand) * (action != 0)
+      for (int t = tid; t < tpad; t += kThreads) {
+        int u = min(t, T) - 1;
+        while (u >= 0 && sact[u] != 0) --u;
+        float used = 0.0f;
+        for (int v = u + 1; v < min(t, T); ++v) used = used + dem[min(max(sact[v] - 1, 0), N - 2)];
+        srem[t] = used;
+      }
+    }
+    if (ENV == RL4CO_ENV_OP) {
+      // tour length BEFORE column t, accumulated in visiting order like tour += |loc_a - loc_cur|
+      for (int t = tid; t < tpad; t += kThreads) {
+        float used = 0.0f;
+        int prev = 0;
+        for (int v = 0; v < min(t, T); ++v) {
+          const int nx = sact[v];
+          const float dx = oplocs[2 * nx] - oplocs[2 * prev], dy = oplocs[2 * nx + 1] - oplocs[2 * prev + 1];
+          used = used + sqrtf(fmaf(dy, dy, dx * dx));
+          prev = nx;
+        }
+        srem[t] = used;
+      }
+    }
+    if (ENV == RL4CO_ENV_PDP) {  // no context scalar (context.py:232-243)
+      for (int t = tid; t < tpad; t += kThreads) srem[t] = 0.0f;
+    }
+    if (ENV == RL4CO_ENV_PCTSP) {
+      // prize collected BEFORE column t, accumulated in visiting order like prize += real_prize[a]
+      for (int t = tid; t < tpad; t += kThreads) {
+        float used = 0.0f;
+        for (int v = 0; v < min(t, T); ++v) used = used + dem[sact[v]];
+        srem[t] = used;
+      }
+    }
+    __syncthreads();
+    const int t_end = sinfo[0];
+    if (ENV == RL4CO_ENV_TSP) {
+      // feasibility words of a column in two ballots: wave w takes columns w, w + 8, ..; lane = node (and node + 64);
+      // node j is feasible at column t until it has been visited, spos[j] >= t
+      const int p0 = (lane < N) ? spos[lane] : -1, p1 = (lane + 64 < N) ? spos[lane + 64] : -1;
+      for (int t = w; t < tpad; t += kWaves) {
+        const unsigned long long b0 = __ballot(p0 >= t), b1 = __ballot(p1 >= t);
+        if (lane == 0)
+          *reinterpret_cast<uint4*>(smask + 4 * t) = (t < t_end) ? make_uint4((uint32_t)b0, (uint32_t)(b0 >> 32), (uint32_t)b1, (uint32_t)(b1 >> 32))
+                                                                 : make_uint4(1u, 0u, 0u, 0u);
+      }
+    }
+    // feasibility words: thread (t, k) builds word k of column t
+    for (int idx = tid; ENV != RL4CO_ENV_TSP && idx < tpad * 4; idx += kThreads) {
+      const int t = idx >> 2, k = idx & 3;
+      const bool live = t < t_end;
+      uint32_t word = 0;
+      if (ENV == RL4CO_ENV_TSP) {
+        for (int b = 0; b < 32; ++b) {
+          const int j = 32 * k + b;
+          if (j < N && spos[j] >= t) word |= 1u << b;
+        }
+      } else if (ENV == RL4CO_ENV_OP) {
+        // op/env.py:137-154: unvisited, depot not yet closed, and the node can still be entered
+        const float used = srem[t];
+        const int cur = (t == 0) ? 0 : sact[t - 1];
+        const float cx = oplocs[2 * cur], cy = oplocs[2 * cur + 1];
+        const bool depot_visited = spos[0] < t;
+        for (int b = 0; b < 32; ++b) {
+          const int j = 32 * k + b;
+          if (j < N) {
+            const float dx = oplocs[2 * j] - cx, dy = oplocs[2 * j + 1] - cy;
+            const bool exceeds = used + sqrtf(fmaf(dy, dy, dx * dx)) > opmax[j];
+            if (j == 0 || !(spos[j] < t || depot_visited || exceeds)) word |= 1u << b;
+          }
+        }
+      } else if (ENV == RL4CO_ENV_PDP) {
+        // pdp/env.py:64-99: unvisited, a delivery only once its pickup is on the tour; the depot only as the
+        // forced first step of force_start_at_depot (recognised by the trajectory starting at node 0)
+        const int half = (N - 1) / 2;
+        for (int b = 0; b < 32; ++b) {
+          const int j = 32 * k + b;
+          if (j >= 1 && j < N && spos[j] >= t && (j <= half || spos[j - half] < t)) word |= 1u << b;
+        }
+        if (t == 0 && sact[0] == 0) word = (k == 0) ? 1u : 0u;
+      } else if (ENV == RL4CO_ENV_PCTSP) {
+        // pctsp/env.py:141-148: customers while unvisited and the depot not yet closed; the depot opens
+        // once a total prize of 1 is collected or no customer is left
+        const bool depot_visited = spos[0] < t;
+        uint32_t left = 0;
+        for (int b = 0; b < 32; ++b) {
+          const int j = 32 * k + b;
+          if (j >= 1 && j < N && spos[j] >= t) left |= 1u << b;
+        }
+        word = depot_visited ? 0u : left;
+        left |= rl4co::bfly_i<1>((int)left);
+        left |= rl4co::bfly_i<2>((int)left);
+        if (k == 0 && !((srem[t] < 1.0f) && left != 0u)) word |= 1u;
+      } else {
+        const float used = srem[t];
+        for (int b = 0; b < 32; ++b) {
+          const int j = 32 * k + b;
+          if (j >= 1 && j < N && spos[j] >= t && !(dem[j - 1] + used > thr)) word |= 1u << b;
+        }
+        // depot: infeasible only while standing on it with a customer still feasible (cvrp/env.py:126-136)
+        uint32_t any = word;
+        any |= rl4co::bfly_i<1>((int)any);
+        any |= rl4co::bfly_i<2>((int)any);
+        const int cur = (t == 0) ? 0 : sact[t - 1];
+        if (k == 0 && !((cur == 0) && any != 0u)) word |= 1u;
+        if (kClock) {  // cvrptw/env.py:91-95: only nodes whose window is still open on arrival (the depot too)
+          const float now = stime[t], cx = twl[2 * cur], cy = twl[2 * cur + 1];
+          for (int b = 0; b < 32; ++b) {
+            const int j = 32 * k + b;
+            if ((word >> b) & 1u) {
+              const float dx = twl[2 * j] - cx, dy = twl[2 * j + 1] - cy;
+              if (!(now + sqrtf(fmaf(dy, dy, dx * dx)) <= tww[2 * j + 1])) word &= ~(1u << b);
+            }
+          }
+        }
+      }
+      smask[idx] = live ? word : (k == 0 ? 1u : 0u);  // dead columns: a finite dummy (node 0 only), gradient 0
+    }
+    for (int t = tid; t < tpad; t += kThreads) {
+      const bool valid = t >= a.t0 && t < t_end;
+      sval[t] = valid ? 1 : 0;
+      sg[t] = valid ? sng[t] : 0.0f;
+    }
+    __syncthreads();
+    if (tid < kMaxT) {
       snact[tid] = (an < 0 || an >= N) ? 255 : an;
       sng[tid] = gn;
     }
-  };
-  // d ctx_cur[cur] += dq. The table rows of an instance are touched by ITS workgroup only, a wave (head) owns its 16
-  // columns and a lane its column. Depot environments (node 0 is revisited): fp32 L2 atomics. TSP: every node is left
-  // exactly once per trajectory, so among the columns of ONE trajectory the sum is a plain read-modify-write whose read
-  // went out a stage earlier; a block can hold columns of a second trajectory (packed columns), and a column of it that
-  // leaves the same node as an earlier column of the block ("late", found at set-up: ~0.5 per two-trajectory block) does
-  // its read-modify-write AFTER the others' stores have been acknowledged. (First r06 build: L2 atomics for every column
-  // of such a block — a third of all blocks; 2048 lane-atomics per block cost 0.9 ms of the launch, all-atomic 3.6 ms.)
-  // Either way the scatter of a block leaves at the top of the NEXT one, behind its context fetch: vmcnt is one in-order
-  // counter, issued at the end of their own block the stores stalled each block's first stage (tools/teacher_clock_probe.py).
-  auto scatter_pending = [&](const float (&pend)[4], int& pend_cur, bool pend_late) {
-    const bool have = pend_cur >= 0;
-    if (have && !(ENV == RL4CO_ENV_TSP && pend_late)) {
-      float* row = dcc + (int64_t)pend_cur * kD + dcol;
-      if (ENV == RL4CO_ENV_TSP) {
-        *reinterpret_cast<float4*>(row) = make_float4(pend[0], pend[1], pend[2], pend[3]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(row + e, pend[e]);
-      }
-    }
-    if (ENV == RL4CO_ENV_TSP && __any(have && pend_late)) {
-      // the stores above are acknowledged by L2 before the late lanes read (a plain counter wait: an agent-scope release
-      // fence also issues buffer_wbl2, an L2 write-back this exchange inside one workgroup has no use for)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (have && pend_late) {
-        float* row = dcc + (int64_t)pend_cur * kD + dcol;
-        const float4 old = load4_l2(row);
-        *reinterpret_cast<float4*>(row) = make_float4(old.x + pend[0], old.y + pend[1], old.z + pend[2], old.w + pend[3]);
-      }
-    }
-    pend_cur = -1;
-  };
-  // d ctx_first (TSP): the lanes named by `give` hand their sums to the row of the first node they were summing for — the
-  // giving lanes of a row group have the same one (the trajectory their columns just left), so ONE sum over the group's 16
-  // lanes and one L2 atomic per dim; per-lane atomics only if that ever does not hold. Called by the whole wave.
-  // (First r06 build: four atomics per giving lane, sixteen lanes on the same address — 16 K contended lane-atomics per
-  // instance; together with the two-trajectory blocks' atomics the launch took 8.2 ms instead of 5.1.)
-  auto flush_first = [&](bool give_in) {
-    const bool give = give_in && my_first >= 0;
-    const int mine = give ? my_first : -1;
-    const int top = rl4co::bfly_i_max<1>(mine);  // (whole wave: every row group flushes the same trajectory)
-    const bool uniform_row = __all(!give || my_first == top);
-    const unsigned long long bal = __ballot(give);
-    const unsigned grp = (unsigned)(bal >> (16 * g)) & 0xffffu;
-    if (uniform_row) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float v = step_sum(give ? dqf[e] : 0.0f);
-        if (give && tl == __builtin_ctz(grp | 0x10000u)) unsafeAtomicAdd(dcf + (int64_t)my_first * kD + e, v);
-      }
-    } else if (give) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dcf + (int64_t)my_first * kD + e, dqf[e]);
-    }
-    if (give_in) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) dqf[e] = 0.0f;
-    }
-  };
-  fetch_group(0);
-  stage_group();
-
-  for (int s0 = 0; s0 < S; s0 += G) {
-    const int gsz = min(G, S - s0);
-    __syncthreads();  // the previous group's tables are no longer read; the fetched columns are complete
-    fetch_group(s0 + G);  // in flight under the set-up below, staged after its last barrier
-
-    // ---- column tables of this group (the environment of each trajectory replayed in closed form) -----------------
-    int base = 0;  // packed columns so far (identical in every thread)
-    for (int k = 0; k < gsz; ++k) {
-      const int r = (s0 + k) * a.B_inst + inst;
-      // sraw[t]: action; spos[j]: first column that visits node j (tsp/env.py:60-86, cvrp/env.py:66-96)
-      if (tid < kMaxT) {
-        int at = 0;
-        if (tid < T) {
-          if (L.npre > 0) {
-            at = snact[k * T + tid];
-          } else {
-            const int raw = (int)a.actions[(int64_t)r * T + tid];
-            at = (raw < 0 || raw >= N) ? 255 : raw;
-          }
-          if (at == 255) {
-            errbits |= RL4CO_EBIT_INFEASIBLE;
-            at = 0;
-          }
-        }
-        sraw[tid] = at;
-      }
-      for (int j = tid; j < 128; j += kThreads) spos[j] = 0x7fffffff;
-      __syncthreads();
-      for (int t = tid; t < T; t += kThreads) atomicMin(&spos[sraw[t]], t);
-      __syncthreads();
-      if (tid == 0) {
-        int t_end = T;
-        if (kCvrpLike) {  // done once every node (depot included) has been visited (cvrp/env.py:80-83)
-          int last = 0;
-          for (int j = 0; j < N; ++j) last = max(last, spos[j]);
-          if (last != 0x7fffffff) t_end = min(T, last + 1);
-        }
-        if (ENV == RL4CO_ENV_OP || ENV == RL4CO_ENV_PCTSP) {  // done at the first return to the depot after step 0 (op/env.py:84, pctsp/env.py:73)
-          for (int t = 1; t < T; ++t)
-            if (sraw[t] == 0) {
-              t_end = t + 1;
-              break;
-            }
-        }
-        sinfo[0] = t_end;
-      }
-      // per-column scalars BEFORE column t, written at the column's packed place base + t - t0 (columns past the
-      // trajectory's end land in the next trajectory's range and are overwritten by its own set-up / the dead fill)
-      if (kClock) {
-        // the clock, replayed in visiting order: advance by the distance, wait for the window, serve;
-        // back at the depot it restarts (cvrptw/env.py:97-113, same fp32 sequence as the decode kernel)
-        for (int t = t0c + tid; t < T; t += kThreads) {
-          float now = 0.0f;
-          int prev = 0;
-          for (int v = 0; v < t; ++v) {
-            const int nx = sraw[v];
-            const float dx = twl[2 * nx] - twl[2 * prev], dy = twl[2 * nx + 1] - twl[2 * prev + 1];
-            now = (nx != 0 ? 1.0f : 0.0f) * (fmaxf(now + sqrtf(fmaf(dy, dy, dx * dx)), tww[2 * nx]) + twd[nx]);
-            prev = nx;
-          }
-          stime[base + t - t0c] = now;
-        }
-      }
-      if (kCvrpLike) {
-        // used capacity: the loads since the last depot visit, summed in visiting
-        // order from zero — the same fp32 sequence as used = (used + demand) * (action != 0)
-        for (int t = t0c + tid; t < T; t += kThreads) {
-          int u = t - 1;
-          while (u >= 0 && sraw[u] != 0) --u;
-          float used = 0.0f;
-          for (int v = u + 1; v < t; ++v) used = used + dem[min(max((int)sraw[v] - 1, 0), N - 2)];
-          srem[base + t - t0c] = used;
-        }
-      }
-      if (ENV == RL4CO_ENV_OP) {
-        // tour length, accumulated in visiting order like tour += |loc_a - loc_cur|
-        for (int t = t0c + tid; t < T; t += kThreads) {
-          float used = 0.0f;
-          int prev = 0;
-          for (int v = 0; v < t; ++v) {
-            const int nx = sraw[v];
-            const float dx = oplocs[2 * nx] - oplocs[2 * prev], dy = oplocs[2 * nx + 1] - oplocs[2 * prev + 1];
-            used = used + sqrtf(fmaf(dy, dy, dx * dx));
-            prev = nx;
-          }
-          srem[base + t - t0c] = used;
-        }
-      }
-      if (ENV == RL4CO_ENV_PCTSP) {
-        // prize collected, accumulated in visiting order like prize += real_prize[a]
-        for (int t = t0c + tid; t < T; t += kThreads) {
-          float used = 0.0f;
-          for (int v = 0; v < t; ++v) used = used + dem[sraw[v]];
-          srem[base + t - t0c] = used;
-        }
-      }
-      __syncthreads();
-      const int t_end = sinfo[0];
-      const int live = max(0, t_end - t0c);
-      if (ENV == RL4CO_ENV_TSP) {
-        // feasibility words of a column in two ballots: wave w takes columns w, w + 8, ..; lane = node (and node + 64);
-        // node j is feasible at column t until it has been visited, spos[j] >= t
-        const int p0 = (lane < N) ? spos[lane] : -1, p1 = (lane + 64 < N) ? spos[lane + 64] : -1;
-        for (int t = t0c + w; t < t_end; t += kWaves) {
-          const unsigned long long b0 = __ballot(p0 >= t), b1 = __ballot(p1 >= t);
-          if (lane == 0)
-            *reinterpret_cast<uint4*>(smask + 4 * (base + t - t0c)) = make_uint4((uint32_t)b0, (uint32_t)(b0 >> 32), (uint32_t)b1, (uint32_t)(b1 >> 32));
-        }
-      }
-      // feasibility words: thread (t, kw) builds word kw of column t
-      for (int idx = tid; ENV != RL4CO_ENV_TSP && idx < live * 4; idx += kThreads) {
-        const int t = t0c + (idx >> 2), kw = idx & 3, col = base + (idx >> 2);
-        uint32_t word = 0;
-        if (ENV == RL4CO_ENV_OP) {
-          // op/env.py:137-154: unvisited, depot not yet closed, and the node can still be entered
-          const float used = srem[col];
-          const int cur = (t == 0) ? 0 : sraw[t - 1];
-          const float cx = oplocs[2 * cur], cy = oplocs[2 * cur + 1];
-          const bool depot_visited = spos[0] < t;
-          for (int b = 0; b < 32; ++b) {
-            const int j = 32 * kw + b;
-            if (j < N) {
-              const float dx = oplocs[2 * j] - cx, dy = oplocs[2 * j + 1] - cy;
-              const bool exceeds = used + sqrtf(fmaf(dy, dy, dx * dx)) > opmax[j];
-              if (j == 0 || !(spos[j] < t || depot_visited || exceeds)) word |= 1u << b;
-            }
-          }
-        } else if (ENV == RL4CO_ENV_PDP) {
-          // pdp/env.py:64-99: unvisited, a delivery only once its pickup is on the tour; the depot only as the
-          // forced first step of force_start_at_depot (recognised by the trajectory starting at node 0)
-          const int half = (N - 1) / 2;
-          for (int b = 0; b < 32; ++b) {
-            const int j = 32 * kw + b;
-            if (j >= 1 && j < N && spos[j] >= t && (j <= half || spos[j - half] < t)) word |= 1u << b;
-          }
-          if (t == 0 && sraw[0] == 0) word = (kw == 0) ? 1u : 0u;
-        } else if (ENV == RL4CO_ENV_PCTSP) {
-          // pctsp/env.py:141-148: customers while unvisited and the depot not yet closed; the depot opens
-          // once a total prize of 1 is collected or no customer is left
-          const bool depot_visited = spos[0] < t;
-          uint32_t left = 0;
-          for (int b = 0; b < 32; ++b) {
-            const int j = 32 * kw + b;
-            if (j >= 1 && j < N && spos[j] >= t) left |= 1u << b;
-          }
-          word = depot_visited ? 0u : left;
-          left |= rl4co::bfly_i<1>((int)left);
-          left |= rl4co::bfly_i<2>((int)left);
-          if (kw == 0 && !((srem[col] < 1.0f) && left != 0u)) word |= 1u;
-        } else {
-          const float used = srem[col];
-          for (int b = 0; b < 32; ++b) {
-            const int j = 32 * kw + b;
-            if (j >= 1 && j < N && spos[j] >= t && !(dem[j - 1] + used > thr)) word |= 1u << b;
-          }
-          // depot: infeasible only while standing on it with a customer still feasible (cvrp/env.py:126-136)
-          uint32_t any = word;
-          any |= rl4co::bfly_i<1>((int)any);
-          any |= rl4co::bfly_i<2>((int)any);
-          const int cur = (t == 0) ? 0 : sraw[t - 1];
-          if (kw == 0 && !((cur == 0) && any != 0u)) word |= 1u;
-          if (kClock) {  // cvrptw/env.py:91-95: only nodes whose window is still open on arrival (the depot too)
-            const float now = stime[col], cx = twl[2 * cur], cy = twl[2 * cur + 1];
-            for (int b = 0; b < 32; ++b) {
-              const int j = 32 * kw + b;
-              if ((word >> b) & 1u) {
-                const float dx = twl[2 * j] - cx, dy = twl[2 * j + 1] - cy;
-                if (!(now + sqrtf(fmaf(dy, dy, dx * dx)) <= tww[2 * j + 1])) word &= ~(1u << b);
-              }
-            }
-          }
-        }
-        smask[4 * col + kw] = word;
-      }
-      for (int i = tid; i < live; i += kThreads) {
-        const int t = t0c + i, col = base + i;
-        scol[col] = (uint32_t)sraw[t] | ((t == 0 ? 0u : (uint32_t)sraw[t - 1]) << 8) | ((uint32_t)sraw[0] << 16) |
-                    ((uint32_t)(1 | (t == 0 ? 2 : 0) | (k << 2)) << 24);
-        sstep[col] = (uint8_t)t;
-        sg[col] = L.npre > 0 ? sng[k * T + t] : a.grad_logp[(int64_t)r * T + t];
-      }
-      __syncthreads();  // sraw / spos / sinfo are rewritten by the next trajectory; the words and scalars are complete
-      base += live;
-    }
-    const int ncols = base;
-    const int ntb = (ncols + 15) >> 4;
-    // dead columns (the last block's tail and the look-ahead block behind it): a finite dummy (node 0 only), gradient 0
-    for (int col = ncols + tid; col < 16 * ntb + 16; col += kThreads) {
-      scol[col] = 0;
-      sstep[col] = 0;
-      sg[col] = 0.0f;
-      if (kScalar) srem[col] = 0.0f;
-      if (kClock) stime[col] = 0.0f;
-      *reinterpret_cast<uint4*>(smask + 4 * col) = make_uint4(1u, 0u, 0u, 0u);
-    }
-    if (kScalar) {  // srem: used -> remaining capacity / length (context.py:147-149, 211-213); the mask words are all built
-      for (int col = tid; col < ncols; col += kThreads) {
-        float rem = cap - srem[col];
+    if (ENV != RL4CO_ENV_TSP) {  // srem: used -> remaining capacity / length (context.py:147-149, 211-213), own entries only
+      for (int t = tid; t < tpad; t += kThreads) {
+        float rem = cap - srem[t];
         if (ENV == RL4CO_ENV_PCTSP && !(rem > 0.0f)) rem = 0.0f;
-        srem[col] = rem;
+        srem[t] = rem;
       }
+      __syncthreads();
     }
-    if (ENV == RL4CO_ENV_TSP && gsz > 1) {
-      // "late" columns (stage 5): a column whose current node is also the current node of an EARLIER column of its block —
-      // possible only across the two trajectories a block can hold. Its context-row sum must see the earlier column's.
-      for (int col = tid; col < ncols; col += kThreads) {
-        const uint32_t f = scol[col];
-        bool late = false;
-        if ((f & 0x03000000u) == 0x01000000u) {  // valid, not step 0: the column scatters
-          for (int c2 = col & ~15; c2 < col; ++c2) {
-            const uint32_t f2 = scol[c2];  // other scatters, other slot, same current node
-            late |= (f2 & 0x03000000u) == 0x01000000u && ((f2 ^ f) & 0x7c000000u) != 0 && ((f2 ^ f) & 0x0000ff00u) == 0;
-          }
-        }
-        if (late) scol[col] = f | 0x80000000u;  // (own word; the scans above ignore bit 31)
-      }
-    }
-    stage_group();
-    __syncthreads();
 
-    // context rows of a lane's column are fetched one block ahead (an L2 round trip otherwise opens every block's
-    // dependency chain); the first block's leave here
-    uint32_t coln = scol[tl];  // this lane's column word, read one block ahead like the rows it names
-    float4 c4n = ctx_row(ctxc, (coln >> 8) & 0xffu);
-    float4 f4n = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ENV == RL4CO_ENV_TSP) f4n = ctx_row(ctxf, (coln >> 16) & 0xffu);
-    // the rows just fetched are "used" here, before the loop: otherwise the waitcnt state merged at the loop header still
-    // counts them as in flight and every block's first stage waits — vmcnt is one in-order counter — for the fetch it has
-    // JUST issued (r06: this line missing cost 0.7 us per block, the whole gain of the packed columns)
+    const int ntb = (t_end + 15) >> 4;
+    // the rows fetched during the set-up are "used" here, before the loop: otherwise the waitcnt state merged at the loop
+    // header still counts them as in flight and every block's first stage waits for the fetch it has JUST issued
     asm volatile("" : "+v"(c4n.x), "+v"(c4n.y), "+v"(c4n.z), "+v"(c4n.w));
-    if (ENV == RL4CO_ENV_TSP) asm volatile("" : "+v"(f4n.x), "+v"(f4n.y), "+v"(f4n.z), "+v"(f4n.w));
+    if (ENV == RL4CO_ENV_TSP) asm volatile("" : "+v"(f4[0]), "+v"(f4[1]), "+v"(f4[2]), "+v"(f4[3]));
     float pend[4] = {0.f, 0.f, 0.f, 0.f};  // this lane's deferred context-row scatter
     int pend_cur = -1;
-    bool pend_late = false;
     for (int tb = 0; tb < ntb; ++tb) {
-      const int t = 16 * tb + tl;  // this lane's packed column (same in the four row groups)
-      const uint32_t colw = coln;
-      coln = scol[t + 16];
-      const int at = colw & 0xffu, cur = (colw >> 8) & 0xffu;
+      const int t = 16 * tb + tl;  // this lane's column (same in the four row groups)
+      const int cur = (t == 0) ? 0 : sact[t - 1];
+      const int at = sact[t];
       const float gt = sg[t];
-      const uint32_t fl = colw >> 24;
-      const bool valid = (fl & 1u) != 0, tzero = (fl & 2u) != 0;
+      const bool valid = sval[t] != 0;
       const uint4 mw4 = *reinterpret_cast<const uint4*>(smask + 4 * t);
       const uint32_t mw[4] = {mw4.x, mw4.y, mw4.z, mw4.w};
-      const float rem = kScalar ? srem[t] : 0.0f;
+      const float rem = (ENV != RL4CO_ENV_TSP) ? srem[t] : 0.0f;
       const float now = kClock ? stime[t] : 0.0f;
-      // TSP: an earlier column of this block (the other trajectory) leaves the same node — see stage 5
-      const bool late = ENV == RL4CO_ENV_TSP && (fl & 0x80u) != 0;
-      const int slot = (int)(fl >> 2) & 31;  // the column's trajectory inside the group
 
       // ---- 0. query of head h for the block's 16 steps (context.py:105-149, decoder.py:135-136) --
       bf16x4 qf;
       {
         const float4 c4 = c4n;
         const float c[4] = {c4.x, c4.y, c4.z, c4.w};
-        const float f4[4] = {f4n.x, f4n.y, f4n.z, f4n.w};
-        c4n = ctx_row(ctxc, (coln >> 8) & 0xffu);  // the next block's column of this lane
-        if (ENV == RL4CO_ENV_TSP) {
-          f4n = ctx_row(ctxf, (coln >> 16) & 0xffu);
-          const int fn = (colw >> 16) & 0xffu;
-          const bool moved = valid && fn != my_first;  // the lane's column moved on to a trajectory with another first node
-          if (__any(moved)) {
-            flush_first(moved);
-            if (moved) my_first = fn;
-          }
-        }
+        c4n = *reinterpret_cast<const float4*>(ctxc + (int64_t)sact[min(t + 15, kMaxT - 1)] * kD);  // cur of step t + 16
         // the PREVIOUS block's context-row scatter leaves here, behind the fetch: vmcnt is one in-order counter on
         // gfx9, so the wait for the row above also waits for every atomic issued before it — issued at the end of
         // their own block they stalled each block's first stage for their whole L2 round trip (tools/teacher_clock_probe.py)
-        scatter_pending(pend, pend_cur, pend_late);
+        if (pend_cur >= 0) {
+          scatter_row<ENV>(dcc + (int64_t)pend_cur * kD + dcol, pend);
+          pend_cur = -1;
+        }
         float q4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float q;
-          if (ENV == RL4CO_ENV_TSP) q = tzero ? qx4[e] + qb4[e] : (f4[e] + c[e]) + qb4[e];
+          if (ENV == RL4CO_ENV_TSP) q = (t == 0) ? qx4[e] + qb4[e] : (f4[e] + c[e]) + qb4[e];
           else if (kClock) q = fmaf(qt4[e], now, fmaf(qx4[e], rem, c[e])) + qb4[e];  // context.py:152-166
           else q = fmaf(qx4[e], rem, c[e]) + qb4[e];
           q4[e] = q * (0.25f * kLog2e);
@@ -648,30 +498,14 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
 
       // ---- 1. scores^T and softmax numerators over nodes (attention.py:300-314) -----------------------
       bf16x4 pf[NT];
-#ifndef RL4CO_TEACHER_NO_BATCH
-      bf16x4 vf[NT];
-#endif
       float inv_l;
       {
         f32x4 sc[NT];
         float m = kNegInf;
-#ifndef RL4CO_TEACHER_NO_BATCH
-        // every operand read of a stage goes out BEFORE its first product (r06). Written tile by tile the compiler keeps
-        // that order — ds_read, s_waitcnt lgkmcnt(0), v_mfma, per tile — and every one of the ~50 LDS reads of a block
-        // exposes its full latency on the wave's chain (r06 ISA; the attention backward had the same shape, r05)
-        bf16x4 kf[NT];
-#pragma unroll
-        for (int jt = 0; jt < NT; ++jt) kf[jt] = lds_b64(kgs + 16 * jt * kRS + 16 * h + nao);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
           {
-#ifndef RL4CO_TEACHER_NO_BATCH
-            sc[jt] = mfma16(kf[jt], qf, zero4());
-#else
             sc[jt] = mfma16(lds_b64(kgs + 16 * jt * kRS + 16 * h + nao), qf, zero4());
-#endif
             const uint32_t bits = (a.mask_inner ? mw[jt >> 1] : nv[jt >> 1]) >> (16 * (jt & 1) + 4 * g);
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
@@ -683,12 +517,6 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
         m = rg_max(m);
         const f32x2 m2 = {m, m};
         f32x2 l2 = {0.0f, 0.0f};
-#ifndef RL4CO_TEACHER_NO_BATCH
-        // the glimpse's value tiles travel under the exponentials
-#pragma unroll
-        for (int jt = 0; jt < NT; ++jt) vf[jt] = lds_tr(vs + 16 * jt * kRS + 16 * h + tro);
-        __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
           {
@@ -707,20 +535,9 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
       // ---- 2. glimpse O_h^T = V_h^T P^T --------------------------------------------------------------
       f32x4 o = zero4();  // kept: the softmax backward's sum_j a_j dA_j is O_h . dO_h
       {
-#ifndef RL4CO_TEACHER_NO_BATCH
-        f32x4 o1 = zero4();  // two accumulators: half the dependent-MFMA chain
-#pragma unroll
-        for (int jt = 0; jt < NT; ++jt) {
-          if (jt & 1) o1 = mfma16(vf[jt], pf[jt], o1);
-          else o = mfma16(vf[jt], pf[jt], o);
-        }
-#pragma unroll
-        for (int rr = 0; rr < 4; ++rr) o[rr] += o1[rr];
-#else
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt)
           o = mfma16(lds_tr(vs + 16 * jt * kRS + 16 * h + tro), pf[jt], o);
-#endif
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) o[rr] *= inv_l;
         *reinterpret_cast<bf16x4*>(ob + tl * kRS + dcol) = to_bf16(o);
@@ -825,7 +642,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
           const bool feasible = (aw >> (at & 31)) & 1u;
           if (!feasible) errbits |= RL4CO_EBIT_INFEASIBLE;
           if (!(lp > -1000.0f)) errbits |= RL4CO_EBIT_NEG_INF_LOGP;
-          if (a.logp_out) a.logp_out[(int64_t)((s0 + slot) * a.B_inst + inst) * T + sstep[t]] = lp;
+          if (a.logp_out) a.logp_out[(int64_t)r * T + t] = lp;
         }
         if (w < NT) {
           f32x4 du;
@@ -862,11 +679,10 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
       // instead of a first pass over all node tiles; dA^T itself is produced tile by tile, turned into dS, staged and
       // fed to d query at once
       f32x4 dq = zero4();
-      const bool scatter = valid && (ENV != RL4CO_ENV_TSP || !tzero);
-      // d ctx_cur[cur] += dq, four dims of one row: see scatter_pending. TSP: the read of the read-modify-write goes out
-      // here, a whole stage ahead of its use ("late" columns read at the scatter itself)
+      const bool scatter = valid && (ENV != RL4CO_ENV_TSP || t != 0);
       float4 row_old = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ENV == RL4CO_ENV_TSP && scatter && !late) row_old = *reinterpret_cast<const float4*>(dcc + (int64_t)cur * kD + dcol);
+      if (ENV == RL4CO_ENV_TSP && scatter)  // read of the read-modify-write below: a whole stage ahead of its use
+        row_old = *reinterpret_cast<const float4*>(dcc + (int64_t)cur * kD + dcol);
       {
         float ada = 0.0f;
 #pragma unroll
@@ -911,7 +727,7 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
           const float dqr = 0.25f * dq[e];
           dqb[e] += dqr;
           if (ENV == RL4CO_ENV_TSP) {
-            if (tzero) dqx[e] += dqr;
+            if (t == 0) dqx[e] += dqr;
             else dqf[e] += dqr;
           } else {
             dqx[e] = fmaf(dqr, rem, dqx[e]);
@@ -919,18 +735,25 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
           }
           pend[e] = old4[e] + dqr;  // d ctx_cur[cur] += dqr: leaves at the top of the next block (or after the last)
         }
-        if (scatter) {
-          pend_cur = cur;
-          pend_late = late;
-        }
+        if (scatter) pend_cur = cur;
       }
       rl4co::lds_barrier();  // B4: the glimpse / d-logit blocks are rewritten by the next step block (LDS only:
                              // the context-row atomics stay in flight)
     }
 
-    scatter_pending(pend, pend_cur, pend_late);  // the last block's scatter
+    if (pend_cur >= 0) {  // the last block's scatter
+      scatter_row<ENV>(dcc + (int64_t)pend_cur * kD + dcol, pend);
+      pend_cur = -1;
+    }
+    // d ctx_first: one row per trajectory (every step after the first reads h[first])
+    if (ENV == RL4CO_ENV_TSP) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float v = step_sum(dqf[e]);
+        if (tl == 0) unsafeAtomicAdd(a.d_ctx_first + ((int64_t)inst * N + first) * kD + dcol + e, v);
+      }
+    }
   }
-  if (ENV == RL4CO_ENV_TSP) flush_first(my_first >= 0);  // d ctx_first: what the lanes still hold
 
   // ---- the instance's plane gradients: dims 16 h + 4 g .. + 3 of node 16 jt + (lane & 15) -----------
   const float c = 1.0f / kLog2e;  // the staged queries carried log2(e)
@@ -974,42 +797,6 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
     }
   }
   if (errbits) atomicOr(a.err, (int)errbits);
-  if (a.d_ctx_in_planes) {
-    // the context-table gradients leave as planes 3 / 4 of the caller's 16-bit gradient matrix (the fold GEMMs' operand):
-    // every scatter of this instance has been issued by this workgroup — drained (vmcnt(0) inside __syncthreads), made
-    // visible, and read back through L2 (the sums were built by atomics: load4_l2)
-    __threadfence();
-    __syncthreads();
-    elem_t* dp = static_cast<elem_t*>(a.d_planes_bf16) + (int64_t)inst * a.d_planes_batch_stride;
-    const int p_cur = (ENV == RL4CO_ENV_TSP) ? 4 : 3;
-    // NT * 16 rows x 32 four-dim pieces over 512 threads = NT pieces per thread: all loads of a table out before the first
-    // conversion (a fixed trip count over clamped rows — the rows past N repeat the last one's bytes to the same address)
-    float4 v[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int i = tid + kThreads * j, row = min(i >> 5, N - 1), c4 = (i & 31) * 4;
-      v[j] = load4_l2(dcc + (int64_t)row * kD + c4);
-    }
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int i = tid + kThreads * j, row = min(i >> 5, N - 1), c4 = (i & 31) * 4;
-      *reinterpret_cast<bf16x4*>(dp + p_cur * a.d_planes_plane_stride + (int64_t)row * a.d_planes_row_stride + c4) =
-          rl4co_e16::cvt4(v[j].x, v[j].y, v[j].z, v[j].w);
-    }
-    if (ENV == RL4CO_ENV_TSP) {
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int i = tid + kThreads * j, row = min(i >> 5, N - 1), c4 = (i & 31) * 4;
-        v[j] = load4_l2(a.d_ctx_first + ((int64_t)inst * N + row) * kD + c4);
-      }
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int i = tid + kThreads * j, row = min(i >> 5, N - 1), c4 = (i & 31) * 4;
-        *reinterpret_cast<bf16x4*>(dp + 3 * a.d_planes_plane_stride + (int64_t)row * a.d_planes_row_stride + c4) =
-            rl4co_e16::cvt4(v[j].x, v[j].y, v[j].z, v[j].w);
-      }
-    }
-  }
 }
 
 }  // namespace
@@ -1021,19 +808,14 @@ int teacher_mma_max_nodes() { return 16 * kMaxTiles; }
 int teacher_mma_max_steps() { return kMaxT; }
 #endif
 
-template <int ENV, int NT, bool CTX16>
-static int launch_tiles_ctx(const rl4co_am_teacher_args& a, hipStream_t stream) {
-  const Layout L = make_layout(NT, ENV);
-  if (L.total > 160 * 1024) return rl4co::record_arg_error("am_teacher_mma: LDS layout exceeds 160 KB");
-  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_teacher_mma_kernel<ENV, NT, CTX16>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
-  hipLaunchKernelGGL((am_teacher_mma_kernel<ENV, NT, CTX16>), dim3(a.B_inst), dim3(kThreads), L.total, stream, a);
-  RL4CO_HIP_TRY(hipGetLastError());
-  return RL4CO_OK;
-}
 template <int ENV, int NT>
 static int launch_tiles(const rl4co_am_teacher_args& a, hipStream_t stream) {
-  return a.ctx_dtype != RL4CO_DT_F32 ? launch_tiles_ctx<ENV, NT, true>(a, stream) : launch_tiles_ctx<ENV, NT, false>(a, stream);
+  const Layout L = make_layout(NT);
+  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(am_teacher_mma_kernel<ENV, NT>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, L.total));
+  hipLaunchKernelGGL((am_teacher_mma_kernel<ENV, NT>), dim3(a.B_inst), dim3(kThreads), L.total, stream, a);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
 }
 
 template <int ENV>
