@@ -12,8 +12,9 @@
 //   dKg_h^T[d,j] += sum_t Q_h^T[d,t] dS[t,j]
 //
 // One 512-thread workgroup per INSTANCE (8 waves = 8 heads, two waves per SIMD so the VALU of one
-// overlaps the MFMAs of the other); its S multistart trajectories are replayed one after the other
-// in blocks of 16 steps, all products on v_mfma_f32_16x16x16_bf16. In that instruction's
+// overlaps the MFMAs of the other); the LIVE steps of its S multistart trajectories are laid side by
+// side (make_layout: packed columns, r06) and replayed in blocks of 16 columns, all products on
+// v_mfma_f32_16x16x16_bf16. In that instruction's
 // accumulator layout a lane owns ONE step (column lane & 15) and four consecutive rows, which is
 // also its B-operand layout: softmax / log-softmax over nodes are in-lane reductions plus two
 // cross-row-group exchanges, and accumulators chain into the next product without a shuffle.
@@ -203,7 +204,11 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
   }
   float* dcc = a.d_ctx_cur + (int64_t)inst * N * kD;
   for (int i = tid; i < N * kD / 4; i += kThreads) reinterpret_cast<float4*>(dcc)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  __threadfence();  // the zeros reach L2 before this workgroup's atomics on the same rows
+  // the zeros are acknowledged by L2 before this workgroup's atomics / loads of the same rows. A counter wait, not
+  // __threadfence(): the agent-scope fence also issues buffer_wbl2 + buffer_inv — an L2 write-back and invalidate per
+  // workgroup that nothing here needs (every consumer of these rows sits in this workgroup and reads through L2 or after
+  // its own CU's write-through stores); at the end of the kernel the same fence cost 1.0 ms of a 5.7 ms launch (r06)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   uint32_t nv[4];  // nodes that exist, per 32-node word
 #pragma unroll
@@ -976,10 +981,9 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
   if (errbits) atomicOr(a.err, (int)errbits);
   if (a.d_ctx_in_planes) {
     // the context-table gradients leave as planes 3 / 4 of the caller's 16-bit gradient matrix (the fold GEMMs' operand):
-    // every scatter of this instance has been issued by this workgroup — drained (vmcnt(0) inside __syncthreads), made
-    // visible, and read back through L2 (the sums were built by atomics: load4_l2)
-    __threadfence();
-    __syncthreads();
+    // every scatter of this instance has been issued by this workgroup — drained (vmcnt(0) inside __syncthreads) and read
+    // back through L2 (the sums were built by atomics: load4_l2)
+    __syncthreads();  // (s_waitcnt vmcnt(0) of every wave, then the barrier: all stores and atomics are at L2)
     elem_t* dp = static_cast<elem_t*>(a.d_planes_bf16) + (int64_t)inst * a.d_planes_batch_stride;
     const int p_cur = (ENV == RL4CO_ENV_TSP) ? 4 : 3;
     // NT * 16 rows x 32 four-dim pieces over 512 threads = NT pieces per thread: all loads of a table out before the first

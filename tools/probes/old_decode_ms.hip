@@ -95,18 +95,6 @@ struct Bits128 {
   }
 };
 
-#if defined(RL4CO_MS_PROBE) && RL4CO_MS_PROBE == 7  // phase clocks (tools/ms_phases.py): shader-clock sums per step segment, per wave class
-__device__ unsigned long long g_ms_clk[16];
-#define RL4CO_MS_MARK(i)                                          \
-  {                                                               \
-    const unsigned long long now_ = __builtin_readcyclecounter(); \
-    acc_[i] += now_ - clk_;                                       \
-    clk_ = now_;                                                  \
-  }
-#else
-#define RL4CO_MS_MARK(i)
-#endif
-
 struct __align__(16) Xchg {  // per (node tile, trajectory) pieces of the log-softmax / selection over nodes
   float zmax, se, best_key, best_z;
   int best_idx;
@@ -174,21 +162,11 @@ struct Sel {  // log-softmax / selection pieces over a set of nodes
 // step here (the Gumbel noise is log(-log u) of four uniforms), none of whose arguments can be denormal: uniforms and
 // exponential noise are >= 2^-33, -log u >= 2^-25, sums of exponentials >= 1
 __device__ inline float ln_fast(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994531f; }
-// BOUNDED (r06): clipped logits live in [-C, C], C = tanh_clipping / temperature; up to C = 60 their exponentials and the
-// sum over <= 128 nodes are plain fp32 numbers, so the log-sum-exp needs no running maximum — the pieces are exp(z) sums
-// and a merge is ONE addition instead of a maximum, two subtractions, two exponentials and a multiply-add (five merges per
-// wave and step: the step is VALU-issue bound, r05 counters: 795 VALU instructions per wave-step against 44 MFMAs). The
-// teacher kernel (am_teacher_mma.hip, `bounded`) has summed its log-softmax that way since r03.
-__device__ inline Sel merge(const Sel& p, const Sel& q, bool bounded) {
+__device__ inline Sel merge(const Sel& p, const Sel& q) {
   Sel o;
-  if (bounded) {
-    o.zmax = 0.0f;
-    o.se = p.se + q.se;
-  } else {
-    o.zmax = fmaxf(p.zmax, q.zmax);
-    const float zs = (o.zmax > kNegInf) ? o.zmax : 0.0f;
-    o.se = p.se * __expf(p.zmax - zs) + q.se * __expf(q.zmax - zs);  // exp(-inf) = 0 for an empty set
-  }
+  o.zmax = fmaxf(p.zmax, q.zmax);
+  const float zs = (o.zmax > kNegInf) ? o.zmax : 0.0f;
+  o.se = p.se * __expf(p.zmax - zs) + q.se * __expf(q.zmax - zs);  // exp(-inf) = 0 for an empty set
   const bool take_q = (q.idx != 0x7fffffff) & ((p.idx == 0x7fffffff) | (q.key > p.key) | ((q.key == p.key) & (q.idx < p.idx)));
   o.key = take_q ? q.key : p.key;
   o.z = take_q ? q.z : p.z;
@@ -252,20 +230,8 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
   const float cap = (kCvrpLike || ENV == RL4CO_ENV_PCTSP) ? a.vehicle_capacity[inst]
                                                                      : (ENV == RL4CO_ENV_OP ? a.max_length[(int64_t)inst * N] : 0.0f);
   const float thr = cap + 1e-5f;
-  // context tables: dense fp32 [B_inst,N,128], or (r06, ctx_dtype) rows in the planes' 16-bit type with the caller's strides
-  const bool ctx16 = a.ctx_dtype != RL4CO_DT_F32;
-  const int64_t ctx_esz = ctx16 ? 2 : 4;
-  const int64_t ctx_rs = (a.ctx_row_stride ? a.ctx_row_stride : (int64_t)kD) * ctx_esz;  // bytes between node rows
-  const int64_t ctx_off = ((int64_t)inst * (a.ctx_batch_stride ? a.ctx_batch_stride : (int64_t)N * kD) + dcol) * ctx_esz;
-  const char* ctxc = static_cast<const char*>(a.ctx_cur) + ctx_off;
-  const char* ctxf = (ENV == RL4CO_ENV_TSP) ? static_cast<const char*>(a.ctx_first) + ctx_off : nullptr;
-  auto first_row = [&](int node, float (&f)[4]) {
-    const float4 v = rl4co_e16::load_ctx4(ctxf + (int64_t)node * ctx_rs, ctx16);
-    f[0] = v.x;
-    f[1] = v.y;
-    f[2] = v.z;
-    f[3] = v.w;
-  };
+  const float* ctxc = static_cast<const float*>(a.ctx_cur) + (int64_t)inst * N * kD + dcol;
+  const float* ctxf = (ENV == RL4CO_ENV_TSP) ? static_cast<const float*>(a.ctx_first) + (int64_t)inst * N * kD + dcol : nullptr;
   float qb4[4], qx4[4], qt4[4];  // graph context; placeholder query (TSP) or capacity column; CVRPTW: the time column
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -277,7 +243,6 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
   const float inv_temp = 1.0f / a.temperature;
   const float clip_over_temp = a.tanh_clipping * inv_temp;
   const bool clip = a.tanh_clipping > 0.0f;
-  const bool bounded = clip && clip_over_temp <= 60.0f;  // (uniform: a scalar branch around the maximum bookkeeping, see merge)
   Bits128 nv;  // nodes that exist (j < N), per 32-node word
 #pragma unroll
   for (int k = 0; k < 4; ++k) nv.put(k, (N >= 32 * (k + 1)) ? 0xffffffffu : (N > 32 * k ? ((1u << (N - 32 * k)) - 1u) : 0u));
@@ -316,8 +281,7 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
     x.park_logp = 0.0f;
     x.park_col = -1;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) x.f4[e] = 0.0f;
-    if (ENV == RL4CO_ENV_TSP && x.step_i > 0) first_row(x.first, x.f4);
+    for (int e = 0; e < 4; ++e) x.f4[e] = (ENV == RL4CO_ENV_TSP && x.step_i > 0) ? ctxf[(int64_t)x.first * kD + e] : 0.0f;
   }
   // the logit-key tile of this wave (nodes 16 w .., all 128 dims) is the same at every step — 16 registers for the
   // whole rollout instead of a third LDS plane (rows past the graph: any finite value, their logits are masked)
@@ -330,25 +294,6 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
       const uint16_t* row2 = sh.kl_g2 + (int64_t)min(16 * w + tl, N - 1) * sh.kl_rs + 4 * g;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) lfr2[PAIR ? ks : 0] = *reinterpret_cast<const bf16x4*>(row2 + 16 * ks);
-    }
-  }
-  // PAIR (r06): the glimpse operands of head h — key rows and transposed value tiles of BOTH instances, 4 x NT fragments =
-  // 56 registers at NT = 7 — are the same at every step too; the paired kernel is LDS-bound at two waves per SIMD with
-  // 153 of its 256 registers in use, so they are read ONCE: 4 NT LDS reads per wave and step (of ~45) leave the step's
-  // chain and the LDS pipe (conflict ratio 0.46, r05 counters). The unpaired kernel lives in 128 registers and keeps reading.
-#ifdef RL4CO_MS_NO_REG_PLANES
-  constexpr bool kRegPlanes = false;
-#else
-  constexpr bool kRegPlanes = PAIR;
-#endif
-  bf16x4 kfr[kRegPlanes ? NT : 1], kfr2[kRegPlanes ? NT : 1], vfr[kRegPlanes ? NT : 1], vfr2[kRegPlanes ? NT : 1];
-  if constexpr (kRegPlanes) {
-#pragma unroll
-    for (int jt = 0; jt < NT; ++jt) {
-      kfr[jt] = lds_b64(sh.kgs + 16 * jt * kRS + 16 * h + nao);
-      kfr2[jt] = lds_b64(sh.kgs + sh.plane2 + 16 * jt * kRS + 16 * h + nao);
-      vfr[jt] = lds_tr(sh.vs + 16 * jt * kRS + 16 * h + tro);
-      vfr2[jt] = lds_tr(sh.vs + sh.plane2 + 16 * jt * kRS + 16 * h + tro);
     }
   }
   const bf16x4 zero_b = {(elem_t)0.0f, (elem_t)0.0f, (elem_t)0.0f, (elem_t)0.0f};
@@ -364,9 +309,6 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
   // the launch's Philox key, read ONCE: fetched inside the step loop it was a vector-memory load whose wait
   // (vmcnt is one in-order counter) also held the Philox rounds back behind the context row's L2 round trip
   const unsigned long long seed = a.philox_seed ^ (a.philox_seed_dev ? *a.philox_seed_dev : 0ull);
-#if defined(RL4CO_MS_PROBE) && RL4CO_MS_PROBE == 7
-  unsigned long long acc_[7] = {0, 0, 0, 0, 0, 0, 0};
-#endif
   int t = 0;
   for (; t < a.max_steps; ++t) {
     bool all_done = true;
@@ -374,18 +316,11 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
     for (int c = 0; c < CT; ++c) all_done &= tj[c].done;
     if (!single && __all(all_done)) break;  // identical on every wave
     const int64_t tcol = (int64_t)a.t0 + t;
-#if defined(RL4CO_MS_PROBE) && RL4CO_MS_PROBE == 7
-    unsigned long long clk_ = __builtin_readcyclecounter();
-#endif
 
     // ---- 1. query of head h (folded context + graph context), x 1/sqrt(16) x log2(e) -----------------
     float4 c4v[CT];
 #pragma unroll
-#if defined(RL4CO_MS_PROBE) && RL4CO_MS_PROBE == 2  // timing probe: no context-row fetch on the step's chain
-    for (int c = 0; c < CT; ++c) c4v[c] = make_float4(0.01f * tj[c].cur, 0.02f, 0.03f, 0.04f);
-#else
-    for (int c = 0; c < CT; ++c) c4v[c] = rl4co_e16::load_ctx4(ctxc + (int64_t)tj[c].cur * ctx_rs, ctx16);  // L2-resident context row
-#endif
+    for (int c = 0; c < CT; ++c) c4v[c] = *reinterpret_cast<const float4*>(ctxc + (int64_t)tj[c].cur * kD);  // L2-resident context row
     // this step's noise: log(Exp(1) noise) of the four nodes this lane owns in the logits stage (they share
     // one Philox block, rl4co_math.h). Depends on (step, row, node) only, so it is drawn HERE — ten dependent
     // Philox rounds and two logarithms that used to sit between the two barriers, on the step's critical path,
@@ -404,18 +339,13 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
             lnz_c[c][i] = (node0 + i < N && x.ok) ? ln_fast(a.exp_noise[((int64_t)t * a.B + x.r) * N + node0 + i]) : 0.0f;
         } else {
           float uu4[4];
-#if defined(RL4CO_MS_PROBE) && RL4CO_MS_PROBE == 1  // timing probe: no Philox rounds
-          uu4[0] = 0.3f + 1e-3f * (float)(tcol & 7); uu4[1] = 0.5f; uu4[2] = 0.7f; uu4[3] = 0.2f + 1e-3f * (float)node0;
-#else
           rl4co_uniform4(seed, a.philox_offset + (uint64_t)tcol,
                          (uint32_t)x.r, (uint32_t)(node0 >> 2), uu4);
-#endif
 #pragma unroll
           for (int i = 0; i < 4; ++i) lnz_c[c][i] = ln_fast(-ln_fast(uu4[i]));
         }
       }
     }
-    RL4CO_MS_MARK(0)  // noise drawn (the context row is in flight)
     bf16x4 qf[CT];
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
@@ -442,7 +372,6 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
       qf[c] = rl4co_e16::cvt4(q4[0], q4[1], q4[2], q4[3]);  // (two pair conversions: elem16.h)
     }
     // ---- 2. glimpse of head h ---------------------------------------------------------------------------
-    RL4CO_MS_MARK(1)  // query ready (includes the wait for the context row)
     {
       f32x4 sc[CT][NT];
       float m[CT];
@@ -450,11 +379,11 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
       for (int c = 0; c < CT; ++c) m[c] = kNegInf;
 #pragma clang loop unroll(full)
       for (int jt = 0; jt < NT; ++jt) {
-        const bf16x4 kf = kRegPlanes ? kfr[kRegPlanes ? jt : 0] : lds_b64(sh.kgs + 16 * jt * kRS + 16 * h + nao);
+        const bf16x4 kf = lds_b64(sh.kgs + 16 * jt * kRS + 16 * h + nao);
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
           if (PAIR) {
-            const bf16x4 kf2 = kRegPlanes ? kfr2[kRegPlanes ? jt : 0] : lds_b64(sh.kgs + sh.plane2 + 16 * jt * kRS + 16 * h + nao);
+            const bf16x4 kf2 = lds_b64(sh.kgs + sh.plane2 + 16 * jt * kRS + 16 * h + nao);
             sc[c][jt] = mfma16(kf2, only1(qf[c]), mfma16(kf, only0(qf[c]), zero4()));
           } else {
             sc[c][jt] = mfma16(kf, qf[c], zero4());
@@ -488,22 +417,18 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
       }
 #pragma clang loop unroll(full)
       for (int jt = 0; jt < NT; ++jt) {
-        const bf16x4 vf = kRegPlanes ? vfr[kRegPlanes ? jt : 0] : lds_tr(sh.vs + 16 * jt * kRS + 16 * h + tro);
+        const bf16x4 vf = lds_tr(sh.vs + 16 * jt * kRS + 16 * h + tro);
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
           float p4[4];
 #pragma unroll
           for (int rr = 0; rr < 4; ++rr) {
-#if defined(RL4CO_MS_PROBE) && RL4CO_MS_PROBE == 5  // timing probe: no exponentials in the glimpse softmax (finite garbage)
-            p4[rr] = fmaxf(sc[c][jt][rr] - m[c], -1.0f) + 1.0f;
-#else
             p4[rr] = __builtin_amdgcn_exp2f(sc[c][jt][rr] - m[c]);
-#endif
             l[c] += p4[rr];
           }
           const bf16x4 pf = rl4co_e16::cvt4(p4[0], p4[1], p4[2], p4[3]);
           if (PAIR) {
-            const bf16x4 vf2 = kRegPlanes ? vfr2[kRegPlanes ? jt : 0] : lds_tr(sh.vs + sh.plane2 + 16 * jt * kRS + 16 * h + tro);
+            const bf16x4 vf2 = lds_tr(sh.vs + sh.plane2 + 16 * jt * kRS + 16 * h + tro);
             if (jt & 1) {
               o1[c] = mfma16(vf, pf, o1[c]);
               p1[c] = mfma16(vf2, pf, p1[c]);
@@ -532,9 +457,7 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
         *reinterpret_cast<bf16x4*>(sh.hs + (16 * c + tl) * kRS + dcol) = rl4co_e16::cvt4(o4[0], o4[1], o4[2], o4[3]);
       }
     }
-    RL4CO_MS_MARK(2)  // glimpse written
     rl4co::lds_barrier();  // B1 (LDS only: parked stores stay in flight)
-    RL4CO_MS_MARK(3)  // B1 passed
 
     // ---- 3. logits of node tile w, local log-softmax / selection pieces ------------------------------------
     if (w < NT) {
@@ -588,24 +511,14 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
           if (PAIR) usum = half == 0 ? usum : v0[c][rr] + v1[c][rr];
           const float uu = usum * (1.0f / kSqrtD);
           nan_seen |= uu != uu;
-#if defined(RL4CO_MS_PROBE) && RL4CO_MS_PROBE == 6  // timing probe: no tanh
-          const float th = fminf(fmaxf(uu, -1.0f), 1.0f) * clip_over_temp;
-#else
           const float ex = __expf(-2.0f * fabsf(uu));
           const float th = copysignf((1.0f - ex) * __builtin_amdgcn_rcpf(1.0f + ex), uu) * clip_over_temp;
-#endif
           const float zz = clip ? th : uu * inv_temp;
           z[rr] = ((lbits >> rr) & 1u) ? zz : kNegInf;
+          p.zmax = fmaxf(p.zmax, z[rr]);
         }
         if (nan_seen & x.ok & !x.done) errbits |= RL4CO_EBIT_NAN_LOGIT;
-        float zs = 0.0f;
-        if (bounded) {
-          p.zmax = 0.0f;
-        } else {
-#pragma unroll
-          for (int rr = 0; rr < 4; ++rr) p.zmax = fmaxf(p.zmax, z[rr]);
-          zs = (p.zmax > kNegInf) ? p.zmax : 0.0f;
-        }
+        const float zs = (p.zmax > kNegInf) ? p.zmax : 0.0f;
         p.se = 0.0f;
         p.key = kNegInf;
         p.z = kNegInf;
@@ -625,8 +538,8 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
           if (MODE == RL4CO_DECODE_EVALUATE) p.fz = (node == forced[c]) ? zz : p.fz;
         }
         // the four row groups hold different nodes of the same trajectory
-        p = merge(p, partner<16>(p), bounded);
-        p = merge(p, partner<32>(p), bounded);
+        p = merge(p, partner<16>(p));
+        p = merge(p, partner<32>(p));
         if (g == 0) {
           Xchg e;
           e.zmax = p.zmax;
@@ -641,9 +554,7 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
         }
       }
     }
-    RL4CO_MS_MARK(4)  // logits / selection pieces written
     rl4co::lds_barrier();  // B2
-    RL4CO_MS_MARK(5)  // B2 passed
 
     // ---- 4. every lane: finish the selection of its trajectory, transition ------------------------------
     // row group g folds node tiles g and g + 4, then the row groups meet in two butterfly steps
@@ -671,11 +582,11 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
         q.z = has ? e.best_z : kNegInf;
         q.idx = has ? e.best_idx : 0x7fffffff;
         q.fz = has ? e.forced_z : kNegInf;
-        p = merge(p, q, bounded);
+        p = merge(p, q);
       }
-      p = merge(p, partner<16>(p), bounded);
-      p = merge(p, partner<32>(p), bounded);
-      const float lse = (bounded ? 0.0f : p.zmax) + ln_fast(p.se);
+      p = merge(p, partner<16>(p));
+      p = merge(p, partner<32>(p));
+      const float lse = p.zmax + ln_fast(p.se);
       int act;
       float logp;
       if (MODE == RL4CO_DECODE_EVALUATE) {
@@ -702,7 +613,8 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
         if (ENV == RL4CO_ENV_TSP) {
           if (x.step_i == 0) {
             x.first = act;
-            first_row(x.first, x.f4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x.f4[e] = ctxf[(int64_t)x.first * kD + e];
           }
           x.cur = act;
           x.step_i += 1;
@@ -812,14 +724,9 @@ __device__ __forceinline__ void rollout_tiles(const rl4co_am_decode_args& a, con
         x.park_col = -1;
       }
     }
-    RL4CO_MS_MARK(6)  // selection finished, state advanced
     if (single) break;
   }
 
-#if defined(RL4CO_MS_PROBE) && RL4CO_MS_PROBE == 7
-  if (lane == 0 && blockIdx.x < 256)
-    for (int i = 0; i < 7; ++i) atomicAdd(&g_ms_clk[(w == 0 ? 0 : 8) + i], acc_[i]);
-#endif
   // ---- parked outputs, final state of the column tiles ------------------------------------------------------
 #pragma unroll
   for (int c = 0; c < CT; ++c) {
@@ -983,17 +890,6 @@ int dispatch_tiles(const rl4co_am_decode_args& a, hipStream_t stream) {
 
 }  // namespace
 
-#if defined(RL4CO_MS_PROBE) && RL4CO_MS_PROBE == 7
-extern "C" int rl4co_ms_probe_read(unsigned long long* out, int reset) {
-  RL4CO_HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ms_clk), sizeof(g_ms_clk)));
-  if (reset) {
-    unsigned long long z[16] = {0};
-    RL4CO_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_ms_clk), z, sizeof(z)));
-  }
-  return RL4CO_OK;
-}
-#endif
-
 // dynamic LDS of the multistart variant at the largest graph (N = 128)
 #if !RL4CO_ELEM_F16
 extern "C" int rl4co_am_decode_ms_lds_bytes(void) { return make_layout(8, 128, 2).total; }
@@ -1001,9 +897,7 @@ extern "C" int rl4co_am_decode_ms_lds_bytes(void) { return make_layout(8, 128, 2
 
 namespace rl4co {
 int RL4CO_CXX(launch_decode_ms)(const rl4co_am_decode_args& a, hipStream_t stream) {
-#ifdef RL4CO_MS_PROBE_ONLY  // timing probes (tools/ms_variants.sh): one instantiation instead of 144 — a 10 s build
   return launch_mode<RL4CO_ENV_TSP, 7, RL4CO_DECODE_SAMPLE>(a, stream);
-#else
   switch (a.env) {
     case RL4CO_ENV_TSP: return dispatch_tiles<RL4CO_ENV_TSP>(a, stream);
     case RL4CO_ENV_CVRP: return dispatch_tiles<RL4CO_ENV_CVRP>(a, stream);
@@ -1013,6 +907,5 @@ int RL4CO_CXX(launch_decode_ms)(const rl4co_am_decode_args& a, hipStream_t strea
     case RL4CO_ENV_CVRPTW: return dispatch_tiles<RL4CO_ENV_CVRPTW>(a, stream);
     default: return RL4CO_ERR_ARG;
   }
-#endif
 }
 }  // namespace rl4co
