@@ -410,7 +410,9 @@ typedef struct rl4co_am_encoder_args {
                           RL4CO_DT_BF16 (autocast bfloat16) or RL4CO_DT_F16 (autocast float16, the reference's
                           default "16-mixed", utils/trainer.py:57: v_mfma_f32_32x32x16_f16, softmax always
                           max-subtracted — fp16 lacks the range of the bounded-score shortcut) */
-  int32_t reserved0;   /* keeps the pointers 8-byte aligned; must be 0              */
+  int32_t ctx_dtype;   /* (r06; was reserved0 = 0) element type of ctx_first / ctx_cur: RL4CO_DT_F32 (0, the default) or —
+                          rl4co_am_encoder only, 16-bit planes — act_dtype: the tables written as dense 16-bit [B,N,128] rows
+                          for rl4co_am_decode_args.ctx_dtype; every other entry point requires 0 */
   const float* locs;   /* [B,N,2] (CVRP: depot first, cvrp/env.py:108)             */
   const float* demand; /* [B,N-1] CVRP demand / OP prize / PCTSP expected prize     */
   const float* feature4; /* [B,N-1] PCTSP penalty / CVRPTW tw start (w_init is then [128,4] / [128,6]) or NULL */
@@ -439,8 +441,8 @@ typedef struct rl4co_am_encoder_args {
   void* kvl;                /* planes 0..2 of the folded cache                      */
   int64_t kvl_plane_stride; /* elements between planes                              */
   int64_t kvl_batch_stride; /* elements between instances                           */
-  float* ctx_first;         /* [B,N,128] TSP                                        */
-  float* ctx_cur;           /* [B,N,128]                                            */
+  void* ctx_first;          /* [B,N,128] TSP; fp32 unless ctx_dtype says otherwise   */
+  void* ctx_cur;            /* [B,N,128]                                            */
   float* q_bias;            /* [B,128] or NULL                                      */
   float* hidden;            /* [B,N,128] final node embeddings, or NULL             */
 } rl4co_am_encoder_args;

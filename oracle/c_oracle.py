@@ -196,14 +196,17 @@ def am_decode(cache, state: dict, *, mode: str, max_steps: int, actions: Tensor,
         a.node_embed, a.w_ctx_t, a.w_out_t = (_p(_cpu(x, torch.float32)) for x in (cache.node_embed, cache.w_ctx_t, cache.w_out_t))
         a.w_placeholder = _p(None if cache.w_placeholder is None else _cpu(cache.w_placeholder, torch.float32))
     else:
-        a.ctx_cur = _p(_cpu(cache.ctx_cur, torch.float32))
+        # (16-bit context tables of the 16-bit regime: widened exactly, as the kernels do on load; the locals keep them alive)
+        ctx_cur32 = cache.ctx_cur.float().contiguous()
+        a.ctx_cur = _p(_cpu(ctx_cur32, torch.float32))
     a.q_bias = _p(None if cache.q_bias is None else _cpu(cache.q_bias, torch.float32))
     a.action_mask = _p(mask)
     a.current_node = _p(_cpu(state["current_node"], torch.int64))
     a.done = _p(_u8(state["done"]))
     if cache.env_name == "tsp":
         if not a.unfold:
-            a.ctx_first = _p(_cpu(cache.ctx_first, torch.float32))
+            ctx_first32 = cache.ctx_first.float().contiguous()
+            a.ctx_first = _p(_cpu(ctx_first32, torch.float32))
             a.q_step0 = _p(_cpu(cache.q_step0, torch.float32))
         a.first_node = _p(_cpu(state["first_node"], torch.int64))
         a.step_i = _p(_cpu(state["i"], torch.int64))

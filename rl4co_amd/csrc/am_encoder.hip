@@ -885,8 +885,13 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
     gemm_t<TT, true, true, 1>(acc, wf, xs, lane, wf_all + (int64_t)(blk + 1 < nblocks ? blk + 1 : 0) * kD * kD, 8, w, 0, zero16());  // (last block: dummy)
     // The tile leaves through LDS (`ys` is free after the last layer): stored straight from the accumulators a lane
     // owns 8 / 16 bytes in each of 32 token rows; staged, a plane of an instance is ONE contiguous run of 16-byte lanes.
-    if (blk < 3 && a.cache_dtype != RL4CO_DT_F32) {  // 16-bit planes carry the element type of the activations
-      E* out = static_cast<E*>(a.kvl) + (int64_t)blk * a.kvl_plane_stride + (int64_t)b * a.kvl_batch_stride;
+    // 16-bit planes carry the element type of the activations — and so do (r06, ctx_dtype) the context tables: the decode
+    // kernels widen their rows on load (rl4co_am_decode_args.ctx_dtype), the reference's own query is 16-bit under autocast
+    // (project_context is a Linear), and the fold is bound by its HBM writes: 179 -> 128 KB per instance at TSP-100
+    if ((blk < 3 || a.ctx_dtype != RL4CO_DT_F32) && a.cache_dtype != RL4CO_DT_F32) {
+      E* out;
+      if (blk < 3) out = static_cast<E*>(a.kvl) + (int64_t)blk * a.kvl_plane_stride + (int64_t)b * a.kvl_batch_stride;
+      else out = static_cast<E*>((a.env == RL4CO_ENV_TSP && blk == 3) ? a.ctx_first : a.ctx_cur) + (int64_t)b * N * kD;
       store_t<TT>(ys, acc, 32 * w, lane);
       rl4co::lds_barrier();
       rows_out<TT>(ys, out, kD, N, tid);  // (a fixed number of stores: the next block's first MFMA waits for its weights only)
@@ -896,9 +901,9 @@ __global__ void __launch_bounds__(kThreads, 2) am_encoder_kernel(const rl4co_am_
       if (blk < 3) {
         out = static_cast<float*>(a.kvl) + (int64_t)blk * a.kvl_plane_stride + (int64_t)b * a.kvl_batch_stride;
       } else if (a.env == RL4CO_ENV_TSP) {
-        out = (blk == 3 ? a.ctx_first : a.ctx_cur) + (int64_t)b * N * kD;
+        out = static_cast<float*>(blk == 3 ? a.ctx_first : a.ctx_cur) + (int64_t)b * N * kD;
       } else {
-        out = a.ctx_cur + (int64_t)b * N * kD;
+        out = static_cast<float*>(a.ctx_cur) + (int64_t)b * N * kD;
       }
       constexpr int kFS = kD + 4;  // fp32 staging row stride: 64 token rows fit the 34 KB of ys
       float* fs = reinterpret_cast<float*>(ys);
@@ -1376,8 +1381,8 @@ __global__ void __launch_bounds__(kThreads, 2) tok16_fold_kernel(const E* __rest
     } else {
       float* out;
       if (blk < 3) out = static_cast<float*>(a.kvl) + (int64_t)blk * a.kvl_plane_stride + (int64_t)b * a.kvl_batch_stride;
-      else if (a.env == RL4CO_ENV_TSP) out = (blk == 3 ? a.ctx_first : a.ctx_cur) + (int64_t)b * N * kD;
-      else out = a.ctx_cur + (int64_t)b * N * kD;
+      else if (a.env == RL4CO_ENV_TSP) out = static_cast<float*>(blk == 3 ? a.ctx_first : a.ctx_cur) + (int64_t)b * N * kD;
+      else out = static_cast<float*>(a.ctx_cur) + (int64_t)b * N * kD;
       out += (int64_t)n0 * kD;
       constexpr int kFS = kD + 4;  // fp32 staging row stride: 64 token rows fit the 34 KB of ys
       float* fs = reinterpret_cast<float*>(ys);
@@ -1646,6 +1651,9 @@ extern "C" int rl4co_am_encoder(const rl4co_am_encoder_args* args, void* stream)
   RL4CO_REQUIRE(a.wqkv_packed && a.wo_packed && a.w1_packed && a.w2_packed && a.wfold_packed);
   RL4CO_REQUIRE(a.bqkv && a.bo && a.b1 && a.b2 && a.n1_scale && a.n1_shift && a.n2_scale && a.n2_shift);
   RL4CO_REQUIRE(a.kvl && a.ctx_cur && (a.env != RL4CO_ENV_TSP || a.ctx_first));
+  // (r06) context tables in the activations' 16-bit type beside 16-bit planes (16-byte rows for the row copies)
+  RL4CO_REQUIRE(a.ctx_dtype == RL4CO_DT_F32 || (a.ctx_dtype == a.act_dtype && a.cache_dtype == a.act_dtype));
+  RL4CO_REQUIRE(a.ctx_dtype == RL4CO_DT_F32 || ((reinterpret_cast<uintptr_t>(a.ctx_cur) | reinterpret_cast<uintptr_t>(a.ctx_first)) & 15) == 0);
   RL4CO_REQUIRE(a.q_bias == nullptr || a.w_fixed != nullptr);
   RL4CO_REQUIRE(a.kvl_batch_stride >= (int64_t)a.N * kD && a.kvl_plane_stride >= a.kvl_batch_stride);
   hipStream_t s = rl4co::as_stream(stream);
@@ -1677,6 +1685,7 @@ extern "C" int rl4co_am_encoder_tokens16(const rl4co_am_encoder_args* args, void
   RL4CO_REQUIRE(a.wqkv_packed && a.wo_packed && a.w1_packed && a.w2_packed && a.wfold_packed);
   RL4CO_REQUIRE(a.bqkv && a.b1 && a.n1_scale && a.n1_shift && a.n2_scale && a.n2_shift);
   RL4CO_REQUIRE(a.kvl && a.ctx_cur && (a.env != RL4CO_ENV_TSP || a.ctx_first));
+  RL4CO_REQUIRE(a.ctx_dtype == RL4CO_DT_F32);  // (the token path's context tables come from the fp32 fold kernel)
   RL4CO_REQUIRE(a.q_bias == nullptr || a.w_fixed != nullptr);
   RL4CO_REQUIRE(a.kvl_batch_stride >= (int64_t)a.N * kD && a.kvl_plane_stride >= a.kvl_batch_stride);
   RL4CO_REQUIRE(workspace != nullptr && workspace_bytes >= rl4co_am_encoder_tokens16_workspace(a.B, a.N));

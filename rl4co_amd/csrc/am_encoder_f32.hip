@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(kThreads) am_encoder_f32_kernel(const rl4co_am
       const int64_t off = (int64_t)blk * a.kvl_plane_stride + (int64_t)b * a.kvl_batch_stride;
       out = plane16 ? static_cast<void*>(static_cast<uint16_t*>(a.kvl) + off) : static_cast<void*>(static_cast<float*>(a.kvl) + off);
     } else {
-      out = ((blk == 3 && a.ctx_first) ? a.ctx_first : a.ctx_cur) + (int64_t)b * N * kD;
+      out = static_cast<float*>((blk == 3 && a.ctx_first) ? a.ctx_first : a.ctx_cur) + (int64_t)b * N * kD;
     }
     fold_block_out<TT>(acc, ys, w, lane, tid, N, out, plane16);
   }
@@ -281,6 +281,7 @@ extern "C" int rl4co_am_encoder_f32(const rl4co_am_encoder_args* args, void* str
   RL4CO_REQUIRE(a.bqkv && a.bo && a.b1 && a.b2 && a.n1_scale && a.n1_shift && a.n2_scale && a.n2_shift);
   RL4CO_REQUIRE(a.kvl != nullptr);
   RL4CO_REQUIRE(a.ctx_first == nullptr || a.ctx_cur != nullptr);  // block order: planes, (ctx_first), (ctx_cur)
+  RL4CO_REQUIRE(a.ctx_dtype == RL4CO_DT_F32);  // the exact kernels write fp32 context tables
   RL4CO_REQUIRE(a.q_bias == nullptr || a.w_fixed != nullptr);
   RL4CO_REQUIRE(a.kvl_batch_stride >= (int64_t)a.N * kD && a.kvl_plane_stride >= a.kvl_batch_stride);
   hipStream_t s = rl4co::as_stream(stream);

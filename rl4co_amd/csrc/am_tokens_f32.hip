@@ -534,6 +534,7 @@ extern "C" int rl4co_am_encoder_tokens_f32(const rl4co_am_encoder_args* args, vo
   RL4CO_REQUIRE(a.bqkv && a.bo && a.b1 && a.b2 && a.n1_scale && a.n1_shift && a.n2_scale && a.n2_shift);
   RL4CO_REQUIRE(a.kvl != nullptr);
   RL4CO_REQUIRE(a.ctx_first == nullptr || a.ctx_cur != nullptr);
+  RL4CO_REQUIRE(a.ctx_dtype == RL4CO_DT_F32);
   RL4CO_REQUIRE(a.q_bias == nullptr || a.w_fixed != nullptr);
   RL4CO_REQUIRE(a.kvl_batch_stride >= (int64_t)a.N * kD && a.kvl_plane_stride >= a.kvl_batch_stride);
   RL4CO_REQUIRE(workspace != nullptr && workspace_bytes >= workspace_floats(a.B, a.N) * 4);

@@ -13,6 +13,7 @@ Inference only; training goes through ``train_ops`` (autograd around the HIP ker
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 from torch import Tensor
@@ -28,7 +29,7 @@ class AmEncoderArgs(C.Structure):
 
     _fields_ = [
         ("env", _i32), ("B", _i32), ("N", _i32), ("num_layers", _i32), ("norm", _i32), ("cache_dtype", _i32),
-        ("act_dtype", _i32), ("reserved0", _i32),
+        ("act_dtype", _i32), ("ctx_dtype", _i32),
         ("locs", _vp), ("demand", _vp), ("feature4", _vp), ("feature5", _vp), ("feature6", _vp), ("w_init", _vp), ("b_init", _vp), ("w_depot", _vp), ("b_depot", _vp), ("w_extra", _vp), ("b_extra", _vp),
         ("wqkv_packed", _vp), ("bqkv", _vp), ("wo_packed", _vp), ("bo", _vp), ("n1_scale", _vp), ("n1_shift", _vp),
         ("w1_packed", _vp), ("b1", _vp), ("w2_packed", _vp), ("b2", _vp), ("n2_scale", _vp), ("n2_shift", _vp),
@@ -255,14 +256,23 @@ class PackedEncoder:
         dev = locs.device
         d = EMBED_DIM
         kvl = torch.empty((3, b, n, d), dtype=cache_dtype, device=dev)
-        ctx_cur = torch.empty((b, n, d), dtype=torch.float32, device=dev) if fold else None
-        ctx_first = torch.empty((b, n, d), dtype=torch.float32, device=dev) if (fold and pol.env_name == "tsp") else None
+        if tokens is None:
+            tokens = n > _lib.lib().rl4co_am_encoder_max_nodes()
+        # (r06) 16-bit regime, fused kernel, 16-bit planes: the context tables leave in the activations' type too — the decode
+        # kernels widen the rows on load (FoldedCache.ctx_* may then be 16-bit; kernels._ctx_table). The fold is bound by its
+        # HBM writes: 179 -> 128 KB per instance at TSP-100. RL4CO_CTX_FP32=1 keeps the fp32 tables of r05 (A/B timing).
+        ctx_dt = torch.float32
+        if not exact and not tokens and cache_dtype == self.act_dtype and not os.environ.get("RL4CO_CTX_FP32"):
+            ctx_dt = self.act_dtype
+        ctx_cur = torch.empty((b, n, d), dtype=ctx_dt, device=dev) if fold else None
+        ctx_first = torch.empty((b, n, d), dtype=ctx_dt, device=dev) if (fold and pol.env_name == "tsp") else None
         q_bias = torch.empty((b, d), dtype=torch.float32, device=dev) if t["w_fixed"] is not None else None
         hidden = torch.empty((b, n, d), dtype=torch.float32, device=dev) if (want_hidden or not fold) else None
         a = AmEncoderArgs()
         a.env = {"tsp": _lib.ENV_TSP, "pdp": _lib.ENV_PDP}.get(pol.env_name, _lib.ENV_CVRP)
         a.B, a.N, a.num_layers, a.norm = b, n, self.num_layers, self.norm_kind
         a.cache_dtype, a.act_dtype = _lib.dtype_id(cache_dtype), _lib.dtype_id(self.act_dtype)
+        a.ctx_dtype = _lib.dtype_id(ctx_dt) if ctx_dt != torch.float32 else 0
         a.locs = locs.data_ptr()
         ptr = lambda x: None if x is None else x.data_ptr()  # noqa: E731
         if pol.env_name in ("cvrp", "op", "pctsp", "cvrptw"):
@@ -290,8 +300,6 @@ class PackedEncoder:
         a.wfold_packed, a.w_fixed = ptr(t["wfold"] if fold else t["wnode"]), ptr(t["w_fixed"])
         a.kvl, a.kvl_plane_stride, a.kvl_batch_stride = kvl.data_ptr(), kvl.stride(0), kvl.stride(1)
         a.ctx_first, a.ctx_cur, a.q_bias, a.hidden = ptr(ctx_first), ptr(ctx_cur), ptr(q_bias), ptr(hidden)
-        if tokens is None:
-            tokens = n > _lib.lib().rl4co_am_encoder_max_nodes()
         if tokens:
             entry = "rl4co_am_encoder_tokens_f32" if exact else "rl4co_am_encoder_tokens16"
             need = getattr(_lib.lib(), entry + "_workspace")(b, n)
