@@ -124,13 +124,13 @@ def algorithmic_bytes_per_instance_step(env_name: str, n: int, elem: int) -> int
     return 3 * n * d * elem + 2 * n + ctx + d * 4 + 16
 
 
-def must_move_bytes(env_name: str, n: int, elem: int, rows_read: int, instance_steps: int, trajectories: int) -> int:
+def must_move_bytes(env_name: str, n: int, elem: int, rows_read: int, instance_steps: int, trajectories: int, ctx_elem: int = 4) -> int:
     """Bytes one decode launch has to move through HBM given what it actually visits: `rows_read` cache rows per
-    plane (counted in-kernel: the feasible rows of every step), per step the gathered fp32 context rows (TSP two,
+    plane (counted in-kernel: the feasible rows of every step), per step the gathered context rows (TSP two,
     CVRP one + the load scalar) and the action / log-prob it stores, per trajectory its mask in and out, graph
     context and state words (the mask lives in LDS between entry and exit)."""
     d = 128
-    per_step = (2 * d * 4 if env_name == "tsp" else d * 4 + 8) + 12
+    per_step = (2 * d * ctx_elem if env_name == "tsp" else d * ctx_elem + 8) + 12  # (r06: 16-bit context rows beside 16-bit planes)
     per_traj = 2 * n + d * 4 + 64
     return rows_read * 3 * d * elem + instance_steps * per_step + trajectories * per_traj
 
@@ -568,7 +568,8 @@ class Bench:
                 res["scaling_efficiency"] = solo_ms / (wall / steps * 1e3)
         mean_decode_ms = sum(decode_ms) / len(decode_ms)
         per_launch_rows, per_launch_steps = rows / steps, inst_steps / steps
-        need = must_move_bytes(env_name, n_nodes, elem, per_launch_rows, per_launch_steps, batch)
+        need = must_move_bytes(env_name, n_nodes, elem, per_launch_rows, per_launch_steps, batch,
+                               ctx_elem=int(getattr(policy, "last_ctx_elem_bytes", 4)))
         contract = algorithmic_bytes_per_instance_step(env_name, n_nodes, elem) * per_launch_steps
         achieved = need / (mean_decode_ms * 1e-3) / 1e9
         traffic, traffic_source = self.traffic(leg)

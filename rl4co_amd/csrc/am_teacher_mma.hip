@@ -576,7 +576,8 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
       for (int col = tid; col < ncols; col += kThreads) {
         const uint32_t f = scol[col];
         bool late = false;
-        if ((f & 0x03000000u) == 0x01000000u) {  // valid, not step 0: the column scatters
+        // (only a column of the block's SECOND trajectory can be late: the scan is skipped for all the others)
+        if ((f & 0x03000000u) == 0x01000000u && ((scol[col & ~15] ^ f) & 0x7c000000u) != 0) {  // valid, not step 0: the column scatters
           for (int c2 = col & ~15; c2 < col; ++c2) {
             const uint32_t f2 = scol[c2];  // other scatters, other slot, same current node
             late |= (f2 & 0x03000000u) == 0x01000000u && ((f2 ^ f) & 0x7c000000u) != 0 && ((f2 ^ f) & 0x0000ff00u) == 0;
@@ -992,7 +993,10 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int i = tid + kThreads * j, row = min(i >> 5, N - 1), c4 = (i & 31) * 4;
-      v[j] = load4_l2(dcc + (int64_t)row * kD + c4);
+      // (TSP: these sums were built by this CU's own plain read-modify-writes — a plain 16-byte load sees them exactly as
+      // the read-modify-write of the next trajectory did; the depot environments add with L2 atomics: read through L2)
+      if (ENV == RL4CO_ENV_TSP) v[j] = *reinterpret_cast<const float4*>(dcc + (int64_t)row * kD + c4);
+      else v[j] = load4_l2(dcc + (int64_t)row * kD + c4);
     }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {

@@ -673,15 +673,11 @@ class AttentionModelPolicy(nn.Module):
                 self._ambient_autocast = None
         return self._forward(td, *args, **kwargs)
 
-    def _forward(self, td: TensorDict, env: str | RL4COEnvBase | None = None, phase: str = "train",
-                 calc_reward: bool = True, return_actions: bool = True, return_entropy: bool = False,
-                 return_hidden: bool = False, return_init_embeds: bool = False,
-                 return_sum_log_likelihood: bool = True, actions: Tensor | None = None,
-                 max_steps: int = 1_000_000, **decoding_kwargs) -> dict:
-        grad_path = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if not self.fold and grad_path:
-            raise NotImplementedError("fold=False is the inference parity configuration; train with the folded cache")
-        cache_dtype = self._plane_dtype(grad_path)
+    def _encode_for_rollout(self, td: TensorDict, grad_path: bool, cache_dtype, return_hidden: bool, return_init_embeds: bool):
+        """Step 1 of ``_forward`` (constructive/base.py:196-204): (cache | None, hidden | None, init_embeds | None). Inference:
+        the fused kernels (16-bit regimes and exact fp32, N <= 128) return the folded cache itself; the token-tile kernels
+        (N > 128) and the torch modules (training: autograd) return the node embeddings for the fold that follows."""
+        init_embeds = None
         regime16 = self._encoder_regime() if self._encoder_regime() in (torch.bfloat16, torch.float16) else None
         # fused MFMA encoder: a 16-bit autocast regime (bf16, or fp16 = the reference's default "16-mixed") whose planes
         # are fp32 or that same 16-bit type
@@ -730,8 +726,12 @@ class AttentionModelPolicy(nn.Module):
                                      "the fused MFMA encoder (up to 128 nodes) and the token-tile kernels (beyond) serve bf16 / fp16 with the "
                                      "folded cache and planes in fp32 or the activations' type")
                 hidden, init_embeds = self._encode(td)
-        if isinstance(env, str) or env is None:
-            env = get_env(self.env_name if env is None else env)
+        return cache, hidden, init_embeds
+
+    def _parse_decoding(self, td: TensorDict, env, phase: str, actions, decoding_kwargs: dict):
+        """Step 2 of ``_forward``: the decoding arguments (utils/decoding.py:238-255, get_decoding_strategy / DecodingStrategy
+        .__init__) as a namespace; pops what it consumes from ``decoding_kwargs`` (``philox_seed_dev`` / ``_defer_finish`` stay)."""
+        from types import SimpleNamespace
 
         decode_type = decoding_kwargs.pop("decode_type", None)
         if actions is not None:
@@ -745,7 +745,7 @@ class AttentionModelPolicy(nn.Module):
         # (not a reference argument) hand the [B, T, N] log-softmax of every step back as out["all_logp"]: the parity
         # tests and bench.py's parity block measure argmax regret / per-step agreement along a forced trajectory with it
         return_all_logp = bool(decoding_kwargs.pop("return_all_logp", False))
-        store_all_logp = decoding_kwargs.pop("store_all_logp", return_entropy) or return_all_logp
+        store_all_logp = bool(decoding_kwargs.pop("store_all_logp", False)) or return_all_logp
         select_best = decoding_kwargs.pop("select_best", False)
         num_starts = decoding_kwargs.pop("num_starts", None)
         num_samples = decoding_kwargs.pop("num_samples", None)
@@ -776,6 +776,30 @@ class AttentionModelPolicy(nn.Module):
         else:
             n_rep = 0
 
+        return SimpleNamespace(mode=mode, multistart=multistart, n_rep=n_rep, temperature=temperature, tanh_clipping=tanh_clipping,
+                               mask_logits=mask_logits, return_all_logp=return_all_logp, store_all_logp=store_all_logp,
+                               select_best=select_best, exp_noise=exp_noise, seed=seed, select_start_nodes_fn=select_start_nodes_fn)
+
+    def _forward(self, td: TensorDict, env: str | RL4COEnvBase | None = None, phase: str = "train",
+                 calc_reward: bool = True, return_actions: bool = True, return_entropy: bool = False,
+                 return_hidden: bool = False, return_init_embeds: bool = False,
+                 return_sum_log_likelihood: bool = True, actions: Tensor | None = None,
+                 max_steps: int = 1_000_000, **decoding_kwargs) -> dict:
+        grad_path = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if not self.fold and grad_path:
+            raise NotImplementedError("fold=False is the inference parity configuration; train with the folded cache")
+        cache_dtype = self._plane_dtype(grad_path)
+        # 1. encoder (+ the cache fold where the fused kernels produce it)
+        cache, hidden, init_embeds = self._encode_for_rollout(td, grad_path, cache_dtype, return_hidden, return_init_embeds)
+        if isinstance(env, str) or env is None:
+            env = get_env(self.env_name if env is None else env)
+        # 2. decoding arguments, in the reference's order of precedence
+        opt = self._parse_decoding(td, env, phase, actions, decoding_kwargs)
+        mode, multistart, n_rep = opt.mode, opt.multistart, opt.n_rep
+        temperature, tanh_clipping, mask_logits = opt.temperature, opt.tanh_clipping, opt.mask_logits
+        return_all_logp, store_all_logp, select_best = opt.return_all_logp, opt.store_all_logp or return_entropy, opt.select_best
+        exp_noise, seed, select_start_nodes_fn = opt.exp_noise, opt.seed, opt.select_start_nodes_fn
+
         device = td["action_mask"].device
         b_inst, n = td["action_mask"].shape[0], td["action_mask"].shape[-1]
         b = b_inst * max(n_rep, 1)
@@ -797,6 +821,8 @@ class AttentionModelPolicy(nn.Module):
                 cache = self.decoder.precompute_cache(hidden.detach(), cache_dtype,
                                                       torch.bfloat16 if (regime == torch.bfloat16 and cache_dtype != torch.float16)
                                                       else torch.float32, fold=self.fold)
+        # (bench.py's byte model: the context rows a decode step gathers are fp32 or, r06, the planes' 16-bit type)
+        self.last_ctx_elem_bytes = cache.ctx_cur.element_size() if cache.ctx_cur is not None else 4
         state = self._initial_state(td, n_rep)
         horizon = min(self._max_horizon(self.env_name, n), max_steps)
         if self.env_name == "pdp" and not getattr(env, "force_start_at_depot", False):
@@ -880,109 +906,151 @@ class AttentionModelPolicy(nn.Module):
         defer = bool(decoding_kwargs.pop("_defer_finish", False))
         launched = (out_actions, logps, all_logps, td_early, reward_early)
 
-        def finish():
-            nonlocal out_actions, logps, all_logps, td_early, reward_early
-            out_actions, logps, all_logps, td_early, reward_early = launched  # re-runnable: a graph replay refills the same buffers
-            err_bits, _, horizon_used, streamed, rows_lo, rows_hi = status.tolist()  # one 24-byte read-back, no reduction launches
-            rows_read = (rows_hi << 32) | (rows_lo & 0xFFFFFFFF)
-            t_used = t0 + int(horizon_used)
-            self.last_instance_steps = int(streamed)  # instance-steps the decode launch really streamed
-            self.last_rows_read = int(rows_read)      # cache rows (per plane) it read from HBM doing so
-            from . import _lib as _l
+        from types import SimpleNamespace
 
-            _l.raise_for_error_bits(int(err_bits))
-            out_actions = out_actions[:, :t_used].contiguous()
-            logps = logps[:, :t_used]
-            if all_logps is not None:
-                all_logps = all_logps[:, :t_used]
+        r = SimpleNamespace(
+            launched=launched, status=status, t0=t0, td=td, env=env, state=state, n_rep=n_rep, b_inst=b_inst, n=n,
+            device=device, grad_path=grad_path, cache_g=cache_g, cache=cache, cache_dtype=cache_dtype, hidden=hidden,
+            init_embeds=init_embeds, mask_logits=mask_logits, tanh_clipping=tanh_clipping, temperature=temperature,
+            return_entropy=return_entropy, select_best=select_best, calc_reward=calc_reward, checked=checked,
+            return_sum_log_likelihood=return_sum_log_likelihood, return_actions=return_actions,
+            return_all_logp=return_all_logp, return_hidden=return_hidden, return_init_embeds=return_init_embeds,
+        )
+        if defer:
+            return lambda: self._finish_rollout(r)
+        return self._finish_rollout(r)
 
-            # td mirrors the reference's final state (batchified rows when multistart)
-            td_out = td_early if td_early is not None else self._final_td(td, state, n_rep)
-            td_out.set("action", out_actions[:, -1])
+    def _finish_rollout(self, r) -> dict:
+        """Step 4 of ``_forward``: the rollout's ONE host read-back (status words), the reference's assertions, the
+        differentiable re-evaluation of a training step, best-of selection, reward and the output dict (constructive/base.py:
+        240-263). Re-runnable: ``graph.GraphedRollout`` calls it after every replay of the captured launches — it only reads
+        the buffers they wrote (``r``: what ``_forward`` enqueued)."""
+        out_actions, logps, all_logps, td_early, reward_early = r.launched  # re-runnable: a graph replay refills the same buffers
+        status = r.status
+        t0 = r.t0
+        td = r.td
+        env = r.env
+        state = r.state
+        n_rep = r.n_rep
+        b_inst = r.b_inst
+        n = r.n
+        device = r.device
+        grad_path = r.grad_path
+        cache_g = r.cache_g
+        cache = r.cache
+        cache_dtype = r.cache_dtype
+        hidden = r.hidden
+        init_embeds = r.init_embeds
+        mask_logits = r.mask_logits
+        tanh_clipping = r.tanh_clipping
+        temperature = r.temperature
+        return_entropy = r.return_entropy
+        select_best = r.select_best
+        calc_reward = r.calc_reward
+        checked = r.checked
+        return_sum_log_likelihood = r.return_sum_log_likelihood
+        return_actions = r.return_actions
+        return_all_logp = r.return_all_logp
+        return_hidden = r.return_hidden
+        return_init_embeds = r.return_init_embeds
+        err_bits, _, horizon_used, streamed, rows_lo, rows_hi = status.tolist()  # one 24-byte read-back, no reduction launches
+        rows_read = (rows_hi << 32) | (rows_lo & 0xFFFFFFFF)
+        t_used = t0 + int(horizon_used)
+        self.last_instance_steps = int(streamed)  # instance-steps the decode launch really streamed
+        self.last_rows_read = int(rows_read)      # cache rows (per plane) it read from HBM doing so
+        from . import _lib as _l
 
-            # differentiable re-evaluation of the ROLLED-OUT rows (all s * b_inst of them: the replay needs the imposed
-            # start nodes and the batchified state) — before any best-of selection narrows the rows
-            full_logp = None  # [B, T, N] differentiable log-softmax, only when a differentiable entropy is asked for
-            if grad_path and cache_g is not None:
-                from . import teacher
+        _l.raise_for_error_bits(int(err_bits))
+        out_actions = out_actions[:, :t_used].contiguous()
+        logps = logps[:, :t_used]
+        if all_logps is not None:
+            all_logps = all_logps[:, :t_used]
 
-                if self._bwd_err is None or self._bwd_err.device != device:
-                    self._bwd_err = torch.zeros(1, dtype=torch.int32, device=device)
-                meta = dict(t0=t0, mask_inner=self.decoder.mask_inner, mask_logits=mask_logits, err_sink=self._bwd_err,
-                            tanh_clipping=tanh_clipping, temperature=temperature, teacher_variant=self.teacher_variant)
-                if self.env_name in ("cvrp", "cvrptw"):
-                    meta.update(demand=td["demand"], vehicle_capacity=td["vehicle_capacity"])
-                    if self.env_name == "cvrptw":
-                        meta.update(locs=td["locs"], time_windows=td["time_windows"], durations=td["durations"])
-                elif self.env_name == "op":
-                    meta.update(locs=td["locs"], max_length=td["max_length"])
-                elif self.env_name == "pctsp":
-                    meta.update(real_prize=td["real_prize"], prize_required=td["prize_required"])
-                step_logps = teacher.teacher_forced_logps(self.env_name, cache_g, cache, out_actions, logps, meta)
-            elif grad_path:
-                if hidden.is_cuda and self.fused_backward and not return_entropy:
-                    from . import _lib as _l
+        # td mirrors the reference's final state (batchified rows when multistart)
+        td_out = td_early if td_early is not None else self._final_td(td, state, n_rep)
+        td_out.set("action", out_actions[:, -1])
 
-                    t_max = __import__("rl4co_amd.teacher", fromlist=["max_nodes"]).max_nodes()
-                    why = (f"{n} nodes are beyond the kernels' limit ({t_max})" if n > t_max else
-                           f"{cache_dtype} planes are not served by the backward kernels (float32, bfloat16 or float16 planes) for this call")
-                    _l.warn_fallback(f"teacher/{self.env_name}/{n}/{cache_dtype}",
-                                     f"teacher-forced backward for {self.env_name}: {why} — dense torch re-evaluation with autograd")
-                step_logps = self.evaluate_log_probs(td, hidden, out_actions, n_rep, tanh_clipping, temperature,
-                                                     mask_logits, skip_first=(t0 == 1), return_full=return_entropy)
-                if return_entropy:
-                    step_logps, full_logp = step_logps
-            else:
-                step_logps = logps
+        # differentiable re-evaluation of the ROLLED-OUT rows (all s * b_inst of them: the replay needs the imposed
+        # start nodes and the batchified state) — before any best-of selection narrows the rows
+        full_logp = None  # [B, T, N] differentiable log-softmax, only when a differentiable entropy is asked for
+        if grad_path and cache_g is not None:
+            from . import teacher
 
-            if n_rep > 0 and select_best:
-                rewards = env.get_reward(td_out, out_actions)
-                best = rewards.view(n_rep, b_inst).transpose(0, 1).max(dim=-1)[1]  # unbatchify + max
-                rows = best * b_inst + torch.arange(b_inst, device=device)
-                out_actions, logps, step_logps = out_actions[rows], logps[rows], step_logps[rows]
-                if all_logps is not None:
-                    all_logps = all_logps[rows]
-                if full_logp is not None:
-                    full_logp = full_logp[rows]
-                td_out = td_out[rows] if hasattr(td_out, "__getitem__") else td_out
-                reward = rewards[rows] if calc_reward else None
-            elif reward_early is not None:
-                reward = reward_early
-            else:
-                reward = (env.get_reward(td_out, out_actions, check_solution=False if checked else None)
-                          if calc_reward else td_out.get("reward", None))
-            if calc_reward:
-                td_out.set("reward", reward)
-            # decoding.py:56: on the kernel path this is the RL4CO_EBIT_NEG_INF_LOGP sticky bit (already
-            # raised above); only the autograd re-evaluation needs its own check
-            if grad_path and not bool((step_logps.detach() > -1000).all()):
-                raise AssertionError("Logprobs should not be -inf, check sampling procedure!")
-            outdict = {
-                "reward": reward,
-                "log_likelihood": step_logps.sum(1) if return_sum_log_likelihood else step_logps,
-            }
-            if return_actions:
-                outdict["actions"] = out_actions
+            if self._bwd_err is None or self._bwd_err.device != device:
+                self._bwd_err = torch.zeros(1, dtype=torch.int32, device=device)
+            meta = dict(t0=t0, mask_inner=self.decoder.mask_inner, mask_logits=mask_logits, err_sink=self._bwd_err,
+                        tanh_clipping=tanh_clipping, temperature=temperature, teacher_variant=self.teacher_variant)
+            if self.env_name in ("cvrp", "cvrptw"):
+                meta.update(demand=td["demand"], vehicle_capacity=td["vehicle_capacity"])
+                if self.env_name == "cvrptw":
+                    meta.update(locs=td["locs"], time_windows=td["time_windows"], durations=td["durations"])
+            elif self.env_name == "op":
+                meta.update(locs=td["locs"], max_length=td["max_length"])
+            elif self.env_name == "pctsp":
+                meta.update(real_prize=td["real_prize"], prize_required=td["prize_required"])
+            step_logps = teacher.teacher_forced_logps(self.env_name, cache_g, cache, out_actions, logps, meta)
+        elif grad_path:
+            if hidden.is_cuda and self.fused_backward and not return_entropy:
+                from . import _lib as _l
+
+                t_max = __import__("rl4co_amd.teacher", fromlist=["max_nodes"]).max_nodes()
+                why = (f"{n} nodes are beyond the kernels' limit ({t_max})" if n > t_max else
+                       f"{cache_dtype} planes are not served by the backward kernels (float32, bfloat16 or float16 planes) for this call")
+                _l.warn_fallback(f"teacher/{self.env_name}/{n}/{cache_dtype}",
+                                 f"teacher-forced backward for {self.env_name}: {why} — dense torch re-evaluation with autograd")
+            step_logps = self.evaluate_log_probs(td, hidden, out_actions, n_rep, tanh_clipping, temperature,
+                                                 mask_logits, skip_first=(t0 == 1), return_full=return_entropy)
             if return_entropy:
-                # ops.py:103-111 on the [B, T, N] log-probs. Under autograd the reference's entropy carries history (PPO's
-                # entropy bonus differentiates it): then it is built from the differentiable log-softmax of the
-                # re-evaluation, not from the kernel's (history-free) all_logps; the imposed multistart step has p = 1
-                lp_src = all_logps
-                if full_logp is not None:
-                    lp_src = full_logp if t0 == 0 else torch.cat([all_logps[:, :1], full_logp[:, 1:]], 1)
-                lp = torch.nan_to_num(lp_src, nan=0.0)
-                entropy = -(lp.exp() * lp).sum(dim=-1).sum(dim=1)
-                assert entropy.isfinite().all(), "Entropy is not finite"
-                outdict["entropy"] = entropy
-            if return_all_logp:
-                outdict["all_logp"] = all_logps
-            if return_hidden:
-                outdict["hidden"] = hidden
-            if return_init_embeds:
-                outdict["init_embeds"] = init_embeds
-            return outdict
+                step_logps, full_logp = step_logps
+        else:
+            step_logps = logps
 
-        return finish if defer else finish()
+        if n_rep > 0 and select_best:
+            rewards = env.get_reward(td_out, out_actions)
+            best = rewards.view(n_rep, b_inst).transpose(0, 1).max(dim=-1)[1]  # unbatchify + max
+            rows = best * b_inst + torch.arange(b_inst, device=device)
+            out_actions, logps, step_logps = out_actions[rows], logps[rows], step_logps[rows]
+            if all_logps is not None:
+                all_logps = all_logps[rows]
+            if full_logp is not None:
+                full_logp = full_logp[rows]
+            td_out = td_out[rows] if hasattr(td_out, "__getitem__") else td_out
+            reward = rewards[rows] if calc_reward else None
+        elif reward_early is not None:
+            reward = reward_early
+        else:
+            reward = (env.get_reward(td_out, out_actions, check_solution=False if checked else None)
+                      if calc_reward else td_out.get("reward", None))
+        if calc_reward:
+            td_out.set("reward", reward)
+        # decoding.py:56: on the kernel path this is the RL4CO_EBIT_NEG_INF_LOGP sticky bit (already
+        # raised above); only the autograd re-evaluation needs its own check
+        if grad_path and not bool((step_logps.detach() > -1000).all()):
+            raise AssertionError("Logprobs should not be -inf, check sampling procedure!")
+        outdict = {
+            "reward": reward,
+            "log_likelihood": step_logps.sum(1) if return_sum_log_likelihood else step_logps,
+        }
+        if return_actions:
+            outdict["actions"] = out_actions
+        if return_entropy:
+            # ops.py:103-111 on the [B, T, N] log-probs. Under autograd the reference's entropy carries history (PPO's
+            # entropy bonus differentiates it): then it is built from the differentiable log-softmax of the
+            # re-evaluation, not from the kernel's (history-free) all_logps; the imposed multistart step has p = 1
+            lp_src = all_logps
+            if full_logp is not None:
+                lp_src = full_logp if t0 == 0 else torch.cat([all_logps[:, :1], full_logp[:, 1:]], 1)
+            lp = torch.nan_to_num(lp_src, nan=0.0)
+            entropy = -(lp.exp() * lp).sum(dim=-1).sum(dim=1)
+            assert entropy.isfinite().all(), "Entropy is not finite"
+            outdict["entropy"] = entropy
+        if return_all_logp:
+            outdict["all_logp"] = all_logps
+        if return_hidden:
+            outdict["hidden"] = hidden
+        if return_init_embeds:
+            outdict["init_embeds"] = init_embeds
+        return outdict
 
     def check_backward_errors(self) -> None:
         """Raise the reference's assertion for any sticky bit the LAST teacher-forced backward kernel set (a sync).

@@ -12,11 +12,11 @@ cd /tmp
 for LEG in $LEGS; do
   O=$R/gpurun_out/$TAG/$LEG
   mkdir -p $O
-  ARGS="--legs $LEG --steps 10 --warmup 2 --no-cpu-baseline --no-parity --launch eager"
+  ARGS="--legs $LEG --steps 10 --warmup 2 --no-cpu-baseline --no-parity --no-large-batch --launch eager"
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python $R/bench.py $ARGS > $O/bench_trace.json 2> $O/bench_trace.err
   if [ -n "$PMC" ] && [ "$LEG" != "c4_train" ]; then
-    timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --legs $LEG --steps 3 --warmup 1 --no-cpu-baseline --no-parity --launch eager > $O/bench_pmc_fetch.json 2> $O/bench_pmc_fetch.err
-    timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --legs $LEG --steps 3 --warmup 1 --no-cpu-baseline --no-parity --launch eager > $O/bench_pmc_write.json 2> $O/bench_pmc_write.err
+    timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -- python $R/bench.py --legs $LEG --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-large-batch --launch eager > $O/bench_pmc_fetch.json 2> $O/bench_pmc_fetch.err
+    timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -- python $R/bench.py --legs $LEG --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-large-batch --launch eager > $O/bench_pmc_write.json 2> $O/bench_pmc_write.err
   fi
   # keep only the small summaries (the per-dispatch traces are tens of MB); the counter files lose the ~25 000 dispatches of
   # bench.py's one-second warm-up (hbm_read_probe_kernel) except the last ten — the 2 GiB calibration launches

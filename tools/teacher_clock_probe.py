@@ -21,7 +21,7 @@ SRC = os.path.join(ROOT, "rl4co_amd", "csrc")
 OUT = os.path.join(ROOT, "tools", "probes", "bin")
 
 SEGMENTS = ["0 query", "1 scores+softmax", "2 glimpse", "B1 wait", "3 logits+lse pieces", "B2 wait", "3b lse + d logits", "B3 wait",
-            "4 dO, dKl", "5 softmax bwd, dV, dS, dQ, dKg", "6 ctx atomics", "B4 wait", "trajectory setup"]
+            "4 dO, dKl", "5 softmax bwd, dV, dS, dQ, dKg", "6 ctx atomics", "B4 wait", "group setup (tables of <= 4 trajectories)"]
 
 # (unique anchor in the source, clock index, insert "before" or "after" the anchor line)
 MARKS = [
@@ -79,15 +79,15 @@ def variant_source(kind="clk") -> str:
     s = s.replace("namespace {\n\nconstexpr int kD", PRELUDE + "\nnamespace {\n\nconstexpr int kD", 1)
     assert "g_clk" in s
     # the running timestamp: scalar, starts at the top of every trajectory
-    anchor = "  for (int s = 0; s < S; ++s) {\n"
+    anchor = "  for (int s0 = 0; s0 < S; s0 += G) {\n"
     assert s.count(anchor) == 1
     s = s.replace(anchor, "  __shared__ unsigned long long s_clk[8][16];\n  if (tid < 128) s_clk[tid >> 4][tid & 15] = 0;\n  __syncthreads();\n"
                   "  long long _last = __builtin_readcyclecounter();\n" + anchor)
     # LDS accumulators (ds_add_u64, fire and forget) flushed once per workgroup: global atomics per segment would stall every
     # s_waitcnt vmcnt of the block loop behind them
-    tail = "  if (errbits) atomicOr(a.err, (int)errbits);\n}"
+    tail = "  if (errbits) atomicOr(a.err, (int)errbits);\n"
     assert s.count(tail) == 1
-    s = s.replace(tail, "  if (errbits) atomicOr(a.err, (int)errbits);\n  __syncthreads();\n  if (tid < 128) atomicAdd(&g_clk[tid >> 4][tid & 15], s_clk[tid >> 4][tid & 15]);\n}")
+    s = s.replace(tail, "  __syncthreads();\n  if (tid < 128) atomicAdd(&g_clk[tid >> 4][tid & 15], s_clk[tid >> 4][tid & 15]);\n" + tail)
     return s
 
 
