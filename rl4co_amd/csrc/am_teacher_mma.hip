@@ -119,8 +119,9 @@ __host__ __device__ inline Layout make_layout(int nt, int env) {
   L.stime = o; o += env == RL4CO_ENV_CVRPTW ? mcp * 4 : 0;
   o = (o + 15) & ~15;
   L.smask = o; o += mcp * 16;
-  L.sraw = o; o += kMaxT;       // the trajectory under set-up: its T actions
-  L.spos = o; o += 128 * 4;     // ... and the first column that visits node j
+  const int nq = nt <= 7 ? 4 : 1;   // trajectories tabulated at once (eight node tiles leave no LDS for more than one)
+  L.sraw = o; o += nq * kMaxT;      // the trajectories under set-up: their T actions
+  L.spos = o; o += nq * 128 * 4;    // ... and the first column that visits node j
   L.xz = o; o += kWaves * 16 * 2 * 4;
   L.xa = o; o += 16 * 4;
   L.sinfo = o; o += 16;
@@ -375,182 +376,212 @@ __global__ void __launch_bounds__(kThreads, 2) am_teacher_mma_kernel(const rl4co
 
     // ---- column tables of this group (the environment of each trajectory replayed in closed form) -----------------
     int base = 0;  // packed columns so far (identical in every thread)
-    for (int k = 0; k < gsz; ++k) {
-      const int r = (s0 + k) * a.B_inst + inst;
-      // sraw[t]: action; spos[j]: first column that visits node j (tsp/env.py:60-86, cvrp/env.py:66-96)
-      if (tid < kMaxT) {
-        int at = 0;
-        if (tid < T) {
-          if (L.npre > 0) {
-            at = snact[k * T + tid];
-          } else {
-            const int raw = (int)a.actions[(int64_t)r * T + tid];
-            at = (raw < 0 || raw >= N) ? 255 : raw;
-          }
-          if (at == 255) {
-            errbits |= RL4CO_EBIT_INFEASIBLE;
-            at = 0;
-          }
-        }
-        sraw[tid] = at;
-      }
-      for (int j = tid; j < 128; j += kThreads) spos[j] = 0x7fffffff;
-      __syncthreads();
-      for (int t = tid; t < T; t += kThreads) atomicMin(&spos[sraw[t]], t);
-      __syncthreads();
-      if (tid == 0) {
-        int t_end = T;
-        if (kCvrpLike) {  // done once every node (depot included) has been visited (cvrp/env.py:80-83)
-          int last = 0;
-          for (int j = 0; j < N; ++j) last = max(last, spos[j]);
-          if (last != 0x7fffffff) t_end = min(T, last + 1);
-        }
-        if (ENV == RL4CO_ENV_OP || ENV == RL4CO_ENV_PCTSP) {  // done at the first return to the depot after step 0 (op/env.py:84, pctsp/env.py:73)
-          for (int t = 1; t < T; ++t)
-            if (sraw[t] == 0) {
-              t_end = t + 1;
-              break;
+    // Up to FOUR trajectories are tabulated at once (N <= 112), one per quarter of the workgroup (128 threads = two waves): one after
+    // the other (the first r06 form) the set-up was 7 % of the launch — four barriers and as many dependent LDS round
+    // trips per trajectory, 32 of them per instance (profiles/r06_teacher_phase_clocks.json).
+    constexpr int kNQ = NT <= 7 ? 4 : 1;  // (make_layout: nq)
+    constexpr int kQuarter = kThreads / kNQ;
+    const int qd = tid / kQuarter, tq = tid - qd * kQuarter;
+    uint8_t* srq = sraw + qd * kMaxT;
+    int* spq = spos + qd * 128;
+    for (int k0 = 0; k0 < gsz; k0 += kNQ) {
+      const int k = k0 + qd;
+      const bool active = k < gsz;
+      const int r = (s0 + (active ? k : k0)) * a.B_inst + inst;
+      // srq[t]: action; spq[j]: first column that visits node j (tsp/env.py:60-86, cvrp/env.py:66-96)
+      if (active) {
+        for (int tt = tq; tt < kMaxT; tt += kQuarter) {
+          int at = 0;
+          if (tt < T) {
+            if (L.npre > 0) {
+              at = snact[k * T + tt];
+            } else {
+              const int raw = (int)a.actions[(int64_t)r * T + tt];
+              at = (raw < 0 || raw >= N) ? 255 : raw;
             }
-        }
-        sinfo[0] = t_end;
-      }
-      // per-column scalars BEFORE column t, written at the column's packed place base + t - t0 (columns past the
-      // trajectory's end land in the next trajectory's range and are overwritten by its own set-up / the dead fill)
-      if (kClock) {
-        // the clock, replayed in visiting order: advance by the distance, wait for the window, serve;
-        // back at the depot it restarts (cvrptw/env.py:97-113, same fp32 sequence as the decode kernel)
-        for (int t = t0c + tid; t < T; t += kThreads) {
-          float now = 0.0f;
-          int prev = 0;
-          for (int v = 0; v < t; ++v) {
-            const int nx = sraw[v];
-            const float dx = twl[2 * nx] - twl[2 * prev], dy = twl[2 * nx + 1] - twl[2 * prev + 1];
-            now = (nx != 0 ? 1.0f : 0.0f) * (fmaxf(now + sqrtf(fmaf(dy, dy, dx * dx)), tww[2 * nx]) + twd[nx]);
-            prev = nx;
+            if (at == 255) {
+              errbits |= RL4CO_EBIT_INFEASIBLE;
+              at = 0;
+            }
           }
-          stime[base + t - t0c] = now;
+          srq[tt] = at;
         }
-      }
-      if (kCvrpLike) {
-        // used capacity: the loads since the last depot visit, summed in visiting
-        // order from zero — the same fp32 sequence as used = (used + demand) * (action != 0)
-        for (int t = t0c + tid; t < T; t += kThreads) {
-          int u = t - 1;
-          while (u >= 0 && sraw[u] != 0) --u;
-          float used = 0.0f;
-          for (int v = u + 1; v < t; ++v) used = used + dem[min(max((int)sraw[v] - 1, 0), N - 2)];
-          srem[base + t - t0c] = used;
-        }
-      }
-      if (ENV == RL4CO_ENV_OP) {
-        // tour length, accumulated in visiting order like tour += |loc_a - loc_cur|
-        for (int t = t0c + tid; t < T; t += kThreads) {
-          float used = 0.0f;
-          int prev = 0;
-          for (int v = 0; v < t; ++v) {
-            const int nx = sraw[v];
-            const float dx = oplocs[2 * nx] - oplocs[2 * prev], dy = oplocs[2 * nx + 1] - oplocs[2 * prev + 1];
-            used = used + sqrtf(fmaf(dy, dy, dx * dx));
-            prev = nx;
-          }
-          srem[base + t - t0c] = used;
-        }
-      }
-      if (ENV == RL4CO_ENV_PCTSP) {
-        // prize collected, accumulated in visiting order like prize += real_prize[a]
-        for (int t = t0c + tid; t < T; t += kThreads) {
-          float used = 0.0f;
-          for (int v = 0; v < t; ++v) used = used + dem[sraw[v]];
-          srem[base + t - t0c] = used;
-        }
+        for (int j = tq; j < 128; j += kQuarter) spq[j] = 0x7fffffff;
       }
       __syncthreads();
-      const int t_end = sinfo[0];
+      if (active)
+        for (int t = tq; t < T; t += kQuarter) atomicMin(&spq[srq[t]], t);
+      __syncthreads();
+      if (active) {
+        if (tq == 0) {
+          int t_end = T;
+          if (kCvrpLike) {  // done once every node (depot included) has been visited (cvrp/env.py:80-83)
+            int last = 0;
+            for (int j = 0; j < N; ++j) last = max(last, spq[j]);
+            if (last != 0x7fffffff) t_end = min(T, last + 1);
+          }
+          if (ENV == RL4CO_ENV_OP || ENV == RL4CO_ENV_PCTSP) {  // done at the first return to the depot after step 0 (op/env.py:84, pctsp/env.py:73)
+            for (int t = 1; t < T; ++t)
+              if (srq[t] == 0) {
+                t_end = t + 1;
+                break;
+              }
+          }
+          sinfo[qd] = t_end;
+        }
+      } else if (tq == 0) {
+        sinfo[qd] = t0c;  // (no trajectory in this quarter: no live column)
+      }
+      __syncthreads();
+      // packed place of this quarter's trajectory: behind the live columns of the quarters before it
+      int bq = base, live_round = 0;
+#pragma unroll
+      for (int j = 0; j < kNQ; ++j) {
+        const int lj = max(0, sinfo[j] - t0c);
+        if (j < qd) bq += lj;
+        live_round += lj;
+      }
+      const int t_end = sinfo[qd];
       const int live = max(0, t_end - t0c);
-      if (ENV == RL4CO_ENV_TSP) {
-        // feasibility words of a column in two ballots: wave w takes columns w, w + 8, ..; lane = node (and node + 64);
-        // node j is feasible at column t until it has been visited, spos[j] >= t
-        const int p0 = (lane < N) ? spos[lane] : -1, p1 = (lane + 64 < N) ? spos[lane + 64] : -1;
-        for (int t = t0c + w; t < t_end; t += kWaves) {
-          const unsigned long long b0 = __ballot(p0 >= t), b1 = __ballot(p1 >= t);
-          if (lane == 0)
-            *reinterpret_cast<uint4*>(smask + 4 * (base + t - t0c)) = make_uint4((uint32_t)b0, (uint32_t)(b0 >> 32), (uint32_t)b1, (uint32_t)(b1 >> 32));
+      if (active && kScalar) {
+        // per-column scalars BEFORE column t, written at the column's packed place bq + t - t0 (live columns only: the
+        // range behind them belongs to the next quarter's trajectory, which is writing it at the same time)
+        if (kClock) {
+          // the clock, replayed in visiting order: advance by the distance, wait for the window, serve;
+          // back at the depot it restarts (cvrptw/env.py:97-113, same fp32 sequence as the decode kernel)
+          for (int t = t0c + tq; t < t_end; t += kQuarter) {
+            float now = 0.0f;
+            int prev = 0;
+            for (int v = 0; v < t; ++v) {
+              const int nx = srq[v];
+              const float dx = twl[2 * nx] - twl[2 * prev], dy = twl[2 * nx + 1] - twl[2 * prev + 1];
+              now = (nx != 0 ? 1.0f : 0.0f) * (fmaxf(now + sqrtf(fmaf(dy, dy, dx * dx)), tww[2 * nx]) + twd[nx]);
+              prev = nx;
+            }
+            stime[bq + t - t0c] = now;
+          }
+        }
+        if (kCvrpLike) {
+          // used capacity: the loads since the last depot visit, summed in visiting
+          // order from zero — the same fp32 sequence as used = (used + demand) * (action != 0)
+          for (int t = t0c + tq; t < t_end; t += kQuarter) {
+            int u = t - 1;
+            while (u >= 0 && srq[u] != 0) --u;
+            float used = 0.0f;
+            for (int v = u + 1; v < t; ++v) used = used + dem[min(max((int)srq[v] - 1, 0), N - 2)];
+            srem[bq + t - t0c] = used;
+          }
+        }
+        if (ENV == RL4CO_ENV_OP) {
+          // tour length, accumulated in visiting order like tour += |loc_a - loc_cur|
+          for (int t = t0c + tq; t < t_end; t += kQuarter) {
+            float used = 0.0f;
+            int prev = 0;
+            for (int v = 0; v < t; ++v) {
+              const int nx = srq[v];
+              const float dx = oplocs[2 * nx] - oplocs[2 * prev], dy = oplocs[2 * nx + 1] - oplocs[2 * prev + 1];
+              used = used + sqrtf(fmaf(dy, dy, dx * dx));
+              prev = nx;
+            }
+            srem[bq + t - t0c] = used;
+          }
+        }
+        if (ENV == RL4CO_ENV_PCTSP) {
+          // prize collected, accumulated in visiting order like prize += real_prize[a]
+          for (int t = t0c + tq; t < t_end; t += kQuarter) {
+            float used = 0.0f;
+            for (int v = 0; v < t; ++v) used = used + dem[srq[v]];
+            srem[bq + t - t0c] = used;
+          }
         }
       }
-      // feasibility words: thread (t, kw) builds word kw of column t
-      for (int idx = tid; ENV != RL4CO_ENV_TSP && idx < live * 4; idx += kThreads) {
-        const int t = t0c + (idx >> 2), kw = idx & 3, col = base + (idx >> 2);
-        uint32_t word = 0;
-        if (ENV == RL4CO_ENV_OP) {
-          // op/env.py:137-154: unvisited, depot not yet closed, and the node can still be entered
-          const float used = srem[col];
-          const int cur = (t == 0) ? 0 : sraw[t - 1];
-          const float cx = oplocs[2 * cur], cy = oplocs[2 * cur + 1];
-          const bool depot_visited = spos[0] < t;
-          for (int b = 0; b < 32; ++b) {
-            const int j = 32 * kw + b;
-            if (j < N) {
-              const float dx = oplocs[2 * j] - cx, dy = oplocs[2 * j + 1] - cy;
-              const bool exceeds = used + sqrtf(fmaf(dy, dy, dx * dx)) > opmax[j];
-              if (j == 0 || !(spos[j] < t || depot_visited || exceeds)) word |= 1u << b;
-            }
+      if (kScalar) __syncthreads();  // the mask words read the scalars of their column
+      if (active) {
+        if (ENV == RL4CO_ENV_TSP) {
+          // feasibility words of a column in two ballots: wave w takes columns w, w + 8, ..; lane = node (and node + 64);
+          // node j is feasible at column t until it has been visited, spq[j] >= t
+          const int p0 = (lane < N) ? spq[lane] : -1, p1 = (lane + 64 < N) ? spq[lane + 64] : -1;
+          for (int t = t0c + (w % (kWaves / kNQ)); t < t_end; t += kWaves / kNQ) {  // the quarter's waves
+            const unsigned long long b0 = __ballot(p0 >= t), b1 = __ballot(p1 >= t);
+            if (lane == 0)
+              *reinterpret_cast<uint4*>(smask + 4 * (bq + t - t0c)) = make_uint4((uint32_t)b0, (uint32_t)(b0 >> 32), (uint32_t)b1, (uint32_t)(b1 >> 32));
           }
-        } else if (ENV == RL4CO_ENV_PDP) {
-          // pdp/env.py:64-99: unvisited, a delivery only once its pickup is on the tour; the depot only as the
-          // forced first step of force_start_at_depot (recognised by the trajectory starting at node 0)
-          const int half = (N - 1) / 2;
-          for (int b = 0; b < 32; ++b) {
-            const int j = 32 * kw + b;
-            if (j >= 1 && j < N && spos[j] >= t && (j <= half || spos[j - half] < t)) word |= 1u << b;
-          }
-          if (t == 0 && sraw[0] == 0) word = (kw == 0) ? 1u : 0u;
-        } else if (ENV == RL4CO_ENV_PCTSP) {
-          // pctsp/env.py:141-148: customers while unvisited and the depot not yet closed; the depot opens
-          // once a total prize of 1 is collected or no customer is left
-          const bool depot_visited = spos[0] < t;
-          uint32_t left = 0;
-          for (int b = 0; b < 32; ++b) {
-            const int j = 32 * kw + b;
-            if (j >= 1 && j < N && spos[j] >= t) left |= 1u << b;
-          }
-          word = depot_visited ? 0u : left;
-          left |= rl4co::bfly_i<1>((int)left);
-          left |= rl4co::bfly_i<2>((int)left);
-          if (kw == 0 && !((srem[col] < 1.0f) && left != 0u)) word |= 1u;
-        } else {
-          const float used = srem[col];
-          for (int b = 0; b < 32; ++b) {
-            const int j = 32 * kw + b;
-            if (j >= 1 && j < N && spos[j] >= t && !(dem[j - 1] + used > thr)) word |= 1u << b;
-          }
-          // depot: infeasible only while standing on it with a customer still feasible (cvrp/env.py:126-136)
-          uint32_t any = word;
-          any |= rl4co::bfly_i<1>((int)any);
-          any |= rl4co::bfly_i<2>((int)any);
-          const int cur = (t == 0) ? 0 : sraw[t - 1];
-          if (kw == 0 && !((cur == 0) && any != 0u)) word |= 1u;
-          if (kClock) {  // cvrptw/env.py:91-95: only nodes whose window is still open on arrival (the depot too)
-            const float now = stime[col], cx = twl[2 * cur], cy = twl[2 * cur + 1];
+        }
+        // feasibility words: thread (t, kw) builds word kw of column t
+        for (int idx = tq; ENV != RL4CO_ENV_TSP && idx < live * 4; idx += kQuarter) {
+          const int t = t0c + (idx >> 2), kw = idx & 3, col = bq + (idx >> 2);
+          uint32_t word = 0;
+          if (ENV == RL4CO_ENV_OP) {
+            // op/env.py:137-154: unvisited, depot not yet closed, and the node can still be entered
+            const float used = srem[col];
+            const int cur = (t == 0) ? 0 : srq[t - 1];
+            const float cx = oplocs[2 * cur], cy = oplocs[2 * cur + 1];
+            const bool depot_visited = spq[0] < t;
             for (int b = 0; b < 32; ++b) {
               const int j = 32 * kw + b;
-              if ((word >> b) & 1u) {
-                const float dx = twl[2 * j] - cx, dy = twl[2 * j + 1] - cy;
-                if (!(now + sqrtf(fmaf(dy, dy, dx * dx)) <= tww[2 * j + 1])) word &= ~(1u << b);
+              if (j < N) {
+                const float dx = oplocs[2 * j] - cx, dy = oplocs[2 * j + 1] - cy;
+                const bool exceeds = used + sqrtf(fmaf(dy, dy, dx * dx)) > opmax[j];
+                if (j == 0 || !(spq[j] < t || depot_visited || exceeds)) word |= 1u << b;
+              }
+            }
+          } else if (ENV == RL4CO_ENV_PDP) {
+            // pdp/env.py:64-99: unvisited, a delivery only once its pickup is on the tour; the depot only as the
+            // forced first step of force_start_at_depot (recognised by the trajectory starting at node 0)
+            const int half = (N - 1) / 2;
+            for (int b = 0; b < 32; ++b) {
+              const int j = 32 * kw + b;
+              if (j >= 1 && j < N && spq[j] >= t && (j <= half || spq[j - half] < t)) word |= 1u << b;
+            }
+            if (t == 0 && srq[0] == 0) word = (kw == 0) ? 1u : 0u;
+          } else if (ENV == RL4CO_ENV_PCTSP) {
+            // pctsp/env.py:141-148: customers while unvisited and the depot not yet closed; the depot opens
+            // once a total prize of 1 is collected or no customer is left
+            const bool depot_visited = spq[0] < t;
+            uint32_t left = 0;
+            for (int b = 0; b < 32; ++b) {
+              const int j = 32 * kw + b;
+              if (j >= 1 && j < N && spq[j] >= t) left |= 1u << b;
+            }
+            word = depot_visited ? 0u : left;
+            left |= rl4co::bfly_i<1>((int)left);
+            left |= rl4co::bfly_i<2>((int)left);
+            if (kw == 0 && !((srem[col] < 1.0f) && left != 0u)) word |= 1u;
+          } else {
+            const float used = srem[col];
+            for (int b = 0; b < 32; ++b) {
+              const int j = 32 * kw + b;
+              if (j >= 1 && j < N && spq[j] >= t && !(dem[j - 1] + used > thr)) word |= 1u << b;
+            }
+            // depot: infeasible only while standing on it with a customer still feasible (cvrp/env.py:126-136)
+            uint32_t any = word;
+            any |= rl4co::bfly_i<1>((int)any);
+            any |= rl4co::bfly_i<2>((int)any);
+            const int cur = (t == 0) ? 0 : srq[t - 1];
+            if (kw == 0 && !((cur == 0) && any != 0u)) word |= 1u;
+            if (kClock) {  // cvrptw/env.py:91-95: only nodes whose window is still open on arrival (the depot too)
+              const float now = stime[col], cx = twl[2 * cur], cy = twl[2 * cur + 1];
+              for (int b = 0; b < 32; ++b) {
+                const int j = 32 * kw + b;
+                if ((word >> b) & 1u) {
+                  const float dx = twl[2 * j] - cx, dy = twl[2 * j + 1] - cy;
+                  if (!(now + sqrtf(fmaf(dy, dy, dx * dx)) <= tww[2 * j + 1])) word &= ~(1u << b);
+                }
               }
             }
           }
+          smask[4 * col + kw] = word;
         }
-        smask[4 * col + kw] = word;
+        for (int i = tq; i < live; i += kQuarter) {
+          const int t = t0c + i, col = bq + i;
+          scol[col] = (uint32_t)srq[t] | ((t == 0 ? 0u : (uint32_t)srq[t - 1]) << 8) | ((uint32_t)srq[0] << 16) |
+                      ((uint32_t)(1 | (t == 0 ? 2 : 0) | (k << 2)) << 24);
+          sstep[col] = (uint8_t)t;
+          sg[col] = L.npre > 0 ? sng[k * T + t] : a.grad_logp[(int64_t)r * T + t];
+        }
       }
-      for (int i = tid; i < live; i += kThreads) {
-        const int t = t0c + i, col = base + i;
-        scol[col] = (uint32_t)sraw[t] | ((t == 0 ? 0u : (uint32_t)sraw[t - 1]) << 8) | ((uint32_t)sraw[0] << 16) |
-                    ((uint32_t)(1 | (t == 0 ? 2 : 0) | (k << 2)) << 24);
-        sstep[col] = (uint8_t)t;
-        sg[col] = L.npre > 0 ? sng[k * T + t] : a.grad_logp[(int64_t)r * T + t];
-      }
-      __syncthreads();  // sraw / spos / sinfo are rewritten by the next trajectory; the words and scalars are complete
-      base += live;
+      __syncthreads();  // srq / spq / sinfo are rewritten by the next round; the words and scalars are complete
+      base += live_round;
     }
     const int ncols = base;
     const int ntb = (ncols + 15) >> 4;
