@@ -246,7 +246,7 @@ def cpu_baseline(env_name: str, num_loc: int, sample_batch: int, repeats: int = 
     }
 
 
-TRAIN_PMC_FILE = "r05_c4_train_pmc.json"  # counters of the training kernels as they are in THIS tree (tools/train_pmc.sh)
+TRAIN_PMC_FILE = "r06_c4_train_pmc.json"  # counters of the training kernels as they are in THIS tree (tools/train_pmc.sh)
 MAX_LINE_BYTES = 4096  # the driver parses the ONE stdout line; r03's 27 KB line came back as `parsed: null`
 
 

@@ -33,4 +33,13 @@ for f in re.split(r'\n(?=_Z[\w]+:)', t):
     single=sum(1 for l in L if re.search(r'v_cvt_pk_bf16_f32 v\d+, v\d+, s\d+',l))
     canon=sum(1 for l in L if re.search(r'v_max_f32_e32 (v\d+), (v\d+), \2\b',l))
     agpr=sum(1 for i,l in enumerate(L) if 'v_accvgpr_' in l and inl(i))
-    print(f"{dn:70s} lines {len(L):5d} loop-vmcnt0 {vm0:3d} loop-scratch {scr:3d} single-cvt {single:4d} canon {canon:3d} loop-agpr-moves {agpr:3d}")
+    # (r06) agent-scope fences: buffer_wbl2 is an L2 write-back (0.6 - 1.0 ms of the teacher launch per fence and workgroup)
+    wbl2=sum(1 for l in L if 'buffer_wbl2' in l or 'buffer_inv' in l)
+    # (r06) a vmcnt wait that can only be for a load issued a few instructions earlier IN a loop (an exposed round trip):
+    # s_waitcnt vmcnt(0..1) within 10 instructions behind a global / buffer load, no store in between
+    early=0
+    for i,l in enumerate(L):
+        if inl(i) and re.search(r's_waitcnt vmcnt\([01]\)',l):
+            back=[x for x in L[max(0,i-10):i] if not x.strip().startswith(';')]
+            if any(re.search(r'(global|buffer|flat)_load',x) for x in back): early+=1
+    print(f"{dn:70s} lines {len(L):5d} loop-vmcnt0 {vm0:3d} loop-scratch {scr:3d} single-cvt {single:4d} canon {canon:3d} loop-agpr-moves {agpr:3d} wbl2/inv {wbl2:2d} early-wait {early:3d}")
