@@ -38,6 +38,49 @@ __device__ inline void load_wfrags(f32x4 (&wf)[8], const float* packed, int chun
   for (int j = 0; j < 8; ++j) wf[j] = load_w(packed, chunks_total, tile, j0 + j, lane);
 }
 
+// ---- RL4CO_F32_SPLIT (r06 experiment): fp32 products as six bf16 products ------------------------------------------------
+// An fp32 value splits EXACTLY into three bf16 pieces by truncation (v = p1 + p2 + p3 + r, |r| <= 2^-24 |v|: each piece is
+// the top 8 significant bits of what the previous ones left, the subtractions are exact). a b = sum of the nine piece
+// products; the six of weight >= 2^-16 reproduce it to ~2^-23 |a b| — the size of an fp32 product's own rounding — and every
+// piece product is exact in the MFMA's fp32 accumulator. A lane's 16-byte fragment (four consecutive k at 4 g of a 16-k
+// chunk) IS the operand layout of v_mfma_f32_16x16x16_bf16, so six of those (8 passes each) replace the chunk's four
+// v_mfma_f32_16x16x4_f32 (32 passes each): 48 instead of 128 matrix cycles per chunk and token tile, for 18 VALU operations
+// per fragment. NOT the k-ordered fmaf chain of the exact kernel any more: the summation order inside an MFMA is the
+// hardware's — accepted only where the trained-weight parity holds.
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+struct Split3 {
+  bf16x4_t p1, p2, p3;
+};
+__device__ inline Split3 split3(const f32x4& v) {
+  uint32_t u[4], r1[4], r2[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    u[s] = __float_as_uint(v[s]);
+    const float a = v[s] - __uint_as_float(u[s] & 0xffff0000u);
+    r1[s] = __float_as_uint(a);
+    r2[s] = __float_as_uint(a - __uint_as_float(r1[s] & 0xffff0000u));
+  }
+  // the upper halves of two words side by side: bytes (x0.b2, x0.b3, x1.b2, x1.b3)
+  auto hi2 = [](uint32_t x1, uint32_t x0) { return __builtin_amdgcn_perm(x1, x0, 0x07060302u); };
+  Split3 o;
+  o.p1 = __builtin_bit_cast(bf16x4_t, make_uint2(hi2(u[1], u[0]), hi2(u[3], u[2])));
+  o.p2 = __builtin_bit_cast(bf16x4_t, make_uint2(hi2(r1[1], r1[0]), hi2(r1[3], r1[2])));
+  o.p3 = __builtin_bit_cast(bf16x4_t, make_uint2(hi2(r2[1], r2[0]), hi2(r2[3], r2[2])));
+  return o;
+}
+__device__ inline f32x4 mfma16b(const bf16x4_t& a, const bf16x4_t& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+// c += a . b over the chunk's 16 k, smallest terms first
+__device__ inline f32x4 mfma_split(const Split3& a, const Split3& b, f32x4 c) {
+  c = mfma16b(a.p3, b.p1, c);
+  c = mfma16b(a.p2, b.p2, c);
+  c = mfma16b(a.p1, b.p3, c);
+  c = mfma16b(a.p2, b.p1, c);
+  c = mfma16b(a.p1, b.p2, c);
+  return mfma16b(a.p1, b.p1, c);
+}
+
 // acc[tt] += (W tile) . X^T over K = 128 (8 chunks of 16, four MFMA steps each). W_IS_A: transposed form (rows = dims,
 // columns = tokens); otherwise plain form (rows = tokens, columns = dims). The weight fragments `wf` were requested one
 // call ahead; as soon as chunk j has fed its last MFMA its registers take chunk j of the NEXT GEMM (nxt; nullptr: none),
@@ -56,12 +99,23 @@ __device__ inline void gemm16(f32x4 (&acc)[TT], f32x4 (&wf)[8], const float* xs,
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt) x[(j + 1) & 1][tt] = *reinterpret_cast<const f32x4*>(xrow + 16 * tt * kRS + 16 * (j + 1));
     }
+#ifdef RL4CO_F32_SPLIT
+    {
+      const Split3 ws = split3(wf[j]);
+#pragma unroll
+      for (int tt = 0; tt < TT; ++tt) {
+        const Split3 xs3 = split3(x[j & 1][tt]);
+        acc[tt] = W_IS_A ? mfma_split(ws, xs3, acc[tt]) : mfma_split(xs3, ws, acc[tt]);
+      }
+    }
+#else
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
       for (int tt = 0; tt < TT; ++tt)
         acc[tt] = W_IS_A ? mfma4(wf[j][s], x[j & 1][tt][s], acc[tt]) : mfma4(x[j & 1][tt][s], wf[j][s], acc[tt]);
     }
+#endif
     if (nxt) wf[j] = load_w(nxt, nxt_chunks, nxt_tile, nxt_j0 + j, lane);
     __builtin_amdgcn_sched_barrier(0);  // chunk by chunk: hoisted, the LDS reads of all eight chunks would be live at once
   }
