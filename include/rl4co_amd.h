@@ -34,8 +34,9 @@ extern "C" {
  * mismatch: a changed argument list under an unchanged symbol name still links (r05: rl4co_attn_bwd_* gained `out` in
  * second position — a caller built for the old list would pass dout as out and lse as dout).
  *   6: rl4co_attn_bwd_{bf16,f16} take the forward's `out`; rl4co_abi_version() itself.
- *   7: rl4co_am_decode_args / rl4co_am_teacher_args end in the context tables' dtype and strides (ctx_dtype ...). */
-#define RL4CO_ABI_VERSION 7
+ *   7: rl4co_am_decode_args / rl4co_am_teacher_args end in the context tables' dtype and strides (ctx_dtype ...).
+ *   8: the 16 rl4co_<op>_bf16 / rl4co_<op>_f16 pairs are ONE rl4co_<op>(int dtype, ...) each. */
+#define RL4CO_ABI_VERSION 8
 
 /* ---- status codes ------------------------------------------------------ */
 #define RL4CO_OK 0
@@ -593,7 +594,7 @@ typedef struct rl4co_am_teacher_args {
   /* MMA variant: the three plane gradients as bf16 rows with the caller's strides instead of fp32 d_kvl (which may
    * then be NULL) — element [p][b][n][c] at d_planes_bf16 + p * plane_stride + b * batch_stride + n * row_stride + c.
    * Lets the caller place them next to each other as the columns of ONE [B_inst * N, 5 * 128] gradient matrix, the
-   * operand of the fold GEMMs' backward (rl4co_linear_bf16 / rl4co_wgrad_bf16), without an fp32 round trip. */
+   * operand of the fold GEMMs' backward (rl4co_linear / rl4co_wgrad), without an fp32 round trip. */
   void* d_planes_bf16;
   int64_t d_planes_row_stride;
   int64_t d_planes_batch_stride;
@@ -615,14 +616,24 @@ int rl4co_am_teacher_max_nodes(void);
 int rl4co_am_teacher_variant(const rl4co_am_teacher_args* args);
 
 /* --------------------------------------------------------------------------
+ * Element type of the 16-bit training-encoder / attention entry points (r06: ONE entry point per operation; until r05
+ * every one of them existed twice, rl4co_<op>_bf16 and rl4co_<op>_f16). `dtype` = RL4CO_DT_BF16 (torch.autocast(bfloat16))
+ * or RL4CO_DT_F16 (torch.autocast(float16): the reference's DEFAULT precision, Lightning's "16-mixed",
+ * rl4co/utils/trainer.py:57); any other value is RL4CO_ERR_ARG. Every `const void*` / `void*` activation, weight or
+ * gradient operand holds elements of that type, fp32 operands stay fp32; conversions to half round to nearest even and
+ * overflow to infinity (what GradScaler's inf check expects). One source per kernel, compiled for both element types
+ * (csrc/elem16.h); csrc/entry16.hip dispatches. The comments below say "bf16" where they mean "the 16-bit type".
+ * -------------------------------------------------------------------------- */
+
+/* --------------------------------------------------------------------------
  * a11 (training)  init embedding  env_embeddings/init.py:55-68,115-136
  * out[m,:] = W[128,F] . feats[m,:F] + b  (F <= 6: x, y (, demand, ...)); fp32 in, bf16 out [M,128].
  * -------------------------------------------------------------------------- */
-int rl4co_init_embed_bf16(const float* feats, const float* w, const float* b, int64_t M, int F, void* out, void* stream);
+int rl4co_init_embed(int dtype, const float* feats, const float* w, const float* b, int64_t M, int F, void* out, void* stream);
 /* backward of the above w.r.t. W and b: partial[g, c, 0..F-1] = sum over the rows of block g of dout[m,c] * feats[m,f],
  * partial[g, c, F] = sum of dout[m,c]; dout bf16 [M,128], partial fp32 [blocks,128,F+1] (summed over g by the caller in a
  * fixed order: deterministic). Returns the number of blocks the launch uses through *blocks_out when partial == NULL. */
-int rl4co_init_embed_wgrad_bf16(const void* dout, const float* feats, int64_t M, int F, float* partial, int* blocks_out,
+int rl4co_init_embed_wgrad(int dtype, const void* dout, const float* feats, int64_t M, int F, float* partial, int* blocks_out,
                                 void* stream);
 
 /* --------------------------------------------------------------------------
@@ -634,9 +645,9 @@ int rl4co_init_embed_wgrad_bf16(const void* dout, const float* feats, int64_t M,
  * backward: dy (the gradient of BOTH skip inputs) from dout; dgamma / dbeta [B,128]: the per-instance
  *           contributions (every element written; the caller sums over B). N <= rl4co_skip_inorm_max_nodes().
  * -------------------------------------------------------------------------- */
-int rl4co_skip_inorm_fwd_bf16(const void* x, const void* s, const float* gamma, const float* beta, float eps,
+int rl4co_skip_inorm_fwd(int dtype, const void* x, const void* s, const float* gamma, const float* beta, float eps,
                               int B, int N, void* y, void* out, float* mean, float* rstd, void* stream);
-int rl4co_skip_inorm_bwd_bf16(const void* dout, const void* y, const float* gamma, const float* mean,
+int rl4co_skip_inorm_bwd(int dtype, const void* dout, const void* y, const float* gamma, const float* mean,
                               const float* rstd, int B, int N, void* dy, float* dgamma, float* dbeta,
                               void* stream);
 int rl4co_skip_inorm_max_nodes(void);
@@ -650,9 +661,9 @@ int rl4co_skip_inorm_max_nodes(void);
  * backward: dy (the gradient of BOTH skip inputs) = r (dout - sum(dout) / M - xh sum(dout xh) / (M - 1)), xh = (y - mean) r.
  *           N <= rl4co_skip_inorm_max_nodes().
  * -------------------------------------------------------------------------- */
-int rl4co_skip_lnorm_fwd_bf16(const void* x, const void* s, float eps, int B, int N, void* y, void* out, float* stats,
+int rl4co_skip_lnorm_fwd(int dtype, const void* x, const void* s, float eps, int B, int N, void* y, void* out, float* stats,
                               void* stream);
-int rl4co_skip_lnorm_bwd_bf16(const void* dout, const void* y, const float* stats, int B, int N, void* dy, void* stream);
+int rl4co_skip_lnorm_bwd(int dtype, const void* dout, const void* y, const float* stats, int B, int N, void* dy, void* stream);
 
 /* --------------------------------------------------------------------------
  * a12 (training)  SkipConnection + Normalization("batch") — the AttentionModel default
@@ -664,14 +675,14 @@ int rl4co_skip_lnorm_bwd_bf16(const void* dout, const void* y, const float* stat
  *   bwd   : sums[0][c] += sum dout, sums[1][c] += sum dout * xh  (zero-initialised), then
  *           dy = rstd gamma (dout - sums[0]/M - xh sums[1]/M); sums[1] = dgamma, sums[0] = dbeta.
  * -------------------------------------------------------------------------- */
-int rl4co_skip_bnorm_stats_bf16(const void* x, const void* s, int64_t M, void* y, float* sums, void* stream);
-int rl4co_bnorm_apply_bf16(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
+int rl4co_skip_bnorm_stats(int dtype, const void* x, const void* s, int64_t M, void* y, float* sums, void* stream);
+int rl4co_bnorm_apply(int dtype, const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
                            int64_t M, void* out, void* stream);
 /* out = bn_eval(x + skip) in one pass (SkipConnection + Normalization("batch") in eval mode, nn/ops.py:9-54): the
  * token-parallel inference encoder for graphs beyond rl4co_am_encoder_max_nodes(); x, skip, out bf16 [M,128]. */
-int rl4co_skip_bnorm_eval_bf16(const void* x, const void* skip, const float* mean, const float* rstd, const float* gamma,
+int rl4co_skip_bnorm_eval(int dtype, const void* x, const void* skip, const float* mean, const float* rstd, const float* gamma,
                                const float* beta, int64_t M, void* out, void* stream);
-int rl4co_bnorm_bwd_bf16(const void* dout, const void* y, const float* mean, const float* rstd, const float* gamma,
+int rl4co_bnorm_bwd(int dtype, const void* dout, const void* y, const float* mean, const float* rstd, const float* gamma,
                          int64_t M, float* sums, void* dy, void* stream);
 
 /* --------------------------------------------------------------------------
@@ -684,7 +695,7 @@ int rl4co_bnorm_bwd_bf16(const void* dout, const void* y, const float* mean, con
  * With W = weight^T (contiguous) it is the input gradient dX = dY . weight.
  * N and K multiples of 128; bias, mask and residual may be NULL.
  * -------------------------------------------------------------------------- */
-int rl4co_linear_bf16(const void* a, const void* w, const float* bias, const void* mask, const void* residual, int64_t M,
+int rl4co_linear(int dtype, const void* a, const void* w, const float* bias, const void* mask, const void* residual, int64_t M,
                       int N, int K, int relu, void* out, void* stream);
 /* Weight gradient of the same layers: partial[c][N,K] = dY[rows of chunk c]^T . X[rows of chunk c]
  * (bf16 dY [M,N], X [M,K]; fp32 partial [chunks,N,K], every element written); dW = sum over c.
@@ -692,7 +703,7 @@ int rl4co_linear_bf16(const void* a, const void* w, const float* bias, const voi
  * The rows are split into `chunks` equal ranges (a multiple of 32 rows each).
  * chunk_stride: elements between consecutive chunks of BOTH partial arrays; 0 = packed (N*K and N). With
  * partial_bias = partial + N*K and chunk_stride = N*K + N one reduction over the chunk axis yields dW and db. */
-int rl4co_wgrad_bf16(const void* dy, const void* x, int64_t M, int N, int K, int chunks, float* partial,
+int rl4co_wgrad(int dtype, const void* dy, const void* x, int64_t M, int N, int K, int chunks, float* partial,
                      float* partial_bias, int64_t chunk_stride, void* stream);
 
 /* --------------------------------------------------------------------------
@@ -703,8 +714,8 @@ int rl4co_wgrad_bf16(const void* dy, const void* x, int64_t M, int N, int K, int
  * backward: dqkv [B,N,384] bf16 from dout [B,N,128] and the forward's own out (the softmax
  * backward's row term sum_keys P dP is taken as sum_d dout out). N <= rl4co_attn_max_nodes().
  * -------------------------------------------------------------------------- */
-int rl4co_attn_fwd_bf16(const void* qkv, int B, int N, void* out, float* lse, void* stream);
-int rl4co_attn_bwd_bf16(const void* qkv, const void* out, const void* dout, const float* lse, int B, int N,
+int rl4co_attn_fwd(int dtype, const void* qkv, int B, int N, void* out, float* lse, void* stream);
+int rl4co_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, int B, int N,
                         void* dqkv, void* stream);
 int rl4co_attn_max_nodes(void);
 
@@ -715,11 +726,11 @@ int rl4co_attn_max_nodes(void);
  * 64 nodes with a running (max, sum, output) per query — the N x N score matrix is never materialised
  * (csrc/am_attn_flash.hip). Serves the encoder beyond rl4co_am_encoder_max_nodes() (BASELINE configs[4]).
  * -------------------------------------------------------------------------- */
-int rl4co_attn_flash_bf16(const void* qkv, int B, int N, void* out, void* stream);
+int rl4co_attn_flash(int dtype, const void* qkv, int B, int N, void* out, void* stream);
 /* The same with q already in the exp2 domain (1/4 log2 e folded into the packed W_q: rl4co_am_encoder_tokens16) and,
  * bound != NULL, per (instance, head) the maxima over the nodes of |q_h|^2 and |k_h|^2 ([B,8,2] fp32): heads whose
  * product stays below 48^2 take the max-free softmax path (bf16 only; every |score| is then below 48 by Cauchy-Schwarz). */
-int rl4co_attn_flash_pre_bf16(const void* qkv, const float* bound, int B, int N, void* out, void* stream);
+int rl4co_attn_flash_pre(int dtype, const void* qkv, const float* bound, int B, int N, void* out, void* stream);
 
 /* --------------------------------------------------------------------------
  * a19  select_start_nodes        rl4co/utils/ops.py:128-161
@@ -727,42 +738,6 @@ int rl4co_attn_flash_pre_bf16(const void* qkv, const float* bound, int B, int N,
  * -------------------------------------------------------------------------- */
 int rl4co_select_start_nodes(int64_t* out, int B, int num_starts, int num_loc, int has_depot,
                              void* stream);
-
-/* --------------------------------------------------------------------------
- * The same training-encoder / attention entry points for IEEE half activations (torch.float16): the reference's
- * DEFAULT precision is Lightning's "16-mixed" = fp16 autocast (rl4co/utils/trainer.py:57). Identical arguments,
- * layouts and semantics as their _bf16 namesakes above — every `const void*` / `void*` activation, weight or
- * gradient operand holds binary16 instead of bfloat16, fp32 operands stay fp32; conversions to half round to
- * nearest even and overflow to infinity (what GradScaler's inf check expects). One source per kernel, compiled
- * for both element types (csrc/elem16.h).
- * -------------------------------------------------------------------------- */
-int rl4co_init_embed_f16(const float* feats, const float* w, const float* b, int64_t M, int F, void* out, void* stream);
-int rl4co_init_embed_wgrad_f16(const void* dout, const float* feats, int64_t M, int F, float* partial, int* blocks_out,
-                                void* stream);
-int rl4co_skip_inorm_fwd_f16(const void* x, const void* s, const float* gamma, const float* beta, float eps,
-                              int B, int N, void* y, void* out, float* mean, float* rstd, void* stream);
-int rl4co_skip_inorm_bwd_f16(const void* dout, const void* y, const float* gamma, const float* mean,
-                              const float* rstd, int B, int N, void* dy, float* dgamma, float* dbeta,
-                              void* stream);
-int rl4co_skip_lnorm_fwd_f16(const void* x, const void* s, float eps, int B, int N, void* y, void* out, float* stats,
-                             void* stream);
-int rl4co_skip_lnorm_bwd_f16(const void* dout, const void* y, const float* stats, int B, int N, void* dy, void* stream);
-int rl4co_skip_bnorm_stats_f16(const void* x, const void* s, int64_t M, void* y, float* sums, void* stream);
-int rl4co_bnorm_apply_f16(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                           int64_t M, void* out, void* stream);
-int rl4co_skip_bnorm_eval_f16(const void* x, const void* skip, const float* mean, const float* rstd, const float* gamma,
-                               const float* beta, int64_t M, void* out, void* stream);
-int rl4co_bnorm_bwd_f16(const void* dout, const void* y, const float* mean, const float* rstd, const float* gamma,
-                         int64_t M, float* sums, void* dy, void* stream);
-int rl4co_linear_f16(const void* a, const void* w, const float* bias, const void* mask, const void* residual, int64_t M,
-                      int N, int K, int relu, void* out, void* stream);
-int rl4co_wgrad_f16(const void* dy, const void* x, int64_t M, int N, int K, int chunks, float* partial,
-                     float* partial_bias, int64_t chunk_stride, void* stream);
-int rl4co_attn_fwd_f16(const void* qkv, int B, int N, void* out, float* lse, void* stream);
-int rl4co_attn_bwd_f16(const void* qkv, const void* out, const void* dout, const float* lse, int B, int N,
-                       void* dqkv, void* stream);
-int rl4co_attn_flash_f16(const void* qkv, int B, int N, void* out, void* stream);
-int rl4co_attn_flash_pre_f16(const void* qkv, const float* bound, int B, int N, void* out, void* stream);
 
 /* --------------------------------------------------------------------------
  * N3  state augmentation                      rl4co/data/transforms.py:16-87, 105-151

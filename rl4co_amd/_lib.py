@@ -12,7 +12,7 @@ from functools import lru_cache
 from . import build as _build
 
 RL4CO_OK = 0
-ABI_VERSION = 7  # RL4CO_ABI_VERSION of include/rl4co_amd.h this binding's argument lists were written for
+ABI_VERSION = 8  # RL4CO_ABI_VERSION of include/rl4co_amd.h this binding's argument lists were written for
 ENV_TSP, ENV_CVRP, ENV_OP, ENV_PCTSP, ENV_PDP, ENV_CVRPTW = 0, 1, 2, 3, 4, 5
 DECODE_GREEDY, DECODE_SAMPLE, DECODE_EVALUATE = 0, 1, 2
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
@@ -109,25 +109,25 @@ SYMBOLS = {
     "rl4co_am_teacher_backward": (C.c_int, [_vp, _vp]),
     "rl4co_am_teacher_max_nodes": (C.c_int, []),
     "rl4co_am_teacher_variant": (C.c_int, [_vp]),
-    "rl4co_skip_inorm_fwd_bf16": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
-    "rl4co_skip_inorm_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
-    "rl4co_skip_lnorm_fwd_bf16": (C.c_int, [_vp, _vp, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
-    "rl4co_skip_lnorm_bwd_bf16": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_skip_inorm_fwd": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),  # (dtype id first: RL4CO_DT_BF16 / RL4CO_DT_F16)
+    "rl4co_skip_inorm_bwd": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),  # (dtype id first: RL4CO_DT_BF16 / RL4CO_DT_F16)
+    "rl4co_skip_lnorm_fwd": (C.c_int, [C.c_int, _vp, _vp, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),  # (dtype id first: RL4CO_DT_BF16 / RL4CO_DT_F16)
+    "rl4co_skip_lnorm_bwd": (C.c_int, [C.c_int, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),  # (dtype id first: RL4CO_DT_BF16 / RL4CO_DT_F16)
     "rl4co_skip_inorm_max_nodes": (C.c_int, []),
     "rl4co_mlp_input_grad": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, C.c_int, _vp, _vp, _vp]),
-    "rl4co_skip_bnorm_stats_bf16": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp]),
-    "rl4co_bnorm_apply_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp]),
-    "rl4co_skip_bnorm_eval_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp]),
-    "rl4co_bnorm_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
-    "rl4co_init_embed_bf16": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp]),
-    "rl4co_init_embed_wgrad_bf16": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp]),
-    "rl4co_linear_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp]),
-    "rl4co_attn_fwd_bf16": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
-    "rl4co_attn_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_skip_bnorm_stats": (C.c_int, [C.c_int, _vp, _vp, C.c_int64, _vp, _vp, _vp]),  # (dtype id first: RL4CO_DT_BF16 / RL4CO_DT_F16)
+    "rl4co_bnorm_apply": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp]),  # (dtype id first: RL4CO_DT_BF16 / RL4CO_DT_F16)
+    "rl4co_skip_bnorm_eval": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp]),  # (dtype id first: RL4CO_DT_BF16 / RL4CO_DT_F16)
+    "rl4co_bnorm_bwd": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),  # (dtype id first: RL4CO_DT_BF16 / RL4CO_DT_F16)
+    "rl4co_init_embed": (C.c_int, [C.c_int, _vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp]),  # (dtype id first: RL4CO_DT_BF16 / RL4CO_DT_F16)
+    "rl4co_init_embed_wgrad": (C.c_int, [C.c_int, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp]),  # (dtype id first: RL4CO_DT_BF16 / RL4CO_DT_F16)
+    "rl4co_linear": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp]),  # (dtype id first: RL4CO_DT_BF16 / RL4CO_DT_F16)
+    "rl4co_attn_fwd": (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),  # (dtype id first: RL4CO_DT_BF16 / RL4CO_DT_F16)
+    "rl4co_attn_bwd": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),  # (dtype id first: RL4CO_DT_BF16 / RL4CO_DT_F16)
     "rl4co_attn_max_nodes": (C.c_int, []),
-    "rl4co_attn_flash_bf16": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
-    "rl4co_attn_flash_pre_bf16": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
-    "rl4co_wgrad_bf16": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp]),
+    "rl4co_attn_flash": (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),  # (dtype id first: RL4CO_DT_BF16 / RL4CO_DT_F16)
+    "rl4co_attn_flash_pre": (C.c_int, [C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),  # (dtype id first: RL4CO_DT_BF16 / RL4CO_DT_F16)
+    "rl4co_wgrad": (C.c_int, [C.c_int, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp]),  # (dtype id first: RL4CO_DT_BF16 / RL4CO_DT_F16)
     "rl4co_am_encoder": (C.c_int, [_vp, _vp]),
     "rl4co_am_encoder_max_nodes": (C.c_int, []),
     "rl4co_am_encoder_train_fwd": (C.c_int, [_vp, _vp, _vp]),
@@ -150,22 +150,6 @@ SYMBOLS = {
     "rl4co_math_probe_f32": (C.c_int, [C.c_int, _vp, _i64, _vp, _vp]),
     "rl4co_uniform_f32": (C.c_int, [_vp, _i64, C.c_float, C.c_float, C.c_uint64, C.c_uint32, C.c_int, C.c_float, _vp]),
     # IEEE-half twins of the training-encoder / attention kernels (csrc/elem16.h)
-    "rl4co_skip_inorm_fwd_f16": (C.c_int, [_vp, _vp, _vp, _vp, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]),
-    "rl4co_skip_inorm_bwd_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
-    "rl4co_skip_lnorm_fwd_f16": (C.c_int, [_vp, _vp, C.c_float, C.c_int, C.c_int, _vp, _vp, _vp, _vp]),
-    "rl4co_skip_lnorm_bwd_f16": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
-    "rl4co_skip_bnorm_stats_f16": (C.c_int, [_vp, _vp, C.c_int64, _vp, _vp, _vp]),
-    "rl4co_bnorm_apply_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp]),
-    "rl4co_skip_bnorm_eval_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp]),
-    "rl4co_bnorm_bwd_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp]),
-    "rl4co_init_embed_f16": (C.c_int, [_vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp]),
-    "rl4co_init_embed_wgrad_f16": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp]),
-    "rl4co_linear_f16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp]),
-    "rl4co_attn_fwd_f16": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp, _vp]),
-    "rl4co_attn_bwd_f16": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
-    "rl4co_attn_flash_f16": (C.c_int, [_vp, C.c_int, C.c_int, _vp, _vp]),
-    "rl4co_attn_flash_pre_f16": (C.c_int, [_vp, _vp, C.c_int, C.c_int, _vp, _vp]),
-    "rl4co_wgrad_f16": (C.c_int, [_vp, _vp, C.c_int64, C.c_int, C.c_int, C.c_int, _vp, _vp, C.c_int64, _vp]),
 }
 
 

@@ -1454,8 +1454,7 @@ int launch_tokens16(const rl4co_am_encoder_args& a, void* workspace, hipStream_t
   for (int layer = 0; layer < a.num_layers; ++layer) {
     RL4CO_HIP_TRY(hipMemsetAsync(bound, 0, (size_t)a.B * 8 * 2 * 4, s));
     hipLaunchKernelGGL(tok16_qkv_kernel<E>, grid, block, lds_qkv, s, xin, N, wqkv + (int64_t)layer * 3 * kD * kD, a.bqkv + layer * 3 * kD, qkv, bound);
-    const int st = half ? rl4co_attn_flash_pre_f16(qkv, reinterpret_cast<const float*>(bound), a.B, N, att, s)
-                        : rl4co_attn_flash_pre_bf16(qkv, reinterpret_cast<const float*>(bound), a.B, N, att, s);
+    const int st = rl4co_attn_flash_pre(half ? RL4CO_DT_F16 : RL4CO_DT_BF16, qkv, reinterpret_cast<const float*>(bound), a.B, N, att, s);
     if (st != RL4CO_OK) return st;
     if (a.norm == 0) {
       hipLaunchKernelGGL(tok16_mlp_kernel<E>, grid, block, lds_mlp, s, xin, att, N, wo + (int64_t)layer * kD * kD, w1 + (int64_t)layer * kFF * kD,

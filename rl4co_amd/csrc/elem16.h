@@ -1,10 +1,11 @@
 // elem16.h — the 16-bit element type of a training / attention translation unit.
 //
 // The training-encoder kernels (am_train_ops.hip, am_train_attn.hip) and the flash attention (am_attn_flash.hip) are
-// written once against `elem_t` and compiled twice: as they stand for bfloat16 (torch.autocast(bfloat16), entry points
-// rl4co_*_bf16) and through the one-line wrappers *_f16.hip, which define RL4CO_ELEM_F16 and include the same source, for
-// IEEE half (torch.autocast(float16) — the reference's default "16-mixed" precision, rl4co/utils/trainer.py:57 — entry
-// points rl4co_*_f16). Storage, LDS layouts, transpose reads and MFMA shapes are identical; what differs is the MFMA
+// written once against `elem_t` and compiled twice: as they stand for bfloat16 (torch.autocast(bfloat16), hidden
+// implementation symbols rl4co_*_impl_bf16) and through the one-line wrappers *_f16.hip, which define RL4CO_ELEM_F16 and
+// include the same source, for IEEE half (torch.autocast(float16) — the reference's default "16-mixed" precision,
+// rl4co/utils/trainer.py:57 — rl4co_*_impl_f16). The C-ABI has ONE entry point per operation with the element type as its
+// first argument (csrc/entry16.hip, r06). Storage, LDS layouts, transpose reads and MFMA shapes are identical; what differs is the MFMA
 // opcode and the conversions: bf16 <-> fp32 is a 16-bit shift, half <-> fp32 the hardware's v_cvt (round to nearest
 // even, overflow to infinity — what GradScaler's inf check expects of fp16 gradients).
 #ifndef RL4CO_ELEM16_H
@@ -19,11 +20,11 @@
 
 #if RL4CO_ELEM_F16
 typedef _Float16 elem_t;
-#define RL4CO_ENTRY(stem) stem##_f16
+#define RL4CO_ENTRY(stem) __attribute__((visibility("hidden"))) stem##_impl_f16
 #define RL4CO_CXX(stem) stem##_f16
 #else
 typedef __bf16 elem_t;
-#define RL4CO_ENTRY(stem) stem##_bf16
+#define RL4CO_ENTRY(stem) __attribute__((visibility("hidden"))) stem##_impl_bf16
 #define RL4CO_CXX(stem) stem
 #endif
 

@@ -22,11 +22,12 @@ HALF = (torch.bfloat16, torch.float16)  # element types the kernels are built fo
 
 
 def _k(stem: str, dtype: torch.dtype):
-    """The entry point of ``stem`` for activations of ``dtype``: rl4co_<stem>_bf16 or its IEEE-half twin rl4co_<stem>_f16
-    (the reference's default "16-mixed" precision is fp16 autocast, utils/trainer.py:57)."""
+    """The entry point ``stem`` bound to the element type of ``dtype`` (its first argument since r06: RL4CO_DT_BF16, or
+    RL4CO_DT_F16 — the reference's default "16-mixed" precision is fp16 autocast, utils/trainer.py:57)."""
     if dtype not in HALF:
         raise TypeError(f"the training kernels take bfloat16 or float16 activations, got {dtype}")
-    return getattr(_lib.lib(), f"{stem}_{'f16' if dtype == torch.float16 else 'bf16'}")
+    fn, did = getattr(_lib.lib(), stem), _lib.dtype_id(dtype)
+    return lambda *args: fn(did, *args)
 
 
 def max_nodes() -> int:

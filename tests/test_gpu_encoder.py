@@ -438,9 +438,9 @@ def test_token_tile_attention_fast_and_exact_paths_agree():
     out = {}
     for name, bound in (("fast", torch.full((b, 8, 2), 1.0, device="cuda")), ("exact", torch.full((b, 8, 2), 1e9, device="cuda")), ("null", None)):
         o = torch.empty(b, n, 128, dtype=torch.bfloat16, device="cuda")
-        st = _lib.lib().rl4co_attn_flash_pre_bf16(qkv.data_ptr(), None if bound is None else bound.data_ptr(), b, n, o.data_ptr(),
+        st = _lib.lib().rl4co_attn_flash_pre(_lib.DT_BF16, qkv.data_ptr(), None if bound is None else bound.data_ptr(), b, n, o.data_ptr(),
                                                   torch.cuda.current_stream().cuda_stream)
-        _lib.check(st, "rl4co_attn_flash_pre_bf16")
+        _lib.check(st, "rl4co_attn_flash_pre")
         out[name] = o.float()
     q, k, v = (qkv.float()[..., i * 128:(i + 1) * 128].view(b, n, 8, 16).transpose(1, 2) for i in range(3))
     want = torch.softmax((q @ k.transpose(-1, -2)) * 0.6931471805599453, -1) @ v  # scores are in the exp2 domain

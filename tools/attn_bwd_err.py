@@ -16,10 +16,10 @@ for b, n, scale in ((4096, 100, 1.0), (256, 100, 0.5), (256, 50, 1.0), (256, 128
     lse = torch.empty(b, 8, n, device="cuda")
     dqkv = torch.empty_like(qkv)
     s = torch.cuda.current_stream().cuda_stream
-    assert lib.rl4co_attn_fwd_bf16(vp(qkv.data_ptr()), b, n, vp(out.data_ptr()), vp(lse.data_ptr()), vp(s)) == 0
+    assert lib.rl4co_attn_fwd(1, vp(qkv.data_ptr()), b, n, vp(out.data_ptr()), vp(lse.data_ptr()), vp(s)) == 0
 
     def bwd():
-        return lib.rl4co_attn_bwd_bf16(vp(qkv.data_ptr()), vp(out.data_ptr()), vp(go.data_ptr()), vp(lse.data_ptr()), b, n, vp(dqkv.data_ptr()), vp(s))
+        return lib.rl4co_attn_bwd(1, vp(qkv.data_ptr()), vp(out.data_ptr()), vp(go.data_ptr()), vp(lse.data_ptr()), b, n, vp(dqkv.data_ptr()), vp(s))
 
     assert bwd() == 0
     torch.cuda.synchronize()

@@ -15,8 +15,8 @@ for b, n in ((4096, 100), (256, 100), (4096, 50)):
     lse = torch.empty(b, 8, n, device="cuda")
     dqkv = torch.empty_like(qkv)
     s = torch.cuda.current_stream().cuda_stream
-    lib.rl4co_attn_fwd_bf16(vp(qkv.data_ptr()), b, n, vp(out.data_ptr()), vp(lse.data_ptr()), vp(s))
-    bwd = lambda: lib.rl4co_attn_bwd_bf16(vp(qkv.data_ptr()), vp(out.data_ptr()), vp(go.data_ptr()), vp(lse.data_ptr()), b, n, vp(dqkv.data_ptr()), vp(s))  # noqa: E731
+    lib.rl4co_attn_fwd(1, vp(qkv.data_ptr()), b, n, vp(out.data_ptr()), vp(lse.data_ptr()), vp(s))
+    bwd = lambda: lib.rl4co_attn_bwd(1, vp(qkv.data_ptr()), vp(out.data_ptr()), vp(go.data_ptr()), vp(lse.data_ptr()), b, n, vp(dqkv.data_ptr()), vp(s))  # noqa: E731
     for _ in range(3):
         bwd()
     torch.cuda.synchronize()

@@ -33,7 +33,7 @@ with torch.inference_mode():
     out = torch.empty(B, N, 128, device="cuda", dtype=DT)
     st = torch.cuda.current_stream().cuda_stream
     bound = torch.full((B, 8, 2), 4.0, device="cuda")  # |q|^2 |k|^2 = 16 <= 48^2: the max-free path
-    fast = timeit(lambda: _lib.check(_lib.lib().rl4co_attn_flash_pre_bf16(qkv.data_ptr(), bound.data_ptr(), B, N, out.data_ptr(), st), "flash"))
+    fast = timeit(lambda: _lib.check(_lib.lib().rl4co_attn_flash_pre(1, qkv.data_ptr(), bound.data_ptr(), B, N, out.data_ptr(), st), "flash"))
     big = torch.full((B, 8, 2), 1e4, device="cuda")
-    exact = timeit(lambda: _lib.check(_lib.lib().rl4co_attn_flash_pre_bf16(qkv.data_ptr(), big.data_ptr(), B, N, out.data_ptr(), st), "flash"))
+    exact = timeit(lambda: _lib.check(_lib.lib().rl4co_attn_flash_pre(1, qkv.data_ptr(), big.data_ptr(), B, N, out.data_ptr(), st), "flash"))
 print(f"C5 encoder {enc:.3f} ms   attention launch: max-free path {fast * 1e3:.0f} us, exact path {exact * 1e3:.0f} us")

@@ -1,5 +1,5 @@
-"""Micro-benchmarks of the training kernels on the training shapes (M = 4096 x 100 token rows): rl4co_linear_bf16 vs hipBLASLt,
-rl4co_wgrad_bf16 (partial-sum reduction included), skip + instance norm and self-attention forward / backward."""
+"""Micro-benchmarks of the training kernels on the training shapes (M = 4096 x 100 token rows): rl4co_linear vs hipBLASLt,
+rl4co_wgrad (partial-sum reduction included), skip + instance norm and self-attention forward / backward."""
 import sys, torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from rl4co_amd import train_ops as T
