@@ -795,8 +795,9 @@ class AttentionModelPolicy(nn.Module):
                  return_sum_log_likelihood: bool = True, actions: Tensor | None = None,
                  max_steps: int = 1_000_000, **decoding_kwargs) -> dict:
         grad_path = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if not self.fold and grad_path:
-            raise NotImplementedError("fold=False is the inference parity configuration; train with the folded cache")
+        # fold=False (the reference's own association of the decoder, tsp / cvrp) also trains since r06: the rollout runs on the
+        # unfolded decode kernel, the gradient comes from the dense torch re-evaluation of the same trajectories
+        # (evaluate_log_probs: the reference's modules applied in the reference's order) — no teacher-forced kernel, said once
         cache_dtype = self._plane_dtype(grad_path)
         # 1. encoder (+ the cache fold where the fused kernels produce it)
         cache, hidden, init_embeds = self._encode_for_rollout(td, grad_path, cache_dtype, return_hidden, return_init_embeds)
@@ -813,7 +814,7 @@ class AttentionModelPolicy(nn.Module):
         b_inst, n = td["action_mask"].shape[0], td["action_mask"].shape[-1]
         b = b_inst * max(n_rep, 1)
         cache_g = None
-        if cache is None and grad_path and self.fused_backward and hidden.is_cuda:
+        if cache is None and grad_path and self.fused_backward and hidden.is_cuda and self.fold:
             from . import teacher
 
             if teacher.supports(self.env_name, cache_dtype, n) and not return_entropy:
@@ -1019,7 +1020,8 @@ class AttentionModelPolicy(nn.Module):
                 from . import _lib as _l
 
                 t_max = __import__("rl4co_amd.teacher", fromlist=["max_nodes"]).max_nodes()
-                why = (f"{n} nodes are beyond the kernels' limit ({t_max})" if n > t_max else
+                why = ("fold=False keeps the reference's per-step association, which the backward kernels do not implement" if not self.fold else
+                       f"{n} nodes are beyond the kernels' limit ({t_max})" if n > t_max else
                        f"{cache_dtype} planes are not served by the backward kernels (float32, bfloat16 or float16 planes) for this call")
                 _l.warn_fallback(f"teacher/{self.env_name}/{n}/{cache_dtype}",
                                  f"teacher-forced backward for {self.env_name}: {why} — dense torch re-evaluation with autograd")
