@@ -404,6 +404,8 @@ class Bench:
         torch.manual_seed(0)  # random-init weights of the reference architecture, identical on every rank
         policy = AttentionModelPolicy(env_name=env_name, cache_dtype=cache_dtype,
                                       encoder_autocast=enc_dtype).to(self.device).eval()
+        if os.environ.get("RL4CO_BENCH_DECODE_VARIANT"):  # probe: pin the decode kernel variant (stream / lds / wide / ms)
+            policy.decode_variant = os.environ["RL4CO_BENCH_DECODE_VARIANT"]
         env = get_env(env_name, generator_params=dict(num_loc=num_loc, device=self.device), device=self.device,
                       check_solution=not a.no_check_solution)
         torch.manual_seed(1234 + self.rank)  # each rank owns its shard of the synthetic instances

@@ -882,6 +882,7 @@ class AttentionModelPolicy(nn.Module):
             tanh_clipping=tanh_clipping, temperature=temperature, mask_inner=self.decoder.mask_inner,
             mask_logits=mask_logits, exp_noise=exp_noise, philox_seed=philox_seed, philox_seed_dev=seed_dev,
             forced_actions=forced, all_logps=all_logps, steps_summary=status[2:6],
+            variant=getattr(self, "decode_variant", "auto"),  # ("auto": the library chooses; bench / probes may pin one)
         )
         if self.decode_events is not None:
             ev1.record()
