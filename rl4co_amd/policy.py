@@ -429,6 +429,19 @@ class AttentionModelDecoder(nn.Module):
 _KNOWN_DECODE_TYPES = ("greedy", "sampling", "multistart_greedy", "multistart_sampling", "evaluate")
 
 
+def _cuda_tensors(objs):
+    """The CUDA tensors of an encoder result (a FoldedCache or None, the node embeddings, the initial embeddings)."""
+    for o in objs:
+        if torch.is_tensor(o):
+            if o.is_cuda:
+                yield o
+        elif isinstance(o, FoldedCache):
+            for k in FoldedCache.TENSOR_FIELDS:
+                t = getattr(o, k)
+                if t is not None and t.is_cuda:
+                    yield t
+
+
 def _parse_decode_type(decode_type: str):
     if decode_type not in _KNOWN_DECODE_TYPES:
         if decode_type == "beam_search":
@@ -800,7 +813,19 @@ class AttentionModelPolicy(nn.Module):
         # (evaluate_log_probs: the reference's modules applied in the reference's order) — no teacher-forced kernel, said once
         cache_dtype = self._plane_dtype(grad_path)
         # 1. encoder (+ the cache fold where the fused kernels produce it)
-        cache, hidden, init_embeds = self._encode_for_rollout(td, grad_path, cache_dtype, return_hidden, return_init_embeds)
+        es = getattr(self, "encoder_stream", None)
+        if es is not None and not grad_path and td["locs"].is_cuda:
+            # (graph.PriorityPipeline) the encoder launch goes out on a stream of its own — a high-priority one shared by
+            # every rollout in flight — and this rollout's stream picks the cache up behind it
+            cur = torch.cuda.current_stream()
+            es.wait_stream(cur)
+            with torch.cuda.stream(es):
+                cache, hidden, init_embeds = self._encode_for_rollout(td, grad_path, cache_dtype, return_hidden, return_init_embeds)
+            cur.wait_stream(es)
+            for t in _cuda_tensors((cache, hidden, init_embeds)):
+                t.record_stream(cur)
+        else:
+            cache, hidden, init_embeds = self._encode_for_rollout(td, grad_path, cache_dtype, return_hidden, return_init_embeds)
         if isinstance(env, str) or env is None:
             env = get_env(self.env_name if env is None else env)
         # 2. decoding arguments, in the reference's order of precedence
