@@ -36,7 +36,7 @@ extern "C" {
  *   6: rl4co_attn_bwd_{bf16,f16} take the forward's `out`; rl4co_abi_version() itself.
  *   7: rl4co_am_decode_args / rl4co_am_teacher_args end in the context tables' dtype and strides (ctx_dtype ...).
  *   8: the 16 rl4co_<op>_bf16 / rl4co_<op>_f16 pairs are ONE rl4co_<op>(int dtype, ...) each. */
-#define RL4CO_ABI_VERSION 8
+#define RL4CO_ABI_VERSION 9
 
 /* ---- status codes ------------------------------------------------------ */
 #define RL4CO_OK 0
@@ -219,6 +219,57 @@ int rl4co_pdp_step(const int64_t* action, uint8_t* available, uint8_t* to_delive
                    uint8_t* action_mask, uint8_t* done, int B, int N, int32_t* err, void* stream);
 int rl4co_pdp_check_solution(const int64_t* actions, int B, int N, int T, int force_start_at_depot, int32_t* err,
                              void* stream);
+
+/* --------------------------------------------------------------------------
+ * T transitions of given trajectories in ONE launch, with what the decoder saw before each of them
+ * (the `evaluate` decoding strategy's state sequence: utils/decoding.py:448-461, models/common/constructive/base.py:226-263
+ * with `actions` given; rl/ppo/ppo.py:128-170 re-evaluates stored actions the same way). Equivalent to, for t in [0, T):
+ *   masks[:, t] = action_mask ; prev[:, t] = current_node ;
+ *   TSP: first[:, t] = first_node ; use_placeholder[:, t] = (i < 1)                     (env_embeddings/context.py:86-103)
+ *   CVRP / CVRPTW / OP / PCTSP: rem[:, t] = rem_base - scalar (PCTSP: clamped at 0)     (context.py:105-213)
+ *   CVRPTW: now[:, t] = current_time ;
+ *   rl4co_<env>_step(actions[:, t], state ...)
+ * on the same state arrays (updated in place; the step semantics are those entry points', literally the same device code).
+ * `scalar` = used_capacity (CVRP, CVRPTW), tour_length (OP), cur_total_prize (PCTSP); `visited` = `available` for PDP;
+ * `demand` = real_prize [B_inst, N] for PCTSP; `max_length` = the OP entry-limit table of rl4co_op_max_length.
+ * -------------------------------------------------------------------------- */
+typedef struct rl4co_env_replay_args {
+  int32_t env;    /* RL4CO_ENV_* */
+  int32_t B;      /* trajectories (rows of the state) */
+  int32_t B_inst; /* instances (rows of the instance data); B % B_inst == 0, row b reads instance b % B_inst */
+  int32_t N;      /* nodes */
+  int32_t T;      /* steps to replay */
+  int32_t reserved0;
+  const int64_t* actions; /* [B, T] */
+  /* state, updated in place */
+  uint8_t* action_mask;  /* [B, N] */
+  int64_t* current_node; /* [B] */
+  uint8_t* done;         /* [B] */
+  int64_t* first_node;   /* [B]    TSP */
+  int64_t* step_i;       /* [B]    TSP, OP, PCTSP, PDP */
+  uint8_t* visited;      /* [B, N] CVRP, CVRPTW, OP, PCTSP; PDP: available */
+  uint8_t* to_deliver;   /* [B, N] PDP */
+  float* scalar;         /* [B]    see above */
+  float* current_time;   /* [B]    CVRPTW */
+  /* instance data */
+  const float* vehicle_capacity; /* [B]             CVRP, CVRPTW */
+  const float* demand;           /* [B_inst, N - 1] CVRP, CVRPTW; PCTSP: real prize [B_inst, N] */
+  const float* locs;             /* [B_inst, N, 2]  OP, CVRPTW */
+  const float* max_length;       /* [B_inst, N]     OP */
+  const float* time_windows;     /* [B_inst, N, 2]  CVRPTW */
+  const float* durations;        /* [B_inst, N]     CVRPTW */
+  const float* rem_base;         /* [B] minuend of the context scalar: capacity / max_length[:, 0] / prize_required */
+  /* outputs */
+  uint8_t* masks;           /* [B, T, N] */
+  int64_t* prev;            /* [B, T] */
+  int64_t* first;           /* [B, T] TSP */
+  uint8_t* use_placeholder; /* [B, T] TSP */
+  float* rem;               /* [B, T] CVRP, CVRPTW, OP, PCTSP */
+  float* now;               /* [B, T] CVRPTW */
+  int32_t* err;             /* sticky bits (RL4CO_EBIT_INFEASIBLE: an action out of range), may be NULL */
+} rl4co_env_replay_args;
+
+int rl4co_env_replay(const rl4co_env_replay_args* args, void* stream);
 
 /* --------------------------------------------------------------------------
  * N4  CVRPTWEnv (CVRP + time windows)   envs/routing/cvrptw/env.py:83-190

@@ -12,7 +12,7 @@ from functools import lru_cache
 from . import build as _build
 
 RL4CO_OK = 0
-ABI_VERSION = 8  # RL4CO_ABI_VERSION of include/rl4co_amd.h this binding's argument lists were written for
+ABI_VERSION = 9  # RL4CO_ABI_VERSION of include/rl4co_amd.h this binding's argument lists were written for
 ENV_TSP, ENV_CVRP, ENV_OP, ENV_PCTSP, ENV_PDP, ENV_CVRPTW = 0, 1, 2, 3, 4, 5
 DECODE_GREEDY, DECODE_SAMPLE, DECODE_EVALUATE = 0, 1, 2
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
@@ -83,6 +83,20 @@ class AmDecodeArgs(C.Structure):
     ]
 
 
+class EnvReplayArgs(C.Structure):
+    """Mirror of ``struct rl4co_env_replay_args``."""
+
+    _fields_ = [
+        ("env", _i32), ("B", _i32), ("B_inst", _i32), ("N", _i32), ("T", _i32), ("reserved0", _i32),
+        ("actions", _vp),
+        ("action_mask", _vp), ("current_node", _vp), ("done", _vp), ("first_node", _vp), ("step_i", _vp), ("visited", _vp),
+        ("to_deliver", _vp), ("scalar", _vp), ("current_time", _vp),
+        ("vehicle_capacity", _vp), ("demand", _vp), ("locs", _vp), ("max_length", _vp), ("time_windows", _vp),
+        ("durations", _vp), ("rem_base", _vp),
+        ("masks", _vp), ("prev", _vp), ("first", _vp), ("use_placeholder", _vp), ("rem", _vp), ("now", _vp), ("err", _vp),
+    ]
+
+
 # name -> (restype, argtypes); every symbol include/rl4co_amd.h declares.
 SYMBOLS = {
     "rl4co_version": (C.c_char_p, []),
@@ -105,6 +119,7 @@ SYMBOLS = {
     "rl4co_cvrptw_check_solution": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_pdp_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),
     "rl4co_pdp_check_solution": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
+    "rl4co_env_replay": (C.c_int, [C.POINTER(EnvReplayArgs), _vp]),
     "rl4co_am_decode": (C.c_int, [C.POINTER(AmDecodeArgs), _vp]),
     "rl4co_am_teacher_backward": (C.c_int, [_vp, _vp]),
     "rl4co_am_teacher_max_nodes": (C.c_int, []),

@@ -13,16 +13,14 @@
 
 namespace {
 
-__global__ void __launch_bounds__(64) tsp_step_kernel(const int64_t* __restrict__ action,
-                                                      uint8_t* __restrict__ mask,
-                                                      int64_t* __restrict__ first,
-                                                      int64_t* __restrict__ cur,
-                                                      int64_t* __restrict__ step_i,
-                                                      uint8_t* __restrict__ done, int B, int N,
-                                                      int32_t* err) {
-  const int b = blockIdx.x;
-  const int lane = threadIdx.x;
-  int64_t a = action[b];
+__device__ inline void tsp_step_body(const int64_t* action,
+                                                      uint8_t* mask,
+                                                      int64_t* first,
+                                                      int64_t* cur,
+                                                      int64_t* step_i,
+                                                      uint8_t* done, int B, int N,
+                                                      int32_t* err, const int b, const int lane) {
+  int64_t a = *action;
   bool bad = false;
   if (a < 0 || a >= N) {
     bad = true;
@@ -49,13 +47,24 @@ __global__ void __launch_bounds__(64) tsp_step_kernel(const int64_t* __restrict_
   }
 }
 
-__global__ void __launch_bounds__(64) cvrp_step_kernel(
-    const int64_t* __restrict__ action, const float* __restrict__ demand,
-    float* __restrict__ used_capacity, const float* __restrict__ vehicle_capacity,
-    uint8_t* __restrict__ visited, int64_t* __restrict__ cur, uint8_t* __restrict__ mask,
-    uint8_t* __restrict__ done, int B, int B_inst, int N, int32_t* err) {
-  const int b = blockIdx.x;
-  const int lane = threadIdx.x;
+__global__ void __launch_bounds__(64) tsp_step_kernel(
+    const int64_t* action,
+    uint8_t* mask,
+    int64_t* first,
+    int64_t* cur,
+    int64_t* step_i,
+    uint8_t* done,
+    int B,
+    int N,
+    int32_t* err) {
+  tsp_step_body(action ? action + blockIdx.x : nullptr, mask, first, cur, step_i, done, B, N, err, (int)blockIdx.x, (int)threadIdx.x);
+}
+
+__device__ inline void cvrp_step_body(
+    const int64_t* action, const float* demand,
+    float* used_capacity, const float* vehicle_capacity,
+    uint8_t* visited, int64_t* cur, uint8_t* mask,
+    uint8_t* done, int B, int B_inst, int N, int32_t* err, const int b, const int lane) {
   const float* dem = demand + (int64_t)(b % B_inst) * (N - 1);
   uint8_t* vis = visited + (int64_t)b * N;
   uint8_t* row = mask + (int64_t)b * N;
@@ -63,7 +72,7 @@ __global__ void __launch_bounds__(64) cvrp_step_kernel(
   int64_t c = cur[b];
   bool bad = false;
   if (action != nullptr) {
-    int64_t a = action[b];
+    int64_t a = *action;
     if (a < 0 || a >= N) {
       bad = true;
       a = 0;
@@ -100,6 +109,22 @@ __global__ void __launch_bounds__(64) cvrp_step_kernel(
     }
     if (bad && err) atomicOr(err, RL4CO_EBIT_INFEASIBLE);
   }
+}
+
+__global__ void __launch_bounds__(64) cvrp_step_kernel(
+    const int64_t* action,
+    const float* demand,
+    float* used_capacity,
+    const float* vehicle_capacity,
+    uint8_t* visited,
+    int64_t* cur,
+    uint8_t* mask,
+    uint8_t* done,
+    int B,
+    int B_inst,
+    int N,
+    int32_t* err) {
+  cvrp_step_body(action ? action + blockIdx.x : nullptr, demand, used_capacity, vehicle_capacity, visited, cur, mask, done, B, B_inst, N, err, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 }  // namespace
@@ -148,12 +173,11 @@ __global__ void op_max_length_kernel(const float* __restrict__ locs, const float
   table[idx] = (max_length[b] - op_dist(locs + (int64_t)b * N * 2, j, 0)) - 1e-6f;  // op/env.py:118-122
 }
 
-__global__ void __launch_bounds__(64) op_step_kernel(const int64_t* __restrict__ action, const float* __restrict__ locs,
-                                                     const float* __restrict__ maxlen, float* __restrict__ tour_length,
-                                                     uint8_t* __restrict__ visited, int64_t* __restrict__ cur,
-                                                     int64_t* __restrict__ step_i, uint8_t* __restrict__ mask,
-                                                     uint8_t* __restrict__ done, int B, int B_inst, int N, int32_t* err) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+__device__ inline void op_step_body(const int64_t* action, const float* locs,
+                                                     const float* maxlen, float* tour_length,
+                                                     uint8_t* visited, int64_t* cur,
+                                                     int64_t* step_i, uint8_t* mask,
+                                                     uint8_t* done, int B, int B_inst, int N, int32_t* err, const int b, const int lane) {
   const float* lc = locs + (int64_t)(b % B_inst) * N * 2;
   const float* ml = maxlen + (int64_t)(b % B_inst) * N;
   uint8_t* vis = visited + (int64_t)b * N;
@@ -162,7 +186,7 @@ __global__ void __launch_bounds__(64) op_step_kernel(const int64_t* __restrict__
   int c = (int)cur[b];
   bool bad = false;
   if (action != nullptr) {
-    int64_t a = action[b];
+    int64_t a = *action;
     if (a < 0 || a >= N) {
       bad = true;
       a = 0;
@@ -185,6 +209,23 @@ __global__ void __launch_bounds__(64) op_step_kernel(const int64_t* __restrict__
     row[j] = (j == 0 || !(vis[j] != 0 || depot_visited || exceeds)) ? 1 : 0;
   }
   if (bad && lane == 0 && err) atomicOr(err, RL4CO_EBIT_INFEASIBLE);
+}
+
+__global__ void __launch_bounds__(64) op_step_kernel(
+    const int64_t* action,
+    const float* locs,
+    const float* maxlen,
+    float* tour_length,
+    uint8_t* visited,
+    int64_t* cur,
+    int64_t* step_i,
+    uint8_t* mask,
+    uint8_t* done,
+    int B,
+    int B_inst,
+    int N,
+    int32_t* err) {
+  op_step_body(action ? action + blockIdx.x : nullptr, locs, maxlen, tour_length, visited, cur, step_i, mask, done, B, B_inst, N, err, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // op/env.py:168-194 on the padded action buffer (trailing depot zeros are neutral): duplicates among
@@ -222,14 +263,13 @@ __global__ void __launch_bounds__(64) op_check_kernel(const int64_t* __restrict_
 }
 
 // ---- CVRP with time windows (envs/routing/cvrptw/env.py:83-113) -----------------------------------
-__global__ void __launch_bounds__(64) cvrptw_step_kernel(const int64_t* __restrict__ action, const float* __restrict__ demand,
-                                                         const float* __restrict__ locs, const float* __restrict__ tw,
-                                                         const float* __restrict__ dur, float* __restrict__ used_capacity,
-                                                         const float* __restrict__ vehicle_capacity,
-                                                         float* __restrict__ current_time, uint8_t* __restrict__ visited,
-                                                         int64_t* __restrict__ cur, uint8_t* __restrict__ mask,
-                                                         uint8_t* __restrict__ done, int B_inst, int N, int32_t* err) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+__device__ inline void cvrptw_step_body(const int64_t* action, const float* demand,
+                                                         const float* locs, const float* tw,
+                                                         const float* dur, float* used_capacity,
+                                                         const float* vehicle_capacity,
+                                                         float* current_time, uint8_t* visited,
+                                                         int64_t* cur, uint8_t* mask,
+                                                         uint8_t* done, int B_inst, int N, int32_t* err, const int b, const int lane) {
   const int ib = b % B_inst;
   const float* dem = demand + (int64_t)ib * (N - 1);
   const float* lc = locs + (int64_t)ib * N * 2;
@@ -241,7 +281,7 @@ __global__ void __launch_bounds__(64) cvrptw_step_kernel(const int64_t* __restri
   int c = (int)cur[b];
   bool bad = false;
   if (action != nullptr) {
-    int64_t a = action[b];
+    int64_t a = *action;
     if (a < 0 || a >= N) {
       bad = true;
       a = 0;
@@ -280,6 +320,25 @@ __global__ void __launch_bounds__(64) cvrptw_step_kernel(const int64_t* __restri
     }
     if (bad && err) atomicOr(err, RL4CO_EBIT_INFEASIBLE);
   }
+}
+
+__global__ void __launch_bounds__(64) cvrptw_step_kernel(
+    const int64_t* action,
+    const float* demand,
+    const float* locs,
+    const float* tw,
+    const float* dur,
+    float* used_capacity,
+    const float* vehicle_capacity,
+    float* current_time,
+    uint8_t* visited,
+    int64_t* cur,
+    uint8_t* mask,
+    uint8_t* done,
+    int B_inst,
+    int N,
+    int32_t* err) {
+  cvrptw_step_body(action ? action + blockIdx.x : nullptr, demand, locs, tw, dur, used_capacity, vehicle_capacity, current_time, visited, cur, mask, done, B_inst, N, err, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // cvrptw/env.py:146-190 without its CVRP part (rl4co_cvrp_check_solution): instance-data assertions and the
@@ -325,20 +384,19 @@ __global__ void __launch_bounds__(64) cvrptw_check_kernel(const int64_t* __restr
 }
 
 // ---- prize-collecting TSP (envs/routing/pctsp/env.py:62-91,141-148) ---------------------------
-__global__ void __launch_bounds__(64) pctsp_step_kernel(const int64_t* __restrict__ action,
-                                                        const float* __restrict__ real_prize,
-                                                        float* __restrict__ total_prize, uint8_t* __restrict__ visited,
-                                                        int64_t* __restrict__ cur, int64_t* __restrict__ step_i,
-                                                        uint8_t* __restrict__ mask, uint8_t* __restrict__ done, int B_inst,
-                                                        int N, int32_t* err) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+__device__ inline void pctsp_step_body(const int64_t* action,
+                                                        const float* real_prize,
+                                                        float* total_prize, uint8_t* visited,
+                                                        int64_t* cur, int64_t* step_i,
+                                                        uint8_t* mask, uint8_t* done, int B_inst,
+                                                        int N, int32_t* err, const int b, const int lane) {
   const float* rp = real_prize + (int64_t)(b % B_inst) * N;
   uint8_t* vis = visited + (int64_t)b * N;
   uint8_t* row = mask + (int64_t)b * N;
   float prize = total_prize[b];
   bool bad = false;
   if (action != nullptr) {
-    int64_t a = action[b];
+    int64_t a = *action;
     if (a < 0 || a >= N) {
       bad = true;
       a = 0;
@@ -365,6 +423,21 @@ __global__ void __launch_bounds__(64) pctsp_step_kernel(const int64_t* __restric
   unvisited = __any(unvisited);
   if (lane == 0) row[0] = ((prize < 1.0f) && unvisited) ? 0 : 1;  // pctsp/env.py:144-147
   if (bad && lane == 0 && err) atomicOr(err, RL4CO_EBIT_INFEASIBLE);
+}
+
+__global__ void __launch_bounds__(64) pctsp_step_kernel(
+    const int64_t* action,
+    const float* real_prize,
+    float* total_prize,
+    uint8_t* visited,
+    int64_t* cur,
+    int64_t* step_i,
+    uint8_t* mask,
+    uint8_t* done,
+    int B_inst,
+    int N,
+    int32_t* err) {
+  pctsp_step_body(action ? action + blockIdx.x : nullptr, real_prize, total_prize, visited, cur, step_i, mask, done, B_inst, N, err, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // pctsp/env.py:175-201 on the padded action buffer: duplicates among the customers; total prize
@@ -394,17 +467,16 @@ __global__ void __launch_bounds__(64) pctsp_check_kernel(const int64_t* __restri
 }
 
 // ---- pickup and delivery (envs/routing/pdp/env.py:64-99) --------------------------------------
-__global__ void __launch_bounds__(64) pdp_step_kernel(const int64_t* __restrict__ action, uint8_t* __restrict__ available,
-                                                      uint8_t* __restrict__ to_deliver, int64_t* __restrict__ cur,
-                                                      int64_t* __restrict__ step_i, uint8_t* __restrict__ mask,
-                                                      uint8_t* __restrict__ done, int N, int32_t* err) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+__device__ inline void pdp_step_body(const int64_t* action, uint8_t* available,
+                                                      uint8_t* to_deliver, int64_t* cur,
+                                                      int64_t* step_i, uint8_t* mask,
+                                                      uint8_t* done, int N, int32_t* err, const int b, const int lane) {
   uint8_t* av = available + (int64_t)b * N;
   uint8_t* td = to_deliver + (int64_t)b * N;
   uint8_t* row = mask + (int64_t)b * N;
   bool bad = false;
   if (action != nullptr) {
-    int64_t a = action[b];
+    int64_t a = *action;
     if (a < 0 || a >= N) {
       bad = true;
       a = 0;
@@ -427,6 +499,19 @@ __global__ void __launch_bounds__(64) pdp_step_kernel(const int64_t* __restrict_
   left = __any(left);
   if (action != nullptr && lane == 0) done[b] = left ? 0 : 1;  // pdp/env.py:83
   if (bad && lane == 0 && err) atomicOr(err, RL4CO_EBIT_INFEASIBLE);
+}
+
+__global__ void __launch_bounds__(64) pdp_step_kernel(
+    const int64_t* action,
+    uint8_t* available,
+    uint8_t* to_deliver,
+    int64_t* cur,
+    int64_t* step_i,
+    uint8_t* mask,
+    uint8_t* done,
+    int N,
+    int32_t* err) {
+  pdp_step_body(action ? action + blockIdx.x : nullptr, available, to_deliver, cur, step_i, mask, done, N, err, (int)blockIdx.x, (int)threadIdx.x);
 }
 
 // pdp/env.py:204-223. The tour checked is 0 ++ actions unless force_start_at_depot (then actions itself).
@@ -466,7 +551,86 @@ __global__ void __launch_bounds__(64) pdp_check_kernel(const int64_t* __restrict
   if (!dup && __any(order) && lane == 0) atomicOr(err, RL4CO_EBIT_NO_PICKUP);
 }
 
+// ---- T transitions in ONE launch, with what the decoder saw before each of them ----------------------
+// The dense re-evaluation of given trajectories (policy.evaluate_log_probs: the training gradient beyond the backward
+// kernels' node limit, `evaluate` decoding with autograd, PPO) needs per step the mask, the context node(s) and the context
+// scalar(s) — ppo.py:128-170, decoding.py:448-461. Stepping the state with the kernels above costs T launches of 64-thread
+// workgroups per call (CVRP-500 x 64: 658 steps, 20 ms of launches for 2 ms of work); this is the same loop on the device:
+// one wave per trajectory runs the SAME step bodies T times over the same state arrays and tabulates between them.
+__global__ void __launch_bounds__(64) env_replay_kernel(const rl4co_env_replay_args a) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int N = a.N, T = a.T;
+  const uint8_t* row = a.action_mask + (int64_t)b * N;
+  for (int t = 0; t < T; ++t) {
+    const int64_t o = (int64_t)b * T + t;
+    uint8_t* out = a.masks + o * N;
+    for (int j = lane; j < N; j += 64) out[j] = row[j];
+    if (lane == 0) {
+      a.prev[o] = a.current_node[b];
+      if (a.env == RL4CO_ENV_TSP) {
+        a.first[o] = a.first_node[b];
+        a.use_placeholder[o] = a.step_i[b] < 1 ? 1 : 0;  // context.py:86-103: the placeholder until a node is chosen
+      } else if (a.env != RL4CO_ENV_PDP) {
+        float r = a.rem_base[b] - a.scalar[b];           // context.py:105-213: capacity / length / prize still to go
+        if (a.env == RL4CO_ENV_PCTSP && r < 0.0f) r = 0.0f;  // clamp(min=0), context.py:195
+        a.rem[o] = r;
+        if (a.env == RL4CO_ENV_CVRPTW) a.now[o] = a.current_time[b];
+      }
+    }
+    __syncthreads();
+    const int64_t* act = a.actions + o;
+    switch (a.env) {
+      case RL4CO_ENV_TSP:
+        tsp_step_body(act, a.action_mask, a.first_node, a.current_node, a.step_i, a.done, a.B, N, a.err, b, lane);
+        break;
+      case RL4CO_ENV_CVRP:
+        cvrp_step_body(act, a.demand, a.scalar, a.vehicle_capacity, a.visited, a.current_node, a.action_mask, a.done, a.B,
+                       a.B_inst, N, a.err, b, lane);
+        break;
+      case RL4CO_ENV_OP:
+        op_step_body(act, a.locs, a.max_length, a.scalar, a.visited, a.current_node, a.step_i, a.action_mask, a.done, a.B,
+                     a.B_inst, N, a.err, b, lane);
+        break;
+      case RL4CO_ENV_CVRPTW:
+        cvrptw_step_body(act, a.demand, a.locs, a.time_windows, a.durations, a.scalar, a.vehicle_capacity, a.current_time,
+                         a.visited, a.current_node, a.action_mask, a.done, a.B_inst, N, a.err, b, lane);
+        break;
+      case RL4CO_ENV_PCTSP:
+        pctsp_step_body(act, a.demand, a.scalar, a.visited, a.current_node, a.step_i, a.action_mask, a.done, a.B_inst, N,
+                        a.err, b, lane);
+        break;
+      default:
+        pdp_step_body(act, a.visited, a.to_deliver, a.current_node, a.step_i, a.action_mask, a.done, N, a.err, b, lane);
+        break;
+    }
+    __syncthreads();  // the row and the scalars lane 0 wrote are this wave's next reads
+  }
+}
+
 }  // namespace
+
+extern "C" int rl4co_env_replay(const rl4co_env_replay_args* args, void* stream) {
+  RL4CO_REQUIRE(args != nullptr);
+  const rl4co_env_replay_args& a = *args;
+  RL4CO_REQUIRE(a.env == RL4CO_ENV_TSP || a.env == RL4CO_ENV_CVRP || a.env == RL4CO_ENV_OP || a.env == RL4CO_ENV_PCTSP ||
+                a.env == RL4CO_ENV_PDP || a.env == RL4CO_ENV_CVRPTW);
+  RL4CO_REQUIRE(a.B > 0 && a.B_inst > 0 && a.B % a.B_inst == 0 && a.N >= 2 && a.T >= 1);
+  RL4CO_REQUIRE(a.actions && a.action_mask && a.current_node && a.done && a.masks && a.prev);
+  if (a.env == RL4CO_ENV_TSP) {
+    RL4CO_REQUIRE(a.first_node && a.step_i && a.first && a.use_placeholder);
+  } else if (a.env == RL4CO_ENV_PDP) {
+    RL4CO_REQUIRE(a.visited && a.to_deliver && a.step_i && a.N >= 3 && (a.N - 1) % 2 == 0);
+  } else {
+    RL4CO_REQUIRE(a.visited && a.scalar && a.rem_base && a.rem);
+    if (a.env == RL4CO_ENV_CVRP || a.env == RL4CO_ENV_CVRPTW) RL4CO_REQUIRE(a.demand && a.vehicle_capacity);
+    if (a.env == RL4CO_ENV_PCTSP) RL4CO_REQUIRE(a.demand && a.step_i);
+    if (a.env == RL4CO_ENV_OP) RL4CO_REQUIRE(a.locs && a.max_length && a.step_i);
+    if (a.env == RL4CO_ENV_CVRPTW) RL4CO_REQUIRE(a.locs && a.time_windows && a.durations && a.current_time && a.now);
+  }
+  hipLaunchKernelGGL(env_replay_kernel, dim3(a.B), dim3(64), 0, rl4co::as_stream(stream), a);
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
 
 extern "C" int rl4co_cvrptw_step(const int64_t* action, const float* demand, const float* locs, const float* time_windows,
                                  const float* durations, float* used_capacity, const float* vehicle_capacity,

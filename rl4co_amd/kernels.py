@@ -406,6 +406,90 @@ def pdp_step(action: Tensor | None, available: Tensor, to_deliver: Tensor, curre
     _lib.check(st, "rl4co_pdp_step")
 
 
+def env_replay(env_name: str, state: dict, actions: Tensor, rem_base: Tensor | None, err: Tensor | None = None) -> dict:
+    """``T`` environment transitions of the given trajectories in ONE launch (``rl4co_env_replay``): the state tensors of
+    ``policy._initial_state`` are stepped in place with ``actions[:, t]`` exactly as ``T`` calls of the env's step entry
+    would, and what the decoder saw BEFORE each step is tabulated — ``masks`` [B,T,N] bool, ``prev`` [B,T] and, by
+    environment, ``first`` / ``use_placeholder`` (TSP), ``rem`` (the context scalar: ``rem_base`` minus the running
+    capacity / length / prize), ``now`` (CVRPTW). The `evaluate` decoding's state sequence (decoding.py:448-461)."""
+    mask = _u8(state["action_mask"], "action_mask")
+    b, n = mask.shape
+    acts = _dev(actions, torch.int64, "actions")
+    if acts.dim() != 2 or acts.shape[0] != b:
+        raise ValueError(f"actions must be [B = {b}, T], got {tuple(acts.shape)}")
+    t_len = acts.shape[1]
+    dev = acts.device
+    a = _lib.EnvReplayArgs()
+    a.env, a.B, a.N, a.T = ENV_IDS[env_name], b, n, t_len
+    out = {"masks": torch.empty((b, t_len, n), dtype=torch.bool, device=dev),
+           "prev": torch.empty((b, t_len), dtype=torch.int64, device=dev)}
+    a.actions, a.action_mask = acts.data_ptr(), mask.data_ptr()
+    a.current_node = _dev(state["current_node"], torch.int64, "current_node").data_ptr()
+    a.done = _u8(state["done"], "done").data_ptr()
+    a.masks, a.prev = out["masks"].data_ptr(), out["prev"].data_ptr()
+    a.err = _ptr(err)
+    _check_rows(b, current_node=state["current_node"], done=state["done"])
+    b_inst = b
+
+    def f32(key, rows=None):
+        t = _dev(state[key], torch.float32, key)
+        if rows is not None and t.shape[0] != rows:
+            raise ValueError(f"{key} has {t.shape[0]} rows, expected {rows}")
+        return t
+
+    if env_name == "tsp":
+        out["first"] = torch.empty((b, t_len), dtype=torch.int64, device=dev)
+        out["use_placeholder"] = torch.empty((b, t_len), dtype=torch.bool, device=dev)
+        _check_rows(b, first_node=state["first_node"], i=state["i"])
+        a.first_node = _dev(state["first_node"], torch.int64, "first_node").data_ptr()
+        a.step_i = _dev(state["i"], torch.int64, "i").data_ptr()
+        a.first, a.use_placeholder = out["first"].data_ptr(), out["use_placeholder"].data_ptr()
+    elif env_name == "pdp":
+        _check_rows(b, available=state["available"], to_deliver=state["to_deliver"], i=state["i"])
+        a.visited = _u8(state["available"], "available").data_ptr()
+        a.to_deliver = _u8(state["to_deliver"], "to_deliver").data_ptr()
+        a.step_i = _dev(state["i"], torch.int64, "i").data_ptr()
+    else:
+        scalar_key = {"cvrp": "used_capacity", "cvrptw": "used_capacity", "op": "tour_length", "pctsp": "cur_total_prize"}[env_name]
+        if rem_base is None:
+            raise ValueError(f"{env_name}: rem_base (the context scalar's minuend, one per trajectory) is required")
+        base = _dev(rem_base, torch.float32, "rem_base")
+        _check_rows(b, visited=state["visited"], rem_base=base, **{scalar_key: state[scalar_key]})
+        out["rem"] = torch.empty((b, t_len), dtype=torch.float32, device=dev)
+        a.visited = _u8(state["visited"], "visited").data_ptr()
+        a.scalar, a.rem_base, a.rem = f32(scalar_key).data_ptr(), base.data_ptr(), out["rem"].data_ptr()
+        if env_name in ("cvrp", "cvrptw"):
+            dem = f32("demand")
+            b_inst = dem.shape[0]
+            if dem.shape[1] != n - 1:
+                raise ValueError(f"demand must be [B_inst, {n - 1}], got {tuple(dem.shape)}")
+            a.demand, a.vehicle_capacity = dem.data_ptr(), f32("vehicle_capacity", b).data_ptr()
+            if env_name == "cvrptw":
+                out["now"] = torch.empty((b, t_len), dtype=torch.float32, device=dev)
+                a.locs = f32("locs", b_inst).data_ptr()
+                a.time_windows, a.durations = f32("time_windows", b_inst).data_ptr(), f32("durations", b_inst).data_ptr()
+                a.current_time, a.now = f32("current_time", b).data_ptr(), out["now"].data_ptr()
+        elif env_name == "pctsp":
+            rp = f32("real_prize")
+            b_inst = rp.shape[0]
+            if rp.shape[1] != n:
+                raise ValueError(f"real_prize must be [B_inst, {n}], got {tuple(rp.shape)}")
+            a.demand, a.step_i = rp.data_ptr(), _dev(state["i"], torch.int64, "i").data_ptr()
+        else:  # op
+            lc = f32("locs")
+            b_inst = lc.shape[0]
+            a.locs, a.max_length = lc.data_ptr(), f32("max_length", b_inst).data_ptr()
+            a.step_i = _dev(state["i"], torch.int64, "i").data_ptr()
+    if b % b_inst:
+        raise ValueError(f"{b} trajectories over {b_inst} instances")
+    a.B_inst = b_inst
+    import ctypes
+
+    st = _lib.lib().rl4co_env_replay(ctypes.byref(a), _stream())
+    _lib.check(st, "rl4co_env_replay")
+    return out
+
+
 def pdp_check_solution(actions: Tensor, num_nodes: int, force_start_at_depot: bool, err: Tensor) -> None:
     """pdp/env.py:204-223 into the sticky error word (NOT_ALL_NODES / DEPOT_MIDDLE / NO_PICKUP)."""
     b, t = actions.shape

@@ -149,7 +149,8 @@ class _EncoderLayer(nn.Sequential):
                 and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)):
             from . import train_ops
 
-            x = x.to(torch.get_autocast_dtype("cuda"))
+            s_dtype = torch.get_autocast_dtype("cuda")
+            x = x.to(s_dtype)
             attn, ffn = self[0].module, self[2].module
             gemm_ok = (self.fused_linear and train_ops.linear_usable(x, attn.Wqkv.weight, attn.out_proj.weight,
                                                                       *(lin.weight for lin in ffn.lins)))
@@ -167,6 +168,8 @@ class _EncoderLayer(nn.Sequential):
                              "sub-block kernels (graph beyond the attention / norm kernels' node limit, or an unusual layer "
                              "shape): falling back piecewise to the per-op kernels and torch")
             for skip, norm in ((self[0], self[1]), (self[2], self[3])):
+                if x.dtype != s_dtype:  # torch's norm under autocast hands back fp32: the kernels take the 16-bit rows
+                    x = x.to(s_dtype)
                 s = skip.module(x, fused=gemm_ok)
                 if norm.kind == "batch" and train_ops.batch_usable(x, s):
                     x = train_ops.skip_batch_norm(x, s, norm.normalizer)
@@ -1241,8 +1244,31 @@ class AttentionModelPolicy(nn.Module):
 
     @torch.no_grad()
     def _replay(self, td, actions: Tensor, n_rep: int):
-        """Replay the trajectory through the env-step kernels to recover, per step, the mask the
-        decoder saw and the context indices (cheap: T tiny launches, no host sync)."""
+        """Per step of the given trajectories: the mask the decoder saw, the context node(s) and the context scalar(s) —
+        ONE launch (``rl4co_env_replay``: the env-step device code looped over T on the device; r06 — the T x ~2 launches
+        of ``_replay_stepwise`` were 20 of the 46 ms of a CVRP-500 x 64 REINFORCE step)."""
+        state = self._initial_state(td, n_rep)
+        b = actions.shape[0]
+        rem_base = None
+        if self.env_name == "op":
+            ml0 = state["max_length"][:, 0]
+            rem_base = (ml0 if ml0.shape[0] == b else ml0.repeat(b // ml0.shape[0])).contiguous()
+        elif self.env_name == "pctsp":
+            rem_base = state["prize_required"]
+        elif self.env_name in ("cvrp", "cvrptw"):
+            rem_base = state["vehicle_capacity"]
+        err = K.new_error_word(actions.device)
+        r = K.env_replay(self.env_name, state, actions.contiguous(), rem_base, err)
+        if self.env_name == "tsp":
+            return r["masks"], (r["first"], r["prev"]), r["use_placeholder"]
+        if self.env_name == "pdp":
+            return r["masks"], (r["prev"],), None
+        return r["masks"], (r["prev"],), (r["rem"] if self.env_name != "cvrptw" else torch.stack((r["rem"], r["now"]), -1))
+
+    @torch.no_grad()
+    def _replay_stepwise(self, td, actions: Tensor, n_rep: int):
+        """``_replay`` as T calls of the env-step kernels (what ``rl4co_env_replay`` loops on the device): the tests'
+        cross-check of the one-launch form."""
         state = self._initial_state(td, n_rep)
         b, t_len = actions.shape
         n = state["action_mask"].shape[1]

@@ -1,0 +1,100 @@
+"""rl4co_env_replay: T environment transitions of given trajectories in one launch, against T calls of the step entry points
+(the `evaluate` decoding's state sequence: /root/reference/rl4co/utils/decoding.py:448-461, constructive/base.py:226-263),
+and the REINFORCE step beyond the backward kernels' node limit that is built on it."""
+import warnings
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ENVS = [("tsp", 20), ("cvrp", 20), ("op", 20), ("pctsp", 20), ("pdp", 20), ("cvrptw", 20), ("cvrp", 150), ("tsp", 200)]
+
+
+def _rollout(env_name, num_loc, batch, starts):
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    torch.manual_seed(0)
+    policy = AttentionModelPolicy(env_name).cuda().eval()
+    env = get_env(env_name, generator_params=dict(num_loc=num_loc, device="cuda"), device="cuda", check_solution=False)
+    torch.manual_seed(5)
+    data = env.generator(batch_size=[batch])
+    kw = dict(decode_type="multistart_sampling", num_starts=starts) if starts else dict(decode_type="sampling")
+    with torch.no_grad():
+        out = policy(env.reset(data), env, phase="test", seed=11, **kw)
+    return policy, env, data, out["actions"]
+
+
+@pytest.mark.parametrize("env_name,num_loc", ENVS)
+@pytest.mark.parametrize("starts", [0, 3])
+def test_one_launch_replay_equals_the_step_by_step_replay(env_name, num_loc, starts):
+    """Bit-exact: masks, context nodes, context scalars of every step; the state is left where T step calls leave it."""
+    if starts and env_name in ("pdp",):
+        pytest.skip("no multistart for pickup-delivery in this package's environments")
+    policy, env, data, actions = _rollout(env_name, num_loc, 12, starts)
+    a = policy._replay(env.reset(data), actions, starts)
+    b = policy._replay_stepwise(env.reset(data), actions, starts)
+    assert a[0].dtype == torch.bool and torch.equal(a[0], b[0])
+    assert len(a[1]) == len(b[1]) and all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
+    if env_name == "pdp":
+        assert a[2] is None
+    else:
+        assert a[2].dtype == b[2].dtype and torch.equal(a[2], b[2])
+    # (ragged environments: some trajectories are padded past their end — the padding steps are replayed like any other)
+
+
+def test_replay_rejects_rows_that_do_not_match_and_reports_actions_out_of_range():
+    from rl4co_amd import _lib
+    from rl4co_amd import kernels as K
+
+    policy, env, data, actions = _rollout("cvrp", 20, 8, 0)
+    state = policy._initial_state(env.reset(data), 0)
+    with pytest.raises(ValueError):
+        K.env_replay("cvrp", state, actions[:4].contiguous(), state["vehicle_capacity"])
+    with pytest.raises(ValueError):
+        K.env_replay("cvrp", state, actions, None)
+    err = K.new_error_word("cuda")
+    bad = actions.clone()
+    bad[0, 3] = 99
+    K.env_replay("cvrp", state, bad, state["vehicle_capacity"], err)
+    assert int(err.item()) & _lib.EBIT_INFEASIBLE
+
+
+@pytest.mark.parametrize("env_name,num_loc,starts", [("cvrp", 150, 0), ("tsp", 160, 4)])
+def test_reinforce_step_beyond_the_backward_kernels_node_limit(env_name, num_loc, starts):
+    """Graphs beyond 128 nodes train through the per-op kernels where they serve, torch where they do not, and the dense
+    re-evaluation (r06: the step used to raise a TypeError under 16-bit autocast — torch's norm hands fp32 rows to the
+    16-bit MLP kernel). The log-likelihood the step differentiates equals the rollout's, and the gradients are those of the
+    same step on the torch encoder (cosine over all parameters)."""
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.policy import AttentionModelPolicy, _EncoderLayer
+
+    env = get_env(env_name, generator_params=dict(num_loc=num_loc, device="cuda"), device="cuda", check_solution=False)
+    torch.manual_seed(2)
+    data = env.generator(batch_size=[6])
+    grads, lls = {}, {}
+    for fused in (True, False):
+        torch.manual_seed(0)
+        pol = AttentionModelPolicy(env_name, num_encoder_layers=3, normalization="instance", use_graph_context=False,
+                                   cache_dtype=torch.bfloat16, encoder_autocast=torch.bfloat16,
+                                   train_decode_type="multistart_sampling" if starts else "sampling").cuda().train()
+        for m in pol.modules():
+            if isinstance(m, _EncoderLayer):
+                m.fused_train = fused
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            kw = dict(num_starts=starts) if starts else {}
+            out = pol(env.reset(data), env, phase="train", seed=7, **kw)
+        ll = out["log_likelihood"]
+        assert torch.isfinite(ll).all() and ll.requires_grad
+        adv = torch.linspace(-1.0, 1.0, ll.shape[0], device="cuda")
+        (adv * ll).mean().backward()
+        grads[fused] = {k: p.grad.detach().float().flatten() for k, p in pol.named_parameters() if p.grad is not None}
+        lls[fused] = (ll.detach(), out["actions"])
+        assert all(torch.isfinite(g).all() for g in grads[fused].values())
+    if torch.equal(lls[True][1], lls[False][1]):  # same trajectories sampled (the encoders differ by 16-bit rounding only)
+        a, b = grads[True], grads[False]
+        dots = sum(float(a[k] @ b[k]) for k in a)
+        cos = dots / (sum(float(v @ v) for v in a.values()) * sum(float(v @ v) for v in b.values())) ** 0.5
+        assert cos >= 0.98, cos
