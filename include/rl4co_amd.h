@@ -36,7 +36,7 @@ extern "C" {
  *   6: rl4co_attn_bwd_{bf16,f16} take the forward's `out`; rl4co_abi_version() itself.
  *   7: rl4co_am_decode_args / rl4co_am_teacher_args end in the context tables' dtype and strides (ctx_dtype ...).
  *   8: the 16 rl4co_<op>_bf16 / rl4co_<op>_f16 pairs are ONE rl4co_<op>(int dtype, ...) each. */
-#define RL4CO_ABI_VERSION 9
+#define RL4CO_ABI_VERSION 10
 
 /* ---- status codes ------------------------------------------------------ */
 #define RL4CO_OK 0
@@ -702,6 +702,9 @@ int rl4co_skip_inorm_bwd(int dtype, const void* dout, const void* y, const float
                               const float* rstd, int B, int N, void* dy, float* dgamma, float* dbeta,
                               void* stream);
 int rl4co_skip_inorm_max_nodes(void);
+/* rl4co_skip_inorm_fwd / _bwd serve N <= rl4co_skip_inorm_wide_max_nodes() (r06): beyond rl4co_skip_inorm_max_nodes() the
+ * instance's rows are re-read per pass instead of waiting in registers; same arithmetic, same accumulation order. */
+int rl4co_skip_inorm_wide_max_nodes(void);
 
 /* --------------------------------------------------------------------------
  * a12 (training)  SkipConnection + Normalization("layer")
@@ -763,12 +766,20 @@ int rl4co_wgrad(int dtype, const void* dy, const void* x, int64_t M, int N, int 
  * qkv [B,N,384] bf16 = per node (q | k | v), each 8 heads x 16 dims. forward: out [B,N,128] bf16
  * (heads concatenated) and lse [B,8,N] fp32 (log2-domain log-sum-exp of the scaled scores);
  * backward: dqkv [B,N,384] bf16 from dout [B,N,128] and the forward's own out (the softmax
- * backward's row term sum_keys P dP is taken as sum_d dout out). N <= rl4co_attn_max_nodes().
+ * backward's row term sum_keys P dP is taken as sum_d dout out). rl4co_attn_bwd: N <= rl4co_attn_max_nodes() (one
+ * workgroup holds an instance's keys); rl4co_attn_fwd: N <= rl4co_attn_wide_max_nodes() (beyond rl4co_attn_max_nodes()
+ * the keys stream through LDS with an online softmax, r06).
+ * rl4co_attn_bwd_wide (r06): the backward for any N <= rl4co_attn_wide_max_nodes(): one workgroup per (instance, half of
+ * the heads, chunk of 128 keys); d k / d v of a chunk are complete in its workgroup, the chunks' shares of d q go through
+ * `dq_partial` — a caller-provided fp32 workspace [ceil(N / 128), B, N, 128] — and are summed in chunk order.
  * -------------------------------------------------------------------------- */
 int rl4co_attn_fwd(int dtype, const void* qkv, int B, int N, void* out, float* lse, void* stream);
 int rl4co_attn_bwd(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, int B, int N,
                         void* dqkv, void* stream);
+int rl4co_attn_bwd_wide(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, int B, int N,
+                        void* dqkv, float* dq_partial, void* stream);
 int rl4co_attn_max_nodes(void);
+int rl4co_attn_wide_max_nodes(void);
 
 /* --------------------------------------------------------------------------
  * a12 (inference, large graphs)  MultiHeadAttention.forward   rl4co/models/nn/attention.py:110-134

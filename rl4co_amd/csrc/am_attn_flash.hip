@@ -74,7 +74,7 @@ __device__ inline void block_map(int b, int B, int QB, int& inst, int& qb) {
 constexpr float kFastBound = 48.0f;
 template <bool PRE>
 __global__ void __launch_bounds__(kThreads, 4) attn_flash_kernel(const uint16_t* __restrict__ qkv, const float* __restrict__ bound, int B,
-                                                                 int N, int QB, uint16_t* __restrict__ out) {
+                                                                 int N, int QB, uint16_t* __restrict__ out, float* __restrict__ lse) {
   constexpr int kLds = kKB * kKS > kQT * 16 * kOS ? kKB * kKS : kQT * 16 * kOS;
   __shared__ __align__(16) elem_t kv[kLds];  // one key block: [64][k 128 | v 128]; later the output staging rows
   const int tid = threadIdx.x, h = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
@@ -227,7 +227,12 @@ __global__ void __launch_bounds__(kThreads, 4) attn_flash_kernel(const uint16_t*
   // ---- normalise, stage, leave as contiguous 16-byte lanes ------------------------------------------------------
 #pragma unroll
   for (int t = 0; t < kQT; ++t) {
-    const float inv = __builtin_amdgcn_rcpf(rl4co::bfly_sum<16, 64>(l[t]));
+    const float lt = rl4co::bfly_sum<16, 64>(l[t]);
+    const float inv = __builtin_amdgcn_rcpf(lt);
+    // training (rl4co_attn_fwd beyond one workgroup's nodes): the log-sum-exp of the scaled scores, log2 domain — what
+    // am_train_attn.hip's backward kernels rebuild the probabilities from
+    if (!PRE && lse != nullptr && g == 0 && q0 + 16 * t + tl < N)
+      lse[((int64_t)inst * kWaves + h) * N + q0 + 16 * t + tl] = m[t] + __builtin_amdgcn_logf(lt);
     *reinterpret_cast<bf16x4*>(kv + (16 * t + tl) * kOS + 16 * h + 4 * g) =
         rl4co_e16::cvt4(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv);
   }
@@ -247,7 +252,19 @@ extern "C" int RL4CO_ENTRY(rl4co_attn_flash)(const void* qkv, int B, int N, void
   const int QB = (N + kQT * 16 - 1) / (kQT * 16);
   RL4CO_REQUIRE((int64_t)B * QB < (1ll << 31));
   hipLaunchKernelGGL(attn_flash_kernel<false>, dim3(B * QB), dim3(kThreads), 0, rl4co::as_stream(stream),
-                     static_cast<const uint16_t*>(qkv), static_cast<const float*>(nullptr), B, N, QB, static_cast<uint16_t*>(out));
+                     static_cast<const uint16_t*>(qkv), static_cast<const float*>(nullptr), B, N, QB, static_cast<uint16_t*>(out),
+                     static_cast<float*>(nullptr));
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
+}
+
+// the same launch with the log-sum-exp kept [B, 8, N]: rl4co_attn_fwd's path beyond rl4co_attn_max_nodes() (am_train_attn.hip)
+extern "C" int RL4CO_ENTRY(rl4co_attn_flash_lse)(const void* qkv, int B, int N, void* out, float* lse, void* stream) {
+  RL4CO_REQUIRE(qkv && out && lse && B > 0 && N >= 1 && N <= 65536);
+  const int QB = (N + kQT * 16 - 1) / (kQT * 16);
+  RL4CO_REQUIRE((int64_t)B * QB < (1ll << 31));
+  hipLaunchKernelGGL(attn_flash_kernel<false>, dim3(B * QB), dim3(kThreads), 0, rl4co::as_stream(stream),
+                     static_cast<const uint16_t*>(qkv), static_cast<const float*>(nullptr), B, N, QB, static_cast<uint16_t*>(out), lse);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }
@@ -257,7 +274,7 @@ extern "C" int RL4CO_ENTRY(rl4co_attn_flash_pre)(const void* qkv, const float* b
   const int QB = (N + kQT * 16 - 1) / (kQT * 16);
   RL4CO_REQUIRE((int64_t)B * QB < (1ll << 31));
   hipLaunchKernelGGL(attn_flash_kernel<true>, dim3(B * QB), dim3(kThreads), 0, rl4co::as_stream(stream),
-                     static_cast<const uint16_t*>(qkv), bound, B, N, QB, static_cast<uint16_t*>(out));
+                     static_cast<const uint16_t*>(qkv), bound, B, N, QB, static_cast<uint16_t*>(out), static_cast<float*>(nullptr));
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }

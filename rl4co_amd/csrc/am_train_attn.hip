@@ -390,6 +390,188 @@ __global__ void __launch_bounds__(kBwdThreads, 3) attn_bwd_kernel(const uint16_t
   RL4CO_ABP_MARK(3)
 }
 
+// Backward beyond one workgroup's nodes (N > 128; r06). The same workgroup as above — four waves = four heads of one half,
+// eight key tiles — now owns ONE CHUNK of 128 keys of an instance: its k | v rows sit in LDS, their d k / d v accumulate in
+// registers over ALL query blocks of the instance (the probabilities are rebuilt from the forward's log-sum-exp over all
+// keys, so a chunk needs nothing from the others), and what the chunk contributes to d q — the one product that contracts
+// over keys — leaves per query block as fp32 partial rows [chunk][B][N][128]; attn_dq_reduce_kernel sums the chunks in a
+// fixed order, applies the 1 / 4 and writes the 16-bit d q columns. (Atomics instead of the partial rows: 2 x B N 128 of
+// them into L2 at TSP-200 — as long as the kernel itself; a second, query-stationary kernel for d q: every score and
+// every dP twice.)
+constexpr int kWT = 8;           // key tiles per chunk
+constexpr int kDW = 2 * 64 + 8;  // output staging row: d k | d v of four heads
+
+__global__ void __launch_bounds__(kBwdThreads, 3) attn_bwd_wide_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
+                                                                       const uint16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                                       int B, int N, int KC, uint16_t* __restrict__ dqkv,
+                                                                       float* __restrict__ dq_partial) {
+  constexpr int NT = kWT;
+  extern __shared__ __align__(16) unsigned char smem[];
+  elem_t* kv = reinterpret_cast<elem_t*>(smem);  // [128][kKH]: k (4 heads) | v (4 heads) of this chunk's keys
+  const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, tl = lane & 15, g = lane >> 4;
+  const int hh = blockIdx.x & 1, kc = (blockIdx.x >> 1) % KC;  // the chunks and halves of ONE instance are neighbours: they
+  const int64_t inst = (blockIdx.x >> 1) / KC;                 // re-read the same q / d out / out rows (L2)
+  const int h = 4 * hh + w;
+  const int key0 = 16 * NT * kc;
+  constexpr int kWaveStage = NT * 16 * kSS + 16 * kQD + 64;
+  elem_t* dsb = kv + NT * 16 * kKH + w * kWaveStage;
+  elem_t* qd = dsb + NT * 16 * kSS;
+  float2* ld = reinterpret_cast<float2*>(qd + 16 * kQD);
+  const uint16_t* base = qkv + inst * N * 3 * kD;
+  {
+    constexpr int total = NT * 16 * 16;
+    for (int c0 = tid; c0 < total; c0 += 8 * kBwdThreads) {
+      uint4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = min(c0 + j * kBwdThreads, total - 1);
+        const int row = min(key0 + (c >> 4), N - 1), part = (c >> 3) & 1, ch = c & 7;
+        v[j] = *reinterpret_cast<const uint4*>(base + (int64_t)row * 3 * kD + kD * (1 + part) + 64 * hh + 8 * ch);
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = c0 + j * kBwdThreads;
+        if (c < total) {
+          const int row = c >> 4, col = (c & 15) * 8;
+          *reinterpret_cast<uint4*>(kv + row * kKH + col) = key0 + row < N ? v[j] : make_uint4(0, 0, 0, 0);
+        }
+      }
+    }
+  }
+  const uint16_t* qrow = base + 16 * h + 4 * g;
+  const uint16_t* dorow = dout + inst * N * kD + 16 * h + 4 * g;
+  const uint16_t* orow = out + inst * N * kD + 16 * h + 4 * g;
+  const float* lrow = lse + (inst * kWaves + h) * N;
+  float* dqp = dq_partial + (((int64_t)kc * B + inst) * N) * kD + 16 * h + 4 * g;
+  const int QT = (N + 15) >> 4;
+  auto row_of = [&](int tb) { return (int64_t)min(16 * tb + tl, N - 1); };
+  uint2 q_next = *reinterpret_cast<const uint2*>(qrow + row_of(0) * 3 * kD);
+  uint2 do_next = *reinterpret_cast<const uint2*>(dorow + row_of(0) * kD);
+  uint2 o_next = *reinterpret_cast<const uint2*>(orow + row_of(0) * kD);
+  float L_next = lrow[row_of(0)];
+  __syncthreads();
+  const int nao = tl * kKH + 4 * g;
+  const int tro = (4 * g + (tl >> 2)) * kKH + 4 * (tl & 3), tro_q = (4 * g + (tl >> 2)) * kQD + 4 * (tl & 3),
+            tro_s = (4 * g + (tl >> 2)) * kSS + 4 * (tl & 3);
+  f32x4 dk[NT], dv[NT];
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+    dk[jt] = zero4();
+    dv[jt] = zero4();
+  }
+  for (int tb = 0; tb < QT; ++tb) {
+    const int t = 16 * tb + tl;
+    const bool tv = t < N;
+    const bf16x4 qf = __builtin_bit_cast(bf16x4, q_next);
+    const bf16x4 dof = __builtin_bit_cast(bf16x4, tv ? do_next : make_uint2(0u, 0u));
+    const float L = L_next;
+    float dsum;  // -D = -sum_d dO O of this (query, head): see attn_bwd_kernel
+    {
+      const uint2 ou = o_next, du = tv ? do_next : make_uint2(0u, 0u);
+      dsum = rl4co_e16::lo(ou.x) * rl4co_e16::lo(du.x);
+      dsum = fmaf(rl4co_e16::hi(ou.x), rl4co_e16::hi(du.x), dsum);
+      dsum = fmaf(rl4co_e16::lo(ou.y), rl4co_e16::lo(du.y), dsum);
+      dsum = fmaf(rl4co_e16::hi(ou.y), rl4co_e16::hi(du.y), dsum);
+      dsum = -rg_sum(dsum);
+    }
+    {
+      const int64_t rn = row_of(min(tb + 1, QT - 1));  // (the last block re-reads itself: no branch around the loads)
+      q_next = *reinterpret_cast<const uint2*>(qrow + rn * 3 * kD);
+      do_next = *reinterpret_cast<const uint2*>(dorow + rn * kD);
+      o_next = *reinterpret_cast<const uint2*>(orow + rn * kD);
+      L_next = lrow[rn];
+    }
+    *reinterpret_cast<bf16x4*>(qd + tl * kQD + 4 * g) = dof;
+    *reinterpret_cast<bf16x4*>(qd + tl * kQD + 16 + 4 * g) = qf;
+    if (g == 0) ld[tl] = make_float2(L, dsum);
+    wave_lds_sync();
+    const float4 s01 = *reinterpret_cast<const float4*>(ld + 4 * g), s23 = *reinterpret_cast<const float4*>(ld + 4 * g + 2);
+    const float Lr[4] = {s01.x, s01.z, s23.x, s23.z};
+    const f32x4 negD = {s01.y, s01.w, s23.y, s23.w};
+    const bf16x4 dt = lds_tr(qd + tro_q);
+    const bf16x4 qt = lds_tr(qd + 16 + tro_q);
+    constexpr int kG = 2;
+#pragma clang loop unroll(full)
+    for (int j0 = 0; j0 < NT; j0 += kG) {
+      bf16x4 kf[kG], vf[kG], pf[kG], dsf[kG];
+      f32x4 sc[kG], dp[kG];
+#pragma unroll
+      for (int j = 0; j < kG; ++j) {
+        kf[j] = lds_b64(kv + 16 * (j0 + j) * kKH + 16 * w + nao);
+        vf[j] = lds_b64(kv + 16 * (j0 + j) * kKH + 64 + 16 * w + nao);
+      }
+#pragma unroll
+      for (int j = 0; j < kG; ++j) sc[j] = mfma16(qf, kf[j], zero4());  // S[query 4 g + r][key tl]
+#pragma unroll
+      for (int j = 0; j < kG; ++j) dp[j] = mfma16(dof, vf[j], negD);    // dP - D
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < kG; ++j) {
+        float p4[4];
+        const bool kvd = key0 + 16 * (j0 + j) + tl < N;  // keys past the graph: P = 0, hence dS = 0 (see attn_bwd_kernel)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const float e = __builtin_amdgcn_exp2f(fmaf(sc[j][rr], kScale, -Lr[rr]));
+          p4[rr] = kvd ? e : 0.0f;
+        }
+        pf[j] = rl4co_e16::cvt4(p4[0], p4[1], p4[2], p4[3]);
+        dsf[j] = rl4co_e16::cvt4(p4[0] * dp[j][0], p4[1] * dp[j][1], p4[2] * dp[j][2], p4[3] * dp[j][3]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < kG; ++j) {
+        dv[j0 + j] = mfma16(dt, pf[j], dv[j0 + j]);
+        dk[j0 + j] = mfma16(qt, dsf[j], dk[j0 + j]);
+        *reinterpret_cast<bf16x4*>(dsb + (16 * (j0 + j) + tl) * kSS + 4 * g) = dsf[j];  // [key][queries 4 g ..]
+      }
+    }
+    wave_lds_sync();
+    f32x4 dq = zero4();
+#pragma clang loop unroll(full)
+    for (int jt = 0; jt < NT; ++jt)
+      dq = mfma16(lds_tr(kv + 16 * jt * kKH + 16 * w + tro), lds_tr(dsb + 16 * jt * kSS + tro_s), dq);
+    if (tv) *reinterpret_cast<f32x4*>(dqp + (int64_t)t * kD) = dq;  // this chunk's share, unscaled: [dims 4 g ..] of query t
+    wave_lds_sync();  // the next query block rewrites this wave's staging block
+  }
+  __syncthreads();  // every wave is done with k | v: the LDS becomes [128][d k | d v] of the four heads
+  elem_t* os = reinterpret_cast<elem_t*>(smem);
+#pragma unroll
+  for (int jt = 0; jt < NT; ++jt) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) dk[jt][rr] *= 0.25f;
+    elem_t* row = os + (16 * jt + tl) * kDW + 16 * w + 4 * g;
+    *reinterpret_cast<bf16x4*>(row) = to_bf16(dk[jt]);
+    *reinterpret_cast<bf16x4*>(row + 64) = to_bf16(dv[jt]);
+  }
+  __syncthreads();
+  const int nk = min(16 * NT, N - key0);
+  for (int c = tid; c < nk * 16; c += kBwdThreads) {  // two 128-byte segments per row
+    const int row = c >> 4, seg = (c >> 3) & 1, ch = c & 7;
+    *reinterpret_cast<uint4*>(dqkv + (inst * N + key0 + row) * 3 * kD + (1 + seg) * kD + 64 * hh + 8 * ch) =
+        *reinterpret_cast<const uint4*>(os + row * kDW + 64 * seg + 8 * ch);
+  }
+}
+
+// d q = 1 / 4 of the sum of the key chunks' shares, in chunk order -> the q columns of d qkv
+__global__ void __launch_bounds__(256) attn_dq_reduce_kernel(const float* __restrict__ part, int KC, int64_t rows,
+                                                             uint16_t* __restrict__ dqkv) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= rows * 16) return;
+  const int64_t row = idx >> 4;
+  const int col = (int)(idx & 15) * 8;
+  f32x4 a0 = zero4(), a1 = zero4();
+  for (int c = 0; c < KC; ++c) {
+    const float* p = part + ((int64_t)c * rows + row) * kD + col;
+    a0 += *reinterpret_cast<const f32x4*>(p);
+    a1 += *reinterpret_cast<const f32x4*>(p + 4);
+  }
+  const bf16x4 lo = rl4co_e16::cvt4(0.25f * a0[0], 0.25f * a0[1], 0.25f * a0[2], 0.25f * a0[3]);
+  const bf16x4 hi = rl4co_e16::cvt4(0.25f * a1[0], 0.25f * a1[1], 0.25f * a1[2], 0.25f * a1[3]);
+  uint16_t* dst = dqkv + row * 3 * kD + col;
+  *reinterpret_cast<bf16x4*>(dst) = lo;
+  *reinterpret_cast<bf16x4*>(dst + 4) = hi;
+}
+
 template <int NT>
 int launch_fwd(const void* qkv, int B, int N, void* out, float* lse, hipStream_t s) {
   const int lds = NT * 16 * kKV * 2;
@@ -412,8 +594,11 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
 
 }  // namespace
 
+extern "C" int RL4CO_ENTRY(rl4co_attn_flash_lse)(const void* qkv, int B, int N, void* out, float* lse, void* stream);  // am_attn_flash.hip
+
 #if !RL4CO_ELEM_F16
 extern "C" int rl4co_attn_max_nodes(void) { return 128; }
+extern "C" int rl4co_attn_wide_max_nodes(void) { return 1024; }
 #if RL4CO_ATTN_BWD_PROBE >= 3
 extern "C" int rl4co_attn_bwd_probe_read(unsigned long long* out, int reset) {
   RL4CO_HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_bwd_clk), sizeof(g_attn_bwd_clk)));
@@ -427,7 +612,8 @@ extern "C" int rl4co_attn_bwd_probe_read(unsigned long long* out, int reset) {
 #endif
 
 extern "C" int RL4CO_ENTRY(rl4co_attn_fwd)(const void* qkv, int B, int N, void* out, float* lse, void* stream) {
-  RL4CO_REQUIRE(qkv && out && lse && B > 0 && N >= 1 && N <= 128);
+  RL4CO_REQUIRE(qkv && out && lse && B > 0 && N >= 1 && N <= 1024);
+  if (N > 128) return RL4CO_IMPL(rl4co_attn_flash_lse)(qkv, B, N, out, lse, stream);  // keys streamed through LDS, online softmax
   hipStream_t s = rl4co::as_stream(stream);
   const int nt = (N + 15) >> 4;
   if (nt <= 2) return launch_fwd<2>(qkv, B, N, out, lse, s);
@@ -445,4 +631,24 @@ extern "C" int RL4CO_ENTRY(rl4co_attn_bwd)(const void* qkv, const void* out, con
   if (nt <= 4) return launch_bwd<4>(qkv, out, dout, lse, B, N, dqkv, s);
   if (nt <= 7) return launch_bwd<7>(qkv, out, dout, lse, B, N, dqkv, s);
   return launch_bwd<8>(qkv, out, dout, lse, B, N, dqkv, s);
+}
+
+extern "C" int RL4CO_ENTRY(rl4co_attn_bwd_wide)(const void* qkv, const void* out, const void* dout, const float* lse, int B, int N,
+                                                void* dqkv, float* dq_partial, void* stream) {
+  RL4CO_REQUIRE(qkv && out && dout && lse && dqkv && dq_partial && B > 0 && N >= 1 && N <= 1024);
+  const int KC = (N + 16 * kWT - 1) / (16 * kWT);
+  RL4CO_REQUIRE((int64_t)B * KC * 2 < (1ll << 31));
+  hipStream_t s = rl4co::as_stream(stream);
+  constexpr int work = (kWT * 16 * kKH + kBwdWaves * (kWT * 16 * kSS + 16 * kQD + 64)) * 2, stage = kWT * 16 * kDW * 2;
+  constexpr int lds = work > stage ? work : stage;
+  RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_wide_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  hipLaunchKernelGGL(attn_bwd_wide_kernel, dim3(2 * B * KC), dim3(kBwdThreads), lds, s, static_cast<const uint16_t*>(qkv),
+                     static_cast<const uint16_t*>(out), static_cast<const uint16_t*>(dout), lse, B, N, KC,
+                     static_cast<uint16_t*>(dqkv), dq_partial);
+  RL4CO_HIP_TRY(hipGetLastError());
+  const int64_t rows = (int64_t)B * N;
+  hipLaunchKernelGGL(attn_dq_reduce_kernel, dim3((unsigned)((rows * 16 + 255) / 256)), dim3(256), 0, s, dq_partial, KC, rows,
+                     static_cast<uint16_t*>(dqkv));
+  RL4CO_HIP_TRY(hipGetLastError());
+  return RL4CO_OK;
 }

@@ -167,6 +167,100 @@ __global__ void __launch_bounds__(kThreads) skip_inorm_bwd_kernel(const uint32_t
   }
 }
 
+// ---- the same two kernels for graphs beyond 4 * kMaxRows nodes (r06). Nothing waits in registers: the instance's rows
+// (256 bytes per node) are read again for each pass — from L2, the workgroup wrote or read them a moment ago. Thread
+// layout, accumulation order and arithmetic are the register-resident kernels', so the results are theirs bit for bit.
+constexpr int kWideRows = 8;  // rows in flight per thread and pass
+
+template <typename F>
+__device__ inline void wide_rows(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, int64_t base, int cp, int q, int N,
+                                 F&& body) {
+  for (int n0 = q; n0 < N; n0 += 4 * kWideRows) {
+    uint32_t ra[kWideRows], rb[kWideRows];
+#pragma unroll
+    for (int i = 0; i < kWideRows; ++i) {  // all loads first; rows past N re-read the last row and are ignored
+      const int n = min(n0 + 4 * i, N - 1);
+      ra[i] = a[base + (int64_t)n * (kD / 2) + cp];
+      rb[i] = b != nullptr ? b[base + (int64_t)n * (kD / 2) + cp] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < kWideRows; ++i)
+      if (n0 + 4 * i < N) body(n0 + 4 * i, ra[i], rb[i]);
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) skip_inorm_fwd_wide_kernel(const uint32_t* __restrict__ x, const uint32_t* __restrict__ s,
+                                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                       float eps, int N, uint32_t* y, uint32_t* __restrict__ out,
+                                                                       float* __restrict__ mean, float* __restrict__ rstd) {
+  __shared__ float red[kThreads * 2];
+  const int tid = threadIdx.x, cp = tid & 63, q = tid >> 6;
+  const int64_t base = (int64_t)blockIdx.x * N * (kD / 2);
+  float sum[2] = {0.0f, 0.0f};
+  wide_rows(x, s, base, cp, q, N, [&](int n, uint32_t a, uint32_t b) {
+    const uint32_t ys = pack_bf16(bf16_lo(a) + bf16_lo(b), bf16_hi(a) + bf16_hi(b));
+    y[base + (int64_t)n * (kD / 2) + cp] = ys;
+    sum[0] += bf16_lo(ys);
+    sum[1] += bf16_hi(ys);
+  });
+  sum4(sum, red, tid);
+  const float inv_n = 1.0f / (float)N;
+  const float mu[2] = {sum[0] * inv_n, sum[1] * inv_n};
+  float sq[2] = {0.0f, 0.0f};
+  // (a thread re-reads the words it wrote itself: same address, program order)
+  wide_rows(y, nullptr, base, cp, q, N, [&](int, uint32_t ys, uint32_t) {
+    const float d0 = bf16_lo(ys) - mu[0], d1 = bf16_hi(ys) - mu[1];
+    sq[0] = fmaf(d0, d0, sq[0]);
+    sq[1] = fmaf(d1, d1, sq[1]);
+  });
+  sum4(sq, red, tid);
+  const float rs[2] = {rsqrtf(sq[0] * inv_n + eps), rsqrtf(sq[1] * inv_n + eps)};
+  const float g0 = gamma[2 * cp], g1 = gamma[2 * cp + 1], b0 = beta[2 * cp], b1 = beta[2 * cp + 1];
+  wide_rows(y, nullptr, base, cp, q, N, [&](int n, uint32_t ys, uint32_t) {
+    out[base + (int64_t)n * (kD / 2) + cp] =
+        pack_bf16(fmaf((bf16_lo(ys) - mu[0]) * rs[0], g0, b0), fmaf((bf16_hi(ys) - mu[1]) * rs[1], g1, b1));
+  });
+  if (q == 0) {
+    mean[(int64_t)blockIdx.x * kD + 2 * cp] = mu[0];
+    mean[(int64_t)blockIdx.x * kD + 2 * cp + 1] = mu[1];
+    rstd[(int64_t)blockIdx.x * kD + 2 * cp] = rs[0];
+    rstd[(int64_t)blockIdx.x * kD + 2 * cp + 1] = rs[1];
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) skip_inorm_bwd_wide_kernel(const uint32_t* __restrict__ dout, const uint32_t* __restrict__ y,
+                                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                                       const float* __restrict__ rstd, int N, uint32_t* __restrict__ dy,
+                                                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float red[kThreads * 2];
+  const int tid = threadIdx.x, cp = tid & 63, q = tid >> 6;
+  const int64_t base = (int64_t)blockIdx.x * N * (kD / 2);
+  const float mu[2] = {mean[(int64_t)blockIdx.x * kD + 2 * cp], mean[(int64_t)blockIdx.x * kD + 2 * cp + 1]};
+  const float rs[2] = {rstd[(int64_t)blockIdx.x * kD + 2 * cp], rstd[(int64_t)blockIdx.x * kD + 2 * cp + 1]};
+  const float g[2] = {gamma[2 * cp], gamma[2 * cp + 1]};
+  float s_d[2] = {0.0f, 0.0f}, s_dx[2] = {0.0f, 0.0f};
+  wide_rows(dout, y, base, cp, q, N, [&](int, uint32_t a, uint32_t b) {
+    const float d0 = bf16_lo(a), d1 = bf16_hi(a);
+    s_d[0] += d0;
+    s_d[1] += d1;
+    s_dx[0] = fmaf(d0, (bf16_lo(b) - mu[0]) * rs[0], s_dx[0]);
+    s_dx[1] = fmaf(d1, (bf16_hi(b) - mu[1]) * rs[1], s_dx[1]);
+  });
+  sum4(s_d, red, tid);
+  sum4(s_dx, red, tid);
+  const float inv_n = 1.0f / (float)N;
+  wide_rows(dout, y, base, cp, q, N, [&](int n, uint32_t a, uint32_t b) {
+    const float x0 = (bf16_lo(b) - mu[0]) * rs[0], x1 = (bf16_hi(b) - mu[1]) * rs[1];
+    const float r0 = rs[0] * g[0] * (bf16_lo(a) - s_d[0] * inv_n - x0 * s_dx[0] * inv_n);
+    const float r1 = rs[1] * g[1] * (bf16_hi(a) - s_d[1] * inv_n - x1 * s_dx[1] * inv_n);
+    dy[base + (int64_t)n * (kD / 2) + cp] = pack_bf16(r0, r1);
+  });
+  if (q == 0) {
+    *reinterpret_cast<float2*>(dgamma + (int64_t)blockIdx.x * kD + 2 * cp) = make_float2(s_dx[0], s_dx[1]);
+    *reinterpret_cast<float2*>(dbeta + (int64_t)blockIdx.x * kD + 2 * cp) = make_float2(s_d[0], s_d[1]);
+  }
+}
+
 // ---- normalization="layer" (nn/ops.py:48-51): (y - mean) / sqrt(var + 1e-5) with ONE mean and ONE UNBIASED variance over
 // all M = N x 128 values of the instance, no affine. Same thread layout as the instance-norm kernels above; the
 // statistics are workgroup-wide sums.
@@ -275,7 +369,8 @@ __global__ void __launch_bounds__(kThreads) skip_lnorm_bwd_kernel(const uint32_t
 }  // namespace
 
 #if !RL4CO_ELEM_F16
-extern "C" int rl4co_skip_inorm_max_nodes(void) { return 4 * kMaxRows; }
+extern "C" int rl4co_skip_inorm_max_nodes(void) { return 4 * kMaxRows; }  // the register-resident kernels (instance and layer norm)
+extern "C" int rl4co_skip_inorm_wide_max_nodes(void) { return 1024; }      // rl4co_skip_inorm_fwd / _bwd: rows re-read per pass beyond that
 #endif
 
 extern "C" int RL4CO_ENTRY(rl4co_skip_lnorm_fwd)(const void* x, const void* s, float eps, int B, int N, void* y, void* out,
@@ -301,10 +396,15 @@ extern "C" int RL4CO_ENTRY(rl4co_skip_lnorm_bwd)(const void* dout, const void* y
 extern "C" int RL4CO_ENTRY(rl4co_skip_inorm_fwd)(const void* x, const void* s, const float* gamma, const float* beta, float eps, int B,
                                          int N, void* y, void* out, float* mean, float* rstd, void* stream) {
   RL4CO_REQUIRE(x && s && gamma && beta && y && out && mean && rstd);
-  RL4CO_REQUIRE(B > 0 && N >= 1 && N <= 4 * kMaxRows && eps > 0.0f);
-  hipLaunchKernelGGL(skip_inorm_fwd_kernel, dim3(B), dim3(kThreads), 0, rl4co::as_stream(stream),
-                     static_cast<const uint32_t*>(x), static_cast<const uint32_t*>(s), gamma, beta, eps, N,
-                     static_cast<uint32_t*>(y), static_cast<uint32_t*>(out), mean, rstd);
+  RL4CO_REQUIRE(B > 0 && N >= 1 && N <= 1024 && eps > 0.0f);
+  if (N > 4 * kMaxRows)
+    hipLaunchKernelGGL(skip_inorm_fwd_wide_kernel, dim3(B), dim3(kThreads), 0, rl4co::as_stream(stream),
+                       static_cast<const uint32_t*>(x), static_cast<const uint32_t*>(s), gamma, beta, eps, N,
+                       static_cast<uint32_t*>(y), static_cast<uint32_t*>(out), mean, rstd);
+  else
+    hipLaunchKernelGGL(skip_inorm_fwd_kernel, dim3(B), dim3(kThreads), 0, rl4co::as_stream(stream),
+                       static_cast<const uint32_t*>(x), static_cast<const uint32_t*>(s), gamma, beta, eps, N,
+                       static_cast<uint32_t*>(y), static_cast<uint32_t*>(out), mean, rstd);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }
@@ -312,10 +412,15 @@ extern "C" int RL4CO_ENTRY(rl4co_skip_inorm_fwd)(const void* x, const void* s, c
 extern "C" int RL4CO_ENTRY(rl4co_skip_inorm_bwd)(const void* dout, const void* y, const float* gamma, const float* mean,
                                          const float* rstd, int B, int N, void* dy, float* dgamma, float* dbeta, void* stream) {
   RL4CO_REQUIRE(dout && y && gamma && mean && rstd && dy && dgamma && dbeta);
-  RL4CO_REQUIRE(B > 0 && N >= 1 && N <= 4 * kMaxRows);
-  hipLaunchKernelGGL(skip_inorm_bwd_kernel, dim3(B), dim3(kThreads), 0, rl4co::as_stream(stream),
-                     static_cast<const uint32_t*>(dout), static_cast<const uint32_t*>(y), gamma, mean, rstd, N,
-                     static_cast<uint32_t*>(dy), dgamma, dbeta);
+  RL4CO_REQUIRE(B > 0 && N >= 1 && N <= 1024);
+  if (N > 4 * kMaxRows)
+    hipLaunchKernelGGL(skip_inorm_bwd_wide_kernel, dim3(B), dim3(kThreads), 0, rl4co::as_stream(stream),
+                       static_cast<const uint32_t*>(dout), static_cast<const uint32_t*>(y), gamma, mean, rstd, N,
+                       static_cast<uint32_t*>(dy), dgamma, dbeta);
+  else
+    hipLaunchKernelGGL(skip_inorm_bwd_kernel, dim3(B), dim3(kThreads), 0, rl4co::as_stream(stream),
+                       static_cast<const uint32_t*>(dout), static_cast<const uint32_t*>(y), gamma, mean, rstd, N,
+                       static_cast<uint32_t*>(dy), dgamma, dbeta);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }

@@ -21,10 +21,12 @@
 #if RL4CO_ELEM_F16
 typedef _Float16 elem_t;
 #define RL4CO_ENTRY(stem) __attribute__((visibility("hidden"))) stem##_impl_f16
+#define RL4CO_IMPL(stem) stem##_impl_f16  // the name alone: a call from another translation unit of the same element type
 #define RL4CO_CXX(stem) stem##_f16
 #else
 typedef __bf16 elem_t;
 #define RL4CO_ENTRY(stem) __attribute__((visibility("hidden"))) stem##_impl_bf16
+#define RL4CO_IMPL(stem) stem##_impl_bf16
 #define RL4CO_CXX(stem) stem
 #endif
 

@@ -8,6 +8,8 @@
 
 extern "C" __attribute__((visibility("hidden"))) int rl4co_attn_bwd_impl_bf16(const void* qkv, const void* out, const void* dout, const float* lse, int B, int N, void* dqkv, void* stream);
 extern "C" __attribute__((visibility("hidden"))) int rl4co_attn_bwd_impl_f16(const void* qkv, const void* out, const void* dout, const float* lse, int B, int N, void* dqkv, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int rl4co_attn_bwd_wide_impl_bf16(const void* qkv, const void* out, const void* dout, const float* lse, int B, int N, void* dqkv, float* dq_partial, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int rl4co_attn_bwd_wide_impl_f16(const void* qkv, const void* out, const void* dout, const float* lse, int B, int N, void* dqkv, float* dq_partial, void* stream);
 extern "C" __attribute__((visibility("hidden"))) int rl4co_attn_flash_impl_bf16(const void* qkv, int B, int N, void* out, void* stream);
 extern "C" __attribute__((visibility("hidden"))) int rl4co_attn_flash_impl_f16(const void* qkv, int B, int N, void* out, void* stream);
 extern "C" __attribute__((visibility("hidden"))) int rl4co_attn_flash_pre_impl_bf16(const void* qkv, const float* bound, int B, int N, void* out, void* stream);
@@ -43,6 +45,11 @@ extern "C" int rl4co_attn_bwd(int dtype, const void* qkv, const void* out, const
   if (dtype == RL4CO_DT_BF16) return rl4co_attn_bwd_impl_bf16(qkv, out, dout, lse, B, N, dqkv, stream);
   if (dtype == RL4CO_DT_F16) return rl4co_attn_bwd_impl_f16(qkv, out, dout, lse, B, N, dqkv, stream);
   return rl4co::record_arg_error("rl4co_attn_bwd: dtype must be RL4CO_DT_BF16 or RL4CO_DT_F16");
+}
+extern "C" int rl4co_attn_bwd_wide(int dtype, const void* qkv, const void* out, const void* dout, const float* lse, int B, int N, void* dqkv, float* dq_partial, void* stream) {
+  if (dtype == RL4CO_DT_BF16) return rl4co_attn_bwd_wide_impl_bf16(qkv, out, dout, lse, B, N, dqkv, dq_partial, stream);
+  if (dtype == RL4CO_DT_F16) return rl4co_attn_bwd_wide_impl_f16(qkv, out, dout, lse, B, N, dqkv, dq_partial, stream);
+  return rl4co::record_arg_error("rl4co_attn_bwd_wide: dtype must be RL4CO_DT_BF16 or RL4CO_DT_F16");
 }
 extern "C" int rl4co_attn_flash(int dtype, const void* qkv, int B, int N, void* out, void* stream) {
   if (dtype == RL4CO_DT_BF16) return rl4co_attn_flash_impl_bf16(qkv, B, N, out, stream);

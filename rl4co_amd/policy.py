@@ -173,7 +173,7 @@ class _EncoderLayer(nn.Sequential):
                 s = skip.module(x, fused=gemm_ok)
                 if norm.kind == "batch" and train_ops.batch_usable(x, s):
                     x = train_ops.skip_batch_norm(x, s, norm.normalizer)
-                elif norm.kind == "instance" and train_ops.usable(x, s):
+                elif norm.kind == "instance" and train_ops.usable(x, s, "instance"):
                     x = train_ops.skip_instance_norm(x, s, norm.normalizer.weight, norm.normalizer.bias, norm.normalizer.eps)
                 elif norm.kind == "layer" and train_ops.usable(x, s):
                     x = train_ops.skip_layer_norm(x, s)

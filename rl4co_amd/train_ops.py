@@ -175,10 +175,16 @@ def skip_batch_norm_eval(x: Tensor, s: Tensor, bn: torch.nn.BatchNorm1d) -> Tens
     return out
 
 
-def usable(x: Tensor, s: Tensor) -> bool:
-    """bf16 [B,N,128] activations on the GPU with N inside the kernel's register budget."""
+def inorm_max_nodes() -> int:
+    """Nodes the skip + instance-norm kernels serve (beyond ``max_nodes()`` the rows are re-read per pass, r06)."""
+    return _lib.lib().rl4co_skip_inorm_wide_max_nodes()
+
+
+def usable(x: Tensor, s: Tensor, kind: str = "layer") -> bool:
+    """16-bit [B,N,128] activations on the GPU with N inside the norm kernels' limit (``kind``: "instance" or "layer")."""
+    limit = inorm_max_nodes() if kind == "instance" else max_nodes()
     return (x.is_cuda and x.dtype in HALF and s.dtype == x.dtype and x.dim() == 3
-            and x.shape == s.shape and x.shape[-1] == EMBED_DIM and x.shape[1] <= max_nodes())
+            and x.shape == s.shape and x.shape[-1] == EMBED_DIM and x.shape[1] <= limit)
 
 
 def batch_usable(x: Tensor, s: Tensor) -> bool:
@@ -403,6 +409,27 @@ def mlp(x: Tensor, w1: Tensor, b1: Tensor, w2: Tensor, b2: Tensor) -> Tensor:
 # ---------------------------------------------------------------------------------------------------
 # encoder self-attention on the packed qkv rows (csrc/am_train_attn.hip)
 # ---------------------------------------------------------------------------------------------------
+def attn_max_nodes() -> int:
+    """Nodes the training attention serves: forward and backward; beyond ``rl4co_attn_max_nodes()`` (one workgroup holds an
+    instance's keys) on the key-streaming forward and the key-chunk backward (r06)."""
+    return _lib.lib().rl4co_attn_wide_max_nodes()
+
+
+def _attn_backward(qkv: Tensor, att: Tensor, datt: Tensor, lse: Tensor) -> Tensor:
+    """d qkv [B,N,384] of the packed attention from d att (csrc/am_train_attn.hip); ``att`` is the forward's own output."""
+    b, n, _ = qkv.shape
+    dqkv = torch.empty_like(qkv)
+    stream = torch.cuda.current_stream().cuda_stream
+    if n <= _lib.lib().rl4co_attn_max_nodes():
+        _lib.check(_k("rl4co_attn_bwd", qkv.dtype)(qkv.data_ptr(), att.data_ptr(), datt.data_ptr(), lse.data_ptr(), b, n,
+                                                   dqkv.data_ptr(), stream), "rl4co_attn_bwd")
+    else:  # key chunks of 128: their shares of d q meet in an fp32 workspace
+        part = torch.empty(((n + 127) // 128, b, n, EMBED_DIM), dtype=torch.float32, device=qkv.device)
+        _lib.check(_k("rl4co_attn_bwd_wide", qkv.dtype)(qkv.data_ptr(), att.data_ptr(), datt.data_ptr(), lse.data_ptr(), b, n,
+                                                        dqkv.data_ptr(), part.data_ptr(), stream), "rl4co_attn_bwd_wide")
+    return dqkv
+
+
 class _Attention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv: Tensor):
@@ -419,18 +446,12 @@ class _Attention(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout: Tensor):
         q, lse, out = ctx.saved_tensors
-        b, n, _ = q.shape
-        d = dout.to(q.dtype).contiguous()
-        dqkv = torch.empty_like(q)
-        st = _k("rl4co_attn_bwd", q.dtype)(q.data_ptr(), out.data_ptr(), d.data_ptr(), lse.data_ptr(), b, n, dqkv.data_ptr(),
-                                            torch.cuda.current_stream().cuda_stream)
-        _lib.check(st, "rl4co_attn_bwd")
-        return dqkv
+        return _attn_backward(q, out, dout.to(q.dtype).contiguous(), lse)
 
 
 def attention_usable(qkv: Tensor) -> bool:
     return (qkv.is_cuda and qkv.dtype in HALF and qkv.dim() == 3 and qkv.shape[-1] == 3 * EMBED_DIM
-            and qkv.shape[1] <= _lib.lib().rl4co_attn_max_nodes())
+            and qkv.shape[1] <= attn_max_nodes())
 
 
 def attention(qkv: Tensor) -> Tensor:
@@ -495,9 +516,7 @@ def _attention_block_bwd(kind, dout, x2, wqkv16, wo16, qkv, lse, att, y, g32, me
     d2 = dy.view(-1, d)
     datt = _gemm(d2, wo16.t().contiguous() if wt is None else wt[1])
     hwo = _wgrad(d2, att.reshape(-1, d), with_bias=True, arena=arena, key=("wo", layer))
-    dqkv = torch.empty_like(qkv)
-    _lib.check(_k("rl4co_attn_bwd", qkv.dtype)(qkv.data_ptr(), att.data_ptr(), datt.data_ptr(), lse.data_ptr(), b, n, dqkv.data_ptr(),
-                                              torch.cuda.current_stream().cuda_stream), "rl4co_attn_bwd")
+    dqkv = _attn_backward(qkv, att, datt.view(b, n, d), lse)
     dq2 = dqkv.view(-1, 3 * d)
     dx = _gemm(dq2, wqkv16.t().contiguous() if wt is None else wt[0], residual=d2)
     hwqkv = _wgrad(dq2, x2.reshape(-1, d), with_bias=True, arena=arena, key=("wqkv", layer))
@@ -745,9 +764,9 @@ def block_usable(x: Tensor, kind: str, *weights: Tensor) -> bool:
     """bf16 [B,N,128] rows whose every kernel (GEMMs, attention, skip + norm) is served: one autograd node per sub-block."""
     if kind not in ("instance", "batch", "layer") or not linear_usable(x, *weights) or x.dim() != 3 or x.shape[-1] != EMBED_DIM:
         return False
-    if x.shape[1] > _lib.lib().rl4co_attn_max_nodes():
+    if x.shape[1] > attn_max_nodes():
         return False
-    return kind == "batch" or x.shape[1] <= max_nodes()
+    return kind == "batch" or x.shape[1] <= (inorm_max_nodes() if kind == "instance" else max_nodes())
 
 
 def attention_block(x: Tensor, attn, norm) -> Tensor:
