@@ -36,7 +36,7 @@ extern "C" {
  *   6: rl4co_attn_bwd_{bf16,f16} take the forward's `out`; rl4co_abi_version() itself.
  *   7: rl4co_am_decode_args / rl4co_am_teacher_args end in the context tables' dtype and strides (ctx_dtype ...).
  *   8: the 16 rl4co_<op>_bf16 / rl4co_<op>_f16 pairs are ONE rl4co_<op>(int dtype, ...) each. */
-#define RL4CO_ABI_VERSION 10
+#define RL4CO_ABI_VERSION 11
 
 /* ---- status codes ------------------------------------------------------ */
 #define RL4CO_OK 0
@@ -267,6 +267,10 @@ typedef struct rl4co_env_replay_args {
   float* rem;               /* [B, T] CVRP, CVRPTW, OP, PCTSP */
   float* now;               /* [B, T] CVRPTW */
   int32_t* err;             /* sticky bits (RL4CO_EBIT_INFEASIBLE: an action out of range), may be NULL */
+  uint32_t* mask_bits;      /* [B, T, mask_words] optional: `masks` as bits (bit j of word j / 32 = node j feasible; the
+                               padding bits are 0) — rl4co_cross_attn_*'s mask */
+  int32_t mask_words;       /* >= ceil(N / 32) */
+  int32_t reserved1;
 } rl4co_env_replay_args;
 
 int rl4co_env_replay(const rl4co_env_replay_args* args, void* stream);
@@ -780,6 +784,40 @@ int rl4co_attn_bwd_wide(int dtype, const void* qkv, const void* out, const void*
                         void* dqkv, float* dq_partial, void* stream);
 int rl4co_attn_max_nodes(void);
 int rl4co_attn_wide_max_nodes(void);
+
+/* --------------------------------------------------------------------------
+ * (r06) The decoder's masked glimpse attention over ALL steps of given trajectories at once, forward and backward —
+ * the inner multi-head attention of PointerAttention (rl4co/models/nn/attention.py:255-296 with the action mask,
+ * models/zoo/am/decoder.py:150-190) as the dense re-evaluation of known actions uses it (`evaluate` decoding with
+ * autograd: utils/decoding.py:448-461; rl/ppo/ppo.py:128-170): T step queries per trajectory against the N node keys of
+ * its instance. 16-bit operands (dtype argument), fp32 softmax; heads = softmax_keys(q k^T / 4, masked) v per head.
+ *   q    [B, T] rows of 128 (8 heads x 16), `q_stride` elements apart
+ *   kv   [B_inst, N] rows of k 128 | v 128, `kv_stride` elements apart; trajectory b reads instance b % B_inst
+ *   mask [B, T, mask_words] words of 32 keys, bit j = node j feasible at that step (rl4co_env_replay's mask_bits);
+ *        mask_words % 4 == 0; NULL = every key. Every query needs at least one feasible key.
+ *   forward : out [B, T, 128], lse [B, 8, T] (log2 domain)
+ *   backward: dq [B, T, 128]; dkv [B_inst, N, dk 128 | dv 128] summed over steps and starts; `dq_partial` = fp32
+ *             workspace [rl4co_cross_attn_chunks(N), B, T, 128]
+ * -------------------------------------------------------------------------- */
+typedef struct rl4co_cross_attn_args {
+  int32_t B, B_inst, T, N;
+  const void* q;
+  int64_t q_stride;
+  const void* kv;
+  int64_t kv_stride;
+  const uint32_t* mask;
+  int32_t mask_words;
+  int32_t reserved0;
+  void* out;
+  float* lse;
+  const void* dout; /* backward only from here */
+  void* dq;
+  void* dkv;
+  float* dq_partial;
+} rl4co_cross_attn_args;
+int rl4co_cross_attn_fwd(int dtype, const rl4co_cross_attn_args* args, void* stream);
+int rl4co_cross_attn_bwd(int dtype, const rl4co_cross_attn_args* args, void* stream);
+int rl4co_cross_attn_chunks(int N);
 
 /* --------------------------------------------------------------------------
  * a12 (inference, large graphs)  MultiHeadAttention.forward   rl4co/models/nn/attention.py:110-134

@@ -12,7 +12,7 @@ from functools import lru_cache
 from . import build as _build
 
 RL4CO_OK = 0
-ABI_VERSION = 10  # RL4CO_ABI_VERSION of include/rl4co_amd.h this binding's argument lists were written for
+ABI_VERSION = 11  # RL4CO_ABI_VERSION of include/rl4co_amd.h this binding's argument lists were written for
 ENV_TSP, ENV_CVRP, ENV_OP, ENV_PCTSP, ENV_PDP, ENV_CVRPTW = 0, 1, 2, 3, 4, 5
 DECODE_GREEDY, DECODE_SAMPLE, DECODE_EVALUATE = 0, 1, 2
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
@@ -94,6 +94,18 @@ class EnvReplayArgs(C.Structure):
         ("vehicle_capacity", _vp), ("demand", _vp), ("locs", _vp), ("max_length", _vp), ("time_windows", _vp),
         ("durations", _vp), ("rem_base", _vp),
         ("masks", _vp), ("prev", _vp), ("first", _vp), ("use_placeholder", _vp), ("rem", _vp), ("now", _vp), ("err", _vp),
+        ("mask_bits", _vp), ("mask_words", _i32), ("reserved1", _i32),
+    ]
+
+
+class CrossAttnArgs(C.Structure):
+    """Mirror of ``struct rl4co_cross_attn_args``."""
+
+    _fields_ = [
+        ("B", _i32), ("B_inst", _i32), ("T", _i32), ("N", _i32),
+        ("q", _vp), ("q_stride", _i64), ("kv", _vp), ("kv_stride", _i64),
+        ("mask", _vp), ("mask_words", _i32), ("reserved0", _i32),
+        ("out", _vp), ("lse", _vp), ("dout", _vp), ("dq", _vp), ("dkv", _vp), ("dq_partial", _vp),
     ]
 
 
@@ -142,6 +154,9 @@ SYMBOLS = {
     "rl4co_attn_max_nodes": (C.c_int, []),
     "rl4co_attn_bwd_wide": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, C.c_int, C.c_int, _vp, _vp, _vp]),  # (dtype id first)
     "rl4co_attn_wide_max_nodes": (C.c_int, []),
+    "rl4co_cross_attn_fwd": (C.c_int, [C.c_int, C.POINTER(CrossAttnArgs), _vp]),
+    "rl4co_cross_attn_bwd": (C.c_int, [C.c_int, C.POINTER(CrossAttnArgs), _vp]),
+    "rl4co_cross_attn_chunks": (C.c_int, [C.c_int]),
     "rl4co_skip_inorm_wide_max_nodes": (C.c_int, []),
     "rl4co_attn_flash": (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),  # (dtype id first: RL4CO_DT_BF16 / RL4CO_DT_F16)
     "rl4co_attn_flash_pre": (C.c_int, [C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),  # (dtype id first: RL4CO_DT_BF16 / RL4CO_DT_F16)

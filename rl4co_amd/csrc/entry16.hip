@@ -20,6 +20,10 @@ extern "C" __attribute__((visibility("hidden"))) int rl4co_bnorm_apply_impl_bf16
 extern "C" __attribute__((visibility("hidden"))) int rl4co_bnorm_apply_impl_f16(const void* y, const float* mean, const float* rstd, const float* gamma, const float* beta, int64_t M, void* out, void* stream);
 extern "C" __attribute__((visibility("hidden"))) int rl4co_bnorm_bwd_impl_bf16(const void* dout, const void* y, const float* mean, const float* rstd, const float* gamma, int64_t M, float* sums, void* dy, void* stream);
 extern "C" __attribute__((visibility("hidden"))) int rl4co_bnorm_bwd_impl_f16(const void* dout, const void* y, const float* mean, const float* rstd, const float* gamma, int64_t M, float* sums, void* dy, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int rl4co_cross_attn_fwd_impl_bf16(const rl4co_cross_attn_args* args, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int rl4co_cross_attn_fwd_impl_f16(const rl4co_cross_attn_args* args, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int rl4co_cross_attn_bwd_impl_bf16(const rl4co_cross_attn_args* args, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int rl4co_cross_attn_bwd_impl_f16(const rl4co_cross_attn_args* args, void* stream);
 extern "C" __attribute__((visibility("hidden"))) int rl4co_init_embed_impl_bf16(const float* feats, const float* w, const float* b, int64_t M, int F, void* out, void* stream);
 extern "C" __attribute__((visibility("hidden"))) int rl4co_init_embed_impl_f16(const float* feats, const float* w, const float* b, int64_t M, int F, void* out, void* stream);
 extern "C" __attribute__((visibility("hidden"))) int rl4co_init_embed_wgrad_impl_bf16(const void* dout, const float* feats, int64_t M, int F, float* partial, int* blocks_out, void* stream);
@@ -50,6 +54,16 @@ extern "C" int rl4co_attn_bwd_wide(int dtype, const void* qkv, const void* out, 
   if (dtype == RL4CO_DT_BF16) return rl4co_attn_bwd_wide_impl_bf16(qkv, out, dout, lse, B, N, dqkv, dq_partial, stream);
   if (dtype == RL4CO_DT_F16) return rl4co_attn_bwd_wide_impl_f16(qkv, out, dout, lse, B, N, dqkv, dq_partial, stream);
   return rl4co::record_arg_error("rl4co_attn_bwd_wide: dtype must be RL4CO_DT_BF16 or RL4CO_DT_F16");
+}
+extern "C" int rl4co_cross_attn_fwd(int dtype, const rl4co_cross_attn_args* args, void* stream) {
+  if (dtype == RL4CO_DT_BF16) return rl4co_cross_attn_fwd_impl_bf16(args, stream);
+  if (dtype == RL4CO_DT_F16) return rl4co_cross_attn_fwd_impl_f16(args, stream);
+  return rl4co::record_arg_error("rl4co_cross_attn_fwd: dtype must be RL4CO_DT_BF16 or RL4CO_DT_F16");
+}
+extern "C" int rl4co_cross_attn_bwd(int dtype, const rl4co_cross_attn_args* args, void* stream) {
+  if (dtype == RL4CO_DT_BF16) return rl4co_cross_attn_bwd_impl_bf16(args, stream);
+  if (dtype == RL4CO_DT_F16) return rl4co_cross_attn_bwd_impl_f16(args, stream);
+  return rl4co::record_arg_error("rl4co_cross_attn_bwd: dtype must be RL4CO_DT_BF16 or RL4CO_DT_F16");
 }
 extern "C" int rl4co_attn_flash(int dtype, const void* qkv, int B, int N, void* out, void* stream) {
   if (dtype == RL4CO_DT_BF16) return rl4co_attn_flash_impl_bf16(qkv, B, N, out, stream);

@@ -564,7 +564,19 @@ __global__ void __launch_bounds__(64) env_replay_kernel(const rl4co_env_replay_a
   for (int t = 0; t < T; ++t) {
     const int64_t o = (int64_t)b * T + t;
     uint8_t* out = a.masks + o * N;
-    for (int j = lane; j < N; j += 64) out[j] = row[j];
+    for (int j0 = 0; j0 < N; j0 += 64) {
+      const int j = j0 + lane;
+      const uint8_t v = j < N ? row[j] : 0;
+      if (j < N) out[j] = v;
+      if (a.mask_bits != nullptr) {  // the same row as bits
+        const unsigned long long bal = __ballot(v != 0);
+        uint32_t* wrow = a.mask_bits + o * a.mask_words + (j0 >> 5);
+        if (lane == 0) wrow[0] = (uint32_t)bal;
+        if (lane == 1 && (j0 >> 5) + 1 < a.mask_words) wrow[1] = (uint32_t)(bal >> 32);
+      }
+    }
+    if (a.mask_bits != nullptr)  // words past the graph
+      for (int wd = ((N + 63) >> 6) * 2 + lane; wd < a.mask_words; wd += 64) a.mask_bits[o * a.mask_words + wd] = 0u;
     if (lane == 0) {
       a.prev[o] = a.current_node[b];
       if (a.env == RL4CO_ENV_TSP) {
@@ -627,6 +639,7 @@ extern "C" int rl4co_env_replay(const rl4co_env_replay_args* args, void* stream)
     if (a.env == RL4CO_ENV_OP) RL4CO_REQUIRE(a.locs && a.max_length && a.step_i);
     if (a.env == RL4CO_ENV_CVRPTW) RL4CO_REQUIRE(a.locs && a.time_windows && a.durations && a.current_time && a.now);
   }
+  RL4CO_REQUIRE(a.mask_bits == nullptr || a.mask_words * 32 >= a.N);
   hipLaunchKernelGGL(env_replay_kernel, dim3(a.B), dim3(64), 0, rl4co::as_stream(stream), a);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;

@@ -406,12 +406,14 @@ def pdp_step(action: Tensor | None, available: Tensor, to_deliver: Tensor, curre
     _lib.check(st, "rl4co_pdp_step")
 
 
-def env_replay(env_name: str, state: dict, actions: Tensor, rem_base: Tensor | None, err: Tensor | None = None) -> dict:
+def env_replay(env_name: str, state: dict, actions: Tensor, rem_base: Tensor | None, err: Tensor | None = None,
+               mask_bits: bool = False) -> dict:
     """``T`` environment transitions of the given trajectories in ONE launch (``rl4co_env_replay``): the state tensors of
     ``policy._initial_state`` are stepped in place with ``actions[:, t]`` exactly as ``T`` calls of the env's step entry
     would, and what the decoder saw BEFORE each step is tabulated — ``masks`` [B,T,N] bool, ``prev`` [B,T] and, by
     environment, ``first`` / ``use_placeholder`` (TSP), ``rem`` (the context scalar: ``rem_base`` minus the running
-    capacity / length / prize), ``now`` (CVRPTW). The `evaluate` decoding's state sequence (decoding.py:448-461)."""
+    capacity / length / prize), ``now`` (CVRPTW), ``mask_bits`` [B,T,W] int32 on request. The `evaluate` decoding's state
+    sequence (decoding.py:448-461)."""
     mask = _u8(state["action_mask"], "action_mask")
     b, n = mask.shape
     acts = _dev(actions, torch.int64, "actions")
@@ -428,6 +430,10 @@ def env_replay(env_name: str, state: dict, actions: Tensor, rem_base: Tensor | N
     a.done = _u8(state["done"], "done").data_ptr()
     a.masks, a.prev = out["masks"].data_ptr(), out["prev"].data_ptr()
     a.err = _ptr(err)
+    if mask_bits:  # the same masks as bits, rows padded to whole 128-key chunks (train_ops.glimpse_attention's mask)
+        words = 4 * ((n + 127) // 128)
+        out["mask_bits"] = torch.empty((b, t_len, words), dtype=torch.int32, device=dev)
+        a.mask_bits, a.mask_words = out["mask_bits"].data_ptr(), words
     _check_rows(b, current_node=state["current_node"], done=state["done"])
     b_inst = b
 

@@ -1197,7 +1197,12 @@ class AttentionModelPolicy(nn.Module):
         hidden = hidden.float()  # encoder_autocast may hand over bf16 activations
         b_inst, n, d = hidden.shape
         b, t_len = actions.shape
-        masks, ctx_nodes, extras = self._replay(td, actions, n_rep)
+        # 16-bit regime on the GPU: the masked glimpse attention of all steps on csrc/am_cross_attn.hip (keys shared by the
+        # starts of an instance, the mask as bits from the same replay launch); otherwise torch's SDPA in fp32
+        regime = self._encoder_regime()
+        glimpse_kernel = (hidden.is_cuda and regime in (torch.bfloat16, torch.float16) and dec.mask_inner and dec.num_heads == 8
+                          and d == 128 and self.fused_backward)
+        masks, ctx_nodes, extras, mask_bits = self._replay(td, actions, n_rep, mask_bits=glimpse_kernel)
         h = hidden if s == 1 else hidden.unsqueeze(0).expand(s, b_inst, n, d).reshape(b, n, d)
         w_ctx = dec.context_embedding.project_context.weight
         if self.env_name == "tsp":
@@ -1221,16 +1226,24 @@ class AttentionModelPolicy(nn.Module):
             g = dec.project_fixed_context(hidden.mean(1))
             g = g if s == 1 else g.unsqueeze(0).expand(s, b_inst, d).reshape(b, d)
             q = q + g[:, None, :]
-        kvl = dec.project_node_embeddings(hidden)
-        kvl = kvl if s == 1 else kvl.unsqueeze(0).expand(s, b_inst, n, 3 * d).reshape(b, n, 3 * d)
+        kvl_inst = dec.project_node_embeddings(hidden)  # [B_inst, N, 3 d]
+        kvl = kvl_inst if s == 1 else kvl_inst.unsqueeze(0).expand(s, b_inst, n, 3 * d).reshape(b, n, 3 * d)
         k_g, v_g, k_l = kvl.chunk(3, dim=-1)
         nh = dec.num_heads
-        qh = q.view(b, t_len, nh, d // nh).transpose(1, 2)
-        kh = k_g.reshape(b, n, nh, d // nh).transpose(1, 2)
-        vh = v_g.reshape(b, n, nh, d // nh).transpose(1, 2)
-        attn_mask = masks[:, None, :, :] if dec.mask_inner else None
-        heads = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=attn_mask)
-        glimpse = dec.pointer.project_out(heads.transpose(1, 2).reshape(b, t_len, d))
+        heads = None
+        if glimpse_kernel:
+            from . import train_ops
+
+            q16, kv16 = q.to(regime), kvl_inst[..., : 2 * d].to(regime)
+            if train_ops.glimpse_attention_usable(q16, kv16, mask_bits):
+                heads = train_ops.glimpse_attention(q16, kv16, mask_bits).float()
+        if heads is None:
+            qh = q.view(b, t_len, nh, d // nh).transpose(1, 2)
+            kh = k_g.reshape(b, n, nh, d // nh).transpose(1, 2)
+            vh = v_g.reshape(b, n, nh, d // nh).transpose(1, 2)
+            attn_mask = masks[:, None, :, :] if dec.mask_inner else None
+            heads = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=attn_mask).transpose(1, 2).reshape(b, t_len, d)
+        glimpse = dec.pointer.project_out(heads)
         logits = torch.bmm(glimpse, k_l.transpose(1, 2)) / math.sqrt(d)
         if tanh_clipping > 0:
             logits = torch.tanh(logits) * tanh_clipping
@@ -1243,7 +1256,7 @@ class AttentionModelPolicy(nn.Module):
         return (step_logps, logp) if return_full else step_logps
 
     @torch.no_grad()
-    def _replay(self, td, actions: Tensor, n_rep: int):
+    def _replay(self, td, actions: Tensor, n_rep: int, mask_bits: bool = False):
         """Per step of the given trajectories: the mask the decoder saw, the context node(s) and the context scalar(s) —
         ONE launch (``rl4co_env_replay``: the env-step device code looped over T on the device; r06 — the T x ~2 launches
         of ``_replay_stepwise`` were 20 of the 46 ms of a CVRP-500 x 64 REINFORCE step)."""
@@ -1258,12 +1271,14 @@ class AttentionModelPolicy(nn.Module):
         elif self.env_name in ("cvrp", "cvrptw"):
             rem_base = state["vehicle_capacity"]
         err = K.new_error_word(actions.device)
-        r = K.env_replay(self.env_name, state, actions.contiguous(), rem_base, err)
+        r = K.env_replay(self.env_name, state, actions.contiguous(), rem_base, err, mask_bits=mask_bits)
+        bits = r.get("mask_bits")
         if self.env_name == "tsp":
-            return r["masks"], (r["first"], r["prev"]), r["use_placeholder"]
+            return r["masks"], (r["first"], r["prev"]), r["use_placeholder"], bits
         if self.env_name == "pdp":
-            return r["masks"], (r["prev"],), None
-        return r["masks"], (r["prev"],), (r["rem"] if self.env_name != "cvrptw" else torch.stack((r["rem"], r["now"]), -1))
+            return r["masks"], (r["prev"],), None, bits
+        return (r["masks"], (r["prev"],), (r["rem"] if self.env_name != "cvrptw" else torch.stack((r["rem"], r["now"]), -1)),
+                bits)
 
     @torch.no_grad()
     def _replay_stepwise(self, td, actions: Tensor, n_rep: int):

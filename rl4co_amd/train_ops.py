@@ -449,6 +449,64 @@ class _Attention(torch.autograd.Function):
         return _attn_backward(q, out, dout.to(q.dtype).contiguous(), lse)
 
 
+class _GlimpseAttention(torch.autograd.Function):
+    """The decoder's masked glimpse attention over all steps of given trajectories (csrc/am_cross_attn.hip)."""
+
+    @staticmethod
+    def _args(q, kv, bits, out, lse):
+        a = _lib.CrossAttnArgs()
+        a.B, a.T, a.B_inst, a.N = q.shape[0], q.shape[1], kv.shape[0], kv.shape[1]
+        a.q, a.q_stride, a.kv, a.kv_stride = q.data_ptr(), q.stride(1), kv.data_ptr(), kv.stride(1)
+        if bits is not None:
+            a.mask, a.mask_words = bits.data_ptr(), bits.shape[-1]
+        a.out, a.lse = out.data_ptr(), lse.data_ptr()
+        return a
+
+    @staticmethod
+    def forward(ctx, q: Tensor, kv: Tensor, bits: Tensor | None):
+        import ctypes
+
+        q, kv = q.contiguous(), kv.contiguous()
+        b, t, _ = q.shape
+        out = torch.empty((b, t, EMBED_DIM), dtype=q.dtype, device=q.device)
+        lse = torch.empty((b, 8, t), dtype=torch.float32, device=q.device)
+        a = _GlimpseAttention._args(q, kv, bits, out, lse)
+        st = _lib.lib().rl4co_cross_attn_fwd(_lib.dtype_id(q.dtype), ctypes.byref(a), torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "rl4co_cross_attn_fwd")
+        ctx.save_for_backward(q, kv, out, lse, *(() if bits is None else (bits,)))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: Tensor):
+        import ctypes
+
+        q, kv, out, lse, *rest = ctx.saved_tensors
+        bits = rest[0] if rest else None
+        d = dout.to(q.dtype).contiguous()
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        part = torch.empty((_lib.lib().rl4co_cross_attn_chunks(kv.shape[1]), q.shape[0], q.shape[1], EMBED_DIM),
+                           dtype=torch.float32, device=q.device)
+        a = _GlimpseAttention._args(q, kv, bits, out, lse)
+        a.dout, a.dq, a.dkv, a.dq_partial = d.data_ptr(), dq.data_ptr(), dkv.data_ptr(), part.data_ptr()
+        st = _lib.lib().rl4co_cross_attn_bwd(_lib.dtype_id(q.dtype), ctypes.byref(a), torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "rl4co_cross_attn_bwd")
+        return dq, dkv, None
+
+
+def glimpse_attention_usable(q: Tensor, kv: Tensor, bits: Tensor | None) -> bool:
+    return (q.is_cuda and q.dtype in HALF and kv.dtype == q.dtype and q.dim() == 3 and kv.dim() == 3
+            and q.shape[-1] == EMBED_DIM and kv.shape[-1] == 2 * EMBED_DIM and q.shape[0] % kv.shape[0] == 0
+            and (bits is None or (bits.dtype == torch.int32 and bits.is_contiguous() and bits.shape[:2] == q.shape[:2]
+                                  and bits.shape[-1] % 4 == 0 and bits.shape[-1] * 32 >= kv.shape[1])))
+
+
+def glimpse_attention(q: Tensor, kv: Tensor, bits: Tensor | None) -> Tensor:
+    """``softmax_keys(q k^T / 4, masked) v`` per head (8 x 16) for q [B,T,128] step queries against kv [B_inst,N, k 128 | v 128]
+    (trajectory b reads instance b % B_inst), ``bits`` [B,T,W] int32 feasibility bits (``kernels.env_replay(mask_bits=True)``)
+    -> heads [B,T,128]; forward and backward on csrc/am_cross_attn.hip (nn/attention.py:255-296's inner attention)."""
+    return _GlimpseAttention.apply(q, kv, bits)
+
+
 def attention_usable(qkv: Tensor) -> bool:
     return (qkv.is_cuda and qkv.dtype in HALF and qkv.dim() == 3 and qkv.shape[-1] == 3 * EMBED_DIM
             and qkv.shape[1] <= attn_max_nodes())

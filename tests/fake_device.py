@@ -136,7 +136,7 @@ def _am_decode(cache, state, **kw):
     c_oracle.am_decode(cache, state, row_groups=groups, **kw)
 
 
-def _env_replay(env_name, state, actions, rem_base, err=None):
+def _env_replay(env_name, state, actions, rem_base, err=None, mask_bits=False):
     """kernels.env_replay on CPU tensors: the tabulation between T calls of the (patched) step functions."""
     from rl4co_amd import kernels as K
 

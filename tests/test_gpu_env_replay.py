@@ -36,6 +36,7 @@ def test_one_launch_replay_equals_the_step_by_step_replay(env_name, num_loc, sta
     a = policy._replay(env.reset(data), actions, starts)
     b = policy._replay_stepwise(env.reset(data), actions, starts)
     assert a[0].dtype == torch.bool and torch.equal(a[0], b[0])
+    assert len(a) == 4 and a[3] is None  # (mask bits only on request)
     assert len(a[1]) == len(b[1]) and all(torch.equal(x, y) for x, y in zip(a[1], b[1]))
     if env_name == "pdp":
         assert a[2] is None
@@ -98,3 +99,60 @@ def test_reinforce_step_beyond_the_backward_kernels_node_limit(env_name, num_loc
         dots = sum(float(a[k] @ b[k]) for k in a)
         cos = dots / (sum(float(v @ v) for v in a.values()) * sum(float(v @ v) for v in b.values())) ** 0.5
         assert cos >= 0.98, cos
+
+
+def _bits_of(mask):
+    """[B,T,N] bool -> [B,T,W] int32 feasibility bits, rows padded to whole 128-key chunks (what env_replay emits)."""
+    b, t, n = mask.shape
+    w = 4 * ((n + 127) // 128)
+    m = torch.zeros((b, t, w * 32), dtype=torch.bool, device=mask.device)
+    m[..., :n] = mask
+    weights = (1 << torch.arange(32, device=mask.device, dtype=torch.int64))
+    words = (m.view(b, t, w, 32).to(torch.int64) * weights).sum(-1)
+    return (words & 0xFFFFFFFF).to(torch.int64).where(words < 2**31, words - 2**32).to(torch.int32).contiguous()
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+@pytest.mark.parametrize("b_inst,s,t,n,masked", [(6, 1, 20, 20, True), (4, 3, 37, 50, True), (3, 2, 130, 129, True),
+                                                 (5, 1, 200, 200, True), (2, 2, 300, 501, True), (3, 1, 64, 100, False)])
+def test_glimpse_attention_matches_torch_sdpa_with_the_same_mask(b_inst, s, t, n, masked, dt):
+    """csrc/am_cross_attn.hip forward / backward vs torch SDPA in fp32 on the same 16-bit operands and the same mask:
+    heads within 1.5e-2 absolute, dq / dk / dv within 3e-2 relative Frobenius error (the training attention's bars);
+    keys shared by the s starts of an instance, their gradients summed over the starts."""
+    import torch.nn.functional as F
+
+    from rl4co_amd import train_ops
+
+    torch.manual_seed(100 * n + t)
+    b = b_inst * s
+    q = torch.randn(b, t, 128, device="cuda").to(dt)
+    kv = torch.randn(b_inst, n, 256, device="cuda").to(dt)
+    go = torch.randn(b, t, 128, device="cuda").to(dt)
+    mask = torch.rand(b, t, n, device="cuda") < 0.6
+    mask[..., 0] |= ~mask.any(-1)  # every query keeps a feasible key
+    mask[:, :, -1] = False if n > 1 else mask[:, :, -1]
+    bits = _bits_of(mask) if masked else None
+    assert train_ops.glimpse_attention_usable(q, kv, bits)
+    qk, kk = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+    out = train_ops.glimpse_attention(qk, kk, bits)
+    gq, gkv = torch.autograd.grad(out, [qk, kk], go)
+    qr, kr = q.float().requires_grad_(True), kv.float().requires_grad_(True)
+    kx = kr.unsqueeze(0).expand(s, b_inst, n, 256).reshape(b, n, 256)
+    qh = qr.view(b, t, 8, 16).transpose(1, 2)
+    kh = kx[..., :128].reshape(b, n, 8, 16).transpose(1, 2)
+    vh = kx[..., 128:].reshape(b, n, 8, 16).transpose(1, 2)
+    ref = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=mask[:, None] if masked else None).transpose(1, 2).reshape(b, t, 128)
+    rq, rkv = torch.autograd.grad(ref, [qr, kr], go.float())
+    torch.testing.assert_close(out.detach().float(), ref.detach(), rtol=1.6e-2, atol=1.5e-2)
+    for name, got, want in (("dq", gq, rq), ("dk", gkv[..., :128], rkv[..., :128]), ("dv", gkv[..., 128:], rkv[..., 128:])):
+        rel = float((got.float() - want).norm() / want.norm())
+        assert rel <= 3e-2, (name, rel)
+
+
+def test_replay_mask_bits_are_the_mask_rows():
+    policy, env, data, actions = _rollout("cvrp", 150, 5, 0)
+    from rl4co_amd import kernels as K
+
+    state = policy._initial_state(env.reset(data), 0)
+    r = K.env_replay("cvrp", state, actions.contiguous(), state["vehicle_capacity"], None, mask_bits=True)
+    assert r["mask_bits"].shape[-1] == 8 and torch.equal(r["mask_bits"], _bits_of(r["masks"]))
