@@ -994,11 +994,6 @@ extern "C" int rl4co_ms_probe_read(unsigned long long* out, int reset) {
 }
 #endif
 
-// dynamic LDS of the multistart variant at the largest graph (N = 128)
-#if !RL4CO_ELEM_F16
-extern "C" int rl4co_am_decode_ms_lds_bytes(void) { return make_layout(8, 128, 2).total; }
-#endif
-
 namespace rl4co {
 int RL4CO_CXX(launch_decode_ms)(const rl4co_am_decode_args& a, hipStream_t stream) {
 #ifdef RL4CO_MS_PROBE_ONLY  // timing probes (tools/ms_variants.sh): one instantiation instead of 144 — a 10 s build
