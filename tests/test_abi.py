@@ -53,6 +53,29 @@ def test_struct_layout_matches_header():
     from rl4co_amd.teacher import AmTeacherArgs
 
     assert _c_fields("rl4co_am_teacher_args") == [f[0] for f in AmTeacherArgs._fields_]
+    assert _c_fields("rl4co_env_replay_args") == [f[0] for f in _lib.EnvReplayArgs._fields_]
+    # (several fields per line in this one: compare the flattened declaration order)
+    body = re.search(r"typedef struct rl4co_cross_attn_args \{(.*?)\} rl4co_cross_attn_args;", HEADER, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = [n for decl in body.split(";") for n in re.findall(r"(\w+)\s*(?:,|$)", decl.strip())]
+    assert names == [f[0] for f in _lib.CrossAttnArgs._fields_]
+
+
+def test_library_exports_nothing_the_header_does_not_declare():
+    import shutil
+    import subprocess
+
+    from rl4co_amd import _lib
+
+    nm = shutil.which("nm")
+    if nm is None:
+        pytest.skip("nm not available")
+    _lib.lib()
+    from rl4co_amd import build as B
+
+    out = subprocess.run([nm, "-D", "--defined-only", str(B.LIB_PATH)], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if " T rl4co_" in line)
+    assert exported == declared_functions()
 
 
 def test_weight_packing_is_the_documented_fragment_order():
