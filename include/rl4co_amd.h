@@ -36,7 +36,7 @@ extern "C" {
  *   6: rl4co_attn_bwd_{bf16,f16} take the forward's `out`; rl4co_abi_version() itself.
  *   7: rl4co_am_decode_args / rl4co_am_teacher_args end in the context tables' dtype and strides (ctx_dtype ...).
  *   8: the 16 rl4co_<op>_bf16 / rl4co_<op>_f16 pairs are ONE rl4co_<op>(int dtype, ...) each. */
-#define RL4CO_ABI_VERSION 11
+#define RL4CO_ABI_VERSION 12
 
 /* ---- status codes ------------------------------------------------------ */
 #define RL4CO_OK 0
@@ -818,6 +818,21 @@ typedef struct rl4co_cross_attn_args {
 int rl4co_cross_attn_fwd(int dtype, const rl4co_cross_attn_args* args, void* stream);
 int rl4co_cross_attn_bwd(int dtype, const rl4co_cross_attn_args* args, void* stream);
 int rl4co_cross_attn_chunks(int N);
+
+/* --------------------------------------------------------------------------
+ * (r06) log p(a_t | s_t) of GIVEN actions from the pointer's raw logits (glimpse . logit_key, before the 1 / sqrt(128)),
+ * every step of every trajectory as one row — the tail of the dense re-evaluation:
+ *   u = raw / sqrt(128); z = tanh_clipping * tanh(u) (0: z = u); z = -inf where infeasible; z /= temperature;
+ *   logp = log_softmax(z)[action]        rl4co/models/nn/attention.py:291-293, utils/decoding.py:169-188, :381
+ * raw [rows, N] fp32; mask_bits [rows, mask_words] (bit j = node j feasible; NULL = all, i.e. mask_logits = False);
+ * actions [rows]; forward -> logp [rows], lse [rows]; backward: d_raw [rows, N] from grad_logp [rows] and the saved lse.
+ * err: RL4CO_EBIT_NAN_LOGIT / RL4CO_EBIT_INFEASIBLE (an action out of range), may be NULL.
+ * -------------------------------------------------------------------------- */
+int rl4co_logit_logp_fwd(const float* raw, const uint32_t* mask_bits, int mask_words, const int64_t* actions, int64_t rows, int N,
+                         float tanh_clipping, float temperature, float* logp, float* lse, int32_t* err, void* stream);
+int rl4co_logit_logp_bwd(const float* raw, const uint32_t* mask_bits, int mask_words, const int64_t* actions, const float* lse,
+                         const float* grad_logp, int64_t rows, int N, float tanh_clipping, float temperature, float* d_raw,
+                         void* stream);
 
 /* --------------------------------------------------------------------------
  * a12 (inference, large graphs)  MultiHeadAttention.forward   rl4co/models/nn/attention.py:110-134

@@ -12,7 +12,7 @@ from functools import lru_cache
 from . import build as _build
 
 RL4CO_OK = 0
-ABI_VERSION = 11  # RL4CO_ABI_VERSION of include/rl4co_amd.h this binding's argument lists were written for
+ABI_VERSION = 12  # RL4CO_ABI_VERSION of include/rl4co_amd.h this binding's argument lists were written for
 ENV_TSP, ENV_CVRP, ENV_OP, ENV_PCTSP, ENV_PDP, ENV_CVRPTW = 0, 1, 2, 3, 4, 5
 DECODE_GREEDY, DECODE_SAMPLE, DECODE_EVALUATE = 0, 1, 2
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
@@ -157,6 +157,8 @@ SYMBOLS = {
     "rl4co_cross_attn_fwd": (C.c_int, [C.c_int, C.POINTER(CrossAttnArgs), _vp]),
     "rl4co_cross_attn_bwd": (C.c_int, [C.c_int, C.POINTER(CrossAttnArgs), _vp]),
     "rl4co_cross_attn_chunks": (C.c_int, [C.c_int]),
+    "rl4co_logit_logp_fwd": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int64, C.c_int, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
+    "rl4co_logit_logp_bwd": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int64, C.c_int, C.c_float, C.c_float, _vp, _vp]),
     "rl4co_skip_inorm_wide_max_nodes": (C.c_int, []),
     "rl4co_attn_flash": (C.c_int, [C.c_int, _vp, C.c_int, C.c_int, _vp, _vp]),  # (dtype id first: RL4CO_DT_BF16 / RL4CO_DT_F16)
     "rl4co_attn_flash_pre": (C.c_int, [C.c_int, _vp, _vp, C.c_int, C.c_int, _vp, _vp]),  # (dtype id first: RL4CO_DT_BF16 / RL4CO_DT_F16)

@@ -24,7 +24,7 @@ OBJ_DIR = LIB_DIR / "obj"
 LIB_PATH = LIB_DIR / "librl4co_amd.so"
 HASH_PATH = LIB_DIR / "librl4co_amd.so.hash"
 
-SOURCES = ["api.hip", "entry16.hip", "env_step.hip", "tour_length.hip", "am_decode.hip", "am_decode_ms.hip", "am_encoder.hip", "am_encoder_f32.hip", "am_tokens_f32.hip", "am_teacher.hip", "am_teacher_mma.hip", "am_train_ops.hip", "am_train_attn.hip", "am_attn_flash.hip", "am_cross_attn.hip", "augment.hip",
+SOURCES = ["api.hip", "entry16.hip", "env_step.hip", "tour_length.hip", "am_decode.hip", "am_decode_ms.hip", "am_encoder.hip", "am_encoder_f32.hip", "am_tokens_f32.hip", "am_teacher.hip", "am_teacher_mma.hip", "am_train_ops.hip", "am_train_attn.hip", "am_attn_flash.hip", "am_cross_attn.hip", "am_logit_logp.hip", "augment.hip",
            "am_train_ops_f16.hip", "am_train_attn_f16.hip", "am_attn_flash_f16.hip", "am_cross_attn_f16.hip",
            "am_decode_ms_f16.hip", "am_teacher_mma_f16.hip"]
 HEADERS = ["common.h", "rl4co_math.h", "elem16.h", "enc_f32.h"]

@@ -1244,6 +1244,20 @@ class AttentionModelPolicy(nn.Module):
             attn_mask = masks[:, None, :, :] if dec.mask_inner else None
             heads = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=attn_mask).transpose(1, 2).reshape(b, t_len, d)
         glimpse = dec.pointer.project_out(heads)
+        if glimpse_kernel and mask_bits is not None and not return_full:
+            # clip, mask, log-softmax and the gather of the given action in one pass each way (csrc/am_logit_logp.hip); the
+            # logit keys stay per instance: starts s-major -> [B_inst, s T, 128] against [B_inst, 128, N]
+            from . import train_ops
+
+            kl_inst = kvl_inst[..., 2 * d:]
+            gl = glimpse if s == 1 else glimpse.view(s, b_inst, t_len, d).transpose(0, 1).reshape(b_inst, s * t_len, d)
+            raw = torch.bmm(gl, kl_inst.transpose(1, 2))
+            if s > 1:
+                raw = raw.view(b_inst, s, t_len, n).transpose(0, 1).reshape(b, t_len, n)
+            step_logps = train_ops.logit_logp(raw.float(), mask_bits if mask_logits else None, actions, tanh_clipping, temperature)
+            if skip_first:  # multistart: the first action is imposed, its log-prob is 0 (decoding.py:318-323)
+                step_logps = torch.cat([torch.zeros_like(step_logps[:, :1]), step_logps[:, 1:]], 1)
+            return step_logps
         logits = torch.bmm(glimpse, k_l.transpose(1, 2)) / math.sqrt(d)
         if tanh_clipping > 0:
             logits = torch.tanh(logits) * tanh_clipping

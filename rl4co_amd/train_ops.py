@@ -507,6 +507,49 @@ def glimpse_attention(q: Tensor, kv: Tensor, bits: Tensor | None) -> Tensor:
     return _GlimpseAttention.apply(q, kv, bits)
 
 
+class _LogitLogp(torch.autograd.Function):
+    """log p of given actions from the pointer's raw logits, all steps at once (csrc/am_logit_logp.hip)."""
+
+    @staticmethod
+    def forward(ctx, raw: Tensor, bits: Tensor | None, actions: Tensor, tanh_clipping: float, temperature: float, err: Tensor | None):
+        raw, acts = raw.contiguous(), actions.contiguous()
+        b, t, n = raw.shape
+        logp = torch.empty((b, t), dtype=torch.float32, device=raw.device)
+        lse = torch.empty((b, t), dtype=torch.float32, device=raw.device)
+        st = _lib.lib().rl4co_logit_logp_fwd(raw.data_ptr(), None if bits is None else bits.data_ptr(), 0 if bits is None else bits.shape[-1],
+                                             acts.data_ptr(), b * t, n, float(tanh_clipping), float(temperature), logp.data_ptr(),
+                                             lse.data_ptr(), None if err is None else err.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "rl4co_logit_logp_fwd")
+        ctx.save_for_backward(raw, acts, lse, *(() if bits is None else (bits,)))
+        ctx.clip, ctx.temp = float(tanh_clipping), float(temperature)
+        return logp
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        raw, acts, lse, *rest = ctx.saved_tensors
+        bits = rest[0] if rest else None
+        b, t, n = raw.shape
+        gg = g.float().contiguous()
+        d_raw = torch.empty_like(raw)
+        st = _lib.lib().rl4co_logit_logp_bwd(raw.data_ptr(), None if bits is None else bits.data_ptr(), 0 if bits is None else bits.shape[-1],
+                                             acts.data_ptr(), lse.data_ptr(), gg.data_ptr(), b * t, n, ctx.clip, ctx.temp,
+                                             d_raw.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        _lib.check(st, "rl4co_logit_logp_bwd")
+        return d_raw, None, None, None, None, None
+
+
+def logit_logp(raw: Tensor, bits: Tensor | None, actions: Tensor, tanh_clipping: float, temperature: float,
+               err: Tensor | None = None) -> Tensor:
+    """``log_softmax(mask(tanh_clipping * tanh(raw / sqrt(128))) / temperature)[actions]`` for raw logits [B,T,N] fp32 (the
+    pointer's glimpse . logit_key), ``bits`` [B,T,W] int32 feasibility bits (None: no masking of the logits), ``actions``
+    [B,T] -> [B,T]; one pass each way (nn/attention.py:291-293, utils/decoding.py:169-188)."""
+    assert raw.is_cuda and raw.dtype == torch.float32 and raw.dim() == 3 and actions.shape == raw.shape[:2] and actions.dtype == torch.int64
+    assert bits is None or (bits.dtype == torch.int32 and bits.is_contiguous() and bits.shape[:2] == raw.shape[:2]
+                            and bits.shape[-1] * 32 >= raw.shape[-1])
+    return _LogitLogp.apply(raw, bits, actions, tanh_clipping, temperature, err)
+
+
 def attention_usable(qkv: Tensor) -> bool:
     return (qkv.is_cuda and qkv.dtype in HALF and qkv.dim() == 3 and qkv.shape[-1] == 3 * EMBED_DIM
             and qkv.shape[1] <= attn_max_nodes())
