@@ -1053,7 +1053,8 @@ class AttentionModelPolicy(nn.Module):
                        f"{n} nodes are beyond the kernels' limit ({t_max})" if n > t_max else
                        f"{cache_dtype} planes are not served by the backward kernels (float32, bfloat16 or float16 planes) for this call")
                 _l.warn_fallback(f"teacher/{self.env_name}/{n}/{cache_dtype}",
-                                 f"teacher-forced backward for {self.env_name}: {why} — dense torch re-evaluation with autograd")
+                                 f"teacher-forced backward for {self.env_name}: {why} — dense re-evaluation of all steps with autograd "
+                                 "(16-bit regimes: glimpse attention and log-prob kernels between library GEMMs; fp32: torch)")
             step_logps = self.evaluate_log_probs(td, hidden, out_actions, n_rep, tanh_clipping, temperature,
                                                  mask_logits, skip_first=(t0 == 1), return_full=return_entropy)
             if return_entropy:
