@@ -558,15 +558,47 @@ __global__ void __launch_bounds__(64) pdp_check_kernel(const int64_t* __restrict
 // workgroups per call (CVRP-500 x 64: 658 steps, 20 ms of launches for 2 ms of work); this is the same loop on the device:
 // one wave per trajectory runs the SAME step bodies T times over the same state arrays and tabulates between them.
 __global__ void __launch_bounds__(64) env_replay_kernel(const rl4co_env_replay_args a) {
+  // The trajectory's state lives in LDS for the T steps (a step is a chain of dependent reads and writes of its mask /
+  // visited rows and scalars: through L2 that chain was 2.5 - 4 us per step) and goes back to the caller's arrays at the end;
+  // the step bodies are called on the LDS copies with row index 0 and this trajectory's instance data.
+  extern __shared__ __align__(16) unsigned char rsm[];
   const int b = blockIdx.x, lane = threadIdx.x;
   const int N = a.N, T = a.T;
-  const uint8_t* row = a.action_mask + (int64_t)b * N;
+  const int Np = (N + 15) & ~15;
+  uint8_t* lmask = rsm;
+  uint8_t* lvis = lmask + Np;
+  uint8_t* ltod = lvis + Np;
+  int64_t* l64 = reinterpret_cast<int64_t*>(ltod + Np);  // current_node, first_node, step_i
+  float* lf = reinterpret_cast<float*>(l64 + 3);         // scalar, current_time
+  uint8_t* ldone = reinterpret_cast<uint8_t*>(lf + 2);
+  const int ib = b % a.B_inst;
+  for (int j = lane; j < N; j += 64) {
+    lmask[j] = a.action_mask[(int64_t)b * N + j];
+    lvis[j] = a.visited ? a.visited[(int64_t)b * N + j] : 0;
+    ltod[j] = a.to_deliver ? a.to_deliver[(int64_t)b * N + j] : 0;
+  }
+  if (lane == 0) {
+    l64[0] = a.current_node[b];
+    l64[1] = a.first_node ? a.first_node[b] : 0;
+    l64[2] = a.step_i ? a.step_i[b] : 0;
+    lf[0] = a.scalar ? a.scalar[b] : 0.0f;
+    lf[1] = a.current_time ? a.current_time[b] : 0.0f;
+    ldone[0] = a.done[b];
+  }
+  __syncthreads();
+  const float* dem = a.demand ? a.demand + (int64_t)ib * (a.env == RL4CO_ENV_PCTSP ? N : N - 1) : nullptr;
+  const float* locs = a.locs ? a.locs + (int64_t)ib * N * 2 : nullptr;
+  const float* maxlen = a.max_length ? a.max_length + (int64_t)ib * N : nullptr;
+  const float* tw = a.time_windows ? a.time_windows + (int64_t)ib * N * 2 : nullptr;
+  const float* dur = a.durations ? a.durations + (int64_t)ib * N : nullptr;
+  const float* cap = a.vehicle_capacity ? a.vehicle_capacity + b : nullptr;
+  const float base = a.rem_base ? a.rem_base[b] : 0.0f;
   for (int t = 0; t < T; ++t) {
     const int64_t o = (int64_t)b * T + t;
     uint8_t* out = a.masks + o * N;
     for (int j0 = 0; j0 < N; j0 += 64) {
       const int j = j0 + lane;
-      const uint8_t v = j < N ? row[j] : 0;
+      const uint8_t v = j < N ? lmask[j] : 0;
       if (j < N) out[j] = v;
       if (a.mask_bits != nullptr) {  // the same row as bits
         const unsigned long long bal = __ballot(v != 0);
@@ -578,44 +610,54 @@ __global__ void __launch_bounds__(64) env_replay_kernel(const rl4co_env_replay_a
     if (a.mask_bits != nullptr)  // words past the graph
       for (int wd = ((N + 63) >> 6) * 2 + lane; wd < a.mask_words; wd += 64) a.mask_bits[o * a.mask_words + wd] = 0u;
     if (lane == 0) {
-      a.prev[o] = a.current_node[b];
+      a.prev[o] = l64[0];
       if (a.env == RL4CO_ENV_TSP) {
-        a.first[o] = a.first_node[b];
-        a.use_placeholder[o] = a.step_i[b] < 1 ? 1 : 0;  // context.py:86-103: the placeholder until a node is chosen
+        a.first[o] = l64[1];
+        a.use_placeholder[o] = l64[2] < 1 ? 1 : 0;  // context.py:86-103: the placeholder until a node is chosen
       } else if (a.env != RL4CO_ENV_PDP) {
-        float r = a.rem_base[b] - a.scalar[b];           // context.py:105-213: capacity / length / prize still to go
+        float r = base - lf[0];                          // context.py:105-213: capacity / length / prize still to go
         if (a.env == RL4CO_ENV_PCTSP && r < 0.0f) r = 0.0f;  // clamp(min=0), context.py:195
         a.rem[o] = r;
-        if (a.env == RL4CO_ENV_CVRPTW) a.now[o] = a.current_time[b];
+        if (a.env == RL4CO_ENV_CVRPTW) a.now[o] = lf[1];
       }
     }
     __syncthreads();
     const int64_t* act = a.actions + o;
     switch (a.env) {
       case RL4CO_ENV_TSP:
-        tsp_step_body(act, a.action_mask, a.first_node, a.current_node, a.step_i, a.done, a.B, N, a.err, b, lane);
+        tsp_step_body(act, lmask, l64 + 1, l64, l64 + 2, ldone, 1, N, a.err, 0, lane);
         break;
       case RL4CO_ENV_CVRP:
-        cvrp_step_body(act, a.demand, a.scalar, a.vehicle_capacity, a.visited, a.current_node, a.action_mask, a.done, a.B,
-                       a.B_inst, N, a.err, b, lane);
+        cvrp_step_body(act, dem, lf, cap, lvis, l64, lmask, ldone, 1, 1, N, a.err, 0, lane);
         break;
       case RL4CO_ENV_OP:
-        op_step_body(act, a.locs, a.max_length, a.scalar, a.visited, a.current_node, a.step_i, a.action_mask, a.done, a.B,
-                     a.B_inst, N, a.err, b, lane);
+        op_step_body(act, locs, maxlen, lf, lvis, l64, l64 + 2, lmask, ldone, 1, 1, N, a.err, 0, lane);
         break;
       case RL4CO_ENV_CVRPTW:
-        cvrptw_step_body(act, a.demand, a.locs, a.time_windows, a.durations, a.scalar, a.vehicle_capacity, a.current_time,
-                         a.visited, a.current_node, a.action_mask, a.done, a.B_inst, N, a.err, b, lane);
+        cvrptw_step_body(act, dem, locs, tw, dur, lf, cap, lf + 1, lvis, l64, lmask, ldone, 1, N, a.err, 0, lane);
         break;
       case RL4CO_ENV_PCTSP:
-        pctsp_step_body(act, a.demand, a.scalar, a.visited, a.current_node, a.step_i, a.action_mask, a.done, a.B_inst, N,
-                        a.err, b, lane);
+        pctsp_step_body(act, dem, lf, lvis, l64, l64 + 2, lmask, ldone, 1, N, a.err, 0, lane);
         break;
       default:
-        pdp_step_body(act, a.visited, a.to_deliver, a.current_node, a.step_i, a.action_mask, a.done, N, a.err, b, lane);
+        pdp_step_body(act, lvis, ltod, l64, l64 + 2, lmask, ldone, N, a.err, 0, lane);
         break;
     }
     __syncthreads();  // the row and the scalars lane 0 wrote are this wave's next reads
+  }
+  // the state as T step calls leave it
+  for (int j = lane; j < N; j += 64) {
+    a.action_mask[(int64_t)b * N + j] = lmask[j];
+    if (a.visited) a.visited[(int64_t)b * N + j] = lvis[j];
+    if (a.to_deliver) a.to_deliver[(int64_t)b * N + j] = ltod[j];
+  }
+  if (lane == 0) {
+    a.current_node[b] = l64[0];
+    if (a.first_node) a.first_node[b] = l64[1];
+    if (a.step_i) a.step_i[b] = l64[2];
+    if (a.scalar) a.scalar[b] = lf[0];
+    if (a.current_time) a.current_time[b] = lf[1];
+    a.done[b] = ldone[0];
   }
 }
 
@@ -640,7 +682,9 @@ extern "C" int rl4co_env_replay(const rl4co_env_replay_args* args, void* stream)
     if (a.env == RL4CO_ENV_CVRPTW) RL4CO_REQUIRE(a.locs && a.time_windows && a.durations && a.current_time && a.now);
   }
   RL4CO_REQUIRE(a.mask_bits == nullptr || a.mask_words * 32 >= a.N);
-  hipLaunchKernelGGL(env_replay_kernel, dim3(a.B), dim3(64), 0, rl4co::as_stream(stream), a);
+  const int lds = 3 * ((a.N + 15) & ~15) + 3 * 8 + 2 * 4 + 16;
+  RL4CO_REQUIRE(lds <= 64 * 1024);  // (N <= 21 800 nodes)
+  hipLaunchKernelGGL(env_replay_kernel, dim3(a.B), dim3(64), lds, rl4co::as_stream(stream), a);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }

@@ -189,3 +189,21 @@ def test_logit_logp_matches_the_torch_chain_it_replaces(b, t, n, clip, temp, mas
     assert float((dr - rr).norm() / rr.norm()) <= 2e-5
     if masked:
         assert bool((dr[~mask] == 0).all())
+
+
+@pytest.mark.parametrize("env_name", ["tsp", "cvrp", "op", "pctsp", "pdp", "cvrptw"])
+def test_replay_leaves_the_state_where_the_step_calls_leave_it(env_name):
+    from rl4co_amd import kernels as K
+
+    policy, env, data, actions = _rollout(env_name, 20, 9, 0)
+    s1 = policy._initial_state(env.reset(data), 0)
+    s2 = policy._initial_state(env.reset(data), 0)
+    base = {"op": lambda s: s["max_length"][:, 0].contiguous(), "pctsp": lambda s: s["prize_required"],
+            "cvrp": lambda s: s["vehicle_capacity"], "cvrptw": lambda s: s["vehicle_capacity"]}.get(env_name, lambda s: None)(s1)
+    K.env_replay(env_name, s1, actions.contiguous(), base)
+    err = K.new_error_word("cuda")
+    for t in range(actions.shape[1]):
+        policy._env_step_state(s2, actions[:, t].contiguous(), err)
+    assert s1.keys() == s2.keys()
+    for k in s1:
+        assert torch.equal(s1[k], s2[k]), k
