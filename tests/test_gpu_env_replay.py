@@ -62,8 +62,9 @@ def test_replay_rejects_rows_that_do_not_match_and_reports_actions_out_of_range(
     assert int(err.item()) & _lib.EBIT_INFEASIBLE
 
 
-@pytest.mark.parametrize("env_name,num_loc,starts", [("cvrp", 150, 0), ("tsp", 160, 4)])
-def test_reinforce_step_beyond_the_backward_kernels_node_limit(env_name, num_loc, starts):
+@pytest.mark.parametrize("env_name,num_loc,starts,norm", [("cvrp", 150, 0, "instance"), ("tsp", 160, 4, "instance"),
+                                                          ("tsp", 140, 0, "batch"), ("cvrp", 129, 0, "layer")])
+def test_reinforce_step_beyond_the_backward_kernels_node_limit(env_name, num_loc, starts, norm):
     """Graphs beyond 128 nodes train through the per-op kernels where they serve, torch where they do not, and the dense
     re-evaluation (r06: the step used to raise a TypeError under 16-bit autocast — torch's norm hands fp32 rows to the
     16-bit MLP kernel). The log-likelihood the step differentiates equals the rollout's, and the gradients are those of the
@@ -77,7 +78,7 @@ def test_reinforce_step_beyond_the_backward_kernels_node_limit(env_name, num_loc
     grads, lls = {}, {}
     for fused in (True, False):
         torch.manual_seed(0)
-        pol = AttentionModelPolicy(env_name, num_encoder_layers=3, normalization="instance", use_graph_context=False,
+        pol = AttentionModelPolicy(env_name, num_encoder_layers=3, normalization=norm, use_graph_context=norm == "batch",
                                    cache_dtype=torch.bfloat16, encoder_autocast=torch.bfloat16,
                                    train_decode_type="multistart_sampling" if starts else "sampling").cuda().train()
         for m in pol.modules():
