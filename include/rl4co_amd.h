@@ -706,8 +706,9 @@ int rl4co_skip_inorm_bwd(int dtype, const void* dout, const void* y, const float
                               const float* rstd, int B, int N, void* dy, float* dgamma, float* dbeta,
                               void* stream);
 int rl4co_skip_inorm_max_nodes(void);
-/* rl4co_skip_inorm_fwd / _bwd serve N <= rl4co_skip_inorm_wide_max_nodes() (r06): beyond rl4co_skip_inorm_max_nodes() the
- * instance's rows are re-read per pass instead of waiting in registers; same arithmetic, same accumulation order. */
+/* rl4co_skip_inorm_fwd / _bwd and rl4co_skip_lnorm_fwd / _bwd serve N <= rl4co_skip_inorm_wide_max_nodes() (r06): beyond
+ * rl4co_skip_inorm_max_nodes() the instance's rows are re-read per pass instead of waiting in registers; same arithmetic,
+ * same accumulation order. */
 int rl4co_skip_inorm_wide_max_nodes(void);
 
 /* --------------------------------------------------------------------------

@@ -366,19 +366,76 @@ __global__ void __launch_bounds__(kThreads) skip_lnorm_bwd_kernel(const uint32_t
   }
 }
 
+// the layer formula beyond 4 * kMaxRows nodes (r06): rows re-read per pass, as the instance-norm kernels above
+__global__ void __launch_bounds__(kThreads) skip_lnorm_fwd_wide_kernel(const uint32_t* __restrict__ x, const uint32_t* __restrict__ s,
+                                                                       float eps, int N, uint32_t* y, uint32_t* __restrict__ out,
+                                                                       float* __restrict__ stats) {
+  __shared__ float red4[4];
+  const int tid = threadIdx.x, cp = tid & 63, q = tid >> 6;
+  const int64_t base = (int64_t)blockIdx.x * N * (kD / 2);
+  float sum = 0.0f;
+  wide_rows(x, s, base, cp, q, N, [&](int n, uint32_t a, uint32_t b) {
+    const uint32_t ys = pack_bf16(bf16_lo(a) + bf16_lo(b), bf16_hi(a) + bf16_hi(b));
+    y[base + (int64_t)n * (kD / 2) + cp] = ys;
+    sum += bf16_lo(ys) + bf16_hi(ys);
+  });
+  const float cnt = (float)(N * kD);
+  const float mu = block_sum(sum, red4, tid) / cnt;
+  float sq = 0.0f;
+  wide_rows(y, nullptr, base, cp, q, N, [&](int, uint32_t ys, uint32_t) {
+    const float d0 = bf16_lo(ys) - mu, d1 = bf16_hi(ys) - mu;
+    sq = fmaf(d0, d0, sq);
+    sq = fmaf(d1, d1, sq);
+  });
+  const float rs = rsqrtf(block_sum(sq, red4, tid) / (cnt - 1.0f) + eps);
+  wide_rows(y, nullptr, base, cp, q, N, [&](int n, uint32_t ys, uint32_t) {
+    out[base + (int64_t)n * (kD / 2) + cp] = pack_bf16((bf16_lo(ys) - mu) * rs, (bf16_hi(ys) - mu) * rs);
+  });
+  if (tid == 0) {
+    stats[2 * (int64_t)blockIdx.x] = mu;
+    stats[2 * (int64_t)blockIdx.x + 1] = rs;
+  }
+}
+
+__global__ void __launch_bounds__(kThreads) skip_lnorm_bwd_wide_kernel(const uint32_t* __restrict__ dout, const uint32_t* __restrict__ y,
+                                                                       const float* __restrict__ stats, int N, uint32_t* __restrict__ dy) {
+  __shared__ float red4[4];
+  const int tid = threadIdx.x, cp = tid & 63, q = tid >> 6;
+  const int64_t base = (int64_t)blockIdx.x * N * (kD / 2);
+  const float mu = stats[2 * (int64_t)blockIdx.x], rs = stats[2 * (int64_t)blockIdx.x + 1];
+  float s_d = 0.0f, s_dx = 0.0f;
+  wide_rows(dout, y, base, cp, q, N, [&](int, uint32_t a, uint32_t b) {
+    const float d0 = bf16_lo(a), d1 = bf16_hi(a);
+    s_d += d0 + d1;
+    s_dx = fmaf(d0, (bf16_lo(b) - mu) * rs, s_dx);
+    s_dx = fmaf(d1, (bf16_hi(b) - mu) * rs, s_dx);
+  });
+  const float cnt = (float)(N * kD);
+  const float m_d = block_sum(s_d, red4, tid) / cnt;
+  const float m_dx = block_sum(s_dx, red4, tid) / (cnt - 1.0f);
+  wide_rows(dout, y, base, cp, q, N, [&](int n, uint32_t a, uint32_t b) {
+    const float x0 = (bf16_lo(b) - mu) * rs, x1 = (bf16_hi(b) - mu) * rs;
+    dy[base + (int64_t)n * (kD / 2) + cp] = pack_bf16(rs * (bf16_lo(a) - m_d - x0 * m_dx), rs * (bf16_hi(a) - m_d - x1 * m_dx));
+  });
+}
+
 }  // namespace
 
 #if !RL4CO_ELEM_F16
 extern "C" int rl4co_skip_inorm_max_nodes(void) { return 4 * kMaxRows; }  // the register-resident kernels (instance and layer norm)
-extern "C" int rl4co_skip_inorm_wide_max_nodes(void) { return 1024; }      // rl4co_skip_inorm_fwd / _bwd: rows re-read per pass beyond that
+extern "C" int rl4co_skip_inorm_wide_max_nodes(void) { return 1024; }      // rl4co_skip_inorm_* / rl4co_skip_lnorm_*: rows re-read per pass beyond that
 #endif
 
 extern "C" int RL4CO_ENTRY(rl4co_skip_lnorm_fwd)(const void* x, const void* s, float eps, int B, int N, void* y, void* out,
                                                  float* stats, void* stream) {
   RL4CO_REQUIRE(x && s && y && out && stats);
-  RL4CO_REQUIRE(B > 0 && N >= 1 && N <= 4 * kMaxRows && eps > 0.0f);
-  hipLaunchKernelGGL(skip_lnorm_fwd_kernel, dim3(B), dim3(kThreads), 0, rl4co::as_stream(stream), static_cast<const uint32_t*>(x),
-                     static_cast<const uint32_t*>(s), eps, N, static_cast<uint32_t*>(y), static_cast<uint32_t*>(out), stats);
+  RL4CO_REQUIRE(B > 0 && N >= 1 && N <= 1024 && eps > 0.0f);
+  if (N > 4 * kMaxRows)
+    hipLaunchKernelGGL(skip_lnorm_fwd_wide_kernel, dim3(B), dim3(kThreads), 0, rl4co::as_stream(stream), static_cast<const uint32_t*>(x),
+                       static_cast<const uint32_t*>(s), eps, N, static_cast<uint32_t*>(y), static_cast<uint32_t*>(out), stats);
+  else
+    hipLaunchKernelGGL(skip_lnorm_fwd_kernel, dim3(B), dim3(kThreads), 0, rl4co::as_stream(stream), static_cast<const uint32_t*>(x),
+                       static_cast<const uint32_t*>(s), eps, N, static_cast<uint32_t*>(y), static_cast<uint32_t*>(out), stats);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }
@@ -386,9 +443,13 @@ extern "C" int RL4CO_ENTRY(rl4co_skip_lnorm_fwd)(const void* x, const void* s, f
 extern "C" int RL4CO_ENTRY(rl4co_skip_lnorm_bwd)(const void* dout, const void* y, const float* stats, int B, int N, void* dy,
                                                  void* stream) {
   RL4CO_REQUIRE(dout && y && stats && dy);
-  RL4CO_REQUIRE(B > 0 && N >= 1 && N <= 4 * kMaxRows);
-  hipLaunchKernelGGL(skip_lnorm_bwd_kernel, dim3(B), dim3(kThreads), 0, rl4co::as_stream(stream),
-                     static_cast<const uint32_t*>(dout), static_cast<const uint32_t*>(y), stats, N, static_cast<uint32_t*>(dy));
+  RL4CO_REQUIRE(B > 0 && N >= 1 && N <= 1024);
+  if (N > 4 * kMaxRows)
+    hipLaunchKernelGGL(skip_lnorm_bwd_wide_kernel, dim3(B), dim3(kThreads), 0, rl4co::as_stream(stream),
+                       static_cast<const uint32_t*>(dout), static_cast<const uint32_t*>(y), stats, N, static_cast<uint32_t*>(dy));
+  else
+    hipLaunchKernelGGL(skip_lnorm_bwd_kernel, dim3(B), dim3(kThreads), 0, rl4co::as_stream(stream),
+                       static_cast<const uint32_t*>(dout), static_cast<const uint32_t*>(y), stats, N, static_cast<uint32_t*>(dy));
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
 }

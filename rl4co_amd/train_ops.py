@@ -182,7 +182,7 @@ def inorm_max_nodes() -> int:
 
 def usable(x: Tensor, s: Tensor, kind: str = "layer") -> bool:
     """16-bit [B,N,128] activations on the GPU with N inside the norm kernels' limit (``kind``: "instance" or "layer")."""
-    limit = inorm_max_nodes() if kind == "instance" else max_nodes()
+    limit = inorm_max_nodes()  # (r06: both formulas re-read their rows per pass beyond ``max_nodes()``)
     return (x.is_cuda and x.dtype in HALF and s.dtype == x.dtype and x.dim() == 3
             and x.shape == s.shape and x.shape[-1] == EMBED_DIM and x.shape[1] <= limit)
 
@@ -867,7 +867,7 @@ def block_usable(x: Tensor, kind: str, *weights: Tensor) -> bool:
         return False
     if x.shape[1] > attn_max_nodes():
         return False
-    return kind == "batch" or x.shape[1] <= (inorm_max_nodes() if kind == "instance" else max_nodes())
+    return kind == "batch" or x.shape[1] <= inorm_max_nodes()
 
 
 def attention_block(x: Tensor, attn, norm) -> Tensor:
