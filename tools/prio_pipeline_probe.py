@@ -25,7 +25,7 @@ dev = torch.device("cuda:0")
 kw = dict(cache_dtype=torch.float32, encoder_autocast=None) if regime == "fp32" else dict(cache_dtype=torch.bfloat16, encoder_autocast=torch.bfloat16)
 torch.manual_seed(0)
 policy = AttentionModelPolicy(env_name="tsp", **kw).to(dev).eval()
-env = get_env("tsp", generator_params=dict(num_loc=100, device=dev), device=dev, check_solution=False)
+env = get_env("tsp", generator_params=dict(num_loc=100, device=dev), device=dev, check_solution="--nocheck" not in sys.argv)
 torch.manual_seed(1234)
 data = env.generator(batch_size=[4096])
 lo, hi = -1, 0
