@@ -571,6 +571,7 @@ __global__ void __launch_bounds__(64) env_replay_kernel(const rl4co_env_replay_a
   int64_t* l64 = reinterpret_cast<int64_t*>(ltod + Np);  // current_node, first_node, step_i
   float* lf = reinterpret_cast<float*>(l64 + 3);         // scalar, current_time
   uint8_t* ldone = reinterpret_cast<uint8_t*>(lf + 2);
+  float* linst = reinterpret_cast<float*>(ldone + 16);  // the instance's data: demand / prize [N], locs [2 N], max_length [N], windows [2 N], durations [N]
   const int ib = b % a.B_inst;
   for (int j = lane; j < N; j += 64) {
     lmask[j] = a.action_mask[(int64_t)b * N + j];
@@ -585,12 +586,26 @@ __global__ void __launch_bounds__(64) env_replay_kernel(const rl4co_env_replay_a
     lf[1] = a.current_time ? a.current_time[b] : 0.0f;
     ldone[0] = a.done[b];
   }
+  // (every step reads them: from L2 that was one more round trip on the step's chain)
+  const int nd = a.env == RL4CO_ENV_PCTSP ? N : N - 1;
+  float* ldem = linst;
+  float* llocs = ldem + N;
+  float* lmaxlen = llocs + 2 * N;
+  float* ltw = lmaxlen + N;
+  float* ldur = ltw + 2 * N;
+  for (int j = lane; j < 2 * N; j += 64) {
+    if (a.demand && j < nd) ldem[j] = a.demand[(int64_t)ib * nd + j];
+    if (a.locs) llocs[j] = a.locs[(int64_t)ib * N * 2 + j];
+    if (a.max_length && j < N) lmaxlen[j] = a.max_length[(int64_t)ib * N + j];
+    if (a.time_windows) ltw[j] = a.time_windows[(int64_t)ib * N * 2 + j];
+    if (a.durations && j < N) ldur[j] = a.durations[(int64_t)ib * N + j];
+  }
   __syncthreads();
-  const float* dem = a.demand ? a.demand + (int64_t)ib * (a.env == RL4CO_ENV_PCTSP ? N : N - 1) : nullptr;
-  const float* locs = a.locs ? a.locs + (int64_t)ib * N * 2 : nullptr;
-  const float* maxlen = a.max_length ? a.max_length + (int64_t)ib * N : nullptr;
-  const float* tw = a.time_windows ? a.time_windows + (int64_t)ib * N * 2 : nullptr;
-  const float* dur = a.durations ? a.durations + (int64_t)ib * N : nullptr;
+  const float* dem = a.demand ? ldem : nullptr;
+  const float* locs = a.locs ? llocs : nullptr;
+  const float* maxlen = a.max_length ? lmaxlen : nullptr;
+  const float* tw = a.time_windows ? ltw : nullptr;
+  const float* dur = a.durations ? ldur : nullptr;
   const float* cap = a.vehicle_capacity ? a.vehicle_capacity + b : nullptr;
   const float base = a.rem_base ? a.rem_base[b] : 0.0f;
   for (int t = 0; t < T; ++t) {
@@ -682,8 +697,10 @@ extern "C" int rl4co_env_replay(const rl4co_env_replay_args* args, void* stream)
     if (a.env == RL4CO_ENV_CVRPTW) RL4CO_REQUIRE(a.locs && a.time_windows && a.durations && a.current_time && a.now);
   }
   RL4CO_REQUIRE(a.mask_bits == nullptr || a.mask_words * 32 >= a.N);
-  const int lds = 3 * ((a.N + 15) & ~15) + 3 * 8 + 2 * 4 + 16;
-  RL4CO_REQUIRE(lds <= 64 * 1024);  // (N <= 21 800 nodes)
+  const int lds = 3 * ((a.N + 15) & ~15) + 3 * 8 + 2 * 4 + 16 + 7 * a.N * 4;
+  RL4CO_REQUIRE(lds <= 160 * 1024);  // (N <= 5 300 nodes)
+  if (lds > 64 * 1024)
+    RL4CO_HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(env_replay_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
   hipLaunchKernelGGL(env_replay_kernel, dim3(a.B), dim3(64), lds, rl4co::as_stream(stream), a);
   RL4CO_HIP_TRY(hipGetLastError());
   return RL4CO_OK;
