@@ -239,3 +239,19 @@ def test_training_beyond_128_nodes_learns():
             opt.step()
             hist.append(float(-r.mean()))
     assert sum(hist[-5:]) / 5 < 0.6 * sum(hist[:5]) / 5, (hist[:5], hist[-5:])
+
+
+def test_replay_of_a_2500_node_tour():
+    """(beyond 64 KB of dynamic LDS for the state and instance data)"""
+    from rl4co_amd.envs import get_env
+    from rl4co_amd.policy import AttentionModelPolicy
+
+    torch.manual_seed(0)
+    policy = AttentionModelPolicy("tsp").cuda().eval()
+    env = get_env("tsp", generator_params=dict(num_loc=2500, device="cuda"), device="cuda", check_solution=False)
+    data = env.generator(batch_size=[2])
+    actions = torch.stack([torch.randperm(2500, device="cuda") for _ in range(2)])
+    a = policy._replay(env.reset(data), actions, 0, mask_bits=True)
+    b = policy._replay_stepwise(env.reset(data), actions, 0)
+    assert torch.equal(a[0], b[0]) and all(torch.equal(x, y) for x, y in zip(a[1], b[1])) and torch.equal(a[2], b[2])
+    assert torch.equal(a[3], _bits_of(a[0]))
